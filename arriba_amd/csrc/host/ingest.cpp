@@ -1,0 +1,828 @@
+// arriba_amd/csrc/host/ingest.cpp -- BAM ingest: classify STAR records into chimeric fragments and pack
+// them into the structure-of-arrays batch.  Restates the reference's read_chimeric_alignments
+// (source/read_chimeric_alignments.cpp:19-773) for the standard workflow (-x only, STAR
+// --chimOutType WithinBAM) and coverage_t::add_fragment (source/read_stats.cpp:161-266).
+#include "arriba_host.h"
+
+#include <algorithm>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <zlib.h>
+
+namespace arriba {
+
+// ---- byte sources -------------------------------------------------------------------------------
+
+namespace {
+
+class GzSource: public ByteSource {
+public:
+	explicit GzSource(const std::string& path) {
+		file_ = gzopen(path.c_str(), "rb");
+		if (file_ == NULL)
+			throw std::runtime_error("failed to open SAM file");
+		gzbuffer(file_, 4u << 20);
+	}
+	~GzSource() { gzclose(file_); }
+	size_t read(uint8_t* buffer, size_t capacity) {
+		int got = gzread(file_, buffer, (unsigned int) std::min<size_t>(capacity, 1u << 30));
+		if (got < 0)
+			throw std::runtime_error("failed to load alignments");
+		return got;
+	}
+private:
+	gzFile file_;
+};
+
+class MemorySource: public ByteSource {
+public:
+	MemorySource(const uint8_t* data, size_t size): data_(data), size_(size), position_(0) {}
+	size_t read(uint8_t* buffer, size_t capacity) {
+		size_t n = std::min(capacity, size_ - position_);
+		memcpy(buffer, data_ + position_, n);
+		position_ += n;
+		return n;
+	}
+private:
+	const uint8_t* data_; size_t size_, position_;
+};
+
+}
+
+ByteSource* open_bam_file(const std::string& path) { return new GzSource(path); }
+ByteSource* open_memory_source(const uint8_t* data, size_t size) { return new MemorySource(data, size); }
+
+// ---- record decoding ----------------------------------------------------------------------------
+
+namespace {
+
+const uint16_t BAM_FPAIRED = 1, BAM_FPROPER_PAIR = 2, BAM_FUNMAP = 4, BAM_FMUNMAP = 8, BAM_FREVERSE = 16, BAM_FREAD1 = 64, BAM_FSECONDARY = 256, BAM_FDUP = 1024, BAM_FSUPPLEMENTARY = 2048;
+const char NT16[] = "=ACMGRSVTWYHKDBN";
+
+inline uint32_t le32(const uint8_t* p) { return (uint32_t) p[0] | (uint32_t) p[1] << 8 | (uint32_t) p[2] << 16 | (uint32_t) p[3] << 24; }
+inline uint16_t le16(const uint8_t* p) { return (uint16_t) (p[0] | p[1] << 8); }
+
+struct Record { // one decoded BAM alignment record (SAMv1 section 4.2)
+	int32_t tid, pos;
+	uint16_t flag;
+	int32_t l_seq;
+	std::string qname;
+	std::vector<uint32_t> cigar;
+	std::vector<uint8_t> seq;  // 4-bit packed
+	std::vector<uint8_t> aux;
+	uint32_t n_cigar() const { return cigar.size(); }
+	bool reverse() const { return flag & BAM_FREVERSE; }
+	bool forward_strand() const { return !(flag & BAM_FREVERSE); } // strand_t FORWARD == true
+	char base(int i) const { return NT16[(seq[i >> 1] >> ((~i & 1) << 2)) & 15]; }
+	int qlen(uint32_t n) const { int l = 0; for (uint32_t i = 0; i < n; ++i) if (cigar_consumes_query(cigar_op(cigar[i]))) l += cigar_len(cigar[i]); return l; }
+	int rlen(uint32_t n) const { int l = 0; for (uint32_t i = 0; i < n; ++i) if (cigar_consumes_reference(cigar_op(cigar[i]))) l += cigar_len(cigar[i]); return l; }
+	int endpos() const { int l = (!(flag & BAM_FUNMAP) && !cigar.empty()) ? rlen(cigar.size()) : 1; return pos + (l == 0 ? 1 : l); }
+	// aux lookup; returns pointer at the type byte or NULL
+	const uint8_t* aux_get(char t0, char t1) const {
+		const uint8_t* s = aux.data();
+		const uint8_t* end = s + aux.size();
+		while (s + 3 <= end) {
+			const uint8_t* value = s + 2;
+			size_t size;
+			switch (*value) {
+				case 'A': case 'c': case 'C': size = 2; break;
+				case 's': case 'S': size = 3; break;
+				case 'i': case 'I': case 'f': size = 5; break;
+				case 'd': size = 9; break;
+				case 'Z': case 'H': { const uint8_t* p = value + 1; while (p < end && *p) ++p; if (p >= end) return NULL; size = p - value + 1; break; }
+				case 'B': {
+					if (value + 6 > end) return NULL;
+					size_t element = (value[1] == 'c' || value[1] == 'C') ? 1 : (value[1] == 's' || value[1] == 'S') ? 2 : 4;
+					size = 6 + element * le32(value + 2);
+					break;
+				}
+				default: return NULL;
+			}
+			if (value + size > end) return NULL;
+			if (s[0] == (uint8_t) t0 && s[1] == (uint8_t) t1) return value;
+			s = value + size;
+		}
+		return NULL;
+	}
+	static int64_t aux_to_int(const uint8_t* s) {
+		switch (*s) {
+			case 'c': return (int8_t) s[1];
+			case 'C': return s[1];
+			case 's': return (int16_t) le16(s + 1);
+			case 'S': return le16(s + 1);
+			case 'i': return (int32_t) le32(s + 1);
+			case 'I': return le32(s + 1);
+			default: return 0;
+		}
+	}
+};
+
+class BamStream {
+public:
+	explicit BamStream(ByteSource& source): source_(source), begin_(0), end_(0), eof_(false) { buffer_.resize(8u << 20); }
+	bool need(size_t n) { // make n bytes available at begin_
+		while (end_ - begin_ < n) {
+			if (eof_) return false;
+			if (begin_ > 0) { memmove(&buffer_[0], &buffer_[begin_], end_ - begin_); end_ -= begin_; begin_ = 0; }
+			if (buffer_.size() < n) buffer_.resize(n + (n >> 1));
+			size_t got = source_.read(&buffer_[end_], buffer_.size() - end_);
+			if (got == 0) eof_ = true;
+			end_ += got;
+		}
+		return true;
+	}
+	const uint8_t* data() const { return &buffer_[begin_]; }
+	void consume(size_t n) { begin_ += n; }
+	size_t available() const { return end_ - begin_; }
+	void read_header(std::vector<std::string>& target_names) {
+		if (!need(12) || memcmp(data(), "BAM\1", 4) != 0) throw std::runtime_error("failed to read SAM header");
+		uint32_t l_text = le32(data() + 4);
+		consume(8);
+		if (!need(l_text + 4)) throw std::runtime_error("failed to read SAM header");
+		consume(l_text);
+		uint32_t n_ref = le32(data());
+		consume(4);
+		for (uint32_t i = 0; i < n_ref; ++i) {
+			if (!need(4)) throw std::runtime_error("failed to read SAM header");
+			uint32_t l_name = le32(data());
+			consume(4);
+			if (!need(l_name + 4)) throw std::runtime_error("failed to read SAM header");
+			target_names.push_back(std::string((const char*) data(), l_name > 0 ? l_name - 1 : 0));
+			consume(l_name + 4);
+		}
+	}
+	bool next(Record& r) { // false at clean end of stream
+		if (!need(4)) {
+			if (available() == 0) return false;
+			throw std::runtime_error("failed to load alignments");
+		}
+		uint32_t block_size = le32(data());
+		if (block_size < 32 || !need(4 + (size_t) block_size)) throw std::runtime_error("failed to load alignments");
+		const uint8_t* p = data() + 4;
+		r.tid = (int32_t) le32(p);
+		r.pos = (int32_t) le32(p + 4);
+		uint32_t l_read_name = p[8];
+		uint32_t n_cigar = le16(p + 12);
+		r.flag = le16(p + 14);
+		r.l_seq = (int32_t) le32(p + 16);
+		const uint8_t* q = p + 32;
+		size_t fixed = (size_t) l_read_name + 4 * (size_t) n_cigar + ((size_t) r.l_seq + 1) / 2 + (size_t) r.l_seq;
+		if (32 + fixed > block_size) throw std::runtime_error("failed to load alignments");
+		r.qname.assign((const char*) q, strnlen((const char*) q, l_read_name));
+		q += l_read_name;
+		r.cigar.resize(n_cigar);
+		for (uint32_t i = 0; i < n_cigar; ++i) r.cigar[i] = le32(q + 4 * i);
+		q += 4 * n_cigar;
+		r.seq.assign(q, q + (r.l_seq + 1) / 2);
+		q += (r.l_seq + 1) / 2 + r.l_seq;
+		r.aux.assign(q, p + block_size);
+		consume(4 + (size_t) block_size);
+		return true;
+	}
+private:
+	ByteSource& source_;
+	std::vector<uint8_t> buffer_;
+	size_t begin_, end_;
+	bool eof_;
+};
+
+// ---- in-flight fragment table -------------------------------------------------------------------
+
+struct Alignment { // reference: alignment_t, source/common.hpp:191-207
+	bool supplementary = false, first_in_pair = false, strand = false;
+	contig_t contig = 0;
+	position_t start = 0, end = 0;
+	std::vector<uint32_t> cigar;
+	std::string sequence;
+	unsigned int preclipping() const { uint32_t op = cigar_op(cigar.at(0)); return (op == CIGAR_S || op == CIGAR_H) ? cigar_len(cigar.at(0)) : 0; }
+	unsigned int postclipping() const { uint32_t op = cigar_op(cigar.at(cigar.size() - 1)); return (op == CIGAR_S || op == CIGAR_H) ? cigar_len(cigar.at(cigar.size() - 1)) : 0; }
+};
+struct Fragment { // reference: mates_t, source/common.hpp:212-219
+	std::vector<Alignment> alignments;
+	bool single_end = false, duplicate = false;
+};
+typedef std::unordered_map<std::string, Fragment> fragment_table_t;
+
+const unsigned char CLIP_NONE = 0, CLIP_START = 1, CLIP_END = 2;
+
+std::string decode_sequence(const Record& r) {
+	std::string sequence(r.l_seq, 'N');
+	for (int i = 0; i < r.l_seq; ++i)
+		sequence[i] = r.base(i);
+	return sequence;
+}
+
+// reference: source/read_chimeric_alignments.cpp:50-91
+void add_chimeric_alignment(Fragment& mates, const Record& r, bool is_supplementary = false, unsigned int cigar_index = 0, unsigned char clip = CLIP_NONE) {
+	mates.single_end = !(r.flag & BAM_FPAIRED);
+	mates.duplicate = mates.duplicate || (r.flag & BAM_FDUP);
+	mates.alignments.resize(mates.alignments.size() + 1);
+	Alignment& alignment = mates.alignments.back();
+	alignment.strand = r.forward_strand();
+	alignment.first_in_pair = r.flag & BAM_FREAD1;
+	alignment.contig = r.tid;
+	alignment.supplementary = is_supplementary;
+	if (!is_supplementary)
+		alignment.sequence = decode_sequence(r);
+	if (clip == CLIP_START) {
+		alignment.start = r.pos + r.rlen(cigar_index);
+		alignment.end = r.endpos() - 1;
+		uint32_t clip_type = cigar_op(r.cigar[0]) == CIGAR_H ? CIGAR_H : CIGAR_S;
+		alignment.cigar.resize(r.n_cigar() - cigar_index + 1);
+		alignment.cigar[0] = cigar_make(r.qlen(cigar_index), clip_type);
+		for (unsigned int i = cigar_index; i < r.n_cigar(); ++i)
+			alignment.cigar[i - cigar_index + 1] = r.cigar[i];
+	} else if (clip == CLIP_END) {
+		alignment.start = r.pos;
+		alignment.end = r.pos + r.rlen(cigar_index + 1) - 1;
+		uint32_t clip_type = cigar_op(r.cigar[r.n_cigar() - 1]) == CIGAR_H ? CIGAR_H : CIGAR_S;
+		alignment.cigar.resize(cigar_index + 2);
+		for (unsigned int i = 0; i <= cigar_index; ++i)
+			alignment.cigar[i] = r.cigar[i];
+		alignment.cigar[cigar_index + 1] = cigar_make(r.l_seq - r.qlen(cigar_index + 1), clip_type);
+	} else {
+		alignment.start = r.pos;
+		alignment.end = r.endpos() - 1;
+		alignment.cigar = r.cigar;
+	}
+}
+
+// reference: source/read_chimeric_alignments.cpp:19-41
+bool find_spanning_intron(const Record& r, position_t gene1_end, position_t gene2_start, unsigned int& cigar_index, position_t& read_pos) {
+	if (r.n_cigar() < 3)
+		return false;
+	position_t before = r.pos, after;
+	for (unsigned int i = 0; i < r.n_cigar(); ++i) {
+		uint32_t op = r.cigar[i];
+		unsigned int op_length = cigar_consumes_reference(cigar_op(op)) ? cigar_len(op) : 0;
+		after = before + op_length;
+		if (cigar_op(op) == CIGAR_N && (before <= gene1_end && after > gene1_end || before < gene2_start && after >= gene2_start)) {
+			cigar_index = i;
+			read_pos = r.qlen(i);
+			return true;
+		}
+		before = after;
+	}
+	return false;
+}
+
+// reference: source/annotation.cpp:558-567
+void get_boundaries_of_biggest_gene(const std::vector<uint32_t>& genes, const Annotation& annotation, position_t& start, position_t& end) {
+	start = -1; end = -1;
+	for (size_t g = 0; g < genes.size(); ++g) {
+		const GeneRecord& gene = annotation.genes[genes[g]];
+		if (start == -1 || start > gene.start) start = gene.start;
+		if (end == -1 || end < gene.end) end = gene.end;
+	}
+}
+
+// reference: source/read_chimeric_alignments.cpp:93-193
+bool extract_read_through_alignment(fragment_table_t& fragments, const std::string& read_name, const Record* forward_mate, const Record* reverse_mate, const Annotation& annotation, const FlatIndex& gene_index) {
+	if (!forward_mate->forward_strand())
+		std::swap(forward_mate, reverse_mate);
+	std::vector<uint32_t> forward_genes, reverse_genes, common_genes;
+	if (forward_mate != NULL) get_annotation_by_coordinate(forward_mate->tid, forward_mate->pos, forward_mate->pos, forward_genes, gene_index);
+	else get_annotation_by_coordinate(reverse_mate->tid, reverse_mate->pos, reverse_mate->pos, forward_genes, gene_index);
+	if (reverse_mate != NULL) get_annotation_by_coordinate(reverse_mate->tid, reverse_mate->endpos(), reverse_mate->endpos(), reverse_genes, gene_index);
+	else get_annotation_by_coordinate(forward_mate->tid, forward_mate->endpos(), forward_mate->endpos(), reverse_genes, gene_index);
+	std::set_intersection(forward_genes.begin(), forward_genes.end(), reverse_genes.begin(), reverse_genes.end(), std::back_inserter(common_genes));
+	if (!(common_genes.empty() && !(forward_genes.empty() && reverse_genes.empty())))
+		return false;
+
+	position_t forward_gene_start, forward_gene_end, reverse_gene_start, reverse_gene_end;
+	get_boundaries_of_biggest_gene(forward_genes, annotation, forward_gene_start, forward_gene_end);
+	get_boundaries_of_biggest_gene(reverse_genes, annotation, reverse_gene_start, reverse_gene_end);
+	if (forward_gene_end == -1) forward_gene_end = reverse_gene_start - 1;
+	if (reverse_gene_start == -1) reverse_gene_start = forward_gene_end + 1;
+
+	unsigned int forward_cigar_op = 0, reverse_cigar_op = 0;
+	position_t forward_read_pos = 0, reverse_read_pos = 0;
+	bool forward_has_intron = (forward_mate == NULL) ? false : find_spanning_intron(*forward_mate, forward_gene_end, reverse_gene_start, forward_cigar_op, forward_read_pos);
+	bool reverse_has_intron = (reverse_mate == NULL) ? false : find_spanning_intron(*reverse_mate, forward_gene_end, reverse_gene_start, reverse_cigar_op, reverse_read_pos);
+	if (forward_has_intron && (!reverse_has_intron || forward_read_pos < reverse_mate->l_seq - reverse_read_pos)) {
+		std::pair<fragment_table_t::iterator, bool> mates = fragments.insert(std::make_pair(read_name, Fragment()));
+		if (mates.second) {
+			add_chimeric_alignment(mates.first->second, *forward_mate, false, forward_cigar_op + 1, CLIP_START);
+			add_chimeric_alignment(mates.first->second, *forward_mate, true, forward_cigar_op - 1, CLIP_END);
+			if (reverse_mate != NULL) {
+				if (reverse_has_intron) add_chimeric_alignment(mates.first->second, *reverse_mate, false, reverse_cigar_op + 1, CLIP_START);
+				else add_chimeric_alignment(mates.first->second, *reverse_mate);
+			}
+			return true;
+		}
+	} else if (reverse_has_intron) {
+		std::pair<fragment_table_t::iterator, bool> mates = fragments.insert(std::make_pair(read_name, Fragment()));
+		if (mates.second) {
+			add_chimeric_alignment(mates.first->second, *reverse_mate, true, reverse_cigar_op + 1, CLIP_START);
+			add_chimeric_alignment(mates.first->second, *reverse_mate, false, reverse_cigar_op - 1, CLIP_END);
+			if (forward_mate != NULL) {
+				if (forward_has_intron) add_chimeric_alignment(mates.first->second, *forward_mate, false, forward_cigar_op - 1, CLIP_END);
+				else add_chimeric_alignment(mates.first->second, *forward_mate);
+			}
+			return true;
+		}
+	} else if (forward_mate != NULL && reverse_mate != NULL && reverse_mate->pos >= reverse_gene_start && forward_mate->endpos() <= forward_gene_end) {
+		std::pair<fragment_table_t::iterator, bool> mates = fragments.insert(std::make_pair(read_name, Fragment()));
+		if (mates.second) {
+			add_chimeric_alignment(mates.first->second, *forward_mate);
+			add_chimeric_alignment(mates.first->second, *reverse_mate);
+		}
+		return true;
+	}
+	return false;
+}
+
+// reference: source/read_chimeric_alignments.cpp:197-211
+bool clipped_sequence_is_adapter(const Record* mate1, const Record* mate2) {
+	if (mate1 == NULL || mate2 == NULL)
+		return false;
+	if (mate1->pos == mate2->pos) {
+		if (mate1->reverse() && cigar_op(mate1->cigar[0]) == CIGAR_S && !mate2->reverse() && cigar_op(mate2->cigar.back()) == CIGAR_S &&
+		    cigar_len(mate1->cigar[0]) == cigar_len(mate2->cigar.back()))
+			return true;
+		if (mate2->reverse() && cigar_op(mate2->cigar[0]) == CIGAR_S && !mate1->reverse() && cigar_op(mate1->cigar.back()) == CIGAR_S &&
+		    cigar_len(mate2->cigar[0]) == cigar_len(mate1->cigar.back()))
+			return true;
+	}
+	return false;
+}
+
+// reference: source/read_chimeric_alignments.cpp:215-336 (integer types chosen to reproduce its mixed signed/unsigned arithmetic)
+bool is_tandem_duplication(const Record* r, const Assembly& assembly, const unsigned int max_itd_length, Alignment& tandem) {
+	const unsigned int min_clipped_length = 12, min_duplication_length = 9, max_duplication_length = max_itd_length;
+	const unsigned int max_mismatches = 1, max_non_template_bases = 6, min_alignment_length = 15;
+	if (r == NULL)
+		return false;
+	unsigned int clipped_length = 0, clipped_position = 0;
+	bool clipped_start = true;
+	int direction = +1, window_start = 0, window_end = 0, extended_read_start = 0;
+	if (cigar_op(r->cigar[0]) == CIGAR_S && cigar_len(r->cigar[0]) >= min_clipped_length) {
+		clipped_length = cigar_len(r->cigar[0]);
+		clipped_position = 0;
+		direction = -1;
+		window_start = r->pos + min_duplication_length - clipped_length;
+		window_end = r->pos + max_duplication_length - clipped_length;
+		extended_read_start = r->pos - clipped_length;
+		clipped_start = true;
+	}
+	if (cigar_op(r->cigar.back()) == CIGAR_S && cigar_len(r->cigar.back()) >= std::max(min_clipped_length, clipped_length)) {
+		clipped_length = cigar_len(r->cigar.back());
+		clipped_position = r->l_seq - clipped_length;
+		direction = +1;
+		window_start = r->endpos() - max_duplication_length;
+		window_end = r->endpos() - min_duplication_length;
+		extended_read_start = r->endpos();
+		clipped_start = false;
+	}
+	if (clipped_length == 0)
+		return false;
+	if (r->tid < 0 || !assembly.has(r->tid))
+		return false;
+	const std::string& contig_sequence = assembly.sequence[r->tid];
+	if (window_end + max_duplication_length + clipped_length + 1 >= contig_sequence.size() ||
+	    window_start <= (int) (max_duplication_length + clipped_length + 1))
+		return false;
+
+	std::string clipped(clipped_length, 'N');
+	for (unsigned int i = 0; i < clipped_length; ++i)
+		clipped[i] = r->base(clipped_position + i);
+
+	const float min_extended_align_fraction = 0.7;
+	unsigned int extended_matches = 0;
+	for (unsigned int read_pos = 0; read_pos < clipped_length; ++read_pos)
+		if (extended_read_start + read_pos < contig_sequence.size()) // unsigned arithmetic as in the reference
+			if (contig_sequence[extended_read_start + read_pos] == clipped[read_pos])
+				extended_matches++;
+	if (1.0 * extended_matches / clipped_length >= min_extended_align_fraction)
+		return false;
+
+	for (int contig_pos = window_start; contig_pos <= window_end; ++contig_pos) {
+		unsigned int matches = 0, mismatches = 0;
+		tandem.start = contig_sequence.size();
+		tandem.end = -1;
+		for (unsigned int i = 0; i < clipped_length; i++) {
+			int read_pos = (direction == +1) ? i : clipped_length - 1 - i;
+			if (contig_sequence[contig_pos + read_pos] == clipped[read_pos]) {
+				matches++;
+				if (contig_pos + read_pos < tandem.start) tandem.start = contig_pos + read_pos;
+				if (contig_pos + read_pos > tandem.end) tandem.end = contig_pos + read_pos;
+			} else if (i >= max_non_template_bases) {
+				mismatches++;
+				if (mismatches > max_mismatches)
+					break;
+			}
+		}
+		if (matches >= min_alignment_length || matches + mismatches == clipped_length) {
+			tandem.strand = r->forward_strand();
+			tandem.first_in_pair = r->flag & BAM_FREAD1;
+			tandem.contig = r->tid;
+			tandem.supplementary = !(r->flag & BAM_FPAIRED) || clipped_start && r->forward_strand() || !clipped_start && !r->forward_strand();
+			if (!tandem.supplementary)
+				tandem.sequence = decode_sequence(*r);
+			uint32_t clip_left = clipped_start ? 0 : r->l_seq - clipped_length;
+			uint32_t clip_right = clipped_start ? r->l_seq - clipped_length : 0;
+			if (tandem.start > contig_pos) clip_left += tandem.start - contig_pos;
+			if (tandem.end < contig_pos + (int) clipped_length - 1) clip_right += contig_pos + clipped_length - 1 - tandem.end;
+			if (clip_left > 0) tandem.cigar.push_back(cigar_make(clip_left, CIGAR_S));
+			tandem.cigar.push_back(cigar_make(tandem.end - tandem.start + 1, CIGAR_M));
+			if (clip_right > 0) tandem.cigar.push_back(cigar_make(clip_right, CIGAR_S));
+			return true;
+		}
+	}
+	return false;
+}
+
+// reference: source/read_chimeric_alignments.cpp:340-373
+bool disjoin_split_read_segments(Alignment& split_read, Alignment& supplementary) {
+	const int min_remaining_supplementary_segment = 10;
+	unsigned int clipped_split_read = split_read.strand ? split_read.preclipping() : split_read.postclipping();
+	unsigned int clipped_supplementary = supplementary.strand ? supplementary.postclipping() : supplementary.preclipping();
+	int overlap = (int) split_read.sequence.size() - clipped_split_read - clipped_supplementary;
+	if (overlap <= 0)
+		return true;
+	unsigned int clipped_op = supplementary.strand ? supplementary.cigar.size() - 1 : 0;
+	unsigned int matching_op = supplementary.strand ? clipped_op - 1 : 1;
+	if (supplementary.cigar.size() < 2 || cigar_op(supplementary.cigar.at(matching_op)) != CIGAR_M ||
+	    (int) cigar_len(supplementary.cigar.at(matching_op)) < overlap + min_remaining_supplementary_segment)
+		return false;
+	supplementary.cigar[clipped_op] = cigar_make(cigar_len(supplementary.cigar[clipped_op]) + overlap, cigar_op(supplementary.cigar[clipped_op]));
+	supplementary.cigar[matching_op] = cigar_make(cigar_len(supplementary.cigar[matching_op]) - overlap, cigar_op(supplementary.cigar[matching_op]));
+	if (supplementary.strand) supplementary.end -= overlap; else supplementary.start += overlap;
+	return true;
+}
+
+inline bool complement_strand_if(bool strand, bool condition) { return condition ? !strand : strand; }
+
+// reference: source/read_chimeric_alignments.cpp:377-506; returns false if the fragment is malformed
+bool normalize_fragment(Fragment& f) {
+	std::vector<Alignment>& a = f.alignments;
+	if (f.single_end) {
+		if (!(a.size() == 2 && (a[MATE1].supplementary != a[MATE2].supplementary)))
+			return false;
+		if (a[MATE1].end - a[MATE1].start > a[MATE2].end - a[MATE2].start) {
+			a.push_back(a[MATE2]);
+			a[MATE2] = a[MATE1];
+		} else {
+			a.push_back(a[MATE1]);
+			a[MATE1] = a[MATE2];
+		}
+		if (!a[MATE1].supplementary) {
+			a[SPLIT_READ].sequence = a[MATE1].sequence;
+		} else if (!a[SPLIT_READ].supplementary) {
+			a[MATE1].sequence = a[SPLIT_READ].sequence;
+		} else {
+			a[MATE1].sequence = a[SUPPLEMENTARY].sequence;
+			a[SPLIT_READ].sequence = a[SUPPLEMENTARY].sequence;
+		}
+		a[SUPPLEMENTARY].sequence.clear();
+		if (cigar_op(a[MATE1].cigar.at(0)) == CIGAR_H)
+			a[MATE1].cigar[0] = cigar_make(cigar_len(a[MATE1].cigar[0]), CIGAR_S);
+		if (cigar_op(a[MATE1].cigar.back()) == CIGAR_H)
+			a[MATE1].cigar.back() = cigar_make(cigar_len(a[MATE1].cigar.back()), CIGAR_S);
+		if (cigar_op(a[SPLIT_READ].cigar.at(0)) == CIGAR_H)
+			a[SPLIT_READ].cigar[0] = cigar_make(cigar_len(a[SPLIT_READ].cigar[0]), CIGAR_S);
+		if (cigar_op(a[SPLIT_READ].cigar.back()) == CIGAR_H) // the length is taken from MATE1's CIGAR at SPLIT_READ's last index, exactly as the reference does (:415)
+			a[SPLIT_READ].cigar.back() = cigar_make(cigar_len(a[MATE1].cigar.at(a[SPLIT_READ].cigar.size() - 1)), CIGAR_S);
+		a[SUPPLEMENTARY].supplementary = true;
+		a[MATE1].supplementary = false;
+		a[SPLIT_READ].supplementary = false;
+		bool flip_mate1_strand;
+		bool same = a[SPLIT_READ].strand == a[SUPPLEMENTARY].strand;
+		if (a[SPLIT_READ].sequence.length() - a[SPLIT_READ].preclipping() - (same ? a[SUPPLEMENTARY].postclipping() : a[SUPPLEMENTARY].preclipping()) <
+		    a[SPLIT_READ].sequence.length() - a[SPLIT_READ].postclipping() - (same ? a[SUPPLEMENTARY].preclipping() : a[SUPPLEMENTARY].postclipping()))
+			flip_mate1_strand = a[SPLIT_READ].strand == true;
+		else
+			flip_mate1_strand = a[SPLIT_READ].strand == false;
+		a[MATE1].strand = complement_strand_if(a[MATE1].strand, flip_mate1_strand);
+		a[SPLIT_READ].strand = complement_strand_if(a[SPLIT_READ].strand, !flip_mate1_strand);
+		a[SUPPLEMENTARY].strand = complement_strand_if(a[SUPPLEMENTARY].strand, !flip_mate1_strand);
+		a[MATE1].first_in_pair = !flip_mate1_strand;
+		a[SPLIT_READ].first_in_pair = flip_mate1_strand;
+		a[SUPPLEMENTARY].first_in_pair = flip_mate1_strand;
+		if (!disjoin_split_read_segments(a[SPLIT_READ], a[SUPPLEMENTARY]))
+			return false;
+	} else {
+		if (a.size() == 3) {
+			if (a[MATE1].supplementary) std::swap(a[MATE1], a[SUPPLEMENTARY]);
+			else if (a[MATE2].supplementary) std::swap(a[MATE2], a[SUPPLEMENTARY]);
+			if (a[SPLIT_READ].first_in_pair != a[SUPPLEMENTARY].first_in_pair)
+				std::swap(a[MATE1], a[MATE2]);
+			if (a[MATE1].supplementary || a[SPLIT_READ].supplementary || !a[SUPPLEMENTARY].supplementary)
+				return false;
+			if (a[MATE1].contig != a[SPLIT_READ].contig || a[MATE1].strand == a[SPLIT_READ].strand)
+				return false;
+			if (!disjoin_split_read_segments(a[SPLIT_READ], a[SUPPLEMENTARY]))
+				return false;
+		} else if (a.size() == 2) {
+			if (a[MATE1].supplementary || a[MATE2].supplementary)
+				return false;
+		} else {
+			return false;
+		}
+	}
+	if (cigar_op(a[MATE1].cigar.at(0)) == CIGAR_H || cigar_op(a[MATE1].cigar.back()) == CIGAR_H ||
+	    cigar_op(a[MATE2].cigar.at(0)) == CIGAR_H || cigar_op(a[MATE2].cigar.back()) == CIGAR_H)
+		return false;
+	return true;
+}
+
+// reference: source/read_chimeric_alignments.cpp:511-522
+bool is_clipped_at_correct_end(const Record& r) {
+	if (!(r.flag & BAM_FPAIRED))
+		return true;
+	unsigned int clipped_end;
+	if (r.flag & BAM_FSUPPLEMENTARY)
+		clipped_end = r.forward_strand() ? r.n_cigar() - 1 : 0;
+	else
+		clipped_end = r.forward_strand() ? 0 : r.n_cigar() - 1;
+	uint32_t op = cigar_op(r.cigar[clipped_end]);
+	return op == CIGAR_S || op == CIGAR_H;
+}
+
+// reference: source/read_chimeric_alignments.cpp:526-558
+bool is_pristine_alignment(const Record& r) {
+	for (unsigned int i = 0; i < r.n_cigar(); i++) {
+		uint32_t op = cigar_op(r.cigar[i]);
+		if (op != CIGAR_N && op != CIGAR_M && op != CIGAR_X)
+			return false;
+	}
+	std::string sequence = decode_sequence(r);
+	for (unsigned int i = 2, repeat = 0, count = 1; i + 2 < sequence.size(); i += 2) {
+		if (sequence[i] == sequence[repeat] && sequence[i + 1] == sequence[repeat + 1]) {
+			count++;
+		} else if (sequence[i + 1] == sequence[repeat + 1] && sequence[i + 2] == sequence[repeat + 2]) {
+			count++;
+			i++;
+		} else {
+			count = 1;
+			repeat = i;
+		}
+		if (count >= 8)
+			return false;
+	}
+	return true;
+}
+
+// reference: source/read_stats.cpp:161-266.  flag1 is mate1's flag word as the caller left it (the
+// reference zeroes it for discordant mates, source/read_chimeric_alignments.cpp:664).
+void add_fragment_to_coverage(Coverage& coverage, const Record& mate1, uint16_t flag1, const Record* mate2_or_null, bool is_chimeric) {
+	const Record& mate2 = (mate2_or_null == NULL) ? mate1 : *mate2_or_null;
+	uint16_t flag2 = (mate2_or_null == NULL) ? flag1 : mate2.flag;
+	if ((unsigned int) mate1.tid >= coverage.fragment_starts.size() || coverage.fragment_starts[mate1.tid].empty() ||
+	    (unsigned int) mate2.tid >= coverage.fragment_starts.size() || coverage.fragment_starts[mate2.tid].empty())
+		return;
+	// the reference compares bam_cigar_type() (0..3) against BAM_CSOFT_CLIP (4), which never matches,
+	// so only the proper-pair flag can turn a fragment chimeric here
+	if ((flag1 & BAM_FPAIRED) && !(flag1 & BAM_FPROPER_PAIR))
+		is_chimeric = true;
+	if (!is_chimeric) {
+		if (!(flag1 & BAM_FREVERSE) || !(flag1 & BAM_FPAIRED))
+			coverage.fragment_starts[mate1.tid][mate1.pos / COVERAGE_RESOLUTION] = 1;
+		else
+			coverage.fragment_starts[mate2.tid][mate2.pos / COVERAGE_RESOLUTION] = 1;
+	}
+	position_t position1 = mate1.pos, position2 = mate2.pos;
+	position_t position = std::min(position1, position2);
+	int window = position / COVERAGE_RESOLUTION;
+	unsigned int i1 = 0, i2 = 0;
+	while (true) {
+		uint32_t op1 = 0, op2 = 0;
+		unsigned int length1, length2;
+		if (i1 < mate1.n_cigar()) {
+			op1 = mate1.cigar[i1];
+			length1 = cigar_consumes_reference(cigar_op(op1)) ? cigar_len(op1) : 0;
+		} else {
+			length1 = 0;
+			window = std::max(window, position2 / COVERAGE_RESOLUTION);
+		}
+		if (i2 < mate2.n_cigar()) {
+			op2 = mate2.cigar[i2];
+			length2 = cigar_consumes_reference(cigar_op(op2)) ? cigar_len(op2) : 0;
+		} else {
+			length2 = 0;
+			window = std::max(window, position1 / COVERAGE_RESOLUTION);
+		}
+		int contig;
+		uint32_t op;
+		if (i1 < mate1.n_cigar() && (position1 + length1 < position2 + length2 || i2 >= mate2.n_cigar())) {
+			i1++;
+			if (length1 == 0) continue;
+			op = op1; contig = mate1.tid; position1 += length1; position = position1;
+		} else if (i2 < mate2.n_cigar()) {
+			i2++;
+			if (length2 == 0) continue;
+			op = op2; contig = mate2.tid; position2 += length2; position = position2;
+		} else {
+			break;
+		}
+		std::vector<uint16_t>& windows = coverage.coverage[contig];
+		if (cigar_consumes_query(cigar_op(op))) {
+			while (window <= position / COVERAGE_RESOLUTION) {
+				if (window >= 0 && (size_t) window < windows.size() && windows[window] < 65535)
+					if (position - window * COVERAGE_RESOLUTION >= COVERAGE_RESOLUTION / 2)
+						windows[window]++;
+				++window;
+			}
+		} else {
+			window = position / COVERAGE_RESOLUTION;
+		}
+	}
+	if (!is_chimeric) {
+		if ((flag1 & BAM_FREVERSE) || !(flag1 & BAM_FPAIRED))
+			coverage.fragment_ends[mate1.tid][(position1 - 1) / COVERAGE_RESOLUTION] = 1;
+		else
+			coverage.fragment_ends[mate2.tid][(position2 - 1) / COVERAGE_RESOLUTION] = 1;
+	}
+}
+
+uint8_t encode_base(char c) {
+	switch (c) {
+		case '=': return 0; case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6; case 'V': return 7;
+		case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14; default: return 15;
+	}
+}
+
+void pack_batch(std::vector<std::pair<const std::string*, Fragment*> >& sorted, Batch& batch) {
+	size_t n = sorted.size();
+	batch.n = n;
+	batch.n_aln.resize(n); batch.fbits.resize(n); batch.filter.assign(n, FILTER_none); batch.group.resize(n);
+	for (int s = 0; s < 3; ++s) {
+		batch.contig[s].assign(n, 0); batch.start[s].assign(n, 0); batch.end[s].assign(n, 0); batch.abits[s].assign(n, 0);
+		batch.cigar_offset[s].assign(n, 0); batch.cigar_count[s].assign(n, 0);
+	}
+	for (int s = 0; s < 2; ++s) { batch.seq_offset[s].assign(n, 0); batch.seq_length[s].assign(n, 0); }
+	batch.name_offset.assign(n + 1, 0);
+	uint32_t group = 0;
+	for (size_t i = 0; i < n; ++i) {
+		const std::string& name = *sorted[i].first;
+		const Fragment& f = *sorted[i].second;
+		batch.name_offset[i] = batch.names.size();
+		batch.names += name;
+		// multimapper groups: identical names up to the last ',' (source/common.hpp:222)
+		if (i > 0) {
+			const std::string& previous = *sorted[i - 1].first;
+			size_t a = name.find_last_of(','), b = previous.find_last_of(',');
+			if (!(name.compare(0, a, previous, 0, b) == 0))
+				++group;
+		}
+		batch.group[i] = group;
+		batch.n_aln[i] = f.alignments.size();
+		batch.fbits[i] = (f.single_end ? FBIT_SINGLE_END : 0) | (f.duplicate ? FBIT_DUPLICATE : 0);
+		for (size_t s = 0; s < f.alignments.size(); ++s) {
+			const Alignment& a = f.alignments[s];
+			batch.contig[s][i] = a.contig; batch.start[s][i] = a.start; batch.end[s][i] = a.end;
+			batch.abits[s][i] = (a.strand ? ABIT_STRAND : 0) | (a.first_in_pair ? ABIT_FIRST_IN_PAIR : 0) | (a.supplementary ? ABIT_SUPPLEMENTARY : 0) | ABIT_PREDICTED_STRAND_AMBIGUOUS;
+			batch.cigar_offset[s][i] = batch.cigar_pool.size();
+			batch.cigar_count[s][i] = a.cigar.size();
+			batch.cigar_pool.insert(batch.cigar_pool.end(), a.cigar.begin(), a.cigar.end());
+			if (s < 2) {
+				batch.seq_offset[s][i] = batch.seq_pool.size() / 4;
+				batch.seq_length[s][i] = a.sequence.size();
+				size_t bytes = (a.sequence.size() + 1) / 2;
+				size_t base = batch.seq_pool.size();
+				batch.seq_pool.resize(base + ((bytes + 3) & ~(size_t) 3), 0);
+				for (size_t b = 0; b < a.sequence.size(); ++b)
+					batch.seq_pool[base + (b >> 1)] |= encode_base(a.sequence[b]) << ((~b & 1) << 2);
+			}
+		}
+	}
+	batch.name_offset[n] = batch.names.size();
+}
+
+}
+
+// reference: source/read_chimeric_alignments.cpp:560-773
+void read_chimeric_alignments(ByteSource& source, const Assembly& assembly, Contigs& contigs, const Annotation& annotation, const FlatIndex& gene_index, const IngestOptions& options, IngestResult& result) {
+	BamStream stream(source);
+	std::vector<std::string> target_names;
+	stream.read_header(target_names);
+
+	std::vector<contig_t> tid_to_contig(target_names.size());
+	std::vector<bool> interesting_tids(target_names.size());
+	for (size_t target = 0; target < target_names.size(); ++target) {
+		std::string contig_name = remove_chr(target_names[target]);
+		tid_to_contig[target] = contigs.add(target_names[target]);
+		if (tid_to_contig[target] >= interesting_tids.size())
+			interesting_tids.resize(tid_to_contig[target] + 1);
+		interesting_tids[tid_to_contig[target]] = is_interesting_contig(contig_name, options.interesting_contigs);
+	}
+	result.coverage.resize(contigs, assembly);
+	for (std::map<std::string, contig_t>::const_iterator contig = contigs.by_name.begin(); contig != contigs.by_name.end(); ++contig)
+		if (!assembly.has(contig->second) && is_interesting_contig(contig->first, options.interesting_contigs))
+			throw std::runtime_error("could not find sequence of contig '" + contig->first + "'");
+	std::vector<bool> viral_contigs(contigs.size());
+	for (std::map<std::string, contig_t>::const_iterator contig = contigs.by_name.begin(); contig != contigs.by_name.end(); ++contig)
+		viral_contigs[contig->second] = is_interesting_contig(contig->first, options.viral_contigs);
+	result.mapped_viral_reads_by_contig.assign(contigs.size(), 0);
+
+	fragment_table_t fragments;
+	std::unordered_map<std::string, Record> collated; // first mate parked until the second arrives
+	bool no_chimeric_reads = true;
+	Record record;
+	std::string read_name;
+	while (stream.next(record)) {
+		result.records++;
+		if ((record.flag & BAM_FUNMAP) || (record.flag & BAM_FPAIRED) && (record.flag & BAM_FMUNMAP))
+			continue;
+		int64_t hit_index = 1;
+		const uint8_t* hi_tag = record.aux_get('H', 'I');
+		if (hi_tag != NULL) {
+			hit_index = Record::aux_to_int(hi_tag);
+		} else if (record.flag & BAM_FSECONDARY) {
+			result.missing_hi_tag++;
+			continue;
+		}
+		read_name = record.qname;
+		read_name += "," + std::to_string(hit_index);
+		if (record.tid < 0 || (size_t) record.tid >= tid_to_contig.size())
+			throw std::runtime_error("failed to load alignments");
+		record.tid = tid_to_contig[record.tid];
+
+		if (record.flag & BAM_FSUPPLEMENTARY) {
+			if (is_clipped_at_correct_end(record))
+				add_chimeric_alignment(fragments[read_name], record, true);
+			else
+				result.malformed_count++;
+			no_chimeric_reads = false;
+			continue;
+		}
+		if (interesting_tids[record.tid])
+			result.mapped_reads++;
+		if ((record.flag & BAM_FPAIRED) && !(record.flag & BAM_FPROPER_PAIR)) {
+			add_chimeric_alignment(fragments[read_name], record);
+			no_chimeric_reads = false;
+			if (!options.external_duplicate_marking || !(record.flag & BAM_FDUP))
+				add_fragment_to_coverage(result.coverage, record, 0 /* flag &= !BAM_FPAIRED zeroes the word */, NULL, true);
+			continue;
+		}
+
+		Record previous;
+		bool have_previous = false;
+		if (record.flag & BAM_FPAIRED) {
+			std::unordered_map<std::string, Record>::iterator parked = collated.find(read_name);
+			if (parked == collated.end()) {
+				collated.insert(std::make_pair(read_name, record));
+				continue; // first mate: wait for the second
+			}
+			previous = parked->second;
+			have_previous = true;
+			collated.erase(parked);
+		}
+		const Record* previous_mate = have_previous ? &previous : NULL;
+
+		bool is_tandem_alignment = false;
+		Alignment tandem;
+		if (!clipped_sequence_is_adapter(&record, previous_mate) &&
+		    (previous_mate == NULL || record.forward_strand() != previous_mate->forward_strand()) &&
+		    (is_tandem_duplication(&record, assembly, options.max_itd_length, tandem) || is_tandem_duplication(previous_mate, assembly, options.max_itd_length, tandem))) {
+			Fragment& mates = fragments[read_name + "ITD"];
+			add_chimeric_alignment(mates, record, record.forward_strand() == tandem.strand && !tandem.supplementary);
+			if (previous_mate != NULL)
+				add_chimeric_alignment(mates, *previous_mate, previous_mate->forward_strand() == tandem.strand && !tandem.supplementary);
+			mates.alignments.push_back(tandem);
+			is_tandem_alignment = true;
+		}
+
+		bool is_read_through = false;
+		if (record.aux_get('S', 'A') != NULL && is_clipped_at_correct_end(record) ||
+		    previous_mate != NULL && previous_mate->aux_get('S', 'A') != NULL && is_clipped_at_correct_end(*previous_mate)) {
+			Fragment& mates = fragments[read_name];
+			add_chimeric_alignment(mates, record);
+			if (previous_mate != NULL)
+				add_chimeric_alignment(mates, *previous_mate);
+			no_chimeric_reads = false;
+		} else if (!is_tandem_alignment) {
+			is_read_through = extract_read_through_alignment(fragments, read_name, &record, previous_mate, annotation, gene_index);
+			if (viral_contigs[record.tid])
+				for (const Record* mate = &record; mate != NULL; mate = (mate == previous_mate) ? NULL : previous_mate)
+					if (is_pristine_alignment(*mate))
+						result.mapped_viral_reads_by_contig[mate->tid]++;
+		}
+		if (!options.external_duplicate_marking || !(record.flag & BAM_FDUP))
+			add_fragment_to_coverage(result.coverage, record, record.flag, previous_mate, is_read_through);
+	}
+
+	if (result.mapped_reads == 0)
+		throw std::runtime_error("no normal reads found");
+
+	// sanity check + slot normalisation, then order by name (hazard H3: std::string order of "QNAME,HI")
+	std::vector<std::pair<const std::string*, Fragment*> > sorted;
+	sorted.reserve(fragments.size());
+	for (fragment_table_t::iterator fragment = fragments.begin(); fragment != fragments.end(); ++fragment) {
+		if (normalize_fragment(fragment->second))
+			sorted.push_back(std::make_pair(&fragment->first, &fragment->second));
+		else
+			result.malformed_count++;
+	}
+	if (result.malformed_count > 0)
+		std::cerr << "WARNING: " << result.malformed_count << " SAM records were malformed and ignored" << std::endl;
+	if (no_chimeric_reads)
+		throw std::runtime_error("no split reads or discordant mates found (STAR must either be run with '--chimOutType WithinBAM' or the file 'Chimeric.out.sam' must be passed to Arriba via the argument -c)");
+	if (result.missing_hi_tag > 0)
+		std::cerr << "WARNING: " << result.missing_hi_tag << " secondary alignments lack the 'HI' tag and were ignored (STAR must be run with '--outSAMattributes HI' for Arriba to make use of multi-mapping reads for fusion detection)" << std::endl;
+	std::sort(sorted.begin(), sorted.end(), [](const std::pair<const std::string*, Fragment*>& a, const std::pair<const std::string*, Fragment*>& b) { return *a.first < *b.first; });
+	pack_batch(sorted, result.batch);
+}
+
+}
