@@ -1,0 +1,147 @@
+"""ctypes bindings of the two C ABIs (include/arriba_gpu.h, include/arriba_host.h).
+
+The device library is mandatory: there is no CPU fallback for the hot path.  Loading fails loudly if
+``arriba_amd/lib/libarriba_gpu.so`` is missing (build it with ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
+
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+FILTER_COUNT = 38
+FILTER_NAMES = [
+    "", "duplicates", "inconsistently_clipped", "homopolymer", "read_through", "same_gene", "small_insert_size", "long_gap", "hairpin",
+    "multimappers", "mismatches", "mismappers", "relative_support", "intronic", "non_coding_neighbors", "intragenic_exonic",
+    "internal_tandem_duplication", "min_support", "known_fusions", "spliced", "blacklist", "end_to_end", "in_vitro", "merge_adjacent",
+    "select_best", "marginal_read_through", "short_anchor", "no_coverage", "many_spliced", "no_genomic_support", "uninteresting_contigs",
+    "viral_contigs", "top_expressed_viral_contigs", "low_coverage_viral_contigs", "genomic_support", "isoforms", "low_entropy", "homologs",
+]
+
+
+class FlatIndex(ctypes.Structure):
+    _fields_ = [("n_contigs", c_uint32), ("contig_offset", POINTER(c_uint32)), ("n_keys", c_uint32), ("keys", POINTER(c_int32)),
+                ("member_offset", POINTER(c_uint32)), ("n_members", c_uint32), ("members", POINTER(c_uint32))]
+
+
+class AnnotationView(ctypes.Structure):
+    _fields_ = [("n_genes", c_uint32), ("gene_contig", POINTER(c_uint16)), ("gene_start", POINTER(c_int32)), ("gene_end", POINTER(c_int32)),
+                ("gene_bits", POINTER(c_uint8)), ("gene_exonic_length", POINTER(c_int32)),
+                ("n_exons", c_uint32), ("exon_start", POINTER(c_int32)), ("exon_end", POINTER(c_int32)), ("exon_gene", POINTER(c_uint32)),
+                ("exon_previous", POINTER(c_int32)), ("exon_next", POINTER(c_int32)), ("exon_cds_start", POINTER(c_int32)), ("exon_cds_end", POINTER(c_int32)),
+                ("exon_index", FlatIndex), ("gene_index", FlatIndex)]
+
+
+class GenomeView(ctypes.Structure):
+    _fields_ = [("n_contigs", c_uint32), ("contig_offset", POINTER(c_uint64)), ("contig_bits", POINTER(c_uint8)), ("bases", c_void_p)]
+
+
+class BatchView(ctypes.Structure):
+    _fields_ = [("n", c_uint64), ("n_aln", POINTER(c_uint8)), ("fbits", POINTER(c_uint8)), ("group", POINTER(c_uint32)),
+                ("contig", POINTER(c_uint16) * 3), ("start", POINTER(c_int32) * 3), ("end", POINTER(c_int32) * 3), ("abits", POINTER(c_uint8) * 3),
+                ("cigar_offset", POINTER(c_uint32) * 3), ("cigar_count", POINTER(c_uint16) * 3),
+                ("cigar_pool_size", c_uint64), ("cigar_pool", POINTER(c_uint32)),
+                ("seq_offset", POINTER(c_uint32) * 2), ("seq_length", POINTER(c_uint32) * 2),
+                ("seq_pool_size", c_uint64), ("seq_pool", POINTER(c_uint8))]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("homopolymer_length", c_uint32), ("min_read_through_distance", c_uint32), ("max_itd_length", c_uint32), ("subsampling_threshold", c_uint32),
+                ("mismatch_pvalue_cutoff", c_float), ("max_kmer_content", c_float), ("evalue_cutoff", c_float), ("max_mismapper_fraction", c_float),
+                ("fragment_length", c_uint32), ("external_duplicate_marking", c_uint8), ("strandedness", c_uint8), ("filter_enabled", c_uint8 * FILTER_COUNT)]
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: the MI355X hot path has no CPU fallback. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950)." % path)
+    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+def bind_device_api(lib, prefix="agpu_"):
+    """Declare the argument types of the device C ABI on `lib` and return a namespace of its functions."""
+    class Api(object):
+        pass
+    api = Api()
+    ctx = c_void_p
+    signatures = {
+        "last_error": (c_char_p, []),
+        "api_version": (c_int, []),
+        "device_count": (c_int, []),
+        "default_params": (None, [POINTER(Params)]),
+        "create": (ctx, [c_int, POINTER(Params)]),
+        "destroy": (None, [ctx]),
+        "set_params": (c_int, [ctx, POINTER(Params)]),
+        "upload_annotation": (c_int, [ctx, POINTER(AnnotationView)]),
+        "upload_genome": (c_int, [ctx, POINTER(GenomeView)]),
+        "upload_batch": (c_int, [ctx, POINTER(BatchView)]),
+        "mark_multimappers": (c_int, [ctx, POINTER(c_uint64)]),
+        "annotate": (c_int, [ctx, POINTER(c_uint32)]),
+        "read_filters_stage1": (c_int, [ctx, c_void_p, c_void_p]),
+        "get_viral_integration_sites": (c_int, [ctx, c_void_p, c_uint64, POINTER(c_uint64)]),
+        "fragment_length_samples": (c_int, [ctx, c_void_p, POINTER(c_uint32), POINTER(c_uint64)]),
+        "read_filters_stage2": (c_int, [ctx, c_void_p]),
+        "find_fusions": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
+        "get_filters": (c_int, [ctx, c_void_p]),
+        "get_alignment_bits": (c_int, [ctx, c_int, c_void_p]),
+        "get_fragment_bits": (c_int, [ctx, c_void_p]),
+        "get_gene_sets": (c_int, [ctx, c_int, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
+        "get_gene_table": (c_int, [ctx, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "last_kernel_ms": (c_int, [ctx, POINTER(c_float)]),
+        "last_kernel_bytes": (c_int, [ctx, POINTER(c_uint64)]),
+    }
+    for name, (restype, argtypes) in signatures.items():
+        function = getattr(lib, prefix + name, None)
+        if function is None:
+            continue
+        function.restype = restype
+        function.argtypes = argtypes
+        setattr(api, name, function)
+    api.exported = sorted(name for name in signatures if hasattr(api, name))
+    api.declared = sorted(signatures)
+    return api
+
+
+def bind_host_api(lib):
+    session = c_void_p
+    signatures = {
+        "ahost_last_error": (c_char_p, []),
+        "ahost_open": (session, [c_char_p, c_char_p, c_char_p, c_char_p, c_char_p]),
+        "ahost_close": (None, [session]),
+        "ahost_ingest_bam_file": (c_int, [session, c_char_p, c_int, ctypes.c_uint]),
+        "ahost_ingest_bam_memory": (c_int, [session, c_void_p, c_size_t, c_int, ctypes.c_uint]),
+        "ahost_annotation_view": (POINTER(AnnotationView), [session]),
+        "ahost_genome_view": (POINTER(GenomeView), [session]),
+        "ahost_batch_view": (POINTER(BatchView), [session]),
+        "ahost_fragment_count": (c_uint64, [session]),
+        "ahost_mapped_reads": (c_uint64, [session]),
+        "ahost_contig_count": (c_uint32, [session]),
+        "ahost_contig_name": (c_char_p, [session, c_uint32]),
+        "ahost_fragment_name": (c_void_p, [session, c_uint64, POINTER(c_uint32)]),
+        "ahost_detect_strandedness": (c_int, [session]),
+        "ahost_viral_verdicts": (c_int, [session, c_void_p, c_uint64, c_void_p, c_uint32, ctypes.c_uint, c_float, c_void_p, c_void_p]),
+        "ahost_estimate_fragment_length": (c_int, [session, c_void_p, c_uint32, c_uint64, ctypes.c_uint, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int32)]),
+    }
+    for name, (restype, argtypes) in signatures.items():
+        function = getattr(lib, name)
+        function.restype = restype
+        function.argtypes = argtypes
+    return lib
+
+
+_device_lib = None
+_host_lib = None
+
+
+def device_library():
+    global _device_lib
+    if _device_lib is None:
+        _device_lib = _load(os.path.join(LIB_DIR, "libarriba_gpu.so"))
+    return _device_lib
+
+
+def host_library():
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = bind_host_api(_load(os.path.join(LIB_DIR, "libarriba_host.so")))
+    return _host_lib

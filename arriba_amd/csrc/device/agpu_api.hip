@@ -1,0 +1,716 @@
+// arriba_amd/csrc/device/agpu_api.hip -- HIP kernels (gfx950) and the C ABI of include/arriba_gpu.h.
+//
+// Kernel inventory (all HBM-bandwidth / latency bound integer work, one thread per chimeric fragment,
+// columns read with coalesced loads, no MFMA):
+//   mark_multimappers_kernel   neighbour compare of the name-group column
+//   annotate_stage1_kernel     strands, exon/gene interval lookups, splice-site disambiguation, unmapped positions
+//   dummy_*_kernel             segmentation of the sorted unmapped positions into intergenic dummy genes
+//   annotate_stage2_kernel     dummy-gene assignment, viral integration-site pairs
+//   duplicate_*_kernel         duplicate keys, lock-free hash insert (min name rank per key), resolve
+//   stage1_kernel              duplicates + contig filters
+//   sample_*_kernel            ordered mate-gap samples for the fragment-length estimate
+//   stage2_kernel              read_through ... low_entropy cascade (k-mer counters in LDS)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+#include "agpu_context.hpp"
+
+using namespace agpu;
+
+namespace agpu {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& message) { g_last_error = message; }
+}
+
+namespace {
+
+const int BLOCK = 256;
+enum { COUNTER_GENE_POOL = 0, COUNTER_UNMAPPED = 1, COUNTER_ERROR = 2, COUNTER_VIRAL_PAIRS = 3, COUNTER_MARKED = 4, COUNTER_SAMPLES = 5, COUNTER_VISITED_LO = 6, COUNTER_VISITED_HI = 7, COUNTER_COUNT = 16 };
+enum { ERROR_GENE_SET_OVERFLOW = 1, ERROR_VIRAL_PAIR_OVERFLOW = 2 };
+const uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
+const uint32_t MAX_SAMPLES = 100001;
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
+
+inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1) / BLOCK); }
+
+// ---- kernels ------------------------------------------------------------------------------------
+
+__global__ void mark_multimappers_kernel(BatchView b, uint32_t* counters) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	uint32_t group = b.group[i];
+	bool same_as_previous = i > 0 && b.group[i - 1] == group;
+	bool same_as_next = i + 1 < b.n && b.group[i + 1] == group;
+	if (same_as_previous || same_as_next) b.fbits[i] |= FBIT_MULTIMAPPER;
+	if (same_as_next) atomicAdd(&counters[COUNTER_MARKED], 1u); // the compiler folds this into one add per wave
+}
+
+__global__ void annotate_stage1_kernel(BatchView b, AnnotationView ann, uint32_t strandedness, uint64_t* unmapped_keys, uint32_t* counters) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	if (!annotate_fragment_stage1(b, ann, strandedness, i, unmapped_keys, &counters[COUNTER_UNMAPPED]))
+		atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_GENE_SET_OVERFLOW);
+}
+
+__global__ void dummy_flags_kernel(const uint64_t* sorted_keys, uint32_t n, FlatIndexView gene_index, uint32_t* flags) {
+	uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	flags[i] = dummy_gene_starts_here(sorted_keys, i, gene_index) ? 1u : 0u;
+}
+
+// ids = inclusive scan of flags; dummy gene j = ids[i]-1 covers the run of positions with that id
+__global__ void dummy_write_kernel(const uint64_t* sorted_keys, uint32_t n, const uint32_t* flags, const uint32_t* ids, uint64_t* dummy_start_key, uint64_t* dummy_end_key) {
+	uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	uint32_t j = ids[i] - 1;
+	if (flags[i]) dummy_start_key[j] = sorted_keys[i];
+	if (i + 1 == n || flags[i + 1]) dummy_end_key[j] = sorted_keys[i];
+}
+
+__global__ void dummy_gene_table_kernel(uint32_t n_genes, uint32_t n_dummy, const uint64_t* dummy_start_key, const uint64_t* dummy_end_key,
+                                        uint16_t* gene_contig, int32_t* gene_start, int32_t* gene_end, uint8_t* gene_bits, int32_t* gene_exonic_length) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= n_dummy) return;
+	uint32_t g = n_genes + j;
+	gene_contig[g] = (uint16_t) (dummy_start_key[j] >> 32);
+	gene_start[g] = (int32_t) (uint32_t) dummy_start_key[j];
+	gene_end[g] = (int32_t) (uint32_t) dummy_end_key[j];
+	gene_bits[g] = GBIT_STRAND | GBIT_DUMMY;  // strand FORWARD, not protein coding (source/arriba.cpp:238-241)
+	gene_exonic_length[g] = 10000;
+}
+
+__global__ void annotate_stage2_kernel(BatchView b, AnnotationView ann, GenomeView genome, uint32_t* viral_pairs, uint32_t viral_pair_capacity, uint32_t* counters) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	if (!annotate_fragment_stage2(b, ann, i))
+		atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_GENE_SET_OVERFLOW);
+	// virus-host chimeric fragments: host genes per viral contig (source/filter_top_expressed_viral_contigs.cpp:95-112)
+	int mate2 = (b.n_aln[i] == 3) ? SUPPLEMENTARY : MATE2;
+	int viral_slot = -1, host_slot = -1;
+	uint8_t bits1 = genome.contig_bits[b.contig[MATE1][i]], bits2 = genome.contig_bits[b.contig[mate2][i]];
+	if (bits1 & CBIT_VIRAL) viral_slot = MATE1; else if (bits1 & CBIT_INTERESTING) host_slot = MATE1;
+	if (bits2 & CBIT_VIRAL) viral_slot = mate2; else if (bits2 & CBIT_INTERESTING) host_slot = mate2;
+	if (viral_slot >= 0 && host_slot >= 0) {
+		IdSet genes; load_genes(b, host_slot, i, genes);
+		uint32_t at = atomicAdd(&counters[COUNTER_VIRAL_PAIRS], genes.n);
+		if (at + genes.n > viral_pair_capacity) { atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_VIRAL_PAIR_OVERFLOW); return; }
+		for (uint32_t g = 0; g < genes.n; ++g) {
+			viral_pairs[2 * (at + g)] = b.contig[viral_slot][i];
+			viral_pairs[2 * (at + g) + 1] = genes.v[g];
+		}
+	}
+}
+
+__global__ void duplicate_keys_kernel(BatchView b, DuplicateKey* keys) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	keys[i] = duplicate_key(b, i);
+}
+
+// lock-free open addressing: every slot holds the smallest name rank seen for its key
+__global__ void duplicate_insert_kernel(uint64_t n, const DuplicateKey* keys, uint32_t* slots, uint32_t mask) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= n) return;
+	DuplicateKey key = keys[i];
+	uint32_t h = (uint32_t) hash_duplicate_key(key) & mask;
+	while (true) {
+		uint32_t owner = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (owner == EMPTY_SLOT) {
+			owner = atomicCAS(&slots[h], EMPTY_SLOT, (uint32_t) i);
+			if (owner == EMPTY_SLOT) return;
+		}
+		if (keys_equal(keys[owner], key)) { atomicMin(&slots[h], (uint32_t) i); return; }
+		h = (h + 1) & mask;
+	}
+}
+
+__global__ void stage1_kernel(BatchView b, GenomeView genome, FilterTables t, const uint8_t* enabled, const DuplicateKey* keys, const uint32_t* slots, uint32_t mask, unsigned long long* stage_counts) {
+	__shared__ unsigned int hits[5];
+	if (threadIdx.x < 5) hits[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i < b.n) {
+		uint8_t filter = b.filter[i];
+		if (filter == FILTER_none && enabled[FILTER_duplicates]) {
+			if (t.external_duplicate_marking) {
+				if (b.fbits[i] & FBIT_DUPLICATE) filter = FILTER_duplicates;
+			} else {
+				DuplicateKey key = keys[i];
+				uint32_t h = (uint32_t) hash_duplicate_key(key) & mask;
+				while (true) {
+					uint32_t owner = slots[h];
+					if (keys_equal(keys[owner], key)) { if (owner != (uint32_t) i) filter = FILTER_duplicates; break; }
+					h = (h + 1) & mask;
+				}
+			}
+			if (filter != FILTER_none) atomicAdd(&hits[0], 1u);
+		}
+		if (filter == FILTER_none) {
+			uint8_t hit = contig_filters(b, genome, t, i);
+			if (hit != FILTER_none && enabled[hit]) {
+				filter = hit;
+				atomicAdd(&hits[hit == FILTER_uninteresting_contigs ? 1 : hit == FILTER_viral_contigs ? 2 : hit == FILTER_top_expressed_viral_contigs ? 3 : 4], 1u);
+			}
+		}
+		b.filter[i] = filter;
+	}
+	__syncthreads();
+	if (threadIdx.x < 5 && hits[threadIdx.x]) atomicAdd(&stage_counts[threadIdx.x], (unsigned long long) hits[threadIdx.x]);
+}
+
+__global__ void sample_flags_kernel(BatchView b, AnnotationView ann, uint64_t first, uint64_t count, uint8_t* flags, int32_t* values) {
+	uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k >= count) return;
+	uint64_t i = first + k;
+	bool sample = b.filter[i] == FILTER_none && !(b.fbits[i] & FBIT_SINGLE_END) && b.n_aln[i] == 3;
+	flags[k] = sample;
+	if (sample) values[k] = mate_gap_sample(b, ann, i);
+}
+
+// one workgroup appends the flagged values in order until MAX_SAMPLES are collected
+__global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint8_t* flags, const int32_t* values, int32_t* samples, uint32_t* counters) {
+	__shared__ uint32_t wave_totals[16];
+	__shared__ uint32_t base;
+	__shared__ uint32_t done;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+	if (threadIdx.x == 0) { base = counters[COUNTER_SAMPLES]; done = 0; }
+	__syncthreads();
+	for (uint64_t offset = 0; offset < count; offset += blockDim.x) {
+		uint64_t k = offset + threadIdx.x;
+		bool flag = k < count && flags[k];
+		unsigned long long ballot = __ballot(flag);
+		uint32_t before = __popcll(ballot & ((1ull << lane) - 1));
+		if (lane == 0) wave_totals[wave] = __popcll(ballot);
+		__syncthreads();
+		uint32_t wave_offset = 0, total = 0;
+		for (uint32_t w = 0; w < waves; ++w) { if (w < wave) wave_offset += wave_totals[w]; total += wave_totals[w]; }
+		uint32_t position = base + wave_offset + before;
+		if (flag && position < MAX_SAMPLES) {
+			samples[position] = values[k];
+			if (position == MAX_SAMPLES - 1) { // the reference stops right after this fragment
+				uint64_t visited = first + k + 1;
+				counters[COUNTER_VISITED_LO] = (uint32_t) visited; counters[COUNTER_VISITED_HI] = (uint32_t) (visited >> 32);
+				done = 1;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) base += total;
+		__syncthreads();
+		if (done) break;
+	}
+	if (threadIdx.x == 0) counters[COUNTER_SAMPLES] = base < MAX_SAMPLES ? base : MAX_SAMPLES;
+}
+
+__global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationView ann, GenomeView genome, FilterTables t, const uint8_t* enabled, unsigned long long* stage_counts) {
+	__shared__ uint16_t previous_position[64 * BLOCK];
+	__shared__ uint8_t count_all[64 * BLOCK], count_aligned1[64 * BLOCK], count_aligned2[64 * BLOCK];
+	__shared__ unsigned int hits[10];
+	if (threadIdx.x < 10) hits[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i < b.n) {
+		KmerScratch scratch;
+		scratch.previous_position = previous_position + threadIdx.x; scratch.count_all = count_all + threadIdx.x;
+		scratch.count_aligned1 = count_aligned1 + threadIdx.x; scratch.count_aligned2 = count_aligned2 + threadIdx.x; scratch.stride = BLOCK;
+		uint32_t first_hit;
+		uint8_t filter = read_filters_stage2(b, ann, genome, t, enabled, i, b.filter[i], scratch, first_hit);
+		b.filter[i] = filter;
+		atomicAdd(&hits[first_hit], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 10 && hits[threadIdx.x]) atomicAdd(&stage_counts[5 + threadIdx.x], (unsigned long long) hits[threadIdx.x]);
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------
+
+template <class T> int upload(DeviceBuffer& buffer, const T* host, size_t count, hipStream_t stream) {
+	if (!buffer.allocate(count * sizeof(T))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (count > 0) HIP_CHECK(hipMemcpyAsync(buffer.ptr, host, count * sizeof(T), hipMemcpyHostToDevice, stream));
+	return AGPU_OK;
+}
+#define TRY(call) do { int s_ = (call); if (s_ != AGPU_OK) return s_; } while (0)
+
+int upload_index(const agpu_flat_index& in, DeviceBuffer& contig_offset, DeviceBuffer& keys, DeviceBuffer& member_offset, DeviceBuffer& members, FlatIndexView& out, hipStream_t stream) {
+	TRY(upload(contig_offset, in.contig_offset, (size_t) in.n_contigs + 1, stream));
+	TRY(upload(keys, in.keys, in.n_keys, stream));
+	TRY(upload(member_offset, in.member_offset, (size_t) in.n_keys + 1, stream));
+	TRY(upload(members, in.members, in.n_members, stream));
+	out.n_contigs = in.n_contigs;
+	out.contig_offset = contig_offset.as<uint32_t>(); out.keys = keys.as<int32_t>();
+	out.member_offset = member_offset.as<uint32_t>(); out.members = members.as<uint32_t>();
+	return AGPU_OK;
+}
+
+void begin_timing(agpu_ctx* ctx) { (void) hipEventRecord(ctx->event_start, ctx->stream); }
+int end_timing(agpu_ctx* ctx, uint64_t bytes) {
+	HIP_CHECK(hipEventRecord(ctx->event_stop, ctx->stream));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	ctx->last_bytes = bytes;
+	return AGPU_OK;
+}
+
+int read_counters(agpu_ctx* ctx, uint32_t* host) {
+	HIP_CHECK(hipMemcpyAsync(host, ctx->counters.ptr, COUNTER_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return AGPU_OK;
+}
+
+// the verdict of the mismatch filter as a function of (mismatches, aligned length); arithmetic exactly as in
+// source/filter_mismatches.cpp:55-99 (float / double / long double mix, hazard H5), evaluated once on the host
+double binomial_coefficient(const unsigned int k, const unsigned int n) {
+	double result = 1;
+	for (unsigned int i = n - k + 1; i <= n; ++i) result *= i;
+	for (unsigned int i = 1; i <= k; ++i) result /= i;
+	return result;
+}
+float binomial_distribution(const unsigned int k, const unsigned int n, const float p) {
+	return binomial_coefficient(k, n) * pow(p, k) * pow(1 - p, n - k);
+}
+bool mismatch_verdict(unsigned int mismatches, unsigned int alignment_length, const float mismatch_probability, unsigned long int genome_size, const float pvalue_cutoff) {
+	if (binomial_distribution(mismatches, alignment_length, mismatch_probability) < pvalue_cutoff) {
+		return true;
+	} else if (mismatches > 0) {
+		long double number_of_permutations_of_bases = pow(4, alignment_length - mismatches);
+		if (genome_size >= number_of_permutations_of_bases)
+			return true;
+		return (1 - pow(1 - genome_size / number_of_permutations_of_bases, binomial_coefficient(mismatches, alignment_length))) > 0.01;
+	}
+	return false;
+}
+
+int build_tables(agpu_ctx* ctx) {
+	const uint32_t max_length = std::max<uint32_t>(ctx->max_read_length, 1) + 8;
+	std::vector<uint32_t> verdict(((size_t) (max_length + 1) * (max_length + 2) / 2 + 31) / 32, 0);
+	const float mismatch_probability = 0.01; // source/arriba.cpp:403
+	for (uint32_t n = 0; n <= max_length; ++n)
+		for (uint32_t k = 0; k <= n; ++k)
+			if (mismatch_verdict(k, n, mismatch_probability, ctx->genome_size, ctx->params.mismatch_pvalue_cutoff)) {
+				uint32_t bit = n * (n + 1) / 2 + k;
+				verdict[bit >> 5] |= 1u << (bit & 31);
+			}
+	std::vector<uint32_t> threshold(max_length + 1);
+	const unsigned int kmer_length = 3;
+	const float kmer_content = ctx->params.max_kmer_content;
+	for (uint32_t length = 0; length <= max_length; ++length) {
+		unsigned int value = length * kmer_content / kmer_length + 0.5; // source/filter_low_entropy.cpp:67-69
+		threshold[length] = value;
+	}
+	TRY(upload(ctx->mismatch_verdict, verdict.data(), verdict.size(), ctx->stream));
+	TRY(upload(ctx->kmer_threshold, threshold.data(), threshold.size(), ctx->stream));
+	TRY(upload(ctx->filter_enabled, ctx->params.filter_enabled, AGPU_FILTER_COUNT, ctx->stream));
+	FilterTables& t = ctx->tables;
+	t.mismatch_verdict = ctx->mismatch_verdict.as<uint32_t>(); t.mismatch_max_length = max_length;
+	t.kmer_threshold = ctx->kmer_threshold.as<uint32_t>(); t.kmer_threshold_size = max_length + 1;
+	t.max_kmer_content = kmer_content;
+	t.homopolymer_length = ctx->params.homopolymer_length;
+	t.min_read_through_distance = (int32_t) ctx->params.min_read_through_distance;
+	t.max_itd_length = ctx->params.max_itd_length;
+	t.external_duplicate_marking = ctx->params.external_duplicate_marking;
+	t.top_expressed_viral_verdict = nullptr; t.low_coverage_viral_verdict = nullptr;
+	return AGPU_OK;
+}
+
+void refresh_annotation_view(agpu_ctx* ctx) {
+	AnnotationView& a = ctx->annotation;
+	a.n_genes = ctx->n_genes; a.n_dummy = ctx->n_dummy;
+	a.gene_contig = ctx->gene_contig.as<uint16_t>(); a.gene_start = ctx->gene_start.as<int32_t>(); a.gene_end = ctx->gene_end.as<int32_t>();
+	a.gene_bits = ctx->gene_bits.as<uint8_t>(); a.gene_exonic_length = ctx->gene_exonic_length.as<int32_t>();
+	a.n_exons = ctx->n_exons;
+	a.exon_start = ctx->exon_start.as<int32_t>(); a.exon_end = ctx->exon_end.as<int32_t>(); a.exon_gene = ctx->exon_gene.as<uint32_t>();
+	a.exon_previous = ctx->exon_previous.as<int32_t>(); a.exon_next = ctx->exon_next.as<int32_t>();
+	a.exon_cds_start = ctx->exon_cds_start.as<int32_t>(); a.exon_cds_end = ctx->exon_cds_end.as<int32_t>();
+	a.dummy_start_key = ctx->dummy_start_key.as<uint64_t>(); a.dummy_end_key = ctx->dummy_end_key.as<uint64_t>();
+}
+
+uint64_t annotation_bytes(const agpu_ctx* ctx) { // columns touched once by the annotate kernels
+	return ctx->batch_input_bytes + ctx->n * (3 * (1 + 1 + GENE_INLINE * 4));
+}
+
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+
+extern "C" {
+
+const char* agpu_last_error(void) { return g_last_error.c_str(); }
+int agpu_api_version(void) { return AGPU_API_VERSION; }
+
+int agpu_device_count(void) {
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+	return count;
+}
+
+void agpu_default_params(agpu_params* p) { // source/options.cpp:71-107
+	memset(p, 0, sizeof(*p));
+	p->homopolymer_length = 6; p->min_read_through_distance = 10000; p->max_itd_length = 100; p->subsampling_threshold = 300;
+	p->mismatch_pvalue_cutoff = 0.01; p->max_kmer_content = 0.6; p->evalue_cutoff = 0.3; p->max_mismapper_fraction = 0.8;
+	p->fragment_length = 200; p->external_duplicate_marking = 0; p->strandedness = 0;
+	for (int f = 1; f < AGPU_FILTER_COUNT; ++f) p->filter_enabled[f] = 1;
+}
+
+agpu_ctx* agpu_create(int device, const agpu_params* params) {
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { set_last_error("no HIP device visible: the hot path requires an MI355X (gfx950) and has no CPU fallback"); return nullptr; }
+	if (device < 0 || device >= count) { set_last_error("invalid device ordinal"); return nullptr; }
+	if (hipSetDevice(device) != hipSuccess) { set_last_error("hipSetDevice failed"); return nullptr; }
+	agpu_ctx* ctx = new agpu_ctx();
+	ctx->device = device;
+	if (params) ctx->params = *params; else agpu_default_params(&ctx->params);
+	if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->event_start) != hipSuccess || hipEventCreate(&ctx->event_stop) != hipSuccess) {
+		set_last_error("failed to create HIP stream/events"); delete ctx; return nullptr;
+	}
+	if (!ctx->counters.allocate(COUNTER_COUNT * sizeof(uint32_t)) || !ctx->stage_counts.allocate(16 * sizeof(unsigned long long))) { set_last_error("hipMalloc failed"); delete ctx; return nullptr; }
+	(void) hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes, ctx->stream);
+	(void) hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, ctx->stream);
+	return ctx;
+}
+
+void agpu_destroy(agpu_ctx* ctx) {
+	if (!ctx) return;
+	(void) hipSetDevice(ctx->device);
+	(void) hipStreamSynchronize(ctx->stream);
+	if (ctx->event_start) (void) hipEventDestroy(ctx->event_start);
+	if (ctx->event_stop) (void) hipEventDestroy(ctx->event_stop);
+	if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int agpu_set_params(agpu_ctx* ctx, const agpu_params* params) {
+	if (!ctx || !params) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	ctx->params = *params;
+	if (ctx->have_batch && ctx->have_genome) TRY(build_tables(ctx));
+	return AGPU_OK;
+}
+
+int agpu_upload_annotation(agpu_ctx* ctx, const agpu_annotation_view* in) {
+	if (!ctx || !in) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	ctx->n_genes = in->n_genes; ctx->n_exons = in->n_exons; ctx->n_dummy = 0;
+	TRY(upload(ctx->gene_contig, in->gene_contig, in->n_genes, s)); TRY(upload(ctx->gene_start, in->gene_start, in->n_genes, s)); TRY(upload(ctx->gene_end, in->gene_end, in->n_genes, s));
+	TRY(upload(ctx->gene_bits, in->gene_bits, in->n_genes, s)); TRY(upload(ctx->gene_exonic_length, in->gene_exonic_length, in->n_genes, s));
+	TRY(upload(ctx->exon_start, in->exon_start, in->n_exons, s)); TRY(upload(ctx->exon_end, in->exon_end, in->n_exons, s)); TRY(upload(ctx->exon_gene, in->exon_gene, in->n_exons, s));
+	TRY(upload(ctx->exon_previous, in->exon_previous, in->n_exons, s)); TRY(upload(ctx->exon_next, in->exon_next, in->n_exons, s));
+	TRY(upload(ctx->exon_cds_start, in->exon_cds_start, in->n_exons, s)); TRY(upload(ctx->exon_cds_end, in->exon_cds_end, in->n_exons, s));
+	TRY(upload_index(in->exon_index, ctx->exon_index_contig_offset, ctx->exon_index_keys, ctx->exon_index_member_offset, ctx->exon_index_members, ctx->annotation.exon_index, s));
+	TRY(upload_index(in->gene_index, ctx->gene_index_contig_offset, ctx->gene_index_keys, ctx->gene_index_member_offset, ctx->gene_index_members, ctx->annotation.gene_index, s));
+	refresh_annotation_view(ctx);
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->have_annotation = true; ctx->annotated = false;
+	return AGPU_OK;
+}
+
+int agpu_upload_genome(agpu_ctx* ctx, const agpu_genome_view* in) {
+	if (!ctx || !in) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	TRY(upload(ctx->genome_contig_offset, in->contig_offset, (size_t) in->n_contigs + 1, s));
+	TRY(upload(ctx->genome_contig_bits, in->contig_bits, in->n_contigs, s));
+	TRY(upload(ctx->genome_bases, in->bases, in->contig_offset[in->n_contigs], s));
+	ctx->genome.n_contigs = in->n_contigs; ctx->genome.contig_offset = ctx->genome_contig_offset.as<uint64_t>();
+	ctx->genome.contig_bits = ctx->genome_contig_bits.as<uint8_t>(); ctx->genome.bases = ctx->genome_bases.as<char>();
+	ctx->host_contig_bits.assign(in->contig_bits, in->contig_bits + in->n_contigs);
+	ctx->host_contig_offset.assign(in->contig_offset, in->contig_offset + in->n_contigs + 1);
+	ctx->genome_size = 0; // source/filter_mismatches.cpp:103-108: total size of the interesting contigs
+	for (uint32_t c = 0; c < in->n_contigs; ++c)
+		if (in->contig_bits[c] & AGPU_CBIT_INTERESTING) ctx->genome_size += in->contig_offset[c + 1] - in->contig_offset[c];
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->have_genome = true;
+	if (ctx->have_batch) TRY(build_tables(ctx));
+	return AGPU_OK;
+}
+
+int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
+	if (!ctx || !in) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (in->n >= 0xFFFFFFF0ull) { set_last_error("a batch holds at most 2^32-16 fragments; shard larger inputs"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = in->n;
+	ctx->n = n;
+	uint64_t bytes = 0;
+	TRY(upload(ctx->n_aln, in->n_aln, n, s)); TRY(upload(ctx->fbits, in->fbits, n, s)); TRY(upload(ctx->group, in->group, n, s));
+	bytes += n * (1 + 1 + 4);
+	if (!ctx->filter.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	HIP_CHECK(hipMemsetAsync(ctx->filter.ptr, 0, n ? n : 1, s));
+	for (int k = 0; k < 3; ++k) {
+		TRY(upload(ctx->contig[k], in->contig[k], n, s)); TRY(upload(ctx->start[k], in->start[k], n, s)); TRY(upload(ctx->end[k], in->end[k], n, s));
+		TRY(upload(ctx->abits[k], in->abits[k], n, s)); TRY(upload(ctx->cigar_offset[k], in->cigar_offset[k], n, s)); TRY(upload(ctx->cigar_count[k], in->cigar_count[k], n, s));
+		bytes += n * (2 + 4 + 4 + 1 + 4 + 2);
+		if (!ctx->gene_count[k].allocate(n) || !ctx->genes[k].allocate(n * GENE_INLINE * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		HIP_CHECK(hipMemsetAsync(ctx->gene_count[k].ptr, 0, n ? n : 1, s));
+	}
+	TRY(upload(ctx->cigar_pool, in->cigar_pool, in->cigar_pool_size, s));
+	bytes += in->cigar_pool_size * 4;
+	ctx->max_read_length = 0;
+	for (int k = 0; k < 2; ++k) {
+		TRY(upload(ctx->seq_offset[k], in->seq_offset[k], n, s)); TRY(upload(ctx->seq_length[k], in->seq_length[k], n, s));
+		bytes += n * 8;
+		for (uint64_t i = 0; i < n; ++i) if (in->seq_length[k][i] > ctx->max_read_length) ctx->max_read_length = in->seq_length[k][i];
+	}
+	if (ctx->max_read_length > 1024) { set_last_error("reads longer than 1024 nt are not supported by the low_entropy kernel's 8-bit k-mer counters"); return AGPU_ERR_INVALID; }
+	TRY(upload(ctx->seq_pool, in->seq_pool, in->seq_pool_size, s));
+	bytes += in->seq_pool_size;
+	ctx->batch_input_bytes = bytes;
+	uint32_t pool_capacity = (uint32_t) std::min<uint64_t>(n / 2 + (1u << 20), 0x7FFFFFFFull);
+	if (!ctx->gene_pool.allocate((size_t) pool_capacity * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->unmapped_keys.allocate((2 * n + 2) * sizeof(uint64_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	ctx->viral_pair_capacity = std::max<uint64_t>(1u << 20, n / 8);
+	if (!ctx->viral_pairs.allocate(ctx->viral_pair_capacity * 2 * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	HIP_CHECK(hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes, s));
+	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
+
+	BatchView& b = ctx->batch;
+	b.n = n; b.n_aln = ctx->n_aln.as<uint8_t>(); b.fbits = ctx->fbits.as<uint8_t>(); b.filter = ctx->filter.as<uint8_t>(); b.group = ctx->group.as<uint32_t>();
+	for (int k = 0; k < 3; ++k) {
+		b.contig[k] = ctx->contig[k].as<uint16_t>(); b.start[k] = ctx->start[k].as<int32_t>(); b.end[k] = ctx->end[k].as<int32_t>(); b.abits[k] = ctx->abits[k].as<uint8_t>();
+		b.cigar_offset[k] = ctx->cigar_offset[k].as<uint32_t>(); b.cigar_count[k] = ctx->cigar_count[k].as<uint16_t>();
+		b.gene_count[k] = ctx->gene_count[k].as<uint8_t>(); b.genes[k] = ctx->genes[k].as<uint32_t>();
+	}
+	b.cigar_pool = ctx->cigar_pool.as<uint32_t>();
+	for (int k = 0; k < 2; ++k) { b.seq_offset[k] = ctx->seq_offset[k].as<uint32_t>(); b.seq_length[k] = ctx->seq_length[k].as<uint32_t>(); }
+	b.seq_pool = ctx->seq_pool.as<uint8_t>();
+	b.gene_pool = ctx->gene_pool.as<uint32_t>(); b.gene_pool_used = ctx->counters.as<uint32_t>() + COUNTER_GENE_POOL; b.gene_pool_capacity = pool_capacity;
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false;
+	if (ctx->have_genome) TRY(build_tables(ctx));
+	return AGPU_OK;
+}
+
+int agpu_mark_multimappers(agpu_ctx* ctx, uint64_t* marked) {
+	if (!ctx || !ctx->have_batch) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	begin_timing(ctx);
+	if (ctx->n > 0) mark_multimappers_kernel<<<grid_for(ctx->n), BLOCK, 0, ctx->stream>>>(ctx->batch, ctx->counters.as<uint32_t>());
+	TRY(end_timing(ctx, ctx->n * (4 + 1 + 1)));
+	uint32_t counters[COUNTER_COUNT];
+	TRY(read_counters(ctx, counters));
+	if (marked) *marked = counters[COUNTER_MARKED];
+	return AGPU_OK;
+}
+
+int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes) {
+	if (!ctx || !ctx->have_batch || !ctx->have_annotation || !ctx->have_genome) { set_last_error("annotation, genome and batch must be uploaded first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	uint32_t* counters = ctx->counters.as<uint32_t>();
+	begin_timing(ctx);
+	if (n > 0) annotate_stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->params.strandedness, ctx->unmapped_keys.as<uint64_t>(), counters);
+	uint32_t host_counters[COUNTER_COUNT];
+	TRY(read_counters(ctx, host_counters));
+	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
+	const uint32_t unmapped = host_counters[COUNTER_UNMAPPED];
+	ctx->n_dummy = 0;
+	if (unmapped > 0) {
+		// sort the unmapped positions and cut them into dummy genes (source/arriba.cpp:232-260)
+		if (!ctx->sorted_keys.allocate((size_t) unmapped * 8) || !ctx->scan_flags.allocate((size_t) unmapped * 4) || !ctx->scan_ids.allocate((size_t) unmapped * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		size_t sort_bytes = 0, scan_bytes = 0;
+		HIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, ctx->unmapped_keys.as<uint64_t>(), ctx->sorted_keys.as<uint64_t>(), unmapped, 0, 48, s));
+		HIP_CHECK(rocprim::inclusive_scan(nullptr, scan_bytes, ctx->scan_flags.as<uint32_t>(), ctx->scan_ids.as<uint32_t>(), unmapped, rocprim::plus<uint32_t>(), s));
+		if (!ctx->sort_scratch.allocate(std::max(sort_bytes, scan_bytes))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		HIP_CHECK(rocprim::radix_sort_keys(ctx->sort_scratch.ptr, sort_bytes, ctx->unmapped_keys.as<uint64_t>(), ctx->sorted_keys.as<uint64_t>(), unmapped, 0, 48, s));
+		dummy_flags_kernel<<<grid_for(unmapped), BLOCK, 0, s>>>(ctx->sorted_keys.as<uint64_t>(), unmapped, ctx->annotation.gene_index, ctx->scan_flags.as<uint32_t>());
+		HIP_CHECK(rocprim::inclusive_scan(ctx->sort_scratch.ptr, scan_bytes, ctx->scan_flags.as<uint32_t>(), ctx->scan_ids.as<uint32_t>(), unmapped, rocprim::plus<uint32_t>(), s));
+		uint32_t n_dummy = 0;
+		HIP_CHECK(hipMemcpyAsync(&n_dummy, ctx->scan_ids.as<uint32_t>() + (unmapped - 1), 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		ctx->n_dummy = n_dummy;
+		if (!ctx->dummy_start_key.allocate((size_t) n_dummy * 8) || !ctx->dummy_end_key.allocate((size_t) n_dummy * 8)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		dummy_write_kernel<<<grid_for(unmapped), BLOCK, 0, s>>>(ctx->sorted_keys.as<uint64_t>(), unmapped, ctx->scan_flags.as<uint32_t>(), ctx->scan_ids.as<uint32_t>(), ctx->dummy_start_key.as<uint64_t>(), ctx->dummy_end_key.as<uint64_t>());
+		// extend the gene table by the dummy genes
+		const uint32_t total = ctx->n_genes + n_dummy;
+		DeviceBuffer contig, start, end, bits, exonic;
+		if (!contig.allocate((size_t) total * 2) || !start.allocate((size_t) total * 4) || !end.allocate((size_t) total * 4) || !bits.allocate(total) || !exonic.allocate((size_t) total * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		HIP_CHECK(hipMemcpyAsync(contig.ptr, ctx->gene_contig.ptr, (size_t) ctx->n_genes * 2, hipMemcpyDeviceToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(start.ptr, ctx->gene_start.ptr, (size_t) ctx->n_genes * 4, hipMemcpyDeviceToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(end.ptr, ctx->gene_end.ptr, (size_t) ctx->n_genes * 4, hipMemcpyDeviceToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(bits.ptr, ctx->gene_bits.ptr, (size_t) ctx->n_genes, hipMemcpyDeviceToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(exonic.ptr, ctx->gene_exonic_length.ptr, (size_t) ctx->n_genes * 4, hipMemcpyDeviceToDevice, s));
+		dummy_gene_table_kernel<<<grid_for(n_dummy), BLOCK, 0, s>>>(ctx->n_genes, n_dummy, ctx->dummy_start_key.as<uint64_t>(), ctx->dummy_end_key.as<uint64_t>(),
+			contig.as<uint16_t>(), start.as<int32_t>(), end.as<int32_t>(), bits.as<uint8_t>(), exonic.as<int32_t>());
+		HIP_CHECK(hipStreamSynchronize(s));
+		std::swap(ctx->gene_contig.ptr, contig.ptr); std::swap(ctx->gene_contig.bytes, contig.bytes);
+		std::swap(ctx->gene_start.ptr, start.ptr); std::swap(ctx->gene_start.bytes, start.bytes);
+		std::swap(ctx->gene_end.ptr, end.ptr); std::swap(ctx->gene_end.bytes, end.bytes);
+		std::swap(ctx->gene_bits.ptr, bits.ptr); std::swap(ctx->gene_bits.bytes, bits.bytes);
+		std::swap(ctx->gene_exonic_length.ptr, exonic.ptr); std::swap(ctx->gene_exonic_length.bytes, exonic.bytes);
+	}
+	refresh_annotation_view(ctx);
+	if (n > 0) annotate_stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->viral_pairs.as<uint32_t>(), (uint32_t) ctx->viral_pair_capacity, counters);
+	TRY(end_timing(ctx, annotation_bytes(ctx)));
+	TRY(read_counters(ctx, host_counters));
+	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
+	if (host_counters[COUNTER_ERROR] & ERROR_VIRAL_PAIR_OVERFLOW) { set_last_error("too many virus-host fragments for the integration-site buffer"); return AGPU_ERR_CAPACITY; }
+	if (n_dummy_genes) *n_dummy_genes = ctx->n_dummy;
+	ctx->annotated = true;
+	return AGPU_OK;
+}
+
+int agpu_get_viral_integration_sites(agpu_ctx* ctx, uint32_t* pairs, uint64_t capacity, uint64_t* count) {
+	if (!ctx || !ctx->annotated) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	uint32_t counters[COUNTER_COUNT];
+	TRY(read_counters(ctx, counters));
+	uint64_t available = counters[COUNTER_VIRAL_PAIRS];
+	if (count) *count = available;
+	if (pairs && available > 0) {
+		uint64_t copy = std::min(available, capacity);
+		HIP_CHECK(hipMemcpy(pairs, ctx->viral_pairs.ptr, copy * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	}
+	return AGPU_OK;
+}
+
+int agpu_read_filters_stage1(agpu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict) {
+	if (!ctx || !ctx->annotated) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	if (top_verdict) { TRY(upload(ctx->viral_verdict_top, top_verdict, ctx->genome.n_contigs, s)); ctx->tables.top_expressed_viral_verdict = ctx->viral_verdict_top.as<uint8_t>(); } else ctx->tables.top_expressed_viral_verdict = nullptr;
+	if (low_verdict) { TRY(upload(ctx->viral_verdict_low, low_verdict, ctx->genome.n_contigs, s)); ctx->tables.low_coverage_viral_verdict = ctx->viral_verdict_low.as<uint8_t>(); } else ctx->tables.low_coverage_viral_verdict = nullptr;
+	uint32_t mask = 0;
+	if (!ctx->params.external_duplicate_marking) {
+		uint64_t slots = 1024;
+		while (slots < 2 * n) slots <<= 1;
+		mask = (uint32_t) (slots - 1);
+		if (!ctx->duplicate_keys.allocate((size_t) n * sizeof(DuplicateKey)) || !ctx->duplicate_slots.allocate(slots * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		HIP_CHECK(hipMemsetAsync(ctx->duplicate_slots.ptr, 0xFF, slots * 4, s));
+	}
+	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
+	begin_timing(ctx);
+	if (n > 0) {
+		if (!ctx->params.external_duplicate_marking) {
+			duplicate_keys_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->duplicate_keys.as<DuplicateKey>());
+			duplicate_insert_kernel<<<grid_for(n), BLOCK, 0, s>>>(n, ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask);
+		}
+		stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, ctx->stage_counts.as<unsigned long long>());
+	}
+	TRY(end_timing(ctx, n * (3 * (2 + 4 + 4 + 1) + 2 * (4 + 2 + 8) + 12 * 2 + 8 + 2)));
+	ctx->stage1_done = true;
+	return AGPU_OK;
+}
+
+int agpu_fragment_length_samples(agpu_ctx* ctx, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited) {
+	if (!ctx || !ctx->stage1_done) { set_last_error("agpu_read_filters_stage1 must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n, chunk = 1u << 20;
+	if (!ctx->sample_flags.allocate(chunk) || !ctx->sample_values.allocate(chunk * 4) || !ctx->samples.allocate(MAX_SAMPLES * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	uint32_t zero[3] = { 0, 0, 0 };
+	HIP_CHECK(hipMemcpyAsync(ctx->counters.as<uint32_t>() + COUNTER_SAMPLES, zero, sizeof(zero), hipMemcpyHostToDevice, s));
+	begin_timing(ctx);
+	uint32_t counters[COUNTER_COUNT] = { 0 };
+	for (uint64_t first = 0; first < n; first += chunk) {
+		uint64_t count = std::min(chunk, n - first);
+		sample_flags_kernel<<<grid_for(count), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, first, count, ctx->sample_flags.as<uint8_t>(), ctx->sample_values.as<int32_t>());
+		sample_compact_kernel<<<1, 1024, 0, s>>>(first, count, ctx->sample_flags.as<uint8_t>(), ctx->sample_values.as<int32_t>(), ctx->samples.as<int32_t>(), ctx->counters.as<uint32_t>());
+		TRY(read_counters(ctx, counters));
+		if (counters[COUNTER_SAMPLES] >= MAX_SAMPLES) break;
+	}
+	TRY(end_timing(ctx, 0));
+	uint32_t collected = counters[COUNTER_SAMPLES];
+	if (n_samples) *n_samples = collected;
+	if (fragments_visited) *fragments_visited = (collected >= MAX_SAMPLES) ? ((uint64_t) counters[COUNTER_VISITED_HI] << 32 | counters[COUNTER_VISITED_LO]) : n;
+	if (mate_gaps && collected > 0) HIP_CHECK(hipMemcpy(mate_gaps, ctx->samples.ptr, (size_t) collected * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
+	if (!ctx || !ctx->stage1_done) { set_last_error("agpu_read_filters_stage1 must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	begin_timing(ctx);
+	if (n > 0) stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->stage_counts.as<unsigned long long>());
+	TRY(end_timing(ctx, ctx->batch_input_bytes + n * (3 * (1 + GENE_INLINE * 4) + 2) + n * 200 /* reference bases gathered by the mismatch walk */));
+	unsigned long long counts[16];
+	HIP_CHECK(hipMemcpy(counts, ctx->stage_counts.ptr, sizeof(counts), hipMemcpyDeviceToHost));
+	if (remaining) {
+		// order of execution (source/arriba.cpp:327-409) -> "(remaining=N)" after each stage
+		static const int order[14] = { 1 /*duplicates*/, 30, 31, 32, 33, 4 /*read_through*/, 2, 3, 6, 7, 5, 8, 10, 36 };
+		for (int f = 0; f < AGPU_FILTER_COUNT; ++f) remaining[f] = 0;
+		uint64_t left = n;
+		for (int k = 0; k < 14; ++k) { left -= counts[k]; remaining[order[k]] = left; }
+	}
+	ctx->stage2_done = true;
+	return AGPU_OK;
+}
+
+int agpu_find_fusions(agpu_ctx*, int32_t, uint64_t*) { set_last_error("agpu_find_fusions is not implemented yet"); return AGPU_ERR_INVALID; }
+
+int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter) {
+	if (!ctx || !ctx->have_batch || !filter) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->n) HIP_CHECK(hipMemcpy(filter, ctx->filter.ptr, ctx->n, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+int agpu_get_alignment_bits(agpu_ctx* ctx, int slot, uint8_t* abits) {
+	if (!ctx || !ctx->have_batch || !abits || slot < 0 || slot > 2) { set_last_error("bad argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->n) HIP_CHECK(hipMemcpy(abits, ctx->abits[slot].ptr, ctx->n, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+int agpu_get_fragment_bits(agpu_ctx* ctx, uint8_t* fbits) {
+	if (!ctx || !ctx->have_batch || !fbits) { set_last_error("bad argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->n) HIP_CHECK(hipMemcpy(fbits, ctx->fbits.ptr, ctx->n, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+int agpu_get_gene_sets(agpu_ctx* ctx, int slot, uint8_t* count, uint32_t* genes, uint64_t capacity, uint64_t* total) {
+	if (!ctx || !ctx->annotated || slot < 0 || slot > 2) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	const uint64_t n = ctx->n;
+	std::vector<uint8_t> counts(n);
+	std::vector<uint32_t> inline_ids(n * GENE_INLINE);
+	if (n) {
+		HIP_CHECK(hipMemcpy(counts.data(), ctx->gene_count[slot].ptr, n, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(inline_ids.data(), ctx->genes[slot].ptr, n * GENE_INLINE * 4, hipMemcpyDeviceToHost));
+	}
+	uint32_t counters[COUNTER_COUNT];
+	TRY(read_counters(ctx, counters));
+	std::vector<uint32_t> pool(counters[COUNTER_GENE_POOL]);
+	if (!pool.empty()) HIP_CHECK(hipMemcpy(pool.data(), ctx->gene_pool.ptr, pool.size() * 4, hipMemcpyDeviceToHost));
+	uint64_t sum = 0;
+	for (uint64_t i = 0; i < n; ++i) sum += counts[i];
+	if (total) *total = sum;
+	if (count && n) memcpy(count, counts.data(), n);
+	if (genes) {
+		if (capacity < sum) { set_last_error("gene buffer too small"); return AGPU_ERR_INVALID; }
+		uint64_t at = 0;
+		for (uint64_t i = 0; i < n; ++i) {
+			const uint32_t* source = (counts[i] <= GENE_INLINE) ? &inline_ids[i * GENE_INLINE] : &pool[inline_ids[i * GENE_INLINE]];
+			for (uint32_t k = 0; k < counts[i]; ++k) genes[at++] = source[k];
+		}
+	}
+	return AGPU_OK;
+}
+
+int agpu_get_gene_table(agpu_ctx* ctx, uint32_t first, uint32_t count, uint16_t* contig, int32_t* start, int32_t* end, uint8_t* bits, int32_t* exonic_length) {
+	if (!ctx || !ctx->have_annotation) { set_last_error("no annotation uploaded"); return AGPU_ERR_INVALID; }
+	if ((uint64_t) first + count > (uint64_t) ctx->n_genes + ctx->n_dummy) { set_last_error("gene range out of bounds"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (count == 0) return AGPU_OK;
+	if (contig) HIP_CHECK(hipMemcpy(contig, ctx->gene_contig.as<uint16_t>() + first, (size_t) count * 2, hipMemcpyDeviceToHost));
+	if (start) HIP_CHECK(hipMemcpy(start, ctx->gene_start.as<int32_t>() + first, (size_t) count * 4, hipMemcpyDeviceToHost));
+	if (end) HIP_CHECK(hipMemcpy(end, ctx->gene_end.as<int32_t>() + first, (size_t) count * 4, hipMemcpyDeviceToHost));
+	if (bits) HIP_CHECK(hipMemcpy(bits, ctx->gene_bits.as<uint8_t>() + first, (size_t) count, hipMemcpyDeviceToHost));
+	if (exonic_length) HIP_CHECK(hipMemcpy(exonic_length, ctx->gene_exonic_length.as<int32_t>() + first, (size_t) count * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+int agpu_last_kernel_ms(agpu_ctx* ctx, float* ms) { if (!ctx || !ms) return AGPU_ERR_INVALID; *ms = ctx->last_ms; return AGPU_OK; }
+int agpu_last_kernel_bytes(agpu_ctx* ctx, uint64_t* bytes) { if (!ctx || !bytes) return AGPU_ERR_INVALID; *bytes = ctx->last_bytes; return AGPU_OK; }
+
+} // extern "C"

@@ -1,0 +1,85 @@
+// arriba_amd/csrc/device/agpu_context.hpp -- device context: owns every HBM buffer of the hot path.
+#ifndef AGPU_CONTEXT_HPP
+#define AGPU_CONTEXT_HPP 1
+
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../../include/arriba_gpu.h"
+#include "filter_core.hpp"
+
+namespace agpu {
+
+void set_last_error(const std::string& message);
+
+struct DeviceBuffer {
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	DeviceBuffer() {}
+	DeviceBuffer(const DeviceBuffer&) = delete;
+	DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+	~DeviceBuffer() { release(); }
+	bool allocate(size_t n) {
+		release();
+		if (n == 0) n = 16;
+		if (hipMalloc(&ptr, n) != hipSuccess) { ptr = nullptr; return false; }
+		bytes = n;
+		return true;
+	}
+	void release() { if (ptr) { (void) hipFree(ptr); ptr = nullptr; bytes = 0; } }
+	template <class T> T* as() const { return (T*) ptr; }
+};
+
+}
+
+struct agpu_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t event_start = nullptr, event_stop = nullptr;
+	float last_ms = 0;
+	uint64_t last_bytes = 0;
+	agpu_params params;
+
+	// annotation
+	uint32_t n_genes = 0, n_exons = 0, n_dummy = 0;
+	agpu::DeviceBuffer gene_contig, gene_start, gene_end, gene_bits, gene_exonic_length;
+	agpu::DeviceBuffer exon_start, exon_end, exon_gene, exon_previous, exon_next, exon_cds_start, exon_cds_end;
+	agpu::DeviceBuffer exon_index_contig_offset, exon_index_keys, exon_index_member_offset, exon_index_members;
+	agpu::DeviceBuffer gene_index_contig_offset, gene_index_keys, gene_index_member_offset, gene_index_members;
+	agpu::DeviceBuffer dummy_start_key, dummy_end_key;
+	agpu::AnnotationView annotation;
+	bool have_annotation = false;
+
+	// genome
+	agpu::DeviceBuffer genome_contig_offset, genome_contig_bits, genome_bases;
+	agpu::GenomeView genome;
+	std::vector<uint8_t> host_contig_bits;
+	std::vector<uint64_t> host_contig_offset;
+	bool have_genome = false;
+
+	// batch
+	uint64_t n = 0;
+	agpu::DeviceBuffer n_aln, fbits, filter, group;
+	agpu::DeviceBuffer contig[3], start[3], end[3], abits[3], cigar_offset[3], cigar_count[3], cigar_pool;
+	agpu::DeviceBuffer seq_offset[2], seq_length[2], seq_pool;
+	agpu::DeviceBuffer gene_count[3], genes[3], gene_pool, counters;
+	agpu::BatchView batch;
+	uint64_t batch_input_bytes = 0;
+	uint32_t max_read_length = 0;
+	bool have_batch = false, annotated = false, stage1_done = false, stage2_done = false;
+
+	// scratch
+	agpu::DeviceBuffer unmapped_keys, sort_scratch, sorted_keys, scan_flags, scan_ids;
+	agpu::DeviceBuffer viral_pairs;
+	uint64_t viral_pair_capacity = 0;
+	agpu::DeviceBuffer duplicate_keys, duplicate_slots;
+	agpu::DeviceBuffer sample_flags, sample_values, samples;
+	agpu::DeviceBuffer stage_counts;
+
+	// tables
+	agpu::DeviceBuffer mismatch_verdict, kmer_threshold, filter_enabled, viral_verdict_top, viral_verdict_low;
+	agpu::FilterTables tables;
+	uint64_t genome_size = 0;
+};
+
+#endif

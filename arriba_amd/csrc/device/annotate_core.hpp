@@ -1,0 +1,483 @@
+// arriba_amd/csrc/device/annotate_core.hpp -- per-fragment annotation logic of the device path.
+//
+// One thread handles one chimeric fragment.  The functions restate, on the flattened interval index,
+//   get_annotation_by_coordinate   reference: source/annotation.t.hpp:47-101
+//   is_breakpoint_spliced          reference: source/annotation.cpp:379-429
+//   annotate_alignment(s)          reference: source/annotation.cpp:431-555
+//   strand assignment              reference: source/read_chimeric_alignments.cpp:775-790
+//   gene fallback / dummy genes    reference: source/arriba.cpp:190-319
+// They are __host__ __device__ so that tests/emu can single-step the identical code on a CPU-only box;
+// the product only ever runs them inside the HIP kernels of annotate.hip.
+#ifndef AGPU_ANNOTATE_CORE_HPP
+#define AGPU_ANNOTATE_CORE_HPP 1
+
+#include "views.hpp"
+
+namespace agpu {
+
+AGPU_HD uint32_t atomic_add_u32(uint32_t* address, uint32_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return atomicAdd(address, value);
+#else
+	uint32_t old = *address; *address += value; return old;
+#endif
+}
+
+// small sorted set of ids held in registers/scratch
+const int SET_CAPACITY = 16;
+struct IdSet {
+	uint32_t n;
+	uint32_t overflow;
+	uint32_t v[SET_CAPACITY];
+	AGPU_HD void clear() { n = 0; overflow = 0; }
+	AGPU_HD void insert(uint32_t x) {
+		uint32_t at = 0;
+		while (at < n && v[at] < x) ++at;
+		if (at < n && v[at] == x) return;
+		if (n == SET_CAPACITY) { overflow = 1; return; }
+		for (uint32_t j = n; j > at; --j) v[j] = v[j - 1];
+		v[at] = x;
+		++n;
+	}
+	AGPU_HD void assign_single(uint32_t x) { n = 1; v[0] = x; }
+};
+
+AGPU_HD void intersect_sets(const IdSet& a, const IdSet& b, IdSet& out) {
+	out.clear();
+	uint32_t i = 0, j = 0;
+	while (i < a.n && j < b.n) {
+		if (a.v[i] < b.v[j]) ++i;
+		else if (b.v[j] < a.v[i]) ++j;
+		else { out.v[out.n++] = a.v[i]; ++i; ++j; }
+	}
+}
+// intersection, or the union if the intersection is empty (reference: combine_annotations, source/annotation.t.hpp:47-53)
+AGPU_HD void combine_sets(const IdSet& a, const IdSet& b, IdSet& out, bool make_union) {
+	intersect_sets(a, b, out);
+	if (out.n == 0 && make_union) {
+		for (uint32_t i = 0; i < a.n; ++i) out.insert(a.v[i]);
+		for (uint32_t j = 0; j < b.n; ++j) out.insert(b.v[j]);
+		out.overflow |= a.overflow | b.overflow;
+	}
+}
+
+AGPU_HD void load_genes(const BatchView& b, int slot, uint64_t i, IdSet& out) {
+	out.clear();
+	uint32_t count = b.gene_count[slot][i];
+	const uint32_t* inline_ids = b.genes[slot] + i * GENE_INLINE;
+	if (count <= (uint32_t) GENE_INLINE) {
+		for (uint32_t k = 0; k < count; ++k) out.v[k] = inline_ids[k];
+	} else {
+		const uint32_t* pool = b.gene_pool + inline_ids[0];
+		if (count > (uint32_t) SET_CAPACITY) { count = SET_CAPACITY; out.overflow = 1; }
+		for (uint32_t k = 0; k < count; ++k) out.v[k] = pool[k];
+	}
+	out.n = count;
+}
+
+// returns false if the overflow pool is exhausted
+AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& set) {
+	uint32_t* inline_ids = b.genes[slot] + i * GENE_INLINE;
+	b.gene_count[slot][i] = (uint8_t) set.n;
+	if (set.n <= (uint32_t) GENE_INLINE) {
+		for (uint32_t k = 0; k < set.n; ++k) inline_ids[k] = set.v[k];
+		return true;
+	}
+	uint32_t offset = atomic_add_u32(b.gene_pool_used, set.n);
+	if (offset + set.n > b.gene_pool_capacity) {
+		b.gene_count[slot][i] = 0;
+		return false;
+	}
+	inline_ids[0] = offset;
+	for (uint32_t k = 0; k < set.n; ++k) b.gene_pool[offset + k] = set.v[k];
+	return true;
+}
+
+// ---- flattened interval index ---------------------------------------------------------------------
+
+AGPU_HD uint32_t index_lower_bound(const FlatIndexView& index, uint32_t contig, int32_t position) {
+	uint32_t lo = index.contig_offset[contig], hi = index.contig_offset[contig + 1];
+	while (lo < hi) {
+		uint32_t mid = lo + ((hi - lo) >> 1);
+		if (index.keys[mid] < position) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+struct ListRef { const uint32_t* p; uint32_t n; };
+AGPU_HD ListRef index_bucket(const FlatIndexView& index, uint32_t k) {
+	ListRef list;
+	uint32_t begin = index.member_offset[k];
+	list.p = index.members + begin;
+	list.n = index.member_offset[k + 1] - begin;
+	return list;
+}
+AGPU_HD ListRef empty_list() { ListRef list; list.p = 0; list.n = 0; return list; }
+
+struct IdentityMap { AGPU_HD uint32_t operator()(uint32_t id) const { return id; } };
+struct ExonToGeneMap { const uint32_t* exon_gene; AGPU_HD uint32_t operator()(uint32_t exon) const { return exon_gene[exon]; } };
+
+template <class Map> AGPU_HD uint32_t emit_intersection(ListRef a, ListRef b, const Map& map, IdSet& out) {
+	uint32_t i = 0, j = 0, common = 0;
+	while (i < a.n && j < b.n) {
+		uint32_t x = a.p[i], y = b.p[j];
+		if (x < y) ++i;
+		else if (y < x) ++j;
+		else { out.insert(map(x)); ++common; ++i; ++j; }
+	}
+	return common;
+}
+template <class Map> AGPU_HD void emit_all(ListRef a, const Map& map, IdSet& out) {
+	for (uint32_t i = 0; i < a.n; ++i) out.insert(map(a.p[i]));
+}
+
+// features at [start,end]: (features at start) ∩ (features at end), or their union if that is empty; each side also
+// takes the neighbouring bucket if its boundary lies within 2 bp (reference: source/annotation.t.hpp:55-101).
+// The set algebra is done on feature ids; `map` translates the surviving ids (exon -> gene for the exon index).
+template <class Map> AGPU_HD void query_by_coordinate(const FlatIndexView& index, uint32_t contig, int32_t start, int32_t end, const Map& map, IdSet& out) {
+	out.clear();
+	if (contig >= index.n_contigs) return;
+	uint32_t contig_begin = index.contig_offset[contig], contig_end = index.contig_offset[contig + 1];
+	if (start == end) {
+		uint32_t k = index_lower_bound(index, contig, start);
+		if (k != contig_end) emit_all(index_bucket(index, k), map, out);
+		return;
+	}
+	if (start > end) { int32_t t = start; start = end; end = t; }
+	ListRef a = empty_list(), b = empty_list(), c = empty_list(), d = empty_list();
+	uint32_t k = index_lower_bound(index, contig, start);
+	if (k != contig_end) {
+		a = index_bucket(index, k);
+		if (index.keys[k] - start <= 2) {
+			++k;
+			if (k != contig_end) b = index_bucket(index, k);
+		}
+	}
+	k = index_lower_bound(index, contig, end);
+	if (k != contig_end) c = index_bucket(index, k);
+	if (k != contig_begin && contig_end > contig_begin) {
+		--k;
+		if (end - index.keys[k] <= 2) d = index_bucket(index, k);
+	}
+	uint32_t common = emit_intersection(a, c, map, out) + emit_intersection(a, d, map, out) + emit_intersection(b, c, map, out) + emit_intersection(b, d, map, out);
+	if (common == 0) {
+		emit_all(a, map, out); emit_all(b, map, out); emit_all(c, map, out); emit_all(d, map, out);
+	}
+}
+
+// reference: filter_exons_near_splice_site, source/annotation.cpp:379-401
+AGPU_HD bool bucket_has_splice_site(const AnnotationView& ann, uint32_t gene, bool upstream, int32_t breakpoint, uint32_t k) {
+	ListRef exons = index_bucket(ann.exon_index, k);
+	for (uint32_t m = 0; m < exons.n; ++m) {
+		uint32_t e = exons.p[m];
+		if (ann.exon_gene[e] != gene) continue;
+		int32_t previous = ann.exon_previous[e], next = ann.exon_next[e];
+		if (upstream) {
+			int32_t start = ann.exon_start[e];
+			int32_t distance = start - breakpoint; if (distance < 0) distance = -distance;
+			if (distance <= MAX_SPLICE_SITE_DISTANCE &&
+			    (previous != -1 || (previous == -1 && next == -1 && ann.exon_cds_start[e] != -1) || start == ann.exon_cds_start[e]))
+				return true;
+		} else {
+			int32_t end = ann.exon_end[e];
+			int32_t distance = end - breakpoint; if (distance < 0) distance = -distance;
+			if (distance <= MAX_SPLICE_SITE_DISTANCE &&
+			    (next != -1 || (previous == -1 && next == -1 && ann.exon_cds_start[e] != -1) || end == ann.exon_cds_end[e]))
+				return true;
+		}
+	}
+	return false;
+}
+
+// reference: source/annotation.cpp:404-429
+AGPU_HD bool is_breakpoint_spliced(const AnnotationView& ann, uint32_t gene, bool upstream, int32_t breakpoint) {
+	uint32_t contig = ann.gene_contig[gene];
+	const FlatIndexView& index = ann.exon_index;
+	if (contig >= index.n_contigs) return false;
+	uint32_t contig_begin = index.contig_offset[contig], contig_end = index.contig_offset[contig + 1];
+	if (contig_begin == contig_end) return false;
+	uint32_t at = index_lower_bound(index, contig, breakpoint);
+	if (at != contig_end) {
+		if (bucket_has_splice_site(ann, gene, upstream, breakpoint, at)) return true;
+		if (at + 1 != contig_end && bucket_has_splice_site(ann, gene, upstream, breakpoint, at + 1)) return true;
+	}
+	if (at != contig_begin && bucket_has_splice_site(ann, gene, upstream, breakpoint, at - 1)) return true;
+	return false;
+}
+
+AGPU_HD bool complement_strand_if(bool strand, bool condition) { return condition ? !strand : strand; }
+
+// reference: annotate_alignment, source/annotation.cpp:431-503.  `bits` carries strand / predicted strand in and out.
+AGPU_HD void annotate_alignment(const BatchView& b, const AnnotationView& ann, uint64_t i, int slot, uint8_t& bits, IdSet& genes) {
+	uint32_t contig = b.contig[slot][i];
+	int32_t start = b.start[slot][i];
+	ExonToGeneMap to_gene; to_gene.exon_gene = ann.exon_gene;
+	query_by_coordinate(ann.exon_index, contig, start, b.end[slot][i], to_gene, genes);
+
+	uint32_t n_cigar = b.cigar_count[slot][i];
+	bool ambiguous = bits & ABIT_PREDICTED_STRAND_AMBIGUOUS;
+	if (n_cigar > 1 && (genes.n > 1 || ambiguous)) {
+		const uint32_t* cigar = b.cigar_pool + b.cigar_offset[slot][i];
+		IdSet supported; supported.clear();
+		int32_t reference_position = start;
+		for (uint32_t c = 0; c < n_cigar && supported.n == 0; ++c) {
+			uint32_t op = cigar[c] & 15, length = cigar[c] >> 4;
+			bool is_clip = (op == CIGAR_S || op == CIGAR_H);
+			if (is_clip || op == CIGAR_N) {
+				for (uint32_t g = 0; g < genes.n; ++g) {
+					uint32_t gene = genes.v[g];
+					bool discard;
+					if (is_clip)
+						discard = (c == 0) ? !is_breakpoint_spliced(ann, gene, true, reference_position) : !is_breakpoint_spliced(ann, gene, false, reference_position);
+					else
+						discard = !is_breakpoint_spliced(ann, gene, false, reference_position) && !is_breakpoint_spliced(ann, gene, true, reference_position + (int32_t) length);
+					if (!discard) supported.v[supported.n++] = gene;
+				}
+			}
+			if (op == CIGAR_N || op == CIGAR_M || op == CIGAR_X || op == CIGAR_EQ || op == CIGAR_D)
+				reference_position += length;
+		}
+		if (supported.n > 0) {
+			if (supported.n < genes.n) genes = supported;
+			if (ambiguous) {
+				bool predicted = ann.gene_bits[supported.v[0]] & GBIT_STRAND;
+				bool still_ambiguous = false;
+				for (uint32_t g = 0; g < supported.n && !still_ambiguous; ++g)
+					if (((ann.gene_bits[supported.v[g]] & GBIT_STRAND) != 0) != predicted)
+						still_ambiguous = true;
+				if (!still_ambiguous)
+					bits = (bits & ~(ABIT_PREDICTED_STRAND | ABIT_PREDICTED_STRAND_AMBIGUOUS)) | (predicted ? ABIT_PREDICTED_STRAND : 0);
+			}
+		}
+	}
+}
+
+AGPU_HD bool abit(uint8_t bits, uint8_t mask) { return (bits & mask) != 0; }
+AGPU_HD void set_predicted(uint8_t& bits, bool strand) { bits = (bits & ~(ABIT_PREDICTED_STRAND | ABIT_PREDICTED_STRAND_AMBIGUOUS)) | (strand ? ABIT_PREDICTED_STRAND : 0); }
+AGPU_HD void set_ambiguous(uint8_t& bits) { bits |= ABIT_PREDICTED_STRAND_AMBIGUOUS; }
+
+AGPU_HD int32_t breakpoint_of(const BatchView& b, int slot, uint64_t i, uint8_t bits, bool split_read_convention) {
+	// split read: forward -> start; supplementary / discordant mate: forward -> end
+	bool forward = bits & ABIT_STRAND;
+	if (split_read_convention) return forward ? b.start[slot][i] : b.end[slot][i];
+	return forward ? b.end[slot][i] : b.start[slot][i];
+}
+
+// Stage 1 of the annotation of one fragment (reference: source/arriba.cpp:160-231):
+// strands from strandedness, exon-based annotation, gene-index fallback, and the list of positions that map to no gene.
+// unmapped_keys receives contig << 32 | position for every alignment end that needs a dummy gene.
+AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& ann, uint32_t strandedness, uint64_t i, uint64_t* unmapped_keys, uint32_t* unmapped_count) {
+	int n_aln = b.n_aln[i];
+	uint8_t bits[3];
+	IdSet genes[3];
+	for (int s = 0; s < 3; ++s) { bits[s] = (s < n_aln) ? (uint8_t) (b.abits[s][i] | ABIT_PREDICTED_STRAND_AMBIGUOUS) : 0; genes[s].clear(); }
+
+	// reference: assign_strands_from_strandedness, source/read_chimeric_alignments.cpp:775-790
+	if (strandedness != 0) {
+		int first = abit(bits[MATE1], ABIT_FIRST_IN_PAIR) ? MATE1 : MATE2;
+		int second = abit(bits[MATE1], ABIT_FIRST_IN_PAIR) ? MATE2 : MATE1;
+		bool first_predicted = complement_strand_if(abit(bits[first], ABIT_STRAND), strandedness == 2);
+		set_predicted(bits[first], first_predicted);
+		set_predicted(bits[second], complement_strand_if(first_predicted, abit(bits[first], ABIT_STRAND) == abit(bits[second], ABIT_STRAND)));
+		if (n_aln == 3)
+			set_predicted(bits[SUPPLEMENTARY], complement_strand_if(abit(bits[SPLIT_READ], ABIT_PREDICTED_STRAND), abit(bits[SUPPLEMENTARY], ABIT_STRAND) != abit(bits[SPLIT_READ], ABIT_STRAND)));
+	}
+
+	// reference: annotate_alignments, source/annotation.cpp:505-555
+	for (int s = 0; s < n_aln; ++s) {
+		annotate_alignment(b, ann, i, s, bits[s], genes[s]);
+		if (genes[s].n > 0) bits[s] |= ABIT_EXONIC;
+	}
+	{
+		bool amb1 = abit(bits[MATE1], ABIT_PREDICTED_STRAND_AMBIGUOUS), amb2 = abit(bits[MATE2], ABIT_PREDICTED_STRAND_AMBIGUOUS);
+		bool same_strand = abit(bits[MATE1], ABIT_STRAND) == abit(bits[MATE2], ABIT_STRAND);
+		if (amb1 && !amb2) set_predicted(bits[MATE1], complement_strand_if(abit(bits[MATE2], ABIT_PREDICTED_STRAND), same_strand));
+		else if (!amb1 && amb2) set_predicted(bits[MATE2], complement_strand_if(abit(bits[MATE1], ABIT_PREDICTED_STRAND), same_strand));
+		else if (!amb1 && !amb2) {
+			if ((abit(bits[MATE1], ABIT_PREDICTED_STRAND) != abit(bits[MATE2], ABIT_PREDICTED_STRAND)) != same_strand) {
+				set_ambiguous(bits[MATE1]); set_ambiguous(bits[MATE2]);
+			}
+		}
+	}
+	IdSet combined;
+	if (n_aln == 3) {
+		combine_sets(genes[SPLIT_READ], genes[MATE1], combined, true);
+		if (genes[MATE1].n == 0 || combined.n < genes[MATE1].n) genes[MATE1] = combined;
+		if (genes[SPLIT_READ].n == 0 || combined.n < genes[SPLIT_READ].n) genes[SPLIT_READ] = combined;
+		bool amb_split = abit(bits[SPLIT_READ], ABIT_PREDICTED_STRAND_AMBIGUOUS), amb_supp = abit(bits[SUPPLEMENTARY], ABIT_PREDICTED_STRAND_AMBIGUOUS);
+		bool different_strand = abit(bits[SUPPLEMENTARY], ABIT_STRAND) != abit(bits[SPLIT_READ], ABIT_STRAND);
+		if (amb_split && !amb_supp) {
+			bool predicted = complement_strand_if(abit(bits[SUPPLEMENTARY], ABIT_PREDICTED_STRAND), different_strand);
+			set_predicted(bits[MATE1], predicted);
+			set_predicted(bits[SPLIT_READ], predicted);
+		} else if (!amb_split && amb_supp) {
+			set_predicted(bits[SUPPLEMENTARY], complement_strand_if(abit(bits[SPLIT_READ], ABIT_PREDICTED_STRAND), different_strand));
+		} else if (!amb_split && !amb_supp) {
+			if ((abit(bits[SPLIT_READ], ABIT_PREDICTED_STRAND) != abit(bits[SUPPLEMENTARY], ABIT_PREDICTED_STRAND)) != different_strand) {
+				set_ambiguous(bits[MATE1]); set_ambiguous(bits[SPLIT_READ]); set_ambiguous(bits[SUPPLEMENTARY]);
+			}
+		}
+	}
+
+	// reference: gene-index fallback, source/arriba.cpp:190-205
+	IdentityMap identity;
+	for (int s = 0; s < n_aln; ++s)
+		if (genes[s].n == 0)
+			query_by_coordinate(ann.gene_index, b.contig[s][i], b.start[s][i], b.end[s][i], identity, genes[s]);
+	if (n_aln == 3) {
+		combine_sets(genes[SPLIT_READ], genes[MATE1], combined, true);
+		if (genes[MATE1].n == 0 || combined.n < genes[MATE1].n) genes[MATE1] = combined;
+		if (genes[SPLIT_READ].n == 0 || combined.n < genes[SPLIT_READ].n) genes[SPLIT_READ] = combined;
+	}
+
+	// reference: positions that need a dummy gene, source/arriba.cpp:207-231
+	if (n_aln == 3) {
+		if (genes[SPLIT_READ].n == 0)
+			unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[SPLIT_READ][i] << 32 | (uint32_t) breakpoint_of(b, SPLIT_READ, i, bits[SPLIT_READ], true);
+		if (genes[SUPPLEMENTARY].n == 0)
+			unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[SUPPLEMENTARY][i] << 32 | (uint32_t) breakpoint_of(b, SUPPLEMENTARY, i, bits[SUPPLEMENTARY], false);
+	} else {
+		for (int s = 0; s < n_aln; ++s)
+			if (genes[s].n == 0)
+				unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[s][i] << 32 | (uint32_t) breakpoint_of(b, s, i, bits[s], false);
+	}
+
+	bool ok = true;
+	for (int s = 0; s < n_aln; ++s) {
+		b.abits[s][i] = bits[s];
+		ok = store_genes(b, s, i, genes[s]) && !genes[s].overflow && ok;
+	}
+	return ok;
+}
+
+// ---- dummy genes ----------------------------------------------------------------------------------
+
+AGPU_HD uint32_t lower_bound_u64(const uint64_t* keys, uint32_t n, uint64_t value) {
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		uint32_t mid = lo + ((hi - lo) >> 1);
+		if (keys[mid] < value) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+// A new dummy gene starts at sorted position i (reference: source/arriba.cpp:243-259) when the contig changes, the gap to the
+// previous position exceeds 10 kb, or a boundary key of the gene index lies in [previous position, this position].
+AGPU_HD bool dummy_gene_starts_here(const uint64_t* sorted_keys, uint32_t i, const FlatIndexView& gene_index) {
+	if (i == 0) return true;
+	uint64_t previous = sorted_keys[i - 1], current = sorted_keys[i];
+	uint32_t contig = (uint32_t) (current >> 32);
+	if ((uint32_t) (previous >> 32) != contig) return true;
+	int32_t previous_position = (int32_t) (uint32_t) previous, position = (int32_t) (uint32_t) current;
+	if (previous_position + 10000 < position) return true;
+	if (contig < gene_index.n_contigs) {
+		uint32_t k = index_lower_bound(gene_index, contig, previous_position);
+		if (k != gene_index.contig_offset[contig + 1] && gene_index.keys[k] <= position) return true;
+	}
+	return false;
+}
+
+// Point query on the gene index as it looks after the dummy genes were added (reference: source/arriba.cpp:262-264 rebuilds the
+// index): the bucket of the first boundary key >= position, where the boundary keys of the dummy genes (end, start-1) are merged in.
+AGPU_HD void query_point_with_dummy_genes(const AnnotationView& ann, uint32_t contig, int32_t position, IdSet& out) {
+	out.clear();
+	bool have_real = false, have_key = false;
+	int32_t key = 0;
+	uint32_t real_bucket = 0;
+	if (contig < ann.gene_index.n_contigs) {
+		uint32_t k = index_lower_bound(ann.gene_index, contig, position);
+		if (k != ann.gene_index.contig_offset[contig + 1]) { have_real = true; real_bucket = k; key = ann.gene_index.keys[k]; have_key = true; }
+	}
+	if (ann.n_dummy > 0) {
+		uint64_t base = (uint64_t) contig << 32;
+		uint32_t j = lower_bound_u64(ann.dummy_end_key, ann.n_dummy, base | (uint32_t) position);
+		if (j < ann.n_dummy && (uint32_t) (ann.dummy_end_key[j] >> 32) == contig) {
+			int32_t candidate = (int32_t) (uint32_t) ann.dummy_end_key[j];
+			if (!have_key || candidate < key) { key = candidate; have_key = true; }
+		}
+		j = lower_bound_u64(ann.dummy_start_key, ann.n_dummy, base | (uint32_t) (position + 1));
+		if (j < ann.n_dummy && (uint32_t) (ann.dummy_start_key[j] >> 32) == contig) {
+			int32_t candidate = (int32_t) (uint32_t) ann.dummy_start_key[j] - 1;
+			if (!have_key || candidate < key) { key = candidate; have_key = true; }
+		}
+	}
+	if (!have_key) return;
+	if (have_real) { // the real genes containing `key` are those of the first real boundary >= position
+		IdentityMap identity;
+		emit_all(index_bucket(ann.gene_index, real_bucket), identity, out);
+	}
+	if (ann.n_dummy > 0) {
+		uint64_t base = (uint64_t) contig << 32;
+		uint32_t j = lower_bound_u64(ann.dummy_end_key, ann.n_dummy, base | (uint32_t) key);
+		while (j < ann.n_dummy && (uint32_t) (ann.dummy_start_key[j] >> 32) == contig && (int32_t) (uint32_t) ann.dummy_start_key[j] <= key) {
+			out.insert(ann.n_genes + j);
+			++j;
+		}
+	}
+}
+
+AGPU_HD bool gene_contains(const AnnotationView& ann, uint32_t gene, int32_t position) { return ann.gene_start[gene] <= position && ann.gene_end[gene] >= position; }
+
+// Stage 2 (reference: source/arriba.cpp:262-319): map still unannotated alignments to the dummy genes and reduce
+// alignments that span several dummy genes to the one containing the breakpoint.
+AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& ann, uint64_t i) {
+	int n_aln = b.n_aln[i];
+	IdSet genes[3];
+	uint8_t bits[3];
+	bool changed[3] = { false, false, false };
+	for (int s = 0; s < 3; ++s) { genes[s].clear(); bits[s] = 0; }
+	for (int s = 0; s < n_aln; ++s) { load_genes(b, s, i, genes[s]); bits[s] = b.abits[s][i]; }
+
+	if (n_aln == 3) {
+		if (genes[MATE1].n == 0 || genes[SPLIT_READ].n == 0) {
+			query_point_with_dummy_genes(ann, b.contig[SPLIT_READ][i], breakpoint_of(b, SPLIT_READ, i, bits[SPLIT_READ], true), genes[SPLIT_READ]);
+			genes[MATE1] = genes[SPLIT_READ];
+			changed[MATE1] = changed[SPLIT_READ] = true;
+		}
+		if (genes[SUPPLEMENTARY].n == 0) {
+			query_point_with_dummy_genes(ann, b.contig[SUPPLEMENTARY][i], breakpoint_of(b, SUPPLEMENTARY, i, bits[SUPPLEMENTARY], false), genes[SUPPLEMENTARY]);
+			changed[SUPPLEMENTARY] = true;
+		}
+	} else {
+		for (int s = 0; s < n_aln; ++s)
+			if (genes[s].n == 0) {
+				query_point_with_dummy_genes(ann, b.contig[s][i], breakpoint_of(b, s, i, bits[s], false), genes[s]);
+				changed[s] = true;
+			}
+	}
+
+	for (int s = 0; s < n_aln; ++s) {
+		if (genes[s].n > 1 && (ann.gene_bits[genes[s].v[0]] & GBIT_DUMMY)) {
+			int32_t breakpoint = breakpoint_of(b, s, i, bits[s], true); // forward -> start for every slot here (source/arriba.cpp:291)
+			uint32_t encompassing = genes[MATE1].v[0];
+			for (uint32_t g = 0; g < genes[s].n; ++g)
+				if (gene_contains(ann, genes[s].v[g], breakpoint))
+					encompassing = genes[s].v[g];
+			genes[s].assign_single(encompassing);
+			changed[s] = true;
+		}
+	}
+	if (n_aln == 3 && genes[MATE1].n > 0 && genes[SPLIT_READ].n > 0) {
+		uint32_t g1 = genes[MATE1].v[0], g2 = genes[SPLIT_READ].v[0];
+		if (g1 != g2 && (ann.gene_bits[g1] & GBIT_DUMMY) && (ann.gene_bits[g2] & GBIT_DUMMY)) {
+			int32_t breakpoint = breakpoint_of(b, SPLIT_READ, i, bits[SPLIT_READ], true);
+			uint32_t encompassing = g1;
+			for (uint32_t g = 0; g < genes[MATE1].n; ++g)
+				if (gene_contains(ann, genes[MATE1].v[g], breakpoint)) encompassing = genes[MATE1].v[g];
+			for (uint32_t g = 0; g < genes[SPLIT_READ].n; ++g)
+				if (gene_contains(ann, genes[SPLIT_READ].v[g], breakpoint)) encompassing = genes[SPLIT_READ].v[g];
+			genes[MATE1].assign_single(encompassing);
+			genes[SPLIT_READ].assign_single(encompassing);
+			changed[MATE1] = changed[SPLIT_READ] = true;
+		}
+	}
+	bool ok = true;
+	for (int s = 0; s < n_aln; ++s)
+		if (changed[s])
+			ok = store_genes(b, s, i, genes[s]) && !genes[s].overflow && ok;
+	return ok;
+}
+
+}
+
+#endif

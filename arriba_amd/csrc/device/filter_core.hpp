@@ -1,0 +1,509 @@
+// arriba_amd/csrc/device/filter_core.hpp -- the read-level filter cascade, one thread per chimeric fragment.
+//
+// Each predicate restates one reference stage as a pure function of the fragment's columns:
+//   duplicates key          source/filter_duplicates.cpp:22-45
+//   uninteresting_contigs   source/filter_uninteresting_contigs.cpp:8-26
+//   viral_contigs           source/filter_viral_contigs.cpp:8-27
+//   top_expressed / low_coverage viral contigs (per-read part)   source/filter_top_expressed_viral_contigs.cpp:128-151, source/filter_low_coverage_viral_contigs.cpp:28-48
+//   read_through            source/filter_proximal_read_through.cpp:8-47
+//   inconsistently_clipped  source/filter_inconsistently_clipped.cpp:6-25
+//   homopolymer             source/filter_homopolymer.cpp:7-62
+//   small_insert_size       source/filter_small_insert_size.cpp:7-30
+//   long_gap                source/filter_long_gap.cpp:6-89
+//   same_gene               source/filter_same_gene.cpp:8-46
+//   hairpin                 source/filter_hairpin.cpp:7-80
+//   mismatches              source/filter_mismatches.cpp:12-135 (verdict via a host-built table, hazard H5)
+//   low_entropy             source/filter_low_entropy.cpp:9-112, kmer_to_int source/filter_mismappers.cpp:33-45
+#ifndef AGPU_FILTER_CORE_HPP
+#define AGPU_FILTER_CORE_HPP 1
+
+#include "annotate_core.hpp"
+
+namespace agpu {
+
+struct FilterTables {
+	// mismatch verdict for (mismatches k, aligned length n), k <= n <= mismatch_max_length: bit (n*(n+1)/2 + k); k > n is always a discard
+	const uint32_t* mismatch_verdict;
+	uint32_t mismatch_max_length;
+	// low-entropy thresholds per segment length: unsigned(len * max_kmer_content / 3 + 0.5) computed with the reference's float/double mix
+	const uint32_t* kmer_threshold;
+	uint32_t kmer_threshold_size;
+	float max_kmer_content;
+	uint32_t homopolymer_length;
+	int32_t min_read_through_distance;
+	uint32_t max_itd_length;
+	uint8_t external_duplicate_marking;
+	const uint8_t* top_expressed_viral_verdict; // per contig, may be null
+	const uint8_t* low_coverage_viral_verdict;  // per contig, may be null
+};
+
+AGPU_HD uint32_t preclipping(const uint32_t* cigar, uint32_t n) { uint32_t op = cigar[0] & 15; return (op == CIGAR_S || op == CIGAR_H) ? cigar[0] >> 4 : 0; }
+AGPU_HD uint32_t postclipping(const uint32_t* cigar, uint32_t n) { uint32_t op = cigar[n - 1] & 15; return (op == CIGAR_S || op == CIGAR_H) ? cigar[n - 1] >> 4 : 0; }
+AGPU_HD const uint32_t* cigar_of(const BatchView& b, int slot, uint64_t i) { return b.cigar_pool + b.cigar_offset[slot][i]; }
+
+// BAM 4-bit code -> ASCII as the reference stores it (seq_nt16_str)
+AGPU_HD char base_char(uint32_t code) {
+	switch (code) {
+		case 0: return '='; case 1: return 'A'; case 2: return 'C'; case 3: return 'M'; case 4: return 'G'; case 5: return 'R'; case 6: return 'S'; case 7: return 'V';
+		case 8: return 'T'; case 9: return 'W'; case 10: return 'Y'; case 11: return 'H'; case 12: return 'K'; case 13: return 'D'; case 14: return 'B'; default: return 'N';
+	}
+}
+AGPU_HD uint32_t base_code(const uint8_t* packed, uint32_t position) { return (packed[position >> 1] >> ((~position & 1) << 2)) & 15; }
+// complement on codes (reference: dna_to_complement, source/assembly.hpp:9-21 swaps only A<->T and C<->G)
+AGPU_HD uint32_t complement_code(uint32_t code) { return code == 1 ? 8 : code == 8 ? 1 : code == 2 ? 4 : code == 4 ? 2 : code; }
+
+struct SequenceRef {
+	const uint8_t* packed; uint32_t length; bool reverse_complement;
+	AGPU_HD uint32_t code(uint32_t position) const { return reverse_complement ? complement_code(base_code(packed, length - 1 - position)) : base_code(packed, position); }
+	AGPU_HD char at(uint32_t position) const { return base_char(code(position)); }
+};
+AGPU_HD SequenceRef sequence_of(const BatchView& b, int slot, uint64_t i) {
+	SequenceRef s; s.packed = b.seq_pool + (uint64_t) b.seq_offset[slot][i] * 4; s.length = b.seq_length[slot][i]; s.reverse_complement = false; return s;
+}
+
+// ---- duplicates -----------------------------------------------------------------------------------
+
+struct DuplicateKey { uint32_t contigs; int32_t position1, position2; }; // contigs = contig1 << 16 | contig2
+AGPU_HD bool keys_equal(const DuplicateKey& a, const DuplicateKey& b) { return a.contigs == b.contigs && a.position1 == b.position1 && a.position2 == b.position2; }
+
+AGPU_HD DuplicateKey duplicate_key(const BatchView& b, uint64_t i) {
+	int mate2 = (b.n_aln[i] == 2) ? MATE2 : SUPPLEMENTARY;
+	const uint32_t* cigar1 = cigar_of(b, MATE1, i); uint32_t n1 = b.cigar_count[MATE1][i];
+	const uint32_t* cigar2 = cigar_of(b, mate2, i); uint32_t n2 = b.cigar_count[mate2][i];
+	int32_t position1 = (b.abits[MATE1][i] & ABIT_STRAND) ? b.start[MATE1][i] - (int32_t) preclipping(cigar1, n1) : b.end[MATE1][i] + (int32_t) postclipping(cigar1, n1);
+	int32_t position2 = (b.abits[mate2][i] & ABIT_STRAND) ? b.start[mate2][i] - (int32_t) preclipping(cigar2, n2) : b.end[mate2][i] + (int32_t) postclipping(cigar2, n2);
+	uint32_t contig1 = b.contig[MATE1][i], contig2 = b.contig[mate2][i];
+	if (position1 > position2) { int32_t t = position1; position1 = position2; position2 = t; uint32_t c = contig1; contig1 = contig2; contig2 = c; }
+	DuplicateKey key; key.contigs = contig1 << 16 | contig2; key.position1 = position1; key.position2 = position2;
+	return key;
+}
+AGPU_HD uint64_t hash_duplicate_key(const DuplicateKey& key) {
+	uint64_t h = ((uint64_t) (uint32_t) key.position1 << 32 | (uint32_t) key.position2) * 0x9E3779B97F4A7C15ULL;
+	h ^= (uint64_t) key.contigs * 0xC2B2AE3D27D4EB4FULL;
+	h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+	return h;
+}
+
+// ---- contig based filters (stage group 1) ----------------------------------------------------------
+
+// returns the filter id that discards fragment i, or FILTER_none
+AGPU_HD uint8_t contig_filters(const BatchView& b, const GenomeView& genome, const FilterTables& t, uint64_t i) {
+	int n_aln = b.n_aln[i];
+	bool all_viral = true;
+	for (int s = 0; s < n_aln; ++s) {
+		uint8_t bits = genome.contig_bits[b.contig[s][i]];
+		if (!(bits & CBIT_INTERESTING)) return FILTER_uninteresting_contigs;
+	}
+	for (int s = 0; s < n_aln; ++s)
+		if (!(genome.contig_bits[b.contig[s][i]] & CBIT_VIRAL)) all_viral = false;
+	if (all_viral) return FILTER_viral_contigs;
+	if (t.top_expressed_viral_verdict != 0)
+		for (int s = 0; s < n_aln; ++s) {
+			uint32_t contig = b.contig[s][i];
+			if ((genome.contig_bits[contig] & CBIT_VIRAL) && t.top_expressed_viral_verdict[contig]) return FILTER_top_expressed_viral_contigs;
+		}
+	if (t.low_coverage_viral_verdict != 0)
+		for (int s = 0; s < n_aln; ++s) {
+			uint32_t contig = b.contig[s][i];
+			if ((genome.contig_bits[contig] & CBIT_VIRAL) && t.low_coverage_viral_verdict[contig]) return FILTER_low_coverage_viral_contigs;
+		}
+	return FILTER_none;
+}
+
+// ---- spliced distance (for the fragment-length samples) -------------------------------------------
+
+// reference: get_spliced_distance, source/annotation.cpp:570-618
+AGPU_HD int32_t spliced_distance(const AnnotationView& ann, uint32_t contig, int32_t position1, int32_t position2, uint32_t gene) {
+	if (position1 > position2) { int32_t t = position1; position1 = position2; position2 = t; }
+	const FlatIndexView& index = ann.exon_index;
+	if (contig >= index.n_contigs || index.contig_offset[contig] == index.contig_offset[contig + 1])
+		return position2 - position1;
+	uint32_t k = index_lower_bound(index, contig, position1);
+	uint32_t contig_end = index.contig_offset[contig + 1];
+	int32_t distance = 0;
+	if (k != contig_end && index.keys[k] < position2) {
+		distance += index.keys[k] - position1;
+		position1 = index.keys[k];
+	}
+	for (; k != contig_end && index.keys[k] < position2; ++k) {
+		if (index.keys[k] < position1) continue;
+		int32_t best_start = -1, best_end = -1, best_skip = -1;
+		ListRef exons = index_bucket(index, k);
+		for (uint32_t m = 0; m < exons.n; ++m) {
+			uint32_t e = exons.p[m];
+			if (ann.exon_gene[e] != gene) continue;
+			int32_t next = ann.exon_next[e];
+			if (next == -1 || ann.exon_start[next] > position2) continue;
+			int32_t exon_start = ann.exon_start[e] > position1 ? ann.exon_start[e] : position1;
+			int32_t exon_end = ann.exon_end[e] < position2 ? ann.exon_end[e] : position2;
+			int32_t exon_skip = ann.exon_start[next] - exon_start + 1;
+			if (best_start == -1 || 1.0 * (exon_end - exon_start) / exon_skip < 1.0 * (best_end - best_start) / best_skip) {
+				best_start = exon_start; best_end = exon_end; best_skip = exon_skip;
+			}
+		}
+		if (best_start != -1) {
+			distance += best_end - best_start + 1;
+			position1 = best_start + best_skip - 1;
+		}
+	}
+	distance += position2 - position1;
+	return distance;
+}
+
+// mate gap of a paired split read as estimate_fragment_length samples it (source/read_stats.cpp:27-39)
+AGPU_HD int32_t mate_gap_sample(const BatchView& b, const AnnotationView& ann, uint64_t i) {
+	int forward = MATE1, reverse = SPLIT_READ;
+	if (!(b.abits[MATE1][i] & ABIT_STRAND)) { forward = SPLIT_READ; reverse = MATE1; }
+	IdSet genes; load_genes(b, forward, i, genes);
+	int32_t forward_end = b.end[forward][i], reverse_start = b.start[reverse][i];
+	int32_t distance = spliced_distance(ann, b.contig[forward][i], forward_end, reverse_start, genes.v[0]);
+	if (forward_end > reverse_start) distance *= -1;
+	int32_t forward_length = (int32_t) b.seq_length[forward][i], reverse_length = (int32_t) b.seq_length[reverse][i];
+	if (distance < -forward_length) distance = -forward_length;
+	if (distance < -reverse_length) distance = -reverse_length;
+	return distance;
+}
+
+// ---- stage group 2 predicates -----------------------------------------------------------------------
+
+AGPU_HD void gene_boundaries(const AnnotationView& ann, const IdSet& genes, int32_t& start, int32_t& end) { // source/annotation.cpp:558-567
+	start = -1; end = -1;
+	for (uint32_t g = 0; g < genes.n; ++g) {
+		int32_t gene_start = ann.gene_start[genes.v[g]], gene_end = ann.gene_end[genes.v[g]];
+		if (start == -1 || start > gene_start) start = gene_start;
+		if (end == -1 || end < gene_end) end = gene_end;
+	}
+}
+
+AGPU_HD bool is_proximal_read_through(const BatchView& b, const AnnotationView& ann, const FilterTables& t, uint64_t i, const IdSet* genes) {
+	int n_aln = b.n_aln[i];
+	int forward, reverse;
+	if (n_aln == 2) {
+		bool mate1_forward = b.abits[MATE1][i] & ABIT_STRAND;
+		forward = mate1_forward ? MATE1 : MATE2; reverse = mate1_forward ? MATE2 : MATE1;
+	} else {
+		bool split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND;
+		forward = split_forward ? SUPPLEMENTARY : SPLIT_READ; reverse = split_forward ? SPLIT_READ : SUPPLEMENTARY;
+	}
+	bool forward_strand = b.abits[forward][i] & ABIT_STRAND, reverse_strand = b.abits[reverse][i] & ABIT_STRAND;
+	bool colinear = b.contig[forward][i] == b.contig[reverse][i] && b.end[forward][i] < b.start[reverse][i];
+	if ((n_aln == 2 && forward_strand != reverse_strand && colinear) || (n_aln == 3 && forward_strand == reverse_strand && colinear)) {
+		int32_t forward_gene_start, forward_gene_end, reverse_gene_start, reverse_gene_end;
+		gene_boundaries(ann, genes[forward], forward_gene_start, forward_gene_end);
+		gene_boundaries(ann, genes[reverse], reverse_gene_start, reverse_gene_end);
+		if (b.end[forward][i] >= reverse_gene_start - t.min_read_through_distance || b.start[reverse][i] <= forward_gene_end + t.min_read_through_distance)
+			return true;
+	}
+	return false;
+}
+
+AGPU_HD bool is_inconsistently_clipped(const BatchView& b, uint64_t i) {
+	if (b.n_aln[i] != 3) return false;
+	bool forward = b.abits[MATE1][i] & ABIT_STRAND;
+	return (forward && b.end[MATE1][i] > b.end[SPLIT_READ][i] + 3) || (!forward && b.start[MATE1][i] < b.start[SPLIT_READ][i] - 3);
+}
+
+AGPU_HD bool split_read_is_spliced(const BatchView& b, const AnnotationView& ann, uint64_t i, const IdSet& genes) { // source/filter_homopolymer.cpp:7-14
+	bool forward = b.abits[SPLIT_READ][i] & ABIT_STRAND;
+	int32_t breakpoint = forward ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i];
+	for (uint32_t g = 0; g < genes.n; ++g)
+		if (is_breakpoint_spliced(ann, genes.v[g], forward, breakpoint))
+			return true;
+	return false;
+}
+
+AGPU_HD bool has_homopolymer_at_breakpoint(const BatchView& b, const AnnotationView& ann, const FilterTables& t, uint64_t i, const IdSet& split_read_genes) {
+	if (b.n_aln[i] != 3) return false;
+	SequenceRef sequence = sequence_of(b, SPLIT_READ, i);
+	const uint32_t* cigar = cigar_of(b, SPLIT_READ, i); uint32_t n_cigar = b.cigar_count[SPLIT_READ][i];
+	uint32_t H = t.homopolymer_length, length = sequence.length;
+	// the reference concatenates up to two H-mers, each followed by a blank; segments: [start, start+H)
+	uint32_t segment_start[2]; int segments = 0;
+	if (b.abits[SPLIT_READ][i] & ABIT_STRAND) {
+		uint32_t clip = preclipping(cigar, n_cigar);
+		if (clip >= H) segment_start[segments++] = clip - H;
+		if (length - clip >= H) segment_start[segments++] = clip;
+	} else {
+		uint32_t clip = postclipping(cigar, n_cigar);
+		if (clip >= H) segment_start[segments++] = length - clip;
+		if (length - clip >= H) segment_start[segments++] = length - clip - H;
+	}
+	// runs cannot cross the blank separator, so each H-mer is checked on its own: a run of H equal characters == all H equal
+	for (int s = 0; s < segments; ++s) {
+		uint32_t run = 1;
+		for (uint32_t c = 1; c < H; ++c) {
+			if (sequence.code(segment_start[s] + c - 1) == sequence.code(segment_start[s] + c)) {
+				++run;
+				if (run == H && !split_read_is_spliced(b, ann, i, split_read_genes))
+					return true;
+			} else {
+				run = 1;
+			}
+		}
+	}
+	return false;
+}
+
+AGPU_HD bool has_small_insert_size(const BatchView& b, uint64_t i, int32_t max_overhang) {
+	if (b.n_aln[i] != 2) return false;
+	if (((b.abits[MATE1][i] ^ b.abits[MATE2][i]) & ABIT_STRAND) && b.contig[MATE1][i] == b.contig[MATE2][i]) {
+		int32_t d1 = b.start[MATE1][i] - b.start[MATE2][i]; if (d1 < 0) d1 = -d1;
+		int32_t d2 = b.end[MATE1][i] - b.end[MATE2][i]; if (d2 < 0) d2 = -d2;
+		// the reference compares abs(int) with an unsigned max_overhang; both are non-negative
+		return d1 <= max_overhang || d2 <= max_overhang;
+	}
+	return false;
+}
+
+AGPU_HD bool has_long_gap(const BatchView& b, uint64_t i) {
+	const int32_t min_long_gap = 700000, max_long_gap = 1500000;
+	const uint32_t short_segment = 15;
+	int n_aln = b.n_aln[i];
+	int32_t size_of_deletion = 0;
+	if (n_aln == 3 && b.contig[SPLIT_READ][i] == b.contig[SUPPLEMENTARY][i]) {
+		bool split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND, supp_forward = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND;
+		if (!split_forward && !supp_forward) size_of_deletion = b.start[SUPPLEMENTARY][i] - b.end[SPLIT_READ][i];
+		else if (split_forward && supp_forward) size_of_deletion = b.start[SPLIT_READ][i] - b.end[SUPPLEMENTARY][i];
+	}
+	for (int s = 0; s < n_aln; ++s) {
+		const uint32_t* cigar = cigar_of(b, s, i); uint32_t n = b.cigar_count[s][i];
+		for (uint32_t c = 1; c + 1 < n; ++c) {
+			if ((cigar[c] & 15) == CIGAR_N && ((int32_t) (cigar[c] >> 4) >= min_long_gap || (size_of_deletion >= min_long_gap && size_of_deletion <= max_long_gap))) {
+				uint32_t left = 0, right = 0;
+				for (int32_t j = (int32_t) c - 1; j >= 0; --j) {
+					uint32_t op = cigar[j] & 15;
+					if (op == CIGAR_M || op == CIGAR_X || op == CIGAR_EQ) left += cigar[j] >> 4;
+					else if (op == CIGAR_D || op == CIGAR_I || op == CIGAR_P) {}
+					else break;
+				}
+				for (uint32_t j = c + 1; j < n; ++j) {
+					uint32_t op = cigar[j] & 15;
+					if (op == CIGAR_M || op == CIGAR_X || op == CIGAR_EQ) right += cigar[j] >> 4;
+					else if (op == CIGAR_D || op == CIGAR_I || op == CIGAR_P) {}
+					else break;
+				}
+				if (left <= short_segment && right <= short_segment)
+					return true;
+			}
+		}
+	}
+	return false;
+}
+
+AGPU_HD bool is_same_gene_artifact(const BatchView& b, uint64_t i, const IdSet* genes) {
+	IdSet common;
+	if (b.n_aln[i] == 2) intersect_sets(genes[MATE1], genes[MATE2], common);
+	else intersect_sets(genes[MATE2], genes[SUPPLEMENTARY], common);
+	if (common.n == 0) return false;
+	if (b.n_aln[i] == 2) {
+		bool forward1 = b.abits[MATE1][i] & ABIT_STRAND, forward2 = b.abits[MATE2][i] & ABIT_STRAND;
+		return (forward1 && !forward2 && b.start[MATE1][i] <= b.end[MATE2][i]) || (!forward1 && forward2 && b.end[MATE1][i] >= b.start[MATE2][i]);
+	}
+	bool split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND, supp_forward = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND;
+	return (split_forward && supp_forward && b.start[SPLIT_READ][i] >= b.end[SUPPLEMENTARY][i]) || (!split_forward && !supp_forward && b.end[SPLIT_READ][i] <= b.start[SUPPLEMENTARY][i]);
+}
+
+AGPU_HD bool breakpoint_within_aligned_segment(const BatchView& b, int slot, uint64_t i, int32_t breakpoint) { // source/filter_hairpin.cpp:7-27
+	const uint32_t* cigar = cigar_of(b, slot, i); uint32_t n = b.cigar_count[slot][i];
+	int32_t reference_position = b.start[slot][i];
+	for (uint32_t c = 0; c < n; ++c) {
+		uint32_t op = cigar[c] & 15; int32_t length = cigar[c] >> 4;
+		if (op == CIGAR_N || op == CIGAR_D) reference_position += length;
+		else if (op == CIGAR_M || op == CIGAR_X || op == CIGAR_EQ) {
+			if (breakpoint >= reference_position && breakpoint <= reference_position + length) return true;
+			reference_position += length;
+		}
+	}
+	return false;
+}
+
+AGPU_HD bool is_hairpin(const BatchView& b, uint64_t i, const IdSet* genes) {
+	IdSet common;
+	if (b.n_aln[i] == 2) {
+		intersect_sets(genes[MATE1], genes[MATE2], common);
+		if (common.n == 0 && b.contig[MATE1][i] != b.contig[MATE2][i]) return false;
+		int32_t breakpoint1 = (b.abits[MATE1][i] & ABIT_STRAND) ? b.end[MATE1][i] : b.start[MATE1][i];
+		int32_t breakpoint2 = (b.abits[MATE2][i] & ABIT_STRAND) ? b.end[MATE2][i] : b.start[MATE2][i];
+		return breakpoint_within_aligned_segment(b, MATE2, i, breakpoint1) || breakpoint_within_aligned_segment(b, MATE1, i, breakpoint2);
+	}
+	intersect_sets(genes[SPLIT_READ], genes[SUPPLEMENTARY], common);
+	if (common.n == 0 && b.contig[SPLIT_READ][i] != b.contig[SUPPLEMENTARY][i]) return false;
+	int32_t breakpoint_split = (b.abits[SPLIT_READ][i] & ABIT_STRAND) ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i];
+	int32_t breakpoint_supp = (b.abits[SUPPLEMENTARY][i] & ABIT_STRAND) ? b.end[SUPPLEMENTARY][i] : b.start[SUPPLEMENTARY][i];
+	return breakpoint_within_aligned_segment(b, SUPPLEMENTARY, i, breakpoint_split) || breakpoint_within_aligned_segment(b, SPLIT_READ, i, breakpoint_supp) ||
+	       breakpoint_within_aligned_segment(b, MATE1, i, breakpoint_supp);
+}
+
+// reference: count_mismatches + test_mismatch_probability, source/filter_mismatches.cpp:12-99
+AGPU_HD bool has_too_many_mismatches(const BatchView& b, const GenomeView& genome, const FilterTables& t, uint64_t i, int slot, const SequenceRef& sequence, bool is_multimapper) {
+	const uint32_t* cigar = cigar_of(b, slot, i); uint32_t n = b.cigar_count[slot][i];
+	uint32_t contig = b.contig[slot][i];
+	uint64_t contig_begin = genome.contig_offset[contig], contig_size = genome.contig_offset[contig + 1] - contig_begin;
+	const char* reference = genome.bases + contig_begin;
+	bool forward = b.abits[slot][i] & ABIT_STRAND;
+	uint32_t mismatches = 0, alignment_length = 0;
+	int64_t reference_position = b.start[slot][i];
+	uint32_t read_position = 0;
+	for (uint32_t c = 0; c < n; ++c) {
+		uint32_t op = cigar[c] & 15, length = cigar[c] >> 4;
+		switch (op) {
+			case CIGAR_S: case CIGAR_H:
+				read_position += length;
+				if (!((c == 0 && !forward) || (c == n - 1 && forward))) mismatches++;
+				break;
+			case CIGAR_D:
+				mismatches++;
+				reference_position += length;
+				break;
+			case CIGAR_N:
+				reference_position += length;
+				break;
+			case CIGAR_I:
+				mismatches++;
+				read_position += length;
+				break;
+			case CIGAR_M: case CIGAR_EQ: case CIGAR_X:
+				for (uint32_t k = 0; k < length; ++k) {
+					char base = (read_position < sequence.length) ? sequence.at(read_position) : '\0';
+					if (base != 'N') {
+						char reference_base = (reference_position >= 0 && (uint64_t) reference_position < contig_size) ? reference[reference_position] : '\0';
+						if (base != reference_base) mismatches++;
+						alignment_length++;
+					}
+					reference_position++;
+					read_position++;
+				}
+				break;
+			default: break;
+		}
+	}
+	if (is_multimapper) mismatches += 2;
+	if (mismatches > alignment_length) return true;
+	if (alignment_length > t.mismatch_max_length) return true; // unreachable for reads within the table; fail closed
+	uint32_t bit = alignment_length * (alignment_length + 1) / 2 + mismatches;
+	return (t.mismatch_verdict[bit >> 5] >> (bit & 31)) & 1;
+}
+
+AGPU_HD bool fails_mismatch_filter(const BatchView& b, const GenomeView& genome, const FilterTables& t, uint64_t i) {
+	bool multimapper = b.fbits[i] & FBIT_MULTIMAPPER;
+	int other = (b.n_aln[i] == 2) ? MATE2 : SUPPLEMENTARY;
+	bool viral1 = genome.contig_bits[b.contig[MATE1][i]] & CBIT_VIRAL, viral2 = genome.contig_bits[b.contig[other][i]] & CBIT_VIRAL;
+	if (!viral1 && has_too_many_mismatches(b, genome, t, i, MATE1, sequence_of(b, MATE1, i), multimapper && !viral2))
+		return true;
+	if (!viral2) {
+		SequenceRef sequence;
+		if (b.n_aln[i] == 2) sequence = sequence_of(b, MATE2, i);
+		else {
+			sequence = sequence_of(b, SPLIT_READ, i);
+			sequence.reverse_complement = ((b.abits[SUPPLEMENTARY][i] ^ b.abits[SPLIT_READ][i]) & ABIT_STRAND) != 0;
+		}
+		if (has_too_many_mismatches(b, genome, t, i, other, sequence, multimapper && !viral1))
+			return true;
+	}
+	return false;
+}
+
+// reference: kmer_to_int with k=3 (source/filter_mismappers.cpp:33-45): T=0, G=1, C=2, everything else 3
+AGPU_HD uint32_t kmer_digit(uint32_t code) { return code == 8 ? 0 : code == 4 ? 1 : code == 2 ? 2 : 3; }
+
+AGPU_HD uint32_t kmer_threshold(const FilterTables& t, uint32_t length) {
+	if (length < t.kmer_threshold_size) return t.kmer_threshold[length];
+	return (uint32_t) ((double) ((float) length * t.max_kmer_content / 3.0f) + 0.5); // same operation order as the reference; only reached for absurd lengths
+}
+
+AGPU_HD bool looks_like_internal_tandem_duplication(const BatchView& b, const FilterTables& t, uint64_t i) { // source/filter_low_entropy.cpp:17-27
+	if (b.n_aln[i] != 3) return false;
+	bool split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND, supp_forward = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND;
+	if (split_forward != supp_forward || b.contig[SPLIT_READ][i] != b.contig[SUPPLEMENTARY][i]) return false;
+	int32_t max_itd = (int32_t) t.max_itd_length;
+	if (split_forward) return b.start[SPLIT_READ][i] < b.end[SUPPLEMENTARY][i] && b.start[SPLIT_READ][i] + max_itd >= b.end[SUPPLEMENTARY][i];
+	return b.end[SPLIT_READ][i] > b.start[SUPPLEMENTARY][i] && b.end[SPLIT_READ][i] <= b.start[SUPPLEMENTARY][i] + max_itd;
+}
+
+// Per-thread counters for the 64 possible 3-mers.  `stride` lets the kernel interleave the counters of a
+// workgroup in LDS (bank = thread), the host harness uses stride 1.
+struct KmerScratch {
+	uint16_t* previous_position; uint8_t* count_all; uint8_t* count_aligned1; uint8_t* count_aligned2; uint32_t stride;
+	AGPU_HD void reset() {
+		for (uint32_t k = 0; k < 64; ++k) { previous_position[k * stride] = 0; count_all[k * stride] = 0; count_aligned1[k * stride] = 0; count_aligned2[k * stride] = 0; }
+	}
+};
+
+AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t i, KmerScratch& scratch) {
+	const uint32_t K = 3;
+	for (int mate = MATE1; mate <= MATE2; ++mate) {
+		SequenceRef sequence = sequence_of(b, mate, i);
+		uint32_t length = sequence.length;
+		if (length < K) continue;
+		const uint32_t* cigar = cigar_of(b, mate, i); uint32_t n = b.cigar_count[mate][i];
+		uint32_t aligned_start1 = ((cigar[0] & 15) == CIGAR_S) ? cigar[0] >> 4 : 0;
+		uint32_t aligned_end1 = length;
+		if ((cigar[n - 1] & 15) == CIGAR_S) aligned_end1 -= cigar[n - 1] >> 4;
+		uint32_t aligned_start2, aligned_end2;
+		if (b.n_aln[i] == 3 && mate == SPLIT_READ) {
+			const uint32_t* supp = cigar_of(b, SUPPLEMENTARY, i); uint32_t m = b.cigar_count[SUPPLEMENTARY][i];
+			aligned_start2 = ((supp[0] & 15) == CIGAR_S) ? supp[0] >> 4 : 0;
+			aligned_end2 = length;
+			if ((supp[m - 1] & 15) == CIGAR_S) aligned_end2 -= supp[m - 1] >> 4;
+			if ((b.abits[SUPPLEMENTARY][i] ^ b.abits[SPLIT_READ][i]) & ABIT_STRAND) {
+				aligned_start2 = length - aligned_start2;
+				aligned_end2 = length - aligned_end2;
+				uint32_t swap = aligned_start2; aligned_start2 = aligned_end2; aligned_end2 = swap;
+			}
+		} else {
+			aligned_start2 = aligned_start1;
+			aligned_end2 = aligned_end1;
+		}
+		uint32_t max_count = kmer_threshold(t, length);
+		uint32_t max_count_aligned1 = kmer_threshold(t, aligned_end1 - aligned_start1);
+		uint32_t max_count_aligned2 = kmer_threshold(t, aligned_end2 - aligned_start2);
+		scratch.reset();
+		uint32_t kmer = kmer_digit(sequence.code(0)) << 2 | kmer_digit(sequence.code(1));
+		for (uint32_t position = 0; position < length - K; ++position) { // the last k-mer is skipped, as in the reference (:77)
+			kmer = ((kmer << 2) | kmer_digit(sequence.code(position + 2))) & 63;
+			uint32_t slot = kmer * scratch.stride;
+			if (scratch.previous_position[slot] <= position) {
+				scratch.previous_position[slot] = (uint16_t) (position + K);
+				uint32_t count = ++scratch.count_all[slot];
+				uint32_t count1 = scratch.count_aligned1[slot], count2 = scratch.count_aligned2[slot];
+				if (position + 1 >= aligned_start1 && position < aligned_end1) count1 = ++scratch.count_aligned1[slot];
+				if (position + 1 >= aligned_start2 && position < aligned_end2) count2 = ++scratch.count_aligned2[slot];
+				if (count >= max_count || count1 >= max_count_aligned1 || count2 >= max_count_aligned2)
+					return true;
+			}
+		}
+	}
+	return false;
+}
+
+// The stage-2 cascade for one fragment; `filter` is the state after stage group 1.  Returns the new filter id.
+// first_hit receives the ordinal (0..8) of the stage that discarded the read, 9 if none (for the per-stage "remaining" counts).
+AGPU_HD uint8_t read_filters_stage2(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const FilterTables& t, const uint8_t* enabled, uint64_t i, uint8_t filter, KmerScratch& scratch, uint32_t& first_hit) {
+	first_hit = 9;
+	if (filter == FILTER_none) {
+		IdSet genes[3];
+		int n_aln = b.n_aln[i];
+		for (int s = 0; s < 3; ++s) { genes[s].clear(); if (s < n_aln) load_genes(b, s, i, genes[s]); }
+		if (enabled[FILTER_read_through] && is_proximal_read_through(b, ann, t, i, genes)) { filter = FILTER_read_through; first_hit = 0; }
+		else if (enabled[FILTER_inconsistently_clipped] && is_inconsistently_clipped(b, i)) { filter = FILTER_inconsistently_clipped; first_hit = 1; }
+		else if (enabled[FILTER_homopolymer] && has_homopolymer_at_breakpoint(b, ann, t, i, genes[SPLIT_READ])) { filter = FILTER_homopolymer; first_hit = 2; }
+		else if (enabled[FILTER_small_insert_size] && has_small_insert_size(b, i, 5)) { filter = FILTER_small_insert_size; first_hit = 3; }
+		else if (enabled[FILTER_long_gap] && has_long_gap(b, i)) { filter = FILTER_long_gap; first_hit = 4; }
+		else if (enabled[FILTER_same_gene] && is_same_gene_artifact(b, i, genes)) { filter = FILTER_same_gene; first_hit = 5; }
+		else if (enabled[FILTER_hairpin] && is_hairpin(b, i, genes)) { filter = FILTER_hairpin; first_hit = 6; }
+		else if (enabled[FILTER_mismatches] && fails_mismatch_filter(b, genome, t, i)) { filter = FILTER_mismatches; first_hit = 7; }
+	}
+	if (enabled[FILTER_low_entropy]) {
+		// ITD-shaped reads are tested even if an earlier filter (other than duplicates) discarded them (source/filter_low_entropy.cpp:29-31)
+		bool test = (filter == FILTER_none) || (filter != FILTER_duplicates && looks_like_internal_tandem_duplication(b, t, i));
+		if (test && has_low_entropy(b, t, i, scratch)) {
+			if (filter == FILTER_none) first_hit = 8;
+			filter = FILTER_low_entropy;
+		}
+	}
+	return filter;
+}
+
+}
+
+#endif

@@ -1,0 +1,352 @@
+// arriba_amd/csrc/host/host_capi.cpp -- C ABI of the host driver library (include/arriba_host.h) and the
+// sequential scalar stages that sit between the device stages of the hot path.
+#include "../../../include/arriba_host.h"
+#include "arriba_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <set>
+#include <stdexcept>
+
+using namespace arriba;
+
+namespace {
+thread_local std::string g_error;
+const char* const DEFAULT_GTF_FEATURES = "gene_name=gene_name|gene_id gene_id=gene_id transcript_id=transcript_id feature_exon=exon feature_CDS=CDS";
+}
+
+struct ahost_session {
+	IngestOptions options;
+	Contigs contigs;
+	Assembly assembly;
+	Annotation annotation;
+	FlatIndex exon_index, gene_index;
+	IngestResult ingest;
+	bool have_batch = false;
+
+	// flattened tables backing the views
+	std::vector<uint16_t> gene_contig; std::vector<int32_t> gene_start, gene_end, gene_exonic_length; std::vector<uint8_t> gene_bits;
+	std::vector<int32_t> exon_start, exon_end, exon_previous, exon_next, exon_cds_start, exon_cds_end; std::vector<uint32_t> exon_gene;
+	std::vector<uint64_t> genome_offset; std::vector<uint8_t> contig_bits; std::string genome_bases;
+	agpu_annotation_view annotation_view;
+	agpu_genome_view genome_view;
+	agpu_batch_view batch_view;
+	std::string name_scratch;
+
+	void build_reference_views() {
+		size_t G = annotation.genes.size(), E = annotation.exons.size();
+		gene_contig.resize(G); gene_start.resize(G); gene_end.resize(G); gene_exonic_length.resize(G); gene_bits.resize(G);
+		for (size_t g = 0; g < G; ++g) {
+			const GeneRecord& r = annotation.genes[g];
+			gene_contig[g] = r.contig; gene_start[g] = r.start; gene_end[g] = r.end; gene_exonic_length[g] = r.exonic_length;
+			gene_bits[g] = (r.strand ? AGPU_GBIT_STRAND : 0) | (r.is_dummy ? AGPU_GBIT_DUMMY : 0) | (r.is_protein_coding ? AGPU_GBIT_PROTEIN_CODING : 0);
+		}
+		exon_start.resize(E); exon_end.resize(E); exon_previous.resize(E); exon_next.resize(E); exon_cds_start.resize(E); exon_cds_end.resize(E); exon_gene.resize(E);
+		for (size_t e = 0; e < E; ++e) {
+			const ExonRecord& r = annotation.exons[e];
+			exon_start[e] = r.start; exon_end[e] = r.end; exon_previous[e] = r.previous_exon; exon_next[e] = r.next_exon;
+			exon_cds_start[e] = r.coding_region_start; exon_cds_end[e] = r.coding_region_end; exon_gene[e] = r.gene;
+		}
+		agpu_annotation_view& v = annotation_view;
+		v.n_genes = G; v.gene_contig = gene_contig.data(); v.gene_start = gene_start.data(); v.gene_end = gene_end.data(); v.gene_bits = gene_bits.data(); v.gene_exonic_length = gene_exonic_length.data();
+		v.n_exons = E; v.exon_start = exon_start.data(); v.exon_end = exon_end.data(); v.exon_gene = exon_gene.data(); v.exon_previous = exon_previous.data(); v.exon_next = exon_next.data();
+		v.exon_cds_start = exon_cds_start.data(); v.exon_cds_end = exon_cds_end.data();
+		fill_index_view(exon_index, v.exon_index);
+		fill_index_view(gene_index, v.gene_index);
+	}
+	static void fill_index_view(const FlatIndex& index, agpu_flat_index& view) {
+		view.n_contigs = index.n_contigs(); view.contig_offset = index.contig_offset.data();
+		view.n_keys = index.keys.size(); view.keys = index.keys.data();
+		view.member_offset = index.member_offset.data(); view.n_members = index.members.size(); view.members = index.members.data();
+	}
+	void build_genome_view() { // contigs may have been added by the BAM header
+		size_t C = contigs.size();
+		genome_offset.assign(C + 1, 0); contig_bits.assign(C, 0); genome_bases.clear();
+		std::vector<std::string> name_by_id(C);
+		for (std::map<std::string, contig_t>::const_iterator c = contigs.by_name.begin(); c != contigs.by_name.end(); ++c) name_by_id[c->second] = c->first;
+		for (size_t c = 0; c < C; ++c) {
+			genome_offset[c] = genome_bases.size();
+			if (assembly.has(c)) genome_bases += assembly.sequence[c];
+			contig_bits[c] = (is_interesting_contig(name_by_id[c], options.interesting_contigs) ? AGPU_CBIT_INTERESTING : 0) | (is_interesting_contig(name_by_id[c], options.viral_contigs) ? AGPU_CBIT_VIRAL : 0);
+		}
+		genome_offset[C] = genome_bases.size();
+		genome_view.n_contigs = C; genome_view.contig_offset = genome_offset.data(); genome_view.contig_bits = contig_bits.data(); genome_view.bases = genome_bases.data();
+	}
+	void build_batch_view() {
+		const Batch& b = ingest.batch;
+		agpu_batch_view& v = batch_view;
+		v.n = b.n; v.n_aln = b.n_aln.data(); v.fbits = b.fbits.data(); v.group = b.group.data();
+		for (int s = 0; s < 3; ++s) {
+			v.contig[s] = b.contig[s].data(); v.start[s] = b.start[s].data(); v.end[s] = b.end[s].data(); v.abits[s] = b.abits[s].data();
+			v.cigar_offset[s] = b.cigar_offset[s].data(); v.cigar_count[s] = b.cigar_count[s].data();
+		}
+		v.cigar_pool_size = b.cigar_pool.size(); v.cigar_pool = b.cigar_pool.data();
+		for (int s = 0; s < 2; ++s) { v.seq_offset[s] = b.seq_offset[s].data(); v.seq_length[s] = b.seq_length[s].data(); }
+		v.seq_pool_size = b.seq_pool.size(); v.seq_pool = b.seq_pool.data();
+	}
+};
+
+namespace {
+
+int ingest(ahost_session* session, ByteSource* source_raw, int external_duplicate_marking, unsigned int max_itd_length) {
+	std::unique_ptr<ByteSource> source(source_raw);
+	try {
+		session->options.external_duplicate_marking = external_duplicate_marking != 0;
+		session->options.max_itd_length = max_itd_length;
+		session->ingest = IngestResult();
+		read_chimeric_alignments(*source, session->assembly, session->contigs, session->annotation, session->gene_index, session->options, session->ingest);
+		session->build_genome_view();
+		session->build_batch_view();
+		session->have_batch = true;
+		return 0;
+	} catch (const std::exception& e) {
+		g_error = e.what();
+		return -1;
+	}
+}
+
+// reference: kmer_to_int, source/filter_mismappers.cpp:33-45
+unsigned int kmer_to_int(const std::string& sequence, size_t position, int kmer_length) {
+	unsigned int result = 0;
+	for (int base = 0; base < kmer_length; ++base) {
+		result = result << 2;
+		switch (sequence.c_str()[position + base]) {
+			case 'T': result += 0; break;
+			case 'G': result += 1; break;
+			case 'C': result += 2; break;
+			default: result += 3; break;
+		}
+	}
+	return result;
+}
+
+// reference: source/filter_top_expressed_viral_contigs.cpp:22-49
+bool related_viral_strains(const std::string& virus1, const std::string& virus2) {
+	const std::string* small_virus = &virus1;
+	const std::string* big_virus = &virus2;
+	if (small_virus->size() > big_virus->size()) std::swap(small_virus, big_virus);
+	const char kmer_length = 12;
+	std::map<unsigned int, unsigned int> small_virus_kmers;
+	for (size_t i = 0; i + kmer_length <= small_virus->size(); i++)
+		small_virus_kmers[kmer_to_int(*small_virus, i, kmer_length)] = 0;
+	unsigned int shared_kmers = 0;
+	const unsigned int min_shared_kmers = small_virus_kmers.size() / 10;
+	for (size_t i = 0; i + kmer_length <= big_virus->size(); i++) {
+		std::map<unsigned int, unsigned int>::iterator hit = small_virus_kmers.find(kmer_to_int(*big_virus, i, kmer_length));
+		if (hit != small_virus_kmers.end() && hit->second++ == 0)
+			if (++shared_kmers >= min_shared_kmers)
+				return true;
+	}
+	return false;
+}
+
+}
+
+extern "C" {
+
+const char* ahost_last_error(void) { return g_error.c_str(); }
+
+ahost_session* ahost_open(const char* fasta_path, const char* gtf_path, const char* interesting_contigs, const char* viral_contigs, const char* gtf_features) {
+	std::unique_ptr<ahost_session> session(new ahost_session());
+	try {
+		if (interesting_contigs) session->options.interesting_contigs = interesting_contigs;
+		if (viral_contigs) session->options.viral_contigs = viral_contigs;
+		load_assembly(session->assembly, fasta_path, session->contigs, session->options.interesting_contigs);
+		read_annotation_gtf(session->annotation, gtf_path, gtf_features ? gtf_features : DEFAULT_GTF_FEATURES, session->contigs, session->assembly);
+		// the reference sizes its index by the number of features (source/annotation.t.hpp:26), i.e. every contig id is in range
+		make_flat_index(session->annotation.exons, std::max(session->annotation.exons.size(), session->contigs.size()), session->exon_index);
+		make_flat_index(session->annotation.genes, std::max(session->annotation.genes.size(), session->contigs.size()), session->gene_index);
+		compute_exonic_length(session->annotation, session->exon_index);
+		session->build_reference_views();
+		session->build_genome_view();
+		return session.release();
+	} catch (const std::exception& e) {
+		g_error = e.what();
+		return NULL;
+	}
+}
+
+void ahost_close(ahost_session* session) { delete session; }
+
+int ahost_ingest_bam_file(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length) {
+	try { return ingest(session, open_bam_file(bam_path), external_duplicate_marking, max_itd_length); }
+	catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t size, int external_duplicate_marking, unsigned int max_itd_length) {
+	return ingest(session, open_memory_source(data, size), external_duplicate_marking, max_itd_length);
+}
+
+const agpu_annotation_view* ahost_annotation_view(ahost_session* session) { return &session->annotation_view; }
+const agpu_genome_view* ahost_genome_view(ahost_session* session) { return &session->genome_view; }
+const agpu_batch_view* ahost_batch_view(ahost_session* session) { return session->have_batch ? &session->batch_view : NULL; }
+uint64_t ahost_fragment_count(ahost_session* session) { return session->ingest.batch.n; }
+uint64_t ahost_mapped_reads(ahost_session* session) { return session->ingest.mapped_reads; }
+uint32_t ahost_contig_count(ahost_session* session) { return session->contigs.size(); }
+const char* ahost_contig_name(ahost_session* session, uint32_t contig) { return contig < session->contigs.original_names.size() ? session->contigs.original_names[contig].c_str() : ""; }
+const char* ahost_fragment_name(ahost_session* session, uint64_t i, uint32_t* length) {
+	const Batch& b = session->ingest.batch;
+	if (i >= b.n) { if (length) *length = 0; return ""; }
+	if (length) *length = b.name_offset[i + 1] - b.name_offset[i];
+	return b.names.data() + b.name_offset[i];
+}
+
+// reference: source/read_stats.cpp:94-143
+int ahost_detect_strandedness(ahost_session* session) {
+	const Batch& b = session->ingest.batch;
+	const unsigned int sample_size = 100;
+	const float threshold = 0.95;
+	unsigned int count = 0, matching_strand = 0;
+	std::vector<uint32_t> genes;
+	for (size_t i = 0; i < b.n; ++i) {
+		if (b.n_aln[i] != 3) continue;
+		bool split_strand = b.abits[SPLIT_READ][i] & ABIT_STRAND, supp_strand = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND;
+		if (b.contig[SPLIT_READ][i] == b.contig[SUPPLEMENTARY][i] && split_strand == supp_strand && abs(b.start[SPLIT_READ][i] - b.start[SUPPLEMENTARY][i]) < 400000) {
+			get_annotation_by_coordinate(b.contig[SPLIT_READ][i], b.start[SPLIT_READ][i], b.end[SPLIT_READ][i], genes, session->gene_index);
+			if (genes.size() == 1) {
+				bool upstream = split_strand;
+				position_t position = split_strand ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i];
+				if (is_breakpoint_spliced(genes[0], upstream, position, session->annotation, session->exon_index)) {
+					bool gene_strand = session->annotation.genes[genes[0]].strand;
+					bool mate1_strand = b.abits[MATE1][i] & ABIT_STRAND;
+					if ((b.abits[SPLIT_READ][i] & ABIT_FIRST_IN_PAIR) && split_strand == gene_strand || (b.abits[MATE1][i] & ABIT_FIRST_IN_PAIR) && mate1_strand == gene_strand)
+						matching_strand++;
+					count++;
+					if (count >= sample_size) break;
+				}
+			}
+		}
+	}
+	if (count < sample_size) return 0;
+	if (matching_strand < (1 - threshold) * count) return 2;
+	if (matching_strand > threshold * count) return 1;
+	return 0;
+}
+
+int ahost_viral_verdicts(ahost_session* session, const uint32_t* pairs, uint64_t n_pairs, const uint8_t* gene_bits, uint32_t n_genes,
+                         unsigned int top_count, float min_covered_fraction, uint8_t* top_verdict, uint8_t* low_verdict) {
+	const size_t C = session->contigs.size();
+	const std::vector<uint64_t>& mapped = session->ingest.mapped_viral_reads_by_contig;
+	const Assembly& assembly = session->assembly;
+	std::vector<bool> viral(C);
+	for (size_t c = 0; c < C; ++c) viral[c] = session->contig_bits[c] & AGPU_CBIT_VIRAL;
+
+	// ---- filter_top_expressed_viral_contigs, source/filter_top_expressed_viral_contigs.cpp:51-127
+	std::vector<float> expression;
+	expression.reserve(mapped.size());
+	for (size_t c = 0; c < mapped.size(); ++c)
+		expression.push_back(assembly.has(c) ? 1.0 * mapped[c] / assembly.sequence[c].size() : 0);
+	std::vector<contig_t> sorted;
+	for (size_t c = 0; c < expression.size(); ++c) sorted.push_back(c);
+	std::sort(sorted.begin(), sorted.end(), [&](contig_t x, contig_t y) { return (expression[x] != expression[y]) ? expression[x] > expression[y] : x > y; });
+	unsigned int corrected_top_count = 0;
+	for (unsigned int i = 1; i < sorted.size() && expression[sorted[i]] > 0 && top_count > 0; ++i) {
+		corrected_top_count++;
+		if (!assembly.has(sorted[i]) || !assembly.has(sorted[i - 1]) || !related_viral_strains(assembly.sequence[sorted[i]], assembly.sequence[sorted[i - 1]]))
+			top_count--;
+	}
+	if (corrected_top_count != 0) corrected_top_count--;
+	float min_expression_threshold = sorted.empty() ? 0 : expression[sorted[corrected_top_count]];
+	float min_fraction_intergenic = 0.33;
+	unsigned int top_intergenic = 50;
+	if (top_intergenic > mapped.size()) top_intergenic = mapped.size();
+	top_intergenic = mapped.size() - top_intergenic;
+	float min_expression_threshold_intergenic = sorted.empty() ? 0 : expression[sorted[top_intergenic]];
+	std::vector<std::set<uint32_t> > sites(C);
+	for (uint64_t p = 0; p < n_pairs; ++p)
+		if (pairs[2 * p] < C && pairs[2 * p + 1] < n_genes)
+			sites[pairs[2 * p]].insert(pairs[2 * p + 1]);
+	std::vector<float> fraction_intergenic(C);
+	for (size_t c = 0; c < C; ++c) {
+		unsigned int intergenic = 0, genic = 0;
+		for (std::set<uint32_t>::const_iterator gene = sites[c].begin(); gene != sites[c].end(); ++gene)
+			if (gene_bits[*gene] & AGPU_GBIT_DUMMY) intergenic++; else genic++;
+		if (intergenic > 0) fraction_intergenic[c] = 1.0 * intergenic / (genic + intergenic);
+	}
+	for (size_t c = 0; c < C; ++c) {
+		bool verdict = false;
+		if (viral[c] && c < expression.size())
+			if (expression[c] == 0 || expression[c] < min_expression_threshold)
+				if (fraction_intergenic[c] < min_fraction_intergenic || expression[c] == 0 || expression[c] < min_expression_threshold_intergenic)
+					verdict = true;
+		top_verdict[c] = verdict;
+	}
+
+	// ---- filter_low_coverage_viral_contigs, source/filter_low_coverage_viral_contigs.cpp:11-43
+	const Coverage& coverage = session->ingest.coverage;
+	const float min_covered_bases = 100;
+	for (size_t c = 0; c < C; ++c) {
+		bool verdict = false;
+		if (viral[c] && c < coverage.coverage.size()) {
+			const std::vector<uint16_t>& windows = coverage.coverage[c];
+			float average = 0;
+			for (size_t w = 0; w < windows.size(); ++w) average += windows[w];
+			average /= windows.size();
+			float sufficient = 0;
+			for (size_t w = 0; w < windows.size(); ++w)
+				if (windows[w] > 0.05 * average) sufficient++;
+			if (sufficient / windows.size() < min_covered_fraction || COVERAGE_RESOLUTION * sufficient <= min_covered_bases)
+				verdict = true;
+		}
+		low_verdict[c] = verdict;
+	}
+	return 0;
+}
+
+// reference: source/read_stats.cpp:11-92 and source/arriba.cpp:352-364
+int ahost_estimate_fragment_length(ahost_session* session, const int32_t* mate_gaps_in, uint32_t n_samples, uint64_t fragments_visited, unsigned int default_fragment_length,
+                                   float* mate_gap_mean_out, float* mate_gap_stddev_out, float* read_length_mean_out, int32_t* max_mate_gap_out) {
+	const Batch& b = session->ingest.batch;
+	float read_length_mean = 0;
+	unsigned int read_length_count = 0;
+	if (fragments_visited > b.n) fragments_visited = b.n;
+	for (uint64_t i = 0; i < fragments_visited; ++i) { // sequential float accumulation, hazard H4
+		read_length_mean += ((size_t) b.seq_length[MATE1][i] + (size_t) b.seq_length[MATE2][i]) / 2;
+		read_length_count++;
+	}
+	unsigned int mate_gap_count = n_samples;
+	if (mate_gap_count < 10000) {
+		std::cerr << "WARNING: not enough chimeric reads to estimate mate gap distribution, using default values" << std::endl;
+		*max_mate_gap_out = default_fragment_length;
+		*read_length_mean_out = default_fragment_length;
+		*mate_gap_mean_out = 0; *mate_gap_stddev_out = 0;
+		return 0;
+	}
+	read_length_mean = read_length_mean / read_length_count;
+	std::list<int> mate_gaps(mate_gaps_in, mate_gaps_in + n_samples);
+	float mate_gap_mean = 0, mate_gap_stddev = 0;
+	bool no_more_outliers = false;
+	while (true) {
+		mate_gap_mean = 0;
+		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); i++) mate_gap_mean += *i;
+		mate_gap_mean /= mate_gap_count;
+		mate_gap_stddev = 0;
+		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); i++) mate_gap_stddev += (*i - mate_gap_mean) * (*i - mate_gap_mean);
+		mate_gap_stddev = sqrt(1.0 / (mate_gap_count - 1) * mate_gap_stddev);
+		unsigned int within_range = 0;
+		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); ++i)
+			if (*i > mate_gap_mean - mate_gap_stddev || *i < mate_gap_mean + mate_gap_stddev) // sic (hazard H6)
+				within_range++;
+		if (1.0 * within_range / mate_gap_count < 0.683 || no_more_outliers)
+			break;
+		no_more_outliers = true;
+		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end();) {
+			if (*i < mate_gap_mean - 3 * mate_gap_stddev || *i > mate_gap_mean + 3 * mate_gap_stddev) {
+				i = mate_gaps.erase(i);
+				mate_gap_count--;
+				no_more_outliers = false;
+			} else {
+				++i;
+			}
+		}
+	}
+	*mate_gap_mean_out = mate_gap_mean; *mate_gap_stddev_out = mate_gap_stddev; *read_length_mean_out = read_length_mean;
+	*max_mate_gap_out = std::max(0, (int) (mate_gap_mean + 3 * mate_gap_stddev));
+	return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's stage order for the hot path (reference: source/arriba.cpp:119-413).
+
+``HostSession`` reads FASTA/GTF/BAM through libarriba_host.so and owns the structure-of-arrays views.
+``DevicePipeline`` pushes them through the C ABI of libarriba_gpu.so (include/arriba_gpu.h) and calls the
+device stages where the reference calls the corresponding stage function.  Method names follow the reference.
+"""
+import ctypes
+from ctypes import byref, c_float, c_int32, c_uint32, c_uint64
+
+import numpy as np
+
+from . import _capi
+
+
+class ArribaError(RuntimeError):
+    pass
+
+
+class HostSession(object):
+    """load_assembly + read_annotation_gtf + read_chimeric_alignments (reference: source/arriba.cpp:91-130)."""
+
+    def __init__(self, fasta, gtf, interesting_contigs=None, viral_contigs=None, gtf_features=None):
+        self._lib = _capi.host_library()
+        enc = lambda s: None if s is None else s.encode()
+        self._session = self._lib.ahost_open(enc(fasta), enc(gtf), enc(interesting_contigs), enc(viral_contigs), enc(gtf_features))
+        if not self._session:
+            raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
+        self._keepalive = None
+
+    def close(self):
+        if self._session:
+            self._lib.ahost_close(self._session)
+            self._session = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def read_chimeric_alignments(self, bam, external_duplicate_marking=False, max_itd_length=100):
+        """bam: path to a BAM file, or a bytes-like object / numpy uint8 array holding the raw (inflated) BAM stream."""
+        if isinstance(bam, str):
+            status = self._lib.ahost_ingest_bam_file(self._session, bam.encode(), int(external_duplicate_marking), max_itd_length)
+        else:
+            array = np.frombuffer(bam, dtype=np.uint8) if not isinstance(bam, np.ndarray) else bam
+            self._keepalive = array
+            status = self._lib.ahost_ingest_bam_memory(self._session, array.ctypes.data, array.size, int(external_duplicate_marking), max_itd_length)
+        if status != 0:
+            raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
+        return self.fragment_count
+
+    @property
+    def fragment_count(self):
+        return int(self._lib.ahost_fragment_count(self._session))
+
+    @property
+    def mapped_reads(self):
+        return int(self._lib.ahost_mapped_reads(self._session))
+
+    @property
+    def annotation_view(self):
+        return self._lib.ahost_annotation_view(self._session)
+
+    @property
+    def genome_view(self):
+        return self._lib.ahost_genome_view(self._session)
+
+    @property
+    def batch_view(self):
+        view = self._lib.ahost_batch_view(self._session)
+        if not view:
+            raise ArribaError("no BAM ingested yet")
+        return view
+
+    def contig_names(self):
+        return [self._lib.ahost_contig_name(self._session, c).decode() for c in range(self._lib.ahost_contig_count(self._session))]
+
+    def fragment_names(self):
+        names = []
+        length = c_uint32()
+        for i in range(self.fragment_count):
+            pointer = self._lib.ahost_fragment_name(self._session, i, byref(length))
+            names.append(ctypes.string_at(pointer, length.value).decode())
+        return names
+
+    def detect_strandedness(self):
+        return int(self._lib.ahost_detect_strandedness(self._session))
+
+    def viral_verdicts(self, pairs, gene_bits, top_count=5, min_covered_fraction=0.05):
+        n_contigs = self._lib.ahost_contig_count(self._session)
+        top = np.zeros(n_contigs, dtype=np.uint8)
+        low = np.zeros(n_contigs, dtype=np.uint8)
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+        gene_bits = np.ascontiguousarray(gene_bits, dtype=np.uint8)
+        self._lib.ahost_viral_verdicts(self._session, pairs.ctypes.data, pairs.size // 2, gene_bits.ctypes.data, gene_bits.size, top_count, min_covered_fraction, top.ctypes.data, low.ctypes.data)
+        return top, low
+
+    def estimate_fragment_length(self, mate_gaps, fragments_visited, default_fragment_length=200):
+        mate_gaps = np.ascontiguousarray(mate_gaps, dtype=np.int32)
+        mean, stddev, read_length = c_float(), c_float(), c_float()
+        max_mate_gap = c_int32()
+        estimated = self._lib.ahost_estimate_fragment_length(self._session, mate_gaps.ctypes.data, mate_gaps.size, fragments_visited, default_fragment_length,
+                                                             byref(mean), byref(stddev), byref(read_length), byref(max_mate_gap))
+        return {"estimated": bool(estimated), "mate_gap_mean": mean.value, "mate_gap_stddev": stddev.value, "read_length_mean": read_length.value, "max_mate_gap": max_mate_gap.value}
+
+
+class DevicePipeline(object):
+    """The device stages of the hot path in the reference's order.
+
+    `api` defaults to the product library (libarriba_gpu.so, prefix agpu_); the CPU-only tests pass the host
+    stepping harness of tests/emu instead.
+    """
+
+    def __init__(self, session, params=None, api=None, device=0):
+        self.session = session
+        self.api = api if api is not None else _capi.bind_device_api(_capi.device_library(), "agpu_")
+        self.params = _capi.Params()
+        self.api.default_params(byref(self.params))
+        if params:
+            for key, value in params.items():
+                if key == "disable_filters":
+                    for name in value:
+                        self.params.filter_enabled[_capi.FILTER_NAMES.index(name)] = 0
+                else:
+                    setattr(self.params, key, value)
+        self.ctx = self.api.create(device, byref(self.params))
+        if not self.ctx:
+            raise ArribaError("ERROR: " + self.api.last_error().decode())
+        self.timings = {}
+        self._check(self.api.upload_annotation(self.ctx, session.annotation_view))
+        self._check(self.api.upload_genome(self.ctx, session.genome_view))
+        self._check(self.api.upload_batch(self.ctx, session.batch_view))
+        self.n = session.fragment_count
+        self.n_real_genes = session.annotation_view.contents.n_genes
+        self.n_dummy_genes = 0
+        self.scalars = {}
+
+    def close(self):
+        if self.ctx:
+            self.api.destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status):
+        if status != 0:
+            raise ArribaError("ERROR: " + self.api.last_error().decode() + " (status %d)" % status)
+
+    def _record(self, stage):
+        ms, size = c_float(), c_uint64()
+        self.api.last_kernel_ms(self.ctx, byref(ms))
+        self.api.last_kernel_bytes(self.ctx, byref(size))
+        self.timings[stage] = {"ms": ms.value, "bytes": size.value}
+
+    # ---- stages, named after the reference functions they replace ---------------------------------
+
+    def mark_multimappers(self):
+        marked = c_uint64()
+        self._check(self.api.mark_multimappers(self.ctx, byref(marked)))
+        self._record("mark_multimappers")
+        return marked.value
+
+    def annotate_alignments(self, strandedness=None):
+        if strandedness is None:
+            strandedness = self.session.detect_strandedness()
+        self.scalars["strandedness"] = strandedness
+        self.params.strandedness = strandedness
+        self._check(self.api.set_params(self.ctx, byref(self.params)))
+        n_dummy = c_uint32()
+        self._check(self.api.annotate(self.ctx, byref(n_dummy)))
+        self._record("annotate")
+        self.n_dummy_genes = n_dummy.value
+        return self.n_dummy_genes
+
+    def filter_duplicates_and_contigs(self, top_viral_contigs=5, viral_contig_min_covered_fraction=0.05):
+        count = c_uint64()
+        self._check(self.api.get_viral_integration_sites(self.ctx, None, 0, byref(count)))
+        pairs = np.zeros(2 * max(count.value, 1), dtype=np.uint32)
+        self._check(self.api.get_viral_integration_sites(self.ctx, pairs.ctypes.data, count.value, byref(count)))
+        gene_bits = self.gene_table()["bits"]
+        top, low = self.session.viral_verdicts(pairs[:2 * count.value], gene_bits, top_viral_contigs, viral_contig_min_covered_fraction)
+        self._check(self.api.read_filters_stage1(self.ctx, top.ctypes.data, low.ctypes.data))
+        self._record("read_filters_stage1")
+
+    def estimate_fragment_length(self):
+        gaps = np.zeros(100001, dtype=np.int32)
+        n_samples, visited = c_uint32(), c_uint64()
+        self._check(self.api.fragment_length_samples(self.ctx, gaps.ctypes.data, byref(n_samples), byref(visited)))
+        self._record("fragment_length_samples")
+        estimate = self.session.estimate_fragment_length(gaps[:n_samples.value], visited.value, self.params.fragment_length)
+        self.scalars.update(estimate)
+        self.scalars["mate_gap_samples"] = n_samples.value
+        return estimate
+
+    def filter_reads(self):
+        remaining = np.zeros(_capi.FILTER_COUNT, dtype=np.uint64)
+        self._check(self.api.read_filters_stage2(self.ctx, remaining.ctypes.data))
+        self._record("read_filters_stage2")
+        self.remaining = {_capi.FILTER_NAMES[f]: int(remaining[f]) for f in (1, 30, 31, 32, 33, 4, 2, 3, 6, 7, 5, 8, 10, 36)}
+        return self.remaining
+
+    def run_read_level(self, strandedness=None):
+        """mark_multimappers ... filter_low_entropy (reference: source/arriba.cpp:141-409)."""
+        self.scalars["marked_multimappers"] = self.mark_multimappers()
+        self.annotate_alignments(strandedness)
+        self.filter_duplicates_and_contigs()
+        self.estimate_fragment_length()
+        return self.filter_reads()
+
+    # ---- result access -------------------------------------------------------------------------------
+
+    def filters(self):
+        out = np.zeros(self.n, dtype=np.uint8)
+        self._check(self.api.get_filters(self.ctx, out.ctypes.data))
+        return out
+
+    def alignment_bits(self, slot):
+        out = np.zeros(self.n, dtype=np.uint8)
+        self._check(self.api.get_alignment_bits(self.ctx, slot, out.ctypes.data))
+        return out
+
+    def fragment_bits(self):
+        out = np.zeros(self.n, dtype=np.uint8)
+        self._check(self.api.get_fragment_bits(self.ctx, out.ctypes.data))
+        return out
+
+    def gene_sets(self, slot):
+        """Returns (count[n], genes[total]) -- CSR of the gene ids annotated to alignment `slot` of every fragment."""
+        total = c_uint64()
+        count = np.zeros(self.n, dtype=np.uint8)
+        self._check(self.api.get_gene_sets(self.ctx, slot, count.ctypes.data, None, 0, byref(total)))
+        genes = np.zeros(max(total.value, 1), dtype=np.uint32)
+        self._check(self.api.get_gene_sets(self.ctx, slot, count.ctypes.data, genes.ctypes.data, total.value, byref(total)))
+        return count, genes[:total.value]
+
+    def gene_table(self):
+        total = self.n_real_genes + self.n_dummy_genes
+        table = {"contig": np.zeros(total, dtype=np.uint16), "start": np.zeros(total, dtype=np.int32), "end": np.zeros(total, dtype=np.int32),
+                 "bits": np.zeros(total, dtype=np.uint8), "exonic_length": np.zeros(total, dtype=np.int32)}
+        self._check(self.api.get_gene_table(self.ctx, 0, total, table["contig"].ctypes.data, table["start"].ctypes.data, table["end"].ctypes.data,
+                                            table["bits"].ctypes.data, table["exonic_length"].ctypes.data))
+        return table

@@ -1,0 +1,204 @@
+/*
+ * include/arriba_gpu.h -- C ABI of the MI355X-native hot path of the fusion caller.
+ *
+ * The reference (suhrig/arriba v2.5.1) has no plugin/FFI interface; its de-facto operator API is the
+ * set of free stage functions that main() calls in a fixed order, each mutating a container in place
+ * and returning the number of still-unfiltered entries (source/arriba.cpp:119-565).  This header is
+ * the boundary a maintainer would bind instead of those calls: plain pointers and sizes, no C++ or
+ * torch types, int status codes (0 = ok, negative = error, text via agpu_last_error()).
+ *
+ * Data handed over is structure-of-arrays, produced once by the host driver
+ * (arriba_amd/csrc/host/): the flattened gene/exon interval index, the genome, and the packed
+ * table of chimeric fragments in read-name order (index == name rank).  All results stay resident
+ * in HBM between calls and are fetched with the agpu_get_* functions.
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef ARRIBA_GPU_H
+#define ARRIBA_GPU_H 1
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGPU_API_VERSION 1
+
+/* status codes */
+#define AGPU_OK 0
+#define AGPU_ERR_INVALID (-1)       /* bad argument / call order */
+#define AGPU_ERR_DEVICE (-2)        /* HIP runtime error */
+#define AGPU_ERR_CAPACITY (-3)      /* an internal device pool overflowed (retry after agpu_set_capacity) */
+#define AGPU_ERR_NO_DEVICE (-4)     /* no gfx950 device visible */
+
+/* filter ids == position in the reference's registry (source/common.hpp:29-67) */
+#define AGPU_FILTER_COUNT 38
+
+/* bits of agpu_batch_view.abits / alignment bits returned by agpu_get_alignment_bits (source/common.hpp:191-204) */
+#define AGPU_ABIT_STRAND 1u                        /* 1 = forward */
+#define AGPU_ABIT_FIRST_IN_PAIR 2u
+#define AGPU_ABIT_SUPPLEMENTARY 4u
+#define AGPU_ABIT_EXONIC 8u
+#define AGPU_ABIT_PREDICTED_STRAND 16u             /* 1 = forward; meaningless while AMBIGUOUS is set */
+#define AGPU_ABIT_PREDICTED_STRAND_AMBIGUOUS 32u
+/* bits of agpu_batch_view.fbits (source/common.hpp:212-219) */
+#define AGPU_FBIT_SINGLE_END 1u
+#define AGPU_FBIT_MULTIMAPPER 2u
+#define AGPU_FBIT_DUPLICATE 4u
+/* bits of agpu_annotation_view.gene_bits */
+#define AGPU_GBIT_STRAND 1u
+#define AGPU_GBIT_DUMMY 2u
+#define AGPU_GBIT_PROTEIN_CODING 4u
+/* bits of agpu_genome_view.contig_bits */
+#define AGPU_CBIT_INTERESTING 1u
+#define AGPU_CBIT_VIRAL 2u
+
+typedef struct agpu_ctx agpu_ctx;
+
+/* Flattened interval index (source/annotation.t.hpp:25-45): per contig a sorted array of boundary keys;
+ * bucket k lists the ids of the features containing position keys[k], ascending. */
+typedef struct {
+	uint32_t n_contigs;
+	const uint32_t* contig_offset;   /* [n_contigs+1] into keys */
+	uint32_t n_keys;
+	const int32_t* keys;
+	const uint32_t* member_offset;   /* [n_keys+1] into members */
+	uint32_t n_members;
+	const uint32_t* members;
+} agpu_flat_index;
+
+/* Gene and exon tables (source/common.hpp:148-183); ids are the reference's gene->id and the exon's
+ * rank in allocation order (the canonical order inside exon sets). */
+typedef struct {
+	uint32_t n_genes;
+	const uint16_t* gene_contig;
+	const int32_t* gene_start;
+	const int32_t* gene_end;
+	const uint8_t* gene_bits;
+	const int32_t* gene_exonic_length;
+	uint32_t n_exons;
+	const int32_t* exon_start;
+	const int32_t* exon_end;
+	const uint32_t* exon_gene;
+	const int32_t* exon_previous;    /* exon id or -1 */
+	const int32_t* exon_next;
+	const int32_t* exon_cds_start;   /* -1 = non-coding */
+	const int32_t* exon_cds_end;
+	agpu_flat_index exon_index;
+	agpu_flat_index gene_index;      /* GTF genes only; dummy genes are created on the device */
+} agpu_annotation_view;
+
+/* Genome as upper-case ASCII, contigs concatenated (source/assembly.cpp:28-58). */
+typedef struct {
+	uint32_t n_contigs;
+	const uint64_t* contig_offset;   /* [n_contigs+1] into bases; empty range = sequence not loaded */
+	const uint8_t* contig_bits;      /* [n_contigs] AGPU_CBIT_* */
+	const char* bases;
+} agpu_genome_view;
+
+/* Packed chimeric fragments in name order (source/common.hpp:191-220).  Slot-major columns: slot 0 =
+ * MATE1, slot 1 = MATE2 / SPLIT_READ, slot 2 = SUPPLEMENTARY.  Sequences are BAM 4-bit codes (two
+ * bases per byte, high nibble first), each starting on a 4-byte boundary; slots 0 and 1 only. */
+typedef struct {
+	uint64_t n;
+	const uint8_t* n_aln;            /* 2 or 3 */
+	const uint8_t* fbits;
+	const uint32_t* group;           /* fragments of one read name (all HI values) share a group id; ascending */
+	const uint16_t* contig[3];
+	const int32_t* start[3];
+	const int32_t* end[3];
+	const uint8_t* abits[3];
+	const uint32_t* cigar_offset[3];
+	const uint16_t* cigar_count[3];
+	uint64_t cigar_pool_size;
+	const uint32_t* cigar_pool;
+	const uint32_t* seq_offset[2];   /* in units of 4 bytes */
+	const uint32_t* seq_length[2];   /* in bases */
+	uint64_t seq_pool_size;          /* bytes */
+	const uint8_t* seq_pool;
+} agpu_batch_view;
+
+/* Parameters (defaults of source/options.cpp:71-107) */
+typedef struct {
+	uint32_t homopolymer_length;         /* -H 6 */
+	uint32_t min_read_through_distance;  /* -R 10000 */
+	uint32_t max_itd_length;             /* -l 100 */
+	uint32_t subsampling_threshold;      /* -U 300 */
+	float mismatch_pvalue_cutoff;        /* -V 0.01 */
+	float max_kmer_content;              /* -K 0.6 */
+	float evalue_cutoff;                 /* -E 0.3 */
+	float max_mismapper_fraction;        /* -m 0.8 */
+	uint32_t fragment_length;            /* -F 200 */
+	uint8_t external_duplicate_marking;  /* -u */
+	uint8_t strandedness;                /* 0 no, 1 yes, 2 reverse (already resolved; 3 = auto is a host decision) */
+	uint8_t filter_enabled[AGPU_FILTER_COUNT]; /* -f */
+} agpu_params;
+
+void agpu_default_params(agpu_params* params);
+
+const char* agpu_last_error(void);
+int agpu_api_version(void);
+int agpu_device_count(void);
+
+agpu_ctx* agpu_create(int device, const agpu_params* params);
+void agpu_destroy(agpu_ctx* ctx);
+int agpu_set_params(agpu_ctx* ctx, const agpu_params* params);
+
+/* uploads (host pointers; copied to HBM) -- replace the in-memory containers every reference stage receives */
+int agpu_upload_annotation(agpu_ctx* ctx, const agpu_annotation_view* annotation); /* gene/exon annotation + index: source/arriba.cpp:100-113 */
+int agpu_upload_genome(agpu_ctx* ctx, const agpu_genome_view* genome);               /* assembly_t: source/arriba.cpp:97-98 */
+int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* batch);                  /* chimeric_alignments_t: source/arriba.cpp:119-130 */
+
+/* mark_multimappers (source/read_chimeric_alignments.cpp:792-802); returns the reference's "marked" count in *marked */
+int agpu_mark_multimappers(agpu_ctx* ctx, uint64_t* marked);
+
+/* assign_strands_from_strandedness + annotate_alignments + gene fallback + dummy genes + gene ids
+ * (source/arriba.cpp:160-325, source/annotation.cpp:431-555).  n_dummy_genes receives the number of
+ * synthesized intergenic genes (ids n_genes .. n_genes+n_dummy-1). */
+int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes);
+
+/* Read-level filter cascade, stage group 1 (source/arriba.cpp:327-350): duplicates, uninteresting_contigs,
+ * viral_contigs, top_expressed_viral_contigs, low_coverage_viral_contigs.  The two viral filters take
+ * per-contig verdict tables that the host derives from coverage / expression scalars
+ * (source/filter_top_expressed_viral_contigs.cpp:51-127, source/filter_low_coverage_viral_contigs.cpp:11-27);
+ * pass NULL to treat no contig as filtered. */
+int agpu_read_filters_stage1(agpu_ctx* ctx, const uint8_t* top_expressed_viral_verdict, const uint8_t* low_coverage_viral_verdict);
+
+/* Host genes hit by virus-host chimeric fragments (input of filter_top_expressed_viral_contigs,
+ * source/filter_top_expressed_viral_contigs.cpp:95-112): pairs (viral contig, gene id). */
+int agpu_get_viral_integration_sites(agpu_ctx* ctx, uint32_t* pairs /* [2*capacity] */, uint64_t capacity, uint64_t* count);
+
+/* Mate-gap samples for estimate_fragment_length (source/read_stats.cpp:11-44): the spliced distances of
+ * the first <=100001 unfiltered paired split reads in name order, and the number of fragments the
+ * reference's loop visits before it stops (for its sequential float read-length mean). */
+int agpu_fragment_length_samples(agpu_ctx* ctx, int32_t* mate_gaps /* [100001] */, uint32_t* n_samples, uint64_t* fragments_visited);
+
+/* Read-level filter cascade, stage group 2 (source/arriba.cpp:366-409): read_through, inconsistently_clipped,
+ * homopolymer, small_insert_size, long_gap, same_gene, hairpin, mismatches, low_entropy.
+ * remaining[AGPU_FILTER_COUNT] receives, for each read-level filter id, the reference's "(remaining=N)" count. */
+int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining);
+
+/* find_fusions (source/fusions.cpp:203-473).  Returns the number of candidates in *n_candidates. */
+int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidates);
+
+/* result access (device -> host copies) */
+int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);
+int agpu_get_alignment_bits(agpu_ctx* ctx, int slot, uint8_t* abits /* [n] */);
+int agpu_get_fragment_bits(agpu_ctx* ctx, uint8_t* fbits /* [n] */);
+/* gene sets as CSR: count[n] then the concatenated ids; call with genes == NULL to get the total in *total */
+int agpu_get_gene_sets(agpu_ctx* ctx, int slot, uint8_t* count /* [n] */, uint32_t* genes, uint64_t capacity, uint64_t* total);
+/* gene table including dummy genes */
+int agpu_get_gene_table(agpu_ctx* ctx, uint32_t first, uint32_t count, uint16_t* contig, int32_t* start, int32_t* end, uint8_t* bits, int32_t* exonic_length);
+
+/* timing of the kernels launched by the last call, measured with HIP events on the launch stream (ms) */
+int agpu_last_kernel_ms(agpu_ctx* ctx, float* ms);
+/* algorithmic bytes (inputs read + outputs written once) of the kernels launched by the last call */
+int agpu_last_kernel_bytes(agpu_ctx* ctx, uint64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ARRIBA_GPU_H */

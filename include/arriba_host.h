@@ -1,0 +1,61 @@
+/*
+ * include/arriba_host.h -- C ABI of the host driver library (libarriba_host.so).
+ *
+ * The host side reads the reference data and the BAM once and produces the structure-of-arrays views
+ * of include/arriba_gpu.h; it also holds the few inherently sequential scalar stages of the path
+ * (strandedness vote, fragment-length estimate, per-contig viral verdicts) that the reference
+ * computes between its per-read stages.  No per-read filtering or clustering happens here.
+ * Each entry point cites the reference code it restates.
+ */
+#ifndef ARRIBA_HOST_C_H
+#define ARRIBA_HOST_C_H 1
+
+#include "arriba_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ahost_session ahost_session;
+
+const char* ahost_last_error(void);
+
+/* load_assembly + read_annotation_gtf + make_annotation_index (source/arriba.cpp:91-113).
+ * NULL strings select the reference defaults (source/options.cpp:74-75, source/annotation.hpp:23). */
+ahost_session* ahost_open(const char* fasta_path, const char* gtf_path, const char* interesting_contigs, const char* viral_contigs, const char* gtf_features);
+void ahost_close(ahost_session* session);
+
+/* read_chimeric_alignments for -x (source/read_chimeric_alignments.cpp:560-773); data = raw (inflated) BAM stream */
+int ahost_ingest_bam_file(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length);
+int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t size, int external_duplicate_marking, unsigned int max_itd_length);
+
+const agpu_annotation_view* ahost_annotation_view(ahost_session* session);
+const agpu_genome_view* ahost_genome_view(ahost_session* session);
+const agpu_batch_view* ahost_batch_view(ahost_session* session);
+
+uint64_t ahost_fragment_count(ahost_session* session);
+uint64_t ahost_mapped_reads(ahost_session* session);
+uint32_t ahost_contig_count(ahost_session* session);
+const char* ahost_contig_name(ahost_session* session, uint32_t contig);
+/* "QNAME,HI" of fragment i (the reference's map key); valid until the session is closed */
+const char* ahost_fragment_name(ahost_session* session, uint64_t i, uint32_t* length);
+
+/* detect_strandedness (source/read_stats.cpp:94-143): 0 no, 1 yes, 2 reverse */
+int ahost_detect_strandedness(ahost_session* session);
+
+/* per-contig verdicts of filter_top_expressed_viral_contigs (source/filter_top_expressed_viral_contigs.cpp:51-127) and
+ * filter_low_coverage_viral_contigs (source/filter_low_coverage_viral_contigs.cpp:11-27); pairs = (viral contig, gene id)
+ * from agpu_get_viral_integration_sites, gene_bits = AGPU_GBIT_* for every gene id incl. dummy genes */
+int ahost_viral_verdicts(ahost_session* session, const uint32_t* pairs, uint64_t n_pairs, const uint8_t* gene_bits, uint32_t n_genes,
+                         unsigned int top_count, float min_covered_fraction, uint8_t* top_expressed_verdict, uint8_t* low_coverage_verdict);
+
+/* estimate_fragment_length (source/read_stats.cpp:11-92) + source/arriba.cpp:352-364.  mate_gaps / fragments_visited come from
+ * agpu_fragment_length_samples.  Returns 1 if estimated, 0 if the defaults were used. */
+int ahost_estimate_fragment_length(ahost_session* session, const int32_t* mate_gaps, uint32_t n_samples, uint64_t fragments_visited, unsigned int default_fragment_length,
+                                   float* mate_gap_mean, float* mate_gap_stddev, float* read_length_mean, int32_t* max_mate_gap);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif
