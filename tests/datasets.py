@@ -1,0 +1,67 @@
+"""Synthetic datasets shared by the tests, tools/make_golden.py and bench.py (test tooling).
+
+A dataset is a parameter set of the deterministic generator (tools/gen_synth.cpp).  The golden fixtures in
+tests/golden/<name>/ hold what the oracle build of the reference (oracle/_ref/arriba_ref_dump) produced for
+exactly these inputs; `bam_sha256` in meta.json pins the generator.
+"""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN_SYNTH = os.path.join(ROOT, "arriba_amd", "lib", "gen_synth")
+ARRIBA_REF = os.path.join(ROOT, "oracle", "_ref", "arriba_ref")
+ARRIBA_REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "arriba_ref_dump")
+
+DEFAULT_GOLDEN_FILES = ["reads.*_annotated.tsv", "filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv", "fusions.*_find_fusions.tsv",
+                        "fusions.*_estimate_expected_fusions.tsv", "fusions.*_filter_relative_support.tsv", "fusions.*_before_filter_mismappers.tsv",
+                        "fusions.*_filter_mismappers.tsv", "filters.*_before_filter_mismappers.tsv", "filters.*_filter_mismappers.tsv",
+                        "reads.*_after_find_fusions.tsv"]
+
+DATASETS = {
+    # small, every record kind, sorted names, default (too few samples) fragment-length path
+    "toy3k": {"args": ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"]},
+    # shuffled names + separated mates: exercises collation and the name sort (ingest), stranded library
+    "shuffled2k": {"args": ["--seed", "5", "--fragments", "2000", "--contigs", "3", "--contig-len", "250000", "--junctions", "40", "--shuffle", "--separate-mates", "--stranded"],
+                   "golden_files": ["reads.*_annotated.tsv", "filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},
+    # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
+    "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
+               "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},
+}
+
+
+def generate(spec, directory, name="data"):
+    prefix = os.path.join(directory, name)
+    subprocess.run([GEN_SYNTH, "--out", prefix] + spec["args"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return prefix
+
+
+def reference_available():
+    return os.path.exists(ARRIBA_REF_DUMP)
+
+
+def run_reference(prefix, dump_directory, spec=None, extra_args=()):
+    """Runs the oracle build of the reference; returns its stdout+stderr."""
+    env = dict(os.environ)
+    env["ARRIBA_ORACLE_DUMP"] = dump_directory
+    command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv", "-f", "blacklist"] + list(extra_args)
+    result = subprocess.run(command, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if result.returncode != 0:
+        raise RuntimeError("reference failed:\n" + result.stdout)
+    return re.sub(r"\[\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\] ", "", result.stdout)
+
+
+def parse_remaining(log):
+    """(remaining=N) counts of the read-level filters from the reference's log, keyed by filter name."""
+    patterns = [("duplicates", "Filtering duplicates"), ("uninteresting_contigs", "do not map to interesting contigs"), ("viral_contigs", "only map to viral contigs"),
+                ("top_expressed_viral_contigs", "expression lower than the top"), ("low_coverage_viral_contigs", "% coverage"), ("read_through", "Filtering read-through fragments"),
+                ("inconsistently_clipped", "inconsistently clipped"), ("homopolymer", "adjacent to homopolymers"), ("small_insert_size", "small insert size"),
+                ("long_gap", "long gaps"), ("same_gene", "both mates in the same gene"), ("hairpin", "hairpin structures"), ("mismatches", "mismatch p-value"), ("low_entropy", "low entropy")]
+    remaining = {}
+    for line in log.splitlines():
+        for name, pattern in patterns:
+            if pattern in line:
+                match = re.search(r"\(remaining=(\d+)\)", line)
+                if match:
+                    remaining[name] = int(match.group(1))
+    return remaining

@@ -1,0 +1,106 @@
+"""Comparison helpers shared by the CPU-tier (host stepping harness) and GPU-tier (HIP kernels) parity tests."""
+import os
+
+import numpy as np
+
+import datasets
+import golden_io
+
+
+def run_read_level(session_factory, prefix, api=None):
+    from arriba_amd.pipeline import DevicePipeline
+    session = session_factory(prefix)
+    pipeline = DevicePipeline(session, api=api)
+    pipeline.run_read_level()
+    return session, pipeline
+
+
+def open_session(prefix):
+    from arriba_amd.pipeline import HostSession
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    session.read_chimeric_alignments(prefix + ".bam")
+    return session
+
+
+def check_ingest(session, golden):
+    """packed batch vs the reference's read table after annotation (ingest-time fields only)"""
+    reads = golden_io.read_reads(golden_io.find_dump(golden, "reads", "annotated"))
+    names = session.fragment_names()
+    assert names == [r["name"] for r in reads]
+    view = session.batch_view.contents
+    ops = "MIDNSHP=XB"
+    codes = "=ACMGRSVTWYHKDBN"
+    pool = np.ctypeslib.as_array(view.seq_pool, shape=(max(int(view.seq_pool_size), 1),))
+    cigar_pool = np.ctypeslib.as_array(view.cigar_pool, shape=(max(int(view.cigar_pool_size), 1),))
+    for i, read in enumerate(reads):
+        assert view.n_aln[i] == len(read["alignments"]), read["name"]
+        assert (view.fbits[i] & 1) == read["single_end"] and ((view.fbits[i] >> 2) & 1) == read["duplicate"]
+        for slot, alignment in enumerate(read["alignments"]):
+            bits = view.abits[slot][i]
+            assert (bits & 1, (bits >> 1) & 1, (bits >> 2) & 1) == (alignment["strand"], alignment["first_in_pair"], alignment["supplementary"]), read["name"]
+            assert (view.contig[slot][i], view.start[slot][i], view.end[slot][i]) == (alignment["contig"], alignment["start"], alignment["end"]), read["name"]
+            offset, count = view.cigar_offset[slot][i], view.cigar_count[slot][i]
+            cigar = "".join("%d%s" % (c >> 4, ops[c & 15]) for c in cigar_pool[offset:offset + count])
+            assert cigar == alignment["cigar"], read["name"]
+            if slot < 2:
+                length = view.seq_length[slot][i]
+                packed = pool[view.seq_offset[slot][i] * 4: view.seq_offset[slot][i] * 4 + (length + 1) // 2]
+                sequence = "".join(codes[(packed[b >> 1] >> ((~b & 1) << 2)) & 15] for b in range(length))
+                assert sequence == alignment["sequence"], read["name"]
+    return len(reads)
+
+
+def check_annotation(session, pipeline, golden):
+    reads = golden_io.read_reads(golden_io.find_dump(golden, "reads", "annotated"))
+    names = session.fragment_names()
+    assert names == [r["name"] for r in reads]
+    mismatches = []
+    for slot in range(3):
+        count, genes = pipeline.gene_sets(slot)
+        bits = pipeline.alignment_bits(slot)
+        offsets = np.concatenate([[0], np.cumsum(count.astype(np.int64))]).astype(np.int64)
+        for i, read in enumerate(reads):
+            if slot >= len(read["alignments"]):
+                continue
+            alignment = read["alignments"][slot]
+            mine = [int(g) for g in genes[offsets[i]:offsets[i + 1]]]
+            exonic, ambiguous = (bits[i] >> 3) & 1, (bits[i] >> 5) & 1
+            predicted = 0 if ambiguous else (bits[i] >> 4) & 1
+            if mine != alignment["genes"] or (exonic, ambiguous, predicted) != (alignment["exonic"], alignment["ambiguous"], alignment["predicted_strand"]):
+                mismatches.append((read["name"], slot, mine, alignment["genes"]))
+    assert not mismatches, mismatches[:10]
+    fragment_bits = pipeline.fragment_bits()
+    assert [int((b >> 1) & 1) for b in fragment_bits] == [r["multimapper"] for r in reads]
+
+
+def check_gene_table(pipeline, golden):
+    table = pipeline.gene_table()
+    genes = golden_io.read_genes(os.path.join(golden, "genes.tsv"))
+    assert len(genes) == len(table["start"])
+    for g in genes:
+        i = g["id"]
+        assert (table["contig"][i], table["start"][i], table["end"][i], table["bits"][i] & 1, (table["bits"][i] >> 1) & 1, (table["bits"][i] >> 2) & 1, table["exonic_length"][i]) == \
+               (g["contig"], g["start"], g["end"], g["strand"], g["is_dummy"], g["is_protein_coding"], g["exonic_length"]), g
+
+
+def check_read_filters(session, pipeline, golden):
+    names, filters = golden_io.read_filters(golden_io.find_dump(golden, "filters", "read_filters_final"))
+    assert session.fragment_names() == names
+    mine = pipeline.filters()
+    different = [(names[i], int(mine[i]), filters[i]) for i in range(len(names)) if mine[i] != filters[i]]
+    assert not different, different[:10]
+
+
+def check_scalars(pipeline, golden):
+    scalars = golden_io.read_scalars(os.path.join(golden, "scalars.tsv"))
+    assert pipeline.scalars["marked_multimappers"] == int(scalars["marked_multimappers"])
+    assert pipeline.scalars["strandedness"] == int(scalars["strandedness"])
+    assert pipeline.scalars["max_mate_gap"] == int(scalars["max_mate_gap"])
+    assert int(pipeline.scalars["estimated"]) == int(scalars["fragment_length_estimated"])
+    if pipeline.scalars["estimated"]:
+        bits = lambda value: int(np.float32(value).view(np.uint32))
+        assert bits(pipeline.scalars["mate_gap_mean"]) == int(scalars["mate_gap_mean_bits"], 16)
+        assert bits(pipeline.scalars["mate_gap_stddev"]) == int(scalars["mate_gap_stddev_bits"], 16)
+        assert bits(pipeline.scalars["read_length_mean"]) == int(scalars["read_length_mean_bits"], 16)
+    log = open(os.path.join(golden, "reference.log")).read()
+    assert pipeline.remaining == datasets.parse_remaining(log)

@@ -1,0 +1,71 @@
+"""GPU tier: the HIP kernels, called through the C ABI of libarriba_gpu.so, against the golden dumps of the reference
+and (when the prebuilt oracle binary travelled with the repo) against the reference run live on a fresh dataset."""
+import os
+
+import numpy as np
+import pytest
+
+import conftest
+import datasets
+import golden_io
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k"])
+def test_read_level_cascade_matches_reference(name, dataset_files):
+    golden = conftest.golden_dir(name)
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name))
+    parity.check_gene_table(pipeline, golden)
+    parity.check_read_filters(session, pipeline, golden)
+    parity.check_scalars(pipeline, golden)
+    if name != "mid30k":
+        parity.check_annotation(session, pipeline, golden)
+
+
+def test_live_reference_on_larger_dataset(built, tmp_path):
+    if not datasets.reference_available():
+        pytest.skip("oracle/_ref/arriba_ref_dump did not travel with the repository")
+    spec = {"args": ["--seed", "21", "--fragments", "120000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    env_lists = os.environ.get("ARRIBA_ORACLE_DUMP_LISTS")
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump)
+    finally:
+        if env_lists is None:
+            del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    parity.check_gene_table(pipeline, dump)
+    parity.check_read_filters(session, pipeline, dump)
+    parity.check_scalars(pipeline, dump)
+    parity.check_annotation(session, pipeline, dump)
+
+
+def test_cascade_properties_at_scale(built, tmp_path):
+    """Size-independent properties on a dataset too large for the oracle in a unit test: stage counts are monotone,
+    a duplicate key survives exactly once, and rerunning the cascade on the same batch is idempotent."""
+    from arriba_amd.pipeline import DevicePipeline
+    spec = {"args": ["--seed", "33", "--fragments", "400000", "--normal-mult", "0.1", "--contigs", "8", "--contig-len", "800000", "--junctions", "4000"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    session = parity.open_session(prefix)
+    first = DevicePipeline(session)
+    remaining = first.run_read_level()
+    order = ["duplicates", "uninteresting_contigs", "viral_contigs", "top_expressed_viral_contigs", "low_coverage_viral_contigs", "read_through", "inconsistently_clipped",
+             "homopolymer", "small_insert_size", "long_gap", "same_gene", "hairpin", "mismatches", "low_entropy"]
+    counts = [remaining[name] for name in order]
+    assert all(a >= b for a, b in zip(counts, counts[1:])) and counts[0] <= first.n
+    filters = first.filters()
+    assert int((filters == 0).sum()) == remaining["low_entropy"]
+    second = DevicePipeline(session)
+    second.run_read_level()
+    assert np.array_equal(filters, second.filters())
+    for slot in range(3):
+        count1, genes1 = first.gene_sets(slot)
+        count2, genes2 = second.gene_sets(slot)
+        assert np.array_equal(count1, count2) and np.array_equal(genes1, genes2)

@@ -1,0 +1,80 @@
+"""CPU tier: host stages against the golden dumps of the reference, the C ABI surface, and the device code's
+per-fragment logic single-stepped on the host (tests/emu) against the same dumps."""
+import os
+import re
+
+import pytest
+
+import conftest
+import datasets
+import parity
+
+ROOT = conftest.ROOT
+
+
+def declared_symbols(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)))
+
+
+def test_device_library_exports_every_declared_symbol(built):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "arriba_amd", "lib", "libarriba_gpu.so"))
+    symbols = declared_symbols("arriba_gpu.h", "agpu_")
+    assert len(symbols) >= 20
+    missing = [s for s in symbols if not hasattr(lib, s)]
+    assert not missing, missing
+    lib.agpu_api_version.restype = ctypes.c_int
+    assert lib.agpu_api_version() == 1
+
+
+def test_host_library_exports_every_declared_symbol(built):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "arriba_amd", "lib", "libarriba_host.so"))
+    symbols = declared_symbols("arriba_host.h", "ahost_")
+    missing = [s for s in symbols if not hasattr(lib, s)]
+    assert len(symbols) >= 15 and not missing, missing
+
+
+def test_product_fails_loudly_without_gpu(built):
+    """No CPU fallback: creating a device context without a GPU must raise, not silently compute elsewhere."""
+    from arriba_amd import _capi
+    api = _capi.bind_device_api(_capi.device_library())
+    if api.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    assert not api.create(0, None)
+    assert b"no HIP device" in api.last_error() or b"fallback" in api.last_error()
+
+
+@pytest.mark.parametrize("name", ["toy3k", "shuffled2k"])
+def test_ingest_matches_reference_read_table(name, dataset_files):
+    session = parity.open_session(dataset_files(name))
+    assert parity.check_ingest(session, conftest.golden_dir(name)) > 1000
+
+
+@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k"])
+def test_device_logic_on_host_matches_reference(name, dataset_files, emu_api):
+    golden = conftest.golden_dir(name)
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name), api=emu_api)
+    parity.check_gene_table(pipeline, golden)
+    parity.check_read_filters(session, pipeline, golden)
+    parity.check_scalars(pipeline, golden)
+    if name != "mid30k":
+        parity.check_annotation(session, pipeline, golden)
+    if name == "mid30k":
+        assert pipeline.scalars["estimated"] and pipeline.scalars["mate_gap_samples"] >= 10000
+
+
+def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
+    """The reference exits with 'no normal reads found' on a BAM without mapped reads (source/read_chimeric_alignments.cpp:759)."""
+    import struct
+    from arriba_amd.pipeline import ArribaError, HostSession
+    prefix = datasets.generate({"args": ["--seed", "2", "--fragments", "10", "--contigs", "2", "--contig-len", "150000", "--junctions", "5", "--reference-only"]}, str(tmp_path))
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    names = [b"1", b"2"]
+    header = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", len(names))
+    for name in names:
+        header += struct.pack("<i", len(name) + 1) + name + b"\x00" + struct.pack("<i", 150000)
+    with pytest.raises(ArribaError, match="no normal reads found"):
+        session.read_chimeric_alignments(header)

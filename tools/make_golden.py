@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""tools/make_golden.py -- regenerate the golden fixtures under tests/golden/ (test tooling).
+
+For every dataset in tests/datasets.py this script generates the synthetic FASTA/GTF/BAM with the
+deterministic generator (arriba_amd/lib/gen_synth), runs the oracle build of the UNMODIFIED reference
+(oracle/_ref/arriba_ref_dump, built by oracle/Makefile from /root/reference/source) on it and stores the
+dumps of the stages the tests compare against, gzip-compressed, together with a checksum of the BAM so
+that a drifting generator is detected.  Needs /root/reference (or a prebuilt oracle/_ref/); the tests
+themselves only need the committed files.
+"""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import datasets  # noqa: E402
+
+
+def main():
+    only = sys.argv[1:]
+    for name, spec in datasets.DATASETS.items():
+        if only and name not in only:
+            continue
+        work = tempfile.mkdtemp(prefix="golden_" + name + "_")
+        prefix = datasets.generate(spec, work)
+        dump = os.path.join(work, "dump")
+        os.makedirs(dump)
+        log = datasets.run_reference(prefix, dump, spec)
+        target = os.path.join(ROOT, "tests", "golden", name)
+        shutil.rmtree(target, ignore_errors=True)
+        os.makedirs(target)
+        keep = spec.get("golden_files", datasets.DEFAULT_GOLDEN_FILES)
+        for entry in sorted(os.listdir(dump)):
+            stage = entry.split(".", 1)[1] if "." in entry else entry
+            if any(entry.startswith(k.split("*")[0]) and entry.endswith(k.split("*")[-1]) for k in keep):
+                with open(os.path.join(dump, entry), "rb") as source, gzip.GzipFile(os.path.join(target, entry + ".gz"), "wb", mtime=0) as out:
+                    shutil.copyfileobj(source, out)
+        for entry in ("fusions.tsv", "discarded.tsv"):
+            with open(prefix + "." + entry, "rb") as source, gzip.GzipFile(os.path.join(target, entry + ".gz"), "wb", mtime=0) as out:
+                shutil.copyfileobj(source, out)
+        with open(os.path.join(target, "reference.log"), "w") as out:
+            out.write(log)
+        meta = {"dataset": name, "spec": {k: v for k, v in spec.items() if k != "golden_files"}, "bam_sha256": hashlib.sha256(open(prefix + ".bam", "rb").read()).hexdigest(),
+                "reference": "suhrig/arriba v2.5.1 sources at /root/reference/source, built by oracle/Makefile"}
+        with open(os.path.join(target, "meta.json"), "w") as out:
+            json.dump(meta, out, indent=1, sort_keys=True)
+        size = sum(os.path.getsize(os.path.join(target, f)) for f in os.listdir(target))
+        print("%s: %d files, %.1f KiB" % (name, len(os.listdir(target)), size / 1024.0))
+        shutil.rmtree(work)
+
+
+if __name__ == "__main__":
+    main()
