@@ -377,9 +377,28 @@ AGPU_HD bool dummy_gene_starts_here(const uint64_t* sorted_keys, uint32_t i, con
 	return false;
 }
 
-// Point query on the gene index as it looks after the dummy genes were added (reference: source/arriba.cpp:262-264 rebuilds the
-// index): the bucket of the first boundary key >= position, where the boundary keys of the dummy genes (end, start-1) are merged in.
-AGPU_HD void query_point_with_dummy_genes(const AnnotationView& ann, uint32_t contig, int32_t position, IdSet& out) {
+// Result of a point query on the gene index as it looks after the dummy genes were added: GTF genes plus a contiguous
+// range of dummy gene ids.  Many identical dummy genes can pile up on one position (every PCR duplicate of an intergenic
+// read that sits exactly on a boundary key becomes its own dummy gene), so the range is kept symbolic.
+struct GeneQuery {
+	IdSet real;
+	uint32_t dummy_first, dummy_count; // gene ids n_genes + dummy_first ... (all larger than any GTF gene id)
+	AGPU_HD void clear() { real.clear(); dummy_first = 0; dummy_count = 0; }
+	AGPU_HD uint32_t size() const { return real.n + dummy_count; }
+	AGPU_HD uint32_t element(const AnnotationView& ann, uint32_t k) const { return k < real.n ? real.v[k] : ann.n_genes + dummy_first + (k - real.n); }
+	AGPU_HD void assign_single(uint32_t gene) { real.clear(); real.assign_single(gene); dummy_first = 0; dummy_count = 0; }
+	AGPU_HD void from_set(const IdSet& set) { real = set; dummy_first = 0; dummy_count = 0; }
+	// false if the materialised set would not fit
+	AGPU_HD bool to_set(const AnnotationView& ann, IdSet& out) const {
+		out = real;
+		for (uint32_t k = 0; k < dummy_count; ++k) out.insert(ann.n_genes + dummy_first + k);
+		return !out.overflow;
+	}
+};
+
+// Point query (reference: source/arriba.cpp:262-264 rebuilds the index with the dummy genes): the bucket of the first boundary
+// key >= position, where the boundary keys of the dummy genes (end, start-1) are merged in.
+AGPU_HD void query_point_with_dummy_genes(const AnnotationView& ann, uint32_t contig, int32_t position, GeneQuery& out) {
 	out.clear();
 	bool have_real = false, have_key = false;
 	int32_t key = 0;
@@ -404,68 +423,70 @@ AGPU_HD void query_point_with_dummy_genes(const AnnotationView& ann, uint32_t co
 	if (!have_key) return;
 	if (have_real) { // the real genes containing `key` are those of the first real boundary >= position
 		IdentityMap identity;
-		emit_all(index_bucket(ann.gene_index, real_bucket), identity, out);
+		emit_all(index_bucket(ann.gene_index, real_bucket), identity, out.real);
 	}
-	if (ann.n_dummy > 0) {
+	if (ann.n_dummy > 0) { // dummy genes containing `key`: a contiguous run (they are sorted and disjoint up to identical duplicates)
 		uint64_t base = (uint64_t) contig << 32;
 		uint32_t j = lower_bound_u64(ann.dummy_end_key, ann.n_dummy, base | (uint32_t) key);
-		while (j < ann.n_dummy && (uint32_t) (ann.dummy_start_key[j] >> 32) == contig && (int32_t) (uint32_t) ann.dummy_start_key[j] <= key) {
-			out.insert(ann.n_genes + j);
-			++j;
-		}
+		out.dummy_first = j;
+		while (j < ann.n_dummy && (uint32_t) (ann.dummy_start_key[j] >> 32) == contig && (int32_t) (uint32_t) ann.dummy_start_key[j] <= key) ++j;
+		out.dummy_count = j - out.dummy_first;
 	}
 }
 
 AGPU_HD bool gene_contains(const AnnotationView& ann, uint32_t gene, int32_t position) { return ann.gene_start[gene] <= position && ann.gene_end[gene] >= position; }
 
+// last element of the query that contains the position, or `fallback`
+AGPU_HD uint32_t last_gene_containing(const AnnotationView& ann, const GeneQuery& genes, int32_t position, uint32_t fallback) {
+	for (uint32_t k = genes.size(); k > 0; --k) {
+		uint32_t gene = genes.element(ann, k - 1);
+		if (gene_contains(ann, gene, position)) return gene;
+	}
+	return fallback;
+}
+
 // Stage 2 (reference: source/arriba.cpp:262-319): map still unannotated alignments to the dummy genes and reduce
 // alignments that span several dummy genes to the one containing the breakpoint.
 AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& ann, uint64_t i) {
 	int n_aln = b.n_aln[i];
-	IdSet genes[3];
+	GeneQuery genes[3];
 	uint8_t bits[3];
 	bool changed[3] = { false, false, false };
 	for (int s = 0; s < 3; ++s) { genes[s].clear(); bits[s] = 0; }
-	for (int s = 0; s < n_aln; ++s) { load_genes(b, s, i, genes[s]); bits[s] = b.abits[s][i]; }
+	for (int s = 0; s < n_aln; ++s) { IdSet loaded; load_genes(b, s, i, loaded); genes[s].from_set(loaded); bits[s] = b.abits[s][i]; }
 
 	if (n_aln == 3) {
-		if (genes[MATE1].n == 0 || genes[SPLIT_READ].n == 0) {
+		if (genes[MATE1].size() == 0 || genes[SPLIT_READ].size() == 0) {
 			query_point_with_dummy_genes(ann, b.contig[SPLIT_READ][i], breakpoint_of(b, SPLIT_READ, i, bits[SPLIT_READ], true), genes[SPLIT_READ]);
 			genes[MATE1] = genes[SPLIT_READ];
 			changed[MATE1] = changed[SPLIT_READ] = true;
 		}
-		if (genes[SUPPLEMENTARY].n == 0) {
+		if (genes[SUPPLEMENTARY].size() == 0) {
 			query_point_with_dummy_genes(ann, b.contig[SUPPLEMENTARY][i], breakpoint_of(b, SUPPLEMENTARY, i, bits[SUPPLEMENTARY], false), genes[SUPPLEMENTARY]);
 			changed[SUPPLEMENTARY] = true;
 		}
 	} else {
 		for (int s = 0; s < n_aln; ++s)
-			if (genes[s].n == 0) {
+			if (genes[s].size() == 0) {
 				query_point_with_dummy_genes(ann, b.contig[s][i], breakpoint_of(b, s, i, bits[s], false), genes[s]);
 				changed[s] = true;
 			}
 	}
 
 	for (int s = 0; s < n_aln; ++s) {
-		if (genes[s].n > 1 && (ann.gene_bits[genes[s].v[0]] & GBIT_DUMMY)) {
+		if (genes[s].size() > 1 && (ann.gene_bits[genes[s].element(ann, 0)] & GBIT_DUMMY)) {
 			int32_t breakpoint = breakpoint_of(b, s, i, bits[s], true); // forward -> start for every slot here (source/arriba.cpp:291)
-			uint32_t encompassing = genes[MATE1].v[0];
-			for (uint32_t g = 0; g < genes[s].n; ++g)
-				if (gene_contains(ann, genes[s].v[g], breakpoint))
-					encompassing = genes[s].v[g];
+			uint32_t encompassing = last_gene_containing(ann, genes[s], breakpoint, genes[MATE1].element(ann, 0));
 			genes[s].assign_single(encompassing);
 			changed[s] = true;
 		}
 	}
-	if (n_aln == 3 && genes[MATE1].n > 0 && genes[SPLIT_READ].n > 0) {
-		uint32_t g1 = genes[MATE1].v[0], g2 = genes[SPLIT_READ].v[0];
+	if (n_aln == 3 && genes[MATE1].size() > 0 && genes[SPLIT_READ].size() > 0) {
+		uint32_t g1 = genes[MATE1].element(ann, 0), g2 = genes[SPLIT_READ].element(ann, 0);
 		if (g1 != g2 && (ann.gene_bits[g1] & GBIT_DUMMY) && (ann.gene_bits[g2] & GBIT_DUMMY)) {
 			int32_t breakpoint = breakpoint_of(b, SPLIT_READ, i, bits[SPLIT_READ], true);
-			uint32_t encompassing = g1;
-			for (uint32_t g = 0; g < genes[MATE1].n; ++g)
-				if (gene_contains(ann, genes[MATE1].v[g], breakpoint)) encompassing = genes[MATE1].v[g];
-			for (uint32_t g = 0; g < genes[SPLIT_READ].n; ++g)
-				if (gene_contains(ann, genes[SPLIT_READ].v[g], breakpoint)) encompassing = genes[SPLIT_READ].v[g];
+			uint32_t encompassing = last_gene_containing(ann, genes[MATE1], breakpoint, g1);
+			encompassing = last_gene_containing(ann, genes[SPLIT_READ], breakpoint, encompassing);
 			genes[MATE1].assign_single(encompassing);
 			genes[SPLIT_READ].assign_single(encompassing);
 			changed[MATE1] = changed[SPLIT_READ] = true;
@@ -473,8 +494,11 @@ AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& 
 	}
 	bool ok = true;
 	for (int s = 0; s < n_aln; ++s)
-		if (changed[s])
-			ok = store_genes(b, s, i, genes[s]) && !genes[s].overflow && ok;
+		if (changed[s]) {
+			IdSet out;
+			ok = genes[s].to_set(ann, out) && ok;
+			ok = store_genes(b, s, i, out) && ok;
+		}
 	return ok;
 }
 
