@@ -212,6 +212,39 @@ class DevicePipeline(object):
         self.estimate_fragment_length()
         return self.filter_reads()
 
+    def find_fusions(self, max_mate_gap=None):
+        """reference: find_fusions, source/fusions.cpp:203-473; returns the number of candidates"""
+        if max_mate_gap is None:
+            max_mate_gap = self.scalars["max_mate_gap"]
+        count = c_uint64()
+        self._check(self.api.find_fusions(self.ctx, max_mate_gap, byref(count)))
+        self._record("find_fusions")
+        self.n_candidates = count.value
+        return self.n_candidates
+
+    def candidates(self):
+        """Candidate table in the reference's insertion order; lists as (offset[3n+1], reads)."""
+        n = self.n_candidates
+        u32 = lambda: np.zeros(max(n, 1), dtype=np.uint32)
+        i32 = lambda: np.zeros(max(n, 1), dtype=np.int32)
+        table = {"gene1": u32(), "gene2": u32(), "contigs": u32(), "breakpoint1": i32(), "breakpoint2": i32(), "flags": u32(), "filter": np.zeros(max(n, 1), dtype=np.uint8),
+                 "split_reads1": u32(), "split_reads2": u32(), "discordant_mates": u32(), "anchor_start1": i32(), "anchor_start2": i32(), "list_offset": np.zeros(3 * n + 1, dtype=np.uint32)}
+        order = ["gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2", "list_offset"]
+        self._check(self.api.get_candidates(self.ctx, *[table[k].ctypes.data for k in order]))
+        total = c_uint64()
+        self._check(self.api.get_candidate_read_lists(self.ctx, None, 0, byref(total)))
+        reads = np.zeros(max(total.value, 1), dtype=np.uint32)
+        self._check(self.api.get_candidate_read_lists(self.ctx, reads.ctypes.data, total.value, byref(total)))
+        for key in order[:-1]:
+            table[key] = table[key][:n]
+        table["read_lists"] = reads[:total.value]
+        return table
+
+    def discordant_swapped(self):
+        out = np.zeros(self.n, dtype=np.uint8)
+        self._check(self.api.get_discordant_swapped(self.ctx, out.ctypes.data))
+        return out
+
     # ---- result access -------------------------------------------------------------------------------
 
     def filters(self):

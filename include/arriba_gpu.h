@@ -55,6 +55,19 @@ extern "C" {
 #define AGPU_CBIT_INTERESTING 1u
 #define AGPU_CBIT_VIRAL 2u
 
+/* bits of the candidate flags returned by agpu_get_candidates (source/common.hpp:237-250) */
+#define AGPU_CFLAG_UPSTREAM1 1u                    /* direction1 == UPSTREAM */
+#define AGPU_CFLAG_UPSTREAM2 2u
+#define AGPU_CFLAG_EXONIC1 4u
+#define AGPU_CFLAG_EXONIC2 8u
+#define AGPU_CFLAG_SPLICED1 16u
+#define AGPU_CFLAG_SPLICED2 32u
+#define AGPU_CFLAG_PREDICTED_STRAND1 64u           /* 1 = forward */
+#define AGPU_CFLAG_PREDICTED_STRAND2 128u
+#define AGPU_CFLAG_PREDICTED_STRANDS_AMBIGUOUS 256u
+#define AGPU_CFLAG_TRANSCRIPT_START_GENE1 512u
+#define AGPU_CFLAG_TRANSCRIPT_START_AMBIGUOUS 1024u
+
 typedef struct agpu_ctx agpu_ctx;
 
 /* Flattened interval index (source/annotation.t.hpp:25-45): per contig a sorted array of boundary keys;
@@ -182,6 +195,15 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining);
 
 /* find_fusions (source/fusions.cpp:203-473).  Returns the number of candidates in *n_candidates. */
 int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidates);
+
+/* Candidate table after find_fusions, in order of first occurrence in name order (== the order in which the reference inserts
+ * candidates into fusions_t, source/fusions.cpp:252).  Any pointer may be NULL.  flags = AGPU_CFLAG_*; contigs = contig1 << 16 | contig2;
+ * list_offset[3*n+1] indexes the concatenated read lists (split_read1_list, split_read2_list, discordant_mate_list per candidate). */
+int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
+                        uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor_start1, int32_t* anchor_start2, uint32_t* list_offset);
+int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capacity, uint64_t* total);
+/* 1 for every discordant fragment whose MATE1/MATE2 the reference swaps in place while attaching it (source/fusions.cpp:414-421) */
+int agpu_get_discordant_swapped(agpu_ctx* ctx, uint8_t* swapped /* [n] */);
 
 /* result access (device -> host copies) */
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);
