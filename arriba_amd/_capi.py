@@ -75,6 +75,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "upload_annotation": (c_int, [ctx, POINTER(AnnotationView)]),
         "upload_genome": (c_int, [ctx, POINTER(GenomeView)]),
         "upload_batch": (c_int, [ctx, POINTER(BatchView)]),
+        "reset": (c_int, [ctx]),
         "mark_multimappers": (c_int, [ctx, POINTER(c_uint64)]),
         "annotate": (c_int, [ctx, POINTER(c_uint32)]),
         "read_filters_stage1": (c_int, [ctx, c_void_p, c_void_p]),

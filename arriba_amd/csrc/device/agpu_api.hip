@@ -436,12 +436,13 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 	ctx->n = n;
 	uint64_t bytes = 0;
 	TRY(upload(ctx->n_aln, in->n_aln, n, s)); TRY(upload(ctx->fbits, in->fbits, n, s)); TRY(upload(ctx->group, in->group, n, s));
+	TRY(upload(ctx->pristine_fbits, in->fbits, n, s));
 	bytes += n * (1 + 1 + 4);
 	if (!ctx->filter.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
 	HIP_CHECK(hipMemsetAsync(ctx->filter.ptr, 0, n ? n : 1, s));
 	for (int k = 0; k < 3; ++k) {
 		TRY(upload(ctx->contig[k], in->contig[k], n, s)); TRY(upload(ctx->start[k], in->start[k], n, s)); TRY(upload(ctx->end[k], in->end[k], n, s));
-		TRY(upload(ctx->abits[k], in->abits[k], n, s)); TRY(upload(ctx->cigar_offset[k], in->cigar_offset[k], n, s)); TRY(upload(ctx->cigar_count[k], in->cigar_count[k], n, s));
+		TRY(upload(ctx->abits[k], in->abits[k], n, s)); TRY(upload(ctx->pristine_abits[k], in->abits[k], n, s)); TRY(upload(ctx->cigar_offset[k], in->cigar_offset[k], n, s)); TRY(upload(ctx->cigar_count[k], in->cigar_count[k], n, s));
 		bytes += n * (2 + 4 + 4 + 1 + 4 + 2);
 		if (!ctx->gene_count[k].allocate(n) || !ctx->genes[k].allocate(n * GENE_INLINE * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
 		HIP_CHECK(hipMemsetAsync(ctx->gene_count[k].ptr, 0, n ? n : 1, s));
@@ -478,8 +479,31 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 	b.seq_pool = ctx->seq_pool.as<uint8_t>();
 	b.gene_pool = ctx->gene_pool.as<uint32_t>(); b.gene_pool_used = ctx->counters.as<uint32_t>() + COUNTER_GENE_POOL; b.gene_pool_capacity = pool_capacity;
 	HIP_CHECK(hipStreamSynchronize(s));
-	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false;
+	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
 	if (ctx->have_genome) TRY(build_tables(ctx));
+	return AGPU_OK;
+}
+
+int agpu_reset(agpu_ctx* ctx) {
+	if (!ctx || !ctx->have_batch) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	if (n > 0) {
+		HIP_CHECK(hipMemcpyAsync(ctx->fbits.ptr, ctx->pristine_fbits.ptr, n, hipMemcpyDeviceToDevice, s));
+		HIP_CHECK(hipMemsetAsync(ctx->filter.ptr, 0, n, s));
+		for (int k = 0; k < 3; ++k) {
+			HIP_CHECK(hipMemcpyAsync(ctx->abits[k].ptr, ctx->pristine_abits[k].ptr, n, hipMemcpyDeviceToDevice, s));
+			HIP_CHECK(hipMemsetAsync(ctx->gene_count[k].ptr, 0, n, s));
+		}
+	}
+	HIP_CHECK(hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes, s));
+	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
+	// the gene table shrinks back to the GTF genes; the dummy genes are re-created by agpu_annotate
+	ctx->n_dummy = 0;
+	refresh_annotation_view(ctx);
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
 	return AGPU_OK;
 }
 
@@ -641,8 +665,6 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 	ctx->stage2_done = true;
 	return AGPU_OK;
 }
-
-int agpu_find_fusions(agpu_ctx*, int32_t, uint64_t*) { set_last_error("agpu_find_fusions is not implemented yet"); return AGPU_ERR_INVALID; }
 
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter) {
 	if (!ctx || !ctx->have_batch || !filter) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }

@@ -6,7 +6,7 @@
 #include <string>
 #include <vector>
 #include "../../../include/arriba_gpu.h"
-#include "filter_core.hpp"
+#include "fusion_core.hpp"
 
 namespace agpu {
 
@@ -60,6 +60,7 @@ struct agpu_ctx {
 	// batch
 	uint64_t n = 0;
 	agpu::DeviceBuffer n_aln, fbits, filter, group;
+	agpu::DeviceBuffer pristine_fbits, pristine_abits[3]; // state as uploaded, restored by agpu_reset
 	agpu::DeviceBuffer contig[3], start[3], end[3], abits[3], cigar_offset[3], cigar_count[3], cigar_pool;
 	agpu::DeviceBuffer seq_offset[2], seq_length[2], seq_pool;
 	agpu::DeviceBuffer gene_count[3], genes[3], gene_pool, counters;
@@ -75,6 +76,14 @@ struct agpu_ctx {
 	agpu::DeviceBuffer duplicate_keys, duplicate_slots;
 	agpu::DeviceBuffer sample_flags, sample_values, samples;
 	agpu::DeviceBuffer stage_counts;
+
+	// find_fusions
+	agpu::DeviceBuffer emissions, discordant_swapped;
+	agpu::DeviceBuffer cand_gene1, cand_gene2, cand_contigs, cand_breakpoint1, cand_breakpoint2, cand_flags, cand_filter, cand_split_reads1, cand_split_reads2, cand_discordant_mates;
+	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists;
+	agpu::CandidateTable candidates;
+	uint32_t n_emissions = 0, n_candidates = 0, n_list_entries = 0;
+	bool fusions_done = false;
 
 	// tables
 	agpu::DeviceBuffer mismatch_verdict, kmer_threshold, filter_enabled, viral_verdict_top, viral_verdict_low;

@@ -1,0 +1,348 @@
+// arriba_amd/csrc/device/agpu_fusions.hip -- find_fusions on the device (reference: source/fusions.cpp:203-473).
+//
+// Pipeline (all arrays resident in HBM; M = emissions, C = candidates):
+//   emission_count_kernel + exclusive scan      reads -> M
+//   emission_write_kernel                       one record per read x gene1 x gene2, in name order
+//   candidate_insert/resolve_kernel             lock-free hash table: representative = first emission with the same key
+//   radix sort of (representative << 32 | e)    groups a candidate's emissions, name order inside, candidates in first-occurrence order
+//   gather_sorted_kernel                        physical reorder + head flags; inclusive scan -> candidate index
+//   rank scan (RankCombine)                     per-side read / unfiltered-read prefix counts -> who joins the read lists
+//   fold scan (CandidateCombine)                filter / counts / anchors / exonic per candidate at the segment tails
+//   discordant buckets                          discordant emissions sorted by (gene1, gene2, directions), stable in name order
+//   attach_discordant_kernel (count + fill)     one thread per unfiltered candidate walks its bucket (early exit at the subsampling threshold)
+//   split_list_fill_kernel, finish_kernel       read lists, strands, splice sites, transcript start
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+#include "agpu_context.hpp"
+#include "fusion_core.hpp"
+
+using namespace agpu;
+
+namespace {
+
+const int BLOCK = 256;
+const uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
+inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1) / BLOCK); }
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+
+__global__ void emission_count_kernel(BatchView b, uint32_t* counts) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	counts[i] = emission_count(b, i);
+}
+
+__global__ void emission_write_kernel(BatchView b, const uint32_t* offsets, const uint32_t* counts, FusionEmission* emissions) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n || counts[i] == 0) return;
+	write_emissions(b, i, emissions + offsets[i]);
+}
+
+__global__ void candidate_insert_kernel(uint32_t M, const FusionEmission* emissions, uint32_t* slots, uint32_t mask) {
+	uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+	if (e >= M) return;
+	FusionEmission mine = emissions[e];
+	uint32_t h = (uint32_t) hash_candidate(mine) & mask;
+	while (true) {
+		uint32_t owner = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (owner == EMPTY_SLOT) {
+			owner = atomicCAS(&slots[h], EMPTY_SLOT, e);
+			if (owner == EMPTY_SLOT) return;
+		}
+		if (same_candidate(emissions[owner], mine)) { atomicMin(&slots[h], e); return; }
+		h = (h + 1) & mask;
+	}
+}
+
+__global__ void candidate_resolve_kernel(uint32_t M, const FusionEmission* emissions, const uint32_t* slots, uint32_t mask, uint64_t* keys) {
+	uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+	if (e >= M) return;
+	FusionEmission mine = emissions[e];
+	uint32_t h = (uint32_t) hash_candidate(mine) & mask;
+	while (true) {
+		uint32_t owner = slots[h];
+		if (same_candidate(emissions[owner], mine)) { keys[e] = (uint64_t) owner << 32 | e; return; }
+		h = (h + 1) & mask;
+	}
+}
+
+__global__ void gather_sorted_kernel(uint32_t M, const uint64_t* sorted_keys, const FusionEmission* emissions, FusionEmission* sorted, uint32_t* heads) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= M) return;
+	uint64_t key = sorted_keys[j];
+	sorted[j] = emissions[(uint32_t) key];
+	heads[j] = (j == 0 || (sorted_keys[j - 1] >> 32) != (key >> 32)) ? 1u : 0u;
+}
+
+__global__ void rank_input_kernel(uint32_t M, const FusionEmission* sorted, const uint32_t* heads, RankState* out) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= M) return;
+	out[j] = rank_input(sorted[j], heads[j]);
+}
+
+__global__ void fold_input_kernel(uint32_t M, const FusionEmission* sorted, const uint32_t* heads, const RankState* ranks, uint32_t threshold, CandidateFold* out) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= M) return;
+	FusionEmission e = sorted[j];
+	bool joins = (e.info & EINFO_SPLIT) && joins_split_read_list(e, ranks[j], threshold);
+	out[j] = candidate_input(e, heads[j], joins);
+}
+
+__global__ void candidate_write_kernel(uint32_t M, const FusionEmission* sorted, const uint32_t* heads, const uint32_t* candidate_of, const CandidateFold* folds, CandidateTable t, uint32_t* list_size) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= M) return;
+	if (!(j + 1 == M || heads[j + 1])) return; // only segment tails carry the aggregate
+	uint32_t c = candidate_of[j] - 1;
+	FusionEmission e = sorted[j];
+	CandidateFold f = folds[j];
+	t.gene1[c] = e.gene1; t.gene2[c] = e.gene2; t.contigs[c] = e.contigs; t.breakpoint1[c] = e.breakpoint1; t.breakpoint2[c] = e.breakpoint2;
+	t.flags[c] = ((e.info & EINFO_UPSTREAM1) ? CFLAG_UPSTREAM1 : 0) | ((e.info & EINFO_UPSTREAM2) ? CFLAG_UPSTREAM2 : 0) | ((f.info_or & EINFO_EXONIC1) ? CFLAG_EXONIC1 : 0) | ((f.info_or & EINFO_EXONIC2) ? CFLAG_EXONIC2 : 0);
+	t.filter[c] = candidate_filter(f);
+	t.split_reads1[c] = f.split_reads[0]; t.split_reads2[c] = f.split_reads[1]; t.discordant_mates[c] = 0;
+	t.anchor1[c] = anchor_apply(0, f.anchor1, e.info & EINFO_UPSTREAM1);
+	t.anchor2[c] = anchor_apply(0, f.anchor2, e.info & EINFO_UPSTREAM2);
+	list_size[3 * (uint64_t) c] = f.list_size[0]; list_size[3 * (uint64_t) c + 1] = f.list_size[1]; list_size[3 * (uint64_t) c + 2] = 0;
+}
+
+__global__ void discordant_flag_kernel(uint32_t M, const FusionEmission* emissions, uint8_t* flags) {
+	uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+	if (e >= M) return;
+	flags[e] = !(emissions[e].info & EINFO_SPLIT);
+}
+AGPU_HD uint64_t gene_pair_key(uint32_t gene1, uint32_t gene2, uint32_t direction_bits) { return (uint64_t) gene1 << 33 | (uint64_t) gene2 << 2 | (direction_bits & 3u); }
+__global__ void discordant_key_kernel(uint32_t Md, const uint32_t* indices, const FusionEmission* emissions, uint64_t* keys) {
+	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= Md) return;
+	const FusionEmission& e = emissions[indices[k]];
+	keys[k] = gene_pair_key(e.gene1, e.gene2, e.info);
+}
+__global__ void discordant_gather_kernel(uint32_t Md, const uint32_t* sorted_indices, const FusionEmission* emissions, FusionEmission* bucket_emissions) {
+	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= Md) return;
+	bucket_emissions[k] = emissions[sorted_indices[k]];
+}
+
+AGPU_HD uint32_t lower_bound_key(const uint64_t* keys, uint32_t n, uint64_t value) {
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < value) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+// one thread per candidate; fill == false: count pass, fill == true: write lists / anchors / swap flags
+__global__ void attach_discordant_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint64_t* bucket_keys, const FusionEmission* bucket_emissions, uint32_t Md,
+                                         int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, bool fill) {
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	if (t.filter[c] != FILTER_none) return;
+	uint32_t flags = t.flags[c];
+	uint64_t key = gene_pair_key(t.gene1[c], t.gene2[c], ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u));
+	uint32_t begin = lower_bound_key(bucket_keys, Md, key), end = lower_bound_key(bucket_keys, Md, key + 1);
+	if (begin == end) return;
+	bool has_split_reads;
+	uint32_t* out_list = nullptr;
+	if (fill) {
+		const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+		has_split_reads = offsets[2] > offsets[0];
+		out_list = t.read_lists + offsets[2];
+	} else {
+		has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
+	}
+	uint32_t size = attach_discordant_mates(b, ann, t, c, bucket_emissions + begin, end - begin, max_mate_gap, threshold, has_split_reads, fill ? out_list : nullptr, discordant_swapped);
+	if (!fill) list_size[3 * (uint64_t) c + 2] = size;
+}
+
+__global__ void split_list_fill_kernel(uint32_t M, const FusionEmission* sorted, const uint32_t* candidate_of, const RankState* ranks, const CandidateFold* folds, uint32_t threshold, CandidateTable t) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= M) return;
+	FusionEmission e = sorted[j];
+	if (!(e.info & EINFO_SPLIT) || !joins_split_read_list(e, ranks[j], threshold)) return;
+	int side = (e.info & EINFO_SWAPPED) ? 1 : 0;
+	uint32_t c = candidate_of[j] - 1;
+	t.read_lists[t.list_offset[3 * (uint64_t) c + side] + folds[j].list_size[side] - 1] = e.read;
+}
+
+__global__ void finish_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint8_t* discordant_swapped) {
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	finish_candidate(b, ann, t, discordant_swapped, c);
+}
+
+struct Scratch { // grows on demand; reused by every rocprim call
+	DeviceBuffer buffer;
+	int ensure(size_t bytes) { if (bytes > buffer.bytes) { if (!buffer.allocate(bytes + (bytes >> 2))) { set_last_error("hipMalloc failed (scratch)"); return AGPU_ERR_DEVICE; } } return AGPU_OK; }
+};
+
+}
+
+extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidates) {
+	if (!ctx || !ctx->stage2_done) { set_last_error("agpu_read_filters_stage2 must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	const uint32_t threshold = ctx->params.subsampling_threshold;
+	Scratch scratch;
+	size_t bytes = 0;
+	(void) hipEventRecord(ctx->event_start, s);
+
+	// ---- emissions
+	DeviceBuffer counts, offsets;
+	ALLOC(counts, (n + 1) * 4); ALLOC(offsets, (n + 1) * 4);
+	HIP_CHECK(hipMemsetAsync(counts.ptr, 0, (n + 1) * 4, s));
+	if (n > 0) emission_count_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, counts.as<uint32_t>());
+	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n + 1, rocprim::plus<uint32_t>(), s));
+	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n + 1, rocprim::plus<uint32_t>(), s));
+	uint32_t M = 0;
+	HIP_CHECK(hipMemcpyAsync(&M, offsets.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (M >= 0xFFFFFFF0u) { set_last_error("too many gene-pair emissions for one batch; shard the input"); return AGPU_ERR_CAPACITY; }
+	ctx->n_emissions = M;
+	ctx->n_candidates = 0;
+	if (M == 0) {
+		if (n_candidates) *n_candidates = 0;
+		ctx->fusions_done = true;
+		return AGPU_OK;
+	}
+	ALLOC(ctx->emissions, (size_t) M * sizeof(FusionEmission));
+	FusionEmission* emissions = ctx->emissions.as<FusionEmission>();
+	emission_write_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, offsets.as<uint32_t>(), counts.as<uint32_t>(), emissions);
+
+	// ---- group by candidate key
+	uint64_t slots = 1024;
+	while (slots < 2ull * M) slots <<= 1;
+	const uint32_t mask = (uint32_t) (slots - 1);
+	DeviceBuffer table, keys, sorted_keys;
+	ALLOC(table, slots * 4); ALLOC(keys, (size_t) M * 8); ALLOC(sorted_keys, (size_t) M * 8);
+	HIP_CHECK(hipMemsetAsync(table.ptr, 0xFF, slots * 4, s));
+	candidate_insert_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask);
+	candidate_resolve_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask, keys.as<uint64_t>());
+	HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, keys.as<uint64_t>(), sorted_keys.as<uint64_t>(), M, 0, 64, s));
+	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+	HIP_CHECK(rocprim::radix_sort_keys(scratch.buffer.ptr, bytes, keys.as<uint64_t>(), sorted_keys.as<uint64_t>(), M, 0, 64, s));
+	table.release(); keys.release();
+	DeviceBuffer sorted, heads, candidate_of;
+	ALLOC(sorted, (size_t) M * sizeof(FusionEmission)); ALLOC(heads, (size_t) M * 4); ALLOC(candidate_of, (size_t) M * 4);
+	gather_sorted_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted_keys.as<uint64_t>(), emissions, sorted.as<FusionEmission>(), heads.as<uint32_t>());
+	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, heads.as<uint32_t>(), candidate_of.as<uint32_t>(), M, rocprim::plus<uint32_t>(), s));
+	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+	HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, heads.as<uint32_t>(), candidate_of.as<uint32_t>(), M, rocprim::plus<uint32_t>(), s));
+	uint32_t C = 0;
+	HIP_CHECK(hipMemcpyAsync(&C, candidate_of.as<uint32_t>() + (M - 1), 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	sorted_keys.release();
+
+	// ---- prefix counts and per-candidate folds
+	DeviceBuffer rank_in, ranks, fold_in, folds;
+	ALLOC(rank_in, (size_t) M * sizeof(RankState)); ALLOC(ranks, (size_t) M * sizeof(RankState));
+	rank_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), rank_in.as<RankState>());
+	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, rank_in.as<RankState>(), ranks.as<RankState>(), M, RankCombine(), s));
+	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+	HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, rank_in.as<RankState>(), ranks.as<RankState>(), M, RankCombine(), s));
+	rank_in.release();
+	ALLOC(fold_in, (size_t) M * sizeof(CandidateFold)); ALLOC(folds, (size_t) M * sizeof(CandidateFold));
+	fold_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), ranks.as<RankState>(), threshold, fold_in.as<CandidateFold>());
+	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, fold_in.as<CandidateFold>(), folds.as<CandidateFold>(), M, CandidateCombine(), s));
+	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+	HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, fold_in.as<CandidateFold>(), folds.as<CandidateFold>(), M, CandidateCombine(), s));
+	fold_in.release();
+
+	// ---- candidate table
+	ALLOC(ctx->cand_gene1, (size_t) C * 4); ALLOC(ctx->cand_gene2, (size_t) C * 4); ALLOC(ctx->cand_contigs, (size_t) C * 4); ALLOC(ctx->cand_breakpoint1, (size_t) C * 4); ALLOC(ctx->cand_breakpoint2, (size_t) C * 4);
+	ALLOC(ctx->cand_flags, (size_t) C * 4); ALLOC(ctx->cand_filter, (size_t) C); ALLOC(ctx->cand_split_reads1, (size_t) C * 4); ALLOC(ctx->cand_split_reads2, (size_t) C * 4); ALLOC(ctx->cand_discordant_mates, (size_t) C * 4);
+	ALLOC(ctx->cand_anchor1, (size_t) C * 4); ALLOC(ctx->cand_anchor2, (size_t) C * 4); ALLOC(ctx->cand_list_offset, (3 * (size_t) C + 1) * 4);
+	ALLOC(ctx->discordant_swapped, n ? n : 1);
+	HIP_CHECK(hipMemsetAsync(ctx->discordant_swapped.ptr, 0, n ? n : 1, s));
+	CandidateTable& t = ctx->candidates;
+	t.n = C; t.gene1 = ctx->cand_gene1.as<uint32_t>(); t.gene2 = ctx->cand_gene2.as<uint32_t>(); t.contigs = ctx->cand_contigs.as<uint32_t>();
+	t.breakpoint1 = ctx->cand_breakpoint1.as<int32_t>(); t.breakpoint2 = ctx->cand_breakpoint2.as<int32_t>(); t.flags = ctx->cand_flags.as<uint32_t>(); t.filter = ctx->cand_filter.as<uint8_t>();
+	t.split_reads1 = ctx->cand_split_reads1.as<uint32_t>(); t.split_reads2 = ctx->cand_split_reads2.as<uint32_t>(); t.discordant_mates = ctx->cand_discordant_mates.as<uint32_t>();
+	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint32_t>(); t.read_lists = nullptr;
+	DeviceBuffer list_size;
+	ALLOC(list_size, (3 * (size_t) C + 1) * 4);
+	HIP_CHECK(hipMemsetAsync(list_size.ptr, 0, (3 * (size_t) C + 1) * 4, s));
+	candidate_write_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), candidate_of.as<uint32_t>(), folds.as<CandidateFold>(), t, list_size.as<uint32_t>());
+
+	// ---- discordant buckets by gene pair
+	DeviceBuffer discordant_flags, discordant_indices, selected_count, bucket_keys_in, bucket_keys, bucket_indices, bucket_emissions;
+	ALLOC(discordant_flags, M); ALLOC(discordant_indices, (size_t) M * 4); ALLOC(selected_count, 8);
+	discordant_flag_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, discordant_flags.as<uint8_t>());
+	HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), discordant_flags.as<uint8_t>(), discordant_indices.as<uint32_t>(), selected_count.as<uint32_t>(), M, s));
+	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+	HIP_CHECK(rocprim::select(scratch.buffer.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), discordant_flags.as<uint8_t>(), discordant_indices.as<uint32_t>(), selected_count.as<uint32_t>(), M, s));
+	uint32_t Md = 0;
+	HIP_CHECK(hipMemcpyAsync(&Md, selected_count.ptr, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	discordant_flags.release();
+	ALLOC(bucket_keys, (size_t) std::max<uint32_t>(Md, 1) * 8); ALLOC(bucket_emissions, (size_t) std::max<uint32_t>(Md, 1) * sizeof(FusionEmission));
+	if (Md > 0) {
+		ALLOC(bucket_keys_in, (size_t) Md * 8); ALLOC(bucket_indices, (size_t) Md * 4);
+		discordant_key_kernel<<<grid_for(Md), BLOCK, 0, s>>>(Md, discordant_indices.as<uint32_t>(), emissions, bucket_keys_in.as<uint64_t>());
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, bucket_keys_in.as<uint64_t>(), bucket_keys.as<uint64_t>(), discordant_indices.as<uint32_t>(), bucket_indices.as<uint32_t>(), Md, 0, 64, s));
+		if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.buffer.ptr, bytes, bucket_keys_in.as<uint64_t>(), bucket_keys.as<uint64_t>(), discordant_indices.as<uint32_t>(), bucket_indices.as<uint32_t>(), Md, 0, 64, s));
+		discordant_gather_kernel<<<grid_for(Md), BLOCK, 0, s>>>(Md, bucket_indices.as<uint32_t>(), emissions, bucket_emissions.as<FusionEmission>());
+	}
+
+	// ---- discordant mates: count, offsets, fill
+	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), false);
+	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
+	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
+	uint32_t total_list = 0;
+	HIP_CHECK(hipMemcpyAsync(&total_list, t.list_offset + 3 * (size_t) C, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	ALLOC(ctx->cand_read_lists, (size_t) std::max<uint32_t>(total_list, 1) * 4);
+	t.read_lists = ctx->cand_read_lists.as<uint32_t>();
+	ctx->n_list_entries = total_list;
+	split_list_fill_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), candidate_of.as<uint32_t>(), ranks.as<RankState>(), folds.as<CandidateFold>(), threshold, t);
+	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), true);
+	finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>());
+
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	// algorithmic bytes: fragment end columns + gene sets read once, one emission written, candidate table + lists written
+	ctx->last_bytes = n * (3 * (2 + 4 + 4 + 1) + 3 * (1 + GENE_INLINE * 4) + 1) + (uint64_t) M * sizeof(FusionEmission) + (uint64_t) C * 53 + (uint64_t) total_list * 4;
+	ctx->n_candidates = C;
+	ctx->fusions_done = true;
+	if (n_candidates) *n_candidates = C;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
+                                   uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor1, int32_t* anchor2, uint32_t* list_offset) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	const size_t C = ctx->n_candidates;
+	if (C == 0) { if (list_offset) list_offset[0] = 0; return AGPU_OK; }
+	struct { void* host; const DeviceBuffer* device; size_t bytes; } copies[] = {
+		{ gene1, &ctx->cand_gene1, C * 4 }, { gene2, &ctx->cand_gene2, C * 4 }, { contigs, &ctx->cand_contigs, C * 4 }, { breakpoint1, &ctx->cand_breakpoint1, C * 4 }, { breakpoint2, &ctx->cand_breakpoint2, C * 4 },
+		{ flags, &ctx->cand_flags, C * 4 }, { filter, &ctx->cand_filter, C }, { split_reads1, &ctx->cand_split_reads1, C * 4 }, { split_reads2, &ctx->cand_split_reads2, C * 4 },
+		{ discordant_mates, &ctx->cand_discordant_mates, C * 4 }, { anchor1, &ctx->cand_anchor1, C * 4 }, { anchor2, &ctx->cand_anchor2, C * 4 }, { list_offset, &ctx->cand_list_offset, (3 * C + 1) * 4 } };
+	for (size_t k = 0; k < sizeof(copies) / sizeof(copies[0]); ++k)
+		if (copies[k].host) HIP_CHECK(hipMemcpy(copies[k].host, copies[k].device->ptr, copies[k].bytes, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capacity, uint64_t* total) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (total) *total = ctx->n_list_entries;
+	if (reads && ctx->n_list_entries > 0) HIP_CHECK(hipMemcpy(reads, ctx->cand_read_lists.ptr, std::min<uint64_t>(capacity, ctx->n_list_entries) * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_get_discordant_swapped(agpu_ctx* ctx, uint8_t* swapped) {
+	if (!ctx || !ctx->fusions_done || !swapped) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->n) HIP_CHECK(hipMemcpy(swapped, ctx->discordant_swapped.ptr, ctx->n, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}

@@ -276,6 +276,42 @@ AGPU_HD bool discordant_mates_need_swap(const BatchView& b, uint64_t i) {
 	return contig1 > contig2 || (contig1 == contig2 && breakpoint1 > breakpoint2);
 }
 
+// Attach the discordant mates of the candidate's gene pair (bucket = their emissions in name order) to candidate c
+// (source/fusions.cpp:367-437).  With out_list == NULL only the list size is returned (count pass); otherwise the list is
+// written, the anchors and the unfiltered count are updated and the fragments whose mates the reference swaps are flagged.
+AGPU_HD uint32_t attach_discordant_mates(const BatchView& b, const AnnotationView& ann, const CandidateTable& t, uint32_t c, const FusionEmission* bucket, uint32_t bucket_size,
+                                         int32_t max_mate_gap, uint32_t threshold, bool has_split_reads, uint32_t* out_list, uint8_t* discordant_swapped) {
+	if (t.filter[c] != FILTER_none) return 0;
+	uint32_t flags = t.flags[c];
+	bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
+	uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
+	int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
+	uint32_t list_size = 0, unfiltered = 0;
+	AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
+	for (uint32_t k = 0; k < bucket_size; ++k) {
+		const FusionEmission& e = bucket[k];
+		if (!discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, e.breakpoint1, e.breakpoint2))
+			continue;
+		bool read_unfiltered = (e.info >> EINFO_FILTER_SHIFT & 255) == FILTER_none;
+		if (!read_unfiltered && list_size >= threshold) continue;
+		if (unfiltered >= threshold) break;
+		if (out_list) {
+			out_list[list_size] = e.read;
+			if (discordant_mates_need_swap(b, e.read)) discordant_swapped[e.read] = 1;
+			fold1 = anchor_combine(fold1, anchor_single(e.anchor1, upstream1), upstream1);
+			fold2 = anchor_combine(fold2, anchor_single(e.anchor2, upstream2), upstream2);
+		}
+		++list_size;
+		if (read_unfiltered) ++unfiltered;
+	}
+	if (out_list) {
+		t.discordant_mates[c] = unfiltered;
+		t.anchor1[c] = anchor_apply(t.anchor1[c], fold1, upstream1);
+		t.anchor2[c] = anchor_apply(t.anchor2[c], fold2, upstream2);
+	}
+	return list_size;
+}
+
 // ---- strands, splice sites, transcript start (source/fusions.cpp:15-200, 443-470) -----------------------------------
 
 // vote of one discordant mate for the strand of gene1's side (source/fusions.cpp:42-79); returns 0 no vote, 1 forward, 2 reverse

@@ -157,6 +157,11 @@ class DevicePipeline(object):
         self.api.last_kernel_bytes(self.ctx, byref(size))
         self.timings[stage] = {"ms": ms.value, "bytes": size.value}
 
+    def reset(self):
+        """back to the state right after the upload (for repeated timed passes over the same resident batch)"""
+        self._check(self.api.reset(self.ctx))
+        self.n_dummy_genes = 0
+
     # ---- stages, named after the reference functions they replace ---------------------------------
 
     def mark_multimappers(self):

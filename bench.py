@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X hot path on BASELINE.json's synthetic 10 M chimeric-read configuration.
+
+A "step" is one pass of the hot path (mark_multimappers -> annotate -> read-level filter cascade -> find_fusions) over one
+batch of synthetic chimeric fragments that is already resident in HBM; the batch comes from the deterministic generator
+(tools/gen_synth.cpp, BAM records streamed through the host ingest).  With --gpus N every rank processes its own shard
+(weak scaling: reads shard naturally by read).  Rank 0 prints ONE JSON line.
+
+The CPU baseline is the oracle build of the UNMODIFIED reference (oracle/_ref/arriba_ref, 1 core, it is single-threaded by
+design) timed on a bounded sample of the same workload; if that binary did not travel, the field says so.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def workload_args(fragments, seed):
+    # 2x100 bp, 55 % split-read triplets / 35 % discordant pairs / 10 % read-through, Zipf junction
+    # support, 30 % PCR duplicates, synthetic 24-contig genome with GENCODE-like annotation (no hg38 offline)
+    return ["--seed", str(seed), "--fragments", str(fragments), "--normal-mult", "0", "--contigs", "24", "--contig-len", "12000000", "--genes-per-mb", "20",
+            "--junctions", str(max(1000, fragments // 50))]
+
+
+def generate_and_ingest(fragments, seed, directory):
+    """Writes the reference (FASTA/GTF) to `directory`, streams the BAM records through a pipe into the host ingest."""
+    from arriba_amd.pipeline import HostSession
+    import datasets
+    prefix = os.path.join(directory, "bench")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--reference-only"] + workload_args(fragments, seed), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    fifo = prefix + ".bam.fifo"
+    os.mkfifo(fifo)
+    producer = subprocess.Popen([datasets.GEN_SYNTH, "--out", prefix, "--raw-bam-to", fifo] + workload_args(fragments, seed), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    started = time.time()
+    session.read_chimeric_alignments(fifo)
+    producer.wait()
+    return session, prefix, time.time() - started
+
+
+def cpu_baseline(seed, directory):
+    """The unmodified reference (oracle/_ref/arriba_ref) on a bounded sample of the same workload, 1 core."""
+    import datasets
+    if not os.path.exists(datasets.ARRIBA_REF):
+        return {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref/arriba_ref not present on this box"}
+    sample_fragments = 200000
+    prefix = os.path.join(directory, "cpu")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix] + workload_args(sample_fragments, seed), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    started = time.time()
+    result = subprocess.run([datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-f", "blacklist"],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    elapsed = time.time() - started
+    if result.returncode != 0:
+        return {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "reference failed: " + result.stdout[-200:]}
+    import re
+    total = re.search(r"Reading chimeric alignments from .*\(total=(\d+)\)", result.stdout.replace("\n", " "))
+    chimeric = int(total.group(1)) if total else sample_fragments
+    return {"value": chimeric / elapsed, "unit": "chimeric reads/s", "cores": 1, "kind": "reference",
+            "sample": "%d chimeric fragments of the same synthetic workload, whole reference binary BAM->fusions.tsv, %.1f s wall" % (chimeric, elapsed)}
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=3)
+    parser.add_argument("--warmup", type=int, default=1)
+    parser.add_argument("--fragments", type=int, default=10000000, help="chimeric fragments per GPU (BASELINE.json config 2: 10 M)")
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if distributed:
+        dist.barrier()
+    from arriba_amd.pipeline import DevicePipeline
+
+    directory = tempfile.mkdtemp(prefix="bench_r%d_" % rank)
+    session, prefix, ingest_seconds = generate_and_ingest(args.fragments, 1000 + rank, directory)
+    pipeline = DevicePipeline(session, device=local_rank)
+    n = pipeline.n
+
+    def step():
+        pipeline.reset()
+        pipeline.run_read_level()
+        pipeline.find_fusions()
+
+    for _ in range(args.warmup):
+        step()
+    stage_ms = {}
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    started = time.time()
+    for _ in range(args.steps):
+        step()
+        for stage, timing in pipeline.timings.items():
+            stage_ms.setdefault(stage, []).append(timing)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.time() - started
+    if distributed:
+        tensor = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
+        elapsed = float(tensor.item())
+        counts = torch.tensor([n], device="cuda", dtype=torch.int64)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        total_fragments = int(counts.item())
+    else:
+        total_fragments = n
+
+    if rank == 0:
+        per_stage = {stage: {"ms": sum(t["ms"] for t in ts) / len(ts), "bytes": ts[-1]["bytes"]} for stage, ts in stage_ms.items()}
+        dominant = max(per_stage, key=lambda stage_name: per_stage[stage_name]["ms"])
+        achieved = per_stage[dominant]["bytes"] / (per_stage[dominant]["ms"] * 1e-3) / 1e9 if per_stage[dominant]["ms"] > 0 else 0.0
+        line = {
+            "metric": "chimeric reads/s end-to-end (BAM->fusions.tsv), synthetic, device hot path with inputs resident in HBM",
+            "value": total_fragments * args.steps / elapsed,
+            "unit": "chimeric reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "synthetic %d chimeric fragments per GPU (2x100 bp, 24-contig synthetic genome, GENCODE-like GTF), default filters" % args.fragments,
+                       "fragments_per_gpu": n, "candidates": pipeline.n_candidates,
+                       "stages_timed": "mark_multimappers, annotate, read filters (14), fragment-length samples, find_fusions",
+                       "host_ingest_reads_per_s": n / ingest_seconds},
+            "stage_ms": {stage: round(values["ms"], 3) for stage, values in per_stage.items()},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+        }
+        line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped"} if args.no_cpu_baseline else cpu_baseline(1000, directory)
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

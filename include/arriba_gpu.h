@@ -164,6 +164,9 @@ int agpu_upload_annotation(agpu_ctx* ctx, const agpu_annotation_view* annotation
 int agpu_upload_genome(agpu_ctx* ctx, const agpu_genome_view* genome);               /* assembly_t: source/arriba.cpp:97-98 */
 int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* batch);                  /* chimeric_alignments_t: source/arriba.cpp:119-130 */
 
+/* restore the batch to its state right after agpu_upload_batch (filters, strands and gene sets cleared) so that the stages can be run again */
+int agpu_reset(agpu_ctx* ctx);
+
 /* mark_multimappers (source/read_chimeric_alignments.cpp:792-802); returns the reference's "marked" count in *marked */
 int agpu_mark_multimappers(agpu_ctx* ctx, uint64_t* marked);
 

@@ -152,6 +152,8 @@ int emu_upload_batch(emu_ctx* ctx, const agpu_batch_view* in) {
 	return 0;
 }
 
+int emu_reset(emu_ctx*) { g_error = "emu_reset is not provided by the stepping harness"; return AGPU_ERR_INVALID; }
+
 int emu_mark_multimappers(emu_ctx* ctx, uint64_t* marked) {
 	BatchView& b = ctx->batch;
 	uint64_t count = 0;

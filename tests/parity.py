@@ -104,3 +104,47 @@ def check_scalars(pipeline, golden):
         assert bits(pipeline.scalars["read_length_mean"]) == int(scalars["read_length_mean_bits"], 16)
     log = open(os.path.join(golden, "reference.log")).read()
     assert pipeline.remaining == datasets.parse_remaining(log)
+
+
+def check_candidates(session, pipeline, golden):
+    """candidate table after find_fusions vs the reference's fusions_t dump (every field and the three read lists)"""
+    fusions = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "find_fusions"))
+    table = pipeline.candidates()
+    assert len(fusions) == pipeline.n_candidates
+    names = session.fragment_names()
+    offsets = table["list_offset"].astype(np.int64)
+    lists = table["read_lists"]
+    mine = {}
+    for c in range(pipeline.n_candidates):
+        flags = int(table["flags"][c])
+        key = (int(table["gene1"][c]), int(table["gene2"][c]), int(table["contigs"][c]) >> 16, int(table["contigs"][c]) & 0xFFFF,
+               int(table["breakpoint1"][c]), int(table["breakpoint2"][c]), flags & 1, (flags >> 1) & 1)
+        mine[key] = c
+    assert len(mine) == pipeline.n_candidates
+    problems = []
+    with_lists = None
+    for f in fusions:
+        key = (f["gene1"], f["gene2"], f["contig1"], f["contig2"], f["breakpoint1"], f["breakpoint2"], f["direction1"], f["direction2"])
+        if key not in mine:
+            problems.append(("missing", key))
+            continue
+        c = mine[key]
+        flags = int(table["flags"][c])
+        got = {"filter": int(table["filter"][c]), "split_reads1": int(table["split_reads1"][c]), "split_reads2": int(table["split_reads2"][c]),
+               "discordant_mates": int(table["discordant_mates"][c]), "exonic1": (flags >> 2) & 1, "exonic2": (flags >> 3) & 1, "spliced1": (flags >> 4) & 1, "spliced2": (flags >> 5) & 1,
+               "predicted_strand1": (flags >> 6) & 1, "predicted_strand2": (flags >> 7) & 1, "predicted_strands_ambiguous": (flags >> 8) & 1,
+               "transcript_start": (flags >> 9) & 1, "transcript_start_ambiguous": (flags >> 10) & 1,
+               "anchor_start1": int(table["anchor_start1"][c]), "anchor_start2": int(table["anchor_start2"][c])}
+        for field, value in got.items():
+            if value != f[field]:
+                problems.append((field, key, value, f[field]))
+        for k, field in enumerate(("split_read1_list", "split_read2_list", "discordant_mate_list")):
+            reads = lists[offsets[3 * c + k]:offsets[3 * c + k + 1]]
+            expected = f[field]
+            if len(expected) == 1 and expected[0].isdigit():  # dumps written with ARRIBA_ORACLE_DUMP_LISTS=0 hold the list size only
+                if len(reads) != int(expected[0]):
+                    problems.append((field + ".size", key, len(reads), int(expected[0])))
+            elif [names[r] for r in reads] != expected:
+                problems.append((field, key))
+    assert not problems, problems[:10]
+    return len(fusions)

@@ -22,6 +22,9 @@ def test_read_level_cascade_matches_reference(name, dataset_files):
     parity.check_scalars(pipeline, golden)
     if name != "mid30k":
         parity.check_annotation(session, pipeline, golden)
+    if name == "toy3k":
+        pipeline.find_fusions()
+        assert parity.check_candidates(session, pipeline, golden) > 1000
 
 
 def test_live_reference_on_larger_dataset(built, tmp_path):
@@ -45,6 +48,8 @@ def test_live_reference_on_larger_dataset(built, tmp_path):
     parity.check_read_filters(session, pipeline, dump)
     parity.check_scalars(pipeline, dump)
     parity.check_annotation(session, pipeline, dump)
+    pipeline.find_fusions()
+    assert parity.check_candidates(session, pipeline, dump) > 10000
 
 
 def test_cascade_properties_at_scale(built, tmp_path):
@@ -62,8 +67,19 @@ def test_cascade_properties_at_scale(built, tmp_path):
     assert all(a >= b for a, b in zip(counts, counts[1:])) and counts[0] <= first.n
     filters = first.filters()
     assert int((filters == 0).sum()) == remaining["low_entropy"]
+    first.find_fusions()
+    table = first.candidates()
+    # every read is emitted once per gene pair; the candidate table partitions the emissions
+    assert int(table["list_offset"][-1]) == len(table["read_lists"])
+    assert (table["split_reads1"] <= 300).all() and (table["split_reads2"] <= 300).all() and (table["discordant_mates"] <= 300).all()
+    unfiltered = table["filter"] == 0
+    assert ((table["split_reads1"] + table["split_reads2"] + table["discordant_mates"])[unfiltered] >= 1).all()
     second = DevicePipeline(session)
     second.run_read_level()
+    second.find_fusions()
+    again = second.candidates()
+    for key in table:
+        assert np.array_equal(table[key], again[key]), key
     assert np.array_equal(filters, second.filters())
     for slot in range(3):
         count1, genes1 = first.gene_sets(slot)

@@ -62,6 +62,9 @@ def test_device_logic_on_host_matches_reference(name, dataset_files, emu_api):
     parity.check_scalars(pipeline, golden)
     if name != "mid30k":
         parity.check_annotation(session, pipeline, golden)
+    if name == "toy3k":
+        pipeline.find_fusions()
+        assert parity.check_candidates(session, pipeline, golden) > 1000
     if name == "mid30k":
         assert pipeline.scalars["estimated"] and pipeline.scalars["mate_gap_samples"] >= 10000
 

@@ -932,7 +932,7 @@ static void usage() {
 		"usage: gen_synth --out PREFIX [--seed N] [--fragments N] [--normal-mult X] [--contigs N] [--contig-len N]\n"
 		"                 [--genes-per-mb X] [--read-len N] [--junctions N] [--clip-min N] [--clip-max N]\n"
 		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--shuffle] [--separate-mates]\n"
-		"                 [--stranded] [--no-viral] [--reference-only]\n"
+		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH]\n"
 		"writes PREFIX.fa PREFIX.gtf PREFIX.bam\n");
 }
 
@@ -940,6 +940,7 @@ int main(int argc, char** argv) {
 	synth::Config config;
 	std::string out;
 	bool reference_only = false;
+	std::string raw_bam_path;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
 		auto value = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
@@ -963,16 +964,24 @@ int main(int argc, char** argv) {
 		else if (a == "--stranded") config.stranded = true;
 		else if (a == "--no-viral") config.viral = false;
 		else if (a == "--reference-only") reference_only = true;
+		else if (a == "--raw-bam-to") raw_bam_path = value();
 		else { usage(); return 1; }
 	}
 	if (out.empty()) { usage(); return 1; }
 	try {
 		synth::Generator generator(config);
 		generator.build_reference();
-		generator.write_fasta(out + ".fa");
-		generator.write_gtf(out + ".gtf");
-		if (!reference_only)
-			generator.write_bam(out + ".bam");
+		if (!raw_bam_path.empty()) { // stream the raw (un-BGZF'd) BAM records to a file or FIFO; the reference files are not rewritten
+			FILE* raw = fopen(raw_bam_path.c_str(), "wb");
+			if (raw == NULL) throw std::runtime_error("cannot write " + raw_bam_path);
+			generator.stream_bam([&](const uint8_t* data, size_t size) { if (fwrite(data, 1, size, raw) != size) throw std::runtime_error("short write"); });
+			fclose(raw);
+		} else {
+			generator.write_fasta(out + ".fa");
+			generator.write_gtf(out + ".gtf");
+			if (!reference_only)
+				generator.write_bam(out + ".bam");
+		}
 		fprintf(stderr, "gen_synth: %zu contigs, %zu genes, %ld records\n", generator.contig_names().size(), generator.genes().size(), generator.records_written());
 	} catch (const std::exception& e) {
 		fprintf(stderr, "gen_synth: %s\n", e.what());
