@@ -41,13 +41,19 @@ inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1
 // ---- kernels ------------------------------------------------------------------------------------
 
 __global__ void mark_multimappers_kernel(BatchView b, uint32_t* counters) {
+	__shared__ unsigned int marked;
+	if (threadIdx.x == 0) marked = 0;
+	__syncthreads();
 	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i >= b.n) return;
-	uint32_t group = b.group[i];
-	bool same_as_previous = i > 0 && b.group[i - 1] == group;
-	bool same_as_next = i + 1 < b.n && b.group[i + 1] == group;
-	if (same_as_previous || same_as_next) b.fbits[i] |= FBIT_MULTIMAPPER;
-	if (same_as_next) atomicAdd(&counters[COUNTER_MARKED], 1u); // the compiler folds this into one add per wave
+	if (i < b.n) {
+		uint32_t group = b.group[i];
+		bool same_as_previous = i > 0 && b.group[i - 1] == group;
+		bool same_as_next = i + 1 < b.n && b.group[i + 1] == group;
+		if (same_as_previous || same_as_next) b.fbits[i] |= FBIT_MULTIMAPPER;
+		if (same_as_next) atomicAdd(&marked, 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && marked) atomicAdd(&counters[COUNTER_MARKED], marked);
 }
 
 __global__ void annotate_stage1_kernel(BatchView b, AnnotationView ann, uint32_t strandedness, uint64_t* unmapped_keys, uint32_t* counters) {
@@ -124,7 +130,7 @@ __global__ void duplicate_insert_kernel(uint64_t n, const DuplicateKey* keys, ui
 			owner = atomicCAS(&slots[h], EMPTY_SLOT, (uint32_t) i);
 			if (owner == EMPTY_SLOT) return;
 		}
-		if (keys_equal(keys[owner], key)) { atomicMin(&slots[h], (uint32_t) i); return; }
+		if (keys_equal(keys[owner], key)) { if ((uint32_t) i < owner) atomicMin(&slots[h], (uint32_t) i); return; } // the slot only ever decreases
 		h = (h + 1) & mask;
 	}
 }
@@ -206,24 +212,42 @@ __global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint
 	if (threadIdx.x == 0) counters[COUNTER_SAMPLES] = base < MAX_SAMPLES ? base : MAX_SAMPLES;
 }
 
+// read_through ... mismatches: one thread per fragment, no LDS
 __global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationView ann, GenomeView genome, FilterTables t, const uint8_t* enabled, unsigned long long* stage_counts) {
-	__shared__ uint16_t previous_position[64 * BLOCK];
-	__shared__ uint8_t count_all[64 * BLOCK], count_aligned1[64 * BLOCK], count_aligned2[64 * BLOCK];
 	__shared__ unsigned int hits[10];
 	if (threadIdx.x < 10) hits[threadIdx.x] = 0;
 	__syncthreads();
 	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i < b.n) {
-		KmerScratch scratch;
-		scratch.previous_position = previous_position + threadIdx.x; scratch.count_all = count_all + threadIdx.x;
-		scratch.count_aligned1 = count_aligned1 + threadIdx.x; scratch.count_aligned2 = count_aligned2 + threadIdx.x; scratch.stride = BLOCK;
 		uint32_t first_hit;
-		uint8_t filter = read_filters_stage2(b, ann, genome, t, enabled, i, b.filter[i], scratch, first_hit);
-		b.filter[i] = filter;
-		atomicAdd(&hits[first_hit], 1u);
+		uint8_t before = b.filter[i];
+		uint8_t filter = read_filters_stage2(b, ann, genome, t, enabled, i, before, no_stage(), first_hit);
+		if (filter != before) b.filter[i] = filter;
+		if (first_hit < 9) atomicAdd(&hits[first_hit], 1u);
 	}
 	__syncthreads();
 	if (threadIdx.x < 10 && hits[threadIdx.x]) atomicAdd(&stage_counts[5 + threadIdx.x], (unsigned long long) hits[threadIdx.x]);
+}
+
+// low_entropy: 3-mer counters of a thread live in LDS, interleaved so that a thread always hits its own bank
+const int ENTROPY_BLOCK = 128;
+__global__ void __launch_bounds__(ENTROPY_BLOCK) low_entropy_kernel(BatchView b, FilterTables t, unsigned long long* stage_counts) {
+	__shared__ uint32_t counters[64 * ENTROPY_BLOCK];
+	__shared__ unsigned int hits;
+	if (threadIdx.x == 0) hits = 0;
+	KmerScratch scratch; scratch.counters = counters + threadIdx.x; scratch.stride = ENTROPY_BLOCK;
+	scratch.clear();
+	__syncthreads();
+	uint64_t i = blockIdx.x * (uint64_t) ENTROPY_BLOCK + threadIdx.x;
+	if (i < b.n) {
+		uint8_t filter = b.filter[i];
+		if (needs_low_entropy_test(b, t, i, filter) && has_low_entropy(b, t, i, scratch, no_stage())) {
+			if (filter == FILTER_none) atomicAdd(&hits, 1u);
+			b.filter[i] = FILTER_low_entropy;
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && hits) atomicAdd(&stage_counts[13], (unsigned long long) hits);
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------
@@ -651,7 +675,11 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 	hipStream_t s = ctx->stream;
 	const uint64_t n = ctx->n;
 	begin_timing(ctx);
-	if (n > 0) stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->stage_counts.as<unsigned long long>());
+	if (n > 0) {
+		stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->stage_counts.as<unsigned long long>());
+		if (ctx->params.filter_enabled[FILTER_low_entropy])
+			low_entropy_kernel<<<(unsigned int) ((n + ENTROPY_BLOCK - 1) / ENTROPY_BLOCK), ENTROPY_BLOCK, 0, s>>>(ctx->batch, ctx->tables, ctx->stage_counts.as<unsigned long long>());
+	}
 	TRY(end_timing(ctx, ctx->batch_input_bytes + n * (3 * (1 + GENE_INLINE * 4) + 2) + n * 200 /* reference bases gathered by the mismatch walk */));
 	unsigned long long counts[16];
 	HIP_CHECK(hipMemcpy(counts, ctx->stage_counts.ptr, sizeof(counts), hipMemcpyDeviceToHost));

@@ -54,7 +54,7 @@ __global__ void candidate_insert_kernel(uint32_t M, const FusionEmission* emissi
 			owner = atomicCAS(&slots[h], EMPTY_SLOT, e);
 			if (owner == EMPTY_SLOT) return;
 		}
-		if (same_candidate(emissions[owner], mine)) { atomicMin(&slots[h], e); return; }
+		if (same_candidate(emissions[owner], mine)) { if (e < owner) atomicMin(&slots[h], e); return; } // the slot only ever decreases
 		h = (h + 1) & mask;
 	}
 }
@@ -133,9 +133,15 @@ AGPU_HD uint32_t lower_bound_key(const uint64_t* keys, uint32_t n, uint64_t valu
 	return lo;
 }
 
-// one thread per candidate; fill == false: count pass, fill == true: write lists / anchors / swap flags
+const uint32_t SMALL_BUCKET = 24;  // buckets up to this size are walked by the candidate's own thread, larger ones by a whole wave
+const uint32_t SMALL_LIST = 32;
+
+struct BucketRef { uint32_t candidate, begin, end; };
+
+// one thread per candidate: small buckets are handled inline, large ones are queued for the wave kernel.
+// fill == false: count pass (list sizes), fill == true: write lists / anchors / swap flags
 __global__ void attach_discordant_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint64_t* bucket_keys, const FusionEmission* bucket_emissions, uint32_t Md,
-                                         int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, bool fill) {
+                                         int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, BucketRef* worklist, uint32_t* worklist_size, bool fill) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n) return;
 	if (t.filter[c] != FILTER_none) return;
@@ -143,6 +149,11 @@ __global__ void attach_discordant_kernel(BatchView b, AnnotationView ann, Candid
 	uint64_t key = gene_pair_key(t.gene1[c], t.gene2[c], ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u));
 	uint32_t begin = lower_bound_key(bucket_keys, Md, key), end = lower_bound_key(bucket_keys, Md, key + 1);
 	if (begin == end) return;
+	if (end - begin > SMALL_BUCKET) {
+		BucketRef ref; ref.candidate = c; ref.begin = begin; ref.end = end;
+		worklist[atomicAdd(worklist_size, 1u)] = ref;
+		return;
+	}
 	bool has_split_reads;
 	uint32_t* out_list = nullptr;
 	if (fill) {
@@ -152,8 +163,82 @@ __global__ void attach_discordant_kernel(BatchView b, AnnotationView ann, Candid
 	} else {
 		has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
 	}
-	uint32_t size = attach_discordant_mates(b, ann, t, c, bucket_emissions + begin, end - begin, max_mate_gap, threshold, has_split_reads, fill ? out_list : nullptr, discordant_swapped);
+	uint32_t size = attach_discordant_mates(b, ann, t, c, bucket_emissions + begin, end - begin, max_mate_gap, threshold, has_split_reads, out_list, discordant_swapped);
 	if (!fill) list_size[3 * (uint64_t) c + 2] = size;
+}
+
+__device__ __forceinline__ AnchorFold wave_fold_in_lane_order(AnchorFold mine, bool upstream) {
+	for (int offset = 1; offset < 64; offset <<= 1) {
+		AnchorFold other;
+		other.has_zero = __shfl_down(mine.has_zero, offset);
+		other.value = __shfl_down(mine.value, offset);
+		mine = anchor_combine(mine, other, upstream);
+	}
+	return mine; // lane 0 holds the fold over lanes 0..63 in order
+}
+
+// one wave per queued candidate: 64 discordant mates are tested at once; the order-dependent subsampling rule of the reference
+// (source/fusions.cpp:398-407) becomes prefix popcounts over the ballots
+__global__ void attach_discordant_wave_kernel(BatchView b, AnnotationView ann, CandidateTable t, const FusionEmission* bucket_emissions, int32_t max_mate_gap, uint32_t threshold,
+                                              uint32_t* list_size, uint8_t* discordant_swapped, const BucketRef* worklist, const uint32_t* worklist_size, bool fill) {
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (wave >= *worklist_size) return;
+	const BucketRef ref = worklist[wave];
+	const uint32_t c = ref.candidate;
+	const uint32_t flags = t.flags[c];
+	const bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
+	const uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
+	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
+	bool has_split_reads;
+	uint32_t* out_list = nullptr;
+	if (fill) {
+		const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+		has_split_reads = offsets[2] > offsets[0];
+		out_list = t.read_lists + offsets[2];
+	} else {
+		has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
+	}
+	const unsigned long long lanes_before = (1ull << lane) - 1;
+	uint32_t passing = 0, unfiltered = 0, appended = 0;
+	AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
+	for (uint32_t base = ref.begin; base < ref.end; base += 64) {
+		const uint32_t k = base + lane;
+		bool pass = false, is_unfiltered = false;
+		FusionEmission e;
+		if (k < ref.end) {
+			e = bucket_emissions[k];
+			pass = discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, e.breakpoint1, e.breakpoint2);
+			is_unfiltered = pass && (e.info >> EINFO_FILTER_SHIFT & 255) == FILTER_none;
+		}
+		const unsigned long long ballot_pass = __ballot(pass), ballot_unfiltered = __ballot(is_unfiltered);
+		const uint32_t position = passing + __popcll(ballot_pass & lanes_before);
+		const uint32_t unfiltered_before = unfiltered + __popcll(ballot_unfiltered & lanes_before);
+		const bool joins = pass && (position < threshold || (is_unfiltered && unfiltered_before < threshold));
+		const unsigned long long ballot_joins = __ballot(joins);
+		if (fill) {
+			if (joins) {
+				out_list[appended + __popcll(ballot_joins & lanes_before)] = e.read;
+				if (discordant_mates_need_swap(b, e.read)) discordant_swapped[e.read] = 1;
+			}
+			AnchorFold chunk1 = wave_fold_in_lane_order(joins ? anchor_single(e.anchor1, upstream1) : anchor_identity(), upstream1);
+			AnchorFold chunk2 = wave_fold_in_lane_order(joins ? anchor_single(e.anchor2, upstream2) : anchor_identity(), upstream2);
+			fold1 = anchor_combine(fold1, chunk1, upstream1);
+			fold2 = anchor_combine(fold2, chunk2, upstream2);
+		}
+		passing += __popcll(ballot_pass);
+		unfiltered += __popcll(ballot_unfiltered);
+		appended += __popcll(ballot_joins);
+		if (unfiltered >= threshold) break; // the reference stops at the next unfiltered mate; filtered ones no longer fit either
+	}
+	if (lane == 0) {
+		if (fill) {
+			t.discordant_mates[c] = unfiltered < threshold ? unfiltered : threshold;
+			t.anchor1[c] = anchor_apply(t.anchor1[c], fold1, upstream1);
+			t.anchor2[c] = anchor_apply(t.anchor2[c], fold2, upstream2);
+		} else {
+			list_size[3 * (uint64_t) c + 2] = appended;
+		}
+	}
 }
 
 __global__ void split_list_fill_kernel(uint32_t M, const FusionEmission* sorted, const uint32_t* candidate_of, const RankState* ranks, const CandidateFold* folds, uint32_t threshold, CandidateTable t) {
@@ -166,10 +251,27 @@ __global__ void split_list_fill_kernel(uint32_t M, const FusionEmission* sorted,
 	t.read_lists[t.list_offset[3 * (uint64_t) c + side] + folds[j].list_size[side] - 1] = e.read;
 }
 
-__global__ void finish_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint8_t* discordant_swapped) {
+// strands / splice sites / transcript start: short read lists inline, long ones queued for the wave kernel
+__global__ void finish_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint8_t* discordant_swapped, uint32_t* worklist, uint32_t* worklist_size) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n) return;
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	if (offsets[3] - offsets[0] > SMALL_LIST) { worklist[atomicAdd(worklist_size, 1u)] = c; return; }
 	finish_candidate(b, ann, t, discordant_swapped, c);
+}
+
+__global__ void finish_wave_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint8_t* discordant_swapped, const uint32_t* worklist, const uint32_t* worklist_size) {
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (wave >= *worklist_size) return;
+	const uint32_t c = worklist[wave];
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	uint32_t forward = 0, reverse = 0;
+	for (uint32_t k = offsets[0] + lane; k < offsets[3]; k += 64) {
+		int vote = list_entry_strand_vote(b, t, discordant_swapped, c, k);
+		if (vote == 1) ++forward; else if (vote == 2) ++reverse;
+	}
+	for (int offset = 32; offset > 0; offset >>= 1) { forward += __shfl_down(forward, offset); reverse += __shfl_down(reverse, offset); }
+	if (lane == 0) finalize_candidate(ann, t, c, forward, reverse);
 }
 
 struct Scratch { // grows on demand; reused by every rocprim call
@@ -289,7 +391,16 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	}
 
 	// ---- discordant mates: count, offsets, fill
-	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), false);
+	DeviceBuffer bucket_worklist, finish_worklist, worklist_sizes;
+	ALLOC(bucket_worklist, (size_t) C * sizeof(BucketRef)); ALLOC(finish_worklist, (size_t) C * 4); ALLOC(worklist_sizes, 16);
+	HIP_CHECK(hipMemsetAsync(worklist_sizes.ptr, 0, 16, s));
+	uint32_t* worklist_counts = worklist_sizes.as<uint32_t>(); // [0] attach (count pass), [1] attach (fill pass), [2] finish
+	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
+	uint32_t queued = 0;
+	HIP_CHECK(hipMemcpyAsync(&queued, worklist_counts + 0, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (queued > 0)
+		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_emissions.as<FusionEmission>(), max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
 	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
 	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
@@ -300,8 +411,15 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	t.read_lists = ctx->cand_read_lists.as<uint32_t>();
 	ctx->n_list_entries = total_list;
 	split_list_fill_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), candidate_of.as<uint32_t>(), ranks.as<RankState>(), folds.as<CandidateFold>(), threshold, t);
-	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), true);
-	finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>());
+	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
+	if (queued > 0) // the fill pass queues the same candidates (possibly in another order)
+		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_emissions.as<FusionEmission>(), max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
+	finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>(), finish_worklist.as<uint32_t>(), worklist_counts + 2);
+	{
+		// upper bound of the number of long lists without a round trip: every queued candidate owns more than SMALL_LIST list entries
+		uint64_t max_long = std::min<uint64_t>(C, (uint64_t) total_list / (SMALL_LIST + 1) + 1);
+		finish_wave_kernel<<<grid_for(max_long * 64), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>(), finish_worklist.as<uint32_t>(), worklist_counts + 2);
+	}
 
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));

@@ -41,24 +41,39 @@ AGPU_HD uint32_t preclipping(const uint32_t* cigar, uint32_t n) { uint32_t op = 
 AGPU_HD uint32_t postclipping(const uint32_t* cigar, uint32_t n) { uint32_t op = cigar[n - 1] & 15; return (op == CIGAR_S || op == CIGAR_H) ? cigar[n - 1] >> 4 : 0; }
 AGPU_HD const uint32_t* cigar_of(const BatchView& b, int slot, uint64_t i) { return b.cigar_pool + b.cigar_offset[slot][i]; }
 
-// BAM 4-bit code -> ASCII as the reference stores it (seq_nt16_str)
+// BAM 4-bit code -> ASCII as the reference stores it (seq_nt16_str = "=ACMGRSVTWYHKDBN"), from two 64-bit register constants
 AGPU_HD char base_char(uint32_t code) {
-	switch (code) {
-		case 0: return '='; case 1: return 'A'; case 2: return 'C'; case 3: return 'M'; case 4: return 'G'; case 5: return 'R'; case 6: return 'S'; case 7: return 'V';
-		case 8: return 'T'; case 9: return 'W'; case 10: return 'Y'; case 11: return 'H'; case 12: return 'K'; case 13: return 'D'; case 14: return 'B'; default: return 'N';
-	}
+	const uint64_t low = 0x56535247'4d43413dULL, high = 0x4e42444b'48595754ULL; // "=ACMGRSV" / "TWYHKDBN", little endian
+	return (char) (((code & 8) ? high : low) >> ((code & 7) * 8));
 }
-AGPU_HD uint32_t base_code(const uint8_t* packed, uint32_t position) { return (packed[position >> 1] >> ((~position & 1) << 2)) & 15; }
+// sequences are packed two bases per byte (high nibble first) and start on a 4-byte boundary: read them as 32-bit words
+AGPU_HD uint32_t base_code_from_words(const uint32_t* words, uint32_t position) {
+	uint32_t word = words[position >> 3];
+	return (word >> ((((position & 7) >> 1) << 3) + ((~position & 1) << 2))) & 15;
+}
 // complement on codes (reference: dna_to_complement, source/assembly.hpp:9-21 swaps only A<->T and C<->G)
 AGPU_HD uint32_t complement_code(uint32_t code) { return code == 1 ? 8 : code == 8 ? 1 : code == 2 ? 4 : code == 4 ? 2 : code; }
 
 struct SequenceRef {
-	const uint8_t* packed; uint32_t length; bool reverse_complement;
-	AGPU_HD uint32_t code(uint32_t position) const { return reverse_complement ? complement_code(base_code(packed, length - 1 - position)) : base_code(packed, position); }
+	const uint32_t* words; uint32_t length; bool reverse_complement;
+	AGPU_HD uint32_t code(uint32_t position) const { return reverse_complement ? complement_code(base_code_from_words(words, length - 1 - position)) : base_code_from_words(words, position); }
 	AGPU_HD char at(uint32_t position) const { return base_char(code(position)); }
 };
-AGPU_HD SequenceRef sequence_of(const BatchView& b, int slot, uint64_t i) {
-	SequenceRef s; s.packed = b.seq_pool + (uint64_t) b.seq_offset[slot][i] * 4; s.length = b.seq_length[slot][i]; s.reverse_complement = false; return s;
+// The kernels may stage the sequence pool span of a workgroup in LDS; `staged` then points at the LDS copy of pool word
+// `staged_first_word` and covers `staged_words` words.  Sequences outside the staged span are read from HBM.
+struct SequenceStage { const uint32_t* staged; uint32_t staged_first_word, staged_words; };
+AGPU_HD SequenceStage no_stage() { SequenceStage s; s.staged = 0; s.staged_first_word = 0; s.staged_words = 0; return s; }
+AGPU_HD SequenceRef sequence_of(const BatchView& b, int slot, uint64_t i, const SequenceStage& stage) {
+	SequenceRef s;
+	uint32_t first_word = b.seq_offset[slot][i];
+	s.length = b.seq_length[slot][i];
+	uint32_t words = (s.length + 7) >> 3;
+	if (stage.staged != 0 && first_word >= stage.staged_first_word && first_word + words <= stage.staged_first_word + stage.staged_words)
+		s.words = stage.staged + (first_word - stage.staged_first_word);
+	else
+		s.words = (const uint32_t*) b.seq_pool + first_word;
+	s.reverse_complement = false;
+	return s;
 }
 
 // ---- duplicates -----------------------------------------------------------------------------------
@@ -212,9 +227,9 @@ AGPU_HD bool split_read_is_spliced(const BatchView& b, const AnnotationView& ann
 	return false;
 }
 
-AGPU_HD bool has_homopolymer_at_breakpoint(const BatchView& b, const AnnotationView& ann, const FilterTables& t, uint64_t i, const IdSet& split_read_genes) {
+AGPU_HD bool has_homopolymer_at_breakpoint(const BatchView& b, const AnnotationView& ann, const FilterTables& t, uint64_t i, const IdSet& split_read_genes, const SequenceStage& stage) {
 	if (b.n_aln[i] != 3) return false;
-	SequenceRef sequence = sequence_of(b, SPLIT_READ, i);
+	SequenceRef sequence = sequence_of(b, SPLIT_READ, i, stage);
 	const uint32_t* cigar = cigar_of(b, SPLIT_READ, i); uint32_t n_cigar = b.cigar_count[SPLIT_READ][i];
 	uint32_t H = t.homopolymer_length, length = sequence.length;
 	// the reference concatenates up to two H-mers, each followed by a blank; segments: [start, start+H)
@@ -334,16 +349,18 @@ AGPU_HD bool is_hairpin(const BatchView& b, uint64_t i, const IdSet* genes) {
 	       breakpoint_within_aligned_segment(b, MATE1, i, breakpoint_supp);
 }
 
-// reference: count_mismatches + test_mismatch_probability, source/filter_mismatches.cpp:12-99
+// reference: count_mismatches + test_mismatch_probability, source/filter_mismatches.cpp:12-99.  The genome is read one
+// aligned 32-bit word per four bases.
 AGPU_HD bool has_too_many_mismatches(const BatchView& b, const GenomeView& genome, const FilterTables& t, uint64_t i, int slot, const SequenceRef& sequence, bool is_multimapper) {
 	const uint32_t* cigar = cigar_of(b, slot, i); uint32_t n = b.cigar_count[slot][i];
 	uint32_t contig = b.contig[slot][i];
 	uint64_t contig_begin = genome.contig_offset[contig], contig_size = genome.contig_offset[contig + 1] - contig_begin;
-	const char* reference = genome.bases + contig_begin;
+	const uint32_t* genome_words = (const uint32_t*) genome.bases;
 	bool forward = b.abits[slot][i] & ABIT_STRAND;
 	uint32_t mismatches = 0, alignment_length = 0;
 	int64_t reference_position = b.start[slot][i];
 	uint32_t read_position = 0;
+	uint64_t cached_word_index = ~0ull; uint32_t cached_word = 0;
 	for (uint32_t c = 0; c < n; ++c) {
 		uint32_t op = cigar[c] & 15, length = cigar[c] >> 4;
 		switch (op) {
@@ -364,9 +381,15 @@ AGPU_HD bool has_too_many_mismatches(const BatchView& b, const GenomeView& genom
 				break;
 			case CIGAR_M: case CIGAR_EQ: case CIGAR_X:
 				for (uint32_t k = 0; k < length; ++k) {
-					char base = (read_position < sequence.length) ? sequence.at(read_position) : '\0';
-					if (base != 'N') {
-						char reference_base = (reference_position >= 0 && (uint64_t) reference_position < contig_size) ? reference[reference_position] : '\0';
+					uint32_t code = (read_position < sequence.length) ? sequence.code(read_position) : 16;
+					if (code != 15) { // 'N' bases are skipped
+						char reference_base = '\0';
+						if (reference_position >= 0 && (uint64_t) reference_position < contig_size) {
+							uint64_t byte_index = contig_begin + (uint64_t) reference_position;
+							if ((byte_index >> 2) != cached_word_index) { cached_word_index = byte_index >> 2; cached_word = genome_words[cached_word_index]; }
+							reference_base = (char) (cached_word >> ((byte_index & 3) << 3));
+						}
+						char base = (code < 16) ? base_char(code) : '\0';
 						if (base != reference_base) mismatches++;
 						alignment_length++;
 					}
@@ -384,17 +407,17 @@ AGPU_HD bool has_too_many_mismatches(const BatchView& b, const GenomeView& genom
 	return (t.mismatch_verdict[bit >> 5] >> (bit & 31)) & 1;
 }
 
-AGPU_HD bool fails_mismatch_filter(const BatchView& b, const GenomeView& genome, const FilterTables& t, uint64_t i) {
+AGPU_HD bool fails_mismatch_filter(const BatchView& b, const GenomeView& genome, const FilterTables& t, uint64_t i, const SequenceStage& stage) {
 	bool multimapper = b.fbits[i] & FBIT_MULTIMAPPER;
 	int other = (b.n_aln[i] == 2) ? MATE2 : SUPPLEMENTARY;
 	bool viral1 = genome.contig_bits[b.contig[MATE1][i]] & CBIT_VIRAL, viral2 = genome.contig_bits[b.contig[other][i]] & CBIT_VIRAL;
-	if (!viral1 && has_too_many_mismatches(b, genome, t, i, MATE1, sequence_of(b, MATE1, i), multimapper && !viral2))
+	if (!viral1 && has_too_many_mismatches(b, genome, t, i, MATE1, sequence_of(b, MATE1, i, stage), multimapper && !viral2))
 		return true;
 	if (!viral2) {
 		SequenceRef sequence;
-		if (b.n_aln[i] == 2) sequence = sequence_of(b, MATE2, i);
+		if (b.n_aln[i] == 2) sequence = sequence_of(b, MATE2, i, stage);
 		else {
-			sequence = sequence_of(b, SPLIT_READ, i);
+			sequence = sequence_of(b, SPLIT_READ, i, stage);
 			sequence.reverse_complement = ((b.abits[SUPPLEMENTARY][i] ^ b.abits[SPLIT_READ][i]) & ABIT_STRAND) != 0;
 		}
 		if (has_too_many_mismatches(b, genome, t, i, other, sequence, multimapper && !viral1))
@@ -404,7 +427,7 @@ AGPU_HD bool fails_mismatch_filter(const BatchView& b, const GenomeView& genome,
 }
 
 // reference: kmer_to_int with k=3 (source/filter_mismappers.cpp:33-45): T=0, G=1, C=2, everything else 3
-AGPU_HD uint32_t kmer_digit(uint32_t code) { return code == 8 ? 0 : code == 4 ? 1 : code == 2 ? 2 : 3; }
+AGPU_HD uint32_t kmer_digit(uint32_t code) { return (0xFFFCFDEFu >> (code << 1)) & 3u; } // 2-bit table: code 8 (T) -> 0, 4 (G) -> 1, 2 (C) -> 2, others 3
 
 AGPU_HD uint32_t kmer_threshold(const FilterTables& t, uint32_t length) {
 	if (length < t.kmer_threshold_size) return t.kmer_threshold[length];
@@ -420,19 +443,23 @@ AGPU_HD bool looks_like_internal_tandem_duplication(const BatchView& b, const Fi
 	return b.end[SPLIT_READ][i] > b.start[SUPPLEMENTARY][i] && b.end[SPLIT_READ][i] <= b.start[SUPPLEMENTARY][i] + max_itd;
 }
 
-// Per-thread counters for the 64 possible 3-mers.  `stride` lets the kernel interleave the counters of a
-// workgroup in LDS (bank = thread), the host harness uses stride 1.
+// Per-thread counters for the 64 possible 3-mers: one 32-bit word per k-mer = tag (8 bits) | count in aligned segment 2 | count in
+// aligned segment 1 | count in the whole read (8 bits each).  A word whose tag differs from the current tag counts as zero, so the
+// 64 words are cleared once per thread, not once per read.  `stride` interleaves the counters of a workgroup in LDS (bank = thread);
+// the host harness uses stride 1.
 struct KmerScratch {
-	uint16_t* previous_position; uint8_t* count_all; uint8_t* count_aligned1; uint8_t* count_aligned2; uint32_t stride;
-	AGPU_HD void reset() {
-		for (uint32_t k = 0; k < 64; ++k) { previous_position[k * stride] = 0; count_all[k * stride] = 0; count_aligned1[k * stride] = 0; count_aligned2[k * stride] = 0; }
-	}
+	uint32_t* counters; uint32_t stride; uint32_t tag;
+	AGPU_HD void clear() { for (uint32_t k = 0; k < 64; ++k) counters[k * stride] = 0; tag = 0; }
+	AGPU_HD void next_read() { if (++tag == 256) clear(), tag = 1; }
 };
 
-AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t i, KmerScratch& scratch) {
-	const uint32_t K = 3;
+// reference: source/filter_low_entropy.cpp:33-101.  The reference counts an occurrence of a 3-mer only if it starts at or after the
+// end of the previously counted occurrence of the same 3-mer; with k = 3 that means "not counted at either of the two preceding
+// positions", so two registers replace its previous_kmer_pos array.
+AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t i, KmerScratch& scratch, const SequenceStage& stage) {
+	const uint32_t K = 3, NONE = 64;
 	for (int mate = MATE1; mate <= MATE2; ++mate) {
-		SequenceRef sequence = sequence_of(b, mate, i);
+		SequenceRef sequence = sequence_of(b, mate, i, stage);
 		uint32_t length = sequence.length;
 		if (length < K) continue;
 		const uint32_t* cigar = cigar_of(b, mate, i); uint32_t n = b.cigar_count[mate][i];
@@ -457,18 +484,34 @@ AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t
 		uint32_t max_count = kmer_threshold(t, length);
 		uint32_t max_count_aligned1 = kmer_threshold(t, aligned_end1 - aligned_start1);
 		uint32_t max_count_aligned2 = kmer_threshold(t, aligned_end2 - aligned_start2);
-		scratch.reset();
-		uint32_t kmer = kmer_digit(sequence.code(0)) << 2 | kmer_digit(sequence.code(1));
-		for (uint32_t position = 0; position < length - K; ++position) { // the last k-mer is skipped, as in the reference (:77)
-			kmer = ((kmer << 2) | kmer_digit(sequence.code(position + 2))) & 63;
-			uint32_t slot = kmer * scratch.stride;
-			if (scratch.previous_position[slot] <= position) {
-				scratch.previous_position[slot] = (uint16_t) (position + K);
-				uint32_t count = ++scratch.count_all[slot];
-				uint32_t count1 = scratch.count_aligned1[slot], count2 = scratch.count_aligned2[slot];
-				if (position + 1 >= aligned_start1 && position < aligned_end1) count1 = ++scratch.count_aligned1[slot];
-				if (position + 1 >= aligned_start2 && position < aligned_end2) count2 = ++scratch.count_aligned2[slot];
-				if (count >= max_count || count1 >= max_count_aligned1 || count2 >= max_count_aligned2)
+		scratch.next_read();
+		const uint32_t tag = scratch.tag << 24;
+		uint32_t counted_previous = NONE, counted_before_previous = NONE; // 3-mers counted at position-1 / position-2
+		uint32_t kmer = 0;
+		const uint32_t last_position = length - K; // exclusive: the last k-mer is skipped, as in the reference (:77)
+		const uint32_t n_words = (length + 7) >> 3;
+		for (uint32_t w = 0; w < n_words; ++w) {
+			uint32_t word = sequence.words[w];
+			word = ((word & 0x0F0F0F0Fu) << 4) | ((word >> 4) & 0x0F0F0F0Fu); // base j of this word now sits at bits 4j..4j+3
+			uint32_t bases_here = (length - (w << 3)) < 8 ? (length - (w << 3)) : 8;
+			for (uint32_t j = 0; j < bases_here; ++j) {
+				kmer = ((kmer << 2) | kmer_digit((word >> (j << 2)) & 15)) & 63;
+				uint32_t base_position = (w << 3) + j;
+				if (base_position < 2) continue;
+				uint32_t position = base_position - 2; // start of the 3-mer ending at this base
+				if (position >= last_position) break;
+				bool counted = kmer != counted_previous && kmer != counted_before_previous;
+				counted_before_previous = counted_previous;
+				counted_previous = counted ? kmer : NONE;
+				if (!counted) continue;
+				uint32_t* counter = scratch.counters + kmer * scratch.stride;
+				uint32_t value = *counter;
+				if ((value & 0xFF000000u) != tag) value = tag;
+				value += 1u;
+				if (position + 1 >= aligned_start1 && position < aligned_end1) value += 1u << 8;
+				if (position + 1 >= aligned_start2 && position < aligned_end2) value += 1u << 16;
+				*counter = value;
+				if ((value & 255u) >= max_count || ((value >> 8) & 255u) >= max_count_aligned1 || ((value >> 16) & 255u) >= max_count_aligned2)
 					return true;
 			}
 		}
@@ -476,32 +519,30 @@ AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t
 	return false;
 }
 
-// The stage-2 cascade for one fragment; `filter` is the state after stage group 1.  Returns the new filter id.
-// first_hit receives the ordinal (0..8) of the stage that discarded the read, 9 if none (for the per-stage "remaining" counts).
-AGPU_HD uint8_t read_filters_stage2(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const FilterTables& t, const uint8_t* enabled, uint64_t i, uint8_t filter, KmerScratch& scratch, uint32_t& first_hit) {
+// Stage-2 cascade without low_entropy for one fragment; `filter` is the state after stage group 1.  Returns the new filter id.
+// first_hit receives the ordinal (0..7) of the stage that discarded the read, 9 if none (for the per-stage "remaining" counts).
+AGPU_HD uint8_t read_filters_stage2(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const FilterTables& t, const uint8_t* enabled, uint64_t i, uint8_t filter, const SequenceStage& stage, uint32_t& first_hit) {
 	first_hit = 9;
-	if (filter == FILTER_none) {
-		IdSet genes[3];
-		int n_aln = b.n_aln[i];
-		for (int s = 0; s < 3; ++s) { genes[s].clear(); if (s < n_aln) load_genes(b, s, i, genes[s]); }
-		if (enabled[FILTER_read_through] && is_proximal_read_through(b, ann, t, i, genes)) { filter = FILTER_read_through; first_hit = 0; }
-		else if (enabled[FILTER_inconsistently_clipped] && is_inconsistently_clipped(b, i)) { filter = FILTER_inconsistently_clipped; first_hit = 1; }
-		else if (enabled[FILTER_homopolymer] && has_homopolymer_at_breakpoint(b, ann, t, i, genes[SPLIT_READ])) { filter = FILTER_homopolymer; first_hit = 2; }
-		else if (enabled[FILTER_small_insert_size] && has_small_insert_size(b, i, 5)) { filter = FILTER_small_insert_size; first_hit = 3; }
-		else if (enabled[FILTER_long_gap] && has_long_gap(b, i)) { filter = FILTER_long_gap; first_hit = 4; }
-		else if (enabled[FILTER_same_gene] && is_same_gene_artifact(b, i, genes)) { filter = FILTER_same_gene; first_hit = 5; }
-		else if (enabled[FILTER_hairpin] && is_hairpin(b, i, genes)) { filter = FILTER_hairpin; first_hit = 6; }
-		else if (enabled[FILTER_mismatches] && fails_mismatch_filter(b, genome, t, i)) { filter = FILTER_mismatches; first_hit = 7; }
-	}
-	if (enabled[FILTER_low_entropy]) {
-		// ITD-shaped reads are tested even if an earlier filter (other than duplicates) discarded them (source/filter_low_entropy.cpp:29-31)
-		bool test = (filter == FILTER_none) || (filter != FILTER_duplicates && looks_like_internal_tandem_duplication(b, t, i));
-		if (test && has_low_entropy(b, t, i, scratch)) {
-			if (filter == FILTER_none) first_hit = 8;
-			filter = FILTER_low_entropy;
-		}
-	}
+	if (filter != FILTER_none) return filter;
+	IdSet genes[3];
+	int n_aln = b.n_aln[i];
+	for (int s = 0; s < 3; ++s) { genes[s].clear(); if (s < n_aln) load_genes(b, s, i, genes[s]); }
+	if (enabled[FILTER_read_through] && is_proximal_read_through(b, ann, t, i, genes)) { filter = FILTER_read_through; first_hit = 0; }
+	else if (enabled[FILTER_inconsistently_clipped] && is_inconsistently_clipped(b, i)) { filter = FILTER_inconsistently_clipped; first_hit = 1; }
+	else if (enabled[FILTER_homopolymer] && has_homopolymer_at_breakpoint(b, ann, t, i, genes[SPLIT_READ], stage)) { filter = FILTER_homopolymer; first_hit = 2; }
+	else if (enabled[FILTER_small_insert_size] && has_small_insert_size(b, i, 5)) { filter = FILTER_small_insert_size; first_hit = 3; }
+	else if (enabled[FILTER_long_gap] && has_long_gap(b, i)) { filter = FILTER_long_gap; first_hit = 4; }
+	else if (enabled[FILTER_same_gene] && is_same_gene_artifact(b, i, genes)) { filter = FILTER_same_gene; first_hit = 5; }
+	else if (enabled[FILTER_hairpin] && is_hairpin(b, i, genes)) { filter = FILTER_hairpin; first_hit = 6; }
+	else if (enabled[FILTER_mismatches] && fails_mismatch_filter(b, genome, t, i, stage)) { filter = FILTER_mismatches; first_hit = 7; }
 	return filter;
+}
+
+// low_entropy for one fragment (the last read-level filter).  ITD-shaped reads are tested even if an earlier filter other than
+// duplicates discarded them (source/filter_low_entropy.cpp:29-31).  was_unfiltered tells the caller whether the read counted as
+// remaining before this filter.
+AGPU_HD bool needs_low_entropy_test(const BatchView& b, const FilterTables& t, uint64_t i, uint8_t filter) {
+	return filter == FILTER_none || (filter != FILTER_duplicates && looks_like_internal_tandem_duplication(b, t, i));
 }
 
 }

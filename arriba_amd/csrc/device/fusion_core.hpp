@@ -386,28 +386,25 @@ AGPU_HD void predict_transcript_start(const AnnotationView& ann, uint32_t gene1,
 	         (start_gene1 ? CFLAG_TRANSCRIPT_START_GENE1 : 0) | (ambiguous ? CFLAG_TRANSCRIPT_START_AMBIGUOUS : 0);
 }
 
-// strands + splice sites + transcript start of one candidate from its read lists (source/fusions.cpp:443-470).
-// discordant_swapped[i] tells whether find_fusions swapped MATE1/MATE2 of fragment i in place.
-AGPU_HD void finish_candidate(const BatchView& b, const AnnotationView& ann, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c) {
+// strand vote of entry k of the concatenated read lists of candidate c: 0 none, 1 forward, 2 reverse (source/fusions.cpp:22-79)
+AGPU_HD int list_entry_strand_vote(const BatchView& b, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c, uint32_t k) {
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	uint32_t read = t.read_lists[k];
+	if (k < offsets[2]) { // split_read1_list votes with SPLIT_READ's predicted strand, split_read2_list with SUPPLEMENTARY's
+		uint8_t bits = b.abits[k < offsets[1] ? SPLIT_READ : SUPPLEMENTARY][read];
+		if (bits & ABIT_PREDICTED_STRAND_AMBIGUOUS) return 0;
+		return (bits & ABIT_PREDICTED_STRAND) ? 1 : 2;
+	}
+	return discordant_strand_vote(b, read, t.contigs[c] >> 16, t.flags[c] & CFLAG_UPSTREAM1, t.breakpoint1[c], t.breakpoint2[c], discordant_swapped[read]);
+}
+
+// strands, splice sites and transcript start from the vote counts (source/fusions.cpp:81-87, 443-470)
+AGPU_HD void finalize_candidate(const AnnotationView& ann, const CandidateTable& t, uint32_t c, uint32_t forward, uint32_t reverse) {
 	uint32_t flags = t.flags[c];
 	uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
 	int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
 	bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
-	uint32_t forward = 0, reverse = 0;
 	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
-	for (uint32_t k = offsets[0]; k < offsets[1]; ++k) { // split_read1_list: SPLIT_READ's predicted strand
-		uint8_t bits = b.abits[SPLIT_READ][t.read_lists[k]];
-		if (!(bits & ABIT_PREDICTED_STRAND_AMBIGUOUS)) { if (bits & ABIT_PREDICTED_STRAND) ++forward; else ++reverse; }
-	}
-	for (uint32_t k = offsets[1]; k < offsets[2]; ++k) { // split_read2_list: SUPPLEMENTARY's predicted strand
-		uint8_t bits = b.abits[SUPPLEMENTARY][t.read_lists[k]];
-		if (!(bits & ABIT_PREDICTED_STRAND_AMBIGUOUS)) { if (bits & ABIT_PREDICTED_STRAND) ++forward; else ++reverse; }
-	}
-	for (uint32_t k = offsets[2]; k < offsets[3]; ++k) {
-		uint32_t read = t.read_lists[k];
-		int vote = discordant_strand_vote(b, read, t.contigs[c] >> 16, upstream1, breakpoint1, breakpoint2, discordant_swapped[read]);
-		if (vote == 1) ++forward; else if (vote == 2) ++reverse;
-	}
 	flags &= ~(CFLAG_PREDICTED_STRAND1 | CFLAG_PREDICTED_STRAND2 | CFLAG_PREDICTED_STRANDS_AMBIGUOUS | CFLAG_SPLICED1 | CFLAG_SPLICED2);
 	if (forward == reverse) {
 		flags |= CFLAG_PREDICTED_STRANDS_AMBIGUOUS | CFLAG_PREDICTED_STRAND1 | CFLAG_PREDICTED_STRAND2; // fusion_t() initialises both strands to FORWARD
@@ -424,6 +421,18 @@ AGPU_HD void finish_candidate(const BatchView& b, const AnnotationView& ann, con
 	}
 	predict_transcript_start(ann, gene1, gene2, t.contigs[c], breakpoint1, breakpoint2, t.split_reads1[c] + t.split_reads2[c], flags);
 	t.flags[c] = flags;
+}
+
+// sequential form: strands + splice sites + transcript start of one candidate from its read lists.
+// discordant_swapped[i] tells whether find_fusions swapped MATE1/MATE2 of fragment i in place.
+AGPU_HD void finish_candidate(const BatchView& b, const AnnotationView& ann, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c) {
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	uint32_t forward = 0, reverse = 0;
+	for (uint32_t k = offsets[0]; k < offsets[3]; ++k) {
+		int vote = list_entry_strand_vote(b, t, discordant_swapped, c, k);
+		if (vote == 1) ++forward; else if (vote == 2) ++reverse;
+	}
+	finalize_candidate(ann, t, c, forward, reverse);
 }
 
 }

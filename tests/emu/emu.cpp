@@ -277,13 +277,21 @@ int emu_fragment_length_samples(emu_ctx* ctx, int32_t* mate_gaps, uint32_t* n_sa
 
 int emu_read_filters_stage2(emu_ctx* ctx, uint64_t* remaining) {
 	BatchView& b = ctx->batch;
-	uint16_t previous_position[64]; uint8_t count_all[64], count_aligned1[64], count_aligned2[64];
-	KmerScratch scratch; scratch.previous_position = previous_position; scratch.count_all = count_all; scratch.count_aligned1 = count_aligned1; scratch.count_aligned2 = count_aligned2; scratch.stride = 1;
+	uint32_t counters[64];
+	KmerScratch scratch; scratch.counters = counters; scratch.stride = 1; scratch.clear();
 	for (uint64_t i = 0; i < b.n; ++i) {
 		uint32_t first_hit;
-		b.filter[i] = read_filters_stage2(b, ctx->annotation, ctx->genome, ctx->tables, ctx->params.filter_enabled, i, b.filter[i], scratch, first_hit);
-		ctx->stage_counts[5 + first_hit]++;
+		b.filter[i] = read_filters_stage2(b, ctx->annotation, ctx->genome, ctx->tables, ctx->params.filter_enabled, i, b.filter[i], no_stage(), first_hit);
+		if (first_hit < 9) ctx->stage_counts[5 + first_hit]++;
 	}
+	if (ctx->params.filter_enabled[FILTER_low_entropy])
+		for (uint64_t i = 0; i < b.n; ++i) {
+			uint8_t filter = b.filter[i];
+			if (needs_low_entropy_test(b, ctx->tables, i, filter) && has_low_entropy(b, ctx->tables, i, scratch, no_stage())) {
+				if (filter == FILTER_none) ctx->stage_counts[13]++;
+				b.filter[i] = FILTER_low_entropy;
+			}
+		}
 	if (remaining) {
 		static const int order[14] = { 1, 30, 31, 32, 33, 4, 2, 3, 6, 7, 5, 8, 10, 36 };
 		for (int f = 0; f < AGPU_FILTER_COUNT; ++f) remaining[f] = 0;

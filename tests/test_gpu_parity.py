@@ -52,6 +52,35 @@ def test_live_reference_on_larger_dataset(built, tmp_path):
     assert parity.check_candidates(session, pipeline, dump) > 10000
 
 
+def test_hip_path_matches_oracle_restatement_on_fresh_inputs(built, tmp_path):
+    """Inputs without a committed dump: the HIP kernels against the independent CPU restatement (oracle/liboracle.so)."""
+    import oracle_lib
+    for seed, extra in ((101, []), (102, ["--shuffle", "--separate-mates"]), (103, ["--stranded", "--dup", "0.5", "--noise", "0.7"])):
+        spec = {"args": ["--seed", str(seed), "--fragments", "40000", "--normal-mult", "0.2", "--contigs", "5", "--contig-len", "500000", "--junctions", "400"] + extra}
+        prefix = datasets.generate(spec, str(tmp_path), name="fresh%d" % seed)
+        session, pipeline = parity.run_read_level(parity.open_session, prefix)
+        pipeline.find_fusions()
+        oracle = oracle_lib.OraclePipeline(session)
+        oracle.run_read_level(pipeline.scalars["strandedness"])
+        assert oracle.remaining == pipeline.remaining
+        assert np.array_equal(oracle.filters(), pipeline.filters())
+        assert np.array_equal(oracle.fragment_bits(), pipeline.fragment_bits())
+        for slot in range(3):
+            count_a, genes_a = oracle.gene_sets(slot)
+            count_b, genes_b = pipeline.gene_sets(slot)
+            assert np.array_equal(count_a, count_b) and np.array_equal(genes_a, genes_b)
+        oracle.find_fusions(pipeline.scalars["max_mate_gap"])
+        mine, theirs = pipeline.candidates(), oracle.candidates()
+        assert pipeline.n_candidates == oracle.n_candidates
+        for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2", "list_offset", "read_lists"):
+            assert np.array_equal(np.asarray(mine[key], dtype=np.int64), np.asarray(theirs[key], dtype=np.int64)), (seed, key)
+        assert np.array_equal(pipeline.discordant_swapped(), oracle.oracle.discordant_swapped())
+        # strands after annotation (slot order as uploaded)
+        for slot in range(3):
+            normalise = lambda bits: np.where(bits & 32, bits & 0x2F, bits & 0x3F)  # the predicted strand is meaningless while it is ambiguous
+            assert np.array_equal(normalise(oracle.alignment_bits(slot)), normalise(pipeline.alignment_bits(slot))), (seed, slot)
+
+
 def test_cascade_properties_at_scale(built, tmp_path):
     """Size-independent properties on a dataset too large for the oracle in a unit test: stage counts are monotone,
     a duplicate key survives exactly once, and rerunning the cascade on the same batch is idempotent."""
