@@ -9,6 +9,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 FILTER_COUNT = 38
+KERNEL_NAME_LENGTH = 48
 FILTER_NAMES = [
     "", "duplicates", "inconsistently_clipped", "homopolymer", "read_through", "same_gene", "small_insert_size", "long_gap", "hairpin",
     "multimappers", "mismatches", "mismappers", "relative_support", "intronic", "non_coding_neighbors", "intragenic_exonic",
@@ -91,6 +92,13 @@ def bind_device_api(lib, prefix="agpu_"):
         "get_fragment_bits": (c_int, [ctx, c_void_p]),
         "get_gene_sets": (c_int, [ctx, c_int, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
         "get_gene_table": (c_int, [ctx, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "get_fusion_stats": (c_int, [ctx, c_void_p]),
+        "set_candidate_state": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "estimate_expected_fusions": (c_int, [ctx, c_uint64, c_void_p]),
+        "get_evalues": (c_int, [ctx, c_void_p]),
+        "filter_relative_support": (c_int, [ctx, POINTER(c_uint64)]),
+        "set_profiling": (c_int, [ctx, c_int]),
+        "get_kernel_profile": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
         "last_kernel_ms": (c_int, [ctx, POINTER(c_float)]),
         "last_kernel_bytes": (c_int, [ctx, POINTER(c_uint64)]),
     }
@@ -124,6 +132,7 @@ def bind_host_api(lib):
         "ahost_fragment_name": (c_void_p, [session, c_uint64, POINTER(c_uint32)]),
         "ahost_detect_strandedness": (c_int, [session]),
         "ahost_viral_verdicts": (c_int, [session, c_void_p, c_uint64, c_void_p, c_uint32, ctypes.c_uint, c_float, c_void_p, c_void_p]),
+        "ahost_candidate_iteration_order": (c_int, [c_uint64] + [c_void_p] * 7),
         "ahost_estimate_fragment_length": (c_int, [session, c_void_p, c_uint32, c_uint64, ctypes.c_uint, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int32)]),
     }
     for name, (restype, argtypes) in signatures.items():

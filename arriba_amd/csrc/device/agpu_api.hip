@@ -270,12 +270,25 @@ int upload_index(const agpu_flat_index& in, DeviceBuffer& contig_offset, DeviceB
 	return AGPU_OK;
 }
 
+// make room for new_bytes while keeping the first keep_bytes (the GTF genes); with headroom, so that the next pass over the same batch does not reallocate
+int grow_preserving(DeviceBuffer& buffer, size_t keep_bytes, size_t new_bytes, hipStream_t stream) {
+	if (new_bytes <= buffer.capacity) { buffer.bytes = new_bytes; return AGPU_OK; }
+	DeviceBuffer larger;
+	if (!larger.allocate(new_bytes + (new_bytes >> 2))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (keep_bytes > 0) HIP_CHECK(hipMemcpyAsync(larger.ptr, buffer.ptr, keep_bytes, hipMemcpyDeviceToDevice, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	buffer.swap(larger);
+	buffer.bytes = new_bytes;
+	return AGPU_OK;
+}
+
 void begin_timing(agpu_ctx* ctx) { (void) hipEventRecord(ctx->event_start, ctx->stream); }
 int end_timing(agpu_ctx* ctx, uint64_t bytes) {
 	HIP_CHECK(hipEventRecord(ctx->event_stop, ctx->stream));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
 	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
 	ctx->last_bytes = bytes;
+	collect_kernel_samples(ctx);
 	return AGPU_OK;
 }
 
@@ -352,8 +365,19 @@ void refresh_annotation_view(agpu_ctx* ctx) {
 	a.dummy_start_key = ctx->dummy_start_key.as<uint64_t>(); a.dummy_end_key = ctx->dummy_end_key.as<uint64_t>();
 }
 
-uint64_t annotation_bytes(const agpu_ctx* ctx) { // columns touched once by the annotate kernels
-	return ctx->batch_input_bytes + ctx->n * (3 * (1 + 1 + GENE_INLINE * 4));
+// Algorithmic bytes per launch: every input column the kernel needs read once + every output written once.
+uint64_t fragment_column_bytes(const agpu_ctx* ctx) { // n_aln, fbits + per slot contig/start/end/abits/cigar_offset/cigar_count
+	return ctx->n * (1 + 1 + 3 * (2 + 4 + 4 + 1 + 4 + 2));
+}
+uint64_t annotate_stage1_bytes(const agpu_ctx* ctx) { // fragment columns + CIGARs in, abits + gene sets out
+	return fragment_column_bytes(ctx) + ctx->cigar_pool.bytes + ctx->n * (3 * (1 + 1 + GENE_INLINE * 4));
+}
+uint64_t annotation_bytes(const agpu_ctx* ctx) { return annotate_stage1_bytes(ctx) + ctx->n * (1 + 3 * (2 + 1 + 1 + GENE_INLINE * 4)); }
+uint64_t stage2_bytes(const agpu_ctx* ctx) { // fragment columns, CIGARs, gene sets, both sequences, the aligned reference bases (1 B per base), filter in/out
+	return fragment_column_bytes(ctx) + ctx->cigar_pool.bytes + ctx->n * (3 * (1 + GENE_INLINE * 4) + 2 * 8 + 2) + ctx->seq_pool.bytes + 2 * ctx->seq_pool.bytes;
+}
+uint64_t low_entropy_bytes(const agpu_ctx* ctx) { // sequences + their offsets/lengths, clip lengths from the CIGARs, filter in/out
+	return ctx->seq_pool.bytes + ctx->n * (2 * 8 + 3 * (4 + 2 + 8) + 1 + 3 + 2);
 }
 
 }
@@ -402,6 +426,8 @@ void agpu_destroy(agpu_ctx* ctx) {
 	(void) hipStreamSynchronize(ctx->stream);
 	if (ctx->event_start) (void) hipEventDestroy(ctx->event_start);
 	if (ctx->event_stop) (void) hipEventDestroy(ctx->event_stop);
+	collect_kernel_samples(ctx);
+	for (size_t k = 0; k < ctx->event_pool.size(); ++k) (void) hipEventDestroy(ctx->event_pool[k]);
 	if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -535,7 +561,7 @@ int agpu_mark_multimappers(agpu_ctx* ctx, uint64_t* marked) {
 	if (!ctx || !ctx->have_batch) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	begin_timing(ctx);
-	if (ctx->n > 0) mark_multimappers_kernel<<<grid_for(ctx->n), BLOCK, 0, ctx->stream>>>(ctx->batch, ctx->counters.as<uint32_t>());
+	if (ctx->n > 0) { KernelTimer timer(ctx, "mark_multimappers_kernel", ctx->n * (4 + 1 + 1)); mark_multimappers_kernel<<<grid_for(ctx->n), BLOCK, 0, ctx->stream>>>(ctx->batch, ctx->counters.as<uint32_t>()); }
 	TRY(end_timing(ctx, ctx->n * (4 + 1 + 1)));
 	uint32_t counters[COUNTER_COUNT];
 	TRY(read_counters(ctx, counters));
@@ -550,7 +576,7 @@ int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes) {
 	const uint64_t n = ctx->n;
 	uint32_t* counters = ctx->counters.as<uint32_t>();
 	begin_timing(ctx);
-	if (n > 0) annotate_stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->params.strandedness, ctx->unmapped_keys.as<uint64_t>(), counters);
+	if (n > 0) { KernelTimer timer(ctx, "annotate_stage1_kernel", annotate_stage1_bytes(ctx)); annotate_stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->params.strandedness, ctx->unmapped_keys.as<uint64_t>(), counters); }
 	uint32_t host_counters[COUNTER_COUNT];
 	TRY(read_counters(ctx, host_counters));
 	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
@@ -574,24 +600,14 @@ int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes) {
 		dummy_write_kernel<<<grid_for(unmapped), BLOCK, 0, s>>>(ctx->sorted_keys.as<uint64_t>(), unmapped, ctx->scan_flags.as<uint32_t>(), ctx->scan_ids.as<uint32_t>(), ctx->dummy_start_key.as<uint64_t>(), ctx->dummy_end_key.as<uint64_t>());
 		// extend the gene table by the dummy genes
 		const uint32_t total = ctx->n_genes + n_dummy;
-		DeviceBuffer contig, start, end, bits, exonic;
-		if (!contig.allocate((size_t) total * 2) || !start.allocate((size_t) total * 4) || !end.allocate((size_t) total * 4) || !bits.allocate(total) || !exonic.allocate((size_t) total * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-		HIP_CHECK(hipMemcpyAsync(contig.ptr, ctx->gene_contig.ptr, (size_t) ctx->n_genes * 2, hipMemcpyDeviceToDevice, s));
-		HIP_CHECK(hipMemcpyAsync(start.ptr, ctx->gene_start.ptr, (size_t) ctx->n_genes * 4, hipMemcpyDeviceToDevice, s));
-		HIP_CHECK(hipMemcpyAsync(end.ptr, ctx->gene_end.ptr, (size_t) ctx->n_genes * 4, hipMemcpyDeviceToDevice, s));
-		HIP_CHECK(hipMemcpyAsync(bits.ptr, ctx->gene_bits.ptr, (size_t) ctx->n_genes, hipMemcpyDeviceToDevice, s));
-		HIP_CHECK(hipMemcpyAsync(exonic.ptr, ctx->gene_exonic_length.ptr, (size_t) ctx->n_genes * 4, hipMemcpyDeviceToDevice, s));
+		TRY(grow_preserving(ctx->gene_contig, (size_t) ctx->n_genes * 2, (size_t) total * 2, s)); TRY(grow_preserving(ctx->gene_start, (size_t) ctx->n_genes * 4, (size_t) total * 4, s));
+		TRY(grow_preserving(ctx->gene_end, (size_t) ctx->n_genes * 4, (size_t) total * 4, s)); TRY(grow_preserving(ctx->gene_bits, (size_t) ctx->n_genes, (size_t) total, s));
+		TRY(grow_preserving(ctx->gene_exonic_length, (size_t) ctx->n_genes * 4, (size_t) total * 4, s));
 		dummy_gene_table_kernel<<<grid_for(n_dummy), BLOCK, 0, s>>>(ctx->n_genes, n_dummy, ctx->dummy_start_key.as<uint64_t>(), ctx->dummy_end_key.as<uint64_t>(),
-			contig.as<uint16_t>(), start.as<int32_t>(), end.as<int32_t>(), bits.as<uint8_t>(), exonic.as<int32_t>());
-		HIP_CHECK(hipStreamSynchronize(s));
-		std::swap(ctx->gene_contig.ptr, contig.ptr); std::swap(ctx->gene_contig.bytes, contig.bytes);
-		std::swap(ctx->gene_start.ptr, start.ptr); std::swap(ctx->gene_start.bytes, start.bytes);
-		std::swap(ctx->gene_end.ptr, end.ptr); std::swap(ctx->gene_end.bytes, end.bytes);
-		std::swap(ctx->gene_bits.ptr, bits.ptr); std::swap(ctx->gene_bits.bytes, bits.bytes);
-		std::swap(ctx->gene_exonic_length.ptr, exonic.ptr); std::swap(ctx->gene_exonic_length.bytes, exonic.bytes);
+			ctx->gene_contig.as<uint16_t>(), ctx->gene_start.as<int32_t>(), ctx->gene_end.as<int32_t>(), ctx->gene_bits.as<uint8_t>(), ctx->gene_exonic_length.as<int32_t>());
 	}
 	refresh_annotation_view(ctx);
-	if (n > 0) annotate_stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->viral_pairs.as<uint32_t>(), (uint32_t) ctx->viral_pair_capacity, counters);
+	if (n > 0) { KernelTimer timer(ctx, "annotate_stage2_kernel", n * (1 + 3 * (2 + 1 + 1 + GENE_INLINE * 4))); annotate_stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->viral_pairs.as<uint32_t>(), (uint32_t) ctx->viral_pair_capacity, counters); }
 	TRY(end_timing(ctx, annotation_bytes(ctx)));
 	TRY(read_counters(ctx, host_counters));
 	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
@@ -634,9 +650,10 @@ int agpu_read_filters_stage1(agpu_ctx* ctx, const uint8_t* top_verdict, const ui
 	begin_timing(ctx);
 	if (n > 0) {
 		if (!ctx->params.external_duplicate_marking) {
-			duplicate_keys_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->duplicate_keys.as<DuplicateKey>());
-			duplicate_insert_kernel<<<grid_for(n), BLOCK, 0, s>>>(n, ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask);
+			{ KernelTimer timer(ctx, "duplicate_keys_kernel", n * (1 + 2 * (2 + 4 + 4 + 1 + 4 + 2 + 8) + 12)); duplicate_keys_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->duplicate_keys.as<DuplicateKey>()); }
+			{ KernelTimer timer(ctx, "duplicate_insert_kernel", n * (12 + 4)); duplicate_insert_kernel<<<grid_for(n), BLOCK, 0, s>>>(n, ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask); }
 		}
+		KernelTimer timer(ctx, "stage1_kernel", n * (1 + 1 + 12 + 4 + 3 * 2 + 1));
 		stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, ctx->stage_counts.as<unsigned long long>());
 	}
 	TRY(end_timing(ctx, n * (3 * (2 + 4 + 4 + 1) + 2 * (4 + 2 + 8) + 12 * 2 + 8 + 2)));
@@ -676,11 +693,13 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 	const uint64_t n = ctx->n;
 	begin_timing(ctx);
 	if (n > 0) {
-		stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->stage_counts.as<unsigned long long>());
-		if (ctx->params.filter_enabled[FILTER_low_entropy])
+		{ KernelTimer timer(ctx, "stage2_kernel", stage2_bytes(ctx)); stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->stage_counts.as<unsigned long long>()); }
+		if (ctx->params.filter_enabled[FILTER_low_entropy]) {
+			KernelTimer timer(ctx, "low_entropy_kernel", low_entropy_bytes(ctx));
 			low_entropy_kernel<<<(unsigned int) ((n + ENTROPY_BLOCK - 1) / ENTROPY_BLOCK), ENTROPY_BLOCK, 0, s>>>(ctx->batch, ctx->tables, ctx->stage_counts.as<unsigned long long>());
+		}
 	}
-	TRY(end_timing(ctx, ctx->batch_input_bytes + n * (3 * (1 + GENE_INLINE * 4) + 2) + n * 200 /* reference bases gathered by the mismatch walk */));
+	TRY(end_timing(ctx, stage2_bytes(ctx) + low_entropy_bytes(ctx)));
 	unsigned long long counts[16];
 	HIP_CHECK(hipMemcpy(counts, ctx->stage_counts.ptr, sizeof(counts), hipMemcpyDeviceToHost));
 	if (remaining) {
@@ -760,6 +779,25 @@ int agpu_get_gene_table(agpu_ctx* ctx, uint32_t first, uint32_t count, uint16_t*
 	return AGPU_OK;
 }
 
+int agpu_set_profiling(agpu_ctx* ctx, int enabled) {
+	if (!ctx) return AGPU_ERR_INVALID;
+	ctx->profiling = enabled != 0;
+	ctx->samples_done.clear();
+	return AGPU_OK;
+}
+int agpu_get_kernel_profile(agpu_ctx* ctx, char* names, float* ms, uint64_t* bytes, uint32_t capacity, uint32_t* count) {
+	if (!ctx || !count) return AGPU_ERR_INVALID;
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	collect_kernel_samples(ctx);
+	*count = (uint32_t) ctx->samples_done.size();
+	for (uint32_t k = 0; k < *count && k < capacity; ++k) {
+		if (names) { strncpy(names + (size_t) k * AGPU_KERNEL_NAME_LENGTH, ctx->samples_done[k].name, AGPU_KERNEL_NAME_LENGTH - 1); names[(size_t) k * AGPU_KERNEL_NAME_LENGTH + AGPU_KERNEL_NAME_LENGTH - 1] = 0; }
+		if (ms) ms[k] = ctx->samples_done[k].ms;
+		if (bytes) bytes[k] = ctx->samples_done[k].bytes;
+	}
+	return AGPU_OK;
+}
 int agpu_last_kernel_ms(agpu_ctx* ctx, float* ms) { if (!ctx || !ms) return AGPU_ERR_INVALID; *ms = ctx->last_ms; return AGPU_OK; }
 int agpu_last_kernel_bytes(agpu_ctx* ctx, uint64_t* bytes) { if (!ctx || !bytes) return AGPU_ERR_INVALID; *bytes = ctx->last_bytes; return AGPU_OK; }
 

@@ -3,10 +3,12 @@
 #define AGPU_CONTEXT_HPP 1
 
 #include <hip/hip_runtime.h>
+#include <map>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../../include/arriba_gpu.h"
-#include "fusion_core.hpp"
+#include "evalue_core.hpp"
 
 namespace agpu {
 
@@ -19,16 +21,24 @@ struct DeviceBuffer {
 	DeviceBuffer(const DeviceBuffer&) = delete;
 	DeviceBuffer& operator=(const DeviceBuffer&) = delete;
 	~DeviceBuffer() { release(); }
+	// grow-only: a buffer that is already large enough is reused, so that repeated passes over batches of the same size
+	// (and the stage calls inside one pass) do not go back to hipMalloc/hipFree; `bytes` is the size asked for last
+	size_t capacity = 0;
 	bool allocate(size_t n) {
-		release();
 		if (n == 0) n = 16;
+		if (ptr != nullptr && n <= capacity) { bytes = n; return true; }
+		release();
 		if (hipMalloc(&ptr, n) != hipSuccess) { ptr = nullptr; return false; }
-		bytes = n;
+		bytes = n; capacity = n;
 		return true;
 	}
-	void release() { if (ptr) { (void) hipFree(ptr); ptr = nullptr; bytes = 0; } }
+	void release() { if (ptr) { (void) hipFree(ptr); ptr = nullptr; bytes = 0; capacity = 0; } }
+	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); }
 	template <class T> T* as() const { return (T*) ptr; }
 };
+
+// per-kernel timing with HIP events on the launch stream (agpu_set_profiling / agpu_get_kernel_profile)
+struct KernelSample { const char* name; hipEvent_t start, stop; uint64_t bytes; float ms; };
 
 }
 
@@ -39,6 +49,12 @@ struct agpu_ctx {
 	float last_ms = 0;
 	uint64_t last_bytes = 0;
 	agpu_params params;
+	bool profiling = false;
+	std::vector<agpu::KernelSample> samples_pending, samples_done;
+	std::vector<hipEvent_t> event_pool;
+	// scratch buffers of the stage calls, kept between calls (grow-only) and addressed by name
+	std::map<std::string, agpu::DeviceBuffer> scratch_pool;
+	agpu::DeviceBuffer& scratch(const char* name) { return scratch_pool[name]; }
 
 	// annotation
 	uint32_t n_genes = 0, n_exons = 0, n_dummy = 0;
@@ -80,9 +96,12 @@ struct agpu_ctx {
 	// find_fusions
 	agpu::DeviceBuffer emissions, discordant_swapped;
 	agpu::DeviceBuffer cand_gene1, cand_gene2, cand_contigs, cand_breakpoint1, cand_breakpoint2, cand_flags, cand_filter, cand_split_reads1, cand_split_reads2, cand_discordant_mates;
-	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists;
+	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists, cand_evalue;
+	agpu::DeviceBuffer evalue_support_scale, evalue_intragenic_support, evalue_intergenic_support, evalue_distance_tables;
+	agpu::EvalueGlobals evalue_globals;
+	bool evalue_done = false;
 	agpu::CandidateTable candidates;
-	uint32_t n_emissions = 0, n_candidates = 0, n_list_entries = 0;
+	uint32_t n_emissions = 0, n_candidates = 0, n_list_entries = 0, n_queued_buckets = 0, n_discordant_emissions = 0;
 	bool fusions_done = false;
 
 	// tables
@@ -90,5 +109,38 @@ struct agpu_ctx {
 	agpu::FilterTables tables;
 	uint64_t genome_size = 0;
 };
+
+namespace agpu {
+
+// Brackets one kernel launch (or library call) with HIP events when profiling is on.  Usage:
+//   { KernelTimer timer(ctx, "stage2_kernel", bytes); stage2_kernel<<<...>>>(...); }
+struct KernelTimer {
+	agpu_ctx* ctx; int index;
+	KernelTimer(agpu_ctx* c, const char* name, uint64_t bytes) : ctx(c), index(-1) {
+		if (!ctx->profiling) return;
+		KernelSample sample; sample.name = name; sample.bytes = bytes; sample.ms = 0;
+		hipEvent_t* events[2] = { &sample.start, &sample.stop };
+		for (int k = 0; k < 2; ++k) {
+			if (!ctx->event_pool.empty()) { *events[k] = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+			else if (hipEventCreate(events[k]) != hipSuccess) return;
+		}
+		(void) hipEventRecord(sample.start, ctx->stream);
+		ctx->samples_pending.push_back(sample);
+		index = (int) ctx->samples_pending.size() - 1;
+	}
+	~KernelTimer() { if (index >= 0) (void) hipEventRecord(ctx->samples_pending[index].stop, ctx->stream); }
+};
+// resolve the pending samples (call after the stream was synchronised)
+inline void collect_kernel_samples(agpu_ctx* ctx) {
+	for (size_t k = 0; k < ctx->samples_pending.size(); ++k) {
+		KernelSample& sample = ctx->samples_pending[k];
+		if (hipEventElapsedTime(&sample.ms, sample.start, sample.stop) != hipSuccess) sample.ms = 0;
+		ctx->event_pool.push_back(sample.start); ctx->event_pool.push_back(sample.stop);
+		ctx->samples_done.push_back(sample);
+	}
+	ctx->samples_pending.clear();
+}
+
+}
 
 #endif

@@ -1,0 +1,255 @@
+// arriba_amd/csrc/device/agpu_evalue.hip -- estimate_expected_fusions + filter_relative_support on the device
+// (reference: source/filter_relative_support.cpp:17-224).
+//
+//   partner_insert/resolve_kernel   first event per (gene, breakpoint1, breakpoint2) in the reference's iteration order: lock-free
+//                                   open addressing, the slot holds min(priority << 32 | event handle) of its key (64-bit atomicMin)
+//   radix sort + partner_size/count distinct (gene, partner) pairs -> |partners(gene)| -> fusion_partner_count(gene)
+//   evalue_globals_kernel           the eight sample-wide counters + per-gene marks (read-through fraction)
+//   evalue_kernel                   per candidate: the float/double multiplication chain over host-tabulated pow() factors
+//   relative_support_kernel         e-value cutoff
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+#include "agpu_context.hpp"
+#include "evalue_host.hpp"
+
+using namespace agpu;
+
+namespace {
+
+const int BLOCK = 256;
+const unsigned long long EMPTY_SLOT64 = ~0ull;
+inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1) / BLOCK); }
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+
+__global__ void partner_insert_kernel(CandidateTable t, const uint32_t* iteration_rank, unsigned long long* slots, uint32_t mask) {
+	uint32_t handle = blockIdx.x * BLOCK + threadIdx.x;
+	if (handle >= 2 * t.n) return;
+	uint32_t c = handle >> 1;
+	if (!raises_partner_events(t, c)) return;
+	PartnerKey key = partner_event_key(t, handle);
+	unsigned long long mine = (unsigned long long) (2 * (uint64_t) iteration_rank[c] + (handle & 1)) << 32 | handle;
+	uint32_t h = (uint32_t) hash_partner_key(key) & mask;
+	while (true) {
+		unsigned long long owner = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (owner == EMPTY_SLOT64) {
+			owner = atomicCAS(&slots[h], EMPTY_SLOT64, mine);
+			if (owner == EMPTY_SLOT64) return;
+		}
+		if (partner_keys_equal(partner_event_key(t, (uint32_t) owner), key)) { if (mine < owner) atomicMin(&slots[h], mine); return; } // a slot never changes its key
+		h = (h + 1) & mask;
+	}
+}
+
+// winners emit (gene << 32 | partner)
+__global__ void partner_resolve_kernel(CandidateTable t, const unsigned long long* slots, uint32_t mask, uint64_t* pairs, uint32_t* pair_count) {
+	uint32_t handle = blockIdx.x * BLOCK + threadIdx.x;
+	if (handle >= 2 * t.n) return;
+	uint32_t c = handle >> 1;
+	if (!raises_partner_events(t, c)) return;
+	PartnerKey key = partner_event_key(t, handle);
+	uint32_t h = (uint32_t) hash_partner_key(key) & mask;
+	while (true) {
+		unsigned long long owner = slots[h];
+		if (partner_keys_equal(partner_event_key(t, (uint32_t) owner), key)) {
+			if ((uint32_t) owner == handle) pairs[atomicAdd(pair_count, 1u)] = (uint64_t) key.gene << 32 | partner_event_partner(t, handle);
+			return;
+		}
+		h = (h + 1) & mask;
+	}
+}
+
+__global__ void partner_size_kernel(const uint64_t* sorted_pairs, uint32_t n, int32_t* partner_set_size) {
+	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= n) return;
+	if (k == 0 || sorted_pairs[k - 1] != sorted_pairs[k]) atomicAdd(&partner_set_size[sorted_pairs[k] >> 32], 1);
+}
+// fusion_partner_count[gene] = number of partners whose own partner set is not larger (source/filter_relative_support.cpp:33-41)
+__global__ void partner_count_kernel(const uint64_t* sorted_pairs, uint32_t n, const int32_t* partner_set_size, int32_t* partner_count) {
+	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= n) return;
+	if (k != 0 && sorted_pairs[k - 1] == sorted_pairs[k]) return;
+	uint32_t gene = (uint32_t) (sorted_pairs[k] >> 32), partner = (uint32_t) sorted_pairs[k];
+	if (partner_set_size[gene] >= partner_set_size[partner]) atomicAdd(&partner_count[gene], 1);
+}
+
+__global__ void evalue_globals_kernel(AnnotationView ann, CandidateTable t, unsigned int* counters /* [EG_COUNT + 1]: classes, max supporting reads */, uint8_t* gene_marks) {
+	__shared__ unsigned int block_counters[EG_COUNT];
+	__shared__ unsigned int block_max;
+	if (threadIdx.x < EG_COUNT) block_counters[threadIdx.x] = 0;
+	if (threadIdx.x == 0) block_max = 0;
+	__syncthreads();
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n) {
+		EvalueContribution r = evalue_contribution(ann, t, c);
+		if (r.breakpoint_class >= 0) atomicAdd(&block_counters[r.breakpoint_class], 1u);
+		if (r.intragenic_class >= 0) atomicAdd(&block_counters[r.intragenic_class], 1u);
+		if (r.spliced_class >= 0) atomicAdd(&block_counters[r.spliced_class], 1u);
+		if (r.marks_genes) {
+			uint8_t mark = r.marks_read_through ? 3 : 1;
+			uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
+			if ((gene_marks[gene1] & mark) != mark) atomicOr((unsigned int*) (gene_marks + (gene1 & ~3u)), (unsigned int) mark << ((gene1 & 3u) * 8));
+			if ((gene_marks[gene2] & mark) != mark) atomicOr((unsigned int*) (gene_marks + (gene2 & ~3u)), (unsigned int) mark << ((gene2 & 3u) * 8));
+		}
+		atomicMax(&block_max, t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c]);
+	}
+	__syncthreads();
+	if (threadIdx.x < EG_COUNT && block_counters[threadIdx.x]) atomicAdd(&counters[threadIdx.x], block_counters[threadIdx.x]);
+	if (threadIdx.x == 0 && block_max) atomicMax(&counters[EG_COUNT], block_max);
+}
+__global__ void gene_mark_count_kernel(const uint8_t* gene_marks, uint32_t n_genes, unsigned int* counts /* [2]: genes with fusions, with read-through fusions */) {
+	uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+	uint8_t mark = g < n_genes ? gene_marks[g] : 0;
+	unsigned long long with_fusions = __ballot(mark & 1), with_read_through = __ballot(mark & 2);
+	if ((threadIdx.x & 63) == 0) {
+		if (with_fusions) atomicAdd(&counts[0], (unsigned int) __popcll(with_fusions));
+		if (with_read_through) atomicAdd(&counts[1], (unsigned int) __popcll(with_read_through));
+	}
+}
+
+__global__ void evalue_kernel(AnnotationView ann, CandidateTable t, const int32_t* partner_count, EvalueGlobals g, EvalueTables tables, float* evalue) {
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	evalue[c] = candidate_evalue(ann, t, c, partner_count, g, tables);
+}
+
+__global__ void relative_support_kernel(AnnotationView ann, CandidateTable t, const float* evalue, float evalue_cutoff, unsigned int* remaining) {
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	bool kept = false;
+	if (c < t.n && t.filter[c] == FILTER_none) {
+		if (fails_relative_support(ann, t, c, evalue[c], evalue_cutoff)) t.filter[c] = FILTER_relative_support; else kept = true;
+	}
+	unsigned long long ballot = __ballot(kept);
+	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(remaining, (unsigned int) __popcll(ballot));
+}
+
+template <class T> int upload_table(DeviceBuffer& buffer, const std::vector<T>& host, hipStream_t stream) {
+	if (!buffer.allocate(host.size() * sizeof(T))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	HIP_CHECK(hipMemcpyAsync(buffer.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+	return AGPU_OK;
+}
+
+}
+
+extern "C" int agpu_set_candidate_state(agpu_ctx* ctx, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	const size_t C = ctx->n_candidates;
+	if (C == 0) return AGPU_OK;
+	if (filter) HIP_CHECK(hipMemcpyAsync(ctx->cand_filter.ptr, filter, C, hipMemcpyHostToDevice, ctx->stream));
+	if (split_reads1) HIP_CHECK(hipMemcpyAsync(ctx->cand_split_reads1.ptr, split_reads1, C * 4, hipMemcpyHostToDevice, ctx->stream));
+	if (split_reads2) HIP_CHECK(hipMemcpyAsync(ctx->cand_split_reads2.ptr, split_reads2, C * 4, hipMemcpyHostToDevice, ctx->stream));
+	if (discordant_mates) HIP_CHECK(hipMemcpyAsync(ctx->cand_discordant_mates.ptr, discordant_mates, C * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_reads, const uint32_t* iteration_rank) {
+	if (!ctx || !ctx->fusions_done || !iteration_rank) { set_last_error("agpu_find_fusions must run first and the iteration order is required"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint32_t n_genes = ctx->n_genes + ctx->n_dummy;
+	const CandidateTable& t = ctx->candidates;
+	ALLOC(ctx->cand_evalue, (size_t) std::max<uint32_t>(C, 1) * 4);
+	ctx->evalue_done = false;
+	if (C == 0) { ctx->evalue_done = true; return AGPU_OK; }
+	if (2ull * C >= 0xFFFFFFF0ull) { set_last_error("too many candidates for the partner table"); return AGPU_ERR_CAPACITY; }
+
+	DeviceBuffer rank, slots, pairs, sorted_pairs, pair_count, set_size, partner_count, counters, gene_marks, scratch;
+	ALLOC(rank, (size_t) C * 4);
+	HIP_CHECK(hipMemcpyAsync(rank.ptr, iteration_rank, (size_t) C * 4, hipMemcpyHostToDevice, s));
+	uint64_t n_slots = 1024;
+	while (n_slots < 4ull * C) n_slots <<= 1; // two events per candidate, load factor <= 0.5
+	const uint32_t mask = (uint32_t) (n_slots - 1);
+	ALLOC(slots, n_slots * 8); ALLOC(pairs, 2 * (size_t) C * 8); ALLOC(sorted_pairs, 2 * (size_t) C * 8); ALLOC(pair_count, 16);
+	ALLOC(set_size, (size_t) n_genes * 4); ALLOC(partner_count, (size_t) n_genes * 4); ALLOC(counters, 16 * 4); ALLOC(gene_marks, ((size_t) n_genes + 8) & ~(size_t) 3);
+	HIP_CHECK(hipMemsetAsync(slots.ptr, 0xFF, n_slots * 8, s));
+	HIP_CHECK(hipMemsetAsync(pair_count.ptr, 0, 16, s));
+	HIP_CHECK(hipMemsetAsync(set_size.ptr, 0, (size_t) n_genes * 4, s));
+	HIP_CHECK(hipMemsetAsync(partner_count.ptr, 0, (size_t) n_genes * 4, s));
+	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 16 * 4, s));
+	HIP_CHECK(hipMemsetAsync(gene_marks.ptr, 0, gene_marks.bytes, s));
+
+	(void) hipEventRecord(ctx->event_start, s);
+	{ KernelTimer timer(ctx, "partner_insert_kernel", (uint64_t) C * (4 + 1 + 16 + 2 * 8)); partner_insert_kernel<<<grid_for(2ull * C), BLOCK, 0, s>>>(t, rank.as<uint32_t>(), slots.as<unsigned long long>(), mask); }
+	{ KernelTimer timer(ctx, "partner_resolve_kernel", (uint64_t) C * (1 + 16 + 2 * 8 + 2 * 8)); partner_resolve_kernel<<<grid_for(2ull * C), BLOCK, 0, s>>>(t, slots.as<unsigned long long>(), mask, pairs.as<uint64_t>(), pair_count.as<uint32_t>()); }
+	{ KernelTimer timer(ctx, "evalue_globals_kernel", (uint64_t) C * 34); evalue_globals_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, counters.as<unsigned int>(), gene_marks.as<uint8_t>()); }
+	gene_mark_count_kernel<<<grid_for(n_genes), BLOCK, 0, s>>>(gene_marks.as<uint8_t>(), n_genes, counters.as<unsigned int>() + 12);
+	uint32_t n_pairs = 0;
+	unsigned int host_counters[16];
+	HIP_CHECK(hipMemcpyAsync(&n_pairs, pair_count.ptr, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(host_counters, counters.ptr, sizeof(host_counters), hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (n_pairs > 0) {
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, pairs.as<uint64_t>(), sorted_pairs.as<uint64_t>(), n_pairs, 0, 64, s));
+		ALLOC(scratch, bytes);
+		{ KernelTimer timer(ctx, "rocprim::radix_sort_keys(partner pairs)", (uint64_t) n_pairs * 16);
+		  HIP_CHECK(rocprim::radix_sort_keys(scratch.ptr, bytes, pairs.as<uint64_t>(), sorted_pairs.as<uint64_t>(), n_pairs, 0, 64, s)); }
+		partner_size_kernel<<<grid_for(n_pairs), BLOCK, 0, s>>>(sorted_pairs.as<uint64_t>(), n_pairs, set_size.as<int32_t>());
+		partner_count_kernel<<<grid_for(n_pairs), BLOCK, 0, s>>>(sorted_pairs.as<uint64_t>(), n_pairs, set_size.as<int32_t>(), partner_count.as<int32_t>());
+	}
+
+	// sample-wide covariates with the reference's fallbacks for small samples; pow() factors tabulated with the host's libm
+	EvalueGlobals g = make_evalue_globals(host_counters, host_counters[12], host_counters[13]);
+	ctx->evalue_globals = g;
+	const unsigned int max_support = host_counters[EG_COUNT];
+	EvalueHostTables host_tables;
+	host_tables.build_support_tables(mapped_reads, max_support);
+	if (upload_table(ctx->evalue_support_scale, host_tables.support_scale, s) != AGPU_OK || upload_table(ctx->evalue_intragenic_support, host_tables.intragenic_support, s) != AGPU_OK ||
+	    upload_table(ctx->evalue_intergenic_support, host_tables.intergenic_support, s) != AGPU_OK) return AGPU_ERR_DEVICE;
+	if (ctx->evalue_distance_tables.ptr == nullptr) { // independent of the sample: built once per context
+		host_tables.build_distance_tables();
+		if (upload_table(ctx->evalue_distance_tables, host_tables.distances, s) != AGPU_OK) return AGPU_ERR_DEVICE;
+	}
+	HIP_CHECK(hipStreamSynchronize(s)); // the host vectors go out of scope
+	EvalueTables tables = evalue_table_view(ctx->evalue_support_scale.as<double>(), ctx->evalue_intragenic_support.as<double>(), ctx->evalue_intergenic_support.as<double>(), max_support, ctx->evalue_distance_tables.as<double>());
+
+	{ KernelTimer timer(ctx, "evalue_kernel", (uint64_t) C * (34 + 4)); evalue_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, partner_count.as<int32_t>(), g, tables, ctx->cand_evalue.as<float>()); }
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * (34 + 4 + 4 + 2 * 24);
+	ctx->evalue_done = true;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_get_evalues(agpu_ctx* ctx, float* evalue) {
+	if (!ctx || !ctx->evalue_done || !evalue) { set_last_error("agpu_estimate_expected_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->n_candidates) HIP_CHECK(hipMemcpy(evalue, ctx->cand_evalue.ptr, (size_t) ctx->n_candidates * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining) {
+	if (!ctx || !ctx->evalue_done) { set_last_error("agpu_estimate_expected_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer counter;
+	ALLOC(counter, 16);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && ctx->params.filter_enabled[FILTER_relative_support]) {
+		KernelTimer timer(ctx, "relative_support_kernel", (uint64_t) C * (1 + 4 + 24 + 1));
+		relative_support_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, ctx->candidates, ctx->cand_evalue.as<float>(), ctx->params.evalue_cutoff, counter.as<unsigned int>());
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 30;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}

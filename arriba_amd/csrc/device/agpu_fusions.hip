@@ -121,10 +121,12 @@ __global__ void discordant_key_kernel(uint32_t Md, const uint32_t* indices, cons
 	const FusionEmission& e = emissions[indices[k]];
 	keys[k] = gene_pair_key(e.gene1, e.gene2, e.info);
 }
-__global__ void discordant_gather_kernel(uint32_t Md, const uint32_t* sorted_indices, const FusionEmission* emissions, FusionEmission* bucket_emissions) {
+struct DiscordantBucketColumns { int32_t* breakpoint1; int32_t* breakpoint2; uint32_t* info; uint32_t* read; int32_t* anchor1; int32_t* anchor2; };
+__global__ void discordant_gather_kernel(uint32_t Md, const uint32_t* sorted_indices, const FusionEmission* emissions, DiscordantBucketColumns out) {
 	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
 	if (k >= Md) return;
-	bucket_emissions[k] = emissions[sorted_indices[k]];
+	FusionEmission e = emissions[sorted_indices[k]];
+	out.breakpoint1[k] = e.breakpoint1; out.breakpoint2[k] = e.breakpoint2; out.info[k] = e.info; out.read[k] = e.read; out.anchor1[k] = e.anchor1; out.anchor2[k] = e.anchor2;
 }
 
 AGPU_HD uint32_t lower_bound_key(const uint64_t* keys, uint32_t n, uint64_t value) {
@@ -140,7 +142,7 @@ struct BucketRef { uint32_t candidate, begin, end; };
 
 // one thread per candidate: small buckets are handled inline, large ones are queued for the wave kernel.
 // fill == false: count pass (list sizes), fill == true: write lists / anchors / swap flags
-__global__ void attach_discordant_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint64_t* bucket_keys, const FusionEmission* bucket_emissions, uint32_t Md,
+__global__ void attach_discordant_kernel(AnnotationView ann, CandidateTable t, const uint64_t* bucket_keys, DiscordantBuckets buckets, uint32_t Md,
                                          int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, BucketRef* worklist, uint32_t* worklist_size, bool fill) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n) return;
@@ -163,7 +165,7 @@ __global__ void attach_discordant_kernel(BatchView b, AnnotationView ann, Candid
 	} else {
 		has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
 	}
-	uint32_t size = attach_discordant_mates(b, ann, t, c, bucket_emissions + begin, end - begin, max_mate_gap, threshold, has_split_reads, out_list, discordant_swapped);
+	uint32_t size = attach_discordant_mates(ann, t, c, buckets, begin, end - begin, max_mate_gap, threshold, has_split_reads, out_list, discordant_swapped);
 	if (!fill) list_size[3 * (uint64_t) c + 2] = size;
 }
 
@@ -176,10 +178,59 @@ __device__ __forceinline__ AnchorFold wave_fold_in_lane_order(AnchorFold mine, b
 	}
 	return mine; // lane 0 holds the fold over lanes 0..63 in order
 }
+// order-free accumulation of anchors that are all non-zero: 0 = unset
+__device__ __forceinline__ int32_t anchor_merge(int32_t a, int32_t b, bool upstream) {
+	if (a == 0) return b;
+	if (b == 0) return a;
+	return upstream ? (a > b ? a : b) : (a < b ? a : b);
+}
 
 // one wave per queued candidate: 64 discordant mates are tested at once; the order-dependent subsampling rule of the reference
-// (source/fusions.cpp:398-407) becomes prefix popcounts over the ballots
-__global__ void attach_discordant_wave_kernel(BatchView b, AnnotationView ann, CandidateTable t, const FusionEmission* bucket_emissions, int32_t max_mate_gap, uint32_t threshold,
+// (source/fusions.cpp:398-407) becomes prefix popcounts over the ballots.  MODE 0: count the list entries; MODE 1: write the list
+// and accumulate the anchors per lane (valid while no downstream anchor is 0); MODE 2: anchors only, folded in name order (the rare
+// case of an anchor at position 0, which resets a running minimum).
+template <int MODE> __device__ __forceinline__ void scan_bucket(const AnnotationView& ann, const DiscordantBuckets& buckets, const BucketRef& ref, uint32_t gene1, uint32_t gene2,
+		int32_t breakpoint1, int32_t breakpoint2, bool upstream1, bool upstream2, bool has_split_reads, int32_t max_mate_gap, uint32_t threshold, uint32_t lane,
+		uint32_t* out_list, uint8_t* discordant_swapped, uint32_t& unfiltered, uint32_t& appended, int32_t& lane_anchor1, int32_t& lane_anchor2, bool& zero_seen, AnchorFold& fold1, AnchorFold& fold2) {
+	const unsigned long long lanes_before = (1ull << lane) - 1;
+	uint32_t passing = 0;
+	unfiltered = 0; appended = 0;
+	for (uint32_t base = ref.begin; base < ref.end; base += 64) {
+		const uint32_t k = base + lane;
+		bool pass = false, is_unfiltered = false;
+		uint32_t info = 0;
+		if (k < ref.end) {
+			pass = discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, buckets.breakpoint1[k], buckets.breakpoint2[k]);
+			if (pass) { info = buckets.info[k]; is_unfiltered = (info >> EINFO_FILTER_SHIFT & 255) == FILTER_none; }
+		}
+		const unsigned long long ballot_pass = __ballot(pass), ballot_unfiltered = __ballot(is_unfiltered);
+		const uint32_t position = passing + __popcll(ballot_pass & lanes_before);
+		const uint32_t unfiltered_before = unfiltered + __popcll(ballot_unfiltered & lanes_before);
+		const bool joins = pass && (position < threshold || (is_unfiltered && unfiltered_before < threshold));
+		const unsigned long long ballot_joins = __ballot(joins);
+		if (MODE == 1 && joins) {
+			const uint32_t read = buckets.read[k];
+			out_list[appended + __popcll(ballot_joins & lanes_before)] = read;
+			if ((info & EINFO_MATES_SWAPPED) && !discordant_swapped[read]) discordant_swapped[read] = 1;
+			const int32_t anchor1 = buckets.anchor1[k], anchor2 = buckets.anchor2[k];
+			if ((!upstream1 && anchor1 == 0) || (!upstream2 && anchor2 == 0)) zero_seen = true;
+			lane_anchor1 = anchor_merge(lane_anchor1, anchor1, upstream1);
+			lane_anchor2 = anchor_merge(lane_anchor2, anchor2, upstream2);
+		}
+		if (MODE == 2 && ballot_joins != 0) {
+			AnchorFold chunk1 = wave_fold_in_lane_order(joins ? anchor_single(buckets.anchor1[k], upstream1) : anchor_identity(), upstream1);
+			AnchorFold chunk2 = wave_fold_in_lane_order(joins ? anchor_single(buckets.anchor2[k], upstream2) : anchor_identity(), upstream2);
+			fold1 = anchor_combine(fold1, chunk1, upstream1);
+			fold2 = anchor_combine(fold2, chunk2, upstream2);
+		}
+		passing += __popcll(ballot_pass);
+		unfiltered += __popcll(ballot_unfiltered);
+		appended += __popcll(ballot_joins);
+		if (unfiltered >= threshold) break; // the reference stops at the next unfiltered mate; filtered ones no longer fit either
+	}
+}
+
+__global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, int32_t max_mate_gap, uint32_t threshold,
                                               uint32_t* list_size, uint8_t* discordant_swapped, const BucketRef* worklist, const uint32_t* worklist_size, bool fill) {
 	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
 	if (wave >= *worklist_size) return;
@@ -189,55 +240,33 @@ __global__ void attach_discordant_wave_kernel(BatchView b, AnnotationView ann, C
 	const bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
 	const uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
 	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
-	bool has_split_reads;
-	uint32_t* out_list = nullptr;
-	if (fill) {
-		const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
-		has_split_reads = offsets[2] > offsets[0];
-		out_list = t.read_lists + offsets[2];
-	} else {
-		has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
-	}
-	const unsigned long long lanes_before = (1ull << lane) - 1;
-	uint32_t passing = 0, unfiltered = 0, appended = 0;
+	uint32_t unfiltered = 0, appended = 0;
+	int32_t lane_anchor1 = 0, lane_anchor2 = 0;
+	bool zero_seen = false;
 	AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
-	for (uint32_t base = ref.begin; base < ref.end; base += 64) {
-		const uint32_t k = base + lane;
-		bool pass = false, is_unfiltered = false;
-		FusionEmission e;
-		if (k < ref.end) {
-			e = bucket_emissions[k];
-			pass = discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, e.breakpoint1, e.breakpoint2);
-			is_unfiltered = pass && (e.info >> EINFO_FILTER_SHIFT & 255) == FILTER_none;
+	if (!fill) {
+		const bool has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
+		scan_bucket<0>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered, appended, lane_anchor1, lane_anchor2, zero_seen, fold1, fold2);
+		if (lane == 0) list_size[3 * (uint64_t) c + 2] = appended;
+		return;
+	}
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	const bool has_split_reads = offsets[2] > offsets[0];
+	scan_bucket<1>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, t.read_lists + offsets[2], discordant_swapped, unfiltered, appended, lane_anchor1, lane_anchor2, zero_seen, fold1, fold2);
+	if (__ballot(zero_seen) != 0) {
+		uint32_t unfiltered_again, appended_again;
+		scan_bucket<2>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered_again, appended_again, lane_anchor1, lane_anchor2, zero_seen, fold1, fold2);
+	} else {
+		for (int offset = 32; offset > 0; offset >>= 1) {
+			lane_anchor1 = anchor_merge(lane_anchor1, __shfl_down(lane_anchor1, offset), upstream1);
+			lane_anchor2 = anchor_merge(lane_anchor2, __shfl_down(lane_anchor2, offset), upstream2);
 		}
-		const unsigned long long ballot_pass = __ballot(pass), ballot_unfiltered = __ballot(is_unfiltered);
-		const uint32_t position = passing + __popcll(ballot_pass & lanes_before);
-		const uint32_t unfiltered_before = unfiltered + __popcll(ballot_unfiltered & lanes_before);
-		const bool joins = pass && (position < threshold || (is_unfiltered && unfiltered_before < threshold));
-		const unsigned long long ballot_joins = __ballot(joins);
-		if (fill) {
-			if (joins) {
-				out_list[appended + __popcll(ballot_joins & lanes_before)] = e.read;
-				if (discordant_mates_need_swap(b, e.read)) discordant_swapped[e.read] = 1;
-			}
-			AnchorFold chunk1 = wave_fold_in_lane_order(joins ? anchor_single(e.anchor1, upstream1) : anchor_identity(), upstream1);
-			AnchorFold chunk2 = wave_fold_in_lane_order(joins ? anchor_single(e.anchor2, upstream2) : anchor_identity(), upstream2);
-			fold1 = anchor_combine(fold1, chunk1, upstream1);
-			fold2 = anchor_combine(fold2, chunk2, upstream2);
-		}
-		passing += __popcll(ballot_pass);
-		unfiltered += __popcll(ballot_unfiltered);
-		appended += __popcll(ballot_joins);
-		if (unfiltered >= threshold) break; // the reference stops at the next unfiltered mate; filtered ones no longer fit either
+		fold1.value = lane_anchor1; fold2.value = lane_anchor2;
 	}
 	if (lane == 0) {
-		if (fill) {
-			t.discordant_mates[c] = unfiltered < threshold ? unfiltered : threshold;
-			t.anchor1[c] = anchor_apply(t.anchor1[c], fold1, upstream1);
-			t.anchor2[c] = anchor_apply(t.anchor2[c], fold2, upstream2);
-		} else {
-			list_size[3 * (uint64_t) c + 2] = appended;
-		}
+		t.discordant_mates[c] = unfiltered < threshold ? unfiltered : threshold;
+		t.anchor1[c] = anchor_apply(t.anchor1[c], fold1, upstream1);
+		t.anchor2[c] = anchor_apply(t.anchor2[c], fold2, upstream2);
 	}
 }
 
@@ -275,8 +304,9 @@ __global__ void finish_wave_kernel(BatchView b, AnnotationView ann, CandidateTab
 }
 
 struct Scratch { // grows on demand; reused by every rocprim call
-	DeviceBuffer buffer;
-	int ensure(size_t bytes) { if (bytes > buffer.bytes) { if (!buffer.allocate(bytes + (bytes >> 2))) { set_last_error("hipMalloc failed (scratch)"); return AGPU_ERR_DEVICE; } } return AGPU_OK; }
+	DeviceBuffer& buffer;
+	explicit Scratch(DeviceBuffer& pooled) : buffer(pooled) {}
+	int ensure(size_t bytes) { if (bytes > buffer.capacity) { if (!buffer.allocate(bytes + (bytes >> 2))) { set_last_error("hipMalloc failed (scratch)"); return AGPU_ERR_DEVICE; } } return AGPU_OK; }
 };
 
 }
@@ -287,18 +317,19 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	hipStream_t s = ctx->stream;
 	const uint64_t n = ctx->n;
 	const uint32_t threshold = ctx->params.subsampling_threshold;
-	Scratch scratch;
+	Scratch scratch(ctx->scratch("fusions.rocprim"));
 	size_t bytes = 0;
 	(void) hipEventRecord(ctx->event_start, s);
 
 	// ---- emissions
-	DeviceBuffer counts, offsets;
+	DeviceBuffer& counts = ctx->scratch("fusions.counts"); DeviceBuffer& offsets = ctx->scratch("fusions.offsets");
 	ALLOC(counts, (n + 1) * 4); ALLOC(offsets, (n + 1) * 4);
 	HIP_CHECK(hipMemsetAsync(counts.ptr, 0, (n + 1) * 4, s));
-	if (n > 0) emission_count_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, counts.as<uint32_t>());
+	{ KernelTimer timer(ctx, "emission_count_kernel", (uint64_t) n * (1 + 3 * (2 + 4 + 4 + 1 + 1) + 4)); if (n > 0) emission_count_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, counts.as<uint32_t>()); }
 	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n + 1, rocprim::plus<uint32_t>(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n + 1, rocprim::plus<uint32_t>(), s));
+	{ KernelTimer timer(ctx, "rocprim::exclusive_scan(emission offsets)", (uint64_t) n * 8);
+	  HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n + 1, rocprim::plus<uint32_t>(), s)); }
 	uint32_t M = 0;
 	HIP_CHECK(hipMemcpyAsync(&M, offsets.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -312,46 +343,46 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	}
 	ALLOC(ctx->emissions, (size_t) M * sizeof(FusionEmission));
 	FusionEmission* emissions = ctx->emissions.as<FusionEmission>();
-	emission_write_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, offsets.as<uint32_t>(), counts.as<uint32_t>(), emissions);
+	{ KernelTimer timer(ctx, "emission_write_kernel", (uint64_t) n * (1 + 3 * (2 + 4 + 4 + 1 + 1 + GENE_INLINE * 4) + 1 + 8) + (uint64_t) M * sizeof(FusionEmission)); emission_write_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, offsets.as<uint32_t>(), counts.as<uint32_t>(), emissions); }
 
 	// ---- group by candidate key
 	uint64_t slots = 1024;
 	while (slots < 2ull * M) slots <<= 1;
 	const uint32_t mask = (uint32_t) (slots - 1);
-	DeviceBuffer table, keys, sorted_keys;
+	DeviceBuffer& table = ctx->scratch("fusions.table"); DeviceBuffer& keys = ctx->scratch("fusions.keys"); DeviceBuffer& sorted_keys = ctx->scratch("fusions.sorted_keys");
 	ALLOC(table, slots * 4); ALLOC(keys, (size_t) M * 8); ALLOC(sorted_keys, (size_t) M * 8);
 	HIP_CHECK(hipMemsetAsync(table.ptr, 0xFF, slots * 4, s));
-	candidate_insert_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask);
-	candidate_resolve_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask, keys.as<uint64_t>());
+	{ KernelTimer timer(ctx, "candidate_insert_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4)); candidate_insert_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask); }
+	{ KernelTimer timer(ctx, "candidate_resolve_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4 + 8)); candidate_resolve_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask, keys.as<uint64_t>()); }
 	HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, keys.as<uint64_t>(), sorted_keys.as<uint64_t>(), M, 0, 64, s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-	HIP_CHECK(rocprim::radix_sort_keys(scratch.buffer.ptr, bytes, keys.as<uint64_t>(), sorted_keys.as<uint64_t>(), M, 0, 64, s));
-	table.release(); keys.release();
-	DeviceBuffer sorted, heads, candidate_of;
+	{ KernelTimer timer(ctx, "rocprim::radix_sort_keys(emissions by candidate)", (uint64_t) M * 16);
+	  HIP_CHECK(rocprim::radix_sort_keys(scratch.buffer.ptr, bytes, keys.as<uint64_t>(), sorted_keys.as<uint64_t>(), M, 0, 64, s)); }
+	DeviceBuffer& sorted = ctx->scratch("fusions.sorted"); DeviceBuffer& heads = ctx->scratch("fusions.heads"); DeviceBuffer& candidate_of = ctx->scratch("fusions.candidate_of");
 	ALLOC(sorted, (size_t) M * sizeof(FusionEmission)); ALLOC(heads, (size_t) M * 4); ALLOC(candidate_of, (size_t) M * 4);
-	gather_sorted_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted_keys.as<uint64_t>(), emissions, sorted.as<FusionEmission>(), heads.as<uint32_t>());
+	{ KernelTimer timer(ctx, "gather_sorted_kernel", (uint64_t) M * (8 + 2 * sizeof(FusionEmission) + 4)); gather_sorted_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted_keys.as<uint64_t>(), emissions, sorted.as<FusionEmission>(), heads.as<uint32_t>()); }
 	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, heads.as<uint32_t>(), candidate_of.as<uint32_t>(), M, rocprim::plus<uint32_t>(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-	HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, heads.as<uint32_t>(), candidate_of.as<uint32_t>(), M, rocprim::plus<uint32_t>(), s));
+	{ KernelTimer timer(ctx, "rocprim::inclusive_scan(candidate ids)", (uint64_t) M * 8);
+	  HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, heads.as<uint32_t>(), candidate_of.as<uint32_t>(), M, rocprim::plus<uint32_t>(), s)); }
 	uint32_t C = 0;
 	HIP_CHECK(hipMemcpyAsync(&C, candidate_of.as<uint32_t>() + (M - 1), 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	sorted_keys.release();
 
 	// ---- prefix counts and per-candidate folds
-	DeviceBuffer rank_in, ranks, fold_in, folds;
+	DeviceBuffer& rank_in = ctx->scratch("fusions.rank_in"); DeviceBuffer& ranks = ctx->scratch("fusions.ranks"); DeviceBuffer& fold_in = ctx->scratch("fusions.fold_in"); DeviceBuffer& folds = ctx->scratch("fusions.folds");
 	ALLOC(rank_in, (size_t) M * sizeof(RankState)); ALLOC(ranks, (size_t) M * sizeof(RankState));
-	rank_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), rank_in.as<RankState>());
+	{ KernelTimer timer(ctx, "rank_input_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4 + sizeof(RankState))); rank_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), rank_in.as<RankState>()); }
 	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, rank_in.as<RankState>(), ranks.as<RankState>(), M, RankCombine(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-	HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, rank_in.as<RankState>(), ranks.as<RankState>(), M, RankCombine(), s));
-	rank_in.release();
+	{ KernelTimer timer(ctx, "rocprim::inclusive_scan(RankCombine)", (uint64_t) M * 2 * sizeof(RankState));
+	  HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, rank_in.as<RankState>(), ranks.as<RankState>(), M, RankCombine(), s)); }
 	ALLOC(fold_in, (size_t) M * sizeof(CandidateFold)); ALLOC(folds, (size_t) M * sizeof(CandidateFold));
-	fold_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), ranks.as<RankState>(), threshold, fold_in.as<CandidateFold>());
+	{ KernelTimer timer(ctx, "fold_input_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4 + sizeof(RankState) + sizeof(CandidateFold))); fold_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), ranks.as<RankState>(), threshold, fold_in.as<CandidateFold>()); }
 	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, fold_in.as<CandidateFold>(), folds.as<CandidateFold>(), M, CandidateCombine(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-	HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, fold_in.as<CandidateFold>(), folds.as<CandidateFold>(), M, CandidateCombine(), s));
-	fold_in.release();
+	{ KernelTimer timer(ctx, "rocprim::inclusive_scan(CandidateCombine)", (uint64_t) M * 2 * sizeof(CandidateFold));
+	  HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, fold_in.as<CandidateFold>(), folds.as<CandidateFold>(), M, CandidateCombine(), s)); }
 
 	// ---- candidate table
 	ALLOC(ctx->cand_gene1, (size_t) C * 4); ALLOC(ctx->cand_gene2, (size_t) C * 4); ALLOC(ctx->cand_contigs, (size_t) C * 4); ALLOC(ctx->cand_breakpoint1, (size_t) C * 4); ALLOC(ctx->cand_breakpoint2, (size_t) C * 4);
@@ -364,43 +395,53 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	t.breakpoint1 = ctx->cand_breakpoint1.as<int32_t>(); t.breakpoint2 = ctx->cand_breakpoint2.as<int32_t>(); t.flags = ctx->cand_flags.as<uint32_t>(); t.filter = ctx->cand_filter.as<uint8_t>();
 	t.split_reads1 = ctx->cand_split_reads1.as<uint32_t>(); t.split_reads2 = ctx->cand_split_reads2.as<uint32_t>(); t.discordant_mates = ctx->cand_discordant_mates.as<uint32_t>();
 	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint32_t>(); t.read_lists = nullptr;
-	DeviceBuffer list_size;
+	DeviceBuffer& list_size = ctx->scratch("fusions.list_size");
 	ALLOC(list_size, (3 * (size_t) C + 1) * 4);
 	HIP_CHECK(hipMemsetAsync(list_size.ptr, 0, (3 * (size_t) C + 1) * 4, s));
-	candidate_write_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), candidate_of.as<uint32_t>(), folds.as<CandidateFold>(), t, list_size.as<uint32_t>());
+	{ KernelTimer timer(ctx, "candidate_write_kernel", (uint64_t) M * (4 + 4) + (uint64_t) C * (sizeof(FusionEmission) + sizeof(CandidateFold) + 53)); candidate_write_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), candidate_of.as<uint32_t>(), folds.as<CandidateFold>(), t, list_size.as<uint32_t>()); }
 
 	// ---- discordant buckets by gene pair
-	DeviceBuffer discordant_flags, discordant_indices, selected_count, bucket_keys_in, bucket_keys, bucket_indices, bucket_emissions;
+	DeviceBuffer& discordant_flags = ctx->scratch("fusions.discordant_flags"); DeviceBuffer& discordant_indices = ctx->scratch("fusions.discordant_indices"); DeviceBuffer& selected_count = ctx->scratch("fusions.selected_count"); DeviceBuffer& bucket_keys_in = ctx->scratch("fusions.bucket_keys_in"); DeviceBuffer& bucket_keys = ctx->scratch("fusions.bucket_keys"); DeviceBuffer& bucket_indices = ctx->scratch("fusions.bucket_indices"); DeviceBuffer& bucket_columns = ctx->scratch("fusions.bucket_columns");
 	ALLOC(discordant_flags, M); ALLOC(discordant_indices, (size_t) M * 4); ALLOC(selected_count, 8);
-	discordant_flag_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, discordant_flags.as<uint8_t>());
+	{ KernelTimer timer(ctx, "discordant_flag_kernel", (uint64_t) M * (4 + 1)); discordant_flag_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, discordant_flags.as<uint8_t>()); }
 	HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), discordant_flags.as<uint8_t>(), discordant_indices.as<uint32_t>(), selected_count.as<uint32_t>(), M, s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-	HIP_CHECK(rocprim::select(scratch.buffer.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), discordant_flags.as<uint8_t>(), discordant_indices.as<uint32_t>(), selected_count.as<uint32_t>(), M, s));
+	{ KernelTimer timer(ctx, "rocprim::select(discordant)", (uint64_t) M * (1 + 4));
+	  HIP_CHECK(rocprim::select(scratch.buffer.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), discordant_flags.as<uint8_t>(), discordant_indices.as<uint32_t>(), selected_count.as<uint32_t>(), M, s)); }
 	uint32_t Md = 0;
 	HIP_CHECK(hipMemcpyAsync(&Md, selected_count.ptr, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	discordant_flags.release();
-	ALLOC(bucket_keys, (size_t) std::max<uint32_t>(Md, 1) * 8); ALLOC(bucket_emissions, (size_t) std::max<uint32_t>(Md, 1) * sizeof(FusionEmission));
+	const size_t Md1 = std::max<uint32_t>(Md, 1);
+	ALLOC(bucket_keys, Md1 * 8); ALLOC(bucket_columns, Md1 * 6 * 4);
+	DiscordantBucketColumns columns;
+	columns.breakpoint1 = bucket_columns.as<int32_t>(); columns.breakpoint2 = columns.breakpoint1 + Md1; columns.info = (uint32_t*) (columns.breakpoint2 + Md1); columns.read = columns.info + Md1;
+	columns.anchor1 = (int32_t*) (columns.read + Md1); columns.anchor2 = columns.anchor1 + Md1;
+	DiscordantBuckets buckets;
+	buckets.breakpoint1 = columns.breakpoint1; buckets.breakpoint2 = columns.breakpoint2; buckets.info = columns.info; buckets.read = columns.read; buckets.anchor1 = columns.anchor1; buckets.anchor2 = columns.anchor2;
 	if (Md > 0) {
 		ALLOC(bucket_keys_in, (size_t) Md * 8); ALLOC(bucket_indices, (size_t) Md * 4);
-		discordant_key_kernel<<<grid_for(Md), BLOCK, 0, s>>>(Md, discordant_indices.as<uint32_t>(), emissions, bucket_keys_in.as<uint64_t>());
+		{ KernelTimer timer(ctx, "discordant_key_kernel", (uint64_t) Md * (4 + 12 + 8)); discordant_key_kernel<<<grid_for(Md), BLOCK, 0, s>>>(Md, discordant_indices.as<uint32_t>(), emissions, bucket_keys_in.as<uint64_t>()); }
 		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, bucket_keys_in.as<uint64_t>(), bucket_keys.as<uint64_t>(), discordant_indices.as<uint32_t>(), bucket_indices.as<uint32_t>(), Md, 0, 64, s));
 		if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-		HIP_CHECK(rocprim::radix_sort_pairs(scratch.buffer.ptr, bytes, bucket_keys_in.as<uint64_t>(), bucket_keys.as<uint64_t>(), discordant_indices.as<uint32_t>(), bucket_indices.as<uint32_t>(), Md, 0, 64, s));
-		discordant_gather_kernel<<<grid_for(Md), BLOCK, 0, s>>>(Md, bucket_indices.as<uint32_t>(), emissions, bucket_emissions.as<FusionEmission>());
+		{ KernelTimer timer(ctx, "rocprim::radix_sort_pairs(buckets)", (uint64_t) Md * 2 * (8 + 4));
+		  HIP_CHECK(rocprim::radix_sort_pairs(scratch.buffer.ptr, bytes, bucket_keys_in.as<uint64_t>(), bucket_keys.as<uint64_t>(), discordant_indices.as<uint32_t>(), bucket_indices.as<uint32_t>(), Md, 0, 64, s)); }
+		{ KernelTimer timer(ctx, "discordant_gather_kernel", (uint64_t) Md * (4 + sizeof(FusionEmission) + 24)); discordant_gather_kernel<<<grid_for(Md), BLOCK, 0, s>>>(Md, bucket_indices.as<uint32_t>(), emissions, columns); }
 	}
 
 	// ---- discordant mates: count, offsets, fill
-	DeviceBuffer bucket_worklist, finish_worklist, worklist_sizes;
+	DeviceBuffer& bucket_worklist = ctx->scratch("fusions.bucket_worklist"); DeviceBuffer& finish_worklist = ctx->scratch("fusions.finish_worklist"); DeviceBuffer& worklist_sizes = ctx->scratch("fusions.worklist_sizes");
 	ALLOC(bucket_worklist, (size_t) C * sizeof(BucketRef)); ALLOC(finish_worklist, (size_t) C * 4); ALLOC(worklist_sizes, 16);
 	HIP_CHECK(hipMemsetAsync(worklist_sizes.ptr, 0, 16, s));
 	uint32_t* worklist_counts = worklist_sizes.as<uint32_t>(); // [0] attach (count pass), [1] attach (fill pass), [2] finish
-	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
+	{ KernelTimer timer(ctx, "attach_discordant_kernel(count)", (uint64_t) C * 25);
+	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, bucket_keys.as<uint64_t>(), buckets, Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false); }
 	uint32_t queued = 0;
 	HIP_CHECK(hipMemcpyAsync(&queued, worklist_counts + 0, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	if (queued > 0)
-		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_emissions.as<FusionEmission>(), max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
+	if (queued > 0) {
+		KernelTimer timer(ctx, "attach_discordant_wave_kernel(count)", 0);
+		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
+	}
 	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
 	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
@@ -410,20 +451,31 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	ALLOC(ctx->cand_read_lists, (size_t) std::max<uint32_t>(total_list, 1) * 4);
 	t.read_lists = ctx->cand_read_lists.as<uint32_t>();
 	ctx->n_list_entries = total_list;
-	split_list_fill_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), candidate_of.as<uint32_t>(), ranks.as<RankState>(), folds.as<CandidateFold>(), threshold, t);
-	attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_keys.as<uint64_t>(), bucket_emissions.as<FusionEmission>(), Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
-	if (queued > 0) // the fill pass queues the same candidates (possibly in another order)
-		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, bucket_emissions.as<FusionEmission>(), max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
-	finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>(), finish_worklist.as<uint32_t>(), worklist_counts + 2);
+	{ KernelTimer timer(ctx, "split_list_fill_kernel", (uint64_t) M * (sizeof(FusionEmission) + sizeof(RankState)));
+	  split_list_fill_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), candidate_of.as<uint32_t>(), ranks.as<RankState>(), folds.as<CandidateFold>(), threshold, t); }
+	{ KernelTimer timer(ctx, "attach_discordant_kernel(fill)", (uint64_t) C * 25);
+	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, bucket_keys.as<uint64_t>(), buckets, Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true); }
+	if (queued > 0) { // the fill pass queues the same candidates (possibly in another order)
+		// algorithmic bytes: every list entry is produced from one bucket row (two breakpoints, info, read, two anchors) and written once
+		KernelTimer timer(ctx, "attach_discordant_wave_kernel(fill)", (uint64_t) total_list * (24 + 4));
+		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
+	}
+	{ KernelTimer timer(ctx, "finish_kernel", (uint64_t) C * 45);
+	  finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>(), finish_worklist.as<uint32_t>(), worklist_counts + 2); }
 	{
 		// upper bound of the number of long lists without a round trip: every queued candidate owns more than SMALL_LIST list entries
 		uint64_t max_long = std::min<uint64_t>(C, (uint64_t) total_list / (SMALL_LIST + 1) + 1);
+		// algorithmic bytes: per list entry the read id + the fragment's strand/contig/coordinate columns the vote looks at
+		KernelTimer timer(ctx, "finish_wave_kernel", (uint64_t) total_list * (4 + 2 * (1 + 2 + 4) + 1));
 		finish_wave_kernel<<<grid_for(max_long * 64), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>(), finish_worklist.as<uint32_t>(), worklist_counts + 2);
 	}
+	ctx->n_queued_buckets = queued;
+	ctx->n_discordant_emissions = Md;
 
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
 	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
 	// algorithmic bytes: fragment end columns + gene sets read once, one emission written, candidate table + lists written
 	ctx->last_bytes = n * (3 * (2 + 4 + 4 + 1) + 3 * (1 + GENE_INLINE * 4) + 1) + (uint64_t) M * sizeof(FusionEmission) + (uint64_t) C * 53 + (uint64_t) total_list * 4;
 	ctx->n_candidates = C;
@@ -454,6 +506,12 @@ extern "C" int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uin
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	if (total) *total = ctx->n_list_entries;
 	if (reads && ctx->n_list_entries > 0) HIP_CHECK(hipMemcpy(reads, ctx->cand_read_lists.ptr, std::min<uint64_t>(capacity, ctx->n_list_entries) * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_get_fusion_stats(agpu_ctx* ctx, uint64_t* stats) {
+	if (!ctx || !ctx->fusions_done || !stats) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	stats[0] = ctx->n_emissions; stats[1] = ctx->n_candidates; stats[2] = ctx->n_list_entries; stats[3] = ctx->n_discordant_emissions; stats[4] = ctx->n_queued_buckets;
 	return AGPU_OK;
 }
 

@@ -20,7 +20,9 @@
 namespace agpu {
 
 // info bits of an emission / candidate
-enum : uint32_t { EINFO_UPSTREAM1 = 1, EINFO_UPSTREAM2 = 2, EINFO_SWAPPED = 4, EINFO_EXONIC1 = 8, EINFO_EXONIC2 = 16, EINFO_SPLIT = 32, EINFO_FILTER_SHIFT = 8 };
+// EINFO_SWAPPED: split read whose ends were exchanged to order the breakpoints; EINFO_MATES_SWAPPED: the same for a discordant
+// fragment (find_fusions swaps MATE1/MATE2 of such a fragment in place when it attaches it to a candidate, source/fusions.cpp:414-421)
+enum : uint32_t { EINFO_UPSTREAM1 = 1, EINFO_UPSTREAM2 = 2, EINFO_SWAPPED = 4, EINFO_EXONIC1 = 8, EINFO_EXONIC2 = 16, EINFO_SPLIT = 32, EINFO_MATES_SWAPPED = 64, EINFO_FILTER_SHIFT = 8 };
 
 struct FusionEmission {
 	uint32_t gene1, gene2;
@@ -106,7 +108,7 @@ AGPU_HD void write_emissions(const BatchView& b, uint64_t i, FusionEmission* out
 	load_genes(b, f.slot1, i, genes1); load_genes(b, f.slot2, i, genes2);
 	FusionEmission e;
 	e.breakpoint1 = f.breakpoint1; e.breakpoint2 = f.breakpoint2; e.contigs = f.contig1 << 16 | f.contig2;
-	e.info = (f.upstream1 ? EINFO_UPSTREAM1 : 0) | (f.upstream2 ? EINFO_UPSTREAM2 : 0) | (f.swapped && f.is_split ? EINFO_SWAPPED : 0) | (f.exonic1 ? EINFO_EXONIC1 : 0) | (f.exonic2 ? EINFO_EXONIC2 : 0) |
+	e.info = (f.upstream1 ? EINFO_UPSTREAM1 : 0) | (f.upstream2 ? EINFO_UPSTREAM2 : 0) | (f.swapped && f.is_split ? EINFO_SWAPPED : 0) | (f.swapped && !f.is_split ? EINFO_MATES_SWAPPED : 0) | (f.exonic1 ? EINFO_EXONIC1 : 0) | (f.exonic2 ? EINFO_EXONIC2 : 0) |
 	         (f.is_split ? EINFO_SPLIT : 0) | ((uint32_t) b.filter[i] << EINFO_FILTER_SHIFT);
 	e.anchor1 = f.anchor1; e.anchor2 = f.anchor2; e.read = (uint32_t) i;
 	uint32_t k = 0;
@@ -276,10 +278,13 @@ AGPU_HD bool discordant_mates_need_swap(const BatchView& b, uint64_t i) {
 	return contig1 > contig2 || (contig1 == contig2 && breakpoint1 > breakpoint2);
 }
 
+// The discordant emissions grouped by gene pair and directions (name order inside a bucket), as columns
+struct DiscordantBuckets { const int32_t* breakpoint1; const int32_t* breakpoint2; const uint32_t* info; const uint32_t* read; const int32_t* anchor1; const int32_t* anchor2; };
+
 // Attach the discordant mates of the candidate's gene pair (bucket = their emissions in name order) to candidate c
 // (source/fusions.cpp:367-437).  With out_list == NULL only the list size is returned (count pass); otherwise the list is
 // written, the anchors and the unfiltered count are updated and the fragments whose mates the reference swaps are flagged.
-AGPU_HD uint32_t attach_discordant_mates(const BatchView& b, const AnnotationView& ann, const CandidateTable& t, uint32_t c, const FusionEmission* bucket, uint32_t bucket_size,
+AGPU_HD uint32_t attach_discordant_mates(const AnnotationView& ann, const CandidateTable& t, uint32_t c, const DiscordantBuckets& buckets, uint32_t bucket_begin, uint32_t bucket_size,
                                          int32_t max_mate_gap, uint32_t threshold, bool has_split_reads, uint32_t* out_list, uint8_t* discordant_swapped) {
 	if (t.filter[c] != FILTER_none) return 0;
 	uint32_t flags = t.flags[c];
@@ -288,18 +293,19 @@ AGPU_HD uint32_t attach_discordant_mates(const BatchView& b, const AnnotationVie
 	int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
 	uint32_t list_size = 0, unfiltered = 0;
 	AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
-	for (uint32_t k = 0; k < bucket_size; ++k) {
-		const FusionEmission& e = bucket[k];
-		if (!discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, e.breakpoint1, e.breakpoint2))
+	for (uint32_t k = bucket_begin; k < bucket_begin + bucket_size; ++k) {
+		if (!discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, buckets.breakpoint1[k], buckets.breakpoint2[k]))
 			continue;
-		bool read_unfiltered = (e.info >> EINFO_FILTER_SHIFT & 255) == FILTER_none;
+		uint32_t info = buckets.info[k];
+		bool read_unfiltered = (info >> EINFO_FILTER_SHIFT & 255) == FILTER_none;
 		if (!read_unfiltered && list_size >= threshold) continue;
 		if (unfiltered >= threshold) break;
 		if (out_list) {
-			out_list[list_size] = e.read;
-			if (discordant_mates_need_swap(b, e.read)) discordant_swapped[e.read] = 1;
-			fold1 = anchor_combine(fold1, anchor_single(e.anchor1, upstream1), upstream1);
-			fold2 = anchor_combine(fold2, anchor_single(e.anchor2, upstream2), upstream2);
+			uint32_t read = buckets.read[k];
+			out_list[list_size] = read;
+			if ((info & EINFO_MATES_SWAPPED) && !discordant_swapped[read]) discordant_swapped[read] = 1;
+			fold1 = anchor_combine(fold1, anchor_single(buckets.anchor1[k], upstream1), upstream1);
+			fold2 = anchor_combine(fold2, anchor_single(buckets.anchor2[k], upstream2), upstream2);
 		}
 		++list_size;
 		if (read_unfiltered) ++unfiltered;

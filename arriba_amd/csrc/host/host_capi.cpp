@@ -12,6 +12,8 @@
 #include <memory>
 #include <set>
 #include <stdexcept>
+#include <tuple>
+#include <unordered_map>
 
 using namespace arriba;
 
@@ -350,3 +352,38 @@ int ahost_estimate_fragment_length(ahost_session* session, const int32_t* mate_g
 }
 
 } // extern "C"
+
+// ---- iteration order of the reference's candidate container (hazard H2) ---------------------------------------------------
+
+namespace {
+// the reference's tuple hash (source/common.hpp:294-314): h(element k) ^ (hash of the remaining elements << 4), std::hash of an integer = its value
+typedef std::tuple<unsigned int, unsigned int, unsigned short, unsigned short, int, int, bool, bool> CandidateKey;
+struct CandidateKeyHash {
+	size_t operator()(const CandidateKey& key) const {
+		size_t h7 = (size_t) std::get<7>(key);
+		size_t h6 = (size_t) std::get<6>(key) ^ h7 << 4;
+		size_t h5 = (size_t) std::get<5>(key) ^ h6 << 4; // int -> size_t sign-extends, as std::hash<int> does
+		size_t h4 = (size_t) std::get<4>(key) ^ h5 << 4;
+		size_t h3 = (size_t) std::get<3>(key) ^ h4 << 4;
+		size_t h2 = (size_t) std::get<2>(key) ^ h3 << 4;
+		size_t h1 = (size_t) std::get<1>(key) ^ h2 << 4;
+		return (size_t) std::get<0>(key) ^ h1 << 4;
+	}
+};
+}
+
+extern "C" int ahost_candidate_iteration_order(uint64_t n, const uint32_t* gene1, const uint32_t* gene2, const uint32_t* contigs, const int32_t* breakpoint1, const int32_t* breakpoint2, const uint32_t* flags, uint32_t* iteration_rank) {
+	// The reference keeps its candidates in std::unordered_map<8-tuple, fusion_t> (source/common.hpp:286) and several stages depend on
+	// the order in which that container iterates.  The order is a function of the insertion order (== candidate index here) and the
+	// hash values only, so the very same container type, filled in the same order, reproduces it.
+	if (!gene1 || !gene2 || !contigs || !breakpoint1 || !breakpoint2 || !flags || !iteration_rank) { g_error = "null argument"; return -1; }
+	std::unordered_map<CandidateKey, uint32_t, CandidateKeyHash> container;
+	for (uint64_t c = 0; c < n; ++c) {
+		CandidateKey key((unsigned int) gene1[c], (unsigned int) gene2[c], (unsigned short) (contigs[c] >> 16), (unsigned short) (contigs[c] & 0xFFFF), breakpoint1[c], breakpoint2[c],
+		                 (flags[c] & AGPU_CFLAG_UPSTREAM1) != 0, (flags[c] & AGPU_CFLAG_UPSTREAM2) != 0);
+		if (!container.insert(std::make_pair(key, (uint32_t) c)).second) { g_error = "duplicate candidate key"; return -1; }
+	}
+	uint32_t rank = 0;
+	for (auto entry = container.begin(); entry != container.end(); ++entry) iteration_rank[entry->second] = rank++;
+	return 0;
+}

@@ -245,6 +245,60 @@ class DevicePipeline(object):
         table["read_lists"] = reads[:total.value]
         return table
 
+    def candidate_iteration_order(self, table=None):
+        """rank of every candidate in the iteration order of the reference's fusions_t (hazard H2), computed by the host library"""
+        table = table if table is not None else self.candidates()
+        rank = np.zeros(max(self.n_candidates, 1), dtype=np.uint32)
+        columns = [np.ascontiguousarray(table[k]) for k in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags")]
+        if _capi.host_library().ahost_candidate_iteration_order(self.n_candidates, *[c.ctypes.data for c in columns], rank.ctypes.data) != 0:
+            raise ArribaError("ERROR: " + _capi.host_library().ahost_last_error().decode())
+        return rank[:self.n_candidates]
+
+    def set_candidate_state(self, filter=None, split_reads1=None, split_reads2=None, discordant_mates=None):
+        """push the columns an event-level host stage changed (reference: merge_adjacent_fusions, filter_multimappers)"""
+        arrays = [None if a is None else np.ascontiguousarray(a, dtype=t) for a, t in ((filter, np.uint8), (split_reads1, np.uint32), (split_reads2, np.uint32), (discordant_mates, np.uint32))]
+        self._check(self.api.set_candidate_state(self.ctx, *[None if a is None else a.ctypes.data for a in arrays]))
+
+    def estimate_expected_fusions(self, mapped_reads=None, iteration_rank=None):
+        """reference: estimate_expected_fusions, source/filter_relative_support.cpp:17-207; returns the e-values (float32)"""
+        if mapped_reads is None:
+            mapped_reads = self.session.mapped_reads
+        if iteration_rank is None:
+            iteration_rank = self.candidate_iteration_order()
+        iteration_rank = np.ascontiguousarray(iteration_rank, dtype=np.uint32)
+        self._check(self.api.estimate_expected_fusions(self.ctx, mapped_reads, iteration_rank.ctypes.data))
+        self._record("estimate_expected_fusions")
+        evalue = np.zeros(max(self.n_candidates, 1), dtype=np.float32)
+        self._check(self.api.get_evalues(self.ctx, evalue.ctypes.data))
+        return evalue[:self.n_candidates]
+
+    def filter_relative_support(self):
+        remaining = c_uint64()
+        self._check(self.api.filter_relative_support(self.ctx, byref(remaining)))
+        self._record("filter_relative_support")
+        return remaining.value
+
+    def fusion_stats(self):
+        stats = np.zeros(5, dtype=np.uint64)
+        self._check(self.api.get_fusion_stats(self.ctx, stats.ctypes.data))
+        return dict(zip(("emissions", "candidates", "list_entries", "discordant_emissions", "wave_buckets"), (int(v) for v in stats)))
+
+    def set_profiling(self, enabled):
+        """per-kernel HIP-event timing on the launch stream (reset on every call)"""
+        self._check(self.api.set_profiling(self.ctx, int(enabled)))
+
+    def kernel_profile(self):
+        """[(kernel name, ms, algorithmic bytes)] for every launch since set_profiling(True)"""
+        count = c_uint32()
+        self._check(self.api.get_kernel_profile(self.ctx, None, None, None, 0, byref(count)))
+        n = count.value
+        names = ctypes.create_string_buffer(max(n, 1) * _capi.KERNEL_NAME_LENGTH)
+        ms = np.zeros(max(n, 1), dtype=np.float32)
+        size = np.zeros(max(n, 1), dtype=np.uint64)
+        self._check(self.api.get_kernel_profile(self.ctx, names, ms.ctypes.data, size.ctypes.data, n, byref(count)))
+        raw = names.raw
+        return [(raw[k * _capi.KERNEL_NAME_LENGTH:(k + 1) * _capi.KERNEL_NAME_LENGTH].split(b"\0")[0].decode(), float(ms[k]), int(size[k])) for k in range(n)]
+
     def discordant_swapped(self):
         out = np.zeros(self.n, dtype=np.uint8)
         self._check(self.api.get_discordant_swapped(self.ctx, out.ctypes.data))

@@ -205,8 +205,22 @@ int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidate
 int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
                         uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor_start1, int32_t* anchor_start2, uint32_t* list_offset);
 int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capacity, uint64_t* total);
+/* sizes of the last agpu_find_fusions: stats[0] gene-pair emissions, [1] candidates, [2] read-list entries, [3] discordant emissions,
+ * [4] candidates whose discordant bucket was scanned by a whole wavefront */
+int agpu_get_fusion_stats(agpu_ctx* ctx, uint64_t* stats /* [5] */);
 /* 1 for every discordant fragment whose MATE1/MATE2 the reference swaps in place while attaching it (source/fusions.cpp:414-421) */
 int agpu_get_discordant_swapped(agpu_ctx* ctx, uint8_t* swapped /* [n] */);
+
+/* Candidate state as changed by the event-level stages that run on the host between find_fusions and the e-value
+ * (merge_adjacent_fusions, filter_multimappers: source/arriba.cpp:420-430).  NULL = leave the column as it is. */
+int agpu_set_candidate_state(agpu_ctx* ctx, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates);
+
+/* estimate_expected_fusions (source/filter_relative_support.cpp:17-207).  iteration_rank[c] = position of candidate c in the iteration
+ * order of the reference's fusions_t (ahost_candidate_iteration_order): the partner dedup of :22-29 keeps the first event per key. */
+int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_reads, const uint32_t* iteration_rank);
+int agpu_get_evalues(agpu_ctx* ctx, float* evalue /* [n_candidates] */);
+/* filter_relative_support (source/filter_relative_support.cpp:209-224); *remaining = the reference's "(remaining=N)" */
+int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining);
 
 /* result access (device -> host copies) */
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);
@@ -216,6 +230,13 @@ int agpu_get_fragment_bits(agpu_ctx* ctx, uint8_t* fbits /* [n] */);
 int agpu_get_gene_sets(agpu_ctx* ctx, int slot, uint8_t* count /* [n] */, uint32_t* genes, uint64_t capacity, uint64_t* total);
 /* gene table including dummy genes */
 int agpu_get_gene_table(agpu_ctx* ctx, uint32_t first, uint32_t count, uint16_t* contig, int32_t* start, int32_t* end, uint8_t* bits, int32_t* exonic_length);
+
+/* Per-kernel timing: while enabled, every kernel launch of the stage calls is bracketed by HIP events on the launch stream.
+ * agpu_get_kernel_profile returns one sample per launch since profiling was switched on (names: [capacity][AGPU_KERNEL_NAME_LENGTH],
+ * ms: duration, bytes: algorithmic bytes of that launch, 0 = not modelled); *count receives the number of samples available. */
+#define AGPU_KERNEL_NAME_LENGTH 48
+int agpu_set_profiling(agpu_ctx* ctx, int enabled);
+int agpu_get_kernel_profile(agpu_ctx* ctx, char* names, float* ms, uint64_t* bytes, uint32_t capacity, uint32_t* count);
 
 /* timing of the kernels launched by the last call, measured with HIP events on the launch stream (ms) */
 int agpu_last_kernel_ms(agpu_ctx* ctx, float* ms);

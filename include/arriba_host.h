@@ -54,6 +54,11 @@ int ahost_viral_verdicts(ahost_session* session, const uint32_t* pairs, uint64_t
 int ahost_estimate_fragment_length(ahost_session* session, const int32_t* mate_gaps, uint32_t n_samples, uint64_t fragments_visited, unsigned int default_fragment_length,
                                    float* mate_gap_mean, float* mate_gap_stddev, float* read_length_mean, int32_t* max_mate_gap);
 
+/* Position of every candidate in the iteration order of the reference's fusions_t (std::unordered_map with the tuple hash of
+ * source/common.hpp:286-314), given the candidates in insertion order as agpu_get_candidates returns them.  Stages whose result
+ * depends on that order (partner dedup in estimate_expected_fusions, source/filter_relative_support.cpp:22-29) take it as input. */
+int ahost_candidate_iteration_order(uint64_t n, const uint32_t* gene1, const uint32_t* gene2, const uint32_t* contigs, const int32_t* breakpoint1, const int32_t* breakpoint2, const uint32_t* flags, uint32_t* iteration_rank);
+
 #ifdef __cplusplus
 }
 #endif

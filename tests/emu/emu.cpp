@@ -15,6 +15,10 @@
 #include "../../include/arriba_gpu.h"
 #include "../../arriba_amd/csrc/device/filter_core.hpp"
 #include "../../arriba_amd/csrc/device/fusion_core.hpp"
+#include "../../arriba_amd/csrc/device/evalue_host.hpp"
+#include <map>
+#include <set>
+#include <tuple>
 
 using namespace agpu;
 

@@ -148,3 +148,57 @@ def check_candidates(session, pipeline, golden):
                 problems.append((field, key))
     assert not problems, problems[:10]
     return len(fusions)
+
+
+def candidate_keys(table, n):
+    return [(int(table["gene1"][c]), int(table["gene2"][c]), int(table["contigs"][c]) >> 16, int(table["contigs"][c]) & 0xFFFF, int(table["breakpoint1"][c]), int(table["breakpoint2"][c]),
+             int(table["flags"][c]) & 1, (int(table["flags"][c]) >> 1) & 1) for c in range(n)]
+
+
+def fusion_key(f):
+    return (f["gene1"], f["gene2"], f["contig1"], f["contig2"], f["breakpoint1"], f["breakpoint2"], f["direction1"], f["direction2"])
+
+
+def check_evalues(session, pipeline, golden):
+    """estimate_expected_fusions + filter_relative_support against the reference's dumps.  The stages between find_fusions and the e-value
+    (merge_adjacent_fusions, filter_multimappers) are not part of this check: their effect on the candidate columns is taken from the dump."""
+    after_evalue = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "estimate_expected_fusions"))
+    table = pipeline.candidates()
+    n = pipeline.n_candidates
+    assert len(after_evalue) == n
+    index = {key: c for c, key in enumerate(candidate_keys(table, n))}
+    # hazard H2: the dump is written in the iteration order of the reference's unordered_map
+    rank = pipeline.candidate_iteration_order(table)
+    assert [index[fusion_key(f)] for f in after_evalue] == [int(c) for c in np.argsort(rank)]
+    state = {k: np.zeros(n, dtype=np.uint32) for k in ("filter", "split_reads1", "split_reads2", "discordant_mates")}
+    expected = np.zeros(n, dtype=np.uint32)
+    for f in after_evalue:
+        c = index[fusion_key(f)]
+        for k in state:
+            state[k][c] = f[k]
+        expected[c] = f["evalue_bits"]
+        flags = int(table["flags"][c])  # the flag columns are not touched by the intermediate stages
+        assert ((flags >> 4) & 1, (flags >> 5) & 1, (flags >> 2) & 1, (flags >> 3) & 1) == (f["spliced1"], f["spliced2"], f["exonic1"], f["exonic2"])
+    pipeline.set_candidate_state(state["filter"].astype(np.uint8), state["split_reads1"], state["split_reads2"], state["discordant_mates"])
+    evalue = pipeline.estimate_expected_fusions(iteration_rank=rank)
+    bits = evalue.view(np.uint32)
+    different = [(c, hex(int(bits[c])), hex(int(expected[c]))) for c in range(n) if bits[c] != expected[c]]
+    assert not different, (len(different), different[:10])
+    # filter_relative_support: state before = dump after with `relative_support` undone (the stages in between only set other ids)
+    after_filter = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_relative_support"))
+    relative_support = 12
+    before = np.zeros(n, dtype=np.uint8)
+    expected_filter = np.zeros(n, dtype=np.uint8)
+    for f in after_filter:
+        c = index[fusion_key(f)]
+        expected_filter[c] = f["filter"]
+        before[c] = 0 if f["filter"] == relative_support else f["filter"]
+        assert f["evalue_bits"] == expected[c]
+    pipeline.set_candidate_state(filter=before)
+    remaining = pipeline.filter_relative_support()
+    assert np.array_equal(pipeline.candidates()["filter"], expected_filter)
+    log = open(os.path.join(golden, "reference.log")).read()
+    import re
+    match = re.search(r"Filtering fusions with an e-value[^\n]*\(remaining=(\d+)\)", log)
+    assert match and remaining == int(match.group(1))
+    return n

@@ -25,6 +25,7 @@ def test_read_level_cascade_matches_reference(name, dataset_files):
     if name == "toy3k":
         pipeline.find_fusions()
         assert parity.check_candidates(session, pipeline, golden) > 1000
+        assert parity.check_evalues(session, pipeline, golden) > 1000
 
 
 def test_live_reference_on_larger_dataset(built, tmp_path):
@@ -50,6 +51,7 @@ def test_live_reference_on_larger_dataset(built, tmp_path):
     parity.check_annotation(session, pipeline, dump)
     pipeline.find_fusions()
     assert parity.check_candidates(session, pipeline, dump) > 10000
+    assert parity.check_evalues(session, pipeline, dump) > 10000
 
 
 def test_hip_path_matches_oracle_restatement_on_fresh_inputs(built, tmp_path):

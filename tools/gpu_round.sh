@@ -1,12 +1,24 @@
+# tools/gpu_round.sh TAG [pmc] -- one GPU-box round: GPU parity tests, bench line, rocprofv3 kernel trace, optional PMC passes.
+TAG=${1:-r01x}
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-nproc > gpurun_out/nproc.txt; lscpu | head -20 >> gpurun_out/nproc.txt
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
-timeout 900 python bench.py > gpurun_out/bench_1.json 2> gpurun_out/bench_1.err; echo "bench exit $?" >> gpurun_out/bench_1.err
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/${TAG}_pytest_gpu.log
+timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench exit $?" >> gpurun_out/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r1b -o bench10m -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/bench_prof.json 2> $GRAFT_REPO_ROOT/gpurun_out/bench_prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o bench10m -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_prof.json 2> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_prof.err
 cd $GRAFT_REPO_ROOT
-find gpurun_out/prof_r1b -name '*.db' | head -1 | xargs -I{} python tools/rocprof_summary.py {} "round 1b: bench.py 10M fragments, steps 3 warmup 1" > gpurun_out/prof_r1b_summary.txt 2>&1
-find gpurun_out/prof_r1b -name '*.db' -delete
-tail -5 gpurun_out/pytest_gpu.log; cat gpurun_out/bench_1.json; head -12 gpurun_out/prof_r1b_summary.txt
+find gpurun_out/prof_${TAG} -name '*.db' | head -1 | xargs -I{} python tools/rocprof_summary.py {} "${TAG}: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 (10 M fragments)" > gpurun_out/${TAG}_kernel_stats.txt 2>&1
+rm -rf gpurun_out/prof_${TAG}
+if [ "$2" = "pmc" ]; then
+  cd /tmp
+  for COUNTER in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $COUNTER --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$COUNTER -o pmc -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$COUNTER.log 2>&1
+  done
+  cd $GRAFT_REPO_ROOT
+  python tools/pmc_summary.py gpurun_out/${TAG}_pmc.json gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE > gpurun_out/${TAG}_pmc_summary.txt 2>&1
+  ls -R gpurun_out/pmc_${TAG}_FETCH_SIZE | head -20
+  head -3 $(find gpurun_out/pmc_${TAG}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+  rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
+fi
+tail -5 gpurun_out/${TAG}_pytest_gpu.log; cat gpurun_out/${TAG}_bench.json; head -14 gpurun_out/${TAG}_kernel_stats.txt
