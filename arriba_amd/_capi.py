@@ -93,6 +93,10 @@ def bind_device_api(lib, prefix="agpu_"):
         "get_gene_sets": (c_int, [ctx, c_int, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
         "get_gene_table": (c_int, [ctx, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
         "get_fusion_stats": (c_int, [ctx, c_void_p]),
+        "set_read_filters": (c_int, [ctx, c_void_p]),
+        "make_kmer_index": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
+        "filter_mismappers": (c_int, [ctx, c_int32, POINTER(c_uint64), POINTER(c_uint64)]),
+        "candidate_iteration_order": (c_int, [ctx, c_void_p]),
         "set_candidate_state": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_void_p]),
         "estimate_expected_fusions": (c_int, [ctx, c_uint64, c_void_p]),
         "get_evalues": (c_int, [ctx, c_void_p]),

@@ -453,7 +453,7 @@ int agpu_upload_annotation(agpu_ctx* ctx, const agpu_annotation_view* in) {
 	TRY(upload_index(in->gene_index, ctx->gene_index_contig_offset, ctx->gene_index_keys, ctx->gene_index_member_offset, ctx->gene_index_members, ctx->annotation.gene_index, s));
 	refresh_annotation_view(ctx);
 	HIP_CHECK(hipStreamSynchronize(s));
-	ctx->have_annotation = true; ctx->annotated = false;
+	ctx->have_annotation = true; ctx->annotated = false; ctx->have_splice_sites = false;
 	return AGPU_OK;
 }
 
@@ -530,6 +530,7 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 	b.gene_pool = ctx->gene_pool.as<uint32_t>(); b.gene_pool_used = ctx->counters.as<uint32_t>() + COUNTER_GENE_POOL; b.gene_pool_capacity = pool_capacity;
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
+	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false;
 	if (ctx->have_genome) TRY(build_tables(ctx));
 	return AGPU_OK;
 }
@@ -554,6 +555,7 @@ int agpu_reset(agpu_ctx* ctx) {
 	refresh_annotation_view(ctx);
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
+	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false;
 	return AGPU_OK;
 }
 

@@ -96,10 +96,15 @@ struct agpu_ctx {
 	// find_fusions
 	agpu::DeviceBuffer emissions, discordant_swapped;
 	agpu::DeviceBuffer cand_gene1, cand_gene2, cand_contigs, cand_breakpoint1, cand_breakpoint2, cand_flags, cand_filter, cand_split_reads1, cand_split_reads2, cand_discordant_mates;
-	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists, cand_evalue;
+	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists, cand_evalue, cand_iteration_rank;
 	agpu::DeviceBuffer evalue_support_scale, evalue_intragenic_support, evalue_intergenic_support, evalue_distance_tables;
 	agpu::EvalueGlobals evalue_globals;
-	bool evalue_done = false;
+	bool evalue_done = false, iteration_order_done = false;
+
+	// k-mer index + splice sites (filter_mismappers)
+	agpu::DeviceBuffer kmer_contig_table, kmer_offsets, kmer_positions, splice_offset, splice_sites;
+	uint32_t kmer_positions_count = 0, splice_sites_for_dummy = 0, mismapper_jobs = 0;
+	bool kmer_index_done = false, have_splice_sites = false;
 	agpu::CandidateTable candidates;
 	uint32_t n_emissions = 0, n_candidates = 0, n_list_entries = 0, n_queued_buckets = 0, n_discordant_emissions = 0;
 	bool fusions_done = false;

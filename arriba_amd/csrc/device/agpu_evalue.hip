@@ -151,7 +151,8 @@ extern "C" int agpu_set_candidate_state(agpu_ctx* ctx, const uint8_t* filter, co
 }
 
 extern "C" int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_reads, const uint32_t* iteration_rank) {
-	if (!ctx || !ctx->fusions_done || !iteration_rank) { set_last_error("agpu_find_fusions must run first and the iteration order is required"); return AGPU_ERR_INVALID; }
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!iteration_rank && !ctx->iteration_order_done) { set_last_error("pass the iteration order or call agpu_candidate_iteration_order first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	const uint32_t C = ctx->n_candidates;
@@ -162,9 +163,15 @@ extern "C" int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_rea
 	if (C == 0) { ctx->evalue_done = true; return AGPU_OK; }
 	if (2ull * C >= 0xFFFFFFF0ull) { set_last_error("too many candidates for the partner table"); return AGPU_ERR_CAPACITY; }
 
-	DeviceBuffer rank, slots, pairs, sorted_pairs, pair_count, set_size, partner_count, counters, gene_marks, scratch;
-	ALLOC(rank, (size_t) C * 4);
-	HIP_CHECK(hipMemcpyAsync(rank.ptr, iteration_rank, (size_t) C * 4, hipMemcpyHostToDevice, s));
+	DeviceBuffer& rank = ctx->scratch("evalue.rank"); DeviceBuffer& slots = ctx->scratch("evalue.slots"); DeviceBuffer& pairs = ctx->scratch("evalue.pairs"); DeviceBuffer& sorted_pairs = ctx->scratch("evalue.sorted_pairs");
+	DeviceBuffer& pair_count = ctx->scratch("evalue.pair_count"); DeviceBuffer& set_size = ctx->scratch("evalue.set_size"); DeviceBuffer& partner_count = ctx->scratch("evalue.partner_count");
+	DeviceBuffer& counters = ctx->scratch("evalue.counters"); DeviceBuffer& gene_marks = ctx->scratch("evalue.gene_marks"); DeviceBuffer& scratch = ctx->scratch("evalue.rocprim");
+	const uint32_t* device_rank = ctx->cand_iteration_rank.as<uint32_t>();
+	if (iteration_rank) {
+		ALLOC(rank, (size_t) C * 4);
+		HIP_CHECK(hipMemcpyAsync(rank.ptr, iteration_rank, (size_t) C * 4, hipMemcpyHostToDevice, s));
+		device_rank = rank.as<uint32_t>();
+	}
 	uint64_t n_slots = 1024;
 	while (n_slots < 4ull * C) n_slots <<= 1; // two events per candidate, load factor <= 0.5
 	const uint32_t mask = (uint32_t) (n_slots - 1);
@@ -178,7 +185,7 @@ extern "C" int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_rea
 	HIP_CHECK(hipMemsetAsync(gene_marks.ptr, 0, gene_marks.bytes, s));
 
 	(void) hipEventRecord(ctx->event_start, s);
-	{ KernelTimer timer(ctx, "partner_insert_kernel", (uint64_t) C * (4 + 1 + 16 + 2 * 8)); partner_insert_kernel<<<grid_for(2ull * C), BLOCK, 0, s>>>(t, rank.as<uint32_t>(), slots.as<unsigned long long>(), mask); }
+	{ KernelTimer timer(ctx, "partner_insert_kernel", (uint64_t) C * (4 + 1 + 16 + 2 * 8)); partner_insert_kernel<<<grid_for(2ull * C), BLOCK, 0, s>>>(t, device_rank, slots.as<unsigned long long>(), mask); }
 	{ KernelTimer timer(ctx, "partner_resolve_kernel", (uint64_t) C * (1 + 16 + 2 * 8 + 2 * 8)); partner_resolve_kernel<<<grid_for(2ull * C), BLOCK, 0, s>>>(t, slots.as<unsigned long long>(), mask, pairs.as<uint64_t>(), pair_count.as<uint32_t>()); }
 	{ KernelTimer timer(ctx, "evalue_globals_kernel", (uint64_t) C * 34); evalue_globals_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, counters.as<unsigned int>(), gene_marks.as<uint8_t>()); }
 	gene_mark_count_kernel<<<grid_for(n_genes), BLOCK, 0, s>>>(gene_marks.as<uint8_t>(), n_genes, counters.as<unsigned int>() + 12);
@@ -190,7 +197,7 @@ extern "C" int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_rea
 	if (n_pairs > 0) {
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, pairs.as<uint64_t>(), sorted_pairs.as<uint64_t>(), n_pairs, 0, 64, s));
-		ALLOC(scratch, bytes);
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
 		{ KernelTimer timer(ctx, "rocprim::radix_sort_keys(partner pairs)", (uint64_t) n_pairs * 16);
 		  HIP_CHECK(rocprim::radix_sort_keys(scratch.ptr, bytes, pairs.as<uint64_t>(), sorted_pairs.as<uint64_t>(), n_pairs, 0, 64, s)); }
 		partner_size_kernel<<<grid_for(n_pairs), BLOCK, 0, s>>>(sorted_pairs.as<uint64_t>(), n_pairs, set_size.as<int32_t>());
@@ -235,7 +242,7 @@ extern "C" int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining) 
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	const uint32_t C = ctx->n_candidates;
-	DeviceBuffer counter;
+	DeviceBuffer& counter = ctx->scratch("evalue.remaining");
 	ALLOC(counter, 16);
 	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
 	(void) hipEventRecord(ctx->event_start, s);

@@ -1,0 +1,312 @@
+// arriba_amd/csrc/device/agpu_mismappers.hip -- make_kmer_index + filter_mismappers on the device
+// (reference: source/filter_mismappers.cpp:16-359, called at source/arriba.cpp:547-565).
+//
+//   kmer_gene_flag_kernel       genes of unfiltered candidates with gene1 != gene2 (:50-58)
+//   kmer_window_mark_kernel     bitmap over the genome: positions inside the padded window of an indexed gene (:65-74)
+//   kmer_count/write_kernel     (table << 16 | 8-mer, position) for every marked position whose base is not N, in genome order
+//   rocPRIM radix_sort_pairs    stable sort by (contig table, 8-mer): positions stay ascending inside a bucket (:77-84)
+//   kmer_offsets_kernel         CSR offsets: 4^8 + 1 per indexed contig
+//   splice_site_count/write     downstream splice sites of every gene (:16-31) as a second CSR
+//   mismapper_flag/verdict      reads of unfiltered candidates -> greedy seed-and-extend re-alignment (mismapper_core.hpp), one thread per read
+//   mismapper_candidate_kernel  fraction of mis-mappers per candidate (:336-356)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+#include "agpu_context.hpp"
+#include "mismapper_core.hpp"
+
+using namespace agpu;
+
+namespace {
+
+const int BLOCK = 256;
+const int ALIGN_BLOCK = 64; // the frame stack of align() lives in scratch: keep the workgroups small
+inline unsigned int grid_for(uint64_t n, int block = BLOCK) { return (unsigned int) ((n + block - 1) / block); }
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+
+__global__ void kmer_gene_flag_kernel(CandidateTable t, uint8_t* gene_flags) {
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n || t.filter[c] != FILTER_none) return;
+	uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
+	if (gene1 == gene2) return; // sequence similarity only makes sense between different genes
+	gene_flags[gene1] = 1; gene_flags[gene2] = 1;
+}
+
+// window of gene g: positions p with max(start - padding, 0) <= p and p + 8 < min(end + padding, contig size - 1)
+__global__ void kmer_window_mark_kernel(AnnotationView ann, GenomeView genome, const uint8_t* gene_flags, int32_t padding, uint32_t* bitmap) {
+	const uint32_t gene = blockIdx.x;
+	if (!gene_flags[gene]) return;
+	const uint32_t contig = ann.gene_contig[gene];
+	const uint64_t contig_begin = genome.contig_offset[contig];
+	const int64_t contig_size = (int64_t) (genome.contig_offset[contig + 1] - contig_begin);
+	int64_t first = (int64_t) ann.gene_start[gene] - padding; if (first < 0) first = 0;
+	int64_t gene_end = (int64_t) ann.gene_end[gene] + padding; if (gene_end > contig_size - 1) gene_end = contig_size - 1;
+	const int64_t last = gene_end - KMER_LENGTH; // exclusive
+	if (first >= last) return;
+	const uint64_t bit_begin = contig_begin + (uint64_t) first, bit_end = contig_begin + (uint64_t) last;
+	for (uint64_t word = (bit_begin >> 5) + threadIdx.x; word <= ((bit_end - 1) >> 5); word += blockDim.x) {
+		uint32_t mask = 0xFFFFFFFFu;
+		if (word == (bit_begin >> 5)) mask &= 0xFFFFFFFFu << (bit_begin & 31);
+		if (word == ((bit_end - 1) >> 5)) mask &= 0xFFFFFFFFu >> (31 - ((bit_end - 1) & 31));
+		atomicOr(&bitmap[word], mask);
+	}
+}
+
+__device__ __forceinline__ uint32_t indexable_bits(const GenomeView& genome, const uint32_t* bitmap, uint64_t word, uint64_t genome_size) {
+	uint32_t bits = bitmap[word];
+	if (bits == 0) return 0;
+	uint32_t valid = 0;
+	for (uint32_t k = 0; k < 32; ++k) {
+		uint64_t position = (word << 5) + k;
+		if ((bits >> k & 1) && position < genome_size && genome.bases[position] != 'N') valid |= 1u << k; // masked regions are not indexed
+	}
+	return valid;
+}
+__global__ void kmer_count_kernel(GenomeView genome, const uint32_t* bitmap, uint64_t n_words, uint64_t genome_size, uint32_t* counts) {
+	uint64_t word = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (word >= n_words) return;
+	counts[word] = __popc(indexable_bits(genome, bitmap, word, genome_size));
+}
+__global__ void kmer_write_kernel(GenomeView genome, const uint32_t* bitmap, uint64_t n_words, uint64_t genome_size, const uint32_t* offsets, const uint32_t* contig_table, uint32_t* keys, int32_t* positions) {
+	uint64_t word = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (word >= n_words) return;
+	uint32_t valid = indexable_bits(genome, bitmap, word, genome_size);
+	if (valid == 0) return;
+	uint32_t at = offsets[word];
+	// contig of the first position of this word
+	uint32_t lo = 0, hi = genome.n_contigs;
+	const uint64_t base = word << 5;
+	while (lo + 1 < hi) { uint32_t mid = (lo + hi) >> 1; if (genome.contig_offset[mid] <= base) lo = mid; else hi = mid; }
+	uint32_t contig = lo;
+	for (uint32_t k = 0; k < 32; ++k) {
+		if (!(valid >> k & 1)) continue;
+		uint64_t position = base + k;
+		while (contig + 1 < genome.n_contigs && position >= genome.contig_offset[contig + 1]) ++contig;
+		uint32_t kmer = 0;
+		for (int j = 0; j < KMER_LENGTH; ++j) kmer = kmer << 2 | kmer_digit_of_char(genome.bases[position + j]);
+		keys[at] = contig_table[contig] << 16 | kmer;
+		positions[at] = (int32_t) (position - genome.contig_offset[contig]);
+		++at;
+	}
+}
+__global__ void kmer_offsets_kernel(const uint32_t* sorted_keys, uint32_t n, uint32_t n_entries, uint32_t* offsets) {
+	uint32_t entry = blockIdx.x * BLOCK + threadIdx.x;
+	if (entry > n_entries) return;
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (sorted_keys[mid] < entry) lo = mid + 1; else hi = mid; }
+	offsets[entry] = lo;
+}
+
+// reference: get_downstream_splice_sites (source/filter_mismappers.cpp:16-31); write == false counts
+__global__ void splice_site_kernel(AnnotationView ann, uint32_t n_genes_total, const uint32_t* offsets, uint32_t* counts, int32_t* sites, bool write) {
+	uint32_t gene = blockIdx.x * BLOCK + threadIdx.x;
+	if (gene >= n_genes_total) return;
+	const FlatIndexView& index = ann.exon_index;
+	uint32_t contig = ann.gene_contig[gene];
+	uint32_t found = 0;
+	if (contig < index.n_contigs && index.contig_offset[contig] != index.contig_offset[contig + 1]) {
+		uint32_t k = index_lower_bound(index, contig, ann.gene_start[gene]);
+		const uint32_t contig_end = index.contig_offset[contig + 1];
+		const int32_t gene_end = ann.gene_end[gene];
+		for (; k != contig_end && index.keys[k] <= gene_end; ++k)
+			if (is_breakpoint_spliced(ann, gene, false, index.keys[k])) {
+				if (write) sites[offsets[gene] + found] = index.keys[k];
+				++found;
+			}
+	}
+	if (!write) counts[gene] = found;
+}
+
+__global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags) {
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n || t.filter[c] != FILTER_none) return;
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	for (uint32_t k = offsets[0]; k < offsets[3]; ++k) {
+		uint32_t read = t.read_lists[k];
+		if (b.filter[read] == FILTER_none && !read_flags[read]) read_flags[read] = 1;
+	}
+}
+
+__global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap, unsigned int* discarded) {
+	uint32_t j = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
+	bool mismapper = false;
+	if (j < n_jobs) {
+		AlignFrame stack[ALIGN_MAX_DEPTH];
+		uint32_t read = jobs[j];
+		mismapper = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, stack);
+		if (mismapper) b.filter[read] = FILTER_mismappers;
+	}
+	unsigned long long ballot = __ballot(mismapper);
+	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(discarded, (unsigned int) __popcll(ballot));
+}
+
+__global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, unsigned int* remaining) {
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	bool kept = false;
+	if (c < t.n && t.filter[c] == FILTER_none) {
+		if (count_candidate_mismappers(b, t, c, max_mismapper_fraction)) t.filter[c] = FILTER_mismappers; else kept = true;
+	}
+	unsigned long long ballot = __ballot(kept);
+	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(remaining, (unsigned int) __popcll(ballot));
+}
+
+int build_splice_sites(agpu_ctx* ctx) {
+	hipStream_t s = ctx->stream;
+	const uint32_t n_genes_total = ctx->n_genes + ctx->n_dummy;
+	DeviceBuffer& counts = ctx->scratch("mismappers.splice_counts"); DeviceBuffer& scratch = ctx->scratch("mismappers.rocprim");
+	ALLOC(counts, ((size_t) n_genes_total + 1) * 4); ALLOC(ctx->splice_offset, ((size_t) n_genes_total + 1) * 4);
+	HIP_CHECK(hipMemsetAsync(counts.ptr, 0, ((size_t) n_genes_total + 1) * 4, s));
+	splice_site_kernel<<<grid_for(n_genes_total), BLOCK, 0, s>>>(ctx->annotation, n_genes_total, nullptr, counts.as<uint32_t>(), nullptr, false);
+	size_t bytes = 0;
+	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, counts.as<uint32_t>(), ctx->splice_offset.as<uint32_t>(), 0u, (size_t) n_genes_total + 1, rocprim::plus<uint32_t>(), s));
+	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+	HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, counts.as<uint32_t>(), ctx->splice_offset.as<uint32_t>(), 0u, (size_t) n_genes_total + 1, rocprim::plus<uint32_t>(), s));
+	uint32_t total = 0;
+	HIP_CHECK(hipMemcpyAsync(&total, ctx->splice_offset.as<uint32_t>() + n_genes_total, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	ALLOC(ctx->splice_sites, (size_t) std::max<uint32_t>(total, 1) * 4);
+	splice_site_kernel<<<grid_for(n_genes_total), BLOCK, 0, s>>>(ctx->annotation, n_genes_total, ctx->splice_offset.as<uint32_t>(), nullptr, ctx->splice_sites.as<int32_t>(), true);
+	ctx->splice_sites_for_dummy = ctx->n_dummy;
+	ctx->have_splice_sites = true;
+	return AGPU_OK;
+}
+
+}
+
+extern "C" int agpu_set_read_filters(agpu_ctx* ctx, const uint8_t* filter) {
+	if (!ctx || !ctx->have_batch || !filter) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (ctx->n) HIP_CHECK(hipMemcpy(ctx->filter.ptr, filter, ctx->n, hipMemcpyHostToDevice));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_make_kmer_index(agpu_ctx* ctx, int32_t padding, uint64_t* n_positions) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint32_t n_genes_total = ctx->n_genes + ctx->n_dummy;
+	const uint32_t n_contigs = ctx->genome.n_contigs;
+	const uint64_t genome_size = ctx->host_contig_offset[n_contigs];
+	const uint64_t n_words = (genome_size + 31) >> 5;
+	if (padding < 0) padding = 0;
+	ctx->kmer_index_done = false;
+	DeviceBuffer& gene_flags = ctx->scratch("mismappers.gene_flags"); DeviceBuffer& bitmap = ctx->scratch("mismappers.bitmap"); DeviceBuffer& counts = ctx->scratch("mismappers.counts");
+	DeviceBuffer& offsets = ctx->scratch("mismappers.offsets"); DeviceBuffer& keys = ctx->scratch("mismappers.keys"); DeviceBuffer& positions = ctx->scratch("mismappers.positions");
+	DeviceBuffer& sorted_keys = ctx->scratch("mismappers.sorted_keys"); DeviceBuffer& scratch = ctx->scratch("mismappers.rocprim");
+	ALLOC(gene_flags, std::max<uint32_t>(n_genes_total, 1)); ALLOC(bitmap, (n_words + 1) * 4); ALLOC(counts, (n_words + 1) * 4); ALLOC(offsets, (n_words + 1) * 4);
+	HIP_CHECK(hipMemsetAsync(gene_flags.ptr, 0, std::max<uint32_t>(n_genes_total, 1), s));
+	HIP_CHECK(hipMemsetAsync(bitmap.ptr, 0, (n_words + 1) * 4, s));
+	HIP_CHECK(hipMemsetAsync(counts.ptr, 0, (n_words + 1) * 4, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0) { KernelTimer timer(ctx, "kmer_gene_flag_kernel", (uint64_t) C * 9); kmer_gene_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->candidates, gene_flags.as<uint8_t>()); }
+
+	// contigs that hold an indexed gene get an offset table
+	std::vector<uint8_t> host_flags(n_genes_total);
+	std::vector<uint16_t> host_gene_contig(n_genes_total);
+	if (n_genes_total) {
+		HIP_CHECK(hipMemcpyAsync(host_flags.data(), gene_flags.ptr, n_genes_total, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(host_gene_contig.data(), ctx->gene_contig.ptr, (size_t) n_genes_total * 2, hipMemcpyDeviceToHost, s));
+	}
+	HIP_CHECK(hipStreamSynchronize(s));
+	std::vector<uint32_t> contig_table(n_contigs, NO_KMER_TABLE);
+	uint32_t n_tables = 0, n_indexed_genes = 0;
+	for (uint32_t g = 0; g < n_genes_total; ++g)
+		if (host_flags[g]) {
+			++n_indexed_genes;
+			if (host_gene_contig[g] < n_contigs && contig_table[host_gene_contig[g]] == NO_KMER_TABLE) contig_table[host_gene_contig[g]] = 0;
+		}
+	for (uint32_t contig = 0; contig < n_contigs; ++contig) if (contig_table[contig] != NO_KMER_TABLE) contig_table[contig] = n_tables++;
+	if (n_tables >= 65536) { set_last_error("too many contigs with indexed genes"); return AGPU_ERR_CAPACITY; }
+	ALLOC(ctx->kmer_contig_table, (size_t) std::max<uint32_t>(n_contigs, 1) * 4);
+	HIP_CHECK(hipMemcpyAsync(ctx->kmer_contig_table.ptr, contig_table.data(), (size_t) n_contigs * 4, hipMemcpyHostToDevice, s));
+
+	uint32_t total = 0;
+	if (n_indexed_genes > 0) {
+		{ KernelTimer timer(ctx, "kmer_window_mark_kernel", 0); kmer_window_mark_kernel<<<n_genes_total, BLOCK, 0, s>>>(ctx->annotation, ctx->genome, gene_flags.as<uint8_t>(), padding, bitmap.as<uint32_t>()); }
+		{ KernelTimer timer(ctx, "kmer_count_kernel", n_words * 8); kmer_count_kernel<<<grid_for(n_words), BLOCK, 0, s>>>(ctx->genome, bitmap.as<uint32_t>(), n_words, genome_size, counts.as<uint32_t>()); }
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n_words + 1, rocprim::plus<uint32_t>(), s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n_words + 1, rocprim::plus<uint32_t>(), s));
+		HIP_CHECK(hipMemcpyAsync(&total, offsets.as<uint32_t>() + n_words, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	ALLOC(ctx->kmer_positions, (size_t) std::max<uint32_t>(total, 1) * 4);
+	ALLOC(ctx->kmer_offsets, ((size_t) std::max<uint32_t>(n_tables, 1) * KMER_COUNT + 1) * 4);
+	if (total > 0) {
+		ALLOC(keys, (size_t) total * 4); ALLOC(positions, (size_t) total * 4); ALLOC(sorted_keys, (size_t) total * 4);
+		{ KernelTimer timer(ctx, "kmer_write_kernel", (uint64_t) total * (8 + 8) + n_words * 8);
+		  kmer_write_kernel<<<grid_for(n_words), BLOCK, 0, s>>>(ctx->genome, bitmap.as<uint32_t>(), n_words, genome_size, offsets.as<uint32_t>(), ctx->kmer_contig_table.as<uint32_t>(), keys.as<uint32_t>(), positions.as<int32_t>()); }
+		uint32_t key_bits = 16;
+		while ((1u << (key_bits - 16)) < n_tables) ++key_bits;
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys.as<uint32_t>(), sorted_keys.as<uint32_t>(), positions.as<int32_t>(), ctx->kmer_positions.as<int32_t>(), total, 0, key_bits, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		{ KernelTimer timer(ctx, "rocprim::radix_sort_pairs(kmer index)", (uint64_t) total * 16);
+		  HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys.as<uint32_t>(), sorted_keys.as<uint32_t>(), positions.as<int32_t>(), ctx->kmer_positions.as<int32_t>(), total, 0, key_bits, s)); }
+	}
+	const uint32_t n_entries = std::max<uint32_t>(n_tables, 1) * KMER_COUNT;
+	{ KernelTimer timer(ctx, "kmer_offsets_kernel", (uint64_t) n_entries * 4); kmer_offsets_kernel<<<grid_for((uint64_t) n_entries + 1), BLOCK, 0, s>>>(sorted_keys.as<uint32_t>(), total, n_entries, ctx->kmer_offsets.as<uint32_t>()); }
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) total * 24 + n_words * 16;
+	ctx->kmer_positions_count = total;
+	ctx->kmer_index_done = true;
+	if (n_positions) *n_positions = total;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* remaining, uint64_t* discarded_reads) {
+	if (!ctx || !ctx->kmer_index_done) { set_last_error("agpu_make_kmer_index must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint64_t n = ctx->n;
+	if (!ctx->have_splice_sites || ctx->splice_sites_for_dummy != ctx->n_dummy) { int status = build_splice_sites(ctx); if (status != AGPU_OK) return status; }
+	DeviceBuffer& read_flags = ctx->scratch("mismappers.read_flags"); DeviceBuffer& jobs = ctx->scratch("mismappers.jobs"); DeviceBuffer& counters = ctx->scratch("mismappers.counters");
+	DeviceBuffer& scratch = ctx->scratch("mismappers.rocprim");
+	ALLOC(read_flags, n ? n : 1); ALLOC(jobs, (n ? n : 1) * 4); ALLOC(counters, 16);
+	HIP_CHECK(hipMemsetAsync(read_flags.ptr, 0, n ? n : 1, s));
+	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 16, s));
+	unsigned int* device_counters = counters.as<unsigned int>(); // [0] jobs, [1] reads discarded, [2] candidates remaining
+	KmerIndexView kmers;
+	kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
+	SpliceSiteView splice;
+	splice.offset = ctx->splice_offset.as<uint32_t>(); splice.sites = ctx->splice_sites.as<int32_t>();
+	(void) hipEventRecord(ctx->event_start, s);
+	uint32_t n_jobs = 0;
+	if (C > 0 && n > 0) {
+		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>()); }
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::select(scratch.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
+		HIP_CHECK(hipMemcpyAsync(&n_jobs, device_counters, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (n_jobs > 0) {
+			KernelTimer timer(ctx, "mismapper_verdict_kernel", (uint64_t) n_jobs * 300);
+			mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
+		}
+		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
+		  mismapper_candidate_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, device_counters + 2); }
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) n_jobs * 300 + (uint64_t) ctx->n_list_entries * 10;
+	unsigned int host_counters[4];
+	HIP_CHECK(hipMemcpy(host_counters, counters.ptr, sizeof(host_counters), hipMemcpyDeviceToHost));
+	if (remaining) *remaining = host_counters[2];
+	if (discarded_reads) *discarded_reads = host_counters[1];
+	ctx->mismapper_jobs = n_jobs;
+	return AGPU_OK;
+}

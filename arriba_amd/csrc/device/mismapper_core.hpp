@@ -1,0 +1,291 @@
+// arriba_amd/csrc/device/mismapper_core.hpp -- re-alignment of chimeric reads to the "other" gene
+// (reference: make_kmer_index, align, align_both_strands, extend_split_read, filter_mismappers; source/filter_mismappers.cpp:16-359).
+//
+// The reference's k-mer index (unordered_map<8-mer, sorted vector<position>> per contig) is a CSR here: for every contig that
+// holds an indexed gene a table of 4^8 + 1 offsets into one array of ascending positions.  The downstream splice sites of every
+// gene (source/filter_mismappers.cpp:16-31) are a second CSR.  align() is the reference's greedy seed-and-extend search with its
+// two recursive re-seeds; the recursion is an explicit stack of resumable frames, the order of evaluation is the reference's.
+#ifndef AGPU_MISMAPPER_CORE_HPP
+#define AGPU_MISMAPPER_CORE_HPP 1
+
+#include <math.h>
+#include "fusion_core.hpp"
+
+namespace agpu {
+
+const int KMER_LENGTH = 8;                 // source/arriba.cpp:548
+const uint32_t KMER_COUNT = 1u << (2 * KMER_LENGTH);
+const uint32_t NO_KMER_TABLE = 0xFFFFFFFFu;
+
+struct KmerIndexView {
+	const uint32_t* contig_table;   // [n_contigs] slot of the contig's offset table or NO_KMER_TABLE
+	const uint32_t* offsets;        // [n_tables * KMER_COUNT + 1] into positions
+	const int32_t* positions;       // ascending within a (contig, k-mer) bucket
+	uint32_t n_contigs;
+};
+struct SpliceSiteView {
+	const uint32_t* offset;         // [n_genes + n_dummy + 1]
+	const int32_t* sites;           // downstream splice sites of the gene, ascending
+};
+
+// reference: kmer_to_int (source/filter_mismappers.cpp:33-45) on the genome's ASCII bases: T=0, G=1, C=2, everything else 3
+AGPU_HD uint32_t kmer_digit_of_char(char base) { return base == 'T' ? 0u : base == 'G' ? 1u : base == 'C' ? 2u : 3u; }
+
+// a substring of a read's sequence, optionally reverse-complemented (dna_to_reverse_complement, source/assembly.cpp)
+struct Segment {
+	SequenceRef sequence; uint32_t offset, length; bool reverse_complement;
+	AGPU_HD uint32_t code(uint32_t i) const { return reverse_complement ? complement_code(sequence.code(offset + length - 1 - i)) : sequence.code(offset + i); }
+	AGPU_HD char at(uint32_t i) const { return base_char(code(i)); }
+	AGPU_HD uint32_t kmer(uint32_t position) const {
+		uint32_t result = 0;
+		for (int k = 0; k < KMER_LENGTH; ++k) result = result << 2 | kmer_digit(code(position + k));
+		return result;
+	}
+};
+
+struct AlignTarget { // one gene window on one contig
+	const char* contig_bases; // bases of the contig (genome.bases + contig offset)
+	const uint32_t* kmer_offsets; // the contig's offset table (KMER_COUNT + 1 entries) or null
+	const int32_t* positions;
+	const int32_t* splice_sites; uint32_t n_splice_sites;
+	int32_t gene_start, gene_end;
+};
+
+AGPU_HD uint32_t lower_bound_i32(const int32_t* values, uint32_t lo, uint32_t hi, int32_t value) {
+	while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (values[mid] < value) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+AGPU_HD bool is_splice_site(const AlignTarget& target, int32_t position) {
+	uint32_t at = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, position);
+	return at < target.n_splice_sites && target.splice_sites[at] == position;
+}
+
+// One invocation of the reference's align() (source/filter_mismappers.cpp:86-199) as a resumable frame: the two recursive
+// re-seeds of the reference push a child frame and continue behind the call when the child reports failure.
+enum { ALIGN_NEXT_READ_POSITION = 0, ALIGN_NEXT_HIT = 1, ALIGN_RIGHT_LOOP = 2, ALIGN_COMPARE_BASE = 3, ALIGN_AFTER_MISMATCH = 4, ALIGN_ADVANCE = 5 };
+struct AlignFrame {
+	int32_t score, read_pos, skipped_bases, gene_pos, max_deletions;
+	uint32_t hit, hits_end;               // current / end index into positions for the k-mer at read_pos
+	int32_t extended_score, extended_read_pos, extended_gene_pos;
+	uint32_t mismatch_count, consecutive_mismatches;
+	uint8_t leading;                      // read_pos == skipped_bases (only the outermost call starts at read position 0)
+	uint8_t state;
+	uint8_t started;                      // the read_pos loop has been entered (its increment runs before every later iteration)
+};
+const int ALIGN_MAX_DEPTH = 40;           // every nested call starts >= 8 bases further into a read of < 300 bases
+
+AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t gene_pos, int32_t max_deletions) {
+	f.score = score; f.read_pos = read_pos; f.skipped_bases = 0; f.gene_pos = gene_pos; f.max_deletions = max_deletions;
+	f.leading = read_pos == 0; f.state = ALIGN_NEXT_READ_POSITION; f.started = 0; f.hit = 0; f.hits_end = 0;
+}
+
+// returns true if the segment aligns to the target with a score >= min_score
+AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack) {
+	const int32_t length = (int32_t) read.length;
+	int depth = 0;
+	align_enter(stack[0], 0, 0, target.gene_start, 1);
+	while (depth >= 0) {
+		AlignFrame& f = stack[depth];
+		switch (f.state) {
+			case ALIGN_NEXT_READ_POSITION: { // for (; read_pos + k < length && ...; read_pos++, score--, skipped_bases++)
+				if (f.started) { f.read_pos++; f.score--; f.skipped_bases++; }
+				f.started = 1;
+				if (!(f.read_pos + KMER_LENGTH < length && f.read_pos + min_score <= length + f.score + 2 * KMER_LENGTH)) { --depth; break; } // this call returns false
+				if (target.kmer_offsets == 0) break; // no k-mer index on this contig: every lookup misses
+				uint32_t kmer = read.kmer((uint32_t) f.read_pos);
+				uint32_t begin = target.kmer_offsets[kmer], end = target.kmer_offsets[kmer + 1];
+				f.hit = lower_bound_i32(target.positions, begin, end, f.gene_pos);
+				f.hits_end = end;
+				f.state = ALIGN_NEXT_HIT;
+				if (f.hit < f.hits_end) --f.hit; else f.state = ALIGN_NEXT_READ_POSITION; // ALIGN_NEXT_HIT pre-increments
+				break;
+			}
+			case ALIGN_NEXT_HIT: { // for (hit = lower_bound(gene_pos); hit != end && *hit < gene_end; ++hit)
+				++f.hit;
+				if (!(f.hit < f.hits_end && target.positions[f.hit] < target.gene_end)) { f.state = ALIGN_NEXT_READ_POSITION; break; }
+				const int32_t kmer_hit = target.positions[f.hit];
+				f.extended_score = f.score + KMER_LENGTH;
+				if (f.leading) f.extended_score += f.skipped_bases; // no penalty for leading skipped bases (local alignment)
+				if (f.extended_score >= min_score) return true;
+				// extend to the left over the skipped bases, one mismatch allowed
+				int32_t left_read_pos = f.read_pos - 1, left_gene_pos = kmer_hit - 1;
+				uint32_t left_mismatches = 0;
+				while (left_read_pos >= f.read_pos - f.skipped_bases && left_gene_pos >= target.gene_start) {
+					if (read.at((uint32_t) left_read_pos) == target.contig_bases[left_gene_pos]) {
+						f.extended_score += f.leading ? 1 : 2;
+						if (f.extended_score >= min_score) return true;
+					} else {
+						if (++left_mismatches > 1) break;
+					}
+					left_read_pos--; left_gene_pos--;
+				}
+				f.extended_read_pos = f.read_pos + KMER_LENGTH;
+				f.extended_gene_pos = kmer_hit + KMER_LENGTH;
+				f.mismatch_count = 0; f.consecutive_mismatches = 0;
+				f.state = ALIGN_RIGHT_LOOP;
+				break;
+			}
+			case ALIGN_RIGHT_LOOP: { // while (extended_read_pos < length && extended_gene_pos <= gene_end)
+				if (!(f.extended_read_pos < length && f.extended_gene_pos <= target.gene_end)) { f.state = ALIGN_NEXT_HIT; break; }
+				f.state = ALIGN_COMPARE_BASE;
+				if (is_splice_site(target, f.extended_gene_pos - 1)) { // re-seed behind a splice site (spliced alignment)
+					if (depth + 1 >= ALIGN_MAX_DEPTH) return false; // unreachable for reads < 300 bases
+					align_enter(stack[depth + 1], f.extended_score, f.extended_read_pos, f.extended_gene_pos, f.max_deletions);
+					++depth;
+				}
+				break;
+			}
+			case ALIGN_COMPARE_BASE: {
+				if (read.at((uint32_t) f.extended_read_pos) == target.contig_bases[f.extended_gene_pos]) {
+					f.extended_score++;
+					if (f.extended_score >= min_score) return true;
+					f.consecutive_mismatches = 0;
+					f.state = ALIGN_ADVANCE;
+				} else {
+					f.mismatch_count++;
+					f.state = ALIGN_AFTER_MISMATCH;
+					if (f.mismatch_count == 1 && f.max_deletions > 0 && length >= 30) { // re-seed once after the first mismatch (deletion / intron)
+						if (depth + 1 >= ALIGN_MAX_DEPTH) return false;
+						align_enter(stack[depth + 1], f.extended_score, f.extended_read_pos, f.extended_gene_pos, f.max_deletions - 1);
+						++depth;
+					}
+				}
+				break;
+			}
+			case ALIGN_AFTER_MISMATCH: {
+				f.extended_score--;
+				f.consecutive_mismatches++;
+				f.state = (f.consecutive_mismatches >= 4) ? ALIGN_NEXT_HIT : ALIGN_ADVANCE;
+				break;
+			}
+			default: { // ALIGN_ADVANCE
+				f.extended_read_pos++; f.extended_gene_pos++;
+				f.state = ALIGN_RIGHT_LOOP;
+				break;
+			}
+		}
+	}
+	return false;
+}
+
+// reference: align_both_strands (source/filter_mismappers.cpp:201-245).  `segment` is the part of the read to re-align, read_length the
+// length of the whole read; the genes are those of the other end of the fragment.
+AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int32_t max_mate_gap, bool breakpoints_on_same_contig, int32_t alignment_start, int32_t alignment_end,
+                                const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, const IdSet& genes, float min_align_fraction, AlignFrame* stack) {
+	if (segment.length >= 300) return false; // long reads are not re-aligned
+	const int32_t min_score = (int32_t) ((double) (min_align_fraction * (float) segment.length) + 0.5);
+	for (uint32_t g = 0; g < genes.n; ++g) {
+		const uint32_t gene = genes.v[g];
+		const uint32_t contig = ann.gene_contig[gene];
+		const int64_t contig_size = (int64_t) (genome.contig_offset[contig + 1] - genome.contig_offset[contig]);
+		AlignTarget target;
+		target.gene_start = ann.gene_start[gene] - max_mate_gap - read_length; if (target.gene_start < 0) target.gene_start = 0;
+		target.gene_end = ann.gene_end[gene] + max_mate_gap + read_length; if ((int64_t) target.gene_end > contig_size - 1) target.gene_end = (int32_t) (contig_size - 1);
+		// intragenic events / overlapping genes: donor and acceptor both overlap the breakpoint, the read would always be discarded
+		if (breakpoints_on_same_contig && ((alignment_start >= target.gene_start && alignment_start <= target.gene_end) || (alignment_end >= target.gene_start && alignment_end <= target.gene_end)))
+			continue;
+		const uint32_t table = contig < kmers.n_contigs ? kmers.contig_table[contig] : NO_KMER_TABLE;
+		target.kmer_offsets = table == NO_KMER_TABLE ? 0 : kmers.offsets + (size_t) table * KMER_COUNT;
+		target.positions = kmers.positions;
+		target.contig_bases = genome.bases + genome.contig_offset[contig];
+		target.splice_sites = splice.sites + splice.offset[gene]; target.n_splice_sites = splice.offset[gene + 1] - splice.offset[gene];
+		Segment forward = segment; forward.reverse_complement = false;
+		if (align(forward, target, min_score, stack)) return true;
+		Segment reverse = segment; reverse.reverse_complement = true;
+		if (align(reverse, target, min_score, stack)) return true;
+	}
+	return false;
+}
+
+// reference: extend_split_read (source/filter_mismappers.cpp:247-270): did the aligner clip prematurely?
+AGPU_HD bool extend_split_read(const BatchView& b, const GenomeView& genome, uint64_t i, const SequenceRef& sequence, float min_align_fraction) {
+	const uint32_t* cigar = cigar_of(b, SPLIT_READ, i); const uint32_t n_cigar = b.cigar_count[SPLIT_READ][i];
+	const uint32_t contig = b.contig[SPLIT_READ][i];
+	const char* contig_bases = genome.bases + genome.contig_offset[contig];
+	const int64_t contig_size = (int64_t) (genome.contig_offset[contig + 1] - genome.contig_offset[contig]);
+	int64_t clipped_count, read_from, reference_from;
+	if (b.abits[SPLIT_READ][i] & ABIT_STRAND) {
+		const int64_t clip = preclipping(cigar, n_cigar), start = b.start[SPLIT_READ][i];
+		clipped_count = clip < start ? clip : start; // do not run over the contig boundary
+		read_from = clip - clipped_count; reference_from = start - clipped_count;
+	} else {
+		const int64_t clip = postclipping(cigar, n_cigar), end = b.end[SPLIT_READ][i];
+		clipped_count = clip < contig_size - end - 2 ? clip : contig_size - end - 2;
+		read_from = (int64_t) sequence.length - clip; reference_from = end + 1;
+	}
+	if (clipped_count < 0 || read_from < 0) clipped_count = 0; // out of the reference's defined behaviour (substr would throw)
+	if (read_from + clipped_count > (int64_t) sequence.length) clipped_count = (int64_t) sequence.length > read_from ? (int64_t) sequence.length - read_from : 0; // substr clamps
+	uint32_t matching_bases = 0;
+	for (int64_t k = 0; k < clipped_count; ++k) {
+		const int64_t reference_position = reference_from + k;
+		const char reference_base = (reference_position >= 0 && reference_position < contig_size) ? contig_bases[reference_position] : '\0';
+		if (sequence.at((uint32_t) (read_from + k)) == reference_base) ++matching_bases;
+	}
+	return (float) matching_bases >= floorf((float) clipped_count * min_align_fraction);
+}
+
+// Does fragment i support its fusion only because it is mis-mapped?  reference: the per-read part of filter_mismappers
+// (source/filter_mismappers.cpp:283-332); a pure function of the fragment, its gene sets, max_mate_gap and the k-mer index.
+AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, uint64_t i, int32_t max_mate_gap, AlignFrame* stack) {
+	const float min_align_fraction = 0.8f, min_extended_align_fraction = 0.7f;
+	IdSet genes;
+	if (b.n_aln[i] == 3) {
+		const SequenceRef split_sequence = sequence_of(b, SPLIT_READ, i, no_stage()), mate1_sequence = sequence_of(b, MATE1, i, no_stage());
+		const bool same_contig = b.contig[SPLIT_READ][i] == b.contig[SUPPLEMENTARY][i]; // == fusion.contig1 == fusion.contig2
+		if (extend_split_read(b, genome, i, split_sequence, min_extended_align_fraction)) return true;
+		const uint32_t* split_cigar = cigar_of(b, SPLIT_READ, i); const uint32_t split_n = b.cigar_count[SPLIT_READ][i];
+		const uint32_t* mate1_cigar = cigar_of(b, MATE1, i); const uint32_t mate1_n = b.cigar_count[MATE1][i];
+		Segment clipped, mate; clipped.sequence = split_sequence; clipped.reverse_complement = false; mate.sequence = mate1_sequence; mate.reverse_complement = false;
+		if (b.abits[SPLIT_READ][i] & ABIT_STRAND) {
+			uint32_t clip = preclipping(split_cigar, split_n); if (clip > split_sequence.length) clip = split_sequence.length;
+			clipped.offset = 0; clipped.length = clip;                                         // sequence.substr(0, preclipping)
+			uint32_t mate_clip = preclipping(mate1_cigar, mate1_n); if (mate_clip > mate1_sequence.length) mate_clip = mate1_sequence.length;
+			mate.offset = mate_clip; mate.length = mate1_sequence.length - mate_clip;          // mate1.sequence.substr(preclipping)
+		} else {
+			uint32_t clip = postclipping(split_cigar, split_n); if (clip > split_sequence.length) clip = split_sequence.length;
+			clipped.offset = split_sequence.length - clip; clipped.length = clip;             // sequence.substr(length - postclipping)
+			uint32_t mate_clip = postclipping(mate1_cigar, mate1_n); if (mate_clip > mate1_sequence.length) mate_clip = mate1_sequence.length;
+			mate.offset = 0; mate.length = mate1_sequence.length - mate_clip;                  // mate1.sequence.substr(0, length - postclipping)
+		}
+		load_genes(b, SPLIT_READ, i, genes);
+		if (align_both_strands(clipped, (int32_t) split_sequence.length, max_mate_gap, same_contig, b.start[SUPPLEMENTARY][i], b.end[SUPPLEMENTARY][i], ann, genome, kmers, splice, genes, min_align_fraction, stack))
+			return true; // the clipped segment aligns to the donor
+		load_genes(b, SUPPLEMENTARY, i, genes);
+		return align_both_strands(mate, (int32_t) mate1_sequence.length, max_mate_gap, same_contig, b.start[MATE1][i], b.end[MATE1][i], ann, genome, kmers, splice, genes, min_align_fraction, stack); // the mate aligns to the acceptor
+	}
+	// discordant mates: an alignment as long as the chimeric alignment suffices
+	const bool same_contig = b.contig[MATE1][i] == b.contig[MATE2][i];
+	for (int mate = MATE1; mate <= MATE2; ++mate) {
+		const SequenceRef sequence = sequence_of(b, mate, i, no_stage());
+		const uint32_t* cigar = cigar_of(b, mate, i); const uint32_t n_cigar = b.cigar_count[mate][i];
+		const float clipped_fraction = ((float) preclipping(cigar, n_cigar) + postclipping(cigar, n_cigar)) / sequence.length;
+		const float reduced = min_align_fraction * (1 - clipped_fraction);
+		Segment whole; whole.sequence = sequence; whole.offset = 0; whole.length = sequence.length; whole.reverse_complement = false;
+		load_genes(b, mate == MATE1 ? MATE2 : MATE1, i, genes);
+		if (align_both_strands(whole, (int32_t) sequence.length, max_mate_gap, same_contig, b.start[mate][i], b.end[mate][i], ann, genome, kmers, splice, genes, reduced < min_align_fraction ? reduced : min_align_fraction, stack))
+			return true;
+	}
+	return false;
+}
+
+// reference: count_mismappers + the final loop of filter_mismappers (source/filter_mismappers.cpp:247-258, 336-356) for an unfiltered
+// candidate: updates its three counters and returns true if the candidate is discarded
+AGPU_HD bool count_candidate_mismappers(const BatchView& b, const CandidateTable& t, uint32_t c, float max_mismapper_fraction) {
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	uint16_t total_reads = 0, mismappers = 0; // short unsigned int in the reference
+	uint32_t* counters[3] = { t.split_reads1 + c, t.split_reads2 + c, t.discordant_mates + c };
+	for (int list = 0; list < 3; ++list) {
+		uint32_t supporting_reads = *counters[list];
+		for (uint32_t k = offsets[list]; k < offsets[list + 1]; ++k) {
+			uint8_t filter = b.filter[t.read_lists[k]];
+			if (filter == FILTER_none) total_reads++;
+			else if (filter == FILTER_mismappers) { total_reads++; mismappers++; if (supporting_reads > 0) supporting_reads--; }
+		}
+		*counters[list] = supporting_reads;
+	}
+	return mismappers > 0 && (double) mismappers >= floor((double) (max_mismapper_fraction * (float) total_reads));
+}
+
+}
+
+#endif

@@ -245,8 +245,15 @@ class DevicePipeline(object):
         table["read_lists"] = reads[:total.value]
         return table
 
-    def candidate_iteration_order(self, table=None):
-        """rank of every candidate in the iteration order of the reference's fusions_t (hazard H2), computed by the host library"""
+    def candidate_iteration_order(self):
+        """rank of every candidate in the iteration order of the reference's fusions_t (hazard H2), computed on the device"""
+        rank = np.zeros(max(self.n_candidates, 1), dtype=np.uint32)
+        self._check(self.api.candidate_iteration_order(self.ctx, rank.ctypes.data))
+        self._record("candidate_iteration_order")
+        return rank[:self.n_candidates]
+
+    def candidate_iteration_order_on_host(self, table=None):
+        """the same order from the literal std::unordered_map of the host library (the check of the device computation)"""
         table = table if table is not None else self.candidates()
         rank = np.zeros(max(self.n_candidates, 1), dtype=np.uint32)
         columns = [np.ascontiguousarray(table[k]) for k in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags")]
@@ -264,9 +271,13 @@ class DevicePipeline(object):
         if mapped_reads is None:
             mapped_reads = self.session.mapped_reads
         if iteration_rank is None:
-            iteration_rank = self.candidate_iteration_order()
-        iteration_rank = np.ascontiguousarray(iteration_rank, dtype=np.uint32)
-        self._check(self.api.estimate_expected_fusions(self.ctx, mapped_reads, iteration_rank.ctypes.data))
+            self._check(self.api.candidate_iteration_order(self.ctx, None))
+            self._record("candidate_iteration_order")
+            pointer = None
+        else:
+            iteration_rank = np.ascontiguousarray(iteration_rank, dtype=np.uint32)
+            pointer = iteration_rank.ctypes.data
+        self._check(self.api.estimate_expected_fusions(self.ctx, mapped_reads, pointer))
         self._record("estimate_expected_fusions")
         evalue = np.zeros(max(self.n_candidates, 1), dtype=np.float32)
         self._check(self.api.get_evalues(self.ctx, evalue.ctypes.data))
@@ -277,6 +288,30 @@ class DevicePipeline(object):
         self._check(self.api.filter_relative_support(self.ctx, byref(remaining)))
         self._record("filter_relative_support")
         return remaining.value
+
+    def set_read_filters(self, filters):
+        """push the read-level filter ids a host stage changed (reference: filter_multimappers)"""
+        filters = np.ascontiguousarray(filters, dtype=np.uint8)
+        assert filters.size == self.n
+        self._check(self.api.set_read_filters(self.ctx, filters.ctypes.data))
+
+    def make_kmer_index(self, padding=None):
+        """reference: make_kmer_index, source/filter_mismappers.cpp:47-84; padding as in source/arriba.cpp:552"""
+        if padding is None:
+            padding = int(np.float32(self.scalars["max_mate_gap"]) + np.float32(2) * np.float32(self.scalars["read_length_mean"]))
+        positions = c_uint64()
+        self._check(self.api.make_kmer_index(self.ctx, padding, byref(positions)))
+        self._record("make_kmer_index")
+        return positions.value
+
+    def filter_mismappers(self, max_mate_gap=None):
+        """reference: filter_mismappers, source/filter_mismappers.cpp:272-359; returns (remaining candidates, reads discarded)"""
+        if max_mate_gap is None:
+            max_mate_gap = self.scalars["max_mate_gap"]
+        remaining, discarded = c_uint64(), c_uint64()
+        self._check(self.api.filter_mismappers(self.ctx, max_mate_gap, byref(remaining), byref(discarded)))
+        self._record("filter_mismappers")
+        return remaining.value, discarded.value
 
     def fusion_stats(self):
         stats = np.zeros(5, dtype=np.uint64)

@@ -215,12 +215,29 @@ int agpu_get_discordant_swapped(agpu_ctx* ctx, uint8_t* swapped /* [n] */);
  * (merge_adjacent_fusions, filter_multimappers: source/arriba.cpp:420-430).  NULL = leave the column as it is. */
 int agpu_set_candidate_state(agpu_ctx* ctx, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates);
 
+/* Position of every candidate in the iteration order of the reference's fusions_t (std::unordered_map with the tuple hash of
+ * source/common.hpp:286-314, hazard H2), computed on the device and kept there for the stages that need it; iteration_rank may be NULL. */
+int agpu_candidate_iteration_order(agpu_ctx* ctx, uint32_t* iteration_rank /* [n_candidates] */);
+
 /* estimate_expected_fusions (source/filter_relative_support.cpp:17-207).  iteration_rank[c] = position of candidate c in the iteration
- * order of the reference's fusions_t (ahost_candidate_iteration_order): the partner dedup of :22-29 keeps the first event per key. */
+ * order of the reference's fusions_t: the partner dedup of :22-29 keeps the first event per key.  NULL = use the order computed by
+ * agpu_candidate_iteration_order. */
 int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_reads, const uint32_t* iteration_rank);
 int agpu_get_evalues(agpu_ctx* ctx, float* evalue /* [n_candidates] */);
 /* filter_relative_support (source/filter_relative_support.cpp:209-224); *remaining = the reference's "(remaining=N)" */
 int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining);
+
+/* Read-level filter state as changed by stages that run on the host after the read-level cascade (filter_multimappers,
+ * source/arriba.cpp:427-430): replaces the filter id of every fragment. */
+int agpu_set_read_filters(agpu_ctx* ctx, const uint8_t* filter /* [n] */);
+
+/* make_kmer_index (source/filter_mismappers.cpp:47-84, called at source/arriba.cpp:547-553): 8-mer positions of the genes of all
+ * unfiltered candidates with gene1 != gene2, padded by `padding` = max_mate_gap + 2 * read_length_mean (as int). */
+int agpu_make_kmer_index(agpu_ctx* ctx, int32_t padding, uint64_t* n_positions);
+/* filter_mismappers (source/filter_mismappers.cpp:272-359): re-aligns the reads of every unfiltered candidate to the other gene
+ * (mis-mapped reads get the filter id `mismappers`), then discards candidates that consist mostly of mis-mappers and lowers
+ * their counters.  *remaining = the reference's "(remaining=N)"; *discarded_reads = reads newly marked as mis-mappers. */
+int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* remaining, uint64_t* discarded_reads);
 
 /* result access (device -> host copies) */
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);

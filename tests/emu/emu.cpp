@@ -16,6 +16,8 @@
 #include "../../arriba_amd/csrc/device/filter_core.hpp"
 #include "../../arriba_amd/csrc/device/fusion_core.hpp"
 #include "../../arriba_amd/csrc/device/evalue_host.hpp"
+#include "../../arriba_amd/csrc/device/order_host.hpp"
+#include "../../arriba_amd/csrc/device/mismapper_core.hpp"
 #include <map>
 #include <set>
 #include <tuple>

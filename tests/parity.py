@@ -168,7 +168,8 @@ def check_evalues(session, pipeline, golden):
     assert len(after_evalue) == n
     index = {key: c for c, key in enumerate(candidate_keys(table, n))}
     # hazard H2: the dump is written in the iteration order of the reference's unordered_map
-    rank = pipeline.candidate_iteration_order(table)
+    rank = pipeline.candidate_iteration_order()
+    assert np.array_equal(rank, pipeline.candidate_iteration_order_on_host(table))  # literal std::unordered_map on the host
     assert [index[fusion_key(f)] for f in after_evalue] == [int(c) for c in np.argsort(rank)]
     state = {k: np.zeros(n, dtype=np.uint32) for k in ("filter", "split_reads1", "split_reads2", "discordant_mates")}
     expected = np.zeros(n, dtype=np.uint32)
@@ -180,7 +181,7 @@ def check_evalues(session, pipeline, golden):
         flags = int(table["flags"][c])  # the flag columns are not touched by the intermediate stages
         assert ((flags >> 4) & 1, (flags >> 5) & 1, (flags >> 2) & 1, (flags >> 3) & 1) == (f["spliced1"], f["spliced2"], f["exonic1"], f["exonic2"])
     pipeline.set_candidate_state(state["filter"].astype(np.uint8), state["split_reads1"], state["split_reads2"], state["discordant_mates"])
-    evalue = pipeline.estimate_expected_fusions(iteration_rank=rank)
+    evalue = pipeline.estimate_expected_fusions()
     bits = evalue.view(np.uint32)
     different = [(c, hex(int(bits[c])), hex(int(expected[c]))) for c in range(n) if bits[c] != expected[c]]
     assert not different, (len(different), different[:10])

@@ -22,3 +22,4 @@ if [ "$2" = "pmc" ]; then
   rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
 fi
 tail -5 gpurun_out/${TAG}_pytest_gpu.log; cat gpurun_out/${TAG}_bench.json; head -14 gpurun_out/${TAG}_kernel_stats.txt
+if [ "$3" = "probe" ]; then timeout 600 python tools/stage_probe.py 3000000 > gpurun_out/${TAG}_probe.json 2> gpurun_out/${TAG}_probe.err; cat gpurun_out/${TAG}_probe.json; fi
