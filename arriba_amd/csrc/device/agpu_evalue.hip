@@ -47,22 +47,32 @@ __global__ void partner_insert_kernel(CandidateTable t, const uint32_t* iteratio
 	}
 }
 
-// winners emit (gene << 32 | partner)
+// winners emit (gene << 32 | partner); one atomic per wavefront reserves the output range
 __global__ void partner_resolve_kernel(CandidateTable t, const unsigned long long* slots, uint32_t mask, uint64_t* pairs, uint32_t* pair_count) {
 	uint32_t handle = blockIdx.x * BLOCK + threadIdx.x;
-	if (handle >= 2 * t.n) return;
-	uint32_t c = handle >> 1;
-	if (!raises_partner_events(t, c)) return;
-	PartnerKey key = partner_event_key(t, handle);
-	uint32_t h = (uint32_t) hash_partner_key(key) & mask;
-	while (true) {
-		unsigned long long owner = slots[h];
-		if (partner_keys_equal(partner_event_key(t, (uint32_t) owner), key)) {
-			if ((uint32_t) owner == handle) pairs[atomicAdd(pair_count, 1u)] = (uint64_t) key.gene << 32 | partner_event_partner(t, handle);
-			return;
+	bool winner = false;
+	uint64_t pair = 0;
+	if (handle < 2 * t.n && raises_partner_events(t, handle >> 1)) {
+		PartnerKey key = partner_event_key(t, handle);
+		uint32_t h = (uint32_t) hash_partner_key(key) & mask;
+		while (true) {
+			unsigned long long owner = slots[h];
+			if (partner_keys_equal(partner_event_key(t, (uint32_t) owner), key)) {
+				winner = (uint32_t) owner == handle;
+				pair = (uint64_t) key.gene << 32 | partner_event_partner(t, handle);
+				break;
+			}
+			h = (h + 1) & mask;
 		}
-		h = (h + 1) & mask;
 	}
+	const unsigned long long ballot = __ballot(winner);
+	if (ballot == 0) return;
+	const uint32_t lane = threadIdx.x & 63;
+	const int leader = __ffsll((long long) ballot) - 1;
+	uint32_t base = 0;
+	if ((int) lane == leader) base = atomicAdd(pair_count, (uint32_t) __popcll(ballot));
+	base = __shfl(base, leader);
+	if (winner) pairs[base + __popcll(ballot & ((1ull << lane) - 1))] = pair;
 }
 
 __global__ void partner_size_kernel(const uint64_t* sorted_pairs, uint32_t n, int32_t* partner_set_size) {

@@ -191,7 +191,7 @@ __device__ __forceinline__ int32_t anchor_merge(int32_t a, int32_t b, bool upstr
 // case of an anchor at position 0, which resets a running minimum).
 template <int MODE> __device__ __forceinline__ void scan_bucket(const AnnotationView& ann, const DiscordantBuckets& buckets, const BucketRef& ref, uint32_t gene1, uint32_t gene2,
 		int32_t breakpoint1, int32_t breakpoint2, bool upstream1, bool upstream2, bool has_split_reads, int32_t max_mate_gap, uint32_t threshold, uint32_t lane,
-		uint32_t* out_list, uint8_t* discordant_swapped, uint32_t& unfiltered, uint32_t& appended, int32_t& lane_anchor1, int32_t& lane_anchor2, bool& zero_seen, AnchorFold& fold1, AnchorFold& fold2) {
+		uint32_t* out_list, uint8_t* discordant_swapped, uint32_t& unfiltered, uint32_t& appended, int32_t& lane_anchor1, int32_t& lane_anchor2, uint32_t& lane_votes, bool& zero_seen, AnchorFold& fold1, AnchorFold& fold2) {
 	const unsigned long long lanes_before = (1ull << lane) - 1;
 	uint32_t passing = 0;
 	unfiltered = 0; appended = 0;
@@ -216,6 +216,8 @@ template <int MODE> __device__ __forceinline__ void scan_bucket(const Annotation
 			if ((!upstream1 && anchor1 == 0) || (!upstream2 && anchor2 == 0)) zero_seen = true;
 			lane_anchor1 = anchor_merge(lane_anchor1, anchor1, upstream1);
 			lane_anchor2 = anchor_merge(lane_anchor2, anchor2, upstream2);
+			const int vote = discordant_mate_vote(info, upstream1, upstream2, breakpoint1, breakpoint2, buckets.breakpoint1[k], buckets.breakpoint2[k]);
+			lane_votes += (vote == 1) ? 1u : (vote == 2) ? 0x10000u : 0u; // forward in the low half, reverse in the high half (<= 64 K entries per lane)
 		}
 		if (MODE == 2 && ballot_joins != 0) {
 			AnchorFold chunk1 = wave_fold_in_lane_order(joins ? anchor_single(buckets.anchor1[k], upstream1) : anchor_identity(), upstream1);
@@ -242,20 +244,21 @@ __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable
 	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
 	uint32_t unfiltered = 0, appended = 0;
 	int32_t lane_anchor1 = 0, lane_anchor2 = 0;
+	uint32_t lane_votes = 0;
 	bool zero_seen = false;
 	AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
 	if (!fill) {
 		const bool has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
-		scan_bucket<0>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered, appended, lane_anchor1, lane_anchor2, zero_seen, fold1, fold2);
+		scan_bucket<0>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
 		if (lane == 0) list_size[3 * (uint64_t) c + 2] = appended;
 		return;
 	}
 	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	const bool has_split_reads = offsets[2] > offsets[0];
-	scan_bucket<1>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, t.read_lists + offsets[2], discordant_swapped, unfiltered, appended, lane_anchor1, lane_anchor2, zero_seen, fold1, fold2);
+	scan_bucket<1>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, t.read_lists + offsets[2], discordant_swapped, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
 	if (__ballot(zero_seen) != 0) {
-		uint32_t unfiltered_again, appended_again;
-		scan_bucket<2>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered_again, appended_again, lane_anchor1, lane_anchor2, zero_seen, fold1, fold2);
+		uint32_t unfiltered_again, appended_again, lane_votes_again = 0;
+		scan_bucket<2>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered_again, appended_again, lane_anchor1, lane_anchor2, lane_votes_again, zero_seen, fold1, fold2);
 	} else {
 		for (int offset = 32; offset > 0; offset >>= 1) {
 			lane_anchor1 = anchor_merge(lane_anchor1, __shfl_down(lane_anchor1, offset), upstream1);
@@ -263,7 +266,10 @@ __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable
 		}
 		fold1.value = lane_anchor1; fold2.value = lane_anchor2;
 	}
+	uint32_t forward_votes = lane_votes & 0xFFFFu, reverse_votes = lane_votes >> 16;
+	for (int offset = 32; offset > 0; offset >>= 1) { forward_votes += __shfl_down(forward_votes, offset); reverse_votes += __shfl_down(reverse_votes, offset); }
 	if (lane == 0) {
+		t.votes[2 * (uint64_t) c] += forward_votes; t.votes[2 * (uint64_t) c + 1] += reverse_votes;
 		t.discordant_mates[c] = unfiltered < threshold ? unfiltered : threshold;
 		t.anchor1[c] = anchor_apply(t.anchor1[c], fold1, upstream1);
 		t.anchor2[c] = anchor_apply(t.anchor2[c], fold2, upstream2);
@@ -278,29 +284,15 @@ __global__ void split_list_fill_kernel(uint32_t M, const FusionEmission* sorted,
 	int side = (e.info & EINFO_SWAPPED) ? 1 : 0;
 	uint32_t c = candidate_of[j] - 1;
 	t.read_lists[t.list_offset[3 * (uint64_t) c + side] + folds[j].list_size[side] - 1] = e.read;
+	int vote = split_read_vote(e.info);
+	if (vote != 0) atomicAdd(&t.votes[2 * (uint64_t) c + (vote - 1)], 1u);
 }
 
-// strands / splice sites / transcript start: short read lists inline, long ones queued for the wave kernel
-__global__ void finish_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint8_t* discordant_swapped, uint32_t* worklist, uint32_t* worklist_size) {
+// strands / splice sites / transcript start from the strand votes collected while the read lists were filled
+__global__ void finish_kernel(AnnotationView ann, CandidateTable t) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n) return;
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
-	if (offsets[3] - offsets[0] > SMALL_LIST) { worklist[atomicAdd(worklist_size, 1u)] = c; return; }
-	finish_candidate(b, ann, t, discordant_swapped, c);
-}
-
-__global__ void finish_wave_kernel(BatchView b, AnnotationView ann, CandidateTable t, const uint8_t* discordant_swapped, const uint32_t* worklist, const uint32_t* worklist_size) {
-	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-	if (wave >= *worklist_size) return;
-	const uint32_t c = worklist[wave];
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
-	uint32_t forward = 0, reverse = 0;
-	for (uint32_t k = offsets[0] + lane; k < offsets[3]; k += 64) {
-		int vote = list_entry_strand_vote(b, t, discordant_swapped, c, k);
-		if (vote == 1) ++forward; else if (vote == 2) ++reverse;
-	}
-	for (int offset = 32; offset > 0; offset >>= 1) { forward += __shfl_down(forward, offset); reverse += __shfl_down(reverse, offset); }
-	if (lane == 0) finalize_candidate(ann, t, c, forward, reverse);
+	finalize_candidate(ann, t, c, t.votes[2 * (uint64_t) c], t.votes[2 * (uint64_t) c + 1]);
 }
 
 struct Scratch { // grows on demand; reused by every rocprim call
@@ -395,6 +387,9 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	t.breakpoint1 = ctx->cand_breakpoint1.as<int32_t>(); t.breakpoint2 = ctx->cand_breakpoint2.as<int32_t>(); t.flags = ctx->cand_flags.as<uint32_t>(); t.filter = ctx->cand_filter.as<uint8_t>();
 	t.split_reads1 = ctx->cand_split_reads1.as<uint32_t>(); t.split_reads2 = ctx->cand_split_reads2.as<uint32_t>(); t.discordant_mates = ctx->cand_discordant_mates.as<uint32_t>();
 	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint32_t>(); t.read_lists = nullptr;
+	ALLOC(ctx->cand_votes, (size_t) C * 8);
+	HIP_CHECK(hipMemsetAsync(ctx->cand_votes.ptr, 0, (size_t) C * 8, s));
+	t.votes = ctx->cand_votes.as<uint32_t>();
 	DeviceBuffer& list_size = ctx->scratch("fusions.list_size");
 	ALLOC(list_size, (3 * (size_t) C + 1) * 4);
 	HIP_CHECK(hipMemsetAsync(list_size.ptr, 0, (3 * (size_t) C + 1) * 4, s));
@@ -429,8 +424,8 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	}
 
 	// ---- discordant mates: count, offsets, fill
-	DeviceBuffer& bucket_worklist = ctx->scratch("fusions.bucket_worklist"); DeviceBuffer& finish_worklist = ctx->scratch("fusions.finish_worklist"); DeviceBuffer& worklist_sizes = ctx->scratch("fusions.worklist_sizes");
-	ALLOC(bucket_worklist, (size_t) C * sizeof(BucketRef)); ALLOC(finish_worklist, (size_t) C * 4); ALLOC(worklist_sizes, 16);
+	DeviceBuffer& bucket_worklist = ctx->scratch("fusions.bucket_worklist"); DeviceBuffer& worklist_sizes = ctx->scratch("fusions.worklist_sizes");
+	ALLOC(bucket_worklist, (size_t) C * sizeof(BucketRef)); ALLOC(worklist_sizes, 16);
 	HIP_CHECK(hipMemsetAsync(worklist_sizes.ptr, 0, 16, s));
 	uint32_t* worklist_counts = worklist_sizes.as<uint32_t>(); // [0] attach (count pass), [1] attach (fill pass), [2] finish
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(count)", (uint64_t) C * 25);
@@ -460,15 +455,7 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 		KernelTimer timer(ctx, "attach_discordant_wave_kernel(fill)", (uint64_t) total_list * (24 + 4));
 		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
 	}
-	{ KernelTimer timer(ctx, "finish_kernel", (uint64_t) C * 45);
-	  finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>(), finish_worklist.as<uint32_t>(), worklist_counts + 2); }
-	{
-		// upper bound of the number of long lists without a round trip: every queued candidate owns more than SMALL_LIST list entries
-		uint64_t max_long = std::min<uint64_t>(C, (uint64_t) total_list / (SMALL_LIST + 1) + 1);
-		// algorithmic bytes: per list entry the read id + the fragment's strand/contig/coordinate columns the vote looks at
-		KernelTimer timer(ctx, "finish_wave_kernel", (uint64_t) total_list * (4 + 2 * (1 + 2 + 4) + 1));
-		finish_wave_kernel<<<grid_for(max_long * 64), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, t, ctx->discordant_swapped.as<uint8_t>(), finish_worklist.as<uint32_t>(), worklist_counts + 2);
-	}
+	{ KernelTimer timer(ctx, "finish_kernel", (uint64_t) C * 53); finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t); }
 	ctx->n_queued_buckets = queued;
 	ctx->n_discordant_emissions = Md;
 

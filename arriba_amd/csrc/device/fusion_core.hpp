@@ -22,7 +22,10 @@ namespace agpu {
 // info bits of an emission / candidate
 // EINFO_SWAPPED: split read whose ends were exchanged to order the breakpoints; EINFO_MATES_SWAPPED: the same for a discordant
 // fragment (find_fusions swaps MATE1/MATE2 of such a fragment in place when it attaches it to a candidate, source/fusions.cpp:414-421)
-enum : uint32_t { EINFO_UPSTREAM1 = 1, EINFO_UPSTREAM2 = 2, EINFO_SWAPPED = 4, EINFO_EXONIC1 = 8, EINFO_EXONIC2 = 16, EINFO_SPLIT = 32, EINFO_MATES_SWAPPED = 64, EINFO_FILTER_SHIFT = 8 };
+// EINFO_PREDICTED1/2, EINFO_AMBIGUOUS1: predicted strand of the alignment on side 1 / 2 of the (ordered) breakpoint pair -- what the strand
+// vote of predict_fusion_strands (source/fusions.cpp:15-91) looks at, carried along so that the vote needs no second look at the read
+enum : uint32_t { EINFO_UPSTREAM1 = 1, EINFO_UPSTREAM2 = 2, EINFO_SWAPPED = 4, EINFO_EXONIC1 = 8, EINFO_EXONIC2 = 16, EINFO_SPLIT = 32, EINFO_MATES_SWAPPED = 64, EINFO_FILTER_SHIFT = 8,
+                  EINFO_PREDICTED1 = 1u << 16, EINFO_AMBIGUOUS1 = 1u << 17, EINFO_PREDICTED2 = 1u << 18 };
 
 struct FusionEmission {
 	uint32_t gene1, gene2;
@@ -109,7 +112,9 @@ AGPU_HD void write_emissions(const BatchView& b, uint64_t i, FusionEmission* out
 	FusionEmission e;
 	e.breakpoint1 = f.breakpoint1; e.breakpoint2 = f.breakpoint2; e.contigs = f.contig1 << 16 | f.contig2;
 	e.info = (f.upstream1 ? EINFO_UPSTREAM1 : 0) | (f.upstream2 ? EINFO_UPSTREAM2 : 0) | (f.swapped && f.is_split ? EINFO_SWAPPED : 0) | (f.swapped && !f.is_split ? EINFO_MATES_SWAPPED : 0) | (f.exonic1 ? EINFO_EXONIC1 : 0) | (f.exonic2 ? EINFO_EXONIC2 : 0) |
-	         (f.is_split ? EINFO_SPLIT : 0) | ((uint32_t) b.filter[i] << EINFO_FILTER_SHIFT);
+	         (f.is_split ? EINFO_SPLIT : 0) | ((uint32_t) b.filter[i] << EINFO_FILTER_SHIFT) |
+	         ((b.abits[f.slot1][i] & ABIT_PREDICTED_STRAND) ? EINFO_PREDICTED1 : 0) | ((b.abits[f.slot1][i] & ABIT_PREDICTED_STRAND_AMBIGUOUS) ? EINFO_AMBIGUOUS1 : 0) |
+	         ((b.abits[f.slot2][i] & ABIT_PREDICTED_STRAND) ? EINFO_PREDICTED2 : 0);
 	e.anchor1 = f.anchor1; e.anchor2 = f.anchor2; e.read = (uint32_t) i;
 	uint32_t k = 0;
 	for (uint32_t g1 = 0; g1 < genes1.n; ++g1)
@@ -244,6 +249,7 @@ struct CandidateTable { // structure of arrays, index = order of first occurrenc
 	uint32_t* flags; uint8_t* filter;
 	uint32_t* split_reads1; uint32_t* split_reads2; uint32_t* discordant_mates;
 	int32_t* anchor1; int32_t* anchor2;
+	uint32_t* votes;                // [2*n] strand votes of the reads in the lists: forward, reverse (source/fusions.cpp:22-79)
 	uint32_t* list_offset;          // [3*n + 1] into read_lists: split_read1_list, split_read2_list, discordant_mate_list of candidate c at 3c, 3c+1, 3c+2
 	uint32_t* read_lists;
 };
@@ -278,6 +284,28 @@ AGPU_HD bool discordant_mates_need_swap(const BatchView& b, uint64_t i) {
 	return contig1 > contig2 || (contig1 == contig2 && breakpoint1 > breakpoint2);
 }
 
+// Strand votes from the emission record alone; 0 no vote, 1 forward, 2 reverse.
+// A split read votes with the predicted strand of SPLIT_READ (split_read1_list) or SUPPLEMENTARY (split_read2_list), i.e. with the
+// alignment on side 1 of its ordered breakpoint pair (source/fusions.cpp:22-40).
+AGPU_HD int split_read_vote(uint32_t info) { return (info & EINFO_AMBIGUOUS1) ? 0 : (info & EINFO_PREDICTED1) ? 1 : 2; }
+// A discordant mate attached to a candidate shares its gene pair and directions; the reference picks the mate that belongs to gene1 by
+// contig and strand (always the side-1 mate here) or, if both mates have the same strand, by distance to the breakpoints
+// (source/fusions.cpp:42-79).  mate_breakpoint1/2 = ends of the side-1 / side-2 mate.
+AGPU_HD int discordant_mate_vote(uint32_t info, bool upstream1, bool upstream2, int32_t breakpoint1, int32_t breakpoint2, int32_t mate_breakpoint1, int32_t mate_breakpoint2) {
+	if ((info & EINFO_AMBIGUOUS1) || (info >> EINFO_FILTER_SHIFT & 255) == FILTER_hairpin) return 0;
+	bool use_side2 = false;
+	if (upstream1 == upstream2) { // both mates on the same strand
+		int32_t a = breakpoint1 - mate_breakpoint1; if (a < 0) a = -a;
+		int32_t c = breakpoint2 - mate_breakpoint2; if (c < 0) c = -c;
+		int32_t d = breakpoint2 - mate_breakpoint1; if (d < 0) d = -d;
+		int32_t e = breakpoint1 - mate_breakpoint2; if (e < 0) e = -e;
+		uint32_t distance1 = (uint32_t) a + (uint32_t) c, distance2 = (uint32_t) d + (uint32_t) e;
+		if (distance1 == distance2) return 0;
+		use_side2 = distance2 < distance1;
+	}
+	return (info & (use_side2 ? EINFO_PREDICTED2 : EINFO_PREDICTED1)) ? 1 : 2;
+}
+
 // The discordant emissions grouped by gene pair and directions (name order inside a bucket), as columns
 struct DiscordantBuckets { const int32_t* breakpoint1; const int32_t* breakpoint2; const uint32_t* info; const uint32_t* read; const int32_t* anchor1; const int32_t* anchor2; };
 
@@ -291,7 +319,7 @@ AGPU_HD uint32_t attach_discordant_mates(const AnnotationView& ann, const Candid
 	bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
 	uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
 	int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
-	uint32_t list_size = 0, unfiltered = 0;
+	uint32_t list_size = 0, unfiltered = 0, forward_votes = 0, reverse_votes = 0;
 	AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
 	for (uint32_t k = bucket_begin; k < bucket_begin + bucket_size; ++k) {
 		if (!discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, buckets.breakpoint1[k], buckets.breakpoint2[k]))
@@ -306,6 +334,8 @@ AGPU_HD uint32_t attach_discordant_mates(const AnnotationView& ann, const Candid
 			if ((info & EINFO_MATES_SWAPPED) && !discordant_swapped[read]) discordant_swapped[read] = 1;
 			fold1 = anchor_combine(fold1, anchor_single(buckets.anchor1[k], upstream1), upstream1);
 			fold2 = anchor_combine(fold2, anchor_single(buckets.anchor2[k], upstream2), upstream2);
+			int vote = discordant_mate_vote(info, upstream1, upstream2, breakpoint1, breakpoint2, buckets.breakpoint1[k], buckets.breakpoint2[k]);
+			if (vote == 1) ++forward_votes; else if (vote == 2) ++reverse_votes;
 		}
 		++list_size;
 		if (read_unfiltered) ++unfiltered;
@@ -314,6 +344,7 @@ AGPU_HD uint32_t attach_discordant_mates(const AnnotationView& ann, const Candid
 		t.discordant_mates[c] = unfiltered;
 		t.anchor1[c] = anchor_apply(t.anchor1[c], fold1, upstream1);
 		t.anchor2[c] = anchor_apply(t.anchor2[c], fold2, upstream2);
+		t.votes[2 * (uint64_t) c] += forward_votes; t.votes[2 * (uint64_t) c + 1] += reverse_votes;
 	}
 	return list_size;
 }
@@ -429,16 +460,16 @@ AGPU_HD void finalize_candidate(const AnnotationView& ann, const CandidateTable&
 	t.flags[c] = flags;
 }
 
-// sequential form: strands + splice sites + transcript start of one candidate from its read lists.
+// sequential form of the strand vote: walks the read lists of candidate c and looks at the reads themselves (the device path collects
+// the same votes from the emission records while it fills the lists; tests/emu checks the two against each other).
 // discordant_swapped[i] tells whether find_fusions swapped MATE1/MATE2 of fragment i in place.
-AGPU_HD void finish_candidate(const BatchView& b, const AnnotationView& ann, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c) {
+AGPU_HD void count_list_votes(const BatchView& b, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c, uint32_t& forward, uint32_t& reverse) {
 	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
-	uint32_t forward = 0, reverse = 0;
+	forward = 0; reverse = 0;
 	for (uint32_t k = offsets[0]; k < offsets[3]; ++k) {
 		int vote = list_entry_strand_vote(b, t, discordant_swapped, c, k);
 		if (vote == 1) ++forward; else if (vote == 2) ++reverse;
 	}
-	finalize_candidate(ann, t, c, forward, reverse);
 }
 
 }

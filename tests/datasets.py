@@ -40,11 +40,11 @@ def reference_available():
     return os.path.exists(ARRIBA_REF_DUMP)
 
 
-def run_reference(prefix, dump_directory, spec=None, extra_args=()):
+def run_reference(prefix, dump_directory, spec=None, extra_args=(), disable_filters=()):
     """Runs the oracle build of the reference; returns its stdout+stderr."""
     env = dict(os.environ)
     env["ARRIBA_ORACLE_DUMP"] = dump_directory
-    command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv", "-f", "blacklist"] + list(extra_args)
+    command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv", "-f", ",".join(["blacklist"] + list(disable_filters))] + list(extra_args)
     result = subprocess.run(command, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     if result.returncode != 0:
         raise RuntimeError("reference failed:\n" + result.stdout)

@@ -12,7 +12,9 @@ def _open(path):
 
 def find_dump(directory, kind, stage):
     """Path (without .gz) of <kind>.<nn>_<stage>.tsv in a dump directory."""
-    matches = sorted(glob.glob(os.path.join(directory, "%s.*_%s.tsv*" % (kind, stage))))
+    import re
+    pattern = re.compile(r"^%s\.\d+_%s\.tsv(\.gz)?$" % (re.escape(kind), re.escape(stage)))  # the stage name must match completely
+    matches = sorted(path for path in glob.glob(os.path.join(directory, "%s.*_%s.tsv*" % (kind, stage))) if pattern.match(os.path.basename(path)))
     if not matches:
         raise FileNotFoundError("%s.*_%s.tsv in %s" % (kind, stage, directory))
     path = matches[0]

@@ -203,3 +203,44 @@ def check_evalues(session, pipeline, golden):
     match = re.search(r"Filtering fusions with an e-value[^\n]*\(remaining=(\d+)\)", log)
     assert match and remaining == int(match.group(1))
     return n
+
+
+def check_mismappers(session, pipeline, golden):
+    """make_kmer_index + filter_mismappers against the reference's dumps right before / after filter_mismappers.  The candidate and
+    read state the event-level host stages produced in between is taken from the `before` dumps."""
+    import re
+    before = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "before_filter_mismappers"))
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_mismappers"))
+    names, read_filters_before = golden_io.read_filters(golden_io.find_dump(golden, "filters", "before_filter_mismappers"))
+    _, read_filters_after = golden_io.read_filters(golden_io.find_dump(golden, "filters", "filter_mismappers"))
+    assert session.fragment_names() == names
+    scalars = golden_io.read_scalars(os.path.join(golden, "scalars.tsv"))
+    table = pipeline.candidates()
+    n = pipeline.n_candidates
+    index = {key: c for c, key in enumerate(candidate_keys(table, n))}
+    state = {k: np.zeros(n, dtype=np.uint32) for k in ("filter", "split_reads1", "split_reads2", "discordant_mates")}
+    for f in before:
+        for k in state:
+            state[k][index[fusion_key(f)]] = f[k]
+    pipeline.set_candidate_state(state["filter"].astype(np.uint8), state["split_reads1"], state["split_reads2"], state["discordant_mates"])
+    pipeline.set_read_filters(np.array(read_filters_before, dtype=np.uint8))
+    positions = pipeline.make_kmer_index(int(scalars["kmer_index_padding"]))
+    expected_positions = sum(int(value.split(",")[1]) for key, value in scalars.items() if key.startswith("kmer_index.") and key != "kmer_index_padding")
+    assert positions == expected_positions, (positions, expected_positions)
+    remaining, discarded = pipeline.filter_mismappers(int(scalars["max_mate_gap"]))
+    mine = pipeline.filters()
+    different = [(names[i], int(mine[i]), read_filters_after[i]) for i in range(len(names)) if mine[i] != read_filters_after[i]]
+    assert not different, (len(different), different[:10])
+    assert discarded == sum(1 for a, b in zip(read_filters_before, read_filters_after) if a != b)
+    result = pipeline.candidates()
+    problems = []
+    for f in after:
+        c = index[fusion_key(f)]
+        got = (int(result["filter"][c]), int(result["split_reads1"][c]), int(result["split_reads2"][c]), int(result["discordant_mates"][c]))
+        if got != (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"]):
+            problems.append((fusion_key(f), got, (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"])))
+    assert not problems, (len(problems), problems[:10])
+    log = open(os.path.join(golden, "reference.log")).read()
+    match = re.search(r"Re-aligning chimeric reads[^\n]*\(remaining=(\d+)\)", log)
+    assert match and remaining == int(match.group(1))
+    return discarded

@@ -26,6 +26,7 @@ def test_read_level_cascade_matches_reference(name, dataset_files):
         pipeline.find_fusions()
         assert parity.check_candidates(session, pipeline, golden) > 1000
         assert parity.check_evalues(session, pipeline, golden) > 1000
+        assert parity.check_mismappers(session, pipeline, golden) == 2
 
 
 def test_live_reference_on_larger_dataset(built, tmp_path):
@@ -52,6 +53,30 @@ def test_live_reference_on_larger_dataset(built, tmp_path):
     pipeline.find_fusions()
     assert parity.check_candidates(session, pipeline, dump) > 10000
     assert parity.check_evalues(session, pipeline, dump) > 10000
+
+
+def test_live_reference_mismapper_stress(built, tmp_path):
+    """make_kmer_index + filter_mismappers on a dataset whose clipped segments stem from the split read's own gene, with the
+    event-level filters in front switched off in the reference so that every candidate's reads are re-aligned."""
+    if not datasets.reference_available():
+        pytest.skip("oracle/_ref/arriba_ref_dump did not travel with the repository")
+    spec = {"args": ["--seed", "32", "--fragments", "60000", "--normal-mult", "0.3", "--contigs", "6", "--contig-len", "500000", "--junctions", "600", "--dup", "0.1",
+                     "--partner-clip", "0.5", "--clip-min", "40", "--clip-max", "70"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump, disable_filters=["relative_support", "min_support", "intronic", "non_coding_neighbors", "intragenic_exonic", "in_vitro", "no_coverage",
+                                                                    "end_to_end", "short_anchor", "select_best", "marginal_read_through", "homologs", "merge_adjacent", "multimappers"])
+    finally:
+        del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    pipeline.find_fusions()
+    assert parity.check_candidates(session, pipeline, dump) > 10000
+    assert parity.check_mismappers(session, pipeline, dump) > 20
 
 
 def test_hip_path_matches_oracle_restatement_on_fresh_inputs(built, tmp_path):

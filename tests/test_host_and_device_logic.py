@@ -66,6 +66,7 @@ def test_device_logic_on_host_matches_reference(name, dataset_files, emu_api):
         pipeline.find_fusions()
         assert parity.check_candidates(session, pipeline, golden) > 1000
         assert parity.check_evalues(session, pipeline, golden) > 1000
+        assert parity.check_mismappers(session, pipeline, golden) == 2
     if name == "mid30k":
         assert pipeline.scalars["estimated"] and pipeline.scalars["mate_gap_samples"] >= 10000
 

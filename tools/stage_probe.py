@@ -32,6 +32,20 @@ def main():
             kernels[kernel] = round(kernels.get(kernel, 0.0) + ms, 3)
         results[name] = {"kernels": kernels, "remaining": pipeline.remaining}
         pipeline.close()
+    # the candidate-level stages once, with per-kernel times
+    pipeline = DevicePipeline(session)
+    pipeline.run_read_level()
+    pipeline.set_profiling(True)
+    pipeline.find_fusions()
+    pipeline.estimate_expected_fusions()
+    remaining_after_evalue = pipeline.filter_relative_support()
+    positions = pipeline.make_kmer_index()
+    remaining, discarded = pipeline.filter_mismappers()
+    kernels = {}
+    for kernel, ms, size in pipeline.kernel_profile():
+        kernels[kernel] = round(kernels.get(kernel, 0.0) + ms, 3)
+    results["candidate_stages"] = {"kernels": kernels, "candidates": pipeline.n_candidates, "remaining_after_relative_support": remaining_after_evalue, "kmer_positions": positions,
+                                   "remaining_after_mismappers": remaining, "reads_discarded_as_mismappers": discarded, "stage_ms": {k: round(v["ms"], 3) for k, v in pipeline.timings.items()}}
     print(json.dumps({"fragments": session.fragment_count, "results": results}))
 
 
