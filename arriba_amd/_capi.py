@@ -93,6 +93,18 @@ def bind_device_api(lib, prefix="agpu_"):
         "get_gene_sets": (c_int, [ctx, c_int, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
         "get_gene_table": (c_int, [ctx, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
         "get_fusion_stats": (c_int, [ctx, c_void_p]),
+        "set_shard": (c_int, [ctx, c_uint64, c_uint64]),
+        "annotate_begin": (c_int, [ctx, POINTER(c_uint64)]),
+        "copy_unmapped_positions": (c_int, [ctx, c_void_p]),
+        "annotate_finish": (c_int, [ctx, c_void_p, c_uint64, POINTER(c_uint32)]),
+        "duplicates_begin": (c_int, [ctx, POINTER(c_uint64)]),
+        "copy_duplicate_entries": (c_int, [ctx, c_void_p]),
+        "read_filters_stage1_global": (c_int, [ctx, c_void_p, c_uint64, c_void_p, c_void_p]),
+        "fragment_length_samples_limited": (c_int, [ctx, c_uint32, c_void_p, POINTER(c_uint32), POINTER(c_uint64)]),
+        "build_emissions": (c_int, [ctx, c_uint32, c_void_p]),
+        "copy_emissions": (c_int, [ctx, c_void_p]),
+        "find_fusions_from_emissions": (c_int, [ctx, c_void_p, c_uint64, c_int32, POINTER(c_uint64)]),
+        "get_candidate_first_occurrence": (c_int, [ctx, c_void_p]),
         "set_read_filters": (c_int, [ctx, c_void_p]),
         "make_kmer_index": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
         "filter_mismappers": (c_int, [ctx, c_int32, POINTER(c_uint64), POINTER(c_uint64)]),
@@ -136,6 +148,10 @@ def bind_host_api(lib):
         "ahost_fragment_name": (c_void_p, [session, c_uint64, POINTER(c_uint32)]),
         "ahost_detect_strandedness": (c_int, [session]),
         "ahost_viral_verdicts": (c_int, [session, c_void_p, c_uint64, c_void_p, c_uint32, ctypes.c_uint, c_float, c_void_p, c_void_p]),
+        "ahost_read_length_sum": (c_float, [session, c_float, c_uint64, c_uint64]),
+        "ahost_shard_boundary": (c_uint64, [session, c_uint64]),
+        "ahost_batch_slice_view": (POINTER(BatchView), [session, c_uint64, c_uint64]),
+        "ahost_estimate_fragment_length_from_sums": (c_int, [c_void_p, c_uint32, c_float, c_uint64, ctypes.c_uint, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int32)]),
         "ahost_candidate_iteration_order": (c_int, [c_uint64] + [c_void_p] * 7),
         "ahost_estimate_fragment_length": (c_int, [session, c_void_p, c_uint32, c_uint64, ctypes.c_uint, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int32)]),
     }

@@ -135,7 +135,54 @@ __global__ void duplicate_insert_kernel(uint64_t n, const DuplicateKey* keys, ui
 	}
 }
 
-__global__ void stage1_kernel(BatchView b, GenomeView genome, FilterTables t, const uint8_t* enabled, const DuplicateKey* keys, const uint32_t* slots, uint32_t mask, unsigned long long* stage_counts) {
+// sharded samples: the local winners (key, global name rank) are exchanged between the shards; DuplicateEntry is the wire format
+struct DuplicateEntry { DuplicateKey key; uint32_t rank; };
+__global__ void duplicate_winner_flag_kernel(uint64_t n, const DuplicateKey* keys, const uint32_t* slots, uint32_t mask, uint8_t* flags) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= n) return;
+	DuplicateKey key = keys[i];
+	uint32_t h = (uint32_t) hash_duplicate_key(key) & mask;
+	while (true) {
+		uint32_t owner = slots[h];
+		if (keys_equal(keys[owner], key)) { flags[i] = owner == (uint32_t) i; return; }
+		h = (h + 1) & mask;
+	}
+}
+__global__ void duplicate_entry_write_kernel(uint32_t n_winners, const uint32_t* winners, const DuplicateKey* keys, uint64_t first_rank, DuplicateEntry* entries) {
+	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= n_winners) return;
+	DuplicateEntry entry; entry.key = keys[winners[k]]; entry.rank = (uint32_t) (first_rank + winners[k]);
+	entries[k] = entry;
+}
+// table over the entries of all shards (ascending global rank): a slot holds the smallest entry index of its key
+__global__ void duplicate_entry_insert_kernel(uint64_t n_entries, const DuplicateEntry* entries, uint32_t* slots, uint32_t mask) {
+	uint64_t e = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (e >= n_entries) return;
+	DuplicateKey key = entries[e].key;
+	uint32_t h = (uint32_t) hash_duplicate_key(key) & mask;
+	while (true) {
+		uint32_t owner = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (owner == EMPTY_SLOT) {
+			owner = atomicCAS(&slots[h], EMPTY_SLOT, (uint32_t) e);
+			if (owner == EMPTY_SLOT) return;
+		}
+		if (keys_equal(entries[owner].key, key)) { if ((uint32_t) e < owner) atomicMin(&slots[h], (uint32_t) e); return; }
+		h = (h + 1) & mask;
+	}
+}
+__global__ void duplicate_global_verdict_kernel(BatchView b, const DuplicateKey* keys, const DuplicateEntry* entries, const uint32_t* slots, uint32_t mask, uint8_t* is_duplicate) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	DuplicateKey key = keys[i];
+	uint32_t h = (uint32_t) hash_duplicate_key(key) & mask;
+	while (true) {
+		uint32_t owner = slots[h];
+		if (keys_equal(entries[owner].key, key)) { is_duplicate[i] = entries[owner].rank != (uint32_t) (b.first_rank + i); return; }
+		h = (h + 1) & mask;
+	}
+}
+
+__global__ void stage1_kernel(BatchView b, GenomeView genome, FilterTables t, const uint8_t* enabled, const DuplicateKey* keys, const uint32_t* slots, uint32_t mask, const uint8_t* global_duplicate, unsigned long long* stage_counts) {
 	__shared__ unsigned int hits[5];
 	if (threadIdx.x < 5) hits[threadIdx.x] = 0;
 	__syncthreads();
@@ -145,6 +192,8 @@ __global__ void stage1_kernel(BatchView b, GenomeView genome, FilterTables t, co
 		if (filter == FILTER_none && enabled[FILTER_duplicates]) {
 			if (t.external_duplicate_marking) {
 				if (b.fbits[i] & FBIT_DUPLICATE) filter = FILTER_duplicates;
+			} else if (global_duplicate != nullptr) { // verdict from the table over all shards
+				if (global_duplicate[i]) filter = FILTER_duplicates;
 			} else {
 				DuplicateKey key = keys[i];
 				uint32_t h = (uint32_t) hash_duplicate_key(key) & mask;
@@ -179,7 +228,7 @@ __global__ void sample_flags_kernel(BatchView b, AnnotationView ann, uint64_t fi
 }
 
 // one workgroup appends the flagged values in order until MAX_SAMPLES are collected
-__global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint8_t* flags, const int32_t* values, int32_t* samples, uint32_t* counters) {
+__global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint8_t* flags, const int32_t* values, int32_t* samples, uint32_t* counters, uint32_t limit) {
 	__shared__ uint32_t wave_totals[16];
 	__shared__ uint32_t base;
 	__shared__ uint32_t done;
@@ -196,9 +245,9 @@ __global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint
 		uint32_t wave_offset = 0, total = 0;
 		for (uint32_t w = 0; w < waves; ++w) { if (w < wave) wave_offset += wave_totals[w]; total += wave_totals[w]; }
 		uint32_t position = base + wave_offset + before;
-		if (flag && position < MAX_SAMPLES) {
+		if (flag && position < limit) {
 			samples[position] = values[k];
-			if (position == MAX_SAMPLES - 1) { // the reference stops right after this fragment
+			if (position == limit - 1) { // the reference stops right after this fragment
 				uint64_t visited = first + k + 1;
 				counters[COUNTER_VISITED_LO] = (uint32_t) visited; counters[COUNTER_VISITED_HI] = (uint32_t) (visited >> 32);
 				done = 1;
@@ -209,7 +258,7 @@ __global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint
 		__syncthreads();
 		if (done) break;
 	}
-	if (threadIdx.x == 0) counters[COUNTER_SAMPLES] = base < MAX_SAMPLES ? base : MAX_SAMPLES;
+	if (threadIdx.x == 0) counters[COUNTER_SAMPLES] = base < limit ? base : limit;
 }
 
 // read_through ... mismatches: one thread per fragment, no LDS
@@ -518,7 +567,7 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
 
 	BatchView& b = ctx->batch;
-	b.n = n; b.n_aln = ctx->n_aln.as<uint8_t>(); b.fbits = ctx->fbits.as<uint8_t>(); b.filter = ctx->filter.as<uint8_t>(); b.group = ctx->group.as<uint32_t>();
+	b.n = n; b.first_rank = 0; b.n_aln = ctx->n_aln.as<uint8_t>(); b.fbits = ctx->fbits.as<uint8_t>(); b.filter = ctx->filter.as<uint8_t>(); b.group = ctx->group.as<uint32_t>();
 	for (int k = 0; k < 3; ++k) {
 		b.contig[k] = ctx->contig[k].as<uint16_t>(); b.start[k] = ctx->start[k].as<int32_t>(); b.end[k] = ctx->end[k].as<int32_t>(); b.abits[k] = ctx->abits[k].as<uint8_t>();
 		b.cigar_offset[k] = ctx->cigar_offset[k].as<uint32_t>(); b.cigar_count[k] = ctx->cigar_count[k].as<uint16_t>();
@@ -571,7 +620,7 @@ int agpu_mark_multimappers(agpu_ctx* ctx, uint64_t* marked) {
 	return AGPU_OK;
 }
 
-int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes) {
+int agpu_annotate_begin(agpu_ctx* ctx, uint64_t* n_unmapped) {
 	if (!ctx || !ctx->have_batch || !ctx->have_annotation || !ctx->have_genome) { set_last_error("annotation, genome and batch must be uploaded first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
@@ -582,7 +631,33 @@ int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes) {
 	uint32_t host_counters[COUNTER_COUNT];
 	TRY(read_counters(ctx, host_counters));
 	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
-	const uint32_t unmapped = host_counters[COUNTER_UNMAPPED];
+	ctx->n_unmapped = host_counters[COUNTER_UNMAPPED];
+	ctx->annotate_begun = true;
+	if (n_unmapped) *n_unmapped = ctx->n_unmapped;
+	return AGPU_OK;
+}
+
+int agpu_copy_unmapped_positions(agpu_ctx* ctx, uint64_t* destination) {
+	if (!ctx || !ctx->annotate_begun || !destination) { set_last_error("agpu_annotate_begin must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (ctx->n_unmapped) HIP_CHECK(hipMemcpy(destination, ctx->unmapped_keys.ptr, (size_t) ctx->n_unmapped * 8, hipMemcpyDefault));
+	return AGPU_OK;
+}
+
+int agpu_annotate_finish(agpu_ctx* ctx, const uint64_t* positions, uint64_t n_positions, uint32_t* n_dummy_genes) {
+	if (!ctx || !ctx->annotate_begun) { set_last_error("agpu_annotate_begin must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	uint32_t* counters = ctx->counters.as<uint32_t>();
+	uint32_t host_counters[COUNTER_COUNT];
+	if (positions != nullptr) { // the unmapped positions of all shards: dummy genes are cut from the sorted positions of the whole sample
+		if (n_positions >= 0xFFFFFFF0ull) { set_last_error("too many unmapped positions"); return AGPU_ERR_CAPACITY; }
+		if (!ctx->unmapped_keys.allocate((std::max<uint64_t>(n_positions, 2 * n + 2)) * 8)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (n_positions) HIP_CHECK(hipMemcpyAsync(ctx->unmapped_keys.ptr, positions, (size_t) n_positions * 8, hipMemcpyDefault, s));
+		ctx->n_unmapped = (uint32_t) n_positions;
+	}
+	const uint32_t unmapped = ctx->n_unmapped;
 	ctx->n_dummy = 0;
 	if (unmapped > 0) {
 		// sort the unmapped positions and cut them into dummy genes (source/arriba.cpp:232-260)
@@ -615,7 +690,21 @@ int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes) {
 	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
 	if (host_counters[COUNTER_ERROR] & ERROR_VIRAL_PAIR_OVERFLOW) { set_last_error("too many virus-host fragments for the integration-site buffer"); return AGPU_ERR_CAPACITY; }
 	if (n_dummy_genes) *n_dummy_genes = ctx->n_dummy;
-	ctx->annotated = true;
+	ctx->annotated = true; ctx->annotate_begun = false;
+	return AGPU_OK;
+}
+
+int agpu_annotate(agpu_ctx* ctx, uint32_t* n_dummy_genes) {
+	TRY(agpu_annotate_begin(ctx, nullptr));
+	float begin_ms = ctx->last_ms;
+	(void) begin_ms;
+	return agpu_annotate_finish(ctx, nullptr, 0, n_dummy_genes);
+}
+
+int agpu_set_shard(agpu_ctx* ctx, uint64_t first_rank, uint64_t global_n) {
+	if (!ctx || !ctx->have_batch) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
+	if (first_rank + ctx->n > global_n || global_n >= 0xFFFFFFF0ull) { set_last_error("shard range out of bounds"); return AGPU_ERR_INVALID; }
+	ctx->batch.first_rank = first_rank; ctx->global_n = global_n;
 	return AGPU_OK;
 }
 
@@ -633,37 +722,119 @@ int agpu_get_viral_integration_sites(agpu_ctx* ctx, uint32_t* pairs, uint64_t ca
 	return AGPU_OK;
 }
 
-int agpu_read_filters_stage1(agpu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict) {
-	if (!ctx || !ctx->annotated) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
-	HIP_CHECK(hipSetDevice(ctx->device));
+namespace {
+// duplicate keys + the local table (smallest local index per key)
+int build_local_duplicate_table(agpu_ctx* ctx, uint32_t& mask) {
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	uint64_t slots = 1024;
+	while (slots < 2 * n) slots <<= 1;
+	mask = (uint32_t) (slots - 1);
+	if (!ctx->duplicate_keys.allocate((size_t) std::max<uint64_t>(n, 1) * sizeof(DuplicateKey)) || !ctx->duplicate_slots.allocate(slots * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	HIP_CHECK(hipMemsetAsync(ctx->duplicate_slots.ptr, 0xFF, slots * 4, s));
+	if (n > 0) {
+		{ KernelTimer timer(ctx, "duplicate_keys_kernel", n * (1 + 2 * (2 + 4 + 4 + 1 + 4 + 2 + 8) + 12)); duplicate_keys_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->duplicate_keys.as<DuplicateKey>()); }
+		{ KernelTimer timer(ctx, "duplicate_insert_kernel", n * (12 + 4)); duplicate_insert_kernel<<<grid_for(n), BLOCK, 0, s>>>(n, ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask); }
+	}
+	return AGPU_OK;
+}
+
+int run_stage1(agpu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict, uint32_t mask, const uint8_t* global_duplicate) {
 	hipStream_t s = ctx->stream;
 	const uint64_t n = ctx->n;
 	if (top_verdict) { TRY(upload(ctx->viral_verdict_top, top_verdict, ctx->genome.n_contigs, s)); ctx->tables.top_expressed_viral_verdict = ctx->viral_verdict_top.as<uint8_t>(); } else ctx->tables.top_expressed_viral_verdict = nullptr;
 	if (low_verdict) { TRY(upload(ctx->viral_verdict_low, low_verdict, ctx->genome.n_contigs, s)); ctx->tables.low_coverage_viral_verdict = ctx->viral_verdict_low.as<uint8_t>(); } else ctx->tables.low_coverage_viral_verdict = nullptr;
-	uint32_t mask = 0;
-	if (!ctx->params.external_duplicate_marking) {
-		uint64_t slots = 1024;
-		while (slots < 2 * n) slots <<= 1;
-		mask = (uint32_t) (slots - 1);
-		if (!ctx->duplicate_keys.allocate((size_t) n * sizeof(DuplicateKey)) || !ctx->duplicate_slots.allocate(slots * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-		HIP_CHECK(hipMemsetAsync(ctx->duplicate_slots.ptr, 0xFF, slots * 4, s));
-	}
 	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
-	begin_timing(ctx);
 	if (n > 0) {
-		if (!ctx->params.external_duplicate_marking) {
-			{ KernelTimer timer(ctx, "duplicate_keys_kernel", n * (1 + 2 * (2 + 4 + 4 + 1 + 4 + 2 + 8) + 12)); duplicate_keys_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->duplicate_keys.as<DuplicateKey>()); }
-			{ KernelTimer timer(ctx, "duplicate_insert_kernel", n * (12 + 4)); duplicate_insert_kernel<<<grid_for(n), BLOCK, 0, s>>>(n, ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask); }
-		}
 		KernelTimer timer(ctx, "stage1_kernel", n * (1 + 1 + 12 + 4 + 3 * 2 + 1));
-		stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, ctx->stage_counts.as<unsigned long long>());
+		stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, global_duplicate, ctx->stage_counts.as<unsigned long long>());
 	}
-	TRY(end_timing(ctx, n * (3 * (2 + 4 + 4 + 1) + 2 * (4 + 2 + 8) + 12 * 2 + 8 + 2)));
+	return AGPU_OK;
+}
+}
+
+int agpu_read_filters_stage1(agpu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict) {
+	if (!ctx || !ctx->annotated) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	uint32_t mask = 0;
+	begin_timing(ctx);
+	if (!ctx->params.external_duplicate_marking) TRY(build_local_duplicate_table(ctx, mask));
+	TRY(run_stage1(ctx, top_verdict, low_verdict, mask, nullptr));
+	TRY(end_timing(ctx, ctx->n * (3 * (2 + 4 + 4 + 1) + 2 * (4 + 2 + 8) + 12 * 2 + 8 + 2)));
 	ctx->stage1_done = true;
 	return AGPU_OK;
 }
 
+// ---- sharded samples: filter_duplicates keeps the first fragment in name order of the WHOLE sample (source/filter_duplicates.cpp:8-55)
+
+int agpu_duplicates_begin(agpu_ctx* ctx, uint64_t* n_entries) {
+	if (!ctx || !ctx->annotated) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	uint32_t mask = 0;
+	begin_timing(ctx);
+	TRY(build_local_duplicate_table(ctx, mask));
+	DeviceBuffer& flags = ctx->scratch("duplicates.flags"); DeviceBuffer& winners = ctx->scratch("duplicates.winners"); DeviceBuffer& count = ctx->scratch("duplicates.count"); DeviceBuffer& scratch = ctx->scratch("duplicates.rocprim");
+	if (!flags.allocate(std::max<uint64_t>(n, 1)) || !winners.allocate(std::max<uint64_t>(n, 1) * 4) || !count.allocate(16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	uint32_t n_winners = 0;
+	if (n > 0) {
+		duplicate_winner_flag_kernel<<<grid_for(n), BLOCK, 0, s>>>(n, ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, flags.as<uint8_t>());
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), winners.as<uint32_t>(), count.as<uint32_t>(), n, s));
+		if (bytes > scratch.capacity && !scratch.allocate(bytes)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		HIP_CHECK(rocprim::select(scratch.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), winners.as<uint32_t>(), count.as<uint32_t>(), n, s)); // keeps name order
+		HIP_CHECK(hipMemcpyAsync(&n_winners, count.ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	if (!ctx->duplicate_entries.allocate((size_t) std::max<uint32_t>(n_winners, 1) * sizeof(DuplicateEntry))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (n_winners > 0) duplicate_entry_write_kernel<<<grid_for(n_winners), BLOCK, 0, s>>>(n_winners, winners.as<uint32_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->batch.first_rank, ctx->duplicate_entries.as<DuplicateEntry>());
+	TRY(end_timing(ctx, n * 44 + (uint64_t) n_winners * 16));
+	ctx->n_duplicate_entries = n_winners;
+	if (n_entries) *n_entries = n_winners;
+	return AGPU_OK;
+}
+
+int agpu_copy_duplicate_entries(agpu_ctx* ctx, void* destination) {
+	if (!ctx || !destination) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (ctx->n_duplicate_entries) HIP_CHECK(hipMemcpy(destination, ctx->duplicate_entries.ptr, (size_t) ctx->n_duplicate_entries * sizeof(DuplicateEntry), hipMemcpyDefault));
+	return AGPU_OK;
+}
+
+int agpu_read_filters_stage1_global(agpu_ctx* ctx, const void* entries, uint64_t n_entries, const uint8_t* top_verdict, const uint8_t* low_verdict) {
+	if (!ctx || !ctx->annotated || (!entries && n_entries)) { set_last_error("agpu_annotate and agpu_duplicates_begin must run first"); return AGPU_ERR_INVALID; }
+	if (n_entries >= 0xFFFFFFF0ull) { set_last_error("too many duplicate entries"); return AGPU_ERR_CAPACITY; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	DeviceBuffer& all_entries = ctx->scratch("duplicates.all_entries"); DeviceBuffer& global_slots = ctx->scratch("duplicates.global_slots"); DeviceBuffer& verdict = ctx->scratch("duplicates.verdict");
+	uint64_t slots = 1024;
+	while (slots < 2 * n_entries) slots <<= 1;
+	const uint32_t mask = (uint32_t) (slots - 1);
+	if (!all_entries.allocate(std::max<uint64_t>(n_entries, 1) * sizeof(DuplicateEntry)) || !global_slots.allocate(slots * 4) || !verdict.allocate(std::max<uint64_t>(n, 1))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (n_entries) HIP_CHECK(hipMemcpyAsync(all_entries.ptr, entries, (size_t) n_entries * sizeof(DuplicateEntry), hipMemcpyDefault, s));
+	HIP_CHECK(hipMemsetAsync(global_slots.ptr, 0xFF, slots * 4, s));
+	begin_timing(ctx);
+	const uint8_t* global_duplicate = nullptr;
+	if (!ctx->params.external_duplicate_marking && n > 0) {
+		duplicate_entry_insert_kernel<<<grid_for(n_entries), BLOCK, 0, s>>>(n_entries, all_entries.as<DuplicateEntry>(), global_slots.as<uint32_t>(), mask);
+		duplicate_global_verdict_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->duplicate_keys.as<DuplicateKey>(), all_entries.as<DuplicateEntry>(), global_slots.as<uint32_t>(), mask, verdict.as<uint8_t>());
+		global_duplicate = verdict.as<uint8_t>();
+	}
+	TRY(run_stage1(ctx, top_verdict, low_verdict, 0, global_duplicate));
+	TRY(end_timing(ctx, n * 60 + n_entries * 20));
+	ctx->stage1_done = true;
+	return AGPU_OK;
+}
+
+int agpu_fragment_length_samples_limited(agpu_ctx* ctx, uint32_t limit, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited);
 int agpu_fragment_length_samples(agpu_ctx* ctx, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited) {
+	return agpu_fragment_length_samples_limited(ctx, MAX_SAMPLES, mate_gaps, n_samples, fragments_visited);
+}
+
+int agpu_fragment_length_samples_limited(agpu_ctx* ctx, uint32_t limit, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited) {
+	if (limit == 0 || limit > MAX_SAMPLES) { set_last_error("the sample limit must be in 1..100001"); return AGPU_ERR_INVALID; }
 	if (!ctx || !ctx->stage1_done) { set_last_error("agpu_read_filters_stage1 must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
@@ -676,14 +847,14 @@ int agpu_fragment_length_samples(agpu_ctx* ctx, int32_t* mate_gaps, uint32_t* n_
 	for (uint64_t first = 0; first < n; first += chunk) {
 		uint64_t count = std::min(chunk, n - first);
 		sample_flags_kernel<<<grid_for(count), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, first, count, ctx->sample_flags.as<uint8_t>(), ctx->sample_values.as<int32_t>());
-		sample_compact_kernel<<<1, 1024, 0, s>>>(first, count, ctx->sample_flags.as<uint8_t>(), ctx->sample_values.as<int32_t>(), ctx->samples.as<int32_t>(), ctx->counters.as<uint32_t>());
+		sample_compact_kernel<<<1, 1024, 0, s>>>(first, count, ctx->sample_flags.as<uint8_t>(), ctx->sample_values.as<int32_t>(), ctx->samples.as<int32_t>(), ctx->counters.as<uint32_t>(), limit);
 		TRY(read_counters(ctx, counters));
-		if (counters[COUNTER_SAMPLES] >= MAX_SAMPLES) break;
+		if (counters[COUNTER_SAMPLES] >= limit) break;
 	}
 	TRY(end_timing(ctx, 0));
 	uint32_t collected = counters[COUNTER_SAMPLES];
 	if (n_samples) *n_samples = collected;
-	if (fragments_visited) *fragments_visited = (collected >= MAX_SAMPLES) ? ((uint64_t) counters[COUNTER_VISITED_HI] << 32 | counters[COUNTER_VISITED_LO]) : n;
+	if (fragments_visited) *fragments_visited = (collected >= limit) ? ((uint64_t) counters[COUNTER_VISITED_HI] << 32 | counters[COUNTER_VISITED_LO]) : n;
 	if (mate_gaps && collected > 0) HIP_CHECK(hipMemcpy(mate_gaps, ctx->samples.ptr, (size_t) collected * 4, hipMemcpyDeviceToHost));
 	return AGPU_OK;
 }

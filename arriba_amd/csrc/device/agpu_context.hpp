@@ -83,20 +83,23 @@ struct agpu_ctx {
 	agpu::BatchView batch;
 	uint64_t batch_input_bytes = 0;
 	uint32_t max_read_length = 0;
-	bool have_batch = false, annotated = false, stage1_done = false, stage2_done = false;
+	bool have_batch = false, annotated = false, stage1_done = false, stage2_done = false, annotate_begun = false;
+	uint32_t n_unmapped = 0;
+	uint64_t global_n = 0; // fragments of the whole sample when this context holds one shard of it (agpu_set_shard); 0 = not sharded
 
 	// scratch
 	agpu::DeviceBuffer unmapped_keys, sort_scratch, sorted_keys, scan_flags, scan_ids;
 	agpu::DeviceBuffer viral_pairs;
 	uint64_t viral_pair_capacity = 0;
-	agpu::DeviceBuffer duplicate_keys, duplicate_slots;
+	agpu::DeviceBuffer duplicate_keys, duplicate_slots, duplicate_entries;
+	uint32_t n_duplicate_entries = 0;
 	agpu::DeviceBuffer sample_flags, sample_values, samples;
 	agpu::DeviceBuffer stage_counts;
 
 	// find_fusions
 	agpu::DeviceBuffer emissions, discordant_swapped;
 	agpu::DeviceBuffer cand_gene1, cand_gene2, cand_contigs, cand_breakpoint1, cand_breakpoint2, cand_flags, cand_filter, cand_split_reads1, cand_split_reads2, cand_discordant_mates;
-	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists, cand_evalue, cand_iteration_rank, cand_votes;
+	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists, cand_evalue, cand_iteration_rank, cand_votes, cand_first_occurrence;
 	agpu::DeviceBuffer evalue_support_scale, evalue_intragenic_support, evalue_intergenic_support, evalue_distance_tables;
 	agpu::EvalueGlobals evalue_globals;
 	bool evalue_done = false, iteration_order_done = false;

@@ -109,6 +109,34 @@ __global__ void candidate_write_kernel(uint32_t M, const FusionEmission* sorted,
 	list_size[3 * (uint64_t) c] = f.list_size[0]; list_size[3 * (uint64_t) c + 1] = f.list_size[1]; list_size[3 * (uint64_t) c + 2] = 0;
 }
 
+// sharded samples: emissions travel to the rank that owns their gene pair (all candidates and discordant mates of a gene pair meet there)
+AGPU_HD uint32_t emission_owner(const FusionEmission& e, uint32_t n_partitions) {
+	uint64_t h = ((uint64_t) e.gene1 << 32 | e.gene2) * 0x9E3779B97F4A7C15ULL;
+	h ^= h >> 31; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+	return (uint32_t) (h % n_partitions);
+}
+__global__ void emission_owner_kernel(uint32_t M, const FusionEmission* emissions, uint32_t n_partitions, uint32_t* owners) {
+	uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+	if (e < M) owners[e] = emission_owner(emissions[e], n_partitions);
+}
+__global__ void emission_permute_kernel(uint32_t M, const uint32_t* order, const FusionEmission* emissions, FusionEmission* out) {
+	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k < M) out[k] = emissions[order[k]];
+}
+__global__ void partition_offsets_kernel(const uint32_t* sorted_owners, uint32_t M, uint32_t n_partitions, uint32_t* offsets) {
+	uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+	if (p > n_partitions) return;
+	uint32_t lo = 0, hi = M;
+	while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (sorted_owners[mid] < p) lo = mid + 1; else hi = mid; }
+	offsets[p] = lo;
+}
+// first occurrence of a candidate in the name order of the whole sample: name rank of the read << 8 | position among the read's emissions
+__global__ void candidate_first_occurrence_kernel(uint32_t M, const FusionEmission* sorted, const uint32_t* heads, const uint32_t* candidate_of, uint64_t* first_occurrence) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= M || !heads[j]) return;
+	first_occurrence[candidate_of[j] - 1] = (uint64_t) sorted[j].read << 8 | (sorted[j].info >> EINFO_ORDINAL_SHIFT & 255u);
+}
+
 __global__ void discordant_flag_kernel(uint32_t M, const FusionEmission* emissions, uint8_t* flags) {
 	uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
 	if (e >= M) return;
@@ -303,17 +331,14 @@ struct Scratch { // grows on demand; reused by every rocprim call
 
 }
 
-extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidates) {
-	if (!ctx || !ctx->stage2_done) { set_last_error("agpu_read_filters_stage2 must run first"); return AGPU_ERR_INVALID; }
-	HIP_CHECK(hipSetDevice(ctx->device));
+namespace {
+
+// emissions of the fragments of this context (one record per read x gene1 x gene2, name order); read ids are global name ranks
+int build_emissions(agpu_ctx* ctx, uint32_t& M) {
 	hipStream_t s = ctx->stream;
 	const uint64_t n = ctx->n;
-	const uint32_t threshold = ctx->params.subsampling_threshold;
 	Scratch scratch(ctx->scratch("fusions.rocprim"));
 	size_t bytes = 0;
-	(void) hipEventRecord(ctx->event_start, s);
-
-	// ---- emissions
 	DeviceBuffer& counts = ctx->scratch("fusions.counts"); DeviceBuffer& offsets = ctx->scratch("fusions.offsets");
 	ALLOC(counts, (n + 1) * 4); ALLOC(offsets, (n + 1) * 4);
 	HIP_CHECK(hipMemsetAsync(counts.ptr, 0, (n + 1) * 4, s));
@@ -322,20 +347,32 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
 	{ KernelTimer timer(ctx, "rocprim::exclusive_scan(emission offsets)", (uint64_t) n * 8);
 	  HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, n + 1, rocprim::plus<uint32_t>(), s)); }
-	uint32_t M = 0;
+	M = 0;
 	HIP_CHECK(hipMemcpyAsync(&M, offsets.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (M >= 0xFFFFFFF0u) { set_last_error("too many gene-pair emissions for one batch; shard the input"); return AGPU_ERR_CAPACITY; }
 	ctx->n_emissions = M;
+	ALLOC(ctx->emissions, (size_t) std::max<uint32_t>(M, 1) * sizeof(FusionEmission));
+	if (M > 0) {
+		KernelTimer timer(ctx, "emission_write_kernel", (uint64_t) n * (1 + 3 * (2 + 4 + 4 + 1 + 1 + GENE_INLINE * 4) + 1 + 8) + (uint64_t) M * sizeof(FusionEmission));
+		emission_write_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, offsets.as<uint32_t>(), counts.as<uint32_t>(), ctx->emissions.as<FusionEmission>());
+	}
+	return AGPU_OK;
+}
+
+// candidates from M emissions in name order (reads carry global name ranks; n_reads = number of fragments the ranks refer to)
+int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t M, uint64_t n_reads, int32_t max_mate_gap, uint64_t* n_candidates) {
+	hipStream_t s = ctx->stream;
+	const uint64_t n = n_reads;
+	const uint32_t threshold = ctx->params.subsampling_threshold;
+	Scratch scratch(ctx->scratch("fusions.rocprim"));
+	size_t bytes = 0;
 	ctx->n_candidates = 0;
 	if (M == 0) {
 		if (n_candidates) *n_candidates = 0;
 		ctx->fusions_done = true;
 		return AGPU_OK;
 	}
-	ALLOC(ctx->emissions, (size_t) M * sizeof(FusionEmission));
-	FusionEmission* emissions = ctx->emissions.as<FusionEmission>();
-	{ KernelTimer timer(ctx, "emission_write_kernel", (uint64_t) n * (1 + 3 * (2 + 4 + 4 + 1 + 1 + GENE_INLINE * 4) + 1 + 8) + (uint64_t) M * sizeof(FusionEmission)); emission_write_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, offsets.as<uint32_t>(), counts.as<uint32_t>(), emissions); }
 
 	// ---- group by candidate key
 	uint64_t slots = 1024;
@@ -394,6 +431,9 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	ALLOC(list_size, (3 * (size_t) C + 1) * 4);
 	HIP_CHECK(hipMemsetAsync(list_size.ptr, 0, (3 * (size_t) C + 1) * 4, s));
 	{ KernelTimer timer(ctx, "candidate_write_kernel", (uint64_t) M * (4 + 4) + (uint64_t) C * (sizeof(FusionEmission) + sizeof(CandidateFold) + 53)); candidate_write_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), candidate_of.as<uint32_t>(), folds.as<CandidateFold>(), t, list_size.as<uint32_t>()); }
+
+	ALLOC(ctx->cand_first_occurrence, (size_t) C * 8);
+	candidate_first_occurrence_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), candidate_of.as<uint32_t>(), ctx->cand_first_occurrence.as<uint64_t>());
 
 	// ---- discordant buckets by gene pair
 	DeviceBuffer& discordant_flags = ctx->scratch("fusions.discordant_flags"); DeviceBuffer& discordant_indices = ctx->scratch("fusions.discordant_indices"); DeviceBuffer& selected_count = ctx->scratch("fusions.selected_count"); DeviceBuffer& bucket_keys_in = ctx->scratch("fusions.bucket_keys_in"); DeviceBuffer& bucket_keys = ctx->scratch("fusions.bucket_keys"); DeviceBuffer& bucket_indices = ctx->scratch("fusions.bucket_indices"); DeviceBuffer& bucket_columns = ctx->scratch("fusions.bucket_columns");
@@ -459,15 +499,30 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 	ctx->n_queued_buckets = queued;
 	ctx->n_discordant_emissions = Md;
 
-	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
-	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
-	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
-	collect_kernel_samples(ctx);
+	HIP_CHECK(hipStreamSynchronize(s));
 	// algorithmic bytes: fragment end columns + gene sets read once, one emission written, candidate table + lists written
 	ctx->last_bytes = n * (3 * (2 + 4 + 4 + 1) + 3 * (1 + GENE_INLINE * 4) + 1) + (uint64_t) M * sizeof(FusionEmission) + (uint64_t) C * 53 + (uint64_t) total_list * 4;
 	ctx->n_candidates = C;
 	ctx->fusions_done = true;
 	if (n_candidates) *n_candidates = C;
+	return AGPU_OK;
+}
+
+}
+
+extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidates) {
+	if (!ctx || !ctx->stage2_done) { set_last_error("agpu_read_filters_stage2 must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	(void) hipEventRecord(ctx->event_start, ctx->stream);
+	uint32_t M = 0;
+	int status = build_emissions(ctx, M);
+	if (status != AGPU_OK) return status;
+	status = candidates_from_emissions(ctx, ctx->emissions.as<FusionEmission>(), M, ctx->n, max_mate_gap, n_candidates);
+	if (status != AGPU_OK) return status;
+	HIP_CHECK(hipEventRecord(ctx->event_stop, ctx->stream));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
 	return AGPU_OK;
 }
 
@@ -507,5 +562,75 @@ extern "C" int agpu_get_discordant_swapped(agpu_ctx* ctx, uint8_t* swapped) {
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	if (ctx->n) HIP_CHECK(hipMemcpy(swapped, ctx->discordant_swapped.ptr, ctx->n, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+// ---- sharded samples -----------------------------------------------------------------------------------------
+
+extern "C" int agpu_build_emissions(agpu_ctx* ctx, uint32_t n_partitions, uint64_t* counts) {
+	if (!ctx || !ctx->stage2_done || n_partitions == 0 || n_partitions > 4096) { set_last_error("agpu_read_filters_stage2 must run first; 1..4096 partitions"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	(void) hipEventRecord(ctx->event_start, s);
+	uint32_t M = 0;
+	int status = build_emissions(ctx, M);
+	if (status != AGPU_OK) return status;
+	std::vector<uint32_t> offsets(n_partitions + 1, 0);
+	offsets[n_partitions] = M;
+	if (n_partitions > 1 && M > 0) {
+		DeviceBuffer& owners = ctx->scratch("shard.owners"); DeviceBuffer& sorted_owners = ctx->scratch("shard.sorted_owners"); DeviceBuffer& order = ctx->scratch("shard.order");
+		DeviceBuffer& partitioned = ctx->scratch("shard.partitioned"); DeviceBuffer& device_offsets = ctx->scratch("shard.offsets"); DeviceBuffer& scratch = ctx->scratch("shard.rocprim");
+		ALLOC(owners, (size_t) M * 4); ALLOC(sorted_owners, (size_t) M * 4); ALLOC(order, (size_t) M * 4); ALLOC(partitioned, (size_t) M * sizeof(FusionEmission)); ALLOC(device_offsets, ((size_t) n_partitions + 1) * 4);
+		emission_owner_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, ctx->emissions.as<FusionEmission>(), n_partitions, owners.as<uint32_t>());
+		uint32_t bits = 1;
+		while ((1u << bits) < n_partitions) ++bits;
+		size_t bytes = 0; // the radix sort is stable: name order is kept inside every partition
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, owners.as<uint32_t>(), sorted_owners.as<uint32_t>(), rocprim::counting_iterator<uint32_t>(0), order.as<uint32_t>(), M, 0, bits, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, owners.as<uint32_t>(), sorted_owners.as<uint32_t>(), rocprim::counting_iterator<uint32_t>(0), order.as<uint32_t>(), M, 0, bits, s));
+		emission_permute_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, order.as<uint32_t>(), ctx->emissions.as<FusionEmission>(), partitioned.as<FusionEmission>());
+		partition_offsets_kernel<<<grid_for((uint64_t) n_partitions + 1), BLOCK, 0, s>>>(sorted_owners.as<uint32_t>(), M, n_partitions, device_offsets.as<uint32_t>());
+		HIP_CHECK(hipMemcpyAsync(offsets.data(), device_offsets.ptr, ((size_t) n_partitions + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(ctx->emissions.ptr, partitioned.ptr, (size_t) M * sizeof(FusionEmission), hipMemcpyDeviceToDevice, s));
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = ctx->n * 60 + (uint64_t) M * 2 * sizeof(FusionEmission);
+	if (counts) for (uint32_t p = 0; p < n_partitions; ++p) counts[p] = offsets[p + 1] - offsets[p];
+	return AGPU_OK;
+}
+
+extern "C" int agpu_copy_emissions(agpu_ctx* ctx, void* destination) {
+	if (!ctx || !destination) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (ctx->n_emissions) HIP_CHECK(hipMemcpy(destination, ctx->emissions.ptr, (size_t) ctx->n_emissions * sizeof(FusionEmission), hipMemcpyDefault));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_find_fusions_from_emissions(agpu_ctx* ctx, const void* emissions, uint64_t n_emissions, int32_t max_mate_gap, uint64_t* n_candidates) {
+	if (!ctx || !ctx->annotated || (!emissions && n_emissions)) { set_last_error("the context must be annotated (dummy genes of the whole sample) first"); return AGPU_ERR_INVALID; }
+	if (n_emissions >= 0xFFFFFFF0ull) { set_last_error("too many emissions for one owner"); return AGPU_ERR_CAPACITY; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	DeviceBuffer& received = ctx->scratch("shard.received");
+	ALLOC(received, (size_t) std::max<uint64_t>(n_emissions, 1) * sizeof(FusionEmission));
+	if (n_emissions) HIP_CHECK(hipMemcpyAsync(received.ptr, emissions, (size_t) n_emissions * sizeof(FusionEmission), hipMemcpyDefault, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	int status = candidates_from_emissions(ctx, received.as<FusionEmission>(), (uint32_t) n_emissions, ctx->global_n ? ctx->global_n : ctx->n, max_mate_gap, n_candidates);
+	if (status != AGPU_OK) return status;
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	return AGPU_OK;
+}
+
+extern "C" int agpu_get_candidate_first_occurrence(agpu_ctx* ctx, uint64_t* first_occurrence) {
+	if (!ctx || !ctx->fusions_done || !first_occurrence) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->n_candidates) HIP_CHECK(hipMemcpy(first_occurrence, ctx->cand_first_occurrence.ptr, (size_t) ctx->n_candidates * 8, hipMemcpyDeviceToHost));
 	return AGPU_OK;
 }

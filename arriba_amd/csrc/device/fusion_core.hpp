@@ -25,7 +25,8 @@ namespace agpu {
 // EINFO_PREDICTED1/2, EINFO_AMBIGUOUS1: predicted strand of the alignment on side 1 / 2 of the (ordered) breakpoint pair -- what the strand
 // vote of predict_fusion_strands (source/fusions.cpp:15-91) looks at, carried along so that the vote needs no second look at the read
 enum : uint32_t { EINFO_UPSTREAM1 = 1, EINFO_UPSTREAM2 = 2, EINFO_SWAPPED = 4, EINFO_EXONIC1 = 8, EINFO_EXONIC2 = 16, EINFO_SPLIT = 32, EINFO_MATES_SWAPPED = 64, EINFO_FILTER_SHIFT = 8,
-                  EINFO_PREDICTED1 = 1u << 16, EINFO_AMBIGUOUS1 = 1u << 17, EINFO_PREDICTED2 = 1u << 18 };
+                  EINFO_PREDICTED1 = 1u << 16, EINFO_AMBIGUOUS1 = 1u << 17, EINFO_PREDICTED2 = 1u << 18,
+                  EINFO_ORDINAL_SHIFT = 19 /* 8 bits: position of the emission among its read's gene1 x gene2 emissions */ };
 
 struct FusionEmission {
 	uint32_t gene1, gene2;
@@ -115,11 +116,12 @@ AGPU_HD void write_emissions(const BatchView& b, uint64_t i, FusionEmission* out
 	         (f.is_split ? EINFO_SPLIT : 0) | ((uint32_t) b.filter[i] << EINFO_FILTER_SHIFT) |
 	         ((b.abits[f.slot1][i] & ABIT_PREDICTED_STRAND) ? EINFO_PREDICTED1 : 0) | ((b.abits[f.slot1][i] & ABIT_PREDICTED_STRAND_AMBIGUOUS) ? EINFO_AMBIGUOUS1 : 0) |
 	         ((b.abits[f.slot2][i] & ABIT_PREDICTED_STRAND) ? EINFO_PREDICTED2 : 0);
-	e.anchor1 = f.anchor1; e.anchor2 = f.anchor2; e.read = (uint32_t) i;
+	e.anchor1 = f.anchor1; e.anchor2 = f.anchor2; e.read = (uint32_t) (b.first_rank + i);
 	uint32_t k = 0;
 	for (uint32_t g1 = 0; g1 < genes1.n; ++g1)
 		for (uint32_t g2 = 0; g2 < genes2.n; ++g2) {
 			e.gene1 = genes1.v[g1]; e.gene2 = genes2.v[g2];
+			e.info = (e.info & ~(255u << EINFO_ORDINAL_SHIFT)) | (k & 255u) << EINFO_ORDINAL_SHIFT;
 			out[k++] = e;
 		}
 }

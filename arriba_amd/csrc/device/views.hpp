@@ -60,6 +60,7 @@ struct GenomeView {
 
 struct BatchView {
 	uint64_t n;
+	uint64_t first_rank;       // global name rank of fragment 0 (non-zero when the context holds one shard of the sample)
 	const uint8_t* n_aln;
 	uint8_t* fbits;
 	uint8_t* filter;

@@ -37,7 +37,7 @@ struct ahost_session {
 	std::vector<uint64_t> genome_offset; std::vector<uint8_t> contig_bits; std::string genome_bases;
 	agpu_annotation_view annotation_view;
 	agpu_genome_view genome_view;
-	agpu_batch_view batch_view;
+	agpu_batch_view batch_view, slice_view;
 	std::string name_scratch;
 
 	void build_reference_views() {
@@ -186,6 +186,21 @@ int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t 
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session) { return &session->annotation_view; }
 const agpu_genome_view* ahost_genome_view(ahost_session* session) { return &session->genome_view; }
 const agpu_batch_view* ahost_batch_view(ahost_session* session) { return session->have_batch ? &session->batch_view : NULL; }
+uint64_t ahost_shard_boundary(ahost_session* session, uint64_t target) {
+	const agpu_batch_view& v = session->batch_view;
+	if (!session->have_batch || target >= v.n) return session->have_batch ? v.n : 0;
+	while (target > 0 && target < v.n && v.group[target - 1] == v.group[target]) ++target; // fragments of one read name (multi-mappers) stay together
+	return target;
+}
+const agpu_batch_view* ahost_batch_slice_view(ahost_session* session, uint64_t first, uint64_t count) {
+	if (!session->have_batch || first > session->batch_view.n || count > session->batch_view.n - first) { g_error = "slice out of range"; return NULL; }
+	agpu_batch_view& v = session->slice_view;
+	v = session->batch_view; // the CIGAR and sequence pools are shared, the per-fragment columns are offset
+	v.n = count; v.n_aln += first; v.fbits += first; v.group += first;
+	for (int k = 0; k < 3; ++k) { v.contig[k] += first; v.start[k] += first; v.end[k] += first; v.abits[k] += first; v.cigar_offset[k] += first; v.cigar_count[k] += first; }
+	for (int k = 0; k < 2; ++k) { v.seq_offset[k] += first; v.seq_length[k] += first; }
+	return &v;
+}
 uint64_t ahost_fragment_count(ahost_session* session) { return session->ingest.batch.n; }
 uint64_t ahost_mapped_reads(ahost_session* session) { return session->ingest.mapped_reads; }
 uint32_t ahost_contig_count(ahost_session* session) { return session->contigs.size(); }
@@ -300,16 +315,26 @@ int ahost_viral_verdicts(ahost_session* session, const uint32_t* pairs, uint64_t
 }
 
 // reference: source/read_stats.cpp:11-92 and source/arriba.cpp:352-364
+float ahost_read_length_sum(ahost_session* session, float running_sum, uint64_t first, uint64_t count) {
+	const Batch& b = session->ingest.batch;
+	if (first > b.n) first = b.n;
+	if (count > b.n - first) count = b.n - first;
+	for (uint64_t i = first; i < first + count; ++i) // sequential float accumulation in name order, hazard H4
+		running_sum += ((size_t) b.seq_length[MATE1][i] + (size_t) b.seq_length[MATE2][i]) / 2;
+	return running_sum;
+}
+
 int ahost_estimate_fragment_length(ahost_session* session, const int32_t* mate_gaps_in, uint32_t n_samples, uint64_t fragments_visited, unsigned int default_fragment_length,
                                    float* mate_gap_mean_out, float* mate_gap_stddev_out, float* read_length_mean_out, int32_t* max_mate_gap_out) {
-	const Batch& b = session->ingest.batch;
-	float read_length_mean = 0;
-	unsigned int read_length_count = 0;
-	if (fragments_visited > b.n) fragments_visited = b.n;
-	for (uint64_t i = 0; i < fragments_visited; ++i) { // sequential float accumulation, hazard H4
-		read_length_mean += ((size_t) b.seq_length[MATE1][i] + (size_t) b.seq_length[MATE2][i]) / 2;
-		read_length_count++;
-	}
+	if (fragments_visited > session->ingest.batch.n) fragments_visited = session->ingest.batch.n;
+	return ahost_estimate_fragment_length_from_sums(mate_gaps_in, n_samples, ahost_read_length_sum(session, 0, 0, fragments_visited), fragments_visited, default_fragment_length,
+	                                                mate_gap_mean_out, mate_gap_stddev_out, read_length_mean_out, max_mate_gap_out);
+}
+
+int ahost_estimate_fragment_length_from_sums(const int32_t* mate_gaps_in, uint32_t n_samples, float read_length_sum, uint64_t fragments_visited, unsigned int default_fragment_length,
+                                             float* mate_gap_mean_out, float* mate_gap_stddev_out, float* read_length_mean_out, int32_t* max_mate_gap_out) {
+	float read_length_mean = read_length_sum;
+	unsigned int read_length_count = (unsigned int) fragments_visited;
 	unsigned int mate_gap_count = n_samples;
 	if (mate_gap_count < 10000) {
 		std::cerr << "WARNING: not enough chimeric reads to estimate mate gap distribution, using default values" << std::endl;

@@ -112,7 +112,7 @@ class DevicePipeline(object):
     stepping harness of tests/emu instead.
     """
 
-    def __init__(self, session, params=None, api=None, device=0):
+    def __init__(self, session, params=None, api=None, device=0, batch_view=None):
         self.session = session
         self.api = api if api is not None else _capi.bind_device_api(_capi.device_library(), "agpu_")
         self.params = _capi.Params()
@@ -130,8 +130,8 @@ class DevicePipeline(object):
         self.timings = {}
         self._check(self.api.upload_annotation(self.ctx, session.annotation_view))
         self._check(self.api.upload_genome(self.ctx, session.genome_view))
-        self._check(self.api.upload_batch(self.ctx, session.batch_view))
-        self.n = session.fragment_count
+        self._check(self.api.upload_batch(self.ctx, batch_view if batch_view is not None else session.batch_view))
+        self.n = int(batch_view.contents.n) if batch_view is not None else session.fragment_count
         self.n_real_genes = session.annotation_view.contents.n_genes
         self.n_dummy_genes = 0
         self.scalars = {}

@@ -239,6 +239,36 @@ int agpu_make_kmer_index(agpu_ctx* ctx, int32_t padding, uint64_t* n_positions);
  * their counters.  *remaining = the reference's "(remaining=N)"; *discarded_reads = reads newly marked as mis-mappers. */
 int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* remaining, uint64_t* discarded_reads);
 
+/* ---- Sharded samples: one context per GPU holds a contiguous range of the fragments in name order.
+ * The per-fragment stages run on the shard; the entry points below expose the three places where the reference's result depends on
+ * fragments of other shards, so that the host can exchange the state between the ranks (RCCL / any transport) in between.
+ * Pointers named `destination` / `positions` / `entries` / `emissions` may be host or device memory. */
+/* global name rank of fragment 0 of this context and the number of fragments of the whole sample */
+int agpu_set_shard(agpu_ctx* ctx, uint64_t first_rank, uint64_t global_n);
+/* agpu_annotate in two steps: the dummy genes (source/arriba.cpp:207-260) are cut from the unmapped positions of ALL shards */
+int agpu_annotate_begin(agpu_ctx* ctx, uint64_t* n_unmapped);
+int agpu_copy_unmapped_positions(agpu_ctx* ctx, uint64_t* destination /* [n_unmapped] contig << 32 | position */);
+int agpu_annotate_finish(agpu_ctx* ctx, const uint64_t* positions /* of all shards, any order; NULL = own */, uint64_t n_positions, uint32_t* n_dummy_genes);
+/* filter_duplicates keeps the first fragment of a key in the name order of the whole sample (source/filter_duplicates.cpp:8-55):
+ * the local winners (16 bytes each: contigs u32, position1 i32, position2 i32, global name rank u32; ascending rank) are exchanged,
+ * then every shard filters against the concatenation of all shards' entries in rank order */
+#define AGPU_DUPLICATE_ENTRY_BYTES 16
+int agpu_duplicates_begin(agpu_ctx* ctx, uint64_t* n_entries);
+int agpu_copy_duplicate_entries(agpu_ctx* ctx, void* destination);
+int agpu_read_filters_stage1_global(agpu_ctx* ctx, const void* entries, uint64_t n_entries, const uint8_t* top_expressed_viral_verdict, const uint8_t* low_coverage_viral_verdict);
+/* agpu_fragment_length_samples stopping after `limit` samples (the shards contribute to the first 100001 samples in name order) */
+int agpu_fragment_length_samples_limited(agpu_ctx* ctx, uint32_t limit, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited);
+/* find_fusions over shards: the emissions (one 36-byte record per read x gene1 x gene2) are partitioned by the owner of their gene
+ * pair, name order kept inside a partition; the owner builds the candidates of its gene pairs from the emissions of all shards
+ * concatenated in shard order.  counts[p] = emissions for partition p. */
+#define AGPU_EMISSION_BYTES 36
+int agpu_build_emissions(agpu_ctx* ctx, uint32_t n_partitions, uint64_t* counts /* [n_partitions] */);
+int agpu_copy_emissions(agpu_ctx* ctx, void* destination /* all partitions, in partition order */);
+int agpu_find_fusions_from_emissions(agpu_ctx* ctx, const void* emissions, uint64_t n_emissions, int32_t max_mate_gap, uint64_t* n_candidates);
+/* first occurrence of every candidate in the name order of the whole sample (name rank of the read << 8 | ordinal of the emission):
+ * sorting the candidates of all owners by it gives the reference's insertion order */
+int agpu_get_candidate_first_occurrence(agpu_ctx* ctx, uint64_t* first_occurrence /* [n_candidates] */);
+
 /* result access (device -> host copies) */
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);
 int agpu_get_alignment_bits(agpu_ctx* ctx, int slot, uint8_t* abits /* [n] */);

@@ -32,6 +32,11 @@ int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t 
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session);
 const agpu_genome_view* ahost_genome_view(ahost_session* session);
 const agpu_batch_view* ahost_batch_view(ahost_session* session);
+/* Shards of the batch for one context per GPU: contiguous ranges of fragments in name order.  ahost_shard_boundary moves a cut forward
+ * until it does not separate fragments of one read name (mark_multimappers compares neighbours, source/read_chimeric_alignments.cpp:792-802);
+ * ahost_batch_slice_view returns the view of fragments [first, first + count) (valid until the next call). */
+uint64_t ahost_shard_boundary(ahost_session* session, uint64_t target);
+const agpu_batch_view* ahost_batch_slice_view(ahost_session* session, uint64_t first, uint64_t count);
 
 uint64_t ahost_fragment_count(ahost_session* session);
 uint64_t ahost_mapped_reads(ahost_session* session);
@@ -53,6 +58,13 @@ int ahost_viral_verdicts(ahost_session* session, const uint32_t* pairs, uint64_t
  * agpu_fragment_length_samples.  Returns 1 if estimated, 0 if the defaults were used. */
 int ahost_estimate_fragment_length(ahost_session* session, const int32_t* mate_gaps, uint32_t n_samples, uint64_t fragments_visited, unsigned int default_fragment_length,
                                    float* mate_gap_mean, float* mate_gap_stddev, float* read_length_mean, int32_t* max_mate_gap);
+
+/* The same for a sample whose fragments are spread over several sessions (shards in name order): the reference's float sum of the read
+ * lengths is sequential over the whole sample (hazard H4), so each shard continues the running sum of the shards before it
+ * (ahost_read_length_sum) and the estimate is made from the mate gaps, the final sum and the number of fragments visited. */
+float ahost_read_length_sum(ahost_session* session, float running_sum, uint64_t first, uint64_t count);
+int ahost_estimate_fragment_length_from_sums(const int32_t* mate_gaps, uint32_t n_samples, float read_length_sum, uint64_t fragments_visited, unsigned int default_fragment_length,
+                                             float* mate_gap_mean, float* mate_gap_stddev, float* read_length_mean, int32_t* max_mate_gap);
 
 /* Position of every candidate in the iteration order of the reference's fusions_t (std::unordered_map with the tuple hash of
  * source/common.hpp:286-314), given the candidates in insertion order as agpu_get_candidates returns them.  Stages whose result

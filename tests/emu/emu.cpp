@@ -70,6 +70,9 @@ struct emu_ctx {
 	uint64_t stage_counts[16];
 	std::vector<FusionEmission> emissions;
 	uint32_t n_real_genes = 0;
+	std::vector<uint64_t> unmapped;              // positions that need a dummy gene (between annotate_begin and annotate_finish)
+	std::vector<uint8_t> duplicate_entries;      // wire format of the sharded duplicate exchange: 12-byte key + 4-byte global name rank
+	uint64_t global_n = 0;
 };
 
 static void refresh_annotation(emu_ctx* ctx) {
@@ -141,7 +144,7 @@ int emu_upload_batch(emu_ctx* ctx, const agpu_batch_view* in) {
 	ctx->n = n;
 	ctx->fbits.assign(in->fbits, in->fbits + n); ctx->filter.assign(n, 0);
 	BatchView& b = ctx->batch;
-	b.n = n; b.n_aln = in->n_aln; b.fbits = ctx->fbits.data(); b.filter = ctx->filter.data(); b.group = in->group;
+	b.n = n; b.first_rank = 0; b.n_aln = in->n_aln; b.fbits = ctx->fbits.data(); b.filter = ctx->filter.data(); b.group = in->group;
 	for (int s = 0; s < 3; ++s) {
 		ctx->abits[s].assign(in->abits[s], in->abits[s] + n); ctx->gene_count[s].assign(n, 0); ctx->genes[s].assign(n * GENE_INLINE, 0);
 		b.contig[s] = in->contig[s]; b.start[s] = in->start[s]; b.end[s] = in->end[s]; b.abits[s] = ctx->abits[s].data();
@@ -172,15 +175,27 @@ int emu_mark_multimappers(emu_ctx* ctx, uint64_t* marked) {
 	return 0;
 }
 
-int emu_annotate(emu_ctx* ctx, uint32_t* n_dummy_genes) {
+int emu_set_shard(emu_ctx* ctx, uint64_t first_rank, uint64_t global_n) { ctx->batch.first_rank = first_rank; ctx->global_n = global_n; return 0; }
+
+int emu_annotate_begin(emu_ctx* ctx, uint64_t* n_unmapped) {
 	BatchView& b = ctx->batch;
-	std::vector<uint64_t> unmapped(2 * b.n + 2);
+	ctx->unmapped.assign(2 * b.n + 2, 0);
 	uint32_t unmapped_count = 0;
 	bool ok = true;
 	for (uint64_t i = 0; i < b.n; ++i)
-		ok = annotate_fragment_stage1(b, ctx->annotation, ctx->params.strandedness, i, unmapped.data(), &unmapped_count) && ok;
+		ok = annotate_fragment_stage1(b, ctx->annotation, ctx->params.strandedness, i, ctx->unmapped.data(), &unmapped_count) && ok;
 	if (!ok) { g_error = "a gene set exceeded the device capacity"; return AGPU_ERR_CAPACITY; }
-	unmapped.resize(unmapped_count);
+	ctx->unmapped.resize(unmapped_count);
+	if (n_unmapped) *n_unmapped = unmapped_count;
+	return 0;
+}
+int emu_copy_unmapped_positions(emu_ctx* ctx, uint64_t* destination) { memcpy(destination, ctx->unmapped.data(), ctx->unmapped.size() * 8); return 0; }
+
+int emu_annotate_finish(emu_ctx* ctx, const uint64_t* positions, uint64_t n_positions, uint32_t* n_dummy_genes) {
+	BatchView& b = ctx->batch;
+	bool ok = true;
+	std::vector<uint64_t> unmapped = positions ? std::vector<uint64_t>(positions, positions + n_positions) : ctx->unmapped;
+	const uint32_t unmapped_count = unmapped.size();
 	std::sort(unmapped.begin(), unmapped.end());
 	ctx->dummy_start_key.clear(); ctx->dummy_end_key.clear();
 	for (uint32_t i = 0; i < unmapped_count; ++i) {
@@ -213,6 +228,10 @@ int emu_annotate(emu_ctx* ctx, uint32_t* n_dummy_genes) {
 	if (n_dummy_genes) *n_dummy_genes = n_dummy;
 	return 0;
 }
+int emu_annotate(emu_ctx* ctx, uint32_t* n_dummy_genes) {
+	int status = emu_annotate_begin(ctx, nullptr);
+	return status ? status : emu_annotate_finish(ctx, nullptr, 0, n_dummy_genes);
+}
 
 int emu_get_viral_integration_sites(emu_ctx* ctx, uint32_t* pairs, uint64_t capacity, uint64_t* count) {
 	uint64_t available = ctx->viral_pairs.size() / 2;
@@ -221,7 +240,20 @@ int emu_get_viral_integration_sites(emu_ctx* ctx, uint32_t* pairs, uint64_t capa
 	return 0;
 }
 
-int emu_read_filters_stage1(emu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict) {
+struct EmuDuplicateEntry { DuplicateKey key; uint32_t rank; };
+static int emu_stage1(emu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict, const EmuDuplicateEntry* entries, uint64_t n_entries, bool export_winners);
+int emu_read_filters_stage1(emu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict) { return emu_stage1(ctx, top_verdict, low_verdict, nullptr, 0, false); }
+int emu_duplicates_begin(emu_ctx* ctx, uint64_t* n_entries) {
+	int status = emu_stage1(ctx, nullptr, nullptr, nullptr, 0, true);
+	if (n_entries) *n_entries = ctx->duplicate_entries.size() / sizeof(EmuDuplicateEntry);
+	return status;
+}
+int emu_copy_duplicate_entries(emu_ctx* ctx, void* destination) { memcpy(destination, ctx->duplicate_entries.data(), ctx->duplicate_entries.size()); return 0; }
+int emu_read_filters_stage1_global(emu_ctx* ctx, const void* entries, uint64_t n_entries, const uint8_t* top_verdict, const uint8_t* low_verdict) {
+	return emu_stage1(ctx, top_verdict, low_verdict, (const EmuDuplicateEntry*) entries, n_entries, false);
+}
+
+static int emu_stage1(emu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_verdict, const EmuDuplicateEntry* entries, uint64_t n_entries, bool export_winners) {
 	BatchView& b = ctx->batch;
 	if (top_verdict) { ctx->verdict_top.assign(top_verdict, top_verdict + ctx->genome.n_contigs); ctx->tables.top_expressed_viral_verdict = ctx->verdict_top.data(); } else ctx->tables.top_expressed_viral_verdict = nullptr;
 	if (low_verdict) { ctx->verdict_low.assign(low_verdict, low_verdict + ctx->genome.n_contigs); ctx->tables.low_coverage_viral_verdict = ctx->verdict_low.data(); } else ctx->tables.low_coverage_viral_verdict = nullptr;
@@ -242,11 +274,31 @@ int emu_read_filters_stage1(emu_ctx* ctx, const uint8_t* top_verdict, const uint
 			h = (h + 1) & mask;
 		}
 	}
+	if (export_winners) { // the local winners in name order, for the exchange between shards; no filtering yet
+		ctx->duplicate_entries.clear();
+		for (uint64_t i = 0; i < b.n; ++i) {
+			uint32_t h = (uint32_t) hash_duplicate_key(keys[i]) & mask;
+			while (!keys_equal(keys[table[h]], keys[i])) h = (h + 1) & mask;
+			if (table[h] != i) continue;
+			EmuDuplicateEntry entry; entry.key = keys[i]; entry.rank = (uint32_t) (b.first_rank + i);
+			const uint8_t* bytes = (const uint8_t*) &entry;
+			ctx->duplicate_entries.insert(ctx->duplicate_entries.end(), bytes, bytes + sizeof(entry));
+		}
+		return 0;
+	}
+	std::map<std::tuple<uint32_t, int32_t, int32_t>, uint32_t> global_winner; // key -> smallest global name rank over all shards
+	for (uint64_t e = 0; e < n_entries; ++e) {
+		auto key = std::make_tuple(entries[e].key.contigs, entries[e].key.position1, entries[e].key.position2);
+		auto found = global_winner.find(key);
+		if (found == global_winner.end() || entries[e].rank < found->second) global_winner[key] = entries[e].rank;
+	}
 	for (uint64_t i = 0; i < b.n; ++i) {
 		uint8_t filter = b.filter[i];
 		if (filter == FILTER_none && enabled[FILTER_duplicates]) {
 			if (ctx->tables.external_duplicate_marking) { if (b.fbits[i] & FBIT_DUPLICATE) filter = FILTER_duplicates; }
-			else {
+			else if (entries != nullptr) {
+				if (global_winner.at(std::make_tuple(keys[i].contigs, keys[i].position1, keys[i].position2)) != (uint32_t) (b.first_rank + i)) filter = FILTER_duplicates;
+			} else {
 				uint32_t h = (uint32_t) hash_duplicate_key(keys[i]) & mask;
 				while (!keys_equal(keys[table[h]], keys[i])) h = (h + 1) & mask;
 				if (table[h] != i) filter = FILTER_duplicates;
@@ -265,7 +317,9 @@ int emu_read_filters_stage1(emu_ctx* ctx, const uint8_t* top_verdict, const uint
 	return 0;
 }
 
-int emu_fragment_length_samples(emu_ctx* ctx, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited) {
+int emu_fragment_length_samples_limited(emu_ctx* ctx, uint32_t limit, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited);
+int emu_fragment_length_samples(emu_ctx* ctx, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited) { return emu_fragment_length_samples_limited(ctx, MAX_SAMPLES, mate_gaps, n_samples, fragments_visited); }
+int emu_fragment_length_samples_limited(emu_ctx* ctx, uint32_t limit, int32_t* mate_gaps, uint32_t* n_samples, uint64_t* fragments_visited) {
 	BatchView& b = ctx->batch;
 	uint32_t count = 0;
 	uint64_t visited = b.n;
@@ -273,7 +327,7 @@ int emu_fragment_length_samples(emu_ctx* ctx, int32_t* mate_gaps, uint32_t* n_sa
 		if (b.filter[i] == FILTER_none && !(b.fbits[i] & FBIT_SINGLE_END) && b.n_aln[i] == 3) {
 			if (mate_gaps) mate_gaps[count] = mate_gap_sample(b, ctx->annotation, i);
 			++count;
-			if (count == MAX_SAMPLES) { visited = i + 1; break; }
+			if (count == limit) { visited = i + 1; break; }
 		}
 	}
 	if (n_samples) *n_samples = count;
