@@ -105,6 +105,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "copy_emissions": (c_int, [ctx, c_void_p]),
         "find_fusions_from_emissions": (c_int, [ctx, c_void_p, c_uint64, c_int32, POINTER(c_uint64)]),
         "get_candidate_first_occurrence": (c_int, [ctx, c_void_p]),
+        "import_candidates": (c_int, [ctx, c_uint64] + [c_void_p] * 12),
         "set_read_filters": (c_int, [ctx, c_void_p]),
         "make_kmer_index": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
         "filter_mismappers": (c_int, [ctx, c_int32, POINTER(c_uint64), POINTER(c_uint64)]),

@@ -634,3 +634,33 @@ extern "C" int agpu_get_candidate_first_occurrence(agpu_ctx* ctx, uint64_t* firs
 	if (ctx->n_candidates) HIP_CHECK(hipMemcpy(first_occurrence, ctx->cand_first_occurrence.ptr, (size_t) ctx->n_candidates * 8, hipMemcpyDeviceToHost));
 	return AGPU_OK;
 }
+
+extern "C" int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, const uint32_t* gene1, const uint32_t* gene2, const uint32_t* contigs, const int32_t* breakpoint1, const int32_t* breakpoint2,
+                                      const uint32_t* flags, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates, const int32_t* anchor1, const int32_t* anchor2) {
+	if (!ctx || !ctx->annotated) { set_last_error("the context must be annotated first"); return AGPU_ERR_INVALID; }
+	if (n_candidates >= 0x7FFFFFF0ull) { set_last_error("too many candidates"); return AGPU_ERR_CAPACITY; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const size_t C = n_candidates, C1 = std::max<size_t>(C, 1);
+	struct { DeviceBuffer* buffer; const void* source; size_t width; } columns[] = {
+		{ &ctx->cand_gene1, gene1, 4 }, { &ctx->cand_gene2, gene2, 4 }, { &ctx->cand_contigs, contigs, 4 }, { &ctx->cand_breakpoint1, breakpoint1, 4 }, { &ctx->cand_breakpoint2, breakpoint2, 4 },
+		{ &ctx->cand_flags, flags, 4 }, { &ctx->cand_filter, filter, 1 }, { &ctx->cand_split_reads1, split_reads1, 4 }, { &ctx->cand_split_reads2, split_reads2, 4 }, { &ctx->cand_discordant_mates, discordant_mates, 4 },
+		{ &ctx->cand_anchor1, anchor1, 4 }, { &ctx->cand_anchor2, anchor2, 4 } };
+	for (size_t k = 0; k < sizeof(columns) / sizeof(columns[0]); ++k) {
+		if (!columns[k].source && C) { set_last_error("null column"); return AGPU_ERR_INVALID; }
+		ALLOC(*columns[k].buffer, C1 * columns[k].width);
+		if (C) HIP_CHECK(hipMemcpyAsync(columns[k].buffer->ptr, columns[k].source, C * columns[k].width, hipMemcpyDefault, s));
+	}
+	ALLOC(ctx->cand_list_offset, (3 * C + 1) * 4); ALLOC(ctx->cand_read_lists, 16); ALLOC(ctx->cand_votes, C1 * 8);
+	HIP_CHECK(hipMemsetAsync(ctx->cand_list_offset.ptr, 0, (3 * C + 1) * 4, s)); // the read lists stay with the owners of the gene pairs
+	CandidateTable& t = ctx->candidates;
+	t.n = (uint32_t) C; t.gene1 = ctx->cand_gene1.as<uint32_t>(); t.gene2 = ctx->cand_gene2.as<uint32_t>(); t.contigs = ctx->cand_contigs.as<uint32_t>();
+	t.breakpoint1 = ctx->cand_breakpoint1.as<int32_t>(); t.breakpoint2 = ctx->cand_breakpoint2.as<int32_t>(); t.flags = ctx->cand_flags.as<uint32_t>(); t.filter = ctx->cand_filter.as<uint8_t>();
+	t.split_reads1 = ctx->cand_split_reads1.as<uint32_t>(); t.split_reads2 = ctx->cand_split_reads2.as<uint32_t>(); t.discordant_mates = ctx->cand_discordant_mates.as<uint32_t>();
+	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint32_t>(); t.read_lists = ctx->cand_read_lists.as<uint32_t>();
+	t.votes = ctx->cand_votes.as<uint32_t>();
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->n_candidates = (uint32_t) C; ctx->n_list_entries = 0;
+	ctx->fusions_done = true; ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false;
+	return AGPU_OK;
+}

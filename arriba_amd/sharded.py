@@ -40,8 +40,11 @@ def shard_ranges(session, world):
 class ShardedPipeline(DevicePipeline):
     """DevicePipeline over the fragments [first, first + count) of `session`; the sample is the concatenation of the shards of all ranks."""
 
-    def __init__(self, session, first, count, params=None, api=None, device=0, group=None):
+    def __init__(self, session, first, count, params=None, api=None, device=0, group=None, independent_sessions=False):
+        """independent_sessions: every rank ingested only its own shard (its host session knows nothing about the other shards), as opposed to
+        every rank holding the host session of the whole sample and driving a slice of it"""
         self.group = group
+        self.independent_sessions = independent_sessions
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.first_local, self.count_local = first, count
@@ -58,6 +61,11 @@ class ShardedPipeline(DevicePipeline):
 
     # ---- collectives over raw bytes --------------------------------------------------------------------
 
+    def _sync(self):
+        """The C ABI works on its own HIP stream: make the collective's result (and torch's fills before it) visible to it."""
+        if self.collective_device.type == "cuda":
+            torch.cuda.synchronize(self.collective_device)
+
     def _all_gather_int(self, value):
         tensor = torch.tensor([int(value)], dtype=torch.int64, device=self.collective_device)
         out = [torch.zeros_like(tensor) for _ in range(self.world)]
@@ -72,6 +80,7 @@ class ShardedPipeline(DevicePipeline):
         padded[:mine.numel()] = mine
         parts = [torch.zeros(width, dtype=torch.uint8, device=self.collective_device) for _ in range(self.world)]
         dist.all_gather(parts, padded, group=self.group)
+        self._sync()
         if sum(sizes) == 0:
             return torch.zeros(0, dtype=torch.uint8, device=self.collective_device), sizes
         return torch.cat([parts[r][:sizes[r]] for r in range(self.world)]), sizes
@@ -79,6 +88,7 @@ class ShardedPipeline(DevicePipeline):
     def _all_gather_bytes(self, n_bytes, fill):
         """`fill(pointer)` writes this rank's n_bytes straight into the collective's buffer (host or device memory)"""
         mine = torch.zeros(max(n_bytes, 1), dtype=torch.uint8, device=self.collective_device)
+        self._sync()
         if n_bytes:
             fill(mine.data_ptr())
         return self._all_gather_tensor(mine[:n_bytes])
@@ -183,6 +193,7 @@ class ShardedPipeline(DevicePipeline):
         self._check(self.api.build_emissions(self.ctx, self.world, counts.ctypes.data))
         send_counts = [int(c) for c in counts]
         send = torch.zeros(max(sum(send_counts) * EMISSION_BYTES, 1), dtype=torch.uint8, device=self.collective_device)
+        self._sync()
         if sum(send_counts):
             self._check(self.api.copy_emissions(self.ctx, send.data_ptr()))
         # how much every rank sends to every rank
@@ -193,12 +204,37 @@ class ShardedPipeline(DevicePipeline):
         received = torch.zeros(max(sum(receive_counts) * EMISSION_BYTES, 1), dtype=torch.uint8, device=self.collective_device)
         dist.all_to_all_single(received[:sum(receive_counts) * EMISSION_BYTES], send[:sum(send_counts) * EMISSION_BYTES],
                                [c * EMISSION_BYTES for c in receive_counts], [c * EMISSION_BYTES for c in send_counts], group=self.group)
+        self._sync()
         count = c_uint64()
         self._check(self.api.find_fusions_from_emissions(self.ctx, received.data_ptr() if sum(receive_counts) else None, sum(receive_counts), max_mate_gap, byref(count)))
         self._record("find_fusions")
         self.n_candidates = count.value
         self.exchange = {"emissions_sent": sum(send_counts), "emissions_received": sum(receive_counts)}
         return self.n_candidates
+
+    def replicate_candidates(self):
+        """all-gather of the owners' candidate columns in the reference's insertion order and import into this rank's context, so that the
+        candidate-level stages (iteration order, e-value, relative support) run replicated on every rank.  The read lists stay with the owners."""
+        table = self.candidates()
+        first = self.first_occurrence()
+        all_first, _ = self._all_gather_array(first)
+        order = np.argsort(all_first, kind="stable")
+        columns = {}
+        for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2"):
+            column, _ = self._all_gather_array(table[key])
+            columns[key] = np.ascontiguousarray(column[order])
+        total = int(all_first.size)
+        self._check(self.api.import_candidates(self.ctx, total, *[columns[k].ctypes.data for k in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2")]))
+        self.n_owned_candidates = self.n_candidates
+        self.n_candidates = total
+        return total
+
+    def estimate_expected_fusions(self, mapped_reads=None, iteration_rank=None):
+        if mapped_reads is None and self.independent_sessions:  # mapped reads of the whole sample
+            total = torch.tensor([self.session.mapped_reads], dtype=torch.int64, device=self.collective_device)
+            dist.all_reduce(total, group=self.group)
+            mapped_reads = int(total.item())
+        return super().estimate_expected_fusions(mapped_reads, iteration_rank)
 
     def first_occurrence(self):
         out = np.zeros(max(self.n_candidates, 1), dtype=np.uint64)

@@ -25,23 +25,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def workload_args(fragments, seed):
+def workload_args(fragments, seed, read_seed=0):
     # 2x100 bp, 55 % split-read triplets / 35 % discordant pairs / 10 % read-through, Zipf junction
     # support, 30 % PCR duplicates, synthetic 24-contig genome with GENCODE-like annotation (no hg38 offline)
-    return ["--seed", str(seed), "--fragments", str(fragments), "--normal-mult", "0", "--contigs", "24", "--contig-len", "12000000", "--genes-per-mb", "20",
+    return ["--seed", str(seed), "--read-seed", str(read_seed), "--fragments", str(fragments), "--normal-mult", "0", "--contigs", "24", "--contig-len", "12000000", "--genes-per-mb", "20",
             "--junctions", str(max(1000, fragments // 50))]
 
 
-def generate_and_ingest(fragments, seed, directory):
+def generate_and_ingest(fragments, seed, directory, read_seed=0):
     """Writes the reference (FASTA/GTF) to `directory`, streams the BAM records through a pipe into the host ingest."""
     from arriba_amd.pipeline import HostSession
     import datasets
     prefix = os.path.join(directory, "bench")
-    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--reference-only"] + workload_args(fragments, seed), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--reference-only"] + workload_args(fragments, seed, read_seed), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     session = HostSession(prefix + ".fa", prefix + ".gtf")
     fifo = prefix + ".bam.fifo"
     os.mkfifo(fifo)
-    producer = subprocess.Popen([datasets.GEN_SYNTH, "--out", prefix, "--raw-bam-to", fifo] + workload_args(fragments, seed), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    producer = subprocess.Popen([datasets.GEN_SYNTH, "--out", prefix, "--raw-bam-to", fifo] + workload_args(fragments, seed, read_seed), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     started = time.time()
     session.read_chimeric_alignments(fifo)
     producer.wait()
@@ -85,11 +85,13 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()  # (several ranks share a device only in the single-GPU dry run of the N > 1 path)
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        # nccl == RCCL over xGMI; ARRIBA_BENCH_BACKEND=gloo is the dry run of the N > 1 path on a box with fewer GPUs than ranks
+        dist.init_process_group(backend=os.environ.get("ARRIBA_BENCH_BACKEND", "nccl"))
 
     import __graft_entry__
     if rank == 0:
@@ -99,14 +101,25 @@ def main():
     from arriba_amd.pipeline import DevicePipeline
 
     directory = tempfile.mkdtemp(prefix="bench_r%d_" % rank)
-    session, prefix, ingest_seconds = generate_and_ingest(args.fragments, 1000 + rank, directory)
-    pipeline = DevicePipeline(session, device=local_rank)
+    # every rank draws its own reads from the same genome and annotation: the shards of one sample
+    session, prefix, ingest_seconds = generate_and_ingest(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank)
+    if distributed:
+        # one shard per rank; the sample is the concatenation of the shards in rank order (arriba_amd/sharded.py: four exchanges over RCCL)
+        from arriba_amd.sharded import ShardedPipeline
+        pipeline = ShardedPipeline(session, 0, session.fragment_count, device=local_rank, independent_sessions=True)
+    else:
+        pipeline = DevicePipeline(session, device=local_rank)
     n = pipeline.n
+
+    step_stats = {}
 
     def step():
         pipeline.reset()
         pipeline.run_read_level()
         pipeline.find_fusions()
+        if distributed:
+            step_stats.update(pipeline.fusion_stats())
+            pipeline.replicate_candidates()    # all-gather of the owners' candidate columns: the candidate-level stages run replicated
         pipeline.estimate_expected_fusions()   # includes the device computation of the reference container's iteration order (hazard H2)
         pipeline.filter_relative_support()
 
@@ -127,10 +140,11 @@ def main():
         dist.barrier()
     elapsed = time.time() - started
     if distributed:
-        tensor = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        collective_device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        tensor = torch.tensor([elapsed], device=collective_device, dtype=torch.float64)
         dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
         elapsed = float(tensor.item())
-        counts = torch.tensor([n], device="cuda", dtype=torch.int64)
+        counts = torch.tensor([n], device=collective_device, dtype=torch.int64)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         total_fragments = int(counts.item())
     else:
@@ -152,7 +166,7 @@ def main():
         achieved = dominant_bytes / (dominant_ms * 1e-3) / 1e9 if dominant_ms > 0 else 0.0
         cascade_bytes = sum(values["bytes"] for values in per_stage.values())
         cascade_ms = sum(values["ms"] for values in per_stage.values())
-        stats = pipeline.fusion_stats()
+        stats = step_stats if distributed else pipeline.fusion_stats()
         line = {
             "metric": "chimeric reads/s end-to-end (BAM->fusions.tsv), synthetic, device hot path with inputs resident in HBM",
             "value": total_fragments * args.steps / elapsed,
@@ -161,7 +175,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "synthetic %d chimeric fragments per GPU (2x100 bp, 24-contig synthetic genome, GENCODE-like GTF), default filters" % args.fragments,
-                       "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "gene_pair_emissions": stats["emissions"], "read_list_entries": stats["list_entries"],
+                       "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "parallelism": ("%d shards by read: all-gather of unmapped positions, duplicate winners and mate-gap samples, all-to-all of gene-pair emissions, all-gather of candidate columns (RCCL)" % world) if distributed else "1 GPU", "gene_pair_emissions": stats["emissions"], "read_list_entries": stats["list_entries"],
                        "stages_timed": "mark_multimappers, annotate, read filters (14), fragment-length samples, find_fusions, fusions_t iteration order, estimate_expected_fusions, filter_relative_support",
                        "host_ingest_reads_per_s": n / ingest_seconds},
             "stage_ms": {stage: round(values["ms"], 3) for stage, values in per_stage.items()},

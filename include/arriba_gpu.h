@@ -269,6 +269,11 @@ int agpu_find_fusions_from_emissions(agpu_ctx* ctx, const void* emissions, uint6
  * sorting the candidates of all owners by it gives the reference's insertion order */
 int agpu_get_candidate_first_occurrence(agpu_ctx* ctx, uint64_t* first_occurrence /* [n_candidates] */);
 
+/* candidate columns of the whole sample (gathered from the owners, in insertion order) as this context's candidate table, so that the
+ * candidate-level stages can run replicated on every rank; the read lists stay with the owners */
+int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, const uint32_t* gene1, const uint32_t* gene2, const uint32_t* contigs, const int32_t* breakpoint1, const int32_t* breakpoint2,
+                           const uint32_t* flags, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates, const int32_t* anchor_start1, const int32_t* anchor_start2);
+
 /* result access (device -> host copies) */
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);
 int agpu_get_alignment_bits(agpu_ctx* ctx, int slot, uint8_t* abits /* [n] */);

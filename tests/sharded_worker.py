@@ -30,7 +30,11 @@ def main():
     sharded.find_fusions()
     merged = sharded.gather_candidates()
     local_filters = sharded.filters()
-    report = {"rank": rank, "first": first, "count": count, "exchange": sharded.exchange, "owned_candidates": sharded.n_candidates}
+    sharded.replicate_candidates()
+    evalue = sharded.estimate_expected_fusions()
+    relative_support_remaining = sharded.filter_relative_support()
+    candidate_filters = sharded.candidates()["filter"]
+    report = {"rank": rank, "first": first, "count": count, "exchange": sharded.exchange, "owned_candidates": sharded.n_owned_candidates}
     if rank == 0:
         whole = DevicePipeline(session, api=api)
         expected_remaining = whole.run_read_level()
@@ -49,6 +53,11 @@ def main():
         for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2", "list_offset", "read_lists"):
             if not np.array_equal(np.asarray(merged[key], dtype=np.int64), np.asarray(table[key], dtype=np.int64)):
                 problems.append(("candidates." + key, len(merged[key]), len(table[key])))
+        expected_evalue = whole.estimate_expected_fusions()
+        if not np.array_equal(evalue.view(np.uint32), expected_evalue.view(np.uint32)):
+            problems.append(("e-values", int((evalue.view(np.uint32) != expected_evalue.view(np.uint32)).sum())))
+        if relative_support_remaining != whole.filter_relative_support() or not np.array_equal(candidate_filters, whole.candidates()["filter"]):
+            problems.append(("filter_relative_support",))
         report.update({"problems": problems, "candidates": int(whole.n_candidates), "fragments": int(whole.n)})
     with open("%s.rank%d.json" % (out_path, rank), "w") as out:
         json.dump(report, out, default=str)

@@ -141,3 +141,12 @@ def test_cascade_properties_at_scale(built, tmp_path):
         count1, genes1 = first.gene_sets(slot)
         count2, genes2 = second.gene_sets(slot)
         assert np.array_equal(count1, count2) and np.array_equal(genes1, genes2)
+
+
+def test_sharded_pipeline_two_ranks_on_one_device(built, dataset_files, tmp_path):
+    """The sharded entry points of the C ABI on the GPU: two processes (gloo for the exchanges) drive one shard each on cuda:0;
+    the merged result must equal the single-process pipeline (the RCCL transport itself needs >= 2 GPUs and is exercised by bench.py --gpus N)."""
+    import test_sharded
+    reports = test_sharded.run_sharded(dataset_files("mid30k"), 2, "gpu", str(tmp_path / "report"), 29655)
+    assert reports[0]["problems"] == [], reports[0]["problems"]
+    assert sum(r["owned_candidates"] for r in reports) == reports[0]["candidates"]

@@ -767,6 +767,7 @@ struct BamEncoder {
 void Generator::stream_bam(const ByteSink& sink) {
 	if (genes_.empty())
 		build_reference();
+	if (config_.read_seed != 0) impl_->rng = Rng(config_.read_seed);
 	Rng& rng = impl_->rng;
 	const Config& c = config_;
 	Builder builder = { c, contig_sequences_, genes_, *impl_, rng };
@@ -946,6 +947,7 @@ int main(int argc, char** argv) {
 		auto value = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
 		if (a == "--out") out = value();
 		else if (a == "--seed") config.seed = strtoull(value(), NULL, 10);
+		else if (a == "--read-seed") config.read_seed = strtoull(value(), NULL, 10);
 		else if (a == "--fragments") config.fragments = atol(value());
 		else if (a == "--normal-mult") config.normal_multiplier = atof(value());
 		else if (a == "--contigs") config.contigs = atoi(value());

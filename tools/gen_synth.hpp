@@ -20,6 +20,7 @@ namespace synth {
 
 struct Config {
 	uint64_t seed = 1;
+	uint64_t read_seed = 0; // non-zero: the reads are drawn from this seed while genome and annotation come from `seed` (shards of one sample)
 	int contigs = 6;                 // main contigs named 1..N
 	int contig_length = 400000;
 	double genes_per_mb = 60;

@@ -23,3 +23,6 @@ if [ "$2" = "pmc" ]; then
 fi
 tail -5 gpurun_out/${TAG}_pytest_gpu.log; cat gpurun_out/${TAG}_bench.json; head -14 gpurun_out/${TAG}_kernel_stats.txt
 if [ "$3" = "probe" ]; then timeout 600 python tools/stage_probe.py 3000000 > gpurun_out/${TAG}_probe.json 2> gpurun_out/${TAG}_probe.err; cat gpurun_out/${TAG}_probe.json; fi
+if [ "$4" = "dryrun2" ]; then
+  ARRIBA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --fragments 2000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_2ranks_dryrun.json 2> gpurun_out/${TAG}_bench_2ranks_dryrun.err; tail -1 gpurun_out/${TAG}_bench_2ranks_dryrun.json | cut -c1-1500; tail -5 gpurun_out/${TAG}_bench_2ranks_dryrun.err
+fi
