@@ -107,7 +107,7 @@ __global__ void annotate_stage2_kernel(BatchView b, AnnotationView ann, GenomeVi
 		if (at + genes.n > viral_pair_capacity) { atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_VIRAL_PAIR_OVERFLOW); return; }
 		for (uint32_t g = 0; g < genes.n; ++g) {
 			viral_pairs[2 * (at + g)] = b.contig[viral_slot][i];
-			viral_pairs[2 * (at + g) + 1] = genes.v[g];
+			viral_pairs[2 * (at + g) + 1] = genes.get(g);
 		}
 	}
 }

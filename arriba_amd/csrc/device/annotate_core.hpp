@@ -23,20 +23,48 @@ AGPU_HD uint32_t atomic_add_u32(uint32_t* address, uint32_t value) {
 #endif
 }
 
-// small sorted set of ids held in registers/scratch
+// Small sorted set of ids.  On the device the elements must stay in registers: a register file cannot be indexed with a run-time
+// index (the array would be spilled to scratch, i.e. to HBM -- rocprofv3 showed 4 GB of scratch writes per annotate launch).  Every
+// access is therefore written out with constant element indices (AGPU_EACH_ELEMENT expands a statement for 0..15), so that the
+// compiler's scalar replacement sees nothing but constants from the very first pass on.
 const int SET_CAPACITY = 16;
+#define AGPU_EACH_ELEMENT(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
 struct IdSet {
 	uint32_t n;
 	uint32_t overflow;
 	uint32_t v[SET_CAPACITY];
 	AGPU_HD void clear() { n = 0; overflow = 0; }
-	AGPU_HD void insert(uint32_t x) {
-		uint32_t at = 0;
-		while (at < n && v[at] < x) ++at;
-		if (at < n && v[at] == x) return;
+	AGPU_HD uint32_t get(uint32_t k) const {
+		uint32_t value = v[0];
+#define AGPU_GET(j) value = (k == j##u) ? v[j] : value;
+		AGPU_EACH_ELEMENT(AGPU_GET)
+#undef AGPU_GET
+		return value;
+	}
+	AGPU_HD void put(uint32_t k, uint32_t x) {
+#define AGPU_PUT(j) v[j] = (k == j##u) ? x : v[j];
+		AGPU_EACH_ELEMENT(AGPU_PUT)
+#undef AGPU_PUT
+	}
+	AGPU_HD void push_back(uint32_t x) { // caller keeps the order
 		if (n == SET_CAPACITY) { overflow = 1; return; }
-		for (uint32_t j = n; j > at; --j) v[j] = v[j - 1];
-		v[at] = x;
+		put(n, x);
+		++n;
+	}
+	AGPU_HD bool contains(uint32_t x) const {
+		bool present = false;
+#define AGPU_CONTAINS(j) present = present || (j##u < n && v[j] == x);
+		AGPU_EACH_ELEMENT(AGPU_CONTAINS)
+#undef AGPU_CONTAINS
+		return present;
+	}
+	AGPU_HD void insert(uint32_t x) {
+		if (contains(x)) return;
+		if (n == SET_CAPACITY) { overflow = 1; return; }
+		uint32_t carry = x; // bubble x to its place: every larger element moves up by one
+#define AGPU_INSERT(j) { const uint32_t current = v[j]; const bool exchange = j##u < n && current > carry; v[j] = (exchange || j##u == n) ? carry : current; carry = exchange ? current : carry; }
+		AGPU_EACH_ELEMENT(AGPU_INSERT)
+#undef AGPU_INSERT
 		++n;
 	}
 	AGPU_HD void assign_single(uint32_t x) { n = 1; v[0] = x; }
@@ -44,19 +72,18 @@ struct IdSet {
 
 AGPU_HD void intersect_sets(const IdSet& a, const IdSet& b, IdSet& out) {
 	out.clear();
-	uint32_t i = 0, j = 0;
-	while (i < a.n && j < b.n) {
-		if (a.v[i] < b.v[j]) ++i;
-		else if (b.v[j] < a.v[i]) ++j;
-		else { out.v[out.n++] = a.v[i]; ++i; ++j; }
-	}
+#define AGPU_INTERSECT(i) if (i##u < a.n && b.contains(a.v[i])) out.push_back(a.v[i]); /* a is ascending, so is the result */
+	AGPU_EACH_ELEMENT(AGPU_INTERSECT)
+#undef AGPU_INTERSECT
 }
 // intersection, or the union if the intersection is empty (reference: combine_annotations, source/annotation.t.hpp:47-53)
 AGPU_HD void combine_sets(const IdSet& a, const IdSet& b, IdSet& out, bool make_union) {
 	intersect_sets(a, b, out);
 	if (out.n == 0 && make_union) {
-		for (uint32_t i = 0; i < a.n; ++i) out.insert(a.v[i]);
-		for (uint32_t j = 0; j < b.n; ++j) out.insert(b.v[j]);
+		out = a;
+#define AGPU_UNION(j) if (j##u < b.n) out.insert(b.v[j]);
+		AGPU_EACH_ELEMENT(AGPU_UNION)
+#undef AGPU_UNION
 		out.overflow |= a.overflow | b.overflow;
 	}
 }
@@ -64,14 +91,12 @@ AGPU_HD void combine_sets(const IdSet& a, const IdSet& b, IdSet& out, bool make_
 AGPU_HD void load_genes(const BatchView& b, int slot, uint64_t i, IdSet& out) {
 	out.clear();
 	uint32_t count = b.gene_count[slot][i];
-	const uint32_t* inline_ids = b.genes[slot] + i * GENE_INLINE;
-	if (count <= (uint32_t) GENE_INLINE) {
-		for (uint32_t k = 0; k < count; ++k) out.v[k] = inline_ids[k];
-	} else {
-		const uint32_t* pool = b.gene_pool + inline_ids[0];
-		if (count > (uint32_t) SET_CAPACITY) { count = SET_CAPACITY; out.overflow = 1; }
-		for (uint32_t k = 0; k < count; ++k) out.v[k] = pool[k];
-	}
+	const uint32_t* source = b.genes[slot] + i * GENE_INLINE;
+	if (count > (uint32_t) GENE_INLINE) source = b.gene_pool + source[0];
+	if (count > (uint32_t) SET_CAPACITY) { count = SET_CAPACITY; out.overflow = 1; }
+#define AGPU_LOAD(k) if (k##u < count) out.v[k] = source[k];
+	AGPU_EACH_ELEMENT(AGPU_LOAD)
+#undef AGPU_LOAD
 	out.n = count;
 }
 
@@ -80,7 +105,8 @@ AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& 
 	uint32_t* inline_ids = b.genes[slot] + i * GENE_INLINE;
 	b.gene_count[slot][i] = (uint8_t) set.n;
 	if (set.n <= (uint32_t) GENE_INLINE) {
-		for (uint32_t k = 0; k < set.n; ++k) inline_ids[k] = set.v[k];
+		if (set.n > 0) inline_ids[0] = set.v[0];
+		if (set.n > 1) inline_ids[1] = set.v[1];
 		return true;
 	}
 	uint32_t offset = atomic_add_u32(b.gene_pool_used, set.n);
@@ -89,7 +115,9 @@ AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& 
 		return false;
 	}
 	inline_ids[0] = offset;
-	for (uint32_t k = 0; k < set.n; ++k) b.gene_pool[offset + k] = set.v[k];
+#define AGPU_STORE(k) if (k##u < set.n) b.gene_pool[offset + k] = set.v[k];
+	AGPU_EACH_ELEMENT(AGPU_STORE)
+#undef AGPU_STORE
 	return true;
 }
 
@@ -225,13 +253,13 @@ AGPU_HD void annotate_alignment(const BatchView& b, const AnnotationView& ann, u
 			bool is_clip = (op == CIGAR_S || op == CIGAR_H);
 			if (is_clip || op == CIGAR_N) {
 				for (uint32_t g = 0; g < genes.n; ++g) {
-					uint32_t gene = genes.v[g];
+					uint32_t gene = genes.get(g);
 					bool discard;
 					if (is_clip)
 						discard = (c == 0) ? !is_breakpoint_spliced(ann, gene, true, reference_position) : !is_breakpoint_spliced(ann, gene, false, reference_position);
 					else
 						discard = !is_breakpoint_spliced(ann, gene, false, reference_position) && !is_breakpoint_spliced(ann, gene, true, reference_position + (int32_t) length);
-					if (!discard) supported.v[supported.n++] = gene;
+					if (!discard) supported.push_back(gene);
 				}
 			}
 			if (op == CIGAR_N || op == CIGAR_M || op == CIGAR_X || op == CIGAR_EQ || op == CIGAR_D)
@@ -243,7 +271,7 @@ AGPU_HD void annotate_alignment(const BatchView& b, const AnnotationView& ann, u
 				bool predicted = ann.gene_bits[supported.v[0]] & GBIT_STRAND;
 				bool still_ambiguous = false;
 				for (uint32_t g = 0; g < supported.n && !still_ambiguous; ++g)
-					if (((ann.gene_bits[supported.v[g]] & GBIT_STRAND) != 0) != predicted)
+					if (((ann.gene_bits[supported.get(g)] & GBIT_STRAND) != 0) != predicted)
 						still_ambiguous = true;
 				if (!still_ambiguous)
 					bits = (bits & ~(ABIT_PREDICTED_STRAND | ABIT_PREDICTED_STRAND_AMBIGUOUS)) | (predicted ? ABIT_PREDICTED_STRAND : 0);
@@ -270,21 +298,24 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 	int n_aln = b.n_aln[i];
 	uint8_t bits[3];
 	IdSet genes[3];
-	for (int s = 0; s < 3; ++s) { bits[s] = (s < n_aln) ? (uint8_t) (b.abits[s][i] | ABIT_PREDICTED_STRAND_AMBIGUOUS) : 0; genes[s].clear(); }
+	// (the slot loops are unrolled so that bits[] and genes[] are only ever indexed with constants and stay in registers)
+	AGPU_UNROLL for (int s = 0; s < 3; ++s) { bits[s] = (s < n_aln) ? (uint8_t) (b.abits[s][i] | ABIT_PREDICTED_STRAND_AMBIGUOUS) : 0; genes[s].clear(); }
 
 	// reference: assign_strands_from_strandedness, source/read_chimeric_alignments.cpp:775-790
 	if (strandedness != 0) {
-		int first = abit(bits[MATE1], ABIT_FIRST_IN_PAIR) ? MATE1 : MATE2;
-		int second = abit(bits[MATE1], ABIT_FIRST_IN_PAIR) ? MATE2 : MATE1;
-		bool first_predicted = complement_strand_if(abit(bits[first], ABIT_STRAND), strandedness == 2);
-		set_predicted(bits[first], first_predicted);
-		set_predicted(bits[second], complement_strand_if(first_predicted, abit(bits[first], ABIT_STRAND) == abit(bits[second], ABIT_STRAND)));
+		const bool mate1_is_first = abit(bits[MATE1], ABIT_FIRST_IN_PAIR);
+		uint8_t first = mate1_is_first ? bits[MATE1] : bits[MATE2], second = mate1_is_first ? bits[MATE2] : bits[MATE1];
+		bool first_predicted = complement_strand_if(abit(first, ABIT_STRAND), strandedness == 2);
+		set_predicted(first, first_predicted);
+		set_predicted(second, complement_strand_if(first_predicted, abit(first, ABIT_STRAND) == abit(second, ABIT_STRAND)));
+		bits[MATE1] = mate1_is_first ? first : second; bits[MATE2] = mate1_is_first ? second : first;
 		if (n_aln == 3)
 			set_predicted(bits[SUPPLEMENTARY], complement_strand_if(abit(bits[SPLIT_READ], ABIT_PREDICTED_STRAND), abit(bits[SUPPLEMENTARY], ABIT_STRAND) != abit(bits[SPLIT_READ], ABIT_STRAND)));
 	}
 
 	// reference: annotate_alignments, source/annotation.cpp:505-555
-	for (int s = 0; s < n_aln; ++s) {
+	AGPU_UNROLL for (int s = 0; s < 3; ++s) {
+		if (s >= n_aln) continue;
 		annotate_alignment(b, ann, i, s, bits[s], genes[s]);
 		if (genes[s].n > 0) bits[s] |= ABIT_EXONIC;
 	}
@@ -321,8 +352,8 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 
 	// reference: gene-index fallback, source/arriba.cpp:190-205
 	IdentityMap identity;
-	for (int s = 0; s < n_aln; ++s)
-		if (genes[s].n == 0)
+	AGPU_UNROLL for (int s = 0; s < 3; ++s)
+		if (s < n_aln && genes[s].n == 0)
 			query_by_coordinate(ann.gene_index, b.contig[s][i], b.start[s][i], b.end[s][i], identity, genes[s]);
 	if (n_aln == 3) {
 		combine_sets(genes[SPLIT_READ], genes[MATE1], combined, true);
@@ -337,13 +368,14 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 		if (genes[SUPPLEMENTARY].n == 0)
 			unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[SUPPLEMENTARY][i] << 32 | (uint32_t) breakpoint_of(b, SUPPLEMENTARY, i, bits[SUPPLEMENTARY], false);
 	} else {
-		for (int s = 0; s < n_aln; ++s)
+		AGPU_UNROLL for (int s = 0; s < 2; ++s)
 			if (genes[s].n == 0)
 				unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[s][i] << 32 | (uint32_t) breakpoint_of(b, s, i, bits[s], false);
 	}
 
 	bool ok = true;
-	for (int s = 0; s < n_aln; ++s) {
+	AGPU_UNROLL for (int s = 0; s < 3; ++s) {
+		if (s >= n_aln) continue;
 		b.abits[s][i] = bits[s];
 		ok = store_genes(b, s, i, genes[s]) && !genes[s].overflow && ok;
 	}
@@ -385,7 +417,7 @@ struct GeneQuery {
 	uint32_t dummy_first, dummy_count; // gene ids n_genes + dummy_first ... (all larger than any GTF gene id)
 	AGPU_HD void clear() { real.clear(); dummy_first = 0; dummy_count = 0; }
 	AGPU_HD uint32_t size() const { return real.n + dummy_count; }
-	AGPU_HD uint32_t element(const AnnotationView& ann, uint32_t k) const { return k < real.n ? real.v[k] : ann.n_genes + dummy_first + (k - real.n); }
+	AGPU_HD uint32_t element(const AnnotationView& ann, uint32_t k) const { return k < real.n ? real.get(k) : ann.n_genes + dummy_first + (k - real.n); }
 	AGPU_HD void assign_single(uint32_t gene) { real.clear(); real.assign_single(gene); dummy_first = 0; dummy_count = 0; }
 	AGPU_HD void from_set(const IdSet& set) { real = set; dummy_first = 0; dummy_count = 0; }
 	// false if the materialised set would not fit
@@ -452,8 +484,10 @@ AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& 
 	GeneQuery genes[3];
 	uint8_t bits[3];
 	bool changed[3] = { false, false, false };
-	for (int s = 0; s < 3; ++s) { genes[s].clear(); bits[s] = 0; }
-	for (int s = 0; s < n_aln; ++s) { IdSet loaded; load_genes(b, s, i, loaded); genes[s].from_set(loaded); bits[s] = b.abits[s][i]; }
+	AGPU_UNROLL for (int s = 0; s < 3; ++s) {
+		genes[s].clear(); bits[s] = 0;
+		if (s < n_aln) { IdSet loaded; load_genes(b, s, i, loaded); genes[s].from_set(loaded); bits[s] = b.abits[s][i]; }
+	}
 
 	if (n_aln == 3) {
 		if (genes[MATE1].size() == 0 || genes[SPLIT_READ].size() == 0) {
@@ -466,15 +500,15 @@ AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& 
 			changed[SUPPLEMENTARY] = true;
 		}
 	} else {
-		for (int s = 0; s < n_aln; ++s)
+		AGPU_UNROLL for (int s = 0; s < 2; ++s)
 			if (genes[s].size() == 0) {
 				query_point_with_dummy_genes(ann, b.contig[s][i], breakpoint_of(b, s, i, bits[s], false), genes[s]);
 				changed[s] = true;
 			}
 	}
 
-	for (int s = 0; s < n_aln; ++s) {
-		if (genes[s].size() > 1 && (ann.gene_bits[genes[s].element(ann, 0)] & GBIT_DUMMY)) {
+	AGPU_UNROLL for (int s = 0; s < 3; ++s) {
+		if (s < n_aln && genes[s].size() > 1 && (ann.gene_bits[genes[s].element(ann, 0)] & GBIT_DUMMY)) {
 			int32_t breakpoint = breakpoint_of(b, s, i, bits[s], true); // forward -> start for every slot here (source/arriba.cpp:291)
 			uint32_t encompassing = last_gene_containing(ann, genes[s], breakpoint, genes[MATE1].element(ann, 0));
 			genes[s].assign_single(encompassing);
@@ -493,8 +527,8 @@ AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& 
 		}
 	}
 	bool ok = true;
-	for (int s = 0; s < n_aln; ++s)
-		if (changed[s]) {
+	AGPU_UNROLL for (int s = 0; s < 3; ++s)
+		if (s < n_aln && changed[s]) {
 			IdSet out;
 			ok = genes[s].to_set(ann, out) && ok;
 			ok = store_genes(b, s, i, out) && ok;

@@ -181,16 +181,22 @@ AGPU_HD int32_t mate_gap_sample(const BatchView& b, const AnnotationView& ann, u
 
 // ---- stage group 2 predicates -----------------------------------------------------------------------
 
-AGPU_HD void gene_boundaries(const AnnotationView& ann, const IdSet& genes, int32_t& start, int32_t& end) { // source/annotation.cpp:558-567
+// boundaries of the genes of alignment `slot` (source/annotation.cpp:558-567); the ids are read from the gene-set columns, so that a slot
+// chosen at run time does not force an array of sets out of the registers
+AGPU_HD void gene_boundaries(const BatchView& b, const AnnotationView& ann, int slot, uint64_t i, int32_t& start, int32_t& end) {
 	start = -1; end = -1;
-	for (uint32_t g = 0; g < genes.n; ++g) {
-		int32_t gene_start = ann.gene_start[genes.v[g]], gene_end = ann.gene_end[genes.v[g]];
+	const uint32_t count = b.gene_count[slot][i];
+	const uint32_t* ids = b.genes[slot] + i * GENE_INLINE;
+	if (count > (uint32_t) GENE_INLINE) ids = b.gene_pool + ids[0];
+	for (uint32_t g = 0; g < count; ++g) {
+		const uint32_t gene = ids[g];
+		int32_t gene_start = ann.gene_start[gene], gene_end = ann.gene_end[gene];
 		if (start == -1 || start > gene_start) start = gene_start;
 		if (end == -1 || end < gene_end) end = gene_end;
 	}
 }
 
-AGPU_HD bool is_proximal_read_through(const BatchView& b, const AnnotationView& ann, const FilterTables& t, uint64_t i, const IdSet* genes) {
+AGPU_HD bool is_proximal_read_through(const BatchView& b, const AnnotationView& ann, const FilterTables& t, uint64_t i) {
 	int n_aln = b.n_aln[i];
 	int forward, reverse;
 	if (n_aln == 2) {
@@ -204,8 +210,8 @@ AGPU_HD bool is_proximal_read_through(const BatchView& b, const AnnotationView& 
 	bool colinear = b.contig[forward][i] == b.contig[reverse][i] && b.end[forward][i] < b.start[reverse][i];
 	if ((n_aln == 2 && forward_strand != reverse_strand && colinear) || (n_aln == 3 && forward_strand == reverse_strand && colinear)) {
 		int32_t forward_gene_start, forward_gene_end, reverse_gene_start, reverse_gene_end;
-		gene_boundaries(ann, genes[forward], forward_gene_start, forward_gene_end);
-		gene_boundaries(ann, genes[reverse], reverse_gene_start, reverse_gene_end);
+		gene_boundaries(b, ann, forward, i, forward_gene_start, forward_gene_end);
+		gene_boundaries(b, ann, reverse, i, reverse_gene_start, reverse_gene_end);
 		if (b.end[forward][i] >= reverse_gene_start - t.min_read_through_distance || b.start[reverse][i] <= forward_gene_end + t.min_read_through_distance)
 			return true;
 	}
@@ -222,7 +228,7 @@ AGPU_HD bool split_read_is_spliced(const BatchView& b, const AnnotationView& ann
 	bool forward = b.abits[SPLIT_READ][i] & ABIT_STRAND;
 	int32_t breakpoint = forward ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i];
 	for (uint32_t g = 0; g < genes.n; ++g)
-		if (is_breakpoint_spliced(ann, genes.v[g], forward, breakpoint))
+		if (is_breakpoint_spliced(ann, genes.get(g), forward, breakpoint))
 			return true;
 	return false;
 }
@@ -379,8 +385,17 @@ AGPU_HD bool has_too_many_mismatches(const BatchView& b, const GenomeView& genom
 				mismatches++;
 				read_position += length;
 				break;
-			case CIGAR_M: case CIGAR_EQ: case CIGAR_X:
-				for (uint32_t k = 0; k < length; ++k) {
+			case CIGAR_M: case CIGAR_EQ: case CIGAR_X: {
+				uint32_t k = 0;
+				if (reference_position >= 0 && (uint64_t) reference_position + length <= contig_size && (uint64_t) read_position + length <= sequence.length) {
+					const uint64_t genome_last_word = (genome.contig_offset[genome.n_contigs] - 1) >> 2;
+					while (k < length) {
+						const uint32_t count = length - k < 16 ? length - k : 16;
+						if (!compare_chunk(sequence, read_position, genome_words, genome_last_word, contig_begin + (uint64_t) reference_position, count, alignment_length, mismatches)) break;
+						reference_position += count; read_position += count; k += count;
+					}
+				}
+				for (; k < length; ++k) {
 					uint32_t code = (read_position < sequence.length) ? sequence.code(read_position) : 16;
 					if (code != 15) { // 'N' bases are skipped
 						char reference_base = '\0';
@@ -397,6 +412,7 @@ AGPU_HD bool has_too_many_mismatches(const BatchView& b, const GenomeView& genom
 					read_position++;
 				}
 				break;
+			}
 			default: break;
 		}
 	}
@@ -526,8 +542,8 @@ AGPU_HD uint8_t read_filters_stage2(const BatchView& b, const AnnotationView& an
 	if (filter != FILTER_none) return filter;
 	IdSet genes[3];
 	int n_aln = b.n_aln[i];
-	for (int s = 0; s < 3; ++s) { genes[s].clear(); if (s < n_aln) load_genes(b, s, i, genes[s]); }
-	if (enabled[FILTER_read_through] && is_proximal_read_through(b, ann, t, i, genes)) { filter = FILTER_read_through; first_hit = 0; }
+	AGPU_UNROLL for (int s = 0; s < 3; ++s) { genes[s].clear(); if (s < n_aln) load_genes(b, s, i, genes[s]); }
+	if (enabled[FILTER_read_through] && is_proximal_read_through(b, ann, t, i)) { filter = FILTER_read_through; first_hit = 0; }
 	else if (enabled[FILTER_inconsistently_clipped] && is_inconsistently_clipped(b, i)) { filter = FILTER_inconsistently_clipped; first_hit = 1; }
 	else if (enabled[FILTER_homopolymer] && has_homopolymer_at_breakpoint(b, ann, t, i, genes[SPLIT_READ], stage)) { filter = FILTER_homopolymer; first_hit = 2; }
 	else if (enabled[FILTER_small_insert_size] && has_small_insert_size(b, i, 5)) { filter = FILTER_small_insert_size; first_hit = 3; }

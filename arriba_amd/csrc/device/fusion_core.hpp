@@ -120,7 +120,7 @@ AGPU_HD void write_emissions(const BatchView& b, uint64_t i, FusionEmission* out
 	uint32_t k = 0;
 	for (uint32_t g1 = 0; g1 < genes1.n; ++g1)
 		for (uint32_t g2 = 0; g2 < genes2.n; ++g2) {
-			e.gene1 = genes1.v[g1]; e.gene2 = genes2.v[g2];
+			e.gene1 = genes1.get(g1); e.gene2 = genes2.get(g2);
 			e.info = (e.info & ~(255u << EINFO_ORDINAL_SHIFT)) | (k & 255u) << EINFO_ORDINAL_SHIFT;
 			out[k++] = e;
 		}

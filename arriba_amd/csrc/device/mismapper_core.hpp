@@ -175,7 +175,7 @@ AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int
 	if (segment.length >= 300) return false; // long reads are not re-aligned
 	const int32_t min_score = (int32_t) ((double) (min_align_fraction * (float) segment.length) + 0.5);
 	for (uint32_t g = 0; g < genes.n; ++g) {
-		const uint32_t gene = genes.v[g];
+		const uint32_t gene = genes.get(g);
 		const uint32_t contig = ann.gene_contig[gene];
 		const int64_t contig_size = (int64_t) (genome.contig_offset[contig + 1] - genome.contig_offset[contig]);
 		AlignTarget target;

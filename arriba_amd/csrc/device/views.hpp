@@ -6,8 +6,10 @@
 
 #if defined(__HIPCC__)
 #define AGPU_HD __host__ __device__ __forceinline__
+#define AGPU_UNROLL _Pragma("unroll")
 #else
 #define AGPU_HD inline
+#define AGPU_UNROLL
 #endif
 
 namespace agpu {
