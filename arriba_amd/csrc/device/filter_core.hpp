@@ -355,8 +355,109 @@ AGPU_HD bool is_hairpin(const BatchView& b, uint64_t i, const IdSet* genes) {
 	       breakpoint_within_aligned_segment(b, MATE1, i, breakpoint_supp);
 }
 
-// reference: count_mismatches + test_mismatch_probability, source/filter_mismatches.cpp:12-99.  The genome is read one
-// aligned 32-bit word per four bases.
+// ---- sixteen bases at a time ------------------------------------------------------------------------------------------------
+// The mismatch walk of source/filter_mismatches.cpp:12-52 compares read and reference base by base.  Here an aligned block (M/=/X)
+// is processed in chunks of 16 bases: three sequence words and five genome words are loaded back to back (independent loads instead
+// of one dependent load per four bases), the sixteen 4-bit read codes are turned into characters four at a time and XOR-ed with the
+// reference bytes.
+
+AGPU_HD uint32_t swap_nibbles(uint32_t word) { return ((word & 0x0F0F0F0Fu) << 4) | ((word >> 4) & 0x0F0F0F0Fu); } // base j of the word -> bits 4j..4j+3
+
+// codes of the physical positions first .. first+15 of the sequence (code k at bits 4k); positions behind the last word repeat it
+AGPU_HD uint64_t physical_codes16(const uint32_t* words, uint32_t n_words, uint32_t first) {
+	const uint32_t w = first >> 3, shift = (first & 7) << 2;
+	const uint32_t last = n_words - 1;
+	const uint64_t low = (uint64_t) swap_nibbles(words[w + 1 < last ? w + 1 : last]) << 32 | swap_nibbles(words[w < last ? w : last]);
+	const uint64_t high = swap_nibbles(words[w + 2 < last ? w + 2 : last]);
+	return shift ? (low >> shift) | (high << (64 - shift)) : low;
+}
+AGPU_HD uint64_t reverse_nibbles(uint64_t x) {
+	x = (x >> 32) | (x << 32);
+	x = ((x & 0xFFFF0000FFFF0000ULL) >> 16) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+	x = ((x & 0xFF00FF00FF00FF00ULL) >> 8) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+	return ((x & 0xF0F0F0F0F0F0F0F0ULL) >> 4) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+}
+// complement of A/C/G/T codes (1,2,4,8) = bit reversal of the nibble; 0 and 15 map to themselves.  Other ambiguity codes do not:
+// the caller checks only_plain_codes() first.
+AGPU_HD uint64_t complement_plain_codes(uint64_t x) {
+	return ((x & 0x1111111111111111ULL) << 3) | ((x & 0x2222222222222222ULL) << 1) | ((x & 0x4444444444444444ULL) >> 1) | ((x & 0x8888888888888888ULL) >> 3);
+}
+AGPU_HD bool only_plain_codes(uint64_t x) { // every nibble has at most one bit set or is 15
+	const uint64_t ones = 0x1111111111111111ULL;
+	const uint64_t sum = (x & ones) + ((x >> 1) & ones) + ((x >> 2) & ones) + ((x >> 3) & ones); // bits set per nibble: 0..4
+	return (((sum >> 1) & ones) & ~((sum >> 2) & ones)) == 0;                                      // none has 2 or 3
+}
+// codes of the logical positions position .. position+15 of a (possibly reverse-complemented) sequence; ok = false if the chunk holds
+// an ambiguity code that the nibble tricks do not complement like the reference does
+AGPU_HD uint64_t logical_codes16(const SequenceRef& sequence, uint32_t position, bool& ok) {
+	const uint32_t n_words = (sequence.length + 7) >> 3;
+	ok = true;
+	if (!sequence.reverse_complement) return physical_codes16(sequence.words, n_words, position);
+	// logical p <-> physical length-1-p: the sixteen positions end at physical `top`
+	const int32_t top = (int32_t) sequence.length - 1 - (int32_t) position, first = top - 15;
+	uint64_t codes = physical_codes16(sequence.words, n_words, first > 0 ? (uint32_t) first : 0u);
+	if (first < 0) codes <<= (uint32_t) (-first) << 2; // the chunk starts before the sequence: its leading (logical: trailing) codes are not used
+	codes = reverse_nibbles(codes);
+	ok = only_plain_codes(codes);
+	return complement_plain_codes(codes);
+}
+
+// four 4-bit codes (one per byte of `spread`, values 0..15) -> the four characters of seq_nt16_str
+AGPU_HD uint32_t characters_of_codes(uint32_t spread) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t select = spread & 0x07070707u;
+	const uint32_t low = __builtin_amdgcn_perm(0x56535247u, 0x4d43413du, select);   // "=ACM" | "GRSV"
+	const uint32_t high = __builtin_amdgcn_perm(0x4e42444bu, 0x48595754u, select);  // "TWYH" | "KDBN"
+	const uint32_t take_high = ((spread >> 3) & 0x01010101u) * 0xFFu;
+	return (high & take_high) | (low & ~take_high);
+#else
+	return (uint32_t) (uint8_t) base_char(spread & 15) | (uint32_t) (uint8_t) base_char(spread >> 8 & 15) << 8 | (uint32_t) (uint8_t) base_char(spread >> 16 & 15) << 16 | (uint32_t) (uint8_t) base_char(spread >> 24 & 15) << 24;
+#endif
+}
+AGPU_HD uint32_t popcount32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint32_t) __popc(x);
+#else
+	return (uint32_t) __builtin_popcount(x);
+#endif
+}
+
+// `count` (1..16) bases of an aligned block: read positions read_position.., reference bytes at byte offset `reference_offset` of the genome.
+// Adds the number of compared (non-N) bases and of mismatches.  Returns false if the chunk needs the base-by-base walk.
+AGPU_HD bool compare_chunk(const SequenceRef& sequence, uint32_t read_position, const uint32_t* genome_words, uint64_t genome_last_word, uint64_t reference_offset, uint32_t count,
+                           uint32_t& alignment_length, uint32_t& mismatches) {
+	bool ok;
+	const uint64_t codes = logical_codes16(sequence, read_position, ok);
+	if (!ok) return false;
+	const uint64_t word_index = reference_offset >> 2;
+	const uint32_t shift = (uint32_t) (reference_offset & 3) << 3;
+	// (the five loads do not depend on each other)
+	const uint32_t g0 = genome_words[word_index];
+	const uint32_t g1 = genome_words[word_index + 1 < genome_last_word ? word_index + 1 : genome_last_word];
+	const uint32_t g2 = genome_words[word_index + 2 < genome_last_word ? word_index + 2 : genome_last_word];
+	const uint32_t g3 = genome_words[word_index + 3 < genome_last_word ? word_index + 3 : genome_last_word];
+	const uint32_t g4 = genome_words[word_index + 4 < genome_last_word ? word_index + 4 : genome_last_word];
+#define AGPU_QUAD(q, LOW, HIGH) { \
+		const uint32_t valid_bytes = count > 4u * q ? (count - 4u * q >= 4u ? 0xFFFFFFFFu : (1u << ((count - 4u * q) << 3)) - 1u) : 0u; \
+		const uint32_t reference = (uint32_t) (((uint64_t) HIGH << 32 | LOW) >> shift); \
+		const uint32_t four = (uint32_t) (codes >> (16 * q)) & 0xFFFFu; \
+		uint32_t spread = (four & 0x00FFu) | (four & 0xFF00u) << 8; \
+		spread = (spread | spread << 4) & 0x0F0F0F0Fu; \
+		const uint32_t is_n = ((spread + 0x01010101u) & 0x10101010u) << 3;            /* 0x80 in every byte whose code is 15 */ \
+		const uint32_t difference = characters_of_codes(spread) ^ reference; \
+		const uint32_t differs = (((difference & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | difference) & 0x80808080u; \
+		const uint32_t compared = ~is_n & 0x80808080u & valid_bytes; \
+		alignment_length += popcount32(compared); \
+		mismatches += popcount32(differs & compared); \
+	}
+	AGPU_QUAD(0, g0, g1) AGPU_QUAD(1, g1, g2) AGPU_QUAD(2, g2, g3) AGPU_QUAD(3, g3, g4)
+#undef AGPU_QUAD
+	return true;
+}
+
+// reference: count_mismatches + test_mismatch_probability, source/filter_mismatches.cpp:12-99.  Aligned blocks that lie inside the
+// contig and the read are compared sixteen bases at a time; anything else falls back to the base-by-base walk (one aligned 32-bit
+// genome word per four bases).
 AGPU_HD bool has_too_many_mismatches(const BatchView& b, const GenomeView& genome, const FilterTables& t, uint64_t i, int slot, const SequenceRef& sequence, bool is_multimapper) {
 	const uint32_t* cigar = cigar_of(b, slot, i); uint32_t n = b.cigar_count[slot][i];
 	uint32_t contig = b.contig[slot][i];
