@@ -278,25 +278,19 @@ __global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationVi
 	if (threadIdx.x < 10 && hits[threadIdx.x]) atomicAdd(&stage_counts[5 + threadIdx.x], (unsigned long long) hits[threadIdx.x]);
 }
 
-// low_entropy: 3-mer counters of a thread live in LDS, interleaved so that a thread always hits its own bank
-const int ENTROPY_BLOCK = 128;
-__global__ void __launch_bounds__(ENTROPY_BLOCK) low_entropy_kernel(BatchView b, FilterTables t, unsigned long long* stage_counts) {
-	__shared__ uint32_t counters[64 * ENTROPY_BLOCK];
-	__shared__ unsigned int hits;
-	if (threadIdx.x == 0) hits = 0;
-	KmerScratch scratch; scratch.counters = counters + threadIdx.x; scratch.stride = ENTROPY_BLOCK;
-	scratch.clear();
-	__syncthreads();
-	uint64_t i = blockIdx.x * (uint64_t) ENTROPY_BLOCK + threadIdx.x;
+// low_entropy: the 3-mer counters of a thread are bit-sliced registers (filter_core.hpp), no LDS
+__global__ void __launch_bounds__(BLOCK) low_entropy_kernel(BatchView b, FilterTables t, unsigned long long* stage_counts) {
+	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	bool hit = false;
 	if (i < b.n) {
 		uint8_t filter = b.filter[i];
-		if (needs_low_entropy_test(b, t, i, filter) && has_low_entropy(b, t, i, scratch, no_stage())) {
-			if (filter == FILTER_none) atomicAdd(&hits, 1u);
+		if (needs_low_entropy_test(b, t, i, filter) && has_low_entropy(b, t, i, no_stage())) {
+			hit = filter == FILTER_none;
 			b.filter[i] = FILTER_low_entropy;
 		}
 	}
-	__syncthreads();
-	if (threadIdx.x == 0 && hits) atomicAdd(&stage_counts[13], (unsigned long long) hits);
+	unsigned long long ballot = __ballot(hit);
+	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(&stage_counts[13], (unsigned long long) __popcll(ballot));
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------
@@ -554,7 +548,7 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 		bytes += n * 8;
 		for (uint64_t i = 0; i < n; ++i) if (in->seq_length[k][i] > ctx->max_read_length) ctx->max_read_length = in->seq_length[k][i];
 	}
-	if (ctx->max_read_length > 1024) { set_last_error("reads longer than 1024 nt are not supported by the low_entropy kernel's 8-bit k-mer counters"); return AGPU_ERR_INVALID; }
+	if (ctx->max_read_length > 1024) { set_last_error("reads longer than 1024 nt are not supported by the low_entropy kernel's 8-plane k-mer counters"); return AGPU_ERR_INVALID; }
 	TRY(upload(ctx->seq_pool, in->seq_pool, in->seq_pool_size, s));
 	bytes += in->seq_pool_size;
 	ctx->batch_input_bytes = bytes;
@@ -869,7 +863,7 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 		{ KernelTimer timer(ctx, "stage2_kernel", stage2_bytes(ctx)); stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->stage_counts.as<unsigned long long>()); }
 		if (ctx->params.filter_enabled[FILTER_low_entropy]) {
 			KernelTimer timer(ctx, "low_entropy_kernel", low_entropy_bytes(ctx));
-			low_entropy_kernel<<<(unsigned int) ((n + ENTROPY_BLOCK - 1) / ENTROPY_BLOCK), ENTROPY_BLOCK, 0, s>>>(ctx->batch, ctx->tables, ctx->stage_counts.as<unsigned long long>());
+			low_entropy_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, ctx->stage_counts.as<unsigned long long>());
 		}
 	}
 	TRY(end_timing(ctx, stage2_bytes(ctx) + low_entropy_bytes(ctx)));

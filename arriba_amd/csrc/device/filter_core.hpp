@@ -560,20 +560,39 @@ AGPU_HD bool looks_like_internal_tandem_duplication(const BatchView& b, const Fi
 	return b.end[SPLIT_READ][i] > b.start[SUPPLEMENTARY][i] && b.end[SPLIT_READ][i] <= b.start[SUPPLEMENTARY][i] + max_itd;
 }
 
-// Per-thread counters for the 64 possible 3-mers: one 32-bit word per k-mer = tag (8 bits) | count in aligned segment 2 | count in
-// aligned segment 1 | count in the whole read (8 bits each).  A word whose tag differs from the current tag counts as zero, so the
-// 64 words are cleared once per thread, not once per read.  `stride` interleaves the counters of a workgroup in LDS (bank = thread);
-// the host harness uses stride 1.
-struct KmerScratch {
-	uint32_t* counters; uint32_t stride; uint32_t tag;
-	AGPU_HD void clear() { for (uint32_t k = 0; k < 64; ++k) counters[k * stride] = 0; tag = 0; }
-	AGPU_HD void next_read() { if (++tag == 256) clear(), tag = 1; }
+// Counters of the 64 possible 3-mers, bit-sliced: plane p holds bit p of all 64 counters (counter k = bit k of every plane), so the
+// counters live in sixteen 32-bit registers, need no LDS and no run-time indexing.  Adding one to counter k is a ripple carry over
+// the planes (on average two planes); "is any counter >= T" is one bit-parallel comparison over all 64 counters.
+const int KMER_PLANES = 8; // counts up to 255; a carry out of the last plane is remembered (it exceeds every threshold of a read of <= 1024 bases)
+struct KmerCounters {
+	uint64_t plane[KMER_PLANES];
+	bool overflow;
+	AGPU_HD void clear() {
+		plane[0] = plane[1] = plane[2] = plane[3] = plane[4] = plane[5] = plane[6] = plane[7] = 0;
+		overflow = false;
+	}
+	AGPU_HD void increment(uint64_t carry) { // carry = the counter's bit
+#define AGPU_RIPPLE(p) if (carry) { const uint64_t next = plane[p] & carry; plane[p] ^= carry; carry = next; }
+		AGPU_RIPPLE(0) AGPU_RIPPLE(1) AGPU_RIPPLE(2) AGPU_RIPPLE(3) AGPU_RIPPLE(4) AGPU_RIPPLE(5) AGPU_RIPPLE(6) AGPU_RIPPLE(7)
+#undef AGPU_RIPPLE
+		if (carry) overflow = true;
+	}
+	// bit k set iff counter k >= threshold
+	AGPU_HD uint64_t at_least(uint32_t threshold) const {
+		if (threshold >> KMER_PLANES) return overflow ? ~0ull : 0ull; // cannot be decided beyond the planes: only reachable for reads the kernel rejects
+		uint64_t less = 0; // counter < threshold, decided from the least significant bit upwards
+#define AGPU_COMPARE(p) less = (threshold >> p & 1u) ? (~plane[p] | less) : (less & ~plane[p]);
+		AGPU_COMPARE(0) AGPU_COMPARE(1) AGPU_COMPARE(2) AGPU_COMPARE(3) AGPU_COMPARE(4) AGPU_COMPARE(5) AGPU_COMPARE(6) AGPU_COMPARE(7)
+#undef AGPU_COMPARE
+		return ~less;
+	}
 };
 
 // reference: source/filter_low_entropy.cpp:33-101.  The reference counts an occurrence of a 3-mer only if it starts at or after the
 // end of the previously counted occurrence of the same 3-mer; with k = 3 that means "not counted at either of the two preceding
-// positions", so two registers replace its previous_kmer_pos array.
-AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t i, KmerScratch& scratch, const SequenceStage& stage) {
+// positions", so two registers replace its previous_kmer_pos array.  It tests the three counters of a 3-mer whenever that 3-mer is
+// counted; counters only grow, so testing all counters of all counted 3-mers once at the end of the read gives the same verdict.
+AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t i, const SequenceStage& stage) {
 	const uint32_t K = 3, NONE = 64;
 	for (int mate = MATE1; mate <= MATE2; ++mate) {
 		SequenceRef sequence = sequence_of(b, mate, i, stage);
@@ -598,18 +617,18 @@ AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t
 			aligned_start2 = aligned_start1;
 			aligned_end2 = aligned_end1;
 		}
-		uint32_t max_count = kmer_threshold(t, length);
-		uint32_t max_count_aligned1 = kmer_threshold(t, aligned_end1 - aligned_start1);
-		uint32_t max_count_aligned2 = kmer_threshold(t, aligned_end2 - aligned_start2);
-		scratch.next_read();
-		const uint32_t tag = scratch.tag << 24;
+		const uint32_t max_count = kmer_threshold(t, length);
+		const uint32_t max_count_aligned1 = kmer_threshold(t, aligned_end1 - aligned_start1);
+		const uint32_t max_count_aligned2 = kmer_threshold(t, aligned_end2 - aligned_start2);
+		KmerCounters whole, aligned1, aligned2;
+		whole.clear(); aligned1.clear(); aligned2.clear();
+		uint64_t counted_kmers = 0; // 3-mers that were counted at least once
 		uint32_t counted_previous = NONE, counted_before_previous = NONE; // 3-mers counted at position-1 / position-2
 		uint32_t kmer = 0;
 		const uint32_t last_position = length - K; // exclusive: the last k-mer is skipped, as in the reference (:77)
 		const uint32_t n_words = (length + 7) >> 3;
 		for (uint32_t w = 0; w < n_words; ++w) {
-			uint32_t word = sequence.words[w];
-			word = ((word & 0x0F0F0F0Fu) << 4) | ((word >> 4) & 0x0F0F0F0Fu); // base j of this word now sits at bits 4j..4j+3
+			uint32_t word = swap_nibbles(sequence.words[w]); // base j of this word now sits at bits 4j..4j+3
 			uint32_t bases_here = (length - (w << 3)) < 8 ? (length - (w << 3)) : 8;
 			for (uint32_t j = 0; j < bases_here; ++j) {
 				kmer = ((kmer << 2) | kmer_digit((word >> (j << 2)) & 15)) & 63;
@@ -621,17 +640,16 @@ AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t
 				counted_before_previous = counted_previous;
 				counted_previous = counted ? kmer : NONE;
 				if (!counted) continue;
-				uint32_t* counter = scratch.counters + kmer * scratch.stride;
-				uint32_t value = *counter;
-				if ((value & 0xFF000000u) != tag) value = tag;
-				value += 1u;
-				if (position + 1 >= aligned_start1 && position < aligned_end1) value += 1u << 8;
-				if (position + 1 >= aligned_start2 && position < aligned_end2) value += 1u << 16;
-				*counter = value;
-				if ((value & 255u) >= max_count || ((value >> 8) & 255u) >= max_count_aligned1 || ((value >> 16) & 255u) >= max_count_aligned2)
-					return true;
+				const uint64_t bit = 1ull << kmer;
+				counted_kmers |= bit;
+				whole.increment(bit);
+				if (position + 1 >= aligned_start1 && position < aligned_end1) aligned1.increment(bit);
+				if (position + 1 >= aligned_start2 && position < aligned_end2) aligned2.increment(bit);
 			}
 		}
+		if ((whole.at_least(max_count) | aligned1.at_least(max_count_aligned1) | aligned2.at_least(max_count_aligned2)) & counted_kmers)
+			return true;
+		if (whole.overflow || aligned1.overflow || aligned2.overflow) return true;
 	}
 	return false;
 }

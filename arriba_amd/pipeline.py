@@ -128,6 +128,9 @@ class DevicePipeline(object):
         if not self.ctx:
             raise ArribaError("ERROR: " + self.api.last_error().decode())
         self.timings = {}
+        self.wall_ms = {}
+        import time
+        self._last_record = time.perf_counter()
         self._check(self.api.upload_annotation(self.ctx, session.annotation_view))
         self._check(self.api.upload_genome(self.ctx, session.genome_view))
         self._check(self.api.upload_batch(self.ctx, batch_view if batch_view is not None else session.batch_view))
@@ -152,6 +155,10 @@ class DevicePipeline(object):
             raise ArribaError("ERROR: " + self.api.last_error().decode() + " (status %d)" % status)
 
     def _record(self, stage):
+        import time
+        now = time.perf_counter()
+        self.wall_ms[stage] = self.wall_ms.get(stage, 0.0) + (now - self._last_record) * 1e3  # host wall time since the previous stage ended
+        self._last_record = now
         ms, size = c_float(), c_uint64()
         self.api.last_kernel_ms(self.ctx, byref(ms))
         self.api.last_kernel_bytes(self.ctx, byref(size))
@@ -160,6 +167,7 @@ class DevicePipeline(object):
     def reset(self):
         """back to the state right after the upload (for repeated timed passes over the same resident batch)"""
         self._check(self.api.reset(self.ctx))
+        self._record("reset")
         self.n_dummy_genes = 0
 
     # ---- stages, named after the reference functions they replace ---------------------------------

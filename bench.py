@@ -127,6 +127,7 @@ def main():
         step()
     stage_ms = {}
     pipeline.set_profiling(True)  # HIP events around every kernel launch, recorded on the launch stream
+    pipeline.wall_ms.clear()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -179,6 +180,7 @@ def main():
                        "stages_timed": "mark_multimappers, annotate, read filters (14), fragment-length samples, find_fusions, fusions_t iteration order, estimate_expected_fusions, filter_relative_support",
                        "host_ingest_reads_per_s": n / ingest_seconds},
             "stage_ms": {stage: round(values["ms"], 3) for stage, values in per_stage.items()},
+            "stage_wall_ms": {stage: round(value / args.steps, 3) for stage, value in pipeline.wall_ms.items()},
             "kernel_ms": {name: round(values["ms"] / values["launches"], 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:12]},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes,

@@ -337,8 +337,6 @@ int emu_fragment_length_samples_limited(emu_ctx* ctx, uint32_t limit, int32_t* m
 
 int emu_read_filters_stage2(emu_ctx* ctx, uint64_t* remaining) {
 	BatchView& b = ctx->batch;
-	uint32_t counters[64];
-	KmerScratch scratch; scratch.counters = counters; scratch.stride = 1; scratch.clear();
 	for (uint64_t i = 0; i < b.n; ++i) {
 		uint32_t first_hit;
 		b.filter[i] = read_filters_stage2(b, ctx->annotation, ctx->genome, ctx->tables, ctx->params.filter_enabled, i, b.filter[i], no_stage(), first_hit);
@@ -347,7 +345,7 @@ int emu_read_filters_stage2(emu_ctx* ctx, uint64_t* remaining) {
 	if (ctx->params.filter_enabled[FILTER_low_entropy])
 		for (uint64_t i = 0; i < b.n; ++i) {
 			uint8_t filter = b.filter[i];
-			if (needs_low_entropy_test(b, ctx->tables, i, filter) && has_low_entropy(b, ctx->tables, i, scratch, no_stage())) {
+			if (needs_low_entropy_test(b, ctx->tables, i, filter) && has_low_entropy(b, ctx->tables, i, no_stage())) {
 				if (filter == FILTER_none) ctx->stage_counts[13]++;
 				b.filter[i] = FILTER_low_entropy;
 			}
