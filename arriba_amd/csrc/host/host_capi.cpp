@@ -38,6 +38,7 @@ struct ahost_session {
 	agpu_annotation_view annotation_view;
 	agpu_genome_view genome_view;
 	agpu_batch_view batch_view, slice_view;
+	std::map<std::pair<contig_t, contig_t>, bool> related_viruses;
 	std::string name_scratch;
 
 	void build_reference_views() {
@@ -263,7 +264,16 @@ int ahost_viral_verdicts(ahost_session* session, const uint32_t* pairs, uint64_t
 	unsigned int corrected_top_count = 0;
 	for (unsigned int i = 1; i < sorted.size() && expression[sorted[i]] > 0 && top_count > 0; ++i) {
 		corrected_top_count++;
-		if (!assembly.has(sorted[i]) || !assembly.has(sorted[i - 1]) || !related_viral_strains(assembly.sequence[sorted[i]], assembly.sequence[sorted[i - 1]]))
+		bool related = false;
+		if (assembly.has(sorted[i]) && assembly.has(sorted[i - 1])) {
+			// relatedness of two viral genomes is a property of the assembly alone: computed once per pair and session
+			std::pair<contig_t, contig_t> pair(sorted[i], sorted[i - 1]);
+			std::map<std::pair<contig_t, contig_t>, bool>::const_iterator known = session->related_viruses.find(pair);
+			if (known == session->related_viruses.end())
+				known = session->related_viruses.insert(std::make_pair(pair, related_viral_strains(assembly.sequence[sorted[i]], assembly.sequence[sorted[i - 1]]))).first;
+			related = known->second;
+		}
+		if (!related)
 			top_count--;
 	}
 	if (corrected_top_count != 0) corrected_top_count--;
@@ -344,32 +354,33 @@ int ahost_estimate_fragment_length_from_sums(const int32_t* mate_gaps_in, uint32
 		return 0;
 	}
 	read_length_mean = read_length_mean / read_length_count;
-	std::list<int> mate_gaps(mate_gaps_in, mate_gaps_in + n_samples);
+	std::vector<int> mate_gaps(mate_gaps_in, mate_gaps_in + n_samples); // (the reference uses a std::list; a vector compacted in place keeps the same order and sums)
 	float mate_gap_mean = 0, mate_gap_stddev = 0;
 	bool no_more_outliers = false;
 	while (true) {
 		mate_gap_mean = 0;
-		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); i++) mate_gap_mean += *i;
+		for (std::vector<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); i++) mate_gap_mean += *i;
 		mate_gap_mean /= mate_gap_count;
 		mate_gap_stddev = 0;
-		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); i++) mate_gap_stddev += (*i - mate_gap_mean) * (*i - mate_gap_mean);
+		for (std::vector<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); i++) mate_gap_stddev += (*i - mate_gap_mean) * (*i - mate_gap_mean);
 		mate_gap_stddev = sqrt(1.0 / (mate_gap_count - 1) * mate_gap_stddev);
 		unsigned int within_range = 0;
-		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); ++i)
+		for (std::vector<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end(); ++i)
 			if (*i > mate_gap_mean - mate_gap_stddev || *i < mate_gap_mean + mate_gap_stddev) // sic (hazard H6)
 				within_range++;
 		if (1.0 * within_range / mate_gap_count < 0.683 || no_more_outliers)
 			break;
 		no_more_outliers = true;
-		for (std::list<int>::iterator i = mate_gaps.begin(); i != mate_gaps.end();) {
-			if (*i < mate_gap_mean - 3 * mate_gap_stddev || *i > mate_gap_mean + 3 * mate_gap_stddev) {
-				i = mate_gaps.erase(i);
+		size_t kept = 0;
+		for (size_t i = 0; i < mate_gaps.size(); ++i) {
+			if (mate_gaps[i] < mate_gap_mean - 3 * mate_gap_stddev || mate_gaps[i] > mate_gap_mean + 3 * mate_gap_stddev) {
 				mate_gap_count--;
 				no_more_outliers = false;
 			} else {
-				++i;
+				mate_gaps[kept++] = mate_gaps[i];
 			}
 		}
+		mate_gaps.resize(kept);
 	}
 	*mate_gap_mean_out = mate_gap_mean; *mate_gap_stddev_out = mate_gap_stddev; *read_length_mean_out = read_length_mean;
 	*max_mate_gap_out = std::max(0, (int) (mate_gap_mean + 3 * mate_gap_stddev));

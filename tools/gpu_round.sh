@@ -16,9 +16,13 @@ if [ "$2" = "pmc" ]; then
     timeout 600 rocprofv3 --pmc $COUNTER --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$COUNTER -o pmc -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$COUNTER.log 2>&1
   done
   cd $GRAFT_REPO_ROOT
-  python tools/pmc_summary.py gpurun_out/${TAG}_pmc.json gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE > gpurun_out/${TAG}_pmc_summary.txt 2>&1
-  ls -R gpurun_out/pmc_${TAG}_FETCH_SIZE | head -20
-  head -3 $(find gpurun_out/pmc_${TAG}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+  python tools/pmc_summary.py gpurun_out/${TAG}_pmc_kernels.json gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE > gpurun_out/${TAG}_pmc_summary.txt 2>&1
+  python - <<PY
+import json
+kernels = json.load(open("gpurun_out/${TAG}_pmc_kernels.json"))
+line = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0; KB summed over the dispatches of a kernel", "fragments": line["config"]["fragments_per_gpu"], "kernels": kernels}, open("gpurun_out/${TAG}_pmc.json", "w"), indent=1, sort_keys=True)
+PY
   rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
 fi
 tail -5 gpurun_out/${TAG}_pytest_gpu.log; cat gpurun_out/${TAG}_bench.json; head -14 gpurun_out/${TAG}_kernel_stats.txt
