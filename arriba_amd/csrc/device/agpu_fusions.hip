@@ -538,7 +538,7 @@ extern "C" int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gen
 		{ flags, &ctx->cand_flags, C * 4 }, { filter, &ctx->cand_filter, C }, { split_reads1, &ctx->cand_split_reads1, C * 4 }, { split_reads2, &ctx->cand_split_reads2, C * 4 },
 		{ discordant_mates, &ctx->cand_discordant_mates, C * 4 }, { anchor1, &ctx->cand_anchor1, C * 4 }, { anchor2, &ctx->cand_anchor2, C * 4 }, { list_offset, &ctx->cand_list_offset, (3 * C + 1) * 4 } };
 	for (size_t k = 0; k < sizeof(copies) / sizeof(copies[0]); ++k)
-		if (copies[k].host) HIP_CHECK(hipMemcpy(copies[k].host, copies[k].device->ptr, copies[k].bytes, hipMemcpyDeviceToHost));
+		if (copies[k].host) HIP_CHECK(hipMemcpy(copies[k].host, copies[k].device->ptr, copies[k].bytes, hipMemcpyDefault)); // host or device destination
 	return AGPU_OK;
 }
 
@@ -631,7 +631,7 @@ extern "C" int agpu_get_candidate_first_occurrence(agpu_ctx* ctx, uint64_t* firs
 	if (!ctx || !ctx->fusions_done || !first_occurrence) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
-	if (ctx->n_candidates) HIP_CHECK(hipMemcpy(first_occurrence, ctx->cand_first_occurrence.ptr, (size_t) ctx->n_candidates * 8, hipMemcpyDeviceToHost));
+	if (ctx->n_candidates) HIP_CHECK(hipMemcpy(first_occurrence, ctx->cand_first_occurrence.ptr, (size_t) ctx->n_candidates * 8, hipMemcpyDefault));
 	return AGPU_OK;
 }
 

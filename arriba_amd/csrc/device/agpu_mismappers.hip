@@ -7,7 +7,8 @@
 //   rocPRIM radix_sort_pairs    stable sort by (contig table, 8-mer): positions stay ascending inside a bucket (:77-84)
 //   kmer_offsets_kernel         CSR offsets: 4^8 + 1 per indexed contig
 //   splice_site_count/write     downstream splice sites of every gene (:16-31) as a second CSR
-//   mismapper_flag/verdict      reads of unfiltered candidates -> greedy seed-and-extend re-alignment (mismapper_core.hpp), one thread per read
+//   mismapper_flag/verdict      reads of unfiltered candidates -> greedy seed-and-extend re-alignment (mismapper_core.hpp), one wavefront per read,
+//                               64 read positions of the seed search tried at once
 //   mismapper_candidate_kernel  fraction of mis-mappers per candidate (:336-356)
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -132,17 +133,18 @@ __global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* re
 	}
 }
 
+// one wavefront per read: the lanes try 64 read positions of a seed search at once (AlignRunner); everything else is wave-uniform
 __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap, unsigned int* discarded) {
-	uint32_t j = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
-	bool mismapper = false;
-	if (j < n_jobs) {
-		AlignFrame stack[ALIGN_MAX_DEPTH];
-		uint32_t read = jobs[j];
-		mismapper = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, stack);
-		if (mismapper) b.filter[read] = FILTER_mismappers;
+	const uint32_t j = blockIdx.x; // ALIGN_BLOCK == 64: one wavefront per workgroup
+	if (j >= n_jobs) return;
+	AlignFrame stack[ALIGN_MAX_DEPTH];
+	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = ALIGN_BLOCK;
+	const uint32_t read = jobs[j];
+	const bool mismapper = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
+	if (mismapper && threadIdx.x == 0) {
+		b.filter[read] = FILTER_mismappers;
+		atomicAdd(discarded, 1u);
 	}
-	unsigned long long ballot = __ballot(mismapper);
-	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(discarded, (unsigned int) __popcll(ballot));
 }
 
 __global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, unsigned int* remaining) {
@@ -293,7 +295,7 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (n_jobs > 0) {
 			KernelTimer timer(ctx, "mismapper_verdict_kernel", (uint64_t) n_jobs * 300);
-			mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
+			mismapper_verdict_kernel<<<n_jobs, ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
 		}
 		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
 		  mismapper_candidate_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, device_counters + 2); }

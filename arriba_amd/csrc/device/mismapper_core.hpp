@@ -79,15 +79,20 @@ AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t
 	f.leading = read_pos == 0; f.state = ALIGN_NEXT_READ_POSITION; f.started = 0; f.hit = 0; f.hits_end = 0;
 }
 
-// returns true if the segment aligns to the target with a score >= min_score
-AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack) {
+// One iteration of the outermost read_pos loop of the reference's align(): the seeds at read position `first_read_pos` with everything
+// that follows from them (extensions, nested re-seeds).  The outermost loop only ever skips bases (score = -read_pos, all skipped bases
+// leading), and its bound is monotone in read_pos, so its iterations are independent attempts: align() succeeds iff one of them does.
+// That is what lets a wavefront try 64 read positions at once.
+AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int32_t first_read_pos) {
 	const int32_t length = (int32_t) read.length;
 	int depth = 0;
-	align_enter(stack[0], 0, 0, target.gene_start, 1);
+	align_enter(stack[0], -first_read_pos, first_read_pos, target.gene_start, 1);
+	stack[0].skipped_bases = first_read_pos; stack[0].leading = 1;
 	while (depth >= 0) {
 		AlignFrame& f = stack[depth];
 		switch (f.state) {
 			case ALIGN_NEXT_READ_POSITION: { // for (; read_pos + k < length && ...; read_pos++, score--, skipped_bases++)
+				if (f.started && depth == 0) return false; // the other read positions of the outermost loop are other attempts
 				if (f.started) { f.read_pos++; f.score--; f.skipped_bases++; }
 				f.started = 1;
 				if (!(f.read_pos + KMER_LENGTH < length && f.read_pos + min_score <= length + f.score + 2 * KMER_LENGTH)) { --depth; break; } // this call returns false
@@ -168,10 +173,32 @@ AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_s
 	return false;
 }
 
+// Who tries the read positions: one thread after the other on the host (lanes = 1), the 64 lanes of a wavefront on the device.
+struct AlignRunner {
+	AlignFrame* stack; uint32_t lane, lanes;
+	AGPU_HD bool any(bool mine) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		return lanes > 1 ? __any(mine) != 0 : mine;
+#else
+		return mine;
+#endif
+	}
+	// reference: align(0, read, 0, contig, gene_start, gene_start, gene_end, ...) (source/filter_mismappers.cpp:86-199)
+	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
+		const int32_t length = (int32_t) read.length;
+		for (int32_t base = 0; base + KMER_LENGTH < length && 2 * base + min_score <= length + 2 * KMER_LENGTH; base += (int32_t) lanes) { // the loop bound of the reference at read_pos = base
+			const int32_t read_pos = base + (int32_t) lane;
+			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, read_pos);
+			if (any(found)) return true;
+		}
+		return false;
+	}
+};
+
 // reference: align_both_strands (source/filter_mismappers.cpp:201-245).  `segment` is the part of the read to re-align, read_length the
 // length of the whole read; the genes are those of the other end of the fragment.
 AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int32_t max_mate_gap, bool breakpoints_on_same_contig, int32_t alignment_start, int32_t alignment_end,
-                                const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, const IdSet& genes, float min_align_fraction, AlignFrame* stack) {
+                                const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, const IdSet& genes, float min_align_fraction, const AlignRunner& runner) {
 	if (segment.length >= 300) return false; // long reads are not re-aligned
 	const int32_t min_score = (int32_t) ((double) (min_align_fraction * (float) segment.length) + 0.5);
 	for (uint32_t g = 0; g < genes.n; ++g) {
@@ -190,9 +217,9 @@ AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int
 		target.contig_bases = genome.bases + genome.contig_offset[contig];
 		target.splice_sites = splice.sites + splice.offset[gene]; target.n_splice_sites = splice.offset[gene + 1] - splice.offset[gene];
 		Segment forward = segment; forward.reverse_complement = false;
-		if (align(forward, target, min_score, stack)) return true;
+		if (runner.align(forward, target, min_score)) return true;
 		Segment reverse = segment; reverse.reverse_complement = true;
-		if (align(reverse, target, min_score, stack)) return true;
+		if (runner.align(reverse, target, min_score)) return true;
 	}
 	return false;
 }
@@ -226,7 +253,7 @@ AGPU_HD bool extend_split_read(const BatchView& b, const GenomeView& genome, uin
 
 // Does fragment i support its fusion only because it is mis-mapped?  reference: the per-read part of filter_mismappers
 // (source/filter_mismappers.cpp:283-332); a pure function of the fragment, its gene sets, max_mate_gap and the k-mer index.
-AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, uint64_t i, int32_t max_mate_gap, AlignFrame* stack) {
+AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, uint64_t i, int32_t max_mate_gap, const AlignRunner& runner) {
 	const float min_align_fraction = 0.8f, min_extended_align_fraction = 0.7f;
 	IdSet genes;
 	if (b.n_aln[i] == 3) {
@@ -248,10 +275,10 @@ AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const G
 			mate.offset = 0; mate.length = mate1_sequence.length - mate_clip;                  // mate1.sequence.substr(0, length - postclipping)
 		}
 		load_genes(b, SPLIT_READ, i, genes);
-		if (align_both_strands(clipped, (int32_t) split_sequence.length, max_mate_gap, same_contig, b.start[SUPPLEMENTARY][i], b.end[SUPPLEMENTARY][i], ann, genome, kmers, splice, genes, min_align_fraction, stack))
+		if (align_both_strands(clipped, (int32_t) split_sequence.length, max_mate_gap, same_contig, b.start[SUPPLEMENTARY][i], b.end[SUPPLEMENTARY][i], ann, genome, kmers, splice, genes, min_align_fraction, runner))
 			return true; // the clipped segment aligns to the donor
 		load_genes(b, SUPPLEMENTARY, i, genes);
-		return align_both_strands(mate, (int32_t) mate1_sequence.length, max_mate_gap, same_contig, b.start[MATE1][i], b.end[MATE1][i], ann, genome, kmers, splice, genes, min_align_fraction, stack); // the mate aligns to the acceptor
+		return align_both_strands(mate, (int32_t) mate1_sequence.length, max_mate_gap, same_contig, b.start[MATE1][i], b.end[MATE1][i], ann, genome, kmers, splice, genes, min_align_fraction, runner); // the mate aligns to the acceptor
 	}
 	// discordant mates: an alignment as long as the chimeric alignment suffices
 	const bool same_contig = b.contig[MATE1][i] == b.contig[MATE2][i];
@@ -262,7 +289,7 @@ AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const G
 		const float reduced = min_align_fraction * (1 - clipped_fraction);
 		Segment whole; whole.sequence = sequence; whole.offset = 0; whole.length = sequence.length; whole.reverse_complement = false;
 		load_genes(b, mate == MATE1 ? MATE2 : MATE1, i, genes);
-		if (align_both_strands(whole, (int32_t) sequence.length, max_mate_gap, same_contig, b.start[mate][i], b.end[mate][i], ann, genome, kmers, splice, genes, reduced < min_align_fraction ? reduced : min_align_fraction, stack))
+		if (align_both_strands(whole, (int32_t) sequence.length, max_mate_gap, same_contig, b.start[mate][i], b.end[mate][i], ann, genome, kmers, splice, genes, reduced < min_align_fraction ? reduced : min_align_fraction, runner))
 			return true;
 	}
 	return false;

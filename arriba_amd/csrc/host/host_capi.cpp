@@ -283,17 +283,20 @@ int ahost_viral_verdicts(ahost_session* session, const uint32_t* pairs, uint64_t
 	if (top_intergenic > mapped.size()) top_intergenic = mapped.size();
 	top_intergenic = mapped.size() - top_intergenic;
 	float min_expression_threshold_intergenic = sorted.empty() ? 0 : expression[sorted[top_intergenic]];
-	std::vector<std::set<uint32_t> > sites(C);
-	for (uint64_t p = 0; p < n_pairs; ++p)
-		if (pairs[2 * p] < C && pairs[2 * p + 1] < n_genes)
-			sites[pairs[2 * p]].insert(pairs[2 * p + 1]);
-	std::vector<float> fraction_intergenic(C);
-	for (size_t c = 0; c < C; ++c) {
-		unsigned int intergenic = 0, genic = 0;
-		for (std::set<uint32_t>::const_iterator gene = sites[c].begin(); gene != sites[c].end(); ++gene)
-			if (gene_bits[*gene] & AGPU_GBIT_DUMMY) intergenic++; else genic++;
-		if (intergenic > 0) fraction_intergenic[c] = 1.0 * intergenic / (genic + intergenic);
+	// distinct host genes hit per viral contig, split into intergenic (dummy) and genic ones (:95-112); one bitmap per viral contig that occurs
+	std::vector<std::vector<uint8_t> > seen(C);
+	std::vector<unsigned int> intergenic_sites(C, 0), genic_sites(C, 0);
+	for (uint64_t p = 0; p < n_pairs; ++p) {
+		const uint32_t contig = pairs[2 * p], gene = pairs[2 * p + 1];
+		if (contig >= C || gene >= n_genes) continue;
+		if (seen[contig].empty()) seen[contig].assign(n_genes, 0);
+		if (seen[contig][gene]) continue;
+		seen[contig][gene] = 1;
+		if (gene_bits[gene] & AGPU_GBIT_DUMMY) intergenic_sites[contig]++; else genic_sites[contig]++;
 	}
+	std::vector<float> fraction_intergenic(C);
+	for (size_t c = 0; c < C; ++c)
+		if (intergenic_sites[c] > 0) fraction_intergenic[c] = 1.0 * intergenic_sites[c] / (genic_sites[c] + intergenic_sites[c]);
 	for (size_t c = 0; c < C; ++c) {
 		bool verdict = false;
 		if (viral[c] && c < expression.size())

@@ -213,19 +213,36 @@ class ShardedPipeline(DevicePipeline):
         return self.n_candidates
 
     def replicate_candidates(self):
-        """all-gather of the owners' candidate columns in the reference's insertion order and import into this rank's context, so that the
-        candidate-level stages (iteration order, e-value, relative support) run replicated on every rank.  The read lists stay with the owners."""
-        table = self.candidates()
-        first = self.first_occurrence()
-        all_first, _ = self._all_gather_array(first)
-        order = np.argsort(all_first, kind="stable")
-        columns = {}
-        for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2"):
-            column, _ = self._all_gather_array(table[key])
-            columns[key] = np.ascontiguousarray(column[order])
-        total = int(all_first.size)
-        self._check(self.api.import_candidates(self.ctx, total, *[columns[k].ctypes.data for k in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2")]))
-        self.n_owned_candidates = self.n_candidates
+        """all-gather of the owners' candidate columns and import in the reference's insertion order (ascending first occurrence), so that the
+        candidate-level stages (iteration order, e-value, relative support) run replicated on every rank.  Everything stays on the collective
+        device: the C ABI copies the columns straight into / out of the collective's buffers.  The read lists stay with the owners."""
+        n = self.n_candidates
+        device = self.collective_device
+        names = ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2")
+        dtypes = {name: (torch.uint8 if name == "filter" else torch.int32) for name in names}  # 32-bit columns travel as int32 bit patterns
+        local = {name: torch.zeros(max(n, 1), dtype=dtypes[name], device=device) for name in names}
+        first = torch.zeros(max(n, 1), dtype=torch.int64, device=device)
+        self._sync()
+        if n:
+            self._check(self.api.get_candidates(self.ctx, *[local[name].data_ptr() for name in names], None))
+            self._check(self.api.get_candidate_first_occurrence(self.ctx, first.data_ptr()))
+        counts = self._all_gather_int(n)
+        width = max(max(counts), 1)
+
+        def gather(tensor):
+            padded = torch.zeros(width, dtype=tensor.dtype, device=device)
+            padded[:n] = tensor[:n]
+            parts = [torch.zeros(width, dtype=tensor.dtype, device=device) for _ in range(self.world)]
+            dist.all_gather(parts, padded, group=self.group)
+            return torch.cat([parts[r][:counts[r]] for r in range(self.world)])
+
+        all_first = gather(first)
+        order = torch.argsort(all_first, stable=True)  # (read rank << 8 | ordinal) is non-negative as int64
+        columns = {name: gather(local[name])[order].contiguous() for name in names}
+        total = int(all_first.numel())
+        self._sync()
+        self._check(self.api.import_candidates(self.ctx, total, *[columns[name].data_ptr() if total else None for name in names]))
+        self.n_owned_candidates = n
         self.n_candidates = total
         return total
 
