@@ -261,13 +261,37 @@ __global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint
 	if (threadIdx.x == 0) counters[COUNTER_SAMPLES] = base < limit ? base : limit;
 }
 
-// read_through ... mismatches: one thread per fragment, no LDS
-__global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationView ann, GenomeView genome, FilterTables t, const uint8_t* enabled, unsigned long long* stage_counts) {
+// ---- stream compaction between the filter stages ---------------------------------------------------------------------------
+// Most fragments are already discarded when the expensive stages run (30 % PCR duplicates alone); a wavefront of which half the lanes
+// return at once still pays for the whole walk of the others.  So the survivors are compacted first: every wavefront ballots its
+// survivors, lane 0 reserves the output range with one atomic, the lanes write their fragment index at the prefix popcount.  The
+// order inside the list is arbitrary (the stages do not depend on it).
+enum { SELECT_UNFILTERED = 0, SELECT_LOW_ENTROPY_TEST = 1 };
+__global__ void __launch_bounds__(BLOCK) select_fragments_kernel(BatchView b, FilterTables t, int what, uint32_t* selected, uint32_t* count) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	bool keep = false;
+	if (i < b.n) {
+		const uint8_t filter = b.filter[i];
+		keep = (what == SELECT_UNFILTERED) ? filter == FILTER_none : needs_low_entropy_test(b, t, i, filter);
+	}
+	const unsigned long long ballot = __ballot(keep);
+	if (ballot == 0) return;
+	const uint32_t lane = threadIdx.x & 63;
+	const int leader = __ffsll((long long) ballot) - 1;
+	uint32_t base = 0;
+	if ((int) lane == leader) base = atomicAdd(count, (uint32_t) __popcll(ballot));
+	base = __shfl(base, leader);
+	if (keep) selected[base + __popcll(ballot & ((1ull << lane) - 1))] = (uint32_t) i;
+}
+
+// read_through ... mismatches: one thread per fragment that is still unfiltered
+__global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationView ann, GenomeView genome, FilterTables t, const uint8_t* enabled, const uint32_t* selected, const uint32_t* n_selected, unsigned long long* stage_counts) {
 	__shared__ unsigned int hits[10];
 	if (threadIdx.x < 10) hits[threadIdx.x] = 0;
 	__syncthreads();
-	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i < b.n) {
+	uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k < *n_selected) {
+		const uint64_t i = selected[k];
 		uint32_t first_hit;
 		uint8_t before = b.filter[i];
 		uint8_t filter = read_filters_stage2(b, ann, genome, t, enabled, i, before, no_stage(), first_hit);
@@ -278,14 +302,14 @@ __global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationVi
 	if (threadIdx.x < 10 && hits[threadIdx.x]) atomicAdd(&stage_counts[5 + threadIdx.x], (unsigned long long) hits[threadIdx.x]);
 }
 
-// low_entropy: the 3-mer counters of a thread are bit-sliced registers (filter_core.hpp), no LDS
-__global__ void __launch_bounds__(BLOCK) low_entropy_kernel(BatchView b, FilterTables t, unsigned long long* stage_counts) {
-	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+// low_entropy: the 3-mer counters of a thread are bit-sliced registers (filter_core.hpp), no LDS; one thread per fragment that needs the test
+__global__ void __launch_bounds__(BLOCK) low_entropy_kernel(BatchView b, FilterTables t, const uint32_t* selected, const uint32_t* n_selected, unsigned long long* stage_counts) {
+	uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	bool hit = false;
-	if (i < b.n) {
-		uint8_t filter = b.filter[i];
-		if (needs_low_entropy_test(b, t, i, filter) && has_low_entropy(b, t, i, no_stage())) {
-			hit = filter == FILTER_none;
+	if (k < *n_selected) {
+		const uint64_t i = selected[k];
+		if (has_low_entropy(b, t, i, no_stage())) {
+			hit = b.filter[i] == FILTER_none;
 			b.filter[i] = FILTER_low_entropy;
 		}
 	}
@@ -859,16 +883,33 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 	hipStream_t s = ctx->stream;
 	const uint64_t n = ctx->n;
 	begin_timing(ctx);
+	DeviceBuffer& selected = ctx->scratch("stage2.selected"); DeviceBuffer& selected_count = ctx->scratch("stage2.selected_count");
+	if (!selected.allocate(std::max<uint64_t>(n, 1) * 4) || !selected_count.allocate(16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	HIP_CHECK(hipMemsetAsync(selected_count.ptr, 0, 16, s));
 	if (n > 0) {
-		{ KernelTimer timer(ctx, "stage2_kernel", stage2_bytes(ctx)); stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->stage_counts.as<unsigned long long>()); }
+		// the grids are sized for all fragments (no round trip for the count); workgroups behind the end of the list return at once
+		uint32_t* counts = selected_count.as<uint32_t>();
+		{ KernelTimer timer(ctx, "select_fragments_kernel(unfiltered)", n * (1 + 4)); select_fragments_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_UNFILTERED, selected.as<uint32_t>(), counts); }
+		{ KernelTimer timer(ctx, "stage2_kernel", stage2_bytes(ctx)); stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), selected.as<uint32_t>(), counts, ctx->stage_counts.as<unsigned long long>()); }
 		if (ctx->params.filter_enabled[FILTER_low_entropy]) {
+			{ KernelTimer timer(ctx, "select_fragments_kernel(low_entropy)", n * (1 + 4)); select_fragments_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_LOW_ENTROPY_TEST, selected.as<uint32_t>(), counts + 1); }
 			KernelTimer timer(ctx, "low_entropy_kernel", low_entropy_bytes(ctx));
-			low_entropy_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, ctx->stage_counts.as<unsigned long long>());
+			low_entropy_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, selected.as<uint32_t>(), counts + 1, ctx->stage_counts.as<unsigned long long>());
 		}
 	}
 	TRY(end_timing(ctx, stage2_bytes(ctx) + low_entropy_bytes(ctx)));
 	unsigned long long counts[16];
 	HIP_CHECK(hipMemcpy(counts, ctx->stage_counts.ptr, sizeof(counts), hipMemcpyDeviceToHost));
+	{ // the two stages only touch the fragments that were selected for them: scale their algorithmic bytes accordingly
+		uint32_t selected_counts[2] = { 0, 0 };
+		HIP_CHECK(hipMemcpy(selected_counts, selected_count.ptr, sizeof(selected_counts), hipMemcpyDeviceToHost));
+		for (size_t k = ctx->samples_done.size(); k > 0 && n > 0; --k) {
+			KernelSample& sample = ctx->samples_done[k - 1];
+			if (strcmp(sample.name, "low_entropy_kernel") == 0) sample.bytes = (uint64_t) ((double) sample.bytes * selected_counts[1] / n);
+			else if (strcmp(sample.name, "stage2_kernel") == 0) { sample.bytes = (uint64_t) ((double) sample.bytes * selected_counts[0] / n); break; }
+		}
+		ctx->last_bytes = (uint64_t) ((double) stage2_bytes(ctx) * selected_counts[0] / std::max<uint64_t>(n, 1) + (double) low_entropy_bytes(ctx) * selected_counts[1] / std::max<uint64_t>(n, 1)) + n * 10;
+	}
 	if (remaining) {
 		// order of execution (source/arriba.cpp:327-409) -> "(remaining=N)" after each stage
 		static const int order[14] = { 1 /*duplicates*/, 30, 31, 32, 33, 4 /*read_through*/, 2, 3, 6, 7, 5, 8, 10, 36 };
