@@ -18,6 +18,7 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
+#include "device_utils.hpp"
 
 using namespace agpu;
 
@@ -56,11 +57,17 @@ __global__ void mark_multimappers_kernel(BatchView b, uint32_t* counters) {
 	if (threadIdx.x == 0 && marked) atomicAdd(&counters[COUNTER_MARKED], marked);
 }
 
-__global__ void annotate_stage1_kernel(BatchView b, AnnotationView ann, uint32_t strandedness, uint64_t* unmapped_keys, uint32_t* counters) {
+__global__ void __launch_bounds__(BLOCK) annotate_stage1_kernel(BatchView b, AnnotationView ann, uint32_t strandedness, uint64_t* unmapped_keys, uint32_t* counters) {
+	__shared__ uint32_t wave_offset[BLOCK / 64];
+	__shared__ uint32_t block_base;
 	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i >= b.n) return;
-	if (!annotate_fragment_stage1(b, ann, strandedness, i, unmapped_keys, &counters[COUNTER_UNMAPPED]))
+	uint64_t unmapped[2];
+	uint32_t n_unmapped = 0;
+	if (i < b.n && !annotate_fragment_stage1(b, ann, strandedness, i, unmapped, n_unmapped))
 		atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_GENE_SET_OVERFLOW);
+	const uint32_t at = block_append<BLOCK>(n_unmapped, &counters[COUNTER_UNMAPPED], wave_offset, &block_base); // one atomic per workgroup
+	if (n_unmapped >= 1) unmapped_keys[at] = unmapped[0];
+	if (n_unmapped >= 2) unmapped_keys[at + 1] = unmapped[1];
 }
 
 __global__ void dummy_flags_kernel(const uint64_t* sorted_keys, uint32_t n, FlatIndexView gene_index, uint32_t* flags) {
@@ -90,25 +97,29 @@ __global__ void dummy_gene_table_kernel(uint32_t n_genes, uint32_t n_dummy, cons
 	gene_exonic_length[g] = 10000;
 }
 
-__global__ void annotate_stage2_kernel(BatchView b, AnnotationView ann, GenomeView genome, uint32_t* viral_pairs, uint32_t viral_pair_capacity, uint32_t* counters) {
+__global__ void __launch_bounds__(BLOCK) annotate_stage2_kernel(BatchView b, AnnotationView ann, GenomeView genome, uint32_t* viral_pairs, uint32_t viral_pair_capacity, uint32_t* counters) {
+	__shared__ uint32_t wave_offset[BLOCK / 64];
+	__shared__ uint32_t block_base;
 	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i >= b.n) return;
-	if (!annotate_fragment_stage2(b, ann, i))
-		atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_GENE_SET_OVERFLOW);
-	// virus-host chimeric fragments: host genes per viral contig (source/filter_top_expressed_viral_contigs.cpp:95-112)
-	int mate2 = (b.n_aln[i] == 3) ? SUPPLEMENTARY : MATE2;
-	int viral_slot = -1, host_slot = -1;
-	uint8_t bits1 = genome.contig_bits[b.contig[MATE1][i]], bits2 = genome.contig_bits[b.contig[mate2][i]];
-	if (bits1 & CBIT_VIRAL) viral_slot = MATE1; else if (bits1 & CBIT_INTERESTING) host_slot = MATE1;
-	if (bits2 & CBIT_VIRAL) viral_slot = mate2; else if (bits2 & CBIT_INTERESTING) host_slot = mate2;
-	if (viral_slot >= 0 && host_slot >= 0) {
-		IdSet genes; load_genes(b, host_slot, i, genes);
-		uint32_t at = atomicAdd(&counters[COUNTER_VIRAL_PAIRS], genes.n);
-		if (at + genes.n > viral_pair_capacity) { atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_VIRAL_PAIR_OVERFLOW); return; }
-		for (uint32_t g = 0; g < genes.n; ++g) {
-			viral_pairs[2 * (at + g)] = b.contig[viral_slot][i];
-			viral_pairs[2 * (at + g) + 1] = genes.get(g);
-		}
+	IdSet genes; genes.clear();
+	uint32_t viral_contig = 0;
+	if (i < b.n) {
+		if (!annotate_fragment_stage2(b, ann, i))
+			atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_GENE_SET_OVERFLOW);
+		// virus-host chimeric fragments: host genes per viral contig (source/filter_top_expressed_viral_contigs.cpp:95-112)
+		int mate2 = (b.n_aln[i] == 3) ? SUPPLEMENTARY : MATE2;
+		int viral_slot = -1, host_slot = -1;
+		uint8_t bits1 = genome.contig_bits[b.contig[MATE1][i]], bits2 = genome.contig_bits[b.contig[mate2][i]];
+		if (bits1 & CBIT_VIRAL) viral_slot = MATE1; else if (bits1 & CBIT_INTERESTING) host_slot = MATE1;
+		if (bits2 & CBIT_VIRAL) viral_slot = mate2; else if (bits2 & CBIT_INTERESTING) host_slot = mate2;
+		if (viral_slot >= 0 && host_slot >= 0) { load_genes(b, host_slot, i, genes); viral_contig = b.contig[viral_slot][i]; }
+	}
+	const uint32_t at = block_reserve<BLOCK>(genes.n, &counters[COUNTER_VIRAL_PAIRS], wave_offset, &block_base); // one atomic per workgroup
+	if (genes.n == 0) return;
+	if (at + genes.n > viral_pair_capacity) { atomicOr(&counters[COUNTER_ERROR], (uint32_t) ERROR_VIRAL_PAIR_OVERFLOW); return; }
+	for (uint32_t g = 0; g < genes.n; ++g) {
+		viral_pairs[2 * (at + g)] = viral_contig;
+		viral_pairs[2 * (at + g) + 1] = genes.get(g);
 	}
 }
 
@@ -267,21 +278,27 @@ __global__ void sample_compact_kernel(uint64_t first, uint64_t count, const uint
 // survivors, lane 0 reserves the output range with one atomic, the lanes write their fragment index at the prefix popcount.  The
 // order inside the list is arbitrary (the stages do not depend on it).
 enum { SELECT_UNFILTERED = 0, SELECT_LOW_ENTROPY_TEST = 1 };
-__global__ void __launch_bounds__(BLOCK) select_fragments_kernel(BatchView b, FilterTables t, int what, uint32_t* selected, uint32_t* count) {
-	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+const int SELECT_BLOCK = 1024; // one atomic per 1024 fragments: ~10 k atomics on the list cursor per launch at 10 M fragments
+__global__ void __launch_bounds__(SELECT_BLOCK) select_fragments_kernel(BatchView b, FilterTables t, int what, uint32_t* selected, uint32_t* count) {
+	__shared__ uint32_t wave_offset[SELECT_BLOCK / 64];
+	__shared__ uint32_t block_base;
+	const uint64_t i = blockIdx.x * (uint64_t) SELECT_BLOCK + threadIdx.x;
 	bool keep = false;
 	if (i < b.n) {
 		const uint8_t filter = b.filter[i];
 		keep = (what == SELECT_UNFILTERED) ? filter == FILTER_none : needs_low_entropy_test(b, t, i, filter);
 	}
 	const unsigned long long ballot = __ballot(keep);
-	if (ballot == 0) return;
-	const uint32_t lane = threadIdx.x & 63;
-	const int leader = __ffsll((long long) ballot) - 1;
-	uint32_t base = 0;
-	if ((int) lane == leader) base = atomicAdd(count, (uint32_t) __popcll(ballot));
-	base = __shfl(base, leader);
-	if (keep) selected[base + __popcll(ballot & ((1ull << lane) - 1))] = (uint32_t) i;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (lane == 0) wave_offset[wave] = (uint32_t) __popcll(ballot);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (int w = 0; w < SELECT_BLOCK / 64; ++w) { uint32_t c = wave_offset[w]; wave_offset[w] = total; total += c; }
+		block_base = total ? atomicAdd(count, total) : 0;
+	}
+	__syncthreads();
+	if (keep) selected[block_base + wave_offset[wave] + __popcll(ballot & ((1ull << lane) - 1))] = (uint32_t) i;
 }
 
 // read_through ... mismatches: one thread per fragment that is still unfiltered
@@ -889,10 +906,10 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 	if (n > 0) {
 		// the grids are sized for all fragments (no round trip for the count); workgroups behind the end of the list return at once
 		uint32_t* counts = selected_count.as<uint32_t>();
-		{ KernelTimer timer(ctx, "select_fragments_kernel(unfiltered)", n * (1 + 4)); select_fragments_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_UNFILTERED, selected.as<uint32_t>(), counts); }
+		{ KernelTimer timer(ctx, "select_fragments_kernel(unfiltered)", n * (1 + 4)); select_fragments_kernel<<<(unsigned int) ((n + SELECT_BLOCK - 1) / SELECT_BLOCK), SELECT_BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_UNFILTERED, selected.as<uint32_t>(), counts); }
 		{ KernelTimer timer(ctx, "stage2_kernel", stage2_bytes(ctx)); stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), selected.as<uint32_t>(), counts, ctx->stage_counts.as<unsigned long long>()); }
 		if (ctx->params.filter_enabled[FILTER_low_entropy]) {
-			{ KernelTimer timer(ctx, "select_fragments_kernel(low_entropy)", n * (1 + 4)); select_fragments_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_LOW_ENTROPY_TEST, selected.as<uint32_t>(), counts + 1); }
+			{ KernelTimer timer(ctx, "select_fragments_kernel(low_entropy)", n * (1 + 4)); select_fragments_kernel<<<(unsigned int) ((n + SELECT_BLOCK - 1) / SELECT_BLOCK), SELECT_BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_LOW_ENTROPY_TEST, selected.as<uint32_t>(), counts + 1); }
 			KernelTimer timer(ctx, "low_entropy_kernel", low_entropy_bytes(ctx));
 			low_entropy_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, selected.as<uint32_t>(), counts + 1, ctx->stage_counts.as<unsigned long long>());
 		}

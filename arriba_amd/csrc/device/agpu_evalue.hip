@@ -15,6 +15,7 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
+#include "device_utils.hpp"
 #include "evalue_host.hpp"
 
 using namespace agpu;
@@ -47,8 +48,10 @@ __global__ void partner_insert_kernel(CandidateTable t, const uint32_t* iteratio
 	}
 }
 
-// winners emit (gene << 32 | partner); one atomic per wavefront reserves the output range
-__global__ void partner_resolve_kernel(CandidateTable t, const unsigned long long* slots, uint32_t mask, uint64_t* pairs, uint32_t* pair_count) {
+// winners emit (gene << 32 | partner); one atomic per workgroup reserves the output range
+__global__ void __launch_bounds__(BLOCK) partner_resolve_kernel(CandidateTable t, const unsigned long long* slots, uint32_t mask, uint64_t* pairs, uint32_t* pair_count) {
+	__shared__ uint32_t wave_offset[BLOCK / 64];
+	__shared__ uint32_t block_base;
 	uint32_t handle = blockIdx.x * BLOCK + threadIdx.x;
 	bool winner = false;
 	uint64_t pair = 0;
@@ -65,14 +68,8 @@ __global__ void partner_resolve_kernel(CandidateTable t, const unsigned long lon
 			h = (h + 1) & mask;
 		}
 	}
-	const unsigned long long ballot = __ballot(winner);
-	if (ballot == 0) return;
-	const uint32_t lane = threadIdx.x & 63;
-	const int leader = __ffsll((long long) ballot) - 1;
-	uint32_t base = 0;
-	if ((int) lane == leader) base = atomicAdd(pair_count, (uint32_t) __popcll(ballot));
-	base = __shfl(base, leader);
-	if (winner) pairs[base + __popcll(ballot & ((1ull << lane) - 1))] = pair;
+	const uint32_t at = block_append<BLOCK>(winner ? 1u : 0u, pair_count, wave_offset, &block_base);
+	if (winner) pairs[at] = pair;
 }
 
 __global__ void partner_size_kernel(const uint64_t* sorted_pairs, uint32_t n, int32_t* partner_set_size) {

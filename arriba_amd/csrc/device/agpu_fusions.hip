@@ -18,6 +18,7 @@
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
+#include "device_utils.hpp"
 #include "fusion_core.hpp"
 
 using namespace agpu;
@@ -170,20 +171,25 @@ struct BucketRef { uint32_t candidate, begin, end; };
 
 // one thread per candidate: small buckets are handled inline, large ones are queued for the wave kernel.
 // fill == false: count pass (list sizes), fill == true: write lists / anchors / swap flags
-__global__ void attach_discordant_kernel(AnnotationView ann, CandidateTable t, const uint64_t* bucket_keys, DiscordantBuckets buckets, uint32_t Md,
+__global__ void __launch_bounds__(BLOCK) attach_discordant_kernel(AnnotationView ann, CandidateTable t, const uint64_t* bucket_keys, DiscordantBuckets buckets, uint32_t Md,
                                          int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, BucketRef* worklist, uint32_t* worklist_size, bool fill) {
+	__shared__ uint32_t wave_offset[BLOCK / 64];
+	__shared__ uint32_t block_base;
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c >= t.n) return;
-	if (t.filter[c] != FILTER_none) return;
-	uint32_t flags = t.flags[c];
-	uint64_t key = gene_pair_key(t.gene1[c], t.gene2[c], ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u));
-	uint32_t begin = lower_bound_key(bucket_keys, Md, key), end = lower_bound_key(bucket_keys, Md, key + 1);
-	if (begin == end) return;
-	if (end - begin > SMALL_BUCKET) {
+	uint32_t begin = 0, end = 0;
+	if (c < t.n && t.filter[c] == FILTER_none) {
+		uint32_t flags = t.flags[c];
+		uint64_t key = gene_pair_key(t.gene1[c], t.gene2[c], ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u));
+		begin = lower_bound_key(bucket_keys, Md, key); end = lower_bound_key(bucket_keys, Md, key + 1);
+	}
+	const bool queue = end - begin > SMALL_BUCKET;
+	const uint32_t at = block_append<BLOCK>(queue ? 1u : 0u, worklist_size, wave_offset, &block_base); // one atomic per workgroup
+	if (queue) {
 		BucketRef ref; ref.candidate = c; ref.begin = begin; ref.end = end;
-		worklist[atomicAdd(worklist_size, 1u)] = ref;
+		worklist[at] = ref;
 		return;
 	}
+	if (begin == end) return;
 	bool has_split_reads;
 	uint32_t* out_list = nullptr;
 	if (fill) {

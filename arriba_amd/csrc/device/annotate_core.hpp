@@ -328,7 +328,9 @@ AGPU_HD int32_t breakpoint_of(const BatchView& b, int slot, uint64_t i, uint8_t 
 // Stage 1 of the annotation of one fragment (reference: source/arriba.cpp:160-231):
 // strands from strandedness, exon-based annotation, gene-index fallback, and the list of positions that map to no gene.
 // unmapped_keys receives contig << 32 | position for every alignment end that needs a dummy gene.
-AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& ann, uint32_t strandedness, uint64_t i, uint64_t* unmapped_keys, uint32_t* unmapped_count) {
+// A fragment yields at most two such positions; they are returned in unmapped[0..n_unmapped) and appended to the global list by the caller
+// (one atomic per workgroup on the device, see annotate_stage1_kernel).
+AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& ann, uint32_t strandedness, uint64_t i, uint64_t unmapped[2], uint32_t& n_unmapped) {
 	int n_aln = b.n_aln[i];
 	uint8_t bits[3];
 	IdSet genes[3];
@@ -396,15 +398,16 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 	}
 
 	// reference: positions that need a dummy gene, source/arriba.cpp:207-231
+	n_unmapped = 0;
 	if (n_aln == 3) {
 		if (genes[SPLIT_READ].n == 0)
-			unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[SPLIT_READ][i] << 32 | (uint32_t) breakpoint_of(b, SPLIT_READ, i, bits[SPLIT_READ], true);
+			unmapped[n_unmapped++] = (uint64_t) b.contig[SPLIT_READ][i] << 32 | (uint32_t) breakpoint_of(b, SPLIT_READ, i, bits[SPLIT_READ], true);
 		if (genes[SUPPLEMENTARY].n == 0)
-			unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[SUPPLEMENTARY][i] << 32 | (uint32_t) breakpoint_of(b, SUPPLEMENTARY, i, bits[SUPPLEMENTARY], false);
+			unmapped[n_unmapped++] = (uint64_t) b.contig[SUPPLEMENTARY][i] << 32 | (uint32_t) breakpoint_of(b, SUPPLEMENTARY, i, bits[SUPPLEMENTARY], false);
 	} else {
 		AGPU_UNROLL for (int s = 0; s < 2; ++s)
 			if (genes[s].n == 0)
-				unmapped_keys[atomic_add_u32(unmapped_count, 1)] = (uint64_t) b.contig[s][i] << 32 | (uint32_t) breakpoint_of(b, s, i, bits[s], false);
+				unmapped[n_unmapped++] = (uint64_t) b.contig[s][i] << 32 | (uint32_t) breakpoint_of(b, s, i, bits[s], false);
 	}
 
 	bool ok = true;

@@ -1,0 +1,49 @@
+// arriba_amd/csrc/device/device_utils.hpp -- device-only helpers shared by the kernels.
+#ifndef AGPU_DEVICE_UTILS_HPP
+#define AGPU_DEVICE_UTILS_HPP 1
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace agpu {
+
+// Appends 0..2 items per thread to a global list with ONE atomic per workgroup (a list cursor that every wavefront or thread bumps on its
+// own serialises at the L2: ~10 ns per atomic, i.e. milliseconds per launch at 10^5..10^6 appends).  Ballots give the position inside
+// the wavefront, LDS the position of the wavefront inside the workgroup.  Returns the index of the thread's first item.  Every thread of
+// the workgroup must call it.  wave_offset: LDS, BLOCK_THREADS / 64 words; block_base: LDS, one word.
+template <int BLOCK_THREADS> __device__ __forceinline__ uint32_t block_append(uint32_t mine, uint32_t* cursor, uint32_t* wave_offset, uint32_t* block_base) {
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long one = __ballot(mine >= 1), two = __ballot(mine >= 2), before = (1ull << lane) - 1;
+	if (lane == 0) wave_offset[wave] = (uint32_t) (__popcll(one) + __popcll(two));
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (int w = 0; w < BLOCK_THREADS / 64; ++w) { uint32_t c = wave_offset[w]; wave_offset[w] = total; total += c; }
+		*block_base = total ? atomicAdd(cursor, total) : 0;
+	}
+	__syncthreads();
+	return *block_base + wave_offset[wave] + (uint32_t) (__popcll(one & before) + __popcll(two & before));
+}
+
+// The same for an arbitrary number of items per thread (wave inclusive scan with shuffles).
+template <int BLOCK_THREADS> __device__ __forceinline__ uint32_t block_reserve(uint32_t mine, uint32_t* cursor, uint32_t* wave_offset, uint32_t* block_base) {
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t inclusive = mine;
+	for (int offset = 1; offset < 64; offset <<= 1) {
+		const uint32_t other = __shfl_up(inclusive, offset);
+		if (lane >= (uint32_t) offset) inclusive += other;
+	}
+	if (lane == 63) wave_offset[wave] = inclusive;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (int w = 0; w < BLOCK_THREADS / 64; ++w) { uint32_t c = wave_offset[w]; wave_offset[w] = total; total += c; }
+		*block_base = total ? atomicAdd(cursor, total) : 0;
+	}
+	__syncthreads();
+	return *block_base + wave_offset[wave] + inclusive - mine;
+}
+
+}
+
+#endif

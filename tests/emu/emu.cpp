@@ -183,7 +183,11 @@ int emu_annotate_begin(emu_ctx* ctx, uint64_t* n_unmapped) {
 	uint32_t unmapped_count = 0;
 	bool ok = true;
 	for (uint64_t i = 0; i < b.n; ++i)
-		ok = annotate_fragment_stage1(b, ctx->annotation, ctx->params.strandedness, i, ctx->unmapped.data(), &unmapped_count) && ok;
+	{
+		uint64_t positions[2]; uint32_t n_positions;
+		ok = annotate_fragment_stage1(b, ctx->annotation, ctx->params.strandedness, i, positions, n_positions) && ok;
+		for (uint32_t k = 0; k < n_positions; ++k) ctx->unmapped[unmapped_count++] = positions[k];
+	}
 	if (!ok) { g_error = "a gene set exceeded the device capacity"; return AGPU_ERR_CAPACITY; }
 	ctx->unmapped.resize(unmapped_count);
 	if (n_unmapped) *n_unmapped = unmapped_count;
