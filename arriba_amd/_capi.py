@@ -48,7 +48,8 @@ class BatchView(ctypes.Structure):
 class Params(ctypes.Structure):
     _fields_ = [("homopolymer_length", c_uint32), ("min_read_through_distance", c_uint32), ("max_itd_length", c_uint32), ("subsampling_threshold", c_uint32),
                 ("mismatch_pvalue_cutoff", c_float), ("max_kmer_content", c_float), ("evalue_cutoff", c_float), ("max_mismapper_fraction", c_float),
-                ("fragment_length", c_uint32), ("external_duplicate_marking", c_uint8), ("strandedness", c_uint8), ("filter_enabled", c_uint8 * FILTER_COUNT)]
+                ("fragment_length", c_uint32), ("external_duplicate_marking", c_uint8), ("strandedness", c_uint8), ("filter_enabled", c_uint8 * FILTER_COUNT),
+                ("exonic_fraction", c_float), ("min_support", c_uint32)]
 
 
 def _load(path):
@@ -113,6 +114,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "set_candidate_state": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_void_p]),
         "estimate_expected_fusions": (c_int, [ctx, c_uint64, c_void_p]),
         "get_evalues": (c_int, [ctx, c_void_p]),
+        "filter_candidate_predicates": (c_int, [ctx, c_void_p]),
         "filter_relative_support": (c_int, [ctx, POINTER(c_uint64)]),
         "set_profiling": (c_int, [ctx, c_int]),
         "get_kernel_profile": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),

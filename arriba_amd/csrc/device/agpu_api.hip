@@ -483,7 +483,7 @@ void agpu_default_params(agpu_params* p) { // source/options.cpp:71-107
 	memset(p, 0, sizeof(*p));
 	p->homopolymer_length = 6; p->min_read_through_distance = 10000; p->max_itd_length = 100; p->subsampling_threshold = 300;
 	p->mismatch_pvalue_cutoff = 0.01; p->max_kmer_content = 0.6; p->evalue_cutoff = 0.3; p->max_mismapper_fraction = 0.8;
-	p->fragment_length = 200; p->external_duplicate_marking = 0; p->strandedness = 0;
+	p->fragment_length = 200; p->external_duplicate_marking = 0; p->strandedness = 0; p->exonic_fraction = 0.33; p->min_support = 2;
 	for (int f = 1; f < AGPU_FILTER_COUNT; ++f) p->filter_enabled[f] = 1;
 }
 

@@ -136,6 +136,22 @@ __global__ void relative_support_kernel(AnnotationView ann, CandidateTable t, co
 	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(remaining, (unsigned int) __popcll(ballot));
 }
 
+__global__ void candidate_predicates_kernel(AnnotationView ann, CandidateTable t, const uint8_t* enabled, float exonic_fraction, int32_t min_support, unsigned int* discarded /* [3] */) {
+	__shared__ unsigned int block_discarded[3];
+	if (threadIdx.x < 3) block_discarded[threadIdx.x] = 0;
+	__syncthreads();
+	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n && t.filter[c] == FILTER_none) {
+		const int stage = candidate_predicate_stage(ann, t, c, enabled, exonic_fraction, min_support);
+		if (stage < 3) {
+			t.filter[c] = stage == 0 ? 14 : stage == 1 ? 15 : 17; // non_coding_neighbors, intragenic_exonic, min_support (source/common.hpp:29-67)
+			atomicAdd(&block_discarded[stage], 1u);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 3 && block_discarded[threadIdx.x]) atomicAdd(&discarded[threadIdx.x], block_discarded[threadIdx.x]);
+}
+
 template <class T> int upload_table(DeviceBuffer& buffer, const std::vector<T>& host, hipStream_t stream) {
 	if (!buffer.allocate(host.size() * sizeof(T))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
 	HIP_CHECK(hipMemcpyAsync(buffer.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
@@ -265,5 +281,30 @@ extern "C" int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining) 
 	unsigned int kept = 0;
 	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
 	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_filter_candidate_predicates(agpu_ctx* ctx, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counters = ctx->scratch("evalue.predicate_counters");
+	ALLOC(counters, 8 * 4);
+	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 8 * 4, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0) {
+		// unfiltered candidates before the stage: counted on the device to keep the call self-contained
+		KernelTimer timer(ctx, "candidate_predicates_kernel", (uint64_t) C * 40);
+		candidate_predicates_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, ctx->candidates, ctx->filter_enabled.as<uint8_t>(), ctx->params.exonic_fraction, (int32_t) ctx->params.min_support, counters.as<unsigned int>());
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 40;
+	unsigned int discarded[3] = { 0, 0, 0 };
+	HIP_CHECK(hipMemcpy(discarded, counters.ptr, sizeof(discarded), hipMemcpyDeviceToHost));
+	if (remaining) { remaining[0] = discarded[0]; remaining[1] = discarded[1]; remaining[2] = discarded[2]; } // numbers discarded per stage; the caller knows how many were unfiltered before
 	return AGPU_OK;
 }

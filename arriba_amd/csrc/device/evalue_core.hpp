@@ -119,6 +119,30 @@ AGPU_HD EvalueContribution evalue_contribution(const AnnotationView& ann, const 
 	return r;
 }
 
+// The three candidate predicates main() runs between the e-value and filter_relative_support (source/arriba.cpp:437-455):
+// filter_non_coding_neighbors (source/filter_non_coding_neighbors.cpp:7-19), filter_intragenic_both_exonic
+// (source/filter_intragenic_both_exonic.cpp:9-35) and filter_min_support (source/filter_min_support.cpp:7-19).  Each skips candidates
+// that already have a filter, so for one candidate they are a cascade: returns the stage (0, 1, 2) that discards candidate c, or 3.
+AGPU_HD bool breakpoint_overlaps_both_genes(const AnnotationView& ann, const CandidateTable& t, uint32_t c) { // source/common.hpp:260-264 (coordinates only, as in the reference)
+	const uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
+	return (t.breakpoint1[c] >= ann.gene_start[gene2] && t.breakpoint1[c] <= ann.gene_end[gene2]) || (t.breakpoint2[c] >= ann.gene_start[gene1] && t.breakpoint2[c] <= ann.gene_end[gene1]);
+}
+AGPU_HD int candidate_predicate_stage(const AnnotationView& ann, const CandidateTable& t, uint32_t c, const uint8_t* enabled, float exonic_fraction, int32_t min_support) {
+	const uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c], flags = t.flags[c];
+	if (enabled[14 /* non_coding_neighbors */] && !(ann.gene_bits[gene1] & GBIT_PROTEIN_CODING) && !(ann.gene_bits[gene2] & GBIT_PROTEIN_CODING) &&
+	    candidate_is_read_through(t.contigs[c], t.breakpoint1[c], t.breakpoint2[c], flags))
+		return 0;
+	const bool overlaps = breakpoint_overlaps_both_genes(ann, t, c);
+	if (enabled[15 /* intragenic_exonic */] && (overlaps || gene1 == gene2) && (flags & CFLAG_EXONIC1) && (flags & CFLAG_EXONIC2) && !((flags & CFLAG_SPLICED1) && (flags & CFLAG_SPLICED2))) {
+		const int32_t distance_spliced = spliced_distance(ann, t.contigs[c] >> 16, t.breakpoint1[c], t.breakpoint2[c], gene1);
+		const int32_t distance = t.breakpoint2[c] - t.breakpoint1[c];
+		if (distance_spliced == distance || 1.0 * distance_spliced / distance < (double) exonic_fraction) return 1;
+	}
+	const int32_t split_reads = (int32_t) (t.split_reads1[c] + t.split_reads2[c]);
+	if (enabled[17 /* min_support */] && (split_reads + (int32_t) t.discordant_mates[c] < min_support || (overlaps && split_reads < min_support))) return 2;
+	return 3;
+}
+
 // filter_relative_support (source/filter_relative_support.cpp:209-224): true = discard
 AGPU_HD bool fails_relative_support(const AnnotationView& ann, const CandidateTable& t, uint32_t c, float evalue, float evalue_cutoff) {
 	bool keep = evalue < evalue_cutoff &&

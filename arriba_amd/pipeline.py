@@ -291,6 +291,14 @@ class DevicePipeline(object):
         self._check(self.api.get_evalues(self.ctx, evalue.ctypes.data))
         return evalue[:self.n_candidates]
 
+    def filter_candidate_predicates(self):
+        """reference: filter_non_coding_neighbors, filter_intragenic_both_exonic, filter_min_support (source/arriba.cpp:437-455);
+        returns the number of candidates each of the three discarded"""
+        discarded = np.zeros(3, dtype=np.uint64)
+        self._check(self.api.filter_candidate_predicates(self.ctx, discarded.ctypes.data))
+        self._record("filter_candidate_predicates")
+        return {"non_coding_neighbors": int(discarded[0]), "intragenic_exonic": int(discarded[1]), "min_support": int(discarded[2])}
+
     def filter_relative_support(self):
         remaining = c_uint64()
         self._check(self.api.filter_relative_support(self.ctx, byref(remaining)))

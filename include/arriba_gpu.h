@@ -147,6 +147,8 @@ typedef struct {
 	uint8_t external_duplicate_marking;  /* -u */
 	uint8_t strandedness;                /* 0 no, 1 yes, 2 reverse (already resolved; 3 = auto is a host decision) */
 	uint8_t filter_enabled[AGPU_FILTER_COUNT]; /* -f */
+	float exonic_fraction;               /* -e 0.33 */
+	uint32_t min_support;                /* -S 2 */
 } agpu_params;
 
 void agpu_default_params(agpu_params* params);
@@ -224,6 +226,9 @@ int agpu_candidate_iteration_order(agpu_ctx* ctx, uint32_t* iteration_rank /* [n
  * agpu_candidate_iteration_order. */
 int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_reads, const uint32_t* iteration_rank);
 int agpu_get_evalues(agpu_ctx* ctx, float* evalue /* [n_candidates] */);
+/* The three candidate predicates main() runs between the e-value and filter_relative_support (source/arriba.cpp:437-455):
+ * filter_non_coding_neighbors, filter_intragenic_both_exonic, filter_min_support.  discarded[k] = candidates discarded by stage k. */
+int agpu_filter_candidate_predicates(agpu_ctx* ctx, uint64_t* discarded /* [3] */);
 /* filter_relative_support (source/filter_relative_support.cpp:209-224); *remaining = the reference's "(remaining=N)" */
 int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining);
 

@@ -115,7 +115,7 @@ int emu_device_count(void) { return 1; }
 void emu_default_params(agpu_params* p) {
 	memset(p, 0, sizeof(*p));
 	p->homopolymer_length = 6; p->min_read_through_distance = 10000; p->max_itd_length = 100; p->subsampling_threshold = 300;
-	p->mismatch_pvalue_cutoff = 0.01; p->max_kmer_content = 0.6; p->evalue_cutoff = 0.3; p->max_mismapper_fraction = 0.8; p->fragment_length = 200;
+	p->mismatch_pvalue_cutoff = 0.01; p->max_kmer_content = 0.6; p->evalue_cutoff = 0.3; p->max_mismapper_fraction = 0.8; p->fragment_length = 200; p->exonic_fraction = 0.33; p->min_support = 2;
 	for (int f = 1; f < AGPU_FILTER_COUNT; ++f) p->filter_enabled[f] = 1;
 }
 emu_ctx* emu_create(int, const agpu_params* params) { emu_ctx* ctx = new emu_ctx(); if (params) ctx->params = *params; else emu_default_params(&ctx->params); memset(ctx->stage_counts, 0, sizeof(ctx->stage_counts)); return ctx; }

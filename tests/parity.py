@@ -185,21 +185,23 @@ def check_evalues(session, pipeline, golden):
     bits = evalue.view(np.uint32)
     different = [(c, hex(int(bits[c])), hex(int(expected[c]))) for c in range(n) if bits[c] != expected[c]]
     assert not different, (len(different), different[:10])
-    # filter_relative_support: state before = dump after with `relative_support` undone (the stages in between only set other ids)
+    # the stages main() runs next (source/arriba.cpp:437-460): filter_non_coding_neighbors, filter_intragenic_both_exonic, filter_min_support,
+    # filter_relative_support; the device continues from the state it has (the dump of estimate_expected_fusions)
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    unfiltered = int((state["filter"] == 0).sum())
+    discarded = pipeline.filter_candidate_predicates()
+    for name, pattern in (("non_coding_neighbors", "adjacent non-coding"), ("intragenic_exonic", "intragenic fusions with both breakpoints in exonic"), ("min_support", r"supporting reads")):
+        unfiltered -= discarded[name]
+        match = re.search(r"Filtering[^\n]*%s[^\n]*\(remaining=(\d+)\)" % pattern, log)
+        assert match and unfiltered == int(match.group(1)), (name, unfiltered, match and match.group(1))
+    remaining = pipeline.filter_relative_support()
     after_filter = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_relative_support"))
-    relative_support = 12
-    before = np.zeros(n, dtype=np.uint8)
     expected_filter = np.zeros(n, dtype=np.uint8)
     for f in after_filter:
-        c = index[fusion_key(f)]
-        expected_filter[c] = f["filter"]
-        before[c] = 0 if f["filter"] == relative_support else f["filter"]
-        assert f["evalue_bits"] == expected[c]
-    pipeline.set_candidate_state(filter=before)
-    remaining = pipeline.filter_relative_support()
+        expected_filter[index[fusion_key(f)]] = f["filter"]
+        assert f["evalue_bits"] == expected[index[fusion_key(f)]]
     assert np.array_equal(pipeline.candidates()["filter"], expected_filter)
-    log = open(os.path.join(golden, "reference.log")).read()
-    import re
     match = re.search(r"Filtering fusions with an e-value[^\n]*\(remaining=(\d+)\)", log)
     assert match and remaining == int(match.group(1))
     return n

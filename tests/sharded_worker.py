@@ -32,6 +32,7 @@ def main():
     local_filters = sharded.filters()
     sharded.replicate_candidates()
     evalue = sharded.estimate_expected_fusions()
+    predicates = sharded.filter_candidate_predicates()
     relative_support_remaining = sharded.filter_relative_support()
     candidate_filters = sharded.candidates()["filter"]
     report = {"rank": rank, "first": first, "count": count, "exchange": sharded.exchange, "owned_candidates": sharded.n_owned_candidates}
@@ -56,6 +57,8 @@ def main():
         expected_evalue = whole.estimate_expected_fusions()
         if not np.array_equal(evalue.view(np.uint32), expected_evalue.view(np.uint32)):
             problems.append(("e-values", int((evalue.view(np.uint32) != expected_evalue.view(np.uint32)).sum())))
+        if predicates != whole.filter_candidate_predicates():
+            problems.append(("candidate predicates", predicates))
         if relative_support_remaining != whole.filter_relative_support() or not np.array_equal(candidate_filters, whole.candidates()["filter"]):
             problems.append(("filter_relative_support",))
         report.update({"problems": problems, "candidates": int(whole.n_candidates), "fragments": int(whole.n)})
