@@ -99,7 +99,7 @@ struct agpu_ctx {
 	// find_fusions
 	agpu::DeviceBuffer emissions, discordant_swapped;
 	agpu::DeviceBuffer cand_gene1, cand_gene2, cand_contigs, cand_breakpoint1, cand_breakpoint2, cand_flags, cand_filter, cand_split_reads1, cand_split_reads2, cand_discordant_mates;
-	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists, cand_evalue, cand_iteration_rank, cand_votes, cand_first_occurrence;
+	agpu::DeviceBuffer cand_anchor1, cand_anchor2, cand_list_offset, cand_read_lists, cand_evalue, cand_iteration_rank, cand_votes, cand_first_occurrence, cand_extra_split_list;
 	agpu::DeviceBuffer evalue_support_scale, evalue_intragenic_support, evalue_intergenic_support, evalue_distance_tables;
 	agpu::EvalueGlobals evalue_globals;
 	bool evalue_done = false, iteration_order_done = false;

@@ -253,6 +253,13 @@ class DevicePipeline(object):
         table["read_lists"] = reads[:total.value]
         return table
 
+    def merge_adjacent_fusions(self, max_distance=5):
+        """reference: merge_adjacent_fusions, source/merge_adjacent_fusions.cpp:19-108; returns the number of unfiltered candidates"""
+        remaining = c_uint64()
+        self._check(self.api.merge_adjacent_fusions(self.ctx, max_distance, byref(remaining)))
+        self._record("merge_adjacent_fusions")
+        return remaining.value
+
     def candidate_iteration_order(self):
         """rank of every candidate in the iteration order of the reference's fusions_t (hazard H2), computed on the device"""
         rank = np.zeros(max(self.n_candidates, 1), dtype=np.uint32)

@@ -213,6 +213,12 @@ int agpu_get_fusion_stats(agpu_ctx* ctx, uint64_t* stats /* [5] */);
 /* 1 for every discordant fragment whose MATE1/MATE2 the reference swaps in place while attaching it (source/fusions.cpp:414-421) */
 int agpu_get_discordant_swapped(agpu_ctx* ctx, uint8_t* swapped /* [n] */);
 
+/* merge_adjacent_fusions (source/merge_adjacent_fusions.cpp:19-108, called at source/arriba.cpp:420-423 with max_distance 5):
+ * a candidate absorbs the split reads of the candidates of its gene pair whose breakpoints are shifted by <= max_distance bp along the
+ * same diagonal if it has the most support; the absorbed ones get the filter `merge_adjacent`.  *remaining = "(remaining=N)".
+ * (For internal tandem duplications the reference also appends the read lists of the absorbed candidates; here only their sizes are kept.) */
+int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, uint64_t* remaining);
+
 /* Candidate state as changed by the event-level stages that run on the host between find_fusions and the e-value
  * (merge_adjacent_fusions, filter_multimappers: source/arriba.cpp:420-430).  NULL = leave the column as it is. */
 int agpu_set_candidate_state(agpu_ctx* ctx, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates);

@@ -24,6 +24,10 @@ DATASETS = {
     # shuffled names + separated mates: exercises collation and the name sort (ingest), stranded library
     "shuffled2k": {"args": ["--seed", "5", "--fragments", "2000", "--contigs", "3", "--contig-len", "250000", "--junctions", "40", "--shuffle", "--separate-mates", "--stranded"],
                    "golden_files": ["reads.*_annotated.tsv", "filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},
+    # toy3k with the reference's filter_multimappers switched off: the chain find_fusions -> merge_adjacent_fusions -> e-value -> candidate
+    # predicates -> filter_relative_support can then be compared without taking any intermediate state from the reference
+    "toy3k_chain": {"args": ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"], "reference_disable_filters": ["multimappers"],
+                    "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_merge_adjacent_fusions.tsv", "fusions.*_filter_relative_support.tsv"]},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},

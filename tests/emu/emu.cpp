@@ -18,6 +18,7 @@
 #include "../../arriba_amd/csrc/device/evalue_host.hpp"
 #include "../../arriba_amd/csrc/device/order_host.hpp"
 #include "../../arriba_amd/csrc/device/mismapper_core.hpp"
+#include "../../arriba_amd/csrc/device/merge_core.hpp"
 #include <map>
 #include <set>
 #include <tuple>

@@ -246,3 +246,52 @@ def check_mismappers(session, pipeline, golden):
     match = re.search(r"Re-aligning chimeric reads[^\n]*\(remaining=(\d+)\)", log)
     assert match and remaining == int(match.group(1))
     return discarded
+
+
+def check_merge_adjacent(session, pipeline, golden):
+    """merge_adjacent_fusions on the device state right after find_fusions against the reference's dump of that stage"""
+    import re
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "merge_adjacent_fusions"))
+    remaining = pipeline.merge_adjacent_fusions()
+    table = pipeline.candidates()
+    n = pipeline.n_candidates
+    index = {key: c for c, key in enumerate(candidate_keys(table, n))}
+    problems = []
+    for f in after:
+        c = index[fusion_key(f)]
+        got = (int(table["filter"][c]), int(table["split_reads1"][c]), int(table["split_reads2"][c]), int(table["discordant_mates"][c]))
+        if got != (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"]):
+            problems.append((fusion_key(f), got, (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"])))
+    assert not problems, (len(problems), problems[:10])
+    log = open(os.path.join(golden, "reference.log")).read()
+    match = re.search(r"Merging adjacent fusion breakpoints \(remaining=(\d+)\)", log)
+    assert match and remaining == int(match.group(1)), (remaining, match and match.group(1))
+    return sum(1 for f in after if f["filter"] == 23)
+
+
+def check_chain_to_relative_support(session, pipeline, golden):
+    """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support on the device without any state
+    taken from the reference, against a reference run in which the stages that are not implemented here (filter_multimappers) are switched off"""
+    pipeline.find_fusions()
+    pipeline.merge_adjacent_fusions()
+    evalue = pipeline.estimate_expected_fusions()
+    pipeline.filter_candidate_predicates()
+    remaining = pipeline.filter_relative_support()
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_relative_support"))
+    table = pipeline.candidates()
+    n = pipeline.n_candidates
+    assert len(after) == n
+    index = {key: c for c, key in enumerate(candidate_keys(table, n))}
+    bits = evalue.view(np.uint32)
+    problems = []
+    for f in after:
+        c = index[fusion_key(f)]
+        got = (int(table["filter"][c]), int(table["split_reads1"][c]), int(table["split_reads2"][c]), int(table["discordant_mates"][c]), int(bits[c]))
+        if got != (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"], f["evalue_bits"]):
+            problems.append((fusion_key(f), got, (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"], f["evalue_bits"])))
+    assert not problems, (len(problems), problems[:10])
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    match = re.search(r"Filtering fusions with an e-value[^\n]*\(remaining=(\d+)\)", log)
+    assert match and remaining == int(match.group(1))
+    return n

@@ -30,6 +30,7 @@ def main():
     sharded.find_fusions()
     merged = sharded.gather_candidates()
     local_filters = sharded.filters()
+    merged_remaining = sharded.merge_adjacent_fusions()  # on the owners: a cluster of adjacent breakpoints lives inside one gene pair
     sharded.replicate_candidates()
     evalue = sharded.estimate_expected_fusions()
     predicates = sharded.filter_candidate_predicates()
@@ -54,6 +55,7 @@ def main():
         for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2", "list_offset", "read_lists"):
             if not np.array_equal(np.asarray(merged[key], dtype=np.int64), np.asarray(table[key], dtype=np.int64)):
                 problems.append(("candidates." + key, len(merged[key]), len(table[key])))
+        whole.merge_adjacent_fusions()
         expected_evalue = whole.estimate_expected_fusions()
         if not np.array_equal(evalue.view(np.uint32), expected_evalue.view(np.uint32)):
             problems.append(("e-values", int((evalue.view(np.uint32) != expected_evalue.view(np.uint32)).sum())))

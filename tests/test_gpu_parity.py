@@ -55,6 +55,35 @@ def test_live_reference_on_larger_dataset(built, tmp_path):
     assert parity.check_evalues(session, pipeline, dump) > 10000
 
 
+def test_chain_to_relative_support_without_injected_state(built, dataset_files, tmp_path):
+    """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support on the GPU, nothing taken from the
+    reference in between: against the committed dumps of a reference run without filter_multimappers, and against the reference run live"""
+    golden = conftest.golden_dir("toy3k_chain")
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k_chain"))
+    pipeline.find_fusions()
+    assert parity.check_merge_adjacent(session, pipeline, golden) >= 0
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k_chain"))
+    assert parity.check_chain_to_relative_support(session, pipeline, golden) > 1000
+    if not datasets.reference_available():
+        return
+    spec = {"args": ["--seed", "23", "--fragments", "120000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump, disable_filters=["multimappers"])
+    finally:
+        del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    pipeline.find_fusions()
+    assert parity.check_merge_adjacent(session, pipeline, dump) >= 0
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    assert parity.check_chain_to_relative_support(session, pipeline, dump) > 10000
+
+
 def test_live_reference_mismapper_stress(built, tmp_path):
     """make_kmer_index + filter_mismappers on a dataset whose clipped segments stem from the split read's own gene, with the
     event-level filters in front switched off in the reference so that every candidate's reads are re-aligned."""

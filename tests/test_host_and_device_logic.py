@@ -83,3 +83,13 @@ def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
         header += struct.pack("<i", len(name) + 1) + name + b"\x00" + struct.pack("<i", 150000)
     with pytest.raises(ArribaError, match="no normal reads found"):
         session.read_chimeric_alignments(header)
+
+
+def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
+    """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
+    golden = conftest.golden_dir("toy3k_chain")
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k_chain"), api=emu_api)
+    pipeline.find_fusions()
+    assert parity.check_merge_adjacent(session, pipeline, golden) >= 0
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k_chain"), api=emu_api)
+    assert parity.check_chain_to_relative_support(session, pipeline, golden) > 1000

@@ -31,7 +31,7 @@ def main():
         prefix = datasets.generate(spec, work)
         dump = os.path.join(work, "dump")
         os.makedirs(dump)
-        log = datasets.run_reference(prefix, dump, spec)
+        log = datasets.run_reference(prefix, dump, spec, disable_filters=spec.get("reference_disable_filters", ()))
         target = os.path.join(ROOT, "tests", "golden", name)
         shutil.rmtree(target, ignore_errors=True)
         os.makedirs(target)
