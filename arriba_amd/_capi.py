@@ -112,6 +112,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "filter_mismappers": (c_int, [ctx, c_int32, POINTER(c_uint64), POINTER(c_uint64)]),
         "candidate_iteration_order": (c_int, [ctx, c_void_p]),
         "merge_adjacent_fusions": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
+        "filter_multimappers": (c_int, [ctx, POINTER(c_uint64), POINTER(c_uint64)]),
         "set_candidate_state": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_void_p]),
         "estimate_expected_fusions": (c_int, [ctx, c_uint64, c_void_p]),
         "get_evalues": (c_int, [ctx, c_void_p]),

@@ -1,6 +1,6 @@
 // arriba_amd/csrc/device/agpu_merge.hip -- merge_adjacent_fusions on the device (reference: source/merge_adjacent_fusions.cpp:19-108,
-// called at source/arriba.cpp:420-423).  Two stable radix sorts bring the candidates of one gene pair and direction pair together in
-// the reference's coordinate order; one thread per cluster (merge_core.hpp) runs the reference's sequential sweep.
+// called at source/arriba.cpp:420-423).  Three stable radix sorts bring the candidates of one gene pair, direction pair and diagonal together
+// in the reference's coordinate order; one thread per cluster (merge_core.hpp) runs the reference's sequential sweep.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
@@ -23,21 +23,19 @@ __global__ void merge_coordinate_key_kernel(CandidateTable t, uint64_t* keys) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c < t.n) keys[c] = (uint64_t) (uint32_t) t.breakpoint1[c] << 32 | (uint32_t) t.breakpoint2[c]; // breakpoints are non-negative
 }
-// gene pair + directions of the candidate at sorted position j; candidates that do not take part sort behind all others
-__global__ void merge_group_key_kernel(CandidateTable t, const uint32_t* order, uint32_t max_itd_length, uint64_t* keys) {
+// pass 1: the diagonal, pass 2: gene pair + directions of the candidate at sorted position j
+__global__ void merge_sort_key_kernel(CandidateTable t, const uint32_t* order, int pass, uint32_t max_itd_length, uint64_t* keys) {
 	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
 	if (j >= t.n) return;
 	const uint32_t c = order[j];
-	const uint32_t flags = t.flags[c];
-	keys[j] = takes_part_in_merge(t, c, max_itd_length) ? (uint64_t) t.gene1[c] << 33 | (uint64_t) t.gene2[c] << 2 | ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u) : ~0ull;
+	keys[j] = pass == 1 ? merge_diagonal_key(t, c) : merge_group_key(t, c, max_itd_length);
 }
 __global__ void merge_cluster_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, int32_t max_distance, uint32_t max_itd_length, uint32_t* extra_split_list) {
 	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
 	if (j >= t.n || group_keys[j] == ~0ull) return;
-	// a cluster starts where the group changes or the chain of first breakpoints breaks
-	if (j > 0 && group_keys[j - 1] == group_keys[j] && t.breakpoint1[order[j]] - t.breakpoint1[order[j - 1]] <= max_distance) return;
+	if (j > 0 && merge_cluster_continues(t, order, j, max_distance, max_itd_length)) return; // not the first of its cluster
 	uint32_t end = j + 1;
-	while (end < t.n && group_keys[end] == group_keys[j] && t.breakpoint1[order[end]] - t.breakpoint1[order[end - 1]] <= max_distance) ++end;
+	while (end < t.n && merge_cluster_continues(t, order, end, max_distance, max_itd_length)) ++end;
 	if (end - j > 1) merge_cluster(t, order, j, end, max_distance, max_itd_length, extra_split_list);
 }
 __global__ void count_unfiltered_kernel(CandidateTable t, unsigned int* remaining) {
@@ -68,13 +66,18 @@ extern "C" int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, 
 		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
 		{ KernelTimer timer(ctx, "rocprim::radix_sort_pairs(merge: coordinates)", (uint64_t) C * 24);
 		  HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), order_a.as<uint32_t>(), C, 0, 64, s)); }
-		{ KernelTimer timer(ctx, "merge_group_key_kernel", (uint64_t) C * 30); merge_group_key_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, order_a.as<uint32_t>(), ctx->params.max_itd_length, keys_in.as<uint64_t>()); }
-		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
-		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
-		{ KernelTimer timer(ctx, "rocprim::radix_sort_pairs(merge: gene pairs)", (uint64_t) C * 24); // stable: the coordinate order survives inside a gene pair
-		  HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s)); }
+		uint32_t* order = order_a.as<uint32_t>(); uint32_t* next = order_b.as<uint32_t>();
+		for (int pass = 1; pass <= 2; ++pass) { // stable: the coordinate order survives inside a diagonal, the diagonal order inside a gene pair
+			const int end_bit = pass == 1 ? MERGE_DIAGONAL_KEY_BITS : 64;
+			{ KernelTimer timer(ctx, "merge_sort_key_kernel", (uint64_t) C * 30); merge_sort_key_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, order, pass, ctx->params.max_itd_length, keys_in.as<uint64_t>()); }
+			HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order, next, C, 0, end_bit, s));
+			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+			{ KernelTimer timer(ctx, pass == 1 ? "rocprim::radix_sort_pairs(merge: diagonals)" : "rocprim::radix_sort_pairs(merge: gene pairs)", (uint64_t) C * 24);
+			  HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order, next, C, 0, end_bit, s)); }
+			std::swap(order, next);
+		}
 		{ KernelTimer timer(ctx, "merge_cluster_kernel", (uint64_t) C * 40);
-		  merge_cluster_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), max_distance, ctx->params.max_itd_length, ctx->cand_extra_split_list.as<uint32_t>()); }
+		  merge_cluster_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, order, keys_out.as<uint64_t>(), max_distance, ctx->params.max_itd_length, ctx->cand_extra_split_list.as<uint32_t>()); }
 	}
 	if (C > 0) count_unfiltered_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->candidates, counter.as<unsigned int>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));

@@ -3,9 +3,12 @@
 // The reference sorts the unfiltered candidates by coordinate and sweeps them sequentially: a candidate absorbs the split reads of the
 // candidates of the same gene pair and directions whose breakpoints are shifted by at most 5 bp along the same diagonal, if it has the
 // most support; the absorbed ones get the filter `merge_adjacent`.  The sweep mutates the counters it later compares, so its order matters
-// -- but only inside a CLUSTER: candidates of one gene pair and direction pair whose first breakpoints form a chain with gaps <= 5 bp.
-// Clusters are independent, so the device sorts the candidates by (gene pair, directions, breakpoint1, breakpoint2), cuts the clusters and
-// lets one thread run the reference's sweep over each cluster.
+// -- but only inside a CLUSTER: candidates of one gene pair and direction pair ON ONE DIAGONAL (breakpoint1 + breakpoint2 constant when the
+// directions are equal, breakpoint2 - breakpoint1 constant otherwise) whose first breakpoints form a chain with gaps <= 5 bp.  Only
+// internal tandem duplications are merged across diagonals, so the groups that can hold them (gene1 == gene2, upstream/downstream) keep
+// all their diagonals in one cluster.  Clusters are independent and almost always tiny (a dense hot spot of 20 000 candidates within a
+// few hundred bp falls apart into diagonals of at most ~100), so the device sorts the candidates by (gene pair + directions, diagonal,
+// breakpoint1, breakpoint2), cuts the clusters and lets one thread run the reference's sweep over each cluster.
 #ifndef AGPU_MERGE_CORE_HPP
 #define AGPU_MERGE_CORE_HPP 1
 
@@ -26,6 +29,26 @@ AGPU_HD uint32_t merge_supporting_reads(const CandidateTable& t, uint32_t c) { r
 // size of split_read1_list + split_read2_list; extra_split_list = entries appended by earlier ITD merges (sizes only)
 AGPU_HD uint32_t merge_split_list_size(const CandidateTable& t, const uint32_t* extra_split_list, uint32_t c) {
 	return t.list_offset[3 * (uint64_t) c + 2] - t.list_offset[3 * (uint64_t) c] + extra_split_list[c];
+}
+
+// sort keys: candidates that do not take part sort behind all others
+AGPU_HD uint64_t merge_group_key(const CandidateTable& t, uint32_t c, uint32_t max_itd_length) {
+	const uint32_t flags = t.flags[c];
+	return takes_part_in_merge(t, c, max_itd_length) ? (uint64_t) t.gene1[c] << 33 | (uint64_t) t.gene2[c] << 2 | ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u) : ~0ull;
+}
+const int MERGE_DIAGONAL_KEY_BITS = 34;
+AGPU_HD uint64_t merge_diagonal_key(const CandidateTable& t, uint32_t c) {
+	const uint32_t flags = t.flags[c];
+	const bool upstream1 = (flags & CFLAG_UPSTREAM1) != 0, upstream2 = (flags & CFLAG_UPSTREAM2) != 0;
+	if (t.gene1[c] == t.gene2[c] && upstream1 && !upstream2) return 0; // this group may hold internal tandem duplications: one cluster for all diagonals
+	const int64_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
+	return 1 + (uint64_t) (upstream1 == upstream2 ? breakpoint1 + breakpoint2 : breakpoint2 - breakpoint1 + (int64_t(1) << 31));
+}
+// do the candidates at the sorted positions j-1 and j belong to one cluster?
+AGPU_HD bool merge_cluster_continues(const CandidateTable& t, const uint32_t* order, uint32_t j, int32_t max_distance, uint32_t max_itd_length) {
+	const uint32_t previous = order[j - 1], current = order[j];
+	return merge_group_key(t, previous, max_itd_length) == merge_group_key(t, current, max_itd_length) && merge_diagonal_key(t, previous) == merge_diagonal_key(t, current) &&
+	       t.breakpoint1[current] - t.breakpoint1[previous] <= max_distance;
 }
 
 // The reference's sweep over the cluster order[begin .. end) (ascending breakpoint1, then breakpoint2).

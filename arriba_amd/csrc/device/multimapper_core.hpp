@@ -1,0 +1,120 @@
+// arriba_amd/csrc/device/multimapper_core.hpp -- filter_multimappers (reference: source/filter_multimappers.cpp:17-221).
+//
+// The reference (1) finds for every read the candidate with the most support among the candidates that list the read, under the strict
+// total order fusion_has_more_support (:79-107), (2) keeps, in every group of alignments of one read name, the alignment with the highest
+// score (ties: the one whose best candidate has more support, then the first), and gives the others the filter `multimappers`,
+// (3) lowers the counters of the candidates accordingly.  A strict total order makes (1) a minimum over ranks: the device ranks the
+// candidates once with stable radix sorts and takes an atomicMin per list entry of a multi-mapping read.
+#ifndef AGPU_MULTIMAPPER_CORE_HPP
+#define AGPU_MULTIMAPPER_CORE_HPP 1
+
+#include "filter_core.hpp"
+#include "fusion_core.hpp"
+
+namespace agpu {
+
+const uint32_t NO_FUSION = 0xFFFFFFFFu; // the read is in no candidate's list (most_supported_fusion == NULL)
+
+// reference: is_gap_at_splice_site (:17-22)
+AGPU_HD bool gap_at_splice_site(const AnnotationView& ann, int32_t position, bool upstream, const IdSet& genes) {
+	for (uint32_t g = 0; g < genes.n; ++g)
+		if (is_breakpoint_spliced(ann, genes.get(g), upstream, position)) return true;
+	return false;
+}
+
+// reference: calculate_segment_score (:24-67): matches minus gaps of alignment `slot`, `sequence` = the read it belongs to
+AGPU_HD int32_t segment_score(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, uint64_t i, int slot, const SequenceRef& sequence) {
+	const uint32_t contig = b.contig[slot][i];
+	const uint64_t contig_begin = genome.contig_offset[contig], contig_size = genome.contig_offset[contig + 1] - contig_begin;
+	if (contig_size == 0) return 0; // no sequence loaded for this contig
+	IdSet genes; load_genes(b, slot, i, genes);
+	const uint32_t* cigar = cigar_of(b, slot, i); const uint32_t n = b.cigar_count[slot][i];
+	int32_t score = 0;
+	int64_t reference_position = b.start[slot][i];
+	uint32_t read_position = 0;
+	for (uint32_t c = 0; c < n; ++c) {
+		const uint32_t op = cigar[c] & 15, length = cigar[c] >> 4;
+		switch (op) {
+			case CIGAR_S: case CIGAR_H: read_position += length; break;
+			case CIGAR_D: score--; reference_position += length; break;
+			case CIGAR_N:
+				if (!gap_at_splice_site(ann, (int32_t) reference_position, false, genes) || !gap_at_splice_site(ann, (int32_t) (reference_position + length), true, genes))
+					score--; // reference skips are penalised except at splice sites
+				reference_position += length;
+				break;
+			case CIGAR_I: score--; read_position += length; break;
+			case CIGAR_EQ: score += (int32_t) length; reference_position += length; read_position += length; break;
+			case CIGAR_X: reference_position += length; read_position += length; break;
+			case CIGAR_M:
+				for (uint32_t k = 0; k < length; ++k) {
+					const char base = read_position < sequence.length ? sequence.at(read_position) : '\\0';
+					const char reference_base = (reference_position >= 0 && (uint64_t) reference_position < contig_size) ? genome.bases[contig_begin + (uint64_t) reference_position] : '\\0';
+					if (base == reference_base) score++;
+					reference_position++; read_position++;
+				}
+				break;
+			default: break;
+		}
+	}
+	return score;
+}
+
+// reference: calculate_alignment_score (:69-77)
+AGPU_HD int32_t alignment_score(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, uint64_t i) {
+	const SequenceRef sequence1 = sequence_of(b, MATE1, i, no_stage()), sequence2 = sequence_of(b, MATE2, i, no_stage());
+	int32_t score = segment_score(b, ann, genome, i, MATE1, sequence1) + segment_score(b, ann, genome, i, MATE2, sequence2);
+	if (b.n_aln[i] == 3) {
+		SequenceRef split_sequence = sequence2; // SPLIT_READ == slot 1
+		const bool supplementary_forward = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND, split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND;
+		split_sequence.reverse_complement = supplementary_forward != split_forward;
+		score += segment_score(b, ann, genome, i, SUPPLEMENTARY, split_sequence);
+		IdSet genes;
+		load_genes(b, SUPPLEMENTARY, i, genes);
+		const bool supplementary_spliced = gap_at_splice_site(ann, supplementary_forward ? b.end[SUPPLEMENTARY][i] : b.start[SUPPLEMENTARY][i], !supplementary_forward, genes);
+		load_genes(b, SPLIT_READ, i, genes);
+		const bool split_spliced = gap_at_splice_site(ann, split_forward ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i], split_forward, genes);
+		if (!supplementary_spliced || !split_spliced) score--; // the read is not split at a splice site
+	}
+	return score;
+}
+
+// reference: the cluster loop of filter_multimappers (:141-186) for the group of alignments that starts at fragment `first`.
+// best_rank[i] = rank (0 = most support) of the best candidate of fragment i or NO_FUSION.  Returns the number of fragments discarded.
+AGPU_HD uint32_t resolve_multimapper_group(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const uint32_t* best_rank, uint64_t first) {
+	const uint32_t group = b.group[first];
+	uint64_t end = first + 1;
+	while (end < b.n && b.group[end] == group) ++end;
+	if (end - first < 2) return 0; // uniquely mapping read
+	uint64_t best = first;
+	int32_t best_score = 0;
+	bool have_best = false;
+	for (uint64_t i = first; i < end; ++i) {
+		const int32_t score = alignment_score(b, ann, genome, i);
+		if (!have_best || best_score < score) { best = i; best_score = score; have_best = true; }
+		else if (best_score == score && best_rank[i] != NO_FUSION && (best_rank[best] == NO_FUSION || best_rank[i] < best_rank[best])) best = i; // fusion_has_more_support
+	}
+	uint32_t discarded = 0;
+	for (uint64_t i = first; i < end; ++i)
+		if (i != best && b.filter[i] == FILTER_none) { b.filter[i] = FILTER_multimappers; ++discarded; }
+	return discarded;
+}
+
+// reference: :188-211 for candidate c: counters lose the reads that became multi-mappers; returns true if the candidate stays unfiltered
+AGPU_HD bool recount_after_multimappers(const BatchView& b, const CandidateTable& t, uint32_t c) {
+	if (t.filter[c] != FILTER_none) return false;
+	if (t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c] == 0) return true;
+	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	uint32_t* counters[3] = { t.split_reads1 + c, t.split_reads2 + c, t.discordant_mates + c };
+	for (int list = 0; list < 3; ++list) {
+		uint32_t count = *counters[list];
+		for (uint32_t k = offsets[list]; k < offsets[list + 1]; ++k)
+			if (b.filter[t.read_lists[k]] == FILTER_multimappers && count > 0) count--;
+		*counters[list] = count;
+	}
+	if (t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c] == 0) { t.filter[c] = FILTER_multimappers; return false; }
+	return true;
+}
+
+}
+
+#endif

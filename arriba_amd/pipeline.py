@@ -260,6 +260,13 @@ class DevicePipeline(object):
         self._record("merge_adjacent_fusions")
         return remaining.value
 
+    def filter_multimappers(self):
+        """reference: filter_multimappers, source/filter_multimappers.cpp:109-221; returns (remaining candidates, fragments discarded)"""
+        remaining, discarded = c_uint64(), c_uint64()
+        self._check(self.api.filter_multimappers(self.ctx, byref(remaining), byref(discarded)))
+        self._record("filter_multimappers")
+        return remaining.value, discarded.value
+
     def candidate_iteration_order(self):
         """rank of every candidate in the iteration order of the reference's fusions_t (hazard H2), computed on the device"""
         rank = np.zeros(max(self.n_candidates, 1), dtype=np.uint32)

@@ -219,6 +219,12 @@ int agpu_get_discordant_swapped(agpu_ctx* ctx, uint8_t* swapped /* [n] */);
  * (For internal tandem duplications the reference also appends the read lists of the absorbed candidates; here only their sizes are kept.) */
 int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, uint64_t* remaining);
 
+/* filter_multimappers (source/filter_multimappers.cpp:109-221, called at source/arriba.cpp:426-429): of the alignments of one read name the
+ * one with the highest alignment score stays (ties: the one whose best candidate has more support), the others get the filter id
+ * `multimappers`; candidates lose those reads from their counters and are discarded when none is left.
+ * *remaining = "(remaining=N)", *discarded_reads = fragments newly filtered. */
+int agpu_filter_multimappers(agpu_ctx* ctx, uint64_t* remaining, uint64_t* discarded_reads);
+
 /* Candidate state as changed by the event-level stages that run on the host between find_fusions and the e-value
  * (merge_adjacent_fusions, filter_multimappers: source/arriba.cpp:420-430).  NULL = leave the column as it is. */
 int agpu_set_candidate_state(agpu_ctx* ctx, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates);

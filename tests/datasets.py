@@ -14,7 +14,7 @@ ARRIBA_REF = os.path.join(ROOT, "oracle", "_ref", "arriba_ref")
 ARRIBA_REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "arriba_ref_dump")
 
 DEFAULT_GOLDEN_FILES = ["reads.*_annotated.tsv", "filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv", "fusions.*_find_fusions.tsv",
-                        "fusions.*_estimate_expected_fusions.tsv", "fusions.*_filter_relative_support.tsv", "fusions.*_before_filter_mismappers.tsv",
+                        "fusions.*_merge_adjacent_fusions.tsv", "fusions.*_filter_multimappers.tsv", "filters.*_filter_multimappers.tsv", "fusions.*_estimate_expected_fusions.tsv", "fusions.*_filter_relative_support.tsv", "fusions.*_before_filter_mismappers.tsv",
                         "fusions.*_filter_mismappers.tsv", "filters.*_before_filter_mismappers.tsv", "filters.*_filter_mismappers.tsv",
                         "reads.*_after_find_fusions.tsv"]
 

@@ -19,6 +19,7 @@
 #include "../../arriba_amd/csrc/device/order_host.hpp"
 #include "../../arriba_amd/csrc/device/mismapper_core.hpp"
 #include "../../arriba_amd/csrc/device/merge_core.hpp"
+#include "../../arriba_amd/csrc/device/multimapper_core.hpp"
 #include <map>
 #include <set>
 #include <tuple>

@@ -269,11 +269,45 @@ def check_merge_adjacent(session, pipeline, golden):
     return sum(1 for f in after if f["filter"] == 23)
 
 
-def check_chain_to_relative_support(session, pipeline, golden):
-    """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support on the device without any state
-    taken from the reference, against a reference run in which the stages that are not implemented here (filter_multimappers) are switched off"""
+def check_multimappers(session, pipeline, golden):
+    """find_fusions -> merge_adjacent_fusions -> filter_multimappers against the reference's dumps right after filter_multimappers
+    (candidate counters and filters, and the filter id of every fragment)"""
+    import re
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_multimappers"))
+    names, read_filters_after = golden_io.read_filters(golden_io.find_dump(golden, "filters", "filter_multimappers"))
+    assert session.fragment_names() == names
+    pipeline.find_fusions()
+    before = pipeline.filters().copy()
+    pipeline.merge_adjacent_fusions()
+    remaining, discarded = pipeline.filter_multimappers()
+    mine = pipeline.filters()
+    different = [(names[i], int(mine[i]), read_filters_after[i]) for i in range(len(names)) if mine[i] != read_filters_after[i]]
+    assert not different, (len(different), different[:10])
+    assert discarded == int((mine != before).sum())
+    table = pipeline.candidates()
+    n = pipeline.n_candidates
+    assert len(after) == n
+    index = {key: c for c, key in enumerate(candidate_keys(table, n))}
+    problems = []
+    for f in after:
+        c = index[fusion_key(f)]
+        got = (int(table["filter"][c]), int(table["split_reads1"][c]), int(table["split_reads2"][c]), int(table["discordant_mates"][c]))
+        if got != (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"]):
+            problems.append((fusion_key(f), got, (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"])))
+    assert not problems, (len(problems), problems[:10])
+    log = open(os.path.join(golden, "reference.log")).read()
+    match = re.search(r"Filtering multi-mapping[^\n]*\(remaining=(\d+)\)", log)
+    assert match and remaining == int(match.group(1)), (remaining, match and match.group(1))
+    return discarded
+
+
+def check_chain_to_relative_support(session, pipeline, golden, multimappers=False):
+    """find_fusions -> merge_adjacent_fusions -> [filter_multimappers] -> e-value -> candidate predicates -> filter_relative_support on the
+    device without any state taken from the reference.  multimappers=False: against a reference run with filter_multimappers switched off."""
     pipeline.find_fusions()
     pipeline.merge_adjacent_fusions()
+    if multimappers:
+        pipeline.filter_multimappers()
     evalue = pipeline.estimate_expected_fusions()
     pipeline.filter_candidate_predicates()
     remaining = pipeline.filter_relative_support()

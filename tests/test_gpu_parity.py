@@ -64,6 +64,11 @@ def test_chain_to_relative_support_without_injected_state(built, dataset_files, 
     assert parity.check_merge_adjacent(session, pipeline, golden) >= 0
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k_chain"))
     assert parity.check_chain_to_relative_support(session, pipeline, golden) > 1000
+    golden = conftest.golden_dir("toy3k")  # default filters: filter_multimappers in the chain
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"))
+    assert parity.check_multimappers(session, pipeline, golden) > 50
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"))
+    assert parity.check_chain_to_relative_support(session, pipeline, golden, multimappers=True) > 1000
     if not datasets.reference_available():
         return
     spec = {"args": ["--seed", "23", "--fragments", "120000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15"]}
@@ -82,6 +87,20 @@ def test_chain_to_relative_support_without_injected_state(built, dataset_files, 
     assert parity.check_merge_adjacent(session, pipeline, dump) >= 0
     session, pipeline = parity.run_read_level(parity.open_session, prefix)
     assert parity.check_chain_to_relative_support(session, pipeline, dump) > 10000
+    # the same sample with the reference's default filters
+    dump = str(tmp_path / "dump_default")
+    os.makedirs(dump)
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump)
+    finally:
+        del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    assert parity.check_multimappers(session, pipeline, dump) > 100
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    assert parity.check_chain_to_relative_support(session, pipeline, dump, multimappers=True) > 10000
 
 
 def test_live_reference_mismapper_stress(built, tmp_path):

@@ -93,3 +93,9 @@ def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api
     assert parity.check_merge_adjacent(session, pipeline, golden) >= 0
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k_chain"), api=emu_api)
     assert parity.check_chain_to_relative_support(session, pipeline, golden) > 1000
+    # with the default filters: filter_multimappers in the chain
+    golden = conftest.golden_dir("toy3k")
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
+    assert parity.check_multimappers(session, pipeline, golden) > 50
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
+    assert parity.check_chain_to_relative_support(session, pipeline, golden, multimappers=True) > 1000

@@ -37,6 +37,8 @@ def main():
     pipeline.run_read_level()
     pipeline.set_profiling(True)
     pipeline.find_fusions()
+    remaining_after_merge = pipeline.merge_adjacent_fusions()
+    remaining_after_multimappers, multimapper_reads = pipeline.filter_multimappers()
     pipeline.estimate_expected_fusions()
     remaining_after_evalue = pipeline.filter_relative_support()
     positions = pipeline.make_kmer_index()
@@ -44,7 +46,7 @@ def main():
     kernels = {}
     for kernel, ms, size in pipeline.kernel_profile():
         kernels[kernel] = round(kernels.get(kernel, 0.0) + ms, 3)
-    results["candidate_stages"] = {"kernels": kernels, "candidates": pipeline.n_candidates, "remaining_after_relative_support": remaining_after_evalue, "kmer_positions": positions,
+    results["candidate_stages"] = {"kernels": kernels, "candidates": pipeline.n_candidates, "remaining_after_merge_adjacent": remaining_after_merge, "remaining_after_multimappers": remaining_after_multimappers, "reads_discarded_as_multimappers": multimapper_reads, "remaining_after_relative_support": remaining_after_evalue, "kmer_positions": positions,
                                    "remaining_after_mismappers": remaining, "reads_discarded_as_mismappers": discarded, "stage_ms": {k: round(v["ms"], 3) for k, v in pipeline.timings.items()}}
     print(json.dumps({"fragments": session.fragment_count, "results": results}))
 
