@@ -113,6 +113,13 @@ def bind_device_api(lib, prefix="agpu_"):
         "candidate_iteration_order": (c_int, [ctx, c_void_p]),
         "merge_adjacent_fusions": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
         "filter_multimappers": (c_int, [ctx, POINTER(c_uint64), POINTER(c_uint64)]),
+        "set_owned_candidates": (c_int, [ctx, c_void_p, c_uint64]),
+        "copy_multimapper_flags": (c_int, [ctx, c_void_p]),
+        "multimappers_begin": (c_int, [ctx, c_void_p, POINTER(c_uint64)]),
+        "multimappers_partial_best": (c_int, [ctx, c_void_p]),
+        "multimappers_resolve": (c_int, [ctx, c_void_p, c_void_p, POINTER(c_uint64)]),
+        "multimappers_recount": (c_int, [ctx, c_void_p, c_void_p]),
+        "multimappers_finish": (c_int, [ctx, c_void_p, POINTER(c_uint64)]),
         "set_candidate_state": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_void_p]),
         "estimate_expected_fusions": (c_int, [ctx, c_uint64, c_void_p]),
         "get_evalues": (c_int, [ctx, c_void_p]),

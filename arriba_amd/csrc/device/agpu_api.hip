@@ -19,6 +19,7 @@
 #include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
 #include "device_utils.hpp"
+#include "index_bins.hpp"
 
 using namespace agpu;
 
@@ -42,19 +43,16 @@ inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1
 // ---- kernels ------------------------------------------------------------------------------------
 
 __global__ void mark_multimappers_kernel(BatchView b, uint32_t* counters) {
-	__shared__ unsigned int marked;
-	if (threadIdx.x == 0) marked = 0;
-	__syncthreads();
-	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i < b.n) {
+	__shared__ uint32_t marked;
+	uint32_t mine = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; i < b.n; i += gridDim.x * (uint64_t) BLOCK) {
 		uint32_t group = b.group[i];
 		bool same_as_previous = i > 0 && b.group[i - 1] == group;
 		bool same_as_next = i + 1 < b.n && b.group[i + 1] == group;
 		if (same_as_previous || same_as_next) b.fbits[i] |= FBIT_MULTIMAPPER;
-		if (same_as_next) atomicAdd(&marked, 1u);
+		if (same_as_next) ++mine;
 	}
-	__syncthreads();
-	if (threadIdx.x == 0 && marked) atomicAdd(&counters[COUNTER_MARKED], marked);
+	block_tally(mine, &counters[COUNTER_MARKED], &marked);
 }
 
 __global__ void __launch_bounds__(BLOCK) annotate_stage1_kernel(BatchView b, AnnotationView ann, uint32_t strandedness, uint64_t* unmapped_keys, uint32_t* counters) {
@@ -197,8 +195,8 @@ __global__ void stage1_kernel(BatchView b, GenomeView genome, FilterTables t, co
 	__shared__ unsigned int hits[5];
 	if (threadIdx.x < 5) hits[threadIdx.x] = 0;
 	__syncthreads();
-	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i < b.n) {
+	// capped grid with a grid-stride loop: the five counters of a workgroup are flushed once (one cache line of counters takes ~10 ns per atomic)
+	for (uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; i < b.n; i += gridDim.x * (uint64_t) BLOCK) {
 		uint8_t filter = b.filter[i];
 		if (filter == FILTER_none && enabled[FILTER_duplicates]) {
 			if (t.external_duplicate_marking) {
@@ -306,8 +304,8 @@ __global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationVi
 	__shared__ unsigned int hits[10];
 	if (threadIdx.x < 10) hits[threadIdx.x] = 0;
 	__syncthreads();
-	uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (k < *n_selected) {
+	const uint64_t n = *n_selected;
+	for (uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; k < n; k += gridDim.x * (uint64_t) BLOCK) {
 		const uint64_t i = selected[k];
 		uint32_t first_hit;
 		uint8_t before = b.filter[i];
@@ -321,17 +319,21 @@ __global__ void __launch_bounds__(BLOCK) stage2_kernel(BatchView b, AnnotationVi
 
 // low_entropy: the 3-mer counters of a thread are bit-sliced registers (filter_core.hpp), no LDS; one thread per fragment that needs the test
 __global__ void __launch_bounds__(BLOCK) low_entropy_kernel(BatchView b, FilterTables t, const uint32_t* selected, const uint32_t* n_selected, unsigned long long* stage_counts) {
-	uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	bool hit = false;
-	if (k < *n_selected) {
+	__shared__ unsigned int hits;
+	if (threadIdx.x == 0) hits = 0;
+	__syncthreads();
+	const uint64_t n = *n_selected;
+	uint32_t mine = 0;
+	for (uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; k < n; k += gridDim.x * (uint64_t) BLOCK) {
 		const uint64_t i = selected[k];
 		if (has_low_entropy(b, t, i, no_stage())) {
-			hit = b.filter[i] == FILTER_none;
+			if (b.filter[i] == FILTER_none) ++mine;
 			b.filter[i] = FILTER_low_entropy;
 		}
 	}
-	unsigned long long ballot = __ballot(hit);
-	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(&stage_counts[13], (unsigned long long) __popcll(ballot));
+	if (mine) atomicAdd(&hits, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && hits) atomicAdd(&stage_counts[13], (unsigned long long) hits);
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------
@@ -343,7 +345,13 @@ template <class T> int upload(DeviceBuffer& buffer, const T* host, size_t count,
 }
 #define TRY(call) do { int s_ = (call); if (s_ != AGPU_OK) return s_; } while (0)
 
-int upload_index(const agpu_flat_index& in, DeviceBuffer& contig_offset, DeviceBuffer& keys, DeviceBuffer& member_offset, DeviceBuffer& members, FlatIndexView& out, hipStream_t stream) {
+int upload_index(const agpu_flat_index& in, DeviceBuffer& contig_offset, DeviceBuffer& keys, DeviceBuffer& member_offset, DeviceBuffer& members, DeviceBuffer& bin_offset, DeviceBuffer& bins, FlatIndexView& out, hipStream_t stream) {
+	std::vector<uint32_t> host_bin_offset, host_bins;
+	build_index_bins(in.n_contigs, in.contig_offset, in.keys, host_bin_offset, host_bins);
+	TRY(upload(bin_offset, host_bin_offset.data(), host_bin_offset.size(), stream));
+	TRY(upload(bins, host_bins.data(), host_bins.size(), stream));
+	HIP_CHECK(hipStreamSynchronize(stream)); // the host vectors go out of scope
+	out.bin_offset = bin_offset.as<uint32_t>(); out.bins = bins.as<uint32_t>(); out.bin_shift = INDEX_BIN_SHIFT;
 	TRY(upload(contig_offset, in.contig_offset, (size_t) in.n_contigs + 1, stream));
 	TRY(upload(keys, in.keys, in.n_keys, stream));
 	TRY(upload(member_offset, in.member_offset, (size_t) in.n_keys + 1, stream));
@@ -533,8 +541,8 @@ int agpu_upload_annotation(agpu_ctx* ctx, const agpu_annotation_view* in) {
 	TRY(upload(ctx->exon_start, in->exon_start, in->n_exons, s)); TRY(upload(ctx->exon_end, in->exon_end, in->n_exons, s)); TRY(upload(ctx->exon_gene, in->exon_gene, in->n_exons, s));
 	TRY(upload(ctx->exon_previous, in->exon_previous, in->n_exons, s)); TRY(upload(ctx->exon_next, in->exon_next, in->n_exons, s));
 	TRY(upload(ctx->exon_cds_start, in->exon_cds_start, in->n_exons, s)); TRY(upload(ctx->exon_cds_end, in->exon_cds_end, in->n_exons, s));
-	TRY(upload_index(in->exon_index, ctx->exon_index_contig_offset, ctx->exon_index_keys, ctx->exon_index_member_offset, ctx->exon_index_members, ctx->annotation.exon_index, s));
-	TRY(upload_index(in->gene_index, ctx->gene_index_contig_offset, ctx->gene_index_keys, ctx->gene_index_member_offset, ctx->gene_index_members, ctx->annotation.gene_index, s));
+	TRY(upload_index(in->exon_index, ctx->exon_index_contig_offset, ctx->exon_index_keys, ctx->exon_index_member_offset, ctx->exon_index_members, ctx->exon_index_bin_offset, ctx->exon_index_bins, ctx->annotation.exon_index, s));
+	TRY(upload_index(in->gene_index, ctx->gene_index_contig_offset, ctx->gene_index_keys, ctx->gene_index_member_offset, ctx->gene_index_members, ctx->gene_index_bin_offset, ctx->gene_index_bins, ctx->annotation.gene_index, s));
 	refresh_annotation_view(ctx);
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->have_annotation = true; ctx->annotated = false; ctx->have_splice_sites = false;
@@ -647,7 +655,7 @@ int agpu_mark_multimappers(agpu_ctx* ctx, uint64_t* marked) {
 	if (!ctx || !ctx->have_batch) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	begin_timing(ctx);
-	if (ctx->n > 0) { KernelTimer timer(ctx, "mark_multimappers_kernel", ctx->n * (4 + 1 + 1)); mark_multimappers_kernel<<<grid_for(ctx->n), BLOCK, 0, ctx->stream>>>(ctx->batch, ctx->counters.as<uint32_t>()); }
+	if (ctx->n > 0) { KernelTimer timer(ctx, "mark_multimappers_kernel", ctx->n * (4 + 1 + 1)); mark_multimappers_kernel<<<tally_grid(ctx->n, BLOCK), BLOCK, 0, ctx->stream>>>(ctx->batch, ctx->counters.as<uint32_t>()); }
 	TRY(end_timing(ctx, ctx->n * (4 + 1 + 1)));
 	uint32_t counters[COUNTER_COUNT];
 	TRY(read_counters(ctx, counters));
@@ -719,7 +727,7 @@ int agpu_annotate_finish(agpu_ctx* ctx, const uint64_t* positions, uint64_t n_po
 			ctx->gene_contig.as<uint16_t>(), ctx->gene_start.as<int32_t>(), ctx->gene_end.as<int32_t>(), ctx->gene_bits.as<uint8_t>(), ctx->gene_exonic_length.as<int32_t>());
 	}
 	refresh_annotation_view(ctx);
-	if (n > 0) { KernelTimer timer(ctx, "annotate_stage2_kernel", n * (1 + 3 * (2 + 1 + 1 + GENE_INLINE * 4))); annotate_stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->viral_pairs.as<uint32_t>(), (uint32_t) ctx->viral_pair_capacity, counters); }
+	if (n > 0) { KernelTimer timer(ctx, "annotate_stage2_kernel", n * (1 + 3 * (2 + 1 + 1 + GENE_INLINE * 4))); annotate_stage2_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->viral_pairs.as<uint32_t>(), (uint32_t) ctx->viral_pair_capacity, counters); }
 	TRY(end_timing(ctx, annotation_bytes(ctx)));
 	TRY(read_counters(ctx, host_counters));
 	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
@@ -782,7 +790,7 @@ int run_stage1(agpu_ctx* ctx, const uint8_t* top_verdict, const uint8_t* low_ver
 	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
 	if (n > 0) {
 		KernelTimer timer(ctx, "stage1_kernel", n * (1 + 1 + 12 + 4 + 3 * 2 + 1));
-		stage1_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, global_duplicate, ctx->stage_counts.as<unsigned long long>());
+		stage1_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, global_duplicate, ctx->stage_counts.as<unsigned long long>());
 	}
 	return AGPU_OK;
 }
@@ -907,11 +915,11 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 		// the grids are sized for all fragments (no round trip for the count); workgroups behind the end of the list return at once
 		uint32_t* counts = selected_count.as<uint32_t>();
 		{ KernelTimer timer(ctx, "select_fragments_kernel(unfiltered)", n * (1 + 4)); select_fragments_kernel<<<(unsigned int) ((n + SELECT_BLOCK - 1) / SELECT_BLOCK), SELECT_BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_UNFILTERED, selected.as<uint32_t>(), counts); }
-		{ KernelTimer timer(ctx, "stage2_kernel", stage2_bytes(ctx)); stage2_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), selected.as<uint32_t>(), counts, ctx->stage_counts.as<unsigned long long>()); }
+		{ KernelTimer timer(ctx, "stage2_kernel", stage2_bytes(ctx)); stage2_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, ctx->tables, ctx->filter_enabled.as<uint8_t>(), selected.as<uint32_t>(), counts, ctx->stage_counts.as<unsigned long long>()); }
 		if (ctx->params.filter_enabled[FILTER_low_entropy]) {
 			{ KernelTimer timer(ctx, "select_fragments_kernel(low_entropy)", n * (1 + 4)); select_fragments_kernel<<<(unsigned int) ((n + SELECT_BLOCK - 1) / SELECT_BLOCK), SELECT_BLOCK, 0, s>>>(ctx->batch, ctx->tables, SELECT_LOW_ENTROPY_TEST, selected.as<uint32_t>(), counts + 1); }
 			KernelTimer timer(ctx, "low_entropy_kernel", low_entropy_bytes(ctx));
-			low_entropy_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->tables, selected.as<uint32_t>(), counts + 1, ctx->stage_counts.as<unsigned long long>());
+			low_entropy_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->tables, selected.as<uint32_t>(), counts + 1, ctx->stage_counts.as<unsigned long long>());
 		}
 	}
 	TRY(end_timing(ctx, stage2_bytes(ctx) + low_entropy_bytes(ctx)));

@@ -60,8 +60,8 @@ struct agpu_ctx {
 	uint32_t n_genes = 0, n_exons = 0, n_dummy = 0;
 	agpu::DeviceBuffer gene_contig, gene_start, gene_end, gene_bits, gene_exonic_length;
 	agpu::DeviceBuffer exon_start, exon_end, exon_gene, exon_previous, exon_next, exon_cds_start, exon_cds_end;
-	agpu::DeviceBuffer exon_index_contig_offset, exon_index_keys, exon_index_member_offset, exon_index_members;
-	agpu::DeviceBuffer gene_index_contig_offset, gene_index_keys, gene_index_member_offset, gene_index_members;
+	agpu::DeviceBuffer exon_index_contig_offset, exon_index_keys, exon_index_member_offset, exon_index_members, exon_index_bin_offset, exon_index_bins;
+	agpu::DeviceBuffer gene_index_contig_offset, gene_index_keys, gene_index_member_offset, gene_index_members, gene_index_bin_offset, gene_index_bins;
 	agpu::DeviceBuffer dummy_start_key, dummy_end_key;
 	agpu::AnnotationView annotation;
 	bool have_annotation = false;
@@ -85,6 +85,11 @@ struct agpu_ctx {
 	uint32_t max_read_length = 0;
 	bool have_batch = false, annotated = false, stage1_done = false, stage2_done = false, annotate_begun = false;
 	uint32_t n_unmapped = 0;
+	// the read lists of the candidates this rank built, kept when the replicated table is imported (agpu_import_candidates)
+	agpu::DeviceBuffer owned_list_offset, owned_read_lists, owned_global_index;
+	uint32_t n_owned = 0, n_owned_list_entries = 0;
+	bool candidates_imported = false, owned_index_set = false, multimappers_begun = false;
+	uint64_t n_multimappers_global = 0;
 	uint64_t global_n = 0; // fragments of the whole sample when this context holds one shard of it (agpu_set_shard); 0 = not sharded
 
 	// scratch

@@ -73,9 +73,23 @@ __global__ void __launch_bounds__(BLOCK) partner_resolve_kernel(CandidateTable t
 }
 
 __global__ void partner_size_kernel(const uint64_t* sorted_pairs, uint32_t n, int32_t* partner_set_size) {
+	// the pairs are sorted by gene: the lanes of one gene are contiguous, the first of them adds the distinct pairs of the run in this wavefront
 	uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-	if (k >= n) return;
-	if (k == 0 || sorted_pairs[k - 1] != sorted_pairs[k]) atomicAdd(&partner_set_size[sorted_pairs[k] >> 32], 1);
+	const uint32_t lane = threadIdx.x & 63;
+	const bool valid = k < n;
+	const uint64_t pair = valid ? sorted_pairs[k] : ~0ull;
+	const uint32_t gene = (uint32_t) (pair >> 32);
+	const bool distinct = valid && (k == 0 || sorted_pairs[k - 1] != pair);
+	const uint32_t previous_gene = __shfl_up(gene, 1);
+	const bool head = lane == 0 || previous_gene != gene;
+	const unsigned long long heads = __ballot(head), distincts = __ballot(distinct);
+	if (head && valid) {
+		const unsigned long long later_heads = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1);
+		const int run_end = later_heads ? __ffsll((unsigned long long) later_heads) - 1 : 64;
+		const unsigned long long run = (run_end == 64 ? ~0ull : (1ull << run_end) - 1) & ~((1ull << lane) - 1);
+		const int count = __popcll(distincts & run);
+		if (count) atomicAdd(&partner_set_size[gene], count);
+	}
 }
 // fusion_partner_count[gene] = number of partners whose own partner set is not larger (source/filter_relative_support.cpp:33-41)
 __global__ void partner_count_kernel(const uint64_t* sorted_pairs, uint32_t n, const int32_t* partner_set_size, int32_t* partner_count) {
@@ -92,8 +106,7 @@ __global__ void evalue_globals_kernel(AnnotationView ann, CandidateTable t, unsi
 	if (threadIdx.x < EG_COUNT) block_counters[threadIdx.x] = 0;
 	if (threadIdx.x == 0) block_max = 0;
 	__syncthreads();
-	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c < t.n) {
+	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
 		EvalueContribution r = evalue_contribution(ann, t, c);
 		if (r.breakpoint_class >= 0) atomicAdd(&block_counters[r.breakpoint_class], 1u);
 		if (r.intragenic_class >= 0) atomicAdd(&block_counters[r.intragenic_class], 1u);
@@ -127,21 +140,21 @@ __global__ void evalue_kernel(AnnotationView ann, CandidateTable t, const int32_
 }
 
 __global__ void relative_support_kernel(AnnotationView ann, CandidateTable t, const float* evalue, float evalue_cutoff, unsigned int* remaining) {
-	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	bool kept = false;
-	if (c < t.n && t.filter[c] == FILTER_none) {
-		if (fails_relative_support(ann, t, c, evalue[c], evalue_cutoff)) t.filter[c] = FILTER_relative_support; else kept = true;
+	__shared__ uint32_t block_sum;
+	uint32_t kept = 0;
+	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
+		if (t.filter[c] != FILTER_none) continue;
+		if (fails_relative_support(ann, t, c, evalue[c], evalue_cutoff)) t.filter[c] = FILTER_relative_support; else ++kept;
 	}
-	unsigned long long ballot = __ballot(kept);
-	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(remaining, (unsigned int) __popcll(ballot));
+	block_tally(kept, remaining, &block_sum);
 }
 
 __global__ void candidate_predicates_kernel(AnnotationView ann, CandidateTable t, const uint8_t* enabled, float exonic_fraction, int32_t min_support, unsigned int* discarded /* [3] */) {
 	__shared__ unsigned int block_discarded[3];
 	if (threadIdx.x < 3) block_discarded[threadIdx.x] = 0;
 	__syncthreads();
-	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c < t.n && t.filter[c] == FILTER_none) {
+	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
+		if (t.filter[c] != FILTER_none) continue;
 		const int stage = candidate_predicate_stage(ann, t, c, enabled, exonic_fraction, min_support);
 		if (stage < 3) {
 			t.filter[c] = stage == 0 ? 14 : stage == 1 ? 15 : 17; // non_coding_neighbors, intragenic_exonic, min_support (source/common.hpp:29-67)
@@ -210,7 +223,7 @@ extern "C" int agpu_estimate_expected_fusions(agpu_ctx* ctx, uint64_t mapped_rea
 	(void) hipEventRecord(ctx->event_start, s);
 	{ KernelTimer timer(ctx, "partner_insert_kernel", (uint64_t) C * (4 + 1 + 16 + 2 * 8)); partner_insert_kernel<<<grid_for(2ull * C), BLOCK, 0, s>>>(t, device_rank, slots.as<unsigned long long>(), mask); }
 	{ KernelTimer timer(ctx, "partner_resolve_kernel", (uint64_t) C * (1 + 16 + 2 * 8 + 2 * 8)); partner_resolve_kernel<<<grid_for(2ull * C), BLOCK, 0, s>>>(t, slots.as<unsigned long long>(), mask, pairs.as<uint64_t>(), pair_count.as<uint32_t>()); }
-	{ KernelTimer timer(ctx, "evalue_globals_kernel", (uint64_t) C * 34); evalue_globals_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, counters.as<unsigned int>(), gene_marks.as<uint8_t>()); }
+	{ KernelTimer timer(ctx, "evalue_globals_kernel", (uint64_t) C * 34); evalue_globals_kernel<<<tally_grid(C, BLOCK), BLOCK, 0, s>>>(ctx->annotation, t, counters.as<unsigned int>(), gene_marks.as<uint8_t>()); }
 	gene_mark_count_kernel<<<grid_for(n_genes), BLOCK, 0, s>>>(gene_marks.as<uint8_t>(), n_genes, counters.as<unsigned int>() + 12);
 	uint32_t n_pairs = 0;
 	unsigned int host_counters[16];
@@ -271,7 +284,7 @@ extern "C" int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining) 
 	(void) hipEventRecord(ctx->event_start, s);
 	if (C > 0 && ctx->params.filter_enabled[FILTER_relative_support]) {
 		KernelTimer timer(ctx, "relative_support_kernel", (uint64_t) C * (1 + 4 + 24 + 1));
-		relative_support_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, ctx->candidates, ctx->cand_evalue.as<float>(), ctx->params.evalue_cutoff, counter.as<unsigned int>());
+		relative_support_kernel<<<tally_grid(C, BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->candidates, ctx->cand_evalue.as<float>(), ctx->params.evalue_cutoff, counter.as<unsigned int>());
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
@@ -296,7 +309,7 @@ extern "C" int agpu_filter_candidate_predicates(agpu_ctx* ctx, uint64_t* remaini
 	if (C > 0) {
 		// unfiltered candidates before the stage: counted on the device to keep the call self-contained
 		KernelTimer timer(ctx, "candidate_predicates_kernel", (uint64_t) C * 40);
-		candidate_predicates_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, ctx->candidates, ctx->filter_enabled.as<uint8_t>(), ctx->params.exonic_fraction, (int32_t) ctx->params.min_support, counters.as<unsigned int>());
+		candidate_predicates_kernel<<<tally_grid(C, BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->candidates, ctx->filter_enabled.as<uint8_t>(), ctx->params.exonic_fraction, (int32_t) ctx->params.min_support, counters.as<unsigned int>());
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));

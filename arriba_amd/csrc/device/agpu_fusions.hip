@@ -376,7 +376,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	ctx->n_candidates = 0;
 	if (M == 0) {
 		if (n_candidates) *n_candidates = 0;
-		ctx->fusions_done = true;
+		ctx->fusions_done = true; ctx->candidates_imported = false; ctx->n_list_entries = 0;
 		return AGPU_OK;
 	}
 
@@ -509,7 +509,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	// algorithmic bytes: fragment end columns + gene sets read once, one emission written, candidate table + lists written
 	ctx->last_bytes = n * (3 * (2 + 4 + 4 + 1) + 3 * (1 + GENE_INLINE * 4) + 1) + (uint64_t) M * sizeof(FusionEmission) + (uint64_t) C * 53 + (uint64_t) total_list * 4;
 	ctx->n_candidates = C;
-	ctx->fusions_done = true;
+	ctx->fusions_done = true; ctx->candidates_imported = false;
 	if (n_candidates) *n_candidates = C;
 	return AGPU_OK;
 }
@@ -657,8 +657,13 @@ extern "C" int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, cons
 		ALLOC(*columns[k].buffer, C1 * columns[k].width);
 		if (C) HIP_CHECK(hipMemcpyAsync(columns[k].buffer->ptr, columns[k].source, C * columns[k].width, hipMemcpyDefault, s));
 	}
+	if (ctx->fusions_done && ctx->global_n != 0 && !ctx->candidates_imported) { // the read lists stay with the owners of the gene pairs
+		ctx->owned_list_offset.swap(ctx->cand_list_offset); ctx->owned_read_lists.swap(ctx->cand_read_lists);
+		ctx->n_owned = ctx->n_candidates; ctx->n_owned_list_entries = ctx->n_list_entries;
+		ctx->owned_index_set = false; ctx->multimappers_begun = false;
+	}
 	ALLOC(ctx->cand_list_offset, (3 * C + 1) * 4); ALLOC(ctx->cand_read_lists, 16); ALLOC(ctx->cand_votes, C1 * 8);
-	HIP_CHECK(hipMemsetAsync(ctx->cand_list_offset.ptr, 0, (3 * C + 1) * 4, s)); // the read lists stay with the owners of the gene pairs
+	HIP_CHECK(hipMemsetAsync(ctx->cand_list_offset.ptr, 0, (3 * C + 1) * 4, s));
 	CandidateTable& t = ctx->candidates;
 	t.n = (uint32_t) C; t.gene1 = ctx->cand_gene1.as<uint32_t>(); t.gene2 = ctx->cand_gene2.as<uint32_t>(); t.contigs = ctx->cand_contigs.as<uint32_t>();
 	t.breakpoint1 = ctx->cand_breakpoint1.as<int32_t>(); t.breakpoint2 = ctx->cand_breakpoint2.as<int32_t>(); t.flags = ctx->cand_flags.as<uint32_t>(); t.filter = ctx->cand_filter.as<uint8_t>();
@@ -667,6 +672,6 @@ extern "C" int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, cons
 	t.votes = ctx->cand_votes.as<uint32_t>();
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->n_candidates = (uint32_t) C; ctx->n_list_entries = 0;
-	ctx->fusions_done = true; ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false;
+	ctx->fusions_done = true; ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->candidates_imported = true;
 	return AGPU_OK;
 }

@@ -8,6 +8,7 @@
 #include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
 #include "merge_core.hpp"
+#include "device_utils.hpp"
 
 using namespace agpu;
 
@@ -39,9 +40,10 @@ __global__ void merge_cluster_kernel(CandidateTable t, const uint32_t* order, co
 	if (end - j > 1) merge_cluster(t, order, j, end, max_distance, max_itd_length, extra_split_list);
 }
 __global__ void count_unfiltered_kernel(CandidateTable t, unsigned int* remaining) {
-	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	unsigned long long ballot = __ballot(c < t.n && t.filter[c] == FILTER_none);
-	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(remaining, (unsigned int) __popcll(ballot));
+	__shared__ uint32_t block_sum;
+	uint32_t kept = 0;
+	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) kept += t.filter[c] == FILTER_none;
+	block_tally(kept, remaining, &block_sum);
 }
 
 }
@@ -79,7 +81,7 @@ extern "C" int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, 
 		{ KernelTimer timer(ctx, "merge_cluster_kernel", (uint64_t) C * 40);
 		  merge_cluster_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, order, keys_out.as<uint64_t>(), max_distance, ctx->params.max_itd_length, ctx->cand_extra_split_list.as<uint32_t>()); }
 	}
-	if (C > 0) count_unfiltered_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->candidates, counter.as<unsigned int>());
+	if (C > 0) count_unfiltered_kernel<<<tally_grid(C, BLOCK), BLOCK, 0, s>>>(ctx->candidates, counter.as<unsigned int>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
 	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));

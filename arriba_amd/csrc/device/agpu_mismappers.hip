@@ -18,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
 #include "mismapper_core.hpp"
+#include "device_utils.hpp"
 
 using namespace agpu;
 
@@ -148,13 +149,13 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 }
 
 __global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, unsigned int* remaining) {
-	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	bool kept = false;
-	if (c < t.n && t.filter[c] == FILTER_none) {
-		if (count_candidate_mismappers(b, t, c, max_mismapper_fraction)) t.filter[c] = FILTER_mismappers; else kept = true;
+	__shared__ uint32_t block_sum;
+	uint32_t kept = 0;
+	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
+		if (t.filter[c] != FILTER_none) continue;
+		if (count_candidate_mismappers(b, t, c, max_mismapper_fraction)) t.filter[c] = FILTER_mismappers; else ++kept;
 	}
-	unsigned long long ballot = __ballot(kept);
-	if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(remaining, (unsigned int) __popcll(ballot));
+	block_tally(kept, remaining, &block_sum);
 }
 
 int build_splice_sites(agpu_ctx* ctx) {
@@ -298,7 +299,7 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 			mismapper_verdict_kernel<<<n_jobs, ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
 		}
 		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
-		  mismapper_candidate_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, device_counters + 2); }
+		  mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, device_counters + 2); }
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));

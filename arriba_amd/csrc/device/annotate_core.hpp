@@ -125,6 +125,15 @@ AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& 
 
 AGPU_HD uint32_t index_lower_bound(const FlatIndexView& index, uint32_t contig, int32_t position) {
 	uint32_t lo = index.contig_offset[contig], hi = index.contig_offset[contig + 1];
+	if (index.bins != nullptr) { // narrow [lo, hi] to the keys of one bin
+		const uint32_t base = index.bin_offset[contig], n_bins = index.bin_offset[contig + 1] - base;
+		if (position < 0) { if (n_bins > 0) hi = index.bins[base]; }
+		else {
+			const uint32_t bin = (uint32_t) position >> index.bin_shift;
+			if (bin + 1 >= n_bins) return hi; // behind the last key of the contig
+			lo = index.bins[base + bin]; hi = index.bins[base + bin + 1];
+		}
+	}
 	while (lo < hi) {
 		uint32_t mid = lo + ((hi - lo) >> 1);
 		if (index.keys[mid] < position) lo = mid + 1; else hi = mid;

@@ -44,6 +44,23 @@ template <int BLOCK_THREADS> __device__ __forceinline__ uint32_t block_reserve(u
 	return *block_base + wave_offset[wave] + inclusive - mine;
 }
 
+// Adds the per-thread tallies of a workgroup to a global counter with ONE atomic per workgroup; kernels that only count run as a capped
+// grid (tally_grid) with a grid-stride loop, so a launch over millions of items issues ~10^3 atomics instead of one per wavefront.
+// Every thread of the workgroup must call it.  block_sum: LDS, one word (any value on entry).
+__device__ __forceinline__ void block_tally(uint32_t mine, unsigned int* counter, uint32_t* block_sum) {
+	if (threadIdx.x == 0) *block_sum = 0;
+	__syncthreads();
+	for (int offset = 32; offset > 0; offset >>= 1) mine += __shfl_down(mine, offset);
+	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(block_sum, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && *block_sum) atomicAdd(counter, *block_sum);
+}
+const unsigned int TALLY_MAX_BLOCKS = 2048;
+inline unsigned int tally_grid(uint64_t n, int block_threads) {
+	const uint64_t blocks = (n + block_threads - 1) / block_threads;
+	return (unsigned int) (blocks < 1 ? 1 : blocks > TALLY_MAX_BLOCKS ? TALLY_MAX_BLOCKS : blocks);
+}
+
 }
 
 #endif

@@ -13,7 +13,7 @@
 
 namespace agpu {
 
-const uint32_t NO_FUSION = 0xFFFFFFFFu; // the read is in no candidate's list (most_supported_fusion == NULL)
+const uint32_t NO_FUSION = 0x7FFFFFFFu; // the read is in no candidate's list (most_supported_fusion == NULL); ranks are below 2^31
 
 // reference: is_gap_at_splice_site (:17-22)
 AGPU_HD bool gap_at_splice_site(const AnnotationView& ann, int32_t position, bool upstream, const IdSet& genes) {
@@ -47,8 +47,8 @@ AGPU_HD int32_t segment_score(const BatchView& b, const AnnotationView& ann, con
 			case CIGAR_X: reference_position += length; read_position += length; break;
 			case CIGAR_M:
 				for (uint32_t k = 0; k < length; ++k) {
-					const char base = read_position < sequence.length ? sequence.at(read_position) : '\\0';
-					const char reference_base = (reference_position >= 0 && (uint64_t) reference_position < contig_size) ? genome.bases[contig_begin + (uint64_t) reference_position] : '\\0';
+					const char base = read_position < sequence.length ? sequence.at(read_position) : '\0';
+					const char reference_base = (reference_position >= 0 && (uint64_t) reference_position < contig_size) ? genome.bases[contig_begin + (uint64_t) reference_position] : '\0';
 					if (base == reference_base) score++;
 					reference_position++; read_position++;
 				}
@@ -79,8 +79,9 @@ AGPU_HD int32_t alignment_score(const BatchView& b, const AnnotationView& ann, c
 }
 
 // reference: the cluster loop of filter_multimappers (:141-186) for the group of alignments that starts at fragment `first`.
-// best_rank[i] = rank (0 = most support) of the best candidate of fragment i or NO_FUSION.  Returns the number of fragments discarded.
-AGPU_HD uint32_t resolve_multimapper_group(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const uint32_t* best_rank, uint64_t first) {
+// best_rank[i] = rank (0 = most support) of the best candidate of fragment i or NO_FUSION; scores[i] = alignment_score of fragment i (computed
+// here when scores == NULL).  Returns the number of fragments discarded.
+AGPU_HD uint32_t resolve_multimapper_group(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const uint32_t* best_rank, uint64_t first, const int32_t* scores = nullptr) {
 	const uint32_t group = b.group[first];
 	uint64_t end = first + 1;
 	while (end < b.n && b.group[end] == group) ++end;
@@ -89,7 +90,7 @@ AGPU_HD uint32_t resolve_multimapper_group(const BatchView& b, const AnnotationV
 	int32_t best_score = 0;
 	bool have_best = false;
 	for (uint64_t i = first; i < end; ++i) {
-		const int32_t score = alignment_score(b, ann, genome, i);
+		const int32_t score = scores ? scores[i] : alignment_score(b, ann, genome, i);
 		if (!have_best || best_score < score) { best = i; best_score = score; have_best = true; }
 		else if (best_score == score && best_rank[i] != NO_FUSION && (best_rank[best] == NO_FUSION || best_rank[i] < best_rank[best])) best = i; // fusion_has_more_support
 	}

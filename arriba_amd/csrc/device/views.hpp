@@ -38,6 +38,11 @@ struct FlatIndexView {
 	const int32_t* keys;
 	const uint32_t* member_offset;
 	const uint32_t* members;
+	// optional coarse directory over the keys (device only): bins[bin_offset[contig] + j] = lower bound of position j << bin_shift.  It replaces
+	// the ~12 upper levels of a binary search (dependent loads that miss the L2 in their lower half) by one load of two neighbouring words.
+	const uint32_t* bin_offset = nullptr;
+	const uint32_t* bins = nullptr;
+	uint32_t bin_shift = 0;
 };
 
 struct AnnotationView {

@@ -242,9 +242,46 @@ class ShardedPipeline(DevicePipeline):
         total = int(all_first.numel())
         self._sync()
         self._check(self.api.import_candidates(self.ctx, total, *[columns[name].data_ptr() if total else None for name in names]))
+        # where the candidates this rank built ended up: their read lists stay here (filter_multimappers needs them)
+        inverse = torch.empty_like(order)
+        inverse[order] = torch.arange(total, dtype=order.dtype, device=device)
+        base = int(sum(counts[:self.rank]))
+        owned = inverse[base:base + n].to(torch.int32).contiguous()
+        self._sync()
+        self._check(self.api.set_owned_candidates(self.ctx, owned.data_ptr() if n else None, n))
         self.n_owned_candidates = n
         self.n_candidates = total
         return total
+
+    def filter_multimappers(self):
+        """reference: filter_multimappers (source/filter_multimappers.cpp:109-221) over the shards; needs replicate_candidates() first.
+        Exchanges: multi-mapper flags (all-gather), best candidate rank per multi-mapping read (all-reduce MIN), reads discarded
+        (all-gather), candidate counters (all-reduce MIN).  Returns (remaining candidates, fragments discarded in the whole sample)."""
+        device = self.collective_device
+        flags, _ = self._all_gather_bytes(self.count_local, lambda pointer: self._check(self.api.copy_multimapper_flags(self.ctx, pointer)))
+        n_multimappers = c_uint64()
+        self._check(self.api.multimappers_begin(self.ctx, flags.data_ptr() if flags.numel() else None, byref(n_multimappers)))
+        best = torch.full((max(n_multimappers.value, 1),), 0x7FFFFFFF, dtype=torch.int32, device=device)
+        self._sync()
+        self._check(self.api.multimappers_partial_best(self.ctx, best.data_ptr()))
+        dist.all_reduce(best, op=dist.ReduceOp.MIN, group=self.group)
+        self._sync()
+        discarded_local = torch.zeros(max(self.count_local, 1), dtype=torch.uint8, device=device)
+        discarded = c_uint64()
+        self._sync()
+        self._check(self.api.multimappers_resolve(self.ctx, best.data_ptr(), discarded_local.data_ptr(), byref(discarded)))
+        discarded_global, _ = self._all_gather_tensor(discarded_local[:self.count_local])
+        counters = torch.zeros(max(3 * self.n_candidates, 1), dtype=torch.int32, device=device)
+        self._sync()
+        self._check(self.api.multimappers_recount(self.ctx, discarded_global.data_ptr() if discarded_global.numel() else None, counters.data_ptr()))
+        dist.all_reduce(counters, op=dist.ReduceOp.MIN, group=self.group)
+        self._sync()
+        remaining = c_uint64()
+        self._check(self.api.multimappers_finish(self.ctx, counters.data_ptr(), byref(remaining)))
+        self._record("filter_multimappers")
+        total = torch.tensor([discarded.value], dtype=torch.int64, device=device)
+        dist.all_reduce(total, group=self.group)
+        return remaining.value, int(total.item())
 
     def estimate_expected_fusions(self, mapped_reads=None, iteration_rank=None):
         if mapped_reads is None and self.independent_sessions:  # mapped reads of the whole sample

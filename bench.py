@@ -121,6 +121,7 @@ def main():
         if distributed:
             step_stats.update(pipeline.fusion_stats())
             pipeline.replicate_candidates()    # all-gather of the owners' candidate columns: the candidate-level stages run replicated
+        pipeline.filter_multimappers()         # best alignment of every multi-mapping read; with shards: two all-gathers + two all-reduce MIN
         pipeline.estimate_expected_fusions()   # includes the device computation of the reference container's iteration order (hazard H2)
         pipeline.filter_candidate_predicates() # non_coding_neighbors, intragenic_exonic, min_support (source/arriba.cpp:437-455)
         pipeline.filter_relative_support()
@@ -189,7 +190,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "synthetic %d chimeric fragments per GPU (2x100 bp, 24-contig synthetic genome, GENCODE-like GTF), default filters" % args.fragments,
                        "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "parallelism": ("%d shards by read: all-gather of unmapped positions, duplicate winners and mate-gap samples, all-to-all of gene-pair emissions, all-gather of candidate columns (RCCL)" % world) if distributed else "1 GPU", "gene_pair_emissions": stats["emissions"], "read_list_entries": stats["list_entries"],
-                       "stages_timed": "mark_multimappers, annotate, read filters (14), fragment-length samples, find_fusions, merge_adjacent_fusions, fusions_t iteration order, estimate_expected_fusions, filter_non_coding_neighbors, filter_intragenic_both_exonic, filter_min_support, filter_relative_support",
+                       "stages_timed": "mark_multimappers, annotate, read filters (14), fragment-length samples, find_fusions, merge_adjacent_fusions, filter_multimappers, fusions_t iteration order, estimate_expected_fusions, filter_non_coding_neighbors, filter_intragenic_both_exonic, filter_min_support, filter_relative_support",
                        "host_ingest_reads_per_s": n / ingest_seconds},
             "stage_ms": {stage: round(values["ms"], 3) for stage, values in per_stage.items()},
             "stage_wall_ms": {stage: round(value / args.steps, 3) for stage, value in pipeline.wall_ms.items()},

@@ -225,6 +225,24 @@ int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, uint64_t* r
  * *remaining = "(remaining=N)", *discarded_reads = fragments newly filtered. */
 int agpu_filter_multimappers(agpu_ctx* ctx, uint64_t* remaining, uint64_t* discarded_reads);
 
+/* filter_multimappers when this context holds one shard of the sample.  After agpu_import_candidates the candidate table is
+ * replicated, the read lists are with the rank that built a candidate, the reads with the rank that holds their shard.  Every rank calls, in order:
+ *   agpu_set_owned_candidates     position in the replicated table of every candidate this rank built
+ *   agpu_copy_multimapper_flags   flags[n]: 1 = the fragment is one of several alignments of a read name      -> all-gather (rank order)
+ *   agpu_multimappers_begin       ranks the candidates (fusion_has_more_support), numbers the multi-mapping reads of the sample
+ *   agpu_multimappers_partial_best  best[n_multimappers] (int32, 0x7FFFFFFF = none): best rank among the owned candidates -> all-reduce MIN
+ *   agpu_multimappers_resolve     keeps the best alignment of every group of this shard; discarded_flags[n]  -> all-gather (rank order)
+ *   agpu_multimappers_recount     owners lower their candidates' counters; counters[3 * n_candidates] (int32)   -> all-reduce MIN
+ *   agpu_multimappers_finish      takes the reduced counters, filters the candidates left without support, *remaining = "(remaining=N)"
+ * Pointers may be host or device memory. */
+int agpu_set_owned_candidates(agpu_ctx* ctx, const uint32_t* global_index, uint64_t n_owned);
+int agpu_copy_multimapper_flags(agpu_ctx* ctx, uint8_t* flags);
+int agpu_multimappers_begin(agpu_ctx* ctx, const uint8_t* global_flags, uint64_t* n_multimappers);
+int agpu_multimappers_partial_best(agpu_ctx* ctx, int32_t* best);
+int agpu_multimappers_resolve(agpu_ctx* ctx, const int32_t* best, uint8_t* discarded_flags, uint64_t* discarded);
+int agpu_multimappers_recount(agpu_ctx* ctx, const uint8_t* global_discarded, int32_t* counters);
+int agpu_multimappers_finish(agpu_ctx* ctx, const int32_t* counters, uint64_t* remaining);
+
 /* Candidate state as changed by the event-level stages that run on the host between find_fusions and the e-value
  * (merge_adjacent_fusions, filter_multimappers: source/arriba.cpp:420-430).  NULL = leave the column as it is. */
 int agpu_set_candidate_state(agpu_ctx* ctx, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates);

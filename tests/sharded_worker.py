@@ -32,11 +32,13 @@ def main():
     local_filters = sharded.filters()
     merged_remaining = sharded.merge_adjacent_fusions()  # on the owners: a cluster of adjacent breakpoints lives inside one gene pair
     sharded.replicate_candidates()
+    multimappers = sharded.filter_multimappers()
+    filters_after_multimappers = sharded.filters()
     evalue = sharded.estimate_expected_fusions()
     predicates = sharded.filter_candidate_predicates()
     relative_support_remaining = sharded.filter_relative_support()
     candidate_filters = sharded.candidates()["filter"]
-    report = {"rank": rank, "first": first, "count": count, "exchange": sharded.exchange, "owned_candidates": sharded.n_owned_candidates}
+    report = {"rank": rank, "first": first, "count": count, "exchange": sharded.exchange, "multimappers": multimappers, "owned_candidates": sharded.n_owned_candidates}
     if rank == 0:
         whole = DevicePipeline(session, api=api)
         expected_remaining = whole.run_read_level()
@@ -56,6 +58,11 @@ def main():
             if not np.array_equal(np.asarray(merged[key], dtype=np.int64), np.asarray(table[key], dtype=np.int64)):
                 problems.append(("candidates." + key, len(merged[key]), len(table[key])))
         whole.merge_adjacent_fusions()
+        expected_multimappers = whole.filter_multimappers()
+        if tuple(multimappers) != tuple(expected_multimappers):
+            problems.append(("filter_multimappers", multimappers, expected_multimappers))
+        if not np.array_equal(filters_after_multimappers, whole.filters()[first:first + count]):
+            problems.append(("read filters of shard 0 after filter_multimappers",))
         expected_evalue = whole.estimate_expected_fusions()
         if not np.array_equal(evalue.view(np.uint32), expected_evalue.view(np.uint32)):
             problems.append(("e-values", int((evalue.view(np.uint32) != expected_evalue.view(np.uint32)).sum())))

@@ -28,3 +28,4 @@ def test_sharded_pipeline_equals_single_process(world, name, dataset_files, emu_
     assert sum(r["count"] for r in reports) == reports[0]["fragments"]
     assert sum(r["owned_candidates"] for r in reports) == reports[0]["candidates"]
     assert all(r["exchange"]["emissions_sent"] > 0 for r in reports)
+    assert reports[0]["multimappers"][1] > 0  # fragments discarded by filter_multimappers across the shards
