@@ -57,6 +57,7 @@ __global__ void read_bitmap_kernel(BatchView b, const uint8_t* bytes, uint64_t n
 	const unsigned long long ballot = __ballot(bit);
 	if ((threadIdx.x & 63) == 0 && i < n) { words[i >> 5] = (uint32_t) ballot; if (i + 32 < ((n + 31) & ~31ull)) words[(i >> 5) + 1] = (uint32_t) (ballot >> 32); }
 }
+const int LIST_UNROLL = 4;
 __device__ __forceinline__ bool bitmap_test(const uint32_t* words, uint32_t read) { return (words[read >> 5] >> (read & 31)) & 1u; }
 __global__ void bitmap_popcount_kernel(const uint32_t* words, uint64_t n_words, uint32_t* counts) {
 	const uint64_t w = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
@@ -80,20 +81,22 @@ __global__ void __launch_bounds__(BLOCK) list_best_rank_kernel(uint32_t n_listed
 	const uint32_t my_end = c < n_listed ? list_offset[3 * (uint64_t) c + 3] : 0xFFFFFFFFu;
 	const uint32_t my_rank = c < n_listed ? rank[global_index ? global_index[c] : c] : 0;
 	const uint32_t begin = list_offset[3 * (uint64_t) c0], end = list_offset[3 * (uint64_t) last];
-	for (uint32_t base = begin; base < end; base += 64) {
-		const uint32_t k = base + lane;
-		uint32_t read = 0; bool hit = false;
-		if (k < end) { read = read_lists[k]; hit = bitmap_test(multimapper_bits, read); }
-		unsigned long long hits = __ballot(hit);
-		while (hits) {
-			const int l = __ffsll((unsigned long long) hits) - 1;
-			hits &= hits - 1;
-			const uint32_t entry = base + l;
-			const int owner = __ffsll((unsigned long long) __ballot(my_end > entry)) - 1;
-			const uint32_t owner_rank = __shfl(my_rank, owner);
-			if ((int) lane == l) {
-				const uint32_t target = word_prefix ? word_prefix[read >> 5] + __popc(multimapper_bits[read >> 5] & ((1u << (read & 31)) - 1)) : read;
-				if (best[target] > owner_rank) atomicMin(&best[target], owner_rank);
+	for (uint32_t base = begin; base < end; base += 64 * LIST_UNROLL) { // LIST_UNROLL x 64 entries in flight: the loop is bound by the latency of two dependent loads
+		uint32_t read[LIST_UNROLL]; bool hit[LIST_UNROLL];
+		AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) { const uint32_t k = base + 64 * u + lane; read[u] = k < end ? read_lists[k] : 0xFFFFFFFFu; }
+		AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) hit[u] = read[u] != 0xFFFFFFFFu && bitmap_test(multimapper_bits, read[u]);
+		AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) {
+			unsigned long long hits = __ballot(hit[u]);
+			while (hits) {
+				const int l = __ffsll((unsigned long long) hits) - 1;
+				hits &= hits - 1;
+				const uint32_t entry = base + 64 * u + l;
+				const int owner = __ffsll((unsigned long long) __ballot(my_end > entry)) - 1;
+				const uint32_t owner_rank = __shfl(my_rank, owner);
+				if ((int) lane == l) {
+					const uint32_t target = word_prefix ? word_prefix[read[u] >> 5] + __popc(multimapper_bits[read[u] >> 5] & ((1u << (read[u] & 31)) - 1)) : read[u];
+					if (best[target] > owner_rank) atomicMin(&best[target], owner_rank);
+				}
 			}
 		}
 	}
@@ -116,14 +119,17 @@ __global__ void __launch_bounds__(BLOCK) list_recount_kernel(CandidateTable t, u
 		const uint32_t begin = list_offset[3 * (uint64_t) c0], end = list_offset[3 * (uint64_t) last];
 		const uint32_t previous_end = __shfl_up(end3, 1);
 		const uint32_t my_begin = lane == 0 ? begin : previous_end;
-		for (uint32_t base = begin; base < end; base += 64) {
-			const uint32_t k = base + lane;
-			const bool hit = k < end && bitmap_test(discarded_bits, read_lists[k]);
-			unsigned long long hits = __ballot(hit);
-			while (hits) {
-				const uint32_t entry = base + (uint32_t) (__ffsll((unsigned long long) hits) - 1);
-				hits &= hits - 1;
-				if (entry >= my_begin && entry < end3) { if (entry < end1) ++lost1; else if (entry < end2) ++lost2; else ++lost3; }
+		for (uint32_t base = begin; base < end; base += 64 * LIST_UNROLL) {
+			uint32_t read[LIST_UNROLL]; bool hit[LIST_UNROLL];
+			AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) { const uint32_t k = base + 64 * u + lane; read[u] = k < end ? read_lists[k] : 0xFFFFFFFFu; }
+			AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) hit[u] = read[u] != 0xFFFFFFFFu && bitmap_test(discarded_bits, read[u]);
+			AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) {
+				unsigned long long hits = __ballot(hit[u]);
+				while (hits) {
+					const uint32_t entry = base + 64 * u + (uint32_t) (__ffsll((unsigned long long) hits) - 1);
+					hits &= hits - 1;
+					if (entry >= my_begin && entry < end3) { if (entry < end1) ++lost1; else if (entry < end2) ++lost2; else ++lost3; }
+				}
 			}
 		}
 		if (valid && t.filter[g] == FILTER_none) {
@@ -151,11 +157,16 @@ __global__ void __launch_bounds__(1024) select_multimappers_kernel(BatchView b, 
 	const uint32_t at = block_append<1024>(keep ? 1u : 0u, count, wave_offset, &block_base);
 	if (keep) selected[at] = (uint32_t) i;
 }
+// one thread per summand of the alignment score (MATE1, MATE2, supplementary); the three threads of a fragment sit in three different wavefronts
+// (part-major order), so a wavefront walks alignments of one kind
 __global__ void multimapper_score_kernel(BatchView b, AnnotationView ann, GenomeView genome, const uint32_t* selected, const uint32_t* n_selected, int32_t* scores) {
-	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-	if (k >= *n_selected) return;
-	const uint32_t i = selected[k];
-	scores[i] = alignment_score(b, ann, genome, i);
+	const uint64_t thread = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	const uint32_t n = *n_selected;
+	if (thread >= 3ull * n) return;
+	const int part = (int) (thread / n);
+	const uint32_t i = selected[thread - (uint64_t) part * n];
+	const int32_t score = alignment_score_part(b, ann, genome, i, part);
+	if (score != 0) atomicAdd(&scores[i], score);
 }
 __global__ void multimapper_group_kernel(BatchView b, AnnotationView ann, GenomeView genome, const uint32_t* selected, const uint32_t* n_selected, const uint32_t* best_rank, const int32_t* scores, unsigned int* discarded) {
 	__shared__ uint32_t block_sum;
@@ -244,9 +255,10 @@ int resolve_groups(agpu_ctx* ctx, const uint32_t* best_rank, unsigned int* count
 	const uint64_t n = ctx->n;
 	DeviceBuffer& selected = ctx->scratch("multimappers.selected"); DeviceBuffer& scores = ctx->scratch("multimappers.scores");
 	ALLOC(selected, n * 4); ALLOC(scores, n * 4);
+	HIP_CHECK(hipMemsetAsync(scores.ptr, 0, n * 4, s));
 	unsigned int* n_selected = counters + 2;
 	{ KernelTimer timer(ctx, "select_multimappers_kernel", n * 2); select_multimappers_kernel<<<(unsigned int) ((n + 1023) / 1024), 1024, 0, s>>>(ctx->batch, selected.as<uint32_t>(), n_selected); }
-	{ KernelTimer timer(ctx, "multimapper_score_kernel", n * 12); multimapper_score_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, selected.as<uint32_t>(), n_selected, scores.as<int32_t>()); }
+	{ KernelTimer timer(ctx, "multimapper_score_kernel", n * 12); multimapper_score_kernel<<<grid_for(3 * n), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, selected.as<uint32_t>(), n_selected, scores.as<int32_t>()); }
 	{ KernelTimer timer(ctx, "multimapper_group_kernel", n * 1);
 	  multimapper_group_kernel<<<tally_grid(n / 8 + 1, BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, selected.as<uint32_t>(), n_selected, best_rank, scores.as<int32_t>(), counters); }
 	return AGPU_OK;

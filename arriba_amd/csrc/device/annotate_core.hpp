@@ -223,9 +223,17 @@ template <class Map> AGPU_HD void query_by_coordinate(const FlatIndexView& index
 		--k;
 		if (end - index.keys[k] <= 2) d = index_bucket(index, k);
 	}
-	uint32_t common = emit_intersection(a, c, map, out) + emit_intersection(a, d, map, out) + emit_intersection(b, c, map, out) + emit_intersection(b, d, map, out);
+	// (a, c), (a, d), (b, c), (b, d); then a, b, c, d -- rolled loops, one instance of the merge in the code
+	uint32_t common = 0;
+	AGPU_NOUNROLL for (int pair = 0; pair < 4; ++pair) {
+		const ListRef left = pair < 2 ? a : b, right = (pair & 1) ? d : c;
+		common += emit_intersection(left, right, map, out);
+	}
 	if (common == 0) {
-		emit_all(a, map, out); emit_all(b, map, out); emit_all(c, map, out); emit_all(d, map, out);
+		AGPU_NOUNROLL for (int list = 0; list < 4; ++list) {
+			const ListRef members = list == 0 ? a : list == 1 ? b : list == 2 ? c : d;
+			emit_all(members, map, out);
+		}
 	}
 }
 
@@ -265,12 +273,13 @@ AGPU_HD bool is_breakpoint_spliced(const AnnotationView& ann, uint32_t gene, boo
 	if (contig >= index.n_contigs) return false;
 	uint32_t contig_begin = index.contig_offset[contig], contig_end = index.contig_offset[contig + 1];
 	if (contig_begin == contig_end) return false;
-	uint32_t at = index_lower_bound_near(index, contig, breakpoint, hint);
-	if (at != contig_end) {
-		if (bucket_has_splice_site(ann, gene, upstream, breakpoint, at)) return true;
-		if (at + 1 != contig_end && bucket_has_splice_site(ann, gene, upstream, breakpoint, at + 1)) return true;
+	const uint32_t at = index_lower_bound_near(index, contig, breakpoint, hint);
+	// the buckets at, at + 1, at - 1 in the reference's order (a rolled loop: one instance of the bucket scan in the code)
+	AGPU_NOUNROLL for (int probe = 0; probe < 3; ++probe) {
+		const uint32_t k = probe == 0 ? at : probe == 1 ? at + 1 : at - 1;
+		const bool exists = probe == 0 ? at != contig_end : probe == 1 ? (at != contig_end && at + 1 != contig_end) : at != contig_begin;
+		if (exists && bucket_has_splice_site(ann, gene, upstream, breakpoint, k)) return true;
 	}
-	if (at != contig_begin && bucket_has_splice_site(ann, gene, upstream, breakpoint, at - 1)) return true;
 	return false;
 }
 
@@ -296,13 +305,14 @@ AGPU_HD void annotate_alignment(const BatchView& b, const AnnotationView& ann, u
 			if (is_clip || op == CIGAR_N) {
 				for (uint32_t g = 0; g < genes.n; ++g) {
 					uint32_t gene = genes.get(g);
-					bool discard;
+					// clip: the clipped end must be a splice site (upstream for the first CIGAR operation); intron: either end must be one
 					// (the genes of an alignment lie on its contig, so the hint is a key index of the right contig)
-					if (is_clip)
-						discard = (c == 0) ? !is_breakpoint_spliced(ann, gene, true, reference_position, hint) : !is_breakpoint_spliced(ann, gene, false, reference_position, hint);
-					else
-						discard = !is_breakpoint_spliced(ann, gene, false, reference_position, hint) && !is_breakpoint_spliced(ann, gene, true, reference_position + (int32_t) length, hint);
-					if (!discard) supported.push_back(gene);
+					bool spliced = false;
+					AGPU_NOUNROLL for (int end = 0; end < (is_clip ? 1 : 2) && !spliced; ++end) {
+						const bool upstream = is_clip ? c == 0 : end == 1;
+						spliced = is_breakpoint_spliced(ann, gene, upstream, end == 1 ? reference_position + (int32_t) length : reference_position, hint);
+					}
+					if (spliced) supported.push_back(gene);
 				}
 			}
 			if (op == CIGAR_N || op == CIGAR_M || op == CIGAR_X || op == CIGAR_EQ || op == CIGAR_D)
@@ -359,10 +369,15 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 	}
 
 	// reference: annotate_alignments, source/annotation.cpp:505-555
-	AGPU_UNROLL for (int s = 0; s < 3; ++s) {
-		if (s >= n_aln) continue;
-		annotate_alignment(b, ann, i, s, bits[s], genes[s]);
-		if (genes[s].n > 0) bits[s] |= ABIT_EXONIC;
+	// One instance of annotate_alignment in the code, run n_aln times (a rolled loop over the uniform slot number): unrolled three times the
+	// kernel was 44 k instructions, three times the instruction cache.  The results are copied to constant indices, so bits[] and genes[]
+	// still live in registers.
+	AGPU_NOUNROLL for (int s = 0; s < n_aln; ++s) {
+		uint8_t bit = s == 0 ? bits[0] : s == 1 ? bits[1] : bits[2];
+		IdSet found; found.clear();
+		annotate_alignment(b, ann, i, s, bit, found);
+		if (found.n > 0) bit |= ABIT_EXONIC;
+		if (s == 0) { bits[0] = bit; genes[0] = found; } else if (s == 1) { bits[1] = bit; genes[1] = found; } else { bits[2] = bit; genes[2] = found; }
 	}
 	{
 		bool amb1 = abit(bits[MATE1], ABIT_PREDICTED_STRAND_AMBIGUOUS), amb2 = abit(bits[MATE2], ABIT_PREDICTED_STRAND_AMBIGUOUS);
@@ -397,9 +412,13 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 
 	// reference: gene-index fallback, source/arriba.cpp:190-205
 	IdentityMap identity;
-	AGPU_UNROLL for (int s = 0; s < 3; ++s)
-		if (s < n_aln && genes[s].n == 0)
-			query_by_coordinate(ann.gene_index, b.contig[s][i], b.start[s][i], b.end[s][i], identity, genes[s]);
+	AGPU_NOUNROLL for (int s = 0; s < n_aln; ++s) {
+		const uint32_t count = s == 0 ? genes[0].n : s == 1 ? genes[1].n : genes[2].n;
+		if (count != 0) continue;
+		IdSet found;
+		query_by_coordinate(ann.gene_index, b.contig[s][i], b.start[s][i], b.end[s][i], identity, found);
+		if (s == 0) genes[0] = found; else if (s == 1) genes[1] = found; else genes[2] = found;
+	}
 	if (n_aln == 3) {
 		combine_sets(genes[SPLIT_READ], genes[MATE1], combined, true);
 		if (genes[MATE1].n == 0 || combined.n < genes[MATE1].n) genes[MATE1] = combined;

@@ -59,23 +59,27 @@ AGPU_HD int32_t segment_score(const BatchView& b, const AnnotationView& ann, con
 	return score;
 }
 
-// reference: calculate_alignment_score (:69-77)
-AGPU_HD int32_t alignment_score(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, uint64_t i) {
-	const SequenceRef sequence1 = sequence_of(b, MATE1, i, no_stage()), sequence2 = sequence_of(b, MATE2, i, no_stage());
-	int32_t score = segment_score(b, ann, genome, i, MATE1, sequence1) + segment_score(b, ann, genome, i, MATE2, sequence2);
-	if (b.n_aln[i] == 3) {
-		SequenceRef split_sequence = sequence2; // SPLIT_READ == slot 1
-		const bool supplementary_forward = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND, split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND;
-		split_sequence.reverse_complement = supplementary_forward != split_forward;
-		score += segment_score(b, ann, genome, i, SUPPLEMENTARY, split_sequence);
-		IdSet genes;
-		load_genes(b, SUPPLEMENTARY, i, genes);
-		const bool supplementary_spliced = gap_at_splice_site(ann, supplementary_forward ? b.end[SUPPLEMENTARY][i] : b.start[SUPPLEMENTARY][i], !supplementary_forward, genes);
-		load_genes(b, SPLIT_READ, i, genes);
-		const bool split_spliced = gap_at_splice_site(ann, split_forward ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i], split_forward, genes);
-		if (!supplementary_spliced || !split_spliced) score--; // the read is not split at a splice site
-	}
+// reference: calculate_alignment_score (:69-77), cut into its three summands so that the device can walk them in parallel:
+// part 0 = MATE1, part 1 = MATE2, part 2 = the supplementary alignment of a split read plus the penalty for a split off a splice site
+AGPU_HD int32_t alignment_score_part(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, uint64_t i, int part) {
+	if (part == 0) return segment_score(b, ann, genome, i, MATE1, sequence_of(b, MATE1, i, no_stage()));
+	const SequenceRef sequence2 = sequence_of(b, MATE2, i, no_stage());
+	if (part == 1) return segment_score(b, ann, genome, i, MATE2, sequence2);
+	if (b.n_aln[i] != 3) return 0;
+	SequenceRef split_sequence = sequence2; // SPLIT_READ == slot 1
+	const bool supplementary_forward = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND, split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND;
+	split_sequence.reverse_complement = supplementary_forward != split_forward;
+	int32_t score = segment_score(b, ann, genome, i, SUPPLEMENTARY, split_sequence);
+	IdSet genes;
+	load_genes(b, SUPPLEMENTARY, i, genes);
+	const bool supplementary_spliced = gap_at_splice_site(ann, supplementary_forward ? b.end[SUPPLEMENTARY][i] : b.start[SUPPLEMENTARY][i], !supplementary_forward, genes);
+	load_genes(b, SPLIT_READ, i, genes);
+	const bool split_spliced = gap_at_splice_site(ann, split_forward ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i], split_forward, genes);
+	if (!supplementary_spliced || !split_spliced) score--; // the read is not split at a splice site
 	return score;
+}
+AGPU_HD int32_t alignment_score(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, uint64_t i) {
+	return alignment_score_part(b, ann, genome, i, 0) + alignment_score_part(b, ann, genome, i, 1) + alignment_score_part(b, ann, genome, i, 2);
 }
 
 // reference: the cluster loop of filter_multimappers (:141-186) for the group of alignments that starts at fragment `first`.

@@ -7,9 +7,11 @@
 #if defined(__HIPCC__)
 #define AGPU_HD __host__ __device__ __forceinline__
 #define AGPU_UNROLL _Pragma("unroll")
+#define AGPU_NOUNROLL _Pragma("nounroll")
 #else
 #define AGPU_HD inline
 #define AGPU_UNROLL
+#define AGPU_NOUNROLL
 #endif
 
 namespace agpu {
