@@ -346,13 +346,12 @@ template <class T> int upload(DeviceBuffer& buffer, const T* host, size_t count,
 }
 #define TRY(call) do { int s_ = (call); if (s_ != AGPU_OK) return s_; } while (0)
 
-int upload_index(const agpu_flat_index& in, DeviceBuffer& contig_offset, DeviceBuffer& keys, DeviceBuffer& member_offset, DeviceBuffer& members, DeviceBuffer& bin_offset, DeviceBuffer& bins, FlatIndexView& out, hipStream_t stream) {
-	std::vector<uint32_t> host_bin_offset, host_bins;
-	build_index_bins(in.n_contigs, in.contig_offset, in.keys, host_bin_offset, host_bins);
-	TRY(upload(bin_offset, host_bin_offset.data(), host_bin_offset.size(), stream));
+int upload_index(const agpu_flat_index& in, DeviceBuffer& contig_offset, DeviceBuffer& keys, DeviceBuffer& member_offset, DeviceBuffer& members, DeviceBuffer& bins, FlatIndexView& out, hipStream_t stream) {
+	std::vector<uint32_t> host_bins;
+	build_index_bins(in.n_contigs, in.contig_offset, in.keys, host_bins);
 	TRY(upload(bins, host_bins.data(), host_bins.size(), stream));
-	HIP_CHECK(hipStreamSynchronize(stream)); // the host vectors go out of scope
-	out.bin_offset = bin_offset.as<uint32_t>(); out.bins = bins.as<uint32_t>(); out.bin_shift = INDEX_BIN_SHIFT;
+	HIP_CHECK(hipStreamSynchronize(stream)); // the host vector goes out of scope
+	out.bins = bins.as<uint32_t>();
 	TRY(upload(contig_offset, in.contig_offset, (size_t) in.n_contigs + 1, stream));
 	TRY(upload(keys, in.keys, in.n_keys, stream));
 	TRY(upload(member_offset, in.member_offset, (size_t) in.n_keys + 1, stream));
@@ -542,8 +541,8 @@ int agpu_upload_annotation(agpu_ctx* ctx, const agpu_annotation_view* in) {
 	TRY(upload(ctx->exon_start, in->exon_start, in->n_exons, s)); TRY(upload(ctx->exon_end, in->exon_end, in->n_exons, s)); TRY(upload(ctx->exon_gene, in->exon_gene, in->n_exons, s));
 	TRY(upload(ctx->exon_previous, in->exon_previous, in->n_exons, s)); TRY(upload(ctx->exon_next, in->exon_next, in->n_exons, s));
 	TRY(upload(ctx->exon_cds_start, in->exon_cds_start, in->n_exons, s)); TRY(upload(ctx->exon_cds_end, in->exon_cds_end, in->n_exons, s));
-	TRY(upload_index(in->exon_index, ctx->exon_index_contig_offset, ctx->exon_index_keys, ctx->exon_index_member_offset, ctx->exon_index_members, ctx->exon_index_bin_offset, ctx->exon_index_bins, ctx->annotation.exon_index, s));
-	TRY(upload_index(in->gene_index, ctx->gene_index_contig_offset, ctx->gene_index_keys, ctx->gene_index_member_offset, ctx->gene_index_members, ctx->gene_index_bin_offset, ctx->gene_index_bins, ctx->annotation.gene_index, s));
+	TRY(upload_index(in->exon_index, ctx->exon_index_contig_offset, ctx->exon_index_keys, ctx->exon_index_member_offset, ctx->exon_index_members, ctx->exon_index_bins, ctx->annotation.exon_index, s));
+	TRY(upload_index(in->gene_index, ctx->gene_index_contig_offset, ctx->gene_index_keys, ctx->gene_index_member_offset, ctx->gene_index_members, ctx->gene_index_bins, ctx->annotation.gene_index, s));
 	refresh_annotation_view(ctx);
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->have_annotation = true; ctx->annotated = false; ctx->have_splice_sites = false;

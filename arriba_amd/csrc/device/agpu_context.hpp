@@ -60,8 +60,8 @@ struct agpu_ctx {
 	uint32_t n_genes = 0, n_exons = 0, n_dummy = 0;
 	agpu::DeviceBuffer gene_contig, gene_start, gene_end, gene_bits, gene_exonic_length;
 	agpu::DeviceBuffer exon_start, exon_end, exon_gene, exon_previous, exon_next, exon_cds_start, exon_cds_end;
-	agpu::DeviceBuffer exon_index_contig_offset, exon_index_keys, exon_index_member_offset, exon_index_members, exon_index_bin_offset, exon_index_bins;
-	agpu::DeviceBuffer gene_index_contig_offset, gene_index_keys, gene_index_member_offset, gene_index_members, gene_index_bin_offset, gene_index_bins;
+	agpu::DeviceBuffer exon_index_contig_offset, exon_index_keys, exon_index_member_offset, exon_index_members, exon_index_bins;
+	agpu::DeviceBuffer gene_index_contig_offset, gene_index_keys, gene_index_member_offset, gene_index_members, gene_index_bins;
 	agpu::DeviceBuffer dummy_start_key, dummy_end_key;
 	agpu::AnnotationView annotation;
 	bool have_annotation = false;

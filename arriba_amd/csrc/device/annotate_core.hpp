@@ -29,6 +29,20 @@ AGPU_HD uint32_t atomic_add_u32(uint32_t* address, uint32_t value) {
 // compiler's scalar replacement sees nothing but constants from the very first pass on.
 const int SET_CAPACITY = 16;
 #define AGPU_EACH_ELEMENT(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+// Almost every set holds one or two ids: the element-wise statements are split into the first SET_LOW elements, always executed, and the
+// rest, executed only by the lanes whose set is that large (a wavefront without such a lane skips the block): the cost of a set
+// operation follows the typical size, not the capacity.  AGPU_IDSET_SPLIT=0 builds the flat variant (A/B measurements).
+#ifndef AGPU_IDSET_SPLIT
+#define AGPU_IDSET_SPLIT 1
+#endif
+const uint32_t SET_LOW = 4;
+#define AGPU_EACH_LOW(F) F(0) F(1) F(2) F(3)
+#define AGPU_EACH_HIGH(F) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+#if AGPU_IDSET_SPLIT
+#define AGPU_EACH_SPLIT(F, needs_high) { AGPU_EACH_LOW(F) if (needs_high) { AGPU_EACH_HIGH(F) } }
+#else
+#define AGPU_EACH_SPLIT(F, needs_high) { AGPU_EACH_ELEMENT(F) }
+#endif
 struct IdSet {
 	uint32_t n;
 	uint32_t overflow;
@@ -37,13 +51,13 @@ struct IdSet {
 	AGPU_HD uint32_t get(uint32_t k) const {
 		uint32_t value = v[0];
 #define AGPU_GET(j) value = (k == j##u) ? v[j] : value;
-		AGPU_EACH_ELEMENT(AGPU_GET)
+		AGPU_EACH_SPLIT(AGPU_GET, k >= SET_LOW)
 #undef AGPU_GET
 		return value;
 	}
 	AGPU_HD void put(uint32_t k, uint32_t x) {
 #define AGPU_PUT(j) v[j] = (k == j##u) ? x : v[j];
-		AGPU_EACH_ELEMENT(AGPU_PUT)
+		AGPU_EACH_SPLIT(AGPU_PUT, k >= SET_LOW)
 #undef AGPU_PUT
 	}
 	AGPU_HD void push_back(uint32_t x) { // caller keeps the order
@@ -54,7 +68,7 @@ struct IdSet {
 	AGPU_HD bool contains(uint32_t x) const {
 		bool present = false;
 #define AGPU_CONTAINS(j) present = present || (j##u < n && v[j] == x);
-		AGPU_EACH_ELEMENT(AGPU_CONTAINS)
+		AGPU_EACH_SPLIT(AGPU_CONTAINS, n > SET_LOW)
 #undef AGPU_CONTAINS
 		return present;
 	}
@@ -63,7 +77,7 @@ struct IdSet {
 		if (n == SET_CAPACITY) { overflow = 1; return; }
 		uint32_t carry = x; // bubble x to its place: every larger element moves up by one
 #define AGPU_INSERT(j) { const uint32_t current = v[j]; const bool exchange = j##u < n && current > carry; v[j] = (exchange || j##u == n) ? carry : current; carry = exchange ? current : carry; }
-		AGPU_EACH_ELEMENT(AGPU_INSERT)
+		AGPU_EACH_SPLIT(AGPU_INSERT, n >= SET_LOW) // element j >= SET_LOW is touched only if j <= n
 #undef AGPU_INSERT
 		++n;
 	}
@@ -73,7 +87,7 @@ struct IdSet {
 AGPU_HD void intersect_sets(const IdSet& a, const IdSet& b, IdSet& out) {
 	out.clear();
 #define AGPU_INTERSECT(i) if (i##u < a.n && b.contains(a.v[i])) out.push_back(a.v[i]); /* a is ascending, so is the result */
-	AGPU_EACH_ELEMENT(AGPU_INTERSECT)
+	AGPU_EACH_SPLIT(AGPU_INTERSECT, a.n > SET_LOW)
 #undef AGPU_INTERSECT
 }
 // intersection, or the union if the intersection is empty (reference: combine_annotations, source/annotation.t.hpp:47-53)
@@ -82,7 +96,7 @@ AGPU_HD void combine_sets(const IdSet& a, const IdSet& b, IdSet& out, bool make_
 	if (out.n == 0 && make_union) {
 		out = a;
 #define AGPU_UNION(j) if (j##u < b.n) out.insert(b.v[j]);
-		AGPU_EACH_ELEMENT(AGPU_UNION)
+		AGPU_EACH_SPLIT(AGPU_UNION, b.n > SET_LOW)
 #undef AGPU_UNION
 		out.overflow |= a.overflow | b.overflow;
 	}
@@ -95,7 +109,7 @@ AGPU_HD void load_genes(const BatchView& b, int slot, uint64_t i, IdSet& out) {
 	if (count > (uint32_t) GENE_INLINE) source = b.gene_pool + source[0];
 	if (count > (uint32_t) SET_CAPACITY) { count = SET_CAPACITY; out.overflow = 1; }
 #define AGPU_LOAD(k) if (k##u < count) out.v[k] = source[k];
-	AGPU_EACH_ELEMENT(AGPU_LOAD)
+	AGPU_EACH_SPLIT(AGPU_LOAD, count > SET_LOW)
 #undef AGPU_LOAD
 	out.n = count;
 }
@@ -116,7 +130,7 @@ AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& 
 	}
 	inline_ids[0] = offset;
 #define AGPU_STORE(k) if (k##u < set.n) b.gene_pool[offset + k] = set.v[k];
-	AGPU_EACH_ELEMENT(AGPU_STORE)
+	AGPU_EACH_SPLIT(AGPU_STORE, set.n > SET_LOW)
 #undef AGPU_STORE
 	return true;
 }
@@ -126,10 +140,10 @@ AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& 
 AGPU_HD uint32_t index_lower_bound(const FlatIndexView& index, uint32_t contig, int32_t position) {
 	uint32_t lo = index.contig_offset[contig], hi = index.contig_offset[contig + 1];
 	if (index.bins != nullptr) { // narrow [lo, hi] to the keys of one bin
-		const uint32_t base = index.bin_offset[contig], n_bins = index.bin_offset[contig + 1] - base;
+		const uint32_t base = index.bins[contig], n_bins = index.bins[contig + 1] - base;
 		if (position < 0) { if (n_bins > 0) hi = index.bins[base]; }
 		else {
-			const uint32_t bin = (uint32_t) position >> index.bin_shift;
+			const uint32_t bin = (uint32_t) position >> INDEX_BIN_SHIFT;
 			if (bin + 1 >= n_bins) return hi; // behind the last key of the contig
 			lo = index.bins[base + bin]; hi = index.bins[base + bin + 1];
 		}

@@ -6,17 +6,16 @@
 
 #include <stdint.h>
 #include <vector>
+#include "views.hpp"
 
 namespace agpu {
 
-const uint32_t INDEX_BIN_SHIFT = 10; // 1 kb bins: about one exon boundary per bin in a GENCODE-scale annotation, 12 MB of directory for a 3.1 Gb genome
-
-inline void build_index_bins(uint32_t n_contigs, const uint32_t* contig_offset, const int32_t* keys, std::vector<uint32_t>& bin_offset, std::vector<uint32_t>& bins) {
-	bin_offset.assign((size_t) n_contigs + 1, 0);
-	bins.clear();
+// bins[0 .. n_contigs] = offset of the contig's directory inside `bins`, then the directories
+inline void build_index_bins(uint32_t n_contigs, const uint32_t* contig_offset, const int32_t* keys, std::vector<uint32_t>& bins) {
+	bins.assign((size_t) n_contigs + 1, 0);
 	for (uint32_t contig = 0; contig < n_contigs; ++contig) {
 		const uint32_t begin = contig_offset[contig], end = contig_offset[contig + 1];
-		bin_offset[contig] = (uint32_t) bins.size();
+		bins[contig] = (uint32_t) bins.size();
 		if (end > begin) {
 			const int32_t last_key = keys[end - 1];
 			const uint32_t n_bins = last_key < 0 ? 1 : ((uint32_t) last_key >> INDEX_BIN_SHIFT) + 2;
@@ -28,7 +27,7 @@ inline void build_index_bins(uint32_t n_contigs, const uint32_t* contig_offset, 
 			}
 		}
 	}
-	bin_offset[n_contigs] = (uint32_t) bins.size();
+	bins[n_contigs] = (uint32_t) bins.size();
 }
 
 }

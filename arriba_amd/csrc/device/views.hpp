@@ -40,12 +40,12 @@ struct FlatIndexView {
 	const int32_t* keys;
 	const uint32_t* member_offset;
 	const uint32_t* members;
-	// optional coarse directory over the keys (device only): bins[bin_offset[contig] + j] = lower bound of position j << bin_shift.  It replaces
-	// the ~12 upper levels of a binary search (dependent loads that miss the L2 in their lower half) by one load of two neighbouring words.
-	const uint32_t* bin_offset = nullptr;
+	// optional coarse directory over the keys: bins[bins[contig] + j] = lower bound of position j << INDEX_BIN_SHIFT (the first n_contigs + 1
+	// words are the per-contig offsets into the array itself).  It replaces the ~12 upper levels of a binary search (dependent loads that
+	// miss the L2 in their lower half) by one load of two neighbouring words.  One pointer only: the kernels are short of scalar registers.
 	const uint32_t* bins = nullptr;
-	uint32_t bin_shift = 0;
 };
+const uint32_t INDEX_BIN_SHIFT = 10; // 1 kb bins: about one exon boundary per bin in a GENCODE-scale annotation, 12 MB of directory for a 3.1 Gb genome
 
 struct AnnotationView {
 	uint32_t n_genes;          // GTF genes

@@ -76,7 +76,7 @@ struct emu_ctx {
 	std::vector<uint64_t> unmapped;              // positions that need a dummy gene (between annotate_begin and annotate_finish)
 	std::vector<uint8_t> duplicate_entries;      // wire format of the sharded duplicate exchange: 12-byte key + 4-byte global name rank
 	uint64_t global_n = 0;
-	std::vector<uint32_t> exon_bin_offset, exon_bins, gene_bin_offset, gene_bins;
+	std::vector<uint32_t> exon_bins, gene_bins;
 };
 
 static void refresh_annotation(emu_ctx* ctx) {
@@ -88,10 +88,10 @@ static void refresh_annotation(emu_ctx* ctx) {
 	a.exon_cds_start = in.exon_cds_start; a.exon_cds_end = in.exon_cds_end;
 	a.exon_index.n_contigs = in.exon_index.n_contigs; a.exon_index.contig_offset = in.exon_index.contig_offset; a.exon_index.keys = in.exon_index.keys; a.exon_index.member_offset = in.exon_index.member_offset; a.exon_index.members = in.exon_index.members;
 	// the same directory over the keys as on the device (index_bins.hpp), so that the host stepping covers the narrowed binary search
-	build_index_bins(in.exon_index.n_contigs, in.exon_index.contig_offset, in.exon_index.keys, ctx->exon_bin_offset, ctx->exon_bins);
-	a.exon_index.bin_offset = ctx->exon_bin_offset.data(); a.exon_index.bins = ctx->exon_bins.data(); a.exon_index.bin_shift = INDEX_BIN_SHIFT;
-	build_index_bins(in.gene_index.n_contigs, in.gene_index.contig_offset, in.gene_index.keys, ctx->gene_bin_offset, ctx->gene_bins);
-	a.gene_index.bin_offset = ctx->gene_bin_offset.data(); a.gene_index.bins = ctx->gene_bins.data(); a.gene_index.bin_shift = INDEX_BIN_SHIFT;
+	build_index_bins(in.exon_index.n_contigs, in.exon_index.contig_offset, in.exon_index.keys, ctx->exon_bins);
+	a.exon_index.bins = ctx->exon_bins.data();
+	build_index_bins(in.gene_index.n_contigs, in.gene_index.contig_offset, in.gene_index.keys, ctx->gene_bins);
+	a.gene_index.bins = ctx->gene_bins.data();
 	a.gene_index.n_contigs = in.gene_index.n_contigs; a.gene_index.contig_offset = in.gene_index.contig_offset; a.gene_index.keys = in.gene_index.keys; a.gene_index.member_offset = in.gene_index.member_offset; a.gene_index.members = in.gene_index.members;
 	a.dummy_start_key = ctx->dummy_start_key.data(); a.dummy_end_key = ctx->dummy_end_key.data();
 }

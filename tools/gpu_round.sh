@@ -30,3 +30,14 @@ if [ "$3" = "probe" ]; then timeout 600 python tools/stage_probe.py 3000000 > gp
 if [ "$4" = "dryrun2" ]; then
   ARRIBA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --fragments 2000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_2ranks_dryrun.json 2> gpurun_out/${TAG}_bench_2ranks_dryrun.err; tail -1 gpurun_out/${TAG}_bench_2ranks_dryrun.json | cut -c1-1500; tail -5 gpurun_out/${TAG}_bench_2ranks_dryrun.err
 fi
+if [ "$5" = "diag" ]; then
+  # where the wave cycles of every kernel go (issue vs wait) and the instruction mix: two SQ passes
+  cd /tmp
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq_${TAG}_a -o pmc -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_sq_a.log 2>&1
+  timeout 600 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQ_INSTS_SMEM SQ_INSTS_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq_${TAG}_b -o pmc -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_sq_b.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/pmc_summary.py gpurun_out/${TAG}_sq.json gpurun_out/sq_${TAG}_a gpurun_out/sq_${TAG}_b > gpurun_out/${TAG}_sq_summary.txt 2>&1
+  rm -rf gpurun_out/sq_${TAG}_a gpurun_out/sq_${TAG}_b
+  head -30 gpurun_out/${TAG}_sq_summary.txt | cut -c1-400
+fi
+if [ -n "$6" ]; then timeout 600 python tools/ab_probe.py 3000000 libarriba_gpu.so $6 > gpurun_out/${TAG}_ab.json 2> gpurun_out/${TAG}_ab.err; cat gpurun_out/${TAG}_ab.json; fi
