@@ -23,41 +23,44 @@ AGPU_HD uint32_t atomic_add_u32(uint32_t* address, uint32_t value) {
 #endif
 }
 
-// Small sorted set of ids.  On the device the elements must stay in registers: a register file cannot be indexed with a run-time
-// index (the array would be spilled to scratch, i.e. to HBM -- rocprofv3 showed 4 GB of scratch writes per annotate launch).  Every
-// access is therefore written out with constant element indices (AGPU_EACH_ELEMENT expands a statement for 0..15), so that the
-// compiler's scalar replacement sees nothing but constants from the very first pass on.
+// Small sorted set of ids.  The annotate and filter kernels wait on dependent gathers (SQ counters: ~75 % of the wave cycles parked on
+// s_waitcnt), so what they need is wavefronts in flight, i.e. few registers.  A register file cannot be indexed with a run-time index:
+// an indexed array goes to scratch memory (HBM -- 4 GB of scratch writes per annotate launch in the first version), while sixteen
+// constant-indexed elements per set cost 90 VGPRs for the five sets of the annotation (3 waves per SIMD).  Almost every set holds one
+// or two ids, so the set is split: the first SET_LOW elements live in registers (every access written out with constant indices, so
+// that scalar replacement sees nothing but constants), the elements behind them in a small per-lane array in scratch memory that only
+// the lanes with such a large set ever touch (a wavefront without one skips the block; copies move the tail only if there is one).
 const int SET_CAPACITY = 16;
-#define AGPU_EACH_ELEMENT(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
-// Almost every set holds one or two ids: the element-wise statements are split into the first SET_LOW elements, always executed, and the
-// rest, executed only by the lanes whose set is that large (a wavefront without such a lane skips the block): the cost of a set
-// operation follows the typical size, not the capacity.  AGPU_IDSET_SPLIT=0 builds the flat variant (A/B measurements).
-#ifndef AGPU_IDSET_SPLIT
-#define AGPU_IDSET_SPLIT 1
-#endif
 const uint32_t SET_LOW = 4;
 #define AGPU_EACH_LOW(F) F(0) F(1) F(2) F(3)
-#define AGPU_EACH_HIGH(F) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
-#if AGPU_IDSET_SPLIT
-#define AGPU_EACH_SPLIT(F, needs_high) { AGPU_EACH_LOW(F) if (needs_high) { AGPU_EACH_HIGH(F) } }
-#else
-#define AGPU_EACH_SPLIT(F, needs_high) { AGPU_EACH_ELEMENT(F) }
-#endif
 struct IdSet {
 	uint32_t n;
 	uint32_t overflow;
-	uint32_t v[SET_CAPACITY];
+	uint32_t low[SET_LOW];
+	uint32_t high[SET_CAPACITY - SET_LOW]; // elements SET_LOW .. n-1
+	AGPU_HD IdSet() {}
+	AGPU_HD IdSet(const IdSet& other) { copy_from(other); }
+	AGPU_HD IdSet& operator=(const IdSet& other) { copy_from(other); return *this; }
+	AGPU_HD void copy_from(const IdSet& other) {
+		n = other.n; overflow = other.overflow;
+#define AGPU_COPY(j) low[j] = other.low[j];
+		AGPU_EACH_LOW(AGPU_COPY)
+#undef AGPU_COPY
+		if (other.n > SET_LOW) for (uint32_t j = SET_LOW; j < other.n; ++j) high[j - SET_LOW] = other.high[j - SET_LOW];
+	}
 	AGPU_HD void clear() { n = 0; overflow = 0; }
 	AGPU_HD uint32_t get(uint32_t k) const {
-		uint32_t value = v[0];
-#define AGPU_GET(j) value = (k == j##u) ? v[j] : value;
-		AGPU_EACH_SPLIT(AGPU_GET, k >= SET_LOW)
+		if (k >= SET_LOW) return high[k - SET_LOW];
+		uint32_t value = low[0];
+#define AGPU_GET(j) value = (k == j##u) ? low[j] : value;
+		AGPU_EACH_LOW(AGPU_GET)
 #undef AGPU_GET
 		return value;
 	}
 	AGPU_HD void put(uint32_t k, uint32_t x) {
-#define AGPU_PUT(j) v[j] = (k == j##u) ? x : v[j];
-		AGPU_EACH_SPLIT(AGPU_PUT, k >= SET_LOW)
+		if (k >= SET_LOW) { high[k - SET_LOW] = x; return; }
+#define AGPU_PUT(j) low[j] = (k == j##u) ? x : low[j];
+		AGPU_EACH_LOW(AGPU_PUT)
 #undef AGPU_PUT
 	}
 	AGPU_HD void push_back(uint32_t x) { // caller keeps the order
@@ -67,37 +70,47 @@ struct IdSet {
 	}
 	AGPU_HD bool contains(uint32_t x) const {
 		bool present = false;
-#define AGPU_CONTAINS(j) present = present || (j##u < n && v[j] == x);
-		AGPU_EACH_SPLIT(AGPU_CONTAINS, n > SET_LOW)
+#define AGPU_CONTAINS(j) present = present || (j##u < n && low[j] == x);
+		AGPU_EACH_LOW(AGPU_CONTAINS)
 #undef AGPU_CONTAINS
+		if (n > SET_LOW) for (uint32_t j = SET_LOW; j < n; ++j) present = present || high[j - SET_LOW] == x;
 		return present;
 	}
 	AGPU_HD void insert(uint32_t x) {
 		if (contains(x)) return;
 		if (n == SET_CAPACITY) { overflow = 1; return; }
 		uint32_t carry = x; // bubble x to its place: every larger element moves up by one
-#define AGPU_INSERT(j) { const uint32_t current = v[j]; const bool exchange = j##u < n && current > carry; v[j] = (exchange || j##u == n) ? carry : current; carry = exchange ? current : carry; }
-		AGPU_EACH_SPLIT(AGPU_INSERT, n >= SET_LOW) // element j >= SET_LOW is touched only if j <= n
+#define AGPU_INSERT(j) { const uint32_t current = low[j]; const bool exchange = j##u < n && current > carry; low[j] = (exchange || j##u == n) ? carry : current; carry = exchange ? current : carry; }
+		AGPU_EACH_LOW(AGPU_INSERT)
 #undef AGPU_INSERT
+		if (n >= SET_LOW) {
+			for (uint32_t j = SET_LOW; j < n; ++j) {
+				const uint32_t current = high[j - SET_LOW];
+				if (current > carry) { high[j - SET_LOW] = carry; carry = current; }
+			}
+			high[n - SET_LOW] = carry;
+		}
 		++n;
 	}
-	AGPU_HD void assign_single(uint32_t x) { n = 1; v[0] = x; }
+	AGPU_HD void assign_single(uint32_t x) { n = 1; low[0] = x; }
 };
 
 AGPU_HD void intersect_sets(const IdSet& a, const IdSet& b, IdSet& out) {
 	out.clear();
-#define AGPU_INTERSECT(i) if (i##u < a.n && b.contains(a.v[i])) out.push_back(a.v[i]); /* a is ascending, so is the result */
-	AGPU_EACH_SPLIT(AGPU_INTERSECT, a.n > SET_LOW)
+#define AGPU_INTERSECT(i) if (i##u < a.n && b.contains(a.low[i])) out.push_back(a.low[i]); /* a is ascending, so is the result */
+	AGPU_EACH_LOW(AGPU_INTERSECT)
 #undef AGPU_INTERSECT
+	if (a.n > SET_LOW) for (uint32_t i = SET_LOW; i < a.n; ++i) { const uint32_t x = a.high[i - SET_LOW]; if (b.contains(x)) out.push_back(x); }
 }
 // intersection, or the union if the intersection is empty (reference: combine_annotations, source/annotation.t.hpp:47-53)
 AGPU_HD void combine_sets(const IdSet& a, const IdSet& b, IdSet& out, bool make_union) {
 	intersect_sets(a, b, out);
 	if (out.n == 0 && make_union) {
 		out = a;
-#define AGPU_UNION(j) if (j##u < b.n) out.insert(b.v[j]);
-		AGPU_EACH_SPLIT(AGPU_UNION, b.n > SET_LOW)
+#define AGPU_UNION(j) if (j##u < b.n) out.insert(b.low[j]);
+		AGPU_EACH_LOW(AGPU_UNION)
 #undef AGPU_UNION
+		if (b.n > SET_LOW) for (uint32_t j = SET_LOW; j < b.n; ++j) out.insert(b.high[j - SET_LOW]);
 		out.overflow |= a.overflow | b.overflow;
 	}
 }
@@ -108,9 +121,10 @@ AGPU_HD void load_genes(const BatchView& b, int slot, uint64_t i, IdSet& out) {
 	const uint32_t* source = b.genes[slot] + i * GENE_INLINE;
 	if (count > (uint32_t) GENE_INLINE) source = b.gene_pool + source[0];
 	if (count > (uint32_t) SET_CAPACITY) { count = SET_CAPACITY; out.overflow = 1; }
-#define AGPU_LOAD(k) if (k##u < count) out.v[k] = source[k];
-	AGPU_EACH_SPLIT(AGPU_LOAD, count > SET_LOW)
+#define AGPU_LOAD(k) if (k##u < count) out.low[k] = source[k];
+	AGPU_EACH_LOW(AGPU_LOAD)
 #undef AGPU_LOAD
+	if (count > SET_LOW) for (uint32_t k = SET_LOW; k < count; ++k) out.high[k - SET_LOW] = source[k];
 	out.n = count;
 }
 
@@ -119,8 +133,8 @@ AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& 
 	uint32_t* inline_ids = b.genes[slot] + i * GENE_INLINE;
 	b.gene_count[slot][i] = (uint8_t) set.n;
 	if (set.n <= (uint32_t) GENE_INLINE) {
-		if (set.n > 0) inline_ids[0] = set.v[0];
-		if (set.n > 1) inline_ids[1] = set.v[1];
+		if (set.n > 0) inline_ids[0] = set.low[0];
+		if (set.n > 1) inline_ids[1] = set.low[1];
 		return true;
 	}
 	uint32_t offset = atomic_add_u32(b.gene_pool_used, set.n);
@@ -129,9 +143,10 @@ AGPU_HD bool store_genes(const BatchView& b, int slot, uint64_t i, const IdSet& 
 		return false;
 	}
 	inline_ids[0] = offset;
-#define AGPU_STORE(k) if (k##u < set.n) b.gene_pool[offset + k] = set.v[k];
-	AGPU_EACH_SPLIT(AGPU_STORE, set.n > SET_LOW)
+#define AGPU_STORE(k) if (k##u < set.n) b.gene_pool[offset + k] = set.low[k];
+	AGPU_EACH_LOW(AGPU_STORE)
 #undef AGPU_STORE
+	if (set.n > SET_LOW) for (uint32_t k = SET_LOW; k < set.n; ++k) b.gene_pool[offset + k] = set.high[k - SET_LOW];
 	return true;
 }
 
@@ -335,7 +350,7 @@ AGPU_HD void annotate_alignment(const BatchView& b, const AnnotationView& ann, u
 		if (supported.n > 0) {
 			if (supported.n < genes.n) genes = supported;
 			if (ambiguous) {
-				bool predicted = ann.gene_bits[supported.v[0]] & GBIT_STRAND;
+				bool predicted = ann.gene_bits[supported.low[0]] & GBIT_STRAND;
 				bool still_ambiguous = false;
 				for (uint32_t g = 0; g < supported.n && !still_ambiguous; ++g)
 					if (((ann.gene_bits[supported.get(g)] & GBIT_STRAND) != 0) != predicted)

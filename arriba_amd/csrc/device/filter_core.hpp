@@ -171,7 +171,7 @@ AGPU_HD int32_t mate_gap_sample(const BatchView& b, const AnnotationView& ann, u
 	if (!(b.abits[MATE1][i] & ABIT_STRAND)) { forward = SPLIT_READ; reverse = MATE1; }
 	IdSet genes; load_genes(b, forward, i, genes);
 	int32_t forward_end = b.end[forward][i], reverse_start = b.start[reverse][i];
-	int32_t distance = spliced_distance(ann, b.contig[forward][i], forward_end, reverse_start, genes.v[0]);
+	int32_t distance = spliced_distance(ann, b.contig[forward][i], forward_end, reverse_start, genes.low[0]);
 	if (forward_end > reverse_start) distance *= -1;
 	int32_t forward_length = (int32_t) b.seq_length[forward][i], reverse_length = (int32_t) b.seq_length[reverse][i];
 	if (distance < -forward_length) distance = -forward_length;

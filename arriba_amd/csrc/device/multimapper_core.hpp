@@ -45,14 +45,25 @@ AGPU_HD int32_t segment_score(const BatchView& b, const AnnotationView& ann, con
 			case CIGAR_I: score--; read_position += length; break;
 			case CIGAR_EQ: score += (int32_t) length; reference_position += length; read_position += length; break;
 			case CIGAR_X: reference_position += length; read_position += length; break;
-			case CIGAR_M:
-				for (uint32_t k = 0; k < length; ++k) {
+			case CIGAR_M: {
+				uint32_t k = 0;
+				// eight bases per step while read and contig cover them: the sixteen loads are issued back to back (the walk waits on memory, not on
+				// arithmetic), then compared; the ends of the operation go base by base with the reference's out-of-range behaviour ('\0')
+				while (k + 8 <= length && read_position + 8 <= sequence.length && reference_position >= 0 && (uint64_t) reference_position + 8 <= contig_size) {
+					char read_bases[8], reference_bases[8];
+					AGPU_UNROLL for (int u = 0; u < 8; ++u) reference_bases[u] = genome.bases[contig_begin + (uint64_t) reference_position + u];
+					AGPU_UNROLL for (int u = 0; u < 8; ++u) read_bases[u] = sequence.at(read_position + u);
+					AGPU_UNROLL for (int u = 0; u < 8; ++u) score += read_bases[u] == reference_bases[u] ? 1 : 0;
+					reference_position += 8; read_position += 8; k += 8;
+				}
+				for (; k < length; ++k) {
 					const char base = read_position < sequence.length ? sequence.at(read_position) : '\0';
 					const char reference_base = (reference_position >= 0 && (uint64_t) reference_position < contig_size) ? genome.bases[contig_begin + (uint64_t) reference_position] : '\0';
 					if (base == reference_base) score++;
 					reference_position++; read_position++;
 				}
 				break;
+			}
 			default: break;
 		}
 	}

@@ -173,6 +173,7 @@ class ShardedPipeline(DevicePipeline):
 
     def filter_reads(self):
         remaining = super().filter_reads()  # counts of this shard; the sample's "(remaining=N)" is their sum
+        self.remaining_local = dict(remaining)
         names = list(remaining)
         totals = torch.tensor([remaining[k] for k in names], dtype=torch.int64, device=self.collective_device)
         dist.all_reduce(totals, group=self.group)

@@ -154,6 +154,22 @@ def main():
     else:
         total_fragments = n
 
+    # post-conditions of the last step on the full-size batch (untimed; no oracle involved): a kernel that silently skipped a part of the
+    # batch would leave alignments without a gene or a read filter count that does not add up
+    import numpy as np
+    self_check = []
+    for slot in (0, 1):
+        without_gene = int((pipeline.gene_sets(slot)[0] == 0).sum())
+        if without_gene:
+            self_check.append("%d alignments in slot %d have no gene after annotate" % (without_gene, slot))
+    unfiltered = int((pipeline.filters() == 0).sum())
+    remaining_local = pipeline.remaining_local["low_entropy"] if hasattr(pipeline, "remaining_local") else pipeline.remaining["low_entropy"]
+    multimapper_discards = int((pipeline.filters() == 9).sum())
+    if unfiltered + multimapper_discards != remaining_local:
+        self_check.append("fragments without a filter (%d) + discarded as multi-mappers (%d) != remaining after the read filters (%d)" % (unfiltered, multimapper_discards, remaining_local))
+    if self_check:
+        raise SystemExit("bench self-check failed: " + "; ".join(self_check))
+
     if rank == 0:
         per_stage = {stage: {"ms": sum(t["ms"] for t in ts) / len(ts), "bytes": ts[-1]["bytes"]} for stage, ts in stage_ms.items()}
         # per-kernel launch durations of the timed steps (HIP events on the launch stream); the dominant kernel is the one with the largest total
@@ -199,6 +215,7 @@ def main():
                          "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes,
                          "cascade": {"algorithmic_bytes": cascade_bytes, "kernel_ms": cascade_ms, "achieved": cascade_bytes / (cascade_ms * 1e-3) / 1e9, "frac": cascade_bytes / (cascade_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
+        line["self_check"] = "every alignment has a gene; unfiltered + multi-mapper discards == remaining after the read filters"
         line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped"} if args.no_cpu_baseline else cpu_baseline(1000, directory)
         print(json.dumps(line))
     if distributed:

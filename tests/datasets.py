@@ -28,6 +28,9 @@ DATASETS = {
     # predicates -> filter_relative_support can then be compared without taking any intermediate state from the reference
     "toy3k_chain": {"args": ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"], "reference_disable_filters": ["multimappers"],
                     "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_merge_adjacent_fusions.tsv", "fusions.*_filter_relative_support.tsv"]},
+    # piles of overlapping genes on one locus: gene sets of up to 10 ids (the tail of a set lives outside the registers on the device)
+    "stacked4k": {"args": ["--seed", "13", "--fragments", "4000", "--contigs", "3", "--contig-len", "300000", "--junctions", "80", "--genes-per-mb", "40", "--gene-stack", "9"],
+                  "golden_files": ["reads.*_annotated.tsv", "filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv", "fusions.*_find_fusions.tsv"]},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},

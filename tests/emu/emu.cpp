@@ -234,7 +234,7 @@ int emu_annotate_finish(emu_ctx* ctx, const uint64_t* positions, uint64_t n_posi
 		if (bits2 & CBIT_VIRAL) viral_slot = mate2; else if (bits2 & CBIT_INTERESTING) host_slot = mate2;
 		if (viral_slot >= 0 && host_slot >= 0) {
 			IdSet genes; load_genes(b, host_slot, i, genes);
-			for (uint32_t g = 0; g < genes.n; ++g) { ctx->viral_pairs.push_back(b.contig[viral_slot][i]); ctx->viral_pairs.push_back(genes.v[g]); }
+			for (uint32_t g = 0; g < genes.n; ++g) { ctx->viral_pairs.push_back(b.contig[viral_slot][i]); ctx->viral_pairs.push_back(genes.get(g)); }
 		}
 	}
 	if (!ok) { g_error = "a gene set exceeded the device capacity"; return AGPU_ERR_CAPACITY; }
@@ -385,7 +385,7 @@ int emu_get_gene_sets(emu_ctx* ctx, int slot, uint8_t* count, uint32_t* genes, u
 		uint64_t at = 0;
 		for (uint64_t i = 0; i < ctx->n; ++i) {
 			IdSet set; load_genes(ctx->batch, slot, i, set);
-			for (uint32_t k = 0; k < set.n; ++k) genes[at++] = set.v[k];
+			for (uint32_t k = 0; k < set.n; ++k) genes[at++] = set.get(k);
 		}
 	}
 	return 0;

@@ -13,7 +13,7 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k"])
+@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k", "stacked4k"])
 def test_read_level_cascade_matches_reference(name, dataset_files):
     golden = conftest.golden_dir(name)
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name))
@@ -22,6 +22,11 @@ def test_read_level_cascade_matches_reference(name, dataset_files):
     parity.check_scalars(pipeline, golden)
     if name != "mid30k":
         parity.check_annotation(session, pipeline, golden)
+    if name == "stacked4k":
+        counts = np.concatenate([pipeline.gene_sets(slot)[0] for slot in range(3)])
+        assert (counts > 4).sum() > 500 and counts.max() >= 9  # the memory-resident tail of the gene sets is exercised
+        pipeline.find_fusions()
+        assert parity.check_candidates(session, pipeline, golden) > 5000
     if name == "toy3k":
         pipeline.find_fusions()
         assert parity.check_candidates(session, pipeline, golden) > 1000
@@ -101,6 +106,31 @@ def test_chain_to_relative_support_without_injected_state(built, dataset_files, 
     assert parity.check_multimappers(session, pipeline, dump) > 100
     session, pipeline = parity.run_read_level(parity.open_session, prefix)
     assert parity.check_chain_to_relative_support(session, pipeline, dump, multimappers=True) > 10000
+
+
+def test_live_reference_above_launch_grid_caps(built, tmp_path):
+    """700 k fragments: more than the 2048 x 256 threads of the capped launch grids (counting kernels with grid-stride loops), so a kernel that
+    is launched on a capped grid without looping over its items fails here; the smaller datasets cannot see that."""
+    if not datasets.reference_available():
+        pytest.skip("oracle/_ref/arriba_ref_dump did not travel with the repository")
+    spec = {"args": ["--seed", "51", "--fragments", "700000", "--normal-mult", "0.05", "--contigs", "8", "--contig-len", "1500000", "--junctions", "8000", "--dup", "0.2"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    switches = {"ARRIBA_ORACLE_DUMP_LISTS": "0", "ARRIBA_ORACLE_DUMP_READS": "0", "ARRIBA_ORACLE_DUMP_STAGES": "key"}  # compact dumps: ~45 s of reference
+    os.environ.update(switches)
+    try:
+        log = datasets.run_reference(prefix, dump)
+    finally:
+        for key in switches:
+            del os.environ[key]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    assert pipeline.n > 2048 * 256
+    parity.check_read_filters(session, pipeline, dump)
+    parity.check_scalars(pipeline, dump)
+    assert parity.check_chain_to_relative_support(session, pipeline, dump, multimappers=True) > 100000
 
 
 def test_live_reference_mismapper_stress(built, tmp_path):

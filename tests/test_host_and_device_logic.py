@@ -3,6 +3,7 @@ per-fragment logic single-stepped on the host (tests/emu) against the same dumps
 import os
 import re
 
+import numpy as np
 import pytest
 
 import conftest
@@ -53,7 +54,7 @@ def test_ingest_matches_reference_read_table(name, dataset_files):
     assert parity.check_ingest(session, conftest.golden_dir(name)) > 1000
 
 
-@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k"])
+@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k", "stacked4k"])
 def test_device_logic_on_host_matches_reference(name, dataset_files, emu_api):
     golden = conftest.golden_dir(name)
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name), api=emu_api)
@@ -62,6 +63,11 @@ def test_device_logic_on_host_matches_reference(name, dataset_files, emu_api):
     parity.check_scalars(pipeline, golden)
     if name != "mid30k":
         parity.check_annotation(session, pipeline, golden)
+    if name == "stacked4k":
+        counts = np.concatenate([pipeline.gene_sets(slot)[0] for slot in range(3)])
+        assert (counts > 4).sum() > 500 and counts.max() >= 9  # the memory-resident tail of the gene sets is exercised
+        pipeline.find_fusions()
+        assert parity.check_candidates(session, pipeline, golden) > 5000
     if name == "toy3k":
         pipeline.find_fusions()
         assert parity.check_candidates(session, pipeline, golden) > 1000

@@ -9,7 +9,7 @@ import oracle_lib
 import parity
 
 
-@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k"])
+@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k", "stacked4k"])
 def test_oracle_restatement_matches_reference(name, dataset_files):
     golden = conftest.golden_dir(name)
     session = parity.open_session(dataset_files(name))

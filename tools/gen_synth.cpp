@@ -201,6 +201,37 @@ void Generator::build_reference() {
 					p = std::max(p, antisense.end + 1);
 				}
 			}
+			// a pile of overlapping genes on the same locus (gene families, read-through transcripts): gene sets of up to gene_stack + 1 ids.
+			// (no random numbers are drawn when the option is off: the default datasets stay byte-identical)
+			if (c.gene_stack > 0 && rng.chance(0.2)) {
+				const int copies = rng.range(2, c.gene_stack);
+				for (int copy = 1; copy <= copies; ++copy) {
+					Gene stacked;
+					stacked.contig = contig;
+					stacked.plus = rng.chance(0.7) ? gene.plus : !gene.plus;
+					Transcript t;
+					const int shift = rng.range(3, 40) * copy;
+					for (size_t e = 0; e < full.exons.size(); ++e) {
+						if (e > 0 && e + 1 < full.exons.size() && rng.chance(0.2)) continue;
+						Exon exon;
+						exon.start = full.exons[e].start + shift;
+						exon.end = full.exons[e].end + shift;
+						t.exons.push_back(exon);
+					}
+					stacked.start = t.exons.front().start;
+					stacked.end = t.exons.back().end;
+					if (stacked.end >= length - 30000) break;
+					snprintf(buffer, sizeof(buffer), "ENSG%011d.%d", ++gene_serial, rng.range(1, 15));
+					stacked.id = buffer;
+					stacked.name = "SYN" + std::to_string(gene_serial) + "-L" + std::to_string(copy);
+					snprintf(buffer, sizeof(buffer), "ENST%011d.%d", ++transcript_serial, rng.range(1, 9));
+					t.id = buffer;
+					stacked.transcripts.push_back(t);
+					impl_->genes_by_contig[contig].push_back(genes_.size());
+					genes_.push_back(stacked);
+					p = std::max(p, stacked.end + 1);
+				}
+			}
 			cursor = std::max(p, gene.end) + (int) (mean_spacing * (0.1 + 1.5 * rng.unif()));
 		}
 	}
@@ -953,6 +984,7 @@ int main(int argc, char** argv) {
 		else if (a == "--contigs") config.contigs = atoi(value());
 		else if (a == "--contig-len") config.contig_length = atoi(value());
 		else if (a == "--genes-per-mb") config.genes_per_mb = atof(value());
+		else if (a == "--gene-stack") config.gene_stack = atoi(value());
 		else if (a == "--read-len") config.read_length = atoi(value());
 		else if (a == "--junctions") config.junctions = atoi(value());
 		else if (a == "--clip-min") config.clip_min = atoi(value());

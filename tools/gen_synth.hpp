@@ -24,6 +24,7 @@ struct Config {
 	int contigs = 6;                 // main contigs named 1..N
 	int contig_length = 400000;
 	double genes_per_mb = 60;
+	int gene_stack = 0;              // > 0: 20 % of the genes get 2..gene_stack overlapping copies on the same locus (large gene sets)
 	int read_length = 100;
 	long fragments = 20000;          // chimeric fragments (split-read triplets, discordant pairs, read-through)
 	double normal_multiplier = 1.0;  // ordinary proper pairs per chimeric fragment
