@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(BLOCK) annotate_stage2_kernel(BatchView b, Ann
 	__shared__ uint32_t wave_offset[BLOCK / 64];
 	__shared__ uint32_t block_base;
 	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	IdSet genes; genes.clear();
+	AGPU_IDSET(genes); genes.clear();
 	uint32_t viral_contig = 0;
 	if (i < b.n) {
 		if (!annotate_fragment_stage2(b, ann, i))

@@ -30,17 +30,23 @@ AGPU_HD uint32_t atomic_add_u32(uint32_t* address, uint32_t value) {
 // or two ids, so the set is split: the first SET_LOW elements live in registers (every access written out with constant indices, so
 // that scalar replacement sees nothing but constants), the elements behind them in a small per-lane array in scratch memory that only
 // the lanes with such a large set ever touch (a wavefront without one skips the block; copies move the tail only if there is one).
+// The tail is a SEPARATE object (IdSetTail) that the set only points to: as a member array it would be indexed with a run-time index
+// inside the same stack object as n and low[], and scalar replacement then leaves the whole object in memory (measured: 6 GB of
+// scratch writes per annotate launch).  AGPU_IDSET(name) declares a set together with its tail.
 const int SET_CAPACITY = 16;
 const uint32_t SET_LOW = 4;
 #define AGPU_EACH_LOW(F) F(0) F(1) F(2) F(3)
+struct IdSetTail { uint32_t words[SET_CAPACITY - SET_LOW]; };
+#define AGPU_IDSET(name) IdSetTail name##_tail; IdSet name(name##_tail.words)
+#define AGPU_IDSET3(name) IdSetTail name##_tail[3]; IdSet name[3] = { IdSet(name##_tail[0].words), IdSet(name##_tail[1].words), IdSet(name##_tail[2].words) }
 struct IdSet {
 	uint32_t n;
 	uint32_t overflow;
 	uint32_t low[SET_LOW];
-	uint32_t high[SET_CAPACITY - SET_LOW]; // elements SET_LOW .. n-1
-	AGPU_HD IdSet() {}
-	AGPU_HD IdSet(const IdSet& other) { copy_from(other); }
-	AGPU_HD IdSet& operator=(const IdSet& other) { copy_from(other); return *this; }
+	uint32_t* high; // elements SET_LOW .. n-1, in the IdSetTail of this set
+	AGPU_HD explicit IdSet(uint32_t* tail) : high(tail) {}
+	IdSet(const IdSet&) = delete; // a copy would share the tail
+	AGPU_HD IdSet& operator=(const IdSet& other) { copy_from(other); return *this; } // copies the elements, keeps its own tail
 	AGPU_HD void copy_from(const IdSet& other) {
 		n = other.n; overflow = other.overflow;
 #define AGPU_COPY(j) low[j] = other.low[j];
@@ -326,7 +332,7 @@ AGPU_HD void annotate_alignment(const BatchView& b, const AnnotationView& ann, u
 	bool ambiguous = bits & ABIT_PREDICTED_STRAND_AMBIGUOUS;
 	if (n_cigar > 1 && (genes.n > 1 || ambiguous)) {
 		const uint32_t* cigar = b.cigar_pool + b.cigar_offset[slot][i];
-		IdSet supported; supported.clear();
+		AGPU_IDSET(supported); supported.clear();
 		int32_t reference_position = start;
 		for (uint32_t c = 0; c < n_cigar && supported.n == 0; ++c) {
 			uint32_t op = cigar[c] & 15, length = cigar[c] >> 4;
@@ -381,7 +387,7 @@ AGPU_HD int32_t breakpoint_of(const BatchView& b, int slot, uint64_t i, uint8_t 
 AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& ann, uint32_t strandedness, uint64_t i, uint64_t unmapped[2], uint32_t& n_unmapped) {
 	int n_aln = b.n_aln[i];
 	uint8_t bits[3];
-	IdSet genes[3];
+	AGPU_IDSET3(genes);
 	// (the slot loops are unrolled so that bits[] and genes[] are only ever indexed with constants and stay in registers)
 	AGPU_UNROLL for (int s = 0; s < 3; ++s) { bits[s] = (s < n_aln) ? (uint8_t) (b.abits[s][i] | ABIT_PREDICTED_STRAND_AMBIGUOUS) : 0; genes[s].clear(); }
 
@@ -403,7 +409,7 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 	// still live in registers.
 	AGPU_NOUNROLL for (int s = 0; s < n_aln; ++s) {
 		uint8_t bit = s == 0 ? bits[0] : s == 1 ? bits[1] : bits[2];
-		IdSet found; found.clear();
+		AGPU_IDSET(found); found.clear();
 		annotate_alignment(b, ann, i, s, bit, found);
 		if (found.n > 0) bit |= ABIT_EXONIC;
 		if (s == 0) { bits[0] = bit; genes[0] = found; } else if (s == 1) { bits[1] = bit; genes[1] = found; } else { bits[2] = bit; genes[2] = found; }
@@ -419,7 +425,7 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 			}
 		}
 	}
-	IdSet combined;
+	AGPU_IDSET(combined);
 	if (n_aln == 3) {
 		combine_sets(genes[SPLIT_READ], genes[MATE1], combined, true);
 		if (genes[MATE1].n == 0 || combined.n < genes[MATE1].n) genes[MATE1] = combined;
@@ -444,7 +450,7 @@ AGPU_HD bool annotate_fragment_stage1(const BatchView& b, const AnnotationView& 
 	AGPU_NOUNROLL for (int s = 0; s < n_aln; ++s) {
 		const uint32_t count = s == 0 ? genes[0].n : s == 1 ? genes[1].n : genes[2].n;
 		if (count != 0) continue;
-		IdSet found;
+		AGPU_IDSET(found);
 		query_by_coordinate(ann.gene_index, b.contig[s][i], b.start[s][i], b.end[s][i], identity, found);
 		if (s == 0) genes[0] = found; else if (s == 1) genes[1] = found; else genes[2] = found;
 	}
@@ -509,6 +515,7 @@ AGPU_HD bool dummy_gene_starts_here(const uint64_t* sorted_keys, uint32_t i, con
 struct GeneQuery {
 	IdSet real;
 	uint32_t dummy_first, dummy_count; // gene ids n_genes + dummy_first ... (all larger than any GTF gene id)
+	AGPU_HD explicit GeneQuery(uint32_t* tail) : real(tail) {}
 	AGPU_HD void clear() { real.clear(); dummy_first = 0; dummy_count = 0; }
 	AGPU_HD uint32_t size() const { return real.n + dummy_count; }
 	AGPU_HD uint32_t element(const AnnotationView& ann, uint32_t k) const { return k < real.n ? real.get(k) : ann.n_genes + dummy_first + (k - real.n); }
@@ -575,12 +582,13 @@ AGPU_HD uint32_t last_gene_containing(const AnnotationView& ann, const GeneQuery
 // alignments that span several dummy genes to the one containing the breakpoint.
 AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& ann, uint64_t i) {
 	int n_aln = b.n_aln[i];
-	GeneQuery genes[3];
+	IdSetTail genes_tail[3];
+	GeneQuery genes[3] = { GeneQuery(genes_tail[0].words), GeneQuery(genes_tail[1].words), GeneQuery(genes_tail[2].words) };
 	uint8_t bits[3];
 	bool changed[3] = { false, false, false };
 	AGPU_UNROLL for (int s = 0; s < 3; ++s) {
 		genes[s].clear(); bits[s] = 0;
-		if (s < n_aln) { IdSet loaded; load_genes(b, s, i, loaded); genes[s].from_set(loaded); bits[s] = b.abits[s][i]; }
+		if (s < n_aln) { AGPU_IDSET(loaded); load_genes(b, s, i, loaded); genes[s].from_set(loaded); bits[s] = b.abits[s][i]; }
 	}
 
 	if (n_aln == 3) {
@@ -623,7 +631,7 @@ AGPU_HD bool annotate_fragment_stage2(const BatchView& b, const AnnotationView& 
 	bool ok = true;
 	AGPU_UNROLL for (int s = 0; s < 3; ++s)
 		if (s < n_aln && changed[s]) {
-			IdSet out;
+			AGPU_IDSET(out);
 			ok = genes[s].to_set(ann, out) && ok;
 			ok = store_genes(b, s, i, out) && ok;
 		}

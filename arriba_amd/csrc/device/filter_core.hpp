@@ -169,7 +169,7 @@ AGPU_HD int32_t spliced_distance(const AnnotationView& ann, uint32_t contig, int
 AGPU_HD int32_t mate_gap_sample(const BatchView& b, const AnnotationView& ann, uint64_t i) {
 	int forward = MATE1, reverse = SPLIT_READ;
 	if (!(b.abits[MATE1][i] & ABIT_STRAND)) { forward = SPLIT_READ; reverse = MATE1; }
-	IdSet genes; load_genes(b, forward, i, genes);
+	AGPU_IDSET(genes); load_genes(b, forward, i, genes);
 	int32_t forward_end = b.end[forward][i], reverse_start = b.start[reverse][i];
 	int32_t distance = spliced_distance(ann, b.contig[forward][i], forward_end, reverse_start, genes.low[0]);
 	if (forward_end > reverse_start) distance *= -1;
@@ -312,7 +312,7 @@ AGPU_HD bool has_long_gap(const BatchView& b, uint64_t i) {
 }
 
 AGPU_HD bool is_same_gene_artifact(const BatchView& b, uint64_t i, const IdSet* genes) {
-	IdSet common;
+	AGPU_IDSET(common);
 	if (b.n_aln[i] == 2) intersect_sets(genes[MATE1], genes[MATE2], common);
 	else intersect_sets(genes[MATE2], genes[SUPPLEMENTARY], common);
 	if (common.n == 0) return false;
@@ -339,7 +339,7 @@ AGPU_HD bool breakpoint_within_aligned_segment(const BatchView& b, int slot, uin
 }
 
 AGPU_HD bool is_hairpin(const BatchView& b, uint64_t i, const IdSet* genes) {
-	IdSet common;
+	AGPU_IDSET(common);
 	if (b.n_aln[i] == 2) {
 		intersect_sets(genes[MATE1], genes[MATE2], common);
 		if (common.n == 0 && b.contig[MATE1][i] != b.contig[MATE2][i]) return false;
@@ -659,7 +659,7 @@ AGPU_HD bool has_low_entropy(const BatchView& b, const FilterTables& t, uint64_t
 AGPU_HD uint8_t read_filters_stage2(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const FilterTables& t, const uint8_t* enabled, uint64_t i, uint8_t filter, const SequenceStage& stage, uint32_t& first_hit) {
 	first_hit = 9;
 	if (filter != FILTER_none) return filter;
-	IdSet genes[3];
+	AGPU_IDSET3(genes);
 	int n_aln = b.n_aln[i];
 	AGPU_UNROLL for (int s = 0; s < 3; ++s) { genes[s].clear(); if (s < n_aln) load_genes(b, s, i, genes[s]); }
 	if (enabled[FILTER_read_through] && is_proximal_read_through(b, ann, t, i)) { filter = FILTER_read_through; first_hit = 0; }

@@ -108,7 +108,7 @@ AGPU_HD uint32_t emission_count(const BatchView& b, uint64_t i) {
 
 AGPU_HD void write_emissions(const BatchView& b, uint64_t i, FusionEmission* out) {
 	FragmentEnds f; fragment_ends(b, i, f);
-	IdSet genes1, genes2;
+	AGPU_IDSET(genes1); AGPU_IDSET(genes2);
 	load_genes(b, f.slot1, i, genes1); load_genes(b, f.slot2, i, genes2);
 	FusionEmission e;
 	e.breakpoint1 = f.breakpoint1; e.breakpoint2 = f.breakpoint2; e.contigs = f.contig1 << 16 | f.contig2;

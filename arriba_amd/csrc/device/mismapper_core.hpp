@@ -255,7 +255,7 @@ AGPU_HD bool extend_split_read(const BatchView& b, const GenomeView& genome, uin
 // (source/filter_mismappers.cpp:283-332); a pure function of the fragment, its gene sets, max_mate_gap and the k-mer index.
 AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, uint64_t i, int32_t max_mate_gap, const AlignRunner& runner) {
 	const float min_align_fraction = 0.8f, min_extended_align_fraction = 0.7f;
-	IdSet genes;
+	AGPU_IDSET(genes);
 	if (b.n_aln[i] == 3) {
 		const SequenceRef split_sequence = sequence_of(b, SPLIT_READ, i, no_stage()), mate1_sequence = sequence_of(b, MATE1, i, no_stage());
 		const bool same_contig = b.contig[SPLIT_READ][i] == b.contig[SUPPLEMENTARY][i]; // == fusion.contig1 == fusion.contig2

@@ -27,7 +27,7 @@ AGPU_HD int32_t segment_score(const BatchView& b, const AnnotationView& ann, con
 	const uint32_t contig = b.contig[slot][i];
 	const uint64_t contig_begin = genome.contig_offset[contig], contig_size = genome.contig_offset[contig + 1] - contig_begin;
 	if (contig_size == 0) return 0; // no sequence loaded for this contig
-	IdSet genes; load_genes(b, slot, i, genes);
+	AGPU_IDSET(genes); load_genes(b, slot, i, genes);
 	const uint32_t* cigar = cigar_of(b, slot, i); const uint32_t n = b.cigar_count[slot][i];
 	int32_t score = 0;
 	int64_t reference_position = b.start[slot][i];
@@ -81,7 +81,7 @@ AGPU_HD int32_t alignment_score_part(const BatchView& b, const AnnotationView& a
 	const bool supplementary_forward = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND, split_forward = b.abits[SPLIT_READ][i] & ABIT_STRAND;
 	split_sequence.reverse_complement = supplementary_forward != split_forward;
 	int32_t score = segment_score(b, ann, genome, i, SUPPLEMENTARY, split_sequence);
-	IdSet genes;
+	AGPU_IDSET(genes);
 	load_genes(b, SUPPLEMENTARY, i, genes);
 	const bool supplementary_spliced = gap_at_splice_site(ann, supplementary_forward ? b.end[SUPPLEMENTARY][i] : b.start[SUPPLEMENTARY][i], !supplementary_forward, genes);
 	load_genes(b, SPLIT_READ, i, genes);

@@ -233,7 +233,7 @@ int emu_annotate_finish(emu_ctx* ctx, const uint64_t* positions, uint64_t n_posi
 		if (bits1 & CBIT_VIRAL) viral_slot = MATE1; else if (bits1 & CBIT_INTERESTING) host_slot = MATE1;
 		if (bits2 & CBIT_VIRAL) viral_slot = mate2; else if (bits2 & CBIT_INTERESTING) host_slot = mate2;
 		if (viral_slot >= 0 && host_slot >= 0) {
-			IdSet genes; load_genes(b, host_slot, i, genes);
+			AGPU_IDSET(genes); load_genes(b, host_slot, i, genes);
 			for (uint32_t g = 0; g < genes.n; ++g) { ctx->viral_pairs.push_back(b.contig[viral_slot][i]); ctx->viral_pairs.push_back(genes.get(g)); }
 		}
 	}
@@ -384,7 +384,7 @@ int emu_get_gene_sets(emu_ctx* ctx, int slot, uint8_t* count, uint32_t* genes, u
 		if (capacity < sum) { g_error = "gene buffer too small"; return AGPU_ERR_INVALID; }
 		uint64_t at = 0;
 		for (uint64_t i = 0; i < ctx->n; ++i) {
-			IdSet set; load_genes(ctx->batch, slot, i, set);
+			AGPU_IDSET(set); load_genes(ctx->batch, slot, i, set);
 			for (uint32_t k = 0; k < set.n; ++k) genes[at++] = set.get(k);
 		}
 	}
