@@ -480,7 +480,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	HIP_CHECK(hipMemcpyAsync(&queued, worklist_counts + 0, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (queued > 0) {
-		KernelTimer timer(ctx, "attach_discordant_wave_kernel(count)", 0);
+		KernelTimer timer(ctx, "attach_discordant_wave_kernel(count)", (uint64_t) Md * 24 + (uint64_t) queued * 25); // every bucket row read once, one size written per queued candidate
 		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
 	}
 	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
@@ -497,8 +497,10 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(fill)", (uint64_t) C * 25);
 	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, bucket_keys.as<uint64_t>(), buckets, Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true); }
 	if (queued > 0) { // the fill pass queues the same candidates (possibly in another order)
-		// algorithmic bytes: every list entry is produced from one bucket row (two breakpoints, info, read, two anchors) and written once
-		KernelTimer timer(ctx, "attach_discordant_wave_kernel(fill)", (uint64_t) total_list * (24 + 4));
+		// algorithmic bytes: every bucket row (two breakpoints, info, read, two anchors: 24 B) read once, every list entry written once (4 B; total_list
+		// also counts the few split-read entries), the queued candidates' columns.  What the kernel really moves is several times more (PMC): the
+		// candidates of one gene pair scan the same bucket rows one after the other.
+		KernelTimer timer(ctx, "attach_discordant_wave_kernel(fill)", (uint64_t) Md * 24 + (uint64_t) total_list * 4 + (uint64_t) queued * 25);
 		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
 	}
 	{ KernelTimer timer(ctx, "finish_kernel", (uint64_t) C * 53); finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t); }
