@@ -155,6 +155,7 @@ def bind_host_api(lib):
         "ahost_batch_view": (POINTER(BatchView), [session]),
         "ahost_fragment_count": (c_uint64, [session]),
         "ahost_mapped_reads": (c_uint64, [session]),
+        "ahost_coverage_checksum": (c_uint64, [session]),
         "ahost_contig_count": (c_uint32, [session]),
         "ahost_contig_name": (c_char_p, [session, c_uint32]),
         "ahost_fragment_name": (c_void_p, [session, c_uint64, POINTER(c_uint32)]),

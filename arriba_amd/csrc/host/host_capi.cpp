@@ -204,6 +204,17 @@ const agpu_batch_view* ahost_batch_slice_view(ahost_session* session, uint64_t f
 }
 uint64_t ahost_fragment_count(ahost_session* session) { return session->ingest.batch.n; }
 uint64_t ahost_mapped_reads(ahost_session* session) { return session->ingest.mapped_reads; }
+uint64_t ahost_coverage_checksum(ahost_session* session) {
+	uint64_t hash = 1469598103934665603ull;
+	auto mix = [&hash](const uint8_t* bytes, size_t n) { for (size_t i = 0; i < n; ++i) hash = (hash ^ bytes[i]) * 1099511628211ull; };
+	const Coverage& coverage = session->ingest.coverage;
+	for (size_t contig = 0; contig < coverage.coverage.size(); ++contig) {
+		mix((const uint8_t*) coverage.coverage[contig].data(), coverage.coverage[contig].size() * sizeof(uint16_t));
+		if (contig < coverage.fragment_starts.size()) mix(coverage.fragment_starts[contig].data(), coverage.fragment_starts[contig].size());
+		if (contig < coverage.fragment_ends.size()) mix(coverage.fragment_ends[contig].data(), coverage.fragment_ends[contig].size());
+	}
+	return hash;
+}
 uint32_t ahost_contig_count(ahost_session* session) { return session->contigs.size(); }
 const char* ahost_contig_name(ahost_session* session, uint32_t contig) { return contig < session->contigs.original_names.size() ? session->contigs.original_names[contig].c_str() : ""; }
 const char* ahost_fragment_name(ahost_session* session, uint64_t i, uint32_t* length) {

@@ -5,9 +5,17 @@
 #include "arriba_host.h"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <zlib.h>
 
 namespace arriba {
@@ -118,6 +126,27 @@ struct Record { // one decoded BAM alignment record (SAMv1 section 4.2)
 	}
 };
 
+// decodes the block of one alignment record (p points behind block_size)
+void decode_record(const uint8_t* p, uint32_t block_size, Record& r) {
+	r.tid = (int32_t) le32(p);
+	r.pos = (int32_t) le32(p + 4);
+	uint32_t l_read_name = p[8];
+	uint32_t n_cigar = le16(p + 12);
+	r.flag = le16(p + 14);
+	r.l_seq = (int32_t) le32(p + 16);
+	const uint8_t* q = p + 32;
+	size_t fixed = (size_t) l_read_name + 4 * (size_t) n_cigar + ((size_t) r.l_seq + 1) / 2 + (size_t) r.l_seq;
+	if (32 + fixed > block_size) throw std::runtime_error("failed to load alignments");
+	r.qname.assign((const char*) q, strnlen((const char*) q, l_read_name));
+	q += l_read_name;
+	r.cigar.resize(n_cigar);
+	for (uint32_t i = 0; i < n_cigar; ++i) r.cigar[i] = le32(q + 4 * i);
+	q += 4 * n_cigar;
+	r.seq.assign(q, q + (r.l_seq + 1) / 2);
+	q += (r.l_seq + 1) / 2 + r.l_seq;
+	r.aux.assign(q, p + block_size);
+}
+
 class BamStream {
 public:
 	explicit BamStream(ByteSource& source): source_(source), begin_(0), end_(0), eof_(false) { buffer_.resize(8u << 20); }
@@ -152,31 +181,15 @@ public:
 			consume(l_name + 4);
 		}
 	}
-	bool next(Record& r) { // false at clean end of stream
+	// the next record as raw bytes (block_size + block, valid until the next call); false at clean end of stream
+	bool next_raw(const uint8_t*& record, uint32_t& block_size) {
 		if (!need(4)) {
 			if (available() == 0) return false;
 			throw std::runtime_error("failed to load alignments");
 		}
-		uint32_t block_size = le32(data());
+		block_size = le32(data());
 		if (block_size < 32 || !need(4 + (size_t) block_size)) throw std::runtime_error("failed to load alignments");
-		const uint8_t* p = data() + 4;
-		r.tid = (int32_t) le32(p);
-		r.pos = (int32_t) le32(p + 4);
-		uint32_t l_read_name = p[8];
-		uint32_t n_cigar = le16(p + 12);
-		r.flag = le16(p + 14);
-		r.l_seq = (int32_t) le32(p + 16);
-		const uint8_t* q = p + 32;
-		size_t fixed = (size_t) l_read_name + 4 * (size_t) n_cigar + ((size_t) r.l_seq + 1) / 2 + (size_t) r.l_seq;
-		if (32 + fixed > block_size) throw std::runtime_error("failed to load alignments");
-		r.qname.assign((const char*) q, strnlen((const char*) q, l_read_name));
-		q += l_read_name;
-		r.cigar.resize(n_cigar);
-		for (uint32_t i = 0; i < n_cigar; ++i) r.cigar[i] = le32(q + 4 * i);
-		q += 4 * n_cigar;
-		r.seq.assign(q, q + (r.l_seq + 1) / 2);
-		q += (r.l_seq + 1) / 2 + r.l_seq;
-		r.aux.assign(q, p + block_size);
+		record = data();
 		consume(4 + (size_t) block_size);
 		return true;
 	}
@@ -566,6 +579,13 @@ bool is_pristine_alignment(const Record& r) {
 
 // reference: source/read_stats.cpp:161-266.  flag1 is mate1's flag word as the caller left it (the
 // reference zeroes it for discordant mates, source/read_chimeric_alignments.cpp:664).
+// The coverage windows are shared by the ingest workers: +1 with saturation commutes, so relaxed atomics give the sequential result.
+inline void increment_saturating(uint16_t& window) {
+	uint16_t seen = __atomic_load_n(&window, __ATOMIC_RELAXED);
+	while (seen < 65535 && !__atomic_compare_exchange_n(&window, &seen, (uint16_t) (seen + 1), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+inline void set_flag(uint8_t& flag) { __atomic_store_n(&flag, (uint8_t) 1, __ATOMIC_RELAXED); }
+
 void add_fragment_to_coverage(Coverage& coverage, const Record& mate1, uint16_t flag1, const Record* mate2_or_null, bool is_chimeric) {
 	const Record& mate2 = (mate2_or_null == NULL) ? mate1 : *mate2_or_null;
 	uint16_t flag2 = (mate2_or_null == NULL) ? flag1 : mate2.flag;
@@ -578,9 +598,9 @@ void add_fragment_to_coverage(Coverage& coverage, const Record& mate1, uint16_t 
 		is_chimeric = true;
 	if (!is_chimeric) {
 		if (!(flag1 & BAM_FREVERSE) || !(flag1 & BAM_FPAIRED))
-			coverage.fragment_starts[mate1.tid][mate1.pos / COVERAGE_RESOLUTION] = 1;
+			set_flag(coverage.fragment_starts[mate1.tid][mate1.pos / COVERAGE_RESOLUTION]);
 		else
-			coverage.fragment_starts[mate2.tid][mate2.pos / COVERAGE_RESOLUTION] = 1;
+			set_flag(coverage.fragment_starts[mate2.tid][mate2.pos / COVERAGE_RESOLUTION]);
 	}
 	position_t position1 = mate1.pos, position2 = mate2.pos;
 	position_t position = std::min(position1, position2);
@@ -619,9 +639,8 @@ void add_fragment_to_coverage(Coverage& coverage, const Record& mate1, uint16_t 
 		std::vector<uint16_t>& windows = coverage.coverage[contig];
 		if (cigar_consumes_query(cigar_op(op))) {
 			while (window <= position / COVERAGE_RESOLUTION) {
-				if (window >= 0 && (size_t) window < windows.size() && windows[window] < 65535)
-					if (position - window * COVERAGE_RESOLUTION >= COVERAGE_RESOLUTION / 2)
-						windows[window]++;
+				if (window >= 0 && (size_t) window < windows.size() && position - window * COVERAGE_RESOLUTION >= COVERAGE_RESOLUTION / 2)
+					increment_saturating(windows[window]); // the reference tests `< 65535` first and then the half window: same result
 				++window;
 			}
 		} else {
@@ -630,9 +649,9 @@ void add_fragment_to_coverage(Coverage& coverage, const Record& mate1, uint16_t 
 	}
 	if (!is_chimeric) {
 		if ((flag1 & BAM_FREVERSE) || !(flag1 & BAM_FPAIRED))
-			coverage.fragment_ends[mate1.tid][(position1 - 1) / COVERAGE_RESOLUTION] = 1;
+			set_flag(coverage.fragment_ends[mate1.tid][(position1 - 1) / COVERAGE_RESOLUTION]);
 		else
-			coverage.fragment_ends[mate2.tid][(position2 - 1) / COVERAGE_RESOLUTION] = 1;
+			set_flag(coverage.fragment_ends[mate2.tid][(position2 - 1) / COVERAGE_RESOLUTION]);
 	}
 }
 
@@ -643,7 +662,19 @@ uint8_t encode_base(char c) {
 	}
 }
 
-void pack_batch(std::vector<std::pair<const std::string*, Fragment*> >& sorted, Batch& batch) {
+// runs body(first, last) over [0, n) cut into one range per thread
+template <class Body> void parallel_ranges(size_t n, unsigned int n_threads, const Body& body, size_t min_items = 4096) {
+	if (n_threads <= 1 || n < min_items) { body((size_t) 0, n); return; }
+	std::vector<std::thread> threads;
+	for (unsigned int t = 0; t < n_threads; ++t)
+		threads.push_back(std::thread([&body, n, n_threads, t] { body(n * t / n_threads, n * (t + 1) / n_threads); }));
+	for (unsigned int t = 0; t < n_threads; ++t)
+		threads[t].join();
+}
+
+// Two passes: the offsets of every fragment inside the pools (names, CIGARs, sequences) are a running sum over the fragments in name
+// order; with them every fragment can be written independently, so the columns and pools are allocated once and filled by all threads.
+void pack_batch(std::vector<std::pair<const std::string*, Fragment*> >& sorted, Batch& batch, unsigned int n_threads) {
 	size_t n = sorted.size();
 	batch.n = n;
 	batch.n_aln.resize(n); batch.fbits.resize(n); batch.filter.assign(n, FILTER_none); batch.group.resize(n);
@@ -653,108 +684,130 @@ void pack_batch(std::vector<std::pair<const std::string*, Fragment*> >& sorted, 
 	}
 	for (int s = 0; s < 2; ++s) { batch.seq_offset[s].assign(n, 0); batch.seq_length[s].assign(n, 0); }
 	batch.name_offset.assign(n + 1, 0);
+	std::vector<size_t> cigar_base(n + 1, 0), seq_base(n + 1, 0); // seq_base in bytes
+	std::vector<uint32_t> name_length(n), cigar_length(n), seq_bytes(n);
+	std::vector<uint8_t> new_group(n, 0);
+	parallel_ranges(n, n_threads, [&sorted, &name_length, &cigar_length, &seq_bytes, &new_group](size_t first, size_t last) {
+		for (size_t i = first; i < last; ++i) {
+			const std::string& name = *sorted[i].first;
+			const Fragment& f = *sorted[i].second;
+			name_length[i] = name.size();
+			// multimapper groups: identical names up to the last ',' (source/common.hpp:222)
+			if (i > 0) {
+				const std::string& previous = *sorted[i - 1].first;
+				size_t a = name.find_last_of(','), b = previous.find_last_of(',');
+				new_group[i] = !(name.compare(0, a, previous, 0, b) == 0);
+			}
+			uint32_t cigar_words = 0, bytes = 0;
+			for (size_t s = 0; s < f.alignments.size(); ++s) {
+				cigar_words += f.alignments[s].cigar.size();
+				if (s < 2) bytes += (((f.alignments[s].sequence.size() + 1) / 2) + 3) & ~(size_t) 3;
+			}
+			cigar_length[i] = cigar_words; seq_bytes[i] = bytes;
+		}
+	});
+	size_t names_size = 0, cigar_size = 0, seq_size = 0;
 	uint32_t group = 0;
 	for (size_t i = 0; i < n; ++i) {
-		const std::string& name = *sorted[i].first;
-		const Fragment& f = *sorted[i].second;
-		batch.name_offset[i] = batch.names.size();
-		batch.names += name;
-		// multimapper groups: identical names up to the last ',' (source/common.hpp:222)
-		if (i > 0) {
-			const std::string& previous = *sorted[i - 1].first;
-			size_t a = name.find_last_of(','), b = previous.find_last_of(',');
-			if (!(name.compare(0, a, previous, 0, b) == 0))
-				++group;
-		}
-		batch.group[i] = group;
-		batch.n_aln[i] = f.alignments.size();
-		batch.fbits[i] = (f.single_end ? FBIT_SINGLE_END : 0) | (f.duplicate ? FBIT_DUPLICATE : 0);
-		for (size_t s = 0; s < f.alignments.size(); ++s) {
-			const Alignment& a = f.alignments[s];
-			batch.contig[s][i] = a.contig; batch.start[s][i] = a.start; batch.end[s][i] = a.end;
-			batch.abits[s][i] = (a.strand ? ABIT_STRAND : 0) | (a.first_in_pair ? ABIT_FIRST_IN_PAIR : 0) | (a.supplementary ? ABIT_SUPPLEMENTARY : 0) | ABIT_PREDICTED_STRAND_AMBIGUOUS;
-			batch.cigar_offset[s][i] = batch.cigar_pool.size();
-			batch.cigar_count[s][i] = a.cigar.size();
-			batch.cigar_pool.insert(batch.cigar_pool.end(), a.cigar.begin(), a.cigar.end());
-			if (s < 2) {
-				batch.seq_offset[s][i] = batch.seq_pool.size() / 4;
-				batch.seq_length[s][i] = a.sequence.size();
-				size_t bytes = (a.sequence.size() + 1) / 2;
-				size_t base = batch.seq_pool.size();
-				batch.seq_pool.resize(base + ((bytes + 3) & ~(size_t) 3), 0);
-				for (size_t b = 0; b < a.sequence.size(); ++b)
-					batch.seq_pool[base + (b >> 1)] |= encode_base(a.sequence[b]) << ((~b & 1) << 2);
+		batch.name_offset[i] = names_size; names_size += name_length[i];
+		group += new_group[i]; batch.group[i] = group;
+		cigar_base[i] = cigar_size; cigar_size += cigar_length[i];
+		seq_base[i] = seq_size; seq_size += seq_bytes[i];
+	}
+	batch.name_offset[n] = names_size;
+	if (names_size >= 0xFFFFFFFFull || cigar_size >= 0xFFFFFFFFull || seq_size / 4 >= 0xFFFFFFFFull)
+		throw std::runtime_error("batch too large for 32-bit pool offsets");
+	batch.names.assign(names_size, ' ');
+	batch.cigar_pool.assign(cigar_size, 0);
+	batch.seq_pool.assign(seq_size, 0);
+	parallel_ranges(n, n_threads, [&sorted, &batch, &cigar_base, &seq_base](size_t first, size_t last) {
+		for (size_t i = first; i < last; ++i) {
+			const std::string& name = *sorted[i].first;
+			const Fragment& f = *sorted[i].second;
+			memcpy(&batch.names[batch.name_offset[i]], name.data(), name.size());
+			batch.n_aln[i] = f.alignments.size();
+			batch.fbits[i] = (f.single_end ? FBIT_SINGLE_END : 0) | (f.duplicate ? FBIT_DUPLICATE : 0);
+			size_t cigar_at = cigar_base[i], seq_at = seq_base[i];
+			for (size_t s = 0; s < f.alignments.size(); ++s) {
+				const Alignment& a = f.alignments[s];
+				batch.contig[s][i] = a.contig; batch.start[s][i] = a.start; batch.end[s][i] = a.end;
+				batch.abits[s][i] = (a.strand ? ABIT_STRAND : 0) | (a.first_in_pair ? ABIT_FIRST_IN_PAIR : 0) | (a.supplementary ? ABIT_SUPPLEMENTARY : 0) | ABIT_PREDICTED_STRAND_AMBIGUOUS;
+				batch.cigar_offset[s][i] = cigar_at;
+				batch.cigar_count[s][i] = a.cigar.size();
+				if (!a.cigar.empty()) memcpy(&batch.cigar_pool[cigar_at], a.cigar.data(), a.cigar.size() * sizeof(uint32_t));
+				cigar_at += a.cigar.size();
+				if (s < 2) {
+					batch.seq_offset[s][i] = seq_at / 4;
+					batch.seq_length[s][i] = a.sequence.size();
+					for (size_t b = 0; b < a.sequence.size(); ++b)
+						batch.seq_pool[seq_at + (b >> 1)] |= encode_base(a.sequence[b]) << ((~b & 1) << 2);
+					seq_at += (((a.sequence.size() + 1) / 2) + 3) & ~(size_t) 3;
+				}
 			}
 		}
-	}
-	batch.name_offset[n] = batch.names.size();
+	});
 }
 
 }
 
-// reference: source/read_chimeric_alignments.cpp:560-773
-void read_chimeric_alignments(ByteSource& source, const Assembly& assembly, Contigs& contigs, const Annotation& annotation, const FlatIndex& gene_index, const IngestOptions& options, IngestResult& result) {
-	BamStream stream(source);
-	std::vector<std::string> target_names;
-	stream.read_header(target_names);
+namespace {
 
-	std::vector<contig_t> tid_to_contig(target_names.size());
-	std::vector<bool> interesting_tids(target_names.size());
-	for (size_t target = 0; target < target_names.size(); ++target) {
-		std::string contig_name = remove_chr(target_names[target]);
-		tid_to_contig[target] = contigs.add(target_names[target]);
-		if (tid_to_contig[target] >= interesting_tids.size())
-			interesting_tids.resize(tid_to_contig[target] + 1);
-		interesting_tids[tid_to_contig[target]] = is_interesting_contig(contig_name, options.interesting_contigs);
-	}
-	result.coverage.resize(contigs, assembly);
-	for (std::map<std::string, contig_t>::const_iterator contig = contigs.by_name.begin(); contig != contigs.by_name.end(); ++contig)
-		if (!assembly.has(contig->second) && is_interesting_contig(contig->first, options.interesting_contigs))
-			throw std::runtime_error("could not find sequence of contig '" + contig->first + "'");
-	std::vector<bool> viral_contigs(contigs.size());
-	for (std::map<std::string, contig_t>::const_iterator contig = contigs.by_name.begin(); contig != contigs.by_name.end(); ++contig)
-		viral_contigs[contig->second] = is_interesting_contig(contig->first, options.viral_contigs);
-	result.mapped_viral_reads_by_contig.assign(contigs.size(), 0);
+// ---- the classification of the records (reference: the loop body of read_chimeric_alignments, source/read_chimeric_alignments.cpp:585-757) ----
+// Everything a record does depends only on the records of the same read name that came before it (the parked first mate, the fragment's
+// alignment list) and on shared read-only data; the counters and the coverage commute.  So the stream can be dealt to several workers by
+// the hash of the read name: every worker sees the records of its names in stream order and keeps its own tables.
+struct IngestShared {
+	const Assembly& assembly; const Annotation& annotation; const FlatIndex& gene_index; const IngestOptions& options;
+	std::vector<contig_t> tid_to_contig; std::vector<bool> interesting_tids, viral_contigs;
+	Coverage& coverage;
+};
 
+struct IngestWorker {
+	const IngestShared& shared;
 	fragment_table_t fragments;
 	std::unordered_map<std::string, Record> collated; // first mate parked until the second arrives
 	bool no_chimeric_reads = true;
-	Record record;
+	uint64_t mapped_reads = 0;
+	std::vector<uint64_t> mapped_viral_reads_by_contig;
+	unsigned int malformed_count = 0, missing_hi_tag = 0;
+	std::vector<std::pair<const std::string*, Fragment*> > sorted; // the valid fragments of this worker in name order (finish())
 	std::string read_name;
-	while (stream.next(record)) {
-		result.records++;
+	explicit IngestWorker(const IngestShared& shared_state, size_t n_contigs): shared(shared_state), mapped_viral_reads_by_contig(n_contigs, 0) {}
+
+	void process(Record& record) {
+		const IngestOptions& options = shared.options;
 		if ((record.flag & BAM_FUNMAP) || (record.flag & BAM_FPAIRED) && (record.flag & BAM_FMUNMAP))
-			continue;
+			return;
 		int64_t hit_index = 1;
 		const uint8_t* hi_tag = record.aux_get('H', 'I');
 		if (hi_tag != NULL) {
 			hit_index = Record::aux_to_int(hi_tag);
 		} else if (record.flag & BAM_FSECONDARY) {
-			result.missing_hi_tag++;
-			continue;
+			missing_hi_tag++;
+			return;
 		}
 		read_name = record.qname;
 		read_name += "," + std::to_string(hit_index);
-		if (record.tid < 0 || (size_t) record.tid >= tid_to_contig.size())
+		if (record.tid < 0 || (size_t) record.tid >= shared.tid_to_contig.size())
 			throw std::runtime_error("failed to load alignments");
-		record.tid = tid_to_contig[record.tid];
+		record.tid = shared.tid_to_contig[record.tid];
 
 		if (record.flag & BAM_FSUPPLEMENTARY) {
 			if (is_clipped_at_correct_end(record))
 				add_chimeric_alignment(fragments[read_name], record, true);
 			else
-				result.malformed_count++;
+				malformed_count++;
 			no_chimeric_reads = false;
-			continue;
+			return;
 		}
-		if (interesting_tids[record.tid])
-			result.mapped_reads++;
+		if (shared.interesting_tids[record.tid])
+			mapped_reads++;
 		if ((record.flag & BAM_FPAIRED) && !(record.flag & BAM_FPROPER_PAIR)) {
 			add_chimeric_alignment(fragments[read_name], record);
 			no_chimeric_reads = false;
 			if (!options.external_duplicate_marking || !(record.flag & BAM_FDUP))
-				add_fragment_to_coverage(result.coverage, record, 0 /* flag &= !BAM_FPAIRED zeroes the word */, NULL, true);
-			continue;
+				add_fragment_to_coverage(shared.coverage, record, 0 /* flag &= !BAM_FPAIRED zeroes the word */, NULL, true);
+			return;
 		}
 
 		Record previous;
@@ -763,9 +816,9 @@ void read_chimeric_alignments(ByteSource& source, const Assembly& assembly, Cont
 			std::unordered_map<std::string, Record>::iterator parked = collated.find(read_name);
 			if (parked == collated.end()) {
 				collated.insert(std::make_pair(read_name, record));
-				continue; // first mate: wait for the second
+				return; // first mate: wait for the second
 			}
-			previous = parked->second;
+			previous = std::move(parked->second);
 			have_previous = true;
 			collated.erase(parked);
 		}
@@ -775,7 +828,7 @@ void read_chimeric_alignments(ByteSource& source, const Assembly& assembly, Cont
 		Alignment tandem;
 		if (!clipped_sequence_is_adapter(&record, previous_mate) &&
 		    (previous_mate == NULL || record.forward_strand() != previous_mate->forward_strand()) &&
-		    (is_tandem_duplication(&record, assembly, options.max_itd_length, tandem) || is_tandem_duplication(previous_mate, assembly, options.max_itd_length, tandem))) {
+		    (is_tandem_duplication(&record, shared.assembly, options.max_itd_length, tandem) || is_tandem_duplication(previous_mate, shared.assembly, options.max_itd_length, tandem))) {
 			Fragment& mates = fragments[read_name + "ITD"];
 			add_chimeric_alignment(mates, record, record.forward_strand() == tandem.strand && !tandem.supplementary);
 			if (previous_mate != NULL)
@@ -793,36 +846,213 @@ void read_chimeric_alignments(ByteSource& source, const Assembly& assembly, Cont
 				add_chimeric_alignment(mates, *previous_mate);
 			no_chimeric_reads = false;
 		} else if (!is_tandem_alignment) {
-			is_read_through = extract_read_through_alignment(fragments, read_name, &record, previous_mate, annotation, gene_index);
-			if (viral_contigs[record.tid])
+			is_read_through = extract_read_through_alignment(fragments, read_name, &record, previous_mate, shared.annotation, shared.gene_index);
+			if (shared.viral_contigs[record.tid])
 				for (const Record* mate = &record; mate != NULL; mate = (mate == previous_mate) ? NULL : previous_mate)
 					if (is_pristine_alignment(*mate))
-						result.mapped_viral_reads_by_contig[mate->tid]++;
+						mapped_viral_reads_by_contig[mate->tid]++;
 		}
 		if (!options.external_duplicate_marking || !(record.flag & BAM_FDUP))
-			add_fragment_to_coverage(result.coverage, record, record.flag, previous_mate, is_read_through);
+			add_fragment_to_coverage(shared.coverage, record, record.flag, previous_mate, is_read_through);
 	}
 
+	// sanity check + slot normalisation, then the worker's fragments in name order (hazard H3: std::string order of "QNAME,HI")
+	void finish() {
+		collated.clear();
+		sorted.reserve(fragments.size());
+		for (fragment_table_t::iterator fragment = fragments.begin(); fragment != fragments.end(); ++fragment) {
+			if (normalize_fragment(fragment->second))
+				sorted.push_back(std::make_pair(&fragment->first, &fragment->second));
+			else
+				malformed_count++;
+		}
+		std::sort(sorted.begin(), sorted.end(), [](const std::pair<const std::string*, Fragment*>& a, const std::pair<const std::string*, Fragment*>& b) { return *a.first < *b.first; });
+	}
+};
+
+// a bounded queue of byte chunks (concatenated raw records) from the reader to one worker
+struct ChunkQueue {
+	std::mutex mutex;
+	std::condition_variable not_empty, not_full;
+	std::deque<std::vector<uint8_t> > chunks;
+	bool closed = false;
+	void push(std::vector<uint8_t>&& chunk) {
+		std::unique_lock<std::mutex> lock(mutex);
+		not_full.wait(lock, [this] { return chunks.size() < 8; });
+		chunks.push_back(std::move(chunk));
+		not_empty.notify_one();
+	}
+	void close() { std::unique_lock<std::mutex> lock(mutex); closed = true; not_empty.notify_all(); }
+	bool pop(std::vector<uint8_t>& chunk) {
+		std::unique_lock<std::mutex> lock(mutex);
+		not_empty.wait(lock, [this] { return !chunks.empty() || closed; });
+		if (chunks.empty()) return false;
+		chunk = std::move(chunks.front());
+		chunks.pop_front();
+		not_full.notify_one();
+		return true;
+	}
+};
+
+unsigned int ingest_threads() { // ARRIBA_INGEST_THREADS overrides; the reader is one more thread
+	const char* setting = getenv("ARRIBA_INGEST_THREADS");
+	if (setting != NULL && atoi(setting) > 0) return (unsigned int) atoi(setting);
+	unsigned int cores = std::thread::hardware_concurrency();
+	return std::max(1u, std::min(16u, cores > 1 ? cores - 1 : 1u));
+}
+
+}
+
+// reference: source/read_chimeric_alignments.cpp:560-773
+void read_chimeric_alignments(ByteSource& source, const Assembly& assembly, Contigs& contigs, const Annotation& annotation, const FlatIndex& gene_index, const IngestOptions& options, IngestResult& result) {
+	BamStream stream(source);
+	std::vector<std::string> target_names;
+	stream.read_header(target_names);
+
+	IngestShared shared = { assembly, annotation, gene_index, options, std::vector<contig_t>(target_names.size()), std::vector<bool>(target_names.size()), std::vector<bool>(), result.coverage };
+	for (size_t target = 0; target < target_names.size(); ++target) {
+		std::string contig_name = remove_chr(target_names[target]);
+		shared.tid_to_contig[target] = contigs.add(target_names[target]);
+		if (shared.tid_to_contig[target] >= shared.interesting_tids.size())
+			shared.interesting_tids.resize(shared.tid_to_contig[target] + 1);
+		shared.interesting_tids[shared.tid_to_contig[target]] = is_interesting_contig(contig_name, options.interesting_contigs);
+	}
+	result.coverage.resize(contigs, assembly);
+	for (std::map<std::string, contig_t>::const_iterator contig = contigs.by_name.begin(); contig != contigs.by_name.end(); ++contig)
+		if (!assembly.has(contig->second) && is_interesting_contig(contig->first, options.interesting_contigs))
+			throw std::runtime_error("could not find sequence of contig '" + contig->first + "'");
+	shared.viral_contigs.resize(contigs.size());
+	for (std::map<std::string, contig_t>::const_iterator contig = contigs.by_name.begin(); contig != contigs.by_name.end(); ++contig)
+		shared.viral_contigs[contig->second] = is_interesting_contig(contig->first, options.viral_contigs);
+
+	const unsigned int n_workers = ingest_threads();
+	const bool timing = getenv("ARRIBA_INGEST_TIMING") != NULL;
+	const std::chrono::steady_clock::time_point started = std::chrono::steady_clock::now();
+	auto lap = [&started, timing](const char* phase) { if (timing) std::cerr << "ingest: " << phase << " at " << std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count() << " s" << std::endl; };
+	std::vector<std::unique_ptr<IngestWorker> > workers;
+	for (unsigned int w = 0; w < n_workers; ++w)
+		workers.push_back(std::unique_ptr<IngestWorker>(new IngestWorker(shared, contigs.size())));
+
+	const uint8_t* raw;
+	uint32_t block_size;
+	if (n_workers == 1) {
+		Record record;
+		while (stream.next_raw(raw, block_size)) {
+			result.records++;
+			decode_record(raw + 4, block_size, record);
+			workers[0]->process(record);
+		}
+		workers[0]->finish();
+	} else {
+		// the reader only cuts the stream into records and deals them out by the hash of the read name; the workers decode and classify
+		std::vector<std::unique_ptr<ChunkQueue> > queues;
+		std::vector<std::exception_ptr> failures(n_workers);
+		std::vector<std::thread> threads;
+		for (unsigned int w = 0; w < n_workers; ++w)
+			queues.push_back(std::unique_ptr<ChunkQueue>(new ChunkQueue()));
+		for (unsigned int w = 0; w < n_workers; ++w)
+			threads.push_back(std::thread([w, &workers, &queues, &failures] {
+				std::vector<uint8_t> chunk;
+				Record record;
+				bool failed = false;
+				while (queues[w]->pop(chunk)) {
+					if (failed) continue; // keep draining so that the reader never blocks
+					try {
+						for (size_t at = 0; at < chunk.size(); ) {
+							uint32_t size = le32(&chunk[at]);
+							decode_record(&chunk[at + 4], size, record);
+							workers[w]->process(record);
+							at += 4 + (size_t) size;
+						}
+					} catch (...) { failures[w] = std::current_exception(); failed = true; }
+				}
+				if (!failed) {
+					try { workers[w]->finish(); } catch (...) { failures[w] = std::current_exception(); }
+				}
+			}));
+		const size_t chunk_bytes = 1u << 20;
+		std::vector<std::vector<uint8_t> > filling(n_workers);
+		std::exception_ptr reader_failure;
+		try {
+			while (stream.next_raw(raw, block_size)) {
+				result.records++;
+				const uint32_t l_read_name = raw[4 + 8];
+				if (36 + (size_t) l_read_name > 4 + (size_t) block_size) throw std::runtime_error("failed to load alignments");
+				uint64_t hash = 1469598103934665603ull; // FNV-1a over the read name
+				for (const uint8_t* c = raw + 36; c < raw + 36 + l_read_name && *c; ++c) hash = (hash ^ *c) * 1099511628211ull;
+				std::vector<uint8_t>& chunk = filling[(hash >> 17) % n_workers];
+				if (chunk.capacity() == 0) chunk.reserve(chunk_bytes + (64u << 10));
+				chunk.insert(chunk.end(), raw, raw + 4 + (size_t) block_size);
+				if (chunk.size() >= chunk_bytes) {
+					const unsigned int w = (unsigned int) (&chunk - &filling[0]);
+					queues[w]->push(std::move(chunk));
+					chunk = std::vector<uint8_t>();
+				}
+			}
+		} catch (...) { reader_failure = std::current_exception(); }
+		lap("stream cut into records and dealt out");
+		for (unsigned int w = 0; w < n_workers; ++w) {
+			if (!filling[w].empty() && !reader_failure) queues[w]->push(std::move(filling[w]));
+			queues[w]->close();
+		}
+		for (unsigned int w = 0; w < n_workers; ++w)
+			threads[w].join();
+		if (reader_failure) std::rethrow_exception(reader_failure);
+		for (unsigned int w = 0; w < n_workers; ++w)
+			if (failures[w]) std::rethrow_exception(failures[w]);
+	}
+
+	lap("records classified, fragments normalised and sorted per worker");
+	bool no_chimeric_reads = true;
+	result.mapped_viral_reads_by_contig.assign(contigs.size(), 0);
+	size_t n_fragments = 0;
+	for (unsigned int w = 0; w < n_workers; ++w) {
+		const IngestWorker& worker = *workers[w];
+		result.mapped_reads += worker.mapped_reads;
+		result.malformed_count += worker.malformed_count;
+		result.missing_hi_tag += worker.missing_hi_tag;
+		no_chimeric_reads = no_chimeric_reads && worker.no_chimeric_reads;
+		for (size_t contig = 0; contig < worker.mapped_viral_reads_by_contig.size(); ++contig)
+			result.mapped_viral_reads_by_contig[contig] += worker.mapped_viral_reads_by_contig[contig];
+		n_fragments += worker.sorted.size();
+	}
 	if (result.mapped_reads == 0)
 		throw std::runtime_error("no normal reads found");
-
-	// sanity check + slot normalisation, then order by name (hazard H3: std::string order of "QNAME,HI")
-	std::vector<std::pair<const std::string*, Fragment*> > sorted;
-	sorted.reserve(fragments.size());
-	for (fragment_table_t::iterator fragment = fragments.begin(); fragment != fragments.end(); ++fragment) {
-		if (normalize_fragment(fragment->second))
-			sorted.push_back(std::make_pair(&fragment->first, &fragment->second));
-		else
-			result.malformed_count++;
-	}
 	if (result.malformed_count > 0)
 		std::cerr << "WARNING: " << result.malformed_count << " SAM records were malformed and ignored" << std::endl;
 	if (no_chimeric_reads)
 		throw std::runtime_error("no split reads or discordant mates found (STAR must either be run with '--chimOutType WithinBAM' or the file 'Chimeric.out.sam' must be passed to Arriba via the argument -c)");
 	if (result.missing_hi_tag > 0)
 		std::cerr << "WARNING: " << result.missing_hi_tag << " secondary alignments lack the 'HI' tag and were ignored (STAR must be run with '--outSAMattributes HI' for Arriba to make use of multi-mapping reads for fusion detection)" << std::endl;
-	std::sort(sorted.begin(), sorted.end(), [](const std::pair<const std::string*, Fragment*>& a, const std::pair<const std::string*, Fragment*>& b) { return *a.first < *b.first; });
-	pack_batch(sorted, result.batch);
+
+	// merge of the workers' name-sorted lists (names are unique across workers)
+	std::vector<std::pair<const std::string*, Fragment*> > sorted;
+	sorted.reserve(n_fragments);
+	if (n_workers == 1) {
+		sorted.swap(workers[0]->sorted);
+	} else {
+		typedef std::pair<const std::string*, Fragment*> Entry;
+		std::vector<size_t> cursor(n_workers, 0);
+		auto later = [&workers, &cursor](unsigned int a, unsigned int b) { return *workers[b]->sorted[cursor[b]].first < *workers[a]->sorted[cursor[a]].first; };
+		std::vector<unsigned int> heap;
+		for (unsigned int w = 0; w < n_workers; ++w)
+			if (!workers[w]->sorted.empty()) heap.push_back(w);
+		std::make_heap(heap.begin(), heap.end(), later);
+		while (!heap.empty()) {
+			std::pop_heap(heap.begin(), heap.end(), later);
+			const unsigned int w = heap.back();
+			const Entry& entry = workers[w]->sorted[cursor[w]];
+			sorted.push_back(entry);
+			if (++cursor[w] < workers[w]->sorted.size()) std::push_heap(heap.begin(), heap.end(), later);
+			else heap.pop_back();
+		}
+	}
+	lap("lists merged");
+	pack_batch(sorted, result.batch, n_workers);
+	lap("batch packed");
+	// the tables are millions of heap nodes: every worker's table is freed by a thread of its own
+	parallel_ranges(n_workers, n_workers > 1 ? n_workers : 0, [&workers](size_t first, size_t last) { for (size_t w = first; w < last; ++w) workers[w].reset(); }, 2);
+	lap("tables freed");
 }
 
 }

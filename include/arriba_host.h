@@ -40,6 +40,9 @@ const agpu_batch_view* ahost_batch_slice_view(ahost_session* session, uint64_t f
 
 uint64_t ahost_fragment_count(ahost_session* session);
 uint64_t ahost_mapped_reads(ahost_session* session);
+/* FNV-1a over coverage_t as the ingest built it (coverage windows, fragment start/end flags of every contig; reference: coverage_t,
+ * source/read_stats.hpp:17-27) -- a fingerprint for tests and for comparing runs, e.g. with different numbers of ingest threads. */
+uint64_t ahost_coverage_checksum(ahost_session* session);
 uint32_t ahost_contig_count(ahost_session* session);
 const char* ahost_contig_name(ahost_session* session, uint32_t contig);
 /* "QNAME,HI" of fragment i (the reference's map key); valid until the session is closed */

@@ -77,6 +77,47 @@ def test_device_logic_on_host_matches_reference(name, dataset_files, emu_api):
         assert pipeline.scalars["estimated"] and pipeline.scalars["mate_gap_samples"] >= 10000
 
 
+def _batch_columns(session):
+    """every column of the packed batch as bytes (the pointers of the C view copied out), plus the scalars of the ingest"""
+    import ctypes
+    view = session.batch_view.contents
+    n = int(view.n)
+    columns = {"n": n, "mapped_reads": session.mapped_reads, "names": session.fragment_names()}
+    for name, width in (("n_aln", 1), ("fbits", 1), ("group", 4)):
+        columns[name] = ctypes.string_at(getattr(view, name), n * width)
+    for slot in range(3):
+        for name, width in (("contig", 2), ("start", 4), ("end", 4), ("abits", 1), ("cigar_offset", 4), ("cigar_count", 2)):
+            columns["%s%d" % (name, slot)] = ctypes.string_at(getattr(view, name)[slot], n * width)
+    for slot in range(2):
+        for name in ("seq_offset", "seq_length"):
+            columns["%s%d" % (name, slot)] = ctypes.string_at(getattr(view, name)[slot], n * 4)
+    columns["cigar_pool"] = ctypes.string_at(view.cigar_pool, int(view.cigar_pool_size) * 4)
+    columns["seq_pool"] = ctypes.string_at(view.seq_pool, int(view.seq_pool_size))
+    return columns
+
+
+def test_ingest_with_several_threads_equals_single_threaded(built, tmp_path, monkeypatch):
+    """The reader deals the records to the workers by the hash of the read name (arriba_amd/csrc/host/ingest.cpp); batch, counters and the
+    coverage-dependent verdicts must not depend on the number of workers.  Shuffled names and separated mates: the first mate waits parked."""
+    spec = {"args": ["--seed", "17", "--fragments", "40000", "--normal-mult", "0.5", "--contigs", "5", "--contig-len", "400000", "--junctions", "400", "--dup", "0.2", "--shuffle", "--separate-mates"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    results = []
+    for threads in ("1", "2", "5"):
+        monkeypatch.setenv("ARRIBA_INGEST_THREADS", threads)
+        session = parity.open_session(prefix)
+        columns = _batch_columns(session)
+        pairs = np.array([[c, 0] for c in range(len(session.contig_names()))], dtype=np.uint32).reshape(-1)
+        top, low = session.viral_verdicts(pairs, np.zeros(4, dtype=np.uint8))  # reads the coverage windows and the per-contig viral read counts
+        columns["verdicts"] = top.tobytes() + low.tobytes()
+        columns["strandedness"] = session.detect_strandedness()
+        columns["coverage"] = int(session._lib.ahost_coverage_checksum(session._session))
+        results.append(columns)
+    assert results[0]["n"] > 30000
+    for other in results[1:]:
+        different = [key for key in results[0] if results[0][key] != other[key]]
+        assert not different, different
+
+
 def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
     """The reference exits with 'no normal reads found' on a BAM without mapped reads (source/read_chimeric_alignments.cpp:759)."""
     import struct
