@@ -150,6 +150,8 @@ def bind_host_api(lib):
         "ahost_close": (None, [session]),
         "ahost_ingest_bam_file": (c_int, [session, c_char_p, c_int, ctypes.c_uint]),
         "ahost_ingest_bam_memory": (c_int, [session, c_void_p, c_size_t, c_int, ctypes.c_uint]),
+        "ahost_save_ingest": (c_int, [session, c_char_p]),
+        "ahost_load_ingest": (c_int, [session, c_char_p]),
         "ahost_annotation_view": (POINTER(AnnotationView), [session]),
         "ahost_genome_view": (POINTER(GenomeView), [session]),
         "ahost_batch_view": (POINTER(BatchView), [session]),

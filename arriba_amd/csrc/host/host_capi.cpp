@@ -2,6 +2,8 @@
 // sequential scalar stages that sit between the device stages of the hot path.
 #include "../../../include/arriba_host.h"
 #include "arriba_host.h"
+#include <cstdio>
+#include <cstring>
 
 #include <algorithm>
 #include <cmath>
@@ -150,6 +152,32 @@ bool related_viral_strains(const std::string& virus1, const std::string& virus2)
 
 }
 
+// ---- the ingest result as a file (tooling: repeated benchmark / profiling runs over the same batch skip the parse) ----------------------
+namespace {
+const char INGEST_MAGIC[8] = { 'A', 'R', 'I', 'B', 'I', 'N', 'G', '2' };
+template <class T> void write_vector(FILE* file, const std::vector<T>& values) {
+	uint64_t n = values.size();
+	if (fwrite(&n, sizeof(n), 1, file) != 1 || (n > 0 && fwrite(values.data(), sizeof(T), n, file) != n)) throw std::runtime_error("failed to write the ingest file");
+}
+template <class T> void read_vector(FILE* file, std::vector<T>& values) {
+	uint64_t n = 0;
+	if (fread(&n, sizeof(n), 1, file) != 1) throw std::runtime_error("truncated ingest file");
+	values.resize(n);
+	if (n > 0 && fread(values.data(), sizeof(T), n, file) != n) throw std::runtime_error("truncated ingest file");
+}
+void write_string(FILE* file, const std::string& text) { write_vector(file, std::vector<char>(text.begin(), text.end())); }
+void read_string(FILE* file, std::string& text) { std::vector<char> bytes; read_vector(file, bytes); text.assign(bytes.begin(), bytes.end()); }
+template <class Visit> void visit_ingest(IngestResult& r, Visit& visit) { // the same member order for writing and reading
+	Batch& b = r.batch;
+	visit(b.n_aln); visit(b.fbits); visit(b.filter); visit(b.group);
+	for (int s = 0; s < 3; ++s) { visit(b.contig[s]); visit(b.start[s]); visit(b.end[s]); visit(b.abits[s]); visit(b.cigar_offset[s]); visit(b.cigar_count[s]); }
+	visit(b.cigar_pool);
+	for (int s = 0; s < 2; ++s) { visit(b.seq_offset[s]); visit(b.seq_length[s]); }
+	visit(b.seq_pool); visit(b.name_offset);
+	visit(r.mapped_viral_reads_by_contig);
+}
+}
+
 extern "C" {
 
 const char* ahost_last_error(void) { return g_error.c_str(); }
@@ -180,6 +208,66 @@ int ahost_ingest_bam_file(ahost_session* session, const char* bam_path, int exte
 	try { return ingest(session, open_bam_file(bam_path), external_duplicate_marking, max_itd_length); }
 	catch (const std::exception& e) { g_error = e.what(); return -1; }
 }
+int ahost_save_ingest(ahost_session* session, const char* path) {
+	if (!session || !session->have_batch) { g_error = "no BAM ingested yet"; return -1; }
+	FILE* file = fopen(path, "wb");
+	if (!file) { g_error = std::string("cannot write ") + path; return -1; }
+	try {
+		IngestResult& r = session->ingest;
+		uint64_t scalars[6] = { r.batch.n, r.mapped_reads, r.malformed_count, r.missing_hi_tag, r.records, session->contigs.size() };
+		if (fwrite(INGEST_MAGIC, 8, 1, file) != 1 || fwrite(scalars, sizeof(scalars), 1, file) != 1) throw std::runtime_error("failed to write the ingest file");
+		std::vector<std::string> name_by_id(session->contigs.size());
+		for (std::map<std::string, contig_t>::const_iterator c = session->contigs.by_name.begin(); c != session->contigs.by_name.end(); ++c) name_by_id[c->second] = c->first;
+		for (size_t c = 0; c < name_by_id.size(); ++c) write_string(file, name_by_id[c]);
+		auto write = [file](auto& values) { write_vector(file, values); };
+		visit_ingest(r, write);
+		write_string(file, r.batch.names);
+		uint64_t n_coverage = r.coverage.coverage.size();
+		if (fwrite(&n_coverage, 8, 1, file) != 1) throw std::runtime_error("failed to write the ingest file");
+		for (size_t c = 0; c < n_coverage; ++c) { write_vector(file, r.coverage.coverage[c]); write_vector(file, r.coverage.fragment_starts[c]); write_vector(file, r.coverage.fragment_ends[c]); }
+		if (fclose(file) != 0) { file = NULL; throw std::runtime_error("failed to write the ingest file"); }
+		return 0;
+	} catch (const std::exception& e) {
+		if (file) fclose(file);
+		g_error = e.what();
+		return -1;
+	}
+}
+
+int ahost_load_ingest(ahost_session* session, const char* path) {
+	if (!session) { g_error = "null session"; return -1; }
+	FILE* file = fopen(path, "rb");
+	if (!file) { g_error = std::string("cannot read ") + path; return -1; }
+	try {
+		char magic[8]; uint64_t scalars[6];
+		if (fread(magic, 8, 1, file) != 1 || memcmp(magic, INGEST_MAGIC, 8) != 0 || fread(scalars, sizeof(scalars), 1, file) != 1) throw std::runtime_error("not an ingest file of this version");
+		session->ingest = IngestResult();
+		IngestResult& r = session->ingest;
+		r.batch.n = scalars[0]; r.mapped_reads = scalars[1]; r.malformed_count = (unsigned int) scalars[2]; r.missing_hi_tag = (unsigned int) scalars[3]; r.records = scalars[4];
+		for (uint64_t c = 0; c < scalars[5]; ++c) { // the contigs the BAM header added behind those of the assembly, in the same order
+			std::string name; read_string(file, name);
+			const contig_t id = session->contigs.add(name);
+			if (id != c) throw std::runtime_error("the ingest file was written with another assembly (contig '" + name + "')");
+		}
+		auto read = [file](auto& values) { read_vector(file, values); };
+		visit_ingest(r, read);
+		read_string(file, r.batch.names);
+		uint64_t n_coverage = 0;
+		if (fread(&n_coverage, 8, 1, file) != 1) throw std::runtime_error("truncated ingest file");
+		r.coverage.coverage.resize(n_coverage); r.coverage.fragment_starts.resize(n_coverage); r.coverage.fragment_ends.resize(n_coverage);
+		for (size_t c = 0; c < n_coverage; ++c) { read_vector(file, r.coverage.coverage[c]); read_vector(file, r.coverage.fragment_starts[c]); read_vector(file, r.coverage.fragment_ends[c]); }
+		fclose(file);
+		if (r.batch.n_aln.size() != r.batch.n || r.batch.name_offset.size() != r.batch.n + 1) throw std::runtime_error("inconsistent ingest file");
+		session->build_genome_view();
+		session->build_batch_view();
+		session->have_batch = true;
+		return 0;
+	} catch (const std::exception& e) {
+		g_error = e.what();
+		return -1;
+	}
+}
+
 int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t size, int external_duplicate_marking, unsigned int max_itd_length) {
 	return ingest(session, open_memory_source(data, size), external_duplicate_marking, max_itd_length);
 }

@@ -50,6 +50,16 @@ class HostSession(object):
             raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
         return self.fragment_count
 
+    def save_ingest(self, path):
+        """the ingest result (batch, counters, coverage) as a file; load_ingest() of a session on the same FASTA/GTF restores it without parsing"""
+        if self._lib.ahost_save_ingest(self._session, path.encode()) != 0:
+            raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
+
+    def load_ingest(self, path):
+        if self._lib.ahost_load_ingest(self._session, path.encode()) != 0:
+            raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
+        return self.fragment_count
+
     @property
     def fragment_count(self):
         return int(self._lib.ahost_fragment_count(self._session))

@@ -28,6 +28,10 @@ void ahost_close(ahost_session* session);
 /* read_chimeric_alignments for -x (source/read_chimeric_alignments.cpp:560-773); data = raw (inflated) BAM stream */
 int ahost_ingest_bam_file(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length);
 int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t size, int external_duplicate_marking, unsigned int max_itd_length);
+/* The result of an ingest (batch, counters, coverage) as a file, and back into a session opened on the same assembly and annotation: repeated
+ * benchmark and profiling runs over one batch skip the parse.  Tooling; not a step of the reference. */
+int ahost_save_ingest(ahost_session* session, const char* path);
+int ahost_load_ingest(ahost_session* session, const char* path);
 
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session);
 const agpu_genome_view* ahost_genome_view(ahost_session* session);

@@ -118,6 +118,23 @@ def test_ingest_with_several_threads_equals_single_threaded(built, tmp_path, mon
         assert not different, different
 
 
+def test_ingest_result_survives_save_and_load(built, dataset_files, tmp_path):
+    from arriba_amd.pipeline import ArribaError, HostSession
+    prefix = dataset_files("shuffled2k")
+    session = parity.open_session(prefix)
+    path = str(tmp_path / "ingest.bin")
+    session.save_ingest(path)
+    restored = HostSession(prefix + ".fa", prefix + ".gtf")
+    assert restored.load_ingest(path) == session.fragment_count
+    assert _batch_columns(session) == _batch_columns(restored)
+    assert session._lib.ahost_coverage_checksum(session._session) == restored._lib.ahost_coverage_checksum(restored._session)
+    assert session.contig_names() == restored.contig_names() and session.detect_strandedness() == restored.detect_strandedness()
+    with open(path, "r+b") as handle:
+        handle.write(b"XXXX")
+    with pytest.raises(ArribaError, match="not an ingest file"):
+        HostSession(prefix + ".fa", prefix + ".gtf").load_ingest(path)
+
+
 def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
     """The reference exits with 'no normal reads found' on a BAM without mapped reads (source/read_chimeric_alignments.cpp:759)."""
     import struct

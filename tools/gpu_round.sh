@@ -3,6 +3,7 @@ TAG=${1:-r01x}
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+export ARRIBA_BENCH_CACHE=/tmp/arriba_bench_cache   # the bench invocations below share one ingested batch
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/${TAG}_pytest_gpu.log
 # SKIP_PLAIN_BENCH=1: the traced run below also prints the bench line (GPU minutes are scarce: every bench invocation generates and ingests 10 M fragments first)
 if [ -z "$SKIP_PLAIN_BENCH" ]; then timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench exit $?" >> gpurun_out/${TAG}_bench.err; fi
