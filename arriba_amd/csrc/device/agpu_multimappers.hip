@@ -280,16 +280,20 @@ extern "C" int agpu_filter_multimappers(agpu_ctx* ctx, uint64_t* remaining, uint
 	HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t) best_rank.ptr, (int) NO_FUSION, n1, s));
 	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 16, s));
 	(void) hipEventRecord(ctx->event_start, s);
-	if (C > 0 && n > 0 && ctx->params.filter_enabled[FILTER_multimappers]) {
+	if (n > 0 && ctx->params.filter_enabled[FILTER_multimappers]) { // (the groups of alignments are resolved even when there is no candidate at all, as in the reference)
 		const CandidateTable& t = ctx->candidates;
-		{ const int status = compute_support_rank(ctx, rank.as<uint32_t>()); if (status != AGPU_OK) return status; }
-		{ const int status = build_read_bitmap(ctx, bits, BITS_MULTIMAPPER, nullptr, n); if (status != AGPU_OK) return status; }
-		{ KernelTimer timer(ctx, "list_best_rank_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 8);
-		  list_best_rank_kernel<<<grid_for(C), BLOCK, 0, s>>>(C, t.list_offset, t.read_lists, nullptr, rank.as<uint32_t>(), bits.as<uint32_t>(), nullptr, best_rank.as<uint32_t>()); }
+		if (C > 0) {
+			{ const int status = compute_support_rank(ctx, rank.as<uint32_t>()); if (status != AGPU_OK) return status; }
+			{ const int status = build_read_bitmap(ctx, bits, BITS_MULTIMAPPER, nullptr, n); if (status != AGPU_OK) return status; }
+			KernelTimer timer(ctx, "list_best_rank_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 8);
+			list_best_rank_kernel<<<grid_for(C), BLOCK, 0, s>>>(C, t.list_offset, t.read_lists, nullptr, rank.as<uint32_t>(), bits.as<uint32_t>(), nullptr, best_rank.as<uint32_t>());
+		}
 		{ const int status = resolve_groups(ctx, best_rank.as<uint32_t>(), counters.as<unsigned int>()); if (status != AGPU_OK) return status; }
-		{ const int status = build_read_bitmap(ctx, bits, BITS_DISCARDED, nullptr, n); if (status != AGPU_OK) return status; }
-		{ KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 26);
-		  list_recount_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, C, t.list_offset, t.read_lists, nullptr, bits.as<uint32_t>(), true, counters.as<unsigned int>() + 1); }
+		if (C > 0) {
+			{ const int status = build_read_bitmap(ctx, bits, BITS_DISCARDED, nullptr, n); if (status != AGPU_OK) return status; }
+			KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 26);
+			list_recount_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, C, t.list_offset, t.read_lists, nullptr, bits.as<uint32_t>(), true, counters.as<unsigned int>() + 1);
+		}
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
