@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""tools/sanitize_device_logic.py -- the per-fragment / per-candidate device logic (arriba_amd/csrc/device/*_core.hpp), stepped on the host by
+tests/emu, under AddressSanitizer + UBSan against the golden dumps (test tooling).  Run through tools/sanitize_device_logic.sh, which builds
+the instrumented harness and preloads the sanitizer runtimes into Python."""
+import sys, os, ctypes
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import parity, conftest, datasets, tempfile
+from arriba_amd import _capi
+api=_capi.bind_device_api(ctypes.CDLL(os.environ['ARRIBA_EMU_LIBRARY']),'emu_')
+tmp=tempfile.mkdtemp(prefix='asan_')
+for name in ['toy3k','stacked4k']:
+    prefix=datasets.generate(datasets.DATASETS[name], tmp, name)
+    golden=conftest.golden_dir(name)
+    s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+    parity.check_read_filters(s,p,golden); parity.check_annotation(s,p,golden)
+    p.find_fusions(); print(name,'candidates',parity.check_candidates(s,p,golden))
+    if name=='toy3k':
+        print('evalues',parity.check_evalues(s,p,golden)); print('mismappers',parity.check_mismappers(s,p,golden))
+        s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+        print('multimappers',parity.check_multimappers(s,p,golden))
+        s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+        print('chain',parity.check_chain_to_relative_support(s,p,golden,multimappers=True))
+print('done')
