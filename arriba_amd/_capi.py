@@ -36,6 +36,10 @@ class GenomeView(ctypes.Structure):
     _fields_ = [("n_contigs", c_uint32), ("contig_offset", POINTER(c_uint64)), ("contig_bits", POINTER(c_uint8)), ("bases", c_void_p)]
 
 
+class CoverageView(ctypes.Structure):
+    _fields_ = [("n_contigs", c_uint32), ("window_offset", POINTER(c_uint64)), ("coverage", POINTER(c_uint16)), ("fragment_starts", POINTER(c_uint8)), ("fragment_ends", POINTER(c_uint8))]
+
+
 class BatchView(ctypes.Structure):
     _fields_ = [("n", c_uint64), ("n_aln", POINTER(c_uint8)), ("fbits", POINTER(c_uint8)), ("group", POINTER(c_uint32)),
                 ("contig", POINTER(c_uint16) * 3), ("start", POINTER(c_int32) * 3), ("end", POINTER(c_int32) * 3), ("abits", POINTER(c_uint8) * 3),
@@ -113,6 +117,11 @@ def bind_device_api(lib, prefix="agpu_"):
         "candidate_iteration_order": (c_int, [ctx, c_void_p]),
         "merge_adjacent_fusions": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
         "filter_multimappers": (c_int, [ctx, POINTER(c_uint64), POINTER(c_uint64)]),
+        "upload_coverage": (c_int, [ctx, POINTER(CoverageView)]),
+        "filter_both_intronic": (c_int, [ctx, POINTER(c_uint64)]),
+        "filter_short_anchor": (c_int, [ctx, c_uint32, POINTER(c_uint64)]),
+        "filter_end_to_end": (c_int, [ctx, POINTER(c_uint64)]),
+        "filter_no_coverage": (c_int, [ctx, POINTER(c_uint64)]),
         "set_owned_candidates": (c_int, [ctx, c_void_p, c_uint64]),
         "copy_multimapper_flags": (c_int, [ctx, c_void_p]),
         "multimappers_begin": (c_int, [ctx, c_void_p, POINTER(c_uint64)]),
@@ -158,6 +167,7 @@ def bind_host_api(lib):
         "ahost_fragment_count": (c_uint64, [session]),
         "ahost_mapped_reads": (c_uint64, [session]),
         "ahost_coverage_checksum": (c_uint64, [session]),
+        "ahost_coverage_view": (POINTER(CoverageView), [session]),
         "ahost_contig_count": (c_uint32, [session]),
         "ahost_contig_name": (c_char_p, [session, c_uint32]),
         "ahost_fragment_name": (c_void_p, [session, c_uint64, POINTER(c_uint32)]),

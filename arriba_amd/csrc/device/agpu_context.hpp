@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../../include/arriba_gpu.h"
 #include "evalue_core.hpp"
+#include "event_core.hpp"
 
 namespace agpu {
 
@@ -90,6 +91,10 @@ struct agpu_ctx {
 	uint32_t n_owned = 0, n_owned_list_entries = 0;
 	bool candidates_imported = false, owned_index_set = false, multimappers_begun = false;
 	uint64_t n_multimappers_global = 0;
+	// coverage_t (agpu_upload_coverage)
+	agpu::DeviceBuffer coverage_window_offset, coverage_windows, coverage_fragment_starts, coverage_fragment_ends;
+	agpu::CoverageView coverage = { 0, nullptr, nullptr, nullptr, nullptr };
+	bool have_coverage = false;
 	uint64_t global_n = 0; // fragments of the whole sample when this context holds one shard of it (agpu_set_shard); 0 = not sharded
 
 	// scratch

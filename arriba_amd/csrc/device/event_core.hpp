@@ -1,0 +1,184 @@
+// arriba_amd/csrc/device/event_core.hpp -- event-level predicates behind filter_relative_support: pure functions of one
+// candidate, its read lists, the annotation and coverage_t.
+//   filter_both_intronic      source/filter_both_intronic.cpp:8-36
+//   filter_short_anchor       source/filter_short_anchor.cpp:7-24
+//   filter_end_to_end_fusions source/filter_end_to_end.cpp:8-78
+//   filter_no_coverage        source/filter_no_coverage.cpp:9-103
+#ifndef AGPU_EVENT_CORE_HPP
+#define AGPU_EVENT_CORE_HPP 1
+
+#include "fusion_core.hpp"
+
+namespace agpu {
+
+const uint8_t FILTER_intronic = 13, FILTER_end_to_end = 21, FILTER_short_anchor = 26, FILTER_no_coverage = 27; // source/common.hpp:29-67
+const int32_t COVERAGE_RESOLUTION = 20; // source/read_stats.hpp:12
+
+// coverage_t (source/read_stats.hpp:17-27) flattened: the windows of contig c are [window_offset[c], window_offset[c + 1])
+struct CoverageView {
+	uint32_t n_contigs;
+	const uint64_t* window_offset;
+	const uint16_t* coverage;
+	const uint8_t* fragment_starts;
+	const uint8_t* fragment_ends;
+};
+
+// reference: coverage_t::fragment_starts_here / fragment_ends_here, source/read_stats.cpp:269-292
+AGPU_HD bool fragment_starts_here(const CoverageView& coverage, uint32_t contig, int32_t start, int32_t end) {
+	if (contig >= coverage.n_contigs) return false;
+	const uint64_t begin = coverage.window_offset[contig], size = coverage.window_offset[contig + 1] - begin;
+	for (int32_t window = start / COVERAGE_RESOLUTION + 1; window <= end / COVERAGE_RESOLUTION; ++window) {
+		if ((uint64_t) (uint32_t) window >= size) return false;
+		if (coverage.fragment_starts[begin + (uint32_t) window]) return true;
+	}
+	return false;
+}
+AGPU_HD bool fragment_ends_here(const CoverageView& coverage, uint32_t contig, int32_t start, int32_t end) {
+	if (contig >= coverage.n_contigs) return false;
+	const uint64_t begin = coverage.window_offset[contig], size = coverage.window_offset[contig + 1] - begin;
+	for (int32_t window = start / COVERAGE_RESOLUTION; window < end / COVERAGE_RESOLUTION; ++window) {
+		if ((uint64_t) (uint32_t) window >= size) return false;
+		if (coverage.fragment_ends[begin + (uint32_t) window]) return true;
+	}
+	return false;
+}
+
+AGPU_HD bool candidate_is_read_through(const CandidateTable& t, uint32_t c) { // source/common.hpp:265-269
+	const uint32_t flags = t.flags[c];
+	return (t.contigs[c] >> 16) == (t.contigs[c] & 0xFFFF) && t.breakpoint2[c] - t.breakpoint1[c] < 400000 && !(flags & CFLAG_UPSTREAM1) && (flags & CFLAG_UPSTREAM2);
+}
+AGPU_HD bool candidate_overlaps_both_genes(const AnnotationView& ann, const CandidateTable& t, uint32_t c) { // source/common.hpp:260-264
+	const uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
+	return (t.breakpoint1[c] >= ann.gene_start[gene2] && t.breakpoint1[c] <= ann.gene_end[gene2]) || (t.breakpoint2[c] >= ann.gene_start[gene1] && t.breakpoint2[c] <= ann.gene_end[gene1]);
+}
+AGPU_HD bool contig_is_viral(const GenomeView& genome, uint32_t contig) { return contig < genome.n_contigs && (genome.contig_bits[contig] & CBIT_VIRAL); }
+
+// ---- filter_both_intronic: true = no unfiltered read of the candidate has an exonic alignment
+AGPU_HD bool has_only_intronic_reads(const BatchView& b, const GenomeView& genome, const CandidateTable& t, uint32_t c) {
+	if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return false; // viral contigs are often not annotated
+	for (uint32_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
+		const uint32_t read = t.read_lists[k];
+		if (b.filter[read] != FILTER_none) continue;
+		for (int slot = 0; slot < b.n_aln[read]; ++slot)
+			if (b.abits[slot][read] & ABIT_EXONIC) return false;
+	}
+	return true;
+}
+
+// ---- filter_short_anchor
+AGPU_HD bool has_short_anchor(const CandidateTable& t, uint32_t c, uint32_t min_length) {
+	const uint32_t flags = t.flags[c];
+	if ((flags & CFLAG_SPLICED1) && (flags & CFLAG_SPLICED2)) return false;
+	int32_t distance1 = t.anchor1[c] - t.breakpoint1[c]; if (distance1 < 0) distance1 = -distance1;
+	int32_t distance2 = t.anchor2[c] - t.breakpoint2[c]; if (distance2 < 0) distance2 = -distance2;
+	return (uint32_t) distance1 < min_length || (uint32_t) distance2 < min_length;
+}
+
+// ---- filter_end_to_end_fusions
+// reference: calculate_intronic_fraction (:9-26): bases of the gene not covered by the exon found first in every boundary bucket
+AGPU_HD float intronic_fraction(const AnnotationView& ann, uint32_t gene) {
+	const FlatIndexView& index = ann.exon_index;
+	const uint32_t contig = ann.gene_contig[gene];
+	const int32_t gene_start = ann.gene_start[gene], gene_end = ann.gene_end[gene];
+	uint32_t intronic_bases = 0;
+	int32_t previous_position = gene_start;
+	if (contig < index.n_contigs) {
+		const uint32_t contig_end = index.contig_offset[contig + 1];
+		for (uint32_t k = index_lower_bound(index, contig, gene_start); k != contig_end && index.keys[k] <= gene_end; ++k) {
+			const ListRef exons = index_bucket(index, k);
+			for (uint32_t m = 0; m < exons.n; ++m) {
+				const uint32_t exon = exons.p[m];
+				if (ann.exon_gene[exon] != gene) continue;
+				if (previous_position < ann.exon_start[exon]) intronic_bases += (uint32_t) (ann.exon_start[exon] - previous_position);
+				if (previous_position < ann.exon_end[exon]) previous_position = ann.exon_end[exon] + 1;
+				break;
+			}
+		}
+	}
+	return ((float) intronic_bases) / (float) (gene_end - gene_start + 1);
+}
+AGPU_HD bool gene_is_fused_end_to_end(const AnnotationView& ann, uint32_t gene, bool upstream) { // the gene's start of transcription points away from the breakpoint
+	const uint8_t bits = ann.gene_bits[gene];
+	return (bits & GBIT_DUMMY) || (((bits & GBIT_STRAND) != 0) == upstream);
+}
+AGPU_HD bool is_end_to_end_fusion(const AnnotationView& ann, const GenomeView& genome, const CandidateTable& t, uint32_t c) {
+	if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return false;
+	const uint32_t flags = t.flags[c], gene1 = t.gene1[c], gene2 = t.gene2[c];
+	if (!candidate_is_read_through(t, c) && gene1 != gene2 && (flags & (CFLAG_SPLICED1 | CFLAG_SPLICED2))) return false; // spliced breakpoints are likely true
+	const uint32_t split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c];
+	if (!(discordant_mates + split_reads1 == 0 || discordant_mates + split_reads2 == 0 || split_reads1 + split_reads2 == 0 ||
+	      (candidate_overlaps_both_genes(ann, t, c) && (split_reads1 == 0 || split_reads2 == 0)))) return false; // only breakpoints with low support
+	if (!gene_is_fused_end_to_end(ann, gene1, flags & CFLAG_UPSTREAM1) || !gene_is_fused_end_to_end(ann, gene2, flags & CFLAG_UPSTREAM2)) return false;
+	const uint32_t many_discordant_mates = 10;
+	const int32_t min_breakpoint_distance = 1000000;
+	const float max_intronic_fraction = 0.66f;
+	if (discordant_mates < many_discordant_mates) return true;
+	int32_t distance = t.breakpoint1[c] - t.breakpoint2[c]; if (distance < 0) distance = -distance;
+	if ((t.contigs[c] >> 16) == (t.contigs[c] & 0xFFFF) && distance < min_breakpoint_distance) return true;
+	return (flags & CFLAG_EXONIC1) && (flags & CFLAG_EXONIC2) && intronic_fraction(ann, gene1) > max_intronic_fraction && intronic_fraction(ann, gene2) > max_intronic_fraction;
+}
+
+// ---- filter_no_coverage
+AGPU_HD bool breakpoint_in_terminal_exon(const AnnotationView& ann, uint32_t contig, int32_t breakpoint, uint32_t gene) {
+	const FlatIndexView& index = ann.exon_index;
+	if (contig >= index.n_contigs) return false;
+	const uint32_t k = index_lower_bound(index, contig, breakpoint); // get_annotation_by_coordinate(contig, bp, bp): the bucket of the first boundary >= bp
+	if (k == index.contig_offset[contig + 1]) return false;
+	const ListRef exons = index_bucket(index, k);
+	for (uint32_t m = 0; m < exons.n; ++m) {
+		const uint32_t exon = exons.p[m];
+		if (ann.exon_gene[exon] == gene && (ann.exon_previous[exon] == -1 || ann.exon_next[exon] == -1)) return true;
+	}
+	return false;
+}
+AGPU_HD bool breakpoint_lacks_coverage(const AnnotationView& ann, const CoverageView& coverage, uint32_t contig, int32_t breakpoint, int32_t anchor_start, bool upstream, uint32_t gene, bool no_split_reads) {
+	const int32_t scan_range = 200;
+	if (breakpoint_in_terminal_exon(ann, contig, breakpoint, gene)) return false;
+	int32_t start, end;
+	if (upstream) {
+		start = breakpoint;
+		if (no_split_reads) start -= scan_range;
+		end = breakpoint + scan_range > anchor_start ? breakpoint + scan_range : anchor_start;
+		return !fragment_starts_here(coverage, contig, start, end);
+	}
+	start = breakpoint - scan_range < anchor_start ? breakpoint - scan_range : anchor_start;
+	end = breakpoint;
+	if (no_split_reads) end += scan_range;
+	return !fragment_ends_here(coverage, contig, start, end);
+}
+AGPU_HD bool has_no_coverage(const AnnotationView& ann, const CoverageView& coverage, const CandidateTable& t, uint32_t c) {
+	const uint32_t flags = t.flags[c];
+	const uint32_t split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c];
+	if (!candidate_is_read_through(t, c)) {
+		if (split_reads1 + split_reads2 != 0 && split_reads1 + discordant_mates != 0 && split_reads2 + discordant_mates != 0) return false; // high support
+		if (flags & (CFLAG_SPLICED1 | CFLAG_SPLICED2)) return false; // spliced breakpoints are more credible
+	} else if ((flags & CFLAG_SPLICED1) && (flags & CFLAG_SPLICED2)) {
+		return false;
+	}
+	const bool no_split_reads = split_reads1 + split_reads2 == 0;
+	if (breakpoint_lacks_coverage(ann, coverage, t.contigs[c] >> 16, t.breakpoint1[c], t.anchor1[c], flags & CFLAG_UPSTREAM1, t.gene1[c], no_split_reads)) return true;
+	return breakpoint_lacks_coverage(ann, coverage, t.contigs[c] & 0xFFFF, t.breakpoint2[c], t.anchor2[c], flags & CFLAG_UPSTREAM2, t.gene2[c], no_split_reads);
+}
+
+// the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or
+// EVENT_KEPT_UNCOUNTED if it stays without entering the "(remaining=N)" of the stage: filter_both_intronic and filter_end_to_end_fusions skip
+// the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)
+const uint8_t EVENT_KEPT_UNCOUNTED = 0xFF;
+enum { EVENT_count_only = -1, EVENT_both_intronic = 0, EVENT_short_anchor = 1, EVENT_end_to_end = 2, EVENT_no_coverage = 3 };
+AGPU_HD uint8_t event_predicate(int stage, const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const CoverageView& coverage, const CandidateTable& t, uint32_t c, uint32_t min_anchor_length) {
+	switch (stage) {
+		case EVENT_both_intronic:
+			if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return EVENT_KEPT_UNCOUNTED;
+			return has_only_intronic_reads(b, genome, t, c) ? FILTER_intronic : FILTER_none;
+		case EVENT_short_anchor: return has_short_anchor(t, c, min_anchor_length) ? FILTER_short_anchor : FILTER_none;
+		case EVENT_end_to_end:
+			if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return EVENT_KEPT_UNCOUNTED;
+			return is_end_to_end_fusion(ann, genome, t, c) ? FILTER_end_to_end : FILTER_none;
+		case EVENT_no_coverage: return has_no_coverage(ann, coverage, t, c) ? FILTER_no_coverage : FILTER_none;
+		default: return FILTER_none; // EVENT_count_only: the stage is switched off (-f), the caller still gets the number of unfiltered candidates
+	}
+}
+
+}
+
+#endif

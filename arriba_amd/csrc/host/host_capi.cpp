@@ -39,6 +39,23 @@ struct ahost_session {
 	std::vector<uint64_t> genome_offset; std::vector<uint8_t> contig_bits; std::string genome_bases;
 	agpu_annotation_view annotation_view;
 	agpu_genome_view genome_view;
+	agpu_coverage_view coverage_view;
+	std::vector<uint64_t> coverage_offset; std::vector<uint16_t> coverage_windows; std::vector<uint8_t> coverage_starts, coverage_ends;
+	void build_coverage_view() { // coverage_t of the ingest, the windows of all contigs concatenated
+		const Coverage& c = ingest.coverage;
+		const size_t n = c.coverage.size();
+		coverage_offset.assign(n + 1, 0); coverage_windows.clear(); coverage_starts.clear(); coverage_ends.clear();
+		for (size_t contig = 0; contig < n; ++contig) {
+			coverage_offset[contig] = coverage_windows.size();
+			coverage_windows.insert(coverage_windows.end(), c.coverage[contig].begin(), c.coverage[contig].end());
+			coverage_starts.insert(coverage_starts.end(), c.fragment_starts[contig].begin(), c.fragment_starts[contig].end());
+			coverage_ends.insert(coverage_ends.end(), c.fragment_ends[contig].begin(), c.fragment_ends[contig].end());
+			if (coverage_starts.size() != coverage_windows.size() || coverage_ends.size() != coverage_windows.size()) throw std::runtime_error("coverage_t: windows and flags differ in length");
+		}
+		coverage_offset[n] = coverage_windows.size();
+		coverage_view.n_contigs = (uint32_t) n; coverage_view.window_offset = coverage_offset.data(); coverage_view.coverage = coverage_windows.data();
+		coverage_view.fragment_starts = coverage_starts.data(); coverage_view.fragment_ends = coverage_ends.data();
+	}
 	agpu_batch_view batch_view, slice_view;
 	std::map<std::pair<contig_t, contig_t>, bool> related_viruses;
 	std::string name_scratch;
@@ -274,6 +291,11 @@ int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t 
 
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session) { return &session->annotation_view; }
 const agpu_genome_view* ahost_genome_view(ahost_session* session) { return &session->genome_view; }
+const agpu_coverage_view* ahost_coverage_view(ahost_session* session) {
+	if (!session->have_batch) return NULL;
+	try { session->build_coverage_view(); } catch (const std::exception& e) { g_error = e.what(); return NULL; }
+	return &session->coverage_view;
+}
 const agpu_batch_view* ahost_batch_view(ahost_session* session) { return session->have_batch ? &session->batch_view : NULL; }
 uint64_t ahost_shard_boundary(ahost_session* session, uint64_t target) {
 	const agpu_batch_view& v = session->batch_view;

@@ -277,6 +277,35 @@ class DevicePipeline(object):
         self._record("filter_multimappers")
         return remaining.value, discarded.value
 
+    # event-level predicates behind filter_relative_support (each returns the reference's "(remaining=N)")
+    def upload_coverage(self):
+        view = self.session._lib.ahost_coverage_view(self.session._session)
+        if not view:
+            raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
+        self._check(self.api.upload_coverage(self.ctx, view))
+
+    def _event_stage(self, name, *arguments):
+        remaining = c_uint64()
+        self._check(getattr(self.api, name)(self.ctx, *arguments, byref(remaining)))
+        self._record(name)
+        return remaining.value
+
+    def filter_both_intronic(self):
+        """reference: filter_both_intronic, source/filter_both_intronic.cpp:18-36"""
+        return self._event_stage("filter_both_intronic")
+
+    def filter_short_anchor(self, min_length=23):
+        """reference: filter_short_anchor, source/filter_short_anchor.cpp:7-24 (-A, default 23)"""
+        return self._event_stage("filter_short_anchor", min_length)
+
+    def filter_end_to_end(self):
+        """reference: filter_end_to_end_fusions, source/filter_end_to_end.cpp:28-78"""
+        return self._event_stage("filter_end_to_end")
+
+    def filter_no_coverage(self):
+        """reference: filter_no_coverage, source/filter_no_coverage.cpp:9-103"""
+        return self._event_stage("filter_no_coverage")
+
     def candidate_iteration_order(self):
         """rank of every candidate in the iteration order of the reference's fusions_t (hazard H2), computed on the device"""
         rank = np.zeros(max(self.n_candidates, 1), dtype=np.uint32)

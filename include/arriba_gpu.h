@@ -103,6 +103,16 @@ typedef struct {
 	agpu_flat_index gene_index;      /* GTF genes only; dummy genes are created on the device */
 } agpu_annotation_view;
 
+/* coverage_t (source/read_stats.hpp:17-27) flattened: the 20 bp windows of contig c are [window_offset[c], window_offset[c+1]); contigs without a
+ * loaded sequence have no windows.  Built by the ingest (ahost_coverage_view). */
+typedef struct {
+	uint32_t n_contigs;
+	const uint64_t* window_offset;   /* [n_contigs+1] */
+	const uint16_t* coverage;        /* saturating fragment count per window */
+	const uint8_t* fragment_starts;  /* 1 = a non-chimeric fragment starts in the window */
+	const uint8_t* fragment_ends;
+} agpu_coverage_view;
+
 /* Genome as upper-case ASCII, contigs concatenated (source/assembly.cpp:28-58). */
 typedef struct {
 	uint32_t n_contigs;
@@ -261,6 +271,21 @@ int agpu_get_evalues(agpu_ctx* ctx, float* evalue /* [n_candidates] */);
 int agpu_filter_candidate_predicates(agpu_ctx* ctx, uint64_t* discarded /* [3] */);
 /* filter_relative_support (source/filter_relative_support.cpp:209-224); *remaining = the reference's "(remaining=N)" */
 int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining);
+
+/* Event-level predicates behind filter_relative_support, each a pure function of one candidate; candidates that already
+ * have a filter are skipped, *remaining = "(remaining=N)" as the reference counts it (filter_both_intronic and filter_end_to_end_fusions leave the
+ * candidates on viral contigs out of their count).  The state the stages in between produce on the host (recover_*, select_best, ...)
+ * goes in with agpu_set_candidate_state / agpu_set_read_filters.
+ *   agpu_upload_coverage       coverage_t of the ingest (source/read_stats.cpp:161-266), needed by filter_no_coverage
+ *   agpu_filter_both_intronic  source/filter_both_intronic.cpp:18-36, called at source/arriba.cpp:469-472
+ *   agpu_filter_short_anchor   source/filter_short_anchor.cpp:7-24,  source/arriba.cpp:531-534 (min_length = -A, default 23)
+ *   agpu_filter_end_to_end     source/filter_end_to_end.cpp:28-78,   source/arriba.cpp:536-539
+ *   agpu_filter_no_coverage    source/filter_no_coverage.cpp:9-103,  source/arriba.cpp:541-544 */
+int agpu_upload_coverage(agpu_ctx* ctx, const agpu_coverage_view* coverage);
+int agpu_filter_both_intronic(agpu_ctx* ctx, uint64_t* remaining);
+int agpu_filter_short_anchor(agpu_ctx* ctx, uint32_t min_length, uint64_t* remaining);
+int agpu_filter_end_to_end(agpu_ctx* ctx, uint64_t* remaining);
+int agpu_filter_no_coverage(agpu_ctx* ctx, uint64_t* remaining);
 
 /* Read-level filter state as changed by stages that run on the host after the read-level cascade (filter_multimappers,
  * source/arriba.cpp:427-430): replaces the filter id of every fragment. */

@@ -35,6 +35,7 @@ int ahost_load_ingest(ahost_session* session, const char* path);
 
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session);
 const agpu_genome_view* ahost_genome_view(ahost_session* session);
+const agpu_coverage_view* ahost_coverage_view(ahost_session* session);  /* coverage_t of the ingest for agpu_upload_coverage; NULL before an ingest */
 const agpu_batch_view* ahost_batch_view(ahost_session* session);
 /* Shards of the batch for one context per GPU: contiguous ranges of fragments in name order.  ahost_shard_boundary moves a cut forward
  * until it does not separate fragments of one read name (mark_multimappers compares neighbours, source/read_chimeric_alignments.cpp:792-802);

@@ -19,6 +19,7 @@
 #include "../../arriba_amd/csrc/device/order_host.hpp"
 #include "../../arriba_amd/csrc/device/mismapper_core.hpp"
 #include "../../arriba_amd/csrc/device/merge_core.hpp"
+#include "../../arriba_amd/csrc/device/event_core.hpp"
 #include "../../arriba_amd/csrc/device/index_bins.hpp"
 #include "../../arriba_amd/csrc/device/multimapper_core.hpp"
 #include <map>
@@ -77,6 +78,7 @@ struct emu_ctx {
 	std::vector<uint8_t> duplicate_entries;      // wire format of the sharded duplicate exchange: 12-byte key + 4-byte global name rank
 	uint64_t global_n = 0;
 	std::vector<uint32_t> exon_bins, gene_bins;
+	CoverageView coverage = { 0, nullptr, nullptr, nullptr, nullptr };
 };
 
 static void refresh_annotation(emu_ctx* ctx) {

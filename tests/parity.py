@@ -248,6 +248,64 @@ def check_mismappers(session, pipeline, golden):
     return discarded
 
 
+def _inject_candidate_state(pipeline, index, fusions):
+    n = pipeline.n_candidates
+    state = {k: np.zeros(n, dtype=np.uint32) for k in ("filter", "split_reads1", "split_reads2", "discordant_mates")}
+    for f in fusions:
+        for k in state:
+            state[k][index[fusion_key(f)]] = f[k]
+    pipeline.set_candidate_state(state["filter"].astype(np.uint8), state["split_reads1"], state["split_reads2"], state["discordant_mates"])
+
+
+def _compare_candidate_filters(pipeline, index, expected, stage):
+    table = pipeline.candidates()
+    problems = []
+    for f in expected:
+        c = index[fusion_key(f)]
+        if int(table["filter"][c]) != f["filter"]:
+            problems.append((stage, fusion_key(f), int(table["filter"][c]), f["filter"]))
+    assert not problems, (len(problems), problems[:10])
+    return sum(1 for f in expected if f["filter"] == 0)
+
+
+def check_event_predicates(session, pipeline, golden):
+    """filter_both_intronic from the reference's state behind recover_internal_tandem_duplication; filter_short_anchor -> filter_end_to_end ->
+    filter_no_coverage chained from the state behind recover_many_spliced.  The state of the host stages in between (candidate filters and
+    counters, read filters) is taken from the reference's dumps, as for filter_mismappers."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    def logged(pattern):
+        match = re.search(pattern + r"[^\n]*\(remaining=(\d+)\)", log)
+        assert match, pattern
+        return int(match.group(1))
+    pipeline.find_fusions()
+    pipeline.upload_coverage()
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    # filter_both_intronic
+    before = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_internal_tandem_duplication"))
+    names, read_filters = golden_io.read_filters(golden_io.find_dump(golden, "filters", "recover_internal_tandem_duplication"))
+    assert session.fragment_names() == names
+    _inject_candidate_state(pipeline, index, before)
+    pipeline.set_read_filters(np.array(read_filters, dtype=np.uint8))
+    remaining = pipeline.filter_both_intronic()
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_both_intronic"))
+    _compare_candidate_filters(pipeline, index, after, "both_intronic")
+    assert remaining == logged("Filtering fusions with both breakpoints in intronic/intergenic regions"), (remaining, logged("Filtering fusions with both breakpoints in intronic/intergenic regions"))
+    discarded = {"both_intronic": sum(1 for f in after if f["filter"] == 13)}
+    # filter_short_anchor -> filter_end_to_end -> filter_no_coverage
+    _inject_candidate_state(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_many_spliced")))
+    for stage, run, filter_id, pattern in (("filter_short_anchor", pipeline.filter_short_anchor, 26, "Filtering fusions with anchors"),
+                                           ("filter_end_to_end_fusions", pipeline.filter_end_to_end, 21, "Filtering end-to-end fusions with low support"),
+                                           ("filter_no_coverage", pipeline.filter_no_coverage, 27, "Filtering fusions with no coverage around the breakpoints")):
+        remaining = run()
+        after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))
+        _compare_candidate_filters(pipeline, index, after, stage)
+        assert remaining == logged(pattern), (stage, remaining, logged(pattern))
+        discarded[stage] = sum(1 for f in after if f["filter"] == filter_id)
+    return discarded
+
+
 def check_merge_adjacent(session, pipeline, golden):
     """merge_adjacent_fusions on the device state right after find_fusions against the reference's dump of that stage"""
     import re

@@ -228,3 +228,27 @@ def test_sharded_pipeline_two_ranks_on_one_device(built, dataset_files, tmp_path
     reports = test_sharded.run_sharded(dataset_files("mid30k"), 2, "gpu", str(tmp_path / "report"), 29655)
     assert reports[0]["problems"] == [], reports[0]["problems"]
     assert sum(r["owned_candidates"] for r in reports) == reports[0]["candidates"]
+
+
+def test_event_level_predicates_match_reference(built, dataset_files, tmp_path):
+    """filter_both_intronic, filter_short_anchor, filter_end_to_end_fusions, filter_no_coverage on the GPU: against the committed dumps, and against
+    the reference run live with the filters in front of them switched off, so that thousands of candidates reach every predicate"""
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"))
+    assert parity.check_event_predicates(session, pipeline, conftest.golden_dir("toy3k"))["both_intronic"] > 20
+    if not datasets.reference_available():
+        return
+    spec = {"args": ["--seed", "33", "--fragments", "60000", "--normal-mult", "0.3", "--contigs", "6", "--contig-len", "500000", "--junctions", "600", "--dup", "0.1"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump, disable_filters=["relative_support", "min_support", "non_coding_neighbors", "intragenic_exonic", "in_vitro", "select_best", "marginal_read_through",
+                                                                    "homologs", "merge_adjacent", "multimappers"])
+    finally:
+        del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    discarded = parity.check_event_predicates(session, pipeline, dump)
+    assert min(discarded.values()) > 1000, discarded

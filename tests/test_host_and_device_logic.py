@@ -149,6 +149,13 @@ def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
         session.read_chimeric_alignments(header)
 
 
+def test_event_level_predicates_match_reference(dataset_files, emu_api):
+    """filter_both_intronic, filter_short_anchor, filter_end_to_end_fusions, filter_no_coverage (event_core.hpp) against the reference's dumps"""
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
+    discarded = parity.check_event_predicates(session, pipeline, conftest.golden_dir("toy3k"))
+    assert discarded["both_intronic"] > 20
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
