@@ -31,7 +31,7 @@ __global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView an
 int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* kernel_name, uint32_t min_anchor_length, uint64_t* remaining) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
 	if (stage == EVENT_both_intronic && ctx->candidates_imported) { set_last_error("filter_both_intronic reads the read lists: not available on an imported (replicated) candidate table"); return AGPU_ERR_INVALID; }
-	if (stage == EVENT_no_coverage && !ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
+	if ((stage == EVENT_no_coverage || stage == EVENT_marginal_read_through) && !ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	const uint32_t C = ctx->n_candidates;
@@ -81,3 +81,4 @@ extern "C" int agpu_filter_both_intronic(agpu_ctx* ctx, uint64_t* remaining) { r
 extern "C" int agpu_filter_short_anchor(agpu_ctx* ctx, uint32_t min_length, uint64_t* remaining) { return run_event_stage(ctx, EVENT_short_anchor, FILTER_short_anchor, "event_predicate_kernel(short_anchor)", min_length, remaining); }
 extern "C" int agpu_filter_end_to_end(agpu_ctx* ctx, uint64_t* remaining) { return run_event_stage(ctx, EVENT_end_to_end, FILTER_end_to_end, "event_predicate_kernel(end_to_end)", 0, remaining); }
 extern "C" int agpu_filter_no_coverage(agpu_ctx* ctx, uint64_t* remaining) { return run_event_stage(ctx, EVENT_no_coverage, FILTER_no_coverage, "event_predicate_kernel(no_coverage)", 0, remaining); }
+extern "C" int agpu_filter_marginal_read_through(agpu_ctx* ctx, uint64_t* remaining) { return run_event_stage(ctx, EVENT_marginal_read_through, FILTER_marginal_read_through, "event_predicate_kernel(marginal_read_through)", 0, remaining); }

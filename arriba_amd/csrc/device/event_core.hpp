@@ -4,6 +4,7 @@
 //   filter_short_anchor       source/filter_short_anchor.cpp:7-24
 //   filter_end_to_end_fusions source/filter_end_to_end.cpp:8-78
 //   filter_no_coverage        source/filter_no_coverage.cpp:9-103
+//   filter_marginal_read_through source/filter_marginal_read_through.cpp:8-46
 #ifndef AGPU_EVENT_CORE_HPP
 #define AGPU_EVENT_CORE_HPP 1
 
@@ -11,7 +12,7 @@
 
 namespace agpu {
 
-const uint8_t FILTER_intronic = 13, FILTER_end_to_end = 21, FILTER_short_anchor = 26, FILTER_no_coverage = 27; // source/common.hpp:29-67
+const uint8_t FILTER_intronic = 13, FILTER_end_to_end = 21, FILTER_marginal_read_through = 25, FILTER_short_anchor = 26, FILTER_no_coverage = 27; // source/common.hpp:29-67
 const int32_t COVERAGE_RESOLUTION = 20; // source/read_stats.hpp:12
 
 // coverage_t (source/read_stats.hpp:17-27) flattened: the windows of contig c are [window_offset[c], window_offset[c + 1])
@@ -41,6 +42,15 @@ AGPU_HD bool fragment_ends_here(const CoverageView& coverage, uint32_t contig, i
 		if (coverage.fragment_ends[begin + (uint32_t) window]) return true;
 	}
 	return false;
+}
+
+// reference: coverage_t::get_coverage, source/read_stats.cpp:295-306: the window before (upstream) / behind (downstream) the position
+AGPU_HD int32_t coverage_near(const CoverageView& coverage, uint32_t contig, int32_t position, bool upstream) {
+	if (contig >= coverage.n_contigs) return -1;
+	const uint64_t begin = coverage.window_offset[contig], size = coverage.window_offset[contig + 1] - begin;
+	if (size == 0) return -1;
+	if (upstream) return position < COVERAGE_RESOLUTION ? 0 : coverage.coverage[begin + (uint64_t) (position / COVERAGE_RESOLUTION - 1)];
+	return coverage.coverage[begin + (uint64_t) (position / COVERAGE_RESOLUTION + 1)];
 }
 
 AGPU_HD bool candidate_is_read_through(const CandidateTable& t, uint32_t c) { // source/common.hpp:265-269
@@ -160,11 +170,33 @@ AGPU_HD bool has_no_coverage(const AnnotationView& ann, const CoverageView& cove
 	return breakpoint_lacks_coverage(ann, coverage, t.contigs[c] & 0xFFFF, t.breakpoint2[c], t.anchor2[c], flags & CFLAG_UPSTREAM2, t.gene2[c], no_split_reads);
 }
 
+// ---- filter_marginal_read_through: read-through events whose breakpoints sit in the last percent of donor and acceptor and whose reads are a
+// small fraction of the coverage.  The arithmetic types are the reference's: double positions, float margin and allele fraction.
+AGPU_HD bool is_marginal_read_through(const AnnotationView& ann, const CoverageView& coverage, const CandidateTable& t, uint32_t c) {
+	if (!candidate_is_read_through(t, c)) return false;
+	const float margin = 0.01f, min_vaf = 0.07f;
+	const uint32_t flags = t.flags[c], gene1 = t.gene1[c], gene2 = t.gene2[c];
+	const bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
+	const uint8_t bits1 = ann.gene_bits[gene1], bits2 = ann.gene_bits[gene2];
+	const bool dummy1 = bits1 & GBIT_DUMMY, dummy2 = bits2 & GBIT_DUMMY, forward1 = bits1 & GBIT_STRAND, forward2 = bits2 & GBIT_STRAND;
+	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
+	double position_in_donor = 1, position_in_acceptor = 1;
+	if (!dummy1 && forward1 && !upstream1) position_in_donor = 1.0 * (breakpoint1 - ann.gene_start[gene1]) / (ann.gene_end[gene1] - ann.gene_start[gene1]);
+	else if (!dummy2 && !forward2 && upstream2) position_in_donor = 1.0 * (ann.gene_end[gene2] - breakpoint2) / (ann.gene_end[gene2] - ann.gene_start[gene2]);
+	else if (!dummy1 && !forward1 && !upstream1) position_in_acceptor = 1.0 * (breakpoint1 - ann.gene_start[gene1]) / (ann.gene_end[gene1] - ann.gene_start[gene1]);
+	else if (!dummy2 && forward2 && upstream2) position_in_acceptor = 1.0 * (ann.gene_end[gene2] - breakpoint2) / (ann.gene_end[gene2] - ann.gene_start[gene2]);
+	else return false; // both breakpoints are intergenic
+	const int32_t coverage1 = coverage_near(coverage, t.contigs[c] >> 16, breakpoint1, !upstream1), coverage2 = coverage_near(coverage, t.contigs[c] & 0xFFFF, breakpoint2, !upstream2);
+	const uint32_t supporting_reads = t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c];
+	const float one_minus_margin = 1 - margin;
+	return position_in_donor > one_minus_margin && position_in_acceptor > one_minus_margin && (float) supporting_reads < min_vaf * (float) (coverage1 > coverage2 ? coverage1 : coverage2);
+}
+
 // the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or
 // EVENT_KEPT_UNCOUNTED if it stays without entering the "(remaining=N)" of the stage: filter_both_intronic and filter_end_to_end_fusions skip
 // the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)
 const uint8_t EVENT_KEPT_UNCOUNTED = 0xFF;
-enum { EVENT_count_only = -1, EVENT_both_intronic = 0, EVENT_short_anchor = 1, EVENT_end_to_end = 2, EVENT_no_coverage = 3 };
+enum { EVENT_count_only = -1, EVENT_both_intronic = 0, EVENT_short_anchor = 1, EVENT_end_to_end = 2, EVENT_no_coverage = 3, EVENT_marginal_read_through = 4 };
 AGPU_HD uint8_t event_predicate(int stage, const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const CoverageView& coverage, const CandidateTable& t, uint32_t c, uint32_t min_anchor_length) {
 	switch (stage) {
 		case EVENT_both_intronic:
@@ -175,6 +207,7 @@ AGPU_HD uint8_t event_predicate(int stage, const BatchView& b, const AnnotationV
 			if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return EVENT_KEPT_UNCOUNTED;
 			return is_end_to_end_fusion(ann, genome, t, c) ? FILTER_end_to_end : FILTER_none;
 		case EVENT_no_coverage: return has_no_coverage(ann, coverage, t, c) ? FILTER_no_coverage : FILTER_none;
+		case EVENT_marginal_read_through: return is_marginal_read_through(ann, coverage, t, c) ? FILTER_marginal_read_through : FILTER_none;
 		default: return FILTER_none; // EVENT_count_only: the stage is switched off (-f), the caller still gets the number of unfiltered candidates
 	}
 }

@@ -306,6 +306,10 @@ class DevicePipeline(object):
         """reference: filter_no_coverage, source/filter_no_coverage.cpp:9-103"""
         return self._event_stage("filter_no_coverage")
 
+    def filter_marginal_read_through(self):
+        """reference: filter_marginal_read_through, source/filter_marginal_read_through.cpp:8-46"""
+        return self._event_stage("filter_marginal_read_through")
+
     def candidate_iteration_order(self):
         """rank of every candidate in the iteration order of the reference's fusions_t (hazard H2), computed on the device"""
         rank = np.zeros(max(self.n_candidates, 1), dtype=np.uint32)

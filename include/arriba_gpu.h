@@ -280,12 +280,14 @@ int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining);
  *   agpu_filter_both_intronic  source/filter_both_intronic.cpp:18-36, called at source/arriba.cpp:469-472
  *   agpu_filter_short_anchor   source/filter_short_anchor.cpp:7-24,  source/arriba.cpp:531-534 (min_length = -A, default 23)
  *   agpu_filter_end_to_end     source/filter_end_to_end.cpp:28-78,   source/arriba.cpp:536-539
- *   agpu_filter_no_coverage    source/filter_no_coverage.cpp:9-103,  source/arriba.cpp:541-544 */
+ *   agpu_filter_no_coverage    source/filter_no_coverage.cpp:9-103,  source/arriba.cpp:541-544
+ *   agpu_filter_marginal_read_through  source/filter_marginal_read_through.cpp:8-46, source/arriba.cpp:503-506 */
 int agpu_upload_coverage(agpu_ctx* ctx, const agpu_coverage_view* coverage);
 int agpu_filter_both_intronic(agpu_ctx* ctx, uint64_t* remaining);
 int agpu_filter_short_anchor(agpu_ctx* ctx, uint32_t min_length, uint64_t* remaining);
 int agpu_filter_end_to_end(agpu_ctx* ctx, uint64_t* remaining);
 int agpu_filter_no_coverage(agpu_ctx* ctx, uint64_t* remaining);
+int agpu_filter_marginal_read_through(agpu_ctx* ctx, uint64_t* remaining);
 
 /* Read-level filter state as changed by stages that run on the host after the read-level cascade (filter_multimappers,
  * source/arriba.cpp:427-430): replaces the filter id of every fragment. */

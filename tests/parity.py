@@ -293,6 +293,17 @@ def check_event_predicates(session, pipeline, golden):
     _compare_candidate_filters(pipeline, index, after, "both_intronic")
     assert remaining == logged("Filtering fusions with both breakpoints in intronic/intergenic regions"), (remaining, logged("Filtering fusions with both breakpoints in intronic/intergenic regions"))
     discarded = {"both_intronic": sum(1 for f in after if f["filter"] == 13)}
+    # filter_marginal_read_through from the state behind select_most_supported_breakpoints (its first call, source/arriba.cpp:497-500)
+    try:
+        before = golden_io.find_dump(golden, "fusions", "select_most_supported_breakpoints")
+    except FileNotFoundError:  # select_best switched off in this reference run
+        before = golden_io.find_dump(golden, "fusions", "recover_both_spliced")
+    _inject_candidate_state(pipeline, index, golden_io.read_fusions(before))
+    remaining = pipeline.filter_marginal_read_through()
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_marginal_read_through"))
+    _compare_candidate_filters(pipeline, index, after, "filter_marginal_read_through")
+    assert remaining == logged("Filtering read-through fusions with breakpoints near the gene boundary"), remaining
+    discarded["filter_marginal_read_through"] = sum(1 for f in after if f["filter"] == 25)
     # filter_short_anchor -> filter_end_to_end -> filter_no_coverage
     _inject_candidate_state(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_many_spliced")))
     for stage, run, filter_id, pattern in (("filter_short_anchor", pipeline.filter_short_anchor, 26, "Filtering fusions with anchors"),

@@ -243,7 +243,7 @@ def test_event_level_predicates_match_reference(built, dataset_files, tmp_path):
     os.makedirs(dump)
     os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
     try:
-        log = datasets.run_reference(prefix, dump, disable_filters=["relative_support", "min_support", "non_coding_neighbors", "intragenic_exonic", "in_vitro", "select_best", "marginal_read_through",
+        log = datasets.run_reference(prefix, dump, disable_filters=["relative_support", "min_support", "non_coding_neighbors", "intragenic_exonic", "in_vitro", "select_best",
                                                                     "homologs", "merge_adjacent", "multimappers"])
     finally:
         del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
