@@ -3,7 +3,9 @@
 // One thread per candidate; the tallies go through one atomic per workgroup (device_utils.hpp).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 #include <string>
+#include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
 #include "event_core.hpp"
 #include "device_utils.hpp"
@@ -26,6 +28,41 @@ __global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView an
 		if (verdict == FILTER_none) ++kept; else if (verdict != EVENT_KEPT_UNCOUNTED) t.filter[c] = verdict;
 	}
 	block_tally(kept, remaining, &block_sum);
+}
+
+// select_most_supported_breakpoints: sort keys and the fold over the groups
+__global__ void select_best_key_kernel(CandidateTable t, const uint32_t* order, const uint32_t* iteration_rank, int pass, uint64_t* keys) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= t.n) return;
+	const uint32_t c = order ? order[j] : j;
+	keys[j] = pass == 0 ? (uint64_t) iteration_rank[c] : select_best_group_key(t, c);
+}
+__global__ void select_best_group_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, unsigned int* remaining) {
+	__shared__ uint32_t block_sum;
+	uint32_t heads = 0;
+	for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < t.n; j += gridDim.x * BLOCK) {
+		if (group_keys[j] == ~0ull || (j > 0 && group_keys[j - 1] == group_keys[j])) continue; // filtered, or not the first of its group
+		uint32_t end = j + 1;
+		while (end < t.n && group_keys[end] == group_keys[j]) ++end;
+		if (end - j > 1) select_best_in_group(t, order, j, end);
+		++heads; // one candidate per group stays
+	}
+	block_tally(heads, remaining, &block_sum);
+}
+
+// recover_many_spliced: sort keys and the per-pair pass
+__global__ void many_spliced_key_kernel(AnnotationView ann, CandidateTable t, const uint32_t* order, int pass, uint64_t* keys) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= t.n) return;
+	const uint32_t c = order ? order[j] : j;
+	keys[j] = pass == 0 ? many_spliced_bin_key(t, c) : many_spliced_pair_key(ann, t, c);
+}
+__global__ void many_spliced_pair_kernel(CandidateTable t, const uint32_t* order, const uint64_t* pair_keys, uint32_t min_spliced_events) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= t.n || pair_keys[j] == ~0ull || (j > 0 && pair_keys[j - 1] == pair_keys[j])) return; // not the first of a gene pair
+	uint32_t end = j + 1;
+	while (end < t.n && pair_keys[end] == pair_keys[j]) ++end;
+	recover_many_spliced_in_pair(t, order, j, end, min_spliced_events);
 }
 
 int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* kernel_name, uint32_t min_anchor_length, uint64_t* remaining) {
@@ -82,3 +119,84 @@ extern "C" int agpu_filter_short_anchor(agpu_ctx* ctx, uint32_t min_length, uint
 extern "C" int agpu_filter_end_to_end(agpu_ctx* ctx, uint64_t* remaining) { return run_event_stage(ctx, EVENT_end_to_end, FILTER_end_to_end, "event_predicate_kernel(end_to_end)", 0, remaining); }
 extern "C" int agpu_filter_no_coverage(agpu_ctx* ctx, uint64_t* remaining) { return run_event_stage(ctx, EVENT_no_coverage, FILTER_no_coverage, "event_predicate_kernel(no_coverage)", 0, remaining); }
 extern "C" int agpu_filter_marginal_read_through(agpu_ctx* ctx, uint64_t* remaining) { return run_event_stage(ctx, EVENT_marginal_read_through, FILTER_marginal_read_through, "event_predicate_kernel(marginal_read_through)", 0, remaining); }
+
+extern "C" int agpu_select_most_supported_breakpoints(agpu_ctx* ctx, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->iteration_order_done) { const int status = agpu_candidate_iteration_order(ctx, nullptr); if (status != AGPU_OK) return status; } // hazard H2
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& keys_in = ctx->scratch("events.keys_in"); DeviceBuffer& keys_out = ctx->scratch("events.keys_out");
+	DeviceBuffer& order_a = ctx->scratch("events.order_a"); DeviceBuffer& order_b = ctx->scratch("events.order_b"); DeviceBuffer& scratch = ctx->scratch("events.rocprim");
+	const size_t C1 = std::max<uint32_t>(C, 1);
+	ALLOC(counter, 16); ALLOC(keys_in, C1 * 8); ALLOC(keys_out, C1 * 8); ALLOC(order_a, C1 * 4); ALLOC(order_b, C1 * 4);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && ctx->params.filter_enabled[FILTER_select_best]) {
+		const CandidateTable& t = ctx->candidates;
+		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
+		size_t bytes = 0;
+		// stable sorts: by iteration rank, then by group
+		select_best_key_kernel<<<grid, BLOCK, 0, s>>>(t, nullptr, ctx->cand_iteration_rank.as<uint32_t>(), 0, keys_in.as<uint64_t>());
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), order_a.as<uint32_t>(), C, 0, 32, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), order_a.as<uint32_t>(), C, 0, 32, s));
+		select_best_key_kernel<<<grid, BLOCK, 0, s>>>(t, order_a.as<uint32_t>(), ctx->cand_iteration_rank.as<uint32_t>(), 1, keys_in.as<uint64_t>());
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
+		KernelTimer timer(ctx, "select_best_group_kernel", (uint64_t) C * 40);
+		select_best_group_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), counter.as<unsigned int>());
+	} else if (C > 0) {
+		event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 100;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_events, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& keys_in = ctx->scratch("events.keys_in"); DeviceBuffer& keys_out = ctx->scratch("events.keys_out");
+	DeviceBuffer& order_a = ctx->scratch("events.order_a"); DeviceBuffer& order_b = ctx->scratch("events.order_b"); DeviceBuffer& scratch = ctx->scratch("events.rocprim");
+	const size_t C1 = std::max<uint32_t>(C, 1);
+	ALLOC(counter, 16); ALLOC(keys_in, C1 * 8); ALLOC(keys_out, C1 * 8); ALLOC(order_a, C1 * 4); ALLOC(order_b, C1 * 4);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0) {
+		const CandidateTable& t = ctx->candidates;
+		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
+		if (ctx->params.filter_enabled[28 /* many_spliced */]) {
+			size_t bytes = 0;
+			many_spliced_key_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, t, nullptr, 0, keys_in.as<uint64_t>());
+			HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), order_a.as<uint32_t>(), C, 0, 64, s));
+			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+			HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), order_a.as<uint32_t>(), C, 0, 64, s));
+			many_spliced_key_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, t, order_a.as<uint32_t>(), 1, keys_in.as<uint64_t>());
+			HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
+			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+			HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
+			KernelTimer timer(ctx, "many_spliced_pair_kernel", (uint64_t) C * 40);
+			many_spliced_pair_kernel<<<grid, BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), min_spliced_events);
+		}
+		event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 100;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}

@@ -192,6 +192,65 @@ AGPU_HD bool is_marginal_read_through(const AnnotationView& ann, const CoverageV
 	return position_in_donor > one_minus_margin && position_in_acceptor > one_minus_margin && (float) supporting_reads < min_vaf * (float) (coverage1 > coverage2 ? coverage1 : coverage2);
 }
 
+// ---- select_most_supported_breakpoints (source/select_best.cpp:8-80): of the unfiltered candidates of one gene pair and direction pair the
+// "best" one stays.  The reference folds the candidates in the iteration order of fusions_t (hazard H2) with a rule that is not antisymmetric
+// (the exonic clause), so the result depends on that order: the device sorts the unfiltered candidates by (gene pair + directions, iteration
+// rank) and one thread replays the fold over each group.
+const uint8_t FILTER_select_best = 24;
+AGPU_HD uint32_t select_best_rank(const CandidateTable& t, uint32_t c) { // reference: rank_fusion (:8-19)
+	const bool split1 = t.split_reads1[c] != 0, split2 = t.split_reads2[c] != 0, discordant = t.discordant_mates[c] != 0;
+	if (split1 && split2) return 3;
+	if ((split1 || split2) && discordant) return 2;
+	if (split1 || split2) return 1;
+	return 0;
+}
+// does `fusion` replace `best` as the best breakpoint of their gene pair? (:33-60)
+AGPU_HD bool select_best_replaces(const CandidateTable& t, uint32_t fusion, uint32_t best) {
+	const uint32_t rank_fusion = select_best_rank(t, fusion), rank_best = select_best_rank(t, best);
+	if (rank_fusion != rank_best) return rank_fusion > rank_best;
+	const uint32_t support_fusion = t.split_reads1[fusion] + t.split_reads2[fusion] + t.discordant_mates[fusion], support_best = t.split_reads1[best] + t.split_reads2[best] + t.discordant_mates[best];
+	if (support_fusion != support_best) return support_fusion > support_best;
+	const uint32_t flags = t.flags[fusion], flags_best = t.flags[best];
+	const bool exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2, best_exonic1 = flags_best & CFLAG_EXONIC1, best_exonic2 = flags_best & CFLAG_EXONIC2;
+	if ((exonic1 && !best_exonic1) || (exonic2 && !best_exonic2)) return true;
+	if (!((!best_exonic1 || exonic1 == best_exonic1) && (!best_exonic2 || exonic2 == best_exonic2))) return false;
+	const bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2; // the same for both: the directions are part of the group
+	if (upstream1 ? t.breakpoint1[fusion] < t.breakpoint1[best] : t.breakpoint1[fusion] > t.breakpoint1[best]) return true;
+	if (t.breakpoint1[fusion] != t.breakpoint1[best]) return false;
+	return upstream2 ? t.breakpoint2[fusion] < t.breakpoint2[best] : t.breakpoint2[fusion] > t.breakpoint2[best];
+}
+AGPU_HD uint64_t select_best_group_key(const CandidateTable& t, uint32_t c) { // filtered candidates sort behind all groups
+	const uint32_t flags = t.flags[c];
+	return t.filter[c] == FILTER_none ? (uint64_t) t.gene1[c] << 33 | (uint64_t) t.gene2[c] << 2 | ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u) : ~0ull;
+}
+// the group order[begin .. end) is in iteration order; everything but the best gets the filter
+AGPU_HD void select_best_in_group(const CandidateTable& t, const uint32_t* order, uint32_t begin, uint32_t end) {
+	uint32_t best = order[begin];
+	for (uint32_t j = begin + 1; j < end; ++j)
+		if (select_best_replaces(t, order[j], best)) best = order[j];
+	for (uint32_t j = begin; j < end; ++j)
+		if (order[j] != best) t.filter[order[j]] = FILTER_select_best;
+}
+
+// ---- recover_many_spliced (source/recover_many_spliced.cpp:8-51): a gene pair with >= min_spliced_events distinct spliced breakpoint pairs (binned
+// to 10 bp) gets its spliced candidates back that were discarded by inconsistently_clipped, relative_support, min_support or select_best.  Every
+// candidate that can be recovered also counts towards the events of its pair, so one sorted list serves both passes of the reference.
+AGPU_HD bool many_spliced_takes_part(const AnnotationView& ann, const CandidateTable& t, uint32_t c) {
+	const uint8_t filter = t.filter[c];
+	return !candidate_is_read_through(t, c) && (t.flags[c] & (CFLAG_SPLICED1 | CFLAG_SPLICED2)) && t.gene1[c] != t.gene2[c] && !candidate_overlaps_both_genes(ann, t, c) &&
+	       (filter == FILTER_none || filter == FILTER_inconsistently_clipped || filter == FILTER_relative_support || filter == 17 /* min_support */ || filter == FILTER_select_best);
+}
+AGPU_HD uint64_t many_spliced_pair_key(const AnnotationView& ann, const CandidateTable& t, uint32_t c) { return many_spliced_takes_part(ann, t, c) ? (uint64_t) t.gene1[c] << 32 | t.gene2[c] : ~0ull; }
+AGPU_HD uint64_t many_spliced_bin_key(const CandidateTable& t, uint32_t c) { return (uint64_t) (uint32_t) (t.breakpoint1[c] / 10) << 32 | (uint32_t) (t.breakpoint2[c] / 10); }
+// the gene pair order[begin .. end), sorted by bin key
+AGPU_HD void recover_many_spliced_in_pair(const CandidateTable& t, const uint32_t* order, uint32_t begin, uint32_t end, uint32_t min_spliced_events) {
+	uint32_t events = 1;
+	for (uint32_t j = begin + 1; j < end; ++j)
+		if (many_spliced_bin_key(t, order[j]) != many_spliced_bin_key(t, order[j - 1])) ++events;
+	if (events < min_spliced_events) return;
+	for (uint32_t j = begin; j < end; ++j) t.filter[order[j]] = FILTER_none;
+}
+
 // the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or
 // EVENT_KEPT_UNCOUNTED if it stays without entering the "(remaining=N)" of the stage: filter_both_intronic and filter_end_to_end_fusions skip
 // the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)

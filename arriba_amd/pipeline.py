@@ -306,6 +306,14 @@ class DevicePipeline(object):
         """reference: filter_no_coverage, source/filter_no_coverage.cpp:9-103"""
         return self._event_stage("filter_no_coverage")
 
+    def select_most_supported_breakpoints(self):
+        """reference: select_most_supported_breakpoints, source/select_best.cpp:21-80"""
+        return self._event_stage("select_most_supported_breakpoints")
+
+    def recover_many_spliced(self, min_spliced_events=4):
+        """reference: recover_many_spliced, source/recover_many_spliced.cpp:8-51 (-M, default 4)"""
+        return self._event_stage("recover_many_spliced", min_spliced_events)
+
     def filter_marginal_read_through(self):
         """reference: filter_marginal_read_through, source/filter_marginal_read_through.cpp:8-46"""
         return self._event_stage("filter_marginal_read_through")

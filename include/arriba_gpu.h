@@ -288,6 +288,12 @@ int agpu_filter_short_anchor(agpu_ctx* ctx, uint32_t min_length, uint64_t* remai
 int agpu_filter_end_to_end(agpu_ctx* ctx, uint64_t* remaining);
 int agpu_filter_no_coverage(agpu_ctx* ctx, uint64_t* remaining);
 int agpu_filter_marginal_read_through(agpu_ctx* ctx, uint64_t* remaining);
+/* select_most_supported_breakpoints (source/select_best.cpp:21-80, called at source/arriba.cpp:497-500 and :567-570): of the unfiltered candidates of
+ * one gene pair and direction pair only the best stays; the reference's fold runs in the iteration order of fusions_t (hazard H2), which the device
+ * computes (agpu_candidate_iteration_order) if it has not been computed yet. */
+int agpu_select_most_supported_breakpoints(agpu_ctx* ctx, uint64_t* remaining);
+/* recover_many_spliced (source/recover_many_spliced.cpp:8-51, called at source/arriba.cpp:511-514; min_spliced_events = -M, default 4) */
+int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_events, uint64_t* remaining);
 
 /* Read-level filter state as changed by stages that run on the host after the read-level cascade (filter_multimappers,
  * source/arriba.cpp:427-430): replaces the filter id of every fragment. */

@@ -293,6 +293,17 @@ def check_event_predicates(session, pipeline, golden):
     _compare_candidate_filters(pipeline, index, after, "both_intronic")
     assert remaining == logged("Filtering fusions with both breakpoints in intronic/intergenic regions"), (remaining, logged("Filtering fusions with both breakpoints in intronic/intergenic regions"))
     discarded = {"both_intronic": sum(1 for f in after if f["filter"] == 13)}
+    # select_most_supported_breakpoints (its first call, source/arriba.cpp:497-500) from the state behind recover_both_spliced
+    try:
+        after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "select_most_supported_breakpoints"))
+    except FileNotFoundError:
+        after = None  # select_best switched off in this reference run
+    if after is not None:
+        _inject_candidate_state(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_both_spliced")))
+        remaining = pipeline.select_most_supported_breakpoints()
+        _compare_candidate_filters(pipeline, index, after, "select_most_supported_breakpoints")
+        assert remaining == logged("Selecting best breakpoints from genes with multiple breakpoints"), remaining
+        discarded["select_most_supported_breakpoints"] = sum(1 for f in after if f["filter"] == 24)
     # filter_marginal_read_through from the state behind select_most_supported_breakpoints (its first call, source/arriba.cpp:497-500)
     try:
         before = golden_io.find_dump(golden, "fusions", "select_most_supported_breakpoints")
@@ -304,16 +315,22 @@ def check_event_predicates(session, pipeline, golden):
     _compare_candidate_filters(pipeline, index, after, "filter_marginal_read_through")
     assert remaining == logged("Filtering read-through fusions with breakpoints near the gene boundary"), remaining
     discarded["filter_marginal_read_through"] = sum(1 for f in after if f["filter"] == 25)
-    # filter_short_anchor -> filter_end_to_end -> filter_no_coverage
-    _inject_candidate_state(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_many_spliced")))
-    for stage, run, filter_id, pattern in (("filter_short_anchor", pipeline.filter_short_anchor, 26, "Filtering fusions with anchors"),
+    # recover_many_spliced -> filter_short_anchor -> filter_end_to_end -> filter_no_coverage, chained from the state behind filter_marginal_read_through
+    _inject_candidate_state(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_marginal_read_through")))
+    before_recovery = pipeline.candidates()["filter"].copy()
+    min_spliced_events = int(re.search(r"Searching for fusions with >=(\d+) spliced events", log).group(1))  # -M of the reference run
+    for stage, run, filter_id, pattern in (("recover_many_spliced", lambda: pipeline.recover_many_spliced(min_spliced_events), None, "Searching for fusions with >=\\d+ spliced events"),
+                                           ("filter_short_anchor", pipeline.filter_short_anchor, 26, "Filtering fusions with anchors"),
                                            ("filter_end_to_end_fusions", pipeline.filter_end_to_end, 21, "Filtering end-to-end fusions with low support"),
                                            ("filter_no_coverage", pipeline.filter_no_coverage, 27, "Filtering fusions with no coverage around the breakpoints")):
         remaining = run()
         after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))
         _compare_candidate_filters(pipeline, index, after, stage)
         assert remaining == logged(pattern), (stage, remaining, logged(pattern))
-        discarded[stage] = sum(1 for f in after if f["filter"] == filter_id)
+        if filter_id is None:
+            discarded[stage] = int(((before_recovery != 0) & (pipeline.candidates()["filter"] == 0)).sum())  # candidates recovered
+        else:
+            discarded[stage] = sum(1 for f in after if f["filter"] == filter_id)
     return discarded
 
 
