@@ -5,10 +5,12 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 #include "agpu_context.hpp"
 #include "event_core.hpp"
 #include "device_utils.hpp"
+#include "in_vitro_host.hpp"
 
 using namespace agpu;
 
@@ -63,6 +65,28 @@ __global__ void many_spliced_pair_kernel(CandidateTable t, const uint32_t* order
 	uint32_t end = j + 1;
 	while (end < t.n && pair_keys[end] == pair_keys[j]) ++end;
 	recover_many_spliced_in_pair(t, order, j, end, min_spliced_events);
+}
+
+// filter_in_vitro: expression proxy, gene-pair table, verdicts
+__global__ void gene_read_count_kernel(BatchView b, uint32_t* gene_read_count) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	AGPU_IDSET(genes);
+	load_genes(b, MATE1, i, genes);
+	for (uint32_t g = 0; g < genes.n; ++g) atomicAdd(&gene_read_count[genes.get(g)], 1u);
+	load_genes(b, in_vitro_second_slot(b, i), i, genes);
+	for (uint32_t g = 0; g < genes.n; ++g) atomicAdd(&gene_read_count[genes.get(g)], 1u);
+}
+__global__ void in_vitro_pair_key_kernel(CandidateTable t, uint64_t* keys) { // two keys per candidate: (gene1, gene2) and (gene2, gene1); ~0 = does not count
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	const bool counts = counts_as_exonic_breakpoint(t, c);
+	keys[2 * (uint64_t) c] = counts ? (uint64_t) t.gene1[c] << 32 | t.gene2[c] : ~0ull;
+	keys[2 * (uint64_t) c + 1] = counts ? (uint64_t) t.gene2[c] << 32 | t.gene1[c] : ~0ull;
+}
+__global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n && is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
 }
 
 int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* kernel_name, uint32_t min_anchor_length, uint64_t* remaining) {
@@ -195,6 +219,62 @@ extern "C" int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_eve
 	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
 	collect_kernel_samples(ctx);
 	ctx->last_bytes = (uint64_t) C * 100;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantile, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n)) { set_last_error("filter_in_vitro needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
+	if (!ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint64_t n = ctx->n;
+	const size_t n_genes = (size_t) ctx->n_genes + ctx->n_dummy;
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& gene_read_count = ctx->scratch("events.gene_read_count"); DeviceBuffer& keys_in = ctx->scratch("events.pair_keys_in");
+	DeviceBuffer& keys_sorted = ctx->scratch("events.pair_keys_sorted"); DeviceBuffer& unique_keys = ctx->scratch("events.pair_unique"); DeviceBuffer& unique_counts = ctx->scratch("events.pair_counts");
+	DeviceBuffer& n_runs = ctx->scratch("events.pair_runs"); DeviceBuffer& scratch = ctx->scratch("events.rocprim");
+	const size_t C1 = std::max<uint32_t>(C, 1);
+	ALLOC(counter, 16); ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4); ALLOC(keys_in, C1 * 16); ALLOC(keys_sorted, C1 * 16); ALLOC(unique_keys, C1 * 16); ALLOC(unique_counts, C1 * 8); ALLOC(n_runs, 16);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && ctx->params.filter_enabled[FILTER_in_vitro]) {
+		const CandidateTable& t = ctx->candidates;
+		// (1) chimeric fragments per gene and the quantile of the non-zero counts (the quantile is taken on the host: a few 10^4 numbers)
+		HIP_CHECK(hipMemsetAsync(gene_read_count.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
+		if (n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", n * 22); gene_read_count_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, gene_read_count.as<uint32_t>()); }
+		std::vector<uint32_t> host_counts(n_genes);
+		if (n_genes > 0) HIP_CHECK(hipMemcpyAsync(host_counts.data(), gene_read_count.ptr, n_genes * 4, hipMemcpyDeviceToHost, s));
+		// (2) breakpoints inside exons per ordered gene pair: sort the keys, run lengths
+		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
+		in_vitro_pair_key_kernel<<<grid, BLOCK, 0, s>>>(t, keys_in.as<uint64_t>());
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, keys_in.as<uint64_t>(), keys_sorted.as<uint64_t>(), 2 * (size_t) C, 0, 64, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_keys(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_sorted.as<uint64_t>(), 2 * (size_t) C, 0, 64, s));
+		HIP_CHECK(rocprim::run_length_encode(nullptr, bytes, keys_sorted.as<uint64_t>(), 2 * (size_t) C, unique_keys.as<uint64_t>(), unique_counts.as<uint32_t>(), n_runs.as<uint32_t>(), s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::run_length_encode(scratch.ptr, bytes, keys_sorted.as<uint64_t>(), 2 * (size_t) C, unique_keys.as<uint64_t>(), unique_counts.as<uint32_t>(), n_runs.as<uint32_t>(), s));
+		uint32_t runs = 0;
+		HIP_CHECK(hipMemcpyAsync(&runs, n_runs.ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		InVitroTables tables;
+		tables.gene_read_count = gene_read_count.as<uint32_t>();
+		tables.high_expression_threshold = high_expression_threshold(host_counts, high_expression_quantile);
+		tables.pair_keys = unique_keys.as<uint64_t>(); tables.pair_counts = unique_counts.as<uint32_t>(); tables.n_pairs = runs; // (the run of ~0 keys at the end is never looked up)
+		// (3) the verdicts
+		KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
+		in_vitro_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, t);
+	}
+	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 120 + n * 22;
 	unsigned int kept = 0;
 	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
 	if (remaining) *remaining = kept;

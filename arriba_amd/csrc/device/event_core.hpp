@@ -251,6 +251,88 @@ AGPU_HD void recover_many_spliced_in_pair(const CandidateTable& t, const uint32_
 	for (uint32_t j = begin; j < end; ++j) t.filter[order[j]] = FILTER_none;
 }
 
+// ---- filter_in_vitro (source/filter_in_vitro.cpp:17-228): events with the characteristics of fusions made during reverse transcription -- few split
+// reads, partners expressed in the top quantile (chimeric reads per gene as the proxy), breakpoints inside exons.
+const uint8_t FILTER_in_vitro = 22;
+struct InVitroTables {
+	const uint32_t* gene_read_count;       // chimeric fragments per gene (find_top_expressed_genes, :49-58), GTF genes and dummy genes
+	uint32_t high_expression_threshold;    // the quantile of the non-zero counts (:60-80)
+	const uint64_t* pair_keys; const uint32_t* pair_counts; uint32_t n_pairs; // exonic_breakpoints_by_gene_pair (:93-105): sorted keys gene1 << 32 | gene2
+};
+// genes of a fragment that count towards the expression proxy: those of MATE1 and of MATE2 (discordant mates) or SUPPLEMENTARY (split read) (:52-57)
+AGPU_HD int in_vitro_second_slot(const BatchView& b, uint64_t i) { return b.n_aln[i] == 2 ? MATE2 : SUPPLEMENTARY; }
+AGPU_HD bool counts_as_exonic_breakpoint(const CandidateTable& t, uint32_t c) { // :96-101
+	const uint32_t flags = t.flags[c];
+	return t.gene1[c] != t.gene2[c] && !(flags & (CFLAG_SPLICED1 | CFLAG_SPLICED2)) && (flags & CFLAG_EXONIC1) && (flags & CFLAG_EXONIC2) &&
+	       t.list_offset[3 * (uint64_t) c + 2] - t.list_offset[3 * (uint64_t) c] > 0 && t.filter[c] != 23 /* merge_adjacent */ && t.filter[c] != FILTER_uninteresting_contigs;
+}
+AGPU_HD uint32_t exonic_breakpoints_of_pair(const InVitroTables& tables, uint32_t gene1, uint32_t gene2) {
+	const uint64_t key = (uint64_t) gene1 << 32 | gene2;
+	const uint32_t at = lower_bound_u64(tables.pair_keys, tables.n_pairs, key);
+	return (at < tables.n_pairs && tables.pair_keys[at] == key) ? tables.pair_counts[at] : 0;
+}
+// reference: find_higher_expressed_gene (:17-29): of the genes overlapping the breakpoint (dummy genes included) the first with a strictly higher count
+AGPU_HD uint32_t higher_expressed_gene(const AnnotationView& ann, const InVitroTables& tables, uint32_t contig, int32_t breakpoint, uint32_t gene, GeneQuery& overlapping) {
+	uint32_t highest_expression = tables.gene_read_count[gene];
+	query_point_with_dummy_genes(ann, contig, breakpoint, overlapping);
+	for (uint32_t k = 0; k < overlapping.size(); ++k) {
+		const uint32_t other = overlapping.element(ann, k);
+		if (tables.gene_read_count[other] > highest_expression) { highest_expression = tables.gene_read_count[other]; gene = other; }
+	}
+	return gene;
+}
+AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c) {
+	const uint32_t flags = t.flags[c];
+	const bool spliced1 = flags & CFLAG_SPLICED1, spliced2 = flags & CFLAG_SPLICED2, exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2;
+	const uint8_t filter = t.filter[c];
+	// also filtered events are tagged if they are spliced, so that the filters 'spliced' and 'many_spliced' do not recover them (:112-115)
+	if (filter != FILTER_none && !((spliced1 || spliced2) && (filter == FILTER_relative_support || filter == 17 /* min_support */ || filter == FILTER_homopolymer))) return false;
+	float potential_rt_breakpoints = 0;
+	if (!exonic1) potential_rt_breakpoints += 0.5; else if (!spliced1) potential_rt_breakpoints += 1;
+	if (!exonic2) potential_rt_breakpoints += 0.5; else if (!spliced2) potential_rt_breakpoints += 1;
+	const uint32_t contig1 = t.contigs[c] >> 16, contig2 = t.contigs[c] & 0xFFFF;
+	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
+	// discordant mates that are clipped right at a breakpoint count as split reads (:133-158)
+	const uint32_t min_clipped_length = 3;
+	uint32_t clipped_discordant_mates1 = 0, clipped_discordant_mates2 = 0;
+	for (uint32_t k = t.list_offset[3 * (uint64_t) c + 2]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
+		const uint32_t read = t.read_lists[k];
+		if (b.filter[read] != FILTER_none) continue;
+		for (int slot = 0; slot < b.n_aln[read]; ++slot) {
+			const uint32_t* cigar = cigar_of(b, slot, read); const uint32_t n_cigar = b.cigar_count[slot][read];
+			const bool forward = b.abits[slot][read] & ABIT_STRAND;
+			if (forward && postclipping(cigar, n_cigar) >= min_clipped_length) {
+				if (b.contig[slot][read] == contig1 && b.end[slot][read] == breakpoint1) clipped_discordant_mates1++;
+				else if (b.contig[slot][read] == contig2 && b.end[slot][read] == breakpoint2) clipped_discordant_mates2++;
+			} else if (!forward && preclipping(cigar, n_cigar) >= min_clipped_length) {
+				if (b.contig[slot][read] == contig1 && b.start[slot][read] == breakpoint1) clipped_discordant_mates1++;
+				else if (b.contig[slot][read] == contig2 && b.start[slot][read] == breakpoint2) clipped_discordant_mates2++;
+			}
+		}
+	}
+	const uint32_t split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c];
+	const uint32_t total_split_reads = (clipped_discordant_mates1 < clipped_discordant_mates2 ? clipped_discordant_mates1 : clipped_discordant_mates2) + split_reads1 + split_reads2;
+	IdSetTail overlapping_tail; GeneQuery overlapping(overlapping_tail.words);
+	const uint32_t gene1 = higher_expressed_gene(ann, tables, contig1, breakpoint1, t.gene1[c], overlapping);
+	const uint32_t gene2 = higher_expressed_gene(ann, tables, contig2, breakpoint2, t.gene2[c], overlapping);
+	const uint32_t gene1_expression = tables.gene_read_count[gene1], gene2_expression = tables.gene_read_count[gene2];
+	const uint32_t own_pair = exonic_breakpoints_of_pair(tables, t.gene1[c], t.gene2[c]), expressed_pair = exonic_breakpoints_of_pair(tables, gene1, gene2);
+	const uint32_t exonic_breakpoints = expressed_pair > own_pair ? expressed_pair : own_pair;
+	const int32_t coverage1 = coverage_near(coverage, contig1, breakpoint1, !(flags & CFLAG_UPSTREAM1)), coverage2 = coverage_near(coverage, contig2, breakpoint2, !(flags & CFLAG_UPSTREAM2));
+	const uint32_t supporting_reads = split_reads1 + split_reads2 + discordant_mates;
+	const uint32_t threshold = tables.high_expression_threshold, max_exonic_breakpoints_by_gene_pair = 8;
+	return (double) total_split_reads <= 2 + 0.0001 * (double) (gene1_expression + gene2_expression) &&
+	       (total_split_reads * 2 <= discordant_mates || total_split_reads <= 2) &&
+	       gene1_expression + gene2_expression > threshold &&
+	       !(supporting_reads >= 10 && ((int32_t) supporting_reads * 4) >= (coverage1 > coverage2 ? coverage1 : coverage2) && coverage1 > (int32_t) supporting_reads && coverage2 > (int32_t) supporting_reads &&
+	         (spliced1 || spliced2) && ((spliced1 || !exonic1) && (spliced2 || !exonic2))) &&
+	       (potential_rt_breakpoints > 1 ||
+	        (potential_rt_breakpoints > 0 && (gene1_expression > threshold || gene2_expression > threshold)) ||
+	        gene1_expression > 2 * threshold || gene2_expression > 2 * threshold || (gene1_expression > threshold && gene2_expression > threshold) ||
+	        exonic_breakpoints > max_exonic_breakpoints_by_gene_pair ||
+	        supporting_reads <= 1);
+}
+
 // the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or
 // EVENT_KEPT_UNCOUNTED if it stays without entering the "(remaining=N)" of the stage: filter_both_intronic and filter_end_to_end_fusions skip
 // the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)

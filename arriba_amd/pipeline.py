@@ -310,6 +310,10 @@ class DevicePipeline(object):
         """reference: select_most_supported_breakpoints, source/select_best.cpp:21-80"""
         return self._event_stage("select_most_supported_breakpoints")
 
+    def filter_in_vitro(self, high_expression_quantile=0.998):
+        """reference: filter_in_vitro, source/filter_in_vitro.cpp:82-228 (-Q, default 0.998)"""
+        return self._event_stage("filter_in_vitro", c_float(high_expression_quantile))
+
     def recover_many_spliced(self, min_spliced_events=4):
         """reference: recover_many_spliced, source/recover_many_spliced.cpp:8-51 (-M, default 4)"""
         return self._event_stage("recover_many_spliced", min_spliced_events)

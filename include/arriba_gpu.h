@@ -294,6 +294,9 @@ int agpu_filter_marginal_read_through(agpu_ctx* ctx, uint64_t* remaining);
 int agpu_select_most_supported_breakpoints(agpu_ctx* ctx, uint64_t* remaining);
 /* recover_many_spliced (source/recover_many_spliced.cpp:8-51, called at source/arriba.cpp:511-514; min_spliced_events = -M, default 4) */
 int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_events, uint64_t* remaining);
+/* filter_in_vitro (source/filter_in_vitro.cpp:82-228, called at source/arriba.cpp:483-486; high_expression_quantile = -Q, default 0.998): chimeric
+ * fragments per gene as the expression proxy, breakpoints inside exons per gene pair, the verdict per candidate. */
+int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantile, uint64_t* remaining);
 
 /* Read-level filter state as changed by stages that run on the host after the read-level cascade (filter_multimappers,
  * source/arriba.cpp:427-430): replaces the filter id of every fragment. */

@@ -17,7 +17,7 @@ DEFAULT_GOLDEN_FILES = ["reads.*_annotated.tsv", "filters.*_read_filters_final.t
                         "fusions.*_merge_adjacent_fusions.tsv", "fusions.*_filter_multimappers.tsv", "filters.*_filter_multimappers.tsv", "fusions.*_estimate_expected_fusions.tsv", "fusions.*_filter_relative_support.tsv", "fusions.*_before_filter_mismappers.tsv",
                         "fusions.*_filter_mismappers.tsv", "filters.*_before_filter_mismappers.tsv", "filters.*_filter_mismappers.tsv",
                         "fusions.*_recover_internal_tandem_duplication.tsv", "filters.*_recover_internal_tandem_duplication.tsv", "fusions.*_filter_both_intronic.tsv",
-                        "fusions.*_recover_both_spliced.tsv", "fusions.*_select_most_supported_breakpoints.tsv", "fusions.*_filter_marginal_read_through.tsv", "fusions.*_recover_many_spliced.tsv", "fusions.*_filter_short_anchor.tsv", "fusions.*_filter_end_to_end_fusions.tsv", "fusions.*_filter_no_coverage.tsv",
+                        "fusions.*_filter_in_vitro.tsv", "fusions.*_recover_both_spliced.tsv", "fusions.*_select_most_supported_breakpoints.tsv", "fusions.*_filter_marginal_read_through.tsv", "fusions.*_recover_many_spliced.tsv", "fusions.*_filter_short_anchor.tsv", "fusions.*_filter_end_to_end_fusions.tsv", "fusions.*_filter_no_coverage.tsv",
                         "reads.*_after_find_fusions.tsv"]
 
 DATASETS = {

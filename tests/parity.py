@@ -293,6 +293,18 @@ def check_event_predicates(session, pipeline, golden):
     _compare_candidate_filters(pipeline, index, after, "both_intronic")
     assert remaining == logged("Filtering fusions with both breakpoints in intronic/intergenic regions"), (remaining, logged("Filtering fusions with both breakpoints in intronic/intergenic regions"))
     discarded = {"both_intronic": sum(1 for f in after if f["filter"] == 13)}
+    # filter_in_vitro from the state behind filter_both_intronic (read filters as above)
+    try:
+        after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_in_vitro"))
+    except FileNotFoundError:
+        after = None  # in_vitro switched off in this reference run
+    if after is not None:
+        _inject_candidate_state(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_both_intronic")))
+        quantile = float(re.search(r"expression above the ([0-9.]+)% quantile", log).group(1)) / 100
+        remaining = pipeline.filter_in_vitro(quantile)
+        _compare_candidate_filters(pipeline, index, after, "filter_in_vitro")
+        assert remaining == logged("Filtering in vitro-generated fusions"), remaining
+        discarded["filter_in_vitro"] = sum(1 for f in after if f["filter"] == 22) - sum(1 for f in golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_both_intronic")) if f["filter"] == 22)
     # select_most_supported_breakpoints (its first call, source/arriba.cpp:497-500) from the state behind recover_both_spliced
     try:
         after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "select_most_supported_breakpoints"))
