@@ -89,6 +89,48 @@ __global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView co
 	if (c < t.n && is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
 }
 
+// recover_both_spliced
+__global__ void both_spliced_reads_kernel(BatchView b, AnnotationView ann, CoverageView coverage, const uint32_t* gene_read_count, uint32_t threshold, CandidateTable t, int32_t max_exon_size, uint32_t max_coverage,
+                                          uint32_t* reads, uint64_t* keys) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	const uint32_t count = both_spliced_is_member(ann, t, c) ? both_spliced_supporting_reads(b, ann, coverage, gene_read_count, threshold, t, c, max_exon_size, max_coverage) : 0;
+	reads[c] = count;
+	keys[c] = count > 0 ? both_spliced_group_key(t, c, false) : ~0ull;
+}
+__global__ void both_spliced_gather_kernel(const uint32_t* members, const uint32_t* reads, uint32_t n, uint32_t* member_reads) {
+	const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j < n) member_reads[j] = reads[members[j]];
+}
+__global__ void both_spliced_eligible_kernel(AnnotationView ann, CandidateTable t, const uint64_t* member_keys, const uint32_t* members, const uint32_t* member_reads, uint8_t* eligible, uint32_t* histogram) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	bool yes = false;
+	if (both_spliced_is_recoverable(ann, t, c)) yes = both_spliced_pair_support(ann, t, c, member_keys, members, member_reads, t.n) >= 2; // at least two reads, or the false positive rate sky-rockets
+	eligible[c] = yes;
+	if (yes) { const uint32_t supporting = t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c]; atomicAdd(&histogram[supporting < BOTH_SPLICED_HISTOGRAM_BINS ? supporting : BOTH_SPLICED_HISTOGRAM_BINS - 1], 1u); }
+}
+__global__ void both_spliced_recover_kernel(CandidateTable t, const uint8_t* eligible, uint32_t min_supporting_reads) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n && eligible[c] && t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c] >= min_supporting_reads + both_spliced_proximal_bonus(t, c)) t.filter[c] = FILTER_none;
+}
+
+// chimeric fragments per gene on the device (left in scratch "events.gene_read_count") and the quantile of the non-zero counts
+int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& threshold) {
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	const size_t n_genes = (size_t) ctx->n_genes + ctx->n_dummy;
+	DeviceBuffer& gene_read_count = ctx->scratch("events.gene_read_count");
+	ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4);
+	HIP_CHECK(hipMemsetAsync(gene_read_count.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
+	if (n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", n * 22); gene_read_count_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, gene_read_count.as<uint32_t>()); }
+	std::vector<uint32_t> host_counts(n_genes);
+	if (n_genes > 0) HIP_CHECK(hipMemcpyAsync(host_counts.data(), gene_read_count.ptr, n_genes * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	threshold = high_expression_threshold(host_counts, high_expression_quantile);
+	return AGPU_OK;
+}
+
 int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* kernel_name, uint32_t min_anchor_length, uint64_t* remaining) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
 	if (stage == EVENT_both_intronic && ctx->candidates_imported) { set_last_error("filter_both_intronic reads the read lists: not available on an imported (replicated) candidate table"); return AGPU_ERR_INVALID; }
@@ -235,19 +277,18 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 	const uint64_t n = ctx->n;
 	const size_t n_genes = (size_t) ctx->n_genes + ctx->n_dummy;
 	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& gene_read_count = ctx->scratch("events.gene_read_count"); DeviceBuffer& keys_in = ctx->scratch("events.pair_keys_in");
+	(void) n_genes;
 	DeviceBuffer& keys_sorted = ctx->scratch("events.pair_keys_sorted"); DeviceBuffer& unique_keys = ctx->scratch("events.pair_unique"); DeviceBuffer& unique_counts = ctx->scratch("events.pair_counts");
 	DeviceBuffer& n_runs = ctx->scratch("events.pair_runs"); DeviceBuffer& scratch = ctx->scratch("events.rocprim");
 	const size_t C1 = std::max<uint32_t>(C, 1);
-	ALLOC(counter, 16); ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4); ALLOC(keys_in, C1 * 16); ALLOC(keys_sorted, C1 * 16); ALLOC(unique_keys, C1 * 16); ALLOC(unique_counts, C1 * 8); ALLOC(n_runs, 16);
+	ALLOC(counter, 16); ALLOC(keys_in, C1 * 16); ALLOC(keys_sorted, C1 * 16); ALLOC(unique_keys, C1 * 16); ALLOC(unique_counts, C1 * 8); ALLOC(n_runs, 16);
 	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
 	(void) hipEventRecord(ctx->event_start, s);
 	if (C > 0 && ctx->params.filter_enabled[FILTER_in_vitro]) {
 		const CandidateTable& t = ctx->candidates;
 		// (1) chimeric fragments per gene and the quantile of the non-zero counts (the quantile is taken on the host: a few 10^4 numbers)
-		HIP_CHECK(hipMemsetAsync(gene_read_count.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
-		if (n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", n * 22); gene_read_count_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, gene_read_count.as<uint32_t>()); }
-		std::vector<uint32_t> host_counts(n_genes);
-		if (n_genes > 0) HIP_CHECK(hipMemcpyAsync(host_counts.data(), gene_read_count.ptr, n_genes * 4, hipMemcpyDeviceToHost, s));
+		uint32_t threshold = 0;
+		{ const int status = expression_proxy(ctx, high_expression_quantile, threshold); if (status != AGPU_OK) return status; }
 		// (2) breakpoints inside exons per ordered gene pair: sort the keys, run lengths
 		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
 		in_vitro_pair_key_kernel<<<grid, BLOCK, 0, s>>>(t, keys_in.as<uint64_t>());
@@ -263,7 +304,7 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 		HIP_CHECK(hipStreamSynchronize(s));
 		InVitroTables tables;
 		tables.gene_read_count = gene_read_count.as<uint32_t>();
-		tables.high_expression_threshold = high_expression_threshold(host_counts, high_expression_quantile);
+		tables.high_expression_threshold = threshold;
 		tables.pair_keys = unique_keys.as<uint64_t>(); tables.pair_counts = unique_counts.as<uint32_t>(); tables.n_pairs = runs; // (the run of ~0 keys at the end is never looked up)
 		// (3) the verdicts
 		KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
@@ -275,6 +316,53 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
 	collect_kernel_samples(ctx);
 	ctx->last_bytes = (uint64_t) C * 120 + n * 22;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_recover, float high_expression_quantile, int32_t max_exon_size, uint32_t max_coverage, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n)) { set_last_error("recover_both_spliced needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
+	if (!ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& reads = ctx->scratch("events.reads"); DeviceBuffer& keys_in = ctx->scratch("events.keys_in"); DeviceBuffer& keys_out = ctx->scratch("events.keys_out");
+	DeviceBuffer& members = ctx->scratch("events.order_a"); DeviceBuffer& member_reads = ctx->scratch("events.member_reads"); DeviceBuffer& eligible = ctx->scratch("events.eligible");
+	DeviceBuffer& histogram = ctx->scratch("events.histogram"); DeviceBuffer& scratch = ctx->scratch("events.rocprim");
+	const size_t C1 = std::max<uint32_t>(C, 1);
+	ALLOC(counter, 16); ALLOC(reads, C1 * 4); ALLOC(keys_in, C1 * 8); ALLOC(keys_out, C1 * 8); ALLOC(members, C1 * 4); ALLOC(member_reads, C1 * 4); ALLOC(eligible, C1); ALLOC(histogram, (size_t) BOTH_SPLICED_HISTOGRAM_BINS * 4);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && ctx->params.filter_enabled[19 /* spliced */]) {
+		const CandidateTable& t = ctx->candidates;
+		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
+		uint32_t threshold = 0;
+		{ const int status = expression_proxy(ctx, high_expression_quantile, threshold); if (status != AGPU_OK) return status; }
+		HIP_CHECK(hipMemsetAsync(histogram.ptr, 0, (size_t) BOTH_SPLICED_HISTOGRAM_BINS * 4, s));
+		{ KernelTimer timer(ctx, "both_spliced_reads_kernel", (uint64_t) C * 70 + (uint64_t) ctx->n_list_entries * 6);
+		  both_spliced_reads_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, ctx->scratch("events.gene_read_count").as<uint32_t>(), threshold, t, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>()); }
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), members.as<uint32_t>(), C, 0, 64, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), members.as<uint32_t>(), C, 0, 64, s));
+		both_spliced_gather_kernel<<<grid, BLOCK, 0, s>>>(members.as<uint32_t>(), reads.as<uint32_t>(), C, member_reads.as<uint32_t>());
+		{ KernelTimer timer(ctx, "both_spliced_eligible_kernel", (uint64_t) C * 60);
+		  both_spliced_eligible_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, t, keys_out.as<uint64_t>(), members.as<uint32_t>(), member_reads.as<uint32_t>(), eligible.as<uint8_t>(), histogram.as<uint32_t>()); }
+		std::vector<uint32_t> host_histogram(BOTH_SPLICED_HISTOGRAM_BINS);
+		HIP_CHECK(hipMemcpyAsync(host_histogram.data(), histogram.ptr, (size_t) BOTH_SPLICED_HISTOGRAM_BINS * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		const uint32_t min_supporting_reads = both_spliced_min_supporting_reads(host_histogram, max_fusions_to_recover);
+		both_spliced_recover_kernel<<<grid, BLOCK, 0, s>>>(t, eligible.as<uint8_t>(), min_supporting_reads);
+	}
+	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 200;
 	unsigned int kept = 0;
 	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
 	if (remaining) *remaining = kept;

@@ -333,6 +333,83 @@ AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann,
 	        supporting_reads <= 1);
 }
 
+// ---- recover_both_spliced (source/recover_both_spliced.cpp:13-182): candidates with two spliced breakpoints that were discarded for low support come
+// back when the reads of all candidates of their gene pair (same orientation, or the reciprocal orientation) add up to >= 2.
+AGPU_HD bool both_breakpoints_spliced(const AnnotationView& ann, const CandidateTable& t, uint32_t c) { // source/common.hpp:280-284
+	const uint32_t flags = t.flags[c];
+	if (!(flags & CFLAG_SPLICED1) || !(flags & CFLAG_SPLICED2)) return false;
+	const bool same_strand = ((ann.gene_bits[t.gene1[c]] ^ ann.gene_bits[t.gene2[c]]) & GBIT_STRAND) == 0, same_direction = ((flags & CFLAG_UPSTREAM1) != 0) == ((flags & CFLAG_UPSTREAM2) != 0);
+	return same_strand ? !same_direction : same_direction;
+}
+AGPU_HD bool breakpoint_in_large_exon(const AnnotationView& ann, uint32_t contig, int32_t breakpoint, int32_t max_exon_size) {
+	const FlatIndexView& index = ann.exon_index;
+	if (contig >= index.n_contigs) return false;
+	const uint32_t k = index_lower_bound(index, contig, breakpoint);
+	if (k == index.contig_offset[contig + 1]) return false;
+	const ListRef exons = index_bucket(index, k);
+	for (uint32_t m = 0; m < exons.n; ++m)
+		if (ann.exon_end[exons.p[m]] + 1 - ann.exon_start[exons.p[m]] > max_exon_size) return true;
+	return false;
+}
+// reference: count_supporting_reads (:13-70)
+AGPU_HD uint32_t both_spliced_supporting_reads(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const uint32_t* gene_read_count, uint32_t high_expression_threshold,
+                                               const CandidateTable& t, uint32_t c, int32_t max_exon_size, uint32_t max_coverage) {
+	const bool both_spliced = both_breakpoints_spliced(ann, t, c);
+	const uint32_t split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c];
+	if (gene_read_count[t.gene1[c]] > high_expression_threshold || gene_read_count[t.gene2[c]] > high_expression_threshold)
+		return (both_spliced && discordant_mates <= split_reads1 + split_reads2) ? 1 : 0; // highly expressed partner: count the event as one read at most
+	if (!both_spliced) {
+		const uint32_t flags = t.flags[c];
+		const uint32_t coverage1 = (uint32_t) coverage_near(coverage, t.contigs[c] >> 16, t.breakpoint1[c], !(flags & CFLAG_UPSTREAM1)); // unsigned as in the reference: -1 wraps
+		const uint32_t coverage2 = (uint32_t) coverage_near(coverage, t.contigs[c] & 0xFFFF, t.breakpoint2[c], !(flags & CFLAG_UPSTREAM2));
+		if (coverage1 + coverage2 > (split_reads1 + split_reads2 + discordant_mates) * max_coverage) return 0;
+		if (breakpoint_in_large_exon(ann, t.contigs[c] >> 16, t.breakpoint1[c], max_exon_size) || breakpoint_in_large_exon(ann, t.contigs[c] & 0xFFFF, t.breakpoint2[c], max_exon_size)) return 0;
+	}
+	uint32_t multimappers = 0, unique_mappers = 0;
+	const uint32_t begin = t.list_offset[3 * (uint64_t) c], end = t.list_offset[3 * (uint64_t) c + 3];
+	for (uint32_t k = begin; k < end; ++k) {
+		const uint32_t read = t.read_lists[k];
+		if (b.fbits[read] & FBIT_MULTIMAPPER) multimappers++; else if (b.filter[read] == FILTER_none) unique_mappers++;
+	}
+	if ((double) multimappers >= 0.5 * (double) (end - begin)) return 0;
+	return unique_mappers == 0 ? 1 : unique_mappers;
+}
+// candidates whose reads count for their gene pair (:78-87); the key carries the orientation.  Intragenic groups are never looked up.
+AGPU_HD bool both_spliced_is_member(const AnnotationView& ann, const CandidateTable& t, uint32_t c) {
+	const uint8_t filter = t.filter[c];
+	return t.gene1[c] != t.gene2[c] && filter != 23 /* merge_adjacent */ &&
+	       (filter == FILTER_none || filter == FILTER_in_vitro || filter == FILTER_intronic || filter == FILTER_relative_support || filter == 17 /* min_support */ ||
+	        (filter == FILTER_inconsistently_clipped && both_breakpoints_spliced(ann, t, c)));
+}
+AGPU_HD uint64_t both_spliced_group_key(const CandidateTable& t, uint32_t c, bool reciprocal) {
+	uint32_t directions = ((t.flags[c] & CFLAG_UPSTREAM1) ? 1u : 0u) | ((t.flags[c] & CFLAG_UPSTREAM2) ? 2u : 0u);
+	if (reciprocal) directions ^= 3u;
+	return (uint64_t) t.gene1[c] << 33 | (uint64_t) t.gene2[c] << 2 | directions;
+}
+AGPU_HD bool both_spliced_is_recoverable(const AnnotationView& ann, const CandidateTable& t, uint32_t c) { // :100-113
+	const uint8_t filter = t.filter[c];
+	return filter != FILTER_none && both_breakpoints_spliced(ann, t, c) && t.gene1[c] != t.gene2[c] && !candidate_overlaps_both_genes(ann, t, c) && !candidate_is_read_through(t, c) &&
+	       (filter == FILTER_relative_support || filter == 17 /* min_support */ || filter == FILTER_in_vitro);
+}
+// sum over the members of the candidate's gene pair; members[] = candidates sorted by group key, member_keys[] their keys, reads[] = their counts (> 0)
+AGPU_HD uint32_t both_spliced_pair_support(const AnnotationView& ann, const CandidateTable& t, uint32_t c, const uint64_t* member_keys, const uint32_t* members, const uint32_t* reads, uint32_t n_members) {
+	uint32_t sum = 0;
+	const uint64_t same = both_spliced_group_key(t, c, false), reciprocal = both_spliced_group_key(t, c, true);
+	for (uint32_t j = lower_bound_u64(member_keys, n_members, same); j < n_members && member_keys[j] == same; ++j) sum += reads[j];
+	const bool downstream1 = !(t.flags[c] & CFLAG_UPSTREAM1), downstream2 = !(t.flags[c] & CFLAG_UPSTREAM2);
+	for (uint32_t j = lower_bound_u64(member_keys, n_members, reciprocal); j < n_members && member_keys[j] == reciprocal; ++j) {
+		const uint32_t other = members[j];
+		if (candidate_is_read_through(t, other)) continue;
+		// two events with all breakpoints spliced are not questioned; otherwise the reciprocal pair must support a common genomic breakpoint (:125-130)
+		if (both_breakpoints_spliced(ann, t, other) || ((downstream1 != (t.breakpoint1[c] > t.breakpoint1[other])) && (downstream2 != (t.breakpoint2[c] > t.breakpoint2[other])))) sum += reads[j];
+	}
+	return sum;
+}
+AGPU_HD uint32_t both_spliced_proximal_bonus(const CandidateTable& t, uint32_t c) { // :135
+	int32_t distance = t.breakpoint1[c] - t.breakpoint2[c]; if (distance < 0) distance = -distance;
+	return ((t.contigs[c] >> 16) == (t.contigs[c] & 0xFFFF) && distance < 1000000) ? 1 : 0;
+}
+
 // the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or
 // EVENT_KEPT_UNCOUNTED if it stays without entering the "(remaining=N)" of the stage: filter_both_intronic and filter_end_to_end_fusions skip
 // the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)

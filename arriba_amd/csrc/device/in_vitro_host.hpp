@@ -23,6 +23,19 @@ inline uint32_t high_expression_threshold(const std::vector<uint32_t>& gene_read
 	return counts[quantile];
 }
 
+// recover_both_spliced (source/recover_both_spliced.cpp:152-170): histogram[r] = candidates with r supporting reads that would be recovered; the
+// smallest number of supporting reads is raised until fewer than max_fusions_to_recover candidates with more reads than that are recovered
+inline uint32_t both_spliced_min_supporting_reads(const std::vector<uint32_t>& histogram, uint32_t max_fusions_to_recover) {
+	uint32_t would_be_recovered = 0;
+	for (size_t reads = histogram.size(); reads-- > 0; ) {
+		if (histogram[reads] == 0) continue;
+		would_be_recovered += histogram[reads];
+		if (would_be_recovered >= max_fusions_to_recover) return (uint32_t) reads + 1;
+	}
+	return 1;
+}
+const uint32_t BOTH_SPLICED_HISTOGRAM_BINS = 3 * 32768; // three 15-bit counters
+
 }
 
 #endif

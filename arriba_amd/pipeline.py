@@ -314,6 +314,10 @@ class DevicePipeline(object):
         """reference: filter_in_vitro, source/filter_in_vitro.cpp:82-228 (-Q, default 0.998)"""
         return self._event_stage("filter_in_vitro", c_float(high_expression_quantile))
 
+    def recover_both_spliced(self, max_fusions_to_recover=200, high_expression_quantile=0.998, max_exon_size=1000, max_coverage=1000):
+        """reference: recover_both_spliced, source/recover_both_spliced.cpp:72-182 (the arguments of the call at source/arriba.cpp:491)"""
+        return self._event_stage("recover_both_spliced", max_fusions_to_recover, c_float(high_expression_quantile), max_exon_size, max_coverage)
+
     def recover_many_spliced(self, min_spliced_events=4):
         """reference: recover_many_spliced, source/recover_many_spliced.cpp:8-51 (-M, default 4)"""
         return self._event_stage("recover_many_spliced", min_spliced_events)

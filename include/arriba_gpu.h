@@ -297,6 +297,8 @@ int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_events, uint64
 /* filter_in_vitro (source/filter_in_vitro.cpp:82-228, called at source/arriba.cpp:483-486; high_expression_quantile = -Q, default 0.998): chimeric
  * fragments per gene as the expression proxy, breakpoints inside exons per gene pair, the verdict per candidate. */
 int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantile, uint64_t* remaining);
+/* recover_both_spliced (source/recover_both_spliced.cpp:72-182, called at source/arriba.cpp:489-492 as recover_both_spliced(..., 200, 0.998, 1000, 1000)) */
+int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_recover, float high_expression_quantile, int32_t max_exon_size, uint32_t max_coverage, uint64_t* remaining);
 
 /* Read-level filter state as changed by stages that run on the host after the read-level cascade (filter_multimappers,
  * source/arriba.cpp:427-430): replaces the filter id of every fragment. */

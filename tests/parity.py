@@ -305,6 +305,19 @@ def check_event_predicates(session, pipeline, golden):
         _compare_candidate_filters(pipeline, index, after, "filter_in_vitro")
         assert remaining == logged("Filtering in vitro-generated fusions"), remaining
         discarded["filter_in_vitro"] = sum(1 for f in after if f["filter"] == 22) - sum(1 for f in golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_both_intronic")) if f["filter"] == 22)
+    # recover_both_spliced from the state behind filter_in_vitro
+    try:
+        state = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_in_vitro"))
+        after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_both_spliced"))
+    except FileNotFoundError:
+        after = None
+    if after is not None:
+        _inject_candidate_state(pipeline, index, state)
+        remaining = pipeline.recover_both_spliced()
+        _compare_candidate_filters(pipeline, index, after, "recover_both_spliced")
+        assert remaining == logged("Searching for fusions with spliced split reads"), remaining
+        before_filter = {fusion_key(f): f["filter"] for f in state}
+        discarded["recover_both_spliced"] = sum(1 for f in after if f["filter"] == 0 and before_filter[fusion_key(f)] != 0)  # candidates recovered
     # select_most_supported_breakpoints (its first call, source/arriba.cpp:497-500) from the state behind recover_both_spliced
     try:
         after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "select_most_supported_breakpoints"))
