@@ -359,6 +359,42 @@ def check_event_predicates(session, pipeline, golden):
     return discarded
 
 
+def check_event_chain(session, pipeline, golden):
+    """filter_both_intronic -> filter_in_vitro -> recover_both_spliced -> select_most_supported_breakpoints -> filter_marginal_read_through ->
+    recover_many_spliced -> filter_short_anchor -> filter_end_to_end_fusions -> filter_no_coverage in one go on the device, from the reference's
+    state behind recover_internal_tandem_duplication (the stage in front that is not built): every "(remaining=N)" and the final filters"""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    def logged(pattern):
+        return int(re.search(pattern + r"[^\n]*\(remaining=(\d+)\)", log).group(1))
+    pipeline.find_fusions()
+    pipeline.upload_coverage()
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    names, read_filters = golden_io.read_filters(golden_io.find_dump(golden, "filters", "recover_internal_tandem_duplication"))
+    _inject_candidate_state(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_internal_tandem_duplication")))
+    pipeline.set_read_filters(np.array(read_filters, dtype=np.uint8))
+    quantile = float(re.search(r"expression above the ([0-9.]+)% quantile", log).group(1)) / 100
+    min_spliced_events = int(re.search(r"Searching for fusions with >=(\d+) spliced events", log).group(1))
+    min_anchor_length = int(re.search(r"Filtering fusions with anchors <=(\d+)nt", log).group(1))
+    stages = [(pipeline.filter_both_intronic, "Filtering fusions with both breakpoints in intronic/intergenic regions"),
+              (lambda: pipeline.filter_in_vitro(quantile), "Filtering in vitro-generated fusions"),
+              (pipeline.recover_both_spliced, "Searching for fusions with spliced split reads"),
+              (pipeline.select_most_supported_breakpoints, "Selecting best breakpoints from genes with multiple breakpoints"),
+              (pipeline.filter_marginal_read_through, "Filtering read-through fusions with breakpoints near the gene boundary"),
+              (lambda: pipeline.recover_many_spliced(min_spliced_events), "Searching for fusions with >=\\d+ spliced events"),
+              (lambda: pipeline.filter_short_anchor(min_anchor_length), "Filtering fusions with anchors"),
+              (pipeline.filter_end_to_end, "Filtering end-to-end fusions with low support"),
+              (pipeline.filter_no_coverage, "Filtering fusions with no coverage around the breakpoints")]
+    counts = []
+    for run, pattern in stages:
+        remaining = run()
+        assert remaining == logged(pattern), (pattern, remaining, logged(pattern))
+        counts.append(remaining)
+    _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_no_coverage")), "chain filter_both_intronic .. filter_no_coverage")
+    return counts
+
+
 def check_merge_adjacent(session, pipeline, golden):
     """merge_adjacent_fusions on the device state right after find_fusions against the reference's dump of that stage"""
     import re

@@ -235,6 +235,8 @@ def test_event_level_predicates_match_reference(built, dataset_files, tmp_path):
     the reference run live with the filters in front of them switched off, so that thousands of candidates reach every predicate"""
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"))
     assert parity.check_event_predicates(session, pipeline, conftest.golden_dir("toy3k"))["both_intronic"] > 20
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"))
+    assert parity.check_event_chain(session, pipeline, conftest.golden_dir("toy3k"))[-1] > 0
     if not datasets.reference_available():
         return
     spec = {"args": ["--seed", "33", "--fragments", "60000", "--normal-mult", "0.3", "--contigs", "6", "--contig-len", "500000", "--junctions", "600", "--dup", "0.1"]}
@@ -253,3 +255,5 @@ def test_event_level_predicates_match_reference(built, dataset_files, tmp_path):
     discarded = parity.check_event_predicates(session, pipeline, dump)
     assert discarded["filter_in_vitro"] > 3000 and discarded["recover_both_spliced"] >= 0 and discarded["select_most_supported_breakpoints"] > 5000 and discarded["recover_many_spliced"] > 0 and discarded["filter_marginal_read_through"] > 0, discarded
     assert min(discarded[stage] for stage in ("both_intronic", "filter_short_anchor", "filter_end_to_end_fusions", "filter_no_coverage")) > 1000, discarded
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    assert parity.check_event_chain(session, pipeline, dump)[-1] > 1000

@@ -153,7 +153,10 @@ def test_event_level_predicates_match_reference(dataset_files, emu_api):
     """filter_both_intronic, filter_short_anchor, filter_end_to_end_fusions, filter_no_coverage (event_core.hpp) against the reference's dumps"""
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
     discarded = parity.check_event_predicates(session, pipeline, conftest.golden_dir("toy3k"))
-    assert discarded["both_intronic"] > 20
+    assert discarded["both_intronic"] > 20 and discarded["filter_in_vitro"] > 20 and discarded["select_most_supported_breakpoints"] > 100
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
+    counts = parity.check_event_chain(session, pipeline, conftest.golden_dir("toy3k"))  # the nine stages in one go, state injected only in front
+    assert counts[0] > counts[-1] > 0
 
 
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
