@@ -20,4 +20,8 @@ for name in ['toy3k','stacked4k']:
         print('multimappers',parity.check_multimappers(s,p,golden))
         s,p=parity.run_read_level(parity.open_session,prefix,api=api)
         print('chain',parity.check_chain_to_relative_support(s,p,golden,multimappers=True))
+        s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+        print('event predicates',parity.check_event_predicates(s,p,golden))
+        s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+        print('event chain',parity.check_event_chain(s,p,golden))
 print('done')
