@@ -87,6 +87,7 @@ AGPU_HD bool has_short_anchor(const CandidateTable& t, uint32_t c, uint32_t min_
 // ---- filter_end_to_end_fusions
 // reference: calculate_intronic_fraction (:9-26): bases of the gene not covered by the exon found first in every boundary bucket
 AGPU_HD float intronic_fraction(const AnnotationView& ann, uint32_t gene) {
+	AGPU_FP_AS_WRITTEN
 	const FlatIndexView& index = ann.exon_index;
 	const uint32_t contig = ann.gene_contig[gene];
 	const int32_t gene_start = ann.gene_start[gene], gene_end = ann.gene_end[gene];
@@ -173,6 +174,7 @@ AGPU_HD bool has_no_coverage(const AnnotationView& ann, const CoverageView& cove
 // ---- filter_marginal_read_through: read-through events whose breakpoints sit in the last percent of donor and acceptor and whose reads are a
 // small fraction of the coverage.  The arithmetic types are the reference's: double positions, float margin and allele fraction.
 AGPU_HD bool is_marginal_read_through(const AnnotationView& ann, const CoverageView& coverage, const CandidateTable& t, uint32_t c) {
+	AGPU_FP_AS_WRITTEN
 	if (!candidate_is_read_through(t, c)) return false;
 	const float margin = 0.01f, min_vaf = 0.07f;
 	const uint32_t flags = t.flags[c], gene1 = t.gene1[c], gene2 = t.gene2[c];
@@ -282,6 +284,7 @@ AGPU_HD uint32_t higher_expressed_gene(const AnnotationView& ann, const InVitroT
 	return gene;
 }
 AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c) {
+	AGPU_FP_AS_WRITTEN
 	const uint32_t flags = t.flags[c];
 	const bool spliced1 = flags & CFLAG_SPLICED1, spliced2 = flags & CFLAG_SPLICED2, exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2;
 	const uint8_t filter = t.filter[c];

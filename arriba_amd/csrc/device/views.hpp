@@ -8,10 +8,14 @@
 #define AGPU_HD __host__ __device__ __forceinline__
 #define AGPU_UNROLL _Pragma("unroll")
 #define AGPU_NOUNROLL _Pragma("nounroll")
+// put at the top of a function body whose floating-point expressions restate the reference's: no fused multiply-add (the host compiler of the
+// reference does not contract on baseline x86-64), so that a*b+c rounds twice as it does there
+#define AGPU_FP_AS_WRITTEN _Pragma("clang fp contract(off)")
 #else
 #define AGPU_HD inline
 #define AGPU_UNROLL
 #define AGPU_NOUNROLL
+#define AGPU_FP_AS_WRITTEN
 #endif
 
 namespace agpu {
