@@ -815,7 +815,7 @@ struct IngestWorker {
 		if (record.flag & BAM_FPAIRED) {
 			std::unordered_map<std::string, Record>::iterator parked = collated.find(read_name);
 			if (parked == collated.end()) {
-				collated.insert(std::make_pair(read_name, record));
+				collated.emplace(read_name, std::move(record)); // (the caller decodes the next record into `record`: its buffers may be taken)
 				return; // first mate: wait for the second
 			}
 			previous = std::move(parked->second);
