@@ -230,6 +230,13 @@ def test_sharded_pipeline_two_ranks_on_one_device(built, dataset_files, tmp_path
     assert sum(r["owned_candidates"] for r in reports) == reports[0]["candidates"]
 
 
+def test_gene_set_capacity_is_reported_not_truncated(built, tmp_path):
+    from arriba_amd.pipeline import ArribaError
+    prefix = datasets.generate({"args": ["--seed", "13", "--fragments", "3000", "--contigs", "3", "--contig-len", "300000", "--junctions", "80", "--genes-per-mb", "40", "--gene-stack", "24"]}, str(tmp_path))
+    with pytest.raises(ArribaError, match="gene set exceeded the device capacity"):
+        parity.run_read_level(parity.open_session, prefix)
+
+
 def test_event_level_predicates_match_reference(built, dataset_files, tmp_path):
     """filter_both_intronic, filter_short_anchor, filter_end_to_end_fusions, filter_no_coverage on the GPU: against the committed dumps, and against
     the reference run live with the filters in front of them switched off, so that thousands of candidates reach every predicate"""

@@ -149,6 +149,14 @@ def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
         session.read_chimeric_alignments(header)
 
 
+def test_gene_set_capacity_is_reported_not_truncated(built, emu_api, tmp_path):
+    """An alignment annotated with more genes than a device gene set holds (16) must end the stage with an error, never with a truncated set."""
+    from arriba_amd.pipeline import ArribaError
+    prefix = datasets.generate({"args": ["--seed", "13", "--fragments", "3000", "--contigs", "3", "--contig-len", "300000", "--junctions", "80", "--genes-per-mb", "40", "--gene-stack", "24"]}, str(tmp_path))
+    with pytest.raises(ArribaError, match="gene set exceeded the device capacity"):
+        parity.run_read_level(parity.open_session, prefix, api=emu_api)
+
+
 def test_event_level_predicates_match_reference(dataset_files, emu_api):
     """filter_both_intronic, filter_short_anchor, filter_end_to_end_fusions, filter_no_coverage (event_core.hpp) against the reference's dumps"""
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
