@@ -149,6 +149,21 @@ def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
         session.read_chimeric_alignments(header)
 
 
+def test_bench_cpu_baseline_leg_reports_the_contract_fields(built, tmp_path):
+    """bench.py's cpu_baseline object (the reference binary on a bounded sample, 1 core) and the ingest rate measured on the same file"""
+    import sys
+    sys.path.insert(0, conftest.ROOT)
+    import bench
+    if not datasets.reference_available():
+        pytest.skip("oracle/_ref/arriba_ref is not built")
+    baseline = bench.cpu_baseline(1000, str(tmp_path))
+    assert baseline["kind"] == "reference" and baseline["cores"] == 1 and baseline["unit"] == "chimeric reads/s"
+    assert baseline["value"] > 1000 and "chimeric fragments of the same synthetic workload" in baseline["sample"]
+    assert baseline["host_ingest_same_sample"]["value"] > baseline["value"]  # the ingest alone is faster than the reference's whole job
+    same_reference, other_reads = bench.workload_args(1000, 7, 0), bench.workload_args(1000, 7, 9)
+    assert same_reference[:2] == other_reads[:2] and same_reference[2:4] != other_reads[2:4]  # shards of one sample: one genome seed, different read seeds
+
+
 def test_gene_set_capacity_is_reported_not_truncated(built, emu_api, tmp_path):
     """An alignment annotated with more genes than a device gene set holds (16) must end the stage with an error, never with a truncated set."""
     from arriba_amd.pipeline import ArribaError
