@@ -30,6 +30,17 @@ def test_device_library_exports_every_declared_symbol(built):
     assert lib.agpu_api_version() == 1
 
 
+@pytest.mark.parametrize("header", ["arriba_gpu.h", "arriba_host.h"])
+def test_public_headers_are_plain_c(header, tmp_path):
+    """The drop-in boundary is a C ABI: the headers must compile as C99 on their own (no C++ types, no torch types in the signatures)."""
+    import subprocess
+    source = tmp_path / "include_check.c"
+    source.write_text('#include "%s"\nint main(void) { return 0; }\n' % header)
+    result = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + os.path.join(conftest.ROOT, "include"), str(source)],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert result.returncode == 0, result.stdout
+
+
 def test_host_library_exports_every_declared_symbol(built):
     import ctypes
     lib = ctypes.CDLL(os.path.join(ROOT, "arriba_amd", "lib", "libarriba_host.so"))
