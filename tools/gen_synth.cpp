@@ -64,6 +64,8 @@ struct Generator::Impl {
 	std::vector<double> gene_cdf;
 	std::vector<std::pair<int,int> > read_through_pairs; // (left gene, right gene) on the same strand, close together
 	std::vector<std::vector<int> > genes_by_contig;
+	struct ItdHotspot { int gene, q, d; };
+	std::vector<ItdHotspot> itd_hotspots;
 	int n_main_contigs = 0, viral_contig = -1, viral_contig2 = -1, boring_contig = -1;
 	explicit Impl(uint64_t seed): rng(seed) {}
 };
@@ -292,6 +294,21 @@ void Generator::build_reference() {
 		impl_->gene_cdf.resize(genes_.size());
 		for (size_t i = 0; i < weight.size(); ++i) { total += weight[i]; impl_->gene_cdf[i] = total; }
 		for (size_t i = 0; i < weight.size(); ++i) impl_->gene_cdf[i] /= total;
+	}
+
+	// recurrent internal tandem duplications: a fixed segment [q, q + d) inside a coding exon (drawn from a generator of their own)
+	if (c.itd_hotspots > 0) {
+		Rng hotspot_rng(c.seed ^ 0x17D5ULL);
+		for (int attempt = 0; attempt < 100000 && (int) impl_->itd_hotspots.size() < c.itd_hotspots; ++attempt) {
+			const int g = (int) hotspot_rng.below(genes_.size());
+			const Transcript& t = genes_[g].transcripts[0];
+			if (t.cds_start < 0) continue;
+			const Exon& exon = t.exons[hotspot_rng.below(t.exons.size())];
+			if (exon.end - exon.start < 260 || exon.start < t.cds_start || exon.end > t.cds_end) continue;
+			Impl::ItdHotspot hotspot;
+			hotspot.gene = g; hotspot.d = hotspot_rng.range(18, 48); hotspot.q = hotspot_rng.range(exon.start + 90, exon.end - hotspot.d - 90);
+			impl_->itd_hotspots.push_back(hotspot);
+		}
 	}
 
 	// neighbouring genes on the same strand (read-through candidates)
@@ -683,7 +700,30 @@ struct Builder {
 	}
 
 	// ordinary proper pair inside one transcript; occasionally an internal-tandem-duplication read or an adapter-clipped pair
+	// a read pair over one of the recurrent internal tandem duplications: the forward read runs to the end of the duplicated segment and re-enters it
+	Fragment itd_hotspot_pair() const {
+		const int L = c.read_length;
+		const Generator::Impl::ItdHotspot& hotspot = impl.itd_hotspots[rng.below(impl.itd_hotspots.size())];
+		const Gene& gene = genes[hotspot.gene];
+		const int m = rng.range(45, 65), clip = L - m, insert = rng.range(L + 20, L + 120);
+		Fragment fragment(2);
+		Record& f = fragment[0];
+		Record& r = fragment[1];
+		Aln reverse = build(gene.contig, hotspot.gene, hotspot.q + hotspot.d - m, true, insert - L, L);
+		const bool forward_is_read1 = rng.chance(0.5);
+		f.contig = gene.contig; f.pos = hotspot.q + hotspot.d - m; f.sa = false;
+		f.cigar.push_back(cig(m, OP_M)); f.cigar.push_back(cig(clip, OP_S));
+		f.seq = sequences[gene.contig].substr(hotspot.q + hotspot.d - m, m) + sequences[gene.contig].substr(hotspot.q, clip);
+		r.contig = reverse.contig; r.pos = reverse.start; r.cigar = reverse.cigar; r.seq = reverse.seq; r.sa = false;
+		f.flag = F_PAIRED | F_PROPER | F_MREVERSE | (forward_is_read1 ? F_READ1 : F_READ2);
+		r.flag = F_PAIRED | F_PROPER | F_REVERSE | (forward_is_read1 ? F_READ2 : F_READ1);
+		if (rng.chance(0.5))
+			std::swap(fragment[0], fragment[1]);
+		return fragment;
+	}
+
 	Fragment normal_pair() const {
+		if (!impl.itd_hotspots.empty() && rng.chance(c.frac_itd_hotspot)) return itd_hotspot_pair();
 		int L = c.read_length;
 		double u = rng.unif();
 		size_t g = std::lower_bound(impl.gene_cdf.begin(), impl.gene_cdf.end(), u) - impl.gene_cdf.begin();
@@ -985,6 +1025,8 @@ int main(int argc, char** argv) {
 		else if (a == "--contig-len") config.contig_length = atoi(value());
 		else if (a == "--genes-per-mb") config.genes_per_mb = atof(value());
 		else if (a == "--gene-stack") config.gene_stack = atoi(value());
+		else if (a == "--itd-hotspots") config.itd_hotspots = atoi(value());
+		else if (a == "--itd-hotspot-frac") config.frac_itd_hotspot = atof(value());
 		else if (a == "--read-len") config.read_length = atoi(value());
 		else if (a == "--junctions") config.junctions = atoi(value());
 		else if (a == "--clip-min") config.clip_min = atoi(value());

@@ -37,6 +37,8 @@ struct Config {
 	double frac_low_complexity_junctions = 0.04;
 	double frac_paralog_genes = 0.05;
 	double frac_itd = 0.01;          // of ordinary pairs: internal tandem duplication reads
+	int itd_hotspots = 0;            // > 0: that many recurrent internal tandem duplications (fixed position and length inside a coding exon), each
+	double frac_itd_hotspot = 0.02;  //      hit by this fraction of the ordinary pairs divided among them (no random numbers are drawn when 0)
 	double frac_malformed = 0.003;
 	double error_rate = 0.005, high_error_fraction = 0.01, high_error_rate = 0.08;
 	int clip_min = 12, clip_max = 60;
