@@ -31,13 +31,34 @@ __global__ void merge_sort_key_kernel(CandidateTable t, const uint32_t* order, i
 	const uint32_t c = order[j];
 	keys[j] = pass == 1 ? merge_diagonal_key(t, c) : merge_group_key(t, c, max_itd_length);
 }
-__global__ void merge_cluster_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, int32_t max_distance, uint32_t max_itd_length, uint32_t* extra_split_list) {
+__global__ void merge_cluster_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, int32_t max_distance, uint32_t max_itd_length, uint32_t* extra_split_list, ItdAppended appended) {
 	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
 	if (j >= t.n || group_keys[j] == ~0ull) return;
 	if (j > 0 && merge_cluster_continues(t, order, j, max_distance, max_itd_length)) return; // not the first of its cluster
 	uint32_t end = j + 1;
 	while (end < t.n && merge_cluster_continues(t, order, end, max_distance, max_itd_length)) ++end;
-	if (end - j > 1) merge_cluster(t, order, j, end, max_distance, max_itd_length, extra_split_list);
+	if (end - j > 1) merge_cluster(t, order, j, end, max_distance, max_itd_length, extra_split_list, appended);
+}
+// after the sweep, only if an internal tandem duplication absorbed another one: the read lists with the appended entries merged in
+__global__ void merged_list_size_kernel(CandidateTable t, ItdAppended appended, uint32_t* sizes) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	for (uint32_t list = 0; list < 3; ++list)
+		sizes[3 * (uint64_t) c + list] = t.list_offset[3 * (uint64_t) c + list + 1] - t.list_offset[3 * (uint64_t) c + list] + (list < 2 ? appended.length[2 * (uint64_t) c + list] : 0);
+}
+__global__ void merged_list_copy_kernel(CandidateTable t, ItdAppended appended, const uint32_t* new_offset, uint32_t* new_lists) {
+	// one wavefront per candidate: the lists of a hot candidate hold hundreds of entries
+	const uint32_t c = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (c >= t.n) return;
+	for (uint32_t list = 0; list < 3; ++list) {
+		const uint32_t own_begin = t.list_offset[3 * (uint64_t) c + list], own_length = t.list_offset[3 * (uint64_t) c + list + 1] - own_begin;
+		uint32_t* out = new_lists + new_offset[3 * (uint64_t) c + list];
+		for (uint32_t j = lane; j < own_length; j += 64) out[j] = t.read_lists[own_begin + j];
+		if (list < 2) {
+			const uint32_t* extra = appended.pool + appended.begin[2 * (uint64_t) c + list];
+			for (uint32_t j = lane; j < appended.length[2 * (uint64_t) c + list]; j += 64) out[own_length + j] = extra[j];
+		}
+	}
 }
 __global__ void count_unfiltered_kernel(CandidateTable t, unsigned int* remaining) {
 	__shared__ uint32_t block_sum;
@@ -55,10 +76,20 @@ extern "C" int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, 
 	const uint32_t C = ctx->n_candidates;
 	DeviceBuffer& keys_in = ctx->scratch("merge.keys_in"); DeviceBuffer& keys_out = ctx->scratch("merge.keys_out"); DeviceBuffer& order_a = ctx->scratch("merge.order_a"); DeviceBuffer& order_b = ctx->scratch("merge.order_b");
 	DeviceBuffer& counter = ctx->scratch("merge.counter"); DeviceBuffer& scratch = ctx->scratch("merge.rocprim");
+	DeviceBuffer& appended_pool = ctx->scratch("merge.appended_pool"); DeviceBuffer& appended_begin = ctx->scratch("merge.appended_begin"); DeviceBuffer& appended_length = ctx->scratch("merge.appended_length");
 	const size_t C1 = std::max<uint32_t>(C, 1);
 	ALLOC(keys_in, C1 * 8); ALLOC(keys_out, C1 * 8); ALLOC(order_a, C1 * 4); ALLOC(order_b, C1 * 4); ALLOC(counter, 16); ALLOC(ctx->cand_extra_split_list, C1 * 4);
 	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
 	HIP_CHECK(hipMemsetAsync(ctx->cand_extra_split_list.ptr, 0, C1 * 4, s));
+	// entries that internal tandem duplications take over from the candidates they absorb: rare, a pool of 1 M entries + 1 per list entry (at most 64 M) is ample
+	// (a candidate's region is rewritten whenever it absorbs again); counter[1] = pool cursor, counter[2] = overflow flag
+	const uint32_t pool_capacity = (uint32_t) std::min<uint64_t>(64u << 20, (uint64_t) ctx->n_list_entries + (1u << 20));
+	ALLOC(appended_pool, (size_t) pool_capacity * 4); ALLOC(appended_begin, C1 * 8); ALLOC(appended_length, C1 * 8);
+	HIP_CHECK(hipMemsetAsync(appended_begin.ptr, 0, C1 * 8, s));
+	HIP_CHECK(hipMemsetAsync(appended_length.ptr, 0, C1 * 8, s));
+	ItdAppended appended;
+	appended.pool = appended_pool.as<uint32_t>(); appended.capacity = pool_capacity; appended.cursor = counter.as<uint32_t>() + 1; appended.overflow = counter.as<uint32_t>() + 2;
+	appended.begin = appended_begin.as<uint32_t>(); appended.length = appended_length.as<uint32_t>();
 	(void) hipEventRecord(ctx->event_start, s);
 	if (C > 0 && ctx->params.filter_enabled[FILTER_merge_adjacent]) {
 		const CandidateTable& t = ctx->candidates;
@@ -79,7 +110,32 @@ extern "C" int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, 
 			std::swap(order, next);
 		}
 		{ KernelTimer timer(ctx, "merge_cluster_kernel", (uint64_t) C * 40);
-		  merge_cluster_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, order, keys_out.as<uint64_t>(), max_distance, ctx->params.max_itd_length, ctx->cand_extra_split_list.as<uint32_t>()); }
+		  merge_cluster_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, order, keys_out.as<uint64_t>(), max_distance, ctx->params.max_itd_length, ctx->cand_extra_split_list.as<uint32_t>(), appended); }
+		// did an internal tandem duplication absorb another one?  Then the read lists are rebuilt with the appended entries behind the own ones.
+		uint32_t pool_state[2] = { 0, 0 };
+		HIP_CHECK(hipMemcpyAsync(pool_state, counter.as<uint32_t>() + 1, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (pool_state[1]) { set_last_error("merge_adjacent_fusions: the pool of read-list entries appended to internal tandem duplications is exhausted"); return AGPU_ERR_CAPACITY; }
+		if (pool_state[0] > 0) {
+			DeviceBuffer& sizes = ctx->scratch("merge.list_sizes"); DeviceBuffer& new_offset = ctx->scratch("merge.list_offset"); DeviceBuffer& new_lists = ctx->scratch("merge.read_lists");
+			ALLOC(sizes, (3 * (size_t) C + 1) * 4); ALLOC(new_offset, (3 * (size_t) C + 1) * 4);
+			HIP_CHECK(hipMemsetAsync(sizes.as<uint32_t>() + 3 * (size_t) C, 0, 4, s));
+			merged_list_size_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, appended, sizes.as<uint32_t>());
+			HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, sizes.as<uint32_t>(), new_offset.as<uint32_t>(), 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
+			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+			HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, sizes.as<uint32_t>(), new_offset.as<uint32_t>(), 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
+			uint32_t total = 0;
+			HIP_CHECK(hipMemcpyAsync(&total, new_offset.as<uint32_t>() + 3 * (size_t) C, 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+			ALLOC(new_lists, std::max<size_t>(total, 1) * 4);
+			{ KernelTimer timer(ctx, "merged_list_copy_kernel", (uint64_t) total * 8);
+			  merged_list_copy_kernel<<<grid_for((uint64_t) C * 64), BLOCK, 0, s>>>(t, appended, new_offset.as<uint32_t>(), new_lists.as<uint32_t>()); }
+			HIP_CHECK(hipStreamSynchronize(s));
+			ctx->cand_list_offset.swap(new_offset); ctx->cand_read_lists.swap(new_lists);
+			ctx->candidates.list_offset = ctx->cand_list_offset.as<uint32_t>(); ctx->candidates.read_lists = ctx->cand_read_lists.as<uint32_t>();
+			ctx->n_list_entries = total;
+			HIP_CHECK(hipMemsetAsync(ctx->cand_extra_split_list.ptr, 0, C1 * 4, s)); // the appended entries are part of the lists now
+		}
 	}
 	if (C > 0) count_unfiltered_kernel<<<tally_grid(C, BLOCK), BLOCK, 0, s>>>(ctx->candidates, counter.as<unsigned int>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));

@@ -51,8 +51,37 @@ AGPU_HD bool merge_cluster_continues(const CandidateTable& t, const uint32_t* or
 	       t.breakpoint1[current] - t.breakpoint1[previous] <= max_distance;
 }
 
+// When an internal tandem duplication absorbs another one, the reference appends the split-read lists of the absorbed candidate to its own
+// (source/merge_adjacent_fusions.cpp:99-103): later stages walk these reads (filter_multimappers, recover_internal_tandem_duplication, ...).
+// The appended entries are collected here -- per candidate and split list a region of `pool` holding everything appended so far, in the
+// order of the reference -- and merged into the read lists after the sweep (agpu_merge.hip: rebuild).  A candidate lives in one cluster and a
+// cluster is swept by one thread, so only the pool cursor is shared.
+struct ItdAppended {
+	uint32_t* pool; uint32_t capacity; uint32_t* cursor;
+	uint32_t* begin;   // [2 * n_candidates] region of split_read1_list / split_read2_list
+	uint32_t* length;  // [2 * n_candidates]
+	uint32_t* overflow;
+};
+AGPU_HD void itd_append_lists(const CandidateTable& t, const ItdAppended& appended, uint32_t fusion, uint32_t other) {
+	for (uint32_t list = 0; list < 2; ++list) {
+		const uint32_t own_begin = t.list_offset[3 * (uint64_t) other + list], own_length = t.list_offset[3 * (uint64_t) other + list + 1] - own_begin;
+		const uint32_t other_length = appended.length[2 * (uint64_t) other + list], old_length = appended.length[2 * (uint64_t) fusion + list];
+		if (own_length + other_length == 0) continue;
+		const uint32_t new_length = old_length + own_length + other_length;
+		const uint32_t at = atomic_add_u32(appended.cursor, new_length);
+		if ((uint64_t) at + new_length > appended.capacity) { *appended.overflow = 1; continue; }
+		uint32_t* out = appended.pool + at;
+		const uint32_t* old = appended.pool + appended.begin[2 * (uint64_t) fusion + list];
+		for (uint32_t j = 0; j < old_length; ++j) out[j] = old[j];
+		for (uint32_t j = 0; j < own_length; ++j) out[old_length + j] = t.read_lists[own_begin + j];
+		const uint32_t* theirs = appended.pool + appended.begin[2 * (uint64_t) other + list];
+		for (uint32_t j = 0; j < other_length; ++j) out[old_length + own_length + j] = theirs[j];
+		appended.begin[2 * (uint64_t) fusion + list] = at; appended.length[2 * (uint64_t) fusion + list] = new_length;
+	}
+}
+
 // The reference's sweep over the cluster order[begin .. end) (ascending breakpoint1, then breakpoint2).
-AGPU_HD void merge_cluster(const CandidateTable& t, const uint32_t* order, uint32_t begin, uint32_t end, int32_t max_distance, uint32_t max_itd_length, uint32_t* extra_split_list) {
+AGPU_HD void merge_cluster(const CandidateTable& t, const uint32_t* order, uint32_t begin, uint32_t end, int32_t max_distance, uint32_t max_itd_length, uint32_t* extra_split_list, const ItdAppended& appended) {
 	for (uint32_t e = begin; e < end; ++e) {
 		const uint32_t fusion = order[e];
 		const bool is_itd = candidate_is_internal_tandem_duplication(t, fusion, max_itd_length);
@@ -83,6 +112,7 @@ AGPU_HD void merge_cluster(const CandidateTable& t, const uint32_t* order, uint3
 						sum_split_lists += merge_split_list_size(t, extra_split_list, other);
 					} else {
 						t.filter[other] = FILTER_merge_adjacent;
+						if (is_itd) itd_append_lists(t, appended, fusion, other);
 					}
 				}
 				if (!fusion_has_most_support) break;

@@ -359,6 +359,29 @@ def check_event_predicates(session, pipeline, golden):
     return discarded
 
 
+def check_read_lists(session, pipeline, golden, stage):
+    """the three read lists of every candidate against the reference's dump of `stage` (contents, or sizes for dumps written without lists)"""
+    fusions = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))
+    table = pipeline.candidates()
+    names = session.fragment_names()
+    offsets = table["list_offset"].astype(np.int64)
+    lists = table["read_lists"]
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    problems, appended = [], 0
+    for f in fusions:
+        c = index[fusion_key(f)]
+        for k, field in enumerate(("split_read1_list", "split_read2_list", "discordant_mate_list")):
+            reads = lists[offsets[3 * c + k]:offsets[3 * c + k + 1]]
+            expected = f[field]
+            if len(expected) == 1 and expected[0].isdigit():
+                if len(reads) != int(expected[0]):
+                    problems.append((field + ".size", fusion_key(f), len(reads), int(expected[0])))
+            elif [names[r] for r in reads] != expected:
+                problems.append((field, fusion_key(f), len(reads), len(expected)))
+    assert not problems, (len(problems), problems[:10])
+    return len(fusions)
+
+
 def check_event_chain(session, pipeline, golden):
     """filter_both_intronic -> filter_in_vitro -> recover_both_spliced -> select_most_supported_breakpoints -> filter_marginal_read_through ->
     recover_many_spliced -> filter_short_anchor -> filter_end_to_end_fusions -> filter_no_coverage in one go on the device, from the reference's
