@@ -118,6 +118,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "merge_adjacent_fusions": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
         "filter_multimappers": (c_int, [ctx, POINTER(c_uint64), POINTER(c_uint64)]),
         "upload_coverage": (c_int, [ctx, POINTER(CoverageView)]),
+        "recover_internal_tandem_duplication": (c_int, [ctx, c_uint32, c_float, POINTER(c_uint64)]),
         "filter_both_intronic": (c_int, [ctx, POINTER(c_uint64)]),
         "filter_short_anchor": (c_int, [ctx, c_uint32, POINTER(c_uint64)]),
         "filter_end_to_end": (c_int, [ctx, POINTER(c_uint64)]),

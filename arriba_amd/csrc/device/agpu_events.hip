@@ -115,6 +115,37 @@ __global__ void both_spliced_recover_kernel(CandidateTable t, const uint8_t* eli
 	if (c < t.n && eligible[c] && t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c] >= min_supporting_reads + both_spliced_proximal_bonus(t, c)) t.filter[c] = FILTER_none;
 }
 
+// recover_internal_tandem_duplication
+__global__ void count_duplicates_kernel(BatchView b, unsigned int* duplicates) {
+	__shared__ uint32_t block_sum;
+	uint32_t mine = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; i < b.n; i += gridDim.x * (uint64_t) BLOCK) mine += b.filter[i] == FILTER_duplicates;
+	block_tally(mine, duplicates, &block_sum);
+}
+__global__ void itd_verdict_kernel(BatchView b, AnnotationView ann, CoverageView coverage, CandidateTable t, uint32_t max_itd_length, uint32_t min_supporting_reads, float min_fraction_of_coverage,
+                                   uint32_t subsampling_threshold, float duplication_rate, const uint32_t* iteration_rank, uint8_t* verdict, uint32_t* owner, unsigned int* error) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	const int result = itd_verdict(b, ann, coverage, t, c, max_itd_length, min_supporting_reads, min_fraction_of_coverage, subsampling_threshold, duplication_rate);
+	if (result == 2) atomicOr(error, 1u);
+	verdict[c] = result == 1;
+	if (result == 1) // claim the reads this candidate would clear: the first recovered candidate in iteration order counts them
+		for (uint32_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k) {
+			const uint32_t read = t.read_lists[k];
+			if (itd_read_is_cleared(b.filter[read])) atomicMin(&owner[read], iteration_rank[c]);
+		}
+}
+__global__ void itd_recover_kernel(BatchView b, CandidateTable t, const uint32_t* iteration_rank, const uint8_t* verdict, uint32_t* owner) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n || !verdict[c]) return;
+	itd_count_cleared_reads(b, t, c, iteration_rank[c], owner);
+	t.filter[c] = FILTER_none;
+}
+__global__ void itd_clear_reads_kernel(BatchView b, const uint32_t* owner) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i < b.n && owner[i] != ITD_READ_UNCLAIMED) b.filter[i] = FILTER_none;
+}
+
 // chimeric fragments per gene on the device (left in scratch "events.gene_read_count") and the quantile of the non-zero counts
 int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& threshold) {
 	hipStream_t s = ctx->stream;
@@ -366,5 +397,48 @@ extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_
 	unsigned int kept = 0;
 	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
 	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_recover_internal_tandem_duplication(agpu_ctx* ctx, uint32_t min_supporting_reads, float min_fraction_of_coverage, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n)) { set_last_error("recover_internal_tandem_duplication needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
+	if (!ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->iteration_order_done) { const int status = agpu_candidate_iteration_order(ctx, nullptr); if (status != AGPU_OK) return status; } // hazard H2
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint64_t n = ctx->n;
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& verdict = ctx->scratch("events.itd_verdict"); DeviceBuffer& owner = ctx->scratch("events.itd_owner");
+	const size_t C1 = std::max<uint32_t>(C, 1), n1 = std::max<uint64_t>(n, 1);
+	ALLOC(counter, 16); ALLOC(verdict, C1); ALLOC(owner, n1 * 4);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && n > 0 && ctx->params.filter_enabled[FILTER_internal_tandem_duplication]) {
+		const CandidateTable& t = ctx->candidates;
+		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
+		// the duplication rate, because the coverage includes duplicates (:15-20)
+		count_duplicates_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(ctx->batch, counter.as<unsigned int>() + 1);
+		unsigned int duplicates = 0;
+		HIP_CHECK(hipMemcpyAsync(&duplicates, counter.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		const float duplication_rate = 1.0 * duplicates / n;
+		HIP_CHECK(hipMemsetAsync(owner.ptr, 0xFF, n1 * 4, s));
+		{ KernelTimer timer(ctx, "itd_verdict_kernel", (uint64_t) C * 40);
+		  itd_verdict_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, t, ctx->params.max_itd_length, min_supporting_reads, min_fraction_of_coverage, ctx->params.subsampling_threshold, duplication_rate,
+			ctx->cand_iteration_rank.as<uint32_t>(), verdict.as<uint8_t>(), owner.as<uint32_t>(), counter.as<unsigned int>() + 2); }
+		itd_recover_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, t, ctx->cand_iteration_rank.as<uint32_t>(), verdict.as<uint8_t>(), owner.as<uint32_t>());
+		itd_clear_reads_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, owner.as<uint32_t>());
+	}
+	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 60 + n * 5;
+	unsigned int host_counters[3] = { 0, 0, 0 };
+	HIP_CHECK(hipMemcpy(host_counters, counter.ptr, sizeof(host_counters), hipMemcpyDeviceToHost));
+	if (host_counters[2]) { set_last_error("recover_internal_tandem_duplication: more exons at a breakpoint than a device set holds"); return AGPU_ERR_CAPACITY; }
+	if (remaining) *remaining = host_counters[0];
 	return AGPU_OK;
 }

@@ -413,6 +413,58 @@ AGPU_HD uint32_t both_spliced_proximal_bonus(const CandidateTable& t, uint32_t c
 	return ((t.contigs[c] >> 16) == (t.contigs[c] & 0xFFFF) && distance < 1000000) ? 1 : 0;
 }
 
+// ---- recover_internal_tandem_duplication (source/recover_internal_tandem_duplication.cpp:11-85): internal tandem duplications inside a coding exon
+// that were discarded for one of five reasons come back when enough split reads (unfiltered, or discarded as hairpin / inconsistently clipped /
+// mismatches) support them; those reads are un-filtered and counted.  A read listed by several recovered candidates is counted by the first of
+// them in the iteration order of fusions_t (hazard H2): the device finds that one with an atomicMin over the iteration ranks.
+const uint8_t FILTER_internal_tandem_duplication = 16, FILTER_intragenic_exonic = 15;
+AGPU_HD bool itd_read_counts(uint8_t filter) { return filter == FILTER_none || filter == FILTER_hairpin || filter == FILTER_inconsistently_clipped || filter == FILTER_mismatches; }
+AGPU_HD bool itd_read_is_cleared(uint8_t filter) { return filter == FILTER_hairpin || filter == FILTER_inconsistently_clipped || filter == FILTER_mismatches; }
+// returns 1 = recover, 0 = leave, 2 = the exons at the breakpoints do not fit a device set (capacity error)
+AGPU_HD int itd_verdict(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const CandidateTable& t, uint32_t c, uint32_t max_itd_length, uint32_t min_supporting_reads,
+                        float min_fraction_of_coverage, uint32_t subsampling_threshold, float duplication_rate) {
+	AGPU_FP_AS_WRITTEN
+	const uint8_t filter = t.filter[c];
+	if (filter != FILTER_relative_support && filter != FILTER_intragenic_exonic && filter != FILTER_hairpin && filter != FILTER_inconsistently_clipped && filter != FILTER_mismatches) return 0;
+	const uint32_t flags = t.flags[c], gene = t.gene1[c];
+	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
+	if (!(gene == t.gene2[c] && (flags & CFLAG_EXONIC1) && (flags & CFLAG_EXONIC2) && (flags & CFLAG_UPSTREAM1) && !(flags & CFLAG_UPSTREAM2) && (ann.gene_bits[gene] & GBIT_PROTEIN_CODING) &&
+	      (uint32_t) (breakpoint2 - breakpoint1) < max_itd_length)) return 0;
+	// both breakpoints in the coding region of one exon of the gene (they may protrude into the introns by 7 bases)
+	const int32_t protrude_into_introns = 7;
+	AGPU_IDSET(exons);
+	IdentityMap identity;
+	query_by_coordinate(ann.exon_index, t.contigs[c] >> 16, breakpoint1, breakpoint2, identity, exons);
+	if (exons.overflow) return 2;
+	bool is_in_coding_region = false;
+	for (uint32_t k = 0; k < exons.n; ++k) {
+		const uint32_t exon = exons.get(k);
+		if (ann.exon_gene[exon] == gene && ann.exon_cds_start[exon] <= breakpoint1 + protrude_into_introns && ann.exon_cds_end[exon] + protrude_into_introns >= breakpoint1 &&
+		    ann.exon_cds_start[exon] <= breakpoint2 + protrude_into_introns && ann.exon_cds_end[exon] + protrude_into_introns >= breakpoint2) is_in_coding_region = true;
+	}
+	if (!is_in_coding_region) return 0;
+	const int32_t coverage1 = coverage_near(coverage, t.contigs[c] >> 16, breakpoint1, false), coverage2 = coverage_near(coverage, t.contigs[c] & 0xFFFF, breakpoint2, true); // directions: upstream / downstream
+	uint32_t split_reads = 0;
+	for (uint32_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k)
+		if (itd_read_counts(b.filter[t.read_lists[k]])) split_reads++;
+	return split_reads >= min_supporting_reads &&
+	       (1.0 * split_reads / (coverage1 > coverage2 ? coverage1 : coverage2) / (1 - duplication_rate) > min_fraction_of_coverage || split_reads >= subsampling_threshold);
+}
+const uint32_t ITD_READ_UNCLAIMED = 0xFFFFFFFFu, ITD_READ_COUNTED = 0xFFFFFFFEu;
+// a recovered candidate counts the reads it is the first to clear, split_read1_list before split_read2_list (owner[read] = iteration rank of the first
+// recovered candidate that lists the read; set to ITD_READ_COUNTED once counted)
+AGPU_HD void itd_count_cleared_reads(const BatchView& b, const CandidateTable& t, uint32_t c, uint32_t my_rank, uint32_t* owner) {
+	for (uint32_t list = 0; list < 2; ++list) {
+		uint32_t cleared = 0;
+		for (uint32_t k = t.list_offset[3 * (uint64_t) c + list]; k < t.list_offset[3 * (uint64_t) c + list + 1]; ++k) {
+			const uint32_t read = t.read_lists[k];
+			if (itd_read_is_cleared(b.filter[read]) && owner[read] == my_rank) { owner[read] = ITD_READ_COUNTED; ++cleared; }
+		}
+		uint32_t* counter = list == 0 ? t.split_reads1 + c : t.split_reads2 + c;
+		*counter = (*counter + cleared) & 0x7FFFu; // 15-bit counters (hazard H10)
+	}
+}
+
 // the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or
 // EVENT_KEPT_UNCOUNTED if it stays without entering the "(remaining=N)" of the stage: filter_both_intronic and filter_end_to_end_fusions skip
 // the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)

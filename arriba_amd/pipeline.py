@@ -290,6 +290,10 @@ class DevicePipeline(object):
         self._record(name)
         return remaining.value
 
+    def recover_internal_tandem_duplication(self, min_supporting_reads=10, min_fraction_of_coverage=0.07):
+        """reference: recover_internal_tandem_duplication, source/recover_internal_tandem_duplication.cpp:11-85 (-Z, -z)"""
+        return self._event_stage("recover_internal_tandem_duplication", min_supporting_reads, c_float(min_fraction_of_coverage))
+
     def filter_both_intronic(self):
         """reference: filter_both_intronic, source/filter_both_intronic.cpp:18-36"""
         return self._event_stage("filter_both_intronic")

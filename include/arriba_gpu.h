@@ -283,6 +283,9 @@ int agpu_filter_relative_support(agpu_ctx* ctx, uint64_t* remaining);
  *   agpu_filter_no_coverage    source/filter_no_coverage.cpp:9-103,  source/arriba.cpp:541-544
  *   agpu_filter_marginal_read_through  source/filter_marginal_read_through.cpp:8-46, source/arriba.cpp:503-506 */
 int agpu_upload_coverage(agpu_ctx* ctx, const agpu_coverage_view* coverage);
+/* recover_internal_tandem_duplication (source/recover_internal_tandem_duplication.cpp:11-85, called at source/arriba.cpp:463-466 with -Z min_itd_support,
+ * default 10, and -z min_itd_allele_fraction, default 0.07; max_itd_length and the subsampling threshold come from agpu_params).  Also un-filters reads. */
+int agpu_recover_internal_tandem_duplication(agpu_ctx* ctx, uint32_t min_supporting_reads, float min_fraction_of_coverage, uint64_t* remaining);
 int agpu_filter_both_intronic(agpu_ctx* ctx, uint64_t* remaining);
 int agpu_filter_short_anchor(agpu_ctx* ctx, uint32_t min_length, uint64_t* remaining);
 int agpu_filter_end_to_end(agpu_ctx* ctx, uint64_t* remaining);

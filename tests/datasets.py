@@ -33,6 +33,10 @@ DATASETS = {
     # piles of overlapping genes on one locus: gene sets of up to 10 ids (the tail of a set lives outside the registers on the device)
     "stacked4k": {"args": ["--seed", "13", "--fragments", "4000", "--contigs", "3", "--contig-len", "300000", "--junctions", "80", "--genes-per-mb", "40", "--gene-stack", "9"],
                   "golden_files": ["reads.*_annotated.tsv", "filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv", "fusions.*_find_fusions.tsv"]},
+    # recurrent internal tandem duplications: merge_adjacent_fusions appends read lists, recover_internal_tandem_duplication recovers candidates and un-filters reads
+    "itd6k": {"args": ["--seed", "61", "--fragments", "6000", "--normal-mult", "1.0", "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--itd-hotspots", "3", "--itd-hotspot-frac", "0.05"],
+              "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_find_fusions.tsv", "fusions.*_merge_adjacent_fusions.tsv", "fusions.*_filter_multimappers.tsv", "filters.*_filter_multimappers.tsv",
+                               "fusions.*_filter_relative_support.tsv", "fusions.*_recover_internal_tandem_duplication.tsv", "filters.*_recover_internal_tandem_duplication.tsv", "fusions.*_filter_no_coverage.tsv"]},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},

@@ -359,6 +359,89 @@ def check_event_predicates(session, pipeline, golden):
     return discarded
 
 
+def check_recover_itd(session, pipeline, golden):
+    """recover_internal_tandem_duplication from the reference's state behind filter_relative_support: candidate filters and counters, the filter
+    of every read afterwards, the remaining count.  The pipeline must have run find_fusions + merge_adjacent_fusions (merged read lists)."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    pipeline.upload_coverage()
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    before = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_relative_support"))
+    names, read_filters = golden_io.read_filters(golden_io.find_dump(golden, "filters", "filter_multimappers"))
+    assert session.fragment_names() == names
+    _inject_candidate_state(pipeline, index, before)
+    pipeline.set_read_filters(np.array(read_filters, dtype=np.uint8))
+    parameters = re.search(r"Searching for internal tandem duplications <=\d+bp with >=(\d+) supporting reads and >=([0-9.]+)% allele fraction[^\n]*\(remaining=(\d+)\)", log)
+    remaining = pipeline.recover_internal_tandem_duplication(int(parameters.group(1)), float(parameters.group(2)) / 100)
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_internal_tandem_duplication"))
+    result = pipeline.candidates()
+    problems = []
+    for f in after:
+        c = index[fusion_key(f)]
+        got = (int(result["filter"][c]), int(result["split_reads1"][c]), int(result["split_reads2"][c]), int(result["discordant_mates"][c]))
+        if got != (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"]):
+            problems.append((fusion_key(f), got, (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"])))
+    assert not problems, (len(problems), problems[:10])
+    assert remaining == int(parameters.group(3)), (remaining, parameters.group(3))
+    _, read_filters_after = golden_io.read_filters(golden_io.find_dump(golden, "filters", "recover_internal_tandem_duplication"))
+    mine = pipeline.filters()
+    different = [(names[i], int(mine[i]), read_filters_after[i]) for i in range(len(names)) if mine[i] != read_filters_after[i]]
+    assert not different, (len(different), different[:10])
+    before_filter = {fusion_key(f): f["filter"] for f in before}
+    return sum(1 for f in after if f["filter"] == 0 and before_filter[fusion_key(f)] != 0), sum(1 for a, b in zip(read_filters, read_filters_after) if a != b)
+
+
+def check_chain_to_no_coverage(session, pipeline, golden):
+    """The reference's stages 18-35 (find_fusions ... filter_no_coverage, default filters) on the device in one go, nothing taken from the reference:
+    every "(remaining=N)" of the log, and at the end the filter and the counters of every candidate and the filter of every read."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    def logged(pattern):
+        return int(re.search(pattern + r"[^\n]*\(remaining=(\d+)\)", log).group(1))
+    itd = re.search(r"Searching for internal tandem duplications <=\d+bp with >=(\d+) supporting reads and >=([0-9.]+)% allele fraction", log)
+    quantile = float(re.search(r"expression above the ([0-9.]+)% quantile", log).group(1)) / 100
+    min_spliced_events = int(re.search(r"Searching for fusions with >=(\d+) spliced events", log).group(1))
+    min_anchor_length = int(re.search(r"Filtering fusions with anchors <=(\d+)nt", log).group(1))
+    pipeline.find_fusions()
+    pipeline.upload_coverage()
+    counts = [pipeline.merge_adjacent_fusions(), pipeline.filter_multimappers()[0]]
+    pipeline.estimate_expected_fusions()
+    pipeline.filter_candidate_predicates()
+    counts.append(pipeline.filter_relative_support())
+    expected = [logged("Merging adjacent fusion breakpoints"), logged("Filtering multi-mapping fusions"), logged("Filtering fusions with an e-value")]
+    stages = [(lambda: pipeline.recover_internal_tandem_duplication(int(itd.group(1)), float(itd.group(2)) / 100), "Searching for internal tandem duplications"),
+              (pipeline.filter_both_intronic, "Filtering fusions with both breakpoints in intronic/intergenic regions"),
+              (lambda: pipeline.filter_in_vitro(quantile), "Filtering in vitro-generated fusions"),
+              (pipeline.recover_both_spliced, "Searching for fusions with spliced split reads"),
+              (pipeline.select_most_supported_breakpoints, "Selecting best breakpoints from genes with multiple breakpoints"),
+              (pipeline.filter_marginal_read_through, "Filtering read-through fusions with breakpoints near the gene boundary"),
+              (lambda: pipeline.recover_many_spliced(min_spliced_events), "Searching for fusions with >=\\d+ spliced events"),
+              (lambda: pipeline.filter_short_anchor(min_anchor_length), "Filtering fusions with anchors"),
+              (pipeline.filter_end_to_end, "Filtering end-to-end fusions with low support"),
+              (pipeline.filter_no_coverage, "Filtering fusions with no coverage around the breakpoints")]
+    for run, pattern in stages:
+        counts.append(run())
+        expected.append(logged(pattern))
+    assert counts == expected, list(zip(counts, expected))
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_no_coverage"))
+    table = pipeline.candidates()
+    assert len(after) == pipeline.n_candidates
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    problems = []
+    for f in after:
+        c = index[fusion_key(f)]
+        got = (int(table["filter"][c]), int(table["split_reads1"][c]), int(table["split_reads2"][c]), int(table["discordant_mates"][c]))
+        if got != (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"]):
+            problems.append((fusion_key(f), got, (f["filter"], f["split_reads1"], f["split_reads2"], f["discordant_mates"])))
+    assert not problems, (len(problems), problems[:10])
+    names, read_filters = golden_io.read_filters(golden_io.find_dump(golden, "filters", "recover_internal_tandem_duplication"))
+    mine = pipeline.filters()
+    different = [(names[i], int(mine[i]), read_filters[i]) for i in range(len(names)) if mine[i] != read_filters[i]]
+    assert not different, (len(different), different[:10])
+    return counts
+
+
 def check_read_lists(session, pipeline, golden, stage):
     """the three read lists of every candidate against the reference's dump of `stage` (contents, or sizes for dumps written without lists)"""
     fusions = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))

@@ -264,3 +264,32 @@ def test_event_level_predicates_match_reference(built, dataset_files, tmp_path):
     assert min(discarded[stage] for stage in ("both_intronic", "filter_short_anchor", "filter_end_to_end_fusions", "filter_no_coverage")) > 1000, discarded
     session, pipeline = parity.run_read_level(parity.open_session, prefix)
     assert parity.check_event_chain(session, pipeline, dump)[-1] > 1000
+
+
+def test_chain_to_no_coverage_without_injected_state(built, dataset_files, tmp_path):
+    """find_fusions ... filter_no_coverage (the reference's stages 18-35, default filters) on the GPU with nothing taken from the reference: golden
+    datasets (one with recurrent internal tandem duplications: appended read lists, recovered candidates, un-filtered reads) and a live 120 k run"""
+    golden = conftest.golden_dir("itd6k")
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("itd6k"))
+    pipeline.find_fusions()
+    pipeline.merge_adjacent_fusions()
+    assert parity.check_read_lists(session, pipeline, golden, "merge_adjacent_fusions") > 2000
+    assert parity.check_recover_itd(session, pipeline, golden)[0] >= 3
+    for name in ("toy3k", "itd6k"):
+        session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name))
+        assert parity.check_chain_to_no_coverage(session, pipeline, conftest.golden_dir(name))[-1] > 0
+    if not datasets.reference_available():
+        return
+    spec = {"args": ["--seed", "23", "--fragments", "120000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump)
+    finally:
+        del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    assert parity.check_chain_to_no_coverage(session, pipeline, dump)[-1] > 100

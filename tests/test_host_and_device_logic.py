@@ -193,6 +193,27 @@ def test_event_level_predicates_match_reference(dataset_files, emu_api):
     assert counts[0] > counts[-1] > 0
 
 
+def test_internal_tandem_duplications(dataset_files, emu_api):
+    """A dataset with recurrent internal tandem duplications: the read lists merge_adjacent_fusions appends to the absorbing candidates, and
+    recover_internal_tandem_duplication (candidates recovered, reads un-filtered, first candidate in iteration order counts a shared read)"""
+    golden = conftest.golden_dir("itd6k")
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("itd6k"), api=emu_api)
+    pipeline.find_fusions()
+    assert parity.check_candidates(session, pipeline, golden) > 2000
+    pipeline.merge_adjacent_fusions()
+    assert parity.check_read_lists(session, pipeline, golden, "merge_adjacent_fusions") > 2000  # list contents incl. the appended entries
+    recovered, cleared = parity.check_recover_itd(session, pipeline, golden)
+    assert recovered >= 3 and cleared > 200
+
+
+@pytest.mark.parametrize("name", ["toy3k", "itd6k"])
+def test_chain_to_no_coverage_without_injected_state(name, dataset_files, emu_api):
+    """find_fusions ... filter_no_coverage (the reference's stages 18-35, default filters): nothing taken from the reference"""
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name), api=emu_api)
+    counts = parity.check_chain_to_no_coverage(session, pipeline, conftest.golden_dir(name))
+    assert counts[0] > counts[-1] > 0
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
