@@ -8,11 +8,12 @@ import parity, conftest, datasets, tempfile
 from arriba_amd import _capi
 api=_capi.bind_device_api(ctypes.CDLL(os.environ['ARRIBA_EMU_LIBRARY']),'emu_')
 tmp=tempfile.mkdtemp(prefix='asan_')
-for name in ['toy3k','stacked4k']:
+for name in ['toy3k','stacked4k','itd6k']:
     prefix=datasets.generate(datasets.DATASETS[name], tmp, name)
     golden=conftest.golden_dir(name)
     s,p=parity.run_read_level(parity.open_session,prefix,api=api)
-    parity.check_read_filters(s,p,golden); parity.check_annotation(s,p,golden)
+    if name!='itd6k':
+        parity.check_read_filters(s,p,golden); parity.check_annotation(s,p,golden)
     p.find_fusions(); print(name,'candidates',parity.check_candidates(s,p,golden))
     if name=='toy3k':
         print('evalues',parity.check_evalues(s,p,golden)); print('mismappers',parity.check_mismappers(s,p,golden))
@@ -24,4 +25,8 @@ for name in ['toy3k','stacked4k']:
         print('event predicates',parity.check_event_predicates(s,p,golden))
         s,p=parity.run_read_level(parity.open_session,prefix,api=api)
         print('event chain',parity.check_event_chain(s,p,golden))
+    if name=='itd6k':
+        p.merge_adjacent_fusions(); print('merged lists',parity.check_read_lists(s,p,golden,'merge_adjacent_fusions')); print('recover_itd',parity.check_recover_itd(s,p,golden))
+        s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+        print('chain to no_coverage',parity.check_chain_to_no_coverage(s,p,golden))
 print('done')
