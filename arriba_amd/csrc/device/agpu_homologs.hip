@@ -1,0 +1,95 @@
+// arriba_amd/csrc/device/agpu_homologs.hip -- filter_homologs (reference: source/filter_homologs.cpp:68-141, called at source/arriba.cpp:556-560).
+// The homology verdicts (k-mer index + genome, homolog_core.hpp) are evaluated on the device, one thread per gene pair, for every pair of genes the
+// elimination can ask about; the elimination itself is sequential and runs on the host over the few unfiltered candidates that are left at
+// this point of the workflow (it is quadratic in their number in the reference too).
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "agpu_context.hpp"
+#include "homolog_host.hpp"
+
+using namespace agpu;
+
+namespace {
+
+const int BLOCK = 256;
+const uint32_t MAX_REMAINING = 50000; // the elimination compares every pair of unfiltered candidates
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+
+__global__ void homolog_collect_kernel(CandidateTable t, const uint32_t* iteration_rank, const float* evalue, RemainingCandidate* out, uint32_t capacity, unsigned int* count) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n || t.filter[c] != FILTER_none) return;
+	const uint32_t at = atomicAdd(count, 1u); // few candidates are left at this stage
+	if (at >= capacity) return;
+	RemainingCandidate r;
+	r.candidate = c; r.iteration_rank = iteration_rank[c]; r.gene1 = t.gene1[c]; r.gene2 = t.gene2[c]; r.breakpoint1 = t.breakpoint1[c]; r.breakpoint2 = t.breakpoint2[c];
+	r.split_reads1 = t.split_reads1[c]; r.split_reads2 = t.split_reads2[c]; r.discordant_mates = t.discordant_mates[c]; r.evalue = evalue[c];
+	out[at] = r;
+}
+__global__ void homolog_verdict_kernel(AnnotationView ann, GenomeView genome, KmerIndexView kmers, const uint64_t* pairs, uint32_t n_pairs, float max_identity_fraction, uint8_t* verdicts) {
+	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k < n_pairs) verdicts[k] = genes_are_homologs(ann, genome, kmers, (uint32_t) (pairs[k] >> 32), (uint32_t) pairs[k], max_identity_fraction);
+}
+__global__ void homolog_apply_kernel(CandidateTable t, const uint32_t* candidates, const uint8_t* filters, uint32_t n) {
+	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k < n) t.filter[candidates[k]] = filters[k];
+}
+
+}
+
+extern "C" int agpu_filter_homologs(agpu_ctx* ctx, float max_identity_fraction, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->kmer_index_done) { set_last_error("agpu_make_kmer_index must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->evalue_done) { set_last_error("agpu_estimate_expected_fusions must run first (the e-value breaks ties)"); return AGPU_ERR_INVALID; }
+	if (!ctx->iteration_order_done) { const int status = agpu_candidate_iteration_order(ctx, nullptr); if (status != AGPU_OK) return status; } // hazard H2
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counter = ctx->scratch("homologs.counter"); DeviceBuffer& collected = ctx->scratch("homologs.collected");
+	ALLOC(counter, 16); ALLOC(collected, (size_t) MAX_REMAINING * sizeof(RemainingCandidate));
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	uint32_t n_remaining = 0;
+	if (C > 0) {
+		homolog_collect_kernel<<<(C + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(ctx->candidates, ctx->cand_iteration_rank.as<uint32_t>(), ctx->cand_evalue.as<float>(), collected.as<RemainingCandidate>(), MAX_REMAINING, counter.as<unsigned int>());
+		HIP_CHECK(hipMemcpyAsync(&n_remaining, counter.ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	uint64_t kept = n_remaining;
+	if (n_remaining > 0 && ctx->params.filter_enabled[FILTER_homologs]) {
+		if (n_remaining > MAX_REMAINING) { set_last_error("filter_homologs: more unfiltered candidates than the pairwise elimination is sized for (run the filters in front of it first)"); return AGPU_ERR_CAPACITY; }
+		std::vector<RemainingCandidate> list(n_remaining);
+		HIP_CHECK(hipMemcpy(list.data(), collected.ptr, (size_t) n_remaining * sizeof(RemainingCandidate), hipMemcpyDeviceToHost));
+		HomologElimination elimination;
+		elimination.prepare(list);
+		const std::vector<uint64_t>& pairs = elimination.pairs;
+		DeviceBuffer& device_pairs = ctx->scratch("homologs.pairs"); DeviceBuffer& device_verdicts = ctx->scratch("homologs.verdicts");
+		ALLOC(device_pairs, pairs.size() * 8); ALLOC(device_verdicts, pairs.size());
+		HIP_CHECK(hipMemcpyAsync(device_pairs.ptr, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, s));
+		KmerIndexView kmers;
+		kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
+		{ KernelTimer timer(ctx, "homolog_verdict_kernel", pairs.size() * 64);
+		  homolog_verdict_kernel<<<(unsigned int) ((pairs.size() + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->genome, kmers, device_pairs.as<uint64_t>(), (uint32_t) pairs.size(), max_identity_fraction, device_verdicts.as<uint8_t>()); }
+		std::vector<uint8_t> host_verdicts(pairs.size());
+		HIP_CHECK(hipMemcpyAsync(host_verdicts.data(), device_verdicts.ptr, pairs.size(), hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		kept = elimination.run(host_verdicts);
+		const std::vector<uint32_t>& candidates = elimination.candidates;
+		const std::vector<uint8_t>& filter = elimination.filter;
+		DeviceBuffer& device_candidates = ctx->scratch("homologs.candidates"); DeviceBuffer& device_filters = ctx->scratch("homologs.filters");
+		ALLOC(device_candidates, (size_t) n_remaining * 4); ALLOC(device_filters, n_remaining);
+		HIP_CHECK(hipMemcpyAsync(device_candidates.ptr, candidates.data(), (size_t) n_remaining * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(device_filters.ptr, filter.data(), n_remaining, hipMemcpyHostToDevice, s));
+		homolog_apply_kernel<<<(n_remaining + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(ctx->candidates, device_candidates.as<uint32_t>(), device_filters.as<uint8_t>(), n_remaining);
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 2;
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}

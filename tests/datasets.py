@@ -37,6 +37,15 @@ DATASETS = {
     "itd6k": {"args": ["--seed", "61", "--fragments", "6000", "--normal-mult", "1.0", "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--itd-hotspots", "3", "--itd-hotspot-frac", "0.05"],
               "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_find_fusions.tsv", "fusions.*_merge_adjacent_fusions.tsv", "fusions.*_filter_multimappers.tsv", "filters.*_filter_multimappers.tsv",
                                "fusions.*_filter_relative_support.tsv", "fusions.*_recover_internal_tandem_duplication.tsv", "filters.*_recover_internal_tandem_duplication.tsv", "fusions.*_filter_no_coverage.tsv"]},
+    # families of homologous genes (one locus copied over another) with junctions to a common partner and between them: filter_homologs fires
+    "homologs8k": {"args": ["--seed", "29", "--fragments", "8000", "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--homolog-families", "4"],
+                   "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_filter_no_coverage.tsv", "filters.*_recover_internal_tandem_duplication.tsv",
+                                    "fusions.*_before_filter_mismappers.tsv", "fusions.*_filter_mismappers.tsv", "filters.*_filter_mismappers.tsv"]},
+    # the same sample with the reference's event-level filters in front of filter_homologs switched off: thousands of candidates reach the elimination
+    "homologs8k_open": {"args": ["--seed", "29", "--fragments", "8000", "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--homolog-families", "4"],
+                        "reference_disable_filters": ["relative_support", "min_support", "select_best", "intronic", "in_vitro", "end_to_end", "no_coverage", "short_anchor", "non_coding_neighbors", "intragenic_exonic"],
+                        "reference_env": {"ARRIBA_ORACLE_DUMP_LISTS": "0"},
+                        "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_recover_many_spliced.tsv", "fusions.*_before_filter_mismappers.tsv"]},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},
@@ -56,6 +65,7 @@ def reference_available():
 def run_reference(prefix, dump_directory, spec=None, extra_args=(), disable_filters=()):
     """Runs the oracle build of the reference; returns its stdout+stderr."""
     env = dict(os.environ)
+    env.update((spec or {}).get("reference_env", {}))
     env["ARRIBA_ORACLE_DUMP"] = dump_directory
     command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv", "-f", ",".join(["blacklist"] + list(disable_filters))] + list(extra_args)
     result = subprocess.run(command, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)

@@ -21,6 +21,7 @@
 #include "../../arriba_amd/csrc/device/merge_core.hpp"
 #include "../../arriba_amd/csrc/device/event_core.hpp"
 #include "../../arriba_amd/csrc/device/in_vitro_host.hpp"
+#include "../../arriba_amd/csrc/device/homolog_host.hpp"
 #include "../../arriba_amd/csrc/device/index_bins.hpp"
 #include "../../arriba_amd/csrc/device/multimapper_core.hpp"
 #include <map>

@@ -442,6 +442,54 @@ def check_chain_to_no_coverage(session, pipeline, golden):
     return counts
 
 
+def check_homologs(session, pipeline, golden, multimappers=True, state_from="filter_no_coverage"):
+    """make_kmer_index + filter_homologs from the reference's candidate state behind filter_no_coverage (injected; the e-values that break ties are
+    the device's own) against the reference's dump behind filter_homologs.  Returns (candidates entering, candidates discarded)."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    identity = float(re.search(r"Filtering genes with >=([0-9.]+)% identity", log).group(1)) / 100
+    pipeline.find_fusions()
+    pipeline.merge_adjacent_fusions()
+    if multimappers:
+        pipeline.filter_multimappers()
+    pipeline.estimate_expected_fusions()
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    before = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", state_from))
+    _inject_candidate_state(pipeline, index, before)
+    pipeline.make_kmer_index()
+    remaining = pipeline.filter_homologs(identity)
+    assert remaining == int(re.search(r"Filtering genes with[^\n]*\(remaining=(\d+)\)", log).group(1))
+    entering = sum(1 for f in before if f["filter"] == 0)
+    assert _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "before_filter_mismappers")), "filter_homologs") == remaining
+    return entering, entering - remaining
+
+
+def check_chain_to_mismappers(session, pipeline, golden):
+    """The reference's stages 18-38 (find_fusions ... filter_no_coverage -> make_kmer_index -> filter_homologs -> filter_mismappers, default filters)
+    on the device in one go, nothing taken from the reference (the padding of the k-mer index and max_mate_gap come from the pipeline's own scalars)."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    def logged(pattern):
+        return int(re.search(pattern + r"[^\n]*\(remaining=(\d+)\)", log).group(1))
+    counts = check_chain_to_no_coverage(session, pipeline, golden)
+    identity = float(re.search(r"Filtering genes with >=([0-9.]+)% identity", log).group(1)) / 100
+    pipeline.make_kmer_index()
+    after_homologs = pipeline.filter_homologs(identity)
+    assert after_homologs == logged("Filtering genes with"), (after_homologs, logged("Filtering genes with"))
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "before_filter_mismappers")), "filter_homologs")
+    after_mismappers, discarded = pipeline.filter_mismappers()
+    assert after_mismappers == logged("Re-aligning chimeric reads"), (after_mismappers, logged("Re-aligning chimeric reads"))
+    _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "filter_mismappers")), "filter_mismappers")
+    names, read_filters = golden_io.read_filters(golden_io.find_dump(golden, "filters", "filter_mismappers"))
+    mine = pipeline.filters()
+    different = [(names[i], int(mine[i]), read_filters[i]) for i in range(len(names)) if mine[i] != read_filters[i]]
+    assert not different, (len(different), different[:10])
+    return counts + [after_homologs, after_mismappers], discarded
+
+
 def check_read_lists(session, pipeline, golden, stage):
     """the three read lists of every candidate against the reference's dump of `stage` (contents, or sizes for dumps written without lists)"""
     fusions = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))

@@ -214,6 +214,25 @@ def test_chain_to_no_coverage_without_injected_state(name, dataset_files, emu_ap
     assert counts[0] > counts[-1] > 0
 
 
+def test_homologs_and_chain_to_mismappers(dataset_files, emu_api):
+    """filter_homologs on a sample with families of homologous genes: thousands of candidates through the elimination (the reference run with the
+    filters in front switched off, state injected behind them), then the reference's stages 18-38 (find_fusions ... filter_homologs ->
+    filter_mismappers, default filters) as one chain with nothing taken from the reference"""
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("homologs8k_open"), api=emu_api)
+    entering, discarded = parity.check_homologs(session, pipeline, conftest.golden_dir("homologs8k_open"), state_from="recover_many_spliced")
+    assert entering > 3000 and discarded > 400
+    for name in ("homologs8k", "toy3k"):
+        session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name), api=emu_api)
+        counts, reads_discarded = parity.check_chain_to_mismappers(session, pipeline, conftest.golden_dir(name))
+        assert counts[0] > counts[-1] > 0
+    assert counts[-3] == counts[-2] == 46  # toy3k: no homologs
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("homologs8k"), api=emu_api)
+    pipeline.find_fusions()
+    from arriba_amd.pipeline import ArribaError
+    with pytest.raises(ArribaError):  # needs the k-mer index
+        pipeline.filter_homologs()
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")

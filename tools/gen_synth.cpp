@@ -324,14 +324,8 @@ void Generator::build_reference() {
 	}
 
 	// recurrent junctions
-	for (int j = 0; j < c.junctions; ++j) {
+	auto make_junction = [&](Rng& rng, int gene_a, int gene_b) {
 		Junction junction;
-		int gene_a = rng.below(genes_.size());
-		int gene_b = rng.below(genes_.size());
-		for (int attempt = 0; attempt < 20 && (gene_b == gene_a || (rng.chance(0.7) && genes_[gene_b].contig == genes_[gene_a].contig)); ++attempt)
-			gene_b = rng.below(genes_.size());
-		if (gene_b == gene_a)
-			gene_b = (gene_a + 1) % genes_.size();
 		bool spliced = rng.chance(0.75);
 		for (int which = 0; which < 2; ++which) {
 			int g = which == 0 ? gene_a : gene_b;
@@ -367,7 +361,47 @@ void Generator::build_reference() {
 				sequence[p] = (kind == 0) ? 'A' : (kind == 1) ? "CA"[i % 2] : "CAG"[i % 3];
 			}
 		}
-		impl_->junctions.push_back(junction);
+		return junction;
+	};
+	for (int j = 0; j < c.junctions; ++j) {
+		int gene_a = rng.below(genes_.size());
+		int gene_b = rng.below(genes_.size());
+		for (int attempt = 0; attempt < 20 && (gene_b == gene_a || (rng.chance(0.7) && genes_[gene_b].contig == genes_[gene_a].contig)); ++attempt)
+			gene_b = rng.below(genes_.size());
+		if (gene_b == gene_a)
+			gene_b = (gene_a + 1) % genes_.size();
+		impl_->junctions.push_back(make_junction(rng, gene_a, gene_b));
+	}
+
+	// families of homologous genes: the whole locus of one gene copied (with ~2 % edits, reverse-complemented between genes on different strands) over
+	// the locus of another, plus well supported junctions gene-partner, homolog-partner and gene-homolog (drawn from a generator of their own)
+	if (c.homolog_families > 0) {
+		Rng family_rng(c.seed ^ 0x40F0106ULL);
+		int made = 0;
+		for (int attempt = 0; attempt < 100000 && made < c.homolog_families; ++attempt) {
+			const int a = (int) family_rng.below(genes_.size()), b = (int) family_rng.below(genes_.size()), partner = (int) family_rng.below(genes_.size());
+			if (a == b || a == partner || b == partner) continue;
+			const Gene& from = genes_[a];
+			const Gene& to = genes_[b];
+			if (from.contig == to.contig && from.start <= to.end + 1000 && to.start <= from.end + 1000) continue;
+			bool clear = true; // neither locus may carry another gene (its sequence would change under it)
+			for (size_t g = 0; g < genes_.size() && clear; ++g)
+				if ((int) g != b && genes_[g].contig == to.contig && genes_[g].start <= to.end && to.start <= genes_[g].end) clear = false;
+			if (!clear) continue;
+			const int n = std::min(from.end - from.start, to.end - to.start) + 1;
+			const bool reverse = from.plus != to.plus;
+			for (int i = 0; i < n; ++i) {
+				char base = reverse ? complement(contig_sequences_[from.contig][from.start + n - 1 - i]) : contig_sequences_[from.contig][from.start + i];
+				if (family_rng.chance(0.02)) base = random_base(family_rng);
+				contig_sequences_[to.contig][to.start + i] = base;
+			}
+			const Junction family[3] = { make_junction(family_rng, a, partner), make_junction(family_rng, b, partner), make_junction(family_rng, a, b) };
+			for (int k = 0; k < 3; ++k) {
+				const size_t at = std::min<size_t>(impl_->junctions.size(), (size_t) (2 + 4 * made + k + (k == 1 ? 6 : 0))); // near the head of the Zipf ranking, unequal support
+				impl_->junctions.insert(impl_->junctions.begin() + at, family[k]);
+			}
+			++made;
+		}
 	}
 	{
 		double total = 0;
@@ -1026,6 +1060,7 @@ int main(int argc, char** argv) {
 		else if (a == "--genes-per-mb") config.genes_per_mb = atof(value());
 		else if (a == "--gene-stack") config.gene_stack = atoi(value());
 		else if (a == "--itd-hotspots") config.itd_hotspots = atoi(value());
+		else if (a == "--homolog-families") config.homolog_families = atoi(value());
 		else if (a == "--itd-hotspot-frac") config.frac_itd_hotspot = atof(value());
 		else if (a == "--read-len") config.read_length = atoi(value());
 		else if (a == "--junctions") config.junctions = atoi(value());

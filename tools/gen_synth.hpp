@@ -39,6 +39,7 @@ struct Config {
 	double frac_itd = 0.01;          // of ordinary pairs: internal tandem duplication reads
 	int itd_hotspots = 0;            // > 0: that many recurrent internal tandem duplications (fixed position and length inside a coding exon), each
 	double frac_itd_hotspot = 0.02;  //      hit by this fraction of the ordinary pairs divided among them (no random numbers are drawn when 0)
+	int homolog_families = 0;        // > 0: that many gene pairs with one locus copied over the other, with junctions to a common partner and between them
 	double frac_malformed = 0.003;
 	double error_rate = 0.005, high_error_fraction = 0.01, high_error_rate = 0.08;
 	int clip_min = 12, clip_max = 60;
