@@ -67,6 +67,22 @@ __global__ void many_spliced_pair_kernel(CandidateTable t, const uint32_t* order
 	recover_many_spliced_in_pair(t, order, j, end, min_spliced_events);
 }
 
+// recover_isoforms: sort keys (pass 0: iteration rank, pass 1: gene pair + directions of the unfiltered candidates) and the verdicts
+__global__ void isoform_key_kernel(CandidateTable t, const uint32_t* order, const uint32_t* iteration_rank, int pass, uint64_t* keys) {
+	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j >= t.n) return;
+	const uint32_t c = order ? order[j] : j;
+	keys[j] = pass == 0 ? (uint64_t) iteration_rank[c] : isoform_pair_key(t, c);
+}
+__global__ void isoform_verdict_kernel(CandidateTable t, const uint64_t* member_keys, const uint32_t* members, uint8_t* recovered) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n) recovered[c] = isoform_may_be_recovered(t, c) && isoform_is_recovered(t, c, member_keys, members, t.n);
+}
+__global__ void isoform_recover_kernel(CandidateTable t, const uint8_t* recovered) { // a kernel of its own: the verdicts read the filters of all candidates
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n && recovered[c]) t.filter[c] = FILTER_none;
+}
+
 // filter_in_vitro: expression proxy, gene-pair table, verdicts
 __global__ void gene_read_count_kernel(BatchView b, uint32_t* gene_read_count) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
@@ -287,6 +303,48 @@ extern "C" int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_eve
 		}
 		event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
 	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 100;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_recover_isoforms(agpu_ctx* ctx, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->iteration_order_done) { const int status = agpu_candidate_iteration_order(ctx, nullptr); if (status != AGPU_OK) return status; } // hazard H2
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& keys_in = ctx->scratch("events.keys_in"); DeviceBuffer& keys_out = ctx->scratch("events.keys_out");
+	DeviceBuffer& order_a = ctx->scratch("events.order_a"); DeviceBuffer& order_b = ctx->scratch("events.order_b"); DeviceBuffer& scratch = ctx->scratch("events.rocprim");
+	DeviceBuffer& recovered = ctx->scratch("events.eligible");
+	const size_t C1 = std::max<uint32_t>(C, 1);
+	ALLOC(counter, 16); ALLOC(keys_in, C1 * 8); ALLOC(keys_out, C1 * 8); ALLOC(order_a, C1 * 4); ALLOC(order_b, C1 * 4); ALLOC(recovered, C1);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && ctx->params.filter_enabled[FILTER_isoforms]) {
+		const CandidateTable& t = ctx->candidates;
+		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
+		size_t bytes = 0;
+		// stable sorts: by iteration rank, then by gene pair + directions (candidates that did not pass all filters go to the end)
+		isoform_key_kernel<<<grid, BLOCK, 0, s>>>(t, nullptr, ctx->cand_iteration_rank.as<uint32_t>(), 0, keys_in.as<uint64_t>());
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), order_a.as<uint32_t>(), C, 0, 32, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), order_a.as<uint32_t>(), C, 0, 32, s));
+		isoform_key_kernel<<<grid, BLOCK, 0, s>>>(t, order_a.as<uint32_t>(), ctx->cand_iteration_rank.as<uint32_t>(), 1, keys_in.as<uint64_t>());
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
+		{ KernelTimer timer(ctx, "isoform_verdict_kernel", (uint64_t) C * 40);
+		  isoform_verdict_kernel<<<grid, BLOCK, 0, s>>>(t, keys_out.as<uint64_t>(), order_b.as<uint32_t>(), recovered.as<uint8_t>()); }
+		isoform_recover_kernel<<<grid, BLOCK, 0, s>>>(t, recovered.as<uint8_t>());
+	}
+	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
 	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));

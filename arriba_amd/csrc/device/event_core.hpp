@@ -9,6 +9,7 @@
 #define AGPU_EVENT_CORE_HPP 1
 
 #include "fusion_core.hpp"
+#include "merge_core.hpp"
 
 namespace agpu {
 
@@ -463,6 +464,37 @@ AGPU_HD void itd_count_cleared_reads(const BatchView& b, const CandidateTable& t
 		uint32_t* counter = list == 0 ? t.split_reads1 + c : t.split_reads2 + c;
 		*counter = (*counter + cleared) & 0x7FFFu; // 15-bit counters (hazard H10)
 	}
+}
+
+// ---- recover_isoforms (source/recover_isoforms.cpp:10-47): a discarded candidate with both breakpoints at splice sites comes back when its gene pair
+// (with the same directions) has a candidate that passed all filters and whose breakpoints are not the same splice sites.  The reference keeps ONE
+// unfiltered candidate per gene pair in a std::map filled while iterating fusions_t: the last one in iteration order (hazard H2).  Here the
+// unfiltered candidates are sorted by (gene pair + directions, iteration rank); the last of a run is that candidate.  The table is complete before
+// the first recovery, as in the reference.
+const uint8_t FILTER_isoforms = 35, FILTER_blacklist = 20;
+AGPU_HD uint64_t isoform_pair_key(const CandidateTable& t, uint32_t c) { return t.filter[c] == FILTER_none ? both_spliced_group_key(t, c, false) : ~0ull; } // ~0: not in the table
+AGPU_HD bool isoform_may_be_recovered(const CandidateTable& t, uint32_t c) { // :26-34
+	const uint8_t filter = t.filter[c];
+	if (filter == FILTER_none) return false;
+	if (filter == FILTER_merge_adjacent || // alternative alignments
+	    filter == FILTER_blacklist ||         // normal splice variants and artifacts
+	    filter == FILTER_end_to_end ||        // alignments that happen to end at splice sites
+	    filter == FILTER_duplicates ||        // nothing but duplicates
+	    t.gene1[c] == t.gene2[c])             // circular RNAs
+		return false;
+	return (t.flags[c] & CFLAG_SPLICED1) && (t.flags[c] & CFLAG_SPLICED2);
+}
+// member_keys[] = isoform_pair_key of the candidates sorted by (key, iteration rank), members[] the candidates in that order
+AGPU_HD bool isoform_is_recovered(const CandidateTable& t, uint32_t c, const uint64_t* member_keys, const uint32_t* members, uint32_t n_members) {
+	const uint64_t key = both_spliced_group_key(t, c, false);
+	uint32_t lo = 0, hi = n_members; // first position behind the run of `key`
+	while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (member_keys[mid] <= key) lo = mid + 1; else hi = mid; }
+	if (lo == 0 || member_keys[lo - 1] != key) return false;
+	const uint32_t passed = members[lo - 1];
+	int32_t distance1 = t.breakpoint1[passed] - t.breakpoint1[c], distance2 = t.breakpoint2[passed] - t.breakpoint2[c];
+	if (distance1 < 0) distance1 = -distance1;
+	if (distance2 < 0) distance2 = -distance2;
+	return distance1 > MAX_SPLICE_SITE_DISTANCE || distance2 > MAX_SPLICE_SITE_DISTANCE; // the same splice sites: an alternative alignment
 }
 
 // the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or

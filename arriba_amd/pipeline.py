@@ -322,6 +322,10 @@ class DevicePipeline(object):
         """reference: recover_both_spliced, source/recover_both_spliced.cpp:72-182 (the arguments of the call at source/arriba.cpp:491)"""
         return self._event_stage("recover_both_spliced", max_fusions_to_recover, c_float(high_expression_quantile), max_exon_size, max_coverage)
 
+    def recover_isoforms(self):
+        """reference: recover_isoforms, source/recover_isoforms.cpp:10-47"""
+        return self._event_stage("recover_isoforms")
+
     def filter_homologs(self, max_identity_fraction=0.3):
         """reference: filter_homologs, source/filter_homologs.cpp:68-141 (-L, default 0.3); after make_kmer_index"""
         return self._event_stage("filter_homologs", c_float(max_identity_fraction))

@@ -309,6 +309,8 @@ int agpu_set_read_filters(agpu_ctx* ctx, const uint8_t* filter /* [n] */);
 
 /* make_kmer_index (source/filter_mismappers.cpp:47-84, called at source/arriba.cpp:547-553): 8-mer positions of the genes of all
  * unfiltered candidates with gene1 != gene2, padded by `padding` = max_mate_gap + 2 * read_length_mean (as int). */
+/* recover_isoforms (source/recover_isoforms.cpp:10-47, called at source/arriba.cpp:580-584): the last of the candidate-level filters */
+int agpu_recover_isoforms(agpu_ctx* ctx, uint64_t* remaining);
 /* filter_homologs (source/filter_homologs.cpp:68-141, called at source/arriba.cpp:556-560 behind make_kmer_index; max_identity_fraction = -L, default 0.3).
  * Needs the k-mer index, the e-values and at most 50 000 unfiltered candidates (the elimination is pairwise, as in the reference). */
 int agpu_filter_homologs(agpu_ctx* ctx, float max_identity_fraction, uint64_t* remaining);

@@ -10,14 +10,14 @@ def _open(path):
     return gzip.open(path + ".gz", "rt")
 
 
-def find_dump(directory, kind, stage):
-    """Path (without .gz) of <kind>.<nn>_<stage>.tsv in a dump directory."""
+def find_dump(directory, kind, stage, which=0):
+    """Path (without .gz) of <kind>.<nn>_<stage>.tsv in a dump directory; a stage that runs twice: which=0 the first, which=-1 the last dump."""
     import re
     pattern = re.compile(r"^%s\.\d+_%s\.tsv(\.gz)?$" % (re.escape(kind), re.escape(stage)))  # the stage name must match completely
     matches = sorted(path for path in glob.glob(os.path.join(directory, "%s.*_%s.tsv*" % (kind, stage))) if pattern.match(os.path.basename(path)))
     if not matches:
         raise FileNotFoundError("%s.*_%s.tsv in %s" % (kind, stage, directory))
-    path = matches[0]
+    path = matches[which]
     return path[:-3] if path.endswith(".gz") else path
 
 

@@ -490,6 +490,43 @@ def check_chain_to_mismappers(session, pipeline, golden):
     return counts + [after_homologs, after_mismappers], discarded
 
 
+def check_isoforms(session, pipeline, golden, state_from="select_most_supported_breakpoints"):
+    """recover_isoforms from the reference's candidate state in front of it (injected) against its dump behind it.  Returns (entering, recovered)."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    pipeline.find_fusions()
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    before = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", state_from, which=-1))
+    _inject_candidate_state(pipeline, index, before)
+    remaining = pipeline.recover_isoforms()
+    assert remaining == int(re.search(r"Searching for additional isoforms[^\n]*\(remaining=(\d+)\)", log).group(1)), remaining
+    assert _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_isoforms")), "recover_isoforms") == remaining
+    entering = sum(1 for f in before if f["filter"] == 0)
+    return entering, remaining - entering
+
+
+def check_chain_to_isoforms(session, pipeline, golden):
+    """The reference's candidate-level workflow to its end: stages 18-38 as in check_chain_to_mismappers, then select_most_supported_breakpoints a
+    second time and recover_isoforms (source/arriba.cpp:571-584); nothing taken from the reference.  What follows in the reference
+    (assign_confidence, the output writer) does not change filters or counters."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    counts, discarded = check_chain_to_mismappers(session, pipeline, golden)
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    selected = pipeline.select_most_supported_breakpoints()
+    assert selected == int(re.findall(r"Selecting best breakpoints[^\n]*\(remaining=(\d+)\)", log)[-1])
+    recovered = pipeline.recover_isoforms()
+    assert recovered == int(re.search(r"Searching for additional isoforms[^\n]*\(remaining=(\d+)\)", log).group(1)), recovered
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_isoforms"))
+    assert _compare_candidate_filters(pipeline, index, after, "recover_isoforms") == recovered
+    result = pipeline.candidates()
+    problems = [fusion_key(f) for f in after if (int(result["split_reads1"][index[fusion_key(f)]]), int(result["split_reads2"][index[fusion_key(f)]]), int(result["discordant_mates"][index[fusion_key(f)]])) != (f["split_reads1"], f["split_reads2"], f["discordant_mates"])]
+    assert not problems, (len(problems), problems[:10])
+    return counts + [selected, recovered], discarded
+
+
 def check_read_lists(session, pipeline, golden, stage):
     """the three read lists of every candidate against the reference's dump of `stage` (contents, or sizes for dumps written without lists)"""
     fusions = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))

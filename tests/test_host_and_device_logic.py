@@ -214,18 +214,21 @@ def test_chain_to_no_coverage_without_injected_state(name, dataset_files, emu_ap
     assert counts[0] > counts[-1] > 0
 
 
-def test_homologs_and_chain_to_mismappers(dataset_files, emu_api):
+def test_homologs_and_chain_to_the_last_filter(dataset_files, emu_api):
     """filter_homologs on a sample with families of homologous genes: thousands of candidates through the elimination (the reference run with the
-    filters in front switched off, state injected behind them), then the reference's stages 18-38 (find_fusions ... filter_homologs ->
-    filter_mismappers, default filters) as one chain with nothing taken from the reference"""
+    filters in front switched off, state injected behind them), then the reference's stages 18-40 (find_fusions ... filter_homologs ->
+    filter_mismappers -> select_most_supported_breakpoints -> recover_isoforms, default filters: every filter of the
+    candidate-level workflow) as one chain with nothing taken from the reference"""
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("homologs8k_open"), api=emu_api)
     entering, discarded = parity.check_homologs(session, pipeline, conftest.golden_dir("homologs8k_open"), state_from="recover_many_spliced")
     assert entering > 3000 and discarded > 400
     for name in ("homologs8k", "toy3k"):
         session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name), api=emu_api)
-        counts, reads_discarded = parity.check_chain_to_mismappers(session, pipeline, conftest.golden_dir(name))
+        counts, reads_discarded = parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name))
         assert counts[0] > counts[-1] > 0
-    assert counts[-3] == counts[-2] == 46  # toy3k: no homologs
+    assert counts[-5] == counts[-4] == 46 and counts[-1] == 48  # toy3k: no homologs, two isoforms recovered
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
+    assert parity.check_isoforms(session, pipeline, conftest.golden_dir("toy3k")) == (46, 2)
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("homologs8k"), api=emu_api)
     pipeline.find_fusions()
     from arriba_amd.pipeline import ArribaError

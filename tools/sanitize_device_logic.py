@@ -29,7 +29,7 @@ for name in ['toy3k','stacked4k','itd6k']:
         p.merge_adjacent_fusions(); print('merged lists',parity.check_read_lists(s,p,golden,'merge_adjacent_fusions')); print('recover_itd',parity.check_recover_itd(s,p,golden))
         s,p=parity.run_read_level(parity.open_session,prefix,api=api)
         print('chain to no_coverage',parity.check_chain_to_no_coverage(s,p,golden))
-for name, check in (('homologs8k_open', lambda s,p,g: parity.check_homologs(s,p,g,state_from='recover_many_spliced')), ('homologs8k', parity.check_chain_to_mismappers)):
+for name, check in (('homologs8k_open', lambda s,p,g: parity.check_homologs(s,p,g,state_from='recover_many_spliced')), ('homologs8k', parity.check_chain_to_isoforms)):
     prefix=datasets.generate(datasets.DATASETS[name], tmp, name)
     s,p=parity.run_read_level(parity.open_session,prefix,api=api)
     print(name, check(s,p,conftest.golden_dir(name)))
