@@ -129,6 +129,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "filter_in_vitro": (c_int, [ctx, c_float, POINTER(c_uint64)]),
         "filter_homologs": (c_int, [ctx, c_float, POINTER(c_uint64)]),
         "recover_isoforms": (c_int, [ctx, POINTER(c_uint64)]),
+        "assign_confidence": (c_int, [ctx, c_void_p]),
         "recover_both_spliced": (c_int, [ctx, c_uint32, c_float, c_int32, c_uint32, POINTER(c_uint64)]),
         "set_owned_candidates": (c_int, [ctx, c_void_p, c_uint64]),
         "copy_multimapper_flags": (c_int, [ctx, c_void_p]),

@@ -83,6 +83,16 @@ __global__ void isoform_recover_kernel(CandidateTable t, const uint8_t* recovere
 	if (c < t.n && recovered[c]) t.filter[c] = FILTER_none;
 }
 
+// assign_confidence: sort keys (pass 0: gene pair, pass 1: gene2) and the verdicts
+__global__ void confidence_key_kernel(CandidateTable t, int pass, uint64_t* keys) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n) keys[c] = confidence_sort_key(t, c, pass);
+}
+__global__ void confidence_kernel(AnnotationView ann, CoverageView coverage, CandidateTable t, const float* evalues, ConfidenceTables tables, uint8_t* confidence) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < t.n) confidence[c] = candidate_confidence(ann, coverage, t, evalues, tables, c);
+}
+
 // filter_in_vitro: expression proxy, gene-pair table, verdicts
 __global__ void gene_read_count_kernel(BatchView b, uint32_t* gene_read_count) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
@@ -311,6 +321,45 @@ extern "C" int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_eve
 	unsigned int kept = 0;
 	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
 	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->evalue_done) { set_last_error("agpu_estimate_expected_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& keys_in = ctx->scratch("events.keys_in"); DeviceBuffer& pair_keys = ctx->scratch("events.keys_out"); DeviceBuffer& gene2_keys = ctx->scratch("events.gene2_keys");
+	DeviceBuffer& pair_members = ctx->scratch("events.order_a"); DeviceBuffer& gene2_members = ctx->scratch("events.order_b"); DeviceBuffer& scratch = ctx->scratch("events.rocprim");
+	DeviceBuffer& result = ctx->scratch("events.confidence");
+	const size_t C1 = std::max<uint32_t>(C, 1);
+	ALLOC(keys_in, C1 * 8); ALLOC(pair_keys, C1 * 8); ALLOC(gene2_keys, C1 * 8); ALLOC(pair_members, C1 * 4); ALLOC(gene2_members, C1 * 4); ALLOC(result, C1);
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0) {
+		const CandidateTable& t = ctx->candidates;
+		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
+		size_t bytes = 0;
+		confidence_key_kernel<<<grid, BLOCK, 0, s>>>(t, 0, keys_in.as<uint64_t>());
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), pair_keys.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), pair_members.as<uint32_t>(), C, 0, 64, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), pair_keys.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), pair_members.as<uint32_t>(), C, 0, 64, s));
+		confidence_key_kernel<<<grid, BLOCK, 0, s>>>(t, 1, keys_in.as<uint64_t>());
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), gene2_keys.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), gene2_members.as<uint32_t>(), C, 0, 32, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), gene2_keys.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), gene2_members.as<uint32_t>(), C, 0, 32, s));
+		ConfidenceTables tables;
+		tables.pair_keys = pair_keys.as<uint64_t>(); tables.pair_members = pair_members.as<uint32_t>(); tables.gene2_keys = gene2_keys.as<uint64_t>(); tables.gene2_members = gene2_members.as<uint32_t>(); tables.n = C;
+		KernelTimer timer(ctx, "confidence_kernel", (uint64_t) C * 60);
+		confidence_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, t, ctx->cand_evalue.as<float>(), tables, result.as<uint8_t>());
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 100;
+	if (confidence && C > 0) HIP_CHECK(hipMemcpy(confidence, result.ptr, C, hipMemcpyDeviceToHost));
 	return AGPU_OK;
 }
 

@@ -497,6 +497,92 @@ AGPU_HD bool isoform_is_recovered(const CandidateTable& t, uint32_t c, const uin
 	return distance1 > MAX_SPLICE_SITE_DISTANCE || distance2 > MAX_SPLICE_SITE_DISTANCE; // the same splice sites: an alternative alignment
 }
 
+// ---- assign_confidence (source/filter_genomic_support.cpp:222-399, called at source/arriba.cpp:587-589; without structural variants from WGS:
+// closest_genomic_breakpoint1 is -1 and the last clause never applies).  A verdict per candidate from its own columns, the coverage, and two
+// questions about its neighbourhood that only ask whether at least one other candidate exists: (a) another deletion-like event of one of its
+// genes spanning it (read-through events), (b) another spliced event of the same gene pair at other splice sites.  The reference walks
+// fusions_by_gene[gene1] and [gene2]; every candidate that can satisfy (a) or (b) shares gene1 (first list) or gene2 (second list) with the
+// candidate, so the walks are runs of two sorted orders here: by (gene1, gene2) and by gene2.
+enum { CONFIDENCE_LOW = 0, CONFIDENCE_MEDIUM = 1, CONFIDENCE_HIGH = 2 };
+struct ConfidenceTables {
+	const uint64_t* pair_keys; const uint32_t* pair_members;   // candidates sorted by gene1 << 32 | gene2
+	const uint64_t* gene2_keys; const uint32_t* gene2_members; // candidates sorted by gene2
+	uint32_t n;
+};
+AGPU_HD uint64_t confidence_sort_key(const CandidateTable& t, uint32_t c, int pass) { return pass == 0 ? ((uint64_t) t.gene1[c] << 32 | t.gene2[c]) : (uint64_t) t.gene2[c]; }
+AGPU_HD bool confidence_is_spanning_deletion(const CandidateTable& t, uint32_t other, uint32_t c) { // :268-276
+	return t.filter[other] == FILTER_none && t.split_reads1[other] + t.split_reads2[other] > 0 &&
+	       !(t.flags[other] & CFLAG_UPSTREAM1) && (t.flags[other] & CFLAG_UPSTREAM2) &&
+	       ((t.gene1[other] == t.gene1[c] && t.gene2[other] != t.gene2[c]) || (t.gene1[other] != t.gene1[c] && t.gene2[other] == t.gene2[c])) && // not a different isoform
+	       (t.breakpoint1[other] != t.breakpoint1[c] || t.breakpoint2[other] != t.breakpoint2[c]) &&
+	       t.breakpoint2[other] > t.breakpoint1[c] && t.breakpoint1[other] < t.breakpoint2[c];
+}
+AGPU_HD bool confidence_has_spanning_deletion(const CandidateTable& t, const ConfidenceTables& tables, uint32_t c) {
+	const uint64_t first = (uint64_t) t.gene1[c] << 32;
+	for (uint32_t j = lower_bound_u64(tables.pair_keys, tables.n, first); j < tables.n && (tables.pair_keys[j] >> 32) == t.gene1[c]; ++j)
+		if (confidence_is_spanning_deletion(t, tables.pair_members[j], c)) return true;
+	for (uint32_t j = lower_bound_u64(tables.gene2_keys, tables.n, t.gene2[c]); j < tables.n && tables.gene2_keys[j] == t.gene2[c]; ++j)
+		if (confidence_is_spanning_deletion(t, tables.gene2_members[j], c)) return true;
+	return false;
+}
+AGPU_HD bool confidence_has_other_spliced_event(const CandidateTable& t, const ConfidenceTables& tables, uint32_t c) { // :331-347, filtered candidates count too
+	const uint64_t key = (uint64_t) t.gene1[c] << 32 | t.gene2[c];
+	for (uint32_t j = lower_bound_u64(tables.pair_keys, tables.n, key); j < tables.n && tables.pair_keys[j] == key; ++j) {
+		const uint32_t other = tables.pair_members[j];
+		if (!(t.flags[other] & CFLAG_SPLICED1) || !(t.flags[other] & CFLAG_SPLICED2)) continue;
+		int32_t distance1 = t.breakpoint1[other] - t.breakpoint1[c], distance2 = t.breakpoint2[other] - t.breakpoint2[c];
+		if (distance1 < 0) distance1 = -distance1;
+		if (distance2 < 0) distance2 = -distance2;
+		if (distance1 > 2 || distance2 > 2) return true;
+	}
+	return false;
+}
+AGPU_HD uint8_t candidate_confidence(const AnnotationView& ann, const CoverageView& coverage, const CandidateTable& t, const float* evalues, const ConfidenceTables& tables, uint32_t c) {
+	AGPU_FP_AS_WRITTEN
+	if (t.filter[c] != FILTER_none) return CONFIDENCE_LOW; // discarded events get low confidence, no matter what
+	const uint32_t flags = t.flags[c], split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c], supporting_reads = split_reads1 + split_reads2 + discordant_mates;
+	const bool spliced1 = flags & CFLAG_SPLICED1, spliced2 = flags & CFLAG_SPLICED2, exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2, same_gene = t.gene1[c] == t.gene2[c];
+	const float evalue = evalues[c];
+	// supporting reads as a fraction of the coverage; the sizes of the read lists, because the coverage includes duplicates, too (:235-239)
+	const int32_t coverage1 = coverage_near(coverage, t.contigs[c] >> 16, t.breakpoint1[c], !(flags & CFLAG_UPSTREAM1)), coverage2 = coverage_near(coverage, t.contigs[c] & 0xFFFF, t.breakpoint2[c], !(flags & CFLAG_UPSTREAM2));
+	const int32_t larger = coverage1 > coverage2 ? coverage1 : coverage2;
+	const float coverage_fraction = ((float) (t.list_offset[3 * (uint64_t) c + 3] - t.list_offset[3 * (uint64_t) c])) / (larger > 1 ? larger : 1);
+	const bool read_through = candidate_is_read_through(t, c);
+	int confidence = CONFIDENCE_HIGH; // high by default, reduced by penalties
+	if (evalue > 0.3 || supporting_reads < 2) {
+		confidence = CONFIDENCE_LOW; // poor support
+	} else if (read_through) {
+		confidence = CONFIDENCE_LOW; // unless well supported, or other deletions hint at the same genomic event
+		if (((split_reads1 > 0 && split_reads2 > 0) || (split_reads1 > 0 && discordant_mates > 0) || (split_reads2 > 0 && discordant_mates > 0)) && supporting_reads >= 10)
+			confidence = (split_reads1 + split_reads2 >= 10 && coverage_fraction > 0.07) ? CONFIDENCE_HIGH : CONFIDENCE_MEDIUM;
+		else if (confidence_has_spanning_deletion(t, tables, c))
+			confidence = CONFIDENCE_MEDIUM;
+	} else if (candidate_overlaps_both_genes(ann, t, c) || same_gene) { // intragenic: low by default, there are so many artifacts
+		confidence = CONFIDENCE_LOW;
+		if (split_reads1 + split_reads2 > 0) {
+			if (!exonic1 && !exonic2) confidence = (split_reads1 > 0 && split_reads2 > 0) ? CONFIDENCE_HIGH : CONFIDENCE_MEDIUM;   // most intragenic artifacts have both breakpoints in exons
+			else if (!exonic1 || !exonic2) confidence = (split_reads1 > 3 && split_reads2 > 3) ? CONFIDENCE_HIGH : CONFIDENCE_MEDIUM; // one breakpoint in an intron: more split reads
+		}
+	}
+	// rescued internal tandem duplications (:318-328)
+	if (confidence == CONFIDENCE_LOW && same_gene && exonic1 && exonic2 && !spliced1 && !spliced2 && t.breakpoint2[c] - t.breakpoint1[c] < 100 && split_reads1 > 0 && split_reads2 > 0 &&
+	    split_reads1 + split_reads2 >= 10 && coverage_fraction > 0.15 && (flags & CFLAG_UPSTREAM1) && !(flags & CFLAG_UPSTREAM2))
+		confidence = CONFIDENCE_MEDIUM;
+	// several spliced events between the same pair of genes (:331-350)
+	if (confidence < CONFIDENCE_HIGH && spliced1 && spliced2 && !read_through && !same_gene && confidence_has_other_spliced_event(t, tables, c)) ++confidence;
+	// true events are likely to have at least one spliced breakpoint, unless intragenic (:354-357)
+	if (!same_gene && confidence > CONFIDENCE_LOW && !spliced1 && !spliced2) --confidence;
+	// excellent support (:360-361)
+	if (split_reads1 > 20 && split_reads2 > 20 && supporting_reads > 60) confidence = CONFIDENCE_HIGH;
+	// something does not look right with the number of supporting reads (:364-388)
+	if (confidence > CONFIDENCE_LOW) {
+		if (split_reads1 + split_reads2 == 0 || split_reads1 + discordant_mates == 0 || split_reads2 + discordant_mates == 0) --confidence; // reads from both ends are expected
+		else if ((split_reads1 + split_reads2) * 20 < discordant_mates) --confidence;                                                 // split reads and discordant mates should be balanced
+		else if (evalue > 0.2 || coverage_fraction < 0.01) confidence = CONFIDENCE_MEDIUM;                                            // not overwhelming compared to the coverage
+	}
+	return (uint8_t) confidence;
+}
+
 // the stage as one switch (kernel and host stepping share it); returns the filter id the candidate gets, FILTER_none if it stays, or
 // EVENT_KEPT_UNCOUNTED if it stays without entering the "(remaining=N)" of the stage: filter_both_intronic and filter_end_to_end_fusions skip
 // the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)

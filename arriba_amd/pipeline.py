@@ -322,6 +322,13 @@ class DevicePipeline(object):
         """reference: recover_both_spliced, source/recover_both_spliced.cpp:72-182 (the arguments of the call at source/arriba.cpp:491)"""
         return self._event_stage("recover_both_spliced", max_fusions_to_recover, c_float(high_expression_quantile), max_exon_size, max_coverage)
 
+    def assign_confidence(self):
+        """reference: assign_confidence, source/filter_genomic_support.cpp:222-399; returns the confidence (0 low, 1 medium, 2 high) of every candidate"""
+        confidence = np.zeros(max(self.n_candidates, 1), dtype=np.uint8)
+        self._check(self.api.assign_confidence(self.ctx, confidence.ctypes.data))
+        self._record("assign_confidence")
+        return confidence[:self.n_candidates]
+
     def recover_isoforms(self):
         """reference: recover_isoforms, source/recover_isoforms.cpp:10-47"""
         return self._event_stage("recover_isoforms")

@@ -309,6 +309,9 @@ int agpu_set_read_filters(agpu_ctx* ctx, const uint8_t* filter /* [n] */);
 
 /* make_kmer_index (source/filter_mismappers.cpp:47-84, called at source/arriba.cpp:547-553): 8-mer positions of the genes of all
  * unfiltered candidates with gene1 != gene2, padded by `padding` = max_mate_gap + 2 * read_length_mean (as int). */
+/* assign_confidence (source/filter_genomic_support.cpp:222-399, called at source/arriba.cpp:587-589; without structural variants from WGS).
+ * confidence: [n_candidates] 0 = low, 1 = medium, 2 = high (source/common.hpp:224-227); may be NULL */
+int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence);
 /* recover_isoforms (source/recover_isoforms.cpp:10-47, called at source/arriba.cpp:580-584): the last of the candidate-level filters */
 int agpu_recover_isoforms(agpu_ctx* ctx, uint64_t* remaining);
 /* filter_homologs (source/filter_homologs.cpp:68-141, called at source/arriba.cpp:556-560 behind make_kmer_index; max_identity_fraction = -L, default 0.3).

@@ -18,7 +18,7 @@ DEFAULT_GOLDEN_FILES = ["reads.*_annotated.tsv", "filters.*_read_filters_final.t
                         "fusions.*_filter_mismappers.tsv", "filters.*_before_filter_mismappers.tsv", "filters.*_filter_mismappers.tsv",
                         "fusions.*_recover_internal_tandem_duplication.tsv", "filters.*_recover_internal_tandem_duplication.tsv", "fusions.*_filter_both_intronic.tsv",
                         "fusions.*_filter_in_vitro.tsv", "fusions.*_recover_both_spliced.tsv", "fusions.*_select_most_supported_breakpoints.tsv", "fusions.*_filter_marginal_read_through.tsv", "fusions.*_recover_many_spliced.tsv", "fusions.*_filter_short_anchor.tsv", "fusions.*_filter_end_to_end_fusions.tsv", "fusions.*_filter_no_coverage.tsv",
-                        "reads.*_after_find_fusions.tsv", "fusions.*_recover_isoforms.tsv"]
+                        "reads.*_after_find_fusions.tsv", "fusions.*_assign_confidence.tsv"]
 
 DATASETS = {
     # small, every record kind, sorted names, default (too few samples) fragment-length path
@@ -40,7 +40,7 @@ DATASETS = {
     # families of homologous genes (one locus copied over another) with junctions to a common partner and between them: filter_homologs fires
     "homologs8k": {"args": ["--seed", "29", "--fragments", "8000", "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--homolog-families", "4"],
                    "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_filter_no_coverage.tsv", "filters.*_recover_internal_tandem_duplication.tsv",
-                                    "fusions.*_before_filter_mismappers.tsv", "fusions.*_filter_mismappers.tsv", "filters.*_filter_mismappers.tsv", "fusions.*_recover_isoforms.tsv"]},
+                                    "fusions.*_before_filter_mismappers.tsv", "fusions.*_filter_mismappers.tsv", "filters.*_filter_mismappers.tsv", "fusions.*_assign_confidence.tsv"]},
     # the same sample with the reference's event-level filters in front of filter_homologs switched off: thousands of candidates reach the elimination
     "homologs8k_open": {"args": ["--seed", "29", "--fragments", "8000", "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--homolog-families", "4"],
                         "reference_disable_filters": ["relative_support", "min_support", "select_best", "intronic", "in_vitro", "end_to_end", "no_coverage", "short_anchor", "non_coding_neighbors", "intragenic_exonic"],

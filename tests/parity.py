@@ -501,9 +501,28 @@ def check_isoforms(session, pipeline, golden, state_from="select_most_supported_
     _inject_candidate_state(pipeline, index, before)
     remaining = pipeline.recover_isoforms()
     assert remaining == int(re.search(r"Searching for additional isoforms[^\n]*\(remaining=(\d+)\)", log).group(1)), remaining
-    assert _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_isoforms")), "recover_isoforms") == remaining
+    assert _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "assign_confidence", which=-1)), "recover_isoforms") == remaining
     entering = sum(1 for f in before if f["filter"] == 0)
     return entering, remaining - entering
+
+
+def check_confidence(session, pipeline, golden, multimappers=True):
+    """assign_confidence from the reference's candidate state in front of it (injected; e-values and coverage are the device's own) against its dump.
+    Returns the number of candidates per confidence level."""
+    pipeline.find_fusions()
+    pipeline.upload_coverage()
+    pipeline.merge_adjacent_fusions()
+    if multimappers:
+        pipeline.filter_multimappers()
+    pipeline.estimate_expected_fusions()
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    expected = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "assign_confidence", which=-1))
+    _inject_candidate_state(pipeline, index, expected)
+    confidence = pipeline.assign_confidence()
+    wrong = [(fusion_key(f), int(confidence[index[fusion_key(f)]]), f["confidence"]) for f in expected if int(confidence[index[fusion_key(f)]]) != f["confidence"]]
+    assert not wrong, (len(wrong), wrong[:10])
+    return [int((confidence == level).sum()) for level in (0, 1, 2)]
 
 
 def check_chain_to_isoforms(session, pipeline, golden):
@@ -519,12 +538,16 @@ def check_chain_to_isoforms(session, pipeline, golden):
     assert selected == int(re.findall(r"Selecting best breakpoints[^\n]*\(remaining=(\d+)\)", log)[-1])
     recovered = pipeline.recover_isoforms()
     assert recovered == int(re.search(r"Searching for additional isoforms[^\n]*\(remaining=(\d+)\)", log).group(1)), recovered
-    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "recover_isoforms"))
+    after = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", "assign_confidence", which=-1))  # assign_confidence changes no filter: the state behind recover_isoforms
     assert _compare_candidate_filters(pipeline, index, after, "recover_isoforms") == recovered
+    confidence = pipeline.assign_confidence()
+    wrong = [(fusion_key(f), int(confidence[index[fusion_key(f)]]), f["confidence"]) for f in after if int(confidence[index[fusion_key(f)]]) != f["confidence"]]
+    assert not wrong, (len(wrong), wrong[:10])
     result = pipeline.candidates()
     problems = [fusion_key(f) for f in after if (int(result["split_reads1"][index[fusion_key(f)]]), int(result["split_reads2"][index[fusion_key(f)]]), int(result["discordant_mates"][index[fusion_key(f)]])) != (f["split_reads1"], f["split_reads2"], f["discordant_mates"])]
     assert not problems, (len(problems), problems[:10])
-    return counts + [selected, recovered], discarded
+    levels = [int((confidence == level).sum()) for level in (0, 1, 2)]
+    return counts + [selected, recovered], discarded, levels
 
 
 def check_read_lists(session, pipeline, golden, stage):

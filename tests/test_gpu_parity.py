@@ -297,17 +297,19 @@ def test_chain_to_no_coverage_without_injected_state(built, dataset_files, tmp_p
 
 def test_homologs_and_chain_to_the_last_filter(built, dataset_files, tmp_path):
     """filter_homologs on the GPU (verdicts: one thread per gene pair; elimination on the host): a sample with families of homologous genes with the
-    reference's filters in front switched off (thousands of candidates), then the reference's stages 18-40 (to recover_isoforms, the last filter) as one chain with nothing
-    taken from the reference, on the golden datasets and on a live run"""
+    reference's filters in front switched off (thousands of candidates), then the reference's stages 18-41 (to recover_isoforms, the last filter, and assign_confidence) as one
+    chain with nothing taken from the reference, on the golden datasets and on a live run"""
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("homologs8k_open"))
     entering, discarded = parity.check_homologs(session, pipeline, conftest.golden_dir("homologs8k_open"), state_from="recover_many_spliced")
     assert entering > 3000 and discarded > 400
     for name in ("homologs8k", "toy3k"):
         session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name))
-        counts, reads_discarded = parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name))
+        counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name))
         assert counts[0] > counts[-1] > 0
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"))
     assert parity.check_isoforms(session, pipeline, conftest.golden_dir("toy3k")) == (46, 2)
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"))
+    assert parity.check_confidence(session, pipeline, conftest.golden_dir("toy3k")) == confidence_levels
     if not datasets.reference_available():
         return
     spec = {"args": ["--seed", "41", "--fragments", "120000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15", "--homolog-families", "60"]}
@@ -322,5 +324,5 @@ def test_homologs_and_chain_to_the_last_filter(built, dataset_files, tmp_path):
     with open(os.path.join(dump, "reference.log"), "w") as out:
         out.write(log)
     session, pipeline = parity.run_read_level(parity.open_session, prefix)
-    counts, reads_discarded = parity.check_chain_to_isoforms(session, pipeline, dump)
+    counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, dump)
     assert counts[-5] > counts[-4] > 100 and counts[-1] > counts[-2], counts

@@ -224,11 +224,14 @@ def test_homologs_and_chain_to_the_last_filter(dataset_files, emu_api):
     assert entering > 3000 and discarded > 400
     for name in ("homologs8k", "toy3k"):
         session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name), api=emu_api)
-        counts, reads_discarded = parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name))
+        counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name))
         assert counts[0] > counts[-1] > 0
     assert counts[-5] == counts[-4] == 46 and counts[-1] == 48  # toy3k: no homologs, two isoforms recovered
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
     assert parity.check_isoforms(session, pipeline, conftest.golden_dir("toy3k")) == (46, 2)
+    assert confidence_levels[1] > 0 and confidence_levels[2] > 0 and sum(confidence_levels) == pipeline.n_candidates  # assign_confidence at the end of the chain
+    session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
+    assert parity.check_confidence(session, pipeline, conftest.golden_dir("toy3k")) == confidence_levels
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("homologs8k"), api=emu_api)
     pipeline.find_fusions()
     from arriba_amd.pipeline import ArribaError

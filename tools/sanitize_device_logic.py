@@ -33,4 +33,7 @@ for name, check in (('homologs8k_open', lambda s,p,g: parity.check_homologs(s,p,
     prefix=datasets.generate(datasets.DATASETS[name], tmp, name)
     s,p=parity.run_read_level(parity.open_session,prefix,api=api)
     print(name, check(s,p,conftest.golden_dir(name)))
+prefix=datasets.generate(datasets.DATASETS['toy3k'], tmp, 'toy3k_confidence')
+s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+print('confidence', parity.check_confidence(s,p,conftest.golden_dir('toy3k')))
 print('done')
