@@ -40,6 +40,14 @@ class CoverageView(ctypes.Structure):
     _fields_ = [("n_contigs", c_uint32), ("window_offset", POINTER(c_uint64)), ("coverage", POINTER(c_uint16)), ("fragment_starts", POINTER(c_uint8)), ("fragment_ends", POINTER(c_uint8))]
 
 
+class RangeItem(ctypes.Structure):
+    _fields_ = [("type", c_uint8), ("strand_defined", c_uint8), ("strand", c_uint8), ("reserved", c_uint8), ("contig", c_uint32), ("start", c_int32), ("end", c_int32), ("gene", c_uint32)]
+
+
+class RangeRule(ctypes.Structure):
+    _fields_ = [("first", RangeItem), ("second", RangeItem)]
+
+
 class BatchView(ctypes.Structure):
     _fields_ = [("n", c_uint64), ("n_aln", POINTER(c_uint8)), ("fbits", POINTER(c_uint8)), ("group", POINTER(c_uint32)),
                 ("contig", POINTER(c_uint16) * 3), ("start", POINTER(c_int32) * 3), ("end", POINTER(c_int32) * 3), ("abits", POINTER(c_uint8) * 3),
@@ -129,6 +137,8 @@ def bind_device_api(lib, prefix="agpu_"):
         "filter_in_vitro": (c_int, [ctx, c_float, POINTER(c_uint64)]),
         "filter_homologs": (c_int, [ctx, c_float, POINTER(c_uint64)]),
         "recover_isoforms": (c_int, [ctx, POINTER(c_uint64)]),
+        "filter_blacklisted_ranges": (c_int, [ctx, POINTER(RangeRule), c_uint32, c_float, c_int32, POINTER(c_uint64)]),
+        "recover_known_fusions": (c_int, [ctx, POINTER(RangeRule), c_uint32, c_int32, POINTER(c_uint64)]),
         "assign_confidence": (c_int, [ctx, c_void_p]),
         "recover_both_spliced": (c_int, [ctx, c_uint32, c_float, c_int32, c_uint32, POINTER(c_uint64)]),
         "set_owned_candidates": (c_int, [ctx, c_void_p, c_uint64]),
@@ -177,6 +187,7 @@ def bind_host_api(lib):
         "ahost_mapped_reads": (c_uint64, [session]),
         "ahost_coverage_checksum": (c_uint64, [session]),
         "ahost_coverage_view": (POINTER(CoverageView), [session]),
+        "ahost_load_range_rules": (c_int, [session, c_char_p, c_int, POINTER(POINTER(RangeRule)), POINTER(c_uint32)]),
         "ahost_contig_count": (c_uint32, [session]),
         "ahost_contig_name": (c_char_p, [session, c_uint32]),
         "ahost_fragment_name": (c_void_p, [session, c_uint64, POINTER(c_uint32)]),

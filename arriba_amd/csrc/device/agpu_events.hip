@@ -11,6 +11,7 @@
 #include "event_core.hpp"
 #include "device_utils.hpp"
 #include "in_vitro_host.hpp"
+#include "range_rule_host.hpp"
 
 using namespace agpu;
 
@@ -81,6 +82,13 @@ __global__ void isoform_verdict_kernel(CandidateTable t, const uint64_t* member_
 __global__ void isoform_recover_kernel(CandidateTable t, const uint8_t* recovered) { // a kernel of its own: the verdicts read the filters of all candidates
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c < t.n && recovered[c]) t.filter[c] = FILTER_none;
+}
+
+// filter_blacklisted_ranges (mode 0) / recover_known_fusions (mode 1)
+__global__ void range_rule_kernel(AnnotationView ann, CoverageView coverage, CandidateTable t, const float* evalues, RangeRuleIndex index, int mode, int32_t max_mate_gap, float evalue_cutoff) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n || !(mode == 0 ? blacklist_considers(t, c) : known_fusions_considers(t, c))) return;
+	if (candidate_matches_any_rule(ann, coverage, t, evalues, c, index, mode, max_mate_gap, evalue_cutoff)) t.filter[c] = mode == 0 ? FILTER_blacklist : FILTER_none;
 }
 
 // assign_confidence: sort keys (pass 0: gene pair, pass 1: gene2) and the verdicts
@@ -322,6 +330,63 @@ extern "C" int agpu_recover_many_spliced(agpu_ctx* ctx, uint32_t min_spliced_eve
 	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
 	if (remaining) *remaining = kept;
 	return AGPU_OK;
+}
+
+namespace {
+int run_range_rules(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rules, int mode, uint8_t filter_id, int32_t max_mate_gap, float evalue_cutoff, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (n_rules > 0 && !rules) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (!ctx->evalue_done) { set_last_error("agpu_estimate_expected_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (mode == 1 && !ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
+	for (uint32_t r = 0; r < n_rules; ++r) {
+		const agpu_range_item* items[2] = { &rules[r].first, &rules[r].second };
+		for (int k = 0; k < 2; ++k) {
+			if (items[k]->type > AGPU_RULE_NOT_BOTH_SPLICED) { set_last_error("range rule with an unknown item type"); return AGPU_ERR_INVALID; }
+			if (items[k]->type == AGPU_RULE_GENE && items[k]->gene >= ctx->n_genes + ctx->n_dummy) { set_last_error("range rule names a gene outside the annotation"); return AGPU_ERR_INVALID; }
+		}
+	}
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& device_rules = ctx->scratch("rules.rules"); DeviceBuffer& bin_keys = ctx->scratch("rules.bin_keys");
+	DeviceBuffer& bin_offset = ctx->scratch("rules.bin_offset"); DeviceBuffer& bin_rules = ctx->scratch("rules.bin_rules");
+	ALLOC(counter, 16);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && n_rules > 0 && ctx->params.filter_enabled[filter_id]) {
+		RangeRuleBins bins;
+		build_range_rule_bins(rules, n_rules, mode == 0 ? max_mate_gap : 0, bins);
+		if (!bins.bin_keys.empty()) { // a file of keywords only has no bins: nothing can match
+			ALLOC(device_rules, (size_t) n_rules * sizeof(agpu_range_rule)); ALLOC(bin_keys, bins.bin_keys.size() * 8); ALLOC(bin_offset, bins.bin_offset.size() * 4); ALLOC(bin_rules, bins.bin_rules.size() * 4);
+			HIP_CHECK(hipMemcpyAsync(device_rules.ptr, rules, (size_t) n_rules * sizeof(agpu_range_rule), hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(bin_keys.ptr, bins.bin_keys.data(), bins.bin_keys.size() * 8, hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(bin_offset.ptr, bins.bin_offset.data(), bins.bin_offset.size() * 4, hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(bin_rules.ptr, bins.bin_rules.data(), bins.bin_rules.size() * 4, hipMemcpyHostToDevice, s));
+			RangeRuleIndex index;
+			index.rules = device_rules.as<agpu_range_rule>(); index.n_rules = n_rules; index.bin_keys = bin_keys.as<uint64_t>(); index.bin_offset = bin_offset.as<uint32_t>(); index.bin_rules = bin_rules.as<uint32_t>();
+			index.n_bins = (uint32_t) bins.bin_keys.size();
+			KernelTimer timer(ctx, mode == 0 ? "range_rule_kernel(blacklist)" : "range_rule_kernel(known_fusions)", (uint64_t) C * 40);
+			range_rule_kernel<<<(unsigned int) ((C + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, ctx->candidates, ctx->cand_evalue.as<float>(), index, mode, max_mate_gap, evalue_cutoff);
+			HIP_CHECK(hipStreamSynchronize(s)); // the host vectors of the index are read by the copies above
+		}
+	}
+	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 40;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+}
+extern "C" int agpu_filter_blacklisted_ranges(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rules, float evalue_cutoff, int32_t max_mate_gap, uint64_t* remaining) {
+	return run_range_rules(ctx, rules, n_rules, 0, FILTER_blacklist, max_mate_gap, evalue_cutoff, remaining);
+}
+extern "C" int agpu_recover_known_fusions(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rules, int32_t max_mate_gap, uint64_t* remaining) {
+	return run_range_rules(ctx, rules, n_rules, 1, FILTER_known_fusions, max_mate_gap, 0, remaining);
 }
 
 extern "C" int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence) {

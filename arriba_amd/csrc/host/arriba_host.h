@@ -9,6 +9,7 @@
 #define ARRIBA_HOST_H 1
 
 #include <cstdint>
+#include "../../../include/arriba_gpu.h"
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -86,6 +87,8 @@ struct Annotation {
 	size_t real_genes = 0;                      // genes[0..real_genes) come from the GTF
 };
 // reference: source/annotation.cpp:161-377
+// blacklist (keywords allowed in the second column) or known-fusions file -> rules; reference: source/filter_blacklisted_ranges.cpp:17-118, :244-264
+void load_range_rules(const std::string& path, const Contigs& contigs, const Annotation& annotation, bool allow_keyword_in_second_column, std::vector<agpu_range_rule>& rules);
 void read_annotation_gtf(Annotation& annotation, const std::string& gtf_path, const std::string& gtf_features, Contigs& contigs, const Assembly& assembly);
 
 // Flattened interval index (reference: source/annotation.t.hpp:25-45): per contig a sorted array of

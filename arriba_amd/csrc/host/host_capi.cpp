@@ -32,6 +32,7 @@ struct ahost_session {
 	FlatIndex exon_index, gene_index;
 	IngestResult ingest;
 	bool have_batch = false;
+	std::vector<agpu_range_rule> range_rules[2]; // [0] known fusions, [1] blacklist (keywords allowed)
 
 	// flattened tables backing the views
 	std::vector<uint16_t> gene_contig; std::vector<int32_t> gene_start, gene_end, gene_exonic_length; std::vector<uint8_t> gene_bits;
@@ -198,6 +199,17 @@ template <class Visit> void visit_ingest(IngestResult& r, Visit& visit) { // the
 extern "C" {
 
 const char* ahost_last_error(void) { return g_error.c_str(); }
+
+int ahost_load_range_rules(ahost_session* session, const char* path, int allow_keywords, const agpu_range_rule** rules, uint32_t* n_rules) {
+	if (!session || !path || !rules || !n_rules) { g_error = "null argument"; return -1; }
+	try {
+		std::vector<agpu_range_rule>& slot = session->range_rules[allow_keywords ? 1 : 0];
+		load_range_rules(path, session->contigs, session->annotation, allow_keywords != 0, slot);
+		*rules = slot.empty() ? nullptr : slot.data();
+		*n_rules = (uint32_t) slot.size();
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
 
 ahost_session* ahost_open(const char* fasta_path, const char* gtf_path, const char* interesting_contigs, const char* viral_contigs, const char* gtf_features) {
 	std::unique_ptr<ahost_session> session(new ahost_session());

@@ -703,4 +703,112 @@ std::string Batch::sequence(unsigned slot, size_t i) const {
 	return result;
 }
 
+// ---- blacklist / known-fusions files (reference: source/filter_blacklisted_ranges.cpp:17-118, the line loops at :244-264 and
+// source/recover_known_fusions.cpp:21-37) --------------------------------------------------------
+
+namespace {
+
+// one field of the reference's tsv_stream_t (source/read_compressed_file.cpp:62-88): fails when the cursor is at or behind the end
+struct FieldCursor {
+	const std::string& data; char delimiter; size_t position; bool failed;
+	FieldCursor(const std::string& text, char d): data(text), delimiter(d), position(0), failed(false) {}
+	void next(std::string& out) {
+		if (position >= data.size()) { failed = true; return; }
+		const size_t start = position;
+		position = data.find(delimiter, start);
+		out = data.substr(start, position - start);
+		if (position < data.size()) position++;
+	}
+	void next(int& out) {
+		std::string field;
+		const bool was_failed = failed;
+		next(field);
+		if (failed && !was_failed) return;
+		// reference: str_to_int (source/common.hpp:316-321)
+		const char* text = field.c_str();
+		char* end_of_parsing;
+		const long value = strtol(text, &end_of_parsing, 10);
+		out = (int) value;
+		if (!(*text != ' ' && end_of_parsing != text && *end_of_parsing == '\0' && value != LONG_MAX && value != LONG_MIN)) failed = true;
+	}
+};
+
+void warn_malformed_range(const std::string& range) { fprintf(stderr, "WARNING: unknown gene or malformed range: %s\n", range.c_str()); }
+
+// reference: parse_range (:17-80)
+bool parse_range(std::string range, const Contigs& contigs, agpu_range_item& item) {
+	const std::string original = range;
+	const size_t separator = range.find_last_of(':'); // the last colon: contig names may hold colons
+	if (separator < range.size()) range[separator] = '\t';
+	FieldCursor fields(range, '\t');
+	std::string contig_name, start_and_end;
+	fields.next(contig_name); fields.next(start_and_end);
+	if (fields.failed || contig_name.empty() || start_and_end.empty()) { warn_malformed_range(range); return false; }
+	item.strand_defined = contig_name[0] == '+' || contig_name[0] == '-';
+	if (item.strand_defined) { item.strand = contig_name[0] == '+'; contig_name = contig_name.substr(1); }
+	contig_name = remove_chr(contig_name);
+	std::map<std::string, contig_t>::const_iterator contig;
+	if (contig_name.size() >= 2 && contig_name[contig_name.size() - 1] == '*') { // a trailing asterisk: the closest match
+		contig_name = contig_name.substr(0, contig_name.size() - 1);
+		contig = contigs.by_name.lower_bound(contig_name);
+		if (contig != contigs.by_name.end() && contig_name != contig->first.substr(0, contig_name.size())) contig = contigs.by_name.end();
+	} else {
+		contig = contigs.by_name.find(contig_name);
+		if (contig == contigs.by_name.end()) warn_malformed_range(range);
+	}
+	if (contig == contigs.by_name.end()) return false;
+	item.contig = contig->second;
+	FieldCursor positions(start_and_end, '-');
+	int start = 0, end = 0;
+	if (start_and_end.find('-') < start_and_end.size()) { // contig:start-end
+		positions.next(start); positions.next(end);
+		if (positions.failed) { warn_malformed_range(range); return false; }
+		item.start = start - 1; item.end = end - 1; // zero-based
+	} else { // contig:position
+		positions.next(start);
+		if (positions.failed) { warn_malformed_range(range); return false; }
+		item.start = item.end = start - 1;
+	}
+	return true;
+}
+
+// reference: parse_blacklist_item (:83-118)
+bool parse_range_item(const std::string& text, agpu_range_item& item, const Contigs& contigs, const Annotation& annotation, bool allow_keyword) {
+	memset(&item, 0, sizeof(item));
+	if (text.empty()) { fprintf(stderr, "WARNING: encountered a line with an empty column => skipped\n"); return false; }
+	if (allow_keyword) {
+		static const struct { const char* word; uint8_t type; } keywords[] = { { "any", AGPU_RULE_ANY }, { "split_read_donor", AGPU_RULE_SPLIT_READ_DONOR }, { "split_read_acceptor", AGPU_RULE_SPLIT_READ_ACCEPTOR },
+			{ "split_read_any", AGPU_RULE_SPLIT_READ_ANY }, { "discordant_mates", AGPU_RULE_DISCORDANT_MATES }, { "read_through", AGPU_RULE_READ_THROUGH }, { "low_support", AGPU_RULE_LOW_SUPPORT },
+			{ "filter_spliced", AGPU_RULE_FILTER_SPLICED }, { "not_both_spliced", AGPU_RULE_NOT_BOTH_SPLICED } };
+		for (size_t k = 0; k < sizeof(keywords) / sizeof(keywords[0]); ++k)
+			if (text == keywords[k].word) { item.type = keywords[k].type; return true; }
+	}
+	std::unordered_map<std::string, int>::const_iterator gene = annotation.gene_by_name.find(text);
+	if (gene != annotation.gene_by_name.end()) {
+		const GeneRecord& record = annotation.genes[gene->second];
+		item.type = AGPU_RULE_GENE; item.gene = (uint32_t) gene->second; item.contig = record.contig; item.start = record.start; item.end = record.end;
+		return true;
+	}
+	if (!parse_range(text, contigs, item)) return false;
+	item.type = item.start == item.end ? AGPU_RULE_POSITION : AGPU_RULE_RANGE;
+	return true;
+}
+
+}
+
+void load_range_rules(const std::string& path, const Contigs& contigs, const Annotation& annotation, bool allow_keyword_in_second_column, std::vector<agpu_range_rule>& rules) {
+	rules.clear();
+	LineReader file(path);
+	std::string line;
+	while (file.getline(line)) {
+		if (line.empty() || line[0] == '#') continue;
+		FieldCursor fields(line, '\t');
+		std::string range1, range2;
+		fields.next(range1); fields.next(range2);
+		agpu_range_rule rule;
+		if (!parse_range_item(range1, rule.first, contigs, annotation, false) || !parse_range_item(range2, rule.second, contigs, annotation, allow_keyword_in_second_column)) continue;
+		rules.push_back(rule);
+	}
+}
+
 }

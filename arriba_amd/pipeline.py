@@ -5,7 +5,7 @@
 device stages where the reference calls the corresponding stage function.  Method names follow the reference.
 """
 import ctypes
-from ctypes import byref, c_float, c_int32, c_uint32, c_uint64
+from ctypes import POINTER, byref, c_float, c_int32, c_uint32, c_uint64
 
 import numpy as np
 
@@ -321,6 +321,25 @@ class DevicePipeline(object):
     def recover_both_spliced(self, max_fusions_to_recover=200, high_expression_quantile=0.998, max_exon_size=1000, max_coverage=1000):
         """reference: recover_both_spliced, source/recover_both_spliced.cpp:72-182 (the arguments of the call at source/arriba.cpp:491)"""
         return self._event_stage("recover_both_spliced", max_fusions_to_recover, c_float(high_expression_quantile), max_exon_size, max_coverage)
+
+    def load_range_rules(self, path, allow_keywords):
+        """a blacklist (allow_keywords=True) or known-fusions file -> (pointer to rules, count); reference: parse_blacklist_item, source/filter_blacklisted_ranges.cpp:83-118"""
+        rules, count = POINTER(_capi.RangeRule)(), c_uint32()
+        if self.session._lib.ahost_load_range_rules(self.session._session, path.encode(), int(allow_keywords), byref(rules), byref(count)) != 0:
+            raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
+        return rules, count.value
+
+    def filter_blacklisted_ranges(self, path, evalue_cutoff=0.3, max_mate_gap=None):
+        """reference: filter_blacklisted_ranges, source/filter_blacklisted_ranges.cpp:227-301 (-b)"""
+        rules, count = self.load_range_rules(path, True)
+        gap = int(self.scalars["max_mate_gap"] if max_mate_gap is None else max_mate_gap)
+        return self._event_stage("filter_blacklisted_ranges", rules, count, c_float(evalue_cutoff), gap)
+
+    def recover_known_fusions(self, path, max_mate_gap=None):
+        """reference: recover_known_fusions, source/recover_known_fusions.cpp:14-100 (-k)"""
+        rules, count = self.load_range_rules(path, False)
+        gap = int(self.scalars["max_mate_gap"] if max_mate_gap is None else max_mate_gap)
+        return self._event_stage("recover_known_fusions", rules, count, gap)
 
     def assign_confidence(self):
         """reference: assign_confidence, source/filter_genomic_support.cpp:222-399; returns the confidence (0 low, 1 medium, 2 high) of every candidate"""

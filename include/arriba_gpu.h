@@ -309,6 +309,26 @@ int agpu_set_read_filters(agpu_ctx* ctx, const uint8_t* filter /* [n] */);
 
 /* make_kmer_index (source/filter_mismappers.cpp:47-84, called at source/arriba.cpp:547-553): 8-mer positions of the genes of all
  * unfiltered candidates with gene1 != gene2, padded by `padding` = max_mate_gap + 2 * read_length_mean (as int). */
+/* A line of a blacklist or known-fusions file (source/filter_blacklisted_ranges.hpp:13-22): two items, each a gene, a position, a range or -- second
+ * column of a blacklist -- a keyword.  ahost_load_range_rules (arriba_host.h) parses the files. */
+enum { AGPU_RULE_RANGE = 0, AGPU_RULE_POSITION = 1, AGPU_RULE_GENE = 2, AGPU_RULE_ANY = 3, AGPU_RULE_SPLIT_READ_DONOR = 4, AGPU_RULE_SPLIT_READ_ACCEPTOR = 5, AGPU_RULE_SPLIT_READ_ANY = 6,
+       AGPU_RULE_DISCORDANT_MATES = 7, AGPU_RULE_READ_THROUGH = 8, AGPU_RULE_LOW_SUPPORT = 9, AGPU_RULE_FILTER_SPLICED = 10, AGPU_RULE_NOT_BOTH_SPLICED = 11 };
+typedef struct {
+	uint8_t type;            /* AGPU_RULE_* */
+	uint8_t strand_defined;  /* position / range given as +contig:... or -contig:... */
+	uint8_t strand;          /* 1 = forward */
+	uint8_t reserved;
+	uint32_t contig;         /* position / range / gene */
+	int32_t start, end;      /* 0-based inclusive; a gene: its start and end */
+	uint32_t gene;           /* gene id (AGPU_RULE_GENE) */
+} agpu_range_item;
+typedef struct { agpu_range_item first, second; } agpu_range_rule;
+/* filter_blacklisted_ranges (source/filter_blacklisted_ranges.cpp:227-301, called at source/arriba.cpp:527-530 with -E evalue_cutoff and max_mate_gap):
+ * an unfiltered candidate that a line matches gets the filter `blacklist`.  Needs the e-values. */
+int agpu_filter_blacklisted_ranges(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rules, float evalue_cutoff, int32_t max_mate_gap, uint64_t* remaining);
+/* recover_known_fusions (source/recover_known_fusions.cpp:14-100, called at source/arriba.cpp:475-478): a candidate discarded for low support
+ * (relative_support, min_support) between different genes that a line matches comes back.  Needs the coverage. */
+int agpu_recover_known_fusions(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rules, int32_t max_mate_gap, uint64_t* remaining);
 /* assign_confidence (source/filter_genomic_support.cpp:222-399, called at source/arriba.cpp:587-589; without structural variants from WGS).
  * confidence: [n_candidates] 0 = low, 1 = medium, 2 = high (source/common.hpp:224-227); may be NULL */
 int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence);

@@ -33,6 +33,12 @@ int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t 
 int ahost_save_ingest(ahost_session* session, const char* path);
 int ahost_load_ingest(ahost_session* session, const char* path);
 
+/* A blacklist (allow_keywords = 1: the second column may hold a keyword, source/filter_blacklisted_ranges.cpp:91-102) or a known-fusions file
+ * (allow_keywords = 0) parsed into rules for agpu_filter_blacklisted_ranges / agpu_recover_known_fusions (parse_blacklist_item, parse_range:
+ * source/filter_blacklisted_ranges.cpp:17-118; plain or gzip).  Malformed lines are skipped with the reference's warning.  The rules stay
+ * valid until the next call with the same allow_keywords or ahost_close. */
+int ahost_load_range_rules(ahost_session* session, const char* path, int allow_keywords, const agpu_range_rule** rules, uint32_t* n_rules);
+
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session);
 const agpu_genome_view* ahost_genome_view(ahost_session* session);
 const agpu_coverage_view* ahost_coverage_view(ahost_session* session);  /* coverage_t of the ingest for agpu_upload_coverage; NULL before an ingest */

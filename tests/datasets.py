@@ -46,6 +46,11 @@ DATASETS = {
                         "reference_disable_filters": ["relative_support", "min_support", "select_best", "intronic", "in_vitro", "end_to_end", "no_coverage", "short_anchor", "non_coding_neighbors", "intragenic_exonic"],
                         "reference_env": {"ARRIBA_ORACLE_DUMP_LISTS": "0"},
                         "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_recover_many_spliced.tsv", "fusions.*_before_filter_mismappers.tsv"]},
+    # with a blacklist and a known-fusions file (every kind of item, malformed lines): filter_blacklisted_ranges and recover_known_fusions in the chain
+    "rules8k": {"args": ["--seed", "17", "--fragments", "8000", "--contigs", "4", "--contig-len", "300000", "--junctions", "120", "--rule-files"], "rule_files": True,
+                "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_filter_both_intronic.tsv", "fusions.*_recover_known_fusions.tsv", "fusions.*_recover_many_spliced.tsv", "fusions.*_filter_blacklisted_ranges.tsv",
+                                 "fusions.*_filter_no_coverage.tsv", "filters.*_recover_internal_tandem_duplication.tsv", "fusions.*_assign_confidence.tsv", "filters.*_filter_mismappers.tsv",
+                                 "fusions.*_before_filter_mismappers.tsv", "fusions.*_filter_mismappers.tsv"], "reference_env": {"ARRIBA_ORACLE_DUMP_LISTS": "0"}},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},
@@ -67,7 +72,11 @@ def run_reference(prefix, dump_directory, spec=None, extra_args=(), disable_filt
     env = dict(os.environ)
     env.update((spec or {}).get("reference_env", {}))
     env["ARRIBA_ORACLE_DUMP"] = dump_directory
-    command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv", "-f", ",".join(["blacklist"] + list(disable_filters))] + list(extra_args)
+    with_rules = bool((spec or {}).get("rule_files"))  # a blacklist and a known-fusions file written by the generator (--rule-files)
+    disabled = list(disable_filters) if with_rules else ["blacklist"] + list(disable_filters)
+    command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv"] + (["-f", ",".join(disabled)] if disabled else []) + list(extra_args)
+    if with_rules:
+        command += ["-b", prefix + ".blacklist.tsv", "-k", prefix + ".known_fusions.tsv"]
     result = subprocess.run(command, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     if result.returncode != 0:
         raise RuntimeError("reference failed:\n" + result.stdout)

@@ -248,6 +248,12 @@ def check_mismappers(session, pipeline, golden):
     return discarded
 
 
+def logged_remaining(log, pattern, which=0):
+    """the "(remaining=N)" the reference's log prints for the stage whose line matches `pattern` (warnings of the stage may sit between "=" and N)"""
+    import re
+    return int(re.findall(pattern + r"[^\n]*\(remaining=(?:WARNING:[^\n]*\n)*(\d+)\)", log)[which])
+
+
 def _inject_candidate_state(pipeline, index, fusions):
     n = pipeline.n_candidates
     state = {k: np.zeros(n, dtype=np.uint32) for k in ("filter", "split_reads1", "split_reads2", "discordant_mates")}
@@ -392,13 +398,14 @@ def check_recover_itd(session, pipeline, golden):
     return sum(1 for f in after if f["filter"] == 0 and before_filter[fusion_key(f)] != 0), sum(1 for a, b in zip(read_filters, read_filters_after) if a != b)
 
 
-def check_chain_to_no_coverage(session, pipeline, golden):
+def check_chain_to_no_coverage(session, pipeline, golden, rules_prefix=None):
     """The reference's stages 18-35 (find_fusions ... filter_no_coverage, default filters) on the device in one go, nothing taken from the reference:
     every "(remaining=N)" of the log, and at the end the filter and the counters of every candidate and the filter of every read."""
     import re
     log = open(os.path.join(golden, "reference.log")).read()
     def logged(pattern):
-        return int(re.search(pattern + r"[^\n]*\(remaining=(\d+)\)", log).group(1))
+        return logged_remaining(log, pattern)
+    evalue_cutoff = float(re.search(r"Filtering fusions with an e-value >=([0-9.eE+-]+)", log).group(1))
     itd = re.search(r"Searching for internal tandem duplications <=\d+bp with >=(\d+) supporting reads and >=([0-9.]+)% allele fraction", log)
     quantile = float(re.search(r"expression above the ([0-9.]+)% quantile", log).group(1)) / 100
     min_spliced_events = int(re.search(r"Searching for fusions with >=(\d+) spliced events", log).group(1))
@@ -411,13 +418,15 @@ def check_chain_to_no_coverage(session, pipeline, golden):
     counts.append(pipeline.filter_relative_support())
     expected = [logged("Merging adjacent fusion breakpoints"), logged("Filtering multi-mapping fusions"), logged("Filtering fusions with an e-value")]
     stages = [(lambda: pipeline.recover_internal_tandem_duplication(int(itd.group(1)), float(itd.group(2)) / 100), "Searching for internal tandem duplications"),
-              (pipeline.filter_both_intronic, "Filtering fusions with both breakpoints in intronic/intergenic regions"),
-              (lambda: pipeline.filter_in_vitro(quantile), "Filtering in vitro-generated fusions"),
+              (pipeline.filter_both_intronic, "Filtering fusions with both breakpoints in intronic/intergenic regions")] + \
+             ([(lambda: pipeline.recover_known_fusions(rules_prefix + ".known_fusions.tsv"), "Searching for known fusions")] if rules_prefix else []) + \
+             [(lambda: pipeline.filter_in_vitro(quantile), "Filtering in vitro-generated fusions"),
               (pipeline.recover_both_spliced, "Searching for fusions with spliced split reads"),
               (pipeline.select_most_supported_breakpoints, "Selecting best breakpoints from genes with multiple breakpoints"),
               (pipeline.filter_marginal_read_through, "Filtering read-through fusions with breakpoints near the gene boundary"),
-              (lambda: pipeline.recover_many_spliced(min_spliced_events), "Searching for fusions with >=\\d+ spliced events"),
-              (lambda: pipeline.filter_short_anchor(min_anchor_length), "Filtering fusions with anchors"),
+              (lambda: pipeline.recover_many_spliced(min_spliced_events), "Searching for fusions with >=\\d+ spliced events")] + \
+             ([(lambda: pipeline.filter_blacklisted_ranges(rules_prefix + ".blacklist.tsv", evalue_cutoff), "Filtering blacklisted fusions")] if rules_prefix else []) + \
+             [(lambda: pipeline.filter_short_anchor(min_anchor_length), "Filtering fusions with anchors"),
               (pipeline.filter_end_to_end, "Filtering end-to-end fusions with low support"),
               (pipeline.filter_no_coverage, "Filtering fusions with no coverage around the breakpoints")]
     for run, pattern in stages:
@@ -465,14 +474,40 @@ def check_homologs(session, pipeline, golden, multimappers=True, state_from="fil
     return entering, entering - remaining
 
 
-def check_chain_to_mismappers(session, pipeline, golden):
+def check_range_rules(session, pipeline, golden, rules_prefix, multimappers=True, known_from="filter_both_intronic", blacklist_from="recover_many_spliced"):
+    """recover_known_fusions and filter_blacklisted_ranges, each from the reference's candidate state in front of it (injected; e-values and coverage are the
+    device's own) against its dump.  Returns (known fusions recovered, candidates blacklisted)."""
+    import re
+    log = open(os.path.join(golden, "reference.log")).read()
+    evalue_cutoff = float(re.search(r"Filtering fusions with an e-value >=([0-9.eE+-]+)", log).group(1)) if "Filtering fusions with an e-value" in log else 0.3
+    pipeline.find_fusions()
+    pipeline.upload_coverage()
+    pipeline.merge_adjacent_fusions()
+    if multimappers:
+        pipeline.filter_multimappers()
+    pipeline.estimate_expected_fusions()
+    table = pipeline.candidates()
+    index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
+    results = []
+    for stage, state_from, run, pattern in (("recover_known_fusions", known_from, lambda: pipeline.recover_known_fusions(rules_prefix + ".known_fusions.tsv"), "Searching for known fusions"),
+                                            ("filter_blacklisted_ranges", blacklist_from, lambda: pipeline.filter_blacklisted_ranges(rules_prefix + ".blacklist.tsv", evalue_cutoff), "Filtering blacklisted fusions")):
+        before = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", state_from))
+        _inject_candidate_state(pipeline, index, before)
+        remaining = run()
+        assert remaining == logged_remaining(log, pattern), (stage, remaining, logged_remaining(log, pattern))
+        assert _compare_candidate_filters(pipeline, index, golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage)), stage) == remaining
+        results.append(abs(remaining - sum(1 for f in before if f["filter"] == 0)))
+    return tuple(results)
+
+
+def check_chain_to_mismappers(session, pipeline, golden, rules_prefix=None):
     """The reference's stages 18-38 (find_fusions ... filter_no_coverage -> make_kmer_index -> filter_homologs -> filter_mismappers, default filters)
     on the device in one go, nothing taken from the reference (the padding of the k-mer index and max_mate_gap come from the pipeline's own scalars)."""
     import re
     log = open(os.path.join(golden, "reference.log")).read()
     def logged(pattern):
         return int(re.search(pattern + r"[^\n]*\(remaining=(\d+)\)", log).group(1))
-    counts = check_chain_to_no_coverage(session, pipeline, golden)
+    counts = check_chain_to_no_coverage(session, pipeline, golden, rules_prefix)
     identity = float(re.search(r"Filtering genes with >=([0-9.]+)% identity", log).group(1)) / 100
     pipeline.make_kmer_index()
     after_homologs = pipeline.filter_homologs(identity)
@@ -525,13 +560,13 @@ def check_confidence(session, pipeline, golden, multimappers=True):
     return [int((confidence == level).sum()) for level in (0, 1, 2)]
 
 
-def check_chain_to_isoforms(session, pipeline, golden):
+def check_chain_to_isoforms(session, pipeline, golden, rules_prefix=None):
     """The reference's candidate-level workflow to its end: stages 18-38 as in check_chain_to_mismappers, then select_most_supported_breakpoints a
     second time and recover_isoforms (source/arriba.cpp:571-584); nothing taken from the reference.  What follows in the reference
     (assign_confidence, the output writer) does not change filters or counters."""
     import re
     log = open(os.path.join(golden, "reference.log")).read()
-    counts, discarded = check_chain_to_mismappers(session, pipeline, golden)
+    counts, discarded = check_chain_to_mismappers(session, pipeline, golden, rules_prefix)
     table = pipeline.candidates()
     index = {key: c for c, key in enumerate(candidate_keys(table, pipeline.n_candidates))}
     selected = pipeline.select_most_supported_breakpoints()

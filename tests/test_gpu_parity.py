@@ -326,3 +326,32 @@ def test_homologs_and_chain_to_the_last_filter(built, dataset_files, tmp_path):
     session, pipeline = parity.run_read_level(parity.open_session, prefix)
     counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, dump)
     assert counts[-5] > counts[-4] > 100 and counts[-1] > counts[-2], counts
+
+
+def test_blacklist_and_known_fusions(built, dataset_files, tmp_path):
+    """filter_blacklisted_ranges and recover_known_fusions on the GPU (one thread per candidate through the genome-bin index of the rules): from injected
+    state and inside the chain find_fusions ... assign_confidence, on the golden dataset and on a live run with 2000 junctions"""
+    prefix = dataset_files("rules8k")
+    golden = conftest.golden_dir("rules8k")
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    recovered, blacklisted = parity.check_range_rules(session, pipeline, golden, prefix)
+    assert recovered > 50 and blacklisted > 10
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, golden, rules_prefix=prefix)
+    assert len(counts) == 19 and counts[-1] > 0
+    if not datasets.reference_available():
+        return
+    spec = {"args": ["--seed", "47", "--fragments", "100000", "--normal-mult", "0.3", "--contigs", "6", "--contig-len", "500000", "--junctions", "2000", "--dup", "0.1", "--rule-files"], "rule_files": True}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump, spec)
+    finally:
+        del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, dump, rules_prefix=prefix)
+    assert counts[5] > counts[4] + 1000 and counts[11] < counts[10] - 100, counts  # known fusions recovered, candidates blacklisted

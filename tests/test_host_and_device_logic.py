@@ -239,6 +239,30 @@ def test_homologs_and_chain_to_the_last_filter(dataset_files, emu_api):
         pipeline.filter_homologs()
 
 
+def test_blacklist_and_known_fusions(dataset_files, emu_api):
+    """filter_blacklisted_ranges and recover_known_fusions: the parser (every kind of item, keywords, contig prefixes, malformed lines) and the
+    per-candidate match through the genome bins, from injected state and inside the chain find_fusions ... assign_confidence"""
+    prefix = dataset_files("rules8k")
+    golden = conftest.golden_dir("rules8k")
+    session, pipeline = parity.run_read_level(parity.open_session, prefix, api=emu_api)
+    rules, count = pipeline.load_range_rules(prefix + ".blacklist.tsv", True)
+    lines = [line for line in open(prefix + ".blacklist.tsv").read().split("\n") if line and not line.startswith("#")]
+    assert count == len(lines) - 10  # the ten malformed lines the generator appends are skipped (the reference warns about exactly those)
+    kinds = {(rules[k].first.type, rules[k].second.type) for k in range(count)}
+    assert {pair[0] for pair in kinds} == {0, 1, 2} and len({pair[1] for pair in kinds}) >= 9  # ranges, positions, genes; keywords in the second column
+    assert any(rules[k].first.strand_defined for k in range(count))
+    rules, count = pipeline.load_range_rules(prefix + ".known_fusions.tsv", False)
+    assert count == len([line for line in open(prefix + ".known_fusions.tsv") if not line.startswith("#")]) - 2  # "any" is not a keyword there
+    recovered, blacklisted = parity.check_range_rules(session, pipeline, golden, prefix)
+    assert recovered > 50 and blacklisted > 10
+    session, pipeline = parity.run_read_level(parity.open_session, prefix, api=emu_api)
+    counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, golden, rules_prefix=prefix)
+    assert len(counts) == 19 and counts[-1] > 0
+    from arriba_amd.pipeline import ArribaError
+    with pytest.raises(ArribaError):
+        pipeline.load_range_rules(prefix + ".no_such_file.tsv", True)
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")

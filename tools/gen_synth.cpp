@@ -425,6 +425,73 @@ void Generator::write_fasta(const std::string& path) const {
 	fclose(f);
 }
 
+// A blacklist and a known-fusions file (the reference's -b / -k) that exercise every kind of item: gene names, exact positions (1-based, optionally
+// with a strand), ranges, contig names with a "chr" prefix or a trailing asterisk, every keyword, comments and malformed lines.  Derived from
+// the junction table by a generator of its own, so that lines hit candidates: well supported junctions for the blacklist, all of them (mostly
+// poorly supported ones) for the known fusions.
+void Generator::write_rule_files(const std::string& blacklist_path, const std::string& known_fusions_path) const {
+	Rng rng(config_.seed ^ 0xB1AC4157ULL);
+	const std::vector<Junction>& junctions = impl_->junctions;
+	auto position = [&](const Side& side, bool with_strand, bool chr_prefix) {
+		std::string text = with_strand ? (rng.chance(0.5) ? "+" : "-") : "";
+		return text + (chr_prefix ? "chr" : "") + contig_names_[side.contig] + ":" + std::to_string(side.bp + 1);
+	};
+	auto range_of_gene = [&](int gene, bool with_strand) {
+		const Gene& g = genes_[gene];
+		const int shrink = rng.range(-2000, (g.end - g.start) / 3); // sometimes wider than the gene, sometimes covering less than half of it
+		std::string text = with_strand ? (g.plus ? "+" : "-") : "";
+		return text + contig_names_[g.contig] + ":" + std::to_string(std::max(1, g.start + 1 + shrink)) + "-" + std::to_string(g.end + 1 - shrink / 2);
+	};
+	static const char* const keywords[] = { "any", "split_read_donor", "split_read_acceptor", "split_read_any", "discordant_mates", "read_through", "low_support", "filter_spliced", "not_both_spliced" };
+	FILE* f = fopen(blacklist_path.c_str(), "w");
+	if (f == NULL) throw std::runtime_error("cannot write " + blacklist_path);
+	fprintf(f, "# synthetic blacklist\n\n");
+	for (size_t j = 0; j < junctions.size(); ++j) {
+		const Junction& junction = junctions[j];
+		if (junction.a.gene < 0 || junction.b.gene < 0 || !rng.chance(j < 40 ? 0.5 : 0.15)) continue;
+		const bool swap = rng.chance(0.5);
+		const Side& first = swap ? junction.b : junction.a;
+		const Side& second = swap ? junction.a : junction.b;
+		switch (rng.range(0, 7)) {
+			case 0: fprintf(f, "%s\t%s\n", genes_[first.gene].name.c_str(), genes_[second.gene].name.c_str()); break;
+			case 1: fprintf(f, "%s\t%s\n", position(first, rng.chance(0.6), rng.chance(0.3)).c_str(), position(second, rng.chance(0.4), false).c_str()); break;
+			case 2: fprintf(f, "%s\t%s\n", range_of_gene(first.gene, rng.chance(0.6)).c_str(), range_of_gene(second.gene, rng.chance(0.3)).c_str()); break;
+			case 3: fprintf(f, "%s\t%s\n", genes_[first.gene].name.c_str(), keywords[rng.below(9)]); break;
+			case 4: fprintf(f, "%s\t%s\n", position(first, false, false).c_str(), keywords[rng.below(9)]); break;
+			case 5: fprintf(f, "%s\t%s\n", range_of_gene(first.gene, false).c_str(), keywords[rng.below(9)]); break;
+			case 6: fprintf(f, "%s\t%s\n", genes_[first.gene].name.c_str(), position(second, false, false).c_str()); break;
+			default: { // discordant mates near a position: shifted breakpoints
+				Side shifted = second; shifted.bp += rng.range(-300, 300);
+				fprintf(f, "%s\t%s\r\n", genes_[first.gene].name.c_str(), position(shifted, false, false).c_str()); // DOS line end
+			}
+		}
+	}
+	// contigs by prefix, and lines the parser has to skip
+	fprintf(f, "%s*:1-%d\tdiscordant_mates\n", contig_names_[0].c_str(), 30000);
+	fprintf(f, "NC_*:1-7900\tany\n");
+	fprintf(f, "NOT_A_GENE\tany\n%s\n%s\t\n1:abc\tany\n1:100-\tany\n1:-5\tany\nchrUn_1:5\tany\n%s\tno_such_keyword\n\tany\n1: 5\tany\n",
+	        genes_[0].name.c_str(), genes_[0].name.c_str(), genes_[0].name.c_str());
+	fclose(f);
+
+	f = fopen(known_fusions_path.c_str(), "w");
+	if (f == NULL) throw std::runtime_error("cannot write " + known_fusions_path);
+	fprintf(f, "# synthetic known fusions\n");
+	for (size_t j = 0; j < junctions.size(); ++j) {
+		const Junction& junction = junctions[j];
+		if (junction.a.gene < 0 || junction.b.gene < 0 || !rng.chance(0.6)) continue;
+		const bool swap = rng.chance(0.3); // the junction table holds the 5' gene first: a swapped line only matches an ambiguous transcript start
+		const Side& first = swap ? junction.b : junction.a;
+		const Side& second = swap ? junction.a : junction.b;
+		switch (rng.range(0, 3)) {
+			case 0: case 1: fprintf(f, "%s\t%s\n", genes_[first.gene].name.c_str(), genes_[second.gene].name.c_str()); break;
+			case 2: fprintf(f, "%s\t%s\n", position(first, false, rng.chance(0.3)).c_str(), position(second, false, false).c_str()); break;
+			default: fprintf(f, "%s\t%s\n", range_of_gene(first.gene, false).c_str(), genes_[second.gene].name.c_str()); break;
+		}
+	}
+	fprintf(f, "%s\tany\nNOT_A_GENE\t%s\n", genes_[0].name.c_str(), genes_[0].name.c_str()); // keywords are not allowed here: "any" is an unknown gene
+	fclose(f);
+}
+
 void Generator::write_gtf(const std::string& path) const {
 	FILE* f = fopen(path.c_str(), "w");
 	if (f == NULL) throw std::runtime_error("cannot write " + path);
@@ -1045,7 +1112,7 @@ static void usage() {
 int main(int argc, char** argv) {
 	synth::Config config;
 	std::string out;
-	bool reference_only = false;
+	bool reference_only = false, rule_files = false;
 	std::string raw_bam_path;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -1061,6 +1128,7 @@ int main(int argc, char** argv) {
 		else if (a == "--gene-stack") config.gene_stack = atoi(value());
 		else if (a == "--itd-hotspots") config.itd_hotspots = atoi(value());
 		else if (a == "--homolog-families") config.homolog_families = atoi(value());
+		else if (a == "--rule-files") rule_files = true;
 		else if (a == "--itd-hotspot-frac") config.frac_itd_hotspot = atof(value());
 		else if (a == "--read-len") config.read_length = atoi(value());
 		else if (a == "--junctions") config.junctions = atoi(value());
@@ -1090,6 +1158,7 @@ int main(int argc, char** argv) {
 		} else {
 			generator.write_fasta(out + ".fa");
 			generator.write_gtf(out + ".gtf");
+			if (rule_files) generator.write_rule_files(out + ".blacklist.tsv", out + ".known_fusions.tsv");
 			if (!reference_only)
 				generator.write_bam(out + ".bam");
 		}

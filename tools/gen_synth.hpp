@@ -73,6 +73,7 @@ public:
 	void build_reference();                       // genome + genes + junction table
 	void write_fasta(const std::string& path) const;
 	void write_gtf(const std::string& path) const;
+	void write_rule_files(const std::string& blacklist_path, const std::string& known_fusions_path) const; // a blacklist and a known-fusions file derived from the junction table
 	void write_bam(const std::string& path);      // BGZF with stored (uncompressed) blocks, like STAR --outBAMcompression 0
 	void stream_bam(const ByteSink& sink);        // raw (un-BGZF'd) BAM stream for in-memory consumers
 	const std::vector<std::string>& contig_names() const { return contig_names_; }

@@ -36,4 +36,7 @@ for name, check in (('homologs8k_open', lambda s,p,g: parity.check_homologs(s,p,
 prefix=datasets.generate(datasets.DATASETS['toy3k'], tmp, 'toy3k_confidence')
 s,p=parity.run_read_level(parity.open_session,prefix,api=api)
 print('confidence', parity.check_confidence(s,p,conftest.golden_dir('toy3k')))
+prefix=datasets.generate(datasets.DATASETS['rules8k'], tmp, 'rules8k')
+s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+print('range rules', parity.check_range_rules(s,p,conftest.golden_dir('rules8k'),prefix))
 print('done')
