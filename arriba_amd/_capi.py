@@ -48,6 +48,12 @@ class RangeRule(ctypes.Structure):
     _fields_ = [("first", RangeItem), ("second", RangeItem)]
 
 
+class FusionTable(ctypes.Structure):
+    _fields_ = [("n_candidates", c_uint32), ("gene1", c_void_p), ("gene2", c_void_p), ("contigs", c_void_p), ("breakpoint1", c_void_p), ("breakpoint2", c_void_p), ("flags", c_void_p), ("filter", c_void_p),
+                ("split_reads1", c_void_p), ("split_reads2", c_void_p), ("discordant_mates", c_void_p), ("list_offset", c_void_p), ("read_lists", c_void_p), ("evalue", c_void_p), ("confidence", c_void_p),
+                ("iteration_rank", c_void_p), ("read_filter", c_void_p), ("n_genes", c_uint32), ("gene_contig", c_void_p), ("gene_start", c_void_p), ("gene_end", c_void_p)]
+
+
 class BatchView(ctypes.Structure):
     _fields_ = [("n", c_uint64), ("n_aln", POINTER(c_uint8)), ("fbits", POINTER(c_uint8)), ("group", POINTER(c_uint32)),
                 ("contig", POINTER(c_uint16) * 3), ("start", POINTER(c_int32) * 3), ("end", POINTER(c_int32) * 3), ("abits", POINTER(c_uint8) * 3),
@@ -187,6 +193,7 @@ def bind_host_api(lib):
         "ahost_mapped_reads": (c_uint64, [session]),
         "ahost_coverage_checksum": (c_uint64, [session]),
         "ahost_coverage_view": (POINTER(CoverageView), [session]),
+        "ahost_write_fusions": (c_int, [session, POINTER(FusionTable), c_char_p, c_int, c_int, c_uint32]),
         "ahost_load_range_rules": (c_int, [session, c_char_p, c_int, POINTER(POINTER(RangeRule)), POINTER(c_uint32)]),
         "ahost_contig_count": (c_uint32, [session]),
         "ahost_contig_name": (c_char_p, [session, c_uint32]),

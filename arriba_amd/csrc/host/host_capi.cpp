@@ -2,6 +2,7 @@
 // sequential scalar stages that sit between the device stages of the hot path.
 #include "../../../include/arriba_host.h"
 #include "arriba_host.h"
+#include "output.h"
 #include <cstdio>
 #include <cstring>
 
@@ -199,6 +200,20 @@ template <class Visit> void visit_ingest(IngestResult& r, Visit& visit) { // the
 extern "C" {
 
 const char* ahost_last_error(void) { return g_error.c_str(); }
+
+int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length) {
+	if (!session || !table || !path) { g_error = "null argument"; return -1; }
+	if (!session->have_batch) { g_error = "no BAM ingested yet"; return -1; }
+	try {
+		FusionTable t;
+		t.n_candidates = table->n_candidates; t.gene1 = table->gene1; t.gene2 = table->gene2; t.contigs = table->contigs; t.breakpoint1 = table->breakpoint1; t.breakpoint2 = table->breakpoint2;
+		t.flags = table->flags; t.filter = table->filter; t.split_reads1 = table->split_reads1; t.split_reads2 = table->split_reads2; t.discordant_mates = table->discordant_mates;
+		t.list_offset = table->list_offset; t.read_lists = table->read_lists; t.evalue = table->evalue; t.confidence = table->confidence; t.iteration_rank = table->iteration_rank;
+		t.read_filter = table->read_filter; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
+		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length);
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
 
 int ahost_load_range_rules(ahost_session* session, const char* path, int allow_keywords, const agpu_range_rule** rules, uint32_t* n_rules) {
 	if (!session || !path || !rules || !n_rules) { g_error = "null argument"; return -1; }

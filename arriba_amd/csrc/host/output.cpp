@@ -1,0 +1,265 @@
+// arriba_amd/csrc/host/output.cpp -- the output files (reference: source/output_fusions.cpp:468-710, :1043-1261): one line per candidate, the
+// surviving ones sorted by support with the events of one gene pair kept together, the discarded ones in the iteration order of the
+// reference's fusions_t (hazard H2; the rank comes from the device).  Runs on the host over the candidate table the device hands back:
+// string formatting of a few thousand (fusions.tsv) to a few hundred thousand (discarded.tsv) rows.
+#include "arriba_host.h"
+#include "output.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace arriba {
+
+namespace {
+
+const unsigned N_FILTER_NAMES = FILTER_COUNT; // FILTER_NAMES: arriba_host.h (source/common.hpp:29-67)
+
+struct Fusion { // one row, as the reference's fusion_t sees it
+	uint32_t candidate;
+	int gene1, gene2; contig_t contig1, contig2; position_t breakpoint1, breakpoint2;
+	bool upstream1, upstream2, exonic1, exonic2, spliced1, spliced2, predicted_strand1, predicted_strand2, strands_ambiguous, transcript_start_gene1;
+	unsigned split_reads1, split_reads2, discordant_mates; uint8_t filter, confidence; float evalue;
+	unsigned supporting_reads() const { return split_reads1 + split_reads2 + discordant_mates; }
+	bool is_read_through() const { return contig1 == contig2 && breakpoint2 - breakpoint1 < 400000 && !upstream1 && upstream2; } // source/common.hpp:265-269
+};
+
+// reference: sort_fusions_by_support (:468-484)
+bool more_support(const Fusion& x, const Fusion& y) {
+	if (x.confidence != y.confidence) return x.confidence > y.confidence;
+	if (x.supporting_reads() != y.supporting_reads()) return x.supporting_reads() > y.supporting_reads();
+	if (x.evalue != y.evalue) return x.evalue < y.evalue;
+	if (x.gene1 != y.gene1) return x.gene1 < y.gene1; // gene ids: deterministic order, events of one gene pair together
+	if (x.gene2 != y.gene2) return x.gene2 < y.gene2;
+	if (x.breakpoint1 != y.breakpoint1) return x.breakpoint1 < y.breakpoint1;
+	return x.breakpoint2 < y.breakpoint2;
+}
+
+struct Writer {
+	const Annotation& annotation; const Contigs& contigs; const Coverage& coverage; const FusionTable& table;
+	std::vector<GeneRecord> genes;  // GTF genes + the dummy genes of this sample
+	FlatIndex gene_index;           // over all of them (the reference regenerates its index after adding the dummy genes, source/arriba.cpp:262-263)
+	const FlatIndex& exon_index;
+
+	// reference: gene_to_name (:498-545)
+	std::string gene_to_name(int gene, contig_t contig, position_t breakpoint) const {
+		if (!genes[gene].is_dummy) return genes[gene].name;
+		std::string result;
+		if ((size_t) contig >= gene_index.n_contigs()) return ".";
+		const uint32_t begin = gene_index.contig_begin(contig), end = gene_index.contig_end(contig);
+		const uint32_t hit2 = gene_index.lower_bound(contig, breakpoint);
+		auto bucket_is_flanking = [&](uint32_t k) { // not empty, and its first gene (the lowest id) is not a dummy gene
+			return gene_index.member_offset[k] < gene_index.member_offset[k + 1] && !genes[gene_index.members[gene_index.member_offset[k]]].is_dummy;
+		};
+		int64_t up = (int64_t) hit2 - 1; // the reverse iterator starts in front of the hit
+		while (up >= (int64_t) begin && !bucket_is_flanking((uint32_t) up)) --up;
+		if (up >= (int64_t) begin)
+			for (uint32_t m = gene_index.member_offset[up]; m < gene_index.member_offset[up + 1]; ++m) {
+				const GeneRecord& flanking = genes[gene_index.members[m]];
+				if (flanking.is_dummy) continue;
+				if (!result.empty()) result += ",";
+				result += flanking.name + "(" + std::to_string((long long) (breakpoint - flanking.end)) + ")";
+			}
+		uint32_t down = hit2;
+		while (down < end && !bucket_is_flanking(down)) ++down;
+		if (down < end)
+			for (uint32_t m = gene_index.member_offset[down]; m < gene_index.member_offset[down + 1]; ++m) {
+				const GeneRecord& flanking = genes[gene_index.members[m]];
+				if (flanking.is_dummy) continue;
+				if (!result.empty()) result += ",";
+				result += flanking.name + "(" + std::to_string((long long) (flanking.start - breakpoint)) + ")";
+			}
+		return result.empty() ? "." : result;
+	}
+
+	// reference: get_fusion_type (:547-614)
+	std::string fusion_type(const Fusion& f, unsigned max_itd_length) const {
+		const GeneRecord& gene1 = genes[f.gene1]; const GeneRecord& gene2 = genes[f.gene2];
+		const bool any_dummy = gene1.is_dummy || gene2.is_dummy;
+		if (f.contig1 != f.contig2) {
+			if (any_dummy || (f.upstream1 == f.upstream2 && gene1.strand != gene2.strand) || (f.upstream1 != f.upstream2 && gene1.strand == gene2.strand)) return "translocation";
+			if (((f.upstream1 && gene1.strand) || (!f.upstream1 && !gene1.strand)) && ((f.upstream2 && gene2.strand) || (!f.upstream2 && !gene2.strand))) return "translocation/3'-3'";
+			return "translocation/5'-5'";
+		}
+		if (!f.upstream1 && f.upstream2) {
+			const std::string kind = f.is_read_through() ? "deletion/read-through" : "deletion";
+			if (any_dummy || gene1.strand == gene2.strand) return kind;
+			return kind + ((gene1.strand || !gene2.strand) ? "/5'-5'" : "/3'-3'");
+		}
+		if (f.upstream1 == f.upstream2) {
+			if (any_dummy || gene1.strand != gene2.strand) return "inversion";
+			return (f.upstream1 && !gene1.strand) ? "inversion/5'-5'" : "inversion/3'-3'";
+		}
+		// upstream / downstream
+		if (any_dummy || gene1.strand == gene2.strand) {
+			if (f.gene1 == f.gene2 && f.spliced1 && f.spliced2) return "duplication/non-canonical_splicing";
+			if (f.gene1 == f.gene2 && (unsigned) f.breakpoint2 - (unsigned) f.breakpoint1 < max_itd_length) return "duplication/ITD"; // is_internal_tandem_duplication (source/common.hpp:270-274); the directions are given here
+			return "duplication";
+		}
+		return !gene1.strand ? "duplication/5'-5'" : "duplication/3'-3'";
+	}
+
+	// reference: get_fusion_strand (:616-635)
+	std::string fusion_strand(bool strand, int gene, bool ambiguous) const {
+		std::string result = genes[gene].is_dummy ? "." : (genes[gene].strand ? "+" : "-");
+		result += "/";
+		result += ambiguous ? "." : (strand ? "+" : "-");
+		return result;
+	}
+
+	// reference: get_fusion_site (:637-709); the exons at the breakpoint are visited in the order of the reference's exon set (hazard H1)
+	std::string fusion_site(int gene, bool spliced, bool exonic, contig_t contig, position_t breakpoint) const {
+		const GeneRecord& record = genes[gene];
+		if (record.is_dummy || breakpoint < record.start || breakpoint > record.end) return "intergenic";
+		if (!exonic) return "intron";
+		std::vector<uint32_t> exons;
+		get_annotation_by_coordinate(contig, breakpoint, breakpoint, exons, exon_index);
+		bool has_overlapping_exon = false, is_utr = true;
+		unsigned is_3_end = 0, is_5_end = 0;
+		for (size_t e = 0; e < exons.size(); ++e) {
+			const ExonRecord& exon = annotation.exons[exons[e]];
+			if (exon.gene != gene) continue;
+			has_overlapping_exon = true;
+			if (exon.coding_region_start <= breakpoint && exon.coding_region_end >= breakpoint) is_utr = false;
+			if (!is_utr || !record.is_protein_coding) continue;
+			// 5' or 3' UTR: which comes first when walking away from the breakpoint, a coding exon or the end of the transcript?
+			if (exon.coding_region_start != -1 && exon.coding_region_start > breakpoint) { if (record.strand) ++is_5_end; else ++is_3_end; }
+			else if (exon.coding_region_end != -1 && exon.coding_region_end < breakpoint) { if (!record.strand) ++is_5_end; else ++is_3_end; }
+			else {
+				int next_exon = exon.next_exon;
+				while (next_exon != -1 && annotation.exons[next_exon].coding_region_start == -1) next_exon = annotation.exons[next_exon].next_exon;
+				int previous_exon = exon.previous_exon;
+				while (previous_exon != -1 && annotation.exons[previous_exon].coding_region_start == -1) previous_exon = annotation.exons[previous_exon].previous_exon;
+				if (previous_exon != -1 || next_exon != -1) { // the transcript has a coding region
+					if ((next_exon == -1) != !record.strand) ++is_3_end; else ++is_5_end;
+				}
+			}
+		}
+		std::string site;
+		if (!has_overlapping_exon) site = "intron";
+		else if (!record.is_protein_coding) site = "exon";
+		else if (!is_utr) site = "CDS";
+		else if (is_3_end > is_5_end) site = "3'UTR";
+		else if (is_3_end < is_5_end) site = "5'UTR";
+		else if (is_3_end + is_5_end == 0) site = "exon";
+		else site = "UTR";
+		if (spliced && site != "intron") site += "/splice-site";
+		return site;
+	}
+
+	Fusion row(uint32_t c) const {
+		Fusion f;
+		const uint32_t flags = table.flags[c];
+		f.candidate = c; f.gene1 = (int) table.gene1[c]; f.gene2 = (int) table.gene2[c]; f.contig1 = (contig_t) (table.contigs[c] >> 16); f.contig2 = (contig_t) (table.contigs[c] & 0xFFFF);
+		f.breakpoint1 = table.breakpoint1[c]; f.breakpoint2 = table.breakpoint2[c];
+		f.upstream1 = flags & AGPU_CFLAG_UPSTREAM1; f.upstream2 = flags & AGPU_CFLAG_UPSTREAM2; f.exonic1 = flags & AGPU_CFLAG_EXONIC1; f.exonic2 = flags & AGPU_CFLAG_EXONIC2;
+		f.spliced1 = flags & AGPU_CFLAG_SPLICED1; f.spliced2 = flags & AGPU_CFLAG_SPLICED2; f.predicted_strand1 = flags & AGPU_CFLAG_PREDICTED_STRAND1; f.predicted_strand2 = flags & AGPU_CFLAG_PREDICTED_STRAND2;
+		f.strands_ambiguous = flags & AGPU_CFLAG_PREDICTED_STRANDS_AMBIGUOUS; f.transcript_start_gene1 = flags & AGPU_CFLAG_TRANSCRIPT_START_GENE1;
+		f.split_reads1 = table.split_reads1[c]; f.split_reads2 = table.split_reads2[c]; f.discordant_mates = table.discordant_mates[c];
+		f.filter = table.filter[c]; f.confidence = table.confidence[c]; f.evalue = table.evalue[c];
+		return f;
+	}
+};
+
+std::string coverage_text(int coverage) { return coverage >= 0 ? std::to_string((long long) coverage) : "."; }
+
+}
+
+void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Coverage& coverage, const Batch* batch, const FusionTable& table,
+                           const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length) {
+	Writer writer = { annotation, contigs, coverage, table, std::vector<GeneRecord>(), FlatIndex(), exon_index };
+	// the gene records of this sample: the GTF genes, then the dummy genes the device cut from the unmapped positions
+	if (table.n_genes < annotation.real_genes) throw std::runtime_error("gene table smaller than the annotation");
+	writer.genes.assign(annotation.genes.begin(), annotation.genes.begin() + annotation.real_genes);
+	for (uint32_t g = (uint32_t) annotation.real_genes; g < table.n_genes; ++g) {
+		GeneRecord dummy;
+		dummy.contig = table.gene_contig[g]; dummy.start = table.gene_start[g]; dummy.end = table.gene_end[g]; dummy.strand = true; dummy.exonic_length = 10000; dummy.is_dummy = true; dummy.is_protein_coding = false;
+		writer.genes.push_back(dummy);
+	}
+	make_flat_index(writer.genes, std::max(writer.genes.size(), contigs.size()), writer.gene_index);
+
+	std::vector<Fusion> rows;
+	for (uint32_t c = 0; c < table.n_candidates; ++c)
+		if (write_discarded != (table.filter[c] == 0)) rows.push_back(writer.row(c));
+	if (write_discarded) {
+		// not sorted: the iteration order of fusions_t
+		std::sort(rows.begin(), rows.end(), [&](const Fusion& x, const Fusion& y) { return table.iteration_rank[x.candidate] < table.iteration_rank[y.candidate]; });
+	} else {
+		// events of one gene pair stay together, at the rank of the best of them (:1059-1074)
+		std::map<std::pair<int, int>, const Fusion*> best_of_pair;
+		for (size_t r = 0; r < rows.size(); ++r) {
+			const Fusion*& best = best_of_pair[std::make_pair(rows[r].gene1, rows[r].gene2)];
+			if (best == NULL || more_support(rows[r], *best)) best = &rows[r];
+		}
+		std::vector<const Fusion*> order(rows.size());
+		for (size_t r = 0; r < rows.size(); ++r) order[r] = &rows[r];
+		std::sort(order.begin(), order.end(), [&](const Fusion* x, const Fusion* y) {
+			const Fusion* best_x = best_of_pair.at(std::make_pair(x->gene1, x->gene2)); const Fusion* best_y = best_of_pair.at(std::make_pair(y->gene1, y->gene2));
+			return best_x != best_y ? more_support(*best_x, *best_y) : more_support(*x, *y);
+		});
+		std::vector<Fusion> sorted;
+		sorted.reserve(rows.size());
+		for (size_t r = 0; r < order.size(); ++r) sorted.push_back(*order[r]);
+		rows.swap(sorted);
+	}
+
+	FILE* out = fopen(path.c_str(), "w");
+	if (out == NULL) throw std::runtime_error("failed to open output file");
+	std::string text = "#gene1\tgene2\tstrand1(gene/fusion)\tstrand2(gene/fusion)\tbreakpoint1\tbreakpoint2\tsite1\tsite2\ttype\tsplit_reads1\tsplit_reads2\tdiscordant_mates\tcoverage1\tcoverage2\tconfidence\treading_frame\ttags\t"
+	                   "retained_protein_domains\tclosest_genomic_breakpoint1\tclosest_genomic_breakpoint2\tgene_id1\tgene_id2\ttranscript_id1\ttranscript_id2\tdirection1\tdirection2\tfilters\tfusion_transcript\tpeptide_sequence\tread_identifiers\n";
+	static const char* const confidence_names[] = { "low", "medium", "high", "high" };
+	for (size_t r = 0; r < rows.size(); ++r) {
+		const Fusion& f = rows[r];
+		std::string site_5 = writer.fusion_site(f.gene1, f.spliced1, f.exonic1, f.contig1, f.breakpoint1), site_3 = writer.fusion_site(f.gene2, f.spliced2, f.exonic2, f.contig2, f.breakpoint2);
+		// the 5' gene comes first
+		int gene_5 = f.gene1, gene_3 = f.gene2; contig_t contig_5 = f.contig1, contig_3 = f.contig2; position_t breakpoint_5 = f.breakpoint1, breakpoint_3 = f.breakpoint2;
+		bool upstream_5 = f.upstream1, upstream_3 = f.upstream2, strand_5 = f.predicted_strand1, strand_3 = f.predicted_strand2; unsigned split_reads_5 = f.split_reads1, split_reads_3 = f.split_reads2;
+		if (!f.transcript_start_gene1) {
+			std::swap(gene_5, gene_3); std::swap(contig_5, contig_3); std::swap(breakpoint_5, breakpoint_3); std::swap(upstream_5, upstream_3); std::swap(strand_5, strand_3);
+			std::swap(split_reads_5, split_reads_3); std::swap(site_5, site_3);
+		}
+		const int coverage_5 = coverage.get_coverage(contig_5, breakpoint_5, !upstream_5), coverage_3 = coverage.get_coverage(contig_3, breakpoint_3, !upstream_3);
+		std::string transcript_sequence = ".", peptide_sequence = ".", reading_frame = ".", transcript_id_5 = ".", transcript_id_3 = ".";
+		text += writer.gene_to_name(gene_5, contig_5, breakpoint_5) + "\t" + writer.gene_to_name(gene_3, contig_3, breakpoint_3) + "\t";
+		text += writer.fusion_strand(strand_5, gene_5, f.strands_ambiguous) + "\t" + writer.fusion_strand(strand_3, gene_3, f.strands_ambiguous) + "\t";
+		text += contigs.original_names[contig_5] + ":" + std::to_string(breakpoint_5 + 1) + "\t" + contigs.original_names[contig_3] + ":" + std::to_string(breakpoint_3 + 1) + "\t";
+		text += site_5 + "\t" + site_3 + "\t" + writer.fusion_type(f, max_itd_length) + "\t" + std::to_string(split_reads_5) + "\t" + std::to_string(split_reads_3) + "\t" + std::to_string(f.discordant_mates) + "\t";
+		text += coverage_text(coverage_5) + "\t" + coverage_text(coverage_3) + "\t" + confidence_names[f.confidence & 3] + "\t" + reading_frame;
+		text += "\t.\t.\t.\t."; // tags, retained protein domains, closest genomic breakpoints: no tags / domains / structural variants file
+		// reads discarded by a filter, by name of the filter
+		std::map<std::string, unsigned> filters;
+		if (f.filter != 0) filters[f.filter < N_FILTER_NAMES ? FILTER_NAMES[f.filter] : "?"] = 0;
+		const uint32_t list_begin = table.list_offset[3 * (size_t) f.candidate], list_end = table.list_offset[3 * (size_t) f.candidate + 3];
+		for (uint32_t k = list_begin; k < list_end; ++k) {
+			const uint8_t read_filter = table.read_filter[table.read_lists[k]];
+			if (read_filter != 0) filters[read_filter < N_FILTER_NAMES ? FILTER_NAMES[read_filter] : "?"]++;
+		}
+		text += "\t" + (writer.genes[gene_5].is_dummy ? std::string(".") : writer.genes[gene_5].gene_id) + "\t" + (writer.genes[gene_3].is_dummy ? std::string(".") : writer.genes[gene_3].gene_id);
+		text += "\t" + transcript_id_5 + "\t" + transcript_id_3;
+		text += std::string("\t") + (upstream_5 ? "upstream" : "downstream") + "\t" + (upstream_3 ? "upstream" : "downstream") + "\t";
+		if (filters.empty()) text += ".";
+		else
+			for (std::map<std::string, unsigned>::const_iterator filter = filters.begin(); filter != filters.end(); ++filter) {
+				if (filter != filters.begin()) text += ",";
+				text += filter->first;
+				if (filter->second != 0) text += "(" + std::to_string(filter->second) + ")";
+			}
+		text += "\t" + transcript_sequence + "\t" + peptide_sequence + "\t";
+		if (print_extra_info && list_end > list_begin && batch != NULL) {
+			for (uint32_t k = list_begin; k < list_end; ++k) {
+				if (k != list_begin) text += ",";
+				const std::string name = batch->name(table.read_lists[k]); // "QNAME,HI": the HI tag goes
+				text += name.substr(0, name.find_last_of(','));
+			}
+		} else text += ".";
+		text += "\n";
+		if (text.size() > (1u << 20)) { if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fclose(out); throw std::runtime_error("failed to write to file"); } text.clear(); }
+	}
+	const bool ok = fwrite(text.data(), 1, text.size(), out) == text.size();
+	if (fclose(out) != 0 || !ok) throw std::runtime_error("failed to write to file");
+}
+
+}

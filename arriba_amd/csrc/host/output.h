@@ -1,0 +1,24 @@
+// arriba_amd/csrc/host/output.h -- the candidate table as the output writer reads it (filled from the device's result getters)
+#ifndef ARRIBA_HOST_OUTPUT_H
+#define ARRIBA_HOST_OUTPUT_H 1
+
+#include "arriba_host.h"
+
+namespace arriba {
+
+struct FusionTable {
+	uint32_t n_candidates;
+	const uint32_t* gene1; const uint32_t* gene2; const uint32_t* contigs; const int32_t* breakpoint1; const int32_t* breakpoint2; const uint32_t* flags; const uint8_t* filter;
+	const uint32_t* split_reads1; const uint32_t* split_reads2; const uint32_t* discordant_mates;
+	const uint32_t* list_offset; const uint32_t* read_lists;
+	const float* evalue; const uint8_t* confidence; const uint32_t* iteration_rank;
+	const uint8_t* read_filter;
+	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end; // GTF genes + dummy genes (agpu_get_gene_table)
+};
+// reference: write_fusions_to_file (source/output_fusions.cpp:1043-1261)
+void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Coverage& coverage, const Batch* batch, const FusionTable& table,
+                           const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length);
+
+}
+
+#endif

@@ -341,6 +341,27 @@ class DevicePipeline(object):
         gap = int(self.scalars["max_mate_gap"] if max_mate_gap is None else max_mate_gap)
         return self._event_stage("recover_known_fusions", rules, count, gap)
 
+    def write_fusions(self, path, discarded=False, print_extra_info=None, max_itd_length=100):
+        """reference: write_fusions_to_file, source/output_fusions.cpp:1043-1261 (-o / -O); the device's results are fetched and formatted by the host library"""
+        table = self.candidates()
+        n = self.n_candidates
+        columns = {key: np.ascontiguousarray(table[key]) for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "list_offset", "read_lists")}
+        columns["evalue"] = np.ascontiguousarray(self.evalues(), dtype=np.float32)
+        columns["confidence"] = np.ascontiguousarray(self.assign_confidence())
+        columns["iteration_rank"] = np.ascontiguousarray(self.candidate_iteration_order(), dtype=np.uint32)
+        columns["read_filter"] = np.ascontiguousarray(self.filters(), dtype=np.uint8)
+        genes = self.gene_table()
+        columns["gene_contig"], columns["gene_start"], columns["gene_end"] = (np.ascontiguousarray(genes[key]) for key in ("contig", "start", "end"))
+        view = _capi.FusionTable()
+        view.n_candidates = n
+        view.n_genes = len(columns["gene_contig"])
+        for key, column in columns.items():
+            setattr(view, key, column.ctypes.data if column.size else None)
+        if print_extra_info is None:
+            print_extra_info = not discarded
+        if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length) != 0:
+            raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
+
     def assign_confidence(self):
         """reference: assign_confidence, source/filter_genomic_support.cpp:222-399; returns the confidence (0 low, 1 medium, 2 high) of every candidate"""
         confidence = np.zeros(max(self.n_candidates, 1), dtype=np.uint8)
@@ -398,6 +419,12 @@ class DevicePipeline(object):
             pointer = iteration_rank.ctypes.data
         self._check(self.api.estimate_expected_fusions(self.ctx, mapped_reads, pointer))
         self._record("estimate_expected_fusions")
+        evalue = np.zeros(max(self.n_candidates, 1), dtype=np.float32)
+        self._check(self.api.get_evalues(self.ctx, evalue.ctypes.data))
+        return evalue[:self.n_candidates]
+
+    def evalues(self):
+        """the e-value of every candidate (after estimate_expected_fusions)"""
         evalue = np.zeros(max(self.n_candidates, 1), dtype=np.float32)
         self._check(self.api.get_evalues(self.ctx, evalue.ctypes.data))
         return evalue[:self.n_candidates]

@@ -39,6 +39,23 @@ int ahost_load_ingest(ahost_session* session, const char* path);
  * valid until the next call with the same allow_keywords or ahost_close. */
 int ahost_load_range_rules(ahost_session* session, const char* path, int allow_keywords, const agpu_range_rule** rules, uint32_t* n_rules);
 
+/* The output files (write_fusions_to_file, source/output_fusions.cpp:1043-1261, called at source/arriba.cpp:604-610).  The candidate table is what the
+ * device hands back at the end of the workflow: agpu_get_candidates + agpu_get_candidate_read_lists, agpu_get_evalues, agpu_assign_confidence,
+ * agpu_candidate_iteration_order (the discarded candidates are written in the iteration order of the reference's fusions_t), agpu_get_filters
+ * (filter of every fragment) and agpu_get_gene_table (GTF genes + the dummy genes of the sample).  write_discarded = 0: the candidates that passed
+ * all filters, sorted by support; 1: the discarded ones.  print_extra_info: read identifiers (and, once built, transcript / peptide columns). */
+typedef struct {
+	uint32_t n_candidates;
+	const uint32_t* gene1; const uint32_t* gene2; const uint32_t* contigs; const int32_t* breakpoint1; const int32_t* breakpoint2; const uint32_t* flags; const uint8_t* filter;
+	const uint32_t* split_reads1; const uint32_t* split_reads2; const uint32_t* discordant_mates;
+	const uint32_t* list_offset;   /* [3 * n_candidates + 1] */
+	const uint32_t* read_lists;
+	const float* evalue; const uint8_t* confidence; const uint32_t* iteration_rank;
+	const uint8_t* read_filter;    /* [fragments of the session's batch] */
+	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end;
+} ahost_fusion_table;
+int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length);
+
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session);
 const agpu_genome_view* ahost_genome_view(ahost_session* session);
 const agpu_coverage_view* ahost_coverage_view(ahost_session* session);  /* coverage_t of the ingest for agpu_upload_coverage; NULL before an ingest */

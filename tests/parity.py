@@ -585,6 +585,30 @@ def check_chain_to_isoforms(session, pipeline, golden, rules_prefix=None):
     return counts + [selected, recovered], discarded, levels
 
 
+def check_output_files(session, pipeline, golden, directory, skip_columns=("reading_frame", "transcript_id1", "transcript_id2", "fusion_transcript", "peptide_sequence"), reference_prefix=None):
+    """After the chain: the two output files against the reference's (tests/golden/<name>/fusions.tsv.gz, discarded.tsv.gz): every line in the same
+    order; the columns named in skip_columns (the transcript assembly, not built) are not compared in fusions.tsv.  Returns (lines, discarded lines)."""
+    import gzip
+    results = []
+    for name, discarded in (("fusions.tsv", False), ("discarded.tsv", True)):
+        path = os.path.join(directory, name)
+        pipeline.write_fusions(path, discarded=discarded)
+        mine = open(path).read().split("\n")
+        source = reference_prefix + "." + name if reference_prefix else os.path.join(golden, name)  # a live run wrote <prefix>.fusions.tsv / <prefix>.discarded.tsv
+        expected = (open(source).read() if os.path.exists(source) else gzip.open(source + ".gz", "rt").read()).split("\n")
+        assert len(mine) == len(expected), (name, len(mine), len(expected))
+        header = expected[0].split("\t")
+        skipped = set() if discarded else {header.index(column) for column in skip_columns}
+        for number, (a, b) in enumerate(zip(mine, expected)):
+            if a == b:
+                continue
+            fields_a, fields_b = a.split("\t"), b.split("\t")
+            different = [header[k] for k in range(max(len(fields_a), len(fields_b))) if k not in skipped and (fields_a[k:k + 1] != fields_b[k:k + 1])]
+            assert not different, (name, number, different, a[:300], b[:300])
+        results.append(len(expected) - 2)
+    return tuple(results)
+
+
 def check_read_lists(session, pipeline, golden, stage):
     """the three read lists of every candidate against the reference's dump of `stage` (contents, or sizes for dumps written without lists)"""
     fusions = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))

@@ -355,3 +355,33 @@ def test_blacklist_and_known_fusions(built, dataset_files, tmp_path):
     session, pipeline = parity.run_read_level(parity.open_session, prefix)
     counts, reads_discarded, confidence_levels = parity.check_chain_to_isoforms(session, pipeline, dump, rules_prefix=prefix)
     assert counts[5] > counts[4] + 1000 and counts[11] < counts[10] - 100, counts  # known fusions recovered, candidates blacklisted
+
+
+def test_output_files_equal_the_reference(built, dataset_files, tmp_path):
+    """After the whole chain on the GPU: discarded.tsv byte for byte, fusions.tsv line by line in the reference's order (all columns but the transcript
+    assembly); golden datasets and a live run (tens of thousands of discarded candidates, dummy genes named by their flanking genes)"""
+    for name in ("toy3k", "rules8k"):
+        prefix = dataset_files(name)
+        session, pipeline = parity.run_read_level(parity.open_session, prefix)
+        parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name), rules_prefix=prefix if name == "rules8k" else None)
+        os.makedirs(str(tmp_path / name))
+        fusions, discarded = parity.check_output_files(session, pipeline, conftest.golden_dir(name), str(tmp_path / name))
+        assert fusions > 40 and discarded > 1500
+    if not datasets.reference_available():
+        return
+    spec = {"args": ["--seed", "53", "--fragments", "120000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    os.environ["ARRIBA_ORACLE_DUMP_LISTS"] = "0"
+    try:
+        log = datasets.run_reference(prefix, dump)
+    finally:
+        del os.environ["ARRIBA_ORACLE_DUMP_LISTS"]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix)
+    parity.check_chain_to_isoforms(session, pipeline, dump)
+    os.makedirs(str(tmp_path / "mine"))
+    fusions, discarded = parity.check_output_files(session, pipeline, dump, str(tmp_path / "mine"), reference_prefix=prefix)
+    assert fusions > 100 and discarded > 30000

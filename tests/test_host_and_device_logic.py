@@ -263,6 +263,17 @@ def test_blacklist_and_known_fusions(dataset_files, emu_api):
         pipeline.load_range_rules(prefix + ".no_such_file.tsv", True)
 
 
+@pytest.mark.parametrize("name", ["toy3k", "rules8k"])
+def test_output_files_equal_the_reference(name, dataset_files, emu_api, tmp_path):
+    """After the whole chain: discarded.tsv byte for byte (thousands of lines in the iteration order of fusions_t), fusions.tsv line by line in the
+    reference's sort order, every column except the transcript assembly (reading frame, transcript ids, fusion transcript, peptide)"""
+    prefix = dataset_files(name)
+    session, pipeline = parity.run_read_level(parity.open_session, prefix, api=emu_api)
+    parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name), rules_prefix=prefix if name == "rules8k" else None)
+    fusions, discarded = parity.check_output_files(session, pipeline, conftest.golden_dir(name), str(tmp_path))
+    assert fusions > 40 and discarded > 1500
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
