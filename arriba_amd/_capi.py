@@ -228,5 +228,5 @@ def device_library():
 def host_library():
     global _host_lib
     if _host_lib is None:
-        _host_lib = bind_host_api(_load(os.path.join(LIB_DIR, "libarriba_host.so")))
+        _host_lib = bind_host_api(_load(os.environ.get("ARRIBA_HOST_LIBRARY", os.path.join(LIB_DIR, "libarriba_host.so"))))  # the override: a sanitizer build (tools/)
     return _host_lib

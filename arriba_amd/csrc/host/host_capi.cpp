@@ -210,7 +210,7 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 		t.flags = table->flags; t.filter = table->filter; t.split_reads1 = table->split_reads1; t.split_reads2 = table->split_reads2; t.discordant_mates = table->discordant_mates;
 		t.list_offset = table->list_offset; t.read_lists = table->read_lists; t.evalue = table->evalue; t.confidence = table->confidence; t.iteration_rank = table->iteration_rank;
 		t.read_filter = table->read_filter; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
-		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length);
+		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length);
 		return 0;
 	} catch (const std::exception& e) { g_error = e.what(); return -1; }
 }

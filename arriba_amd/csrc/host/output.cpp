@@ -4,6 +4,7 @@
 // string formatting of a few thousand (fusions.tsv) to a few hundred thousand (discarded.tsv) rows.
 #include "arriba_host.h"
 #include "output.h"
+#include "transcript.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -22,6 +23,7 @@ struct Fusion { // one row, as the reference's fusion_t sees it
 	uint32_t candidate;
 	int gene1, gene2; contig_t contig1, contig2; position_t breakpoint1, breakpoint2;
 	bool upstream1, upstream2, exonic1, exonic2, spliced1, spliced2, predicted_strand1, predicted_strand2, strands_ambiguous, transcript_start_gene1;
+	bool transcript_start_ambiguous;
 	unsigned split_reads1, split_reads2, discordant_mates; uint8_t filter, confidence; float evalue;
 	unsigned supporting_reads() const { return split_reads1 + split_reads2 + discordant_mates; }
 	bool is_read_through() const { return contig1 == contig2 && breakpoint2 - breakpoint1 < 400000 && !upstream1 && upstream2; } // source/common.hpp:265-269
@@ -157,7 +159,7 @@ struct Writer {
 		f.breakpoint1 = table.breakpoint1[c]; f.breakpoint2 = table.breakpoint2[c];
 		f.upstream1 = flags & AGPU_CFLAG_UPSTREAM1; f.upstream2 = flags & AGPU_CFLAG_UPSTREAM2; f.exonic1 = flags & AGPU_CFLAG_EXONIC1; f.exonic2 = flags & AGPU_CFLAG_EXONIC2;
 		f.spliced1 = flags & AGPU_CFLAG_SPLICED1; f.spliced2 = flags & AGPU_CFLAG_SPLICED2; f.predicted_strand1 = flags & AGPU_CFLAG_PREDICTED_STRAND1; f.predicted_strand2 = flags & AGPU_CFLAG_PREDICTED_STRAND2;
-		f.strands_ambiguous = flags & AGPU_CFLAG_PREDICTED_STRANDS_AMBIGUOUS; f.transcript_start_gene1 = flags & AGPU_CFLAG_TRANSCRIPT_START_GENE1;
+		f.strands_ambiguous = flags & AGPU_CFLAG_PREDICTED_STRANDS_AMBIGUOUS; f.transcript_start_gene1 = flags & AGPU_CFLAG_TRANSCRIPT_START_GENE1; f.transcript_start_ambiguous = flags & AGPU_CFLAG_TRANSCRIPT_START_AMBIGUOUS;
 		f.split_reads1 = table.split_reads1[c]; f.split_reads2 = table.split_reads2[c]; f.discordant_mates = table.discordant_mates[c];
 		f.filter = table.filter[c]; f.confidence = table.confidence[c]; f.evalue = table.evalue[c];
 		return f;
@@ -168,7 +170,7 @@ std::string coverage_text(int coverage) { return coverage >= 0 ? std::to_string(
 
 }
 
-void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Coverage& coverage, const Batch* batch, const FusionTable& table,
+void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Assembly& assembly, const Coverage& coverage, const Batch* batch, const FusionTable& table,
                            const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length) {
 	Writer writer = { annotation, contigs, coverage, table, std::vector<GeneRecord>(), FlatIndex(), exon_index };
 	// the gene records of this sample: the GTF genes, then the dummy genes the device cut from the unmapped positions
@@ -223,6 +225,38 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		}
 		const int coverage_5 = coverage.get_coverage(contig_5, breakpoint_5, !upstream_5), coverage_3 = coverage.get_coverage(contig_3, breakpoint_3, !upstream_3);
 		std::string transcript_sequence = ".", peptide_sequence = ".", reading_frame = ".", transcript_id_5 = ".", transcript_id_3 = ".";
+		if (print_extra_info && batch != NULL) {
+			// the fusion transcript from the pileups of the supporting reads, then the pair of annotated transcripts that gives an in-frame peptide (:1118-1154)
+			const TranscriptInput input = { *batch, table.read_filter, assembly, annotation, exon_index };
+			const uint32_t* offsets = table.list_offset + 3 * (size_t) f.candidate;
+			FusionEvent event;
+			event.contig_of_gene1 = writer.genes[f.gene1].contig; event.contig_of_gene2 = writer.genes[f.gene2].contig; event.breakpoint1 = f.breakpoint1; event.breakpoint2 = f.breakpoint2;
+			event.upstream1 = f.upstream1; event.upstream2 = f.upstream2; event.predicted_strand1 = f.predicted_strand1; event.predicted_strand2 = f.predicted_strand2; event.strands_ambiguous = f.strands_ambiguous;
+			event.transcript_start_gene1 = f.transcript_start_gene1; event.transcript_start_ambiguous = f.transcript_start_ambiguous;
+			event.split_read1_list = table.read_lists + offsets[0]; event.split_read2_list = table.read_lists + offsets[1]; event.discordant_mate_list = table.read_lists + offsets[2];
+			event.n_split_reads1 = offsets[1] - offsets[0]; event.n_split_reads2 = offsets[2] - offsets[1]; event.n_discordant_mates = offsets[3] - offsets[2];
+			std::vector<position_t> positions;
+			fusion_transcript_sequence(input, event, transcript_sequence, positions);
+			std::vector<int> transcripts_5, transcripts_3;
+			best_fitting_transcripts(input, transcript_sequence, positions, gene_5, writer.genes[gene_5].is_dummy, writer.genes[gene_5].contig, writer.genes[gene_5].strand, strand_5, f.strands_ambiguous, 5, transcripts_5);
+			best_fitting_transcripts(input, transcript_sequence, positions, gene_3, writer.genes[gene_3].is_dummy, writer.genes[gene_3].contig, writer.genes[gene_3].strand, strand_3, f.strands_ambiguous, 3, transcripts_3);
+			const PeptideGenes peptide_genes = { writer.genes[gene_5].contig, writer.genes[gene_3].contig, writer.genes[gene_5].strand, writer.genes[gene_3].strand, writer.genes[gene_5].is_dummy, writer.genes[gene_3].is_dummy, strand_3 };
+			int transcript_5 = -1, transcript_3 = -1;
+			// every combination until one is in-frame; without candidates on one side the loop body still runs once with no transcript on that side
+			for (size_t i5 = 0; (transcripts_5.empty() || i5 != transcripts_5.size()) && reading_frame != "in-frame"; ++i5) {
+				if (i5 != transcripts_5.size()) transcript_5 = transcripts_5[i5];
+				for (size_t i3 = 0; (transcripts_3.empty() || i3 != transcripts_3.size()) && reading_frame != "in-frame"; ++i3) {
+					if (i3 != transcripts_3.size()) transcript_3 = transcripts_3[i3];
+					peptide_sequence = fusion_peptide_sequence(input, transcript_sequence, positions, peptide_genes, transcript_5, transcript_3);
+					reading_frame = reading_frame_verdict(peptide_sequence);
+					if (i3 == transcripts_3.size()) break;
+				}
+				if (i5 == transcripts_5.size() || transcripts_3.empty()) break;
+			}
+			if (reading_frame == "stop-codon") peptide_sequence = "."; // a stop codon in front of the junction: no peptide
+			if (transcript_5 != -1) transcript_id_5 = annotation.transcripts[transcript_5].name;
+			if (transcript_3 != -1) transcript_id_3 = annotation.transcripts[transcript_3].name;
+		}
 		text += writer.gene_to_name(gene_5, contig_5, breakpoint_5) + "\t" + writer.gene_to_name(gene_3, contig_3, breakpoint_3) + "\t";
 		text += writer.fusion_strand(strand_5, gene_5, f.strands_ambiguous) + "\t" + writer.fusion_strand(strand_3, gene_3, f.strands_ambiguous) + "\t";
 		text += contigs.original_names[contig_5] + ":" + std::to_string(breakpoint_5 + 1) + "\t" + contigs.original_names[contig_3] + ":" + std::to_string(breakpoint_3 + 1) + "\t";

@@ -16,7 +16,7 @@ struct FusionTable {
 	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end; // GTF genes + dummy genes (agpu_get_gene_table)
 };
 // reference: write_fusions_to_file (source/output_fusions.cpp:1043-1261)
-void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Coverage& coverage, const Batch* batch, const FusionTable& table,
+void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Assembly& assembly, const Coverage& coverage, const Batch* batch, const FusionTable& table,
                            const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length);
 
 }

@@ -358,8 +358,8 @@ def test_blacklist_and_known_fusions(built, dataset_files, tmp_path):
 
 
 def test_output_files_equal_the_reference(built, dataset_files, tmp_path):
-    """After the whole chain on the GPU: discarded.tsv byte for byte, fusions.tsv line by line in the reference's order (all columns but the transcript
-    assembly); golden datasets and a live run (tens of thousands of discarded candidates, dummy genes named by their flanking genes)"""
+    """After the whole chain on the GPU both output files equal the reference's byte for byte (fusions.tsv with the fusion transcript assembled from
+    the read pileups, best transcripts, peptide and reading frame); golden datasets and a live run (tens of thousands of discarded candidates)"""
     for name in ("toy3k", "rules8k"):
         prefix = dataset_files(name)
         session, pipeline = parity.run_read_level(parity.open_session, prefix)

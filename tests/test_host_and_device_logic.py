@@ -265,8 +265,8 @@ def test_blacklist_and_known_fusions(dataset_files, emu_api):
 
 @pytest.mark.parametrize("name", ["toy3k", "rules8k"])
 def test_output_files_equal_the_reference(name, dataset_files, emu_api, tmp_path):
-    """After the whole chain: discarded.tsv byte for byte (thousands of lines in the iteration order of fusions_t), fusions.tsv line by line in the
-    reference's sort order, every column except the transcript assembly (reading frame, transcript ids, fusion transcript, peptide)"""
+    """After the whole chain both output files equal the reference's byte for byte: discarded.tsv (thousands of lines in the iteration order of
+    fusions_t) and fusions.tsv (the reference's sort order; fusion transcript from the read pileups, best transcripts, peptide, reading frame)"""
     prefix = dataset_files(name)
     session, pipeline = parity.run_read_level(parity.open_session, prefix, api=emu_api)
     parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name), rules_prefix=prefix if name == "rules8k" else None)

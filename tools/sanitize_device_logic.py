@@ -39,4 +39,10 @@ print('confidence', parity.check_confidence(s,p,conftest.golden_dir('toy3k')))
 prefix=datasets.generate(datasets.DATASETS['rules8k'], tmp, 'rules8k')
 s,p=parity.run_read_level(parity.open_session,prefix,api=api)
 print('range rules', parity.check_range_rules(s,p,conftest.golden_dir('rules8k'),prefix))
+for name in ('toy3k', 'rules8k'):  # the whole chain and the output writer (host library built with the sanitizers, too)
+    prefix=datasets.generate(datasets.DATASETS[name], tmp, name+'_out')
+    s,p=parity.run_read_level(parity.open_session,prefix,api=api)
+    parity.check_chain_to_isoforms(s,p,conftest.golden_dir(name),rules_prefix=prefix if name=='rules8k' else None)
+    os.makedirs(os.path.join(tmp,name+'_files'))
+    print('output files', name, parity.check_output_files(s,p,conftest.golden_dir(name),os.path.join(tmp,name+'_files')))
 print('done')

@@ -4,7 +4,8 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 WORK=$(mktemp -d /tmp/sanitize_emu_XXXXXX)
 (cd $ROOT/tests/emu && g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-parentheses -Wno-sign-compare -o $WORK/libemu_asan.so emu.cpp)
-ARRIBA_EMU_LIBRARY=$WORK/libemu_asan.so LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
+(cd $ROOT/arriba_amd/csrc && g++ -std=c++17 -O1 -g -fPIC -shared -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-parentheses -Wno-sign-compare -o $WORK/libhost_asan.so host/*.cpp -lz)
+ARRIBA_HOST_LIBRARY=$WORK/libhost_asan.so ARRIBA_EMU_LIBRARY=$WORK/libemu_asan.so LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
 	python $ROOT/tools/sanitize_device_logic.py 2>&1 | tee $WORK/log | grep -v "SAM records\|not enough chimeric reads"
 echo "sanitizer reports: $(grep -c 'runtime error\|AddressSanitizer' $WORK/log || true)"
 rm -rf $WORK
