@@ -235,6 +235,44 @@ class DevicePipeline(object):
         self.estimate_fragment_length()
         return self.filter_reads()
 
+    def run_workflow(self, output_file, discarded_output_file=None, blacklist_file=None, known_fusions_file=None, strandedness=None, evalue_cutoff=0.3,
+                     min_itd_support=10, min_itd_allele_fraction=0.07, high_expression_quantile=0.998, min_spliced_events=4, min_anchor_length=23,
+                     max_homolog_identity=0.3, max_itd_length=100, log=None):
+        """The reference's main() behind read_chimeric_alignments (source/arriba.cpp:119-610) with its default parameters: the read-level cascade, find_fusions,
+        every candidate-level filter in the reference's order, assign_confidence, and the two output files.  `log` receives (stage, remaining) pairs --
+        the numbers the reference prints as "(remaining=N)".  Filters switched off with -f are skipped by the stages themselves (agpu_params.filter_enabled)."""
+        note = log if log is not None else (lambda stage, remaining: None)
+        self.run_read_level(strandedness)
+        note("find_fusions", self.find_fusions())
+        self.upload_coverage()
+        note("merge_adjacent_fusions", self.merge_adjacent_fusions())
+        note("filter_multimappers", self.filter_multimappers()[0])
+        self.estimate_expected_fusions()
+        self.filter_candidate_predicates()
+        note("filter_relative_support", self.filter_relative_support())
+        note("recover_internal_tandem_duplication", self.recover_internal_tandem_duplication(min_itd_support, min_itd_allele_fraction))
+        note("filter_both_intronic", self.filter_both_intronic())
+        if known_fusions_file:
+            note("recover_known_fusions", self.recover_known_fusions(known_fusions_file))
+        note("filter_in_vitro", self.filter_in_vitro(high_expression_quantile))
+        note("recover_both_spliced", self.recover_both_spliced())
+        note("select_most_supported_breakpoints", self.select_most_supported_breakpoints())
+        note("filter_marginal_read_through", self.filter_marginal_read_through())
+        note("recover_many_spliced", self.recover_many_spliced(min_spliced_events))
+        if blacklist_file:
+            note("filter_blacklisted_ranges", self.filter_blacklisted_ranges(blacklist_file, evalue_cutoff))
+        note("filter_short_anchor", self.filter_short_anchor(min_anchor_length))
+        note("filter_end_to_end", self.filter_end_to_end())
+        note("filter_no_coverage", self.filter_no_coverage())
+        self.make_kmer_index()
+        note("filter_homologs", self.filter_homologs(max_homolog_identity))
+        note("filter_mismappers", self.filter_mismappers()[0])
+        note("select_most_supported_breakpoints", self.select_most_supported_breakpoints())
+        note("recover_isoforms", self.recover_isoforms())
+        self.write_fusions(output_file, discarded=False, max_itd_length=max_itd_length)
+        if discarded_output_file:
+            self.write_fusions(discarded_output_file, discarded=True, max_itd_length=max_itd_length)
+
     def find_fusions(self, max_mate_gap=None):
         """reference: find_fusions, source/fusions.cpp:203-473; returns the number of candidates"""
         if max_mate_gap is None:

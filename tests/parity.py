@@ -610,6 +610,39 @@ def check_output_files(session, pipeline, golden, directory, skip_columns=(), re
     return tuple(results)
 
 
+def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None):
+    """FASTA + GTF + BAM (+ blacklist / known fusions) -> fusions.tsv, discarded.tsv through DevicePipeline.run_workflow with the reference's default
+    parameters: nothing is taken from the reference, not even the parameters its log prints.  Both files must equal the reference's byte for byte, and
+    every "(remaining=N)" of its log must come out."""
+    import gzip
+    from arriba_amd.pipeline import DevicePipeline
+    session = open_session(prefix)
+    pipeline = DevicePipeline(session, api=api)
+    stages = []
+    outputs = [os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv")]
+    pipeline.run_workflow(outputs[0], outputs[1], blacklist_file=prefix + ".blacklist.tsv" if rules else None, known_fusions_file=prefix + ".known_fusions.tsv" if rules else None,
+                          log=lambda stage, remaining: stages.append((stage, remaining)))
+    for mine, name in zip(outputs, ("fusions.tsv", "discarded.tsv")):
+        source = reference_prefix + "." + name if reference_prefix else os.path.join(golden, name)
+        expected = open(source).read() if os.path.exists(source) else gzip.open(source + ".gz", "rt").read()
+        assert open(mine).read() == expected, name
+    log = open(os.path.join(golden, "reference.log")).read()
+    patterns = {"merge_adjacent_fusions": "Merging adjacent fusion breakpoints", "filter_multimappers": "Filtering multi-mapping fusions", "filter_relative_support": "Filtering fusions with an e-value",
+                "recover_internal_tandem_duplication": "Searching for internal tandem duplications", "filter_both_intronic": "Filtering fusions with both breakpoints in intronic", "recover_known_fusions": "Searching for known fusions",
+                "filter_in_vitro": "Filtering in vitro-generated fusions", "recover_both_spliced": "Searching for fusions with spliced split reads", "filter_marginal_read_through": "Filtering read-through fusions with breakpoints near",
+                "recover_many_spliced": "Searching for fusions with >=\\d+ spliced events", "filter_blacklisted_ranges": "Filtering blacklisted fusions", "filter_short_anchor": "Filtering fusions with anchors",
+                "filter_end_to_end": "Filtering end-to-end fusions", "filter_no_coverage": "Filtering fusions with no coverage", "filter_homologs": "Filtering genes with", "filter_mismappers": "Re-aligning chimeric reads",
+                "recover_isoforms": "Searching for additional isoforms"}
+    seen_select_best = 0
+    for stage, remaining in stages:
+        if stage == "select_most_supported_breakpoints":
+            assert remaining == logged_remaining(log, "Selecting best breakpoints", seen_select_best), (stage, remaining)
+            seen_select_best += 1
+        elif stage in patterns:
+            assert remaining == logged_remaining(log, patterns[stage]), (stage, remaining, logged_remaining(log, patterns[stage]))
+    return stages
+
+
 def check_read_lists(session, pipeline, golden, stage):
     """the three read lists of every candidate against the reference's dump of `stage` (contents, or sizes for dumps written without lists)"""
     fusions = golden_io.read_fusions(golden_io.find_dump(golden, "fusions", stage))

@@ -385,3 +385,31 @@ def test_output_files_equal_the_reference(built, dataset_files, tmp_path):
     os.makedirs(str(tmp_path / "mine"))
     fusions, discarded = parity.check_output_files(session, pipeline, dump, str(tmp_path / "mine"), reference_prefix=prefix)
     assert fusions > 100 and discarded > 30000
+
+
+def test_workflow_from_input_files_to_output_files(built, dataset_files, tmp_path):
+    """FASTA + GTF + BAM (+ blacklist and known fusions) -> fusions.tsv + discarded.tsv on the GPU through DevicePipeline.run_workflow with the reference's
+    default parameters, nothing taken from the reference: both files byte-identical to the reference's (golden datasets; a live run of 150 k fragments)"""
+    for name in ("toy3k", "rules8k", "homologs8k"):
+        os.makedirs(str(tmp_path / name))
+        stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path / name), rules=name == "rules8k")
+        assert stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
+    if not datasets.reference_available():
+        return
+    spec = {"args": ["--seed", "59", "--fragments", "150000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15", "--rule-files", "--homolog-families", "20",
+                     "--itd-hotspots", "3", "--itd-hotspot-frac", "0.02"], "rule_files": True}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    switches = {"ARRIBA_ORACLE_DUMP_LISTS": "0", "ARRIBA_ORACLE_DUMP_READS": "0", "ARRIBA_ORACLE_DUMP_STAGES": "key"}
+    os.environ.update(switches)
+    try:
+        log = datasets.run_reference(prefix, dump, spec)
+    finally:
+        for key in switches:
+            del os.environ[key]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), rules=True, reference_prefix=prefix)
+    assert stages[-1][1] > 300

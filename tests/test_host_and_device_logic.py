@@ -274,6 +274,14 @@ def test_output_files_equal_the_reference(name, dataset_files, emu_api, tmp_path
     assert fusions > 40 and discarded > 1500
 
 
+@pytest.mark.parametrize("name", ["toy3k", "rules8k"])
+def test_workflow_from_input_files_to_output_files(name, dataset_files, emu_api, tmp_path):
+    """FASTA + GTF + BAM (+ blacklist and known fusions) -> fusions.tsv + discarded.tsv through DevicePipeline.run_workflow with the reference's default
+    parameters and nothing taken from the reference: both files byte-identical, every "(remaining=N)" of the reference's log reproduced"""
+    stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path), api=emu_api, rules=name == "rules8k")
+    assert len(stages) >= 18 and stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
