@@ -89,6 +89,12 @@ struct Annotation {
 // reference: source/annotation.cpp:161-377
 // blacklist (keywords allowed in the second column) or known-fusions file -> rules; reference: source/filter_blacklisted_ranges.cpp:17-118, :244-264
 void load_range_rules(const std::string& path, const Contigs& contigs, const Annotation& annotation, bool allow_keyword_in_second_column, std::vector<agpu_range_rule>& rules);
+// tags (-t; reference: source/annotate_tags.cpp:11-44): lines of two items (no keywords) and a tag, looked up through 100 kb genome bins
+struct TagRule { agpu_range_item first, second; std::string tag; };
+struct Tags { std::vector<TagRule> rules; std::map<uint64_t, std::vector<uint32_t> > by_bin; bool empty() const { return by_bin.empty(); } };
+void load_tags(const std::string& path, const Contigs& contigs, const Annotation& annotation, Tags& tags);
+// protein domains (-p; reference: source/annotate_protein_domains.cpp:33-121): GFF3 records mapped to genes by id or name, indexed like the exons
+struct ProteinDomain { contig_t contig; position_t start, end; bool strand; int gene; std::string name; };
 void read_annotation_gtf(Annotation& annotation, const std::string& gtf_path, const std::string& gtf_features, Contigs& contigs, const Assembly& assembly);
 
 // Flattened interval index (reference: source/annotation.t.hpp:25-45): per contig a sorted array of
@@ -108,6 +114,8 @@ struct FlatIndex {
 template <class Feature> void make_flat_index(const std::vector<Feature>& features, size_t n_contigs, FlatIndex& index);
 // reference: source/arriba.cpp:166-184
 void compute_exonic_length(Annotation& annotation, const FlatIndex& exon_index);
+
+void load_protein_domains(const std::string& path, const Contigs& contigs, const Annotation& annotation, std::vector<ProteinDomain>& domains, FlatIndex& index);
 
 // host-side queries on the flat index (used by ingest and by host-only stages)
 void get_annotation_by_coordinate(contig_t contig, position_t start, position_t end, std::vector<uint32_t>& result, const FlatIndex& index); // reference: source/annotation.t.hpp:55-101

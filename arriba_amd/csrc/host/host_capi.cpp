@@ -33,6 +33,7 @@ struct ahost_session {
 	FlatIndex exon_index, gene_index;
 	IngestResult ingest;
 	bool have_batch = false;
+	Tags tags; std::vector<ProteinDomain> protein_domains; FlatIndex protein_domain_index;
 	std::vector<agpu_range_rule> range_rules[2]; // [0] known fusions, [1] blacklist (keywords allowed)
 
 	// flattened tables backing the views
@@ -201,7 +202,18 @@ extern "C" {
 
 const char* ahost_last_error(void) { return g_error.c_str(); }
 
-int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length) {
+int ahost_load_tags(ahost_session* session, const char* path) {
+	if (!session || !path) { g_error = "null argument"; return -1; }
+	try { load_tags(path, session->contigs, session->annotation, session->tags); return 0; }
+	catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+int ahost_load_protein_domains(ahost_session* session, const char* path) {
+	if (!session || !path) { g_error = "null argument"; return -1; }
+	try { load_protein_domains(path, session->contigs, session->annotation, session->protein_domains, session->protein_domain_index); return 0; }
+	catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+
+int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap) {
 	if (!session || !table || !path) { g_error = "null argument"; return -1; }
 	if (!session->have_batch) { g_error = "no BAM ingested yet"; return -1; }
 	try {
@@ -210,7 +222,8 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 		t.flags = table->flags; t.filter = table->filter; t.split_reads1 = table->split_reads1; t.split_reads2 = table->split_reads2; t.discordant_mates = table->discordant_mates;
 		t.list_offset = table->list_offset; t.read_lists = table->read_lists; t.evalue = table->evalue; t.confidence = table->confidence; t.iteration_rank = table->iteration_rank;
 		t.read_filter = table->read_filter; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
-		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length);
+		const OutputExtras extras = { &session->tags, &session->protein_domains, &session->protein_domain_index, max_mate_gap };
+		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
 		return 0;
 	} catch (const std::exception& e) { g_error = e.what(); return -1; }
 }

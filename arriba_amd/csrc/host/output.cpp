@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <unordered_map>
 
@@ -152,6 +153,71 @@ struct Writer {
 		return site;
 	}
 
+	// reference: matches_blacklist_item (source/filter_blacklisted_ranges.cpp:136-218) for the items a tags file can hold (gene, position, range)
+	bool matches_item(const agpu_range_item& item, const Fusion& f, int which_breakpoint, int max_mate_gap) const {
+		const int gene = which_breakpoint == 1 ? f.gene1 : f.gene2;
+		if (item.type == AGPU_RULE_GENE) return gene == (int) item.gene;
+		if (item.type != AGPU_RULE_POSITION && item.type != AGPU_RULE_RANGE) return false;
+		if ((which_breakpoint == 1 ? f.contig1 : f.contig2) != item.contig) return false;
+		if (item.strand_defined && !f.strands_ambiguous && (which_breakpoint == 1 ? f.predicted_strand1 : f.predicted_strand2) != (item.strand != 0)) return false;
+		if (item.type == AGPU_RULE_RANGE) { // the gene of the breakpoint overlaps the range by more than half (overlapping_fraction, :121-133)
+			const position_t start1 = genes[gene].start, end1 = genes[gene].end, start2 = item.start, end2 = item.end;
+			float fraction = 0;
+			if (start1 >= start2 && end1 <= end2) fraction = 1;
+			else if (start1 < start2 && end1 > end2) fraction = 1.0 * (end2 - start2) / (end1 - start1 + 1);
+			else if (start1 >= start2 && start1 <= end2) fraction = 1.0 * (end2 - start1) / (end1 - start1 + 1);
+			else if (end1 >= start2 && end1 <= end2) fraction = 1.0 * (end1 - start2) / (end1 - start1 + 1);
+			return fraction > 0.5;
+		}
+		const position_t breakpoint = which_breakpoint == 1 ? f.breakpoint1 : f.breakpoint2;
+		if (breakpoint == item.start) return true;
+		if (f.split_reads1 + f.split_reads2 == 0) { // discordant mates near the position and pointing towards it
+			const bool upstream = which_breakpoint == 1 ? f.upstream1 : f.upstream2;
+			if ((!upstream && breakpoint <= item.start && breakpoint >= item.start - max_mate_gap) || (upstream && breakpoint >= item.start && breakpoint <= item.start + max_mate_gap)) return true;
+		}
+		return false;
+	}
+	// reference: annotate_tags (source/annotate_tags.cpp:46-84)
+	std::string tags_of(const Fusion& f, const Tags& tags, int max_mate_gap) const {
+		const contig_t contig_of[4] = { f.contig1, f.contig2, f.contig1, f.contig2 };
+		const position_t start_of[4] = { f.breakpoint1, f.breakpoint2, genes[f.gene1].start, genes[f.gene2].start }, end_of[4] = { f.breakpoint1, f.breakpoint2, genes[f.gene1].end, genes[f.gene2].end };
+		const int gene_5 = f.transcript_start_gene1 ? 1 : 2, gene_3 = 3 - gene_5;
+		std::set<std::string> matching;
+		for (int range = 0; range < 4; ++range)
+			for (position_t bin = start_of[range] / 100000; bin <= (end_of[range] + 100000 - 1) / 100000; ++bin) {
+				const std::map<uint64_t, std::vector<uint32_t> >::const_iterator candidates = tags.by_bin.find((uint64_t) contig_of[range] << 32 | (uint32_t) (bin * 100000));
+				if (candidates == tags.by_bin.end()) continue;
+				for (size_t k = 0; k < candidates->second.size(); ++k) {
+					const TagRule& rule = tags.rules[candidates->second[k]];
+					if (matches_item(rule.first, f, gene_5, max_mate_gap) && matches_item(rule.second, f, gene_3, max_mate_gap)) matching.insert(rule.tag);
+				}
+			}
+		std::string result;
+		for (std::set<std::string>::const_iterator tag = matching.begin(); tag != matching.end(); ++tag) { if (!result.empty()) result += ","; result += *tag; }
+		return result.empty() ? "." : result;
+	}
+	// reference: annotate_retained_protein_domains (source/annotate_protein_domains.cpp:123-160): the domains of the gene on the retained side of the breakpoint;
+	// a domain counts once per index bucket it spans, as in the reference (domains of one name add up)
+	std::string retained_domains(contig_t contig, position_t breakpoint, bool predicted_strand, bool strand_ambiguous, int gene, bool upstream, const std::vector<ProteinDomain>& domains, const FlatIndex& index) const {
+		const GeneRecord& record = genes[gene];
+		if (!record.is_protein_coding || strand_ambiguous || predicted_strand != record.strand || (size_t) contig >= index.n_contigs()) return "";
+		std::map<std::string, std::pair<unsigned, unsigned> > retained; // name -> (length, retained bases)
+		for (uint32_t bucket = index.lower_bound(contig, record.start); bucket != index.contig_end(contig) && index.keys[bucket] <= record.end; ++bucket)
+			for (uint32_t m = index.member_offset[bucket]; m < index.member_offset[bucket + 1]; ++m) {
+				const ProteinDomain& domain = domains[index.members[m]];
+				if (domain.gene != gene) continue;
+				unsigned retained_bases = 0;
+				if (upstream && domain.end >= breakpoint) retained_bases = domain.end - std::max(domain.start, breakpoint) + 1;
+				else if (!upstream && domain.start <= breakpoint) retained_bases = std::min(domain.end, breakpoint) - domain.start + 1;
+				std::pair<unsigned, unsigned>& entry = retained[domain.name];
+				entry.first += domain.end - domain.start + 1; entry.second += retained_bases;
+			}
+		std::string result;
+		for (std::map<std::string, std::pair<unsigned, unsigned> >::const_iterator domain = retained.begin(); domain != retained.end(); ++domain)
+			if (domain->second.second > 0) { if (!result.empty()) result += ","; result += domain->first + "(" + std::to_string((long long) (domain->second.second * 100 / domain->second.first)) + "%)"; }
+		return result;
+	}
+
 	Fusion row(uint32_t c) const {
 		Fusion f;
 		const uint32_t flags = table.flags[c];
@@ -171,7 +237,7 @@ std::string coverage_text(int coverage) { return coverage >= 0 ? std::to_string(
 }
 
 void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Assembly& assembly, const Coverage& coverage, const Batch* batch, const FusionTable& table,
-                           const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length) {
+                           const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length, const OutputExtras& extras) {
 	Writer writer = { annotation, contigs, coverage, table, std::vector<GeneRecord>(), FlatIndex(), exon_index };
 	// the gene records of this sample: the GTF genes, then the dummy genes the device cut from the unmapped positions
 	if (table.n_genes < annotation.real_genes) throw std::runtime_error("gene table smaller than the annotation");
@@ -262,7 +328,14 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		text += contigs.original_names[contig_5] + ":" + std::to_string(breakpoint_5 + 1) + "\t" + contigs.original_names[contig_3] + ":" + std::to_string(breakpoint_3 + 1) + "\t";
 		text += site_5 + "\t" + site_3 + "\t" + writer.fusion_type(f, max_itd_length) + "\t" + std::to_string(split_reads_5) + "\t" + std::to_string(split_reads_3) + "\t" + std::to_string(f.discordant_mates) + "\t";
 		text += coverage_text(coverage_5) + "\t" + coverage_text(coverage_3) + "\t" + confidence_names[f.confidence & 3] + "\t" + reading_frame;
-		text += "\t.\t.\t.\t."; // tags, retained protein domains, closest genomic breakpoints: no tags / domains / structural variants file
+		text += "\t" + (extras.tags != NULL && !extras.tags->empty() ? writer.tags_of(f, *extras.tags, extras.max_mate_gap) : std::string("."));
+		std::string domains = ".";
+		if (extras.protein_domains != NULL && !extras.protein_domains->empty()) {
+			const std::string domains_5 = writer.retained_domains(contig_5, breakpoint_5, strand_5, f.strands_ambiguous, gene_5, upstream_5, *extras.protein_domains, *extras.protein_domain_index);
+			const std::string domains_3 = writer.retained_domains(contig_3, breakpoint_3, strand_3, f.strands_ambiguous, gene_3, upstream_3, *extras.protein_domains, *extras.protein_domain_index);
+			if (!domains_5.empty() || !domains_3.empty()) domains = domains_5 + "|" + domains_3;
+		}
+		text += "\t" + domains + "\t.\t."; // closest genomic breakpoints: no structural variants file
 		// reads discarded by a filter, by name of the filter
 		std::map<std::string, unsigned> filters;
 		if (f.filter != 0) filters[f.filter < N_FILTER_NAMES ? FILTER_NAMES[f.filter] : "?"] = 0;

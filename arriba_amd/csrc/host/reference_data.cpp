@@ -512,6 +512,7 @@ template <class Feature> void make_flat_index(const std::vector<Feature>& featur
 }
 template void make_flat_index<GeneRecord>(const std::vector<GeneRecord>&, size_t, FlatIndex&);
 template void make_flat_index<ExonRecord>(const std::vector<ExonRecord>&, size_t, FlatIndex&);
+template void make_flat_index<ProteinDomain>(const std::vector<ProteinDomain>&, size_t, FlatIndex&);
 
 uint32_t FlatIndex::lower_bound(contig_t contig, position_t position) const {
 	const position_t* begin = &keys[0] + contig_offset[contig];
@@ -809,6 +810,87 @@ void load_range_rules(const std::string& path, const Contigs& contigs, const Ann
 		if (!parse_range_item(range1, rule.first, contigs, annotation, false) || !parse_range_item(range2, rule.second, contigs, annotation, allow_keyword_in_second_column)) continue;
 		rules.push_back(rule);
 	}
+}
+
+// ---- tags and protein domains (columns of the output file) ----------------------------------------
+
+namespace {
+// reference: get_genome_bins_from_range (source/filter_blacklisted_ranges.cpp:221-225)
+void add_to_genome_bins(const agpu_range_item& item, uint32_t rule, std::map<uint64_t, std::vector<uint32_t> >& by_bin) {
+	const int bin_size = 100000;
+	for (position_t bin = item.start / bin_size; bin <= (item.end + bin_size - 1) / bin_size; ++bin) by_bin[(uint64_t) item.contig << 32 | (uint32_t) (bin * bin_size)].push_back(rule);
+}
+// reference: get_gff3_attribute (source/annotate_protein_domains.cpp:14-31)
+bool get_gff3_attribute(const std::string& attributes, const std::string& name, std::string& value) {
+	size_t start = attributes.find(name + "=");
+	if (start >= attributes.size()) { fprintf(stderr, "WARNING: failed to extract %s from line in GFF3 file: %s\n", name.c_str(), attributes.c_str()); return false; }
+	start += name.size() + 1;
+	size_t end = attributes.find(';', start);
+	if (end >= attributes.size()) end = attributes.size();
+	value = attributes.substr(start, end - start);
+	return true;
+}
+bool is_hex_digit(char c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F'); }
+}
+
+void load_tags(const std::string& path, const Contigs& contigs, const Annotation& annotation, Tags& tags) {
+	tags.rules.clear(); tags.by_bin.clear();
+	LineReader file(path);
+	std::string line;
+	while (file.getline(line)) {
+		if (line.empty() || line[0] == '#') continue;
+		FieldCursor fields(line, '\t');
+		std::string range1, range2, tag;
+		fields.next(range1); fields.next(range2); fields.next(tag);
+		if (tag.empty()) { fprintf(stderr, "WARNING: encountered a line with an empty tag => skipped\n"); continue; }
+		TagRule rule;
+		if (!parse_range_item(range1, rule.first, contigs, annotation, false) || !parse_range_item(range2, rule.second, contigs, annotation, false)) continue;
+		for (size_t k = 0; k < tag.size(); ++k) if (tag[k] < '!' || tag[k] > '~' || tag[k] == ',') tag[k] = '_'; // characters with a meaning in the output format
+		rule.tag = tag;
+		tags.rules.push_back(rule);
+		add_to_genome_bins(rule.first, (uint32_t) tags.rules.size() - 1, tags.by_bin);
+		add_to_genome_bins(rule.second, (uint32_t) tags.rules.size() - 1, tags.by_bin);
+	}
+}
+
+void load_protein_domains(const std::string& path, const Contigs& contigs, const Annotation& annotation, std::vector<ProteinDomain>& domains, FlatIndex& index) {
+	domains.clear();
+	std::unordered_map<std::string, int> gene_by_id; // later genes win (source/annotate_protein_domains.cpp:36-38)
+	for (size_t g = 0; g < annotation.genes.size(); ++g) gene_by_id[strip_ensembl_version_number(annotation.genes[g].gene_id)] = (int) g;
+	LineReader file(path);
+	std::string line;
+	std::set<std::string> unknown_genes;
+	while (file.getline(line)) {
+		if (line.empty() || line[0] == '#') continue;
+		FieldCursor fields(line, '\t');
+		ProteinDomain domain;
+		std::string contig, strand, attributes, gene_name, gene_id, trash;
+		int start = 0, end = 0;
+		fields.next(contig); fields.next(trash); fields.next(trash); fields.next(start); fields.next(end); fields.next(trash); fields.next(strand); fields.next(trash); fields.next(attributes);
+		if (fields.failed || contig.empty() || strand.empty() || attributes.empty()) { fprintf(stderr, "WARNING: failed to parse line in GFF3 file: %s\n", line.c_str()); continue; }
+		if (!get_gff3_attribute(attributes, "gene_name", gene_name) || !get_gff3_attribute(attributes, "gene_id", gene_id) || !get_gff3_attribute(attributes, "Name", domain.name)) continue;
+		std::map<std::string, contig_t>::const_iterator known_contig = contigs.by_name.find(remove_chr(contig));
+		if (known_contig == contigs.by_name.end()) { fprintf(stderr, "WARNING: unknown contig: %s\n", contig.c_str()); continue; }
+		// "%2C" and the like stand for special characters
+		for (std::string::size_type pos = domain.name.find("%"); pos < domain.name.size(); pos = domain.name.find("%", pos + 1))
+			if (pos + 2 < domain.name.size() && is_hex_digit(domain.name[pos + 1]) && is_hex_digit(domain.name[pos + 2]))
+				domain.name = domain.name.substr(0, pos) + (char) strtoul(domain.name.substr(pos + 1, 2).c_str(), NULL, 16) + domain.name.substr(pos + 3);
+		for (size_t k = 0; k < domain.name.size(); ++k) if (domain.name[k] < '!' || domain.name[k] > '~' || domain.name[k] == ',' || domain.name[k] == '|') domain.name[k] = '_';
+		std::unordered_map<std::string, int>::const_iterator by_id = gene_by_id.find(strip_ensembl_version_number(gene_id));
+		if (by_id != gene_by_id.end()) domain.gene = by_id->second;
+		else {
+			std::unordered_map<std::string, int>::const_iterator by_name = annotation.gene_by_name.find(gene_name);
+			if (by_name == annotation.gene_by_name.end()) {
+				if (unknown_genes.insert(gene_name + " " + gene_id).second) fprintf(stderr, "WARNING: unknown gene: %s %s\n", gene_name.c_str(), gene_id.c_str()); // once per gene
+				continue;
+			}
+			domain.gene = by_name->second;
+		}
+		domain.contig = known_contig->second; domain.start = start - 1; domain.end = end - 1; domain.strand = strand[0] == '+';
+		domains.push_back(domain);
+	}
+	if (domains.empty()) throw std::runtime_error("failed to parse GFF3 file");
+	make_flat_index(domains, std::max(domains.size(), contigs.size()), index);
 }
 
 }

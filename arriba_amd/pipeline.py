@@ -50,6 +50,16 @@ class HostSession(object):
             raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
         return self.fragment_count
 
+    def load_tags(self, path):
+        """-t: tags for the column `tags` of the output files (reference: load_tags, source/annotate_tags.cpp:11-44)"""
+        if self._lib.ahost_load_tags(self._session, path.encode()) != 0:
+            raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
+
+    def load_protein_domains(self, path):
+        """-p: protein domains (GFF3) for the column `retained_protein_domains` (reference: load_protein_domains, source/annotate_protein_domains.cpp:33-121)"""
+        if self._lib.ahost_load_protein_domains(self._session, path.encode()) != 0:
+            raise ArribaError("ERROR: " + self._lib.ahost_last_error().decode())
+
     def save_ingest(self, path):
         """the ingest result (batch, counters, coverage) as a file; load_ingest() of a session on the same FASTA/GTF restores it without parsing"""
         if self._lib.ahost_save_ingest(self._session, path.encode()) != 0:
@@ -235,7 +245,7 @@ class DevicePipeline(object):
         self.estimate_fragment_length()
         return self.filter_reads()
 
-    def run_workflow(self, output_file, discarded_output_file=None, blacklist_file=None, known_fusions_file=None, strandedness=None, evalue_cutoff=0.3,
+    def run_workflow(self, output_file, discarded_output_file=None, blacklist_file=None, known_fusions_file=None, tags_file=None, protein_domains_file=None, strandedness=None, evalue_cutoff=0.3,
                      min_itd_support=10, min_itd_allele_fraction=0.07, high_expression_quantile=0.998, min_spliced_events=4, min_anchor_length=23,
                      max_homolog_identity=0.3, max_itd_length=100, log=None):
         """The reference's main() behind read_chimeric_alignments (source/arriba.cpp:119-610) with its default parameters: the read-level cascade, find_fusions,
@@ -269,6 +279,10 @@ class DevicePipeline(object):
         note("filter_mismappers", self.filter_mismappers()[0])
         note("select_most_supported_breakpoints", self.select_most_supported_breakpoints())
         note("recover_isoforms", self.recover_isoforms())
+        if tags_file:
+            self.session.load_tags(tags_file)
+        if protein_domains_file:
+            self.session.load_protein_domains(protein_domains_file)
         self.write_fusions(output_file, discarded=False, max_itd_length=max_itd_length)
         if discarded_output_file:
             self.write_fusions(discarded_output_file, discarded=True, max_itd_length=max_itd_length)
@@ -397,7 +411,7 @@ class DevicePipeline(object):
             setattr(view, key, column.ctypes.data if column.size else None)
         if print_extra_info is None:
             print_extra_info = not discarded
-        if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length) != 0:
+        if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"])) != 0:
             raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
 
     def assign_confidence(self):

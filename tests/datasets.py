@@ -76,7 +76,7 @@ def run_reference(prefix, dump_directory, spec=None, extra_args=(), disable_filt
     disabled = list(disable_filters) if with_rules else ["blacklist"] + list(disable_filters)
     command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv"] + (["-f", ",".join(disabled)] if disabled else []) + list(extra_args)
     if with_rules:
-        command += ["-b", prefix + ".blacklist.tsv", "-k", prefix + ".known_fusions.tsv"]
+        command += ["-b", prefix + ".blacklist.tsv", "-k", prefix + ".known_fusions.tsv", "-t", prefix + ".tags.tsv", "-p", prefix + ".protein_domains.gff3"]
     result = subprocess.run(command, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     if result.returncode != 0:
         raise RuntimeError("reference failed:\n" + result.stdout)

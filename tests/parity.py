@@ -585,12 +585,15 @@ def check_chain_to_isoforms(session, pipeline, golden, rules_prefix=None):
     return counts + [selected, recovered], discarded, levels
 
 
-def check_output_files(session, pipeline, golden, directory, skip_columns=(), reference_prefix=None):
+def check_output_files(session, pipeline, golden, directory, skip_columns=(), reference_prefix=None, rules_prefix=None):
     """After the chain: the two output files against the reference's (tests/golden/<name>/fusions.tsv.gz, discarded.tsv.gz, or the files a live run
     wrote): byte for byte, every line in the same order (columns named in skip_columns are left out of the comparison of fusions.tsv).
     Returns (lines of fusions.tsv, lines of discarded.tsv)."""
     import gzip
     results = []
+    if rules_prefix:  # the reference ran with -t and -p as well
+        session.load_tags(rules_prefix + ".tags.tsv")
+        session.load_protein_domains(rules_prefix + ".protein_domains.gff3")
     for name, discarded in (("fusions.tsv", False), ("discarded.tsv", True)):
         path = os.path.join(directory, name)
         pipeline.write_fusions(path, discarded=discarded)
@@ -621,6 +624,7 @@ def check_workflow(prefix, golden, directory, api=None, rules=False, reference_p
     stages = []
     outputs = [os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv")]
     pipeline.run_workflow(outputs[0], outputs[1], blacklist_file=prefix + ".blacklist.tsv" if rules else None, known_fusions_file=prefix + ".known_fusions.tsv" if rules else None,
+                          tags_file=prefix + ".tags.tsv" if rules else None, protein_domains_file=prefix + ".protein_domains.gff3" if rules else None,
                           log=lambda stage, remaining: stages.append((stage, remaining)))
     for mine, name in zip(outputs, ("fusions.tsv", "discarded.tsv")):
         source = reference_prefix + "." + name if reference_prefix else os.path.join(golden, name)

@@ -365,7 +365,7 @@ def test_output_files_equal_the_reference(built, dataset_files, tmp_path):
         session, pipeline = parity.run_read_level(parity.open_session, prefix)
         parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name), rules_prefix=prefix if name == "rules8k" else None)
         os.makedirs(str(tmp_path / name))
-        fusions, discarded = parity.check_output_files(session, pipeline, conftest.golden_dir(name), str(tmp_path / name))
+        fusions, discarded = parity.check_output_files(session, pipeline, conftest.golden_dir(name), str(tmp_path / name), rules_prefix=prefix if name == "rules8k" else None)
         assert fusions > 40 and discarded > 1500
     if not datasets.reference_available():
         return

@@ -270,7 +270,7 @@ def test_output_files_equal_the_reference(name, dataset_files, emu_api, tmp_path
     prefix = dataset_files(name)
     session, pipeline = parity.run_read_level(parity.open_session, prefix, api=emu_api)
     parity.check_chain_to_isoforms(session, pipeline, conftest.golden_dir(name), rules_prefix=prefix if name == "rules8k" else None)
-    fusions, discarded = parity.check_output_files(session, pipeline, conftest.golden_dir(name), str(tmp_path))
+    fusions, discarded = parity.check_output_files(session, pipeline, conftest.golden_dir(name), str(tmp_path), rules_prefix=prefix if name == "rules8k" else None)
     assert fusions > 40 and discarded > 1500
 
 

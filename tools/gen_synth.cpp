@@ -490,6 +490,55 @@ void Generator::write_rule_files(const std::string& blacklist_path, const std::s
 	}
 	fprintf(f, "%s\tany\nNOT_A_GENE\t%s\n", genes_[0].name.c_str(), genes_[0].name.c_str()); // keywords are not allowed here: "any" is an unknown gene
 	fclose(f);
+
+	// tags (-t): like the known fusions with a third column, some tags with characters that the output format reserves
+	const std::string tags_path = known_fusions_path.substr(0, known_fusions_path.size() - std::string("known_fusions.tsv").size()) + "tags.tsv";
+	f = fopen(tags_path.c_str(), "w");
+	if (f == NULL) throw std::runtime_error("cannot write " + tags_path);
+	fprintf(f, "# synthetic tags\n");
+	static const char* const tag_names[] = { "Mitelman", "cancer gene, curated", "COSMIC", "known pair", "recurrent_artifact", "ChimerDB 4.0" };
+	for (size_t j = 0; j < junctions.size(); ++j) {
+		const Junction& junction = junctions[j];
+		if (junction.a.gene < 0 || junction.b.gene < 0 || !rng.chance(0.5)) continue;
+		const bool swap = rng.chance(0.2);
+		const Side& first = swap ? junction.b : junction.a;
+		const Side& second = swap ? junction.a : junction.b;
+		const char* tag = tag_names[rng.below(6)];
+		switch (rng.range(0, 3)) {
+			case 0: case 1: fprintf(f, "%s\t%s\t%s\n", genes_[first.gene].name.c_str(), genes_[second.gene].name.c_str(), tag); break;
+			case 2: fprintf(f, "%s\t%s\t%s\n", position(first, false, false).c_str(), genes_[second.gene].name.c_str(), tag); break;
+			default: fprintf(f, "%s\t%s\t%s\n", range_of_gene(first.gene, false).c_str(), range_of_gene(second.gene, false).c_str(), tag); break;
+		}
+	}
+	fprintf(f, "%s\t%s\n%s\tNOT_A_GENE\ttag\n", genes_[0].name.c_str(), genes_[1].name.c_str(), genes_[0].name.c_str()); // no tag; unknown gene
+	fclose(f);
+
+	// protein domains (-p, GFF3): two to four domains inside the coding region of every second coding gene, some with a name of several
+	// domains (added up by the reference), percent-encoded characters, and lines the parser skips
+	const std::string domains_path = known_fusions_path.substr(0, known_fusions_path.size() - std::string("known_fusions.tsv").size()) + "protein_domains.gff3";
+	f = fopen(domains_path.c_str(), "w");
+	if (f == NULL) throw std::runtime_error("cannot write " + domains_path);
+	fprintf(f, "##gff-version 3\n");
+	static const char* const domain_names[] = { "Protein_kinase_domain", "SH2 domain", "Zinc finger%2C C2H2", "Ig-like|V-type", "PDZ", "Helix-loop-helix%20motif" };
+	for (size_t g = 0; g < genes_.size(); ++g) {
+		const Gene& gene = genes_[g];
+		const Transcript& t = gene.transcripts[0];
+		if (t.cds_start < 0 || !rng.chance(0.5)) continue;
+		const int n_domains = rng.range(2, 4);
+		for (int k = 0; k < n_domains; ++k) {
+			const Exon& exon = t.exons[rng.below(t.exons.size())];
+			const int start = std::max(exon.start, t.cds_start), end = std::min(exon.end, t.cds_end);
+			if (end - start < 30) continue;
+			const int from = rng.range(start, end - 20), to = rng.range(from + 10, end);
+			const bool by_name_only = rng.chance(0.2); // an id the annotation does not know: the gene is found by its name
+			fprintf(f, "%s%s\tsynth\tprotein_domain\t%d\t%d\t.\t%c\t.\tName=%s;gene_name=%s;gene_id=%s;color=#808080\n", rng.chance(0.3) ? "chr" : "", contig_names_[gene.contig].c_str(), from + 1, to + 1, gene.plus ? '+' : '-',
+			        domain_names[rng.below(6)], gene.name.c_str(), by_name_only ? "ENSG99999999999.1" : gene.id.c_str());
+		}
+	}
+	fprintf(f, "1\tsynth\tprotein_domain\t10\t20\t.\t+\t.\tName=Orphan;gene_name=NOT_A_GENE;gene_id=ENSG99999999998.1\n1\tsynth\tprotein_domain\tx\t20\t.\t+\t.\tName=Bad;gene_name=%s;gene_id=%s\n"
+	           "1\tsynth\tprotein_domain\t10\t20\t.\t+\t.\tgene_name=%s;gene_id=%s\nchrNowhere\tsynth\tprotein_domain\t10\t20\t.\t+\t.\tName=Lost;gene_name=%s;gene_id=%s\n",
+	        genes_[0].name.c_str(), genes_[0].id.c_str(), genes_[0].name.c_str(), genes_[0].id.c_str(), genes_[0].name.c_str(), genes_[0].id.c_str());
+	fclose(f);
 }
 
 void Generator::write_gtf(const std::string& path) const {

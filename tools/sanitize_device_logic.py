@@ -44,5 +44,5 @@ for name in ('toy3k', 'rules8k'):  # the whole chain and the output writer (host
     s,p=parity.run_read_level(parity.open_session,prefix,api=api)
     parity.check_chain_to_isoforms(s,p,conftest.golden_dir(name),rules_prefix=prefix if name=='rules8k' else None)
     os.makedirs(os.path.join(tmp,name+'_files'))
-    print('output files', name, parity.check_output_files(s,p,conftest.golden_dir(name),os.path.join(tmp,name+'_files')))
+    print('output files', name, parity.check_output_files(s,p,conftest.golden_dir(name),os.path.join(tmp,name+'_files'),rules_prefix=prefix if name=='rules8k' else None))
 print('done')
