@@ -193,7 +193,7 @@ def bind_host_api(lib):
         "ahost_mapped_reads": (c_uint64, [session]),
         "ahost_coverage_checksum": (c_uint64, [session]),
         "ahost_coverage_view": (POINTER(CoverageView), [session]),
-        "ahost_write_fusions": (c_int, [session, POINTER(FusionTable), c_char_p, c_int, c_int, c_uint32, c_int]),
+        "ahost_write_fusions": (c_int, [session, POINTER(FusionTable), c_char_p, c_int, c_int, c_uint32, c_int, c_int]),
         "ahost_load_tags": (c_int, [session, c_char_p]),
         "ahost_load_protein_domains": (c_int, [session, c_char_p]),
         "ahost_load_range_rules": (c_int, [session, c_char_p, c_int, POINTER(POINTER(RangeRule)), POINTER(c_uint32)]),

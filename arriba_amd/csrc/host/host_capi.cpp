@@ -213,7 +213,7 @@ int ahost_load_protein_domains(ahost_session* session, const char* path) {
 	catch (const std::exception& e) { g_error = e.what(); return -1; }
 }
 
-int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap) {
+int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps) {
 	if (!session || !table || !path) { g_error = "null argument"; return -1; }
 	if (!session->have_batch) { g_error = "no BAM ingested yet"; return -1; }
 	try {
@@ -222,7 +222,7 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 		t.flags = table->flags; t.filter = table->filter; t.split_reads1 = table->split_reads1; t.split_reads2 = table->split_reads2; t.discordant_mates = table->discordant_mates;
 		t.list_offset = table->list_offset; t.read_lists = table->read_lists; t.evalue = table->evalue; t.confidence = table->confidence; t.iteration_rank = table->iteration_rank;
 		t.read_filter = table->read_filter; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
-		const OutputExtras extras = { &session->tags, &session->protein_domains, &session->protein_domain_index, max_mate_gap };
+		const OutputExtras extras = { &session->tags, &session->protein_domains, &session->protein_domain_index, max_mate_gap, fill_sequence_gaps != 0 };
 		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
 		return 0;
 	} catch (const std::exception& e) { g_error = e.what(); return -1; }

@@ -308,11 +308,17 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			best_fitting_transcripts(input, transcript_sequence, positions, gene_3, writer.genes[gene_3].is_dummy, writer.genes[gene_3].contig, writer.genes[gene_3].strand, strand_3, f.strands_ambiguous, 3, transcripts_3);
 			const PeptideGenes peptide_genes = { writer.genes[gene_5].contig, writer.genes[gene_3].contig, writer.genes[gene_5].strand, writer.genes[gene_3].strand, writer.genes[gene_5].is_dummy, writer.genes[gene_3].is_dummy, strand_3 };
 			int transcript_5 = -1, transcript_3 = -1;
+			const std::string sequence_as_assembled = transcript_sequence; const std::vector<position_t> positions_as_assembled = positions;
+			const bool is_itd = f.gene1 == f.gene2 && (unsigned) f.breakpoint2 - (unsigned) f.breakpoint1 < max_itd_length && f.upstream1 && !f.upstream2; // source/common.hpp:270-274
 			// every combination until one is in-frame; without candidates on one side the loop body still runs once with no transcript on that side
 			for (size_t i5 = 0; (transcripts_5.empty() || i5 != transcripts_5.size()) && reading_frame != "in-frame"; ++i5) {
 				if (i5 != transcripts_5.size()) transcript_5 = transcripts_5[i5];
 				for (size_t i3 = 0; (transcripts_3.empty() || i3 != transcripts_3.size()) && reading_frame != "in-frame"; ++i3) {
 					if (i3 != transcripts_3.size()) transcript_3 = transcripts_3[i3];
+					if (extras.fill_sequence_gaps) { // -I: for every pair of transcripts anew, from the sequence as assembled
+						transcript_sequence = sequence_as_assembled; positions = positions_as_assembled;
+						fill_gaps_in_fusion_transcript(input, transcript_sequence, positions, transcript_5, transcript_3, strand_5, strand_3, is_itd);
+					}
 					peptide_sequence = fusion_peptide_sequence(input, transcript_sequence, positions, peptide_genes, transcript_5, transcript_3);
 					reading_frame = reading_frame_verdict(peptide_sequence);
 					if (i3 == transcripts_3.size()) break;

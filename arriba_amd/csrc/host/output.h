@@ -15,7 +15,7 @@ struct FusionTable {
 	const uint8_t* read_filter;
 	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end; // GTF genes + dummy genes (agpu_get_gene_table)
 };
-struct OutputExtras { const Tags* tags; const std::vector<ProteinDomain>* protein_domains; const FlatIndex* protein_domain_index; int max_mate_gap; }; // -t, -p; NULL = not given
+struct OutputExtras { const Tags* tags; const std::vector<ProteinDomain>* protein_domains; const FlatIndex* protein_domain_index; int max_mate_gap; bool fill_sequence_gaps; }; // -t, -p (NULL = not given), -I
 // reference: write_fusions_to_file (source/output_fusions.cpp:1043-1261)
 void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Assembly& assembly, const Coverage& coverage, const Batch* batch, const FusionTable& table,
                            const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length, const OutputExtras& extras);

@@ -2,7 +2,7 @@
 // transcript assembled from the pileup of the reads at the two breakpoints (reference: source/output_fusions.cpp:25-466), the annotated
 // transcripts that fit it best (:711-818), the peptide and its reading frame (source/annotate_protein_domains.cpp:163-446).  Host code over
 // the few candidates that pass all filters; every quirk of the reference's string handling is kept because the columns are compared byte
-// for byte.  Not built: fill_gaps_in_fusion_transcript_sequence (-I, off by default).
+// for byte.  fill_gaps_in_fusion_transcript (-I, :820-1041) completes the assembled sequence with the reference genome along the chosen transcripts.
 //
 // One place of the reference cannot be reproduced in general: get_transcripts walks an unordered_map keyed by heap pointers
 // (source/output_fusions.cpp:792-804), so its choice between transcripts with mixed coding status depends on addresses (it differs between
@@ -371,6 +371,125 @@ void best_fitting_transcripts(const TranscriptInput& in, const std::string& sequ
 		return a.id < b.id;
 	});
 	if (best.size() > 1) best.push_back(best[0]); // the best of them first and last: picked whether or not an in-frame combination turns up
+}
+
+// reference: fill_gaps_in_fusion_transcript_sequence (:820-1041): with -I the stretches of the chosen transcripts that the reads do not cover are
+// taken from the assembly, in parentheses; "^" and "$" mark a sequence that reaches the start / end of the transcript
+void fill_gaps_in_fusion_transcript(const TranscriptInput& in, std::string& sequence, std::vector<position_t>& positions, int transcript_5, int transcript_3, bool strand_5, bool strand_3, bool is_internal_tandem_duplication) {
+	const Annotation& a = in.annotation;
+	bool five_prime_done = false;
+	if (transcript_5 != -1 && in.assembly.has(a.exons[a.transcripts[transcript_5].first_exon].contig)) {
+		const TranscriptRecord& transcript = a.transcripts[transcript_5];
+		const ExonRecord& first_exon = a.exons[transcript.first_exon]; const ExonRecord& last_exon = a.exons[transcript.last_exon];
+		const std::string& genome = in.assembly.sequence[first_exon.contig];
+		// the gap closest to the junction: the sequence is completed from there
+		const size_t breakpoint = sequence.find('|');
+		size_t gap = sequence.find_last_of("...", breakpoint);
+		bool imprecise_breakpoint = false, fill = true;
+		if (gap < sequence.size() && gap + 1 == breakpoint && gap >= 3) { imprecise_breakpoint = true; gap -= 3; } // "...|": a splice site close by may serve as the breakpoint
+		else if (gap < sequence.size() && positions[gap + 1] > first_exon.start && positions[gap + 1] < last_exon.end) gap++; // behind the "..."
+		else if (gap >= sequence.size() && positions[0] > first_exon.start && positions[0] < last_exon.end) gap = 0;          // no gap, but the transcribed region does not reach the start
+		else {
+			// no gaps and the transcript is covered: trim to its boundaries
+			for (unsigned int i = 0; i < breakpoint; i++)
+				if (positions[i] >= first_exon.start && positions[i] <= last_exon.end) {
+					if (i > 0) { sequence = sequence.substr(i); positions.erase(positions.begin(), positions.begin() + i); }
+					break;
+				}
+			if ((strand_5 && positions[0] == first_exon.start) || (!strand_5 && positions[0] == last_exon.end)) { sequence = "^" + sequence; positions.insert(positions.begin(), -1); }
+			fill = false; five_prime_done = true;
+		}
+		if (fill) {
+			// a position between gap and junction inside an exon of the transcript
+			bool overlap_found = false;
+			int overlapping_exon = -1;
+			for (; gap != breakpoint; gap++) {
+				for (overlapping_exon = transcript.first_exon; overlapping_exon != -1; overlapping_exon = a.exons[overlapping_exon].next_exon)
+					if (positions[gap] >= a.exons[overlapping_exon].start && positions[gap] <= a.exons[overlapping_exon].end) { overlap_found = true; break; }
+				if (overlap_found) break;
+			}
+			if (imprecise_breakpoint && ((strand_5 && overlapping_exon == transcript.last_exon) || (!strand_5 && overlapping_exon == transcript.first_exon) || is_internal_tandem_duplication)) overlap_found = false;
+			if (overlap_found) {
+				if (imprecise_breakpoint) { // pretend the breakpoint is the closest exon boundary
+					gap = breakpoint - 1;
+					positions[gap] = strand_5 ? a.exons[overlapping_exon].end : a.exons[overlapping_exon].start;
+					sequence[gap] = strand_5 ? genome[positions[gap]] : complement_of(genome[positions[gap]]);
+				}
+				std::string from_assembly = "(";
+				std::vector<position_t> assembly_positions(1, -1);
+				for (int exon = strand_5 ? transcript.first_exon : transcript.last_exon; exon != -1; exon = strand_5 ? a.exons[exon].next_exon : a.exons[exon].previous_exon) {
+					const ExonRecord& e = a.exons[exon];
+					position_t position;
+					for (position = strand_5 ? e.start : e.end; position != positions[gap] && position >= e.start && position <= e.end; position += strand_5 ? +1 : -1) {
+						from_assembly += strand_5 ? genome[position] : complement_of(genome[position]);
+						assembly_positions.push_back(position);
+					}
+					if (position == positions[gap]) break;
+					from_assembly += "___";
+					assembly_positions.resize(assembly_positions.size() + 3, -1);
+				}
+				if (imprecise_breakpoint) { from_assembly += sequence[gap]; assembly_positions.push_back(positions[gap]); gap++; }
+				from_assembly += ")";
+				assembly_positions.push_back(-1);
+				from_assembly.append(sequence, gap, std::string::npos);
+				assembly_positions.insert(assembly_positions.end(), positions.begin() + gap, positions.end());
+				sequence = from_assembly; positions = assembly_positions;
+				if ((strand_5 && positions[1] == first_exon.start) || (!strand_5 && positions[1] == last_exon.end)) { sequence = "^" + sequence; positions.insert(positions.begin(), -1); }
+			}
+		}
+	}
+	(void) five_prime_done;
+	if (transcript_3 != -1 && in.assembly.has(a.exons[a.transcripts[transcript_3].first_exon].contig)) {
+		const TranscriptRecord& transcript = a.transcripts[transcript_3];
+		const ExonRecord& first_exon = a.exons[transcript.first_exon]; const ExonRecord& last_exon = a.exons[transcript.last_exon];
+		const std::string& genome = in.assembly.sequence[first_exon.contig];
+		const size_t breakpoint = sequence.find_last_of('|');
+		size_t gap = sequence.find("...", breakpoint);
+		bool imprecise_breakpoint = false;
+		if (gap < sequence.size() && gap - 1 == breakpoint && gap + 3 < sequence.size()) { imprecise_breakpoint = true; gap += 3; }
+		else if (gap < sequence.size() && positions[gap - 1] > first_exon.start && positions[gap - 1] < last_exon.end) gap--; // the last position in front of "..."
+		else if (gap >= sequence.size() && positions[sequence.size() - 1] > first_exon.start && positions[sequence.size() - 1] < last_exon.end) gap = sequence.size() - 1;
+		else {
+			for (unsigned int i = sequence.size() - 1; i > breakpoint; i--)
+				if (positions[i] >= first_exon.start && positions[i] <= last_exon.end) {
+					if (i < sequence.size() - 1) { sequence = sequence.substr(0, i + 1); positions.erase(positions.begin() + i + 1, positions.end()); }
+					break;
+				}
+			if ((strand_3 && positions[positions.size() - 1] == last_exon.end) || (!strand_3 && positions[positions.size() - 1] == first_exon.start)) { sequence += "$"; positions.push_back(-1); }
+			return;
+		}
+		bool overlap_found = false;
+		int overlapping_exon = -1;
+		for (; gap != breakpoint; gap--) {
+			for (overlapping_exon = transcript.first_exon; overlapping_exon != -1; overlapping_exon = a.exons[overlapping_exon].next_exon)
+				if (positions[gap] >= a.exons[overlapping_exon].start && positions[gap] <= a.exons[overlapping_exon].end) { overlap_found = true; break; }
+			if (overlap_found) break;
+		}
+		if (imprecise_breakpoint && ((strand_3 && overlapping_exon == transcript.last_exon) || (!strand_3 && overlapping_exon == transcript.first_exon) || is_internal_tandem_duplication)) overlap_found = false;
+		if (!overlap_found) return;
+		if (imprecise_breakpoint) {
+			gap = breakpoint + 1;
+			positions[gap] = strand_3 ? a.exons[overlapping_exon].start : a.exons[overlapping_exon].end;
+			sequence[gap] = strand_3 ? genome[positions[gap]] : complement_of(genome[positions[gap]]);
+		}
+		std::string from_assembly;
+		std::vector<position_t> assembly_positions;
+		for (int exon = overlapping_exon; exon != -1; exon = strand_3 ? a.exons[exon].next_exon : a.exons[exon].previous_exon) {
+			const ExonRecord& e = a.exons[exon];
+			for (position_t position = strand_3 ? std::max(e.start, positions[gap] + 1) : std::min(e.end, positions[gap] - 1); position >= e.start && position <= e.end; position += strand_3 ? +1 : -1) {
+				from_assembly += strand_3 ? genome[position] : complement_of(genome[position]);
+				assembly_positions.push_back(position);
+			}
+			if ((strand_3 && e.next_exon != -1) || (!strand_3 && e.previous_exon != -1)) { from_assembly += "___"; assembly_positions.resize(assembly_positions.size() + 3, -1); }
+		}
+		sequence.resize(gap + 1); sequence += "(";
+		positions.resize(gap + 1); positions.push_back(-1);
+		sequence += from_assembly;
+		positions.insert(positions.end(), assembly_positions.begin(), assembly_positions.end());
+		sequence += ")"; positions.push_back(-1);
+		if (imprecise_breakpoint) { std::swap(sequence[breakpoint + 1], sequence[breakpoint + 2]); std::swap(positions[breakpoint + 1], positions[breakpoint + 2]); }
+		if ((strand_3 && positions[positions.size() - 2] == last_exon.end) || (!strand_3 && positions[positions.size() - 2] == first_exon.start)) { sequence += "$"; positions.push_back(-1); }
+	}
 }
 
 namespace {

@@ -19,6 +19,7 @@ struct PeptideGenes { contig_t contig_5, contig_3; bool forward_5, forward_3, du
 void fusion_transcript_sequence(const TranscriptInput& in, const FusionEvent& fusion, std::string& sequence, std::vector<position_t>& positions);
 void best_fitting_transcripts(const TranscriptInput& in, const std::string& sequence, const std::vector<position_t>& transcribed_bases, int gene, bool gene_is_dummy, contig_t gene_contig, bool gene_forward,
                               bool strand, bool strand_ambiguous, int which_end, std::vector<int>& best);
+void fill_gaps_in_fusion_transcript(const TranscriptInput& in, std::string& sequence, std::vector<position_t>& positions, int transcript_5, int transcript_3, bool strand_5, bool strand_3, bool is_internal_tandem_duplication);
 std::string fusion_peptide_sequence(const TranscriptInput& in, const std::string& sequence, const std::vector<position_t>& positions, const PeptideGenes& genes, int transcript_5, int transcript_3);
 std::string reading_frame_verdict(const std::string& peptide);
 

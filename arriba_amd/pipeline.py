@@ -247,7 +247,7 @@ class DevicePipeline(object):
 
     def run_workflow(self, output_file, discarded_output_file=None, blacklist_file=None, known_fusions_file=None, tags_file=None, protein_domains_file=None, strandedness=None, evalue_cutoff=0.3,
                      min_itd_support=10, min_itd_allele_fraction=0.07, high_expression_quantile=0.998, min_spliced_events=4, min_anchor_length=23,
-                     max_homolog_identity=0.3, max_itd_length=100, log=None):
+                     max_homolog_identity=0.3, max_itd_length=100, fill_sequence_gaps=False, log=None):
         """The reference's main() behind read_chimeric_alignments (source/arriba.cpp:119-610) with its default parameters: the read-level cascade, find_fusions,
         every candidate-level filter in the reference's order, assign_confidence, and the two output files.  `log` receives (stage, remaining) pairs --
         the numbers the reference prints as "(remaining=N)".  Filters switched off with -f are skipped by the stages themselves (agpu_params.filter_enabled)."""
@@ -283,9 +283,9 @@ class DevicePipeline(object):
             self.session.load_tags(tags_file)
         if protein_domains_file:
             self.session.load_protein_domains(protein_domains_file)
-        self.write_fusions(output_file, discarded=False, max_itd_length=max_itd_length)
+        self.write_fusions(output_file, discarded=False, max_itd_length=max_itd_length, fill_sequence_gaps=fill_sequence_gaps)
         if discarded_output_file:
-            self.write_fusions(discarded_output_file, discarded=True, max_itd_length=max_itd_length)
+            self.write_fusions(discarded_output_file, discarded=True, max_itd_length=max_itd_length, fill_sequence_gaps=fill_sequence_gaps)
 
     def find_fusions(self, max_mate_gap=None):
         """reference: find_fusions, source/fusions.cpp:203-473; returns the number of candidates"""
@@ -393,7 +393,7 @@ class DevicePipeline(object):
         gap = int(self.scalars["max_mate_gap"] if max_mate_gap is None else max_mate_gap)
         return self._event_stage("recover_known_fusions", rules, count, gap)
 
-    def write_fusions(self, path, discarded=False, print_extra_info=None, max_itd_length=100):
+    def write_fusions(self, path, discarded=False, print_extra_info=None, max_itd_length=100, fill_sequence_gaps=False):
         """reference: write_fusions_to_file, source/output_fusions.cpp:1043-1261 (-o / -O); the device's results are fetched and formatted by the host library"""
         table = self.candidates()
         n = self.n_candidates
@@ -411,7 +411,7 @@ class DevicePipeline(object):
             setattr(view, key, column.ctypes.data if column.size else None)
         if print_extra_info is None:
             print_extra_info = not discarded
-        if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"])) != 0:
+        if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps)) != 0:
             raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
 
     def assign_confidence(self):

@@ -54,7 +54,8 @@ typedef struct {
 	const uint8_t* read_filter;    /* [fragments of the session's batch] */
 	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end;
 } ahost_fusion_table;
-int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap);
+int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap,
+                        int fill_sequence_gaps /* -I: complete the fusion transcript from the assembly along the chosen transcripts */);
 /* Optional inputs of the output files: a tags file (-t; load_tags, source/annotate_tags.cpp:11-44) and protein domains in GFF3 (-p; load_protein_domains,
  * source/annotate_protein_domains.cpp:33-121).  Loaded into the session; ahost_write_fusions fills the columns `tags` and `retained_protein_domains` from them. */
 int ahost_load_tags(ahost_session* session, const char* path);

@@ -51,6 +51,8 @@ DATASETS = {
                 "golden_files": ["scalars.tsv", "genes.tsv", "fusions.*_filter_both_intronic.tsv", "fusions.*_recover_known_fusions.tsv", "fusions.*_recover_many_spliced.tsv", "fusions.*_filter_blacklisted_ranges.tsv",
                                  "fusions.*_filter_no_coverage.tsv", "filters.*_recover_internal_tandem_duplication.tsv", "fusions.*_assign_confidence.tsv", "filters.*_filter_mismappers.tsv",
                                  "fusions.*_before_filter_mismappers.tsv", "fusions.*_filter_mismappers.tsv"], "reference_env": {"ARRIBA_ORACLE_DUMP_LISTS": "0"}},
+    # toy3k with -I: the fusion transcripts completed from the assembly along the chosen transcripts (only the output files are kept)
+    "toy3k_fill": {"args": ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"], "reference_extra_args": ["-I"], "golden_files": ["scalars.tsv"]},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},
@@ -74,6 +76,7 @@ def run_reference(prefix, dump_directory, spec=None, extra_args=(), disable_filt
     env["ARRIBA_ORACLE_DUMP"] = dump_directory
     with_rules = bool((spec or {}).get("rule_files"))  # a blacklist and a known-fusions file written by the generator (--rule-files)
     disabled = list(disable_filters) if with_rules else ["blacklist"] + list(disable_filters)
+    extra_args = list(extra_args) + list((spec or {}).get("reference_extra_args", []))
     command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv"] + (["-f", ",".join(disabled)] if disabled else []) + list(extra_args)
     if with_rules:
         command += ["-b", prefix + ".blacklist.tsv", "-k", prefix + ".known_fusions.tsv", "-t", prefix + ".tags.tsv", "-p", prefix + ".protein_domains.gff3"]

@@ -613,7 +613,7 @@ def check_output_files(session, pipeline, golden, directory, skip_columns=(), re
     return tuple(results)
 
 
-def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None):
+def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None, fill_sequence_gaps=False):
     """FASTA + GTF + BAM (+ blacklist / known fusions) -> fusions.tsv, discarded.tsv through DevicePipeline.run_workflow with the reference's default
     parameters: nothing is taken from the reference, not even the parameters its log prints.  Both files must equal the reference's byte for byte, and
     every "(remaining=N)" of its log must come out."""
@@ -625,7 +625,7 @@ def check_workflow(prefix, golden, directory, api=None, rules=False, reference_p
     outputs = [os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv")]
     pipeline.run_workflow(outputs[0], outputs[1], blacklist_file=prefix + ".blacklist.tsv" if rules else None, known_fusions_file=prefix + ".known_fusions.tsv" if rules else None,
                           tags_file=prefix + ".tags.tsv" if rules else None, protein_domains_file=prefix + ".protein_domains.gff3" if rules else None,
-                          log=lambda stage, remaining: stages.append((stage, remaining)))
+                          fill_sequence_gaps=fill_sequence_gaps, log=lambda stage, remaining: stages.append((stage, remaining)))
     for mine, name in zip(outputs, ("fusions.tsv", "discarded.tsv")):
         source = reference_prefix + "." + name if reference_prefix else os.path.join(golden, name)
         expected = open(source).read() if os.path.exists(source) else gzip.open(source + ".gz", "rt").read()

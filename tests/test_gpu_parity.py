@@ -390,9 +390,9 @@ def test_output_files_equal_the_reference(built, dataset_files, tmp_path):
 def test_workflow_from_input_files_to_output_files(built, dataset_files, tmp_path):
     """FASTA + GTF + BAM (+ blacklist and known fusions) -> fusions.tsv + discarded.tsv on the GPU through DevicePipeline.run_workflow with the reference's
     default parameters, nothing taken from the reference: both files byte-identical to the reference's (golden datasets; a live run of 150 k fragments)"""
-    for name in ("toy3k", "rules8k", "homologs8k"):
+    for name in ("toy3k", "rules8k", "homologs8k", "toy3k_fill"):
         os.makedirs(str(tmp_path / name))
-        stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path / name), rules=name == "rules8k")
+        stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path / name), rules=name == "rules8k", fill_sequence_gaps=name == "toy3k_fill")
         assert stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
     if not datasets.reference_available():
         return
