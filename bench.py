@@ -94,6 +94,7 @@ def main():
     parser.add_argument("--warmup", type=int, default=1)
     parser.add_argument("--fragments", type=int, default=10000000, help="chimeric fragments per GPU (BASELINE.json config 2: 10 M)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--workflow", action="store_true", help="after the timed steps, also run the whole workflow once (every candidate-level filter, assign_confidence, both output files) and report its wall time; 1 GPU only")
     args = parser.parse_args()
 
     import torch
@@ -235,6 +236,18 @@ def main():
         }
         line["self_check"] = "every alignment has a gene; unfiltered + multi-mapper discards == remaining after the read filters"
         line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped"} if args.no_cpu_baseline else cpu_baseline(1000, directory)
+        if args.workflow and not distributed:
+            # untimed extra (not part of `value`): the reference's main() behind the ingest, to the two output files, once over the same batch
+            try:
+                remaining = []
+                pipeline.reset()
+                torch.cuda.synchronize()
+                workflow_started = time.time()
+                pipeline.run_workflow(os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv"), log=lambda stage, count: remaining.append((stage, count, round(time.time() - workflow_started, 3))))
+                torch.cuda.synchronize()
+                line["workflow"] = {"seconds": time.time() - workflow_started, "stages": remaining, "fusions": remaining[-1][1] if remaining else None}
+            except Exception as error:  # the candidate-level stages must not cost the bench line
+                line["workflow"] = {"error": str(error)}
         print(json.dumps(line))
     if distributed:
         dist.barrier()
