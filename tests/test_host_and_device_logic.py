@@ -129,6 +129,56 @@ def test_ingest_with_several_threads_equals_single_threaded(built, tmp_path, mon
         assert not different, different
 
 
+def _bam_payload(path):
+    """the uncompressed BAM stream of a BGZF file"""
+    import gzip
+    return gzip.open(path, "rb").read()
+
+
+def _write_bgzf(path, payload, level, block=0xff00):
+    import struct
+    import zlib
+    with open(path, "wb") as out:
+        for at in list(range(0, len(payload), block)) + [len(payload)]:
+            chunk = payload[at:at + block] if at < len(payload) else b""  # the empty block at the end: the BGZF end-of-file marker
+            compressor = zlib.compressobj(level, zlib.DEFLATED, -15)
+            data = compressor.compress(chunk) + compressor.flush()
+            out.write(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(data) + 25))
+            out.write(data + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+def test_ingest_reads_every_container_of_a_bam_stream(built, dataset_files, tmp_path):
+    """The block-parallel BGZF reader (stored blocks as the generator and STAR --outBAMcompression 0 write them, deflated blocks, small blocks that
+    straddle the batches), the zlib fallback for a plain gzip stream, and the errors: a truncated block, a corrupted checksum"""
+    import gzip
+    from arriba_amd.pipeline import ArribaError, HostSession
+    prefix = dataset_files("toy3k")
+    payload = _bam_payload(prefix + ".bam")
+    variants = {"deflated": str(tmp_path / "deflated.bam"), "small_blocks": str(tmp_path / "small.bam"), "plain_gzip": str(tmp_path / "plain.bam")}
+    _write_bgzf(variants["deflated"], payload, 6)
+    _write_bgzf(variants["small_blocks"], payload, 1, block=997)
+    with gzip.open(variants["plain_gzip"], "wb") as out:
+        out.write(payload)
+    def ingest(path):
+        session = HostSession(prefix + ".fa", prefix + ".gtf")
+        session.read_chimeric_alignments(path)
+        columns = _batch_columns(session)
+        columns["coverage"] = int(session._lib.ahost_coverage_checksum(session._session))
+        return columns
+    expected = ingest(prefix + ".bam")
+    assert expected["n"] > 2000
+    for name, path in variants.items():
+        assert ingest(path) == expected, name
+    raw = open(variants["deflated"], "rb").read()
+    open(str(tmp_path / "truncated.bam"), "wb").write(raw[:len(raw) // 2])
+    damaged = bytearray(raw)
+    damaged[len(raw) // 3] ^= 0x5A
+    open(str(tmp_path / "damaged.bam"), "wb").write(bytes(damaged))
+    for name in ("truncated.bam", "damaged.bam"):
+        with pytest.raises(ArribaError):
+            ingest(str(tmp_path / name))
+
+
 def test_ingest_result_survives_save_and_load(built, dataset_files, tmp_path):
     from arriba_amd.pipeline import ArribaError, HostSession
     prefix = dataset_files("shuffled2k")
