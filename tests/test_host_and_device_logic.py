@@ -332,6 +332,21 @@ def test_workflow_from_input_files_to_output_files(name, dataset_files, emu_api,
     assert len(stages) >= 18 and stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
 
 
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+@pytest.mark.parametrize("fragments", [1, 5, 40, 200])
+def test_workflow_on_tiny_inputs_against_the_live_reference(fragments, emu_api, tmp_path):
+    """one to a few hundred chimeric fragments: no candidate survives, or none exists at all; the output files still equal the reference's"""
+    spec = {"args": ["--seed", "71", "--fragments", str(fragments), "--contigs", "3", "--contig-len", "200000", "--junctions", "10", "--normal-mult", "1.0"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, spec))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix)
+    assert stages[0][1] >= 1
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
