@@ -48,10 +48,14 @@ class RangeRule(ctypes.Structure):
     _fields_ = [("first", RangeItem), ("second", RangeItem)]
 
 
+class GenomicBreakpoint(ctypes.Structure):
+    _fields_ = [("contig1", c_uint32), ("contig2", c_uint32), ("position1", c_int32), ("position2", c_int32), ("upstream1", c_uint8), ("upstream2", c_uint8), ("reserved", c_uint8 * 2)]
+
+
 class FusionTable(ctypes.Structure):
     _fields_ = [("n_candidates", c_uint32), ("gene1", c_void_p), ("gene2", c_void_p), ("contigs", c_void_p), ("breakpoint1", c_void_p), ("breakpoint2", c_void_p), ("flags", c_void_p), ("filter", c_void_p),
                 ("split_reads1", c_void_p), ("split_reads2", c_void_p), ("discordant_mates", c_void_p), ("list_offset", c_void_p), ("read_lists", c_void_p), ("evalue", c_void_p), ("confidence", c_void_p),
-                ("iteration_rank", c_void_p), ("read_filter", c_void_p), ("n_genes", c_uint32), ("gene_contig", c_void_p), ("gene_start", c_void_p), ("gene_end", c_void_p)]
+                ("iteration_rank", c_void_p), ("read_filter", c_void_p), ("closest_genomic_breakpoint1", c_void_p), ("closest_genomic_breakpoint2", c_void_p), ("n_genes", c_uint32), ("gene_contig", c_void_p), ("gene_start", c_void_p), ("gene_end", c_void_p)]
 
 
 class BatchView(ctypes.Structure):
@@ -143,6 +147,10 @@ def bind_device_api(lib, prefix="agpu_"):
         "filter_in_vitro": (c_int, [ctx, c_float, POINTER(c_uint64)]),
         "filter_homologs": (c_int, [ctx, c_float, POINTER(c_uint64)]),
         "recover_isoforms": (c_int, [ctx, POINTER(c_uint64)]),
+        "mark_genomic_support": (c_int, [ctx, POINTER(GenomicBreakpoint), c_uint32, c_int32, POINTER(c_uint64)]),
+        "get_genomic_support": (c_int, [ctx, c_void_p, c_void_p]),
+        "filter_no_genomic_support": (c_int, [ctx, POINTER(c_uint64)]),
+        "recover_genomic_support": (c_int, [ctx, POINTER(c_uint64)]),
         "filter_blacklisted_ranges": (c_int, [ctx, POINTER(RangeRule), c_uint32, c_float, c_int32, POINTER(c_uint64)]),
         "recover_known_fusions": (c_int, [ctx, POINTER(RangeRule), c_uint32, c_int32, POINTER(c_uint64)]),
         "assign_confidence": (c_int, [ctx, c_void_p]),
@@ -195,6 +203,7 @@ def bind_host_api(lib):
         "ahost_coverage_view": (POINTER(CoverageView), [session]),
         "ahost_write_fusions": (c_int, [session, POINTER(FusionTable), c_char_p, c_int, c_int, c_uint32, c_int, c_int]),
         "ahost_load_tags": (c_int, [session, c_char_p]),
+        "ahost_load_genomic_breakpoints": (c_int, [session, c_char_p, POINTER(POINTER(GenomicBreakpoint)), POINTER(c_uint32)]),
         "ahost_load_protein_domains": (c_int, [session, c_char_p]),
         "ahost_load_range_rules": (c_int, [session, c_char_p, c_int, POINTER(POINTER(RangeRule)), POINTER(c_uint32)]),
         "ahost_contig_count": (c_uint32, [session]),

@@ -622,7 +622,7 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 	b.gene_pool = ctx->gene_pool.as<uint32_t>(); b.gene_pool_used = ctx->counters.as<uint32_t>() + COUNTER_GENE_POOL; b.gene_pool_capacity = pool_capacity;
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
-	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false;
+	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
 	if (ctx->have_genome) TRY(build_tables(ctx));
 	return AGPU_OK;
 }
@@ -647,7 +647,7 @@ int agpu_reset(agpu_ctx* ctx) {
 	refresh_annotation_view(ctx);
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
-	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false;
+	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
 	return AGPU_OK;
 }
 

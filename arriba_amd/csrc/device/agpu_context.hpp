@@ -95,6 +95,11 @@ struct agpu_ctx {
 	agpu::DeviceBuffer coverage_window_offset, coverage_windows, coverage_fragment_starts, coverage_fragment_ends;
 	agpu::CoverageView coverage = { 0, nullptr, nullptr, nullptr, nullptr };
 	bool have_coverage = false;
+	// closest genomic breakpoints per candidate (agpu_mark_genomic_support); not marked: every candidate -1
+	agpu::DeviceBuffer cand_closest1, cand_closest2;
+	bool genomic_support_marked = false;
+	uint32_t confidence_candidates = 0xFFFFFFFFu; // n_candidates of the last agpu_assign_confidence (its result stays in scratch "events.confidence")
+	agpu::GenomicSupport genomic_support() { agpu::GenomicSupport wgs = { genomic_support_marked ? cand_closest1.as<int32_t>() : nullptr, genomic_support_marked ? cand_closest2.as<int32_t>() : nullptr }; return wgs; }
 	uint64_t global_n = 0; // fragments of the whole sample when this context holds one shard of it (agpu_set_shard); 0 = not sharded
 
 	// scratch

@@ -12,6 +12,7 @@
 #include "device_utils.hpp"
 #include "in_vitro_host.hpp"
 #include "range_rule_host.hpp"
+#include "genomic_support_core.hpp"
 
 using namespace agpu;
 
@@ -85,9 +86,9 @@ __global__ void isoform_recover_kernel(CandidateTable t, const uint8_t* recovere
 }
 
 // filter_blacklisted_ranges (mode 0) / recover_known_fusions (mode 1)
-__global__ void range_rule_kernel(AnnotationView ann, CoverageView coverage, CandidateTable t, const float* evalues, RangeRuleIndex index, int mode, int32_t max_mate_gap, float evalue_cutoff) {
+__global__ void range_rule_kernel(AnnotationView ann, CoverageView coverage, CandidateTable t, const float* evalues, RangeRuleIndex index, int mode, int32_t max_mate_gap, float evalue_cutoff, GenomicSupport wgs) {
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c >= t.n || !(mode == 0 ? blacklist_considers(t, c) : known_fusions_considers(t, c))) return;
+	if (c >= t.n || !(mode == 0 ? blacklist_considers(t, c, wgs) : known_fusions_considers(t, c))) return;
 	if (candidate_matches_any_rule(ann, coverage, t, evalues, c, index, mode, max_mate_gap, evalue_cutoff)) t.filter[c] = mode == 0 ? FILTER_blacklist : FILTER_none;
 }
 
@@ -96,9 +97,26 @@ __global__ void confidence_key_kernel(CandidateTable t, int pass, uint64_t* keys
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c < t.n) keys[c] = confidence_sort_key(t, c, pass);
 }
-__global__ void confidence_kernel(AnnotationView ann, CoverageView coverage, CandidateTable t, const float* evalues, ConfidenceTables tables, uint8_t* confidence) {
+__global__ void confidence_kernel(AnnotationView ann, CoverageView coverage, CandidateTable t, const float* evalues, ConfidenceTables tables, GenomicSupport wgs, uint8_t* confidence) {
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c < t.n) confidence[c] = candidate_confidence(ann, coverage, t, evalues, tables, c);
+	if (c < t.n) confidence[c] = candidate_confidence(ann, coverage, t, evalues, tables, c, wgs);
+}
+
+// structural variants from WGS: closest genomic breakpoints per candidate; the two filters that use them (mode 0: filter_no_genomic_support, 1: recover_genomic_support)
+__global__ void genomic_support_kernel(AnnotationView ann, CandidateTable t, GenomicBreakpoints variants, int32_t max_distance, uint32_t max_itd_length, int32_t* closest1, int32_t* closest2, unsigned int* marked) {
+	__shared__ uint32_t block_sum;
+	uint32_t mine = 0;
+	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
+		closest_genomic_breakpoints(ann, t, variants, c, max_distance, max_itd_length, closest1[c], closest2[c]);
+		mine += closest1[c] >= 0;
+	}
+	block_tally(mine, marked, &block_sum);
+}
+__global__ void genomic_support_filter_kernel(GenomeView genome, CandidateTable t, GenomicSupport wgs, const uint8_t* confidence, int mode) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n) return;
+	if (mode == 0) { if (t.filter[c] == FILTER_none && lacks_genomic_support(genome, t, wgs, confidence, c)) t.filter[c] = FILTER_no_genomic_support; }
+	else if (t.filter[c] != FILTER_none && recovered_by_genomic_support(t, wgs, c)) t.filter[c] = FILTER_none;
 }
 
 // filter_in_vitro: expression proxy, gene-pair table, verdicts
@@ -366,7 +384,7 @@ int run_range_rules(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rule
 			index.rules = device_rules.as<agpu_range_rule>(); index.n_rules = n_rules; index.bin_keys = bin_keys.as<uint64_t>(); index.bin_offset = bin_offset.as<uint32_t>(); index.bin_rules = bin_rules.as<uint32_t>();
 			index.n_bins = (uint32_t) bins.bin_keys.size();
 			KernelTimer timer(ctx, mode == 0 ? "range_rule_kernel(blacklist)" : "range_rule_kernel(known_fusions)", (uint64_t) C * 40);
-			range_rule_kernel<<<(unsigned int) ((C + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, ctx->candidates, ctx->cand_evalue.as<float>(), index, mode, max_mate_gap, evalue_cutoff);
+			range_rule_kernel<<<(unsigned int) ((C + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, ctx->candidates, ctx->cand_evalue.as<float>(), index, mode, max_mate_gap, evalue_cutoff, ctx->genomic_support());
 			HIP_CHECK(hipStreamSynchronize(s)); // the host vectors of the index are read by the copies above
 		}
 	}
@@ -388,6 +406,86 @@ extern "C" int agpu_filter_blacklisted_ranges(agpu_ctx* ctx, const agpu_range_ru
 extern "C" int agpu_recover_known_fusions(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rules, int32_t max_mate_gap, uint64_t* remaining) {
 	return run_range_rules(ctx, rules, n_rules, 1, FILTER_known_fusions, max_mate_gap, 0, remaining);
 }
+
+extern "C" int agpu_mark_genomic_support(agpu_ctx* ctx, const agpu_genomic_breakpoint* variants, uint32_t n_variants, int32_t max_distance, uint64_t* marked) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (n_variants > 0 && !variants) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	// one array sorted by (contigs + directions, first position, line of the file): the reference's nested index flattened
+	std::vector<uint32_t> order(n_variants);
+	for (uint32_t k = 0; k < n_variants; ++k) order[k] = k;
+	std::vector<uint64_t> keys(n_variants);
+	for (uint32_t k = 0; k < n_variants; ++k) keys[k] = genomic_breakpoint_key(variants[k].contig1, variants[k].contig2, variants[k].upstream1 != 0, variants[k].upstream2 != 0);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return keys[x] != keys[y] ? keys[x] < keys[y] : variants[x].position1 < variants[y].position1; });
+	std::vector<uint64_t> sorted_keys(n_variants); std::vector<int32_t> position1(n_variants), position2(n_variants);
+	for (uint32_t k = 0; k < n_variants; ++k) { sorted_keys[k] = keys[order[k]]; position1[k] = variants[order[k]].position1; position2[k] = variants[order[k]].position2; }
+	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& device_keys = ctx->scratch("wgs.keys"); DeviceBuffer& device_position1 = ctx->scratch("wgs.position1"); DeviceBuffer& device_position2 = ctx->scratch("wgs.position2");
+	const size_t C1 = std::max<uint32_t>(C, 1), V1 = std::max<uint32_t>(n_variants, 1);
+	ALLOC(counter, 16); ALLOC(device_keys, V1 * 8); ALLOC(device_position1, V1 * 4); ALLOC(device_position2, V1 * 4); ALLOC(ctx->cand_closest1, C1 * 4); ALLOC(ctx->cand_closest2, C1 * 4);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	HIP_CHECK(hipMemsetAsync(ctx->cand_closest1.ptr, 0xFF, C1 * 4, s));
+	HIP_CHECK(hipMemsetAsync(ctx->cand_closest2.ptr, 0xFF, C1 * 4, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && n_variants > 0) {
+		HIP_CHECK(hipMemcpyAsync(device_keys.ptr, sorted_keys.data(), (size_t) n_variants * 8, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(device_position1.ptr, position1.data(), (size_t) n_variants * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(device_position2.ptr, position2.data(), (size_t) n_variants * 4, hipMemcpyHostToDevice, s));
+		GenomicBreakpoints index = { device_keys.as<uint64_t>(), device_position1.as<int32_t>(), device_position2.as<int32_t>(), n_variants };
+		KernelTimer timer(ctx, "genomic_support_kernel", (uint64_t) C * 40);
+		genomic_support_kernel<<<tally_grid(C, BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->candidates, index, max_distance, ctx->params.max_itd_length, ctx->cand_closest1.as<int32_t>(), ctx->cand_closest2.as<int32_t>(), counter.as<unsigned int>());
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop)); // the host arrays of the index are read by the copies above
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 40;
+	ctx->genomic_support_marked = true;
+	unsigned int count = 0;
+	HIP_CHECK(hipMemcpy(&count, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (marked) *marked = count;
+	return AGPU_OK;
+}
+extern "C" int agpu_get_genomic_support(agpu_ctx* ctx, int32_t* closest1, int32_t* closest2) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	const uint32_t C = ctx->n_candidates;
+	if (!ctx->genomic_support_marked) { for (uint32_t c = 0; c < C; ++c) { if (closest1) closest1[c] = -1; if (closest2) closest2[c] = -1; } return AGPU_OK; }
+	if (closest1 && C > 0) HIP_CHECK(hipMemcpy(closest1, ctx->cand_closest1.ptr, (size_t) C * 4, hipMemcpyDeviceToHost));
+	if (closest2 && C > 0) HIP_CHECK(hipMemcpy(closest2, ctx->cand_closest2.ptr, (size_t) C * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+namespace {
+int run_genomic_support_filter(agpu_ctx* ctx, int mode, uint8_t filter_id, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->genomic_support_marked) { set_last_error("agpu_mark_genomic_support must run first"); return AGPU_ERR_INVALID; }
+	if (mode == 0 && ctx->confidence_candidates != ctx->n_candidates) { set_last_error("agpu_assign_confidence must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& counter = ctx->scratch("events.counter");
+	ALLOC(counter, 16);
+	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0) {
+		if (ctx->params.filter_enabled[filter_id])
+			genomic_support_filter_kernel<<<(unsigned int) ((C + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->genome, ctx->candidates, ctx->genomic_support(), ctx->scratch("events.confidence").as<uint8_t>(), mode);
+		event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 10;
+	unsigned int kept = 0;
+	HIP_CHECK(hipMemcpy(&kept, counter.ptr, 4, hipMemcpyDeviceToHost));
+	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+}
+extern "C" int agpu_filter_no_genomic_support(agpu_ctx* ctx, uint64_t* remaining) { return run_genomic_support_filter(ctx, 0, FILTER_no_genomic_support, remaining); }
+extern "C" int agpu_recover_genomic_support(agpu_ctx* ctx, uint64_t* remaining) { return run_genomic_support_filter(ctx, 1, FILTER_genomic_support, remaining); }
 
 extern "C" int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
@@ -417,7 +515,8 @@ extern "C" int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence) {
 		ConfidenceTables tables;
 		tables.pair_keys = pair_keys.as<uint64_t>(); tables.pair_members = pair_members.as<uint32_t>(); tables.gene2_keys = gene2_keys.as<uint64_t>(); tables.gene2_members = gene2_members.as<uint32_t>(); tables.n = C;
 		KernelTimer timer(ctx, "confidence_kernel", (uint64_t) C * 60);
-		confidence_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, t, ctx->cand_evalue.as<float>(), tables, result.as<uint8_t>());
+		confidence_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, t, ctx->cand_evalue.as<float>(), tables, ctx->genomic_support(), result.as<uint8_t>());
+		ctx->confidence_candidates = C;
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));

@@ -376,7 +376,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	ctx->n_candidates = 0;
 	if (M == 0) {
 		if (n_candidates) *n_candidates = 0;
-		ctx->fusions_done = true; ctx->candidates_imported = false; ctx->n_list_entries = 0;
+		ctx->fusions_done = true; ctx->candidates_imported = false; ctx->n_list_entries = 0; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
 		return AGPU_OK;
 	}
 
@@ -511,7 +511,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	// algorithmic bytes: fragment end columns + gene sets read once, one emission written, candidate table + lists written
 	ctx->last_bytes = n * (3 * (2 + 4 + 4 + 1) + 3 * (1 + GENE_INLINE * 4) + 1) + (uint64_t) M * sizeof(FusionEmission) + (uint64_t) C * 53 + (uint64_t) total_list * 4;
 	ctx->n_candidates = C;
-	ctx->fusions_done = true; ctx->candidates_imported = false;
+	ctx->fusions_done = true; ctx->candidates_imported = false; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
 	if (n_candidates) *n_candidates = C;
 	return AGPU_OK;
 }
@@ -674,6 +674,6 @@ extern "C" int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, cons
 	t.votes = ctx->cand_votes.as<uint32_t>();
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->n_candidates = (uint32_t) C; ctx->n_list_entries = 0;
-	ctx->fusions_done = true; ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->candidates_imported = true;
+	ctx->fusions_done = true; ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->candidates_imported = true; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
 	return AGPU_OK;
 }

@@ -504,6 +504,11 @@ AGPU_HD bool isoform_is_recovered(const CandidateTable& t, uint32_t c, const uin
 // fusions_by_gene[gene1] and [gene2]; every candidate that can satisfy (a) or (b) shares gene1 (first list) or gene2 (second list) with the
 // candidate, so the walks are runs of two sorted orders here: by (gene1, gene2) and by gene2.
 enum { CONFIDENCE_LOW = 0, CONFIDENCE_MEDIUM = 1, CONFIDENCE_HIGH = 2 };
+// closest pair of genomic breakpoints per candidate (structural variants from WGS, -d; genomic_support_core.hpp); null = no file given: every candidate -1
+struct GenomicSupport {
+	const int32_t* closest1; const int32_t* closest2;
+	AGPU_HD bool has(uint32_t c) const { return closest1 != nullptr && closest1[c] >= 0; }
+};
 struct ConfidenceTables {
 	const uint64_t* pair_keys; const uint32_t* pair_members;   // candidates sorted by gene1 << 32 | gene2
 	const uint64_t* gene2_keys; const uint32_t* gene2_members; // candidates sorted by gene2
@@ -537,7 +542,7 @@ AGPU_HD bool confidence_has_other_spliced_event(const CandidateTable& t, const C
 	}
 	return false;
 }
-AGPU_HD uint8_t candidate_confidence(const AnnotationView& ann, const CoverageView& coverage, const CandidateTable& t, const float* evalues, const ConfidenceTables& tables, uint32_t c) {
+AGPU_HD uint8_t candidate_confidence(const AnnotationView& ann, const CoverageView& coverage, const CandidateTable& t, const float* evalues, const ConfidenceTables& tables, uint32_t c, const GenomicSupport& wgs = GenomicSupport{ nullptr, nullptr }) {
 	AGPU_FP_AS_WRITTEN
 	if (t.filter[c] != FILTER_none) return CONFIDENCE_LOW; // discarded events get low confidence, no matter what
 	const uint32_t flags = t.flags[c], split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c], supporting_reads = split_reads1 + split_reads2 + discordant_mates;
@@ -579,6 +584,18 @@ AGPU_HD uint8_t candidate_confidence(const AnnotationView& ann, const CoverageVi
 		if (split_reads1 + split_reads2 == 0 || split_reads1 + discordant_mates == 0 || split_reads2 + discordant_mates == 0) --confidence; // reads from both ends are expected
 		else if ((split_reads1 + split_reads2) * 20 < discordant_mates) --confidence;                                                 // split reads and discordant mates should be balanced
 		else if (evalue > 0.2 || coverage_fraction < 0.01) confidence = CONFIDENCE_MEDIUM;                                            // not overwhelming compared to the coverage
+	}
+	// a supporting structural variant (:391-397)
+	if (confidence < CONFIDENCE_HIGH && wgs.has(c)) {
+		int32_t distance1 = t.breakpoint1[c] - wgs.closest1[c], distance2 = t.breakpoint2[c] - wgs.closest2[c], span = t.breakpoint2[c] - t.breakpoint1[c];
+		if (distance1 < 0) distance1 = -distance1;
+		if (distance2 < 0) distance2 = -distance2;
+		if (span < 0) span = -span;
+		if ((evalue < 0.3 && supporting_reads >= 2) ||                      // good e-value, or
+		    (spliced1 && spliced2 && !same_gene) ||                         // recovered due to splicing, or
+		    distance1 + distance2 < 20000 ||                                // genomic breakpoints very close to the transcriptomic ones, or
+		    (t.contigs[c] >> 16) != (t.contigs[c] & 0xFFFF) || (span > 1000000 && !same_gene)) // a distant translocation
+			++confidence;
 	}
 	return (uint8_t) confidence;
 }

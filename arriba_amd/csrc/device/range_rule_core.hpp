@@ -102,7 +102,7 @@ AGPU_HD bool known_fusion_rule_recovers(const AnnotationView& ann, const Coverag
 }
 
 // which candidates are looked at (blacklist :229-230 without genomic support; known fusions :43-50)
-AGPU_HD bool blacklist_considers(const CandidateTable& t, uint32_t c) { return t.filter[c] == FILTER_none; }
+AGPU_HD bool blacklist_considers(const CandidateTable& t, uint32_t c, const GenomicSupport& wgs = GenomicSupport{ nullptr, nullptr }) { return t.filter[c] == FILTER_none || wgs.has(c); } // a filtered candidate with genomic support may be recovered later
 AGPU_HD bool known_fusions_considers(const CandidateTable& t, uint32_t c) { return t.gene1[c] != t.gene2[c] && (t.filter[c] == FILTER_relative_support || t.filter[c] == FILTER_min_support); }
 
 // walks the rules in the genome bins of the candidate (breakpoint1, breakpoint2, gene1, gene2; :235-240, :53-57); mode 0 = blacklist, 1 = known fusions

@@ -115,6 +115,8 @@ template <class Feature> void make_flat_index(const std::vector<Feature>& featur
 // reference: source/arriba.cpp:166-184
 void compute_exonic_length(Annotation& annotation, const FlatIndex& exon_index);
 
+// structural variants from WGS (-d): Arriba's four-column format or VCF (BND, INV, DEL, DUP); reference: source/filter_genomic_support.cpp:15-165
+void load_genomic_breakpoints(const std::string& path, const Contigs& contigs, std::vector<agpu_genomic_breakpoint>& variants);
 void load_protein_domains(const std::string& path, const Contigs& contigs, const Annotation& annotation, std::vector<ProteinDomain>& domains, FlatIndex& index);
 
 // host-side queries on the flat index (used by ingest and by host-only stages)

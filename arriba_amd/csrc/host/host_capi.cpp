@@ -34,6 +34,7 @@ struct ahost_session {
 	IngestResult ingest;
 	bool have_batch = false;
 	Tags tags; std::vector<ProteinDomain> protein_domains; FlatIndex protein_domain_index;
+	std::vector<agpu_genomic_breakpoint> genomic_breakpoints;
 	std::vector<agpu_range_rule> range_rules[2]; // [0] known fusions, [1] blacklist (keywords allowed)
 
 	// flattened tables backing the views
@@ -202,6 +203,15 @@ extern "C" {
 
 const char* ahost_last_error(void) { return g_error.c_str(); }
 
+int ahost_load_genomic_breakpoints(ahost_session* session, const char* path, const agpu_genomic_breakpoint** variants, uint32_t* n_variants) {
+	if (!session || !path || !variants || !n_variants) { g_error = "null argument"; return -1; }
+	try {
+		load_genomic_breakpoints(path, session->contigs, session->genomic_breakpoints);
+		*variants = session->genomic_breakpoints.empty() ? nullptr : session->genomic_breakpoints.data();
+		*n_variants = (uint32_t) session->genomic_breakpoints.size();
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
 int ahost_load_tags(ahost_session* session, const char* path) {
 	if (!session || !path) { g_error = "null argument"; return -1; }
 	try { load_tags(path, session->contigs, session->annotation, session->tags); return 0; }
@@ -221,7 +231,7 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 		t.n_candidates = table->n_candidates; t.gene1 = table->gene1; t.gene2 = table->gene2; t.contigs = table->contigs; t.breakpoint1 = table->breakpoint1; t.breakpoint2 = table->breakpoint2;
 		t.flags = table->flags; t.filter = table->filter; t.split_reads1 = table->split_reads1; t.split_reads2 = table->split_reads2; t.discordant_mates = table->discordant_mates;
 		t.list_offset = table->list_offset; t.read_lists = table->read_lists; t.evalue = table->evalue; t.confidence = table->confidence; t.iteration_rank = table->iteration_rank;
-		t.read_filter = table->read_filter; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
+		t.read_filter = table->read_filter; t.closest_genomic_breakpoint1 = table->closest_genomic_breakpoint1; t.closest_genomic_breakpoint2 = table->closest_genomic_breakpoint2; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
 		const OutputExtras extras = { &session->tags, &session->protein_domains, &session->protein_domain_index, max_mate_gap, fill_sequence_gaps != 0 };
 		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
 		return 0;

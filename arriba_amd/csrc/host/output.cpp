@@ -341,7 +341,12 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			const std::string domains_3 = writer.retained_domains(contig_3, breakpoint_3, strand_3, f.strands_ambiguous, gene_3, upstream_3, *extras.protein_domains, *extras.protein_domain_index);
 			if (!domains_5.empty() || !domains_3.empty()) domains = domains_5 + "|" + domains_3;
 		}
-		text += "\t" + domains + "\t.\t."; // closest genomic breakpoints: no structural variants file
+		// closest genomic breakpoints as <contig>:<position>(<distance to the transcriptomic breakpoint>) (:1193-1203)
+		position_t genomic_5 = table.closest_genomic_breakpoint1 != NULL ? table.closest_genomic_breakpoint1[f.candidate] : -1, genomic_3 = table.closest_genomic_breakpoint2 != NULL ? table.closest_genomic_breakpoint2[f.candidate] : -1;
+		if (!f.transcript_start_gene1) std::swap(genomic_5, genomic_3);
+		text += "\t" + domains;
+		text += "\t" + (genomic_5 >= 0 ? contigs.original_names[contig_5] + ":" + std::to_string((long long) genomic_5 + 1) + "(" + std::to_string((long long) abs(breakpoint_5 - genomic_5)) + ")" : std::string("."));
+		text += "\t" + (genomic_3 >= 0 ? contigs.original_names[contig_3] + ":" + std::to_string((long long) genomic_3 + 1) + "(" + std::to_string((long long) abs(breakpoint_3 - genomic_3)) + ")" : std::string("."));
 		// reads discarded by a filter, by name of the filter
 		std::map<std::string, unsigned> filters;
 		if (f.filter != 0) filters[f.filter < N_FILTER_NAMES ? FILTER_NAMES[f.filter] : "?"] = 0;

@@ -13,6 +13,7 @@ struct FusionTable {
 	const uint32_t* list_offset; const uint32_t* read_lists;
 	const float* evalue; const uint8_t* confidence; const uint32_t* iteration_rank;
 	const uint8_t* read_filter;
+	const int32_t* closest_genomic_breakpoint1; const int32_t* closest_genomic_breakpoint2; // NULL = none
 	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end; // GTF genes + dummy genes (agpu_get_gene_table)
 };
 struct OutputExtras { const Tags* tags; const std::vector<ProteinDomain>* protein_domains; const FlatIndex* protein_domain_index; int max_mate_gap; bool fill_sequence_gaps; }; // -t, -p (NULL = not given), -I

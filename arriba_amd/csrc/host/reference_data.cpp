@@ -893,4 +893,88 @@ void load_protein_domains(const std::string& path, const Contigs& contigs, const
 	make_flat_index(domains, std::max(domains.size(), contigs.size()), index);
 }
 
+// ---- structural variants from whole-genome sequencing (-d; reference: source/filter_genomic_support.cpp:15-165) -----------------------
+
+namespace {
+// reference: parse_breakpoint (:15-36)
+bool parse_genomic_breakpoint(std::string text, const Contigs& contigs, uint32_t& contig, int32_t& position) {
+	const size_t separator = text.find_last_of(':');
+	if (separator < text.size()) text[separator] = '\t';
+	FieldCursor fields(text, '\t');
+	std::string contig_name;
+	fields.next(contig_name);
+	std::map<std::string, contig_t>::const_iterator known = contigs.by_name.find(remove_chr(contig_name));
+	if (known == contigs.by_name.end()) return false;
+	contig = known->second;
+	int value = 0;
+	fields.next(value);
+	if (fields.failed) return false;
+	position = value - 1;
+	return true;
+}
+bool parse_direction(const std::string& text, bool& upstream) {
+	if (text == "upstream" || text == "-") upstream = true; else if (text == "downstream" || text == "+") upstream = false; else return false;
+	return true;
+}
+// reference: parse_vcf_info (:49-60)
+bool parse_vcf_info(const std::string& info, const std::string& field, std::string& value) {
+	size_t start;
+	if (info.substr(0, field.size() + 1) == field + "=") start = field.size() + 1;
+	else { start = info.find(";" + field + "="); if (start >= info.size()) return false; start += field.size() + 2; }
+	value = info.substr(start, info.find(';', start) - start);
+	return true;
+}
+}
+
+void load_genomic_breakpoints(const std::string& path, const Contigs& contigs, std::vector<agpu_genomic_breakpoint>& variants) {
+	variants.clear();
+	LineReader file(path);
+	std::string line;
+	while (file.getline(line)) {
+		if (line.empty() || line[0] == '#') continue;
+		// the four-column format first: contig1:position1, contig2:position2, direction1, direction2
+		FieldCursor fields(line, '\t');
+		std::string breakpoint1, breakpoint2, direction_text1, direction_text2, sv_type;
+		fields.next(breakpoint1); fields.next(breakpoint2); fields.next(direction_text1); fields.next(direction_text2);
+		uint32_t contig1 = 0, contig2 = 0; int32_t position1 = 0, position2 = 0; bool upstream1 = false, upstream2 = false;
+		bool parsed = parse_genomic_breakpoint(breakpoint1, contigs, contig1, position1) && parse_genomic_breakpoint(breakpoint2, contigs, contig2, position2) && parse_direction(direction_text1, upstream1) && parse_direction(direction_text2, upstream2);
+		if (!parsed) { // then VCF
+			FieldCursor vcf(line, '\t');
+			std::string chrom, pos, alt, info, filter, ignore;
+			vcf.next(chrom); vcf.next(pos); vcf.next(ignore); vcf.next(ignore); vcf.next(alt); vcf.next(ignore); vcf.next(filter); vcf.next(info);
+			bool failed = !parse_vcf_info(info, "SVTYPE", sv_type), skip = false;
+			if (!failed && sv_type == "BND") {
+				const size_t opening = alt.find('['), closing = alt.find(']');
+				const char bracket = opening < closing ? '[' : ']';
+				const size_t first = std::min(opening, closing), second = alt.find(bracket, first + 1);
+				if (first >= alt.size() || second >= alt.size()) {
+					if (!alt.empty() && (alt[0] == '.' || alt[alt.size() - 1] == '.')) skip = true; // a single breakend: silently ignored
+					else failed = true;
+				} else {
+					upstream1 = first == 0; upstream2 = bracket == '[';
+					breakpoint2 = alt.substr(first + 1, second - first - 1);
+				}
+			} else if (!failed) {
+				std::string end;
+				if (!parse_vcf_info(info, "END", end)) failed = true;
+				else {
+					breakpoint2 = chrom + ":" + end;
+					if (sv_type == "INV") { upstream1 = false; upstream2 = false; }
+					else if (sv_type == "DEL") { upstream1 = false; upstream2 = true; }
+					else if (sv_type == "DUP") { upstream1 = true; upstream2 = false; }
+					else failed = true;
+				}
+			}
+			if (skip) continue;
+			if (!failed && (!parse_genomic_breakpoint(chrom + ":" + pos, contigs, contig1, position1) || !parse_genomic_breakpoint(breakpoint2, contigs, contig2, position2))) failed = true;
+			if (failed) { fprintf(stderr, "WARNING: failed to parse line: %s\n", line.c_str()); continue; }
+			if (filter != "PASS") continue;
+		}
+		if (contig2 < contig1 || (contig2 == contig1 && position2 < position1)) { std::swap(contig1, contig2); std::swap(position1, position2); std::swap(upstream1, upstream2); } // indexed by the smaller coordinate
+		agpu_genomic_breakpoint variant = { contig1, contig2, position1, position2, (uint8_t) upstream1, (uint8_t) upstream2, { 0, 0 } };
+		variants.push_back(variant);
+		if (sv_type == "INV") { variant.upstream1 = variant.upstream2 = 1; variants.push_back(variant); } // the VCF type INV stands for two breakpoints
+	}
+}
+
 }

@@ -245,7 +245,8 @@ class DevicePipeline(object):
         self.estimate_fragment_length()
         return self.filter_reads()
 
-    def run_workflow(self, output_file, discarded_output_file=None, blacklist_file=None, known_fusions_file=None, tags_file=None, protein_domains_file=None, strandedness=None, evalue_cutoff=0.3,
+    def run_workflow(self, output_file, discarded_output_file=None, blacklist_file=None, known_fusions_file=None, tags_file=None, protein_domains_file=None, genomic_breakpoints_file=None,
+                     max_genomic_breakpoint_distance=100000, strandedness=None, evalue_cutoff=0.3,
                      min_itd_support=10, min_itd_allele_fraction=0.07, high_expression_quantile=0.998, min_spliced_events=4, min_anchor_length=23,
                      max_homolog_identity=0.3, max_itd_length=100, fill_sequence_gaps=False, log=None):
         """The reference's main() behind read_chimeric_alignments (source/arriba.cpp:119-610) with its default parameters: the read-level cascade, find_fusions,
@@ -255,6 +256,8 @@ class DevicePipeline(object):
         self.run_read_level(strandedness)
         note("find_fusions", self.find_fusions())
         self.upload_coverage()
+        if genomic_breakpoints_file:
+            note("mark_genomic_support", self.mark_genomic_support(genomic_breakpoints_file, max_genomic_breakpoint_distance))
         note("merge_adjacent_fusions", self.merge_adjacent_fusions())
         note("filter_multimappers", self.filter_multimappers()[0])
         self.estimate_expected_fusions()
@@ -269,6 +272,9 @@ class DevicePipeline(object):
         note("select_most_supported_breakpoints", self.select_most_supported_breakpoints())
         note("filter_marginal_read_through", self.filter_marginal_read_through())
         note("recover_many_spliced", self.recover_many_spliced(min_spliced_events))
+        if genomic_breakpoints_file:
+            self.assign_confidence()  # filter_no_genomic_support looks at the confidence (source/arriba.cpp:516-523)
+            note("filter_no_genomic_support", self.filter_no_genomic_support())
         if blacklist_file:
             note("filter_blacklisted_ranges", self.filter_blacklisted_ranges(blacklist_file, evalue_cutoff))
         note("filter_short_anchor", self.filter_short_anchor(min_anchor_length))
@@ -277,6 +283,8 @@ class DevicePipeline(object):
         self.make_kmer_index()
         note("filter_homologs", self.filter_homologs(max_homolog_identity))
         note("filter_mismappers", self.filter_mismappers()[0])
+        if genomic_breakpoints_file:
+            note("recover_genomic_support", self.recover_genomic_support())
         note("select_most_supported_breakpoints", self.select_most_supported_breakpoints())
         note("recover_isoforms", self.recover_isoforms())
         if tags_file:
@@ -402,6 +410,7 @@ class DevicePipeline(object):
         columns["confidence"] = np.ascontiguousarray(self.assign_confidence())
         columns["iteration_rank"] = np.ascontiguousarray(self.candidate_iteration_order(), dtype=np.uint32)
         columns["read_filter"] = np.ascontiguousarray(self.filters(), dtype=np.uint8)
+        columns["closest_genomic_breakpoint1"], columns["closest_genomic_breakpoint2"] = (np.ascontiguousarray(column) for column in self.genomic_support())
         genes = self.gene_table()
         columns["gene_contig"], columns["gene_start"], columns["gene_end"] = (np.ascontiguousarray(genes[key]) for key in ("contig", "start", "end"))
         view = _capi.FusionTable()
@@ -413,6 +422,29 @@ class DevicePipeline(object):
             print_extra_info = not discarded
         if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps)) != 0:
             raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
+
+    def mark_genomic_support(self, path, max_distance=100000):
+        """reference: mark_genomic_support, source/filter_genomic_support.cpp:81-219 (-d, -D); returns the number of candidates with a supporting structural variant"""
+        variants, count, marked = POINTER(_capi.GenomicBreakpoint)(), c_uint32(), c_uint64()
+        if self.session._lib.ahost_load_genomic_breakpoints(self.session._session, path.encode(), byref(variants), byref(count)) != 0:
+            raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
+        self._check(self.api.mark_genomic_support(self.ctx, variants, count.value, max_distance, byref(marked)))
+        self._record("mark_genomic_support")
+        return marked.value
+
+    def genomic_support(self):
+        """closest genomic breakpoints of every candidate (-1 = none)"""
+        closest1, closest2 = np.zeros(max(self.n_candidates, 1), dtype=np.int32), np.zeros(max(self.n_candidates, 1), dtype=np.int32)
+        self._check(self.api.get_genomic_support(self.ctx, closest1.ctypes.data, closest2.ctypes.data))
+        return closest1[:self.n_candidates], closest2[:self.n_candidates]
+
+    def filter_no_genomic_support(self):
+        """reference: filter_no_genomic_support, source/filter_genomic_support.cpp:401-417 (behind assign_confidence)"""
+        return self._event_stage("filter_no_genomic_support")
+
+    def recover_genomic_support(self):
+        """reference: recover_genomic_support, source/filter_genomic_support.cpp:419-444"""
+        return self._event_stage("recover_genomic_support")
 
     def assign_confidence(self):
         """reference: assign_confidence, source/filter_genomic_support.cpp:222-399; returns the confidence (0 low, 1 medium, 2 high) of every candidate"""

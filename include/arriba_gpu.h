@@ -329,6 +329,15 @@ int agpu_filter_blacklisted_ranges(agpu_ctx* ctx, const agpu_range_rule* rules, 
 /* recover_known_fusions (source/recover_known_fusions.cpp:14-100, called at source/arriba.cpp:475-478): a candidate discarded for low support
  * (relative_support, min_support) between different genes that a line matches comes back.  Needs the coverage. */
 int agpu_recover_known_fusions(agpu_ctx* ctx, const agpu_range_rule* rules, uint32_t n_rules, int32_t max_mate_gap, uint64_t* remaining);
+/* Structural variants from whole-genome sequencing (-d; source/filter_genomic_support.cpp).  ahost_load_genomic_breakpoints (arriba_host.h) parses the file.
+ * agpu_mark_genomic_support (mark_genomic_support, :81-219, called at source/arriba.cpp:415-418 behind find_fusions; max_distance = -D, default 100000):
+ *   the closest pair of genomic breakpoints that can explain a candidate; used by the blacklist, assign_confidence, the two filters below and the output.
+ * agpu_filter_no_genomic_support (:401-417, source/arriba.cpp:516-523; behind agpu_assign_confidence), agpu_recover_genomic_support (:419-444, source/arriba.cpp:568-571). */
+typedef struct { uint32_t contig1, contig2; int32_t position1, position2; uint8_t upstream1, upstream2, reserved[2]; } agpu_genomic_breakpoint; /* contig1/position1 = the smaller coordinate */
+int agpu_mark_genomic_support(agpu_ctx* ctx, const agpu_genomic_breakpoint* variants, uint32_t n_variants, int32_t max_distance, uint64_t* marked);
+int agpu_get_genomic_support(agpu_ctx* ctx, int32_t* closest_genomic_breakpoint1 /* [n_candidates], -1 = none */, int32_t* closest_genomic_breakpoint2);
+int agpu_filter_no_genomic_support(agpu_ctx* ctx, uint64_t* remaining);
+int agpu_recover_genomic_support(agpu_ctx* ctx, uint64_t* remaining);
 /* assign_confidence (source/filter_genomic_support.cpp:222-399, called at source/arriba.cpp:587-589; without structural variants from WGS).
  * confidence: [n_candidates] 0 = low, 1 = medium, 2 = high (source/common.hpp:224-227); may be NULL */
 int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence);

@@ -52,6 +52,7 @@ typedef struct {
 	const uint32_t* read_lists;
 	const float* evalue; const uint8_t* confidence; const uint32_t* iteration_rank;
 	const uint8_t* read_filter;    /* [fragments of the session's batch] */
+	const int32_t* closest_genomic_breakpoint1; const int32_t* closest_genomic_breakpoint2; /* agpu_get_genomic_support; NULL = no structural variants given */
 	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end;
 } ahost_fusion_table;
 int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap,
@@ -59,6 +60,9 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 /* Optional inputs of the output files: a tags file (-t; load_tags, source/annotate_tags.cpp:11-44) and protein domains in GFF3 (-p; load_protein_domains,
  * source/annotate_protein_domains.cpp:33-121).  Loaded into the session; ahost_write_fusions fills the columns `tags` and `retained_protein_domains` from them. */
 int ahost_load_tags(ahost_session* session, const char* path);
+/* Structural variants from WGS (-d) for agpu_mark_genomic_support: Arriba's four-column format or VCF (source/filter_genomic_support.cpp:15-165).  The
+ * variants stay valid until the next call or ahost_close. */
+int ahost_load_genomic_breakpoints(ahost_session* session, const char* path, const agpu_genomic_breakpoint** variants, uint32_t* n_variants);
 int ahost_load_protein_domains(ahost_session* session, const char* path);
 
 const agpu_annotation_view* ahost_annotation_view(ahost_session* session);

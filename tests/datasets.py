@@ -53,6 +53,9 @@ DATASETS = {
                                  "fusions.*_before_filter_mismappers.tsv", "fusions.*_filter_mismappers.tsv"], "reference_env": {"ARRIBA_ORACLE_DUMP_LISTS": "0"}},
     # toy3k with -I: the fusion transcripts completed from the assembly along the chosen transcripts (only the output files are kept)
     "toy3k_fill": {"args": ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"], "reference_extra_args": ["-I"], "golden_files": ["scalars.tsv"]},
+    # rules8k with structural variants from WGS (-d): genomic support marked, filter_no_genomic_support, recover_genomic_support, confidence, output columns
+    "wgs8k": {"args": ["--seed", "17", "--fragments", "8000", "--contigs", "4", "--contig-len", "300000", "--junctions", "120", "--rule-files"], "rule_files": True, "structural_variants": True,
+              "golden_files": ["scalars.tsv", "fusions.*_mark_genomic_support.tsv", "fusions.*_filter_no_genomic_support.tsv", "fusions.*_recover_genomic_support.tsv", "fusions.*_assign_confidence.tsv"], "reference_env": {"ARRIBA_ORACLE_DUMP_LISTS": "0"}},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},
@@ -80,6 +83,8 @@ def run_reference(prefix, dump_directory, spec=None, extra_args=(), disable_filt
     command = [ARRIBA_REF_DUMP, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv"] + (["-f", ",".join(disabled)] if disabled else []) + list(extra_args)
     if with_rules:
         command += ["-b", prefix + ".blacklist.tsv", "-k", prefix + ".known_fusions.tsv", "-t", prefix + ".tags.tsv", "-p", prefix + ".protein_domains.gff3"]
+        if (spec or {}).get("structural_variants"):  # -d: structural variants from WGS
+            command += ["-d", prefix + ".sv.tsv"]
     result = subprocess.run(command, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     if result.returncode != 0:
         raise RuntimeError("reference failed:\n" + result.stdout)

@@ -23,6 +23,7 @@
 #include "../../arriba_amd/csrc/device/in_vitro_host.hpp"
 #include "../../arriba_amd/csrc/device/homolog_host.hpp"
 #include "../../arriba_amd/csrc/device/range_rule_host.hpp"
+#include "../../arriba_amd/csrc/device/genomic_support_core.hpp"
 #include "../../arriba_amd/csrc/device/index_bins.hpp"
 #include "../../arriba_amd/csrc/device/multimapper_core.hpp"
 #include <map>

@@ -613,11 +613,12 @@ def check_output_files(session, pipeline, golden, directory, skip_columns=(), re
     return tuple(results)
 
 
-def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None, fill_sequence_gaps=False):
+def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None, fill_sequence_gaps=False, structural_variants=False):
     """FASTA + GTF + BAM (+ blacklist / known fusions) -> fusions.tsv, discarded.tsv through DevicePipeline.run_workflow with the reference's default
     parameters: nothing is taken from the reference, not even the parameters its log prints.  Both files must equal the reference's byte for byte, and
     every "(remaining=N)" of its log must come out."""
     import gzip
+    import re
     from arriba_amd.pipeline import DevicePipeline
     session = open_session(prefix)
     pipeline = DevicePipeline(session, api=api)
@@ -625,6 +626,7 @@ def check_workflow(prefix, golden, directory, api=None, rules=False, reference_p
     outputs = [os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv")]
     pipeline.run_workflow(outputs[0], outputs[1], blacklist_file=prefix + ".blacklist.tsv" if rules else None, known_fusions_file=prefix + ".known_fusions.tsv" if rules else None,
                           tags_file=prefix + ".tags.tsv" if rules else None, protein_domains_file=prefix + ".protein_domains.gff3" if rules else None,
+                          genomic_breakpoints_file=prefix + ".sv.tsv" if structural_variants else None,
                           fill_sequence_gaps=fill_sequence_gaps, log=lambda stage, remaining: stages.append((stage, remaining)))
     for mine, name in zip(outputs, ("fusions.tsv", "discarded.tsv")):
         source = reference_prefix + "." + name if reference_prefix else os.path.join(golden, name)
@@ -636,12 +638,14 @@ def check_workflow(prefix, golden, directory, api=None, rules=False, reference_p
                 "filter_in_vitro": "Filtering in vitro-generated fusions", "recover_both_spliced": "Searching for fusions with spliced split reads", "filter_marginal_read_through": "Filtering read-through fusions with breakpoints near",
                 "recover_many_spliced": "Searching for fusions with >=\\d+ spliced events", "filter_blacklisted_ranges": "Filtering blacklisted fusions", "filter_short_anchor": "Filtering fusions with anchors",
                 "filter_end_to_end": "Filtering end-to-end fusions", "filter_no_coverage": "Filtering fusions with no coverage", "filter_homologs": "Filtering genes with", "filter_mismappers": "Re-aligning chimeric reads",
-                "recover_isoforms": "Searching for additional isoforms"}
+                "recover_isoforms": "Searching for additional isoforms", "filter_no_genomic_support": "Filtering low-confidence events with no support from WGS", "recover_genomic_support": "Searching for fusions with support from WGS"}
     seen_select_best = 0
     for stage, remaining in stages:
         if stage == "select_most_supported_breakpoints":
             assert remaining == logged_remaining(log, "Selecting best breakpoints", seen_select_best), (stage, remaining)
             seen_select_best += 1
+        elif stage == "mark_genomic_support":
+            assert remaining == int(re.search(r"Marking fusions with support[^\n]*\(marked=(?:WARNING:[^\n]*\n)*(\d+)\)", log).group(1)), (stage, remaining)
         elif stage in patterns:
             assert remaining == logged_remaining(log, patterns[stage]), (stage, remaining, logged_remaining(log, patterns[stage]))
     return stages

@@ -390,14 +390,14 @@ def test_output_files_equal_the_reference(built, dataset_files, tmp_path):
 def test_workflow_from_input_files_to_output_files(built, dataset_files, tmp_path):
     """FASTA + GTF + BAM (+ blacklist and known fusions) -> fusions.tsv + discarded.tsv on the GPU through DevicePipeline.run_workflow with the reference's
     default parameters, nothing taken from the reference: both files byte-identical to the reference's (golden datasets; a live run of 150 k fragments)"""
-    for name in ("toy3k", "rules8k", "homologs8k", "toy3k_fill"):
+    for name in ("toy3k", "rules8k", "homologs8k", "toy3k_fill", "wgs8k"):
         os.makedirs(str(tmp_path / name))
-        stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path / name), rules=name == "rules8k", fill_sequence_gaps=name == "toy3k_fill")
+        stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path / name), rules=name in ("rules8k", "wgs8k"), fill_sequence_gaps=name == "toy3k_fill", structural_variants=name == "wgs8k")
         assert stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
     if not datasets.reference_available():
         return
     spec = {"args": ["--seed", "59", "--fragments", "150000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15", "--rule-files", "--homolog-families", "20",
-                     "--itd-hotspots", "3", "--itd-hotspot-frac", "0.02"], "rule_files": True}
+                     "--itd-hotspots", "3", "--itd-hotspot-frac", "0.02"], "rule_files": True, "structural_variants": True}
     prefix = datasets.generate(spec, str(tmp_path))
     dump = str(tmp_path / "dump")
     os.makedirs(dump)
@@ -411,5 +411,5 @@ def test_workflow_from_input_files_to_output_files(built, dataset_files, tmp_pat
     with open(os.path.join(dump, "reference.log"), "w") as out:
         out.write(log)
     os.makedirs(str(tmp_path / "mine"))
-    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), rules=True, reference_prefix=prefix)
-    assert stages[-1][1] > 300
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), rules=True, reference_prefix=prefix, structural_variants=True)
+    assert stages[-1][1] > 300 and dict(stages)["mark_genomic_support"] > 10000

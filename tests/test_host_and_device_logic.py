@@ -324,11 +324,12 @@ def test_output_files_equal_the_reference(name, dataset_files, emu_api, tmp_path
     assert fusions > 40 and discarded > 1500
 
 
-@pytest.mark.parametrize("name", ["toy3k", "rules8k", "toy3k_fill"])
+@pytest.mark.parametrize("name", ["toy3k", "rules8k", "toy3k_fill", "wgs8k"])
 def test_workflow_from_input_files_to_output_files(name, dataset_files, emu_api, tmp_path):
     """FASTA + GTF + BAM (+ blacklist and known fusions) -> fusions.tsv + discarded.tsv through DevicePipeline.run_workflow with the reference's default
     parameters and nothing taken from the reference: both files byte-identical, every "(remaining=N)" of the reference's log reproduced"""
-    stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path), api=emu_api, rules=name == "rules8k", fill_sequence_gaps=name == "toy3k_fill")  # toy3k_fill: -I
+    stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path), api=emu_api, rules=name in ("rules8k", "wgs8k"), fill_sequence_gaps=name == "toy3k_fill",
+                                   structural_variants=name == "wgs8k")  # toy3k_fill: -I; wgs8k: -d (structural variants from WGS: marked, filtered, recovered, confidence, output columns)
     assert len(stages) >= 18 and stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
 
 

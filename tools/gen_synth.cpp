@@ -539,6 +539,43 @@ void Generator::write_rule_files(const std::string& blacklist_path, const std::s
 	           "1\tsynth\tprotein_domain\t10\t20\t.\t+\t.\tgene_name=%s;gene_id=%s\nchrNowhere\tsynth\tprotein_domain\t10\t20\t.\t+\t.\tName=Lost;gene_name=%s;gene_id=%s\n",
 	        genes_[0].name.c_str(), genes_[0].id.c_str(), genes_[0].name.c_str(), genes_[0].id.c_str(), genes_[0].name.c_str(), genes_[0].id.c_str());
 	fclose(f);
+
+	// structural variants from WGS (-d): genomic breakpoints close to the junctions, in Arriba's four-column format and as VCF records (BND, DEL, DUP,
+	// INV), some of them not usable (filter not PASS, single breakends, malformed lines)
+	const std::string variants_path = known_fusions_path.substr(0, known_fusions_path.size() - std::string("known_fusions.tsv").size()) + "sv.tsv";
+	f = fopen(variants_path.c_str(), "w");
+	if (f == NULL) throw std::runtime_error("cannot write " + variants_path);
+	fprintf(f, "##fileformat=VCFv4.2 (mixed with Arriba's own format)\n");
+	for (size_t j = 0; j < junctions.size(); ++j) {
+		const Junction& junction = junctions[j];
+		if (!rng.chance(0.6)) continue;
+		for (int variant = 0; variant < 2; ++variant) { // the directions as the junction table has them, and inverted: one of the two is how the caller sees the event
+			const bool upstream_a = variant == 0 ? junction.a.upstream : !junction.a.upstream, upstream_b = variant == 0 ? junction.b.upstream : !junction.b.upstream;
+			const int spread = rng.chance(0.2) ? 150000 : 3000; // some farther away than -D allows
+			const int position_a = std::max(1, junction.a.bp + 1 + (upstream_a ? -rng.range(0, spread) + rng.range(0, 7) : rng.range(0, spread) - rng.range(0, 7)));
+			const int position_b = std::max(1, junction.b.bp + 1 + (upstream_b ? -rng.range(0, spread) + rng.range(0, 7) : rng.range(0, spread) - rng.range(0, 7)));
+			const std::string contig_a = contig_names_[junction.a.contig], contig_b = contig_names_[junction.b.contig];
+			switch (rng.range(0, 5)) {
+				case 0: case 1: fprintf(f, "%s:%d\t%s:%d\t%s\t%s\n", contig_a.c_str(), position_a, contig_b.c_str(), position_b, upstream_a ? "upstream" : "downstream", upstream_b ? "upstream" : "downstream"); break;
+				case 2: fprintf(f, "chr%s:%d\t%s:%d\t%s\t%s\n", contig_a.c_str(), position_a, contig_b.c_str(), position_b, upstream_a ? "-" : "+", upstream_b ? "-" : "+"); break;
+				case 3: { // VCF breakend
+					const char bracket = upstream_b ? '[' : ']';
+					const std::string mate = contig_b + ":" + std::to_string(position_b);
+					const std::string alt = upstream_a ? std::string(1, bracket) + mate + bracket + "N" : "N" + std::string(1, bracket) + mate + bracket;
+					fprintf(f, "%s\t%d\tbnd_%zu\tN\t%s\t.\t%s\tSVTYPE=BND;MATEID=x\n", contig_a.c_str(), position_a, j, alt.c_str(), rng.chance(0.85) ? "PASS" : "LowQual");
+					break;
+				}
+				case 4: if (junction.a.contig == junction.b.contig) { // VCF with END: the type sets the directions
+					static const char* const types[] = { "DEL", "DUP", "INV" };
+					fprintf(f, "%s\t%d\tsv_%zu\tN\t<%s>\t.\tPASS\tIMPRECISE;SVTYPE=%s;END=%d\n", contig_a.c_str(), std::min(position_a, position_b), j, types[j % 3], types[j % 3], std::max(position_a, position_b));
+					break;
+				} // else: fall through to a breakend without a mate
+				default: fprintf(f, "%s\t%d\tsingle_%zu\tN\tN.\t.\tPASS\tSVTYPE=BND\n", contig_a.c_str(), position_a, j); break;
+			}
+		}
+	}
+	fprintf(f, "1:100\t2:200\tsideways\tupstream\nnowhere:5\t1:7\tupstream\tupstream\n1\t500\tx\tN\t<CNV>\t.\tPASS\tSVTYPE=CNV;END=900\n1\t500\tx\tN\tN[[\t.\tPASS\tSVTYPE=BND\nnot a variant at all\n");
+	fclose(f);
 }
 
 void Generator::write_gtf(const std::string& path) const {

@@ -45,4 +45,7 @@ for name in ('toy3k', 'rules8k'):  # the whole chain and the output writer (host
     parity.check_chain_to_isoforms(s,p,conftest.golden_dir(name),rules_prefix=prefix if name=='rules8k' else None)
     os.makedirs(os.path.join(tmp,name+'_files'))
     print('output files', name, parity.check_output_files(s,p,conftest.golden_dir(name),os.path.join(tmp,name+'_files'),rules_prefix=prefix if name=='rules8k' else None))
+prefix=datasets.generate(datasets.DATASETS['wgs8k'], tmp, 'wgs8k')
+os.makedirs(os.path.join(tmp,'wgs8k_files'))
+print('workflow with -d', parity.check_workflow(prefix,conftest.golden_dir('wgs8k'),os.path.join(tmp,'wgs8k_files'),api=api,rules=True,structural_variants=True)[-1])
 print('done')
