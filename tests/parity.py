@@ -613,21 +613,23 @@ def check_output_files(session, pipeline, golden, directory, skip_columns=(), re
     return tuple(results)
 
 
-def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None, fill_sequence_gaps=False, structural_variants=False):
+def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None, fill_sequence_gaps=False, structural_variants=False, params=None, workflow_options=None, max_itd_length=100):
     """FASTA + GTF + BAM (+ blacklist / known fusions) -> fusions.tsv, discarded.tsv through DevicePipeline.run_workflow with the reference's default
     parameters: nothing is taken from the reference, not even the parameters its log prints.  Both files must equal the reference's byte for byte, and
     every "(remaining=N)" of its log must come out."""
     import gzip
     import re
     from arriba_amd.pipeline import DevicePipeline
-    session = open_session(prefix)
-    pipeline = DevicePipeline(session, api=api)
+    from arriba_amd.pipeline import HostSession
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    session.read_chimeric_alignments(prefix + ".bam", max_itd_length=max_itd_length)
+    pipeline = DevicePipeline(session, params=params, api=api)
     stages = []
     outputs = [os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv")]
     pipeline.run_workflow(outputs[0], outputs[1], blacklist_file=prefix + ".blacklist.tsv" if rules else None, known_fusions_file=prefix + ".known_fusions.tsv" if rules else None,
                           tags_file=prefix + ".tags.tsv" if rules else None, protein_domains_file=prefix + ".protein_domains.gff3" if rules else None,
                           genomic_breakpoints_file=prefix + ".sv.tsv" if structural_variants else None,
-                          fill_sequence_gaps=fill_sequence_gaps, log=lambda stage, remaining: stages.append((stage, remaining)))
+                          fill_sequence_gaps=fill_sequence_gaps, log=lambda stage, remaining: stages.append((stage, remaining)), **(workflow_options or {}))
     for mine, name in zip(outputs, ("fusions.tsv", "discarded.tsv")):
         source = reference_prefix + "." + name if reference_prefix else os.path.join(golden, name)
         expected = open(source).read() if os.path.exists(source) else gzip.open(source + ".gz", "rt").read()
@@ -646,9 +648,41 @@ def check_workflow(prefix, golden, directory, api=None, rules=False, reference_p
             seen_select_best += 1
         elif stage == "mark_genomic_support":
             assert remaining == int(re.search(r"Marking fusions with support[^\n]*\(marked=(?:WARNING:[^\n]*\n)*(\d+)\)", log).group(1)), (stage, remaining)
-        elif stage in patterns:
+        elif stage in patterns and re.search(patterns[stage], log):  # a filter switched off with -f prints no line
             assert remaining == logged_remaining(log, patterns[stage]), (stage, remaining, logged_remaining(log, patterns[stage]))
     return stages
+
+NON_DEFAULT_OPTIONS = {
+    "reference": ["-E", "0.1", "-S", "3", "-A", "30", "-M", "2", "-L", "0.5", "-Z", "5", "-z", "0.03", "-e", "0.5", "-R", "5000", "-H", "5", "-V", "0.05", "-K", "0.5", "-m", "0.5", "-Q", "0.99", "-U", "100",
+                  "-l", "60", "-D", "20000"],
+    "disabled": ["homopolymer", "short_anchor"],
+    "params": {"homopolymer_length": 5, "min_read_through_distance": 5000, "max_itd_length": 60, "subsampling_threshold": 100, "mismatch_pvalue_cutoff": 0.05, "max_kmer_content": 0.5, "evalue_cutoff": 0.1,
+               "max_mismapper_fraction": 0.5, "exonic_fraction": 0.5, "min_support": 3, "disable_filters": ["homopolymer", "short_anchor"]},
+    "workflow": {"evalue_cutoff": 0.1, "min_itd_support": 5, "min_itd_allele_fraction": 0.03, "high_expression_quantile": 0.99, "min_spliced_events": 2, "min_anchor_length": 30, "max_homolog_identity": 0.5,
+                 "max_itd_length": 60, "max_genomic_breakpoint_distance": 20000},
+}
+
+
+def check_workflow_with_non_default_options(fragments, directory, api=None):
+    """Nineteen options away from their defaults and two filters switched off, on both sides: the reference run live with the command-line options, the
+    workflow with the same values through agpu_params and the stage arguments; blacklist, known fusions, tags, protein domains and structural variants given."""
+    spec = {"args": ["--seed", "67", "--fragments", str(fragments), "--normal-mult", "0.4", "--contigs", "6", "--contig-len", "500000", "--junctions", "700", "--dup", "0.15", "--rule-files", "--homolog-families", "10",
+                     "--itd-hotspots", "3", "--itd-hotspot-frac", "0.03"], "rule_files": True, "structural_variants": True}
+    prefix = datasets.generate(spec, directory)
+    dump = os.path.join(directory, "dump")
+    os.makedirs(dump)
+    switches = {"ARRIBA_ORACLE_DUMP_LISTS": "0", "ARRIBA_ORACLE_DUMP_READS": "0", "ARRIBA_ORACLE_DUMP_STAGES": "key"}
+    os.environ.update(switches)
+    try:
+        log = datasets.run_reference(prefix, dump, spec, extra_args=NON_DEFAULT_OPTIONS["reference"], disable_filters=NON_DEFAULT_OPTIONS["disabled"])
+    finally:
+        for key in switches:
+            del os.environ[key]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    os.makedirs(os.path.join(directory, "mine"))
+    return check_workflow(prefix, dump, os.path.join(directory, "mine"), api=api, rules=True, reference_prefix=prefix, structural_variants=True, params=NON_DEFAULT_OPTIONS["params"],
+                          workflow_options=NON_DEFAULT_OPTIONS["workflow"], max_itd_length=60)
 
 
 def check_read_lists(session, pipeline, golden, stage):

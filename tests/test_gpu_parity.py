@@ -413,3 +413,11 @@ def test_workflow_from_input_files_to_output_files(built, dataset_files, tmp_pat
     os.makedirs(str(tmp_path / "mine"))
     stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), rules=True, reference_prefix=prefix, structural_variants=True)
     assert stages[-1][1] > 300 and dict(stages)["mark_genomic_support"] > 10000
+
+
+def test_workflow_with_non_default_options_against_the_live_reference(built, tmp_path):
+    """the whole workflow on the GPU with 19 options away from their defaults, two filters off and every optional input file given, against the reference run live"""
+    if not datasets.reference_available():
+        pytest.skip("needs the oracle build of the reference (oracle/_ref)")
+    stages = parity.check_workflow_with_non_default_options(60000, str(tmp_path))
+    assert dict(stages)["mark_genomic_support"] > 1000 and stages[-1][1] > 200

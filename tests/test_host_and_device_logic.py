@@ -348,6 +348,13 @@ def test_workflow_on_tiny_inputs_against_the_live_reference(fragments, emu_api, 
     assert stages[0][1] >= 1
 
 
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+def test_workflow_with_non_default_options_against_the_live_reference(emu_api, tmp_path):
+    """the options of the reference reach the stages: 19 of them away from their defaults, two filters off, every optional input file given"""
+    stages = parity.check_workflow_with_non_default_options(20000, str(tmp_path), api=emu_api)
+    assert dict(stages)["mark_genomic_support"] > 100 and stages[-1][1] > 50
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
