@@ -237,23 +237,24 @@ class DevicePipeline(object):
         self.remaining = {_capi.FILTER_NAMES[f]: int(remaining[f]) for f in (1, 30, 31, 32, 33, 4, 2, 3, 6, 7, 5, 8, 10, 36)}
         return self.remaining
 
-    def run_read_level(self, strandedness=None):
+    def run_read_level(self, strandedness=None, top_viral_contigs=5, viral_contig_min_covered_fraction=0.05):
         """mark_multimappers ... filter_low_entropy (reference: source/arriba.cpp:141-409)."""
         self.scalars["marked_multimappers"] = self.mark_multimappers()
         self.annotate_alignments(strandedness)
-        self.filter_duplicates_and_contigs()
+        self.filter_duplicates_and_contigs(top_viral_contigs, viral_contig_min_covered_fraction)
         self.estimate_fragment_length()
         return self.filter_reads()
 
     def run_workflow(self, output_file, discarded_output_file=None, blacklist_file=None, known_fusions_file=None, tags_file=None, protein_domains_file=None, genomic_breakpoints_file=None,
                      max_genomic_breakpoint_distance=100000, strandedness=None, evalue_cutoff=0.3,
                      min_itd_support=10, min_itd_allele_fraction=0.07, high_expression_quantile=0.998, min_spliced_events=4, min_anchor_length=23,
-                     max_homolog_identity=0.3, max_itd_length=100, fill_sequence_gaps=False, log=None):
+                     max_homolog_identity=0.3, max_itd_length=100, fill_sequence_gaps=False, top_viral_contigs=5, viral_contig_min_covered_fraction=0.05,
+                     print_extra_info_for_discarded_fusions=False, log=None):
         """The reference's main() behind read_chimeric_alignments (source/arriba.cpp:119-610) with its default parameters: the read-level cascade, find_fusions,
         every candidate-level filter in the reference's order, assign_confidence, and the two output files.  `log` receives (stage, remaining) pairs --
         the numbers the reference prints as "(remaining=N)".  Filters switched off with -f are skipped by the stages themselves (agpu_params.filter_enabled)."""
         note = log if log is not None else (lambda stage, remaining: None)
-        self.run_read_level(strandedness)
+        self.run_read_level(strandedness, top_viral_contigs, viral_contig_min_covered_fraction)
         note("find_fusions", self.find_fusions())
         self.upload_coverage()
         if genomic_breakpoints_file:
@@ -293,7 +294,7 @@ class DevicePipeline(object):
             self.session.load_protein_domains(protein_domains_file)
         self.write_fusions(output_file, discarded=False, max_itd_length=max_itd_length, fill_sequence_gaps=fill_sequence_gaps)
         if discarded_output_file:
-            self.write_fusions(discarded_output_file, discarded=True, max_itd_length=max_itd_length, fill_sequence_gaps=fill_sequence_gaps)
+            self.write_fusions(discarded_output_file, discarded=True, print_extra_info=print_extra_info_for_discarded_fusions, max_itd_length=max_itd_length, fill_sequence_gaps=fill_sequence_gaps)
 
     def find_fusions(self, max_mate_gap=None):
         """reference: find_fusions, source/fusions.cpp:203-473; returns the number of candidates"""

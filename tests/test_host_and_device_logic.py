@@ -355,6 +355,25 @@ def test_workflow_with_non_default_options_against_the_live_reference(emu_api, t
     assert dict(stages)["mark_genomic_support"] > 100 and stages[-1][1] > 50
 
 
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+@pytest.mark.parametrize("label,options,params,workflow_options,ingest", [
+    ("duplicates_marked_externally_reverse_stranded_viral", ["-u", "-s", "reverse", "-T", "2", "-C", "0.2", "-F", "150", "-X"], {"fragment_length": 150, "external_duplicate_marking": 1},
+     {"strandedness": 2, "top_viral_contigs": 2, "viral_contig_min_covered_fraction": 0.2, "print_extra_info_for_discarded_fusions": True}, {"external_duplicate_marking": True}),
+    ("stranded", ["-s", "yes"], {}, {"strandedness": 1}, {}),
+    ("unstranded", ["-s", "no"], {}, {"strandedness": 0}, {})])
+def test_workflow_with_library_options_against_the_live_reference(label, options, params, workflow_options, ingest, emu_api, tmp_path):
+    """-u, -s, -T, -C, -F and -X (fusion transcripts and read identifiers for the discarded candidates, too) on a stranded library"""
+    spec = {"args": ["--seed", "73", "--fragments", "12000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.2", "--stranded"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, spec, extra_args=options))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, params=params, workflow_options=workflow_options, **ingest)
+    assert stages[-1][1] > 100
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
