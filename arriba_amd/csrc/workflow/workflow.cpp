@@ -1,0 +1,201 @@
+// arriba_amd/csrc/workflow/workflow.cpp -- the order in which the reference's main() calls its stages (source/arriba.cpp:84-615), over the two C ABIs.
+// Host C++ like the reference; no arithmetic of the path lives here: every step is a call into libarriba_host (loaders, ingest, sequential
+// scalar stages, writer) or libarriba_gpu (the stages on the device).  arriba_amd/pipeline.py: DevicePipeline.run_workflow is the same sequence for
+// the tests and the bench.
+#include "../../../include/arriba_workflow.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_error;
+
+struct Failure { std::string text; };
+void device_check(int status) { if (status != AGPU_OK) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
+void host_check(int status) { if (status != 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() }; }
+
+// filter ids (positions in FILTERS, source/common.hpp:29-67) of the filters main() asks about itself
+enum { F_known_fusions = 18, F_blacklist = 20, F_no_genomic_support = 29, F_genomic_support = 34, F_many_spliced = 28, F_select_best = 24 };
+
+struct Run {
+	const arriba_workflow_options& options;
+	arriba_workflow_report* report;
+	ahost_session* host;
+	agpu_ctx* device;
+	uint32_t dummy_genes;
+	uint64_t n_candidates;
+	Run(const arriba_workflow_options& o, arriba_workflow_report* r): options(o), report(r), host(nullptr), device(nullptr), dummy_genes(0), n_candidates(0) {}
+	~Run() { if (device) agpu_destroy(device); if (host) ahost_close(host); }
+	void note(const char* stage, uint64_t count) {
+		if (!report || report->n_stages >= sizeof(report->stages) / sizeof(report->stages[0])) return;
+		arriba_workflow_stage& entry = report->stages[report->n_stages++];
+		snprintf(entry.stage, sizeof(entry.stage), "%s", stage);
+		entry.count = count;
+	}
+	bool enabled(unsigned filter) const { return options.device.filter_enabled[filter] != 0; }
+};
+
+// the output files: the device's results brought back once, formatted by the host library (source/arriba.cpp:586-610)
+void write_output_files(Run& run, int32_t max_mate_gap) {
+	const size_t n = (size_t) run.n_candidates, n1 = n > 0 ? n : 1;
+	std::vector<uint32_t> gene1(n1), gene2(n1), contigs(n1), flags(n1), split_reads1(n1), split_reads2(n1), discordant_mates(n1), list_offset(3 * n + 1), iteration_rank(n1);
+	std::vector<int32_t> breakpoint1(n1), breakpoint2(n1), anchor1(n1), anchor2(n1), closest1(n1), closest2(n1);
+	std::vector<uint8_t> filter(n1), confidence(n1);
+	std::vector<float> evalue(n1);
+	device_check(agpu_get_candidates(run.device, gene1.data(), gene2.data(), contigs.data(), breakpoint1.data(), breakpoint2.data(), flags.data(), filter.data(), split_reads1.data(), split_reads2.data(),
+	                                 discordant_mates.data(), anchor1.data(), anchor2.data(), list_offset.data()));
+	uint64_t total = 0;
+	device_check(agpu_get_candidate_read_lists(run.device, nullptr, 0, &total));
+	std::vector<uint32_t> read_lists(total > 0 ? total : 1);
+	device_check(agpu_get_candidate_read_lists(run.device, read_lists.data(), total, &total));
+	device_check(agpu_get_evalues(run.device, evalue.data()));
+	device_check(agpu_assign_confidence(run.device, confidence.data())); // behind the 'isoforms' filter: recovered isoforms are scored anew
+	device_check(agpu_candidate_iteration_order(run.device, iteration_rank.data()));
+	device_check(agpu_get_genomic_support(run.device, closest1.data(), closest2.data()));
+	const agpu_batch_view* batch = ahost_batch_view(run.host);
+	std::vector<uint8_t> read_filter(batch->n > 0 ? batch->n : 1);
+	device_check(agpu_get_filters(run.device, read_filter.data()));
+	const uint32_t n_genes = ahost_annotation_view(run.host)->n_genes + run.dummy_genes;
+	std::vector<uint16_t> gene_contig(n_genes > 0 ? n_genes : 1);
+	std::vector<int32_t> gene_start(gene_contig.size()), gene_end(gene_contig.size());
+	device_check(agpu_get_gene_table(run.device, 0, n_genes, gene_contig.data(), gene_start.data(), gene_end.data(), nullptr, nullptr));
+
+	ahost_fusion_table table;
+	memset(&table, 0, sizeof(table));
+	table.n_candidates = (uint32_t) n;
+	table.gene1 = gene1.data(); table.gene2 = gene2.data(); table.contigs = contigs.data(); table.breakpoint1 = breakpoint1.data(); table.breakpoint2 = breakpoint2.data(); table.flags = flags.data(); table.filter = filter.data();
+	table.split_reads1 = split_reads1.data(); table.split_reads2 = split_reads2.data(); table.discordant_mates = discordant_mates.data(); table.list_offset = list_offset.data(); table.read_lists = read_lists.data();
+	table.evalue = evalue.data(); table.confidence = confidence.data(); table.iteration_rank = iteration_rank.data(); table.read_filter = read_filter.data();
+	table.closest_genomic_breakpoint1 = closest1.data(); table.closest_genomic_breakpoint2 = closest2.data();
+	table.n_genes = n_genes; table.gene_contig = gene_contig.data(); table.gene_start = gene_start.data(); table.gene_end = gene_end.data();
+	if (run.options.tags_file) host_check(ahost_load_tags(run.host, run.options.tags_file));
+	if (run.options.protein_domains_file) host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file));
+	host_check(ahost_write_fusions(run.host, &table, run.options.output_file, 0, 1, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
+	if (run.options.discarded_output_file)
+		host_check(ahost_write_fusions(run.host, &table, run.options.discarded_output_file, 1, run.options.print_extra_info_for_discarded_fusions, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
+}
+
+void run_workflow(Run& run) {
+	const arriba_workflow_options& o = run.options;
+	if (!o.assembly_file || !o.gene_annotation_file || !o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
+	// source/arriba.cpp:97-130: assembly, annotation, index, chimeric alignments
+	run.host = ahost_open(o.assembly_file, o.gene_annotation_file, o.interesting_contigs, o.viral_contigs, o.gtf_features);
+	if (!run.host) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+	host_check(ahost_ingest_bam_file(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length));
+	agpu_params params = o.device;
+	if (params.strandedness > 2) params.strandedness = 0; // resolved below
+	run.device = agpu_create(o.device_index, &params);
+	if (!run.device) throw Failure{ std::string("ERROR: ") + agpu_last_error() };
+	device_check(agpu_upload_annotation(run.device, ahost_annotation_view(run.host)));
+	device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host)));
+	device_check(agpu_upload_batch(run.device, ahost_batch_view(run.host)));
+
+	// :141-325 multi-mappers, strandedness, annotation
+	uint64_t count = 0;
+	device_check(agpu_mark_multimappers(run.device, &count)); run.note("mark_multimappers", count);
+	params.strandedness = o.device.strandedness > 2 ? (uint8_t) ahost_detect_strandedness(run.host) : o.device.strandedness;
+	device_check(agpu_set_params(run.device, &params));
+	device_check(agpu_annotate(run.device, &run.dummy_genes));
+	// :327-350 duplicates, uninteresting and viral contigs (the per-contig verdicts are sequential host work)
+	uint64_t n_pairs = 0;
+	device_check(agpu_get_viral_integration_sites(run.device, nullptr, 0, &n_pairs));
+	std::vector<uint32_t> pairs(2 * (n_pairs > 0 ? n_pairs : 1));
+	device_check(agpu_get_viral_integration_sites(run.device, pairs.data(), n_pairs, &n_pairs));
+	const uint32_t n_genes = ahost_annotation_view(run.host)->n_genes + run.dummy_genes, n_contigs = ahost_contig_count(run.host);
+	std::vector<uint8_t> gene_bits(n_genes > 0 ? n_genes : 1), top(n_contigs > 0 ? n_contigs : 1), low(top.size());
+	device_check(agpu_get_gene_table(run.device, 0, n_genes, nullptr, nullptr, nullptr, gene_bits.data(), nullptr));
+	host_check(ahost_viral_verdicts(run.host, pairs.data(), n_pairs, gene_bits.data(), n_genes, o.top_viral_contigs, o.viral_contig_min_covered_fraction, top.data(), low.data()) < 0 ? -1 : 0);
+	device_check(agpu_read_filters_stage1(run.device, top.data(), low.data()));
+	// :352-364 fragment length
+	std::vector<int32_t> mate_gaps(100001);
+	uint32_t n_samples = 0; uint64_t visited = 0;
+	device_check(agpu_fragment_length_samples(run.device, mate_gaps.data(), &n_samples, &visited));
+	float mate_gap_mean = 0, mate_gap_stddev = 0, read_length_mean = 0; int32_t max_mate_gap = 0;
+	if (ahost_estimate_fragment_length(run.host, mate_gaps.data(), n_samples, visited, params.fragment_length, &mate_gap_mean, &mate_gap_stddev, &read_length_mean, &max_mate_gap) < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+	// :366-409 the read-level filters
+	std::vector<uint64_t> remaining(AGPU_FILTER_COUNT);
+	device_check(agpu_read_filters_stage2(run.device, remaining.data()));
+	static const struct { unsigned id; const char* name; } read_filters[] = { { 1, "filter_duplicates" }, { 30, "filter_uninteresting_contigs" }, { 31, "filter_viral_contigs" }, { 32, "filter_top_expressed_viral_contigs" },
+		{ 33, "filter_low_coverage_viral_contigs" }, { 4, "filter_proximal_read_through" }, { 2, "filter_inconsistently_clipped_mates" }, { 3, "filter_homopolymer" }, { 6, "filter_small_insert_size" }, { 7, "filter_long_gap" },
+		{ 5, "filter_same_gene" }, { 8, "filter_hairpin" }, { 10, "filter_mismatches" }, { 36, "filter_low_entropy" } };
+	for (size_t f = 0; f < sizeof(read_filters) / sizeof(read_filters[0]); ++f) run.note(read_filters[f].name, remaining[read_filters[f].id]);
+
+	// :411-460 candidates
+	device_check(agpu_find_fusions(run.device, max_mate_gap, &count)); run.note("find_fusions", count);
+	run.n_candidates = count;
+	device_check(agpu_upload_coverage(run.device, ahost_coverage_view(run.host)));
+	if (o.genomic_breakpoints_file) {
+		const agpu_genomic_breakpoint* variants = nullptr; uint32_t n_variants = 0;
+		host_check(ahost_load_genomic_breakpoints(run.host, o.genomic_breakpoints_file, &variants, &n_variants));
+		device_check(agpu_mark_genomic_support(run.device, variants, n_variants, o.max_genomic_breakpoint_distance, &count)); run.note("mark_genomic_support", count);
+	}
+	device_check(agpu_merge_adjacent_fusions(run.device, 5, &count)); run.note("merge_adjacent_fusions", count);
+	uint64_t discarded_reads = 0, discarded[3];
+	device_check(agpu_filter_multimappers(run.device, &count, &discarded_reads)); run.note("filter_multimappers", count);
+	device_check(agpu_candidate_iteration_order(run.device, nullptr)); // hazard H2: the order in which the reference's container is walked, kept on the device
+	device_check(agpu_estimate_expected_fusions(run.device, ahost_mapped_reads(run.host), nullptr));
+	device_check(agpu_filter_candidate_predicates(run.device, discarded));
+	device_check(agpu_filter_relative_support(run.device, &count)); run.note("filter_relative_support", count);
+	// :463-544 the candidate-level filters (each stage skips itself when its filter is switched off with -f)
+	device_check(agpu_recover_internal_tandem_duplication(run.device, o.min_itd_support, o.min_itd_allele_fraction, &count)); run.note("recover_internal_tandem_duplication", count);
+	device_check(agpu_filter_both_intronic(run.device, &count)); run.note("filter_both_intronic", count);
+	if (o.known_fusions_file && run.enabled(F_known_fusions)) {
+		const agpu_range_rule* rules = nullptr; uint32_t n_rules = 0;
+		host_check(ahost_load_range_rules(run.host, o.known_fusions_file, 0, &rules, &n_rules));
+		device_check(agpu_recover_known_fusions(run.device, rules, n_rules, max_mate_gap, &count)); run.note("recover_known_fusions", count);
+	}
+	device_check(agpu_filter_in_vitro(run.device, o.high_expression_quantile, &count)); run.note("filter_in_vitro", count);
+	device_check(agpu_recover_both_spliced(run.device, 200, 0.998f, 1000, 1000, &count)); run.note("recover_both_spliced", count); // the constants of source/arriba.cpp:491
+	device_check(agpu_select_most_supported_breakpoints(run.device, &count)); run.note("select_most_supported_breakpoints", count);
+	device_check(agpu_filter_marginal_read_through(run.device, &count)); run.note("filter_marginal_read_through", count);
+	device_check(agpu_recover_many_spliced(run.device, o.min_spliced_events, &count)); run.note("recover_many_spliced", count);
+	if (o.genomic_breakpoints_file && run.enabled(F_no_genomic_support)) {
+		device_check(agpu_assign_confidence(run.device, nullptr)); // this filter looks at the confidence (:516-523)
+		device_check(agpu_filter_no_genomic_support(run.device, &count)); run.note("filter_no_genomic_support", count);
+	}
+	if (o.blacklist_file && run.enabled(F_blacklist)) {
+		const agpu_range_rule* rules = nullptr; uint32_t n_rules = 0;
+		host_check(ahost_load_range_rules(run.host, o.blacklist_file, 1, &rules, &n_rules));
+		device_check(agpu_filter_blacklisted_ranges(run.device, rules, n_rules, params.evalue_cutoff, max_mate_gap, &count)); run.note("filter_blacklisted_ranges", count);
+	}
+	device_check(agpu_filter_short_anchor(run.device, o.min_anchor_length, &count)); run.note("filter_short_anchor", count);
+	device_check(agpu_filter_end_to_end(run.device, &count)); run.note("filter_end_to_end_fusions", count);
+	device_check(agpu_filter_no_coverage(run.device, &count)); run.note("filter_no_coverage", count);
+	// :546-565 the k-mer index and the two filters that use it; padding as in :552 (float arithmetic, truncated)
+	uint64_t n_positions = 0;
+	device_check(agpu_make_kmer_index(run.device, (int32_t) ((float) max_mate_gap + 2.0f * read_length_mean), &n_positions));
+	device_check(agpu_filter_homologs(run.device, o.max_homolog_identity, &count)); run.note("filter_homologs", count);
+	device_check(agpu_filter_mismappers(run.device, max_mate_gap, &count, &discarded_reads)); run.note("filter_mismappers", count);
+	// :567-584
+	if (o.genomic_breakpoints_file && run.enabled(F_genomic_support)) { device_check(agpu_recover_genomic_support(run.device, &count)); run.note("recover_genomic_support", count); }
+	if ((o.genomic_breakpoints_file && run.enabled(F_genomic_support)) || run.enabled(F_many_spliced)) { device_check(agpu_select_most_supported_breakpoints(run.device, &count)); run.note("select_most_supported_breakpoints", count); }
+	device_check(agpu_recover_isoforms(run.device, &count)); run.note("recover_isoforms", count);
+	write_output_files(run, max_mate_gap);
+}
+
+}
+
+extern "C" {
+
+void arriba_workflow_default_options(arriba_workflow_options* options) {
+	memset(options, 0, sizeof(*options));
+	agpu_default_params(&options->device);
+	options->device.strandedness = 3; // -s auto
+	options->min_itd_support = 10; options->min_itd_allele_fraction = 0.07f; options->high_expression_quantile = 0.998f; options->min_spliced_events = 4; options->min_anchor_length = 23;
+	options->max_homolog_identity = 0.3f; options->top_viral_contigs = 5; options->viral_contig_min_covered_fraction = 0.05f; options->max_genomic_breakpoint_distance = 100000;
+}
+
+const char* arriba_workflow_last_error(void) { return g_error.c_str(); }
+
+int arriba_workflow_run(const arriba_workflow_options* options, arriba_workflow_report* report) {
+	if (!options) { g_error = "ERROR: null options"; return -1; }
+	if (report) report->n_stages = 0;
+	try { Run run(*options, report); run_workflow(run); return 0; }
+	catch (const Failure& failure) { g_error = failure.text; return -1; }
+	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); return -1; }
+}
+
+}

@@ -421,3 +421,20 @@ def test_workflow_with_non_default_options_against_the_live_reference(built, tmp
         pytest.skip("needs the oracle build of the reference (oracle/_ref)")
     stages = parity.check_workflow_with_non_default_options(60000, str(tmp_path))
     assert dict(stages)["mark_genomic_support"] > 1000 and stages[-1][1] > 200
+
+
+def test_cpp_workflow_driver_over_the_c_abis(built, dataset_files, tmp_path):
+    """arriba_amd/lib/arriba_gpu_workflow: the reference's main() behind its option parser as C++ over the two C ABIs (no Python in the loop), on the GPU:
+    both output files equal the reference's byte for byte, without and with every optional input file"""
+    import gzip
+    import subprocess
+    for name in ("toy3k", "wgs8k"):
+        prefix = dataset_files(name)
+        os.makedirs(str(tmp_path / name))
+        outputs = [str(tmp_path / name / "fusions.tsv"), str(tmp_path / name / "discarded.tsv")]
+        optional = [prefix + suffix for suffix in (".blacklist.tsv", ".known_fusions.tsv", ".tags.tsv", ".protein_domains.gff3", ".sv.tsv")] if name == "wgs8k" else []
+        result = subprocess.run([os.path.join(conftest.ROOT, "arriba_amd", "lib", "arriba_gpu_workflow"), prefix + ".fa", prefix + ".gtf", prefix + ".bam"] + outputs + optional,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        assert result.returncode == 0, result.stderr[-2000:]
+        for mine, reference in zip(outputs, ("fusions.tsv.gz", "discarded.tsv.gz")):
+            assert open(mine).read() == gzip.open(os.path.join(conftest.golden_dir(name), reference), "rt").read(), (name, reference)

@@ -30,7 +30,7 @@ def test_device_library_exports_every_declared_symbol(built):
     assert lib.agpu_api_version() == 1
 
 
-@pytest.mark.parametrize("header", ["arriba_gpu.h", "arriba_host.h"])
+@pytest.mark.parametrize("header", ["arriba_gpu.h", "arriba_host.h", "arriba_workflow.h"])
 def test_public_headers_are_plain_c(header, tmp_path):
     """The drop-in boundary is a C ABI: the headers must compile as C99 on their own (no C++ types, no torch types in the signatures)."""
     import subprocess
@@ -372,6 +372,25 @@ def test_workflow_with_library_options_against_the_live_reference(label, options
     os.makedirs(str(tmp_path / "mine"))
     stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, params=params, workflow_options=workflow_options, **ingest)
     assert stages[-1][1] > 100
+
+
+@pytest.mark.parametrize("name", ["toy3k", "wgs8k"])
+def test_cpp_workflow_driver_over_the_c_abis(name, dataset_files, emu_api, tmp_path):
+    """arriba_workflow_run (arriba_amd/csrc/workflow: the reference's main() behind its option parser, C++ over the two C ABIs, no Python in the loop),
+    linked against the stepping harness in place of the device library: both output files equal the reference's byte for byte"""
+    import gzip
+    import subprocess
+    directory = os.path.join(conftest.ROOT, "tests", "emu")
+    subprocess.run(["make", "-s", "-C", directory, "workflow_on_harness"], check=True)
+    prefix = dataset_files(name)
+    outputs = [str(tmp_path / "fusions.tsv"), str(tmp_path / "discarded.tsv")]
+    optional = [prefix + suffix for suffix in (".blacklist.tsv", ".known_fusions.tsv", ".tags.tsv", ".protein_domains.gff3", ".sv.tsv")] if name == "wgs8k" else []
+    result = subprocess.run([os.path.join(directory, "workflow_on_harness"), prefix + ".fa", prefix + ".gtf", prefix + ".bam"] + outputs + optional, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True)
+    assert result.returncode == 0, result.stdout
+    stages = dict(line.split("\t") for line in result.stdout.strip().split("\n"))
+    assert int(stages["find_fusions"]) > 1000 and int(stages["recover_isoforms"]) > 40
+    for mine, reference in zip(outputs, ("fusions.tsv.gz", "discarded.tsv.gz")):
+        assert open(mine).read() == gzip.open(os.path.join(conftest.golden_dir(name), reference), "rt").read(), reference
 
 
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
