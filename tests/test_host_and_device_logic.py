@@ -393,6 +393,22 @@ def test_cpp_workflow_driver_over_the_c_abis(name, dataset_files, emu_api, tmp_p
         assert open(mine).read() == gzip.open(os.path.join(conftest.golden_dir(name), reference), "rt").read(), reference
 
 
+def test_cpp_workflow_library_fails_loudly_without_a_gpu(built, dataset_files, tmp_path):
+    """libarriba_workflow.so exports what include/arriba_workflow.h declares; without a GPU arriba_gpu_workflow stops with the device library's error, no CPU fallback"""
+    import ctypes
+    import subprocess
+    import torch
+    lib = ctypes.CDLL(os.path.join(conftest.ROOT, "arriba_amd", "lib", "libarriba_workflow.so"))
+    for symbol in ("arriba_workflow_default_options", "arriba_workflow_run", "arriba_workflow_last_error"):
+        assert hasattr(lib, symbol), symbol
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    prefix = dataset_files("toy3k")
+    result = subprocess.run([os.path.join(conftest.ROOT, "arriba_amd", "lib", "arriba_gpu_workflow"), prefix + ".fa", prefix + ".gtf", prefix + ".bam", str(tmp_path / "fusions.tsv")],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert result.returncode == 1 and "ERROR" in result.stderr and not os.path.exists(str(tmp_path / "fusions.tsv")), (result.returncode, result.stderr[-500:])
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
