@@ -13,7 +13,7 @@ using namespace agpu;
 namespace {
 
 const int BLOCK = 256;
-const uint32_t MAX_REMAINING = 50000; // the elimination compares every pair of unfiltered candidates
+const uint32_t MAX_REMAINING = 4u << 20; // unfiltered candidates gathered to the host (40 bytes each)
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
 #define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
@@ -48,18 +48,19 @@ extern "C" int agpu_filter_homologs(agpu_ctx* ctx, float max_identity_fraction, 
 	hipStream_t s = ctx->stream;
 	const uint32_t C = ctx->n_candidates;
 	DeviceBuffer& counter = ctx->scratch("homologs.counter"); DeviceBuffer& collected = ctx->scratch("homologs.collected");
-	ALLOC(counter, 16); ALLOC(collected, (size_t) MAX_REMAINING * sizeof(RemainingCandidate));
+	const uint32_t capacity = std::min<uint32_t>(std::max<uint32_t>(C, 1), MAX_REMAINING);
+	ALLOC(counter, 16); ALLOC(collected, (size_t) capacity * sizeof(RemainingCandidate));
 	HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 16, s));
 	(void) hipEventRecord(ctx->event_start, s);
 	uint32_t n_remaining = 0;
 	if (C > 0) {
-		homolog_collect_kernel<<<(C + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(ctx->candidates, ctx->cand_iteration_rank.as<uint32_t>(), ctx->cand_evalue.as<float>(), collected.as<RemainingCandidate>(), MAX_REMAINING, counter.as<unsigned int>());
+		homolog_collect_kernel<<<(C + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(ctx->candidates, ctx->cand_iteration_rank.as<uint32_t>(), ctx->cand_evalue.as<float>(), collected.as<RemainingCandidate>(), capacity, counter.as<unsigned int>());
 		HIP_CHECK(hipMemcpyAsync(&n_remaining, counter.ptr, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 	}
 	uint64_t kept = n_remaining;
 	if (n_remaining > 0 && ctx->params.filter_enabled[FILTER_homologs]) {
-		if (n_remaining > MAX_REMAINING) { set_last_error("filter_homologs: more unfiltered candidates than the pairwise elimination is sized for (run the filters in front of it first)"); return AGPU_ERR_CAPACITY; }
+		if (n_remaining > capacity) { set_last_error("filter_homologs: more unfiltered candidates than the elimination on the host is sized for (4 M)"); return AGPU_ERR_CAPACITY; }
 		std::vector<RemainingCandidate> list(n_remaining);
 		HIP_CHECK(hipMemcpy(list.data(), collected.ptr, (size_t) n_remaining * sizeof(RemainingCandidate), hipMemcpyDeviceToHost));
 		HomologElimination elimination;

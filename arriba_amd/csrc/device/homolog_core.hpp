@@ -74,32 +74,12 @@ AGPU_HD bool homolog_partners(const CandidateTable& t, uint32_t fusion, uint32_t
 }
 AGPU_HD uint32_t homolog_anchor_count(const CandidateTable& t, uint32_t c) { return (t.split_reads1[c] > 0) + (t.split_reads2[c] > 0) + (t.discordant_mates[c] > 0); }
 
-// the elimination (:68-139) over remaining[0 .. n) = the unfiltered candidates in the reference's list order; `verdict(gene_a, gene_b)` answers
-// is_homolog.  Returns the number still unfiltered.
-template <class Verdict> AGPU_HD uint32_t eliminate_homologs(const CandidateTable& t, const float* evalue, const uint32_t* remaining, uint32_t n, const Verdict& verdict) {
-	for (uint32_t i = 0; i < n; ++i) {
-		const uint32_t fusion = remaining[i];
-		if (t.filter[fusion] != FILTER_none) continue;
-		if (verdict(t.gene1[fusion], t.gene2[fusion])) { t.filter[fusion] = FILTER_homologs; continue; }
-		for (uint32_t j = i + 1; j < n; ++j) {
-			const uint32_t other = remaining[j];
-			if (t.filter[other] != FILTER_none) continue;
-			uint32_t homolog1, homolog2;
-			if (!homolog_partners(t, fusion, other, homolog1, homolog2)) continue;
-			if (!verdict(homolog1, homolog2)) continue;
-			const uint32_t anchor1 = homolog_anchor_count(t, fusion), anchor2 = homolog_anchor_count(t, other);
-			const uint32_t support1 = t.split_reads1[fusion] + t.split_reads2[fusion] + t.discordant_mates[fusion], support2 = t.split_reads1[other] + t.split_reads2[other] + t.discordant_mates[other];
-			if (anchor1 > anchor2 || (anchor1 == anchor2 && support1 > support2) || (anchor1 == anchor2 && support1 == support2 && evalue[fusion] <= evalue[other])) {
-				t.filter[other] = FILTER_homologs;
-			} else {
-				t.filter[fusion] = FILTER_homologs;
-				break;
-			}
-		}
-	}
-	uint32_t kept = 0;
-	for (uint32_t i = 0; i < n; ++i) if (t.filter[remaining[i]] == FILTER_none) ++kept;
-	return kept;
+// of two candidates that share a gene and whose other genes are homologs: does `fusion` (earlier in the list) stay? (:106-127) more kinds of
+// supporting reads, then more reads, then the better e-value
+AGPU_HD bool homolog_candidate_prevails(const CandidateTable& t, const float* evalue, uint32_t fusion, uint32_t other) {
+	const uint32_t anchor1 = homolog_anchor_count(t, fusion), anchor2 = homolog_anchor_count(t, other);
+	const uint32_t support1 = t.split_reads1[fusion] + t.split_reads2[fusion] + t.discordant_mates[fusion], support2 = t.split_reads1[other] + t.split_reads2[other] + t.discordant_mates[other];
+	return anchor1 > anchor2 || (anchor1 == anchor2 && support1 > support2) || (anchor1 == anchor2 && support1 == support2 && evalue[fusion] <= evalue[other]);
 }
 
 }

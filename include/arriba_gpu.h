@@ -344,7 +344,7 @@ int agpu_assign_confidence(agpu_ctx* ctx, uint8_t* confidence);
 /* recover_isoforms (source/recover_isoforms.cpp:10-47, called at source/arriba.cpp:580-584): the last of the candidate-level filters */
 int agpu_recover_isoforms(agpu_ctx* ctx, uint64_t* remaining);
 /* filter_homologs (source/filter_homologs.cpp:68-141, called at source/arriba.cpp:556-560 behind make_kmer_index; max_identity_fraction = -L, default 0.3).
- * Needs the k-mer index, the e-values and at most 50 000 unfiltered candidates (the elimination is pairwise, as in the reference). */
+ * Needs the k-mer index and the e-values.  The elimination only compares candidates that share a gene (the reference compares all pairs). */
 int agpu_filter_homologs(agpu_ctx* ctx, float max_identity_fraction, uint64_t* remaining);
 int agpu_make_kmer_index(agpu_ctx* ctx, int32_t padding, uint64_t* n_positions);
 /* filter_mismappers (source/filter_mismappers.cpp:272-359): re-aligns the reads of every unfiltered candidate to the other gene
