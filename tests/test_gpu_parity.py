@@ -428,12 +428,14 @@ def test_cpp_workflow_driver_over_the_c_abis(built, dataset_files, tmp_path):
     both output files equal the reference's byte for byte, without and with every optional input file"""
     import gzip
     import subprocess
+    driver = os.path.join(conftest.ROOT, "arriba_amd", "lib", "arriba_gpu_workflow")
+    os.chmod(driver, 0o755)  # the snapshot that travels to the GPU box may drop the mode
     for name in ("toy3k", "wgs8k"):
         prefix = dataset_files(name)
         os.makedirs(str(tmp_path / name))
         outputs = [str(tmp_path / name / "fusions.tsv"), str(tmp_path / name / "discarded.tsv")]
         optional = [prefix + suffix for suffix in (".blacklist.tsv", ".known_fusions.tsv", ".tags.tsv", ".protein_domains.gff3", ".sv.tsv")] if name == "wgs8k" else []
-        result = subprocess.run([os.path.join(conftest.ROOT, "arriba_amd", "lib", "arriba_gpu_workflow"), prefix + ".fa", prefix + ".gtf", prefix + ".bam"] + outputs + optional,
+        result = subprocess.run([driver, prefix + ".fa", prefix + ".gtf", prefix + ".bam"] + outputs + optional,
                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
         assert result.returncode == 0, result.stderr[-2000:]
         for mine, reference in zip(outputs, ("fusions.tsv.gz", "discarded.tsv.gz")):
