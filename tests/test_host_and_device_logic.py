@@ -409,6 +409,43 @@ def test_cpp_workflow_library_fails_loudly_without_a_gpu(built, dataset_files, t
     assert result.returncode == 1 and "ERROR" in result.stderr and not os.path.exists(str(tmp_path / "fusions.tsv")), (result.returncode, result.stderr[-500:])
 
 
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzzed_rule_files_against_the_live_reference(seed, emu_api, tmp_path):
+    """blacklist, known-fusions and tags files made of random items (contigs with strand, chr prefix, asterisk; positions and ranges that are empty,
+    negative, reversed, hexadecimal, padded with blanks; gene names; keywords in the wrong place; missing and extra columns; DOS line ends): whatever the
+    reference's parser makes of a line, the output files must not differ"""
+    import gzip
+    import random
+    rng = random.Random(seed)
+    spec = dict(datasets.DATASETS["rules8k"])
+    prefix = datasets.generate(spec, str(tmp_path))
+    genes = [line.split("\t")[0] for line in gzip.open(os.path.join(conftest.golden_dir("rules8k"), "fusions.tsv.gz"), "rt").read().split("\n")[1:40] if line]
+    contigs = ["1", "2", "3", "4", "chr1", "chr2", "1*", "NC_*", "AC_*", "GL*", "X", "chrX", "nowhere", "+1", "-2", "+chr3", "-4*"]
+    def position():
+        return rng.choice(["%d" % rng.randint(1, 300000), "%d-%d" % (rng.randint(1, 150000), rng.randint(150000, 300000)), "0", "-5", "5-", "-", "abc", "1e3", "0x10", "+5", " 5", "5 ", "200000-1000", "", "1-2-3"])
+    def item():
+        r = rng.random()
+        if r < 0.3:
+            return rng.choice(genes)
+        if r < 0.9:
+            return rng.choice(contigs) + ":" + position()
+        return rng.choice(["any", "split_read_donor", "read_through", "low_support", "filter_spliced", "not_both_spliced", "discordant_mates", "split_read_any", "split_read_acceptor", "ANY", "", ":5", "1:", "::", "1:2:3"])
+    with open(prefix + ".blacklist.tsv", "w") as out:
+        out.write("\n".join("\t".join(item() for _ in range(rng.choice([2, 2, 2, 2, 1, 3]))) + rng.choice(["", "", "\r", "\t"]) for _ in range(400)) + "\n")
+    with open(prefix + ".known_fusions.tsv", "w") as out:
+        out.write("\n".join("\t".join(item() for _ in range(rng.choice([2, 2, 3]))) for _ in range(300)) + "\n")
+    with open(prefix + ".tags.tsv", "w") as out:
+        out.write("\n".join("\t".join([item(), item(), rng.choice(["tag A", "x,y", "", "ok", "t\x01b"])][:rng.choice([3, 3, 2])]) for _ in range(300)) + "\n")
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, spec))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = dict(parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, rules=True, reference_prefix=prefix))
+    assert stages["filter_blacklisted_ranges"] < stages["recover_many_spliced"]  # some of the random lines hit
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
