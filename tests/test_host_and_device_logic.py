@@ -446,6 +446,51 @@ def test_fuzzed_rule_files_against_the_live_reference(seed, emu_api, tmp_path):
     assert stages["filter_blacklisted_ranges"] < stages["recover_many_spliced"]  # some of the random lines hit
 
 
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzzed_variant_and_domain_files_against_the_live_reference(seed, emu_api, tmp_path):
+    """structural variants (four-column and VCF lines with fields swapped for nonsense, truncated, extended, DOS line ends) and protein domains (GFF3 lines
+    with broken attributes, percent escapes, bad coordinates): whatever the reference's parsers make of a line, the output files must not differ"""
+    import random
+    rng = random.Random(seed)
+    spec = dict(datasets.DATASETS["wgs8k"])
+    prefix = datasets.generate(spec, str(tmp_path))
+    variants = [line for line in open(prefix + ".sv.tsv").read().split("\n") if line and not line.startswith("#")]
+    def mutated_variant(line):
+        fields, r = line.split("\t"), rng.random()
+        if r < 0.15 and len(fields) > 1:
+            fields[rng.randrange(len(fields))] = rng.choice(["", ".", "PASS", "upstream", "-", "+", "x:y", "1:abc", "SVTYPE=DEL", "SVTYPE=DEL;END=", "SVTYPE=INV;END=500", "END=9;SVTYPE=DUP", "N[1:5[", "]2:77]N", "[3:9[N", "N]4:1]", "N.", ".N", "<DEL>"])
+        elif r < 0.25:
+            fields = fields[:rng.randrange(1, len(fields) + 1)]
+        elif r < 0.3:
+            fields = fields + ["extra"]
+        elif r < 0.35:
+            return "\t".join(fields).replace(":", " :", 1)
+        return "\t".join(fields) + rng.choice(["", "", "\r"])
+    with open(prefix + ".sv.tsv", "w") as out:
+        out.write("#comment\n" + "\n".join(mutated_variant(rng.choice(variants)) for _ in range(600)) + "\n")
+    domains = [line for line in open(prefix + ".protein_domains.gff3").read().split("\n") if line and not line.startswith("#")]
+    def mutated_domain(line):
+        fields, r = line.split("\t"), rng.random()
+        if r < 0.2 and len(fields) > 8:
+            fields[8] = rng.choice([fields[8].replace("Name=", "name="), fields[8] + ";Name=Second%2", "Name=%ZZbad%4;gene_name=SYN1;gene_id=E", "gene_id=X;gene_name=SYN2;Name=a b|c,d",
+                                    "Name=Q%41%2c;gene_name=SYN3;gene_id=ENSG00000000003.12", fields[8].replace("gene_id=ENSG", "gene_id=XNSG")])
+        elif r < 0.3:
+            fields[rng.randrange(len(fields))] = rng.choice(["", "x", "-1", "0", "+", "?"])
+        elif r < 0.35:
+            fields = fields[:rng.randrange(1, len(fields))]
+        return "\t".join(fields) + rng.choice(["", "\r"])
+    with open(prefix + ".protein_domains.gff3", "w") as out:
+        out.write("##gff-version 3\n" + "\n".join(mutated_domain(rng.choice(domains)) for _ in range(400)) + "\n")
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, spec))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = dict(parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, rules=True, reference_prefix=prefix, structural_variants=True))
+    assert stages["mark_genomic_support"] > 500
+
+
 def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api):
     """find_fusions -> merge_adjacent_fusions -> e-value -> candidate predicates -> filter_relative_support, nothing taken from the reference in between"""
     golden = conftest.golden_dir("toy3k_chain")
