@@ -10,7 +10,8 @@ import datasets
 import golden_io
 import parity
 
-pytestmark = pytest.mark.gpu
+# a kernel that never returns must not hold the GPU box until the harness gives up: the test process exits after 20 minutes in one test
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200, method="thread")]
 
 
 @pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "mid30k", "stacked4k"])
