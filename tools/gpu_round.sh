@@ -6,7 +6,8 @@ mkdir -p gpurun_out
 export ARRIBA_BENCH_CACHE=/tmp/arriba_bench_cache   # the bench invocations below share one ingested batch
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/${TAG}_pytest_gpu.log
 # SKIP_PLAIN_BENCH=1: the traced run below also prints the bench line (GPU minutes are scarce: every bench invocation generates and ingests 10 M fragments first)
-if [ -z "$SKIP_PLAIN_BENCH" ]; then timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench exit $?" >> gpurun_out/${TAG}_bench.err; fi
+# BENCH_FLAGS, e.g. BENCH_FLAGS=--workflow: one untimed pass of the whole workflow (candidate-level stages, output files) is added to the bench line
+if [ -z "$SKIP_PLAIN_BENCH" ]; then timeout 900 python bench.py $BENCH_FLAGS > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench exit $?" >> gpurun_out/${TAG}_bench.err; fi
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o bench10m -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_prof.json 2> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_prof.err
 cd $GRAFT_REPO_ROOT
