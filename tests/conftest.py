@@ -20,7 +20,7 @@ def pytest_configure(config):
 
 def _ensure_built():
     lib = os.path.join(ROOT, "arriba_amd", "lib")
-    needed = [os.path.join(lib, f) for f in ("libarriba_host.so", "libarriba_gpu.so", "gen_synth")]
+    needed = [os.path.join(lib, f) for f in ("libarriba_host.so", "libarriba_gpu.so", "libarriba_workflow.so", "arriba_gpu_workflow", "gen_synth")]
     if not all(os.path.exists(p) for p in needed):
         import __graft_entry__
         __graft_entry__.build()
