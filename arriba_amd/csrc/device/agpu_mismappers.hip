@@ -148,12 +148,12 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 	}
 }
 
-__global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, unsigned int* remaining) {
+__global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, bool count_only, unsigned int* remaining) {
 	__shared__ uint32_t block_sum;
 	uint32_t kept = 0;
 	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
 		if (t.filter[c] != FILTER_none) continue;
-		if (count_candidate_mismappers(b, t, c, max_mismapper_fraction)) t.filter[c] = FILTER_mismappers; else ++kept;
+		if (!count_only && count_candidate_mismappers(b, t, c, max_mismapper_fraction)) t.filter[c] = FILTER_mismappers; else ++kept;
 	}
 	block_tally(kept, remaining, &block_sum);
 }
@@ -286,7 +286,10 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 	splice.offset = ctx->splice_offset.as<uint32_t>(); splice.sites = ctx->splice_sites.as<int32_t>();
 	(void) hipEventRecord(ctx->event_start, s);
 	uint32_t n_jobs = 0;
-	if (C > 0 && n > 0) {
+	if (C > 0 && !ctx->params.filter_enabled[FILTER_mismappers]) {
+		// switched off with -f: the reference skips the stage (source/arriba.cpp:562); no read and no candidate is touched, the unfiltered candidates are counted
+		mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, true, device_counters + 2);
+	} else if (C > 0 && n > 0) {
 		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>()); }
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
@@ -299,7 +302,7 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 			mismapper_verdict_kernel<<<n_jobs, ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
 		}
 		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
-		  mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, device_counters + 2); }
+		  mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, false, device_counters + 2); }
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));

@@ -24,23 +24,74 @@ namespace arriba {
 
 namespace {
 
-class GzSource: public ByteSource {
+// One open stream serves every container: the first bytes are read once (sniffed for the format) and handed to the chosen source, so that
+// the path may be a pipe or /dev/stdin (the reference's standard invocation is `STAR ... | arriba -x /dev/stdin`, run_arriba.sh:42;
+// sam_open reads any path once, source/read_chimeric_alignments.cpp:563).
+class PrefixedFile {
 public:
-	explicit GzSource(const std::string& path) {
-		file_ = gzopen(path.c_str(), "rb");
-		if (file_ == NULL)
-			throw std::runtime_error("failed to open SAM file");
-		gzbuffer(file_, 4u << 20);
-	}
-	~GzSource() { gzclose(file_); }
-	size_t read(uint8_t* buffer, size_t capacity) {
-		int got = gzread(file_, buffer, (unsigned int) std::min<size_t>(capacity, 1u << 30));
-		if (got < 0)
-			throw std::runtime_error("failed to load alignments");
-		return got;
+	PrefixedFile(FILE* file, const uint8_t* prefix, size_t prefix_size): file_(file), prefix_(prefix, prefix + prefix_size), taken_(0) {}
+	~PrefixedFile() { if (file_ != NULL && file_ != stdin) fclose(file_); }
+	size_t read(uint8_t* buffer, size_t capacity) { // like fread: short only at the end of the stream
+		size_t n = std::min(capacity, prefix_.size() - taken_);
+		if (n > 0) { memcpy(buffer, &prefix_[taken_], n); taken_ += n; }
+		while (n < capacity) {
+			const size_t got = fread(buffer + n, 1, capacity - n, file_);
+			if (got == 0) {
+				if (ferror(file_)) throw std::runtime_error("failed to load alignments");
+				break;
+			}
+			n += got;
+		}
+		return n;
 	}
 private:
-	gzFile file_;
+	FILE* file_;
+	std::vector<uint8_t> prefix_;
+	size_t taken_;
+};
+
+// uncompressed BAM stream (magic BAM\1 at byte 0)
+class RawSource: public ByteSource {
+public:
+	RawSource(FILE* file, const uint8_t* prefix, size_t prefix_size): input_(file, prefix, prefix_size) {}
+	size_t read(uint8_t* buffer, size_t capacity) { return input_.read(buffer, capacity); }
+private:
+	PrefixedFile input_;
+};
+
+// plain gzip (RFC 1952, possibly several members) that is not BGZF: one inflate stream on the reader thread
+class GzipSource: public ByteSource {
+public:
+	GzipSource(FILE* file, const uint8_t* prefix, size_t prefix_size): input_(file, prefix, prefix_size), in_(1u << 20), in_fill_(0), in_at_(0), open_(false), end_(false) { memset(&stream_, 0, sizeof(stream_)); }
+	~GzipSource() { if (open_) inflateEnd(&stream_); }
+	size_t read(uint8_t* buffer, size_t capacity) {
+		size_t produced = 0;
+		while (produced == 0 && capacity > 0) {
+			if (in_at_ == in_fill_) {
+				if (end_) break;
+				in_fill_ = input_.read(&in_[0], in_.size()); in_at_ = 0;
+				if (in_fill_ == 0) { end_ = true; if (open_) throw std::runtime_error("failed to load alignments"); break; } // truncated member
+			}
+			if (!open_) {
+				if (inflateInit2(&stream_, 15 + 16) != Z_OK) throw std::runtime_error("failed to load alignments");
+				open_ = true;
+			}
+			stream_.next_in = &in_[in_at_]; stream_.avail_in = (unsigned int) (in_fill_ - in_at_);
+			stream_.next_out = buffer; stream_.avail_out = (unsigned int) std::min<size_t>(capacity, 1u << 30);
+			const int status = inflate(&stream_, Z_NO_FLUSH);
+			if (status != Z_OK && status != Z_STREAM_END && status != Z_BUF_ERROR) throw std::runtime_error("failed to load alignments");
+			in_at_ = in_fill_ - stream_.avail_in;
+			produced = std::min<size_t>(capacity, 1u << 30) - stream_.avail_out;
+			if (status == Z_STREAM_END) { inflateEnd(&stream_); open_ = false; } // the next member, if any, starts a new stream
+		}
+		return produced;
+	}
+private:
+	PrefixedFile input_;
+	std::vector<uint8_t> in_;
+	size_t in_fill_, in_at_;
+	z_stream stream_;
+	bool open_, end_;
 };
 
 class MemorySource: public ByteSource {
@@ -134,6 +185,7 @@ void decode_record(const uint8_t* p, uint32_t block_size, Record& r) {
 	r.flag = le16(p + 14);
 	r.l_seq = (int32_t) le32(p + 16);
 	const uint8_t* q = p + 32;
+	if (r.l_seq < 0 || l_read_name == 0) throw std::runtime_error("failed to load alignments"); // untrusted input: sizes are checked before they are used
 	size_t fixed = (size_t) l_read_name + 4 * (size_t) n_cigar + ((size_t) r.l_seq + 1) / 2 + (size_t) r.l_seq;
 	if (32 + fixed > block_size) throw std::runtime_error("failed to load alignments");
 	r.qname.assign((const char*) q, strnlen((const char*) q, l_read_name));
@@ -897,7 +949,7 @@ unsigned int ingest_threads() { // ARRIBA_INGEST_THREADS overrides; the reader i
 	const char* setting = getenv("ARRIBA_INGEST_THREADS");
 	if (setting != NULL && atoi(setting) > 0) return (unsigned int) atoi(setting);
 	unsigned int cores = std::thread::hardware_concurrency();
-	return std::max(1u, std::min(16u, cores > 1 ? cores - 1 : 1u));
+	return std::max(1u, std::min(48u, cores > 1 ? cores - 1 : 1u)); // one reader deals the records out: more workers than this wait for it
 }
 
 }
@@ -908,20 +960,10 @@ unsigned int ingest_threads() { // ARRIBA_INGEST_THREADS overrides; the reader i
 // work -- above all the CRC -- on the one thread that also cuts the stream into records; it limited the ingest to ~0.8 GB/s.
 class BgzfSource: public ByteSource {
 public:
-	static bool is_bgzf(const std::string& path) {
-		FILE* file = fopen(path.c_str(), "rb");
-		if (file == NULL) return false;
-		uint8_t header[18];
-		const bool complete = fread(header, 1, sizeof(header), file) == sizeof(header);
-		fclose(file);
-		return complete && block_size_from_header(header, sizeof(header)) > 0;
-	}
-	BgzfSource(const std::string& path, unsigned int n_threads): n_threads_(std::max(1u, n_threads)), raw_fill_(0), served_(0), end_of_file_(false) {
-		file_ = fopen(path.c_str(), "rb");
-		if (file_ == NULL) throw std::runtime_error("failed to open SAM file");
+	static bool is_bgzf_header(const uint8_t* header, size_t available) { return available >= 18 && block_size_from_header(header, available) > 0; }
+	BgzfSource(FILE* file, const uint8_t* prefix, size_t prefix_size, unsigned int n_threads): input_(file, prefix, prefix_size), n_threads_(std::max(1u, n_threads)), raw_fill_(0), served_(0), end_of_file_(false) {
 		raw_.resize(32u << 20);
 	}
-	~BgzfSource() { fclose(file_); }
 	size_t read(uint8_t* buffer, size_t capacity) {
 		while (served_ == decoded_.size()) { // decode the next batch of blocks
 			if (end_of_file_ && raw_fill_ == 0) return 0;
@@ -948,7 +990,7 @@ private:
 	struct Block { size_t raw_offset, raw_size, out_offset, out_size; };
 	void decode_batch() {
 		if (!end_of_file_) {
-			const size_t got = fread(&raw_[raw_fill_], 1, raw_.size() - raw_fill_, file_);
+			const size_t got = input_.read(&raw_[raw_fill_], raw_.size() - raw_fill_);
 			raw_fill_ += got;
 			if (got == 0) end_of_file_ = true;
 		}
@@ -990,16 +1032,28 @@ private:
 		memmove(&raw_[0], &raw_[at], raw_fill_ - at); // an incomplete block stays for the next batch
 		raw_fill_ -= at;
 	}
-	FILE* file_;
+	PrefixedFile input_;
 	unsigned int n_threads_;
 	std::vector<uint8_t> raw_, decoded_;
 	size_t raw_fill_, served_;
 	bool end_of_file_;
 };
 
+// The container is recognised from the first 18 bytes of the ONE open stream (never by opening the path a second time: it may be a pipe):
+// a BGZF block header -> block-parallel inflate; any other gzip member -> streaming inflate; otherwise the bytes are taken as the BAM stream.
 ByteSource* open_bam_file(const std::string& path) {
-	if (BgzfSource::is_bgzf(path)) return new BgzfSource(path, ingest_threads());
-	return new GzSource(path); // plain gzip or uncompressed: zlib's gz layer reads both
+	FILE* file = (path == "-") ? stdin : fopen(path.c_str(), "rb"); // htslib reads standard input for "-"
+	if (file == NULL) throw std::runtime_error("failed to open SAM file");
+	uint8_t header[18];
+	size_t got = 0;
+	while (got < sizeof(header)) {
+		const size_t n = fread(header + got, 1, sizeof(header) - got, file);
+		if (n == 0) break;
+		got += n;
+	}
+	if (BgzfSource::is_bgzf_header(header, got)) return new BgzfSource(file, header, got, ingest_threads());
+	if (got >= 2 && header[0] == 31 && header[1] == 139) return new GzipSource(file, header, got);
+	return new RawSource(file, header, got);
 }
 
 // reference: source/read_chimeric_alignments.cpp:560-773

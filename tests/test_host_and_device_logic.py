@@ -179,6 +179,44 @@ def test_ingest_reads_every_container_of_a_bam_stream(built, dataset_files, tmp_
             ingest(str(tmp_path / name))
 
 
+def test_ingest_reads_pipes_and_standard_input(built, dataset_files, tmp_path):
+    """The reference's standard invocation is a pipe: `STAR ... | arriba -x /dev/stdin` (run_arriba.sh:42; sam_open reads any path once,
+    source/read_chimeric_alignments.cpp:563).  The container must be recognised from the one open stream: a named pipe fed by the generator
+    (raw BAM, what bench.py does), and /dev/stdin / "-" of a child process with raw, BGZF and plain-gzip streams."""
+    import gzip
+    import subprocess
+    import sys
+    prefix = dataset_files("toy3k")
+    payload = _bam_payload(prefix + ".bam")
+    session = parity.open_session(prefix)
+    expected = _batch_columns(session)
+    expected["coverage"] = int(session._lib.ahost_coverage_checksum(session._session))
+    from arriba_amd.pipeline import HostSession
+    # (a) a FIFO fed by gen_synth --raw-bam-to, exactly as bench.py streams its workload
+    fifo = str(tmp_path / "records.fifo")
+    os.mkfifo(fifo)
+    producer = subprocess.Popen([datasets.GEN_SYNTH, "--out", str(tmp_path / "unused"), "--raw-bam-to", fifo] + datasets.DATASETS["toy3k"]["args"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    piped = HostSession(prefix + ".fa", prefix + ".gtf")
+    piped.read_chimeric_alignments(fifo)
+    assert producer.wait() == 0
+    columns = _batch_columns(piped)
+    columns["coverage"] = int(piped._lib.ahost_coverage_checksum(piped._session))
+    assert columns == expected
+    # (b) standard input of a child process: raw, BGZF (stored blocks), plain gzip; as /dev/stdin and as "-"
+    streams = {"raw": payload, "bgzf": open(prefix + ".bam", "rb").read(), "gzip": gzip.compress(payload, 1)}
+    child = ("import sys; sys.path[:0] = %r; import parity; from arriba_amd.pipeline import HostSession; "
+             "s = HostSession(%r, %r); s.read_chimeric_alignments(sys.argv[1]); "
+             "print(s.fragment_count, s.mapped_reads, s._lib.ahost_coverage_checksum(s._session))") % ([conftest.ROOT, os.path.join(conftest.ROOT, "tests")], prefix + ".fa", prefix + ".gtf")
+    for name, data in streams.items():
+        for path in ("/dev/stdin", "-"):
+            result = subprocess.run([sys.executable, "-c", child, path], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert result.returncode == 0, (name, path, result.stderr.decode()[-500:])
+            assert result.stdout.decode().split() == [str(expected["n"]), str(expected["mapped_reads"]), str(expected["coverage"])], (name, path)
+    # a stream that is cut in the middle of a record is an error, not a short batch
+    result = subprocess.run([sys.executable, "-c", child, "/dev/stdin"], input=payload[:len(payload) // 2 + 7], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert result.returncode != 0 and b"failed to load alignments" in result.stderr
+
+
 def test_ingest_result_survives_save_and_load(built, dataset_files, tmp_path):
     from arriba_amd.pipeline import ArribaError, HostSession
     prefix = dataset_files("shuffled2k")
@@ -372,6 +410,24 @@ def test_workflow_with_library_options_against_the_live_reference(label, options
     os.makedirs(str(tmp_path / "mine"))
     stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, params=params, workflow_options=workflow_options, **ingest)
     assert stages[-1][1] > 100
+
+
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+@pytest.mark.parametrize("disabled", [["mismappers"], ["homologs", "mismappers"]])
+def test_workflow_with_mismappers_switched_off_against_the_live_reference(disabled, emu_api, tmp_path):
+    """-f mismappers: the reference skips the stage (source/arriba.cpp:562), reads and candidates keep their state; clipped segments copied from the
+    partner gene make the stage fire when it is on (the same dataset with the default filters discards reads as mis-mappers)"""
+    spec = {"args": ["--seed", "79", "--fragments", "15000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--partner-clip", "0.5", "--clip-min", "40", "--clip-max", "70",
+                     "--homolog-families", "4"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, spec, disable_filters=disabled))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, params={"disable_filters": disabled})
+    counts = dict(stages)
+    assert counts["filter_mismappers"] == counts["filter_homologs"] and stages[-1][1] > 20
 
 
 @pytest.mark.parametrize("name", ["toy3k", "wgs8k"])
