@@ -1,0 +1,745 @@
+// arriba_amd/csrc/device/ingest_core.hpp -- read_chimeric_alignments on the device: BAM records in HBM -> chimeric fragments.
+//
+// The stream of uncompressed BAM records lies in HBM as it came out of the container.  The functions below restate, on the raw record bytes,
+//   the record loop of read_chimeric_alignments   reference: source/read_chimeric_alignments.cpp:585-757   (replay_group)
+//   add_chimeric_alignment                        reference: source/read_chimeric_alignments.cpp:50-91     (materialize)
+//   find_spanning_intron                          reference: source/read_chimeric_alignments.cpp:19-41
+//   extract_read_through_alignment                reference: source/read_chimeric_alignments.cpp:93-193
+//   clipped_sequence_is_adapter                   reference: source/read_chimeric_alignments.cpp:197-211
+//   is_tandem_duplication                         reference: source/read_chimeric_alignments.cpp:215-336
+//   disjoin_split_read_segments                   reference: source/read_chimeric_alignments.cpp:340-373
+//   remove_malformed_alignments                   reference: source/read_chimeric_alignments.cpp:377-506   (normalize_plan)
+//   is_clipped_at_correct_end / is_pristine_alignment   reference: source/read_chimeric_alignments.cpp:511-558
+//   coverage_t::add_fragment                      reference: source/read_stats.cpp:161-266
+// What a record does depends only on the records of the same read name ("QNAME,HI") in front of it (the parked first mate, the alignment list of the
+// name) and on read-only data; counters and coverage windows commute.  So the records are grouped by name (hash + stable sort keeps the file order
+// inside a group) and one thread replays the reference's loop body over the records of one name.  A fragment is kept as a PLAN (which record, which
+// part of its CIGAR); start / end / CIGAR / sequence are derived from the record bytes whenever they are needed, nothing is copied before the final pack.
+// __host__ __device__: tests/emu steps the identical code on a CPU-only box; the product runs it inside the kernels of agpu_ingest.hip only.
+#ifndef AGPU_INGEST_CORE_HPP
+#define AGPU_INGEST_CORE_HPP 1
+
+#include "annotate_core.hpp"
+#include "event_core.hpp"
+
+namespace agpu {
+
+// ---- raw record access (SAMv1 section 4.2; little endian; fields are not aligned) ------------------------------------------------------------------
+
+AGPU_HD uint32_t load_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+AGPU_HD uint16_t load_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+enum : uint16_t { BAMF_PAIRED = 1, BAMF_PROPER_PAIR = 2, BAMF_UNMAP = 4, BAMF_MUNMAP = 8, BAMF_REVERSE = 16, BAMF_READ1 = 64, BAMF_SECONDARY = 256, BAMF_DUP = 1024, BAMF_SUPPLEMENTARY = 2048 };
+
+AGPU_HD bool op_consumes_query(uint32_t op) { return (0x3C1A7u >> (op << 1)) & 1; }      // bam_cigar_type, htslib
+AGPU_HD bool op_consumes_reference(uint32_t op) { return (0x3C1A7u >> (op << 1)) & 2; }
+
+struct IngestStream {
+	const uint8_t* bytes;            // uncompressed BAM stream (header + records)
+	uint64_t size;
+	const uint64_t* record_offset;   // [n_records] offset of the block_size word of every record
+	uint64_t n_records;
+	uint32_t n_targets;
+	const uint32_t* tid_to_contig;   // BAM reference id -> contig id of the session
+};
+
+// one record, its fixed fields decoded (the variable parts stay in the stream)
+struct Rec {
+	const uint8_t* cigar_bytes; const uint8_t* seq_bytes; const uint8_t* name; const uint8_t* aux; const uint8_t* end;
+	int32_t contig, pos, l_seq;
+	uint32_t n_cigar, l_read_name;
+	uint16_t flag;
+	AGPU_HD uint32_t cigar(uint32_t i) const { return load_u32(cigar_bytes + 4 * (size_t) i); }
+	AGPU_HD uint32_t op(uint32_t i) const { return cigar(i) & 15; }
+	AGPU_HD uint32_t len(uint32_t i) const { return cigar(i) >> 4; }
+	AGPU_HD uint32_t code(int32_t i) const { return (seq_bytes[i >> 1] >> ((~i & 1) << 2)) & 15; } // 4-bit base code, "=ACMGRSVTWYHKDBN"
+	AGPU_HD bool forward() const { return !(flag & BAMF_REVERSE); }
+	AGPU_HD bool paired() const { return flag & BAMF_PAIRED; }
+	AGPU_HD int32_t qlen(uint32_t n) const { int32_t l = 0; for (uint32_t i = 0; i < n; ++i) if (op_consumes_query(op(i))) l += (int32_t) len(i); return l; }
+	AGPU_HD int32_t rlen(uint32_t n) const { int32_t l = 0; for (uint32_t i = 0; i < n; ++i) if (op_consumes_reference(op(i))) l += (int32_t) len(i); return l; }
+	AGPU_HD int32_t endpos() const { int32_t l = (!(flag & BAMF_UNMAP) && n_cigar > 0) ? rlen(n_cigar) : 1; return pos + (l == 0 ? 1 : l); } // bam_endpos
+};
+
+// validity of the sizes inside a record block (checked once per record; a violation is the reference's "failed to load alignments")
+AGPU_HD bool record_sizes_ok(const uint8_t* block, uint32_t block_size) {
+	if (block_size < 32) return false;
+	const uint32_t l_read_name = block[8], n_cigar = load_u16(block + 12);
+	const int32_t l_seq = (int32_t) load_u32(block + 16);
+	if (l_seq < 0 || l_read_name == 0) return false;
+	const uint64_t fixed = 32ull + l_read_name + 4ull * n_cigar + ((uint64_t) l_seq + 1) / 2 + (uint64_t) l_seq;
+	return fixed <= block_size;
+}
+
+AGPU_HD Rec load_record(const IngestStream& in, uint32_t r) {
+	const uint8_t* p = in.bytes + in.record_offset[r];
+	const uint32_t block_size = load_u32(p);
+	p += 4;
+	Rec rec;
+	const int32_t tid = (int32_t) load_u32(p);
+	rec.contig = (tid >= 0 && (uint32_t) tid < in.n_targets) ? (int32_t) in.tid_to_contig[tid] : -1;
+	rec.pos = (int32_t) load_u32(p + 4);
+	rec.l_read_name = p[8];
+	rec.n_cigar = load_u16(p + 12);
+	rec.flag = load_u16(p + 14);
+	rec.l_seq = (int32_t) load_u32(p + 16);
+	rec.name = p + 32;
+	rec.cigar_bytes = rec.name + rec.l_read_name;
+	rec.seq_bytes = rec.cigar_bytes + 4 * (size_t) rec.n_cigar;
+	rec.aux = rec.seq_bytes + ((size_t) rec.l_seq + 1) / 2 + (size_t) rec.l_seq;
+	rec.end = p + block_size;
+	return rec;
+}
+
+// aux fields: the first "HI" (integer types) and the presence of "SA", as bam_aux_get would find them (a malformed field ends the walk)
+struct AuxTags { bool has_hi, has_sa; int64_t hi; };
+AGPU_HD AuxTags scan_aux(const uint8_t* s, const uint8_t* end) {
+	AuxTags tags; tags.has_hi = false; tags.has_sa = false; tags.hi = 0;
+	while (s + 3 <= end) {
+		const uint8_t* value = s + 2;
+		size_t size;
+		switch (*value) {
+			case 'A': case 'c': case 'C': size = 2; break;
+			case 's': case 'S': size = 3; break;
+			case 'i': case 'I': case 'f': size = 5; break;
+			case 'd': size = 9; break;
+			case 'Z': case 'H': { const uint8_t* p = value + 1; while (p < end && *p) ++p; if (p >= end) return tags; size = (size_t) (p - value) + 1; break; }
+			case 'B': {
+				if (value + 6 > end) return tags;
+				const size_t element = (value[1] == 'c' || value[1] == 'C') ? 1 : (value[1] == 's' || value[1] == 'S') ? 2 : 4;
+				size = 6 + element * (size_t) load_u32(value + 2);
+				break;
+			}
+			default: return tags;
+		}
+		if (value + size > end) return tags;
+		if (s[0] == 'H' && s[1] == 'I' && !tags.has_hi) {
+			tags.has_hi = true;
+			switch (*value) { // bam_aux2i
+				case 'c': tags.hi = (int8_t) value[1]; break;
+				case 'C': tags.hi = value[1]; break;
+				case 's': tags.hi = (int16_t) load_u16(value + 1); break;
+				case 'S': tags.hi = load_u16(value + 1); break;
+				case 'i': tags.hi = (int32_t) load_u32(value + 1); break;
+				case 'I': tags.hi = load_u32(value + 1); break;
+				default: tags.hi = 0; break;
+			}
+		}
+		if (s[0] == 'S' && s[1] == 'A') tags.has_sa = true;
+		if (tags.has_hi && tags.has_sa) return tags;
+		s = value + size;
+	}
+	return tags;
+}
+
+// per-record verdict of the first lines of the loop body (source/read_chimeric_alignments.cpp:611-631)
+enum : uint8_t { RECORD_SKIPPED = 0, RECORD_ACTIVE = 1, RECORD_MISSING_HI = 2, RECORD_BROKEN = 3, RECORD_STATUS_MASK = 3, RECORD_HAS_SA = 4 };
+
+AGPU_HD uint32_t qname_length(const Rec& r) { uint32_t n = 0; while (n < r.l_read_name && r.name[n]) ++n; return n; }
+
+// 64-bit key of "QNAME,HI": FNV-1a over the name bytes, the hit index mixed in, finalised (murmur3 fmix64); ~0 is reserved for records that take no part
+AGPU_HD uint64_t name_key(const Rec& r, int64_t hit_index, uint64_t seed) {
+	uint64_t h = 1469598103934665603ull ^ seed;
+	for (uint32_t i = 0; i < r.l_read_name && r.name[i]; ++i) h = (h ^ r.name[i]) * 1099511628211ull;
+	h ^= (uint64_t) hit_index * 0x9E3779B97F4A7C15ull;
+	h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
+	return h == ~0ull ? ~0ull - 1 : h;
+}
+AGPU_HD bool same_name(const Rec& a, int64_t hi_a, const Rec& b, int64_t hi_b) {
+	if (hi_a != hi_b) return false;
+	const uint32_t n = qname_length(a);
+	if (n != qname_length(b)) return false;
+	for (uint32_t i = 0; i < n; ++i) if (a.name[i] != b.name[i]) return false;
+	return true;
+}
+
+// ---- plans: a fragment as references into the stream ----------------------------------------------------------------------------------------------
+
+enum : uint8_t { CLIP_NONE = 0, CLIP_START = 1, CLIP_END = 2, PLAN_TANDEM = 3 };
+const uint32_t NO_RECORD = 0xFFFFFFFFu;
+
+struct PlanEntry { uint32_t record; uint16_t cigar_index; uint8_t clip; uint8_t supplementary; };
+// the alignment is_tandem_duplication synthesises (source/read_chimeric_alignments.cpp:316-334)
+struct TandemAlignment { int32_t start, end; uint32_t cigar[3]; uint32_t record; uint8_t n_cigar, strand, first_in_pair, supplementary; };
+struct FragmentPlan { // mates_t while it is being filled: the first three alignments and how many were pushed
+	PlanEntry entry[3];
+	uint8_t count;        // saturates at 255; more than three alignments are malformed anyway
+	uint8_t single_end, duplicate, reserved;
+};
+struct TandemPlan { FragmentPlan plan; TandemAlignment tandem; };
+
+AGPU_HD void plan_clear(FragmentPlan& plan) { plan.count = 0; plan.single_end = 0; plan.duplicate = 0; plan.reserved = 0; for (int k = 0; k < 3; ++k) { plan.entry[k].record = NO_RECORD; plan.entry[k].cigar_index = 0; plan.entry[k].clip = 0; plan.entry[k].supplementary = 0; } }
+AGPU_HD void plan_push(FragmentPlan& plan, uint32_t record, const Rec& r, bool is_supplementary, uint32_t cigar_index, uint8_t clip) { // add_chimeric_alignment
+	plan.single_end = !(r.flag & BAMF_PAIRED);
+	plan.duplicate = plan.duplicate || (r.flag & BAMF_DUP);
+	if (plan.count < 3) {
+		PlanEntry& e = plan.entry[plan.count];
+		e.record = record; e.cigar_index = (uint16_t) cigar_index; e.clip = clip; e.supplementary = is_supplementary;
+	}
+	if (plan.count < 255) ++plan.count;
+}
+AGPU_HD void plan_push_tandem(FragmentPlan& plan) {
+	if (plan.count < 3) { PlanEntry& e = plan.entry[plan.count]; e.record = NO_RECORD; e.cigar_index = 0; e.clip = PLAN_TANDEM; e.supplementary = 0; }
+	if (plan.count < 255) ++plan.count;
+}
+
+// an alignment_t derived from a plan entry (source/common.hpp:191-207); its CIGAR is the record's, cut as add_chimeric_alignment cuts it, with up to
+// two elements replaced afterwards (remove_malformed_alignments rewrites clipped elements)
+struct Aln {
+	Rec rec;                 // source record (CIGAR); for a tandem alignment the record the sequence comes from
+	uint32_t record;         // its index, NO_RECORD for a tandem alignment without sequence
+	uint32_t sequence_record; // record whose bases are this alignment's `sequence`, NO_RECORD = empty
+	int32_t sequence_length;
+	int32_t contig, start, end;
+	uint32_t n_cigar;
+	uint32_t cigar_index;
+	uint32_t patch_index[2], patch_value[2];
+	uint32_t tandem_cigar[3];
+	uint8_t clip, n_patch;
+	bool supplementary, first_in_pair, strand;
+	AGPU_HD uint32_t base_cigar(uint32_t i) const {
+		if (clip == PLAN_TANDEM) return tandem_cigar[i];
+		if (clip == CLIP_START) {
+			if (i == 0) return (uint32_t) rec.qlen(cigar_index) << 4 | (rec.op(0) == CIGAR_H ? CIGAR_H : CIGAR_S);
+			return rec.cigar(cigar_index + i - 1);
+		}
+		if (clip == CLIP_END) {
+			if (i == cigar_index + 1) return (uint32_t) (rec.l_seq - rec.qlen(cigar_index + 1)) << 4 | (rec.op(rec.n_cigar - 1) == CIGAR_H ? CIGAR_H : CIGAR_S);
+			return rec.cigar(i);
+		}
+		return rec.cigar(i);
+	}
+	AGPU_HD uint32_t cigar(uint32_t i) const {
+		uint32_t value = base_cigar(i);
+		for (uint32_t k = 0; k < n_patch; ++k) if (patch_index[k] == i) value = patch_value[k]; // later rewrites win
+		return value;
+	}
+	AGPU_HD void set_cigar(uint32_t i, uint32_t value) {
+		for (uint32_t k = 0; k < n_patch; ++k) if (patch_index[k] == i) { patch_value[k] = value; return; }
+		if (n_patch < 2) { patch_index[n_patch] = i; patch_value[n_patch] = value; ++n_patch; }
+	}
+	AGPU_HD uint32_t preclipping() const { const uint32_t c = cigar(0), op = c & 15; return (op == CIGAR_S || op == CIGAR_H) ? c >> 4 : 0; }
+	AGPU_HD uint32_t postclipping() const { const uint32_t c = cigar(n_cigar - 1), op = c & 15; return (op == CIGAR_S || op == CIGAR_H) ? c >> 4 : 0; }
+};
+
+AGPU_HD Aln materialize(const IngestStream& in, const PlanEntry& e, const TandemAlignment* tandem) {
+	Aln a;
+	a.n_patch = 0; a.patch_index[0] = a.patch_index[1] = 0; a.patch_value[0] = a.patch_value[1] = 0;
+	a.tandem_cigar[0] = a.tandem_cigar[1] = a.tandem_cigar[2] = 0;
+	a.clip = e.clip; a.cigar_index = e.cigar_index;
+	if (e.clip == PLAN_TANDEM) {
+		a.rec = load_record(in, tandem->record);
+		a.record = NO_RECORD;
+		a.supplementary = tandem->supplementary; a.first_in_pair = tandem->first_in_pair; a.strand = tandem->strand;
+		a.contig = a.rec.contig; a.start = tandem->start; a.end = tandem->end;
+		a.n_cigar = tandem->n_cigar;
+		for (int k = 0; k < 3; ++k) a.tandem_cigar[k] = tandem->cigar[k];
+		a.sequence_record = a.supplementary ? NO_RECORD : tandem->record;
+		a.sequence_length = a.supplementary ? 0 : a.rec.l_seq;
+		return a;
+	}
+	a.rec = load_record(in, e.record);
+	a.record = e.record;
+	const Rec& r = a.rec;
+	a.strand = r.forward(); a.first_in_pair = r.flag & BAMF_READ1; a.contig = r.contig; a.supplementary = e.supplementary;
+	a.sequence_record = e.supplementary ? NO_RECORD : e.record;
+	a.sequence_length = e.supplementary ? 0 : r.l_seq;
+	if (e.clip == CLIP_START) {
+		a.start = r.pos + r.rlen(e.cigar_index); a.end = r.endpos() - 1;
+		a.n_cigar = r.n_cigar - e.cigar_index + 1;
+	} else if (e.clip == CLIP_END) {
+		a.start = r.pos; a.end = r.pos + r.rlen((uint32_t) e.cigar_index + 1) - 1;
+		a.n_cigar = (uint32_t) e.cigar_index + 2;
+	} else {
+		a.start = r.pos; a.end = r.endpos() - 1;
+		a.n_cigar = r.n_cigar;
+	}
+	return a;
+}
+
+// ---- the helpers of the loop body ------------------------------------------------------------------------------------------------------------------
+
+// reference: source/read_chimeric_alignments.cpp:511-522
+AGPU_HD bool is_clipped_at_correct_end(const Rec& r) {
+	if (!(r.flag & BAMF_PAIRED)) return true;
+	if (r.n_cigar == 0) return false;
+	uint32_t clipped_end;
+	if (r.flag & BAMF_SUPPLEMENTARY) clipped_end = r.forward() ? r.n_cigar - 1 : 0;
+	else clipped_end = r.forward() ? 0 : r.n_cigar - 1;
+	const uint32_t op = r.op(clipped_end);
+	return op == CIGAR_S || op == CIGAR_H;
+}
+
+// reference: source/read_chimeric_alignments.cpp:526-558 (the comparison of characters is a comparison of 4-bit codes)
+AGPU_HD bool is_pristine_alignment(const Rec& r) {
+	for (uint32_t i = 0; i < r.n_cigar; ++i) {
+		const uint32_t op = r.op(i);
+		if (op != CIGAR_N && op != CIGAR_M && op != CIGAR_X) return false;
+	}
+	const uint32_t size = (uint32_t) r.l_seq;
+	for (uint32_t i = 2, repeat = 0, count = 1; i + 2 < size; i += 2) {
+		if (r.code(i) == r.code(repeat) && r.code(i + 1) == r.code(repeat + 1)) {
+			count++;
+		} else if (r.code(i + 1) == r.code(repeat + 1) && r.code(i + 2) == r.code(repeat + 2)) {
+			count++;
+			i++;
+		} else {
+			count = 1;
+			repeat = i;
+		}
+		if (count >= 8) return false;
+	}
+	return true;
+}
+
+// reference: source/read_chimeric_alignments.cpp:197-211
+AGPU_HD bool clipped_sequence_is_adapter(const Rec& mate1, const Rec* mate2) {
+	if (mate2 == nullptr) return false;
+	if (mate1.pos == mate2->pos && mate1.n_cigar > 0 && mate2->n_cigar > 0) {
+		if (!mate1.forward() && mate1.op(0) == CIGAR_S && mate2->forward() && mate2->op(mate2->n_cigar - 1) == CIGAR_S && mate1.len(0) == mate2->len(mate2->n_cigar - 1)) return true;
+		if (!mate2->forward() && mate2->op(0) == CIGAR_S && mate1.forward() && mate1.op(mate1.n_cigar - 1) == CIGAR_S && mate2->len(0) == mate1.len(mate1.n_cigar - 1)) return true;
+	}
+	return false;
+}
+
+AGPU_HD char base_character(uint32_t code) { return "=ACMGRSVTWYHKDBN"[code]; }
+
+// reference: source/read_chimeric_alignments.cpp:215-336 (integer types as there: its mixed signed/unsigned arithmetic is part of the result)
+AGPU_HD bool is_tandem_duplication(const Rec* r, uint32_t record, const GenomeView& genome, const uint32_t max_itd_length, TandemAlignment& tandem) {
+	const unsigned int min_clipped_length = 12, min_duplication_length = 9, max_duplication_length = max_itd_length;
+	const unsigned int max_mismatches = 1, max_non_template_bases = 6, min_alignment_length = 15;
+	if (r == nullptr || r->n_cigar == 0) return false;
+	unsigned int clipped_length = 0, clipped_position = 0;
+	bool clipped_start = true;
+	int direction = +1, window_start = 0, window_end = 0, extended_read_start = 0;
+	if (r->op(0) == CIGAR_S && r->len(0) >= min_clipped_length) {
+		clipped_length = r->len(0);
+		clipped_position = 0;
+		direction = -1;
+		window_start = r->pos + min_duplication_length - clipped_length;
+		window_end = r->pos + max_duplication_length - clipped_length;
+		extended_read_start = r->pos - clipped_length;
+		clipped_start = true;
+	}
+	if (r->op(r->n_cigar - 1) == CIGAR_S && r->len(r->n_cigar - 1) >= (min_clipped_length > clipped_length ? min_clipped_length : clipped_length)) {
+		clipped_length = r->len(r->n_cigar - 1);
+		clipped_position = r->l_seq - clipped_length;
+		direction = +1;
+		window_start = r->endpos() - max_duplication_length;
+		window_end = r->endpos() - min_duplication_length;
+		extended_read_start = r->endpos();
+		clipped_start = false;
+	}
+	if (clipped_length == 0) return false;
+	if (r->contig < 0 || (uint32_t) r->contig >= genome.n_contigs) return false;
+	const uint64_t contig_begin = genome.contig_offset[r->contig];
+	const uint64_t contig_size = genome.contig_offset[r->contig + 1] - contig_begin; // size_t in the reference
+	if (contig_size == 0) return false; // assembly.has()
+	const char* contig_sequence = genome.bases + contig_begin;
+	if ((uint64_t) (unsigned int) (window_end + max_duplication_length + clipped_length + 1) >= contig_size ||
+	    window_start <= (int) (max_duplication_length + clipped_length + 1))
+		return false;
+
+	const float min_extended_align_fraction = 0.7;
+	unsigned int extended_matches = 0;
+	for (unsigned int read_pos = 0; read_pos < clipped_length; ++read_pos)
+		if ((uint64_t) (unsigned int) (extended_read_start + read_pos) < contig_size)
+			if (contig_sequence[(unsigned int) (extended_read_start + read_pos)] == base_character(r->code((int32_t) (clipped_position + read_pos))))
+				extended_matches++;
+	if (1.0 * extended_matches / clipped_length >= min_extended_align_fraction) return false;
+
+	for (int contig_pos = window_start; contig_pos <= window_end; ++contig_pos) {
+		unsigned int matches = 0, mismatches = 0;
+		int tandem_start = (int) contig_size, tandem_end = -1;
+		for (unsigned int i = 0; i < clipped_length; i++) {
+			const int read_pos = (direction == +1) ? (int) i : (int) (clipped_length - 1 - i);
+			if (contig_sequence[contig_pos + read_pos] == base_character(r->code((int32_t) clipped_position + read_pos))) {
+				matches++;
+				if (contig_pos + read_pos < tandem_start) tandem_start = contig_pos + read_pos;
+				if (contig_pos + read_pos > tandem_end) tandem_end = contig_pos + read_pos;
+			} else if (i >= max_non_template_bases) {
+				mismatches++;
+				if (mismatches > max_mismatches) break;
+			}
+		}
+		if (matches >= min_alignment_length || matches + mismatches == clipped_length) {
+			tandem.start = tandem_start; tandem.end = tandem_end;
+			tandem.record = record;
+			tandem.strand = r->forward();
+			tandem.first_in_pair = (r->flag & BAMF_READ1) != 0;
+			tandem.supplementary = !(r->flag & BAMF_PAIRED) || (clipped_start && r->forward()) || (!clipped_start && !r->forward());
+			uint32_t clip_left = clipped_start ? 0 : r->l_seq - clipped_length;
+			uint32_t clip_right = clipped_start ? r->l_seq - clipped_length : 0;
+			if (tandem_start > contig_pos) clip_left += tandem_start - contig_pos;
+			if (tandem_end < contig_pos + (int) clipped_length - 1) clip_right += contig_pos + clipped_length - 1 - tandem_end;
+			tandem.n_cigar = 0;
+			tandem.cigar[0] = tandem.cigar[1] = tandem.cigar[2] = 0;
+			if (clip_left > 0) tandem.cigar[tandem.n_cigar++] = clip_left << 4 | CIGAR_S;
+			tandem.cigar[tandem.n_cigar++] = (uint32_t) (tandem_end - tandem_start + 1) << 4 | CIGAR_M;
+			if (clip_right > 0) tandem.cigar[tandem.n_cigar++] = clip_right << 4 | CIGAR_S;
+			return true;
+		}
+	}
+	return false;
+}
+
+// reference: source/read_chimeric_alignments.cpp:19-41
+AGPU_HD bool find_spanning_intron(const Rec& r, int32_t gene1_end, int32_t gene2_start, uint32_t& cigar_index, int32_t& read_pos) {
+	if (r.n_cigar < 3) return false;
+	int32_t before = r.pos, after;
+	for (uint32_t i = 0; i < r.n_cigar; ++i) {
+		const uint32_t op = r.op(i);
+		const uint32_t op_length = op_consumes_reference(op) ? r.len(i) : 0;
+		after = before + (int32_t) op_length;
+		if (op == CIGAR_N && ((before <= gene1_end && after > gene1_end) || (before < gene2_start && after >= gene2_start))) {
+			cigar_index = i;
+			read_pos = r.qlen(i);
+			return true;
+		}
+		before = after;
+	}
+	return false;
+}
+
+// genes at one position (get_annotation_by_coordinate with start == end: one bucket of the index, ascending ids)
+AGPU_HD ListRef genes_at(const FlatIndexView& gene_index, int32_t contig, int32_t position) {
+	if (contig < 0 || (uint32_t) contig >= gene_index.n_contigs) return empty_list();
+	const uint32_t k = index_lower_bound(gene_index, (uint32_t) contig, position);
+	if (k == gene_index.contig_offset[contig + 1]) return empty_list();
+	return index_bucket(gene_index, k);
+}
+AGPU_HD bool lists_intersect(ListRef a, ListRef b) {
+	uint32_t i = 0, j = 0;
+	while (i < a.n && j < b.n) { const uint32_t x = a.p[i], y = b.p[j]; if (x < y) ++i; else if (y < x) ++j; else return true; }
+	return false;
+}
+// reference: get_boundaries_of_biggest_gene, source/annotation.cpp:558-567
+AGPU_HD void boundaries_of_biggest_gene(const AnnotationView& ann, ListRef genes, int32_t& start, int32_t& end) {
+	start = -1; end = -1;
+	for (uint32_t g = 0; g < genes.n; ++g) {
+		const int32_t gene_start = ann.gene_start[genes.p[g]], gene_end = ann.gene_end[genes.p[g]];
+		if (start == -1 || start > gene_start) start = gene_start;
+		if (end == -1 || end < gene_end) end = gene_end;
+	}
+}
+
+// reference: source/read_chimeric_alignments.cpp:93-193.  `record` is never null; `previous` may be.
+AGPU_HD bool extract_read_through_alignment(FragmentPlan& plan, uint32_t record_index, const Rec& record, uint32_t previous_index, const Rec* previous, const AnnotationView& ann) {
+	const Rec* forward_mate = &record; const Rec* reverse_mate = previous;
+	uint32_t forward_index = record_index, reverse_index = previous_index;
+	if (!forward_mate->forward()) { const Rec* t = forward_mate; forward_mate = reverse_mate; reverse_mate = t; const uint32_t ti = forward_index; forward_index = reverse_index; reverse_index = ti; }
+	ListRef forward_genes, reverse_genes;
+	if (forward_mate != nullptr) forward_genes = genes_at(ann.gene_index, forward_mate->contig, forward_mate->pos);
+	else forward_genes = genes_at(ann.gene_index, reverse_mate->contig, reverse_mate->pos);
+	if (reverse_mate != nullptr) reverse_genes = genes_at(ann.gene_index, reverse_mate->contig, reverse_mate->endpos());
+	else reverse_genes = genes_at(ann.gene_index, forward_mate->contig, forward_mate->endpos());
+	const bool common_empty = !lists_intersect(forward_genes, reverse_genes);
+	if (!(common_empty && !(forward_genes.n == 0 && reverse_genes.n == 0))) return false;
+
+	int32_t forward_gene_start, forward_gene_end, reverse_gene_start, reverse_gene_end;
+	boundaries_of_biggest_gene(ann, forward_genes, forward_gene_start, forward_gene_end);
+	boundaries_of_biggest_gene(ann, reverse_genes, reverse_gene_start, reverse_gene_end);
+	if (forward_gene_end == -1) forward_gene_end = reverse_gene_start - 1;
+	if (reverse_gene_start == -1) reverse_gene_start = forward_gene_end + 1;
+
+	uint32_t forward_cigar_op = 0, reverse_cigar_op = 0;
+	int32_t forward_read_pos = 0, reverse_read_pos = 0;
+	const bool forward_has_intron = (forward_mate == nullptr) ? false : find_spanning_intron(*forward_mate, forward_gene_end, reverse_gene_start, forward_cigar_op, forward_read_pos);
+	const bool reverse_has_intron = (reverse_mate == nullptr) ? false : find_spanning_intron(*reverse_mate, forward_gene_end, reverse_gene_start, reverse_cigar_op, reverse_read_pos);
+	const bool is_new = plan.count == 0; // fragments.insert(...).second
+	if (forward_has_intron && (!reverse_has_intron || forward_read_pos < reverse_mate->l_seq - reverse_read_pos)) {
+		if (is_new) {
+			plan_push(plan, forward_index, *forward_mate, false, forward_cigar_op + 1, CLIP_START);
+			plan_push(plan, forward_index, *forward_mate, true, forward_cigar_op - 1, CLIP_END);
+			if (reverse_mate != nullptr) {
+				if (reverse_has_intron) plan_push(plan, reverse_index, *reverse_mate, false, reverse_cigar_op + 1, CLIP_START);
+				else plan_push(plan, reverse_index, *reverse_mate, false, 0, CLIP_NONE);
+			}
+			return true;
+		}
+	} else if (reverse_has_intron) {
+		if (is_new) {
+			plan_push(plan, reverse_index, *reverse_mate, true, reverse_cigar_op + 1, CLIP_START);
+			plan_push(plan, reverse_index, *reverse_mate, false, reverse_cigar_op - 1, CLIP_END);
+			if (forward_mate != nullptr) {
+				if (forward_has_intron) plan_push(plan, forward_index, *forward_mate, false, forward_cigar_op - 1, CLIP_END);
+				else plan_push(plan, forward_index, *forward_mate, false, 0, CLIP_NONE);
+			}
+			return true;
+		}
+	} else if (forward_mate != nullptr && reverse_mate != nullptr && reverse_mate->pos >= reverse_gene_start && forward_mate->endpos() <= forward_gene_end) {
+		if (is_new) {
+			plan_push(plan, forward_index, *forward_mate, false, 0, CLIP_NONE);
+			plan_push(plan, reverse_index, *reverse_mate, false, 0, CLIP_NONE);
+		}
+		return true;
+	}
+	return false;
+}
+
+// ---- coverage (reference: coverage_t::add_fragment, source/read_stats.cpp:161-266) ----------------------------------------------------------------
+// The windows are shared by all threads: +1 with saturation commutes, so the windows are counted in 32 bits with relaxed atomics and clamped to the
+// reference's 16 bits when the ingest is over; the start/end flags are plain stores of 1.
+
+struct CoverageBuild {
+	uint32_t n_contigs;
+	const uint64_t* window_offset; // [n_contigs + 1]; a contig without sequence has no windows
+	uint32_t* windows;
+	uint8_t* fragment_starts;
+	uint8_t* fragment_ends;
+};
+
+AGPU_HD void coverage_increment(uint32_t* window) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	__hip_atomic_fetch_add(window, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+	__atomic_fetch_add(window, 1u, __ATOMIC_RELAXED);
+#endif
+}
+
+AGPU_HD void add_fragment_to_coverage(const CoverageBuild& coverage, const Rec& mate1, uint16_t flag1, const Rec* mate2_or_null, bool is_chimeric) {
+	const Rec& mate2 = (mate2_or_null == nullptr) ? mate1 : *mate2_or_null;
+	if (mate1.contig < 0 || (uint32_t) mate1.contig >= coverage.n_contigs || mate2.contig < 0 || (uint32_t) mate2.contig >= coverage.n_contigs) return;
+	const uint64_t begin1 = coverage.window_offset[mate1.contig], size1 = coverage.window_offset[mate1.contig + 1] - begin1;
+	const uint64_t begin2 = coverage.window_offset[mate2.contig], size2 = coverage.window_offset[mate2.contig + 1] - begin2;
+	if (size1 == 0 || size2 == 0) return;
+	// the reference compares bam_cigar_type() (0..3) with BAM_CSOFT_CLIP (4), which never matches: only the proper-pair flag turns a fragment chimeric here
+	if ((flag1 & BAMF_PAIRED) && !(flag1 & BAMF_PROPER_PAIR)) is_chimeric = true;
+	if (!is_chimeric) {
+		if (!(flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) coverage.fragment_starts[begin1 + (uint64_t) (mate1.pos / COVERAGE_RESOLUTION)] = 1;
+		else coverage.fragment_starts[begin2 + (uint64_t) (mate2.pos / COVERAGE_RESOLUTION)] = 1;
+	}
+	int32_t position1 = mate1.pos, position2 = mate2.pos;
+	int32_t position = position1 < position2 ? position1 : position2;
+	int32_t window = position / COVERAGE_RESOLUTION;
+	uint32_t i1 = 0, i2 = 0;
+	while (true) {
+		uint32_t op1 = 0, op2 = 0, length1, length2;
+		if (i1 < mate1.n_cigar) { op1 = mate1.cigar(i1); length1 = op_consumes_reference(op1 & 15) ? op1 >> 4 : 0; }
+		else { length1 = 0; if (position2 / COVERAGE_RESOLUTION > window) window = position2 / COVERAGE_RESOLUTION; }
+		if (i2 < mate2.n_cigar) { op2 = mate2.cigar(i2); length2 = op_consumes_reference(op2 & 15) ? op2 >> 4 : 0; }
+		else { length2 = 0; if (position1 / COVERAGE_RESOLUTION > window) window = position1 / COVERAGE_RESOLUTION; }
+		uint32_t op;
+		uint64_t begin, size;
+		if (i1 < mate1.n_cigar && (position1 + (int32_t) length1 < position2 + (int32_t) length2 || i2 >= mate2.n_cigar)) {
+			i1++;
+			if (length1 == 0) continue;
+			op = op1; begin = begin1; size = size1; position1 += (int32_t) length1; position = position1;
+		} else if (i2 < mate2.n_cigar) {
+			i2++;
+			if (length2 == 0) continue;
+			op = op2; begin = begin2; size = size2; position2 += (int32_t) length2; position = position2;
+		} else {
+			break;
+		}
+		if (op_consumes_query(op & 15)) {
+			while (window <= position / COVERAGE_RESOLUTION) {
+				if (window >= 0 && (uint64_t) window < size && position - window * COVERAGE_RESOLUTION >= COVERAGE_RESOLUTION / 2) coverage_increment(&coverage.windows[begin + (uint64_t) window]);
+				++window;
+			}
+		} else {
+			window = position / COVERAGE_RESOLUTION;
+		}
+	}
+	if (!is_chimeric) {
+		if ((flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) coverage.fragment_ends[begin1 + (uint64_t) ((position1 - 1) / COVERAGE_RESOLUTION)] = 1;
+		else coverage.fragment_ends[begin2 + (uint64_t) ((position2 - 1) / COVERAGE_RESOLUTION)] = 1;
+	}
+}
+
+// ---- the loop body over the records of one read name ----------------------------------------------------------------------------------------------
+
+struct IngestContext {
+	IngestStream stream;
+	AnnotationView annotation;   // GTF genes (gene_index before the dummy genes)
+	GenomeView genome;           // contig_bits: interesting / viral
+	CoverageBuild coverage;
+	const uint8_t* record_bits;  // RECORD_* per record
+	uint32_t max_itd_length;
+	uint8_t external_duplicate_marking;
+};
+
+struct GroupTally { uint32_t malformed; uint32_t chimeric; }; // malformed_count, !no_chimeric_reads
+
+// `records` = the indices of the active records of one "QNAME,HI" in stream order.  plain = fragments[read_name], itd = fragments[read_name + "ITD"].
+// viral_reads[contig] += pristine reads (64-bit counters).
+template <class ViralCounter> AGPU_HD void replay_group(const IngestContext& ctx, const uint32_t* records, uint32_t n_records, FragmentPlan& plain, TandemPlan& itd, GroupTally& tally, ViralCounter& count_viral_read) {
+	plan_clear(plain); plan_clear(itd.plan);
+	itd.tandem.start = 0; itd.tandem.end = 0; itd.tandem.cigar[0] = itd.tandem.cigar[1] = itd.tandem.cigar[2] = 0; itd.tandem.record = NO_RECORD;
+	itd.tandem.n_cigar = 0; itd.tandem.strand = 0; itd.tandem.first_in_pair = 0; itd.tandem.supplementary = 0;
+	uint32_t parked = NO_RECORD; // the first mate waiting for the second (the reference's collated_bam_records)
+	for (uint32_t k = 0; k < n_records; ++k) {
+		const uint32_t index = records[k];
+		const Rec record = load_record(ctx.stream, index);
+		if (record.flag & BAMF_SUPPLEMENTARY) {
+			if (is_clipped_at_correct_end(record)) plan_push(plain, index, record, true, 0, CLIP_NONE);
+			else tally.malformed++;
+			tally.chimeric = 1;
+			continue;
+		}
+		if ((record.flag & BAMF_PAIRED) && !(record.flag & BAMF_PROPER_PAIR)) { // discordant mate
+			plan_push(plain, index, record, false, 0, CLIP_NONE);
+			tally.chimeric = 1;
+			if (!ctx.external_duplicate_marking || !(record.flag & BAMF_DUP)) add_fragment_to_coverage(ctx.coverage, record, 0 /* the reference zeroes the flag word */, nullptr, true);
+			continue;
+		}
+		uint32_t previous_index = NO_RECORD;
+		Rec previous_storage;
+		const Rec* previous = nullptr;
+		if (record.flag & BAMF_PAIRED) {
+			if (parked == NO_RECORD) { parked = index; continue; }
+			previous_index = parked; parked = NO_RECORD;
+			previous_storage = load_record(ctx.stream, previous_index);
+			previous = &previous_storage;
+		}
+		bool is_tandem_alignment = false;
+		if (!clipped_sequence_is_adapter(record, previous) && (previous == nullptr || record.forward() != previous->forward())) {
+			TandemAlignment tandem;
+			if (is_tandem_duplication(&record, index, ctx.genome, ctx.max_itd_length, tandem) || is_tandem_duplication(previous, previous_index, ctx.genome, ctx.max_itd_length, tandem)) {
+				plan_push(itd.plan, index, record, record.forward() == (bool) tandem.strand && !tandem.supplementary, 0, CLIP_NONE);
+				if (previous != nullptr) plan_push(itd.plan, previous_index, *previous, previous->forward() == (bool) tandem.strand && !tandem.supplementary, 0, CLIP_NONE);
+				if (itd.plan.count < 3) itd.tandem = tandem; // (a fourth alignment makes the fragment malformed whatever it is)
+				plan_push_tandem(itd.plan);
+				is_tandem_alignment = true;
+			}
+		}
+		bool is_read_through = false;
+		const bool record_has_sa = ctx.record_bits[index] & RECORD_HAS_SA, previous_has_sa = previous != nullptr && (ctx.record_bits[previous_index] & RECORD_HAS_SA);
+		if ((record_has_sa && is_clipped_at_correct_end(record)) || (previous_has_sa && is_clipped_at_correct_end(*previous))) {
+			plan_push(plain, index, record, false, 0, CLIP_NONE);
+			if (previous != nullptr) plan_push(plain, previous_index, *previous, false, 0, CLIP_NONE);
+			tally.chimeric = 1;
+		} else if (!is_tandem_alignment) {
+			is_read_through = extract_read_through_alignment(plain, index, record, previous_index, previous, ctx.annotation);
+			if (record.contig >= 0 && (ctx.genome.contig_bits[record.contig] & CBIT_VIRAL)) {
+				if (is_pristine_alignment(record)) count_viral_read((uint32_t) record.contig);
+				if (previous != nullptr && is_pristine_alignment(*previous)) count_viral_read((uint32_t) previous->contig);
+			}
+		}
+		if (!ctx.external_duplicate_marking || !(record.flag & BAMF_DUP)) add_fragment_to_coverage(ctx.coverage, record, record.flag, previous, is_read_through);
+	}
+}
+
+// ---- sanity check and slot order (reference: remove_malformed_alignments, source/read_chimeric_alignments.cpp:377-506) -----------------------------
+
+struct Fragment3 { Aln a[3]; uint32_t n; bool single_end, duplicate; };
+
+// reference: source/read_chimeric_alignments.cpp:340-373
+AGPU_HD bool disjoin_split_read_segments(Aln& split_read, Aln& supplementary) {
+	const int min_remaining_supplementary_segment = 10;
+	const unsigned int clipped_split_read = split_read.strand ? split_read.preclipping() : split_read.postclipping();
+	const unsigned int clipped_supplementary = supplementary.strand ? supplementary.postclipping() : supplementary.preclipping();
+	const int overlap = (int) split_read.sequence_length - clipped_split_read - clipped_supplementary;
+	if (overlap <= 0) return true;
+	const unsigned int clipped_op = supplementary.strand ? supplementary.n_cigar - 1 : 0;
+	const unsigned int matching_op = supplementary.strand ? clipped_op - 1 : 1;
+	if (supplementary.n_cigar < 2 || (supplementary.cigar(matching_op) & 15) != CIGAR_M || (int) (supplementary.cigar(matching_op) >> 4) < overlap + min_remaining_supplementary_segment) return false;
+	const uint32_t clipped_element = supplementary.cigar(clipped_op), matching_element = supplementary.cigar(matching_op);
+	supplementary.set_cigar(clipped_op, ((clipped_element >> 4) + overlap) << 4 | (clipped_element & 15));
+	supplementary.set_cigar(matching_op, ((matching_element >> 4) - overlap) << 4 | (matching_element & 15));
+	if (supplementary.strand) supplementary.end -= overlap; else supplementary.start += overlap;
+	return true;
+}
+
+AGPU_HD void swap_alignments(Aln& x, Aln& y) { const Aln t = x; x = y; y = t; }
+AGPU_HD void take_sequence(Aln& target, const Aln& source) { target.sequence_record = source.sequence_record; target.sequence_length = source.sequence_length; }
+
+// materialises the plan and applies the reference's checks; false = malformed (counted by the caller)
+AGPU_HD bool normalize_plan(const IngestStream& in, const FragmentPlan& plan, const TandemAlignment* tandem, Fragment3& f) {
+	f.single_end = plan.single_end; f.duplicate = plan.duplicate;
+	const uint32_t size = plan.count;
+	if (size < 2 || size > 3) return false; // every other size is rejected below in the reference, too (single-end wants 2, paired-end 2 or 3)
+	for (uint32_t k = 0; k < size; ++k) f.a[k] = materialize(in, plan.entry[k], tandem);
+	for (uint32_t k = 0; k < size; ++k) if (f.a[k].n_cigar == 0) return false; // (the reference reads cigar[0] of an empty CIGAR: undefined there)
+	Aln* a = f.a;
+	f.n = size;
+	if (plan.single_end) {
+		if (!(size == 2 && (a[MATE1].supplementary != a[MATE2].supplementary))) return false;
+		if (a[MATE1].end - a[MATE1].start > a[MATE2].end - a[MATE2].start) { a[2] = a[MATE2]; a[MATE2] = a[MATE1]; }
+		else { a[2] = a[MATE1]; a[MATE1] = a[MATE2]; }
+		f.n = 3;
+		if (!a[MATE1].supplementary) take_sequence(a[SPLIT_READ], a[MATE1]);
+		else if (!a[SPLIT_READ].supplementary) take_sequence(a[MATE1], a[SPLIT_READ]);
+		else { take_sequence(a[MATE1], a[SUPPLEMENTARY]); take_sequence(a[SPLIT_READ], a[SUPPLEMENTARY]); }
+		a[SUPPLEMENTARY].sequence_record = NO_RECORD; a[SUPPLEMENTARY].sequence_length = 0;
+		// hard clips become soft clips
+		if ((a[MATE1].cigar(0) & 15) == CIGAR_H) a[MATE1].set_cigar(0, a[MATE1].cigar(0) >> 4 << 4 | CIGAR_S);
+		if ((a[MATE1].cigar(a[MATE1].n_cigar - 1) & 15) == CIGAR_H) a[MATE1].set_cigar(a[MATE1].n_cigar - 1, a[MATE1].cigar(a[MATE1].n_cigar - 1) >> 4 << 4 | CIGAR_S);
+		if ((a[SPLIT_READ].cigar(0) & 15) == CIGAR_H) a[SPLIT_READ].set_cigar(0, a[SPLIT_READ].cigar(0) >> 4 << 4 | CIGAR_S);
+		if ((a[SPLIT_READ].cigar(a[SPLIT_READ].n_cigar - 1) & 15) == CIGAR_H) { // the length is taken from MATE1's CIGAR at SPLIT_READ's last index, as the reference does (:415)
+			const uint32_t last = a[SPLIT_READ].n_cigar - 1;
+			if (last >= a[MATE1].n_cigar) return false; // (std::vector::at throws there)
+			a[SPLIT_READ].set_cigar(last, a[MATE1].cigar(last) >> 4 << 4 | CIGAR_S);
+		}
+		a[SUPPLEMENTARY].supplementary = true; a[MATE1].supplementary = false; a[SPLIT_READ].supplementary = false;
+		bool flip_mate1_strand;
+		const bool same = a[SPLIT_READ].strand == a[SUPPLEMENTARY].strand;
+		const uint64_t length = (uint64_t) (uint32_t) a[SPLIT_READ].sequence_length; // size_t arithmetic in the reference
+		if (length - a[SPLIT_READ].preclipping() - (same ? a[SUPPLEMENTARY].postclipping() : a[SUPPLEMENTARY].preclipping()) <
+		    length - a[SPLIT_READ].postclipping() - (same ? a[SUPPLEMENTARY].preclipping() : a[SUPPLEMENTARY].postclipping()))
+			flip_mate1_strand = a[SPLIT_READ].strand == true;
+		else
+			flip_mate1_strand = a[SPLIT_READ].strand == false;
+		a[MATE1].strand = complement_strand_if(a[MATE1].strand, flip_mate1_strand);
+		a[SPLIT_READ].strand = complement_strand_if(a[SPLIT_READ].strand, !flip_mate1_strand);
+		a[SUPPLEMENTARY].strand = complement_strand_if(a[SUPPLEMENTARY].strand, !flip_mate1_strand);
+		a[MATE1].first_in_pair = !flip_mate1_strand;
+		a[SPLIT_READ].first_in_pair = flip_mate1_strand;
+		a[SUPPLEMENTARY].first_in_pair = flip_mate1_strand;
+		if (!disjoin_split_read_segments(a[SPLIT_READ], a[SUPPLEMENTARY])) return false;
+	} else {
+		if (size == 3) {
+			if (a[MATE1].supplementary) swap_alignments(a[MATE1], a[SUPPLEMENTARY]);
+			else if (a[MATE2].supplementary) swap_alignments(a[MATE2], a[SUPPLEMENTARY]);
+			if (a[SPLIT_READ].first_in_pair != a[SUPPLEMENTARY].first_in_pair) swap_alignments(a[MATE1], a[MATE2]);
+			if (a[MATE1].supplementary || a[SPLIT_READ].supplementary || !a[SUPPLEMENTARY].supplementary) return false;
+			if (a[MATE1].contig != a[SPLIT_READ].contig || a[MATE1].strand == a[SPLIT_READ].strand) return false;
+			if (!disjoin_split_read_segments(a[SPLIT_READ], a[SUPPLEMENTARY])) return false;
+		} else {
+			if (a[MATE1].supplementary || a[MATE2].supplementary) return false;
+		}
+	}
+	if ((a[MATE1].cigar(0) & 15) == CIGAR_H || (a[MATE1].cigar(a[MATE1].n_cigar - 1) & 15) == CIGAR_H ||
+	    (a[MATE2].cigar(0) & 15) == CIGAR_H || (a[MATE2].cigar(a[MATE2].n_cigar - 1) & 15) == CIGAR_H)
+		return false;
+	return true;
+}
+
+// ---- names ("QNAME,HI" [+ "ITD"]: the key of the reference's std::map, hazard H3) -------------------------------------------------------------------
+
+AGPU_HD uint32_t decimal_digits(int64_t value, char* out /* [21] */) { // std::to_string(long)
+	char reversed[21]; uint32_t n = 0;
+	uint64_t magnitude = value < 0 ? (uint64_t) (-(value + 1)) + 1 : (uint64_t) value;
+	do { reversed[n++] = (char) ('0' + magnitude % 10); magnitude /= 10; } while (magnitude > 0);
+	uint32_t at = 0;
+	if (value < 0) out[at++] = '-';
+	while (n > 0) out[at++] = reversed[--n];
+	return at;
+}
+
+struct FragmentName { const uint8_t* qname; uint32_t qname_length; char suffix[28]; uint32_t suffix_length; }; // suffix = "," + HI + ["ITD"]
+AGPU_HD FragmentName fragment_name(const Rec& representative, bool itd) {
+	FragmentName name;
+	name.qname = representative.name; name.qname_length = qname_length(representative);
+	const AuxTags tags = scan_aux(representative.aux, representative.end);
+	name.suffix[0] = ',';
+	name.suffix_length = 1 + decimal_digits(tags.has_hi ? tags.hi : 1, name.suffix + 1);
+	if (itd) { name.suffix[name.suffix_length++] = 'I'; name.suffix[name.suffix_length++] = 'T'; name.suffix[name.suffix_length++] = 'D'; }
+	return name;
+}
+AGPU_HD uint32_t name_length(const FragmentName& name) { return name.qname_length + name.suffix_length; }
+AGPU_HD uint8_t name_byte(const FragmentName& name, uint32_t i) { return i < name.qname_length ? name.qname[i] : (i - name.qname_length < name.suffix_length ? (uint8_t) name.suffix[i - name.qname_length] : 0); }
+// eight bytes of the name from position 8 * chunk, big endian, zero padded: unsigned comparison of the chunks in order == std::string::compare
+AGPU_HD uint64_t name_chunk(const FragmentName& name, uint32_t chunk) {
+	uint64_t value = 0;
+	for (uint32_t k = 0; k < 8; ++k) value = value << 8 | name_byte(name, 8 * chunk + k);
+	return value;
+}
+AGPU_HD int compare_names(const FragmentName& x, const FragmentName& y) {
+	const uint32_t nx = name_length(x), ny = name_length(y), n = nx < ny ? nx : ny;
+	for (uint32_t i = 0; i < n; ++i) { const uint8_t cx = name_byte(x, i), cy = name_byte(y, i); if (cx != cy) return cx < cy ? -1 : 1; }
+	return nx < ny ? -1 : nx > ny ? 1 : 0;
+}
+
+}
+
+#endif
