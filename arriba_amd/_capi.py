@@ -67,6 +67,31 @@ class BatchView(ctypes.Structure):
                 ("seq_pool_size", c_uint64), ("seq_pool", POINTER(c_uint8))]
 
 
+class IngestConfig(ctypes.Structure):
+    _fields_ = [("n_targets", c_uint32), ("tid_to_contig", POINTER(c_uint32)), ("first_record_offset", c_uint64), ("stream_size_hint", c_uint64), ("n_contigs", c_uint32),
+                ("coverage_window_offset", POINTER(c_uint64)), ("external_duplicate_marking", c_uint8), ("max_itd_length", c_uint32)]
+
+
+class BgzfBlock(ctypes.Structure):
+    _fields_ = [("raw_offset", c_uint64), ("payload_offset", c_uint32), ("payload_size", c_uint32), ("stream_offset", c_uint64), ("crc32", c_uint32), ("reserved", c_uint32)]
+
+
+class IngestResult(ctypes.Structure):
+    _fields_ = [("records", c_uint64), ("fragments", c_uint64), ("mapped_reads", c_uint64), ("malformed_count", c_uint64), ("missing_hi_tag", c_uint64), ("no_chimeric_reads", c_uint8),
+                ("names_were_sorted", c_uint8), ("reserved", c_uint8 * 6), ("stream_bytes", c_uint64)]
+
+
+class BamPiece(ctypes.Structure):
+    _fields_ = [("stored_bgzf", c_int), ("bytes", c_size_t), ("stream_bytes", c_size_t), ("n_blocks", c_uint32)]
+
+
+class BatchRows(ctypes.Structure):
+    _fields_ = [("n", c_uint64), ("n_aln", c_void_p), ("fbits", c_void_p), ("group", c_void_p),
+                ("contig", c_void_p * 3), ("start", c_void_p * 3), ("end", c_void_p * 3), ("abits", c_void_p * 3), ("cigar_offset", c_void_p * 3), ("cigar_count", c_void_p * 3),
+                ("cigar_pool_size", c_uint64), ("cigar_pool", c_void_p), ("seq_offset", c_void_p * 2), ("seq_length", c_void_p * 2), ("seq_pool_size", c_uint64), ("seq_pool", c_void_p),
+                ("name_offset", c_void_p), ("names_size", c_uint64), ("names", c_void_p)]
+
+
 class Params(ctypes.Structure):
     _fields_ = [("homopolymer_length", c_uint32), ("min_read_through_distance", c_uint32), ("max_itd_length", c_uint32), ("subsampling_threshold", c_uint32),
                 ("mismatch_pvalue_cutoff", c_float), ("max_kmer_content", c_float), ("evalue_cutoff", c_float), ("max_mismapper_fraction", c_float),
@@ -167,6 +192,18 @@ def bind_device_api(lib, prefix="agpu_"):
         "get_evalues": (c_int, [ctx, c_void_p]),
         "filter_candidate_predicates": (c_int, [ctx, c_void_p]),
         "filter_relative_support": (c_int, [ctx, POINTER(c_uint64)]),
+        "host_alloc": (c_void_p, [c_size_t]),
+        "host_free": (None, [c_void_p]),
+        "ingest_begin": (c_int, [ctx, POINTER(IngestConfig)]),
+        "ingest_push": (c_int, [ctx, c_void_p, c_size_t]),
+        "ingest_push_bgzf": (c_int, [ctx, c_void_p, c_size_t, POINTER(BgzfBlock), c_uint32, c_size_t]),
+        "ingest_finish": (c_int, [ctx, POINTER(IngestResult)]),
+        "get_viral_read_counts": (c_int, [ctx, c_void_p]),
+        "get_coverage": (c_int, [ctx, c_void_p, c_void_p, c_void_p]),
+        "detect_strandedness": (c_int, [ctx, POINTER(c_int)]),
+        "get_read_lengths": (c_int, [ctx, c_uint64, c_uint64, c_void_p, c_void_p]),
+        "gather_rows_begin": (c_int, [ctx, c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+        "gather_rows_copy": (c_int, [ctx, POINTER(BatchRows)]),
         "set_profiling": (c_int, [ctx, c_int]),
         "get_kernel_profile": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
         "last_kernel_ms": (c_int, [ctx, POINTER(c_float)]),
@@ -216,6 +253,13 @@ def bind_host_api(lib):
         "ahost_batch_slice_view": (POINTER(BatchView), [session, c_uint64, c_uint64]),
         "ahost_estimate_fragment_length_from_sums": (c_int, [c_void_p, c_uint32, c_float, c_uint64, ctypes.c_uint, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int32)]),
         "ahost_candidate_iteration_order": (c_int, [c_uint64] + [c_void_p] * 7),
+        "ahost_bam_open": (c_int, [session, c_char_p, c_int, ctypes.c_uint, POINTER(IngestConfig)]),
+        "ahost_bam_next": (c_int, [session, c_void_p, c_size_t, POINTER(BgzfBlock), c_uint32, POINTER(BamPiece)]),
+        "ahost_bam_close": (None, [session]),
+        "ahost_adopt_device_ingest": (c_int, [session, POINTER(IngestResult), c_void_p, c_void_p, c_void_p, c_void_p]),
+        "ahost_set_batch_rows": (c_int, [session, POINTER(BatchRows), c_void_p]),
+        "ahost_fusion_table_reads": (c_int, [POINTER(FusionTable), c_int, c_void_p, c_uint64, POINTER(c_uint64)]),
+        "ahost_read_length_sum_of": (c_float, [c_float, c_void_p, c_void_p, c_uint64]),
         "ahost_estimate_fragment_length": (c_int, [session, c_void_p, c_uint32, c_uint64, ctypes.c_uint, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int32)]),
     }
     for name, (restype, argtypes) in signatures.items():

@@ -474,6 +474,51 @@ uint64_t low_entropy_bytes(const agpu_ctx* ctx) { // sequences + their offsets/l
 
 }
 
+namespace agpu {
+// everything behind the columns of a batch (uploaded from the host or built on the device by the ingest): result columns, pools, pristine copies, tables
+int finish_batch_setup(agpu_ctx* ctx) {
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->n;
+	if (ctx->max_read_length > 1024) { set_last_error("reads longer than 1024 nt are not supported by the low_entropy kernel's 8-plane k-mer counters"); return AGPU_ERR_INVALID; }
+	if (!ctx->filter.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	HIP_CHECK(hipMemsetAsync(ctx->filter.ptr, 0, n ? n : 1, s));
+	if (!ctx->pristine_fbits.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (n > 0) HIP_CHECK(hipMemcpyAsync(ctx->pristine_fbits.ptr, ctx->fbits.ptr, n, hipMemcpyDeviceToDevice, s));
+	for (int k = 0; k < 3; ++k) {
+		if (!ctx->pristine_abits[k].allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (n > 0) HIP_CHECK(hipMemcpyAsync(ctx->pristine_abits[k].ptr, ctx->abits[k].ptr, n, hipMemcpyDeviceToDevice, s));
+		if (!ctx->gene_count[k].allocate(n) || !ctx->genes[k].allocate(n * GENE_INLINE * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		HIP_CHECK(hipMemsetAsync(ctx->gene_count[k].ptr, 0, n ? n : 1, s));
+	}
+	uint32_t pool_capacity = (uint32_t) std::min<uint64_t>(n / 2 + (1u << 20), 0x7FFFFFFFull);
+	if (!ctx->gene_pool.allocate((size_t) pool_capacity * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->unmapped_keys.allocate((2 * n + 2) * sizeof(uint64_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	ctx->viral_pair_capacity = std::max<uint64_t>(1u << 20, n / 8);
+	if (!ctx->viral_pairs.allocate(ctx->viral_pair_capacity * 2 * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	HIP_CHECK(hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes, s));
+	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
+
+	BatchView& b = ctx->batch;
+	b.n = n; b.first_rank = 0; b.n_aln = ctx->n_aln.as<uint8_t>(); b.fbits = ctx->fbits.as<uint8_t>(); b.filter = ctx->filter.as<uint8_t>(); b.group = ctx->group.as<uint32_t>();
+	for (int k = 0; k < 3; ++k) {
+		b.contig[k] = ctx->contig[k].as<uint16_t>(); b.start[k] = ctx->start[k].as<int32_t>(); b.end[k] = ctx->end[k].as<int32_t>(); b.abits[k] = ctx->abits[k].as<uint8_t>();
+		b.cigar_offset[k] = ctx->cigar_offset[k].as<uint32_t>(); b.cigar_count[k] = ctx->cigar_count[k].as<uint16_t>();
+		b.gene_count[k] = ctx->gene_count[k].as<uint8_t>(); b.genes[k] = ctx->genes[k].as<uint32_t>();
+	}
+	b.cigar_pool = ctx->cigar_pool.as<uint32_t>();
+	for (int k = 0; k < 2; ++k) { b.seq_offset[k] = ctx->seq_offset[k].as<uint32_t>(); b.seq_length[k] = ctx->seq_length[k].as<uint32_t>(); }
+	b.seq_pool = ctx->seq_pool.as<uint8_t>();
+	b.gene_pool = ctx->gene_pool.as<uint32_t>(); b.gene_pool_used = ctx->counters.as<uint32_t>() + COUNTER_GENE_POOL; b.gene_pool_capacity = pool_capacity;
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
+	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
+	ctx->n_dummy = 0; ctx->candidates_imported = false;
+	refresh_annotation_view(ctx);
+	if (ctx->have_genome) TRY(build_tables(ctx));
+	return AGPU_OK;
+}
+}
+
 // ---- C ABI ----------------------------------------------------------------------------------------
 
 extern "C" {
@@ -578,16 +623,11 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 	ctx->n = n;
 	uint64_t bytes = 0;
 	TRY(upload(ctx->n_aln, in->n_aln, n, s)); TRY(upload(ctx->fbits, in->fbits, n, s)); TRY(upload(ctx->group, in->group, n, s));
-	TRY(upload(ctx->pristine_fbits, in->fbits, n, s));
 	bytes += n * (1 + 1 + 4);
-	if (!ctx->filter.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-	HIP_CHECK(hipMemsetAsync(ctx->filter.ptr, 0, n ? n : 1, s));
 	for (int k = 0; k < 3; ++k) {
 		TRY(upload(ctx->contig[k], in->contig[k], n, s)); TRY(upload(ctx->start[k], in->start[k], n, s)); TRY(upload(ctx->end[k], in->end[k], n, s));
-		TRY(upload(ctx->abits[k], in->abits[k], n, s)); TRY(upload(ctx->pristine_abits[k], in->abits[k], n, s)); TRY(upload(ctx->cigar_offset[k], in->cigar_offset[k], n, s)); TRY(upload(ctx->cigar_count[k], in->cigar_count[k], n, s));
+		TRY(upload(ctx->abits[k], in->abits[k], n, s)); TRY(upload(ctx->cigar_offset[k], in->cigar_offset[k], n, s)); TRY(upload(ctx->cigar_count[k], in->cigar_count[k], n, s));
 		bytes += n * (2 + 4 + 4 + 1 + 4 + 2);
-		if (!ctx->gene_count[k].allocate(n) || !ctx->genes[k].allocate(n * GENE_INLINE * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-		HIP_CHECK(hipMemsetAsync(ctx->gene_count[k].ptr, 0, n ? n : 1, s));
 	}
 	TRY(upload(ctx->cigar_pool, in->cigar_pool, in->cigar_pool_size, s));
 	bytes += in->cigar_pool_size * 4;
@@ -597,33 +637,10 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 		bytes += n * 8;
 		for (uint64_t i = 0; i < n; ++i) if (in->seq_length[k][i] > ctx->max_read_length) ctx->max_read_length = in->seq_length[k][i];
 	}
-	if (ctx->max_read_length > 1024) { set_last_error("reads longer than 1024 nt are not supported by the low_entropy kernel's 8-plane k-mer counters"); return AGPU_ERR_INVALID; }
 	TRY(upload(ctx->seq_pool, in->seq_pool, in->seq_pool_size, s));
 	bytes += in->seq_pool_size;
 	ctx->batch_input_bytes = bytes;
-	uint32_t pool_capacity = (uint32_t) std::min<uint64_t>(n / 2 + (1u << 20), 0x7FFFFFFFull);
-	if (!ctx->gene_pool.allocate((size_t) pool_capacity * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-	if (!ctx->unmapped_keys.allocate((2 * n + 2) * sizeof(uint64_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-	ctx->viral_pair_capacity = std::max<uint64_t>(1u << 20, n / 8);
-	if (!ctx->viral_pairs.allocate(ctx->viral_pair_capacity * 2 * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-	HIP_CHECK(hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes, s));
-	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
-
-	BatchView& b = ctx->batch;
-	b.n = n; b.first_rank = 0; b.n_aln = ctx->n_aln.as<uint8_t>(); b.fbits = ctx->fbits.as<uint8_t>(); b.filter = ctx->filter.as<uint8_t>(); b.group = ctx->group.as<uint32_t>();
-	for (int k = 0; k < 3; ++k) {
-		b.contig[k] = ctx->contig[k].as<uint16_t>(); b.start[k] = ctx->start[k].as<int32_t>(); b.end[k] = ctx->end[k].as<int32_t>(); b.abits[k] = ctx->abits[k].as<uint8_t>();
-		b.cigar_offset[k] = ctx->cigar_offset[k].as<uint32_t>(); b.cigar_count[k] = ctx->cigar_count[k].as<uint16_t>();
-		b.gene_count[k] = ctx->gene_count[k].as<uint8_t>(); b.genes[k] = ctx->genes[k].as<uint32_t>();
-	}
-	b.cigar_pool = ctx->cigar_pool.as<uint32_t>();
-	for (int k = 0; k < 2; ++k) { b.seq_offset[k] = ctx->seq_offset[k].as<uint32_t>(); b.seq_length[k] = ctx->seq_length[k].as<uint32_t>(); }
-	b.seq_pool = ctx->seq_pool.as<uint8_t>();
-	b.gene_pool = ctx->gene_pool.as<uint32_t>(); b.gene_pool_used = ctx->counters.as<uint32_t>() + COUNTER_GENE_POOL; b.gene_pool_capacity = pool_capacity;
-	HIP_CHECK(hipStreamSynchronize(s));
-	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
-	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
-	if (ctx->have_genome) TRY(build_tables(ctx));
+	TRY(agpu::finish_batch_setup(ctx));
 	return AGPU_OK;
 }
 

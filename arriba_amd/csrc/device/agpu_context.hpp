@@ -95,6 +95,18 @@ struct agpu_ctx {
 	agpu::DeviceBuffer coverage_window_offset, coverage_windows, coverage_fragment_starts, coverage_fragment_ends;
 	agpu::CoverageView coverage = { 0, nullptr, nullptr, nullptr, nullptr };
 	bool have_coverage = false;
+	// read_chimeric_alignments on the device (agpu_ingest.hip): the uncompressed BAM stream while it is being pushed, and what stays behind the pack
+	agpu::DeviceBuffer ingest_stream, ingest_raw[2], ingest_blocks[2], ingest_tid_to_contig, ingest_viral_counts, coverage_windows32;
+	agpu::DeviceBuffer names, name_offset; // "QNAME,HI" of every fragment of a batch built on the device
+	uint64_t ingest_stream_size = 0, ingest_first_record = 0, names_size = 0;
+	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0;
+	uint8_t ingest_external_duplicate_marking = 0;
+	bool ingest_active = false, batch_from_ingest = false;
+	hipEvent_t ingest_events[2] = { nullptr, nullptr };
+	std::vector<uint64_t> host_coverage_window_offset;
+	agpu::DeviceBuffer gather_ids, gather_cigar_base, gather_seq_base, gather_name_base; // agpu_gather_rows_begin -> _copy
+	uint64_t gather_n = 0, gather_sizes[3] = { 0, 0, 0 };
+	bool gather_all = false;
 	// closest genomic breakpoints per candidate (agpu_mark_genomic_support); not marked: every candidate -1
 	agpu::DeviceBuffer cand_closest1, cand_closest2;
 	bool genomic_support_marked = false;
@@ -134,6 +146,9 @@ struct agpu_ctx {
 };
 
 namespace agpu {
+
+// agpu_api.hip: what follows the columns of a batch, whoever filled them (agpu_upload_batch, or the ingest on the device: agpu_ingest.hip)
+int finish_batch_setup(agpu_ctx* ctx);
 
 // Brackets one kernel launch (or library call) with HIP events when profiling is on.  Usage:
 //   { KernelTimer timer(ctx, "stage2_kernel", bytes); stage2_kernel<<<...>>>(...); }

@@ -1,0 +1,826 @@
+// arriba_amd/csrc/device/agpu_ingest.hip -- read_chimeric_alignments on the MI355X (reference: source/read_chimeric_alignments.cpp:560-773).
+//
+// The host feeds the bytes of the BAM file; everything else happens in HBM:
+//   bgzf_unwrap_kernel        payloads of stored BGZF blocks (STAR --outBAMcompression 0) moved into the contiguous record stream, one workgroup per block
+//   segment_guess/check/repair/emit   the record chain (every record starts where the previous one ends) cut in parallel: every 8 KB segment guesses its
+//                             first record by the plausibility of two consecutive headers and walks to its end; a guess is accepted only if it is the
+//                             exact end of the segment before it, otherwise the segment is walked again from there -- by induction from the known first
+//                             record the result is the true chain, whatever the guesses were
+//   record_parse_kernel       per record: skip rules, HI / SA aux tags, key of "QNAME,HI" (source/read_chimeric_alignments.cpp:611-631,653)
+//   rocPRIM radix sort        records of one name adjacent, file order kept inside (stable); group_head_kernel marks the groups and proves the keys collision-free
+//   group_replay_kernel       one thread replays the reference's loop body over the records of one name (ingest_core.hpp): alignment plans, coverage_t, counters;
+//                             remove_malformed_alignments on the result
+//   name order                fragments ordered by first occurrence; if that is not the order of the names (std::map order, hazard H3) an LSD radix sort
+//                             over 8-byte chunks of the names follows
+//   fragment_layout/pack      pool offsets by prefix sums in name order, then every fragment writes its columns, CIGARs, 4-bit sequences and name
+// All of it is integer / byte work bound by HBM bandwidth and by the latency of dependent loads; no MFMA.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+#include "agpu_context.hpp"
+#include "ingest_core.hpp"
+#include "device_utils.hpp"
+
+using namespace agpu;
+
+namespace {
+
+const int BLOCK = 256;
+const uint32_t SEGMENT_BYTES = 8192;
+const uint64_t SEARCH_LIMIT = 4u << 20;    // how far a segment looks for its first record before it leaves the answer to the repair pass
+const uint64_t OFFSET_NONE = ~0ull, OFFSET_BROKEN = ~0ull - 1;
+inline unsigned int grid_for(uint64_t n, int block = BLOCK) { return (unsigned int) ((n + block - 1) / block); }
+
+enum { IC_ACTIVE = 0, IC_MAPPED_READS = 1, IC_MISSING_HI = 2, IC_BROKEN = 3, IC_MALFORMED = 4, IC_CHIMERIC = 5, IC_COLLISION = 6, IC_MISMATCH = 7, IC_UNSORTED = 8, IC_MAX_NAME = 9,
+       IC_MAX_READ_LENGTH = 10, IC_STRAND_COUNT = 11, IC_STRAND_MATCHING = 12, IC_COUNT = 16 };
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define TRY(call) do { int s_ = (call); if (s_ != AGPU_OK) return s_; } while (0)
+
+// ---- container ------------------------------------------------------------------------------------------------------------------------------------
+
+// one workgroup per stored block: payload bytes raw -> stream (both sides unaligned; the destination is written in aligned words where possible)
+__global__ void __launch_bounds__(BLOCK) bgzf_unwrap_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint8_t* stream) {
+	const agpu_bgzf_block block = blocks[blockIdx.x];
+	const uint8_t* source = raw + block.raw_offset + block.payload_offset;
+	uint8_t* target = stream + block.stream_offset;
+	const uint32_t size = block.payload_size;
+	uint32_t head = (uint32_t) ((4 - ((uintptr_t) target & 3)) & 3);
+	if (head > size) head = size;
+	if (threadIdx.x < head) target[threadIdx.x] = source[threadIdx.x];
+	const uint32_t words = (size - head) / 4;
+	for (uint32_t w = threadIdx.x; w < words; w += BLOCK) *(uint32_t*) (target + head + 4 * (size_t) w) = load_u32(source + head + 4 * (size_t) w);
+	const uint32_t tail = head + 4 * words;
+	if (threadIdx.x < size - tail) target[tail + threadIdx.x] = source[tail + threadIdx.x];
+}
+
+// CRC-32 (the gzip polynomial) of every stored block, one thread per block, four bytes per step (slicing-by-4 tables in constant memory would be
+// faster; the blocks are independent and there are 10^5..10^6 of them, so one lane per block keeps the chip busy)
+__device__ uint32_t crc32_update(uint32_t crc, uint8_t byte) {
+	crc ^= byte;
+	for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1)));
+	return crc;
+}
+
+// ---- the record chain -----------------------------------------------------------------------------------------------------------------------------
+
+// a record header that could be real: sizes consistent, reference ids in range, the name terminated
+__device__ bool plausible_record(const uint8_t* bytes, uint64_t size, uint64_t o, uint32_t n_targets) {
+	if (o + 36 > size) return false;
+	const uint32_t block_size = load_u32(bytes + o);
+	if (block_size < 32 || block_size > (1u << 28) || o + 4 + (uint64_t) block_size > size) return false;
+	const uint8_t* p = bytes + o + 4;
+	const int32_t tid = (int32_t) load_u32(p), pos = (int32_t) load_u32(p + 4), next_tid = (int32_t) load_u32(p + 20), next_pos = (int32_t) load_u32(p + 24);
+	if (tid < -1 || tid >= (int32_t) n_targets || next_tid < -1 || next_tid >= (int32_t) n_targets || pos < -1 || next_pos < -1) return false;
+	if (!record_sizes_ok(p, block_size)) return false;
+	const uint32_t l_read_name = p[8];
+	return p[32 + l_read_name - 1] == 0;
+}
+
+// walks the chain from `start` to the first record at or behind `segment_end`; OFFSET_BROKEN if a block size cannot be right
+__device__ uint64_t walk_segment(const uint8_t* bytes, uint64_t size, uint64_t start, uint64_t segment_end, uint32_t& count, uint64_t* offsets) {
+	uint64_t o = start;
+	count = 0;
+	while (o < segment_end) {
+		if (o + 4 > size) return OFFSET_BROKEN;
+		const uint32_t block_size = load_u32(bytes + o);
+		if (block_size < 32 || o + 4 + (uint64_t) block_size > size) return OFFSET_BROKEN;
+		if (offsets != nullptr) offsets[count] = o;
+		++count;
+		o += 4 + (uint64_t) block_size;
+	}
+	return o;
+}
+
+__global__ void segment_guess_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, uint32_t n_targets, uint64_t* first, uint64_t* end, uint32_t* count) {
+	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (s >= n_segments) return;
+	const uint64_t begin = base + s * SEGMENT_BYTES, segment_end = (begin + SEGMENT_BYTES < size) ? begin + SEGMENT_BYTES : size;
+	uint64_t start = OFFSET_NONE;
+	if (s == 0) start = base;
+	else {
+		const uint64_t limit = (begin + SEARCH_LIMIT < size) ? begin + SEARCH_LIMIT : size;
+		for (uint64_t o = begin; o < limit; ++o) {
+			if (!plausible_record(bytes, size, o, n_targets)) continue;
+			const uint64_t next = o + 4 + (uint64_t) load_u32(bytes + o);
+			if (next == size || plausible_record(bytes, size, next, n_targets)) { start = o; break; }
+		}
+	}
+	first[s] = start;
+	uint32_t n = 0;
+	end[s] = (start == OFFSET_NONE) ? OFFSET_NONE : walk_segment(bytes, size, start, segment_end, n, nullptr);
+	count[s] = n;
+}
+
+__global__ void segment_check_kernel(const uint64_t* first, const uint64_t* end, uint64_t n_segments, uint8_t* mismatch, uint32_t* counters) {
+	__shared__ uint32_t block_sum;
+	uint32_t mine = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; s < n_segments; s += gridDim.x * (uint64_t) BLOCK) {
+		const bool bad = s > 0 && first[s] != end[s - 1];
+		mismatch[s] = bad;
+		mine += bad;
+	}
+	block_tally(mine, &counters[IC_MISMATCH], &block_sum);
+}
+
+// a segment whose guess is not the end of the segment before it starts again from there (`previous_end`: the ends as they were before this launch)
+__global__ void segment_repair_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, const uint8_t* mismatch, const uint64_t* previous_end, uint64_t* first, uint64_t* end, uint32_t* count) {
+	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (s >= n_segments || !mismatch[s]) return;
+	const uint64_t begin = base + s * SEGMENT_BYTES, segment_end = (begin + SEGMENT_BYTES < size) ? begin + SEGMENT_BYTES : size;
+	const uint64_t start = previous_end[s - 1];
+	first[s] = start;
+	uint32_t n = 0;
+	end[s] = (start >= OFFSET_BROKEN) ? start : walk_segment(bytes, size, start, segment_end, n, nullptr);
+	count[s] = n;
+}
+
+__global__ void segment_emit_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, const uint64_t* first, const uint32_t* record_base, uint64_t* record_offset) {
+	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (s >= n_segments) return;
+	const uint64_t begin = base + s * SEGMENT_BYTES, segment_end = (begin + SEGMENT_BYTES < size) ? begin + SEGMENT_BYTES : size;
+	uint32_t n = 0;
+	walk_segment(bytes, size, first[s], segment_end, n, record_offset + record_base[s]);
+}
+
+// ---- per record -----------------------------------------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, GenomeView genome, uint64_t seed, uint64_t* keys, uint8_t* bits, uint32_t* counters) {
+	__shared__ uint32_t sums[4];
+	uint32_t active = 0, mapped = 0, missing = 0, broken = 0;
+	for (uint64_t r = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; r < in.n_records; r += gridDim.x * (uint64_t) BLOCK) {
+		const uint8_t* p = in.bytes + in.record_offset[r];
+		const uint32_t block_size = load_u32(p);
+		uint64_t key = ~0ull;
+		uint8_t status = RECORD_SKIPPED;
+		if (!record_sizes_ok(p + 4, block_size)) { status = RECORD_BROKEN; ++broken; }
+		else {
+			const Rec record = load_record(in, (uint32_t) r);
+			if (!((record.flag & BAMF_UNMAP) || ((record.flag & BAMF_PAIRED) && (record.flag & BAMF_MUNMAP)))) {
+				const AuxTags tags = scan_aux(record.aux, record.end);
+				if (!tags.has_hi && (record.flag & BAMF_SECONDARY)) { status = RECORD_MISSING_HI; ++missing; }
+				else if (record.contig < 0) { status = RECORD_BROKEN; ++broken; } // reference id outside the header
+				else {
+					status = RECORD_ACTIVE | (tags.has_sa ? RECORD_HAS_SA : 0);
+					key = name_key(record, tags.has_hi ? tags.hi : 1, seed);
+					++active;
+					if (!(record.flag & BAMF_SUPPLEMENTARY) && (genome.contig_bits[record.contig] & CBIT_INTERESTING)) ++mapped;
+				}
+			}
+		}
+		keys[r] = key;
+		bits[r] = status;
+	}
+	block_tally(active, &counters[IC_ACTIVE], &sums[0]);
+	block_tally(mapped, &counters[IC_MAPPED_READS], &sums[1]);
+	block_tally(missing, &counters[IC_MISSING_HI], &sums[2]);
+	block_tally(broken, &counters[IC_BROKEN], &sums[3]);
+}
+
+// position p of the sorted records starts a group if its key differs from the key before it; equal keys must be equal names
+__global__ void group_head_kernel(IngestStream in, const uint64_t* sorted_keys, const uint32_t* sorted_records, uint64_t n_active, uint8_t* head, uint32_t* counters) {
+	const uint64_t p = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (p >= n_active) return;
+	const bool is_head = p == 0 || sorted_keys[p] != sorted_keys[p - 1];
+	head[p] = is_head;
+	if (!is_head) {
+		const Rec a = load_record(in, sorted_records[p]), b = load_record(in, sorted_records[p - 1]);
+		const AuxTags tags_a = scan_aux(a.aux, a.end), tags_b = scan_aux(b.aux, b.end);
+		if (!same_name(a, tags_a.has_hi ? tags_a.hi : 1, b, tags_b.has_hi ? tags_b.hi : 1)) atomicOr(&counters[IC_COLLISION], 1u);
+	}
+}
+
+struct ViralCounter {
+	unsigned long long* counts;
+	__device__ void operator()(uint32_t contig) { atomicAdd(&counts[contig], 1ull); }
+};
+
+__global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_start, uint32_t n_groups, uint64_t n_active,
+                                                             FragmentPlan* plain, TandemPlan* itd, uint8_t* valid, FragmentSizes* sizes, unsigned long long* viral_counts, uint32_t* counters) {
+	__shared__ uint32_t sums[2];
+	GroupTally tally; tally.malformed = 0; tally.chimeric = 0;
+	const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g < n_groups) {
+		const uint32_t begin = group_start[g];
+		const uint32_t n_records = (uint32_t) ((g + 1 < n_groups ? (uint64_t) group_start[g + 1] : n_active) - begin);
+		FragmentPlan plain_plan; TandemPlan itd_plan;
+		ViralCounter viral = { viral_counts };
+		replay_group(ctx, sorted_records + begin, n_records, plain_plan, itd_plan, tally, viral);
+		const Rec representative = load_record(ctx.stream, sorted_records[begin]);
+		Fragment3 fragment;
+		FragmentSizes none; none.cigar_words = 0; none.sequence_bytes = 0; none.name_length = 0;
+		bool ok = false;
+		if (plain_plan.count > 0) {
+			ok = normalize_plan(ctx.stream, plain_plan, nullptr, fragment);
+			if (!ok) tally.malformed++;
+		}
+		valid[2 * (size_t) g] = ok;
+		if (ok) { plain[g] = plain_plan; fragment_sizes(fragment, representative, false, sizes[2 * (size_t) g]); } else sizes[2 * (size_t) g] = none;
+		ok = false;
+		if (itd_plan.plan.count > 0) {
+			ok = normalize_plan(ctx.stream, itd_plan.plan, &itd_plan.tandem, fragment);
+			if (!ok) tally.malformed++;
+		}
+		valid[2 * (size_t) g + 1] = ok;
+		if (ok) { itd[g] = itd_plan; fragment_sizes(fragment, representative, true, sizes[2 * (size_t) g + 1]); } else sizes[2 * (size_t) g + 1] = none;
+	}
+	block_tally(tally.malformed, &counters[IC_MALFORMED], &sums[0]);
+	block_tally(tally.chimeric, &counters[IC_CHIMERIC], &sums[1]);
+}
+
+// ---- name order -----------------------------------------------------------------------------------------------------------------------------------
+
+// fragment reference = 2 * group + (1 for the "ITD" entry); key of its first occurrence = index of the group's first record, the ITD entry behind the plain one
+__global__ void occurrence_key_kernel(const uint32_t* refs, uint64_t n, const uint32_t* sorted_records, const uint32_t* group_start, uint64_t* keys) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t ref = refs[i];
+	keys[i] = (uint64_t) sorted_records[group_start[ref >> 1]] << 1 | (ref & 1);
+}
+
+__device__ FragmentName name_of(const IngestStream& in, const uint32_t* sorted_records, const uint32_t* group_start, uint32_t ref, Rec& storage) {
+	storage = load_record(in, sorted_records[group_start[ref >> 1]]);
+	return fragment_name(storage, ref & 1);
+}
+
+__global__ void name_order_check_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, uint32_t* counters) {
+	__shared__ uint32_t block_max;
+	if (threadIdx.x == 0) block_max = 0;
+	__syncthreads();
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i < n) {
+		Rec storage_a, storage_b;
+		const FragmentName mine = name_of(in, sorted_records, group_start, order[i], storage_a);
+		atomicMax(&block_max, name_length(mine));
+		if (i > 0) {
+			const FragmentName before = name_of(in, sorted_records, group_start, order[i - 1], storage_b);
+			if (compare_names(before, mine) >= 0) atomicOr(&counters[IC_UNSORTED], 1u);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_NAME], block_max);
+}
+
+__global__ void name_chunk_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= n) return;
+	Rec storage;
+	keys[i] = name_chunk(name_of(in, sorted_records, group_start, order[i], storage), chunk);
+}
+
+// ---- layout and pack ------------------------------------------------------------------------------------------------------------------------------
+
+__global__ void fragment_layout_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, const FragmentSizes* sizes,
+                                       uint32_t* cigar_words, uint32_t* sequence_bytes, uint32_t* name_lengths, uint32_t* new_group) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i > n) return;
+	if (i == n) { cigar_words[i] = 0; sequence_bytes[i] = 0; name_lengths[i] = 0; return; } // the element behind the last one carries the totals of the exclusive scans
+	const uint32_t ref = order[i];
+	const FragmentSizes mine = sizes[ref];
+	cigar_words[i] = mine.cigar_words; sequence_bytes[i] = mine.sequence_bytes; name_lengths[i] = mine.name_length;
+	// multi-mapper groups: identical names up to the last ',' (source/common.hpp:222), i.e. identical QNAMEs
+	uint32_t differs = 0;
+	if (i > 0) {
+		const Rec a = load_record(in, sorted_records[group_start[ref >> 1]]), b = load_record(in, sorted_records[group_start[order[i - 1] >> 1]]);
+		const uint32_t length = qname_length(a);
+		differs = length != qname_length(b);
+		for (uint32_t k = 0; k < length && !differs; ++k) differs = a.name[k] != b.name[k];
+	}
+	new_group[i] = differs;
+}
+
+__global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, const FragmentPlan* plain, const TandemPlan* itd,
+                                                              const uint64_t* cigar_base, const uint64_t* sequence_base, const uint64_t* name_base, const uint32_t* group_id, PackTarget out, uint32_t* counters) {
+	__shared__ uint32_t block_max;
+	if (threadIdx.x == 0) block_max = 0;
+	__syncthreads();
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i == n) out.name_offset[n] = (uint32_t) name_base[n];
+	if (i < n) {
+		const uint32_t ref = order[i], g = ref >> 1;
+		const bool is_itd = ref & 1;
+		Fragment3 f;
+		normalize_plan(in, is_itd ? itd[g].plan : plain[g], is_itd ? &itd[g].tandem : nullptr, f);
+		Rec storage;
+		const FragmentName name = name_of(in, sorted_records, group_start, ref, storage);
+		atomicMax(&block_max, write_fragment(in, f, name, i, cigar_base[i], sequence_base[i], name_base[i], group_id[i], out));
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_READ_LENGTH], block_max);
+}
+
+__global__ void coverage_clamp_kernel(const uint32_t* windows, uint64_t n, uint16_t* out) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i < n) out[i] = windows[i] > 65535u ? (uint16_t) 65535 : (uint16_t) windows[i];
+}
+
+// ---- rows of a resident batch for the host (names, CIGARs and sequences of the reads the output writer prints) -------------------------------------
+
+__global__ void gather_sizes_kernel(BatchView b, const uint32_t* name_offset, const uint32_t* ids, uint64_t n, uint32_t* cigar_words, uint32_t* sequence_bytes, uint32_t* name_lengths) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k > n) return;
+	if (k == n) { cigar_words[k] = 0; sequence_bytes[k] = 0; name_lengths[k] = 0; return; }
+	row_sizes(b, name_offset, ids ? ids[k] : k, cigar_words[k], sequence_bytes[k], name_lengths[k]);
+}
+
+__global__ void gather_copy_kernel(BatchView b, const uint8_t* pristine_fbits, const uint8_t* const* pristine_abits, const uint32_t* name_offset, const char* names, const uint32_t* ids, uint64_t n,
+                                   const uint64_t* cigar_base, const uint64_t* sequence_base, const uint64_t* name_base, PackTarget out) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k == n) out.name_offset[n] = (uint32_t) name_base[n];
+	if (k >= n) return;
+	copy_row(b, pristine_fbits, pristine_abits, name_offset, names, ids ? ids[k] : k, k, cigar_base[k], sequence_base[k], name_base[k], out);
+}
+
+// ---- detect_strandedness (source/read_stats.cpp:94-143): the first 100 informative split reads in name order ---------------------------------------
+
+// 0 = not informative, 1 = informative, 3 = informative and matching the gene's strand
+__global__ void strandedness_flag_kernel(BatchView b, AnnotationView ann, uint64_t first, uint64_t count, uint8_t* flags) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k >= count) return;
+	flags[k] = strandedness_vote(b, ann, first + k);
+}
+
+// one thread: the first `wanted` informative fragments of the chunk, in order
+__global__ void strandedness_take_kernel(const uint8_t* flags, uint64_t count, uint32_t wanted, uint32_t* counters) {
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	uint32_t seen = counters[IC_STRAND_COUNT], matching = counters[IC_STRAND_MATCHING];
+	for (uint64_t k = 0; k < count && seen < wanted; ++k)
+		if (flags[k]) { ++seen; if (flags[k] & 2) ++matching; }
+	counters[IC_STRAND_COUNT] = seen; counters[IC_STRAND_MATCHING] = matching;
+}
+
+// ---- host side of the C ABI -----------------------------------------------------------------------------------------------------------------------
+
+int grow_stream(agpu_ctx* ctx, uint64_t needed) {
+	if (needed <= ctx->ingest_stream.capacity) { ctx->ingest_stream.bytes = needed; return AGPU_OK; }
+	DeviceBuffer larger;
+	const uint64_t doubled = ctx->ingest_stream.capacity * 2;
+	if (!larger.allocate(std::max<uint64_t>(needed + (needed >> 3), std::max<uint64_t>(doubled, 64u << 20)))) { set_last_error("hipMalloc failed (BAM stream)"); return AGPU_ERR_DEVICE; }
+	if (ctx->ingest_stream_size > 0) HIP_CHECK(hipMemcpyAsync(larger.ptr, ctx->ingest_stream.ptr, ctx->ingest_stream_size, hipMemcpyDeviceToDevice, ctx->stream));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	ctx->ingest_stream.swap(larger);
+	return AGPU_OK;
+}
+
+int wait_for_previous_push(agpu_ctx* ctx) {
+	// push k was enqueued; the buffer of push k - 1 must be free when the caller gets control back
+	if (ctx->ingest_pushes >= 1) HIP_CHECK(hipEventSynchronize(ctx->ingest_events[(ctx->ingest_pushes - 1) & 1]));
+	return AGPU_OK;
+}
+
+template <class Key> int sort_pairs(agpu_ctx* ctx, DeviceBuffer& scratch, Key* keys_in, Key* keys_out, uint32_t* values_in, uint32_t* values_out, uint64_t n, unsigned int end_bit, const char* label, bool counting_values) {
+	size_t bytes = 0;
+	hipStream_t s = ctx->stream;
+	if (counting_values) HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), values_out, n, 0, end_bit, s));
+	else HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, values_in, values_out, n, 0, end_bit, s));
+	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+	KernelTimer timer(ctx, label, n * (uint64_t) (sizeof(Key) + 4) * 2);
+	if (counting_values) HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), values_out, n, 0, end_bit, s));
+	else HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in, keys_out, values_in, values_out, n, 0, end_bit, s));
+	return AGPU_OK;
+}
+
+// indices of the set flags, in order; *count on the device (one word of `counters`)
+int select_flagged(agpu_ctx* ctx, DeviceBuffer& scratch, const uint8_t* flags, uint32_t* out, uint32_t* device_count, uint64_t n) {
+	size_t bytes = 0;
+	HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags, out, device_count, n, ctx->stream));
+	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+	HIP_CHECK(rocprim::select(scratch.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags, out, device_count, n, ctx->stream));
+	return AGPU_OK;
+}
+
+int exclusive_sum_u64(agpu_ctx* ctx, DeviceBuffer& scratch, const uint32_t* in, uint64_t* out, uint64_t n) {
+	size_t bytes = 0;
+	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), ctx->stream));
+	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+	HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, in, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), ctx->stream));
+	return AGPU_OK;
+}
+
+void fill_pack_target(agpu_ctx* ctx, PackTarget& out) {
+	out.n_aln = ctx->n_aln.as<uint8_t>(); out.fbits = ctx->fbits.as<uint8_t>(); out.group = ctx->group.as<uint32_t>();
+	for (int k = 0; k < 3; ++k) {
+		out.contig[k] = ctx->contig[k].as<uint16_t>(); out.start[k] = ctx->start[k].as<int32_t>(); out.end[k] = ctx->end[k].as<int32_t>(); out.abits[k] = ctx->abits[k].as<uint8_t>();
+		out.cigar_offset[k] = ctx->cigar_offset[k].as<uint32_t>(); out.cigar_count[k] = ctx->cigar_count[k].as<uint16_t>();
+	}
+	out.cigar_pool = ctx->cigar_pool.as<uint32_t>();
+	for (int k = 0; k < 2; ++k) { out.seq_offset[k] = ctx->seq_offset[k].as<uint32_t>(); out.seq_length[k] = ctx->seq_length[k].as<uint32_t>(); }
+	out.seq_pool = ctx->seq_pool.as<uint8_t>(); out.name_offset = ctx->name_offset.as<uint32_t>(); out.names = ctx->names.as<char>();
+}
+
+}
+
+extern "C" {
+
+void* agpu_host_alloc(size_t bytes) {
+	void* pointer = nullptr;
+	if (hipHostMalloc(&pointer, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { set_last_error("hipHostMalloc failed"); return nullptr; }
+	return pointer;
+}
+void agpu_host_free(void* pointer) { if (pointer) (void) hipHostFree(pointer); }
+
+int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
+	if (!ctx || !config) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (!ctx->have_annotation || !ctx->have_genome) { set_last_error("annotation and genome must be uploaded before the ingest"); return AGPU_ERR_INVALID; }
+	if (config->n_contigs != ctx->genome.n_contigs) { set_last_error("the genome view on the device does not hold the contigs of the BAM header (upload it after the header was parsed)"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	for (int k = 0; k < 2; ++k) if (!ctx->ingest_events[k]) HIP_CHECK(hipEventCreateWithFlags(&ctx->ingest_events[k], hipEventDisableTiming));
+	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
+	ctx->ingest_external_duplicate_marking = config->external_duplicate_marking; ctx->ingest_max_itd_length = config->max_itd_length;
+	ALLOC(ctx->ingest_tid_to_contig, std::max<size_t>(config->n_targets, 1) * 4);
+	if (config->n_targets) HIP_CHECK(hipMemcpyAsync(ctx->ingest_tid_to_contig.ptr, config->tid_to_contig, (size_t) config->n_targets * 4, hipMemcpyHostToDevice, s));
+	ctx->host_coverage_window_offset.assign(config->coverage_window_offset, config->coverage_window_offset + config->n_contigs + 1);
+	const uint64_t windows = ctx->host_coverage_window_offset.back();
+	ALLOC(ctx->coverage_window_offset, ((size_t) config->n_contigs + 1) * 8); ALLOC(ctx->coverage_windows32, std::max<uint64_t>(windows, 1) * 4); ALLOC(ctx->coverage_windows, std::max<uint64_t>(windows, 1) * 2);
+	ALLOC(ctx->coverage_fragment_starts, std::max<uint64_t>(windows, 1)); ALLOC(ctx->coverage_fragment_ends, std::max<uint64_t>(windows, 1));
+	HIP_CHECK(hipMemcpyAsync(ctx->coverage_window_offset.ptr, config->coverage_window_offset, ((size_t) config->n_contigs + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(windows, 1) * 4, s));
+	HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_starts.ptr, 0, std::max<uint64_t>(windows, 1), s));
+	HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_ends.ptr, 0, std::max<uint64_t>(windows, 1), s));
+	ALLOC(ctx->ingest_viral_counts, std::max<size_t>(config->n_contigs, 1) * 8);
+	HIP_CHECK(hipMemsetAsync(ctx->ingest_viral_counts.ptr, 0, std::max<size_t>(config->n_contigs, 1) * 8, s));
+	if (config->stream_size_hint > 0) TRY(grow_stream(ctx, config->stream_size_hint));
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->ingest_active = true; ctx->have_batch = false; ctx->have_coverage = false;
+	return AGPU_OK;
+}
+
+int agpu_ingest_push(agpu_ctx* ctx, const void* bytes, size_t size) {
+	if (!ctx || !ctx->ingest_active) { set_last_error("agpu_ingest_begin must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (size > 0) {
+		TRY(grow_stream(ctx, ctx->ingest_stream_size + size));
+		HIP_CHECK(hipMemcpyAsync(ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size, bytes, size, hipMemcpyHostToDevice, ctx->stream));
+		ctx->ingest_stream_size += size;
+	}
+	HIP_CHECK(hipEventRecord(ctx->ingest_events[ctx->ingest_pushes & 1], ctx->stream));
+	TRY(wait_for_previous_push(ctx));
+	++ctx->ingest_pushes;
+	return AGPU_OK;
+}
+
+int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const agpu_bgzf_block* blocks, uint32_t n_blocks, size_t stream_bytes) {
+	if (!ctx || !ctx->ingest_active) { set_last_error("agpu_ingest_begin must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const unsigned int slot = ctx->ingest_pushes & 1;
+	if (n_blocks > 0 && raw_size > 0) {
+		TRY(grow_stream(ctx, ctx->ingest_stream_size + stream_bytes));
+		ALLOC(ctx->ingest_raw[slot], raw_size); ALLOC(ctx->ingest_blocks[slot], (size_t) n_blocks * sizeof(agpu_bgzf_block));
+		HIP_CHECK(hipMemcpyAsync(ctx->ingest_raw[slot].ptr, raw, raw_size, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(ctx->ingest_blocks[slot].ptr, blocks, (size_t) n_blocks * sizeof(agpu_bgzf_block), hipMemcpyHostToDevice, s));
+		{ KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes);
+		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
+		ctx->ingest_stream_size += stream_bytes;
+	}
+	HIP_CHECK(hipEventRecord(ctx->ingest_events[slot], s));
+	TRY(wait_for_previous_push(ctx));
+	++ctx->ingest_pushes;
+	return AGPU_OK;
+}
+
+int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
+	if (!ctx || !ctx->ingest_active) { set_last_error("agpu_ingest_begin must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	ctx->ingest_active = false;
+	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
+	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
+	const uint8_t* bytes = ctx->ingest_stream.as<uint8_t>();
+	DeviceBuffer& counters = ctx->scratch("ingest.counters"); DeviceBuffer& rocprim_scratch = ctx->scratch("ingest.rocprim");
+	ALLOC(counters, IC_COUNT * 4);
+	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, IC_COUNT * 4, s));
+	uint32_t* device_counters = counters.as<uint32_t>();
+	uint32_t host_counters[IC_COUNT];
+	auto read_counters = [&]() -> int { HIP_CHECK(hipMemcpyAsync(host_counters, counters.ptr, IC_COUNT * 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); return AGPU_OK; };
+	(void) hipEventRecord(ctx->event_start, s);
+
+	// 1. the record chain
+	const uint64_t n_segments = (size - base + SEGMENT_BYTES - 1) / SEGMENT_BYTES;
+	DeviceBuffer& segment_first = ctx->scratch("ingest.segment_first"); DeviceBuffer& segment_end = ctx->scratch("ingest.segment_end"); DeviceBuffer& segment_end_before = ctx->scratch("ingest.segment_end_before");
+	DeviceBuffer& segment_count = ctx->scratch("ingest.segment_count"); DeviceBuffer& segment_base = ctx->scratch("ingest.segment_base"); DeviceBuffer& segment_mismatch = ctx->scratch("ingest.segment_mismatch");
+	DeviceBuffer& record_offset = ctx->scratch("ingest.record_offset");
+	uint64_t n_records = 0;
+	if (n_segments > 0) {
+		ALLOC(segment_first, n_segments * 8); ALLOC(segment_end, n_segments * 8); ALLOC(segment_end_before, n_segments * 8); ALLOC(segment_count, (n_segments + 1) * 4); ALLOC(segment_base, (n_segments + 1) * 4); ALLOC(segment_mismatch, n_segments);
+		{ KernelTimer timer(ctx, "segment_guess_kernel", size - base);
+		  segment_guess_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, n_segments, ctx->ingest_n_targets, segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), segment_count.as<uint32_t>()); }
+		while (true) {
+			HIP_CHECK(hipMemsetAsync(device_counters + IC_MISMATCH, 0, 4, s));
+			segment_check_kernel<<<tally_grid(n_segments, BLOCK), BLOCK, 0, s>>>(segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), n_segments, segment_mismatch.as<uint8_t>(), device_counters);
+			TRY(read_counters());
+			if (host_counters[IC_MISMATCH] == 0) break;
+			HIP_CHECK(hipMemcpyAsync(segment_end_before.ptr, segment_end.ptr, n_segments * 8, hipMemcpyDeviceToDevice, s));
+			KernelTimer timer(ctx, "segment_repair_kernel", 0);
+			segment_repair_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, n_segments, segment_mismatch.as<uint8_t>(), segment_end_before.as<uint64_t>(), segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), segment_count.as<uint32_t>());
+		}
+		uint64_t last_end = 0;
+		HIP_CHECK(hipMemcpyAsync(&last_end, segment_end.as<uint64_t>() + (n_segments - 1), 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (last_end != size) { set_last_error("failed to load alignments"); return AGPU_ERR_INVALID; } // a record that does not end where the stream ends, or an impossible block size
+		HIP_CHECK(hipMemsetAsync(segment_count.as<uint32_t>() + n_segments, 0, 4, s));
+		size_t scan_bytes = 0;
+		HIP_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, segment_count.as<uint32_t>(), segment_base.as<uint32_t>(), 0u, n_segments + 1, rocprim::plus<uint32_t>(), s));
+		if (scan_bytes > rocprim_scratch.capacity) ALLOC(rocprim_scratch, scan_bytes);
+		HIP_CHECK(rocprim::exclusive_scan(rocprim_scratch.ptr, scan_bytes, segment_count.as<uint32_t>(), segment_base.as<uint32_t>(), 0u, n_segments + 1, rocprim::plus<uint32_t>(), s));
+		uint32_t total = 0;
+		HIP_CHECK(hipMemcpyAsync(&total, segment_base.as<uint32_t>() + n_segments, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		n_records = total;
+		// (the 32-bit scan wraps beyond 2^32 records: such a stream has more than 2^32 * 36 bytes)
+		if ((size - base) / 36 >= 0xFFFFFFF0ull) { set_last_error("more than 2^32-16 alignment records: shard the input"); return AGPU_ERR_INVALID; }
+		ALLOC(record_offset, std::max<uint64_t>(n_records, 1) * 8);
+		{ KernelTimer timer(ctx, "segment_emit_kernel", n_records * 8);
+		  segment_emit_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, n_segments, segment_first.as<uint64_t>(), segment_base.as<uint32_t>(), record_offset.as<uint64_t>()); }
+	}
+	IngestStream in;
+	in.bytes = bytes; in.size = size; in.record_offset = record_offset.as<uint64_t>(); in.n_records = n_records; in.n_targets = ctx->ingest_n_targets; in.tid_to_contig = ctx->ingest_tid_to_contig.as<uint32_t>();
+
+	// 2. per record: status and name key; 3. records of one name adjacent
+	DeviceBuffer& keys = ctx->scratch("ingest.keys"); DeviceBuffer& keys_sorted = ctx->scratch("ingest.keys_sorted"); DeviceBuffer& record_bits = ctx->scratch("ingest.record_bits");
+	DeviceBuffer& sorted_records = ctx->scratch("ingest.sorted_records"); DeviceBuffer& head = ctx->scratch("ingest.head"); DeviceBuffer& group_start = ctx->scratch("ingest.group_start");
+	const uint64_t records1 = std::max<uint64_t>(n_records, 1);
+	ALLOC(keys, records1 * 8); ALLOC(keys_sorted, records1 * 8); ALLOC(record_bits, records1); ALLOC(sorted_records, records1 * 4);
+	uint64_t n_active = 0, seed = 0;
+	uint32_t n_groups = 0;
+	while (true) {
+		HIP_CHECK(hipMemsetAsync(device_counters, 0, IC_COUNT * 4, s));
+		if (n_records > 0) {
+			{ KernelTimer timer(ctx, "record_parse_kernel", n_records * (8 + 64 + 9));
+			  record_parse_kernel<<<tally_grid(n_records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, seed, keys.as<uint64_t>(), record_bits.as<uint8_t>(), device_counters); }
+			TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(), nullptr, sorted_records.as<uint32_t>(), n_records, 64, "rocprim::radix_sort_pairs(record keys)", true));
+		}
+		TRY(read_counters());
+		if (host_counters[IC_BROKEN] > 0) { set_last_error("failed to load alignments"); return AGPU_ERR_INVALID; }
+		n_active = host_counters[IC_ACTIVE];
+		n_groups = 0;
+		if (n_active > 0) {
+			ALLOC(head, n_active); ALLOC(group_start, (n_active + 1) * 4);
+			{ KernelTimer timer(ctx, "group_head_kernel", n_active * (8 + 4 + 1));
+			  group_head_kernel<<<grid_for(n_active), BLOCK, 0, s>>>(in, keys_sorted.as<uint64_t>(), sorted_records.as<uint32_t>(), n_active, head.as<uint8_t>(), device_counters); }
+			TRY(select_flagged(ctx, rocprim_scratch, head.as<uint8_t>(), group_start.as<uint32_t>(), device_counters + IC_MAX_NAME /* borrowed as the count */, n_active));
+			TRY(read_counters());
+			n_groups = host_counters[IC_MAX_NAME];
+			HIP_CHECK(hipMemsetAsync(device_counters + IC_MAX_NAME, 0, 4, s));
+			if (host_counters[IC_COLLISION]) { seed += 0x632BE59BD9B4E019ull; continue; } // two names with one key: hash again with another seed (once in ~10^3 runs of 10^8 names)
+		}
+		break;
+	}
+	const uint64_t mapped_reads = host_counters[IC_MAPPED_READS], missing_hi_tag = host_counters[IC_MISSING_HI];
+
+	// 4. the loop body of the reference per name; 5. the valid fragments in name order
+	DeviceBuffer& plain = ctx->scratch("ingest.plain_plans"); DeviceBuffer& itd = ctx->scratch("ingest.itd_plans"); DeviceBuffer& valid = ctx->scratch("ingest.valid"); DeviceBuffer& sizes = ctx->scratch("ingest.sizes");
+	DeviceBuffer& refs = ctx->scratch("ingest.refs"); DeviceBuffer& order = ctx->scratch("ingest.order"); DeviceBuffer& order_keys = ctx->scratch("ingest.order_keys"); DeviceBuffer& order_keys_sorted = ctx->scratch("ingest.order_keys_sorted");
+	const uint64_t groups1 = std::max<uint32_t>(n_groups, 1);
+	ALLOC(plain, groups1 * sizeof(FragmentPlan)); ALLOC(itd, groups1 * sizeof(TandemPlan)); ALLOC(valid, 2 * groups1); ALLOC(sizes, 2 * groups1 * sizeof(FragmentSizes)); ALLOC(refs, 2 * groups1 * 4);
+	IngestContext context;
+	context.stream = in; context.annotation = ctx->annotation; context.annotation.n_dummy = 0; context.genome = ctx->genome;
+	context.coverage.n_contigs = ctx->genome.n_contigs; context.coverage.window_offset = ctx->coverage_window_offset.as<uint64_t>(); context.coverage.windows = ctx->coverage_windows32.as<uint32_t>();
+	context.coverage.fragment_starts = ctx->coverage_fragment_starts.as<uint8_t>(); context.coverage.fragment_ends = ctx->coverage_fragment_ends.as<uint8_t>();
+	context.record_bits = record_bits.as<uint8_t>(); context.max_itd_length = ctx->ingest_max_itd_length; context.external_duplicate_marking = ctx->ingest_external_duplicate_marking;
+	uint64_t n_fragments = 0;
+	if (n_groups > 0) {
+		{ KernelTimer timer(ctx, "group_replay_kernel", size - base);
+		  group_replay_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(context, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), n_groups, n_active, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
+		                                                            sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
+		TRY(select_flagged(ctx, rocprim_scratch, valid.as<uint8_t>(), refs.as<uint32_t>(), device_counters + IC_MAX_NAME, 2 * (uint64_t) n_groups));
+		TRY(read_counters());
+		n_fragments = host_counters[IC_MAX_NAME];
+		HIP_CHECK(hipMemsetAsync(device_counters + IC_MAX_NAME, 0, 4, s));
+	} else TRY(read_counters());
+	const uint64_t malformed_count = host_counters[IC_MALFORMED];
+	const bool no_chimeric_reads = host_counters[IC_CHIMERIC] == 0;
+	if (n_fragments >= 0xFFFFFFF0ull) { set_last_error("a batch holds at most 2^32-16 fragments; shard larger inputs"); return AGPU_ERR_INVALID; }
+	const uint64_t fragments1 = std::max<uint64_t>(n_fragments, 1);
+	bool names_were_sorted = true;
+	ALLOC(order, fragments1 * 4);
+	if (n_fragments > 0) {
+		ALLOC(order_keys, fragments1 * 8); ALLOC(order_keys_sorted, fragments1 * 8);
+		occurrence_key_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(refs.as<uint32_t>(), n_fragments, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order_keys.as<uint64_t>());
+		unsigned int key_bits = 2; while (key_bits < 64 && (n_records >> (key_bits - 1)) > 0) ++key_bits;
+		TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, order_keys.as<uint64_t>(), order_keys_sorted.as<uint64_t>(), refs.as<uint32_t>(), order.as<uint32_t>(), n_fragments, key_bits, "rocprim::radix_sort_pairs(first occurrence)", false));
+		{ KernelTimer timer(ctx, "name_order_check_kernel", n_fragments * (4 + 2 * 40));
+		  name_order_check_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n_fragments, device_counters); }
+		TRY(read_counters());
+		if (host_counters[IC_UNSORTED]) { // the names are not in std::string order: least-significant-chunk-first radix sort over the 8-byte chunks of the names
+			names_were_sorted = false;
+			const uint32_t chunks = (host_counters[IC_MAX_NAME] + 7) / 8;
+			for (uint32_t chunk = chunks; chunk-- > 0; ) {
+				{ KernelTimer timer(ctx, "name_chunk_kernel", n_fragments * (4 + 8 + 40));
+				  name_chunk_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n_fragments, chunk, order_keys.as<uint64_t>()); }
+				TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, order_keys.as<uint64_t>(), order_keys_sorted.as<uint64_t>(), order.as<uint32_t>(), refs.as<uint32_t>(), n_fragments, 64, "rocprim::radix_sort_pairs(name chunk)", false));
+				order.swap(refs);
+			}
+		}
+	}
+
+	// 6. pool offsets, then the batch
+	DeviceBuffer& cigar_words = ctx->scratch("ingest.cigar_words"); DeviceBuffer& sequence_bytes = ctx->scratch("ingest.sequence_bytes"); DeviceBuffer& name_lengths = ctx->scratch("ingest.name_lengths"); DeviceBuffer& new_group = ctx->scratch("ingest.new_group");
+	DeviceBuffer& cigar_base = ctx->scratch("ingest.cigar_base"); DeviceBuffer& sequence_base = ctx->scratch("ingest.sequence_base"); DeviceBuffer& name_base = ctx->scratch("ingest.name_base"); DeviceBuffer& group_id = ctx->scratch("ingest.group_id");
+	ALLOC(cigar_words, (n_fragments + 1) * 4); ALLOC(sequence_bytes, (n_fragments + 1) * 4); ALLOC(name_lengths, (n_fragments + 1) * 4); ALLOC(new_group, (n_fragments + 1) * 4);
+	ALLOC(cigar_base, (n_fragments + 1) * 8); ALLOC(sequence_base, (n_fragments + 1) * 8); ALLOC(name_base, (n_fragments + 1) * 8); ALLOC(group_id, (n_fragments + 1) * 4);
+	{ KernelTimer timer(ctx, "fragment_layout_kernel", n_fragments * (4 + 8 + 16 + 2 * 40));
+	  fragment_layout_kernel<<<grid_for(n_fragments + 1), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n_fragments, sizes.as<FragmentSizes>(),
+	                                                                   cigar_words.as<uint32_t>(), sequence_bytes.as<uint32_t>(), name_lengths.as<uint32_t>(), new_group.as<uint32_t>()); }
+	TRY(exclusive_sum_u64(ctx, rocprim_scratch, cigar_words.as<uint32_t>(), cigar_base.as<uint64_t>(), n_fragments + 1));
+	TRY(exclusive_sum_u64(ctx, rocprim_scratch, sequence_bytes.as<uint32_t>(), sequence_base.as<uint64_t>(), n_fragments + 1));
+	TRY(exclusive_sum_u64(ctx, rocprim_scratch, name_lengths.as<uint32_t>(), name_base.as<uint64_t>(), n_fragments + 1));
+	if (n_fragments > 0) {
+		size_t scan_bytes = 0;
+		HIP_CHECK(rocprim::inclusive_scan(nullptr, scan_bytes, new_group.as<uint32_t>(), group_id.as<uint32_t>(), n_fragments, rocprim::plus<uint32_t>(), s));
+		if (scan_bytes > rocprim_scratch.capacity) ALLOC(rocprim_scratch, scan_bytes);
+		HIP_CHECK(rocprim::inclusive_scan(rocprim_scratch.ptr, scan_bytes, new_group.as<uint32_t>(), group_id.as<uint32_t>(), n_fragments, rocprim::plus<uint32_t>(), s));
+	}
+	uint64_t totals[3] = { 0, 0, 0 };
+	HIP_CHECK(hipMemcpyAsync(&totals[0], cigar_base.as<uint64_t>() + n_fragments, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&totals[1], sequence_base.as<uint64_t>() + n_fragments, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&totals[2], name_base.as<uint64_t>() + n_fragments, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (totals[2] >= 0xFFFFFFFFull || totals[0] >= 0xFFFFFFFFull || totals[1] / 4 >= 0xFFFFFFFFull) { set_last_error("batch too large for 32-bit pool offsets"); return AGPU_ERR_INVALID; }
+	const uint64_t n = n_fragments;
+	ctx->n = n;
+	ALLOC(ctx->n_aln, n); ALLOC(ctx->fbits, n); ALLOC(ctx->group, n * 4);
+	for (int k = 0; k < 3; ++k) { ALLOC(ctx->contig[k], n * 2); ALLOC(ctx->start[k], n * 4); ALLOC(ctx->end[k], n * 4); ALLOC(ctx->abits[k], n); ALLOC(ctx->cigar_offset[k], n * 4); ALLOC(ctx->cigar_count[k], n * 2); }
+	for (int k = 0; k < 2; ++k) { ALLOC(ctx->seq_offset[k], n * 4); ALLOC(ctx->seq_length[k], n * 4); }
+	ALLOC(ctx->cigar_pool, totals[0] * 4); ALLOC(ctx->seq_pool, totals[1]); ALLOC(ctx->names, totals[2]); ALLOC(ctx->name_offset, (n + 1) * 4);
+	ctx->names_size = totals[2];
+	PackTarget target;
+	fill_pack_target(ctx, target);
+	{ KernelTimer timer(ctx, "fragment_pack_kernel", n * (1 + 1 + 4 + 3 * 17 + 16 + 4 + 24) + totals[0] * 8 + totals[1] * 2 + totals[2] * 2);
+	  fragment_pack_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n, plain.as<FragmentPlan>(), itd.as<TandemPlan>(),
+	                                                       cigar_base.as<uint64_t>(), sequence_base.as<uint64_t>(), name_base.as<uint64_t>(), group_id.as<uint32_t>(), target, device_counters); }
+	const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
+	if (windows > 0) { KernelTimer timer(ctx, "coverage_clamp_kernel", windows * 6); coverage_clamp_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_windows32.as<uint32_t>(), windows, ctx->coverage_windows.as<uint16_t>()); }
+	TRY(read_counters());
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (size - base) * 2 + n_records * 40 + n * 250;
+	ctx->max_read_length = host_counters[IC_MAX_READ_LENGTH];
+	ctx->batch_input_bytes = n * (1 + 1 + 4 + 3 * 17 + 16) + totals[0] * 4 + totals[1];
+	ctx->coverage.n_contigs = ctx->genome.n_contigs; ctx->coverage.window_offset = ctx->coverage_window_offset.as<uint64_t>(); ctx->coverage.coverage = ctx->coverage_windows.as<uint16_t>();
+	ctx->coverage.fragment_starts = ctx->coverage_fragment_starts.as<uint8_t>(); ctx->coverage.fragment_ends = ctx->coverage_fragment_ends.as<uint8_t>();
+	ctx->have_coverage = true;
+	TRY(agpu::finish_batch_setup(ctx));
+	ctx->batch_from_ingest = true;
+	// the stream and the per-record tables are not needed any more: give the memory back (a 10^8-fragment stream is ~54 GB)
+	if (getenv("ARRIBA_KEEP_INGEST_BUFFERS") == nullptr) {
+		ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release(); ctx->coverage_windows32.release();
+		static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.plain_plans", "ingest.itd_plans",
+			"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
+			"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
+		for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) ctx->scratch(temporary[k]).release();
+	}
+	ctx->ingest_stream_size = 0;
+	if (result) {
+		memset(result, 0, sizeof(*result));
+		result->records = n_records; result->fragments = n; result->mapped_reads = mapped_reads; result->malformed_count = malformed_count; result->missing_hi_tag = missing_hi_tag;
+		result->no_chimeric_reads = no_chimeric_reads; result->names_were_sorted = names_were_sorted; result->stream_bytes = size;
+	}
+	return AGPU_OK;
+}
+
+int agpu_get_viral_read_counts(agpu_ctx* ctx, uint64_t* counts) {
+	if (!ctx || !ctx->batch_from_ingest || !counts) { set_last_error("no batch built by the ingest"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipMemcpy(counts, ctx->ingest_viral_counts.ptr, (size_t) ctx->genome.n_contigs * 8, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+int agpu_get_coverage(agpu_ctx* ctx, uint16_t* coverage, uint8_t* fragment_starts, uint8_t* fragment_ends) {
+	if (!ctx || !ctx->have_coverage) { set_last_error("no coverage on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
+	if (windows == 0) return AGPU_OK;
+	if (coverage) HIP_CHECK(hipMemcpy(coverage, ctx->coverage_windows.ptr, windows * 2, hipMemcpyDeviceToHost));
+	if (fragment_starts) HIP_CHECK(hipMemcpy(fragment_starts, ctx->coverage_fragment_starts.ptr, windows, hipMemcpyDeviceToHost));
+	if (fragment_ends) HIP_CHECK(hipMemcpy(fragment_ends, ctx->coverage_fragment_ends.ptr, windows, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+int agpu_detect_strandedness(agpu_ctx* ctx, int* strandedness) {
+	if (!ctx || !ctx->have_batch || !ctx->have_annotation) { set_last_error("annotation and batch must be on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t sample_size = 100;
+	const float threshold = 0.95;
+	DeviceBuffer& counters = ctx->scratch("strandedness.counters"); DeviceBuffer& flags = ctx->scratch("strandedness.flags");
+	ALLOC(counters, IC_COUNT * 4);
+	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, IC_COUNT * 4, s));
+	AnnotationView annotation = ctx->annotation; annotation.n_dummy = 0; // the GTF genes: the reference looks before the dummy genes exist (source/arriba.cpp:141-158)
+	// the pristine alignment bits (the strands as ingested) are what the reference looks at, before assign_strands_from_strandedness
+	BatchView batch = ctx->batch;
+	for (int k = 0; k < 3; ++k) batch.abits[k] = ctx->pristine_abits[k].as<uint8_t>();
+	uint32_t host_counters[IC_COUNT]; memset(host_counters, 0, sizeof(host_counters));
+	uint64_t chunk = 1u << 20;
+	for (uint64_t first = 0; first < ctx->n && host_counters[IC_STRAND_COUNT] < sample_size; first += chunk, chunk *= 4) {
+		const uint64_t count = std::min<uint64_t>(chunk, ctx->n - first);
+		ALLOC(flags, count);
+		strandedness_flag_kernel<<<grid_for(count), BLOCK, 0, s>>>(batch, annotation, first, count, flags.as<uint8_t>());
+		strandedness_take_kernel<<<1, 64, 0, s>>>(flags.as<uint8_t>(), count, sample_size, counters.as<uint32_t>());
+		HIP_CHECK(hipMemcpyAsync(host_counters, counters.ptr, IC_COUNT * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	const uint32_t count = host_counters[IC_STRAND_COUNT], matching = host_counters[IC_STRAND_MATCHING];
+	int verdict = 0;
+	if (count >= sample_size) {
+		if (matching < (1 - threshold) * count) verdict = 2;
+		else if (matching > threshold * count) verdict = 1;
+	}
+	if (strandedness) *strandedness = verdict;
+	return AGPU_OK;
+}
+
+int agpu_get_read_lengths(agpu_ctx* ctx, uint64_t first, uint64_t count, uint32_t* mate1, uint32_t* mate2) {
+	if (!ctx || !ctx->have_batch) { set_last_error("no batch on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (first > ctx->n) first = ctx->n;
+	if (count > ctx->n - first) count = ctx->n - first;
+	if (count == 0) return AGPU_OK;
+	if (mate1) HIP_CHECK(hipMemcpy(mate1, ctx->seq_length[0].as<uint32_t>() + first, count * 4, hipMemcpyDeviceToHost));
+	if (mate2) HIP_CHECK(hipMemcpy(mate2, ctx->seq_length[1].as<uint32_t>() + first, count * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+
+int agpu_gather_rows_begin(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint64_t* cigar_pool_size, uint64_t* seq_pool_size, uint64_t* names_size) {
+	if (!ctx || !ctx->have_batch) { set_last_error("no batch on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	ctx->gather_all = fragments == nullptr;
+	if (ctx->gather_all) n = ctx->n;
+	else {
+		for (uint64_t k = 0; k < n; ++k) if (fragments[k] >= ctx->n) { set_last_error("fragment index out of range"); return AGPU_ERR_INVALID; }
+		ALLOC(ctx->gather_ids, std::max<uint64_t>(n, 1) * 4);
+		if (n > 0) HIP_CHECK(hipMemcpyAsync(ctx->gather_ids.ptr, fragments, n * 4, hipMemcpyHostToDevice, s));
+	}
+	ctx->gather_n = n;
+	DeviceBuffer& cigar_words = ctx->scratch("gather.cigar_words"); DeviceBuffer& sequence_bytes = ctx->scratch("gather.sequence_bytes"); DeviceBuffer& name_lengths = ctx->scratch("gather.name_lengths"); DeviceBuffer& rocprim_scratch = ctx->scratch("gather.rocprim");
+	ALLOC(cigar_words, (n + 1) * 4); ALLOC(sequence_bytes, (n + 1) * 4); ALLOC(name_lengths, (n + 1) * 4);
+	ALLOC(ctx->gather_cigar_base, (n + 1) * 8); ALLOC(ctx->gather_seq_base, (n + 1) * 8); ALLOC(ctx->gather_name_base, (n + 1) * 8);
+	const uint32_t* ids = ctx->gather_all ? nullptr : ctx->gather_ids.as<uint32_t>();
+	gather_sizes_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(ctx->batch, ctx->batch_from_ingest ? ctx->name_offset.as<uint32_t>() : nullptr, ids, n, cigar_words.as<uint32_t>(), sequence_bytes.as<uint32_t>(), name_lengths.as<uint32_t>());
+	TRY(exclusive_sum_u64(ctx, rocprim_scratch, cigar_words.as<uint32_t>(), ctx->gather_cigar_base.as<uint64_t>(), n + 1));
+	TRY(exclusive_sum_u64(ctx, rocprim_scratch, sequence_bytes.as<uint32_t>(), ctx->gather_seq_base.as<uint64_t>(), n + 1));
+	TRY(exclusive_sum_u64(ctx, rocprim_scratch, name_lengths.as<uint32_t>(), ctx->gather_name_base.as<uint64_t>(), n + 1));
+	HIP_CHECK(hipMemcpyAsync(&ctx->gather_sizes[0], ctx->gather_cigar_base.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&ctx->gather_sizes[1], ctx->gather_seq_base.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&ctx->gather_sizes[2], ctx->gather_name_base.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (cigar_pool_size) *cigar_pool_size = ctx->gather_sizes[0];
+	if (seq_pool_size) *seq_pool_size = ctx->gather_sizes[1];
+	if (names_size) *names_size = ctx->gather_sizes[2];
+	return AGPU_OK;
+}
+
+int agpu_gather_rows_copy(agpu_ctx* ctx, agpu_batch_rows* rows) {
+	if (!ctx || !ctx->have_batch || !rows) { set_last_error("agpu_gather_rows_begin must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t n = ctx->gather_n, n1 = std::max<uint64_t>(n, 1);
+	// staged in device buffers of the same layout, then copied column by column
+	struct Column { const char* name; size_t bytes; void* host; size_t copy_bytes; };
+	std::vector<Column> columns;
+	columns.push_back({ "gather.n_aln", n1, rows->n_aln, n }); columns.push_back({ "gather.fbits", n1, rows->fbits, n }); columns.push_back({ "gather.group", n1 * 4, rows->group, n * 4 });
+	static const char* const slot_names[3][6] = { { "gather.contig0", "gather.start0", "gather.end0", "gather.abits0", "gather.cigar_offset0", "gather.cigar_count0" }, { "gather.contig1", "gather.start1", "gather.end1", "gather.abits1", "gather.cigar_offset1", "gather.cigar_count1" },
+	                                              { "gather.contig2", "gather.start2", "gather.end2", "gather.abits2", "gather.cigar_offset2", "gather.cigar_count2" } };
+	for (int k = 0; k < 3; ++k) {
+		columns.push_back({ slot_names[k][0], n1 * 2, rows->contig[k], n * 2 }); columns.push_back({ slot_names[k][1], n1 * 4, rows->start[k], n * 4 }); columns.push_back({ slot_names[k][2], n1 * 4, rows->end[k], n * 4 });
+		columns.push_back({ slot_names[k][3], n1, rows->abits[k], n }); columns.push_back({ slot_names[k][4], n1 * 4, rows->cigar_offset[k], n * 4 }); columns.push_back({ slot_names[k][5], n1 * 2, rows->cigar_count[k], n * 2 });
+	}
+	columns.push_back({ "gather.seq_offset0", n1 * 4, rows->seq_offset[0], n * 4 }); columns.push_back({ "gather.seq_length0", n1 * 4, rows->seq_length[0], n * 4 });
+	columns.push_back({ "gather.seq_offset1", n1 * 4, rows->seq_offset[1], n * 4 }); columns.push_back({ "gather.seq_length1", n1 * 4, rows->seq_length[1], n * 4 });
+	columns.push_back({ "gather.cigar_pool", std::max<uint64_t>(ctx->gather_sizes[0], 1) * 4, rows->cigar_pool, ctx->gather_sizes[0] * 4 }); columns.push_back({ "gather.seq_pool", std::max<uint64_t>(ctx->gather_sizes[1], 4), rows->seq_pool, ctx->gather_sizes[1] });
+	columns.push_back({ "gather.name_offset", (n + 1) * 4, rows->name_offset, (n + 1) * 4 }); columns.push_back({ "gather.names", std::max<uint64_t>(ctx->gather_sizes[2], 1), rows->names, ctx->gather_sizes[2] });
+	for (size_t c = 0; c < columns.size(); ++c) ALLOC(ctx->scratch(columns[c].name), columns[c].bytes);
+	PackTarget out;
+	size_t c = 0;
+	out.n_aln = ctx->scratch(columns[c++].name).as<uint8_t>(); out.fbits = ctx->scratch(columns[c++].name).as<uint8_t>(); out.group = ctx->scratch(columns[c++].name).as<uint32_t>();
+	for (int k = 0; k < 3; ++k) {
+		out.contig[k] = ctx->scratch(columns[c++].name).as<uint16_t>(); out.start[k] = ctx->scratch(columns[c++].name).as<int32_t>(); out.end[k] = ctx->scratch(columns[c++].name).as<int32_t>();
+		out.abits[k] = ctx->scratch(columns[c++].name).as<uint8_t>(); out.cigar_offset[k] = ctx->scratch(columns[c++].name).as<uint32_t>(); out.cigar_count[k] = ctx->scratch(columns[c++].name).as<uint16_t>();
+	}
+	out.seq_offset[0] = ctx->scratch(columns[c++].name).as<uint32_t>(); out.seq_length[0] = ctx->scratch(columns[c++].name).as<uint32_t>();
+	out.seq_offset[1] = ctx->scratch(columns[c++].name).as<uint32_t>(); out.seq_length[1] = ctx->scratch(columns[c++].name).as<uint32_t>();
+	out.cigar_pool = ctx->scratch(columns[c++].name).as<uint32_t>(); out.seq_pool = ctx->scratch(columns[c++].name).as<uint8_t>();
+	out.name_offset = ctx->scratch(columns[c++].name).as<uint32_t>(); out.names = ctx->scratch(columns[c++].name).as<char>();
+	DeviceBuffer& abits_pointers = ctx->scratch("gather.abits_pointers");
+	ALLOC(abits_pointers, 3 * sizeof(void*));
+	const uint8_t* pristine[3] = { ctx->pristine_abits[0].as<uint8_t>(), ctx->pristine_abits[1].as<uint8_t>(), ctx->pristine_abits[2].as<uint8_t>() };
+	HIP_CHECK(hipMemcpyAsync(abits_pointers.ptr, pristine, sizeof(pristine), hipMemcpyHostToDevice, s));
+	const uint32_t* ids = ctx->gather_all ? nullptr : ctx->gather_ids.as<uint32_t>();
+	gather_copy_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(ctx->batch, ctx->pristine_fbits.as<uint8_t>(), abits_pointers.as<const uint8_t*>(), ctx->batch_from_ingest ? ctx->name_offset.as<uint32_t>() : nullptr,
+	                                                     ctx->names.as<char>(), ids, n, ctx->gather_cigar_base.as<uint64_t>(), ctx->gather_seq_base.as<uint64_t>(), ctx->gather_name_base.as<uint64_t>(), out);
+	for (size_t k = 0; k < columns.size(); ++k)
+		if (columns[k].host != nullptr && columns[k].copy_bytes > 0) HIP_CHECK(hipMemcpyAsync(columns[k].host, ctx->scratch(columns[k].name).ptr, columns[k].copy_bytes, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	rows->n = n; rows->cigar_pool_size = ctx->gather_sizes[0]; rows->seq_pool_size = ctx->gather_sizes[1]; rows->names_size = ctx->gather_sizes[2];
+	return AGPU_OK;
+}
+
+}

@@ -505,8 +505,9 @@ AGPU_HD void add_fragment_to_coverage(const CoverageBuild& coverage, const Rec& 
 	// the reference compares bam_cigar_type() (0..3) with BAM_CSOFT_CLIP (4), which never matches: only the proper-pair flag turns a fragment chimeric here
 	if ((flag1 & BAMF_PAIRED) && !(flag1 & BAMF_PROPER_PAIR)) is_chimeric = true;
 	if (!is_chimeric) {
-		if (!(flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) coverage.fragment_starts[begin1 + (uint64_t) (mate1.pos / COVERAGE_RESOLUTION)] = 1;
-		else coverage.fragment_starts[begin2 + (uint64_t) (mate2.pos / COVERAGE_RESOLUTION)] = 1;
+		// (the reference indexes without a check; a position behind its contig would be undefined behaviour there)
+		if (!(flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) { const uint64_t w = (uint64_t) (mate1.pos / COVERAGE_RESOLUTION); if (mate1.pos >= 0 && w < size1) coverage.fragment_starts[begin1 + w] = 1; }
+		else { const uint64_t w = (uint64_t) (mate2.pos / COVERAGE_RESOLUTION); if (mate2.pos >= 0 && w < size2) coverage.fragment_starts[begin2 + w] = 1; }
 	}
 	int32_t position1 = mate1.pos, position2 = mate2.pos;
 	int32_t position = position1 < position2 ? position1 : position2;
@@ -541,8 +542,8 @@ AGPU_HD void add_fragment_to_coverage(const CoverageBuild& coverage, const Rec& 
 		}
 	}
 	if (!is_chimeric) {
-		if ((flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) coverage.fragment_ends[begin1 + (uint64_t) ((position1 - 1) / COVERAGE_RESOLUTION)] = 1;
-		else coverage.fragment_ends[begin2 + (uint64_t) ((position2 - 1) / COVERAGE_RESOLUTION)] = 1;
+		if ((flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) { const uint64_t w = (uint64_t) ((position1 - 1) / COVERAGE_RESOLUTION); if (position1 >= 1 && w < size1) coverage.fragment_ends[begin1 + w] = 1; }
+		else { const uint64_t w = (uint64_t) ((position2 - 1) / COVERAGE_RESOLUTION); if (position2 >= 1 && w < size2) coverage.fragment_ends[begin2 + w] = 1; }
 	}
 }
 
@@ -738,6 +739,125 @@ AGPU_HD int compare_names(const FragmentName& x, const FragmentName& y) {
 	const uint32_t nx = name_length(x), ny = name_length(y), n = nx < ny ? nx : ny;
 	for (uint32_t i = 0; i < n; ++i) { const uint8_t cx = name_byte(x, i), cy = name_byte(y, i); if (cx != cy) return cx < cy ? -1 : 1; }
 	return nx < ny ? -1 : nx > ny ? 1 : 0;
+}
+
+// ---- the packed batch: what one fragment writes (reference of the layout: include/arriba_gpu.h: agpu_batch_view) ------------------------------------
+
+struct FragmentSizes { uint32_t cigar_words, sequence_bytes, name_length; };
+AGPU_HD uint32_t padded_sequence_bytes(uint32_t bases) { return (((bases + 1) / 2) + 3) & ~3u; } // two bases per byte, every sequence on a 4-byte boundary
+AGPU_HD void fragment_sizes(const Fragment3& f, const Rec& representative, bool itd, FragmentSizes& sizes) {
+	uint32_t cigar_words = 0, sequence_bytes = 0;
+	for (uint32_t s = 0; s < f.n; ++s) {
+		cigar_words += f.a[s].n_cigar;
+		if (s < 2) sequence_bytes += padded_sequence_bytes((uint32_t) f.a[s].sequence_length);
+	}
+	sizes.cigar_words = cigar_words; sizes.sequence_bytes = sequence_bytes;
+	sizes.name_length = name_length(fragment_name(representative, itd));
+}
+
+struct PackTarget {
+	uint8_t* n_aln; uint8_t* fbits; uint32_t* group;
+	uint16_t* contig[3]; int32_t* start[3]; int32_t* end[3]; uint8_t* abits[3]; uint32_t* cigar_offset[3]; uint16_t* cigar_count[3];
+	uint32_t* cigar_pool; uint32_t* seq_offset[2]; uint32_t* seq_length[2]; uint8_t* seq_pool; uint32_t* name_offset; char* names;
+};
+
+// row i of the batch from a sanity-checked fragment; returns the length of its longest read
+AGPU_HD uint32_t write_fragment(const IngestStream& in, const Fragment3& f, const FragmentName& name, uint64_t i, uint64_t cigar_at, uint64_t sequence_at, uint64_t name_at, uint32_t group, const PackTarget& out) {
+	out.n_aln[i] = (uint8_t) f.n;
+	out.fbits[i] = (f.single_end ? FBIT_SINGLE_END : 0) | (f.duplicate ? FBIT_DUPLICATE : 0);
+	out.group[i] = group;
+	uint32_t longest = 0;
+	for (uint32_t s = 0; s < 3; ++s) {
+		if (s >= f.n) {
+			out.contig[s][i] = 0; out.start[s][i] = 0; out.end[s][i] = 0; out.abits[s][i] = 0; out.cigar_offset[s][i] = 0; out.cigar_count[s][i] = 0;
+			if (s < 2) { out.seq_offset[s][i] = 0; out.seq_length[s][i] = 0; }
+			continue;
+		}
+		const Aln& a = f.a[s];
+		out.contig[s][i] = (uint16_t) a.contig; out.start[s][i] = a.start; out.end[s][i] = a.end;
+		out.abits[s][i] = (a.strand ? ABIT_STRAND : 0) | (a.first_in_pair ? ABIT_FIRST_IN_PAIR : 0) | (a.supplementary ? ABIT_SUPPLEMENTARY : 0) | ABIT_PREDICTED_STRAND_AMBIGUOUS;
+		out.cigar_offset[s][i] = (uint32_t) cigar_at; out.cigar_count[s][i] = (uint16_t) a.n_cigar;
+		for (uint32_t k = 0; k < a.n_cigar; ++k) out.cigar_pool[cigar_at + k] = a.cigar(k);
+		cigar_at += a.n_cigar;
+		if (s < 2) {
+			const uint32_t length = (uint32_t) a.sequence_length, bytes = (length + 1) / 2, padded = padded_sequence_bytes(length);
+			out.seq_offset[s][i] = (uint32_t) (sequence_at / 4); out.seq_length[s][i] = length;
+			if (length > longest) longest = length;
+			if (length > 0) {
+				const Rec source = (a.sequence_record == a.record) ? a.rec : load_record(in, a.sequence_record);
+				uint32_t* target = (uint32_t*) (out.seq_pool + sequence_at); // sequences start on 4-byte boundaries
+				for (uint32_t w = 0; w < padded / 4; ++w) {
+					uint32_t value = 0;
+					if (4 * w + 4 < bytes) value = load_u32(source.seq_bytes + 4 * w);
+					else for (uint32_t b = 0; b < 4; ++b) {
+						const uint32_t at = 4 * w + b;
+						if (at >= bytes) break;
+						uint32_t byte = source.seq_bytes[at];
+						if (at == bytes - 1 && (length & 1)) byte &= 0xF0u; // the unused low nibble of an odd length
+						value |= byte << (8 * b);
+					}
+					target[w] = value;
+				}
+			}
+			sequence_at += padded;
+		}
+	}
+	out.name_offset[i] = (uint32_t) name_at;
+	const uint32_t length = name_length(name);
+	for (uint32_t k = 0; k < length; ++k) out.names[name_at + k] = (char) name_byte(name, k);
+	return longest;
+}
+
+// rows of a resident batch copied out for the host (agpu_gather_rows_*): sizes of row i, then the copy into row k of the target
+AGPU_HD void row_sizes(const BatchView& b, const uint32_t* name_offset, uint64_t i, uint32_t& cigar_words, uint32_t& sequence_bytes, uint32_t& name_bytes) {
+	cigar_words = 0; sequence_bytes = 0;
+	for (uint32_t s = 0; s < b.n_aln[i]; ++s) {
+		cigar_words += b.cigar_count[s][i];
+		if (s < 2) sequence_bytes += padded_sequence_bytes(b.seq_length[s][i]);
+	}
+	name_bytes = name_offset ? name_offset[i + 1] - name_offset[i] : 0;
+}
+AGPU_HD void copy_row(const BatchView& b, const uint8_t* pristine_fbits, const uint8_t* const* pristine_abits, const uint32_t* name_offset, const char* names, uint64_t i, uint64_t k,
+                      uint64_t cigar_at, uint64_t sequence_at, uint64_t name_at, const PackTarget& out) {
+	const uint32_t n_aln = b.n_aln[i];
+	out.n_aln[k] = (uint8_t) n_aln; out.fbits[k] = pristine_fbits[i]; out.group[k] = b.group[i];
+	for (uint32_t s = 0; s < 3; ++s) {
+		out.contig[s][k] = b.contig[s][i]; out.start[s][k] = b.start[s][i]; out.end[s][k] = b.end[s][i]; out.abits[s][k] = pristine_abits[s][i];
+		const uint32_t count = s < n_aln ? b.cigar_count[s][i] : 0;
+		out.cigar_count[s][k] = (uint16_t) count; out.cigar_offset[s][k] = s < n_aln ? (uint32_t) cigar_at : 0;
+		for (uint32_t c = 0; c < count; ++c) out.cigar_pool[cigar_at + c] = b.cigar_pool[b.cigar_offset[s][i] + c];
+		cigar_at += count;
+		if (s < 2) {
+			const uint32_t length = s < n_aln ? b.seq_length[s][i] : 0, padded = padded_sequence_bytes(length);
+			out.seq_length[s][k] = length; out.seq_offset[s][k] = s < n_aln ? (uint32_t) (sequence_at / 4) : 0;
+			if (length > 0) {
+				const uint32_t* source = (const uint32_t*) b.seq_pool + b.seq_offset[s][i];
+				uint32_t* target = (uint32_t*) (out.seq_pool + sequence_at);
+				for (uint32_t w = 0; w < padded / 4; ++w) target[w] = source[w];
+			}
+			sequence_at += padded;
+		}
+	}
+	out.name_offset[k] = (uint32_t) name_at;
+	if (name_offset) for (uint32_t c = name_offset[i]; c < name_offset[i + 1]; ++c) out.names[name_at + (c - name_offset[i])] = names[c];
+}
+
+// detect_strandedness (source/read_stats.cpp:94-143) asks every split read: 0 = not informative, 1 = informative, 3 = informative and on the gene's strand.
+// `b.abits`: the strands as ingested; `ann`: the GTF genes.
+AGPU_HD uint8_t strandedness_vote(const BatchView& b, const AnnotationView& ann, uint64_t i) {
+	if (b.n_aln[i] != 3) return 0;
+	const bool split_strand = b.abits[SPLIT_READ][i] & ABIT_STRAND, supplementary_strand = b.abits[SUPPLEMENTARY][i] & ABIT_STRAND;
+	int32_t distance = b.start[SPLIT_READ][i] - b.start[SUPPLEMENTARY][i]; if (distance < 0) distance = -distance;
+	if (!(b.contig[SPLIT_READ][i] == b.contig[SUPPLEMENTARY][i] && split_strand == supplementary_strand && distance < 400000)) return 0;
+	AGPU_IDSET(genes);
+	query_by_coordinate(ann.gene_index, b.contig[SPLIT_READ][i], b.start[SPLIT_READ][i], b.end[SPLIT_READ][i], IdentityMap(), genes);
+	if (genes.n != 1 || genes.overflow) return 0;
+	const uint32_t gene = genes.get(0);
+	const int32_t position = split_strand ? b.start[SPLIT_READ][i] : b.end[SPLIT_READ][i];
+	if (!is_breakpoint_spliced(ann, gene, split_strand, position)) return 0;
+	const bool gene_strand = ann.gene_bits[gene] & GBIT_STRAND, mate1_strand = b.abits[MATE1][i] & ABIT_STRAND;
+	const bool matching = ((b.abits[SPLIT_READ][i] & ABIT_FIRST_IN_PAIR) && split_strand == gene_strand) || ((b.abits[MATE1][i] & ABIT_FIRST_IN_PAIR) && mate1_strand == gene_strand);
+	return matching ? 3 : 1;
 }
 
 }

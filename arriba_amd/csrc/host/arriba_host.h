@@ -9,7 +9,7 @@
 #define ARRIBA_HOST_H 1
 
 #include <cstdint>
-#include "../../../include/arriba_gpu.h"
+#include "../../../include/arriba_host.h"
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -189,6 +189,14 @@ struct IngestResult {
 struct ByteSource { virtual size_t read(uint8_t* buffer, size_t capacity) = 0; virtual ~ByteSource() {} };
 ByteSource* open_bam_file(const std::string& path);               // BGZF/gzip or raw BAM, file or /dev/stdin
 ByteSource* open_memory_source(const uint8_t* data, size_t size); // raw (already inflated) BAM stream
+
+// The file side of the device ingest (agpu_ingest_*): container recognised from the one open stream, BAM header parsed, bytes handed on in pieces.
+class BamFeed;
+BamFeed* open_bam_feed(const std::string& path);
+void close_bam_feed(BamFeed* feed);
+uint64_t bam_feed_header(BamFeed* feed, std::vector<std::string>& target_names); // returns the size of the header = offset of the first record in the uncompressed stream
+uint64_t bam_feed_size_hint(BamFeed* feed);                                       // expected size of the uncompressed stream, 0 = unknown
+bool bam_feed_next(BamFeed* feed, uint8_t* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece& piece);
 
 // reference: source/read_chimeric_alignments.cpp:560-773 with separate_chimeric_bam_file=false, is_rna_bam_file=true
 // gene_index must be the index over the GTF genes (before dummy genes are added).

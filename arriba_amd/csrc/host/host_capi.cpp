@@ -61,6 +61,13 @@ struct ahost_session {
 		coverage_view.fragment_starts = coverage_starts.data(); coverage_view.fragment_ends = coverage_ends.data();
 	}
 	agpu_batch_view batch_view, slice_view;
+	// device ingest: the open file and what agpu_ingest_begin needs from its header
+	BamFeed* feed = nullptr;
+	bool device_batch = false;           // the fragments live on the device (ahost_adopt_device_ingest)
+	std::vector<uint32_t> row_fragments; // device ingest: the fragment of every row of ingest.batch (ascending); empty = the batch holds every fragment
+	std::vector<uint32_t> tid_to_contig;
+	std::vector<uint64_t> window_offset;
+	~ahost_session() { if (feed) close_bam_feed(feed); }
 	std::map<std::pair<contig_t, contig_t>, bool> related_viruses;
 	std::string name_scratch;
 
@@ -125,6 +132,7 @@ int ingest(ahost_session* session, ByteSource* source_raw, int external_duplicat
 		session->options.external_duplicate_marking = external_duplicate_marking != 0;
 		session->options.max_itd_length = max_itd_length;
 		session->ingest = IngestResult();
+		session->row_fragments.clear(); session->device_batch = false;
 		read_chimeric_alignments(*source, session->assembly, session->contigs, session->annotation, session->gene_index, session->options, session->ingest);
 		session->build_genome_view();
 		session->build_batch_view();
@@ -233,9 +241,53 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 		t.list_offset = table->list_offset; t.read_lists = table->read_lists; t.evalue = table->evalue; t.confidence = table->confidence; t.iteration_rank = table->iteration_rank;
 		t.read_filter = table->read_filter; t.closest_genomic_breakpoint1 = table->closest_genomic_breakpoint1; t.closest_genomic_breakpoint2 = table->closest_genomic_breakpoint2; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
 		const OutputExtras extras = { &session->tags, &session->protein_domains, &session->protein_domain_index, max_mate_gap, fill_sequence_gaps != 0 };
-		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
+		// device ingest: the batch of the session holds only the rows fetched for this table (ahost_set_batch_rows); the read lists of the candidates
+		// that get written and the filter column are translated from fragments to rows
+		std::vector<uint32_t> lists_as_rows; std::vector<uint8_t> filter_of_rows;
+		if (print_extra_info && session->device_batch && t.n_candidates > 0) {
+			const std::vector<uint32_t>& fragments = session->row_fragments;
+			lists_as_rows.assign(t.read_lists, t.read_lists + t.list_offset[3 * (size_t) t.n_candidates]);
+			filter_of_rows.resize(fragments.size() + 1);
+			for (size_t row = 0; row < fragments.size(); ++row) filter_of_rows[row] = t.read_filter[fragments[row]];
+			for (uint32_t c = 0; c < t.n_candidates; ++c) {
+				const bool written = (write_discarded != 0) != (t.filter[c] == 0);
+				for (uint32_t k = t.list_offset[3 * (size_t) c]; k < t.list_offset[3 * (size_t) c + 3]; ++k) {
+					if (!written) { lists_as_rows[k] = 0; continue; }
+					const std::vector<uint32_t>::const_iterator row = std::lower_bound(fragments.begin(), fragments.end(), t.read_lists[k]);
+					if (row == fragments.end() || *row != t.read_lists[k]) throw std::runtime_error("a supporting read of a written candidate is not among the rows handed over (ahost_fusion_table_reads / ahost_set_batch_rows)");
+					lists_as_rows[k] = (uint32_t) (row - fragments.begin());
+				}
+			}
+			t.read_lists = lists_as_rows.data(); t.read_filter = filter_of_rows.data();
+		}
+		const bool no_rows = session->device_batch && !print_extra_info;
+		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, no_rows ? NULL : &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
 		return 0;
 	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+
+int ahost_fusion_table_reads(const ahost_fusion_table* table, int write_discarded, uint32_t* fragments, uint64_t capacity, uint64_t* count) {
+	if (!table || !count) { g_error = "null argument"; return -1; }
+	try {
+		std::vector<uint32_t> reads;
+		for (uint32_t c = 0; c < table->n_candidates; ++c)
+			if ((write_discarded != 0) != (table->filter[c] == 0))
+				reads.insert(reads.end(), table->read_lists + table->list_offset[3 * (size_t) c], table->read_lists + table->list_offset[3 * (size_t) c + 3]);
+		std::sort(reads.begin(), reads.end());
+		reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
+		*count = reads.size();
+		if (fragments) {
+			if (capacity < reads.size()) { g_error = "capacity too small"; return -1; }
+			std::copy(reads.begin(), reads.end(), fragments);
+		}
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+
+float ahost_read_length_sum_of(float running_sum, const uint32_t* mate1_lengths, const uint32_t* mate2_lengths, uint64_t count) {
+	for (uint64_t i = 0; i < count; ++i) // sequential float accumulation in name order, hazard H4
+		running_sum += ((size_t) mate1_lengths[i] + (size_t) mate2_lengths[i]) / 2;
+	return running_sum;
 }
 
 int ahost_load_range_rules(ahost_session* session, const char* path, int allow_keywords, const agpu_range_rule** rules, uint32_t* n_rules) {
@@ -333,6 +385,101 @@ int ahost_load_ingest(ahost_session* session, const char* path) {
 		g_error = e.what();
 		return -1;
 	}
+}
+
+int ahost_bam_open(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length, agpu_ingest_config* config) {
+	if (!session || !bam_path || !config) { g_error = "null argument"; return -1; }
+	try {
+		if (session->feed) { close_bam_feed(session->feed); session->feed = nullptr; }
+		session->options.external_duplicate_marking = external_duplicate_marking != 0;
+		session->options.max_itd_length = max_itd_length;
+		session->ingest = IngestResult();
+		session->have_batch = false;
+		session->feed = open_bam_feed(bam_path);
+		std::vector<std::string> target_names;
+		const uint64_t header_size = bam_feed_header(session->feed, target_names);
+		// reference: source/read_chimeric_alignments.cpp:566-582 (contigs of the header join contigs_t; interesting contigs need a sequence)
+		session->tid_to_contig.resize(target_names.size());
+		for (size_t target = 0; target < target_names.size(); ++target) session->tid_to_contig[target] = session->contigs.add(target_names[target]);
+		session->ingest.coverage.resize(session->contigs, session->assembly);
+		for (std::map<std::string, contig_t>::const_iterator contig = session->contigs.by_name.begin(); contig != session->contigs.by_name.end(); ++contig)
+			if (!session->assembly.has(contig->second) && is_interesting_contig(contig->first, session->options.interesting_contigs))
+				throw std::runtime_error("could not find sequence of contig '" + contig->first + "'");
+		session->build_genome_view();
+		const Coverage& coverage = session->ingest.coverage;
+		session->window_offset.assign(session->contigs.size() + 1, 0);
+		for (size_t contig = 0; contig < session->contigs.size(); ++contig)
+			session->window_offset[contig + 1] = session->window_offset[contig] + (contig < coverage.coverage.size() ? coverage.coverage[contig].size() : 0);
+		memset(config, 0, sizeof(*config));
+		config->n_targets = (uint32_t) session->tid_to_contig.size(); config->tid_to_contig = session->tid_to_contig.data();
+		config->first_record_offset = header_size; config->stream_size_hint = bam_feed_size_hint(session->feed);
+		config->n_contigs = (uint32_t) session->contigs.size(); config->coverage_window_offset = session->window_offset.data();
+		config->external_duplicate_marking = external_duplicate_marking != 0; config->max_itd_length = max_itd_length;
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+
+int ahost_bam_next(ahost_session* session, void* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece* piece) {
+	if (!session || !session->feed || !buffer || !piece) { g_error = "ahost_bam_open must run first"; return -1; }
+	try { return bam_feed_next(session->feed, (uint8_t*) buffer, capacity, blocks, block_capacity, *piece) ? 1 : 0; }
+	catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+
+void ahost_bam_close(ahost_session* session) { if (session && session->feed) { close_bam_feed(session->feed); session->feed = nullptr; } }
+
+int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* result, const uint64_t* viral_read_counts, const uint16_t* coverage, const uint8_t* fragment_starts, const uint8_t* fragment_ends) {
+	if (!session || !result) { g_error = "null argument"; return -1; }
+	try {
+		IngestResult& r = session->ingest;
+		r.records = result->records; r.mapped_reads = result->mapped_reads; r.malformed_count = (unsigned int) result->malformed_count; r.missing_hi_tag = (unsigned int) result->missing_hi_tag;
+		r.mapped_viral_reads_by_contig.assign(session->contigs.size(), 0);
+		if (viral_read_counts) for (size_t contig = 0; contig < session->contigs.size(); ++contig) r.mapped_viral_reads_by_contig[contig] = viral_read_counts[contig];
+		// reference: source/read_chimeric_alignments.cpp:759-771
+		if (r.mapped_reads == 0) throw std::runtime_error("no normal reads found");
+		if (r.malformed_count > 0) std::cerr << "WARNING: " << r.malformed_count << " SAM records were malformed and ignored" << std::endl;
+		if (result->no_chimeric_reads) throw std::runtime_error("no split reads or discordant mates found (STAR must either be run with '--chimOutType WithinBAM' or the file 'Chimeric.out.sam' must be passed to Arriba via the argument -c)");
+		if (r.missing_hi_tag > 0) std::cerr << "WARNING: " << r.missing_hi_tag << " secondary alignments lack the 'HI' tag and were ignored (STAR must be run with '--outSAMattributes HI' for Arriba to make use of multi-mapping reads for fusion detection)" << std::endl;
+		Coverage& c = r.coverage;
+		for (size_t contig = 0; contig < c.coverage.size() && contig + 1 < session->window_offset.size(); ++contig) {
+			const uint64_t begin = session->window_offset[contig], size = session->window_offset[contig + 1] - begin;
+			if (size != c.coverage[contig].size()) throw std::runtime_error("coverage_t: the windows of the device do not match the session's");
+			if (coverage) memcpy(c.coverage[contig].data(), coverage + begin, size * sizeof(uint16_t));
+			if (fragment_starts) memcpy(c.fragment_starts[contig].data(), fragment_starts + begin, size);
+			if (fragment_ends) memcpy(c.fragment_ends[contig].data(), fragment_ends + begin, size);
+		}
+		r.batch = Batch();
+		r.batch.n = 0;
+		session->row_fragments.clear();
+		session->device_batch = true;
+		session->have_batch = true; // (an empty host batch: the fragments live on the device; ahost_set_batch_rows brings the rows the writer needs)
+		session->build_batch_view();
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+
+int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments) {
+	if (!session || !rows || (!fragments && rows->n > 0)) { g_error = "null argument"; return -1; }
+	try {
+		Batch& b = session->ingest.batch;
+		const size_t n = rows->n;
+		b = Batch();
+		b.n = n;
+		b.n_aln.assign(rows->n_aln, rows->n_aln + n); b.fbits.assign(rows->fbits, rows->fbits + n); b.filter.assign(n, 0); b.group.assign(rows->group, rows->group + n);
+		for (int s = 0; s < 3; ++s) {
+			b.contig[s].assign(rows->contig[s], rows->contig[s] + n); b.start[s].assign(rows->start[s], rows->start[s] + n); b.end[s].assign(rows->end[s], rows->end[s] + n); b.abits[s].assign(rows->abits[s], rows->abits[s] + n);
+			b.cigar_offset[s].assign(rows->cigar_offset[s], rows->cigar_offset[s] + n); b.cigar_count[s].assign(rows->cigar_count[s], rows->cigar_count[s] + n);
+		}
+		b.cigar_pool.assign(rows->cigar_pool, rows->cigar_pool + rows->cigar_pool_size);
+		for (int s = 0; s < 2; ++s) { b.seq_offset[s].assign(rows->seq_offset[s], rows->seq_offset[s] + n); b.seq_length[s].assign(rows->seq_length[s], rows->seq_length[s] + n); }
+		b.seq_pool.assign(rows->seq_pool, rows->seq_pool + rows->seq_pool_size);
+		b.name_offset.assign(rows->name_offset, rows->name_offset + n + 1);
+		b.names.assign(rows->names, rows->names_size);
+		session->row_fragments.assign(fragments, fragments + n);
+		for (size_t k = 1; k < n; ++k) if (fragments[k] <= fragments[k - 1]) throw std::runtime_error("fragments of the rows must ascend");
+		session->have_batch = true;
+		session->build_batch_view();
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
 }
 
 int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t size, int external_duplicate_marking, unsigned int max_itd_length) {

@@ -17,6 +17,10 @@
 #include <stdexcept>
 #include <thread>
 #include <zlib.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace arriba {
 
@@ -961,6 +965,22 @@ unsigned int ingest_threads() { // ARRIBA_INGEST_THREADS overrides; the reader i
 class BgzfSource: public ByteSource {
 public:
 	static bool is_bgzf_header(const uint8_t* header, size_t available) { return available >= 18 && block_size_from_header(header, available) > 0; }
+	static size_t block_size(const uint8_t* header, size_t available) { return block_size_from_header(header, available); }
+	// inflates one block (any deflate content) into `target` and checks size and CRC-32 of the trailer
+	static bool inflate_block(const uint8_t* block, size_t raw_size, uint8_t* target, size_t out_size) {
+		const size_t data_offset = 12 + (block[10] | (size_t) block[11] << 8);
+		if (raw_size < data_offset + 8) return false;
+		z_stream stream;
+		memset(&stream, 0, sizeof(stream));
+		if (inflateInit2(&stream, -15) != Z_OK) return false;
+		uint8_t nothing = 0;
+		stream.next_in = const_cast<uint8_t*>(block + data_offset); stream.avail_in = (unsigned int) (raw_size - data_offset - 8);
+		stream.next_out = target != NULL ? target : &nothing; stream.avail_out = (unsigned int) out_size;
+		const int status = inflate(&stream, Z_FINISH);
+		const bool complete = status == Z_STREAM_END && stream.total_out == out_size;
+		inflateEnd(&stream);
+		return complete && (uint32_t) crc32(crc32(0L, Z_NULL, 0), target != NULL ? target : &nothing, (unsigned int) out_size) == le32(block + raw_size - 8);
+	}
 	BgzfSource(FILE* file, const uint8_t* prefix, size_t prefix_size, unsigned int n_threads): input_(file, prefix, prefix_size), n_threads_(std::max(1u, n_threads)), raw_fill_(0), served_(0), end_of_file_(false) {
 		raw_.resize(32u << 20);
 	}
@@ -1207,5 +1227,249 @@ void read_chimeric_alignments(ByteSource& source, const Assembly& assembly, Cont
 	parallel_ranges(n_workers, n_workers > 1 ? n_workers : 0, [&workers](size_t first, size_t last) { for (size_t w = first; w < last; ++w) workers[w].reset(); }, 2);
 	lap("tables freed");
 }
+
+
+// ---- feeding the device ingest (agpu_ingest_*: read_chimeric_alignments on the GPU) ----------------------------------------------------------------
+// The host opens the file once, parses the BAM header (the contigs of the run must be known before the records are classified) and hands the bytes on
+// in pieces: a BGZF file whose blocks are stored (STAR --outBAMcompression 0, run_arriba.sh:34) goes to the device as it is, with the table of
+// its blocks -- the payloads are moved into place in HBM; deflated blocks are inflated here by all cores straight into the caller's (pinned) buffer.
+
+namespace {
+
+// reads n bytes at the current position of a descriptor: all threads with pread on a regular file, one read loop on a pipe
+struct FileBytes {
+	int fd; bool seekable; uint64_t position; unsigned int n_threads;
+	size_t read(uint8_t* buffer, size_t capacity) {
+		if (!seekable || capacity < (8u << 20) || n_threads <= 1) {
+			size_t got = 0;
+			while (got < capacity) {
+				const ssize_t n = seekable ? pread(fd, buffer + got, capacity - got, (off_t) (position + got)) : ::read(fd, buffer + got, capacity - got);
+				if (n < 0) { if (errno == EINTR) continue; throw std::runtime_error("failed to load alignments"); }
+				if (n == 0) break;
+				got += (size_t) n;
+			}
+			position += got;
+			return got;
+		}
+		std::vector<size_t> got(n_threads, 0);
+		std::vector<uint8_t> failed(n_threads, 0);
+		const uint64_t base = position;
+		parallel_ranges(capacity, n_threads, [&](size_t first, size_t last) {
+			const unsigned int t = (unsigned int) (first * n_threads / capacity);
+			size_t done = 0;
+			while (first + done < last) {
+				const ssize_t n = pread(fd, buffer + first + done, last - first - done, (off_t) (base + first + done));
+				if (n < 0) { if (errno == EINTR) continue; failed[t < n_threads ? t : 0] = 1; break; }
+				if (n == 0) break;
+				done += (size_t) n;
+			}
+			got[t < n_threads ? t : 0] += done;
+		}, 1);
+		size_t total = 0; // the bytes form a prefix: a short range means the end of the file
+		for (unsigned int t = 0; t < n_threads; ++t) { if (failed[t]) throw std::runtime_error("failed to load alignments"); total += got[t]; }
+		position += total;
+		return total;
+	}
+};
+
+}
+
+class BamFeed {
+public:
+	enum Mode { RAW, BGZF_STORED, BGZF_DEFLATED, GZIP };
+	BamFeed(const std::string& path): gzip_open_(false), end_(false) {
+		fd_ = (path == "-") ? 0 : open(path.c_str(), O_RDONLY);
+		if (fd_ < 0) throw std::runtime_error("failed to open SAM file");
+		file_.fd = fd_; file_.position = 0; file_.n_threads = std::min(16u, ingest_threads());
+		struct stat status;
+		file_.seekable = fstat(fd_, &status) == 0 && S_ISREG(status.st_mode);
+		file_size_ = file_.seekable ? (uint64_t) status.st_size : 0;
+		n_threads_ = ingest_threads();
+		// the first bytes decide the container; they stay in `pending_` and are delivered again as the start of the stream
+		pending_.resize(1u << 20);
+		pending_.resize(file_.read(&pending_[0], pending_.size()));
+		if (BgzfSource::is_bgzf_header(pending_.data(), pending_.size())) mode_ = block_is_stored(pending_.data(), pending_.size()) ? BGZF_STORED : BGZF_DEFLATED;
+		else if (pending_.size() >= 2 && pending_[0] == 31 && pending_[1] == 139) mode_ = GZIP;
+		else mode_ = RAW;
+	}
+	~BamFeed() { if (gzip_open_) inflateEnd(&gzip_); if (fd_ > 0) close(fd_); }
+
+	// the BAM header (magic, text, reference names), from the start of the uncompressed stream; returns its size
+	uint64_t read_header(std::vector<std::string>& target_names) {
+		std::vector<uint8_t> head;
+		size_t consumed_raw = 0; // BGZF: bytes of pending_ already inflated into head
+		while (true) {
+			if (mode_ == RAW) head = pending_;
+			else if (mode_ == GZIP) { head.clear(); inflate_prefix(head); }
+			else {
+				while (true) {
+					const size_t block = BgzfSource::block_size(pending_.data() + consumed_raw, pending_.size() - consumed_raw);
+					if (block == 0 || pending_.size() - consumed_raw < block) break;
+					const size_t out = le32(&pending_[consumed_raw + block - 4]), at = head.size();
+					head.resize(at + out);
+					if (!BgzfSource::inflate_block(&pending_[consumed_raw], block, out > 0 ? &head[at] : NULL, out)) throw std::runtime_error("failed to read SAM header");
+					consumed_raw += block;
+				}
+			}
+			uint64_t size = 0;
+			if (parse_header(head, target_names, size)) return size;
+			// the header is longer than what is there: read more
+			const size_t before = pending_.size();
+			pending_.resize(before + (4u << 20));
+			const size_t got = file_.read(&pending_[before], pending_.size() - before);
+			pending_.resize(before + got);
+			if (got == 0) throw std::runtime_error("failed to read SAM header");
+		}
+	}
+	uint64_t stream_size_hint() const { return (mode_ == RAW || mode_ == BGZF_STORED) ? file_size_ + (1u << 20) : 0; }
+
+	// the next piece; false at the end of the file.  kind 1: `buffer` holds raw BGZF bytes whose blocks are all stored, `blocks` their table
+	bool next(uint8_t* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece& piece) {
+		memset(&piece, 0, sizeof(piece));
+		if (capacity < (1u << 20)) throw std::runtime_error("piece buffer too small");
+		if (mode_ == RAW) {
+			size_t n = take_pending(buffer, capacity);
+			if (n < capacity && !end_) { const size_t got = file_.read(buffer + n, capacity - n); if (got == 0) end_ = true; n += got; }
+			piece.bytes = n; piece.stream_bytes = n;
+			return n > 0;
+		}
+		if (mode_ == GZIP) {
+			const size_t n = inflate_stream(buffer, capacity);
+			piece.bytes = n; piece.stream_bytes = n;
+			return n > 0;
+		}
+		if (mode_ == BGZF_STORED) {
+			size_t n = take_pending(buffer, capacity);
+			if (n < capacity && !end_) { const size_t got = file_.read(buffer + n, capacity - n); if (got == 0) end_ = true; n += got; }
+			if (n == 0) return false;
+			size_t at = 0, out = 0; uint32_t count = 0;
+			bool deflated_ahead = false;
+			while (n - at >= 18) {
+				const size_t size = BgzfSource::block_size(buffer + at, n - at);
+				if (size == 0 || size < 26) throw std::runtime_error("failed to load alignments");
+				if (n - at < size) break;
+				if (!block_is_stored(buffer + at, size)) { deflated_ahead = true; break; }
+				if (count == block_capacity) break;
+				const size_t data_offset = 12 + (buffer[at + 10] | (size_t) buffer[at + 11] << 8), payload = le32(buffer + at + size - 4);
+				if (payload > 0) { agpu_bgzf_block& b = blocks[count++]; b.raw_offset = at; b.payload_offset = (uint32_t) (data_offset + 5); b.payload_size = (uint32_t) payload; b.stream_offset = out; b.crc32 = le32(buffer + at + size - 8); b.reserved = 0; }
+				at += size; out += payload;
+			}
+			if (at == 0 && !deflated_ahead && end_) throw std::runtime_error("failed to load alignments"); // a truncated block at the end of the file
+			pending_.assign(buffer + at, buffer + n); // an incomplete block (or everything from the first deflated block on) waits for the next call
+			if (deflated_ahead) mode_ = BGZF_DEFLATED;
+			piece.stored_bgzf = 1; piece.bytes = at; piece.stream_bytes = out; piece.n_blocks = count;
+			return at > 0 || deflated_ahead || !pending_.empty();
+		}
+		// BGZF_DEFLATED: raw bytes into an internal buffer, the blocks inflated by all threads into the caller's buffer
+		raw_.resize(std::max<size_t>(capacity / 3, 4u << 20));
+		size_t n = take_pending(raw_.data(), raw_.size());
+		if (n < raw_.size() && !end_) { const size_t got = file_.read(&raw_[n], raw_.size() - n); if (got == 0) end_ = true; n += got; }
+		if (n == 0) return false;
+		struct Block { size_t raw_offset, raw_size, out_offset, out_size; };
+		std::vector<Block> list;
+		size_t at = 0, out = 0;
+		while (n - at >= 18) {
+			const size_t size = BgzfSource::block_size(&raw_[at], n - at);
+			if (size == 0 || size < 26) throw std::runtime_error("failed to load alignments");
+			if (n - at < size) break;
+			const size_t out_size = le32(&raw_[at + size - 4]);
+			if (out + out_size > capacity) break;
+			Block block = { at, size, out, out_size };
+			list.push_back(block);
+			at += size; out += out_size;
+		}
+		if (list.empty() && end_) throw std::runtime_error("failed to load alignments");
+		std::vector<uint8_t> failed(1, 0);
+		const std::vector<uint8_t>& raw = raw_;
+		parallel_ranges(list.size(), n_threads_, [&list, &raw, buffer, &failed](size_t first, size_t last) {
+			for (size_t b = first; b < last; ++b)
+				if (!BgzfSource::inflate_block(&raw[list[b].raw_offset], list[b].raw_size, list[b].out_size > 0 ? buffer + list[b].out_offset : NULL, list[b].out_size)) failed[0] = 1;
+		}, 8);
+		if (failed[0]) throw std::runtime_error("failed to load alignments");
+		pending_.assign(raw_.begin() + at, raw_.begin() + n);
+		piece.bytes = out; piece.stream_bytes = out;
+		return !list.empty() || !pending_.empty();
+	}
+private:
+	static bool block_is_stored(const uint8_t* block, size_t available) { // one stored deflate block that fills the member
+		const size_t size = BgzfSource::block_size(block, available);
+		if (size == 0 || available < size) return false;
+		const size_t data_offset = 12 + (block[10] | (size_t) block[11] << 8);
+		if (size < data_offset + 5 + 8) return false;
+		const size_t payload = le32(block + size - 4), length = block[data_offset + 1] | (size_t) block[data_offset + 2] << 8, inverse = block[data_offset + 3] | (size_t) block[data_offset + 4] << 8;
+		return block[data_offset] == 1 && length == payload && (length ^ inverse) == 0xFFFF && data_offset + 5 + payload + 8 == size;
+	}
+	static bool parse_header(const std::vector<uint8_t>& head, std::vector<std::string>& target_names, uint64_t& size) {
+		target_names.clear();
+		if (head.size() < 12) return false;
+		if (memcmp(head.data(), "BAM\1", 4) != 0) throw std::runtime_error("failed to read SAM header");
+		uint64_t at = 8 + (uint64_t) le32(&head[4]);
+		if (head.size() < at + 4) return false;
+		const uint32_t n_ref = le32(&head[at]);
+		at += 4;
+		for (uint32_t i = 0; i < n_ref; ++i) {
+			if (head.size() < at + 4) return false;
+			const uint32_t l_name = le32(&head[at]);
+			at += 4;
+			if (head.size() < at + l_name + 4) return false;
+			target_names.push_back(std::string((const char*) &head[at], l_name > 0 ? l_name - 1 : 0));
+			at += (uint64_t) l_name + 4;
+		}
+		size = at;
+		return true;
+	}
+	size_t take_pending(uint8_t* buffer, size_t capacity) {
+		const size_t n = std::min(capacity, pending_.size());
+		if (n > 0) { memcpy(buffer, pending_.data(), n); pending_.erase(pending_.begin(), pending_.begin() + n); }
+		return n;
+	}
+	// plain gzip: the header is parsed from a throw-away inflate of the bytes read so far, the stream is inflated again from the start when it is delivered
+	void inflate_prefix(std::vector<uint8_t>& head) {
+		z_stream stream; memset(&stream, 0, sizeof(stream));
+		if (inflateInit2(&stream, 15 + 16) != Z_OK) throw std::runtime_error("failed to read SAM header");
+		head.resize(std::max<size_t>(pending_.size() * 8, 1u << 20));
+		stream.next_in = pending_.data(); stream.avail_in = (unsigned int) pending_.size(); stream.next_out = head.data(); stream.avail_out = (unsigned int) head.size();
+		const int status = inflate(&stream, Z_SYNC_FLUSH);
+		head.resize(stream.total_out);
+		inflateEnd(&stream);
+		if (status != Z_OK && status != Z_STREAM_END && status != Z_BUF_ERROR) throw std::runtime_error("failed to read SAM header");
+	}
+	size_t inflate_stream(uint8_t* buffer, size_t capacity) {
+		size_t produced = 0;
+		while (produced < capacity) {
+			if (pending_.empty()) {
+				if (end_) break;
+				pending_.resize(4u << 20);
+				const size_t got = file_.read(&pending_[0], pending_.size());
+				pending_.resize(got);
+				if (got == 0) { end_ = true; if (gzip_open_) throw std::runtime_error("failed to load alignments"); break; }
+			}
+			if (!gzip_open_) { memset(&gzip_, 0, sizeof(gzip_)); if (inflateInit2(&gzip_, 15 + 16) != Z_OK) throw std::runtime_error("failed to load alignments"); gzip_open_ = true; }
+			gzip_.next_in = pending_.data(); gzip_.avail_in = (unsigned int) pending_.size();
+			gzip_.next_out = buffer + produced; gzip_.avail_out = (unsigned int) std::min<size_t>(capacity - produced, 1u << 30);
+			const size_t room = gzip_.avail_out;
+			const int status = inflate(&gzip_, Z_NO_FLUSH);
+			if (status != Z_OK && status != Z_STREAM_END && status != Z_BUF_ERROR) throw std::runtime_error("failed to load alignments");
+			produced += room - gzip_.avail_out;
+			pending_.erase(pending_.begin(), pending_.end() - gzip_.avail_in);
+			if (status == Z_STREAM_END) { inflateEnd(&gzip_); gzip_open_ = false; }
+		}
+		return produced;
+	}
+	int fd_;
+	FileBytes file_;
+	uint64_t file_size_;
+	unsigned int n_threads_;
+	Mode mode_;
+	std::vector<uint8_t> pending_, raw_;
+	z_stream gzip_;
+	bool gzip_open_, end_;
+};
+
+BamFeed* open_bam_feed(const std::string& path) { return new BamFeed(path); }
+void close_bam_feed(BamFeed* feed) { delete feed; }
+uint64_t bam_feed_header(BamFeed* feed, std::vector<std::string>& target_names) { return feed->read_header(target_names); }
+uint64_t bam_feed_size_hint(BamFeed* feed) { return feed->stream_size_hint(); }
+bool bam_feed_next(BamFeed* feed, uint8_t* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece& piece) { return feed->next(buffer, capacity, blocks, block_capacity, piece); }
 
 }

@@ -26,9 +26,11 @@ struct Run {
 	ahost_session* host;
 	agpu_ctx* device;
 	uint32_t dummy_genes;
-	uint64_t n_candidates;
-	Run(const arriba_workflow_options& o, arriba_workflow_report* r): options(o), report(r), host(nullptr), device(nullptr), dummy_genes(0), n_candidates(0) {}
-	~Run() { if (device) agpu_destroy(device); if (host) ahost_close(host); }
+	uint64_t n_candidates, n_fragments, mapped_reads;
+	bool device_ingest;
+	void* pieces[2];
+	Run(const arriba_workflow_options& o, arriba_workflow_report* r): options(o), report(r), host(nullptr), device(nullptr), dummy_genes(0), n_candidates(0), n_fragments(0), mapped_reads(0), device_ingest(false) { pieces[0] = pieces[1] = nullptr; }
+	~Run() { for (int k = 0; k < 2; ++k) if (pieces[k]) agpu_host_free(pieces[k]); if (device) agpu_destroy(device); if (host) ahost_close(host); }
 	void note(const char* stage, uint64_t count) {
 		if (!report || report->n_stages >= sizeof(report->stages) / sizeof(report->stages[0])) return;
 		arriba_workflow_stage& entry = report->stages[report->n_stages++];
@@ -37,6 +39,68 @@ struct Run {
 	}
 	bool enabled(unsigned filter) const { return options.device.filter_enabled[filter] != 0; }
 };
+
+// read_chimeric_alignments on the device (source/read_chimeric_alignments.cpp:560-773): the host opens the file, parses the BAM header and feeds the bytes in
+// pieces through two pinned buffers in turn; the batch and coverage_t are built in HBM, the host takes over the counters and coverage_t
+void read_chimeric_alignments_on_device(Run& run) {
+	const arriba_workflow_options& o = run.options;
+	agpu_ingest_config config;
+	host_check(ahost_bam_open(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length, &config));
+	device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host))); // with the contigs of the BAM header
+	device_check(agpu_ingest_begin(run.device, &config));
+	const size_t piece_bytes = 256u << 20;
+	const uint32_t block_capacity = (uint32_t) (piece_bytes / 4096 + 16);
+	std::vector<agpu_bgzf_block> tables[2] = { std::vector<agpu_bgzf_block>(block_capacity), std::vector<agpu_bgzf_block>(block_capacity) };
+	for (int k = 0; k < 2; ++k) { run.pieces[k] = agpu_host_alloc(piece_bytes); if (!run.pieces[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
+	for (unsigned int push = 0; ; ++push) {
+		ahost_bam_piece piece;
+		const int status = ahost_bam_next(run.host, run.pieces[push & 1], piece_bytes, tables[push & 1].data(), block_capacity, &piece);
+		if (status < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+		if (status == 0) break;
+		if (piece.stored_bgzf) device_check(agpu_ingest_push_bgzf(run.device, run.pieces[push & 1], piece.bytes, tables[push & 1].data(), piece.n_blocks, piece.stream_bytes));
+		else device_check(agpu_ingest_push(run.device, run.pieces[push & 1], piece.bytes));
+	}
+	agpu_ingest_result result;
+	device_check(agpu_ingest_finish(run.device, &result));
+	ahost_bam_close(run.host);
+	for (int k = 0; k < 2; ++k) { agpu_host_free(run.pieces[k]); run.pieces[k] = nullptr; }
+	const uint64_t windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0;
+	std::vector<uint64_t> viral(config.n_contigs > 0 ? config.n_contigs : 1);
+	std::vector<uint16_t> coverage(windows > 0 ? windows : 1);
+	std::vector<uint8_t> starts(coverage.size()), ends(coverage.size());
+	device_check(agpu_get_viral_read_counts(run.device, viral.data()));
+	device_check(agpu_get_coverage(run.device, coverage.data(), starts.data(), ends.data()));
+	host_check(ahost_adopt_device_ingest(run.host, &result, viral.data(), coverage.data(), starts.data(), ends.data()));
+	run.n_fragments = result.fragments;
+}
+
+// the writer prints names, CIGAR-derived pileups and sequences of the supporting reads of the candidates it writes: their rows come back from the device
+void fetch_rows_for_writer(Run& run, const ahost_fusion_table& table, int write_discarded) {
+	if (!run.device_ingest) return;
+	uint64_t count = 0;
+	host_check(ahost_fusion_table_reads(&table, write_discarded, nullptr, 0, &count));
+	std::vector<uint32_t> fragments(count > 0 ? count : 1);
+	host_check(ahost_fusion_table_reads(&table, write_discarded, fragments.data(), count, &count));
+	uint64_t cigar_words = 0, sequence_bytes = 0, name_bytes = 0;
+	device_check(agpu_gather_rows_begin(run.device, fragments.data(), count, &cigar_words, &sequence_bytes, &name_bytes));
+	const size_t n1 = count > 0 ? count : 1;
+	std::vector<uint8_t> n_aln(n1), fbits(n1), abits[3], seq_pool(sequence_bytes + 4);
+	std::vector<uint32_t> group(n1), cigar_offset[3], cigar_pool(cigar_words + 1), seq_offset[2], seq_length[2], name_offset(count + 1);
+	std::vector<uint16_t> contig[3], cigar_count[3];
+	std::vector<int32_t> start[3], end[3];
+	std::vector<char> names(name_bytes + 1);
+	agpu_batch_rows rows;
+	memset(&rows, 0, sizeof(rows));
+	rows.n_aln = n_aln.data(); rows.fbits = fbits.data(); rows.group = group.data();
+	for (int k = 0; k < 3; ++k) {
+		contig[k].resize(n1); start[k].resize(n1); end[k].resize(n1); abits[k].resize(n1); cigar_offset[k].resize(n1); cigar_count[k].resize(n1);
+		rows.contig[k] = contig[k].data(); rows.start[k] = start[k].data(); rows.end[k] = end[k].data(); rows.abits[k] = abits[k].data(); rows.cigar_offset[k] = cigar_offset[k].data(); rows.cigar_count[k] = cigar_count[k].data();
+	}
+	for (int k = 0; k < 2; ++k) { seq_offset[k].resize(n1); seq_length[k].resize(n1); rows.seq_offset[k] = seq_offset[k].data(); rows.seq_length[k] = seq_length[k].data(); }
+	rows.cigar_pool = cigar_pool.data(); rows.seq_pool = seq_pool.data(); rows.name_offset = name_offset.data(); rows.names = names.data();
+	device_check(agpu_gather_rows_copy(run.device, &rows));
+	host_check(ahost_set_batch_rows(run.host, &rows, count > 0 ? fragments.data() : nullptr));
+}
 
 // the output files: the device's results brought back once, formatted by the host library (source/arriba.cpp:586-610)
 void write_output_files(Run& run, int32_t max_mate_gap) {
@@ -55,8 +119,7 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 	device_check(agpu_assign_confidence(run.device, confidence.data())); // behind the 'isoforms' filter: recovered isoforms are scored anew
 	device_check(agpu_candidate_iteration_order(run.device, iteration_rank.data()));
 	device_check(agpu_get_genomic_support(run.device, closest1.data(), closest2.data()));
-	const agpu_batch_view* batch = ahost_batch_view(run.host);
-	std::vector<uint8_t> read_filter(batch->n > 0 ? batch->n : 1);
+	std::vector<uint8_t> read_filter(run.n_fragments > 0 ? run.n_fragments : 1);
 	device_check(agpu_get_filters(run.device, read_filter.data()));
 	const uint32_t n_genes = ahost_annotation_view(run.host)->n_genes + run.dummy_genes;
 	std::vector<uint16_t> gene_contig(n_genes > 0 ? n_genes : 1);
@@ -73,9 +136,12 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 	table.n_genes = n_genes; table.gene_contig = gene_contig.data(); table.gene_start = gene_start.data(); table.gene_end = gene_end.data();
 	if (run.options.tags_file) host_check(ahost_load_tags(run.host, run.options.tags_file));
 	if (run.options.protein_domains_file) host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file));
+	fetch_rows_for_writer(run, table, 0);
 	host_check(ahost_write_fusions(run.host, &table, run.options.output_file, 0, 1, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
-	if (run.options.discarded_output_file)
+	if (run.options.discarded_output_file) {
+		if (run.options.print_extra_info_for_discarded_fusions) fetch_rows_for_writer(run, table, 1);
 		host_check(ahost_write_fusions(run.host, &table, run.options.discarded_output_file, 1, run.options.print_extra_info_for_discarded_fusions, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
+	}
 }
 
 void run_workflow(Run& run) {
@@ -84,19 +150,27 @@ void run_workflow(Run& run) {
 	// source/arriba.cpp:97-130: assembly, annotation, index, chimeric alignments
 	run.host = ahost_open(o.assembly_file, o.gene_annotation_file, o.interesting_contigs, o.viral_contigs, o.gtf_features);
 	if (!run.host) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
-	host_check(ahost_ingest_bam_file(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length));
 	agpu_params params = o.device;
 	if (params.strandedness > 2) params.strandedness = 0; // resolved below
 	run.device = agpu_create(o.device_index, &params);
 	if (!run.device) throw Failure{ std::string("ERROR: ") + agpu_last_error() };
 	device_check(agpu_upload_annotation(run.device, ahost_annotation_view(run.host)));
-	device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host)));
-	device_check(agpu_upload_batch(run.device, ahost_batch_view(run.host)));
+	run.device_ingest = !o.host_ingest;
+	if (run.device_ingest) read_chimeric_alignments_on_device(run);
+	else {
+		host_check(ahost_ingest_bam_file(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length));
+		device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host)));
+		device_check(agpu_upload_batch(run.device, ahost_batch_view(run.host)));
+		run.n_fragments = ahost_batch_view(run.host)->n;
+	}
+	run.mapped_reads = ahost_mapped_reads(run.host);
 
 	// :141-325 multi-mappers, strandedness, annotation
 	uint64_t count = 0;
 	device_check(agpu_mark_multimappers(run.device, &count)); run.note("mark_multimappers", count);
-	params.strandedness = o.device.strandedness > 2 ? (uint8_t) ahost_detect_strandedness(run.host) : o.device.strandedness;
+	if (o.device.strandedness <= 2) params.strandedness = o.device.strandedness;
+	else if (run.device_ingest) { int verdict = 0; device_check(agpu_detect_strandedness(run.device, &verdict)); params.strandedness = (uint8_t) verdict; }
+	else params.strandedness = (uint8_t) ahost_detect_strandedness(run.host);
 	device_check(agpu_set_params(run.device, &params));
 	device_check(agpu_annotate(run.device, &run.dummy_genes));
 	// :327-350 duplicates, uninteresting and viral contigs (the per-contig verdicts are sequential host work)
@@ -114,7 +188,13 @@ void run_workflow(Run& run) {
 	uint32_t n_samples = 0; uint64_t visited = 0;
 	device_check(agpu_fragment_length_samples(run.device, mate_gaps.data(), &n_samples, &visited));
 	float mate_gap_mean = 0, mate_gap_stddev = 0, read_length_mean = 0; int32_t max_mate_gap = 0;
-	if (ahost_estimate_fragment_length(run.host, mate_gaps.data(), n_samples, visited, params.fragment_length, &mate_gap_mean, &mate_gap_stddev, &read_length_mean, &max_mate_gap) < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+	if (run.device_ingest) { // the sequential float sum of the read lengths (hazard H4) stays on the host, over the lengths of the fragments the reference's loop visits
+		const uint64_t count = visited < run.n_fragments ? visited : run.n_fragments;
+		std::vector<uint32_t> length1(count > 0 ? count : 1), length2(length1.size());
+		device_check(agpu_get_read_lengths(run.device, 0, count, length1.data(), length2.data()));
+		if (ahost_estimate_fragment_length_from_sums(mate_gaps.data(), n_samples, ahost_read_length_sum_of(0, length1.data(), length2.data(), count), count, params.fragment_length, &mate_gap_mean, &mate_gap_stddev, &read_length_mean, &max_mate_gap) < 0)
+			throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+	} else if (ahost_estimate_fragment_length(run.host, mate_gaps.data(), n_samples, visited, params.fragment_length, &mate_gap_mean, &mate_gap_stddev, &read_length_mean, &max_mate_gap) < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
 	// :366-409 the read-level filters
 	std::vector<uint64_t> remaining(AGPU_FILTER_COUNT);
 	device_check(agpu_read_filters_stage2(run.device, remaining.data()));
@@ -126,7 +206,7 @@ void run_workflow(Run& run) {
 	// :411-460 candidates
 	device_check(agpu_find_fusions(run.device, max_mate_gap, &count)); run.note("find_fusions", count);
 	run.n_candidates = count;
-	device_check(agpu_upload_coverage(run.device, ahost_coverage_view(run.host)));
+	if (!run.device_ingest) device_check(agpu_upload_coverage(run.device, ahost_coverage_view(run.host))); // (the device ingest built coverage_t in place)
 	if (o.genomic_breakpoints_file) {
 		const agpu_genomic_breakpoint* variants = nullptr; uint32_t n_variants = 0;
 		host_check(ahost_load_genomic_breakpoints(run.host, o.genomic_breakpoints_file, &variants, &n_variants));
@@ -136,7 +216,7 @@ void run_workflow(Run& run) {
 	uint64_t discarded_reads = 0, discarded[3];
 	device_check(agpu_filter_multimappers(run.device, &count, &discarded_reads)); run.note("filter_multimappers", count);
 	device_check(agpu_candidate_iteration_order(run.device, nullptr)); // hazard H2: the order in which the reference's container is walked, kept on the device
-	device_check(agpu_estimate_expected_fusions(run.device, ahost_mapped_reads(run.host), nullptr));
+	device_check(agpu_estimate_expected_fusions(run.device, run.mapped_reads, nullptr));
 	device_check(agpu_filter_candidate_predicates(run.device, discarded));
 	device_check(agpu_filter_relative_support(run.device, &count)); run.note("filter_relative_support", count);
 	// :463-544 the candidate-level filters (each stage skips itself when its filter is switched off with -f)

@@ -132,7 +132,9 @@ class DevicePipeline(object):
     stepping harness of tests/emu instead.
     """
 
-    def __init__(self, session, params=None, api=None, device=0, batch_view=None):
+    def __init__(self, session, params=None, api=None, device=0, batch_view=None, bam=None, external_duplicate_marking=False, max_itd_length=100, piece_bytes=64 << 20):
+        """bam: path of the BAM file -> read_chimeric_alignments runs on the device (agpu_ingest_*): the host session only opens the file, parses the
+        header and feeds the bytes; the batch never exists on the host.  Without it the batch of the session's host ingest is uploaded."""
         self.session = session
         self.api = api if api is not None else _capi.bind_device_api(_capi.device_library(), "agpu_")
         self.params = _capi.Params()
@@ -152,9 +154,14 @@ class DevicePipeline(object):
         import time
         self._last_record = time.perf_counter()
         self._check(self.api.upload_annotation(self.ctx, session.annotation_view))
-        self._check(self.api.upload_genome(self.ctx, session.genome_view))
-        self._check(self.api.upload_batch(self.ctx, batch_view if batch_view is not None else session.batch_view))
-        self.n = int(batch_view.contents.n) if batch_view is not None else session.fragment_count
+        self.device_ingest = bam is not None
+        self.ingest_result = None
+        if self.device_ingest:
+            self.read_chimeric_alignments(bam, external_duplicate_marking, max_itd_length, piece_bytes)
+        else:
+            self._check(self.api.upload_genome(self.ctx, session.genome_view))
+            self._check(self.api.upload_batch(self.ctx, batch_view if batch_view is not None else session.batch_view))
+            self.n = int(batch_view.contents.n) if batch_view is not None else session.fragment_count
         self.n_real_genes = session.annotation_view.contents.n_genes
         self.n_dummy_genes = 0
         self.scalars = {}
@@ -163,6 +170,92 @@ class DevicePipeline(object):
         if self.ctx:
             self.api.destroy(self.ctx)
             self.ctx = None
+
+    def read_chimeric_alignments(self, bam, external_duplicate_marking=False, max_itd_length=100, piece_bytes=64 << 20):
+        """reference: read_chimeric_alignments, source/read_chimeric_alignments.cpp:560-773, on the device: the host opens the file, parses the BAM header
+        and feeds the bytes in pieces (two pinned buffers in turn); records are cut, collated by name, classified, sanity-checked, sorted and packed in HBM"""
+        import time
+        lib, handle = self.session._lib, self.session._session
+        host_error = lambda: ArribaError("ERROR: " + lib.ahost_last_error().decode())
+        started = time.perf_counter()
+        config = _capi.IngestConfig()
+        if lib.ahost_bam_open(handle, bam.encode(), int(external_duplicate_marking), max_itd_length, byref(config)) != 0:
+            raise host_error()
+        buffers = []
+        try:
+            self._check(self.api.upload_genome(self.ctx, self.session.genome_view))  # the contigs of the BAM header are part of the run now
+            self._check(self.api.ingest_begin(self.ctx, byref(config)))
+            block_capacity = piece_bytes // 4096 + 16
+            for _ in range(2):
+                pointer = self.api.host_alloc(piece_bytes)
+                if not pointer:
+                    raise ArribaError("ERROR: " + self.api.last_error().decode())
+                buffers.append(pointer)
+            tables = [(_capi.BgzfBlock * block_capacity)(), (_capi.BgzfBlock * block_capacity)()]
+            piece = _capi.BamPiece()
+            pushes = 0
+            while True:
+                status = lib.ahost_bam_next(handle, buffers[pushes & 1], piece_bytes, tables[pushes & 1], block_capacity, byref(piece))
+                if status < 0:
+                    raise host_error()
+                if status == 0:
+                    break
+                if piece.stored_bgzf:
+                    self._check(self.api.ingest_push_bgzf(self.ctx, buffers[pushes & 1], piece.bytes, tables[pushes & 1], piece.n_blocks, piece.stream_bytes))
+                else:
+                    self._check(self.api.ingest_push(self.ctx, buffers[pushes & 1], piece.bytes))
+                pushes += 1
+            fed = time.perf_counter()
+            result = _capi.IngestResult()
+            self._check(self.api.ingest_finish(self.ctx, byref(result)))
+        finally:
+            lib.ahost_bam_close(handle)
+            for pointer in buffers:
+                self.api.host_free(pointer)
+        finished = time.perf_counter()
+        self._record("read_chimeric_alignments")
+        n_contigs = config.n_contigs
+        viral = np.zeros(max(n_contigs, 1), dtype=np.uint64)
+        self._check(self.api.get_viral_read_counts(self.ctx, viral.ctypes.data))
+        # (config.coverage_window_offset points into the session: read it before anything else touches the session)
+        windows = int(config.coverage_window_offset[n_contigs]) if n_contigs else 0
+        coverage, starts, ends = np.zeros(max(windows, 1), dtype=np.uint16), np.zeros(max(windows, 1), dtype=np.uint8), np.zeros(max(windows, 1), dtype=np.uint8)
+        self._check(self.api.get_coverage(self.ctx, coverage.ctypes.data, starts.ctypes.data, ends.ctypes.data))
+        if lib.ahost_adopt_device_ingest(handle, byref(result), viral.ctypes.data, coverage.ctypes.data, starts.ctypes.data, ends.ctypes.data) != 0:
+            raise host_error()
+        self.ingest_result = result
+        self.ingest_seconds = {"feed": fed - started, "device": finished - fed, "adopt": time.perf_counter() - finished}
+        self.n = int(result.fragments)
+        self.device_ingest = True
+        return self.n
+
+    def batch_rows(self, fragments=None):
+        """rows of the batch on the device as numpy arrays (fragments=None: all) -- what agpu_gather_rows_* hands to the host's writer; also the test's view of a batch built on the device"""
+        if fragments is not None:
+            fragments = np.ascontiguousarray(fragments, dtype=np.uint32)
+        sizes = [c_uint64(), c_uint64(), c_uint64()]
+        n = self.n if fragments is None else fragments.size
+        self._check(self.api.gather_rows_begin(self.ctx, None if fragments is None else fragments.ctypes.data, n, byref(sizes[0]), byref(sizes[1]), byref(sizes[2])))
+        rows = _capi.BatchRows()
+        arrays = {"n_aln": np.zeros(max(n, 1), np.uint8), "fbits": np.zeros(max(n, 1), np.uint8), "group": np.zeros(max(n, 1), np.uint32),
+                  "cigar_pool": np.zeros(max(sizes[0].value, 1), np.uint32), "seq_pool": np.zeros(max(sizes[1].value, 4), np.uint8), "name_offset": np.zeros(n + 1, np.uint32), "names": np.zeros(max(sizes[2].value, 1), np.uint8)}
+        for slot in range(3):
+            for name, dtype in (("contig", np.uint16), ("start", np.int32), ("end", np.int32), ("abits", np.uint8), ("cigar_offset", np.uint32), ("cigar_count", np.uint16)):
+                arrays["%s%d" % (name, slot)] = np.zeros(max(n, 1), dtype)
+                getattr(rows, name)[slot] = arrays["%s%d" % (name, slot)].ctypes.data
+        for slot in range(2):
+            for name in ("seq_offset", "seq_length"):
+                arrays["%s%d" % (name, slot)] = np.zeros(max(n, 1), np.uint32)
+                getattr(rows, name)[slot] = arrays["%s%d" % (name, slot)].ctypes.data
+        for name in ("n_aln", "fbits", "group", "cigar_pool", "seq_pool", "name_offset", "names"):
+            setattr(rows, name, arrays[name].ctypes.data)
+        self._check(self.api.gather_rows_copy(self.ctx, byref(rows)))
+        arrays["n"] = n
+        arrays["cigar_pool"] = arrays["cigar_pool"][:rows.cigar_pool_size]; arrays["seq_pool"] = arrays["seq_pool"][:rows.seq_pool_size]; arrays["names"] = arrays["names"][:rows.names_size]
+        for key in list(arrays):
+            if key not in ("n", "cigar_pool", "seq_pool", "names", "name_offset"):
+                arrays[key] = arrays[key][:n]
+        return arrays, rows
 
     def __del__(self):
         try:
@@ -198,9 +291,17 @@ class DevicePipeline(object):
         self._record("mark_multimappers")
         return marked.value
 
+    def detect_strandedness(self):
+        """reference: detect_strandedness, source/read_stats.cpp:94-143 -- on the host's batch, or on the device when the batch was built there"""
+        if not self.device_ingest:
+            return self.session.detect_strandedness()
+        verdict = ctypes.c_int()
+        self._check(self.api.detect_strandedness(self.ctx, byref(verdict)))
+        return verdict.value
+
     def annotate_alignments(self, strandedness=None):
         if strandedness is None:
-            strandedness = self.session.detect_strandedness()
+            strandedness = self.detect_strandedness()
         self.scalars["strandedness"] = strandedness
         self.params.strandedness = strandedness
         self._check(self.api.set_params(self.ctx, byref(self.params)))
@@ -225,7 +326,19 @@ class DevicePipeline(object):
         n_samples, visited = c_uint32(), c_uint64()
         self._check(self.api.fragment_length_samples(self.ctx, gaps.ctypes.data, byref(n_samples), byref(visited)))
         self._record("fragment_length_samples")
-        estimate = self.session.estimate_fragment_length(gaps[:n_samples.value], visited.value, self.params.fragment_length)
+        if self.device_ingest:
+            # the reference's sequential float sum of the read lengths (hazard H4) runs on the host over the lengths of the fragments its loop visited
+            count = min(visited.value, self.n)
+            lengths = [np.zeros(max(count, 1), dtype=np.uint32), np.zeros(max(count, 1), dtype=np.uint32)]
+            self._check(self.api.get_read_lengths(self.ctx, 0, count, lengths[0].ctypes.data, lengths[1].ctypes.data))
+            lib = self.session._lib
+            total = lib.ahost_read_length_sum_of(c_float(0), lengths[0].ctypes.data, lengths[1].ctypes.data, count)
+            samples = np.ascontiguousarray(gaps[:n_samples.value], dtype=np.int32)
+            mean, stddev, read_length, max_mate_gap = c_float(), c_float(), c_float(), c_int32()
+            estimated = lib.ahost_estimate_fragment_length_from_sums(samples.ctypes.data, samples.size, c_float(total), count, self.params.fragment_length, byref(mean), byref(stddev), byref(read_length), byref(max_mate_gap))
+            estimate = {"estimated": bool(estimated), "mate_gap_mean": mean.value, "mate_gap_stddev": stddev.value, "read_length_mean": read_length.value, "max_mate_gap": max_mate_gap.value}
+        else:
+            estimate = self.session.estimate_fragment_length(gaps[:n_samples.value], visited.value, self.params.fragment_length)
         self.scalars.update(estimate)
         self.scalars["mate_gap_samples"] = n_samples.value
         return estimate
@@ -340,6 +453,8 @@ class DevicePipeline(object):
 
     # event-level predicates behind filter_relative_support (each returns the reference's "(remaining=N)")
     def upload_coverage(self):
+        if self.device_ingest:
+            return  # coverage_t was built on the device
         view = self.session._lib.ahost_coverage_view(self.session._session)
         if not view:
             raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
@@ -421,6 +536,19 @@ class DevicePipeline(object):
             setattr(view, key, column.ctypes.data if column.size else None)
         if print_extra_info is None:
             print_extra_info = not discarded
+        if self.device_ingest and print_extra_info:
+            # the host's writer works on the rows of the supporting reads of the candidates it writes: fetched from the device now
+            lib = self.session._lib
+            count = c_uint64()
+            if lib.ahost_fusion_table_reads(byref(view), int(discarded), None, 0, byref(count)) != 0:
+                raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
+            fragments = np.zeros(max(count.value, 1), dtype=np.uint32)
+            if lib.ahost_fusion_table_reads(byref(view), int(discarded), fragments.ctypes.data, count.value, byref(count)) != 0:
+                raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
+            fragments = fragments[:count.value]
+            arrays, rows = self.batch_rows(fragments)
+            if lib.ahost_set_batch_rows(self.session._session, byref(rows), fragments.ctypes.data if fragments.size else None) != 0:
+                raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
         if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps)) != 0:
             raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
 

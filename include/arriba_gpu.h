@@ -176,6 +176,69 @@ int agpu_upload_annotation(agpu_ctx* ctx, const agpu_annotation_view* annotation
 int agpu_upload_genome(agpu_ctx* ctx, const agpu_genome_view* genome);               /* assembly_t: source/arriba.cpp:97-98 */
 int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* batch);                  /* chimeric_alignments_t: source/arriba.cpp:119-130 */
 
+/* ---- read_chimeric_alignments on the device (source/read_chimeric_alignments.cpp:560-773) --------------------------------
+ * Instead of agpu_upload_batch: the uncompressed BAM stream goes to HBM as it comes out of the container, the records are cut, classified, collated
+ * by read name, sanity-checked (remove_malformed_alignments, :377-506), sorted by name (the order of the reference's std::map) and packed into the
+ * batch on the device; coverage_t (source/read_stats.cpp:161-266) is built there, too.  The host only feeds bytes:
+ *   agpu_ingest_begin        the BAM header as the host parsed it (reference id -> contig id), the windows of coverage_t
+ *   agpu_ingest_push         the next piece of the uncompressed stream (host memory; pinned memory from agpu_host_alloc makes the copy asynchronous)
+ *   agpu_ingest_push_bgzf    the next piece of a BGZF file whose blocks are stored (STAR --outBAMcompression 0, run_arriba.sh:34): the raw bytes and
+ *                            the table of the blocks inside them; the payloads are moved into the stream on the device
+ *   agpu_ingest_finish       everything else; the batch is then resident as after agpu_upload_batch
+ * A push returns when the piece pushed BEFORE it has left its buffer: the caller alternates between two buffers.
+ * Needs agpu_upload_annotation and agpu_upload_genome (gene index for the read-through extraction, assembly for the tandem-duplication probe). */
+typedef struct {
+	uint32_t n_targets;              /* reference sequences of the BAM header */
+	const uint32_t* tid_to_contig;   /* [n_targets] contig id of every reference id (contigs_t of the run) */
+	uint64_t first_record_offset;    /* size of the BAM header in the uncompressed stream */
+	uint64_t stream_size_hint;       /* expected size of the uncompressed stream, 0 = unknown (the buffer grows) */
+	uint32_t n_contigs;
+	const uint64_t* coverage_window_offset; /* [n_contigs + 1] windows of coverage_t per contig (assembly size / 20 + 2; none without sequence) */
+	uint8_t external_duplicate_marking;     /* -u */
+	uint32_t max_itd_length;                /* -l */
+} agpu_ingest_config;
+typedef struct { uint64_t raw_offset; uint32_t payload_offset, payload_size; uint64_t stream_offset; uint32_t crc32; uint32_t reserved; } agpu_bgzf_block; /* offsets inside the pushed piece / the piece's part of the stream */
+typedef struct {
+	uint64_t records;                /* alignment records in the stream */
+	uint64_t fragments;              /* chimeric fragments in the batch (chimeric_alignments.size()) */
+	uint64_t mapped_reads;           /* source/read_chimeric_alignments.cpp:653-654 */
+	uint64_t malformed_count;        /* "WARNING: N SAM records were malformed and ignored" (:761-763) */
+	uint64_t missing_hi_tag;         /* (:622-625) */
+	uint8_t no_chimeric_reads;       /* (:767-770) */
+	uint8_t names_were_sorted;       /* 1 = the order of first occurrence was the name order (no string sort needed) */
+	uint8_t reserved[6];
+	uint64_t stream_bytes;
+} agpu_ingest_result;
+void* agpu_host_alloc(size_t bytes);  /* pinned host memory for the pieces (NULL on failure) */
+void agpu_host_free(void* pointer);
+int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config);
+int agpu_ingest_push(agpu_ctx* ctx, const void* bytes, size_t size);
+int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const agpu_bgzf_block* blocks, uint32_t n_blocks, size_t stream_bytes);
+int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result);
+/* what the host's sequential stages and its output writer need from a batch that lives on the device:
+ *   agpu_get_viral_read_counts   mapped_viral_reads_by_contig (source/read_chimeric_alignments.cpp:735-739)
+ *   agpu_get_coverage            coverage_t as the reference holds it (16-bit saturating windows, start/end flags); sizes by coverage_window_offset
+ *   agpu_detect_strandedness     detect_strandedness (source/read_stats.cpp:94-143): 0 no, 1 yes, 2 reverse
+ *   agpu_get_read_lengths        sequence lengths of MATE1 / MATE2 of fragments [first, first + count) (the float sum of estimate_fragment_length is the host's)
+ *   agpu_gather_rows_begin/copy  the rows of the given fragments as a small batch of the same layout plus their names ("QNAME,HI"), alignment and
+ *                                fragment bits as ingested; begin returns the pool sizes, copy fills the caller's arrays */
+int agpu_get_viral_read_counts(agpu_ctx* ctx, uint64_t* counts /* [n_contigs] */);
+int agpu_get_coverage(agpu_ctx* ctx, uint16_t* coverage, uint8_t* fragment_starts, uint8_t* fragment_ends);
+int agpu_detect_strandedness(agpu_ctx* ctx, int* strandedness);
+int agpu_get_read_lengths(agpu_ctx* ctx, uint64_t first, uint64_t count, uint32_t* mate1, uint32_t* mate2);
+typedef struct {
+	uint64_t n;
+	uint8_t* n_aln; uint8_t* fbits; uint32_t* group;
+	uint16_t* contig[3]; int32_t* start[3]; int32_t* end[3]; uint8_t* abits[3]; uint32_t* cigar_offset[3]; uint16_t* cigar_count[3];
+	uint64_t cigar_pool_size; uint32_t* cigar_pool;
+	uint32_t* seq_offset[2]; uint32_t* seq_length[2];
+	uint64_t seq_pool_size; uint8_t* seq_pool;
+	uint32_t* name_offset;           /* [n + 1] */
+	uint64_t names_size; char* names;
+} agpu_batch_rows;
+int agpu_gather_rows_begin(agpu_ctx* ctx, const uint32_t* fragments /* NULL = all, in order */, uint64_t n, uint64_t* cigar_pool_size, uint64_t* seq_pool_size, uint64_t* names_size);
+int agpu_gather_rows_copy(agpu_ctx* ctx, agpu_batch_rows* rows);
+
 /* restore the batch to its state right after agpu_upload_batch (filters, strands and gene sets cleared) so that the stages can be run again */
 int agpu_reset(agpu_ctx* ctx);
 

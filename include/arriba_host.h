@@ -33,6 +33,25 @@ int ahost_ingest_bam_memory(ahost_session* session, const uint8_t* data, size_t 
 int ahost_save_ingest(ahost_session* session, const char* path);
 int ahost_load_ingest(ahost_session* session, const char* path);
 
+/* ---- read_chimeric_alignments on the device (agpu_ingest_*, include/arriba_gpu.h): the host side --------------------------------------------------
+ * The host opens the file (BGZF, gzip or raw BAM; a path, a pipe, /dev/stdin or "-": sam_open, source/read_chimeric_alignments.cpp:563), parses the BAM
+ * header -- the contigs of the run must be known before the records are classified (:566-582) -- and hands the bytes on in pieces.
+ *   ahost_bam_open     opens and parses the header; fills `config` for agpu_ingest_begin (its pointers stay valid until ahost_bam_close).  The genome
+ *                      view of the session then holds the contigs of the header, too: upload it (again) before agpu_ingest_begin.
+ *   ahost_bam_next     the next piece into `buffer` (>= 1 MiB; pinned memory from agpu_host_alloc): stored_bgzf = 1: raw BGZF bytes whose blocks are
+ *                      all stored, with the table of the blocks -> agpu_ingest_push_bgzf; 0: bytes of the uncompressed stream (deflated blocks inflated
+ *                      by all cores, CRC-checked) -> agpu_ingest_push.  Returns 1, 0 at the end of the file, -1 on error.
+ *   ahost_adopt_device_ingest   what the device found: the reference's checks and warnings behind its loop (:759-771: "no normal reads found", malformed
+ *                      records, no chimeric reads, missing HI tags), the counters, and coverage_t (flat arrays in the order of config.coverage_window_offset)
+ *   ahost_set_batch_rows   the rows of the batch the host itself works on (the output writer: names, CIGARs and sequences of the supporting reads), fetched
+ *                      with agpu_gather_rows_*; fragment indices in an ahost_fusion_table then refer to these rows */
+typedef struct { int stored_bgzf; size_t bytes; size_t stream_bytes; uint32_t n_blocks; } ahost_bam_piece;
+int ahost_bam_open(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length, agpu_ingest_config* config);
+int ahost_bam_next(ahost_session* session, void* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece* piece);
+void ahost_bam_close(ahost_session* session);
+int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* result, const uint64_t* viral_read_counts, const uint16_t* coverage, const uint8_t* fragment_starts, const uint8_t* fragment_ends);
+int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments /* [rows->n] ascending: the fragment every row holds */);
+
 /* A blacklist (allow_keywords = 1: the second column may hold a keyword, source/filter_blacklisted_ranges.cpp:91-102) or a known-fusions file
  * (allow_keywords = 0) parsed into rules for agpu_filter_blacklisted_ranges / agpu_recover_known_fusions (parse_blacklist_item, parse_range:
  * source/filter_blacklisted_ranges.cpp:17-118; plain or gzip).  Malformed lines are skipped with the reference's warning.  The rules stay
@@ -57,6 +76,12 @@ typedef struct {
 } ahost_fusion_table;
 int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap,
                         int fill_sequence_gaps /* -I: complete the fusion transcript from the assembly along the chosen transcripts */);
+/* the fragments whose rows ahost_write_fusions(table, write_discarded, print_extra_info = 1) reads: the supporting reads of the candidates it writes, ascending, unique.
+ * Call with fragments == NULL to get the number in *count.  (Without print_extra_info the writer needs no rows.) */
+int ahost_fusion_table_reads(const ahost_fusion_table* table, int write_discarded, uint32_t* fragments, uint64_t capacity, uint64_t* count);
+/* estimate_fragment_length's float sum of the read lengths (source/read_stats.cpp:30-37, hazard H4: sequential, in name order) over lengths fetched from the
+ * device (agpu_get_read_lengths); continues `running_sum` */
+float ahost_read_length_sum_of(float running_sum, const uint32_t* mate1_lengths, const uint32_t* mate2_lengths, uint64_t count);
 /* Optional inputs of the output files: a tags file (-t; load_tags, source/annotate_tags.cpp:11-44) and protein domains in GFF3 (-p; load_protein_domains,
  * source/annotate_protein_domains.cpp:33-121).  Loaded into the session; ahost_write_fusions fills the columns `tags` and `retained_protein_domains` from them. */
 int ahost_load_tags(ahost_session* session, const char* path);

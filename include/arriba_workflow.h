@@ -41,6 +41,8 @@ typedef struct {
 	uint8_t print_extra_info_for_discarded_fusions; /* -X */
 	uint8_t fill_sequence_gaps;           /* -I */
 	int device_index;                     /* which GPU */
+	uint8_t host_ingest;                  /* 0 (default): read_chimeric_alignments runs on the device (agpu_ingest_*), the host feeds the bytes of the file;
+	                                         1: the multi-threaded host ingest builds the batch and uploads it */
 } arriba_workflow_options;
 
 /* what the reference prints as "(remaining=N)" / "(total=N)" / "(marked=N)", in the order of the stages; stage names as in the reference's source */

@@ -26,6 +26,7 @@
 #include "../../arriba_amd/csrc/device/genomic_support_core.hpp"
 #include "../../arriba_amd/csrc/device/index_bins.hpp"
 #include "../../arriba_amd/csrc/device/multimapper_core.hpp"
+#include "../../arriba_amd/csrc/device/ingest_core.hpp"
 #include <map>
 #include <set>
 #include <tuple>
@@ -409,5 +410,6 @@ int emu_last_kernel_ms(emu_ctx*, float* ms) { *ms = 0; return 0; }
 int emu_last_kernel_bytes(emu_ctx*, uint64_t* bytes) { *bytes = 0; return 0; }
 
 #include "emu_fusions.inc"
+#include "emu_ingest.inc"
 
 }

@@ -613,7 +613,7 @@ def check_output_files(session, pipeline, golden, directory, skip_columns=(), re
     return tuple(results)
 
 
-def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None, fill_sequence_gaps=False, structural_variants=False, params=None, workflow_options=None, max_itd_length=100, external_duplicate_marking=False):
+def check_workflow(prefix, golden, directory, api=None, rules=False, reference_prefix=None, fill_sequence_gaps=False, structural_variants=False, params=None, workflow_options=None, max_itd_length=100, external_duplicate_marking=False, device_ingest=False):
     """FASTA + GTF + BAM (+ blacklist / known fusions) -> fusions.tsv, discarded.tsv through DevicePipeline.run_workflow with the reference's default
     parameters: nothing is taken from the reference, not even the parameters its log prints.  Both files must equal the reference's byte for byte, and
     every "(remaining=N)" of its log must come out."""
@@ -622,8 +622,11 @@ def check_workflow(prefix, golden, directory, api=None, rules=False, reference_p
     from arriba_amd.pipeline import DevicePipeline
     from arriba_amd.pipeline import HostSession
     session = HostSession(prefix + ".fa", prefix + ".gtf")
-    session.read_chimeric_alignments(prefix + ".bam", external_duplicate_marking=external_duplicate_marking, max_itd_length=max_itd_length)
-    pipeline = DevicePipeline(session, params=params, api=api)
+    if device_ingest:  # read_chimeric_alignments on the device: the host never holds the batch
+        pipeline = DevicePipeline(session, params=params, api=api, bam=prefix + ".bam", external_duplicate_marking=external_duplicate_marking, max_itd_length=max_itd_length, piece_bytes=2 << 20)
+    else:
+        session.read_chimeric_alignments(prefix + ".bam", external_duplicate_marking=external_duplicate_marking, max_itd_length=max_itd_length)
+        pipeline = DevicePipeline(session, params=params, api=api)
     stages = []
     outputs = [os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv")]
     pipeline.run_workflow(outputs[0], outputs[1], blacklist_file=prefix + ".blacklist.tsv" if rules else None, known_fusions_file=prefix + ".known_fusions.tsv" if rules else None,

@@ -217,6 +217,104 @@ def test_ingest_reads_pipes_and_standard_input(built, dataset_files, tmp_path):
     assert result.returncode != 0 and b"failed to load alignments" in result.stderr
 
 
+def _device_batch_columns(session, pipeline):
+    """the batch a device ingest built (all rows fetched through agpu_gather_rows_*), keyed like _batch_columns"""
+    arrays, _ = pipeline.batch_rows()
+    names = arrays["names"].tobytes().decode()
+    offsets = arrays["name_offset"]
+    columns = {"n": arrays["n"], "mapped_reads": session.mapped_reads, "names": [names[offsets[i]:offsets[i + 1]] for i in range(arrays["n"])]}
+    for key in ("n_aln", "fbits", "group", "cigar_pool", "seq_pool"):
+        columns[key] = arrays[key].tobytes()
+    for slot in range(3):
+        for key in ("contig", "start", "end", "abits", "cigar_offset", "cigar_count"):
+            columns["%s%d" % (key, slot)] = arrays["%s%d" % (key, slot)].tobytes()
+    for slot in range(2):
+        for key in ("seq_offset", "seq_length"):
+            columns["%s%d" % (key, slot)] = arrays["%s%d" % (key, slot)].tobytes()
+    columns["coverage"] = int(session._lib.ahost_coverage_checksum(session._session))
+    return columns
+
+
+DEVICE_INGEST_DATASETS = {
+    "toy3k": datasets.DATASETS["toy3k"]["args"], "shuffled2k": datasets.DATASETS["shuffled2k"]["args"], "stacked4k": datasets.DATASETS["stacked4k"]["args"], "itd6k": datasets.DATASETS["itd6k"]["args"],
+    "mid30k": datasets.DATASETS["mid30k"]["args"],
+    "shuffled_dups_40k": ["--seed", "17", "--fragments", "40000", "--normal-mult", "0.5", "--contigs", "5", "--contig-len", "400000", "--junctions", "400", "--dup", "0.2", "--shuffle", "--separate-mates"],
+    "stranded_multimappers_20k": ["--seed", "23", "--fragments", "20000", "--normal-mult", "1.5", "--contigs", "4", "--contig-len", "300000", "--junctions", "200", "--multimap", "0.2", "--stranded", "--itd-hotspots", "2"],
+}
+
+
+@pytest.mark.parametrize("name", sorted(DEVICE_INGEST_DATASETS))
+def test_device_ingest_builds_the_batch_of_the_host_ingest(name, built, emu_api, tmp_path):
+    """read_chimeric_alignments on the device (ingest_core.hpp stepped on the host): records cut from the stream, collated by name key, the reference's loop
+    body replayed per name, sanity check, name order, pack -- every column, pool and name of the batch, coverage_t, the counters, the strandedness vote and
+    the viral verdicts equal what the host ingest (itself byte-identical to the reference's read table) produces"""
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    prefix = datasets.generate({"args": DEVICE_INGEST_DATASETS[name]}, str(tmp_path))
+    host = parity.open_session(prefix)
+    expected = _batch_columns(host)
+    expected["coverage"] = int(host._lib.ahost_coverage_checksum(host._session))
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    pipeline = DevicePipeline(session, api=emu_api, bam=prefix + ".bam", piece_bytes=1 << 20)
+    columns = _device_batch_columns(session, pipeline)
+    different = [key for key in expected if expected[key] != columns[key]]
+    assert not different, different
+    assert pipeline.ingest_result.names_were_sorted == (0 if "--shuffle" in DEVICE_INGEST_DATASETS[name] else 1)
+    assert pipeline.detect_strandedness() == host.detect_strandedness()
+    pairs = np.array([[c, 0] for c in range(len(session.contig_names()))], dtype=np.uint32).reshape(-1)
+    for mine, theirs in zip(session.viral_verdicts(pairs, np.zeros(4, dtype=np.uint8)), host.viral_verdicts(pairs, np.zeros(4, dtype=np.uint8))):
+        assert mine.tobytes() == theirs.tobytes()
+    assert expected["n"] > 1500
+
+
+def test_device_ingest_reads_every_container_and_pipes(built, dataset_files, emu_api, tmp_path, monkeypatch):
+    """the file side of the device ingest (BamFeed): stored BGZF handed on raw with its block table, deflated BGZF inflated by all threads, a switch from stored
+    to deflated blocks in the middle of a file, plain gzip, raw BAM from a named pipe; truncated and damaged files are errors"""
+    import gzip
+    import subprocess
+    from arriba_amd.pipeline import ArribaError, DevicePipeline, HostSession
+    prefix = dataset_files("toy3k")
+    payload = _bam_payload(prefix + ".bam")
+    def ingest(path, piece_bytes=1 << 20):
+        session = HostSession(prefix + ".fa", prefix + ".gtf")
+        return _device_batch_columns(session, DevicePipeline(session, api=emu_api, bam=path, piece_bytes=piece_bytes))
+    expected = ingest(prefix + ".bam")
+    assert expected["n"] > 2000
+    variants = {"deflated": str(tmp_path / "deflated.bam"), "small_blocks": str(tmp_path / "small.bam"), "plain_gzip": str(tmp_path / "plain.bam"), "raw": str(tmp_path / "raw.bam"), "mixed": str(tmp_path / "mixed.bam")}
+    _write_bgzf(variants["deflated"], payload, 6)
+    _write_bgzf(variants["small_blocks"], payload, 1, block=997)
+    with gzip.open(variants["plain_gzip"], "wb") as out:
+        out.write(payload)
+    open(variants["raw"], "wb").write(payload)
+    stored = open(prefix + ".bam", "rb").read()
+    # mixed: the first stored blocks of the generator's file, then the rest of the stream deflated
+    cut_blocks, at, taken = 5, 0, 0
+    for _ in range(cut_blocks):
+        size = int.from_bytes(stored[at + 16:at + 18], "little") + 1
+        taken += int.from_bytes(stored[at + size - 4:at + size], "little")
+        at += size
+    _write_bgzf(str(tmp_path / "tail.bam"), payload[taken:], 6)
+    open(variants["mixed"], "wb").write(stored[:at] + open(str(tmp_path / "tail.bam"), "rb").read())
+    for name, path in variants.items():
+        assert ingest(path) == expected, name
+    monkeypatch.setenv("ARRIBA_INGEST_THREADS", "3")
+    assert ingest(variants["deflated"], piece_bytes=3 << 20) == expected
+    fifo = str(tmp_path / "records.fifo")
+    os.mkfifo(fifo)
+    producer = subprocess.Popen([datasets.GEN_SYNTH, "--out", str(tmp_path / "unused"), "--raw-bam-to", fifo] + datasets.DATASETS["toy3k"]["args"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert ingest(fifo) == expected
+    assert producer.wait() == 0
+    raw = open(variants["deflated"], "rb").read()
+    open(str(tmp_path / "truncated.bam"), "wb").write(raw[:len(raw) // 2])
+    damaged = bytearray(raw)
+    damaged[len(raw) // 3] ^= 0x5A
+    open(str(tmp_path / "damaged.bam"), "wb").write(bytes(damaged))
+    open(str(tmp_path / "cut_record.bam"), "wb").write(payload[:len(payload) // 2 + 7])
+    open(str(tmp_path / "cut_stored.bam"), "wb").write(stored[:len(stored) // 2])
+    for name in ("truncated.bam", "damaged.bam", "cut_record.bam", "cut_stored.bam"):
+        with pytest.raises(ArribaError):
+            ingest(str(tmp_path / name))
+
+
 def test_ingest_result_survives_save_and_load(built, dataset_files, tmp_path):
     from arriba_amd.pipeline import ArribaError, HostSession
     prefix = dataset_files("shuffled2k")
@@ -371,9 +469,19 @@ def test_workflow_from_input_files_to_output_files(name, dataset_files, emu_api,
     assert len(stages) >= 18 and stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
 
 
+@pytest.mark.parametrize("name", ["toy3k", "rules8k", "toy3k_fill", "wgs8k"])
+def test_workflow_from_the_bam_file_through_the_device_ingest(name, dataset_files, emu_api, tmp_path):
+    """the same, with read_chimeric_alignments on the device (the host feeds bytes; strandedness, the float sum of the read lengths and the rows of the
+    supporting reads the writer prints come back from the device): both output files byte-identical to the reference's"""
+    stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path), api=emu_api, rules=name in ("rules8k", "wgs8k"), fill_sequence_gaps=name == "toy3k_fill",
+                                   structural_variants=name == "wgs8k", device_ingest=True)
+    assert len(stages) >= 18 and stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
+
+
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+@pytest.mark.parametrize("device_ingest", [False, True])
 @pytest.mark.parametrize("fragments", [1, 5, 40, 200])
-def test_workflow_on_tiny_inputs_against_the_live_reference(fragments, emu_api, tmp_path):
+def test_workflow_on_tiny_inputs_against_the_live_reference(fragments, device_ingest, emu_api, tmp_path):
     """one to a few hundred chimeric fragments: no candidate survives, or none exists at all; the output files still equal the reference's"""
     spec = {"args": ["--seed", "71", "--fragments", str(fragments), "--contigs", "3", "--contig-len", "200000", "--junctions", "10", "--normal-mult", "1.0"]}
     prefix = datasets.generate(spec, str(tmp_path))
@@ -382,7 +490,7 @@ def test_workflow_on_tiny_inputs_against_the_live_reference(fragments, emu_api, 
     with open(os.path.join(dump, "reference.log"), "w") as out:
         out.write(datasets.run_reference(prefix, dump, spec))
     os.makedirs(str(tmp_path / "mine"))
-    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix)
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, device_ingest=device_ingest)
     assert stages[0][1] >= 1
 
 
@@ -398,7 +506,10 @@ def test_workflow_with_non_default_options_against_the_live_reference(emu_api, t
     ("duplicates_marked_externally_reverse_stranded_viral", ["-u", "-s", "reverse", "-T", "2", "-C", "0.2", "-F", "150", "-X"], {"fragment_length": 150, "external_duplicate_marking": 1},
      {"strandedness": 2, "top_viral_contigs": 2, "viral_contig_min_covered_fraction": 0.2, "print_extra_info_for_discarded_fusions": True}, {"external_duplicate_marking": True}),
     ("stranded", ["-s", "yes"], {}, {"strandedness": 1}, {}),
-    ("unstranded", ["-s", "no"], {}, {"strandedness": 0}, {})])
+    ("unstranded", ["-s", "no"], {}, {"strandedness": 0}, {}),
+    ("device_ingest_duplicates_marked_externally_short_itd", ["-u", "-l", "40", "-X"], {"external_duplicate_marking": 1, "max_itd_length": 40}, {"print_extra_info_for_discarded_fusions": True, "max_itd_length": 40},
+     {"external_duplicate_marking": True, "max_itd_length": 40, "device_ingest": True}),
+    ("device_ingest_auto_strandedness", [], {}, {}, {"device_ingest": True})])
 def test_workflow_with_library_options_against_the_live_reference(label, options, params, workflow_options, ingest, emu_api, tmp_path):
     """-u, -s, -T, -C, -F and -X (fusion transcripts and read identifiers for the discarded candidates, too) on a stranded library"""
     spec = {"args": ["--seed", "73", "--fragments", "12000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.2", "--stranded"]}
