@@ -150,6 +150,7 @@ class DevicePipeline(object):
         if not self.ctx:
             raise ArribaError("ERROR: " + self.api.last_error().decode())
         self.timings = {}
+        self._profiling_on = False
         self.wall_ms = {}
         import time
         self._last_record = time.perf_counter()
@@ -227,6 +228,8 @@ class DevicePipeline(object):
         self.ingest_seconds = {"feed": fed - started, "device": finished - fed, "adopt": time.perf_counter() - finished}
         self.n = int(result.fragments)
         self.device_ingest = True
+        self.n_dummy_genes = 0
+        self.scalars = {}
         return self.n
 
     def batch_rows(self, fragments=None):
@@ -688,6 +691,7 @@ class DevicePipeline(object):
     def set_profiling(self, enabled):
         """per-kernel HIP-event timing on the launch stream (reset on every call)"""
         self._check(self.api.set_profiling(self.ctx, int(enabled)))
+        self._profiling_on = bool(enabled)
 
     def kernel_profile(self):
         """[(kernel name, ms, algorithmic bytes)] for every launch since set_profiling(True)"""

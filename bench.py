@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X hot path on BASELINE.json's synthetic 10 M chimeric-read configuration.
+"""bench.py -- BASELINE.json's metric on one MI355X: chimeric reads/s END TO END, BAM file -> fusions.tsv.
 
-A "step" is one pass of the hot path (mark_multimappers -> annotate -> read-level filter cascade -> find_fusions) over one
-batch of synthetic chimeric fragments that is already resident in HBM; the batch comes from the deterministic generator
-(tools/gen_synth.cpp, BAM records streamed through the host ingest).  With --gpus N every rank processes its own shard
-(weak scaling: reads shard naturally by read).  Rank 0 prints ONE JSON line.
+A "step" is one whole run of the workflow over one sample (BASELINE.json config 2/3: synthetic chimeric-read BAM, 2x100 bp, uncompressed BGZF as STAR
+--outBAMcompression 0 writes it, run_arriba.sh:34): the BAM file (resident in the page cache / tmpfs, as the reference would read it) is opened, its
+header parsed, its bytes fed to the GPU, read_chimeric_alignments runs in HBM (agpu_ingest.hip), then every stage of the reference's main() in its order --
+the read-level cascade, find_fusions, merge_adjacent, filter_multimappers, e-value, every candidate-level filter, make_kmer_index + filter_homologs +
+filter_mismappers, recover_isoforms, assign_confidence -- and the output file fusions.tsv is written (-O discarded.tsv with --discarded).  `value` =
+chimeric fragments of the sample (the reference's "(total=N)") / seconds per step.  Loading the assembly and the annotation (ahost_open) and creating the
+device context happen once before the timed region, as in a resident service; the reference binary timed beside it pays for them inside its own time and
+the line says how much that is.  The time from the resident batch to the end of filter_relative_support -- what round 1 reported -- is the secondary
+field `device_resident_step`.
 
-The CPU baseline is the oracle build of the UNMODIFIED reference (oracle/_ref/arriba_ref, 1 core, it is single-threaded by
-design) timed on a bounded sample of the same workload; if that binary did not travel, the field says so.
+With --gpus N every rank runs the workflow over its own sample of the same size on its own GPU (samples are independent: no collective on the data path);
+value = fragments of all samples / the slowest rank's time.  Rank 0 prints ONE JSON line.
+
+The CPU baseline is the oracle build of the UNMODIFIED reference (oracle/_ref/arriba_ref, single-threaded by design) on a bounded sample of the same workload.
+--host-only: no GPU needed -- generates a small sample, runs the file side of the device ingest (BamFeed) and the classic host ingest from a named pipe and
+from a file, prints their rates; run it in the CPU container before committing a change under arriba_amd/csrc/host/.
 """
 import argparse
 import json
 import os
+import re
+import shutil
 import subprocess
 import sys
 import tempfile
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,66 +35,116 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def workload_args(fragments, seed, read_seed=0):
-    # 2x100 bp, 55 % split-read triplets / 35 % discordant pairs / 10 % read-through, Zipf junction
-    # support, 30 % PCR duplicates, synthetic 24-contig genome with GENCODE-like annotation (no hg38 offline)
-    return ["--seed", str(seed), "--read-seed", str(read_seed), "--fragments", str(fragments), "--normal-mult", "0", "--contigs", "24", "--contig-len", "12000000", "--genes-per-mb", "20",
+def workload_args(fragments, seed, read_seed=0, stress=False):
+    # 2x100 bp, 55 % split-read triplets / 35 % discordant pairs / 10 % read-through, Zipf junction support, 30 % PCR
+    # duplicates, synthetic 24-contig genome with GENCODE-like annotation (no hg38 offline).  stress = config 3: long clips copied from the partner gene
+    args = ["--seed", str(seed), "--read-seed", str(read_seed), "--fragments", str(fragments), "--normal-mult", "0", "--contigs", "24", "--contig-len", "12000000", "--genes-per-mb", "20",
             "--junctions", str(max(1000, fragments // 50))]
+    if stress:
+        args += ["--clip-min", "40", "--clip-max", "70", "--partner-clip", "0.5"]
+    return args
 
 
-def generate_and_ingest(fragments, seed, directory, read_seed=0):
-    """Writes the reference (FASTA/GTF) to `directory`, streams the BAM records through a pipe into the host ingest."""
-    from arriba_amd.pipeline import HostSession
+def scratch_directory(need_bytes):
+    """a directory for the sample: tmpfs if it has the room (the BAM is read from memory, as from the page cache), else the default temporary directory"""
+    for base in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if shutil.disk_usage(base).free > need_bytes * 1.3 + (4 << 30):
+                return tempfile.mkdtemp(prefix="arriba_bench_", dir=base)
+        except OSError:
+            pass
+    return tempfile.mkdtemp(prefix="arriba_bench_")
+
+
+def generate_sample(fragments, seed, directory, read_seed=0, stress=False, threads=None):
     import datasets
     prefix = os.path.join(directory, "bench")
-    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--reference-only"] + workload_args(fragments, seed, read_seed), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    session = HostSession(prefix + ".fa", prefix + ".gtf")
-    # ARRIBA_BENCH_CACHE=<directory>: the ingested batch is kept as a file, so that the profiling passes of one GPU session (each a new process
-    # of this script) do not generate and parse the same 10 M fragments again (~1 minute each)
-    cache = os.environ.get("ARRIBA_BENCH_CACHE")
-    cache_file = os.path.join(cache, "ingest_%d_%d_%d.bin" % (fragments, seed, read_seed)) if cache else None
-    if cache_file and os.path.exists(cache_file):
-        session.load_ingest(cache_file)
-        return session, prefix, None
-    fifo = prefix + ".bam.fifo"
-    os.mkfifo(fifo)
-    producer = subprocess.Popen([datasets.GEN_SYNTH, "--out", prefix, "--raw-bam-to", fifo] + workload_args(fragments, seed, read_seed), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    threads = threads or min(64, max(1, (os.cpu_count() or 2) - 2))
     started = time.time()
-    session.read_chimeric_alignments(fifo)
-    producer.wait()
-    elapsed = time.time() - started
-    if cache_file:
-        os.makedirs(cache, exist_ok=True)
-        session.save_ingest(cache_file)
-    return session, prefix, elapsed
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(threads)] + workload_args(fragments, seed, read_seed, stress), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return prefix, time.time() - started
 
 
-def cpu_baseline(seed, directory):
+def cpu_baseline(seed, directory, stress=False, sample_fragments=200000):
     """The unmodified reference (oracle/_ref/arriba_ref) on a bounded sample of the same workload, 1 core."""
     import datasets
+    unit = "chimeric reads/s"
     if not os.path.exists(datasets.ARRIBA_REF):
-        return {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref/arriba_ref not present on this box"}
-    sample_fragments = 200000
+        return {"value": None, "unit": unit, "cores": 1, "kind": "reference", "sample": "oracle/_ref/arriba_ref not present on this box"}
     prefix = os.path.join(directory, "cpu")
-    subprocess.run([datasets.GEN_SYNTH, "--out", prefix] + workload_args(sample_fragments, seed), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix] + workload_args(sample_fragments, seed, stress=stress), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    command = [datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-f", "blacklist"] + (["-U", "32767"] if stress else [])
     started = time.time()
-    result = subprocess.run([datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-f", "blacklist"],
-                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    process = subprocess.Popen(command, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    loaded_at, lines = None, []
+    for line in process.stdout:  # the moment the reference starts on the BAM file separates its loading phase from its per-sample work
+        lines.append(line)
+        if loaded_at is None and "Reading chimeric alignments" in line:
+            loaded_at = time.time()
+    process.wait()
     elapsed = time.time() - started
-    if result.returncode != 0:
-        return {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "reference failed: " + result.stdout[-200:]}
-    import re
-    total = re.search(r"Reading chimeric alignments from .*\(total=(\d+)\)", result.stdout.replace("\n", " "))
+    output = "".join(lines)
+    if process.returncode != 0:
+        return {"value": None, "unit": unit, "cores": 1, "kind": "reference", "sample": "reference failed: " + output[-200:]}
+    total = re.search(r"Reading chimeric alignments from .*\(total=(\d+)\)", output.replace("\n", " "))
     chimeric = int(total.group(1)) if total else sample_fragments
-    # the host ingest of this repository on the same file (BAM records -> SoA batch; reader + worker threads, arriba_amd/csrc/host/ingest.cpp)
+    loading = (loaded_at - started) if loaded_at else 0.0
+    return {"value": chimeric / elapsed, "unit": unit, "cores": 1, "kind": "reference",
+            "sample": "%d chimeric fragments of the same synthetic workload, whole reference binary BAM->fusions.tsv%s, %.1f s wall of which %.1f s load the assembly and the annotation" % (chimeric, " with -U 32767" if stress else "", elapsed, loading),
+            "value_without_loading": chimeric / max(elapsed - loading, 1e-9), "seconds": round(elapsed, 2), "loading_seconds": round(loading, 2)}
+
+
+def host_only(args):
+    """the host side alone (no GPU): rates of the file side of the device ingest and of the classic host ingest; a smoke test for changes under csrc/host/"""
+    import ctypes
+    import datasets
+    import __graft_entry__
+    from arriba_amd import _capi
     from arriba_amd.pipeline import HostSession
-    session = HostSession(prefix + ".fa", prefix + ".gtf")
-    ingest_started = time.time()
-    session.read_chimeric_alignments(prefix + ".bam")
-    ingest_elapsed = time.time() - ingest_started
-    return {"value": chimeric / elapsed, "unit": "chimeric reads/s", "cores": 1, "kind": "reference",
-            "sample": "%d chimeric fragments of the same synthetic workload, whole reference binary BAM->fusions.tsv, %.1f s wall" % (chimeric, elapsed),
-            "host_ingest_same_sample": {"value": session.fragment_count / ingest_elapsed, "unit": "chimeric reads/s", "threads": "1 reader + min(16, cores - 1) workers", "seconds": round(ingest_elapsed, 2)}}
+    directory = scratch_directory(args.fragments * 600)
+    try:
+        prefix, generate_seconds = generate_sample(args.fragments, 1000, directory)
+        lib = _capi.host_library()
+        line = {"mode": "host-only", "fragments": args.fragments, "bam_bytes": os.path.getsize(prefix + ".bam"), "generate_seconds": round(generate_seconds, 2)}
+        session = HostSession(prefix + ".fa", prefix + ".gtf")
+        # (a) BamFeed: header + all pieces, stored BGZF handed on raw
+        config = _capi.IngestConfig()
+        started = time.time()
+        if lib.ahost_bam_open(session._session, (prefix + ".bam").encode(), 0, 100, ctypes.byref(config)) != 0:
+            raise SystemExit("ahost_bam_open: " + lib.ahost_last_error().decode())
+        piece_bytes = 64 << 20
+        buffer = ctypes.create_string_buffer(piece_bytes)
+        blocks = (_capi.BgzfBlock * (piece_bytes // 4096 + 16))()
+        piece = _capi.BamPiece()
+        fed = stream = pieces = 0
+        while True:
+            status = lib.ahost_bam_next(session._session, buffer, piece_bytes, blocks, len(blocks), ctypes.byref(piece))
+            if status < 0:
+                raise SystemExit("ahost_bam_next: " + lib.ahost_last_error().decode())
+            if status == 0:
+                break
+            fed += piece.bytes; stream += piece.stream_bytes; pieces += 1
+        lib.ahost_bam_close(session._session)
+        seconds = time.time() - started
+        line["bam_feed"] = {"seconds": round(seconds, 3), "file_GB_per_s": fed / seconds / 1e9, "pieces": pieces, "stream_bytes": stream, "first_record_offset": int(config.first_record_offset), "n_targets": int(config.n_targets)}
+        # (b) the classic host ingest from a file and from a named pipe (what round 1's bench streamed through)
+        for source in ("file", "fifo"):
+            host = HostSession(prefix + ".fa", prefix + ".gtf")
+            path = prefix + ".bam"
+            producer = None
+            if source == "fifo":
+                path = prefix + ".fifo"
+                os.mkfifo(path)
+                producer = subprocess.Popen(["sh", "-c", 'cat "$0" > "$1"', prefix + ".bam", path])  # (the shell opens the pipe: opening it here would block until the reader is there)
+            started = time.time()
+            host.read_chimeric_alignments(path)
+            seconds = time.time() - started
+            if producer:
+                producer.wait()
+            line["host_ingest_from_" + source] = {"seconds": round(seconds, 3), "chimeric_reads_per_s": host.fragment_count / seconds, "fragments": host.fragment_count}
+        print(json.dumps(line))
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
 
 
 def main():
@@ -92,10 +152,17 @@ def main():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=3)
     parser.add_argument("--warmup", type=int, default=1)
-    parser.add_argument("--fragments", type=int, default=10000000, help="chimeric fragments per GPU (BASELINE.json config 2: 10 M)")
+    parser.add_argument("--fragments", type=int, default=None, help="chimeric fragments per GPU (default: 100 M, BASELINE.json's 100 M-read synthetic, if the box has the memory for the 54 GB file; 20000 with --host-only)")
+    parser.add_argument("--stress", action="store_true", help="BASELINE.json config 3: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (filter_mismappers sees every read)")
+    parser.add_argument("--discarded", action="store_true", help="also write discarded.tsv (-O) inside the step")
+    parser.add_argument("--host-ingest", action="store_true", help="read_chimeric_alignments by the multi-threaded host ingest instead of on the device (round 1's path)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
-    parser.add_argument("--workflow", action="store_true", help="after the timed steps, also run the whole workflow once (every candidate-level filter, assign_confidence, both output files) and report its wall time; 1 GPU only")
+    parser.add_argument("--host-only", action="store_true")
+    parser.add_argument("--keep", help="keep the sample and the output files in this directory")
     args = parser.parse_args()
+    if args.host_only:
+        args.fragments = args.fragments or 20000
+        return host_only(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -104,12 +171,11 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    local_rank %= torch.cuda.device_count()  # (several ranks share a device only in the single-GPU dry run of the N > 1 path)
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # nccl == RCCL over xGMI; ARRIBA_BENCH_BACKEND=gloo is the dry run of the N > 1 path on a box with fewer GPUs than ranks
         dist.init_process_group(backend=os.environ.get("ARRIBA_BENCH_BACKEND", "nccl"))
 
     import __graft_entry__
@@ -117,138 +183,149 @@ def main():
         __graft_entry__.build()
     if distributed:
         dist.barrier()
-    from arriba_amd.pipeline import DevicePipeline
-
-    directory = tempfile.mkdtemp(prefix="bench_r%d_" % rank)
-    # every rank draws its own reads from the same genome and annotation: the shards of one sample
-    session, prefix, ingest_seconds = generate_and_ingest(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank)
-    if distributed:
-        # one shard per rank; the sample is the concatenation of the shards in rank order (arriba_amd/sharded.py: four exchanges over RCCL)
-        from arriba_amd.sharded import ShardedPipeline
-        pipeline = ShardedPipeline(session, 0, session.fragment_count, device=local_rank, independent_sessions=True)
-    else:
-        pipeline = DevicePipeline(session, device=local_rank)
-    n = pipeline.n
-
-    step_stats = {}
-
-    def step():
-        pipeline.reset()
-        pipeline.run_read_level()
-        pipeline.find_fusions()
-        pipeline.merge_adjacent_fusions()      # clusters live inside one gene pair: with shards, every owner merges its own candidates
-        if distributed:
-            step_stats.update(pipeline.fusion_stats())
-            pipeline.replicate_candidates()    # all-gather of the owners' candidate columns: the candidate-level stages run replicated
-        pipeline.filter_multimappers()         # best alignment of every multi-mapping read; with shards: two all-gathers + two all-reduce MIN
-        pipeline.estimate_expected_fusions()   # includes the device computation of the reference container's iteration order (hazard H2)
-        pipeline.filter_candidate_predicates() # non_coding_neighbors, intragenic_exonic, min_support (source/arriba.cpp:437-455)
-        pipeline.filter_relative_support()
-
-    for _ in range(args.warmup):
-        step()
-    stage_ms = {}
-    pipeline.set_profiling(True)  # HIP events around every kernel launch, recorded on the launch stream
-    pipeline.wall_ms.clear()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    started = time.time()
-    for _ in range(args.steps):
-        step()
-        for stage, timing in pipeline.timings.items():
-            stage_ms.setdefault(stage, []).append(timing)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.time() - started
-    if distributed:
-        collective_device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        tensor = torch.tensor([elapsed], device=collective_device, dtype=torch.float64)
-        dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
-        elapsed = float(tensor.item())
-        counts = torch.tensor([n], device=collective_device, dtype=torch.int64)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        total_fragments = int(counts.item())
-    else:
-        total_fragments = n
-
-    # post-conditions of the last step on the full-size batch (untimed; no oracle involved): a kernel that silently skipped a part of the
-    # batch would leave alignments without a gene or a read filter count that does not add up
     import numpy as np
-    self_check = []
-    for slot in (0, 1):
-        without_gene = int((pipeline.gene_sets(slot)[0] == 0).sum())
-        if without_gene:
-            self_check.append("%d alignments in slot %d have no gene after annotate" % (without_gene, slot))
-    unfiltered = int((pipeline.filters() == 0).sum())
-    remaining_local = pipeline.remaining_local["low_entropy"] if hasattr(pipeline, "remaining_local") else pipeline.remaining["low_entropy"]
-    multimapper_discards = int((pipeline.filters() == 9).sum())
-    if unfiltered + multimapper_discards != remaining_local:
-        self_check.append("fragments without a filter (%d) + discarded as multi-mappers (%d) != remaining after the read filters (%d)" % (unfiltered, multimapper_discards, remaining_local))
-    if self_check:
-        raise SystemExit("bench self-check failed: " + "; ".join(self_check))
+    from arriba_amd.pipeline import DevicePipeline, HostSession
 
-    if rank == 0:
-        per_stage = {stage: {"ms": sum(t["ms"] for t in ts) / len(ts), "bytes": ts[-1]["bytes"]} for stage, ts in stage_ms.items()}
-        # per-kernel launch durations of the timed steps (HIP events on the launch stream); the dominant kernel is the one with the largest total
-        kernels = {}
-        for name, ms, size in pipeline.kernel_profile():
-            entry = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
-            entry["launches"] += 1
-            entry["ms"] += ms
-            entry["bytes"] += size
-        dominant = max(kernels, key=lambda name: kernels[name]["ms"])
-        launches = kernels[dominant]["launches"]
-        dominant_ms = kernels[dominant]["ms"] / launches
-        dominant_bytes = kernels[dominant]["bytes"] / launches
-        achieved = dominant_bytes / (dominant_ms * 1e-3) / 1e9 if dominant_ms > 0 else 0.0
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected in separate
-        # runs, tools/gpu_round.sh; KB per kernel over all dispatches).  Calibration in the same passes on the runtime's copy kernel with a
-        # known byte count: FETCH_SIZE reports half of the bytes read (as MI355X_MICROARCH.md states for wide loads), WRITE_SIZE all of them.
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            entry = pmc.get("kernels", {}).get(dominant.split("(")[0])
-            if entry and entry.get("dispatches") and pmc.get("fragments") == n:
-                traffic = (2.0 * entry.get("FETCH_SIZE", 0.0) + entry.get("WRITE_SIZE", 0.0)) * 1024.0 / entry["dispatches"]
-        cascade_bytes = sum(values["bytes"] for values in per_stage.values())
-        cascade_ms = sum(values["ms"] for values in per_stage.values())
-        stats = step_stats if distributed else pipeline.fusion_stats()
-        line = {
-            "metric": "chimeric reads/s end-to-end (BAM->fusions.tsv), synthetic, device hot path with inputs resident in HBM",
-            "value": total_fragments * args.steps / elapsed,
-            "unit": "chimeric reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "synthetic %d chimeric fragments per GPU (2x100 bp, 24-contig synthetic genome, GENCODE-like GTF), default filters" % args.fragments,
-                       "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "parallelism": ("%d shards by read: all-gather of unmapped positions, duplicate winners and mate-gap samples, all-to-all of gene-pair emissions, all-gather of candidate columns (RCCL)" % world) if distributed else "1 GPU", "gene_pair_emissions": stats["emissions"], "read_list_entries": stats["list_entries"],
-                       "stages_timed": "mark_multimappers, annotate, read filters (14), fragment-length samples, find_fusions, merge_adjacent_fusions, filter_multimappers, fusions_t iteration order, estimate_expected_fusions, filter_non_coding_neighbors, filter_intragenic_both_exonic, filter_min_support, filter_relative_support",
-                       "generate_and_ingest_reads_per_s": (n / ingest_seconds) if ingest_seconds else "batch loaded from ARRIBA_BENCH_CACHE"},
-            "stage_ms": {stage: round(values["ms"], 3) for stage, values in per_stage.items()},
-            "stage_wall_ms": {stage: round(value / args.steps, 3) for stage, value in pipeline.wall_ms.items()},
-            "kernel_ms": {name: round(values["ms"] / values["launches"], 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:12]},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes,
-                         "cascade": {"algorithmic_bytes": cascade_bytes, "kernel_ms": cascade_ms, "achieved": cascade_bytes / (cascade_ms * 1e-3) / 1e9, "frac": cascade_bytes / (cascade_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-        }
-        line["self_check"] = "every alignment has a gene; unfiltered + multi-mapper discards == remaining after the read filters"
-        line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped"} if args.no_cpu_baseline else cpu_baseline(1000, directory)
-        if args.workflow and not distributed:
-            # untimed extra (not part of `value`): the reference's main() behind the ingest, to the two output files, once over the same batch
-            try:
-                remaining = []
-                pipeline.reset()
-                torch.cuda.synchronize()
-                workflow_started = time.time()
-                pipeline.run_workflow(os.path.join(directory, "workflow.fusions.tsv"), os.path.join(directory, "workflow.discarded.tsv"), log=lambda stage, count: remaining.append((stage, count, round(time.time() - workflow_started, 3))))
-                torch.cuda.synchronize()
-                line["workflow"] = {"seconds": time.time() - workflow_started, "stages": remaining, "fusions": remaining[-1][1] if remaining else None}
-            except Exception as error:  # the candidate-level stages must not cost the bench line
-                line["workflow"] = {"error": str(error)}
-        print(json.dumps(line))
+    if args.fragments is None:
+        memory = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+        shm_free = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else 0
+        args.fragments = 100000000 if (memory > world * (160 << 30) and max(shm_free, shutil.disk_usage(tempfile.gettempdir()).free) > world * (80 << 30)) else 10000000
+    directory = args.keep or scratch_directory(args.fragments * 600)
+    os.makedirs(directory, exist_ok=True)
+    try:
+        prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, ((os.cpu_count() or 2) - 2) // world)))
+        bam_bytes = os.path.getsize(prefix + ".bam")
+        session = HostSession(prefix + ".fa", prefix + ".gtf")  # assembly + annotation, once (resident)
+        params = {"subsampling_threshold": 32767} if args.stress else None
+        pipeline = None
+        outputs = [os.path.join(directory, "fusions.tsv"), os.path.join(directory, "discarded.tsv") if args.discarded else None]
+        stage_log, step_seconds, ingest_parts = [], [], []
+
+        def step():
+            nonlocal pipeline
+            started = time.perf_counter()
+            del stage_log[:]
+            if args.host_ingest:
+                session.read_chimeric_alignments(prefix + ".bam")
+                if pipeline is not None:
+                    pipeline.close()
+                pipeline = DevicePipeline(session, params=params, device=local_rank)
+                pipeline.set_profiling(profiling[0])
+                ingest_parts.append({"host_ingest": time.perf_counter() - started})
+            elif pipeline is None:
+                pipeline = DevicePipeline(session, params=params, device=local_rank, bam=prefix + ".bam", piece_bytes=256 << 20)
+                ingest_parts.append(dict(pipeline.ingest_seconds))
+            else:
+                pipeline.read_chimeric_alignments(prefix + ".bam", piece_bytes=256 << 20)
+                ingest_parts.append(dict(pipeline.ingest_seconds))
+            ingested = time.perf_counter()
+            pipeline.run_workflow(outputs[0], outputs[1], log=lambda stage, count: stage_log.append((stage, count, round(time.perf_counter() - started, 4))))
+            finished = time.perf_counter()
+            step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started})
+
+        profiling = [False]
+        for _ in range(args.warmup):
+            step()
+        profiling[0] = True
+        if pipeline is not None:
+            pipeline.set_profiling(True)  # HIP events around every kernel launch, recorded on the launch stream
+        del step_seconds[:], ingest_parts[:]
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        started = time.time()
+        for _ in range(args.steps):
+            step()
+            if pipeline is not None and not pipeline._profiling_on:
+                pipeline.set_profiling(True)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        elapsed = time.time() - started
+        n = pipeline.n
+        if distributed:
+            device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            tensor = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
+            elapsed = float(tensor.item())
+            counts = torch.tensor([n], device=device, dtype=torch.int64)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            total_fragments = int(counts.item())
+        else:
+            total_fragments = n
+
+        # post-conditions of the last step on the full-size batch (untimed; no oracle involved): a kernel that silently skipped a part of the batch would
+        # leave alignments without a gene, or read filter counts that do not add up; the output file must exist and hold the fusions the log counted
+        self_check = []
+        for slot in (0, 1):
+            without_gene = int((pipeline.gene_sets(slot)[0] == 0).sum())
+            if without_gene:
+                self_check.append("%d alignments in slot %d have no gene after annotate" % (without_gene, slot))
+        fusion_lines = sum(1 for line in open(outputs[0]) if not line.startswith("#"))
+        if not stage_log or stage_log[-1][0] != "recover_isoforms" or fusion_lines != stage_log[-1][1]:
+            self_check.append("fusions.tsv holds %d fusions, the last stage counted %s" % (fusion_lines, stage_log[-1:] or None))
+        if self_check:
+            raise SystemExit("bench self-check failed: " + "; ".join(self_check))
+
+        if rank == 0:
+            kernels = {}
+            for name, ms, size in pipeline.kernel_profile():
+                entry = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+                entry["launches"] += 1
+                entry["ms"] += ms
+                entry["bytes"] += size
+            modelled = {name: values for name, values in kernels.items() if values["bytes"] > 0}
+            dominant = max(modelled, key=lambda name: modelled[name]["ms"])
+            launches = kernels[dominant]["launches"]
+            dominant_ms = kernels[dominant]["ms"] / launches
+            dominant_bytes = kernels[dominant]["bytes"] / launches
+            achieved = dominant_bytes / (dominant_ms * 1e-3) / 1e9 if dominant_ms > 0 else 0.0
+            # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_round.sh)
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+                entry = pmc.get("kernels", {}).get(dominant.split("(")[0])
+                if entry and entry.get("dispatches") and pmc.get("fragments") == n:
+                    traffic = (2.0 * entry.get("FETCH_SIZE", 0.0) + entry.get("WRITE_SIZE", 0.0)) * 1024.0 / entry["dispatches"]
+            kernel_ms_per_step = sum(values["ms"] for values in kernels.values()) / args.steps
+            mean = lambda key: sum(s[key] for s in step_seconds) / len(step_seconds)
+            resident_stages = ("mark_multimappers", "annotate", "read_filters_stage1", "fragment_length_samples", "read_filters_stage2", "find_fusions", "merge_adjacent_fusions", "filter_multimappers",
+                               "candidate_iteration_order", "estimate_expected_fusions", "filter_candidate_predicates", "filter_relative_support")
+            resident_ms = sum(pipeline.timings[stage]["ms"] for stage in resident_stages if stage in pipeline.timings)
+            line = {
+                "metric": "chimeric reads/s end-to-end (BAM->fusions.tsv), synthetic",
+                "value": total_fragments * args.steps / elapsed,
+                "unit": "chimeric reads/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "config": {"workload": "synthetic %d chimeric fragments per GPU (%d BAM records, %.1f GB uncompressed BGZF; 2x100 bp, 24-contig synthetic genome, GENCODE-like GTF)%s, default filters, BAM file in memory -> fusions.tsv%s"
+                                       % (args.fragments, pipeline.ingest_result.records if pipeline.ingest_result else -1, bam_bytes / 1e9, ", mismapper stress (clips of 40-70 nt copied from the partner gene, -U 32767)" if args.stress else "",
+                                          " + discarded.tsv" if args.discarded else ""),
+                           "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
+                           "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
+                           "parallelism": ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
+                           "outside_the_step": "loading assembly + annotation (ahost_open), device context; generating the sample took %.1f s" % generate_seconds,
+                           "names_were_sorted": bool(pipeline.ingest_result.names_were_sorted) if pipeline.ingest_result else None},
+                "seconds_per_step": {"read_chimeric_alignments": round(mean("ingest"), 4), "workflow_to_output_files": round(mean("workflow"), 4), "total": round(mean("total"), 4)},
+                "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
+                "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
+                "stages": stage_log,
+                "stage_kernel_ms": {stage: round(values["ms"], 3) for stage, values in pipeline.timings.items()},
+                "kernel_ms": {name: round(values["ms"] / values["launches"], 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:16]},
+                "kernel_ms_per_step": round(kernel_ms_per_step, 2),
+                "device_resident_step": {"what": "round 1's figure: resident batch -> filter_relative_support (kernel time of the stages between the ingest and the candidate-level filters)", "ms": round(resident_ms, 3),
+                                         "chimeric_reads_per_s": n / (resident_ms * 1e-3) if resident_ms > 0 else None},
+                "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes, "launches_per_step": launches / args.steps},
+            }
+            line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted"
+            line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped"} if args.no_cpu_baseline else cpu_baseline(1000, directory, stress=args.stress)
+            print(json.dumps(line))
+    finally:
+        if not args.keep:
+            shutil.rmtree(directory, ignore_errors=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

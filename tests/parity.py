@@ -666,7 +666,7 @@ NON_DEFAULT_OPTIONS = {
 }
 
 
-def check_workflow_with_non_default_options(fragments, directory, api=None):
+def check_workflow_with_non_default_options(fragments, directory, api=None, device_ingest=False):
     """Nineteen options away from their defaults and two filters switched off, on both sides: the reference run live with the command-line options, the
     workflow with the same values through agpu_params and the stage arguments; blacklist, known fusions, tags, protein domains and structural variants given."""
     spec = {"args": ["--seed", "67", "--fragments", str(fragments), "--normal-mult", "0.4", "--contigs", "6", "--contig-len", "500000", "--junctions", "700", "--dup", "0.15", "--rule-files", "--homolog-families", "10",
@@ -685,7 +685,7 @@ def check_workflow_with_non_default_options(fragments, directory, api=None):
         out.write(log)
     os.makedirs(os.path.join(directory, "mine"))
     return check_workflow(prefix, dump, os.path.join(directory, "mine"), api=api, rules=True, reference_prefix=prefix, structural_variants=True, params=NON_DEFAULT_OPTIONS["params"],
-                          workflow_options=NON_DEFAULT_OPTIONS["workflow"], max_itd_length=60)
+                          workflow_options=NON_DEFAULT_OPTIONS["workflow"], max_itd_length=60, device_ingest=device_ingest)
 
 
 def check_read_lists(session, pipeline, golden, stage):

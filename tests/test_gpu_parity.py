@@ -441,3 +441,63 @@ def test_cpp_workflow_driver_over_the_c_abis(built, dataset_files, tmp_path):
         assert result.returncode == 0, result.stderr[-2000:]
         for mine, reference in zip(outputs, ("fusions.tsv.gz", "discarded.tsv.gz")):
             assert open(mine).read() == gzip.open(os.path.join(conftest.golden_dir(name), reference), "rt").read(), (name, reference)
+
+
+def _batch_columns_of_both(prefix, piece_bytes=8 << 20):
+    """(host ingest's batch, device ingest's batch) of one BAM file as comparable dictionaries"""
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    import test_host_and_device_logic as cpu_tier
+    host = parity.open_session(prefix)
+    expected = cpu_tier._batch_columns(host)
+    expected["coverage"] = int(host._lib.ahost_coverage_checksum(host._session))
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    pipeline = DevicePipeline(session, bam=prefix + ".bam", piece_bytes=piece_bytes)
+    return host, expected, session, pipeline, cpu_tier._device_batch_columns(session, pipeline)
+
+
+@pytest.mark.parametrize("name", ["toy3k", "shuffled2k", "itd6k", "shuffled_dups_40k", "stranded_multimappers_20k"])
+def test_device_ingest_builds_the_batch_of_the_host_ingest(name, built, tmp_path):
+    """read_chimeric_alignments in HBM (agpu_ingest.hip): the record chain cut by speculative segments, records collated with the radix sort, one thread per read
+    name replaying the reference's loop, the name order (first-occurrence fast path and the chunked string sort), pack: every column, pool and name of the batch,
+    coverage_t, counters and the strandedness vote equal the host ingest (which is byte-identical to the reference's read table)"""
+    import test_host_and_device_logic as cpu_tier
+    prefix = datasets.generate({"args": cpu_tier.DEVICE_INGEST_DATASETS[name]}, str(tmp_path))
+    host, expected, session, pipeline, columns = _batch_columns_of_both(prefix, piece_bytes=1 << 20)
+    different = [key for key in expected if expected[key] != columns[key]]
+    assert not different, different
+    assert pipeline.ingest_result.names_were_sorted == (0 if "--shuffle" in cpu_tier.DEVICE_INGEST_DATASETS[name] else 1)
+    assert pipeline.detect_strandedness() == host.detect_strandedness()
+
+
+def test_device_ingest_at_scale_and_every_container(built, tmp_path):
+    """1.2 M fragments + 0.6 M ordinary pairs (more segments, groups and fragments than any launch grid cap), shuffled names: the batch equals the host ingest's;
+    the same stream as deflated BGZF and as raw BAM gives the same batch"""
+    import gzip
+    import test_host_and_device_logic as cpu_tier
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    spec = {"args": ["--seed", "41", "--fragments", "1200000", "--normal-mult", "0.5", "--contigs", "8", "--contig-len", "2000000", "--junctions", "20000", "--dup", "0.2", "--shuffle"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    host, expected, session, pipeline, columns = _batch_columns_of_both(prefix, piece_bytes=64 << 20)
+    different = [key for key in expected if expected[key] != columns[key]]
+    assert not different, different
+    assert expected["n"] > 1100000 and pipeline.ingest_result.names_were_sorted == 0
+    payload = gzip.open(prefix + ".bam", "rb").read()
+    open(str(tmp_path / "raw.bam"), "wb").write(payload)
+    cpu_tier._write_bgzf(str(tmp_path / "deflated.bam"), payload, 1)
+    for variant in ("raw.bam", "deflated.bam"):
+        other = HostSession(prefix + ".fa", prefix + ".gtf")
+        rows = cpu_tier._device_batch_columns(other, DevicePipeline(other, bam=str(tmp_path / variant), piece_bytes=32 << 20))
+        assert [key for key in expected if expected[key] != rows[key]] == [], variant
+
+
+def test_workflow_from_the_bam_file_through_the_device_ingest(built, dataset_files, tmp_path):
+    """BAM bytes -> fusions.tsv + discarded.tsv with read_chimeric_alignments on the GPU and nothing of the batch on the host: byte-identical to the reference's files"""
+    for name in ("toy3k", "rules8k", "homologs8k", "toy3k_fill", "wgs8k"):
+        os.makedirs(str(tmp_path / name))
+        stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path / name), rules=name in ("rules8k", "wgs8k"), fill_sequence_gaps=name == "toy3k_fill",
+                                       structural_variants=name == "wgs8k", device_ingest=True)
+        assert stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
+    if datasets.reference_available():
+        os.makedirs(str(tmp_path / "options"))
+        stages = parity.check_workflow_with_non_default_options(60000, str(tmp_path / "options"), device_ingest=True)
+        assert dict(stages)["mark_genomic_support"] > 1000 and stages[-1][1] > 200

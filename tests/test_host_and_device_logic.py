@@ -347,18 +347,31 @@ def test_empty_like_inputs_are_rejected_like_the_reference(built, tmp_path):
 
 
 def test_bench_cpu_baseline_leg_reports_the_contract_fields(built, tmp_path):
-    """bench.py's cpu_baseline object (the reference binary on a bounded sample, 1 core) and the ingest rate measured on the same file"""
+    """bench.py's cpu_baseline object: the reference binary on a bounded sample, 1 core, its loading phase told apart from its work on the sample"""
     import sys
     sys.path.insert(0, conftest.ROOT)
     import bench
     if not datasets.reference_available():
         pytest.skip("oracle/_ref/arriba_ref is not built")
-    baseline = bench.cpu_baseline(1000, str(tmp_path))
+    baseline = bench.cpu_baseline(1000, str(tmp_path), sample_fragments=50000)
     assert baseline["kind"] == "reference" and baseline["cores"] == 1 and baseline["unit"] == "chimeric reads/s"
     assert baseline["value"] > 1000 and "chimeric fragments of the same synthetic workload" in baseline["sample"]
-    assert baseline["host_ingest_same_sample"]["value"] > baseline["value"]  # the ingest alone is faster than the reference's whole job
+    assert baseline["value_without_loading"] > baseline["value"] and 0 < baseline["loading_seconds"] < baseline["seconds"]
     same_reference, other_reads = bench.workload_args(1000, 7, 0), bench.workload_args(1000, 7, 9)
     assert same_reference[:2] == other_reads[:2] and same_reference[2:4] != other_reads[2:4]  # shards of one sample: one genome seed, different read seeds
+
+
+def test_bench_host_only_leg_runs_without_a_gpu(built):
+    """bench.py --host-only: the file side of the device ingest and the host ingest from a file and from a named pipe (the leg that would have caught round 1's
+    open-read-close of a pipe before the driver did)"""
+    import json
+    import subprocess
+    import sys
+    result = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "bench.py"), "--host-only", "--fragments", "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert result.returncode == 0, result.stderr[-1000:]
+    line = json.loads(result.stdout.strip().splitlines()[-1])
+    assert line["host_ingest_from_fifo"]["fragments"] == line["host_ingest_from_file"]["fragments"] > 15000
+    assert line["bam_feed"]["stream_bytes"] > 0.99 * line["bam_bytes"] - 100000 and line["bam_feed"]["n_targets"] == 27
 
 
 def test_gene_set_capacity_is_reported_not_truncated(built, emu_api, tmp_path):

@@ -1,5 +1,9 @@
 // tools/gen_synth.cpp -- see gen_synth.hpp.  Test + bench tooling, not product code.
 #include "gen_synth.hpp"
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -10,8 +14,6 @@
 #include <zlib.h>
 
 namespace synth {
-
-namespace {
 
 struct Rng {
 	uint64_t state;
@@ -27,6 +29,8 @@ struct Rng {
 	double unif() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
 	bool chance(double p) { return unif() < p; }
 };
+
+namespace {
 
 const uint16_t F_PAIRED = 1, F_PROPER = 2, F_REVERSE = 16, F_MREVERSE = 32, F_READ1 = 64, F_READ2 = 128, F_SECONDARY = 256, F_DUP = 1024, F_SUPPLEMENTARY = 2048;
 enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5 };
@@ -1026,19 +1030,23 @@ void Generator::stream_bam(const ByteSink& sink) {
 	if (genes_.empty())
 		build_reference();
 	if (config_.read_seed != 0) impl_->rng = Rng(config_.read_seed);
-	Rng& rng = impl_->rng;
-	const Config& c = config_;
-	Builder builder = { c, contig_sequences_, genes_, *impl_, rng };
 	BamEncoder encoder;
 	encoder.header(contig_names_, contig_sequences_);
 	sink(encoder.buffer.data(), encoder.buffer.size());
-	encoder.buffer.clear();
+	records_written_ = 0;
+	stream_records(impl_->rng, 0, config_.fragments, sink, records_written_);
+}
+
+// the records of `fragments` chimeric fragments (and the ordinary pairs between them) drawn from `rng`; names count up from `first_serial`
+void Generator::stream_records(Rng& rng, uint64_t first_serial, long fragments, const ByteSink& sink, long& records_written) const {
+	const Config& c = config_;
+	Builder builder = { c, contig_sequences_, genes_, *impl_, rng };
+	BamEncoder encoder;
 
 	struct Pending { std::string name; Record record; bool has_mate; Record mate; };
 	std::vector<Pending> pool; // delay pool for separate_mates
 	std::vector<Fragment> reservoir; // recent chimeric fragments for PCR duplicates
-	uint64_t serial = 0;
-	records_written_ = 0;
+	uint64_t serial = first_serial;
 
 	auto apply_errors = [&](Fragment& fragment) {
 		double rate = rng.chance(c.high_error_fraction) ? c.high_error_rate : c.error_rate;
@@ -1093,7 +1101,7 @@ void Generator::stream_bam(const ByteSink& sink) {
 			} else {
 				encoder.record(name, fragment[i], mate);
 			}
-			++records_written_;
+			++records_written;
 		}
 		if (c.separate_mates)
 			flush(false);
@@ -1104,7 +1112,7 @@ void Generator::stream_bam(const ByteSink& sink) {
 	};
 
 	double normal_debt = 0;
-	for (long n = 0; n < c.fragments; ++n) {
+	for (long n = 0; n < fragments; ++n) {
 		// ordinary pairs interleaved with the chimeric fragments
 		normal_debt += c.normal_multiplier;
 		while (normal_debt >= 1) {
@@ -1146,6 +1154,101 @@ void Generator::stream_bam(const ByteSink& sink) {
 	flush(true);
 	if (!encoder.buffer.empty())
 		sink(encoder.buffer.data(), encoder.buffer.size());
+}
+
+// One BGZF block (gzip member with a 'BC' extra field holding BSIZE, payload as a single stored deflate block) appended to `out`
+static void append_stored_block(std::vector<uint8_t>& out, const uint8_t* data, size_t length) {
+	uint8_t header[18] = { 31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 0, 0 };
+	const uint16_t bsize = (uint16_t) (18 + 5 + length + 8 - 1);
+	header[16] = bsize & 255; header[17] = bsize >> 8;
+	out.insert(out.end(), header, header + 18);
+	const uint8_t stored[5] = { 1, (uint8_t) (length & 255), (uint8_t) (length >> 8), (uint8_t) (~length & 255), (uint8_t) ((~length >> 8) & 255) };
+	out.insert(out.end(), stored, stored + 5);
+	out.insert(out.end(), data, data + length);
+	const uint32_t crc = crc32(crc32(0L, Z_NULL, 0), data, length);
+	const uint8_t trailer[8] = { (uint8_t) (crc & 255), (uint8_t) (crc >> 8 & 255), (uint8_t) (crc >> 16 & 255), (uint8_t) (crc >> 24 & 255), (uint8_t) (length & 255), (uint8_t) (length >> 8 & 255), 0, 0 };
+	out.insert(out.end(), trailer, trailer + 8);
+}
+
+// The same kind of sample written by several threads (the bench's 10^7..10^8 fragments: one thread makes ~0.2 M fragments/s).  The fragments are cut into
+// segments of SEGMENT fragments; segment k draws from its own generator (seeded by read seed and k), numbers its names from k * SEGMENT * 8 and is encoded
+// -- and, for BGZF, cut into stored blocks -- on its own, so the file does not depend on the number of threads.  Not the byte stream of write_bam().
+void Generator::write_bam_segmented(const std::string& path, unsigned int n_threads, bool bgzf) {
+	if (genes_.empty())
+		build_reference();
+	const long SEGMENT = 50000;
+	const size_t BLOCK = 65280;
+	const long n_segments = (config_.fragments + SEGMENT - 1) / SEGMENT;
+	FILE* f = fopen(path.c_str(), "wb");
+	if (f == NULL) throw std::runtime_error("cannot write " + path);
+	auto wrap = [&](const std::vector<uint8_t>& raw, std::vector<uint8_t>& out) {
+		if (!bgzf) { out = raw; return; }
+		out.clear(); out.reserve(raw.size() + raw.size() / 2000 + 64);
+		for (size_t at = 0; at < raw.size(); at += BLOCK) append_stored_block(out, raw.data() + at, std::min(BLOCK, raw.size() - at));
+	};
+	{
+		BamEncoder encoder;
+		encoder.header(contig_names_, contig_sequences_);
+		std::vector<uint8_t> out;
+		wrap(encoder.buffer, out);
+		if (fwrite(out.data(), 1, out.size(), f) != out.size()) throw std::runtime_error("short write");
+	}
+	std::vector<std::vector<uint8_t> > ready(n_segments), spare; // spare: buffers the writer is done with (fresh ~30 MB vectors cost more in page faults than the records in them)
+	std::vector<char> done(n_segments, 0);
+	std::vector<long> records(n_segments, 0);
+	std::mutex mutex; std::condition_variable changed;
+	long next_segment = 0, written = 0;
+	const long window = (long) n_threads * 2 + 2; // segments in flight: bounds the memory
+	std::exception_ptr failure;
+	std::vector<std::thread> threads;
+	for (unsigned int t = 0; t < std::max(1u, n_threads); ++t)
+		threads.push_back(std::thread([&] {
+			std::vector<uint8_t> raw, out;
+			while (true) {
+				long k;
+				{
+					std::unique_lock<std::mutex> lock(mutex);
+					changed.wait(lock, [&] { return failure || next_segment >= n_segments || next_segment < written + window; });
+					if (failure || next_segment >= n_segments) return;
+					k = next_segment++;
+					if (out.capacity() == 0 && !spare.empty()) { out.swap(spare.back()); spare.pop_back(); }
+				}
+				try {
+					Rng rng((config_.read_seed != 0 ? config_.read_seed : config_.seed) * 0x9E3779B97F4A7C15ULL + (uint64_t) k * 0xD1B54A32D192ED03ULL + 1);
+					raw.clear();
+					const long count = std::min(SEGMENT, config_.fragments - k * SEGMENT);
+					stream_records(rng, (uint64_t) k * SEGMENT * 8, count, [&raw](const uint8_t* data, size_t size) { raw.insert(raw.end(), data, data + size); }, records[k]);
+					wrap(raw, out);
+					std::unique_lock<std::mutex> lock(mutex);
+					ready[k].swap(out); done[k] = 1;
+					changed.notify_all();
+				} catch (...) { std::unique_lock<std::mutex> lock(mutex); failure = std::current_exception(); changed.notify_all(); return; }
+			}
+		}));
+	records_written_ = 0;
+	for (long k = 0; k < n_segments && !failure; ++k) {
+		std::vector<uint8_t> out;
+		{
+			std::unique_lock<std::mutex> lock(mutex);
+			changed.wait(lock, [&] { return failure || done[k]; });
+			if (failure) break;
+			out.swap(ready[k]);
+		}
+		if (fwrite(out.data(), 1, out.size(), f) != out.size()) { std::unique_lock<std::mutex> lock(mutex); failure = std::make_exception_ptr(std::runtime_error("short write")); changed.notify_all(); break; }
+		records_written_ += records[k];
+		std::unique_lock<std::mutex> lock(mutex);
+		out.clear(); spare.push_back(std::vector<uint8_t>()); spare.back().swap(out);
+		written = k + 1;
+		changed.notify_all();
+	}
+	{ std::unique_lock<std::mutex> lock(mutex); changed.notify_all(); }
+	for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+	if (bgzf) {
+		static const uint8_t eof_marker[28] = { 31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		fwrite(eof_marker, 1, 28, f);
+	}
+	fclose(f);
+	if (failure) std::rethrow_exception(failure);
 }
 
 void Generator::write_bam(const std::string& path) {
@@ -1191,14 +1294,15 @@ static void usage() {
 		"usage: gen_synth --out PREFIX [--seed N] [--fragments N] [--normal-mult X] [--contigs N] [--contig-len N]\n"
 		"                 [--genes-per-mb X] [--read-len N] [--junctions N] [--clip-min N] [--clip-max N]\n"
 		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--shuffle] [--separate-mates]\n"
-		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH]\n"
+		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH] [--threads N] [--bam-only]\n"
 		"writes PREFIX.fa PREFIX.gtf PREFIX.bam\n");
 }
 
 int main(int argc, char** argv) {
 	synth::Config config;
 	std::string out;
-	bool reference_only = false, rule_files = false;
+	bool reference_only = false, rule_files = false, bam_only = false;
+	unsigned int threads = 0; // > 0: the BAM file is written in segments by that many threads (another byte stream than the default one)
 	std::string raw_bam_path;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -1230,6 +1334,8 @@ int main(int argc, char** argv) {
 		else if (a == "--no-viral") config.viral = false;
 		else if (a == "--reference-only") reference_only = true;
 		else if (a == "--raw-bam-to") raw_bam_path = value();
+		else if (a == "--threads") threads = (unsigned int) atoi(value());
+		else if (a == "--bam-only") bam_only = true;
 		else { usage(); return 1; }
 	}
 	if (out.empty()) { usage(); return 1; }
@@ -1242,11 +1348,15 @@ int main(int argc, char** argv) {
 			generator.stream_bam([&](const uint8_t* data, size_t size) { if (fwrite(data, 1, size, raw) != size) throw std::runtime_error("short write"); });
 			fclose(raw);
 		} else {
-			generator.write_fasta(out + ".fa");
-			generator.write_gtf(out + ".gtf");
-			if (rule_files) generator.write_rule_files(out + ".blacklist.tsv", out + ".known_fusions.tsv");
-			if (!reference_only)
-				generator.write_bam(out + ".bam");
+			if (!bam_only) {
+				generator.write_fasta(out + ".fa");
+				generator.write_gtf(out + ".gtf");
+				if (rule_files) generator.write_rule_files(out + ".blacklist.tsv", out + ".known_fusions.tsv");
+			}
+			if (!reference_only) {
+				if (threads > 0) generator.write_bam_segmented(out + ".bam", threads, true);
+				else generator.write_bam(out + ".bam");
+			}
 		}
 		fprintf(stderr, "gen_synth: %zu contigs, %zu genes, %ld records\n", generator.contig_names().size(), generator.genes().size(), generator.records_written());
 	} catch (const std::exception& e) {

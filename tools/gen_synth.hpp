@@ -18,6 +18,8 @@
 
 namespace synth {
 
+struct Rng;
+
 struct Config {
 	uint64_t seed = 1;
 	uint64_t read_seed = 0; // non-zero: the reads are drawn from this seed while genome and annotation come from `seed` (shards of one sample)
@@ -76,12 +78,14 @@ public:
 	void write_rule_files(const std::string& blacklist_path, const std::string& known_fusions_path) const; // a blacklist and a known-fusions file derived from the junction table
 	void write_bam(const std::string& path);      // BGZF with stored (uncompressed) blocks, like STAR --outBAMcompression 0
 	void stream_bam(const ByteSink& sink);        // raw (un-BGZF'd) BAM stream for in-memory consumers
+	void write_bam_segmented(const std::string& path, unsigned int n_threads, bool bgzf); // large samples: segments of the fragments made by several threads
 	const std::vector<std::string>& contig_names() const { return contig_names_; }
 	const std::vector<std::string>& contig_sequences() const { return contig_sequences_; }
 	const std::vector<Gene>& genes() const { return genes_; }
 	long records_written() const { return records_written_; }
 	struct Impl;
 private:
+	void stream_records(Rng& rng, uint64_t first_serial, long fragments, const ByteSink& sink, long& records_written) const;
 	Config config_;
 	std::vector<std::string> contig_names_;
 	std::vector<std::string> contig_sequences_;
