@@ -405,7 +405,7 @@ int ahost_bam_open(ahost_session* session, const char* bam_path, int external_du
 		for (std::map<std::string, contig_t>::const_iterator contig = session->contigs.by_name.begin(); contig != session->contigs.by_name.end(); ++contig)
 			if (!session->assembly.has(contig->second) && is_interesting_contig(contig->first, session->options.interesting_contigs))
 				throw std::runtime_error("could not find sequence of contig '" + contig->first + "'");
-		session->build_genome_view();
+		if (session->genome_view.n_contigs != session->contigs.size() || session->genome_view.bases == NULL) session->build_genome_view(); // only when the header brought new contigs
 		const Coverage& coverage = session->ingest.coverage;
 		session->window_offset.assign(session->contigs.size() + 1, 0);
 		for (size_t contig = 0; contig < session->contigs.size(); ++contig)

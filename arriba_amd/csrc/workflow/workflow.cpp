@@ -6,6 +6,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <iostream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -32,10 +35,63 @@ struct Run {
 	Run(const arriba_workflow_options& o, arriba_workflow_report* r): options(o), report(r), host(nullptr), device(nullptr), dummy_genes(0), n_candidates(0), n_fragments(0), mapped_reads(0), device_ingest(false) { pieces[0] = pieces[1] = nullptr; }
 	~Run() { for (int k = 0; k < 2; ++k) if (pieces[k]) agpu_host_free(pieces[k]); if (device) agpu_destroy(device); if (host) ahost_close(host); }
 	void note(const char* stage, uint64_t count) {
+		progress(stage, count);
 		if (!report || report->n_stages >= sizeof(report->stages) / sizeof(report->stages[0])) return;
 		arriba_workflow_stage& entry = report->stages[report->n_stages++];
 		snprintf(entry.stage, sizeof(entry.stage), "%s", stage);
 		entry.count = count;
+	}
+	// the progress lines of the reference's main() (source/arriba.cpp:96-610), one per stage; a filter switched off with -f prints none, as there
+	static std::string time_string() { time_t now = time(0); char buffer[100]; strftime(buffer, sizeof(buffer), "[%Y-%m-%dT%X]", localtime(&now)); return buffer; }
+	void say(const std::string& text) const { if (options.log_to_stdout) std::cout << time_string() << " " << text << std::endl; }
+	void progress(const std::string& stage, uint64_t count) const {
+		if (!options.log_to_stdout) return;
+		const arriba_workflow_options& o = options;
+		std::ostringstream text; // (stream formatting of the numbers, as std::cout formats them in the reference)
+		unsigned filter = 0; const char* what = "remaining";
+		if (stage == "mark_multimappers") { text << "Marking multi-mapping alignments "; what = "marked"; }
+		else if (stage == "filter_duplicates") { filter = 1; text << "Filtering duplicates "; }
+		else if (stage == "filter_uninteresting_contigs") { filter = 30; text << "Filtering mates which do not map to interesting contigs (" << (o.interesting_contigs ? o.interesting_contigs : "1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 X Y AC_* NC_*") << ") "; }
+		else if (stage == "filter_viral_contigs") { filter = 31; text << "Filtering mates which only map to viral contigs (" << (o.viral_contigs ? o.viral_contigs : "AC_* NC_*") << ") "; }
+		else if (stage == "filter_top_expressed_viral_contigs") { filter = 32; text << "Filtering viral contigs with expression lower than the top " << o.top_viral_contigs << " "; }
+		else if (stage == "filter_low_coverage_viral_contigs") { filter = 33; text << "Filtering viral contigs with less than " << (o.viral_contig_min_covered_fraction * 100) << "% coverage "; }
+		else if (stage == "filter_proximal_read_through") { filter = 4; text << "Filtering read-through fragments with a distance <=" << o.device.min_read_through_distance << "bp "; }
+		else if (stage == "filter_inconsistently_clipped_mates") { filter = 2; text << "Filtering inconsistently clipped mates "; }
+		else if (stage == "filter_homopolymer") { filter = 3; text << "Filtering breakpoints adjacent to homopolymers >=" << o.device.homopolymer_length << "nt "; }
+		else if (stage == "filter_small_insert_size") { filter = 6; text << "Filtering fragments with small insert size "; }
+		else if (stage == "filter_long_gap") { filter = 7; text << "Filtering alignments with long gaps "; }
+		else if (stage == "filter_same_gene") { filter = 5; text << "Filtering fragments with both mates in the same gene "; }
+		else if (stage == "filter_hairpin") { filter = 8; text << "Filtering fusions arising from hairpin structures "; }
+		else if (stage == "filter_mismatches") { filter = 10; text << "Filtering reads with a mismatch p-value <=" << o.device.mismatch_pvalue_cutoff << " "; }
+		else if (stage == "filter_low_entropy") { filter = 36; text << "Filtering reads with low entropy (k-mer content >=" << (o.device.max_kmer_content * 100) << "%) "; }
+		else if (stage == "find_fusions") { text << "Finding fusions and counting supporting reads "; what = "total"; }
+		else if (stage == "mark_genomic_support") { text << "Marking fusions with support from whole-genome sequencing in '" << o.genomic_breakpoints_file << "' "; what = "marked"; }
+		else if (stage == "merge_adjacent_fusions") { filter = 23; text << "Merging adjacent fusion breakpoints "; }
+		else if (stage == "filter_multimappers") { filter = 9; text << "Filtering multi-mapping fusions by alignment score and read support "; }
+		else if (stage == "filter_non_coding_neighbors") { filter = 14; text << "Filtering fusions with both breakpoints in adjacent non-coding/intergenic regions "; }
+		else if (stage == "filter_intragenic_both_exonic") { filter = 15; text << "Filtering intragenic fusions with both breakpoints in exonic regions "; }
+		else if (stage == "filter_min_support") { filter = 17; text << "Filtering fusions with <" << o.device.min_support << " supporting reads "; }
+		else if (stage == "filter_relative_support") { filter = 12; text << "Filtering fusions with an e-value >=" << o.device.evalue_cutoff << " "; }
+		else if (stage == "recover_internal_tandem_duplication") { filter = 16; text << "Searching for internal tandem duplications <=" << o.device.max_itd_length << "bp with >=" << o.min_itd_support << " supporting reads and >=" << (o.min_itd_allele_fraction * 100) << "% allele fraction "; }
+		else if (stage == "filter_both_intronic") { filter = 13; text << "Filtering fusions with both breakpoints in intronic/intergenic regions "; }
+		else if (stage == "recover_known_fusions") { filter = 18; text << "Searching for known fusions in '" << o.known_fusions_file << "' "; }
+		else if (stage == "filter_in_vitro") { filter = 22; text << "Filtering in vitro-generated fusions between genes with an expression above the " << (o.high_expression_quantile * 100) << "% quantile "; }
+		else if (stage == "recover_both_spliced") { filter = 19; text << "Searching for fusions with spliced split reads "; }
+		else if (stage == "select_most_supported_breakpoints") { filter = 24; text << "Selecting best breakpoints from genes with multiple breakpoints "; }
+		else if (stage == "filter_marginal_read_through") { filter = 25; text << "Filtering read-through fusions with breakpoints near the gene boundary "; }
+		else if (stage == "recover_many_spliced") { filter = 28; text << "Searching for fusions with >=" << o.min_spliced_events << " spliced events "; }
+		else if (stage == "filter_no_genomic_support") { filter = 29; text << "Filtering low-confidence events with no support from WGS "; }
+		else if (stage == "filter_blacklisted_ranges") { filter = 20; text << "Filtering blacklisted fusions in '" << o.blacklist_file << "' "; }
+		else if (stage == "filter_short_anchor") { filter = 26; text << "Filtering fusions with anchors <=" << o.min_anchor_length << "nt "; }
+		else if (stage == "filter_end_to_end_fusions") { filter = 21; text << "Filtering end-to-end fusions with low support "; }
+		else if (stage == "filter_no_coverage") { filter = 27; text << "Filtering fusions with no coverage around the breakpoints "; }
+		else if (stage == "filter_homologs") { filter = 37; text << "Filtering genes with >=" << (o.max_homolog_identity * 100) << "% identity "; }
+		else if (stage == "filter_mismappers") { filter = 11; text << "Re-aligning chimeric reads to filter fusions with >=" << (o.device.max_mismapper_fraction * 100) << "% mis-mappers "; }
+		else if (stage == "recover_genomic_support") { filter = 34; text << "Searching for fusions with support from WGS "; }
+		else if (stage == "recover_isoforms") { filter = 35; text << "Searching for additional isoforms "; }
+		else return;
+		if (filter != 0 && !enabled(filter)) return;
+		std::cout << time_string() << " " << text.str() << "(" << what << "=" << count << ")" << std::endl;
 	}
 	bool enabled(unsigned filter) const { return options.device.filter_enabled[filter] != 0; }
 };
@@ -134,11 +190,13 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 	table.evalue = evalue.data(); table.confidence = confidence.data(); table.iteration_rank = iteration_rank.data(); table.read_filter = read_filter.data();
 	table.closest_genomic_breakpoint1 = closest1.data(); table.closest_genomic_breakpoint2 = closest2.data();
 	table.n_genes = n_genes; table.gene_contig = gene_contig.data(); table.gene_start = gene_start.data(); table.gene_end = gene_end.data();
-	if (run.options.tags_file) host_check(ahost_load_tags(run.host, run.options.tags_file));
-	if (run.options.protein_domains_file) host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file));
+	if (run.options.tags_file) { run.say(std::string("Loading tags from '") + run.options.tags_file + "'"); host_check(ahost_load_tags(run.host, run.options.tags_file)); }
+	if (run.options.protein_domains_file) { run.say(std::string("Loading protein domains from '") + run.options.protein_domains_file + "'"); host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file)); }
+	run.say(std::string("Writing fusions to file '") + run.options.output_file + "' ");
 	fetch_rows_for_writer(run, table, 0);
 	host_check(ahost_write_fusions(run.host, &table, run.options.output_file, 0, 1, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
 	if (run.options.discarded_output_file) {
+		run.say(std::string("Writing discarded fusions to file '") + run.options.discarded_output_file + "'");
 		if (run.options.print_extra_info_for_discarded_fusions) fetch_rows_for_writer(run, table, 1);
 		host_check(ahost_write_fusions(run.host, &table, run.options.discarded_output_file, 1, run.options.print_extra_info_for_discarded_fusions, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
 	}
@@ -148,6 +206,8 @@ void run_workflow(Run& run) {
 	const arriba_workflow_options& o = run.options;
 	if (!o.assembly_file || !o.gene_annotation_file || !o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
 	// source/arriba.cpp:97-130: assembly, annotation, index, chimeric alignments
+	run.say(std::string("Loading assembly from '") + o.assembly_file + "' ");
+	run.say(std::string("Loading annotation from '") + o.gene_annotation_file + "' ");
 	run.host = ahost_open(o.assembly_file, o.gene_annotation_file, o.interesting_contigs, o.viral_contigs, o.gtf_features);
 	if (!run.host) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
 	agpu_params params = o.device;
@@ -164,6 +224,7 @@ void run_workflow(Run& run) {
 		run.n_fragments = ahost_batch_view(run.host)->n;
 	}
 	run.mapped_reads = ahost_mapped_reads(run.host);
+	if (o.log_to_stdout) std::cout << Run::time_string() << " Reading chimeric alignments from '" << o.chimeric_bam_file << "' (total=" << run.n_fragments << ")" << std::endl;
 
 	// :141-325 multi-mappers, strandedness, annotation
 	uint64_t count = 0;
@@ -171,6 +232,9 @@ void run_workflow(Run& run) {
 	if (o.device.strandedness <= 2) params.strandedness = o.device.strandedness;
 	else if (run.device_ingest) { int verdict = 0; device_check(agpu_detect_strandedness(run.device, &verdict)); params.strandedness = (uint8_t) verdict; }
 	else params.strandedness = (uint8_t) ahost_detect_strandedness(run.host);
+	if (o.device.strandedness > 2) run.say(std::string("Detecting strandedness (") + (params.strandedness == 1 ? "yes" : params.strandedness == 2 ? "reverse" : "no") + ")");
+	if (params.strandedness != 0) run.say("Assigning strands to alignments ");
+	run.say("Annotating alignments ");
 	device_check(agpu_set_params(run.device, &params));
 	device_check(agpu_annotate(run.device, &run.dummy_genes));
 	// :327-350 duplicates, uninteresting and viral contigs (the per-contig verdicts are sequential host work)
@@ -198,14 +262,28 @@ void run_workflow(Run& run) {
 	// :366-409 the read-level filters
 	std::vector<uint64_t> remaining(AGPU_FILTER_COUNT);
 	device_check(agpu_read_filters_stage2(run.device, remaining.data()));
+	std::ostringstream fragment_length_line;
+	fragment_length_line << "Estimating fragment length ";
+	if (n_samples >= 10000) fragment_length_line << "(mate gap mean=" << mate_gap_mean << ", mate gap stddev=" << mate_gap_stddev << ", read length mean=" << read_length_mean << ")";
 	static const struct { unsigned id; const char* name; } read_filters[] = { { 1, "filter_duplicates" }, { 30, "filter_uninteresting_contigs" }, { 31, "filter_viral_contigs" }, { 32, "filter_top_expressed_viral_contigs" },
 		{ 33, "filter_low_coverage_viral_contigs" }, { 4, "filter_proximal_read_through" }, { 2, "filter_inconsistently_clipped_mates" }, { 3, "filter_homopolymer" }, { 6, "filter_small_insert_size" }, { 7, "filter_long_gap" },
 		{ 5, "filter_same_gene" }, { 8, "filter_hairpin" }, { 10, "filter_mismatches" }, { 36, "filter_low_entropy" } };
-	for (size_t f = 0; f < sizeof(read_filters) / sizeof(read_filters[0]); ++f) run.note(read_filters[f].name, remaining[read_filters[f].id]);
+	for (size_t f = 0; f < sizeof(read_filters) / sizeof(read_filters[0]); ++f) {
+		if (f == 5) run.say(fragment_length_line.str()); // the estimate sits between the contig filters and the rest (source/arriba.cpp:352)
+		run.note(read_filters[f].name, remaining[read_filters[f].id]);
+	}
 
 	// :411-460 candidates
-	device_check(agpu_find_fusions(run.device, max_mate_gap, &count)); run.note("find_fusions", count);
+	device_check(agpu_find_fusions(run.device, max_mate_gap, &count));
 	run.n_candidates = count;
+	if (o.log_to_stdout) { // the reference's "(total=N)" counts the candidates with at least one read that no filter discarded (source/fusions.cpp:467-472)
+		std::vector<uint8_t> filter(count > 0 ? count : 1);
+		device_check(agpu_get_candidates(run.device, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, filter.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+		uint64_t unfiltered = 0;
+		for (uint64_t c = 0; c < count; ++c) unfiltered += filter[c] == 0;
+		run.progress("find_fusions", unfiltered);
+	}
+	if (run.report && run.report->n_stages < sizeof(run.report->stages) / sizeof(run.report->stages[0])) { arriba_workflow_stage& entry = run.report->stages[run.report->n_stages++]; snprintf(entry.stage, sizeof(entry.stage), "find_fusions"); entry.count = count; }
 	if (!run.device_ingest) device_check(agpu_upload_coverage(run.device, ahost_coverage_view(run.host))); // (the device ingest built coverage_t in place)
 	if (o.genomic_breakpoints_file) {
 		const agpu_genomic_breakpoint* variants = nullptr; uint32_t n_variants = 0;
@@ -216,8 +294,13 @@ void run_workflow(Run& run) {
 	uint64_t discarded_reads = 0, discarded[3];
 	device_check(agpu_filter_multimappers(run.device, &count, &discarded_reads)); run.note("filter_multimappers", count);
 	device_check(agpu_candidate_iteration_order(run.device, nullptr)); // hazard H2: the order in which the reference's container is walked, kept on the device
+	run.say("Estimating expected number of fusions by random chance (e-value) ");
 	device_check(agpu_estimate_expected_fusions(run.device, run.mapped_reads, nullptr));
 	device_check(agpu_filter_candidate_predicates(run.device, discarded));
+	if (o.log_to_stdout) { // the three predicates run in one kernel; their counts follow from what each discarded
+		const uint64_t before = count; // unfiltered candidates behind filter_multimappers
+		run.progress("filter_non_coding_neighbors", before - discarded[0]); run.progress("filter_intragenic_both_exonic", before - discarded[0] - discarded[1]); run.progress("filter_min_support", before - discarded[0] - discarded[1] - discarded[2]);
+	}
 	device_check(agpu_filter_relative_support(run.device, &count)); run.note("filter_relative_support", count);
 	// :463-544 the candidate-level filters (each stage skips itself when its filter is switched off with -f)
 	device_check(agpu_recover_internal_tandem_duplication(run.device, o.min_itd_support, o.min_itd_allele_fraction, &count)); run.note("recover_internal_tandem_duplication", count);
@@ -246,6 +329,7 @@ void run_workflow(Run& run) {
 	device_check(agpu_filter_no_coverage(run.device, &count)); run.note("filter_no_coverage", count);
 	// :546-565 the k-mer index and the two filters that use it; padding as in :552 (float arithmetic, truncated)
 	uint64_t n_positions = 0;
+	run.say("Indexing gene sequences ");
 	device_check(agpu_make_kmer_index(run.device, (int32_t) ((float) max_mate_gap + 2.0f * read_length_mean), &n_positions));
 	device_check(agpu_filter_homologs(run.device, o.max_homolog_identity, &count)); run.note("filter_homologs", count);
 	device_check(agpu_filter_mismappers(run.device, max_mate_gap, &count, &discarded_reads)); run.note("filter_mismappers", count);
@@ -253,6 +337,7 @@ void run_workflow(Run& run) {
 	if (o.genomic_breakpoints_file && run.enabled(F_genomic_support)) { device_check(agpu_recover_genomic_support(run.device, &count)); run.note("recover_genomic_support", count); }
 	if ((o.genomic_breakpoints_file && run.enabled(F_genomic_support)) || run.enabled(F_many_spliced)) { device_check(agpu_select_most_supported_breakpoints(run.device, &count)); run.note("select_most_supported_breakpoints", count); }
 	device_check(agpu_recover_isoforms(run.device, &count)); run.note("recover_isoforms", count);
+	run.say("Assigning confidence scores to events ");
 	write_output_files(run, max_mate_gap);
 }
 

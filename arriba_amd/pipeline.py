@@ -184,7 +184,9 @@ class DevicePipeline(object):
             raise host_error()
         buffers = []
         try:
-            self._check(self.api.upload_genome(self.ctx, self.session.genome_view))  # the contigs of the BAM header are part of the run now
+            if getattr(self, "_genome_contigs", None) != config.n_contigs:
+                self._check(self.api.upload_genome(self.ctx, self.session.genome_view))  # the contigs of the BAM header are part of the run now
+                self._genome_contigs = config.n_contigs
             self._check(self.api.ingest_begin(self.ctx, byref(config)))
             block_capacity = piece_bytes // 4096 + 16
             for _ in range(2):

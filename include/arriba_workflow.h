@@ -1,7 +1,7 @@
 /* include/arriba_workflow.h -- the reference's main() behind its option parser (source/arriba.cpp:84-615) as one call over the two C ABIs
  * (arriba_host.h: loaders, ingest, sequential scalar stages, output writer; arriba_gpu.h: the stages on the MI355X).  The structure mirrors
- * options_t (source/options.hpp); arriba_workflow_default_options fills in the defaults of source/options.cpp:71-107.  Not a command line:
- * parsing argv stays with the caller. */
+ * options_t (source/options.hpp); arriba_workflow_default_options fills in the defaults of source/options.cpp:71-107.  The command line of the
+ * reference (source/options.cpp:270-481) in front of it is arriba_amd/csrc/workflow/main.cpp -> arriba_amd/lib/arriba_gpu_workflow. */
 #ifndef ARRIBA_WORKFLOW_H
 #define ARRIBA_WORKFLOW_H 1
 
@@ -41,6 +41,7 @@ typedef struct {
 	uint8_t print_extra_info_for_discarded_fusions; /* -X */
 	uint8_t fill_sequence_gaps;           /* -I */
 	int device_index;                     /* which GPU */
+	uint8_t log_to_stdout;                /* 1: the progress lines of the reference's main() ("[time] Filtering duplicates (remaining=N)", source/arriba.cpp:96-610) go to stdout */
 	uint8_t host_ingest;                  /* 0 (default): read_chimeric_alignments runs on the device (agpu_ingest_*), the host feeds the bytes of the file;
 	                                         1: the multi-threaded host ingest builds the batch and uploads it */
 } arriba_workflow_options;

@@ -573,6 +573,51 @@ def test_cpp_workflow_driver_over_the_c_abis(name, dataset_files, emu_api, tmp_p
         assert open(mine).read() == gzip.open(os.path.join(conftest.golden_dir(name), reference), "rt").read(), reference
 
 
+def test_command_line_of_the_reference(dataset_files, emu_api, tmp_path):
+    """arriba_gpu_workflow with the reference's flags (source/options.cpp:282: -x -g -a -o -O -b -k -t -p -d -f ...), the BAM file on standard input as in run_arriba.sh:42:
+    the progress lines equal the reference's log line by line (text and counts, time stamps aside), both output files equal its files; the reference's checks of the
+    arguments end with "ERROR: ..." and exit code 1"""
+    import gzip
+    import re
+    import subprocess
+    directory = os.path.join(conftest.ROOT, "tests", "emu")
+    subprocess.run(["make", "-s", "-C", directory, "workflow_on_harness"], check=True)
+    driver = os.path.join(directory, "workflow_on_harness")
+    prefix = dataset_files("wgs8k")
+    golden = conftest.golden_dir("wgs8k")
+    outputs = [str(tmp_path / "fusions.tsv"), str(tmp_path / "discarded.tsv")]
+    command = [driver, "-x", "/dev/stdin", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", outputs[0], "-O", outputs[1], "-b", prefix + ".blacklist.tsv", "-k", prefix + ".known_fusions.tsv",
+               "-t", prefix + ".tags.tsv", "-p", prefix + ".protein_domains.gff3", "-d", prefix + ".sv.tsv"]
+    result = subprocess.run(command, stdin=open(prefix + ".bam", "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert result.returncode == 0, result.stderr[-2000:]
+    for mine, reference in zip(outputs, ("fusions.tsv.gz", "discarded.tsv.gz")):
+        assert open(mine).read() == gzip.open(os.path.join(golden, reference), "rt").read(), reference
+    # (the golden log merges stdout and stderr: a warning lands inside the line that was being written; quoted paths differ between the runs)
+    def progress_lines(text):
+        text = re.sub(r"=(?:WARNING:[^\n]*\n)+", "=", text)
+        text = re.sub(r" WARNING:[^\n]*", "", text)
+        lines = [re.sub(r"'[^']*'", "''", re.sub(r"^\[[^\]]*\] ", "", line)).rstrip() for line in text.splitlines()]
+        return [line for line in lines if "(remaining=" in line or "(total=" in line or "(marked=" in line or line.startswith("Detecting strandedness") or line.startswith("Estimating fragment length")]
+    mine, theirs = progress_lines(result.stdout), progress_lines(open(os.path.join(golden, "reference.log")).read())
+    assert mine == theirs and len(mine) > 40
+    assert result.stdout.rstrip().splitlines()[-1].split("] ", 1)[1].startswith("Done (elapsed time=00:00:")
+    # -f: a filter that is off prints no line; unknown names are errors
+    quiet = subprocess.run(command[:11] + ["-f", "blacklist,mismappers,homologs", "-X", "-I", "-u", "-U", "100"], stdin=open(prefix + ".bam", "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert quiet.returncode == 0 and "Re-aligning chimeric reads" not in quiet.stdout and "Filtering genes with" not in quiet.stdout and "Filtering duplicates" in quiet.stdout
+    for arguments, message in ((["-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", outputs[0], "-f", "blacklist"], "missing mandatory option -x"),
+                               (command[:9], "filter 'blacklist' enabled, but missing option -b"),
+                               (command[:9] + ["-f", "no_such_filter"], "invalid argument to option -f: no_such_filter"),
+                               (command[:9] + ["-f", "blacklist", "-E", "-1"], "argument to -E must be greater than 0"),
+                               (command[:9] + ["-f", "blacklist", "-f", "duplicates"], "option -f specified too often"),
+                               (command[:9] + ["-f", "blacklist", "-U", "40000"], "argument to -U must be an integer between 1 and 32767"),
+                               (command[:9] + ["-f", "blacklist", "-q"], "unknown option: -q"),
+                               (command[:9] + ["-f", "blacklist", "-b"], "option -b requires an argument"),
+                               (command[:3] + ["-g", str(tmp_path / "none.gtf")], "file not found/readable"),
+                               (command[:9] + ["-f", "blacklist", "-c", prefix + ".bam"], "option -c")):
+        failed = subprocess.run([driver] + arguments[1:] if arguments[0] == driver else [driver] + arguments, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        assert failed.returncode == 1 and failed.stderr.startswith("ERROR: ") and message in failed.stderr, (arguments, failed.stderr)
+
+
 def test_cpp_workflow_library_fails_loudly_without_a_gpu(built, dataset_files, tmp_path):
     """libarriba_workflow.so exports what include/arriba_workflow.h declares; without a GPU arriba_gpu_workflow stops with the device library's error, no CPU fallback"""
     import ctypes
