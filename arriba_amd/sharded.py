@@ -112,6 +112,10 @@ class ShardedPipeline(DevicePipeline):
 
     def annotate_alignments(self, strandedness=None):
         if strandedness is None:  # the vote looks at the first fragments of the sample in name order: rank 0 decides
+            if getattr(self, "independent_sessions", False):
+                # every rank ingested its own shard: rank 0's session sees only the first shard, which may hold fewer than the 100 informative split reads the
+                # reference's vote wants while the whole sample has them (source/read_stats.cpp:94-143).  The vote needs the sample: ask the caller.
+                raise ArribaError("ERROR: strandedness must be given (yes/no/reverse) when every rank ingests its own shard: the automatic vote looks at the first fragments of the whole sample")
             value = torch.tensor([self.session.detect_strandedness() if self.rank == 0 else 0], dtype=torch.int64, device=self.collective_device)
             dist.broadcast(value, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             strandedness = int(value.item())

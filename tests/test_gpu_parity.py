@@ -501,3 +501,48 @@ def test_workflow_from_the_bam_file_through_the_device_ingest(built, dataset_fil
         os.makedirs(str(tmp_path / "options"))
         stages = parity.check_workflow_with_non_default_options(60000, str(tmp_path / "options"), device_ingest=True)
         assert dict(stages)["mark_genomic_support"] > 1000 and stages[-1][1] > 200
+
+
+def _run_plain_reference(prefix, directory, extra=()):
+    """the oracle build of the reference without the dump hooks (oracle/_ref/arriba_ref): log + both output files"""
+    import re
+    import subprocess
+    os.makedirs(directory, exist_ok=True)
+    command = [datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv", "-f", "blacklist"] + list(extra)
+    result = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert result.returncode == 0, result.stdout[-2000:]
+    with open(os.path.join(directory, "reference.log"), "w") as out:
+        out.write(re.sub(r"\[\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\] ", "", result.stdout))
+
+
+def test_workflow_at_config_scale_against_the_live_reference(built, tmp_path):
+    """BASELINE.json config 2 at half size -- 5 M chimeric fragments of exactly the workload bench.py times (13 M BAM records, 2.7 GB) -- through the whole workflow
+    on the GPU, read_chimeric_alignments included, against the unmodified reference run on the same files: every "(remaining=N)" of its log, fusions.tsv and
+    discarded.tsv byte for byte.  (A launch-grid bug once skipped 95 % of a 10 M batch while every smaller test was green: profiles/README.md.)"""
+    import subprocess
+    import bench
+    if not os.path.exists(datasets.ARRIBA_REF):
+        pytest.skip("oracle/_ref/arriba_ref did not travel with the repository")
+    fragments = int(os.environ.get("ARRIBA_SCALE_TEST_FRAGMENTS", "5000000"))
+    prefix = str(tmp_path / "scale")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32"] + bench.workload_args(fragments, 1000), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    _run_plain_reference(prefix, str(tmp_path / "reference"))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True)
+    assert dict(stages)["find_fusions"] > fragments // 5 and stages[-1][1] > 100
+
+
+def test_mismapper_stress_at_scale_against_the_live_reference(built, tmp_path):
+    """BASELINE.json config 3 at 1 M fragments: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (no read is subsampled away before
+    filter_mismappers): log counts and both output files against the unmodified reference"""
+    import subprocess
+    import bench
+    if not os.path.exists(datasets.ARRIBA_REF):
+        pytest.skip("oracle/_ref/arriba_ref did not travel with the repository")
+    fragments = int(os.environ.get("ARRIBA_STRESS_TEST_FRAGMENTS", "1000000"))
+    prefix = str(tmp_path / "stress")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32"] + bench.workload_args(fragments, 1000, stress=True), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    _run_plain_reference(prefix, str(tmp_path / "reference"), extra=["-U", "32767"])
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True, params={"subsampling_threshold": 32767})
+    assert dict(stages)["filter_mismappers"] > 1000
