@@ -134,6 +134,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "find_fusions": (c_int, [ctx, c_int32, POINTER(c_uint64)]),
         "get_candidates": (c_int, [ctx] + [c_void_p] * 13),
         "get_candidate_read_lists": (c_int, [ctx, c_void_p, c_uint64, POINTER(c_uint64)]),
+        "get_candidate_read_lists_of": (c_int, [ctx, c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
         "get_discordant_swapped": (c_int, [ctx, c_void_p]),
         "get_filters": (c_int, [ctx, c_void_p]),
         "get_alignment_bits": (c_int, [ctx, c_int, c_void_p]),

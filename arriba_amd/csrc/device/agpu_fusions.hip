@@ -559,6 +559,51 @@ extern "C" int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uin
 	return AGPU_OK;
 }
 
+// the read lists of some candidates only (the writer of the output files needs those of the candidates it prints, a few thousand of millions)
+__global__ void list_sizes_of_kernel(CandidateTable t, const uint32_t* candidates, uint32_t n, uint32_t* sizes) {
+	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k > 3 * n) return;
+	if (k == 3 * n) { sizes[k] = 0; return; }
+	const uint64_t at = 3 * (uint64_t) candidates[k / 3] + k % 3;
+	sizes[k] = t.list_offset[at + 1] - t.list_offset[at];
+}
+__global__ void list_copy_of_kernel(CandidateTable t, const uint32_t* candidates, const uint32_t* compact_offset, uint32_t* reads) {
+	const uint32_t k = blockIdx.x; // one workgroup per list
+	const uint64_t at = 3 * (uint64_t) candidates[k / 3] + k % 3;
+	const uint32_t begin = t.list_offset[at], size = t.list_offset[at + 1] - begin, target = compact_offset[k];
+	for (uint32_t e = threadIdx.x; e < size; e += BLOCK) reads[target + e] = t.read_lists[begin + e];
+}
+
+extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint32_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total) {
+	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (n > 0x3FFFFFFFull) { set_last_error("too many candidates"); return AGPU_ERR_INVALID; }
+	for (uint64_t k = 0; k < n; ++k) if (candidates[k] >= ctx->n_candidates) { set_last_error("candidate index out of range"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	if (n == 0) { if (list_offset) list_offset[0] = 0; if (total) *total = 0; return AGPU_OK; }
+	DeviceBuffer& ids = ctx->scratch("lists_of.ids"); DeviceBuffer& sizes = ctx->scratch("lists_of.sizes"); DeviceBuffer& offsets = ctx->scratch("lists_of.offsets"); DeviceBuffer& out = ctx->scratch("lists_of.reads"); DeviceBuffer& scratch = ctx->scratch("lists_of.rocprim");
+	ALLOC(ids, n * 4); ALLOC(sizes, (3 * n + 1) * 4); ALLOC(offsets, (3 * n + 1) * 4);
+	HIP_CHECK(hipMemcpyAsync(ids.ptr, candidates, n * 4, hipMemcpyHostToDevice, s));
+	list_sizes_of_kernel<<<(unsigned int) ((3 * n + 1 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), (uint32_t) n, sizes.as<uint32_t>());
+	size_t bytes = 0;
+	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, sizes.as<uint32_t>(), offsets.as<uint32_t>(), 0u, 3 * n + 1, rocprim::plus<uint32_t>(), s));
+	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+	HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, sizes.as<uint32_t>(), offsets.as<uint32_t>(), 0u, 3 * n + 1, rocprim::plus<uint32_t>(), s));
+	uint32_t entries = 0;
+	HIP_CHECK(hipMemcpyAsync(&entries, offsets.as<uint32_t>() + 3 * n, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (total) *total = entries;
+	if (list_offset) HIP_CHECK(hipMemcpy(list_offset, offsets.ptr, (3 * n + 1) * 4, hipMemcpyDeviceToHost));
+	if (reads && entries > 0) {
+		if (capacity < entries) { set_last_error("capacity too small for the read lists"); return AGPU_ERR_INVALID; }
+		ALLOC(out, (size_t) entries * 4);
+		list_copy_of_kernel<<<(unsigned int) (3 * n), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), offsets.as<uint32_t>(), out.as<uint32_t>());
+		HIP_CHECK(hipMemcpyAsync(reads, out.ptr, (size_t) entries * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	return AGPU_OK;
+}
+
 extern "C" int agpu_get_fusion_stats(agpu_ctx* ctx, uint64_t* stats) {
 	if (!ctx || !ctx->fusions_done || !stats) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
 	stats[0] = ctx->n_emissions; stats[1] = ctx->n_candidates; stats[2] = ctx->n_list_entries; stats[3] = ctx->n_discordant_emissions; stats[4] = ctx->n_queued_buckets;

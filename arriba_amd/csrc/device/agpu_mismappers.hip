@@ -25,7 +25,7 @@ using namespace agpu;
 namespace {
 
 const int BLOCK = 256;
-const int ALIGN_BLOCK = 64; // the frame stack of align() lives in scratch: keep the workgroups small
+const int ALIGN_BLOCK = 128;
 inline unsigned int grid_for(uint64_t n, int block = BLOCK) { return (unsigned int) ((n + block - 1) / block); }
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
@@ -134,18 +134,21 @@ __global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* re
 	}
 }
 
-// one wavefront per read: the lanes try 64 read positions of a seed search at once (AlignRunner); everything else is wave-uniform
+// One thread per read: the reference's seed-and-extend search (mismapper_core.hpp) is a chain of dependent look-ups -- k-mer table, position list, genome bases --
+// whose length differs from read to read by orders of magnitude, so the lanes of a wavefront are best spent on 64 different reads (a wavefront per read, its lanes
+// on 64 read positions of one seed search, kept 63 lanes waiting for the longest attempt: 3.6 s for 1.1 M reads; this form: the same verdicts, every lane busy).
+// The frame stack of align() lives in scratch memory (ALIGN_MAX_DEPTH frames per lane, almost always only the first two are touched).
 __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap, unsigned int* discarded) {
-	const uint32_t j = blockIdx.x; // ALIGN_BLOCK == 64: one wavefront per workgroup
-	if (j >= n_jobs) return;
-	AlignFrame stack[ALIGN_MAX_DEPTH];
-	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = ALIGN_BLOCK;
-	const uint32_t read = jobs[j];
-	const bool mismapper = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
-	if (mismapper && threadIdx.x == 0) {
-		b.filter[read] = FILTER_mismappers;
-		atomicAdd(discarded, 1u);
+	__shared__ uint32_t block_sum;
+	const uint32_t j = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
+	uint32_t mine = 0;
+	if (j < n_jobs) {
+		AlignFrame stack[ALIGN_MAX_DEPTH];
+		AlignRunner runner; runner.stack = stack; runner.lane = 0; runner.lanes = 1;
+		const uint32_t read = jobs[j];
+		if (is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner)) { b.filter[read] = FILTER_mismappers; mine = 1; }
 	}
+	block_tally(mine, discarded, &block_sum);
 }
 
 __global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, bool count_only, unsigned int* remaining) {
@@ -299,7 +302,7 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (n_jobs > 0) {
 			KernelTimer timer(ctx, "mismapper_verdict_kernel", (uint64_t) n_jobs * 300);
-			mismapper_verdict_kernel<<<n_jobs, ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
+			mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
 		}
 		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
 		  mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, false, device_counters + 2); }

@@ -4,6 +4,10 @@
 // string formatting of a few thousand (fusions.tsv) to a few hundred thousand (discarded.tsv) rows.
 #include "arriba_host.h"
 #include "output.h"
+#include <atomic>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include "transcript.h"
 
 #include <algorithm>
@@ -279,7 +283,7 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 	std::string text = "#gene1\tgene2\tstrand1(gene/fusion)\tstrand2(gene/fusion)\tbreakpoint1\tbreakpoint2\tsite1\tsite2\ttype\tsplit_reads1\tsplit_reads2\tdiscordant_mates\tcoverage1\tcoverage2\tconfidence\treading_frame\ttags\t"
 	                   "retained_protein_domains\tclosest_genomic_breakpoint1\tclosest_genomic_breakpoint2\tgene_id1\tgene_id2\ttranscript_id1\ttranscript_id2\tdirection1\tdirection2\tfilters\tfusion_transcript\tpeptide_sequence\tread_identifiers\n";
 	static const char* const confidence_names[] = { "low", "medium", "high", "high" };
-	for (size_t r = 0; r < rows.size(); ++r) {
+	auto format_row = [&](size_t r, std::string& text) {
 		const Fusion& f = rows[r];
 		std::string site_5 = writer.fusion_site(f.gene1, f.spliced1, f.exonic1, f.contig1, f.breakpoint1), site_3 = writer.fusion_site(f.gene2, f.spliced2, f.exonic2, f.contig2, f.breakpoint2);
 		// the 5' gene comes first
@@ -374,7 +378,41 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			}
 		} else text += ".";
 		text += "\n";
-		if (text.size() > (1u << 20)) { if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fclose(out); throw std::runtime_error("failed to write to file"); } text.clear(); }
+	};
+	// the rows are independent of each other: all threads format a chunk of them (the fusion transcripts from the read pileups are the expensive part), the
+	// chunk is written in order, the warnings of a row come out in row order as well
+	const size_t CHUNK = 16384;
+	unsigned int n_threads = std::thread::hardware_concurrency();
+	if (const char* setting = getenv("ARRIBA_WRITER_THREADS")) if (atoi(setting) > 0) n_threads = (unsigned int) atoi(setting);
+	n_threads = std::max(1u, std::min(n_threads, 64u));
+	std::vector<std::string> row_text, row_warnings;
+	for (size_t chunk_begin = 0; chunk_begin < rows.size(); chunk_begin += CHUNK) {
+		const size_t chunk_end = std::min(rows.size(), chunk_begin + CHUNK), count = chunk_end - chunk_begin;
+		row_text.assign(count, std::string()); row_warnings.assign(count, std::string());
+		std::atomic<size_t> next(0);
+		std::exception_ptr failure;
+		std::mutex failure_mutex;
+		auto work = [&] {
+			for (size_t k = next.fetch_add(1); k < count; k = next.fetch_add(1)) {
+				transcript_warnings = &row_warnings[k];
+				try { format_row(chunk_begin + k, row_text[k]); }
+				catch (...) { std::lock_guard<std::mutex> lock(failure_mutex); if (!failure) failure = std::current_exception(); }
+				transcript_warnings = NULL;
+			}
+		};
+		if (n_threads == 1 || count < 4) work();
+		else {
+			std::vector<std::thread> threads;
+			for (unsigned int t = 0; t < std::min<size_t>(n_threads, count); ++t) threads.push_back(std::thread(work));
+			for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+		}
+		if (failure) { fclose(out); std::rethrow_exception(failure); }
+		for (size_t k = 0; k < count; ++k) {
+			if (!row_warnings[k].empty()) fputs(row_warnings[k].c_str(), stderr);
+			text += row_text[k];
+		}
+		if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fclose(out); throw std::runtime_error("failed to write to file"); }
+		text.clear();
 	}
 	const bool ok = fwrite(text.data(), 1, text.size(), out) == text.size();
 	if (fclose(out) != 0 || !ok) throw std::runtime_error("failed to write to file");

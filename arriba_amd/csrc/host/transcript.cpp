@@ -17,6 +17,9 @@
 
 namespace arriba {
 
+thread_local std::string* transcript_warnings = NULL; // set by the output writer around the formatting of one row
+
+
 namespace {
 
 enum { CIGAR_MATCH = 0, CIGAR_INSERTION = 1, CIGAR_DELETION = 2, CIGAR_SKIP = 3, CIGAR_SOFT_CLIP = 4, CIGAR_HARD_CLIP = 5, CIGAR_EQUAL = 7, CIGAR_DIFF = 8 };
@@ -552,7 +555,9 @@ void reference_protein_of(const TranscriptInput& in, int start_exon, std::map<po
 			protein[position] = amino_acid_of(codon);
 			codon.clear();
 			if (!warned && position < e.coding_region_end && position > e.coding_region_start && protein[position] == '*') {
-				fprintf(stderr, "WARNING: encountered early stop codon in transcript %s at amino acid %zu (error in GTF file?) => predicted peptide sequence may be wrong\n", a.transcripts[e.transcript].name.c_str(), protein.size());
+				char text[512];
+				snprintf(text, sizeof(text), "WARNING: encountered early stop codon in transcript %s at amino acid %zu (error in GTF file?) => predicted peptide sequence may be wrong\n", a.transcripts[e.transcript].name.c_str(), protein.size());
+				if (transcript_warnings != NULL) *transcript_warnings += text; else fputs(text, stderr); // (rows are formatted by several threads: the writer prints the warnings in row order)
 				warned = true;
 			}
 		}

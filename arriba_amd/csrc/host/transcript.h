@@ -6,6 +6,8 @@
 
 namespace arriba {
 
+extern thread_local std::string* transcript_warnings; // where the warnings of the functions below go while a row is formatted (NULL: stderr)
+
 struct TranscriptInput { const Batch& batch; const uint8_t* read_filter; const Assembly& assembly; const Annotation& annotation; const FlatIndex& exon_index; };
 struct FusionEvent { // one candidate with its read lists
 	contig_t contig_of_gene1, contig_of_gene2; // gene->contig: where the reference bases of the pileups are looked up

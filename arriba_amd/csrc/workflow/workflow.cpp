@@ -158,19 +158,22 @@ void fetch_rows_for_writer(Run& run, const ahost_fusion_table& table, int write_
 	host_check(ahost_set_batch_rows(run.host, &rows, count > 0 ? fragments.data() : nullptr));
 }
 
-// the output files: the device's results brought back once, formatted by the host library (source/arriba.cpp:586-610)
+// the output files: the device's results brought back, formatted by the host library (source/arriba.cpp:586-610).  Only the candidates a file will hold
+// travel with their read lists: fusions.tsv holds the few thousand that passed every filter, of millions.
+template <class T> std::vector<T> pick(const std::vector<T>& column, const std::vector<uint32_t>& rows) {
+	std::vector<T> picked(rows.size() > 0 ? rows.size() : 1);
+	for (size_t k = 0; k < rows.size(); ++k) picked[k] = column[rows[k]];
+	return picked;
+}
+
 void write_output_files(Run& run, int32_t max_mate_gap) {
 	const size_t n = (size_t) run.n_candidates, n1 = n > 0 ? n : 1;
-	std::vector<uint32_t> gene1(n1), gene2(n1), contigs(n1), flags(n1), split_reads1(n1), split_reads2(n1), discordant_mates(n1), list_offset(3 * n + 1), iteration_rank(n1);
-	std::vector<int32_t> breakpoint1(n1), breakpoint2(n1), anchor1(n1), anchor2(n1), closest1(n1), closest2(n1);
+	std::vector<uint32_t> gene1(n1), gene2(n1), contigs(n1), flags(n1), split_reads1(n1), split_reads2(n1), discordant_mates(n1), iteration_rank(n1);
+	std::vector<int32_t> breakpoint1(n1), breakpoint2(n1), closest1(n1), closest2(n1);
 	std::vector<uint8_t> filter(n1), confidence(n1);
 	std::vector<float> evalue(n1);
 	device_check(agpu_get_candidates(run.device, gene1.data(), gene2.data(), contigs.data(), breakpoint1.data(), breakpoint2.data(), flags.data(), filter.data(), split_reads1.data(), split_reads2.data(),
-	                                 discordant_mates.data(), anchor1.data(), anchor2.data(), list_offset.data()));
-	uint64_t total = 0;
-	device_check(agpu_get_candidate_read_lists(run.device, nullptr, 0, &total));
-	std::vector<uint32_t> read_lists(total > 0 ? total : 1);
-	device_check(agpu_get_candidate_read_lists(run.device, read_lists.data(), total, &total));
+	                                 discordant_mates.data(), nullptr, nullptr, nullptr));
 	device_check(agpu_get_evalues(run.device, evalue.data()));
 	device_check(agpu_assign_confidence(run.device, confidence.data())); // behind the 'isoforms' filter: recovered isoforms are scored anew
 	device_check(agpu_candidate_iteration_order(run.device, iteration_rank.data()));
@@ -181,24 +184,36 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 	std::vector<uint16_t> gene_contig(n_genes > 0 ? n_genes : 1);
 	std::vector<int32_t> gene_start(gene_contig.size()), gene_end(gene_contig.size());
 	device_check(agpu_get_gene_table(run.device, 0, n_genes, gene_contig.data(), gene_start.data(), gene_end.data(), nullptr, nullptr));
-
-	ahost_fusion_table table;
-	memset(&table, 0, sizeof(table));
-	table.n_candidates = (uint32_t) n;
-	table.gene1 = gene1.data(); table.gene2 = gene2.data(); table.contigs = contigs.data(); table.breakpoint1 = breakpoint1.data(); table.breakpoint2 = breakpoint2.data(); table.flags = flags.data(); table.filter = filter.data();
-	table.split_reads1 = split_reads1.data(); table.split_reads2 = split_reads2.data(); table.discordant_mates = discordant_mates.data(); table.list_offset = list_offset.data(); table.read_lists = read_lists.data();
-	table.evalue = evalue.data(); table.confidence = confidence.data(); table.iteration_rank = iteration_rank.data(); table.read_filter = read_filter.data();
-	table.closest_genomic_breakpoint1 = closest1.data(); table.closest_genomic_breakpoint2 = closest2.data();
-	table.n_genes = n_genes; table.gene_contig = gene_contig.data(); table.gene_start = gene_start.data(); table.gene_end = gene_end.data();
 	if (run.options.tags_file) { run.say(std::string("Loading tags from '") + run.options.tags_file + "'"); host_check(ahost_load_tags(run.host, run.options.tags_file)); }
 	if (run.options.protein_domains_file) { run.say(std::string("Loading protein domains from '") + run.options.protein_domains_file + "'"); host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file)); }
-	run.say(std::string("Writing fusions to file '") + run.options.output_file + "' ");
-	fetch_rows_for_writer(run, table, 0);
-	host_check(ahost_write_fusions(run.host, &table, run.options.output_file, 0, 1, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
-	if (run.options.discarded_output_file) {
-		run.say(std::string("Writing discarded fusions to file '") + run.options.discarded_output_file + "'");
-		if (run.options.print_extra_info_for_discarded_fusions) fetch_rows_for_writer(run, table, 1);
-		host_check(ahost_write_fusions(run.host, &table, run.options.discarded_output_file, 1, run.options.print_extra_info_for_discarded_fusions, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
+
+	for (int write_discarded = 0; write_discarded <= (run.options.discarded_output_file ? 1 : 0); ++write_discarded) {
+		std::vector<uint32_t> written;
+		for (size_t c = 0; c < n; ++c) if ((write_discarded != 0) != (filter[c] == 0)) written.push_back((uint32_t) c);
+		const size_t w = written.size();
+		std::vector<uint32_t> list_offset(3 * w + 1, 0);
+		uint64_t total = 0;
+		device_check(agpu_get_candidate_read_lists_of(run.device, written.data(), w, list_offset.data(), nullptr, 0, &total));
+		std::vector<uint32_t> read_lists(total > 0 ? total : 1);
+		if (total > 0) device_check(agpu_get_candidate_read_lists_of(run.device, written.data(), w, list_offset.data(), read_lists.data(), total, &total));
+		const std::vector<uint32_t> w_gene1 = pick(gene1, written), w_gene2 = pick(gene2, written), w_contigs = pick(contigs, written), w_flags = pick(flags, written), w_split_reads1 = pick(split_reads1, written),
+		                            w_split_reads2 = pick(split_reads2, written), w_discordant_mates = pick(discordant_mates, written), w_iteration_rank = pick(iteration_rank, written);
+		const std::vector<int32_t> w_breakpoint1 = pick(breakpoint1, written), w_breakpoint2 = pick(breakpoint2, written), w_closest1 = pick(closest1, written), w_closest2 = pick(closest2, written);
+		const std::vector<uint8_t> w_filter = pick(filter, written), w_confidence = pick(confidence, written);
+		const std::vector<float> w_evalue = pick(evalue, written);
+		ahost_fusion_table table;
+		memset(&table, 0, sizeof(table));
+		table.n_candidates = (uint32_t) w;
+		table.gene1 = w_gene1.data(); table.gene2 = w_gene2.data(); table.contigs = w_contigs.data(); table.breakpoint1 = w_breakpoint1.data(); table.breakpoint2 = w_breakpoint2.data(); table.flags = w_flags.data(); table.filter = w_filter.data();
+		table.split_reads1 = w_split_reads1.data(); table.split_reads2 = w_split_reads2.data(); table.discordant_mates = w_discordant_mates.data(); table.list_offset = list_offset.data(); table.read_lists = read_lists.data();
+		table.evalue = w_evalue.data(); table.confidence = w_confidence.data(); table.iteration_rank = w_iteration_rank.data(); table.read_filter = read_filter.data();
+		table.closest_genomic_breakpoint1 = w_closest1.data(); table.closest_genomic_breakpoint2 = w_closest2.data();
+		table.n_genes = n_genes; table.gene_contig = gene_contig.data(); table.gene_start = gene_start.data(); table.gene_end = gene_end.data();
+		const int print_extra_info = write_discarded ? run.options.print_extra_info_for_discarded_fusions : 1;
+		if (write_discarded) run.say(std::string("Writing discarded fusions to file '") + run.options.discarded_output_file + "'");
+		else run.say(std::string("Writing fusions to file '") + run.options.output_file + "' ");
+		if (print_extra_info) fetch_rows_for_writer(run, table, write_discarded);
+		host_check(ahost_write_fusions(run.host, &table, write_discarded ? run.options.discarded_output_file : run.options.output_file, write_discarded, print_extra_info, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
 	}
 }
 

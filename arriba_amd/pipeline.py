@@ -424,15 +424,20 @@ class DevicePipeline(object):
         self.n_candidates = count.value
         return self.n_candidates
 
-    def candidates(self):
-        """Candidate table in the reference's insertion order; lists as (offset[3n+1], reads)."""
+    def candidates(self, lists=True):
+        """Candidate table in the reference's insertion order; lists as (offset[3n+1], reads).  lists=False: the columns only."""
         n = self.n_candidates
         u32 = lambda: np.zeros(max(n, 1), dtype=np.uint32)
         i32 = lambda: np.zeros(max(n, 1), dtype=np.int32)
         table = {"gene1": u32(), "gene2": u32(), "contigs": u32(), "breakpoint1": i32(), "breakpoint2": i32(), "flags": u32(), "filter": np.zeros(max(n, 1), dtype=np.uint8),
                  "split_reads1": u32(), "split_reads2": u32(), "discordant_mates": u32(), "anchor_start1": i32(), "anchor_start2": i32(), "list_offset": np.zeros(3 * n + 1, dtype=np.uint32)}
         order = ["gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2", "list_offset"]
-        self._check(self.api.get_candidates(self.ctx, *[table[k].ctypes.data for k in order]))
+        self._check(self.api.get_candidates(self.ctx, *[table[k].ctypes.data if (lists or k != "list_offset") else None for k in order]))
+        if not lists:
+            for key in order[:-1]:
+                table[key] = table[key][:n]
+            del table["list_offset"]
+            return table
         total = c_uint64()
         self._check(self.api.get_candidate_read_lists(self.ctx, None, 0, byref(total)))
         reads = np.zeros(max(total.value, 1), dtype=np.uint32)
@@ -441,6 +446,18 @@ class DevicePipeline(object):
             table[key] = table[key][:n]
         table["read_lists"] = reads[:total.value]
         return table
+
+    def candidate_read_lists_of(self, candidates):
+        """(list_offset[3n+1] starting at 0, reads) of the given candidates only"""
+        candidates = np.ascontiguousarray(candidates, dtype=np.uint32)
+        n = candidates.size
+        offsets = np.zeros(3 * n + 1, dtype=np.uint32)
+        total = c_uint64()
+        self._check(self.api.get_candidate_read_lists_of(self.ctx, candidates.ctypes.data if n else None, n, offsets.ctypes.data, None, 0, byref(total)))
+        reads = np.zeros(max(total.value, 1), dtype=np.uint32)
+        if total.value:
+            self._check(self.api.get_candidate_read_lists_of(self.ctx, candidates.ctypes.data, n, offsets.ctypes.data, reads.ctypes.data, total.value, byref(total)))
+        return offsets, reads[:total.value]
 
     def merge_adjacent_fusions(self, max_distance=5):
         """reference: merge_adjacent_fusions, source/merge_adjacent_fusions.cpp:19-108; returns the number of unfiltered candidates"""
@@ -524,14 +541,21 @@ class DevicePipeline(object):
 
     def write_fusions(self, path, discarded=False, print_extra_info=None, max_itd_length=100, fill_sequence_gaps=False):
         """reference: write_fusions_to_file, source/output_fusions.cpp:1043-1261 (-o / -O); the device's results are fetched and formatted by the host library"""
-        table = self.candidates()
-        n = self.n_candidates
-        columns = {key: np.ascontiguousarray(table[key]) for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "list_offset", "read_lists")}
-        columns["evalue"] = np.ascontiguousarray(self.evalues(), dtype=np.float32)
-        columns["confidence"] = np.ascontiguousarray(self.assign_confidence())
-        columns["iteration_rank"] = np.ascontiguousarray(self.candidate_iteration_order(), dtype=np.uint32)
+        if print_extra_info is None:
+            print_extra_info = not discarded
+        # only the candidates the file will hold travel to the host with their read lists (fusions.tsv: the few thousand that passed every filter, of millions);
+        # discarded.tsv counts the discarded reads of every discarded candidate by filter, so it takes the lists of all of them
+        table = self.candidates(lists=False)
+        written = np.flatnonzero((table["filter"] != 0) if discarded else (table["filter"] == 0)).astype(np.uint32)
+        list_offset, read_lists = self.candidate_read_lists_of(written)
+        n = written.size
+        columns = {key: np.ascontiguousarray(table[key][written]) for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates")}
+        columns["list_offset"], columns["read_lists"] = list_offset, np.ascontiguousarray(read_lists)
+        columns["evalue"] = np.ascontiguousarray(self.evalues()[written], dtype=np.float32)
+        columns["confidence"] = np.ascontiguousarray(self.assign_confidence()[written])
+        columns["iteration_rank"] = np.ascontiguousarray(self.candidate_iteration_order()[written], dtype=np.uint32)
         columns["read_filter"] = np.ascontiguousarray(self.filters(), dtype=np.uint8)
-        columns["closest_genomic_breakpoint1"], columns["closest_genomic_breakpoint2"] = (np.ascontiguousarray(column) for column in self.genomic_support())
+        columns["closest_genomic_breakpoint1"], columns["closest_genomic_breakpoint2"] = (np.ascontiguousarray(column[written]) for column in self.genomic_support())
         genes = self.gene_table()
         columns["gene_contig"], columns["gene_start"], columns["gene_end"] = (np.ascontiguousarray(genes[key]) for key in ("contig", "start", "end"))
         view = _capi.FusionTable()
@@ -539,8 +563,6 @@ class DevicePipeline(object):
         view.n_genes = len(columns["gene_contig"])
         for key, column in columns.items():
             setattr(view, key, column.ctypes.data if column.size else None)
-        if print_extra_info is None:
-            print_extra_info = not discarded
         if self.device_ingest and print_extra_info:
             # the host's writer works on the rows of the supporting reads of the candidates it writes: fetched from the device now
             lib = self.session._lib

@@ -280,6 +280,9 @@ int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidate
 int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
                         uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor_start1, int32_t* anchor_start2, uint32_t* list_offset);
 int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capacity, uint64_t* total);
+/* the read lists of the given candidates only, packed: list_offset[3*n+1] starts at 0 (the output writer wants those of the candidates it prints -- a few
+ * thousand of millions); call with reads == NULL to get *total and list_offset first */
+int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint32_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total);
 /* sizes of the last agpu_find_fusions: stats[0] gene-pair emissions, [1] candidates, [2] read-list entries, [3] discordant emissions,
  * [4] candidates whose discordant bucket was scanned by a whole wavefront */
 int agpu_get_fusion_stats(agpu_ctx* ctx, uint64_t* stats /* [5] */);
