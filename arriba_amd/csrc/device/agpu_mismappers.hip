@@ -124,31 +124,61 @@ __global__ void splice_site_kernel(AnnotationView ann, uint32_t n_genes_total, c
 	if (!write) counts[gene] = found;
 }
 
-__global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags) {
+__global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags, uint32_t* first_entry) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n || t.filter[c] != FILTER_none) return;
 	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	for (uint32_t k = offsets[0]; k < offsets[3]; ++k) {
 		uint32_t read = t.read_lists[k];
-		if (b.filter[read] == FILTER_none && !read_flags[read]) read_flags[read] = 1;
+		if (b.filter[read] != FILTER_none) continue;
+		if (!read_flags[read]) read_flags[read] = 1;
+		atomicMin(&first_entry[read], k); // where the read stands first in the lists: jobs in that order keep the reads of one candidate together
 	}
 }
+__global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, const uint32_t* first_entry, uint32_t* keys) {
+	const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+	if (j < n_jobs) keys[j] = first_entry[jobs[j]];
+}
 
-// One thread per read: the reference's seed-and-extend search (mismapper_core.hpp) is a chain of dependent look-ups -- k-mer table, position list, genome bases --
-// whose length differs from read to read by orders of magnitude, so the lanes of a wavefront are best spent on 64 different reads (a wavefront per read, its lanes
-// on 64 read positions of one seed search, kept 63 lanes waiting for the longest attempt: 3.6 s for 1.1 M reads; this form: the same verdicts, every lane busy).
-// The frame stack of align() lives in scratch memory (ALIGN_MAX_DEPTH frames per lane, almost always only the first two are touched).
-__global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap, unsigned int* discarded) {
+// First pass, one thread per read: the reference's seed-and-extend search (mismapper_core.hpp) is a chain of dependent look-ups -- k-mer table, position list,
+// genome bases -- of ~10^3 steps for an ordinary read, so the lanes of a wavefront are best spent on 64 different reads.  What makes a lane fast: the frame of the
+// call being worked on sits in registers (the stack in scratch memory only sees calls and returns), the bases of the segment sit in LDS (one column per lane),
+// the stack is short (ALIGN_SHALLOW_DEPTH: enough for reads of 128 nt) so that the scratch memory does not limit the wavefronts in flight.  The jobs are ordered
+// by the candidate that lists the read first: the lanes of a wavefront then work on reads of one gene pair -- the same k-mer tables and genome windows, searches of
+// similar length.  A read that runs out of its step budget (or of stack) is put on the `heavy` list: the verdict of a read does not depend on who computes it.
+const int SEGMENT_CACHE = 128; // bases of a segment kept in LDS per lane (longer segments are read from HBM)
+const int64_t FIRST_PASS_STEPS = 16384;
+__global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap,
+                                                                        uint32_t* heavy, unsigned int* counters /* [1] discarded, [3] heavy */) {
 	__shared__ uint32_t block_sum;
+	__shared__ uint8_t segment_bases[SEGMENT_CACHE * ALIGN_BLOCK];
 	const uint32_t j = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
 	uint32_t mine = 0;
 	if (j < n_jobs) {
-		AlignFrame stack[ALIGN_MAX_DEPTH];
-		AlignRunner runner; runner.stack = stack; runner.lane = 0; runner.lanes = 1;
+		AlignFrame stack[ALIGN_SHALLOW_DEPTH];
+		int64_t budget = FIRST_PASS_STEPS;
+		AlignRunner runner; runner.stack = stack; runner.lane = 0; runner.lanes = 1; runner.budget = &budget; runner.max_depth = ALIGN_SHALLOW_DEPTH;
+		runner.cache = segment_bases + threadIdx.x; runner.cache_stride = ALIGN_BLOCK; runner.cache_capacity = SEGMENT_CACHE;
 		const uint32_t read = jobs[j];
-		if (is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner)) { b.filter[read] = FILTER_mismappers; mine = 1; }
+		const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
+		if (runner.exhausted()) heavy[atomicAdd(&counters[3], 1u)] = read;
+		else if (verdict) { b.filter[read] = FILTER_mismappers; mine = 1; }
 	}
-	block_tally(mine, discarded, &block_sum);
+	block_tally(mine, &counters[1], &block_sum);
+}
+
+// Second pass, one wavefront per heavy read: the 64 lanes try 64 read positions of a seed search at once (the iterations of the outermost loop of align() are
+// independent attempts), full stack, no budget; the segment in LDS is shared by the lanes.
+__global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap, unsigned int* counters) {
+	__shared__ uint8_t segment_bases[304];
+	const uint32_t j = blockIdx.x;
+	if (j >= n_heavy) return;
+	AlignFrame stack[ALIGN_MAX_DEPTH];
+	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = nullptr; runner.max_depth = ALIGN_MAX_DEPTH;
+	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
+	const uint32_t read = heavy[j];
+	const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
+	if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
 }
 
 __global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, bool count_only, unsigned int* remaining) {
@@ -278,11 +308,13 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 	const uint64_t n = ctx->n;
 	if (!ctx->have_splice_sites || ctx->splice_sites_for_dummy != ctx->n_dummy) { int status = build_splice_sites(ctx); if (status != AGPU_OK) return status; }
 	DeviceBuffer& read_flags = ctx->scratch("mismappers.read_flags"); DeviceBuffer& jobs = ctx->scratch("mismappers.jobs"); DeviceBuffer& counters = ctx->scratch("mismappers.counters");
-	DeviceBuffer& scratch = ctx->scratch("mismappers.rocprim");
-	ALLOC(read_flags, n ? n : 1); ALLOC(jobs, (n ? n : 1) * 4); ALLOC(counters, 16);
+	DeviceBuffer& scratch = ctx->scratch("mismappers.rocprim"); DeviceBuffer& first_entry = ctx->scratch("mismappers.first_entry"); DeviceBuffer& job_keys = ctx->scratch("mismappers.job_keys");
+	DeviceBuffer& job_keys_sorted = ctx->scratch("mismappers.job_keys_sorted"); DeviceBuffer& jobs_sorted = ctx->scratch("mismappers.jobs_sorted");
+	ALLOC(read_flags, n ? n : 1); ALLOC(jobs, (n ? n : 1) * 4); ALLOC(counters, 16); ALLOC(first_entry, (n ? n : 1) * 4);
 	HIP_CHECK(hipMemsetAsync(read_flags.ptr, 0, n ? n : 1, s));
+	HIP_CHECK(hipMemsetAsync(first_entry.ptr, 0xFF, (n ? n : 1) * 4, s));
 	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 16, s));
-	unsigned int* device_counters = counters.as<unsigned int>(); // [0] jobs, [1] reads discarded, [2] candidates remaining
+	unsigned int* device_counters = counters.as<unsigned int>(); // [0] jobs, [1] reads discarded, [2] candidates remaining, [3] reads left to the second pass
 	KmerIndexView kmers;
 	kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
 	SpliceSiteView splice;
@@ -293,7 +325,7 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 		// switched off with -f: the reference skips the stage (source/arriba.cpp:562); no read and no candidate is touched, the unfiltered candidates are counted
 		mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, true, device_counters + 2);
 	} else if (C > 0 && n > 0) {
-		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>()); }
+		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>(), first_entry.as<uint32_t>()); }
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
 		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
@@ -301,8 +333,29 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 		HIP_CHECK(hipMemcpyAsync(&n_jobs, device_counters, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (n_jobs > 0) {
-			KernelTimer timer(ctx, "mismapper_verdict_kernel", (uint64_t) n_jobs * 300);
-			mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs.as<uint32_t>(), n_jobs, max_mate_gap, device_counters + 1);
+			ALLOC(job_keys, (size_t) n_jobs * 4); ALLOC(job_keys_sorted, (size_t) n_jobs * 4); ALLOC(jobs_sorted, (size_t) n_jobs * 4);
+			mismapper_job_key_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(jobs.as<uint32_t>(), n_jobs, first_entry.as<uint32_t>(), job_keys.as<uint32_t>());
+			HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, job_keys.as<uint32_t>(), job_keys_sorted.as<uint32_t>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, 32, s));
+			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+			HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, job_keys.as<uint32_t>(), job_keys_sorted.as<uint32_t>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, 32, s));
+			DeviceBuffer& heavy = ctx->scratch("mismappers.heavy");
+			ALLOC(heavy, (size_t) n_jobs * 4);
+			uint32_t n_heavy = 0;
+			const char* first_pass = getenv("ARRIBA_MISMAPPER_FIRST_PASS"); // "0": every read goes to the wavefront-per-read pass (for A/B measurements)
+			if (first_pass != nullptr && first_pass[0] == '0') {
+				HIP_CHECK(hipMemcpyAsync(heavy.ptr, jobs_sorted.ptr, (size_t) n_jobs * 4, hipMemcpyDeviceToDevice, s));
+				n_heavy = n_jobs;
+			} else {
+				{ KernelTimer timer(ctx, "mismapper_verdict_kernel", (uint64_t) n_jobs * 300);
+				  mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs_sorted.as<uint32_t>(), n_jobs, max_mate_gap, heavy.as<uint32_t>(), device_counters); }
+				HIP_CHECK(hipMemcpyAsync(&n_heavy, device_counters + 3, 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipStreamSynchronize(s));
+			}
+			ctx->mismapper_heavy = n_heavy;
+			if (n_heavy > 0) {
+				KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
+				mismapper_heavy_kernel<<<n_heavy, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, device_counters);
+			}
 		}
 		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
 		  mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, false, device_counters + 2); }

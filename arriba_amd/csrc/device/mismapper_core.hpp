@@ -34,7 +34,13 @@ AGPU_HD uint32_t kmer_digit_of_char(char base) { return base == 'T' ? 0u : base 
 // a substring of a read's sequence, optionally reverse-complemented (dna_to_reverse_complement, source/assembly.cpp)
 struct Segment {
 	SequenceRef sequence; uint32_t offset, length; bool reverse_complement;
-	AGPU_HD uint32_t code(uint32_t i) const { return reverse_complement ? complement_code(sequence.code(offset + length - 1 - i)) : sequence.code(offset + i); }
+	// optional copy of the segment's base characters as code(i) would give them (strand applied), element i at cache[i * cache_stride]: the search reads every base
+	// of the segment hundreds of times; on the device the copy lives in LDS
+	const uint8_t* cache = nullptr; uint32_t cache_stride = 1;
+	AGPU_HD uint32_t code(uint32_t i) const {
+		if (cache != nullptr) return cache[(size_t) i * cache_stride];
+		return reverse_complement ? complement_code(sequence.code(offset + length - 1 - i)) : sequence.code(offset + i);
+	}
 	AGPU_HD char at(uint32_t i) const { return base_char(code(i)); }
 	AGPU_HD uint32_t kmer(uint32_t position) const {
 		uint32_t result = 0;
@@ -73,6 +79,7 @@ struct AlignFrame {
 	uint8_t started;                      // the read_pos loop has been entered (its increment runs before every later iteration)
 };
 const int ALIGN_MAX_DEPTH = 40;           // every nested call starts >= 8 bases further into a read of < 300 bases
+const int ALIGN_SHALLOW_DEPTH = 16;       // ... of <= 128 bases: the stack of the first pass on the device
 
 AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t gene_pos, int32_t max_deletions) {
 	f.score = score; f.read_pos = read_pos; f.skipped_bases = 0; f.gene_pos = gene_pos; f.max_deletions = max_deletions;
@@ -83,19 +90,27 @@ AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t
 // that follows from them (extensions, nested re-seeds).  The outermost loop only ever skips bases (score = -read_pos, all skipped bases
 // leading), and its bound is monotone in read_pos, so its iterations are independent attempts: align() succeeds iff one of them does.
 // That is what lets a wavefront try 64 read positions at once.
-AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int32_t first_read_pos) {
+// `budget` (may be null): steps this search may still take; when it runs out -- or when the nesting exceeds `max_depth` frames -- the search is abandoned with
+// *budget < 0 (the result is then meaningless and the caller must not use it: AlignRunner::exhausted).  A few reads of repetitive sequence need 10^2..10^4
+// times the steps of an ordinary read, and a scheduler wants to know them.
+// The frame that is being worked on lives in registers; `stack` only holds the frames of the callers (written when a nested call starts, read when it fails).
+AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget) {
 	const int32_t length = (int32_t) read.length;
 	int depth = 0;
-	align_enter(stack[0], -first_read_pos, first_read_pos, target.gene_start, 1);
-	stack[0].skipped_bases = first_read_pos; stack[0].leading = 1;
-	while (depth >= 0) {
-		AlignFrame& f = stack[depth];
+	AlignFrame f;
+	align_enter(f, -first_read_pos, first_read_pos, target.gene_start, 1);
+	f.skipped_bases = first_read_pos; f.leading = 1;
+	f.extended_score = 0; f.extended_read_pos = 0; f.extended_gene_pos = 0; f.mismatch_count = 0; f.consecutive_mismatches = 0;
+	while (true) {
+		if (budget != nullptr && --*budget < 0) return false;
+		bool call = false, fail = false; // start a nested align() from (extended_score, extended_read_pos, extended_gene_pos) / this align() returns false
+		int32_t call_max_deletions = 0;
 		switch (f.state) {
 			case ALIGN_NEXT_READ_POSITION: { // for (; read_pos + k < length && ...; read_pos++, score--, skipped_bases++)
 				if (f.started && depth == 0) return false; // the other read positions of the outermost loop are other attempts
 				if (f.started) { f.read_pos++; f.score--; f.skipped_bases++; }
 				f.started = 1;
-				if (!(f.read_pos + KMER_LENGTH < length && f.read_pos + min_score <= length + f.score + 2 * KMER_LENGTH)) { --depth; break; } // this call returns false
+				if (!(f.read_pos + KMER_LENGTH < length && f.read_pos + min_score <= length + f.score + 2 * KMER_LENGTH)) { fail = true; break; }
 				if (target.kmer_offsets == 0) break; // no k-mer index on this contig: every lookup misses
 				uint32_t kmer = read.kmer((uint32_t) f.read_pos);
 				uint32_t begin = target.kmer_offsets[kmer], end = target.kmer_offsets[kmer + 1];
@@ -133,11 +148,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 			case ALIGN_RIGHT_LOOP: { // while (extended_read_pos < length && extended_gene_pos <= gene_end)
 				if (!(f.extended_read_pos < length && f.extended_gene_pos <= target.gene_end)) { f.state = ALIGN_NEXT_HIT; break; }
 				f.state = ALIGN_COMPARE_BASE;
-				if (is_splice_site(target, f.extended_gene_pos - 1)) { // re-seed behind a splice site (spliced alignment)
-					if (depth + 1 >= ALIGN_MAX_DEPTH) return false; // unreachable for reads < 300 bases
-					align_enter(stack[depth + 1], f.extended_score, f.extended_read_pos, f.extended_gene_pos, f.max_deletions);
-					++depth;
-				}
+				if (is_splice_site(target, f.extended_gene_pos - 1)) { call = true; call_max_deletions = f.max_deletions; } // re-seed behind a splice site (spliced alignment)
 				break;
 			}
 			case ALIGN_COMPARE_BASE: {
@@ -149,11 +160,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				} else {
 					f.mismatch_count++;
 					f.state = ALIGN_AFTER_MISMATCH;
-					if (f.mismatch_count == 1 && f.max_deletions > 0 && length >= 30) { // re-seed once after the first mismatch (deletion / intron)
-						if (depth + 1 >= ALIGN_MAX_DEPTH) return false;
-						align_enter(stack[depth + 1], f.extended_score, f.extended_read_pos, f.extended_gene_pos, f.max_deletions - 1);
-						++depth;
-					}
+					if (f.mismatch_count == 1 && f.max_deletions > 0 && length >= 30) { call = true; call_max_deletions = f.max_deletions - 1; } // re-seed once after the first mismatch (deletion / intron)
 				}
 				break;
 			}
@@ -169,13 +176,41 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				break;
 			}
 		}
+		if (call) { // the caller's frame goes to the stack, the nested call takes the registers
+			if (depth >= max_depth) { if (budget != nullptr) *budget = -1; return false; } // deeper than this stack: left to a caller with a deeper one
+			stack[depth] = f;
+			++depth;
+			const int32_t score = f.extended_score, read_pos = f.extended_read_pos, gene_pos = f.extended_gene_pos;
+			align_enter(f, score, read_pos, gene_pos, call_max_deletions);
+		} else if (fail) { // this call returns false: the caller goes on behind the call
+			if (depth == 0) return false;
+			--depth;
+			f = stack[depth];
+		}
 	}
-	return false;
 }
 
 // Who tries the read positions: one thread after the other on the host (lanes = 1), the 64 lanes of a wavefront on the device.
 struct AlignRunner {
 	AlignFrame* stack; uint32_t lane, lanes;
+	int64_t* budget = nullptr; // steps left for the whole verdict of one read (null: unlimited)
+	int max_depth = ALIGN_MAX_DEPTH; // frames `stack` holds
+	uint8_t* cache = nullptr; uint32_t cache_stride = 1, cache_capacity = 0; // room for a copy of the segment being searched (LDS on the device), shared by the lanes of the runner
+	AGPU_HD bool exhausted() const { return budget != nullptr && *budget < 0; }
+	// the base characters of the segment, strand applied, where the search finds them fast
+	AGPU_HD Segment prepared(const Segment& segment) const {
+		Segment result = segment;
+		if (cache == nullptr || segment.length > cache_capacity) return result;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (lanes > 1) __syncthreads(); // (lanes > 1: the lanes are one workgroup and run this code together; nobody still reads the previous copy)
+#endif
+		for (uint32_t i = lane; i < segment.length; i += lanes) cache[(size_t) i * cache_stride] = (uint8_t) segment.code(i);
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (lanes > 1) __syncthreads();
+#endif
+		result.cache = cache; result.cache_stride = cache_stride;
+		return result;
+	}
 	AGPU_HD bool any(bool mine) const {
 #if defined(__HIP_DEVICE_COMPILE__)
 		return lanes > 1 ? __any(mine) != 0 : mine;
@@ -188,7 +223,8 @@ struct AlignRunner {
 		const int32_t length = (int32_t) read.length;
 		for (int32_t base = 0; base + KMER_LENGTH < length && 2 * base + min_score <= length + 2 * KMER_LENGTH; base += (int32_t) lanes) { // the loop bound of the reference at read_pos = base
 			const int32_t read_pos = base + (int32_t) lane;
-			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, read_pos);
+			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget);
+			if (exhausted()) return false;
 			if (any(found)) return true;
 		}
 		return false;
@@ -217,9 +253,11 @@ AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int
 		target.contig_bases = genome.bases + genome.contig_offset[contig];
 		target.splice_sites = splice.sites + splice.offset[gene]; target.n_splice_sites = splice.offset[gene + 1] - splice.offset[gene];
 		Segment forward = segment; forward.reverse_complement = false;
-		if (runner.align(forward, target, min_score)) return true;
+		if (runner.align(runner.prepared(forward), target, min_score)) return true;
+		if (runner.exhausted()) return false;
 		Segment reverse = segment; reverse.reverse_complement = true;
-		if (runner.align(reverse, target, min_score)) return true;
+		if (runner.align(runner.prepared(reverse), target, min_score)) return true;
+		if (runner.exhausted()) return false;
 	}
 	return false;
 }
@@ -277,6 +315,7 @@ AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const G
 		load_genes(b, SPLIT_READ, i, genes);
 		if (align_both_strands(clipped, (int32_t) split_sequence.length, max_mate_gap, same_contig, b.start[SUPPLEMENTARY][i], b.end[SUPPLEMENTARY][i], ann, genome, kmers, splice, genes, min_align_fraction, runner))
 			return true; // the clipped segment aligns to the donor
+		if (runner.exhausted()) return false;
 		load_genes(b, SUPPLEMENTARY, i, genes);
 		return align_both_strands(mate, (int32_t) mate1_sequence.length, max_mate_gap, same_contig, b.start[MATE1][i], b.end[MATE1][i], ann, genome, kmers, splice, genes, min_align_fraction, runner); // the mate aligns to the acceptor
 	}
@@ -291,6 +330,7 @@ AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const G
 		load_genes(b, mate == MATE1 ? MATE2 : MATE1, i, genes);
 		if (align_both_strands(whole, (int32_t) sequence.length, max_mate_gap, same_contig, b.start[mate][i], b.end[mate][i], ann, genome, kmers, splice, genes, reduced < min_align_fraction ? reduced : min_align_fraction, runner))
 			return true;
+		if (runner.exhausted()) return false;
 	}
 	return false;
 }

@@ -35,6 +35,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+BENCH_STARTED = time.time()
+
+
+def progress(text):
+    """where the time goes, on stderr (stdout carries the one JSON line): a run that is cut off by a time limit still says how far it got"""
+    sys.stderr.write("[bench %7.1f s] %s\n" % (time.time() - BENCH_STARTED, text))
+    sys.stderr.flush()
+
+
 def workload_args(fragments, seed, read_seed=0, stress=False):
     # SURVEY.md section 8(d) config 2: 2x100 bp, 55 % split-read triplets / 35 % discordant pairs / 10 % read-through, Zipf junction support, 30 % PCR
     # duplicates, synthetic 24-contig genome with GENCODE-like annotation (no hg38 offline).  stress = config 3: long clips copied from the partner gene
@@ -195,7 +204,9 @@ def main():
     try:
         prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, ((os.cpu_count() or 2) - 2) // world)))
         bam_bytes = os.path.getsize(prefix + ".bam")
+        progress("sample generated: %d fragments, %.1f GB BAM in %.1f s (%s)" % (args.fragments, bam_bytes / 1e9, generate_seconds, directory))
         session = HostSession(prefix + ".fa", prefix + ".gtf")  # assembly + annotation, once (resident)
+        progress("assembly and annotation loaded")
         params = {"subsampling_threshold": 32767} if args.stress else None
         pipeline = None
         outputs = [os.path.join(directory, "fusions.tsv"), os.path.join(directory, "discarded.tsv") if args.discarded else None]
@@ -222,6 +233,8 @@ def main():
             pipeline.run_workflow(outputs[0], outputs[1], log=lambda stage, count: stage_log.append((stage, count, round(time.perf_counter() - started, 4))))
             finished = time.perf_counter()
             step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started})
+            progress("step done: read_chimeric_alignments %.2f s %s, workflow %.2f s; slowest stages: %s" % (ingested - started, ingest_parts[-1], finished - ingested,
+                     sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4]))
 
         profiling = [False]
         for _ in range(args.warmup):
@@ -254,6 +267,7 @@ def main():
         else:
             total_fragments = n
 
+        progress("timed steps done: %.2f s per step" % (elapsed / args.steps))
         # post-conditions of the last step on the full-size batch (untimed; no oracle involved): a kernel that silently skipped a part of the batch would
         # leave alignments without a gene, or read filter counts that do not add up; the output file must exist and hold the fusions the log counted
         self_check = []
@@ -321,6 +335,7 @@ def main():
                              "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes, "launches_per_step": launches / args.steps},
             }
             line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted"
+            progress("self-check done, kernel profile read")
             line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped"} if args.no_cpu_baseline else cpu_baseline(1000, directory, stress=args.stress)
             print(json.dumps(line))
     finally:

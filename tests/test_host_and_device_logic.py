@@ -537,7 +537,7 @@ def test_workflow_with_library_options_against_the_live_reference(label, options
 
 
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
-@pytest.mark.parametrize("disabled", [["mismappers"], ["homologs", "mismappers"]])
+@pytest.mark.parametrize("disabled", [["mismappers"], ["homologs", "mismappers"], []])
 def test_workflow_with_mismappers_switched_off_against_the_live_reference(disabled, emu_api, tmp_path):
     """-f mismappers: the reference skips the stage (source/arriba.cpp:562), reads and candidates keep their state; clipped segments copied from the
     partner gene make the stage fire when it is on (the same dataset with the default filters discards reads as mis-mappers)"""
@@ -551,7 +551,10 @@ def test_workflow_with_mismappers_switched_off_against_the_live_reference(disabl
     os.makedirs(str(tmp_path / "mine"))
     stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, params={"disable_filters": disabled})
     counts = dict(stages)
-    assert counts["filter_mismappers"] == counts["filter_homologs"] and stages[-1][1] > 20
+    if disabled:
+        assert counts["filter_mismappers"] == counts["filter_homologs"] and stages[-1][1] > 20
+    else:  # the stage on: hundreds of re-alignments decide, candidates go (the budgeted two-pass schedule of the device is stepped with EMU_MISMAPPER_BUDGET, too)
+        assert counts["filter_mismappers"] <= counts["filter_homologs"]  # (both files and every count equal the reference's: check_workflow)
 
 
 @pytest.mark.parametrize("name", ["toy3k", "wgs8k"])
