@@ -600,7 +600,12 @@ int agpu_upload_genome(agpu_ctx* ctx, const agpu_genome_view* in) {
 	hipStream_t s = ctx->stream;
 	TRY(upload(ctx->genome_contig_offset, in->contig_offset, (size_t) in->n_contigs + 1, s));
 	TRY(upload(ctx->genome_contig_bits, in->contig_bits, in->n_contigs, s));
-	TRY(upload(ctx->genome_bases, in->bases, in->contig_offset[in->n_contigs], s));
+	{ // (16 bytes of padding behind the last base: the re-alignment of filter_mismappers reads the genome eight bases at a time)
+		const size_t bases = in->contig_offset[in->n_contigs];
+		if (!ctx->genome_bases.allocate(bases + 16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		HIP_CHECK(hipMemsetAsync((char*) ctx->genome_bases.ptr + bases, 0, 16, s));
+		if (bases > 0) HIP_CHECK(hipMemcpyAsync(ctx->genome_bases.ptr, in->bases, bases, hipMemcpyHostToDevice, s));
+	}
 	ctx->genome.n_contigs = in->n_contigs; ctx->genome.contig_offset = ctx->genome_contig_offset.as<uint64_t>();
 	ctx->genome.contig_bits = ctx->genome_contig_bits.as<uint8_t>(); ctx->genome.bases = ctx->genome_bases.as<char>();
 	ctx->host_contig_bits.assign(in->contig_bits, in->contig_bits + in->n_contigs);

@@ -483,6 +483,17 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 		KernelTimer timer(ctx, "attach_discordant_wave_kernel(count)", (uint64_t) Md * 24 + (uint64_t) queued * 25); // every bucket row read once, one size written per queued candidate
 		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
 	}
+	{ // the read lists are addressed with 32-bit offsets: say so instead of wrapping around (about 10^8 fragments of the bench's workload reach the limit)
+		DeviceBuffer& list_total = ctx->scratch("fusions.list_total");
+		ALLOC(list_total, 8);
+		HIP_CHECK(rocprim::reduce(nullptr, bytes, list_size.as<uint32_t>(), list_total.as<uint64_t>(), (uint64_t) 0, 3 * (size_t) C, rocprim::plus<uint64_t>(), s));
+		if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+		HIP_CHECK(rocprim::reduce(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), list_total.as<uint64_t>(), (uint64_t) 0, 3 * (size_t) C, rocprim::plus<uint64_t>(), s));
+		uint64_t entries = 0;
+		HIP_CHECK(hipMemcpyAsync(&entries, list_total.ptr, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (entries >= 0xFFFFFFF0ull) { set_last_error("the read lists of the candidates hold more than 2^32-16 entries; shard the input"); return AGPU_ERR_CAPACITY; }
+	}
 	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
 	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));

@@ -65,6 +65,12 @@ AGPU_HD bool is_splice_site(const AlignTarget& target, int32_t position) {
 	uint32_t at = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, position);
 	return at < target.n_splice_sites && target.splice_sites[at] == position;
 }
+// the same question asked for ascending positions: `cursor` remembers where the last answer was found (one compare instead of a binary search per base)
+AGPU_HD bool is_splice_site_from(const AlignTarget& target, int32_t position, uint32_t& cursor) {
+	while (cursor < target.n_splice_sites && target.splice_sites[cursor] < position) ++cursor;
+	return cursor < target.n_splice_sites && target.splice_sites[cursor] == position;
+}
+AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; } // eight genome bases at once (the genome buffer is padded behind its end)
 
 // One invocation of the reference's align() (source/filter_mismappers.cpp:86-199) as a resumable frame: the two recursive
 // re-seeds of the reference push a child frame and continue behind the call when the child reports failure.
@@ -74,6 +80,7 @@ struct AlignFrame {
 	uint32_t hit, hits_end;               // current / end index into positions for the k-mer at read_pos
 	int32_t extended_score, extended_read_pos, extended_gene_pos;
 	uint32_t mismatch_count, consecutive_mismatches;
+	uint32_t splice_cursor;               // index of the first splice site of the gene at or behind extended_gene_pos - 1 (the extension only moves forward)
 	uint8_t leading;                      // read_pos == skipped_bases (only the outermost call starts at read position 0)
 	uint8_t state;
 	uint8_t started;                      // the read_pos loop has been entered (its increment runs before every later iteration)
@@ -83,7 +90,7 @@ const int ALIGN_SHALLOW_DEPTH = 16;       // ... of <= 128 bases: the stack of t
 
 AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t gene_pos, int32_t max_deletions) {
 	f.score = score; f.read_pos = read_pos; f.skipped_bases = 0; f.gene_pos = gene_pos; f.max_deletions = max_deletions;
-	f.leading = read_pos == 0; f.state = ALIGN_NEXT_READ_POSITION; f.started = 0; f.hit = 0; f.hits_end = 0;
+	f.leading = read_pos == 0; f.state = ALIGN_NEXT_READ_POSITION; f.started = 0; f.hit = 0; f.hits_end = 0; f.splice_cursor = 0;
 }
 
 // One iteration of the outermost read_pos loop of the reference's align(): the seeds at read position `first_read_pos` with everything
@@ -142,13 +149,33 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				f.extended_read_pos = f.read_pos + KMER_LENGTH;
 				f.extended_gene_pos = kmer_hit + KMER_LENGTH;
 				f.mismatch_count = 0; f.consecutive_mismatches = 0;
+				f.splice_cursor = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, f.extended_gene_pos - 1);
 				f.state = ALIGN_RIGHT_LOOP;
 				break;
 			}
 			case ALIGN_RIGHT_LOOP: { // while (extended_read_pos < length && extended_gene_pos <= gene_end)
-				if (!(f.extended_read_pos < length && f.extended_gene_pos <= target.gene_end)) { f.state = ALIGN_NEXT_HIT; break; }
-				f.state = ALIGN_COMPARE_BASE;
-				if (is_splice_site(target, f.extended_gene_pos - 1)) { call = true; call_max_deletions = f.max_deletions; } // re-seed behind a splice site (spliced alignment)
+				// The extension to the right base by base, in one go until something happens that needs the stack (a nested call) or ends the hit: per base a
+				// compare against a register window of eight genome bases and a compare against the next splice site.  What the states ALIGN_COMPARE_BASE /
+				// ALIGN_AFTER_MISMATCH / ALIGN_ADVANCE do one at a time (they remain as the places where a nested call returns to).
+				uint64_t window = 0; int32_t window_at = 0, window_end = 0; // genome bases [window_at, window_end) of the contig
+				while (true) {
+					if (!(f.extended_read_pos < length && f.extended_gene_pos <= target.gene_end)) { f.state = ALIGN_NEXT_HIT; break; }
+					if (is_splice_site_from(target, f.extended_gene_pos - 1, f.splice_cursor)) { f.state = ALIGN_COMPARE_BASE; call = true; call_max_deletions = f.max_deletions; break; } // re-seed behind a splice site (spliced alignment)
+					if (f.extended_gene_pos >= window_end || f.extended_gene_pos < window_at) { window_at = f.extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
+					const char reference_base = (char) (window >> (8 * (f.extended_gene_pos - window_at)));
+					if (read.at((uint32_t) f.extended_read_pos) == reference_base) {
+						f.extended_score++;
+						if (f.extended_score >= min_score) return true;
+						f.consecutive_mismatches = 0;
+					} else {
+						f.mismatch_count++;
+						if (f.mismatch_count == 1 && f.max_deletions > 0 && length >= 30) { f.state = ALIGN_AFTER_MISMATCH; call = true; call_max_deletions = f.max_deletions - 1; break; } // re-seed once after the first mismatch (deletion / intron)
+						f.extended_score--;
+						f.consecutive_mismatches++;
+						if (f.consecutive_mismatches >= 4) { f.state = ALIGN_NEXT_HIT; break; }
+					}
+					f.extended_read_pos++; f.extended_gene_pos++;
+				}
 				break;
 			}
 			case ALIGN_COMPARE_BASE: {

@@ -108,6 +108,7 @@ struct ahost_session {
 			contig_bits[c] = (is_interesting_contig(name_by_id[c], options.interesting_contigs) ? AGPU_CBIT_INTERESTING : 0) | (is_interesting_contig(name_by_id[c], options.viral_contigs) ? AGPU_CBIT_VIRAL : 0);
 		}
 		genome_offset[C] = genome_bases.size();
+		genome_bases.append(16, '\0'); // padding behind the last base (not part of the view): consumers may read the genome several bases at a time
 		genome_view.n_contigs = C; genome_view.contig_offset = genome_offset.data(); genome_view.contig_bits = contig_bits.data(); genome_view.bases = genome_bases.data();
 	}
 	void build_batch_view() {

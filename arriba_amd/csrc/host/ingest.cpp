@@ -1280,7 +1280,7 @@ public:
 	BamFeed(const std::string& path): gzip_open_(false), end_(false) {
 		fd_ = (path == "-") ? 0 : open(path.c_str(), O_RDONLY);
 		if (fd_ < 0) throw std::runtime_error("failed to open SAM file");
-		file_.fd = fd_; file_.position = 0; file_.n_threads = std::min(16u, ingest_threads());
+		file_.fd = fd_; file_.position = 0; file_.n_threads = std::min(32u, ingest_threads());
 		struct stat status;
 		file_.seekable = fstat(fd_, &status) == 0 && S_ISREG(status.st_mode);
 		file_size_ = file_.seekable ? (uint64_t) status.st_size : 0;

@@ -384,7 +384,7 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 	const size_t CHUNK = 16384;
 	unsigned int n_threads = std::thread::hardware_concurrency();
 	if (const char* setting = getenv("ARRIBA_WRITER_THREADS")) if (atoi(setting) > 0) n_threads = (unsigned int) atoi(setting);
-	n_threads = std::max(1u, std::min(n_threads, 64u));
+	n_threads = std::max(1u, std::min(n_threads, 128u));
 	std::vector<std::string> row_text, row_warnings;
 	for (size_t chunk_begin = 0; chunk_begin < rows.size(); chunk_begin += CHUNK) {
 		const size_t chunk_end = std::min(rows.size(), chunk_begin + CHUNK), count = chunk_end - chunk_begin;

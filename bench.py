@@ -230,13 +230,24 @@ def main():
                 pipeline.read_chimeric_alignments(prefix + ".bam", piece_bytes=256 << 20)
                 ingest_parts.append(dict(pipeline.ingest_seconds))
             ingested = time.perf_counter()
-            pipeline.run_workflow(outputs[0], outputs[1], log=lambda stage, count: stage_log.append((stage, count, round(time.perf_counter() - started, 4))))
+            if verbose:
+                progress("read_chimeric_alignments done: %d fragments in %.2f s %s" % (pipeline.n, ingested - started, ingest_parts[-1]))
+
+            def note(stage, count):
+                stage_log.append((stage, count, round(time.perf_counter() - started, 4)))
+                if verbose:
+                    progress("%s: %d (%.2f s into the step)" % (stage, count, time.perf_counter() - started))
+            pipeline.run_workflow(outputs[0], outputs[1], log=note)
             finished = time.perf_counter()
             step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started})
             progress("step done: read_chimeric_alignments %.2f s %s, workflow %.2f s; slowest stages: %s" % (ingested - started, ingest_parts[-1], finished - ingested,
                      sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4]))
 
         profiling = [False]
+        verbose = args.fragments >= 30000000 or bool(os.environ.get("ARRIBA_BENCH_VERBOSE"))  # large samples: every stage reports on stderr, so that a run cut off by a time limit says where it was
+        if verbose:
+            import faulthandler
+            faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
         for _ in range(args.warmup):
             step()
         profiling[0] = True
@@ -327,7 +338,7 @@ def main():
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
                 "stages": stage_log,
                 "stage_kernel_ms": {stage: round(values["ms"], 3) for stage, values in pipeline.timings.items()},
-                "kernel_ms": {name: round(values["ms"] / values["launches"], 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:16]},
+                "kernel_ms": {name: round(values["ms"] / values["launches"], 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:48]},
                 "kernel_ms_per_step": round(kernel_ms_per_step, 2),
                 "device_resident_step": {"what": "round 1's figure: resident batch -> filter_relative_support (kernel time of the stages between the ingest and the candidate-level filters)", "ms": round(resident_ms, 3),
                                          "chimeric_reads_per_s": n / (resident_ms * 1e-3) if resident_ms > 0 else None},
