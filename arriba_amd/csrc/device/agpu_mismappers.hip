@@ -147,7 +147,7 @@ __global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, 
 // by the candidate that lists the read first: the lanes of a wavefront then work on reads of one gene pair -- the same k-mer tables and genome windows, searches of
 // similar length.  A read that runs out of its step budget (or of stack) is put on the `heavy` list: the verdict of a read does not depend on who computes it.
 const int SEGMENT_CACHE = 128; // bases of a segment kept in LDS per lane (longer segments are read from HBM)
-const int64_t FIRST_PASS_STEPS = 16384;
+const int64_t FIRST_PASS_STEPS = 65536; // steps of the search loop + bases compared; an ordinary read takes a few thousand
 __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap,
                                                                         uint32_t* heavy, unsigned int* counters /* [1] discarded, [3] heavy */) {
 	__shared__ uint32_t block_sum;
@@ -167,14 +167,15 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 	block_tally(mine, &counters[1], &block_sum);
 }
 
-// Second pass, one wavefront per heavy read: the 64 lanes try 64 read positions of a seed search at once (the iterations of the outermost loop of align() are
-// independent attempts), full stack, no budget; the segment in LDS is shared by the lanes.
+// Second pass, one wavefront per heavy read: the read positions one after the other, the seeds of a position split among the 64 lanes (every seed of the outermost
+// loop of align() is an independent attempt), full stack, no budget; the segment in LDS is shared by the lanes.
 __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
 	const uint32_t j = blockIdx.x;
 	if (j >= n_heavy) return;
 	AlignFrame stack[ALIGN_MAX_DEPTH];
 	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = nullptr; runner.max_depth = ALIGN_MAX_DEPTH;
+	runner.lanes_share_seeds = true; // a read lands here because some of its read positions have hundreds of seeds (repeats, runs of N in the gene): the lanes split them
 	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
 	const uint32_t read = heavy[j];
 	const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);

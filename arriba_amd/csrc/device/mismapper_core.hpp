@@ -101,7 +101,9 @@ AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t
 // *budget < 0 (the result is then meaningless and the caller must not use it: AlignRunner::exhausted).  A few reads of repetitive sequence need 10^2..10^4
 // times the steps of an ordinary read, and a scheduler wants to know them.
 // The frame that is being worked on lives in registers; `stack` only holds the frames of the callers (written when a nested call starts, read when it fails).
-AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget) {
+// `hit_offset`, `hit_stride`: of the seeds at the first read position this call only follows number hit_offset, hit_offset + hit_stride, ... (every seed is an
+// independent attempt, too: the lanes of a wavefront share the seeds of one read position among them when a read has many).
+AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1) {
 	const int32_t length = (int32_t) read.length;
 	int depth = 0;
 	AlignFrame f;
@@ -124,11 +126,14 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				f.hit = lower_bound_i32(target.positions, begin, end, f.gene_pos);
 				f.hits_end = end;
 				f.state = ALIGN_NEXT_HIT;
-				if (f.hit < f.hits_end) --f.hit; else f.state = ALIGN_NEXT_READ_POSITION; // ALIGN_NEXT_HIT pre-increments
+				if (depth == 0) { // this caller's share of the seeds
+					if (end - f.hit > hit_offset) f.hit += hit_offset; else f.hit = end;
+					if (f.hit < f.hits_end) f.hit -= hit_stride; else f.state = ALIGN_NEXT_READ_POSITION; // ALIGN_NEXT_HIT pre-increments (unsigned wrap-around on purpose)
+				} else if (f.hit < f.hits_end) --f.hit; else f.state = ALIGN_NEXT_READ_POSITION;
 				break;
 			}
 			case ALIGN_NEXT_HIT: { // for (hit = lower_bound(gene_pos); hit != end && *hit < gene_end; ++hit)
-				++f.hit;
+				f.hit += depth == 0 ? hit_stride : 1u;
 				if (!(f.hit < f.hits_end && target.positions[f.hit] < target.gene_end)) { f.state = ALIGN_NEXT_READ_POSITION; break; }
 				const int32_t kmer_hit = target.positions[f.hit];
 				f.extended_score = f.score + KMER_LENGTH;
@@ -159,6 +164,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				// ALIGN_AFTER_MISMATCH / ALIGN_ADVANCE do one at a time (they remain as the places where a nested call returns to).
 				uint64_t window = 0; int32_t window_at = 0, window_end = 0; // genome bases [window_at, window_end) of the contig
 				while (true) {
+					if (budget != nullptr && --*budget < 0) return false;
 					if (!(f.extended_read_pos < length && f.extended_gene_pos <= target.gene_end)) { f.state = ALIGN_NEXT_HIT; break; }
 					if (is_splice_site_from(target, f.extended_gene_pos - 1, f.splice_cursor)) { f.state = ALIGN_COMPARE_BASE; call = true; call_max_deletions = f.max_deletions; break; } // re-seed behind a splice site (spliced alignment)
 					if (f.extended_gene_pos >= window_end || f.extended_gene_pos < window_at) { window_at = f.extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
@@ -246,8 +252,17 @@ struct AlignRunner {
 #endif
 	}
 	// reference: align(0, read, 0, contig, gene_start, gene_start, gene_end, ...) (source/filter_mismappers.cpp:86-199)
+	bool lanes_share_seeds = false; // the lanes work on the same read position and split its seeds (reads with hundreds of seeds per position); default: one read position per lane
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
+		if (lanes_share_seeds) {
+			for (int32_t read_pos = 0; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; ++read_pos) {
+				const bool found = align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, lane, lanes);
+				if (exhausted()) return false;
+				if (any(found)) return true;
+			}
+			return false;
+		}
 		for (int32_t base = 0; base + KMER_LENGTH < length && 2 * base + min_score <= length + 2 * KMER_LENGTH; base += (int32_t) lanes) { // the loop bound of the reference at read_pos = base
 			const int32_t read_pos = base + (int32_t) lane;
 			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget);

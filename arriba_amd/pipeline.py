@@ -132,7 +132,7 @@ class DevicePipeline(object):
     stepping harness of tests/emu instead.
     """
 
-    def __init__(self, session, params=None, api=None, device=0, batch_view=None, bam=None, external_duplicate_marking=False, max_itd_length=100, piece_bytes=64 << 20):
+    def __init__(self, session, params=None, api=None, device=0, batch_view=None, bam=None, external_duplicate_marking=False, max_itd_length=100, piece_bytes=64 << 20, profiling=False):
         """bam: path of the BAM file -> read_chimeric_alignments runs on the device (agpu_ingest_*): the host session only opens the file, parses the
         header and feeds the bytes; the batch never exists on the host.  Without it the batch of the session's host ingest is uploaded."""
         self.session = session
@@ -157,6 +157,8 @@ class DevicePipeline(object):
         self._check(self.api.upload_annotation(self.ctx, session.annotation_view))
         self.device_ingest = bam is not None
         self.ingest_result = None
+        if profiling:
+            self.set_profiling(True)  # before the ingest: its kernels are part of the profile
         if self.device_ingest:
             self.read_chimeric_alignments(bam, external_duplicate_marking, max_itd_length, piece_bytes)
         else:

@@ -224,7 +224,7 @@ def main():
                 pipeline.set_profiling(profiling[0])
                 ingest_parts.append({"host_ingest": time.perf_counter() - started})
             elif pipeline is None:
-                pipeline = DevicePipeline(session, params=params, device=local_rank, bam=prefix + ".bam", piece_bytes=256 << 20)
+                pipeline = DevicePipeline(session, params=params, device=local_rank, bam=prefix + ".bam", piece_bytes=256 << 20, profiling=profiling[0] or args.warmup == 0)
                 ingest_parts.append(dict(pipeline.ingest_seconds))
             else:
                 pipeline.read_chimeric_alignments(prefix + ".bam", piece_bytes=256 << 20)
