@@ -168,18 +168,27 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 }
 
 // Second pass, one wavefront per heavy read: the read positions one after the other, the seeds of a position split among the 64 lanes (every seed of the outermost
-// loop of align() is an independent attempt), full stack, no budget; the segment in LDS is shared by the lanes.
-__global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap, unsigned int* counters) {
+// loop of align() is an independent attempt), full stack, no budget; the segment in LDS is shared by the lanes, and so is the memo of failed nested calls
+// (AlignMemo, mismapper_core.hpp: it turns the exponential re-evaluation of the reference's recursion into one search per distinct call).  The workgroups are
+// persistent: each owns one memo table in HBM and takes heavy reads in turn.
+const uint32_t MEMO_SLOTS = 1u << 18;   // 2 MB per workgroup
+const uint32_t HEAVY_WORKGROUPS = 1024;
+__global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
+                                                             unsigned long long* memo_tables, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
-	const uint32_t j = blockIdx.x;
-	if (j >= n_heavy) return;
+	__shared__ AlignMemo memo;
+	if (threadIdx.x == 0) { memo.slots = memo_tables + (size_t) blockIdx.x * MEMO_SLOTS; memo.mask = MEMO_SLOTS - 1; memo.epoch = 0; }
+	__syncthreads();
 	AlignFrame stack[ALIGN_MAX_DEPTH];
 	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = nullptr; runner.max_depth = ALIGN_MAX_DEPTH;
-	runner.lanes_share_seeds = true; // a read lands here because some of its read positions have hundreds of seeds (repeats, runs of N in the gene): the lanes split them
+	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position
+	runner.memo = &memo;
 	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
-	const uint32_t read = heavy[j];
-	const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
-	if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
+	for (uint32_t j = blockIdx.x; j < n_heavy; j += gridDim.x) {
+		const uint32_t read = heavy[j];
+		const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
+		if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
+	}
 }
 
 __global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, bool count_only, unsigned int* remaining) {
@@ -354,8 +363,12 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 			}
 			ctx->mismapper_heavy = n_heavy;
 			if (n_heavy > 0) {
+				const uint32_t workgroups = std::min<uint32_t>(n_heavy, HEAVY_WORKGROUPS);
+				DeviceBuffer& memo_tables = ctx->scratch("mismappers.memo_tables");
+				ALLOC(memo_tables, (size_t) workgroups * MEMO_SLOTS * 8);
+				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * MEMO_SLOTS * 8, s));
 				KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-				mismapper_heavy_kernel<<<n_heavy, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, device_counters);
+				mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), device_counters);
 			}
 		}
 		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);

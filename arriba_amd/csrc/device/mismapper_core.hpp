@@ -72,6 +72,57 @@ AGPU_HD bool is_splice_site_from(const AlignTarget& target, int32_t position, ui
 }
 AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; } // eight genome bases at once (the genome buffer is padded behind its end)
 
+// Memo of failed nested calls.  A nested align(score, read_pos, gene_pos, max_deletions) is monotone in `score` -- a higher score only loosens the bound of its
+// read-position loop and raises every score it compares with min_score -- so a call that failed with score s fails with every score <= s.  The reference
+// re-runs such calls from scratch: behind every splice site an extension crosses it starts a full search of the rest of the read against the rest of the gene,
+// whose extensions cross splice sites again -- in a long gene with many exons the number of calls grows exponentially with the nesting (seconds to hours per
+// read), although there are only (read positions x splice sites + seeds) distinct calls.  With the memo every distinct call is searched once per score level.
+// The result is the reference's: only calls that are known to return false are skipped.
+// A slot holds epoch (8 bits: one per align() invocation, so that the table never needs clearing) | gene_pos - gene_start (24) | read_pos (9) | max_deletions (1) |
+// score + 32768 (16): for equal keys the larger word is the higher failed score.
+struct AlignMemo {
+	unsigned long long* slots; uint32_t mask; uint32_t epoch; // (no default initialisers: the device keeps one in LDS)
+	AGPU_HD bool usable(int32_t gene_start, int32_t gene_end) const { return slots != nullptr && (int64_t) gene_end - gene_start < (1 << 24); }
+	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions) const {
+		return ((unsigned long long) (epoch & 255u) << 34 | (unsigned long long) (uint32_t) gene_offset << 10 | (unsigned long long) (uint32_t) read_pos << 1 | (unsigned long long) (max_deletions > 0)) << 16;
+	}
+	AGPU_HD uint32_t slot_of(unsigned long long key) const { unsigned long long h = key * 0x9E3779B97F4A7C15ull; return (uint32_t) (h >> 40) & mask; }
+	// is a call with this key and a score <= the recorded one known to fail?
+	AGPU_HD bool known_to_fail(unsigned long long key, int32_t score) const {
+		uint32_t at = slot_of(key);
+		for (int probe = 0; probe < 8; ++probe, at = (at + 1) & mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			const unsigned long long slot = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+			const unsigned long long slot = slots[at];
+#endif
+			if ((slot >> 16) == (key >> 16)) return score + 32768 <= (int32_t) (slot & 0xFFFF);
+			if ((slot >> 50) != (key >> 50)) return false; // empty or from an earlier align(): the key is not in the table
+		}
+		return false;
+	}
+	AGPU_HD void record_failure(unsigned long long key, int32_t score) const {
+		if (score < -32768 || score > 32767) return;
+		const unsigned long long word = key | (unsigned long long) (uint32_t) (score + 32768);
+		uint32_t at = slot_of(key);
+		for (int probe = 0; probe < 8; ++probe, at = (at + 1) & mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			unsigned long long slot = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((slot >> 16) == (key >> 16)) { atomicMax(&slots[at], word); return; }
+			if ((slot >> 50) != (key >> 50)) { // free for this epoch: take it (if another lane was faster with another key, go on probing)
+				const unsigned long long seen = atomicCAS(&slots[at], slot, word);
+				if (seen == slot) return;
+				if ((seen >> 16) == (key >> 16)) { atomicMax(&slots[at], word); return; }
+			}
+#else
+			const unsigned long long slot = slots[at];
+			if ((slot >> 16) == (key >> 16)) { if (word > slot) slots[at] = word; return; }
+			if ((slot >> 50) != (key >> 50)) { slots[at] = word; return; }
+#endif
+		}
+	}
+};
+
 // One invocation of the reference's align() (source/filter_mismappers.cpp:86-199) as a resumable frame: the two recursive
 // re-seeds of the reference push a child frame and continue behind the call when the child reports failure.
 enum { ALIGN_NEXT_READ_POSITION = 0, ALIGN_NEXT_HIT = 1, ALIGN_RIGHT_LOOP = 2, ALIGN_COMPARE_BASE = 3, ALIGN_AFTER_MISMATCH = 4, ALIGN_ADVANCE = 5 };
@@ -103,8 +154,9 @@ AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t
 // The frame that is being worked on lives in registers; `stack` only holds the frames of the callers (written when a nested call starts, read when it fails).
 // `hit_offset`, `hit_stride`: of the seeds at the first read position this call only follows number hit_offset, hit_offset + hit_stride, ... (every seed is an
 // independent attempt, too: the lanes of a wavefront share the seeds of one read position among them when a read has many).
-AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1) {
+AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1, const AlignMemo* memo = nullptr) {
 	const int32_t length = (int32_t) read.length;
+	const bool use_memo = memo != nullptr && memo->usable(target.gene_start, target.gene_end);
 	int depth = 0;
 	AlignFrame f;
 	align_enter(f, -first_read_pos, first_read_pos, target.gene_start, 1);
@@ -209,6 +261,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				break;
 			}
 		}
+		if (call && use_memo && memo->known_to_fail(memo->key_of(f.extended_read_pos, f.extended_gene_pos - target.gene_start, call_max_deletions), f.extended_score)) call = false; // searched before, with at least this score
 		if (call) { // the caller's frame goes to the stack, the nested call takes the registers
 			if (depth >= max_depth) { if (budget != nullptr) *budget = -1; return false; } // deeper than this stack: left to a caller with a deeper one
 			stack[depth] = f;
@@ -217,6 +270,8 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 			align_enter(f, score, read_pos, gene_pos, call_max_deletions);
 		} else if (fail) { // this call returns false: the caller goes on behind the call
 			if (depth == 0) return false;
+			// (a nested call entered with read position read_pos - skipped_bases and score score + skipped_bases: both move together in its loop)
+			if (use_memo) memo->record_failure(memo->key_of(f.read_pos - f.skipped_bases, f.gene_pos - target.gene_start, f.max_deletions), f.score + f.skipped_bases);
 			--depth;
 			f = stack[depth];
 		}
@@ -252,12 +307,27 @@ struct AlignRunner {
 #endif
 	}
 	// reference: align(0, read, 0, contig, gene_start, gene_start, gene_end, ...) (source/filter_mismappers.cpp:86-199)
+	AlignMemo* memo = nullptr; // table of failed nested calls, shared by the lanes of the runner (second pass on the device); every align() takes a new epoch
 	bool lanes_share_seeds = false; // the lanes work on the same read position and split its seeds (reads with hundreds of seeds per position); default: one read position per lane
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
+		if (memo != nullptr) { // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (lanes > 1) __syncthreads();
+#endif
+			const uint32_t next = (memo->epoch + 1) & 255u; // (every lane reads the same value)
+			if (next == 0) for (uint32_t k = lane; k <= memo->mask; k += lanes) memo->slots[k] = 0; // the epoch numbers wrap around: start clean (epoch 0 = empty slots)
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (lanes > 1) __syncthreads();
+#endif
+			if (lane == 0) memo->epoch = next == 0 ? 1 : next;
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (lanes > 1) __syncthreads();
+#endif
+		}
 		if (lanes_share_seeds) {
 			for (int32_t read_pos = 0; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; ++read_pos) {
-				const bool found = align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, lane, lanes);
+				const bool found = align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, lane, lanes, memo);
 				if (exhausted()) return false;
 				if (any(found)) return true;
 			}
@@ -265,7 +335,7 @@ struct AlignRunner {
 		}
 		for (int32_t base = 0; base + KMER_LENGTH < length && 2 * base + min_score <= length + 2 * KMER_LENGTH; base += (int32_t) lanes) { // the loop bound of the reference at read_pos = base
 			const int32_t read_pos = base + (int32_t) lane;
-			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget);
+			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, 0, 1, memo);
 			if (exhausted()) return false;
 			if (any(found)) return true;
 		}
