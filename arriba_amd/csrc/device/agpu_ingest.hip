@@ -29,9 +29,6 @@ using namespace agpu;
 namespace {
 
 const int BLOCK = 256;
-const uint32_t SEGMENT_BYTES = 8192;
-const uint64_t SEARCH_LIMIT = 4u << 20;    // how far a segment looks for its first record before it leaves the answer to the repair pass
-const uint64_t OFFSET_NONE = ~0ull, OFFSET_BROKEN = ~0ull - 1;
 inline unsigned int grid_for(uint64_t n, int block = BLOCK) { return (unsigned int) ((n + block - 1) / block); }
 
 enum { IC_ACTIVE = 0, IC_MAPPED_READS = 1, IC_MISSING_HI = 2, IC_BROKEN = 3, IC_MALFORMED = 4, IC_CHIMERIC = 5, IC_COLLISION = 6, IC_MISMATCH = 7, IC_UNSORTED = 8, IC_MAX_NAME = 9,
@@ -68,52 +65,9 @@ __device__ uint32_t crc32_update(uint32_t crc, uint8_t byte) {
 
 // ---- the record chain -----------------------------------------------------------------------------------------------------------------------------
 
-// a record header that could be real: sizes consistent, reference ids in range, the name terminated
-__device__ bool plausible_record(const uint8_t* bytes, uint64_t size, uint64_t o, uint32_t n_targets) {
-	if (o + 36 > size) return false;
-	const uint32_t block_size = load_u32(bytes + o);
-	if (block_size < 32 || block_size > (1u << 28) || o + 4 + (uint64_t) block_size > size) return false;
-	const uint8_t* p = bytes + o + 4;
-	const int32_t tid = (int32_t) load_u32(p), pos = (int32_t) load_u32(p + 4), next_tid = (int32_t) load_u32(p + 20), next_pos = (int32_t) load_u32(p + 24);
-	if (tid < -1 || tid >= (int32_t) n_targets || next_tid < -1 || next_tid >= (int32_t) n_targets || pos < -1 || next_pos < -1) return false;
-	if (!record_sizes_ok(p, block_size)) return false;
-	const uint32_t l_read_name = p[8];
-	return p[32 + l_read_name - 1] == 0;
-}
-
-// walks the chain from `start` to the first record at or behind `segment_end`; OFFSET_BROKEN if a block size cannot be right
-__device__ uint64_t walk_segment(const uint8_t* bytes, uint64_t size, uint64_t start, uint64_t segment_end, uint32_t& count, uint64_t* offsets) {
-	uint64_t o = start;
-	count = 0;
-	while (o < segment_end) {
-		if (o + 4 > size) return OFFSET_BROKEN;
-		const uint32_t block_size = load_u32(bytes + o);
-		if (block_size < 32 || o + 4 + (uint64_t) block_size > size) return OFFSET_BROKEN;
-		if (offsets != nullptr) offsets[count] = o;
-		++count;
-		o += 4 + (uint64_t) block_size;
-	}
-	return o;
-}
-
 __global__ void segment_guess_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, uint32_t n_targets, uint64_t* first, uint64_t* end, uint32_t* count) {
 	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (s >= n_segments) return;
-	const uint64_t begin = base + s * SEGMENT_BYTES, segment_end = (begin + SEGMENT_BYTES < size) ? begin + SEGMENT_BYTES : size;
-	uint64_t start = OFFSET_NONE;
-	if (s == 0) start = base;
-	else {
-		const uint64_t limit = (begin + SEARCH_LIMIT < size) ? begin + SEARCH_LIMIT : size;
-		for (uint64_t o = begin; o < limit; ++o) {
-			if (!plausible_record(bytes, size, o, n_targets)) continue;
-			const uint64_t next = o + 4 + (uint64_t) load_u32(bytes + o);
-			if (next == size || plausible_record(bytes, size, next, n_targets)) { start = o; break; }
-		}
-	}
-	first[s] = start;
-	uint32_t n = 0;
-	end[s] = (start == OFFSET_NONE) ? OFFSET_NONE : walk_segment(bytes, size, start, segment_end, n, nullptr);
-	count[s] = n;
+	if (s < n_segments) guess_segment(bytes, size, base, s, n_targets, first, end, count);
 }
 
 __global__ void segment_check_kernel(const uint64_t* first, const uint64_t* end, uint64_t n_segments, uint8_t* mismatch, uint32_t* counters) {
@@ -127,16 +81,9 @@ __global__ void segment_check_kernel(const uint64_t* first, const uint64_t* end,
 	block_tally(mine, &counters[IC_MISMATCH], &block_sum);
 }
 
-// a segment whose guess is not the end of the segment before it starts again from there (`previous_end`: the ends as they were before this launch)
 __global__ void segment_repair_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, const uint8_t* mismatch, const uint64_t* previous_end, uint64_t* first, uint64_t* end, uint32_t* count) {
 	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (s >= n_segments || !mismatch[s]) return;
-	const uint64_t begin = base + s * SEGMENT_BYTES, segment_end = (begin + SEGMENT_BYTES < size) ? begin + SEGMENT_BYTES : size;
-	const uint64_t start = previous_end[s - 1];
-	first[s] = start;
-	uint32_t n = 0;
-	end[s] = (start >= OFFSET_BROKEN) ? start : walk_segment(bytes, size, start, segment_end, n, nullptr);
-	count[s] = n;
+	if (s < n_segments) repair_segment_run(bytes, size, base, n_segments, s, mismatch, previous_end, first, end, count);
 }
 
 __global__ void segment_emit_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, const uint64_t* first, const uint32_t* record_base, uint64_t* record_offset) {

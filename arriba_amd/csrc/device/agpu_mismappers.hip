@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 // loop of align() is an independent attempt), full stack, no budget; the segment in LDS is shared by the lanes, and so is the memo of failed nested calls
 // (AlignMemo, mismapper_core.hpp: it turns the exponential re-evaluation of the reference's recursion into one search per distinct call).  The workgroups are
 // persistent: each owns one memo table in HBM and takes heavy reads in turn.
-const uint32_t MEMO_SLOTS = 1u << 18;   // 2 MB per workgroup
+const uint32_t MEMO_SLOTS = 1u << 21;   // 16 MB per workgroup (a read of a long gene makes 10^5..10^6 distinct nested calls)
 const uint32_t HEAVY_WORKGROUPS = 1024;
 __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
                                                              unsigned long long* memo_tables, unsigned int* counters) {

@@ -90,7 +90,7 @@ struct AlignMemo {
 	// is a call with this key and a score <= the recorded one known to fail?
 	AGPU_HD bool known_to_fail(unsigned long long key, int32_t score) const {
 		uint32_t at = slot_of(key);
-		for (int probe = 0; probe < 8; ++probe, at = (at + 1) & mask) {
+		for (int probe = 0; probe < 16; ++probe, at = (at + 1) & mask) {
 #if defined(__HIP_DEVICE_COMPILE__)
 			const unsigned long long slot = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
@@ -105,7 +105,7 @@ struct AlignMemo {
 		if (score < -32768 || score > 32767) return;
 		const unsigned long long word = key | (unsigned long long) (uint32_t) (score + 32768);
 		uint32_t at = slot_of(key);
-		for (int probe = 0; probe < 8; ++probe, at = (at + 1) & mask) {
+		for (int probe = 0; probe < 16; ++probe, at = (at + 1) & mask) {
 #if defined(__HIP_DEVICE_COMPILE__)
 			unsigned long long slot = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if ((slot >> 16) == (key >> 16)) { atomicMax(&slots[at], word); return; }

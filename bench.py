@@ -212,18 +212,21 @@ def main():
             command = [sys.executable, os.path.abspath(__file__), "--fragments", str(args.fragments), "--steps", str(args.steps), "--warmup", str(args.warmup)]
             command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--no-cpu-baseline", args.no_cpu_baseline)) if on]
             limit = float(os.environ.get("ARRIBA_BENCH_LARGE_LIMIT", "900"))
+            child_scratch = scratch_directory(args.fragments * 600)  # the child's sample lives here; removed below whatever happens to the child
             try:
-                child = subprocess.run(command, stdout=subprocess.PIPE, env=dict(os.environ, ARRIBA_BENCH_CHILD="1"), timeout=limit, universal_newlines=True)
+                child = subprocess.run(command, stdout=subprocess.PIPE, env=dict(os.environ, ARRIBA_BENCH_CHILD="1", ARRIBA_BENCH_SCRATCH=child_scratch), timeout=limit, universal_newlines=True)
                 lines = [line for line in child.stdout.splitlines() if line.startswith("{")]
                 if child.returncode == 0 and lines:
                     print(lines[-1])
                     return
-                fallback_reason = "the 100 M sample ended with exit code %d and no line" % child.returncode
+                fallback_reason = ("a step of the 100 M sample takes too long for %d steps + %d warm-up steps within the time budget (python bench.py --fragments 100000000 --steps 1 --warmup 0 runs it: profiles/r02g_bench100m.json)" % (args.steps, args.warmup)) if child.returncode == 3 else "the 100 M sample ended with exit code %d and no line" % child.returncode
             except subprocess.TimeoutExpired:
                 fallback_reason = "the 100 M sample did not finish within %.0f s" % limit
+            finally:
+                shutil.rmtree(child_scratch, ignore_errors=True)
             progress("falling back to 10 M fragments: " + fallback_reason)
             args.fragments = 10000000
-    directory = args.keep or scratch_directory(args.fragments * 600)
+    directory = args.keep or os.environ.get("ARRIBA_BENCH_SCRATCH") or scratch_directory(args.fragments * 600)
     os.makedirs(directory, exist_ok=True)
     try:
         prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, ((os.cpu_count() or 2) - 2) // world)))
@@ -234,7 +237,7 @@ def main():
         params = {"subsampling_threshold": 32767} if args.stress else None
         pipeline = None
         outputs = [os.path.join(directory, "fusions.tsv"), os.path.join(directory, "discarded.tsv") if args.discarded else None]
-        stage_log, step_seconds, ingest_parts = [], [], []
+        stage_log, step_seconds, ingest_parts, steps_done = [], [], [], [0]
 
         def step():
             nonlocal pipeline
@@ -264,6 +267,12 @@ def main():
             pipeline.run_workflow(outputs[0], outputs[1], log=note)
             finished = time.perf_counter()
             step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started})
+            steps_done[0] += 1
+            remaining = args.warmup + args.steps - steps_done[0]
+            if os.environ.get("ARRIBA_BENCH_CHILD") and remaining * (finished - started) > float(os.environ.get("ARRIBA_BENCH_TIME_BUDGET", "600")):
+                # the large sample with this many steps would take too long for a bench run: say so and let the parent print the line of config 2
+                progress("a step of the %d-fragment sample takes %.1f s: %d more steps do not fit the time budget" % (args.fragments, finished - started, remaining))
+                raise SystemExit(3)  # (through the `finally` below: the 54 GB sample must not stay behind)
             progress("step done: read_chimeric_alignments %.2f s %s, workflow %.2f s; slowest stages: %s" % (ingested - started, ingest_parts[-1], finished - ingested,
                      sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4]))
 

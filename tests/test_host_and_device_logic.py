@@ -315,6 +315,47 @@ def test_device_ingest_reads_every_container_and_pipes(built, dataset_files, emu
             ingest(str(tmp_path / name))
 
 
+def test_device_ingest_survives_a_false_record_start(built, dataset_files, emu_api, tmp_path):
+    """The record chain is cut by segments that GUESS their first record.  A record whose aux array holds two well-formed record headers exactly at the start of
+    an 8 KB segment makes that guess wrong (and flags the segment behind it, whose own guess is right): one repair pass must settle the chain -- not one pass per
+    segment until the end of the stream -- and the batch must be the host ingest's."""
+    import ctypes
+    import struct
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    prefix = dataset_files("toy3k")
+    payload = _bam_payload(prefix + ".bam")
+    l_text = struct.unpack_from("<I", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<I", payload, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 4 + struct.unpack_from("<I", payload, at)[0] + 4
+    base = at
+    cut = base  # a record boundary ~100 kB into the stream
+    while cut < base + 100000:
+        cut += 4 + struct.unpack_from("<I", payload, cut)[0]
+    fake = struct.pack("<IiiBBHHHiiii", 40, 0, 5, 2, 0, 0, 0, 0, 0, -1, -1, 0) + b"y\0" + b"\0" * 6   # block_size 40: a complete, plausible record of 44 bytes
+    assert len(fake) == 44
+    carrier_head = 4 + 32 + 2 + 8  # block_size, fixed fields, name "x\0", aux tag + 'B' + 'C' + count
+    pad = (base - cut - carrier_head) % 8192
+    body = b"\xAA" * pad + fake + fake + b"\xFF" * 64
+    carrier = struct.pack("<iiBBHHHiiii", -1, -1, 2, 0, 0, 0, 4, 0, -1, -1, 0) + b"x\0" + b"ZZBC" + struct.pack("<I", len(body)) + body  # an unmapped record: no stage looks at it
+    stream = payload[:cut] + struct.pack("<I", len(carrier)) + carrier + payload[cut:]
+    assert (cut + carrier_head + pad - base) % 8192 == 0
+    path = str(tmp_path / "false_start.bam")
+    open(path, "wb").write(stream)
+    host = HostSession(prefix + ".fa", prefix + ".gtf")
+    host.read_chimeric_alignments(path)
+    expected = _batch_columns(host)
+    expected["coverage"] = int(host._lib.ahost_coverage_checksum(host._session))
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    pipeline = DevicePipeline(session, api=emu_api, bam=path, piece_bytes=1 << 20)
+    assert _device_batch_columns(session, pipeline) == expected and expected["n"] > 2000
+    harness = ctypes.CDLL(os.path.join(conftest.ROOT, "tests", "emu", "libemu.so"))
+    harness.emu_ingest_repair_passes.restype = ctypes.c_uint64
+    assert harness.emu_ingest_repair_passes() == 1
+
+
 def test_ingest_result_survives_save_and_load(built, dataset_files, tmp_path):
     from arriba_amd.pipeline import ArribaError, HostSession
     prefix = dataset_files("shuffled2k")
