@@ -69,7 +69,7 @@ class BatchView(ctypes.Structure):
 
 class IngestConfig(ctypes.Structure):
     _fields_ = [("n_targets", c_uint32), ("tid_to_contig", POINTER(c_uint32)), ("first_record_offset", c_uint64), ("stream_size_hint", c_uint64), ("n_contigs", c_uint32),
-                ("coverage_window_offset", POINTER(c_uint64)), ("external_duplicate_marking", c_uint8), ("max_itd_length", c_uint32)]
+                ("coverage_window_offset", POINTER(c_uint64)), ("external_duplicate_marking", c_uint8), ("max_itd_length", c_uint32), ("part_of_sample", c_uint8)]
 
 
 class BgzfBlock(ctypes.Structure):
@@ -199,6 +199,12 @@ def bind_device_api(lib, prefix="agpu_"):
         "ingest_push": (c_int, [ctx, c_void_p, c_size_t]),
         "ingest_push_bgzf": (c_int, [ctx, c_void_p, c_size_t, POINTER(BgzfBlock), c_uint32, c_size_t]),
         "ingest_finish": (c_int, [ctx, POINTER(IngestResult)]),
+        "shard_export_size": (c_int, [ctx, POINTER(c_uint64)]),
+        "shard_export": (c_int, [ctx, c_void_p, c_uint64]),
+        "shard_merge": (c_int, [ctx, c_void_p, c_uint64, c_uint32, POINTER(IngestResult)]),
+        "mismapper_jobs": (c_int, [ctx, POINTER(c_uint64)]),
+        "mismapper_verdicts": (c_int, [ctx, c_int32, c_uint32, c_uint32, c_void_p]),
+        "filter_mismappers_apply": (c_int, [ctx, c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
         "get_viral_read_counts": (c_int, [ctx, c_void_p]),
         "get_coverage": (c_int, [ctx, c_void_p, c_void_p, c_void_p]),
         "detect_strandedness": (c_int, [ctx, POINTER(c_int)]),
@@ -255,6 +261,7 @@ def bind_host_api(lib):
         "ahost_estimate_fragment_length_from_sums": (c_int, [c_void_p, c_uint32, c_float, c_uint64, ctypes.c_uint, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int32)]),
         "ahost_candidate_iteration_order": (c_int, [c_uint64] + [c_void_p] * 7),
         "ahost_bam_open": (c_int, [session, c_char_p, c_int, ctypes.c_uint, POINTER(IngestConfig)]),
+        "ahost_bam_open_part": (c_int, [session, c_char_p, c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, POINTER(IngestConfig)]),
         "ahost_bam_next": (c_int, [session, c_void_p, c_size_t, POINTER(BgzfBlock), c_uint32, POINTER(BamPiece)]),
         "ahost_bam_close": (None, [session]),
         "ahost_adopt_device_ingest": (c_int, [session, POINTER(IngestResult), c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -101,7 +101,8 @@ struct agpu_ctx {
 	uint64_t ingest_stream_size = 0, ingest_first_record = 0, names_size = 0;
 	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0;
 	uint8_t ingest_external_duplicate_marking = 0;
-	bool ingest_active = false, batch_from_ingest = false;
+	bool ingest_active = false, batch_from_ingest = false, ingest_part_of_sample = false;
+	agpu_ingest_result ingest_result; uint64_t ingest_pool_sizes[2] = { 0, 0 }; // what the last ingest (or merge of parts) reported; CIGAR words and sequence bytes of its pools
 	hipEvent_t ingest_events[2] = { nullptr, nullptr };
 	std::vector<uint64_t> host_coverage_window_offset;
 	agpu::DeviceBuffer gather_ids, gather_cigar_base, gather_seq_base, gather_name_base; // agpu_gather_rows_begin -> _copy
@@ -134,7 +135,7 @@ struct agpu_ctx {
 	// k-mer index + splice sites (filter_mismappers)
 	agpu::DeviceBuffer kmer_contig_table, kmer_offsets, kmer_positions, splice_offset, splice_sites;
 	uint32_t kmer_positions_count = 0, splice_sites_for_dummy = 0, mismapper_jobs = 0, mismapper_heavy = 0;
-	bool kmer_index_done = false, have_splice_sites = false;
+	bool kmer_index_done = false, have_splice_sites = false, mismapper_jobs_ready = false;
 	agpu::CandidateTable candidates;
 	uint32_t n_emissions = 0, n_candidates = 0, n_list_entries = 0, n_queued_buckets = 0, n_discordant_emissions = 0;
 	bool fusions_done = false;

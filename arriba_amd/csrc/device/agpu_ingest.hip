@@ -23,6 +23,7 @@
 #include "agpu_context.hpp"
 #include "ingest_core.hpp"
 #include "device_utils.hpp"
+#include "shard_host.hpp"
 
 using namespace agpu;
 
@@ -260,6 +261,22 @@ __global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, c
 	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_READ_LENGTH], block_max);
 }
 
+// agpu_shard_merge: a 32-bit column of one part into its place in the whole, pool offsets moved behind the pools of the parts before it
+// (slot < 3: only where the fragment has that alignment -- the unused slots of a row hold 0, as fragment_pack_kernel leaves them)
+__global__ void shard_rebase_kernel(uint32_t* out, const uint32_t* in, uint64_t n, uint32_t base, const uint8_t* n_aln, uint32_t slot) {
+	const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = in[i] + ((slot >= 3 || slot < n_aln[i]) ? base : 0u);
+}
+// ... the coverage of one part added to the whole: windows before their saturation (sums), start / end flags (ORs), viral read counts (sums)
+__global__ void shard_add_coverage_kernel(uint32_t* windows, uint8_t* starts, uint8_t* ends, const uint32_t* part_windows, const uint8_t* part_starts, const uint8_t* part_ends, uint64_t n) {
+	const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { windows[i] += part_windows[i]; starts[i] |= part_starts[i]; ends[i] |= part_ends[i]; }
+}
+__global__ void shard_add_counts_kernel(unsigned long long* counts, const unsigned long long* part, uint32_t n) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) counts[i] += part[i];
+}
+
 __global__ void coverage_clamp_kernel(const uint32_t* windows, uint64_t n, uint16_t* out) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i < n) out[i] = windows[i] > 65535u ? (uint16_t) 65535 : (uint16_t) windows[i];
@@ -378,7 +395,7 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	hipStream_t s = ctx->stream;
 	for (int k = 0; k < 2; ++k) if (!ctx->ingest_events[k]) HIP_CHECK(hipEventCreateWithFlags(&ctx->ingest_events[k], hipEventDisableTiming));
 	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
-	ctx->ingest_external_duplicate_marking = config->external_duplicate_marking; ctx->ingest_max_itd_length = config->max_itd_length;
+	ctx->ingest_external_duplicate_marking = config->external_duplicate_marking; ctx->ingest_max_itd_length = config->max_itd_length; ctx->ingest_part_of_sample = config->part_of_sample != 0;
 	ALLOC(ctx->ingest_tid_to_contig, std::max<size_t>(config->n_targets, 1) * 4);
 	if (config->n_targets) HIP_CHECK(hipMemcpyAsync(ctx->ingest_tid_to_contig.ptr, config->tid_to_contig, (size_t) config->n_targets * 4, hipMemcpyHostToDevice, s));
 	ctx->host_coverage_window_offset.assign(config->coverage_window_offset, config->coverage_window_offset + config->n_contigs + 1);
@@ -595,7 +612,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	for (int k = 0; k < 3; ++k) { ALLOC(ctx->contig[k], n * 2); ALLOC(ctx->start[k], n * 4); ALLOC(ctx->end[k], n * 4); ALLOC(ctx->abits[k], n); ALLOC(ctx->cigar_offset[k], n * 4); ALLOC(ctx->cigar_count[k], n * 2); }
 	for (int k = 0; k < 2; ++k) { ALLOC(ctx->seq_offset[k], n * 4); ALLOC(ctx->seq_length[k], n * 4); }
 	ALLOC(ctx->cigar_pool, totals[0] * 4); ALLOC(ctx->seq_pool, totals[1]); ALLOC(ctx->names, totals[2]); ALLOC(ctx->name_offset, (n + 1) * 4);
-	ctx->names_size = totals[2];
+	ctx->names_size = totals[2]; ctx->ingest_pool_sizes[0] = totals[0]; ctx->ingest_pool_sizes[1] = totals[1];
 	PackTarget target;
 	fill_pack_target(ctx, target);
 	{ KernelTimer timer(ctx, "fragment_pack_kernel", n * (1 + 1 + 4 + 3 * 17 + 16 + 4 + 24) + totals[0] * 8 + totals[1] * 2 + totals[2] * 2);
@@ -618,18 +635,189 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ctx->batch_from_ingest = true;
 	// the stream and the per-record tables are not needed any more: give the memory back (a 10^8-fragment stream is ~54 GB)
 	if (getenv("ARRIBA_KEEP_INGEST_BUFFERS") == nullptr) {
-		ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release(); ctx->coverage_windows32.release();
+		ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release();
+		if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
 		static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.plain_plans", "ingest.itd_plans",
 			"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
 			"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
 		for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) ctx->scratch(temporary[k]).release();
 	}
 	ctx->ingest_stream_size = 0;
-	if (result) {
-		memset(result, 0, sizeof(*result));
-		result->records = n_records; result->fragments = n; result->mapped_reads = mapped_reads; result->malformed_count = malformed_count; result->missing_hi_tag = missing_hi_tag;
-		result->no_chimeric_reads = no_chimeric_reads; result->names_were_sorted = names_were_sorted; result->stream_bytes = size;
+	agpu_ingest_result& mine = ctx->ingest_result;
+	memset(&mine, 0, sizeof(mine));
+	mine.records = n_records; mine.fragments = n; mine.mapped_reads = mapped_reads; mine.malformed_count = malformed_count; mine.missing_hi_tag = missing_hi_tag;
+	mine.no_chimeric_reads = no_chimeric_reads; mine.names_were_sorted = names_were_sorted; mine.stream_bytes = size;
+	if (result) *result = mine;
+	return AGPU_OK;
+}
+
+// ---- one sample over several GPUs: the batch of a part as one block of bytes, the blocks of all parts as the batch of the sample (shard_host.hpp) ------------
+
+static int shard_header_of(agpu_ctx* ctx, ShardHeader& h) {
+	memset(&h, 0, sizeof(h));
+	const uint64_t n = ctx->n;
+	h.magic = SHARD_MAGIC; h.n = n;
+	uint32_t ends[4] = { 0, 0, 0, 0 }; // cigar words, sequence words, name bytes, last group id: what the last row says
+	h.names_bytes = ctx->names_size;
+	h.windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back(); h.n_contigs = ctx->genome.n_contigs;
+	if (n > 0) {
+		HIP_CHECK(hipMemcpy(&ends[3], ctx->group.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost));
+		h.groups = (uint64_t) ends[3] + 1;
 	}
+	h.cigar_words = ctx->ingest_pool_sizes[0]; h.sequence_bytes = ctx->ingest_pool_sizes[1];
+	const agpu_ingest_result& r = ctx->ingest_result;
+	h.records = r.records; h.mapped_reads = r.mapped_reads; h.malformed_count = r.malformed_count; h.missing_hi_tag = r.missing_hi_tag; h.no_chimeric_reads = r.no_chimeric_reads;
+	h.names_were_sorted = r.names_were_sorted; h.stream_bytes = r.stream_bytes; h.max_read_length = ctx->max_read_length;
+	h.total_bytes = shard_layout(h).total;
+	return AGPU_OK;
+}
+
+// the columns of the context's batch in the order of the sections (null where the section has no column of the context)
+static void shard_columns(agpu_ctx* ctx, void* columns[SHARD_SECTIONS]) {
+	for (int k = 0; k < SHARD_SECTIONS; ++k) columns[k] = nullptr;
+	columns[SHARD_N_ALN] = ctx->n_aln.ptr; columns[SHARD_FBITS] = ctx->fbits.ptr; columns[SHARD_GROUP] = ctx->group.ptr;
+	for (int slot = 0; slot < 3; ++slot) {
+		void** c = columns + SHARD_SLOT0 + slot * SHARD_SLOT_FIELDS;
+		c[SHARD_SLOT_CONTIG] = ctx->contig[slot].ptr; c[SHARD_SLOT_START] = ctx->start[slot].ptr; c[SHARD_SLOT_END] = ctx->end[slot].ptr; c[SHARD_SLOT_ABITS] = ctx->abits[slot].ptr;
+		c[SHARD_SLOT_CIGAR_OFFSET] = ctx->cigar_offset[slot].ptr; c[SHARD_SLOT_CIGAR_COUNT] = ctx->cigar_count[slot].ptr;
+	}
+	columns[SHARD_SEQ_OFFSET0] = ctx->seq_offset[0].ptr; columns[SHARD_SEQ_LENGTH0] = ctx->seq_length[0].ptr; columns[SHARD_SEQ_OFFSET1] = ctx->seq_offset[1].ptr; columns[SHARD_SEQ_LENGTH1] = ctx->seq_length[1].ptr;
+	columns[SHARD_CIGAR_POOL] = ctx->cigar_pool.ptr; columns[SHARD_SEQ_POOL] = ctx->seq_pool.ptr; columns[SHARD_NAME_OFFSET] = ctx->name_offset.ptr; columns[SHARD_NAMES] = ctx->names.ptr;
+	columns[SHARD_WINDOWS32] = ctx->coverage_windows32.ptr; columns[SHARD_FRAGMENT_STARTS] = ctx->coverage_fragment_starts.ptr; columns[SHARD_FRAGMENT_ENDS] = ctx->coverage_fragment_ends.ptr;
+	columns[SHARD_VIRAL_COUNTS] = ctx->ingest_viral_counts.ptr;
+}
+
+int agpu_shard_export_size(agpu_ctx* ctx, uint64_t* bytes) {
+	if (!ctx || !ctx->batch_from_ingest || !ctx->ingest_part_of_sample || ctx->annotated || !bytes) { set_last_error("agpu_shard_export works on the batch of an ingest with part_of_sample set, before any stage has run"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	ShardHeader h;
+	TRY(shard_header_of(ctx, h));
+	*bytes = h.total_bytes;
+	return AGPU_OK;
+}
+
+int agpu_shard_export(agpu_ctx* ctx, void* block, uint64_t capacity) {
+	if (!ctx || !ctx->batch_from_ingest || !ctx->ingest_part_of_sample || ctx->annotated || !block) { set_last_error("agpu_shard_export works on the batch of an ingest with part_of_sample set, before any stage has run"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	ShardHeader h;
+	TRY(shard_header_of(ctx, h));
+	if (capacity < h.total_bytes) { set_last_error("the block is smaller than agpu_shard_export_size says"); return AGPU_ERR_INVALID; }
+	const ShardLayout layout = shard_layout(h);
+	void* columns[SHARD_SECTIONS];
+	shard_columns(ctx, columns);
+	HIP_CHECK(hipMemcpyAsync(block, &h, sizeof(h), hipMemcpyDefault, s));
+	for (int k = 0; k < SHARD_SECTIONS; ++k)
+		if (layout.bytes[k] > 0) HIP_CHECK(hipMemcpyAsync((uint8_t*) block + layout.offset[k], columns[k], layout.bytes[k], hipMemcpyDefault, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	return AGPU_OK;
+}
+
+int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_t n_parts, agpu_ingest_result* result) {
+	if (!ctx || !blocks || n_parts == 0 || (stride & 15) != 0) { set_last_error("agpu_shard_merge takes the blocks of all parts at a stride that is a multiple of 16 bytes"); return AGPU_ERR_INVALID; }
+	if (!ctx->have_annotation || !ctx->have_genome || ctx->host_coverage_window_offset.empty()) { set_last_error("the context must have ingested its own part before the parts are merged"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	{ // the kernels below read the blocks: blocks in host memory (a collective that went through the host) are brought to the device first
+		hipPointerAttribute_t attributes;
+		const bool on_device = hipPointerGetAttributes(&attributes, blocks) == hipSuccess && (attributes.type == hipMemoryTypeDevice || attributes.type == hipMemoryTypeManaged);
+		(void) hipGetLastError();
+		if (!on_device) {
+			DeviceBuffer& staged = ctx->scratch("shard.blocks");
+			ALLOC(staged, (size_t) n_parts * stride);
+			HIP_CHECK(hipMemcpy(staged.ptr, blocks, (size_t) n_parts * stride, hipMemcpyHostToDevice));
+			blocks = staged.ptr;
+		}
+	}
+	std::vector<ShardHeader> parts(n_parts);
+	for (uint32_t r = 0; r < n_parts; ++r) HIP_CHECK(hipMemcpy(&parts[r], (const uint8_t*) blocks + (size_t) r * stride, sizeof(ShardHeader), hipMemcpyDefault));
+	ShardHeader total;
+	const char* problem = shard_totals(parts.data(), n_parts, total);
+	if (problem) { set_last_error(problem); return AGPU_ERR_INVALID; }
+	for (uint32_t r = 0; r < n_parts; ++r) if (parts[r].total_bytes > stride) { set_last_error("a part of the sample is larger than the stride of the blocks"); return AGPU_ERR_INVALID; }
+	if (total.windows != ctx->host_coverage_window_offset.back() || total.n_contigs != ctx->genome.n_contigs) { set_last_error("the parts of the sample were read against another assembly than this context holds"); return AGPU_ERR_INVALID; }
+	// the parts must follow each other in the order of the names (the order of the reference's std::map): every part is sorted, so its ends decide
+	{
+		std::string previous; bool have_previous = false;
+		for (uint32_t r = 0; r < n_parts; ++r) {
+			if (parts[r].n == 0) continue;
+			const ShardLayout layout = shard_layout(parts[r]);
+			const uint8_t* block = (const uint8_t*) blocks + (size_t) r * stride;
+			uint32_t offsets[2], last[2];
+			HIP_CHECK(hipMemcpy(offsets, block + layout.offset[SHARD_NAME_OFFSET], 8, hipMemcpyDefault));
+			HIP_CHECK(hipMemcpy(last, block + layout.offset[SHARD_NAME_OFFSET] + (parts[r].n - 1) * 4, 8, hipMemcpyDefault));
+			if (offsets[1] < offsets[0] || last[1] < last[0] || last[1] > parts[r].names_bytes) { set_last_error("a part of the sample is damaged (name offsets)"); return AGPU_ERR_INVALID; }
+			std::string first_name(offsets[1] - offsets[0], '\0'), last_name(last[1] - last[0], '\0');
+			if (!first_name.empty()) HIP_CHECK(hipMemcpy(&first_name[0], block + layout.offset[SHARD_NAMES] + offsets[0], first_name.size(), hipMemcpyDefault));
+			if (!last_name.empty()) HIP_CHECK(hipMemcpy(&last_name[0], block + layout.offset[SHARD_NAMES] + last[0], last_name.size(), hipMemcpyDefault));
+			if (have_previous && !(previous < first_name)) {
+				set_last_error("the read names of the parts of the sample interleave: part " + std::to_string(r) + " starts with " + first_name + ", the part before it ends with " + previous + " (the parts must be ranges of the name order)");
+				return AGPU_ERR_INVALID;
+			}
+			previous = last_name; have_previous = true;
+		}
+	}
+	const uint64_t n = total.n, windows = total.windows;
+	ctx->have_batch = false; ctx->batch_from_ingest = false;
+	ctx->n = n;
+	ALLOC(ctx->n_aln, n); ALLOC(ctx->fbits, n); ALLOC(ctx->group, n * 4);
+	for (int k = 0; k < 3; ++k) { ALLOC(ctx->contig[k], n * 2); ALLOC(ctx->start[k], n * 4); ALLOC(ctx->end[k], n * 4); ALLOC(ctx->abits[k], n); ALLOC(ctx->cigar_offset[k], n * 4); ALLOC(ctx->cigar_count[k], n * 2); }
+	for (int k = 0; k < 2; ++k) { ALLOC(ctx->seq_offset[k], n * 4); ALLOC(ctx->seq_length[k], n * 4); }
+	ALLOC(ctx->cigar_pool, total.cigar_words * 4); ALLOC(ctx->seq_pool, total.sequence_bytes); ALLOC(ctx->names, total.names_bytes); ALLOC(ctx->name_offset, (n + 1) * 4);
+	ALLOC(ctx->coverage_windows32, std::max<uint64_t>(windows, 1) * 4);
+	HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(windows, 1) * 4, s));
+	HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_starts.ptr, 0, std::max<uint64_t>(windows, 1), s));
+	HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_ends.ptr, 0, std::max<uint64_t>(windows, 1), s));
+	HIP_CHECK(hipMemsetAsync(ctx->ingest_viral_counts.ptr, 0, std::max<size_t>(total.n_contigs, 1) * 8, s));
+	void* columns[SHARD_SECTIONS];
+	shard_columns(ctx, columns);
+	static const uint8_t element_bytes[SHARD_SECTIONS] = { 1, 1, 4, 2, 4, 4, 1, 4, 2, 2, 4, 4, 1, 4, 2, 2, 4, 4, 1, 4, 2, 4, 4, 4, 4, 4, 1, 4, 1, 4, 1, 1, 8 };
+	(void) hipEventRecord(ctx->event_start, s);
+	uint64_t row = 0, cigar_at = 0, sequence_at = 0, name_at = 0, group_at = 0;
+	for (uint32_t r = 0; r < n_parts; ++r) {
+		const ShardHeader& h = parts[r];
+		const ShardLayout layout = shard_layout(h);
+		const uint8_t* block = (const uint8_t*) blocks + (size_t) r * stride;
+		const uint8_t* part_n_aln = block + layout.offset[SHARD_N_ALN];
+		for (int k = 0; k < SHARD_WINDOWS32; ++k) {
+			if (h.n == 0 && k != SHARD_NAME_OFFSET) continue;
+			const void* in = block + layout.offset[k];
+			uint64_t at = row; // rows of the parts before this one ...
+			if (k == SHARD_CIGAR_POOL) at = cigar_at; else if (k == SHARD_SEQ_POOL) at = sequence_at; else if (k == SHARD_NAMES) at = name_at; // ... or what they put into the pool
+			uint8_t* out = (uint8_t*) columns[k] + at * element_bytes[k];
+			int slot = -1; uint32_t base = 0; uint64_t count = h.n;
+			if (k == SHARD_GROUP) { slot = 3; base = (uint32_t) group_at; }
+			else if (k == SHARD_NAME_OFFSET) { slot = 3; base = (uint32_t) name_at; count = h.n + (r + 1 == n_parts ? 1 : 0); } // (the last part brings the end of the names)
+			else if (k == SHARD_SEQ_OFFSET0 || k == SHARD_SEQ_OFFSET1) { slot = k == SHARD_SEQ_OFFSET0 ? 0 : 1; base = (uint32_t) (sequence_at / 4); }
+			else if (k >= SHARD_SLOT0 && k < SHARD_SEQ_OFFSET0 && (k - SHARD_SLOT0) % SHARD_SLOT_FIELDS == SHARD_SLOT_CIGAR_OFFSET) { slot = (k - SHARD_SLOT0) / SHARD_SLOT_FIELDS; base = (uint32_t) cigar_at; }
+			if (slot >= 0) { if (count > 0) shard_rebase_kernel<<<grid_for(count), BLOCK, 0, s>>>((uint32_t*) out, (const uint32_t*) in, count, base, part_n_aln, (uint32_t) slot); }
+			else if (layout.bytes[k] > 0) HIP_CHECK(hipMemcpyAsync(out, in, layout.bytes[k], hipMemcpyDefault, s));
+		}
+		if (windows > 0) shard_add_coverage_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_windows32.as<uint32_t>(), ctx->coverage_fragment_starts.as<uint8_t>(), ctx->coverage_fragment_ends.as<uint8_t>(),
+			(const uint32_t*) (block + layout.offset[SHARD_WINDOWS32]), block + layout.offset[SHARD_FRAGMENT_STARTS], block + layout.offset[SHARD_FRAGMENT_ENDS], windows);
+		if (total.n_contigs > 0) shard_add_counts_kernel<<<grid_for(total.n_contigs), BLOCK, 0, s>>>(ctx->ingest_viral_counts.as<unsigned long long>(), (const unsigned long long*) (block + layout.offset[SHARD_VIRAL_COUNTS]), (uint32_t) total.n_contigs);
+		row += h.n; cigar_at += h.cigar_words; sequence_at += h.sequence_bytes; name_at += h.names_bytes; group_at += h.groups;
+	}
+	if (n == 0) HIP_CHECK(hipMemsetAsync(ctx->name_offset.ptr, 0, 4, s));
+	if (windows > 0) coverage_clamp_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_windows32.as<uint32_t>(), windows, ctx->coverage_windows.as<uint16_t>());
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	ctx->last_bytes = 2 * (n * (1 + 1 + 4 + 3 * 17 + 16 + 4) + total.cigar_words * 4 + total.sequence_bytes + total.names_bytes) + (uint64_t) n_parts * windows * 6;
+	ctx->names_size = total.names_bytes; ctx->max_read_length = (uint32_t) total.max_read_length;
+	ctx->ingest_pool_sizes[0] = total.cigar_words; ctx->ingest_pool_sizes[1] = total.sequence_bytes;
+	ctx->batch_input_bytes = n * (1 + 1 + 4 + 3 * 17 + 16) + total.cigar_words * 4 + total.sequence_bytes;
+	ctx->coverage.n_contigs = ctx->genome.n_contigs; ctx->coverage.window_offset = ctx->coverage_window_offset.as<uint64_t>(); ctx->coverage.coverage = ctx->coverage_windows.as<uint16_t>();
+	ctx->coverage.fragment_starts = ctx->coverage_fragment_starts.as<uint8_t>(); ctx->coverage.fragment_ends = ctx->coverage_fragment_ends.as<uint8_t>();
+	ctx->have_coverage = true;
+	TRY(agpu::finish_batch_setup(ctx));
+	ctx->batch_from_ingest = true; ctx->ingest_part_of_sample = false;
+	ctx->coverage_windows32.release(); ctx->scratch("shard.blocks").release();
+	agpu_ingest_result& whole = ctx->ingest_result;
+	memset(&whole, 0, sizeof(whole));
+	whole.records = total.records; whole.fragments = n; whole.mapped_reads = total.mapped_reads; whole.malformed_count = total.malformed_count; whole.missing_hi_tag = total.missing_hi_tag;
+	whole.no_chimeric_reads = (uint8_t) total.no_chimeric_reads; whole.names_were_sorted = (uint8_t) total.names_were_sorted; whole.stream_bytes = total.stream_bytes;
+	if (result) *result = whole;
 	return AGPU_OK;
 }
 

@@ -170,25 +170,46 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 // Second pass, one wavefront per heavy read: the read positions one after the other, the seeds of a position split among the 64 lanes (every seed of the outermost
 // loop of align() is an independent attempt), full stack, no budget; the segment in LDS is shared by the lanes, and so is the memo of failed nested calls
 // (AlignMemo, mismapper_core.hpp: it turns the exponential re-evaluation of the reference's recursion into one search per distinct call).  The workgroups are
-// persistent: each owns one memo table in HBM and takes heavy reads in turn.
-const uint32_t MEMO_SLOTS = 1u << 21;   // 16 MB per workgroup (a read of a long gene makes 10^5..10^6 distinct nested calls)
-const uint32_t HEAVY_WORKGROUPS = 1024;
+// persistent: each owns one memo table in HBM and takes the next heavy read from a queue (counters[4]) when it is done with one -- the searches differ in
+// length by orders of magnitude, a fixed share per workgroup would wait for the unluckiest one.  The kernel waits for dependent loads (k-mer table -> hit list ->
+// genome bases -> memo slot), so the number of wavefronts in flight is what sets its speed: 4096 workgroups of one wavefront = 4 per SIMD.
+const uint32_t MEMO_SLOTS_LOG2 = 21;    // 16 MB per workgroup (a read of a long gene makes 10^5..10^6 distinct nested calls)
+const uint32_t HEAVY_WORKGROUPS = 4096;
 __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
-                                                             unsigned long long* memo_tables, unsigned int* counters) {
+                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
 	__shared__ AlignMemo memo;
-	if (threadIdx.x == 0) { memo.slots = memo_tables + (size_t) blockIdx.x * MEMO_SLOTS; memo.mask = MEMO_SLOTS - 1; memo.epoch = 0; }
+	__shared__ uint32_t next_job;
+	if (threadIdx.x == 0) { memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0; }
 	__syncthreads();
 	AlignFrame stack[ALIGN_MAX_DEPTH];
 	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = nullptr; runner.max_depth = ALIGN_MAX_DEPTH;
 	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position
 	runner.memo = &memo;
 	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
-	for (uint32_t j = blockIdx.x; j < n_heavy; j += gridDim.x) {
-		const uint32_t read = heavy[j];
+	while (true) {
+		__syncthreads(); // (every lane has read next_job of the previous round)
+		if (threadIdx.x == 0) next_job = atomicAdd(&counters[4], 1u);
+		__syncthreads();
+		if (next_job >= n_heavy) break;
+		const uint32_t read = heavy[next_job];
 		const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
 		if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
 	}
+}
+
+// filter_mismappers shared out over several GPUs that hold the same batch: the jobs of one part, the verdicts of a part for the exchange, the verdicts of all parts applied
+__global__ void mismapper_take_part_kernel(const uint32_t* jobs, uint32_t n_jobs, uint32_t part, uint32_t parts, uint32_t* mine) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if ((uint64_t) k * parts + part < n_jobs) mine[k] = jobs[(uint64_t) k * parts + part];
+}
+__global__ void mismapper_collect_kernel(BatchView b, const uint32_t* jobs, uint32_t n_jobs, uint32_t part, uint32_t parts, uint8_t* verdicts) {
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n_jobs) verdicts[j] = (j % parts == part && b.filter[jobs[j]] == FILTER_mismappers) ? 1 : 0;
+}
+__global__ void mismapper_apply_kernel(BatchView b, const uint32_t* jobs, uint32_t n_jobs, const uint8_t* verdicts, unsigned int* counters) {
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n_jobs && verdicts[j]) { b.filter[jobs[j]] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
 }
 
 __global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, bool count_only, unsigned int* remaining) {
@@ -310,8 +331,14 @@ extern "C" int agpu_make_kmer_index(agpu_ctx* ctx, int32_t padding, uint64_t* n_
 	return AGPU_OK;
 }
 
-extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* remaining, uint64_t* discarded_reads) {
+namespace {
+enum { PHASE_JOBS = 1, PHASE_SEARCH = 2, PHASE_FINISH = 4 };
+// filter_mismappers in three phases -- the reads to look at (jobs), their re-alignment (search: all jobs, or every parts-th one from `part` on), the verdicts
+// applied to the candidates (finish) -- so that ranks which hold the same batch can share out the search (agpu_mismapper_jobs / _verdicts / agpu_filter_mismappers_apply)
+int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, uint32_t part, uint32_t parts, uint8_t* verdicts_out, const uint8_t* verdicts_in, uint64_t* remaining, uint64_t* discarded_reads) {
 	if (!ctx || !ctx->kmer_index_done) { set_last_error("agpu_make_kmer_index must run first"); return AGPU_ERR_INVALID; }
+	if (parts == 0 || part >= parts) { set_last_error("part out of range"); return AGPU_ERR_INVALID; }
+	if (!(phases & PHASE_JOBS) && !ctx->mismapper_jobs_ready) { set_last_error("agpu_mismapper_jobs must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	const uint32_t C = ctx->n_candidates;
@@ -320,21 +347,23 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 	DeviceBuffer& read_flags = ctx->scratch("mismappers.read_flags"); DeviceBuffer& jobs = ctx->scratch("mismappers.jobs"); DeviceBuffer& counters = ctx->scratch("mismappers.counters");
 	DeviceBuffer& scratch = ctx->scratch("mismappers.rocprim"); DeviceBuffer& first_entry = ctx->scratch("mismappers.first_entry"); DeviceBuffer& job_keys = ctx->scratch("mismappers.job_keys");
 	DeviceBuffer& job_keys_sorted = ctx->scratch("mismappers.job_keys_sorted"); DeviceBuffer& jobs_sorted = ctx->scratch("mismappers.jobs_sorted");
-	ALLOC(read_flags, n ? n : 1); ALLOC(jobs, (n ? n : 1) * 4); ALLOC(counters, 16); ALLOC(first_entry, (n ? n : 1) * 4);
-	HIP_CHECK(hipMemsetAsync(read_flags.ptr, 0, n ? n : 1, s));
-	HIP_CHECK(hipMemsetAsync(first_entry.ptr, 0xFF, (n ? n : 1) * 4, s));
-	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 16, s));
-	unsigned int* device_counters = counters.as<unsigned int>(); // [0] jobs, [1] reads discarded, [2] candidates remaining, [3] reads left to the second pass
+	ALLOC(counters, 32);
+	if (phases & PHASE_JOBS) {
+		ALLOC(read_flags, n ? n : 1); ALLOC(jobs, (n ? n : 1) * 4); ALLOC(first_entry, (n ? n : 1) * 4);
+		HIP_CHECK(hipMemsetAsync(read_flags.ptr, 0, n ? n : 1, s));
+		HIP_CHECK(hipMemsetAsync(first_entry.ptr, 0xFF, (n ? n : 1) * 4, s));
+		HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 32, s));
+		ctx->mismapper_jobs = 0; ctx->mismapper_jobs_ready = false;
+	}
+	unsigned int* device_counters = counters.as<unsigned int>(); // [0] jobs, [1] reads discarded, [2] candidates remaining, [3] reads left to the second pass, [4] queue of the second pass
 	KmerIndexView kmers;
 	kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
 	SpliceSiteView splice;
 	splice.offset = ctx->splice_offset.as<uint32_t>(); splice.sites = ctx->splice_sites.as<int32_t>();
 	(void) hipEventRecord(ctx->event_start, s);
-	uint32_t n_jobs = 0;
-	if (C > 0 && !ctx->params.filter_enabled[FILTER_mismappers]) {
-		// switched off with -f: the reference skips the stage (source/arriba.cpp:562); no read and no candidate is touched, the unfiltered candidates are counted
-		mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, true, device_counters + 2);
-	} else if (C > 0 && n > 0) {
+	const bool enabled = ctx->params.filter_enabled[FILTER_mismappers] != 0; // switched off with -f: the reference skips the stage (source/arriba.cpp:562); no read and no candidate is touched, the unfiltered candidates are counted
+	uint32_t n_jobs = ctx->mismapper_jobs;
+	if ((phases & PHASE_JOBS) && enabled && C > 0 && n > 0) {
 		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>(), first_entry.as<uint32_t>()); }
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
@@ -342,37 +371,79 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 		HIP_CHECK(rocprim::select(scratch.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
 		HIP_CHECK(hipMemcpyAsync(&n_jobs, device_counters, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
-		if (n_jobs > 0) {
+		if (n_jobs > 0) { // ordered by candidate: reads that search the same genes sit next to each other
 			ALLOC(job_keys, (size_t) n_jobs * 4); ALLOC(job_keys_sorted, (size_t) n_jobs * 4); ALLOC(jobs_sorted, (size_t) n_jobs * 4);
 			mismapper_job_key_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(jobs.as<uint32_t>(), n_jobs, first_entry.as<uint32_t>(), job_keys.as<uint32_t>());
 			HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, job_keys.as<uint32_t>(), job_keys_sorted.as<uint32_t>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, 32, s));
 			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
 			HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, job_keys.as<uint32_t>(), job_keys_sorted.as<uint32_t>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, 32, s));
+		}
+		ctx->mismapper_jobs = n_jobs;
+	}
+	if (phases & PHASE_JOBS) ctx->mismapper_jobs_ready = true;
+	if ((phases & PHASE_SEARCH) && enabled && n_jobs > 0) {
+		{
+			// this context's share of the jobs: all of them, or every parts-th one (neighbours in the order of the candidates cost about the same: the shares are even)
+			const uint32_t n_all = n_jobs;
+			DeviceBuffer& my_jobs = ctx->scratch("mismappers.my_jobs");
+			const uint32_t* job_list = jobs_sorted.as<uint32_t>();
+			if (parts > 1) {
+				n_jobs = (n_all + parts - 1 - part) / parts;
+				ALLOC(my_jobs, (size_t) std::max<uint32_t>(n_jobs, 1) * 4);
+				if (n_jobs > 0) mismapper_take_part_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(jobs_sorted.as<uint32_t>(), n_all, part, parts, my_jobs.as<uint32_t>());
+				job_list = my_jobs.as<uint32_t>();
+			}
 			DeviceBuffer& heavy = ctx->scratch("mismappers.heavy");
-			ALLOC(heavy, (size_t) n_jobs * 4);
+			ALLOC(heavy, (size_t) std::max<uint32_t>(n_jobs, 1) * 4);
 			uint32_t n_heavy = 0;
+			if (n_jobs > 0) {
 			const char* first_pass = getenv("ARRIBA_MISMAPPER_FIRST_PASS"); // "0": every read goes to the wavefront-per-read pass (for A/B measurements)
 			if (first_pass != nullptr && first_pass[0] == '0') {
-				HIP_CHECK(hipMemcpyAsync(heavy.ptr, jobs_sorted.ptr, (size_t) n_jobs * 4, hipMemcpyDeviceToDevice, s));
+				HIP_CHECK(hipMemcpyAsync(heavy.ptr, job_list, (size_t) n_jobs * 4, hipMemcpyDeviceToDevice, s));
 				n_heavy = n_jobs;
 			} else {
 				{ KernelTimer timer(ctx, "mismapper_verdict_kernel", (uint64_t) n_jobs * 300);
-				  mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, jobs_sorted.as<uint32_t>(), n_jobs, max_mate_gap, heavy.as<uint32_t>(), device_counters); }
+				  mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, job_list, n_jobs, max_mate_gap, heavy.as<uint32_t>(), device_counters); }
 				HIP_CHECK(hipMemcpyAsync(&n_heavy, device_counters + 3, 4, hipMemcpyDeviceToHost, s));
 				HIP_CHECK(hipStreamSynchronize(s));
 			}
 			ctx->mismapper_heavy = n_heavy;
 			if (n_heavy > 0) {
-				const uint32_t workgroups = std::min<uint32_t>(n_heavy, HEAVY_WORKGROUPS);
+				// (tuning knobs for measurements: number of persistent workgroups, log2 of the memo slots of each)
+				const char* knob = getenv("ARRIBA_HEAVY_WORKGROUPS");
+				const uint32_t wanted = knob != nullptr && atoi(knob) > 0 ? (uint32_t) atoi(knob) : HEAVY_WORKGROUPS;
+				knob = getenv("ARRIBA_MEMO_SLOTS_LOG2");
+				const uint32_t memo_slots = 1u << (knob != nullptr && atoi(knob) >= 10 && atoi(knob) <= 24 ? (uint32_t) atoi(knob) : MEMO_SLOTS_LOG2);
+				const uint32_t workgroups = std::min<uint32_t>(n_heavy, wanted);
 				DeviceBuffer& memo_tables = ctx->scratch("mismappers.memo_tables");
-				ALLOC(memo_tables, (size_t) workgroups * MEMO_SLOTS * 8);
-				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * MEMO_SLOTS * 8, s));
+				ALLOC(memo_tables, (size_t) workgroups * memo_slots * 8);
+				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));
 				KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-				mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), device_counters);
+				mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, device_counters);
 			}
+			}
+			n_jobs = n_all;
 		}
-		{ KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
-		  mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, false, device_counters + 2); }
+		if (verdicts_out != nullptr) { // for the exchange: one byte per job of the whole list, set where a job of this share is a mis-mapper
+			DeviceBuffer& verdict_bytes = ctx->scratch("mismappers.verdicts");
+			ALLOC(verdict_bytes, n_jobs);
+			mismapper_collect_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(ctx->batch, jobs_sorted.as<uint32_t>(), n_jobs, part, parts, verdict_bytes.as<uint8_t>());
+			HIP_CHECK(hipMemcpyAsync(verdicts_out, verdict_bytes.ptr, n_jobs, hipMemcpyDefault, s));
+		}
+	}
+	if (phases & PHASE_FINISH) {
+		if (verdicts_in != nullptr && enabled && n_jobs > 0) { // the verdicts of all shares: the reads of the others are discarded here, too, and counted
+			DeviceBuffer& verdict_bytes = ctx->scratch("mismappers.verdicts");
+			ALLOC(verdict_bytes, n_jobs);
+			HIP_CHECK(hipMemcpyAsync(verdict_bytes.ptr, verdicts_in, n_jobs, hipMemcpyDefault, s));
+			HIP_CHECK(hipMemsetAsync(device_counters + 1, 0, 4, s));
+			mismapper_apply_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(ctx->batch, jobs_sorted.as<uint32_t>(), n_jobs, verdict_bytes.as<uint8_t>(), device_counters);
+		}
+		if (C > 0 && (!enabled || n > 0)) {
+			KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
+			mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, !enabled, device_counters + 2);
+		}
+		ctx->mismapper_jobs_ready = false;
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
@@ -383,6 +454,23 @@ extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint6
 	HIP_CHECK(hipMemcpy(host_counters, counters.ptr, sizeof(host_counters), hipMemcpyDeviceToHost));
 	if (remaining) *remaining = host_counters[2];
 	if (discarded_reads) *discarded_reads = host_counters[1];
-	ctx->mismapper_jobs = n_jobs;
 	return AGPU_OK;
+}
+}
+
+extern "C" int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* remaining, uint64_t* discarded_reads) {
+	return filter_mismappers_phases(ctx, PHASE_JOBS | PHASE_SEARCH | PHASE_FINISH, max_mate_gap, 0, 1, nullptr, nullptr, remaining, discarded_reads);
+}
+extern "C" int agpu_mismapper_jobs(agpu_ctx* ctx, uint64_t* n_jobs) {
+	const int status = filter_mismappers_phases(ctx, PHASE_JOBS, 0, 0, 1, nullptr, nullptr, nullptr, nullptr);
+	if (status == AGPU_OK && n_jobs) *n_jobs = ctx->mismapper_jobs;
+	return status;
+}
+extern "C" int agpu_mismapper_verdicts(agpu_ctx* ctx, int32_t max_mate_gap, uint32_t part, uint32_t parts, uint8_t* verdicts) {
+	if (!verdicts) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	return filter_mismappers_phases(ctx, PHASE_SEARCH, max_mate_gap, part, parts, verdicts, nullptr, nullptr, nullptr);
+}
+extern "C" int agpu_filter_mismappers_apply(agpu_ctx* ctx, const uint8_t* verdicts, uint64_t* remaining, uint64_t* discarded_reads) {
+	if (!verdicts) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	return filter_mismappers_phases(ctx, PHASE_FINISH, 0, 0, 1, nullptr, verdicts, remaining, discarded_reads);
 }

@@ -72,6 +72,66 @@ AGPU_HD bool is_splice_site_from(const AlignTarget& target, int32_t position, ui
 }
 AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; } // eight genome bases at once (the genome buffer is padded behind its end)
 
+// Frontier of failed nested calls.  Besides being monotone in `score` (see AlignMemo below), a nested align(score, read_pos, gene_pos, max_deletions) is monotone
+// in gene_pos and max_deletions: gene_pos only bounds the seeds from below (lower_bound over the hit list; nothing else of a call depends on it), so a call
+// further into the gene tries a subset of the attempts of a call at an earlier position, each with the same score; and with max_deletions = 0 the re-seed behind
+// the first mismatch is left out while everything else stays.  So a failed call (read_pos, gene_pos g, score s, deletions d) proves the failure of every call
+// at the same read position with gene_pos >= g, score <= s and deletions <= d.  The seeds of a read position are tried in ascending gene position, and the calls
+// they lead to differ in little else: the first one that fails takes the later ones with it -- the branching of the reference's recursion (seeds per k-mer to
+// the power of the nesting depth) collapses.  Per read position a few (gene position, score, deletions) triples none of which makes another redundant are kept
+// (FRONTIER_WAYS of them; what does not fit is forgotten, which costs time, never correctness: only calls known to return false are skipped).
+// A word holds epoch (8 bits, one per align() invocation: the table is never cleared in between) | gene_pos - gene_start (31) | max_deletions > 0 (1) | score + 32768 (16) | 0 (8).
+const uint32_t FRONTIER_WAYS = 4;
+const uint32_t FRONTIER_POSITIONS = 304; // read positions of a segment that is re-aligned (< 300 bases)
+struct AlignFrontier {
+	unsigned long long* words; uint32_t epoch; // FRONTIER_POSITIONS * FRONTIER_WAYS words (no default initialisers: the device keeps one in LDS)
+	AGPU_HD static unsigned long long load(const unsigned long long* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+		return *p;
+#endif
+	}
+	AGPU_HD static void store(unsigned long long* p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+		*p = v;
+#endif
+	}
+	AGPU_HD bool usable(int32_t length) const { return words != nullptr && (uint32_t) length <= FRONTIER_POSITIONS; }
+	AGPU_HD static uint32_t offset_of(unsigned long long w) { return (uint32_t) (w >> 25) & 0x7FFFFFFFu; }
+	AGPU_HD static int32_t score_of(unsigned long long w) { return (int32_t) ((w >> 8) & 0xFFFFu) - 32768; }
+	AGPU_HD static uint32_t deletions_of(unsigned long long w) { return (uint32_t) (w >> 24) & 1u; }
+	AGPU_HD bool known_to_fail(int32_t read_pos, int32_t gene_offset, int32_t max_deletions, int32_t score) const {
+		if ((uint32_t) read_pos >= FRONTIER_POSITIONS) return false;
+		const unsigned long long* list = words + (size_t) read_pos * FRONTIER_WAYS;
+		for (uint32_t way = 0; way < FRONTIER_WAYS; ++way) {
+			const unsigned long long w = load(&list[way]);
+			if ((w >> 56) == (epoch & 255u) && offset_of(w) <= (uint32_t) gene_offset && score_of(w) >= score && deletions_of(w) >= (uint32_t) (max_deletions > 0)) return true;
+		}
+		return false;
+	}
+	AGPU_HD void record_failure(int32_t read_pos, int32_t gene_offset, int32_t max_deletions, int32_t score) const {
+		if ((uint32_t) read_pos >= FRONTIER_POSITIONS || score < -32768 || score > 32767 || gene_offset < 0) return;
+		const uint32_t deletions = max_deletions > 0;
+		const unsigned long long word = (unsigned long long) (epoch & 255u) << 56 | (unsigned long long) (uint32_t) gene_offset << 25 | (unsigned long long) deletions << 24 | (unsigned long long) (uint32_t) (score + 32768) << 8;
+		unsigned long long* list = words + (size_t) read_pos * FRONTIER_WAYS;
+		int free_way = -1, redundant_way = -1, furthest_way = -1; uint32_t furthest = 0;
+		for (uint32_t way = 0; way < FRONTIER_WAYS; ++way) {
+			const unsigned long long w = load(&list[way]);
+			if ((w >> 56) != (epoch & 255u)) { if (free_way < 0) free_way = (int) way; continue; }
+			if (offset_of(w) <= (uint32_t) gene_offset && score_of(w) >= score && deletions_of(w) >= deletions) return; // nothing new
+			if ((uint32_t) gene_offset <= offset_of(w) && score >= score_of(w) && deletions >= deletions_of(w)) { if (redundant_way < 0) redundant_way = (int) way; continue; }
+			if (furthest_way < 0 || offset_of(w) > furthest) { furthest_way = (int) way; furthest = offset_of(w); }
+		}
+		// (lanes that share the table may overwrite each other's words: every word is a true statement about this search, whichever survives)
+		if (redundant_way >= 0) store(&list[redundant_way], word);
+		else if (free_way >= 0) store(&list[free_way], word);
+		else if (furthest_way >= 0 && (uint32_t) gene_offset < furthest) store(&list[furthest_way], word); // the triple that starts earliest in the gene speaks for the most seeds
+	}
+};
+
 // Memo of failed nested calls.  A nested align(score, read_pos, gene_pos, max_deletions) is monotone in `score` -- a higher score only loosens the bound of its
 // read-position loop and raises every score it compares with min_score -- so a call that failed with score s fails with every score <= s.  The reference
 // re-runs such calls from scratch: behind every splice site an extension crosses it starts a full search of the rest of the read against the rest of the gene,
@@ -154,9 +214,17 @@ AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t
 // The frame that is being worked on lives in registers; `stack` only holds the frames of the callers (written when a nested call starts, read when it fails).
 // `hit_offset`, `hit_stride`: of the seeds at the first read position this call only follows number hit_offset, hit_offset + hit_stride, ... (every seed is an
 // independent attempt, too: the lanes of a wavefront share the seeds of one read position among them when a read has many).
-AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1, const AlignMemo* memo = nullptr) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(AGPU_ALIGN_STATS)
+struct AlignStats { unsigned long long read_positions, hits, bases, calls, pruned, failures, depth_sum; };
+static AlignStats g_align_stats;
+#define ALIGN_STAT(field, amount) (g_align_stats.field += (amount))
+#else
+#define ALIGN_STAT(field, amount) ((void) 0)
+#endif
+AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1, const AlignMemo* memo = nullptr, const AlignFrontier* frontier = nullptr) {
 	const int32_t length = (int32_t) read.length;
 	const bool use_memo = memo != nullptr && memo->usable(target.gene_start, target.gene_end);
+	const bool use_frontier = frontier != nullptr && frontier->usable(length);
 	int depth = 0;
 	AlignFrame f;
 	align_enter(f, -first_read_pos, first_read_pos, target.gene_start, 1);
@@ -168,6 +236,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 		int32_t call_max_deletions = 0;
 		switch (f.state) {
 			case ALIGN_NEXT_READ_POSITION: { // for (; read_pos + k < length && ...; read_pos++, score--, skipped_bases++)
+				ALIGN_STAT(read_positions, 1);
 				if (f.started && depth == 0) return false; // the other read positions of the outermost loop are other attempts
 				if (f.started) { f.read_pos++; f.score--; f.skipped_bases++; }
 				f.started = 1;
@@ -185,6 +254,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				break;
 			}
 			case ALIGN_NEXT_HIT: { // for (hit = lower_bound(gene_pos); hit != end && *hit < gene_end; ++hit)
+				ALIGN_STAT(hits, 1);
 				f.hit += depth == 0 ? hit_stride : 1u;
 				if (!(f.hit < f.hits_end && target.positions[f.hit] < target.gene_end)) { f.state = ALIGN_NEXT_READ_POSITION; break; }
 				const int32_t kmer_hit = target.positions[f.hit];
@@ -217,6 +287,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				uint64_t window = 0; int32_t window_at = 0, window_end = 0; // genome bases [window_at, window_end) of the contig
 				while (true) {
 					if (budget != nullptr && --*budget < 0) return false;
+					ALIGN_STAT(bases, 1);
 					if (!(f.extended_read_pos < length && f.extended_gene_pos <= target.gene_end)) { f.state = ALIGN_NEXT_HIT; break; }
 					if (is_splice_site_from(target, f.extended_gene_pos - 1, f.splice_cursor)) { f.state = ALIGN_COMPARE_BASE; call = true; call_max_deletions = f.max_deletions; break; } // re-seed behind a splice site (spliced alignment)
 					if (f.extended_gene_pos >= window_end || f.extended_gene_pos < window_at) { window_at = f.extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
@@ -261,7 +332,12 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				break;
 			}
 		}
+		const bool wanted_call = call;
 		if (call && use_memo && memo->known_to_fail(memo->key_of(f.extended_read_pos, f.extended_gene_pos - target.gene_start, call_max_deletions), f.extended_score)) call = false; // searched before, with at least this score
+		if (call && use_frontier && frontier->known_to_fail(f.extended_read_pos, f.extended_gene_pos - target.gene_start, call_max_deletions, f.extended_score)) call = false; // a call that tries at least these seeds with at least this score has failed
+		if (wanted_call && !call) ALIGN_STAT(pruned, 1);
+		if (call) ALIGN_STAT(calls, 1); else if (fail) ALIGN_STAT(failures, 1);
+		if (call) ALIGN_STAT(depth_sum, depth + 1);
 		if (call) { // the caller's frame goes to the stack, the nested call takes the registers
 			if (depth >= max_depth) { if (budget != nullptr) *budget = -1; return false; } // deeper than this stack: left to a caller with a deeper one
 			stack[depth] = f;
@@ -272,6 +348,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 			if (depth == 0) return false;
 			// (a nested call entered with read position read_pos - skipped_bases and score score + skipped_bases: both move together in its loop)
 			if (use_memo) memo->record_failure(memo->key_of(f.read_pos - f.skipped_bases, f.gene_pos - target.gene_start, f.max_deletions), f.score + f.skipped_bases);
+			if (use_frontier) frontier->record_failure(f.read_pos - f.skipped_bases, f.gene_pos - target.gene_start, f.max_deletions, f.score + f.skipped_bases);
 			--depth;
 			f = stack[depth];
 		}
@@ -308,6 +385,7 @@ struct AlignRunner {
 	}
 	// reference: align(0, read, 0, contig, gene_start, gene_start, gene_end, ...) (source/filter_mismappers.cpp:86-199)
 	AlignMemo* memo = nullptr; // table of failed nested calls, shared by the lanes of the runner (second pass on the device); every align() takes a new epoch
+	AlignFrontier* frontier = nullptr; // failed nested calls by read position (shared by the lanes of the runner); every align() takes a new epoch
 	bool lanes_share_seeds = false; // the lanes work on the same read position and split its seeds (reads with hundreds of seeds per position); default: one read position per lane
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
@@ -325,9 +403,23 @@ struct AlignRunner {
 			if (lanes > 1) __syncthreads();
 #endif
 		}
+		if (frontier != nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (lanes > 1) __syncthreads();
+#endif
+			const uint32_t next = (frontier->epoch + 1) & 255u;
+			if (next == 0) for (uint32_t k = lane; k < FRONTIER_POSITIONS * FRONTIER_WAYS; k += lanes) frontier->words[k] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (lanes > 1) __syncthreads();
+#endif
+			if (lane == 0) frontier->epoch = next == 0 ? 1 : next;
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (lanes > 1) __syncthreads();
+#endif
+		}
 		if (lanes_share_seeds) {
 			for (int32_t read_pos = 0; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; ++read_pos) {
-				const bool found = align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, lane, lanes, memo);
+				const bool found = align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, lane, lanes, memo, frontier);
 				if (exhausted()) return false;
 				if (any(found)) return true;
 			}
@@ -335,7 +427,7 @@ struct AlignRunner {
 		}
 		for (int32_t base = 0; base + KMER_LENGTH < length && 2 * base + min_score <= length + 2 * KMER_LENGTH; base += (int32_t) lanes) { // the loop bound of the reference at read_pos = base
 			const int32_t read_pos = base + (int32_t) lane;
-			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, 0, 1, memo);
+			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, 0, 1, memo, frontier);
 			if (exhausted()) return false;
 			if (any(found)) return true;
 		}

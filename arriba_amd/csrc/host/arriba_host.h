@@ -195,6 +195,7 @@ class BamFeed;
 BamFeed* open_bam_feed(const std::string& path);
 void close_bam_feed(BamFeed* feed);
 uint64_t bam_feed_header(BamFeed* feed, std::vector<std::string>& target_names); // returns the size of the header = offset of the first record in the uncompressed stream
+uint64_t bam_feed_take_part(BamFeed* feed, uint32_t part, uint32_t parts);            // the feed delivers only part `part` of `parts` of the records from now on; returns the offset of its first record in the stream
 uint64_t bam_feed_size_hint(BamFeed* feed);                                       // expected size of the uncompressed stream, 0 = unknown
 bool bam_feed_next(BamFeed* feed, uint8_t* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece& piece);
 

@@ -420,6 +420,16 @@ int ahost_bam_open(ahost_session* session, const char* bam_path, int external_du
 	} catch (const std::exception& e) { g_error = e.what(); return -1; }
 }
 
+int ahost_bam_open_part(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length, unsigned int part, unsigned int parts, agpu_ingest_config* config) {
+	if (ahost_bam_open(session, bam_path, external_duplicate_marking, max_itd_length, config) != 0) return -1;
+	try {
+		config->first_record_offset = bam_feed_take_part(session->feed, part, parts);
+		config->part_of_sample = 1;
+		if (config->stream_size_hint > 0 && parts > 0) config->stream_size_hint = config->stream_size_hint / parts + (64u << 20);
+		return 0;
+	} catch (const std::exception& e) { g_error = e.what(); return -1; }
+}
+
 int ahost_bam_next(ahost_session* session, void* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece* piece) {
 	if (!session || !session->feed || !buffer || !piece) { g_error = "ahost_bam_open must run first"; return -1; }
 	try { return bam_feed_next(session->feed, (uint8_t*) buffer, capacity, blocks, block_capacity, *piece) ? 1 : 0; }

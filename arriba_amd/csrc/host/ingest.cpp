@@ -1239,7 +1239,10 @@ namespace {
 // reads n bytes at the current position of a descriptor: all threads with pread on a regular file, one read loop on a pipe
 struct FileBytes {
 	int fd; bool seekable; uint64_t position; unsigned int n_threads;
+	uint64_t limit = ~(uint64_t) 0; // reads stop here (a part of a file: BamFeed::take_part)
 	size_t read(uint8_t* buffer, size_t capacity) {
+		if (limit != ~(uint64_t) 0) capacity = position >= limit ? 0 : (size_t) std::min<uint64_t>(capacity, limit - position);
+		if (capacity == 0) return 0;
 		if (!seekable || capacity < (8u << 20) || n_threads <= 1) {
 			size_t got = 0;
 			while (got < capacity) {
@@ -1277,7 +1280,7 @@ struct FileBytes {
 class BamFeed {
 public:
 	enum Mode { RAW, BGZF_STORED, BGZF_DEFLATED, GZIP };
-	BamFeed(const std::string& path): gzip_open_(false), end_(false) {
+	BamFeed(const std::string& path): gzip_open_(false), end_(false), n_targets_(0), header_size_(0), header_raw_end_(0), consumed_raw_(0), head_block_raw_(NOWHERE), head_skip_(0), tail_block_raw_(NOWHERE), tail_keep_(0) {
 		fd_ = (path == "-") ? 0 : open(path.c_str(), O_RDONLY);
 		if (fd_ < 0) throw std::runtime_error("failed to open SAM file");
 		file_.fd = fd_; file_.position = 0; file_.n_threads = std::min(32u, ingest_threads());
@@ -1312,7 +1315,22 @@ public:
 				}
 			}
 			uint64_t size = 0;
-			if (parse_header(head, target_names, size)) return size;
+			if (parse_header(head, target_names, size)) {
+				n_targets_ = (uint32_t) target_names.size(); header_size_ = size;
+				// BGZF: the file offset of the block that holds the first record, and where that record starts inside it
+				if (mode_ == BGZF_STORED || mode_ == BGZF_DEFLATED) {
+					size_t raw_at = 0; uint64_t out_at = 0;
+					while (true) {
+						const size_t block = BgzfSource::block_size(pending_.data() + raw_at, pending_.size() - raw_at);
+						if (block == 0 || pending_.size() - raw_at < block) break;
+						const uint64_t out = le32(&pending_[raw_at + block - 4]);
+						if (out_at + out > size) break;
+						raw_at += block; out_at += out;
+					}
+					header_raw_end_ = raw_at; header_inside_ = size - out_at;
+				}
+				return size;
+			}
 			// the header is longer than what is there: read more
 			const size_t before = pending_.size();
 			pending_.resize(before + (4u << 20));
@@ -1331,6 +1349,7 @@ public:
 			size_t n = take_pending(buffer, capacity);
 			if (n < capacity && !end_) { const size_t got = file_.read(buffer + n, capacity - n); if (got == 0) end_ = true; n += got; }
 			piece.bytes = n; piece.stream_bytes = n;
+			consumed_raw_ += n;
 			return n > 0;
 		}
 		if (mode_ == GZIP) {
@@ -1351,12 +1370,19 @@ public:
 				if (!block_is_stored(buffer + at, size)) { deflated_ahead = true; break; }
 				if (count == block_capacity) break;
 				const size_t data_offset = 12 + (buffer[at + 10] | (size_t) buffer[at + 11] << 8), payload = le32(buffer + at + size - 4);
-				if (payload > 0) { agpu_bgzf_block& b = blocks[count++]; b.raw_offset = at; b.payload_offset = (uint32_t) (data_offset + 5); b.payload_size = (uint32_t) payload; b.stream_offset = out; b.crc32 = le32(buffer + at + size - 8); b.reserved = 0; }
-				at += size; out += payload;
+				size_t lo = 0, hi = payload; // (the first and the last block of a part of the file give only the records of the part)
+				if (consumed_raw_ + at == head_block_raw_) lo = std::min<size_t>(head_skip_, payload);
+				if (consumed_raw_ + at == tail_block_raw_) hi = std::max<size_t>(lo, std::min<size_t>(tail_keep_, payload));
+				if (hi > lo) {
+					agpu_bgzf_block& b = blocks[count++];
+					b.raw_offset = at; b.payload_offset = (uint32_t) (data_offset + 5 + lo); b.payload_size = (uint32_t) (hi - lo); b.stream_offset = out; b.crc32 = (lo == 0 && hi == payload) ? le32(buffer + at + size - 8) : 0; b.reserved = 0;
+				}
+				at += size; out += hi - lo;
 			}
 			if (at == 0 && !deflated_ahead && end_) throw std::runtime_error("failed to load alignments"); // a truncated block at the end of the file
 			pending_.assign(buffer + at, buffer + n); // an incomplete block (or everything from the first deflated block on) waits for the next call
 			if (deflated_ahead) mode_ = BGZF_DEFLATED;
+			consumed_raw_ += at;
 			piece.stored_bgzf = 1; piece.bytes = at; piece.stream_bytes = out; piece.n_blocks = count;
 			return at > 0 || deflated_ahead || !pending_.empty();
 		}
@@ -1365,7 +1391,7 @@ public:
 		size_t n = take_pending(raw_.data(), raw_.size());
 		if (n < raw_.size() && !end_) { const size_t got = file_.read(&raw_[n], raw_.size() - n); if (got == 0) end_ = true; n += got; }
 		if (n == 0) return false;
-		struct Block { size_t raw_offset, raw_size, out_offset, out_size; };
+		struct Block { size_t raw_offset, raw_size, out_offset, out_size, lo, hi; };
 		std::vector<Block> list;
 		size_t at = 0, out = 0;
 		while (n - at >= 18) {
@@ -1374,23 +1400,188 @@ public:
 			if (n - at < size) break;
 			const size_t out_size = le32(&raw_[at + size - 4]);
 			if (out + out_size > capacity) break;
-			Block block = { at, size, out, out_size };
+			size_t lo = 0, hi = out_size; // (the first and the last block of a part of the file give only the records of the part)
+			if (consumed_raw_ + at == head_block_raw_) lo = std::min<size_t>(head_skip_, out_size);
+			if (consumed_raw_ + at == tail_block_raw_) hi = std::max<size_t>(lo, std::min<size_t>(tail_keep_, out_size));
+			Block block = { at, size, out, out_size, lo, hi };
 			list.push_back(block);
-			at += size; out += out_size;
+			at += size; out += hi - lo;
 		}
 		if (list.empty() && end_) throw std::runtime_error("failed to load alignments");
 		std::vector<uint8_t> failed(1, 0);
 		const std::vector<uint8_t>& raw = raw_;
 		parallel_ranges(list.size(), n_threads_, [&list, &raw, buffer, &failed](size_t first, size_t last) {
-			for (size_t b = first; b < last; ++b)
-				if (!BgzfSource::inflate_block(&raw[list[b].raw_offset], list[b].raw_size, list[b].out_size > 0 ? buffer + list[b].out_offset : NULL, list[b].out_size)) failed[0] = 1;
+			for (size_t b = first; b < last; ++b) {
+				const Block& block = list[b];
+				if (block.lo == 0 && block.hi == block.out_size) {
+					if (!BgzfSource::inflate_block(&raw[block.raw_offset], block.raw_size, block.out_size > 0 ? buffer + block.out_offset : NULL, block.out_size)) failed[0] = 1;
+				} else {
+					std::vector<uint8_t> whole(block.out_size + 1);
+					if (!BgzfSource::inflate_block(&raw[block.raw_offset], block.raw_size, whole.data(), block.out_size)) failed[0] = 1;
+					else memcpy(buffer + block.out_offset, whole.data() + block.lo, block.hi - block.lo);
+				}
+			}
 		}, 8);
 		if (failed[0]) throw std::runtime_error("failed to load alignments");
 		pending_.assign(raw_.begin() + at, raw_.begin() + n);
+		consumed_raw_ += at;
 		piece.bytes = out; piece.stream_bytes = out;
 		return !list.empty() || !pending_.empty();
 	}
+	// ---- a part of the file (one sample over several GPUs: every rank reads the records of its part; include/arriba_host.h: ahost_bam_open_part) ----------
+	// The file is cut where a new read name begins (the alignments of a read follow each other in STAR's output, as the reference needs them for its
+	// single pass only within a name: source/read_chimeric_alignments.cpp:596-749), near the byte offsets size * k / parts.  cut(target) is a function of
+	// the file alone -- the first record start at or behind `target` that a chain of plausible records confirms, then on to the first record with another
+	// name -- so the rank before the cut and the rank behind it find the same place without talking to each other.
+	// Returns the offset of the first record of the part in the stream this feed delivers (the header size for part 0, else 0).
+	uint64_t take_part(uint32_t part, uint32_t parts) {
+		if (parts == 0 || part >= parts) throw std::runtime_error("part of the sample out of range");
+		if (!file_.seekable || mode_ == GZIP) throw std::runtime_error("a part of a sample can only be read from a BAM file on disk (BGZF or uncompressed): every rank opens the file at its own offset");
+		if (header_size_ == 0) throw std::runtime_error("the BAM header must be read first");
+		const Cut begin = part == 0 ? Cut() : cut(file_size_ / parts * part), end = part + 1 == parts ? Cut() : cut(file_size_ / parts * (part + 1));
+		if (part > 0) {
+			pending_.clear(); end_ = false;
+			file_.position = begin.at_end ? file_size_ : begin.raw; consumed_raw_ = file_.position;
+			if (mode_ != RAW && !begin.at_end && begin.inside > 0) { head_block_raw_ = begin.raw; head_skip_ = begin.inside; }
+			if (mode_ == BGZF_DEFLATED || mode_ == BGZF_STORED) mode_ = BGZF_STORED; // (a block that is not stored switches to the inflating path by itself)
+		}
+		if (part + 1 < parts && !end.at_end) {
+			uint64_t stop = end.raw;
+			if (mode_ != RAW && end.inside > 0) { tail_block_raw_ = end.raw; tail_keep_ = end.inside; stop = end.raw_next; }
+			if (stop < consumed_raw_) stop = consumed_raw_; // (cuts are monotone in their targets; an empty part if they coincide)
+			file_.limit = stop;
+			if (part == 0 && pending_.size() > stop) pending_.resize(stop); // the sniffed first bytes already reach beyond the part
+			if (mode_ != RAW && head_block_raw_ == tail_block_raw_ && head_block_raw_ != NOWHERE && tail_keep_ < head_skip_) tail_keep_ = head_skip_;
+		}
+		return part == 0 ? header_size_ : 0;
+	}
 private:
+	static const uint64_t NOWHERE = ~(uint64_t) 0;
+	struct Cut { bool at_end; uint64_t raw, inside, raw_next; Cut(): at_end(true), raw(0), inside(0), raw_next(0) {} }; // RAW: raw = offset of the record; BGZF: raw = offset of its block, inside = offset in the block's payload, raw_next = the block behind
+	struct Window { std::vector<uint8_t> bytes; std::vector<uint64_t> block_raw, block_out; uint64_t raw_begin; bool reaches_end; }; // uncompressed bytes from a block boundary on; per block: file offset, offset in `bytes`
+
+	size_t pread_at(uint64_t offset, uint8_t* buffer, size_t capacity) const {
+		size_t got = 0;
+		while (got < capacity) {
+			const ssize_t n = pread(fd_, buffer + got, capacity - got, (off_t) (offset + got));
+			if (n < 0) { if (errno == EINTR) continue; throw std::runtime_error("failed to load alignments"); }
+			if (n == 0) break;
+			got += (size_t) n;
+		}
+		return got;
+	}
+	// a record that could be one: sizes that add up, reference ids of the header, a printable nul-terminated name
+	bool plausible_record(const std::vector<uint8_t>& w, uint64_t at, uint64_t& next) const {
+		if (at + 36 > w.size()) return false;
+		const uint64_t block_size = le32(&w[at]);
+		const int32_t ref = (int32_t) le32(&w[at + 4]), pos = (int32_t) le32(&w[at + 8]), next_ref = (int32_t) le32(&w[at + 24]), next_pos = (int32_t) le32(&w[at + 28]), l_seq = (int32_t) le32(&w[at + 20]);
+		const uint32_t l_read_name = w[at + 12], n_cigar = w[at + 16] | (uint32_t) w[at + 17] << 8;
+		if (block_size < 32 + 2 || block_size > (64u << 20) || l_read_name < 2 || l_seq < 0 || ref < -1 || ref >= (int32_t) n_targets_ || next_ref < -1 || next_ref >= (int32_t) n_targets_ || pos < -1 || next_pos < -1) return false;
+		if (32 + (uint64_t) l_read_name + 4 * (uint64_t) n_cigar + ((uint64_t) l_seq + 1) / 2 + (uint64_t) l_seq > block_size) return false;
+		if (at + 36 + l_read_name > w.size()) return false;
+		for (uint32_t k = 0; k + 1 < l_read_name; ++k) if (w[at + 36 + k] < 33 || w[at + 36 + k] > 126) return false;
+		if (w[at + 36 + l_read_name - 1] != 0) return false;
+		next = at + 4 + block_size;
+		return true;
+	}
+	// CHAIN records in a row (or fewer, when they end exactly where the file ends)
+	bool chain_starts_at(const Window& w, uint64_t at) const {
+		const int CHAIN = 32;
+		for (int k = 0; k < CHAIN; ++k) {
+			if (at == w.bytes.size() && w.reaches_end) return k > 0;
+			uint64_t next;
+			if (!plausible_record(w.bytes, at, next)) return false;
+			if (next > w.bytes.size()) return false;
+			at = next;
+		}
+		return true;
+	}
+	// the uncompressed bytes of the file from `raw_begin` (a block boundary; any byte of an uncompressed file) on, at least `want` of them unless the file ends
+	void load_window(uint64_t raw_begin, uint64_t want, Window& w) const {
+		w.bytes.clear(); w.block_raw.clear(); w.block_out.clear(); w.raw_begin = raw_begin; w.reaches_end = false;
+		if (mode_ == RAW) {
+			w.bytes.resize(want);
+			w.bytes.resize(pread_at(raw_begin, w.bytes.data(), want));
+			w.reaches_end = raw_begin + w.bytes.size() >= file_size_;
+			return;
+		}
+		uint64_t raw_at = raw_begin;
+		std::vector<uint8_t> block(1u << 16);
+		while (w.bytes.size() < want) {
+			if (raw_at >= file_size_) { w.reaches_end = true; break; }
+			const size_t got = pread_at(raw_at, block.data(), block.size());
+			const size_t size = BgzfSource::block_size(block.data(), got);
+			if (size < 26 || got < size) throw std::runtime_error("failed to load alignments");
+			const size_t out = le32(&block[size - 4]), at = w.bytes.size();
+			w.block_raw.push_back(raw_at); w.block_out.push_back(at);
+			w.bytes.resize(at + out);
+			if (!BgzfSource::inflate_block(block.data(), size, out > 0 ? &w.bytes[at] : NULL, out)) throw std::runtime_error("failed to load alignments");
+			raw_at += size;
+		}
+		w.block_raw.push_back(raw_at); w.block_out.push_back(w.bytes.size()); // (one behind the last block: the end)
+	}
+	// the first block boundary at or behind `target`: a BGZF header that the headers of the two blocks behind it confirm
+	uint64_t block_boundary(uint64_t target) const {
+		std::vector<uint8_t> bytes(256u << 10);
+		while (true) {
+			if (target >= file_size_) return file_size_;
+			const size_t got = pread_at(target, bytes.data(), bytes.size());
+			for (size_t i = 0; i + 18 <= got; ++i) {
+				size_t at = i; int confirmed = 0; bool valid = true;
+				while (confirmed < 3) {
+					if (target + at == file_size_ || at + 18 > got) break; // the chain ends with the file / with what was read
+					const size_t size = BgzfSource::block_size(&bytes[at], got - at);
+					if (size < 26) { valid = false; break; }
+					at += size; ++confirmed;
+				}
+				if (valid && confirmed > 0 && target + at <= file_size_) return target + i;
+			}
+			if (got < bytes.size()) return file_size_;
+			target += got - 18;
+		}
+	}
+	Cut cut(uint64_t target) const {
+		Cut result;
+		uint64_t raw_begin, search_from = 0;
+		if (mode_ == RAW) raw_begin = std::max<uint64_t>(target, header_size_);
+		else {
+			raw_begin = block_boundary(target);
+			if (raw_begin <= header_raw_end_) { raw_begin = header_raw_end_; search_from = header_inside_; } // not before the first record
+		}
+		if (raw_begin >= file_size_) return result;
+		for (uint64_t want = 4u << 20; ; want *= 4) {
+			Window w;
+			load_window(raw_begin, want, w);
+			// the first record start a chain confirms
+			uint64_t first = NOWHERE;
+			for (uint64_t i = search_from; i + 36 <= w.bytes.size(); ++i) if (chain_starts_at(w, i)) { first = i; break; }
+			if (first == NOWHERE) {
+				if (w.reaches_end) return result; // no record behind the target: the part behind this cut is empty
+				if (want >= (1u << 30)) throw std::runtime_error("failed to load alignments");
+				continue;
+			}
+			// on to the first record with another name
+			uint64_t at = first, next = 0; bool found = false, ran_out = false;
+			const uint32_t name_length = w.bytes[first + 12];
+			while (true) {
+				if (at == w.bytes.size() && w.reaches_end) break; // the name of the cut goes on to the end of the file
+				if (!plausible_record(w.bytes, at, next) || next > w.bytes.size()) { ran_out = true; break; }
+				if (at != first && (w.bytes[at + 12] != name_length || memcmp(&w.bytes[at + 36], &w.bytes[first + 36], name_length) != 0)) { found = true; break; }
+				at = next;
+			}
+			if (ran_out) {
+				if (w.reaches_end || want >= (1u << 30)) throw std::runtime_error("failed to load alignments");
+				continue;
+			}
+			if (!found) return result;
+			result.at_end = false;
+			if (mode_ == RAW) { result.raw = raw_begin + at; return result; }
+			size_t block = 0;
+			while (block + 2 < w.block_out.size() && w.block_out[block + 1] <= at) ++block;
+			result.raw = w.block_raw[block]; result.inside = at - w.block_out[block]; result.raw_next = w.block_raw[block + 1];
+			return result;
+		}
+	}
 	static bool block_is_stored(const uint8_t* block, size_t available) { // one stored deflate block that fills the member
 		const size_t size = BgzfSource::block_size(block, available);
 		if (size == 0 || available < size) return false;
@@ -1464,12 +1655,17 @@ private:
 	std::vector<uint8_t> pending_, raw_;
 	z_stream gzip_;
 	bool gzip_open_, end_;
+	uint32_t n_targets_;
+	uint64_t header_size_, header_raw_end_, header_inside_ = 0; // BGZF: file offset of the block that holds the first record, and the record's offset inside it
+	uint64_t consumed_raw_;                                    // file offset of the first byte the next piece starts with
+	uint64_t head_block_raw_, head_skip_, tail_block_raw_, tail_keep_; // a part of the file: payload bytes to skip in its first block / to keep of its last one
 };
 
 BamFeed* open_bam_feed(const std::string& path) { return new BamFeed(path); }
 void close_bam_feed(BamFeed* feed) { delete feed; }
 uint64_t bam_feed_header(BamFeed* feed, std::vector<std::string>& target_names) { return feed->read_header(target_names); }
 uint64_t bam_feed_size_hint(BamFeed* feed) { return feed->stream_size_hint(); }
+uint64_t bam_feed_take_part(BamFeed* feed, uint32_t part, uint32_t parts) { return feed->take_part(part, parts); }
 bool bam_feed_next(BamFeed* feed, uint8_t* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece& piece) { return feed->next(buffer, capacity, blocks, block_capacity, piece); }
 
 }

@@ -178,11 +178,25 @@ class DevicePipeline(object):
         """reference: read_chimeric_alignments, source/read_chimeric_alignments.cpp:560-773, on the device: the host opens the file, parses the BAM header
         and feeds the bytes in pieces (two pinned buffers in turn); records are cut, collated by name, classified, sanity-checked, sorted and packed in HBM"""
         import time
+        started = time.perf_counter()
+        config, result, fed = self._ingest_records(bam, external_duplicate_marking, max_itd_length, piece_bytes)
+        finished = time.perf_counter()
+        self._record("read_chimeric_alignments")
+        self._adopt_ingest(config, result)
+        self.ingest_seconds = {"feed": fed - started, "device": finished - fed, "adopt": time.perf_counter() - finished}
+        return self.n
+
+    def _ingest_records(self, bam, external_duplicate_marking, max_itd_length, piece_bytes, part=None, parts=None):
+        """opens the file (or part `part` of `parts` of its records), feeds the pieces, runs agpu_ingest_finish; returns (config, result, time the last piece was fed)"""
+        import time
         lib, handle = self.session._lib, self.session._session
         host_error = lambda: ArribaError("ERROR: " + lib.ahost_last_error().decode())
-        started = time.perf_counter()
         config = _capi.IngestConfig()
-        if lib.ahost_bam_open(handle, bam.encode(), int(external_duplicate_marking), max_itd_length, byref(config)) != 0:
+        if part is None:
+            status = lib.ahost_bam_open(handle, bam.encode(), int(external_duplicate_marking), max_itd_length, byref(config))
+        else:
+            status = lib.ahost_bam_open_part(handle, bam.encode(), int(external_duplicate_marking), max_itd_length, part, parts, byref(config))
+        if status != 0:
             raise host_error()
         buffers = []
         try:
@@ -217,19 +231,23 @@ class DevicePipeline(object):
             lib.ahost_bam_close(handle)
             for pointer in buffers:
                 self.api.host_free(pointer)
-        finished = time.perf_counter()
-        self._record("read_chimeric_alignments")
+        # (config.coverage_window_offset points into the session: read it before anything else touches the session)
+        self._coverage_windows = int(config.coverage_window_offset[config.n_contigs]) if config.n_contigs else 0
+        return config, result, fed
+
+    def _adopt_ingest(self, config, result):
+        """hands what the host's sequential stages and its writer need from the ingest on the device to the host session (reference: the tail of
+        read_chimeric_alignments, source/read_chimeric_alignments.cpp:759-771, and coverage_t)"""
+        lib, handle = self.session._lib, self.session._session
         n_contigs = config.n_contigs
         viral = np.zeros(max(n_contigs, 1), dtype=np.uint64)
         self._check(self.api.get_viral_read_counts(self.ctx, viral.ctypes.data))
-        # (config.coverage_window_offset points into the session: read it before anything else touches the session)
-        windows = int(config.coverage_window_offset[n_contigs]) if n_contigs else 0
+        windows = self._coverage_windows
         coverage, starts, ends = np.zeros(max(windows, 1), dtype=np.uint16), np.zeros(max(windows, 1), dtype=np.uint8), np.zeros(max(windows, 1), dtype=np.uint8)
         self._check(self.api.get_coverage(self.ctx, coverage.ctypes.data, starts.ctypes.data, ends.ctypes.data))
         if lib.ahost_adopt_device_ingest(handle, byref(result), viral.ctypes.data, coverage.ctypes.data, starts.ctypes.data, ends.ctypes.data) != 0:
-            raise host_error()
+            raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
         self.ingest_result = result
-        self.ingest_seconds = {"feed": fed - started, "device": finished - fed, "adopt": time.perf_counter() - finished}
         self.n = int(result.fragments)
         self.device_ingest = True
         self.n_dummy_genes = 0

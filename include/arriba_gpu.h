@@ -196,6 +196,7 @@ typedef struct {
 	const uint64_t* coverage_window_offset; /* [n_contigs + 1] windows of coverage_t per contig (assembly size / 20 + 2; none without sequence) */
 	uint8_t external_duplicate_marking;     /* -u */
 	uint32_t max_itd_length;                /* -l */
+	uint8_t part_of_sample;                 /* the stream holds a part of the sample's records, other contexts hold the rest: agpu_shard_export / agpu_shard_merge follow */
 } agpu_ingest_config;
 typedef struct { uint64_t raw_offset; uint32_t payload_offset, payload_size; uint64_t stream_offset; uint32_t crc32; uint32_t reserved; } agpu_bgzf_block; /* offsets inside the pushed piece / the piece's part of the stream */
 typedef struct {
@@ -238,6 +239,20 @@ typedef struct {
 } agpu_batch_rows;
 int agpu_gather_rows_begin(agpu_ctx* ctx, const uint32_t* fragments /* NULL = all, in order */, uint64_t n, uint64_t* cigar_pool_size, uint64_t* seq_pool_size, uint64_t* names_size);
 int agpu_gather_rows_copy(agpu_ctx* ctx, agpu_batch_rows* rows);
+
+/* ---- one sample over the GPUs of a node (SURVEY.md section 8 row e; BASELINE.json config 4) ----------------------------------------------------------
+ * Every rank runs the ingest above over its part of the records (agpu_ingest_config.part_of_sample = 1; no read name in two parts).  What the reference's
+ * loop (source/read_chimeric_alignments.cpp:560-773) leaves behind is additive over such parts: the fragments concatenate (each part is in name order and
+ * the parts follow each other in name order -- checked), mapped_reads / malformed / missing-HI counters and mapped_viral_reads_by_contig add up, coverage_t
+ * adds up before its 16-bit saturation (source/read_stats.cpp:161-266).  The exchange is ONE collective over device memory:
+ *   agpu_shard_export_size / agpu_shard_export   the part of this context as one block of bytes (header + columns; csrc/device/shard_host.hpp), written to
+ *                                                 device (or host) memory of the caller -- e.g. straight into the send buffer of an all-gather
+ *   agpu_shard_merge                              the blocks of all parts, `stride` bytes apart in rank order (the receive buffer of the all-gather): the
+ *                                                 context then holds the batch of the whole sample exactly as a single ingest of all records leaves it
+ * after which every rank runs the stages on the whole batch (they take ~1 % of the time of a sample) and shares out filter_mismappers (below). */
+int agpu_shard_export_size(agpu_ctx* ctx, uint64_t* bytes);
+int agpu_shard_export(agpu_ctx* ctx, void* block, uint64_t capacity);
+int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_t n_parts, agpu_ingest_result* result /* sums over the parts; may be NULL */);
 
 /* restore the batch to its state right after agpu_upload_batch (filters, strands and gene sets cleared) so that the stages can be run again */
 int agpu_reset(agpu_ctx* ctx);
@@ -417,6 +432,15 @@ int agpu_make_kmer_index(agpu_ctx* ctx, int32_t padding, uint64_t* n_positions);
  * (mis-mapped reads get the filter id `mismappers`), then discards candidates that consist mostly of mis-mappers and lowers
  * their counters.  *remaining = the reference's "(remaining=N)"; *discarded_reads = reads newly marked as mis-mappers. */
 int agpu_filter_mismappers(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* remaining, uint64_t* discarded_reads);
+/* The same stage shared out over the ranks that hold the same batch (one sample over several GPUs, after agpu_shard_merge): the re-alignments are
+ * independent per read and make up ~80 % of the time of a large sample, everything around them is the same on every rank.
+ *   agpu_mismapper_jobs            the supporting reads of the unfiltered candidates, ordered by candidate (the same list on every rank): their number
+ *   agpu_mismapper_verdicts        re-aligns the jobs part, part + parts, part + 2 parts, ...; verdicts (n_jobs bytes, device or host memory) receives 1 where
+ *                                  a job of this part is a mis-mapper and 0 everywhere else -> one all-reduce (max) over the ranks
+ *   agpu_filter_mismappers_apply   the verdicts of all ranks: the reads get the filter id, then the candidates are judged as in agpu_filter_mismappers */
+int agpu_mismapper_jobs(agpu_ctx* ctx, uint64_t* n_jobs);
+int agpu_mismapper_verdicts(agpu_ctx* ctx, int32_t max_mate_gap, uint32_t part, uint32_t parts, uint8_t* verdicts);
+int agpu_filter_mismappers_apply(agpu_ctx* ctx, const uint8_t* verdicts, uint64_t* remaining, uint64_t* discarded_reads);
 
 /* ---- Sharded samples: one context per GPU holds a contiguous range of the fragments in name order.
  * The per-fragment stages run on the shard; the entry points below expose the three places where the reference's result depends on

@@ -47,6 +47,11 @@ int ahost_load_ingest(ahost_session* session, const char* path);
  *                      with agpu_gather_rows_*; fragment indices in an ahost_fusion_table then refer to these rows */
 typedef struct { int stored_bgzf; size_t bytes; size_t stream_bytes; uint32_t n_blocks; } ahost_bam_piece;
 int ahost_bam_open(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length, agpu_ingest_config* config);
+/* One sample over several GPUs: as ahost_bam_open, but the pieces that follow hold only part `part` of `parts` of the records -- the file (BGZF or
+ * uncompressed BAM on disk; the alignments of a read name next to each other, as STAR writes them) is cut between read names near the byte offsets
+ * size * k / parts, at places every rank finds by itself from the bytes of the file.  config->part_of_sample is set: agpu_shard_export / agpu_shard_merge
+ * (include/arriba_gpu.h) put the parts together, and ahost_adopt_device_ingest then takes the result of the merge. */
+int ahost_bam_open_part(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length, unsigned int part, unsigned int parts, agpu_ingest_config* config);
 int ahost_bam_next(ahost_session* session, void* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece* piece);
 void ahost_bam_close(ahost_session* session);
 int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* result, const uint64_t* viral_read_counts, const uint16_t* coverage, const uint8_t* fragment_starts, const uint8_t* fragment_ends);

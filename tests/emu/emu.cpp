@@ -27,6 +27,7 @@
 #include "../../arriba_amd/csrc/device/index_bins.hpp"
 #include "../../arriba_amd/csrc/device/multimapper_core.hpp"
 #include "../../arriba_amd/csrc/device/ingest_core.hpp"
+#include "../../arriba_amd/csrc/device/shard_host.hpp"
 #include <map>
 #include <set>
 #include <tuple>

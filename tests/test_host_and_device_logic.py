@@ -315,6 +315,71 @@ def test_device_ingest_reads_every_container_and_pipes(built, dataset_files, emu
             ingest(str(tmp_path / name))
 
 
+def _ingest_in_parts(prefix, path, parts, api, piece_bytes=1 << 20):
+    """what arriba_amd/one_sample.py does, without the processes: every part of the records of `path` ingested by a context of its own, the exported blocks
+    laid out as an all-gather leaves them, merged by the context of part 0; returns (session, pipeline of the merged batch, fragments of the parts)"""
+    from ctypes import byref, c_uint64
+    from arriba_amd import _capi
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+
+    class Part(DevicePipeline):
+        def __init__(self, session, part, **kw):
+            self.part = part
+            super().__init__(session, **kw)
+
+        def read_chimeric_alignments(self, bam, external_duplicate_marking=False, max_itd_length=100, piece_bytes=1 << 20):
+            self.config, result, _ = self._ingest_records(bam, external_duplicate_marking, max_itd_length, piece_bytes, part=self.part, parts=parts)
+            self.n = int(result.fragments)
+            return self.n
+    pipelines = [Part(HostSession(prefix + ".fa", prefix + ".gtf"), part, api=api, bam=path, piece_bytes=piece_bytes) for part in range(parts)]
+    sizes = []
+    for pipeline in pipelines:
+        size = c_uint64()
+        pipeline._check(api.shard_export_size(pipeline.ctx, byref(size)))
+        sizes.append(size.value)
+    stride = (max(sizes) + 15) & ~15
+    blocks = np.zeros(stride * parts, dtype=np.uint8)
+    for pipeline in pipelines:
+        pipeline._check(api.shard_export(pipeline.ctx, blocks.ctypes.data + pipeline.part * stride, stride))
+    merged, result = pipelines[0], _capi.IngestResult()
+    merged._check(api.shard_merge(merged.ctx, blocks.ctypes.data, stride, parts, byref(result)))
+    merged._adopt_ingest(merged.config, result)
+    return merged.session, merged, [pipeline.n for pipeline in pipelines[1:]] + [None]
+
+
+def test_device_ingest_in_parts_gives_the_batch_of_the_whole_file(built, dataset_files, emu_api, tmp_path):
+    """One sample over several GPUs starts with every rank reading its part of the records (BamFeed::take_part cuts the file between read names at places found
+    from the bytes alone) and one merge of the parts (agpu_shard_export / agpu_shard_merge): whatever the container and the number of parts -- more parts than
+    the file has blocks included -- the merged batch, the counters and coverage_t are those of a single ingest of the whole file."""
+    import gzip
+    from arriba_amd.pipeline import ArribaError, DevicePipeline, HostSession
+    for name in ("toy3k", "itd6k"):
+        prefix = dataset_files(name)
+        session = HostSession(prefix + ".fa", prefix + ".gtf")
+        expected = _device_batch_columns(session, DevicePipeline(session, api=emu_api, bam=prefix + ".bam"))
+        payload = _bam_payload(prefix + ".bam")
+        variants = {"stored": prefix + ".bam", "raw": str(tmp_path / (name + ".raw.bam")), "deflated": str(tmp_path / (name + ".deflated.bam")), "small_blocks": str(tmp_path / (name + ".small.bam"))}
+        open(variants["raw"], "wb").write(payload)
+        _write_bgzf(variants["deflated"], payload, 6)
+        _write_bgzf(variants["small_blocks"], payload, 1, block=997)  # (most records lie across block boundaries)
+        for container, path in variants.items():
+            for parts in ((1, 2, 3, 7, 64) if name == "toy3k" else (5,)):
+                merged_session, merged, fragments = _ingest_in_parts(prefix, path, parts, emu_api)
+                assert _device_batch_columns(merged_session, merged) == expected, (name, container, parts)
+                if 1 < parts < 10:
+                    assert all(n is None or n > 0 for n in fragments), (container, parts, fragments)  # every part got records
+    prefix = dataset_files("toy3k")
+    plain = str(tmp_path / "plain.bam")
+    with gzip.open(plain, "wb") as out:
+        out.write(_bam_payload(prefix + ".bam"))
+    with pytest.raises(ArribaError, match="part of a sample"):  # not seekable by blocks: every rank would have to inflate the whole file
+        _ingest_in_parts(prefix, plain, 2, emu_api)
+    # parts that do not follow each other in the order of the names (a file that is not sorted the way the reference's std::map iterates): refused, not merged wrongly
+    shuffled = dataset_files("shuffled2k")
+    with pytest.raises(ArribaError, match="interleave"):
+        _ingest_in_parts(shuffled, shuffled + ".bam", 3, emu_api)
+
+
 def test_device_ingest_survives_a_false_record_start(built, dataset_files, emu_api, tmp_path):
     """The record chain is cut by segments that GUESS their first record.  A record whose aux array holds two well-formed record headers exactly at the start of
     an 8 KB segment makes that guess wrong (and flags the segment behind it, whose own guess is right): one repair pass must settle the chain -- not one pass per

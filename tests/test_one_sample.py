@@ -1,0 +1,39 @@
+"""Multi-process tier (gloo, CPU): one sample over several ranks (arriba_amd/one_sample.py) -- every rank ingests its part of the records of the file, one
+all-gather puts the batch together, filter_mismappers is shared out -- must give exactly the batch, the stage counts and the output files of the
+single-process pipeline over the whole file.  The device stages are stepped on the host (tests/emu)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import conftest
+import datasets
+
+ROOT = conftest.ROOT
+
+
+def run_one_sample(prefix, world, api, out_path, port, bam=None):
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "tests", "one_sample_worker.py"), prefix, api, out_path, bam or prefix + ".bam"]
+    result = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=1500)
+    assert result.returncode == 0, result.stdout[-3000:]
+    return [json.load(open("%s.rank%d.json" % (out_path, rank))) for rank in range(world)]
+
+
+def check_reports(reports):
+    for report in reports:
+        assert "error" not in report, report["error"]
+    assert reports[0]["problems"] == [], reports[0]["problems"]
+    for report in reports[1:]:  # every rank holds the same batch and reaches the same verdicts
+        for key in ("fragments", "records", "mapped_reads", "batch", "log", "filters", "mismapper_jobs"):
+            assert report[key] == reports[0][key], key
+    return reports[0]
+
+
+@pytest.mark.parametrize("world,name", [(2, "toy3k"), (3, "homologs8k"), (4, "mid30k")])
+def test_one_sample_over_ranks_equals_single_process(world, name, dataset_files, emu_api, tmp_path):
+    report = check_reports(run_one_sample(dataset_files(name), world, "emu", str(tmp_path / "report"), 29700 + world))
+    assert sum(1 for size in report["part_bytes"] if size > 4096) == world  # every rank read a part of the file
+    assert report["mismapper_jobs"] > 0 and report["fusions"] > 0
