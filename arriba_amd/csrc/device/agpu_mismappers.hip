@@ -147,16 +147,19 @@ __global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, 
 // by the candidate that lists the read first: the lanes of a wavefront then work on reads of one gene pair -- the same k-mer tables and genome windows, searches of
 // similar length.  A read that runs out of its step budget (or of stack) is put on the `heavy` list: the verdict of a read does not depend on who computes it.
 const int SEGMENT_CACHE = 128; // bases of a segment kept in LDS per lane (longer segments are read from HBM)
-const int64_t FIRST_PASS_STEPS = 65536; // steps of the search loop + bases compared; an ordinary read takes a few thousand
+// Steps of the search loop + bases compared that a read gets in the first pass; the mean is ~1100.  A thread that uses up a long budget keeps its wavefront (63 idle
+// lanes) and with it the whole launch waiting -- ~15 us per step -- while the second pass takes over such a read at no extra cost: measured at 10.4 M fragments
+// (profiles/r02l_first_pass_ab.txt), first + second pass: 65536 steps 1024 + 453 ms, 8192: 232 + 436 ms, 2048: 122 + 453 ms, 512: 59 + 626 ms.
+const int64_t FIRST_PASS_STEPS = 2048;
 __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap,
-                                                                        uint32_t* heavy, unsigned int* counters /* [1] discarded, [3] heavy */) {
+                                                                        int64_t first_pass_steps, uint32_t* heavy, unsigned int* counters /* [1] discarded, [3] heavy */) {
 	__shared__ uint32_t block_sum;
 	__shared__ uint8_t segment_bases[SEGMENT_CACHE * ALIGN_BLOCK];
 	const uint32_t j = blockIdx.x * ALIGN_BLOCK + threadIdx.x;
 	uint32_t mine = 0;
 	if (j < n_jobs) {
 		AlignFrame stack[ALIGN_SHALLOW_DEPTH];
-		int64_t budget = FIRST_PASS_STEPS;
+		int64_t budget = first_pass_steps;
 		AlignRunner runner; runner.stack = stack; runner.lane = 0; runner.lanes = 1; runner.budget = &budget; runner.max_depth = ALIGN_SHALLOW_DEPTH;
 		runner.cache = segment_bases + threadIdx.x; runner.cache_stride = ALIGN_BLOCK; runner.cache_capacity = SEGMENT_CACHE;
 		const uint32_t read = jobs[j];
@@ -398,12 +401,14 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 			uint32_t n_heavy = 0;
 			if (n_jobs > 0) {
 			const char* first_pass = getenv("ARRIBA_MISMAPPER_FIRST_PASS"); // "0": every read goes to the wavefront-per-read pass (for A/B measurements)
+			const char* steps_knob = getenv("ARRIBA_FIRST_PASS_STEPS");
+			const int64_t first_pass_steps = steps_knob != nullptr && atoll(steps_knob) > 0 ? atoll(steps_knob) : FIRST_PASS_STEPS;
 			if (first_pass != nullptr && first_pass[0] == '0') {
 				HIP_CHECK(hipMemcpyAsync(heavy.ptr, job_list, (size_t) n_jobs * 4, hipMemcpyDeviceToDevice, s));
 				n_heavy = n_jobs;
 			} else {
 				{ KernelTimer timer(ctx, "mismapper_verdict_kernel", (uint64_t) n_jobs * 300);
-				  mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, job_list, n_jobs, max_mate_gap, heavy.as<uint32_t>(), device_counters); }
+				  mismapper_verdict_kernel<<<grid_for(n_jobs, ALIGN_BLOCK), ALIGN_BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, job_list, n_jobs, max_mate_gap, first_pass_steps, heavy.as<uint32_t>(), device_counters); }
 				HIP_CHECK(hipMemcpyAsync(&n_heavy, device_counters + 3, 4, hipMemcpyDeviceToHost, s));
 				HIP_CHECK(hipStreamSynchronize(s));
 			}

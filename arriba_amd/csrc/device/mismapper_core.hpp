@@ -42,6 +42,13 @@ struct Segment {
 		return reverse_complement ? complement_code(sequence.code(offset + length - 1 - i)) : sequence.code(offset + i);
 	}
 	AGPU_HD char at(uint32_t i) const { return base_char(code(i)); }
+	// eight bases from position i on as characters, one per byte, the first in the low byte (0 behind the end of the segment): eight independent loads instead of
+	// one per step of the extension
+	AGPU_HD uint64_t chars8(uint32_t i) const {
+		uint64_t value = 0;
+		for (uint32_t k = 0; k < 8; ++k) if (i + k < length) value |= (uint64_t) (uint8_t) at(i + k) << (8 * k);
+		return value;
+	}
 	AGPU_HD uint32_t kmer(uint32_t position) const {
 		uint32_t result = 0;
 		for (int k = 0; k < KMER_LENGTH; ++k) result = result << 2 | kmer_digit(code(position + k));
@@ -284,15 +291,24 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 				// The extension to the right base by base, in one go until something happens that needs the stack (a nested call) or ends the hit: per base a
 				// compare against a register window of eight genome bases and a compare against the next splice site.  What the states ALIGN_COMPARE_BASE /
 				// ALIGN_AFTER_MISMATCH / ALIGN_ADVANCE do one at a time (they remain as the places where a nested call returns to).
+				// What a step waits for is memory, so everything it reads comes in eights or is remembered: the genome bases (a register window of eight), the bases of
+				// the read (another one), the position of the next splice site (looked up again only when the extension has passed it).
 				uint64_t window = 0; int32_t window_at = 0, window_end = 0; // genome bases [window_at, window_end) of the contig
+				uint64_t read_window = 0; int32_t read_window_at = 0, read_window_end = 0; // bases [read_window_at, read_window_end) of the read
+				int32_t next_site = -1; // the first splice site at or behind extended_gene_pos - 1 (INT32_MAX: none); -1: not looked up yet
 				while (true) {
 					if (budget != nullptr && --*budget < 0) return false;
 					ALIGN_STAT(bases, 1);
 					if (!(f.extended_read_pos < length && f.extended_gene_pos <= target.gene_end)) { f.state = ALIGN_NEXT_HIT; break; }
-					if (is_splice_site_from(target, f.extended_gene_pos - 1, f.splice_cursor)) { f.state = ALIGN_COMPARE_BASE; call = true; call_max_deletions = f.max_deletions; break; } // re-seed behind a splice site (spliced alignment)
+					if (next_site < f.extended_gene_pos - 1) {
+						while (f.splice_cursor < target.n_splice_sites && target.splice_sites[f.splice_cursor] < f.extended_gene_pos - 1) ++f.splice_cursor;
+						next_site = f.splice_cursor < target.n_splice_sites ? target.splice_sites[f.splice_cursor] : 0x7FFFFFFF;
+					}
+					if (next_site == f.extended_gene_pos - 1) { f.state = ALIGN_COMPARE_BASE; call = true; call_max_deletions = f.max_deletions; break; } // re-seed behind a splice site (spliced alignment)
 					if (f.extended_gene_pos >= window_end || f.extended_gene_pos < window_at) { window_at = f.extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
+					if (f.extended_read_pos >= read_window_end || f.extended_read_pos < read_window_at) { read_window_at = f.extended_read_pos; read_window_end = read_window_at + 8; read_window = read.chars8((uint32_t) read_window_at); }
 					const char reference_base = (char) (window >> (8 * (f.extended_gene_pos - window_at)));
-					if (read.at((uint32_t) f.extended_read_pos) == reference_base) {
+					if ((char) (read_window >> (8 * (f.extended_read_pos - read_window_at))) == reference_base) {
 						f.extended_score++;
 						if (f.extended_score >= min_score) return true;
 						f.consecutive_mismatches = 0;

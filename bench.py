@@ -11,8 +11,10 @@ device context happen once before the timed region, as in a resident service; th
 the line says how much that is.  The time from the resident batch to the end of filter_relative_support -- what round 1 reported -- is the secondary
 field `device_resident_step`.
 
-With --gpus N every rank runs the workflow over its own sample of the same size on its own GPU (samples are independent: no collective on the data path);
-value = fragments of all samples / the slowest rank's time.  Rank 0 prints ONE JSON line.
+With --gpus N the N ranks work on ONE sample of the same size (BASELINE.json config 4; arriba_amd/one_sample.py): every rank ingests its part of the records of
+the file, one all-gather puts the batch together on every GPU, the stages up to filter_homologs (~1 % of the time) run on every rank, the re-alignments of
+filter_mismappers (~80 %) are shared out with one all-reduce of the verdicts, rank 0 writes the files; value = fragments of the sample / the slowest rank's
+time ("scaling": "strong").  --per-rank-samples gives every rank a sample of its own instead (no collective on the data path; "weak").  Rank 0 prints ONE JSON line.
 
 The CPU baseline is the oracle build of the UNMODIFIED reference (oracle/_ref/arriba_ref, single-threaded by design) on a bounded sample of the same workload.
 --host-only: no GPU needed -- generates a small sample, runs the file side of the device ingest (BamFeed) and the classic host ingest from a named pipe and
@@ -168,6 +170,7 @@ def main():
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--host-only", action="store_true")
     parser.add_argument("--keep", help="keep the sample and the output files in this directory")
+    parser.add_argument("--per-rank-samples", action="store_true", help="with --gpus N: every rank works on a sample of its own (weak scaling, no collective) instead of all ranks on one sample")
     args = parser.parse_args()
     if args.host_only:
         args.fragments = args.fragments or 20000
@@ -194,6 +197,9 @@ def main():
         dist.barrier()
     import numpy as np
     from arriba_amd.pipeline import DevicePipeline, HostSession
+    # --gpus N: BASELINE.json config 4 -- ONE sample over the N GPUs (arriba_amd/one_sample.py: every rank ingests its part of the file, one all-gather, the
+    # re-alignments of filter_mismappers shared out, rank 0 writes the files); the same total work for every N = strong scaling
+    one_sample = distributed and not args.per_rank_samples and not args.host_ingest
 
     fallback_reason = os.environ.get("ARRIBA_BENCH_FALLBACK_REASON")
     if args.fragments is None:
@@ -202,7 +208,12 @@ def main():
         memory = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
         shm_free = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else 0
         device_memory = torch.cuda.get_device_properties(local_rank).total_memory
-        fits = memory > world * (160 << 30) and max(shm_free, shutil.disk_usage(tempfile.gettempdir()).free) > world * (80 << 30) and device_memory > (200 << 30)
+        samples = 1 if one_sample else world
+        fits = memory > samples * (160 << 30) and max(shm_free, shutil.disk_usage(tempfile.gettempdir()).free) > samples * (80 << 30) and device_memory > (200 << 30)
+        if distributed:  # (every rank must come to the same conclusion)
+            verdict = torch.tensor([int(fits)], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+            fits = bool(verdict.item())
         args.fragments = 100000000 if fits else 10000000
         if not fits:
             fallback_reason = "10 M fragments (BASELINE.json config 2) instead of the 100 M sample: host memory %.0f GB, tmpfs %.0f GB free, HBM %.0f GB" % (memory / 2**30, shm_free / 2**30, device_memory / 2**30)
@@ -226,17 +237,29 @@ def main():
                 shutil.rmtree(child_scratch, ignore_errors=True)
             progress("falling back to 10 M fragments: " + fallback_reason)
             args.fragments = 10000000
-    directory = args.keep or os.environ.get("ARRIBA_BENCH_SCRATCH") or scratch_directory(args.fragments * 600)
+    if one_sample:  # rank 0 makes the sample where every rank of the node finds it
+        shared = [args.keep or os.environ.get("ARRIBA_BENCH_SCRATCH") or scratch_directory(args.fragments * 600)] if rank == 0 else [None]
+        dist.broadcast_object_list(shared, src=0)
+        directory = shared[0]
+    else:
+        directory = args.keep or os.environ.get("ARRIBA_BENCH_SCRATCH") or scratch_directory(args.fragments * 600)
     os.makedirs(directory, exist_ok=True)
     try:
-        prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, ((os.cpu_count() or 2) - 2) // world)))
+        if one_sample:
+            timing = [None, None]
+            if rank == 0:
+                timing = list(generate_sample(args.fragments, 1000, directory, stress=args.stress))
+            dist.broadcast_object_list(timing, src=0)  # (also the barrier behind which the files exist)
+            prefix, generate_seconds = timing
+        else:
+            prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, ((os.cpu_count() or 2) - 2) // world)))
         bam_bytes = os.path.getsize(prefix + ".bam")
         progress("sample generated: %d fragments, %.1f GB BAM in %.1f s (%s)" % (args.fragments, bam_bytes / 1e9, generate_seconds, directory))
         session = HostSession(prefix + ".fa", prefix + ".gtf")  # assembly + annotation, once (resident)
         progress("assembly and annotation loaded")
         params = {"subsampling_threshold": 32767} if args.stress else None
         pipeline = None
-        outputs = [os.path.join(directory, "fusions.tsv"), os.path.join(directory, "discarded.tsv") if args.discarded else None]
+        outputs = [os.path.join(directory, "fusions.rank%d.tsv" % rank), os.path.join(directory, "discarded.rank%d.tsv" % rank) if args.discarded else None]
         stage_log, step_seconds, ingest_parts, steps_done = [], [], [], [0]
 
         def step():
@@ -250,6 +273,10 @@ def main():
                 pipeline = DevicePipeline(session, params=params, device=local_rank)
                 pipeline.set_profiling(profiling[0])
                 ingest_parts.append({"host_ingest": time.perf_counter() - started})
+            elif pipeline is None and one_sample:
+                from arriba_amd.one_sample import OneSamplePipeline
+                pipeline = OneSamplePipeline(session, prefix + ".bam", params=params, device=local_rank, piece_bytes=256 << 20, profiling=profiling[0] or args.warmup == 0)
+                ingest_parts.append(dict(pipeline.ingest_seconds))
             elif pipeline is None:
                 pipeline = DevicePipeline(session, params=params, device=local_rank, bam=prefix + ".bam", piece_bytes=256 << 20, profiling=profiling[0] or args.warmup == 0)
                 ingest_parts.append(dict(pipeline.ingest_seconds))
@@ -307,7 +334,7 @@ def main():
             elapsed = float(tensor.item())
             counts = torch.tensor([n], device=device, dtype=torch.int64)
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-            total_fragments = int(counts.item())
+            total_fragments = n if one_sample else int(counts.item())  # one sample: every rank holds (and counted) all of its fragments
         else:
             total_fragments = n
 
@@ -319,7 +346,8 @@ def main():
             without_gene = int((pipeline.gene_sets(slot)[0] == 0).sum())
             if without_gene:
                 self_check.append("%d alignments in slot %d have no gene after annotate" % (without_gene, slot))
-        fusion_lines = sum(1 for line in open(outputs[0]) if not line.startswith("#"))
+        writes_files = rank == 0 or not one_sample
+        fusion_lines = sum(1 for line in open(outputs[0]) if not line.startswith("#")) if writes_files else stage_log[-1][1]
         if not stage_log or stage_log[-1][0] != "recover_isoforms" or fusion_lines != stage_log[-1][1]:
             self_check.append("fusions.tsv holds %d fusions, the last stage counted %s" % (fusion_lines, stage_log[-1:] or None))
         if self_check:
@@ -357,13 +385,15 @@ def main():
                 "unit": "chimeric reads/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-                "config": {"workload": "synthetic %d chimeric fragments per GPU (%d BAM records, %.1f GB uncompressed BGZF; 2x100 bp, 24-contig synthetic genome, GENCODE-like GTF)%s, default filters, BAM file in memory -> fusions.tsv%s"
-                                       % (args.fragments, pipeline.ingest_result.records if pipeline.ingest_result else -1, bam_bytes / 1e9, ", mismapper stress (clips of 40-70 nt copied from the partner gene, -U 32767)" if args.stress else "",
+                "higher_is_better": True, "scaling": "strong" if one_sample else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "config": {"workload": "synthetic %d chimeric fragments " % args.fragments + ("in one sample" if one_sample else "per GPU") + " (%d BAM records, %.1f GB uncompressed BGZF; 2x100 bp, 24-contig synthetic genome, GENCODE-like GTF)%s, default filters, BAM file in memory -> fusions.tsv%s"
+                                       % (pipeline.ingest_result.records if pipeline.ingest_result else -1, bam_bytes / 1e9, ", mismapper stress (clips of 40-70 nt copied from the partner gene, -U 32767)" if args.stress else "",
                                           " + discarded.tsv" if args.discarded else ""),
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
-                           "parallelism": ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
+                           "parallelism": ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
+                                           % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0))) if one_sample
+                                          else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
                            "outside_the_step": "loading assembly + annotation (ahost_open), device context; generating the sample took %.1f s" % generate_seconds,
                            "names_were_sorted": bool(pipeline.ingest_result.names_were_sorted) if pipeline.ingest_result else None,
                            "why_not_the_100M_sample": fallback_reason},
@@ -381,10 +411,18 @@ def main():
             }
             line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted"
             progress("self-check done, kernel profile read")
-            line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped"} if args.no_cpu_baseline else cpu_baseline(1000, directory, stress=args.stress)
+            if args.no_cpu_baseline or distributed:  # (timed at N = 1 only)
+                line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped: the reference is timed by the run with 1 GPU" if distributed else "skipped"}
+            else:
+                line["cpu_baseline"] = cpu_baseline(1000, directory, stress=args.stress)
             print(json.dumps(line))
     finally:
-        if not args.keep:
+        if one_sample:
+            try:
+                dist.barrier()  # nobody removes the sample while another rank still reads it
+            except Exception:
+                pass
+        if not args.keep and (rank == 0 or not one_sample):
             shutil.rmtree(directory, ignore_errors=True)
     if distributed:
         dist.barrier()

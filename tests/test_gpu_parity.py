@@ -231,6 +231,32 @@ def test_sharded_pipeline_two_ranks_on_one_device(built, dataset_files, tmp_path
     assert sum(r["owned_candidates"] for r in reports) == reports[0]["candidates"]
 
 
+def test_one_sample_over_two_ranks_on_one_device(built, dataset_files, tmp_path):
+    """One sample over several ranks (arriba_amd/one_sample.py) with the kernels of the GPU: two processes on cuda:0 ingest their halves of the file, the all-gather
+    of the parts and the all-reduce of the mis-mapper verdicts go through gloo (RCCL needs a GPU per rank: bench.py --gpus N); batch, stage counts and both output
+    files must be those of the single-process run over the whole file."""
+    import test_one_sample
+    report = test_one_sample.check_reports(test_one_sample.run_one_sample(dataset_files("mid30k"), 2, "gpu", str(tmp_path / "report"), 29755))
+    assert report["mismapper_jobs"] > 0 and report["fusions"] > 0
+
+
+def test_device_ingest_in_parts_on_the_gpu(built, dataset_files, tmp_path):
+    """agpu_shard_export / agpu_shard_merge on the GPU: 3 and 7 parts of a stored-BGZF file and of one with 997-byte blocks, merged from blocks in host memory
+    (as a gloo all-gather leaves them) and compared column by column with the ingest of the whole file"""
+    import test_host_and_device_logic as host_tests
+    from arriba_amd import _capi
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    api = _capi.bind_device_api(_capi.device_library(), "agpu_")
+    prefix = dataset_files("itd6k")
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    expected = host_tests._device_batch_columns(session, DevicePipeline(session, bam=prefix + ".bam"))
+    small = str(tmp_path / "small.bam")
+    host_tests._write_bgzf(small, host_tests._bam_payload(prefix + ".bam"), 1, block=997)
+    for path, parts in ((prefix + ".bam", 3), (small, 7)):
+        merged_session, merged, _ = host_tests._ingest_in_parts(prefix, path, parts, api)
+        assert host_tests._device_batch_columns(merged_session, merged) == expected, (path, parts)
+
+
 def test_gene_set_capacity_is_reported_not_truncated(built, tmp_path):
     from arriba_amd.pipeline import ArribaError
     prefix = datasets.generate({"args": ["--seed", "13", "--fragments", "3000", "--contigs", "3", "--contig-len", "300000", "--junctions", "80", "--genes-per-mb", "40", "--gene-stack", "24"]}, str(tmp_path))
