@@ -3,6 +3,9 @@
 #include "../../../include/arriba_host.h"
 #include "arriba_host.h"
 #include "output.h"
+#include <chrono>
+#include <thread>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -236,6 +239,7 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 	if (!session || !table || !path) { g_error = "null argument"; return -1; }
 	if (!session->have_batch) { g_error = "no BAM ingested yet"; return -1; }
 	try {
+		const std::chrono::steady_clock::time_point profile_start = std::chrono::steady_clock::now();
 		FusionTable t;
 		t.n_candidates = table->n_candidates; t.gene1 = table->gene1; t.gene2 = table->gene2; t.contigs = table->contigs; t.breakpoint1 = table->breakpoint1; t.breakpoint2 = table->breakpoint2;
 		t.flags = table->flags; t.filter = table->filter; t.split_reads1 = table->split_reads1; t.split_reads2 = table->split_reads2; t.discordant_mates = table->discordant_mates;
@@ -246,21 +250,42 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 		// that get written and the filter column are translated from fragments to rows
 		std::vector<uint32_t> lists_as_rows; std::vector<uint8_t> filter_of_rows;
 		if (print_extra_info && session->device_batch && t.n_candidates > 0) {
-			const std::vector<uint32_t>& fragments = session->row_fragments;
-			lists_as_rows.assign(t.read_lists, t.read_lists + t.list_offset[3 * (size_t) t.n_candidates]);
+			const std::vector<uint32_t>& fragments = session->row_fragments; // ascending
+			const size_t n_entries = t.list_offset[3 * (size_t) t.n_candidates];
+			lists_as_rows.resize(n_entries);
 			filter_of_rows.resize(fragments.size() + 1);
 			for (size_t row = 0; row < fragments.size(); ++row) filter_of_rows[row] = t.read_filter[fragments[row]];
-			for (uint32_t c = 0; c < t.n_candidates; ++c) {
-				const bool written = (write_discarded != 0) != (t.filter[c] == 0);
-				for (uint32_t k = t.list_offset[3 * (size_t) c]; k < t.list_offset[3 * (size_t) c + 3]; ++k) {
-					if (!written) { lists_as_rows[k] = 0; continue; }
-					const std::vector<uint32_t>::const_iterator row = std::lower_bound(fragments.begin(), fragments.end(), t.read_lists[k]);
-					if (row == fragments.end() || *row != t.read_lists[k]) throw std::runtime_error("a supporting read of a written candidate is not among the rows handed over (ahost_fusion_table_reads / ahost_set_batch_rows)");
-					lists_as_rows[k] = (uint32_t) (row - fragments.begin());
+			// fragment -> row: a bit per fragment and the number of set bits in front of every word (the row of a fragment is its rank among the fragments handed over);
+			// the lists are translated by all threads (10^6 entries of the written candidates of a 10^7-fragment sample; a binary search per entry on one thread took 0.25 s)
+			const size_t words = fragments.empty() ? 1 : (size_t) fragments.back() / 64 + 1;
+			std::vector<uint64_t> bits(words, 0); std::vector<uint32_t> rank(words + 1, 0);
+			for (size_t row = 0; row < fragments.size(); ++row) bits[fragments[row] / 64] |= (uint64_t) 1 << (fragments[row] % 64);
+			for (size_t w = 0; w < words; ++w) rank[w + 1] = rank[w] + (uint32_t) __builtin_popcountll(bits[w]);
+			std::atomic<bool> missing(false);
+			const FusionTable* table_view = &t;
+			unsigned int n_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+			if (n_entries < (1u << 16)) n_threads = 1;
+			std::vector<std::thread> threads;
+			auto translate = [&](uint32_t first_candidate, uint32_t last_candidate) {
+				for (uint32_t c = first_candidate; c < last_candidate; ++c) {
+					const bool written = (write_discarded != 0) != (table_view->filter[c] == 0);
+					for (uint32_t k = table_view->list_offset[3 * (size_t) c]; k < table_view->list_offset[3 * (size_t) c + 3]; ++k) {
+						if (!written) { lists_as_rows[k] = 0; continue; }
+						const uint32_t fragment = table_view->read_lists[k];
+						if ((size_t) fragment / 64 >= words || !(bits[fragment / 64] >> (fragment % 64) & 1)) { missing = true; lists_as_rows[k] = 0; continue; }
+						lists_as_rows[k] = rank[fragment / 64] + (uint32_t) __builtin_popcountll(bits[fragment / 64] & (((uint64_t) 1 << (fragment % 64)) - 1));
+					}
 				}
+			};
+			for (unsigned int thread = 0; thread < n_threads; ++thread) {
+				const uint32_t first_candidate = (uint32_t) ((uint64_t) t.n_candidates * thread / n_threads), last_candidate = (uint32_t) ((uint64_t) t.n_candidates * (thread + 1) / n_threads);
+				if (n_threads == 1) translate(first_candidate, last_candidate); else threads.push_back(std::thread(translate, first_candidate, last_candidate));
 			}
+			for (size_t thread = 0; thread < threads.size(); ++thread) threads[thread].join();
+			if (missing) throw std::runtime_error("a supporting read of a written candidate is not among the rows handed over (ahost_fusion_table_reads / ahost_set_batch_rows)");
 			t.read_lists = lists_as_rows.data(); t.read_filter = filter_of_rows.data();
 		}
+		if (getenv("ARRIBA_WRITER_PROFILE")) fprintf(stderr, "[writer] lists translated to rows: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - profile_start).count());
 		const bool no_rows = session->device_batch && !print_extra_info;
 		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, no_rows ? NULL : &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
 		return 0;
@@ -270,16 +295,23 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 int ahost_fusion_table_reads(const ahost_fusion_table* table, int write_discarded, uint32_t* fragments, uint64_t capacity, uint64_t* count) {
 	if (!table || !count) { g_error = "null argument"; return -1; }
 	try {
-		std::vector<uint32_t> reads;
+		// ascending and without repeats: a bit per fragment instead of a sort of 10^6 list entries
+		uint32_t highest = 0; bool any = false;
 		for (uint32_t c = 0; c < table->n_candidates; ++c)
 			if ((write_discarded != 0) != (table->filter[c] == 0))
-				reads.insert(reads.end(), table->read_lists + table->list_offset[3 * (size_t) c], table->read_lists + table->list_offset[3 * (size_t) c + 3]);
-		std::sort(reads.begin(), reads.end());
-		reads.erase(std::unique(reads.begin(), reads.end()), reads.end());
-		*count = reads.size();
+				for (uint32_t k = table->list_offset[3 * (size_t) c]; k < table->list_offset[3 * (size_t) c + 3]; ++k) { highest = std::max(highest, table->read_lists[k]); any = true; }
+		std::vector<uint64_t> bits(any ? (size_t) highest / 64 + 1 : 0, 0);
+		for (uint32_t c = 0; c < table->n_candidates; ++c)
+			if ((write_discarded != 0) != (table->filter[c] == 0))
+				for (uint32_t k = table->list_offset[3 * (size_t) c]; k < table->list_offset[3 * (size_t) c + 3]; ++k) bits[table->read_lists[k] / 64] |= (uint64_t) 1 << (table->read_lists[k] % 64);
+		uint64_t total = 0;
+		for (size_t w = 0; w < bits.size(); ++w) total += (uint64_t) __builtin_popcountll(bits[w]);
+		*count = total;
 		if (fragments) {
-			if (capacity < reads.size()) { g_error = "capacity too small"; return -1; }
-			std::copy(reads.begin(), reads.end(), fragments);
+			if (capacity < total) { g_error = "capacity too small"; return -1; }
+			uint64_t at = 0;
+			for (size_t w = 0; w < bits.size(); ++w)
+				for (uint64_t word = bits[w]; word != 0; word &= word - 1) fragments[at++] = (uint32_t) (w * 64 + (size_t) __builtin_ctzll(word));
 		}
 		return 0;
 	} catch (const std::exception& e) { g_error = e.what(); return -1; }

@@ -5,6 +5,7 @@
 #include "arriba_host.h"
 #include "output.h"
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -242,6 +243,9 @@ std::string coverage_text(int coverage) { return coverage >= 0 ? std::to_string(
 
 void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Assembly& assembly, const Coverage& coverage, const Batch* batch, const FusionTable& table,
                            const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length, const OutputExtras& extras) {
+	const std::chrono::steady_clock::time_point profile_start = std::chrono::steady_clock::now();
+	const bool profile = getenv("ARRIBA_WRITER_PROFILE") != NULL;
+	auto profile_mark = [&](const char* what) { if (profile) fprintf(stderr, "[writer] %s: %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - profile_start).count()); };
 	Writer writer = { annotation, contigs, coverage, table, std::vector<GeneRecord>(), FlatIndex(), exon_index };
 	// the gene records of this sample: the GTF genes, then the dummy genes the device cut from the unmapped positions
 	if (table.n_genes < annotation.real_genes) throw std::runtime_error("gene table smaller than the annotation");
@@ -278,11 +282,13 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		rows.swap(sorted);
 	}
 
+	profile_mark("genes indexed, rows sorted");
 	FILE* out = fopen(path.c_str(), "w");
 	if (out == NULL) throw std::runtime_error("failed to open output file");
 	std::string text = "#gene1\tgene2\tstrand1(gene/fusion)\tstrand2(gene/fusion)\tbreakpoint1\tbreakpoint2\tsite1\tsite2\ttype\tsplit_reads1\tsplit_reads2\tdiscordant_mates\tcoverage1\tcoverage2\tconfidence\treading_frame\ttags\t"
 	                   "retained_protein_domains\tclosest_genomic_breakpoint1\tclosest_genomic_breakpoint2\tgene_id1\tgene_id2\ttranscript_id1\ttranscript_id2\tdirection1\tdirection2\tfilters\tfusion_transcript\tpeptide_sequence\tread_identifiers\n";
 	static const char* const confidence_names[] = { "low", "medium", "high", "high" };
+	std::atomic<long long> profile_ns[3]; profile_ns[0] = 0; profile_ns[1] = 0; profile_ns[2] = 0; // (ARRIBA_WRITER_PROFILE: transcript from the pileups, best-fitting transcripts, peptides)
 	auto format_row = [&](size_t r, std::string& text) {
 		const Fusion& f = rows[r];
 		std::string site_5 = writer.fusion_site(f.gene1, f.spliced1, f.exonic1, f.contig1, f.breakpoint1), site_3 = writer.fusion_site(f.gene2, f.spliced2, f.exonic2, f.contig2, f.breakpoint2);
@@ -306,11 +312,16 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			event.split_read1_list = table.read_lists + offsets[0]; event.split_read2_list = table.read_lists + offsets[1]; event.discordant_mate_list = table.read_lists + offsets[2];
 			event.n_split_reads1 = offsets[1] - offsets[0]; event.n_split_reads2 = offsets[2] - offsets[1]; event.n_discordant_mates = offsets[3] - offsets[2];
 			std::vector<position_t> positions;
+			const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
 			fusion_transcript_sequence(input, event, transcript_sequence, positions);
+			const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+			if (profile) profile_ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
 			std::vector<int> transcripts_5, transcripts_3;
 			best_fitting_transcripts(input, transcript_sequence, positions, gene_5, writer.genes[gene_5].is_dummy, writer.genes[gene_5].contig, writer.genes[gene_5].strand, strand_5, f.strands_ambiguous, 5, transcripts_5);
 			best_fitting_transcripts(input, transcript_sequence, positions, gene_3, writer.genes[gene_3].is_dummy, writer.genes[gene_3].contig, writer.genes[gene_3].strand, strand_3, f.strands_ambiguous, 3, transcripts_3);
 			const PeptideGenes peptide_genes = { writer.genes[gene_5].contig, writer.genes[gene_3].contig, writer.genes[gene_5].strand, writer.genes[gene_3].strand, writer.genes[gene_5].is_dummy, writer.genes[gene_3].is_dummy, strand_3 };
+			const std::chrono::steady_clock::time_point t2 = std::chrono::steady_clock::now();
+			if (profile) profile_ns[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
 			int transcript_5 = -1, transcript_3 = -1;
 			const std::string sequence_as_assembled = transcript_sequence; const std::vector<position_t> positions_as_assembled = positions;
 			const bool is_itd = f.gene1 == f.gene2 && (unsigned) f.breakpoint2 - (unsigned) f.breakpoint1 < max_itd_length && f.upstream1 && !f.upstream2; // source/common.hpp:270-274
@@ -329,6 +340,7 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 				}
 				if (i5 == transcripts_5.size() || transcripts_3.empty()) break;
 			}
+			if (profile) profile_ns[2] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t2).count();
 			if (reading_frame == "stop-codon") peptide_sequence = "."; // a stop codon in front of the junction: no peptide
 			if (transcript_5 != -1) transcript_id_5 = annotation.transcripts[transcript_5].name;
 			if (transcript_3 != -1) transcript_id_3 = annotation.transcripts[transcript_3].name;
@@ -395,9 +407,11 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		auto work = [&] {
 			for (size_t k = next.fetch_add(1); k < count; k = next.fetch_add(1)) {
 				transcript_warnings = &row_warnings[k];
+				const std::chrono::steady_clock::time_point row_start = std::chrono::steady_clock::now();
 				try { format_row(chunk_begin + k, row_text[k]); }
 				catch (...) { std::lock_guard<std::mutex> lock(failure_mutex); if (!failure) failure = std::current_exception(); }
 				transcript_warnings = NULL;
+				if (profile) { const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - row_start).count(); if (seconds > 0.02) fprintf(stderr, "[writer] row %zu took %.3f s (%u + %u + %u supporting reads)\n", chunk_begin + k, seconds, rows[chunk_begin + k].split_reads1, rows[chunk_begin + k].split_reads2, rows[chunk_begin + k].discordant_mates); }
 			}
 		};
 		if (n_threads == 1 || count < 4) work();
@@ -414,6 +428,8 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fclose(out); throw std::runtime_error("failed to write to file"); }
 		text.clear();
 	}
+	profile_mark("rows formatted and written");
+	if (profile) fprintf(stderr, "[writer] thread time: fusion transcripts %.3f s, best-fitting transcripts %.3f s, peptides %.3f s\n", profile_ns[0] * 1e-9, profile_ns[1] * 1e-9, profile_ns[2] * 1e-9);
 	const bool ok = fwrite(text.data(), 1, text.size(), out) == text.size();
 	if (fclose(out) != 0 || !ok) throw std::runtime_error("failed to write to file");
 }

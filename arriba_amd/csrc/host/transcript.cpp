@@ -24,8 +24,6 @@ namespace {
 
 enum { CIGAR_MATCH = 0, CIGAR_INSERTION = 1, CIGAR_DELETION = 2, CIGAR_SKIP = 3, CIGAR_SOFT_CLIP = 4, CIGAR_HARD_CLIP = 5, CIGAR_EQUAL = 7, CIGAR_DIFF = 8 };
 
-typedef std::map<position_t, std::map<std::string, unsigned> > Pileup; // position -> allele -> reads; alleles: a base, an insertion + the base behind it, "-", and ">" "_" "<" for introns
-
 char complement_of(char base) {
 	switch (base) {
 		case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c';
@@ -42,6 +40,89 @@ std::string reverse_complement(const std::string& dna) {
 bool is_intron_allele(const std::string& allele) { return allele == "_" || allele == ">" || allele == "<"; }
 bool is_lower_case_base(char c) { return c == 'a' || c == 't' || c == 'c' || c == 'g'; }
 
+// The pileup next to a breakpoint: position -> allele -> reads.  Alleles: a base, "-" (deleted), an insertion + the base behind it, and ">" "_" "<" for the
+// start / inside / end of an intron.  The reference keeps it in nested std::maps keyed by std::string (source/output_fusions.cpp:25-107) and pays two tree look-ups
+// per base of every supporting read and one tree node per position of every intron -- ~0.5 ms per fusion, seconds for the best-supported ones.  Here the
+// single-character alleles (all but the insertions) are counted in pages of 256 positions x 20 alleles (the last page is remembered: consecutive bases fall on
+// consecutive positions); what the consensus walks over is the same: the positions in ascending order, at each the alleles in the order of their strings.
+const char* const SINGLE_ALLELES = "-<=>ABCDGHKMNRSTVWY_"; // in ASCII order == the order of std::map<std::string, ...>
+const int N_SINGLE_ALLELES = 20;
+struct Allele { std::string text; unsigned count; };
+struct Column { position_t position; size_t first, n; }; // alleles[first .. first + n)
+class DensePileup {
+public:
+	DensePileup(): last_page_(0), last_(NULL) { for (int c = 0; c < 256; ++c) slot_of_char_[c] = -1; for (int k = 0; k < N_SINGLE_ALLELES; ++k) slot_of_char_[(unsigned char) SINGLE_ALLELES[k]] = k; }
+	int slot_of(char allele) const { return slot_of_char_[(unsigned char) allele]; }
+	void add(position_t position, int slot, unsigned count = 1) {
+		const position_t page = position >> 8;
+		if (last_ == NULL || page != last_page_) { std::vector<unsigned>& counts = pages_[page]; if (counts.empty()) counts.assign(256 * N_SINGLE_ALLELES, 0); last_ = counts.data(); last_page_ = page; }
+		last_[(size_t) (position & 255) * N_SINGLE_ALLELES + slot] += count;
+	}
+	void add(position_t position, const std::string& allele) { // any allele (insertions; what std::string::substr gives at the end of a sequence)
+		if (allele.size() == 1 && slot_of(allele[0]) >= 0) add(position, slot_of(allele[0])); else other_[position][allele]++;
+	}
+	void add_inside_intron(position_t from, position_t to, unsigned count) { if (from <= to && count > 0) { Interval interval = { from, to, count }; inside_introns_.push_back(interval); } } // "_" at every position of [from, to]
+	// The columns in ascending order of their positions, the alleles of a column in the order of their strings.  The insides of introns are kept as intervals: a
+	// stretch of positions that hold nothing but the same number of "_" is a stretch of identical columns, of which the consensus only ever singles out the first or
+	// the last one (the trimming by coverage) and acts on the first one (the intron opens) -- so only these two are made, however long the intron is.
+	void columns(std::vector<Column>& columns, std::vector<Allele>& alleles) const {
+		columns.clear(); alleles.clear();
+		// the positions that hold counted alleles, ascending
+		std::vector<std::pair<position_t, const unsigned*> > counted;
+		for (std::map<position_t, std::vector<unsigned> >::const_iterator page = pages_.begin(); page != pages_.end(); ++page)
+			for (int at = 0; at < 256; ++at) {
+				const unsigned* counts = &page->second[(size_t) at * N_SINGLE_ALLELES];
+				bool any = false;
+				for (int slot = 0; slot < N_SINGLE_ALLELES; ++slot) any = any || counts[slot] > 0;
+				if (any) counted.push_back(std::make_pair(page->first * 256 + at, counts));
+			}
+		std::vector<std::pair<position_t, long long> > events; // the number of reads inside an intron changes by .second at position .first
+		for (size_t k = 0; k < inside_introns_.size(); ++k) { events.push_back(std::make_pair(inside_introns_[k].from, (long long) inside_introns_[k].count)); events.push_back(std::make_pair(inside_introns_[k].to + 1, -(long long) inside_introns_[k].count)); }
+		std::sort(events.begin(), events.end());
+		std::map<position_t, std::map<std::string, unsigned> >::const_iterator other = other_.begin();
+		size_t c = 0, e = 0;
+		long long inside = 0;          // reads inside an intron at the positions from `unemitted` on
+		position_t unemitted = 0; bool have_unemitted = false;
+		auto emit_inside_only = [&](position_t from, position_t to) {
+			if (inside <= 0 || from > to) return;
+			for (int k = 0; k < (to > from ? 2 : 1); ++k) { Column column = { k == 0 ? from : to, alleles.size(), 1 }; Allele allele = { "_", (unsigned) inside }; alleles.push_back(allele); columns.push_back(column); }
+		};
+		while (c < counted.size() || e < events.size() || other != other_.end()) {
+			position_t at = 0; bool have = false;
+			if (c < counted.size()) { at = counted[c].first; have = true; }
+			if (e < events.size() && (!have || events[e].first < at)) { at = events[e].first; have = true; }
+			if (other != other_.end() && (!have || other->first < at)) { at = other->first; have = true; }
+			if (have_unemitted) emit_inside_only(unemitted, at - 1);
+			unemitted = at; have_unemitted = true;
+			while (e < events.size() && events[e].first == at) inside += events[e++].second;
+			const bool counted_here = c < counted.size() && counted[c].first == at, other_here = other != other_.end() && other->first == at;
+			if (!counted_here && !other_here) continue; // (only the number of reads inside introns changed here: the stretch from `at` on is made when its end is known)
+			Column column = { at, alleles.size(), 0 };
+			if (counted_here) { for (int slot = 0; slot < N_SINGLE_ALLELES; ++slot) if (counted[c].second[slot] > 0) { Allele allele = { std::string(1, SINGLE_ALLELES[slot]), counted[c].second[slot] }; alleles.push_back(allele); } ++c; }
+			if (inside > 0) { // ("_" may have been counted here as an ordinary allele, too: one allele, the sum)
+				bool merged = false;
+				for (size_t a = column.first; a < alleles.size() && !merged; ++a) if (alleles[a].text == "_") { alleles[a].count += (unsigned) inside; merged = true; }
+				if (!merged) { Allele allele = { "_", (unsigned) inside }; alleles.push_back(allele); }
+			}
+			if (other_here) {
+				for (std::map<std::string, unsigned>::const_iterator a = other->second.begin(); a != other->second.end(); ++a) { Allele allele = { a->first, a->second }; alleles.push_back(allele); }
+				++other;
+			}
+			std::sort(alleles.begin() + column.first, alleles.end(), [](const Allele& x, const Allele& y) { return x.text < y.text; });
+			column.n = alleles.size() - column.first;
+			columns.push_back(column);
+			unemitted = at + 1;
+		}
+	}
+private:
+	std::map<position_t, std::vector<unsigned> > pages_;
+	std::map<position_t, std::map<std::string, unsigned> > other_;
+	struct Interval { position_t from, to; unsigned count; };
+	std::vector<Interval> inside_introns_;
+	position_t last_page_; unsigned* last_;
+	int slot_of_char_[256];
+};
+
 struct Reads { // the fragments of the sample and their final filters
 	const Batch& batch; const uint8_t* filter;
 	bool strand(unsigned slot, uint32_t read) const { return batch.abits[slot][read] & ABIT_STRAND; }
@@ -53,8 +134,9 @@ struct Reads { // the fragments of the sample and their final filters
 };
 
 // reference: pileup_chimeric_alignments (:25-107): the alignments in slot `mate` of the fragments list[0 .. n)
-void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigned mate, bool reverse, bool upstream, position_t breakpoint, Pileup& pileup) {
+void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigned mate, bool reverse, bool upstream, position_t breakpoint, DensePileup& pileup) {
 	const Batch& b = reads.batch;
+	const int deletion_slot = pileup.slot_of('-');
 	std::map<std::pair<position_t, position_t>, unsigned> introns;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t read = list[k];
@@ -75,7 +157,7 @@ void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigne
 			bool consume_bases = false;
 			switch (operation) {
 				case CIGAR_INSERTION:
-					pileup[reference_offset][sequence.substr(read_offset, length + 1)]++;
+					pileup.add(reference_offset, sequence.substr(read_offset, length + 1));
 					read_offset += length + 1; ++reference_offset; borrowed = 1;
 					break;
 				case CIGAR_SKIP: {
@@ -86,7 +168,7 @@ void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigne
 					break;
 				}
 				case CIGAR_DELETION:
-					for (int base = 0; base < length - borrowed; ++base, ++reference_offset) pileup[reference_offset]["-"]++;
+					for (int base = 0; base < length - borrowed; ++base, ++reference_offset) pileup.add(reference_offset, deletion_slot);
 					borrowed = 0;
 					break;
 				case CIGAR_HARD_CLIP:
@@ -105,53 +187,61 @@ void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigne
 					break;
 			}
 			if (consume_bases) {
-				for (int base = 0; base < length - borrowed; ++base, ++read_offset, ++reference_offset) pileup[reference_offset][sequence.substr(read_offset, 1)]++;
+				for (int base = 0; base < length - borrowed; ++base, ++read_offset, ++reference_offset) {
+					// (std::string::substr semantics of the reference: a position at the end of the sequence gives the empty allele, beyond it is an error)
+					if ((size_t) read_offset < sequence.size() && pileup.slot_of(sequence[read_offset]) >= 0) pileup.add(reference_offset, pileup.slot_of(sequence[read_offset]));
+					else pileup.add(reference_offset, sequence.substr(read_offset, 1));
+				}
 				borrowed = 0;
 			}
 		}
 	}
 	for (std::map<std::pair<position_t, position_t>, unsigned>::const_iterator intron = introns.begin(); intron != introns.end(); ++intron) {
-		pileup[intron->first.first][">"] += intron->second;
-		pileup[intron->first.second]["<"] += intron->second;
-		for (position_t inside = intron->first.first + 1; inside < intron->first.second; ++inside) pileup[inside]["_"] += intron->second;
+		pileup.add(intron->first.first, pileup.slot_of('>'), intron->second);
+		pileup.add(intron->first.second, pileup.slot_of('<'), intron->second);
+		pileup.add_inside_intron(intron->first.first + 1, intron->first.second - 1, intron->second);
 	}
 }
 
-unsigned reads_at(const std::map<std::string, unsigned>& alleles) {
+unsigned reads_at(const std::vector<Allele>& alleles, const Column& column) {
 	unsigned total = 0;
-	for (std::map<std::string, unsigned>::const_iterator allele = alleles.begin(); allele != alleles.end(); ++allele) total += allele->second;
+	for (size_t a = column.first; a < column.first + column.n; ++a) total += alleles[a].count;
 	return total;
 }
 
 // reference: get_sequence_from_pileup (:109-240): the consensus next to one breakpoint; `clipped` receives what lies beyond the breakpoint
-void consensus_of_pileup(const Pileup& pileup, position_t breakpoint, bool upstream, contig_t contig, const Assembly& assembly, std::string& sequence, std::vector<position_t>& positions, std::string& clipped) {
+void consensus_of_pileup(const DensePileup& pileup, position_t breakpoint, bool upstream, contig_t contig, const Assembly& assembly, std::string& sequence, std::vector<position_t>& positions, std::string& clipped) {
+	std::vector<Column> columns; std::vector<Allele> alleles;
+	pileup.columns(columns, alleles);
 	unsigned peak = 0;
-	for (Pileup::const_iterator at = pileup.begin(); at != pileup.end(); ++at) peak = std::max(peak, reads_at(at->second));
+	for (size_t at = 0; at < columns.size(); ++at) peak = std::max(peak, reads_at(alleles, columns[at]));
 	// thin coverage far from the breakpoint probably belongs to other isoforms
 	const float low_coverage_fraction = 0.10;
-	Pileup::const_iterator first = pileup.begin(), last = pileup.end();
-	for (Pileup::const_iterator at = pileup.begin(); at != pileup.end(); ++at) {
-		const unsigned coverage = reads_at(at->second);
+	size_t first = 0, last = columns.size();
+	for (size_t at = 0; at < columns.size(); ++at) {
+		const unsigned coverage = reads_at(alleles, columns[at]);
 		if (!upstream) { if (coverage < peak * low_coverage_fraction) first = at; else break; }
 		else if (coverage > peak * low_coverage_fraction) last = at;
 	}
-	if (last != pileup.end()) ++last;
+	if (last != columns.size()) ++last;
 	bool intron_open = false, intron_closed = true;
-	for (Pileup::const_iterator at = first; at != last; ++at) {
-		if (at != first && std::prev(at)->first < at->first - 1 && !intron_open) { sequence += "..."; positions.resize(positions.size() + 3, -1); } // not covered
+	for (size_t at = first; at < last; ++at) {
+		const Column& column = columns[at];
+		if (at != first && columns[at - 1].position < column.position - 1 && !intron_open) { sequence += "..."; positions.resize(positions.size() + 3, -1); } // not covered
 		std::string reference_base = "N";
-		if (assembly.has(contig) && (unsigned) at->first < assembly.sequence[contig].size()) reference_base = std::string(1, assembly.sequence[contig][at->first]);
+		if (assembly.has(contig) && (unsigned) column.position < assembly.sequence[contig].size()) reference_base = std::string(1, assembly.sequence[contig][column.position]);
 		// the most frequent allele; ties go to the reference base, and to introns before anything else
-		std::map<std::string, unsigned>::const_iterator best = at->second.end();
+		const Allele* best = NULL;
 		unsigned coverage = 0;
-		for (std::map<std::string, unsigned>::const_iterator allele = at->second.begin(); allele != at->second.end(); ++allele) {
-			if (best == at->second.end() || allele->second > best->second ||
-			    (allele->second == best->second && ((allele->first == reference_base && !is_intron_allele(best->first)) || (allele->first == "<" && best->first != "_" && best->first != ">") || allele->first == "_" || allele->first == ">")))
+		for (size_t a = column.first; a < column.first + column.n; ++a) {
+			const Allele* allele = &alleles[a];
+			if (best == NULL || allele->count > best->count ||
+			    (allele->count == best->count && ((allele->text == reference_base && !is_intron_allele(best->text)) || (allele->text == "<" && best->text != "_" && best->text != ">") || allele->text == "_" || allele->text == ">")))
 				best = allele;
-			if (!is_intron_allele(allele->first)) coverage += allele->second;
+			if (!is_intron_allele(allele->text)) coverage += allele->count;
 		}
 		// trusted: >= 75 % of the reads, an intron at least as frequent as the coverage, or the reference base
-		std::string allele = ((is_intron_allele(best->first) && best->second >= coverage) || best->second >= 0.75 * coverage || best->first == reference_base) ? best->first : "?";
+		std::string allele = ((is_intron_allele(best->text) && best->count >= coverage) || best->count >= 0.75 * coverage || best->text == reference_base) ? best->text : "?";
 		if (allele == "_") {
 			if (!intron_open) { sequence += "...___"; positions.resize(positions.size() + 6, -1); intron_open = true; intron_closed = false; } // inside an intron whose start was not seen
 		} else if (allele == ">") {
@@ -169,8 +259,8 @@ void consensus_of_pileup(const Pileup& pileup, position_t breakpoint, bool upstr
 				positions.resize(positions.size() + allele.size() - 1, -1);
 				if (toupper(allele[allele.size() - 1]) == reference_base[0]) allele[allele.size() - 1] = (char) toupper(allele[allele.size() - 1]);
 			}
-			if ((upstream && at->first < breakpoint) || (!upstream && at->first > breakpoint)) clipped += allele;
-			else { sequence += allele; positions.push_back(at->first); }
+			if ((upstream && column.position < breakpoint) || (!upstream && column.position > breakpoint)) clipped += allele;
+			else { sequence += allele; positions.push_back(column.position); }
 		}
 	}
 }
@@ -207,7 +297,7 @@ void fusion_transcript_sequence(const TranscriptInput& in, const FusionEvent& f,
 	if (f.strands_ambiguous || f.transcript_start_ambiguous) { sequence = "."; positions.push_back(-1); return; } // the strands are unknown
 	const Reads reads = { in.batch, in.read_filter };
 	const uint32_t* list1 = f.split_read1_list; const uint32_t* list2 = f.split_read2_list; const uint32_t* mates = f.discordant_mate_list;
-	Pileup pileup1, pileup2;
+	DensePileup pileup1, pileup2;
 	add_to_pileup(reads, list1, f.n_split_reads1, SPLIT_READ, false, f.upstream1, f.breakpoint1, pileup1);
 	add_to_pileup(reads, list1, f.n_split_reads1, MATE1, false, f.upstream1, f.breakpoint1, pileup1);
 	add_to_pileup(reads, list1, f.n_split_reads1, SUPPLEMENTARY, f.upstream1 == f.upstream2, f.upstream2, f.breakpoint2, pileup2);

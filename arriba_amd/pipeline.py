@@ -563,18 +563,25 @@ class DevicePipeline(object):
         """reference: write_fusions_to_file, source/output_fusions.cpp:1043-1261 (-o / -O); the device's results are fetched and formatted by the host library"""
         if print_extra_info is None:
             print_extra_info = not discarded
+        import time
+        marks = [("start", time.perf_counter())]
+        mark = lambda name: marks.append((name, time.perf_counter()))
         # only the candidates the file will hold travel to the host with their read lists (fusions.tsv: the few thousand that passed every filter, of millions);
         # discarded.tsv counts the discarded reads of every discarded candidate by filter, so it takes the lists of all of them
         table = self.candidates(lists=False)
+        mark("candidate columns")
         written = np.flatnonzero((table["filter"] != 0) if discarded else (table["filter"] == 0)).astype(np.uint32)
         list_offset, read_lists = self.candidate_read_lists_of(written)
+        mark("read lists")
         n = written.size
         columns = {key: np.ascontiguousarray(table[key][written]) for key in ("gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates")}
         columns["list_offset"], columns["read_lists"] = list_offset, np.ascontiguousarray(read_lists)
         columns["evalue"] = np.ascontiguousarray(self.evalues()[written], dtype=np.float32)
         columns["confidence"] = np.ascontiguousarray(self.assign_confidence()[written])
         columns["iteration_rank"] = np.ascontiguousarray(self.candidate_iteration_order()[written], dtype=np.uint32)
+        mark("evalue, confidence, order")
         columns["read_filter"] = np.ascontiguousarray(self.filters(), dtype=np.uint8)
+        mark("read filters")
         columns["closest_genomic_breakpoint1"], columns["closest_genomic_breakpoint2"] = (np.ascontiguousarray(column[written]) for column in self.genomic_support())
         genes = self.gene_table()
         columns["gene_contig"], columns["gene_start"], columns["gene_end"] = (np.ascontiguousarray(genes[key]) for key in ("contig", "start", "end"))
@@ -593,11 +600,16 @@ class DevicePipeline(object):
             if lib.ahost_fusion_table_reads(byref(view), int(discarded), fragments.ctypes.data, count.value, byref(count)) != 0:
                 raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
             fragments = fragments[:count.value]
+            mark("reads of the table")
             arrays, rows = self.batch_rows(fragments)
+            mark("rows from the device")
             if lib.ahost_set_batch_rows(self.session._session, byref(rows), fragments.ctypes.data if fragments.size else None) != 0:
                 raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
+            mark("rows into the session")
         if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps)) != 0:
             raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
+        mark("ahost_write_fusions")
+        self.writer_seconds = {name: round(at - marks[k][1], 4) for k, (name, at) in enumerate(marks[1:])}  # where the time of the output side went (bench.py reports it)
 
     def mark_genomic_support(self, path, max_distance=100000):
         """reference: mark_genomic_support, source/filter_genomic_support.cpp:81-219 (-d, -D); returns the number of candidates with a supporting structural variant"""

@@ -300,8 +300,8 @@ def main():
                 # the large sample with this many steps would take too long for a bench run: say so and let the parent print the line of config 2
                 progress("a step of the %d-fragment sample takes %.1f s: %d more steps do not fit the time budget" % (args.fragments, finished - started, remaining))
                 raise SystemExit(3)  # (through the `finally` below: the 54 GB sample must not stay behind)
-            progress("step done: read_chimeric_alignments %.2f s %s, workflow %.2f s; slowest stages: %s" % (ingested - started, ingest_parts[-1], finished - ingested,
-                     sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4]))
+            progress("step done: read_chimeric_alignments %.2f s %s, workflow %.2f s; slowest stages: %s; output side: %s" % (ingested - started, ingest_parts[-1], finished - ingested,
+                     sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4], getattr(pipeline, "writer_seconds", None)))
 
         profiling = [False]
         verbose = args.fragments >= 30000000 or bool(os.environ.get("ARRIBA_BENCH_VERBOSE"))  # large samples: every stage reports on stderr, so that a run cut off by a time limit says where it was
@@ -399,6 +399,7 @@ def main():
                            "why_not_the_100M_sample": fallback_reason},
                 "seconds_per_step": {"read_chimeric_alignments": round(mean("ingest"), 4), "workflow_to_output_files": round(mean("workflow"), 4), "total": round(mean("total"), 4)},
                 "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
+                "output_side_seconds": getattr(pipeline, "writer_seconds", None),
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
                 "stages": stage_log,
                 "stage_kernel_ms": {stage: round(values["ms"], 3) for stage, values in pipeline.timings.items()},
