@@ -277,6 +277,51 @@ __global__ void shard_add_counts_kernel(unsigned long long* counts, const unsign
 	if (i < n) counts[i] += part[i];
 }
 
+// agpu_shard_merge when the names of the parts interleave: the order of std::string over the packed names ("QNAME,HI") of the merged batch
+__global__ void packed_name_length_kernel(const uint32_t* name_offset, uint64_t n, uint32_t* longest) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i < n) atomicMax(longest, name_offset[i + 1] - name_offset[i]);
+}
+__global__ void packed_name_chunk_kernel(const char* names, const uint32_t* name_offset, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t row = order[i], begin = name_offset[row], length = name_offset[row + 1] - begin;
+	uint64_t key = 0; // eight bytes from 8 * chunk on, big endian, zero padded: unsigned comparison of the chunks in order == std::string::compare
+	for (uint32_t k = 0; k < 8; ++k) { const uint32_t at = 8 * chunk + k; key = key << 8 | (at < length ? (uint8_t) names[begin + at] : 0u); }
+	keys[i] = key;
+}
+// rows i - 1 and i of the order: [0] counts equal names (a read name in two parts), new_group[i] says whether the QNAME (the name without ",HI...") changes
+__global__ void packed_name_neighbours_kernel(const char* names, const uint32_t* name_offset, const uint32_t* order, uint64_t n, uint32_t* new_group, uint32_t* equal_names) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= n) return;
+	if (i == 0) { new_group[0] = 0; return; }
+	const uint32_t a = order[i - 1], b = order[i], begin_a = name_offset[a], begin_b = name_offset[b], length_a = name_offset[a + 1] - begin_a, length_b = name_offset[b + 1] - begin_b;
+	bool same = length_a == length_b;
+	for (uint32_t k = 0; same && k < length_a; ++k) same = names[begin_a + k] == names[begin_b + k];
+	if (same) atomicAdd(equal_names, 1u);
+	uint32_t qname_a = length_a, qname_b = length_b; // up to the last comma
+	while (qname_a > 0 && names[begin_a + qname_a - 1] != ',') --qname_a;
+	while (qname_b > 0 && names[begin_b + qname_b - 1] != ',') --qname_b;
+	bool same_qname = qname_a == qname_b;
+	for (uint32_t k = 0; same_qname && k < qname_a; ++k) same_qname = names[begin_a + k] == names[begin_b + k];
+	new_group[i] = same_qname ? 0u : 1u;
+}
+// a part of a sample: where a new read name starts in the stream of the part, and the 128-bit keys of these names (ingest_core.hpp: qname_key128)
+__global__ void qname_run_flag_kernel(IngestStream in, uint64_t n_records, uint8_t* flags) {
+	const uint64_t r = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (r < n_records) flags[r] = starts_qname_run(in, (uint32_t) r) ? 1 : 0;
+}
+__global__ void qname_key_kernel(IngestStream in, const uint32_t* run_starts, uint64_t n_runs, uint64_t* keys) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k < n_runs) qname_key128(load_record(in, run_starts[k]), keys[2 * k], keys[2 * k + 1]);
+}
+__global__ void qname_low_kernel(const uint64_t* keys, uint64_t n, uint64_t* low) { const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; if (k < n) low[k] = keys[2 * k]; }
+__global__ void qname_equal_kernel(const uint64_t* low_sorted, const uint32_t* index_sorted, const uint64_t* keys, uint64_t n, uint32_t* equal) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k > 0 && k < n && low_sorted[k] == low_sorted[k - 1] && keys[2 * (uint64_t) index_sorted[k] + 1] == keys[2 * (uint64_t) index_sorted[k - 1] + 1]) atomicAdd(equal, 1u);
+}
+__global__ void iota_kernel(uint32_t* out, uint64_t n) { const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; if (i < n) out[i] = (uint32_t) i; }
+
 __global__ void coverage_clamp_kernel(const uint32_t* windows, uint64_t n, uint16_t* out) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i < n) out[i] = windows[i] > 65535u ? (uint16_t) 65535 : (uint16_t) windows[i];
@@ -386,6 +431,8 @@ void* agpu_host_alloc(size_t bytes) {
 	return pointer;
 }
 void agpu_host_free(void* pointer) { if (pointer) (void) hipHostFree(pointer); }
+
+static int gather_rows_prepare(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint64_t* pool_sizes);
 
 int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	if (!ctx || !config) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
@@ -504,6 +551,21 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	}
 	IngestStream in;
 	in.bytes = bytes; in.size = size; in.record_offset = record_offset.as<uint64_t>(); in.n_records = n_records; in.n_targets = ctx->ingest_n_targets; in.tid_to_contig = ctx->ingest_tid_to_contig.as<uint32_t>();
+
+	ctx->ingest_qname_runs = 0;
+	if (ctx->ingest_part_of_sample && n_records > 0) { // the read names of this part, for the check that no name has records in another part (agpu_shard_merge)
+		DeviceBuffer& run_flags = ctx->scratch("ingest.run_flags"); DeviceBuffer& run_starts = ctx->scratch("ingest.run_starts");
+		ALLOC(run_flags, n_records); ALLOC(run_starts, n_records * 4);
+		HIP_CHECK(hipMemsetAsync(device_counters, 0, IC_COUNT * 4, s));
+		qname_run_flag_kernel<<<grid_for(n_records), BLOCK, 0, s>>>(in, n_records, run_flags.as<uint8_t>());
+		TRY(select_flagged(ctx, rocprim_scratch, run_flags.as<uint8_t>(), run_starts.as<uint32_t>(), device_counters + IC_MAX_NAME, n_records));
+		TRY(read_counters());
+		const uint64_t n_runs = host_counters[IC_MAX_NAME];
+		ALLOC(ctx->ingest_qname_keys, std::max<uint64_t>(n_runs, 1) * 16);
+		if (n_runs > 0) qname_key_kernel<<<grid_for(n_runs), BLOCK, 0, s>>>(in, run_starts.as<uint32_t>(), n_runs, ctx->ingest_qname_keys.as<uint64_t>());
+		ctx->ingest_qname_runs = n_runs;
+		run_flags.release(); run_starts.release();
+	}
 
 	// 2. per record: status and name key; 3. records of one name adjacent
 	DeviceBuffer& keys = ctx->scratch("ingest.keys"); DeviceBuffer& keys_sorted = ctx->scratch("ingest.keys_sorted"); DeviceBuffer& record_bits = ctx->scratch("ingest.record_bits");
@@ -668,6 +730,7 @@ static int shard_header_of(agpu_ctx* ctx, ShardHeader& h) {
 	const agpu_ingest_result& r = ctx->ingest_result;
 	h.records = r.records; h.mapped_reads = r.mapped_reads; h.malformed_count = r.malformed_count; h.missing_hi_tag = r.missing_hi_tag; h.no_chimeric_reads = r.no_chimeric_reads;
 	h.names_were_sorted = r.names_were_sorted; h.stream_bytes = r.stream_bytes; h.max_read_length = ctx->max_read_length;
+	h.qname_runs = ctx->ingest_qname_runs;
 	h.total_bytes = shard_layout(h).total;
 	return AGPU_OK;
 }
@@ -684,7 +747,7 @@ static void shard_columns(agpu_ctx* ctx, void* columns[SHARD_SECTIONS]) {
 	columns[SHARD_SEQ_OFFSET0] = ctx->seq_offset[0].ptr; columns[SHARD_SEQ_LENGTH0] = ctx->seq_length[0].ptr; columns[SHARD_SEQ_OFFSET1] = ctx->seq_offset[1].ptr; columns[SHARD_SEQ_LENGTH1] = ctx->seq_length[1].ptr;
 	columns[SHARD_CIGAR_POOL] = ctx->cigar_pool.ptr; columns[SHARD_SEQ_POOL] = ctx->seq_pool.ptr; columns[SHARD_NAME_OFFSET] = ctx->name_offset.ptr; columns[SHARD_NAMES] = ctx->names.ptr;
 	columns[SHARD_WINDOWS32] = ctx->coverage_windows32.ptr; columns[SHARD_FRAGMENT_STARTS] = ctx->coverage_fragment_starts.ptr; columns[SHARD_FRAGMENT_ENDS] = ctx->coverage_fragment_ends.ptr;
-	columns[SHARD_VIRAL_COUNTS] = ctx->ingest_viral_counts.ptr;
+	columns[SHARD_VIRAL_COUNTS] = ctx->ingest_viral_counts.ptr; columns[SHARD_QNAME_KEYS] = ctx->ingest_qname_keys.ptr;
 }
 
 int agpu_shard_export_size(agpu_ctx* ctx, uint64_t* bytes) {
@@ -736,7 +799,8 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 	if (problem) { set_last_error(problem); return AGPU_ERR_INVALID; }
 	for (uint32_t r = 0; r < n_parts; ++r) if (parts[r].total_bytes > stride) { set_last_error("a part of the sample is larger than the stride of the blocks"); return AGPU_ERR_INVALID; }
 	if (total.windows != ctx->host_coverage_window_offset.back() || total.n_contigs != ctx->genome.n_contigs) { set_last_error("the parts of the sample were read against another assembly than this context holds"); return AGPU_ERR_INVALID; }
-	// the parts must follow each other in the order of the names (the order of the reference's std::map): every part is sorted, so its ends decide
+	// do the parts follow each other in the order of the names (the order of the reference's std::map)?  Every part is sorted, so its ends decide
+	bool parts_in_name_order = true;
 	{
 		std::string previous; bool have_previous = false;
 		for (uint32_t r = 0; r < n_parts; ++r) {
@@ -750,12 +814,30 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 			std::string first_name(offsets[1] - offsets[0], '\0'), last_name(last[1] - last[0], '\0');
 			if (!first_name.empty()) HIP_CHECK(hipMemcpy(&first_name[0], block + layout.offset[SHARD_NAMES] + offsets[0], first_name.size(), hipMemcpyDefault));
 			if (!last_name.empty()) HIP_CHECK(hipMemcpy(&last_name[0], block + layout.offset[SHARD_NAMES] + last[0], last_name.size(), hipMemcpyDefault));
-			if (have_previous && !(previous < first_name)) {
-				set_last_error("the read names of the parts of the sample interleave: part " + std::to_string(r) + " starts with " + first_name + ", the part before it ends with " + previous + " (the parts must be ranges of the name order)");
-				return AGPU_ERR_INVALID;
-			}
+			if (have_previous && !(previous < first_name)) parts_in_name_order = false; // (STAR writes the reads in the order of the FASTQ file: the merged batch is sorted below)
 			previous = last_name; have_previous = true;
 		}
+	}
+	if (total.qname_runs > 1) { // no read name in two parts (nor twice in one): the keys of all runs of names, sorted, neighbours compared
+		const uint64_t runs = total.qname_runs;
+		DeviceBuffer& all_keys = ctx->scratch("shard.qname_keys"); DeviceBuffer& low = ctx->scratch("shard.qname_low"); DeviceBuffer& low_sorted = ctx->scratch("shard.qname_low_sorted");
+		DeviceBuffer& index_sorted = ctx->scratch("shard.qname_index"); DeviceBuffer& rocprim_scratch = ctx->scratch("shard.rocprim"); DeviceBuffer& small = ctx->scratch("shard.small");
+		ALLOC(all_keys, runs * 16); ALLOC(low, runs * 8); ALLOC(low_sorted, runs * 8); ALLOC(index_sorted, runs * 4); ALLOC(small, 8);
+		HIP_CHECK(hipMemsetAsync(small.ptr, 0, 8, s));
+		uint64_t at = 0;
+		for (uint32_t r = 0; r < n_parts; ++r) {
+			if (parts[r].qname_runs == 0) continue;
+			HIP_CHECK(hipMemcpyAsync(all_keys.as<uint64_t>() + 2 * at, (const uint8_t*) blocks + (size_t) r * stride + shard_layout(parts[r]).offset[SHARD_QNAME_KEYS], parts[r].qname_runs * 16, hipMemcpyDefault, s));
+			at += parts[r].qname_runs;
+		}
+		qname_low_kernel<<<grid_for(runs), BLOCK, 0, s>>>(all_keys.as<uint64_t>(), runs, low.as<uint64_t>());
+		TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, low.as<uint64_t>(), low_sorted.as<uint64_t>(), nullptr, index_sorted.as<uint32_t>(), runs, 64, "rocprim::radix_sort_pairs(read names of the parts)", true));
+		qname_equal_kernel<<<grid_for(runs), BLOCK, 0, s>>>(low_sorted.as<uint64_t>(), index_sorted.as<uint32_t>(), all_keys.as<uint64_t>(), runs, small.as<uint32_t>());
+		uint32_t equal = 0;
+		HIP_CHECK(hipMemcpyAsync(&equal, small.ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		all_keys.release(); low.release(); low_sorted.release(); index_sorted.release();
+		if (equal > 0) { set_last_error("a read name occurs in more than one place of the sample (" + std::to_string(equal) + " times): the alignments of a read must follow each other in the file for it to be read in parts (STAR's output order; samtools collate otherwise)"); return AGPU_ERR_INVALID; }
 	}
 	const uint64_t n = total.n, windows = total.windows;
 	ctx->have_batch = false; ctx->batch_from_ingest = false;
@@ -813,6 +895,56 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 	TRY(agpu::finish_batch_setup(ctx));
 	ctx->batch_from_ingest = true; ctx->ingest_part_of_sample = false;
 	ctx->coverage_windows32.release(); ctx->scratch("shard.blocks").release();
+	if (!parts_in_name_order && n > 1) {
+		// The fragments of the whole sample in name order: least-significant-chunk-first radix sort over the 8-byte chunks of the packed names (as the ingest does
+		// it for the records of one part), the rows moved by the kernels of agpu_gather_rows_*, the read-name groups numbered again.
+		DeviceBuffer& order = ctx->scratch("shard.order"); DeviceBuffer& order_out = ctx->scratch("shard.order_out"); DeviceBuffer& keys = ctx->scratch("shard.keys"); DeviceBuffer& keys_out = ctx->scratch("shard.keys_out");
+		DeviceBuffer& small = ctx->scratch("shard.small"); DeviceBuffer& rocprim_scratch = ctx->scratch("shard.rocprim"); DeviceBuffer& new_group = ctx->scratch("shard.new_group");
+		ALLOC(order, n * 4); ALLOC(order_out, n * 4); ALLOC(keys, n * 8); ALLOC(keys_out, n * 8); ALLOC(small, 8); ALLOC(new_group, n * 4);
+		HIP_CHECK(hipMemsetAsync(small.ptr, 0, 8, s));
+		iota_kernel<<<grid_for(n), BLOCK, 0, s>>>(order.as<uint32_t>(), n);
+		packed_name_length_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->name_offset.as<uint32_t>(), n, small.as<uint32_t>());
+		uint32_t longest = 0;
+		HIP_CHECK(hipMemcpyAsync(&longest, small.ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		for (uint32_t chunk = (longest + 7) / 8; chunk-- > 0; ) {
+			packed_name_chunk_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->names.as<char>(), ctx->name_offset.as<uint32_t>(), order.as<uint32_t>(), n, chunk, keys.as<uint64_t>());
+			TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, keys.as<uint64_t>(), keys_out.as<uint64_t>(), order.as<uint32_t>(), order_out.as<uint32_t>(), n, 64, "rocprim::radix_sort_pairs(name chunk of the merged batch)", false));
+			order.swap(order_out);
+		}
+		packed_name_neighbours_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->names.as<char>(), ctx->name_offset.as<uint32_t>(), order.as<uint32_t>(), n, new_group.as<uint32_t>(), small.as<uint32_t>() + 1);
+		uint32_t equal_names = 0;
+		HIP_CHECK(hipMemcpyAsync(&equal_names, small.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (equal_names > 0) { ctx->have_batch = false; set_last_error("a read name occurs in more than one part of the sample: the alignments of a read must follow each other in the file (STAR's output order; samtools collate otherwise)"); return AGPU_ERR_INVALID; }
+		uint64_t pool_sizes[3];
+		TRY(gather_rows_prepare(ctx, order.as<uint32_t>(), n, pool_sizes));
+		agpu_batch_rows nowhere; memset(&nowhere, 0, sizeof(nowhere)); // (the rows stay on the device: in the scratch buffers "gather.*")
+		TRY(agpu_gather_rows_copy(ctx, &nowhere));
+		{ // the gathered columns become the batch
+			size_t bytes = 0;
+			HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, new_group.as<uint32_t>(), ctx->scratch("gather.group").as<uint32_t>(), n, rocprim::plus<uint32_t>(), s));
+			if (bytes > rocprim_scratch.capacity) ALLOC(rocprim_scratch, bytes);
+			HIP_CHECK(rocprim::inclusive_scan(rocprim_scratch.ptr, bytes, new_group.as<uint32_t>(), ctx->scratch("gather.group").as<uint32_t>(), n, rocprim::plus<uint32_t>(), s));
+			HIP_CHECK(hipStreamSynchronize(s));
+			ctx->n_aln.swap(ctx->scratch("gather.n_aln")); ctx->fbits.swap(ctx->scratch("gather.fbits")); ctx->group.swap(ctx->scratch("gather.group"));
+			static const char* const slot_names[3][6] = { { "gather.contig0", "gather.start0", "gather.end0", "gather.abits0", "gather.cigar_offset0", "gather.cigar_count0" }, { "gather.contig1", "gather.start1", "gather.end1", "gather.abits1", "gather.cigar_offset1", "gather.cigar_count1" },
+			                                              { "gather.contig2", "gather.start2", "gather.end2", "gather.abits2", "gather.cigar_offset2", "gather.cigar_count2" } };
+			for (int k = 0; k < 3; ++k) {
+				ctx->contig[k].swap(ctx->scratch(slot_names[k][0])); ctx->start[k].swap(ctx->scratch(slot_names[k][1])); ctx->end[k].swap(ctx->scratch(slot_names[k][2])); ctx->abits[k].swap(ctx->scratch(slot_names[k][3]));
+				ctx->cigar_offset[k].swap(ctx->scratch(slot_names[k][4])); ctx->cigar_count[k].swap(ctx->scratch(slot_names[k][5]));
+			}
+			ctx->seq_offset[0].swap(ctx->scratch("gather.seq_offset0")); ctx->seq_length[0].swap(ctx->scratch("gather.seq_length0")); ctx->seq_offset[1].swap(ctx->scratch("gather.seq_offset1")); ctx->seq_length[1].swap(ctx->scratch("gather.seq_length1"));
+			ctx->cigar_pool.swap(ctx->scratch("gather.cigar_pool")); ctx->seq_pool.swap(ctx->scratch("gather.seq_pool")); ctx->name_offset.swap(ctx->scratch("gather.name_offset")); ctx->names.swap(ctx->scratch("gather.names"));
+		}
+		TRY(agpu::finish_batch_setup(ctx));
+		ctx->batch_from_ingest = true;
+		static const char* const temporary[] = { "shard.order", "shard.order_out", "shard.keys", "shard.keys_out", "shard.new_group", "shard.rocprim", "gather.n_aln", "gather.fbits", "gather.group", "gather.contig0", "gather.start0", "gather.end0",
+			"gather.abits0", "gather.cigar_offset0", "gather.cigar_count0", "gather.contig1", "gather.start1", "gather.end1", "gather.abits1", "gather.cigar_offset1", "gather.cigar_count1", "gather.contig2", "gather.start2", "gather.end2",
+			"gather.abits2", "gather.cigar_offset2", "gather.cigar_count2", "gather.seq_offset0", "gather.seq_length0", "gather.seq_offset1", "gather.seq_length1", "gather.cigar_pool", "gather.seq_pool", "gather.name_offset", "gather.names" };
+		for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) ctx->scratch(temporary[k]).release();
+		total.names_were_sorted = 0;
+	}
 	agpu_ingest_result& whole = ctx->ingest_result;
 	memset(&whole, 0, sizeof(whole));
 	whole.records = total.records; whole.fragments = n; whole.mapped_reads = total.mapped_reads; whole.malformed_count = total.malformed_count; whole.missing_hi_tag = total.missing_hi_tag;
@@ -886,13 +1018,23 @@ int agpu_get_read_lengths(agpu_ctx* ctx, uint64_t first, uint64_t count, uint32_
 int agpu_gather_rows_begin(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint64_t* cigar_pool_size, uint64_t* seq_pool_size, uint64_t* names_size) {
 	if (!ctx || !ctx->have_batch) { set_last_error("no batch on the device"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
+	if (fragments != nullptr) for (uint64_t k = 0; k < n; ++k) if (fragments[k] >= ctx->n) { set_last_error("fragment index out of range"); return AGPU_ERR_INVALID; }
+	uint64_t sizes[3];
+	TRY(gather_rows_prepare(ctx, fragments, n, sizes));
+	if (cigar_pool_size) *cigar_pool_size = sizes[0];
+	if (seq_pool_size) *seq_pool_size = sizes[1];
+	if (names_size) *names_size = sizes[2];
+	return AGPU_OK;
+}
+
+// the rows `fragments` (host or device memory; null = all, in order) of the resident batch: sizes of their pools, where every row goes
+static int gather_rows_prepare(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint64_t* pool_sizes) {
 	hipStream_t s = ctx->stream;
 	ctx->gather_all = fragments == nullptr;
 	if (ctx->gather_all) n = ctx->n;
 	else {
-		for (uint64_t k = 0; k < n; ++k) if (fragments[k] >= ctx->n) { set_last_error("fragment index out of range"); return AGPU_ERR_INVALID; }
 		ALLOC(ctx->gather_ids, std::max<uint64_t>(n, 1) * 4);
-		if (n > 0) HIP_CHECK(hipMemcpyAsync(ctx->gather_ids.ptr, fragments, n * 4, hipMemcpyHostToDevice, s));
+		if (n > 0) HIP_CHECK(hipMemcpyAsync(ctx->gather_ids.ptr, fragments, n * 4, hipMemcpyDefault, s));
 	}
 	ctx->gather_n = n;
 	DeviceBuffer& cigar_words = ctx->scratch("gather.cigar_words"); DeviceBuffer& sequence_bytes = ctx->scratch("gather.sequence_bytes"); DeviceBuffer& name_lengths = ctx->scratch("gather.name_lengths"); DeviceBuffer& rocprim_scratch = ctx->scratch("gather.rocprim");
@@ -907,9 +1049,7 @@ int agpu_gather_rows_begin(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n,
 	HIP_CHECK(hipMemcpyAsync(&ctx->gather_sizes[1], ctx->gather_seq_base.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&ctx->gather_sizes[2], ctx->gather_name_base.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	if (cigar_pool_size) *cigar_pool_size = ctx->gather_sizes[0];
-	if (seq_pool_size) *seq_pool_size = ctx->gather_sizes[1];
-	if (names_size) *names_size = ctx->gather_sizes[2];
+	for (int k = 0; k < 3; ++k) pool_sizes[k] = ctx->gather_sizes[k];
 	return AGPU_OK;
 }
 

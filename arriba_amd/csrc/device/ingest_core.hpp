@@ -208,6 +208,25 @@ enum : uint8_t { RECORD_SKIPPED = 0, RECORD_ACTIVE = 1, RECORD_MISSING_HI = 2, R
 
 AGPU_HD uint32_t qname_length(const Rec& r) { uint32_t n = 0; while (n < r.l_read_name && r.name[n]) ++n; return n; }
 
+// One sample over several contexts (agpu_shard_merge): no read name may have records in two parts.  Every run of records with one QNAME in the stream of a part gives
+// a 128-bit key of the QNAME (two FNV-1a passes with different offsets, finalised); equal keys anywhere in the sample -- two runs of a name in one part or in two --
+// mean that the alignments of a read do not follow each other in the file.
+AGPU_HD bool starts_qname_run(const IngestStream& in, uint32_t record) {
+	if (record == 0) return true;
+	const Rec a = load_record(in, record - 1), b = load_record(in, record);
+	const uint32_t length = qname_length(b);
+	if (qname_length(a) != length) return true;
+	for (uint32_t i = 0; i < length; ++i) if (a.name[i] != b.name[i]) return true;
+	return false;
+}
+AGPU_HD void qname_key128(const Rec& r, uint64_t& low, uint64_t& high) {
+	uint64_t h = 1469598103934665603ull, g = 0x9AE16A3B2F90404Full;
+	for (uint32_t i = 0; i < r.l_read_name && r.name[i]; ++i) { h = (h ^ r.name[i]) * 1099511628211ull; g = (g ^ (r.name[i] + 0x9Eu)) * 0x100000001B3ull; g ^= g >> 29; }
+	h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
+	g ^= g >> 31; g *= 0x7FB5D329728EA185ull; g ^= g >> 27; g *= 0x81DADEF4BC2DD44Dull; g ^= g >> 33;
+	low = h; high = g;
+}
+
 // 64-bit key of "QNAME,HI": FNV-1a over the name bytes, the hit index mixed in, finalised (murmur3 fmix64); ~0 is reserved for records that take no part
 AGPU_HD uint64_t name_key(const Rec& r, int64_t hit_index, uint64_t seed) {
 	uint64_t h = 1469598103934665603ull ^ seed;

@@ -56,6 +56,9 @@ DATASETS = {
     # rules8k with structural variants from WGS (-d): genomic support marked, filter_no_genomic_support, recover_genomic_support, confidence, output columns
     "wgs8k": {"args": ["--seed", "17", "--fragments", "8000", "--contigs", "4", "--contig-len", "300000", "--junctions", "120", "--rule-files"], "rule_files": True, "structural_variants": True,
               "golden_files": ["scalars.tsv", "fusions.*_mark_genomic_support.tsv", "fusions.*_filter_no_genomic_support.tsv", "fusions.*_recover_genomic_support.tsv", "fusions.*_assign_confidence.tsv"], "reference_env": {"ARRIBA_ORACLE_DUMP_LISTS": "0"}},
+    # toy3k with scrambled read names, the alignments of a read still next to each other -- the order STAR writes (that of the FASTQ file, not of std::string):
+    # a single ingest sorts the fragments by name; one sample over several ranks has to sort the merged batch (no golden dump: compared with the single ingest)
+    "scrambled3k": {"args": ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60", "--shuffle"], "golden_files": []},
     # enough paired split reads for the mate-gap estimate (>= 10000 samples); only compact dumps are committed
     "mid30k": {"args": ["--seed", "3", "--fragments", "30000", "--normal-mult", "0.5", "--contigs", "6", "--contig-len", "400000", "--junctions", "300", "--dup", "0.1"],
                "golden_files": ["filters.*_read_filters_final.tsv", "scalars.tsv", "genes.tsv"]},

@@ -255,6 +255,13 @@ def test_device_ingest_in_parts_on_the_gpu(built, dataset_files, tmp_path):
     for path, parts in ((prefix + ".bam", 3), (small, 7)):
         merged_session, merged, _ = host_tests._ingest_in_parts(prefix, path, parts, api)
         assert host_tests._device_batch_columns(merged_session, merged) == expected, (path, parts)
+    # names in the order of a FASTQ file: the merged batch is sorted on the device
+    scrambled = dataset_files("scrambled3k")
+    session = HostSession(scrambled + ".fa", scrambled + ".gtf")
+    expected = host_tests._device_batch_columns(session, DevicePipeline(session, bam=scrambled + ".bam"))
+    merged_session, merged, _ = host_tests._ingest_in_parts(scrambled, scrambled + ".bam", 4, api)
+    assert merged.ingest_result.names_were_sorted == 0
+    assert host_tests._device_batch_columns(merged_session, merged) == expected
 
 
 def test_gene_set_capacity_is_reported_not_truncated(built, tmp_path):

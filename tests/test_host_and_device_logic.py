@@ -374,10 +374,20 @@ def test_device_ingest_in_parts_gives_the_batch_of_the_whole_file(built, dataset
         out.write(_bam_payload(prefix + ".bam"))
     with pytest.raises(ArribaError, match="part of a sample"):  # not seekable by blocks: every rank would have to inflate the whole file
         _ingest_in_parts(prefix, plain, 2, emu_api)
-    # parts that do not follow each other in the order of the names (a file that is not sorted the way the reference's std::map iterates): refused, not merged wrongly
-    shuffled = dataset_files("shuffled2k")
-    with pytest.raises(ArribaError, match="interleave"):
-        _ingest_in_parts(shuffled, shuffled + ".bam", 3, emu_api)
+    # read names in the order of a FASTQ file, not of std::string (what STAR writes): the parts interleave in name order, the merged batch is sorted
+    scrambled = dataset_files("scrambled3k")
+    session = HostSession(scrambled + ".fa", scrambled + ".gtf")
+    whole = DevicePipeline(session, api=emu_api, bam=scrambled + ".bam")
+    assert whole.ingest_result.names_were_sorted == 0
+    expected = _device_batch_columns(session, whole)
+    for parts in (2, 5):
+        merged_session, merged, fragments = _ingest_in_parts(scrambled, scrambled + ".bam", parts, emu_api)
+        assert merged.ingest_result.names_were_sorted == 0 and all(n is None or n > 0 for n in fragments)
+        assert _device_batch_columns(merged_session, merged) == expected, parts
+    # a file whose alignments are not grouped by read name (mates apart): a name ends up in two parts -- refused, not merged wrongly
+    apart = dataset_files("shuffled2k")
+    with pytest.raises(ArribaError, match="more than one place"):
+        _ingest_in_parts(apart, apart + ".bam", 3, emu_api)
 
 
 def test_device_ingest_survives_a_false_record_start(built, dataset_files, emu_api, tmp_path):

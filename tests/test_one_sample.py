@@ -32,8 +32,8 @@ def check_reports(reports):
     return reports[0]
 
 
-@pytest.mark.parametrize("world,name", [(2, "toy3k"), (3, "homologs8k"), (4, "mid30k")])
+@pytest.mark.parametrize("world,name", [(2, "toy3k"), (3, "homologs8k"), (4, "mid30k"), (3, "scrambled3k")])
 def test_one_sample_over_ranks_equals_single_process(world, name, dataset_files, emu_api, tmp_path):
-    report = check_reports(run_one_sample(dataset_files(name), world, "emu", str(tmp_path / "report"), 29700 + world))
+    report = check_reports(run_one_sample(dataset_files(name), world, "emu", str(tmp_path / "report"), 29700 + world + (10 if name == "scrambled3k" else 0)))
     assert sum(1 for size in report["part_bytes"] if size > 4096) == world  # every rank read a part of the file
     assert report["mismapper_jobs"] > 0 and report["fusions"] > 0
