@@ -179,16 +179,22 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 const uint32_t MEMO_SLOTS_LOG2 = 21;    // 16 MB per workgroup (a read of a long gene makes 10^5..10^6 distinct nested calls)
 const uint32_t HEAVY_WORKGROUPS = 4096;
 __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
-                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned int* counters) {
+                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
 	__shared__ AlignMemo memo;
+	__shared__ AlignWorklist worklist;
+	__shared__ uint32_t worklist_state[4];
 	__shared__ uint32_t next_job;
-	if (threadIdx.x == 0) { memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0; }
+	if (threadIdx.x == 0) {
+		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0;
+		worklist.words = task_lists != nullptr ? task_lists + (size_t) blockIdx.x * task_capacity * 2 : nullptr; worklist.capacity = task_capacity; worklist.state = worklist_state;
+	}
 	__syncthreads();
 	AlignFrame stack[ALIGN_MAX_DEPTH];
 	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = nullptr; runner.max_depth = ALIGN_MAX_DEPTH;
-	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position
+	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position (when the task list is off or overflows)
 	runner.memo = &memo;
+	runner.worklist = task_lists != nullptr ? &worklist : nullptr; // the search as rounds of up to 64 tasks (mismapper_core.hpp: AlignWorklist)
 	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
 	while (true) {
 		__syncthreads(); // (every lane has read next_job of the previous round)
@@ -423,8 +429,14 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				DeviceBuffer& memo_tables = ctx->scratch("mismappers.memo_tables");
 				ALLOC(memo_tables, (size_t) workgroups * memo_slots * 8);
 				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));
+				// the task lists of the workgroups: 2^16 tasks of 16 bytes each (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
+				knob = getenv("ARRIBA_MISMAPPER_WORKLIST");
+				const bool use_worklist = !(knob != nullptr && knob[0] == '0');
+				const uint32_t task_capacity = 1u << 16;
+				DeviceBuffer& task_lists = ctx->scratch("mismappers.task_lists");
+				if (use_worklist) ALLOC(task_lists, (size_t) workgroups * task_capacity * 16);
 				KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-				mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, device_counters);
+				mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity, device_counters);
 			}
 			}
 			n_jobs = n_all;

@@ -79,66 +79,6 @@ AGPU_HD bool is_splice_site_from(const AlignTarget& target, int32_t position, ui
 }
 AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; } // eight genome bases at once (the genome buffer is padded behind its end)
 
-// Frontier of failed nested calls.  Besides being monotone in `score` (see AlignMemo below), a nested align(score, read_pos, gene_pos, max_deletions) is monotone
-// in gene_pos and max_deletions: gene_pos only bounds the seeds from below (lower_bound over the hit list; nothing else of a call depends on it), so a call
-// further into the gene tries a subset of the attempts of a call at an earlier position, each with the same score; and with max_deletions = 0 the re-seed behind
-// the first mismatch is left out while everything else stays.  So a failed call (read_pos, gene_pos g, score s, deletions d) proves the failure of every call
-// at the same read position with gene_pos >= g, score <= s and deletions <= d.  The seeds of a read position are tried in ascending gene position, and the calls
-// they lead to differ in little else: the first one that fails takes the later ones with it -- the branching of the reference's recursion (seeds per k-mer to
-// the power of the nesting depth) collapses.  Per read position a few (gene position, score, deletions) triples none of which makes another redundant are kept
-// (FRONTIER_WAYS of them; what does not fit is forgotten, which costs time, never correctness: only calls known to return false are skipped).
-// A word holds epoch (8 bits, one per align() invocation: the table is never cleared in between) | gene_pos - gene_start (31) | max_deletions > 0 (1) | score + 32768 (16) | 0 (8).
-const uint32_t FRONTIER_WAYS = 4;
-const uint32_t FRONTIER_POSITIONS = 304; // read positions of a segment that is re-aligned (< 300 bases)
-struct AlignFrontier {
-	unsigned long long* words; uint32_t epoch; // FRONTIER_POSITIONS * FRONTIER_WAYS words (no default initialisers: the device keeps one in LDS)
-	AGPU_HD static unsigned long long load(const unsigned long long* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-		return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-		return *p;
-#endif
-	}
-	AGPU_HD static void store(unsigned long long* p, unsigned long long v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-		*p = v;
-#endif
-	}
-	AGPU_HD bool usable(int32_t length) const { return words != nullptr && (uint32_t) length <= FRONTIER_POSITIONS; }
-	AGPU_HD static uint32_t offset_of(unsigned long long w) { return (uint32_t) (w >> 25) & 0x7FFFFFFFu; }
-	AGPU_HD static int32_t score_of(unsigned long long w) { return (int32_t) ((w >> 8) & 0xFFFFu) - 32768; }
-	AGPU_HD static uint32_t deletions_of(unsigned long long w) { return (uint32_t) (w >> 24) & 1u; }
-	AGPU_HD bool known_to_fail(int32_t read_pos, int32_t gene_offset, int32_t max_deletions, int32_t score) const {
-		if ((uint32_t) read_pos >= FRONTIER_POSITIONS) return false;
-		const unsigned long long* list = words + (size_t) read_pos * FRONTIER_WAYS;
-		for (uint32_t way = 0; way < FRONTIER_WAYS; ++way) {
-			const unsigned long long w = load(&list[way]);
-			if ((w >> 56) == (epoch & 255u) && offset_of(w) <= (uint32_t) gene_offset && score_of(w) >= score && deletions_of(w) >= (uint32_t) (max_deletions > 0)) return true;
-		}
-		return false;
-	}
-	AGPU_HD void record_failure(int32_t read_pos, int32_t gene_offset, int32_t max_deletions, int32_t score) const {
-		if ((uint32_t) read_pos >= FRONTIER_POSITIONS || score < -32768 || score > 32767 || gene_offset < 0) return;
-		const uint32_t deletions = max_deletions > 0;
-		const unsigned long long word = (unsigned long long) (epoch & 255u) << 56 | (unsigned long long) (uint32_t) gene_offset << 25 | (unsigned long long) deletions << 24 | (unsigned long long) (uint32_t) (score + 32768) << 8;
-		unsigned long long* list = words + (size_t) read_pos * FRONTIER_WAYS;
-		int free_way = -1, redundant_way = -1, furthest_way = -1; uint32_t furthest = 0;
-		for (uint32_t way = 0; way < FRONTIER_WAYS; ++way) {
-			const unsigned long long w = load(&list[way]);
-			if ((w >> 56) != (epoch & 255u)) { if (free_way < 0) free_way = (int) way; continue; }
-			if (offset_of(w) <= (uint32_t) gene_offset && score_of(w) >= score && deletions_of(w) >= deletions) return; // nothing new
-			if ((uint32_t) gene_offset <= offset_of(w) && score >= score_of(w) && deletions >= deletions_of(w)) { if (redundant_way < 0) redundant_way = (int) way; continue; }
-			if (furthest_way < 0 || offset_of(w) > furthest) { furthest_way = (int) way; furthest = offset_of(w); }
-		}
-		// (lanes that share the table may overwrite each other's words: every word is a true statement about this search, whichever survives)
-		if (redundant_way >= 0) store(&list[redundant_way], word);
-		else if (free_way >= 0) store(&list[free_way], word);
-		else if (furthest_way >= 0 && (uint32_t) gene_offset < furthest) store(&list[furthest_way], word); // the triple that starts earliest in the gene speaks for the most seeds
-	}
-};
-
 // Memo of failed nested calls.  A nested align(score, read_pos, gene_pos, max_deletions) is monotone in `score` -- a higher score only loosens the bound of its
 // read-position loop and raises every score it compares with min_score -- so a call that failed with score s fails with every score <= s.  The reference
 // re-runs such calls from scratch: behind every splice site an extension crosses it starts a full search of the rest of the read against the rest of the gene,
@@ -206,6 +146,43 @@ struct AlignFrame {
 const int ALIGN_MAX_DEPTH = 40;           // every nested call starts >= 8 bases further into a read of < 300 bases
 const int ALIGN_SHALLOW_DEPTH = 16;       // ... of <= 128 bases: the stack of the first pass on the device
 
+// The search as a list of independent pieces of work.  align() returns true as soon as ANY attempt anywhere in its recursion reaches min_score, and false when
+// all of them are exhausted: its result is the OR over a tree of attempts, and the only thing the recursion adds is an order.  So a nested call need not be run
+// where it is made: it is put on a list ("task": score, read position, gene position, deletions allowed) and the caller goes on at once as if the call had
+// failed; whoever has nothing to do takes the next task.  Calls that the memo has seen with at least the same score are not listed again (whether the earlier
+// one has finished or not: if it succeeds the answer is true anyway, if it fails so would this one).  One search of ~10^6 dependent steps in one lane -- the
+// end of the second pass on the device waits for exactly that -- becomes rounds of up to 64 tasks, one per lane.  A list that overflows is abandoned and the
+// search is done by the recursion.
+enum { ALIGN_TASK_DELETIONS = 1, ALIGN_TASK_ROOT = 2 }; // max_deletions > 0 / one iteration of the outermost loop of align() (leading skipped bases are free)
+struct AlignTask { int32_t score, read_pos, gene_pos; uint32_t flags; };
+struct AlignWorklist {
+	unsigned long long* words; uint32_t capacity; // two 64-bit words per task
+	uint32_t* state;                              // [0] tasks listed, [1] overflow, [2] found (memory the lanes of the runner share: LDS on the device)
+	AGPU_HD void push(const AlignTask& task) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		const uint32_t at = atomicAdd(&state[0], 1u);
+#else
+		const uint32_t at = state[0]++;
+#endif
+		if (at >= capacity) { state[1] = 1; return; }
+		const unsigned long long first = (unsigned long long) (uint32_t) task.score | (unsigned long long) (uint32_t) task.read_pos << 32, second = (unsigned long long) (uint32_t) task.gene_pos | (unsigned long long) task.flags << 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+		__hip_atomic_store(&words[2 * (size_t) at], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&words[2 * (size_t) at + 1], second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+		words[2 * (size_t) at] = first; words[2 * (size_t) at + 1] = second;
+#endif
+	}
+	AGPU_HD AlignTask task(uint32_t at) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		const unsigned long long first = __hip_atomic_load(&words[2 * (size_t) at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), second = __hip_atomic_load(&words[2 * (size_t) at + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+		const unsigned long long first = words[2 * (size_t) at], second = words[2 * (size_t) at + 1];
+#endif
+		AlignTask result = { (int32_t) (uint32_t) first, (int32_t) (uint32_t) (first >> 32), (int32_t) (uint32_t) second, (uint32_t) (second >> 32) };
+		return result;
+	}
+};
+
 AGPU_HD void align_enter(AlignFrame& f, int32_t score, int32_t read_pos, int32_t gene_pos, int32_t max_deletions) {
 	f.score = score; f.read_pos = read_pos; f.skipped_bases = 0; f.gene_pos = gene_pos; f.max_deletions = max_deletions;
 	f.leading = read_pos == 0; f.state = ALIGN_NEXT_READ_POSITION; f.started = 0; f.hit = 0; f.hits_end = 0; f.splice_cursor = 0;
@@ -228,14 +205,15 @@ static AlignStats g_align_stats;
 #else
 #define ALIGN_STAT(field, amount) ((void) 0)
 #endif
-AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1, const AlignMemo* memo = nullptr, const AlignFrontier* frontier = nullptr) {
+AGPU_HD bool align_search(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, const AlignTask& task, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1,
+                          const AlignMemo* memo = nullptr, const AlignWorklist* worklist = nullptr) {
 	const int32_t length = (int32_t) read.length;
 	const bool use_memo = memo != nullptr && memo->usable(target.gene_start, target.gene_end);
-	const bool use_frontier = frontier != nullptr && frontier->usable(length);
+	const bool root = (task.flags & ALIGN_TASK_ROOT) != 0;
 	int depth = 0;
 	AlignFrame f;
-	align_enter(f, -first_read_pos, first_read_pos, target.gene_start, 1);
-	f.skipped_bases = first_read_pos; f.leading = 1;
+	align_enter(f, task.score, task.read_pos, task.gene_pos, (task.flags & ALIGN_TASK_DELETIONS) ? 1 : 0);
+	if (root) { f.skipped_bases = task.read_pos; f.leading = 1; } // iteration read_pos of the outermost loop: score -read_pos, all skipped bases leading
 	f.extended_score = 0; f.extended_read_pos = 0; f.extended_gene_pos = 0; f.mismatch_count = 0; f.consecutive_mismatches = 0;
 	while (true) {
 		if (budget != nullptr && --*budget < 0) return false;
@@ -244,7 +222,7 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 		switch (f.state) {
 			case ALIGN_NEXT_READ_POSITION: { // for (; read_pos + k < length && ...; read_pos++, score--, skipped_bases++)
 				ALIGN_STAT(read_positions, 1);
-				if (f.started && depth == 0) return false; // the other read positions of the outermost loop are other attempts
+				if (f.started && depth == 0 && root) return false; // the other read positions of the outermost loop are other attempts
 				if (f.started) { f.read_pos++; f.score--; f.skipped_bases++; }
 				f.started = 1;
 				if (!(f.read_pos + KMER_LENGTH < length && f.read_pos + min_score <= length + f.score + 2 * KMER_LENGTH)) { fail = true; break; }
@@ -350,8 +328,14 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 		}
 		const bool wanted_call = call;
 		if (call && use_memo && memo->known_to_fail(memo->key_of(f.extended_read_pos, f.extended_gene_pos - target.gene_start, call_max_deletions), f.extended_score)) call = false; // searched before, with at least this score
-		if (call && use_frontier && frontier->known_to_fail(f.extended_read_pos, f.extended_gene_pos - target.gene_start, call_max_deletions, f.extended_score)) call = false; // a call that tries at least these seeds with at least this score has failed
 		if (wanted_call && !call) ALIGN_STAT(pruned, 1);
+		if (call && worklist != nullptr) { // listed for whoever is free; this search goes on as if the call had failed (the result is an OR over everything that gets searched)
+			if (use_memo) memo->record_failure(memo->key_of(f.extended_read_pos, f.extended_gene_pos - target.gene_start, call_max_deletions), f.extended_score); // (seen: not listed again with a score <= this one)
+			const AlignTask nested = { f.extended_score, f.extended_read_pos, f.extended_gene_pos, call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u };
+			worklist->push(nested);
+			ALIGN_STAT(calls, 1);
+			call = false;
+		}
 		if (call) ALIGN_STAT(calls, 1); else if (fail) ALIGN_STAT(failures, 1);
 		if (call) ALIGN_STAT(depth_sum, depth + 1);
 		if (call) { // the caller's frame goes to the stack, the nested call takes the registers
@@ -364,11 +348,15 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 			if (depth == 0) return false;
 			// (a nested call entered with read position read_pos - skipped_bases and score score + skipped_bases: both move together in its loop)
 			if (use_memo) memo->record_failure(memo->key_of(f.read_pos - f.skipped_bases, f.gene_pos - target.gene_start, f.max_deletions), f.score + f.skipped_bases);
-			if (use_frontier) frontier->record_failure(f.read_pos - f.skipped_bases, f.gene_pos - target.gene_start, f.max_deletions, f.score + f.skipped_bases);
 			--depth;
 			f = stack[depth];
 		}
 	}
+}
+
+AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1, const AlignMemo* memo = nullptr) {
+	const AlignTask task = { -first_read_pos, first_read_pos, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
+	return align_search(read, target, min_score, stack, max_depth, task, budget, hit_offset, hit_stride, memo, nullptr);
 }
 
 // Who tries the read positions: one thread after the other on the host (lanes = 1), the 64 lanes of a wavefront on the device.
@@ -399,43 +387,50 @@ struct AlignRunner {
 		return mine;
 #endif
 	}
+	AGPU_HD void sync_lanes() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (lanes > 1) __syncthreads();
+#endif
+	}
+	AGPU_HD void new_memo_epoch() const {
+		sync_lanes();
+		const uint32_t next = (memo->epoch + 1) & 255u; // (every lane reads the same value)
+		if (next == 0) for (uint32_t k = lane; k <= memo->mask; k += lanes) memo->slots[k] = 0; // the epoch numbers wrap around: start clean (epoch 0 = empty slots)
+		sync_lanes();
+		if (lane == 0) memo->epoch = next == 0 ? 1 : next;
+		sync_lanes();
+	}
 	// reference: align(0, read, 0, contig, gene_start, gene_start, gene_end, ...) (source/filter_mismappers.cpp:86-199)
 	AlignMemo* memo = nullptr; // table of failed nested calls, shared by the lanes of the runner (second pass on the device); every align() takes a new epoch
-	AlignFrontier* frontier = nullptr; // failed nested calls by read position (shared by the lanes of the runner); every align() takes a new epoch
+	AlignWorklist* worklist = nullptr; // the search as a list of tasks the lanes take in rounds (see AlignWorklist); needs the memo
 	bool lanes_share_seeds = false; // the lanes work on the same read position and split its seeds (reads with hundreds of seeds per position); default: one read position per lane
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
-		if (memo != nullptr) { // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
-#if defined(__HIP_DEVICE_COMPILE__)
-			if (lanes > 1) __syncthreads();
-#endif
-			const uint32_t next = (memo->epoch + 1) & 255u; // (every lane reads the same value)
-			if (next == 0) for (uint32_t k = lane; k <= memo->mask; k += lanes) memo->slots[k] = 0; // the epoch numbers wrap around: start clean (epoch 0 = empty slots)
-#if defined(__HIP_DEVICE_COMPILE__)
-			if (lanes > 1) __syncthreads();
-#endif
-			if (lane == 0) memo->epoch = next == 0 ? 1 : next;
-#if defined(__HIP_DEVICE_COMPILE__)
-			if (lanes > 1) __syncthreads();
-#endif
-		}
-		if (frontier != nullptr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-			if (lanes > 1) __syncthreads();
-#endif
-			const uint32_t next = (frontier->epoch + 1) & 255u;
-			if (next == 0) for (uint32_t k = lane; k < FRONTIER_POSITIONS * FRONTIER_WAYS; k += lanes) frontier->words[k] = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-			if (lanes > 1) __syncthreads();
-#endif
-			if (lane == 0) frontier->epoch = next == 0 ? 1 : next;
-#if defined(__HIP_DEVICE_COMPILE__)
-			if (lanes > 1) __syncthreads();
-#endif
+		if (memo != nullptr) new_memo_epoch(); // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
+		if (worklist != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end)) {
+			sync_lanes();
+			if (lane == 0) { worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0; }
+			sync_lanes();
+			for (int32_t read_pos = (int32_t) lane; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; read_pos += (int32_t) lanes) { // the iterations of the outermost loop
+				const AlignTask outermost = { -read_pos, read_pos, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
+				worklist->push(outermost);
+			}
+			for (uint32_t head = 0; ; head += lanes) { // rounds: every lane takes one task, the tasks it lists are taken in later rounds
+				sync_lanes();
+				const uint32_t listed = worklist->state[0] < worklist->capacity ? worklist->state[0] : worklist->capacity;
+				const bool done = worklist->state[2] != 0 || head >= listed;
+				sync_lanes(); // (nobody lists a task before everybody has read the state of this round)
+				if (done) break;
+				if (head + lane < listed && align_search(read, target, min_score, stack, 0, worklist->task(head + lane), budget, 0, 1, memo, worklist)) worklist->state[2] = 1;
+				if (exhausted()) return false;
+			}
+			if (worklist->state[2] != 0) return true;
+			if (worklist->state[1] == 0) return false;
+			new_memo_epoch(); // the list was too short for this search: done again by the recursion (what the memo has "seen" are not failures)
 		}
 		if (lanes_share_seeds) {
 			for (int32_t read_pos = 0; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; ++read_pos) {
-				const bool found = align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, lane, lanes, memo, frontier);
+				const bool found = align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, lane, lanes, memo);
 				if (exhausted()) return false;
 				if (any(found)) return true;
 			}
@@ -443,7 +438,7 @@ struct AlignRunner {
 		}
 		for (int32_t base = 0; base + KMER_LENGTH < length && 2 * base + min_score <= length + 2 * KMER_LENGTH; base += (int32_t) lanes) { // the loop bound of the reference at read_pos = base
 			const int32_t read_pos = base + (int32_t) lane;
-			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, 0, 1, memo, frontier);
+			bool found = read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH && align_from_read_position(read, target, min_score, stack, max_depth, read_pos, budget, 0, 1, memo);
 			if (exhausted()) return false;
 			if (any(found)) return true;
 		}

@@ -673,6 +673,26 @@ def test_workflow_with_mismappers_switched_off_against_the_live_reference(disabl
         assert counts["filter_mismappers"] <= counts["filter_homologs"]  # (both files and every count equal the reference's: check_workflow)
 
 
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+@pytest.mark.parametrize("schedule", [{"EMU_MISMAPPER_BUDGET": "64"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_WORKLIST": "0"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_WORKLIST_CAPACITY": "6"}])
+def test_every_schedule_of_the_mismapper_search_gives_the_reference(schedule, emu_api, tmp_path, monkeypatch):
+    """The verdict of a read is a pure function of the read, whoever computes it in whatever order: with a step budget of 64 nearly every read goes to the second
+    pass, which is stepped as the list of tasks the device uses (nested calls listed and taken in rounds, deduplicated by the memo), as the recursion with the memo of
+    failed calls, and with a list of 6 tasks that overflows so that the recursion takes over -- reads discarded, candidates and both files equal the reference's."""
+    for key, value in schedule.items():
+        monkeypatch.setenv(key, value)
+    spec = {"args": ["--seed", "79", "--fragments", "15000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--partner-clip", "0.5", "--clip-min", "40", "--clip-max", "70",
+                     "--homolog-families", "4"]}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, spec, extra_args=["-U", "32767"]))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, params={"subsampling_threshold": 32767})
+    assert dict(stages)["filter_mismappers"] <= dict(stages)["filter_homologs"]  # (every count, the read filters of the written candidates and both files equal the reference's: check_workflow)
+
+
 @pytest.mark.parametrize("name", ["toy3k", "wgs8k"])
 def test_cpp_workflow_driver_over_the_c_abis(name, dataset_files, emu_api, tmp_path):
     """arriba_workflow_run (arriba_amd/csrc/workflow: the reference's main() behind its option parser, C++ over the two C ABIs, no Python in the loop),
