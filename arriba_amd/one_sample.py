@@ -76,6 +76,8 @@ class OneSamplePipeline(DevicePipeline):
         result = _capi.IngestResult()
         self._check(self.api.shard_merge(self.ctx, blocks.data_ptr(), stride, self.world, byref(result)))
         del blocks, mine
+        if self.collective_device.type == "cuda":
+            torch.cuda.empty_cache()  # the buffers of the exchange (the size of the whole batch) go back to the device: the stages allocate through the C ABI, not through torch
         merged = time.perf_counter()
         self._record("shard_merge")
         self._adopt_ingest(config, result)
@@ -102,6 +104,7 @@ class OneSamplePipeline(DevicePipeline):
         self._sync()
         remaining, discarded = c_uint64(), c_uint64()
         self._check(self.api.filter_mismappers_apply(self.ctx, verdicts.data_ptr(), byref(remaining), byref(discarded)))
+        del verdicts
         self._record("filter_mismappers")
         spent["ms"] += self.timings["filter_mismappers"]["ms"]
         spent["bytes"] = self.timings["filter_mismappers"]["bytes"]
