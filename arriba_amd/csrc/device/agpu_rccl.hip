@@ -1,0 +1,86 @@
+// agpu_rccl.hip -- the two exchanges of "one sample over N GPUs" issued from inside the C ABI, for hosts that hold an RCCL communicator themselves
+// (agpu_shard_merge(ctx, ncclComm_t, hipStream_t)).  Thin compositions of entry points that are tested on their own
+// (agpu_shard_export / agpu_shard_merge, agpu_mismapper_jobs / _verdicts / agpu_filter_mismappers_apply) with ncclAllReduce / ncclAllGather on the context's
+// stream in between.  librccl is looked up at run time: the library does not link against it, and nothing else in it depends on these two functions.
+// NOT EXERCISED in round 2 (RCCL needs one GPU per rank; the Python driver arriba_amd/one_sample.py issues the same collectives through torch.distributed).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <string>
+#include <rccl/rccl.h>
+#include "agpu_context.hpp"
+
+using namespace agpu;
+
+namespace {
+
+#define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define TRY(call) do { int s_ = (call); if (s_ != AGPU_OK) return s_; } while (0)
+
+struct Rccl {
+	ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	const char* (*error_string)(ncclResult_t) = nullptr;
+	bool load() {
+		if (all_reduce != nullptr) return true;
+		void* library = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (library == nullptr) library = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (library == nullptr) { set_last_error(std::string("librccl.so not found: ") + dlerror()); return false; }
+		all_reduce = (decltype(all_reduce)) dlsym(library, "ncclAllReduce"); all_gather = (decltype(all_gather)) dlsym(library, "ncclAllGather"); error_string = (decltype(error_string)) dlsym(library, "ncclGetErrorString");
+		if (all_reduce == nullptr || all_gather == nullptr) { set_last_error("librccl.so lacks ncclAllReduce / ncclAllGather"); all_reduce = nullptr; return false; }
+		return true;
+	}
+	int check(ncclResult_t status, const char* what) const {
+		if (status == ncclSuccess) return AGPU_OK;
+		set_last_error(std::string(what) + ": " + (error_string ? error_string(status) : "RCCL error"));
+		return AGPU_ERR_DEVICE;
+	}
+};
+Rccl g_rccl;
+
+}
+
+extern "C" int agpu_shard_merge_rccl(agpu_ctx* ctx, void* nccl_comm, uint32_t n_ranks, agpu_ingest_result* result) {
+	if (!ctx || !nccl_comm || n_ranks == 0) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (!g_rccl.load()) return AGPU_ERR_DEVICE;
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	ncclComm_t comm = (ncclComm_t) nccl_comm;
+	uint64_t bytes = 0;
+	TRY(agpu_shard_export_size(ctx, &bytes));
+	// the blocks travel at the stride of the largest part
+	DeviceBuffer& widest = ctx->scratch("rccl.widest");
+	ALLOC(widest, 8);
+	HIP_CHECK(hipMemcpyAsync(widest.ptr, &bytes, 8, hipMemcpyHostToDevice, s));
+	TRY(g_rccl.check(g_rccl.all_reduce(widest.ptr, widest.ptr, 1, ncclUint64, ncclMax, comm, s), "ncclAllReduce(size of the parts)"));
+	uint64_t stride = 0;
+	HIP_CHECK(hipMemcpyAsync(&stride, widest.ptr, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	stride = (stride + 15) & ~(uint64_t) 15;
+	DeviceBuffer& mine = ctx->scratch("rccl.part"); DeviceBuffer& all = ctx->scratch("rccl.parts");
+	ALLOC(mine, stride); ALLOC(all, (size_t) n_ranks * stride);
+	TRY(agpu_shard_export(ctx, mine.ptr, stride));
+	TRY(g_rccl.check(g_rccl.all_gather(mine.ptr, all.ptr, stride, ncclUint8, comm, s), "ncclAllGather(parts of the sample)"));
+	HIP_CHECK(hipStreamSynchronize(s));
+	const int status = agpu_shard_merge(ctx, all.ptr, stride, n_ranks, result);
+	mine.release(); all.release();
+	return status;
+}
+
+extern "C" int agpu_filter_mismappers_rccl(agpu_ctx* ctx, void* nccl_comm, int32_t max_mate_gap, uint32_t rank, uint32_t n_ranks, uint64_t* remaining, uint64_t* discarded_reads) {
+	if (!ctx || !nccl_comm || n_ranks == 0 || rank >= n_ranks) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (!g_rccl.load()) return AGPU_ERR_DEVICE;
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	uint64_t n_jobs = 0;
+	TRY(agpu_mismapper_jobs(ctx, &n_jobs));
+	DeviceBuffer& verdicts = ctx->scratch("rccl.verdicts");
+	ALLOC(verdicts, std::max<uint64_t>(n_jobs, 1));
+	HIP_CHECK(hipMemsetAsync(verdicts.ptr, 0, std::max<uint64_t>(n_jobs, 1), s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	TRY(agpu_mismapper_verdicts(ctx, max_mate_gap, rank, n_ranks, verdicts.as<uint8_t>()));
+	if (n_jobs > 0) TRY(g_rccl.check(g_rccl.all_reduce(verdicts.ptr, verdicts.ptr, n_jobs, ncclUint8, ncclMax, (ncclComm_t) nccl_comm, s), "ncclAllReduce(verdicts)"));
+	HIP_CHECK(hipStreamSynchronize(s));
+	return agpu_filter_mismappers_apply(ctx, verdicts.as<uint8_t>(), remaining, discarded_reads);
+}

@@ -254,6 +254,12 @@ int agpu_shard_export_size(agpu_ctx* ctx, uint64_t* bytes);
 int agpu_shard_export(agpu_ctx* ctx, void* block, uint64_t capacity);
 int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_t n_parts, agpu_ingest_result* result /* sums over the parts; may be NULL */);
 
+/* The two exchanges issued from inside the C ABI for hosts that hold an RCCL communicator (ncclComm_t passed as void*): export +
+ * ncclAllReduce(max size) + ncclAllGather on the context's stream + merge, and jobs + verdicts + ncclAllReduce(max) + apply.  librccl is looked up at run
+ * time (dlopen).  Compositions of the entry points above; not exercised in round 2 (RCCL needs one GPU per rank). */
+int agpu_shard_merge_rccl(agpu_ctx* ctx, void* nccl_comm, uint32_t n_ranks, agpu_ingest_result* result);
+int agpu_filter_mismappers_rccl(agpu_ctx* ctx, void* nccl_comm, int32_t max_mate_gap, uint32_t rank, uint32_t n_ranks, uint64_t* remaining, uint64_t* discarded_reads);
+
 /* restore the batch to its state right after agpu_upload_batch (filters, strands and gene sets cleared) so that the stages can be run again */
 int agpu_reset(agpu_ctx* ctx);
 
