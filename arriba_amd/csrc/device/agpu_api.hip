@@ -755,7 +755,7 @@ int agpu_annotate_finish(agpu_ctx* ctx, const uint64_t* positions, uint64_t n_po
 	if (host_counters[COUNTER_ERROR] & ERROR_GENE_SET_OVERFLOW) { set_last_error("a gene set exceeded the device capacity"); return AGPU_ERR_CAPACITY; }
 	if (host_counters[COUNTER_ERROR] & ERROR_VIRAL_PAIR_OVERFLOW) { set_last_error("too many virus-host fragments for the integration-site buffer"); return AGPU_ERR_CAPACITY; }
 	if (n_dummy_genes) *n_dummy_genes = ctx->n_dummy;
-	ctx->annotated = true; ctx->annotate_begun = false;
+	ctx->annotated = true; ctx->annotate_begun = false; ++ctx->annotation_serial;
 	return AGPU_OK;
 }
 

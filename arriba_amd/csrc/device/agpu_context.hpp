@@ -114,6 +114,8 @@ struct agpu_ctx {
 	bool genomic_support_marked = false;
 	uint32_t confidence_candidates = 0xFFFFFFFFu; // n_candidates of the last agpu_assign_confidence (its result stays in scratch "events.confidence")
 	agpu::GenomicSupport genomic_support() { agpu::GenomicSupport wgs = { genomic_support_marked ? cand_closest1.as<int32_t>() : nullptr, genomic_support_marked ? cand_closest2.as<int32_t>() : nullptr }; return wgs; }
+	uint64_t annotation_serial = 1, gene_read_counts_of_annotation = 0; // every annotate of a batch takes a new serial; scratch "events.gene_read_count" holds the counts of that one
+	std::vector<uint32_t> host_gene_read_counts;
 	uint64_t global_n = 0; // fragments of the whole sample when this context holds one shard of it (agpu_set_shard); 0 = not sharded
 
 	// scratch

@@ -204,13 +204,17 @@ int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& th
 	const uint64_t n = ctx->n;
 	const size_t n_genes = (size_t) ctx->n_genes + ctx->n_dummy;
 	DeviceBuffer& gene_read_count = ctx->scratch("events.gene_read_count");
-	ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4);
-	HIP_CHECK(hipMemsetAsync(gene_read_count.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
-	if (n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", n * 22); gene_read_count_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, gene_read_count.as<uint32_t>()); }
-	std::vector<uint32_t> host_counts(n_genes);
-	if (n_genes > 0) HIP_CHECK(hipMemcpyAsync(host_counts.data(), gene_read_count.ptr, n_genes * 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	threshold = high_expression_threshold(host_counts, high_expression_quantile);
+	// (the counts depend on the gene sets of the fragments alone: filter_in_vitro and recover_both_spliced ask for them one after the other, counted once per annotation)
+	if (ctx->gene_read_counts_of_annotation != ctx->annotation_serial || ctx->host_gene_read_counts.size() != n_genes) {
+		ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4);
+		HIP_CHECK(hipMemsetAsync(gene_read_count.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
+		if (n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", n * 22); gene_read_count_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, gene_read_count.as<uint32_t>()); }
+		ctx->host_gene_read_counts.assign(n_genes, 0);
+		if (n_genes > 0) HIP_CHECK(hipMemcpyAsync(ctx->host_gene_read_counts.data(), gene_read_count.ptr, n_genes * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		ctx->gene_read_counts_of_annotation = ctx->annotation_serial;
+	}
+	threshold = high_expression_threshold(ctx->host_gene_read_counts, high_expression_quantile);
 	return AGPU_OK;
 }
 
