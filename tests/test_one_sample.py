@@ -37,3 +37,23 @@ def test_one_sample_over_ranks_equals_single_process(world, name, dataset_files,
     report = check_reports(run_one_sample(dataset_files(name), world, "emu", str(tmp_path / "report"), 29700 + world + (10 if name == "scrambled3k" else 0)))
     assert sum(1 for size in report["part_bytes"] if size > 4096) == world  # every rank read a part of the file
     assert report["mismapper_jobs"] > 0 and report["fusions"] > 0
+
+
+@pytest.mark.parametrize("flags", [[], ["--per-rank-samples"]])
+def test_bench_with_two_ranks_prints_one_line(flags, built, emu_api, tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per GPU): rank 0 prints ONE JSON line with the contract's fields; by default the
+    ranks work on one sample (scaling: strong), with --per-rank-samples on a sample each (weak).  Run on the stepping harness with torch.cuda stubbed
+    (tests/bench_on_harness.py): only the control flow is under test."""
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(29741 + len(flags)),
+               os.path.join(ROOT, "tests", "bench_on_harness.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--fragments", "20000"] + flags
+    result = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=1500)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, result.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 0 and line["vs_baseline"] is None
+    assert line["scaling"] == ("weak" if flags else "strong")
+    assert ("one sample over 2 GPUs" in line["config"]["parallelism"]) == (not flags)
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
