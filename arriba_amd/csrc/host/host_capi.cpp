@@ -67,6 +67,7 @@ struct ahost_session {
 	// device ingest: the open file and what agpu_ingest_begin needs from its header
 	BamFeed* feed = nullptr;
 	bool device_batch = false;           // the fragments live on the device (ahost_adopt_device_ingest)
+	std::string formatted_rows;          // ahost_format_fusions: the rows of this rank's share of an output file, until the next call
 	std::vector<uint32_t> row_fragments; // device ingest: the fragment of every row of ingest.batch (ascending); empty = the batch holds every fragment
 	std::vector<uint32_t> tid_to_contig;
 	std::vector<uint64_t> window_offset;
@@ -235,7 +236,25 @@ int ahost_load_protein_domains(ahost_session* session, const char* path) {
 	catch (const std::exception& e) { g_error = e.what(); return -1; }
 }
 
+static int write_or_format_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
+                                   unsigned int part, unsigned int parts, std::string* text_of_part);
+
 int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps) {
+	if (!path) { g_error = "null argument"; return -1; }
+	return write_or_format_fusions(session, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_sequence_gaps, 0, 1, NULL);
+}
+
+int ahost_format_fusions(ahost_session* session, const ahost_fusion_table* table, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
+                         unsigned int part, unsigned int parts, const char** text, uint64_t* bytes) {
+	if (!session || !text || !bytes || parts == 0 || part >= parts) { g_error = "null argument"; return -1; }
+	session->formatted_rows.clear();
+	const int status = write_or_format_fusions(session, table, "", write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_sequence_gaps, part, parts, &session->formatted_rows);
+	*text = session->formatted_rows.data(); *bytes = session->formatted_rows.size();
+	return status;
+}
+
+static int write_or_format_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
+                                   unsigned int part, unsigned int parts, std::string* text_of_part) {
 	if (!session || !table || !path) { g_error = "null argument"; return -1; }
 	if (!session->have_batch) { g_error = "no BAM ingested yet"; return -1; }
 	try {
@@ -245,7 +264,8 @@ int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table,
 		t.flags = table->flags; t.filter = table->filter; t.split_reads1 = table->split_reads1; t.split_reads2 = table->split_reads2; t.discordant_mates = table->discordant_mates;
 		t.list_offset = table->list_offset; t.read_lists = table->read_lists; t.evalue = table->evalue; t.confidence = table->confidence; t.iteration_rank = table->iteration_rank;
 		t.read_filter = table->read_filter; t.closest_genomic_breakpoint1 = table->closest_genomic_breakpoint1; t.closest_genomic_breakpoint2 = table->closest_genomic_breakpoint2; t.n_genes = table->n_genes; t.gene_contig = table->gene_contig; t.gene_start = table->gene_start; t.gene_end = table->gene_end;
-		const OutputExtras extras = { &session->tags, &session->protein_domains, &session->protein_domain_index, max_mate_gap, fill_sequence_gaps != 0 };
+		OutputExtras extras = { &session->tags, &session->protein_domains, &session->protein_domain_index, max_mate_gap, fill_sequence_gaps != 0 };
+		extras.part = part; extras.parts = parts; extras.text_of_part = text_of_part;
 		// device ingest: the batch of the session holds only the rows fetched for this table (ahost_set_batch_rows); the read lists of the candidates
 		// that get written and the filter column are translated from fragments to rows
 		std::vector<uint32_t> lists_as_rows; std::vector<uint8_t> filter_of_rows;

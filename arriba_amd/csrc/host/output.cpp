@@ -283,8 +283,14 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 	}
 
 	profile_mark("genes indexed, rows sorted");
-	FILE* out = fopen(path.c_str(), "w");
-	if (out == NULL) throw std::runtime_error("failed to open output file");
+	const bool to_text = extras.text_of_part != NULL;
+	if (to_text && extras.parts > 1) { // this rank's share of the rows, in their order
+		std::vector<Fusion> mine;
+		for (size_t r = extras.part; r < rows.size(); r += extras.parts) mine.push_back(rows[r]);
+		rows.swap(mine);
+	}
+	FILE* out = to_text ? NULL : fopen(path.c_str(), "w");
+	if (out == NULL && !to_text) throw std::runtime_error("failed to open output file");
 	std::string text = "#gene1\tgene2\tstrand1(gene/fusion)\tstrand2(gene/fusion)\tbreakpoint1\tbreakpoint2\tsite1\tsite2\ttype\tsplit_reads1\tsplit_reads2\tdiscordant_mates\tcoverage1\tcoverage2\tconfidence\treading_frame\ttags\t"
 	                   "retained_protein_domains\tclosest_genomic_breakpoint1\tclosest_genomic_breakpoint2\tgene_id1\tgene_id2\ttranscript_id1\ttranscript_id2\tdirection1\tdirection2\tfilters\tfusion_transcript\tpeptide_sequence\tread_identifiers\n";
 	static const char* const confidence_names[] = { "low", "medium", "high", "high" };
@@ -420,15 +426,21 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			for (unsigned int t = 0; t < std::min<size_t>(n_threads, count); ++t) threads.push_back(std::thread(work));
 			for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
 		}
-		if (failure) { fclose(out); std::rethrow_exception(failure); }
+		if (failure) { if (out) fclose(out); std::rethrow_exception(failure); }
 		for (size_t k = 0; k < count; ++k) {
 			if (!row_warnings[k].empty()) fputs(row_warnings[k].c_str(), stderr);
 			text += row_text[k];
 		}
+		if (to_text) continue; // (collected below)
 		if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fclose(out); throw std::runtime_error("failed to write to file"); }
 		text.clear();
 	}
 	profile_mark("rows formatted and written");
+	if (to_text) {
+		if (extras.part != 0) text.erase(0, text.find('\n') + 1); // the header line travels with part 0
+		extras.text_of_part->append(text);
+		return;
+	}
 	if (profile) fprintf(stderr, "[writer] thread time: fusion transcripts %.3f s, best-fitting transcripts %.3f s, peptides %.3f s\n", profile_ns[0] * 1e-9, profile_ns[1] * 1e-9, profile_ns[2] * 1e-9);
 	const bool ok = fwrite(text.data(), 1, text.size(), out) == text.size();
 	if (fclose(out) != 0 || !ok) throw std::runtime_error("failed to write to file");

@@ -16,7 +16,12 @@ struct FusionTable {
 	const int32_t* closest_genomic_breakpoint1; const int32_t* closest_genomic_breakpoint2; // NULL = none
 	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end; // GTF genes + dummy genes (agpu_get_gene_table)
 };
-struct OutputExtras { const Tags* tags; const std::vector<ProteinDomain>* protein_domains; const FlatIndex* protein_domain_index; int max_mate_gap; bool fill_sequence_gaps; }; // -t, -p (NULL = not given), -I
+struct OutputExtras {
+	const Tags* tags; const std::vector<ProteinDomain>* protein_domains; const FlatIndex* protein_domain_index; int max_mate_gap; bool fill_sequence_gaps; // -t, -p (NULL = not given), -I
+	// one sample over several ranks: the rows part, part + parts, ... of the file are formatted and appended to *text_of_part (the header line in front of them
+	// for part 0); nothing is written to `path`.  The rows are independent of each other; whoever holds the texts of all parts interleaves them.
+	unsigned part = 0, parts = 1; std::string* text_of_part = NULL;
+};
 // reference: write_fusions_to_file (source/output_fusions.cpp:1043-1261)
 void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_index, const Contigs& contigs, const Assembly& assembly, const Coverage& coverage, const Batch* batch, const FusionTable& table,
                            const std::string& path, bool write_discarded, bool print_extra_info, unsigned max_itd_length, const OutputExtras& extras);

@@ -9,7 +9,7 @@ Where the time of a large sample goes on one GPU (profiles/r02g_bench100m.json: 
   all stages up to filter_homologs   1.3 s   run on every rank over the whole batch: identical results without a single exchange
   filter_mismappers          72 s     the re-alignments are independent per read: rank r takes the jobs r, r + N, r + 2N, ...
   -- ONE all-reduce (max) of the verdict bytes
-  output files               5.8 s    rank 0 writes them
+  output files               5.8 s    every rank formats the rows r, r + N, ... (the fusion transcripts from the read pileups), rank 0 gathers the texts and writes
 
 So the two exchanges are large and few, as point-to-point xGMI links like them, and everything the reference computes in an order-dependent way
 (source/fusions.cpp, source/filter_duplicates.cpp, the sequential float sums of source/read_stats.cpp) runs unsharded and stays bit-identical by
@@ -29,7 +29,7 @@ from .pipeline import ArribaError, DevicePipeline
 
 class OneSamplePipeline(DevicePipeline):
     """DevicePipeline whose read_chimeric_alignments and filter_mismappers are shared out over the ranks of `group`; after the constructor every rank holds
-    the whole batch.  run_workflow() writes the output files on rank 0 only."""
+    the whole batch.  The rows of the output files are formatted by all ranks and written by rank 0."""
 
     def __init__(self, session, bam, params=None, api=None, device=0, group=None, external_duplicate_marking=False, max_itd_length=100, piece_bytes=64 << 20, profiling=False):
         self.group = group
@@ -112,8 +112,30 @@ class OneSamplePipeline(DevicePipeline):
         self.exchange["mismapper_jobs"] = n_jobs.value
         return remaining.value, discarded.value
 
-    def write_fusions(self, path, *args, **kwargs):
-        """every rank holds the same candidates; rank 0 writes"""
-        if self.rank == 0:
-            return super().write_fusions(path, *args, **kwargs)
-        return None
+    def _emit_fusions(self, view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps):
+        """Every rank holds the same candidates and the rows of their supporting reads: rank r formats the rows r, r + N, r + 2N, ... of the file (the fusion transcripts
+        from the pileups of the supporting reads are the expensive part), the texts are gathered on rank 0, which interleaves them and writes the file."""
+        import ctypes
+        import numpy as np
+        lib = self.session._lib
+        text, size = ctypes.c_void_p(), c_uint64()
+        if lib.ahost_format_fusions(self.session._session, byref(view), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps),
+                                    self.rank, self.world, byref(text), byref(size)) != 0:
+            raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
+        sizes = self._all_gather_int(size.value)
+        width = max(max(sizes), 1)
+        mine = torch.zeros(width, dtype=torch.uint8)
+        if size.value:
+            mine[:size.value] = torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(text, ctypes.POINTER(ctypes.c_uint8)), shape=(size.value,)))
+        mine = mine.to(self.collective_device)
+        parts = [torch.zeros(width, dtype=torch.uint8, device=self.collective_device) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(mine, parts, dst=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        if self.rank != 0:
+            return
+        texts = [parts[r][:sizes[r]].cpu().numpy().tobytes() for r in range(self.world)]
+        header, _, texts[0] = texts[0].partition(b"\n")
+        rows = [text.split(b"\n")[:-1] if text else [] for text in texts]  # (every row ends with a newline)
+        with open(path, "wb") as out:
+            out.write(header + b"\n")
+            for k in range(sum(len(r) for r in rows)):
+                out.write(rows[k % self.world][k // self.world] + b"\n")

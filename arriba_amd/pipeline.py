@@ -606,10 +606,14 @@ class DevicePipeline(object):
             if lib.ahost_set_batch_rows(self.session._session, byref(rows), fragments.ctypes.data if fragments.size else None) != 0:
                 raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
             mark("rows into the session")
-        if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps)) != 0:
-            raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
+        self._emit_fusions(view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps)
         mark("ahost_write_fusions")
         self.writer_seconds = {name: round(at - marks[k][1], 4) for k, (name, at) in enumerate(marks[1:])}  # where the time of the output side went (bench.py reports it)
+
+    def _emit_fusions(self, view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps):
+        """the rows of the file from the table of the candidates it holds (the host library's writer)"""
+        if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps)) != 0:
+            raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
 
     def mark_genomic_support(self, path, max_distance=100000):
         """reference: mark_genomic_support, source/filter_genomic_support.cpp:81-219 (-d, -D); returns the number of candidates with a supporting structural variant"""

@@ -81,6 +81,11 @@ typedef struct {
 } ahost_fusion_table;
 int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap,
                         int fill_sequence_gaps /* -I: complete the fusion transcript from the assembly along the chosen transcripts */);
+/* One sample over several ranks that hold the same candidates: the rows part, part + parts, part + 2 parts, ... of the file ahost_write_fusions would write, as text
+ * (the header line in front of the rows of part 0); *text stays valid until the next call.  Rows are independent of each other: the rank that gathers the texts of all
+ * parts writes row k of the file from the text of part k % parts. */
+int ahost_format_fusions(ahost_session* session, const ahost_fusion_table* table, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
+                         unsigned int part, unsigned int parts, const char** text, uint64_t* bytes);
 /* the fragments whose rows ahost_write_fusions(table, write_discarded, print_extra_info = 1) reads: the supporting reads of the candidates it writes, ascending, unique.
  * Call with fragments == NULL to get the number in *count.  (Without print_extra_info the writer needs no rows.) */
 int ahost_fusion_table_reads(const ahost_fusion_table* table, int write_discarded, uint32_t* fragments, uint64_t capacity, uint64_t* count);
