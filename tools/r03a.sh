@@ -1,0 +1,12 @@
+#!/bin/bash
+# First GPU run of round 3 (written at the end of round 2, when the GPU budget was spent): the measurements DESIGN.md section 8 asks for.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/r03a.sh'
+mkdir -p gpurun_out
+# 1. the GPU tier of the code as round 2 left it (31 tests; the sort path of agpu_shard_merge and the name-key check run on the GPU for the first time)
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/r03a_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/r03a_pytest_gpu.log
+# 2. 10 M end to end: the output side reworked, the task list of the second mismapper pass (on / off), the writer's own profile
+timeout 120 python bench.py --fragments 10000000 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r03a_bench10m.json 2> gpurun_out/r03a_bench10m.err; echo "bench exit $?"; cut -c1-300 gpurun_out/r03a_bench10m.json
+ARRIBA_MISMAPPER_WORKLIST=0 timeout 120 python bench.py --fragments 10000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03a_bench10m_recursion.json 2> gpurun_out/r03a_bench10m_recursion.err; echo "bench exit $?"; cut -c1-300 gpurun_out/r03a_bench10m_recursion.json
+ARRIBA_WRITER_PROFILE=1 timeout 120 python bench.py --fragments 10000000 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/r03a_writer_profile.err; grep "writer\]\|step done" gpurun_out/r03a_writer_profile.err | tail -12 | cut -c1-400
+# 3. the 100 M sample, one step
+timeout 600 python bench.py --fragments 100000000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/r03a_bench100m.json 2> gpurun_out/r03a_bench100m.err; echo "bench exit $?"; cut -c1-300 gpurun_out/r03a_bench100m.json; grep "step done" gpurun_out/r03a_bench100m.err | cut -c1-600
