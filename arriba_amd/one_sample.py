@@ -51,11 +51,27 @@ class OneSamplePipeline(DevicePipeline):
         dist.all_gather(out, mine, group=self.group)
         return [int(t.item()) for t in out]
 
+    def _together(self, work):
+        """runs work() and tells the other ranks how it went before anybody enters the next collective: an error on one rank (a damaged block in its part of the file,
+        no memory) ends the run on all of them with a message instead of leaving the others waiting in an all-gather"""
+        error, result = None, None
+        try:
+            result = work()
+        except ArribaError as problem:
+            error = problem
+        ok = torch.tensor([0 if error else 1], dtype=torch.int64, device=self.collective_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if error:
+            raise error
+        if int(ok.item()) == 0:
+            raise ArribaError("ERROR: another rank of the sample failed (its own message says why)")
+        return result
+
     def read_chimeric_alignments(self, bam, external_duplicate_marking=False, max_itd_length=100, piece_bytes=64 << 20):
         """reference: read_chimeric_alignments (source/read_chimeric_alignments.cpp:560-773): this rank's part of the records, then the parts of all ranks"""
         import time
         started = time.perf_counter()
-        config, _, fed = self._ingest_records(bam, external_duplicate_marking, max_itd_length, piece_bytes, part=self.rank, parts=self.world)
+        config, _, fed = self._together(lambda: self._ingest_records(bam, external_duplicate_marking, max_itd_length, piece_bytes, part=self.rank, parts=self.world))
         ingested = time.perf_counter()
         self._record("read_chimeric_alignments")
         size = c_uint64()
@@ -74,7 +90,7 @@ class OneSamplePipeline(DevicePipeline):
         self._sync()
         gathered = time.perf_counter()
         result = _capi.IngestResult()
-        self._check(self.api.shard_merge(self.ctx, blocks.data_ptr(), stride, self.world, byref(result)))
+        self._together(lambda: self._check(self.api.shard_merge(self.ctx, blocks.data_ptr(), stride, self.world, byref(result))))
         del blocks, mine
         if self.collective_device.type == "cuda":
             torch.cuda.empty_cache()  # the buffers of the exchange (the size of the whole batch) go back to the device: the stages allocate through the C ABI, not through torch
@@ -96,7 +112,7 @@ class OneSamplePipeline(DevicePipeline):
         spent = dict(self.timings["filter_mismappers"])
         verdicts = torch.zeros(max(n_jobs.value, 1), dtype=torch.uint8, device=self.collective_device)
         self._sync()
-        self._check(self.api.mismapper_verdicts(self.ctx, max_mate_gap, self.rank, self.world, verdicts.data_ptr()))
+        self._together(lambda: self._check(self.api.mismapper_verdicts(self.ctx, max_mate_gap, self.rank, self.world, verdicts.data_ptr())))
         self._record("filter_mismappers")
         spent["ms"] += self.timings["filter_mismappers"]["ms"]
         self._sync()
@@ -119,9 +135,11 @@ class OneSamplePipeline(DevicePipeline):
         import numpy as np
         lib = self.session._lib
         text, size = ctypes.c_void_p(), c_uint64()
-        if lib.ahost_format_fusions(self.session._session, byref(view), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps),
-                                    self.rank, self.world, byref(text), byref(size)) != 0:
-            raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
+        def format_rows():
+            if lib.ahost_format_fusions(self.session._session, byref(view), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps),
+                                        self.rank, self.world, byref(text), byref(size)) != 0:
+                raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
+        self._together(format_rows)
         sizes = self._all_gather_int(size.value)
         width = max(max(sizes), 1)
         mine = torch.zeros(width, dtype=torch.uint8)

@@ -57,3 +57,19 @@ def test_bench_with_two_ranks_prints_one_line(flags, built, emu_api, tmp_path):
     assert line["scaling"] == ("weak" if flags else "strong")
     assert ("one sample over 2 GPUs" in line["config"]["parallelism"]) == (not flags)
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_an_error_on_one_rank_ends_the_run_on_all(dataset_files, emu_api, tmp_path):
+    """A damaged BGZF block in the last third of the file: the rank that reads it fails with the reference's message, the others are told before they enter the
+    all-gather of the parts -- nobody is left waiting in a collective."""
+    import test_host_and_device_logic as host_tests
+    prefix = dataset_files("mid30k")
+    damaged = str(tmp_path / "damaged.bam")
+    host_tests._write_bgzf(damaged, host_tests._bam_payload(prefix + ".bam"), 6)
+    raw = bytearray(open(damaged, "rb").read())
+    raw[len(raw) * 5 // 6] ^= 0x5A
+    open(damaged, "wb").write(bytes(raw))
+    reports = run_one_sample(prefix, 3, "emu", str(tmp_path / "report"), 29731, bam=damaged)
+    assert "failed to load alignments" in reports[2]["error"], reports[2]  # (the rank in front of it may meet the block, too, when it looks for the end of its part)
+    assert "another rank of the sample failed" in reports[0]["error"], reports[0]
+    assert all("error" in report for report in reports)
