@@ -652,6 +652,25 @@ def test_workflow_with_library_options_against_the_live_reference(label, options
     assert stages[-1][1] > 100
 
 
+INDEL_SPEC = {"args": ["--seed", "303", "--fragments", "30000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--indels", "1.0"]}
+
+
+@pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
+def test_workflow_with_insertions_and_deletions_against_the_live_reference(emu_api, tmp_path):
+    """Every mate and discordant mate differs from the assembly by a short insertion or deletion (CIGAR operations I and D: the golden datasets have none):
+    the device ingest, the mismatch filters, the pileups of the fusion transcripts (inserted bases in brackets, deleted ones as dashes, uncertain ones as
+    question marks) -- counts and both files equal the reference's"""
+    prefix = datasets.generate(INDEL_SPEC, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, INDEL_SPEC))
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, device_ingest=True)
+    transcripts = [line.split("\t")[27] for line in open(prefix + ".fusions.tsv") if not line.startswith("#")]
+    assert stages[-1][1] > 100 and sum("[" in t for t in transcripts) > 10 and sum("-" in t for t in transcripts) > 10 and sum("?" in t for t in transcripts) > 0
+
+
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
 @pytest.mark.parametrize("disabled", [["mismappers"], ["homologs", "mismappers"], []])
 def test_workflow_with_mismappers_switched_off_against_the_live_reference(disabled, emu_api, tmp_path):

@@ -626,7 +626,7 @@ struct Builder {
 	Rng& rng;
 
 	// n bases starting at genomic position p moving right/left along the transcript (if p lies in one of its exons), after skipping `skip` bases
-	Aln build(int contig, int gene, int p, bool to_right, int skip, int n) const {
+	Aln build(int contig, int gene, int p, bool to_right, int skip, int n, bool may_have_indel = false) const {
 		std::vector<Exon> segments;
 		const Transcript* transcript = (gene >= 0) ? &genes[gene].transcripts[0] : NULL;
 		int exon_index = -1;
@@ -696,11 +696,30 @@ struct Builder {
 		if (segments.back().end >= limit) { int d = segments.back().end - limit + 1; for (size_t i = 0; i < segments.size(); ++i) { segments[i].start -= d; segments[i].end -= d; } }
 		aln.start = segments.front().start;
 		aln.end = segments.back().end;
+		bool indel_pending = may_have_indel && c.frac_indels > 0 && rng.chance(c.frac_indels);
 		for (size_t i = 0; i < segments.size(); ++i) {
 			if (i > 0)
 				aln.cigar.push_back(cig(segments[i].start - segments[i - 1].end - 1, OP_N));
-			aln.cigar.push_back(cig(segments[i].end - segments[i].start + 1, OP_M));
-			aln.seq.append(sequences[contig], segments[i].start, segments[i].end - segments[i].start + 1);
+			const int length = segments[i].end - segments[i].start + 1;
+			if (indel_pending && length >= 40) { // the read differs from the assembly by a short insertion or deletion; the segment keeps its place on the reference
+				indel_pending = false;
+				const int a = rng.range(15, length - 20), k = rng.range(1, 3);
+				aln.cigar.push_back(cig(a, OP_M));
+				aln.seq.append(sequences[contig], segments[i].start, a);
+				if (rng.chance(0.5)) {
+					aln.cigar.push_back(cig(k, OP_D));
+					aln.cigar.push_back(cig(length - a - k, OP_M));
+					aln.seq.append(sequences[contig], segments[i].start + a + k, length - a - k);
+				} else {
+					aln.cigar.push_back(cig(k, OP_I));
+					for (int b = 0; b < k; ++b) aln.seq.push_back("ACGT"[rng.below(4)]);
+					aln.cigar.push_back(cig(length - a, OP_M));
+					aln.seq.append(sequences[contig], segments[i].start + a, length - a);
+				}
+				continue;
+			}
+			aln.cigar.push_back(cig(length, OP_M));
+			aln.seq.append(sequences[contig], segments[i].start, length);
 		}
 		return aln;
 	}
@@ -769,7 +788,7 @@ struct Builder {
 		Aln split = build(y.contig, y.gene, y.bp, y.upstream, 0, anchored);
 		Aln supplementary = build(x.contig, x.gene, x.bp, x.upstream, 0, clip);
 		int offset = rng.range(std::max(0, anchored - 60), anchored + 200);
-		Aln mate = build(y.contig, y.gene, y.bp, y.upstream, offset, L);
+		Aln mate = build(y.contig, y.gene, y.bp, y.upstream, offset, L, true);
 		bool split_forward = y.upstream;
 		bool supplementary_forward = !x.upstream;
 		std::string clipped = (split_forward == supplementary_forward) ? supplementary.seq : revcomp(supplementary.seq);
@@ -866,8 +885,8 @@ struct Builder {
 			spliced.cigar.insert(spliced.cigar.end(), second.cigar.begin(), second.cigar.end());
 			spliced.seq = first.seq + second.seq;
 			bool spliced_is_forward = rng.chance(0.5);
-			Aln other = spliced_is_forward ? build(right.contig, pair.second, acceptor.start, true, rng.range(L - a, L - a + 150), L)
-			                               : build(left.contig, pair.first, donor.end, false, rng.range(a, a + 150), L);
+			Aln other = spliced_is_forward ? build(right.contig, pair.second, acceptor.start, true, rng.range(L - a, L - a + 150), L, true)
+			                               : build(left.contig, pair.first, donor.end, false, rng.range(a, a + 150), L, true);
 			Record mate;
 			mate.contig = other.contig; mate.pos = other.start; mate.cigar = other.cigar; mate.seq = other.seq; mate.sa = false;
 			bool spliced_is_read1 = rng.chance(0.5);
@@ -877,8 +896,8 @@ struct Builder {
 		} else { // forward mate in the left gene, reverse mate in the right gene
 			const Exon& le = tl.exons.back();
 			const Exon& re = tr.exons.front();
-			Aln forward = build(left.contig, pair.first, le.end, false, rng.range(0, 60), L);
-			Aln reverse = build(right.contig, pair.second, re.start, true, rng.range(0, 60), L);
+			Aln forward = build(left.contig, pair.first, le.end, false, rng.range(0, 60), L, true);
+			Aln reverse = build(right.contig, pair.second, re.start, true, rng.range(0, 60), L, true);
 			bool forward_is_read1 = rng.chance(0.5);
 			fragment[0].contig = forward.contig; fragment[0].pos = forward.start; fragment[0].cigar = forward.cigar; fragment[0].seq = forward.seq; fragment[0].sa = false;
 			fragment[0].flag = F_PAIRED | F_PROPER | F_MREVERSE | (forward_is_read1 ? F_READ1 : F_READ2);
@@ -1293,7 +1312,7 @@ static void usage() {
 	fprintf(stderr,
 		"usage: gen_synth --out PREFIX [--seed N] [--fragments N] [--normal-mult X] [--contigs N] [--contig-len N]\n"
 		"                 [--genes-per-mb X] [--read-len N] [--junctions N] [--clip-min N] [--clip-max N]\n"
-		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--shuffle] [--separate-mates]\n"
+		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--shuffle] [--separate-mates]\n"
 		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH] [--threads N] [--bam-only]\n"
 		"writes PREFIX.fa PREFIX.gtf PREFIX.bam\n");
 }
@@ -1328,6 +1347,7 @@ int main(int argc, char** argv) {
 		else if (a == "--dup") config.frac_duplicates = atof(value());
 		else if (a == "--multimap") config.frac_multimappers = atof(value());
 		else if (a == "--partner-clip") config.frac_clip_from_partner = atof(value());
+		else if (a == "--indels") config.frac_indels = atof(value());
 		else if (a == "--shuffle") config.shuffle_names = true;
 		else if (a == "--separate-mates") config.separate_mates = true;
 		else if (a == "--stranded") config.stranded = true;
