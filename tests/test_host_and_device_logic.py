@@ -652,14 +652,14 @@ def test_workflow_with_library_options_against_the_live_reference(label, options
     assert stages[-1][1] > 100
 
 
-INDEL_SPEC = {"args": ["--seed", "303", "--fragments", "30000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--indels", "1.0"]}
+INDEL_SPEC = {"args": ["--seed", "303", "--fragments", "30000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--indels", "1.0", "--non-template", "0.5"]}
 
 
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
 def test_workflow_with_insertions_and_deletions_against_the_live_reference(emu_api, tmp_path):
-    """Every mate and discordant mate differs from the assembly by a short insertion or deletion (CIGAR operations I and D: the golden datasets have none):
-    the device ingest, the mismatch filters, the pileups of the fusion transcripts (inserted bases in brackets, deleted ones as dashes, uncertain ones as
-    question marks) -- counts and both files equal the reference's"""
+    """Every mate and discordant mate differs from the assembly by a short insertion or deletion (CIGAR operations I and D), half of the junctions have bases
+    between the genes that belong to neither (the golden datasets have none of these): the device ingest, the mismatch filters, the pileups of the fusion transcripts
+    (inserted bases in brackets, deleted ones as dashes, uncertain ones as question marks, non-template bases between pipes) -- counts and both files equal the reference's"""
     prefix = datasets.generate(INDEL_SPEC, str(tmp_path))
     dump = str(tmp_path / "dump")
     os.makedirs(dump)
@@ -669,6 +669,7 @@ def test_workflow_with_insertions_and_deletions_against_the_live_reference(emu_a
     stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, device_ingest=True)
     transcripts = [line.split("\t")[27] for line in open(prefix + ".fusions.tsv") if not line.startswith("#")]
     assert stages[-1][1] > 100 and sum("[" in t for t in transcripts) > 10 and sum("-" in t for t in transcripts) > 10 and sum("?" in t for t in transcripts) > 0
+    assert sum(t.count("|") > 1 for t in transcripts) > 30
 
 
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")

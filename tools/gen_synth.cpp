@@ -805,6 +805,17 @@ struct Builder {
 					if (rng.chance(0.05)) clipped[i] = random_base(rng);
 			}
 		}
+		// non-template bases: the same ones in every split read of the junction, between the aligned part and the clipped part (neither alignment covers them)
+		std::string non_template;
+		if (c.frac_non_template > 0) {
+			uint64_t h = (uint64_t) (uint32_t) junction.a.bp * 0x9E3779B97F4A7C15ull ^ (uint64_t) (uint32_t) junction.b.bp * 0xC2B2AE3D27D4EB4Full;
+			h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+			if ((double) (h % 10000) < c.frac_non_template * 10000) {
+				const int k = 1 + (int) ((h >> 16) % 3);
+				for (int b = 0; b < k; ++b) non_template.push_back("ACGT"[(h >> (20 + 2 * b)) & 3]);
+			}
+		}
+		const int extra = (int) non_template.size();
 		bool junction_read_is_read1 = rng.chance(0.5);
 		if (c.stranded) { // read1 is sense to the transcript: approximate via the split read's gene strand
 			bool gene_plus = (y.gene >= 0) ? genes[y.gene].plus : true;
@@ -814,16 +825,16 @@ struct Builder {
 		Record& r0 = fragment[0];
 		r0.flag = F_PAIRED | F_PROPER | (split_forward ? F_MREVERSE : F_REVERSE) | (junction_read_is_read1 ? F_READ1 : F_READ2);
 		r0.contig = split.contig; r0.pos = split.start; r0.sa = true;
-		if (split_forward) { r0.cigar.push_back(cig(clip, OP_S)); r0.cigar.insert(r0.cigar.end(), split.cigar.begin(), split.cigar.end()); r0.seq = clipped + split.seq; }
-		else { r0.cigar = split.cigar; r0.cigar.push_back(cig(clip, OP_S)); r0.seq = split.seq + clipped; }
+		if (split_forward) { r0.cigar.push_back(cig(clip + extra, OP_S)); r0.cigar.insert(r0.cigar.end(), split.cigar.begin(), split.cigar.end()); r0.seq = clipped + non_template + split.seq; }
+		else { r0.cigar = split.cigar; r0.cigar.push_back(cig(clip + extra, OP_S)); r0.seq = split.seq + non_template + clipped; }
 		Record& r1 = fragment[1];
 		r1.flag = F_PAIRED | F_PROPER | (split_forward ? F_REVERSE : F_MREVERSE) | (junction_read_is_read1 ? F_READ2 : F_READ1);
 		r1.contig = mate.contig; r1.pos = mate.start; r1.cigar = mate.cigar; r1.seq = mate.seq; r1.sa = false;
 		Record& r2 = fragment[2];
 		r2.flag = F_PAIRED | F_SUPPLEMENTARY | (supplementary_forward ? 0 : F_REVERSE) | (split_forward ? F_MREVERSE : 0) | (junction_read_is_read1 ? F_READ1 : F_READ2);
 		r2.contig = supplementary.contig; r2.pos = supplementary.start; r2.seq = supplementary.seq; r2.sa = true;
-		if (supplementary_forward) { r2.cigar = supplementary.cigar; r2.cigar.push_back(cig(anchored, OP_H)); }
-		else { r2.cigar.push_back(cig(anchored, OP_H)); r2.cigar.insert(r2.cigar.end(), supplementary.cigar.begin(), supplementary.cigar.end()); }
+		if (supplementary_forward) { r2.cigar = supplementary.cigar; r2.cigar.push_back(cig(anchored + extra, OP_H)); }
+		else { r2.cigar.push_back(cig(anchored + extra, OP_H)); r2.cigar.insert(r2.cigar.end(), supplementary.cigar.begin(), supplementary.cigar.end()); }
 		return fragment;
 	}
 
@@ -1312,7 +1323,7 @@ static void usage() {
 	fprintf(stderr,
 		"usage: gen_synth --out PREFIX [--seed N] [--fragments N] [--normal-mult X] [--contigs N] [--contig-len N]\n"
 		"                 [--genes-per-mb X] [--read-len N] [--junctions N] [--clip-min N] [--clip-max N]\n"
-		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--shuffle] [--separate-mates]\n"
+		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--non-template X] [--shuffle] [--separate-mates]\n"
 		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH] [--threads N] [--bam-only]\n"
 		"writes PREFIX.fa PREFIX.gtf PREFIX.bam\n");
 }
@@ -1348,6 +1359,7 @@ int main(int argc, char** argv) {
 		else if (a == "--multimap") config.frac_multimappers = atof(value());
 		else if (a == "--partner-clip") config.frac_clip_from_partner = atof(value());
 		else if (a == "--indels") config.frac_indels = atof(value());
+		else if (a == "--non-template") config.frac_non_template = atof(value());
 		else if (a == "--shuffle") config.shuffle_names = true;
 		else if (a == "--separate-mates") config.separate_mates = true;
 		else if (a == "--stranded") config.stranded = true;
