@@ -457,21 +457,14 @@ def test_workflow_with_non_default_options_against_the_live_reference(built, tmp
     assert dict(stages)["mark_genomic_support"] > 1000 and stages[-1][1] > 200
 
 
-def test_workflow_with_insertions_and_deletions_against_the_live_reference(built, tmp_path):
-    """CIGAR operations I and D in every mate (the golden datasets have none) through the kernels of the GPU: device ingest, mismatch filters, candidate stages, and the
-    fusion transcripts of the output file (inserted bases in brackets, deleted ones as dashes) against the reference run live"""
+@pytest.mark.parametrize("kind", ["indels_and_non_template_bases", "single_end", "long_reads_multimappers", "short_stranded_single_end"])
+def test_workflow_on_other_kinds_of_libraries_against_the_live_reference(kind, built, tmp_path):
+    """CIGAR operations I and D, non-template bases, single-end libraries, reads of 60 and 150 nt (the golden datasets have none of these) through the kernels of the GPU,
+    against the reference run live: every count and both output files"""
     if not datasets.reference_available():
         pytest.skip("needs the oracle build of the reference (oracle/_ref)")
     import test_host_and_device_logic as cpu_tier
-    prefix = datasets.generate(cpu_tier.INDEL_SPEC, str(tmp_path))
-    dump = str(tmp_path / "dump")
-    os.makedirs(dump)
-    with open(os.path.join(dump, "reference.log"), "w") as out:
-        out.write(datasets.run_reference(prefix, dump, cpu_tier.INDEL_SPEC))
-    os.makedirs(str(tmp_path / "mine"))
-    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True)
-    transcripts = [line.split("\t")[27] for line in open(prefix + ".fusions.tsv") if not line.startswith("#")]
-    assert stages[-1][1] > 100 and sum("[" in t for t in transcripts) > 10 and sum("-" in t for t in transcripts) > 10
+    cpu_tier.check_library_against_the_live_reference(kind, str(tmp_path))
 
 
 def test_cpp_workflow_driver_over_the_c_abis(built, dataset_files, tmp_path):

@@ -652,24 +652,44 @@ def test_workflow_with_library_options_against_the_live_reference(label, options
     assert stages[-1][1] > 100
 
 
-INDEL_SPEC = {"args": ["--seed", "303", "--fragments", "30000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--indels", "1.0", "--non-template", "0.5"]}
+# kinds of libraries and reads the golden datasets do not hold, compared with the reference run live (both tiers)
+LIBRARY_SPECS = {
+    # every mate differs from the assembly by a short insertion or deletion (CIGAR operations I and D), half of the junctions have bases between the genes that belong to neither
+    "indels_and_non_template_bases": ["--seed", "303", "--fragments", "30000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--indels", "1.0", "--non-template", "0.5"],
+    # a single-end library: split read + supplementary alignment, no mates, no pairing flags
+    "single_end": ["--seed", "505", "--fragments", "30000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--single-end"],
+    # reads of 150 nt, many multi-mapping reads
+    "long_reads_multimappers": ["--seed", "606", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--read-len", "150", "--indels", "0.3",
+                                "--non-template", "0.3", "--multimap", "0.2"],
+    # short single-end reads of a stranded library
+    "short_stranded_single_end": ["--seed", "707", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--read-len", "60", "--clip-min", "12",
+                                  "--clip-max", "30", "--single-end", "--stranded", "--multimap", "0.1"],
+}
+INDEL_SPEC = {"args": LIBRARY_SPECS["indels_and_non_template_bases"]}
+
+
+def check_library_against_the_live_reference(kind, directory, api=None):
+    spec = {"args": LIBRARY_SPECS[kind]}
+    prefix = datasets.generate(spec, directory)
+    dump = os.path.join(directory, "dump")
+    os.makedirs(dump)
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(datasets.run_reference(prefix, dump, spec))
+    os.makedirs(os.path.join(directory, "mine"))
+    stages = parity.check_workflow(prefix, dump, os.path.join(directory, "mine"), api=api, reference_prefix=prefix, device_ingest=True)
+    transcripts = [line.split("\t")[27] for line in open(prefix + ".fusions.tsv") if not line.startswith("#")]
+    assert stages[-1][1] > 100
+    if kind == "indels_and_non_template_bases":  # inserted bases in brackets, deleted ones as dashes, uncertain ones as question marks, non-template bases between pipes
+        assert sum("[" in t for t in transcripts) > 10 and sum("-" in t for t in transcripts) > 10 and sum("?" in t for t in transcripts) > 0 and sum(t.count("|") > 1 for t in transcripts) > 30
+    return stages
 
 
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
-def test_workflow_with_insertions_and_deletions_against_the_live_reference(emu_api, tmp_path):
-    """Every mate and discordant mate differs from the assembly by a short insertion or deletion (CIGAR operations I and D), half of the junctions have bases
-    between the genes that belong to neither (the golden datasets have none of these): the device ingest, the mismatch filters, the pileups of the fusion transcripts
-    (inserted bases in brackets, deleted ones as dashes, uncertain ones as question marks, non-template bases between pipes) -- counts and both files equal the reference's"""
-    prefix = datasets.generate(INDEL_SPEC, str(tmp_path))
-    dump = str(tmp_path / "dump")
-    os.makedirs(dump)
-    with open(os.path.join(dump, "reference.log"), "w") as out:
-        out.write(datasets.run_reference(prefix, dump, INDEL_SPEC))
-    os.makedirs(str(tmp_path / "mine"))
-    stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), api=emu_api, reference_prefix=prefix, device_ingest=True)
-    transcripts = [line.split("\t")[27] for line in open(prefix + ".fusions.tsv") if not line.startswith("#")]
-    assert stages[-1][1] > 100 and sum("[" in t for t in transcripts) > 10 and sum("-" in t for t in transcripts) > 10 and sum("?" in t for t in transcripts) > 0
-    assert sum(t.count("|") > 1 for t in transcripts) > 30
+@pytest.mark.parametrize("kind", sorted(LIBRARY_SPECS))
+def test_workflow_on_other_kinds_of_libraries_against_the_live_reference(kind, emu_api, tmp_path):
+    """Insertions and deletions in the reads, non-template bases at the junctions, single-end libraries, other read lengths: the device ingest, the mismatch
+    filters, find_fusions on fragments of two alignments, the pileups of the fusion transcripts -- every count and both files equal the reference's"""
+    check_library_against_the_live_reference(kind, str(tmp_path), emu_api)
 
 
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")

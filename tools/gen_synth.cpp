@@ -1111,6 +1111,13 @@ void Generator::stream_records(Rng& rng, uint64_t first_serial, long fragments, 
 			bool same_strand = ((primary.flag ^ supplementary.flag) & F_REVERSE) == 0;
 			supplementary.seq = same_strand ? clipped : revcomp(clipped);
 		}
+		if (c.single_end) { // the records of the read that the first record belongs to, without the flags of a paired library
+			Fragment kept;
+			const uint16_t read = fragment[0].flag & (F_READ1 | F_READ2);
+			for (size_t i = 0; i < fragment.size(); ++i)
+				if ((fragment[i].flag & (F_READ1 | F_READ2)) == read) { kept.push_back(fragment[i]); kept.back().flag &= (uint16_t) ~(F_PAIRED | F_PROPER | F_MREVERSE | F_READ1 | F_READ2); }
+			fragment.swap(kept);
+		}
 		for (size_t i = 0; i < fragment.size(); ++i) {
 			fragment[i].hi = hi;
 			fragment[i].nh = nh;
@@ -1323,7 +1330,7 @@ static void usage() {
 	fprintf(stderr,
 		"usage: gen_synth --out PREFIX [--seed N] [--fragments N] [--normal-mult X] [--contigs N] [--contig-len N]\n"
 		"                 [--genes-per-mb X] [--read-len N] [--junctions N] [--clip-min N] [--clip-max N]\n"
-		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--non-template X] [--shuffle] [--separate-mates]\n"
+		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--non-template X] [--single-end] [--shuffle] [--separate-mates]\n"
 		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH] [--threads N] [--bam-only]\n"
 		"writes PREFIX.fa PREFIX.gtf PREFIX.bam\n");
 }
@@ -1360,6 +1367,7 @@ int main(int argc, char** argv) {
 		else if (a == "--partner-clip") config.frac_clip_from_partner = atof(value());
 		else if (a == "--indels") config.frac_indels = atof(value());
 		else if (a == "--non-template") config.frac_non_template = atof(value());
+		else if (a == "--single-end") config.single_end = true;
 		else if (a == "--shuffle") config.shuffle_names = true;
 		else if (a == "--separate-mates") config.separate_mates = true;
 		else if (a == "--stranded") config.stranded = true;

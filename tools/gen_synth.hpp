@@ -48,6 +48,7 @@ struct Config {
 	double frac_clip_from_partner = 0.0; // mismapper stress: clipped segment copied from the partner gene
 	double frac_indels = 0.0;        // of the mates / discordant mates: a 1-3 base insertion or deletion inside the first long aligned segment (no random numbers are drawn when 0)
 	double frac_non_template = 0.0;  // of the junctions: 1-3 bases that belong to neither gene between the two parts of every split read (decided by the breakpoints: no random numbers are drawn)
+	bool single_end = false;         // a single-end library: of every fragment only the records of one read (a split read keeps its supplementary alignment), no pairing flags
 	bool shuffle_names = false;      // emit records so that BAM order != sorted name order
 	bool separate_mates = false;     // put other records between the two mates of a pair
 	bool viral = true;
