@@ -457,9 +457,10 @@ def test_workflow_with_non_default_options_against_the_live_reference(built, tmp
     assert dict(stages)["mark_genomic_support"] > 1000 and stages[-1][1] > 200
 
 
-@pytest.mark.parametrize("kind", ["indels_and_non_template_bases", "single_end", "long_reads_multimappers", "short_stranded_single_end"])
+@pytest.mark.parametrize("kind", ["indels_and_non_template_bases", "single_end", "long_reads_multimappers", "short_stranded_single_end", "soft_clips_and_n_bases"])
 def test_workflow_on_other_kinds_of_libraries_against_the_live_reference(kind, built, tmp_path):
-    """CIGAR operations I and D, non-template bases, single-end libraries, reads of 60 and 150 nt (the golden datasets have none of these) through the kernels of the GPU,
+    """CIGAR operations I and D, non-template bases, single-end libraries, reads of 60 and 150 nt, soft-clipped supplementary alignments, N bases (the golden datasets have
+    none of these) through the kernels of the GPU,
     against the reference run live: every count and both output files"""
     if not datasets.reference_available():
         pytest.skip("needs the oracle build of the reference (oracle/_ref)")

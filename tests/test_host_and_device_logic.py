@@ -661,6 +661,9 @@ LIBRARY_SPECS = {
     # reads of 150 nt, many multi-mapping reads
     "long_reads_multimappers": ["--seed", "606", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--read-len", "150", "--indels", "0.3",
                                 "--non-template", "0.3", "--multimap", "0.2"],
+    # supplementary alignments with soft clips and the whole read (STAR --chimOutType WithinBAM SoftClip), 5 % of the bases N, indels, non-template bases
+    "soft_clips_and_n_bases": ["--seed", "911", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--n-bases", "0.05",
+                               "--soft-clip-supplementary", "--non-template", "0.4", "--indels", "0.3"],
     # short single-end reads of a stranded library
     "short_stranded_single_end": ["--seed", "707", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--read-len", "60", "--clip-min", "12",
                                   "--clip-max", "30", "--single-end", "--stranded", "--multimap", "0.1"],

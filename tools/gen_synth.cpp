@@ -1110,6 +1110,30 @@ void Generator::stream_records(Rng& rng, uint64_t first_serial, long fragments, 
 			std::string clipped = (primary.cigar.front() & 15) == OP_S ? primary.seq.substr(0, clip) : primary.seq.substr(primary.seq.size() - clip);
 			bool same_strand = ((primary.flag ^ supplementary.flag) & F_REVERSE) == 0;
 			supplementary.seq = same_strand ? clipped : revcomp(clipped);
+			if (c.soft_clip_supplementary) { // the supplementary alignment carries the whole read, its unaligned part soft-clipped
+				for (size_t k = 0; k < supplementary.cigar.size(); ++k)
+					if ((supplementary.cigar[k] & 15) == OP_H) supplementary.cigar[k] = cig(supplementary.cigar[k] >> 4, OP_S);
+				supplementary.seq = same_strand ? primary.seq : revcomp(primary.seq);
+			}
+		}
+		if (c.frac_n_bases > 0) {
+			for (size_t i = 0; i < fragment.size(); ++i)
+				if (!(fragment.size() == 3 && i == 2)) // (the supplementary alignment takes the bases of its primary)
+					for (size_t p = 0; p < fragment[i].seq.size(); ++p)
+						if (rng.chance(c.frac_n_bases)) fragment[i].seq[p] = 'N';
+			if (fragment.size() == 3) {
+				const Record& primary = fragment[0]; Record& supplementary = fragment[2];
+				const bool same_strand = ((primary.flag ^ supplementary.flag) & F_REVERSE) == 0;
+				if (c.soft_clip_supplementary) supplementary.seq = same_strand ? primary.seq : revcomp(primary.seq);
+				else {
+					uint32_t clip = (primary.cigar.front() & 15) == OP_S ? primary.cigar.front() >> 4 : primary.cigar.back() >> 4;
+					// (with non-template bases the clipped part of the primary is longer than the supplementary alignment: its far end is what the supplementary holds)
+					std::string clipped = (primary.cigar.front() & 15) == OP_S ? primary.seq.substr(0, clip) : primary.seq.substr(primary.seq.size() - clip);
+					const size_t aligned = supplementary.seq.size();
+					if (clipped.size() >= aligned) clipped = (primary.cigar.front() & 15) == OP_S ? clipped.substr(0, aligned) : clipped.substr(clipped.size() - aligned);
+					supplementary.seq = same_strand ? clipped : revcomp(clipped);
+				}
+			}
 		}
 		if (c.single_end) { // the records of the read that the first record belongs to, without the flags of a paired library
 			Fragment kept;
@@ -1330,7 +1354,7 @@ static void usage() {
 	fprintf(stderr,
 		"usage: gen_synth --out PREFIX [--seed N] [--fragments N] [--normal-mult X] [--contigs N] [--contig-len N]\n"
 		"                 [--genes-per-mb X] [--read-len N] [--junctions N] [--clip-min N] [--clip-max N]\n"
-		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--non-template X] [--single-end] [--shuffle] [--separate-mates]\n"
+		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--non-template X] [--single-end] [--soft-clip-supplementary] [--n-bases X] [--shuffle] [--separate-mates]\n"
 		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH] [--threads N] [--bam-only]\n"
 		"writes PREFIX.fa PREFIX.gtf PREFIX.bam\n");
 }
@@ -1368,6 +1392,8 @@ int main(int argc, char** argv) {
 		else if (a == "--indels") config.frac_indels = atof(value());
 		else if (a == "--non-template") config.frac_non_template = atof(value());
 		else if (a == "--single-end") config.single_end = true;
+		else if (a == "--soft-clip-supplementary") config.soft_clip_supplementary = true;
+		else if (a == "--n-bases") config.frac_n_bases = atof(value());
 		else if (a == "--shuffle") config.shuffle_names = true;
 		else if (a == "--separate-mates") config.separate_mates = true;
 		else if (a == "--stranded") config.stranded = true;
