@@ -506,6 +506,7 @@ int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* 
 		for (size_t contig = 0; contig < c.coverage.size() && contig + 1 < session->window_offset.size(); ++contig) {
 			const uint64_t begin = session->window_offset[contig], size = session->window_offset[contig + 1] - begin;
 			if (size != c.coverage[contig].size()) throw std::runtime_error("coverage_t: the windows of the device do not match the session's");
+			if (size == 0) continue; // (a contig without sequence has no windows)
 			if (coverage) memcpy(c.coverage[contig].data(), coverage + begin, size * sizeof(uint16_t));
 			if (fragment_starts) memcpy(c.fragment_starts[contig].data(), fragment_starts + begin, size);
 			if (fragment_ends) memcpy(c.fragment_ends[contig].data(), fragment_ends + begin, size);
