@@ -4,6 +4,7 @@
 // --chimOutType WithinBAM) and coverage_t::add_fragment (source/read_stats.cpp:161-266).
 #include "arriba_host.h"
 
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -1254,22 +1255,21 @@ struct FileBytes {
 			position += got;
 			return got;
 		}
-		std::vector<size_t> got(n_threads, 0);
-		std::vector<uint8_t> failed(n_threads, 0);
+		std::atomic<size_t> got(0);
+		std::atomic<bool> failed(false);
 		const uint64_t base = position;
 		parallel_ranges(capacity, n_threads, [&](size_t first, size_t last) {
-			const unsigned int t = (unsigned int) (first * n_threads / capacity);
 			size_t done = 0;
 			while (first + done < last) {
 				const ssize_t n = pread(fd, buffer + first + done, last - first - done, (off_t) (base + first + done));
-				if (n < 0) { if (errno == EINTR) continue; failed[t < n_threads ? t : 0] = 1; break; }
+				if (n < 0) { if (errno == EINTR) continue; failed = true; break; }
 				if (n == 0) break;
 				done += (size_t) n;
 			}
-			got[t < n_threads ? t : 0] += done;
+			got += done;
 		}, 1);
-		size_t total = 0; // the bytes form a prefix: a short range means the end of the file
-		for (unsigned int t = 0; t < n_threads; ++t) { if (failed[t]) throw std::runtime_error("failed to load alignments"); total += got[t]; }
+		if (failed) throw std::runtime_error("failed to load alignments");
+		const size_t total = got; // the bytes form a prefix: a short range means the end of the file
 		position += total;
 		return total;
 	}
