@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 // persistent: each owns one memo table in HBM and takes the next heavy read from a queue (counters[4]) when it is done with one -- the searches differ in
 // length by orders of magnitude, a fixed share per workgroup would wait for the unluckiest one.  The kernel waits for dependent loads (k-mer table -> hit list ->
 // genome bases -> memo slot), so the number of wavefronts in flight is what sets its speed: 4096 workgroups of one wavefront = 4 per SIMD.
-const uint32_t MEMO_SLOTS_LOG2 = 21;    // 16 MB per workgroup (a read of a long gene makes 10^5..10^6 distinct nested calls)
+const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 32 GB for 4096 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
+                                        // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
 const uint32_t HEAVY_WORKGROUPS = 4096;
 __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
                                                              unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, unsigned int* counters) {
