@@ -457,7 +457,7 @@ def test_workflow_with_non_default_options_against_the_live_reference(built, tmp
     assert dict(stages)["mark_genomic_support"] > 1000 and stages[-1][1] > 200
 
 
-@pytest.mark.parametrize("kind", ["indels_and_non_template_bases", "single_end", "long_reads_multimappers", "short_stranded_single_end", "soft_clips_and_n_bases"])
+@pytest.mark.parametrize("kind", ["indels_and_non_template_bases", "single_end", "long_reads_multimappers", "short_stranded_single_end", "soft_clips_and_n_bases", "missing_hi_tags"])
 def test_workflow_on_other_kinds_of_libraries_against_the_live_reference(kind, built, tmp_path):
     """CIGAR operations I and D, non-template bases, single-end libraries, reads of 60 and 150 nt, soft-clipped supplementary alignments, N bases (the golden datasets have
     none of these) through the kernels of the GPU,

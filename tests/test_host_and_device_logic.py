@@ -664,6 +664,8 @@ LIBRARY_SPECS = {
     # supplementary alignments with soft clips and the whole read (STAR --chimOutType WithinBAM SoftClip), 5 % of the bases N, indels, non-template bases
     "soft_clips_and_n_bases": ["--seed", "911", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--n-bases", "0.05",
                                "--soft-clip-supplementary", "--non-template", "0.4", "--indels", "0.3"],
+    # a fifth of the fragments multi-mapping, half of those with secondary alignments that lack the HI tag (ignored with a warning), contigs outside the interesting set
+    "missing_hi_tags": ["--seed", "1616", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "26", "--contig-len", "150000", "--junctions", "200", "--dup", "0.1", "--multimap", "0.2", "--missing-hi", "0.5"],
     # short single-end reads of a stranded library
     "short_stranded_single_end": ["--seed", "707", "--fragments", "20000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--dup", "0.1", "--read-len", "60", "--clip-min", "12",
                                   "--clip-max", "30", "--single-end", "--stranded", "--multimap", "0.1"],

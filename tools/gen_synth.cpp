@@ -46,6 +46,7 @@ struct Record {
 	std::vector<uint32_t> cigar;
 	std::string seq;
 	bool sa;
+	bool no_hi = false;
 };
 typedef std::vector<Record> Fragment;
 
@@ -1044,7 +1045,7 @@ struct BamEncoder {
 			buffer.push_back(code(r.seq[i]) << 4 | (i + 1 < r.seq.size() ? code(r.seq[i + 1]) : 0));
 		buffer.insert(buffer.end(), r.seq.size(), 30);
 		buffer.insert(buffer.end(), {'N', 'H', 'C', (uint8_t) r.nh});
-		buffer.insert(buffer.end(), {'H', 'I', 'C', (uint8_t) r.hi});
+		if (!r.no_hi) buffer.insert(buffer.end(), {'H', 'I', 'C', (uint8_t) r.hi});
 		if (r.sa) {
 			const char sa[] = "SAZ1,1,+,50M50S,255,0;";
 			buffer.insert(buffer.end(), sa, sa + sizeof(sa)); // includes the terminating NUL
@@ -1199,13 +1200,16 @@ void Generator::stream_records(Rng& rng, uint64_t first_serial, long fragments, 
 		std::string name = make_name();
 		if (rng.chance(c.frac_multimappers)) {
 			int copies = rng.range(2, 3);
+			const bool missing_hi = c.frac_missing_hi > 0 && rng.chance(c.frac_missing_hi);
 			emit(name, fragment, 1, copies);
 			for (int copy = 2; copy <= copies; ++copy) {
 				bool recurrent;
 				Fragment other = (fragment.size() == 3) ? builder.split_read(builder.pick_junction(recurrent)) : builder.discordant_pair(builder.pick_junction(recurrent));
-				for (size_t i = 0; i < other.size(); ++i)
+				for (size_t i = 0; i < other.size(); ++i) {
 					if (!(other[i].flag & F_SUPPLEMENTARY))
 						other[i].flag |= F_SECONDARY;
+					other[i].no_hi = missing_hi;
+				}
 				emit(name, other, copy, copies);
 			}
 		} else {
@@ -1354,7 +1358,7 @@ static void usage() {
 	fprintf(stderr,
 		"usage: gen_synth --out PREFIX [--seed N] [--fragments N] [--normal-mult X] [--contigs N] [--contig-len N]\n"
 		"                 [--genes-per-mb X] [--read-len N] [--junctions N] [--clip-min N] [--clip-max N]\n"
-		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--non-template X] [--single-end] [--soft-clip-supplementary] [--n-bases X] [--shuffle] [--separate-mates]\n"
+		"                 [--noise X] [--dup X] [--multimap X] [--partner-clip X] [--indels X] [--non-template X] [--missing-hi X] [--single-end] [--soft-clip-supplementary] [--n-bases X] [--shuffle] [--separate-mates]\n"
 		"                 [--stranded] [--no-viral] [--reference-only] [--raw-bam-to PATH] [--threads N] [--bam-only]\n"
 		"writes PREFIX.fa PREFIX.gtf PREFIX.bam\n");
 }
@@ -1391,6 +1395,7 @@ int main(int argc, char** argv) {
 		else if (a == "--partner-clip") config.frac_clip_from_partner = atof(value());
 		else if (a == "--indels") config.frac_indels = atof(value());
 		else if (a == "--non-template") config.frac_non_template = atof(value());
+		else if (a == "--missing-hi") config.frac_missing_hi = atof(value());
 		else if (a == "--single-end") config.single_end = true;
 		else if (a == "--soft-clip-supplementary") config.soft_clip_supplementary = true;
 		else if (a == "--n-bases") config.frac_n_bases = atof(value());
