@@ -3,6 +3,7 @@
 #define AGPU_CONTEXT_HPP 1
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <map>
 #include <utility>
 #include <string>
@@ -29,11 +30,35 @@ struct DeviceBuffer {
 		if (n == 0) n = 16;
 		if (ptr != nullptr && n <= capacity) { bytes = n; return true; }
 		release();
-		if (hipMalloc(&ptr, n) != hipSuccess) { ptr = nullptr; return false; }
+		pooled = use_pool();
+		if (pooled) { // stream-ordered allocation on the null stream, made visible to every stream by the synchronisation behind it
+			if (hipMallocAsync(&ptr, n, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void) hipGetLastError(); ptr = nullptr; pooled = false; }
+		}
+		if (!pooled && hipMalloc(&ptr, n) != hipSuccess) { ptr = nullptr; return false; }
 		bytes = n; capacity = n;
 		return true;
 	}
-	void release() { if (ptr) { (void) hipFree(ptr); ptr = nullptr; bytes = 0; capacity = 0; } }
+	void release() {
+		if (!ptr) return;
+		if (pooled) { (void) hipFreeAsync(ptr, nullptr); (void) hipStreamSynchronize(nullptr); } else (void) hipFree(ptr);
+		ptr = nullptr; bytes = 0; capacity = 0; pooled = false;
+	}
+	// ARRIBA_DEVICE_POOL=1 (an experiment, off by default): the buffers come from the device's stream-ordered memory pool, whose release threshold is raised so that
+	// freed pages stay mapped -- at 10^8 fragments ~85 GB of ingest buffers are freed and ~70 GB of stage buffers allocated per sample, and unmapping / mapping them
+	// is the suspected 3-5 s between the kernels.  Every caller releases a buffer only behind a synchronisation of the stream that used it.
+	bool pooled = false;
+	static bool use_pool() {
+		static int state = -1;
+		if (state < 0) {
+			const char* knob = getenv("ARRIBA_DEVICE_POOL");
+			state = knob != nullptr && knob[0] == '1';
+			if (state) {
+				int device = 0; hipMemPool_t pool = nullptr; uint64_t keep = ~(uint64_t) 0;
+				if (hipGetDevice(&device) != hipSuccess || hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) { (void) hipGetLastError(); state = 0; }
+			}
+		}
+		return state == 1;
+	}
 	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); }
 	template <class T> T* as() const { return (T*) ptr; }
 };
