@@ -59,7 +59,7 @@ struct DeviceBuffer {
 		}
 		return state == 1;
 	}
-	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); }
+	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); std::swap(pooled, other.pooled); }
 	template <class T> T* as() const { return (T*) ptr; }
 };
 

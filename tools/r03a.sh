@@ -10,3 +10,5 @@ ARRIBA_MISMAPPER_WORKLIST=0 timeout 120 python bench.py --fragments 10000000 --s
 ARRIBA_WRITER_PROFILE=1 timeout 120 python bench.py --fragments 10000000 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/r03a_writer_profile.err; grep "writer\]\|step done" gpurun_out/r03a_writer_profile.err | tail -12 | cut -c1-400
 # 3. the 100 M sample, one step
 timeout 600 python bench.py --fragments 100000000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/r03a_bench100m.json 2> gpurun_out/r03a_bench100m.err; echo "bench exit $?"; cut -c1-300 gpurun_out/r03a_bench100m.json; grep "step done" gpurun_out/r03a_bench100m.err | cut -c1-600
+# 4. the same 100 M step with the buffers from the stream-ordered pool (pages kept mapped between the ingest and the stages)
+ARRIBA_DEVICE_POOL=1 timeout 600 python bench.py --fragments 100000000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/r03a_bench100m_pool.json 2> gpurun_out/r03a_bench100m_pool.err; echo "bench exit $?"; cut -c1-300 gpurun_out/r03a_bench100m_pool.json; grep "step done" gpurun_out/r03a_bench100m_pool.err | cut -c1-600
