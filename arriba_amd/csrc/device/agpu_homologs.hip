@@ -32,6 +32,29 @@ __global__ void homolog_verdict_kernel(AnnotationView ann, GenomeView genome, Km
 	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
 	if (k < n_pairs) verdicts[k] = genes_are_homologs(ann, genome, kmers, (uint32_t) (pairs[k] >> 32), (uint32_t) pairs[k], max_identity_fraction);
 }
+// The same verdict by a wavefront per gene pair: the 64 lanes ask 64 positions of the smaller gene at once (the answers are independent of each other), then every
+// lane walks the 64 answers in position order with the reference's two early exits (homolog_walk: a few comparisons per position, no memory).  A pair of long genes
+// is 10^5 dependent look-ups for one thread -- the launch waits for the longest pair -- and 10^5 / 64 rounds here.  ARRIBA_HOMOLOG_WAVES=1 (an experiment for the
+// next round, off by default; the thread-per-pair kernel above is the measured one).
+__global__ void __launch_bounds__(64) homolog_verdict_wave_kernel(AnnotationView ann, GenomeView genome, KmerIndexView kmers, const uint64_t* pairs, uint32_t n_pairs, float max_identity_fraction, uint8_t* verdicts) {
+	const uint32_t k = blockIdx.x;
+	if (k >= n_pairs) return;
+	HomologPair p;
+	if (!homolog_pair_setup(ann, genome, kmers, (uint32_t) (pairs[k] >> 32), (uint32_t) pairs[k], p)) { if (threadIdx.x == 0) verdicts[k] = 0; return; }
+	uint32_t matching_kmers = 0;
+	int verdict = 0;
+	for (uint64_t base = 0; base + 2 * KMER_LENGTH < p.size && verdict == 0; base += 64ull * KMER_LENGTH) {
+		const uint64_t pos = base + (uint64_t) threadIdx.x * KMER_LENGTH;
+		const bool mine = pos + 2 * KMER_LENGTH < p.size && homolog_position_matches(p, kmers, pos);
+		const unsigned long long answers = __ballot(mine);
+		for (uint32_t lane = 0; lane < 64 && verdict == 0; ++lane) { // (every lane walks the same answers: the verdict is uniform)
+			const uint64_t at = base + (uint64_t) lane * KMER_LENGTH;
+			if (!(at + 2 * KMER_LENGTH < p.size)) break;
+			verdict = homolog_walk(p, max_identity_fraction, at, (answers >> lane) & 1ull, matching_kmers);
+		}
+	}
+	if (threadIdx.x == 0) verdicts[k] = verdict > 0 ? 1 : 0;
+}
 __global__ void homolog_apply_kernel(CandidateTable t, const uint32_t* candidates, const uint8_t* filters, uint32_t n) {
 	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
 	if (k < n) t.filter[candidates[k]] = filters[k];
@@ -71,6 +94,11 @@ extern "C" int agpu_filter_homologs(agpu_ctx* ctx, float max_identity_fraction, 
 		HIP_CHECK(hipMemcpyAsync(device_pairs.ptr, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, s));
 		KmerIndexView kmers;
 		kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
+		const char* wave_knob = getenv("ARRIBA_HOMOLOG_WAVES");
+		if (wave_knob != nullptr && wave_knob[0] == '1') {
+			KernelTimer timer(ctx, "homolog_verdict_wave_kernel", pairs.size() * 64);
+			homolog_verdict_wave_kernel<<<(unsigned int) pairs.size(), 64, 0, s>>>(ctx->annotation, ctx->genome, kmers, device_pairs.as<uint64_t>(), (uint32_t) pairs.size(), max_identity_fraction, device_verdicts.as<uint8_t>());
+		} else
 		{ KernelTimer timer(ctx, "homolog_verdict_kernel", pairs.size() * 64);
 		  homolog_verdict_kernel<<<(unsigned int) ((pairs.size() + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->genome, kmers, device_pairs.as<uint64_t>(), (uint32_t) pairs.size(), max_identity_fraction, device_verdicts.as<uint8_t>()); }
 		std::vector<uint8_t> host_verdicts(pairs.size());

@@ -16,50 +16,80 @@ const uint8_t FILTER_homologs = 37; // source/common.hpp:29-67
 AGPU_HD char complement_of_base(char base) { return base == 'A' ? 'T' : base == 'T' ? 'A' : base == 'C' ? 'G' : base == 'G' ? 'C' : base; } // the genome is upper case
 
 // reference: is_homolog (:9-66).  Gene length = end - start (source/common.hpp:126); the sequence of the smaller gene is taken from the
-// assembly as substr(start, length) and reverse-complemented if the genes lie on different strands.
-AGPU_HD bool genes_are_homologs(const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, uint32_t gene1, uint32_t gene2, float max_identity_fraction) {
-	AGPU_FP_AS_WRITTEN
-	const uint32_t extended_kmer_length = 8;
+// assembly as substr(start, length) and reverse-complemented if the genes lie on different strands.  Split into the set-up of a gene pair, the question asked at
+// one position of the smaller gene (does its k-mer have a hit in the bigger gene whose next eight bases match, too? -- independent of the other positions) and
+// the reference's walk over the answers in position order with its two early exits; a thread does all three in a loop, a wavefront asks 64 positions at once.
+struct HomologPair {
+	const char* small_bases; const char* big_bases;
+	uint64_t size, big_contig_size;      // bases of the smaller gene that exist (substr is cut at the end of the contig); size of the bigger gene's contig
+	uint32_t small_length, table;
+	int32_t small_start, small_end, big_start, big_end;
+	bool reverse, same_contig;
+};
+// false: the verdict is "no" without looking at any base (the same gene, overlapping genes)
+AGPU_HD bool homolog_pair_setup(const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, uint32_t gene1, uint32_t gene2, HomologPair& p) {
 	if (gene1 == gene2) return false;
 	uint32_t small_gene = gene1, big_gene = gene2;
 	if ((uint32_t) (ann.gene_end[small_gene] - ann.gene_start[small_gene]) > (uint32_t) (ann.gene_end[big_gene] - ann.gene_start[big_gene])) { small_gene = gene2; big_gene = gene1; }
 	const uint32_t small_contig = ann.gene_contig[small_gene], big_contig = ann.gene_contig[big_gene];
-	const int32_t small_start = ann.gene_start[small_gene], small_end = ann.gene_end[small_gene], big_start = ann.gene_start[big_gene], big_end = ann.gene_end[big_gene];
-	if (small_contig == big_contig && ((small_start >= big_start && small_start <= big_end) || (small_end >= big_start && small_end <= big_end))) return false; // overlapping genes
-	const uint32_t small_length = (uint32_t) (small_end - small_start);
-	const uint64_t small_contig_size = genome.contig_offset[small_contig + 1] - genome.contig_offset[small_contig], big_contig_size = genome.contig_offset[big_contig + 1] - genome.contig_offset[big_contig];
-	uint64_t size = small_length; // substr() is cut at the end of the contig
-	if ((uint64_t) small_start >= small_contig_size) size = 0; else if ((uint64_t) small_start + size > small_contig_size) size = small_contig_size - (uint64_t) small_start;
-	const char* small_bases = genome.bases + genome.contig_offset[small_contig] + small_start;
-	const char* big_bases = genome.bases + genome.contig_offset[big_contig];
-	const bool reverse = ((ann.gene_bits[small_gene] ^ ann.gene_bits[big_gene]) & GBIT_STRAND) != 0;
-	const uint32_t table = big_contig < kmers.n_contigs ? kmers.contig_table[big_contig] : NO_KMER_TABLE;
-	uint32_t matching_kmers = 0;
-	for (uint64_t pos = 0; pos + 2 * KMER_LENGTH < size; pos += KMER_LENGTH) {
-		if ((float) ((uint64_t) (matching_kmers * (uint32_t) KMER_LENGTH) + (size - pos)) < (float) small_length * max_identity_fraction) return false; // max_identity_fraction cannot be reached any more
-		if (table == NO_KMER_TABLE) continue;
-		uint32_t kmer = 0;
-		for (uint32_t j = 0; j < (uint32_t) KMER_LENGTH; ++j) kmer = kmer << 2 | kmer_digit_of_char(reverse ? complement_of_base(small_bases[size - 1 - (pos + j)]) : small_bases[pos + j]);
-		const uint32_t* offsets = kmers.offsets + (size_t) table * KMER_COUNT;
-		uint32_t lo = offsets[kmer], hi = offsets[kmer + 1];
-		const uint32_t bucket_end = hi;
-		while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (kmers.positions[mid] < big_start) lo = mid + 1; else hi = mid; }
-		for (uint32_t hit = lo; hit < bucket_end && kmers.positions[hit] <= big_end; ++hit) {
-			const int32_t position = kmers.positions[hit];
-			if (small_contig != big_contig || position < small_start || position > small_end) {
-				bool extended_match = true; // strncmp over the next extended_kmer_length bases; behind the end of the contig the reference's string ends: a mismatch
-				for (uint32_t j = 0; j < extended_kmer_length && extended_match; ++j) {
-					const uint64_t big_at = (uint64_t) position + KMER_LENGTH + j, small_at = pos + KMER_LENGTH + j;
-					const char small_base = reverse ? complement_of_base(small_bases[size - 1 - small_at]) : small_bases[small_at];
-					extended_match = big_at < big_contig_size && big_bases[big_at] == small_base;
-				}
-				if (extended_match) {
-					matching_kmers++;
-					if ((float) (matching_kmers * (uint32_t) KMER_LENGTH) >= (float) small_length * max_identity_fraction) return true;
-					break;
-				}
+	p.small_start = ann.gene_start[small_gene]; p.small_end = ann.gene_end[small_gene]; p.big_start = ann.gene_start[big_gene]; p.big_end = ann.gene_end[big_gene];
+	if (small_contig == big_contig && ((p.small_start >= p.big_start && p.small_start <= p.big_end) || (p.small_end >= p.big_start && p.small_end <= p.big_end))) return false; // overlapping genes
+	p.small_length = (uint32_t) (p.small_end - p.small_start);
+	const uint64_t small_contig_size = genome.contig_offset[small_contig + 1] - genome.contig_offset[small_contig];
+	p.big_contig_size = genome.contig_offset[big_contig + 1] - genome.contig_offset[big_contig];
+	p.size = p.small_length; // substr() is cut at the end of the contig
+	if ((uint64_t) p.small_start >= small_contig_size) p.size = 0; else if ((uint64_t) p.small_start + p.size > small_contig_size) p.size = small_contig_size - (uint64_t) p.small_start;
+	p.small_bases = genome.bases + genome.contig_offset[small_contig] + p.small_start;
+	p.big_bases = genome.bases + genome.contig_offset[big_contig];
+	p.reverse = ((ann.gene_bits[small_gene] ^ ann.gene_bits[big_gene]) & GBIT_STRAND) != 0;
+	p.same_contig = small_contig == big_contig;
+	p.table = big_contig < kmers.n_contigs ? kmers.contig_table[big_contig] : NO_KMER_TABLE;
+	return true;
+}
+// the k-mer of the smaller gene at `pos` (pos + 2 * KMER_LENGTH < p.size): a hit inside the bigger gene (outside the smaller one) whose next eight bases match as well?
+AGPU_HD bool homolog_position_matches(const HomologPair& p, const KmerIndexView& kmers, uint64_t pos) {
+	const uint32_t extended_kmer_length = 8;
+	if (p.table == NO_KMER_TABLE) return false;
+	uint32_t kmer = 0;
+	for (uint32_t j = 0; j < (uint32_t) KMER_LENGTH; ++j) kmer = kmer << 2 | kmer_digit_of_char(p.reverse ? complement_of_base(p.small_bases[p.size - 1 - (pos + j)]) : p.small_bases[pos + j]);
+	const uint32_t* offsets = kmers.offsets + (size_t) p.table * KMER_COUNT;
+	uint32_t lo = offsets[kmer], hi = offsets[kmer + 1];
+	const uint32_t bucket_end = hi;
+	while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (kmers.positions[mid] < p.big_start) lo = mid + 1; else hi = mid; }
+	for (uint32_t hit = lo; hit < bucket_end && kmers.positions[hit] <= p.big_end; ++hit) {
+		const int32_t position = kmers.positions[hit];
+		if (!p.same_contig || position < p.small_start || position > p.small_end) {
+			bool extended_match = true; // strncmp over the next extended_kmer_length bases; behind the end of the contig the reference's string ends: a mismatch
+			for (uint32_t j = 0; j < extended_kmer_length && extended_match; ++j) {
+				const uint64_t big_at = (uint64_t) position + KMER_LENGTH + j, small_at = pos + KMER_LENGTH + j;
+				const char small_base = p.reverse ? complement_of_base(p.small_bases[p.size - 1 - small_at]) : p.small_bases[small_at];
+				extended_match = big_at < p.big_contig_size && p.big_bases[big_at] == small_base;
 			}
+			if (extended_match) return true; // (the reference counts the k-mer once and goes to the next position)
 		}
+	}
+	return false;
+}
+// the reference's loop at position `pos`, given the answer there: -1 = "not homologs" (max_identity_fraction cannot be reached any more), 1 = "homologs", 0 = go on
+AGPU_HD int homolog_walk(const HomologPair& p, float max_identity_fraction, uint64_t pos, bool matches, uint32_t& matching_kmers) {
+	AGPU_FP_AS_WRITTEN
+	if ((float) ((uint64_t) (matching_kmers * (uint32_t) KMER_LENGTH) + (p.size - pos)) < (float) p.small_length * max_identity_fraction) return -1;
+	if (matches) {
+		matching_kmers++;
+		if ((float) (matching_kmers * (uint32_t) KMER_LENGTH) >= (float) p.small_length * max_identity_fraction) return 1;
+	}
+	return 0;
+}
+AGPU_HD bool genes_are_homologs(const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, uint32_t gene1, uint32_t gene2, float max_identity_fraction) {
+	AGPU_FP_AS_WRITTEN
+	HomologPair p;
+	if (!homolog_pair_setup(ann, genome, kmers, gene1, gene2, p)) return false;
+	uint32_t matching_kmers = 0;
+	for (uint64_t pos = 0; pos + 2 * KMER_LENGTH < p.size; pos += KMER_LENGTH) {
+		// (the exit "cannot be reached any more" comes before the look-up in the reference: no look-up behind it here either)
+		if ((float) ((uint64_t) (matching_kmers * (uint32_t) KMER_LENGTH) + (p.size - pos)) < (float) p.small_length * max_identity_fraction) return false;
+		const int verdict = homolog_walk(p, max_identity_fraction, pos, homolog_position_matches(p, kmers, pos), matching_kmers);
+		if (verdict != 0) return verdict > 0;
 	}
 	return false;
 }

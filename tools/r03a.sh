@@ -12,3 +12,7 @@ ARRIBA_WRITER_PROFILE=1 timeout 120 python bench.py --fragments 10000000 --steps
 timeout 600 python bench.py --fragments 100000000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/r03a_bench100m.json 2> gpurun_out/r03a_bench100m.err; echo "bench exit $?"; cut -c1-300 gpurun_out/r03a_bench100m.json; grep "step done" gpurun_out/r03a_bench100m.err | cut -c1-600
 # 4. the same 100 M step with the buffers from the stream-ordered pool (pages kept mapped between the ingest and the stages)
 ARRIBA_DEVICE_POOL=1 timeout 600 python bench.py --fragments 100000000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/r03a_bench100m_pool.json 2> gpurun_out/r03a_bench100m_pool.err; echo "bench exit $?"; cut -c1-300 gpurun_out/r03a_bench100m_pool.json; grep "step done" gpurun_out/r03a_bench100m_pool.err | cut -c1-600
+# 5. filter_homologs by a wavefront per gene pair: parity first (the tests that hold homologs), then the time at 10 M (homolog_verdict_kernel was 26 ms)
+ARRIBA_HOMOLOG_WAVES=1 timeout 300 python -m pytest tests -x -q -m gpu -k "homolog or workflow_from_input_files" > gpurun_out/r03a_pytest_homolog_waves.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/r03a_pytest_homolog_waves.log
+ARRIBA_HOMOLOG_WAVES=1 timeout 120 python bench.py --fragments 10000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03a_bench10m_homolog_waves.json 2> /dev/null; python3 -c "
+import json; d = json.loads(open('gpurun_out/r03a_bench10m_homolog_waves.json').read().strip().splitlines()[-1]); print({k: v for k, v in d['kernel_ms'].items() if 'homolog' in k}, d['ms_per_step'])"
