@@ -136,6 +136,10 @@ __global__ void in_vitro_pair_key_kernel(CandidateTable t, uint64_t* keys) { // 
 	keys[2 * (uint64_t) c] = counts ? (uint64_t) t.gene1[c] << 32 | t.gene2[c] : ~0ull;
 	keys[2 * (uint64_t) c + 1] = counts ? (uint64_t) t.gene2[c] << 32 | t.gene1[c] : ~0ull;
 }
+__global__ void clip_summary_kernel(BatchView b, ClipSummary* summaries) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k < 3 * b.n) summaries[k] = clip_summary_of(b, k / 3, (int) (k % 3));
+}
 __global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t) {
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c < t.n && is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
@@ -612,6 +616,15 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 		tables.gene_read_count = gene_read_count.as<uint32_t>();
 		tables.high_expression_threshold = threshold;
 		tables.pair_keys = unique_keys.as<uint64_t>(); tables.pair_counts = unique_counts.as<uint32_t>(); tables.n_pairs = runs; // (the run of ~0 keys at the end is never looked up)
+		tables.clip_summaries = nullptr;
+		const char* summary_knob = getenv("ARRIBA_IN_VITRO_SUMMARY"); // "1": the clipped ends of the alignments summarised once (an experiment for the next round, off by default)
+		if (summary_knob != nullptr && summary_knob[0] == '1' && ctx->n > 0) {
+			DeviceBuffer& summaries = ctx->scratch("events.clip_summaries");
+			ALLOC(summaries, 3 * ctx->n * sizeof(ClipSummary));
+			{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20));
+			  clip_summary_kernel<<<(unsigned int) ((3 * ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, summaries.as<ClipSummary>()); }
+			tables.clip_summaries = summaries.as<ClipSummary>();
+		}
 		// (3) the verdicts
 		KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
 		in_vitro_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, t);

@@ -257,10 +257,25 @@ AGPU_HD void recover_many_spliced_in_pair(const CandidateTable& t, const uint32_
 // ---- filter_in_vitro (source/filter_in_vitro.cpp:17-228): events with the characteristics of fusions made during reverse transcription -- few split
 // reads, partners expressed in the top quantile (chimeric reads per gene as the proxy), breakpoints inside exons.
 const uint8_t FILTER_in_vitro = 22;
+// What filter_in_vitro asks of every alignment of every discordant mate of every candidate (:133-158): is it clipped by >= 3 bases at its far end, and where does that
+// end lie?  Answered once per alignment (8 bytes) instead of once per list entry from the CIGAR, strand, contig, start and end columns (the lists hold every
+// fragment ~40 times: at 10^7 fragments the kernel moved 218 GB).
+struct ClipSummary { int32_t position; uint16_t contig; uint16_t clipped; }; // clipped: 1 = the alignment is clipped by >= 3 bases at the end `position` (forward: its end, reverse: its start)
+AGPU_HD ClipSummary clip_summary_of(const BatchView& b, uint64_t read, int slot) {
+	ClipSummary summary = { 0, 0, 0 };
+	if (slot >= (int) b.n_aln[read]) return summary;
+	const uint32_t min_clipped_length = 3;
+	const uint32_t* cigar = cigar_of(b, slot, read); const uint32_t n_cigar = b.cigar_count[slot][read];
+	const bool forward = b.abits[slot][read] & ABIT_STRAND;
+	if (forward && postclipping(cigar, n_cigar) >= min_clipped_length) { summary.position = b.end[slot][read]; summary.contig = b.contig[slot][read]; summary.clipped = 1; }
+	else if (!forward && preclipping(cigar, n_cigar) >= min_clipped_length) { summary.position = b.start[slot][read]; summary.contig = b.contig[slot][read]; summary.clipped = 1; }
+	return summary;
+}
 struct InVitroTables {
 	const uint32_t* gene_read_count;       // chimeric fragments per gene (find_top_expressed_genes, :49-58), GTF genes and dummy genes
 	uint32_t high_expression_threshold;    // the quantile of the non-zero counts (:60-80)
 	const uint64_t* pair_keys; const uint32_t* pair_counts; uint32_t n_pairs; // exonic_breakpoints_by_gene_pair (:93-105): sorted keys gene1 << 32 | gene2
+	const ClipSummary* clip_summaries;     // [3 * fragments] or null: then every list entry reads the columns of the batch
 };
 // genes of a fragment that count towards the expression proxy: those of MATE1 and of MATE2 (discordant mates) or SUPPLEMENTARY (split read) (:52-57)
 AGPU_HD int in_vitro_second_slot(const BatchView& b, uint64_t i) { return b.n_aln[i] == 2 ? MATE2 : SUPPLEMENTARY; }
@@ -302,6 +317,15 @@ AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann,
 	for (uint32_t k = t.list_offset[3 * (uint64_t) c + 2]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
 		const uint32_t read = t.read_lists[k];
 		if (b.filter[read] != FILTER_none) continue;
+		if (tables.clip_summaries != nullptr) {
+			for (int slot = 0; slot < 3; ++slot) {
+				const ClipSummary summary = tables.clip_summaries[3 * (uint64_t) read + slot];
+				if (!summary.clipped) continue;
+				if (summary.contig == contig1 && summary.position == breakpoint1) clipped_discordant_mates1++;
+				else if (summary.contig == contig2 && summary.position == breakpoint2) clipped_discordant_mates2++;
+			}
+			continue;
+		}
 		for (int slot = 0; slot < b.n_aln[read]; ++slot) {
 			const uint32_t* cigar = cigar_of(b, slot, read); const uint32_t n_cigar = b.cigar_count[slot][read];
 			const bool forward = b.abits[slot][read] & ABIT_STRAND;

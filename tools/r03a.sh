@@ -16,3 +16,7 @@ ARRIBA_DEVICE_POOL=1 timeout 600 python bench.py --fragments 100000000 --steps 1
 ARRIBA_HOMOLOG_WAVES=1 timeout 300 python -m pytest tests -x -q -m gpu -k "homolog or workflow_from_input_files" > gpurun_out/r03a_pytest_homolog_waves.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/r03a_pytest_homolog_waves.log
 ARRIBA_HOMOLOG_WAVES=1 timeout 120 python bench.py --fragments 10000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03a_bench10m_homolog_waves.json 2> /dev/null; python3 -c "
 import json; d = json.loads(open('gpurun_out/r03a_bench10m_homolog_waves.json').read().strip().splitlines()[-1]); print({k: v for k, v in d['kernel_ms'].items() if 'homolog' in k}, d['ms_per_step'])"
+# 6. filter_in_vitro with the clipped ends summarised once per alignment: parity, then the time at 10 M (in_vitro_kernel was 31 ms, 218 GB of traffic)
+ARRIBA_IN_VITRO_SUMMARY=1 timeout 300 python -m pytest tests -x -q -m gpu -k "chain_to or event_level or workflow_from_input_files" > gpurun_out/r03a_pytest_in_vitro_summary.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/r03a_pytest_in_vitro_summary.log
+ARRIBA_IN_VITRO_SUMMARY=1 timeout 120 python bench.py --fragments 10000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03a_bench10m_in_vitro_summary.json 2> /dev/null; python3 -c "
+import json; d = json.loads(open('gpurun_out/r03a_bench10m_in_vitro_summary.json').read().strip().splitlines()[-1]); print({k: v for k, v in d['kernel_ms'].items() if 'in_vitro' in k or 'clip_summary' in k}, d['ms_per_step'])"
