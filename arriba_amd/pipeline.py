@@ -169,8 +169,15 @@ class DevicePipeline(object):
         self.n_dummy_genes = 0
         self.scalars = {}
 
+    def _free_pieces(self):
+        if getattr(self, "_pieces", None) is not None:
+            for pointer in self._pieces[1]:
+                self.api.host_free(pointer)
+            self._pieces = None
+
     def close(self):
         if self.ctx:
+            self._free_pieces()
             self.api.destroy(self.ctx)
             self.ctx = None
 
@@ -198,19 +205,25 @@ class DevicePipeline(object):
             status = lib.ahost_bam_open_part(handle, bam.encode(), int(external_duplicate_marking), max_itd_length, part, parts, byref(config))
         if status != 0:
             raise host_error()
-        buffers = []
         try:
             if getattr(self, "_genome_contigs", None) != config.n_contigs:
                 self._check(self.api.upload_genome(self.ctx, self.session.genome_view))  # the contigs of the BAM header are part of the run now
                 self._genome_contigs = config.n_contigs
             self._check(self.api.ingest_begin(self.ctx, byref(config)))
             block_capacity = piece_bytes // 4096 + 16
-            for _ in range(2):
-                pointer = self.api.host_alloc(piece_bytes)
-                if not pointer:
-                    raise ArribaError("ERROR: " + self.api.last_error().decode())
-                buffers.append(pointer)
-            tables = [(_capi.BgzfBlock * block_capacity)(), (_capi.BgzfBlock * block_capacity)()]
+            # the two pinned buffers of the pieces stay with the pipeline (pinning 2 x 256 MB costs as much as feeding a gigabyte): a resident service reads sample after sample
+            if getattr(self, "_pieces", None) is None or self._pieces[0] != piece_bytes:
+                self._free_pieces()
+                buffers = []
+                for _ in range(2):
+                    pointer = self.api.host_alloc(piece_bytes)
+                    if not pointer:
+                        for allocated in buffers:
+                            self.api.host_free(allocated)
+                        raise ArribaError("ERROR: " + self.api.last_error().decode())
+                    buffers.append(pointer)
+                self._pieces = (piece_bytes, buffers, [(_capi.BgzfBlock * block_capacity)(), (_capi.BgzfBlock * block_capacity)()])
+            _, buffers, tables = self._pieces
             piece = _capi.BamPiece()
             pushes = 0
             while True:
@@ -229,8 +242,6 @@ class DevicePipeline(object):
             self._check(self.api.ingest_finish(self.ctx, byref(result)))
         finally:
             lib.ahost_bam_close(handle)
-            for pointer in buffers:
-                self.api.host_free(pointer)
         # (config.coverage_window_offset points into the session: read it before anything else touches the session)
         self._coverage_windows = int(config.coverage_window_offset[config.n_contigs]) if config.n_contigs else 0
         return config, result, fed
