@@ -695,8 +695,14 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ctx->have_coverage = true;
 	TRY(agpu::finish_batch_setup(ctx));
 	ctx->batch_from_ingest = true;
-	// the stream and the per-record tables are not needed any more: give the memory back (a 10^8-fragment stream is ~54 GB)
-	if (getenv("ARRIBA_KEEP_INGEST_BUFFERS") == nullptr) {
+	// The stream and the per-record tables are not needed any more.  Where memory is plentiful they stay for the next sample (a resident service reads sample after sample,
+	// and mapping / unmapping gigabytes costs as much as the kernels that use them); where the stages behind the ingest need the room -- a 10^8-fragment sample: 54 GB of
+	// stream, 35 GB of tables, and behind them 36 GB of memo and task lists, the read lists, the k-mer index -- they are given back.  The threshold is what was free in
+	// the measured run of that sample plus a margin.
+	size_t free_bytes = 0, total_bytes = 0;
+	if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { (void) hipGetLastError(); free_bytes = 0; }
+	const bool plenty = free_bytes >= ((size_t) 160 << 30);
+	if (getenv("ARRIBA_KEEP_INGEST_BUFFERS") == nullptr && !plenty) {
 		ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release();
 		if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
 		static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.plain_plans", "ingest.itd_plans",
