@@ -24,6 +24,7 @@
 #include "ingest_core.hpp"
 #include "device_utils.hpp"
 #include "shard_host.hpp"
+#include "crc32_core.hpp"
 
 using namespace agpu;
 
@@ -261,6 +262,32 @@ __global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, c
 	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_READ_LENGTH], block_max);
 }
 
+// CRC-32 of the payload of every stored block of a pushed piece against the trailer of the block (crc32_core.hpp): one workgroup per block, 256 lanes x 256 bytes,
+// the CRCs of the chunks joined in a tree.  Blocks of which only a part is delivered (the ends of a part of a file) carry crc32 = 0 and are not checked.
+__global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, unsigned int* mismatches) {
+	__shared__ uint32_t table[256];
+	__shared__ uint32_t part[256];
+	__shared__ uint32_t length[256];
+	table[threadIdx.x] = crc32_table_entry(threadIdx.x);
+	const agpu_bgzf_block block = blocks[blockIdx.x];
+	__syncthreads();
+	if (block.crc32 == 0 || block.payload_size > 256u * CRC32_CHUNK) return; // (uniform; a BGZF block holds at most 64 KB)
+	const uint8_t* payload = raw + block.raw_offset + block.payload_offset;
+	const uint32_t at = threadIdx.x * CRC32_CHUNK;
+	const uint32_t mine = at < block.payload_size ? (block.payload_size - at < CRC32_CHUNK ? block.payload_size - at : CRC32_CHUNK) : 0u;
+	part[threadIdx.x] = mine ? crc32_of(table, payload + at, mine) : 0u;
+	length[threadIdx.x] = mine;
+	__syncthreads();
+	for (uint32_t stride = 1; stride < 256; stride *= 2) {
+		if (threadIdx.x % (2 * stride) == 0 && length[threadIdx.x + stride] > 0) {
+			part[threadIdx.x] = crc32_joined(part[threadIdx.x], part[threadIdx.x + stride], length[threadIdx.x + stride]);
+			length[threadIdx.x] += length[threadIdx.x + stride];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0 && part[0] != block.crc32) atomicAdd(mismatches, 1u);
+}
+
 // agpu_shard_merge: a 32-bit column of one part into its place in the whole, pool offsets moved behind the pools of the parts before it
 // (slot < 3: only where the fragment has that alignment -- the unused slots of a row hold 0, as fragment_pack_kernel leaves them)
 __global__ void shard_rebase_kernel(uint32_t* out, const uint32_t* in, uint64_t n, uint32_t base, const uint8_t* n_aln, uint32_t slot) {
@@ -442,6 +469,9 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	hipStream_t s = ctx->stream;
 	for (int k = 0; k < 2; ++k) if (!ctx->ingest_events[k]) HIP_CHECK(hipEventCreateWithFlags(&ctx->ingest_events[k], hipEventDisableTiming));
 	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
+	{ const char* knob = getenv("ARRIBA_VERIFY_CRC"); ctx->ingest_verify_crc = knob != nullptr && knob[0] == '1'; }
+	ALLOC(ctx->scratch("ingest.crc_mismatches"), 4);
+	HIP_CHECK(hipMemsetAsync(ctx->scratch("ingest.crc_mismatches").ptr, 0, 4, s));
 	ctx->ingest_external_duplicate_marking = config->external_duplicate_marking; ctx->ingest_max_itd_length = config->max_itd_length; ctx->ingest_part_of_sample = config->part_of_sample != 0;
 	ALLOC(ctx->ingest_tid_to_contig, std::max<size_t>(config->n_targets, 1) * 4);
 	if (config->n_targets) HIP_CHECK(hipMemcpyAsync(ctx->ingest_tid_to_contig.ptr, config->tid_to_contig, (size_t) config->n_targets * 4, hipMemcpyHostToDevice, s));
@@ -488,6 +518,10 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 		{ KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes);
 		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
 		ctx->ingest_stream_size += stream_bytes;
+		if (ctx->ingest_verify_crc) { // (ARRIBA_VERIFY_CRC=1: an experiment for the next round, off by default)
+			KernelTimer timer(ctx, "bgzf_crc_kernel", (uint64_t) stream_bytes);
+			bgzf_crc_kernel<<<n_blocks, 256, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+		}
 	}
 	HIP_CHECK(hipEventRecord(ctx->ingest_events[slot], s));
 	TRY(wait_for_previous_push(ctx));
@@ -502,6 +536,12 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ctx->ingest_active = false;
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
+	if (ctx->ingest_verify_crc) { // a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch")
+		unsigned int mismatches = 0;
+		HIP_CHECK(hipMemcpyAsync(&mismatches, ctx->scratch("ingest.crc_mismatches").ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (mismatches > 0) { set_last_error("failed to load alignments"); return AGPU_ERR_INVALID; }
+	}
 	const uint8_t* bytes = ctx->ingest_stream.as<uint8_t>();
 	DeviceBuffer& counters = ctx->scratch("ingest.counters"); DeviceBuffer& rocprim_scratch = ctx->scratch("ingest.rocprim");
 	ALLOC(counters, IC_COUNT * 4);

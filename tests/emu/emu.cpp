@@ -28,6 +28,7 @@
 #include "../../arriba_amd/csrc/device/multimapper_core.hpp"
 #include "../../arriba_amd/csrc/device/ingest_core.hpp"
 #include "../../arriba_amd/csrc/device/shard_host.hpp"
+#include "../../arriba_amd/csrc/device/crc32_core.hpp"
 #include <map>
 #include <set>
 #include <tuple>

@@ -390,6 +390,36 @@ def test_device_ingest_in_parts_gives_the_batch_of_the_whole_file(built, dataset
         _ingest_in_parts(apart, apart + ".bam", 3, emu_api)
 
 
+def test_stored_blocks_are_checked_against_their_crc(built, dataset_files, emu_api, tmp_path, monkeypatch):
+    """Stored BGZF blocks go to the device as they are; with ARRIBA_VERIFY_CRC=1 their payload is checked against the CRC-32 of the trailer (crc32_core.hpp, stepped
+    here as the kernel does it: 256-byte chunks joined in a tree; the core is checked against zlib on random blocks).  One flipped base of one read -- a record that
+    still parses -- is found; the intact file, whole and in parts (whose first and last blocks are delivered in part and carry no CRC), is accepted."""
+    import zlib
+    from arriba_amd.pipeline import ArribaError, DevicePipeline, HostSession
+    monkeypatch.setenv("ARRIBA_VERIFY_CRC", "1")
+    prefix = dataset_files("toy3k")
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    expected = _device_batch_columns(session, DevicePipeline(session, api=emu_api, bam=prefix + ".bam"))
+    merged_session, merged, _ = _ingest_in_parts(prefix, prefix + ".bam", 5, emu_api)
+    assert _device_batch_columns(merged_session, merged) == expected
+    raw = bytearray(open(prefix + ".bam", "rb").read())
+    at, blocks = 0, []
+    while at + 18 <= len(raw):
+        size = int.from_bytes(raw[at + 16:at + 18], "little") + 1
+        blocks.append((at, size))
+        at += size
+    start, size = blocks[len(blocks) // 2]
+    payload_at = start + 18 + 5 + 2000  # somewhere inside the sequence / quality bytes of a record in the middle of the file
+    assert zlib.crc32(bytes(raw[start + 23:start + size - 8])) == int.from_bytes(raw[start + size - 8:start + size - 4], "little")
+    raw[payload_at] ^= 0x11
+    damaged = str(tmp_path / "damaged.bam")
+    open(damaged, "wb").write(bytes(raw))
+    with pytest.raises(ArribaError, match="failed to load alignments"):
+        DevicePipeline(HostSession(prefix + ".fa", prefix + ".gtf"), api=emu_api, bam=damaged)
+    monkeypatch.delenv("ARRIBA_VERIFY_CRC")
+    DevicePipeline(HostSession(prefix + ".fa", prefix + ".gtf"), api=emu_api, bam=damaged)  # (without the check the damage goes unnoticed: a quality value or a base differs)
+
+
 def test_device_ingest_survives_a_false_record_start(built, dataset_files, emu_api, tmp_path):
     """The record chain is cut by segments that GUESS their first record.  A record whose aux array holds two well-formed record headers exactly at the start of
     an 8 KB segment makes that guess wrong (and flags the segment behind it, whose own guess is right): one repair pass must settle the chain -- not one pass per

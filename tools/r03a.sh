@@ -20,3 +20,7 @@ import json; d = json.loads(open('gpurun_out/r03a_bench10m_homolog_waves.json').
 ARRIBA_IN_VITRO_SUMMARY=1 timeout 300 python -m pytest tests -x -q -m gpu -k "chain_to or event_level or workflow_from_input_files" > gpurun_out/r03a_pytest_in_vitro_summary.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/r03a_pytest_in_vitro_summary.log
 ARRIBA_IN_VITRO_SUMMARY=1 timeout 120 python bench.py --fragments 10000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03a_bench10m_in_vitro_summary.json 2> /dev/null; python3 -c "
 import json; d = json.loads(open('gpurun_out/r03a_bench10m_in_vitro_summary.json').read().strip().splitlines()[-1]); print({k: v for k, v in d['kernel_ms'].items() if 'in_vitro' in k or 'clip_summary' in k}, d['ms_per_step'])"
+# 7. CRC-32 of the stored blocks on the device: parity of the check itself, then what it costs at 10 M (bgzf_crc_kernel in kernel_ms)
+timeout 120 python tools/r03a_crc.py 2>&1 | grep -v "^WARNING" | tail -2
+ARRIBA_VERIFY_CRC=1 timeout 120 python bench.py --fragments 10000000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03a_bench10m_crc.json 2> /dev/null; python3 -c "
+import json; d = json.loads(open('gpurun_out/r03a_bench10m_crc.json').read().strip().splitlines()[-1]); print({k: v for k, v in d['kernel_ms'].items() if 'bgzf' in k}, d['ms_per_step'])"
