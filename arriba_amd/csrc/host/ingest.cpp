@@ -1284,6 +1284,7 @@ public:
 		fd_ = (path == "-") ? 0 : open(path.c_str(), O_RDONLY);
 		if (fd_ < 0) throw std::runtime_error("failed to open SAM file");
 		file_.fd = fd_; file_.position = 0; file_.n_threads = std::min(32u, ingest_threads());
+		if (const char* knob = getenv("ARRIBA_FEED_THREADS")) if (atoi(knob) > 0) file_.n_threads = (unsigned int) std::min(atoi(knob), 256); // (how many threads read a piece of the file: for measurements)
 		struct stat status;
 		file_.seekable = fstat(fd_, &status) == 0 && S_ISREG(status.st_mode);
 		file_size_ = file_.seekable ? (uint64_t) status.st_size : 0;
