@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU run of round 3 (written at the end of round 2, when the GPU budget was spent): the measurements DESIGN.md section 8 asks for.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/r03a.sh'
+#   /usr/local/graft/bin/gpurun --timeout 2700 -- 'bash tools/r03a.sh'   (about 25 GPU-minutes)
 mkdir -p gpurun_out
 # 1. the GPU tier of the code as round 2 left it (31 tests; the sort path of agpu_shard_merge and the name-key check run on the GPU for the first time)
 timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/r03a_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/r03a_pytest_gpu.log
