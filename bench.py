@@ -222,7 +222,7 @@ def main():
             # with the reason -- a bench without a line is worth nothing
             command = [sys.executable, os.path.abspath(__file__), "--fragments", str(args.fragments), "--steps", str(args.steps), "--warmup", str(args.warmup)]
             command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--no-cpu-baseline", args.no_cpu_baseline)) if on]
-            limit = float(os.environ.get("ARRIBA_BENCH_LARGE_LIMIT", "900"))
+            limit = float(os.environ.get("ARRIBA_BENCH_LARGE_LIMIT", "600"))
             child_scratch = scratch_directory(args.fragments * 600)  # the child's sample lives here; removed below whatever happens to the child
             try:
                 child = subprocess.run(command, stdout=subprocess.PIPE, env=dict(os.environ, ARRIBA_BENCH_CHILD="1", ARRIBA_BENCH_SCRATCH=child_scratch), timeout=limit, universal_newlines=True)
@@ -296,7 +296,7 @@ def main():
             step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started})
             steps_done[0] += 1
             remaining = args.warmup + args.steps - steps_done[0]
-            if os.environ.get("ARRIBA_BENCH_CHILD") and remaining * (finished - started) > float(os.environ.get("ARRIBA_BENCH_TIME_BUDGET", "600")):
+            if os.environ.get("ARRIBA_BENCH_CHILD") and remaining * (finished - started) > float(os.environ.get("ARRIBA_BENCH_TIME_BUDGET", "420")):
                 # the large sample with this many steps would take too long for a bench run: say so and let the parent print the line of config 2
                 progress("a step of the %d-fragment sample takes %.1f s: %d more steps do not fit the time budget" % (args.fragments, finished - started, remaining))
                 raise SystemExit(3)  # (through the `finally` below: the 54 GB sample must not stay behind)
