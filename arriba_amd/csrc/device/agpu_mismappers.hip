@@ -430,10 +430,10 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				DeviceBuffer& memo_tables = ctx->scratch("mismappers.memo_tables");
 				ALLOC(memo_tables, (size_t) workgroups * memo_slots * 8);
 				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));
-				// the task lists of the workgroups: 2^16 tasks of 16 bytes each (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
+				// the task lists of the workgroups: 2^17 tasks of 16 bytes each (2 MB; 8 GB for 4096 workgroups) (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
 				knob = getenv("ARRIBA_MISMAPPER_WORKLIST");
 				const bool use_worklist = !(knob != nullptr && knob[0] == '0');
-				const uint32_t task_capacity = 1u << 16;
+				const uint32_t task_capacity = 1u << 17;
 				DeviceBuffer& task_lists = ctx->scratch("mismappers.task_lists");
 				if (use_worklist) ALLOC(task_lists, (size_t) workgroups * task_capacity * 16);
 				KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
