@@ -737,7 +737,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ctx->batch_from_ingest = true;
 	// The stream and the per-record tables are not needed any more.  Where memory is plentiful they stay for the next sample (a resident service reads sample after sample,
 	// and mapping / unmapping gigabytes costs as much as the kernels that use them); where the stages behind the ingest need the room -- a 10^8-fragment sample: 54 GB of
-	// stream, 35 GB of tables, and behind them 36 GB of memo and task lists, the read lists, the k-mer index -- they are given back.  The threshold is what was free in
+	// stream, 35 GB of tables, and behind them 40 GB of memo and task lists, the read lists, the k-mer index -- they are given back.  The threshold is what was free in
 	// the measured run of that sample plus a margin.
 	size_t free_bytes = 0, total_bytes = 0;
 	if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { (void) hipGetLastError(); free_bytes = 0; }
