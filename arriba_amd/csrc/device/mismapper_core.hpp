@@ -403,6 +403,10 @@ struct AlignRunner {
 	// reference: align(0, read, 0, contig, gene_start, gene_start, gene_end, ...) (source/filter_mismappers.cpp:86-199)
 	AlignMemo* memo = nullptr; // table of failed nested calls, shared by the lanes of the runner (second pass on the device); every align() takes a new epoch
 	AlignWorklist* worklist = nullptr; // the search as a list of tasks the lanes take in rounds (see AlignWorklist); needs the memo
+#if !defined(__HIP_DEVICE_COMPILE__)
+	uint32_t virtual_lanes = 1;        // host stepping only: tasks per round, taken one after the other (what 64 lanes take at once on the device)
+	unsigned long long* round_steps = nullptr; // host stepping only (with a budget): [0] += the steps of the longest task of every round, [1] += rounds
+#endif
 	bool lanes_share_seeds = false; // the lanes work on the same read position and split its seeds (reads with hundreds of seeds per position); default: one read position per lane
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
@@ -415,13 +419,28 @@ struct AlignRunner {
 				const AlignTask outermost = { -read_pos, read_pos, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
 				worklist->push(outermost);
 			}
-			for (uint32_t head = 0; ; head += lanes) { // rounds: every lane takes one task, the tasks it lists are taken in later rounds
+			for (uint32_t head = 0, taken = 0; ; head += taken) { // rounds: every lane takes one task, the tasks it lists are taken in later rounds
 				sync_lanes();
 				const uint32_t listed = worklist->state[0] < worklist->capacity ? worklist->state[0] : worklist->capacity;
 				const bool done = worklist->state[2] != 0 || head >= listed;
 				sync_lanes(); // (nobody lists a task before everybody has read the state of this round)
 				if (done) break;
-				if (head + lane < listed && align_search(read, target, min_score, stack, 0, worklist->task(head + lane), budget, 0, 1, memo, worklist)) worklist->state[2] = 1;
+				taken = listed - head < lanes ? listed - head : lanes; // (a round that is not full: the tasks listed during it start behind `listed`, not behind head + lanes)
+#if !defined(__HIP_DEVICE_COMPILE__)
+				if (virtual_lanes > 1) { // the tasks of one round of the device, one after the other
+					taken = listed - head < virtual_lanes ? listed - head : virtual_lanes;
+					long long longest = 0;
+					for (uint32_t v = 0; v < taken; ++v) {
+						const long long before = budget != nullptr ? *budget : 0;
+						if (align_search(read, target, min_score, stack, 0, worklist->task(head + v), budget, 0, 1, memo, worklist)) worklist->state[2] = 1;
+						if (budget != nullptr && before - *budget > longest) longest = before - *budget;
+						if (exhausted()) return false;
+					}
+					if (round_steps != nullptr) { round_steps[0] += (unsigned long long) longest; round_steps[1] += 1; }
+					continue;
+				}
+#endif
+				if (lane < taken && align_search(read, target, min_score, stack, 0, worklist->task(head + lane), budget, 0, 1, memo, worklist)) worklist->state[2] = 1;
 				if (exhausted()) return false;
 			}
 			if (worklist->state[2] != 0) return true;
