@@ -413,12 +413,15 @@ struct AlignRunner {
 		if (memo != nullptr) new_memo_epoch(); // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
 		if (worklist != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end)) {
 			sync_lanes();
-			if (lane == 0) { worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0; }
+			if (lane == 0) { worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0; } // ([3], the host's consistency flag, is the caller's)
 			sync_lanes();
 			for (int32_t read_pos = (int32_t) lane; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; read_pos += (int32_t) lanes) { // the iterations of the outermost loop
 				const AlignTask outermost = { -read_pos, read_pos, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
 				worklist->push(outermost);
 			}
+#if !defined(__HIP_DEVICE_COMPILE__)
+			uint32_t tasks_run = 0; // host stepping: every listed task must have been run when the search ends without a success (state[3] = 1 otherwise)
+#endif
 			for (uint32_t head = 0, taken = 0; ; head += taken) { // rounds: every lane takes one task, the tasks it lists are taken in later rounds
 				sync_lanes();
 				const uint32_t listed = worklist->state[0] < worklist->capacity ? worklist->state[0] : worklist->capacity;
@@ -430,6 +433,7 @@ struct AlignRunner {
 				if (virtual_lanes > 1) { // the tasks of one round of the device, one after the other
 					taken = listed - head < virtual_lanes ? listed - head : virtual_lanes;
 					long long longest = 0;
+					tasks_run += taken;
 					for (uint32_t v = 0; v < taken; ++v) {
 						const long long before = budget != nullptr ? *budget : 0;
 						if (align_search(read, target, min_score, stack, 0, worklist->task(head + v), budget, 0, 1, memo, worklist)) worklist->state[2] = 1;
@@ -440,10 +444,16 @@ struct AlignRunner {
 					continue;
 				}
 #endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+				tasks_run += taken;
+#endif
 				if (lane < taken && align_search(read, target, min_score, stack, 0, worklist->task(head + lane), budget, 0, 1, memo, worklist)) worklist->state[2] = 1;
 				if (exhausted()) return false;
 			}
 			if (worklist->state[2] != 0) return true;
+#if !defined(__HIP_DEVICE_COMPILE__)
+			if (worklist->state[1] == 0 && tasks_run != worklist->state[0]) worklist->state[3] = 1;
+#endif
 			if (worklist->state[1] == 0) return false;
 			new_memo_epoch(); // the list was too short for this search: done again by the recursion (what the memo has "seen" are not failures)
 		}
