@@ -202,6 +202,7 @@ def main():
     one_sample = distributed and not args.per_rank_samples and not args.host_ingest
 
     fallback_reason = os.environ.get("ARRIBA_BENCH_FALLBACK_REASON")
+    large_sample_record = None
     if args.fragments is None:
         # BASELINE.json quotes the metric on the 100 M-read synthetic: that is the default where the box can hold it (54 GB of BAM in memory per GPU, ~140 GB of HBM
         # at the peak); otherwise config 2 (10 M).
@@ -222,15 +223,24 @@ def main():
             # with the reason -- a bench without a line is worth nothing
             command = [sys.executable, os.path.abspath(__file__), "--fragments", str(args.fragments), "--steps", str(args.steps), "--warmup", str(args.warmup)]
             command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--no-cpu-baseline", args.no_cpu_baseline)) if on]
-            limit = float(os.environ.get("ARRIBA_BENCH_LARGE_LIMIT", "600"))
+            # the driver gives a bench run 1800 s; the large sample gets what is left of ~1500 s after a reserve for the line of config 2 (generation, 25 steps of ~1 s, the
+            # reference on its bounded sample: ~150 s), and its child decides after every step whether the steps asked for still fit (ARRIBA_BENCH_DEADLINE)
+            total_limit = float(os.environ.get("ARRIBA_BENCH_TOTAL_LIMIT", "1500"))
+            limit = float(os.environ.get("ARRIBA_BENCH_LARGE_LIMIT", str(max(60.0, total_limit - 150.0 - (time.time() - BENCH_STARTED)))))
             child_scratch = scratch_directory(args.fragments * 600)  # the child's sample lives here; removed below whatever happens to the child
             try:
-                child = subprocess.run(command, stdout=subprocess.PIPE, env=dict(os.environ, ARRIBA_BENCH_CHILD="1", ARRIBA_BENCH_SCRATCH=child_scratch), timeout=limit, universal_newlines=True)
+                child = subprocess.run(command, stdout=subprocess.PIPE, env=dict(os.environ, ARRIBA_BENCH_CHILD="1", ARRIBA_BENCH_SCRATCH=child_scratch, ARRIBA_BENCH_DEADLINE=str(limit - 40.0)), timeout=limit, universal_newlines=True)
                 lines = [line for line in child.stdout.splitlines() if line.startswith("{")]
-                if child.returncode == 0 and lines:
+                if child.returncode == 0 and lines and '"metric"' in lines[-1]:
                     print(lines[-1])
                     return
-                fallback_reason = ("a step of the 100 M sample takes too long for %d steps + %d warm-up steps within the time budget (python bench.py --fragments 100000000 --steps 1 --warmup 0 runs it: profiles/r02g_bench100m.json)" % (args.steps, args.warmup)) if child.returncode == 3 else "the 100 M sample ended with exit code %d and no line" % child.returncode
+                # the steps of the large sample that did run are not thrown away: they go into the line of config 2 as `large_sample`
+                for line in lines:
+                    try:
+                        large_sample_record = json.loads(line).get("large_sample", large_sample_record)
+                    except ValueError:
+                        pass
+                fallback_reason = ("the %d steps + %d warm-up steps asked for do not fit the time limit of the run at the measured step time of the 100 M sample (see large_sample)" % (args.steps, args.warmup)) if child.returncode == 3 else "the 100 M sample ended with exit code %d and no line" % child.returncode
             except subprocess.TimeoutExpired:
                 fallback_reason = "the 100 M sample did not finish within %.0f s" % limit
             finally:
@@ -260,7 +270,7 @@ def main():
         params = {"subsampling_threshold": 32767} if args.stress else None
         pipeline = None
         outputs = [os.path.join(directory, "fusions.rank%d.tsv" % rank), os.path.join(directory, "discarded.rank%d.tsv" % rank) if args.discarded else None]
-        stage_log, step_seconds, ingest_parts, steps_done = [], [], [], [0]
+        stage_log, step_seconds, ingest_parts, steps_done, all_steps = [], [], [], [0], []
 
         def step():
             nonlocal pipeline
@@ -296,10 +306,19 @@ def main():
             step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started})
             steps_done[0] += 1
             remaining = args.warmup + args.steps - steps_done[0]
-            if os.environ.get("ARRIBA_BENCH_CHILD") and remaining * (finished - started) > float(os.environ.get("ARRIBA_BENCH_TIME_BUDGET", "420")):
-                # the large sample with this many steps would take too long for a bench run: say so and let the parent print the line of config 2
-                progress("a step of the %d-fragment sample takes %.1f s: %d more steps do not fit the time budget" % (args.fragments, finished - started, remaining))
-                raise SystemExit(3)  # (through the `finally` below: the 54 GB sample must not stay behind)
+            deadline = os.environ.get("ARRIBA_BENCH_DEADLINE")
+            if os.environ.get("ARRIBA_BENCH_CHILD") and deadline and remaining > 0:
+                # the large sample: do the steps still to come fit?  Priced with the fastest step so far (the first one is cold: allocations, first touches of the
+                # pinned buffers), plus the reference on its bounded sample behind the steps
+                all_steps.append(finished - started)
+                per_step = min(all_steps)
+                if (time.time() - BENCH_STARTED) + remaining * per_step + (0 if args.no_cpu_baseline else 45) > float(deadline):
+                    progress("a step of the %d-fragment sample takes %.1f s: %d more steps do not fit the time limit" % (args.fragments, per_step, remaining))
+                    print(json.dumps({"large_sample": {"fragments": pipeline.n, "seconds_per_step": [round(x, 3) for x in all_steps], "steps_run": len(all_steps), "chimeric_reads_per_s": pipeline.n / per_step,
+                                                       "read_chimeric_alignments_seconds": ingest_parts[-1], "stage_kernel_ms": {stage: round(values["ms"], 1) for stage, values in pipeline.timings.items()},
+                                                       "output_side_seconds": getattr(pipeline, "writer_seconds", None)}}))
+                    sys.stdout.flush()
+                    raise SystemExit(3)  # (through the `finally` below: the 54 GB sample must not stay behind)
             progress("step done: read_chimeric_alignments %.2f s %s, workflow %.2f s; slowest stages: %s; output side: %s" % (ingested - started, ingest_parts[-1], finished - ingested,
                      sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4], getattr(pipeline, "writer_seconds", None)))
 
@@ -396,7 +415,7 @@ def main():
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
                            "outside_the_step": "loading assembly + annotation (ahost_open), device context; generating the sample took %.1f s" % generate_seconds,
                            "names_were_sorted": bool(pipeline.ingest_result.names_were_sorted) if pipeline.ingest_result else None,
-                           "why_not_the_100M_sample": fallback_reason},
+                           "why_not_the_100M_sample": fallback_reason, "large_sample": large_sample_record},
                 "seconds_per_step": {"read_chimeric_alignments": round(mean("ingest"), 4), "workflow_to_output_files": round(mean("workflow"), 4), "total": round(mean("total"), 4)},
                 "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
                 "output_side_seconds": getattr(pipeline, "writer_seconds", None),
