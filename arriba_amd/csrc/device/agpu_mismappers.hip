@@ -180,15 +180,19 @@ const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 32 GB for 4096 of
                                         // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
 const uint32_t HEAVY_WORKGROUPS = 4096;
 __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
-                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, unsigned int* counters) {
+                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_iteration, bool seeds_once, unsigned long long* read_times, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
+	__shared__ AlignRound round;
 	__shared__ AlignMemo memo;
 	__shared__ AlignWorklist worklist;
 	__shared__ uint32_t worklist_state[4];
 	__shared__ uint32_t next_job;
+	__shared__ uint32_t study[4];
 	if (threadIdx.x == 0) {
-		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0;
+		worklist.stats = read_times != nullptr ? study : nullptr;
+		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0; memo.seeds_once = seeds_once;
 		worklist.words = task_lists != nullptr ? task_lists + (size_t) blockIdx.x * task_capacity * 2 : nullptr; worklist.capacity = task_capacity; worklist.state = worklist_state;
+		worklist.round = by_iteration ? &round : nullptr; // the lanes take single iterations of the read-position loops of the listed calls (mismapper_core.hpp: AlignRound)
 	}
 	__syncthreads();
 	AlignFrame stack[ALIGN_MAX_DEPTH];
@@ -203,8 +207,14 @@ __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, Annota
 		__syncthreads();
 		if (next_job >= n_heavy) break;
 		const uint32_t read = heavy[next_job];
+		const unsigned long long started = read_times != nullptr ? wall_clock64() : 0ull;
+		if (read_times != nullptr && threadIdx.x == 0) { study[0] = 0; study[1] = 0; study[2] = 0; study[3] = 0; }
 		const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
 		if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
+		if (read_times != nullptr && threadIdx.x == 0) { // (ARRIBA_MISMAPPER_TIMES=1: ticks of the 100 MHz clock per read, and what the search of the read consisted of)
+			read_times[4 * (size_t) next_job] = wall_clock64() - started; read_times[4 * (size_t) next_job + 1] = (unsigned long long) study[0] << 32 | study[1]; read_times[4 * (size_t) next_job + 2] = (unsigned long long) study[2] << 32 | study[3];
+			read_times[4 * (size_t) next_job + 3] = (unsigned long long) read << 8 | b.n_aln[read];
+		}
 	}
 }
 
@@ -436,8 +446,36 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const uint32_t task_capacity = 1u << 17;
 				DeviceBuffer& task_lists = ctx->scratch("mismappers.task_lists");
 				if (use_worklist) ALLOC(task_lists, (size_t) workgroups * task_capacity * 16);
-				KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-				mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity, device_counters);
+				knob = getenv("ARRIBA_MISMAPPER_BY_ITERATION"); // "0": a lane runs a whole listed call (the schedule of round 2), for A/B measurements
+				const bool by_iteration = !(knob != nullptr && knob[0] == '0');
+				const bool want_times = getenv("ARRIBA_MISMAPPER_TIMES") != nullptr; // a study: how long the wavefronts worked on every read of the second pass, on stderr
+				DeviceBuffer& read_times = ctx->scratch("mismappers.read_times");
+				if (want_times) ALLOC(read_times, (size_t) n_heavy * 32);
+				{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
+				  mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
+				                                                by_iteration, !(getenv("ARRIBA_MISMAPPER_SEEDS_ONCE") != nullptr && getenv("ARRIBA_MISMAPPER_SEEDS_ONCE")[0] == '0'), want_times ? read_times.as<unsigned long long>() : nullptr, device_counters); }
+				if (want_times) {
+					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy);
+					HIP_CHECK(hipMemcpyAsync(ticks.data(), read_times.ptr, (size_t) n_heavy * 32, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(hipStreamSynchronize(s));
+					unsigned long long histogram[40] = { 0 }, total = 0, longest = 0, sums[4] = { 0, 0, 0, 0 };
+					std::vector<std::pair<unsigned long long, uint32_t> > by_time(n_heavy);
+					for (uint32_t k = 0; k < n_heavy; ++k) {
+						const unsigned long long t = ticks[4 * (size_t) k];
+						int bucket = 0; for (unsigned long long u = t / 100; u > 1; u >>= 1) ++bucket; histogram[bucket < 39 ? bucket : 39]++; total += t; if (t > longest) longest = t;
+						sums[0] += ticks[4 * (size_t) k + 1] >> 32; sums[1] += ticks[4 * (size_t) k + 1] & 0xFFFFFFFFu; sums[2] += ticks[4 * (size_t) k + 2] >> 32; sums[3] += ticks[4 * (size_t) k + 2] & 0xFFFFFFFFu;
+						by_time[k] = std::make_pair(t, k);
+					}
+					std::sort(by_time.begin(), by_time.end());
+					fprintf(stderr, "[mismapper_heavy_kernel] %u reads of %u jobs, %u workgroups, by_iteration %d: %.1f ms of wavefront time in all, longest read %.2f ms; calls %llu, iterations %llu, seeds %llu, seeds walked %llu; reads by time (us):", n_heavy, n_jobs, workgroups, (int) by_iteration, total / 1e5, longest / 1e5, sums[0], sums[1], sums[2], sums[3]);
+					for (int bucket = 0; bucket < 40; ++bucket) if (histogram[bucket]) fprintf(stderr, " 2^%d:%llu", bucket, histogram[bucket]);
+					fprintf(stderr, "\n");
+					for (uint32_t rank = 0; rank < 24 && rank < n_heavy; ++rank) { // the slowest reads, and every 1/8 quantile below them
+						const uint32_t k = by_time[rank < 16 ? n_heavy - 1 - rank : (size_t) (n_heavy - 1) * (24 - rank) / 9].second;
+						fprintf(stderr, "[mismapper_heavy_kernel]   read %llu (%llu alignments): %.2f ms, calls %llu, iterations %llu, seeds %llu, walked %llu\n", ticks[4 * (size_t) k + 3] >> 8, ticks[4 * (size_t) k + 3] & 255, ticks[4 * (size_t) k] / 1e5,
+						        ticks[4 * (size_t) k + 1] >> 32, ticks[4 * (size_t) k + 1] & 0xFFFFFFFFu, ticks[4 * (size_t) k + 2] >> 32, ticks[4 * (size_t) k + 2] & 0xFFFFFFFFu);
+					}
+				}
 			}
 			}
 			n_jobs = n_all;

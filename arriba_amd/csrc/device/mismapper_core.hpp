@@ -85,13 +85,21 @@ AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p
 // whose extensions cross splice sites again -- in a long gene with many exons the number of calls grows exponentially with the nesting (seconds to hours per
 // read), although there are only (read positions x splice sites + seeds) distinct calls.  With the memo every distinct call is searched once per score level.
 // The result is the reference's: only calls that are known to return false are skipped.
-// A slot holds epoch (8 bits: one per align() invocation, so that the table never needs clearing) | gene_pos - gene_start (24) | read_pos (9) | max_deletions (1) |
+// A slot holds epoch (8 bits: one per align() invocation, so that the table never needs clearing) | gene_pos - gene_start (24) | read_pos (9) | kind (1) | max_deletions (1) |
 // score + 32768 (16): for equal keys the larger word is the higher failed score.
+// kind 1 = a SEED instead of a call (round 3): the extension to the right of the seed at (read position, gene position) was walked with the recorded score at its start.  The
+// walk itself -- which bases are compared, where it crosses splice sites, where it ends -- does not depend on that score; a walk that starts with a lower score finds no
+// success the earlier one does not find and lists the same nested calls with lower scores, which the memo of the calls prunes.  So a seed is walked again only when it is
+// reached with a higher score than ever before.  Without this the calls of a read in a long gene (read positions x splice sites of them) walk the same few thousand seeds
+// 10^7 times (profiles/r03c_mismapper_second_pass.txt: single reads of 1 s).
+enum { MEMO_CALL = 0, MEMO_SEED = 1 };
 struct AlignMemo {
 	unsigned long long* slots; uint32_t mask; uint32_t epoch; // (no default initialisers: the device keeps one in LDS)
-	AGPU_HD bool usable(int32_t gene_start, int32_t gene_end) const { return slots != nullptr && (int64_t) gene_end - gene_start < (1 << 24); }
-	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions) const {
-		return ((unsigned long long) (epoch & 255u) << 34 | (unsigned long long) (uint32_t) gene_offset << 10 | (unsigned long long) (uint32_t) read_pos << 1 | (unsigned long long) (max_deletions > 0)) << 16;
+	uint32_t seeds_once;                                      // 1: the walks of the seeds are remembered as well (0: A/B measurements)
+	// (the key holds 24 bits of gene offset and 9 bits of read position: longer genes and reads are searched without the memo)
+	AGPU_HD bool usable(int32_t gene_start, int32_t gene_end, int32_t read_length) const { return slots != nullptr && (int64_t) gene_end - gene_start < (1 << 24) && read_length < 512; }
+	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions, uint32_t kind = MEMO_CALL) const {
+		return ((unsigned long long) (epoch & 255u) << 35 | (unsigned long long) (uint32_t) gene_offset << 11 | (unsigned long long) (uint32_t) read_pos << 2 | (unsigned long long) kind << 1 | (unsigned long long) (max_deletions > 0)) << 16;
 	}
 	AGPU_HD uint32_t slot_of(unsigned long long key) const { unsigned long long h = key * 0x9E3779B97F4A7C15ull; return (uint32_t) (h >> 40) & mask; }
 	// is a call with this key and a score <= the recorded one known to fail?
@@ -104,7 +112,7 @@ struct AlignMemo {
 			const unsigned long long slot = slots[at];
 #endif
 			if ((slot >> 16) == (key >> 16)) return score + 32768 <= (int32_t) (slot & 0xFFFF);
-			if ((slot >> 50) != (key >> 50)) return false; // empty or from an earlier align(): the key is not in the table
+			if ((slot >> 51) != (key >> 51)) return false; // empty or from an earlier align(): the key is not in the table
 		}
 		return false;
 	}
@@ -116,7 +124,7 @@ struct AlignMemo {
 #if defined(__HIP_DEVICE_COMPILE__)
 			unsigned long long slot = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if ((slot >> 16) == (key >> 16)) { atomicMax(&slots[at], word); return; }
-			if ((slot >> 50) != (key >> 50)) { // free for this epoch: take it (if another lane was faster with another key, go on probing)
+			if ((slot >> 51) != (key >> 51)) { // free for this epoch: take it (if another lane was faster with another key, go on probing)
 				const unsigned long long seen = atomicCAS(&slots[at], slot, word);
 				if (seen == slot) return;
 				if ((seen >> 16) == (key >> 16)) { atomicMax(&slots[at], word); return; }
@@ -124,7 +132,7 @@ struct AlignMemo {
 #else
 			const unsigned long long slot = slots[at];
 			if ((slot >> 16) == (key >> 16)) { if (word > slot) slots[at] = word; return; }
-			if ((slot >> 50) != (key >> 50)) { slots[at] = word; return; }
+			if ((slot >> 51) != (key >> 51)) { slots[at] = word; return; }
 #endif
 		}
 	}
@@ -153,11 +161,36 @@ const int ALIGN_SHALLOW_DEPTH = 16;       // ... of <= 128 bases: the stack of t
 // one has finished or not: if it succeeds the answer is true anyway, if it fails so would this one).  One search of ~10^6 dependent steps in one lane -- the
 // end of the second pass on the device waits for exactly that -- becomes rounds of up to 64 tasks, one per lane.  A list that overflows is abandoned and the
 // search is done by the recursion.
-enum { ALIGN_TASK_DELETIONS = 1, ALIGN_TASK_ROOT = 2 }; // max_deletions > 0 / one iteration of the outermost loop of align() (leading skipped bases are free)
+// What the list holds are CALLS of align(): (score, read position, gene position) at the entry of the call, ALIGN_TASK_DELETIONS = max_deletions > 0, ALIGN_TASK_ROOT = the outermost
+// call (its skipped bases are leading ones and cost nothing).  What a lane runs is ONE ITERATION of the read-position loop of a call (ALIGN_TASK_ONE, the number of the
+// iteration = the bases skipped so far in flags >> 8): the iterations of the loop are independent attempts as well -- iteration i starts from (score - i, read_pos + i) and the
+// bound of the loop is monotone in i -- and a nested call left to one lane is a chain of ~80 read positions x their seeds, which is what a round used to wait for.
+enum { ALIGN_TASK_DELETIONS = 1, ALIGN_TASK_ROOT = 2, ALIGN_TASK_ONE = 4, ALIGN_TASK_SKIPPED_SHIFT = 8 };
 struct AlignTask { int32_t score, read_pos, gene_pos; uint32_t flags; };
+// iterations of the read-position loop of a call: for (i = 0; read_pos + i + k < length && read_pos + i + min_score <= length + (score - i) + 2 k; ++i)
+AGPU_HD uint32_t align_iterations(const AlignTask& call, int32_t length, int32_t min_score) {
+	const int32_t by_length = length - KMER_LENGTH - call.read_pos;                                   // i < by_length
+	const int32_t slack = length + call.score + 2 * KMER_LENGTH - call.read_pos - min_score;         // 2 i <= slack
+	if (by_length <= 0 || slack < 0) return 0;
+	const int32_t by_score = slack / 2 + 1;
+	return (uint32_t) (by_length < by_score ? by_length : by_score);
+}
+AGPU_HD AlignTask align_iteration(const AlignTask& call, uint32_t i) {
+	const AlignTask item = { call.score - (int32_t) i, call.read_pos + (int32_t) i, call.gene_pos, (call.flags & (ALIGN_TASK_DELETIONS | ALIGN_TASK_ROOT)) | ALIGN_TASK_ONE | i << ALIGN_TASK_SKIPPED_SHIFT };
+	return item;
+}
+// the calls of one round of a runner and the running sum of their iterations (memory the lanes share: LDS on the device)
+// ... and the 64 iterations being worked on: where each one's seeds start in the position list, and the running sum of their seeds.  The lanes then take 64 SEEDS at a time
+// (align_extend_seed): every lane runs the same code -- one extension to the left and to the right -- instead of being somewhere else in the state machine of a whole call.
+struct AlignRound {
+	int32_t score[64], read_pos[64], gene_pos[64]; uint32_t flags[64], end[64];
+	int32_t item_score[64], item_read_pos[64]; uint32_t item_flags[64], item_first_hit[64], item_seed_end[64];
+};
 struct AlignWorklist {
 	unsigned long long* words; uint32_t capacity; // two 64-bit words per task
 	uint32_t* state;                              // [0] tasks listed, [1] overflow, [2] found (memory the lanes of the runner share: LDS on the device)
+	AlignRound* round;                            // the calls of the round being worked on (null: a lane runs a whole call, as before round 3)
+	uint32_t* stats;                              // null, or a study: [0] calls taken, [1] iterations looked up, [2] seeds, [3] seeds walked (not pruned by the memo), shared by the lanes
 	AGPU_HD void push(const AlignTask& task) const {
 #if defined(__HIP_DEVICE_COMPILE__)
 		const uint32_t at = atomicAdd(&state[0], 1u);
@@ -208,12 +241,14 @@ static AlignStats g_align_stats;
 AGPU_HD bool align_search(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, const AlignTask& task, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1,
                           const AlignMemo* memo = nullptr, const AlignWorklist* worklist = nullptr) {
 	const int32_t length = (int32_t) read.length;
-	const bool use_memo = memo != nullptr && memo->usable(target.gene_start, target.gene_end);
+	const bool use_memo = memo != nullptr && memo->usable(target.gene_start, target.gene_end, length);
 	const bool root = (task.flags & ALIGN_TASK_ROOT) != 0;
+	const bool one_iteration = (task.flags & (ALIGN_TASK_ROOT | ALIGN_TASK_ONE)) != 0; // (a root task of the old kind is iteration read_pos of the outermost loop)
 	int depth = 0;
 	AlignFrame f;
 	align_enter(f, task.score, task.read_pos, task.gene_pos, (task.flags & ALIGN_TASK_DELETIONS) ? 1 : 0);
 	if (root) { f.skipped_bases = task.read_pos; f.leading = 1; } // iteration read_pos of the outermost loop: score -read_pos, all skipped bases leading
+	else if (task.flags & ALIGN_TASK_ONE) { f.skipped_bases = (int32_t) (task.flags >> ALIGN_TASK_SKIPPED_SHIFT); f.leading = 0; } // iteration `skipped` of the loop of a nested call
 	f.extended_score = 0; f.extended_read_pos = 0; f.extended_gene_pos = 0; f.mismatch_count = 0; f.consecutive_mismatches = 0;
 	while (true) {
 		if (budget != nullptr && --*budget < 0) return false;
@@ -222,7 +257,7 @@ AGPU_HD bool align_search(const Segment& read, const AlignTarget& target, int32_
 		switch (f.state) {
 			case ALIGN_NEXT_READ_POSITION: { // for (; read_pos + k < length && ...; read_pos++, score--, skipped_bases++)
 				ALIGN_STAT(read_positions, 1);
-				if (f.started && depth == 0 && root) return false; // the other read positions of the outermost loop are other attempts
+				if (f.started && depth == 0 && one_iteration) return false; // the other iterations of this loop are other attempts
 				if (f.started) { f.read_pos++; f.score--; f.skipped_bases++; }
 				f.started = 1;
 				if (!(f.read_pos + KMER_LENGTH < length && f.read_pos + min_score <= length + f.score + 2 * KMER_LENGTH)) { fail = true; break; }
@@ -354,6 +389,95 @@ AGPU_HD bool align_search(const Segment& read, const AlignTarget& target, int32_
 	}
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+static unsigned long long g_align_seed_steps = 0; // host stepping: bases compared by align_extend_seed (the harness reports what a wavefront would wait for)
+#define ALIGN_SEED_STEP() (++g_align_seed_steps)
+#else
+#define ALIGN_SEED_STEP() ((void) 0)
+#endif
+// One seed of one iteration of a call, to its end: the body of the hit loop of the reference's align() (source/filter_mismappers.cpp:106-183) with the nested calls LISTED
+// instead of made (the search goes on as if they had failed: the result of align() is an OR over everything that gets searched, see AlignWorklist).  No stack, no state
+// machine: what ALIGN_NEXT_HIT .. ALIGN_ADVANCE of align_search do for one hit.  `item` = the iteration (ALIGN_TASK_ONE: score and read position of the iteration, skipped
+// bases in the flags), kmer_hit = position of the seed in the gene.
+AGPU_HD bool align_extend_seed(const Segment& read, const AlignTarget& target, int32_t min_score, const AlignTask& item, int32_t kmer_hit, const AlignMemo& memo, const AlignWorklist& worklist) {
+	const int32_t length = (int32_t) read.length;
+	const bool leading = (item.flags & ALIGN_TASK_ROOT) != 0;
+	const int32_t skipped_bases = (int32_t) (item.flags >> ALIGN_TASK_SKIPPED_SHIFT), read_pos = item.read_pos;
+	const int32_t max_deletions = (item.flags & ALIGN_TASK_DELETIONS) ? 1 : 0;
+	ALIGN_STAT(hits, 1);
+	int32_t extended_score = item.score + KMER_LENGTH;
+	if (leading) extended_score += skipped_bases; // no penalty for leading skipped bases (local alignment)
+	if (extended_score >= min_score) return true;
+	{ // extend to the left over the skipped bases, one mismatch allowed
+		int32_t left_read_pos = read_pos - 1, left_gene_pos = kmer_hit - 1;
+		uint32_t left_mismatches = 0;
+		while (left_read_pos >= read_pos - skipped_bases && left_gene_pos >= target.gene_start) {
+			if (read.at((uint32_t) left_read_pos) == target.contig_bases[left_gene_pos]) {
+				extended_score += leading ? 1 : 2;
+				if (extended_score >= min_score) return true;
+			} else if (++left_mismatches > 1) break;
+			left_read_pos--; left_gene_pos--;
+		}
+	}
+	{ // walked before from this seed with at least this score (AlignMemo, kind MEMO_SEED)?
+		const unsigned long long key = memo.key_of(read_pos, kmer_hit - target.gene_start, max_deletions, MEMO_SEED);
+		if (memo.seeds_once) {
+			if (memo.known_to_fail(key, extended_score)) { ALIGN_STAT(pruned, 1); return false; }
+			memo.record_failure(key, extended_score);
+		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (worklist.stats != nullptr) atomicAdd(&worklist.stats[3], 1u);
+#endif
+	}
+	int32_t extended_read_pos = read_pos + KMER_LENGTH, extended_gene_pos = kmer_hit + KMER_LENGTH;
+	uint32_t mismatch_count = 0, consecutive_mismatches = 0;
+	uint32_t splice_cursor = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, extended_gene_pos - 1);
+	int32_t next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF; // the first splice site at or behind extended_gene_pos - 1
+	uint64_t window = 0; int32_t window_at = 0, window_end = 0;                // genome bases [window_at, window_end) of the contig
+	uint64_t read_window = 0; int32_t read_window_at = 0, read_window_end = 0; // bases [read_window_at, read_window_end) of the read
+	ALIGN_SEED_STEP();
+	while (extended_read_pos < length && extended_gene_pos <= target.gene_end) {
+		ALIGN_STAT(bases, 1); ALIGN_SEED_STEP();
+		int32_t call_max_deletions = -1; // >= 0: a nested align(extended_score, extended_read_pos, extended_gene_pos, call_max_deletions) is due
+		if (next_site < extended_gene_pos - 1) {
+			while (splice_cursor < target.n_splice_sites && target.splice_sites[splice_cursor] < extended_gene_pos - 1) ++splice_cursor;
+			next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF;
+		}
+		for (int stage = 0; stage < 2; ++stage) { // 0: behind a splice site (before the base is compared), 1: after the first mismatch (before it is counted against the score)
+			if (stage == 0) { if (next_site == extended_gene_pos - 1) call_max_deletions = max_deletions; }
+			else {
+				if (extended_gene_pos >= window_end || extended_gene_pos < window_at) { window_at = extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
+				if (extended_read_pos >= read_window_end || extended_read_pos < read_window_at) { read_window_at = extended_read_pos; read_window_end = read_window_at + 8; read_window = read.chars8((uint32_t) read_window_at); }
+				if ((char) (read_window >> (8 * (extended_read_pos - read_window_at))) == (char) (window >> (8 * (extended_gene_pos - window_at)))) {
+					extended_score++;
+					if (extended_score >= min_score) return true;
+					consecutive_mismatches = 0;
+					break;
+				}
+				mismatch_count++;
+				if (mismatch_count == 1 && max_deletions > 0 && length >= 30) call_max_deletions = max_deletions - 1; // re-seed once after the first mismatch (deletion / intron)
+			}
+			if (call_max_deletions >= 0) {
+				const unsigned long long key = memo.key_of(extended_read_pos, extended_gene_pos - target.gene_start, call_max_deletions);
+				if (!memo.known_to_fail(key, extended_score)) { // not listed before with at least this score
+					memo.record_failure(key, extended_score);
+					const AlignTask nested = { extended_score, extended_read_pos, extended_gene_pos, call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u };
+					worklist.push(nested);
+					ALIGN_STAT(calls, 1);
+				} else ALIGN_STAT(pruned, 1);
+				call_max_deletions = -1;
+			}
+			if (stage == 1) { // the mismatch counts
+				extended_score--;
+				consecutive_mismatches++;
+			}
+		}
+		if (consecutive_mismatches >= 4) return false; // on to the next seed
+		extended_read_pos++; extended_gene_pos++;
+	}
+	return false;
+}
+
 AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& target, int32_t min_score, AlignFrame* stack, int max_depth, int32_t first_read_pos, int64_t* budget, uint32_t hit_offset = 0, uint32_t hit_stride = 1, const AlignMemo* memo = nullptr) {
 	const AlignTask task = { -first_read_pos, first_read_pos, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
 	return align_search(read, target, min_score, stack, max_depth, task, budget, hit_offset, hit_stride, memo, nullptr);
@@ -408,13 +532,68 @@ struct AlignRunner {
 	unsigned long long* round_steps = nullptr; // host stepping only (with a budget): [0] += the steps of the longest task of every round, [1] += rounds
 #endif
 	bool lanes_share_seeds = false; // the lanes work on the same read position and split its seeds (reads with hundreds of seeds per position); default: one read position per lane
+	// the lanes of a round: on the device every lane does its own share (lane, lane + 64, ...), the host steps through all of them
+	AGPU_HD uint32_t first_of_mine(uint32_t width) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		return lane;
+#else
+		return 0;
+#endif
+	}
+	AGPU_HD uint32_t stride_of_mine(uint32_t width) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		return lanes;
+#else
+		return 1;
+#endif
+	}
+	// values[0 .. n) -> their running sums, in place; returns the total (on the device: every lane sums up to its own element, the barrier in between keeps readers and writers apart)
+	AGPU_HD uint32_t running_sums(uint32_t* values, uint32_t n, uint32_t width) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		uint32_t mine = 0, total = 0;
+		for (uint32_t k = 0; k < n; ++k) { const uint32_t value = values[k]; total += value; if (k <= lane) mine += value; }
+		sync_lanes();
+		if (lane < n) values[lane] = mine;
+		sync_lanes();
+		return total;
+#else
+		uint32_t total = 0;
+		for (uint32_t k = 0; k < n; ++k) { total += values[k]; values[k] = total; }
+		return total;
+#endif
+	}
+	AGPU_HD static void round_load_call(AlignRound& round, uint32_t c, const AlignTask& call, int32_t length, int32_t min_score) {
+		round.score[c] = call.score; round.read_pos[c] = call.read_pos; round.gene_pos[c] = call.gene_pos; round.flags[c] = call.flags;
+		round.end[c] = align_iterations(call, length, min_score);
+	}
+	// iteration number `item` of the calls of the round -> slot k of the iterations being worked on: where its seeds are (source/filter_mismappers.cpp:100-106: the k-mer at the
+	// read position, its positions from gene_pos on, up to the end of the gene)
+	AGPU_HD static void round_load_item(AlignRound& round, uint32_t k, uint32_t item, uint32_t n_calls, const Segment& read, const AlignTarget& target) {
+		uint32_t lo = 0, hi = n_calls - 1; // the first call whose running sum exceeds the item
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (round.end[mid] <= item) lo = mid + 1; else hi = mid; }
+		const AlignTask call = { round.score[lo], round.read_pos[lo], round.gene_pos[lo], round.flags[lo] };
+		const AlignTask iteration = align_iteration(call, item - (lo > 0 ? round.end[lo - 1] : 0u));
+		ALIGN_STAT(read_positions, 1);
+		round.item_score[k] = iteration.score; round.item_read_pos[k] = iteration.read_pos; round.item_flags[k] = iteration.flags;
+		uint32_t first = 0, count = 0;
+		if (target.kmer_offsets != 0) { // (no k-mer index on this contig: every lookup misses)
+			const uint32_t kmer = read.kmer((uint32_t) iteration.read_pos);
+			const uint32_t begin = target.kmer_offsets[kmer], end = target.kmer_offsets[kmer + 1];
+			first = lower_bound_i32(target.positions, begin, end, iteration.gene_pos);
+			count = lower_bound_i32(target.positions, first, end, target.gene_end) - first; // hits at positions < gene_end
+		}
+		round.item_first_hit[k] = first; round.item_seed_end[k] = count;
+	}
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
 		if (memo != nullptr) new_memo_epoch(); // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
-		if (worklist != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end)) {
+		if (worklist != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end, length)) {
 			sync_lanes();
 			if (lane == 0) { worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0; } // ([3], the host's consistency flag, is the caller's)
 			sync_lanes();
+			if (worklist->round != nullptr) {
+				if (lane == 0) { const AlignTask outermost = { 0, 0, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS }; worklist->push(outermost); } // the outermost call; its iterations are taken apart like those of any other
+			} else
 			for (int32_t read_pos = (int32_t) lane; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; read_pos += (int32_t) lanes) { // the iterations of the outermost loop
 				const AlignTask outermost = { -read_pos, read_pos, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
 				worklist->push(outermost);
@@ -429,6 +608,61 @@ struct AlignRunner {
 				sync_lanes(); // (nobody lists a task before everybody has read the state of this round)
 				if (done) break;
 				taken = listed - head < lanes ? listed - head : lanes; // (a round that is not full: the tasks listed during it start behind `listed`, not behind head + lanes)
+				if (worklist->round != nullptr) {
+					// a round = up to 64 calls, their iterations numbered through; 64 iterations at a time look up their seeds; the lanes take 64 seeds at a time
+					AlignRound& round = *worklist->round;
+#if !defined(__HIP_DEVICE_COMPILE__)
+					const uint32_t width = virtual_lanes > 1 ? (virtual_lanes < 64 ? virtual_lanes : 64) : 1; // host stepping: the lanes of the device one after the other
+					taken = listed - head < width ? listed - head : width;
+					tasks_run += taken;
+#else
+					const uint32_t width = lanes;
+#endif
+					for (uint32_t c = first_of_mine(width); c < taken; c += stride_of_mine(width)) round_load_call(round, c, worklist->task(head + c), length, min_score);
+					sync_lanes();
+					const uint32_t total = running_sums(round.end, taken, width);
+#if defined(__HIP_DEVICE_COMPILE__)
+					if (worklist->stats != nullptr && lane == 0) { worklist->stats[0] += taken; worklist->stats[1] += total; }
+#endif
+					for (uint32_t base = 0; base < total; base += width) {
+						const uint32_t n_items = total - base < width ? total - base : width;
+						for (uint32_t k = first_of_mine(width); k < n_items; k += stride_of_mine(width)) round_load_item(round, k, base + k, taken, read, target);
+						sync_lanes();
+						const uint32_t seeds = running_sums(round.item_seed_end, n_items, width);
+#if defined(__HIP_DEVICE_COMPILE__)
+						if (worklist->stats != nullptr && lane == 0) worklist->stats[2] += seeds;
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+						if (round_steps != nullptr) { round_steps[0] += 16; round_steps[1] += 1; } // (what the look-up of the seeds of 64 iterations costs, in the currency of the steps of an extension)
+#endif
+						for (uint32_t seed_base = 0; seed_base < seeds; seed_base += width) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+							unsigned long long longest = 0;
+#endif
+							for (uint32_t seed = seed_base + first_of_mine(width); seed < seeds && seed < seed_base + width; seed += stride_of_mine(width)) {
+								uint32_t lo = 0, hi = n_items - 1; // the first iteration whose running sum exceeds the seed
+								while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (round.item_seed_end[mid] <= seed) lo = mid + 1; else hi = mid; }
+								const AlignTask item = { round.item_score[lo], round.item_read_pos[lo], 0, round.item_flags[lo] };
+								const uint32_t hit = round.item_first_hit[lo] + (seed - (lo > 0 ? round.item_seed_end[lo - 1] : 0u));
+#if !defined(__HIP_DEVICE_COMPILE__)
+								const unsigned long long before = g_align_seed_steps;
+#endif
+								if (align_extend_seed(read, target, min_score, item, target.positions[hit], *memo, *worklist)) worklist->state[2] = 1;
+#if !defined(__HIP_DEVICE_COMPILE__)
+								if (g_align_seed_steps - before > longest) longest = g_align_seed_steps - before;
+								if (budget != nullptr) *budget -= (int64_t) (g_align_seed_steps - before); // (host stepping: the steps of the read, for the statistics of the harness)
+#endif
+							}
+#if !defined(__HIP_DEVICE_COMPILE__)
+							if (round_steps != nullptr) { round_steps[0] += longest; round_steps[1] += 1; }
+#endif
+							sync_lanes();
+							if (worklist->state[2] != 0) break; // (the same for every lane: read behind the barrier)
+						}
+						if (worklist->state[2] != 0) break;
+					}
+					continue;
+				}
 #if !defined(__HIP_DEVICE_COMPILE__)
 				if (virtual_lanes > 1) { // the tasks of one round of the device, one after the other
 					taken = listed - head < virtual_lanes ? listed - head : virtual_lanes;

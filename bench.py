@@ -72,6 +72,8 @@ def generate_sample(fragments, seed, directory, read_seed=0, stress=False, threa
     prefix = os.path.join(directory, "bench")
     threads = threads or min(64, max(1, (os.cpu_count() or 2) - 2))
     started = time.time()
+    if os.environ.get("ARRIBA_BENCH_REUSE") and all(os.path.exists(prefix + suffix) for suffix in (".bam", ".fa", ".gtf")):
+        return prefix, 0.0  # (A/B measurements on one GPU lease: the sample of an earlier run with --keep)
     subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(threads)] + workload_args(fragments, seed, read_seed, stress), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return prefix, time.time() - started
 

@@ -55,6 +55,31 @@ void arriba_workflow_default_options(arriba_workflow_options* options);
 int arriba_workflow_run(const arriba_workflow_options* options, arriba_workflow_report* report /* may be NULL */);
 const char* arriba_workflow_last_error(void);
 
+/* The same workflow as a resident service: what main() does once per process -- load_assembly, read_annotation_gtf, make_annotation_index, the -t / -p files
+ * (source/arriba.cpp:97-113,586-598) and, here, the device context with the annotation in HBM -- happens in arriba_workflow_open; arriba_workflow_sample is
+ * everything main() does per sample: read_chimeric_alignments ... the output file(s) (source/arriba.cpp:119-610).  The buffers of a sample (the pinned pieces the file
+ * is fed through, the HBM of the stages) stay with the session for the next one.  arriba_workflow_run == open + sample + close.  bench.py times arriba_workflow_sample. */
+typedef struct arriba_workflow_session arriba_workflow_session;
+typedef struct { /* seconds of one sample, by part (wall clock of the calling thread) */
+	double total;
+	double feed;             /* the bytes of the file on their way to HBM (ahost_bam_next + agpu_ingest_push*), up to the last piece */
+	double ingest;           /* agpu_ingest_finish: read_chimeric_alignments on the device behind the last piece */
+	double adopt;            /* counters, coverage_t and viral read counts of the ingest back to the host session */
+	double stages;           /* mark_multimappers ... filter_homologs and what follows filter_mismappers up to assign_confidence (every stage on the device but the next line) */
+	double filter_mismappers;
+	double output;           /* write_fusions_to_file for -o (and -O): results back, rows of the supporting reads, formatting, the file */
+	double output_results;   /*   of it: the candidate table and read lists of the written candidates back to the host */
+	double output_rows;      /*   of it: the rows (names, CIGARs, sequences) of their supporting reads */
+	double output_format;    /*   of it: ahost_write_fusions */
+} arriba_workflow_timing;
+/* options->chimeric_bam_file, output_file and discarded_output_file are not used by open (they belong to a sample); NULL + arriba_workflow_last_error() on failure */
+arriba_workflow_session* arriba_workflow_open(const arriba_workflow_options* options);
+int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeric_bam_file, const char* output_file, const char* discarded_output_file /* may be NULL */,
+                           arriba_workflow_report* report /* may be NULL */, arriba_workflow_timing* timing /* may be NULL */);
+agpu_ctx* arriba_workflow_device(arriba_workflow_session* session);      /* the session's device context, e.g. for agpu_set_profiling / agpu_get_kernel_profile */
+ahost_session* arriba_workflow_host(arriba_workflow_session* session);
+void arriba_workflow_close(arriba_workflow_session* session);
+
 #ifdef __cplusplus
 }
 #endif
