@@ -55,7 +55,12 @@ class GenomicBreakpoint(ctypes.Structure):
 class FusionTable(ctypes.Structure):
     _fields_ = [("n_candidates", c_uint32), ("gene1", c_void_p), ("gene2", c_void_p), ("contigs", c_void_p), ("breakpoint1", c_void_p), ("breakpoint2", c_void_p), ("flags", c_void_p), ("filter", c_void_p),
                 ("split_reads1", c_void_p), ("split_reads2", c_void_p), ("discordant_mates", c_void_p), ("list_offset", c_void_p), ("read_lists", c_void_p), ("evalue", c_void_p), ("confidence", c_void_p),
-                ("iteration_rank", c_void_p), ("read_filter", c_void_p), ("closest_genomic_breakpoint1", c_void_p), ("closest_genomic_breakpoint2", c_void_p), ("n_genes", c_uint32), ("gene_contig", c_void_p), ("gene_start", c_void_p), ("gene_end", c_void_p)]
+                ("iteration_rank", c_void_p), ("read_filter", c_void_p), ("closest_genomic_breakpoint1", c_void_p), ("closest_genomic_breakpoint2", c_void_p), ("n_genes", c_uint32), ("gene_contig", c_void_p), ("gene_start", c_void_p), ("gene_end", c_void_p), ("read_filter_of_rows", c_void_p)]
+
+
+class SelectedCandidates(ctypes.Structure):
+    _fields_ = [(name, c_void_p) for name in ("candidate", "gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "evalue", "confidence",
+                                              "iteration_rank", "closest_genomic_breakpoint1", "closest_genomic_breakpoint2")]
 
 
 class BatchView(ctypes.Structure):
@@ -137,6 +142,9 @@ def bind_device_api(lib, prefix="agpu_"):
         "get_candidate_read_lists_of": (c_int, [ctx, c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
         "get_discordant_swapped": (c_int, [ctx, c_void_p]),
         "get_filters": (c_int, [ctx, c_void_p]),
+        "get_filters_of": (c_int, [ctx, c_void_p, c_uint64, c_void_p]),
+        "select_candidates": (c_int, [ctx, c_int, POINTER(c_uint64)]),
+        "get_selected_candidates": (c_int, [ctx, POINTER(SelectedCandidates)]),
         "get_alignment_bits": (c_int, [ctx, c_int, c_void_p]),
         "get_fragment_bits": (c_int, [ctx, c_void_p]),
         "get_gene_sets": (c_int, [ctx, c_int, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
@@ -280,6 +288,48 @@ def bind_host_api(lib):
 
 _device_lib = None
 _host_lib = None
+
+
+class WorkflowOptions(ctypes.Structure):
+    """arriba_workflow_options (include/arriba_workflow.h): options_t of the reference (source/options.hpp)"""
+    _fields_ = [(name, c_char_p) for name in ("assembly_file", "gene_annotation_file", "chimeric_bam_file", "output_file", "discarded_output_file", "blacklist_file", "known_fusions_file", "tags_file",
+                                              "protein_domains_file", "genomic_breakpoints_file", "interesting_contigs", "viral_contigs", "gtf_features")] + [
+        ("device", Params), ("min_itd_support", c_uint32), ("min_itd_allele_fraction", c_float), ("high_expression_quantile", c_float), ("min_spliced_events", c_uint32), ("min_anchor_length", c_uint32),
+        ("max_homolog_identity", c_float), ("top_viral_contigs", c_uint32), ("viral_contig_min_covered_fraction", c_float), ("max_genomic_breakpoint_distance", c_int32),
+        ("print_extra_info_for_discarded_fusions", c_uint8), ("fill_sequence_gaps", c_uint8), ("device_index", c_int), ("log_to_stdout", c_uint8), ("host_ingest", c_uint8)]
+
+
+class WorkflowStage(ctypes.Structure):
+    _fields_ = [("stage", ctypes.c_char * 48), ("count", c_uint64)]
+
+
+class WorkflowReport(ctypes.Structure):
+    _fields_ = [("n_stages", c_uint32), ("stages", WorkflowStage * 64)]
+
+
+class WorkflowTiming(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format")]
+
+
+_workflow_lib = None
+
+
+def workflow_library():
+    """libarriba_workflow.so: the reference's main() over the two C ABIs (include/arriba_workflow.h); tests replace it with the build against the host stepping harness"""
+    global _workflow_lib
+    if _workflow_lib is None:
+        device_library(); host_library()
+        lib = _load(os.environ.get("ARRIBA_WORKFLOW_LIBRARY", os.path.join(LIB_DIR, "libarriba_workflow.so")))
+        lib.arriba_workflow_default_options.argtypes = [POINTER(WorkflowOptions)]; lib.arriba_workflow_default_options.restype = None
+        lib.arriba_workflow_last_error.restype = c_char_p
+        lib.arriba_workflow_run.argtypes = [POINTER(WorkflowOptions), POINTER(WorkflowReport)]; lib.arriba_workflow_run.restype = c_int
+        lib.arriba_workflow_open.argtypes = [POINTER(WorkflowOptions)]; lib.arriba_workflow_open.restype = c_void_p
+        lib.arriba_workflow_sample.argtypes = [c_void_p, c_char_p, c_char_p, c_char_p, POINTER(WorkflowReport), POINTER(WorkflowTiming)]; lib.arriba_workflow_sample.restype = c_int
+        lib.arriba_workflow_device.argtypes = [c_void_p]; lib.arriba_workflow_device.restype = c_void_p
+        lib.arriba_workflow_host.argtypes = [c_void_p]; lib.arriba_workflow_host.restype = c_void_p
+        lib.arriba_workflow_close.argtypes = [c_void_p]; lib.arriba_workflow_close.restype = None
+        _workflow_lib = lib
+    return _workflow_lib
 
 
 def device_library():

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <rocprim/rocprim.hpp>
@@ -26,6 +27,23 @@ using namespace agpu;
 namespace agpu {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& message) { g_last_error = message; }
+
+// the live contexts of the process: an allocation that fails asks them to give back what they only keep for their next sample
+static std::mutex g_contexts_mutex;
+static std::vector<agpu_ctx*> g_contexts;
+bool DeviceBuffer::release_idle_buffers() {
+	std::lock_guard<std::mutex> lock(g_contexts_mutex);
+	bool released = false;
+	for (size_t k = 0; k < g_contexts.size(); ++k) {
+		agpu_ctx* ctx = g_contexts[k];
+		(void) hipStreamSynchronize(ctx->stream);
+		if (!ctx->ingest_active) { if (release_ingest_buffers(ctx)) released = true; }
+		else // an ingest runs: nothing of the stages of the sample before is needed any more
+			for (std::map<std::string, DeviceBuffer>::iterator buffer = ctx->scratch_pool.begin(); buffer != ctx->scratch_pool.end(); ++buffer)
+				if (buffer->first.compare(0, 7, "ingest.") != 0 && buffer->second.ptr != nullptr) { buffer->second.release(); released = true; }
+	}
+	return released;
+}
 }
 
 namespace {
@@ -554,11 +572,13 @@ agpu_ctx* agpu_create(int device, const agpu_params* params) {
 	if (!ctx->counters.allocate(COUNTER_COUNT * sizeof(uint32_t)) || !ctx->stage_counts.allocate(16 * sizeof(unsigned long long))) { set_last_error("hipMalloc failed"); delete ctx; return nullptr; }
 	(void) hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes, ctx->stream);
 	(void) hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, ctx->stream);
+	{ std::lock_guard<std::mutex> lock(g_contexts_mutex); g_contexts.push_back(ctx); }
 	return ctx;
 }
 
 void agpu_destroy(agpu_ctx* ctx) {
 	if (!ctx) return;
+	{ std::lock_guard<std::mutex> lock(g_contexts_mutex); g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), ctx), g_contexts.end()); }
 	(void) hipSetDevice(ctx->device);
 	(void) hipStreamSynchronize(ctx->stream);
 	if (ctx->event_start) (void) hipEventDestroy(ctx->event_start);

@@ -34,10 +34,17 @@ struct DeviceBuffer {
 		if (pooled) { // stream-ordered allocation on the null stream, made visible to every stream by the synchronisation behind it
 			if (hipMallocAsync(&ptr, n, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void) hipGetLastError(); ptr = nullptr; pooled = false; }
 		}
-		if (!pooled && hipMalloc(&ptr, n) != hipSuccess) { ptr = nullptr; return false; }
+		if (!pooled && hipMalloc(&ptr, n) != hipSuccess) {
+			// out of memory: the contexts give back what they only keep for the next sample (the stream and the tables of the last ingest while the stages run, the
+			// buffers of the stages while an ingest runs), then once more
+			(void) hipGetLastError();
+			ptr = nullptr;
+			if (!release_idle_buffers() || hipMalloc(&ptr, n) != hipSuccess) { (void) hipGetLastError(); ptr = nullptr; return false; }
+		}
 		bytes = n; capacity = n;
 		return true;
 	}
+	static bool release_idle_buffers(); // agpu_api.hip; true if anything was given back
 	void release() {
 		if (!ptr) return;
 		if (pooled) { (void) hipFreeAsync(ptr, nullptr); (void) hipStreamSynchronize(nullptr); } else (void) hipFree(ptr);
@@ -137,6 +144,7 @@ struct agpu_ctx {
 	// closest genomic breakpoints per candidate (agpu_mark_genomic_support); not marked: every candidate -1
 	agpu::DeviceBuffer cand_closest1, cand_closest2;
 	bool genomic_support_marked = false;
+	uint32_t n_selected = 0, selected_of_candidates = 0xFFFFFFFFu; // agpu_select_candidates: how many, and of which table (scratch "select.ids" holds them)
 	uint32_t confidence_candidates = 0xFFFFFFFFu; // n_candidates of the last agpu_assign_confidence (its result stays in scratch "events.confidence")
 	agpu::GenomicSupport genomic_support() { agpu::GenomicSupport wgs = { genomic_support_marked ? cand_closest1.as<int32_t>() : nullptr, genomic_support_marked ? cand_closest2.as<int32_t>() : nullptr }; return wgs; }
 	uint64_t annotation_serial = 1, gene_read_counts_of_annotation = 0; // every annotate of a batch takes a new serial; scratch "events.gene_read_count" holds the counts of that one
@@ -176,6 +184,8 @@ struct agpu_ctx {
 
 namespace agpu {
 
+// agpu_ingest.hip: the stream and the per-record tables of the last ingest given back to the device (they are kept for the next sample as long as memory allows); true if there were any
+bool release_ingest_buffers(agpu_ctx* ctx);
 // agpu_api.hip: what follows the columns of a batch, whoever filled them (agpu_upload_batch, or the ingest on the device: agpu_ingest.hip)
 int finish_batch_setup(agpu_ctx* ctx);
 

@@ -464,6 +464,82 @@ extern "C" int agpu_get_genomic_support(agpu_ctx* ctx, int32_t* closest1, int32_
 	if (closest2 && C > 0) HIP_CHECK(hipMemcpy(closest2, ctx->cand_closest2.ptr, (size_t) C * 4, hipMemcpyDeviceToHost));
 	return AGPU_OK;
 }
+
+// ---- the candidates of one output file, picked on the device (agpu_select_candidates / agpu_get_selected_candidates; agpu_get_filters_of) ------------------------------
+namespace {
+__global__ void candidate_written_kernel(const uint8_t* filter, uint32_t n, bool discarded, uint8_t* flags) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < n) flags[c] = ((filter[c] == FILTER_none) != discarded) ? 1 : 0; // source/output_fusions.cpp:1083-1089
+}
+template <class T> __global__ void gather_column_kernel(const T* column, const uint32_t* ids, uint64_t n, T fill, T* out) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k < n) out[k] = column != nullptr ? column[ids[k]] : fill;
+}
+template <class T> int gather_column(agpu_ctx* ctx, const char* scratch_name, const T* column, T fill, const uint32_t* ids, uint64_t n, T* host) {
+	if (host == nullptr || n == 0) return AGPU_OK;
+	DeviceBuffer& staged = ctx->scratch(scratch_name);
+	ALLOC(staged, n * sizeof(T));
+	gather_column_kernel<T><<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, ctx->stream>>>(column, ids, n, fill, staged.as<T>());
+	HIP_CHECK(hipMemcpyAsync(host, staged.ptr, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+	return AGPU_OK;
+}
+}
+extern "C" int agpu_select_candidates(agpu_ctx* ctx, int discarded, uint64_t* n) {
+	if (!ctx || !ctx->fusions_done || !n) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& flags = ctx->scratch("select.flags"); DeviceBuffer& ids = ctx->scratch("select.ids"); DeviceBuffer& count = ctx->scratch("select.count"); DeviceBuffer& scratch = ctx->scratch("select.rocprim");
+	ALLOC(flags, std::max<uint32_t>(C, 1)); ALLOC(ids, (size_t) std::max<uint32_t>(C, 1) * 4); ALLOC(count, 4);
+	HIP_CHECK(hipMemsetAsync(count.ptr, 0, 4, s));
+	uint32_t selected = 0;
+	if (C > 0) {
+		candidate_written_kernel<<<(C + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(ctx->cand_filter.as<uint8_t>(), C, discarded != 0, flags.as<uint8_t>());
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), ids.as<uint32_t>(), count.as<uint32_t>(), C, s));
+		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+		HIP_CHECK(rocprim::select(scratch.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), ids.as<uint32_t>(), count.as<uint32_t>(), C, s));
+		HIP_CHECK(hipMemcpyAsync(&selected, count.ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	ctx->n_selected = selected; ctx->selected_of_candidates = C;
+	*n = selected;
+	return AGPU_OK;
+}
+extern "C" int agpu_get_selected_candidates(agpu_ctx* ctx, const agpu_selected_candidates* out) {
+	if (!ctx || !ctx->fusions_done || !out || ctx->selected_of_candidates != ctx->n_candidates) { set_last_error("agpu_select_candidates must run first"); return AGPU_ERR_INVALID; }
+	if (out->confidence && ctx->confidence_candidates != ctx->n_candidates) { set_last_error("agpu_assign_confidence must run first"); return AGPU_ERR_INVALID; }
+	if (out->iteration_rank && !ctx->iteration_order_done) { set_last_error("agpu_candidate_iteration_order must run first"); return AGPU_ERR_INVALID; }
+	if (out->evalue && !ctx->evalue_done) { set_last_error("agpu_estimate_expected_fusions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	const uint64_t n = ctx->n_selected;
+	if (n == 0) return AGPU_OK;
+	const uint32_t* ids = ctx->scratch("select.ids").as<uint32_t>();
+	if (out->candidate) HIP_CHECK(hipMemcpyAsync(out->candidate, ids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+	#define GATHER(field, buffer, type, fill) do { int status_ = gather_column<type>(ctx, "select." #field, (const type*) (buffer), (type) (fill), ids, n, out->field); if (status_ != AGPU_OK) return status_; } while (0)
+	GATHER(gene1, ctx->cand_gene1.ptr, uint32_t, 0); GATHER(gene2, ctx->cand_gene2.ptr, uint32_t, 0); GATHER(contigs, ctx->cand_contigs.ptr, uint32_t, 0);
+	GATHER(breakpoint1, ctx->cand_breakpoint1.ptr, int32_t, 0); GATHER(breakpoint2, ctx->cand_breakpoint2.ptr, int32_t, 0); GATHER(flags, ctx->cand_flags.ptr, uint32_t, 0); GATHER(filter, ctx->cand_filter.ptr, uint8_t, 0);
+	GATHER(split_reads1, ctx->cand_split_reads1.ptr, uint32_t, 0); GATHER(split_reads2, ctx->cand_split_reads2.ptr, uint32_t, 0); GATHER(discordant_mates, ctx->cand_discordant_mates.ptr, uint32_t, 0);
+	GATHER(evalue, ctx->cand_evalue.ptr, float, 0); GATHER(confidence, ctx->scratch("events.confidence").ptr, uint8_t, 0); GATHER(iteration_rank, ctx->cand_iteration_rank.ptr, uint32_t, 0);
+	GATHER(closest_genomic_breakpoint1, ctx->genomic_support_marked ? ctx->cand_closest1.ptr : nullptr, int32_t, -1); GATHER(closest_genomic_breakpoint2, ctx->genomic_support_marked ? ctx->cand_closest2.ptr : nullptr, int32_t, -1);
+	#undef GATHER
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return AGPU_OK;
+}
+extern "C" int agpu_get_filters_of(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint8_t* filter) {
+	if (!ctx || !ctx->have_batch || (n > 0 && (!fragments || !filter))) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
+	for (uint64_t k = 0; k < n; ++k) if (fragments[k] >= ctx->n) { set_last_error("fragment index out of range"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (n == 0) return AGPU_OK;
+	DeviceBuffer& ids = ctx->scratch("filters_of.ids");
+	ALLOC(ids, n * 4);
+	HIP_CHECK(hipMemcpyAsync(ids.ptr, fragments, n * 4, hipMemcpyHostToDevice, ctx->stream));
+	const int status = gather_column<uint8_t>(ctx, "filters_of.out", ctx->filter.as<uint8_t>(), 0, ids.as<uint32_t>(), n, filter);
+	if (status != AGPU_OK) return status;
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return AGPU_OK;
+}
+
 namespace {
 int run_genomic_support_filter(agpu_ctx* ctx, int mode, uint8_t filter_id, uint64_t* remaining) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }

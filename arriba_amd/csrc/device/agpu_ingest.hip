@@ -450,6 +450,17 @@ void fill_pack_target(agpu_ctx* ctx, PackTarget& out) {
 
 }
 
+bool agpu::release_ingest_buffers(agpu_ctx* ctx) {
+	bool released = ctx->ingest_stream.ptr != nullptr;
+	ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release();
+	if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
+	static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.plain_plans", "ingest.itd_plans",
+		"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
+		"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
+	for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) { DeviceBuffer& buffer = ctx->scratch(temporary[k]); if (buffer.ptr != nullptr) released = true; buffer.release(); }
+	return released;
+}
+
 extern "C" {
 
 void* agpu_host_alloc(size_t bytes) {
@@ -735,21 +746,11 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ctx->have_coverage = true;
 	TRY(agpu::finish_batch_setup(ctx));
 	ctx->batch_from_ingest = true;
-	// The stream and the per-record tables are not needed any more.  Where memory is plentiful they stay for the next sample (a resident service reads sample after sample,
-	// and mapping / unmapping gigabytes costs as much as the kernels that use them); where the stages behind the ingest need the room -- a 10^8-fragment sample: 54 GB of
-	// stream, 35 GB of tables, and behind them 40 GB of memo and task lists, the read lists, the k-mer index -- they are given back.  The threshold is what was free in
-	// the measured run of that sample plus a margin.
-	size_t free_bytes = 0, total_bytes = 0;
-	if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) { (void) hipGetLastError(); free_bytes = 0; }
-	const bool plenty = free_bytes >= ((size_t) 160 << 30);
-	if (getenv("ARRIBA_KEEP_INGEST_BUFFERS") == nullptr && !plenty) {
-		ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release();
-		if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
-		static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.plain_plans", "ingest.itd_plans",
-			"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
-			"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
-		for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) ctx->scratch(temporary[k]).release();
-	}
+	// The stream and the per-record tables are not needed any more, but they stay for the next sample: a resident service reads sample after sample, and mapping /
+	// unmapping gigabytes costs as much as the kernels that use them (a 10^8-fragment sample: 54 GB of stream, 35 GB of tables; with the 48 GB of memo and task lists, the
+	// read lists and the batch behind them ~190 GB of the 288 GB are in use).  Only when an allocation fails are they given back (DeviceBuffer::release_idle_buffers); a part
+	// of a sample hands its windows on as they are (agpu_shard_export), everybody else is done with the 32-bit ones.
+	if (getenv("ARRIBA_RELEASE_INGEST_BUFFERS") != nullptr) agpu::release_ingest_buffers(ctx); // (for measurements: the behaviour of round 2 on samples that leave less than 160 GB free)
 	ctx->ingest_stream_size = 0;
 	agpu_ingest_result& mine = ctx->ingest_result;
 	memset(&mine, 0, sizeof(mine));

@@ -148,9 +148,11 @@ __global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, 
 // similar length.  A read that runs out of its step budget (or of stack) is put on the `heavy` list: the verdict of a read does not depend on who computes it.
 const int SEGMENT_CACHE = 128; // bases of a segment kept in LDS per lane (longer segments are read from HBM)
 // Steps of the search loop + bases compared that a read gets in the first pass; the mean is ~1100.  A thread that uses up a long budget keeps its wavefront (63 idle
-// lanes) and with it the whole launch waiting -- ~15 us per step -- while the second pass takes over such a read at no extra cost: measured at 10.4 M fragments
-// (profiles/r02l_first_pass_ab.txt), first + second pass: 65536 steps 1024 + 453 ms, 8192: 232 + 436 ms, 2048: 122 + 453 ms, 512: 59 + 626 ms.
-const int64_t FIRST_PASS_STEPS = 2048;
+// lanes) and with it the whole launch waiting -- ~15 us per step under divergence -- while the second pass takes over such a read.  Round 2 (second pass: a wavefront per read
+// walking the recursion, profiles/r03c_mismapper_second_pass.txt) was fastest with 2048; since the second pass sweeps every seed of a read once (align_by_sweep) it is the
+// cheaper place for all but the short searches: at 10^8 fragments first + second pass take 641 + 306 ms with 2048 steps, 235 + 471 ms with 512, 119 + 539 ms with 256
+// (profiles/r03e_mismapper_sweep.txt; ARRIBA_FIRST_PASS_STEPS for measurements).
+const int64_t FIRST_PASS_STEPS = 256;
 __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap,
                                                                         int64_t first_pass_steps, uint32_t* heavy, unsigned int* counters /* [1] discarded, [3] heavy */) {
 	__shared__ uint32_t block_sum;
@@ -180,9 +182,9 @@ const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 32 GB for 4096 of
                                         // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
 const uint32_t HEAVY_WORKGROUPS = 4096;
 __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
-                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_iteration, bool seeds_once, unsigned long long* read_times, unsigned int* counters) {
+                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
-	__shared__ AlignRound round;
+	__shared__ AlignSweep sweep;
 	__shared__ AlignMemo memo;
 	__shared__ AlignWorklist worklist;
 	__shared__ uint32_t worklist_state[4];
@@ -190,9 +192,10 @@ __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, Annota
 	__shared__ uint32_t study[4];
 	if (threadIdx.x == 0) {
 		worklist.stats = read_times != nullptr ? study : nullptr;
-		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0; memo.seeds_once = seeds_once;
+		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0;
 		worklist.words = task_lists != nullptr ? task_lists + (size_t) blockIdx.x * task_capacity * 2 : nullptr; worklist.capacity = task_capacity; worklist.state = worklist_state;
-		worklist.round = by_iteration ? &round : nullptr; // the lanes take single iterations of the read-position loops of the listed calls (mismapper_core.hpp: AlignRound)
+		worklist.sweep = by_sweep ? &sweep : nullptr; // one sweep over the read positions, every seed walked once (mismapper_core.hpp: AlignSweep)
+		worklist.relevant_words = task_lists != nullptr ? task_lists + ((size_t) gridDim.x + blockIdx.x) * task_capacity * 2 : nullptr; worklist.relevant_capacity = task_capacity; // (the second half of the buffer: the calls of a block beyond those kept in LDS)
 	}
 	__syncthreads();
 	AlignFrame stack[ALIGN_MAX_DEPTH];
@@ -445,15 +448,15 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const bool use_worklist = !(knob != nullptr && knob[0] == '0');
 				const uint32_t task_capacity = 1u << 17;
 				DeviceBuffer& task_lists = ctx->scratch("mismappers.task_lists");
-				if (use_worklist) ALLOC(task_lists, (size_t) workgroups * task_capacity * 16);
-				knob = getenv("ARRIBA_MISMAPPER_BY_ITERATION"); // "0": a lane runs a whole listed call (the schedule of round 2), for A/B measurements
-				const bool by_iteration = !(knob != nullptr && knob[0] == '0');
+				if (use_worklist) ALLOC(task_lists, (size_t) workgroups * task_capacity * 16 * 2); // (the listed calls of every workgroup, then, behind all of them, the calls of a block beyond the memory of the sweep)
+				knob = getenv("ARRIBA_MISMAPPER_SWEEP"); // "0": the lanes take whole listed calls in rounds (the schedule of round 2), for A/B measurements
+				const bool by_sweep = !(knob != nullptr && knob[0] == '0');
 				const bool want_times = getenv("ARRIBA_MISMAPPER_TIMES") != nullptr; // a study: how long the wavefronts worked on every read of the second pass, on stderr
 				DeviceBuffer& read_times = ctx->scratch("mismappers.read_times");
 				if (want_times) ALLOC(read_times, (size_t) n_heavy * 32);
 				{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
 				  mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
-				                                                by_iteration, !(getenv("ARRIBA_MISMAPPER_SEEDS_ONCE") != nullptr && getenv("ARRIBA_MISMAPPER_SEEDS_ONCE")[0] == '0'), want_times ? read_times.as<unsigned long long>() : nullptr, device_counters); }
+				                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters); }
 				if (want_times) {
 					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy);
 					HIP_CHECK(hipMemcpyAsync(ticks.data(), read_times.ptr, (size_t) n_heavy * 32, hipMemcpyDeviceToHost, s));
@@ -467,12 +470,12 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 						by_time[k] = std::make_pair(t, k);
 					}
 					std::sort(by_time.begin(), by_time.end());
-					fprintf(stderr, "[mismapper_heavy_kernel] %u reads of %u jobs, %u workgroups, by_iteration %d: %.1f ms of wavefront time in all, longest read %.2f ms; calls %llu, iterations %llu, seeds %llu, seeds walked %llu; reads by time (us):", n_heavy, n_jobs, workgroups, (int) by_iteration, total / 1e5, longest / 1e5, sums[0], sums[1], sums[2], sums[3]);
+					fprintf(stderr, "[mismapper_heavy_kernel] %u reads of %u jobs, %u workgroups, sweep %d: %.1f ms of wavefront time in all, longest read %.2f ms; calls listed %llu, calls reaching into the blocks %llu, seeds %llu, walks %llu; reads by time (us):", n_heavy, n_jobs, workgroups, (int) by_sweep, total / 1e5, longest / 1e5, sums[0], sums[1], sums[2], sums[3]);
 					for (int bucket = 0; bucket < 40; ++bucket) if (histogram[bucket]) fprintf(stderr, " 2^%d:%llu", bucket, histogram[bucket]);
 					fprintf(stderr, "\n");
 					for (uint32_t rank = 0; rank < 24 && rank < n_heavy; ++rank) { // the slowest reads, and every 1/8 quantile below them
 						const uint32_t k = by_time[rank < 16 ? n_heavy - 1 - rank : (size_t) (n_heavy - 1) * (24 - rank) / 9].second;
-						fprintf(stderr, "[mismapper_heavy_kernel]   read %llu (%llu alignments): %.2f ms, calls %llu, iterations %llu, seeds %llu, walked %llu\n", ticks[4 * (size_t) k + 3] >> 8, ticks[4 * (size_t) k + 3] & 255, ticks[4 * (size_t) k] / 1e5,
+						fprintf(stderr, "[mismapper_heavy_kernel]   read %llu (%llu alignments): %.2f ms, calls listed %llu, reaching into blocks %llu, seeds %llu, walks %llu\n", ticks[4 * (size_t) k + 3] >> 8, ticks[4 * (size_t) k + 3] & 255, ticks[4 * (size_t) k] / 1e5,
 						        ticks[4 * (size_t) k + 1] >> 32, ticks[4 * (size_t) k + 1] & 0xFFFFFFFFu, ticks[4 * (size_t) k + 2] >> 32, ticks[4 * (size_t) k + 2] & 0xFFFFFFFFu);
 					}
 				}

@@ -85,21 +85,14 @@ AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p
 // whose extensions cross splice sites again -- in a long gene with many exons the number of calls grows exponentially with the nesting (seconds to hours per
 // read), although there are only (read positions x splice sites + seeds) distinct calls.  With the memo every distinct call is searched once per score level.
 // The result is the reference's: only calls that are known to return false are skipped.
-// A slot holds epoch (8 bits: one per align() invocation, so that the table never needs clearing) | gene_pos - gene_start (24) | read_pos (9) | kind (1) | max_deletions (1) |
+// A slot holds epoch (8 bits: one per align() invocation, so that the table never needs clearing) | gene_pos - gene_start (24) | read_pos (9) | max_deletions (1) |
 // score + 32768 (16): for equal keys the larger word is the higher failed score.
-// kind 1 = a SEED instead of a call (round 3): the extension to the right of the seed at (read position, gene position) was walked with the recorded score at its start.  The
-// walk itself -- which bases are compared, where it crosses splice sites, where it ends -- does not depend on that score; a walk that starts with a lower score finds no
-// success the earlier one does not find and lists the same nested calls with lower scores, which the memo of the calls prunes.  So a seed is walked again only when it is
-// reached with a higher score than ever before.  Without this the calls of a read in a long gene (read positions x splice sites of them) walk the same few thousand seeds
-// 10^7 times (profiles/r03c_mismapper_second_pass.txt: single reads of 1 s).
-enum { MEMO_CALL = 0, MEMO_SEED = 1 };
 struct AlignMemo {
 	unsigned long long* slots; uint32_t mask; uint32_t epoch; // (no default initialisers: the device keeps one in LDS)
-	uint32_t seeds_once;                                      // 1: the walks of the seeds are remembered as well (0: A/B measurements)
 	// (the key holds 24 bits of gene offset and 9 bits of read position: longer genes and reads are searched without the memo)
 	AGPU_HD bool usable(int32_t gene_start, int32_t gene_end, int32_t read_length) const { return slots != nullptr && (int64_t) gene_end - gene_start < (1 << 24) && read_length < 512; }
-	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions, uint32_t kind = MEMO_CALL) const {
-		return ((unsigned long long) (epoch & 255u) << 35 | (unsigned long long) (uint32_t) gene_offset << 11 | (unsigned long long) (uint32_t) read_pos << 2 | (unsigned long long) kind << 1 | (unsigned long long) (max_deletions > 0)) << 16;
+	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions) const {
+		return ((unsigned long long) (epoch & 255u) << 34 | (unsigned long long) (uint32_t) gene_offset << 10 | (unsigned long long) (uint32_t) read_pos << 1 | (unsigned long long) (max_deletions > 0)) << 16;
 	}
 	AGPU_HD uint32_t slot_of(unsigned long long key) const { unsigned long long h = key * 0x9E3779B97F4A7C15ull; return (uint32_t) (h >> 40) & mask; }
 	// is a call with this key and a score <= the recorded one known to fail?
@@ -112,7 +105,7 @@ struct AlignMemo {
 			const unsigned long long slot = slots[at];
 #endif
 			if ((slot >> 16) == (key >> 16)) return score + 32768 <= (int32_t) (slot & 0xFFFF);
-			if ((slot >> 51) != (key >> 51)) return false; // empty or from an earlier align(): the key is not in the table
+			if ((slot >> 50) != (key >> 50)) return false; // empty or from an earlier align(): the key is not in the table
 		}
 		return false;
 	}
@@ -124,7 +117,7 @@ struct AlignMemo {
 #if defined(__HIP_DEVICE_COMPILE__)
 			unsigned long long slot = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if ((slot >> 16) == (key >> 16)) { atomicMax(&slots[at], word); return; }
-			if ((slot >> 51) != (key >> 51)) { // free for this epoch: take it (if another lane was faster with another key, go on probing)
+			if ((slot >> 50) != (key >> 50)) { // free for this epoch: take it (if another lane was faster with another key, go on probing)
 				const unsigned long long seen = atomicCAS(&slots[at], slot, word);
 				if (seen == slot) return;
 				if ((seen >> 16) == (key >> 16)) { atomicMax(&slots[at], word); return; }
@@ -132,7 +125,7 @@ struct AlignMemo {
 #else
 			const unsigned long long slot = slots[at];
 			if ((slot >> 16) == (key >> 16)) { if (word > slot) slots[at] = word; return; }
-			if ((slot >> 51) != (key >> 51)) { slots[at] = word; return; }
+			if ((slot >> 50) != (key >> 50)) { slots[at] = word; return; }
 #endif
 		}
 	}
@@ -162,10 +155,8 @@ const int ALIGN_SHALLOW_DEPTH = 16;       // ... of <= 128 bases: the stack of t
 // end of the second pass on the device waits for exactly that -- becomes rounds of up to 64 tasks, one per lane.  A list that overflows is abandoned and the
 // search is done by the recursion.
 // What the list holds are CALLS of align(): (score, read position, gene position) at the entry of the call, ALIGN_TASK_DELETIONS = max_deletions > 0, ALIGN_TASK_ROOT = the outermost
-// call (its skipped bases are leading ones and cost nothing).  What a lane runs is ONE ITERATION of the read-position loop of a call (ALIGN_TASK_ONE, the number of the
-// iteration = the bases skipped so far in flags >> 8): the iterations of the loop are independent attempts as well -- iteration i starts from (score - i, read_pos + i) and the
-// bound of the loop is monotone in i -- and a nested call left to one lane is a chain of ~80 read positions x their seeds, which is what a round used to wait for.
-enum { ALIGN_TASK_DELETIONS = 1, ALIGN_TASK_ROOT = 2, ALIGN_TASK_ONE = 4, ALIGN_TASK_SKIPPED_SHIFT = 8 };
+// call (its skipped bases are leading ones and cost nothing); from bit ALIGN_TASK_ITERATIONS_SHIFT on: the number of iterations of its read-position loop (align_by_sweep).
+enum { ALIGN_TASK_DELETIONS = 1, ALIGN_TASK_ROOT = 2, ALIGN_TASK_ITERATIONS_SHIFT = 8 };
 struct AlignTask { int32_t score, read_pos, gene_pos; uint32_t flags; };
 // iterations of the read-position loop of a call: for (i = 0; read_pos + i + k < length && read_pos + i + min_score <= length + (score - i) + 2 k; ++i)
 AGPU_HD uint32_t align_iterations(const AlignTask& call, int32_t length, int32_t min_score) {
@@ -175,22 +166,28 @@ AGPU_HD uint32_t align_iterations(const AlignTask& call, int32_t length, int32_t
 	const int32_t by_score = slack / 2 + 1;
 	return (uint32_t) (by_length < by_score ? by_length : by_score);
 }
-AGPU_HD AlignTask align_iteration(const AlignTask& call, uint32_t i) {
-	const AlignTask item = { call.score - (int32_t) i, call.read_pos + (int32_t) i, call.gene_pos, (call.flags & (ALIGN_TASK_DELETIONS | ALIGN_TASK_ROOT)) | ALIGN_TASK_ONE | i << ALIGN_TASK_SKIPPED_SHIFT };
-	return item;
-}
-// the calls of one round of a runner and the running sum of their iterations (memory the lanes share: LDS on the device)
-// ... and the 64 iterations being worked on: where each one's seeds start in the position list, and the running sum of their seeds.  The lanes then take 64 SEEDS at a time
-// (align_extend_seed): every lane runs the same code -- one extension to the left and to the right -- instead of being somewhere else in the state machine of a whole call.
-struct AlignRound {
-	int32_t score[64], read_pos[64], gene_pos[64]; uint32_t flags[64], end[64];
-	int32_t item_score[64], item_read_pos[64]; uint32_t item_flags[64], item_first_hit[64], item_seed_end[64];
+// The search of one align() as ONE SWEEP over the read positions (round 3; AlignRunner::align_by_sweep).  A call listed by the extension of a seed at read position p starts at
+// read position p + 8 or later, so when the sweep reaches a block of 8 read positions every call that reaches into the block is known.  For every seed of the block -- a hit of the
+// 8-mer at its read position inside the gene -- the calls that reach it are compared: iteration i = read position - start of the call arrives with score - i + 8 + what the
+// extension to the left over the i skipped bases adds; only the best arrival (per max_deletions) is walked to the right, because the walk itself does not depend on the score it
+// starts with: a lower score finds no success a higher one does not find, and lists the same nested calls with lower scores.  Every seed of the gene is walked once (twice if
+// the best arrival without deletions beats the best one with), where the recursion of the reference -- and the task list of round 2 -- walks it once per call that reaches it:
+// 10^7 times for a read in a gene of some megabases (profiles/r03c_mismapper_second_pass.txt).
+const uint32_t ALIGN_SWEEP_BLOCK = KMER_LENGTH;     // read positions per block
+const uint32_t ALIGN_SWEEP_SEGMENT = 304;          // align_both_strands leaves segments of 300 bases and more alone
+const uint32_t ALIGN_SWEEP_CALLS = 256;            // calls of a block kept in the memory the lanes share; what is beyond goes to AlignWorklist::relevant_words
+struct AlignSweep { // memory the lanes of a runner share (LDS on the device)
+	uint32_t hit_first[ALIGN_SWEEP_SEGMENT], hit_count[ALIGN_SWEEP_SEGMENT]; // per read position: the hits of its 8-mer inside the gene, as a range of the position list
+	uint32_t seed_end[ALIGN_SWEEP_BLOCK];                                     // running sums of the seeds of the read positions of the block
+	int32_t call_score[ALIGN_SWEEP_CALLS], call_read_pos[ALIGN_SWEEP_CALLS], call_gene_pos[ALIGN_SWEEP_CALLS]; uint32_t call_flags[ALIGN_SWEEP_CALLS];
+	uint32_t n_calls, reached;                                                // calls that reach into the block; bit k: read position k of the block is reached by one of them
 };
 struct AlignWorklist {
 	unsigned long long* words; uint32_t capacity; // two 64-bit words per task
 	uint32_t* state;                              // [0] tasks listed, [1] overflow, [2] found (memory the lanes of the runner share: LDS on the device)
-	AlignRound* round;                            // the calls of the round being worked on (null: a lane runs a whole call, as before round 3)
-	uint32_t* stats;                              // null, or a study: [0] calls taken, [1] iterations looked up, [2] seeds, [3] seeds walked (not pruned by the memo), shared by the lanes
+	AlignSweep* sweep;                            // null: the schedule of round 2 (the lanes take whole calls from the list in rounds)
+	unsigned long long* relevant_words; uint32_t relevant_capacity; // the calls of a block beyond ALIGN_SWEEP_CALLS (two words per call; may be null: such a search is left to the recursion)
+	uint32_t* stats;                              // null, or a study: [0] calls listed, [1] calls that reached into a block (summed over the blocks), [2] seeds, [3] walks, shared by the lanes
 	AGPU_HD void push(const AlignTask& task) const {
 #if defined(__HIP_DEVICE_COMPILE__)
 		const uint32_t at = atomicAdd(&state[0], 1u);
@@ -243,12 +240,10 @@ AGPU_HD bool align_search(const Segment& read, const AlignTarget& target, int32_
 	const int32_t length = (int32_t) read.length;
 	const bool use_memo = memo != nullptr && memo->usable(target.gene_start, target.gene_end, length);
 	const bool root = (task.flags & ALIGN_TASK_ROOT) != 0;
-	const bool one_iteration = (task.flags & (ALIGN_TASK_ROOT | ALIGN_TASK_ONE)) != 0; // (a root task of the old kind is iteration read_pos of the outermost loop)
 	int depth = 0;
 	AlignFrame f;
 	align_enter(f, task.score, task.read_pos, task.gene_pos, (task.flags & ALIGN_TASK_DELETIONS) ? 1 : 0);
 	if (root) { f.skipped_bases = task.read_pos; f.leading = 1; } // iteration read_pos of the outermost loop: score -read_pos, all skipped bases leading
-	else if (task.flags & ALIGN_TASK_ONE) { f.skipped_bases = (int32_t) (task.flags >> ALIGN_TASK_SKIPPED_SHIFT); f.leading = 0; } // iteration `skipped` of the loop of a nested call
 	f.extended_score = 0; f.extended_read_pos = 0; f.extended_gene_pos = 0; f.mismatch_count = 0; f.consecutive_mismatches = 0;
 	while (true) {
 		if (budget != nullptr && --*budget < 0) return false;
@@ -257,7 +252,7 @@ AGPU_HD bool align_search(const Segment& read, const AlignTarget& target, int32_
 		switch (f.state) {
 			case ALIGN_NEXT_READ_POSITION: { // for (; read_pos + k < length && ...; read_pos++, score--, skipped_bases++)
 				ALIGN_STAT(read_positions, 1);
-				if (f.started && depth == 0 && one_iteration) return false; // the other iterations of this loop are other attempts
+				if (f.started && depth == 0 && root) return false; // the other read positions of the outermost loop are other attempts
 				if (f.started) { f.read_pos++; f.score--; f.skipped_bases++; }
 				f.started = 1;
 				if (!(f.read_pos + KMER_LENGTH < length && f.read_pos + min_score <= length + f.score + 2 * KMER_LENGTH)) { fail = true; break; }
@@ -390,45 +385,51 @@ AGPU_HD bool align_search(const Segment& read, const AlignTarget& target, int32_
 }
 
 #if !defined(__HIP_DEVICE_COMPILE__)
-static unsigned long long g_align_seed_steps = 0; // host stepping: bases compared by align_extend_seed (the harness reports what a wavefront would wait for)
+static unsigned long long g_align_seed_steps = 0; // host stepping: bases compared by the walks of the sweep (the harness reports what a wavefront would wait for)
 #define ALIGN_SEED_STEP() (++g_align_seed_steps)
 #else
 #define ALIGN_SEED_STEP() ((void) 0)
 #endif
-// One seed of one iteration of a call, to its end: the body of the hit loop of the reference's align() (source/filter_mismappers.cpp:106-183) with the nested calls LISTED
-// instead of made (the search goes on as if they had failed: the result of align() is an OR over everything that gets searched, see AlignWorklist).  No stack, no state
-// machine: what ALIGN_NEXT_HIT .. ALIGN_ADVANCE of align_search do for one hit.  `item` = the iteration (ALIGN_TASK_ONE: score and read position of the iteration, skipped
-// bases in the flags), kmer_hit = position of the seed in the gene.
-AGPU_HD bool align_extend_seed(const Segment& read, const AlignTarget& target, int32_t min_score, const AlignTask& item, int32_t kmer_hit, const AlignMemo& memo, const AlignWorklist& worklist) {
+// The bases to the left of a seed at (read_pos, kmer_hit) as the extension to the left of the reference's align() sees them (source/filter_mismappers.cpp:109-137): the read is
+// compared backwards with the gene, one mismatch is allowed, the second one ends the extension, and so do the start of the read and the start of the gene.  first / second =
+// number of bases compared before the first / second mismatch (or `limit`, the number of bases there are, if it does not come).
+struct LeftProfile { int32_t first, second, limit; };
+AGPU_HD LeftProfile align_left_profile(const Segment& read, const AlignTarget& target, int32_t read_pos, int32_t kmer_hit) {
+	LeftProfile profile;
+	const int32_t by_gene = kmer_hit - target.gene_start; // left_gene_pos = kmer_hit - 1 - j >= gene_start
+	profile.limit = read_pos < by_gene ? read_pos : by_gene;
+	if (profile.limit < 0) profile.limit = 0;
+	profile.first = profile.second = profile.limit;
+	int32_t mismatches = 0;
+	for (int32_t done = 0; done < profile.limit && mismatches < 2; done += 8) {
+		const int32_t gene_from = kmer_hit - done; // the eight gene bases in front of it, the nearest in the high byte
+		uint64_t window = 0;
+		if (gene_from >= 8) window = load_bases8(target.contig_bases + gene_from - 8);
+		else for (int32_t k = 0; k < gene_from; ++k) window |= (uint64_t) (uint8_t) target.contig_bases[gene_from - 1 - k] << (8 * (7 - k));
+		for (int32_t k = 0; k < 8 && done + k < profile.limit; ++k) {
+			ALIGN_SEED_STEP();
+			if (read.at((uint32_t) (read_pos - 1 - done - k)) == (char) (window >> (8 * (7 - k)))) continue;
+			if (++mismatches == 1) profile.first = done + k; else { profile.second = done + k; break; }
+		}
+	}
+	return profile;
+}
+// bases that match among the first i to the left (i skipped bases): those before the second mismatch, less the first mismatch
+AGPU_HD int32_t align_left_matches(const LeftProfile& profile, int32_t i) {
+	const int32_t compared = i < profile.second ? i : profile.second;
+	return compared - (profile.first < compared ? 1 : 0);
+}
+
+// The extension to the right of a seed, to its end: the rest of the body of the hit loop of the reference's align() (source/filter_mismappers.cpp:139-183) with the nested calls LISTED
+// instead of made (the search goes on as if they had failed: the result of align() is an OR over everything that gets searched, see AlignWorklist).  No stack, no state machine:
+// what ALIGN_RIGHT_LOOP .. ALIGN_ADVANCE of align_search do for one hit.  extended_score = the score behind the extension to the left.
+AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int32_t min_score, int32_t extended_score, int32_t read_pos, int32_t kmer_hit, int32_t max_deletions, const AlignMemo& memo, const AlignWorklist& worklist) {
 	const int32_t length = (int32_t) read.length;
-	const bool leading = (item.flags & ALIGN_TASK_ROOT) != 0;
-	const int32_t skipped_bases = (int32_t) (item.flags >> ALIGN_TASK_SKIPPED_SHIFT), read_pos = item.read_pos;
-	const int32_t max_deletions = (item.flags & ALIGN_TASK_DELETIONS) ? 1 : 0;
 	ALIGN_STAT(hits, 1);
-	int32_t extended_score = item.score + KMER_LENGTH;
-	if (leading) extended_score += skipped_bases; // no penalty for leading skipped bases (local alignment)
-	if (extended_score >= min_score) return true;
-	{ // extend to the left over the skipped bases, one mismatch allowed
-		int32_t left_read_pos = read_pos - 1, left_gene_pos = kmer_hit - 1;
-		uint32_t left_mismatches = 0;
-		while (left_read_pos >= read_pos - skipped_bases && left_gene_pos >= target.gene_start) {
-			if (read.at((uint32_t) left_read_pos) == target.contig_bases[left_gene_pos]) {
-				extended_score += leading ? 1 : 2;
-				if (extended_score >= min_score) return true;
-			} else if (++left_mismatches > 1) break;
-			left_read_pos--; left_gene_pos--;
-		}
-	}
-	{ // walked before from this seed with at least this score (AlignMemo, kind MEMO_SEED)?
-		const unsigned long long key = memo.key_of(read_pos, kmer_hit - target.gene_start, max_deletions, MEMO_SEED);
-		if (memo.seeds_once) {
-			if (memo.known_to_fail(key, extended_score)) { ALIGN_STAT(pruned, 1); return false; }
-			memo.record_failure(key, extended_score);
-		}
 #if defined(__HIP_DEVICE_COMPILE__)
-		if (worklist.stats != nullptr) atomicAdd(&worklist.stats[3], 1u);
+	if (worklist.stats != nullptr) atomicAdd(&worklist.stats[3], 1u);
 #endif
-	}
+	if (extended_score >= min_score) return true;
 	int32_t extended_read_pos = read_pos + KMER_LENGTH, extended_gene_pos = kmer_hit + KMER_LENGTH;
 	uint32_t mismatch_count = 0, consecutive_mismatches = 0;
 	uint32_t splice_cursor = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, extended_gene_pos - 1);
@@ -458,13 +459,17 @@ AGPU_HD bool align_extend_seed(const Segment& read, const AlignTarget& target, i
 				if (mismatch_count == 1 && max_deletions > 0 && length >= 30) call_max_deletions = max_deletions - 1; // re-seed once after the first mismatch (deletion / intron)
 			}
 			if (call_max_deletions >= 0) {
-				const unsigned long long key = memo.key_of(extended_read_pos, extended_gene_pos - target.gene_start, call_max_deletions);
-				if (!memo.known_to_fail(key, extended_score)) { // not listed before with at least this score
-					memo.record_failure(key, extended_score);
-					const AlignTask nested = { extended_score, extended_read_pos, extended_gene_pos, call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u };
-					worklist.push(nested);
-					ALIGN_STAT(calls, 1);
-				} else ALIGN_STAT(pruned, 1);
+				AlignTask nested = { extended_score, extended_read_pos, extended_gene_pos, call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u };
+				const uint32_t iterations = align_iterations(nested, length, min_score);
+				if (iterations > 0) { // (a call whose loop does not run returns false at once)
+					const unsigned long long key = memo.key_of(extended_read_pos, extended_gene_pos - target.gene_start, call_max_deletions);
+					if (!memo.known_to_fail(key, extended_score)) { // not listed before with at least this score
+						memo.record_failure(key, extended_score);
+						nested.flags |= iterations << ALIGN_TASK_ITERATIONS_SHIFT;
+						worklist.push(nested);
+						ALIGN_STAT(calls, 1);
+					} else ALIGN_STAT(pruned, 1);
+				}
 				call_max_deletions = -1;
 			}
 			if (stage == 1) { // the mismatch counts
@@ -547,53 +552,182 @@ struct AlignRunner {
 		return 1;
 #endif
 	}
-	// values[0 .. n) -> their running sums, in place; returns the total (on the device: every lane sums up to its own element, the barrier in between keeps readers and writers apart)
-	AGPU_HD uint32_t running_sums(uint32_t* values, uint32_t n, uint32_t width) const {
+	// The calls of the list that reach into the block of read positions [block, block + 8): into the memory of the sweep (the first ALIGN_SWEEP_CALLS) and the overflow list.
+	// Returns false if there are more of them than both hold.
+	AGPU_HD bool sweep_collect_calls(AlignSweep& sweep, int32_t block, uint32_t listed, uint32_t width) const {
+		uint32_t n = 0, reached = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-		uint32_t mine = 0, total = 0;
-		for (uint32_t k = 0; k < n; ++k) { const uint32_t value = values[k]; total += value; if (k <= lane) mine += value; }
+		for (uint32_t base = 0; base < listed; base += lanes) {
+			const uint32_t j = base + lane;
+			AlignTask call = { 0, 0, 0, 0 };
+			bool relevant = false;
+			if (j < listed) {
+				call = worklist->task(j);
+				const int32_t iterations = (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
+				relevant = call.read_pos < block + (int32_t) ALIGN_SWEEP_BLOCK && call.read_pos + iterations > block;
+			}
+			const unsigned long long mask = __ballot(relevant);
+			if (relevant) {
+				const uint32_t at = n + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+				sweep_store_call(sweep, at, call);
+			}
+			for (uint32_t k = 0; k < ALIGN_SWEEP_BLOCK; ++k) { // which read positions of the block does one of these calls reach?
+				const int32_t read_pos = block + (int32_t) k;
+				if (__ballot(relevant && call.read_pos <= read_pos && read_pos - call.read_pos < (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT)) != 0) reached |= 1u << k;
+			}
+			n += (uint32_t) __popcll(mask);
+		}
 		sync_lanes();
-		if (lane < n) values[lane] = mine;
+		if (lane == 0) { sweep.n_calls = n; sweep.reached = reached; }
 		sync_lanes();
-		return total;
 #else
-		uint32_t total = 0;
-		for (uint32_t k = 0; k < n; ++k) { total += values[k]; values[k] = total; }
-		return total;
+		for (uint32_t j = 0; j < listed; ++j) {
+			const AlignTask call = worklist->task(j);
+			const int32_t iterations = (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
+			if (!(call.read_pos < block + (int32_t) ALIGN_SWEEP_BLOCK && call.read_pos + iterations > block)) continue;
+			sweep_store_call(sweep, n++, call);
+			for (uint32_t k = 0; k < ALIGN_SWEEP_BLOCK; ++k) if (call.read_pos <= block + (int32_t) k && block + (int32_t) k - call.read_pos < iterations) reached |= 1u << k;
+		}
+		sweep.n_calls = n; sweep.reached = reached;
+#endif
+		return n <= ALIGN_SWEEP_CALLS + (worklist->relevant_words != nullptr ? worklist->relevant_capacity : 0u);
+	}
+	AGPU_HD void sweep_store_call(AlignSweep& sweep, uint32_t at, const AlignTask& call) const {
+		if (at < ALIGN_SWEEP_CALLS) { sweep.call_score[at] = call.score; sweep.call_read_pos[at] = call.read_pos; sweep.call_gene_pos[at] = call.gene_pos; sweep.call_flags[at] = call.flags; return; }
+		at -= ALIGN_SWEEP_CALLS;
+		if (worklist->relevant_words == nullptr || at >= worklist->relevant_capacity) return; // (the caller sees the count)
+		const unsigned long long first = (unsigned long long) (uint32_t) call.score | (unsigned long long) (uint32_t) call.read_pos << 32, second = (unsigned long long) (uint32_t) call.gene_pos | (unsigned long long) call.flags << 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+		__hip_atomic_store(&worklist->relevant_words[2 * (size_t) at], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&worklist->relevant_words[2 * (size_t) at + 1], second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+		worklist->relevant_words[2 * (size_t) at] = first; worklist->relevant_words[2 * (size_t) at + 1] = second;
 #endif
 	}
-	AGPU_HD static void round_load_call(AlignRound& round, uint32_t c, const AlignTask& call, int32_t length, int32_t min_score) {
-		round.score[c] = call.score; round.read_pos[c] = call.read_pos; round.gene_pos[c] = call.gene_pos; round.flags[c] = call.flags;
-		round.end[c] = align_iterations(call, length, min_score);
+	AGPU_HD AlignTask sweep_call(const AlignSweep& sweep, uint32_t at) const {
+		if (at < ALIGN_SWEEP_CALLS) { const AlignTask call = { sweep.call_score[at], sweep.call_read_pos[at], sweep.call_gene_pos[at], sweep.call_flags[at] }; return call; }
+		at -= ALIGN_SWEEP_CALLS;
+#if defined(__HIP_DEVICE_COMPILE__)
+		const unsigned long long first = __hip_atomic_load(&worklist->relevant_words[2 * (size_t) at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), second = __hip_atomic_load(&worklist->relevant_words[2 * (size_t) at + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+		const unsigned long long first = worklist->relevant_words[2 * (size_t) at], second = worklist->relevant_words[2 * (size_t) at + 1];
+#endif
+		const AlignTask call = { (int32_t) (uint32_t) first, (int32_t) (uint32_t) (first >> 32), (int32_t) (uint32_t) second, (uint32_t) (second >> 32) };
+		return call;
 	}
-	// iteration number `item` of the calls of the round -> slot k of the iterations being worked on: where its seeds are (source/filter_mismappers.cpp:100-106: the k-mer at the
-	// read position, its positions from gene_pos on, up to the end of the gene)
-	AGPU_HD static void round_load_item(AlignRound& round, uint32_t k, uint32_t item, uint32_t n_calls, const Segment& read, const AlignTarget& target) {
-		uint32_t lo = 0, hi = n_calls - 1; // the first call whose running sum exceeds the item
-		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (round.end[mid] <= item) lo = mid + 1; else hi = mid; }
-		const AlignTask call = { round.score[lo], round.read_pos[lo], round.gene_pos[lo], round.flags[lo] };
-		const AlignTask iteration = align_iteration(call, item - (lo > 0 ? round.end[lo - 1] : 0u));
-		ALIGN_STAT(read_positions, 1);
-		round.item_score[k] = iteration.score; round.item_read_pos[k] = iteration.read_pos; round.item_flags[k] = iteration.flags;
-		uint32_t first = 0, count = 0;
-		if (target.kmer_offsets != 0) { // (no k-mer index on this contig: every lookup misses)
-			const uint32_t kmer = read.kmer((uint32_t) iteration.read_pos);
-			const uint32_t begin = target.kmer_offsets[kmer], end = target.kmer_offsets[kmer + 1];
-			first = lower_bound_i32(target.positions, begin, end, iteration.gene_pos);
-			count = lower_bound_i32(target.positions, first, end, target.gene_end) - first; // hits at positions < gene_end
+	// one seed of the block: the best arrival of the calls that reach it, walked to the right
+	AGPU_HD bool sweep_seed(const AlignSweep& sweep, const Segment& read, const AlignTarget& target, int32_t min_score, int32_t read_pos, int32_t kmer_hit) const {
+		const LeftProfile profile = align_left_profile(read, target, read_pos, kmer_hit);
+		const int32_t NONE = -0x40000000;
+		int32_t best[2] = { NONE, NONE }; // by max_deletions
+		const uint32_t n_calls = sweep.n_calls;
+		for (uint32_t c = 0; c < n_calls; ++c) {
+			const AlignTask call = sweep_call(sweep, c);
+			const int32_t i = read_pos - call.read_pos; // the iteration of the call's loop that stands at this read position: score - i, i skipped bases
+			if (i < 0 || i >= (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT) || call.gene_pos > kmer_hit) continue;
+			const int32_t matches = align_left_matches(profile, i);
+			// source/filter_mismappers.cpp:111-135: + k for the seed; leading skipped bases cost nothing and a match among them counts 1, otherwise it takes back the penalty and counts 1: 2
+			const int32_t extended_score = call.score - i + KMER_LENGTH + ((call.flags & ALIGN_TASK_ROOT) ? i + matches : 2 * matches);
+			const int deletions = (call.flags & ALIGN_TASK_DELETIONS) ? 1 : 0;
+			if (extended_score > best[deletions]) best[deletions] = extended_score;
 		}
-		round.item_first_hit[k] = first; round.item_seed_end[k] = count;
+		if (best[1] != NONE && align_walk_seed(read, target, min_score, best[1], read_pos, kmer_hit, 1, *memo, *worklist)) return true;
+		if (best[0] != NONE && best[0] > best[1] && align_walk_seed(read, target, min_score, best[0], read_pos, kmer_hit, 0, *memo, *worklist)) return true; // (with at most the score of a walk that may list more: nothing new)
+		return false;
+	}
+	// returns whether the segment aligns; worklist->state[1] != 0 afterwards: a list was too short, the answer is not known (left to the recursion)
+	AGPU_HD bool align_by_sweep(const Segment& read, const AlignTarget& target, int32_t min_score) const {
+		AlignSweep& sweep = *worklist->sweep;
+		const int32_t length = (int32_t) read.length;
+#if !defined(__HIP_DEVICE_COMPILE__)
+		const uint32_t width = virtual_lanes > 1 ? virtual_lanes : 1; // host stepping: the lanes of the device one after the other
+#else
+		const uint32_t width = lanes;
+#endif
+		sync_lanes();
+		if (lane == 0) {
+			worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0;
+			AlignTask outermost = { 0, 0, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
+			outermost.flags |= align_iterations(outermost, length, min_score) << ALIGN_TASK_ITERATIONS_SHIFT;
+			worklist->push(outermost);
+		}
+		// the seeds of every read position: the hits of its 8-mer from the start of the gene to its end (source/filter_mismappers.cpp:100-106)
+		for (int32_t read_pos = (int32_t) first_of_mine(width); read_pos < length; read_pos += (int32_t) stride_of_mine(width)) {
+			uint32_t first = 0, count = 0;
+			if (read_pos + KMER_LENGTH < length && target.kmer_offsets != 0) {
+				ALIGN_STAT(read_positions, 1);
+				const uint32_t kmer = read.kmer((uint32_t) read_pos);
+				const uint32_t begin = target.kmer_offsets[kmer], end = target.kmer_offsets[kmer + 1];
+				first = lower_bound_i32(target.positions, begin, end, target.gene_start);
+				count = lower_bound_i32(target.positions, first, end, target.gene_end) - first;
+			}
+			sweep.hit_first[read_pos] = first; sweep.hit_count[read_pos] = count;
+		}
+		sync_lanes();
+#if !defined(__HIP_DEVICE_COMPILE__)
+		if (round_steps != nullptr) { round_steps[0] += 16 * (((uint32_t) length + width - 1) / width); round_steps[1] += ((uint32_t) length + width - 1) / width; } // (the look-ups, in the currency of the steps of a walk)
+#endif
+		for (int32_t block = 0; block + KMER_LENGTH < length; block += (int32_t) ALIGN_SWEEP_BLOCK) {
+			sync_lanes();
+			if (worklist->state[1] != 0) return false; // the list of the calls ran over
+			const uint32_t listed = worklist->state[0] < worklist->capacity ? worklist->state[0] : worklist->capacity;
+			sync_lanes(); // (nobody lists a call before everybody has read how many there are)
+			if (!sweep_collect_calls(sweep, block, listed, width)) { if (lane == 0) worklist->state[1] = 1; sync_lanes(); return false; }
+			if (sweep.n_calls == 0) continue;
+			sync_lanes();
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (worklist->stats != nullptr && lane == 0) worklist->stats[1] += sweep.n_calls;
+#endif
+			if (lane == 0) { // the seeds of the read positions that a call reaches, numbered through
+				uint32_t total = 0;
+				for (uint32_t k = 0; k < ALIGN_SWEEP_BLOCK; ++k) { if ((sweep.reached >> k & 1) && block + (int32_t) k < length) total += sweep.hit_count[block + (int32_t) k]; sweep.seed_end[k] = total; }
+			}
+			sync_lanes();
+			const uint32_t seeds = sweep.seed_end[ALIGN_SWEEP_BLOCK - 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (worklist->stats != nullptr && lane == 0) worklist->stats[2] += seeds;
+#endif
+			for (uint32_t seed_base = 0; seed_base < seeds; seed_base += width) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+				unsigned long long longest = 0;
+#endif
+				for (uint32_t seed = seed_base + first_of_mine(width); seed < seeds && seed < seed_base + width; seed += stride_of_mine(width)) {
+					uint32_t k = 0;
+					while (sweep.seed_end[k] <= seed) ++k;
+					const int32_t read_pos = block + (int32_t) k;
+					const uint32_t hit = sweep.hit_first[read_pos] + (seed - (k > 0 ? sweep.seed_end[k - 1] : 0u));
+#if !defined(__HIP_DEVICE_COMPILE__)
+					const unsigned long long before = g_align_seed_steps;
+#endif
+					if (sweep_seed(sweep, read, target, min_score, read_pos, target.positions[hit])) worklist->state[2] = 1;
+#if !defined(__HIP_DEVICE_COMPILE__)
+					if (g_align_seed_steps - before > longest) longest = g_align_seed_steps - before;
+					if (budget != nullptr) *budget -= (int64_t) (g_align_seed_steps - before); // (host stepping: the steps of the read, for the statistics of the harness)
+#endif
+				}
+#if !defined(__HIP_DEVICE_COMPILE__)
+				if (round_steps != nullptr) { round_steps[0] += longest; round_steps[1] += 1; }
+#endif
+				sync_lanes();
+				if (worklist->state[2] != 0) return true; // (the same for every lane: read behind the barrier)
+			}
+		}
+		sync_lanes();
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (worklist->stats != nullptr && lane == 0) worklist->stats[0] += worklist->state[0];
+#endif
+		return worklist->state[2] != 0;
 	}
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
 		if (memo != nullptr) new_memo_epoch(); // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
-		if (worklist != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end, length)) {
+		if (worklist != nullptr && worklist->sweep != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end, length) && (uint32_t) length <= ALIGN_SWEEP_SEGMENT) {
+			const bool found = align_by_sweep(read, target, min_score);
+			if (worklist->state[1] == 0) return found;
+			new_memo_epoch(); // a list was too short for this search: done again by the recursion (what the memo has "seen" are not failures)
+		} else if (worklist != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end, length)) {
 			sync_lanes();
 			if (lane == 0) { worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0; } // ([3], the host's consistency flag, is the caller's)
 			sync_lanes();
-			if (worklist->round != nullptr) {
-				if (lane == 0) { const AlignTask outermost = { 0, 0, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS }; worklist->push(outermost); } // the outermost call; its iterations are taken apart like those of any other
-			} else
 			for (int32_t read_pos = (int32_t) lane; read_pos + KMER_LENGTH < length && 2 * read_pos + min_score <= length + 2 * KMER_LENGTH; read_pos += (int32_t) lanes) { // the iterations of the outermost loop
 				const AlignTask outermost = { -read_pos, read_pos, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
 				worklist->push(outermost);
@@ -608,61 +742,6 @@ struct AlignRunner {
 				sync_lanes(); // (nobody lists a task before everybody has read the state of this round)
 				if (done) break;
 				taken = listed - head < lanes ? listed - head : lanes; // (a round that is not full: the tasks listed during it start behind `listed`, not behind head + lanes)
-				if (worklist->round != nullptr) {
-					// a round = up to 64 calls, their iterations numbered through; 64 iterations at a time look up their seeds; the lanes take 64 seeds at a time
-					AlignRound& round = *worklist->round;
-#if !defined(__HIP_DEVICE_COMPILE__)
-					const uint32_t width = virtual_lanes > 1 ? (virtual_lanes < 64 ? virtual_lanes : 64) : 1; // host stepping: the lanes of the device one after the other
-					taken = listed - head < width ? listed - head : width;
-					tasks_run += taken;
-#else
-					const uint32_t width = lanes;
-#endif
-					for (uint32_t c = first_of_mine(width); c < taken; c += stride_of_mine(width)) round_load_call(round, c, worklist->task(head + c), length, min_score);
-					sync_lanes();
-					const uint32_t total = running_sums(round.end, taken, width);
-#if defined(__HIP_DEVICE_COMPILE__)
-					if (worklist->stats != nullptr && lane == 0) { worklist->stats[0] += taken; worklist->stats[1] += total; }
-#endif
-					for (uint32_t base = 0; base < total; base += width) {
-						const uint32_t n_items = total - base < width ? total - base : width;
-						for (uint32_t k = first_of_mine(width); k < n_items; k += stride_of_mine(width)) round_load_item(round, k, base + k, taken, read, target);
-						sync_lanes();
-						const uint32_t seeds = running_sums(round.item_seed_end, n_items, width);
-#if defined(__HIP_DEVICE_COMPILE__)
-						if (worklist->stats != nullptr && lane == 0) worklist->stats[2] += seeds;
-#endif
-#if !defined(__HIP_DEVICE_COMPILE__)
-						if (round_steps != nullptr) { round_steps[0] += 16; round_steps[1] += 1; } // (what the look-up of the seeds of 64 iterations costs, in the currency of the steps of an extension)
-#endif
-						for (uint32_t seed_base = 0; seed_base < seeds; seed_base += width) {
-#if !defined(__HIP_DEVICE_COMPILE__)
-							unsigned long long longest = 0;
-#endif
-							for (uint32_t seed = seed_base + first_of_mine(width); seed < seeds && seed < seed_base + width; seed += stride_of_mine(width)) {
-								uint32_t lo = 0, hi = n_items - 1; // the first iteration whose running sum exceeds the seed
-								while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (round.item_seed_end[mid] <= seed) lo = mid + 1; else hi = mid; }
-								const AlignTask item = { round.item_score[lo], round.item_read_pos[lo], 0, round.item_flags[lo] };
-								const uint32_t hit = round.item_first_hit[lo] + (seed - (lo > 0 ? round.item_seed_end[lo - 1] : 0u));
-#if !defined(__HIP_DEVICE_COMPILE__)
-								const unsigned long long before = g_align_seed_steps;
-#endif
-								if (align_extend_seed(read, target, min_score, item, target.positions[hit], *memo, *worklist)) worklist->state[2] = 1;
-#if !defined(__HIP_DEVICE_COMPILE__)
-								if (g_align_seed_steps - before > longest) longest = g_align_seed_steps - before;
-								if (budget != nullptr) *budget -= (int64_t) (g_align_seed_steps - before); // (host stepping: the steps of the read, for the statistics of the harness)
-#endif
-							}
-#if !defined(__HIP_DEVICE_COMPILE__)
-							if (round_steps != nullptr) { round_steps[0] += longest; round_steps[1] += 1; }
-#endif
-							sync_lanes();
-							if (worklist->state[2] != 0) break; // (the same for every lane: read behind the barrier)
-						}
-						if (worklist->state[2] != 0) break;
-					}
-					continue;
-				}
 #if !defined(__HIP_DEVICE_COMPILE__)
 				if (virtual_lanes > 1) { // the tasks of one round of the device, one after the other
 					taken = listed - head < virtual_lanes ? listed - head : virtual_lanes;

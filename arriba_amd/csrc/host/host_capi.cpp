@@ -274,7 +274,8 @@ static int write_or_format_fusions(ahost_session* session, const ahost_fusion_ta
 			const size_t n_entries = t.list_offset[3 * (size_t) t.n_candidates];
 			lists_as_rows.resize(n_entries);
 			filter_of_rows.resize(fragments.size() + 1);
-			for (size_t row = 0; row < fragments.size(); ++row) filter_of_rows[row] = t.read_filter[fragments[row]];
+			if (table->read_filter_of_rows != NULL) memcpy(filter_of_rows.data(), table->read_filter_of_rows, fragments.size()); // (the device picked them: agpu_get_filters_of)
+			else { if (t.read_filter == NULL) throw std::runtime_error("the table holds neither read_filter nor read_filter_of_rows"); for (size_t row = 0; row < fragments.size(); ++row) filter_of_rows[row] = t.read_filter[fragments[row]]; }
 			// fragment -> row: a bit per fragment and the number of set bits in front of every word (the row of a fragment is its rank among the fragments handed over);
 			// the lists are translated by all threads (10^6 entries of the written candidates of a 10^7-fragment sample; a binary search per entry on one thread took 0.25 s)
 			const size_t words = fragments.empty() ? 1 : (size_t) fragments.back() / 64 + 1;
@@ -524,9 +525,8 @@ int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* 
 int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments) {
 	if (!session || !rows || (!fragments && rows->n > 0)) { g_error = "null argument"; return -1; }
 	try {
-		Batch& b = session->ingest.batch;
+		Batch& b = session->ingest.batch; // (every member is assigned below: the vectors keep their memory from one file to the next)
 		const size_t n = rows->n;
-		b = Batch();
 		b.n = n;
 		b.n_aln.assign(rows->n_aln, rows->n_aln + n); b.fbits.assign(rows->fbits, rows->fbits + n); b.filter.assign(n, 0); b.group.assign(rows->group, rows->group + n);
 		for (int s = 0; s < 3; ++s) {

@@ -6,7 +6,9 @@
 #include "output.h"
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include "transcript.h"
@@ -24,6 +26,43 @@ namespace arriba {
 namespace {
 
 const unsigned N_FILTER_NAMES = FILTER_COUNT; // FILTER_NAMES: arriba_host.h (source/common.hpp:29-67)
+
+// The threads that format the rows stay between the files of a resident service: a thread that is created per file starts with an empty allocator arena and
+// grows it under the eyes of all others (page faults, mprotect), file after file; the threads of the pool keep theirs, and the pages of their pileups (transcript.cpp).
+class FormatterPool {
+public:
+	~FormatterPool() { { std::lock_guard<std::mutex> lock(mutex_); stop_ = true; } wake_.notify_all(); for (size_t t = 0; t < threads_.size(); ++t) threads_[t].join(); }
+	// `work` on n threads of the pool at once (it takes its items from a shared counter); returns when all of them have left it
+	void run(unsigned n, const std::function<void()>& work) {
+		std::unique_lock<std::mutex> lock(mutex_);
+		while (threads_.size() < n) threads_.push_back(std::thread(&FormatterPool::serve, this, threads_.size()));
+		work_ = &work; wanted_ = n; running_ = n; ++generation_;
+		wake_.notify_all();
+		done_.wait(lock, [&] { return running_ == 0; });
+		work_ = NULL;
+	}
+private:
+	void serve(size_t index) {
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lock(mutex_);
+		while (true) {
+			wake_.wait(lock, [&] { return stop_ || (generation_ != seen && index < wanted_); });
+			if (stop_) return;
+			seen = generation_;
+			const std::function<void()>* work = work_;
+			lock.unlock();
+			(*work)();
+			lock.lock();
+			if (--running_ == 0) done_.notify_all();
+		}
+	}
+	std::mutex mutex_; std::condition_variable wake_, done_;
+	std::vector<std::thread> threads_;
+	const std::function<void()>* work_ = NULL;
+	unsigned wanted_ = 0, running_ = 0; uint64_t generation_ = 0; bool stop_ = false;
+};
+FormatterPool& formatter_pool() { static FormatterPool pool; return pool; }
+std::mutex formatter_pool_in_use; // (one file at a time)
 
 struct Fusion { // one row, as the reference's fusion_t sees it
 	uint32_t candidate;
@@ -421,11 +460,7 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			}
 		};
 		if (n_threads == 1 || count < 4) work();
-		else {
-			std::vector<std::thread> threads;
-			for (unsigned int t = 0; t < std::min<size_t>(n_threads, count); ++t) threads.push_back(std::thread(work));
-			for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
-		}
+		else { std::lock_guard<std::mutex> one_file(formatter_pool_in_use); formatter_pool().run((unsigned) std::min<size_t>(n_threads, count), work); }
 		if (failure) { if (out) fclose(out); std::rethrow_exception(failure); }
 		for (size_t k = 0; k < count; ++k) {
 			if (!row_warnings[k].empty()) fputs(row_warnings[k].c_str(), stderr);

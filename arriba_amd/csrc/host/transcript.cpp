@@ -13,6 +13,7 @@
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 
 namespace arriba {
@@ -49,13 +50,26 @@ const char* const SINGLE_ALLELES = "-<=>ABCDGHKMNRSTVWY_"; // in ASCII order == 
 const int N_SINGLE_ALLELES = 20;
 struct Allele { std::string text; unsigned count; };
 struct Column { position_t position; size_t first, n; }; // alleles[first .. first + n)
+// The pages of the pileups of a thread are kept and handed out again: a row of the output file piles up ~10 pages of 20 KB and gives them back, all writer threads at once;
+// through malloc / free the arenas of the threads grow and shrink by that much per row, and every shrink is an madvise that interrupts all cores (measured on the 256-thread
+// host of the GPU box: 4 ms per row on 128 threads where one thread needs 0.2 ms -- profiles/r03c_mismapper_second_pass.txt, [writer] lines).
+const size_t PILEUP_PAGE_WORDS = 256 * 20;
+struct PilePagePool {
+	std::vector<unsigned*> free_pages;
+	~PilePagePool() { for (size_t k = 0; k < free_pages.size(); ++k) delete[] free_pages[k]; }
+	unsigned* take() { unsigned* page; if (free_pages.empty()) page = new unsigned[PILEUP_PAGE_WORDS]; else { page = free_pages.back(); free_pages.pop_back(); } memset(page, 0, PILEUP_PAGE_WORDS * sizeof(unsigned)); return page; }
+	void give(unsigned* page) { free_pages.push_back(page); }
+};
+thread_local PilePagePool pile_page_pool;
 class DensePileup {
 public:
 	DensePileup(): last_page_(0), last_(NULL) { for (int c = 0; c < 256; ++c) slot_of_char_[c] = -1; for (int k = 0; k < N_SINGLE_ALLELES; ++k) slot_of_char_[(unsigned char) SINGLE_ALLELES[k]] = k; }
+	~DensePileup() { for (std::map<position_t, unsigned*>::iterator page = pages_.begin(); page != pages_.end(); ++page) pile_page_pool.give(page->second); }
+	DensePileup(const DensePileup&) = delete; DensePileup& operator=(const DensePileup&) = delete;
 	int slot_of(char allele) const { return slot_of_char_[(unsigned char) allele]; }
 	void add(position_t position, int slot, unsigned count = 1) {
 		const position_t page = position >> 8;
-		if (last_ == NULL || page != last_page_) { std::vector<unsigned>& counts = pages_[page]; if (counts.empty()) counts.assign(256 * N_SINGLE_ALLELES, 0); last_ = counts.data(); last_page_ = page; }
+		if (last_ == NULL || page != last_page_) { unsigned*& counts = pages_[page]; if (counts == NULL) counts = pile_page_pool.take(); last_ = counts; last_page_ = page; }
 		last_[(size_t) (position & 255) * N_SINGLE_ALLELES + slot] += count;
 	}
 	void add(position_t position, const std::string& allele) { // any allele (insertions; what std::string::substr gives at the end of a sequence)
@@ -68,15 +82,17 @@ public:
 	void columns(std::vector<Column>& columns, std::vector<Allele>& alleles) const {
 		columns.clear(); alleles.clear();
 		// the positions that hold counted alleles, ascending
-		std::vector<std::pair<position_t, const unsigned*> > counted;
-		for (std::map<position_t, std::vector<unsigned> >::const_iterator page = pages_.begin(); page != pages_.end(); ++page)
+		static thread_local std::vector<std::pair<position_t, const unsigned*> > counted; // (kept between the rows of a thread, like the pages)
+		counted.clear();
+		for (std::map<position_t, unsigned*>::const_iterator page = pages_.begin(); page != pages_.end(); ++page)
 			for (int at = 0; at < 256; ++at) {
-				const unsigned* counts = &page->second[(size_t) at * N_SINGLE_ALLELES];
+				const unsigned* counts = page->second + (size_t) at * N_SINGLE_ALLELES;
 				bool any = false;
 				for (int slot = 0; slot < N_SINGLE_ALLELES; ++slot) any = any || counts[slot] > 0;
 				if (any) counted.push_back(std::make_pair(page->first * 256 + at, counts));
 			}
-		std::vector<std::pair<position_t, long long> > events; // the number of reads inside an intron changes by .second at position .first
+		static thread_local std::vector<std::pair<position_t, long long> > events; // the number of reads inside an intron changes by .second at position .first
+		events.clear();
 		for (size_t k = 0; k < inside_introns_.size(); ++k) { events.push_back(std::make_pair(inside_introns_[k].from, (long long) inside_introns_[k].count)); events.push_back(std::make_pair(inside_introns_[k].to + 1, -(long long) inside_introns_[k].count)); }
 		std::sort(events.begin(), events.end());
 		std::map<position_t, std::map<std::string, unsigned> >::const_iterator other = other_.begin();
@@ -115,7 +131,7 @@ public:
 		}
 	}
 private:
-	std::map<position_t, std::vector<unsigned> > pages_;
+	std::map<position_t, unsigned*> pages_;
 	std::map<position_t, std::map<std::string, unsigned> > other_;
 	struct Interval { position_t from, to; unsigned count; };
 	std::vector<Interval> inside_introns_;
@@ -211,7 +227,7 @@ unsigned reads_at(const std::vector<Allele>& alleles, const Column& column) {
 
 // reference: get_sequence_from_pileup (:109-240): the consensus next to one breakpoint; `clipped` receives what lies beyond the breakpoint
 void consensus_of_pileup(const DensePileup& pileup, position_t breakpoint, bool upstream, contig_t contig, const Assembly& assembly, std::string& sequence, std::vector<position_t>& positions, std::string& clipped) {
-	std::vector<Column> columns; std::vector<Allele> alleles;
+	static thread_local std::vector<Column> columns; static thread_local std::vector<Allele> alleles; // (cleared and filled by columns(): their memory stays with the thread)
 	pileup.columns(columns, alleles);
 	unsigned peak = 0;
 	for (size_t at = 0; at < columns.size(); ++at) peak = std::max(peak, reads_at(alleles, columns[at]));

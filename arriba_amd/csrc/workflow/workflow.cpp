@@ -4,10 +4,12 @@
 // the tests and the bench.
 #include "../../../include/arriba_workflow.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
 #include <iostream>
+#include <map>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -23,17 +25,51 @@ void host_check(int status) { if (status != 0) throw Failure{ std::string("ERROR
 // filter ids (positions in FILTERS, source/common.hpp:29-67) of the filters main() asks about itself
 enum { F_known_fusions = 18, F_blacklist = 20, F_no_genomic_support = 29, F_genomic_support = 34, F_many_spliced = 28, F_select_best = 24 };
 
+double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// A session (arriba_workflow_open): what is loaded once, and what a sample leaves behind for the next one.  `options` points at copies of the caller's strings.
 struct Run {
-	const arriba_workflow_options& options;
+	arriba_workflow_options options;
+	std::vector<std::string> strings; // the texts options.* point at (the caller's may be gone after arriba_workflow_open)
 	arriba_workflow_report* report;
+	arriba_workflow_timing* timing;
 	ahost_session* host;
 	agpu_ctx* device;
 	uint32_t dummy_genes;
 	uint64_t n_candidates, n_fragments, mapped_reads;
 	bool device_ingest;
 	void* pieces[2];
-	Run(const arriba_workflow_options& o, arriba_workflow_report* r): options(o), report(r), host(nullptr), device(nullptr), dummy_genes(0), n_candidates(0), n_fragments(0), mapped_reads(0), device_ingest(false) { pieces[0] = pieces[1] = nullptr; }
-	~Run() { for (int k = 0; k < 2; ++k) if (pieces[k]) agpu_host_free(pieces[k]); if (device) agpu_destroy(device); if (host) ahost_close(host); }
+	std::vector<agpu_bgzf_block> tables[2];
+	agpu_params params; // as the last sample resolved them (strandedness)
+	bool tags_loaded = false, domains_loaded = false;
+	// Host memory for what comes back from the device per sample (candidate columns, rows of supporting reads): pinned, kept by the session and only ever grown -- fresh
+	// std::vectors of some hundred MB per sample are zeroed page by page and given back to the system again, which costs more than the transfer they hold.
+	struct Staged { void* pointer = nullptr; size_t capacity = 0; };
+	std::map<std::string, Staged> staged;
+	template <class T> T* stage(const char* name, size_t count) {
+		Staged& buffer = staged[name];
+		const size_t bytes = (count > 0 ? count : 1) * sizeof(T);
+		if (bytes > buffer.capacity) {
+			if (buffer.pointer) agpu_host_free(buffer.pointer);
+			buffer.capacity = bytes + bytes / 4;
+			buffer.pointer = agpu_host_alloc(buffer.capacity);
+			if (!buffer.pointer) { buffer.capacity = 0; throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
+		}
+		return (T*) buffer.pointer;
+	}
+	Run(const arriba_workflow_options& o): options(o), report(nullptr), timing(nullptr), host(nullptr), device(nullptr), dummy_genes(0), n_candidates(0), n_fragments(0), mapped_reads(0), device_ingest(false) {
+		pieces[0] = pieces[1] = nullptr;
+		const char** texts[] = { &options.assembly_file, &options.gene_annotation_file, &options.chimeric_bam_file, &options.output_file, &options.discarded_output_file, &options.blacklist_file, &options.known_fusions_file,
+		                         &options.tags_file, &options.protein_domains_file, &options.genomic_breakpoints_file, &options.interesting_contigs, &options.viral_contigs, &options.gtf_features };
+		strings.reserve(sizeof(texts) / sizeof(texts[0]));
+		for (size_t k = 0; k < sizeof(texts) / sizeof(texts[0]); ++k) if (*texts[k] != nullptr) { strings.push_back(*texts[k]); *texts[k] = strings.back().c_str(); }
+	}
+	~Run() {
+		for (int k = 0; k < 2; ++k) if (pieces[k]) agpu_host_free(pieces[k]);
+		for (std::map<std::string, Staged>::iterator buffer = staged.begin(); buffer != staged.end(); ++buffer) if (buffer->second.pointer) agpu_host_free(buffer->second.pointer);
+		if (device) agpu_destroy(device); if (host) ahost_close(host);
+	}
+	Run(const Run&) = delete; Run& operator=(const Run&) = delete;
 	void note(const char* stage, uint64_t count) {
 		progress(stage, count);
 		if (!report || report->n_stages >= sizeof(report->stages) / sizeof(report->stages[0])) return;
@@ -100,136 +136,157 @@ struct Run {
 // pieces through two pinned buffers in turn; the batch and coverage_t are built in HBM, the host takes over the counters and coverage_t
 void read_chimeric_alignments_on_device(Run& run) {
 	const arriba_workflow_options& o = run.options;
+	const double started = now_seconds();
 	agpu_ingest_config config;
 	host_check(ahost_bam_open(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length, &config));
+	struct Closer { ahost_session* host; bool open; ~Closer() { if (open) ahost_bam_close(host); } } closer = { run.host, true }; // (on every way out)
+	const uint64_t windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0; // (the table belongs to the session: read before anything else touches it)
+	const uint32_t n_contigs = config.n_contigs;
 	device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host))); // with the contigs of the BAM header
 	device_check(agpu_ingest_begin(run.device, &config));
 	const size_t piece_bytes = 256u << 20;
 	const uint32_t block_capacity = (uint32_t) (piece_bytes / 4096 + 16);
-	std::vector<agpu_bgzf_block> tables[2] = { std::vector<agpu_bgzf_block>(block_capacity), std::vector<agpu_bgzf_block>(block_capacity) };
-	for (int k = 0; k < 2; ++k) { run.pieces[k] = agpu_host_alloc(piece_bytes); if (!run.pieces[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
+	for (int k = 0; k < 2; ++k) { // the two pinned buffers stay with the session: pinning 2 x 256 MB costs as much as feeding a gigabyte
+		if (run.tables[k].size() != block_capacity) run.tables[k].assign(block_capacity, agpu_bgzf_block());
+		if (!run.pieces[k]) { run.pieces[k] = agpu_host_alloc(piece_bytes); if (!run.pieces[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
+	}
 	for (unsigned int push = 0; ; ++push) {
 		ahost_bam_piece piece;
-		const int status = ahost_bam_next(run.host, run.pieces[push & 1], piece_bytes, tables[push & 1].data(), block_capacity, &piece);
+		const int status = ahost_bam_next(run.host, run.pieces[push & 1], piece_bytes, run.tables[push & 1].data(), block_capacity, &piece);
 		if (status < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
 		if (status == 0) break;
-		if (piece.stored_bgzf) device_check(agpu_ingest_push_bgzf(run.device, run.pieces[push & 1], piece.bytes, tables[push & 1].data(), piece.n_blocks, piece.stream_bytes));
+		if (piece.stored_bgzf) device_check(agpu_ingest_push_bgzf(run.device, run.pieces[push & 1], piece.bytes, run.tables[push & 1].data(), piece.n_blocks, piece.stream_bytes));
 		else device_check(agpu_ingest_push(run.device, run.pieces[push & 1], piece.bytes));
 	}
+	const double fed = now_seconds();
 	agpu_ingest_result result;
 	device_check(agpu_ingest_finish(run.device, &result));
-	ahost_bam_close(run.host);
-	for (int k = 0; k < 2; ++k) { agpu_host_free(run.pieces[k]); run.pieces[k] = nullptr; }
-	const uint64_t windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0;
-	std::vector<uint64_t> viral(config.n_contigs > 0 ? config.n_contigs : 1);
+	ahost_bam_close(run.host); closer.open = false;
+	const double finished = now_seconds();
+	std::vector<uint64_t> viral(n_contigs > 0 ? n_contigs : 1);
 	std::vector<uint16_t> coverage(windows > 0 ? windows : 1);
 	std::vector<uint8_t> starts(coverage.size()), ends(coverage.size());
 	device_check(agpu_get_viral_read_counts(run.device, viral.data()));
 	device_check(agpu_get_coverage(run.device, coverage.data(), starts.data(), ends.data()));
 	host_check(ahost_adopt_device_ingest(run.host, &result, viral.data(), coverage.data(), starts.data(), ends.data()));
 	run.n_fragments = result.fragments;
+	run.note("bam_records", result.records); // (for the report only: no line of the reference's log)
+	if (run.timing) { run.timing->feed = fed - started; run.timing->ingest = finished - fed; run.timing->adopt = now_seconds() - finished; }
 }
 
-// the writer prints names, CIGAR-derived pileups and sequences of the supporting reads of the candidates it writes: their rows come back from the device
-void fetch_rows_for_writer(Run& run, const ahost_fusion_table& table, int write_discarded) {
+// the writer prints names, CIGAR-derived pileups and sequences of the supporting reads of the candidates it writes: their rows come back from the device, and their filters
+void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discarded, bool filters_of_rows) {
 	if (!run.device_ingest) return;
 	uint64_t count = 0;
 	host_check(ahost_fusion_table_reads(&table, write_discarded, nullptr, 0, &count));
-	std::vector<uint32_t> fragments(count > 0 ? count : 1);
-	host_check(ahost_fusion_table_reads(&table, write_discarded, fragments.data(), count, &count));
+	uint32_t* fragments = run.stage<uint32_t>("rows.fragments", count);
+	host_check(ahost_fusion_table_reads(&table, write_discarded, fragments, count, &count));
 	uint64_t cigar_words = 0, sequence_bytes = 0, name_bytes = 0;
-	device_check(agpu_gather_rows_begin(run.device, fragments.data(), count, &cigar_words, &sequence_bytes, &name_bytes));
-	const size_t n1 = count > 0 ? count : 1;
-	std::vector<uint8_t> n_aln(n1), fbits(n1), abits[3], seq_pool(sequence_bytes + 4);
-	std::vector<uint32_t> group(n1), cigar_offset[3], cigar_pool(cigar_words + 1), seq_offset[2], seq_length[2], name_offset(count + 1);
-	std::vector<uint16_t> contig[3], cigar_count[3];
-	std::vector<int32_t> start[3], end[3];
-	std::vector<char> names(name_bytes + 1);
+	device_check(agpu_gather_rows_begin(run.device, fragments, count, &cigar_words, &sequence_bytes, &name_bytes));
 	agpu_batch_rows rows;
 	memset(&rows, 0, sizeof(rows));
-	rows.n_aln = n_aln.data(); rows.fbits = fbits.data(); rows.group = group.data();
+	rows.n_aln = run.stage<uint8_t>("rows.n_aln", count); rows.fbits = run.stage<uint8_t>("rows.fbits", count); rows.group = run.stage<uint32_t>("rows.group", count);
+	static const char* const names[3][6] = { { "rows.contig0", "rows.start0", "rows.end0", "rows.abits0", "rows.cigar_offset0", "rows.cigar_count0" }, { "rows.contig1", "rows.start1", "rows.end1", "rows.abits1", "rows.cigar_offset1", "rows.cigar_count1" },
+	                                         { "rows.contig2", "rows.start2", "rows.end2", "rows.abits2", "rows.cigar_offset2", "rows.cigar_count2" } };
 	for (int k = 0; k < 3; ++k) {
-		contig[k].resize(n1); start[k].resize(n1); end[k].resize(n1); abits[k].resize(n1); cigar_offset[k].resize(n1); cigar_count[k].resize(n1);
-		rows.contig[k] = contig[k].data(); rows.start[k] = start[k].data(); rows.end[k] = end[k].data(); rows.abits[k] = abits[k].data(); rows.cigar_offset[k] = cigar_offset[k].data(); rows.cigar_count[k] = cigar_count[k].data();
+		rows.contig[k] = run.stage<uint16_t>(names[k][0], count); rows.start[k] = run.stage<int32_t>(names[k][1], count); rows.end[k] = run.stage<int32_t>(names[k][2], count);
+		rows.abits[k] = run.stage<uint8_t>(names[k][3], count); rows.cigar_offset[k] = run.stage<uint32_t>(names[k][4], count); rows.cigar_count[k] = run.stage<uint16_t>(names[k][5], count);
 	}
-	for (int k = 0; k < 2; ++k) { seq_offset[k].resize(n1); seq_length[k].resize(n1); rows.seq_offset[k] = seq_offset[k].data(); rows.seq_length[k] = seq_length[k].data(); }
-	rows.cigar_pool = cigar_pool.data(); rows.seq_pool = seq_pool.data(); rows.name_offset = name_offset.data(); rows.names = names.data();
+	rows.seq_offset[0] = run.stage<uint32_t>("rows.seq_offset0", count); rows.seq_length[0] = run.stage<uint32_t>("rows.seq_length0", count);
+	rows.seq_offset[1] = run.stage<uint32_t>("rows.seq_offset1", count); rows.seq_length[1] = run.stage<uint32_t>("rows.seq_length1", count);
+	rows.cigar_pool = run.stage<uint32_t>("rows.cigar_pool", cigar_words + 1); rows.seq_pool = run.stage<uint8_t>("rows.seq_pool", sequence_bytes + 4);
+	rows.name_offset = run.stage<uint32_t>("rows.name_offset", count + 1); rows.names = run.stage<char>("rows.names", name_bytes + 1);
 	device_check(agpu_gather_rows_copy(run.device, &rows));
-	host_check(ahost_set_batch_rows(run.host, &rows, count > 0 ? fragments.data() : nullptr));
+	if (filters_of_rows) { // the filters of these fragments only, instead of one byte for every fragment of the sample
+		uint8_t* filters = run.stage<uint8_t>("rows.filter", count);
+		device_check(agpu_get_filters_of(run.device, fragments, count, filters));
+		table.read_filter_of_rows = filters;
+	}
+	host_check(ahost_set_batch_rows(run.host, &rows, count > 0 ? fragments : nullptr));
 }
 
 // the output files: the device's results brought back, formatted by the host library (source/arriba.cpp:586-610).  Only the candidates a file will hold
-// travel with their read lists: fusions.tsv holds the few thousand that passed every filter, of millions.
-template <class T> std::vector<T> pick(const std::vector<T>& column, const std::vector<uint32_t>& rows) {
-	std::vector<T> picked(rows.size() > 0 ? rows.size() : 1);
-	for (size_t k = 0; k < rows.size(); ++k) picked[k] = column[rows[k]];
-	return picked;
-}
-
+// travel: fusions.tsv holds the few thousand that passed every filter, of millions -- they are picked on the device (agpu_select_candidates), with their read lists, the
+// rows of their supporting reads and the filters of those.  discarded.tsv (-O) counts the discarded reads of every discarded candidate by filter: the same call, more rows.
 void write_output_files(Run& run, int32_t max_mate_gap) {
-	const size_t n = (size_t) run.n_candidates, n1 = n > 0 ? n : 1;
-	std::vector<uint32_t> gene1(n1), gene2(n1), contigs(n1), flags(n1), split_reads1(n1), split_reads2(n1), discordant_mates(n1), iteration_rank(n1);
-	std::vector<int32_t> breakpoint1(n1), breakpoint2(n1), closest1(n1), closest2(n1);
-	std::vector<uint8_t> filter(n1), confidence(n1);
-	std::vector<float> evalue(n1);
-	device_check(agpu_get_candidates(run.device, gene1.data(), gene2.data(), contigs.data(), breakpoint1.data(), breakpoint2.data(), flags.data(), filter.data(), split_reads1.data(), split_reads2.data(),
-	                                 discordant_mates.data(), nullptr, nullptr, nullptr));
-	device_check(agpu_get_evalues(run.device, evalue.data()));
-	device_check(agpu_assign_confidence(run.device, confidence.data())); // behind the 'isoforms' filter: recovered isoforms are scored anew
-	device_check(agpu_candidate_iteration_order(run.device, iteration_rank.data()));
-	device_check(agpu_get_genomic_support(run.device, closest1.data(), closest2.data()));
-	std::vector<uint8_t> read_filter(run.n_fragments > 0 ? run.n_fragments : 1);
-	device_check(agpu_get_filters(run.device, read_filter.data()));
+	double mark = now_seconds();
+	auto lap = [&](double arriba_workflow_timing::* part) { const double now = now_seconds(); if (run.timing) run.timing->*part += now - mark; mark = now; };
+	device_check(agpu_assign_confidence(run.device, nullptr)); // behind the 'isoforms' filter: recovered isoforms are scored anew
+	device_check(agpu_candidate_iteration_order(run.device, nullptr));
 	const uint32_t n_genes = ahost_annotation_view(run.host)->n_genes + run.dummy_genes;
 	std::vector<uint16_t> gene_contig(n_genes > 0 ? n_genes : 1);
 	std::vector<int32_t> gene_start(gene_contig.size()), gene_end(gene_contig.size());
 	device_check(agpu_get_gene_table(run.device, 0, n_genes, gene_contig.data(), gene_start.data(), gene_end.data(), nullptr, nullptr));
-	if (run.options.tags_file) { run.say(std::string("Loading tags from '") + run.options.tags_file + "'"); host_check(ahost_load_tags(run.host, run.options.tags_file)); }
-	if (run.options.protein_domains_file) { run.say(std::string("Loading protein domains from '") + run.options.protein_domains_file + "'"); host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file)); }
+	if (run.options.tags_file && !run.tags_loaded) { run.say(std::string("Loading tags from '") + run.options.tags_file + "'"); host_check(ahost_load_tags(run.host, run.options.tags_file)); run.tags_loaded = true; } // (once per session)
+	if (run.options.protein_domains_file && !run.domains_loaded) { run.say(std::string("Loading protein domains from '") + run.options.protein_domains_file + "'"); host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file)); run.domains_loaded = true; }
 
 	for (int write_discarded = 0; write_discarded <= (run.options.discarded_output_file ? 1 : 0); ++write_discarded) {
-		std::vector<uint32_t> written;
-		for (size_t c = 0; c < n; ++c) if ((write_discarded != 0) != (filter[c] == 0)) written.push_back((uint32_t) c);
-		const size_t w = written.size();
-		std::vector<uint32_t> list_offset(3 * w + 1, 0);
+		uint64_t w = 0;
+		device_check(agpu_select_candidates(run.device, write_discarded, &w));
+		agpu_selected_candidates columns;
+		columns.candidate = run.stage<uint32_t>("table.candidate", w); columns.gene1 = run.stage<uint32_t>("table.gene1", w); columns.gene2 = run.stage<uint32_t>("table.gene2", w); columns.contigs = run.stage<uint32_t>("table.contigs", w);
+		columns.breakpoint1 = run.stage<int32_t>("table.breakpoint1", w); columns.breakpoint2 = run.stage<int32_t>("table.breakpoint2", w); columns.flags = run.stage<uint32_t>("table.flags", w); columns.filter = run.stage<uint8_t>("table.filter", w);
+		columns.split_reads1 = run.stage<uint32_t>("table.split_reads1", w); columns.split_reads2 = run.stage<uint32_t>("table.split_reads2", w); columns.discordant_mates = run.stage<uint32_t>("table.discordant_mates", w);
+		columns.evalue = run.stage<float>("table.evalue", w); columns.confidence = run.stage<uint8_t>("table.confidence", w); columns.iteration_rank = run.stage<uint32_t>("table.iteration_rank", w);
+		columns.closest_genomic_breakpoint1 = run.stage<int32_t>("table.closest1", w); columns.closest_genomic_breakpoint2 = run.stage<int32_t>("table.closest2", w);
+		device_check(agpu_get_selected_candidates(run.device, &columns));
+		uint32_t* list_offset = run.stage<uint32_t>("table.list_offset", 3 * w + 1);
+		list_offset[0] = 0;
 		uint64_t total = 0;
-		device_check(agpu_get_candidate_read_lists_of(run.device, written.data(), w, list_offset.data(), nullptr, 0, &total));
-		std::vector<uint32_t> read_lists(total > 0 ? total : 1);
-		if (total > 0) device_check(agpu_get_candidate_read_lists_of(run.device, written.data(), w, list_offset.data(), read_lists.data(), total, &total));
-		const std::vector<uint32_t> w_gene1 = pick(gene1, written), w_gene2 = pick(gene2, written), w_contigs = pick(contigs, written), w_flags = pick(flags, written), w_split_reads1 = pick(split_reads1, written),
-		                            w_split_reads2 = pick(split_reads2, written), w_discordant_mates = pick(discordant_mates, written), w_iteration_rank = pick(iteration_rank, written);
-		const std::vector<int32_t> w_breakpoint1 = pick(breakpoint1, written), w_breakpoint2 = pick(breakpoint2, written), w_closest1 = pick(closest1, written), w_closest2 = pick(closest2, written);
-		const std::vector<uint8_t> w_filter = pick(filter, written), w_confidence = pick(confidence, written);
-		const std::vector<float> w_evalue = pick(evalue, written);
+		device_check(agpu_get_candidate_read_lists_of(run.device, columns.candidate, w, list_offset, nullptr, 0, &total));
+		uint32_t* read_lists = run.stage<uint32_t>("table.read_lists", total);
+		if (total > 0) device_check(agpu_get_candidate_read_lists_of(run.device, columns.candidate, w, list_offset, read_lists, total, &total));
 		ahost_fusion_table table;
 		memset(&table, 0, sizeof(table));
 		table.n_candidates = (uint32_t) w;
-		table.gene1 = w_gene1.data(); table.gene2 = w_gene2.data(); table.contigs = w_contigs.data(); table.breakpoint1 = w_breakpoint1.data(); table.breakpoint2 = w_breakpoint2.data(); table.flags = w_flags.data(); table.filter = w_filter.data();
-		table.split_reads1 = w_split_reads1.data(); table.split_reads2 = w_split_reads2.data(); table.discordant_mates = w_discordant_mates.data(); table.list_offset = list_offset.data(); table.read_lists = read_lists.data();
-		table.evalue = w_evalue.data(); table.confidence = w_confidence.data(); table.iteration_rank = w_iteration_rank.data(); table.read_filter = read_filter.data();
-		table.closest_genomic_breakpoint1 = w_closest1.data(); table.closest_genomic_breakpoint2 = w_closest2.data();
+		table.gene1 = columns.gene1; table.gene2 = columns.gene2; table.contigs = columns.contigs; table.breakpoint1 = columns.breakpoint1; table.breakpoint2 = columns.breakpoint2; table.flags = columns.flags; table.filter = columns.filter;
+		table.split_reads1 = columns.split_reads1; table.split_reads2 = columns.split_reads2; table.discordant_mates = columns.discordant_mates; table.list_offset = list_offset; table.read_lists = read_lists;
+		table.evalue = columns.evalue; table.confidence = columns.confidence; table.iteration_rank = columns.iteration_rank;
+		table.closest_genomic_breakpoint1 = columns.closest_genomic_breakpoint1; table.closest_genomic_breakpoint2 = columns.closest_genomic_breakpoint2;
 		table.n_genes = n_genes; table.gene_contig = gene_contig.data(); table.gene_start = gene_start.data(); table.gene_end = gene_end.data();
 		const int print_extra_info = write_discarded ? run.options.print_extra_info_for_discarded_fusions : 1;
 		if (write_discarded) run.say(std::string("Writing discarded fusions to file '") + run.options.discarded_output_file + "'");
 		else run.say(std::string("Writing fusions to file '") + run.options.output_file + "' ");
-		if (print_extra_info) fetch_rows_for_writer(run, table, write_discarded);
+		const bool rows_from_device = print_extra_info && run.device_ingest;
+		if (!rows_from_device) { // the filter of every fragment: the writer counts the discarded reads of a candidate by filter (and, after a host ingest, works on the batch of the session)
+			uint8_t* read_filter = run.stage<uint8_t>("table.read_filter", run.n_fragments);
+			device_check(agpu_get_filters(run.device, read_filter));
+			table.read_filter = read_filter;
+		}
+		lap(&arriba_workflow_timing::output_results);
+		if (rows_from_device) fetch_rows_for_writer(run, table, write_discarded, true);
+		lap(&arriba_workflow_timing::output_rows);
 		host_check(ahost_write_fusions(run.host, &table, write_discarded ? run.options.discarded_output_file : run.options.output_file, write_discarded, print_extra_info, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
+		lap(&arriba_workflow_timing::output_format);
 	}
 }
 
-void run_workflow(Run& run) {
+// what main() does once per process: assembly, annotation, index (source/arriba.cpp:97-113); the device context with the annotation in HBM
+void open_session(Run& run) {
 	const arriba_workflow_options& o = run.options;
-	if (!o.assembly_file || !o.gene_annotation_file || !o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
-	// source/arriba.cpp:97-130: assembly, annotation, index, chimeric alignments
+	if (!o.assembly_file || !o.gene_annotation_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
 	run.say(std::string("Loading assembly from '") + o.assembly_file + "' ");
 	run.say(std::string("Loading annotation from '") + o.gene_annotation_file + "' ");
 	run.host = ahost_open(o.assembly_file, o.gene_annotation_file, o.interesting_contigs, o.viral_contigs, o.gtf_features);
 	if (!run.host) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
-	agpu_params params = o.device;
-	if (params.strandedness > 2) params.strandedness = 0; // resolved below
-	run.device = agpu_create(o.device_index, &params);
+	run.params = o.device;
+	if (run.params.strandedness > 2) run.params.strandedness = 0; // resolved per sample
+	run.device = agpu_create(o.device_index, &run.params);
 	if (!run.device) throw Failure{ std::string("ERROR: ") + agpu_last_error() };
 	device_check(agpu_upload_annotation(run.device, ahost_annotation_view(run.host)));
+}
+
+// what main() does per sample: read_chimeric_alignments ... the output files (source/arriba.cpp:119-610)
+void run_sample(Run& run) {
+	const arriba_workflow_options& o = run.options;
+	if (!o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
+	const double sample_started = now_seconds();
+	if (run.timing) memset(run.timing, 0, sizeof(*run.timing));
+	agpu_params& params = run.params;
+	params = o.device;
+	if (params.strandedness > 2) params.strandedness = 0; // resolved below
+	device_check(agpu_set_params(run.device, &params));
+	run.dummy_genes = 0; run.n_candidates = 0; run.n_fragments = 0;
 	run.device_ingest = !o.host_ingest;
 	if (run.device_ingest) read_chimeric_alignments_on_device(run);
 	else {
@@ -237,9 +294,13 @@ void run_workflow(Run& run) {
 		device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host)));
 		device_check(agpu_upload_batch(run.device, ahost_batch_view(run.host)));
 		run.n_fragments = ahost_batch_view(run.host)->n;
+		if (run.timing) run.timing->feed = now_seconds() - sample_started;
 	}
 	run.mapped_reads = ahost_mapped_reads(run.host);
+	run.note("read_chimeric_alignments", run.n_fragments); // (the log line follows; `note` prints the lines of the stages behind it)
 	if (o.log_to_stdout) std::cout << Run::time_string() << " Reading chimeric alignments from '" << o.chimeric_bam_file << "' (total=" << run.n_fragments << ")" << std::endl;
+	const double stages_started = now_seconds();
+	double mismappers_seconds = 0;
 
 	// :141-325 multi-mappers, strandedness, annotation
 	uint64_t count = 0;
@@ -347,13 +408,20 @@ void run_workflow(Run& run) {
 	run.say("Indexing gene sequences ");
 	device_check(agpu_make_kmer_index(run.device, (int32_t) ((float) max_mate_gap + 2.0f * read_length_mean), &n_positions));
 	device_check(agpu_filter_homologs(run.device, o.max_homolog_identity, &count)); run.note("filter_homologs", count);
-	device_check(agpu_filter_mismappers(run.device, max_mate_gap, &count, &discarded_reads)); run.note("filter_mismappers", count);
+	{ const double before = now_seconds(); device_check(agpu_filter_mismappers(run.device, max_mate_gap, &count, &discarded_reads)); mismappers_seconds = now_seconds() - before; }
+	run.note("filter_mismappers", count);
 	// :567-584
 	if (o.genomic_breakpoints_file && run.enabled(F_genomic_support)) { device_check(agpu_recover_genomic_support(run.device, &count)); run.note("recover_genomic_support", count); }
 	if ((o.genomic_breakpoints_file && run.enabled(F_genomic_support)) || run.enabled(F_many_spliced)) { device_check(agpu_select_most_supported_breakpoints(run.device, &count)); run.note("select_most_supported_breakpoints", count); }
 	device_check(agpu_recover_isoforms(run.device, &count)); run.note("recover_isoforms", count);
 	run.say("Assigning confidence scores to events ");
+	const double output_started = now_seconds();
 	write_output_files(run, max_mate_gap);
+	if (run.timing) {
+		const double finished = now_seconds();
+		run.timing->filter_mismappers = mismappers_seconds; run.timing->stages = output_started - stages_started - mismappers_seconds;
+		run.timing->output = finished - output_started; run.timing->total = finished - sample_started;
+	}
 }
 
 }
@@ -373,9 +441,47 @@ const char* arriba_workflow_last_error(void) { return g_error.c_str(); }
 int arriba_workflow_run(const arriba_workflow_options* options, arriba_workflow_report* report) {
 	if (!options) { g_error = "ERROR: null options"; return -1; }
 	if (report) report->n_stages = 0;
-	try { Run run(*options, report); run_workflow(run); return 0; }
+	try {
+		if (!options->assembly_file || !options->gene_annotation_file || !options->chimeric_bam_file || !options->output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
+		Run run(*options);
+		run.report = report;
+		open_session(run);
+		run_sample(run);
+		return 0;
+	}
 	catch (const Failure& failure) { g_error = failure.text; return -1; }
 	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); return -1; }
 }
+
+struct arriba_workflow_session { Run run; arriba_workflow_session(const arriba_workflow_options& o): run(o) {} };
+
+arriba_workflow_session* arriba_workflow_open(const arriba_workflow_options* options) {
+	if (!options) { g_error = "ERROR: null options"; return nullptr; }
+	arriba_workflow_session* session = nullptr;
+	try { session = new arriba_workflow_session(*options); open_session(session->run); return session; }
+	catch (const Failure& failure) { g_error = failure.text; }
+	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); }
+	delete session;
+	return nullptr;
+}
+
+int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeric_bam_file, const char* output_file, const char* discarded_output_file, arriba_workflow_report* report, arriba_workflow_timing* timing) {
+	if (!session || !chimeric_bam_file || !output_file) { g_error = "ERROR: assembly, gene annotation, alignments and output file are required"; return -1; }
+	if (report) report->n_stages = 0;
+	Run& run = session->run;
+	const std::string bam = chimeric_bam_file, output = output_file, discarded = discarded_output_file ? discarded_output_file : "";
+	run.options.chimeric_bam_file = bam.c_str(); run.options.output_file = output.c_str(); run.options.discarded_output_file = discarded_output_file ? discarded.c_str() : nullptr;
+	run.report = report; run.timing = timing;
+	int status = 0;
+	try { run_sample(run); }
+	catch (const Failure& failure) { g_error = failure.text; status = -1; }
+	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); status = -1; }
+	run.options.chimeric_bam_file = nullptr; run.options.output_file = nullptr; run.options.discarded_output_file = nullptr; run.report = nullptr; run.timing = nullptr;
+	return status;
+}
+
+agpu_ctx* arriba_workflow_device(arriba_workflow_session* session) { return session ? session->run.device : nullptr; }
+ahost_session* arriba_workflow_host(arriba_workflow_session* session) { return session ? session->run.host : nullptr; }
+void arriba_workflow_close(arriba_workflow_session* session) { delete session; }
 
 }

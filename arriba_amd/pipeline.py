@@ -125,6 +125,68 @@ class HostSession(object):
         return {"estimated": bool(estimated), "mate_gap_mean": mean.value, "mate_gap_stddev": stddev.value, "read_length_mean": read_length.value, "max_mate_gap": max_mate_gap.value}
 
 
+class WorkflowSession(object):
+    """The product path as a resident service: arriba_workflow_open once (assembly, annotation, device context), arriba_workflow_sample per BAM file -- the reference's
+    main() in C++ over the two C ABIs (arriba_amd/csrc/workflow/workflow.cpp; reference: source/arriba.cpp:84-615), no Python between the stages.  bench.py times
+    `sample`; `device` is a DevicePipeline view of the session's device context for the kernel profile and the post-conditions."""
+
+    def __init__(self, fasta, gtf, params=None, device=0, api=None, **options):
+        self._lib = _capi.workflow_library()
+        self.options = _capi.WorkflowOptions()
+        self._lib.arriba_workflow_default_options(byref(self.options))
+        self.options.assembly_file, self.options.gene_annotation_file = fasta.encode(), gtf.encode()
+        self.options.device_index = device
+        for key, value in (params or {}).items():
+            if key == "disable_filters":
+                for name in value:
+                    self.options.device.filter_enabled[_capi.FILTER_NAMES.index(name)] = 0
+            else:
+                setattr(self.options.device, key, value)
+        for key, value in options.items():
+            setattr(self.options, key, value.encode() if isinstance(value, str) else value)
+        self._session = self._lib.arriba_workflow_open(byref(self.options))
+        if not self._session:
+            raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        self.api = api if api is not None else _capi.bind_device_api(_capi.device_library(), "agpu_")
+        self.ctx = self._lib.arriba_workflow_device(self._session)
+        self.timing, self.report, self.n, self.n_candidates, self.records = {}, [], 0, 0, -1
+        self.timings, self._profiling_on, self.ingest_result = {}, False, None  # (what bench.py reads from a DevicePipeline)
+
+    def sample(self, bam, output_file, discarded_output_file=None):
+        """one sample, BAM file -> fusions.tsv (and discarded.tsv); returns the stages with their "(remaining=N)" counts"""
+        report, timing = _capi.WorkflowReport(), _capi.WorkflowTiming()
+        if self._lib.arriba_workflow_sample(self._session, bam.encode(), output_file.encode(), discarded_output_file.encode() if discarded_output_file else None, byref(report), byref(timing)) != 0:
+            raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        self.timing = {name: getattr(timing, name) for name, _ in _capi.WorkflowTiming._fields_}
+        self.report = [(report.stages[k].stage.decode(), int(report.stages[k].count)) for k in range(report.n_stages)]
+        return self.report
+
+    def set_profiling(self, enabled):
+        self._check(self.api.set_profiling(self.ctx, int(enabled)))
+        self._profiling_on = bool(enabled)
+
+    def kernel_profile(self):
+        return DevicePipeline.kernel_profile(self)
+
+    def gene_sets(self, slot):
+        return DevicePipeline.gene_sets(self, slot)
+
+    def _check(self, status):
+        if status != 0:
+            raise ArribaError("ERROR: " + self.api.last_error().decode() + " (status %d)" % status)
+
+    def close(self):
+        if self._session:
+            self._lib.arriba_workflow_close(self._session)
+            self._session = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DevicePipeline(object):
     """The device stages of the hot path in the reference's order.
 
@@ -477,6 +539,27 @@ class DevicePipeline(object):
             table[key] = table[key][:n]
         table["read_lists"] = reads[:total.value]
         return table
+
+    def selected_candidates(self, discarded=False):
+        """the candidates an output file holds (-o: filter == none, -O: the others), picked on the device with the columns the writer prints (agpu_select_candidates)"""
+        count = c_uint64()
+        self._check(self.api.select_candidates(self.ctx, int(discarded), byref(count)))
+        n = count.value
+        dtypes = {"candidate": np.uint32, "gene1": np.uint32, "gene2": np.uint32, "contigs": np.uint32, "breakpoint1": np.int32, "breakpoint2": np.int32, "flags": np.uint32, "filter": np.uint8, "split_reads1": np.uint32,
+                  "split_reads2": np.uint32, "discordant_mates": np.uint32, "evalue": np.float32, "confidence": np.uint8, "iteration_rank": np.uint32, "closest_genomic_breakpoint1": np.int32, "closest_genomic_breakpoint2": np.int32}
+        columns = {key: np.zeros(max(n, 1), dtype=dtype) for key, dtype in dtypes.items()}
+        view = _capi.SelectedCandidates()
+        for key, column in columns.items():
+            setattr(view, key, column.ctypes.data)
+        self._check(self.api.get_selected_candidates(self.ctx, byref(view)))
+        return {key: column[:n] for key, column in columns.items()}
+
+    def filters_of(self, fragments):
+        """the filters of the given fragments (agpu_get_filters_of)"""
+        fragments = np.ascontiguousarray(fragments, dtype=np.uint32)
+        out = np.zeros(max(fragments.size, 1), dtype=np.uint8)
+        self._check(self.api.get_filters_of(self.ctx, fragments.ctypes.data if fragments.size else None, fragments.size, out.ctypes.data))
+        return out[:fragments.size]
 
     def candidate_read_lists_of(self, candidates):
         """(list_offset[3n+1] starting at 0, reads) of the given candidates only"""

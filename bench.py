@@ -169,6 +169,7 @@ def main():
     parser.add_argument("--stress", action="store_true", help="BASELINE.json config 3: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (filter_mismappers sees every read)")
     parser.add_argument("--discarded", action="store_true", help="also write discarded.tsv (-O) inside the step")
     parser.add_argument("--host-ingest", action="store_true", help="read_chimeric_alignments by the multi-threaded host ingest instead of on the device (round 1's path)")
+    parser.add_argument("--python-stages", action="store_true", help="time the ctypes mirror of the stage order (arriba_amd/pipeline.py) instead of arriba_workflow_sample of the product library")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--host-only", action="store_true")
     parser.add_argument("--keep", help="keep the sample and the output files in this directory")
@@ -198,7 +199,7 @@ def main():
     if distributed:
         dist.barrier()
     import numpy as np
-    from arriba_amd.pipeline import DevicePipeline, HostSession
+    from arriba_amd.pipeline import DevicePipeline, HostSession, WorkflowSession
     # --gpus N: BASELINE.json config 4 -- ONE sample over the N GPUs (arriba_amd/one_sample.py: every rank ingests its part of the file, one all-gather, the
     # re-alignments of filter_mismappers shared out, rank 0 writes the files); the same total work for every N = strong scaling
     one_sample = distributed and not args.per_rank_samples and not args.host_ingest
@@ -224,7 +225,7 @@ def main():
             # the large sample runs in a child with a time limit: if it does not come back with a line (a time-out, an error), the line of config 2 is printed instead,
             # with the reason -- a bench without a line is worth nothing
             command = [sys.executable, os.path.abspath(__file__), "--fragments", str(args.fragments), "--steps", str(args.steps), "--warmup", str(args.warmup)]
-            command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--no-cpu-baseline", args.no_cpu_baseline)) if on]
+            command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--python-stages", args.python_stages), ("--no-cpu-baseline", args.no_cpu_baseline)) if on]
             # the driver gives a bench run 1800 s; the large sample gets what is left of ~1500 s after a reserve for the line of config 2 (generation, 25 steps of ~1 s, the
             # reference on its bounded sample: ~150 s), and its child decides after every step whether the steps asked for still fit (ARRIBA_BENCH_DEADLINE)
             total_limit = float(os.environ.get("ARRIBA_BENCH_TOTAL_LIMIT", "1500"))
@@ -267,17 +268,38 @@ def main():
             prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, ((os.cpu_count() or 2) - 2) // world)))
         bam_bytes = os.path.getsize(prefix + ".bam")
         progress("sample generated: %d fragments, %.1f GB BAM in %.1f s (%s)" % (args.fragments, bam_bytes / 1e9, generate_seconds, directory))
-        session = HostSession(prefix + ".fa", prefix + ".gtf")  # assembly + annotation, once (resident)
-        progress("assembly and annotation loaded")
         params = {"subsampling_threshold": 32767} if args.stress else None
         pipeline = None
         outputs = [os.path.join(directory, "fusions.rank%d.tsv" % rank), os.path.join(directory, "discarded.rank%d.tsv" % rank) if args.discarded else None]
         stage_log, step_seconds, ingest_parts, steps_done, all_steps = [], [], [], [0], []
+        # One GPU per sample: the step is arriba_workflow_sample of the product library (libarriba_workflow.so: the reference's main() in C++ over the two C ABIs, resident session);
+        # --python-stages times the ctypes mirror of the same stage order instead (arriba_amd/pipeline.py, what rounds 1-2 timed), as do --host-ingest and one sample over N GPUs
+        through_workflow_library = not one_sample and not args.host_ingest and not args.python_stages
+        if through_workflow_library:
+            pipeline = WorkflowSession(prefix + ".fa", prefix + ".gtf", params=params, device=local_rank)
+            session = None
+        else:
+            session = HostSession(prefix + ".fa", prefix + ".gtf")  # assembly + annotation, once (resident)
+        progress("assembly and annotation loaded")
 
         def step():
             nonlocal pipeline
             started = time.perf_counter()
             del stage_log[:]
+            if through_workflow_library:
+                report = pipeline.sample(prefix + ".bam", outputs[0], outputs[1])
+                finished = time.perf_counter()
+                timing = pipeline.timing
+                counts = dict(report)
+                pipeline.n, pipeline.n_candidates, pipeline.records = counts.get("read_chimeric_alignments", 0), counts.get("find_fusions", 0), counts.get("bam_records", -1)
+                pipeline.writer_seconds = {key: round(timing[key], 4) for key in ("output_results", "output_rows", "output_format")}
+                stage_log.extend((stage, count, None) for stage, count in report)
+                ingest_parts.append({"feed": timing["feed"], "device": timing["ingest"], "adopt": timing["adopt"]})
+                ingested = started + timing["feed"] + timing["ingest"] + timing["adopt"]
+                step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started, "stages": timing["stages"], "filter_mismappers": timing["filter_mismappers"], "output": timing["output"]})
+                if verbose:
+                    progress("arriba_workflow_sample: %s" % {key: round(value, 3) for key, value in timing.items()})
+                return after_step(started, finished, ingested)
             if args.host_ingest:
                 session.read_chimeric_alignments(prefix + ".bam")
                 if pipeline is not None:
@@ -306,6 +328,9 @@ def main():
             pipeline.run_workflow(outputs[0], outputs[1], log=note)
             finished = time.perf_counter()
             step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started})
+            return after_step(started, finished, ingested)
+
+        def after_step(started, finished, ingested):
             steps_done[0] += 1
             remaining = args.warmup + args.steps - steps_done[0]
             deadline = os.environ.get("ARRIBA_BENCH_DEADLINE")
@@ -321,8 +346,9 @@ def main():
                                                        "output_side_seconds": getattr(pipeline, "writer_seconds", None)}}))
                     sys.stdout.flush()
                     raise SystemExit(3)  # (through the `finally` below: the 54 GB sample must not stay behind)
-            progress("step done: read_chimeric_alignments %.2f s %s, workflow %.2f s; slowest stages: %s; output side: %s" % (ingested - started, ingest_parts[-1], finished - ingested,
-                     sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4], getattr(pipeline, "writer_seconds", None)))
+            progress("step done: %.2f s; read_chimeric_alignments %.2f s %s, workflow %.2f s; %s; output side: %s" % (finished - started, ingested - started, {k: round(v, 3) for k, v in ingest_parts[-1].items()}, finished - ingested,
+                     ("stages %.2f s, filter_mismappers %.2f s" % (step_seconds[-1]["stages"], step_seconds[-1]["filter_mismappers"])) if through_workflow_library else
+                     "slowest stages: %s" % sorted(((round(v["ms"]), k) for k, v in pipeline.timings.items()), reverse=True)[:4], getattr(pipeline, "writer_seconds", None)))
 
         profiling = [False]
         verbose = args.fragments >= 30000000 or bool(os.environ.get("ARRIBA_BENCH_VERBOSE"))  # large samples: every stage reports on stderr, so that a run cut off by a time limit says where it was
@@ -408,17 +434,19 @@ def main():
                 "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong" if one_sample else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                 "config": {"workload": "synthetic %d chimeric fragments " % args.fragments + ("in one sample" if one_sample else "per GPU") + " (%d BAM records, %.1f GB uncompressed BGZF; 2x100 bp, 24-contig synthetic genome, GENCODE-like GTF)%s, default filters, BAM file in memory -> fusions.tsv%s"
-                                       % (pipeline.ingest_result.records if pipeline.ingest_result else -1, bam_bytes / 1e9, ", mismapper stress (clips of 40-70 nt copied from the partner gene, -U 32767)" if args.stress else "",
+                                       % (pipeline.records if through_workflow_library else pipeline.ingest_result.records if pipeline.ingest_result else -1, bam_bytes / 1e9, ", mismapper stress (clips of 40-70 nt copied from the partner gene, -U 32767)" if args.stress else "",
                                           " + discarded.tsv" if args.discarded else ""),
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
+                           "timed_call": "arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
                            "parallelism": ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
                                            % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0))) if one_sample
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
                            "outside_the_step": "loading assembly + annotation (ahost_open), device context; generating the sample took %.1f s" % generate_seconds,
                            "names_were_sorted": bool(pipeline.ingest_result.names_were_sorted) if pipeline.ingest_result else None,
                            "why_not_the_100M_sample": fallback_reason, "large_sample": large_sample_record},
-                "seconds_per_step": {"read_chimeric_alignments": round(mean("ingest"), 4), "workflow_to_output_files": round(mean("workflow"), 4), "total": round(mean("total"), 4)},
+                "seconds_per_step": dict({"read_chimeric_alignments": round(mean("ingest"), 4), "workflow_to_output_files": round(mean("workflow"), 4), "total": round(mean("total"), 4)},
+                                         **({key: round(mean(key), 4) for key in ("stages", "filter_mismappers", "output")} if through_workflow_library else {})),
                 "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
                 "output_side_seconds": getattr(pipeline, "writer_seconds", None),
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,

@@ -304,6 +304,20 @@ int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capac
 /* the read lists of the given candidates only, packed: list_offset[3*n+1] starts at 0 (the output writer wants those of the candidates it prints -- a few
  * thousand of millions); call with reads == NULL to get *total and list_offset first */
 int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint32_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total);
+/* The candidates one output file holds, picked on the device: write_fusions_to_file (source/output_fusions.cpp:1083-1089) writes the candidates with filter == FILTER_none
+ * to -o (discarded = 0) and the others to -O (1) -- a few thousand of millions for -o, so only their columns travel.  agpu_select_candidates says how many there are,
+ * agpu_get_selected_candidates fills arrays of that many entries (candidate = index in the table, ascending; NULL pointers are skipped).  evalue, confidence,
+ * iteration_rank and the closest genomic breakpoints are those of agpu_get_evalues, agpu_assign_confidence (which must have run behind the last stage that changed a
+ * filter), agpu_candidate_iteration_order and agpu_get_genomic_support. */
+typedef struct {
+	uint32_t* candidate;
+	uint32_t* gene1; uint32_t* gene2; uint32_t* contigs; int32_t* breakpoint1; int32_t* breakpoint2; uint32_t* flags; uint8_t* filter;
+	uint32_t* split_reads1; uint32_t* split_reads2; uint32_t* discordant_mates;
+	float* evalue; uint8_t* confidence; uint32_t* iteration_rank;
+	int32_t* closest_genomic_breakpoint1; int32_t* closest_genomic_breakpoint2;
+} agpu_selected_candidates;
+int agpu_select_candidates(agpu_ctx* ctx, int discarded, uint64_t* n);
+int agpu_get_selected_candidates(agpu_ctx* ctx, const agpu_selected_candidates* out);
 /* sizes of the last agpu_find_fusions: stats[0] gene-pair emissions, [1] candidates, [2] read-list entries, [3] discordant emissions,
  * [4] candidates whose discordant bucket was scanned by a whole wavefront */
 int agpu_get_fusion_stats(agpu_ctx* ctx, uint64_t* stats /* [5] */);
@@ -485,6 +499,8 @@ int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, const uint32_t*
 
 /* result access (device -> host copies) */
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);
+/* ... of the given fragments only (the writer looks at the filters of the supporting reads of the candidates it writes) */
+int agpu_get_filters_of(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint8_t* filter /* [n] */);
 int agpu_get_alignment_bits(agpu_ctx* ctx, int slot, uint8_t* abits /* [n] */);
 int agpu_get_fragment_bits(agpu_ctx* ctx, uint8_t* fbits /* [n] */);
 /* gene sets as CSR: count[n] then the concatenated ids; call with genes == NULL to get the total in *total */

@@ -78,6 +78,7 @@ typedef struct {
 	const uint8_t* read_filter;    /* [fragments of the session's batch] */
 	const int32_t* closest_genomic_breakpoint1; const int32_t* closest_genomic_breakpoint2; /* agpu_get_genomic_support; NULL = no structural variants given */
 	uint32_t n_genes; const uint16_t* gene_contig; const int32_t* gene_start; const int32_t* gene_end;
+	const uint8_t* read_filter_of_rows; /* instead of read_filter (then NULL): the filters of the fragments handed over with ahost_set_batch_rows, in the order of the rows (agpu_get_filters_of) */
 } ahost_fusion_table;
 int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap,
                         int fill_sequence_gaps /* -I: complete the fusion transcript from the assembly along the chosen transcripts */);

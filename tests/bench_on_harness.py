@@ -18,6 +18,7 @@ torch.cuda.set_device = lambda device: None
 torch.cuda.synchronize = lambda *args, **kwargs: None
 torch.cuda.get_device_properties = lambda device: types.SimpleNamespace(total_memory=288 << 30)
 os.environ["ARRIBA_BENCH_BACKEND"] = "gloo"
+os.environ["ARRIBA_WORKFLOW_LIBRARY"] = os.path.join(ROOT, "tests", "emu", "libworkflow_on_harness.so")  # arriba_workflow_sample over the harness
 
 from arriba_amd import _capi  # noqa: E402
 
@@ -25,6 +26,8 @@ _bind = _capi.bind_device_api
 _harness = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libemu.so"))
 _capi.bind_device_api = lambda library, prefix: _bind(_harness, "emu_")
 
+import subprocess  # noqa: E402
+subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libworkflow_on_harness.so"], check=True)
 import bench  # noqa: E402
 
 if __name__ == "__main__":

@@ -382,6 +382,10 @@ int emu_read_filters_stage2(emu_ctx* ctx, uint64_t* remaining) {
 }
 
 int emu_get_filters(emu_ctx* ctx, uint8_t* filter) { memcpy(filter, ctx->filter.data(), ctx->n); return 0; }
+int emu_get_filters_of(emu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint8_t* filter) {
+	for (uint64_t k = 0; k < n; ++k) { if (fragments[k] >= ctx->n) { g_error = "fragment index out of range"; return AGPU_ERR_INVALID; } filter[k] = ctx->filter[fragments[k]]; }
+	return 0;
+}
 int emu_get_alignment_bits(emu_ctx* ctx, int slot, uint8_t* abits) { memcpy(abits, ctx->abits[slot].data(), ctx->n); return 0; }
 int emu_get_fragment_bits(emu_ctx* ctx, uint8_t* fbits) { memcpy(fbits, ctx->fbits.data(), ctx->n); return 0; }
 int emu_get_gene_sets(emu_ctx* ctx, int slot, uint8_t* count, uint32_t* genes, uint64_t capacity, uint64_t* total) {

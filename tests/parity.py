@@ -654,7 +654,24 @@ def check_workflow(prefix, golden, directory, api=None, rules=False, reference_p
         source = reference_prefix + "." + name if reference_prefix else os.path.join(golden, name)
         expected = open(source).read() if os.path.exists(source) else gzip.open(source + ".gz", "rt").read()
         assert open(mine).read() == expected, name
+    check_selected_candidates(pipeline)
     return stages
+
+
+def check_selected_candidates(pipeline):
+    """agpu_select_candidates / agpu_get_selected_candidates / agpu_get_filters_of (what the C++ workflow driver writes its files from) against the whole columns picked on the host"""
+    table = pipeline.candidates(lists=False)
+    whole = dict(table, evalue=pipeline.evalues(), confidence=pipeline.assign_confidence(), iteration_rank=pipeline.candidate_iteration_order())
+    whole["closest_genomic_breakpoint1"], whole["closest_genomic_breakpoint2"] = pipeline.genomic_support()
+    for discarded in (False, True):
+        picked = pipeline.selected_candidates(discarded)
+        expected = np.flatnonzero((table["filter"] != 0) if discarded else (table["filter"] == 0))
+        assert np.array_equal(picked["candidate"], expected), discarded
+        for key, column in picked.items():
+            if key != "candidate":
+                assert np.array_equal(column.view(np.uint32) if column.dtype == np.float32 else column, whole[key][expected].view(np.uint32) if column.dtype == np.float32 else whole[key][expected]), (key, discarded)
+    some = np.unique(np.concatenate([np.arange(0, pipeline.n, max(1, pipeline.n // 997)), np.array([pipeline.n - 1])])).astype(np.uint32) if pipeline.n else np.zeros(0, np.uint32)
+    assert np.array_equal(pipeline.filters_of(some), pipeline.filters()[some])
 
 NON_DEFAULT_OPTIONS = {
     "reference": ["-E", "0.1", "-S", "3", "-A", "30", "-M", "2", "-L", "0.5", "-Z", "5", "-z", "0.03", "-e", "0.5", "-R", "5000", "-H", "5", "-V", "0.05", "-K", "0.5", "-m", "0.5", "-Q", "0.99", "-U", "100",

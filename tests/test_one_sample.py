@@ -59,6 +59,24 @@ def test_bench_with_two_ranks_prints_one_line(flags, built, emu_api, tmp_path):
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
+@pytest.mark.parametrize("flags", [[], ["--python-stages"]])
+def test_bench_with_one_rank_times_the_workflow_library(flags, built, emu_api, tmp_path):
+    """bench.py as the driver runs it at N = 1: the timed call is arriba_workflow_sample of the product library (here its build over the stepping harness,
+    tests/emu/libworkflow_on_harness.so), with --python-stages the ctypes mirror of the stage order; both end with the same counts and one line of the contract."""
+    command = [sys.executable, os.path.join(ROOT, "tests", "bench_on_harness.py"), "--steps", "2", "--warmup", "1", "--fragments", "20000", "--no-cpu-baseline"] + flags
+    result = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=1500)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, result.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+    assert ("arriba_workflow_sample" in line["config"]["timed_call"]) == (not flags)
+    assert line["config"]["fragments_per_gpu"] == 20886 and line["config"]["candidates"] == 10278 and line["config"]["fusions"] == 343  # (the same sample through both)
+    assert [stage for stage, _, _ in line["stages"]][-1] == "recover_isoforms"
+
+
 def test_an_error_on_one_rank_ends_the_run_on_all(dataset_files, emu_api, tmp_path):
     """A damaged BGZF block in the last third of the file: the rank that reads it fails with the reference's message, the others are told before they enter the
     all-gather of the parts -- nobody is left waiting in a collective."""
