@@ -141,6 +141,8 @@ def bind_device_api(lib, prefix="agpu_"):
         "get_candidate_read_lists": (c_int, [ctx, c_void_p, c_uint64, POINTER(c_uint64)]),
         "get_candidate_read_lists_of": (c_int, [ctx, c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
         "get_discordant_swapped": (c_int, [ctx, c_void_p]),
+        "shard_merge_rccl": (c_int, [ctx, c_void_p, c_uint32, POINTER(IngestResult)]),
+        "filter_mismappers_rccl": (c_int, [ctx, c_void_p, c_int32, c_uint32, c_uint32, POINTER(c_uint64), POINTER(c_uint64)]),
         "get_filters": (c_int, [ctx, c_void_p]),
         "get_filters_of": (c_int, [ctx, c_void_p, c_uint64, c_void_p]),
         "select_candidates": (c_int, [ctx, c_int, POINTER(c_uint64)]),

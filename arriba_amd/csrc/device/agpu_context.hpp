@@ -30,11 +30,7 @@ struct DeviceBuffer {
 		if (n == 0) n = 16;
 		if (ptr != nullptr && n <= capacity) { bytes = n; return true; }
 		release();
-		pooled = use_pool();
-		if (pooled) { // stream-ordered allocation on the null stream, made visible to every stream by the synchronisation behind it
-			if (hipMallocAsync(&ptr, n, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void) hipGetLastError(); ptr = nullptr; pooled = false; }
-		}
-		if (!pooled && hipMalloc(&ptr, n) != hipSuccess) {
+		if (hipMalloc(&ptr, n) != hipSuccess) {
 			// out of memory: the contexts give back what they only keep for the next sample (the stream and the tables of the last ingest while the stages run, the
 			// buffers of the stages while an ingest runs), then once more
 			(void) hipGetLastError();
@@ -47,26 +43,10 @@ struct DeviceBuffer {
 	static bool release_idle_buffers(); // agpu_api.hip; true if anything was given back
 	void release() {
 		if (!ptr) return;
-		if (pooled) { (void) hipFreeAsync(ptr, nullptr); (void) hipStreamSynchronize(nullptr); } else (void) hipFree(ptr);
-		ptr = nullptr; bytes = 0; capacity = 0; pooled = false;
+		(void) hipFree(ptr);
+		ptr = nullptr; bytes = 0; capacity = 0;
 	}
-	// ARRIBA_DEVICE_POOL=1 (an experiment, off by default): the buffers come from the device's stream-ordered memory pool, whose release threshold is raised so that
-	// freed pages stay mapped -- at 10^8 fragments ~85 GB of ingest buffers are freed and ~70 GB of stage buffers allocated per sample, and unmapping / mapping them
-	// is the suspected 3-5 s between the kernels.  Every caller releases a buffer only behind a synchronisation of the stream that used it.
-	bool pooled = false;
-	static bool use_pool() {
-		static int state = -1;
-		if (state < 0) {
-			const char* knob = getenv("ARRIBA_DEVICE_POOL");
-			state = knob != nullptr && knob[0] == '1';
-			if (state) {
-				int device = 0; hipMemPool_t pool = nullptr; uint64_t keep = ~(uint64_t) 0;
-				if (hipGetDevice(&device) != hipSuccess || hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) { (void) hipGetLastError(); state = 0; }
-			}
-		}
-		return state == 1;
-	}
-	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); std::swap(pooled, other.pooled); }
+	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); }
 	template <class T> T* as() const { return (T*) ptr; }
 };
 

@@ -120,14 +120,30 @@ __global__ void genomic_support_filter_kernel(GenomeView genome, CandidateTable 
 }
 
 // filter_in_vitro: expression proxy, gene-pair table, verdicts
-__global__ void gene_read_count_kernel(BatchView b, uint32_t* gene_read_count) {
-	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i >= b.n) return;
-	AGPU_IDSET(genes);
-	load_genes(b, MATE1, i, genes);
-	for (uint32_t g = 0; g < genes.n; ++g) atomicAdd(&gene_read_count[genes.get(g)], 1u);
-	load_genes(b, in_vitro_second_slot(b, i), i, genes);
-	for (uint32_t g = 0; g < genes.n; ++g) atomicAdd(&gene_read_count[genes.get(g)], 1u);
+// Fragments per gene (reference: the loop over the alignments of filter_in_vitro, source/filter_in_vitro.cpp:91-104).  A few genes hold most of the fragments of a sample, and an
+// atomic per fragment on their counters serialises at the L2 (134 ms for 10^8 fragments); every workgroup counts in LDS instead -- a table of (gene, count) slots, a gene owns the
+// slot gene % slots once it has claimed it, the rare gene that finds its slot taken by another counts in HBM -- and adds its table to the counters of HBM at the end.
+const uint32_t GENE_COUNT_SLOTS = 8192;
+__device__ __forceinline__ void count_gene(uint32_t gene, uint32_t* slot_gene, uint32_t* slot_count, uint32_t* gene_read_count) {
+	const uint32_t slot = gene & (GENE_COUNT_SLOTS - 1);
+	uint32_t owner = slot_gene[slot];
+	if (owner == 0xFFFFFFFFu) { owner = atomicCAS(&slot_gene[slot], 0xFFFFFFFFu, gene); if (owner == 0xFFFFFFFFu) owner = gene; }
+	if (owner == gene) atomicAdd(&slot_count[slot], 1u); else atomicAdd(&gene_read_count[gene], 1u);
+}
+__global__ void __launch_bounds__(BLOCK) gene_read_count_kernel(BatchView b, uint32_t* gene_read_count) {
+	__shared__ uint32_t slot_gene[GENE_COUNT_SLOTS];
+	__shared__ uint32_t slot_count[GENE_COUNT_SLOTS];
+	for (uint32_t k = threadIdx.x; k < GENE_COUNT_SLOTS; k += BLOCK) { slot_gene[k] = 0xFFFFFFFFu; slot_count[k] = 0; }
+	__syncthreads();
+	for (uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; i < b.n; i += gridDim.x * (uint64_t) BLOCK) {
+		AGPU_IDSET(genes);
+		load_genes(b, MATE1, i, genes);
+		for (uint32_t g = 0; g < genes.n; ++g) count_gene(genes.get(g), slot_gene, slot_count, gene_read_count);
+		load_genes(b, in_vitro_second_slot(b, i), i, genes);
+		for (uint32_t g = 0; g < genes.n; ++g) count_gene(genes.get(g), slot_gene, slot_count, gene_read_count);
+	}
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < GENE_COUNT_SLOTS; k += BLOCK) if (slot_count[k] > 0) atomicAdd(&gene_read_count[slot_gene[k]], slot_count[k]);
 }
 __global__ void in_vitro_pair_key_kernel(CandidateTable t, uint64_t* keys) { // two keys per candidate: (gene1, gene2) and (gene2, gene1); ~0 = does not count
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
@@ -212,7 +228,7 @@ int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& th
 	if (ctx->gene_read_counts_of_annotation != ctx->annotation_serial || ctx->host_gene_read_counts.size() != n_genes) {
 		ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4);
 		HIP_CHECK(hipMemsetAsync(gene_read_count.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
-		if (n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", n * 22); gene_read_count_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, gene_read_count.as<uint32_t>()); }
+		if (n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", n * 22); gene_read_count_kernel<<<(unsigned int) std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 2048), BLOCK, 0, s>>>(ctx->batch, gene_read_count.as<uint32_t>()); }
 		ctx->host_gene_read_counts.assign(n_genes, 0);
 		if (n_genes > 0) HIP_CHECK(hipMemcpyAsync(ctx->host_gene_read_counts.data(), gene_read_count.ptr, n_genes * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
@@ -693,8 +709,8 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 		tables.high_expression_threshold = threshold;
 		tables.pair_keys = unique_keys.as<uint64_t>(); tables.pair_counts = unique_counts.as<uint32_t>(); tables.n_pairs = runs; // (the run of ~0 keys at the end is never looked up)
 		tables.clip_summaries = nullptr;
-		const char* summary_knob = getenv("ARRIBA_IN_VITRO_SUMMARY"); // "1": the clipped ends of the alignments summarised once (an experiment for the next round, off by default)
-		if (summary_knob != nullptr && summary_knob[0] == '1' && ctx->n > 0) {
+		if (ctx->n > 0) { // the clipped ends of the alignments, summarised once in 8 bytes each: the verdicts walk the read lists and would otherwise gather CIGAR ends, strand, contig and
+			// position of up to three alignments per list entry (10^8 fragments: in_vitro_kernel 219 -> 66 + 3 ms, profiles/r03h_output_side_and_ingest.txt)
 			DeviceBuffer& summaries = ctx->scratch("events.clip_summaries");
 			ALLOC(summaries, 3 * ctx->n * sizeof(ClipSummary));
 			{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20));

@@ -28,14 +28,10 @@ __global__ void homolog_collect_kernel(CandidateTable t, const uint32_t* iterati
 	r.split_reads1 = t.split_reads1[c]; r.split_reads2 = t.split_reads2[c]; r.discordant_mates = t.discordant_mates[c]; r.evalue = evalue[c];
 	out[at] = r;
 }
-__global__ void homolog_verdict_kernel(AnnotationView ann, GenomeView genome, KmerIndexView kmers, const uint64_t* pairs, uint32_t n_pairs, float max_identity_fraction, uint8_t* verdicts) {
-	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-	if (k < n_pairs) verdicts[k] = genes_are_homologs(ann, genome, kmers, (uint32_t) (pairs[k] >> 32), (uint32_t) pairs[k], max_identity_fraction);
-}
-// The same verdict by a wavefront per gene pair: the 64 lanes ask 64 positions of the smaller gene at once (the answers are independent of each other), then every
-// lane walks the 64 answers in position order with the reference's two early exits (homolog_walk: a few comparisons per position, no memory).  A pair of long genes
-// is 10^5 dependent look-ups for one thread -- the launch waits for the longest pair -- and 10^5 / 64 rounds here.  ARRIBA_HOMOLOG_WAVES=1 (an experiment for the
-// next round, off by default; the thread-per-pair kernel above is the measured one).
+// The verdict of a gene pair (genes_are_homologs, homolog_core.hpp) by a wavefront per pair: the 64 lanes ask 64 positions of the smaller gene at once (the answers are independent
+// of each other), then every lane walks the 64 answers in position order with the reference's two early exits (homolog_walk: a few comparisons per position, no memory).  A pair
+// of long genes is 10^5 dependent look-ups for one thread -- a launch of a thread per pair waits for the longest pair -- and 10^5 / 64 rounds here (10^7 fragments: 24.4 -> 2.5 ms,
+// 10^8: 52.5 -> 19.7 ms; profiles/r03h_output_side_and_ingest.txt).
 __global__ void __launch_bounds__(64) homolog_verdict_wave_kernel(AnnotationView ann, GenomeView genome, KmerIndexView kmers, const uint64_t* pairs, uint32_t n_pairs, float max_identity_fraction, uint8_t* verdicts) {
 	const uint32_t k = blockIdx.x;
 	if (k >= n_pairs) return;
@@ -94,13 +90,10 @@ extern "C" int agpu_filter_homologs(agpu_ctx* ctx, float max_identity_fraction, 
 		HIP_CHECK(hipMemcpyAsync(device_pairs.ptr, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, s));
 		KmerIndexView kmers;
 		kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
-		const char* wave_knob = getenv("ARRIBA_HOMOLOG_WAVES");
-		if (wave_knob != nullptr && wave_knob[0] == '1') {
+		if (!pairs.empty()) {
 			KernelTimer timer(ctx, "homolog_verdict_wave_kernel", pairs.size() * 64);
 			homolog_verdict_wave_kernel<<<(unsigned int) pairs.size(), 64, 0, s>>>(ctx->annotation, ctx->genome, kmers, device_pairs.as<uint64_t>(), (uint32_t) pairs.size(), max_identity_fraction, device_verdicts.as<uint8_t>());
-		} else
-		{ KernelTimer timer(ctx, "homolog_verdict_kernel", pairs.size() * 64);
-		  homolog_verdict_kernel<<<(unsigned int) ((pairs.size() + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->annotation, ctx->genome, kmers, device_pairs.as<uint64_t>(), (uint32_t) pairs.size(), max_identity_fraction, device_verdicts.as<uint8_t>()); }
+		}
 		std::vector<uint8_t> host_verdicts(pairs.size());
 		HIP_CHECK(hipMemcpyAsync(host_verdicts.data(), device_verdicts.ptr, pairs.size(), hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));

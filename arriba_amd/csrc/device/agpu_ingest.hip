@@ -130,16 +130,36 @@ __global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, Ge
 	block_tally(broken, &counters[IC_BROKEN], &sums[3]);
 }
 
-// position p of the sorted records starts a group if its key differs from the key before it; equal keys must be equal names
-__global__ void group_head_kernel(IngestStream in, const uint64_t* sorted_keys, const uint32_t* sorted_records, uint64_t n_active, uint8_t* head, uint32_t* counters) {
+// position p of the sorted records starts a group if its key differs from the key before it
+__global__ void group_head_kernel(const uint64_t* sorted_keys, uint64_t n_active, uint8_t* head) {
 	const uint64_t p = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (p >= n_active) return;
-	const bool is_head = p == 0 || sorted_keys[p] != sorted_keys[p - 1];
-	head[p] = is_head;
-	if (!is_head) {
-		const Rec a = load_record(in, sorted_records[p]), b = load_record(in, sorted_records[p - 1]);
-		const AuxTags tags_a = scan_aux(a.aux, a.end), tags_b = scan_aux(b.aux, b.end);
-		if (!same_name(a, tags_a.has_hi ? tags_a.hi : 1, b, tags_b.has_hi ? tags_b.hi : 1)) atomicOr(&counters[IC_COLLISION], 1u);
+	if (p < n_active) head[p] = p == 0 || sorted_keys[p] != sorted_keys[p - 1];
+}
+// The groups are found in the order of their keys (hashes of the names), which scatters them over the stream: a wavefront that replays 64 neighbouring groups of that
+// order touches 64 x 3 places of a 54 GB stream.  In the order of their FIRST RECORDS neighbouring groups are neighbours in the stream (STAR writes the alignments of a read
+// next to each other), so the loads of a wavefront fall into a few consecutive kilobytes.  The rank of a group in that order = the number of first records in front of its own:
+// a flag per record, a prefix sum over the records, one scatter.
+__global__ void group_first_flag_kernel(const uint32_t* sorted_records, const uint32_t* group_start, uint32_t n_groups, uint8_t* first_flags) {
+	const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g < n_groups) first_flags[sorted_records[group_start[g]]] = 1;
+}
+__global__ void group_rank_kernel(const uint32_t* sorted_records, const uint32_t* group_start, uint32_t n_groups, uint64_t n_active, const uint32_t* stream_rank, uint32_t* group_first, uint32_t* group_begin, uint32_t* group_count) {
+	const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g >= n_groups) return;
+	const uint32_t begin = group_start[g], first = sorted_records[begin], t = stream_rank[first];
+	group_first[t] = first; group_begin[t] = begin; group_count[t] = (uint32_t) ((g + 1 < n_groups ? (uint64_t) group_start[g + 1] : n_active) - begin);
+}
+// equal keys must be equal names: every record of a group against the first one (in the order of the stream)
+__global__ void group_names_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t n_groups, uint32_t* counters) {
+	const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+	if (t >= n_groups || group_count[t] < 2) return;
+	const uint32_t* records = sorted_records + group_begin[t];
+	const Rec a = load_record(in, records[0]);
+	const AuxTags tags_a = scan_aux(a.aux, a.end);
+	for (uint32_t k = 1; k < group_count[t]; ++k) {
+		const Rec b = load_record(in, records[k]);
+		const AuxTags tags_b = scan_aux(b.aux, b.end);
+		if (!same_name(a, tags_a.has_hi ? tags_a.hi : 1, b, tags_b.has_hi ? tags_b.hi : 1)) { atomicOr(&counters[IC_COLLISION], 1u); return; }
 	}
 }
 
@@ -148,14 +168,14 @@ struct ViralCounter {
 	__device__ void operator()(uint32_t contig) { atomicAdd(&counts[contig], 1ull); }
 };
 
-__global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_start, uint32_t n_groups, uint64_t n_active,
+__global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t n_groups,
                                                              FragmentPlan* plain, TandemPlan* itd, uint8_t* valid, FragmentSizes* sizes, unsigned long long* viral_counts, uint32_t* counters) {
 	__shared__ uint32_t sums[2];
 	GroupTally tally; tally.malformed = 0; tally.chimeric = 0;
-	const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t g = blockIdx.x * BLOCK + threadIdx.x; // (groups numbered in the order of their first records)
 	if (g < n_groups) {
-		const uint32_t begin = group_start[g];
-		const uint32_t n_records = (uint32_t) ((g + 1 < n_groups ? (uint64_t) group_start[g + 1] : n_active) - begin);
+		const uint32_t begin = group_begin[g];
+		const uint32_t n_records = group_count[g];
 		FragmentPlan plain_plan; TandemPlan itd_plan;
 		ViralCounter viral = { viral_counts };
 		replay_group(ctx, sorted_records + begin, n_records, plain_plan, itd_plan, tally, viral);
@@ -183,30 +203,24 @@ __global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, 
 
 // ---- name order -----------------------------------------------------------------------------------------------------------------------------------
 
-// fragment reference = 2 * group + (1 for the "ITD" entry); key of its first occurrence = index of the group's first record, the ITD entry behind the plain one
-__global__ void occurrence_key_kernel(const uint32_t* refs, uint64_t n, const uint32_t* sorted_records, const uint32_t* group_start, uint64_t* keys) {
-	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t ref = refs[i];
-	keys[i] = (uint64_t) sorted_records[group_start[ref >> 1]] << 1 | (ref & 1);
-}
-
-__device__ FragmentName name_of(const IngestStream& in, const uint32_t* sorted_records, const uint32_t* group_start, uint32_t ref, Rec& storage) {
-	storage = load_record(in, sorted_records[group_start[ref >> 1]]);
+// fragment reference = 2 * group + (1 for the "ITD" entry); the groups are numbered by their first records, so ascending references are the fragments in the order of
+// their first occurrence, the ITD entry behind the plain one
+__device__ FragmentName name_of(const IngestStream& in, const uint32_t* group_first, uint32_t ref, Rec& storage) {
+	storage = load_record(in, group_first[ref >> 1]);
 	return fragment_name(storage, ref & 1);
 }
 
-__global__ void name_order_check_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, uint32_t* counters) {
+__global__ void name_order_check_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, uint32_t* counters) {
 	__shared__ uint32_t block_max;
 	if (threadIdx.x == 0) block_max = 0;
 	__syncthreads();
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i < n) {
 		Rec storage_a, storage_b;
-		const FragmentName mine = name_of(in, sorted_records, group_start, order[i], storage_a);
+		const FragmentName mine = name_of(in, group_first, order[i], storage_a);
 		atomicMax(&block_max, name_length(mine));
 		if (i > 0) {
-			const FragmentName before = name_of(in, sorted_records, group_start, order[i - 1], storage_b);
+			const FragmentName before = name_of(in, group_first, order[i - 1], storage_b);
 			if (compare_names(before, mine) >= 0) atomicOr(&counters[IC_UNSORTED], 1u);
 		}
 	}
@@ -214,16 +228,16 @@ __global__ void name_order_check_kernel(IngestStream in, const uint32_t* sorted_
 	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_NAME], block_max);
 }
 
-__global__ void name_chunk_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
+__global__ void name_chunk_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i >= n) return;
 	Rec storage;
-	keys[i] = name_chunk(name_of(in, sorted_records, group_start, order[i], storage), chunk);
+	keys[i] = name_chunk(name_of(in, group_first, order[i], storage), chunk);
 }
 
 // ---- layout and pack ------------------------------------------------------------------------------------------------------------------------------
 
-__global__ void fragment_layout_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, const FragmentSizes* sizes,
+__global__ void fragment_layout_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, const FragmentSizes* sizes,
                                        uint32_t* cigar_words, uint32_t* sequence_bytes, uint32_t* name_lengths, uint32_t* new_group) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i > n) return;
@@ -234,7 +248,7 @@ __global__ void fragment_layout_kernel(IngestStream in, const uint32_t* sorted_r
 	// multi-mapper groups: identical names up to the last ',' (source/common.hpp:222), i.e. identical QNAMEs
 	uint32_t differs = 0;
 	if (i > 0) {
-		const Rec a = load_record(in, sorted_records[group_start[ref >> 1]]), b = load_record(in, sorted_records[group_start[order[i - 1] >> 1]]);
+		const Rec a = load_record(in, group_first[ref >> 1]), b = load_record(in, group_first[order[i - 1] >> 1]);
 		const uint32_t length = qname_length(a);
 		differs = length != qname_length(b);
 		for (uint32_t k = 0; k < length && !differs; ++k) differs = a.name[k] != b.name[k];
@@ -242,7 +256,7 @@ __global__ void fragment_layout_kernel(IngestStream in, const uint32_t* sorted_r
 	new_group[i] = differs;
 }
 
-__global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_start, const uint32_t* order, uint64_t n, const FragmentPlan* plain, const TandemPlan* itd,
+__global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, const FragmentPlan* plain, const TandemPlan* itd,
                                                               const uint64_t* cigar_base, const uint64_t* sequence_base, const uint64_t* name_base, const uint32_t* group_id, PackTarget out, uint32_t* counters) {
 	__shared__ uint32_t block_max;
 	if (threadIdx.x == 0) block_max = 0;
@@ -255,7 +269,7 @@ __global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, c
 		Fragment3 f;
 		normalize_plan(in, is_itd ? itd[g].plan : plain[g], is_itd ? &itd[g].tandem : nullptr, f);
 		Rec storage;
-		const FragmentName name = name_of(in, sorted_records, group_start, ref, storage);
+		const FragmentName name = name_of(in, group_first, ref, storage);
 		atomicMax(&block_max, write_fragment(in, f, name, i, cigar_base[i], sequence_base[i], name_base[i], group_id[i], out));
 	}
 	__syncthreads();
@@ -454,7 +468,7 @@ bool agpu::release_ingest_buffers(agpu_ctx* ctx) {
 	bool released = ctx->ingest_stream.ptr != nullptr;
 	ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release();
 	if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
-	static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.plain_plans", "ingest.itd_plans",
+	static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.first_flags", "ingest.stream_rank", "ingest.group_first", "ingest.group_begin", "ingest.group_count", "ingest.plain_plans", "ingest.itd_plans",
 		"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
 		"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
 	for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) { DeviceBuffer& buffer = ctx->scratch(temporary[k]); if (buffer.ptr != nullptr) released = true; buffer.release(); }
@@ -621,6 +635,8 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	// 2. per record: status and name key; 3. records of one name adjacent
 	DeviceBuffer& keys = ctx->scratch("ingest.keys"); DeviceBuffer& keys_sorted = ctx->scratch("ingest.keys_sorted"); DeviceBuffer& record_bits = ctx->scratch("ingest.record_bits");
 	DeviceBuffer& sorted_records = ctx->scratch("ingest.sorted_records"); DeviceBuffer& head = ctx->scratch("ingest.head"); DeviceBuffer& group_start = ctx->scratch("ingest.group_start");
+	DeviceBuffer& first_flags = ctx->scratch("ingest.first_flags"); DeviceBuffer& stream_rank = ctx->scratch("ingest.stream_rank");
+	DeviceBuffer& group_first = ctx->scratch("ingest.group_first"); DeviceBuffer& group_begin = ctx->scratch("ingest.group_begin"); DeviceBuffer& group_count = ctx->scratch("ingest.group_count");
 	const uint64_t records1 = std::max<uint64_t>(n_records, 1);
 	ALLOC(keys, records1 * 8); ALLOC(keys_sorted, records1 * 8); ALLOC(record_bits, records1); ALLOC(sorted_records, records1 * 4);
 	uint64_t n_active = 0, seed = 0;
@@ -638,12 +654,26 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 		n_groups = 0;
 		if (n_active > 0) {
 			ALLOC(head, n_active); ALLOC(group_start, (n_active + 1) * 4);
-			{ KernelTimer timer(ctx, "group_head_kernel", n_active * (8 + 4 + 1));
-			  group_head_kernel<<<grid_for(n_active), BLOCK, 0, s>>>(in, keys_sorted.as<uint64_t>(), sorted_records.as<uint32_t>(), n_active, head.as<uint8_t>(), device_counters); }
+			{ KernelTimer timer(ctx, "group_head_kernel", n_active * (8 + 1));
+			  group_head_kernel<<<grid_for(n_active), BLOCK, 0, s>>>(keys_sorted.as<uint64_t>(), n_active, head.as<uint8_t>()); }
 			TRY(select_flagged(ctx, rocprim_scratch, head.as<uint8_t>(), group_start.as<uint32_t>(), device_counters + IC_MAX_NAME /* borrowed as the count */, n_active));
 			TRY(read_counters());
 			n_groups = host_counters[IC_MAX_NAME];
 			HIP_CHECK(hipMemsetAsync(device_counters + IC_MAX_NAME, 0, 4, s));
+			// the groups in the order of their first records (see group_first_flag_kernel)
+			ALLOC(first_flags, n_records); ALLOC(stream_rank, (n_records + 1) * 4); ALLOC(group_first, (size_t) n_groups * 4); ALLOC(group_begin, (size_t) n_groups * 4); ALLOC(group_count, (size_t) n_groups * 4);
+			HIP_CHECK(hipMemsetAsync(first_flags.ptr, 0, n_records, s));
+			group_first_flag_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), n_groups, first_flags.as<uint8_t>());
+			{ size_t scan_bytes = 0;
+			  HIP_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, first_flags.as<uint8_t>(), stream_rank.as<uint32_t>(), 0u, n_records, rocprim::plus<uint32_t>(), s));
+			  if (scan_bytes > rocprim_scratch.capacity) ALLOC(rocprim_scratch, scan_bytes);
+			  KernelTimer timer(ctx, "rocprim::exclusive_scan(first records)", n_records * 5);
+			  HIP_CHECK(rocprim::exclusive_scan(rocprim_scratch.ptr, scan_bytes, first_flags.as<uint8_t>(), stream_rank.as<uint32_t>(), 0u, n_records, rocprim::plus<uint32_t>(), s)); }
+			{ KernelTimer timer(ctx, "group_rank_kernel", (uint64_t) n_groups * 24);
+			  group_rank_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), n_groups, n_active, stream_rank.as<uint32_t>(), group_first.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>()); }
+			{ KernelTimer timer(ctx, "group_names_kernel", n_active * (4 + 36 + 16));
+			  group_names_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), n_groups, device_counters); }
+			TRY(read_counters());
 			if (host_counters[IC_COLLISION]) { seed += 0x632BE59BD9B4E019ull; continue; } // two names with one key: hash again with another seed (once in ~10^3 runs of 10^8 names)
 		}
 		break;
@@ -659,11 +689,12 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	context.stream = in; context.annotation = ctx->annotation; context.annotation.n_dummy = 0; context.genome = ctx->genome;
 	context.coverage.n_contigs = ctx->genome.n_contigs; context.coverage.window_offset = ctx->coverage_window_offset.as<uint64_t>(); context.coverage.windows = ctx->coverage_windows32.as<uint32_t>();
 	context.coverage.fragment_starts = ctx->coverage_fragment_starts.as<uint8_t>(); context.coverage.fragment_ends = ctx->coverage_fragment_ends.as<uint8_t>();
+	if (getenv("ARRIBA_INGEST_SKIP_COVERAGE") != nullptr) context.coverage.windows = nullptr; // a measurement (the results are not the reference's): what the atomics on coverage_t cost the replay
 	context.record_bits = record_bits.as<uint8_t>(); context.max_itd_length = ctx->ingest_max_itd_length; context.external_duplicate_marking = ctx->ingest_external_duplicate_marking;
 	uint64_t n_fragments = 0;
 	if (n_groups > 0) {
 		{ KernelTimer timer(ctx, "group_replay_kernel", size - base);
-		  group_replay_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(context, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), n_groups, n_active, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
+		  group_replay_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(context, sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
 		                                                            sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
 		TRY(select_flagged(ctx, rocprim_scratch, valid.as<uint8_t>(), refs.as<uint32_t>(), device_counters + IC_MAX_NAME, 2 * (uint64_t) n_groups));
 		TRY(read_counters());
@@ -678,18 +709,16 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ALLOC(order, fragments1 * 4);
 	if (n_fragments > 0) {
 		ALLOC(order_keys, fragments1 * 8); ALLOC(order_keys_sorted, fragments1 * 8);
-		occurrence_key_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(refs.as<uint32_t>(), n_fragments, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order_keys.as<uint64_t>());
-		unsigned int key_bits = 2; while (key_bits < 64 && (n_records >> (key_bits - 1)) > 0) ++key_bits;
-		TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, order_keys.as<uint64_t>(), order_keys_sorted.as<uint64_t>(), refs.as<uint32_t>(), order.as<uint32_t>(), n_fragments, key_bits, "rocprim::radix_sort_pairs(first occurrence)", false));
+		HIP_CHECK(hipMemcpyAsync(order.ptr, refs.ptr, n_fragments * 4, hipMemcpyDeviceToDevice, s)); // ascending references == the order of first occurrence (the groups are numbered by their first records)
 		{ KernelTimer timer(ctx, "name_order_check_kernel", n_fragments * (4 + 2 * 40));
-		  name_order_check_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n_fragments, device_counters); }
+		  name_order_check_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, device_counters); }
 		TRY(read_counters());
 		if (host_counters[IC_UNSORTED]) { // the names are not in std::string order: least-significant-chunk-first radix sort over the 8-byte chunks of the names
 			names_were_sorted = false;
 			const uint32_t chunks = (host_counters[IC_MAX_NAME] + 7) / 8;
 			for (uint32_t chunk = chunks; chunk-- > 0; ) {
 				{ KernelTimer timer(ctx, "name_chunk_kernel", n_fragments * (4 + 8 + 40));
-				  name_chunk_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n_fragments, chunk, order_keys.as<uint64_t>()); }
+				  name_chunk_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, chunk, order_keys.as<uint64_t>()); }
 				TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, order_keys.as<uint64_t>(), order_keys_sorted.as<uint64_t>(), order.as<uint32_t>(), refs.as<uint32_t>(), n_fragments, 64, "rocprim::radix_sort_pairs(name chunk)", false));
 				order.swap(refs);
 			}
@@ -702,7 +731,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ALLOC(cigar_words, (n_fragments + 1) * 4); ALLOC(sequence_bytes, (n_fragments + 1) * 4); ALLOC(name_lengths, (n_fragments + 1) * 4); ALLOC(new_group, (n_fragments + 1) * 4);
 	ALLOC(cigar_base, (n_fragments + 1) * 8); ALLOC(sequence_base, (n_fragments + 1) * 8); ALLOC(name_base, (n_fragments + 1) * 8); ALLOC(group_id, (n_fragments + 1) * 4);
 	{ KernelTimer timer(ctx, "fragment_layout_kernel", n_fragments * (4 + 8 + 16 + 2 * 40));
-	  fragment_layout_kernel<<<grid_for(n_fragments + 1), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n_fragments, sizes.as<FragmentSizes>(),
+	  fragment_layout_kernel<<<grid_for(n_fragments + 1), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, sizes.as<FragmentSizes>(),
 	                                                                   cigar_words.as<uint32_t>(), sequence_bytes.as<uint32_t>(), name_lengths.as<uint32_t>(), new_group.as<uint32_t>()); }
 	TRY(exclusive_sum_u64(ctx, rocprim_scratch, cigar_words.as<uint32_t>(), cigar_base.as<uint64_t>(), n_fragments + 1));
 	TRY(exclusive_sum_u64(ctx, rocprim_scratch, sequence_bytes.as<uint32_t>(), sequence_base.as<uint64_t>(), n_fragments + 1));
@@ -729,7 +758,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	PackTarget target;
 	fill_pack_target(ctx, target);
 	{ KernelTimer timer(ctx, "fragment_pack_kernel", n * (1 + 1 + 4 + 3 * 17 + 16 + 4 + 24) + totals[0] * 8 + totals[1] * 2 + totals[2] * 2);
-	  fragment_pack_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), order.as<uint32_t>(), n, plain.as<FragmentPlan>(), itd.as<TandemPlan>(),
+	  fragment_pack_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n, plain.as<FragmentPlan>(), itd.as<TandemPlan>(),
 	                                                       cigar_base.as<uint64_t>(), sequence_base.as<uint64_t>(), name_base.as<uint64_t>(), group_id.as<uint32_t>(), target, device_counters); }
 	const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
 	if (windows > 0) { KernelTimer timer(ctx, "coverage_clamp_kernel", windows * 6); coverage_clamp_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_windows32.as<uint32_t>(), windows, ctx->coverage_windows.as<uint16_t>()); }

@@ -405,6 +405,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 	}
 	if (phases & PHASE_JOBS) ctx->mismapper_jobs_ready = true;
 	if ((phases & PHASE_SEARCH) && enabled && n_jobs > 0) {
+		HIP_CHECK(hipMemsetAsync(device_counters + 3, 0, 8, s)); // the reads left to the second pass and its queue: a search that is run again (agpu_mismapper_verdicts called twice) starts with empty ones
 		{
 			// this context's share of the jobs: all of them, or every parts-th one (neighbours in the order of the candidates cost about the same: the shares are even)
 			const uint32_t n_all = n_jobs;

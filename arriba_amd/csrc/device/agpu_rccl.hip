@@ -2,7 +2,8 @@
 // (agpu_shard_merge(ctx, ncclComm_t, hipStream_t)).  Thin compositions of entry points that are tested on their own
 // (agpu_shard_export / agpu_shard_merge, agpu_mismapper_jobs / _verdicts / agpu_filter_mismappers_apply) with ncclAllReduce / ncclAllGather on the context's
 // stream in between.  librccl is looked up at run time: the library does not link against it, and nothing else in it depends on these two functions.
-// NOT EXERCISED in round 2 (RCCL needs one GPU per rank; the Python driver arriba_amd/one_sample.py issues the same collectives through torch.distributed).
+// Exercised on a communicator of one rank by tests/test_gpu_parity.py::test_rccl_compositions_with_one_rank (the GPU box has one GPU); the Python driver
+// arriba_amd/one_sample.py issues the same collectives through torch.distributed.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>

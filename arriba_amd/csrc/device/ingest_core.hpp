@@ -589,6 +589,7 @@ AGPU_HD void coverage_increment(uint32_t* window) {
 
 AGPU_HD void add_fragment_to_coverage(const CoverageBuild& coverage, const Rec& mate1, uint16_t flag1, const Rec* mate2_or_null, bool is_chimeric) {
 	const Rec& mate2 = (mate2_or_null == nullptr) ? mate1 : *mate2_or_null;
+	if (coverage.windows == nullptr) return; // (a measurement without coverage_t: ARRIBA_INGEST_SKIP_COVERAGE)
 	if (mate1.contig < 0 || (uint32_t) mate1.contig >= coverage.n_contigs || mate2.contig < 0 || (uint32_t) mate2.contig >= coverage.n_contigs) return;
 	const uint64_t begin1 = coverage.window_offset[mate1.contig], size1 = coverage.window_offset[mate1.contig + 1] - begin1;
 	const uint64_t begin2 = coverage.window_offset[mate2.contig], size2 = coverage.window_offset[mate2.contig + 1] - begin2;

@@ -17,6 +17,11 @@
 
 namespace arriba {
 
+// The processors this process may actually use at once: the hardware threads it sees, less what its CPU affinity and the CPU quota of its container (cgroup cpu.max /
+// cfs_quota_us) allow.  A host with 256 hardware threads behind a quota of 16 CPUs runs 128 busy threads for 12 ms of every 100 ms and stalls them for the rest
+// (profiles/r03g_probe.txt): every pool of worker threads of the host library sizes itself by this number.
+unsigned int cpu_budget();
+
 typedef int32_t position_t;
 typedef uint16_t contig_t;
 
@@ -167,6 +172,7 @@ struct Batch {
 	std::string name(size_t i) const { return names.substr(name_offset[i], name_offset[i + 1] - name_offset[i]); }
 	std::vector<uint32_t> cigar(unsigned slot, size_t i) const { return std::vector<uint32_t>(cigar_pool.begin() + cigar_offset[slot][i], cigar_pool.begin() + cigar_offset[slot][i] + cigar_count[slot][i]); }
 	std::string sequence(unsigned slot, size_t i) const;
+	void sequence_into(unsigned slot, size_t i, std::string& out) const; // the same into a string the caller keeps (no allocation once it has grown)
 };
 
 struct IngestOptions {

@@ -284,7 +284,7 @@ static int write_or_format_fusions(ahost_session* session, const ahost_fusion_ta
 			for (size_t w = 0; w < words; ++w) rank[w + 1] = rank[w] + (uint32_t) __builtin_popcountll(bits[w]);
 			std::atomic<bool> missing(false);
 			const FusionTable* table_view = &t;
-			unsigned int n_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+			unsigned int n_threads = std::max(1u, std::min(cpu_budget(), 64u));
 			if (n_entries < (1u << 16)) n_threads = 1;
 			std::vector<std::thread> threads;
 			auto translate = [&](uint32_t first_candidate, uint32_t last_candidate) {

@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <sched.h>
 #include <thread>
 #include <zlib.h>
 #include <errno.h>
@@ -953,10 +954,33 @@ struct ChunkQueue {
 unsigned int ingest_threads() { // ARRIBA_INGEST_THREADS overrides; the reader is one more thread
 	const char* setting = getenv("ARRIBA_INGEST_THREADS");
 	if (setting != NULL && atoi(setting) > 0) return (unsigned int) atoi(setting);
-	unsigned int cores = std::thread::hardware_concurrency();
+	unsigned int cores = cpu_budget();
 	return std::max(1u, std::min(48u, cores > 1 ? cores - 1 : 1u)); // one reader deals the records out: more workers than this wait for it
 }
 
+}
+
+unsigned int cpu_budget() {
+	static const unsigned int budget = [] {
+		unsigned int cores = std::max(1u, std::thread::hardware_concurrency());
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int allowed = CPU_COUNT(&set); if (allowed > 0) cores = std::min(cores, (unsigned int) allowed); }
+		double quota = 0; // CPUs per period
+		if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+			char first[64]; long long period = 0;
+			if (fscanf(f, "%63s %lld", first, &period) == 2 && strcmp(first, "max") != 0 && period > 0) quota = (double) atoll(first) / (double) period;
+			fclose(f);
+		} else {
+			long long q = -1, period = 0; // cgroup v1
+			if (FILE* a = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(a, "%lld", &q) != 1) q = -1; fclose(a); }
+			if (FILE* b = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(b, "%lld", &period) != 1) period = 0; fclose(b); }
+			if (q > 0 && period > 0) quota = (double) q / (double) period;
+		}
+		if (quota >= 1) cores = std::min(cores, (unsigned int) quota);
+		if (const char* setting = getenv("ARRIBA_CPU_BUDGET")) if (atoi(setting) > 0) cores = (unsigned int) atoi(setting); // (for measurements)
+		return std::max(1u, cores);
+	}();
+	return budget;
 }
 
 // BGZF (the container of BAM files: gzip members of at most 64 KiB, each with its compressed size in an extra field) read block-parallel:
@@ -1283,7 +1307,7 @@ public:
 	BamFeed(const std::string& path): gzip_open_(false), end_(false), n_targets_(0), header_size_(0), header_raw_end_(0), consumed_raw_(0), head_block_raw_(NOWHERE), head_skip_(0), tail_block_raw_(NOWHERE), tail_keep_(0) {
 		fd_ = (path == "-") ? 0 : open(path.c_str(), O_RDONLY);
 		if (fd_ < 0) throw std::runtime_error("failed to open SAM file");
-		file_.fd = fd_; file_.position = 0; file_.n_threads = std::min(32u, ingest_threads());
+		file_.fd = fd_; file_.position = 0; file_.n_threads = std::min(32u, cpu_budget());
 		if (const char* knob = getenv("ARRIBA_FEED_THREADS")) if (atoi(knob) > 0) file_.n_threads = (unsigned int) std::min(atoi(knob), 256); // (how many threads read a piece of the file: for measurements)
 		struct stat status;
 		file_.seekable = fstat(fd_, &status) == 0 && S_ISREG(status.st_mode);
@@ -1439,6 +1463,9 @@ public:
 		if (parts == 0 || part >= parts) throw std::runtime_error("part of the sample out of range");
 		if (!file_.seekable || mode_ == GZIP) throw std::runtime_error("a part of a sample can only be read from a BAM file on disk (BGZF or uncompressed): every rank opens the file at its own offset");
 		if (header_size_ == 0) throw std::runtime_error("the BAM header must be read first");
+		// told before any rank reads a byte of its part (the check of the read names behind the exchange of the parts would find it, too -- after every rank has ingested its part)
+		if (parts > 1 && sorted_by_coordinate_) throw std::runtime_error("the BAM file is sorted by coordinate (@HD SO:coordinate): its alignments of one read are apart, and a sample is read in parts by several GPUs "
+		                                                                  "only if they follow each other (STAR's output order; `samtools collate` otherwise) -- or run it on one GPU, which collates by name itself");
 		const Cut begin = part == 0 ? Cut() : cut(file_size_ / parts * part), end = part + 1 == parts ? Cut() : cut(file_size_ / parts * (part + 1));
 		if (part > 0) {
 			pending_.clear(); end_ = false;
@@ -1591,12 +1618,18 @@ private:
 		const size_t payload = le32(block + size - 4), length = block[data_offset + 1] | (size_t) block[data_offset + 2] << 8, inverse = block[data_offset + 3] | (size_t) block[data_offset + 4] << 8;
 		return block[data_offset] == 1 && length == payload && (length ^ inverse) == 0xFFFF && data_offset + 5 + payload + 8 == size;
 	}
-	static bool parse_header(const std::vector<uint8_t>& head, std::vector<std::string>& target_names, uint64_t& size) {
+	bool parse_header(const std::vector<uint8_t>& head, std::vector<std::string>& target_names, uint64_t& size) {
 		target_names.clear();
 		if (head.size() < 12) return false;
 		if (memcmp(head.data(), "BAM\1", 4) != 0) throw std::runtime_error("failed to read SAM header");
 		uint64_t at = 8 + (uint64_t) le32(&head[4]);
 		if (head.size() < at + 4) return false;
+		{ // the sort order the header declares ("@HD ... SO:coordinate"): a file sorted by coordinate keeps the alignments of a read apart
+			const std::string text((const char*) &head[8], (size_t) le32(&head[4]));
+			const size_t line_end = text.find('\n');
+			const std::string first_line = text.substr(0, line_end);
+			sorted_by_coordinate_ = first_line.compare(0, 3, "@HD") == 0 && first_line.find("SO:coordinate") != std::string::npos;
+		}
 		const uint32_t n_ref = le32(&head[at]);
 		at += 4;
 		for (uint32_t i = 0; i < n_ref; ++i) {
@@ -1656,6 +1689,7 @@ private:
 	std::vector<uint8_t> pending_, raw_;
 	z_stream gzip_;
 	bool gzip_open_, end_;
+	bool sorted_by_coordinate_ = false; // the header says SO:coordinate
 	uint32_t n_targets_;
 	uint64_t header_size_, header_raw_end_, header_inside_ = 0; // BGZF: file offset of the block that holds the first record, and the record's offset inside it
 	uint64_t consumed_raw_;                                    // file offset of the first byte the next piece starts with

@@ -439,7 +439,7 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 	// the rows are independent of each other: all threads format a chunk of them (the fusion transcripts from the read pileups are the expensive part), the
 	// chunk is written in order, the warnings of a row come out in row order as well
 	const size_t CHUNK = 16384;
-	unsigned int n_threads = std::thread::hardware_concurrency();
+	unsigned int n_threads = cpu_budget();
 	if (const char* setting = getenv("ARRIBA_WRITER_THREADS")) if (atoi(setting) > 0) n_threads = (unsigned int) atoi(setting);
 	n_threads = std::max(1u, std::min(n_threads, 128u));
 	std::vector<std::string> row_text, row_warnings;
@@ -460,6 +460,7 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			}
 		};
 		if (n_threads == 1 || count < 4) work();
+		else if (getenv("ARRIBA_WRITER_SPAWN")) { std::vector<std::thread> threads; for (unsigned int t = 0; t < std::min<size_t>(n_threads, count); ++t) threads.push_back(std::thread(work)); for (size_t t = 0; t < threads.size(); ++t) threads[t].join(); }
 		else { std::lock_guard<std::mutex> one_file(formatter_pool_in_use); formatter_pool().run((unsigned) std::min<size_t>(n_threads, count), work); }
 		if (failure) { if (out) fclose(out); std::rethrow_exception(failure); }
 		for (size_t k = 0; k < count; ++k) {
@@ -476,7 +477,11 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		extras.text_of_part->append(text);
 		return;
 	}
-	if (profile) fprintf(stderr, "[writer] thread time: fusion transcripts %.3f s, best-fitting transcripts %.3f s, peptides %.3f s\n", profile_ns[0] * 1e-9, profile_ns[1] * 1e-9, profile_ns[2] * 1e-9);
+	if (profile) {
+		fprintf(stderr, "[writer] thread time: fusion transcripts %.3f s, best-fitting transcripts %.3f s, peptides %.3f s\n", profile_ns[0] * 1e-9, profile_ns[1] * 1e-9, profile_ns[2] * 1e-9);
+		fprintf(stderr, "[writer] fusion transcripts: pile-ups %.3f s, consensus %.3f s (of it the columns of the pile-ups %.3f s), the rest %.3f s\n", transcript_profile_ns[0] * 1e-9, transcript_profile_ns[2] * 1e-9, transcript_profile_ns[1] * 1e-9, transcript_profile_ns[3] * 1e-9);
+		for (int k = 0; k < 4; ++k) transcript_profile_ns[k] = 0;
+	}
 	const bool ok = fwrite(text.data(), 1, text.size(), out) == text.size();
 	if (fclose(out) != 0 || !ok) throw std::runtime_error("failed to write to file");
 }

@@ -696,12 +696,16 @@ int Coverage::get_coverage(contig_t contig, position_t position, bool upstream) 
 }
 
 std::string Batch::sequence(unsigned slot, size_t i) const {
-	static const char codes[] = "=ACMGRSVTWYHKDBN";
-	std::string result(seq_length[slot][i], 'N');
-	const uint8_t* packed = &seq_pool[0] + (size_t) seq_offset[slot][i] * 4;
-	for (size_t b = 0; b < result.size(); ++b)
-		result[b] = codes[(packed[b >> 1] >> ((~b & 1) << 2)) & 15];
+	std::string result;
+	sequence_into(slot, i, result);
 	return result;
+}
+void Batch::sequence_into(unsigned slot, size_t i, std::string& out) const {
+	static const char codes[] = "=ACMGRSVTWYHKDBN";
+	out.resize(seq_length[slot][i]);
+	const uint8_t* packed = &seq_pool[0] + (size_t) seq_offset[slot][i] * 4;
+	for (size_t b = 0; b < out.size(); ++b)
+		out[b] = codes[(packed[b >> 1] >> ((~b & 1) << 2)) & 15];
 }
 
 // ---- blacklist / known-fusions files (reference: source/filter_blacklisted_ranges.cpp:17-118, the line loops at :244-264 and

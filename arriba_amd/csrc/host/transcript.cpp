@@ -10,6 +10,8 @@
 #include "transcript.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +21,16 @@
 namespace arriba {
 
 thread_local std::string* transcript_warnings = NULL; // set by the output writer around the formatting of one row
+// (ARRIBA_WRITER_PROFILE: where the threads spend the time of fusion_transcript_sequence -- pile-ups, columns of the pile-ups, the consensus over them, the rest)
+std::atomic<long long> transcript_profile_ns[4];
+namespace {
+struct ProfileLap {
+	const bool on; std::chrono::steady_clock::time_point mark;
+	ProfileLap(): on(getenv("ARRIBA_WRITER_PROFILE") != NULL && getenv("ARRIBA_WRITER_PROFILE")[0] == '2'), mark(on ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point()) {}
+	void lap(int part) { if (!on) return; const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now(); transcript_profile_ns[part] += std::chrono::duration_cast<std::chrono::nanoseconds>(now - mark).count(); mark = now; }
+};
+}
+
 
 
 namespace {
@@ -39,6 +51,7 @@ std::string reverse_complement(const std::string& dna) {
 	return result;
 }
 bool is_intron_allele(const std::string& allele) { return allele == "_" || allele == ">" || allele == "<"; }
+bool is_intron_character(char allele) { return allele == '_' || allele == '>' || allele == '<'; }
 bool is_lower_case_base(char c) { return c == 'a' || c == 't' || c == 'c' || c == 'g'; }
 
 // The pileup next to a breakpoint: position -> allele -> reads.  Alleles: a base, "-" (deleted), an insertion + the base behind it, and ">" "_" "<" for the
@@ -48,12 +61,17 @@ bool is_lower_case_base(char c) { return c == 'a' || c == 't' || c == 'c' || c =
 // consecutive positions); what the consensus walks over is the same: the positions in ascending order, at each the alleles in the order of their strings.
 const char* const SINGLE_ALLELES = "-<=>ABCDGHKMNRSTVWY_"; // in ASCII order == the order of std::map<std::string, ...>
 const int N_SINGLE_ALLELES = 20;
-struct Allele { std::string text; unsigned count; };
+struct Allele { // `single` = the allele if it is one character (all but insertions), 0 otherwise with `multi` = its string (owned by the pileup): the consensus compares characters, not strings
+	const std::string* multi; unsigned count; char single;
+	Allele(const std::string& t, unsigned c): multi(t.size() == 1 ? NULL : &t), count(c), single(t.size() == 1 ? t[0] : 0) {}
+	Allele(char c, unsigned n): multi(NULL), count(n), single(c) {}
+	std::string text() const { return multi != NULL ? *multi : std::string(1, single); }
+};
 struct Column { position_t position; size_t first, n; }; // alleles[first .. first + n)
 // The pages of the pileups of a thread are kept and handed out again: a row of the output file piles up ~10 pages of 20 KB and gives them back, all writer threads at once;
 // through malloc / free the arenas of the threads grow and shrink by that much per row, and every shrink is an madvise that interrupts all cores (measured on the 256-thread
 // host of the GPU box: 4 ms per row on 128 threads where one thread needs 0.2 ms -- profiles/r03c_mismapper_second_pass.txt, [writer] lines).
-const size_t PILEUP_PAGE_WORDS = 256 * 20;
+const size_t PILEUP_PAGE_WORDS = 256 * 20 + 8 + 256; // the counters of 256 positions x 20 alleles; a bit per position that holds any; per position a bit per allele that was added (columns() visits only those)
 struct PilePagePool {
 	std::vector<unsigned*> free_pages;
 	~PilePagePool() { for (size_t k = 0; k < free_pages.size(); ++k) delete[] free_pages[k]; }
@@ -71,6 +89,8 @@ public:
 		const position_t page = position >> 8;
 		if (last_ == NULL || page != last_page_) { unsigned*& counts = pages_[page]; if (counts == NULL) counts = pile_page_pool.take(); last_ = counts; last_page_ = page; }
 		last_[(size_t) (position & 255) * N_SINGLE_ALLELES + slot] += count;
+		last_[256 * N_SINGLE_ALLELES + ((position & 255) >> 5)] |= 1u << (position & 31);
+		last_[256 * N_SINGLE_ALLELES + 8 + (position & 255)] |= 1u << slot;
 	}
 	void add(position_t position, const std::string& allele) { // any allele (insertions; what std::string::substr gives at the end of a sequence)
 		if (allele.size() == 1 && slot_of(allele[0]) >= 0) add(position, slot_of(allele[0])); else other_[position][allele]++;
@@ -85,12 +105,11 @@ public:
 		static thread_local std::vector<std::pair<position_t, const unsigned*> > counted; // (kept between the rows of a thread, like the pages)
 		counted.clear();
 		for (std::map<position_t, unsigned*>::const_iterator page = pages_.begin(); page != pages_.end(); ++page)
-			for (int at = 0; at < 256; ++at) {
-				const unsigned* counts = page->second + (size_t) at * N_SINGLE_ALLELES;
-				bool any = false;
-				for (int slot = 0; slot < N_SINGLE_ALLELES; ++slot) any = any || counts[slot] > 0;
-				if (any) counted.push_back(std::make_pair(page->first * 256 + at, counts));
-			}
+			for (int word = 0; word < 8; ++word)
+				for (unsigned touched = page->second[256 * N_SINGLE_ALLELES + word]; touched != 0; touched &= touched - 1) {
+					const int at = 32 * word + __builtin_ctz(touched);
+					counted.push_back(std::make_pair(page->first * 256 + at, page->second + (size_t) at * N_SINGLE_ALLELES));
+				}
 		static thread_local std::vector<std::pair<position_t, long long> > events; // the number of reads inside an intron changes by .second at position .first
 		events.clear();
 		for (size_t k = 0; k < inside_introns_.size(); ++k) { events.push_back(std::make_pair(inside_introns_[k].from, (long long) inside_introns_[k].count)); events.push_back(std::make_pair(inside_introns_[k].to + 1, -(long long) inside_introns_[k].count)); }
@@ -101,7 +120,7 @@ public:
 		position_t unemitted = 0; bool have_unemitted = false;
 		auto emit_inside_only = [&](position_t from, position_t to) {
 			if (inside <= 0 || from > to) return;
-			for (int k = 0; k < (to > from ? 2 : 1); ++k) { Column column = { k == 0 ? from : to, alleles.size(), 1 }; Allele allele = { "_", (unsigned) inside }; alleles.push_back(allele); columns.push_back(column); }
+			for (int k = 0; k < (to > from ? 2 : 1); ++k) { Column column = { k == 0 ? from : to, alleles.size(), 1 }; alleles.push_back(Allele('_', (unsigned) inside)); columns.push_back(column); }
 		};
 		while (c < counted.size() || e < events.size() || other != other_.end()) {
 			position_t at = 0; bool have = false;
@@ -114,17 +133,22 @@ public:
 			const bool counted_here = c < counted.size() && counted[c].first == at, other_here = other != other_.end() && other->first == at;
 			if (!counted_here && !other_here) continue; // (only the number of reads inside introns changed here: the stretch from `at` on is made when its end is known)
 			Column column = { at, alleles.size(), 0 };
-			if (counted_here) { for (int slot = 0; slot < N_SINGLE_ALLELES; ++slot) if (counted[c].second[slot] > 0) { Allele allele = { std::string(1, SINGLE_ALLELES[slot]), counted[c].second[slot] }; alleles.push_back(allele); } ++c; }
+			if (counted_here) { // the alleles added at this position, in the order of their characters (a bit per allele behind the counters of the page)
+				const unsigned* counts = counted[c].second;
+				const unsigned* page = counts - (size_t) (at & 255) * N_SINGLE_ALLELES;
+				for (unsigned slots = page[256 * N_SINGLE_ALLELES + 8 + (at & 255)]; slots != 0; slots &= slots - 1) { const int slot = __builtin_ctz(slots); if (counts[slot] > 0) alleles.push_back(Allele(SINGLE_ALLELES[slot], counts[slot])); }
+				++c;
+			}
 			if (inside > 0) { // ("_" may have been counted here as an ordinary allele, too: one allele, the sum)
 				bool merged = false;
-				for (size_t a = column.first; a < alleles.size() && !merged; ++a) if (alleles[a].text == "_") { alleles[a].count += (unsigned) inside; merged = true; }
-				if (!merged) { Allele allele = { "_", (unsigned) inside }; alleles.push_back(allele); }
+				for (size_t a = column.first; a < alleles.size() && !merged; ++a) if (alleles[a].single == '_') { alleles[a].count += (unsigned) inside; merged = true; }
+				if (!merged) alleles.push_back(Allele('_', (unsigned) inside)); // ('_' is the last of the single alleles in the order of their strings: still sorted)
 			}
-			if (other_here) {
-				for (std::map<std::string, unsigned>::const_iterator a = other->second.begin(); a != other->second.end(); ++a) { Allele allele = { a->first, a->second }; alleles.push_back(allele); }
+			if (other_here) { // (rare: insertions, and what substr gives at the end of a sequence) these go where their strings belong
+				for (std::map<std::string, unsigned>::const_iterator a = other->second.begin(); a != other->second.end(); ++a) alleles.push_back(Allele(a->first, a->second));
 				++other;
+				std::sort(alleles.begin() + column.first, alleles.end(), [](const Allele& x, const Allele& y) { return x.text() < y.text(); });
 			}
-			std::sort(alleles.begin() + column.first, alleles.end(), [](const Allele& x, const Allele& y) { return x.text < y.text; });
 			column.n = alleles.size() - column.first;
 			columns.push_back(column);
 			unemitted = at + 1;
@@ -162,8 +186,9 @@ void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigne
 		if (!is_split_read && // discordant mates: only those close to the breakpoint, distant ones may belong to other isoforms
 		    !((!upstream && forward && end <= breakpoint + 2 && end >= breakpoint - 200) || (upstream && !forward && start >= breakpoint - 2 && start <= breakpoint + 200))) continue;
 		if (is_split_read && (mate == SPLIT_READ || mate == SUPPLEMENTARY) && start != breakpoint && end != breakpoint) continue; // alternative alignments with shifted breakpoints
-		std::string sequence = b.sequence(mate == SUPPLEMENTARY ? SPLIT_READ : mate, read);
-		if (reverse) sequence = reverse_complement(sequence);
+		static thread_local std::string sequence; // (kept between the reads of a thread)
+		b.sequence_into(mate == SUPPLEMENTARY ? SPLIT_READ : mate, read, sequence);
+		if (reverse) { std::reverse(sequence.begin(), sequence.end()); for (size_t k = 0; k < sequence.size(); ++k) sequence[k] = complement_of(sequence[k]); }
 		position_t read_offset = 0, reference_offset = start;
 		int borrowed = 0; // an insertion takes one base of the next element along
 		const uint32_t* cigar = &b.cigar_pool[b.cigar_offset[mate][read]];
@@ -228,7 +253,7 @@ unsigned reads_at(const std::vector<Allele>& alleles, const Column& column) {
 // reference: get_sequence_from_pileup (:109-240): the consensus next to one breakpoint; `clipped` receives what lies beyond the breakpoint
 void consensus_of_pileup(const DensePileup& pileup, position_t breakpoint, bool upstream, contig_t contig, const Assembly& assembly, std::string& sequence, std::vector<position_t>& positions, std::string& clipped) {
 	static thread_local std::vector<Column> columns; static thread_local std::vector<Allele> alleles; // (cleared and filled by columns(): their memory stays with the thread)
-	pileup.columns(columns, alleles);
+	{ ProfileLap profile; pileup.columns(columns, alleles); profile.lap(1); }
 	unsigned peak = 0;
 	for (size_t at = 0; at < columns.size(); ++at) peak = std::max(peak, reads_at(alleles, columns[at]));
 	// thin coverage far from the breakpoint probably belongs to other isoforms
@@ -244,39 +269,49 @@ void consensus_of_pileup(const DensePileup& pileup, position_t breakpoint, bool 
 	for (size_t at = first; at < last; ++at) {
 		const Column& column = columns[at];
 		if (at != first && columns[at - 1].position < column.position - 1 && !intron_open) { sequence += "..."; positions.resize(positions.size() + 3, -1); } // not covered
-		std::string reference_base = "N";
-		if (assembly.has(contig) && (unsigned) column.position < assembly.sequence[contig].size()) reference_base = std::string(1, assembly.sequence[contig][column.position]);
+		char reference = 'N';
+		if (assembly.has(contig) && (unsigned) column.position < assembly.sequence[contig].size()) reference = assembly.sequence[contig][column.position];
 		// the most frequent allele; ties go to the reference base, and to introns before anything else
 		const Allele* best = NULL;
 		unsigned coverage = 0;
 		for (size_t a = column.first; a < column.first + column.n; ++a) {
 			const Allele* allele = &alleles[a];
+			const char c = allele->single;
 			if (best == NULL || allele->count > best->count ||
-			    (allele->count == best->count && ((allele->text == reference_base && !is_intron_allele(best->text)) || (allele->text == "<" && best->text != "_" && best->text != ">") || allele->text == "_" || allele->text == ">")))
+			    (allele->count == best->count && ((c == reference && !is_intron_character(best->single)) || (c == '<' && best->single != '_' && best->single != '>') || c == '_' || c == '>')))
 				best = allele;
-			if (!is_intron_allele(allele->text)) coverage += allele->count;
+			if (!is_intron_character(c)) coverage += allele->count;
 		}
 		// trusted: >= 75 % of the reads, an intron at least as frequent as the coverage, or the reference base
-		std::string allele = ((is_intron_allele(best->text) && best->count >= coverage) || best->count >= 0.75 * coverage || best->text == reference_base) ? best->text : "?";
-		if (allele == "_") {
+		const bool trusted = (is_intron_character(best->single) && best->count >= coverage) || best->count >= 0.75 * coverage || best->single == reference;
+		const char single = trusted ? best->single : '?';
+		if (single == '_') {
 			if (!intron_open) { sequence += "...___"; positions.resize(positions.size() + 6, -1); intron_open = true; intron_closed = false; } // inside an intron whose start was not seen
-		} else if (allele == ">") {
+		} else if (single == '>') {
 			if (!intron_open) { sequence += "___"; positions.resize(positions.size() + 3, -1); intron_open = true; intron_closed = false; }
-		} else if (allele == "<") {
+		} else if (single == '<') {
 			if (!intron_open) { sequence += "...___"; positions.resize(positions.size() + 6, -1); }
 			intron_open = true; intron_closed = true;
 		} else {
 			if (!intron_closed) { sequence += "..."; positions.resize(positions.size() + 3, -1); } // the end of the intron was not seen
 			intron_open = false; intron_closed = true;
-			if (allele.size() > 1 || (allele != reference_base && reference_base != "N")) // mismatches and insertions in lower case
-				for (size_t i = 0; i < allele.size(); ++i) allele[i] = (char) tolower(allele[i]);
-			if (allele.size() > 1) { // an insertion in brackets, then the base behind it
-				allele = "[" + allele.substr(0, allele.size() - 1) + "]" + allele[allele.size() - 1];
-				positions.resize(positions.size() + allele.size() - 1, -1);
-				if (toupper(allele[allele.size() - 1]) == reference_base[0]) allele[allele.size() - 1] = (char) toupper(allele[allele.size() - 1]);
+			const bool upstream_of_breakpoint = (upstream && column.position < breakpoint) || (!upstream && column.position > breakpoint);
+			if (single != 0) { // one base (or '?'): a mismatch in lower case
+				const char base = (single != reference && reference != 'N') ? (char) tolower(single) : single;
+				if (upstream_of_breakpoint) clipped += base;
+				else { sequence += base; positions.push_back(column.position); }
+			} else { // an insertion (or the empty allele of a read that ends here), as a string: in lower case, the inserted bases in brackets, then the base behind them
+				std::string allele = best->text();
+				if (allele.size() > 1 || (allele != std::string(1, reference) && reference != 'N'))
+					for (size_t i = 0; i < allele.size(); ++i) allele[i] = (char) tolower(allele[i]);
+				if (allele.size() > 1) {
+					allele = "[" + allele.substr(0, allele.size() - 1) + "]" + allele[allele.size() - 1];
+					positions.resize(positions.size() + allele.size() - 1, -1);
+					if (toupper(allele[allele.size() - 1]) == reference) allele[allele.size() - 1] = (char) toupper(allele[allele.size() - 1]);
+				}
+				if (upstream_of_breakpoint) clipped += allele;
+				else { sequence += allele; positions.push_back(column.position); }
 			}
-			if ((upstream && column.position < breakpoint) || (!upstream && column.position > breakpoint)) clipped += allele;
-			else { sequence += allele; positions.push_back(column.position); }
 		}
 	}
 }
@@ -309,6 +344,7 @@ bool split_off_non_template_bases(bool upstream, std::string& sequence, std::vec
 
 // reference: get_fusion_transcript_sequence (:242-466)
 void fusion_transcript_sequence(const TranscriptInput& in, const FusionEvent& f, std::string& sequence, std::vector<position_t>& positions) {
+	ProfileLap profile;
 	sequence.clear(); positions.clear();
 	if (f.strands_ambiguous || f.transcript_start_ambiguous) { sequence = "."; positions.push_back(-1); return; } // the strands are unknown
 	const Reads reads = { in.batch, in.read_filter };
@@ -324,6 +360,7 @@ void fusion_transcript_sequence(const TranscriptInput& in, const FusionEvent& f,
 	add_to_pileup(reads, mates, f.n_discordant_mates, MATE2, false, f.upstream1, f.breakpoint1, pileup1);
 	add_to_pileup(reads, mates, f.n_discordant_mates, MATE1, false, f.upstream2, f.breakpoint2, pileup2);
 	add_to_pileup(reads, mates, f.n_discordant_mates, MATE2, false, f.upstream2, f.breakpoint2, pileup2);
+	profile.lap(0);
 
 	// non-template bases between the genes: the clipped bases of split read and supplementary alignment add up to more than the read; the most frequent count wins, the first one in list order on a tie
 	unsigned non_template_bases = 0;
@@ -342,6 +379,7 @@ void fusion_transcript_sequence(const TranscriptInput& in, const FusionEvent& f,
 	std::vector<position_t> positions1, positions2;
 	consensus_of_pileup(pileup1, f.breakpoint1, f.upstream1, f.contig_of_gene1, in.assembly, sequence1, positions1, clipped1);
 	consensus_of_pileup(pileup2, f.breakpoint2, f.upstream2, f.contig_of_gene2, in.assembly, sequence2, positions2, clipped2);
+	profile.lap(2);
 
 	if (f.n_split_reads1 + f.n_split_reads2 == 0) { // without split reads the exact breakpoints are unknown
 		if (!f.upstream1) { sequence1 += "..."; positions1.resize(positions1.size() + 3, -1); } else { sequence1 = "..." + sequence1; positions1.insert(positions1.begin(), 3, -1); }
@@ -400,6 +438,7 @@ void fusion_transcript_sequence(const TranscriptInput& in, const FusionEvent& f,
 	while (sequence.size() >= 3 && (sequence.substr(sequence.size() - 3) == "..." || sequence.substr(sequence.size() - 3) == "___")) { sequence = sequence.substr(0, sequence.size() - 3); positions.erase(positions.end() - 3, positions.end()); }
 	if (sequence == "" || sequence == "|" || sequence == "...|" || sequence == "|..." || sequence == "...|...") { sequence = "."; positions.clear(); positions.push_back(-1); return; } // nothing assembled
 	for (size_t i = 0; i < sequence.size(); ++i) if (sequence[i] == 'n' || sequence[i] == 'N') sequence[i] = '?';
+	profile.lap(3);
 }
 
 // reference: get_transcripts (:720-818): the annotated transcripts of `gene` whose exons fit the transcribed bases of one end (5 or 3) best

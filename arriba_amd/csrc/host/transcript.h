@@ -3,9 +3,11 @@
 #define ARRIBA_HOST_TRANSCRIPT_H 1
 
 #include "arriba_host.h"
+#include <atomic>
 
 namespace arriba {
 
+extern std::atomic<long long> transcript_profile_ns[4]; // ARRIBA_WRITER_PROFILE: nanoseconds of all threads in the pile-ups, their columns, the consensus (with the columns), the rest
 extern thread_local std::string* transcript_warnings; // where the warnings of the functions below go while a row is formatted (NULL: stderr)
 
 struct TranscriptInput { const Batch& batch; const uint8_t* read_filter; const Assembly& assembly; const Annotation& annotation; const FlatIndex& exon_index; };

@@ -174,7 +174,7 @@ int main(int argc, char** argv) {
 	require(options.output_file != NULL, "missing mandatory option -o");
 	require(options.assembly_file != NULL, "missing mandatory option -a");
 	require(!(blacklist_enabled && options.blacklist_file == NULL), "filter 'blacklist' enabled, but missing option -b (use '-f blacklist' if you want to disable the blacklist)");
-	if (!options.device.filter_enabled[30] && options.interesting_contigs == NULL) options.interesting_contigs = "*"; // all contigs are loaded when the filter is off (source/arriba.cpp:92-93)
+	if (!options.device.filter_enabled[30]) options.interesting_contigs = "*"; // all contigs are loaded when the filter is off, whatever -i says (source/arriba.cpp:92-93)
 	options.log_to_stdout = 1;
 	if (arriba_workflow_run(&options, NULL) != 0) { std::cerr << arriba_workflow_last_error() << std::endl; return 1; }
 	// source/arriba.cpp:612-628

@@ -57,7 +57,7 @@ class OneSamplePipeline(DevicePipeline):
         error, result = None, None
         try:
             result = work()
-        except ArribaError as problem:
+        except Exception as problem:  # (also what torch or numpy raise inside work(): the other ranks must not be left waiting)
             error = problem
         ok = torch.tensor([0 if error else 1], dtype=torch.int64, device=self.collective_device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
@@ -75,13 +75,13 @@ class OneSamplePipeline(DevicePipeline):
         ingested = time.perf_counter()
         self._record("read_chimeric_alignments")
         size = c_uint64()
-        self._check(self.api.shard_export_size(self.ctx, byref(size)))
+        self._together(lambda: self._check(self.api.shard_export_size(self.ctx, byref(size))))
         sizes = self._all_gather_int(size.value)
         stride = (max(sizes) + 15) & ~15
         mine = torch.empty(stride, dtype=torch.uint8, device=self.collective_device)
         blocks = torch.empty(self.world * stride, dtype=torch.uint8, device=self.collective_device)
         self._sync()
-        self._check(self.api.shard_export(self.ctx, mine.data_ptr(), stride))
+        self._together(lambda: self._check(self.api.shard_export(self.ctx, mine.data_ptr(), stride)))
         exported = time.perf_counter()
         if self.collective_device.type == "cuda":
             dist.all_gather_into_tensor(blocks, mine, group=self.group)
@@ -107,7 +107,7 @@ class OneSamplePipeline(DevicePipeline):
         if max_mate_gap is None:
             max_mate_gap = self.scalars["max_mate_gap"]
         n_jobs = c_uint64()
-        self._check(self.api.mismapper_jobs(self.ctx, byref(n_jobs)))
+        self._together(lambda: self._check(self.api.mismapper_jobs(self.ctx, byref(n_jobs))))
         self._record("filter_mismappers")
         spent = dict(self.timings["filter_mismappers"])
         verdicts = torch.zeros(max(n_jobs.value, 1), dtype=torch.uint8, device=self.collective_device)
@@ -119,7 +119,7 @@ class OneSamplePipeline(DevicePipeline):
         dist.all_reduce(verdicts, op=dist.ReduceOp.MAX, group=self.group)
         self._sync()
         remaining, discarded = c_uint64(), c_uint64()
-        self._check(self.api.filter_mismappers_apply(self.ctx, verdicts.data_ptr(), byref(remaining), byref(discarded)))
+        self._together(lambda: self._check(self.api.filter_mismappers_apply(self.ctx, verdicts.data_ptr(), byref(remaining), byref(discarded))))
         del verdicts
         self._record("filter_mismappers")
         spent["ms"] += self.timings["filter_mismappers"]["ms"]

@@ -56,6 +56,24 @@ def workload_args(fragments, seed, read_seed=0, stress=False):
     return args
 
 
+def cpu_budget():
+    """the processors this process may use at once: os.cpu_count() less what affinity and the CPU quota of the container (cgroup) allow -- the GPU box shows 256 hardware threads
+    behind a quota of 16 CPUs, and 64 busy threads there run for a sixth of the time and stall for the rest (profiles/r03g_probe.txt)"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota, period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                cores = min(cores, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, cores)
+
+
 def scratch_directory(need_bytes):
     """a directory for the sample: tmpfs if it has the room (the BAM is read from memory, as from the page cache), else the default temporary directory"""
     for base in ("/dev/shm", tempfile.gettempdir()):
@@ -70,7 +88,7 @@ def scratch_directory(need_bytes):
 def generate_sample(fragments, seed, directory, read_seed=0, stress=False, threads=None):
     import datasets
     prefix = os.path.join(directory, "bench")
-    threads = threads or min(64, max(1, (os.cpu_count() or 2) - 2))
+    threads = threads or min(64, cpu_budget())
     started = time.time()
     if os.environ.get("ARRIBA_BENCH_REUSE") and all(os.path.exists(prefix + suffix) for suffix in (".bam", ".fa", ".gtf")):
         return prefix, 0.0  # (A/B measurements on one GPU lease: the sample of an earlier run with --keep)
@@ -265,7 +283,7 @@ def main():
             dist.broadcast_object_list(timing, src=0)  # (also the barrier behind which the files exist)
             prefix, generate_seconds = timing
         else:
-            prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, ((os.cpu_count() or 2) - 2) // world)))
+            prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, cpu_budget() // world)))
         bam_bytes = os.path.getsize(prefix + ".bam")
         progress("sample generated: %d fragments, %.1f GB BAM in %.1f s (%s)" % (args.fragments, bam_bytes / 1e9, generate_seconds, directory))
         params = {"subsampling_threshold": 32767} if args.stress else None

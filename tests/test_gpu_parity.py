@@ -264,6 +264,60 @@ def test_device_ingest_in_parts_on_the_gpu(built, dataset_files, tmp_path):
     assert host_tests._device_batch_columns(merged_session, merged) == expected
 
 
+def test_rccl_compositions_with_one_rank(built, dataset_files, tmp_path):
+    """agpu_shard_merge_rccl and agpu_filter_mismappers_rccl -- the two exchanges of one sample over N GPUs issued under the C ABI (include/arriba_gpu.h; SURVEY.md 8b:
+    agpu_shard_merge(ctx, ncclComm_t, hipStream_t)) -- on a communicator of ONE rank (the GPU box has one GPU): librccl is found at run time, ncclAllReduce / ncclAllGather
+    run on the context's stream, and the batch, the candidates, every count and both output files are those of the plain path."""
+    import ctypes
+    from ctypes import byref, c_uint64
+    import test_host_and_device_logic as host_tests
+    from arriba_amd import _capi
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    rccl = ctypes.CDLL("librccl.so")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]; rccl.ncclGetUniqueId.restype = ctypes.c_int
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]; rccl.ncclCommInitRank.restype = ctypes.c_int
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]; rccl.ncclCommDestroy.restype = ctypes.c_int
+    unique, communicator = UniqueId(), ctypes.c_void_p()
+    assert rccl.ncclGetUniqueId(byref(unique)) == 0
+    assert rccl.ncclCommInitRank(byref(communicator), 1, unique, 0) == 0 and communicator.value
+    try:
+        api = _capi.bind_device_api(_capi.device_library(), "agpu_")
+        prefix = dataset_files("homologs8k")  # (hundreds of re-alignments decide in this dataset)
+        session = HostSession(prefix + ".fa", prefix + ".gtf")
+        plain = DevicePipeline(session, bam=prefix + ".bam")
+        expected_batch = host_tests._device_batch_columns(session, plain)
+
+        class OneRank(DevicePipeline):
+            def read_chimeric_alignments(self, bam, external_duplicate_marking=False, max_itd_length=100, piece_bytes=1 << 20):
+                config, _, _ = self._ingest_records(bam, external_duplicate_marking, max_itd_length, piece_bytes, part=0, parts=1)  # (a part of a sample: the batch is handed on by agpu_shard_export)
+                result = _capi.IngestResult()
+                self._check(self.api.shard_merge_rccl(self.ctx, communicator, 1, byref(result)))
+                self._adopt_ingest(config, result)
+                return self.n
+
+            def filter_mismappers(self, max_mate_gap=None):
+                remaining, discarded = c_uint64(), c_uint64()
+                self._check(self.api.filter_mismappers_rccl(self.ctx, communicator, self.scalars["max_mate_gap"] if max_mate_gap is None else max_mate_gap, 0, 1, byref(remaining), byref(discarded)))
+                self._record("filter_mismappers")
+                return remaining.value, discarded.value
+        rccl_session = HostSession(prefix + ".fa", prefix + ".gtf")
+        through_rccl = OneRank(rccl_session, api=api, bam=prefix + ".bam")
+        assert host_tests._device_batch_columns(rccl_session, through_rccl) == expected_batch
+        outputs = {}
+        for name, pipeline in (("plain", plain), ("rccl", through_rccl)):
+            stages = []
+            files = [str(tmp_path / (name + ".fusions.tsv")), str(tmp_path / (name + ".discarded.tsv"))]
+            pipeline.run_workflow(files[0], files[1], log=lambda stage, remaining: stages.append((stage, remaining)))
+            outputs[name] = (stages, open(files[0]).read(), open(files[1]).read())
+        assert outputs["rccl"] == outputs["plain"]
+        assert "filter_mismappers" in through_rccl.timings and dict(outputs["rccl"][0])["filter_mismappers"] > 0
+    finally:
+        rccl.ncclCommDestroy(communicator)
+
+
 def test_gene_set_capacity_is_reported_not_truncated(built, tmp_path):
     from arriba_amd.pipeline import ArribaError
     prefix = datasets.generate({"args": ["--seed", "13", "--fragments", "3000", "--contigs", "3", "--contig-len", "300000", "--junctions", "80", "--genes-per-mb", "40", "--gene-stack", "24"]}, str(tmp_path))

@@ -388,6 +388,18 @@ def test_device_ingest_in_parts_gives_the_batch_of_the_whole_file(built, dataset
     apart = dataset_files("shuffled2k")
     with pytest.raises(ArribaError, match="more than one place"):
         _ingest_in_parts(apart, apart + ".bam", 3, emu_api)
+    # a header that declares the file sorted by coordinate: said at once, before any part is read (one GPU reads such a file as ever: it collates by name)
+    import struct
+    payload = _bam_payload(apart + ".bam")
+    text_length = struct.unpack_from("<I", payload, 4)[0]
+    line = b"@HD\tVN:1.6\tSO:coordinate\n"
+    declared = payload[:4] + struct.pack("<I", text_length + len(line)) + line + payload[8:]
+    by_coordinate = str(tmp_path / "by_coordinate.bam")
+    _write_bgzf(by_coordinate, declared, 0)
+    with pytest.raises(ArribaError, match="sorted by coordinate"):
+        _ingest_in_parts(apart, by_coordinate, 2, emu_api)
+    session = HostSession(apart + ".fa", apart + ".gtf")
+    assert _device_batch_columns(session, DevicePipeline(session, api=emu_api, bam=by_coordinate)) == _device_batch_columns(session, DevicePipeline(session, api=emu_api, bam=apart + ".bam"))
 
 
 def test_stored_blocks_are_checked_against_their_crc(built, dataset_files, emu_api, tmp_path, monkeypatch):
