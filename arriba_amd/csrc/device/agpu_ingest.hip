@@ -57,14 +57,6 @@ __global__ void __launch_bounds__(BLOCK) bgzf_unwrap_kernel(const uint8_t* raw, 
 	if (threadIdx.x < size - tail) target[tail + threadIdx.x] = source[tail + threadIdx.x];
 }
 
-// CRC-32 (the gzip polynomial) of every stored block, one thread per block, four bytes per step (slicing-by-4 tables in constant memory would be
-// faster; the blocks are independent and there are 10^5..10^6 of them, so one lane per block keeps the chip busy)
-__device__ uint32_t crc32_update(uint32_t crc, uint8_t byte) {
-	crc ^= byte;
-	for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1)));
-	return crc;
-}
-
 // ---- the record chain -----------------------------------------------------------------------------------------------------------------------------
 
 __global__ void segment_guess_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, uint32_t n_targets, uint64_t* first, uint64_t* end, uint32_t* count) {
@@ -168,6 +160,8 @@ struct ViralCounter {
 	__device__ void operator()(uint32_t contig) { atomicAdd(&counts[contig], 1ull); }
 };
 
+// (Tried in round 3 and taken back: one wavefront per 64 groups with its slice of the stream copied into 48 KB of LDS -- 1240 ms instead of 455 ms at 10^8 fragments,
+// profiles/r03j_bench100m_lds_staged_replay.json: three wavefronts per CU cannot hide the look-ups that stay in HBM -- offsets, record bits, gene index, genome, coverage_t.)
 __global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t n_groups,
                                                              FragmentPlan* plain, TandemPlan* itd, uint8_t* valid, FragmentSizes* sizes, unsigned long long* viral_counts, uint32_t* counters) {
 	__shared__ uint32_t sums[2];
@@ -276,25 +270,26 @@ __global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, c
 	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_READ_LENGTH], block_max);
 }
 
-// CRC-32 of the payload of every stored block of a pushed piece against the trailer of the block (crc32_core.hpp): one workgroup per block, 256 lanes x 256 bytes,
-// the CRCs of the chunks joined in a tree.  Blocks of which only a part is delivered (the ends of a part of a file) carry crc32 = 0 and are not checked.
-__global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, unsigned int* mismatches) {
-	__shared__ uint32_t table[256];
+// CRC-32 of the payload of every stored block of a pushed piece against the trailer of the block (crc32_core.hpp; htslib checks every block it reads: bgzf.c): one workgroup
+// per block, 256 lanes x 256 bytes four bytes per step, the CRCs of the chunks joined in a tree with the prepared advance operators (tables and operators in LDS).
+// Blocks of which only a part is delivered (the ends of a part of a file) carry crc32 = 0 and are not checked.
+__global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, const Crc32Tables* tables, unsigned int* mismatches) {
+	__shared__ Crc32Tables t;
 	__shared__ uint32_t part[256];
 	__shared__ uint32_t length[256];
-	table[threadIdx.x] = crc32_table_entry(threadIdx.x);
+	for (uint32_t k = threadIdx.x; k < sizeof(Crc32Tables) / 4; k += 256) ((uint32_t*) &t)[k] = ((const uint32_t*) tables)[k];
 	const agpu_bgzf_block block = blocks[blockIdx.x];
 	__syncthreads();
 	if (block.crc32 == 0 || block.payload_size > 256u * CRC32_CHUNK) return; // (uniform; a BGZF block holds at most 64 KB)
 	const uint8_t* payload = raw + block.raw_offset + block.payload_offset;
 	const uint32_t at = threadIdx.x * CRC32_CHUNK;
-	const uint32_t mine = at < block.payload_size ? (block.payload_size - at < CRC32_CHUNK ? block.payload_size - at : CRC32_CHUNK) : 0u;
-	part[threadIdx.x] = mine ? crc32_of(table, payload + at, mine) : 0u;
+	const uint32_t mine = at < block.payload_size ? (block.payload_size - at < CRC32_CHUNK ? block.payload_size - at : CRC32_CHUNK) : 0;
+	part[threadIdx.x] = mine ? crc32_of_sliced(t.slice, payload + at, mine) : 0u;
 	length[threadIdx.x] = mine;
 	__syncthreads();
 	for (uint32_t stride = 1; stride < 256; stride *= 2) {
 		if (threadIdx.x % (2 * stride) == 0 && length[threadIdx.x + stride] > 0) {
-			part[threadIdx.x] = crc32_joined(part[threadIdx.x], part[threadIdx.x + stride], length[threadIdx.x + stride]);
+			part[threadIdx.x] = crc32_joined_with(t.advance, part[threadIdx.x], part[threadIdx.x + stride], length[threadIdx.x + stride]);
 			length[threadIdx.x] += length[threadIdx.x + stride];
 		}
 		__syncthreads();
@@ -494,8 +489,14 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	hipStream_t s = ctx->stream;
 	for (int k = 0; k < 2; ++k) if (!ctx->ingest_events[k]) HIP_CHECK(hipEventCreateWithFlags(&ctx->ingest_events[k], hipEventDisableTiming));
 	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
-	{ const char* knob = getenv("ARRIBA_VERIFY_CRC"); ctx->ingest_verify_crc = knob != nullptr && knob[0] == '1'; }
+	{ const char* knob = getenv("ARRIBA_VERIFY_CRC"); ctx->ingest_verify_crc = !(knob != nullptr && knob[0] == '0'); } // (the stored blocks are checked as htslib checks them; "0": a measurement without)
 	ALLOC(ctx->scratch("ingest.crc_mismatches"), 4);
+	if (ctx->ingest_verify_crc && ctx->scratch("ingest.crc_tables").ptr == nullptr) {
+		ALLOC(ctx->scratch("ingest.crc_tables"), sizeof(Crc32Tables));
+		static Crc32Tables tables; static bool made = false;
+		if (!made) { crc32_make_tables(tables); made = true; }
+		HIP_CHECK(hipMemcpy(ctx->scratch("ingest.crc_tables").ptr, &tables, sizeof(tables), hipMemcpyHostToDevice));
+	}
 	HIP_CHECK(hipMemsetAsync(ctx->scratch("ingest.crc_mismatches").ptr, 0, 4, s));
 	ctx->ingest_external_duplicate_marking = config->external_duplicate_marking; ctx->ingest_max_itd_length = config->max_itd_length; ctx->ingest_part_of_sample = config->part_of_sample != 0;
 	ALLOC(ctx->ingest_tid_to_contig, std::max<size_t>(config->n_targets, 1) * 4);
@@ -543,9 +544,9 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 		{ KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes);
 		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
 		ctx->ingest_stream_size += stream_bytes;
-		if (ctx->ingest_verify_crc) { // (ARRIBA_VERIFY_CRC=1: an experiment for the next round, off by default)
+		if (ctx->ingest_verify_crc) {
 			KernelTimer timer(ctx, "bgzf_crc_kernel", (uint64_t) stream_bytes);
-			bgzf_crc_kernel<<<n_blocks, 256, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+			bgzf_crc_kernel<<<n_blocks, 256, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
 		}
 	}
 	HIP_CHECK(hipEventRecord(ctx->ingest_events[slot], s));

@@ -51,6 +51,41 @@ AGPU_HD uint32_t crc32_joined(uint32_t crc_a, uint32_t crc_b, uint64_t length_b)
 
 const uint32_t CRC32_CHUNK = 256; // bytes per lane and round of the device kernel
 
+// What the device kernel works with (made once per context by crc32_make_tables): the tables of four bytes per step ("slicing by 4": slice[0] is the byte-wise table,
+// slice[k][i] = the register k zero bytes further on), and for every power of two 2^k, k = 0 .. 16, the 32 x 32 matrix over GF(2) that advances a CRC register over 2^k
+// zero bytes -- joining the CRCs of two pieces then costs one matrix-vector product per set bit of the length of the second piece, with the matrices in LDS, where
+// crc32_joined squares them anew in the scratch memory of every lane (13 ms per 256 MB piece, four times the time the piece takes to arrive: profiles/r03h_*).
+const int CRC32_ADVANCE_POWERS = 17; // pieces of up to 2^17 - 1 bytes (a BGZF block holds at most 2^16)
+struct Crc32Tables { uint32_t slice[4][256]; uint32_t advance[CRC32_ADVANCE_POWERS][32]; };
+inline void crc32_make_tables(Crc32Tables& t) {
+	for (uint32_t i = 0; i < 256; ++i) t.slice[0][i] = crc32_table_entry(i);
+	for (int k = 1; k < 4; ++k) for (uint32_t i = 0; i < 256; ++i) t.slice[k][i] = (t.slice[k - 1][i] >> 8) ^ t.slice[0][t.slice[k - 1][i] & 0xFFu];
+	uint32_t even[32], odd[32];
+	odd[0] = CRC32_POLYNOMIAL; // the operator for one zero bit, as in crc32_joined
+	uint32_t row = 1;
+	for (int k = 1; k < 32; ++k) { odd[k] = row; row <<= 1; }
+	gf2_matrix_square(even, odd); gf2_matrix_square(odd, even); // two, four zero bits
+	gf2_matrix_square(t.advance[0], odd);                        // eight: one zero byte
+	for (int k = 1; k < CRC32_ADVANCE_POWERS; ++k) gf2_matrix_square(t.advance[k], t.advance[k - 1]);
+}
+// crc32(0, bytes, n) of zlib, four bytes per step; `bytes` need not be aligned
+AGPU_HD uint32_t crc32_of_sliced(const uint32_t (*slice)[256], const uint8_t* bytes, size_t n) {
+	uint32_t c = 0xFFFFFFFFu;
+	size_t i = 0;
+	for (; i + 4 <= n; i += 4) {
+		uint32_t word; __builtin_memcpy(&word, bytes + i, 4);
+		c ^= word;
+		c = slice[3][c & 0xFFu] ^ slice[2][(c >> 8) & 0xFFu] ^ slice[1][(c >> 16) & 0xFFu] ^ slice[0][c >> 24];
+	}
+	for (; i < n; ++i) c = slice[0][(c ^ bytes[i]) & 0xFFu] ^ (c >> 8);
+	return c ^ 0xFFFFFFFFu;
+}
+// crc32 of A || B from crc32(A), crc32(B) and |B| < 2^17 with the prepared operators
+AGPU_HD uint32_t crc32_joined_with(const uint32_t (*advance)[32], uint32_t crc_a, uint32_t crc_b, uint32_t length_b) {
+	for (int k = 0; length_b != 0; length_b >>= 1, ++k) if (length_b & 1u) crc_a = gf2_matrix_times(advance[k], crc_a);
+	return crc_a ^ crc_b;
+}
+
 }
 
 #endif

@@ -69,6 +69,7 @@ struct ahost_session {
 	bool device_batch = false;           // the fragments live on the device (ahost_adopt_device_ingest)
 	std::string formatted_rows;          // ahost_format_fusions: the rows of this rank's share of an output file, until the next call
 	std::vector<uint32_t> row_fragments; // device ingest: the fragment of every row of ingest.batch (ascending); empty = the batch holds every fragment
+	bool rows_in_list_order = false;     // ... or row k holds the fragment of entry k of the read lists of the table written next (ahost_set_batch_rows without fragments)
 	std::vector<uint32_t> tid_to_contig;
 	std::vector<uint64_t> window_offset;
 	~ahost_session() { if (feed) close_bam_feed(feed); }
@@ -137,7 +138,7 @@ int ingest(ahost_session* session, ByteSource* source_raw, int external_duplicat
 		session->options.external_duplicate_marking = external_duplicate_marking != 0;
 		session->options.max_itd_length = max_itd_length;
 		session->ingest = IngestResult();
-		session->row_fragments.clear(); session->device_batch = false;
+		session->row_fragments.clear(); session->device_batch = false; session->rows_in_list_order = false;
 		read_chimeric_alignments(*source, session->assembly, session->contigs, session->annotation, session->gene_index, session->options, session->ingest);
 		session->build_genome_view();
 		session->build_batch_view();
@@ -269,7 +270,15 @@ static int write_or_format_fusions(ahost_session* session, const ahost_fusion_ta
 		// device ingest: the batch of the session holds only the rows fetched for this table (ahost_set_batch_rows); the read lists of the candidates
 		// that get written and the filter column are translated from fragments to rows
 		std::vector<uint32_t> lists_as_rows; std::vector<uint8_t> filter_of_rows;
-		if (print_extra_info && session->device_batch && t.n_candidates > 0) {
+		if (print_extra_info && session->device_batch && t.n_candidates > 0 && session->rows_in_list_order) {
+			// the rows came in the order of the read lists: entry k of the lists is row k, and the reads of a candidate lie next to each other in every column of the batch
+			// (the pile-ups of the writer walk them one after the other: with rows in fragment order every read is a cache miss in a dozen columns)
+			const size_t n_entries = t.list_offset[3 * (size_t) t.n_candidates];
+			if (session->ingest.batch.n != n_entries || table->read_filter_of_rows == NULL) throw std::runtime_error("rows in list order: one row and one filter per entry of the read lists expected (ahost_set_batch_rows, read_filter_of_rows)");
+			lists_as_rows.resize(n_entries);
+			for (size_t k = 0; k < n_entries; ++k) lists_as_rows[k] = (uint32_t) k;
+			t.read_lists = lists_as_rows.data(); t.read_filter = table->read_filter_of_rows;
+		} else if (print_extra_info && session->device_batch && t.n_candidates > 0) {
 			const std::vector<uint32_t>& fragments = session->row_fragments; // ascending
 			const size_t n_entries = t.list_offset[3 * (size_t) t.n_candidates];
 			lists_as_rows.resize(n_entries);
@@ -514,7 +523,7 @@ int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* 
 		}
 		r.batch = Batch();
 		r.batch.n = 0;
-		session->row_fragments.clear();
+		session->row_fragments.clear(); session->rows_in_list_order = false;
 		session->device_batch = true;
 		session->have_batch = true; // (an empty host batch: the fragments live on the device; ahost_set_batch_rows brings the rows the writer needs)
 		session->build_batch_view();
@@ -523,7 +532,7 @@ int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* 
 }
 
 int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments) {
-	if (!session || !rows || (!fragments && rows->n > 0)) { g_error = "null argument"; return -1; }
+	if (!session || !rows) { g_error = "null argument"; return -1; }
 	try {
 		Batch& b = session->ingest.batch; // (every member is assigned below: the vectors keep their memory from one file to the next)
 		const size_t n = rows->n;
@@ -538,8 +547,11 @@ int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, co
 		b.seq_pool.assign(rows->seq_pool, rows->seq_pool + rows->seq_pool_size);
 		b.name_offset.assign(rows->name_offset, rows->name_offset + n + 1);
 		b.names.assign(rows->names, rows->names_size);
-		session->row_fragments.assign(fragments, fragments + n);
-		for (size_t k = 1; k < n; ++k) if (fragments[k] <= fragments[k - 1]) throw std::runtime_error("fragments of the rows must ascend");
+		session->rows_in_list_order = fragments == NULL;
+		if (fragments != NULL) {
+			session->row_fragments.assign(fragments, fragments + n);
+			for (size_t k = 1; k < n; ++k) if (fragments[k] <= fragments[k - 1]) throw std::runtime_error("fragments of the rows must ascend");
+		} else session->row_fragments.clear();
 		session->have_batch = true;
 		session->build_batch_view();
 		return 0;

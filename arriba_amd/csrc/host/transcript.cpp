@@ -92,6 +92,23 @@ public:
 		last_[256 * N_SINGLE_ALLELES + ((position & 255) >> 5)] |= 1u << (position & 31);
 		last_[256 * N_SINGLE_ALLELES + 8 + (position & 255)] |= 1u << slot;
 	}
+	// single-character alleles at consecutive positions from `position` on, slot_at(k) = the slot of the k-th: the pages are looked up once per page, not once per base
+	template <class SlotAt> void add_run(position_t position, int n, SlotAt slot_at) {
+		for (int k = 0; k < n; ) {
+			const position_t page = position >> 8;
+			if (last_ == NULL || page != last_page_) { unsigned*& counts = pages_[page]; if (counts == NULL) counts = pile_page_pool.take(); last_ = counts; last_page_ = page; }
+			const int first = (int) (position & 255), in_page = std::min(n - k, 256 - first);
+			unsigned* row = last_ + (size_t) first * N_SINGLE_ALLELES; unsigned* masks = last_ + 256 * N_SINGLE_ALLELES + 8 + first;
+			for (int i = 0; i < in_page; ++i, row += N_SINGLE_ALLELES) { const int slot = slot_at(k + i); row[slot]++; masks[i] |= 1u << slot; }
+			for (int at = first; at < first + in_page; ) { // the bits of the touched positions, a word at a time
+				const int word = at >> 5, upto = std::min(first + in_page, (word + 1) << 5);
+				const unsigned bits = (upto - at == 32) ? 0xFFFFFFFFu : (((1u << (upto - at)) - 1u) << (at & 31));
+				last_[256 * N_SINGLE_ALLELES + word] |= bits;
+				at = upto;
+			}
+			k += in_page; position += in_page;
+		}
+	}
 	void add(position_t position, const std::string& allele) { // any allele (insertions; what std::string::substr gives at the end of a sequence)
 		if (allele.size() == 1 && slot_of(allele[0]) >= 0) add(position, slot_of(allele[0])); else other_[position][allele]++;
 	}
@@ -177,6 +194,8 @@ struct Reads { // the fragments of the sample and their final filters
 void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigned mate, bool reverse, bool upstream, position_t breakpoint, DensePileup& pileup) {
 	const Batch& b = reads.batch;
 	const int deletion_slot = pileup.slot_of('-');
+	int slot_of_code[16];
+	for (int code = 0; code < 16; ++code) slot_of_code[code] = pileup.slot_of("=ACMGRSVTWYHKDBN"[code]);
 	std::map<std::pair<position_t, position_t>, unsigned> introns;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t read = list[k];
@@ -186,9 +205,27 @@ void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigne
 		if (!is_split_read && // discordant mates: only those close to the breakpoint, distant ones may belong to other isoforms
 		    !((!upstream && forward && end <= breakpoint + 2 && end >= breakpoint - 200) || (upstream && !forward && start >= breakpoint - 2 && start <= breakpoint + 200))) continue;
 		if (is_split_read && (mate == SPLIT_READ || mate == SUPPLEMENTARY) && start != breakpoint && end != breakpoint) continue; // alternative alignments with shifted breakpoints
-		static thread_local std::string sequence; // (kept between the reads of a thread)
-		b.sequence_into(mate == SUPPLEMENTARY ? SPLIT_READ : mate, read, sequence);
-		if (reverse) { std::reverse(sequence.begin(), sequence.end()); for (size_t k = 0; k < sequence.size(); ++k) sequence[k] = complement_of(sequence[k]); }
+		// the bases of the read stay packed (4 bits each, "=ACMGRSVTWYHKDBN"): the pile-up takes the slot of a code from a table; the characters are only made for the rare
+		// alleles that are strings (insertions, what substr gives at the end of the sequence)
+		const unsigned sequence_slot = mate == SUPPLEMENTARY ? SPLIT_READ : mate;
+		const uint8_t* packed = &b.seq_pool[0] + (size_t) b.seq_offset[sequence_slot][read] * 4;
+		const size_t sequence_length = b.seq_length[sequence_slot][read];
+		static const uint8_t complement_code[16] = { 0, 8, 4, 3, 2, 5, 6, 7, 1, 9, 10, 11, 12, 13, 14, 15 }; // A <-> T, C <-> G, the ambiguity codes as they are (complement_of)
+		auto slot_at = [&](size_t i) -> int {
+			const size_t j = reverse ? sequence_length - 1 - i : i;
+			const unsigned code = (packed[j >> 1] >> ((~j & 1) << 2)) & 15;
+			return slot_of_code[reverse ? complement_code[code] : code];
+		};
+		static thread_local std::string sequence; // (kept between the reads of a thread; filled when a string is needed)
+		bool have_sequence = false;
+		auto need_sequence = [&]() -> const std::string& {
+			if (!have_sequence) {
+				b.sequence_into(sequence_slot, read, sequence);
+				if (reverse) { std::reverse(sequence.begin(), sequence.end()); for (size_t c = 0; c < sequence.size(); ++c) sequence[c] = complement_of(sequence[c]); }
+				have_sequence = true;
+			}
+			return sequence;
+		};
 		position_t read_offset = 0, reference_offset = start;
 		int borrowed = 0; // an insertion takes one base of the next element along
 		const uint32_t* cigar = &b.cigar_pool[b.cigar_offset[mate][read]];
@@ -198,7 +235,7 @@ void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigne
 			bool consume_bases = false;
 			switch (operation) {
 				case CIGAR_INSERTION:
-					pileup.add(reference_offset, sequence.substr(read_offset, length + 1));
+					pileup.add(reference_offset, need_sequence().substr(read_offset, length + 1));
 					read_offset += length + 1; ++reference_offset; borrowed = 1;
 					break;
 				case CIGAR_SKIP: {
@@ -228,11 +265,12 @@ void add_to_pileup(const Reads& reads, const uint32_t* list, uint32_t n, unsigne
 					break;
 			}
 			if (consume_bases) {
-				for (int base = 0; base < length - borrowed; ++base, ++read_offset, ++reference_offset) {
-					// (std::string::substr semantics of the reference: a position at the end of the sequence gives the empty allele, beyond it is an error)
-					if ((size_t) read_offset < sequence.size() && pileup.slot_of(sequence[read_offset]) >= 0) pileup.add(reference_offset, pileup.slot_of(sequence[read_offset]));
-					else pileup.add(reference_offset, sequence.substr(read_offset, 1));
-				}
+				const int bases = length - borrowed;
+				const int inside = read_offset < 0 ? 0 : (int) std::min<long long>(bases, (long long) sequence_length - read_offset); // bases that lie inside the sequence
+				if (inside > 0) { const position_t from = read_offset; pileup.add_run(reference_offset, inside, [&](int k) { return slot_at((size_t) (from + k)); }); }
+				// (std::string::substr semantics of the reference: a position at the end of the sequence gives the empty allele, beyond it is an error)
+				for (int base = inside > 0 ? inside : 0; base < bases; ++base) pileup.add(reference_offset + base, need_sequence().substr(read_offset + base, 1));
+				read_offset += bases; reference_offset += bases;
 				borrowed = 0;
 			}
 		}

@@ -174,13 +174,20 @@ void read_chimeric_alignments_on_device(Run& run) {
 	if (run.timing) { run.timing->feed = fed - started; run.timing->ingest = finished - fed; run.timing->adopt = now_seconds() - finished; }
 }
 
-// the writer prints names, CIGAR-derived pileups and sequences of the supporting reads of the candidates it writes: their rows come back from the device, and their filters
-void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discarded, bool filters_of_rows) {
+// the writer prints names, CIGAR-derived pileups and sequences of the supporting reads of the candidates it writes: their rows come back from the device, and their filters.
+// in_list_order (fusions.tsv): one row per entry of the read lists, in their order -- the reads of a candidate lie next to each other in every column, which is how the writer
+// walks them; otherwise (discarded.tsv with -X: millions of candidates that share their discordant mates) one row per fragment, in fragment order.
+void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discarded, bool in_list_order) {
 	if (!run.device_ingest) return;
 	uint64_t count = 0;
-	host_check(ahost_fusion_table_reads(&table, write_discarded, nullptr, 0, &count));
-	uint32_t* fragments = run.stage<uint32_t>("rows.fragments", count);
-	host_check(ahost_fusion_table_reads(&table, write_discarded, fragments, count, &count));
+	const uint32_t* fragments = nullptr;
+	if (in_list_order) { count = table.list_offset[3 * (size_t) table.n_candidates]; fragments = table.read_lists; }
+	else {
+		host_check(ahost_fusion_table_reads(&table, write_discarded, nullptr, 0, &count));
+		uint32_t* unique = run.stage<uint32_t>("rows.fragments", count);
+		host_check(ahost_fusion_table_reads(&table, write_discarded, unique, count, &count));
+		fragments = unique;
+	}
 	uint64_t cigar_words = 0, sequence_bytes = 0, name_bytes = 0;
 	device_check(agpu_gather_rows_begin(run.device, fragments, count, &cigar_words, &sequence_bytes, &name_bytes));
 	agpu_batch_rows rows;
@@ -197,12 +204,10 @@ void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discar
 	rows.cigar_pool = run.stage<uint32_t>("rows.cigar_pool", cigar_words + 1); rows.seq_pool = run.stage<uint8_t>("rows.seq_pool", sequence_bytes + 4);
 	rows.name_offset = run.stage<uint32_t>("rows.name_offset", count + 1); rows.names = run.stage<char>("rows.names", name_bytes + 1);
 	device_check(agpu_gather_rows_copy(run.device, &rows));
-	if (filters_of_rows) { // the filters of these fragments only, instead of one byte for every fragment of the sample
-		uint8_t* filters = run.stage<uint8_t>("rows.filter", count);
-		device_check(agpu_get_filters_of(run.device, fragments, count, filters));
-		table.read_filter_of_rows = filters;
-	}
-	host_check(ahost_set_batch_rows(run.host, &rows, count > 0 ? fragments : nullptr));
+	uint8_t* filters = run.stage<uint8_t>("rows.filter", count); // the filters of these fragments only, instead of one byte for every fragment of the sample
+	device_check(agpu_get_filters_of(run.device, fragments, count, filters));
+	table.read_filter_of_rows = filters;
+	host_check(ahost_set_batch_rows(run.host, &rows, in_list_order ? nullptr : (count > 0 ? fragments : nullptr)));
 }
 
 // the output files: the device's results brought back, formatted by the host library (source/arriba.cpp:586-610).  Only the candidates a file will hold
@@ -254,7 +259,7 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 			table.read_filter = read_filter;
 		}
 		lap(&arriba_workflow_timing::output_results);
-		if (rows_from_device) fetch_rows_for_writer(run, table, write_discarded, true);
+		if (rows_from_device) fetch_rows_for_writer(run, table, write_discarded, write_discarded == 0);
 		lap(&arriba_workflow_timing::output_rows);
 		host_check(ahost_write_fusions(run.host, &table, write_discarded ? run.options.discarded_output_file : run.options.output_file, write_discarded, print_extra_info, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
 		lap(&arriba_workflow_timing::output_format);

@@ -415,6 +415,15 @@ def main():
         fusion_lines = sum(1 for line in open(outputs[0]) if not line.startswith("#")) if writes_files else stage_log[-1][1]
         if not stage_log or stage_log[-1][0] != "recover_isoforms" or fusion_lines != stage_log[-1][1]:
             self_check.append("fusions.tsv holds %d fusions, the last stage counted %s" % (fusion_lines, stage_log[-1:] or None))
+        # the sample of config 2 (10 M fragments) is the one the unmodified reference was run on once (tests/golden/bench10m): the file written by the last timed step must be its file
+        reference_check = None
+        golden = os.path.join(ROOT, "tests", "golden", "bench10m", "meta.json")
+        if writes_files and args.fragments == 10000000 and not args.stress and not args.discarded and os.path.exists(golden):
+            import hashlib
+            meta = json.load(open(golden))
+            if hashlib.sha256(open(outputs[0], "rb").read()).hexdigest() != meta["fusions_tsv_sha256"]:
+                self_check.append("fusions.tsv differs from the file the unmodified reference writes for this sample (tests/golden/bench10m)")
+            reference_check = "fusions.tsv of the last timed step is byte-identical (SHA-256) to the file the unmodified reference wrote for this very sample (tests/golden/bench10m: %d fusions, reference run time %.0f s where the repository was built)" % (meta["fusions"], meta["reference_seconds_in_the_build_container"])
         if self_check:
             raise SystemExit("bench self-check failed: " + "; ".join(self_check))
 
@@ -483,7 +492,7 @@ def main():
                 best = max(streaming, key=streaming.get)
                 line["roofline_streaming"] = {"bound": "hbm", "kernel": best, "achieved": streaming[best], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": streaming[best] / HBM_PEAK_GBS,
                                               "launch_ms": kernels[best]["ms"] / kernels[best]["launches"], "algorithmic_bytes_per_launch": kernels[best]["bytes"] / kernels[best]["launches"]}
-            line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted"
+            line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted" + ("; " + reference_check if reference_check else "")
             progress("self-check done, kernel profile read")
             if args.no_cpu_baseline or distributed:  # (timed at N = 1 only)
                 line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped: the reference is timed by the run with 1 GPU" if distributed else "skipped"}

@@ -55,7 +55,8 @@ int ahost_bam_open_part(ahost_session* session, const char* bam_path, int extern
 int ahost_bam_next(ahost_session* session, void* buffer, size_t capacity, agpu_bgzf_block* blocks, uint32_t block_capacity, ahost_bam_piece* piece);
 void ahost_bam_close(ahost_session* session);
 int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* result, const uint64_t* viral_read_counts, const uint16_t* coverage, const uint8_t* fragment_starts, const uint8_t* fragment_ends);
-int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments /* [rows->n] ascending: the fragment every row holds */);
+int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments /* [rows->n] ascending: the fragment every row holds; NULL: row k holds the fragment
+                         of entry k of the read lists of the table the next ahost_write_fusions writes (the reads of a candidate next to each other; the table then carries read_filter_of_rows) */);
 
 /* A blacklist (allow_keywords = 1: the second column may hold a keyword, source/filter_blacklisted_ranges.cpp:91-102) or a known-fusions file
  * (allow_keywords = 0) parsed into rules for agpu_filter_blacklisted_ranges / agpu_recover_known_fusions (parse_blacklist_item, parse_range:

@@ -1,6 +1,7 @@
 """GPU tier: the HIP kernels, called through the C ABI of libarriba_gpu.so, against the golden dumps of the reference
 and (when the prebuilt oracle binary travelled with the repo) against the reference run live on a fresh dataset."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -628,6 +629,42 @@ def test_workflow_at_config_scale_against_the_live_reference(built, tmp_path):
     os.makedirs(str(tmp_path / "mine"))
     stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True)
     assert dict(stages)["find_fusions"] > fragments // 5 and stages[-1][1] > 100
+
+
+def test_bench_sample_of_config_2_against_the_reference(built, tmp_path):
+    """BASELINE.json config 2 at FULL size, exactly the sample bench.py times at 10 M (10 444 615 fragments, 26.6 M BAM records): the product path -- arriba_workflow_sample of the
+    C++ workflow library, resident session -- against the unmodified reference, which was run once on this very sample where the repository is built (7 min 40 s, 15.9 GB:
+    tests/golden/bench10m): the generated BAM file is the one the reference read (SHA-256), fusions.tsv is the one it wrote (SHA-256), and the counts of its log are met."""
+    import hashlib
+    import json
+    import subprocess
+    import bench
+    from arriba_amd.pipeline import WorkflowSession
+    golden = conftest.golden_dir("bench10m")
+    meta = json.load(open(os.path.join(golden, "meta.json")))
+    prefix = str(tmp_path / "bench")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(bench.cpu_budget())] + bench.workload_args(10000000, 1000), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def sha256(path):
+        digest = hashlib.sha256()
+        with open(path, "rb") as stream:
+            for piece in iter(lambda: stream.read(1 << 24), b""):
+                digest.update(piece)
+        return digest.hexdigest()
+    assert sha256(prefix + ".bam") == meta["bam_sha256"], "the generator drifted from the sample the reference was run on (tests/golden/bench10m/meta.json)"
+    session = WorkflowSession(prefix + ".fa", prefix + ".gtf")
+    for repeat in range(2):  # (a resident session: the second sample through the same buffers)
+        output = str(tmp_path / ("fusions%d.tsv" % repeat))
+        counts = dict(session.sample(prefix + ".bam", output))
+        assert sha256(output) == meta["fusions_tsv_sha256"], repeat
+    log = open(os.path.join(golden, "reference.log")).read()
+    assert counts["read_chimeric_alignments"] == int(re.search(r"Reading chimeric alignments[^\n]*\(total=(\d+)\)", log).group(1))
+    for stage, pattern in (("filter_duplicates", "Filtering duplicates"), ("filter_mismatches", "Filtering reads with a mismatch"), ("filter_low_entropy", "Filtering reads with low entropy"), ("merge_adjacent_fusions", "Merging adjacent fusion breakpoints"),
+                           ("filter_relative_support", "Filtering fusions with an e-value"), ("filter_in_vitro", "Filtering in vitro-generated fusions"), ("filter_homologs", "Filtering genes with"),
+                           ("filter_mismappers", "Re-aligning chimeric reads"), ("recover_isoforms", "Searching for additional isoforms")):
+        assert counts[stage] == parity.logged_remaining(log, pattern), stage
+    assert counts["recover_isoforms"] == meta["fusions"]
+    session.close()
 
 
 def test_mismapper_stress_at_scale_against_the_live_reference(built, tmp_path):

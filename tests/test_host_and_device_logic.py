@@ -403,7 +403,7 @@ def test_device_ingest_in_parts_gives_the_batch_of_the_whole_file(built, dataset
 
 
 def test_stored_blocks_are_checked_against_their_crc(built, dataset_files, emu_api, tmp_path, monkeypatch):
-    """Stored BGZF blocks go to the device as they are; with ARRIBA_VERIFY_CRC=1 their payload is checked against the CRC-32 of the trailer (crc32_core.hpp, stepped
+    """Stored BGZF blocks go to the device as they are; their payload is checked against the CRC-32 of the trailer (ARRIBA_VERIFY_CRC=0 switches the check off) (crc32_core.hpp, stepped
     here as the kernel does it: 256-byte chunks joined in a tree; the core is checked against zlib on random blocks).  One flipped base of one read -- a record that
     still parses -- is found; the intact file, whole and in parts (whose first and last blocks are delivered in part and carry no CRC), is accepted."""
     import zlib
@@ -428,8 +428,8 @@ def test_stored_blocks_are_checked_against_their_crc(built, dataset_files, emu_a
     open(damaged, "wb").write(bytes(raw))
     with pytest.raises(ArribaError, match="failed to load alignments"):
         DevicePipeline(HostSession(prefix + ".fa", prefix + ".gtf"), api=emu_api, bam=damaged)
-    monkeypatch.delenv("ARRIBA_VERIFY_CRC")
-    DevicePipeline(HostSession(prefix + ".fa", prefix + ".gtf"), api=emu_api, bam=damaged)  # (without the check the damage goes unnoticed: a quality value or a base differs)
+    monkeypatch.setenv("ARRIBA_VERIFY_CRC", "0")
+    DevicePipeline(HostSession(prefix + ".fa", prefix + ".gtf"), api=emu_api, bam=damaged)  # (without the check -- it is on by default, as in htslib -- the damage goes unnoticed: a quality value or a base differs)
 
 
 def test_device_ingest_survives_a_false_record_start(built, dataset_files, emu_api, tmp_path):
