@@ -586,6 +586,8 @@ void agpu_destroy(agpu_ctx* ctx) {
 	collect_kernel_samples(ctx);
 	for (size_t k = 0; k < ctx->event_pool.size(); ++k) (void) hipEventDestroy(ctx->event_pool[k]);
 	if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+	if (ctx->crc_stream) { (void) hipStreamSynchronize(ctx->crc_stream); (void) hipStreamDestroy(ctx->crc_stream); for (int k = 0; k < 2; ++k) { (void) hipEventDestroy(ctx->crc_copied[k]); (void) hipEventDestroy(ctx->crc_checked[k]); } }
+	for (int k = 0; k < 2; ++k) if (ctx->ingest_events[k]) (void) hipEventDestroy(ctx->ingest_events[k]);
 	delete ctx;
 }
 

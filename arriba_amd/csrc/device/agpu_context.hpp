@@ -117,6 +117,7 @@ struct agpu_ctx {
 	agpu::DeviceBuffer ingest_qname_keys; uint64_t ingest_qname_runs = 0; // a part of a sample: 128-bit keys of the runs of read names in its stream
 	agpu_ingest_result ingest_result; uint64_t ingest_pool_sizes[2] = { 0, 0 }; // what the last ingest (or merge of parts) reported; CIGAR words and sequence bytes of its pools
 	hipEvent_t ingest_events[2] = { nullptr, nullptr };
+	hipStream_t crc_stream = nullptr; hipEvent_t crc_copied[2] = { nullptr, nullptr }, crc_checked[2] = { nullptr, nullptr }; // the CRC check of a pushed piece runs beside the copy of the next one
 	std::vector<uint64_t> host_coverage_window_offset;
 	agpu::DeviceBuffer gather_ids, gather_cigar_base, gather_seq_base, gather_name_base; // agpu_gather_rows_begin -> _copy
 	uint64_t gather_n = 0, gather_sizes[3] = { 0, 0, 0 };
@@ -149,7 +150,7 @@ struct agpu_ctx {
 	bool evalue_done = false, iteration_order_done = false;
 
 	// k-mer index + splice sites (filter_mismappers)
-	agpu::DeviceBuffer kmer_contig_table, kmer_offsets, kmer_positions, splice_offset, splice_sites;
+	agpu::DeviceBuffer kmer_contig_table, kmer_offsets, kmer_positions, splice_offset, splice_sites, splice_bits;
 	uint32_t kmer_positions_count = 0, splice_sites_for_dummy = 0, mismapper_jobs = 0, mismapper_heavy = 0;
 	bool kmer_index_done = false, have_splice_sites = false, mismapper_jobs_ready = false;
 	agpu::CandidateTable candidates;

@@ -488,6 +488,10 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	for (int k = 0; k < 2; ++k) if (!ctx->ingest_events[k]) HIP_CHECK(hipEventCreateWithFlags(&ctx->ingest_events[k], hipEventDisableTiming));
+	if (!ctx->crc_stream) {
+		HIP_CHECK(hipStreamCreateWithFlags(&ctx->crc_stream, hipStreamNonBlocking));
+		for (int k = 0; k < 2; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->crc_copied[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->crc_checked[k], hipEventDisableTiming)); }
+	}
 	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
 	{ const char* knob = getenv("ARRIBA_VERIFY_CRC"); ctx->ingest_verify_crc = !(knob != nullptr && knob[0] == '0'); } // (the stored blocks are checked as htslib checks them; "0": a measurement without)
 	ALLOC(ctx->scratch("ingest.crc_mismatches"), 4);
@@ -539,14 +543,17 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 	if (n_blocks > 0 && raw_size > 0) {
 		TRY(grow_stream(ctx, ctx->ingest_stream_size + stream_bytes));
 		ALLOC(ctx->ingest_raw[slot], raw_size); ALLOC(ctx->ingest_blocks[slot], (size_t) n_blocks * sizeof(agpu_bgzf_block));
+		if (ctx->ingest_verify_crc) HIP_CHECK(hipStreamWaitEvent(s, ctx->crc_checked[slot], 0)); // (the check of the piece that lay in this buffer is done; an event that was never recorded does not hold anybody up)
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_raw[slot].ptr, raw, raw_size, hipMemcpyHostToDevice, s));
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_blocks[slot].ptr, blocks, (size_t) n_blocks * sizeof(agpu_bgzf_block), hipMemcpyHostToDevice, s));
 		{ KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes);
 		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
 		ctx->ingest_stream_size += stream_bytes;
-		if (ctx->ingest_verify_crc) {
-			KernelTimer timer(ctx, "bgzf_crc_kernel", (uint64_t) stream_bytes);
-			bgzf_crc_kernel<<<n_blocks, 256, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+		if (ctx->ingest_verify_crc) { // on a stream of its own: the copy of the next piece need not wait for it (0.95 ms per 256 MB piece, 0.3 s of a 54 GB file when it sits between the copies)
+			HIP_CHECK(hipEventRecord(ctx->crc_copied[slot], s));
+			HIP_CHECK(hipStreamWaitEvent(ctx->crc_stream, ctx->crc_copied[slot], 0));
+			bgzf_crc_kernel<<<n_blocks, 256, 0, ctx->crc_stream>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+			HIP_CHECK(hipEventRecord(ctx->crc_checked[slot], ctx->crc_stream));
 		}
 	}
 	HIP_CHECK(hipEventRecord(ctx->ingest_events[slot], s));
@@ -563,6 +570,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
 	if (ctx->ingest_verify_crc) { // a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch")
+		HIP_CHECK(hipStreamSynchronize(ctx->crc_stream));
 		unsigned int mismatches = 0;
 		HIP_CHECK(hipMemcpyAsync(&mismatches, ctx->scratch("ingest.crc_mismatches").ptr, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));

@@ -105,7 +105,7 @@ __global__ void kmer_offsets_kernel(const uint32_t* sorted_keys, uint32_t n, uin
 }
 
 // reference: get_downstream_splice_sites (source/filter_mismappers.cpp:16-31); write == false counts
-__global__ void splice_site_kernel(AnnotationView ann, uint32_t n_genes_total, const uint32_t* offsets, uint32_t* counts, int32_t* sites, bool write) {
+__global__ void splice_site_kernel(AnnotationView ann, GenomeView genome, uint32_t n_genes_total, const uint32_t* offsets, uint32_t* counts, int32_t* sites, uint32_t* bits, bool write) {
 	uint32_t gene = blockIdx.x * BLOCK + threadIdx.x;
 	if (gene >= n_genes_total) return;
 	const FlatIndexView& index = ann.exon_index;
@@ -117,7 +117,11 @@ __global__ void splice_site_kernel(AnnotationView ann, uint32_t n_genes_total, c
 		const int32_t gene_end = ann.gene_end[gene];
 		for (; k != contig_end && index.keys[k] <= gene_end; ++k)
 			if (is_breakpoint_spliced(ann, gene, false, index.keys[k])) {
-				if (write) sites[offsets[gene] + found] = index.keys[k];
+				if (write) { // ... and its bit in the map of all splice sites (SpliceSiteView::bits)
+					sites[offsets[gene] + found] = index.keys[k];
+					const uint64_t bit = genome.contig_offset[contig] + (uint64_t) index.keys[k];
+					if (index.keys[k] >= 0 && contig < genome.n_contigs && bit < genome.contig_offset[genome.n_contigs]) atomicOr(&bits[bit >> 5], 1u << (bit & 31));
+				}
 				++found;
 			}
 	}
@@ -189,7 +193,7 @@ __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, Annota
 	__shared__ AlignWorklist worklist;
 	__shared__ uint32_t worklist_state[4];
 	__shared__ uint32_t next_job;
-	__shared__ uint32_t study[4];
+	__shared__ uint32_t study[8];
 	if (threadIdx.x == 0) {
 		worklist.stats = read_times != nullptr ? study : nullptr;
 		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0;
@@ -211,12 +215,13 @@ __global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, Annota
 		if (next_job >= n_heavy) break;
 		const uint32_t read = heavy[next_job];
 		const unsigned long long started = read_times != nullptr ? wall_clock64() : 0ull;
-		if (read_times != nullptr && threadIdx.x == 0) { study[0] = 0; study[1] = 0; study[2] = 0; study[3] = 0; }
+		if (read_times != nullptr && threadIdx.x == 0) for (int k = 0; k < 8; ++k) study[k] = 0;
 		const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
 		if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
 		if (read_times != nullptr && threadIdx.x == 0) { // (ARRIBA_MISMAPPER_TIMES=1: ticks of the 100 MHz clock per read, and what the search of the read consisted of)
 			read_times[4 * (size_t) next_job] = wall_clock64() - started; read_times[4 * (size_t) next_job + 1] = (unsigned long long) study[0] << 32 | study[1]; read_times[4 * (size_t) next_job + 2] = (unsigned long long) study[2] << 32 | study[3];
 			read_times[4 * (size_t) next_job + 3] = (unsigned long long) read << 8 | b.n_aln[read];
+			atomicAdd(&read_times[4 * (size_t) n_heavy], (unsigned long long) study[4]); atomicAdd(&read_times[4 * (size_t) n_heavy + 1], (unsigned long long) study[5]); atomicAdd(&read_times[4 * (size_t) n_heavy + 2], (unsigned long long) study[6]);
 		}
 	}
 }
@@ -251,7 +256,7 @@ int build_splice_sites(agpu_ctx* ctx) {
 	DeviceBuffer& counts = ctx->scratch("mismappers.splice_counts"); DeviceBuffer& scratch = ctx->scratch("mismappers.rocprim");
 	ALLOC(counts, ((size_t) n_genes_total + 1) * 4); ALLOC(ctx->splice_offset, ((size_t) n_genes_total + 1) * 4);
 	HIP_CHECK(hipMemsetAsync(counts.ptr, 0, ((size_t) n_genes_total + 1) * 4, s));
-	splice_site_kernel<<<grid_for(n_genes_total), BLOCK, 0, s>>>(ctx->annotation, n_genes_total, nullptr, counts.as<uint32_t>(), nullptr, false);
+	splice_site_kernel<<<grid_for(n_genes_total), BLOCK, 0, s>>>(ctx->annotation, ctx->genome, n_genes_total, nullptr, counts.as<uint32_t>(), nullptr, nullptr, false);
 	size_t bytes = 0;
 	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, counts.as<uint32_t>(), ctx->splice_offset.as<uint32_t>(), 0u, (size_t) n_genes_total + 1, rocprim::plus<uint32_t>(), s));
 	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
@@ -260,7 +265,10 @@ int build_splice_sites(agpu_ctx* ctx) {
 	HIP_CHECK(hipMemcpyAsync(&total, ctx->splice_offset.as<uint32_t>() + n_genes_total, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	ALLOC(ctx->splice_sites, (size_t) std::max<uint32_t>(total, 1) * 4);
-	splice_site_kernel<<<grid_for(n_genes_total), BLOCK, 0, s>>>(ctx->annotation, n_genes_total, ctx->splice_offset.as<uint32_t>(), nullptr, ctx->splice_sites.as<int32_t>(), true);
+	const size_t bitmap_bytes = ((size_t) (ctx->host_contig_offset[ctx->genome.n_contigs] + 31) / 32 + 16) * 4; // (a walk looks up to a read length behind a position: room behind the last contig)
+	ALLOC(ctx->splice_bits, bitmap_bytes);
+	HIP_CHECK(hipMemsetAsync(ctx->splice_bits.ptr, 0, bitmap_bytes, s));
+	splice_site_kernel<<<grid_for(n_genes_total), BLOCK, 0, s>>>(ctx->annotation, ctx->genome, n_genes_total, ctx->splice_offset.as<uint32_t>(), nullptr, ctx->splice_sites.as<int32_t>(), ctx->splice_bits.as<uint32_t>(), true);
 	ctx->splice_sites_for_dummy = ctx->n_dummy;
 	ctx->have_splice_sites = true;
 	return AGPU_OK;
@@ -382,7 +390,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 	KmerIndexView kmers;
 	kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
 	SpliceSiteView splice;
-	splice.offset = ctx->splice_offset.as<uint32_t>(); splice.sites = ctx->splice_sites.as<int32_t>();
+	splice.offset = ctx->splice_offset.as<uint32_t>(); splice.sites = ctx->splice_sites.as<int32_t>(); splice.bits = ctx->splice_bits.as<uint32_t>();
 	(void) hipEventRecord(ctx->event_start, s);
 	const bool enabled = ctx->params.filter_enabled[FILTER_mismappers] != 0; // switched off with -f: the reference skips the stage (source/arriba.cpp:562); no read and no candidate is touched, the unfiltered candidates are counted
 	uint32_t n_jobs = ctx->mismapper_jobs;
@@ -454,13 +462,13 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const bool by_sweep = !(knob != nullptr && knob[0] == '0');
 				const bool want_times = getenv("ARRIBA_MISMAPPER_TIMES") != nullptr; // a study: how long the wavefronts worked on every read of the second pass, on stderr
 				DeviceBuffer& read_times = ctx->scratch("mismappers.read_times");
-				if (want_times) ALLOC(read_times, (size_t) n_heavy * 32);
+				if (want_times) { ALLOC(read_times, (size_t) n_heavy * 32 + 32); HIP_CHECK(hipMemsetAsync(read_times.as<unsigned long long>() + 4 * (size_t) n_heavy, 0, 32, s)); }
 				{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
 				  mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
 				                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters); }
 				if (want_times) {
-					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy);
-					HIP_CHECK(hipMemcpyAsync(ticks.data(), read_times.ptr, (size_t) n_heavy * 32, hipMemcpyDeviceToHost, s));
+					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy + 4);
+					HIP_CHECK(hipMemcpyAsync(ticks.data(), read_times.ptr, (size_t) n_heavy * 32 + 32, hipMemcpyDeviceToHost, s));
 					HIP_CHECK(hipStreamSynchronize(s));
 					unsigned long long histogram[40] = { 0 }, total = 0, longest = 0, sums[4] = { 0, 0, 0, 0 };
 					std::vector<std::pair<unsigned long long, uint32_t> > by_time(n_heavy);
@@ -473,7 +481,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 					std::sort(by_time.begin(), by_time.end());
 					fprintf(stderr, "[mismapper_heavy_kernel] %u reads of %u jobs, %u workgroups, sweep %d: %.1f ms of wavefront time in all, longest read %.2f ms; calls listed %llu, calls reaching into the blocks %llu, seeds %llu, walks %llu; reads by time (us):", n_heavy, n_jobs, workgroups, (int) by_sweep, total / 1e5, longest / 1e5, sums[0], sums[1], sums[2], sums[3]);
 					for (int bucket = 0; bucket < 40; ++bucket) if (histogram[bucket]) fprintf(stderr, " 2^%d:%llu", bucket, histogram[bucket]);
-					fprintf(stderr, "\n");
+					fprintf(stderr, "\n[mismapper_heavy_kernel] of the wavefront time: look-ups of the seeds %.1f ms, calls of the blocks collected %.1f ms, seeds %.1f ms\n", ticks[4 * (size_t) n_heavy] / 1e5, ticks[4 * (size_t) n_heavy + 1] / 1e5, ticks[4 * (size_t) n_heavy + 2] / 1e5);
 					for (uint32_t rank = 0; rank < 24 && rank < n_heavy; ++rank) { // the slowest reads, and every 1/8 quantile below them
 						const uint32_t k = by_time[rank < 16 ? n_heavy - 1 - rank : (size_t) (n_heavy - 1) * (24 - rank) / 9].second;
 						fprintf(stderr, "[mismapper_heavy_kernel]   read %llu (%llu alignments): %.2f ms, calls listed %llu, reaching into blocks %llu, seeds %llu, walks %llu\n", ticks[4 * (size_t) k + 3] >> 8, ticks[4 * (size_t) k + 3] & 255, ticks[4 * (size_t) k] / 1e5,

@@ -26,6 +26,9 @@ struct KmerIndexView {
 struct SpliceSiteView {
 	const uint32_t* offset;         // [n_genes + n_dummy + 1]
 	const int32_t* sites;           // downstream splice sites of the gene, ascending
+	// a bit per position of the genome (bit genome.contig_offset[contig] + position): set where ANY gene has a downstream splice site, or null.  A walk that finds no bit
+	// set over the positions it can reach has no splice site of its gene to look for and skips the binary search over the gene's sites (eight dependent look-ups per seed)
+	const uint32_t* bits = nullptr;
 };
 
 // reference: kmer_to_int (source/filter_mismappers.cpp:33-45) on the genome's ASCII bases: T=0, G=1, C=2, everything else 3
@@ -62,7 +65,19 @@ struct AlignTarget { // one gene window on one contig
 	const int32_t* positions;
 	const int32_t* splice_sites; uint32_t n_splice_sites;
 	int32_t gene_start, gene_end;
+	const uint32_t* splice_bits = nullptr; uint64_t splice_bit_base = 0; // SpliceSiteView::bits and the bit of position 0 of the contig
 };
+// is a bit set among bits [first, last] of a bitmap?
+AGPU_HD bool any_bit_in_range(const uint32_t* bits, uint64_t first, uint64_t last) {
+	uint32_t found = 0;
+	for (uint64_t word = first >> 5; word <= (last >> 5); ++word) {
+		uint32_t mask = 0xFFFFFFFFu;
+		if (word == (first >> 5)) mask &= 0xFFFFFFFFu << (first & 31);
+		if (word == (last >> 5)) mask &= 0xFFFFFFFFu >> (31 - (last & 31));
+		found |= bits[word] & mask;
+	}
+	return found != 0;
+}
 
 AGPU_HD uint32_t lower_bound_i32(const int32_t* values, uint32_t lo, uint32_t hi, int32_t value) {
 	while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (values[mid] < value) lo = mid + 1; else hi = mid; }
@@ -187,7 +202,8 @@ struct AlignWorklist {
 	uint32_t* state;                              // [0] tasks listed, [1] overflow, [2] found (memory the lanes of the runner share: LDS on the device)
 	AlignSweep* sweep;                            // null: the schedule of round 2 (the lanes take whole calls from the list in rounds)
 	unsigned long long* relevant_words; uint32_t relevant_capacity; // the calls of a block beyond ALIGN_SWEEP_CALLS (two words per call; may be null: such a search is left to the recursion)
-	uint32_t* stats;                              // null, or a study: [0] calls listed, [1] calls that reached into a block (summed over the blocks), [2] seeds, [3] walks, shared by the lanes
+	uint32_t* stats;                              // null, or a study: [0] calls listed, [1] calls that reached into a block (summed over the blocks), [2] seeds, [3] walks, shared by the lanes;
+	                                              // [4..6] ticks of the 100 MHz clock in the look-ups of the seeds / the collection of the calls of the blocks / the seeds (lane 0's view)
 	AGPU_HD void push(const AlignTask& task) const {
 #if defined(__HIP_DEVICE_COMPILE__)
 		const uint32_t at = atomicAdd(&state[0], 1u);
@@ -432,8 +448,12 @@ AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int
 	if (extended_score >= min_score) return true;
 	int32_t extended_read_pos = read_pos + KMER_LENGTH, extended_gene_pos = kmer_hit + KMER_LENGTH;
 	uint32_t mismatch_count = 0, consecutive_mismatches = 0;
-	uint32_t splice_cursor = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, extended_gene_pos - 1);
-	int32_t next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF; // the first splice site at or behind extended_gene_pos - 1
+	// the first splice site at or behind extended_gene_pos - 1 -- if the walk can reach one at all: it compares positions extended_gene_pos - 1 ... + (length - extended_read_pos)
+	uint32_t splice_cursor = target.n_splice_sites; int32_t next_site = 0x7FFFFFFF;
+	if (target.splice_bits == nullptr || any_bit_in_range(target.splice_bits, target.splice_bit_base + (uint64_t) (extended_gene_pos - 1), target.splice_bit_base + (uint64_t) (extended_gene_pos - 1) + (uint64_t) (length - extended_read_pos))) {
+		splice_cursor = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, extended_gene_pos - 1);
+		next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF;
+	}
 	uint64_t window = 0; int32_t window_at = 0, window_end = 0;                // genome bases [window_at, window_end) of the contig
 	uint64_t read_window = 0; int32_t read_window_at = 0, read_window_end = 0; // bases [read_window_at, read_window_end) of the read
 	ALIGN_SEED_STEP();
@@ -650,6 +670,12 @@ struct AlignRunner {
 			outermost.flags |= align_iterations(outermost, length, min_score) << ALIGN_TASK_ITERATIONS_SHIFT;
 			worklist->push(outermost);
 		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		unsigned long long tick = worklist->stats != nullptr ? wall_clock64() : 0ull;
+#define SWEEP_LAP(slot) do { if (worklist->stats != nullptr && lane == 0) { const unsigned long long now_ = wall_clock64(); worklist->stats[slot] += (uint32_t) (now_ - tick); tick = now_; } else if (worklist->stats != nullptr) tick = wall_clock64(); } while (0)
+#else
+#define SWEEP_LAP(slot) ((void) 0)
+#endif
 		// the seeds of every read position: the hits of its 8-mer from the start of the gene to its end (source/filter_mismappers.cpp:100-106)
 		for (int32_t read_pos = (int32_t) first_of_mine(width); read_pos < length; read_pos += (int32_t) stride_of_mine(width)) {
 			uint32_t first = 0, count = 0;
@@ -663,6 +689,7 @@ struct AlignRunner {
 			sweep.hit_first[read_pos] = first; sweep.hit_count[read_pos] = count;
 		}
 		sync_lanes();
+		SWEEP_LAP(4);
 #if !defined(__HIP_DEVICE_COMPILE__)
 		if (round_steps != nullptr) { round_steps[0] += 16 * (((uint32_t) length + width - 1) / width); round_steps[1] += ((uint32_t) length + width - 1) / width; } // (the look-ups, in the currency of the steps of a walk)
 #endif
@@ -672,6 +699,7 @@ struct AlignRunner {
 			const uint32_t listed = worklist->state[0] < worklist->capacity ? worklist->state[0] : worklist->capacity;
 			sync_lanes(); // (nobody lists a call before everybody has read how many there are)
 			if (!sweep_collect_calls(sweep, block, listed, width)) { if (lane == 0) worklist->state[1] = 1; sync_lanes(); return false; }
+			SWEEP_LAP(5);
 			if (sweep.n_calls == 0) continue;
 			sync_lanes();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -710,6 +738,7 @@ struct AlignRunner {
 				sync_lanes();
 				if (worklist->state[2] != 0) return true; // (the same for every lane: read behind the barrier)
 			}
+			SWEEP_LAP(6);
 		}
 		sync_lanes();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -809,6 +838,7 @@ AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int
 		target.positions = kmers.positions;
 		target.contig_bases = genome.bases + genome.contig_offset[contig];
 		target.splice_sites = splice.sites + splice.offset[gene]; target.n_splice_sites = splice.offset[gene + 1] - splice.offset[gene];
+		target.splice_bits = splice.bits; target.splice_bit_base = genome.contig_offset[contig];
 		Segment forward = segment; forward.reverse_complement = false;
 		if (runner.align(runner.prepared(forward), target, min_score)) return true;
 		if (runner.exhausted()) return false;

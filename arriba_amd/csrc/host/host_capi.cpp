@@ -537,16 +537,40 @@ int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, co
 		Batch& b = session->ingest.batch; // (every member is assigned below: the vectors keep their memory from one file to the next)
 		const size_t n = rows->n;
 		b.n = n;
-		b.n_aln.assign(rows->n_aln, rows->n_aln + n); b.fbits.assign(rows->fbits, rows->fbits + n); b.filter.assign(n, 0); b.group.assign(rows->group, rows->group + n);
+		// the columns and pools of 10^7 rows are more than a gigabyte: the vectors are sized first, the bytes then copied by all threads the process may use
+		struct Copy { void* to; const void* from; size_t bytes; };
+		std::vector<Copy> copies;
+		auto take = [&copies](auto& column, const void* from, size_t count) {
+			column.resize(count);
+			if (count > 0) { Copy copy = { &column[0], from, count * sizeof(column[0]) }; copies.push_back(copy); }
+		};
+		take(b.n_aln, rows->n_aln, n); take(b.fbits, rows->fbits, n); b.filter.assign(n, 0); take(b.group, rows->group, n);
 		for (int s = 0; s < 3; ++s) {
-			b.contig[s].assign(rows->contig[s], rows->contig[s] + n); b.start[s].assign(rows->start[s], rows->start[s] + n); b.end[s].assign(rows->end[s], rows->end[s] + n); b.abits[s].assign(rows->abits[s], rows->abits[s] + n);
-			b.cigar_offset[s].assign(rows->cigar_offset[s], rows->cigar_offset[s] + n); b.cigar_count[s].assign(rows->cigar_count[s], rows->cigar_count[s] + n);
+			take(b.contig[s], rows->contig[s], n); take(b.start[s], rows->start[s], n); take(b.end[s], rows->end[s], n); take(b.abits[s], rows->abits[s], n);
+			take(b.cigar_offset[s], rows->cigar_offset[s], n); take(b.cigar_count[s], rows->cigar_count[s], n);
 		}
-		b.cigar_pool.assign(rows->cigar_pool, rows->cigar_pool + rows->cigar_pool_size);
-		for (int s = 0; s < 2; ++s) { b.seq_offset[s].assign(rows->seq_offset[s], rows->seq_offset[s] + n); b.seq_length[s].assign(rows->seq_length[s], rows->seq_length[s] + n); }
-		b.seq_pool.assign(rows->seq_pool, rows->seq_pool + rows->seq_pool_size);
-		b.name_offset.assign(rows->name_offset, rows->name_offset + n + 1);
-		b.names.assign(rows->names, rows->names_size);
+		take(b.cigar_pool, rows->cigar_pool, rows->cigar_pool_size);
+		for (int s = 0; s < 2; ++s) { take(b.seq_offset[s], rows->seq_offset[s], n); take(b.seq_length[s], rows->seq_length[s], n); }
+		take(b.seq_pool, rows->seq_pool, rows->seq_pool_size);
+		take(b.name_offset, rows->name_offset, n + 1);
+		take(b.names, rows->names, rows->names_size);
+		size_t total = 0;
+		for (size_t k = 0; k < copies.size(); ++k) total += copies[k].bytes;
+		const unsigned int n_threads = total < (64u << 20) ? 1u : std::max(1u, std::min(cpu_budget(), 32u));
+		if (n_threads == 1) for (size_t k = 0; k < copies.size(); ++k) memcpy(copies[k].to, copies[k].from, copies[k].bytes);
+		else { // every thread takes the same share of the bytes, across the boundaries of the columns
+			std::vector<std::thread> threads;
+			for (unsigned int t = 0; t < n_threads; ++t)
+				threads.push_back(std::thread([&copies, total, n_threads, t] {
+					const size_t first = total / n_threads * t, last = t + 1 == n_threads ? total : total / n_threads * (t + 1);
+					size_t at = 0;
+					for (size_t k = 0; k < copies.size() && at < last; at += copies[k].bytes, ++k) {
+						const size_t from = std::max(first, at), to = std::min(last, at + copies[k].bytes);
+						if (from < to) memcpy((char*) copies[k].to + (from - at), (const char*) copies[k].from + (from - at), to - from);
+					}
+				}));
+			for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+		}
 		session->rows_in_list_order = fragments == NULL;
 		if (fragments != NULL) {
 			session->row_fragments.assign(fragments, fragments + n);

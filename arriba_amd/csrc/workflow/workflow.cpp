@@ -179,6 +179,9 @@ void read_chimeric_alignments_on_device(Run& run) {
 // walks them; otherwise (discarded.tsv with -X: millions of candidates that share their discordant mates) one row per fragment, in fragment order.
 void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discarded, bool in_list_order) {
 	if (!run.device_ingest) return;
+	const bool profile = getenv("ARRIBA_WRITER_PROFILE") != nullptr;
+	double mark = now_seconds();
+	auto lap = [&](const char* what) { if (profile) { const double now = now_seconds(); fprintf(stderr, "[rows] %s: %.3f s\n", what, now - mark); mark = now; } };
 	uint64_t count = 0;
 	const uint32_t* fragments = nullptr;
 	if (in_list_order) { count = table.list_offset[3 * (size_t) table.n_candidates]; fragments = table.read_lists; }
@@ -188,8 +191,10 @@ void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discar
 		host_check(ahost_fusion_table_reads(&table, write_discarded, unique, count, &count));
 		fragments = unique;
 	}
+	lap("fragments of the rows");
 	uint64_t cigar_words = 0, sequence_bytes = 0, name_bytes = 0;
 	device_check(agpu_gather_rows_begin(run.device, fragments, count, &cigar_words, &sequence_bytes, &name_bytes));
+	lap("agpu_gather_rows_begin");
 	agpu_batch_rows rows;
 	memset(&rows, 0, sizeof(rows));
 	rows.n_aln = run.stage<uint8_t>("rows.n_aln", count); rows.fbits = run.stage<uint8_t>("rows.fbits", count); rows.group = run.stage<uint32_t>("rows.group", count);
@@ -203,11 +208,16 @@ void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discar
 	rows.seq_offset[1] = run.stage<uint32_t>("rows.seq_offset1", count); rows.seq_length[1] = run.stage<uint32_t>("rows.seq_length1", count);
 	rows.cigar_pool = run.stage<uint32_t>("rows.cigar_pool", cigar_words + 1); rows.seq_pool = run.stage<uint8_t>("rows.seq_pool", sequence_bytes + 4);
 	rows.name_offset = run.stage<uint32_t>("rows.name_offset", count + 1); rows.names = run.stage<char>("rows.names", name_bytes + 1);
+	lap("staging buffers");
 	device_check(agpu_gather_rows_copy(run.device, &rows));
+	lap("agpu_gather_rows_copy");
 	uint8_t* filters = run.stage<uint8_t>("rows.filter", count); // the filters of these fragments only, instead of one byte for every fragment of the sample
 	device_check(agpu_get_filters_of(run.device, fragments, count, filters));
 	table.read_filter_of_rows = filters;
+	lap("agpu_get_filters_of");
 	host_check(ahost_set_batch_rows(run.host, &rows, in_list_order ? nullptr : (count > 0 ? fragments : nullptr)));
+	lap("ahost_set_batch_rows");
+	if (profile) fprintf(stderr, "[rows] %llu rows, %llu CIGAR words, %llu sequence bytes, %llu name bytes\n", (unsigned long long) count, (unsigned long long) cigar_words, (unsigned long long) sequence_bytes, (unsigned long long) name_bytes);
 }
 
 // the output files: the device's results brought back, formatted by the host library (source/arriba.cpp:586-610).  Only the candidates a file will hold

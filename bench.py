@@ -96,7 +96,7 @@ def generate_sample(fragments, seed, directory, read_seed=0, stress=False, threa
     return prefix, time.time() - started
 
 
-def cpu_baseline(seed, directory, stress=False, sample_fragments=200000):
+def cpu_baseline(seed, directory, stress=False, sample_fragments=800000):
     """The unmodified reference (oracle/_ref/arriba_ref) on a bounded sample of the same workload, 1 core."""
     import datasets
     unit = "chimeric reads/s"
@@ -123,6 +123,29 @@ def cpu_baseline(seed, directory, stress=False, sample_fragments=200000):
     return {"value": chimeric / elapsed, "unit": unit, "cores": 1, "kind": "reference",
             "sample": "%d chimeric fragments of the same synthetic workload, whole reference binary BAM->fusions.tsv%s, %.1f s wall of which %.1f s load the assembly and the annotation" % (chimeric, " with -U 32767" if stress else "", elapsed, loading),
             "value_without_loading": chimeric / max(elapsed - loading, 1e-9), "seconds": round(elapsed, 2), "loading_seconds": round(loading, 2)}
+
+
+def normal_pairs_leg(pipeline, directory, fragments=10000000, steps=2):
+    """SURVEY.md section 8(d)-2 specifies the sample of config 2 with 4 N ordinary proper pairs beside the N chimeric fragments (coverage and mapped_reads are then non-trivial and
+    the ingest skips four records in five): the 10 M sample with them -- 107 M records, 21.6 GB -- through the same resident session, reported beside the headline number (a smaller main sample: a leg of its size)."""
+    prefix = os.path.join(directory, "normal")
+    started = time.time()
+    arguments = workload_args(fragments, 1000)
+    arguments[arguments.index("--normal-mult") + 1] = "4"
+    subprocess.run([__import__("datasets").GEN_SYNTH, "--out", prefix, "--threads", str(min(64, cpu_budget()))] + arguments, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    generated = time.time() - started
+    bam_bytes = os.path.getsize(prefix + ".bam")
+    seconds = []
+    for _ in range(steps + 1):  # (the first one is warm-up)
+        started = time.perf_counter()
+        pipeline.sample(prefix + ".bam", prefix + ".fusions.tsv")
+        seconds.append(time.perf_counter() - started)
+    counts = dict(pipeline.report)
+    timing = pipeline.timing
+    os.remove(prefix + ".bam")
+    return {"what": "config 2 with 4 N ordinary proper pairs (SURVEY.md 8d-2): %d chimeric fragments among %d BAM records, %.1f GB" % (counts.get("read_chimeric_alignments", 0), counts.get("bam_records", 0), bam_bytes / 1e9),
+            "chimeric_reads_per_s": counts.get("read_chimeric_alignments", 0) / (sum(seconds[1:]) / steps), "bam_records_per_s": counts.get("bam_records", 0) / (sum(seconds[1:]) / steps), "bam_GB_per_s": bam_bytes / 1e9 / (sum(seconds[1:]) / steps),
+            "seconds_per_step": round(sum(seconds[1:]) / steps, 4), "steps": steps, "last_step": {key: round(value, 4) for key, value in timing.items()}, "generate_seconds": round(generated, 1)}
 
 
 def host_only(args):
@@ -189,6 +212,7 @@ def main():
     parser.add_argument("--host-ingest", action="store_true", help="read_chimeric_alignments by the multi-threaded host ingest instead of on the device (round 1's path)")
     parser.add_argument("--python-stages", action="store_true", help="time the ctypes mirror of the stage order (arriba_amd/pipeline.py) instead of arriba_workflow_sample of the product library")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-normal-pairs", action="store_true", help="skip the secondary measurement on the 10 M sample with 4 N ordinary proper pairs (value_with_normal_pairs)")
     parser.add_argument("--host-only", action="store_true")
     parser.add_argument("--keep", help="keep the sample and the output files in this directory")
     parser.add_argument("--per-rank-samples", action="store_true", help="with --gpus N: every rank works on a sample of its own (weak scaling, no collective) instead of all ranks on one sample")
@@ -243,7 +267,7 @@ def main():
             # the large sample runs in a child with a time limit: if it does not come back with a line (a time-out, an error), the line of config 2 is printed instead,
             # with the reason -- a bench without a line is worth nothing
             command = [sys.executable, os.path.abspath(__file__), "--fragments", str(args.fragments), "--steps", str(args.steps), "--warmup", str(args.warmup)]
-            command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--python-stages", args.python_stages), ("--no-cpu-baseline", args.no_cpu_baseline)) if on]
+            command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--python-stages", args.python_stages), ("--no-cpu-baseline", args.no_cpu_baseline), ("--no-normal-pairs", args.no_normal_pairs)) if on]
             # the driver gives a bench run 1800 s; the large sample gets what is left of ~1500 s after a reserve for the line of config 2 (generation, 25 steps of ~1 s, the
             # reference on its bounded sample: ~150 s), and its child decides after every step whether the steps asked for still fit (ARRIBA_BENCH_DEADLINE)
             total_limit = float(os.environ.get("ARRIBA_BENCH_TOTAL_LIMIT", "1500"))
@@ -494,6 +518,9 @@ def main():
                                               "launch_ms": kernels[best]["ms"] / kernels[best]["launches"], "algorithmic_bytes_per_launch": kernels[best]["bytes"] / kernels[best]["launches"]}
             line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted" + ("; " + reference_check if reference_check else "")
             progress("self-check done, kernel profile read")
+            if through_workflow_library and not distributed and not args.stress and not args.no_normal_pairs:
+                progress("the sample with 4 N ordinary proper pairs")
+                line["value_with_normal_pairs"] = normal_pairs_leg(pipeline, directory, fragments=min(10000000, args.fragments))
             if args.no_cpu_baseline or distributed:  # (timed at N = 1 only)
                 line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped: the reference is timed by the run with 1 GPU" if distributed else "skipped"}
             else:

@@ -608,8 +608,16 @@ def _run_plain_reference(prefix, directory, extra=()):
     import subprocess
     os.makedirs(directory, exist_ok=True)
     command = [datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-O", prefix + ".discarded.tsv", "-f", "blacklist"] + list(extra)
+    import time
+    started = time.time()
     result = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     assert result.returncode == 0, result.stdout[-2000:]
+    try:  # how long the reference takes on the host cores of the GPU box, by sample size: kept for the fit of its run time (profiles/)
+        total = re.search(r"Reading chimeric alignments from .*\(total=(\d+)\)", result.stdout.replace("\n", " "))
+        with open(os.path.join(conftest.ROOT, "gpurun_out", "reference_times.txt"), "a") as times:
+            times.write("%s fragments (total=%s) %s: %.1f s\n" % (os.path.basename(prefix), total.group(1) if total else "?", " ".join(extra), time.time() - started))
+    except OSError:
+        pass
     with open(os.path.join(directory, "reference.log"), "w") as out:
         out.write(re.sub(r"\[\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\] ", "", result.stdout))
 

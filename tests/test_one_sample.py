@@ -75,6 +75,9 @@ def test_bench_with_one_rank_times_the_workflow_library(flags, built, emu_api, t
     assert ("arriba_workflow_sample" in line["config"]["timed_call"]) == (not flags)
     assert line["config"]["fragments_per_gpu"] == 20886 and line["config"]["candidates"] == 10278 and line["config"]["fusions"] == 343  # (the same sample through both)
     assert [stage for stage, _, _ in line["stages"]][-1] == "recover_isoforms"
+    if not flags:  # the leg with 4 N ordinary proper pairs beside the chimeric fragments: five times the records, more chimeric fragments (read-through pairs among the ordinary ones)
+        leg = line["value_with_normal_pairs"]
+        assert leg["chimeric_reads_per_s"] > 0 and leg["bam_records_per_s"] > 4 * leg["chimeric_reads_per_s"] and "4 N ordinary proper pairs" in leg["what"]
 
 
 def test_an_error_on_one_rank_ends_the_run_on_all(dataset_files, emu_api, tmp_path):
