@@ -83,7 +83,7 @@ class BgzfBlock(ctypes.Structure):
 
 class IngestResult(ctypes.Structure):
     _fields_ = [("records", c_uint64), ("fragments", c_uint64), ("mapped_reads", c_uint64), ("malformed_count", c_uint64), ("missing_hi_tag", c_uint64), ("no_chimeric_reads", c_uint8),
-                ("names_were_sorted", c_uint8), ("reserved", c_uint8 * 6), ("stream_bytes", c_uint64)]
+                ("names_were_sorted", c_uint8), ("windows", ctypes.c_uint16), ("reserved", c_uint8 * 4), ("stream_bytes", c_uint64)]
 
 
 class BamPiece(ctypes.Structure):
@@ -310,7 +310,7 @@ class WorkflowReport(ctypes.Structure):
 
 
 class WorkflowTiming(ctypes.Structure):
-    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format")]
+    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format", "feed_read", "feed_push")]
 
 
 _workflow_lib = None

@@ -586,8 +586,13 @@ void agpu_destroy(agpu_ctx* ctx) {
 	collect_kernel_samples(ctx);
 	for (size_t k = 0; k < ctx->event_pool.size(); ++k) (void) hipEventDestroy(ctx->event_pool[k]);
 	if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
-	if (ctx->crc_stream) { (void) hipStreamSynchronize(ctx->crc_stream); (void) hipStreamDestroy(ctx->crc_stream); for (int k = 0; k < 2; ++k) { (void) hipEventDestroy(ctx->crc_copied[k]); (void) hipEventDestroy(ctx->crc_checked[k]); } }
-	for (int k = 0; k < 2; ++k) if (ctx->ingest_events[k]) (void) hipEventDestroy(ctx->ingest_events[k]);
+	{ agpu::IngestProgress& progress = ctx->ingest_progress;
+	  if (progress.work) { (void) hipStreamSynchronize(progress.work); (void) hipStreamDestroy(progress.work); }
+	  for (size_t k = 0; k < progress.windows.size(); ++k) if (progress.windows[k].readback) (void) hipEventDestroy(progress.windows[k].readback);
+	  for (size_t k = 0; k < progress.events.size(); ++k) (void) hipEventDestroy(progress.events[k]);
+	  if (progress.host_words) (void) hipHostFree(progress.host_words); }
+	if (ctx->piece_stream) { (void) hipStreamSynchronize(ctx->piece_stream); (void) hipStreamDestroy(ctx->piece_stream); }
+	for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { if (ctx->piece_copied[k]) (void) hipEventDestroy(ctx->piece_copied[k]); if (ctx->piece_ready[k]) (void) hipEventDestroy(ctx->piece_ready[k]); if (ctx->piece_done[k]) (void) hipEventDestroy(ctx->piece_done[k]); }
 	delete ctx;
 }
 

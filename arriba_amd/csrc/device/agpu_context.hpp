@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <deque>
 #include <map>
 #include <utility>
 #include <string>
@@ -53,8 +54,34 @@ struct DeviceBuffer {
 // per-kernel timing with HIP events on the launch stream (agpu_set_profiling / agpu_get_kernel_profile)
 struct KernelSample { const char* name; hipEvent_t start, stop; uint64_t bytes; float ms; };
 
+// The front of read_chimeric_alignments on the device while the pieces of the file are still arriving (agpu_ingest.hip, "the front as the pieces arrive"): the stream is
+// cut into windows, one per pushed piece; a window goes through four steps on a stream of its own (record chain; offsets, record keys, active records; runs of one name;
+// the loop body of the reference per name), each step behind the read-back of the few words the next one needs to size its launches.  The thread that pushes never waits
+// for them: a step is enqueued when the words of the one before have arrived (hipEventQuery).
+struct IngestWindow {
+	uint64_t avail = 0;                     // bytes of the stream in HBM when the window was made: the size of the stream for its kernels
+	uint64_t segment_begin = 0, segment_end = 0;
+	bool last = false;                      // made by agpu_ingest_finish: reaches to the end of the stream
+	int enqueued = 0, known = 0;            // steps enqueued / steps whose words were read
+	hipEvent_t readback = nullptr;          // behind the read-back of the step enqueued last
+	unsigned int slot = 0;                  // of the ring of read-back words
+	uint64_t record_begin = 0, record_end = 0, active_begin = 0, active_end = 0, head_begin = 0, head_end = 0;
+};
+struct IngestProgress {
+	bool on = false, abandoned = false, touched = false; // abandoned: something the windows cannot decide (a read name in two places, a record longer than the margin, ...): the whole stream is done again at the end
+	hipStream_t work = nullptr;
+	std::deque<IngestWindow> windows;
+	std::vector<hipEvent_t> events;         // free ones
+	uint32_t* host_words = nullptr;         // pinned, INGEST_WINDOW_RING x INGEST_WINDOW_WORDS
+	unsigned int next_slot = 0;
+	uint64_t window_bytes = 0;              // bytes of the stream the last window was made at
+	uint64_t segments_done = 0, records = 0, active = 0, heads = 0, groups_done = 0, size_hint = 0;
+	unsigned int windows_made = 0;
+};
+
 }
 
+enum { AGPU_PIECE_SLOTS = 4 };
 struct agpu_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -108,7 +135,7 @@ struct agpu_ctx {
 	agpu::CoverageView coverage = { 0, nullptr, nullptr, nullptr, nullptr };
 	bool have_coverage = false;
 	// read_chimeric_alignments on the device (agpu_ingest.hip): the uncompressed BAM stream while it is being pushed, and what stays behind the pack
-	agpu::DeviceBuffer ingest_stream, ingest_raw[2], ingest_blocks[2], ingest_tid_to_contig, ingest_viral_counts, coverage_windows32;
+	agpu::DeviceBuffer ingest_stream, ingest_raw[AGPU_PIECE_SLOTS], ingest_blocks[AGPU_PIECE_SLOTS], ingest_tid_to_contig, ingest_viral_counts, coverage_windows32;
 	agpu::DeviceBuffer names, name_offset; // "QNAME,HI" of every fragment of a batch built on the device
 	uint64_t ingest_stream_size = 0, ingest_first_record = 0, names_size = 0;
 	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0;
@@ -116,8 +143,10 @@ struct agpu_ctx {
 	bool ingest_active = false, batch_from_ingest = false, ingest_part_of_sample = false, ingest_verify_crc = false;
 	agpu::DeviceBuffer ingest_qname_keys; uint64_t ingest_qname_runs = 0; // a part of a sample: 128-bit keys of the runs of read names in its stream
 	agpu_ingest_result ingest_result; uint64_t ingest_pool_sizes[2] = { 0, 0 }; // what the last ingest (or merge of parts) reported; CIGAR words and sequence bytes of its pools
-	hipEvent_t ingest_events[2] = { nullptr, nullptr };
-	hipStream_t crc_stream = nullptr; hipEvent_t crc_copied[2] = { nullptr, nullptr }, crc_checked[2] = { nullptr, nullptr }; // the CRC check of a pushed piece runs beside the copy of the next one
+	agpu::IngestProgress ingest_progress;
+	// A pushed piece: copied on the context's stream (piece_copied: the caller's buffer is free), unwrapped and CRC-checked on a stream of its own (piece_stream; piece_ready: its
+	// bytes are in the stream, piece_done: the raw bytes are not needed any more), so that the copy of the next piece never waits for a kernel; AGPU_PIECE_SLOTS raw buffers in turn
+	hipStream_t piece_stream = nullptr; hipEvent_t piece_copied[AGPU_PIECE_SLOTS] = {}, piece_ready[AGPU_PIECE_SLOTS] = {}, piece_done[AGPU_PIECE_SLOTS] = {};
 	std::vector<uint64_t> host_coverage_window_offset;
 	agpu::DeviceBuffer gather_ids, gather_cigar_base, gather_seq_base, gather_name_base; // agpu_gather_rows_begin -> _copy
 	uint64_t gather_n = 0, gather_sizes[3] = { 0, 0, 0 };
@@ -174,7 +203,8 @@ int finish_batch_setup(agpu_ctx* ctx);
 //   { KernelTimer timer(ctx, "stage2_kernel", bytes); stage2_kernel<<<...>>>(...); }
 struct KernelTimer {
 	agpu_ctx* ctx; int index;
-	KernelTimer(agpu_ctx* c, const char* name, uint64_t bytes) : ctx(c), index(-1) {
+	hipStream_t stream;
+	KernelTimer(agpu_ctx* c, const char* name, uint64_t bytes, hipStream_t on = nullptr) : ctx(c), index(-1), stream(on ? on : c->stream) {
 		if (!ctx->profiling) return;
 		KernelSample sample; sample.name = name; sample.bytes = bytes; sample.ms = 0;
 		hipEvent_t* events[2] = { &sample.start, &sample.stop };
@@ -182,11 +212,11 @@ struct KernelTimer {
 			if (!ctx->event_pool.empty()) { *events[k] = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
 			else if (hipEventCreate(events[k]) != hipSuccess) return;
 		}
-		(void) hipEventRecord(sample.start, ctx->stream);
+		(void) hipEventRecord(sample.start, stream);
 		ctx->samples_pending.push_back(sample);
 		index = (int) ctx->samples_pending.size() - 1;
 	}
-	~KernelTimer() { if (index >= 0) (void) hipEventRecord(ctx->samples_pending[index].stop, ctx->stream); }
+	~KernelTimer() { if (index >= 0) (void) hipEventRecord(ctx->samples_pending[index].stop, stream); }
 };
 // resolve the pending samples (call after the stream was synchronised)
 inline void collect_kernel_samples(agpu_ctx* ctx) {

@@ -59,29 +59,30 @@ __global__ void __launch_bounds__(BLOCK) bgzf_unwrap_kernel(const uint8_t* raw, 
 
 // ---- the record chain -----------------------------------------------------------------------------------------------------------------------------
 
-__global__ void segment_guess_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, uint32_t n_targets, uint64_t* first, uint64_t* end, uint32_t* count) {
-	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+// (all four over the segments [segment_begin, n_segments): the whole stream at once, or the segments of one window of it behind those of the windows before)
+__global__ void segment_guess_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t segment_begin, uint64_t n_segments, uint32_t n_targets, uint64_t* first, uint64_t* end, uint32_t* count) {
+	const uint64_t s = segment_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (s < n_segments) guess_segment(bytes, size, base, s, n_targets, first, end, count);
 }
 
-__global__ void segment_check_kernel(const uint64_t* first, const uint64_t* end, uint64_t n_segments, uint8_t* mismatch, uint32_t* counters) {
+__global__ void segment_check_kernel(const uint64_t* first, const uint64_t* end, uint64_t segment_begin, uint64_t n_segments, uint8_t* mismatch, uint32_t* mismatches) {
 	__shared__ uint32_t block_sum;
 	uint32_t mine = 0;
-	for (uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; s < n_segments; s += gridDim.x * (uint64_t) BLOCK) {
+	for (uint64_t s = segment_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x; s < n_segments; s += gridDim.x * (uint64_t) BLOCK) {
 		const bool bad = s > 0 && first[s] != end[s - 1];
 		mismatch[s] = bad;
 		mine += bad;
 	}
-	block_tally(mine, &counters[IC_MISMATCH], &block_sum);
+	block_tally(mine, mismatches, &block_sum);
 }
 
-__global__ void segment_repair_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, const uint8_t* mismatch, const uint64_t* previous_end, uint64_t* first, uint64_t* end, uint32_t* count) {
-	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+__global__ void segment_repair_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t segment_begin, uint64_t n_segments, const uint8_t* mismatch, const uint64_t* previous_end, uint64_t* first, uint64_t* end, uint32_t* count) {
+	const uint64_t s = segment_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (s < n_segments) repair_segment_run(bytes, size, base, n_segments, s, mismatch, previous_end, first, end, count);
 }
 
-__global__ void segment_emit_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t n_segments, const uint64_t* first, const uint32_t* record_base, uint64_t* record_offset) {
-	const uint64_t s = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+__global__ void segment_emit_kernel(const uint8_t* bytes, uint64_t size, uint64_t base, uint64_t segment_begin, uint64_t n_segments, const uint64_t* first, const uint32_t* record_base, uint64_t* record_offset) {
+	const uint64_t s = segment_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (s >= n_segments) return;
 	const uint64_t begin = base + s * SEGMENT_BYTES, segment_end = (begin + SEGMENT_BYTES < size) ? begin + SEGMENT_BYTES : size;
 	uint32_t n = 0;
@@ -90,10 +91,10 @@ __global__ void segment_emit_kernel(const uint8_t* bytes, uint64_t size, uint64_
 
 // ---- per record -----------------------------------------------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, GenomeView genome, uint64_t seed, uint64_t* keys, uint8_t* bits, uint32_t* counters) {
+__global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, GenomeView genome, uint64_t seed, uint64_t record_begin, uint64_t* keys, uint8_t* bits, uint32_t* counters) {
 	__shared__ uint32_t sums[4];
 	uint32_t active = 0, mapped = 0, missing = 0, broken = 0;
-	for (uint64_t r = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; r < in.n_records; r += gridDim.x * (uint64_t) BLOCK) {
+	for (uint64_t r = record_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x; r < in.n_records; r += gridDim.x * (uint64_t) BLOCK) {
 		const uint8_t* p = in.bytes + in.record_offset[r];
 		const uint32_t block_size = load_u32(p);
 		uint64_t key = ~0ull;
@@ -142,8 +143,8 @@ __global__ void group_rank_kernel(const uint32_t* sorted_records, const uint32_t
 	group_first[t] = first; group_begin[t] = begin; group_count[t] = (uint32_t) ((g + 1 < n_groups ? (uint64_t) group_start[g + 1] : n_active) - begin);
 }
 // equal keys must be equal names: every record of a group against the first one (in the order of the stream)
-__global__ void group_names_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t n_groups, uint32_t* counters) {
-	const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+__global__ void group_names_kernel(IngestStream in, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t first_group, uint32_t n_groups, uint32_t* counters) {
+	const uint32_t t = first_group + blockIdx.x * BLOCK + threadIdx.x;
 	if (t >= n_groups || group_count[t] < 2) return;
 	const uint32_t* records = sorted_records + group_begin[t];
 	const Rec a = load_record(in, records[0]);
@@ -155,6 +156,46 @@ __global__ void group_names_kernel(IngestStream in, const uint32_t* sorted_recor
 	}
 }
 
+// ---- the front as the pieces arrive: small kernels of the windows -----------------------------------------------------------------------------------
+
+// the record numbers of a window start behind those of the windows before it: their total, kept on the device, is added to the window's own prefix sums ...
+__global__ void window_carry_kernel(uint32_t* record_base, uint64_t segment_begin, uint64_t segment_end, const uint32_t* records_before) {
+	const uint64_t s = segment_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (s <= segment_end) record_base[s] += *records_before;
+}
+// ... and becomes the total behind this window; words: see INGEST_WINDOW_WORDS
+__global__ void window_summary_kernel(const uint32_t* record_base, const uint64_t* end, uint64_t segment_end, uint32_t* records_before, uint32_t* words) {
+	*records_before = record_base[segment_end];
+	words[1] = record_base[segment_end];
+	const uint64_t last_end = end[segment_end - 1];
+	words[4] = (uint32_t) last_end; words[5] = (uint32_t) (last_end >> 32);
+}
+struct RecordIsActive { __host__ __device__ bool operator()(uint8_t bits) const { return (bits & RECORD_STATUS_MASK) == RECORD_ACTIVE; } };
+// STAR writes the alignments of a read next to each other: the active records in the order of the stream, a new run wherever the key of the name changes.  (Whether a name
+// has a second run somewhere else is checked at the end, over the keys of all runs: run_repeat_kernel.)
+__global__ void run_head_kernel(const uint64_t* keys, const uint32_t* active_records, uint64_t begin, uint64_t end, uint8_t* head) {
+	const uint64_t i = begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i < end) head[i] = i == 0 || keys[active_records[i]] != keys[active_records[i - 1]];
+}
+// the runs [first_group, n_groups) are complete: their first records and sizes (the run behind the last one starts at run_begin[g + 1], or the active records end at active_total)
+__global__ void run_close_kernel(const uint32_t* active_records, const uint32_t* run_begin, uint32_t first_group, uint32_t n_groups, uint32_t n_runs, uint64_t active_total, uint32_t* group_first, uint32_t* group_count) {
+	const uint32_t g = first_group + blockIdx.x * BLOCK + threadIdx.x;
+	if (g >= n_groups) return;
+	const uint32_t begin = run_begin[g];
+	group_first[g] = active_records[begin];
+	group_count[g] = (uint32_t) ((g + 1 < n_runs ? (uint64_t) run_begin[g + 1] : active_total) - begin);
+}
+__global__ void run_key_kernel(const uint64_t* keys, const uint32_t* group_first, uint32_t n_groups, uint64_t* out) {
+	const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+	if (g < n_groups) out[g] = keys[group_first[g]];
+}
+__global__ void run_repeat_kernel(const uint64_t* sorted_keys, uint32_t n_groups, uint32_t* repeats) {
+	__shared__ uint32_t block_sum;
+	uint32_t mine = 0;
+	for (uint64_t g = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; g < n_groups; g += gridDim.x * (uint64_t) BLOCK) mine += g > 0 && sorted_keys[g] == sorted_keys[g - 1];
+	block_tally(mine, repeats, &block_sum);
+}
+
 struct ViralCounter {
 	unsigned long long* counts;
 	__device__ void operator()(uint32_t contig) { atomicAdd(&counts[contig], 1ull); }
@@ -162,11 +203,11 @@ struct ViralCounter {
 
 // (Tried in round 3 and taken back: one wavefront per 64 groups with its slice of the stream copied into 48 KB of LDS -- 1240 ms instead of 455 ms at 10^8 fragments,
 // profiles/r03j_bench100m_lds_staged_replay.json: three wavefronts per CU cannot hide the look-ups that stay in HBM -- offsets, record bits, gene index, genome, coverage_t.)
-__global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t n_groups,
+__global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t first_group, uint32_t n_groups,
                                                              FragmentPlan* plain, TandemPlan* itd, uint8_t* valid, FragmentSizes* sizes, unsigned long long* viral_counts, uint32_t* counters) {
 	__shared__ uint32_t sums[2];
 	GroupTally tally; tally.malformed = 0; tally.chimeric = 0;
-	const uint32_t g = blockIdx.x * BLOCK + threadIdx.x; // (groups numbered in the order of their first records)
+	const uint32_t g = first_group + blockIdx.x * BLOCK + threadIdx.x; // (groups numbered in the order of their first records)
 	if (g < n_groups) {
 		const uint32_t begin = group_begin[g];
 		const uint32_t n_records = group_count[g];
@@ -405,15 +446,17 @@ int grow_stream(agpu_ctx* ctx, uint64_t needed) {
 	DeviceBuffer larger;
 	const uint64_t doubled = ctx->ingest_stream.capacity * 2;
 	if (!larger.allocate(std::max<uint64_t>(needed + (needed >> 3), std::max<uint64_t>(doubled, 64u << 20)))) { set_last_error("hipMalloc failed (BAM stream)"); return AGPU_ERR_DEVICE; }
+	if (ctx->piece_stream) HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); // (the pieces before this one are being unwrapped into the old one)
 	if (ctx->ingest_stream_size > 0) HIP_CHECK(hipMemcpyAsync(larger.ptr, ctx->ingest_stream.ptr, ctx->ingest_stream_size, hipMemcpyDeviceToDevice, ctx->stream));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->ingest_progress.work) HIP_CHECK(hipStreamSynchronize(ctx->ingest_progress.work)); // (the windows in flight read the old one)
 	ctx->ingest_stream.swap(larger);
 	return AGPU_OK;
 }
 
 int wait_for_previous_push(agpu_ctx* ctx) {
 	// push k was enqueued; the buffer of push k - 1 must be free when the caller gets control back
-	if (ctx->ingest_pushes >= 1) HIP_CHECK(hipEventSynchronize(ctx->ingest_events[(ctx->ingest_pushes - 1) & 1]));
+	if (ctx->ingest_pushes >= 1) HIP_CHECK(hipEventSynchronize(ctx->piece_copied[(ctx->ingest_pushes - 1) % AGPU_PIECE_SLOTS]));
 	return AGPU_OK;
 }
 
@@ -446,6 +489,222 @@ int exclusive_sum_u64(agpu_ctx* ctx, DeviceBuffer& scratch, const uint32_t* in, 
 	return AGPU_OK;
 }
 
+// ---- the front as the pieces arrive -----------------------------------------------------------------------------------------------------------------
+// agpu_ingest_finish used to start when the last piece was in HBM: 0.9 s of kernels behind 1.5 s of copies at 10^8 fragments, the device idle while the file is fed.
+// Now every pushed piece makes a window of the stream (IngestWindow, agpu_context.hpp) that goes through the front of the ingest -- record chain, record keys, runs of one
+// name, the loop body of the reference per name -- on a stream of its own while the next pieces are copied; what is left for agpu_ingest_finish are the last windows and
+// everything that needs all fragments (name order, pool offsets, the pack).  The runs of a name in the stream stand in for the groups that the sort by name key finds:
+// the same groups in the same order as long as no name has records in two places, which the keys of all runs tell at the end (run_repeat_kernel); if one has -- or if a
+// window meets anything else it cannot decide on its own -- the windows are abandoned and the whole stream is done the other way, as before.
+
+const unsigned int INGEST_WINDOW_RING = 16, INGEST_WINDOW_WORDS = 8; // read-back words of a window: [0] segments that do not start where the one before ends, [1] records up to
+                                                                     // the end of the window, [2] active records of the window, [3] runs that start in it, [4..5] where its last record ends
+uint64_t g_window_bytes = 128u << 20; // a window is made when this much of the stream has arrived since the last one ...
+uint64_t g_window_margin = 1u << 20;  // ... and ends this far in front of the last byte that has: no record of it reaches behind (one that does: abandoned)
+
+// a buffer that grows while windows behind it are in flight keeps its contents
+int grow_keeping(agpu_ctx* ctx, DeviceBuffer& buffer, size_t needed, size_t used, size_t estimate) {
+	if (needed == 0) needed = 16;
+	if (buffer.ptr != nullptr && needed <= buffer.capacity) { if (needed > buffer.bytes) buffer.bytes = needed; return AGPU_OK; }
+	DeviceBuffer larger;
+	if (!larger.allocate(std::max(needed + needed / 2, estimate)) && !larger.allocate(needed)) { set_last_error("hipMalloc failed (tables of the ingest)"); return AGPU_ERR_DEVICE; }
+	hipStream_t s = ctx->ingest_progress.work;
+	if (used > 0 && buffer.ptr != nullptr) HIP_CHECK(hipMemcpyAsync(larger.ptr, buffer.ptr, std::min(used, buffer.capacity), hipMemcpyDeviceToDevice, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	buffer.swap(larger);
+	return AGPU_OK;
+}
+
+IngestStream window_stream(agpu_ctx* ctx, uint64_t size, uint64_t n_records) {
+	IngestStream in;
+	in.bytes = ctx->ingest_stream.as<uint8_t>(); in.size = size; in.record_offset = ctx->scratch("ingest.record_offset").as<uint64_t>(); in.n_records = n_records;
+	in.n_targets = ctx->ingest_n_targets; in.tid_to_contig = ctx->ingest_tid_to_contig.as<uint32_t>();
+	return in;
+}
+
+IngestContext replay_context(agpu_ctx* ctx, const IngestStream& in) {
+	IngestContext context;
+	context.stream = in; context.annotation = ctx->annotation; context.annotation.n_dummy = 0; context.genome = ctx->genome;
+	context.coverage.n_contigs = ctx->genome.n_contigs; context.coverage.window_offset = ctx->coverage_window_offset.as<uint64_t>(); context.coverage.windows = ctx->coverage_windows32.as<uint32_t>();
+	context.coverage.fragment_starts = ctx->coverage_fragment_starts.as<uint8_t>(); context.coverage.fragment_ends = ctx->coverage_fragment_ends.as<uint8_t>();
+	if (getenv("ARRIBA_INGEST_SKIP_COVERAGE") != nullptr) context.coverage.windows = nullptr; // a measurement (the results are not the reference's): what the atomics on coverage_t cost the replay
+	context.record_bits = ctx->scratch("ingest.record_bits").as<uint8_t>(); context.max_itd_length = ctx->ingest_max_itd_length; context.external_duplicate_marking = ctx->ingest_external_duplicate_marking;
+	return context;
+}
+
+// enqueues the next step of a window; the words it leaves are read by window_note when the event behind them has passed
+int window_step(agpu_ctx* ctx, IngestWindow& w) {
+	IngestProgress& p = ctx->ingest_progress;
+	hipStream_t s = p.work;
+	uint32_t* words = ctx->scratch("ingest.window_words").as<uint32_t>() + (size_t) w.slot * INGEST_WINDOW_WORDS;
+	uint32_t* device_counters = ctx->scratch("ingest.counters").as<uint32_t>();
+	DeviceBuffer& rocprim_scratch = ctx->scratch("ingest.window_rocprim");
+	const uint64_t base = ctx->ingest_first_record;
+	const uint8_t* bytes = ctx->ingest_stream.as<uint8_t>();
+	const uint64_t n = w.segment_end - w.segment_begin;
+	const size_t estimated_records = (size_t) (p.size_hint / 128 + 4096);
+	size_t temporary = 0;
+	switch (w.enqueued + 1) {
+	case 1: { // the record chain of the window's segments, behind the chain of the windows before
+		HIP_CHECK(hipMemsetAsync(words, 0, INGEST_WINDOW_WORDS * 4, s));
+		if (n == 0) break; // (a stream without a record: the last window of an empty file)
+		DeviceBuffer& first = ctx->scratch("ingest.segment_first"); DeviceBuffer& end = ctx->scratch("ingest.segment_end"); DeviceBuffer& end_before = ctx->scratch("ingest.segment_end_before");
+		DeviceBuffer& count = ctx->scratch("ingest.segment_count"); DeviceBuffer& record_base = ctx->scratch("ingest.segment_base"); DeviceBuffer& mismatch = ctx->scratch("ingest.segment_mismatch");
+		const size_t segments = (size_t) w.segment_end + 1, done = (size_t) w.segment_begin + 1, estimate = (size_t) (p.size_hint / SEGMENT_BYTES + 16);
+		TRY(grow_keeping(ctx, first, segments * 8, done * 8, estimate * 8)); TRY(grow_keeping(ctx, end, segments * 8, done * 8, estimate * 8)); TRY(grow_keeping(ctx, end_before, segments * 8, 0, estimate * 8));
+		TRY(grow_keeping(ctx, count, segments * 4, done * 4, estimate * 4)); TRY(grow_keeping(ctx, record_base, segments * 4, done * 4, estimate * 4)); TRY(grow_keeping(ctx, mismatch, segments, done, estimate));
+		{ KernelTimer timer(ctx, "segment_guess_kernel", n * SEGMENT_BYTES, s);
+		  segment_guess_kernel<<<grid_for(n), BLOCK, 0, s>>>(bytes, w.avail, base, w.segment_begin, w.segment_end, ctx->ingest_n_targets, first.as<uint64_t>(), end.as<uint64_t>(), count.as<uint32_t>()); }
+		// (the loop of the other way reads the number of mismatches after every pass; here three passes are made whether they are needed or not -- a pass over segments
+		// that fit is a few microseconds -- and a window that still has a mismatch then gives up)
+		for (int pass = 0; pass < 3; ++pass) {
+			segment_check_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(first.as<uint64_t>(), end.as<uint64_t>(), w.segment_begin, w.segment_end, mismatch.as<uint8_t>(), words + 6);
+			const uint64_t from = w.segment_begin > 0 ? w.segment_begin - 1 : 0;
+			HIP_CHECK(hipMemcpyAsync(end_before.as<uint64_t>() + from, end.as<uint64_t>() + from, (w.segment_end - from) * 8, hipMemcpyDeviceToDevice, s));
+			segment_repair_kernel<<<grid_for(n), BLOCK, 0, s>>>(bytes, w.avail, base, w.segment_begin, w.segment_end, mismatch.as<uint8_t>(), end_before.as<uint64_t>(), first.as<uint64_t>(), end.as<uint64_t>(), count.as<uint32_t>());
+		}
+		segment_check_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(first.as<uint64_t>(), end.as<uint64_t>(), w.segment_begin, w.segment_end, mismatch.as<uint8_t>(), words + 0);
+		HIP_CHECK(hipMemsetAsync(count.as<uint32_t>() + w.segment_end, 0, 4, s));
+		HIP_CHECK(rocprim::exclusive_scan(nullptr, temporary, count.as<uint32_t>() + w.segment_begin, record_base.as<uint32_t>() + w.segment_begin, 0u, n + 1, rocprim::plus<uint32_t>(), s));
+		if (temporary > rocprim_scratch.capacity) ALLOC(rocprim_scratch, temporary);
+		HIP_CHECK(rocprim::exclusive_scan(rocprim_scratch.ptr, temporary, count.as<uint32_t>() + w.segment_begin, record_base.as<uint32_t>() + w.segment_begin, 0u, n + 1, rocprim::plus<uint32_t>(), s));
+		uint32_t* records_before = ctx->scratch("ingest.window_state").as<uint32_t>();
+		window_carry_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(record_base.as<uint32_t>(), w.segment_begin, w.segment_end, records_before);
+		window_summary_kernel<<<1, 1, 0, s>>>(record_base.as<uint32_t>(), end.as<uint64_t>(), w.segment_end, records_before, words);
+		break; }
+	case 2: { // where the records start; status and name key of every record; the active ones, in the order of the stream
+		const uint64_t records = w.record_end - w.record_begin;
+		w.active_begin = p.active; // (the same step of the window before has been read: windows_advance)
+		if (records == 0) break;
+		DeviceBuffer& record_offset = ctx->scratch("ingest.record_offset"); DeviceBuffer& keys = ctx->scratch("ingest.keys"); DeviceBuffer& record_bits = ctx->scratch("ingest.record_bits"); DeviceBuffer& active_records = ctx->scratch("ingest.sorted_records");
+		TRY(grow_keeping(ctx, record_offset, w.record_end * 8, w.record_begin * 8, estimated_records * 8)); TRY(grow_keeping(ctx, keys, w.record_end * 8, w.record_begin * 8, estimated_records * 8));
+		TRY(grow_keeping(ctx, record_bits, w.record_end, w.record_begin, estimated_records)); TRY(grow_keeping(ctx, active_records, (w.active_begin + records) * 4, w.active_begin * 4, estimated_records * 4));
+		{ KernelTimer timer(ctx, "segment_emit_kernel", records * 8, s);
+		  segment_emit_kernel<<<grid_for(n), BLOCK, 0, s>>>(bytes, w.avail, base, w.segment_begin, w.segment_end, ctx->scratch("ingest.segment_first").as<uint64_t>(), ctx->scratch("ingest.segment_base").as<uint32_t>(), record_offset.as<uint64_t>()); }
+		const IngestStream in = window_stream(ctx, w.avail, w.record_end);
+		{ KernelTimer timer(ctx, "record_parse_kernel", records * (8 + 64 + 9), s);
+		  record_parse_kernel<<<tally_grid(records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, 0, w.record_begin, keys.as<uint64_t>(), record_bits.as<uint8_t>(), device_counters); }
+		auto flags = rocprim::make_transform_iterator(record_bits.as<uint8_t>() + w.record_begin, RecordIsActive());
+		HIP_CHECK(rocprim::select(nullptr, temporary, rocprim::counting_iterator<uint32_t>((uint32_t) w.record_begin), flags, active_records.as<uint32_t>() + w.active_begin, words + 2, records, s));
+		if (temporary > rocprim_scratch.capacity) ALLOC(rocprim_scratch, temporary);
+		HIP_CHECK(rocprim::select(rocprim_scratch.ptr, temporary, rocprim::counting_iterator<uint32_t>((uint32_t) w.record_begin), flags, active_records.as<uint32_t>() + w.active_begin, words + 2, records, s));
+		break; }
+	case 3: { // where the runs of one name start
+		const uint64_t active = w.active_end - w.active_begin;
+		w.head_begin = p.heads;
+		if (active == 0) break;
+		DeviceBuffer& head = ctx->scratch("ingest.head"); DeviceBuffer& run_begin = ctx->scratch("ingest.group_begin");
+		TRY(grow_keeping(ctx, head, w.active_end, 0, estimated_records)); TRY(grow_keeping(ctx, run_begin, (w.head_begin + active + 1) * 4, w.head_begin * 4, estimated_records * 2));
+		{ KernelTimer timer(ctx, "run_head_kernel", active * (8 + 4 + 1), s);
+		  run_head_kernel<<<grid_for(active), BLOCK, 0, s>>>(ctx->scratch("ingest.keys").as<uint64_t>(), ctx->scratch("ingest.sorted_records").as<uint32_t>(), w.active_begin, w.active_end, head.as<uint8_t>()); }
+		HIP_CHECK(rocprim::select(nullptr, temporary, rocprim::counting_iterator<uint32_t>((uint32_t) w.active_begin), head.as<uint8_t>() + w.active_begin, run_begin.as<uint32_t>() + w.head_begin, words + 3, active, s));
+		if (temporary > rocprim_scratch.capacity) ALLOC(rocprim_scratch, temporary);
+		HIP_CHECK(rocprim::select(rocprim_scratch.ptr, temporary, rocprim::counting_iterator<uint32_t>((uint32_t) w.active_begin), head.as<uint8_t>() + w.active_begin, run_begin.as<uint32_t>() + w.head_begin, words + 3, active, s));
+		break; }
+	case 4: { // the runs that are complete (all but the one the window ends in, which the next window may continue): equal keys are equal names; the loop body of the reference
+		const uint64_t first_group = p.groups_done, n_groups = w.last ? w.head_end : (w.head_end > 0 ? w.head_end - 1 : 0);
+		if (n_groups <= first_group) break;
+		DeviceBuffer& group_first = ctx->scratch("ingest.group_first"); DeviceBuffer& group_count = ctx->scratch("ingest.group_count");
+		DeviceBuffer& plain = ctx->scratch("ingest.plain_plans"); DeviceBuffer& itd = ctx->scratch("ingest.itd_plans"); DeviceBuffer& valid = ctx->scratch("ingest.valid"); DeviceBuffer& sizes = ctx->scratch("ingest.sizes");
+		const size_t estimated_groups = estimated_records / 3;
+		TRY(grow_keeping(ctx, group_first, n_groups * 4, first_group * 4, estimated_groups * 4)); TRY(grow_keeping(ctx, group_count, n_groups * 4, first_group * 4, estimated_groups * 4));
+		TRY(grow_keeping(ctx, plain, n_groups * sizeof(FragmentPlan), first_group * sizeof(FragmentPlan), estimated_groups * sizeof(FragmentPlan))); TRY(grow_keeping(ctx, itd, n_groups * sizeof(TandemPlan), first_group * sizeof(TandemPlan), estimated_groups * sizeof(TandemPlan)));
+		TRY(grow_keeping(ctx, valid, 2 * n_groups, 2 * first_group, 2 * estimated_groups)); TRY(grow_keeping(ctx, sizes, 2 * n_groups * sizeof(FragmentSizes), 2 * first_group * sizeof(FragmentSizes), 2 * estimated_groups * sizeof(FragmentSizes)));
+		const uint32_t* active_records = ctx->scratch("ingest.sorted_records").as<uint32_t>(); const uint32_t* run_begin = ctx->scratch("ingest.group_begin").as<uint32_t>();
+		const uint64_t groups = n_groups - first_group;
+		run_close_kernel<<<grid_for(groups), BLOCK, 0, s>>>(active_records, run_begin, (uint32_t) first_group, (uint32_t) n_groups, (uint32_t) w.head_end, w.active_end, group_first.as<uint32_t>(), group_count.as<uint32_t>());
+		const IngestStream in = window_stream(ctx, w.avail, w.record_end);
+		{ KernelTimer timer(ctx, "group_names_kernel", groups * 2 * (4 + 36 + 16), s);
+		  group_names_kernel<<<grid_for(groups), BLOCK, 0, s>>>(in, active_records, run_begin, group_count.as<uint32_t>(), (uint32_t) first_group, (uint32_t) n_groups, device_counters); }
+		{ KernelTimer timer(ctx, "group_replay_kernel", n * SEGMENT_BYTES, s);
+		  group_replay_kernel<<<grid_for(groups), BLOCK, 0, s>>>(replay_context(ctx, in), active_records, run_begin, group_count.as<uint32_t>(), (uint32_t) first_group, (uint32_t) n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
+		                                                        sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
+		p.groups_done = n_groups; p.touched = true;
+		break; }
+	}
+	HIP_CHECK(hipMemcpyAsync(p.host_words + (size_t) w.slot * INGEST_WINDOW_WORDS, words, INGEST_WINDOW_WORDS * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipEventRecord(w.readback, s));
+	++w.enqueued;
+	return AGPU_OK;
+}
+
+// the words of the step enqueued last have arrived
+void window_note(agpu_ctx* ctx, IngestWindow& w) {
+	IngestProgress& p = ctx->ingest_progress;
+	const uint32_t* words = p.host_words + (size_t) w.slot * INGEST_WINDOW_WORDS;
+	w.known = w.enqueued;
+	switch (w.known) {
+	case 1: {
+		w.record_begin = p.records;
+		if (w.segment_end == w.segment_begin) { w.record_end = p.records; break; }
+		const uint64_t last_end = (uint64_t) words[4] | (uint64_t) words[5] << 32;
+		if (words[0] != 0 || last_end >= OFFSET_BROKEN || (w.last && last_end != w.avail)) { p.abandoned = true; break; } // (a damaged file, too: the other way says so)
+		w.record_end = words[1]; p.records = w.record_end;
+		break; }
+	case 2: w.active_end = w.active_begin + (w.record_end > w.record_begin ? words[2] : 0); p.active = w.active_end; break;
+	case 3: w.head_end = w.head_begin + (w.active_end > w.active_begin ? words[3] : 0); p.heads = w.head_end; break;
+	}
+}
+
+// moves the windows on as far as the words that have arrived allow; wait: until every window is through (agpu_ingest_finish), otherwise nobody waits for the device
+int windows_advance(agpu_ctx* ctx, bool wait) {
+	IngestProgress& p = ctx->ingest_progress;
+	while (!p.abandoned && !p.windows.empty()) {
+		bool moved = false;
+		for (size_t k = 0; k < p.windows.size() && !p.abandoned; ++k) {
+			IngestWindow& w = p.windows[k];
+			if (w.enqueued > w.known) {
+				const hipError_t state = hipEventQuery(w.readback);
+				if (state == hipErrorNotReady) continue;
+				if (state != hipSuccess) { set_last_error(std::string("hipEventQuery: ") + hipGetErrorString(state)); return AGPU_ERR_DEVICE; }
+				window_note(ctx, w);
+				moved = true;
+				if (p.abandoned) break;
+			}
+			// a step needs what the same step of the window before has left (records, active records, runs so far)
+			if (w.known == w.enqueued && w.enqueued < 4 && (k == 0 || p.windows[k - 1].known > w.enqueued || (w.enqueued == 3 && p.windows[k - 1].enqueued == 4))) { TRY(window_step(ctx, w)); moved = true; }
+		}
+		while (!p.windows.empty() && p.windows.front().known == 4) { p.events.push_back(p.windows.front().readback); p.windows.pop_front(); moved = true; }
+		if (moved) continue;
+		if (!wait) break;
+		for (size_t k = 0; k < p.windows.size(); ++k) if (p.windows[k].enqueued > p.windows[k].known) { HIP_CHECK(hipEventSynchronize(p.windows[k].readback)); break; }
+	}
+	return AGPU_OK;
+}
+
+// a new window over what has arrived (last: over everything, made by agpu_ingest_finish)
+int window_make(agpu_ctx* ctx, bool last) {
+	IngestProgress& p = ctx->ingest_progress;
+	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
+	uint64_t segment_end = 0;
+	if (last) segment_end = size > base ? (size - base + SEGMENT_BYTES - 1) / SEGMENT_BYTES : 0;
+	else if (size > base + g_window_margin) segment_end = (size - base - g_window_margin) / SEGMENT_BYTES;
+	if (!last && segment_end <= p.segments_done) return AGPU_OK;
+	while (p.windows.size() + 2 > INGEST_WINDOW_RING) { // (the device is further behind than the ring is long: wait for the oldest window)
+		IngestWindow& oldest = p.windows.front();
+		if (oldest.enqueued > oldest.known) HIP_CHECK(hipEventSynchronize(oldest.readback));
+		TRY(windows_advance(ctx, false));
+		if (p.abandoned) return AGPU_OK;
+	}
+	IngestWindow w;
+	w.avail = size; w.segment_begin = p.segments_done; w.segment_end = std::max(segment_end, p.segments_done); w.last = last; w.slot = p.next_slot; p.next_slot = (p.next_slot + 1) % INGEST_WINDOW_RING;
+	if (!p.events.empty()) { w.readback = p.events.back(); p.events.pop_back(); } else HIP_CHECK(hipEventCreateWithFlags(&w.readback, hipEventDisableTiming));
+	p.segments_done = w.segment_end; p.window_bytes = size; ++p.windows_made;
+	if (ctx->ingest_pushes > 0) HIP_CHECK(hipStreamWaitEvent(p.work, ctx->piece_ready[(ctx->ingest_pushes - 1) % AGPU_PIECE_SLOTS], 0)); // the bytes of the window are there
+	p.windows.push_back(w);
+	if (p.windows.size() == 1 || p.windows[p.windows.size() - 2].enqueued >= 1) TRY(window_step(ctx, p.windows.back())); // (the chain needs nothing from the host)
+	return AGPU_OK;
+}
+
+// behind a push: a window over the new bytes if enough have arrived, and whatever the windows in flight can do next
+int windows_after_push(agpu_ctx* ctx) {
+	IngestProgress& p = ctx->ingest_progress;
+	if (!p.on || p.abandoned) return AGPU_OK;
+	TRY(windows_advance(ctx, false));
+	if (!p.abandoned && ctx->ingest_stream_size - p.window_bytes >= g_window_bytes) TRY(window_make(ctx, false));
+	return AGPU_OK;
+}
+
 void fill_pack_target(agpu_ctx* ctx, PackTarget& out) {
 	out.n_aln = ctx->n_aln.as<uint8_t>(); out.fbits = ctx->fbits.as<uint8_t>(); out.group = ctx->group.as<uint32_t>();
 	for (int k = 0; k < 3; ++k) {
@@ -461,7 +720,7 @@ void fill_pack_target(agpu_ctx* ctx, PackTarget& out) {
 
 bool agpu::release_ingest_buffers(agpu_ctx* ctx) {
 	bool released = ctx->ingest_stream.ptr != nullptr;
-	ctx->ingest_stream.release(); ctx->ingest_raw[0].release(); ctx->ingest_raw[1].release();
+	ctx->ingest_stream.release(); for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) ctx->ingest_raw[k].release();
 	if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
 	static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.first_flags", "ingest.stream_rank", "ingest.group_first", "ingest.group_begin", "ingest.group_count", "ingest.plain_plans", "ingest.itd_plans",
 		"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
@@ -487,10 +746,11 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	if (config->n_contigs != ctx->genome.n_contigs) { set_last_error("the genome view on the device does not hold the contigs of the BAM header (upload it after the header was parsed)"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
-	for (int k = 0; k < 2; ++k) if (!ctx->ingest_events[k]) HIP_CHECK(hipEventCreateWithFlags(&ctx->ingest_events[k], hipEventDisableTiming));
-	if (!ctx->crc_stream) {
-		HIP_CHECK(hipStreamCreateWithFlags(&ctx->crc_stream, hipStreamNonBlocking));
-		for (int k = 0; k < 2; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->crc_copied[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->crc_checked[k], hipEventDisableTiming)); }
+	if (!ctx->piece_stream) {
+		int least = 0, greatest = 0;
+		HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIP_CHECK(hipStreamCreateWithPriority(&ctx->piece_stream, hipStreamNonBlocking, greatest)); // (in front of the kernels of the windows: the feed waits for these)
+		for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_copied[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_ready[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_done[k], hipEventDisableTiming)); }
 	}
 	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
 	{ const char* knob = getenv("ARRIBA_VERIFY_CRC"); ctx->ingest_verify_crc = !(knob != nullptr && knob[0] == '0'); } // (the stored blocks are checked as htslib checks them; "0": a measurement without)
@@ -516,6 +776,27 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	ALLOC(ctx->ingest_viral_counts, std::max<size_t>(config->n_contigs, 1) * 8);
 	HIP_CHECK(hipMemsetAsync(ctx->ingest_viral_counts.ptr, 0, std::max<size_t>(config->n_contigs, 1) * 8, s));
 	if (config->stream_size_hint > 0) TRY(grow_stream(ctx, config->stream_size_hint));
+	{ // the front of the ingest while the pieces arrive (see "the front as the pieces arrive"); a part of a sample is done at the end, the way it was
+		IngestProgress& p = ctx->ingest_progress;
+		for (size_t k = 0; k < p.windows.size(); ++k) p.events.push_back(p.windows[k].readback); // (an ingest that was begun and never finished)
+		p.windows.clear();
+		const char* knob = getenv("ARRIBA_INGEST_WINDOWS"); // "0": everything behind the last piece (the way of round 2; for measurements and for the tests of that way); "bytes,margin": smaller windows (tests)
+		p.on = !ctx->ingest_part_of_sample && !(knob != nullptr && knob[0] == '0' && knob[1] == 0);
+		g_window_bytes = 128u << 20; g_window_margin = 1u << 20;
+		if (knob != nullptr && strchr(knob, ',') != nullptr) { g_window_bytes = strtoull(knob, nullptr, 10); g_window_margin = std::max<uint64_t>(strtoull(strchr(knob, ',') + 1, nullptr, 10), 1); }
+		p.abandoned = false; p.touched = false; p.next_slot = 0; p.window_bytes = 0; p.segments_done = 0; p.records = 0; p.active = 0; p.heads = 0; p.groups_done = 0; p.windows_made = 0; p.size_hint = config->stream_size_hint;
+		if (p.on) {
+			if (!p.work) {
+				int least = 0, greatest = 0;
+				HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+				HIP_CHECK(hipStreamCreateWithPriority(&p.work, hipStreamNonBlocking, least)); // (behind the copies and the unwrap kernels of the pieces, which the feed waits for)
+				HIP_CHECK(hipHostMalloc((void**) &p.host_words, INGEST_WINDOW_RING * INGEST_WINDOW_WORDS * 4, hipHostMallocDefault));
+			}
+			ALLOC(ctx->scratch("ingest.window_words"), INGEST_WINDOW_RING * INGEST_WINDOW_WORDS * 4); ALLOC(ctx->scratch("ingest.window_state"), 16); ALLOC(ctx->scratch("ingest.counters"), IC_COUNT * 4);
+			HIP_CHECK(hipMemsetAsync(ctx->scratch("ingest.window_state").ptr, 0, 16, s));
+			HIP_CHECK(hipMemsetAsync(ctx->scratch("ingest.counters").ptr, 0, IC_COUNT * 4, s));
+		}
+	}
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->ingest_active = true; ctx->have_batch = false; ctx->have_coverage = false;
 	return AGPU_OK;
@@ -529,37 +810,38 @@ int agpu_ingest_push(agpu_ctx* ctx, const void* bytes, size_t size) {
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size, bytes, size, hipMemcpyHostToDevice, ctx->stream));
 		ctx->ingest_stream_size += size;
 	}
-	HIP_CHECK(hipEventRecord(ctx->ingest_events[ctx->ingest_pushes & 1], ctx->stream));
+	{ const unsigned int slot = ctx->ingest_pushes % AGPU_PIECE_SLOTS;
+	  HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], ctx->stream)); HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], ctx->stream)); }
 	TRY(wait_for_previous_push(ctx));
 	++ctx->ingest_pushes;
-	return AGPU_OK;
+	return windows_after_push(ctx);
 }
 
 int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const agpu_bgzf_block* blocks, uint32_t n_blocks, size_t stream_bytes) {
 	if (!ctx || !ctx->ingest_active) { set_last_error("agpu_ingest_begin must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
-	const unsigned int slot = ctx->ingest_pushes & 1;
+	const unsigned int slot = ctx->ingest_pushes % AGPU_PIECE_SLOTS;
+	hipStream_t pieces = ctx->piece_stream;
 	if (n_blocks > 0 && raw_size > 0) {
 		TRY(grow_stream(ctx, ctx->ingest_stream_size + stream_bytes));
 		ALLOC(ctx->ingest_raw[slot], raw_size); ALLOC(ctx->ingest_blocks[slot], (size_t) n_blocks * sizeof(agpu_bgzf_block));
-		if (ctx->ingest_verify_crc) HIP_CHECK(hipStreamWaitEvent(s, ctx->crc_checked[slot], 0)); // (the check of the piece that lay in this buffer is done; an event that was never recorded does not hold anybody up)
+		HIP_CHECK(hipStreamWaitEvent(s, ctx->piece_done[slot], 0)); // (the piece that lay in this buffer is unwrapped and checked; an event that was never recorded does not hold anybody up)
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_raw[slot].ptr, raw, raw_size, hipMemcpyHostToDevice, s));
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_blocks[slot].ptr, blocks, (size_t) n_blocks * sizeof(agpu_bgzf_block), hipMemcpyHostToDevice, s));
-		{ KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes);
-		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, s>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
+		HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], s));
+		HIP_CHECK(hipStreamWaitEvent(pieces, ctx->piece_copied[slot], 0));
+		{ KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes, pieces);
+		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
 		ctx->ingest_stream_size += stream_bytes;
-		if (ctx->ingest_verify_crc) { // on a stream of its own: the copy of the next piece need not wait for it (0.95 ms per 256 MB piece, 0.3 s of a 54 GB file when it sits between the copies)
-			HIP_CHECK(hipEventRecord(ctx->crc_copied[slot], s));
-			HIP_CHECK(hipStreamWaitEvent(ctx->crc_stream, ctx->crc_copied[slot], 0));
-			bgzf_crc_kernel<<<n_blocks, 256, 0, ctx->crc_stream>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
-			HIP_CHECK(hipEventRecord(ctx->crc_checked[slot], ctx->crc_stream));
-		}
-	}
-	HIP_CHECK(hipEventRecord(ctx->ingest_events[slot], s));
+		HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], pieces));
+		if (ctx->ingest_verify_crc) // (0.95 ms per 256 MB piece; between the copies on one stream it cost 0.3 s of a 54 GB file)
+			bgzf_crc_kernel<<<n_blocks, 256, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+		HIP_CHECK(hipEventRecord(ctx->piece_done[slot], pieces));
+	} else { HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], s)); HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], s)); }
 	TRY(wait_for_previous_push(ctx));
 	++ctx->ingest_pushes;
-	return AGPU_OK;
+	return windows_after_push(ctx);
 }
 
 int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
@@ -569,40 +851,79 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ctx->ingest_active = false;
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); // (the last pieces unwrapped)
 	if (ctx->ingest_verify_crc) { // a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch")
-		HIP_CHECK(hipStreamSynchronize(ctx->crc_stream));
 		unsigned int mismatches = 0;
 		HIP_CHECK(hipMemcpyAsync(&mismatches, ctx->scratch("ingest.crc_mismatches").ptr, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (mismatches > 0) { set_last_error("failed to load alignments"); return AGPU_ERR_INVALID; }
 	}
-	const uint8_t* bytes = ctx->ingest_stream.as<uint8_t>();
 	DeviceBuffer& counters = ctx->scratch("ingest.counters"); DeviceBuffer& rocprim_scratch = ctx->scratch("ingest.rocprim");
 	ALLOC(counters, IC_COUNT * 4);
-	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, IC_COUNT * 4, s));
 	uint32_t* device_counters = counters.as<uint32_t>();
 	uint32_t host_counters[IC_COUNT];
 	auto read_counters = [&]() -> int { HIP_CHECK(hipMemcpyAsync(host_counters, counters.ptr, IC_COUNT * 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); return AGPU_OK; };
 	(void) hipEventRecord(ctx->event_start, s);
+
+	// 0. the windows that went through the front while the pieces arrived: the last one, then whether their runs are the groups of the names
+	IngestProgress& progress = ctx->ingest_progress;
+	bool streamed = false;
+	if (progress.on) {
+		if (!progress.abandoned) TRY(window_make(ctx, true));
+		TRY(windows_advance(ctx, true));
+		HIP_CHECK(hipStreamSynchronize(progress.work));
+		for (size_t k = 0; k < progress.windows.size(); ++k) progress.events.push_back(progress.windows[k].readback);
+		progress.windows.clear();
+		streamed = !progress.abandoned;
+		if (streamed) {
+			TRY(read_counters());
+			if (host_counters[IC_BROKEN] > 0 || host_counters[IC_COLLISION] != 0) streamed = false; // (a damaged record: the other way says so; two names with one key: hashed again there)
+		}
+		if (streamed && progress.heads > 1) { // a name with records in two places of the stream has two runs: the runs are not the reference's groups then
+			DeviceBuffer& run_keys = ctx->scratch("ingest.run_keys"); DeviceBuffer& run_keys_sorted = ctx->scratch("ingest.run_keys_sorted");
+			const uint32_t runs = (uint32_t) progress.heads;
+			ALLOC(run_keys, (size_t) runs * 8); ALLOC(run_keys_sorted, (size_t) runs * 8);
+			run_key_kernel<<<grid_for(runs), BLOCK, 0, s>>>(ctx->scratch("ingest.keys").as<uint64_t>(), ctx->scratch("ingest.group_first").as<uint32_t>(), runs, run_keys.as<uint64_t>());
+			size_t temporary = 0;
+			HIP_CHECK(rocprim::radix_sort_keys(nullptr, temporary, run_keys.as<uint64_t>(), run_keys_sorted.as<uint64_t>(), runs, 0, 64, s));
+			if (temporary > rocprim_scratch.capacity) ALLOC(rocprim_scratch, temporary);
+			{ KernelTimer timer(ctx, "rocprim::radix_sort_keys(keys of the runs)", (uint64_t) runs * 16);
+			  HIP_CHECK(rocprim::radix_sort_keys(rocprim_scratch.ptr, temporary, run_keys.as<uint64_t>(), run_keys_sorted.as<uint64_t>(), runs, 0, 64, s)); }
+			HIP_CHECK(hipMemsetAsync(device_counters + IC_MISMATCH, 0, 4, s));
+			run_repeat_kernel<<<tally_grid(runs, BLOCK), BLOCK, 0, s>>>(run_keys_sorted.as<uint64_t>(), runs, device_counters + IC_MISMATCH);
+			TRY(read_counters());
+			if (host_counters[IC_MISMATCH] != 0) streamed = false;
+		}
+		if (!streamed && progress.touched) { // what the loop bodies of the windows have counted is counted again
+			const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
+			HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(windows, 1) * 4, s));
+			HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_starts.ptr, 0, std::max<uint64_t>(windows, 1), s));
+			HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_ends.ptr, 0, std::max<uint64_t>(windows, 1), s));
+			HIP_CHECK(hipMemsetAsync(ctx->ingest_viral_counts.ptr, 0, std::max<size_t>(ctx->genome.n_contigs, 1) * 8, s));
+		}
+		progress.abandoned = !streamed;
+	}
+	const uint8_t* bytes = ctx->ingest_stream.as<uint8_t>();
+	if (!streamed) HIP_CHECK(hipMemsetAsync(counters.ptr, 0, IC_COUNT * 4, s));
 
 	// 1. the record chain
 	const uint64_t n_segments = (size - base + SEGMENT_BYTES - 1) / SEGMENT_BYTES;
 	DeviceBuffer& segment_first = ctx->scratch("ingest.segment_first"); DeviceBuffer& segment_end = ctx->scratch("ingest.segment_end"); DeviceBuffer& segment_end_before = ctx->scratch("ingest.segment_end_before");
 	DeviceBuffer& segment_count = ctx->scratch("ingest.segment_count"); DeviceBuffer& segment_base = ctx->scratch("ingest.segment_base"); DeviceBuffer& segment_mismatch = ctx->scratch("ingest.segment_mismatch");
 	DeviceBuffer& record_offset = ctx->scratch("ingest.record_offset");
-	uint64_t n_records = 0;
-	if (n_segments > 0) {
+	uint64_t n_records = streamed ? progress.records : 0;
+	if (n_segments > 0 && !streamed) {
 		ALLOC(segment_first, n_segments * 8); ALLOC(segment_end, n_segments * 8); ALLOC(segment_end_before, n_segments * 8); ALLOC(segment_count, (n_segments + 1) * 4); ALLOC(segment_base, (n_segments + 1) * 4); ALLOC(segment_mismatch, n_segments);
 		{ KernelTimer timer(ctx, "segment_guess_kernel", size - base);
-		  segment_guess_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, n_segments, ctx->ingest_n_targets, segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), segment_count.as<uint32_t>()); }
+		  segment_guess_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, 0, n_segments, ctx->ingest_n_targets, segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), segment_count.as<uint32_t>()); }
 		while (true) {
 			HIP_CHECK(hipMemsetAsync(device_counters + IC_MISMATCH, 0, 4, s));
-			segment_check_kernel<<<tally_grid(n_segments, BLOCK), BLOCK, 0, s>>>(segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), n_segments, segment_mismatch.as<uint8_t>(), device_counters);
+			segment_check_kernel<<<tally_grid(n_segments, BLOCK), BLOCK, 0, s>>>(segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), 0, n_segments, segment_mismatch.as<uint8_t>(), device_counters + IC_MISMATCH);
 			TRY(read_counters());
 			if (host_counters[IC_MISMATCH] == 0) break;
 			HIP_CHECK(hipMemcpyAsync(segment_end_before.ptr, segment_end.ptr, n_segments * 8, hipMemcpyDeviceToDevice, s));
 			KernelTimer timer(ctx, "segment_repair_kernel", 0);
-			segment_repair_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, n_segments, segment_mismatch.as<uint8_t>(), segment_end_before.as<uint64_t>(), segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), segment_count.as<uint32_t>());
+			segment_repair_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, 0, n_segments, segment_mismatch.as<uint8_t>(), segment_end_before.as<uint64_t>(), segment_first.as<uint64_t>(), segment_end.as<uint64_t>(), segment_count.as<uint32_t>());
 		}
 		uint64_t last_end = 0;
 		HIP_CHECK(hipMemcpyAsync(&last_end, segment_end.as<uint64_t>() + (n_segments - 1), 8, hipMemcpyDeviceToHost, s));
@@ -621,7 +942,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 		if ((size - base) / 36 >= 0xFFFFFFF0ull) { set_last_error("more than 2^32-16 alignment records: shard the input"); return AGPU_ERR_INVALID; }
 		ALLOC(record_offset, std::max<uint64_t>(n_records, 1) * 8);
 		{ KernelTimer timer(ctx, "segment_emit_kernel", n_records * 8);
-		  segment_emit_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, n_segments, segment_first.as<uint64_t>(), segment_base.as<uint32_t>(), record_offset.as<uint64_t>()); }
+		  segment_emit_kernel<<<grid_for(n_segments), BLOCK, 0, s>>>(bytes, size, base, 0, n_segments, segment_first.as<uint64_t>(), segment_base.as<uint32_t>(), record_offset.as<uint64_t>()); }
 	}
 	IngestStream in;
 	in.bytes = bytes; in.size = size; in.record_offset = record_offset.as<uint64_t>(); in.n_records = n_records; in.n_targets = ctx->ingest_n_targets; in.tid_to_contig = ctx->ingest_tid_to_contig.as<uint32_t>();
@@ -647,14 +968,20 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	DeviceBuffer& first_flags = ctx->scratch("ingest.first_flags"); DeviceBuffer& stream_rank = ctx->scratch("ingest.stream_rank");
 	DeviceBuffer& group_first = ctx->scratch("ingest.group_first"); DeviceBuffer& group_begin = ctx->scratch("ingest.group_begin"); DeviceBuffer& group_count = ctx->scratch("ingest.group_count");
 	const uint64_t records1 = std::max<uint64_t>(n_records, 1);
-	ALLOC(keys, records1 * 8); ALLOC(keys_sorted, records1 * 8); ALLOC(record_bits, records1); ALLOC(sorted_records, records1 * 4);
+	if (!streamed) { ALLOC(keys, records1 * 8); ALLOC(keys_sorted, records1 * 8); ALLOC(record_bits, records1); ALLOC(sorted_records, records1 * 4); }
 	uint64_t n_active = 0, seed = 0;
 	uint32_t n_groups = 0;
-	while (true) {
+	if (streamed) { // (the counters hold what the windows counted; the active records lie in sorted_records in the order of the stream, the runs are the groups)
+		TRY(read_counters());
+		n_active = progress.active; n_groups = (uint32_t) progress.heads;
+		if (n_active != host_counters[IC_ACTIVE] || progress.groups_done != progress.heads) { set_last_error("the windows of the ingest lost count of their records"); return AGPU_ERR_DEVICE; }
+		if (n_groups > 0) ALLOC(group_first, (size_t) n_groups * 4);
+	}
+	while (!streamed) {
 		HIP_CHECK(hipMemsetAsync(device_counters, 0, IC_COUNT * 4, s));
 		if (n_records > 0) {
 			{ KernelTimer timer(ctx, "record_parse_kernel", n_records * (8 + 64 + 9));
-			  record_parse_kernel<<<tally_grid(n_records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, seed, keys.as<uint64_t>(), record_bits.as<uint8_t>(), device_counters); }
+			  record_parse_kernel<<<tally_grid(n_records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, seed, 0, keys.as<uint64_t>(), record_bits.as<uint8_t>(), device_counters); }
 			TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(), nullptr, sorted_records.as<uint32_t>(), n_records, 64, "rocprim::radix_sort_pairs(record keys)", true));
 		}
 		TRY(read_counters());
@@ -681,7 +1008,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 			{ KernelTimer timer(ctx, "group_rank_kernel", (uint64_t) n_groups * 24);
 			  group_rank_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(sorted_records.as<uint32_t>(), group_start.as<uint32_t>(), n_groups, n_active, stream_rank.as<uint32_t>(), group_first.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>()); }
 			{ KernelTimer timer(ctx, "group_names_kernel", n_active * (4 + 36 + 16));
-			  group_names_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), n_groups, device_counters); }
+			  group_names_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(in, sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), 0, n_groups, device_counters); }
 			TRY(read_counters());
 			if (host_counters[IC_COLLISION]) { seed += 0x632BE59BD9B4E019ull; continue; } // two names with one key: hash again with another seed (once in ~10^3 runs of 10^8 names)
 		}
@@ -693,17 +1020,12 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	DeviceBuffer& plain = ctx->scratch("ingest.plain_plans"); DeviceBuffer& itd = ctx->scratch("ingest.itd_plans"); DeviceBuffer& valid = ctx->scratch("ingest.valid"); DeviceBuffer& sizes = ctx->scratch("ingest.sizes");
 	DeviceBuffer& refs = ctx->scratch("ingest.refs"); DeviceBuffer& order = ctx->scratch("ingest.order"); DeviceBuffer& order_keys = ctx->scratch("ingest.order_keys"); DeviceBuffer& order_keys_sorted = ctx->scratch("ingest.order_keys_sorted");
 	const uint64_t groups1 = std::max<uint32_t>(n_groups, 1);
-	ALLOC(plain, groups1 * sizeof(FragmentPlan)); ALLOC(itd, groups1 * sizeof(TandemPlan)); ALLOC(valid, 2 * groups1); ALLOC(sizes, 2 * groups1 * sizeof(FragmentSizes)); ALLOC(refs, 2 * groups1 * 4);
-	IngestContext context;
-	context.stream = in; context.annotation = ctx->annotation; context.annotation.n_dummy = 0; context.genome = ctx->genome;
-	context.coverage.n_contigs = ctx->genome.n_contigs; context.coverage.window_offset = ctx->coverage_window_offset.as<uint64_t>(); context.coverage.windows = ctx->coverage_windows32.as<uint32_t>();
-	context.coverage.fragment_starts = ctx->coverage_fragment_starts.as<uint8_t>(); context.coverage.fragment_ends = ctx->coverage_fragment_ends.as<uint8_t>();
-	if (getenv("ARRIBA_INGEST_SKIP_COVERAGE") != nullptr) context.coverage.windows = nullptr; // a measurement (the results are not the reference's): what the atomics on coverage_t cost the replay
-	context.record_bits = record_bits.as<uint8_t>(); context.max_itd_length = ctx->ingest_max_itd_length; context.external_duplicate_marking = ctx->ingest_external_duplicate_marking;
+	ALLOC(plain, groups1 * sizeof(FragmentPlan)); ALLOC(itd, groups1 * sizeof(TandemPlan)); ALLOC(valid, 2 * groups1); ALLOC(sizes, 2 * groups1 * sizeof(FragmentSizes)); // (behind the windows: large enough already, and filled)
+	ALLOC(refs, 2 * groups1 * 4);
 	uint64_t n_fragments = 0;
 	if (n_groups > 0) {
-		{ KernelTimer timer(ctx, "group_replay_kernel", size - base);
-		  group_replay_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(context, sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
+		if (!streamed) { KernelTimer timer(ctx, "group_replay_kernel", size - base);
+		  group_replay_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(replay_context(ctx, in), sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), 0, n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
 		                                                            sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
 		TRY(select_flagged(ctx, rocprim_scratch, valid.as<uint8_t>(), refs.as<uint32_t>(), device_counters + IC_MAX_NAME, 2 * (uint64_t) n_groups));
 		TRY(read_counters());
@@ -793,7 +1115,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	agpu_ingest_result& mine = ctx->ingest_result;
 	memset(&mine, 0, sizeof(mine));
 	mine.records = n_records; mine.fragments = n; mine.mapped_reads = mapped_reads; mine.malformed_count = malformed_count; mine.missing_hi_tag = missing_hi_tag;
-	mine.no_chimeric_reads = no_chimeric_reads; mine.names_were_sorted = names_were_sorted; mine.stream_bytes = size;
+	mine.no_chimeric_reads = no_chimeric_reads; mine.names_were_sorted = names_were_sorted; mine.stream_bytes = size; mine.windows = streamed ? (uint16_t) std::min<unsigned int>(progress.windows_made, 65535u) : 0;
 	if (result) *result = mine;
 	return AGPU_OK;
 }

@@ -150,15 +150,21 @@ void read_chimeric_alignments_on_device(Run& run) {
 		if (run.tables[k].size() != block_capacity) run.tables[k].assign(block_capacity, agpu_bgzf_block());
 		if (!run.pieces[k]) { run.pieces[k] = agpu_host_alloc(piece_bytes); if (!run.pieces[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
 	}
+	double reading = 0, pushing = 0;
 	for (unsigned int push = 0; ; ++push) {
 		ahost_bam_piece piece;
+		const double before = now_seconds();
 		const int status = ahost_bam_next(run.host, run.pieces[push & 1], piece_bytes, run.tables[push & 1].data(), block_capacity, &piece);
+		const double read = now_seconds();
+		reading += read - before;
 		if (status < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
 		if (status == 0) break;
 		if (piece.stored_bgzf) device_check(agpu_ingest_push_bgzf(run.device, run.pieces[push & 1], piece.bytes, run.tables[push & 1].data(), piece.n_blocks, piece.stream_bytes));
 		else device_check(agpu_ingest_push(run.device, run.pieces[push & 1], piece.bytes));
+		pushing += now_seconds() - read;
 	}
 	const double fed = now_seconds();
+	if (run.timing) { run.timing->feed_read = reading; run.timing->feed_push = pushing; }
 	agpu_ingest_result result;
 	device_check(agpu_ingest_finish(run.device, &result));
 	ahost_bam_close(run.host); closer.open = false;

@@ -207,7 +207,8 @@ typedef struct {
 	uint64_t missing_hi_tag;         /* (:622-625) */
 	uint8_t no_chimeric_reads;       /* (:767-770) */
 	uint8_t names_were_sorted;       /* 1 = the order of first occurrence was the name order (no string sort needed) */
-	uint8_t reserved[6];
+	uint16_t windows;                /* windows of the stream that went through the front of the ingest while the pieces arrived; 0 = everything was done behind the last piece */
+	uint8_t reserved[4];
 	uint64_t stream_bytes;
 } agpu_ingest_result;
 void* agpu_host_alloc(size_t bytes);  /* pinned host memory for the pieces (NULL on failure) */

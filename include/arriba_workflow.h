@@ -71,6 +71,8 @@ typedef struct { /* seconds of one sample, by part (wall clock of the calling th
 	double output_results;   /*   of it: the candidate table and read lists of the written candidates back to the host */
 	double output_rows;      /*   of it: the rows (names, CIGARs, sequences) of their supporting reads */
 	double output_format;    /*   of it: ahost_write_fusions */
+	double feed_read;        /* of feed: inside ahost_bam_next (the bytes of the file into the pinned pieces) */
+	double feed_push;        /* of feed: inside agpu_ingest_push* (enqueue the copy, wait for the copy before it, move the windows of the ingest on) */
 } arriba_workflow_timing;
 /* options->chimeric_bam_file, output_file and discarded_output_file are not used by open (they belong to a sample); NULL + arriba_workflow_last_error() on failure */
 arriba_workflow_session* arriba_workflow_open(const arriba_workflow_options* options);

@@ -568,6 +568,38 @@ def test_device_ingest_builds_the_batch_of_the_host_ingest(name, built, tmp_path
     assert pipeline.detect_strandedness() == host.detect_strandedness()
 
 
+@pytest.mark.parametrize("name", ["mid30k", "stranded_multimappers_20k", "shuffled_dups_40k"])
+def test_front_of_the_ingest_in_windows_and_behind_the_last_piece(name, built, tmp_path, monkeypatch):
+    """The front of the ingest (record chain, record keys, runs of one name, the loop body per name) runs in windows of the stream while the pieces arrive, and behind the last
+    piece only when it has to: windows of 1 MB that end 64 KB in front of the bytes that have arrived (dozens of them over these files, records and runs of a name across their
+    borders), the default (one window: the files are smaller than 128 MB) and ARRIBA_INGEST_WINDOWS=0 (the way of round 2) give the batch of the host ingest; a file whose
+    mates lie apart (--separate-mates: a name in two places of the stream) is noticed by the keys of the runs and done the other way"""
+    import test_host_and_device_logic as cpu_tier
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    prefix = datasets.generate({"args": cpu_tier.DEVICE_INGEST_DATASETS[name]}, str(tmp_path))
+    host = parity.open_session(prefix)
+    expected = cpu_tier._batch_columns(host)
+    expected["coverage"] = int(host._lib.ahost_coverage_checksum(host._session))
+    apart = "--separate-mates" in cpu_tier.DEVICE_INGEST_DATASETS[name]
+    for knob, windows in (("1048576,65536", None), (None, 1), ("0", 0), ("1048576,1", None)):
+        if knob is None:
+            monkeypatch.delenv("ARRIBA_INGEST_WINDOWS", raising=False)
+        else:
+            monkeypatch.setenv("ARRIBA_INGEST_WINDOWS", knob)
+        session = HostSession(prefix + ".fa", prefix + ".gtf")
+        pipeline = DevicePipeline(session, bam=prefix + ".bam", piece_bytes=1 << 20)
+        columns = cpu_tier._device_batch_columns(session, pipeline)
+        assert [key for key in expected if expected[key] != columns[key]] == [], knob
+        made = pipeline.ingest_result.windows
+        if apart:
+            assert made == 0, (knob, made)
+        elif windows is None:
+            assert made >= os.path.getsize(prefix + ".bam") // (2 << 20) and made >= 3, (knob, made)  # (a piece of 1 MB of the file holds a little less than 1 MB of the stream: a window every second piece)
+        else:
+            assert made == windows, (knob, made)
+        assert pipeline.detect_strandedness() == host.detect_strandedness()
+
+
 def test_device_ingest_at_scale_and_every_container(built, tmp_path):
     """1.2 M fragments + 0.6 M ordinary pairs (more segments, groups and fragments than any launch grid cap), shuffled names: the batch equals the host ingest's;
     the same stream as deflated BGZF and as raw BAM gives the same batch"""
@@ -580,6 +612,7 @@ def test_device_ingest_at_scale_and_every_container(built, tmp_path):
     different = [key for key in expected if expected[key] != columns[key]]
     assert not different, different
     assert expected["n"] > 1100000 and pipeline.ingest_result.names_were_sorted == 0
+    assert pipeline.ingest_result.windows >= 3  # (64 MB pieces of a file of ~0.6 GB: a window every second piece, and the last one)
     payload = gzip.open(prefix + ".bam", "rb").read()
     open(str(tmp_path / "raw.bam"), "wb").write(payload)
     cpu_tier._write_bgzf(str(tmp_path / "deflated.bam"), payload, 1)
