@@ -74,7 +74,7 @@ class BatchView(ctypes.Structure):
 
 class IngestConfig(ctypes.Structure):
     _fields_ = [("n_targets", c_uint32), ("tid_to_contig", POINTER(c_uint32)), ("first_record_offset", c_uint64), ("stream_size_hint", c_uint64), ("n_contigs", c_uint32),
-                ("coverage_window_offset", POINTER(c_uint64)), ("external_duplicate_marking", c_uint8), ("max_itd_length", c_uint32), ("part_of_sample", c_uint8)]
+                ("coverage_window_offset", POINTER(c_uint64)), ("external_duplicate_marking", c_uint8), ("max_itd_length", c_uint32), ("part_of_sample", c_uint8), ("host_buffers", c_uint8)]
 
 
 class BgzfBlock(ctypes.Structure):

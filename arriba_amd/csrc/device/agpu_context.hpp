@@ -138,7 +138,7 @@ struct agpu_ctx {
 	agpu::DeviceBuffer ingest_stream, ingest_raw[AGPU_PIECE_SLOTS], ingest_blocks[AGPU_PIECE_SLOTS], ingest_tid_to_contig, ingest_viral_counts, coverage_windows32;
 	agpu::DeviceBuffer names, name_offset; // "QNAME,HI" of every fragment of a batch built on the device
 	uint64_t ingest_stream_size = 0, ingest_first_record = 0, names_size = 0;
-	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0;
+	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0, ingest_host_buffers = 2;
 	uint8_t ingest_external_duplicate_marking = 0;
 	bool ingest_active = false, batch_from_ingest = false, ingest_part_of_sample = false, ingest_verify_crc = false;
 	agpu::DeviceBuffer ingest_qname_keys; uint64_t ingest_qname_runs = 0; // a part of a sample: 128-bit keys of the runs of read names in its stream

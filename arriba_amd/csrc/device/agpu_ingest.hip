@@ -455,8 +455,9 @@ int grow_stream(agpu_ctx* ctx, uint64_t needed) {
 }
 
 int wait_for_previous_push(agpu_ctx* ctx) {
-	// push k was enqueued; the buffer of push k - 1 must be free when the caller gets control back
-	if (ctx->ingest_pushes >= 1) HIP_CHECK(hipEventSynchronize(ctx->piece_copied[(ctx->ingest_pushes - 1) % AGPU_PIECE_SLOTS]));
+	// push k was enqueued; the caller fills the buffer of push k - (host_buffers - 1) next: that piece must have left it when the caller gets control back
+	const uint32_t behind = ctx->ingest_host_buffers - 1;
+	if (ctx->ingest_pushes >= behind) HIP_CHECK(hipEventSynchronize(ctx->piece_copied[(ctx->ingest_pushes - behind) % AGPU_PIECE_SLOTS]));
 	return AGPU_OK;
 }
 
@@ -499,7 +500,7 @@ int exclusive_sum_u64(agpu_ctx* ctx, DeviceBuffer& scratch, const uint32_t* in, 
 
 const unsigned int INGEST_WINDOW_RING = 16, INGEST_WINDOW_WORDS = 8; // read-back words of a window: [0] segments that do not start where the one before ends, [1] records up to
                                                                      // the end of the window, [2] active records of the window, [3] runs that start in it, [4..5] where its last record ends
-uint64_t g_window_bytes = 128u << 20; // a window is made when this much of the stream has arrived since the last one ...
+uint64_t g_window_bytes = 512u << 20; // a window is made when this much of the stream has arrived since the last one (10^8 fragments, step: 256 MB 4.1 s, 512 MB 3.89 s, 1 GB 3.97 s: profiles/r03n) ...
 uint64_t g_window_margin = 1u << 20;  // ... and ends this far in front of the last byte that has: no record of it reaches behind (one that does: abandoned)
 
 // a buffer that grows while windows behind it are in flight keeps its contents
@@ -752,6 +753,8 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 		HIP_CHECK(hipStreamCreateWithPriority(&ctx->piece_stream, hipStreamNonBlocking, greatest)); // (in front of the kernels of the windows: the feed waits for these)
 		for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_copied[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_ready[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_done[k], hipEventDisableTiming)); }
 	}
+	if (config->host_buffers > AGPU_PIECE_SLOTS) { set_last_error("agpu_ingest_config.host_buffers: at most 4"); return AGPU_ERR_INVALID; }
+	ctx->ingest_host_buffers = config->host_buffers < 2 ? 2 : config->host_buffers;
 	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
 	{ const char* knob = getenv("ARRIBA_VERIFY_CRC"); ctx->ingest_verify_crc = !(knob != nullptr && knob[0] == '0'); } // (the stored blocks are checked as htslib checks them; "0": a measurement without)
 	ALLOC(ctx->scratch("ingest.crc_mismatches"), 4);
@@ -782,7 +785,7 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 		p.windows.clear();
 		const char* knob = getenv("ARRIBA_INGEST_WINDOWS"); // "0": everything behind the last piece (the way of round 2; for measurements and for the tests of that way); "bytes,margin": smaller windows (tests)
 		p.on = !ctx->ingest_part_of_sample && !(knob != nullptr && knob[0] == '0' && knob[1] == 0);
-		g_window_bytes = 128u << 20; g_window_margin = 1u << 20;
+		g_window_bytes = 512u << 20; g_window_margin = 1u << 20;
 		if (knob != nullptr && strchr(knob, ',') != nullptr) { g_window_bytes = strtoull(knob, nullptr, 10); g_window_margin = std::max<uint64_t>(strtoull(strchr(knob, ',') + 1, nullptr, 10), 1); }
 		p.abandoned = false; p.touched = false; p.next_slot = 0; p.window_bytes = 0; p.segments_done = 0; p.records = 0; p.active = 0; p.heads = 0; p.groups_done = 0; p.windows_made = 0; p.size_hint = config->stream_size_hint;
 		if (p.on) {

@@ -157,7 +157,7 @@ const int SEGMENT_CACHE = 128; // bases of a segment kept in LDS per lane (longe
 // cheaper place for all but the short searches: at 10^8 fragments first + second pass take 641 + 306 ms with 2048 steps, 235 + 471 ms with 512, 119 + 539 ms with 256
 // (profiles/r03e_mismapper_sweep.txt; ARRIBA_FIRST_PASS_STEPS for measurements).
 const int64_t FIRST_PASS_STEPS = 256;
-__global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap,
+__global__ void __launch_bounds__(ALIGN_BLOCK, 5) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap,
                                                                         int64_t first_pass_steps, uint32_t* heavy, unsigned int* counters /* [1] discarded, [3] heavy */) {
 	__shared__ uint32_t block_sum;
 	__shared__ uint8_t segment_bases[SEGMENT_CACHE * ALIGN_BLOCK];
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(ALIGN_BLOCK) mismapper_verdict_kernel(BatchVie
 const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 32 GB for 4096 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
                                         // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
 const uint32_t HEAVY_WORKGROUPS = 4096;
-__global__ void __launch_bounds__(64) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
+__global__ void __launch_bounds__(64, 4) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
                                                              unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
 	__shared__ AlignSweep sweep;

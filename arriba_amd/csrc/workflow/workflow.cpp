@@ -38,8 +38,9 @@ struct Run {
 	uint32_t dummy_genes;
 	uint64_t n_candidates, n_fragments, mapped_reads;
 	bool device_ingest;
-	void* pieces[2];
-	std::vector<agpu_bgzf_block> tables[2];
+	enum { FEED_BUFFERS = 3 }; // (with two the reader waits for the copy of the piece before: 0.3 s of a 54 GB file, profiles/r03n)
+	void* pieces[FEED_BUFFERS];
+	agpu_bgzf_block* tables[FEED_BUFFERS]; // pinned like the pieces: a copy from pageable memory is staged by the runtime when the stream gets there, and the caller waits for that
 	agpu_params params; // as the last sample resolved them (strandedness)
 	bool tags_loaded = false, domains_loaded = false;
 	// Host memory for what comes back from the device per sample (candidate columns, rows of supporting reads): pinned, kept by the session and only ever grown -- fresh
@@ -58,14 +59,14 @@ struct Run {
 		return (T*) buffer.pointer;
 	}
 	Run(const arriba_workflow_options& o): options(o), report(nullptr), timing(nullptr), host(nullptr), device(nullptr), dummy_genes(0), n_candidates(0), n_fragments(0), mapped_reads(0), device_ingest(false) {
-		pieces[0] = pieces[1] = nullptr;
+		for (int k = 0; k < FEED_BUFFERS; ++k) { pieces[k] = nullptr; tables[k] = nullptr; }
 		const char** texts[] = { &options.assembly_file, &options.gene_annotation_file, &options.chimeric_bam_file, &options.output_file, &options.discarded_output_file, &options.blacklist_file, &options.known_fusions_file,
 		                         &options.tags_file, &options.protein_domains_file, &options.genomic_breakpoints_file, &options.interesting_contigs, &options.viral_contigs, &options.gtf_features };
 		strings.reserve(sizeof(texts) / sizeof(texts[0]));
 		for (size_t k = 0; k < sizeof(texts) / sizeof(texts[0]); ++k) if (*texts[k] != nullptr) { strings.push_back(*texts[k]); *texts[k] = strings.back().c_str(); }
 	}
 	~Run() {
-		for (int k = 0; k < 2; ++k) if (pieces[k]) agpu_host_free(pieces[k]);
+		for (int k = 0; k < FEED_BUFFERS; ++k) { if (pieces[k]) agpu_host_free(pieces[k]); if (tables[k]) agpu_host_free(tables[k]); }
 		for (std::map<std::string, Staged>::iterator buffer = staged.begin(); buffer != staged.end(); ++buffer) if (buffer->second.pointer) agpu_host_free(buffer->second.pointer);
 		if (device) agpu_destroy(device); if (host) ahost_close(host);
 	}
@@ -143,24 +144,26 @@ void read_chimeric_alignments_on_device(Run& run) {
 	const uint64_t windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0; // (the table belongs to the session: read before anything else touches it)
 	const uint32_t n_contigs = config.n_contigs;
 	device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host))); // with the contigs of the BAM header
+	const unsigned int buffers = Run::FEED_BUFFERS;
+	config.host_buffers = buffers;
 	device_check(agpu_ingest_begin(run.device, &config));
 	const size_t piece_bytes = 256u << 20;
 	const uint32_t block_capacity = (uint32_t) (piece_bytes / 4096 + 16);
-	for (int k = 0; k < 2; ++k) { // the two pinned buffers stay with the session: pinning 2 x 256 MB costs as much as feeding a gigabyte
-		if (run.tables[k].size() != block_capacity) run.tables[k].assign(block_capacity, agpu_bgzf_block());
+	for (unsigned int k = 0; k < buffers; ++k) { // the pinned buffers stay with the session: pinning 2 x 256 MB costs as much as feeding a gigabyte
+		if (!run.tables[k]) { run.tables[k] = (agpu_bgzf_block*) agpu_host_alloc((size_t) block_capacity * sizeof(agpu_bgzf_block)); if (!run.tables[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
 		if (!run.pieces[k]) { run.pieces[k] = agpu_host_alloc(piece_bytes); if (!run.pieces[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
 	}
 	double reading = 0, pushing = 0;
 	for (unsigned int push = 0; ; ++push) {
 		ahost_bam_piece piece;
 		const double before = now_seconds();
-		const int status = ahost_bam_next(run.host, run.pieces[push & 1], piece_bytes, run.tables[push & 1].data(), block_capacity, &piece);
+		const int status = ahost_bam_next(run.host, run.pieces[push % buffers], piece_bytes, run.tables[push % buffers], block_capacity, &piece);
 		const double read = now_seconds();
 		reading += read - before;
 		if (status < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
 		if (status == 0) break;
-		if (piece.stored_bgzf) device_check(agpu_ingest_push_bgzf(run.device, run.pieces[push & 1], piece.bytes, run.tables[push & 1].data(), piece.n_blocks, piece.stream_bytes));
-		else device_check(agpu_ingest_push(run.device, run.pieces[push & 1], piece.bytes));
+		if (piece.stored_bgzf) device_check(agpu_ingest_push_bgzf(run.device, run.pieces[push % buffers], piece.bytes, run.tables[push % buffers], piece.n_blocks, piece.stream_bytes));
+		else device_check(agpu_ingest_push(run.device, run.pieces[push % buffers], piece.bytes));
 		pushing += now_seconds() - read;
 	}
 	const double fed = now_seconds();

@@ -185,7 +185,8 @@ int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* batch);             
  *   agpu_ingest_push_bgzf    the next piece of a BGZF file whose blocks are stored (STAR --outBAMcompression 0, run_arriba.sh:34): the raw bytes and
  *                            the table of the blocks inside them; the payloads are moved into the stream on the device
  *   agpu_ingest_finish       everything else; the batch is then resident as after agpu_upload_batch
- * A push returns when the piece pushed BEFORE it has left its buffer: the caller alternates between two buffers.
+ * A push returns when the piece pushed BEFORE it has left its buffer: the caller alternates between two buffers (host_buffers = n: takes n buffers in turn, and a push
+ * returns when the piece pushed n - 1 pushes ago has left its buffer -- with three the reader of the file never waits for a copy; at most 4).
  * Needs agpu_upload_annotation and agpu_upload_genome (gene index for the read-through extraction, assembly for the tandem-duplication probe). */
 typedef struct {
 	uint32_t n_targets;              /* reference sequences of the BAM header */
@@ -197,6 +198,7 @@ typedef struct {
 	uint8_t external_duplicate_marking;     /* -u */
 	uint32_t max_itd_length;                /* -l */
 	uint8_t part_of_sample;                 /* the stream holds a part of the sample's records, other contexts hold the rest: agpu_shard_export / agpu_shard_merge follow */
+	uint8_t host_buffers;                   /* buffers the caller pushes from in turn: 0 or 2 = two (see above) */
 } agpu_ingest_config;
 typedef struct { uint64_t raw_offset; uint32_t payload_offset, payload_size; uint64_t stream_offset; uint32_t crc32; uint32_t reserved; } agpu_bgzf_block; /* offsets inside the pushed piece / the piece's part of the stream */
 typedef struct {
