@@ -751,7 +751,7 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 		int least = 0, greatest = 0;
 		HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
 		HIP_CHECK(hipStreamCreateWithPriority(&ctx->piece_stream, hipStreamNonBlocking, greatest)); // (in front of the kernels of the windows: the feed waits for these)
-		for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_copied[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_ready[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_done[k], hipEventDisableTiming)); }
+		for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_copied[k], hipEventDisableTiming | hipEventBlockingSync)); /* (the thread that waits for a copy leaves its core to the readers of the file) */ HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_ready[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_done[k], hipEventDisableTiming)); }
 	}
 	if (config->host_buffers > AGPU_PIECE_SLOTS) { set_last_error("agpu_ingest_config.host_buffers: at most 4"); return AGPU_ERR_INVALID; }
 	ctx->ingest_host_buffers = config->host_buffers < 2 ? 2 : config->host_buffers;

@@ -67,6 +67,7 @@ struct ahost_session {
 	// device ingest: the open file and what agpu_ingest_begin needs from its header
 	BamFeed* feed = nullptr;
 	bool device_batch = false;           // the fragments live on the device (ahost_adopt_device_ingest)
+	Batch spare_rows;                    // the vectors of the last sample's rows (ahost_set_batch_rows), kept over ahost_bam_open for the next sample's
 	std::string formatted_rows;          // ahost_format_fusions: the rows of this rank's share of an output file, until the next call
 	std::vector<uint32_t> row_fragments; // device ingest: the fragment of every row of ingest.batch (ascending); empty = the batch holds every fragment
 	bool rows_in_list_order = false;     // ... or row k holds the fragment of entry k of the read lists of the table written next (ahost_set_batch_rows without fragments)
@@ -456,6 +457,7 @@ int ahost_bam_open(ahost_session* session, const char* bam_path, int external_du
 		if (session->feed) { close_bam_feed(session->feed); session->feed = nullptr; }
 		session->options.external_duplicate_marking = external_duplicate_marking != 0;
 		session->options.max_itd_length = max_itd_length;
+		if (session->device_batch && session->ingest.batch.seq_pool.capacity() > session->spare_rows.seq_pool.capacity()) session->spare_rows = std::move(session->ingest.batch); // (the rows of the last sample's writer: their memory is taken again by ahost_set_batch_rows)
 		session->ingest = IngestResult();
 		session->have_batch = false;
 		session->feed = open_bam_feed(bam_path);
@@ -534,7 +536,10 @@ int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* 
 int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments) {
 	if (!session || !rows) { g_error = "null argument"; return -1; }
 	try {
-		Batch& b = session->ingest.batch; // (every member is assigned below: the vectors keep their memory from one file to the next)
+		Batch& b = session->ingest.batch;
+		// every member is assigned below.  The vectors of the last sample's rows come back first (ahost_bam_open put them aside): a gigabyte of fresh vectors per sample is mapped,
+		// zero-filled by resize() and faulted in page by page -- 0.34 s for the 9.3 M rows of a 10^8-fragment sample, of which the copy itself is a tenth (profiles/r03p_writer_laps.txt)
+		if (session->spare_rows.seq_pool.capacity() > b.seq_pool.capacity()) b = std::move(session->spare_rows);
 		const size_t n = rows->n;
 		b.n = n;
 		// the columns and pools of 10^7 rows are more than a gigabyte: the vectors are sized first, the bytes then copied by all threads the process may use

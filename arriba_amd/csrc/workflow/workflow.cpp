@@ -5,13 +5,16 @@
 #include "../../../include/arriba_workflow.h"
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -38,7 +41,7 @@ struct Run {
 	uint32_t dummy_genes;
 	uint64_t n_candidates, n_fragments, mapped_reads;
 	bool device_ingest;
-	enum { FEED_BUFFERS = 3 }; // (with two the reader waits for the copy of the piece before: 0.3 s of a 54 GB file, profiles/r03n)
+	enum { FEED_BUFFERS = 4 }; // (see read_chimeric_alignments_on_device)
 	void* pieces[FEED_BUFFERS];
 	agpu_bgzf_block* tables[FEED_BUFFERS]; // pinned like the pieces: a copy from pageable memory is staged by the runtime when the stream gets there, and the caller waits for that
 	agpu_params params; // as the last sample resolved them (strandedness)
@@ -144,8 +147,12 @@ void read_chimeric_alignments_on_device(Run& run) {
 	const uint64_t windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0; // (the table belongs to the session: read before anything else touches it)
 	const uint32_t n_contigs = config.n_contigs;
 	device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host))); // with the contigs of the BAM header
+	// The file is read by one thread (ahost_bam_next: all cores pread into the next pinned buffer) while this one pushes the piece before (agpu_ingest_push*: enqueue the copy,
+	// move the windows of the ingest on -- ~1 ms of runtime calls per piece, 0.17-0.26 s of a 54 GB file when the reader had to wait for them, profiles/r03o, r03p).  A push returns
+	// when the piece pushed two pushes ago has left its buffer (host_buffers = 3); with four buffers in turn the buffer of piece k is free when push k - 2 has returned, so piece k
+	// is read while piece k - 1 is pushed and neither waits for the other's bookkeeping.
 	const unsigned int buffers = Run::FEED_BUFFERS;
-	config.host_buffers = buffers;
+	config.host_buffers = 3;
 	device_check(agpu_ingest_begin(run.device, &config));
 	const size_t piece_bytes = 256u << 20;
 	const uint32_t block_capacity = (uint32_t) (piece_bytes / 4096 + 16);
@@ -153,19 +160,42 @@ void read_chimeric_alignments_on_device(Run& run) {
 		if (!run.tables[k]) { run.tables[k] = (agpu_bgzf_block*) agpu_host_alloc((size_t) block_capacity * sizeof(agpu_bgzf_block)); if (!run.tables[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
 		if (!run.pieces[k]) { run.pieces[k] = agpu_host_alloc(piece_bytes); if (!run.pieces[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
 	}
-	double reading = 0, pushing = 0;
+	struct Feed {
+		std::mutex mutex; std::condition_variable changed;
+		unsigned int read = 0, pushed = 0; // pieces read / pushes that have returned
+		bool at_end = false, stop = false; std::string error;
+		ahost_bam_piece pieces[Run::FEED_BUFFERS];
+		double reading = 0;
+	} feed;
+	std::thread reader([&run, &feed, buffers, piece_bytes, block_capacity] {
+		for (unsigned int k = 0; ; ++k) {
+			{ std::unique_lock<std::mutex> lock(feed.mutex); feed.changed.wait(lock, [&] { return feed.stop || k < buffers || feed.pushed + 1 >= k; }); if (feed.stop) return; } // (push k - 2 has returned: piece k - 4 has left this buffer)
+			const double before = now_seconds();
+			ahost_bam_piece piece;
+			const int status = ahost_bam_next(run.host, run.pieces[k % buffers], piece_bytes, run.tables[k % buffers], block_capacity, &piece);
+			std::lock_guard<std::mutex> lock(feed.mutex);
+			feed.reading += now_seconds() - before;
+			if (status < 0) feed.error = std::string("ERROR: ") + ahost_last_error(); // (the text belongs to this thread)
+			if (status <= 0) { feed.at_end = true; feed.changed.notify_all(); return; }
+			feed.pieces[k % buffers] = piece; feed.read = k + 1;
+			feed.changed.notify_all();
+		}
+	});
+	struct Joiner { std::thread& thread; Feed& feed; ~Joiner() { { std::lock_guard<std::mutex> lock(feed.mutex); feed.stop = true; } feed.changed.notify_all(); if (thread.joinable()) thread.join(); } } joiner = { reader, feed }; // (on every way out)
+	double pushing = 0;
 	for (unsigned int push = 0; ; ++push) {
 		ahost_bam_piece piece;
+		{ std::unique_lock<std::mutex> lock(feed.mutex); feed.changed.wait(lock, [&] { return feed.read > push || feed.at_end; }); if (feed.read <= push) break; piece = feed.pieces[push % buffers]; }
 		const double before = now_seconds();
-		const int status = ahost_bam_next(run.host, run.pieces[push % buffers], piece_bytes, run.tables[push % buffers], block_capacity, &piece);
-		const double read = now_seconds();
-		reading += read - before;
-		if (status < 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
-		if (status == 0) break;
 		if (piece.stored_bgzf) device_check(agpu_ingest_push_bgzf(run.device, run.pieces[push % buffers], piece.bytes, run.tables[push % buffers], piece.n_blocks, piece.stream_bytes));
 		else device_check(agpu_ingest_push(run.device, run.pieces[push % buffers], piece.bytes));
-		pushing += now_seconds() - read;
+		pushing += now_seconds() - before;
+		{ std::lock_guard<std::mutex> lock(feed.mutex); feed.pushed = push + 1; }
+		feed.changed.notify_all();
 	}
+	reader.join();
+	if (!feed.error.empty()) throw Failure{ feed.error };
+	const double reading = feed.reading;
 	const double fed = now_seconds();
 	if (run.timing) { run.timing->feed_read = reading; run.timing->feed_push = pushing; }
 	agpu_ingest_result result;
