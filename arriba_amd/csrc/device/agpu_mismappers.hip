@@ -181,11 +181,11 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, 5) mismapper_verdict_kernel(Batch
 // (AlignMemo, mismapper_core.hpp: it turns the exponential re-evaluation of the reference's recursion into one search per distinct call).  The workgroups are
 // persistent: each owns one memo table in HBM and takes the next heavy read from a queue (counters[4]) when it is done with one -- the searches differ in
 // length by orders of magnitude, a fixed share per workgroup would wait for the unluckiest one.  The kernel waits for dependent loads (k-mer table -> hit list ->
-// genome bases -> memo slot), so the number of wavefronts in flight is what sets its speed: 4096 workgroups of one wavefront = 4 per SIMD.
-const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 32 GB for 4096 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
+// genome bases -> memo slot), so the number of wavefronts in flight is what sets its speed: 5120 workgroups of one wavefront = 5 per SIMD.
+const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 41 GB for 5120 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
                                         // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
-const uint32_t HEAVY_WORKGROUPS = 4096;
-__global__ void __launch_bounds__(64, 4) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
+const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch bounds below)
+template <int WAVES_PER_SIMD> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
                                                              unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters) {
 	__shared__ uint8_t segment_bases[304];
 	__shared__ AlignSweep sweep;
@@ -429,10 +429,13 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 			ALLOC(heavy, (size_t) std::max<uint32_t>(n_jobs, 1) * 4);
 			uint32_t n_heavy = 0;
 			if (n_jobs > 0) {
-			const char* first_pass = getenv("ARRIBA_MISMAPPER_FIRST_PASS"); // "0": every read goes to the wavefront-per-read pass (for A/B measurements)
+			// Since the wavefront-per-read kernel sweeps every seed of a read once it is the cheaper place for every read: without the thread-per-read pass in front of it the
+			// step is 0.04 s shorter at 10^7 fragments and 0.10 s at 10^8 (the 11 % of the reads that the first pass finished cost the second nothing measurable:
+			// profiles/r03r_mismapper_passes.txt).  "1": with the first pass, for measurements.
+			const char* first_pass = getenv("ARRIBA_MISMAPPER_FIRST_PASS");
 			const char* steps_knob = getenv("ARRIBA_FIRST_PASS_STEPS");
 			const int64_t first_pass_steps = steps_knob != nullptr && atoll(steps_knob) > 0 ? atoll(steps_knob) : FIRST_PASS_STEPS;
-			if (first_pass != nullptr && first_pass[0] == '0') {
+			if (!(first_pass != nullptr && first_pass[0] == '1')) {
 				HIP_CHECK(hipMemcpyAsync(heavy.ptr, job_list, (size_t) n_jobs * 4, hipMemcpyDeviceToDevice, s));
 				n_heavy = n_jobs;
 			} else {
@@ -452,7 +455,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				DeviceBuffer& memo_tables = ctx->scratch("mismappers.memo_tables");
 				ALLOC(memo_tables, (size_t) workgroups * memo_slots * 8);
 				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));
-				// the task lists of the workgroups: 2^17 tasks of 16 bytes each (2 MB; 8 GB for 4096 workgroups) (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
+				// the task lists of the workgroups: 2^17 tasks of 16 bytes each (2 MB, and as much again for the calls of a block beyond the memory of the sweep: 21 GB for 5120 workgroups) (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
 				knob = getenv("ARRIBA_MISMAPPER_WORKLIST");
 				const bool use_worklist = !(knob != nullptr && knob[0] == '0');
 				const uint32_t task_capacity = 1u << 17;
@@ -464,7 +467,13 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				DeviceBuffer& read_times = ctx->scratch("mismappers.read_times");
 				if (want_times) { ALLOC(read_times, (size_t) n_heavy * 32 + 32); HIP_CHECK(hipMemsetAsync(read_times.as<unsigned long long>() + 4 * (size_t) n_heavy, 0, 32, s)); }
 				{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-				  mismapper_heavy_kernel<<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
+				  // (launch bounds: left alone the compiler takes 132 VGPRs, which fit 3 wavefronts per SIMD: 554 ms at 10^8 fragments; 4 per SIMD = 128 VGPRs, 3 spilled: 459 ms
+				  //  with 4096 workgroups; 5 = 96 VGPRs, 61 spilled: 416 ms with 5120 workgroups -- profiles/r03p, r03r.  ARRIBA_HEAVY_WAVES=4 with ARRIBA_HEAVY_WORKGROUPS=4096 for measurements)
+				  if (!(getenv("ARRIBA_HEAVY_WAVES") != nullptr && atoi(getenv("ARRIBA_HEAVY_WAVES")) == 4))
+				  mismapper_heavy_kernel<5><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
+				                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters);
+				  else
+				  mismapper_heavy_kernel<4><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
 				                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters); }
 				if (want_times) {
 					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy + 4);
