@@ -469,7 +469,6 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			}
 		};
 		if (n_threads == 1 || count < 4) work();
-		else if (getenv("ARRIBA_WRITER_SPAWN")) { std::vector<std::thread> threads; for (unsigned int t = 0; t < std::min<size_t>(n_threads, count); ++t) threads.push_back(std::thread(work)); for (size_t t = 0; t < threads.size(); ++t) threads[t].join(); }
 		else { std::lock_guard<std::mutex> one_file(formatter_pool_in_use); formatter_pool().run((unsigned) std::min<size_t>(n_threads, count), work); }
 		if (failure) { if (out) fclose(out); std::rethrow_exception(failure); }
 		for (size_t k = 0; k < count; ++k) {
