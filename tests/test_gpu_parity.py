@@ -612,7 +612,7 @@ def test_device_ingest_at_scale_and_every_container(built, tmp_path):
     different = [key for key in expected if expected[key] != columns[key]]
     assert not different, different
     assert expected["n"] > 1100000 and pipeline.ingest_result.names_were_sorted == 0
-    assert pipeline.ingest_result.windows >= 3  # (64 MB pieces of a file of ~0.6 GB: a window every second piece, and the last one)
+    assert pipeline.ingest_result.windows >= 2  # (64 MB pieces of a file of ~0.8 GB: a window when 512 MB have arrived, and the last one)
     payload = gzip.open(prefix + ".bam", "rb").read()
     open(str(tmp_path / "raw.bam"), "wb").write(payload)
     cpu_tier._write_bgzf(str(tmp_path / "deflated.bam"), payload, 1)
