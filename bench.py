@@ -514,7 +514,7 @@ def main():
             }
             # the search kernel that dominates is bound by the latency of dependent look-ups, not by bandwidth; beside it the best streaming kernel of the step, priced the same way
             # (round 2 printed the fastest one here, a 0.1 ms kernel whose input was still in the caches; now the one the step spends most time in)
-            streaming = {name: values["bytes"] / values["ms"] / 1e6 for name, values in modelled.items() if not name.startswith("mismapper_")}
+            streaming = {name: values["bytes"] / values["ms"] / 1e6 for name, values in modelled.items() if not name.startswith("mismapper_") and name != dominant}
             if streaming:
                 best = max(streaming, key=lambda name: modelled[name]["ms"])
                 line["roofline_streaming"] = {"bound": "hbm", "kernel": best, "achieved": streaming[best], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": streaming[best] / HBM_PEAK_GBS,
