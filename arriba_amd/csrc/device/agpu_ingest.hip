@@ -34,7 +34,7 @@ const int BLOCK = 256;
 inline unsigned int grid_for(uint64_t n, int block = BLOCK) { return (unsigned int) ((n + block - 1) / block); }
 
 enum { IC_ACTIVE = 0, IC_MAPPED_READS = 1, IC_MISSING_HI = 2, IC_BROKEN = 3, IC_MALFORMED = 4, IC_CHIMERIC = 5, IC_COLLISION = 6, IC_MISMATCH = 7, IC_UNSORTED = 8, IC_MAX_NAME = 9,
-       IC_MAX_READ_LENGTH = 10, IC_STRAND_COUNT = 11, IC_STRAND_MATCHING = 12, IC_COUNT = 16 };
+       IC_MAX_READ_LENGTH = 10, IC_STRAND_COUNT = 11, IC_STRAND_MATCHING = 12, IC_RUNS_UNSORTED = 13, IC_COUNT = 16 };
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
 #define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
@@ -261,6 +261,21 @@ __global__ void name_order_check_kernel(IngestStream in, const uint32_t* group_f
 	}
 	__syncthreads();
 	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_NAME], block_max);
+}
+
+// The same question asked of the runs of a window while the file is still being copied: is the name of every run behind the name of the run before it -- and behind that
+// run's "ITD" entry where it has a valid one?  If so for all runs, the valid fragments are in name order, too (the names of the runs between two of them chain), and the pass over
+// the fragments behind the last piece is not needed (42 ms at 10^8 fragments); if not -- names in FASTQ order, as STAR writes them, or a run without a fragment out of order --
+// that pass decides as before.
+__global__ void run_name_order_kernel(IngestStream in, const uint32_t* group_first, const uint8_t* valid, uint32_t first_group, uint32_t n_groups, uint32_t* counters) {
+	const uint32_t g = first_group + blockIdx.x * BLOCK + threadIdx.x;
+	if (g >= n_groups || g == 0) return;
+	Rec storage_a, storage_b;
+	const FragmentName mine = name_of(in, group_first, 2 * g, storage_b);
+	FragmentName before = name_of(in, group_first, 2 * (g - 1), storage_a);
+	bool unsorted = compare_names(before, mine) >= 0;
+	if (!unsorted && valid[2 * (size_t) (g - 1) + 1]) { before = fragment_name(storage_a, true); unsorted = compare_names(before, mine) >= 0; }
+	if (unsorted) atomicOr(&counters[IC_RUNS_UNSORTED], 1u);
 }
 
 __global__ void name_chunk_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
@@ -631,6 +646,8 @@ int window_step(agpu_ctx* ctx, IngestWindow& w) {
 		{ KernelTimer timer(ctx, "group_replay_kernel", n * SEGMENT_BYTES, s);
 		  group_replay_kernel<<<grid_for(groups), BLOCK, 0, s>>>(replay_context(ctx, in), active_records, run_begin, group_count.as<uint32_t>(), (uint32_t) first_group, (uint32_t) n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
 		                                                        sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
+		{ KernelTimer timer(ctx, "run_name_order_kernel", groups * 2 * (4 + 40), s);
+		  run_name_order_kernel<<<grid_for(groups), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), valid.as<uint8_t>(), (uint32_t) first_group, (uint32_t) n_groups, device_counters); }
 		p.groups_done = n_groups; p.touched = true;
 		break; }
 	}
@@ -1055,10 +1072,13 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	if (n_fragments > 0) {
 		ALLOC(order_keys, fragments1 * 8); ALLOC(order_keys_sorted, fragments1 * 8);
 		HIP_CHECK(hipMemcpyAsync(order.ptr, refs.ptr, n_fragments * 4, hipMemcpyDeviceToDevice, s)); // ascending references == the order of first occurrence (the groups are numbered by their first records)
-		{ KernelTimer timer(ctx, "name_order_check_kernel", n_fragments * (4 + 2 * 40));
-		  name_order_check_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, device_counters); }
+		const bool runs_in_name_order = streamed && host_counters[IC_RUNS_UNSORTED] == 0; // (told by the windows: run_name_order_kernel)
+		if (!runs_in_name_order) {
+			KernelTimer timer(ctx, "name_order_check_kernel", n_fragments * (4 + 2 * 40));
+			name_order_check_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, device_counters);
+		}
 		TRY(read_counters());
-		if (host_counters[IC_UNSORTED]) { // the names are not in std::string order: least-significant-chunk-first radix sort over the 8-byte chunks of the names
+		if (!runs_in_name_order && host_counters[IC_UNSORTED]) { // the names are not in std::string order: least-significant-chunk-first radix sort over the 8-byte chunks of the names
 			names_were_sorted = false;
 			const uint32_t chunks = (host_counters[IC_MAX_NAME] + 7) / 8;
 			for (uint32_t chunk = chunks; chunk-- > 0; ) {

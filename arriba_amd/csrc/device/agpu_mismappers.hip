@@ -144,18 +144,15 @@ __global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, 
 	if (j < n_jobs) keys[j] = first_entry[jobs[j]];
 }
 
-// First pass, one thread per read: the reference's seed-and-extend search (mismapper_core.hpp) is a chain of dependent look-ups -- k-mer table, position list,
-// genome bases -- of ~10^3 steps for an ordinary read, so the lanes of a wavefront are best spent on 64 different reads.  What makes a lane fast: the frame of the
-// call being worked on sits in registers (the stack in scratch memory only sees calls and returns), the bases of the segment sit in LDS (one column per lane),
-// the stack is short (ALIGN_SHALLOW_DEPTH: enough for reads of 128 nt) so that the scratch memory does not limit the wavefronts in flight.  The jobs are ordered
-// by the candidate that lists the read first: the lanes of a wavefront then work on reads of one gene pair -- the same k-mer tables and genome windows, searches of
-// similar length.  A read that runs out of its step budget (or of stack) is put on the `heavy` list: the verdict of a read does not depend on who computes it.
+// The thread-per-read pass of round 2, off by default since the second pass sweeps every seed of a read once and is the cheaper place for every read (see the launch below;
+// ARRIBA_MISMAPPER_FIRST_PASS=1 turns it on for measurements).  One thread per read: the reference's seed-and-extend search (mismapper_core.hpp) as a chain of dependent
+// look-ups -- k-mer table, position list, genome bases; the frame of the call being worked on sits in registers (the stack in scratch memory only sees calls and returns), the
+// bases of the segment sit in LDS (one column per lane), the stack is short (ALIGN_SHALLOW_DEPTH: enough for reads of 128 nt).  The jobs are ordered by the candidate that lists
+// the read first: the lanes of a wavefront then work on reads of one gene pair.  A read that runs out of its step budget (or of stack) is put on the `heavy` list: the verdict
+// of a read does not depend on who computes it.
 const int SEGMENT_CACHE = 128; // bases of a segment kept in LDS per lane (longer segments are read from HBM)
-// Steps of the search loop + bases compared that a read gets in the first pass; the mean is ~1100.  A thread that uses up a long budget keeps its wavefront (63 idle
-// lanes) and with it the whole launch waiting -- ~15 us per step under divergence -- while the second pass takes over such a read.  Round 2 (second pass: a wavefront per read
-// walking the recursion, profiles/r03c_mismapper_second_pass.txt) was fastest with 2048; since the second pass sweeps every seed of a read once (align_by_sweep) it is the
-// cheaper place for all but the short searches: at 10^8 fragments first + second pass take 641 + 306 ms with 2048 steps, 235 + 471 ms with 512, 119 + 539 ms with 256
-// (profiles/r03e_mismapper_sweep.txt; ARRIBA_FIRST_PASS_STEPS for measurements).
+// Steps of the search loop + bases compared that a read gets in that pass.  At 10^8 fragments first + second pass took 641 + 306 ms with 2048 steps, 235 + 471 ms with 512,
+// 119 + 539 ms with 256 (profiles/r03e_mismapper_sweep.txt; ARRIBA_FIRST_PASS_STEPS for measurements) -- and 0 + 460 ms without the pass (profiles/r03r_mismapper_passes.txt).
 const int64_t FIRST_PASS_STEPS = 256;
 __global__ void __launch_bounds__(ALIGN_BLOCK, 5) mismapper_verdict_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* jobs, uint32_t n_jobs, int32_t max_mate_gap,
                                                                         int64_t first_pass_steps, uint32_t* heavy, unsigned int* counters /* [1] discarded, [3] heavy */) {
