@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on one MI355X: chimeric reads/s END TO END, BAM file -> fusions.tsv.
 
-A "step" is one whole run of the workflow over one sample (BASELINE.json config 2/3: synthetic chimeric-read BAM, 2x100 bp, uncompressed BGZF as STAR
+A "step" is one whole run of the workflow over one sample -- at N = 1 one call of arriba_workflow_sample of libarriba_workflow.so, the C++ driver over the two C ABIs with a resident
+session (--python-stages: the ctypes mirror of the stage order instead) -- (BASELINE.json config 2/3: synthetic chimeric-read BAM, 2x100 bp, uncompressed BGZF as STAR
 --outBAMcompression 0 writes it, run_arriba.sh:34): the BAM file (resident in the page cache / tmpfs, as the reference would read it) is opened, its
 header parsed, its bytes fed to the GPU, read_chimeric_alignments runs in HBM (agpu_ingest.hip), then every stage of the reference's main() in its order --
 the read-level cascade, find_fusions, merge_adjacent, filter_multimappers, e-value, every candidate-level filter, make_kmer_index + filter_homologs +
@@ -12,8 +13,8 @@ the line says how much that is.  The time from the resident batch to the end of 
 field `device_resident_step`.
 
 With --gpus N the N ranks work on ONE sample of the same size (BASELINE.json config 4; arriba_amd/one_sample.py): every rank ingests its part of the records of
-the file, one all-gather puts the batch together on every GPU, the stages up to filter_homologs (~1 % of the time) run on every rank, the re-alignments of
-filter_mismappers (~80 %) are shared out with one all-reduce of the verdicts, rank 0 writes the files; value = fragments of the sample / the slowest rank's
+the file, one all-gather puts the batch together on every GPU, the stages up to filter_homologs run on every rank, the re-alignments of filter_mismappers are shared out
+with one all-reduce of the verdicts, rank 0 writes the files (with the one-GPU step of round 3 the replicated stages cap this at ~1.7x for N = 8: DESIGN.md section 6); value = fragments of the sample / the slowest rank's
 time ("scaling": "strong").  --per-rank-samples gives every rank a sample of its own instead (no collective on the data path; "weak").  Rank 0 prints ONE JSON line.
 
 The CPU baseline is the oracle build of the UNMODIFIED reference (oracle/_ref/arriba_ref, single-threaded by design) on a bounded sample of the same workload.
