@@ -333,25 +333,34 @@ __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const
 	__shared__ Crc32Tables t;
 	__shared__ uint32_t part[256];
 	__shared__ uint32_t length[256];
-	// The payload of the block, staged: read from HBM once, in words that neighbouring lanes read next to each other.  (The first version let every lane walk its own 256 bytes
-	// straight from HBM, four at a time: 64 lanes, 64 lines per load, each line needed again 63 loads later by when the 4096 workgroups in flight had pushed it out of the L2 --
-	// 119 GB fetched for a 5.4 GB stream, profiles/r03s_pmc_summary.txt.)  Chunk c lies at word 65 c: an odd stride, so that the lanes, each on its own chunk, hit different banks.
-	__shared__ uint32_t staged[256 * (CRC32_CHUNK / 4 + 1)];
+	// The payload of the block goes through LDS: read from HBM once, in words that neighbouring lanes read next to each other.  (The first version let every lane walk its own
+	// 256 bytes straight from HBM, four at a time: 64 lanes, 64 lines per load, each line needed again 63 loads later by when the 4096 workgroups in flight had pushed it out of
+	// the L2 -- 119 GB fetched for a 5.4 GB stream, profiles/r03s_pmc_summary.txt.  The second staged the whole block: at its algorithmic bytes, but 75 KB of LDS are two
+	// workgroups per CU and the launch took 2.4 ms instead of 1.1, profiles/r03w_kernel_stats_10m.txt.)  Now in four rounds of 16 words per lane: 17 KB, chunk c at word 17 c --
+	// an odd stride, so that the lanes, each on its own chunk, hit different banks; sixteen neighbouring lanes load 64 consecutive bytes.
+	const uint32_t ROUND_WORDS = CRC32_CHUNK / 16; // words of a lane's chunk per round
+	__shared__ uint32_t staged[256 * (CRC32_CHUNK / 16 + 1)];
 	for (uint32_t k = threadIdx.x; k < sizeof(Crc32Tables) / 4; k += 256) ((uint32_t*) &t)[k] = ((const uint32_t*) tables)[k];
 	const agpu_bgzf_block block = blocks[blockIdx.x];
 	if (block.crc32 == 0 || block.payload_size > 256u * CRC32_CHUNK) return; // (uniform; a BGZF block holds at most 64 KB)
 	const uint8_t* payload = raw + block.raw_offset + block.payload_offset;
-	const uint32_t words = (block.payload_size + 3) / 4;
-	for (uint32_t w = threadIdx.x; w < words; w += 256) {
-		uint32_t word = 0;
-		if (4 * w + 4 <= block.payload_size) word = load_u32(payload + 4 * (size_t) w);
-		else for (uint32_t b = 4 * w; b < block.payload_size; ++b) word |= (uint32_t) payload[b] << (8 * (b - 4 * w)); // (the last bytes of the block: nothing behind them is read)
-		staged[(w / (CRC32_CHUNK / 4)) * (CRC32_CHUNK / 4 + 1) + w % (CRC32_CHUNK / 4)] = word;
-	}
-	__syncthreads();
 	const uint32_t at = threadIdx.x * CRC32_CHUNK;
 	const uint32_t mine = at < block.payload_size ? (block.payload_size - at < CRC32_CHUNK ? block.payload_size - at : CRC32_CHUNK) : 0;
-	part[threadIdx.x] = mine ? crc32_of_sliced(t.slice, (const uint8_t*) &staged[threadIdx.x * (CRC32_CHUNK / 4 + 1)], mine) : 0u;
+	uint32_t running = 0xFFFFFFFFu;
+	for (uint32_t round = 0; round < CRC32_CHUNK / 4 / ROUND_WORDS; ++round) {
+		__syncthreads(); // (the tables are there; the words of the round before have been used)
+		for (uint32_t item = threadIdx.x; item < 256 * ROUND_WORDS; item += 256) {
+			const uint32_t chunk = item / ROUND_WORDS, j = item % ROUND_WORDS, w = chunk * (CRC32_CHUNK / 4) + round * ROUND_WORDS + j; // word w of the payload
+			uint32_t word = 0;
+			if (4 * w + 4 <= block.payload_size) word = load_u32(payload + 4 * (size_t) w);
+			else for (uint32_t b = 4 * w; b < block.payload_size; ++b) word |= (uint32_t) payload[b] << (8 * (b - 4 * w)); // (the last bytes of the block: nothing behind them is read)
+			staged[chunk * (ROUND_WORDS + 1) + j] = word;
+		}
+		__syncthreads();
+		const uint32_t done = round * ROUND_WORDS * 4;
+		if (mine > done) running = crc32_update_sliced(t.slice, running, (const uint8_t*) &staged[threadIdx.x * (ROUND_WORDS + 1)], mine - done < ROUND_WORDS * 4 ? mine - done : ROUND_WORDS * 4);
+	}
+	part[threadIdx.x] = mine ? running ^ 0xFFFFFFFFu : 0u;
 	length[threadIdx.x] = mine;
 	__syncthreads();
 	for (uint32_t stride = 1; stride < 256; stride *= 2) {
@@ -866,8 +875,10 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
 		ctx->ingest_stream_size += stream_bytes;
 		HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], pieces));
-		if (ctx->ingest_verify_crc) // (0.95 ms per 256 MB piece; between the copies on one stream it cost 0.3 s of a 54 GB file)
+		if (ctx->ingest_verify_crc) { // (~1 ms per 256 MB piece; between the copies on one stream it cost 0.3 s of a 54 GB file)
+			KernelTimer timer(ctx, "bgzf_crc_kernel", raw_size, pieces);
 			bgzf_crc_kernel<<<n_blocks, 256, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+		}
 		HIP_CHECK(hipEventRecord(ctx->piece_done[slot], pieces));
 	} else { HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], s)); HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], s)); }
 	TRY(wait_for_previous_push(ctx));

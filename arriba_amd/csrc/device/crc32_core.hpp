@@ -28,6 +28,17 @@ AGPU_HD uint32_t gf2_matrix_times(const uint32_t* matrix, uint32_t vector) {
 	return sum;
 }
 AGPU_HD void gf2_matrix_square(uint32_t* square, const uint32_t* matrix) { for (int k = 0; k < 32; ++k) square[k] = gf2_matrix_times(matrix, matrix[k]); }
+// the same in parts: c = 0xFFFFFFFF before the first part, the CRC is ~c behind the last; every part but the last a multiple of four bytes
+AGPU_HD uint32_t crc32_update_sliced(const uint32_t (*slice)[256], uint32_t c, const uint8_t* bytes, size_t n) {
+	size_t i = 0;
+	for (; i + 4 <= n; i += 4) {
+		uint32_t word; __builtin_memcpy(&word, bytes + i, 4);
+		c ^= word;
+		c = slice[3][c & 0xFFu] ^ slice[2][(c >> 8) & 0xFFu] ^ slice[1][(c >> 16) & 0xFFu] ^ slice[0][c >> 24];
+	}
+	for (; i < n; ++i) c = slice[0][(c ^ bytes[i]) & 0xFFu] ^ (c >> 8);
+	return c;
+}
 // crc32 of A || B from crc32(A), crc32(B) and |B| (zlib: crc32_combine)
 AGPU_HD uint32_t crc32_joined(uint32_t crc_a, uint32_t crc_b, uint64_t length_b) {
 	if (length_b == 0) return crc_a;
