@@ -600,6 +600,24 @@ def test_front_of_the_ingest_in_windows_and_behind_the_last_piece(name, built, t
         assert pipeline.detect_strandedness() == host.detect_strandedness()
 
 
+def test_device_ingest_of_a_file_without_records(built, tmp_path):
+    """a BAM file that is a header and nothing else (raw, and as one stored BGZF block + end-of-file marker): the last -- and only -- window of the ingest has no segment, no
+    record and no run; the workflow ends with the reference's 'no normal reads found' (source/read_chimeric_alignments.cpp:759), as the host ingest does"""
+    import struct
+    import test_host_and_device_logic as cpu_tier
+    from arriba_amd.pipeline import ArribaError, DevicePipeline, HostSession
+    prefix = datasets.generate({"args": ["--seed", "2", "--fragments", "10", "--contigs", "2", "--contig-len", "150000", "--junctions", "5", "--reference-only"]}, str(tmp_path))
+    names = [b"1", b"2"]
+    header = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", len(names))
+    for name in names:
+        header += struct.pack("<i", len(name) + 1) + name + b"\x00" + struct.pack("<i", 150000)
+    open(str(tmp_path / "raw.bam"), "wb").write(header)
+    cpu_tier._write_bgzf(str(tmp_path / "stored.bam"), header, 0)
+    for variant in ("raw.bam", "stored.bam"):
+        with pytest.raises(ArribaError, match="no normal reads found"):
+            DevicePipeline(HostSession(prefix + ".fa", prefix + ".gtf"), bam=str(tmp_path / variant), piece_bytes=1 << 20)
+
+
 def test_device_ingest_at_scale_and_every_container(built, tmp_path):
     """1.2 M fragments + 0.6 M ordinary pairs (more segments, groups and fragments than any launch grid cap), shuffled names: the batch equals the host ingest's;
     the same stream as deflated BGZF and as raw BAM gives the same batch"""
