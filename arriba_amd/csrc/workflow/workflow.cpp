@@ -43,6 +43,7 @@ struct Run {
 	bool device_ingest;
 	enum { FEED_BUFFERS = 4 }; // (see read_chimeric_alignments_on_device)
 	void* pieces[FEED_BUFFERS];
+	size_t piece_bytes = 0;
 	agpu_bgzf_block* tables[FEED_BUFFERS]; // pinned like the pieces: a copy from pageable memory is staged by the runtime when the stream gets there, and the caller waits for that
 	agpu_params params; // as the last sample resolved them (strandedness)
 	bool tags_loaded = false, domains_loaded = false;
@@ -154,7 +155,10 @@ void read_chimeric_alignments_on_device(Run& run) {
 	const unsigned int buffers = Run::FEED_BUFFERS;
 	config.host_buffers = 3;
 	device_check(agpu_ingest_begin(run.device, &config));
-	const size_t piece_bytes = 256u << 20;
+	size_t piece_bytes = 256u << 20;
+	if (const char* knob = getenv("ARRIBA_FEED_PIECE_MB")) if (atoi(knob) >= 1 && atoi(knob) <= 256) piece_bytes = (size_t) atoi(knob) << 20; // (tests: many pieces of a small file through the reader and the pusher)
+	if (run.piece_bytes != 0 && run.piece_bytes != piece_bytes) for (unsigned int k = 0; k < buffers; ++k) { if (run.pieces[k]) agpu_host_free(run.pieces[k]); if (run.tables[k]) agpu_host_free(run.tables[k]); run.pieces[k] = nullptr; run.tables[k] = nullptr; }
+	run.piece_bytes = piece_bytes;
 	const uint32_t block_capacity = (uint32_t) (piece_bytes / 4096 + 16);
 	for (unsigned int k = 0; k < buffers; ++k) { // the pinned buffers stay with the session: pinning 2 x 256 MB costs as much as feeding a gigabyte
 		if (!run.tables[k]) { run.tables[k] = (agpu_bgzf_block*) agpu_host_alloc((size_t) block_capacity * sizeof(agpu_bgzf_block)); if (!run.tables[k]) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }

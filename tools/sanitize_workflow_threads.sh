@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/sanitize_workflow_threads.sh -- the C++ workflow driver (arriba_gpu_workflow's code) on the host stepping harness, host library and harness built with
 # ThreadSanitizer: the threads of the file feed (pread in ranges), of the host side of the device ingest and of the output writer (rows formatted in parallel) on a
-# sample with insertions, deletions and non-template bases, -X (fusion transcripts for the discarded candidates, too).  Test tooling.
+# sample with insertions, deletions and non-template bases, -X (fusion transcripts for the discarded candidates, too); the file in pieces of 1 MB, so that the reader thread and
+# the pusher of the driver (four pinned buffers in turn) hand ~20 pieces to each other.  Test tooling.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 WORK=$(mktemp -d /tmp/tsan_XXXXXX)
@@ -11,6 +12,6 @@ g++ -std=c++17 -O1 -g -fPIC -shared -pthread -fsanitize=thread -Wno-parentheses 
 g++ -std=c++17 -O1 -g -pthread -fsanitize=thread -include emu_names.h -o $WORK/workflow_tsan $ROOT/arriba_amd/csrc/workflow/workflow.cpp $ROOT/arriba_amd/csrc/workflow/main.cpp -L$WORK -lemu -larriba_host -Wl,-rpath,$WORK
 $ROOT/arriba_amd/lib/gen_synth --out $WORK/d --seed 303 --fragments 30000 --normal-mult 0.4 --contigs 5 --contig-len 400000 --junctions 200 --dup 0.1 --indels 1.0 --non-template 0.5 > /dev/null 2>&1
 cd $WORK
-ARRIBA_WRITER_THREADS=8 ARRIBA_INGEST_THREADS=4 ./workflow_tsan -x d.bam -g d.gtf -a d.fa -o f.tsv -O disc.tsv -X -f blacklist > log 2>&1 || true
+ARRIBA_FEED_PIECE_MB=1 ARRIBA_WRITER_THREADS=8 ARRIBA_INGEST_THREADS=4 ./workflow_tsan -x d.bam -g d.gtf -a d.fa -o f.tsv -O disc.tsv -X -f blacklist > log 2>&1 || true
 echo "ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' log || true); $(wc -l < f.tsv) lines in fusions.tsv"
 rm -rf $WORK
