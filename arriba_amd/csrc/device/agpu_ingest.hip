@@ -34,7 +34,7 @@ const int BLOCK = 256;
 inline unsigned int grid_for(uint64_t n, int block = BLOCK) { return (unsigned int) ((n + block - 1) / block); }
 
 enum { IC_ACTIVE = 0, IC_MAPPED_READS = 1, IC_MISSING_HI = 2, IC_BROKEN = 3, IC_MALFORMED = 4, IC_CHIMERIC = 5, IC_COLLISION = 6, IC_MISMATCH = 7, IC_UNSORTED = 8, IC_MAX_NAME = 9,
-       IC_MAX_READ_LENGTH = 10, IC_STRAND_COUNT = 11, IC_STRAND_MATCHING = 12, IC_RUNS_UNSORTED = 13, IC_COUNT = 16 };
+       IC_MAX_READ_LENGTH = 10, IC_STRAND_COUNT = 11, IC_STRAND_MATCHING = 12, IC_RUNS_UNSORTED = 13, IC_QNAME_COMMA = 14, IC_COUNT = 16 };
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
 #define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
@@ -267,12 +267,23 @@ __global__ void name_order_check_kernel(IngestStream in, const uint32_t* group_f
 // run's "ITD" entry where it has a valid one?  If so for all runs, the valid fragments are in name order, too (the names of the runs between two of them chain), and the pass over
 // the fragments behind the last piece is not needed (42 ms at 10^8 fragments); if not -- names in FASTQ order, as STAR writes them, or a run without a fragment out of order --
 // that pass decides as before.
-__global__ void run_name_order_kernel(IngestStream in, const uint32_t* group_first, const uint8_t* valid, uint32_t first_group, uint32_t n_groups, uint32_t* counters) {
+__global__ void run_name_order_kernel(IngestStream in, const uint32_t* group_first, const uint8_t* valid, uint32_t first_group, uint32_t n_groups, uint32_t* qname_differs, uint32_t* counters) {
 	const uint32_t g = first_group + blockIdx.x * BLOCK + threadIdx.x;
-	if (g >= n_groups || g == 0) return;
+	if (g >= n_groups) return;
 	Rec storage_a, storage_b;
 	const FragmentName mine = name_of(in, group_first, 2 * g, storage_b);
+	// ... and for the read-name groups of the batch (fragments with one QNAME: multi-mappers): does the QNAME of this run differ from the one before?  With the runs in name
+	// order and no comma inside a QNAME, the runs of one QNAME lie next to each other, so two fragments have one QNAME exactly if no run between them differs from its
+	// predecessor ("X,a" < "Y,b" < "X,c" makes "Y,b" start with "X,": Y would hold a comma) -- a prefix sum over these flags then stands in for the QNAMEs (fragment_layout_kernel).
+	const uint32_t length = qname_length(storage_b);
+	bool comma = false;
+	for (uint32_t k = 0; k < length; ++k) comma |= storage_b.name[k] == ',';
+	if (comma) atomicOr(&counters[IC_QNAME_COMMA], 1u);
+	if (g == 0) { qname_differs[0] = 0; return; }
 	FragmentName before = name_of(in, group_first, 2 * (g - 1), storage_a);
+	bool differs = length != qname_length(storage_a);
+	for (uint32_t k = 0; k < length && !differs; ++k) differs = storage_b.name[k] != storage_a.name[k];
+	qname_differs[g] = differs;
 	bool unsorted = compare_names(before, mine) >= 0;
 	if (!unsorted && valid[2 * (size_t) (g - 1) + 1]) { before = fragment_name(storage_a, true); unsorted = compare_names(before, mine) >= 0; }
 	if (unsorted) atomicOr(&counters[IC_RUNS_UNSORTED], 1u);
@@ -287,7 +298,7 @@ __global__ void name_chunk_kernel(IngestStream in, const uint32_t* group_first, 
 
 // ---- layout and pack ------------------------------------------------------------------------------------------------------------------------------
 
-__global__ void fragment_layout_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, const FragmentSizes* sizes,
+__global__ void fragment_layout_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, const FragmentSizes* sizes, const uint32_t* qname_run /* may be null */,
                                        uint32_t* cigar_words, uint32_t* sequence_bytes, uint32_t* name_lengths, uint32_t* new_group) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i > n) return;
@@ -297,7 +308,8 @@ __global__ void fragment_layout_kernel(IngestStream in, const uint32_t* group_fi
 	cigar_words[i] = mine.cigar_words; sequence_bytes[i] = mine.sequence_bytes; name_lengths[i] = mine.name_length;
 	// multi-mapper groups: identical names up to the last ',' (source/common.hpp:222), i.e. identical QNAMEs
 	uint32_t differs = 0;
-	if (i > 0) {
+	if (i > 0 && qname_run != nullptr) differs = qname_run[ref >> 1] != qname_run[order[i - 1] >> 1]; // (told by the windows: run_name_order_kernel)
+	else if (i > 0) {
 		const Rec a = load_record(in, group_first[ref >> 1]), b = load_record(in, group_first[order[i - 1] >> 1]);
 		const uint32_t length = qname_length(a);
 		differs = length != qname_length(b);
@@ -655,8 +667,10 @@ int window_step(agpu_ctx* ctx, IngestWindow& w) {
 		{ KernelTimer timer(ctx, "group_replay_kernel", n * SEGMENT_BYTES, s);
 		  group_replay_kernel<<<grid_for(groups), BLOCK, 0, s>>>(replay_context(ctx, in), active_records, run_begin, group_count.as<uint32_t>(), (uint32_t) first_group, (uint32_t) n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
 		                                                        sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
+		DeviceBuffer& qname_differs = ctx->scratch("ingest.qname_differs");
+		TRY(grow_keeping(ctx, qname_differs, n_groups * 4, first_group * 4, estimated_groups * 4));
 		{ KernelTimer timer(ctx, "run_name_order_kernel", groups * 2 * (4 + 40), s);
-		  run_name_order_kernel<<<grid_for(groups), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), valid.as<uint8_t>(), (uint32_t) first_group, (uint32_t) n_groups, device_counters); }
+		  run_name_order_kernel<<<grid_for(groups), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), valid.as<uint8_t>(), (uint32_t) first_group, (uint32_t) n_groups, qname_differs.as<uint32_t>(), device_counters); }
 		p.groups_done = n_groups; p.touched = true;
 		break; }
 	}
@@ -762,7 +776,7 @@ bool agpu::release_ingest_buffers(agpu_ctx* ctx) {
 	if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
 	static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.first_flags", "ingest.stream_rank", "ingest.group_first", "ingest.group_begin", "ingest.group_count", "ingest.plain_plans", "ingest.itd_plans",
 		"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
-		"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
+		"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.qname_differs", "ingest.qname_run", "ingest.run_keys", "ingest.run_keys_sorted", "ingest.window_rocprim", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
 	for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) { DeviceBuffer& buffer = ctx->scratch(temporary[k]); if (buffer.ptr != nullptr) released = true; buffer.release(); }
 	return released;
 }
@@ -1106,8 +1120,18 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	DeviceBuffer& cigar_base = ctx->scratch("ingest.cigar_base"); DeviceBuffer& sequence_base = ctx->scratch("ingest.sequence_base"); DeviceBuffer& name_base = ctx->scratch("ingest.name_base"); DeviceBuffer& group_id = ctx->scratch("ingest.group_id");
 	ALLOC(cigar_words, (n_fragments + 1) * 4); ALLOC(sequence_bytes, (n_fragments + 1) * 4); ALLOC(name_lengths, (n_fragments + 1) * 4); ALLOC(new_group, (n_fragments + 1) * 4);
 	ALLOC(cigar_base, (n_fragments + 1) * 8); ALLOC(sequence_base, (n_fragments + 1) * 8); ALLOC(name_base, (n_fragments + 1) * 8); ALLOC(group_id, (n_fragments + 1) * 4);
-	{ KernelTimer timer(ctx, "fragment_layout_kernel", n_fragments * (4 + 8 + 16 + 2 * 40));
-	  fragment_layout_kernel<<<grid_for(n_fragments + 1), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, sizes.as<FragmentSizes>(),
+	const uint32_t* qname_run = nullptr; // the QNAMEs of the runs numbered (equal numbers = equal QNAMEs), where the windows have told that this is so: see run_name_order_kernel
+	if (streamed && names_were_sorted && n_fragments > 0 && n_groups > 0 && host_counters[IC_RUNS_UNSORTED] == 0 && host_counters[IC_QNAME_COMMA] == 0) {
+		DeviceBuffer& qname_differs = ctx->scratch("ingest.qname_differs"); DeviceBuffer& numbered = ctx->scratch("ingest.qname_run");
+		ALLOC(numbered, (size_t) n_groups * 4);
+		size_t scan_bytes = 0;
+		HIP_CHECK(rocprim::inclusive_scan(nullptr, scan_bytes, qname_differs.as<uint32_t>(), numbered.as<uint32_t>(), n_groups, rocprim::plus<uint32_t>(), s));
+		if (scan_bytes > rocprim_scratch.capacity) ALLOC(rocprim_scratch, scan_bytes);
+		HIP_CHECK(rocprim::inclusive_scan(rocprim_scratch.ptr, scan_bytes, qname_differs.as<uint32_t>(), numbered.as<uint32_t>(), n_groups, rocprim::plus<uint32_t>(), s));
+		qname_run = numbered.as<uint32_t>();
+	}
+	{ KernelTimer timer(ctx, "fragment_layout_kernel", n_fragments * (4 + 8 + 16 + (qname_run ? 8 : 2 * 40)));
+	  fragment_layout_kernel<<<grid_for(n_fragments + 1), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, sizes.as<FragmentSizes>(), qname_run,
 	                                                                   cigar_words.as<uint32_t>(), sequence_bytes.as<uint32_t>(), name_lengths.as<uint32_t>(), new_group.as<uint32_t>()); }
 	TRY(exclusive_sum_u64(ctx, rocprim_scratch, cigar_words.as<uint32_t>(), cigar_base.as<uint64_t>(), n_fragments + 1));
 	TRY(exclusive_sum_u64(ctx, rocprim_scratch, sequence_bytes.as<uint32_t>(), sequence_base.as<uint64_t>(), n_fragments + 1));
