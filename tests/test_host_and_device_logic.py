@@ -832,6 +832,13 @@ def test_command_line_of_the_reference(dataset_files, emu_api, tmp_path):
     mine, theirs = progress_lines(result.stdout), progress_lines(open(os.path.join(golden, "reference.log")).read())
     assert mine == theirs and len(mine) > 40
     assert result.stdout.rstrip().splitlines()[-1].split("] ", 1)[1].startswith("Done (elapsed time=00:00:")
+    # the output file may be a pipe (the writer puts the rows of a file that can seek to their places from all threads; a pipe gets them one after the other)
+    fifo = str(tmp_path / "fusions.fifo")
+    os.mkfifo(fifo)
+    reader = subprocess.Popen(["cat", fifo], stdout=subprocess.PIPE)
+    piped = subprocess.run(command[:7] + ["-o", fifo] + command[9:], stdin=open(prefix + ".bam", "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    text = reader.communicate(timeout=60)[0].decode()
+    assert piped.returncode == 0 and text == gzip.open(os.path.join(golden, "fusions.tsv.gz"), "rt").read()
     # -f: a filter that is off prints no line; unknown names are errors
     quiet = subprocess.run(command[:11] + ["-f", "blacklist,mismappers,homologs", "-X", "-I", "-u", "-U", "100"], stdin=open(prefix + ".bam", "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
     assert quiet.returncode == 0 and "Re-aligning chimeric reads" not in quiet.stdout and "Filtering genes with" not in quiet.stdout and "Filtering duplicates" in quiet.stdout
