@@ -34,10 +34,13 @@ static std::vector<agpu_ctx*> g_contexts;
 bool DeviceBuffer::release_idle_buffers() {
 	std::lock_guard<std::mutex> lock(g_contexts_mutex);
 	bool released = false;
+	int device = -1;
+	(void) hipGetDevice(&device);
 	for (size_t k = 0; k < g_contexts.size(); ++k) {
 		agpu_ctx* ctx = g_contexts[k];
+		if (ctx->device != device) continue; // memory of another device does not help the allocation that failed (and its context may be at work on another thread)
 		(void) hipStreamSynchronize(ctx->stream);
-		if (!ctx->ingest_active) { if (release_ingest_buffers(ctx)) released = true; }
+		if (!ctx->ingest_active && !ctx->ingest_finishing) { if (release_ingest_buffers(ctx)) released = true; }
 		else // an ingest runs: nothing of the stages of the sample before is needed any more
 			for (std::map<std::string, DeviceBuffer>::iterator buffer = ctx->scratch_pool.begin(); buffer != ctx->scratch_pool.end(); ++buffer)
 				if (buffer->first.compare(0, 7, "ingest.") != 0 && buffer->second.ptr != nullptr) { buffer->second.release(); released = true; }

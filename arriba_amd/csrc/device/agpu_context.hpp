@@ -127,7 +127,7 @@ struct agpu_ctx {
 	uint32_t n_unmapped = 0;
 	// the read lists of the candidates this rank built, kept when the replicated table is imported (agpu_import_candidates)
 	agpu::DeviceBuffer owned_list_offset, owned_read_lists, owned_global_index;
-	uint32_t n_owned = 0, n_owned_list_entries = 0;
+	uint32_t n_owned = 0; uint64_t n_owned_list_entries = 0;
 	bool candidates_imported = false, owned_index_set = false, multimappers_begun = false;
 	uint64_t n_multimappers_global = 0;
 	// coverage_t (agpu_upload_coverage)
@@ -140,7 +140,7 @@ struct agpu_ctx {
 	uint64_t ingest_stream_size = 0, ingest_first_record = 0, names_size = 0;
 	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0, ingest_host_buffers = 2;
 	uint8_t ingest_external_duplicate_marking = 0;
-	bool ingest_active = false, batch_from_ingest = false, ingest_part_of_sample = false, ingest_verify_crc = false;
+	bool ingest_active = false, ingest_finishing = false /* inside agpu_ingest_finish: its tables are in use although the feed is over */, batch_from_ingest = false, ingest_part_of_sample = false, ingest_verify_crc = false;
 	agpu::DeviceBuffer ingest_qname_keys; uint64_t ingest_qname_runs = 0; // a part of a sample: 128-bit keys of the runs of read names in its stream
 	agpu_ingest_result ingest_result; uint64_t ingest_pool_sizes[2] = { 0, 0 }; // what the last ingest (or merge of parts) reported; CIGAR words and sequence bytes of its pools
 	agpu::IngestProgress ingest_progress;
@@ -183,7 +183,7 @@ struct agpu_ctx {
 	uint32_t kmer_positions_count = 0, splice_sites_for_dummy = 0, mismapper_jobs = 0, mismapper_heavy = 0;
 	bool kmer_index_done = false, have_splice_sites = false, mismapper_jobs_ready = false;
 	agpu::CandidateTable candidates;
-	uint32_t n_emissions = 0, n_candidates = 0, n_list_entries = 0, n_queued_buckets = 0, n_discordant_emissions = 0;
+	uint32_t n_emissions = 0, n_candidates = 0, n_queued_buckets = 0, n_discordant_emissions = 0; uint64_t n_list_entries = 0;
 	bool fusions_done = false;
 
 	// tables

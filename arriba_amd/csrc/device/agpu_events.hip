@@ -202,7 +202,7 @@ __global__ void itd_verdict_kernel(BatchView b, AnnotationView ann, CoverageView
 	if (result == 2) atomicOr(error, 1u);
 	verdict[c] = result == 1;
 	if (result == 1) // claim the reads this candidate would clear: the first recovered candidate in iteration order counts them
-		for (uint32_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k) {
+		for (uint64_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k) {
 			const uint32_t read = t.read_lists[k];
 			if (itd_read_is_cleared(b.filter[read])) atomicMin(&owner[read], iteration_rank[c]);
 		}

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(BLOCK) attach_discordant_kernel(AnnotationView
 	bool has_split_reads;
 	uint32_t* out_list = nullptr;
 	if (fill) {
-		const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+		const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 		has_split_reads = offsets[2] > offsets[0];
 		out_list = t.read_lists + offsets[2];
 	} else {
@@ -287,7 +287,7 @@ __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable
 		if (lane == 0) list_size[3 * (uint64_t) c + 2] = appended;
 		return;
 	}
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	const bool has_split_reads = offsets[2] > offsets[0];
 	scan_bucket<1>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, t.read_lists + offsets[2], discordant_swapped, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
 	if (__ballot(zero_seen) != 0) {
@@ -422,14 +422,14 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	// ---- candidate table
 	ALLOC(ctx->cand_gene1, (size_t) C * 4); ALLOC(ctx->cand_gene2, (size_t) C * 4); ALLOC(ctx->cand_contigs, (size_t) C * 4); ALLOC(ctx->cand_breakpoint1, (size_t) C * 4); ALLOC(ctx->cand_breakpoint2, (size_t) C * 4);
 	ALLOC(ctx->cand_flags, (size_t) C * 4); ALLOC(ctx->cand_filter, (size_t) C); ALLOC(ctx->cand_split_reads1, (size_t) C * 4); ALLOC(ctx->cand_split_reads2, (size_t) C * 4); ALLOC(ctx->cand_discordant_mates, (size_t) C * 4);
-	ALLOC(ctx->cand_anchor1, (size_t) C * 4); ALLOC(ctx->cand_anchor2, (size_t) C * 4); ALLOC(ctx->cand_list_offset, (3 * (size_t) C + 1) * 4);
+	ALLOC(ctx->cand_anchor1, (size_t) C * 4); ALLOC(ctx->cand_anchor2, (size_t) C * 4); ALLOC(ctx->cand_list_offset, (3 * (size_t) C + 1) * 8);
 	ALLOC(ctx->discordant_swapped, n ? n : 1);
 	HIP_CHECK(hipMemsetAsync(ctx->discordant_swapped.ptr, 0, n ? n : 1, s));
 	CandidateTable& t = ctx->candidates;
 	t.n = C; t.gene1 = ctx->cand_gene1.as<uint32_t>(); t.gene2 = ctx->cand_gene2.as<uint32_t>(); t.contigs = ctx->cand_contigs.as<uint32_t>();
 	t.breakpoint1 = ctx->cand_breakpoint1.as<int32_t>(); t.breakpoint2 = ctx->cand_breakpoint2.as<int32_t>(); t.flags = ctx->cand_flags.as<uint32_t>(); t.filter = ctx->cand_filter.as<uint8_t>();
 	t.split_reads1 = ctx->cand_split_reads1.as<uint32_t>(); t.split_reads2 = ctx->cand_split_reads2.as<uint32_t>(); t.discordant_mates = ctx->cand_discordant_mates.as<uint32_t>();
-	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint32_t>(); t.read_lists = nullptr;
+	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint64_t>(); t.read_lists = nullptr;
 	ALLOC(ctx->cand_votes, (size_t) C * 8);
 	HIP_CHECK(hipMemsetAsync(ctx->cand_votes.ptr, 0, (size_t) C * 8, s));
 	t.votes = ctx->cand_votes.as<uint32_t>();
@@ -483,24 +483,18 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 		KernelTimer timer(ctx, "attach_discordant_wave_kernel(count)", (uint64_t) Md * 24 + (uint64_t) queued * 25); // every bucket row read once, one size written per queued candidate
 		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
 	}
-	{ // the read lists are addressed with 32-bit offsets: say so instead of wrapping around (about 10^8 fragments of the bench's workload reach the limit)
-		DeviceBuffer& list_total = ctx->scratch("fusions.list_total");
-		ALLOC(list_total, 8);
-		HIP_CHECK(rocprim::reduce(nullptr, bytes, list_size.as<uint32_t>(), list_total.as<uint64_t>(), (uint64_t) 0, 3 * (size_t) C, rocprim::plus<uint64_t>(), s));
-		if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-		HIP_CHECK(rocprim::reduce(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), list_total.as<uint64_t>(), (uint64_t) 0, 3 * (size_t) C, rocprim::plus<uint64_t>(), s));
-		uint64_t entries = 0;
-		HIP_CHECK(hipMemcpyAsync(&entries, list_total.ptr, 8, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipStreamSynchronize(s));
-		if (entries >= 0xFFFFFFF0ull) { set_last_error("the read lists of the candidates hold more than 2^32-16 entries; shard the input"); return AGPU_ERR_CAPACITY; }
-	}
-	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
+	// the lists are addressed with 64-bit offsets (sizes of single lists are 32-bit): with -U 32767 (BASELINE.json config 3) a few million fragments already make more than 2^32
+	// entries, every candidate of a gene pair listing the discordant mates of the pair (source/fusions.cpp:398-407 lets a list grow to the subsampling threshold)
+	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, list_size.as<uint32_t>(), t.list_offset, (uint64_t) 0, 3 * (size_t) C + 1, rocprim::plus<uint64_t>(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
-	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), t.list_offset, 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
-	uint32_t total_list = 0;
-	HIP_CHECK(hipMemcpyAsync(&total_list, t.list_offset + 3 * (size_t) C, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, list_size.as<uint32_t>(), t.list_offset, (uint64_t) 0, 3 * (size_t) C + 1, rocprim::plus<uint64_t>(), s));
+	uint64_t total_list = 0;
+	HIP_CHECK(hipMemcpyAsync(&total_list, t.list_offset + 3 * (size_t) C, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	ALLOC(ctx->cand_read_lists, (size_t) std::max<uint32_t>(total_list, 1) * 4);
+	if (!ctx->cand_read_lists.allocate((size_t) std::max<uint64_t>(total_list, 1) * 4)) {
+		set_last_error("the read lists of the candidates hold " + std::to_string(total_list) + " entries (" + std::to_string(total_list * 4 >> 30) + " GB): more than the device has free; lower -U or shard the input");
+		return AGPU_ERR_CAPACITY;
+	}
 	t.read_lists = ctx->cand_read_lists.as<uint32_t>();
 	ctx->n_list_entries = total_list;
 	{ KernelTimer timer(ctx, "split_list_fill_kernel", (uint64_t) M * (sizeof(FusionEmission) + sizeof(RankState)));
@@ -546,7 +540,7 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 }
 
 extern "C" int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
-                                   uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor1, int32_t* anchor2, uint32_t* list_offset) {
+                                   uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor1, int32_t* anchor2, uint64_t* list_offset) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -555,7 +549,7 @@ extern "C" int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gen
 	struct { void* host; const DeviceBuffer* device; size_t bytes; } copies[] = {
 		{ gene1, &ctx->cand_gene1, C * 4 }, { gene2, &ctx->cand_gene2, C * 4 }, { contigs, &ctx->cand_contigs, C * 4 }, { breakpoint1, &ctx->cand_breakpoint1, C * 4 }, { breakpoint2, &ctx->cand_breakpoint2, C * 4 },
 		{ flags, &ctx->cand_flags, C * 4 }, { filter, &ctx->cand_filter, C }, { split_reads1, &ctx->cand_split_reads1, C * 4 }, { split_reads2, &ctx->cand_split_reads2, C * 4 },
-		{ discordant_mates, &ctx->cand_discordant_mates, C * 4 }, { anchor1, &ctx->cand_anchor1, C * 4 }, { anchor2, &ctx->cand_anchor2, C * 4 }, { list_offset, &ctx->cand_list_offset, (3 * C + 1) * 4 } };
+		{ discordant_mates, &ctx->cand_discordant_mates, C * 4 }, { anchor1, &ctx->cand_anchor1, C * 4 }, { anchor2, &ctx->cand_anchor2, C * 4 }, { list_offset, &ctx->cand_list_offset, (3 * C + 1) * 8 } };
 	for (size_t k = 0; k < sizeof(copies) / sizeof(copies[0]); ++k)
 		if (copies[k].host) HIP_CHECK(hipMemcpy(copies[k].host, copies[k].device->ptr, copies[k].bytes, hipMemcpyDefault)); // host or device destination
 	return AGPU_OK;
@@ -576,16 +570,16 @@ __global__ void list_sizes_of_kernel(CandidateTable t, const uint32_t* candidate
 	if (k > 3 * n) return;
 	if (k == 3 * n) { sizes[k] = 0; return; }
 	const uint64_t at = 3 * (uint64_t) candidates[k / 3] + k % 3;
-	sizes[k] = t.list_offset[at + 1] - t.list_offset[at];
+	sizes[k] = (uint32_t) (t.list_offset[at + 1] - t.list_offset[at]);
 }
-__global__ void list_copy_of_kernel(CandidateTable t, const uint32_t* candidates, const uint32_t* compact_offset, uint32_t* reads) {
+__global__ void list_copy_of_kernel(CandidateTable t, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads) {
 	const uint32_t k = blockIdx.x; // one workgroup per list
 	const uint64_t at = 3 * (uint64_t) candidates[k / 3] + k % 3;
-	const uint32_t begin = t.list_offset[at], size = t.list_offset[at + 1] - begin, target = compact_offset[k];
+	const uint64_t begin = t.list_offset[at], target = compact_offset[k]; const uint32_t size = (uint32_t) (t.list_offset[at + 1] - begin);
 	for (uint32_t e = threadIdx.x; e < size; e += BLOCK) reads[target + e] = t.read_lists[begin + e];
 }
 
-extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint32_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total) {
+extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint64_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
 	if (n > 0x3FFFFFFFull) { set_last_error("too many candidates"); return AGPU_ERR_INVALID; }
 	for (uint64_t k = 0; k < n; ++k) if (candidates[k] >= ctx->n_candidates) { set_last_error("candidate index out of range"); return AGPU_ERR_INVALID; }
@@ -593,22 +587,22 @@ extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* c
 	hipStream_t s = ctx->stream;
 	if (n == 0) { if (list_offset) list_offset[0] = 0; if (total) *total = 0; return AGPU_OK; }
 	DeviceBuffer& ids = ctx->scratch("lists_of.ids"); DeviceBuffer& sizes = ctx->scratch("lists_of.sizes"); DeviceBuffer& offsets = ctx->scratch("lists_of.offsets"); DeviceBuffer& out = ctx->scratch("lists_of.reads"); DeviceBuffer& scratch = ctx->scratch("lists_of.rocprim");
-	ALLOC(ids, n * 4); ALLOC(sizes, (3 * n + 1) * 4); ALLOC(offsets, (3 * n + 1) * 4);
+	ALLOC(ids, n * 4); ALLOC(sizes, (3 * n + 1) * 4); ALLOC(offsets, (3 * n + 1) * 8);
 	HIP_CHECK(hipMemcpyAsync(ids.ptr, candidates, n * 4, hipMemcpyHostToDevice, s));
 	list_sizes_of_kernel<<<(unsigned int) ((3 * n + 1 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), (uint32_t) n, sizes.as<uint32_t>());
 	size_t bytes = 0;
-	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, sizes.as<uint32_t>(), offsets.as<uint32_t>(), 0u, 3 * n + 1, rocprim::plus<uint32_t>(), s));
+	HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, sizes.as<uint32_t>(), offsets.as<uint64_t>(), (uint64_t) 0, 3 * n + 1, rocprim::plus<uint64_t>(), s));
 	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
-	HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, sizes.as<uint32_t>(), offsets.as<uint32_t>(), 0u, 3 * n + 1, rocprim::plus<uint32_t>(), s));
-	uint32_t entries = 0;
-	HIP_CHECK(hipMemcpyAsync(&entries, offsets.as<uint32_t>() + 3 * n, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, sizes.as<uint32_t>(), offsets.as<uint64_t>(), (uint64_t) 0, 3 * n + 1, rocprim::plus<uint64_t>(), s));
+	uint64_t entries = 0;
+	HIP_CHECK(hipMemcpyAsync(&entries, offsets.as<uint64_t>() + 3 * n, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (total) *total = entries;
-	if (list_offset) HIP_CHECK(hipMemcpy(list_offset, offsets.ptr, (3 * n + 1) * 4, hipMemcpyDeviceToHost));
+	if (list_offset) HIP_CHECK(hipMemcpy(list_offset, offsets.ptr, (3 * n + 1) * 8, hipMemcpyDeviceToHost));
 	if (reads && entries > 0) {
 		if (capacity < entries) { set_last_error("capacity too small for the read lists"); return AGPU_ERR_INVALID; }
 		ALLOC(out, (size_t) entries * 4);
-		list_copy_of_kernel<<<(unsigned int) (3 * n), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), offsets.as<uint32_t>(), out.as<uint32_t>());
+		list_copy_of_kernel<<<(unsigned int) (3 * n), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>());
 		HIP_CHECK(hipMemcpyAsync(reads, out.ptr, (size_t) entries * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 	}
@@ -720,13 +714,13 @@ extern "C" int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, cons
 		ctx->n_owned = ctx->n_candidates; ctx->n_owned_list_entries = ctx->n_list_entries;
 		ctx->owned_index_set = false; ctx->multimappers_begun = false;
 	}
-	ALLOC(ctx->cand_list_offset, (3 * C + 1) * 4); ALLOC(ctx->cand_read_lists, 16); ALLOC(ctx->cand_votes, C1 * 8);
-	HIP_CHECK(hipMemsetAsync(ctx->cand_list_offset.ptr, 0, (3 * C + 1) * 4, s));
+	ALLOC(ctx->cand_list_offset, (3 * C + 1) * 8); ALLOC(ctx->cand_read_lists, 16); ALLOC(ctx->cand_votes, C1 * 8);
+	HIP_CHECK(hipMemsetAsync(ctx->cand_list_offset.ptr, 0, (3 * C + 1) * 8, s));
 	CandidateTable& t = ctx->candidates;
 	t.n = (uint32_t) C; t.gene1 = ctx->cand_gene1.as<uint32_t>(); t.gene2 = ctx->cand_gene2.as<uint32_t>(); t.contigs = ctx->cand_contigs.as<uint32_t>();
 	t.breakpoint1 = ctx->cand_breakpoint1.as<int32_t>(); t.breakpoint2 = ctx->cand_breakpoint2.as<int32_t>(); t.flags = ctx->cand_flags.as<uint32_t>(); t.filter = ctx->cand_filter.as<uint8_t>();
 	t.split_reads1 = ctx->cand_split_reads1.as<uint32_t>(); t.split_reads2 = ctx->cand_split_reads2.as<uint32_t>(); t.discordant_mates = ctx->cand_discordant_mates.as<uint32_t>();
-	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint32_t>(); t.read_lists = ctx->cand_read_lists.as<uint32_t>();
+	t.anchor1 = ctx->cand_anchor1.as<int32_t>(); t.anchor2 = ctx->cand_anchor2.as<int32_t>(); t.list_offset = ctx->cand_list_offset.as<uint64_t>(); t.read_lists = ctx->cand_read_lists.as<uint32_t>();
 	t.votes = ctx->cand_votes.as<uint32_t>();
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->n_candidates = (uint32_t) C; ctx->n_list_entries = 0;

@@ -706,8 +706,11 @@ int windows_advance(agpu_ctx* ctx, bool wait) {
 		for (size_t k = 0; k < p.windows.size() && !p.abandoned; ++k) {
 			IngestWindow& w = p.windows[k];
 			if (w.enqueued > w.known) {
+				// the words of a step are taken in window order: step 1 of window k takes its first record from what window k-1 has noted (both can be in flight at once, and two
+				// hipEventQuery calls apart a thread that was descheduled in between may see k ready and k-1 not yet)
+				if (k > 0 && p.windows[k - 1].known < w.enqueued) break;
 				const hipError_t state = hipEventQuery(w.readback);
-				if (state == hipErrorNotReady) continue;
+				if (state == hipErrorNotReady) break; // (the windows behind it queue behind it on the same stream)
 				if (state != hipSuccess) { set_last_error(std::string("hipEventQuery: ") + hipGetErrorString(state)); return AGPU_ERR_DEVICE; }
 				window_note(ctx, w);
 				moved = true;
@@ -905,6 +908,9 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	ctx->ingest_active = false;
+	// until this function returns the stream and the tables of the ingest are in use: an allocation that fails in here may take back the scratch of the stages of the sample before
+	// (DeviceBuffer::release_idle_buffers), never the buffers the pointers below point into
+	struct Finishing { agpu_ctx* ctx; explicit Finishing(agpu_ctx* c) : ctx(c) { ctx->ingest_finishing = true; } ~Finishing() { ctx->ingest_finishing = false; } } finishing(ctx);
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); // (the last pieces unwrapped)

@@ -40,20 +40,20 @@ __global__ void merge_cluster_kernel(CandidateTable t, const uint32_t* order, co
 	if (end - j > 1) merge_cluster(t, order, j, end, max_distance, max_itd_length, extra_split_list, appended);
 }
 // after the sweep, only if an internal tandem duplication absorbed another one: the read lists with the appended entries merged in
-__global__ void merged_list_size_kernel(CandidateTable t, ItdAppended appended, uint32_t* sizes) {
+__global__ void merged_list_size_kernel(CandidateTable t, ItdAppended appended, uint64_t* sizes) {
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n) return;
 	for (uint32_t list = 0; list < 3; ++list)
 		sizes[3 * (uint64_t) c + list] = t.list_offset[3 * (uint64_t) c + list + 1] - t.list_offset[3 * (uint64_t) c + list] + (list < 2 ? appended.length[2 * (uint64_t) c + list] : 0);
 }
-__global__ void merged_list_copy_kernel(CandidateTable t, ItdAppended appended, const uint32_t* new_offset, uint32_t* new_lists) {
+__global__ void merged_list_copy_kernel(CandidateTable t, ItdAppended appended, const uint64_t* new_offset, uint32_t* new_lists) {
 	// one wavefront per candidate: the lists of a hot candidate hold hundreds of entries
 	const uint32_t c = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
 	if (c >= t.n) return;
 	for (uint32_t list = 0; list < 3; ++list) {
-		const uint32_t own_begin = t.list_offset[3 * (uint64_t) c + list], own_length = t.list_offset[3 * (uint64_t) c + list + 1] - own_begin;
+		const uint64_t own_begin = t.list_offset[3 * (uint64_t) c + list], own_length = t.list_offset[3 * (uint64_t) c + list + 1] - own_begin;
 		uint32_t* out = new_lists + new_offset[3 * (uint64_t) c + list];
-		for (uint32_t j = lane; j < own_length; j += 64) out[j] = t.read_lists[own_begin + j];
+		for (uint64_t j = lane; j < own_length; j += 64) out[j] = t.read_lists[own_begin + j];
 		if (list < 2) {
 			const uint32_t* extra = appended.pool + appended.begin[2 * (uint64_t) c + list];
 			for (uint32_t j = lane; j < appended.length[2 * (uint64_t) c + list]; j += 64) out[own_length + j] = extra[j];
@@ -118,21 +118,21 @@ extern "C" int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, 
 		if (pool_state[1]) { set_last_error("merge_adjacent_fusions: the pool of read-list entries appended to internal tandem duplications is exhausted"); return AGPU_ERR_CAPACITY; }
 		if (pool_state[0] > 0) {
 			DeviceBuffer& sizes = ctx->scratch("merge.list_sizes"); DeviceBuffer& new_offset = ctx->scratch("merge.list_offset"); DeviceBuffer& new_lists = ctx->scratch("merge.read_lists");
-			ALLOC(sizes, (3 * (size_t) C + 1) * 4); ALLOC(new_offset, (3 * (size_t) C + 1) * 4);
-			HIP_CHECK(hipMemsetAsync(sizes.as<uint32_t>() + 3 * (size_t) C, 0, 4, s));
-			merged_list_size_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, appended, sizes.as<uint32_t>());
-			HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, sizes.as<uint32_t>(), new_offset.as<uint32_t>(), 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
+			ALLOC(sizes, (3 * (size_t) C + 1) * 8); ALLOC(new_offset, (3 * (size_t) C + 1) * 8);
+			HIP_CHECK(hipMemsetAsync(sizes.as<uint64_t>() + 3 * (size_t) C, 0, 8, s));
+			merged_list_size_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, appended, sizes.as<uint64_t>());
+			HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, sizes.as<uint64_t>(), new_offset.as<uint64_t>(), (uint64_t) 0, 3 * (size_t) C + 1, rocprim::plus<uint64_t>(), s));
 			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
-			HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, sizes.as<uint32_t>(), new_offset.as<uint32_t>(), 0u, 3 * (size_t) C + 1, rocprim::plus<uint32_t>(), s));
-			uint32_t total = 0;
-			HIP_CHECK(hipMemcpyAsync(&total, new_offset.as<uint32_t>() + 3 * (size_t) C, 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, bytes, sizes.as<uint64_t>(), new_offset.as<uint64_t>(), (uint64_t) 0, 3 * (size_t) C + 1, rocprim::plus<uint64_t>(), s));
+			uint64_t total = 0;
+			HIP_CHECK(hipMemcpyAsync(&total, new_offset.as<uint64_t>() + 3 * (size_t) C, 8, hipMemcpyDeviceToHost, s));
 			HIP_CHECK(hipStreamSynchronize(s));
 			ALLOC(new_lists, std::max<size_t>(total, 1) * 4);
 			{ KernelTimer timer(ctx, "merged_list_copy_kernel", (uint64_t) total * 8);
-			  merged_list_copy_kernel<<<grid_for((uint64_t) C * 64), BLOCK, 0, s>>>(t, appended, new_offset.as<uint32_t>(), new_lists.as<uint32_t>()); }
+			  merged_list_copy_kernel<<<grid_for((uint64_t) C * 64), BLOCK, 0, s>>>(t, appended, new_offset.as<uint64_t>(), new_lists.as<uint32_t>()); }
 			HIP_CHECK(hipStreamSynchronize(s));
 			ctx->cand_list_offset.swap(new_offset); ctx->cand_read_lists.swap(new_lists);
-			ctx->candidates.list_offset = ctx->cand_list_offset.as<uint32_t>(); ctx->candidates.read_lists = ctx->cand_read_lists.as<uint32_t>();
+			ctx->candidates.list_offset = ctx->cand_list_offset.as<uint64_t>(); ctx->candidates.read_lists = ctx->cand_read_lists.as<uint32_t>();
 			ctx->n_list_entries = total;
 			HIP_CHECK(hipMemsetAsync(ctx->cand_extra_split_list.ptr, 0, C1 * 4, s)); // the appended entries are part of the lists now
 		}

@@ -131,12 +131,12 @@ __global__ void splice_site_kernel(AnnotationView ann, GenomeView genome, uint32
 __global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags, uint32_t* first_entry) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n || t.filter[c] != FILTER_none) return;
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
-	for (uint32_t k = offsets[0]; k < offsets[3]; ++k) {
+	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	for (uint64_t k = offsets[0]; k < offsets[3]; ++k) {
 		uint32_t read = t.read_lists[k];
 		if (b.filter[read] != FILTER_none) continue;
 		if (!read_flags[read]) read_flags[read] = 1;
-		atomicMin(&first_entry[read], k); // where the read stands first in the lists: jobs in that order keep the reads of one candidate together
+		if (first_entry[read] > c) atomicMin(&first_entry[read], c); // the first candidate that lists the read: jobs in that order keep the reads of one candidate together
 	}
 }
 __global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, const uint32_t* first_entry, uint32_t* keys) {

@@ -72,25 +72,25 @@ __global__ void bitmap_popcount_kernel(const uint32_t* words, uint64_t n_words, 
 
 // best[target(read)] = min rank over the candidates that list the multi-mapping read; target = the read itself, or its ordinal among the
 // multi-mapping reads of the sample when word_prefix != NULL
-__global__ void __launch_bounds__(BLOCK) list_best_rank_kernel(uint32_t n_listed, const uint32_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index, const uint32_t* rank,
+__global__ void __launch_bounds__(BLOCK) list_best_rank_kernel(uint32_t n_listed, const uint64_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index, const uint32_t* rank,
                                                                  const uint32_t* multimapper_bits, const uint32_t* word_prefix, uint32_t* best) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t c0 = (blockIdx.x * BLOCK + threadIdx.x) & ~63u;
 	if (c0 >= n_listed) return;
 	const uint32_t c = c0 + lane, last = min(c0 + 64, n_listed);
-	const uint32_t my_end = c < n_listed ? list_offset[3 * (uint64_t) c + 3] : 0xFFFFFFFFu;
+	const uint64_t my_end = c < n_listed ? list_offset[3 * (uint64_t) c + 3] : ~0ull;
 	const uint32_t my_rank = c < n_listed ? rank[global_index ? global_index[c] : c] : 0;
-	const uint32_t begin = list_offset[3 * (uint64_t) c0], end = list_offset[3 * (uint64_t) last];
-	for (uint32_t base = begin; base < end; base += 64 * LIST_UNROLL) { // LIST_UNROLL x 64 entries in flight: the loop is bound by the latency of two dependent loads
+	const uint64_t begin = list_offset[3 * (uint64_t) c0], end = list_offset[3 * (uint64_t) last];
+	for (uint64_t base = begin; base < end; base += 64 * LIST_UNROLL) { // LIST_UNROLL x 64 entries in flight: the loop is bound by the latency of two dependent loads
 		uint32_t read[LIST_UNROLL]; bool hit[LIST_UNROLL];
-		AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) { const uint32_t k = base + 64 * u + lane; read[u] = k < end ? read_lists[k] : 0xFFFFFFFFu; }
+		AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) { const uint64_t k = base + 64 * u + lane; read[u] = k < end ? read_lists[k] : 0xFFFFFFFFu; }
 		AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) hit[u] = read[u] != 0xFFFFFFFFu && bitmap_test(multimapper_bits, read[u]);
 		AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) {
 			unsigned long long hits = __ballot(hit[u]);
 			while (hits) {
 				const int l = __ffsll((unsigned long long) hits) - 1;
 				hits &= hits - 1;
-				const uint32_t entry = base + 64 * u + l;
+				const uint64_t entry = base + 64 * u + l;
 				const int owner = __ffsll((unsigned long long) __ballot(my_end > entry)) - 1;
 				const uint32_t owner_rank = __shfl(my_rank, owner);
 				if ((int) lane == l) {
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(BLOCK) list_best_rank_kernel(uint32_t n_listed
 
 // reference :188-211: the counters of a candidate lose the reads that became multi-mappers.  finalize: candidates left without supporting reads get
 // the filter `multimappers`, the others are counted (single context); otherwise only the counters are lowered (owner in the sharded form).
-__global__ void __launch_bounds__(BLOCK) list_recount_kernel(CandidateTable t, uint32_t n_listed, const uint32_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index,
+__global__ void __launch_bounds__(BLOCK) list_recount_kernel(CandidateTable t, uint32_t n_listed, const uint64_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index,
                                                                const uint32_t* discarded_bits, bool finalize, unsigned int* remaining) {
 	__shared__ uint32_t block_sum;
 	const uint32_t lane = threadIdx.x & 63;
@@ -114,19 +114,19 @@ __global__ void __launch_bounds__(BLOCK) list_recount_kernel(CandidateTable t, u
 		const uint32_t c = c0 + lane, last = min(c0 + 64, n_listed);
 		const bool valid = c < n_listed;
 		const uint32_t g = valid ? (global_index ? global_index[c] : c) : 0;
-		const uint32_t end1 = valid ? list_offset[3 * (uint64_t) c + 1] : 0xFFFFFFFFu, end2 = valid ? list_offset[3 * (uint64_t) c + 2] : 0xFFFFFFFFu, end3 = valid ? list_offset[3 * (uint64_t) c + 3] : 0xFFFFFFFFu;
+		const uint64_t end1 = valid ? list_offset[3 * (uint64_t) c + 1] : ~0ull, end2 = valid ? list_offset[3 * (uint64_t) c + 2] : ~0ull, end3 = valid ? list_offset[3 * (uint64_t) c + 3] : ~0ull;
 		uint32_t lost1 = 0, lost2 = 0, lost3 = 0;
-		const uint32_t begin = list_offset[3 * (uint64_t) c0], end = list_offset[3 * (uint64_t) last];
-		const uint32_t previous_end = __shfl_up(end3, 1);
-		const uint32_t my_begin = lane == 0 ? begin : previous_end;
-		for (uint32_t base = begin; base < end; base += 64 * LIST_UNROLL) {
+		const uint64_t begin = list_offset[3 * (uint64_t) c0], end = list_offset[3 * (uint64_t) last];
+		const uint64_t previous_end = __shfl_up((unsigned long long) end3, 1);
+		const uint64_t my_begin = lane == 0 ? begin : previous_end;
+		for (uint64_t base = begin; base < end; base += 64 * LIST_UNROLL) {
 			uint32_t read[LIST_UNROLL]; bool hit[LIST_UNROLL];
-			AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) { const uint32_t k = base + 64 * u + lane; read[u] = k < end ? read_lists[k] : 0xFFFFFFFFu; }
+			AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) { const uint64_t k = base + 64 * u + lane; read[u] = k < end ? read_lists[k] : 0xFFFFFFFFu; }
 			AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) hit[u] = read[u] != 0xFFFFFFFFu && bitmap_test(discarded_bits, read[u]);
 			AGPU_UNROLL for (int u = 0; u < LIST_UNROLL; ++u) {
 				unsigned long long hits = __ballot(hit[u]);
 				while (hits) {
-					const uint32_t entry = base + 64 * u + (uint32_t) (__ffsll((unsigned long long) hits) - 1);
+					const uint64_t entry = base + 64 * u + (uint32_t) (__ffsll((unsigned long long) hits) - 1);
 					hits &= hits - 1;
 					if (entry >= my_begin && entry < end3) { if (entry < end1) ++lost1; else if (entry < end2) ++lost2; else ++lost3; }
 				}
@@ -372,7 +372,7 @@ extern "C" int agpu_multimappers_partial_best(agpu_ctx* ctx, int32_t* best) {
 	HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t) partial.ptr, (int) NO_FUSION, M, s));
 	if (ctx->n_owned > 0 && ctx->params.filter_enabled[FILTER_multimappers]) {
 		KernelTimer timer(ctx, "list_best_rank_kernel", (uint64_t) ctx->n_owned_list_entries * 4 + (uint64_t) ctx->n_owned * 12);
-		list_best_rank_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(ctx->n_owned, ctx->owned_list_offset.as<uint32_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
+		list_best_rank_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(ctx->n_owned, ctx->owned_list_offset.as<uint64_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
 			ctx->scratch("multimappers.rank").as<uint32_t>(), ctx->scratch("multimappers.bits").as<uint32_t>(), ctx->scratch("multimappers.word_prefix").as<uint32_t>(), partial.as<uint32_t>());
 	}
 	HIP_CHECK(hipMemcpyAsync(best, partial.ptr, M * 4, hipMemcpyDefault, s));
@@ -425,7 +425,7 @@ extern "C" int agpu_multimappers_recount(agpu_ctx* ctx, const uint8_t* global_di
 		had_support_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, had_support.as<uint8_t>());
 		if (ctx->n_owned > 0 && ctx->params.filter_enabled[FILTER_multimappers]) {
 			KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_owned_list_entries * 4 + (uint64_t) ctx->n_owned * 30);
-			list_recount_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(t, ctx->n_owned, ctx->owned_list_offset.as<uint32_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
+			list_recount_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(t, ctx->n_owned, ctx->owned_list_offset.as<uint64_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
 				bits.as<uint32_t>(), false, nullptr);
 		}
 		HIP_CHECK(hipMemcpyAsync(counters, t.split_reads1, (size_t) C * 4, hipMemcpyDefault, s));

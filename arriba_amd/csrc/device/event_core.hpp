@@ -67,7 +67,7 @@ AGPU_HD bool contig_is_viral(const GenomeView& genome, uint32_t contig) { return
 // ---- filter_both_intronic: true = no unfiltered read of the candidate has an exonic alignment
 AGPU_HD bool has_only_intronic_reads(const BatchView& b, const GenomeView& genome, const CandidateTable& t, uint32_t c) {
 	if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return false; // viral contigs are often not annotated
-	for (uint32_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
+	for (uint64_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
 		const uint32_t read = t.read_lists[k];
 		if (b.filter[read] != FILTER_none) continue;
 		for (int slot = 0; slot < b.n_aln[read]; ++slot)
@@ -314,7 +314,7 @@ AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann,
 	// discordant mates that are clipped right at a breakpoint count as split reads (:133-158)
 	const uint32_t min_clipped_length = 3;
 	uint32_t clipped_discordant_mates1 = 0, clipped_discordant_mates2 = 0;
-	for (uint32_t k = t.list_offset[3 * (uint64_t) c + 2]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
+	for (uint64_t k = t.list_offset[3 * (uint64_t) c + 2]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
 		const uint32_t read = t.read_lists[k];
 		if (b.filter[read] != FILTER_none) continue;
 		if (tables.clip_summaries != nullptr) {
@@ -394,8 +394,8 @@ AGPU_HD uint32_t both_spliced_supporting_reads(const BatchView& b, const Annotat
 		if (breakpoint_in_large_exon(ann, t.contigs[c] >> 16, t.breakpoint1[c], max_exon_size) || breakpoint_in_large_exon(ann, t.contigs[c] & 0xFFFF, t.breakpoint2[c], max_exon_size)) return 0;
 	}
 	uint32_t multimappers = 0, unique_mappers = 0;
-	const uint32_t begin = t.list_offset[3 * (uint64_t) c], end = t.list_offset[3 * (uint64_t) c + 3];
-	for (uint32_t k = begin; k < end; ++k) {
+	const uint64_t begin = t.list_offset[3 * (uint64_t) c], end = t.list_offset[3 * (uint64_t) c + 3];
+	for (uint64_t k = begin; k < end; ++k) {
 		const uint32_t read = t.read_lists[k];
 		if (b.fbits[read] & FBIT_MULTIMAPPER) multimappers++; else if (b.filter[read] == FILTER_none) unique_mappers++;
 	}
@@ -470,7 +470,7 @@ AGPU_HD int itd_verdict(const BatchView& b, const AnnotationView& ann, const Cov
 	if (!is_in_coding_region) return 0;
 	const int32_t coverage1 = coverage_near(coverage, t.contigs[c] >> 16, breakpoint1, false), coverage2 = coverage_near(coverage, t.contigs[c] & 0xFFFF, breakpoint2, true); // directions: upstream / downstream
 	uint32_t split_reads = 0;
-	for (uint32_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k)
+	for (uint64_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k)
 		if (itd_read_counts(b.filter[t.read_lists[k]])) split_reads++;
 	return split_reads >= min_supporting_reads &&
 	       (1.0 * split_reads / (coverage1 > coverage2 ? coverage1 : coverage2) / (1 - duplication_rate) > min_fraction_of_coverage || split_reads >= subsampling_threshold);
@@ -481,7 +481,7 @@ const uint32_t ITD_READ_UNCLAIMED = 0xFFFFFFFFu, ITD_READ_COUNTED = 0xFFFFFFFEu;
 AGPU_HD void itd_count_cleared_reads(const BatchView& b, const CandidateTable& t, uint32_t c, uint32_t my_rank, uint32_t* owner) {
 	for (uint32_t list = 0; list < 2; ++list) {
 		uint32_t cleared = 0;
-		for (uint32_t k = t.list_offset[3 * (uint64_t) c + list]; k < t.list_offset[3 * (uint64_t) c + list + 1]; ++k) {
+		for (uint64_t k = t.list_offset[3 * (uint64_t) c + list]; k < t.list_offset[3 * (uint64_t) c + list + 1]; ++k) {
 			const uint32_t read = t.read_lists[k];
 			if (itd_read_is_cleared(b.filter[read]) && owner[read] == my_rank) { owner[read] = ITD_READ_COUNTED; ++cleared; }
 		}

@@ -252,7 +252,7 @@ struct CandidateTable { // structure of arrays, index = order of first occurrenc
 	uint32_t* split_reads1; uint32_t* split_reads2; uint32_t* discordant_mates;
 	int32_t* anchor1; int32_t* anchor2;
 	uint32_t* votes;                // [2*n] strand votes of the reads in the lists: forward, reverse (source/fusions.cpp:22-79)
-	uint32_t* list_offset;          // [3*n + 1] into read_lists: split_read1_list, split_read2_list, discordant_mate_list of candidate c at 3c, 3c+1, 3c+2
+	uint64_t* list_offset;          // [3*n + 1] into read_lists (64-bit: a candidate holds up to -U reads per list, and with -U 32767 the lists of a sample pass 2^32 entries): split_read1_list, split_read2_list, discordant_mate_list of candidate c at 3c, 3c+1, 3c+2
 	uint32_t* read_lists;
 };
 
@@ -426,8 +426,8 @@ AGPU_HD void predict_transcript_start(const AnnotationView& ann, uint32_t gene1,
 }
 
 // strand vote of entry k of the concatenated read lists of candidate c: 0 none, 1 forward, 2 reverse (source/fusions.cpp:22-79)
-AGPU_HD int list_entry_strand_vote(const BatchView& b, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c, uint32_t k) {
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+AGPU_HD int list_entry_strand_vote(const BatchView& b, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c, uint64_t k) {
+	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	uint32_t read = t.read_lists[k];
 	if (k < offsets[2]) { // split_read1_list votes with SPLIT_READ's predicted strand, split_read2_list with SUPPLEMENTARY's
 		uint8_t bits = b.abits[k < offsets[1] ? SPLIT_READ : SUPPLEMENTARY][read];
@@ -443,7 +443,7 @@ AGPU_HD void finalize_candidate(const AnnotationView& ann, const CandidateTable&
 	uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
 	int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
 	bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	flags &= ~(CFLAG_PREDICTED_STRAND1 | CFLAG_PREDICTED_STRAND2 | CFLAG_PREDICTED_STRANDS_AMBIGUOUS | CFLAG_SPLICED1 | CFLAG_SPLICED2);
 	if (forward == reverse) {
 		flags |= CFLAG_PREDICTED_STRANDS_AMBIGUOUS | CFLAG_PREDICTED_STRAND1 | CFLAG_PREDICTED_STRAND2; // fusion_t() initialises both strands to FORWARD
@@ -466,9 +466,9 @@ AGPU_HD void finalize_candidate(const AnnotationView& ann, const CandidateTable&
 // the same votes from the emission records while it fills the lists; tests/emu checks the two against each other).
 // discordant_swapped[i] tells whether find_fusions swapped MATE1/MATE2 of fragment i in place.
 AGPU_HD void count_list_votes(const BatchView& b, const CandidateTable& t, const uint8_t* discordant_swapped, uint32_t c, uint32_t& forward, uint32_t& reverse) {
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	forward = 0; reverse = 0;
-	for (uint32_t k = offsets[0]; k < offsets[3]; ++k) {
+	for (uint64_t k = offsets[0]; k < offsets[3]; ++k) {
 		int vote = list_entry_strand_vote(b, t, discordant_swapped, c, k);
 		if (vote == 1) ++forward; else if (vote == 2) ++reverse;
 	}

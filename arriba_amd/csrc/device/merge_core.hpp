@@ -28,7 +28,7 @@ AGPU_HD bool takes_part_in_merge(const CandidateTable& t, uint32_t c, uint32_t m
 AGPU_HD uint32_t merge_supporting_reads(const CandidateTable& t, uint32_t c) { return t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c]; }
 // size of split_read1_list + split_read2_list; extra_split_list = entries appended by earlier ITD merges (sizes only)
 AGPU_HD uint32_t merge_split_list_size(const CandidateTable& t, const uint32_t* extra_split_list, uint32_t c) {
-	return t.list_offset[3 * (uint64_t) c + 2] - t.list_offset[3 * (uint64_t) c] + extra_split_list[c];
+	return (uint32_t) (t.list_offset[3 * (uint64_t) c + 2] - t.list_offset[3 * (uint64_t) c]) + extra_split_list[c];
 }
 
 // sort keys: candidates that do not take part sort behind all others
@@ -64,7 +64,7 @@ struct ItdAppended {
 };
 AGPU_HD void itd_append_lists(const CandidateTable& t, const ItdAppended& appended, uint32_t fusion, uint32_t other) {
 	for (uint32_t list = 0; list < 2; ++list) {
-		const uint32_t own_begin = t.list_offset[3 * (uint64_t) other + list], own_length = t.list_offset[3 * (uint64_t) other + list + 1] - own_begin;
+		const uint64_t own_begin = t.list_offset[3 * (uint64_t) other + list]; const uint32_t own_length = (uint32_t) (t.list_offset[3 * (uint64_t) other + list + 1] - own_begin);
 		const uint32_t other_length = appended.length[2 * (uint64_t) other + list], old_length = appended.length[2 * (uint64_t) fusion + list];
 		if (own_length + other_length == 0) continue;
 		const uint32_t new_length = old_length + own_length + other_length;

@@ -925,12 +925,12 @@ AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const G
 // reference: count_mismappers + the final loop of filter_mismappers (source/filter_mismappers.cpp:247-258, 336-356) for an unfiltered
 // candidate: updates its three counters and returns true if the candidate is discarded
 AGPU_HD bool count_candidate_mismappers(const BatchView& b, const CandidateTable& t, uint32_t c, float max_mismapper_fraction) {
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	uint16_t total_reads = 0, mismappers = 0; // short unsigned int in the reference
 	uint32_t* counters[3] = { t.split_reads1 + c, t.split_reads2 + c, t.discordant_mates + c };
 	for (int list = 0; list < 3; ++list) {
 		uint32_t supporting_reads = *counters[list];
-		for (uint32_t k = offsets[list]; k < offsets[list + 1]; ++k) {
+		for (uint64_t k = offsets[list]; k < offsets[list + 1]; ++k) {
 			uint8_t filter = b.filter[t.read_lists[k]];
 			if (filter == FILTER_none) total_reads++;
 			else if (filter == FILTER_mismappers) { total_reads++; mismappers++; if (supporting_reads > 0) supporting_reads--; }

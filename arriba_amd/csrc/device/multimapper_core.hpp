@@ -119,11 +119,11 @@ AGPU_HD uint32_t resolve_multimapper_group(const BatchView& b, const AnnotationV
 AGPU_HD bool recount_after_multimappers(const BatchView& b, const CandidateTable& t, uint32_t c) {
 	if (t.filter[c] != FILTER_none) return false;
 	if (t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c] == 0) return true;
-	const uint32_t* offsets = t.list_offset + 3 * (uint64_t) c;
+	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	uint32_t* counters[3] = { t.split_reads1 + c, t.split_reads2 + c, t.discordant_mates + c };
 	for (int list = 0; list < 3; ++list) {
 		uint32_t count = *counters[list];
-		for (uint32_t k = offsets[list]; k < offsets[list + 1]; ++k)
+		for (uint64_t k = offsets[list]; k < offsets[list + 1]; ++k)
 			if (b.filter[t.read_lists[k]] == FILTER_multimappers && count > 0) count--;
 		*counters[list] = count;
 	}

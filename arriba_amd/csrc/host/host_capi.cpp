@@ -275,6 +275,7 @@ static int write_or_format_fusions(ahost_session* session, const ahost_fusion_ta
 			// the rows came in the order of the read lists: entry k of the lists is row k, and the reads of a candidate lie next to each other in every column of the batch
 			// (the pile-ups of the writer walk them one after the other: with rows in fragment order every read is a cache miss in a dozen columns)
 			const size_t n_entries = t.list_offset[3 * (size_t) t.n_candidates];
+			if (n_entries >= 0xFFFFFFFFull) throw std::runtime_error("the candidates to be written list more than 2^32 supporting reads: rows are numbered with 32 bits");
 			if (session->ingest.batch.n != n_entries || table->read_filter_of_rows == NULL) throw std::runtime_error("rows in list order: one row and one filter per entry of the read lists expected (ahost_set_batch_rows, read_filter_of_rows)");
 			lists_as_rows.resize(n_entries);
 			for (size_t k = 0; k < n_entries; ++k) lists_as_rows[k] = (uint32_t) k;
@@ -300,7 +301,7 @@ static int write_or_format_fusions(ahost_session* session, const ahost_fusion_ta
 			auto translate = [&](uint32_t first_candidate, uint32_t last_candidate) {
 				for (uint32_t c = first_candidate; c < last_candidate; ++c) {
 					const bool written = (write_discarded != 0) != (table_view->filter[c] == 0);
-					for (uint32_t k = table_view->list_offset[3 * (size_t) c]; k < table_view->list_offset[3 * (size_t) c + 3]; ++k) {
+					for (uint64_t k = table_view->list_offset[3 * (size_t) c]; k < table_view->list_offset[3 * (size_t) c + 3]; ++k) {
 						if (!written) { lists_as_rows[k] = 0; continue; }
 						const uint32_t fragment = table_view->read_lists[k];
 						if ((size_t) fragment / 64 >= words || !(bits[fragment / 64] >> (fragment % 64) & 1)) { missing = true; lists_as_rows[k] = 0; continue; }
@@ -330,11 +331,11 @@ int ahost_fusion_table_reads(const ahost_fusion_table* table, int write_discarde
 		uint32_t highest = 0; bool any = false;
 		for (uint32_t c = 0; c < table->n_candidates; ++c)
 			if ((write_discarded != 0) != (table->filter[c] == 0))
-				for (uint32_t k = table->list_offset[3 * (size_t) c]; k < table->list_offset[3 * (size_t) c + 3]; ++k) { highest = std::max(highest, table->read_lists[k]); any = true; }
+				for (uint64_t k = table->list_offset[3 * (size_t) c]; k < table->list_offset[3 * (size_t) c + 3]; ++k) { highest = std::max(highest, table->read_lists[k]); any = true; }
 		std::vector<uint64_t> bits(any ? (size_t) highest / 64 + 1 : 0, 0);
 		for (uint32_t c = 0; c < table->n_candidates; ++c)
 			if ((write_discarded != 0) != (table->filter[c] == 0))
-				for (uint32_t k = table->list_offset[3 * (size_t) c]; k < table->list_offset[3 * (size_t) c + 3]; ++k) bits[table->read_lists[k] / 64] |= (uint64_t) 1 << (table->read_lists[k] % 64);
+				for (uint64_t k = table->list_offset[3 * (size_t) c]; k < table->list_offset[3 * (size_t) c + 3]; ++k) bits[table->read_lists[k] / 64] |= (uint64_t) 1 << (table->read_lists[k] % 64);
 		uint64_t total = 0;
 		for (size_t w = 0; w < bits.size(); ++w) total += (uint64_t) __builtin_popcountll(bits[w]);
 		*count = total;

@@ -367,13 +367,13 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		if (print_extra_info && batch != NULL) {
 			// the fusion transcript from the pileups of the supporting reads, then the pair of annotated transcripts that gives an in-frame peptide (:1118-1154)
 			const TranscriptInput input = { *batch, table.read_filter, assembly, annotation, exon_index };
-			const uint32_t* offsets = table.list_offset + 3 * (size_t) f.candidate;
+			const uint64_t* offsets = table.list_offset + 3 * (size_t) f.candidate;
 			FusionEvent event;
 			event.contig_of_gene1 = writer.genes[f.gene1].contig; event.contig_of_gene2 = writer.genes[f.gene2].contig; event.breakpoint1 = f.breakpoint1; event.breakpoint2 = f.breakpoint2;
 			event.upstream1 = f.upstream1; event.upstream2 = f.upstream2; event.predicted_strand1 = f.predicted_strand1; event.predicted_strand2 = f.predicted_strand2; event.strands_ambiguous = f.strands_ambiguous;
 			event.transcript_start_gene1 = f.transcript_start_gene1; event.transcript_start_ambiguous = f.transcript_start_ambiguous;
 			event.split_read1_list = table.read_lists + offsets[0]; event.split_read2_list = table.read_lists + offsets[1]; event.discordant_mate_list = table.read_lists + offsets[2];
-			event.n_split_reads1 = offsets[1] - offsets[0]; event.n_split_reads2 = offsets[2] - offsets[1]; event.n_discordant_mates = offsets[3] - offsets[2];
+			event.n_split_reads1 = (uint32_t) (offsets[1] - offsets[0]); event.n_split_reads2 = (uint32_t) (offsets[2] - offsets[1]); event.n_discordant_mates = (uint32_t) (offsets[3] - offsets[2]);
 			std::vector<position_t> positions;
 			const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
 			fusion_transcript_sequence(input, event, transcript_sequence, positions);
@@ -429,8 +429,8 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 		// reads discarded by a filter, by name of the filter
 		std::map<std::string, unsigned> filters;
 		if (f.filter != 0) filters[f.filter < N_FILTER_NAMES ? FILTER_NAMES[f.filter] : "?"] = 0;
-		const uint32_t list_begin = table.list_offset[3 * (size_t) f.candidate], list_end = table.list_offset[3 * (size_t) f.candidate + 3];
-		for (uint32_t k = list_begin; k < list_end; ++k) {
+		const uint64_t list_begin = table.list_offset[3 * (size_t) f.candidate], list_end = table.list_offset[3 * (size_t) f.candidate + 3];
+		for (uint64_t k = list_begin; k < list_end; ++k) {
 			const uint8_t read_filter = table.read_filter[table.read_lists[k]];
 			if (read_filter != 0) filters[read_filter < N_FILTER_NAMES ? FILTER_NAMES[read_filter] : "?"]++;
 		}
@@ -450,9 +450,9 @@ void write_fusions_to_file(const Annotation& annotation, const FlatIndex& exon_i
 			// the file of a 10^8-fragment sample 9.3 M, and two temporary strings per read were a third of the writer's thread time
 			const char* names = batch->names.data();
 			size_t bytes = 0;
-			for (uint32_t k = list_begin; k < list_end; ++k) { const uint32_t read = table.read_lists[k]; bytes += batch->name_offset[read + 1] - batch->name_offset[read] + 1; }
+			for (uint64_t k = list_begin; k < list_end; ++k) { const uint32_t read = table.read_lists[k]; bytes += batch->name_offset[read + 1] - batch->name_offset[read] + 1; }
 			text.reserve(text.size() + bytes + 1);
-			for (uint32_t k = list_begin; k < list_end; ++k) {
+			for (uint64_t k = list_begin; k < list_end; ++k) {
 				if (k != list_begin) text += ',';
 				const uint32_t read = table.read_lists[k];
 				const char* begin = names + batch->name_offset[read]; const char* end = names + batch->name_offset[read + 1];

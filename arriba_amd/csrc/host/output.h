@@ -10,7 +10,7 @@ struct FusionTable {
 	uint32_t n_candidates;
 	const uint32_t* gene1; const uint32_t* gene2; const uint32_t* contigs; const int32_t* breakpoint1; const int32_t* breakpoint2; const uint32_t* flags; const uint8_t* filter;
 	const uint32_t* split_reads1; const uint32_t* split_reads2; const uint32_t* discordant_mates;
-	const uint32_t* list_offset; const uint32_t* read_lists;
+	const uint64_t* list_offset; const uint32_t* read_lists;
 	const float* evalue; const uint8_t* confidence; const uint32_t* iteration_rank;
 	const uint8_t* read_filter;
 	const int32_t* closest_genomic_breakpoint1; const int32_t* closest_genomic_breakpoint2; // NULL = none

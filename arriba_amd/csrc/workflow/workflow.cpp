@@ -288,7 +288,7 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 		columns.evalue = run.stage<float>("table.evalue", w); columns.confidence = run.stage<uint8_t>("table.confidence", w); columns.iteration_rank = run.stage<uint32_t>("table.iteration_rank", w);
 		columns.closest_genomic_breakpoint1 = run.stage<int32_t>("table.closest1", w); columns.closest_genomic_breakpoint2 = run.stage<int32_t>("table.closest2", w);
 		device_check(agpu_get_selected_candidates(run.device, &columns));
-		uint32_t* list_offset = run.stage<uint32_t>("table.list_offset", 3 * w + 1);
+		uint64_t* list_offset = run.stage<uint64_t>("table.list_offset", 3 * w + 1);
 		list_offset[0] = 0;
 		uint64_t total = 0;
 		device_check(agpu_get_candidate_read_lists_of(run.device, columns.candidate, w, list_offset, nullptr, 0, &total));

@@ -523,7 +523,7 @@ class DevicePipeline(object):
         u32 = lambda: np.zeros(max(n, 1), dtype=np.uint32)
         i32 = lambda: np.zeros(max(n, 1), dtype=np.int32)
         table = {"gene1": u32(), "gene2": u32(), "contigs": u32(), "breakpoint1": i32(), "breakpoint2": i32(), "flags": u32(), "filter": np.zeros(max(n, 1), dtype=np.uint8),
-                 "split_reads1": u32(), "split_reads2": u32(), "discordant_mates": u32(), "anchor_start1": i32(), "anchor_start2": i32(), "list_offset": np.zeros(3 * n + 1, dtype=np.uint32)}
+                 "split_reads1": u32(), "split_reads2": u32(), "discordant_mates": u32(), "anchor_start1": i32(), "anchor_start2": i32(), "list_offset": np.zeros(3 * n + 1, dtype=np.uint64)}
         order = ["gene1", "gene2", "contigs", "breakpoint1", "breakpoint2", "flags", "filter", "split_reads1", "split_reads2", "discordant_mates", "anchor_start1", "anchor_start2", "list_offset"]
         self._check(self.api.get_candidates(self.ctx, *[table[k].ctypes.data if (lists or k != "list_offset") else None for k in order]))
         if not lists:
@@ -565,7 +565,7 @@ class DevicePipeline(object):
         """(list_offset[3n+1] starting at 0, reads) of the given candidates only"""
         candidates = np.ascontiguousarray(candidates, dtype=np.uint32)
         n = candidates.size
-        offsets = np.zeros(3 * n + 1, dtype=np.uint32)
+        offsets = np.zeros(3 * n + 1, dtype=np.uint64)
         total = c_uint64()
         self._check(self.api.get_candidate_read_lists_of(self.ctx, candidates.ctypes.data if n else None, n, offsets.ctypes.data, None, 0, byref(total)))
         reads = np.zeros(max(total.value, 1), dtype=np.uint32)

@@ -323,6 +323,6 @@ class ShardedPipeline(DevicePipeline):
             chunks.append(all_lists[starts[c]:starts[c] + all_sizes[c].sum()])
             new_sizes.extend(all_sizes[c])
         merged["read_lists"] = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint32)
-        merged["list_offset"] = np.concatenate([[0], np.cumsum(np.array(new_sizes, dtype=np.int64))]).astype(np.uint32)
+        merged["list_offset"] = np.concatenate([[0], np.cumsum(np.array(new_sizes, dtype=np.int64))]).astype(np.uint64)
         merged["first_occurrence"] = all_first[order]
         return merged

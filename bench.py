@@ -97,7 +97,40 @@ def generate_sample(fragments, seed, directory, read_seed=0, stress=False, threa
     return prefix, time.time() - started
 
 
-def cpu_baseline(seed, directory, stress=False, sample_fragments=800000):
+def run_reference(command, cwd=None):
+    """runs the reference binary; returns (return code, its stdout, wall seconds, seconds until it starts on the BAM file, the N of its "(total=N)").  stdout is read as it comes:
+    the reference flushes "Reading chimeric alignments from '...' " before it opens the file (source/arriba.cpp:124-129) and ends that line only when the file is read, so a
+    line-wise reader would count the reading as loading; stderr goes to a file of its own (its warnings land in the middle of that very line otherwise)"""
+    started = time.time()
+    with tempfile.TemporaryFile() as errors:
+        process = subprocess.Popen(command, cwd=cwd, stdout=subprocess.PIPE, stderr=errors)
+        loaded_at, chunks = None, []
+        while True:
+            chunk = os.read(process.stdout.fileno(), 65536)
+            if not chunk:
+                break
+            chunks.append(chunk)
+            if loaded_at is None and b"Reading chimeric alignments" in b"".join(chunks[-2:]):
+                loaded_at = time.time()
+        process.wait()
+        elapsed = time.time() - started
+        errors.seek(0)
+        output = b"".join(chunks).decode(errors="replace")
+        total = re.search(r"Reading chimeric alignments from [^\n]*\(total=(\d+)\)", output)
+        return process.returncode, output + errors.read().decode(errors="replace"), elapsed, (loaded_at - started) if loaded_at else 0.0, int(total.group(1)) if total else None
+
+
+def cpu_baseline_fit():
+    """the reference's time at 1 / 5 / 10 / 20 M fragments of this workload, run once where the repository was built (tools/make_bench_golden.py), and the fit SURVEY.md 8(d) asks for"""
+    try:
+        record = json.load(open(os.path.join(ROOT, "tests", "golden", "cpu_baseline_fit.json")))
+    except (OSError, ValueError):
+        return None
+    return {"where": record.get("where"), "points": [{key: p.get(key) for key in ("workload", "chimeric_fragments", "seconds", "loading_seconds", "peak_memory_gb")} for p in record.get("points", [])],
+            "fit": {key: value for key, value in record.items() if key.startswith("fit_")}}
+
+
+def cpu_baseline(seed, directory, stress=False, sample_fragments=800000, subsampling=None):
     """The unmodified reference (oracle/_ref/arriba_ref) on a bounded sample of the same workload, 1 core."""
     import datasets
     unit = "chimeric reads/s"
@@ -105,25 +138,16 @@ def cpu_baseline(seed, directory, stress=False, sample_fragments=800000):
         return {"value": None, "unit": unit, "cores": 1, "kind": "reference", "sample": "oracle/_ref/arriba_ref not present on this box"}
     prefix = os.path.join(directory, "cpu")
     subprocess.run([datasets.GEN_SYNTH, "--out", prefix] + workload_args(sample_fragments, seed, stress=stress), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    command = [datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-f", "blacklist"] + (["-U", "32767"] if stress else [])
-    started = time.time()
-    process = subprocess.Popen(command, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
-    loaded_at, lines = None, []
-    for line in process.stdout:  # the moment the reference starts on the BAM file separates its loading phase from its per-sample work
-        lines.append(line)
-        if loaded_at is None and "Reading chimeric alignments" in line:
-            loaded_at = time.time()
-    process.wait()
-    elapsed = time.time() - started
-    output = "".join(lines)
-    if process.returncode != 0:
+    command = [datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", prefix + ".fusions.tsv", "-f", "blacklist"] + (["-U", str(subsampling)] if subsampling not in (None, 300) else [])
+    returncode, output, elapsed, loading, total = run_reference(command)  # (the moment the reference starts on the BAM file separates its loading phase from its per-sample work)
+    if returncode != 0:
         return {"value": None, "unit": unit, "cores": 1, "kind": "reference", "sample": "reference failed: " + output[-200:]}
-    total = re.search(r"Reading chimeric alignments from .*\(total=(\d+)\)", output.replace("\n", " "))
-    chimeric = int(total.group(1)) if total else sample_fragments
-    loading = (loaded_at - started) if loaded_at else 0.0
+    chimeric = total if total else sample_fragments
     return {"value": chimeric / elapsed, "unit": unit, "cores": 1, "kind": "reference",
-            "sample": "%d chimeric fragments of the same synthetic workload, whole reference binary BAM->fusions.tsv%s, %.1f s wall of which %.1f s load the assembly and the annotation" % (chimeric, " with -U 32767" if stress else "", elapsed, loading),
-            "value_without_loading": chimeric / max(elapsed - loading, 1e-9), "seconds": round(elapsed, 2), "loading_seconds": round(loading, 2)}
+            "sample": "%d chimeric fragments of the same synthetic workload, whole reference binary BAM->fusions.tsv%s, %.1f s wall of which %.1f s load the assembly and the annotation" % (chimeric, (" with -U %d" % subsampling) if subsampling not in (None, 300) else "", elapsed, loading),
+            "value_without_loading": chimeric / max(elapsed - loading, 1e-9), "seconds": round(elapsed, 2), "loading_seconds": round(loading, 2),
+            # the reference slows down with the sample (its containers are trees and hash maps of pointers): the points measured once in the build container and their fit
+            "at_larger_samples": cpu_baseline_fit()}
 
 
 def normal_pairs_leg(pipeline, directory, fragments=10000000, steps=2):
@@ -209,6 +233,7 @@ def main():
     parser.add_argument("--warmup", type=int, default=1)
     parser.add_argument("--fragments", type=int, default=None, help="chimeric fragments per GPU (default: 100 M, BASELINE.json's 100 M-read synthetic, if the box has the memory for the 54 GB file; 20000 with --host-only)")
     parser.add_argument("--stress", action="store_true", help="BASELINE.json config 3: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (filter_mismappers sees every read)")
+    parser.add_argument("--subsampling-threshold", type=int, default=None, help="-U of the reference (source/options.cpp:422-423); default 300, with --stress 32767 as SURVEY.md 8(d) config 3 says")
     parser.add_argument("--discarded", action="store_true", help="also write discarded.tsv (-O) inside the step")
     parser.add_argument("--host-ingest", action="store_true", help="read_chimeric_alignments by the multi-threaded host ingest instead of on the device (round 1's path)")
     parser.add_argument("--python-stages", action="store_true", help="time the ctypes mirror of the stage order (arriba_amd/pipeline.py) instead of arriba_workflow_sample of the product library")
@@ -222,10 +247,24 @@ def main():
         args.fragments = args.fragments or 20000
         return host_only(args)
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called the way the driver calls it at N = 1 (`python bench.py --gpus N ...`): the N ranks are launched from here, one per GPU over RCCL, exactly as the driver's
+        # own command would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`)
+        import socket
+        with socket.socket() as probe:
+            probe.bind(("127.0.0.1", 0))
+            port = probe.getsockname()[1]
+        command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]  # (sys.argv[0]: bench.py, or the harness the CPU tier runs it on)
+        progress("launching %d ranks: %s" % (args.gpus, " ".join(command)))
+        raise SystemExit(subprocess.run(command, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the line would report a number of GPUs that did not take part" % (args.gpus, world))
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -268,6 +307,7 @@ def main():
             # the large sample runs in a child with a time limit: if it does not come back with a line (a time-out, an error), the line of config 2 is printed instead,
             # with the reason -- a bench without a line is worth nothing
             command = [sys.executable, os.path.abspath(__file__), "--fragments", str(args.fragments), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+            command += (["--subsampling-threshold", str(args.subsampling_threshold)] if args.subsampling_threshold is not None else [])
             command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--python-stages", args.python_stages), ("--no-cpu-baseline", args.no_cpu_baseline), ("--no-normal-pairs", args.no_normal_pairs)) if on]
             # the driver gives a bench run 1800 s; the large sample gets what is left of ~1500 s after a reserve for the line of config 2 (generation, 25 steps of ~1 s, the
             # reference on its bounded sample: ~150 s), and its child decides after every step whether the steps asked for still fit (ARRIBA_BENCH_DEADLINE)
@@ -311,7 +351,8 @@ def main():
             prefix, generate_seconds = generate_sample(args.fragments, 1000, directory, read_seed=0 if world == 1 else 7000 + rank, stress=args.stress, threads=max(1, min(64, cpu_budget() // world)))
         bam_bytes = os.path.getsize(prefix + ".bam")
         progress("sample generated: %d fragments, %.1f GB BAM in %.1f s (%s)" % (args.fragments, bam_bytes / 1e9, generate_seconds, directory))
-        params = {"subsampling_threshold": 32767} if args.stress else None
+        subsampling = args.subsampling_threshold if args.subsampling_threshold is not None else (32767 if args.stress else 300)
+        params = {"subsampling_threshold": subsampling} if subsampling != 300 else None
         pipeline = None
         outputs = [os.path.join(directory, "fusions.rank%d.tsv" % rank), os.path.join(directory, "discarded.rank%d.tsv" % rank) if args.discarded else None]
         stage_log, step_seconds, ingest_parts, steps_done, all_steps = [], [], [], [0], []
@@ -442,13 +483,13 @@ def main():
             self_check.append("fusions.tsv holds %d fusions, the last stage counted %s" % (fusion_lines, stage_log[-1:] or None))
         # the sample of config 2 (10 M fragments) is the one the unmodified reference was run on once (tests/golden/bench10m): the file written by the last timed step must be its file
         reference_check = None
-        golden = os.path.join(ROOT, "tests", "golden", "bench10m", "meta.json")
-        if writes_files and args.fragments == 10000000 and not args.stress and not args.discarded and os.path.exists(golden):
+        golden = os.path.join(ROOT, "tests", "golden", ("stress%dm" if args.stress else "bench%dm") % (args.fragments // 1000000), "meta.json")
+        if writes_files and args.fragments % 1000000 == 0 and subsampling == (32767 if args.stress else 300) and not args.discarded and os.path.exists(golden):
             import hashlib
             meta = json.load(open(golden))
             if hashlib.sha256(open(outputs[0], "rb").read()).hexdigest() != meta["fusions_tsv_sha256"]:
-                self_check.append("fusions.tsv differs from the file the unmodified reference writes for this sample (tests/golden/bench10m)")
-            reference_check = "fusions.tsv of the last timed step is byte-identical (SHA-256) to the file the unmodified reference wrote for this very sample (tests/golden/bench10m: %d fusions, reference run time %.0f s where the repository was built)" % (meta["fusions"], meta["reference_seconds_in_the_build_container"])
+                self_check.append("fusions.tsv differs from the file the unmodified reference writes for this sample (%s)" % os.path.relpath(os.path.dirname(golden), ROOT))
+            reference_check = "fusions.tsv of the last timed step is byte-identical (SHA-256) to the file the unmodified reference wrote for this very sample (%s: %d fusions, reference run time %.0f s where the repository was built)" % (os.path.relpath(os.path.dirname(golden), ROOT), meta["fusions"], meta["reference_seconds_in_the_build_container"])
         if self_check:
             raise SystemExit("bench self-check failed: " + "; ".join(self_check))
 
@@ -486,7 +527,7 @@ def main():
                 "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong" if one_sample else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                 "config": {"workload": "synthetic %d chimeric fragments " % args.fragments + ("in one sample" if one_sample else "per GPU") + " (%d BAM records, %.1f GB uncompressed BGZF; 2x100 bp, 24-contig synthetic genome, GENCODE-like GTF)%s, default filters, BAM file in memory -> fusions.tsv%s"
-                                       % (pipeline.records if through_workflow_library else pipeline.ingest_result.records if pipeline.ingest_result else -1, bam_bytes / 1e9, ", mismapper stress (clips of 40-70 nt copied from the partner gene, -U 32767)" if args.stress else "",
+                                       % (pipeline.records if through_workflow_library else pipeline.ingest_result.records if pipeline.ingest_result else -1, bam_bytes / 1e9, (", mismapper stress (clips of 40-70 nt copied from the partner gene, -U %d)" % subsampling) if args.stress else (", -U %d" % subsampling) if subsampling != 300 else "",
                                           " + discarded.tsv" if args.discarded else ""),
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
@@ -503,13 +544,10 @@ def main():
                 "output_side_seconds": getattr(pipeline, "writer_seconds", None),
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
                 "stages": stage_log,
-                "stage_kernel_ms": {stage: round(values["ms"], 3) for stage, values in pipeline.timings.items()},
                 # per step: the sum over the launches of one step (the front of the ingest runs window by window: ~200 launches of its kernels in a step of 10^8 fragments)
                 "kernel_ms": {name: round(values["ms"] / args.steps, 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:48]},
                 "kernel_launches_per_step": {name: round(values["launches"] / args.steps, 1) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:12]},
                 "kernel_ms_per_step": round(kernel_ms_per_step, 2),
-                "device_resident_step": {"what": "round 1's figure: resident batch -> filter_relative_support (kernel time of the stages between the ingest and the candidate-level filters)", "ms": round(resident_ms, 3),
-                                         "chimeric_reads_per_s": n / (resident_ms * 1e-3) if resident_ms > 0 else None},
                 "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes, "launches_per_step": launches / args.steps},
             }
@@ -520,6 +558,10 @@ def main():
                 best = max(streaming, key=lambda name: modelled[name]["ms"])
                 line["roofline_streaming"] = {"bound": "hbm", "kernel": best, "achieved": streaming[best], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": streaming[best] / HBM_PEAK_GBS,
                                               "launch_ms": kernels[best]["ms"] / kernels[best]["launches"], "algorithmic_bytes_per_launch": kernels[best]["bytes"] / kernels[best]["launches"]}
+            if not through_workflow_library:  # (arriba_workflow_sample does not time the stages one by one: its own laps are in seconds_per_step)
+                line["stage_kernel_ms"] = {stage: round(values["ms"], 3) for stage, values in pipeline.timings.items()}
+                line["device_resident_step"] = {"what": "round 1's figure: resident batch -> filter_relative_support (kernel time of the stages between the ingest and the candidate-level filters)", "ms": round(resident_ms, 3),
+                                                "chimeric_reads_per_s": n / (resident_ms * 1e-3) if resident_ms > 0 else None}
             line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted" + ("; " + reference_check if reference_check else "")
             progress("self-check done, kernel profile read")
             if through_workflow_library and not distributed and not args.stress and not args.no_normal_pairs:
@@ -528,7 +570,7 @@ def main():
             if args.no_cpu_baseline or distributed:  # (timed at N = 1 only)
                 line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped: the reference is timed by the run with 1 GPU" if distributed else "skipped"}
             else:
-                line["cpu_baseline"] = cpu_baseline(1000, directory, stress=args.stress)
+                line["cpu_baseline"] = cpu_baseline(1000, directory, stress=args.stress, subsampling=subsampling)
             print(json.dumps(line))
     finally:
         if one_sample:

@@ -302,11 +302,11 @@ int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidate
  * candidates into fusions_t, source/fusions.cpp:252).  Any pointer may be NULL.  flags = AGPU_CFLAG_*; contigs = contig1 << 16 | contig2;
  * list_offset[3*n+1] indexes the concatenated read lists (split_read1_list, split_read2_list, discordant_mate_list per candidate). */
 int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
-                        uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor_start1, int32_t* anchor_start2, uint32_t* list_offset);
+                        uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor_start1, int32_t* anchor_start2, uint64_t* list_offset);
 int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capacity, uint64_t* total);
 /* the read lists of the given candidates only, packed: list_offset[3*n+1] starts at 0 (the output writer wants those of the candidates it prints -- a few
  * thousand of millions); call with reads == NULL to get *total and list_offset first */
-int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint32_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total);
+int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint64_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total);
 /* The candidates one output file holds, picked on the device: write_fusions_to_file (source/output_fusions.cpp:1083-1089) writes the candidates with filter == FILTER_none
  * to -o (discarded = 0) and the others to -O (1) -- a few thousand of millions for -o, so only their columns travel.  agpu_select_candidates says how many there are,
  * agpu_get_selected_candidates fills arrays of that many entries (candidate = index in the table, ascending; NULL pointers are skipped).  evalue, confidence,

@@ -73,7 +73,7 @@ typedef struct {
 	uint32_t n_candidates;
 	const uint32_t* gene1; const uint32_t* gene2; const uint32_t* contigs; const int32_t* breakpoint1; const int32_t* breakpoint2; const uint32_t* flags; const uint8_t* filter;
 	const uint32_t* split_reads1; const uint32_t* split_reads2; const uint32_t* discordant_mates;
-	const uint32_t* list_offset;   /* [3 * n_candidates + 1] */
+	const uint64_t* list_offset;   /* [3 * n_candidates + 1]; 64-bit: with -U 32767 the lists of the candidates of a sample pass 2^32 entries */
 	const uint32_t* read_lists;
 	const float* evalue; const uint8_t* confidence; const uint32_t* iteration_rank;
 	const uint8_t* read_filter;    /* [fragments of the session's batch] */

@@ -59,6 +59,22 @@ def test_bench_with_two_ranks_prints_one_line(flags, built, emu_api, tmp_path):
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
+def test_bench_launches_its_own_ranks_and_refuses_a_wrong_world_size(built, emu_api, tmp_path):
+    """`python bench.py --gpus 2` without a launcher (the way the driver calls it at N = 1) starts the two ranks itself and prints the line of two GPUs; under a launcher
+    whose WORLD_SIZE is not --gpus it refuses instead of reporting GPUs that did not take part."""
+    harness = os.path.join(ROOT, "tests", "bench_on_harness.py")
+    environment = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    result = subprocess.run([sys.executable, harness, "--gpus", "2", "--steps", "1", "--warmup", "0", "--fragments", "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=1500, env=environment)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, result.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "one sample over 2 GPUs" in line["config"]["parallelism"]
+    result = subprocess.run([sys.executable, harness, "--gpus", "4", "--steps", "1", "--warmup", "0", "--fragments", "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600,
+                            env=dict(environment, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert result.returncode != 0 and "WORLD_SIZE=1" in result.stderr and not [line for line in result.stdout.splitlines() if line.startswith("{")]
+
+
 @pytest.mark.parametrize("flags", [[], ["--python-stages"]])
 def test_bench_with_one_rank_times_the_workflow_library(flags, built, emu_api, tmp_path):
     """bench.py as the driver runs it at N = 1: the timed call is arriba_workflow_sample of the product library (here its build over the stepping harness,
