@@ -310,7 +310,7 @@ class WorkflowReport(ctypes.Structure):
 
 
 class WorkflowTiming(ctypes.Structure):
-    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format", "feed_read", "feed_push")]
+    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format", "feed_read", "feed_push", "feed_total")]
 
 
 _workflow_lib = None
@@ -327,7 +327,10 @@ def workflow_library():
         lib.arriba_workflow_run.argtypes = [POINTER(WorkflowOptions), POINTER(WorkflowReport)]; lib.arriba_workflow_run.restype = c_int
         lib.arriba_workflow_open.argtypes = [POINTER(WorkflowOptions)]; lib.arriba_workflow_open.restype = c_void_p
         lib.arriba_workflow_sample.argtypes = [c_void_p, c_char_p, c_char_p, c_char_p, POINTER(WorkflowReport), POINTER(WorkflowTiming)]; lib.arriba_workflow_sample.restype = c_int
+        lib.arriba_workflow_submit.argtypes = [c_void_p, c_char_p]; lib.arriba_workflow_submit.restype = c_int
+        lib.arriba_workflow_cancel.argtypes = [c_void_p]; lib.arriba_workflow_cancel.restype = c_int
         lib.arriba_workflow_device.argtypes = [c_void_p]; lib.arriba_workflow_device.restype = c_void_p
+        lib.arriba_workflow_lane_device.argtypes = [c_void_p, c_int]; lib.arriba_workflow_lane_device.restype = c_void_p
         lib.arriba_workflow_host.argtypes = [c_void_p]; lib.arriba_workflow_host.restype = c_void_p
         lib.arriba_workflow_close.argtypes = [c_void_p]; lib.arriba_workflow_close.restype = None
         _workflow_lib = lib

@@ -39,11 +39,14 @@ bool DeviceBuffer::release_idle_buffers() {
 	for (size_t k = 0; k < g_contexts.size(); ++k) {
 		agpu_ctx* ctx = g_contexts[k];
 		if (ctx->device != device) continue; // memory of another device does not help the allocation that failed (and its context may be at work on another thread)
+		if (ctx->pool.use_count() > 1) continue; // the lanes of a session share their pool: while one feeds the other runs its stages, nothing of it is idle (the session drains and tries again)
 		(void) hipStreamSynchronize(ctx->stream);
 		if (!ctx->ingest_active && !ctx->ingest_finishing) { if (release_ingest_buffers(ctx)) released = true; }
-		else // an ingest runs: nothing of the stages of the sample before is needed any more
-			for (std::map<std::string, DeviceBuffer>::iterator buffer = ctx->scratch_pool.begin(); buffer != ctx->scratch_pool.end(); ++buffer)
+		else { // an ingest runs: nothing of the stages of the sample before is needed any more
+			std::lock_guard<std::mutex> pool_lock(ctx->pool->mutex);
+			for (std::map<std::string, DeviceBuffer>::iterator buffer = ctx->pool->buffers.begin(); buffer != ctx->pool->buffers.end(); ++buffer)
 				if (buffer->first.compare(0, 7, "ingest.") != 0 && buffer->second.ptr != nullptr) { buffer->second.release(); released = true; }
+		}
 	}
 	return released;
 }
@@ -561,12 +564,20 @@ void agpu_default_params(agpu_params* p) { // source/options.cpp:71-107
 	for (int f = 1; f < AGPU_FILTER_COUNT; ++f) p->filter_enabled[f] = 1;
 }
 
-agpu_ctx* agpu_create(int device, const agpu_params* params) {
+static agpu_ctx* create_context(int device, const agpu_params* params, std::shared_ptr<agpu::ScratchPool> pool);
+agpu_ctx* agpu_create(int device, const agpu_params* params) { return create_context(device, params, std::shared_ptr<agpu::ScratchPool>()); }
+agpu_ctx* agpu_create_sibling(agpu_ctx* of) {
+	if (!of) { set_last_error("null argument"); return nullptr; }
+	agpu_ctx* ctx = create_context(of->device, &of->params, of->pool);
+	if (ctx) ctx->profiling = of->profiling;
+	return ctx;
+}
+static agpu_ctx* create_context(int device, const agpu_params* params, std::shared_ptr<agpu::ScratchPool> pool) {
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { set_last_error("no HIP device visible: the hot path requires an MI355X (gfx950) and has no CPU fallback"); return nullptr; }
 	if (device < 0 || device >= count) { set_last_error("invalid device ordinal"); return nullptr; }
 	if (hipSetDevice(device) != hipSuccess) { set_last_error("hipSetDevice failed"); return nullptr; }
-	agpu_ctx* ctx = new agpu_ctx();
+	agpu_ctx* ctx = new agpu_ctx(pool);
 	ctx->device = device;
 	if (params) ctx->params = *params; else agpu_default_params(&ctx->params);
 	if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->event_start) != hipSuccess || hipEventCreate(&ctx->event_stop) != hipSuccess) {
@@ -1066,7 +1077,9 @@ int agpu_get_gene_table(agpu_ctx* ctx, uint32_t first, uint32_t count, uint16_t*
 
 int agpu_set_profiling(agpu_ctx* ctx, int enabled) {
 	if (!ctx) return AGPU_ERR_INVALID;
+	std::lock_guard<std::mutex> lock(ctx->profile_mutex);
 	ctx->profiling = enabled != 0;
+	++ctx->profile_epoch; // (what was launched before this call and has not completed yet is dropped when it does)
 	ctx->samples_done.clear();
 	return AGPU_OK;
 }
@@ -1074,7 +1087,10 @@ int agpu_get_kernel_profile(agpu_ctx* ctx, char* names, float* ms, uint64_t* byt
 	if (!ctx || !count) return AGPU_ERR_INVALID;
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->piece_stream) HIP_CHECK(hipStreamSynchronize(ctx->piece_stream));
+	if (ctx->ingest_progress.work) HIP_CHECK(hipStreamSynchronize(ctx->ingest_progress.work));
 	collect_kernel_samples(ctx);
+	std::lock_guard<std::mutex> lock(ctx->profile_mutex);
 	*count = (uint32_t) ctx->samples_done.size();
 	for (uint32_t k = 0; k < *count && k < capacity; ++k) {
 		if (names) { strncpy(names + (size_t) k * AGPU_KERNEL_NAME_LENGTH, ctx->samples_done[k].name, AGPU_KERNEL_NAME_LENGTH - 1); names[(size_t) k * AGPU_KERNEL_NAME_LENGTH + AGPU_KERNEL_NAME_LENGTH - 1] = 0; }

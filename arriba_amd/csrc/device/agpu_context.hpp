@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <deque>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <utility>
 #include <string>
 #include <vector>
@@ -52,7 +54,7 @@ struct DeviceBuffer {
 };
 
 // per-kernel timing with HIP events on the launch stream (agpu_set_profiling / agpu_get_kernel_profile)
-struct KernelSample { const char* name; hipEvent_t start, stop; uint64_t bytes; float ms; };
+struct KernelSample { const char* name; hipEvent_t start, stop; uint64_t bytes; float ms; unsigned int epoch; };
 
 // The front of read_chimeric_alignments on the device while the pieces of the file are still arriving (agpu_ingest.hip, "the front as the pieces arrive"): the stream is
 // cut into windows, one per pushed piece; a window goes through four steps on a stream of its own (record chain; offsets, record keys, active records; runs of one name;
@@ -82,7 +84,24 @@ struct IngestProgress {
 }
 
 enum { AGPU_PIECE_SLOTS = 4 };
+namespace agpu {
+// The scratch buffers of a context, addressed by name, grow-only.  Two contexts of one device may share a pool (agpu_create_sibling): the lanes of a resident session that feeds
+// the file of the next sample while the stages of the current one run (include/arriba_workflow.h: arriba_workflow_submit).  The two never use the same names at the same time -- one
+// is between agpu_ingest_begin and agpu_ingest_finish ("ingest.*", the stream, the raw pieces), the other in its stages -- so ~150 GB of tables exist once, not twice.
+struct ScratchPool {
+	std::mutex mutex; // (of the map: buffers are looked up from the thread that feeds and from the thread that runs the stages)
+	std::map<std::string, DeviceBuffer> buffers;
+	DeviceBuffer& get(const char* name) { std::lock_guard<std::mutex> lock(mutex); return buffers[name]; }
+};
+struct PoolSlots { DeviceBuffer* slot[AGPU_PIECE_SLOTS]; DeviceBuffer& operator[](size_t k) { return *slot[k]; } };
+}
 struct agpu_ctx {
+	explicit agpu_ctx(std::shared_ptr<agpu::ScratchPool> shared = std::shared_ptr<agpu::ScratchPool>()) : pool(shared ? shared : std::make_shared<agpu::ScratchPool>()),
+		ingest_stream(pool->get("ingest.stream")), coverage_windows32(pool->get("ingest.coverage_windows32")) {
+		static const char* const raw[AGPU_PIECE_SLOTS] = { "ingest.raw0", "ingest.raw1", "ingest.raw2", "ingest.raw3" }; static const char* const blocks[AGPU_PIECE_SLOTS] = { "ingest.blocks0", "ingest.blocks1", "ingest.blocks2", "ingest.blocks3" };
+		for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { ingest_raw.slot[k] = &pool->get(raw[k]); ingest_blocks.slot[k] = &pool->get(blocks[k]); }
+	}
+	agpu_ctx(const agpu_ctx&) = delete; agpu_ctx& operator=(const agpu_ctx&) = delete;
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t event_start = nullptr, event_stop = nullptr;
@@ -90,11 +109,15 @@ struct agpu_ctx {
 	uint64_t last_bytes = 0;
 	agpu_params params;
 	bool profiling = false;
+	// launches are timed from the thread that runs the stages and, in a session with two lanes, from the thread that feeds this context: profile_mutex guards the three vectors;
+	// agpu_set_profiling starts a new epoch, samples of an older one are dropped when their events have completed
+	std::mutex profile_mutex;
+	unsigned int profile_epoch = 0;
 	std::vector<agpu::KernelSample> samples_pending, samples_done;
 	std::vector<hipEvent_t> event_pool;
 	// scratch buffers of the stage calls, kept between calls (grow-only) and addressed by name
-	std::map<std::string, agpu::DeviceBuffer> scratch_pool;
-	agpu::DeviceBuffer& scratch(const char* name) { return scratch_pool[name]; }
+	std::shared_ptr<agpu::ScratchPool> pool;
+	agpu::DeviceBuffer& scratch(const char* name) { return pool->get(name); }
 
 	// annotation
 	uint32_t n_genes = 0, n_exons = 0, n_dummy = 0;
@@ -135,7 +158,8 @@ struct agpu_ctx {
 	agpu::CoverageView coverage = { 0, nullptr, nullptr, nullptr, nullptr };
 	bool have_coverage = false;
 	// read_chimeric_alignments on the device (agpu_ingest.hip): the uncompressed BAM stream while it is being pushed, and what stays behind the pack
-	agpu::DeviceBuffer ingest_stream, ingest_raw[AGPU_PIECE_SLOTS], ingest_blocks[AGPU_PIECE_SLOTS], ingest_tid_to_contig, ingest_viral_counts, coverage_windows32;
+	agpu::DeviceBuffer& ingest_stream; agpu::PoolSlots ingest_raw, ingest_blocks; agpu::DeviceBuffer& coverage_windows32; // (in the pool: shared by the lanes of a session)
+	agpu::DeviceBuffer ingest_tid_to_contig, ingest_viral_counts;
 	agpu::DeviceBuffer names, name_offset; // "QNAME,HI" of every fragment of a batch built on the device
 	uint64_t ingest_stream_size = 0, ingest_first_record = 0, names_size = 0;
 	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0, ingest_host_buffers = 2;
@@ -202,31 +226,39 @@ int finish_batch_setup(agpu_ctx* ctx);
 // Brackets one kernel launch (or library call) with HIP events when profiling is on.  Usage:
 //   { KernelTimer timer(ctx, "stage2_kernel", bytes); stage2_kernel<<<...>>>(...); }
 struct KernelTimer {
-	agpu_ctx* ctx; int index;
+	agpu_ctx* ctx; bool armed;
 	hipStream_t stream;
-	KernelTimer(agpu_ctx* c, const char* name, uint64_t bytes, hipStream_t on = nullptr) : ctx(c), index(-1), stream(on ? on : c->stream) {
+	KernelSample sample;
+	KernelTimer(agpu_ctx* c, const char* name, uint64_t bytes, hipStream_t on = nullptr) : ctx(c), armed(false), stream(on ? on : c->stream) {
 		if (!ctx->profiling) return;
-		KernelSample sample; sample.name = name; sample.bytes = bytes; sample.ms = 0;
-		hipEvent_t* events[2] = { &sample.start, &sample.stop };
-		for (int k = 0; k < 2; ++k) {
-			if (!ctx->event_pool.empty()) { *events[k] = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-			else if (hipEventCreate(events[k]) != hipSuccess) return;
-		}
+		sample.name = name; sample.bytes = bytes; sample.ms = 0; sample.start = nullptr; sample.stop = nullptr;
+		{ std::lock_guard<std::mutex> lock(ctx->profile_mutex);
+		  sample.epoch = ctx->profile_epoch;
+		  hipEvent_t* events[2] = { &sample.start, &sample.stop };
+		  for (int k = 0; k < 2; ++k) if (!ctx->event_pool.empty()) { *events[k] = ctx->event_pool.back(); ctx->event_pool.pop_back(); } }
+		if ((sample.start == nullptr && hipEventCreate(&sample.start) != hipSuccess) || (sample.stop == nullptr && hipEventCreate(&sample.stop) != hipSuccess)) return;
 		(void) hipEventRecord(sample.start, stream);
-		ctx->samples_pending.push_back(sample);
-		index = (int) ctx->samples_pending.size() - 1;
+		armed = true;
 	}
-	~KernelTimer() { if (index >= 0) (void) hipEventRecord(ctx->samples_pending[index].stop, stream); }
+	~KernelTimer() {
+		if (!armed) return;
+		(void) hipEventRecord(sample.stop, stream);
+		std::lock_guard<std::mutex> lock(ctx->profile_mutex);
+		ctx->samples_pending.push_back(sample);
+	}
 };
-// resolve the pending samples (call after the stream was synchronised)
+// resolve the pending samples whose events have completed (the caller has synchronised the streams it launched on; what another thread launched meanwhile stays pending)
 inline void collect_kernel_samples(agpu_ctx* ctx) {
+	std::lock_guard<std::mutex> lock(ctx->profile_mutex);
+	size_t kept = 0;
 	for (size_t k = 0; k < ctx->samples_pending.size(); ++k) {
-		KernelSample& sample = ctx->samples_pending[k];
+		KernelSample sample = ctx->samples_pending[k];
+		if (hipEventQuery(sample.stop) == hipErrorNotReady) { ctx->samples_pending[kept++] = sample; continue; }
 		if (hipEventElapsedTime(&sample.ms, sample.start, sample.stop) != hipSuccess) sample.ms = 0;
 		ctx->event_pool.push_back(sample.start); ctx->event_pool.push_back(sample.stop);
-		ctx->samples_done.push_back(sample);
+		if (sample.epoch == ctx->profile_epoch) ctx->samples_done.push_back(sample);
 	}
-	ctx->samples_pending.clear();
+	ctx->samples_pending.resize(kept);
 }
 
 }

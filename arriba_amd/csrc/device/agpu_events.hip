@@ -263,7 +263,7 @@ int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* ker
 	// algorithmic bytes: a candidate that an earlier filter has dropped costs its filter byte, one that is still alive its row (60 bytes); the number alive is known only now
 	// (the ones this stage drops are not counted: the figure is a lower bound).  Round 2 priced every candidate with 60 bytes: 19 TB/s "achieved" for the late stages.
 	ctx->last_bytes = (uint64_t) C + (uint64_t) kept * 59 + (stage == EVENT_both_intronic ? (uint64_t) ctx->n_list_entries * 8 : 0);
-	if (!ctx->samples_done.empty() && ctx->samples_done.back().name == kernel_name) ctx->samples_done.back().bytes = ctx->last_bytes;
+	{ std::lock_guard<std::mutex> lock(ctx->profile_mutex); if (!ctx->samples_done.empty() && ctx->samples_done.back().name == kernel_name) ctx->samples_done.back().bytes = ctx->last_bytes; }
 	if (remaining) *remaining = kept;
 	return AGPU_OK;
 }

@@ -128,7 +128,7 @@ __global__ void splice_site_kernel(AnnotationView ann, GenomeView genome, uint32
 	if (!write) counts[gene] = found;
 }
 
-__global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags, uint32_t* first_entry) {
+__global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags, unsigned long long* first_entry, bool by_candidate) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= t.n || t.filter[c] != FILTER_none) return;
 	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
@@ -136,10 +136,11 @@ __global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* re
 		uint32_t read = t.read_lists[k];
 		if (b.filter[read] != FILTER_none) continue;
 		if (!read_flags[read]) read_flags[read] = 1;
-		if (first_entry[read] > c) atomicMin(&first_entry[read], c); // the first candidate that lists the read: jobs in that order keep the reads of one candidate together
+		const unsigned long long key = by_candidate ? c : k;
+		if (first_entry[read] > key) atomicMin(&first_entry[read], key); // where the read stands first in the lists: jobs in that order keep the reads of one candidate together
 	}
 }
-__global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, const uint32_t* first_entry, uint32_t* keys) {
+__global__ void mismapper_job_key_kernel(const uint32_t* jobs, uint32_t n_jobs, const unsigned long long* first_entry, unsigned long long* keys) {
 	const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
 	if (j < n_jobs) keys[j] = first_entry[jobs[j]];
 }
@@ -377,9 +378,9 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 	DeviceBuffer& job_keys_sorted = ctx->scratch("mismappers.job_keys_sorted"); DeviceBuffer& jobs_sorted = ctx->scratch("mismappers.jobs_sorted");
 	ALLOC(counters, 32);
 	if (phases & PHASE_JOBS) {
-		ALLOC(read_flags, n ? n : 1); ALLOC(jobs, (n ? n : 1) * 4); ALLOC(first_entry, (n ? n : 1) * 4);
+		ALLOC(read_flags, n ? n : 1); ALLOC(jobs, (n ? n : 1) * 4); ALLOC(first_entry, (n ? n : 1) * 8);
 		HIP_CHECK(hipMemsetAsync(read_flags.ptr, 0, n ? n : 1, s));
-		HIP_CHECK(hipMemsetAsync(first_entry.ptr, 0xFF, (n ? n : 1) * 4, s));
+		HIP_CHECK(hipMemsetAsync(first_entry.ptr, 0xFF, (n ? n : 1) * 8, s));
 		HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 32, s));
 		ctx->mismapper_jobs = 0; ctx->mismapper_jobs_ready = false;
 	}
@@ -392,7 +393,11 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 	const bool enabled = ctx->params.filter_enabled[FILTER_mismappers] != 0; // switched off with -f: the reference skips the stage (source/arriba.cpp:562); no read and no candidate is touched, the unfiltered candidates are counted
 	uint32_t n_jobs = ctx->mismapper_jobs;
 	if ((phases & PHASE_JOBS) && enabled && C > 0 && n > 0) {
-		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>(), first_entry.as<uint32_t>()); }
+		// (ARRIBA_MISMAPPER_JOB_ORDER=candidate: the jobs of a candidate in the order of the reads instead of the order of its lists -- the verdict of a read does not depend on the
+		//  order of the jobs, and a test that runs both orders says so)
+		const char* order_knob = getenv("ARRIBA_MISMAPPER_JOB_ORDER");
+		const bool job_order_by_candidate = order_knob != nullptr && strcmp(order_knob, "candidate") == 0;
+		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>(), first_entry.as<unsigned long long>(), job_order_by_candidate); }
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
 		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
@@ -400,11 +405,13 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 		HIP_CHECK(hipMemcpyAsync(&n_jobs, device_counters, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (n_jobs > 0) { // ordered by candidate: reads that search the same genes sit next to each other
-			ALLOC(job_keys, (size_t) n_jobs * 4); ALLOC(job_keys_sorted, (size_t) n_jobs * 4); ALLOC(jobs_sorted, (size_t) n_jobs * 4);
-			mismapper_job_key_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(jobs.as<uint32_t>(), n_jobs, first_entry.as<uint32_t>(), job_keys.as<uint32_t>());
-			HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, job_keys.as<uint32_t>(), job_keys_sorted.as<uint32_t>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, 32, s));
+			ALLOC(job_keys, (size_t) n_jobs * 8); ALLOC(job_keys_sorted, (size_t) n_jobs * 8); ALLOC(jobs_sorted, (size_t) n_jobs * 4);
+			mismapper_job_key_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(jobs.as<uint32_t>(), n_jobs, first_entry.as<unsigned long long>(), job_keys.as<unsigned long long>());
+			int key_bits = 1; // (the positions of the lists are 64-bit; only the bits a position of this sample can have are sorted)
+			while (key_bits < 64 && (ctx->n_list_entries >> key_bits) != 0) ++key_bits;
+			HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, job_keys.as<unsigned long long>(), job_keys_sorted.as<unsigned long long>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, key_bits, s));
 			if (bytes > scratch.capacity) ALLOC(scratch, bytes);
-			HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, job_keys.as<uint32_t>(), job_keys_sorted.as<uint32_t>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, 32, s));
+			HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, job_keys.as<unsigned long long>(), job_keys_sorted.as<unsigned long long>(), jobs.as<uint32_t>(), jobs_sorted.as<uint32_t>(), n_jobs, 0, key_bits, s));
 		}
 		ctx->mismapper_jobs = n_jobs;
 	}

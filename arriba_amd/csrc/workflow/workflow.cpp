@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <iostream>
 #include <map>
 #include <mutex>
@@ -46,6 +49,11 @@ struct Run {
 	size_t piece_bytes = 0;
 	agpu_bgzf_block* tables[FEED_BUFFERS]; // pinned like the pieces: a copy from pageable memory is staged by the runtime when the stream gets there, and the caller waits for that
 	agpu_params params; // as the last sample resolved them (strandedness)
+	// read_chimeric_alignments in two halves (feed_file: the bytes of the file into HBM, on a thread of its own when the sample was submitted ahead; finish_device_ingest: what is
+	// left behind the last piece): what the first half leaves for the second
+	bool bam_open = false; uint64_t coverage_windows = 0; uint32_t bam_contigs = 0; double feed_started = 0, feed_finished = 0, feed_reading = 0, feed_pushing = 0;
+	std::string bam_path, output_path, discarded_path; // of the sample this lane works on (options.* point at them)
+	std::function<void()> after_ingest; // a session with two lanes: the stream and the tables of the ingest are free for the feed of the next sample
 	bool tags_loaded = false, domains_loaded = false;
 	// Host memory for what comes back from the device per sample (candidate columns, rows of supporting reads): pinned, kept by the session and only ever grown -- fresh
 	// std::vectors of some hundred MB per sample are zeroed page by page and given back to the system again, which costs more than the transfer they hold.
@@ -139,14 +147,16 @@ struct Run {
 
 // read_chimeric_alignments on the device (source/read_chimeric_alignments.cpp:560-773): the host opens the file, parses the BAM header and feeds the bytes in
 // pieces through two pinned buffers in turn; the batch and coverage_t are built in HBM, the host takes over the counters and coverage_t
-void read_chimeric_alignments_on_device(Run& run) {
+void feed_file(Run& run) {
 	const arriba_workflow_options& o = run.options;
 	const double started = now_seconds();
+	run.feed_started = started;
 	agpu_ingest_config config;
 	host_check(ahost_bam_open(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length, &config));
-	struct Closer { ahost_session* host; bool open; ~Closer() { if (open) ahost_bam_close(host); } } closer = { run.host, true }; // (on every way out)
-	const uint64_t windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0; // (the table belongs to the session: read before anything else touches it)
-	const uint32_t n_contigs = config.n_contigs;
+	run.bam_open = true;
+	struct Closer { Run& run; bool armed; ~Closer() { if (armed && run.bam_open) { ahost_bam_close(run.host); run.bam_open = false; } } } closer = { run, true }; // (on every way out but the last line)
+	run.coverage_windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0; // (the table belongs to the session: read before anything else touches it)
+	run.bam_contigs = config.n_contigs;
 	device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host))); // with the contigs of the BAM header
 	// The file is read by one thread (ahost_bam_next: all cores pread into the next pinned buffer) while this one pushes the piece before (agpu_ingest_push*: enqueue the copy,
 	// move the windows of the ingest on -- ~1 ms of runtime calls per piece, 0.17-0.26 s of a 54 GB file when the reader had to wait for them, profiles/r03o, r03p).  A push returns
@@ -199,12 +209,19 @@ void read_chimeric_alignments_on_device(Run& run) {
 	}
 	reader.join();
 	if (!feed.error.empty()) throw Failure{ feed.error };
-	const double reading = feed.reading;
+	run.feed_reading = feed.reading; run.feed_pushing = pushing; run.feed_finished = now_seconds();
+	closer.armed = false; // (finish_device_ingest closes the file)
+}
+
+// ... and what is left of read_chimeric_alignments behind the last piece (agpu_ingest_finish), the counters, coverage_t and viral read counts back to the host session
+void finish_device_ingest(Run& run, double waited_since) {
+	struct Closer { Run& run; ~Closer() { if (run.bam_open) { ahost_bam_close(run.host); run.bam_open = false; } } } closer = { run };
+	const uint64_t windows = run.coverage_windows; const uint32_t n_contigs = run.bam_contigs;
 	const double fed = now_seconds();
-	if (run.timing) { run.timing->feed_read = reading; run.timing->feed_push = pushing; }
+	if (run.timing) { run.timing->feed_read = run.feed_reading; run.timing->feed_push = run.feed_pushing; run.timing->feed_total = run.feed_finished - run.feed_started; }
 	agpu_ingest_result result;
 	device_check(agpu_ingest_finish(run.device, &result));
-	ahost_bam_close(run.host); closer.open = false;
+	if (run.after_ingest) run.after_ingest();
 	const double finished = now_seconds();
 	std::vector<uint64_t> viral(n_contigs > 0 ? n_contigs : 1);
 	std::vector<uint16_t> coverage(windows > 0 ? windows : 1);
@@ -214,7 +231,7 @@ void read_chimeric_alignments_on_device(Run& run) {
 	host_check(ahost_adopt_device_ingest(run.host, &result, viral.data(), coverage.data(), starts.data(), ends.data()));
 	run.n_fragments = result.fragments;
 	run.note("bam_records", result.records); // (for the report only: no line of the reference's log)
-	if (run.timing) { run.timing->feed = fed - started; run.timing->ingest = finished - fed; run.timing->adopt = now_seconds() - finished; }
+	if (run.timing) { run.timing->feed = fed - waited_since; run.timing->ingest = finished - fed; run.timing->adopt = now_seconds() - finished; }
 }
 
 // the writer prints names, CIGAR-derived pileups and sequences of the supporting reads of the candidates it writes: their rows come back from the device, and their filters.
@@ -335,18 +352,25 @@ void open_session(Run& run) {
 }
 
 // what main() does per sample: read_chimeric_alignments ... the output files (source/arriba.cpp:119-610)
-void run_sample(Run& run) {
+// what a sample starts with, in front of its feed (on the caller's thread: the feed may run on one of its own)
+void prepare_sample(Run& run) {
 	const arriba_workflow_options& o = run.options;
-	if (!o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
-	const double sample_started = now_seconds();
-	if (run.timing) memset(run.timing, 0, sizeof(*run.timing));
+	if (!o.chimeric_bam_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
 	agpu_params& params = run.params;
 	params = o.device;
-	if (params.strandedness > 2) params.strandedness = 0; // resolved below
+	if (params.strandedness > 2) params.strandedness = 0; // resolved in run_sample
 	device_check(agpu_set_params(run.device, &params));
 	run.dummy_genes = 0; run.n_candidates = 0; run.n_fragments = 0;
 	run.device_ingest = !o.host_ingest;
-	if (run.device_ingest) read_chimeric_alignments_on_device(run);
+}
+
+// already_fed: the bytes of the file are in HBM (feed_file ran on the feeder thread of a submitted sample); sample_started: when the caller began to wait for this sample
+void run_sample(Run& run, bool already_fed, double sample_started) {
+	const arriba_workflow_options& o = run.options;
+	if (!o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
+	if (run.timing) memset(run.timing, 0, sizeof(*run.timing));
+	agpu_params& params = run.params;
+	if (run.device_ingest) { if (!already_fed) feed_file(run); finish_device_ingest(run, sample_started); }
 	else {
 		host_check(ahost_ingest_bam_file(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length));
 		device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host)));
@@ -504,42 +528,142 @@ int arriba_workflow_run(const arriba_workflow_options* options, arriba_workflow_
 		Run run(*options);
 		run.report = report;
 		open_session(run);
-		run_sample(run);
+		prepare_sample(run);
+		run_sample(run, false, now_seconds());
 		return 0;
 	}
 	catch (const Failure& failure) { g_error = failure.text; return -1; }
 	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); return -1; }
 }
 
-struct arriba_workflow_session { Run run; arriba_workflow_session(const arriba_workflow_options& o): run(o) {} };
+// A resident session.  One lane = one Run (host session + device context); a second lane (same files, a sibling context that shares the scratch buffers of the first:
+// agpu_create_sibling) is made at the first arriba_workflow_submit.  Submitted samples are fed in the order they were submitted, each on a thread of its own, into the lane
+// that is not at work; the stream and the tables of the ingest exist once, so a feed starts when the ingest of the sample before has finished (agpu_ingest_finish) -- which
+// is when the stages of that sample start.  arriba_workflow_sample takes the oldest submitted sample (or submits the one it is given).
+struct arriba_workflow_session {
+	Run* lanes[2];
+	int processed_lane = 0; // of the sample arriba_workflow_sample worked on last
+	struct Submitted { std::string bam; int lane = 0; std::thread feeder; bool fed = false, ingest_finished = false, started = false; std::string error; };
+	std::deque<std::unique_ptr<Submitted>> queue; // oldest first; at most two
+	std::mutex mutex; std::condition_variable changed;
+	bool ingest_busy = false; // a lane is between agpu_ingest_begin and agpu_ingest_finish
+	arriba_workflow_session(const arriba_workflow_options& o) { lanes[0] = new Run(o); lanes[1] = nullptr; }
+	~arriba_workflow_session() {
+		drain();
+		delete lanes[1]; delete lanes[0]; // (the sibling first: either order is allowed)
+	}
+	// the feeds in flight are waited for and thrown away
+	void drain() {
+		while (!queue.empty()) {
+			Submitted& sample = *queue.front();
+			if (sample.feeder.joinable()) sample.feeder.join();
+			Run& run = *lanes[sample.lane];
+			abandon(sample, run);
+			{ std::lock_guard<std::mutex> lock(mutex); queue.pop_front(); }
+		}
+	}
+	// a sample that was fed (or began to be) and will not be finished: the next agpu_ingest_begin of its lane starts over, the stream and the tables are free
+	void abandon(Submitted& sample, Run& run) {
+		if (run.bam_open) { ahost_bam_close(run.host); run.bam_open = false; }
+		if (sample.started && !sample.ingest_finished) { { std::lock_guard<std::mutex> lock(mutex); sample.ingest_finished = true; } release_ingest(); }
+	}
+	void release_ingest() { { std::lock_guard<std::mutex> lock(mutex); ingest_busy = false; } changed.notify_all(); }
+	void submit(const char* bam) {
+		if (queue.size() >= 2) throw Failure{ "ERROR: two samples are submitted already (one at work, one being fed): call arriba_workflow_sample first" };
+		int lane = 0;
+		if (!queue.empty()) lane = 1 - queue.back()->lane; // (the lane that is not at work)
+		else if (lanes[1] != nullptr) lane = 1 - processed_lane;
+		if (lane == 1 && lanes[1] == nullptr) { // the second lane: the same reference data again (the host session holds the state of a sample next to them), a sibling context
+			std::unique_ptr<Run> second(new Run(lanes[0]->options));
+			second->options.log_to_stdout = 0; // (its loading is not a step of any sample's log)
+			const arriba_workflow_options& o = second->options;
+			second->host = ahost_open(o.assembly_file, o.gene_annotation_file, o.interesting_contigs, o.viral_contigs, o.gtf_features);
+			if (!second->host) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+			second->params = lanes[0]->params;
+			second->device = agpu_create_sibling(lanes[0]->device);
+			if (!second->device) throw Failure{ std::string("ERROR: ") + agpu_last_error() };
+			device_check(agpu_upload_annotation(second->device, ahost_annotation_view(second->host)));
+			second->options.log_to_stdout = lanes[0]->options.log_to_stdout;
+			lanes[1] = second.release();
+		}
+		Run& run = *lanes[lane];
+		run.bam_path = bam; run.options.chimeric_bam_file = run.bam_path.c_str();
+		run.timing = nullptr; run.report = nullptr;
+		prepare_sample(run);
+		std::unique_ptr<Submitted> sample(new Submitted());
+		sample->bam = bam; sample->lane = lane;
+		Submitted* mine = sample.get();
+		{ std::lock_guard<std::mutex> lock(mutex); queue.push_back(std::move(sample)); }
+		if (!run.device_ingest) { std::lock_guard<std::mutex> lock(mutex); mine->fed = true; return; } // (the host ingest reads the file inside arriba_workflow_sample)
+		mine->feeder = std::thread([this, mine, &run] {
+			{ std::unique_lock<std::mutex> lock(mutex); changed.wait(lock, [&] { return !ingest_busy && (queue.front().get() == mine || queue.front()->ingest_finished); }); ingest_busy = true; mine->started = true; }
+			try { feed_file(run); }
+			catch (const Failure& failure) { mine->error = failure.text; }
+			catch (const std::exception& e) { mine->error = std::string("ERROR: ") + e.what(); }
+			{ std::lock_guard<std::mutex> lock(mutex); mine->fed = true; }
+			changed.notify_all();
+		});
+	}
+};
 
 arriba_workflow_session* arriba_workflow_open(const arriba_workflow_options* options) {
 	if (!options) { g_error = "ERROR: null options"; return nullptr; }
 	arriba_workflow_session* session = nullptr;
-	try { session = new arriba_workflow_session(*options); open_session(session->run); return session; }
+	try { session = new arriba_workflow_session(*options); open_session(*session->lanes[0]); return session; }
 	catch (const Failure& failure) { g_error = failure.text; }
 	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); }
 	delete session;
 	return nullptr;
 }
 
+int arriba_workflow_submit(arriba_workflow_session* session, const char* chimeric_bam_file) {
+	if (!session || !chimeric_bam_file) { g_error = "ERROR: null argument"; return -1; }
+	try { session->submit(chimeric_bam_file); return 0; }
+	catch (const Failure& failure) { g_error = failure.text; }
+	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); }
+	return -1;
+}
+
 int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeric_bam_file, const char* output_file, const char* discarded_output_file, arriba_workflow_report* report, arriba_workflow_timing* timing) {
 	if (!session || !chimeric_bam_file || !output_file) { g_error = "ERROR: assembly, gene annotation, alignments and output file are required"; return -1; }
 	if (report) report->n_stages = 0;
-	Run& run = session->run;
-	const std::string bam = chimeric_bam_file, output = output_file, discarded = discarded_output_file ? discarded_output_file : "";
-	run.options.chimeric_bam_file = bam.c_str(); run.options.output_file = output.c_str(); run.options.discarded_output_file = discarded_output_file ? discarded.c_str() : nullptr;
-	run.report = report; run.timing = timing;
 	int status = 0;
-	try { run_sample(run); }
+	Run* lane = nullptr;
+	try {
+		const double sample_started = now_seconds();
+		if (session->queue.empty()) session->submit(chimeric_bam_file);
+		arriba_workflow_session::Submitted& sample = *session->queue.front();
+		if (sample.bam != chimeric_bam_file) throw Failure{ "ERROR: samples are worked on in the order they were submitted: '" + sample.bam + "' comes first" };
+		Run& run = *session->lanes[sample.lane];
+		lane = &run;
+		run.output_path = output_file; run.discarded_path = discarded_output_file ? discarded_output_file : "";
+		run.options.output_file = run.output_path.c_str(); run.options.discarded_output_file = discarded_output_file ? run.discarded_path.c_str() : nullptr;
+		run.report = report; run.timing = timing;
+		if (sample.feeder.joinable()) sample.feeder.join(); // (the feed of this sample: under the stages of the sample before if it was submitted ahead)
+		struct Done { arriba_workflow_session& session; ~Done() { // on every way out: the ingest buffers are free for the next feed, the sample leaves the queue
+			arriba_workflow_session::Submitted& sample = *session.queue.front();
+			session.abandon(sample, *session.lanes[sample.lane]); // (nothing to do behind a sample that went through)
+			{ std::lock_guard<std::mutex> lock(session.mutex); session.queue.pop_front(); }
+			session.changed.notify_all(); } } done = { *session };
+		if (!sample.error.empty()) throw Failure{ sample.error };
+		run.after_ingest = [session, &sample] { { std::lock_guard<std::mutex> lock(session->mutex); sample.ingest_finished = true; } session->release_ingest(); };
+		run_sample(run, run.device_ingest, sample_started);
+	}
 	catch (const Failure& failure) { g_error = failure.text; status = -1; }
 	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); status = -1; }
-	run.options.chimeric_bam_file = nullptr; run.options.output_file = nullptr; run.options.discarded_output_file = nullptr; run.report = nullptr; run.timing = nullptr;
+	if (lane) { lane->after_ingest = nullptr; lane->options.chimeric_bam_file = nullptr; lane->options.output_file = nullptr; lane->options.discarded_output_file = nullptr; lane->report = nullptr; lane->timing = nullptr; session->processed_lane = (int) (lane == session->lanes[1]); }
 	return status;
 }
 
-agpu_ctx* arriba_workflow_device(arriba_workflow_session* session) { return session ? session->run.device : nullptr; }
-ahost_session* arriba_workflow_host(arriba_workflow_session* session) { return session ? session->run.host : nullptr; }
+int arriba_workflow_cancel(arriba_workflow_session* session) {
+	if (!session) { g_error = "ERROR: null argument"; return -1; }
+	session->drain();
+	return 0;
+}
+
+agpu_ctx* arriba_workflow_device(arriba_workflow_session* session) { return session ? session->lanes[session->processed_lane]->device : nullptr; }
+agpu_ctx* arriba_workflow_lane_device(arriba_workflow_session* session, int lane) { return session && lane >= 0 && lane < 2 && session->lanes[lane] ? session->lanes[lane]->device : nullptr; }
+ahost_session* arriba_workflow_host(arriba_workflow_session* session) { return session ? session->lanes[session->processed_lane]->host : nullptr; }
 void arriba_workflow_close(arriba_workflow_session* session) { delete session; }
 
 }

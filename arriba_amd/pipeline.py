@@ -151,22 +151,50 @@ class WorkflowSession(object):
         self.ctx = self._lib.arriba_workflow_device(self._session)
         self.timing, self.report, self.n, self.n_candidates, self.records = {}, [], 0, 0, -1
         self.timings, self._profiling_on, self.ingest_result = {}, False, None  # (what bench.py reads from a DevicePipeline)
+        self._profiled = set()
+
+    def submit(self, bam):
+        """the sample that comes after the one `sample` is called for next: its file is fed (PCIe, the front of read_chimeric_alignments) while the stages of that one run"""
+        if self._lib.arriba_workflow_submit(self._session, bam.encode()) != 0:
+            raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        if self._profiling_on:
+            self.set_profiling(True, only_new_lanes=True)
+
+    def cancel(self):
+        """throws away what was submitted and not worked on"""
+        self._lib.arriba_workflow_cancel(self._session)
+
+    def _lane_contexts(self):
+        return [ctx for ctx in (self._lib.arriba_workflow_lane_device(self._session, lane) for lane in (0, 1)) if ctx]
 
     def sample(self, bam, output_file, discarded_output_file=None):
         """one sample, BAM file -> fusions.tsv (and discarded.tsv); returns the stages with their "(remaining=N)" counts"""
         report, timing = _capi.WorkflowReport(), _capi.WorkflowTiming()
         if self._lib.arriba_workflow_sample(self._session, bam.encode(), output_file.encode(), discarded_output_file.encode() if discarded_output_file else None, byref(report), byref(timing)) != 0:
             raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        self.ctx = self._lib.arriba_workflow_device(self._session)  # (the lane that worked on this sample)
         self.timing = {name: getattr(timing, name) for name, _ in _capi.WorkflowTiming._fields_}
         self.report = [(report.stages[k].stage.decode(), int(report.stages[k].count)) for k in range(report.n_stages)]
         return self.report
 
-    def set_profiling(self, enabled):
-        self._check(self.api.set_profiling(self.ctx, int(enabled)))
+    def set_profiling(self, enabled, only_new_lanes=False):
+        for ctx in self._lane_contexts():
+            if only_new_lanes and ctx in self._profiled:
+                continue
+            self._check(self.api.set_profiling(ctx, int(enabled)))
+            self._profiled.add(ctx)
         self._profiling_on = bool(enabled)
 
     def kernel_profile(self):
-        return DevicePipeline.kernel_profile(self)
+        """the launches of both lanes (a sample submitted ahead runs in the other lane)"""
+        mine, launches = self.ctx, []
+        try:
+            for ctx in self._lane_contexts():
+                self.ctx = ctx
+                launches += DevicePipeline.kernel_profile(self)
+        finally:
+            self.ctx = mine
+        return launches
 
     def gene_sets(self, slot):
         return DevicePipeline.gene_sets(self, slot)

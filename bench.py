@@ -237,6 +237,7 @@ def main():
     parser.add_argument("--discarded", action="store_true", help="also write discarded.tsv (-O) inside the step")
     parser.add_argument("--host-ingest", action="store_true", help="read_chimeric_alignments by the multi-threaded host ingest instead of on the device (round 1's path)")
     parser.add_argument("--python-stages", action="store_true", help="time the ctypes mirror of the stage order (arriba_amd/pipeline.py) instead of arriba_workflow_sample of the product library")
+    parser.add_argument("--no-pipeline", action="store_true", help="one sample at a time: without it the file of the next sample is fed (arriba_workflow_submit) while the stages of the current one run")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-normal-pairs", action="store_true", help="skip the secondary measurement on the 10 M sample with 4 N ordinary proper pairs (value_with_normal_pairs)")
     parser.add_argument("--host-only", action="store_true")
@@ -359,6 +360,7 @@ def main():
         # One GPU per sample: the step is arriba_workflow_sample of the product library (libarriba_workflow.so: the reference's main() in C++ over the two C ABIs, resident session);
         # --python-stages times the ctypes mirror of the same stage order instead (arriba_amd/pipeline.py, what rounds 1-2 timed), as do --host-ingest and one sample over N GPUs
         through_workflow_library = not one_sample and not args.host_ingest and not args.python_stages
+        pipelined, primed = through_workflow_library and not args.no_pipeline, [False]
         if through_workflow_library:
             pipeline = WorkflowSession(prefix + ".fa", prefix + ".gtf", params=params, device=local_rank)
             session = None
@@ -371,6 +373,11 @@ def main():
             started = time.perf_counter()
             del stage_log[:]
             if through_workflow_library:
+                if pipelined:  # a resident service with a queue of samples: the next one is submitted before this one is worked on
+                    if not primed[0]:
+                        pipeline.submit(prefix + ".bam")
+                        primed[0] = True
+                    pipeline.submit(prefix + ".bam")
                 report = pipeline.sample(prefix + ".bam", outputs[0], outputs[1])
                 finished = time.perf_counter()
                 timing = pipeline.timing
@@ -378,7 +385,7 @@ def main():
                 pipeline.n, pipeline.n_candidates, pipeline.records = counts.get("read_chimeric_alignments", 0), counts.get("find_fusions", 0), counts.get("bam_records", -1)
                 pipeline.writer_seconds = {key: round(timing[key], 4) for key in ("output_results", "output_rows", "output_format")}
                 stage_log.extend((stage, count, None) for stage, count in report)
-                ingest_parts.append({"feed": timing["feed"], "device": timing["ingest"], "adopt": timing["adopt"], "feed_read": timing.get("feed_read", 0.0), "feed_push": timing.get("feed_push", 0.0)})
+                ingest_parts.append({"feed": timing["feed"], "device": timing["ingest"], "adopt": timing["adopt"], "feed_read": timing.get("feed_read", 0.0), "feed_push": timing.get("feed_push", 0.0), "feed_total": timing.get("feed_total", 0.0)})
                 ingested = started + timing["feed"] + timing["ingest"] + timing["adopt"]
                 step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started, "stages": timing["stages"], "filter_mismappers": timing["filter_mismappers"], "output": timing["output"]})
                 if verbose:
@@ -458,6 +465,14 @@ def main():
             dist.barrier()
         elapsed = time.time() - started
         n = pipeline.n
+        sample_alone = None
+        if pipelined:  # the sample submitted behind the last timed step is thrown away; then one sample alone, for the time from its file to its fusions.tsv when nothing overlaps it
+            pipeline.cancel()
+            primed[0], pipelined = False, False
+            alone_started = time.perf_counter()
+            pipeline.sample(prefix + ".bam", outputs[0], outputs[1])
+            sample_alone = {"seconds": round(time.perf_counter() - alone_started, 4), "parts": {key: round(value, 4) for key, value in pipeline.timing.items()}}
+            pipelined = True
         if distributed:
             device = "cuda" if dist.get_backend() == "nccl" else "cpu"
             tensor = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -531,7 +546,7 @@ def main():
                                           " + discarded.tsv" if args.discarded else ""),
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
-                           "timed_call": "arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
+                           "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor" if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
                            "parallelism": ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
                                            % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0))) if one_sample
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
@@ -542,6 +557,7 @@ def main():
                                          **({key: round(mean(key), 4) for key in ("stages", "filter_mismappers", "output")} if through_workflow_library else {})),
                 "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
                 "output_side_seconds": getattr(pipeline, "writer_seconds", None),
+                "samples_pipelined": bool(pipelined), "one_sample_alone": sample_alone,
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
                 "stages": stage_log,
                 # per step: the sum over the launches of one step (the front of the ingest runs window by window: ~200 launches of its kernels in a step of 10^8 fragments)

@@ -168,6 +168,11 @@ int agpu_api_version(void);
 int agpu_device_count(void);
 
 agpu_ctx* agpu_create(int device, const agpu_params* params);
+/* A second context on the device of `of` that shares its scratch buffers (the stream and the tables of the ingest, the buffers of the stages; everything that is loaded or
+ * built per context -- annotation, genome, batch, candidates -- is its own).  For a resident session that feeds the file of the next sample through one context while the
+ * stages of the current sample run in the other (include/arriba_workflow.h: arriba_workflow_submit): the caller must not let both be between agpu_ingest_begin and
+ * agpu_ingest_finish at once, nor both in their stages.  Destroy both with agpu_destroy, in any order. */
+agpu_ctx* agpu_create_sibling(agpu_ctx* of);
 void agpu_destroy(agpu_ctx* ctx);
 int agpu_set_params(agpu_ctx* ctx, const agpu_params* params);
 

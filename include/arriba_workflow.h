@@ -73,12 +73,22 @@ typedef struct { /* seconds of one sample, by part (wall clock of the calling th
 	double output_format;    /*   of it: ahost_write_fusions */
 	double feed_read;        /* of feed: inside ahost_bam_next (the bytes of the file into the pinned pieces) */
 	double feed_push;        /* of feed: inside agpu_ingest_push* (enqueue the copy, wait for the copy before it, move the windows of the ingest on) */
+	double feed_total;       /* the feed from the moment the file was opened to the last piece, wherever it ran: a sample submitted ahead is fed under the stages of the sample before,
+	                            and `feed` is then only what arriba_workflow_sample still had to wait for */
 } arriba_workflow_timing;
 /* options->chimeric_bam_file, output_file and discarded_output_file are not used by open (they belong to a sample); NULL + arriba_workflow_last_error() on failure */
 arriba_workflow_session* arriba_workflow_open(const arriba_workflow_options* options);
 int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeric_bam_file, const char* output_file, const char* discarded_output_file /* may be NULL */,
                            arriba_workflow_report* report /* may be NULL */, arriba_workflow_timing* timing /* may be NULL */);
-agpu_ctx* arriba_workflow_device(arriba_workflow_session* session);      /* the session's device context, e.g. for agpu_set_profiling / agpu_get_kernel_profile */
+/* Samples one after the other through a resident session: arriba_workflow_submit(next) before arriba_workflow_sample(current) lets the file of the next sample cross PCIe and go
+ * through the front of read_chimeric_alignments (the windows of the ingest) while the stages, filter_mismappers and the writer of the current one run -- a second lane (host
+ * session + sibling device context, agpu_create_sibling) is made for it at the first call.  Samples are worked on in the order they were submitted; at most one can be submitted
+ * ahead of the one at work.  arriba_workflow_sample(bam) with nothing submitted submits bam itself (the behaviour without this call).  A sample that was submitted and never
+ * asked for is thrown away by arriba_workflow_close.  Returns 0, or a negative number with the text in arriba_workflow_last_error(). */
+int arriba_workflow_submit(arriba_workflow_session* session, const char* chimeric_bam_file);
+int arriba_workflow_cancel(arriba_workflow_session* session); /* what was submitted and not yet worked on is thrown away (its feed is waited for first) */
+agpu_ctx* arriba_workflow_device(arriba_workflow_session* session);      /* the device context of the lane that worked on the last sample, e.g. for agpu_get_kernel_profile */
+agpu_ctx* arriba_workflow_lane_device(arriba_workflow_session* session, int lane); /* lane 0 or 1; NULL if the lane does not exist (yet) */
 ahost_session* arriba_workflow_host(arriba_workflow_session* session);
 void arriba_workflow_close(arriba_workflow_session* session);
 

@@ -30,6 +30,7 @@
 #include "../../arriba_amd/csrc/device/shard_host.hpp"
 #include "../../arriba_amd/csrc/device/crc32_core.hpp"
 #include <map>
+#include <mutex>
 #include <set>
 #include <tuple>
 
@@ -137,6 +138,7 @@ void emu_default_params(agpu_params* p) {
 	for (int f = 1; f < AGPU_FILTER_COUNT; ++f) p->filter_enabled[f] = 1;
 }
 emu_ctx* emu_create(int, const agpu_params* params) { emu_ctx* ctx = new emu_ctx(); if (params) ctx->params = *params; else emu_default_params(&ctx->params); memset(ctx->stage_counts, 0, sizeof(ctx->stage_counts)); return ctx; }
+emu_ctx* emu_create_sibling(emu_ctx* of) { return of ? emu_create(0, &of->params) : nullptr; } // (the harness has no scratch buffers to share)
 void emu_destroy(emu_ctx* ctx) { delete ctx; }
 int emu_set_params(emu_ctx* ctx, const agpu_params* params) { ctx->params = *params; if (ctx->n) build_tables(ctx); return 0; }
 

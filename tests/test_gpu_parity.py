@@ -740,3 +740,10 @@ def test_mismapper_stress_at_scale_against_the_live_reference(built, tmp_path):
     os.makedirs(str(tmp_path / "mine"))
     stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True, params={"subsampling_threshold": 32767})
     assert dict(stages)["filter_mismappers"] > 1000
+
+
+def test_samples_in_a_queue_through_one_session_on_the_gpu(built, tmp_path):
+    """arriba_workflow_submit on the device: the file of the next sample is fed through the sibling context while the stages of the current one run -- two different samples,
+    the files of every one equal to those it gives alone (tests/test_host_and_device_logic.py: the same check on the stepping harness)"""
+    import test_host_and_device_logic as host_tests
+    host_tests.check_samples_in_a_queue("product", tmp_path)

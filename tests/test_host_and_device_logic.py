@@ -2,6 +2,8 @@
 per-fragment logic single-stepped on the host (tests/emu) against the same dumps."""
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -968,3 +970,30 @@ def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api
     assert parity.check_multimappers(session, pipeline, golden) > 50
     session, pipeline = parity.run_read_level(parity.open_session, dataset_files("toy3k"), api=emu_api)
     assert parity.check_chain_to_relative_support(session, pipeline, golden, multimappers=True) > 1000
+
+
+def check_samples_in_a_queue(mode, tmp_path):
+    """Two different samples of one genome through a resident session, one at a time and in a queue (arriba_workflow_submit): the same files; the order rule and
+    arriba_workflow_cancel behave as include/arriba_workflow.h says."""
+    import json
+    arguments = ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"]
+    for k, read_seed in ((1, "0"), (2, "5")):
+        subprocess.run([datasets.GEN_SYNTH, "--out", str(tmp_path / ("s%d" % k)), "--read-seed", read_seed] + arguments, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = tmp_path / "out"
+    out.mkdir()
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "workflow_session_worker.py"), mode, str(tmp_path / "s1.fa"), str(tmp_path / "s1.gtf"), str(tmp_path / "s1.bam"), str(tmp_path / "s2.bam"), str(out)],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=1200)
+    assert result.returncode == 0, result.stdout[-3000:]
+    report = json.load(open(str(out / "result.json")))
+    assert "two samples are submitted already" in report["third_submit"] and "order they were submitted" in report["out_of_order"], report
+    assert report["feed_overlapped"]
+    assert report["alone1"] != report["alone2"]  # (two different samples)
+    read = lambda name: open(str(out / name), "rb").read()
+    for queued, alone in (("queued1", "alone1"), ("queued2", "alone2"), ("queued3", "alone1"), ("queued4", "alone2")):
+        assert report[queued] == report[alone], queued
+        assert read(queued + ".tsv") == read(alone + ".tsv") and read(queued + ".discarded.tsv") == read(alone + ".discarded.tsv"), queued
+    assert len(read("alone1.tsv").splitlines()) > 5
+
+
+def test_samples_in_a_queue_through_one_session(built, emu_api, tmp_path):
+    check_samples_in_a_queue("harness", tmp_path)

@@ -1,0 +1,53 @@
+"""TEST-ONLY worker: samples in a queue through one resident workflow session (include/arriba_workflow.h: arriba_workflow_submit / _sample / _cancel).
+usage: workflow_session_worker.py harness|product fasta gtf bam1 bam2 out_directory
+harness: the workflow library built over the host stepping harness (tests/emu), as tests/bench_on_harness.py does; product: libarriba_workflow.so on the GPU.
+Writes the files of every sample and checks nothing itself but the order rule; the test compares the files."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+mode, fasta, gtf, bam1, bam2, out = sys.argv[1:7]
+if mode == "harness":
+    os.environ["ARRIBA_WORKFLOW_LIBRARY"] = os.path.join(ROOT, "tests", "emu", "libworkflow_on_harness.so")
+    from arriba_amd import _capi
+    _bind = _capi.bind_device_api
+    _harness = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libemu.so"))
+    _capi.bind_device_api = lambda library, prefix: _bind(_harness, "emu_")
+from arriba_amd.pipeline import ArribaError, WorkflowSession  # noqa: E402
+
+os.environ.setdefault("ARRIBA_FEED_PIECE_MB", "1")  # (many pieces through the reader and the pusher of the feed)
+result = {}
+path = lambda name: os.path.join(out, name)
+# one sample at a time
+session = WorkflowSession(fasta, gtf)
+result["alone1"] = session.sample(bam1, path("alone1.tsv"), path("alone1.discarded.tsv"))
+result["alone2"] = session.sample(bam2, path("alone2.tsv"), path("alone2.discarded.tsv"))
+session.close()
+# in a queue: the next sample is submitted before the current one is worked on
+session = WorkflowSession(fasta, gtf)
+session.submit(bam1)
+session.submit(bam2)
+try:
+    session.submit(bam1)
+    result["third_submit"] = "accepted"
+except ArribaError as error:
+    result["third_submit"] = str(error)
+result["queued1"] = session.sample(bam1, path("queued1.tsv"), path("queued1.discarded.tsv"))
+result["feed_overlapped"] = session.timing["feed_total"] > 0
+session.submit(bam1)
+result["queued2"] = session.sample(bam2, path("queued2.tsv"), path("queued2.discarded.tsv"))
+session.submit(bam2)
+try:  # bam1 was submitted first
+    session.sample(bam2, path("wrong.tsv"))
+    result["out_of_order"] = "accepted"
+except ArribaError as error:
+    result["out_of_order"] = str(error)
+result["queued3"] = session.sample(bam1, path("queued3.tsv"), path("queued3.discarded.tsv"))
+session.cancel()  # bam2, fed and never asked for
+result["queued4"] = session.sample(bam2, path("queued4.tsv"), path("queued4.discarded.tsv"))  # (submits itself)
+session.submit(bam1)  # left behind: arriba_workflow_close throws it away
+session.close()
+json.dump(result, open(path("result.json"), "w"))
