@@ -690,19 +690,22 @@ def test_workflow_at_config_scale_against_the_live_reference(built, tmp_path):
     assert dict(stages)["find_fusions"] > fragments // 5 and stages[-1][1] > 100
 
 
-def test_bench_sample_of_config_2_against_the_reference(built, tmp_path):
-    """BASELINE.json config 2 at FULL size, exactly the sample bench.py times at 10 M (10 444 615 fragments, 26.6 M BAM records): the product path -- arriba_workflow_sample of the
-    C++ workflow library, resident session -- against the unmodified reference, which was run once on this very sample where the repository is built (7 min 40 s, 15.9 GB:
-    tests/golden/bench10m): the generated BAM file is the one the reference read (SHA-256), fusions.tsv is the one it wrote (SHA-256), and the counts of its log are met."""
+@pytest.mark.parametrize("name,fragments", [("bench10m", 10000000), ("bench20m", 20000000)])
+def test_bench_sample_of_config_2_against_the_reference(name, fragments, built, tmp_path):
+    """BASELINE.json config 2 at FULL size, exactly the sample bench.py times at 10 M (10 444 615 fragments, 26.6 M BAM records) and the same workload at 20 M (20 906 803 fragments): the
+    product path -- arriba_workflow_sample of the C++ workflow library, resident session -- against the unmodified reference, which was run once on these very samples where the
+    repository is built (tools/make_bench_golden.py; 10 M: 7 min 40 s, 15.9 GB; 20 M: 16 min 38 s, 29 GB -- tests/golden/bench10m, bench20m): the generated BAM file is the one the
+    reference read (SHA-256), fusions.tsv is the one it wrote (SHA-256), and the counts of its log are met.  The second sample of every session goes through the queue
+    (arriba_workflow_submit: its file fed while the stages of the first run)."""
     import hashlib
     import json
     import subprocess
     import bench
     from arriba_amd.pipeline import WorkflowSession
-    golden = conftest.golden_dir("bench10m")
+    golden = conftest.golden_dir(name)
     meta = json.load(open(os.path.join(golden, "meta.json")))
     prefix = str(tmp_path / "bench")
-    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(bench.cpu_budget())] + bench.workload_args(10000000, 1000), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(bench.cpu_budget())] + bench.workload_args(fragments, 1000), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
     def sha256(path):
         digest = hashlib.sha256()
@@ -710,10 +713,13 @@ def test_bench_sample_of_config_2_against_the_reference(built, tmp_path):
             for piece in iter(lambda: stream.read(1 << 24), b""):
                 digest.update(piece)
         return digest.hexdigest()
-    assert sha256(prefix + ".bam") == meta["bam_sha256"], "the generator drifted from the sample the reference was run on (tests/golden/bench10m/meta.json)"
+    assert sha256(prefix + ".bam") == meta["bam_sha256"], "the generator drifted from the sample the reference was run on (tests/golden/%s/meta.json)" % name
     session = WorkflowSession(prefix + ".fa", prefix + ".gtf")
-    for repeat in range(2):  # (a resident session: the second sample through the same buffers)
+    session.submit(prefix + ".bam")
+    for repeat in range(2):  # (a resident session: the second sample through the other lane, fed under the stages of the first)
         output = str(tmp_path / ("fusions%d.tsv" % repeat))
+        if repeat == 0:
+            session.submit(prefix + ".bam")
         counts = dict(session.sample(prefix + ".bam", output))
         assert sha256(output) == meta["fusions_tsv_sha256"], repeat
     log = open(os.path.join(golden, "reference.log")).read()
