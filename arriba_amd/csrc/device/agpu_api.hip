@@ -25,8 +25,13 @@
 using namespace agpu;
 
 namespace agpu {
-static thread_local std::string g_last_error;
-void set_last_error(const std::string& message) { g_last_error = message; }
+static thread_local std::string g_last_error, g_allocation_note;
+void set_last_error(const std::string& message) { g_last_error = message; if (message.compare(0, 16, "hipMalloc failed") == 0 && !g_allocation_note.empty()) { g_last_error += g_allocation_note; g_allocation_note.clear(); } }
+void note_failed_allocation(size_t bytes) {
+	size_t free_bytes = 0, total_bytes = 0;
+	(void) hipMemGetInfo(&free_bytes, &total_bytes);
+	g_allocation_note = ": " + std::to_string(bytes >> 20) + " MB asked for, " + std::to_string(free_bytes >> 20) + " of " + std::to_string(total_bytes >> 20) + " MB free on the device";
+}
 
 // the live contexts of the process: an allocation that fails asks them to give back what they only keep for their next sample
 static std::mutex g_contexts_mutex;
@@ -50,6 +55,42 @@ bool DeviceBuffer::release_idle_buffers() {
 	}
 	return released;
 }
+void take_sample_buffers(agpu_ctx* ctx) {
+	agpu_ctx* from = ctx->sibling;
+	if (from == nullptr) return;
+	(void) hipStreamSynchronize(from->stream); // (its last copies back to the host have left the buffers)
+	DeviceBuffer* mine[] = { &ctx->n_aln, &ctx->fbits, &ctx->filter, &ctx->group, &ctx->pristine_fbits, &ctx->pristine_abits[0], &ctx->pristine_abits[1], &ctx->pristine_abits[2],
+		&ctx->contig[0], &ctx->contig[1], &ctx->contig[2], &ctx->start[0], &ctx->start[1], &ctx->start[2], &ctx->end[0], &ctx->end[1], &ctx->end[2], &ctx->abits[0], &ctx->abits[1], &ctx->abits[2],
+		&ctx->cigar_offset[0], &ctx->cigar_offset[1], &ctx->cigar_offset[2], &ctx->cigar_count[0], &ctx->cigar_count[1], &ctx->cigar_count[2], &ctx->cigar_pool, &ctx->seq_offset[0], &ctx->seq_offset[1],
+		&ctx->seq_length[0], &ctx->seq_length[1], &ctx->seq_pool, &ctx->gene_count[0], &ctx->gene_count[1], &ctx->gene_count[2], &ctx->genes[0], &ctx->genes[1], &ctx->genes[2], &ctx->gene_pool,
+		&ctx->names, &ctx->name_offset, &ctx->ingest_qname_keys, &ctx->gather_ids, &ctx->gather_cigar_base, &ctx->gather_seq_base, &ctx->gather_name_base, &ctx->cand_closest1, &ctx->cand_closest2,
+		&ctx->unmapped_keys, &ctx->sort_scratch, &ctx->sorted_keys, &ctx->scan_flags, &ctx->scan_ids, &ctx->viral_pairs, &ctx->duplicate_keys, &ctx->duplicate_slots, &ctx->duplicate_entries,
+		&ctx->sample_flags, &ctx->sample_values, &ctx->samples, &ctx->emissions, &ctx->discordant_swapped,
+		&ctx->cand_gene1, &ctx->cand_gene2, &ctx->cand_contigs, &ctx->cand_breakpoint1, &ctx->cand_breakpoint2, &ctx->cand_flags, &ctx->cand_filter, &ctx->cand_split_reads1, &ctx->cand_split_reads2, &ctx->cand_discordant_mates,
+		&ctx->cand_anchor1, &ctx->cand_anchor2, &ctx->cand_list_offset, &ctx->cand_read_lists, &ctx->cand_evalue, &ctx->cand_iteration_rank, &ctx->cand_votes, &ctx->cand_first_occurrence, &ctx->cand_extra_split_list,
+		&ctx->kmer_contig_table, &ctx->kmer_offsets, &ctx->kmer_positions, &ctx->splice_offset, &ctx->splice_sites, &ctx->splice_bits };
+	DeviceBuffer* theirs[] = { &from->n_aln, &from->fbits, &from->filter, &from->group, &from->pristine_fbits, &from->pristine_abits[0], &from->pristine_abits[1], &from->pristine_abits[2],
+		&from->contig[0], &from->contig[1], &from->contig[2], &from->start[0], &from->start[1], &from->start[2], &from->end[0], &from->end[1], &from->end[2], &from->abits[0], &from->abits[1], &from->abits[2],
+		&from->cigar_offset[0], &from->cigar_offset[1], &from->cigar_offset[2], &from->cigar_count[0], &from->cigar_count[1], &from->cigar_count[2], &from->cigar_pool, &from->seq_offset[0], &from->seq_offset[1],
+		&from->seq_length[0], &from->seq_length[1], &from->seq_pool, &from->gene_count[0], &from->gene_count[1], &from->gene_count[2], &from->genes[0], &from->genes[1], &from->genes[2], &from->gene_pool,
+		&from->names, &from->name_offset, &from->ingest_qname_keys, &from->gather_ids, &from->gather_cigar_base, &from->gather_seq_base, &from->gather_name_base, &from->cand_closest1, &from->cand_closest2,
+		&from->unmapped_keys, &from->sort_scratch, &from->sorted_keys, &from->scan_flags, &from->scan_ids, &from->viral_pairs, &from->duplicate_keys, &from->duplicate_slots, &from->duplicate_entries,
+		&from->sample_flags, &from->sample_values, &from->samples, &from->emissions, &from->discordant_swapped,
+		&from->cand_gene1, &from->cand_gene2, &from->cand_contigs, &from->cand_breakpoint1, &from->cand_breakpoint2, &from->cand_flags, &from->cand_filter, &from->cand_split_reads1, &from->cand_split_reads2, &from->cand_discordant_mates,
+		&from->cand_anchor1, &from->cand_anchor2, &from->cand_list_offset, &from->cand_read_lists, &from->cand_evalue, &from->cand_iteration_rank, &from->cand_votes, &from->cand_first_occurrence, &from->cand_extra_split_list,
+		&from->kmer_contig_table, &from->kmer_offsets, &from->kmer_positions, &from->splice_offset, &from->splice_sites, &from->splice_bits };
+	static_assert(sizeof(mine) == sizeof(theirs), "the same buffers of both contexts");
+	bool any = false;
+	for (size_t k = 0; k < sizeof(mine) / sizeof(mine[0]); ++k) if (theirs[k]->capacity > mine[k]->capacity) { mine[k]->swap(*theirs[k]); any = true; }
+	if (!any) return;
+	// the views of the sibling point at what it gave away: it has no sample until its next ingest
+	from->have_batch = false; from->annotated = false; from->stage1_done = false; from->stage2_done = false; from->fusions_done = false; from->evalue_done = false; from->iteration_order_done = false;
+	from->kmer_index_done = false; from->have_splice_sites = false; from->genomic_support_marked = false; from->mismapper_jobs_ready = false; from->n = 0; from->n_candidates = 0;
+	from->candidates = agpu::CandidateTable(); from->viral_pair_capacity = 0;
+	// ... and what this context kept of its own last sample went with the buffers
+	ctx->have_splice_sites = false; ctx->kmer_index_done = false; ctx->viral_pair_capacity = 0;
+}
+
 }
 
 namespace {
@@ -568,8 +609,9 @@ static agpu_ctx* create_context(int device, const agpu_params* params, std::shar
 agpu_ctx* agpu_create(int device, const agpu_params* params) { return create_context(device, params, std::shared_ptr<agpu::ScratchPool>()); }
 agpu_ctx* agpu_create_sibling(agpu_ctx* of) {
 	if (!of) { set_last_error("null argument"); return nullptr; }
+	if (of->sibling) { set_last_error("the context has a sibling already"); return nullptr; }
 	agpu_ctx* ctx = create_context(of->device, &of->params, of->pool);
-	if (ctx) ctx->profiling = of->profiling;
+	if (ctx) { ctx->profiling = of->profiling; ctx->sibling = of; of->sibling = ctx; }
 	return ctx;
 }
 static agpu_ctx* create_context(int device, const agpu_params* params, std::shared_ptr<agpu::ScratchPool> pool) {
@@ -592,6 +634,7 @@ static agpu_ctx* create_context(int device, const agpu_params* params, std::shar
 
 void agpu_destroy(agpu_ctx* ctx) {
 	if (!ctx) return;
+	if (ctx->sibling) { ctx->sibling->sibling = nullptr; ctx->sibling = nullptr; }
 	{ std::lock_guard<std::mutex> lock(g_contexts_mutex); g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), ctx), g_contexts.end()); }
 	(void) hipSetDevice(ctx->device);
 	(void) hipStreamSynchronize(ctx->stream);

@@ -19,6 +19,7 @@ namespace agpu {
 
 void set_last_error(const std::string& message);
 
+void note_failed_allocation(size_t bytes); // agpu_api.hip: the size asked for and what the device has free go into the next "hipMalloc failed" message of this thread
 struct DeviceBuffer {
 	void* ptr = nullptr;
 	size_t bytes = 0;
@@ -38,7 +39,7 @@ struct DeviceBuffer {
 			// buffers of the stages while an ingest runs), then once more
 			(void) hipGetLastError();
 			ptr = nullptr;
-			if (!release_idle_buffers() || hipMalloc(&ptr, n) != hipSuccess) { (void) hipGetLastError(); ptr = nullptr; return false; }
+			if (!release_idle_buffers() || hipMalloc(&ptr, n) != hipSuccess) { (void) hipGetLastError(); ptr = nullptr; note_failed_allocation(n); return false; }
 		}
 		bytes = n; capacity = n;
 		return true;
@@ -118,6 +119,7 @@ struct agpu_ctx {
 	// scratch buffers of the stage calls, kept between calls (grow-only) and addressed by name
 	std::shared_ptr<agpu::ScratchPool> pool;
 	agpu::DeviceBuffer& scratch(const char* name) { return pool->get(name); }
+	agpu_ctx* sibling = nullptr; // agpu_create_sibling: the other lane of a session (shares `pool`; the buffers of a sample change hands in agpu_ingest_finish: take_sample_buffers)
 
 	// annotation
 	uint32_t n_genes = 0, n_exons = 0, n_dummy = 0;
@@ -220,6 +222,9 @@ namespace agpu {
 
 // agpu_ingest.hip: the stream and the per-record tables of the last ingest given back to the device (they are kept for the next sample as long as memory allows); true if there were any
 bool release_ingest_buffers(agpu_ctx* ctx);
+// agpu_api.hip: the buffers that hold a sample (batch, gene sets, candidates, read lists, k-mer index, ...) change hands between the lanes of a session: `ctx`, about to build
+// its batch, takes what its sibling -- whose sample is done on the device -- holds wherever that is the larger buffer; the sibling's sample is gone afterwards
+void take_sample_buffers(agpu_ctx* ctx);
 // agpu_api.hip: what follows the columns of a batch, whoever filled them (agpu_upload_batch, or the ingest on the device: agpu_ingest.hip)
 int finish_batch_setup(agpu_ctx* ctx);
 

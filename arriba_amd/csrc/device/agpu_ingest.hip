@@ -913,6 +913,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	struct Finishing { agpu_ctx* ctx; explicit Finishing(agpu_ctx* c) : ctx(c) { ctx->ingest_finishing = true; } ~Finishing() { ctx->ingest_finishing = false; } } finishing(ctx);
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
+	take_sample_buffers(ctx); // (a session with two lanes: the batch of this sample is built where the sibling's last one, done on the device, lies)
 	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); // (the last pieces unwrapped)
 	if (ctx->ingest_verify_crc) { // a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch")
 		unsigned int mismatches = 0;
