@@ -78,7 +78,7 @@ class IngestConfig(ctypes.Structure):
 
 
 class BgzfBlock(ctypes.Structure):
-    _fields_ = [("raw_offset", c_uint64), ("payload_offset", c_uint32), ("payload_size", c_uint32), ("stream_offset", c_uint64), ("crc32", c_uint32), ("reserved", c_uint32)]
+    _fields_ = [("raw_offset", c_uint64), ("payload_offset", c_uint32), ("payload_size", c_uint32), ("stream_offset", c_uint64), ("crc32", c_uint32), ("isize", c_uint32), ("skip", c_uint32), ("keep", c_uint32)]
 
 
 class IngestResult(ctypes.Structure):

@@ -25,6 +25,7 @@
 #include "device_utils.hpp"
 #include "shard_host.hpp"
 #include "crc32_core.hpp"
+#include "inflate_core.hpp"
 
 using namespace agpu;
 
@@ -55,6 +56,23 @@ __global__ void __launch_bounds__(BLOCK) bgzf_unwrap_kernel(const uint8_t* raw, 
 	for (uint32_t w = threadIdx.x; w < words; w += BLOCK) *(uint32_t*) (target + head + 4 * (size_t) w) = load_u32(source + head + 4 * (size_t) w);
 	const uint32_t tail = head + 4 * words;
 	if (threadIdx.x < size - tail) target[tail + threadIdx.x] = source[tail + threadIdx.x];
+}
+
+// one wavefront per deflated block (inflate_core.hpp): the DEFLATE stream raw -> the block's place in the record stream.  The first / last block of a part of a file gives only
+// the bytes [skip, skip + keep) of what it holds: such a block is inflated into `spill` (64 KB for block 0, 64 KB for the last one) and its share copied from there.
+__global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint8_t* stream, uint8_t* spill, unsigned int* failures) {
+	__shared__ InflateShared shared;
+	const agpu_bgzf_block block = blocks[blockIdx.x];
+	const bool partial = block.skip != 0 || block.keep != block.isize;
+	uint8_t* target = partial ? spill + (blockIdx.x == 0 ? 0 : 65536) : stream + block.stream_offset;
+	auto sync = [] () { __syncthreads(); };
+	auto broadcast = [] (uint32_t value) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) value); };
+	const int status = inflate_block(raw + block.raw_offset + block.payload_offset, block.payload_size, target, block.isize, shared, threadIdx.x, 64u, sync, broadcast);
+	if (status != INFLATE_OK) { if (threadIdx.x == 0) atomicAdd(failures, 1u); return; }
+	if (partial) {
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < block.keep; k += 64) stream[block.stream_offset + k] = __hip_atomic_load(&target[block.skip + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
 // ---- the record chain -----------------------------------------------------------------------------------------------------------------------------
@@ -341,7 +359,8 @@ __global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, c
 // CRC-32 of the payload of every stored block of a pushed piece against the trailer of the block (crc32_core.hpp; htslib checks every block it reads: bgzf.c): one workgroup
 // per block, 256 lanes x 256 bytes four bytes per step, the CRCs of the chunks joined in a tree with the prepared advance operators (tables and operators in LDS).
 // Blocks of which only a part is delivered (the ends of a part of a file) carry crc32 = 0 and are not checked.
-__global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, const Crc32Tables* tables, unsigned int* mismatches) {
+// INFLATED: the blocks were deflated and `raw` is the stream they were inflated into: the CRC-32 of the gzip trailer is that of the inflated bytes
+template <bool INFLATED> __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, const Crc32Tables* tables, unsigned int* mismatches) {
 	__shared__ Crc32Tables t;
 	__shared__ uint32_t part[256];
 	__shared__ uint32_t length[256];
@@ -353,7 +372,8 @@ __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const
 	const uint32_t ROUND_WORDS = CRC32_CHUNK / 16; // words of a lane's chunk per round
 	__shared__ uint32_t staged[256 * (CRC32_CHUNK / 16 + 1)];
 	for (uint32_t k = threadIdx.x; k < sizeof(Crc32Tables) / 4; k += 256) ((uint32_t*) &t)[k] = ((const uint32_t*) tables)[k];
-	const agpu_bgzf_block block = blocks[blockIdx.x];
+	agpu_bgzf_block block = blocks[blockIdx.x];
+	if (INFLATED) { block.raw_offset = block.stream_offset; block.payload_offset = 0; block.payload_size = block.isize; }
 	if (block.crc32 == 0 || block.payload_size > 256u * CRC32_CHUNK) return; // (uniform; a BGZF block holds at most 64 KB)
 	const uint8_t* payload = raw + block.raw_offset + block.payload_offset;
 	const uint32_t at = threadIdx.x * CRC32_CHUNK;
@@ -882,19 +902,26 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 	hipStream_t pieces = ctx->piece_stream;
 	if (n_blocks > 0 && raw_size > 0) {
 		TRY(grow_stream(ctx, ctx->ingest_stream_size + stream_bytes));
-		ALLOC(ctx->ingest_raw[slot], raw_size); ALLOC(ctx->ingest_blocks[slot], (size_t) n_blocks * sizeof(agpu_bgzf_block));
+		const bool deflated = blocks[0].isize != 0; // (all blocks of a piece are of one kind: include/arriba_gpu.h)
+		ALLOC(ctx->ingest_raw[slot], raw_size + 64); ALLOC(ctx->ingest_blocks[slot], (size_t) n_blocks * sizeof(agpu_bgzf_block)); // (+ 64: the bit reader of bgzf_inflate_kernel looks a few bytes ahead)
+		if (deflated) ALLOC(ctx->scratch("ingest.inflate_spill"), 2 * 65536);
 		HIP_CHECK(hipStreamWaitEvent(s, ctx->piece_done[slot], 0)); // (the piece that lay in this buffer is unwrapped and checked; an event that was never recorded does not hold anybody up)
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_raw[slot].ptr, raw, raw_size, hipMemcpyHostToDevice, s));
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_blocks[slot].ptr, blocks, (size_t) n_blocks * sizeof(agpu_bgzf_block), hipMemcpyHostToDevice, s));
 		HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], s));
 		HIP_CHECK(hipStreamWaitEvent(pieces, ctx->piece_copied[slot], 0));
-		{ KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes, pieces);
+		if (deflated) { KernelTimer timer(ctx, "bgzf_inflate_kernel", (uint64_t) raw_size + stream_bytes, pieces);
+		  bgzf_inflate_kernel<<<n_blocks, 64, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size, ctx->scratch("ingest.inflate_spill").as<uint8_t>(),
+		                                                        ctx->scratch("ingest.crc_mismatches").as<unsigned int>()); }
+		else { KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes, pieces);
 		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
+		const uint64_t piece_stream_offset = ctx->ingest_stream_size;
 		ctx->ingest_stream_size += stream_bytes;
 		HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], pieces));
 		if (ctx->ingest_verify_crc) { // (~1 ms per 256 MB piece; between the copies on one stream it cost 0.3 s of a 54 GB file)
-			KernelTimer timer(ctx, "bgzf_crc_kernel", raw_size, pieces);
-			bgzf_crc_kernel<<<n_blocks, 256, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+			KernelTimer timer(ctx, "bgzf_crc_kernel", deflated ? stream_bytes : raw_size, pieces);
+			if (deflated) bgzf_crc_kernel<true><<<n_blocks, 256, 0, pieces>>>(ctx->ingest_stream.as<uint8_t>() + piece_stream_offset, ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+			else bgzf_crc_kernel<false><<<n_blocks, 256, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
 		}
 		HIP_CHECK(hipEventRecord(ctx->piece_done[slot], pieces));
 	} else { HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], s)); HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], s)); }

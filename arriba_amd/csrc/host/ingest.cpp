@@ -1400,7 +1400,7 @@ public:
 				if (consumed_raw_ + at == tail_block_raw_) hi = std::max<size_t>(lo, std::min<size_t>(tail_keep_, payload));
 				if (hi > lo) {
 					agpu_bgzf_block& b = blocks[count++];
-					b.raw_offset = at; b.payload_offset = (uint32_t) (data_offset + 5 + lo); b.payload_size = (uint32_t) (hi - lo); b.stream_offset = out; b.crc32 = (lo == 0 && hi == payload) ? le32(buffer + at + size - 8) : 0; b.reserved = 0;
+					b.raw_offset = at; b.payload_offset = (uint32_t) (data_offset + 5 + lo); b.payload_size = (uint32_t) (hi - lo); b.stream_offset = out; b.crc32 = (lo == 0 && hi == payload) ? le32(buffer + at + size - 8) : 0; b.isize = 0; b.skip = 0; b.keep = 0;
 				}
 				at += size; out += hi - lo;
 			}
@@ -1411,7 +1411,39 @@ public:
 			piece.stored_bgzf = 1; piece.bytes = at; piece.stream_bytes = out; piece.n_blocks = count;
 			return at > 0 || deflated_ahead || !pending_.empty();
 		}
-		// BGZF_DEFLATED: raw bytes into an internal buffer, the blocks inflated by all threads into the caller's buffer
+		// BGZF_DEFLATED: the blocks go to the device as they are, with their table (piece.stored_bgzf = 2): bgzf_inflate_kernel makes the stream in HBM, a quarter of the bytes
+		// cross the link.  ARRIBA_HOST_INFLATE=1: inflated here by all threads instead (the way of rounds 2-3, kept for measurements and as the second implementation in the tests)
+		static const bool host_inflate = getenv("ARRIBA_HOST_INFLATE") != NULL && getenv("ARRIBA_HOST_INFLATE")[0] == '1';
+		if (!host_inflate) {
+			size_t n = take_pending(buffer, capacity);
+			if (n < capacity && !end_) { const size_t got = file_.read(buffer + n, capacity - n); if (got == 0) end_ = true; n += got; }
+			if (n == 0) return false;
+			size_t at = 0, out = 0; uint32_t count = 0;
+			const size_t out_limit = (size_t) 3 << 30; // (of one piece: the stream grows by that much at once)
+			while (n - at >= 18) {
+				const size_t size = BgzfSource::block_size(buffer + at, n - at);
+				if (size == 0 || size < 26) throw std::runtime_error("failed to load alignments");
+				if (n - at < size) break;
+				if (count == block_capacity) break;
+				const size_t data_offset = 12 + (buffer[at + 10] | (size_t) buffer[at + 11] << 8), out_size = le32(buffer + at + size - 4);
+				if (size < data_offset + 8 || out_size > 65536) throw std::runtime_error("failed to load alignments");
+				if (out + out_size > out_limit) break;
+				size_t lo = 0, hi = out_size; // (the first and the last block of a part of the file give only the records of the part)
+				if (consumed_raw_ + at == head_block_raw_) lo = std::min<size_t>(head_skip_, out_size);
+				if (consumed_raw_ + at == tail_block_raw_) hi = std::max<size_t>(lo, std::min<size_t>(tail_keep_, out_size));
+				if (hi > lo) {
+					agpu_bgzf_block& b = blocks[count++];
+					b.raw_offset = at; b.payload_offset = (uint32_t) data_offset; b.payload_size = (uint32_t) (size - data_offset - 8); b.stream_offset = out; b.crc32 = (lo == 0 && hi == out_size) ? le32(buffer + at + size - 8) : 0;
+					b.isize = (uint32_t) out_size; b.skip = (uint32_t) lo; b.keep = (uint32_t) (hi - lo);
+				}
+				at += size; out += hi - lo;
+			}
+			if (at == 0 && end_) throw std::runtime_error("failed to load alignments"); // a truncated block at the end of the file
+			pending_.assign(buffer + at, buffer + n);
+			consumed_raw_ += at;
+			piece.stored_bgzf = 2; piece.bytes = at; piece.stream_bytes = out; piece.n_blocks = count;
+			return at > 0 || !pending_.empty();
+		}
 		raw_.resize(std::max<size_t>(capacity / 3, 4u << 20));
 		size_t n = take_pending(raw_.data(), raw_.size());
 		if (n < raw_.size() && !end_) { const size_t got = file_.read(&raw_[n], raw_.size() - n); if (got == 0) end_ = true; n += got; }

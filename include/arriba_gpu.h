@@ -205,7 +205,11 @@ typedef struct {
 	uint8_t part_of_sample;                 /* the stream holds a part of the sample's records, other contexts hold the rest: agpu_shard_export / agpu_shard_merge follow */
 	uint8_t host_buffers;                   /* buffers the caller pushes from in turn: 0 or 2 = two (see above) */
 } agpu_ingest_config;
-typedef struct { uint64_t raw_offset; uint32_t payload_offset, payload_size; uint64_t stream_offset; uint32_t crc32; uint32_t reserved; } agpu_bgzf_block; /* offsets inside the pushed piece / the piece's part of the stream */
+/* A BGZF block of a pushed piece (offsets inside the piece / inside the piece's part of the stream).  isize == 0: a stored block -- payload_offset / payload_size are its data
+ * as they are (already cut to the records of a part of the file where the block is the first or last of a part), crc32 the CRC-32 of the whole data, 0 = not to be checked.
+ * isize != 0: a deflated block -- payload_offset / payload_size are its DEFLATE stream, isize what it inflates to (the ISIZE of the gzip trailer), and of that the bytes
+ * [skip, skip + keep) go to the stream (keep == isize but for the first / last block of a part of the file); crc32 as above.  All blocks of a piece are of one kind. */
+typedef struct { uint64_t raw_offset; uint32_t payload_offset, payload_size; uint64_t stream_offset; uint32_t crc32; uint32_t isize; uint32_t skip; uint32_t keep; } agpu_bgzf_block;
 typedef struct {
 	uint64_t records;                /* alignment records in the stream */
 	uint64_t fragments;              /* chimeric fragments in the batch (chimeric_alignments.size()) */
