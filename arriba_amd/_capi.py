@@ -329,6 +329,8 @@ def workflow_library():
         lib.arriba_workflow_sample.argtypes = [c_void_p, c_char_p, c_char_p, c_char_p, POINTER(WorkflowReport), POINTER(WorkflowTiming)]; lib.arriba_workflow_sample.restype = c_int
         lib.arriba_workflow_submit.argtypes = [c_void_p, c_char_p]; lib.arriba_workflow_submit.restype = c_int
         lib.arriba_workflow_cancel.argtypes = [c_void_p]; lib.arriba_workflow_cancel.restype = c_int
+        lib.arriba_workflow_defer_output.argtypes = [c_void_p, c_int]; lib.arriba_workflow_defer_output.restype = c_int
+        lib.arriba_workflow_flush.argtypes = [c_void_p, POINTER(ctypes.c_double)]; lib.arriba_workflow_flush.restype = c_int
         lib.arriba_workflow_device.argtypes = [c_void_p]; lib.arriba_workflow_device.restype = c_void_p
         lib.arriba_workflow_lane_device.argtypes = [c_void_p, c_int]; lib.arriba_workflow_lane_device.restype = c_void_p
         lib.arriba_workflow_host.argtypes = [c_void_p]; lib.arriba_workflow_host.restype = c_void_p

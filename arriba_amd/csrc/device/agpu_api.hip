@@ -622,7 +622,14 @@ static agpu_ctx* create_context(int device, const agpu_params* params, std::shar
 	agpu_ctx* ctx = new agpu_ctx(pool);
 	ctx->device = device;
 	if (params) ctx->params = *params; else agpu_default_params(&ctx->params);
-	if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->event_start) != hipSuccess || hipEventCreate(&ctx->event_stop) != hipSuccess) {
+	// The stream of the stages gets the highest priority, the pieces of a file (unwrap / inflate, CRC) the middle one, the windows of the ingest the lowest: in a session with
+	// two lanes the stages of one sample run beside the feed of the next, and it is the stages the caller waits for (with the pieces in front, as round 3 had them, a 10^8-fragment
+	// step spent 1.33 s in its stages instead of 0.77: profiles/r04c_bench100m.json).  ARRIBA_STREAM_PRIORITIES=pieces: the pieces in front, for measurements.
+	int least_priority = 0, greatest_priority = 0;
+	(void) hipDeviceGetStreamPriorityRange(&least_priority, &greatest_priority);
+	const char* priorities = getenv("ARRIBA_STREAM_PRIORITIES");
+	const bool pieces_first = priorities != nullptr && strcmp(priorities, "pieces") == 0;
+	if (hipStreamCreateWithPriority(&ctx->stream, hipStreamDefault, pieces_first ? (least_priority + greatest_priority) / 2 : greatest_priority) != hipSuccess || hipEventCreate(&ctx->event_start) != hipSuccess || hipEventCreate(&ctx->event_stop) != hipSuccess) {
 		set_last_error("failed to create HIP stream/events"); delete ctx; return nullptr;
 	}
 	if (!ctx->counters.allocate(COUNTER_COUNT * sizeof(uint32_t)) || !ctx->stage_counts.allocate(16 * sizeof(unsigned long long))) { set_last_error("hipMalloc failed"); delete ctx; return nullptr; }

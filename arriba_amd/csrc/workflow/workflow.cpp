@@ -54,6 +54,13 @@ struct Run {
 	bool bam_open = false; uint64_t coverage_windows = 0; uint32_t bam_contigs = 0; double feed_started = 0, feed_finished = 0, feed_reading = 0, feed_pushing = 0;
 	std::string bam_path, output_path, discarded_path; // of the sample this lane works on (options.* point at them)
 	std::function<void()> after_ingest; // a session with two lanes: the stream and the tables of the ingest are free for the feed of the next sample
+	// arriba_workflow_defer_output: the last file of a sample is formatted and written by a thread of its own once everything it needs has left the device, while the caller goes on
+	// with the next sample; what that thread reads stays with the lane until it is joined (the staged columns and rows, the gene table below)
+	bool defer_output = false;
+	std::function<void()> before_host_writer; // (the formatter threads of the host library serve one writer at a time: the writer of the other lane is waited for)
+	std::thread writer; std::string writer_error; double writer_seconds = 0;
+	std::vector<uint16_t> writer_gene_contig; std::vector<int32_t> writer_gene_start, writer_gene_end;
+	void join_writer() { if (writer.joinable()) writer.join(); }
 	bool tags_loaded = false, domains_loaded = false;
 	// Host memory for what comes back from the device per sample (candidate columns, rows of supporting reads): pinned, kept by the session and only ever grown -- fresh
 	// std::vectors of some hundred MB per sample are zeroed page by page and given back to the system again, which costs more than the transfer they hold.
@@ -78,6 +85,7 @@ struct Run {
 		for (size_t k = 0; k < sizeof(texts) / sizeof(texts[0]); ++k) if (*texts[k] != nullptr) { strings.push_back(*texts[k]); *texts[k] = strings.back().c_str(); }
 	}
 	~Run() {
+		join_writer();
 		for (int k = 0; k < FEED_BUFFERS; ++k) { if (pieces[k]) agpu_host_free(pieces[k]); if (tables[k]) agpu_host_free(tables[k]); }
 		for (std::map<std::string, Staged>::iterator buffer = staged.begin(); buffer != staged.end(); ++buffer) if (buffer->second.pointer) agpu_host_free(buffer->second.pointer);
 		if (device) agpu_destroy(device); if (host) ahost_close(host);
@@ -231,6 +239,7 @@ void finish_device_ingest(Run& run, double waited_since) {
 	host_check(ahost_adopt_device_ingest(run.host, &result, viral.data(), coverage.data(), starts.data(), ends.data()));
 	run.n_fragments = result.fragments;
 	run.note("bam_records", result.records); // (for the report only: no line of the reference's log)
+	run.note("bam_stream_bytes", result.stream_bytes);
 	if (run.timing) { run.timing->feed = fed - waited_since; run.timing->ingest = finished - fed; run.timing->adopt = now_seconds() - finished; }
 }
 
@@ -289,8 +298,8 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 	device_check(agpu_assign_confidence(run.device, nullptr)); // behind the 'isoforms' filter: recovered isoforms are scored anew
 	device_check(agpu_candidate_iteration_order(run.device, nullptr));
 	const uint32_t n_genes = ahost_annotation_view(run.host)->n_genes + run.dummy_genes;
-	std::vector<uint16_t> gene_contig(n_genes > 0 ? n_genes : 1);
-	std::vector<int32_t> gene_start(gene_contig.size()), gene_end(gene_contig.size());
+	std::vector<uint16_t>& gene_contig = run.writer_gene_contig; std::vector<int32_t>& gene_start = run.writer_gene_start; std::vector<int32_t>& gene_end = run.writer_gene_end;
+	gene_contig.assign(n_genes > 0 ? n_genes : 1, 0); gene_start.assign(gene_contig.size(), 0); gene_end.assign(gene_contig.size(), 0);
 	device_check(agpu_get_gene_table(run.device, 0, n_genes, gene_contig.data(), gene_start.data(), gene_end.data(), nullptr, nullptr));
 	if (run.options.tags_file && !run.tags_loaded) { run.say(std::string("Loading tags from '") + run.options.tags_file + "'"); host_check(ahost_load_tags(run.host, run.options.tags_file)); run.tags_loaded = true; } // (once per session)
 	if (run.options.protein_domains_file && !run.domains_loaded) { run.say(std::string("Loading protein domains from '") + run.options.protein_domains_file + "'"); host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file)); run.domains_loaded = true; }
@@ -331,6 +340,21 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 		lap(&arriba_workflow_timing::output_results);
 		if (rows_from_device) fetch_rows_for_writer(run, table, write_discarded, write_discarded == 0);
 		lap(&arriba_workflow_timing::output_rows);
+		if (run.before_host_writer) run.before_host_writer();
+		const bool last_file = write_discarded == (run.options.discarded_output_file ? 1 : 0);
+		if (run.defer_output && last_file) { // nothing of this file is on the device any more: formatted and written beside the next sample
+			const std::string path = write_discarded ? run.options.discarded_output_file : run.options.output_file;
+			ahost_session* host = run.host; const unsigned int max_itd_length = run.options.device.max_itd_length; const int fill_gaps = run.options.fill_sequence_gaps;
+			run.writer_error.clear();
+			Run* lane = &run;
+			run.writer = std::thread([lane, host, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps] {
+				const double started = now_seconds();
+				if (ahost_write_fusions(host, &table, path.c_str(), write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps) != 0) lane->writer_error = std::string("ERROR: ") + ahost_last_error();
+				lane->writer_seconds = now_seconds() - started;
+			});
+			lap(&arriba_workflow_timing::output_format);
+			continue;
+		}
 		host_check(ahost_write_fusions(run.host, &table, write_discarded ? run.options.discarded_output_file : run.options.output_file, write_discarded, print_extra_info, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
 		lap(&arriba_workflow_timing::output_format);
 	}
@@ -547,6 +571,16 @@ struct arriba_workflow_session {
 	std::deque<std::unique_ptr<Submitted>> queue; // oldest first; at most two
 	std::mutex mutex; std::condition_variable changed;
 	bool ingest_busy = false; // a lane is between agpu_ingest_begin and agpu_ingest_finish
+	bool defer_output = false;
+	std::string deferred_error; // of a writer that was joined on the way (reported by the next arriba_workflow_sample / arriba_workflow_flush)
+	double deferred_seconds = 0; // the writer joined last
+	void join_writer_of(int lane) {
+		if (lanes[lane] == nullptr || !lanes[lane]->writer.joinable()) return;
+		lanes[lane]->writer.join();
+		deferred_seconds = lanes[lane]->writer_seconds;
+		if (!lanes[lane]->writer_error.empty() && deferred_error.empty()) deferred_error = lanes[lane]->writer_error;
+		lanes[lane]->writer_error.clear();
+	}
 	arriba_workflow_session(const arriba_workflow_options& o) { lanes[0] = new Run(o); lanes[1] = nullptr; }
 	~arriba_workflow_session() {
 		drain();
@@ -586,6 +620,7 @@ struct arriba_workflow_session {
 			second->options.log_to_stdout = lanes[0]->options.log_to_stdout;
 			lanes[1] = second.release();
 		}
+		join_writer_of(lane); // (the last file of the lane's sample before: its writer reads the host session the feed is about to use)
 		Run& run = *lanes[lane];
 		run.bam_path = bam; run.options.chimeric_bam_file = run.bam_path.c_str();
 		run.timing = nullptr; run.report = nullptr;
@@ -639,6 +674,10 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 		run.output_path = output_file; run.discarded_path = discarded_output_file ? discarded_output_file : "";
 		run.options.output_file = run.output_path.c_str(); run.options.discarded_output_file = discarded_output_file ? run.discarded_path.c_str() : nullptr;
 		run.report = report; run.timing = timing;
+		run.defer_output = session->defer_output;
+		const int other = 1 - sample.lane;
+		run.before_host_writer = [session, other] { session->join_writer_of(other); };
+		if (!session->deferred_error.empty()) { const std::string text = session->deferred_error; session->deferred_error.clear(); throw Failure{ text + " (writing the last file of an earlier sample)" }; }
 		if (sample.feeder.joinable()) sample.feeder.join(); // (the feed of this sample: under the stages of the sample before if it was submitted ahead)
 		struct Done { arriba_workflow_session& session; ~Done() { // on every way out: the ingest buffers are free for the next feed, the sample leaves the queue
 			arriba_workflow_session::Submitted& sample = *session.queue.front();
@@ -651,10 +690,22 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 	}
 	catch (const Failure& failure) { g_error = failure.text; status = -1; }
 	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); status = -1; }
-	if (lane) { lane->after_ingest = nullptr; lane->options.chimeric_bam_file = nullptr; lane->options.output_file = nullptr; lane->options.discarded_output_file = nullptr; lane->report = nullptr; lane->timing = nullptr; session->processed_lane = (int) (lane == session->lanes[1]); }
+	if (lane) { lane->after_ingest = nullptr; lane->before_host_writer = nullptr; lane->options.chimeric_bam_file = nullptr; lane->options.output_file = nullptr; lane->options.discarded_output_file = nullptr; lane->report = nullptr; lane->timing = nullptr; session->processed_lane = (int) (lane == session->lanes[1]); }
 	return status;
 }
 
+int arriba_workflow_defer_output(arriba_workflow_session* session, int on) {
+	if (!session) { g_error = "ERROR: null argument"; return -1; }
+	session->defer_output = on != 0;
+	return 0;
+}
+int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_last_writer) {
+	if (!session) { g_error = "ERROR: null argument"; return -1; }
+	session->join_writer_of(0); session->join_writer_of(1);
+	if (seconds_of_last_writer) *seconds_of_last_writer = session->deferred_seconds;
+	if (!session->deferred_error.empty()) { g_error = session->deferred_error; session->deferred_error.clear(); return -1; }
+	return 0;
+}
 int arriba_workflow_cancel(arriba_workflow_session* session) {
 	if (!session) { g_error = "ERROR: null argument"; return -1; }
 	session->drain();

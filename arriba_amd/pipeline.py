@@ -160,6 +160,17 @@ class WorkflowSession(object):
         if self._profiling_on:
             self.set_profiling(True, only_new_lanes=True)
 
+    def defer_output(self, on=True):
+        """the last output file of a sample is written by a thread of the session while the next sample is worked on (complete behind flush())"""
+        self._lib.arriba_workflow_defer_output(self._session, int(on))
+
+    def flush(self):
+        """waits for the deferred writers; returns the seconds the last one took"""
+        seconds = ctypes.c_double()
+        if self._lib.arriba_workflow_flush(self._session, byref(seconds)) != 0:
+            raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        return seconds.value
+
     def cancel(self):
         """throws away what was submitted and not worked on"""
         self._lib.arriba_workflow_cancel(self._session)

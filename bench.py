@@ -173,6 +173,36 @@ def normal_pairs_leg(pipeline, directory, fragments=10000000, steps=2):
             "seconds_per_step": round(sum(seconds[1:]) / steps, 4), "steps": steps, "last_step": {key: round(value, 4) for key, value in timing.items()}, "generate_seconds": round(generated, 1)}
 
 
+def deflated_leg(pipeline, directory, fragments, stress, stored_output, steps=2):
+    """the same sample as a BAM file with deflated BGZF blocks (zlib level 1: what STAR writes by default and what samtools writes -- the reference reads any BAM htslib opens,
+    source/read_chimeric_alignments.cpp:563-566): a quarter of the bytes cross PCIe, bgzf_inflate_kernel makes the record stream in HBM.  The same records: the same fusions.tsv."""
+    import hashlib
+    prefix = os.path.join(directory, "deflated")
+    started = time.time()
+    subprocess.run([__import__("datasets").GEN_SYNTH, "--out", prefix, "--threads", str(min(64, cpu_budget())), "--bam-only", "--bgzf-level", "1"] + workload_args(fragments, 1000, stress=stress), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    generated = time.time() - started
+    bam_bytes = os.path.getsize(prefix + ".bam")
+    output = prefix + ".fusions.tsv"
+    seconds = []
+    pipeline.submit(prefix + ".bam")
+    for _ in range(steps + 1):  # (the first one is warm-up; the samples in a queue, as in the timed steps)
+        pipeline.submit(prefix + ".bam")
+        started = time.perf_counter()
+        pipeline.sample(prefix + ".bam", output)
+        seconds.append(time.perf_counter() - started)
+    pipeline.cancel()
+    pipeline.flush()
+    timing = pipeline.timing
+    counts = dict(pipeline.report)
+    digest = lambda path: hashlib.sha256(open(path, "rb").read()).hexdigest()
+    same = digest(output) == digest(stored_output)
+    os.remove(prefix + ".bam")
+    per_step = sum(seconds[1:]) / steps
+    return {"what": "the same %d fragments as a BAM file with deflated BGZF blocks (zlib level 1, %.1f GB: %.2f x smaller), inflated on the device (bgzf_inflate_kernel)" % (counts.get("read_chimeric_alignments", 0), bam_bytes / 1e9, counts.get("bam_stream_bytes", 0) / max(bam_bytes, 1)),
+            "chimeric_reads_per_s": counts.get("read_chimeric_alignments", 0) / per_step, "seconds_per_step": round(per_step, 4), "steps": steps, "bam_GB": round(bam_bytes / 1e9, 2),
+            "last_step": {key: round(value, 4) for key, value in timing.items()}, "fusions_tsv_equals_the_stored_sample's": same, "generate_seconds": round(generated, 1)}
+
+
 def host_only(args):
     """the host side alone (no GPU): rates of the file side of the device ingest and of the classic host ingest; a smoke test for changes under csrc/host/"""
     import ctypes
@@ -238,7 +268,9 @@ def main():
     parser.add_argument("--host-ingest", action="store_true", help="read_chimeric_alignments by the multi-threaded host ingest instead of on the device (round 1's path)")
     parser.add_argument("--python-stages", action="store_true", help="time the ctypes mirror of the stage order (arriba_amd/pipeline.py) instead of arriba_workflow_sample of the product library")
     parser.add_argument("--no-pipeline", action="store_true", help="one sample at a time: without it the file of the next sample is fed (arriba_workflow_submit) while the stages of the current one run")
+    parser.add_argument("--no-deferred-output", action="store_true", help="with the samples in a queue: fusions.tsv of a sample is written before arriba_workflow_sample returns (without it: by a thread of the session, beside the next sample)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-deflated-leg", action="store_true", help="skip the secondary measurement on the same sample with deflated BGZF blocks (value_deflated: inflated on the device)")
     parser.add_argument("--no-normal-pairs", action="store_true", help="skip the secondary measurement on the 10 M sample with 4 N ordinary proper pairs (value_with_normal_pairs)")
     parser.add_argument("--host-only", action="store_true")
     parser.add_argument("--keep", help="keep the sample and the output files in this directory")
@@ -309,7 +341,7 @@ def main():
             # with the reason -- a bench without a line is worth nothing
             command = [sys.executable, os.path.abspath(__file__), "--fragments", str(args.fragments), "--steps", str(args.steps), "--warmup", str(args.warmup)]
             command += (["--subsampling-threshold", str(args.subsampling_threshold)] if args.subsampling_threshold is not None else [])
-            command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--python-stages", args.python_stages), ("--no-cpu-baseline", args.no_cpu_baseline), ("--no-normal-pairs", args.no_normal_pairs)) if on]
+            command += [flag for flag, on in (("--stress", args.stress), ("--discarded", args.discarded), ("--host-ingest", args.host_ingest), ("--python-stages", args.python_stages), ("--no-cpu-baseline", args.no_cpu_baseline), ("--no-normal-pairs", args.no_normal_pairs), ("--no-deflated-leg", args.no_deflated_leg), ("--no-pipeline", args.no_pipeline), ("--no-deferred-output", args.no_deferred_output)) if on]
             # the driver gives a bench run 1800 s; the large sample gets what is left of ~1500 s after a reserve for the line of config 2 (generation, 25 steps of ~1 s, the
             # reference on its bounded sample: ~150 s), and its child decides after every step whether the steps asked for still fit (ARRIBA_BENCH_DEADLINE)
             total_limit = float(os.environ.get("ARRIBA_BENCH_TOTAL_LIMIT", "1500"))
@@ -375,6 +407,7 @@ def main():
             if through_workflow_library:
                 if pipelined:  # a resident service with a queue of samples: the next one is submitted before this one is worked on
                     if not primed[0]:
+                        pipeline.defer_output(not args.no_deferred_output)
                         pipeline.submit(prefix + ".bam")
                         primed[0] = True
                     pipeline.submit(prefix + ".bam")
@@ -460,6 +493,7 @@ def main():
             step()
             if pipeline is not None and not pipeline._profiling_on:
                 pipeline.set_profiling(True)
+        deferred_writer_seconds = pipeline.flush() if pipelined else None  # (inside the timed region: the file of the last step is complete before the clock stops)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -468,6 +502,7 @@ def main():
         sample_alone = None
         if pipelined:  # the sample submitted behind the last timed step is thrown away; then one sample alone, for the time from its file to its fusions.tsv when nothing overlaps it
             pipeline.cancel()
+            pipeline.defer_output(False)
             primed[0], pipelined = False, False
             alone_started = time.perf_counter()
             pipeline.sample(prefix + ".bam", outputs[0], outputs[1])
@@ -546,7 +581,7 @@ def main():
                                           " + discarded.tsv" if args.discarded else ""),
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
-                           "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor" if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
+                           "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor; fusions.tsv of a sample is formatted and written by a thread of the session beside the next sample (arriba_workflow_defer_output), the last one complete before the clock stops (arriba_workflow_flush)" if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
                            "parallelism": ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
                                            % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0))) if one_sample
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
@@ -557,7 +592,7 @@ def main():
                                          **({key: round(mean(key), 4) for key in ("stages", "filter_mismappers", "output")} if through_workflow_library else {})),
                 "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
                 "output_side_seconds": getattr(pipeline, "writer_seconds", None),
-                "samples_pipelined": bool(pipelined), "one_sample_alone": sample_alone,
+                "samples_pipelined": bool(pipelined), "output_deferred": bool(pipelined and not args.no_deferred_output), "deferred_writer_seconds": deferred_writer_seconds, "one_sample_alone": sample_alone,
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
                 "stages": stage_log,
                 # per step: the sum over the launches of one step (the front of the ingest runs window by window: ~200 launches of its kernels in a step of 10^8 fragments)
@@ -580,6 +615,11 @@ def main():
                                                 "chimeric_reads_per_s": n / (resident_ms * 1e-3) if resident_ms > 0 else None}
             line["self_check"] = "every alignment has a gene; fusions.tsv holds the fusions the last stage counted" + ("; " + reference_check if reference_check else "")
             progress("self-check done, kernel profile read")
+            if through_workflow_library and not distributed and not args.no_deflated_leg:
+                progress("the same sample with deflated BGZF blocks")
+                line["value_deflated"] = deflated_leg(pipeline, directory, args.fragments, args.stress, outputs[0])
+                if not line["value_deflated"]["fusions_tsv_equals_the_stored_sample's"]:
+                    raise SystemExit("bench self-check failed: the deflated sample gives another fusions.tsv than the stored one")
             if through_workflow_library and not distributed and not args.stress and not args.no_normal_pairs:
                 progress("the sample with 4 N ordinary proper pairs")
                 line["value_with_normal_pairs"] = normal_pairs_leg(pipeline, directory, fragments=min(10000000, args.fragments))

@@ -86,6 +86,11 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
  * ahead of the one at work.  arriba_workflow_sample(bam) with nothing submitted submits bam itself (the behaviour without this call).  A sample that was submitted and never
  * asked for is thrown away by arriba_workflow_close.  Returns 0, or a negative number with the text in arriba_workflow_last_error(). */
 int arriba_workflow_submit(arriba_workflow_session* session, const char* chimeric_bam_file);
+/* on: arriba_workflow_sample returns when the last output file of the sample (-O if given, else -o) has everything it needs off the device; the file is formatted and written
+ * by a thread of the session while the next sample is worked on.  It is complete when the next-but-one arriba_workflow_submit / _sample of the session has returned, or
+ * arriba_workflow_flush, or arriba_workflow_close; a failure to write it is reported by the next arriba_workflow_sample or by arriba_workflow_flush.  Off by default. */
+int arriba_workflow_defer_output(arriba_workflow_session* session, int on);
+int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_last_writer /* may be NULL */);
 int arriba_workflow_cancel(arriba_workflow_session* session); /* what was submitted and not yet worked on is thrown away (its feed is waited for first) */
 agpu_ctx* arriba_workflow_device(arriba_workflow_session* session);      /* the device context of the lane that worked on the last sample, e.g. for agpu_get_kernel_profile */
 agpu_ctx* arriba_workflow_lane_device(arriba_workflow_session* session, int lane); /* lane 0 or 1; NULL if the lane does not exist (yet) */

@@ -989,7 +989,7 @@ def check_samples_in_a_queue(mode, tmp_path):
     assert report["feed_overlapped"]
     assert report["alone1"] != report["alone2"]  # (two different samples)
     read = lambda name: open(str(out / name), "rb").read()
-    for queued, alone in (("queued1", "alone1"), ("queued2", "alone2"), ("queued3", "alone1"), ("queued4", "alone2")):
+    for queued, alone in (("queued1", "alone1"), ("queued2", "alone2"), ("queued3", "alone1"), ("queued4", "alone2"), ("deferred1", "alone1"), ("deferred2", "alone2"), ("deferred3", "alone1")):
         assert report[queued] == report[alone], queued
         assert read(queued + ".tsv") == read(alone + ".tsv") and read(queued + ".discarded.tsv") == read(alone + ".discarded.tsv"), queued
     assert len(read("alone1.tsv").splitlines()) > 5
@@ -997,3 +997,10 @@ def check_samples_in_a_queue(mode, tmp_path):
 
 def test_samples_in_a_queue_through_one_session(built, emu_api, tmp_path):
     check_samples_in_a_queue("harness", tmp_path)
+
+
+def test_inflate_core_against_zlib(built):
+    """the DEFLATE decoder of bgzf_inflate_kernel (inflate_core.hpp), stepped with one lane: 1120 blocks of seven kinds of data x sizes x levels x strategies equal zlib's bytes"""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "inflate_check"], check=True)
+    result = subprocess.run([os.path.join(ROOT, "tests", "emu", "inflate_check")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert result.returncode == 0 and "0 failures" in result.stdout, result.stdout[-2000:]

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 mode, fasta, gtf, bam1, bam2, out = sys.argv[1:7]
 if mode == "harness":
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libworkflow_on_harness.so"], check=True)
     os.environ["ARRIBA_WORKFLOW_LIBRARY"] = os.path.join(ROOT, "tests", "emu", "libworkflow_on_harness.so")
     from arriba_amd import _capi
     _bind = _capi.bind_device_api
@@ -48,6 +50,16 @@ except ArribaError as error:
 result["queued3"] = session.sample(bam1, path("queued3.tsv"), path("queued3.discarded.tsv"))
 session.cancel()  # bam2, fed and never asked for
 result["queued4"] = session.sample(bam2, path("queued4.tsv"), path("queued4.discarded.tsv"))  # (submits itself)
+# the last file of a sample written beside the next sample: complete behind flush()
+session.defer_output(True)
+session.submit(bam1)
+session.submit(bam2)
+result["deferred1"] = session.sample(bam1, path("deferred1.tsv"), path("deferred1.discarded.tsv"))
+session.submit(bam1)
+result["deferred2"] = session.sample(bam2, path("deferred2.tsv"), path("deferred2.discarded.tsv"))
+result["deferred3"] = session.sample(bam1, path("deferred3.tsv"), path("deferred3.discarded.tsv"))
+session.flush()
+session.defer_output(False)
 session.submit(bam1)  # left behind: arriba_workflow_close throws it away
 session.close()
 json.dump(result, open(path("result.json"), "w"))

@@ -1235,6 +1235,25 @@ static void append_stored_block(std::vector<uint8_t>& out, const uint8_t* data, 
 	out.insert(out.end(), trailer, trailer + 8);
 }
 
+// ... or with its payload deflated at `level` (what STAR writes by default, and samtools): one raw DEFLATE stream per block
+static void append_deflated_block(std::vector<uint8_t>& out, const uint8_t* data, size_t length, int level) {
+	z_stream z; memset(&z, 0, sizeof(z));
+	if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+	uint8_t packed[65536 + 1024];
+	z.next_in = (Bytef*) data; z.avail_in = (uInt) length; z.next_out = packed; z.avail_out = sizeof(packed);
+	if (deflate(&z, Z_FINISH) != Z_STREAM_END) { deflateEnd(&z); throw std::runtime_error("deflate failed"); }
+	const size_t size = z.total_out;
+	deflateEnd(&z);
+	uint8_t header[18] = { 31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 0, 0 };
+	const uint16_t bsize = (uint16_t) (18 + size + 8 - 1);
+	header[16] = bsize & 255; header[17] = bsize >> 8;
+	out.insert(out.end(), header, header + 18);
+	out.insert(out.end(), packed, packed + size);
+	const uint32_t crc = crc32(crc32(0L, Z_NULL, 0), data, length);
+	const uint8_t trailer[8] = { (uint8_t) (crc & 255), (uint8_t) (crc >> 8 & 255), (uint8_t) (crc >> 16 & 255), (uint8_t) (crc >> 24 & 255), (uint8_t) (length & 255), (uint8_t) (length >> 8 & 255), 0, 0 };
+	out.insert(out.end(), trailer, trailer + 8);
+}
+
 // The same kind of sample written by several threads (the bench's 10^7..10^8 fragments: one thread makes ~0.2 M fragments/s).  The fragments are cut into
 // segments of SEGMENT fragments; segment k draws from its own generator (seeded by read seed and k), numbers its names from k * SEGMENT * 8 and is encoded
 // -- and, for BGZF, cut into stored blocks -- on its own, so the file does not depend on the number of threads.  Not the byte stream of write_bam().
@@ -1249,7 +1268,8 @@ void Generator::write_bam_segmented(const std::string& path, unsigned int n_thre
 	auto wrap = [&](const std::vector<uint8_t>& raw, std::vector<uint8_t>& out) {
 		if (!bgzf) { out = raw; return; }
 		out.clear(); out.reserve(raw.size() + raw.size() / 2000 + 64);
-		for (size_t at = 0; at < raw.size(); at += BLOCK) append_stored_block(out, raw.data() + at, std::min(BLOCK, raw.size() - at));
+		const int level = config_.bgzf_level;
+		for (size_t at = 0; at < raw.size(); at += BLOCK) { if (level > 0) append_deflated_block(out, raw.data() + at, std::min(BLOCK, raw.size() - at), level); else append_stored_block(out, raw.data() + at, std::min(BLOCK, raw.size() - at)); }
 	};
 	{
 		BamEncoder encoder;
@@ -1399,6 +1419,7 @@ int main(int argc, char** argv) {
 		else if (a == "--single-end") config.single_end = true;
 		else if (a == "--soft-clip-supplementary") config.soft_clip_supplementary = true;
 		else if (a == "--n-bases") config.frac_n_bases = atof(value());
+		else if (a == "--bgzf-level") config.bgzf_level = atoi(value());
 		else if (a == "--shuffle") config.shuffle_names = true;
 		else if (a == "--separate-mates") config.separate_mates = true;
 		else if (a == "--stranded") config.stranded = true;
