@@ -206,7 +206,7 @@ struct agpu_ctx {
 
 	// k-mer index + splice sites (filter_mismappers)
 	agpu::DeviceBuffer kmer_contig_table, kmer_offsets, kmer_positions, splice_offset, splice_sites, splice_bits;
-	uint32_t kmer_positions_count = 0, splice_sites_for_dummy = 0, mismapper_jobs = 0, mismapper_heavy = 0;
+	uint32_t kmer_positions_count = 0, splice_sites_for_dummy = 0, mismapper_jobs = 0, mismapper_heavy = 0, mismapper_leftover = 0;
 	bool kmer_index_done = false, have_splice_sites = false, mismapper_jobs_ready = false;
 	agpu::CandidateTable candidates;
 	uint32_t n_emissions = 0, n_candidates = 0, n_queued_buckets = 0, n_discordant_emissions = 0; uint64_t n_list_entries = 0;

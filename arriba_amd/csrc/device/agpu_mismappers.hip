@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, 5) mismapper_verdict_kernel(Batch
 const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 41 GB for 5120 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
                                         // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
 const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch bounds below)
-template <int WAVES_PER_SIMD> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
-                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters) {
+// SWEEP_ONLY: the searches go through the sweep or are given up -- no recursion, no stack of frames in the kernel; the reads of the searches given up are appended to `leftover`
+// (counters[5]) and done by the instantiation that holds everything.  queue: the index of the queue's counter (the second launch has a queue of its own).
+template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
+                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters, uint32_t* leftover, int queue) {
 	__shared__ uint8_t segment_bases[304];
 	__shared__ AlignSweep sweep;
 	__shared__ AlignMemo memo;
@@ -200,21 +202,23 @@ template <int WAVES_PER_SIMD> __global__ void __launch_bounds__(64, WAVES_PER_SI
 		worklist.relevant_words = task_lists != nullptr ? task_lists + ((size_t) gridDim.x + blockIdx.x) * task_capacity * 2 : nullptr; worklist.relevant_capacity = task_capacity; // (the second half of the buffer: the calls of a block beyond those kept in LDS)
 	}
 	__syncthreads();
-	AlignFrame stack[ALIGN_MAX_DEPTH];
-	AlignRunner runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = nullptr; runner.max_depth = ALIGN_MAX_DEPTH;
+	__shared__ int64_t given_up; // (SWEEP_ONLY: < 0 when a search of the read was not one for the sweep)
+	AlignFrame stack[SWEEP_ONLY ? 1 : ALIGN_MAX_DEPTH];
+	AlignRunnerT<SWEEP_ONLY> runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = SWEEP_ONLY ? &given_up : nullptr; runner.max_depth = SWEEP_ONLY ? 1 : ALIGN_MAX_DEPTH;
 	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position (when the task list is off or overflows)
 	runner.memo = &memo;
 	runner.worklist = task_lists != nullptr ? &worklist : nullptr; // the search as rounds of up to 64 tasks (mismapper_core.hpp: AlignWorklist)
 	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
 	while (true) {
 		__syncthreads(); // (every lane has read next_job of the previous round)
-		if (threadIdx.x == 0) next_job = atomicAdd(&counters[4], 1u);
+		if (threadIdx.x == 0) { next_job = atomicAdd(&counters[queue], 1u); given_up = 0; }
 		__syncthreads();
 		if (next_job >= n_heavy) break;
 		const uint32_t read = heavy[next_job];
 		const unsigned long long started = read_times != nullptr ? wall_clock64() : 0ull;
 		if (read_times != nullptr && threadIdx.x == 0) for (int k = 0; k < 8; ++k) study[k] = 0;
 		const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
+		if (SWEEP_ONLY && runner.exhausted()) { if (threadIdx.x == 0) leftover[atomicAdd(&counters[5], 1u)] = read; continue; } // (the same for every lane: written behind a barrier)
 		if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
 		if (read_times != nullptr && threadIdx.x == 0) { // (ARRIBA_MISMAPPER_TIMES=1: ticks of the 100 MHz clock per read, and what the search of the read consisted of)
 			read_times[4 * (size_t) next_job] = wall_clock64() - started; read_times[4 * (size_t) next_job + 1] = (unsigned long long) study[0] << 32 | study[1]; read_times[4 * (size_t) next_job + 2] = (unsigned long long) study[2] << 32 | study[3];
@@ -470,15 +474,38 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const bool want_times = getenv("ARRIBA_MISMAPPER_TIMES") != nullptr; // a study: how long the wavefronts worked on every read of the second pass, on stderr
 				DeviceBuffer& read_times = ctx->scratch("mismappers.read_times");
 				if (want_times) { ALLOC(read_times, (size_t) n_heavy * 32 + 32); HIP_CHECK(hipMemsetAsync(read_times.as<unsigned long long>() + 4 * (size_t) n_heavy, 0, 32, s)); }
-				{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-				  // (launch bounds: left alone the compiler takes 132 VGPRs, which fit 3 wavefronts per SIMD: 554 ms at 10^8 fragments; 4 per SIMD = 128 VGPRs, 3 spilled: 459 ms
-				  //  with 4096 workgroups; 5 = 96 VGPRs, 61 spilled: 416 ms with 5120 workgroups -- profiles/r03p, r03r.  ARRIBA_HEAVY_WAVES=4 with ARRIBA_HEAVY_WORKGROUPS=4096 for measurements)
-				  if (!(getenv("ARRIBA_HEAVY_WAVES") != nullptr && atoi(getenv("ARRIBA_HEAVY_WAVES")) == 4))
-				  mismapper_heavy_kernel<5><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
-				                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters);
-				  else
-				  mismapper_heavy_kernel<4><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
-				                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters); }
+				// The searches go through the sweep in a kernel that holds nothing else (SWEEP_ONLY: no recursion, no stack of frames: fewer registers, no scratch memory behind them);
+				// the few it gives up -- a gene of 2^24 bases and more, lists that ran over, ARRIBA_MISMAPPER_SWEEP=0 / ARRIBA_MISMAPPER_WORKLIST=0 -- are done by the kernel that holds
+				// everything, which is the only one with ARRIBA_MISMAPPER_KERNELS=one (the way of round 3, for measurements).
+				// (launch bounds of the full kernel: left alone the compiler takes 132 VGPRs, which fit 3 wavefronts per SIMD: 554 ms at 10^8 fragments; 4 per SIMD = 128 VGPRs, 3 spilled:
+				//  459 ms with 4096 workgroups; 5 = 96 VGPRs, 61 spilled: 416 ms with 5120 workgroups -- profiles/r03p, r03r.  ARRIBA_HEAVY_WAVES=4 with ARRIBA_HEAVY_WORKGROUPS=4096 for measurements)
+				knob = getenv("ARRIBA_MISMAPPER_KERNELS");
+				const bool sweep_kernel_first = by_sweep && use_worklist && !want_times && !(knob != nullptr && strcmp(knob, "one") == 0);
+				const bool four_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr && atoi(getenv("ARRIBA_HEAVY_WAVES")) == 4;
+				DeviceBuffer& leftover = ctx->scratch("mismappers.leftover");
+				ALLOC(leftover, (size_t) n_heavy * 4);
+				HIP_CHECK(hipMemsetAsync(device_counters + 5, 0, 8, s)); // [5] reads the sweep-only kernel gave up, [6] the queue of the kernel that does them
+				const uint32_t* todo = heavy.as<uint32_t>(); uint32_t n_todo = n_heavy;
+				if (sweep_kernel_first) {
+					{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
+					  if (!four_waves) mismapper_heavy_kernel<5, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
+					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4);
+					  else mismapper_heavy_kernel<4, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
+					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4); }
+					HIP_CHECK(hipMemcpyAsync(&n_todo, device_counters + 5, 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(hipStreamSynchronize(s));
+					todo = leftover.as<uint32_t>();
+					ctx->mismapper_leftover = n_todo;
+				}
+				if (n_todo > 0) {
+					const uint32_t groups = std::min<uint32_t>(n_todo, workgroups);
+					if (sweep_kernel_first) HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) groups * memo_slots * 8, s)); // (the epochs of the memo start again: nothing of the first kernel's searches may match)
+					KernelTimer timer(ctx, sweep_kernel_first ? "mismapper_heavy_kernel(searches the sweep gave up)" : "mismapper_heavy_kernel", (uint64_t) n_todo * 300);
+					if (!four_waves) mismapper_heavy_kernel<5, false><<<groups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, todo, n_todo, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
+					                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4);
+					else mismapper_heavy_kernel<4, false><<<groups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, todo, n_todo, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
+					                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4);
+				}
 				if (want_times) {
 					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy + 4);
 					HIP_CHECK(hipMemcpyAsync(ticks.data(), read_times.ptr, (size_t) n_heavy * 32 + 32, hipMemcpyDeviceToHost, s));

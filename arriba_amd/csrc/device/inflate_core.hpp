@@ -36,19 +36,23 @@ struct InflateShared { // the memory the lanes of one wavefront share (LDS on th
 	uint32_t event[8];     // what the decoding lane tells the others: kind, position, length, distance, error
 };
 
-// the bits of the stream, lowest first; the input is read in 8-byte words one word ahead of need (reads up to 16 bytes behind the end of the block: the caller's buffer is padded)
+// the bits of the stream, lowest first.  The input is read in 4-byte words, and always one word ahead of the one that is needed: the load of word k + 1 is issued when word k goes
+// into the buffer, so that its latency (a chain of dependent loads from HBM would cost ~1 us per word: 30 ms for a block of 16 KB, as the first version of this reader did byte by
+// byte) lies under the decoding of the 32 bits before it.  Reads up to 12 bytes behind the end of the block: the caller's buffer is padded.
 struct InflateBits {
 	const uint8_t* bytes; uint32_t size, at; // `at`: bytes consumed into `buffer`
 	unsigned long long buffer; uint32_t count;
-	AGPU_HD void start(const uint8_t* source, uint32_t n) { bytes = source; size = n; at = 0; buffer = 0; count = 0; }
-	AGPU_HD void refill() { // at least 32 bits afterwards (zeros behind the end of the input: a code that runs over it is caught by `overrun`)
-		while (count <= 56) { buffer |= (unsigned long long) (at < size ? bytes[at] : 0) << count; ++at; count += 8; }
+	uint32_t ahead; // the word at `at`, loaded already
+	AGPU_HD static uint32_t word_at(const uint8_t* source) { uint32_t word; __builtin_memcpy(&word, source, 4); return word; }
+	AGPU_HD void start(const uint8_t* source, uint32_t n) { bytes = source; size = n; at = 0; buffer = 0; count = 0; ahead = word_at(bytes); }
+	AGPU_HD void refill() { // at least 32 bits afterwards (what lies behind the end of the input is never decoded into output: a code that runs over it is caught by `overrun`)
+		if (count <= 32) { buffer |= (unsigned long long) ahead << count; count += 32; at += 4; ahead = word_at(bytes + at); }
 	}
 	AGPU_HD uint32_t peek(int n) const { return (uint32_t) (buffer & ((1ull << n) - 1ull)); }
 	AGPU_HD void drop(int n) { buffer >>= n; count -= n; }
 	AGPU_HD uint32_t take(int n) { const uint32_t value = peek(n); drop(n); return value; }
 	AGPU_HD void to_byte_boundary() { drop((int) (count & 7u)); }
-	AGPU_HD bool overrun() const { return at > size + 8 || (at > size && (at - size) * 8 > count); } // more bits were taken than the input holds
+	AGPU_HD bool overrun() const { return at > size && (at - size) * 8 > count; } // more bits were taken than the input holds
 };
 
 AGPU_HD uint32_t inflate_reverse_bits(uint32_t code, int length) { uint32_t reversed = 0; for (int k = 0; k < length; ++k) { reversed = reversed << 1 | (code & 1u); code >>= 1; } return reversed; }

@@ -509,7 +509,10 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 }
 
 // Who tries the read positions: one thread after the other on the host (lanes = 1), the 64 lanes of a wavefront on the device.
-struct AlignRunner {
+// SWEEP_ONLY: the wavefront-per-read kernel of the device is compiled twice -- once with nothing but the sweep (a search the sweep cannot hold -- a gene of 2^24 bases and more,
+// lists that run over -- is given up with *budget = -1 and the read left to the second instantiation), once with everything: the recursion and its stack of frames need
+// registers and scratch memory that the sweep does not, and the kernel that does almost all of the work should not carry them (agpu_mismappers.hip: mismapper_heavy_kernel).
+template <bool SWEEP_ONLY> struct AlignRunnerT {
 	AlignFrame* stack; uint32_t lane, lanes;
 	int64_t* budget = nullptr; // steps left for the whole verdict of one read (null: unlimited)
 	int max_depth = ALIGN_MAX_DEPTH; // frames `stack` holds
@@ -749,6 +752,16 @@ struct AlignRunner {
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
 		if (memo != nullptr) new_memo_epoch(); // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
+		if constexpr (SWEEP_ONLY) {
+			if (memo->usable(target.gene_start, target.gene_end, length) && (uint32_t) length <= ALIGN_SWEEP_SEGMENT) {
+				const bool found = align_by_sweep(read, target, min_score);
+				if (worklist->state[1] == 0) return found;
+			}
+			sync_lanes();
+			if (lane == 0) *budget = -1; // not a search for the sweep: the read is done again by the kernel that holds the recursion
+			sync_lanes();
+			return false;
+		}
 		if (worklist != nullptr && worklist->sweep != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end, length) && (uint32_t) length <= ALIGN_SWEEP_SEGMENT) {
 			const bool found = align_by_sweep(read, target, min_score);
 			if (worklist->state[1] == 0) return found;
@@ -816,11 +829,13 @@ struct AlignRunner {
 		return false;
 	}
 };
+typedef AlignRunnerT<false> AlignRunner;
+
 
 // reference: align_both_strands (source/filter_mismappers.cpp:201-245).  `segment` is the part of the read to re-align, read_length the
 // length of the whole read; the genes are those of the other end of the fragment.
-AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int32_t max_mate_gap, bool breakpoints_on_same_contig, int32_t alignment_start, int32_t alignment_end,
-                                const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, const IdSet& genes, float min_align_fraction, const AlignRunner& runner) {
+template <class Runner> AGPU_HD bool align_both_strands(const Segment& segment, int32_t read_length, int32_t max_mate_gap, bool breakpoints_on_same_contig, int32_t alignment_start, int32_t alignment_end,
+                                const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, const IdSet& genes, float min_align_fraction, const Runner& runner) {
 	if (segment.length >= 300) return false; // long reads are not re-aligned
 	const int32_t min_score = (int32_t) ((double) (min_align_fraction * (float) segment.length) + 0.5);
 	for (uint32_t g = 0; g < genes.n; ++g) {
@@ -878,7 +893,7 @@ AGPU_HD bool extend_split_read(const BatchView& b, const GenomeView& genome, uin
 
 // Does fragment i support its fusion only because it is mis-mapped?  reference: the per-read part of filter_mismappers
 // (source/filter_mismappers.cpp:283-332); a pure function of the fragment, its gene sets, max_mate_gap and the k-mer index.
-AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, uint64_t i, int32_t max_mate_gap, const AlignRunner& runner) {
+template <class Runner> AGPU_HD bool is_mismapper(const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const KmerIndexView& kmers, const SpliceSiteView& splice, uint64_t i, int32_t max_mate_gap, const Runner& runner) {
 	const float min_align_fraction = 0.8f, min_extended_align_fraction = 0.7f;
 	AGPU_IDSET(genes);
 	if (b.n_aln[i] == 3) {

@@ -21,6 +21,7 @@ namespace arriba {
 // cfs_quota_us) allow.  A host with 256 hardware threads behind a quota of 16 CPUs runs 128 busy threads for 12 ms of every 100 ms and stalls them for the rest
 // (profiles/r03g_probe.txt): every pool of worker threads of the host library sizes itself by this number.
 unsigned int cpu_budget();
+void limit_threads_of_this_thread(unsigned int n); // (0: no limit)
 
 typedef int32_t position_t;
 typedef uint16_t contig_t;

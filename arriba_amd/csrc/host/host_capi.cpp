@@ -217,6 +217,8 @@ template <class Visit> void visit_ingest(IngestResult& r, Visit& visit) { // the
 extern "C" {
 
 const char* ahost_last_error(void) { return g_error.c_str(); }
+unsigned int ahost_cpu_budget(void) { return cpu_budget(); }
+void ahost_limit_threads_of_this_thread(unsigned int n) { limit_threads_of_this_thread(n); }
 
 int ahost_load_genomic_breakpoints(ahost_session* session, const char* path, const agpu_genomic_breakpoint** variants, uint32_t* n_variants) {
 	if (!session || !path || !variants || !n_variants) { g_error = "null argument"; return -1; }

@@ -960,7 +960,13 @@ unsigned int ingest_threads() { // ARRIBA_INGEST_THREADS overrides; the reader i
 
 }
 
-unsigned int cpu_budget() {
+// ahost_limit_threads_of_this_thread: what a thread of a session that does two things at once (the feed of the next sample beside the stages of this one, the writer of the last
+// file beside both) may use of the budget -- every decision about a number of threads that is made on that thread sees the smaller budget
+static thread_local unsigned int g_thread_limit = 0;
+void limit_threads_of_this_thread(unsigned int n) { g_thread_limit = n; }
+static unsigned int whole_cpu_budget();
+unsigned int cpu_budget() { const unsigned int whole = whole_cpu_budget(); return g_thread_limit > 0 ? std::max(1u, std::min(whole, g_thread_limit)) : whole; }
+static unsigned int whole_cpu_budget() {
 	static const unsigned int budget = [] {
 		unsigned int cores = std::max(1u, std::thread::hardware_concurrency());
 		cpu_set_t set;

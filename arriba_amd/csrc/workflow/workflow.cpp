@@ -348,6 +348,8 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 			run.writer_error.clear();
 			Run* lane = &run;
 			run.writer = std::thread([lane, host, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps] {
+				const unsigned int budget = ahost_cpu_budget();
+				ahost_limit_threads_of_this_thread(std::max(2u, budget / 2 > 2 ? budget / 2 - 2 : 2u)); // (beside the feed of the next sample and the thread that runs its stages)
 				const double started = now_seconds();
 				if (ahost_write_fusions(host, &table, path.c_str(), write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps) != 0) lane->writer_error = std::string("ERROR: ") + ahost_last_error();
 				lane->writer_seconds = now_seconds() - started;
@@ -574,13 +576,16 @@ struct arriba_workflow_session {
 	bool defer_output = false;
 	std::string deferred_error; // of a writer that was joined on the way (reported by the next arriba_workflow_sample / arriba_workflow_flush)
 	double deferred_seconds = 0; // the writer joined last
+	std::mutex writer_mutex; // (a writer is joined by the thread that calls the session or by the feeder of the lane's next sample)
 	void join_writer_of(int lane) {
+		std::lock_guard<std::mutex> lock(writer_mutex);
 		if (lanes[lane] == nullptr || !lanes[lane]->writer.joinable()) return;
 		lanes[lane]->writer.join();
 		deferred_seconds = lanes[lane]->writer_seconds;
 		if (!lanes[lane]->writer_error.empty() && deferred_error.empty()) deferred_error = lanes[lane]->writer_error;
 		lanes[lane]->writer_error.clear();
 	}
+	std::string take_deferred_error() { std::lock_guard<std::mutex> lock(writer_mutex); std::string text; text.swap(deferred_error); return text; }
 	arriba_workflow_session(const arriba_workflow_options& o) { lanes[0] = new Run(o); lanes[1] = nullptr; }
 	~arriba_workflow_session() {
 		drain();
@@ -620,7 +625,6 @@ struct arriba_workflow_session {
 			second->options.log_to_stdout = lanes[0]->options.log_to_stdout;
 			lanes[1] = second.release();
 		}
-		join_writer_of(lane); // (the last file of the lane's sample before: its writer reads the host session the feed is about to use)
 		Run& run = *lanes[lane];
 		run.bam_path = bam; run.options.chimeric_bam_file = run.bam_path.c_str();
 		run.timing = nullptr; run.report = nullptr;
@@ -629,8 +633,11 @@ struct arriba_workflow_session {
 		sample->bam = bam; sample->lane = lane;
 		Submitted* mine = sample.get();
 		{ std::lock_guard<std::mutex> lock(mutex); queue.push_back(std::move(sample)); }
-		if (!run.device_ingest) { std::lock_guard<std::mutex> lock(mutex); mine->fed = true; return; } // (the host ingest reads the file inside arriba_workflow_sample)
-		mine->feeder = std::thread([this, mine, &run] {
+		if (!run.device_ingest) { join_writer_of(lane); std::lock_guard<std::mutex> lock(mutex); mine->fed = true; return; } // (the host ingest reads the file inside arriba_workflow_sample)
+		const bool ahead = queue.size() > 1; // fed beside the stages of the sample in front of it: the threads that read the file leave processors to the thread that runs those
+		mine->feeder = std::thread([this, mine, &run, lane, ahead] {
+			if (ahead) ahost_limit_threads_of_this_thread(std::max(2u, ahost_cpu_budget() / 2));
+			join_writer_of(lane); // (the last file of the lane's sample before: its writer reads the host session this feed is about to use)
 			{ std::unique_lock<std::mutex> lock(mutex); changed.wait(lock, [&] { return !ingest_busy && (queue.front().get() == mine || queue.front()->ingest_finished); }); ingest_busy = true; mine->started = true; }
 			try { feed_file(run); }
 			catch (const Failure& failure) { mine->error = failure.text; }
@@ -677,7 +684,7 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 		run.defer_output = session->defer_output;
 		const int other = 1 - sample.lane;
 		run.before_host_writer = [session, other] { session->join_writer_of(other); };
-		if (!session->deferred_error.empty()) { const std::string text = session->deferred_error; session->deferred_error.clear(); throw Failure{ text + " (writing the last file of an earlier sample)" }; }
+		{ const std::string text = session->take_deferred_error(); if (!text.empty()) throw Failure{ text + " (writing the last file of an earlier sample)" }; }
 		if (sample.feeder.joinable()) sample.feeder.join(); // (the feed of this sample: under the stages of the sample before if it was submitted ahead)
 		struct Done { arriba_workflow_session& session; ~Done() { // on every way out: the ingest buffers are free for the next feed, the sample leaves the queue
 			arriba_workflow_session::Submitted& sample = *session.queue.front();
@@ -703,7 +710,7 @@ int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_l
 	if (!session) { g_error = "ERROR: null argument"; return -1; }
 	session->join_writer_of(0); session->join_writer_of(1);
 	if (seconds_of_last_writer) *seconds_of_last_writer = session->deferred_seconds;
-	if (!session->deferred_error.empty()) { g_error = session->deferred_error; session->deferred_error.clear(); return -1; }
+	{ const std::string text = session->take_deferred_error(); if (!text.empty()) { g_error = text; return -1; } }
 	return 0;
 }
 int arriba_workflow_cancel(arriba_workflow_session* session) {

@@ -46,6 +46,11 @@ int ahost_load_ingest(ahost_session* session, const char* path);
  *   ahost_set_batch_rows   the rows of the batch the host itself works on (the output writer: names, CIGARs and sequences of the supporting reads), fetched
  *                      with agpu_gather_rows_*; fragment indices in an ahost_fusion_table then refer to these rows */
 typedef struct { int stored_bgzf; /* 0: the buffer holds bytes of the stream; 1: raw BGZF bytes whose blocks are stored, with their table; 2: raw BGZF bytes whose blocks are deflated, with their table (both: agpu_ingest_push_bgzf) */ size_t bytes; size_t stream_bytes; uint32_t n_blocks; } ahost_bam_piece;
+/* The processors this process may use at once (affinity, CPU quota of the cgroup), and a limit for every decision about a number of threads that is made on the calling thread
+ * from now on (0: none): a session that feeds the next sample beside the stages of the current one and writes the last file beside both gives each of the three its share --
+ * more busy threads than the quota has CPUs are all stopped together for the rest of the scheduler's period. */
+unsigned int ahost_cpu_budget(void);
+void ahost_limit_threads_of_this_thread(unsigned int n);
 int ahost_bam_open(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length, agpu_ingest_config* config);
 /* One sample over several GPUs: as ahost_bam_open, but the pieces that follow hold only part `part` of `parts` of the records -- the file (BGZF or
  * uncompressed BAM on disk; the alignments of a read name next to each other, as STAR writes them) is cut between read names near the byte offsets
