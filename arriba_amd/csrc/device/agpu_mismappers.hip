@@ -267,7 +267,7 @@ int build_splice_sites(agpu_ctx* ctx) {
 	HIP_CHECK(hipMemcpyAsync(&total, ctx->splice_offset.as<uint32_t>() + n_genes_total, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	ALLOC(ctx->splice_sites, (size_t) std::max<uint32_t>(total, 1) * 4);
-	const size_t bitmap_bytes = ((size_t) (ctx->host_contig_offset[ctx->genome.n_contigs] + 31) / 32 + 16) * 4; // (a walk looks up to a read length behind a position: room behind the last contig)
+	const size_t bitmap_bytes = ((size_t) (ctx->host_contig_offset[ctx->genome.n_contigs] + 31) / 32 + 16) * 4; // (a walk looks up to the length of its segment behind a position, and segments of 300 bases and more are not re-aligned at all -- align_both_strands, as the reference: 16 words = 512 bits of room behind the last contig)
 	ALLOC(ctx->splice_bits, bitmap_bytes);
 	HIP_CHECK(hipMemsetAsync(ctx->splice_bits.ptr, 0, bitmap_bytes, s));
 	splice_site_kernel<<<grid_for(n_genes_total), BLOCK, 0, s>>>(ctx->annotation, ctx->genome, n_genes_total, ctx->splice_offset.as<uint32_t>(), nullptr, ctx->splice_sites.as<int32_t>(), ctx->splice_bits.as<uint32_t>(), true);
@@ -459,16 +459,20 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const uint32_t wanted = knob != nullptr && atoi(knob) > 0 ? (uint32_t) atoi(knob) : HEAVY_WORKGROUPS;
 				knob = getenv("ARRIBA_MEMO_SLOTS_LOG2");
 				const uint32_t memo_slots = 1u << (knob != nullptr && atoi(knob) >= 10 && atoi(knob) <= 24 ? (uint32_t) atoi(knob) : MEMO_SLOTS_LOG2);
-				const uint32_t workgroups = std::min<uint32_t>(n_heavy, wanted);
+				uint32_t workgroups = std::min<uint32_t>(n_heavy, wanted);
 				DeviceBuffer& memo_tables = ctx->scratch("mismappers.memo_tables");
-				ALLOC(memo_tables, (size_t) workgroups * memo_slots * 8);
-				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));
-				// the task lists of the workgroups: 2^17 tasks of 16 bytes each (2 MB, and as much again for the calls of a block beyond the memory of the sweep: 21 GB for 5120 workgroups) (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
+				DeviceBuffer& task_lists = ctx->scratch("mismappers.task_lists");
+				const uint32_t task_capacity = 1u << 17;
 				knob = getenv("ARRIBA_MISMAPPER_WORKLIST");
 				const bool use_worklist = !(knob != nullptr && knob[0] == '0');
-				const uint32_t task_capacity = 1u << 17;
-				DeviceBuffer& task_lists = ctx->scratch("mismappers.task_lists");
-				if (use_worklist) ALLOC(task_lists, (size_t) workgroups * task_capacity * 16 * 2); // (the listed calls of every workgroup, then, behind all of them, the calls of a block beyond the memory of the sweep)
+				// 8 MB of memo and 4 MB of task lists per persistent workgroup: 62 GB for 5120 of them.  A device (or what other contexts have left of it) that does not hold them
+				// runs the search with fewer workgroups -- slower, the same verdicts -- instead of failing
+				while (!memo_tables.allocate((size_t) workgroups * memo_slots * 8) || (use_worklist && !task_lists.allocate((size_t) workgroups * task_capacity * 16 * 2))) {
+					if (workgroups <= 64) { set_last_error("hipMalloc failed (the memo tables and task lists of filter_mismappers)"); return AGPU_ERR_DEVICE; }
+					workgroups /= 2;
+				}
+				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));
+				// the task lists of the workgroups: 2^17 tasks of 16 bytes each (2 MB, and as much again for the calls of a block beyond the memory of the sweep: 21 GB for 5120 workgroups) (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
 				knob = getenv("ARRIBA_MISMAPPER_SWEEP"); // "0": the lanes take whole listed calls in rounds (the schedule of round 2), for A/B measurements
 				const bool by_sweep = !(knob != nullptr && knob[0] == '0');
 				const bool want_times = getenv("ARRIBA_MISMAPPER_TIMES") != nullptr; // a study: how long the wavefronts worked on every read of the second pass, on stderr

@@ -18,7 +18,7 @@
 
 namespace agpu {
 
-const uint32_t INFLATE_RING = 16384, INFLATE_FLUSH = 8192;
+const uint32_t INFLATE_RING = 16384, INFLATE_FLUSH = 8192, INFLATE_SHORT_MATCH = 24;
 const int INFLATE_LITLEN_BITS = 10, INFLATE_DISTANCE_BITS = 9;
 enum { INFLATE_OK = 0, INFLATE_BAD_BLOCK_TYPE = 1, INFLATE_BAD_STORED_LENGTH = 2, INFLATE_BAD_CODE_LENGTHS = 3, INFLATE_BAD_SYMBOL = 4, INFLATE_BAD_DISTANCE = 5, INFLATE_OUTPUT_OVERRUN = 6, INFLATE_INPUT_OVERRUN = 7,
        INFLATE_SIZE_MISMATCH = 8 };
@@ -209,6 +209,14 @@ template <class Sync, class Broadcast> AGPU_HD int inflate_block(const uint8_t* 
 				distance = distance_base[distance_symbol] + bits.take(distance_extra[distance_symbol]);
 				if (distance > produced) { kind = EVENT_ERROR; error = INFLATE_BAD_DISTANCE; break; }
 				if (produced + length > out_size) { kind = EVENT_ERROR; error = INFLATE_OUTPUT_OVERRUN; break; }
+				// a short match from inside the ring is copied by the decoding lane itself: most matches of a BAM block at the usual levels are a few bytes long, and handing every
+				// one of them to all lanes (three barriers and a broadcast) cost more than the copy (profiles/r04e_bench100m.json: 17 ms per block)
+				if (length <= INFLATE_SHORT_MATCH && distance + length <= INFLATE_RING / 2) {
+					for (uint32_t i = 0; i < length; ++i) shared.ring[(produced + i) & (INFLATE_RING - 1)] = shared.ring[(produced + i - distance) & (INFLATE_RING - 1)];
+					produced += length;
+					if (produced - flushed >= INFLATE_FLUSH) kind = EVENT_FLUSH;
+					continue;
+				}
 				kind = EVENT_MATCH;
 			}
 			shared.event[0] = kind; shared.event[1] = produced; shared.event[2] = length; shared.event[3] = distance; shared.event[4] = error;
