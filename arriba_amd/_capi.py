@@ -222,6 +222,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "gather_rows_begin": (c_int, [ctx, c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
         "gather_rows_copy": (c_int, [ctx, POINTER(BatchRows)]),
         "set_profiling": (c_int, [ctx, c_int]),
+        "debug_fail_allocation_in_finish": (None, [c_int]),
         "get_kernel_profile": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
         "last_kernel_ms": (c_int, [ctx, POINTER(c_float)]),
         "last_kernel_bytes": (c_int, [ctx, POINTER(c_uint64)]),

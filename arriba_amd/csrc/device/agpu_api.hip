@@ -27,6 +27,11 @@ using namespace agpu;
 namespace agpu {
 static thread_local std::string g_last_error, g_allocation_note;
 void set_last_error(const std::string& message) { g_last_error = message; if (message.compare(0, 16, "hipMalloc failed") == 0 && !g_allocation_note.empty()) { g_last_error += g_allocation_note; g_allocation_note.clear(); } }
+// test hook: the first hipMalloc inside agpu_ingest_finish (on the thread that armed it) is treated as failed, so that the path behind a failure -- the idle buffers given
+// back, the allocation tried again -- runs where a test can see what it does to an ingest that is finishing
+static thread_local int g_fail_allocations_in_finish = 0;
+thread_local bool g_inside_ingest_finish = false;
+bool debug_allocation_fails() { if (g_fail_allocations_in_finish > 0 && g_inside_ingest_finish) { --g_fail_allocations_in_finish; return true; } return false; }
 void note_failed_allocation(size_t bytes) {
 	size_t free_bytes = 0, total_bytes = 0;
 	(void) hipMemGetInfo(&free_bytes, &total_bytes);
@@ -1125,6 +1130,7 @@ int agpu_get_gene_table(agpu_ctx* ctx, uint32_t first, uint32_t count, uint16_t*
 	return AGPU_OK;
 }
 
+void agpu_debug_fail_allocation_in_finish(int count) { agpu::g_fail_allocations_in_finish = count; }
 int agpu_set_profiling(agpu_ctx* ctx, int enabled) {
 	if (!ctx) return AGPU_ERR_INVALID;
 	std::lock_guard<std::mutex> lock(ctx->profile_mutex);

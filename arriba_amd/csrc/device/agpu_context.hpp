@@ -19,6 +19,7 @@ namespace agpu {
 
 void set_last_error(const std::string& message);
 
+bool debug_allocation_fails(); // agpu_api.hip: a test asked for the next allocation inside agpu_ingest_finish to fail once (agpu_debug_fail_allocation_in_finish)
 void note_failed_allocation(size_t bytes); // agpu_api.hip: the size asked for and what the device has free go into the next "hipMalloc failed" message of this thread
 struct DeviceBuffer {
 	void* ptr = nullptr;
@@ -34,7 +35,7 @@ struct DeviceBuffer {
 		if (n == 0) n = 16;
 		if (ptr != nullptr && n <= capacity) { bytes = n; return true; }
 		release();
-		if (hipMalloc(&ptr, n) != hipSuccess) {
+		if (debug_allocation_fails() || hipMalloc(&ptr, n) != hipSuccess) {
 			// out of memory: the contexts give back what they only keep for the next sample (the stream and the tables of the last ingest while the stages run, the
 			// buffers of the stages while an ingest runs), then once more
 			(void) hipGetLastError();

@@ -28,6 +28,7 @@
 #include "inflate_core.hpp"
 
 using namespace agpu;
+namespace agpu { extern thread_local bool g_inside_ingest_finish; } // agpu_api.hip (test hook: agpu_debug_fail_allocation_in_finish)
 
 namespace {
 
@@ -939,7 +940,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	ctx->ingest_active = false;
 	// until this function returns the stream and the tables of the ingest are in use: an allocation that fails in here may take back the scratch of the stages of the sample before
 	// (DeviceBuffer::release_idle_buffers), never the buffers the pointers below point into
-	struct Finishing { agpu_ctx* ctx; explicit Finishing(agpu_ctx* c) : ctx(c) { ctx->ingest_finishing = true; } ~Finishing() { ctx->ingest_finishing = false; } } finishing(ctx);
+	struct Finishing { agpu_ctx* ctx; explicit Finishing(agpu_ctx* c) : ctx(c) { ctx->ingest_finishing = true; g_inside_ingest_finish = true; } ~Finishing() { ctx->ingest_finishing = false; g_inside_ingest_finish = false; } } finishing(ctx);
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
 	take_sample_buffers(ctx); // (a session with two lanes: the batch of this sample is built where the sibling's last one, done on the device, lies)

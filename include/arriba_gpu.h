@@ -173,6 +173,9 @@ agpu_ctx* agpu_create(int device, const agpu_params* params);
  * stages of the current sample run in the other (include/arriba_workflow.h: arriba_workflow_submit): the caller must not let both be between agpu_ingest_begin and
  * agpu_ingest_finish at once, nor both in their stages.  Destroy both with agpu_destroy, in any order. */
 agpu_ctx* agpu_create_sibling(agpu_ctx* of);
+/* test hook: the next `count` device allocations made inside agpu_ingest_finish on the calling thread are treated as failed once each -- the contexts then give back what they
+ * merely keep for their next sample and the allocation is tried again (tests/test_gpu_parity.py: the stream and the tables of the ingest that is finishing must survive that) */
+void agpu_debug_fail_allocation_in_finish(int count);
 void agpu_destroy(agpu_ctx* ctx);
 int agpu_set_params(agpu_ctx* ctx, const agpu_params* params);
 

@@ -782,3 +782,29 @@ def test_samples_in_a_queue_through_one_session_on_the_gpu(built, tmp_path):
     the files of every one equal to those it gives alone (tests/test_host_and_device_logic.py: the same check on the stepping harness)"""
     import test_host_and_device_logic as host_tests
     host_tests.check_samples_in_a_queue("product", tmp_path)
+
+
+def test_an_allocation_that_fails_inside_ingest_finish_leaves_the_ingest_alone(built, tmp_path):
+    """advisor, round 3: an allocation that fails inside agpu_ingest_finish makes the contexts give back what they merely keep (DeviceBuffer::release_idle_buffers) and is tried
+    again -- the stream and the tables of the very ingest that is finishing are not among that.  A resident pipeline works through a small sample (the scratch of its stages stays
+    behind), then ingests a larger one of the same genome with the first three allocations of agpu_ingest_finish failing once each (agpu_debug_fail_allocation_in_finish): the
+    batch is the one a fresh pipeline builds."""
+    import subprocess
+    import test_host_and_device_logic as cpu_tier
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    arguments = ["--seed", "11", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"]
+    for name, fragments, read_seed in (("small", "3000", "0"), ("large", "60000", "5")):
+        subprocess.run([datasets.GEN_SYNTH, "--out", str(tmp_path / name), "--fragments", fragments, "--read-seed", read_seed] + arguments, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    small, large = str(tmp_path / "small"), str(tmp_path / "large")
+    fresh_session = HostSession(large + ".fa", large + ".gtf")
+    expected = cpu_tier._device_batch_columns(fresh_session, DevicePipeline(fresh_session, bam=large + ".bam", piece_bytes=1 << 20))
+    session = HostSession(small + ".fa", small + ".gtf")
+    pipeline = DevicePipeline(session, bam=small + ".bam", piece_bytes=1 << 20)
+    os.makedirs(str(tmp_path / "out"))
+    pipeline.run_workflow(str(tmp_path / "out" / "fusions.tsv"), None)
+    pipeline.api.debug_fail_allocation_in_finish(3)
+    pipeline.read_chimeric_alignments(large + ".bam", piece_bytes=1 << 20)
+    pipeline.api.debug_fail_allocation_in_finish(0)
+    columns = cpu_tier._device_batch_columns(session, pipeline)
+    assert [key for key in expected if expected[key] != columns[key]] == []
+    assert expected["n"] > 50000
