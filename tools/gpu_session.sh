@@ -32,8 +32,11 @@ for LEG in "$@"; do
 import json
 kernels = json.load(open("${OUT}_pmc_kernels.json"))
 line = json.loads([l for l in open("${OUT}_FETCH_SIZE.json").read().splitlines() if l.startswith("{")][-1])
+import sys
+sys.path.insert(0, ".")
+import bench
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only), bench.py $ARGS; KB summed over the dispatches of a kernel", "fragments": line["config"]["fragments_per_gpu"],
-           "git": "${ARRIBA_GIT_HEAD}", "kernels": kernels}, open("${OUT}_pmc.json", "w"), indent=1, sort_keys=True)
+           "git": "${ARRIBA_GIT_HEAD}", "device_code_sha256": bench.device_code_digest(), "kernels": kernels}, open("${OUT}_pmc.json", "w"), indent=1, sort_keys=True)
 PY
            rm -rf gpurun_out/pmc_${TAG}_${NAME}_FETCH_SIZE gpurun_out/pmc_${TAG}_${NAME}_WRITE_SIZE; head -30 ${OUT}_pmc_summary.txt | cut -c1-200 ;;
     sh)    eval "timeout $LIMIT $ARGS" > $OUT.log 2>&1; RC=$?; echo "exit $RC" >> $OUT.log; tail -5 $OUT.log | cut -c1-400 ;;
