@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, c
 	if (threadIdx.x == 0) block_max = 0;
 	__syncthreads();
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i == n) out.name_offset[n] = (uint32_t) name_base[n];
+	if (i == n) out.name_offset[n] = name_base[n];
 	if (i < n) {
 		const uint32_t ref = order[i], g = ref >> 1;
 		const bool is_itd = ref & 1;
@@ -413,6 +413,11 @@ __global__ void shard_rebase_kernel(uint32_t* out, const uint32_t* in, uint64_t 
 	if (i < n) out[i] = in[i] + ((slot >= 3 || slot < n_aln[i]) ? base : 0u);
 }
 // ... the coverage of one part added to the whole: windows before their saturation (sums), start / end flags (ORs), viral read counts (sums)
+// ... the name offsets of a part (64-bit) behind the names of the parts before it
+__global__ void shard_rebase_names_kernel(uint64_t* out, const uint64_t* in, uint64_t n, uint64_t base) {
+	const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = in[i] + base;
+}
 __global__ void shard_add_coverage_kernel(uint32_t* windows, uint8_t* starts, uint8_t* ends, const uint32_t* part_windows, const uint8_t* part_starts, const uint8_t* part_ends, uint64_t n) {
 	const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) { windows[i] += part_windows[i]; starts[i] |= part_starts[i]; ends[i] |= part_ends[i]; }
@@ -423,24 +428,24 @@ __global__ void shard_add_counts_kernel(unsigned long long* counts, const unsign
 }
 
 // agpu_shard_merge when the names of the parts interleave: the order of std::string over the packed names ("QNAME,HI") of the merged batch
-__global__ void packed_name_length_kernel(const uint32_t* name_offset, uint64_t n, uint32_t* longest) {
+__global__ void packed_name_length_kernel(const uint64_t* name_offset, uint64_t n, uint32_t* longest) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i < n) atomicMax(longest, name_offset[i + 1] - name_offset[i]);
+	if (i < n) atomicMax(longest, (uint32_t) (name_offset[i + 1] - name_offset[i]));
 }
-__global__ void packed_name_chunk_kernel(const char* names, const uint32_t* name_offset, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
+__global__ void packed_name_chunk_kernel(const char* names, const uint64_t* name_offset, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i >= n) return;
-	const uint32_t row = order[i], begin = name_offset[row], length = name_offset[row + 1] - begin;
+	const uint32_t row = order[i]; const uint64_t begin = name_offset[row]; const uint32_t length = (uint32_t) (name_offset[row + 1] - begin);
 	uint64_t key = 0; // eight bytes from 8 * chunk on, big endian, zero padded: unsigned comparison of the chunks in order == std::string::compare
 	for (uint32_t k = 0; k < 8; ++k) { const uint32_t at = 8 * chunk + k; key = key << 8 | (at < length ? (uint8_t) names[begin + at] : 0u); }
 	keys[i] = key;
 }
 // rows i - 1 and i of the order: [0] counts equal names (a read name in two parts), new_group[i] says whether the QNAME (the name without ",HI...") changes
-__global__ void packed_name_neighbours_kernel(const char* names, const uint32_t* name_offset, const uint32_t* order, uint64_t n, uint32_t* new_group, uint32_t* equal_names) {
+__global__ void packed_name_neighbours_kernel(const char* names, const uint64_t* name_offset, const uint32_t* order, uint64_t n, uint32_t* new_group, uint32_t* equal_names) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i >= n) return;
 	if (i == 0) { new_group[0] = 0; return; }
-	const uint32_t a = order[i - 1], b = order[i], begin_a = name_offset[a], begin_b = name_offset[b], length_a = name_offset[a + 1] - begin_a, length_b = name_offset[b + 1] - begin_b;
+	const uint32_t a = order[i - 1], b = order[i]; const uint64_t begin_a = name_offset[a], begin_b = name_offset[b]; const uint32_t length_a = (uint32_t) (name_offset[a + 1] - begin_a), length_b = (uint32_t) (name_offset[b + 1] - begin_b);
 	bool same = length_a == length_b;
 	for (uint32_t k = 0; same && k < length_a; ++k) same = names[begin_a + k] == names[begin_b + k];
 	if (same) atomicAdd(equal_names, 1u);
@@ -474,17 +479,17 @@ __global__ void coverage_clamp_kernel(const uint32_t* windows, uint64_t n, uint1
 
 // ---- rows of a resident batch for the host (names, CIGARs and sequences of the reads the output writer prints) -------------------------------------
 
-__global__ void gather_sizes_kernel(BatchView b, const uint32_t* name_offset, const uint32_t* ids, uint64_t n, uint32_t* cigar_words, uint32_t* sequence_bytes, uint32_t* name_lengths) {
+__global__ void gather_sizes_kernel(BatchView b, const uint64_t* name_offset, const uint32_t* ids, uint64_t n, uint32_t* cigar_words, uint32_t* sequence_bytes, uint32_t* name_lengths) {
 	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (k > n) return;
 	if (k == n) { cigar_words[k] = 0; sequence_bytes[k] = 0; name_lengths[k] = 0; return; }
 	row_sizes(b, name_offset, ids ? ids[k] : k, cigar_words[k], sequence_bytes[k], name_lengths[k]);
 }
 
-__global__ void gather_copy_kernel(BatchView b, const uint8_t* pristine_fbits, const uint8_t* const* pristine_abits, const uint32_t* name_offset, const char* names, const uint32_t* ids, uint64_t n,
+__global__ void gather_copy_kernel(BatchView b, const uint8_t* pristine_fbits, const uint8_t* const* pristine_abits, const uint64_t* name_offset, const char* names, const uint32_t* ids, uint64_t n,
                                    const uint64_t* cigar_base, const uint64_t* sequence_base, const uint64_t* name_base, PackTarget out) {
 	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (k == n) out.name_offset[n] = (uint32_t) name_base[n];
+	if (k == n) { if (out.name_offset) out.name_offset[n] = name_base[n]; else out.row_name_offset[n] = (uint32_t) name_base[n]; }
 	if (k >= n) return;
 	copy_row(b, pristine_fbits, pristine_abits, name_offset, names, ids ? ids[k] : k, k, cigar_base[k], sequence_base[k], name_base[k], out);
 }
@@ -789,7 +794,7 @@ void fill_pack_target(agpu_ctx* ctx, PackTarget& out) {
 	}
 	out.cigar_pool = ctx->cigar_pool.as<uint32_t>();
 	for (int k = 0; k < 2; ++k) { out.seq_offset[k] = ctx->seq_offset[k].as<uint32_t>(); out.seq_length[k] = ctx->seq_length[k].as<uint32_t>(); }
-	out.seq_pool = ctx->seq_pool.as<uint8_t>(); out.name_offset = ctx->name_offset.as<uint32_t>(); out.names = ctx->names.as<char>();
+	out.seq_pool = ctx->seq_pool.as<uint8_t>(); out.name_offset = ctx->name_offset.as<uint64_t>(); out.row_name_offset = nullptr; out.names = ctx->names.as<char>();
 }
 
 }
@@ -1184,13 +1189,13 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	HIP_CHECK(hipMemcpyAsync(&totals[1], sequence_base.as<uint64_t>() + n_fragments, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&totals[2], name_base.as<uint64_t>() + n_fragments, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	if (totals[2] >= 0xFFFFFFFFull || totals[0] >= 0xFFFFFFFFull || totals[1] / 4 >= 0xFFFFFFFFull) { set_last_error("batch too large for 32-bit pool offsets"); return AGPU_ERR_INVALID; }
+	if (totals[0] >= 0xFFFFFFFFull || totals[1] / 4 >= 0xFFFFFFFFull) { set_last_error("batch too large for 32-bit pool offsets"); return AGPU_ERR_INVALID; } // (CIGAR words and sequence words: 16 GB each; the names have 64-bit offsets)
 	const uint64_t n = n_fragments;
 	ctx->n = n;
 	ALLOC(ctx->n_aln, n); ALLOC(ctx->fbits, n); ALLOC(ctx->group, n * 4);
 	for (int k = 0; k < 3; ++k) { ALLOC(ctx->contig[k], n * 2); ALLOC(ctx->start[k], n * 4); ALLOC(ctx->end[k], n * 4); ALLOC(ctx->abits[k], n); ALLOC(ctx->cigar_offset[k], n * 4); ALLOC(ctx->cigar_count[k], n * 2); }
 	for (int k = 0; k < 2; ++k) { ALLOC(ctx->seq_offset[k], n * 4); ALLOC(ctx->seq_length[k], n * 4); }
-	ALLOC(ctx->cigar_pool, totals[0] * 4); ALLOC(ctx->seq_pool, totals[1]); ALLOC(ctx->names, totals[2]); ALLOC(ctx->name_offset, (n + 1) * 4);
+	ALLOC(ctx->cigar_pool, totals[0] * 4); ALLOC(ctx->seq_pool, totals[1]); ALLOC(ctx->names, totals[2]); ALLOC(ctx->name_offset, (n + 1) * 8);
 	ctx->names_size = totals[2]; ctx->ingest_pool_sizes[0] = totals[0]; ctx->ingest_pool_sizes[1] = totals[1];
 	PackTarget target;
 	fill_pack_target(ctx, target);
@@ -1320,9 +1325,9 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 			if (parts[r].n == 0) continue;
 			const ShardLayout layout = shard_layout(parts[r]);
 			const uint8_t* block = (const uint8_t*) blocks + (size_t) r * stride;
-			uint32_t offsets[2], last[2];
-			HIP_CHECK(hipMemcpy(offsets, block + layout.offset[SHARD_NAME_OFFSET], 8, hipMemcpyDefault));
-			HIP_CHECK(hipMemcpy(last, block + layout.offset[SHARD_NAME_OFFSET] + (parts[r].n - 1) * 4, 8, hipMemcpyDefault));
+			uint64_t offsets[2], last[2];
+			HIP_CHECK(hipMemcpy(offsets, block + layout.offset[SHARD_NAME_OFFSET], 16, hipMemcpyDefault));
+			HIP_CHECK(hipMemcpy(last, block + layout.offset[SHARD_NAME_OFFSET] + (parts[r].n - 1) * 8, 16, hipMemcpyDefault));
 			if (offsets[1] < offsets[0] || last[1] < last[0] || last[1] > parts[r].names_bytes) { set_last_error("a part of the sample is damaged (name offsets)"); return AGPU_ERR_INVALID; }
 			std::string first_name(offsets[1] - offsets[0], '\0'), last_name(last[1] - last[0], '\0');
 			if (!first_name.empty()) HIP_CHECK(hipMemcpy(&first_name[0], block + layout.offset[SHARD_NAMES] + offsets[0], first_name.size(), hipMemcpyDefault));
@@ -1358,7 +1363,7 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 	ALLOC(ctx->n_aln, n); ALLOC(ctx->fbits, n); ALLOC(ctx->group, n * 4);
 	for (int k = 0; k < 3; ++k) { ALLOC(ctx->contig[k], n * 2); ALLOC(ctx->start[k], n * 4); ALLOC(ctx->end[k], n * 4); ALLOC(ctx->abits[k], n); ALLOC(ctx->cigar_offset[k], n * 4); ALLOC(ctx->cigar_count[k], n * 2); }
 	for (int k = 0; k < 2; ++k) { ALLOC(ctx->seq_offset[k], n * 4); ALLOC(ctx->seq_length[k], n * 4); }
-	ALLOC(ctx->cigar_pool, total.cigar_words * 4); ALLOC(ctx->seq_pool, total.sequence_bytes); ALLOC(ctx->names, total.names_bytes); ALLOC(ctx->name_offset, (n + 1) * 4);
+	ALLOC(ctx->cigar_pool, total.cigar_words * 4); ALLOC(ctx->seq_pool, total.sequence_bytes); ALLOC(ctx->names, total.names_bytes); ALLOC(ctx->name_offset, (n + 1) * 8);
 	ALLOC(ctx->coverage_windows32, std::max<uint64_t>(windows, 1) * 4);
 	HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(windows, 1) * 4, s));
 	HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_starts.ptr, 0, std::max<uint64_t>(windows, 1), s));
@@ -1366,7 +1371,7 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 	HIP_CHECK(hipMemsetAsync(ctx->ingest_viral_counts.ptr, 0, std::max<size_t>(total.n_contigs, 1) * 8, s));
 	void* columns[SHARD_SECTIONS];
 	shard_columns(ctx, columns);
-	static const uint8_t element_bytes[SHARD_SECTIONS] = { 1, 1, 4, 2, 4, 4, 1, 4, 2, 2, 4, 4, 1, 4, 2, 2, 4, 4, 1, 4, 2, 4, 4, 4, 4, 4, 1, 4, 1, 4, 1, 1, 8 };
+	static const uint8_t element_bytes[SHARD_SECTIONS] = { 1, 1, 4, 2, 4, 4, 1, 4, 2, 2, 4, 4, 1, 4, 2, 2, 4, 4, 1, 4, 2, 4, 4, 4, 4, 4, 1, 8, 1, 4, 1, 1, 8 };
 	(void) hipEventRecord(ctx->event_start, s);
 	uint64_t row = 0, cigar_at = 0, sequence_at = 0, name_at = 0, group_at = 0;
 	for (uint32_t r = 0; r < n_parts; ++r) {
@@ -1382,7 +1387,11 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 			uint8_t* out = (uint8_t*) columns[k] + at * element_bytes[k];
 			int slot = -1; uint32_t base = 0; uint64_t count = h.n;
 			if (k == SHARD_GROUP) { slot = 3; base = (uint32_t) group_at; }
-			else if (k == SHARD_NAME_OFFSET) { slot = 3; base = (uint32_t) name_at; count = h.n + (r + 1 == n_parts ? 1 : 0); } // (the last part brings the end of the names)
+			else if (k == SHARD_NAME_OFFSET) { // (64-bit; the last part brings the end of the names)
+				count = h.n + (r + 1 == n_parts ? 1 : 0);
+				if (count > 0) shard_rebase_names_kernel<<<grid_for(count), BLOCK, 0, s>>>((uint64_t*) out, (const uint64_t*) in, count, name_at);
+				continue;
+			}
 			else if (k == SHARD_SEQ_OFFSET0 || k == SHARD_SEQ_OFFSET1) { slot = k == SHARD_SEQ_OFFSET0 ? 0 : 1; base = (uint32_t) (sequence_at / 4); }
 			else if (k >= SHARD_SLOT0 && k < SHARD_SEQ_OFFSET0 && (k - SHARD_SLOT0) % SHARD_SLOT_FIELDS == SHARD_SLOT_CIGAR_OFFSET) { slot = (k - SHARD_SLOT0) / SHARD_SLOT_FIELDS; base = (uint32_t) cigar_at; }
 			if (slot >= 0) { if (count > 0) shard_rebase_kernel<<<grid_for(count), BLOCK, 0, s>>>((uint32_t*) out, (const uint32_t*) in, count, base, part_n_aln, (uint32_t) slot); }
@@ -1393,7 +1402,7 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 		if (total.n_contigs > 0) shard_add_counts_kernel<<<grid_for(total.n_contigs), BLOCK, 0, s>>>(ctx->ingest_viral_counts.as<unsigned long long>(), (const unsigned long long*) (block + layout.offset[SHARD_VIRAL_COUNTS]), (uint32_t) total.n_contigs);
 		row += h.n; cigar_at += h.cigar_words; sequence_at += h.sequence_bytes; name_at += h.names_bytes; group_at += h.groups;
 	}
-	if (n == 0) HIP_CHECK(hipMemsetAsync(ctx->name_offset.ptr, 0, 4, s));
+	if (n == 0) HIP_CHECK(hipMemsetAsync(ctx->name_offset.ptr, 0, 8, s));
 	if (windows > 0) coverage_clamp_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_windows32.as<uint32_t>(), windows, ctx->coverage_windows.as<uint16_t>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
@@ -1416,16 +1425,16 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
 		ALLOC(order, n * 4); ALLOC(order_out, n * 4); ALLOC(keys, n * 8); ALLOC(keys_out, n * 8); ALLOC(small, 8); ALLOC(new_group, n * 4);
 		HIP_CHECK(hipMemsetAsync(small.ptr, 0, 8, s));
 		iota_kernel<<<grid_for(n), BLOCK, 0, s>>>(order.as<uint32_t>(), n);
-		packed_name_length_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->name_offset.as<uint32_t>(), n, small.as<uint32_t>());
+		packed_name_length_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->name_offset.as<uint64_t>(), n, small.as<uint32_t>());
 		uint32_t longest = 0;
 		HIP_CHECK(hipMemcpyAsync(&longest, small.ptr, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		for (uint32_t chunk = (longest + 7) / 8; chunk-- > 0; ) {
-			packed_name_chunk_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->names.as<char>(), ctx->name_offset.as<uint32_t>(), order.as<uint32_t>(), n, chunk, keys.as<uint64_t>());
+			packed_name_chunk_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->names.as<char>(), ctx->name_offset.as<uint64_t>(), order.as<uint32_t>(), n, chunk, keys.as<uint64_t>());
 			TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, keys.as<uint64_t>(), keys_out.as<uint64_t>(), order.as<uint32_t>(), order_out.as<uint32_t>(), n, 64, "rocprim::radix_sort_pairs(name chunk of the merged batch)", false));
 			order.swap(order_out);
 		}
-		packed_name_neighbours_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->names.as<char>(), ctx->name_offset.as<uint32_t>(), order.as<uint32_t>(), n, new_group.as<uint32_t>(), small.as<uint32_t>() + 1);
+		packed_name_neighbours_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->names.as<char>(), ctx->name_offset.as<uint64_t>(), order.as<uint32_t>(), n, new_group.as<uint32_t>(), small.as<uint32_t>() + 1);
 		uint32_t equal_names = 0;
 		HIP_CHECK(hipMemcpyAsync(&equal_names, small.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
@@ -1554,7 +1563,7 @@ static int gather_rows_prepare(agpu_ctx* ctx, const uint32_t* fragments, uint64_
 	ALLOC(cigar_words, (n + 1) * 4); ALLOC(sequence_bytes, (n + 1) * 4); ALLOC(name_lengths, (n + 1) * 4);
 	ALLOC(ctx->gather_cigar_base, (n + 1) * 8); ALLOC(ctx->gather_seq_base, (n + 1) * 8); ALLOC(ctx->gather_name_base, (n + 1) * 8);
 	const uint32_t* ids = ctx->gather_all ? nullptr : ctx->gather_ids.as<uint32_t>();
-	gather_sizes_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(ctx->batch, ctx->batch_from_ingest ? ctx->name_offset.as<uint32_t>() : nullptr, ids, n, cigar_words.as<uint32_t>(), sequence_bytes.as<uint32_t>(), name_lengths.as<uint32_t>());
+	gather_sizes_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(ctx->batch, ctx->batch_from_ingest ? ctx->name_offset.as<uint64_t>() : nullptr, ids, n, cigar_words.as<uint32_t>(), sequence_bytes.as<uint32_t>(), name_lengths.as<uint32_t>());
 	TRY(exclusive_sum_u64(ctx, rocprim_scratch, cigar_words.as<uint32_t>(), ctx->gather_cigar_base.as<uint64_t>(), n + 1));
 	TRY(exclusive_sum_u64(ctx, rocprim_scratch, sequence_bytes.as<uint32_t>(), ctx->gather_seq_base.as<uint64_t>(), n + 1));
 	TRY(exclusive_sum_u64(ctx, rocprim_scratch, name_lengths.as<uint32_t>(), ctx->gather_name_base.as<uint64_t>(), n + 1));
@@ -1584,7 +1593,9 @@ int agpu_gather_rows_copy(agpu_ctx* ctx, agpu_batch_rows* rows) {
 	columns.push_back({ "gather.seq_offset0", n1 * 4, rows->seq_offset[0], n * 4 }); columns.push_back({ "gather.seq_length0", n1 * 4, rows->seq_length[0], n * 4 });
 	columns.push_back({ "gather.seq_offset1", n1 * 4, rows->seq_offset[1], n * 4 }); columns.push_back({ "gather.seq_length1", n1 * 4, rows->seq_length[1], n * 4 });
 	columns.push_back({ "gather.cigar_pool", std::max<uint64_t>(ctx->gather_sizes[0], 1) * 4, rows->cigar_pool, ctx->gather_sizes[0] * 4 }); columns.push_back({ "gather.seq_pool", std::max<uint64_t>(ctx->gather_sizes[1], 4), rows->seq_pool, ctx->gather_sizes[1] });
-	columns.push_back({ "gather.name_offset", (n + 1) * 4, rows->name_offset, (n + 1) * 4 }); columns.push_back({ "gather.names", std::max<uint64_t>(ctx->gather_sizes[2], 1), rows->names, ctx->gather_sizes[2] });
+	const bool rows_become_the_batch = rows->name_offset == nullptr && rows->names == nullptr; // (agpu_shard_merge sorting the merged batch: 64-bit name offsets, as every batch has them)
+	if (!rows_become_the_batch && ctx->gather_sizes[2] >= 0xFFFFFFFFull) { set_last_error("the names of the rows asked for take 4 GB and more: fetch them in portions"); return AGPU_ERR_CAPACITY; }
+	columns.push_back({ "gather.name_offset", (n + 1) * (rows_become_the_batch ? 8 : 4), rows->name_offset, (n + 1) * 4 }); columns.push_back({ "gather.names", std::max<uint64_t>(ctx->gather_sizes[2], 1), rows->names, ctx->gather_sizes[2] });
 	for (size_t c = 0; c < columns.size(); ++c) ALLOC(ctx->scratch(columns[c].name), columns[c].bytes);
 	PackTarget out;
 	size_t c = 0;
@@ -1596,13 +1607,14 @@ int agpu_gather_rows_copy(agpu_ctx* ctx, agpu_batch_rows* rows) {
 	out.seq_offset[0] = ctx->scratch(columns[c++].name).as<uint32_t>(); out.seq_length[0] = ctx->scratch(columns[c++].name).as<uint32_t>();
 	out.seq_offset[1] = ctx->scratch(columns[c++].name).as<uint32_t>(); out.seq_length[1] = ctx->scratch(columns[c++].name).as<uint32_t>();
 	out.cigar_pool = ctx->scratch(columns[c++].name).as<uint32_t>(); out.seq_pool = ctx->scratch(columns[c++].name).as<uint8_t>();
-	out.name_offset = ctx->scratch(columns[c++].name).as<uint32_t>(); out.names = ctx->scratch(columns[c++].name).as<char>();
+	{ DeviceBuffer& offsets = ctx->scratch(columns[c++].name); out.name_offset = rows_become_the_batch ? offsets.as<uint64_t>() : nullptr; out.row_name_offset = rows_become_the_batch ? nullptr : offsets.as<uint32_t>(); }
+	out.names = ctx->scratch(columns[c++].name).as<char>();
 	DeviceBuffer& abits_pointers = ctx->scratch("gather.abits_pointers");
 	ALLOC(abits_pointers, 3 * sizeof(void*));
 	const uint8_t* pristine[3] = { ctx->pristine_abits[0].as<uint8_t>(), ctx->pristine_abits[1].as<uint8_t>(), ctx->pristine_abits[2].as<uint8_t>() };
 	HIP_CHECK(hipMemcpyAsync(abits_pointers.ptr, pristine, sizeof(pristine), hipMemcpyHostToDevice, s));
 	const uint32_t* ids = ctx->gather_all ? nullptr : ctx->gather_ids.as<uint32_t>();
-	gather_copy_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(ctx->batch, ctx->pristine_fbits.as<uint8_t>(), abits_pointers.as<const uint8_t*>(), ctx->batch_from_ingest ? ctx->name_offset.as<uint32_t>() : nullptr,
+	gather_copy_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(ctx->batch, ctx->pristine_fbits.as<uint8_t>(), abits_pointers.as<const uint8_t*>(), ctx->batch_from_ingest ? ctx->name_offset.as<uint64_t>() : nullptr,
 	                                                     ctx->names.as<char>(), ids, n, ctx->gather_cigar_base.as<uint64_t>(), ctx->gather_seq_base.as<uint64_t>(), ctx->gather_name_base.as<uint64_t>(), out);
 	for (size_t k = 0; k < columns.size(); ++k)
 		if (columns[k].host != nullptr && columns[k].copy_bytes > 0) HIP_CHECK(hipMemcpyAsync(columns[k].host, ctx->scratch(columns[k].name).ptr, columns[k].copy_bytes, hipMemcpyDeviceToHost, s));

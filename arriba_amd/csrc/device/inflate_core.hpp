@@ -4,11 +4,11 @@
 // every kind of block, stepped on the host with one lane).
 //
 // How the work is split among the lanes.  Huffman decoding is a chain of dependent steps (the length of a code is known only when it has been looked up), so one lane
-// decodes: bits from a 64-bit buffer refilled with 8-byte loads, symbols through a 10-bit (literals / lengths) and a 9-bit (distances) first-level table in LDS, the
+// decodes: bits from a 64-bit buffer refilled with 4-byte loads issued a word ahead, symbols through a 10-bit (literals / lengths) and a 9-bit (distances) first-level table in LDS, the
 // few longer codes bit by bit over the canonical counts (the method of zlib's puff.c).  Everything that is not a chain is done by all lanes: the tables are filled by all of them,
 // a match (up to 258 bytes from up to 32 KB back, possibly overlapping itself) is copied by all of them at once -- byte i of the match is byte (i mod distance) of the
-// bytes that stand at the distance, all of which are final when the match starts --, and the output goes through a ring of 16 KB in LDS that all lanes write back to
-// HBM in runs of 8 KB, coalesced.  A match that reaches further back than the ring reads what was written back (rare: the ring holds what the last 16 KB hold).
+// bytes that stand at the distance, all of which are final when the match starts --, and the output goes through a ring of 8 KB in LDS that all lanes write back to
+// HBM in runs of 4 KB, coalesced.  A match that reaches further back than the ring reads what was written back.  A short match from inside the ring is copied by the decoding lane itself.
 //
 // `lanes` = 64 on the device, 1 on the host (tests/emu, tests/test_inflate_core.py): every loop over "my share" degenerates to the sequential loop.
 #ifndef AGPU_INFLATE_CORE_HPP
@@ -18,7 +18,7 @@
 
 namespace agpu {
 
-const uint32_t INFLATE_RING = 16384, INFLATE_FLUSH = 8192, INFLATE_SHORT_MATCH = 24;
+const uint32_t INFLATE_RING = 8192, INFLATE_FLUSH = 4096, INFLATE_SHORT_MATCH = 24; // (a ring of 16 KB: 7 wavefronts per CU by their LDS; 8 KB: 12 -- the decoding lanes wait for LDS and HBM most of the time, so more of them in flight is what counts)
 const int INFLATE_LITLEN_BITS = 10, INFLATE_DISTANCE_BITS = 9;
 enum { INFLATE_OK = 0, INFLATE_BAD_BLOCK_TYPE = 1, INFLATE_BAD_STORED_LENGTH = 2, INFLATE_BAD_CODE_LENGTHS = 3, INFLATE_BAD_SYMBOL = 4, INFLATE_BAD_DISTANCE = 5, INFLATE_OUTPUT_OVERRUN = 6, INFLATE_INPUT_OVERRUN = 7,
        INFLATE_SIZE_MISMATCH = 8 };

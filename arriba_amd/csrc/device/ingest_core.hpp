@@ -850,7 +850,9 @@ AGPU_HD void fragment_sizes(const Fragment3& f, const Rec& representative, bool 
 struct PackTarget {
 	uint8_t* n_aln; uint8_t* fbits; uint32_t* group;
 	uint16_t* contig[3]; int32_t* start[3]; int32_t* end[3]; uint8_t* abits[3]; uint32_t* cigar_offset[3]; uint16_t* cigar_count[3];
-	uint32_t* cigar_pool; uint32_t* seq_offset[2]; uint32_t* seq_length[2]; uint8_t* seq_pool; uint32_t* name_offset; char* names;
+	uint32_t* cigar_pool; uint32_t* seq_offset[2]; uint32_t* seq_length[2]; uint8_t* seq_pool; char* names;
+	uint64_t* name_offset;     // of a batch: 64-bit (10^8 fragments with the 45 characters of an Illumina read name are 4.7 GB of names)
+	uint32_t* row_name_offset; // of rows gathered for the host (name_offset == nullptr): their names are a small pool of their own
 };
 
 // row i of the batch from a sanity-checked fragment; returns the length of its longest read
@@ -894,22 +896,22 @@ AGPU_HD uint32_t write_fragment(const IngestStream& in, const Fragment3& f, cons
 			sequence_at += padded;
 		}
 	}
-	out.name_offset[i] = (uint32_t) name_at;
+	out.name_offset[i] = name_at;
 	const uint32_t length = name_length(name);
 	for (uint32_t k = 0; k < length; ++k) out.names[name_at + k] = (char) name_byte(name, k);
 	return longest;
 }
 
 // rows of a resident batch copied out for the host (agpu_gather_rows_*): sizes of row i, then the copy into row k of the target
-AGPU_HD void row_sizes(const BatchView& b, const uint32_t* name_offset, uint64_t i, uint32_t& cigar_words, uint32_t& sequence_bytes, uint32_t& name_bytes) {
+AGPU_HD void row_sizes(const BatchView& b, const uint64_t* name_offset, uint64_t i, uint32_t& cigar_words, uint32_t& sequence_bytes, uint32_t& name_bytes) {
 	cigar_words = 0; sequence_bytes = 0;
 	for (uint32_t s = 0; s < b.n_aln[i]; ++s) {
 		cigar_words += b.cigar_count[s][i];
 		if (s < 2) sequence_bytes += padded_sequence_bytes(b.seq_length[s][i]);
 	}
-	name_bytes = name_offset ? name_offset[i + 1] - name_offset[i] : 0;
+	name_bytes = name_offset ? (uint32_t) (name_offset[i + 1] - name_offset[i]) : 0;
 }
-AGPU_HD void copy_row(const BatchView& b, const uint8_t* pristine_fbits, const uint8_t* const* pristine_abits, const uint32_t* name_offset, const char* names, uint64_t i, uint64_t k,
+AGPU_HD void copy_row(const BatchView& b, const uint8_t* pristine_fbits, const uint8_t* const* pristine_abits, const uint64_t* name_offset, const char* names, uint64_t i, uint64_t k,
                       uint64_t cigar_at, uint64_t sequence_at, uint64_t name_at, const PackTarget& out) {
 	const uint32_t n_aln = b.n_aln[i];
 	out.n_aln[k] = (uint8_t) n_aln; out.fbits[k] = pristine_fbits[i]; out.group[k] = b.group[i];
@@ -930,8 +932,8 @@ AGPU_HD void copy_row(const BatchView& b, const uint8_t* pristine_fbits, const u
 			sequence_at += padded;
 		}
 	}
-	out.name_offset[k] = (uint32_t) name_at;
-	if (name_offset) for (uint32_t c = name_offset[i]; c < name_offset[i + 1]; ++c) out.names[name_at + (c - name_offset[i])] = names[c];
+	if (out.name_offset) out.name_offset[k] = name_at; else out.row_name_offset[k] = (uint32_t) name_at;
+	if (name_offset) for (uint64_t c = name_offset[i]; c < name_offset[i + 1]; ++c) out.names[name_at + (c - name_offset[i])] = names[c];
 }
 
 // detect_strandedness (source/read_stats.cpp:94-143) asks every split read: 0 = not informative, 1 = informative, 3 = informative and on the gene's strand.

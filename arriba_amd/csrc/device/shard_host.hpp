@@ -52,7 +52,7 @@ inline ShardLayout shard_layout(const ShardHeader& h) {
 	for (int slot = 0; slot < 3; ++slot)
 		for (int field = 0; field < SHARD_SLOT_FIELDS; ++field) b[SHARD_SLOT0 + slot * SHARD_SLOT_FIELDS + field] = n * field_bytes[field];
 	b[SHARD_SEQ_OFFSET0] = b[SHARD_SEQ_LENGTH0] = b[SHARD_SEQ_OFFSET1] = b[SHARD_SEQ_LENGTH1] = n * 4;
-	b[SHARD_CIGAR_POOL] = h.cigar_words * 4; b[SHARD_SEQ_POOL] = h.sequence_bytes; b[SHARD_NAME_OFFSET] = (n + 1) * 4; b[SHARD_NAMES] = h.names_bytes;
+	b[SHARD_CIGAR_POOL] = h.cigar_words * 4; b[SHARD_SEQ_POOL] = h.sequence_bytes; b[SHARD_NAME_OFFSET] = (n + 1) * 8; b[SHARD_NAMES] = h.names_bytes;
 	b[SHARD_WINDOWS32] = h.windows * 4; b[SHARD_FRAGMENT_STARTS] = h.windows; b[SHARD_FRAGMENT_ENDS] = h.windows; b[SHARD_VIRAL_COUNTS] = h.n_contigs * 8; b[SHARD_QNAME_KEYS] = h.qname_runs * 16;
 	uint64_t at = sizeof(ShardHeader);
 	for (int section = 0; section < SHARD_SECTIONS; ++section) { layout.offset[section] = at; at += (b[section] + 15) & ~(uint64_t) 15; }
@@ -78,7 +78,7 @@ inline const char* shard_totals(const ShardHeader* parts, uint32_t n_parts, Shar
 	}
 	total.windows = n_parts ? parts[0].windows : 0; total.n_contigs = n_parts ? parts[0].n_contigs : 0;
 	if (total.n >= 0xFFFFFFF0ull || total.qname_runs >= 0xFFFFFFF0ull) return "a batch holds at most 2^32-16 fragments";
-	if (total.names_bytes >= 0xFFFFFFFFull || total.cigar_words >= 0xFFFFFFFFull || total.sequence_bytes / 4 >= 0xFFFFFFFFull) return "batch too large for 32-bit pool offsets";
+	if (total.cigar_words >= 0xFFFFFFFFull || total.sequence_bytes / 4 >= 0xFFFFFFFFull) return "batch too large for 32-bit pool offsets"; // (the names have 64-bit offsets)
 	return nullptr;
 }
 

@@ -1004,3 +1004,30 @@ def test_inflate_core_against_zlib(built):
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "inflate_check"], check=True)
     result = subprocess.run([os.path.join(ROOT, "tests", "emu", "inflate_check")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert result.returncode == 0 and "0 failures" in result.stdout, result.stdout[-2000:]
+
+
+def test_long_read_names_through_the_whole_workflow(built, emu_api, tmp_path):
+    """read names of 45 characters (an Illumina run's; the golden datasets have 11): 64-bit name offsets in the batch -- the device ingest (stepped) builds the batch of the host
+    ingest, and the whole workflow gives the reference's files"""
+    arguments = ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60", "--name-length", "45"]
+    prefix = str(tmp_path / "long")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix] + arguments, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    from arriba_amd.pipeline import DevicePipeline, HostSession
+    host = HostSession(prefix + ".fa", prefix + ".gtf")
+    host.read_chimeric_alignments(prefix + ".bam")
+    expected = _batch_columns(host)
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    columns = _device_batch_columns(session, DevicePipeline(session, api=emu_api, bam=prefix + ".bam", piece_bytes=1 << 20))
+    assert [key for key in expected if expected[key] != columns[key]] == []
+    assert all(len(name) >= 45 for name in columns["names"][:10])
+    if os.path.exists(datasets.ARRIBA_REF):
+        reference = str(tmp_path / "reference"); os.makedirs(reference)
+        result = subprocess.run([datasets.ARRIBA_REF, "-x", prefix + ".bam", "-g", prefix + ".gtf", "-a", prefix + ".fa", "-o", os.path.join(reference, "fusions.tsv"), "-O", os.path.join(reference, "discarded.tsv"), "-f", "blacklist"],
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        assert result.returncode == 0, result.stdout[-2000:]
+        mine = str(tmp_path / "mine"); os.makedirs(mine)
+        other = HostSession(prefix + ".fa", prefix + ".gtf")
+        pipeline = DevicePipeline(other, api=emu_api, bam=prefix + ".bam", piece_bytes=1 << 20)
+        pipeline.run_workflow(os.path.join(mine, "fusions.tsv"), os.path.join(mine, "discarded.tsv"))
+        for name in ("fusions.tsv", "discarded.tsv"):
+            assert open(os.path.join(mine, name), "rb").read() == open(os.path.join(reference, name), "rb").read(), name

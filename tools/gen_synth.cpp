@@ -1091,7 +1091,10 @@ void Generator::stream_records(Rng& rng, uint64_t first_serial, long fragments, 
 		++serial;
 		char buffer[32];
 		snprintf(buffer, sizeof(buffer), "r%010llu", (unsigned long long) id);
-		return std::string(buffer);
+		std::string name(buffer);
+		// --name-length: as long as the names of an Illumina run ("A00123:45:HXXXXXXXX:1:1101:12345:12345": 38-45 characters); the padding follows the number, so the order of the names stays
+		if ((int) name.size() < c.name_length) name += std::string(":A00123:45:HXXXXXXXX:1:1101:00000:00000:pad").substr(0, (size_t) c.name_length - name.size());
+		return name;
 	};
 	auto flush = [&](bool everything) {
 		while (!pool.empty() && (everything || pool.size() > 48)) {
@@ -1420,6 +1423,7 @@ int main(int argc, char** argv) {
 		else if (a == "--soft-clip-supplementary") config.soft_clip_supplementary = true;
 		else if (a == "--n-bases") config.frac_n_bases = atof(value());
 		else if (a == "--bgzf-level") config.bgzf_level = atoi(value());
+		else if (a == "--name-length") config.name_length = atoi(value());
 		else if (a == "--shuffle") config.shuffle_names = true;
 		else if (a == "--separate-mates") config.separate_mates = true;
 		else if (a == "--stranded") config.stranded = true;

@@ -50,6 +50,7 @@ struct Config {
 	double frac_non_template = 0.0;  // of the junctions: 1-3 bases that belong to neither gene between the two parts of every split read (decided by the breakpoints: no random numbers are drawn)
 	bool soft_clip_supplementary = false; // supplementary alignments with soft clips and the whole read sequence (STAR --chimOutType WithinBAM SoftClip) instead of hard clips
 	double frac_n_bases = 0.0;       // of the bases of every read: N (drawn behind the sequencing errors; no random numbers are drawn when 0)
+	int name_length = 0;           // read names padded to this many characters (11 without: "r%010d")
 	int bgzf_level = 0;            // 0: stored BGZF blocks (STAR --outBAMcompression 0); 1-9: deflated at that zlib level (write_bam_segmented)
 	double frac_missing_hi = 0.0;    // of the multi-mapping fragments: the secondary alignments are written without the HI tag (STAR without --outSAMattributes HI; no random numbers are drawn when 0)
 	bool single_end = false;         // a single-end library: of every fragment only the records of one read (a split read keeps its supplementary alignment), no pairing flags
