@@ -41,17 +41,63 @@ __global__ void select_best_key_kernel(CandidateTable t, const uint32_t* order, 
 	const uint32_t c = order ? order[j] : j;
 	keys[j] = pass == 0 ? (uint64_t) iteration_rank[c] : select_best_group_key(t, c);
 }
-__global__ void select_best_group_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, unsigned int* remaining) {
+// A group of up to SELECT_BEST_SMALL candidates is folded by the thread that finds its head; a larger one -- a hot gene pair of a deep sample holds 20 000 candidates, and one thread
+// walking them was the whole 57 ms of the kernel at 10^8 fragments -- is listed for a wavefront of its own (select_best_wave_kernel).
+const uint32_t SELECT_BEST_SMALL = 48;
+struct GroupRange { uint32_t begin, end; };
+__global__ void select_best_group_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, unsigned int* remaining, GroupRange* large_groups, uint32_t* n_large, uint32_t small) {
 	__shared__ uint32_t block_sum;
 	uint32_t heads = 0;
 	for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < t.n; j += gridDim.x * BLOCK) {
 		if (group_keys[j] == ~0ull || (j > 0 && group_keys[j - 1] == group_keys[j])) continue; // filtered, or not the first of its group
 		uint32_t end = j + 1;
-		while (end < t.n && group_keys[end] == group_keys[j]) ++end;
-		if (end - j > 1) select_best_in_group(t, order, j, end);
+		while (end < t.n && end - j <= small && group_keys[end] == group_keys[j]) ++end;
+		if (end - j > small) { // its end is found by the wavefront that takes it
+			GroupRange range; range.begin = j; range.end = 0;
+			large_groups[atomicAdd(n_large, 1u)] = range;
+		} else if (end - j > 1) select_best_in_group(t, order, j, end);
 		++heads; // one candidate per group stays
 	}
 	block_tally(heads, remaining, &block_sum);
+}
+// The fold of the reference (source/select_best.cpp:33-60) replaces the best so far by a candidate of a higher (rank, supporting reads) pair whatever else holds, never by one of a lower pair,
+// and decides only between equal pairs by the rules that depend on the order.  So the candidate that stays is the fold, in iteration order, over the candidates that have the HIGHEST pair of the
+// group, starting with the first of them: whatever stood before it is replaced by it, and nothing of a lower pair replaces what follows.  The wavefront takes the maximum of the pairs over the
+// group (strided, one reduction), then folds the few candidates that have it in the order of their positions (ballots over chunks of 64), then marks all others.
+__global__ void __launch_bounds__(BLOCK) select_best_wave_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, const GroupRange* large_groups, const uint32_t* n_large) {
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (wave >= *n_large) return;
+	const uint32_t begin = large_groups[wave].begin;
+	const uint64_t group = group_keys[begin];
+	uint32_t end = begin + 1; // the end of the group: 64 keys at a time
+	while (true) {
+		const uint32_t j = end + lane;
+		const unsigned long long same = __ballot(j < t.n && group_keys[j] == group);
+		if (same == ~0ull) { end += 64; continue; }
+		end += (uint32_t) __ffsll((unsigned long long) ~same) - 1;
+		break;
+	}
+	unsigned long long highest = 0;
+	for (uint32_t j = begin + lane; j < end; j += 64) {
+		const uint32_t c = order[j];
+		const unsigned long long pair = (unsigned long long) select_best_rank(t, c) << 32 | (t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c]);
+		if (pair > highest) highest = pair;
+	}
+	for (int offset = 32; offset > 0; offset >>= 1) { const unsigned long long other = __shfl_xor(highest, offset); if (other > highest) highest = other; }
+	uint32_t best = 0xFFFFFFFFu;
+	for (uint32_t base = begin; base < end; base += 64) {
+		const uint32_t j = base + lane;
+		uint32_t c = 0; bool candidate = false;
+		if (j < end) { c = order[j]; candidate = ((unsigned long long) select_best_rank(t, c) << 32 | (t.split_reads1[c] + t.split_reads2[c] + t.discordant_mates[c])) == highest; }
+		unsigned long long holders = __ballot(candidate);
+		while (holders) { // in the order of their positions
+			const int l = __ffsll((unsigned long long) holders) - 1;
+			holders &= holders - 1;
+			const uint32_t next = (uint32_t) __shfl((int) c, l);
+			if (best == 0xFFFFFFFFu || select_best_replaces(t, next, best)) best = next; // (every lane folds the same values)
+		}
+	}
+	for (uint32_t j = begin + lane; j < end; j += 64) if (order[j] != best) t.filter[order[j]] = FILTER_select_best;
 }
 
 // recover_many_spliced: sort keys and the per-pair pass
@@ -321,8 +367,17 @@ extern "C" int agpu_select_most_supported_breakpoints(agpu_ctx* ctx, uint64_t* r
 		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
 		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
 		HIP_CHECK(rocprim::radix_sort_pairs(scratch.ptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), order_a.as<uint32_t>(), order_b.as<uint32_t>(), C, 0, 64, s));
-		KernelTimer timer(ctx, "select_best_group_kernel", (uint64_t) C * 40);
-		select_best_group_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), counter.as<unsigned int>());
+		DeviceBuffer& large_groups = ctx->scratch("events.large_groups");
+		const char* knob = getenv("ARRIBA_SELECT_BEST_SMALL"); // (tests: 1 sends every group of two and more through the wavefront's fold)
+		const uint32_t small = knob != nullptr && atoi(knob) >= 1 ? (uint32_t) atoi(knob) : SELECT_BEST_SMALL;
+		ALLOC(large_groups, (C1 / small + 1) * sizeof(GroupRange));
+		{ KernelTimer timer(ctx, "select_best_group_kernel", (uint64_t) C * 40);
+		  select_best_group_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), counter.as<unsigned int>(), large_groups.as<GroupRange>(), counter.as<uint32_t>() + 1, small); }
+		uint32_t n_large = 0;
+		HIP_CHECK(hipMemcpyAsync(&n_large, counter.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (n_large > 0) { KernelTimer timer(ctx, "select_best_wave_kernel", (uint64_t) n_large * small * 40);
+		  select_best_wave_kernel<<<(unsigned int) (((uint64_t) n_large * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), large_groups.as<GroupRange>(), counter.as<uint32_t>() + 1); }
 	} else if (C > 0) {
 		event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
 	}

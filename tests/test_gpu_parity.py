@@ -808,3 +808,11 @@ def test_an_allocation_that_fails_inside_ingest_finish_leaves_the_ingest_alone(b
     columns = cpu_tier._device_batch_columns(session, pipeline)
     assert [key for key in expected if expected[key] != columns[key]] == []
     assert expected["n"] > 50000
+
+
+def test_select_best_by_a_wavefront_per_group(built, dataset_files, tmp_path, monkeypatch):
+    """select_most_supported_breakpoints: a gene pair with more than 48 unfiltered candidates is folded by a wavefront (the maximum of (rank, supporting reads) over the group, then the
+    reference's order-dependent fold over the candidates that have it); ARRIBA_SELECT_BEST_SMALL=1 sends every group of two and more that way: the reference's verdicts on the golden
+    dump and on a live run with the filters in front switched off (thousands of candidates per stage)"""
+    monkeypatch.setenv("ARRIBA_SELECT_BEST_SMALL", "1")
+    test_event_level_predicates_match_reference(built, dataset_files, tmp_path)
