@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(BLOCK) bgzf_unwrap_kernel(const uint8_t* raw, 
 
 // one wavefront per deflated block (inflate_core.hpp): the DEFLATE stream raw -> the block's place in the record stream.  The first / last block of a part of a file gives only
 // the bytes [skip, skip + keep) of what it holds: such a block is inflated into `spill` (64 KB for block 0, 64 KB for the last one) and its share copied from there.
-__global__ void __launch_bounds__(64) bgzf_inflate_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint8_t* stream, uint8_t* spill, unsigned int* failures) {
+__global__ void __launch_bounds__(64, 3) bgzf_inflate_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint8_t* stream, uint8_t* spill, unsigned int* failures) {
 	__shared__ InflateShared shared;
 	const agpu_bgzf_block block = blocks[blockIdx.x];
 	const bool partial = block.skip != 0 || block.keep != block.isize;

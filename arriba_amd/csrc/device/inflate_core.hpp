@@ -34,6 +34,8 @@ struct InflateShared { // the memory the lanes of one wavefront share (LDS on th
 	uint8_t lengths[320];  // code lengths of the block being set up: literals / lengths, then distances
 	uint16_t codes[320];   // their canonical codes, bits reversed (the stream delivers a code with its first bit lowest)
 	uint32_t event[8];     // what the decoding lane tells the others: kind, position, length, distance, error
+	// the small tables of the decoding lane while a code is set up (in registers they are indexed dynamically and cost the kernel 60 VGPRs, i.e. a wavefront per SIMD)
+	uint16_t work_count[16], work_offset[16], work_symbols[19]; uint32_t work_next_code[16]; uint8_t work_code_lengths[19];
 };
 
 // the bits of the stream, lowest first.  The input is read in 4-byte words, and always one word ahead of the one that is needed: the load of word k + 1 is issued when word k goes
@@ -73,16 +75,16 @@ AGPU_HD int inflate_symbol(InflateBits& bits, const uint16_t* fast, int fast_bit
 
 // the tables of a code from the lengths of its symbols (lengths[0..n)); lane 0 numbers the codes, all lanes fill the first-level table.  Returns false for an
 // over-subscribed set of lengths (an incomplete one is allowed where zlib allows it: a single distance code, or none)
-template <class Sync> AGPU_HD bool inflate_build(const uint8_t* lengths, uint32_t n, uint16_t* codes, InflateHuffman& huffman, uint16_t* fast, int fast_bits, uint32_t lane, uint32_t lanes, uint32_t* verdict, Sync sync) {
+template <class Sync> AGPU_HD bool inflate_build(const uint8_t* lengths, uint32_t n, uint16_t* codes, InflateHuffman& huffman, uint16_t* fast, int fast_bits, uint32_t lane, uint32_t lanes, uint32_t* verdict, uint16_t* offset, uint32_t* next_code, Sync sync) {
 	for (uint32_t k = lane; k < (1u << fast_bits); k += lanes) fast[k] = 0;
 	if (lane == 0) {
 		for (int length = 0; length <= 15; ++length) huffman.count[length] = 0;
 		for (uint32_t s = 0; s < n; ++s) huffman.count[lengths[s]]++;
 		int left = 1; bool valid = true;
 		for (int length = 1; length <= 15; ++length) { left <<= 1; left -= huffman.count[length]; if (left < 0) valid = false; }
-		uint16_t offset[16]; offset[1] = 0;
+		offset[1] = 0;
 		for (int length = 1; length < 15; ++length) offset[length + 1] = offset[length] + huffman.count[length];
-		uint32_t next_code[16]; uint32_t code = 0;
+		uint32_t code = 0;
 		for (int length = 1; length <= 15; ++length) { code = (code + (length > 1 ? huffman.count[length - 1] : 0)) << 1; next_code[length] = code; }
 		for (uint32_t s = 0; s < n; ++s) {
 			const int length = lengths[s];
@@ -142,11 +144,11 @@ template <class Sync, class Broadcast> AGPU_HD int inflate_block(const uint8_t* 
 					} else if (type == 2) { // dynamic code: the lengths of the code lengths' code, then the lengths of both codes, run-length coded (3.2.7)
 						const uint32_t n_litlen = bits.take(5) + 257, n_distance = bits.take(5) + 1, n_lengths = bits.take(4) + 4;
 						if (n_litlen > 286 || n_distance > 30) { kind = EVENT_ERROR; error = INFLATE_BAD_CODE_LENGTHS; break; }
-						uint8_t code_lengths[19];
+						uint8_t* code_lengths = shared.work_code_lengths;
 						for (uint32_t k = 0; k < 19; ++k) code_lengths[k] = 0;
 						for (uint32_t k = 0; k < n_lengths; ++k) { bits.refill(); code_lengths[length_order[k]] = (uint8_t) bits.take(3); }
 						// (a code of 19 symbols: decoded over its canonical counts, no table)
-						uint16_t count[16], offset[16], symbols[19];
+						uint16_t* count = shared.work_count; uint16_t* offset = shared.work_offset; uint16_t* symbols = shared.work_symbols;
 						for (int l = 0; l <= 15; ++l) count[l] = 0;
 						for (uint32_t k = 0; k < 19; ++k) count[code_lengths[k]]++;
 						count[0] = 0;
@@ -231,8 +233,8 @@ template <class Sync, class Broadcast> AGPU_HD int inflate_block(const uint8_t* 
 		}
 		if (kind == EVENT_TABLES) {
 			uint32_t* verdict = &shared.event[7];
-			const bool litlen_valid = inflate_build(shared.lengths, 288, shared.codes, shared.litlen, shared.litlen_fast, INFLATE_LITLEN_BITS, lane, lanes, verdict, sync);
-			const bool distance_valid = inflate_build(shared.lengths + 288, broadcast(shared.event[6]), shared.codes, shared.distance, shared.distance_fast, INFLATE_DISTANCE_BITS, lane, lanes, verdict, sync);
+			const bool litlen_valid = inflate_build(shared.lengths, 288, shared.codes, shared.litlen, shared.litlen_fast, INFLATE_LITLEN_BITS, lane, lanes, verdict, shared.work_offset, shared.work_next_code, sync);
+			const bool distance_valid = inflate_build(shared.lengths + 288, broadcast(shared.event[6]), shared.codes, shared.distance, shared.distance_fast, INFLATE_DISTANCE_BITS, lane, lanes, verdict, shared.work_offset, shared.work_next_code, sync);
 			if (!litlen_valid || !distance_valid) return INFLATE_BAD_CODE_LENGTHS;
 		} else if (kind == EVENT_MATCH) {
 			const uint32_t length = broadcast(shared.event[2]), distance = broadcast(shared.event[3]), from = produced - distance;

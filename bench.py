@@ -517,14 +517,17 @@ def main():
             dist.barrier()
         elapsed = time.time() - started
         n = pipeline.n
-        sample_alone = None
+        sample_alone, timed_profile, alone_profile = None, None, None
         if pipelined:  # the sample submitted behind the last timed step is thrown away; then one sample alone, for the time from its file to its fusions.tsv when nothing overlaps it
             pipeline.cancel()
             pipeline.defer_output(False)
+            timed_profile = pipeline.kernel_profile()  # (the launches of the timed steps; the sample alone is profiled on its own)
+            pipeline.set_profiling(True)
             primed[0], pipelined = False, False
             alone_started = time.perf_counter()
             pipeline.sample(prefix + ".bam", outputs[0], outputs[1])
             sample_alone = {"seconds": round(time.perf_counter() - alone_started, 4), "parts": {key: round(value, 4) for key, value in pipeline.timing.items()}}
+            alone_profile = pipeline.kernel_profile()
             pipelined = True
         if distributed:
             device = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -563,7 +566,7 @@ def main():
 
         if rank == 0:
             kernels = {}
-            for name, ms, size in pipeline.kernel_profile():
+            for name, ms, size in (timed_profile if timed_profile is not None else pipeline.kernel_profile()):
                 entry = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
                 entry["launches"] += 1
                 entry["ms"] += ms
@@ -587,6 +590,16 @@ def main():
                 elif entry and entry.get("dispatches"):
                     traffic = (2.0 * entry.get("FETCH_SIZE", 0.0) + entry.get("WRITE_SIZE", 0.0)) * 1024.0 / entry["dispatches"]
                     traffic_note = "2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes; %s)" % pmc.get("source", "profiles/pmc_latest.json")
+            # the same kernel in the sample that ran alone behind the timed steps: with the samples in a queue its launches run beside the stages of the sample in front (and wait behind
+            # the persistent workgroups of filter_mismappers), which is what `achieved` above includes
+            roofline_alone = None
+            if alone_profile is not None:
+                launches_alone = [(ms, size) for name, ms, size in alone_profile if name == dominant and ms > 0]
+                if launches_alone:
+                    ms_alone = sum(ms for ms, _ in launches_alone) / len(launches_alone)
+                    bytes_alone = sum(size for _, size in launches_alone) / len(launches_alone)
+                    roofline_alone = {"achieved": bytes_alone / (ms_alone * 1e-3) / 1e9, "frac": bytes_alone / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": ms_alone, "launches": len(launches_alone),
+                                      "what": "the same kernel in one sample that ran alone behind the timed steps (nothing of another sample beside it)"}
             kernel_ms_per_step = sum(values["ms"] for values in kernels.values()) / args.steps
             mean = lambda key: sum(s[key] for s in step_seconds) / len(step_seconds)
             resident_stages = ("mark_multimappers", "annotate", "read_filters_stage1", "fragment_length_samples", "read_filters_stage2", "find_fusions", "merge_adjacent_fusions", "filter_multimappers",
@@ -622,7 +635,7 @@ def main():
                 "kernel_ms": {name: round(values["ms"] / args.steps, 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:48]},
                 "kernel_launches_per_step": {name: round(values["launches"] / args.steps, 1) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:12]},
                 "kernel_ms_per_step": round(kernel_ms_per_step, 2),
-                "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "alone": roofline_alone,
                              "launch_ms": dominant_ms, "algorithmic_bytes_per_launch": dominant_bytes, "launches_per_step": launches / args.steps},
             }
             # the search kernel that dominates is bound by the latency of dependent look-ups, not by bandwidth; beside it the best streaming kernel of the step, priced the same way
