@@ -110,7 +110,7 @@ __global__ void segment_emit_kernel(const uint8_t* bytes, uint64_t size, uint64_
 
 // ---- per record -----------------------------------------------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, GenomeView genome, uint64_t seed, uint64_t record_begin, uint64_t* keys, uint8_t* bits, uint32_t* counters) {
+__global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, GenomeView genome, uint64_t seed, uint64_t record_begin, uint64_t* keys, uint8_t* bits, int32_t* hit_index, uint32_t* counters) {
 	__shared__ uint32_t sums[4];
 	uint32_t active = 0, mapped = 0, missing = 0, broken = 0;
 	for (uint64_t r = record_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x; r < in.n_records; r += gridDim.x * (uint64_t) BLOCK) {
@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, Ge
 		const uint32_t block_size = load_u32(p);
 		uint64_t key = ~0ull;
 		uint8_t status = RECORD_SKIPPED;
+		int32_t hit = HIT_INDEX_UNKNOWN;
 		if (!record_sizes_ok(p + 4, block_size)) { status = RECORD_BROKEN; ++broken; }
 		else {
 			const Rec record = load_record(in, (uint32_t) r);
@@ -128,6 +129,7 @@ __global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, Ge
 				else {
 					status = RECORD_ACTIVE | (tags.has_sa ? RECORD_HAS_SA : 0);
 					key = name_key(record, tags.has_hi ? tags.hi : 1, seed);
+					hit = hit_index_to_keep(tags);
 					++active;
 					if (!(record.flag & BAMF_SUPPLEMENTARY) && (genome.contig_bits[record.contig] & CBIT_INTERESTING)) ++mapped;
 				}
@@ -135,6 +137,7 @@ __global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, Ge
 		}
 		keys[r] = key;
 		bits[r] = status;
+		hit_index[r] = hit;
 	}
 	block_tally(active, &counters[IC_ACTIVE], &sums[0]);
 	block_tally(mapped, &counters[IC_MAPPED_READS], &sums[1]);
@@ -167,11 +170,10 @@ __global__ void group_names_kernel(IngestStream in, const uint32_t* sorted_recor
 	if (t >= n_groups || group_count[t] < 2) return;
 	const uint32_t* records = sorted_records + group_begin[t];
 	const Rec a = load_record(in, records[0]);
-	const AuxTags tags_a = scan_aux(a.aux, a.end);
+	const int64_t hit_a = hit_index_of(in, records[0], a);
 	for (uint32_t k = 1; k < group_count[t]; ++k) {
 		const Rec b = load_record(in, records[k]);
-		const AuxTags tags_b = scan_aux(b.aux, b.end);
-		if (!same_name(a, tags_a.has_hi ? tags_a.hi : 1, b, tags_b.has_hi ? tags_b.hi : 1)) { atomicOr(&counters[IC_COLLISION], 1u); return; }
+		if (!same_name(a, hit_a, b, hit_index_of(in, records[k], b))) { atomicOr(&counters[IC_COLLISION], 1u); return; }
 	}
 }
 
@@ -222,18 +224,64 @@ struct ViralCounter {
 
 // (Tried in round 3 and taken back: one wavefront per 64 groups with its slice of the stream copied into 48 KB of LDS -- 1240 ms instead of 455 ms at 10^8 fragments,
 // profiles/r03j_bench100m_lds_staged_replay.json: three wavefronts per CU cannot hide the look-ups that stay in HBM -- offsets, record bits, gene index, genome, coverage_t.)
-__global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t first_group, uint32_t n_groups,
-                                                             FragmentPlan* plain, TandemPlan* itd, uint8_t* valid, FragmentSizes* sizes, unsigned long long* viral_counts, uint32_t* counters) {
+// RUNS: the groups are the runs of the windows (neighbouring active records with one key), in the order of the stream.  Then the thread also does what two passes of their own
+// over the same records did before (group_names_kernel 149 ms + run_name_order_kernel 123 ms of kernel time at 10^8 fragments, profiles/r04w_serialized_kernels.json): equal keys
+// must be equal names -- every record against the first one inside the loop body, while its header is at hand --, and the order of the names of neighbouring runs:
+//   Is the name of this run's fragment greater than the name of the run before it?  If so for all runs -- and the "ITD" entry of a run, where it has a valid one, is smaller than
+//   the next name, too: run_itd_order_kernel behind this one, which knows the valid entries -- the valid fragments are in name order (the names of the runs between two of them
+//   chain), and the pass over the fragments behind the last piece is not needed; if not -- names in FASTQ order, as STAR writes them, or a run out of order -- that pass decides.
+//   And for the read-name groups of the batch (fragments with one QNAME: multi-mappers): does the QNAME of this run differ from the one before?  With the runs in name order and
+//   no comma inside a QNAME, the runs of one QNAME lie next to each other, so two fragments have one QNAME exactly if no run between them differs from its predecessor ("X,a" <
+//   "Y,b" < "X,c" makes "Y,b" start with "X,": Y would hold a comma) -- a prefix sum over these flags then stands in for the QNAMEs (fragment_layout_kernel).
+// Registers: left alone the compiler takes 100 VGPRs for this kernel = 4 wavefronts per SIMD.  Held to 64 VGPRs it runs 8 per SIMD for 96 more bytes of scratch per lane
+// (-Rpass-analysis=kernel-resource-usage) -- and is SLOWER: 765 instead of 546 ms of kernel time at 10^8 fragments (profiles/r04v_serialized_kernels_fused_replay*.log; the pack
+// 130 instead of 124 ms): what the lanes of a CU have open of the stream at once no longer fits its share of the L2, and every line comes from further away again for the next
+// field of the record.  AGPU_REPLAY_WAVES / AGPU_PACK_WAVES = n (make variant) holds the kernels to n wavefronts per SIMD, for such comparisons; 0 = the compiler's choice.
+#ifndef AGPU_REPLAY_WAVES
+#define AGPU_REPLAY_WAVES 0
+#endif
+#ifndef AGPU_PACK_WAVES
+#define AGPU_PACK_WAVES 0
+#endif
+#if AGPU_REPLAY_WAVES > 0
+#define AGPU_REPLAY_OCCUPANCY __attribute__((amdgpu_waves_per_eu(AGPU_REPLAY_WAVES, AGPU_REPLAY_WAVES)))
+#else
+#define AGPU_REPLAY_OCCUPANCY
+#endif
+#if AGPU_PACK_WAVES > 0
+#define AGPU_PACK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(AGPU_PACK_WAVES, AGPU_PACK_WAVES)))
+#else
+#define AGPU_PACK_OCCUPANCY
+#endif
+template <bool RUNS> __global__ void __launch_bounds__(BLOCK) AGPU_REPLAY_OCCUPANCY group_replay_kernel(IngestContext ctx, const uint32_t* sorted_records, const uint32_t* group_begin, const uint32_t* group_count, uint32_t first_group, uint32_t n_groups,
+                                                             FragmentPlan* plain, TandemPlan* itd, uint8_t* valid, FragmentSizes* sizes, unsigned long long* viral_counts, uint32_t* qname_differs, uint32_t* counters) {
 	__shared__ uint32_t sums[2];
-	GroupTally tally; tally.malformed = 0; tally.chimeric = 0;
+	GroupTally tally; tally.malformed = 0; tally.chimeric = 0; tally.collision = 0;
 	const uint32_t g = first_group + blockIdx.x * BLOCK + threadIdx.x; // (groups numbered in the order of their first records)
 	if (g < n_groups) {
 		const uint32_t begin = group_begin[g];
 		const uint32_t n_records = group_count[g];
+		const Rec representative = load_record(ctx.stream, sorted_records[begin]);
+		const int64_t hit = hit_index_of(ctx.stream, sorted_records[begin], representative);
+		if (RUNS) {
+			const uint32_t length = qname_length(representative);
+			bool comma = false;
+			for (uint32_t k = 0; k < length; ++k) comma |= representative.name[k] == ',';
+			if (comma) atomicOr(&counters[IC_QNAME_COMMA], 1u);
+			if (g == 0) qname_differs[0] = 0;
+			else {
+				const uint32_t record_before = sorted_records[group_begin[g - 1]];
+				const Rec run_before = load_record(ctx.stream, record_before);
+				bool differs = length != qname_length(run_before);
+				for (uint32_t k = 0; k < length && !differs; ++k) differs = representative.name[k] != run_before.name[k];
+				qname_differs[g] = differs;
+				if (compare_names(fragment_name(run_before, hit_index_of(ctx.stream, record_before, run_before), false), fragment_name(representative, hit, false)) >= 0) atomicOr(&counters[IC_RUNS_UNSORTED], 1u);
+			}
+		}
 		FragmentPlan plain_plan; TandemPlan itd_plan;
 		ViralCounter viral = { viral_counts };
-		replay_group(ctx, sorted_records + begin, n_records, plain_plan, itd_plan, tally, viral);
-		const Rec representative = load_record(ctx.stream, sorted_records[begin]);
+		replay_group(ctx, sorted_records + begin, n_records, plain_plan, itd_plan, tally, viral, RUNS ? &representative : nullptr, hit);
+		if (tally.collision) atomicOr(&counters[IC_COLLISION], 1u);
 		Fragment3 fragment;
 		FragmentSizes none; none.cigar_words = 0; none.sequence_bytes = 0; none.name_length = 0;
 		bool ok = false;
@@ -242,14 +290,14 @@ __global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, 
 			if (!ok) tally.malformed++;
 		}
 		valid[2 * (size_t) g] = ok;
-		if (ok) { plain[g] = plain_plan; fragment_sizes(fragment, representative, false, sizes[2 * (size_t) g]); } else sizes[2 * (size_t) g] = none;
+		if (ok) { plain[g] = plain_plan; fragment_sizes(fragment, representative, hit, false, sizes[2 * (size_t) g]); } else sizes[2 * (size_t) g] = none;
 		ok = false;
 		if (itd_plan.plan.count > 0) {
 			ok = normalize_plan(ctx.stream, itd_plan.plan, &itd_plan.tandem, fragment);
 			if (!ok) tally.malformed++;
 		}
 		valid[2 * (size_t) g + 1] = ok;
-		if (ok) { itd[g] = itd_plan; fragment_sizes(fragment, representative, true, sizes[2 * (size_t) g + 1]); } else sizes[2 * (size_t) g + 1] = none;
+		if (ok) { itd[g] = itd_plan; fragment_sizes(fragment, representative, hit, true, sizes[2 * (size_t) g + 1]); } else sizes[2 * (size_t) g + 1] = none;
 	}
 	block_tally(tally.malformed, &counters[IC_MALFORMED], &sums[0]);
 	block_tally(tally.chimeric, &counters[IC_CHIMERIC], &sums[1]);
@@ -261,7 +309,7 @@ __global__ void __launch_bounds__(BLOCK) group_replay_kernel(IngestContext ctx, 
 // their first occurrence, the ITD entry behind the plain one
 __device__ FragmentName name_of(const IngestStream& in, const uint32_t* group_first, uint32_t ref, Rec& storage) {
 	storage = load_record(in, group_first[ref >> 1]);
-	return fragment_name(storage, ref & 1);
+	return fragment_name(storage, hit_index_of(in, group_first[ref >> 1], storage), ref & 1);
 }
 
 __global__ void name_order_check_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, uint32_t* counters) {
@@ -282,30 +330,15 @@ __global__ void name_order_check_kernel(IngestStream in, const uint32_t* group_f
 	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_NAME], block_max);
 }
 
-// The same question asked of the runs of a window while the file is still being copied: is the name of every run behind the name of the run before it -- and behind that
-// run's "ITD" entry where it has a valid one?  If so for all runs, the valid fragments are in name order, too (the names of the runs between two of them chain), and the pass over
-// the fragments behind the last piece is not needed (42 ms at 10^8 fragments); if not -- names in FASTQ order, as STAR writes them, or a run without a fragment out of order --
-// that pass decides as before.
-__global__ void run_name_order_kernel(IngestStream in, const uint32_t* group_first, const uint8_t* valid, uint32_t first_group, uint32_t n_groups, uint32_t* qname_differs, uint32_t* counters) {
+// ... the second half of the order of the runs (group_replay_kernel<true> has the first): a run with a valid "ITD" entry -- few have one -- must have that name, "QNAME,HIITD", in
+// front of the name of the next run, too
+__global__ void run_itd_order_kernel(IngestStream in, const uint32_t* group_first, const uint8_t* valid, uint32_t first_group, uint32_t n_groups, uint32_t* counters) {
 	const uint32_t g = first_group + blockIdx.x * BLOCK + threadIdx.x;
-	if (g >= n_groups) return;
+	if (g >= n_groups || g == 0 || !valid[2 * (size_t) (g - 1) + 1]) return;
 	Rec storage_a, storage_b;
 	const FragmentName mine = name_of(in, group_first, 2 * g, storage_b);
-	// ... and for the read-name groups of the batch (fragments with one QNAME: multi-mappers): does the QNAME of this run differ from the one before?  With the runs in name
-	// order and no comma inside a QNAME, the runs of one QNAME lie next to each other, so two fragments have one QNAME exactly if no run between them differs from its
-	// predecessor ("X,a" < "Y,b" < "X,c" makes "Y,b" start with "X,": Y would hold a comma) -- a prefix sum over these flags then stands in for the QNAMEs (fragment_layout_kernel).
-	const uint32_t length = qname_length(storage_b);
-	bool comma = false;
-	for (uint32_t k = 0; k < length; ++k) comma |= storage_b.name[k] == ',';
-	if (comma) atomicOr(&counters[IC_QNAME_COMMA], 1u);
-	if (g == 0) { qname_differs[0] = 0; return; }
-	FragmentName before = name_of(in, group_first, 2 * (g - 1), storage_a);
-	bool differs = length != qname_length(storage_a);
-	for (uint32_t k = 0; k < length && !differs; ++k) differs = storage_b.name[k] != storage_a.name[k];
-	qname_differs[g] = differs;
-	bool unsorted = compare_names(before, mine) >= 0;
-	if (!unsorted && valid[2 * (size_t) (g - 1) + 1]) { before = fragment_name(storage_a, true); unsorted = compare_names(before, mine) >= 0; }
-	if (unsorted) atomicOr(&counters[IC_RUNS_UNSORTED], 1u);
+	const FragmentName before = name_of(in, group_first, 2 * (g - 1) + 1, storage_a);
+	if (compare_names(before, mine) >= 0) atomicOr(&counters[IC_RUNS_UNSORTED], 1u);
 }
 
 __global__ void name_chunk_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, uint32_t chunk, uint64_t* keys) {
@@ -327,7 +360,7 @@ __global__ void fragment_layout_kernel(IngestStream in, const uint32_t* group_fi
 	cigar_words[i] = mine.cigar_words; sequence_bytes[i] = mine.sequence_bytes; name_lengths[i] = mine.name_length;
 	// multi-mapper groups: identical names up to the last ',' (source/common.hpp:222), i.e. identical QNAMEs
 	uint32_t differs = 0;
-	if (i > 0 && qname_run != nullptr) differs = qname_run[ref >> 1] != qname_run[order[i - 1] >> 1]; // (told by the windows: run_name_order_kernel)
+	if (i > 0 && qname_run != nullptr) differs = qname_run[ref >> 1] != qname_run[order[i - 1] >> 1]; // (told by the windows: group_replay_kernel<true>, run_itd_order_kernel)
 	else if (i > 0) {
 		const Rec a = load_record(in, group_first[ref >> 1]), b = load_record(in, group_first[order[i - 1] >> 1]);
 		const uint32_t length = qname_length(a);
@@ -337,7 +370,7 @@ __global__ void fragment_layout_kernel(IngestStream in, const uint32_t* group_fi
 	new_group[i] = differs;
 }
 
-__global__ void __launch_bounds__(BLOCK) fragment_pack_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, const FragmentPlan* plain, const TandemPlan* itd,
+__global__ void __launch_bounds__(BLOCK) AGPU_PACK_OCCUPANCY fragment_pack_kernel(IngestStream in, const uint32_t* group_first, const uint32_t* order, uint64_t n, const FragmentPlan* plain, const TandemPlan* itd,
                                                               const uint64_t* cigar_base, const uint64_t* sequence_base, const uint64_t* name_base, const uint32_t* group_id, PackTarget out, uint32_t* counters) {
 	__shared__ uint32_t block_max;
 	if (threadIdx.x == 0) block_max = 0;
@@ -472,6 +505,17 @@ __global__ void qname_equal_kernel(const uint64_t* low_sorted, const uint32_t* i
 }
 __global__ void iota_kernel(uint32_t* out, uint64_t n) { const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x; if (i < n) out[i] = (uint32_t) i; }
 
+// the windows of coverage_t from the prefix sums over the difference array of the replay (ingest_core.hpp: CoverageRange): window i of contig c is slot i + c; the counts in
+// 32 bits (what a part of a sample hands on: agpu_shard_export) and clamped to the reference's 16 bits
+__global__ void coverage_from_differences_kernel(const uint32_t* summed, const uint64_t* window_offset, uint32_t n_contigs, uint64_t n, uint32_t* counts, uint16_t* out) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= n) return;
+	uint32_t low = 0, high = n_contigs; // the contig of window i: the last one with window_offset[c] <= i
+	while (high - low > 1) { const uint32_t middle = (low + high) / 2; if (window_offset[middle] <= i) low = middle; else high = middle; }
+	const uint32_t count = summed[i + low];
+	counts[i] = count;
+	out[i] = count > 65535u ? (uint16_t) 65535 : (uint16_t) count;
+}
 __global__ void coverage_clamp_kernel(const uint32_t* windows, uint64_t n, uint16_t* out) {
 	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (i < n) out[i] = windows[i] > 65535u ? (uint16_t) 65535 : (uint16_t) windows[i];
@@ -593,6 +637,7 @@ IngestStream window_stream(agpu_ctx* ctx, uint64_t size, uint64_t n_records) {
 	IngestStream in;
 	in.bytes = ctx->ingest_stream.as<uint8_t>(); in.size = size; in.record_offset = ctx->scratch("ingest.record_offset").as<uint64_t>(); in.n_records = n_records;
 	in.n_targets = ctx->ingest_n_targets; in.tid_to_contig = ctx->ingest_tid_to_contig.as<uint32_t>();
+	in.hit_index = ctx->scratch("ingest.hit_index").as<int32_t>(); // (null until the first window has parsed its records: nobody asks before)
 	return in;
 }
 
@@ -652,12 +697,13 @@ int window_step(agpu_ctx* ctx, IngestWindow& w) {
 		if (records == 0) break;
 		DeviceBuffer& record_offset = ctx->scratch("ingest.record_offset"); DeviceBuffer& keys = ctx->scratch("ingest.keys"); DeviceBuffer& record_bits = ctx->scratch("ingest.record_bits"); DeviceBuffer& active_records = ctx->scratch("ingest.sorted_records");
 		TRY(grow_keeping(ctx, record_offset, w.record_end * 8, w.record_begin * 8, estimated_records * 8)); TRY(grow_keeping(ctx, keys, w.record_end * 8, w.record_begin * 8, estimated_records * 8));
+		TRY(grow_keeping(ctx, ctx->scratch("ingest.hit_index"), w.record_end * 4, w.record_begin * 4, estimated_records * 4));
 		TRY(grow_keeping(ctx, record_bits, w.record_end, w.record_begin, estimated_records)); TRY(grow_keeping(ctx, active_records, (w.active_begin + records) * 4, w.active_begin * 4, estimated_records * 4));
 		{ KernelTimer timer(ctx, "segment_emit_kernel", records * 8, s);
 		  segment_emit_kernel<<<grid_for(n), BLOCK, 0, s>>>(bytes, w.avail, base, w.segment_begin, w.segment_end, ctx->scratch("ingest.segment_first").as<uint64_t>(), ctx->scratch("ingest.segment_base").as<uint32_t>(), record_offset.as<uint64_t>()); }
 		const IngestStream in = window_stream(ctx, w.avail, w.record_end);
 		{ KernelTimer timer(ctx, "record_parse_kernel", records * (8 + 64 + 9), s);
-		  record_parse_kernel<<<tally_grid(records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, 0, w.record_begin, keys.as<uint64_t>(), record_bits.as<uint8_t>(), device_counters); }
+		  record_parse_kernel<<<tally_grid(records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, 0, w.record_begin, keys.as<uint64_t>(), record_bits.as<uint8_t>(), ctx->scratch("ingest.hit_index").as<int32_t>(), device_counters); }
 		auto flags = rocprim::make_transform_iterator(record_bits.as<uint8_t>() + w.record_begin, RecordIsActive());
 		HIP_CHECK(rocprim::select(nullptr, temporary, rocprim::counting_iterator<uint32_t>((uint32_t) w.record_begin), flags, active_records.as<uint32_t>() + w.active_begin, words + 2, records, s));
 		if (temporary > rocprim_scratch.capacity) ALLOC(rocprim_scratch, temporary);
@@ -688,15 +734,13 @@ int window_step(agpu_ctx* ctx, IngestWindow& w) {
 		const uint64_t groups = n_groups - first_group;
 		run_close_kernel<<<grid_for(groups), BLOCK, 0, s>>>(active_records, run_begin, (uint32_t) first_group, (uint32_t) n_groups, (uint32_t) w.head_end, w.active_end, group_first.as<uint32_t>(), group_count.as<uint32_t>());
 		const IngestStream in = window_stream(ctx, w.avail, w.record_end);
-		{ KernelTimer timer(ctx, "group_names_kernel", groups * 2 * (4 + 36 + 16), s);
-		  group_names_kernel<<<grid_for(groups), BLOCK, 0, s>>>(in, active_records, run_begin, group_count.as<uint32_t>(), (uint32_t) first_group, (uint32_t) n_groups, device_counters); }
-		{ KernelTimer timer(ctx, "group_replay_kernel", n * SEGMENT_BYTES, s);
-		  group_replay_kernel<<<grid_for(groups), BLOCK, 0, s>>>(replay_context(ctx, in), active_records, run_begin, group_count.as<uint32_t>(), (uint32_t) first_group, (uint32_t) n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
-		                                                        sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
 		DeviceBuffer& qname_differs = ctx->scratch("ingest.qname_differs");
 		TRY(grow_keeping(ctx, qname_differs, n_groups * 4, first_group * 4, estimated_groups * 4));
-		{ KernelTimer timer(ctx, "run_name_order_kernel", groups * 2 * (4 + 40), s);
-		  run_name_order_kernel<<<grid_for(groups), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), valid.as<uint8_t>(), (uint32_t) first_group, (uint32_t) n_groups, qname_differs.as<uint32_t>(), device_counters); }
+		{ KernelTimer timer(ctx, "group_replay_kernel", n * SEGMENT_BYTES, s);
+		  group_replay_kernel<true><<<grid_for(groups), BLOCK, 0, s>>>(replay_context(ctx, in), active_records, run_begin, group_count.as<uint32_t>(), (uint32_t) first_group, (uint32_t) n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
+		                                                              sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), qname_differs.as<uint32_t>(), device_counters); }
+		{ KernelTimer timer(ctx, "run_itd_order_kernel", groups * 2, s);
+		  run_itd_order_kernel<<<grid_for(groups), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), valid.as<uint8_t>(), (uint32_t) first_group, (uint32_t) n_groups, device_counters); }
 		p.groups_done = n_groups; p.touched = true;
 		break; }
 	}
@@ -805,7 +849,7 @@ bool agpu::release_ingest_buffers(agpu_ctx* ctx) {
 	if (!ctx->ingest_part_of_sample) ctx->coverage_windows32.release(); // (a part of a sample hands the windows on as they are: agpu_shard_export)
 	static const char* const temporary[] = { "ingest.record_offset", "ingest.keys", "ingest.keys_sorted", "ingest.record_bits", "ingest.sorted_records", "ingest.head", "ingest.group_start", "ingest.first_flags", "ingest.stream_rank", "ingest.group_first", "ingest.group_begin", "ingest.group_count", "ingest.plain_plans", "ingest.itd_plans",
 		"ingest.valid", "ingest.sizes", "ingest.refs", "ingest.order", "ingest.order_keys", "ingest.order_keys_sorted", "ingest.cigar_words", "ingest.sequence_bytes", "ingest.name_lengths", "ingest.new_group", "ingest.cigar_base",
-		"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.qname_differs", "ingest.qname_run", "ingest.run_keys", "ingest.run_keys_sorted", "ingest.window_rocprim", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim" };
+		"ingest.sequence_base", "ingest.name_base", "ingest.group_id", "ingest.qname_differs", "ingest.qname_run", "ingest.run_keys", "ingest.run_keys_sorted", "ingest.window_rocprim", "ingest.segment_first", "ingest.segment_end", "ingest.segment_end_before", "ingest.segment_count", "ingest.segment_base", "ingest.segment_mismatch", "ingest.rocprim", "ingest.coverage_summed", "ingest.hit_index" };
 	for (size_t k = 0; k < sizeof(temporary) / sizeof(temporary[0]); ++k) { DeviceBuffer& buffer = ctx->scratch(temporary[k]); if (buffer.ptr != nullptr) released = true; buffer.release(); }
 	return released;
 }
@@ -852,10 +896,10 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	if (config->n_targets) HIP_CHECK(hipMemcpyAsync(ctx->ingest_tid_to_contig.ptr, config->tid_to_contig, (size_t) config->n_targets * 4, hipMemcpyHostToDevice, s));
 	ctx->host_coverage_window_offset.assign(config->coverage_window_offset, config->coverage_window_offset + config->n_contigs + 1);
 	const uint64_t windows = ctx->host_coverage_window_offset.back();
-	ALLOC(ctx->coverage_window_offset, ((size_t) config->n_contigs + 1) * 8); ALLOC(ctx->coverage_windows32, std::max<uint64_t>(windows, 1) * 4); ALLOC(ctx->coverage_windows, std::max<uint64_t>(windows, 1) * 2);
+	ALLOC(ctx->coverage_window_offset, ((size_t) config->n_contigs + 1) * 8); ALLOC(ctx->coverage_windows32, std::max<uint64_t>(coverage_difference_slots(windows, config->n_contigs), 1) * 4); ALLOC(ctx->coverage_windows, std::max<uint64_t>(windows, 1) * 2);
 	ALLOC(ctx->coverage_fragment_starts, std::max<uint64_t>(windows, 1)); ALLOC(ctx->coverage_fragment_ends, std::max<uint64_t>(windows, 1));
 	HIP_CHECK(hipMemcpyAsync(ctx->coverage_window_offset.ptr, config->coverage_window_offset, ((size_t) config->n_contigs + 1) * 8, hipMemcpyHostToDevice, s));
-	HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(windows, 1) * 4, s));
+	HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(coverage_difference_slots(windows, config->n_contigs), 1) * 4, s));
 	HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_starts.ptr, 0, std::max<uint64_t>(windows, 1), s));
 	HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_ends.ptr, 0, std::max<uint64_t>(windows, 1), s));
 	ALLOC(ctx->ingest_viral_counts, std::max<size_t>(config->n_contigs, 1) * 8);
@@ -994,7 +1038,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 		}
 		if (!streamed && progress.touched) { // what the loop bodies of the windows have counted is counted again
 			const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
-			HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(windows, 1) * 4, s));
+			HIP_CHECK(hipMemsetAsync(ctx->coverage_windows32.ptr, 0, std::max<uint64_t>(coverage_difference_slots(windows, ctx->genome.n_contigs), 1) * 4, s));
 			HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_starts.ptr, 0, std::max<uint64_t>(windows, 1), s));
 			HIP_CHECK(hipMemsetAsync(ctx->coverage_fragment_ends.ptr, 0, std::max<uint64_t>(windows, 1), s));
 			HIP_CHECK(hipMemsetAsync(ctx->ingest_viral_counts.ptr, 0, std::max<size_t>(ctx->genome.n_contigs, 1) * 8, s));
@@ -1044,6 +1088,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	}
 	IngestStream in;
 	in.bytes = bytes; in.size = size; in.record_offset = record_offset.as<uint64_t>(); in.n_records = n_records; in.n_targets = ctx->ingest_n_targets; in.tid_to_contig = ctx->ingest_tid_to_contig.as<uint32_t>();
+	in.hit_index = nullptr; // (set where the records have been parsed: below)
 
 	ctx->ingest_qname_runs = 0;
 	if (ctx->ingest_part_of_sample && n_records > 0) { // the read names of this part, for the check that no name has records in another part (agpu_shard_merge)
@@ -1066,7 +1111,8 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	DeviceBuffer& first_flags = ctx->scratch("ingest.first_flags"); DeviceBuffer& stream_rank = ctx->scratch("ingest.stream_rank");
 	DeviceBuffer& group_first = ctx->scratch("ingest.group_first"); DeviceBuffer& group_begin = ctx->scratch("ingest.group_begin"); DeviceBuffer& group_count = ctx->scratch("ingest.group_count");
 	const uint64_t records1 = std::max<uint64_t>(n_records, 1);
-	if (!streamed) { ALLOC(keys, records1 * 8); ALLOC(keys_sorted, records1 * 8); ALLOC(record_bits, records1); ALLOC(sorted_records, records1 * 4); }
+	if (!streamed) { ALLOC(keys, records1 * 8); ALLOC(keys_sorted, records1 * 8); ALLOC(record_bits, records1); ALLOC(sorted_records, records1 * 4); ALLOC(ctx->scratch("ingest.hit_index"), records1 * 4); }
+	in.hit_index = ctx->scratch("ingest.hit_index").as<int32_t>(); // (of the windows, or filled by the pass below)
 	uint64_t n_active = 0, seed = 0;
 	uint32_t n_groups = 0;
 	if (streamed) { // (the counters hold what the windows counted; the active records lie in sorted_records in the order of the stream, the runs are the groups)
@@ -1079,7 +1125,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 		HIP_CHECK(hipMemsetAsync(device_counters, 0, IC_COUNT * 4, s));
 		if (n_records > 0) {
 			{ KernelTimer timer(ctx, "record_parse_kernel", n_records * (8 + 64 + 9));
-			  record_parse_kernel<<<tally_grid(n_records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, seed, 0, keys.as<uint64_t>(), record_bits.as<uint8_t>(), device_counters); }
+			  record_parse_kernel<<<tally_grid(n_records, BLOCK) * 8, BLOCK, 0, s>>>(in, ctx->genome, seed, 0, keys.as<uint64_t>(), record_bits.as<uint8_t>(), ctx->scratch("ingest.hit_index").as<int32_t>(), device_counters); }
 			TRY(sort_pairs<uint64_t>(ctx, rocprim_scratch, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(), nullptr, sorted_records.as<uint32_t>(), n_records, 64, "rocprim::radix_sort_pairs(record keys)", true));
 		}
 		TRY(read_counters());
@@ -1123,8 +1169,8 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	uint64_t n_fragments = 0;
 	if (n_groups > 0) {
 		if (!streamed) { KernelTimer timer(ctx, "group_replay_kernel", size - base);
-		  group_replay_kernel<<<grid_for(n_groups), BLOCK, 0, s>>>(replay_context(ctx, in), sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), 0, n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
-		                                                            sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), device_counters); }
+		  group_replay_kernel<false><<<grid_for(n_groups), BLOCK, 0, s>>>(replay_context(ctx, in), sorted_records.as<uint32_t>(), group_begin.as<uint32_t>(), group_count.as<uint32_t>(), 0, n_groups, plain.as<FragmentPlan>(), itd.as<TandemPlan>(), valid.as<uint8_t>(),
+		                                                            sizes.as<FragmentSizes>(), ctx->ingest_viral_counts.as<unsigned long long>(), nullptr, device_counters); }
 		TRY(select_flagged(ctx, rocprim_scratch, valid.as<uint8_t>(), refs.as<uint32_t>(), device_counters + IC_MAX_NAME, 2 * (uint64_t) n_groups));
 		TRY(read_counters());
 		n_fragments = host_counters[IC_MAX_NAME];
@@ -1139,7 +1185,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	if (n_fragments > 0) {
 		ALLOC(order_keys, fragments1 * 8); ALLOC(order_keys_sorted, fragments1 * 8);
 		HIP_CHECK(hipMemcpyAsync(order.ptr, refs.ptr, n_fragments * 4, hipMemcpyDeviceToDevice, s)); // ascending references == the order of first occurrence (the groups are numbered by their first records)
-		const bool runs_in_name_order = streamed && host_counters[IC_RUNS_UNSORTED] == 0; // (told by the windows: run_name_order_kernel)
+		const bool runs_in_name_order = streamed && host_counters[IC_RUNS_UNSORTED] == 0; // (told by the windows: group_replay_kernel<true>, run_itd_order_kernel)
 		if (!runs_in_name_order) {
 			KernelTimer timer(ctx, "name_order_check_kernel", n_fragments * (4 + 2 * 40));
 			name_order_check_kernel<<<grid_for(n_fragments), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n_fragments, device_counters);
@@ -1203,7 +1249,17 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	  fragment_pack_kernel<<<grid_for(n + 1), BLOCK, 0, s>>>(in, group_first.as<uint32_t>(), order.as<uint32_t>(), n, plain.as<FragmentPlan>(), itd.as<TandemPlan>(),
 	                                                       cigar_base.as<uint64_t>(), sequence_base.as<uint64_t>(), name_base.as<uint64_t>(), group_id.as<uint32_t>(), target, device_counters); }
 	const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
-	if (windows > 0) { KernelTimer timer(ctx, "coverage_clamp_kernel", windows * 6); coverage_clamp_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_windows32.as<uint32_t>(), windows, ctx->coverage_windows.as<uint16_t>()); }
+	if (windows > 0) { // the difference array of the replay becomes the windows: one prefix sum over all contigs, then the counts to their places (32 bits for a part of a sample, 16 for the stages)
+		const uint64_t slots = coverage_difference_slots(windows, ctx->genome.n_contigs);
+		DeviceBuffer& summed = ctx->scratch("ingest.coverage_summed"); DeviceBuffer& rocprim_scratch = ctx->scratch("ingest.rocprim");
+		ALLOC(summed, slots * 4);
+		size_t temporary = 0;
+		HIP_CHECK(rocprim::inclusive_scan(nullptr, temporary, ctx->coverage_windows32.as<uint32_t>(), summed.as<uint32_t>(), slots, rocprim::plus<uint32_t>(), s));
+		ALLOC(rocprim_scratch, temporary);
+		KernelTimer timer(ctx, "coverage_from_differences_kernel", slots * 8 + windows * 10);
+		HIP_CHECK(rocprim::inclusive_scan(rocprim_scratch.ptr, temporary, ctx->coverage_windows32.as<uint32_t>(), summed.as<uint32_t>(), slots, rocprim::plus<uint32_t>(), s));
+		coverage_from_differences_kernel<<<grid_for(windows), BLOCK, 0, s>>>(summed.as<uint32_t>(), ctx->coverage_window_offset.as<uint64_t>(), ctx->genome.n_contigs, windows, ctx->coverage_windows32.as<uint32_t>(), ctx->coverage_windows.as<uint16_t>());
+	}
 	TRY(read_counters());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));

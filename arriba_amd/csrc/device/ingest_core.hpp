@@ -41,7 +41,9 @@ struct IngestStream {
 	uint64_t n_records;
 	uint32_t n_targets;
 	const uint32_t* tid_to_contig;   // BAM reference id -> contig id of the session
+	const int32_t* hit_index;        // [n_records] the HI of every active record as record_parse_kernel found it (1 without one), HIT_INDEX_UNKNOWN = look again; may be null
 };
+const int32_t HIT_INDEX_UNKNOWN = -0x7FFFFFFF - 1;
 
 // one record, its fixed fields decoded (the variable parts stay in the stream)
 struct Rec {
@@ -201,6 +203,16 @@ AGPU_HD AuxTags scan_aux(const uint8_t* s, const uint8_t* end) {
 		s = value + size;
 	}
 	return tags;
+}
+
+// "HI" of a record, 1 without one (source/read_chimeric_alignments.cpp:618-625): the aux fields are walked once, by record_parse_kernel; whoever needs the hit index of the
+// record later -- the name of its fragment is "QNAME,HI" -- finds it beside the record's status instead of walking the fields again (five tags in front of it in STAR's
+// records, every one a dependent load)
+AGPU_HD int32_t hit_index_to_keep(const AuxTags& tags) { const int64_t hi = tags.has_hi ? tags.hi : 1; return (hi > HIT_INDEX_UNKNOWN && hi <= 0x7FFFFFFF) ? (int32_t) hi : HIT_INDEX_UNKNOWN; }
+AGPU_HD int64_t hit_index_of(const IngestStream& in, uint32_t record, const Rec& rec) {
+	if (in.hit_index != nullptr) { const int32_t kept = in.hit_index[record]; if (kept != HIT_INDEX_UNKNOWN) return kept; }
+	const AuxTags tags = scan_aux(rec.aux, rec.end);
+	return tags.has_hi ? tags.hi : 1;
 }
 
 // per-record verdict of the first lines of the loop body (source/read_chimeric_alignments.cpp:611-631)
@@ -568,24 +580,39 @@ AGPU_HD bool extract_read_through_alignment(FragmentPlan& plan, uint32_t record_
 }
 
 // ---- coverage (reference: coverage_t::add_fragment, source/read_stats.cpp:161-266) ----------------------------------------------------------------
-// The windows are shared by all threads: +1 with saturation commutes, so the windows are counted in 32 bits with relaxed atomics and clamped to the
-// reference's 16 bits when the ingest is over; the start/end flags are plain stores of 1.
+// The windows are shared by all threads: +1 with saturation commutes, so they are counted in 32 bits and clamped to the reference's 16 bits when the ingest is over; the
+// start/end flags are plain stores of 1.  The windows an aligned block covers are a RANGE [lo, hi): instead of one atomic per window (eight for a read of 150 bases -- every
+// one of them a 64-byte request to the fabric, 2 x 690 GB at 10^8 fragments, profiles/r04y_pmc100m_pmc_summary.txt) the range is noted in a difference array, +1 at lo and
+// -1 at hi, neighbouring ranges of a fragment (its blocks behind an insertion, its overlapping mates) as one; a prefix sum behind the last record turns the differences into
+// the counts (coverage_from_differences_kernel).  A contig has one slot more than windows in that array -- the -1 behind its last window -- so window w of contig c is slot
+// window_offset[c] + c + w, every contig sums to zero and one prefix sum over the whole array serves all contigs.
 
 struct CoverageBuild {
 	uint32_t n_contigs;
 	const uint64_t* window_offset; // [n_contigs + 1]; a contig without sequence has no windows
-	uint32_t* windows;
+	uint32_t* windows;             // the difference array: window_offset[n_contigs] + n_contigs slots
 	uint8_t* fragment_starts;
 	uint8_t* fragment_ends;
 };
+AGPU_HD uint64_t coverage_difference_slots(uint64_t windows, uint32_t n_contigs) { return windows + n_contigs; }
 
-AGPU_HD void coverage_increment(uint32_t* window) {
+AGPU_HD void coverage_add(uint32_t* slot, uint32_t value) {
 #if defined(__HIP_DEVICE_COMPILE__)
-	__hip_atomic_fetch_add(window, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_fetch_add(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-	__atomic_fetch_add(window, 1u, __ATOMIC_RELAXED);
+	__atomic_fetch_add(slot, value, __ATOMIC_RELAXED);
 #endif
 }
+// a range of windows waiting for its neighbour: [lo, hi) behind slot `base` of the difference array
+struct CoverageRange {
+	uint64_t base; int64_t lo, hi;
+	AGPU_HD void flush(uint32_t* differences) { if (hi > lo) { coverage_add(&differences[base + (uint64_t) lo], 1u); coverage_add(&differences[base + (uint64_t) hi], 0xFFFFFFFFu); } hi = lo = 0; }
+	AGPU_HD void add(uint32_t* differences, uint64_t to_base, int64_t from, int64_t to) { // windows [from, to), to > from
+		if (hi > lo && to_base == base && from == hi) { hi = to; return; }
+		flush(differences);
+		base = to_base; lo = from; hi = to;
+	}
+};
 
 AGPU_HD void add_fragment_to_coverage(const CoverageBuild& coverage, const Rec& mate1, uint16_t flag1, const Rec* mate2_or_null, bool is_chimeric) {
 	const Rec& mate2 = (mate2_or_null == nullptr) ? mate1 : *mate2_or_null;
@@ -605,6 +632,8 @@ AGPU_HD void add_fragment_to_coverage(const CoverageBuild& coverage, const Rec& 
 	int32_t position = position1 < position2 ? position1 : position2;
 	int32_t window = position / COVERAGE_RESOLUTION;
 	uint32_t i1 = 0, i2 = 0;
+	const uint64_t slots1 = begin1 + (uint64_t) mate1.contig, slots2 = begin2 + (uint64_t) mate2.contig; // (one slot more per contig in front of this one)
+	CoverageRange pending; pending.base = 0; pending.lo = pending.hi = 0;
 	while (true) {
 		uint32_t op1 = 0, op2 = 0, length1, length2;
 		if (i1 < mate1.n_cigar) { op1 = mate1.cigar(i1); length1 = op_consumes_reference(op1 & 15) ? op1 >> 4 : 0; }
@@ -616,23 +645,32 @@ AGPU_HD void add_fragment_to_coverage(const CoverageBuild& coverage, const Rec& 
 		if (i1 < mate1.n_cigar && (position1 + (int32_t) length1 < position2 + (int32_t) length2 || i2 >= mate2.n_cigar)) {
 			i1++;
 			if (length1 == 0) continue;
-			op = op1; begin = begin1; size = size1; position1 += (int32_t) length1; position = position1;
+			op = op1; begin = slots1; size = size1; position1 += (int32_t) length1; position = position1;
 		} else if (i2 < mate2.n_cigar) {
 			i2++;
 			if (length2 == 0) continue;
-			op = op2; begin = begin2; size = size2; position2 += (int32_t) length2; position = position2;
+			op = op2; begin = slots2; size = size2; position2 += (int32_t) length2; position = position2;
 		} else {
 			break;
 		}
 		if (op_consumes_query(op & 15)) {
-			while (window <= position / COVERAGE_RESOLUTION) {
-				if (window >= 0 && (uint64_t) window < size && position - window * COVERAGE_RESOLUTION >= COVERAGE_RESOLUTION / 2) coverage_increment(&coverage.windows[begin + (uint64_t) window]);
-				++window;
+			// the reference's loop -- while (window <= position / resolution) { if (window inside the contig && position - window * resolution >= resolution / 2) ++coverage[window]; ++window; } --
+			// in closed form: the condition holds for every window below the last one and for the last one if the block reaches its middle; nothing is counted at a negative position
+			const int32_t last = position / COVERAGE_RESOLUTION;
+			if (window <= last) {
+				if (position >= 0) {
+					const int64_t from = window > 0 ? window : 0;
+					int64_t to = (position - last * COVERAGE_RESOLUTION >= COVERAGE_RESOLUTION / 2) ? (int64_t) last + 1 : (int64_t) last;
+					if (to > (int64_t) size) to = (int64_t) size;
+					if (to > from) pending.add(coverage.windows, begin, from, to);
+				}
+				window = last + 1;
 			}
 		} else {
 			window = position / COVERAGE_RESOLUTION;
 		}
 	}
+	pending.flush(coverage.windows);
 	if (!is_chimeric) {
 		if ((flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) { const uint64_t w = (uint64_t) ((position1 - 1) / COVERAGE_RESOLUTION); if (position1 >= 1 && w < size1) coverage.fragment_ends[begin1 + w] = 1; }
 		else { const uint64_t w = (uint64_t) ((position2 - 1) / COVERAGE_RESOLUTION); if (position2 >= 1 && w < size2) coverage.fragment_ends[begin2 + w] = 1; }
@@ -651,11 +689,13 @@ struct IngestContext {
 	uint8_t external_duplicate_marking;
 };
 
-struct GroupTally { uint32_t malformed; uint32_t chimeric; }; // malformed_count, !no_chimeric_reads
+struct GroupTally { uint32_t malformed; uint32_t chimeric; uint32_t collision; }; // malformed_count, !no_chimeric_reads; a record whose name is not the one of the first record of its group (two names, one key)
 
 // `records` = the indices of the active records of one "QNAME,HI" in stream order.  plain = fragments[read_name], itd = fragments[read_name + "ITD"].
 // viral_reads[contig] += pristine reads (64-bit counters).
-template <class ViralCounter> AGPU_HD void replay_group(const IngestContext& ctx, const uint32_t* records, uint32_t n_records, FragmentPlan& plain, TandemPlan& itd, GroupTally& tally, ViralCounter& count_viral_read) {
+// names_of != nullptr: the records were put together by their keys and nobody has compared their names yet -- every record against *names_of, the first one, while it is at hand
+template <class ViralCounter> AGPU_HD void replay_group(const IngestContext& ctx, const uint32_t* records, uint32_t n_records, FragmentPlan& plain, TandemPlan& itd, GroupTally& tally, ViralCounter& count_viral_read,
+                                                        const Rec* names_of = nullptr, int64_t hit_index_of_names = 0) {
 	plan_clear(plain); plan_clear(itd.plan);
 	itd.tandem.start = 0; itd.tandem.end = 0; itd.tandem.cigar[0] = itd.tandem.cigar[1] = itd.tandem.cigar[2] = 0; itd.tandem.record = NO_RECORD;
 	itd.tandem.n_cigar = 0; itd.tandem.strand = 0; itd.tandem.first_in_pair = 0; itd.tandem.supplementary = 0;
@@ -663,6 +703,7 @@ template <class ViralCounter> AGPU_HD void replay_group(const IngestContext& ctx
 	for (uint32_t k = 0; k < n_records; ++k) {
 		const uint32_t index = records[k];
 		const Rec record = load_record(ctx.stream, index);
+		if (names_of != nullptr && k > 0 && !same_name(*names_of, hit_index_of_names, record, hit_index_of(ctx.stream, index, record))) tally.collision = 1;
 		if (record.flag & BAMF_SUPPLEMENTARY) {
 			if (is_clipped_at_correct_end(record)) plan_push(plain, index, record, true, 0, CLIP_NONE);
 			else tally.malformed++;
@@ -810,12 +851,11 @@ AGPU_HD uint32_t decimal_digits(int64_t value, char* out /* [21] */) { // std::t
 }
 
 struct FragmentName { const uint8_t* qname; uint32_t qname_length; char suffix[28]; uint32_t suffix_length; }; // suffix = "," + HI + ["ITD"]
-AGPU_HD FragmentName fragment_name(const Rec& representative, bool itd) {
+AGPU_HD FragmentName fragment_name(const Rec& representative, int64_t hit_index /* hit_index_of(representative) */, bool itd) {
 	FragmentName name;
 	name.qname = representative.name; name.qname_length = qname_length(representative);
-	const AuxTags tags = scan_aux(representative.aux, representative.end);
 	name.suffix[0] = ',';
-	name.suffix_length = 1 + decimal_digits(tags.has_hi ? tags.hi : 1, name.suffix + 1);
+	name.suffix_length = 1 + decimal_digits(hit_index, name.suffix + 1);
 	if (itd) { name.suffix[name.suffix_length++] = 'I'; name.suffix[name.suffix_length++] = 'T'; name.suffix[name.suffix_length++] = 'D'; }
 	return name;
 }
@@ -837,14 +877,14 @@ AGPU_HD int compare_names(const FragmentName& x, const FragmentName& y) {
 
 struct FragmentSizes { uint32_t cigar_words, sequence_bytes, name_length; };
 AGPU_HD uint32_t padded_sequence_bytes(uint32_t bases) { return (((bases + 1) / 2) + 3) & ~3u; } // two bases per byte, every sequence on a 4-byte boundary
-AGPU_HD void fragment_sizes(const Fragment3& f, const Rec& representative, bool itd, FragmentSizes& sizes) {
+AGPU_HD void fragment_sizes(const Fragment3& f, const Rec& representative, int64_t hit_index, bool itd, FragmentSizes& sizes) {
 	uint32_t cigar_words = 0, sequence_bytes = 0;
 	for (uint32_t s = 0; s < f.n; ++s) {
 		cigar_words += f.a[s].n_cigar;
 		if (s < 2) sequence_bytes += padded_sequence_bytes((uint32_t) f.a[s].sequence_length);
 	}
 	sizes.cigar_words = cigar_words; sizes.sequence_bytes = sequence_bytes;
-	sizes.name_length = name_length(fragment_name(representative, itd));
+	sizes.name_length = name_length(fragment_name(representative, hit_index, itd));
 }
 
 struct PackTarget {
