@@ -263,41 +263,38 @@ template <bool RUNS> __global__ void __launch_bounds__(BLOCK) AGPU_REPLAY_OCCUPA
 		const uint32_t n_records = group_count[g];
 		const Rec representative = load_record(ctx.stream, sorted_records[begin]);
 		const int64_t hit = hit_index_of(ctx.stream, sorted_records[begin], representative);
+		const uint32_t length = qname_length(representative);
 		if (RUNS) {
-			const uint32_t length = qname_length(representative);
-			bool comma = false;
-			for (uint32_t k = 0; k < length; ++k) comma |= representative.name[k] == ',';
-			if (comma) atomicOr(&counters[IC_QNAME_COMMA], 1u);
+			if (find_byte(representative.name, length, ',') < length) atomicOr(&counters[IC_QNAME_COMMA], 1u);
 			if (g == 0) qname_differs[0] = 0;
 			else {
 				const uint32_t record_before = sorted_records[group_begin[g - 1]];
 				const Rec run_before = load_record(ctx.stream, record_before);
-				bool differs = length != qname_length(run_before);
-				for (uint32_t k = 0; k < length && !differs; ++k) differs = representative.name[k] != run_before.name[k];
-				qname_differs[g] = differs;
-				if (compare_names(fragment_name(run_before, hit_index_of(ctx.stream, record_before, run_before), false), fragment_name(representative, hit, false)) >= 0) atomicOr(&counters[IC_RUNS_UNSORTED], 1u);
+				const uint32_t length_before = qname_length(run_before), shorter = length < length_before ? length : length_before, different = first_difference(run_before.name, representative.name, shorter);
+				qname_differs[g] = length != length_before || different < shorter;
+				bool unsorted;
+				if (different < shorter) unsorted = run_before.name[different] > representative.name[different]; // (the names differ inside their QNAMEs: that byte decides)
+				else unsorted = compare_names(fragment_name(run_before, hit_index_of(ctx.stream, record_before, run_before), false, length_before), fragment_name(representative, hit, false, length)) >= 0;
+				if (unsorted) atomicOr(&counters[IC_RUNS_UNSORTED], 1u);
 			}
 		}
 		FragmentPlan plain_plan; TandemPlan itd_plan;
 		ViralCounter viral = { viral_counts };
-		replay_group(ctx, sorted_records + begin, n_records, plain_plan, itd_plan, tally, viral, RUNS ? &representative : nullptr, hit);
+		replay_group(ctx, sorted_records + begin, n_records, plain_plan, itd_plan, tally, viral, RUNS ? &representative : nullptr, length, hit);
 		if (tally.collision) atomicOr(&counters[IC_COLLISION], 1u);
 		Fragment3 fragment;
-		FragmentSizes none; none.cigar_words = 0; none.sequence_bytes = 0; none.name_length = 0;
-		bool ok = false;
-		if (plain_plan.count > 0) {
-			ok = normalize_plan(ctx.stream, plain_plan, nullptr, fragment);
-			if (!ok) tally.malformed++;
+		AGPU_NOUNROLL for (uint32_t entry = 0; entry < 2; ++entry) { // the fragment of the name, then its "ITD" entry (one copy of the sanity check in the code: the kernel is 140 KB of instructions as it is)
+			const FragmentPlan& plan = entry ? itd_plan.plan : plain_plan;
+			bool ok = false;
+			if (plan.count > 0) {
+				ok = normalize_plan(ctx.stream, plan, entry ? &itd_plan.tandem : nullptr, fragment);
+				if (!ok) tally.malformed++;
+			}
+			valid[2 * (size_t) g + entry] = ok;
+			FragmentSizes mine; mine.cigar_words = 0; mine.sequence_bytes = 0; mine.name_length = 0;
+			if (ok) { if (entry) itd[g] = itd_plan; else plain[g] = plain_plan; fragment_sizes(fragment, representative, hit, entry, mine, length); }
+			sizes[2 * (size_t) g + entry] = mine;
 		}
-		valid[2 * (size_t) g] = ok;
-		if (ok) { plain[g] = plain_plan; fragment_sizes(fragment, representative, hit, false, sizes[2 * (size_t) g]); } else sizes[2 * (size_t) g] = none;
-		ok = false;
-		if (itd_plan.plan.count > 0) {
-			ok = normalize_plan(ctx.stream, itd_plan.plan, &itd_plan.tandem, fragment);
-			if (!ok) tally.malformed++;
-		}
-		valid[2 * (size_t) g + 1] = ok;
-		if (ok) { itd[g] = itd_plan; fragment_sizes(fragment, representative, hit, true, sizes[2 * (size_t) g + 1]); } else sizes[2 * (size_t) g + 1] = none;
 	}
 	block_tally(tally.malformed, &counters[IC_MALFORMED], &sums[0]);
 	block_tally(tally.chimeric, &counters[IC_CHIMERIC], &sums[1]);

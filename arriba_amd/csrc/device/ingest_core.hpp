@@ -27,6 +27,37 @@ namespace agpu {
 // ---- raw record access (SAMv1 section 4.2; little endian; fields are not aligned) ------------------------------------------------------------------
 
 AGPU_HD uint32_t load_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+AGPU_HD uint64_t load_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+// Bytes of the stream eight at a time.  A lane that walks a read name byte by byte issues one load per byte, and the 64 lanes of a wavefront stand in 64 different records: 64
+// cache lines looked up per byte.  The names of a group were walked ~550 bytes worth per read name (lengths, comparisons, the comma) -- half of the replay kernel's loads.
+// index of the first zero byte of v (byte 0 = the lowest address), 8 if it has none
+AGPU_HD uint32_t first_zero_byte(uint64_t v) { const uint64_t z = (v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull; return z ? (uint32_t) __builtin_ctzll(z) >> 3 : 8u; } // (bits above the first zero byte may be wrong, the lowest one never is)
+AGPU_HD uint64_t low_bytes(uint32_t n) { return n >= 8 ? ~0ull : (1ull << (8 * n)) - 1; } // 0xFF in the n lowest bytes
+// index of the first byte equal to `byte` among the n bytes at p, n if there is none; p[0..n) readable
+AGPU_HD uint32_t find_byte(const uint8_t* p, uint32_t n, uint8_t byte) {
+	const uint64_t pattern = 0x0101010101010101ull * byte;
+	uint32_t i = 0;
+	for (; i + 8 <= n; i += 8) { const uint32_t z = first_zero_byte(load_u64(p + i) ^ pattern); if (z < 8) return i + z; }
+	if (i == n) return n;
+	if (n >= 8) { // the last word again, the bytes seen before made non-zero
+		const uint32_t z = first_zero_byte((load_u64(p + n - 8) ^ pattern) | low_bytes(i - (n - 8)));
+		return z < 8 ? n - 8 + z : n;
+	}
+	for (; i < n; ++i) if (p[i] == byte) return i;
+	return n;
+}
+// index of the first byte in which a[0..n) and b[0..n) differ, n if they are equal
+AGPU_HD uint32_t first_difference(const uint8_t* a, const uint8_t* b, uint32_t n) {
+	uint32_t i = 0;
+	for (; i + 8 <= n; i += 8) { const uint64_t x = load_u64(a + i) ^ load_u64(b + i); if (x) return i + ((uint32_t) __builtin_ctzll(x) >> 3); }
+	if (i == n) return n;
+	if (n >= 8) {
+		const uint64_t x = (load_u64(a + n - 8) ^ load_u64(b + n - 8)) & ~low_bytes(i - (n - 8));
+		return x ? n - 8 + ((uint32_t) __builtin_ctzll(x) >> 3) : n;
+	}
+	for (; i < n; ++i) if (a[i] != b[i]) return i;
+	return n;
+}
 AGPU_HD uint16_t load_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 
 enum : uint16_t { BAMF_PAIRED = 1, BAMF_PROPER_PAIR = 2, BAMF_UNMAP = 4, BAMF_MUNMAP = 8, BAMF_REVERSE = 16, BAMF_READ1 = 64, BAMF_SECONDARY = 256, BAMF_DUP = 1024, BAMF_SUPPLEMENTARY = 2048 };
@@ -74,16 +105,17 @@ AGPU_HD bool record_sizes_ok(const uint8_t* block, uint32_t block_size) {
 
 AGPU_HD Rec load_record(const IngestStream& in, uint32_t r) {
 	const uint8_t* p = in.bytes + in.record_offset[r];
-	const uint32_t block_size = load_u32(p);
+	const uint64_t word0 = load_u64(p), word1 = load_u64(p + 8), word2 = load_u64(p + 16); // block_size, refID | pos, l_read_name mapq bin | n_cigar, flag, l_seq: three loads instead of seven
+	const uint32_t block_size = (uint32_t) word0;
 	p += 4;
 	Rec rec;
-	const int32_t tid = (int32_t) load_u32(p);
+	const int32_t tid = (int32_t) (word0 >> 32);
 	rec.contig = (tid >= 0 && (uint32_t) tid < in.n_targets) ? (int32_t) in.tid_to_contig[tid] : -1;
-	rec.pos = (int32_t) load_u32(p + 4);
-	rec.l_read_name = p[8];
-	rec.n_cigar = load_u16(p + 12);
-	rec.flag = load_u16(p + 14);
-	rec.l_seq = (int32_t) load_u32(p + 16);
+	rec.pos = (int32_t) (uint32_t) word1;
+	rec.l_read_name = (uint32_t) (word1 >> 32) & 0xFFu;
+	rec.n_cigar = (uint32_t) word2 & 0xFFFFu;
+	rec.flag = (uint16_t) (word2 >> 16);
+	rec.l_seq = (int32_t) (word2 >> 32);
 	rec.name = p + 32;
 	rec.cigar_bytes = rec.name + rec.l_read_name;
 	rec.seq_bytes = rec.cigar_bytes + 4 * (size_t) rec.n_cigar;
@@ -218,7 +250,7 @@ AGPU_HD int64_t hit_index_of(const IngestStream& in, uint32_t record, const Rec&
 // per-record verdict of the first lines of the loop body (source/read_chimeric_alignments.cpp:611-631)
 enum : uint8_t { RECORD_SKIPPED = 0, RECORD_ACTIVE = 1, RECORD_MISSING_HI = 2, RECORD_BROKEN = 3, RECORD_STATUS_MASK = 3, RECORD_HAS_SA = 4 };
 
-AGPU_HD uint32_t qname_length(const Rec& r) { uint32_t n = 0; while (n < r.l_read_name && r.name[n]) ++n; return n; }
+AGPU_HD uint32_t qname_length(const Rec& r) { return find_byte(r.name, r.l_read_name, 0); } // (the name up to its NUL, at most l_read_name bytes)
 
 // One sample over several contexts (agpu_shard_merge): no read name may have records in two parts.  Every run of records with one QNAME in the stream of a part gives
 // a 128-bit key of the QNAME (two FNV-1a passes with different offsets, finalised); equal keys anywhere in the sample -- two runs of a name in one part or in two --
@@ -247,13 +279,12 @@ AGPU_HD uint64_t name_key(const Rec& r, int64_t hit_index, uint64_t seed) {
 	h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
 	return h == ~0ull ? ~0ull - 1 : h;
 }
-AGPU_HD bool same_name(const Rec& a, int64_t hi_a, const Rec& b, int64_t hi_b) {
+AGPU_HD bool same_name(const Rec& a, uint32_t length_a /* qname_length(a) */, int64_t hi_a, const Rec& b, int64_t hi_b) {
 	if (hi_a != hi_b) return false;
-	const uint32_t n = qname_length(a);
-	if (n != qname_length(b)) return false;
-	for (uint32_t i = 0; i < n; ++i) if (a.name[i] != b.name[i]) return false;
-	return true;
+	if (length_a != qname_length(b)) return false;
+	return first_difference(a.name, b.name, length_a) == length_a;
 }
+AGPU_HD bool same_name(const Rec& a, int64_t hi_a, const Rec& b, int64_t hi_b) { return same_name(a, qname_length(a), hi_a, b, hi_b); }
 
 // ---- plans: a fragment as references into the stream ----------------------------------------------------------------------------------------------
 
@@ -297,19 +328,15 @@ struct Aln {
 	uint32_t cigar_index;
 	uint32_t patch_index[2], patch_value[2];
 	uint32_t tandem_cigar[3];
+	uint32_t made_index, made_value, shift; // the one element add_chimeric_alignment makes up when it cuts a CIGAR (the clipped rest), and where the others stand in the record's
 	uint8_t clip, n_patch;
 	bool supplementary, first_in_pair, strand;
+	// (worked out once, by materialize: this accessor is inlined at some forty places of the sanity check, and with the loop over the CIGAR that finds the length of the
+	// clipped rest inside it the check alone was 49 KB of the replay kernel's instructions)
 	AGPU_HD uint32_t base_cigar(uint32_t i) const {
-		if (clip == PLAN_TANDEM) return tandem_cigar[i];
-		if (clip == CLIP_START) {
-			if (i == 0) return (uint32_t) rec.qlen(cigar_index) << 4 | (rec.op(0) == CIGAR_H ? CIGAR_H : CIGAR_S);
-			return rec.cigar(cigar_index + i - 1);
-		}
-		if (clip == CLIP_END) {
-			if (i == cigar_index + 1) return (uint32_t) (rec.l_seq - rec.qlen(cigar_index + 1)) << 4 | (rec.op(rec.n_cigar - 1) == CIGAR_H ? CIGAR_H : CIGAR_S);
-			return rec.cigar(i);
-		}
-		return rec.cigar(i);
+		if (clip == PLAN_TANDEM) return i == 0 ? tandem_cigar[0] : i == 1 ? tandem_cigar[1] : tandem_cigar[2];
+		if (i == made_index) return made_value;
+		return rec.cigar(i + shift);
 	}
 	AGPU_HD uint32_t cigar(uint32_t i) const {
 		uint32_t value = base_cigar(i);
@@ -329,6 +356,7 @@ AGPU_HD Aln materialize(const IngestStream& in, const PlanEntry& e, const Tandem
 	a.n_patch = 0; a.patch_index[0] = a.patch_index[1] = 0; a.patch_value[0] = a.patch_value[1] = 0;
 	a.tandem_cigar[0] = a.tandem_cigar[1] = a.tandem_cigar[2] = 0;
 	a.clip = e.clip; a.cigar_index = e.cigar_index;
+	a.made_index = NO_RECORD; a.made_value = 0; a.shift = 0;
 	if (e.clip == PLAN_TANDEM) {
 		a.rec = load_record(in, tandem->record);
 		a.record = NO_RECORD;
@@ -349,9 +377,12 @@ AGPU_HD Aln materialize(const IngestStream& in, const PlanEntry& e, const Tandem
 	if (e.clip == CLIP_START) {
 		a.start = r.pos + r.rlen(e.cigar_index); a.end = r.endpos() - 1;
 		a.n_cigar = r.n_cigar - e.cigar_index + 1;
+		a.made_index = 0; a.made_value = (uint32_t) r.qlen(e.cigar_index) << 4 | (r.op(0) == CIGAR_H ? CIGAR_H : CIGAR_S); // element i >= 1 is the record's cigar_index + i - 1
+		a.shift = (uint32_t) e.cigar_index - 1u;
 	} else if (e.clip == CLIP_END) {
 		a.start = r.pos; a.end = r.pos + r.rlen((uint32_t) e.cigar_index + 1) - 1;
 		a.n_cigar = (uint32_t) e.cigar_index + 2;
+		a.made_index = (uint32_t) e.cigar_index + 1; a.made_value = (uint32_t) (r.l_seq - r.qlen((uint32_t) e.cigar_index + 1)) << 4 | (r.op(r.n_cigar - 1) == CIGAR_H ? CIGAR_H : CIGAR_S);
 	} else {
 		a.start = r.pos; a.end = r.endpos() - 1;
 		a.n_cigar = r.n_cigar;
@@ -404,7 +435,16 @@ AGPU_HD bool clipped_sequence_is_adapter(const Rec& mate1, const Rec* mate2) {
 	return false;
 }
 
-AGPU_HD char base_character(uint32_t code) { return "=ACMGRSVTWYHKDBN"[code]; }
+// "=ACMGRSVTWYHKDBN"[code] without a table in memory: the sixteen characters in two words
+AGPU_HD char base_character(uint32_t code) {
+	const uint64_t low = 0x565352474D43413Dull /* "=ACMGRSV" */, high = 0x4E42444B48595754ull /* "TWYHKDBN" */;
+	return (char) (((code & 8) ? high : low) >> (8 * (code & 7)));
+}
+// one bit per byte of x that is not zero (bit i = byte i, the lowest address first)
+AGPU_HD uint32_t nonzero_bytes(uint64_t x) {
+	const uint64_t high = (x | ((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full)) & 0x8080808080808080ull;
+	return (uint32_t) (((high >> 7) * 0x0102040810204080ull) >> 56);
+}
 
 // reference: source/read_chimeric_alignments.cpp:215-336 (integer types as there: its mixed signed/unsigned arithmetic is part of the result)
 AGPU_HD bool is_tandem_duplication(const Rec* r, uint32_t record, const GenomeView& genome, const uint32_t max_itd_length, TandemAlignment& tandem) {
@@ -450,7 +490,34 @@ AGPU_HD bool is_tandem_duplication(const Rec* r, uint32_t record, const GenomeVi
 				extended_matches++;
 	if (1.0 * extended_matches / clipped_length >= min_extended_align_fraction) return false;
 
+	// The window is ~90 positions, and at each the loop below compares bases until the second mismatch behind the sixth base: ~9 bases, two loads each (a character of the
+	// contig, a nibble of the read) -- 1 600 loads per clipped read, most of what the whole replay kernel loads.  The first sixteen bases of the clipped segment in the order of
+	// that loop are therefore kept in two words, the sixteen characters of the contig they would meet are two loads per position, and where the second counted mismatch lies among
+	// them (all but none of the positions) the outcome of the loop is known: it breaks there with fewer than min_alignment_length matches, so the position is a hit only if
+	// matches + 2 == clipped_length -- if that cannot be, on to the next position; everything else goes through the loop as before.
+	const unsigned int held = clipped_length < 16 ? clipped_length : 16;
+	uint64_t read_low = 0, read_high = 0;
+	for (unsigned int i = 0; i < held; ++i) {
+		const int read_pos = (direction == +1) ? (int) i : (int) (clipped_length - 1 - i);
+		const uint64_t character = (uint8_t) base_character(r->code((int32_t) clipped_position + read_pos));
+		if (i < 8) read_low |= character << (8 * i); else read_high |= character << (8 * (i - 8));
+	}
+	const uint32_t held_bits = (1u << held) - 1;
 	for (int contig_pos = window_start; contig_pos <= window_end; ++contig_pos) {
+		if (max_mismatches == 1 && max_non_template_bases == 6) {
+			uint64_t contig_low, contig_high; // the characters of the contig that scan positions 0-7 and 8-15 meet
+			if (direction == +1) { contig_low = load_u64((const uint8_t*) contig_sequence + contig_pos); contig_high = load_u64((const uint8_t*) contig_sequence + contig_pos + 8); }
+			else {
+				const uint8_t* last = (const uint8_t*) contig_sequence + contig_pos + (int) clipped_length - 1;
+				contig_low = __builtin_bswap64(load_u64(last - 7)); contig_high = __builtin_bswap64(load_u64(last - 15));
+			}
+			const uint32_t differs = (nonzero_bytes(contig_low ^ read_low) | nonzero_bytes(contig_high ^ read_high) << 8) & held_bits;
+			const uint32_t counted = differs & ~0x3Fu, second = counted & (counted - 1);
+			if (second != 0) { // the loop would break at the second counted mismatch
+				const uint32_t at = (uint32_t) __builtin_ctz(second);
+				if ((uint32_t) __builtin_popcount(~differs & ((1u << at) - 1)) + 2 != clipped_length) continue;
+			}
+		}
 		unsigned int matches = 0, mismatches = 0;
 		int tandem_start = (int) contig_size, tandem_end = -1;
 		for (unsigned int i = 0; i < clipped_length; i++) {
@@ -695,7 +762,7 @@ struct GroupTally { uint32_t malformed; uint32_t chimeric; uint32_t collision; }
 // viral_reads[contig] += pristine reads (64-bit counters).
 // names_of != nullptr: the records were put together by their keys and nobody has compared their names yet -- every record against *names_of, the first one, while it is at hand
 template <class ViralCounter> AGPU_HD void replay_group(const IngestContext& ctx, const uint32_t* records, uint32_t n_records, FragmentPlan& plain, TandemPlan& itd, GroupTally& tally, ViralCounter& count_viral_read,
-                                                        const Rec* names_of = nullptr, int64_t hit_index_of_names = 0) {
+                                                        const Rec* names_of = nullptr, uint32_t length_of_names = 0 /* qname_length(*names_of) */, int64_t hit_index_of_names = 0) {
 	plan_clear(plain); plan_clear(itd.plan);
 	itd.tandem.start = 0; itd.tandem.end = 0; itd.tandem.cigar[0] = itd.tandem.cigar[1] = itd.tandem.cigar[2] = 0; itd.tandem.record = NO_RECORD;
 	itd.tandem.n_cigar = 0; itd.tandem.strand = 0; itd.tandem.first_in_pair = 0; itd.tandem.supplementary = 0;
@@ -703,53 +770,57 @@ template <class ViralCounter> AGPU_HD void replay_group(const IngestContext& ctx
 	for (uint32_t k = 0; k < n_records; ++k) {
 		const uint32_t index = records[k];
 		const Rec record = load_record(ctx.stream, index);
-		if (names_of != nullptr && k > 0 && !same_name(*names_of, hit_index_of_names, record, hit_index_of(ctx.stream, index, record))) tally.collision = 1;
+		if (names_of != nullptr && k > 0 && !same_name(*names_of, length_of_names, hit_index_of_names, record, hit_index_of(ctx.stream, index, record))) tally.collision = 1;
 		if (record.flag & BAMF_SUPPLEMENTARY) {
 			if (is_clipped_at_correct_end(record)) plan_push(plain, index, record, true, 0, CLIP_NONE);
 			else tally.malformed++;
 			tally.chimeric = 1;
 			continue;
 		}
-		if ((record.flag & BAMF_PAIRED) && !(record.flag & BAMF_PROPER_PAIR)) { // discordant mate
-			plan_push(plain, index, record, false, 0, CLIP_NONE);
-			tally.chimeric = 1;
-			if (!ctx.external_duplicate_marking || !(record.flag & BAMF_DUP)) add_fragment_to_coverage(ctx.coverage, record, 0 /* the reference zeroes the flag word */, nullptr, true);
-			continue;
-		}
+		// (every function of the loop body is called from one place: each call site is a copy of the function in the kernel, which is 90 KB of instructions as it is)
 		uint32_t previous_index = NO_RECORD;
 		Rec previous_storage;
 		const Rec* previous = nullptr;
-		if (record.flag & BAMF_PAIRED) {
-			if (parked == NO_RECORD) { parked = index; continue; }
-			previous_index = parked; parked = NO_RECORD;
-			previous_storage = load_record(ctx.stream, previous_index);
-			previous = &previous_storage;
-		}
-		bool is_tandem_alignment = false;
-		if (!clipped_sequence_is_adapter(record, previous) && (previous == nullptr || record.forward() != previous->forward())) {
-			TandemAlignment tandem;
-			if (is_tandem_duplication(&record, index, ctx.genome, ctx.max_itd_length, tandem) || is_tandem_duplication(previous, previous_index, ctx.genome, ctx.max_itd_length, tandem)) {
-				plan_push(itd.plan, index, record, record.forward() == (bool) tandem.strand && !tandem.supplementary, 0, CLIP_NONE);
-				if (previous != nullptr) plan_push(itd.plan, previous_index, *previous, previous->forward() == (bool) tandem.strand && !tandem.supplementary, 0, CLIP_NONE);
-				if (itd.plan.count < 3) itd.tandem = tandem; // (a fourth alignment makes the fragment malformed whatever it is)
-				plan_push_tandem(itd.plan);
-				is_tandem_alignment = true;
-			}
-		}
 		bool is_read_through = false;
-		const bool record_has_sa = ctx.record_bits[index] & RECORD_HAS_SA, previous_has_sa = previous != nullptr && (ctx.record_bits[previous_index] & RECORD_HAS_SA);
-		if ((record_has_sa && is_clipped_at_correct_end(record)) || (previous_has_sa && is_clipped_at_correct_end(*previous))) {
+		uint16_t coverage_flag = record.flag;
+		const bool discordant_mate = (record.flag & BAMF_PAIRED) && !(record.flag & BAMF_PROPER_PAIR);
+		if (discordant_mate) {
 			plan_push(plain, index, record, false, 0, CLIP_NONE);
-			if (previous != nullptr) plan_push(plain, previous_index, *previous, false, 0, CLIP_NONE);
 			tally.chimeric = 1;
-		} else if (!is_tandem_alignment) {
-			is_read_through = extract_read_through_alignment(plain, index, record, previous_index, previous, ctx.annotation);
-			if (record.contig >= 0 && (ctx.genome.contig_bits[record.contig] & CBIT_VIRAL)) {
-				if (is_pristine_alignment(record)) count_viral_read((uint32_t) record.contig);
-				if (previous != nullptr && is_pristine_alignment(*previous)) count_viral_read((uint32_t) previous->contig);
+			coverage_flag = 0; is_read_through = true; // (the reference zeroes the flag word and passes is_chimeric = true)
+		} else {
+			if (record.flag & BAMF_PAIRED) {
+				if (parked == NO_RECORD) { parked = index; continue; }
+				previous_index = parked; parked = NO_RECORD;
+				previous_storage = load_record(ctx.stream, previous_index);
+				previous = &previous_storage;
+			}
+			bool is_tandem_alignment = false;
+			if (!clipped_sequence_is_adapter(record, previous) && (previous == nullptr || record.forward() != previous->forward())) {
+				TandemAlignment tandem;
+				bool found = false;
+				AGPU_NOUNROLL for (uint32_t mate = 0; mate < 2 && !found; ++mate) found = is_tandem_duplication(mate ? previous : &record, mate ? previous_index : index, ctx.genome, ctx.max_itd_length, tandem);
+				if (found) {
+					plan_push(itd.plan, index, record, record.forward() == (bool) tandem.strand && !tandem.supplementary, 0, CLIP_NONE);
+					if (previous != nullptr) plan_push(itd.plan, previous_index, *previous, previous->forward() == (bool) tandem.strand && !tandem.supplementary, 0, CLIP_NONE);
+					if (itd.plan.count < 3) itd.tandem = tandem; // (a fourth alignment makes the fragment malformed whatever it is)
+					plan_push_tandem(itd.plan);
+					is_tandem_alignment = true;
+				}
+			}
+			const bool record_has_sa = ctx.record_bits[index] & RECORD_HAS_SA, previous_has_sa = previous != nullptr && (ctx.record_bits[previous_index] & RECORD_HAS_SA);
+			if ((record_has_sa && is_clipped_at_correct_end(record)) || (previous_has_sa && is_clipped_at_correct_end(*previous))) {
+				plan_push(plain, index, record, false, 0, CLIP_NONE);
+				if (previous != nullptr) plan_push(plain, previous_index, *previous, false, 0, CLIP_NONE);
+				tally.chimeric = 1;
+			} else if (!is_tandem_alignment) {
+				is_read_through = extract_read_through_alignment(plain, index, record, previous_index, previous, ctx.annotation);
+				if (record.contig >= 0 && (ctx.genome.contig_bits[record.contig] & CBIT_VIRAL)) {
+					AGPU_NOUNROLL for (uint32_t mate = 0; mate < 2; ++mate) { const Rec* read = mate ? previous : &record; if (read != nullptr && is_pristine_alignment(*read)) count_viral_read((uint32_t) read->contig); }
+				}
 			}
 		}
-		if (!ctx.external_duplicate_marking || !(record.flag & BAMF_DUP)) add_fragment_to_coverage(ctx.coverage, record, record.flag, previous, is_read_through);
+		if (!ctx.external_duplicate_marking || !(record.flag & BAMF_DUP)) add_fragment_to_coverage(ctx.coverage, record, coverage_flag, previous, is_read_through);
 	}
 }
 
@@ -851,9 +922,10 @@ AGPU_HD uint32_t decimal_digits(int64_t value, char* out /* [21] */) { // std::t
 }
 
 struct FragmentName { const uint8_t* qname; uint32_t qname_length; char suffix[28]; uint32_t suffix_length; }; // suffix = "," + HI + ["ITD"]
-AGPU_HD FragmentName fragment_name(const Rec& representative, int64_t hit_index /* hit_index_of(representative) */, bool itd) {
+const uint32_t LENGTH_UNKNOWN = 0xFFFFFFFFu;
+AGPU_HD FragmentName fragment_name(const Rec& representative, int64_t hit_index /* hit_index_of(representative) */, bool itd, uint32_t length = LENGTH_UNKNOWN /* qname_length(representative), where the caller has it */) {
 	FragmentName name;
-	name.qname = representative.name; name.qname_length = qname_length(representative);
+	name.qname = representative.name; name.qname_length = length != LENGTH_UNKNOWN ? length : qname_length(representative);
 	name.suffix[0] = ',';
 	name.suffix_length = 1 + decimal_digits(hit_index, name.suffix + 1);
 	if (itd) { name.suffix[name.suffix_length++] = 'I'; name.suffix[name.suffix_length++] = 'T'; name.suffix[name.suffix_length++] = 'D'; }
@@ -869,7 +941,9 @@ AGPU_HD uint64_t name_chunk(const FragmentName& name, uint32_t chunk) {
 }
 AGPU_HD int compare_names(const FragmentName& x, const FragmentName& y) {
 	const uint32_t nx = name_length(x), ny = name_length(y), n = nx < ny ? nx : ny;
-	for (uint32_t i = 0; i < n; ++i) { const uint8_t cx = name_byte(x, i), cy = name_byte(y, i); if (cx != cy) return cx < cy ? -1 : 1; }
+	const uint32_t qnames = x.qname_length < y.qname_length ? x.qname_length : y.qname_length, different = first_difference(x.qname, y.qname, qnames); // as far as both are QNAME: eight bytes at a time
+	if (different < qnames) return x.qname[different] < y.qname[different] ? -1 : 1;
+	for (uint32_t i = qnames; i < n; ++i) { const uint8_t cx = name_byte(x, i), cy = name_byte(y, i); if (cx != cy) return cx < cy ? -1 : 1; }
 	return nx < ny ? -1 : nx > ny ? 1 : 0;
 }
 
@@ -877,14 +951,14 @@ AGPU_HD int compare_names(const FragmentName& x, const FragmentName& y) {
 
 struct FragmentSizes { uint32_t cigar_words, sequence_bytes, name_length; };
 AGPU_HD uint32_t padded_sequence_bytes(uint32_t bases) { return (((bases + 1) / 2) + 3) & ~3u; } // two bases per byte, every sequence on a 4-byte boundary
-AGPU_HD void fragment_sizes(const Fragment3& f, const Rec& representative, int64_t hit_index, bool itd, FragmentSizes& sizes) {
+AGPU_HD void fragment_sizes(const Fragment3& f, const Rec& representative, int64_t hit_index, bool itd, FragmentSizes& sizes, uint32_t length = LENGTH_UNKNOWN /* qname_length(representative) */) {
 	uint32_t cigar_words = 0, sequence_bytes = 0;
 	for (uint32_t s = 0; s < f.n; ++s) {
 		cigar_words += f.a[s].n_cigar;
 		if (s < 2) sequence_bytes += padded_sequence_bytes((uint32_t) f.a[s].sequence_length);
 	}
 	sizes.cigar_words = cigar_words; sizes.sequence_bytes = sequence_bytes;
-	sizes.name_length = name_length(fragment_name(representative, hit_index, itd));
+	sizes.name_length = name_length(fragment_name(representative, hit_index, itd, length));
 }
 
 struct PackTarget {
@@ -938,7 +1012,10 @@ AGPU_HD uint32_t write_fragment(const IngestStream& in, const Fragment3& f, cons
 	}
 	out.name_offset[i] = name_at;
 	const uint32_t length = name_length(name);
-	for (uint32_t k = 0; k < length; ++k) out.names[name_at + k] = (char) name_byte(name, k);
+	uint32_t copied = 0; // the QNAME eight bytes at a time (the neighbours of the name in the pool belong to other fragments: only whole words inside it)
+	for (; copied + 8 <= name.qname_length; copied += 8) { const uint64_t word = load_u64(name.qname + copied); __builtin_memcpy(out.names + name_at + copied, &word, 8); }
+	for (uint32_t k = copied; k < name.qname_length; ++k) out.names[name_at + k] = (char) name.qname[k];
+	for (uint32_t k = name.qname_length; k < length; ++k) out.names[name_at + k] = (char) name_byte(name, k);
 	return longest;
 }
 

@@ -1,0 +1,215 @@
+// tests/emu/words_check.cpp -- TEST ONLY: the word-wise byte helpers of arriba_amd/csrc/device/ingest_core.hpp (find_byte, first_difference, qname_length, same_name,
+// compare_names, the three-word load_record) against their byte-by-byte definitions, on random buffers of every length and alignment.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include "../../arriba_amd/csrc/device/filter_core.hpp"
+#include "../../arriba_amd/csrc/device/ingest_core.hpp"
+using namespace agpu;
+
+static int failures = 0;
+#define CHECK(condition, ...) do { if (!(condition)) { if (++failures < 20) { printf("FAILED %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+
+static uint32_t naive_find(const uint8_t* p, uint32_t n, uint8_t byte) { for (uint32_t i = 0; i < n; ++i) if (p[i] == byte) return i; return n; }
+static uint32_t naive_difference(const uint8_t* a, const uint8_t* b, uint32_t n) { for (uint32_t i = 0; i < n; ++i) if (a[i] != b[i]) return i; return n; }
+
+// a BAM record with this name (l_read_name = name + NUL [+ padding NULs]), one CIGAR element, no sequence
+static std::vector<uint8_t> record_with(const std::string& name, uint32_t padding, int32_t tid, int32_t pos, uint16_t flag) {
+	std::vector<uint8_t> r(36 + name.size() + 1 + padding + 4, 0);
+	const uint32_t block_size = (uint32_t) r.size() - 4, l_read_name = (uint32_t) name.size() + 1 + padding;
+	memcpy(&r[0], &block_size, 4); memcpy(&r[4], &tid, 4); memcpy(&r[8], &pos, 4); r[12] = (uint8_t) l_read_name; r[13] = 7; r[14] = 0x12; r[15] = 0x34;
+	const uint16_t n_cigar = 1; memcpy(&r[16], &n_cigar, 2); memcpy(&r[18], &flag, 2);
+	const int32_t l_seq = 0; memcpy(&r[20], &l_seq, 4);
+	memcpy(&r[36], name.data(), name.size());
+	const uint32_t cigar = 50u << 4; memcpy(&r[36 + l_read_name], &cigar, 4);
+	return r;
+}
+
+// is_tandem_duplication as it stood before the short cut over the first sixteen bases (the restatement of source/read_chimeric_alignments.cpp:215-336, base by base)
+static bool is_tandem_duplication_as_written(const Rec* r, uint32_t record, const GenomeView& genome, const uint32_t max_itd_length, TandemAlignment& tandem) {
+	const unsigned int min_clipped_length = 12, min_duplication_length = 9, max_duplication_length = max_itd_length;
+	const unsigned int max_mismatches = 1, max_non_template_bases = 6, min_alignment_length = 15;
+	if (r == nullptr || r->n_cigar == 0) return false;
+	unsigned int clipped_length = 0, clipped_position = 0;
+	bool clipped_start = true;
+	int direction = +1, window_start = 0, window_end = 0, extended_read_start = 0;
+	if (r->op(0) == CIGAR_S && r->len(0) >= min_clipped_length) {
+		clipped_length = r->len(0);
+		clipped_position = 0;
+		direction = -1;
+		window_start = r->pos + min_duplication_length - clipped_length;
+		window_end = r->pos + max_duplication_length - clipped_length;
+		extended_read_start = r->pos - clipped_length;
+		clipped_start = true;
+	}
+	if (r->op(r->n_cigar - 1) == CIGAR_S && r->len(r->n_cigar - 1) >= (min_clipped_length > clipped_length ? min_clipped_length : clipped_length)) {
+		clipped_length = r->len(r->n_cigar - 1);
+		clipped_position = r->l_seq - clipped_length;
+		direction = +1;
+		window_start = r->endpos() - max_duplication_length;
+		window_end = r->endpos() - min_duplication_length;
+		extended_read_start = r->endpos();
+		clipped_start = false;
+	}
+	if (clipped_length == 0) return false;
+	if (r->contig < 0 || (uint32_t) r->contig >= genome.n_contigs) return false;
+	const uint64_t contig_begin = genome.contig_offset[r->contig];
+	const uint64_t contig_size = genome.contig_offset[r->contig + 1] - contig_begin; // size_t in the reference
+	if (contig_size == 0) return false; // assembly.has()
+	const char* contig_sequence = genome.bases + contig_begin;
+	if ((uint64_t) (unsigned int) (window_end + max_duplication_length + clipped_length + 1) >= contig_size ||
+	    window_start <= (int) (max_duplication_length + clipped_length + 1))
+		return false;
+
+	const float min_extended_align_fraction = 0.7;
+	unsigned int extended_matches = 0;
+	for (unsigned int read_pos = 0; read_pos < clipped_length; ++read_pos)
+		if ((uint64_t) (unsigned int) (extended_read_start + read_pos) < contig_size)
+			if (contig_sequence[(unsigned int) (extended_read_start + read_pos)] == base_character(r->code((int32_t) (clipped_position + read_pos))))
+				extended_matches++;
+	if (1.0 * extended_matches / clipped_length >= min_extended_align_fraction) return false;
+
+	for (int contig_pos = window_start; contig_pos <= window_end; ++contig_pos) {
+		unsigned int matches = 0, mismatches = 0;
+		int tandem_start = (int) contig_size, tandem_end = -1;
+		for (unsigned int i = 0; i < clipped_length; i++) {
+			const int read_pos = (direction == +1) ? (int) i : (int) (clipped_length - 1 - i);
+			if (contig_sequence[contig_pos + read_pos] == base_character(r->code((int32_t) clipped_position + read_pos))) {
+				matches++;
+				if (contig_pos + read_pos < tandem_start) tandem_start = contig_pos + read_pos;
+				if (contig_pos + read_pos > tandem_end) tandem_end = contig_pos + read_pos;
+			} else if (i >= max_non_template_bases) {
+				mismatches++;
+				if (mismatches > max_mismatches) break;
+			}
+		}
+		if (matches >= min_alignment_length || matches + mismatches == clipped_length) {
+			tandem.start = tandem_start; tandem.end = tandem_end;
+			tandem.record = record;
+			tandem.strand = r->forward();
+			tandem.first_in_pair = (r->flag & BAMF_READ1) != 0;
+			tandem.supplementary = !(r->flag & BAMF_PAIRED) || (clipped_start && r->forward()) || (!clipped_start && !r->forward());
+			uint32_t clip_left = clipped_start ? 0 : r->l_seq - clipped_length;
+			uint32_t clip_right = clipped_start ? r->l_seq - clipped_length : 0;
+			if (tandem_start > contig_pos) clip_left += tandem_start - contig_pos;
+			if (tandem_end < contig_pos + (int) clipped_length - 1) clip_right += contig_pos + clipped_length - 1 - tandem_end;
+			tandem.n_cigar = 0;
+			tandem.cigar[0] = tandem.cigar[1] = tandem.cigar[2] = 0;
+			if (clip_left > 0) tandem.cigar[tandem.n_cigar++] = clip_left << 4 | CIGAR_S;
+			tandem.cigar[tandem.n_cigar++] = (uint32_t) (tandem_end - tandem_start + 1) << 4 | CIGAR_M;
+			if (clip_right > 0) tandem.cigar[tandem.n_cigar++] = clip_right << 4 | CIGAR_S;
+			return true;
+		}
+	}
+	return false;
+}
+
+// a record with CIGAR elements and bases (codes 1 2 4 8 15 = A C G T N)
+static std::vector<uint8_t> record_with_bases(const std::vector<uint32_t>& cigar, const std::vector<uint8_t>& codes, int32_t tid, int32_t pos, uint16_t flag) {
+	const std::string name = "r";
+	const uint32_t l_read_name = 2, l_seq = (uint32_t) codes.size();
+	std::vector<uint8_t> r(36 + l_read_name + 4 * cigar.size() + (l_seq + 1) / 2 + l_seq, 0);
+	const uint32_t block_size = (uint32_t) r.size() - 4;
+	memcpy(&r[0], &block_size, 4); memcpy(&r[4], &tid, 4); memcpy(&r[8], &pos, 4); r[12] = (uint8_t) l_read_name;
+	const uint16_t n_cigar = (uint16_t) cigar.size(); memcpy(&r[16], &n_cigar, 2); memcpy(&r[18], &flag, 2); memcpy(&r[20], &l_seq, 4);
+	r[36] = 'r';
+	memcpy(&r[36 + l_read_name], cigar.data(), 4 * cigar.size());
+	uint8_t* seq = &r[36 + l_read_name + 4 * cigar.size()];
+	for (uint32_t i = 0; i < l_seq; ++i) seq[i >> 1] |= (uint8_t) (codes[i] << ((~i & 1) << 2));
+	return r;
+}
+static uint8_t code_of(char base) { return base == 'A' ? 1 : base == 'C' ? 2 : base == 'G' ? 4 : base == 'T' ? 8 : 15; }
+
+int main() {
+	std::mt19937_64 random(20260927);
+	// find_byte / first_difference: every length 0..40, every offset 0..8 into the buffer, few distinct byte values so that hits are frequent
+	for (int trial = 0; trial < 200000; ++trial) {
+		const uint32_t n = random() % 41, offset = random() % 9, alphabet = 1 + random() % 4;
+		std::vector<uint8_t> a(offset + n + 16), b(offset + n + 16);
+		for (auto& x : a) x = (uint8_t) (random() % alphabet);
+		b = a;
+		if (n > 0 && random() % 2) b[offset + random() % n] ^= (uint8_t) (1 + random() % 3);
+		for (size_t k = offset + n; k < b.size(); ++k) b[k] = (uint8_t) random(); // what lies behind the n bytes must not matter
+		const uint8_t byte = (uint8_t) (random() % alphabet);
+		CHECK(find_byte(a.data() + offset, n, byte) == naive_find(a.data() + offset, n, byte), "find_byte n=%u offset=%u", n, offset);
+		CHECK(first_difference(a.data() + offset, b.data() + offset, n) == naive_difference(a.data() + offset, b.data() + offset, n), "first_difference n=%u offset=%u", n, offset);
+	}
+	// first_zero_byte: all positions, with bytes of 0x01 and 0x80 around (the classic false positives of the zero-byte trick lie above the first zero only)
+	for (int trial = 0; trial < 200000; ++trial) {
+		uint64_t v = 0;
+		for (int k = 0; k < 8; ++k) { static const uint8_t kinds[] = { 0x00, 0x01, 0x80, 0x7F, 0xFF, 0x2C }; v |= (uint64_t) kinds[random() % 6] << (8 * k); }
+		uint32_t expected = 8;
+		for (int k = 7; k >= 0; --k) if (((v >> (8 * k)) & 0xFF) == 0) expected = (uint32_t) k;
+		CHECK(first_zero_byte(v) == expected, "first_zero_byte %016llx", (unsigned long long) v);
+	}
+	// records: load_record's fields, qname_length, same_name, compare_names against std::string
+	for (int trial = 0; trial < 100000; ++trial) {
+		auto make_name = [&](uint32_t length) { std::string s; for (uint32_t k = 0; k < length; ++k) s += (char) ("AB,:/0"[random() % 6]); return s; };
+		std::string x = make_name(1 + random() % 40), y = random() % 3 == 0 ? x : make_name(1 + random() % 40);
+		if (random() % 4 == 0) y = x.substr(0, 1 + random() % x.size()); // a prefix
+		const int32_t tid_x = (int32_t) (random() % 5) - 1, pos_x = (int32_t) (random() % 1000000) - 1; const uint16_t flag_x = (uint16_t) random();
+		const std::vector<uint8_t> rx = record_with(x, random() % 3, tid_x, pos_x, flag_x), ry = record_with(y, random() % 3, 1, 5, 0);
+		std::vector<uint8_t> stream(rx); stream.insert(stream.end(), ry.begin(), ry.end()); stream.resize(stream.size() + 16, 0xEE);
+		const uint64_t offsets[2] = { 0, rx.size() };
+		const uint32_t tid_to_contig[4] = { 10, 11, 12, 13 };
+		IngestStream in; in.bytes = stream.data(); in.size = stream.size(); in.record_offset = offsets; in.n_records = 2; in.n_targets = 4; in.tid_to_contig = tid_to_contig; in.hit_index = nullptr;
+		const Rec a = load_record(in, 0), b = load_record(in, 1);
+		CHECK(a.pos == pos_x && a.flag == flag_x && a.n_cigar == 1 && a.l_seq == 0 && a.contig == (tid_x >= 0 ? 10 + tid_x : -1) && a.cigar(0) == (50u << 4), "load_record");
+		CHECK(qname_length(a) == x.size() && qname_length(b) == y.size(), "qname_length %zu %zu", x.size(), y.size());
+		const int64_t hi_x = 1 + (int64_t) (random() % 3), hi_y = 1 + (int64_t) (random() % 3);
+		CHECK(same_name(a, hi_x, b, hi_y) == (x == y && hi_x == hi_y), "same_name");
+		for (int itd_x = 0; itd_x < 2; ++itd_x) for (int itd_y = 0; itd_y < 2; ++itd_y) {
+			const std::string full_x = x + "," + std::to_string(hi_x) + (itd_x ? "ITD" : ""), full_y = y + "," + std::to_string(hi_y) + (itd_y ? "ITD" : "");
+			const int expected = full_x.compare(full_y) < 0 ? -1 : full_x.compare(full_y) > 0 ? 1 : 0;
+			CHECK(compare_names(fragment_name(a, hi_x, itd_x), fragment_name(b, hi_y, itd_y, (uint32_t) y.size())) == expected, "compare_names '%s' '%s'", full_x.c_str(), full_y.c_str());
+		}
+	}
+	// is_tandem_duplication: the short cut against the loop as written -- random contigs (a small alphabet, so that chance hits happen), clipped reads whose clipped bases are
+	// random, a copy of the contig nearby (a real tandem duplication) or such a copy with a few changed bases; clips of 12..40 bases at either end; both strands
+	{
+		uint64_t hits = 0, calls = 0;
+		for (int trial = 0; trial < 60000; ++trial) {
+			const uint32_t contig_length = 2000, alphabet = 2 + random() % 3;
+			std::string contig(contig_length, 'A');
+			for (auto& c : contig) c = "ACGTN"[random() % alphabet];
+			const uint32_t max_itd_length = 9 + random() % 120;
+			const uint32_t clip = 12 + random() % 29, aligned = 30 + random() % 40;
+			const bool clipped_start = random() % 2;
+			const int32_t pos = 400 + (int32_t) (random() % 1000);
+			std::vector<uint32_t> cigar;
+			if (clipped_start) cigar.push_back(clip << 4 | CIGAR_S);
+			cigar.push_back(aligned << 4 | CIGAR_M);
+			if (!clipped_start) cigar.push_back(clip << 4 | CIGAR_S);
+			if (random() % 8 == 0) cigar.insert(cigar.begin() + (clipped_start ? 1 : 0), (uint32_t) (5u << 4 | CIGAR_M)), cigar.insert(cigar.begin() + (clipped_start ? 2 : 1), (uint32_t) (50u << 4 | CIGAR_N));
+			std::vector<uint8_t> codes(clip + aligned + (cigar.size() > 3 ? 5 : 0));
+			for (auto& c : codes) c = code_of("ACGTN"[random() % alphabet]);
+			// the clipped bases: random, or the contig from somewhere inside the window the function searches, with 0-3 bases changed
+			const uint32_t kind = random() % 3;
+			if (kind > 0) {
+				const int32_t end = pos + (int32_t) aligned + (cigar.size() > 3 ? 55 : 0);
+				const int32_t from = clipped_start ? pos + 9 - (int32_t) clip + (int32_t) (random() % (max_itd_length + 1)) : end - (int32_t) max_itd_length + (int32_t) (random() % (max_itd_length + 1));
+				for (uint32_t k = 0; k < clip; ++k) { const int32_t at = from + (int32_t) k; if (at >= 0 && at < (int32_t) contig_length) codes[(clipped_start ? 0 : codes.size() - clip) + k] = code_of(contig[at]); }
+				for (uint32_t changes = kind == 2 ? random() % 4 : 0; changes > 0; --changes) codes[(clipped_start ? 0 : codes.size() - clip) + random() % clip] = code_of("ACGT"[random() % 4]);
+			}
+			const uint16_t flag = (uint16_t) ((random() % 2 ? BAMF_REVERSE : 0) | (random() % 2 ? BAMF_PAIRED | BAMF_PROPER_PAIR : 0) | (random() % 2 ? BAMF_READ1 : 0));
+			std::vector<uint8_t> stream = record_with_bases(cigar, codes, 0, pos, flag);
+			stream.resize(stream.size() + 16, 0);
+			const uint64_t offsets[1] = { 0 }; const uint32_t tid_to_contig[1] = { 0 };
+			IngestStream in; in.bytes = stream.data(); in.size = stream.size(); in.record_offset = offsets; in.n_records = 1; in.n_targets = 1; in.tid_to_contig = tid_to_contig; in.hit_index = nullptr;
+			const Rec r = load_record(in, 0);
+			const uint64_t contig_offset[2] = { 0, contig_length }; const uint8_t contig_bits[1] = { 0 };
+			GenomeView genome; genome.n_contigs = 1; genome.contig_offset = contig_offset; genome.contig_bits = contig_bits; genome.bases = contig.data();
+			TandemAlignment x, y; memset(&x, 0, sizeof(x)); memset(&y, 0, sizeof(y));
+			const bool found_x = is_tandem_duplication(&r, 7, genome, max_itd_length, x), found_y = is_tandem_duplication_as_written(&r, 7, genome, max_itd_length, y);
+			++calls; hits += found_y;
+			CHECK(found_x == found_y && (!found_y || memcmp(&x, &y, sizeof(x)) == 0), "is_tandem_duplication: clip %u at the %s, max_itd_length %u: %d vs %d", clip, clipped_start ? "start" : "end", max_itd_length, (int) found_x, (int) found_y);
+		}
+		CHECK(hits > calls / 20 && hits < calls - calls / 20, "is_tandem_duplication was to be tried on hits and misses alike: %llu hits of %llu", (unsigned long long) hits, (unsigned long long) calls);
+		printf("is_tandem_duplication: %llu hits of %llu calls equal\n", (unsigned long long) hits, (unsigned long long) calls);
+	}
+	printf(failures ? "words_check: %d FAILED\n" : "words_check: ok\n", failures);
+	return failures != 0;
+}

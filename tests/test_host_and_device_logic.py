@@ -1006,6 +1006,14 @@ def test_inflate_core_against_zlib(built):
     assert result.returncode == 0 and "0 failures" in result.stdout, result.stdout[-2000:]
 
 
+def test_word_wise_name_helpers_against_their_definitions(built):
+    """find_byte, first_difference, qname_length, same_name, compare_names and the three-word load_record of ingest_core.hpp (eight bytes of the stream per load instead of one)
+    give what the byte-by-byte definitions give, on every length and alignment; compare_names against std::string::compare of "QNAME,HI[ITD]" """
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "words_check"], check=True)
+    result = subprocess.run([os.path.join(ROOT, "tests", "emu", "words_check")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert result.returncode == 0 and "words_check: ok" in result.stdout, result.stdout[-2000:]
+
+
 def test_long_read_names_through_the_whole_workflow(built, emu_api, tmp_path):
     """read names of 45 characters (an Illumina run's; the golden datasets have 11): 64-bit name offsets in the batch -- the device ingest (stepped) builds the batch of the host
     ingest, and the whole workflow gives the reference's files"""
