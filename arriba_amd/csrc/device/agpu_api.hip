@@ -627,13 +627,14 @@ static agpu_ctx* create_context(int device, const agpu_params* params, std::shar
 	agpu_ctx* ctx = new agpu_ctx(pool);
 	ctx->device = device;
 	if (params) ctx->params = *params; else agpu_default_params(&ctx->params);
-	// The stream of the stages gets the highest priority, the pieces of a file (unwrap / inflate, CRC) the middle one, the windows of the ingest the lowest: in a session with
-	// two lanes the stages of one sample run beside the feed of the next, and it is the stages the caller waits for (with the pieces in front, as round 3 had them, a 10^8-fragment
-	// step spent 1.33 s in its stages instead of 0.77: profiles/r04c_bench100m.json).  ARRIBA_STREAM_PRIORITIES=pieces: the pieces in front, for measurements.
+	// Stream priorities: the pieces of a file (unwrap / inflate, CRC) in front, then the stages, the windows of the ingest last.  In a session with two lanes the stages of one sample
+	// run beside the feed of the next.  Round 4a had the stages in front (with the pieces in front a 10^8-fragment step spent 1.33 s in its stages instead of 0.77:
+	// profiles/r04c_bench100m.json); since the replay kernel of the windows takes 0.24 s instead of 0.8 the step is set by the feed, whose pushes wait for the kernels of the pieces:
+	// 2.15 instead of 2.22 s per step, 2.03 instead of 2.08 with the faster writer (profiles/r04r_*).  ARRIBA_STREAM_PRIORITIES=stages: the stages in front, for measurements.
 	int least_priority = 0, greatest_priority = 0;
 	(void) hipDeviceGetStreamPriorityRange(&least_priority, &greatest_priority);
 	const char* priorities = getenv("ARRIBA_STREAM_PRIORITIES");
-	const bool pieces_first = priorities != nullptr && strcmp(priorities, "pieces") == 0;
+	const bool pieces_first = priorities == nullptr || strcmp(priorities, "stages") != 0;
 	if (hipStreamCreateWithPriority(&ctx->stream, hipStreamDefault, pieces_first ? (least_priority + greatest_priority) / 2 : greatest_priority) != hipSuccess || hipEventCreate(&ctx->event_start) != hipSuccess || hipEventCreate(&ctx->event_stop) != hipSuccess) {
 		set_last_error("failed to create HIP stream/events"); delete ctx; return nullptr;
 	}

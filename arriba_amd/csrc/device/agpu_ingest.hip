@@ -872,7 +872,7 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 		int least = 0, greatest = 0;
 		HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
 		const char* priorities = getenv("ARRIBA_STREAM_PRIORITIES");
-		const bool pieces_first = priorities != nullptr && strcmp(priorities, "pieces") == 0;
+		const bool pieces_first = priorities == nullptr || strcmp(priorities, "stages") != 0;
 		HIP_CHECK(hipStreamCreateWithPriority(&ctx->piece_stream, hipStreamNonBlocking, pieces_first ? greatest : (least + greatest) / 2)); // (in front of the kernels of the windows: the feed waits for these; behind the stages of the other lane of a session)
 		for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_copied[k], hipEventDisableTiming | hipEventBlockingSync)); /* (the thread that waits for a copy leaves its core to the readers of the file) */ HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_ready[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_done[k], hipEventDisableTiming)); }
 	}

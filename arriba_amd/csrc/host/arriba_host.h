@@ -22,6 +22,10 @@ namespace arriba {
 // (profiles/r03g_probe.txt): every pool of worker threads of the host library sizes itself by this number.
 unsigned int cpu_budget();
 void limit_threads_of_this_thread(unsigned int n); // (0: no limit)
+// called by a thread that only reads a file or formats rows: nice 10 (ARRIBA_WORKER_NICE, 0 = as its parent).  In a session with two lanes a dozen of these run beside the one
+// thread that launches the kernels of the stages and waits for their words; with all at one priority that thread took 1.10 s for stages it does in 0.75 s alone, with four
+// readers instead of eight 0.96 s (profiles/r04q_*) -- it should not queue behind memcpy.
+void worker_thread_starts();
 
 typedef int32_t position_t;
 typedef uint16_t contig_t;

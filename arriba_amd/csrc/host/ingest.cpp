@@ -4,6 +4,8 @@
 // --chimOutType WithinBAM) and coverage_t::add_fragment (source/read_stats.cpp:161-266).
 #include "arriba_host.h"
 
+#include <sys/resource.h>
+#include <sys/syscall.h>
 #include <atomic>
 #include <algorithm>
 #include <chrono>
@@ -724,7 +726,7 @@ template <class Body> void parallel_ranges(size_t n, unsigned int n_threads, con
 	if (n_threads <= 1 || n < min_items) { body((size_t) 0, n); return; }
 	std::vector<std::thread> threads;
 	for (unsigned int t = 0; t < n_threads; ++t)
-		threads.push_back(std::thread([&body, n, n_threads, t] { body(n * t / n_threads, n * (t + 1) / n_threads); }));
+		threads.push_back(std::thread([&body, n, n_threads, t] { worker_thread_starts(); body(n * t / n_threads, n * (t + 1) / n_threads); }));
 	for (unsigned int t = 0; t < n_threads; ++t)
 		threads[t].join();
 }
@@ -964,6 +966,10 @@ unsigned int ingest_threads() { // ARRIBA_INGEST_THREADS overrides; the reader i
 // file beside both) may use of the budget -- every decision about a number of threads that is made on that thread sees the smaller budget
 static thread_local unsigned int g_thread_limit = 0;
 void limit_threads_of_this_thread(unsigned int n) { g_thread_limit = n; }
+void worker_thread_starts() {
+	static const int nice_of_workers = [] { const char* setting = getenv("ARRIBA_WORKER_NICE"); const int value = setting ? atoi(setting) : 10; return value < 0 ? 0 : value > 19 ? 19 : value; }();
+	if (nice_of_workers > 0) (void) setpriority(PRIO_PROCESS, (id_t) syscall(SYS_gettid), nice_of_workers); // (per thread on Linux; raising the nice value needs no privilege)
+}
 static unsigned int whole_cpu_budget();
 unsigned int cpu_budget() { const unsigned int whole = whole_cpu_budget(); return g_thread_limit > 0 ? std::max(1u, std::min(whole, g_thread_limit)) : whole; }
 static unsigned int whole_cpu_budget() {

@@ -46,6 +46,7 @@ public:
 	}
 private:
 	void serve(size_t index) {
+		worker_thread_starts();
 		uint64_t seen = 0;
 		std::unique_lock<std::mutex> lock(mutex_);
 		while (true) {
