@@ -275,8 +275,8 @@ def host_only(args):
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=3)
-    parser.add_argument("--warmup", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=4)
+    parser.add_argument("--warmup", type=int, default=2, help="untimed steps in front of the timed ones; the session has two lanes that take the samples in turn, and a lane allocates its buffers with its first sample: with fewer than two that first sample is a timed step (2.99 s instead of 1.92 at 10^8 fragments, profiles/r04f_driver.err)")
     parser.add_argument("--fragments", type=int, default=None, help="chimeric fragments per GPU (default: 100 M, BASELINE.json's 100 M-read synthetic, if the box has the memory for the 54 GB file; 20000 with --host-only)")
     parser.add_argument("--stress", action="store_true", help="BASELINE.json config 3: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (filter_mismappers sees every read)")
     parser.add_argument("--subsampling-threshold", type=int, default=None, help="-U of the reference (source/options.cpp:422-423); default 300, with --stress 32767 as SURVEY.md 8(d) config 3 says")

@@ -123,6 +123,69 @@ static std::vector<uint8_t> record_with_bases(const std::vector<uint32_t>& cigar
 }
 static uint8_t code_of(char base) { return base == 'A' ? 1 : base == 'C' ? 2 : base == 'G' ? 4 : base == 'T' ? 8 : 15; }
 
+// coverage_t::add_fragment one increment per window, as it stood before the ranges of the difference array (source/read_stats.cpp:161-266 restated); `windows` is indexed
+// window_offset[contig] + window here, the counts themselves
+static void coverage_increment_as_written(uint32_t* window) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	__hip_atomic_fetch_add(window, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+	__atomic_fetch_add(window, 1u, __ATOMIC_RELAXED);
+#endif
+}
+
+static void add_fragment_to_coverage_as_written(const CoverageBuild& coverage, const Rec& mate1, uint16_t flag1, const Rec* mate2_or_null, bool is_chimeric) {
+	const Rec& mate2 = (mate2_or_null == nullptr) ? mate1 : *mate2_or_null;
+	if (coverage.windows == nullptr) return; // (a measurement without coverage_t: ARRIBA_INGEST_SKIP_COVERAGE)
+	if (mate1.contig < 0 || (uint32_t) mate1.contig >= coverage.n_contigs || mate2.contig < 0 || (uint32_t) mate2.contig >= coverage.n_contigs) return;
+	const uint64_t begin1 = coverage.window_offset[mate1.contig], size1 = coverage.window_offset[mate1.contig + 1] - begin1;
+	const uint64_t begin2 = coverage.window_offset[mate2.contig], size2 = coverage.window_offset[mate2.contig + 1] - begin2;
+	if (size1 == 0 || size2 == 0) return;
+	// the reference compares bam_cigar_type() (0..3) with BAM_CSOFT_CLIP (4), which never matches: only the proper-pair flag turns a fragment chimeric here
+	if ((flag1 & BAMF_PAIRED) && !(flag1 & BAMF_PROPER_PAIR)) is_chimeric = true;
+	if (!is_chimeric) {
+		// (the reference indexes without a check; a position behind its contig would be undefined behaviour there)
+		if (!(flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) { const uint64_t w = (uint64_t) (mate1.pos / COVERAGE_RESOLUTION); if (mate1.pos >= 0 && w < size1) coverage.fragment_starts[begin1 + w] = 1; }
+		else { const uint64_t w = (uint64_t) (mate2.pos / COVERAGE_RESOLUTION); if (mate2.pos >= 0 && w < size2) coverage.fragment_starts[begin2 + w] = 1; }
+	}
+	int32_t position1 = mate1.pos, position2 = mate2.pos;
+	int32_t position = position1 < position2 ? position1 : position2;
+	int32_t window = position / COVERAGE_RESOLUTION;
+	uint32_t i1 = 0, i2 = 0;
+	while (true) {
+		uint32_t op1 = 0, op2 = 0, length1, length2;
+		if (i1 < mate1.n_cigar) { op1 = mate1.cigar(i1); length1 = op_consumes_reference(op1 & 15) ? op1 >> 4 : 0; }
+		else { length1 = 0; if (position2 / COVERAGE_RESOLUTION > window) window = position2 / COVERAGE_RESOLUTION; }
+		if (i2 < mate2.n_cigar) { op2 = mate2.cigar(i2); length2 = op_consumes_reference(op2 & 15) ? op2 >> 4 : 0; }
+		else { length2 = 0; if (position1 / COVERAGE_RESOLUTION > window) window = position1 / COVERAGE_RESOLUTION; }
+		uint32_t op;
+		uint64_t begin, size;
+		if (i1 < mate1.n_cigar && (position1 + (int32_t) length1 < position2 + (int32_t) length2 || i2 >= mate2.n_cigar)) {
+			i1++;
+			if (length1 == 0) continue;
+			op = op1; begin = begin1; size = size1; position1 += (int32_t) length1; position = position1;
+		} else if (i2 < mate2.n_cigar) {
+			i2++;
+			if (length2 == 0) continue;
+			op = op2; begin = begin2; size = size2; position2 += (int32_t) length2; position = position2;
+		} else {
+			break;
+		}
+		if (op_consumes_query(op & 15)) {
+			while (window <= position / COVERAGE_RESOLUTION) {
+				if (window >= 0 && (uint64_t) window < size && position - window * COVERAGE_RESOLUTION >= COVERAGE_RESOLUTION / 2) coverage_increment_as_written(&coverage.windows[begin + (uint64_t) window]);
+				++window;
+			}
+		} else {
+			window = position / COVERAGE_RESOLUTION;
+		}
+	}
+	if (!is_chimeric) {
+		if ((flag1 & BAMF_REVERSE) || !(flag1 & BAMF_PAIRED)) { const uint64_t w = (uint64_t) ((position1 - 1) / COVERAGE_RESOLUTION); if (position1 >= 1 && w < size1) coverage.fragment_ends[begin1 + w] = 1; }
+		else { const uint64_t w = (uint64_t) ((position2 - 1) / COVERAGE_RESOLUTION); if (position2 >= 1 && w < size2) coverage.fragment_ends[begin2 + w] = 1; }
+	}
+}
+
+
 int main() {
 	std::mt19937_64 random(20260927);
 	// find_byte / first_difference: every length 0..40, every offset 0..8 into the buffer, few distinct byte values so that hits are frequent
@@ -209,6 +272,63 @@ int main() {
 		}
 		CHECK(hits > calls / 20 && hits < calls - calls / 20, "is_tandem_duplication was to be tried on hits and misses alike: %llu hits of %llu", (unsigned long long) hits, (unsigned long long) calls);
 		printf("is_tandem_duplication: %llu hits of %llu calls equal\n", (unsigned long long) hits, (unsigned long long) calls);
+	}
+	// add_fragment_to_coverage: ranges in the difference array + prefix sums against one increment per window -- pairs and single mates, mates that overlap, lie apart or on
+	// two contigs, deletions and introns (a deletion makes the reference count a window twice), insertions, clips, reads at the first and behind the last window of a contig,
+	// positions of -1, contigs without windows
+	{
+		uint64_t fragments = 0, increments = 0;
+		for (int trial = 0; trial < 3000; ++trial) {
+			const uint32_t n_contigs = 1 + random() % 4;
+			std::vector<uint64_t> window_offset(n_contigs + 1, 0);
+			std::vector<uint32_t> contig_length(n_contigs);
+			for (uint32_t c = 0; c < n_contigs; ++c) { contig_length[c] = random() % 5 == 0 ? 0 : 200 + (uint32_t) (random() % 3000); window_offset[c + 1] = window_offset[c] + (contig_length[c] ? contig_length[c] / COVERAGE_RESOLUTION + 1 : 0); }
+			const uint64_t windows = window_offset[n_contigs];
+			std::vector<uint32_t> expected(windows + 1, 0), differences(coverage_difference_slots(windows, n_contigs) + 1, 0);
+			std::vector<uint8_t> starts_a(windows + 1, 0), ends_a(windows + 1, 0), starts_b(windows + 1, 0), ends_b(windows + 1, 0);
+			CoverageBuild as_written = { n_contigs, window_offset.data(), expected.data(), starts_a.data(), ends_a.data() }, ranges = { n_contigs, window_offset.data(), differences.data(), starts_b.data(), ends_b.data() };
+			for (int fragment = 0; fragment < 40; ++fragment) {
+				auto make_cigar = [&](std::vector<uint32_t>& cigar, uint32_t& query) {
+					query = 0;
+					if (random() % 3 == 0) { const uint32_t l = 1 + random() % 30; cigar.push_back(l << 4 | CIGAR_S); query += l; }
+					const uint32_t blocks = 1 + random() % 4;
+					for (uint32_t k = 0; k < blocks; ++k) {
+						if (k > 0) { const uint32_t kind = random() % 3; if (kind == 0) cigar.push_back((uint32_t) (1 + random() % 25) << 4 | CIGAR_D); else if (kind == 1) cigar.push_back((uint32_t) (1 + random() % 400) << 4 | CIGAR_N); else { const uint32_t l = 1 + random() % 5; cigar.push_back(l << 4 | CIGAR_I); query += l; } }
+						const uint32_t l = 1 + random() % 90; cigar.push_back(l << 4 | (random() % 6 == 0 ? CIGAR_X : CIGAR_M)); query += l;
+					}
+					if (random() % 3 == 0) { const uint32_t l = 1 + random() % 30; cigar.push_back(l << 4 | (random() % 4 == 0 ? CIGAR_H : CIGAR_S)); if ((cigar.back() & 15) == CIGAR_S) query += l; }
+				};
+				const int32_t tid1 = (int32_t) (random() % n_contigs), tid2 = random() % 6 == 0 ? (int32_t) (random() % n_contigs) : tid1;
+				const int32_t span = (int32_t) contig_length[tid1] + 400;
+				const int32_t pos1 = random() % 25 == 0 ? -1 : (int32_t) (random() % span) - (random() % 10 == 0 ? 0 : 0), pos2 = random() % 3 == 0 ? pos1 + (int32_t) (random() % 40) - 10 : (int32_t) (random() % ((int32_t) contig_length[tid2] + 400));
+				std::vector<uint32_t> cigar1, cigar2; uint32_t query1, query2;
+				make_cigar(cigar1, query1); make_cigar(cigar2, query2);
+				const bool pair = random() % 3 != 0;
+				uint16_t flag = (uint16_t) ((random() % 2 ? BAMF_REVERSE : 0) | (pair || random() % 2 ? BAMF_PAIRED : 0) | (random() % 4 ? BAMF_PROPER_PAIR : 0));
+				std::vector<uint8_t> stream = record_with_bases(cigar1, std::vector<uint8_t>(query1, 1), tid1, pos1, flag);
+				const uint64_t second = stream.size();
+				const std::vector<uint8_t> other = record_with_bases(cigar2, std::vector<uint8_t>(query2, 1), tid2, pos2 < -1 ? -1 : pos2, (uint16_t) (flag ^ BAMF_REVERSE));
+				stream.insert(stream.end(), other.begin(), other.end()); stream.resize(stream.size() + 16, 0);
+				const uint64_t offsets[2] = { 0, second }; std::vector<uint32_t> tid_to_contig(n_contigs); for (uint32_t c = 0; c < n_contigs; ++c) tid_to_contig[c] = c;
+				IngestStream in; in.bytes = stream.data(); in.size = stream.size(); in.record_offset = offsets; in.n_records = 2; in.n_targets = n_contigs; in.tid_to_contig = tid_to_contig.data(); in.hit_index = nullptr;
+				const Rec mate1 = load_record(in, 0), mate2 = load_record(in, 1);
+				const bool is_chimeric = random() % 2;
+				const uint16_t flag_passed = random() % 5 == 0 ? 0 : flag;
+				add_fragment_to_coverage_as_written(as_written, mate1, flag_passed, pair ? &mate2 : nullptr, is_chimeric);
+				add_fragment_to_coverage(ranges, mate1, flag_passed, pair ? &mate2 : nullptr, is_chimeric);
+				++fragments;
+			}
+			// as coverage_from_differences_kernel: window w of contig c is slot window_offset[c] + c + w; every contig sums to zero
+			uint32_t running = 0; uint64_t slot = 0; bool equal = true, closed = true;
+			for (uint32_t c = 0; c < n_contigs; ++c) {
+				for (uint64_t w = window_offset[c]; w < window_offset[c + 1]; ++w) { running += differences[slot++]; equal = equal && running == expected[w]; increments += expected[w]; }
+				running += differences[slot++]; closed = closed && running == 0;
+			}
+			CHECK(equal && closed, "add_fragment_to_coverage: the windows from the ranges are not those of the increments (trial %d)", trial);
+			CHECK(starts_a == starts_b && ends_a == ends_b, "add_fragment_to_coverage: start / end flags (trial %d)", trial);
+		}
+		CHECK(increments > 20 * fragments / 10, "add_fragment_to_coverage was to be tried on fragments that cover windows: %llu increments of %llu fragments", (unsigned long long) increments, (unsigned long long) fragments);
+		printf("add_fragment_to_coverage: %llu fragments, %llu increments equal\n", (unsigned long long) fragments, (unsigned long long) increments);
 	}
 	printf(failures ? "words_check: %d FAILED\n" : "words_check: ok\n", failures);
 	return failures != 0;
