@@ -4,6 +4,8 @@
 #include "arriba_host.h"
 #include "output.h"
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <atomic>
 #include <cstdio>
@@ -68,6 +70,9 @@ struct ahost_session {
 	BamFeed* feed = nullptr;
 	bool device_batch = false;           // the fragments live on the device (ahost_adopt_device_ingest)
 	Batch spare_rows;                    // the vectors of the last sample's rows (ahost_set_batch_rows), kept over ahost_bam_open for the next sample's
+	// ahost_detach_sample: a writer thread holds what a sample left behind while the session reads the next one.  It shares the reference data of the session that no sample changes
+	// (annotation, assembly, tags, protein domains) and takes a copy of `contigs` -- ahost_bam_open stores the names of the next header there
+	std::mutex detached_mutex; std::condition_variable detached_changed; unsigned int detached_samples = 0; // (the mutex also guards spare_rows; ahost_close waits for the count)
 	std::string formatted_rows;          // ahost_format_fusions: the rows of this rank's share of an output file, until the next call
 	std::vector<uint32_t> row_fragments; // device ingest: the fragment of every row of ingest.batch (ascending); empty = the batch holds every fragment
 	bool rows_in_list_order = false;     // ... or row k holds the fragment of entry k of the read lists of the table written next (ahost_set_batch_rows without fragments)
@@ -220,6 +225,14 @@ const char* ahost_last_error(void) { return g_error.c_str(); }
 unsigned int ahost_cpu_budget(void) { return cpu_budget(); }
 void ahost_limit_threads_of_this_thread(unsigned int n) { limit_threads_of_this_thread(n); }
 
+// what ahost_write_fusions reads of a SAMPLE (as opposed to the reference data): coverage_t, the rows of the supporting reads and how they are numbered
+struct SampleView { const Contigs* contigs; const Coverage* coverage; const Batch* batch; const std::vector<uint32_t>* row_fragments; bool rows_in_list_order, device_batch, have_batch; };
+struct ahost_detached_sample { ahost_session* session; Contigs contigs; Coverage coverage; Batch batch; std::vector<uint32_t> row_fragments; bool rows_in_list_order, device_batch, have_batch; };
+static SampleView sample_of(const ahost_session* session) {
+	SampleView v = { &session->contigs, &session->ingest.coverage, &session->ingest.batch, &session->row_fragments, session->rows_in_list_order, session->device_batch, session->have_batch };
+	return v;
+}
+
 int ahost_load_genomic_breakpoints(ahost_session* session, const char* path, const agpu_genomic_breakpoint** variants, uint32_t* n_variants) {
 	if (!session || !path || !variants || !n_variants) { g_error = "null argument"; return -1; }
 	try {
@@ -240,27 +253,61 @@ int ahost_load_protein_domains(ahost_session* session, const char* path) {
 	catch (const std::exception& e) { g_error = e.what(); return -1; }
 }
 
-static int write_or_format_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
+static int write_or_format_fusions(ahost_session* session, const SampleView& sample, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
                                    unsigned int part, unsigned int parts, std::string* text_of_part);
 
 int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps) {
 	if (!path) { g_error = "null argument"; return -1; }
-	return write_or_format_fusions(session, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_sequence_gaps, 0, 1, NULL);
+	if (!session) { g_error = "null argument"; return -1; }
+	return write_or_format_fusions(session, sample_of(session), table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_sequence_gaps, 0, 1, NULL);
+}
+
+// The last output file of a sample written while the session reads the next sample (arriba_workflow_defer_output): the sample's coverage_t and rows leave the session ...
+ahost_detached_sample* ahost_detach_sample(ahost_session* session) {
+	if (!session) { g_error = "null argument"; return NULL; }
+	try {
+		std::unique_ptr<ahost_detached_sample> sample(new ahost_detached_sample());
+		sample->session = session;
+		sample->contigs = session->contigs;
+		sample->coverage = std::move(session->ingest.coverage); sample->batch = std::move(session->ingest.batch); sample->row_fragments = std::move(session->row_fragments);
+		sample->rows_in_list_order = session->rows_in_list_order; sample->device_batch = session->device_batch; sample->have_batch = session->have_batch;
+		session->ingest.coverage = Coverage(); session->ingest.batch = Batch(); session->row_fragments.clear(); session->rows_in_list_order = false; session->have_batch = false; // (the session has no sample until the next ingest; its counters stay)
+		{ std::lock_guard<std::mutex> lock(session->detached_mutex); ++session->detached_samples; }
+		return sample.release();
+	} catch (const std::exception& e) { g_error = e.what(); return NULL; }
+}
+// ... are written from where they are, by any thread ...
+int ahost_write_fusions_of(ahost_detached_sample* sample, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps) {
+	if (!sample || !path) { g_error = "null argument"; return -1; }
+	const SampleView view = { &sample->contigs, &sample->coverage, &sample->batch, &sample->row_fragments, sample->rows_in_list_order, sample->device_batch, sample->have_batch };
+	return write_or_format_fusions(sample->session, view, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_sequence_gaps, 0, 1, NULL);
+}
+// ... and given back: the vectors of the rows go to the session for the rows of a later sample (a gigabyte of fresh vectors per sample costs 0.3 s: ahost_set_batch_rows)
+void ahost_release_sample(ahost_detached_sample* sample) {
+	if (!sample) return;
+	ahost_session* session = sample->session;
+	{
+		std::lock_guard<std::mutex> lock(session->detached_mutex);
+		if (sample->device_batch && sample->batch.seq_pool.capacity() > session->spare_rows.seq_pool.capacity()) session->spare_rows = std::move(sample->batch);
+		--session->detached_samples;
+	}
+	session->detached_changed.notify_all();
+	delete sample;
 }
 
 int ahost_format_fusions(ahost_session* session, const ahost_fusion_table* table, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
                          unsigned int part, unsigned int parts, const char** text, uint64_t* bytes) {
 	if (!session || !text || !bytes || parts == 0 || part >= parts) { g_error = "null argument"; return -1; }
 	session->formatted_rows.clear();
-	const int status = write_or_format_fusions(session, table, "", write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_sequence_gaps, part, parts, &session->formatted_rows);
+	const int status = write_or_format_fusions(session, sample_of(session), table, "", write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_sequence_gaps, part, parts, &session->formatted_rows);
 	*text = session->formatted_rows.data(); *bytes = session->formatted_rows.size();
 	return status;
 }
 
-static int write_or_format_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
+static int write_or_format_fusions(ahost_session* session, const SampleView& sample, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap, int fill_sequence_gaps,
                                    unsigned int part, unsigned int parts, std::string* text_of_part) {
 	if (!session || !table || !path) { g_error = "null argument"; return -1; }
-	if (!session->have_batch) { g_error = "no BAM ingested yet"; return -1; }
+	if (!sample.have_batch) { g_error = "no BAM ingested yet"; return -1; }
 	try {
 		const std::chrono::steady_clock::time_point profile_start = std::chrono::steady_clock::now();
 		FusionTable t;
@@ -273,17 +320,17 @@ static int write_or_format_fusions(ahost_session* session, const ahost_fusion_ta
 		// device ingest: the batch of the session holds only the rows fetched for this table (ahost_set_batch_rows); the read lists of the candidates
 		// that get written and the filter column are translated from fragments to rows
 		std::vector<uint32_t> lists_as_rows; std::vector<uint8_t> filter_of_rows;
-		if (print_extra_info && session->device_batch && t.n_candidates > 0 && session->rows_in_list_order) {
+		if (print_extra_info && sample.device_batch && t.n_candidates > 0 && sample.rows_in_list_order) {
 			// the rows came in the order of the read lists: entry k of the lists is row k, and the reads of a candidate lie next to each other in every column of the batch
 			// (the pile-ups of the writer walk them one after the other: with rows in fragment order every read is a cache miss in a dozen columns)
 			const size_t n_entries = t.list_offset[3 * (size_t) t.n_candidates];
 			if (n_entries >= 0xFFFFFFFFull) throw std::runtime_error("the candidates to be written list more than 2^32 supporting reads: rows are numbered with 32 bits");
-			if (session->ingest.batch.n != n_entries || table->read_filter_of_rows == NULL) throw std::runtime_error("rows in list order: one row and one filter per entry of the read lists expected (ahost_set_batch_rows, read_filter_of_rows)");
+			if (sample.batch->n != n_entries || table->read_filter_of_rows == NULL) throw std::runtime_error("rows in list order: one row and one filter per entry of the read lists expected (ahost_set_batch_rows, read_filter_of_rows)");
 			lists_as_rows.resize(n_entries);
 			for (size_t k = 0; k < n_entries; ++k) lists_as_rows[k] = (uint32_t) k;
 			t.read_lists = lists_as_rows.data(); t.read_filter = table->read_filter_of_rows;
-		} else if (print_extra_info && session->device_batch && t.n_candidates > 0) {
-			const std::vector<uint32_t>& fragments = session->row_fragments; // ascending
+		} else if (print_extra_info && sample.device_batch && t.n_candidates > 0) {
+			const std::vector<uint32_t>& fragments = *sample.row_fragments; // ascending
 			const size_t n_entries = t.list_offset[3 * (size_t) t.n_candidates];
 			lists_as_rows.resize(n_entries);
 			filter_of_rows.resize(fragments.size() + 1);
@@ -320,8 +367,8 @@ static int write_or_format_fusions(ahost_session* session, const ahost_fusion_ta
 			t.read_lists = lists_as_rows.data(); t.read_filter = filter_of_rows.data();
 		}
 		if (getenv("ARRIBA_WRITER_PROFILE")) fprintf(stderr, "[writer] lists translated to rows: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - profile_start).count());
-		const bool no_rows = session->device_batch && !print_extra_info;
-		write_fusions_to_file(session->annotation, session->exon_index, session->contigs, session->assembly, session->ingest.coverage, no_rows ? NULL : &session->ingest.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
+		const bool no_rows = sample.device_batch && !print_extra_info;
+		write_fusions_to_file(session->annotation, session->exon_index, *sample.contigs, session->assembly, *sample.coverage, no_rows ? NULL : sample.batch, t, path, write_discarded != 0, print_extra_info != 0, max_itd_length, extras);
 		return 0;
 	} catch (const std::exception& e) { g_error = e.what(); return -1; }
 }
@@ -388,7 +435,11 @@ ahost_session* ahost_open(const char* fasta_path, const char* gtf_path, const ch
 	}
 }
 
-void ahost_close(ahost_session* session) { delete session; }
+void ahost_close(ahost_session* session) {
+	if (!session) return;
+	{ std::unique_lock<std::mutex> lock(session->detached_mutex); session->detached_changed.wait(lock, [session] { return session->detached_samples == 0; }); } // (a writer still holds a sample of this session)
+	delete session;
+}
 
 int ahost_ingest_bam_file(ahost_session* session, const char* bam_path, int external_duplicate_marking, unsigned int max_itd_length) {
 	try { return ingest(session, open_bam_file(bam_path), external_duplicate_marking, max_itd_length); }
@@ -460,7 +511,7 @@ int ahost_bam_open(ahost_session* session, const char* bam_path, int external_du
 		if (session->feed) { close_bam_feed(session->feed); session->feed = nullptr; }
 		session->options.external_duplicate_marking = external_duplicate_marking != 0;
 		session->options.max_itd_length = max_itd_length;
-		if (session->device_batch && session->ingest.batch.seq_pool.capacity() > session->spare_rows.seq_pool.capacity()) session->spare_rows = std::move(session->ingest.batch); // (the rows of the last sample's writer: their memory is taken again by ahost_set_batch_rows)
+		{ std::lock_guard<std::mutex> lock(session->detached_mutex); if (session->device_batch && session->ingest.batch.seq_pool.capacity() > session->spare_rows.seq_pool.capacity()) session->spare_rows = std::move(session->ingest.batch); } // (the rows of the last sample's writer: their memory is taken again by ahost_set_batch_rows)
 		session->ingest = IngestResult();
 		session->have_batch = false;
 		session->feed = open_bam_feed(bam_path);
@@ -542,7 +593,7 @@ int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, co
 		Batch& b = session->ingest.batch;
 		// every member is assigned below.  The vectors of the last sample's rows come back first (ahost_bam_open put them aside): a gigabyte of fresh vectors per sample is mapped,
 		// zero-filled by resize() and faulted in page by page -- 0.34 s for the 9.3 M rows of a 10^8-fragment sample, of which the copy itself is a tenth (profiles/r03p_writer_laps.txt)
-		if (session->spare_rows.seq_pool.capacity() > b.seq_pool.capacity()) b = std::move(session->spare_rows);
+		{ std::lock_guard<std::mutex> lock(session->detached_mutex); if (session->spare_rows.seq_pool.capacity() > b.seq_pool.capacity()) b = std::move(session->spare_rows); }
 		const size_t n = rows->n;
 		b.n = n;
 		// the columns and pools of 10^7 rows are more than a gigabyte: the vectors are sized first, the bytes then copied by all threads the process may use

@@ -344,17 +344,24 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 		const bool last_file = write_discarded == (run.options.discarded_output_file ? 1 : 0);
 		if (run.defer_output && last_file) { // nothing of this file is on the device any more: formatted and written beside the next sample
 			const std::string path = write_discarded ? run.options.discarded_output_file : run.options.output_file;
-			ahost_session* host = run.host; const unsigned int max_itd_length = run.options.device.max_itd_length; const int fill_gaps = run.options.fill_sequence_gaps;
+			const unsigned int max_itd_length = run.options.device.max_itd_length; const int fill_gaps = run.options.fill_sequence_gaps;
 			run.writer_error.clear();
 			Run* lane = &run;
-			run.writer = std::thread([lane, host, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps] {
+			// what the writer reads of the sample leaves the host session (ahost_detach_sample): the feed of the lane's next sample may open its file at once.  (Until round 4b it
+			// waited for this file -- 0.43 s of writer against the 0.2 s after which the stream buffer is free: every other step of a queue of 10^8-fragment samples waited 0.2-0.4 s
+			// for its feed, profiles/r04g2_bench100m_steps.txt.)  The tables of `table` are the lane's staging buffers: nothing touches them before the lane's next sample is worked
+			// on, and arriba_workflow_sample joins this thread first.
+			ahost_detached_sample* sample = ahost_detach_sample(run.host);
+			if (!sample) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+			run.writer = std::thread([lane, sample, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps] {
 				const unsigned int budget = ahost_cpu_budget();
 				// (beside the feed of the next sample and the thread that runs its stages.  The next feed on this lane waits for this file -- the host session is the writer's until then --,
 				// so the writer is not to be the slow one: with 6 of 16 threads it took 0.56 s and the feed behind it started 0.18 s late, a 10^8-fragment step 2.22 s; with 10: 0.37 s, 2.08 s,
 				// profiles/r04r_*.  Its threads format at nice 10: worker_thread_starts.)
 				ahost_limit_threads_of_this_thread(std::max(2u, budget * 5 / 8));
 				const double started = now_seconds();
-				if (ahost_write_fusions(host, &table, path.c_str(), write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps) != 0) lane->writer_error = std::string("ERROR: ") + ahost_last_error();
+				if (ahost_write_fusions_of(sample, &table, path.c_str(), write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps) != 0) lane->writer_error = std::string("ERROR: ") + ahost_last_error();
+				ahost_release_sample(sample);
 				lane->writer_seconds = now_seconds() - started;
 			});
 			lap(&arriba_workflow_timing::output_format);
@@ -640,7 +647,6 @@ struct arriba_workflow_session {
 		const bool ahead = queue.size() > 1; // fed beside the stages of the sample in front of it: the threads that read the file leave processors to the thread that runs those
 		mine->feeder = std::thread([this, mine, &run, lane, ahead] {
 			if (ahead) ahost_limit_threads_of_this_thread(std::max(2u, ahost_cpu_budget() / 2));
-			join_writer_of(lane); // (the last file of the lane's sample before: its writer reads the host session this feed is about to use)
 			{ std::unique_lock<std::mutex> lock(mutex); changed.wait(lock, [&] { return !ingest_busy && (queue.front().get() == mine || queue.front()->ingest_finished); }); ingest_busy = true; mine->started = true; }
 			try { feed_file(run); }
 			catch (const Failure& failure) { mine->error = failure.text; }
@@ -689,6 +695,7 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 		run.before_host_writer = [session, other] { session->join_writer_of(other); };
 		{ const std::string text = session->take_deferred_error(); if (!text.empty()) throw Failure{ text + " (writing the last file of an earlier sample)" }; }
 		if (sample.feeder.joinable()) sample.feeder.join(); // (the feed of this sample: under the stages of the sample before if it was submitted ahead)
+		session->join_writer_of(sample.lane); // (the last file of the lane's sample before: written from a detached sample beside this sample's feed; done long ago, normally)
 		struct Done { arriba_workflow_session& session; ~Done() { // on every way out: the ingest buffers are free for the next feed, the sample leaves the queue
 			arriba_workflow_session::Submitted& sample = *session.queue.front();
 			session.abandon(sample, *session.lanes[sample.lane]); // (nothing to do behind a sample that went through)

@@ -88,6 +88,16 @@ typedef struct {
 } ahost_fusion_table;
 int ahost_write_fusions(ahost_session* session, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap,
                         int fill_sequence_gaps /* -I: complete the fusion transcript from the assembly along the chosen transcripts */);
+/* The last output file of a sample written while the session reads the next one (arriba_workflow_defer_output): ahost_detach_sample moves what the writer reads of the SAMPLE --
+ * coverage_t, the rows of ahost_set_batch_rows, the contig names as its header left them -- out of the session (which then holds no sample until its next ingest);
+ * ahost_write_fusions_of writes from there on any thread, beside ahost_bam_open / ahost_bam_next / ahost_adopt_device_ingest of the next sample on the same session, with the
+ * reference data of the session (annotation, assembly, tags, protein domains), which no sample changes; ahost_release_sample gives the vectors of the rows back to the session.
+ * ahost_close waits for the samples that are still detached.  (reference: the same call as ahost_write_fusions, source/output_fusions.cpp:791-1007) */
+typedef struct ahost_detached_sample ahost_detached_sample;
+ahost_detached_sample* ahost_detach_sample(ahost_session* session);
+int ahost_write_fusions_of(ahost_detached_sample* sample, const ahost_fusion_table* table, const char* path, int write_discarded, int print_extra_info, unsigned int max_itd_length, int max_mate_gap,
+                           int fill_sequence_gaps);
+void ahost_release_sample(ahost_detached_sample* sample);
 /* One sample over several ranks that hold the same candidates: the rows part, part + parts, part + 2 parts, ... of the file ahost_write_fusions would write, as text
  * (the header line in front of the rows of part 0); *text stays valid until the next call.  Rows are independent of each other: the rank that gathers the texts of all
  * parts writes row k of the file from the text of part k % parts. */

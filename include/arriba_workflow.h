@@ -87,7 +87,8 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
  * asked for is thrown away by arriba_workflow_close.  Returns 0, or a negative number with the text in arriba_workflow_last_error(). */
 int arriba_workflow_submit(arriba_workflow_session* session, const char* chimeric_bam_file);
 /* on: arriba_workflow_sample returns when the last output file of the sample (-O if given, else -o) has everything it needs off the device; the file is formatted and written
- * by a thread of the session while the next sample is worked on.  It is complete when the next-but-one arriba_workflow_submit / _sample of the session has returned, or
+ * by a thread of the session while the next sample is worked on.  It is complete when the next-but-one arriba_workflow_sample of the session has returned (the writer works from a sample detached from its host session --
+ * ahost_detach_sample -- so the feed of the lane's next sample does not wait for it), or
  * arriba_workflow_flush, or arriba_workflow_close; a failure to write it is reported by the next arriba_workflow_sample or by arriba_workflow_flush.  Off by default. */
 int arriba_workflow_defer_output(arriba_workflow_session* session, int on);
 int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_last_writer /* may be NULL */);
