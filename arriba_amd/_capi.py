@@ -257,6 +257,9 @@ def bind_host_api(lib):
         "ahost_coverage_checksum": (c_uint64, [session]),
         "ahost_coverage_view": (POINTER(CoverageView), [session]),
         "ahost_write_fusions": (c_int, [session, POINTER(FusionTable), c_char_p, c_int, c_int, c_uint32, c_int, c_int]),
+        "ahost_detach_sample": (c_void_p, [session]),
+        "ahost_write_fusions_of": (c_int, [c_void_p, POINTER(FusionTable), c_char_p, c_int, c_int, c_uint32, c_int, c_int]),
+        "ahost_release_sample": (None, [c_void_p]),
         "ahost_format_fusions": (c_int, [session, POINTER(FusionTable), c_int, c_int, c_uint32, c_int, c_int, c_uint32, c_uint32, POINTER(c_void_p), POINTER(c_uint64)]),
         "ahost_load_tags": (c_int, [session, c_char_p]),
         "ahost_load_genomic_breakpoints": (c_int, [session, c_char_p, POINTER(POINTER(GenomicBreakpoint)), POINTER(c_uint32)]),

@@ -73,6 +73,7 @@ struct ahost_session {
 	// ahost_detach_sample: a writer thread holds what a sample left behind while the session reads the next one.  It shares the reference data of the session that no sample changes
 	// (annotation, assembly, tags, protein domains) and takes a copy of `contigs` -- ahost_bam_open stores the names of the next header there
 	std::mutex detached_mutex; std::condition_variable detached_changed; unsigned int detached_samples = 0; // (the mutex also guards spare_rows; ahost_close waits for the count)
+	bool sample_was_detached = false;    // ... and the session holds no sample until its next ingest
 	std::string formatted_rows;          // ahost_format_fusions: the rows of this rank's share of an output file, until the next call
 	std::vector<uint32_t> row_fragments; // device ingest: the fragment of every row of ingest.batch (ascending); empty = the batch holds every fragment
 	bool rows_in_list_order = false;     // ... or row k holds the fragment of entry k of the read lists of the table written next (ahost_set_batch_rows without fragments)
@@ -143,7 +144,7 @@ int ingest(ahost_session* session, ByteSource* source_raw, int external_duplicat
 	try {
 		session->options.external_duplicate_marking = external_duplicate_marking != 0;
 		session->options.max_itd_length = max_itd_length;
-		session->ingest = IngestResult();
+		session->ingest = IngestResult(); session->sample_was_detached = false;
 		session->row_fragments.clear(); session->device_batch = false; session->rows_in_list_order = false;
 		read_chimeric_alignments(*source, session->assembly, session->contigs, session->annotation, session->gene_index, session->options, session->ingest);
 		session->build_genome_view();
@@ -271,7 +272,7 @@ ahost_detached_sample* ahost_detach_sample(ahost_session* session) {
 		sample->contigs = session->contigs;
 		sample->coverage = std::move(session->ingest.coverage); sample->batch = std::move(session->ingest.batch); sample->row_fragments = std::move(session->row_fragments);
 		sample->rows_in_list_order = session->rows_in_list_order; sample->device_batch = session->device_batch; sample->have_batch = session->have_batch;
-		session->ingest.coverage = Coverage(); session->ingest.batch = Batch(); session->row_fragments.clear(); session->rows_in_list_order = false; session->have_batch = false; // (the session has no sample until the next ingest; its counters stay)
+		session->ingest.coverage = Coverage(); session->ingest.batch = Batch(); session->row_fragments.clear(); session->rows_in_list_order = false; session->have_batch = false; session->sample_was_detached = true; // (the session has no sample until the next ingest; its counters stay)
 		{ std::lock_guard<std::mutex> lock(session->detached_mutex); ++session->detached_samples; }
 		return sample.release();
 	} catch (const std::exception& e) { g_error = e.what(); return NULL; }
@@ -478,7 +479,7 @@ int ahost_load_ingest(ahost_session* session, const char* path) {
 	try {
 		char magic[8]; uint64_t scalars[6];
 		if (fread(magic, 8, 1, file) != 1 || memcmp(magic, INGEST_MAGIC, 8) != 0 || fread(scalars, sizeof(scalars), 1, file) != 1) throw std::runtime_error("not an ingest file of this version");
-		session->ingest = IngestResult();
+		session->ingest = IngestResult(); session->sample_was_detached = false;
 		IngestResult& r = session->ingest;
 		r.batch.n = scalars[0]; r.mapped_reads = scalars[1]; r.malformed_count = (unsigned int) scalars[2]; r.missing_hi_tag = (unsigned int) scalars[3]; r.records = scalars[4];
 		for (uint64_t c = 0; c < scalars[5]; ++c) { // the contigs the BAM header added behind those of the assembly, in the same order
@@ -513,7 +514,7 @@ int ahost_bam_open(ahost_session* session, const char* bam_path, int external_du
 		session->options.max_itd_length = max_itd_length;
 		{ std::lock_guard<std::mutex> lock(session->detached_mutex); if (session->device_batch && session->ingest.batch.seq_pool.capacity() > session->spare_rows.seq_pool.capacity()) session->spare_rows = std::move(session->ingest.batch); } // (the rows of the last sample's writer: their memory is taken again by ahost_set_batch_rows)
 		session->ingest = IngestResult();
-		session->have_batch = false;
+		session->have_batch = false; session->sample_was_detached = false;
 		session->feed = open_bam_feed(bam_path);
 		std::vector<std::string> target_names;
 		const uint64_t header_size = bam_feed_header(session->feed, target_names);
@@ -589,6 +590,7 @@ int ahost_adopt_device_ingest(ahost_session* session, const agpu_ingest_result* 
 
 int ahost_set_batch_rows(ahost_session* session, const agpu_batch_rows* rows, const uint32_t* fragments) {
 	if (!session || !rows) { g_error = "null argument"; return -1; }
+	if (session->sample_was_detached) { g_error = "the sample of this session was detached for its writer (ahost_detach_sample): nothing to set rows of until the next ingest"; return -1; }
 	try {
 		Batch& b = session->ingest.batch;
 		// every member is assigned below.  The vectors of the last sample's rows come back first (ahost_bam_open put them aside): a gigabyte of fresh vectors per sample is mapped,

@@ -128,7 +128,7 @@ class OneSamplePipeline(DevicePipeline):
         self.exchange["mismapper_jobs"] = n_jobs.value
         return remaining.value, discarded.value
 
-    def _emit_fusions(self, view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps):
+    def _emit_fusions(self, view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps, detached=False):
         """Every rank holds the same candidates and the rows of their supporting reads: rank r formats the rows r, r + N, r + 2N, ... of the file (the fusion transcripts
         from the pileups of the supporting reads are the expensive part), the texts are gathered on rank 0, which interleaves them and writes the file."""
         import ctypes

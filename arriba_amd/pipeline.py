@@ -692,8 +692,10 @@ class DevicePipeline(object):
         gap = int(self.scalars["max_mate_gap"] if max_mate_gap is None else max_mate_gap)
         return self._event_stage("recover_known_fusions", rules, count, gap)
 
-    def write_fusions(self, path, discarded=False, print_extra_info=None, max_itd_length=100, fill_sequence_gaps=False):
-        """reference: write_fusions_to_file, source/output_fusions.cpp:1043-1261 (-o / -O); the device's results are fetched and formatted by the host library"""
+    def write_fusions(self, path, discarded=False, print_extra_info=None, max_itd_length=100, fill_sequence_gaps=False, detached=False):
+        """reference: write_fusions_to_file, source/output_fusions.cpp:1043-1261 (-o / -O); the device's results are fetched and formatted by the host library.
+        detached: the way the C++ session writes the last file of a sample beside the next sample -- what the writer reads of the sample leaves the host session first
+        (ahost_detach_sample), which then holds no sample until its next ingest"""
         if print_extra_info is None:
             print_extra_info = not discarded
         import time
@@ -739,12 +741,23 @@ class DevicePipeline(object):
             if lib.ahost_set_batch_rows(self.session._session, byref(rows), fragments.ctypes.data if fragments.size else None) != 0:
                 raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
             mark("rows into the session")
-        self._emit_fusions(view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps)
+        self._emit_fusions(view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps, detached)
         mark("ahost_write_fusions")
         self.writer_seconds = {name: round(at - marks[k][1], 4) for k, (name, at) in enumerate(marks[1:])}  # where the time of the output side went (bench.py reports it)
 
-    def _emit_fusions(self, view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps):
+    def _emit_fusions(self, view, path, discarded, print_extra_info, max_itd_length, fill_sequence_gaps, detached=False):
         """the rows of the file from the table of the candidates it holds (the host library's writer)"""
+        if detached:
+            lib = self.session._lib
+            sample = lib.ahost_detach_sample(self.session._session)
+            if not sample:
+                raise ArribaError("ERROR: " + lib.ahost_last_error().decode())
+            status = lib.ahost_write_fusions_of(sample, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps))
+            message = lib.ahost_last_error().decode() if status != 0 else ""
+            lib.ahost_release_sample(sample)
+            if status != 0:
+                raise ArribaError("ERROR: " + message)
+            return
         if self.session._lib.ahost_write_fusions(self.session._session, byref(view), path.encode(), int(discarded), int(print_extra_info), max_itd_length, int(self.scalars["max_mate_gap"]), int(fill_sequence_gaps)) != 0:
             raise ArribaError("ERROR: " + self.session._lib.ahost_last_error().decode())
 

@@ -1016,6 +1016,38 @@ def test_word_wise_name_helpers_against_their_definitions(built):
     assert result.returncode == 0 and "words_check: ok" in result.stdout, result.stdout[-2000:]
 
 
+@pytest.mark.parametrize("device_ingest", [False, True])
+def test_last_file_written_from_a_detached_sample(device_ingest, dataset_files, emu_api, tmp_path):
+    """ahost_detach_sample / ahost_write_fusions_of / ahost_release_sample (the deferred writer of a session with two lanes): the file written from the detached sample is the file
+    ahost_write_fusions writes; the session holds no sample afterwards, ingests the next one as if nothing had happened and writes the same file again"""
+    from arriba_amd.pipeline import ArribaError, DevicePipeline, HostSession
+    prefix = dataset_files("toy3k")
+    files = {"fa": prefix + ".fa", "gtf": prefix + ".gtf", "bam": prefix + ".bam"}
+    def run(directory, detached):
+        os.makedirs(directory)
+        session = HostSession(files["fa"], files["gtf"])
+        if device_ingest:
+            pipeline = DevicePipeline(session, api=emu_api, bam=files["bam"], piece_bytes=1 << 20)
+        else:
+            session.read_chimeric_alignments(files["bam"])
+            pipeline = DevicePipeline(session, api=emu_api)
+        pipeline.run_workflow(os.path.join(directory, "fusions.tsv"), None)
+        pipeline.write_fusions(os.path.join(directory, "discarded.tsv"), discarded=True, print_extra_info=True, detached=detached)
+        return session, pipeline
+    run(str(tmp_path / "attached"), False)
+    session, pipeline = run(str(tmp_path / "detached"), True)
+    for name in ("fusions.tsv", "discarded.tsv"):
+        assert open(str(tmp_path / "attached" / name), "rb").read() == open(str(tmp_path / "detached" / name), "rb").read(), name
+    assert len(open(str(tmp_path / "detached" / "discarded.tsv")).readlines()) > 50
+    with pytest.raises(ArribaError):  # nothing left to write from
+        pipeline.write_fusions(str(tmp_path / "again.tsv"), discarded=True, print_extra_info=True)
+    pipeline.close()
+    if device_ingest:  # the session goes on with the next sample
+        again = DevicePipeline(session, api=emu_api, bam=files["bam"], piece_bytes=1 << 20)
+        again.run_workflow(str(tmp_path / "again_fusions.tsv"), str(tmp_path / "again_discarded.tsv"), print_extra_info_for_discarded_fusions=True)
+        assert open(str(tmp_path / "again_discarded.tsv"), "rb").read() == open(str(tmp_path / "attached" / "discarded.tsv"), "rb").read()
+
+
 def test_long_read_names_through_the_whole_workflow(built, emu_api, tmp_path):
     """read names of 45 characters (an Illumina run's; the golden datasets have 11): 64-bit name offsets in the batch -- the device ingest (stepped) builds the batch of the host
     ingest, and the whole workflow gives the reference's files"""
