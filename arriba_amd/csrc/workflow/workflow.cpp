@@ -355,10 +355,11 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 			if (!sample) throw Failure{ std::string("ERROR: ") + ahost_last_error() };
 			run.writer = std::thread([lane, sample, table, path, write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps] {
 				const unsigned int budget = ahost_cpu_budget();
-				// (beside the feed of the next sample and the thread that runs its stages.  The next feed on this lane waits for this file -- the host session is the writer's until then --,
-				// so the writer is not to be the slow one: with 6 of 16 threads it took 0.56 s and the feed behind it started 0.18 s late, a 10^8-fragment step 2.22 s; with 10: 0.37 s, 2.08 s,
-				// profiles/r04r_*.  Its threads format at nice 10: worker_thread_starts.)
-				ahost_limit_threads_of_this_thread(std::max(2u, budget * 5 / 8));
+				// (beside the feed of the next sample and the thread that runs its stages.  As long as the next feed on this lane waited for this file the writer was not to be the slow one: with 6 of
+				// 16 threads it took 0.56 s and that feed started 0.18 s late, a 10^8-fragment step 2.22 s; with 10: 0.37 s, 2.08 s, profiles/r04r_*.  Since the writer works from a detached
+				// sample nobody waits for it before the lane's next sample is worked on, two steps later, and it is the one to stand back again: 8 readers of the feed + 6 formatters + the two
+				// threads that talk to the device are the 16 CPUs of the quota, and more busy threads than that are all stopped together.  Its threads format at nice 10: worker_thread_starts.)
+				ahost_limit_threads_of_this_thread(std::max(2u, budget * 3 / 8));
 				const double started = now_seconds();
 				if (ahost_write_fusions_of(sample, &table, path.c_str(), write_discarded, print_extra_info, max_itd_length, max_mate_gap, fill_gaps) != 0) lane->writer_error = std::string("ERROR: ") + ahost_last_error();
 				ahost_release_sample(sample);
