@@ -24,6 +24,7 @@ static std::vector<uint8_t> record_with(const std::string& name, uint32_t paddin
 	const uint16_t n_cigar = 1; memcpy(&r[16], &n_cigar, 2); memcpy(&r[18], &flag, 2);
 	const int32_t l_seq = 0; memcpy(&r[20], &l_seq, 4);
 	memcpy(&r[36], name.data(), name.size());
+	for (uint32_t k = 1; k <= padding; ++k) r[36 + name.size() + k] = (k % 2) ? 'Z' : 0; // (what lies behind the first NUL of the name field must not matter)
 	const uint32_t cigar = 50u << 4; memcpy(&r[36 + l_read_name], &cigar, 4);
 	return r;
 }
@@ -214,7 +215,7 @@ int main() {
 		std::string x = make_name(1 + random() % 40), y = random() % 3 == 0 ? x : make_name(1 + random() % 40);
 		if (random() % 4 == 0) y = x.substr(0, 1 + random() % x.size()); // a prefix
 		const int32_t tid_x = (int32_t) (random() % 5) - 1, pos_x = (int32_t) (random() % 1000000) - 1; const uint16_t flag_x = (uint16_t) random();
-		const std::vector<uint8_t> rx = record_with(x, random() % 3, tid_x, pos_x, flag_x), ry = record_with(y, random() % 3, 1, 5, 0);
+		const std::vector<uint8_t> rx = record_with(x, random() % 12, tid_x, pos_x, flag_x), ry = record_with(y, random() % 12, 1, 5, 0);
 		std::vector<uint8_t> stream(rx); stream.insert(stream.end(), ry.begin(), ry.end()); stream.resize(stream.size() + 16, 0xEE);
 		const uint64_t offsets[2] = { 0, rx.size() };
 		const uint32_t tid_to_contig[4] = { 10, 11, 12, 13 };
