@@ -331,6 +331,41 @@ int main() {
 		CHECK(increments > 20 * fragments / 10, "add_fragment_to_coverage was to be tried on fragments that cover windows: %llu increments of %llu fragments", (unsigned long long) increments, (unsigned long long) fragments);
 		printf("add_fragment_to_coverage: %llu fragments, %llu increments equal\n", (unsigned long long) fragments, (unsigned long long) increments);
 	}
+	// the hit index kept beside a record (record_parse_kernel: hit_index_to_keep) and read back (hit_index_of) against the walk over the aux fields, for every integer type of
+	// the HI field, values that do not fit 32 bits or are the marker itself, records without HI, HI behind other fields
+	{
+		const int64_t values[] = { 0, 1, 2, 127, -128, 255, 32767, -32768, 65535, 2147483647LL, -2147483647LL - 1, 4294967295LL, 3000000000LL, -1 };
+		for (int64_t value : values) for (char type : std::string("cCsSiI")) for (int position = 0; position < 3; ++position) {
+			const bool fits = (type == 'c' && value >= -128 && value <= 127) || (type == 'C' && value >= 0 && value <= 255) || (type == 's' && value >= -32768 && value <= 32767) ||
+			                  (type == 'S' && value >= 0 && value <= 65535) || (type == 'i' && value >= -2147483647LL - 1 && value <= 2147483647LL) || (type == 'I' && value >= 0 && value <= 4294967295LL);
+			if (!fits) continue;
+			std::vector<uint8_t> r = record_with("name", 0, 0, 10, 0);
+			auto tag = [&r](const char* name, char kind, int64_t v) { r.push_back(name[0]); r.push_back(name[1]); r.push_back((uint8_t) kind); const int width = (kind == 'c' || kind == 'C') ? 1 : (kind == 's' || kind == 'S') ? 2 : 4; for (int b = 0; b < width; ++b) r.push_back((uint8_t) ((uint64_t) v >> (8 * b))); };
+			if (position >= 1) tag("NH", 'C', 3);
+			if (position == 2) { r.push_back('S'); r.push_back('A'); r.push_back('Z'); for (char c : std::string("1,100,+,50M,60,0;")) r.push_back((uint8_t) c); r.push_back(0); }
+			tag("HI", type, value);
+			tag("AS", 'C', 98);
+			const uint32_t block_size = (uint32_t) r.size() - 4; memcpy(&r[0], &block_size, 4);
+			r.resize(r.size() + 16, 0);
+			const uint64_t offsets[1] = { 0 }; const uint32_t tid_to_contig[1] = { 0 };
+			IngestStream in; in.bytes = r.data(); in.size = r.size(); in.record_offset = offsets; in.n_records = 1; in.n_targets = 1; in.tid_to_contig = tid_to_contig; in.hit_index = nullptr;
+			const Rec record = load_record(in, 0);
+			const AuxTags tags = scan_aux(record.aux, record.end);
+			CHECK(tags.has_hi && tags.hi == value && tags.has_sa == (position == 2), "scan_aux: HI:%c:%lld", type, (long long) value);
+			const int32_t kept[1] = { hit_index_to_keep(tags) };
+			CHECK((kept[0] == HIT_INDEX_UNKNOWN) == (value > 2147483647LL || value <= -2147483647LL - 1), "hit_index_to_keep: HI:%c:%lld kept as %d", type, (long long) value, kept[0]);
+			in.hit_index = kept;
+			CHECK(hit_index_of(in, 0, record) == value, "hit_index_of: HI:%c:%lld", type, (long long) value);
+		}
+		std::vector<uint8_t> r = record_with("name", 0, 0, 10, 0); r.resize(r.size() + 16, 0);
+		const uint64_t offsets[1] = { 0 }; const uint32_t tid_to_contig[1] = { 0 };
+		IngestStream in; in.bytes = r.data(); in.size = r.size() - 16; in.record_offset = offsets; in.n_records = 1; in.n_targets = 1; in.tid_to_contig = tid_to_contig; in.hit_index = nullptr;
+		const Rec record = load_record(in, 0);
+		const AuxTags none = scan_aux(record.aux, record.end);
+		const int32_t kept[1] = { hit_index_to_keep(none) };
+		in.hit_index = kept;
+		CHECK(!none.has_hi && kept[0] == 1 && hit_index_of(in, 0, record) == 1, "a record without HI has hit index 1");
+	}
 	printf(failures ? "words_check: %d FAILED\n" : "words_check: ok\n", failures);
 	return failures != 0;
 }

@@ -1010,7 +1010,8 @@ def test_word_wise_name_helpers_against_their_definitions(built):
     """find_byte, first_difference, qname_length, same_name, compare_names and the three-word load_record of ingest_core.hpp (eight bytes of the stream per load instead of one)
     give what the byte-by-byte definitions give, on every length and alignment; compare_names against std::string::compare of "QNAME,HI[ITD]"; is_tandem_duplication with its
     short cut over the first sixteen bases against the loop as written (60 000 clipped reads, half of them hits); add_fragment_to_coverage as ranges in the difference array +
-    prefix sums against one increment per window (120 000 fragments: pairs, deletions, introns, both ends of a contig, contigs without windows)"""
+    prefix sums against one increment per window (120 000 fragments: pairs, deletions, introns, both ends of a contig, contigs without windows); the hit index kept beside a
+    record against the walk over its aux fields (every integer type of HI, values beyond 32 bits, no HI)"""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "words_check"], check=True)
     result = subprocess.run([os.path.join(ROOT, "tests", "emu", "words_check")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert result.returncode == 0 and "words_check: ok" in result.stdout, result.stdout[-2000:]
