@@ -48,4 +48,25 @@ for name in ('toy3k', 'rules8k'):  # the whole chain and the output writer (host
 prefix=datasets.generate(datasets.DATASETS['wgs8k'], tmp, 'wgs8k')
 os.makedirs(os.path.join(tmp,'wgs8k_files'))
 print('workflow with -d', parity.check_workflow(prefix,conftest.golden_dir('wgs8k'),os.path.join(tmp,'wgs8k_files'),api=api,rules=True,structural_variants=True)[-1])
+# the device ingest, stepped (emu_ingest.inc over ingest_core.hpp: records read in 8-byte words, the ITD probe from two words, coverage_t as ranges, the hit index kept per record):
+# the batch of the host ingest, on datasets with tandem duplications, multi-mappers, duplicates, long names; then the whole workflow from the bytes of the file
+import subprocess
+import test_host_and_device_logic as cpu_tier
+from arriba_amd.pipeline import DevicePipeline, HostSession
+for name in ('toy3k', 'itd6k', 'shuffled_dups_40k', 'stranded_multimappers_20k'):
+    prefix=datasets.generate({'args': cpu_tier.DEVICE_INGEST_DATASETS[name]}, tmp, name+'_ingest')
+    host=HostSession(prefix+'.fa', prefix+'.gtf'); host.read_chimeric_alignments(prefix+'.bam')
+    expected=cpu_tier._batch_columns(host); expected['coverage']=int(host._lib.ahost_coverage_checksum(host._session))
+    session=HostSession(prefix+'.fa', prefix+'.gtf')
+    columns=cpu_tier._device_batch_columns(session, DevicePipeline(session, api=api, bam=prefix+'.bam', piece_bytes=1<<20))
+    print('device ingest', name, [key for key in expected if expected[key]!=columns[key]] or 'equal')
+long_names=os.path.join(tmp,'long')
+subprocess.run([datasets.GEN_SYNTH,'--out',long_names,'--seed','11','--fragments','3000','--contigs','4','--contig-len','300000','--junctions','60','--name-length','45'],check=True,stdout=subprocess.DEVNULL,stderr=subprocess.DEVNULL)
+host=HostSession(long_names+'.fa', long_names+'.gtf'); host.read_chimeric_alignments(long_names+'.bam')
+session=HostSession(long_names+'.fa', long_names+'.gtf')
+columns=cpu_tier._device_batch_columns(session, DevicePipeline(session, api=api, bam=long_names+'.bam', piece_bytes=1<<20))
+print('device ingest, 45-character names', [key for key, value in cpu_tier._batch_columns(host).items() if value!=columns[key]] or 'equal')
+prefix=datasets.generate(datasets.DATASETS['toy3k'], tmp, 'toy3k_from_bytes')
+os.makedirs(os.path.join(tmp,'from_bytes'))
+print('workflow from the bytes of the file', parity.check_workflow(prefix,conftest.golden_dir('toy3k'),os.path.join(tmp,'from_bytes'),api=api,device_ingest=True)[-1])
 print('done')
