@@ -167,7 +167,7 @@ struct agpu_ctx {
 	uint64_t ingest_stream_size = 0, ingest_first_record = 0, names_size = 0;
 	uint32_t ingest_n_targets = 0, ingest_max_itd_length = 100, ingest_pushes = 0, ingest_host_buffers = 2;
 	uint8_t ingest_external_duplicate_marking = 0;
-	bool ingest_active = false, ingest_finishing = false /* inside agpu_ingest_finish: its tables are in use although the feed is over */, batch_from_ingest = false, ingest_part_of_sample = false, ingest_verify_crc = false;
+	bool ingest_active = false, ingest_finishing = false /* inside agpu_ingest_finish: its tables are in use although the feed is over */, batch_from_ingest = false, ingest_part_of_sample = false, ingest_verify_crc = false, ingest_deflated_pieces = false /* a piece of this ingest went through bgzf_inflate_kernel */;
 	agpu::DeviceBuffer ingest_qname_keys; uint64_t ingest_qname_runs = 0; // a part of a sample: 128-bit keys of the runs of read names in its stream
 	agpu_ingest_result ingest_result; uint64_t ingest_pool_sizes[2] = { 0, 0 }; // what the last ingest (or merge of parts) reported; CIGAR words and sequence bytes of its pools
 	agpu::IngestProgress ingest_progress;

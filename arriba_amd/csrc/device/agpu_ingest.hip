@@ -25,7 +25,7 @@
 #include "device_utils.hpp"
 #include "shard_host.hpp"
 #include "crc32_core.hpp"
-#include "inflate_core.hpp"
+#include "inflate_fast_core.hpp"
 
 using namespace agpu;
 namespace agpu { extern thread_local bool g_inside_ingest_finish; } // agpu_api.hip (test hook: agpu_debug_fail_allocation_in_finish)
@@ -59,17 +59,62 @@ __global__ void __launch_bounds__(BLOCK) bgzf_unwrap_kernel(const uint8_t* raw, 
 	if (threadIdx.x < size - tail) target[tail + threadIdx.x] = source[tail + threadIdx.x];
 }
 
-// one wavefront per deflated block (inflate_core.hpp): the DEFLATE stream raw -> the block's place in the record stream.  The first / last block of a part of a file gives only
-// the bytes [skip, skip + keep) of what it holds: such a block is inflated into `spill` (64 KB for block 0, 64 KB for the last one) and its share copied from there.
-__global__ void __launch_bounds__(64, 3) bgzf_inflate_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint8_t* stream, uint8_t* spill, unsigned int* failures) {
+// Deflated blocks (round 5: inflate_fast_core.hpp).  Pass 1: a LANE per block, INFLATE_LANES blocks per workgroup (one wavefront whose lanes run the same loop on different
+// blocks; the tables of a block are 2.7 KB of LDS): literals to their place, matches noted.  The first / last block of a part of a file gives only the bytes [skip, skip + keep) of
+// what it holds: such a block is inflated into `spill` (64 KB for block 0, 64 KB for the last one) and its share copied from there by pass 2.
+template <int LANES> __global__ void __launch_bounds__(LANES) bgzf_inflate_tokens_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint32_t n_blocks, uint8_t* stream, uint8_t* spill,
+                                                                                        unsigned long long* notes, uint32_t* note_count, int* status, unsigned int* failures) {
+	__shared__ InflateFastTables tables[LANES];
+	const uint32_t b = blockIdx.x * LANES + threadIdx.x;
+	if (b >= n_blocks) return;
+	const agpu_bgzf_block block = blocks[b];
+	const bool partial = block.skip != 0 || block.keep != block.isize;
+	uint8_t* target = partial ? spill + (b == 0 ? 0 : 65536) : stream + block.stream_offset;
+	uint32_t noted = 0;
+	const int result = block.isize > 65536 ? (int) INFLATE_OUTPUT_OVERRUN
+	                 : inflate_tokens(raw + block.raw_offset + block.payload_offset, block.payload_size, target, block.isize, notes + (size_t) b * INFLATE_MATCH_CAPACITY, INFLATE_MATCH_CAPACITY, noted, tables[threadIdx.x]);
+	note_count[b] = noted; status[b] = result;
+	if (result != INFLATE_OK && result != INFLATE_RETRY) atomicAdd(failures, 1u);
+}
+
+// Pass 2: a wavefront per block, the noted matches 64 at a time, a lane per match.  A match is copied as soon as the bytes it reads are final (inflate_match_is_ready): all
+// bytes in front of the first match that is still pending are.  The first pending match is always ready, so every round copies at least one; a group whose matches read from in
+// front of the group (most) is done in one round.
+__global__ void __launch_bounds__(BLOCK) bgzf_inflate_resolve_kernel(const agpu_bgzf_block* blocks, uint32_t n_blocks, uint8_t* stream, uint8_t* spill, const unsigned long long* notes, const uint32_t* note_count, const int* status) {
+	const uint32_t b = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (b >= n_blocks || status[b] != INFLATE_OK) return;
+	const agpu_bgzf_block block = blocks[b];
+	const bool partial = block.skip != 0 || block.keep != block.isize;
+	uint8_t* target = partial ? spill + (b == 0 ? 0 : 65536) : stream + block.stream_offset;
+	const unsigned long long* mine = notes + (size_t) b * INFLATE_MATCH_CAPACITY;
+	const uint32_t n = note_count[b];
+	for (uint32_t base = 0; base < n; base += 64) {
+		const unsigned long long note = base + lane < n ? mine[base + lane] : 0ull;
+		const uint32_t position = inflate_note_position(note), length = inflate_note_length(note), distance = inflate_note_distance(note);
+		bool pending = base + lane < n;
+		while (true) {
+			const unsigned long long waiting = __ballot(pending);
+			if (waiting == 0) break;
+			const uint32_t frontier = (uint32_t) __shfl((int) position, __ffsll((unsigned long long) waiting) - 1);
+			if (pending && inflate_match_is_ready(position, length, distance, frontier)) { inflate_copy_match(target, position, length, distance); pending = false; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // what this round wrote is what the next round reads
+		}
+	}
+	if (partial) for (uint32_t k = lane; k < block.keep; k += 64) stream[block.stream_offset + k] = target[block.skip + k];
+}
+
+// The decoder of round 4: one wavefront per deflated block (inflate_core.hpp).  It takes the blocks pass 1 hands back (INFLATE_RETRY: more matches than it has room to note)
+// -- status == nullptr: all blocks (ARRIBA_INFLATE=wave, the measured alternative).
+__global__ void __launch_bounds__(64, 3) bgzf_inflate_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint8_t* stream, uint8_t* spill, int* status, unsigned int* failures) {
 	__shared__ InflateShared shared;
+	if (status != nullptr && status[blockIdx.x] != INFLATE_RETRY) return;
 	const agpu_bgzf_block block = blocks[blockIdx.x];
 	const bool partial = block.skip != 0 || block.keep != block.isize;
 	uint8_t* target = partial ? spill + (blockIdx.x == 0 ? 0 : 65536) : stream + block.stream_offset;
 	auto sync = [] () { __syncthreads(); };
 	auto broadcast = [] (uint32_t value) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) value); };
-	const int status = inflate_block(raw + block.raw_offset + block.payload_offset, block.payload_size, target, block.isize, shared, threadIdx.x, 64u, sync, broadcast);
-	if (status != INFLATE_OK) { if (threadIdx.x == 0) atomicAdd(failures, 1u); return; }
+	const int result = inflate_block(raw + block.raw_offset + block.payload_offset, block.payload_size, target, block.isize, shared, threadIdx.x, 64u, sync, broadcast);
+	if (result != INFLATE_OK) { if (threadIdx.x == 0) atomicAdd(failures, 1u); return; }
 	if (partial) {
 		__syncthreads();
 		for (uint32_t k = threadIdx.x; k < block.keep; k += 64) stream[block.stream_offset + k] = __hip_atomic_load(&target[block.skip + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -556,6 +601,7 @@ __global__ void strandedness_take_kernel(const uint8_t* flags, uint64_t count, u
 // ---- host side of the C ABI -----------------------------------------------------------------------------------------------------------------------
 
 int grow_stream(agpu_ctx* ctx, uint64_t needed) {
+	needed += 64; // (the readers of the stream -- record headers, the copies of bgzf_inflate_resolve_kernel -- load whole words that may end a few bytes behind the last byte)
 	if (needed <= ctx->ingest_stream.capacity) { ctx->ingest_stream.bytes = needed; return AGPU_OK; }
 	DeviceBuffer larger;
 	const uint64_t doubled = ctx->ingest_stream.capacity * 2;
@@ -878,16 +924,16 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	}
 	if (config->host_buffers > AGPU_PIECE_SLOTS) { set_last_error("agpu_ingest_config.host_buffers: at most 4"); return AGPU_ERR_INVALID; }
 	ctx->ingest_host_buffers = config->host_buffers < 2 ? 2 : config->host_buffers;
-	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0;
+	ctx->ingest_n_targets = config->n_targets; ctx->ingest_first_record = config->first_record_offset; ctx->ingest_stream_size = 0; ctx->ingest_pushes = 0; ctx->ingest_deflated_pieces = false;
 	{ const char* knob = getenv("ARRIBA_VERIFY_CRC"); ctx->ingest_verify_crc = !(knob != nullptr && knob[0] == '0'); } // (the stored blocks are checked as htslib checks them; "0": a measurement without)
-	ALLOC(ctx->scratch("ingest.crc_mismatches"), 4);
+	ALLOC(ctx->scratch("ingest.crc_mismatches"), 8); // [0] blocks whose payload does not give the CRC-32 of their trailer, [1] deflated blocks that did not decode (read whatever ARRIBA_VERIFY_CRC says)
 	if (ctx->ingest_verify_crc && ctx->scratch("ingest.crc_tables").ptr == nullptr) {
 		ALLOC(ctx->scratch("ingest.crc_tables"), sizeof(Crc32Tables));
 		static Crc32Tables tables; static bool made = false;
 		if (!made) { crc32_make_tables(tables); made = true; }
 		HIP_CHECK(hipMemcpy(ctx->scratch("ingest.crc_tables").ptr, &tables, sizeof(tables), hipMemcpyHostToDevice));
 	}
-	HIP_CHECK(hipMemsetAsync(ctx->scratch("ingest.crc_mismatches").ptr, 0, 4, s));
+	HIP_CHECK(hipMemsetAsync(ctx->scratch("ingest.crc_mismatches").ptr, 0, 8, s));
 	ctx->ingest_external_duplicate_marking = config->external_duplicate_marking; ctx->ingest_max_itd_length = config->max_itd_length; ctx->ingest_part_of_sample = config->part_of_sample != 0;
 	ALLOC(ctx->ingest_tid_to_contig, std::max<size_t>(config->n_targets, 1) * 4);
 	if (config->n_targets) HIP_CHECK(hipMemcpyAsync(ctx->ingest_tid_to_contig.ptr, config->tid_to_contig, (size_t) config->n_targets * 4, hipMemcpyHostToDevice, s));
@@ -959,9 +1005,34 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_blocks[slot].ptr, blocks, (size_t) n_blocks * sizeof(agpu_bgzf_block), hipMemcpyHostToDevice, s));
 		HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], s));
 		HIP_CHECK(hipStreamWaitEvent(pieces, ctx->piece_copied[slot], 0));
-		if (deflated) { KernelTimer timer(ctx, "bgzf_inflate_kernel", (uint64_t) raw_size + stream_bytes, pieces);
-		  bgzf_inflate_kernel<<<n_blocks, 64, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size, ctx->scratch("ingest.inflate_spill").as<uint8_t>(),
-		                                                        ctx->scratch("ingest.crc_mismatches").as<unsigned int>()); }
+		if (deflated) {
+			ctx->ingest_deflated_pieces = true;
+			uint8_t* target = ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size;
+			unsigned int* failures = ctx->scratch("ingest.crc_mismatches").as<unsigned int>() + 1;
+			static const char* way = getenv("ARRIBA_INFLATE"); // "wave": the one-wavefront-per-block decoder of round 4 for every block; "8" / "20": other numbers of blocks per wavefront in pass 1 (measurements)
+			if (way != nullptr && strcmp(way, "wave") == 0) {
+				KernelTimer timer(ctx, "bgzf_inflate_kernel", (uint64_t) raw_size + stream_bytes, pieces);
+				bgzf_inflate_kernel<<<n_blocks, 64, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), target, ctx->scratch("ingest.inflate_spill").as<uint8_t>(), nullptr, failures);
+			} else {
+				// (the kernels of the pieces run one after the other on one stream: one set of notes serves all slots)
+				DeviceBuffer& notes = ctx->scratch("ingest.inflate_notes"); DeviceBuffer& note_count = ctx->scratch("ingest.inflate_note_count"); DeviceBuffer& status = ctx->scratch("ingest.inflate_status");
+				if ((size_t) n_blocks * INFLATE_MATCH_CAPACITY * 8 > notes.capacity || (size_t) n_blocks * 4 > status.capacity) {
+					HIP_CHECK(hipStreamSynchronize(pieces)); // (the pieces before this one read the buffers that are about to be replaced)
+					ALLOC(notes, (size_t) n_blocks * INFLATE_MATCH_CAPACITY * 8); ALLOC(note_count, (size_t) n_blocks * 4); ALLOC(status, (size_t) n_blocks * 4);
+				}
+				const int lanes = way != nullptr && atoi(way) > 0 ? atoi(way) : 16;
+				{ KernelTimer timer(ctx, "bgzf_inflate_tokens_kernel", (uint64_t) raw_size + stream_bytes, pieces);
+				  #define TOKENS(LANES) bgzf_inflate_tokens_kernel<LANES><<<(n_blocks + LANES - 1) / LANES, LANES, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), n_blocks, target, \
+				  	ctx->scratch("ingest.inflate_spill").as<uint8_t>(), notes.as<unsigned long long>(), note_count.as<uint32_t>(), status.as<int>(), failures)
+				  if (lanes == 8) TOKENS(8); else if (lanes == 20) TOKENS(20); else TOKENS(16);
+				  #undef TOKENS
+				}
+				bgzf_inflate_kernel<<<n_blocks, 64, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), target, ctx->scratch("ingest.inflate_spill").as<uint8_t>(), status.as<int>(), failures); // (returns at once but for the blocks handed back)
+				{ KernelTimer timer(ctx, "bgzf_inflate_resolve_kernel", (uint64_t) stream_bytes, pieces);
+				  bgzf_inflate_resolve_kernel<<<(n_blocks + BLOCK / 64 - 1) / (BLOCK / 64), BLOCK, 0, pieces>>>(ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), n_blocks, target, ctx->scratch("ingest.inflate_spill").as<uint8_t>(),
+				  	notes.as<unsigned long long>(), note_count.as<uint32_t>(), status.as<int>()); }
+			}
+		}
 		else { KernelTimer timer(ctx, "bgzf_unwrap_kernel", (uint64_t) raw_size + stream_bytes, pieces);
 		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
 		const uint64_t piece_stream_offset = ctx->ingest_stream_size;
@@ -991,11 +1062,14 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
 	take_sample_buffers(ctx); // (a session with two lanes: the batch of this sample is built where the sibling's last one, done on the device, lies)
 	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); // (the last pieces unwrapped)
-	if (ctx->ingest_verify_crc) { // a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch")
-		unsigned int mismatches = 0;
-		HIP_CHECK(hipMemcpyAsync(&mismatches, ctx->scratch("ingest.crc_mismatches").ptr, 4, hipMemcpyDeviceToHost, s));
+	if (ctx->ingest_verify_crc || ctx->ingest_deflated_pieces) {
+		// a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch").  A deflated block that did not decode (bad Huffman
+		// code, output overrun, ISIZE mismatch) left its part of the stream unwritten: htslib fails on an inflate error whatever it does about checksums, so that counter is read
+		// whenever a piece was deflated, also with ARRIBA_VERIFY_CRC=0 (advisor, round 4)
+		unsigned int mismatches[2] = { 0, 0 };
+		HIP_CHECK(hipMemcpyAsync(mismatches, ctx->scratch("ingest.crc_mismatches").ptr, 8, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
-		if (mismatches > 0) { set_last_error("failed to load alignments"); return AGPU_ERR_INVALID; }
+		if (mismatches[1] > 0 || (ctx->ingest_verify_crc && mismatches[0] > 0)) { set_last_error("failed to load alignments"); return AGPU_ERR_INVALID; }
 	}
 	DeviceBuffer& counters = ctx->scratch("ingest.counters"); DeviceBuffer& rocprim_scratch = ctx->scratch("ingest.rocprim");
 	ALLOC(counters, IC_COUNT * 4);

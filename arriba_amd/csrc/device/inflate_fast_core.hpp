@@ -1,0 +1,318 @@
+// inflate_fast_core.hpp -- the DEFLATE stream of a BGZF block in two passes, for many blocks at a time (round 5; inflate_core.hpp is the one-wavefront-per-block decoder of
+// round 4, kept as the second implementation and as the way out for the few blocks this one hands back).
+//
+// Why two passes.  Decoding a DEFLATE stream is two different kinds of work: the Huffman codes are a chain (where a code ends is known only when it has been looked up), the
+// copies of the matches are not.  Round 4 gave a whole wavefront to one block: one lane walked the chain, 63 waited, and every match of more than a few bytes cost three barriers:
+// 5.9 GB/s of output on the whole device.  Here
+//   pass 1 (inflate_tokens)   ONE LANE per block, sixteen blocks per wavefront running the same loop on different data: bits from a 64-bit buffer refilled without a branch from an
+//                             8-byte load issued a token ahead, literal / length codes through a two-level table (9 bits, then up to 6 more: 852 entries at most), distance codes
+//                             through an 8-bit table (the rare longer one bit by bit over the canonical counts), base values and extra bits of lengths and distances computed, not
+//                             looked up.  Literals go straight to their place in the output; a match is only NOTED: (position, length, distance), 8 bytes.
+//   pass 2 (resolve)          a wavefront per block takes the noted matches 64 at a time, a lane per match.  A match may be copied as soon as the bytes it reads are final:
+//                             everything in front of the first match that is still pending is (inflate_match_is_ready) -- most matches of a group read from far in front of the
+//                             group and go in the first round.
+// The tables of a block are 2.7 KB of LDS, so 48 blocks are decoded per CU at a time instead of 12, and the lanes of a wavefront no longer wait for one another's barriers.
+//
+// The bytes are those zlib's inflate gives, and the streams zlib refuses are refused (over-subscribed AND incomplete codes: inftrees.c's rule, which the decoder of round 4 did not
+// have); tests/emu/inflate_check.cpp steps both passes on the host against zlib on every kind of block.  A block with more matches than INFLATE_MATCH_CAPACITY returns INFLATE_RETRY
+// and goes through the decoder of round 4.
+#ifndef AGPU_INFLATE_FAST_CORE_HPP
+#define AGPU_INFLATE_FAST_CORE_HPP 1
+
+#include "inflate_core.hpp"
+
+namespace agpu {
+
+const uint32_t FAST_LITLEN_ROOT = 9, FAST_LITLEN_ENTRIES = 852 /* 512 + the 340 entries all second-level tables of a complete code of 286 symbols can have (zlib's "enough") */, FAST_DISTANCE_ROOT = 8;
+const uint32_t INFLATE_MATCH_CAPACITY = 8192; // matches noted per block (64 KB of notes for 64 KB of output); a 64 KB BAM block at the usual levels has 4 000 - 6 000
+enum { INFLATE_RETRY = 9 };
+
+// table entries: payload << 6 | type << 4 | bits.  0 = no such code.
+enum { FAST_LITERAL = 1, FAST_LENGTH = 2 /* payload = symbol - 256: 0 end of block, 1..29 a length code */, FAST_SUBTABLE = 3 /* payload = where it starts, bits = how many bits index it */ };
+AGPU_HD uint16_t fast_entry(uint32_t type, uint32_t payload, uint32_t n_bits) { return (uint16_t) (payload << 6 | type << 4 | n_bits); }
+
+struct InflateFastTables { // what one decoding lane keeps in LDS: 2 688 bytes
+	uint16_t litlen[FAST_LITLEN_ENTRIES];
+	uint16_t distance[1 << FAST_DISTANCE_ROOT]; // 0x8000 | symbol << 4 | bits; 0 = longer than 8 bits (or no such code).  While a dynamic header is read: the 7-bit table of the code-length code, as bytes
+	uint16_t count[16], first[16], next[16];    // codes per length (left at the distance code's for its long codes), first canonical code per length, the next one to hand out
+	uint8_t distance_symbols[32];               // distance symbols by (length, symbol): the canonical decode of codes longer than 8 bits
+	uint8_t lengths[320];                       // code lengths of the block being set up: literals / lengths, then distances
+	uint8_t code_lengths[24];                   // lengths of the code-length code
+};
+
+// the bits of the stream, lowest first; at least 56 of them after refill().  `ahead` is the 8 bytes at `next`, loaded when the refill before this one moved `next`: the latency of
+// the load lies under the decoding of a token.  Reads up to 16 bytes behind the end of the input (the callers pad).
+struct FastBits {
+	const uint8_t* next; const uint8_t* end;
+	unsigned long long buffer, ahead; uint32_t count;
+	AGPU_HD static unsigned long long load64(const uint8_t* p) { unsigned long long word; __builtin_memcpy(&word, p, 8); return word; }
+	AGPU_HD void start(const uint8_t* input, uint32_t size) { next = input; end = input + size; buffer = 0; count = 0; ahead = load64(next); }
+	AGPU_HD void refill() { // (the bits above `count` that the shift leaves in the buffer are the low bits of the byte at `next`: the next refill puts the same bits there again)
+		buffer |= ahead << count;
+		const uint32_t bytes = (63u - count) >> 3;
+		next += bytes; count += bytes << 3;
+		ahead = load64(next);
+	}
+	AGPU_HD uint32_t peek(uint32_t n) const { return (uint32_t) buffer & ((1u << n) - 1u); } // n <= 16
+	AGPU_HD void drop(uint32_t n) { buffer >>= n; count -= n; }
+	AGPU_HD uint32_t take(uint32_t n) { const uint32_t value = peek(n); drop(n); return value; }
+	AGPU_HD bool overrun() const { return next > end && (uint32_t) (next - end) * 8u > count; } // more bits were taken than the input holds
+};
+
+AGPU_HD uint32_t fast_reverse_bits(uint32_t code, uint32_t length) { // the stream delivers a code with its first bit lowest
+#if defined(__clang__)
+	return __builtin_bitreverse32(code) >> (32u - length);
+#else
+	uint32_t reversed = 0;
+	for (uint32_t k = 0; k < length; ++k) { reversed = reversed << 1 | (code & 1u); code >>= 1; }
+	return reversed;
+#endif
+}
+
+// counts per length, the check zlib makes (inftrees.c: over-subscribed sets are refused, incomplete ones too unless the code has a single symbol of one bit -- or none at all),
+// the first canonical code of every length (RFC 1951 3.2.2).  Returns the longest length, -1 for a set zlib refuses.
+AGPU_HD int fast_count_lengths(const uint8_t* lengths, uint32_t n, InflateFastTables& t) {
+	for (uint32_t l = 0; l < 16; ++l) t.count[l] = 0;
+	for (uint32_t s = 0; s < n; ++s) t.count[lengths[s]]++;
+	t.count[0] = 0;
+	int left = 1, longest = 0;
+	for (uint32_t l = 1; l < 16; ++l) {
+		left = (left << 1) - (int) t.count[l];
+		if (left < 0) return -1;
+		if (t.count[l] != 0) longest = (int) l;
+	}
+	if (left > 0 && longest > 1) return -1;
+	uint32_t code = 0;
+	t.first[0] = 0;
+	for (uint32_t l = 1; l < 16; ++l) { code = (code + t.count[l - 1]) << 1; t.first[l] = (uint16_t) code; }
+	return longest;
+}
+
+// literal / length code: 9 bits at once, the longer codes through a second table per 9-bit prefix (as wide as the longest code under that prefix needs)
+AGPU_HD int fast_build_litlen(const uint8_t* lengths, uint32_t n, InflateFastTables& t) {
+	const int longest = fast_count_lengths(lengths, n, t);
+	if (longest < 0) return INFLATE_BAD_CODE_LENGTHS;
+	uint32_t* words = (uint32_t*) t.litlen;
+	for (uint32_t k = 0; k < (1u << FAST_LITLEN_ROOT) / 2; ++k) words[k] = 0;
+	if (longest > (int) FAST_LITLEN_ROOT) { // how wide the second table of every prefix is
+		for (uint32_t l = 0; l < 16; ++l) t.next[l] = t.first[l];
+		for (uint32_t s = 0; s < n; ++s) {
+			const uint32_t length = lengths[s];
+			if (length == 0) continue;
+			const uint32_t code = t.next[length]++;
+			if (length <= FAST_LITLEN_ROOT) continue;
+			const uint32_t prefix = fast_reverse_bits(code, length) & ((1u << FAST_LITLEN_ROOT) - 1u);
+			if ((t.litlen[prefix] & 15u) < length - FAST_LITLEN_ROOT) t.litlen[prefix] = fast_entry(FAST_SUBTABLE, 0, length - FAST_LITLEN_ROOT);
+		}
+	}
+	for (uint32_t l = 0; l < 16; ++l) t.next[l] = t.first[l];
+	uint32_t next_free = 1u << FAST_LITLEN_ROOT;
+	for (uint32_t s = 0; s < n; ++s) {
+		const uint32_t length = lengths[s];
+		if (length == 0) continue;
+		const uint32_t reversed = fast_reverse_bits(t.next[length]++, length);
+		const uint32_t type = s < 256 ? FAST_LITERAL : FAST_LENGTH, payload = s < 256 ? s : s - 256;
+		if (length <= FAST_LITLEN_ROOT) {
+			const uint16_t entry = fast_entry(type, payload, length);
+			for (uint32_t k = reversed; k < (1u << FAST_LITLEN_ROOT); k += 1u << length) t.litlen[k] = entry;
+			continue;
+		}
+		const uint32_t prefix = reversed & ((1u << FAST_LITLEN_ROOT) - 1u);
+		const uint32_t bits = t.litlen[prefix] & 15u;
+		uint32_t offset = t.litlen[prefix] >> 6;
+		if (offset == 0) {
+			offset = next_free; next_free += 1u << bits;
+			if (next_free > FAST_LITLEN_ENTRIES) return INFLATE_RETRY; // (cannot happen with a complete code of at most 286 symbols; the other decoder has no such bound)
+			t.litlen[prefix] = fast_entry(FAST_SUBTABLE, offset, bits);
+		}
+		const uint16_t entry = fast_entry(type, payload, length - FAST_LITLEN_ROOT);
+		for (uint32_t k = reversed >> FAST_LITLEN_ROOT; k < (1u << bits); k += 1u << (length - FAST_LITLEN_ROOT)) t.litlen[offset + k] = entry;
+	}
+	return INFLATE_OK;
+}
+
+// distance code: 8 bits at once; a code of more than 8 bits (a distance that is used less than once in 256 matches) bit by bit over the canonical counts
+AGPU_HD int fast_build_distance(const uint8_t* lengths, uint32_t n, InflateFastTables& t) {
+	if (fast_count_lengths(lengths, n, t) < 0) return INFLATE_BAD_CODE_LENGTHS;
+	uint32_t* words = (uint32_t*) t.distance;
+	for (uint32_t k = 0; k < (1u << FAST_DISTANCE_ROOT) / 2; ++k) words[k] = 0;
+	uint32_t offset = 0;
+	for (uint32_t l = 1; l < 16; ++l) { t.next[l] = (uint16_t) offset; offset += t.count[l]; } // (here: where the symbols of a length start in distance_symbols)
+	for (uint32_t s = 0; s < n; ++s) if (lengths[s] != 0) t.distance_symbols[t.next[lengths[s]]++] = (uint8_t) s;
+	for (uint32_t l = 0; l < 16; ++l) t.next[l] = t.first[l];
+	for (uint32_t s = 0; s < n; ++s) {
+		const uint32_t length = lengths[s];
+		if (length == 0) continue;
+		const uint32_t code = t.next[length]++;
+		if (length > FAST_DISTANCE_ROOT) continue;
+		const uint16_t entry = (uint16_t) (0x8000u | s << 4 | length);
+		for (uint32_t k = fast_reverse_bits(code, length); k < (1u << FAST_DISTANCE_ROOT); k += 1u << length) t.distance[k] = entry;
+	}
+	return INFLATE_OK;
+}
+AGPU_HD int fast_long_distance_symbol(FastBits& bits, const InflateFastTables& t) { // -1: no such code
+	int code = 0, first = 0, index = 0;
+	for (uint32_t length = 1; length < 16; ++length) {
+		code |= (int) bits.take(1);
+		const int count = t.count[length];
+		if (code - count < first) return t.distance_symbols[index + (code - first)];
+		index += count; first += count; first <<= 1; code <<= 1;
+	}
+	return -1;
+}
+
+// the header of a dynamic block (RFC 1951 3.2.7): the lengths of both codes, run-length coded with a code of 19 symbols, itself given by 3-bit lengths
+AGPU_HD int fast_read_dynamic_header(FastBits& bits, InflateFastTables& t, uint32_t& n_litlen, uint32_t& n_distance) {
+	static const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+	bits.refill();
+	n_litlen = bits.take(5) + 257; n_distance = bits.take(5) + 1;
+	const uint32_t n_code_lengths = bits.take(4) + 4;
+	if (n_litlen > 286 || n_distance > 30) return INFLATE_BAD_CODE_LENGTHS;
+	for (uint32_t k = 0; k < 19; ++k) t.code_lengths[k] = 0;
+	for (uint32_t k = 0; k < n_code_lengths; ++k) { if ((k & 7u) == 0) bits.refill(); t.code_lengths[order[k]] = (uint8_t) bits.take(3); }
+	if (bits.overrun()) return INFLATE_INPUT_OVERRUN;
+	// the code of the code lengths must be complete (zlib); 7 bits at once
+	for (uint32_t l = 0; l < 8; ++l) t.count[l] = 0;
+	for (uint32_t k = 0; k < 19; ++k) t.count[t.code_lengths[k]]++;
+	t.count[0] = 0;
+	int left = 1;
+	for (uint32_t l = 1; l < 8; ++l) { left = (left << 1) - (int) t.count[l]; if (left < 0) return INFLATE_BAD_CODE_LENGTHS; }
+	if (left > 0) return INFLATE_BAD_CODE_LENGTHS;
+	uint32_t code = 0;
+	t.next[0] = 0;
+	for (uint32_t l = 1; l < 8; ++l) { code = (code + t.count[l - 1]) << 1; t.next[l] = (uint16_t) code; }
+	uint8_t* table = (uint8_t*) t.distance;
+	for (uint32_t k = 0; k < 19; ++k) {
+		const uint32_t length = t.code_lengths[k];
+		if (length == 0) continue;
+		for (uint32_t j = fast_reverse_bits(t.next[length]++, length); j < 128; j += 1u << length) table[j] = (uint8_t) (k << 3 | length);
+	}
+	const uint32_t total = n_litlen + n_distance;
+	uint32_t filled = 0;
+	while (filled < total) {
+		bits.refill();
+		if (bits.overrun()) return INFLATE_INPUT_OVERRUN; // (advisor, round 4: the loops of the header checked nothing)
+		const uint32_t entry = table[bits.peek(7)];
+		bits.drop(entry & 7u);
+		const uint32_t symbol = entry >> 3;
+		if (symbol < 16) { t.lengths[filled++] = (uint8_t) symbol; continue; }
+		uint32_t repeat, value = 0;
+		if (symbol == 16) { if (filled == 0) return INFLATE_BAD_CODE_LENGTHS; value = t.lengths[filled - 1]; repeat = 3 + bits.take(2); }
+		else if (symbol == 17) repeat = 3 + bits.take(3);
+		else repeat = 11 + bits.take(7);
+		if (filled + repeat > total) return INFLATE_BAD_CODE_LENGTHS;
+		while (repeat-- > 0) t.lengths[filled++] = (uint8_t) value;
+	}
+	if (t.lengths[256] == 0) return INFLATE_BAD_CODE_LENGTHS; // no end-of-block code
+	return INFLATE_OK;
+}
+
+// a noted match: position of its first byte in the block's output | length << 16 | distance << 32
+AGPU_HD unsigned long long inflate_match_note(uint32_t position, uint32_t length, uint32_t distance) { return (unsigned long long) position | (unsigned long long) length << 16 | (unsigned long long) distance << 32; }
+AGPU_HD uint32_t inflate_note_position(unsigned long long note) { return (uint32_t) note & 0xFFFFu; }
+AGPU_HD uint32_t inflate_note_length(unsigned long long note) { return (uint32_t) (note >> 16) & 0xFFFFu; }
+AGPU_HD uint32_t inflate_note_distance(unsigned long long note) { return (uint32_t) (note >> 32); }
+
+// Pass 1, one lane: the literals of the block into `output` (out_size bytes: the ISIZE of the gzip trailer), its matches into `notes`.
+AGPU_HD int inflate_tokens(const uint8_t* input, uint32_t in_size, uint8_t* output, uint32_t out_size, unsigned long long* notes, uint32_t capacity, uint32_t& n_notes, InflateFastTables& t) {
+	FastBits bits; bits.start(input, in_size);
+	uint32_t produced = 0, noted = 0;
+	n_notes = 0;
+	bool last_block = false;
+	while (!last_block) {
+		bits.refill();
+		if (bits.overrun()) return INFLATE_INPUT_OVERRUN;
+		last_block = bits.take(1) != 0;
+		const uint32_t type = bits.take(2);
+		if (type == 0) { // stored: LEN, NLEN, then LEN bytes as they are
+			bits.drop(bits.count & 7u); bits.refill();
+			const uint32_t length = bits.take(16), complement = bits.take(16);
+			if ((length ^ 0xFFFFu) != complement) return INFLATE_BAD_STORED_LENGTH;
+			if (produced + length > out_size) return INFLATE_OUTPUT_OVERRUN;
+			for (uint32_t k = 0; k < length; ++k) {
+				if ((k & 3u) == 0) { bits.refill(); if (bits.overrun()) return INFLATE_INPUT_OVERRUN; }
+				output[produced++] = (uint8_t) bits.take(8);
+			}
+			continue;
+		}
+		if (type == 3) return INFLATE_BAD_BLOCK_TYPE;
+		uint32_t n_litlen = 288, n_distance = 32; // fixed code (3.2.6): 288 and 32 symbols (the last two of each never occur in a valid stream: refused when they are decoded)
+		if (type == 1) {
+			for (uint32_t s = 0; s < 288; ++s) t.lengths[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+			for (uint32_t s = 0; s < 32; ++s) t.lengths[288 + s] = 5;
+		} else { const int status = fast_read_dynamic_header(bits, t, n_litlen, n_distance); if (status != INFLATE_OK) return status; }
+		{ const int status = fast_build_litlen(t.lengths, n_litlen, t); if (status != INFLATE_OK) return status; }
+		{ const int status = fast_build_distance(t.lengths + n_litlen, n_distance, t); if (status != INFLATE_OK) return status; }
+		while (true) { // a token per turn: at most 15 + 5 + 15 + 13 = 48 bits
+			bits.refill();
+			if (bits.next > bits.end && bits.overrun()) return INFLATE_INPUT_OVERRUN;
+			uint32_t entry = t.litlen[bits.peek(FAST_LITLEN_ROOT)];
+			if ((entry >> 4 & 3u) == FAST_SUBTABLE) { bits.drop(FAST_LITLEN_ROOT); entry = t.litlen[(entry >> 6) + bits.peek(entry & 15u)]; }
+			if (entry == 0) return INFLATE_BAD_SYMBOL;
+			bits.drop(entry & 15u);
+			const uint32_t payload = entry >> 6;
+			if ((entry >> 4 & 3u) == FAST_LITERAL) {
+				if (produced >= out_size) return INFLATE_OUTPUT_OVERRUN;
+				output[produced++] = (uint8_t) payload;
+				continue;
+			}
+			if (payload == 0) break; // end of block
+			if (payload > 29) return INFLATE_BAD_SYMBOL;
+			uint32_t length;
+			{ const uint32_t s = payload - 1; // 0..28 (3.2.5: lengths 3..258 in 29 codes, 0..5 extra bits)
+			  if (s < 8) length = 3 + s;
+			  else if (s == 28) length = 258;
+			  else { const uint32_t extra = (s >> 2) - 1; length = 3 + ((4 + (s & 3u)) << extra) + bits.take(extra); } }
+			int symbol;
+			{ const uint32_t found = t.distance[bits.peek(FAST_DISTANCE_ROOT)];
+			  if (found != 0) { bits.drop(found & 15u); symbol = (int) (found >> 4 & 63u); } else symbol = fast_long_distance_symbol(bits, t); }
+			if (symbol < 0 || symbol > 29) return INFLATE_BAD_DISTANCE;
+			uint32_t distance;
+			if (symbol < 4) distance = (uint32_t) symbol + 1;
+			else { const uint32_t extra = ((uint32_t) symbol >> 1) - 1; distance = 1 + ((2 + ((uint32_t) symbol & 1u)) << extra) + bits.take(extra); }
+			if (distance > produced) return INFLATE_BAD_DISTANCE;
+			if (produced + length > out_size) return INFLATE_OUTPUT_OVERRUN;
+			if (noted == capacity) return INFLATE_RETRY;
+			notes[noted++] = inflate_match_note(produced, length, distance);
+			produced += length;
+		}
+	}
+	if (bits.overrun()) return INFLATE_INPUT_OVERRUN;
+	n_notes = noted;
+	return produced == out_size ? INFLATE_OK : INFLATE_SIZE_MISMATCH;
+}
+
+// Pass 2.  A match reads the `min(length, distance)` bytes at its distance (a match that overlaps itself repeats them) and may be copied when they are final; `frontier` is the
+// position of the first match (in the order of the stream) that has not been copied: every byte in front of it is a literal or belongs to a match that has been.
+AGPU_HD bool inflate_match_is_ready(uint32_t position, uint32_t length, uint32_t distance, uint32_t frontier) {
+	return position - distance + (length < distance ? length : distance) <= frontier;
+}
+// one match, by one lane: generations of `distance` bytes, all read from the same place (what stands at the distance when the match starts)
+AGPU_HD void inflate_copy_match(uint8_t* output, uint32_t position, uint32_t length, uint32_t distance) {
+	const uint8_t* source = output + position - distance;
+	uint8_t* target = output + position;
+	if (distance >= 8) {
+		for (uint32_t done = 0; done < length; done += distance) {
+			const uint32_t share = length - done < distance ? length - done : distance;
+			uint32_t k = 0;
+			for (; k + 8 <= share; k += 8) { const unsigned long long word = FastBits::load64(source + k); __builtin_memcpy(target + done + k, &word, 8); }
+			if (k < share) { // (the 8 bytes read here may end up to 7 bytes behind the match's first byte: what lies there is not used, and the buffer of the output is padded)
+				unsigned long long word = FastBits::load64(source + k);
+				for (; k < share; ++k) { target[done + k] = (uint8_t) word; word >>= 8; }
+			}
+		}
+	} else { // a period of fewer than 8 bytes: kept in a register
+		unsigned long long pattern = 0;
+		for (uint32_t k = 0; k < distance; ++k) pattern |= (unsigned long long) source[k] << (8 * k);
+		uint32_t phase = 0;
+		for (uint32_t k = 0; k < length; ++k) { target[k] = (uint8_t) (pattern >> (8 * phase)); if (++phase == distance) phase = 0; }
+	}
+}
+// all matches in the order of the stream (the stepping harness; the device takes them 64 at a time, agpu_ingest.hip: bgzf_resolve_kernel)
+AGPU_HD void inflate_resolve_in_order(uint8_t* output, const unsigned long long* notes, uint32_t n_notes) {
+	for (uint32_t k = 0; k < n_notes; ++k) inflate_copy_match(output, inflate_note_position(notes[k]), inflate_note_length(notes[k]), inflate_note_distance(notes[k]));
+}
+
+}
+
+#endif

@@ -694,7 +694,8 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 		run.defer_output = session->defer_output;
 		const int other = 1 - sample.lane;
 		run.before_host_writer = [session, other] { session->join_writer_of(other); };
-		{ const std::string text = session->take_deferred_error(); if (!text.empty()) throw Failure{ text + " (writing the last file of an earlier sample)" }; }
+		// (advisor, round 4: nothing may throw between here and `done` -- the clean-up behind the catch blocks clears the lane's options, which the feeder of this sample reads
+		// until it is joined, and a sample that stays at the front of the queue with cleared options cannot be retried)
 		if (sample.feeder.joinable()) sample.feeder.join(); // (the feed of this sample: under the stages of the sample before if it was submitted ahead)
 		session->join_writer_of(sample.lane); // (the last file of the lane's sample before: written from a detached sample beside this sample's feed; done long ago, normally)
 		struct Done { arriba_workflow_session& session; ~Done() { // on every way out: the ingest buffers are free for the next feed, the sample leaves the queue
@@ -705,6 +706,9 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 		if (!sample.error.empty()) throw Failure{ sample.error };
 		run.after_ingest = [session, &sample] { { std::lock_guard<std::mutex> lock(session->mutex); sample.ingest_finished = true; } session->release_ingest(); };
 		run_sample(run, run.device_ingest, sample_started);
+		// an I/O error on the deferred file of an EARLIER sample is reported behind this one: this sample has gone through and its own files are as they should be (its last
+		// one possibly still being written, arriba_workflow_flush); the call fails with the earlier sample's message so that the caller hears of it at the first call after it happened
+		{ const std::string text = session->take_deferred_error(); if (!text.empty()) throw Failure{ text + " (writing the last file of an earlier sample; the files of this sample are not affected)" }; }
 	}
 	catch (const Failure& failure) { g_error = failure.text; status = -1; }
 	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); status = -1; }

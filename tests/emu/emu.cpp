@@ -29,7 +29,7 @@
 #include "../../arriba_amd/csrc/device/ingest_core.hpp"
 #include "../../arriba_amd/csrc/device/shard_host.hpp"
 #include "../../arriba_amd/csrc/device/crc32_core.hpp"
-#include "../../arriba_amd/csrc/device/inflate_core.hpp"
+#include "../../arriba_amd/csrc/device/inflate_fast_core.hpp"
 #include <map>
 #include <mutex>
 #include <set>
