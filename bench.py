@@ -217,22 +217,33 @@ def deflated_leg(pipeline, directory, fragments, stress, stored_output, steps=2)
     output = prefix + ".fusions.tsv"
     seconds = []
     pipeline.submit(prefix + ".bam")
-    for _ in range(steps + 1):  # (the first one is warm-up; the samples in a queue, as in the timed steps)
+    for k in range(steps + 1):  # (the first one is warm-up; the samples in a queue, as in the timed steps)
+        if k == 1:
+            pipeline.set_profiling(True)  # (a new epoch: the launches of the timed steps of this leg)
         pipeline.submit(prefix + ".bam")
         started = time.perf_counter()
         pipeline.sample(prefix + ".bam", output)
         seconds.append(time.perf_counter() - started)
     pipeline.cancel()
     pipeline.flush()
+    container_kernels = {}
+    for name, ms, size in pipeline.kernel_profile():  # (the launches of the steps, and of the sample that was fed ahead and thrown away: the sums are per fed sample)
+        if name.startswith("bgzf_"):
+            entry = container_kernels.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0})
+            entry["launches"] += 1; entry["ms"] += ms; entry["bytes"] += size
     timing = pipeline.timing
     counts = dict(pipeline.report)
     digest = lambda path: hashlib.sha256(open(path, "rb").read()).hexdigest()
     same = digest(output) == digest(stored_output)
     os.remove(prefix + ".bam")
     per_step = sum(seconds[1:]) / steps
-    return {"what": "the same %d fragments as a BAM file with deflated BGZF blocks (zlib level 1, %.1f GB: %.2f x smaller), inflated on the device (bgzf_inflate_kernel)" % (counts.get("read_chimeric_alignments", 0), bam_bytes / 1e9, counts.get("bam_stream_bytes", 0) / max(bam_bytes, 1)),
+    return {"what": "the same %d fragments as a BAM file with deflated BGZF blocks (zlib level 1, %.1f GB: %.2f x smaller), inflated on the device (bgzf_inflate_tokens_kernel + bgzf_inflate_resolve_kernel)" % (counts.get("read_chimeric_alignments", 0), bam_bytes / 1e9, counts.get("bam_stream_bytes", 0) / max(bam_bytes, 1)),
             "chimeric_reads_per_s": counts.get("read_chimeric_alignments", 0) / per_step, "seconds_per_step": round(per_step, 4), "steps": steps, "bam_GB": round(bam_bytes / 1e9, 2),
-            "last_step": {key: round(value, 4) for key, value in timing.items()}, "fusions_tsv_equals_the_stored_sample's": same, "generate_seconds": round(generated, 1)}
+            "last_step": {key: round(value, 4) for key, value in timing.items()}, "fusions_tsv_equals_the_stored_sample's": same, "generate_seconds": round(generated, 1),
+            # the kernels of the container (event times: they run beside the stages of the sample in front): ms per launch, GB/s of their algorithmic bytes (compressed in + stream out for
+            # pass 1, the stream for pass 2 and the CRC)
+            "container_kernels": {name: {"launches": values["launches"], "ms_per_launch": round(values["ms"] / values["launches"], 3), "ms_per_fed_sample": round(values["ms"] / (steps + 1), 1),
+                                         "GB_per_s": round(values["bytes"] / max(values["ms"], 1e-9) / 1e6, 1)} for name, values in container_kernels.items()}}
 
 
 def host_only(args):

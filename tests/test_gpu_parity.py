@@ -780,58 +780,61 @@ def test_mismapper_stress_of_config_3_against_the_reference(built, tmp_path):
 def test_filter_mismappers_gives_the_same_verdicts_under_every_schedule(built, tmp_path):
     """review of round 4, item 3: the verdict of a read is a function of the read (source/filter_mismappers.cpp:86-187), but mismapper_heavy_kernel shares a memo table and task
     lists among the 64 lanes of a wavefront and hands the reads of a queue to 5 120 persistent workgroups -- and one GPU box of round 4 once gave 3 reads another verdict
-    (DESIGN.md section 2).  The stage is run again and again on the mismapper stress of config 3 (clips of 40-70 nt copied from the partner gene, -U 32767): ten times with the
-    workgroups of the product, three times with 7, once with a single one (every read behind the other, one memo table for all of them), once with the jobs in the other order
-    and once with four wavefronts per SIMD: the verdict bytes of all runs must be the same bytes."""
+    (DESIGN.md section 2).  The stage is run again and again on two samples -- the mismapper stress of config 3 (clips of 40-70 nt copied from the partner gene, -U 32767: long
+    searches, hardly a mis-mapper among them) and a sample with families of homologous genes (hundreds of reads that ARE mis-mappers) --: ten times with the workgroups of the
+    product, three times with 7, once with a single one (every read behind the other, one memo table for all of them), once with four wavefronts per SIMD and once with the jobs
+    in the other order: the verdict bytes of all runs must be the same bytes."""
     import subprocess
     import bench
     from ctypes import byref, c_uint64
     from arriba_amd.pipeline import DevicePipeline, HostSession
     fragments = int(os.environ.get("ARRIBA_DETERMINISM_FRAGMENTS", "100000"))
-    prefix = str(tmp_path / "stress")
-    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32"] + bench.workload_args(fragments, 1000, stress=True), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    session = HostSession(prefix + ".fa", prefix + ".gtf")
-    pipeline = DevicePipeline(session, params={"subsampling_threshold": 32767}, bam=prefix + ".bam", piece_bytes=8 << 20)
-    pipeline.run_read_level()
-    pipeline.find_fusions()
-    pipeline.upload_coverage()
-    pipeline.merge_adjacent_fusions(); pipeline.filter_multimappers(); pipeline.estimate_expected_fusions(); pipeline.filter_candidate_predicates(); pipeline.filter_relative_support()
-    pipeline.recover_internal_tandem_duplication(); pipeline.filter_both_intronic(); pipeline.filter_in_vitro(); pipeline.recover_both_spliced(); pipeline.select_most_supported_breakpoints()
-    pipeline.filter_marginal_read_through(); pipeline.recover_many_spliced(); pipeline.filter_short_anchor(); pipeline.filter_end_to_end(); pipeline.filter_no_coverage()
-    pipeline.make_kmer_index()
-    pipeline.filter_homologs()
-    filters_before = pipeline.filters().copy()
+    samples = [("stress", bench.workload_args(fragments, 1000, stress=True), {"subsampling_threshold": 32767}, 0),
+               ("homologs", ["--seed", "29", "--fragments", str(2 * fragments), "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--homolog-families", "4"], None, 20)]
     knobs = ("ARRIBA_HEAVY_WORKGROUPS", "ARRIBA_MISMAPPER_JOB_ORDER", "ARRIBA_HEAVY_WAVES")
-    def verdicts(environment):
-        for key in knobs:
-            os.environ.pop(key, None)
-        os.environ.update(environment)
-        try:
-            pipeline.set_read_filters(filters_before)  # (a read that a run marked stays marked: every run starts from the filters in front of the stage)
-            n_jobs = c_uint64()
-            pipeline._check(pipeline.api.mismapper_jobs(pipeline.ctx, byref(n_jobs)))
-            out = np.zeros(max(n_jobs.value, 1), dtype=np.uint8)
-            pipeline._check(pipeline.api.mismapper_verdicts(pipeline.ctx, int(pipeline.scalars["max_mate_gap"]), 0, 1, out.ctypes.data))
-            # the jobs are the same reads whatever their order: the verdicts per read
-            per_read = pipeline.filters() == 11  # FILTER_mismappers (source/common.hpp:29-67)
-            return n_jobs.value, out, per_read
-        finally:
+    for name, arguments, params, least_positive in samples:
+        prefix = str(tmp_path / name)
+        subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32"] + arguments, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        session = HostSession(prefix + ".fa", prefix + ".gtf")
+        pipeline = DevicePipeline(session, params=params, bam=prefix + ".bam", piece_bytes=8 << 20)
+        pipeline.run_read_level()
+        pipeline.find_fusions()
+        pipeline.upload_coverage()
+        pipeline.merge_adjacent_fusions(); pipeline.filter_multimappers(); pipeline.estimate_expected_fusions(); pipeline.filter_candidate_predicates(); pipeline.filter_relative_support()
+        pipeline.recover_internal_tandem_duplication(); pipeline.filter_both_intronic(); pipeline.filter_in_vitro(); pipeline.recover_both_spliced(); pipeline.select_most_supported_breakpoints()
+        pipeline.filter_marginal_read_through(); pipeline.recover_many_spliced(); pipeline.filter_short_anchor(); pipeline.filter_end_to_end(); pipeline.filter_no_coverage()
+        pipeline.make_kmer_index()
+        pipeline.filter_homologs()
+        filters_before = pipeline.filters().copy()
+        def verdicts(environment):
             for key in knobs:
                 os.environ.pop(key, None)
-    n_jobs, first, first_per_read = verdicts({})
-    assert n_jobs > fragments // 20 and first.sum() > 50, (n_jobs, int(first.sum()))  # (the stress sample exists to have reads to re-align and mis-mappers among them)
-    assert int(first.sum()) == int(first_per_read.sum() - (filters_before == 11).sum())
-    schedules = [("5120 workgroups, run %d" % k, {}) for k in range(2, 11)] + [("7 workgroups, run %d" % k, {"ARRIBA_HEAVY_WORKGROUPS": "7"}) for k in range(1, 4)] + \
-                [("one workgroup", {"ARRIBA_HEAVY_WORKGROUPS": "1"}), ("four wavefronts per SIMD", {"ARRIBA_HEAVY_WAVES": "4", "ARRIBA_HEAVY_WORKGROUPS": "4096"})]
-    for label, environment in schedules:
-        count, again, _ = verdicts(environment)
-        assert count == n_jobs, label
-        different = np.flatnonzero(again != first)
-        assert different.size == 0, (label, int(different.size), different[:8].tolist())
-    count, _, per_read = verdicts({"ARRIBA_MISMAPPER_JOB_ORDER": "candidate"})  # (another order of the jobs: compared per read)
-    assert count == n_jobs and np.array_equal(per_read, first_per_read)
-    pipeline.close()
-    session.close()
+            os.environ.update(environment)
+            try:
+                pipeline.set_read_filters(filters_before)  # (a read that a run marked stays marked: every run starts from the filters in front of the stage)
+                n_jobs = c_uint64()
+                pipeline._check(pipeline.api.mismapper_jobs(pipeline.ctx, byref(n_jobs)))
+                out = np.zeros(max(n_jobs.value, 1), dtype=np.uint8)
+                pipeline._check(pipeline.api.mismapper_verdicts(pipeline.ctx, int(pipeline.scalars["max_mate_gap"]), 0, 1, out.ctypes.data))
+                return n_jobs.value, out, pipeline.filters() == 11  # FILTER_mismappers (source/common.hpp:29-67): the jobs are the same reads whatever their order -- the verdicts per read
+            finally:
+                for key in knobs:
+                    os.environ.pop(key, None)
+        n_jobs, first, first_per_read = verdicts({})
+        assert n_jobs > fragments // 50 and first.sum() >= least_positive, (name, n_jobs, int(first.sum()))
+        assert int(first.sum()) == int(first_per_read.sum()) - int((filters_before == 11).sum()), name
+        schedules = [("5120 workgroups, run %d" % k, {}) for k in range(2, 11)] + [("7 workgroups, run %d" % k, {"ARRIBA_HEAVY_WORKGROUPS": "7"}) for k in range(1, 4)] + \
+                    [("one workgroup", {"ARRIBA_HEAVY_WORKGROUPS": "1"}), ("four wavefronts per SIMD", {"ARRIBA_HEAVY_WAVES": "4", "ARRIBA_HEAVY_WORKGROUPS": "4096"})]
+        for label, environment in schedules:
+            count, again, _ = verdicts(environment)
+            assert count == n_jobs, (name, label)
+            different = np.flatnonzero(again != first)
+            assert different.size == 0, (name, label, int(different.size), different[:8].tolist())
+        count, _, per_read = verdicts({"ARRIBA_MISMAPPER_JOB_ORDER": "candidate"})  # (another order of the jobs: compared per read)
+        assert count == n_jobs and np.array_equal(per_read, first_per_read), name
+        print("%s: %d jobs, %d mis-mappers, %d runs identical" % (name, n_jobs, int(first.sum()), len(schedules) + 2))
+        pipeline.close()
+        session.close()
 
 
 def test_samples_in_a_queue_through_one_session_on_the_gpu(built, tmp_path):
