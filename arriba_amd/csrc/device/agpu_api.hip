@@ -666,6 +666,7 @@ void agpu_destroy(agpu_ctx* ctx) {
 	  for (size_t k = 0; k < progress.events.size(); ++k) (void) hipEventDestroy(progress.events[k]);
 	  if (progress.host_words) (void) hipHostFree(progress.host_words); }
 	if (ctx->piece_stream) { (void) hipStreamSynchronize(ctx->piece_stream); (void) hipStreamDestroy(ctx->piece_stream); }
+	if (ctx->piece_stream2) { (void) hipStreamSynchronize(ctx->piece_stream2); (void) hipStreamDestroy(ctx->piece_stream2); }
 	for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { if (ctx->piece_copied[k]) (void) hipEventDestroy(ctx->piece_copied[k]); if (ctx->piece_ready[k]) (void) hipEventDestroy(ctx->piece_ready[k]); if (ctx->piece_done[k]) (void) hipEventDestroy(ctx->piece_done[k]); }
 	delete ctx;
 }
@@ -1148,7 +1149,7 @@ int agpu_get_kernel_profile(agpu_ctx* ctx, char* names, float* ms, uint64_t* byt
 	if (!ctx || !count) return AGPU_ERR_INVALID;
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
-	if (ctx->piece_stream) HIP_CHECK(hipStreamSynchronize(ctx->piece_stream));
+	if (ctx->piece_stream) { HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); HIP_CHECK(hipStreamSynchronize(ctx->piece_stream2)); }
 	if (ctx->ingest_progress.work) HIP_CHECK(hipStreamSynchronize(ctx->ingest_progress.work));
 	collect_kernel_samples(ctx);
 	std::lock_guard<std::mutex> lock(ctx->profile_mutex);

@@ -173,7 +173,7 @@ struct agpu_ctx {
 	agpu::IngestProgress ingest_progress;
 	// A pushed piece: copied on the context's stream (piece_copied: the caller's buffer is free), unwrapped and CRC-checked on a stream of its own (piece_stream; piece_ready: its
 	// bytes are in the stream, piece_done: the raw bytes are not needed any more), so that the copy of the next piece never waits for a kernel; AGPU_PIECE_SLOTS raw buffers in turn
-	hipStream_t piece_stream = nullptr; hipEvent_t piece_copied[AGPU_PIECE_SLOTS] = {}, piece_ready[AGPU_PIECE_SLOTS] = {}, piece_done[AGPU_PIECE_SLOTS] = {};
+	hipStream_t piece_stream = nullptr, piece_stream2 = nullptr /* deflated pieces take the two in turn */; hipEvent_t piece_copied[AGPU_PIECE_SLOTS] = {}, piece_ready[AGPU_PIECE_SLOTS] = {}, piece_done[AGPU_PIECE_SLOTS] = {};
 	std::vector<uint64_t> host_coverage_window_offset;
 	agpu::DeviceBuffer gather_ids, gather_cigar_base, gather_seq_base, gather_name_base; // agpu_gather_rows_begin -> _copy
 	uint64_t gather_n = 0, gather_sizes[3] = { 0, 0, 0 };

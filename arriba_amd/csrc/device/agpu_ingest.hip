@@ -606,7 +606,7 @@ int grow_stream(agpu_ctx* ctx, uint64_t needed) {
 	DeviceBuffer larger;
 	const uint64_t doubled = ctx->ingest_stream.capacity * 2;
 	if (!larger.allocate(std::max<uint64_t>(needed + (needed >> 3), std::max<uint64_t>(doubled, 64u << 20)))) { set_last_error("hipMalloc failed (BAM stream)"); return AGPU_ERR_DEVICE; }
-	if (ctx->piece_stream) HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); // (the pieces before this one are being unwrapped into the old one)
+	if (ctx->piece_stream) { HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); HIP_CHECK(hipStreamSynchronize(ctx->piece_stream2)); } // (the pieces before this one are being unwrapped into the old one)
 	if (ctx->ingest_stream_size > 0) HIP_CHECK(hipMemcpyAsync(larger.ptr, ctx->ingest_stream.ptr, ctx->ingest_stream_size, hipMemcpyDeviceToDevice, ctx->stream));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	if (ctx->ingest_progress.work) HIP_CHECK(hipStreamSynchronize(ctx->ingest_progress.work)); // (the windows in flight read the old one)
@@ -920,6 +920,7 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 		const char* priorities = getenv("ARRIBA_STREAM_PRIORITIES");
 		const bool pieces_first = priorities == nullptr || strcmp(priorities, "stages") != 0;
 		HIP_CHECK(hipStreamCreateWithPriority(&ctx->piece_stream, hipStreamNonBlocking, pieces_first ? greatest : (least + greatest) / 2)); // (in front of the kernels of the windows: the feed waits for these; behind the stages of the other lane of a session)
+		HIP_CHECK(hipStreamCreateWithPriority(&ctx->piece_stream2, hipStreamNonBlocking, pieces_first ? greatest : (least + greatest) / 2)); // (deflated pieces take the two in turn: see agpu_ingest_push_bgzf)
 		for (int k = 0; k < AGPU_PIECE_SLOTS; ++k) { HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_copied[k], hipEventDisableTiming | hipEventBlockingSync)); /* (the thread that waits for a copy leaves its core to the readers of the file) */ HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_ready[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->piece_done[k], hipEventDisableTiming)); }
 	}
 	if (config->host_buffers > AGPU_PIECE_SLOTS) { set_last_error("agpu_ingest_config.host_buffers: at most 4"); return AGPU_ERR_INVALID; }
@@ -998,7 +999,14 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 	if (n_blocks > 0 && raw_size > 0) {
 		TRY(grow_stream(ctx, ctx->ingest_stream_size + stream_bytes));
 		const bool deflated = blocks[0].isize != 0; // (all blocks of a piece are of one kind: include/arriba_gpu.h)
-		ALLOC(ctx->ingest_raw[slot], raw_size + 64); ALLOC(ctx->ingest_blocks[slot], (size_t) n_blocks * sizeof(agpu_bgzf_block)); // (+ 64: the bit reader of bgzf_inflate_kernel looks a few bytes ahead)
+		// Deflated pieces take two streams in turn.  Pass 1 of the decoder holds 48 blocks per CU (its tables fill the LDS) and a piece is ~17 000 blocks: the second round of a piece
+		// fills a third of the device, and passes 2 and the CRC leave most of its LDS-bound slots idle anyway -- with the next piece on the other stream its pass 1 runs in those gaps
+		// (profiles/r05b: 20.7 ms per piece for pass 1 alone on one stream, 10.6 ms for a round).  The windows of the ingest wait for the LAST piece's event only: a piece is
+		// reported ready behind the one in front of it.  Parts of a file (one spill buffer) and ARRIBA_INFLATE_STREAMS=1 stay on one stream.
+		static const bool two_streams = !(getenv("ARRIBA_INFLATE_STREAMS") != nullptr && atoi(getenv("ARRIBA_INFLATE_STREAMS")) == 1);
+		const int set = deflated && two_streams && !ctx->ingest_part_of_sample ? (int) (ctx->ingest_pushes & 1u) : 0;
+		if (set == 1) pieces = ctx->piece_stream2;
+		ALLOC(ctx->ingest_raw[slot], raw_size + 256); ALLOC(ctx->ingest_blocks[slot], (size_t) n_blocks * sizeof(agpu_bgzf_block)); // (+ 256: the bit readers of the inflate kernels load ahead of what they decode: inflate_fast_core.hpp)
 		if (deflated) ALLOC(ctx->scratch("ingest.inflate_spill"), 2 * 65536);
 		HIP_CHECK(hipStreamWaitEvent(s, ctx->piece_done[slot], 0)); // (the piece that lay in this buffer is unwrapped and checked; an event that was never recorded does not hold anybody up)
 		HIP_CHECK(hipMemcpyAsync(ctx->ingest_raw[slot].ptr, raw, raw_size, hipMemcpyHostToDevice, s));
@@ -1014,8 +1022,8 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 				KernelTimer timer(ctx, "bgzf_inflate_kernel", (uint64_t) raw_size + stream_bytes, pieces);
 				bgzf_inflate_kernel<<<n_blocks, 64, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), target, ctx->scratch("ingest.inflate_spill").as<uint8_t>(), nullptr, failures);
 			} else {
-				// (the kernels of the pieces run one after the other on one stream: one set of notes serves all slots)
-				DeviceBuffer& notes = ctx->scratch("ingest.inflate_notes"); DeviceBuffer& note_count = ctx->scratch("ingest.inflate_note_count"); DeviceBuffer& status = ctx->scratch("ingest.inflate_status");
+				// (the kernels of the pieces of one stream run one after the other: one set of notes per stream serves all slots)
+				DeviceBuffer& notes = ctx->scratch(set ? "ingest.inflate_notes2" : "ingest.inflate_notes"); DeviceBuffer& note_count = ctx->scratch(set ? "ingest.inflate_note_count2" : "ingest.inflate_note_count"); DeviceBuffer& status = ctx->scratch(set ? "ingest.inflate_status2" : "ingest.inflate_status");
 				if ((size_t) n_blocks * INFLATE_MATCH_CAPACITY * 8 > notes.capacity || (size_t) n_blocks * 4 > status.capacity) {
 					HIP_CHECK(hipStreamSynchronize(pieces)); // (the pieces before this one read the buffers that are about to be replaced)
 					ALLOC(notes, (size_t) n_blocks * INFLATE_MATCH_CAPACITY * 8); ALLOC(note_count, (size_t) n_blocks * 4); ALLOC(status, (size_t) n_blocks * 4);
@@ -1037,6 +1045,7 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 		  bgzf_unwrap_kernel<<<n_blocks, BLOCK, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size); }
 		const uint64_t piece_stream_offset = ctx->ingest_stream_size;
 		ctx->ingest_stream_size += stream_bytes;
+		if (ctx->ingest_pushes > 0) HIP_CHECK(hipStreamWaitEvent(pieces, ctx->piece_ready[(ctx->ingest_pushes - 1) % AGPU_PIECE_SLOTS], 0)); // (ready in the order of the pieces, whichever stream they took)
 		HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], pieces));
 		if (ctx->ingest_verify_crc) { // (~1 ms per 256 MB piece; between the copies on one stream it cost 0.3 s of a 54 GB file)
 			KernelTimer timer(ctx, "bgzf_crc_kernel", deflated ? stream_bytes : raw_size, pieces);
@@ -1061,7 +1070,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
 	take_sample_buffers(ctx); // (a session with two lanes: the batch of this sample is built where the sibling's last one, done on the device, lies)
-	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); // (the last pieces unwrapped)
+	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); HIP_CHECK(hipStreamSynchronize(ctx->piece_stream2)); // (the last pieces unwrapped)
 	if (ctx->ingest_verify_crc || ctx->ingest_deflated_pieces) {
 		// a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch").  A deflated block that did not decode (bad Huffman
 		// code, output overrun, ISIZE mismatch) left its part of the stream unwritten: htslib fails on an inflate error whatever it does about checksums, so that counter is read

@@ -4,8 +4,8 @@
 // Why two passes.  Decoding a DEFLATE stream is two different kinds of work: the Huffman codes are a chain (where a code ends is known only when it has been looked up), the
 // copies of the matches are not.  Round 4 gave a whole wavefront to one block: one lane walked the chain, 63 waited, and every match of more than a few bytes cost three barriers:
 // 5.9 GB/s of output on the whole device.  Here
-//   pass 1 (inflate_tokens)   ONE LANE per block, sixteen blocks per wavefront running the same loop on different data: bits from a 64-bit buffer refilled without a branch from an
-//                             8-byte load issued a token ahead, literal / length codes through a two-level table (9 bits, then up to 6 more: 852 entries at most), distance codes
+//   pass 1 (inflate_tokens)   ONE LANE per block, sixteen blocks per wavefront running the same loop on different data: bits from a 64-bit buffer refilled without a branch from a
+//                             ring of input bytes in LDS (topped up from HBM once in eight tokens, by all lanes at once), literal / length codes through a two-level table (9 bits, then up to 6 more: 852 entries at most), distance codes
 //                             through an 8-bit table (the rare longer one bit by bit over the canonical counts), base values and extra bits of lengths and distances computed, not
 //                             looked up.  Literals go straight to their place in the output; a match is only NOTED: (position, length, distance), 8 bytes.
 //   pass 2 (resolve)          a wavefront per block takes the noted matches 64 at a time, a lane per match.  A match may be copied as soon as the bytes it reads are final:
@@ -31,7 +31,8 @@ enum { INFLATE_RETRY = 9 };
 enum { FAST_LITERAL = 1, FAST_LENGTH = 2 /* payload = symbol - 256: 0 end of block, 1..29 a length code */, FAST_SUBTABLE = 3 /* payload = where it starts, bits = how many bits index it */ };
 AGPU_HD uint16_t fast_entry(uint32_t type, uint32_t payload, uint32_t n_bits) { return (uint16_t) (payload << 6 | type << 4 | n_bits); }
 
-struct InflateFastTables { // what one decoding lane keeps in LDS: 2 688 bytes
+struct alignas(16) InflateFastTables { // what one decoding lane keeps in LDS: 2 832 bytes
+	unsigned long long input_ring[18];          // the next 128 bytes of the block's DEFLATE stream (FastBits) + two spare words
 	uint16_t litlen[FAST_LITLEN_ENTRIES];
 	uint16_t distance[1 << FAST_DISTANCE_ROOT]; // 0x8000 | symbol << 4 | bits; 0 = longer than 8 bits (or no such code).  While a dynamic header is read: the 7-bit table of the code-length code, as bytes
 	uint16_t count[16], first[16], next[16];    // codes per length (left at the distance code's for its long codes), first canonical code per length, the next one to hand out
@@ -40,23 +41,48 @@ struct InflateFastTables { // what one decoding lane keeps in LDS: 2 688 bytes
 	uint8_t code_lengths[24];                   // lengths of the code-length code
 };
 
-// the bits of the stream, lowest first; at least 56 of them after refill().  `ahead` is the 8 bytes at `next`, loaded when the refill before this one moved `next`: the latency of
-// the load lies under the decoding of a token.  Reads up to 16 bytes behind the end of the input (the callers pad).
+// the bits of the stream, lowest first; at least 56 of them after refill().  The input comes through a ring of 128 bytes in LDS that is topped up from HBM in pieces of 16 bytes
+// -- not at every token: the first version loaded the 8 bytes of the next token from HBM a token ahead, and the `s_waitcnt vmcnt(0)` in front of their use also waited for the
+// store of the token before (a literal, a noted match): a round trip to the L2 per token, 0.9 us of it (profiles/r05b: 20.7 ms per piece of 17 000 blocks).  vmcnt counts loads
+// and stores alike, so the loop of the tokens must not load from HBM at all: refill() reads the ring, the stores are never waited for, and top_up() -- every eighth token, at the
+// same moment in all lanes of the wavefront -- is the only place that waits.  Reads up to 208 bytes behind the end of the input (the callers pad by 256).
+const uint32_t INFLATE_INPUT_RING = 128;
 struct FastBits {
-	const uint8_t* next; const uint8_t* end;
-	unsigned long long buffer, ahead; uint32_t count;
+	const uint8_t* input; uint32_t size, next /* bytes taken into the buffer */, loaded /* the ring holds the bytes [loaded - 128, loaded) of the input */;
+	unsigned long long* ring;
+	unsigned long long buffer; uint32_t count;
 	AGPU_HD static unsigned long long load64(const uint8_t* p) { unsigned long long word; __builtin_memcpy(&word, p, 8); return word; }
-	AGPU_HD void start(const uint8_t* input, uint32_t size) { next = input; end = input + size; buffer = 0; count = 0; ahead = load64(next); }
+	AGPU_HD void top_up() { // afterwards more than 112 bytes lie ahead of `next`: 8 tokens of at most 48 bits, or 64 symbols of a header, before the next call
+		while (loaded - next <= INFLATE_INPUT_RING - 16) {
+			// four pieces are loaded whether they are wanted or not (one wait for all of them; what lies behind the input is padding), those that fit go into the ring
+			struct Pair { unsigned long long low, high; } piece0, piece1, piece2, piece3;
+			__builtin_memcpy(&piece0, input + loaded, 16); __builtin_memcpy(&piece1, input + loaded + 16, 16);
+			__builtin_memcpy(&piece2, input + loaded + 32, 16); __builtin_memcpy(&piece3, input + loaded + 48, 16);
+			const uint32_t fit = (INFLATE_INPUT_RING - (loaded - next)) >> 4; // >= 1
+			const uint32_t word = loaded >> 3, mask = INFLATE_INPUT_RING / 8 - 1; // (16 bytes at a multiple of 16: never across the end of the ring)
+			// (a piece that does not fit is written to the two spare words behind the ring: every load is used inside this branch, so the compiler waits for it here and not -- for
+			//  the registers it would land in -- at the place where the branch joins the loop of the tokens, token after token)
+			const uint32_t at1 = fit > 1 ? (word + 2) & mask : INFLATE_INPUT_RING / 8, at2 = fit > 2 ? (word + 4) & mask : INFLATE_INPUT_RING / 8, at3 = fit > 3 ? (word + 6) & mask : INFLATE_INPUT_RING / 8;
+			ring[word & mask] = piece0.low; ring[(word & mask) + 1] = piece0.high;
+			ring[at1] = piece1.low; ring[at1 + 1] = piece1.high;
+			ring[at2] = piece2.low; ring[at2 + 1] = piece2.high;
+			ring[at3] = piece3.low; ring[at3 + 1] = piece3.high;
+			loaded += 16 * (fit < 4 ? fit : 4);
+		}
+	}
+	AGPU_HD void start(const uint8_t* bytes, uint32_t n, unsigned long long* words) { input = bytes; size = n; next = 0; loaded = 0; ring = words; buffer = 0; count = 0; top_up(); }
 	AGPU_HD void refill() { // (the bits above `count` that the shift leaves in the buffer are the low bits of the byte at `next`: the next refill puts the same bits there again)
-		buffer |= ahead << count;
+		const uint32_t word = next >> 3, shift = (next & 7u) << 3;
+		const unsigned long long low = ring[word & (INFLATE_INPUT_RING / 8 - 1)], high = ring[(word + 1) & (INFLATE_INPUT_RING / 8 - 1)];
+		buffer |= ((low >> shift) | ((high << 1) << (63u - shift))) << count;
 		const uint32_t bytes = (63u - count) >> 3;
 		next += bytes; count += bytes << 3;
-		ahead = load64(next);
 	}
+	AGPU_HD void refill_anywhere() { if (loaded - next < 32) top_up(); refill(); } // (outside the loop of the tokens: headers, stored blocks)
 	AGPU_HD uint32_t peek(uint32_t n) const { return (uint32_t) buffer & ((1u << n) - 1u); } // n <= 16
 	AGPU_HD void drop(uint32_t n) { buffer >>= n; count -= n; }
 	AGPU_HD uint32_t take(uint32_t n) { const uint32_t value = peek(n); drop(n); return value; }
-	AGPU_HD bool overrun() const { return next > end && (uint32_t) (next - end) * 8u > count; } // more bits were taken than the input holds
+	AGPU_HD bool overrun() const { return next > size && (next - size) * 8u > count; } // more bits were taken than the input holds
 };
 
 AGPU_HD uint32_t fast_reverse_bits(uint32_t code, uint32_t length) { // the stream delivers a code with its first bit lowest
@@ -164,12 +190,12 @@ AGPU_HD int fast_long_distance_symbol(FastBits& bits, const InflateFastTables& t
 // the header of a dynamic block (RFC 1951 3.2.7): the lengths of both codes, run-length coded with a code of 19 symbols, itself given by 3-bit lengths
 AGPU_HD int fast_read_dynamic_header(FastBits& bits, InflateFastTables& t, uint32_t& n_litlen, uint32_t& n_distance) {
 	static const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-	bits.refill();
+	bits.refill_anywhere();
 	n_litlen = bits.take(5) + 257; n_distance = bits.take(5) + 1;
 	const uint32_t n_code_lengths = bits.take(4) + 4;
 	if (n_litlen > 286 || n_distance > 30) return INFLATE_BAD_CODE_LENGTHS;
 	for (uint32_t k = 0; k < 19; ++k) t.code_lengths[k] = 0;
-	for (uint32_t k = 0; k < n_code_lengths; ++k) { if ((k & 7u) == 0) bits.refill(); t.code_lengths[order[k]] = (uint8_t) bits.take(3); }
+	for (uint32_t k = 0; k < n_code_lengths; ++k) { if ((k & 7u) == 0) bits.refill_anywhere(); t.code_lengths[order[k]] = (uint8_t) bits.take(3); }
 	if (bits.overrun()) return INFLATE_INPUT_OVERRUN;
 	// the code of the code lengths must be complete (zlib); 7 bits at once
 	for (uint32_t l = 0; l < 8; ++l) t.count[l] = 0;
@@ -190,7 +216,7 @@ AGPU_HD int fast_read_dynamic_header(FastBits& bits, InflateFastTables& t, uint3
 	const uint32_t total = n_litlen + n_distance;
 	uint32_t filled = 0;
 	while (filled < total) {
-		bits.refill();
+		bits.refill_anywhere();
 		if (bits.overrun()) return INFLATE_INPUT_OVERRUN; // (advisor, round 4: the loops of the header checked nothing)
 		const uint32_t entry = table[bits.peek(7)];
 		bits.drop(entry & 7u);
@@ -215,22 +241,22 @@ AGPU_HD uint32_t inflate_note_distance(unsigned long long note) { return (uint32
 
 // Pass 1, one lane: the literals of the block into `output` (out_size bytes: the ISIZE of the gzip trailer), its matches into `notes`.
 AGPU_HD int inflate_tokens(const uint8_t* input, uint32_t in_size, uint8_t* output, uint32_t out_size, unsigned long long* notes, uint32_t capacity, uint32_t& n_notes, InflateFastTables& t) {
-	FastBits bits; bits.start(input, in_size);
+	FastBits bits; bits.start(input, in_size, t.input_ring);
 	uint32_t produced = 0, noted = 0;
 	n_notes = 0;
 	bool last_block = false;
 	while (!last_block) {
-		bits.refill();
+		bits.refill_anywhere();
 		if (bits.overrun()) return INFLATE_INPUT_OVERRUN;
 		last_block = bits.take(1) != 0;
 		const uint32_t type = bits.take(2);
 		if (type == 0) { // stored: LEN, NLEN, then LEN bytes as they are
-			bits.drop(bits.count & 7u); bits.refill();
+			bits.drop(bits.count & 7u); bits.refill_anywhere();
 			const uint32_t length = bits.take(16), complement = bits.take(16);
 			if ((length ^ 0xFFFFu) != complement) return INFLATE_BAD_STORED_LENGTH;
 			if (produced + length > out_size) return INFLATE_OUTPUT_OVERRUN;
 			for (uint32_t k = 0; k < length; ++k) {
-				if ((k & 3u) == 0) { bits.refill(); if (bits.overrun()) return INFLATE_INPUT_OVERRUN; }
+				if ((k & 3u) == 0) { bits.refill_anywhere(); if (bits.overrun()) return INFLATE_INPUT_OVERRUN; }
 				output[produced++] = (uint8_t) bits.take(8);
 			}
 			continue;
@@ -243,9 +269,10 @@ AGPU_HD int inflate_tokens(const uint8_t* input, uint32_t in_size, uint8_t* outp
 		} else { const int status = fast_read_dynamic_header(bits, t, n_litlen, n_distance); if (status != INFLATE_OK) return status; }
 		{ const int status = fast_build_litlen(t.lengths, n_litlen, t); if (status != INFLATE_OK) return status; }
 		{ const int status = fast_build_distance(t.lengths + n_litlen, n_distance, t); if (status != INFLATE_OK) return status; }
-		while (true) { // a token per turn: at most 15 + 5 + 15 + 13 = 48 bits
+		for (uint32_t turn = 0; ; ++turn) { // a token per turn: at most 15 + 5 + 15 + 13 = 48 bits
+			if ((turn & 7u) == 0) bits.top_up(); // (the lanes of a wavefront are in the same turn: they wait for HBM together, once in eight tokens)
 			bits.refill();
-			if (bits.next > bits.end && bits.overrun()) return INFLATE_INPUT_OVERRUN;
+			if (bits.next > bits.size && bits.overrun()) return INFLATE_INPUT_OVERRUN;
 			uint32_t entry = t.litlen[bits.peek(FAST_LITLEN_ROOT)];
 			if ((entry >> 4 & 3u) == FAST_SUBTABLE) { bits.drop(FAST_LITLEN_ROOT); entry = t.litlen[(entry >> 6) + bits.peek(entry & 15u)]; }
 			if (entry == 0) return INFLATE_BAD_SYMBOL;

@@ -13,6 +13,7 @@
 #include <zlib.h>
 #include "../../arriba_amd/csrc/device/inflate_fast_core.hpp"
 using namespace agpu;
+static const size_t PAD = 256; // what the readers of the DEFLATE stream may read behind its end (inflate_fast_core.hpp: FastBits)
 static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t>& in, int level, int strategy) {
 	z_stream z; memset(&z, 0, sizeof(z));
 	deflateInit2(&z, level, Z_DEFLATED, -15, 8, strategy);
@@ -49,9 +50,9 @@ static void resolve_in_rounds(uint8_t* out, const unsigned long long* notes, uin
 static InflateFastTables* g_tables = new InflateFastTables();
 static std::vector<unsigned long long> g_notes(INFLATE_MATCH_CAPACITY + 8, 0x5555555555555555ull);
 // both passes; returns the status; `out` has `size` bytes + 64 of 0xCD behind them
-static int fast_inflate(const std::vector<uint8_t>& packed /* + 16 bytes of padding */, std::vector<uint8_t>& out, uint32_t size, bool in_rounds, unsigned long long& rounds, uint32_t* notes_used = nullptr) {
+static int fast_inflate(const std::vector<uint8_t>& packed /* + PAD bytes of padding */, std::vector<uint8_t>& out, uint32_t size, bool in_rounds, unsigned long long& rounds, uint32_t* notes_used = nullptr) {
 	uint32_t n = 0;
-	const int rc = inflate_tokens(packed.data(), (uint32_t) packed.size() - 16, out.data(), size, g_notes.data(), INFLATE_MATCH_CAPACITY, n, *g_tables);
+	const int rc = inflate_tokens(packed.data(), (uint32_t) packed.size() - PAD, out.data(), size, g_notes.data(), INFLATE_MATCH_CAPACITY, n, *g_tables);
 	if (g_notes[INFLATE_MATCH_CAPACITY] != 0x5555555555555555ull) { printf("NOTES OVERRUN\n"); exit(1); }
 	if (notes_used) *notes_used = n;
 	if (rc != INFLATE_OK) return rc;
@@ -115,10 +116,10 @@ int main() {
 			}
 		}
 		std::vector<uint8_t> packed = deflate_raw(data, level, strategy);
-		packed.resize(packed.size() + 16, 0xAA); // the padding the kernel's buffer has
+		packed.resize(packed.size() + PAD, 0xAA); // the padding the kernel's buffer has
 		std::vector<uint8_t> out(size + 64, 0xCD);
 		auto sync = [] {}; auto broadcast = [](uint32_t v) { return v; };
-		int rc = inflate_block(packed.data(), (uint32_t) packed.size() - 16, out.data(), (uint32_t) size, *shared, 0, 1, sync, broadcast);
+		int rc = inflate_block(packed.data(), (uint32_t) packed.size() - PAD, out.data(), (uint32_t) size, *shared, 0, 1, sync, broadcast);
 		++checked;
 		bool ok = rc == INFLATE_OK && memcmp(out.data(), data.data(), size) == 0 && out[size] == 0xCD;
 		if (!ok) { ++failures; if (failures < 10) printf("FAIL kind %d size %d level %d strategy %d rc %d\n", kind, size, level, strategy, rc); }
@@ -134,16 +135,16 @@ int main() {
 		}
 		// damaged streams must end with an error or a wrong size, never with a write outside the buffer
 		if (size > 100) for (int trial = 0; trial < 3; ++trial) {
-			std::vector<uint8_t> bad = packed; bad[rng() % (bad.size() - 16)] ^= 1u << (rng() & 7);
+			std::vector<uint8_t> bad = packed; bad[rng() % (bad.size() - PAD)] ^= 1u << (rng() & 7);
 			std::fill(out.begin(), out.end(), 0xCD);
-			inflate_block(bad.data(), (uint32_t) bad.size() - 16, out.data(), (uint32_t) size, *shared, 0, 1, sync, broadcast);
+			inflate_block(bad.data(), (uint32_t) bad.size() - PAD, out.data(), (uint32_t) size, *shared, 0, 1, sync, broadcast);
 			if (out[size] != 0xCD) { ++failures; printf("OVERRUN kind %d size %d\n", kind, size); }
 			std::fill(out.begin(), out.end(), 0xCD);
 			const int verdict = fast_inflate(bad, out, (uint32_t) size, false, rounds);
 			for (int k = 0; k < 64; ++k) if (out[size + k] != 0xCD) { ++failures; printf("OVERRUN (two passes) kind %d size %d\n", kind, size); break; }
 			// (what zlib says of the same damaged stream: an error there must be an error here -- a stream zlib accepts may still be refused for its size)
 			std::vector<uint8_t> reference;
-			const int theirs = zlib_inflate_raw(bad.data(), bad.size() - 16, reference);
+			const int theirs = zlib_inflate_raw(bad.data(), bad.size() - PAD, reference);
 			if (theirs == 0 && reference.size() == (size_t) size && verdict == INFLATE_OK && memcmp(out.data(), reference.data(), size) != 0) { ++failures; printf("DAMAGED STREAM DECODED DIFFERENTLY kind %d size %d\n", kind, size); }
 			if (theirs != 0 && verdict == INFLATE_OK) { ++failures; printf("ACCEPTED WHAT ZLIB REFUSES kind %d size %d level %d strategy %d\n", kind, size, level, strategy); }
 		}
@@ -154,7 +155,7 @@ int main() {
 		std::vector<uint8_t> stream = handmade_block(litlen, distance, tokens);
 		std::vector<uint8_t> reference;
 		const int theirs = zlib_inflate_raw(stream.data(), stream.size(), reference);
-		stream.resize(stream.size() + 16, 0);
+		stream.resize(stream.size() + PAD, 0);
 		std::vector<uint8_t> out(reference.size() + 64, 0xCD);
 		const int ours = fast_inflate(stream, out, (uint32_t) reference.size(), true, rounds);
 		++handmade;
