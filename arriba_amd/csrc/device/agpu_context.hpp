@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -211,6 +212,8 @@ struct agpu_ctx {
 	bool kmer_index_done = false, have_splice_sites = false, mismapper_jobs_ready = false;
 	agpu::CandidateTable candidates;
 	uint32_t n_emissions = 0, n_candidates = 0, n_queued_buckets = 0, n_discordant_emissions = 0; uint64_t n_list_entries = 0;
+	// implicit discordant-mate lists (fusion_core.hpp: CandidateTable::discordant_before): where the windows of candidates are cut, what the expansion of a list needs again
+	bool lists_implicit = false; std::vector<uint32_t> list_window_cuts; uint64_t list_window_entries = 0; int32_t lists_max_mate_gap = 0; uint32_t lists_n_bucket_rows = 0;
 	bool fusions_done = false;
 
 	// tables
@@ -253,6 +256,9 @@ struct KernelTimer {
 		ctx->samples_pending.push_back(sample);
 	}
 };
+// the stages that walk the read lists of the candidates (agpu_fusions.hip: implicit discordant lists)
+int for_each_list_window(agpu_ctx* ctx, const std::function<int(const CandidateTable&, uint32_t, uint32_t)>& stage);
+int recut_list_windows(agpu_ctx* ctx);
 // resolve the pending samples whose events have completed (the caller has synchronised the streams it launched on; what another thread launched meanwhile stays pending)
 inline void collect_kernel_samples(agpu_ctx* ctx) {
 	std::lock_guard<std::mutex> lock(ctx->profile_mutex);

@@ -169,18 +169,32 @@ const uint32_t SMALL_LIST = 32;
 
 struct BucketRef { uint32_t candidate, begin, end; };
 
-// one thread per candidate: small buckets are handled inline, large ones are queued for the wave kernel.
-// fill == false: count pass (list sizes), fill == true: write lists / anchors / swap flags
-__global__ void __launch_bounds__(BLOCK) attach_discordant_kernel(AnnotationView ann, CandidateTable t, const uint64_t* bucket_keys, DiscordantBuckets buckets, uint32_t Md,
-                                         int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, BucketRef* worklist, uint32_t* worklist_size, bool fill) {
+// What a candidate keeps of its discordant-mate list when the lists are implicit (fusion_core.hpp: CandidateTable::discordant_before): the range of its bucket and whether it had
+// split reads when find_fusions looked (merge_adjacent_fusions appends split reads later; the predicate of the list must not change with them).  Kept for explicit lists too.
+struct BucketRanges { uint32_t* begin; uint32_t* end; uint8_t* had_split_reads; };
+
+// one thread per candidate of [c_begin, c_end): small buckets are handled inline, large ones are queued for the wave kernel.
+// mode: ATTACH_COUNT the list sizes (and the bucket ranges noted), ATTACH_FILL / ATTACH_FOLD the pass behind it (lists written / not written; anchors, votes, counters),
+// ATTACH_EXPAND the lists of a window of candidates written again (t = the table of the window)
+__global__ void __launch_bounds__(BLOCK) attach_discordant_kernel(AnnotationView ann, CandidateTable t, uint32_t c_begin, uint32_t c_end, const uint64_t* bucket_keys, DiscordantBuckets buckets, uint32_t Md, BucketRanges ranges,
+                                         int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, BucketRef* worklist, uint32_t* worklist_size, int mode) {
 	__shared__ uint32_t wave_offset[BLOCK / 64];
 	__shared__ uint32_t block_base;
-	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t c = c_begin + blockIdx.x * BLOCK + threadIdx.x;
 	uint32_t begin = 0, end = 0;
-	if (c < t.n && t.filter[c] == FILTER_none) {
-		uint32_t flags = t.flags[c];
-		uint64_t key = gene_pair_key(t.gene1[c], t.gene2[c], ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u));
-		begin = lower_bound_key(bucket_keys, Md, key); end = lower_bound_key(bucket_keys, Md, key + 1);
+	bool has_split_reads = false;
+	if (c < c_end) {
+		if (mode == ATTACH_COUNT) {
+			if (t.filter[c] == FILTER_none) {
+				const uint32_t flags = t.flags[c];
+				const uint64_t key = gene_pair_key(t.gene1[c], t.gene2[c], ((flags & CFLAG_UPSTREAM1) ? 1u : 0u) | ((flags & CFLAG_UPSTREAM2) ? 2u : 0u));
+				begin = lower_bound_key(bucket_keys, Md, key); end = lower_bound_key(bucket_keys, Md, key + 1);
+			}
+			has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
+			ranges.begin[c] = begin; ranges.end[c] = end; ranges.had_split_reads[c] = has_split_reads;
+		} else if (mode != ATTACH_EXPAND || t.list_offset[3 * (uint64_t) c + 3] > t.list_offset[3 * (uint64_t) c + 2]) { // (a list that was empty stays empty)
+			begin = ranges.begin[c]; end = ranges.end[c]; has_split_reads = ranges.had_split_reads[c];
+		}
 	}
 	const bool queue = end - begin > SMALL_BUCKET;
 	const uint32_t at = block_append<BLOCK>(queue ? 1u : 0u, worklist_size, wave_offset, &block_base); // one atomic per workgroup
@@ -190,17 +204,9 @@ __global__ void __launch_bounds__(BLOCK) attach_discordant_kernel(AnnotationView
 		return;
 	}
 	if (begin == end) return;
-	bool has_split_reads;
-	uint32_t* out_list = nullptr;
-	if (fill) {
-		const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
-		has_split_reads = offsets[2] > offsets[0];
-		out_list = t.read_lists + offsets[2];
-	} else {
-		has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
-	}
-	uint32_t size = attach_discordant_mates(ann, t, c, buckets, begin, end - begin, max_mate_gap, threshold, has_split_reads, out_list, discordant_swapped);
-	if (!fill) list_size[3 * (uint64_t) c + 2] = size;
+	uint32_t* out_list = mode == ATTACH_FILL || mode == ATTACH_EXPAND ? t.read_lists + t.list_offset[3 * (uint64_t) c + 2] : nullptr;
+	uint32_t size = attach_discordant_mates(ann, t, c, buckets, begin, end - begin, max_mate_gap, threshold, has_split_reads, out_list, discordant_swapped, mode);
+	if (mode == ATTACH_COUNT) list_size[3 * (uint64_t) c + 2] = size;
 }
 
 __device__ __forceinline__ AnchorFold wave_fold_in_lane_order(AnchorFold mine, bool upstream) {
@@ -221,9 +227,9 @@ __device__ __forceinline__ int32_t anchor_merge(int32_t a, int32_t b, bool upstr
 
 // one wave per queued candidate: 64 discordant mates are tested at once; the order-dependent subsampling rule of the reference
 // (source/fusions.cpp:398-407) becomes prefix popcounts over the ballots.  MODE 0: count the list entries; MODE 1: write the list
-// and accumulate the anchors per lane (valid while no downstream anchor is 0); MODE 2: anchors only, folded in name order (the rare
-// case of an anchor at position 0, which resets a running minimum).
-template <int MODE> __device__ __forceinline__ void scan_bucket(const AnnotationView& ann, const DiscordantBuckets& buckets, const BucketRef& ref, uint32_t gene1, uint32_t gene2,
+// and accumulate the anchors per lane (valid while no downstream anchor is 0; WRITE_LIST false: implicit lists, everything but the list); MODE 2: anchors only, folded in name
+// order (the rare case of an anchor at position 0, which resets a running minimum); MODE 3: the list only (an implicit list expanded for a window of candidates).
+template <int MODE, bool WRITE_LIST = true> __device__ __forceinline__ void scan_bucket(const AnnotationView& ann, const DiscordantBuckets& buckets, const BucketRef& ref, uint32_t gene1, uint32_t gene2,
 		int32_t breakpoint1, int32_t breakpoint2, bool upstream1, bool upstream2, bool has_split_reads, int32_t max_mate_gap, uint32_t threshold, uint32_t lane,
 		uint32_t* out_list, uint8_t* discordant_swapped, uint32_t& unfiltered, uint32_t& appended, int32_t& lane_anchor1, int32_t& lane_anchor2, uint32_t& lane_votes, bool& zero_seen, AnchorFold& fold1, AnchorFold& fold2) {
 	const unsigned long long lanes_before = (1ull << lane) - 1;
@@ -242,9 +248,10 @@ template <int MODE> __device__ __forceinline__ void scan_bucket(const Annotation
 		const uint32_t unfiltered_before = unfiltered + __popcll(ballot_unfiltered & lanes_before);
 		const bool joins = pass && (position < threshold || (is_unfiltered && unfiltered_before < threshold));
 		const unsigned long long ballot_joins = __ballot(joins);
+		if (MODE == 3 && joins) out_list[appended + __popcll(ballot_joins & lanes_before)] = buckets.read[k]; // (an implicit list written again: the entries, nothing else)
 		if (MODE == 1 && joins) {
 			const uint32_t read = buckets.read[k];
-			out_list[appended + __popcll(ballot_joins & lanes_before)] = read;
+			if (WRITE_LIST) out_list[appended + __popcll(ballot_joins & lanes_before)] = read;
 			if ((info & EINFO_MATES_SWAPPED) && !discordant_swapped[read]) discordant_swapped[read] = 1;
 			const int32_t anchor1 = buckets.anchor1[k], anchor2 = buckets.anchor2[k];
 			if ((!upstream1 && anchor1 == 0) || (!upstream2 && anchor2 == 0)) zero_seen = true;
@@ -266,8 +273,8 @@ template <int MODE> __device__ __forceinline__ void scan_bucket(const Annotation
 	}
 }
 
-__global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, int32_t max_mate_gap, uint32_t threshold,
-                                              uint32_t* list_size, uint8_t* discordant_swapped, const BucketRef* worklist, const uint32_t* worklist_size, bool fill) {
+__global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, BucketRanges ranges, int32_t max_mate_gap, uint32_t threshold,
+                                              uint32_t* list_size, uint8_t* discordant_swapped, const BucketRef* worklist, const uint32_t* worklist_size, int mode) {
 	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
 	if (wave >= *worklist_size) return;
 	const BucketRef ref = worklist[wave];
@@ -281,15 +288,19 @@ __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable
 	uint32_t lane_votes = 0;
 	bool zero_seen = false;
 	AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
-	if (!fill) {
-		const bool has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
+	const bool has_split_reads = ranges.had_split_reads[c];
+	if (mode == ATTACH_COUNT) {
 		scan_bucket<0>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
 		if (lane == 0) list_size[3 * (uint64_t) c + 2] = appended;
 		return;
 	}
-	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
-	const bool has_split_reads = offsets[2] > offsets[0];
-	scan_bucket<1>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, t.read_lists + offsets[2], discordant_swapped, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
+	uint32_t* out_list = mode == ATTACH_FOLD ? nullptr : t.read_lists + t.list_offset[3 * (uint64_t) c + 2];
+	if (mode == ATTACH_EXPAND) {
+		scan_bucket<3>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, out_list, nullptr, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
+		return;
+	}
+	if (mode == ATTACH_FILL) scan_bucket<1, true>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, out_list, discordant_swapped, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
+	else scan_bucket<1, false>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, discordant_swapped, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
 	if (__ballot(zero_seen) != 0) {
 		uint32_t unfiltered_again, appended_again, lane_votes_again = 0;
 		scan_bucket<2>(ann, buckets, ref, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, threshold, lane, nullptr, nullptr, unfiltered_again, appended_again, lane_anchor1, lane_anchor2, lane_votes_again, zero_seen, fold1, fold2);
@@ -310,6 +321,32 @@ __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable
 	}
 }
 
+// the split-read lists of the candidates of a window into the buffer of the window (one wavefront per candidate)
+__global__ void window_split_copy_kernel(CandidateTable sample, CandidateTable window, uint32_t c_begin, uint32_t c_end) {
+	const uint32_t c = c_begin + ((blockIdx.x * BLOCK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+	if (c >= c_end) return;
+	const uint64_t begin = sample.list_offset[3 * (uint64_t) c], end = sample.list_offset[3 * (uint64_t) c + 2];
+	for (uint64_t k = begin + lane; k < end; k += 64) window.read_lists[k] = split_list_entry(sample, c, k);
+}
+// where the windows are cut: as many candidates as fit `entries` list entries (a candidate alone may hold up to 3 x the threshold); cuts[0] = number of cuts, then the cuts
+__global__ void window_cut_kernel(const uint64_t* list_offset, uint32_t n_candidates, uint64_t entries, uint32_t capacity, uint32_t* cuts) {
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	uint32_t n = 0, c = 0;
+	while (c < n_candidates && n + 2 < capacity) {
+		const uint64_t limit = list_offset[3 * (uint64_t) c] + entries;
+		uint32_t lo = c + 1, hi = n_candidates; // the last candidate whose lists end at or in front of `limit` (at least one candidate per window)
+		while (lo < hi) { const uint32_t mid = lo + ((hi - lo + 1) >> 1); if (list_offset[3 * (uint64_t) mid] <= limit) lo = mid; else hi = mid - 1; }
+		c = lo;
+		cuts[1 + n++] = c;
+	}
+	if (c < n_candidates) cuts[1 + n++] = n_candidates; // (more windows than there is room to note: the last one takes the rest and its allocation says so if it does not fit)
+	cuts[0] = n;
+}
+__global__ void discordant_size_kernel(const uint32_t* list_size, uint32_t n_candidates, uint64_t* sizes) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c <= n_candidates) sizes[c] = c < n_candidates ? list_size[3 * (uint64_t) c + 2] : 0;
+}
+
 __global__ void split_list_fill_kernel(uint32_t M, const FusionEmission* sorted, const uint32_t* candidate_of, const RankState* ranks, const CandidateFold* folds, uint32_t threshold, CandidateTable t) {
 	uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
 	if (j >= M) return;
@@ -317,7 +354,7 @@ __global__ void split_list_fill_kernel(uint32_t M, const FusionEmission* sorted,
 	if (!(e.info & EINFO_SPLIT) || !joins_split_read_list(e, ranks[j], threshold)) return;
 	int side = (e.info & EINFO_SWAPPED) ? 1 : 0;
 	uint32_t c = candidate_of[j] - 1;
-	t.read_lists[t.list_offset[3 * (uint64_t) c + side] + folds[j].list_size[side] - 1] = e.read;
+	t.read_lists[t.list_offset[3 * (uint64_t) c + side] + folds[j].list_size[side] - 1 - (t.discordant_before != nullptr ? t.discordant_before[c] : 0)] = e.read;
 	int vote = split_read_vote(e.info);
 	if (vote != 0) atomicAdd(&t.votes[2 * (uint64_t) c + (vote - 1)], 1u);
 }
@@ -336,6 +373,91 @@ struct Scratch { // grows on demand; reused by every rocprim call
 };
 
 }
+
+namespace {
+
+// ---- implicit discordant lists: the windows (fusion_core.hpp: CandidateTable::discordant_before) ------------------------------------------------------------------------------
+
+// how many list entries a window holds: ARRIBA_LIST_WINDOW_ENTRIES (tests: a few hundred, so that a toy sample has dozens of windows), else a quarter of what the device has free,
+// at most 8 GB of entries
+uint64_t list_window_entries(uint32_t threshold) {
+	const char* knob = getenv("ARRIBA_LIST_WINDOW_ENTRIES");
+	uint64_t entries = knob != nullptr && atoll(knob) > 0 ? (uint64_t) atoll(knob) : 0;
+	if (entries == 0) {
+		size_t free_bytes = 0, total_bytes = 0;
+		(void) hipMemGetInfo(&free_bytes, &total_bytes);
+		entries = std::min<uint64_t>(8ull << 30, free_bytes / 4) / 4;
+	}
+	return std::max<uint64_t>(entries, 1024);
+}
+int cut_list_windows(agpu_ctx* ctx) {
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint32_t capacity = 1u << 16;
+	DeviceBuffer& cuts = ctx->scratch("lists.cuts");
+	ALLOC(cuts, (size_t) capacity * 4);
+	ctx->list_window_entries = list_window_entries(ctx->params.subsampling_threshold);
+	window_cut_kernel<<<1, 64, 0, s>>>(ctx->candidates.list_offset, C, ctx->list_window_entries, capacity, cuts.as<uint32_t>());
+	uint32_t n = 0;
+	HIP_CHECK(hipMemcpyAsync(&n, cuts.ptr, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	ctx->list_window_cuts.assign((size_t) n + 1, 0);
+	if (n > 0) HIP_CHECK(hipMemcpy(ctx->list_window_cuts.data() + 1, cuts.as<uint32_t>() + 1, (size_t) n * 4, hipMemcpyDeviceToHost));
+	return AGPU_OK;
+}
+// all three lists of the candidates [c_begin, c_end) at their positions in a buffer: `window` = the table of the sample with read_lists pointing at that buffer (rebased) and no
+// discordant_before -- the kernels of the stages walk it as they walk explicit lists
+int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, CandidateTable& window) {
+	hipStream_t s = ctx->stream;
+	const CandidateTable& t = ctx->candidates;
+	uint64_t bounds[2] = { 0, 0 };
+	HIP_CHECK(hipMemcpyAsync(&bounds[0], t.list_offset + 3 * (uint64_t) c_begin, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&bounds[1], t.list_offset + 3 * (uint64_t) c_end, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	const uint64_t entries = bounds[1] - bounds[0];
+	DeviceBuffer& buffer = ctx->scratch("lists.window");
+	if (!buffer.allocate((size_t) std::max<uint64_t>(entries, 1) * 4)) { set_last_error("hipMalloc failed (a window of " + std::to_string(entries) + " read-list entries)"); return AGPU_ERR_DEVICE; }
+	window = t;
+	window.read_lists = buffer.as<uint32_t>() - bounds[0]; window.discordant_before = nullptr;
+	if (c_end == c_begin || entries == 0) return AGPU_OK;
+	DeviceBuffer& bucket_worklist = ctx->scratch("fusions.bucket_worklist"); DeviceBuffer& worklist_sizes = ctx->scratch("fusions.worklist_sizes");
+	DiscordantBuckets buckets; BucketRanges ranges;
+	{ const size_t Md1 = std::max<uint32_t>(ctx->lists_n_bucket_rows, 1);
+	  const int32_t* columns = ctx->scratch("fusions.bucket_columns").as<int32_t>();
+	  buckets.breakpoint1 = columns; buckets.breakpoint2 = columns + Md1; buckets.info = (const uint32_t*) (columns + 2 * Md1); buckets.read = buckets.info + Md1; buckets.anchor1 = (const int32_t*) (buckets.read + Md1); buckets.anchor2 = buckets.anchor1 + Md1;
+	  ranges.begin = ctx->scratch("lists.bucket_begin").as<uint32_t>(); ranges.end = ctx->scratch("lists.bucket_end").as<uint32_t>(); ranges.had_split_reads = ctx->scratch("lists.had_split_reads").as<uint8_t>(); }
+	uint32_t* worklist_count = worklist_sizes.as<uint32_t>() + 2;
+	HIP_CHECK(hipMemsetAsync(worklist_count, 0, 4, s));
+	const uint32_t n = c_end - c_begin, threshold = ctx->params.subsampling_threshold;
+	{ KernelTimer timer(ctx, "window_split_copy_kernel", (uint64_t) n * 16);
+	  window_split_copy_kernel<<<grid_for((uint64_t) n * 64), BLOCK, 0, s>>>(t, window, c_begin, c_end); }
+	{ KernelTimer timer(ctx, "attach_discordant_kernel(window)", (uint64_t) n * 25);
+	  attach_discordant_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->annotation, window, c_begin, c_end, nullptr, buckets, ctx->lists_n_bucket_rows, ranges, ctx->lists_max_mate_gap, threshold, nullptr, nullptr, bucket_worklist.as<BucketRef>(), worklist_count, ATTACH_EXPAND); }
+	uint32_t queued = 0;
+	HIP_CHECK(hipMemcpyAsync(&queued, worklist_count, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (queued > 0) {
+		KernelTimer timer(ctx, "attach_discordant_wave_kernel(window)", (uint64_t) entries * 4 + (uint64_t) queued * 25);
+		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, window, buckets, ranges, ctx->lists_max_mate_gap, threshold, nullptr, nullptr, bucket_worklist.as<BucketRef>(), worklist_count, ATTACH_EXPAND);
+	}
+	return AGPU_OK;
+}
+
+}
+
+// Runs `stage` over all candidates, a window at a time: once over [0, n) with the table of the sample while the lists are explicit; with implicit discordant lists over every window
+// with the table of the window (the lists of its candidates expanded).  What `stage` launches must restrict itself to the candidates [begin, end).
+int agpu::for_each_list_window(agpu_ctx* ctx, const std::function<int(const CandidateTable&, uint32_t, uint32_t)>& stage) {
+	if (!ctx->lists_implicit) return stage(ctx->candidates, 0u, ctx->n_candidates);
+	for (size_t w = 0; w + 1 < ctx->list_window_cuts.size(); ++w) {
+		CandidateTable window;
+		int status = expand_list_window(ctx, ctx->list_window_cuts[w], ctx->list_window_cuts[w + 1], window);
+		if (status == AGPU_OK) status = stage(window, ctx->list_window_cuts[w], ctx->list_window_cuts[w + 1]);
+		if (status != AGPU_OK) return status;
+	}
+	return AGPU_OK;
+}
+int agpu::recut_list_windows(agpu_ctx* ctx) { return ctx->lists_implicit ? cut_list_windows(ctx) : AGPU_OK; }
 
 namespace {
 
@@ -377,6 +499,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	if (M == 0) {
 		if (n_candidates) *n_candidates = 0;
 		ctx->fusions_done = true; ctx->candidates_imported = false; ctx->n_list_entries = 0; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
+		ctx->lists_implicit = false; ctx->list_window_cuts.clear(); ctx->candidates.discordant_before = nullptr;
 		return AGPU_OK;
 	}
 
@@ -471,17 +594,19 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 
 	// ---- discordant mates: count, offsets, fill
 	DeviceBuffer& bucket_worklist = ctx->scratch("fusions.bucket_worklist"); DeviceBuffer& worklist_sizes = ctx->scratch("fusions.worklist_sizes");
-	ALLOC(bucket_worklist, (size_t) C * sizeof(BucketRef)); ALLOC(worklist_sizes, 16);
+	DeviceBuffer& range_begin = ctx->scratch("lists.bucket_begin"); DeviceBuffer& range_end = ctx->scratch("lists.bucket_end"); DeviceBuffer& range_split = ctx->scratch("lists.had_split_reads");
+	ALLOC(bucket_worklist, (size_t) C * sizeof(BucketRef)); ALLOC(worklist_sizes, 16); ALLOC(range_begin, (size_t) C * 4); ALLOC(range_end, (size_t) C * 4); ALLOC(range_split, (size_t) C);
 	HIP_CHECK(hipMemsetAsync(worklist_sizes.ptr, 0, 16, s));
-	uint32_t* worklist_counts = worklist_sizes.as<uint32_t>(); // [0] attach (count pass), [1] attach (fill pass), [2] finish
+	uint32_t* worklist_counts = worklist_sizes.as<uint32_t>(); // [0] attach (count pass), [1] attach (fill pass), [2] windows
+	BucketRanges ranges; ranges.begin = range_begin.as<uint32_t>(); ranges.end = range_end.as<uint32_t>(); ranges.had_split_reads = range_split.as<uint8_t>();
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(count)", (uint64_t) C * 25);
-	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, bucket_keys.as<uint64_t>(), buckets, Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false); }
+	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, 0, C, bucket_keys.as<uint64_t>(), buckets, Md, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, ATTACH_COUNT); }
 	uint32_t queued = 0;
 	HIP_CHECK(hipMemcpyAsync(&queued, worklist_counts + 0, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (queued > 0) {
 		KernelTimer timer(ctx, "attach_discordant_wave_kernel(count)", (uint64_t) Md * 24 + (uint64_t) queued * 25); // every bucket row read once, one size written per queued candidate
-		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, false);
+		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, ATTACH_COUNT);
 	}
 	// the lists are addressed with 64-bit offsets (sizes of single lists are 32-bit): with -U 32767 (BASELINE.json config 3) a few million fragments already make more than 2^32
 	// entries, every candidate of a gene pair listing the discordant mates of the pair (source/fusions.cpp:398-407 lets a list grow to the subsampling threshold)
@@ -491,23 +616,51 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	uint64_t total_list = 0;
 	HIP_CHECK(hipMemcpyAsync(&total_list, t.list_offset + 3 * (size_t) C, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	if (!ctx->cand_read_lists.allocate((size_t) std::max<uint64_t>(total_list, 1) * 4)) {
-		set_last_error("the read lists of the candidates hold " + std::to_string(total_list) + " entries (" + std::to_string(total_list * 4 >> 30) + " GB): more than the device has free; lower -U or shard the input");
-		return AGPU_ERR_CAPACITY;
+	// Explicit or implicit discordant lists (fusion_core.hpp: CandidateTable::discordant_before)?  Explicit while they fit a budget (ARRIBA_LIST_BUDGET_GB, default 48: the 10 M
+	// stress sample of config 3 lists 9 G reads = 36 GB and runs fastest with them in memory) and the device has the memory; implicit otherwise, or when ARRIBA_IMPLICIT_LISTS=1 asks
+	// for it (tests: the two ways give the same files).  A context that holds one shard of a sample keeps explicit lists: they stay with the owners of the gene pairs.
+	ctx->lists_implicit = false; ctx->list_window_cuts.clear(); ctx->lists_max_mate_gap = max_mate_gap; ctx->lists_n_bucket_rows = Md;
+	t.discordant_before = nullptr;
+	{
+		const char* knob = getenv("ARRIBA_IMPLICIT_LISTS"); const char* budget_knob = getenv("ARRIBA_LIST_BUDGET_GB");
+		const double budget_gb = budget_knob != nullptr && atof(budget_knob) > 0 ? atof(budget_knob) : 48.0;
+		const bool sharded = ctx->global_n != 0 && ctx->global_n != ctx->n;
+		bool implicit = !sharded && ((knob != nullptr && knob[0] == '1') || (double) total_list * 4 > budget_gb * 1e9);
+		if (!implicit && !ctx->cand_read_lists.allocate((size_t) std::max<uint64_t>(total_list, 1) * 4)) {
+			if (sharded) { set_last_error("the read lists of the candidates hold " + std::to_string(total_list) + " entries (" + std::to_string(total_list * 4 >> 30) + " GB): more than the device has free; lower -U or shard the input"); return AGPU_ERR_CAPACITY; }
+			implicit = true;
+		}
+		ctx->lists_implicit = implicit;
+	}
+	uint64_t total_discordant = 0;
+	if (ctx->lists_implicit) {
+		DeviceBuffer& sizes = ctx->scratch("lists.discordant_sizes"); DeviceBuffer& before = ctx->scratch("lists.discordant_before");
+		ALLOC(sizes, ((size_t) C + 1) * 8); ALLOC(before, ((size_t) C + 1) * 8);
+		discordant_size_kernel<<<grid_for((uint64_t) C + 1), BLOCK, 0, s>>>(list_size.as<uint32_t>(), C, sizes.as<uint64_t>());
+		HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, sizes.as<uint64_t>(), before.as<uint64_t>(), (uint64_t) 0, (size_t) C + 1, rocprim::plus<uint64_t>(), s));
+		if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
+		HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, sizes.as<uint64_t>(), before.as<uint64_t>(), (uint64_t) 0, (size_t) C + 1, rocprim::plus<uint64_t>(), s));
+		HIP_CHECK(hipMemcpyAsync(&total_discordant, before.as<uint64_t>() + C, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (!ctx->cand_read_lists.allocate((size_t) std::max<uint64_t>(total_list - total_discordant, 1) * 4)) { set_last_error("hipMalloc failed (the split-read lists of the candidates)"); return AGPU_ERR_DEVICE; }
+		t.discordant_before = before.as<uint64_t>();
 	}
 	t.read_lists = ctx->cand_read_lists.as<uint32_t>();
 	ctx->n_list_entries = total_list;
 	{ KernelTimer timer(ctx, "split_list_fill_kernel", (uint64_t) M * (sizeof(FusionEmission) + sizeof(RankState)));
 	  split_list_fill_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), candidate_of.as<uint32_t>(), ranks.as<RankState>(), folds.as<CandidateFold>(), threshold, t); }
+	const int fill_mode = ctx->lists_implicit ? ATTACH_FOLD : ATTACH_FILL;
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(fill)", (uint64_t) C * 25);
-	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, bucket_keys.as<uint64_t>(), buckets, Md, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true); }
+	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, 0, C, bucket_keys.as<uint64_t>(), buckets, Md, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, fill_mode); }
 	if (queued > 0) { // the fill pass queues the same candidates (possibly in another order)
 		// algorithmic bytes: every bucket row (two breakpoints, info, read, two anchors: 24 B) read once, every list entry written once (4 B; total_list
 		// also counts the few split-read entries), the queued candidates' columns.  What the kernel really moves is several times more (PMC): the
 		// candidates of one gene pair scan the same bucket rows one after the other.
-		KernelTimer timer(ctx, "attach_discordant_wave_kernel(fill)", (uint64_t) Md * 24 + (uint64_t) total_list * 4 + (uint64_t) queued * 25);
-		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, true);
+		KernelTimer timer(ctx, "attach_discordant_wave_kernel(fill)", (uint64_t) Md * 24 + (ctx->lists_implicit ? 0 : (uint64_t) total_list * 4) + (uint64_t) queued * 25);
+		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, fill_mode);
 	}
+	ctx->n_candidates = C;
+	if (ctx->lists_implicit) { const int status = cut_list_windows(ctx); if (status != AGPU_OK) return status; }
 	{ KernelTimer timer(ctx, "finish_kernel", (uint64_t) C * 53); finish_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t); }
 	ctx->n_queued_buckets = queued;
 	ctx->n_discordant_emissions = Md;
@@ -560,6 +713,16 @@ extern "C" int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uin
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	if (total) *total = ctx->n_list_entries;
+	if (reads && ctx->n_list_entries > 0 && ctx->lists_implicit) { // window after window (what the tests of the implicit lists compare; a sample whose lists are implicit for their number has no host that could take them)
+		if (capacity < ctx->n_list_entries) { set_last_error("the read lists are implicit: all of them or none"); return AGPU_ERR_INVALID; }
+		return for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+			uint64_t bounds[2] = { 0, 0 };
+			HIP_CHECK(hipMemcpy(&bounds[0], window.list_offset + 3 * (uint64_t) begin, 8, hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(&bounds[1], window.list_offset + 3 * (uint64_t) end, 8, hipMemcpyDeviceToHost));
+			if (bounds[1] > bounds[0]) HIP_CHECK(hipMemcpy(reads + bounds[0], window.read_lists + bounds[0], (size_t) (bounds[1] - bounds[0]) * 4, hipMemcpyDeviceToHost));
+			return AGPU_OK;
+		});
+	}
 	if (reads && ctx->n_list_entries > 0) HIP_CHECK(hipMemcpy(reads, ctx->cand_read_lists.ptr, std::min<uint64_t>(capacity, ctx->n_list_entries) * 4, hipMemcpyDeviceToHost));
 	return AGPU_OK;
 }
@@ -574,9 +737,22 @@ __global__ void list_sizes_of_kernel(CandidateTable t, const uint32_t* candidate
 }
 __global__ void list_copy_of_kernel(CandidateTable t, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads) {
 	const uint32_t k = blockIdx.x; // one workgroup per list
-	const uint64_t at = 3 * (uint64_t) candidates[k / 3] + k % 3;
+	if (k % 3 == 2 && t.discordant_before != nullptr) return; // (an implicit list: list_expand_of_kernel)
+	const uint32_t c = candidates[k / 3];
+	const uint64_t at = 3 * (uint64_t) c + k % 3;
 	const uint64_t begin = t.list_offset[at], target = compact_offset[k]; const uint32_t size = (uint32_t) (t.list_offset[at + 1] - begin);
-	for (uint32_t e = threadIdx.x; e < size; e += BLOCK) reads[target + e] = t.read_lists[begin + e];
+	for (uint32_t e = threadIdx.x; e < size; e += BLOCK) reads[target + e] = k % 3 == 2 ? t.read_lists[begin + e] : split_list_entry(t, c, begin + e);
+}
+// the implicit discordant lists of some candidates: one wavefront per candidate walks its bucket again
+__global__ void __launch_bounds__(64) list_expand_of_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, BucketRanges ranges, int32_t max_mate_gap, uint32_t threshold, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads) {
+	const uint32_t k = blockIdx.x, lane = threadIdx.x;
+	const uint32_t c = candidates[k];
+	if (t.list_offset[3 * (uint64_t) c + 3] == t.list_offset[3 * (uint64_t) c + 2]) return;
+	BucketRef ref; ref.candidate = c; ref.begin = ranges.begin[c]; ref.end = ranges.end[c];
+	const uint32_t flags = t.flags[c];
+	uint32_t unfiltered = 0, appended = 0, lane_votes = 0; int32_t lane_anchor1 = 0, lane_anchor2 = 0; bool zero_seen = false; AnchorFold fold1 = anchor_identity(), fold2 = anchor_identity();
+	scan_bucket<3>(ann, buckets, ref, t.gene1[c], t.gene2[c], t.breakpoint1[c], t.breakpoint2[c], flags & CFLAG_UPSTREAM1, flags & CFLAG_UPSTREAM2, ranges.had_split_reads[c], max_mate_gap, threshold, lane,
+	               reads + compact_offset[3 * (uint64_t) k + 2], nullptr, unfiltered, appended, lane_anchor1, lane_anchor2, lane_votes, zero_seen, fold1, fold2);
 }
 
 extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint64_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total) {
@@ -603,6 +779,14 @@ extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* c
 		if (capacity < entries) { set_last_error("capacity too small for the read lists"); return AGPU_ERR_INVALID; }
 		ALLOC(out, (size_t) entries * 4);
 		list_copy_of_kernel<<<(unsigned int) (3 * n), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>());
+		if (ctx->lists_implicit) {
+			DiscordantBuckets buckets; BucketRanges ranges;
+			const size_t Md1 = std::max<uint32_t>(ctx->lists_n_bucket_rows, 1);
+			const int32_t* columns = ctx->scratch("fusions.bucket_columns").as<int32_t>();
+			buckets.breakpoint1 = columns; buckets.breakpoint2 = columns + Md1; buckets.info = (const uint32_t*) (columns + 2 * Md1); buckets.read = buckets.info + Md1; buckets.anchor1 = (const int32_t*) (buckets.read + Md1); buckets.anchor2 = buckets.anchor1 + Md1;
+			ranges.begin = ctx->scratch("lists.bucket_begin").as<uint32_t>(); ranges.end = ctx->scratch("lists.bucket_end").as<uint32_t>(); ranges.had_split_reads = ctx->scratch("lists.had_split_reads").as<uint8_t>();
+			list_expand_of_kernel<<<(unsigned int) n, 64, 0, s>>>(ctx->annotation, ctx->candidates, buckets, ranges, ctx->lists_max_mate_gap, ctx->params.subsampling_threshold, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>());
+		}
 		HIP_CHECK(hipMemcpyAsync(reads, out.ptr, (size_t) entries * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 	}

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(BLOCK) bgzf_unwrap_kernel(const uint8_t* raw, 
 }
 
 // Deflated blocks (round 5: inflate_fast_core.hpp).  Pass 1: a LANE per block, INFLATE_LANES blocks per workgroup (one wavefront whose lanes run the same loop on different
-// blocks; the tables of a block are 2.7 KB of LDS): literals to their place, matches noted.  The first / last block of a part of a file gives only the bytes [skip, skip + keep) of
+// blocks; the tables of a block are 2 KB of LDS): literals to their place, matches noted.  The first / last block of a part of a file gives only the bytes [skip, skip + keep) of
 // what it holds: such a block is inflated into `spill` (64 KB for block 0, 64 KB for the last one) and its share copied from there by pass 2.
 template <int LANES> __global__ void __launch_bounds__(LANES) bgzf_inflate_tokens_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint32_t n_blocks, uint8_t* stream, uint8_t* spill,
                                                                                         unsigned long long* notes, uint32_t* note_count, int* status, unsigned int* failures) {
@@ -1017,7 +1017,7 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 			ctx->ingest_deflated_pieces = true;
 			uint8_t* target = ctx->ingest_stream.as<uint8_t>() + ctx->ingest_stream_size;
 			unsigned int* failures = ctx->scratch("ingest.crc_mismatches").as<unsigned int>() + 1;
-			static const char* way = getenv("ARRIBA_INFLATE"); // "wave": the one-wavefront-per-block decoder of round 4 for every block; "8" / "20": other numbers of blocks per wavefront in pass 1 (measurements)
+			static const char* way = getenv("ARRIBA_INFLATE"); // "wave": the one-wavefront-per-block decoder of round 4 for every block; "16" / "24": other numbers of blocks per wavefront in pass 1 (measurements)
 			if (way != nullptr && strcmp(way, "wave") == 0) {
 				KernelTimer timer(ctx, "bgzf_inflate_kernel", (uint64_t) raw_size + stream_bytes, pieces);
 				bgzf_inflate_kernel<<<n_blocks, 64, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), target, ctx->scratch("ingest.inflate_spill").as<uint8_t>(), nullptr, failures);
@@ -1028,11 +1028,11 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 					HIP_CHECK(hipStreamSynchronize(pieces)); // (the pieces before this one read the buffers that are about to be replaced)
 					ALLOC(notes, (size_t) n_blocks * INFLATE_MATCH_CAPACITY * 8); ALLOC(note_count, (size_t) n_blocks * 4); ALLOC(status, (size_t) n_blocks * 4);
 				}
-				const int lanes = way != nullptr && atoi(way) > 0 ? atoi(way) : 16;
+				const int lanes = way != nullptr && atoi(way) > 0 ? atoi(way) : 20; // (20 lanes x 2 032 bytes of tables: four such workgroups fill the 160 KB of a CU -- 80 blocks per CU, all ~17 000 blocks of a piece resident at once)
 				{ KernelTimer timer(ctx, "bgzf_inflate_tokens_kernel", (uint64_t) raw_size + stream_bytes, pieces);
 				  #define TOKENS(LANES) bgzf_inflate_tokens_kernel<LANES><<<(n_blocks + LANES - 1) / LANES, LANES, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), n_blocks, target, \
 				  	ctx->scratch("ingest.inflate_spill").as<uint8_t>(), notes.as<unsigned long long>(), note_count.as<uint32_t>(), status.as<int>(), failures)
-				  if (lanes == 8) TOKENS(8); else if (lanes == 20) TOKENS(20); else TOKENS(16);
+				  if (lanes == 16) TOKENS(16); else if (lanes == 24) TOKENS(24); else TOKENS(20);
 				  #undef TOKENS
 				}
 				bgzf_inflate_kernel<<<n_blocks, 64, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), target, ctx->scratch("ingest.inflate_spill").as<uint8_t>(), status.as<int>(), failures); // (returns at once but for the blocks handed back)

@@ -254,7 +254,17 @@ struct CandidateTable { // structure of arrays, index = order of first occurrenc
 	uint32_t* votes;                // [2*n] strand votes of the reads in the lists: forward, reverse (source/fusions.cpp:22-79)
 	uint64_t* list_offset;          // [3*n + 1] into read_lists (64-bit: a candidate holds up to -U reads per list, and with -U 32767 the lists of a sample pass 2^32 entries): split_read1_list, split_read2_list, discordant_mate_list of candidate c at 3c, 3c+1, 3c+2
 	uint32_t* read_lists;
+	// Round 5: the discordant-mate lists may be IMPLICIT.  Every candidate of a gene pair lists the discordant mates of the pair that lie near its breakpoints, up to the subsampling
+	// threshold (source/fusions.cpp:379-437) -- with -U 32767 (BASELINE.json config 3) that is 92.7 G entries for 10^8 fragments, which nobody can hold (the reference would
+	// need 740 GB).  A discordant list is a function of (the bucket of its gene pair, the predicate of the candidate, the threshold); when the lists of a sample are too many to keep,
+	// only that function is kept (agpu_fusions.hip: bucket range and predicate per candidate), list_offset stays what it is -- positions in lists that exist only in the mind --
+	// and read_lists holds the split-read lists alone, packed: discordant_before != nullptr, and entry k of a split-read list of candidate c lies at read_lists[k - discordant_before[c]].
+	// A stage that walks discordant lists gets them a WINDOW of candidates at a time (for_each_list_window): a table like this one whose read_lists is a buffer that holds all three
+	// lists of the candidates of the window at their positions k, and discordant_before == nullptr -- the kernels of the stages cannot tell the difference.
+	const uint64_t* discordant_before = nullptr; // [n + 1] entries of discordant lists in front of candidate c's
 };
+// entry k of split_read1_list / split_read2_list of candidate c (k between list_offset[3c] and list_offset[3c + 2]): valid on the table of the sample and on the table of a window
+AGPU_HD uint32_t split_list_entry(const CandidateTable& t, uint32_t c, uint64_t k) { return t.read_lists[t.discordant_before != nullptr ? k - t.discordant_before[c] : k]; }
 
 AGPU_HD bool candidate_is_intragenic(const AnnotationView& ann, uint32_t gene1, uint32_t gene2, int32_t breakpoint1, int32_t breakpoint2) { // source/common.hpp:275-279
 	return gene1 == gene2 || (breakpoint1 >= ann.gene_start[gene2] - 10000 && breakpoint1 <= ann.gene_end[gene2] + 10000 &&
@@ -314,9 +324,14 @@ struct DiscordantBuckets { const int32_t* breakpoint1; const int32_t* breakpoint
 // Attach the discordant mates of the candidate's gene pair (bucket = their emissions in name order) to candidate c
 // (source/fusions.cpp:367-437).  With out_list == NULL only the list size is returned (count pass); otherwise the list is
 // written, the anchors and the unfiltered count are updated and the fragments whose mates the reference swaps are flagged.
+// What a walk over the bucket does: ATTACH_COUNT the size of the list; ATTACH_FILL the pass behind it -- the list written, the anchors folded, the unfiltered mates and the
+// strand votes counted, the fragments whose mates the reference swaps flagged; ATTACH_FOLD the same without writing the list (implicit lists); ATTACH_EXPAND a later expansion
+// of an implicit list: the same entries, nothing else touched (the candidate may have been filtered since).  mode < 0: COUNT without out_list, FILL with one.
+enum { ATTACH_COUNT = 0, ATTACH_FILL = 1, ATTACH_FOLD = 2, ATTACH_EXPAND = 3 };
 AGPU_HD uint32_t attach_discordant_mates(const AnnotationView& ann, const CandidateTable& t, uint32_t c, const DiscordantBuckets& buckets, uint32_t bucket_begin, uint32_t bucket_size,
-                                         int32_t max_mate_gap, uint32_t threshold, bool has_split_reads, uint32_t* out_list, uint8_t* discordant_swapped) {
-	if (t.filter[c] != FILTER_none) return 0;
+                                         int32_t max_mate_gap, uint32_t threshold, bool has_split_reads, uint32_t* out_list, uint8_t* discordant_swapped, int mode = -1) {
+	if (mode < 0) mode = out_list != nullptr ? ATTACH_FILL : ATTACH_COUNT;
+	if (mode != ATTACH_EXPAND && t.filter[c] != FILTER_none) return 0;
 	uint32_t flags = t.flags[c];
 	bool upstream1 = flags & CFLAG_UPSTREAM1, upstream2 = flags & CFLAG_UPSTREAM2;
 	uint32_t gene1 = t.gene1[c], gene2 = t.gene2[c];
@@ -330,9 +345,9 @@ AGPU_HD uint32_t attach_discordant_mates(const AnnotationView& ann, const Candid
 		bool read_unfiltered = (info >> EINFO_FILTER_SHIFT & 255) == FILTER_none;
 		if (!read_unfiltered && list_size >= threshold) continue;
 		if (unfiltered >= threshold) break;
-		if (out_list) {
+		if (mode == ATTACH_FILL || mode == ATTACH_EXPAND) out_list[list_size] = buckets.read[k];
+		if (mode == ATTACH_FILL || mode == ATTACH_FOLD) {
 			uint32_t read = buckets.read[k];
-			out_list[list_size] = read;
 			if ((info & EINFO_MATES_SWAPPED) && !discordant_swapped[read]) discordant_swapped[read] = 1;
 			fold1 = anchor_combine(fold1, anchor_single(buckets.anchor1[k], upstream1), upstream1);
 			fold2 = anchor_combine(fold2, anchor_single(buckets.anchor2[k], upstream2), upstream2);
@@ -342,7 +357,7 @@ AGPU_HD uint32_t attach_discordant_mates(const AnnotationView& ann, const Candid
 		++list_size;
 		if (read_unfiltered) ++unfiltered;
 	}
-	if (out_list) {
+	if (mode == ATTACH_FILL || mode == ATTACH_FOLD) {
 		t.discordant_mates[c] = unfiltered;
 		t.anchor1[c] = anchor_apply(t.anchor1[c], fold1, upstream1);
 		t.anchor2[c] = anchor_apply(t.anchor2[c], fold2, upstream2);

@@ -74,14 +74,15 @@ AGPU_HD int inflate_symbol(InflateBits& bits, const uint16_t* fast, int fast_bit
 }
 
 // the tables of a code from the lengths of its symbols (lengths[0..n)); lane 0 numbers the codes, all lanes fill the first-level table.  Returns false for an
-// over-subscribed set of lengths (an incomplete one is allowed where zlib allows it: a single distance code, or none)
+// over-subscribed or incomplete set of lengths (an incomplete one is allowed where zlib allows it: a single code of one bit, or none)
 template <class Sync> AGPU_HD bool inflate_build(const uint8_t* lengths, uint32_t n, uint16_t* codes, InflateHuffman& huffman, uint16_t* fast, int fast_bits, uint32_t lane, uint32_t lanes, uint32_t* verdict, uint16_t* offset, uint32_t* next_code, Sync sync) {
 	for (uint32_t k = lane; k < (1u << fast_bits); k += lanes) fast[k] = 0;
 	if (lane == 0) {
 		for (int length = 0; length <= 15; ++length) huffman.count[length] = 0;
 		for (uint32_t s = 0; s < n; ++s) huffman.count[lengths[s]]++;
-		int left = 1; bool valid = true;
-		for (int length = 1; length <= 15; ++length) { left <<= 1; left -= huffman.count[length]; if (left < 0) valid = false; }
+		int left = 1, longest = 0; bool valid = true;
+		for (int length = 1; length <= 15; ++length) { left <<= 1; left -= huffman.count[length]; if (left < 0) valid = false; if (huffman.count[length] != 0) longest = length; }
+		if (left > 0 && longest > 1) valid = false; // (advisor, round 4: zlib refuses an incomplete set too, unless it is a single code of one bit -- or no code at all; inftrees.c)
 		offset[1] = 0;
 		for (int length = 1; length < 15; ++length) offset[length + 1] = offset[length] + huffman.count[length];
 		uint32_t code = 0;
@@ -138,8 +139,8 @@ template <class Sync, class Broadcast> AGPU_HD int inflate_block(const uint8_t* 
 						stored = true; stored_left = len; in_block = true;
 					} else if (type == 1) { // fixed code (RFC 1951 3.2.6)
 						for (uint32_t s = 0; s < 288; ++s) shared.lengths[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-						for (uint32_t s = 0; s < 30; ++s) shared.lengths[288 + s] = 5;
-						shared.event[5] = 288; shared.event[6] = 30;
+						for (uint32_t s = 0; s < 32; ++s) shared.lengths[288 + s] = 5; // (32 codes of 5 bits, the last two never used: a complete code, as zlib's fixed table)
+						shared.event[5] = 288; shared.event[6] = 32;
 						stored = false; in_block = true; kind = EVENT_TABLES;
 					} else if (type == 2) { // dynamic code: the lengths of the code lengths' code, then the lengths of both codes, run-length coded (3.2.7)
 						const uint32_t n_litlen = bits.take(5) + 257, n_distance = bits.take(5) + 1, n_lengths = bits.take(4) + 4;

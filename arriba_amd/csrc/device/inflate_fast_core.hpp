@@ -5,13 +5,12 @@
 // copies of the matches are not.  Round 4 gave a whole wavefront to one block: one lane walked the chain, 63 waited, and every match of more than a few bytes cost three barriers:
 // 5.9 GB/s of output on the whole device.  Here
 //   pass 1 (inflate_tokens)   ONE LANE per block, sixteen blocks per wavefront running the same loop on different data: bits from a 64-bit buffer refilled without a branch from a
-//                             ring of input bytes in LDS (topped up from HBM once in eight tokens, by all lanes at once), literal / length codes through a two-level table (9 bits, then up to 6 more: 852 entries at most), distance codes
-//                             through an 8-bit table (the rare longer one bit by bit over the canonical counts), base values and extra bits of lengths and distances computed, not
+//                             ring of input bytes in LDS (topped up from HBM once in eight tokens, by all lanes at once), literal / length codes and distance codes through two-level tables (8 and 7 bits, then as many more as the longest code of the prefix needs), base values and extra bits of lengths and distances computed, not
 //                             looked up.  Literals go straight to their place in the output; a match is only NOTED: (position, length, distance), 8 bytes.
 //   pass 2 (resolve)          a wavefront per block takes the noted matches 64 at a time, a lane per match.  A match may be copied as soon as the bytes it reads are final:
 //                             everything in front of the first match that is still pending is (inflate_match_is_ready) -- most matches of a group read from far in front of the
 //                             group and go in the first round.
-// The tables of a block are 2.7 KB of LDS, so 48 blocks are decoded per CU at a time instead of 12, and the lanes of a wavefront no longer wait for one another's barriers.
+// The tables of a block are 2 KB of LDS, so 80 blocks are decoded per CU at a time instead of 12, and the lanes of a wavefront no longer wait for one another's barriers.
 //
 // The bytes are those zlib's inflate gives, and the streams zlib refuses are refused (over-subscribed AND incomplete codes: inftrees.c's rule, which the decoder of round 4 did not
 // have); tests/emu/inflate_check.cpp steps both passes on the host against zlib on every kind of block.  A block with more matches than INFLATE_MATCH_CAPACITY returns INFLATE_RETRY
@@ -23,22 +22,23 @@
 
 namespace agpu {
 
-const uint32_t FAST_LITLEN_ROOT = 9, FAST_LITLEN_ENTRIES = 852 /* 512 + the 340 entries all second-level tables of a complete code of 286 symbols can have (zlib's "enough") */, FAST_DISTANCE_ROOT = 8;
+// Two-level tables for both codes: `root` bits at once, the longer codes through a second table per prefix (as wide as the longest code under that prefix needs).  The sizes are
+// what a decoding lane can afford in LDS -- 80 lanes per CU at 2 032 bytes each -- not what the worst code needs: a block whose second tables do not fit (zlib's "enough" says
+// 852 entries for 9 bits; the blocks of a BAM file at the usual levels need ~250 of the 384 behind 8 bits, and ~20 of the 128 behind the 7 bits of the distances) is handed back.
+const uint32_t FAST_LITLEN_ROOT = 8, FAST_LITLEN_ENTRIES = 256 + 384, FAST_DISTANCE_ROOT = 7, FAST_DISTANCE_ENTRIES = 128 + 128;
 const uint32_t INFLATE_MATCH_CAPACITY = 8192; // matches noted per block (64 KB of notes for 64 KB of output); a 64 KB BAM block at the usual levels has 4 000 - 6 000
 enum { INFLATE_RETRY = 9 };
 
 // table entries: payload << 6 | type << 4 | bits.  0 = no such code.
-enum { FAST_LITERAL = 1, FAST_LENGTH = 2 /* payload = symbol - 256: 0 end of block, 1..29 a length code */, FAST_SUBTABLE = 3 /* payload = where it starts, bits = how many bits index it */ };
+enum { FAST_LITERAL = 1 /* payload = the byte; in the table of the distances: the distance symbol */, FAST_LENGTH = 2 /* payload = symbol - 256: 0 end of block, 1..29 a length code */, FAST_SUBTABLE = 3 /* payload = where it starts, bits = how many bits index it */ };
 AGPU_HD uint16_t fast_entry(uint32_t type, uint32_t payload, uint32_t n_bits) { return (uint16_t) (payload << 6 | type << 4 | n_bits); }
 
-struct alignas(16) InflateFastTables { // what one decoding lane keeps in LDS: 2 832 bytes
+struct alignas(16) InflateFastTables { // what one decoding lane keeps in LDS: 2 032 bytes
 	unsigned long long input_ring[18];          // the next 128 bytes of the block's DEFLATE stream (FastBits) + two spare words
-	uint16_t litlen[FAST_LITLEN_ENTRIES];
-	uint16_t distance[1 << FAST_DISTANCE_ROOT]; // 0x8000 | symbol << 4 | bits; 0 = longer than 8 bits (or no such code).  While a dynamic header is read: the 7-bit table of the code-length code, as bytes
-	uint16_t count[16], first[16], next[16];    // codes per length (left at the distance code's for its long codes), first canonical code per length, the next one to hand out
-	uint8_t distance_symbols[32];               // distance symbols by (length, symbol): the canonical decode of codes longer than 8 bits
-	uint8_t lengths[320];                       // code lengths of the block being set up: literals / lengths, then distances
-	uint8_t code_lengths[24];                   // lengths of the code-length code
+	uint16_t litlen[FAST_LITLEN_ENTRIES];       // (while a dynamic header is read: the 7-bit table of the code-length code, as bytes)
+	uint16_t distance[FAST_DISTANCE_ENTRIES];   // (until it is built: the code lengths of the block being set up, as bytes -- literals / lengths, then distances)
+	uint16_t count[16], next[16];               // codes per length, the next canonical code of every length to hand out
+	uint8_t code_lengths[32];                   // lengths of the code-length code; then the lengths of the distance code while its table is built
 };
 
 // the bits of the stream, lowest first; at least 56 of them after refill().  The input comes through a ring of 128 bytes in LDS that is topped up from HBM in pieces of 16 bytes
@@ -95,8 +95,8 @@ AGPU_HD uint32_t fast_reverse_bits(uint32_t code, uint32_t length) { // the stre
 #endif
 }
 
-// counts per length, the check zlib makes (inftrees.c: over-subscribed sets are refused, incomplete ones too unless the code has a single symbol of one bit -- or none at all),
-// the first canonical code of every length (RFC 1951 3.2.2).  Returns the longest length, -1 for a set zlib refuses.
+// counts per length and the check zlib makes (inftrees.c: over-subscribed sets are refused, incomplete ones too unless the code has a single symbol of one bit -- or none at all).
+// Returns the longest length, -1 for a set zlib refuses.
 AGPU_HD int fast_count_lengths(const uint8_t* lengths, uint32_t n, InflateFastTables& t) {
 	for (uint32_t l = 0; l < 16; ++l) t.count[l] = 0;
 	for (uint32_t s = 0; s < n; ++s) t.count[lengths[s]]++;
@@ -108,83 +108,61 @@ AGPU_HD int fast_count_lengths(const uint8_t* lengths, uint32_t n, InflateFastTa
 		if (t.count[l] != 0) longest = (int) l;
 	}
 	if (left > 0 && longest > 1) return -1;
-	uint32_t code = 0;
-	t.first[0] = 0;
-	for (uint32_t l = 1; l < 16; ++l) { code = (code + t.count[l - 1]) << 1; t.first[l] = (uint16_t) code; }
 	return longest;
 }
-
-// literal / length code: 9 bits at once, the longer codes through a second table per 9-bit prefix (as wide as the longest code under that prefix needs)
-AGPU_HD int fast_build_litlen(const uint8_t* lengths, uint32_t n, InflateFastTables& t) {
+AGPU_HD void fast_first_codes(InflateFastTables& t) { // the first canonical code of every length (RFC 1951 3.2.2)
+	uint32_t code = 0;
+	t.next[0] = 0;
+	for (uint32_t l = 1; l < 16; ++l) { code = (code + t.count[l - 1]) << 1; t.next[l] = (uint16_t) code; }
+}
+// the table of one code.  litlen: the symbols below 256 are literals, the others lengths / the end of the block; else every symbol is a distance symbol.
+AGPU_HD int fast_build_table(const uint8_t* lengths, uint32_t n, uint16_t* table, uint32_t root, uint32_t capacity, bool litlen, InflateFastTables& t) {
 	const int longest = fast_count_lengths(lengths, n, t);
 	if (longest < 0) return INFLATE_BAD_CODE_LENGTHS;
-	uint32_t* words = (uint32_t*) t.litlen;
-	for (uint32_t k = 0; k < (1u << FAST_LITLEN_ROOT) / 2; ++k) words[k] = 0;
-	if (longest > (int) FAST_LITLEN_ROOT) { // how wide the second table of every prefix is
-		for (uint32_t l = 0; l < 16; ++l) t.next[l] = t.first[l];
+	uint32_t* words = (uint32_t*) table;
+	for (uint32_t k = 0; k < (1u << root) / 2; ++k) words[k] = 0;
+	if (longest > (int) root) { // how wide the second table of every prefix is
+		fast_first_codes(t);
 		for (uint32_t s = 0; s < n; ++s) {
 			const uint32_t length = lengths[s];
 			if (length == 0) continue;
 			const uint32_t code = t.next[length]++;
-			if (length <= FAST_LITLEN_ROOT) continue;
-			const uint32_t prefix = fast_reverse_bits(code, length) & ((1u << FAST_LITLEN_ROOT) - 1u);
-			if ((t.litlen[prefix] & 15u) < length - FAST_LITLEN_ROOT) t.litlen[prefix] = fast_entry(FAST_SUBTABLE, 0, length - FAST_LITLEN_ROOT);
+			if (length <= root) continue;
+			const uint32_t prefix = fast_reverse_bits(code, length) & ((1u << root) - 1u);
+			if ((table[prefix] & 15u) < length - root) table[prefix] = fast_entry(FAST_SUBTABLE, 0, length - root);
 		}
 	}
-	for (uint32_t l = 0; l < 16; ++l) t.next[l] = t.first[l];
-	uint32_t next_free = 1u << FAST_LITLEN_ROOT;
+	fast_first_codes(t);
+	uint32_t next_free = 1u << root;
 	for (uint32_t s = 0; s < n; ++s) {
 		const uint32_t length = lengths[s];
 		if (length == 0) continue;
 		const uint32_t reversed = fast_reverse_bits(t.next[length]++, length);
-		const uint32_t type = s < 256 ? FAST_LITERAL : FAST_LENGTH, payload = s < 256 ? s : s - 256;
-		if (length <= FAST_LITLEN_ROOT) {
+		const uint32_t type = !litlen || s < 256 ? FAST_LITERAL : FAST_LENGTH, payload = !litlen || s < 256 ? s : s - 256;
+		if (length <= root) {
 			const uint16_t entry = fast_entry(type, payload, length);
-			for (uint32_t k = reversed; k < (1u << FAST_LITLEN_ROOT); k += 1u << length) t.litlen[k] = entry;
+			for (uint32_t k = reversed; k < (1u << root); k += 1u << length) table[k] = entry;
 			continue;
 		}
-		const uint32_t prefix = reversed & ((1u << FAST_LITLEN_ROOT) - 1u);
-		const uint32_t bits = t.litlen[prefix] & 15u;
-		uint32_t offset = t.litlen[prefix] >> 6;
+		const uint32_t prefix = reversed & ((1u << root) - 1u);
+		const uint32_t bits = table[prefix] & 15u;
+		uint32_t offset = table[prefix] >> 6;
 		if (offset == 0) {
 			offset = next_free; next_free += 1u << bits;
-			if (next_free > FAST_LITLEN_ENTRIES) return INFLATE_RETRY; // (cannot happen with a complete code of at most 286 symbols; the other decoder has no such bound)
-			t.litlen[prefix] = fast_entry(FAST_SUBTABLE, offset, bits);
+			if (next_free > capacity) return INFLATE_RETRY; // (more second tables than a lane has room for: the other decoder takes the block)
+			table[prefix] = fast_entry(FAST_SUBTABLE, offset, bits);
 		}
-		const uint16_t entry = fast_entry(type, payload, length - FAST_LITLEN_ROOT);
-		for (uint32_t k = reversed >> FAST_LITLEN_ROOT; k < (1u << bits); k += 1u << (length - FAST_LITLEN_ROOT)) t.litlen[offset + k] = entry;
+		const uint16_t entry = fast_entry(type, payload, length - root);
+		for (uint32_t k = reversed >> root; k < (1u << bits); k += 1u << (length - root)) table[offset + k] = entry;
 	}
 	return INFLATE_OK;
 }
-
-// distance code: 8 bits at once; a code of more than 8 bits (a distance that is used less than once in 256 matches) bit by bit over the canonical counts
-AGPU_HD int fast_build_distance(const uint8_t* lengths, uint32_t n, InflateFastTables& t) {
-	if (fast_count_lengths(lengths, n, t) < 0) return INFLATE_BAD_CODE_LENGTHS;
-	uint32_t* words = (uint32_t*) t.distance;
-	for (uint32_t k = 0; k < (1u << FAST_DISTANCE_ROOT) / 2; ++k) words[k] = 0;
-	uint32_t offset = 0;
-	for (uint32_t l = 1; l < 16; ++l) { t.next[l] = (uint16_t) offset; offset += t.count[l]; } // (here: where the symbols of a length start in distance_symbols)
-	for (uint32_t s = 0; s < n; ++s) if (lengths[s] != 0) t.distance_symbols[t.next[lengths[s]]++] = (uint8_t) s;
-	for (uint32_t l = 0; l < 16; ++l) t.next[l] = t.first[l];
-	for (uint32_t s = 0; s < n; ++s) {
-		const uint32_t length = lengths[s];
-		if (length == 0) continue;
-		const uint32_t code = t.next[length]++;
-		if (length > FAST_DISTANCE_ROOT) continue;
-		const uint16_t entry = (uint16_t) (0x8000u | s << 4 | length);
-		for (uint32_t k = fast_reverse_bits(code, length); k < (1u << FAST_DISTANCE_ROOT); k += 1u << length) t.distance[k] = entry;
-	}
-	return INFLATE_OK;
-}
-AGPU_HD int fast_long_distance_symbol(FastBits& bits, const InflateFastTables& t) { // -1: no such code
-	int code = 0, first = 0, index = 0;
-	for (uint32_t length = 1; length < 16; ++length) {
-		code |= (int) bits.take(1);
-		const int count = t.count[length];
-		if (code - count < first) return t.distance_symbols[index + (code - first)];
-		index += count; first += count; first <<= 1; code <<= 1;
-	}
-	return -1;
+// one symbol: the entry of its code (0: no such code), its bits dropped
+AGPU_HD uint32_t fast_symbol(FastBits& bits, const uint16_t* table, uint32_t root) {
+	uint32_t entry = table[bits.peek(root)];
+	if ((entry >> 4 & 3u) == FAST_SUBTABLE) { bits.drop(root); entry = table[(entry >> 6) + bits.peek(entry & 15u)]; }
+	bits.drop(entry & 15u);
+	return entry;
 }
 
 // the header of a dynamic block (RFC 1951 3.2.7): the lengths of both codes, run-length coded with a code of 19 symbols, itself given by 3-bit lengths
@@ -207,7 +185,7 @@ AGPU_HD int fast_read_dynamic_header(FastBits& bits, InflateFastTables& t, uint3
 	uint32_t code = 0;
 	t.next[0] = 0;
 	for (uint32_t l = 1; l < 8; ++l) { code = (code + t.count[l - 1]) << 1; t.next[l] = (uint16_t) code; }
-	uint8_t* table = (uint8_t*) t.distance;
+	uint8_t* table = (uint8_t*) t.litlen; uint8_t* lengths = (uint8_t*) t.distance;
 	for (uint32_t k = 0; k < 19; ++k) {
 		const uint32_t length = t.code_lengths[k];
 		if (length == 0) continue;
@@ -221,15 +199,15 @@ AGPU_HD int fast_read_dynamic_header(FastBits& bits, InflateFastTables& t, uint3
 		const uint32_t entry = table[bits.peek(7)];
 		bits.drop(entry & 7u);
 		const uint32_t symbol = entry >> 3;
-		if (symbol < 16) { t.lengths[filled++] = (uint8_t) symbol; continue; }
+		if (symbol < 16) { lengths[filled++] = (uint8_t) symbol; continue; }
 		uint32_t repeat, value = 0;
-		if (symbol == 16) { if (filled == 0) return INFLATE_BAD_CODE_LENGTHS; value = t.lengths[filled - 1]; repeat = 3 + bits.take(2); }
+		if (symbol == 16) { if (filled == 0) return INFLATE_BAD_CODE_LENGTHS; value = lengths[filled - 1]; repeat = 3 + bits.take(2); }
 		else if (symbol == 17) repeat = 3 + bits.take(3);
 		else repeat = 11 + bits.take(7);
 		if (filled + repeat > total) return INFLATE_BAD_CODE_LENGTHS;
-		while (repeat-- > 0) t.lengths[filled++] = (uint8_t) value;
+		while (repeat-- > 0) lengths[filled++] = (uint8_t) value;
 	}
-	if (t.lengths[256] == 0) return INFLATE_BAD_CODE_LENGTHS; // no end-of-block code
+	if (lengths[256] == 0) return INFLATE_BAD_CODE_LENGTHS; // no end-of-block code
 	return INFLATE_OK;
 }
 
@@ -263,20 +241,22 @@ AGPU_HD int inflate_tokens(const uint8_t* input, uint32_t in_size, uint8_t* outp
 		}
 		if (type == 3) return INFLATE_BAD_BLOCK_TYPE;
 		uint32_t n_litlen = 288, n_distance = 32; // fixed code (3.2.6): 288 and 32 symbols (the last two of each never occur in a valid stream: refused when they are decoded)
+		uint8_t* lengths = (uint8_t*) t.distance;
 		if (type == 1) {
-			for (uint32_t s = 0; s < 288; ++s) t.lengths[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-			for (uint32_t s = 0; s < 32; ++s) t.lengths[288 + s] = 5;
+			for (uint32_t s = 0; s < 288; ++s) lengths[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+			for (uint32_t s = 0; s < 32; ++s) lengths[288 + s] = 5;
 		} else { const int status = fast_read_dynamic_header(bits, t, n_litlen, n_distance); if (status != INFLATE_OK) return status; }
-		{ const int status = fast_build_litlen(t.lengths, n_litlen, t); if (status != INFLATE_OK) return status; }
-		{ const int status = fast_build_distance(t.lengths + n_litlen, n_distance, t); if (status != INFLATE_OK) return status; }
+		{ const int status = fast_build_table(lengths, n_litlen, t.litlen, FAST_LITLEN_ROOT, FAST_LITLEN_ENTRIES, true, t); if (status != INFLATE_OK) return status; }
+		for (uint32_t s = 0; s < n_distance; ++s) t.code_lengths[s] = lengths[n_litlen + s]; // (out of the way of the table that is built where they stand)
+		{ const int status = fast_build_table(t.code_lengths, n_distance, t.distance, FAST_DISTANCE_ROOT, FAST_DISTANCE_ENTRIES, false, t); if (status != INFLATE_OK) return status; }
 		for (uint32_t turn = 0; ; ++turn) { // a token per turn: at most 15 + 5 + 15 + 13 = 48 bits
-			if ((turn & 7u) == 0) bits.top_up(); // (the lanes of a wavefront are in the same turn: they wait for HBM together, once in eight tokens)
+			if ((turn & 7u) == 0) { // (the lanes of a wavefront are in the same turn: they wait for HBM together, once in eight tokens)
+				if (bits.overrun()) return INFLATE_INPUT_OVERRUN; // (at most eight tokens are decoded from what lies behind the input; what they may write is checked token by token)
+				bits.top_up();
+			}
 			bits.refill();
-			if (bits.next > bits.size && bits.overrun()) return INFLATE_INPUT_OVERRUN;
-			uint32_t entry = t.litlen[bits.peek(FAST_LITLEN_ROOT)];
-			if ((entry >> 4 & 3u) == FAST_SUBTABLE) { bits.drop(FAST_LITLEN_ROOT); entry = t.litlen[(entry >> 6) + bits.peek(entry & 15u)]; }
+			const uint32_t entry = fast_symbol(bits, t.litlen, FAST_LITLEN_ROOT);
 			if (entry == 0) return INFLATE_BAD_SYMBOL;
-			bits.drop(entry & 15u);
 			const uint32_t payload = entry >> 6;
 			if ((entry >> 4 & 3u) == FAST_LITERAL) {
 				if (produced >= out_size) return INFLATE_OUTPUT_OVERRUN;
@@ -290,13 +270,12 @@ AGPU_HD int inflate_tokens(const uint8_t* input, uint32_t in_size, uint8_t* outp
 			  if (s < 8) length = 3 + s;
 			  else if (s == 28) length = 258;
 			  else { const uint32_t extra = (s >> 2) - 1; length = 3 + ((4 + (s & 3u)) << extra) + bits.take(extra); } }
-			int symbol;
-			{ const uint32_t found = t.distance[bits.peek(FAST_DISTANCE_ROOT)];
-			  if (found != 0) { bits.drop(found & 15u); symbol = (int) (found >> 4 & 63u); } else symbol = fast_long_distance_symbol(bits, t); }
-			if (symbol < 0 || symbol > 29) return INFLATE_BAD_DISTANCE;
+			const uint32_t found = fast_symbol(bits, t.distance, FAST_DISTANCE_ROOT);
+			const uint32_t symbol = found >> 6;
+			if (found == 0 || symbol > 29) return INFLATE_BAD_DISTANCE;
 			uint32_t distance;
-			if (symbol < 4) distance = (uint32_t) symbol + 1;
-			else { const uint32_t extra = ((uint32_t) symbol >> 1) - 1; distance = 1 + ((2 + ((uint32_t) symbol & 1u)) << extra) + bits.take(extra); }
+			if (symbol < 4) distance = symbol + 1;
+			else { const uint32_t extra = (symbol >> 1) - 1; distance = 1 + ((2 + (symbol & 1u)) << extra) + bits.take(extra); }
 			if (distance > produced) return INFLATE_BAD_DISTANCE;
 			if (produced + length > out_size) return INFLATE_OUTPUT_OVERRUN;
 			if (noted == capacity) return INFLATE_RETRY;

@@ -150,14 +150,20 @@ int main() {
 		}
 	}
 	// hand-made headers: the verdict on a set of code lengths must be zlib's (advisor, round 4: incomplete codes)
-	int handmade = 0, accepted = 0;
+	int handmade = 0, accepted = 0, handed_back = 0;
 	auto check_handmade = [&](const std::vector<int>& litlen, const std::vector<int>& distance, const std::vector<std::pair<int, int>>& tokens, const char* what) {
 		std::vector<uint8_t> stream = handmade_block(litlen, distance, tokens);
 		std::vector<uint8_t> reference;
 		const int theirs = zlib_inflate_raw(stream.data(), stream.size(), reference);
 		stream.resize(stream.size() + PAD, 0);
 		std::vector<uint8_t> out(reference.size() + 64, 0xCD);
-		const int ours = fast_inflate(stream, out, (uint32_t) reference.size(), true, rounds);
+		int ours = fast_inflate(stream, out, (uint32_t) reference.size(), true, rounds);
+		if (ours == INFLATE_RETRY) { // (second tables that a lane has no room for: the block goes to the other decoder, as on the device)
+			++handed_back;
+			auto sync = [] {}; auto broadcast = [](uint32_t v) { return v; };
+			std::fill(out.begin(), out.end(), 0xCD);
+			ours = inflate_block(stream.data(), (uint32_t) stream.size() - PAD, out.data(), (uint32_t) reference.size(), *shared, 0, 1, sync, broadcast);
+		}
 		++handmade;
 		const bool same = theirs == 0 ? (ours == INFLATE_OK && memcmp(out.data(), reference.data(), reference.size()) == 0) : ours != INFLATE_OK;
 		if (theirs == 0) ++accepted;
@@ -207,6 +213,6 @@ int main() {
 		}
 		check_handmade(litlen, distance, tokens, "random code");
 	}
-	printf("%d blocks checked, %d failures; two passes: %llu groups of 64 matches in %llu rounds, %llu blocks handed back; %d hand-made headers (%d of them valid for zlib)\n", checked, failures, groups, rounds, retries, handmade, accepted);
+	printf("%d blocks checked, %d failures; two passes: %llu groups of 64 matches in %llu rounds, %llu blocks handed back; %d hand-made headers (%d of them valid for zlib, %d handed to the other decoder)\n", checked, failures, groups, rounds, retries, handmade, accepted, handed_back);
 	return failures != 0;
 }
