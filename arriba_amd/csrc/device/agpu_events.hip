@@ -23,10 +23,12 @@ const int BLOCK = 256;
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
 #define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
 
-__global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView ann, GenomeView genome, CoverageView coverage, CandidateTable t, uint32_t min_anchor_length, unsigned int* remaining) {
+// (the candidates [first, end): all of them, or a window of them when the stage walks read lists and the discordant lists are implicit -- for_each_list_window)
+__global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView ann, GenomeView genome, CoverageView coverage, CandidateTable t, uint32_t min_anchor_length, unsigned int* remaining, uint32_t first = 0, uint32_t end = 0xFFFFFFFFu) {
 	__shared__ uint32_t block_sum;
 	uint32_t kept = 0;
-	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
+	if (end > t.n) end = t.n;
+	for (uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x; c < end; c += gridDim.x * BLOCK) {
 		if (t.filter[c] != FILTER_none) continue;
 		const uint8_t verdict = event_predicate(stage, b, ann, genome, coverage, t, c, min_anchor_length);
 		if (verdict == FILTER_none) ++kept; else if (verdict != EVENT_KEPT_UNCOUNTED) t.filter[c] = verdict;
@@ -202,16 +204,16 @@ __global__ void clip_summary_kernel(BatchView b, ClipSummary* summaries) {
 	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (k < 3 * b.n) summaries[k] = clip_summary_of(b, k / 3, (int) (k % 3));
 }
-__global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t) {
-	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c < t.n && is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
+__global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end) {
+	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
+	if (c < end && is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
 }
 
 // recover_both_spliced
 __global__ void both_spliced_reads_kernel(BatchView b, AnnotationView ann, CoverageView coverage, const uint32_t* gene_read_count, uint32_t threshold, CandidateTable t, int32_t max_exon_size, uint32_t max_coverage,
-                                          uint32_t* reads, uint64_t* keys) {
-	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c >= t.n) return;
+                                          uint32_t* reads, uint64_t* keys, uint32_t first, uint32_t end) {
+	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= end) return;
 	const uint32_t count = both_spliced_is_member(ann, t, c) ? both_spliced_supporting_reads(b, ann, coverage, gene_read_count, threshold, t, c, max_exon_size, max_coverage) : 0;
 	reads[c] = count;
 	keys[c] = count > 0 ? both_spliced_group_key(t, c, false) : ~0ull;
@@ -249,7 +251,7 @@ __global__ void itd_verdict_kernel(BatchView b, AnnotationView ann, CoverageView
 	verdict[c] = result == 1;
 	if (result == 1) // claim the reads this candidate would clear: the first recovered candidate in iteration order counts them
 		for (uint64_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k) {
-			const uint32_t read = t.read_lists[k];
+			const uint32_t read = split_list_entry(t, c, k);
 			if (itd_read_is_cleared(b.filter[read])) atomicMin(&owner[read], iteration_rank[c]);
 		}
 }
@@ -297,8 +299,17 @@ int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* ker
 	(void) hipEventRecord(ctx->event_start, s);
 	if (C > 0) {
 		const int effective_stage = ctx->params.filter_enabled[filter_id] ? stage : EVENT_count_only; // a stage switched off with -f only counts
-		KernelTimer timer(ctx, kernel_name, (uint64_t) C * 60 + (stage == EVENT_both_intronic ? (uint64_t) ctx->n_list_entries * 8 : 0));
-		event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, min_anchor_length, counter.as<unsigned int>());
+		if (effective_stage == EVENT_both_intronic) { // (walks the read lists)
+			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+				KernelTimer timer(ctx, kernel_name, (uint64_t) C * 60 + (uint64_t) ctx->n_list_entries * 8);
+				event_predicate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), begin, end);
+				return AGPU_OK;
+			});
+			if (status != AGPU_OK) return status;
+		} else {
+			KernelTimer timer(ctx, kernel_name, (uint64_t) C * 60);
+			event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, min_anchor_length, counter.as<unsigned int>());
+		}
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
@@ -776,8 +787,13 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 			tables.clip_summaries = summaries.as<ClipSummary>();
 		}
 		// (3) the verdicts
-		KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
-		in_vitro_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, t);
+		// (the verdict of a candidate looks at the tables made above -- complete -- and at its own discordant list; the filter it sets is read by no other candidate's verdict)
+		const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+			KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
+			in_vitro_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, begin, end);
+			return AGPU_OK;
+		});
+		if (status != AGPU_OK) return status;
 	}
 	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
@@ -811,8 +827,13 @@ extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_
 		uint32_t threshold = 0;
 		{ const int status = expression_proxy(ctx, high_expression_quantile, threshold); if (status != AGPU_OK) return status; }
 		HIP_CHECK(hipMemsetAsync(histogram.ptr, 0, (size_t) BOTH_SPLICED_HISTOGRAM_BINS * 4, s));
-		{ KernelTimer timer(ctx, "both_spliced_reads_kernel", (uint64_t) C * 70 + (uint64_t) ctx->n_list_entries * 6);
-		  both_spliced_reads_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, ctx->scratch("events.gene_read_count").as<uint32_t>(), threshold, t, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>()); }
+		{ const uint32_t* gene_read_count = ctx->scratch("events.gene_read_count").as<uint32_t>();
+		  const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+			KernelTimer timer(ctx, "both_spliced_reads_kernel", (uint64_t) C * 70 + (uint64_t) ctx->n_list_entries * 6);
+			both_spliced_reads_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), begin, end);
+			return AGPU_OK;
+		  });
+		  if (status != AGPU_OK) return status; }
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), rocprim::counting_iterator<uint32_t>(0), members.as<uint32_t>(), C, 0, 64, s));
 		if (bytes > scratch.capacity) ALLOC(scratch, bytes);

@@ -50,10 +50,12 @@ __global__ void merged_list_copy_kernel(CandidateTable t, ItdAppended appended, 
 	// one wavefront per candidate: the lists of a hot candidate hold hundreds of entries
 	const uint32_t c = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
 	if (c >= t.n) return;
-	for (uint32_t list = 0; list < 3; ++list) {
+	// (implicit discordant lists -- fusion_core.hpp: CandidateTable::discordant_before --: only the split-read lists exist, packed; they move, the discordant lists keep their
+	//  numbers of entries, so the entries in front of a candidate's stay what they were)
+	for (uint32_t list = 0; list < (t.discordant_before != nullptr ? 2u : 3u); ++list) {
 		const uint64_t own_begin = t.list_offset[3 * (uint64_t) c + list], own_length = t.list_offset[3 * (uint64_t) c + list + 1] - own_begin;
-		uint32_t* out = new_lists + new_offset[3 * (uint64_t) c + list];
-		for (uint64_t j = lane; j < own_length; j += 64) out[j] = t.read_lists[own_begin + j];
+		uint32_t* out = new_lists + new_offset[3 * (uint64_t) c + list] - (t.discordant_before != nullptr ? t.discordant_before[c] : 0);
+		for (uint64_t j = lane; j < own_length; j += 64) out[j] = list < 2 ? split_list_entry(t, c, own_begin + j) : t.read_lists[own_begin + j];
 		if (list < 2) {
 			const uint32_t* extra = appended.pool + appended.begin[2 * (uint64_t) c + list];
 			for (uint32_t j = lane; j < appended.length[2 * (uint64_t) c + list]; j += 64) out[own_length + j] = extra[j];
@@ -127,13 +129,16 @@ extern "C" int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, 
 			uint64_t total = 0;
 			HIP_CHECK(hipMemcpyAsync(&total, new_offset.as<uint64_t>() + 3 * (size_t) C, 8, hipMemcpyDeviceToHost, s));
 			HIP_CHECK(hipStreamSynchronize(s));
-			ALLOC(new_lists, std::max<size_t>(total, 1) * 4);
+			uint64_t discordant_entries = 0; // (implicit discordant lists: not stored)
+			if (ctx->lists_implicit) HIP_CHECK(hipMemcpy(&discordant_entries, t.discordant_before + C, 8, hipMemcpyDeviceToHost));
+			ALLOC(new_lists, std::max<size_t>(total - discordant_entries, 1) * 4);
 			{ KernelTimer timer(ctx, "merged_list_copy_kernel", (uint64_t) total * 8);
 			  merged_list_copy_kernel<<<grid_for((uint64_t) C * 64), BLOCK, 0, s>>>(t, appended, new_offset.as<uint64_t>(), new_lists.as<uint32_t>()); }
 			HIP_CHECK(hipStreamSynchronize(s));
 			ctx->cand_list_offset.swap(new_offset); ctx->cand_read_lists.swap(new_lists);
 			ctx->candidates.list_offset = ctx->cand_list_offset.as<uint64_t>(); ctx->candidates.read_lists = ctx->cand_read_lists.as<uint32_t>();
 			ctx->n_list_entries = total;
+			{ const int status = recut_list_windows(ctx); if (status != AGPU_OK) return status; } // (the positions of the lists have moved)
 			HIP_CHECK(hipMemsetAsync(ctx->cand_extra_split_list.ptr, 0, C1 * 4, s)); // the appended entries are part of the lists now
 		}
 	}

@@ -128,9 +128,10 @@ __global__ void splice_site_kernel(AnnotationView ann, GenomeView genome, uint32
 	if (!write) counts[gene] = found;
 }
 
-__global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags, unsigned long long* first_entry, bool by_candidate) {
-	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
-	if (c >= t.n || t.filter[c] != FILTER_none) return;
+// (the candidates [first, end): all of them, or a window when the discordant lists are implicit -- for_each_list_window)
+__global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* read_flags, unsigned long long* first_entry, bool by_candidate, uint32_t first, uint32_t end) {
+	uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= end || t.filter[c] != FILTER_none) return;
 	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	for (uint64_t k = offsets[0]; k < offsets[3]; ++k) {
 		uint32_t read = t.read_lists[k];
@@ -242,10 +243,10 @@ __global__ void mismapper_apply_kernel(BatchView b, const uint32_t* jobs, uint32
 	if (j < n_jobs && verdicts[j]) { b.filter[jobs[j]] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
 }
 
-__global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, bool count_only, unsigned int* remaining) {
+__global__ void mismapper_candidate_kernel(BatchView b, CandidateTable t, float max_mismapper_fraction, bool count_only, unsigned int* remaining, uint32_t first, uint32_t end) {
 	__shared__ uint32_t block_sum;
 	uint32_t kept = 0;
-	for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < t.n; c += gridDim.x * BLOCK) {
+	for (uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x; c < end; c += gridDim.x * BLOCK) {
 		if (t.filter[c] != FILTER_none) continue;
 		if (!count_only && count_candidate_mismappers(b, t, c, max_mismapper_fraction)) t.filter[c] = FILTER_mismappers; else ++kept;
 	}
@@ -401,7 +402,12 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 		//  order of the jobs, and a test that runs both orders says so)
 		const char* order_knob = getenv("ARRIBA_MISMAPPER_JOB_ORDER");
 		const bool job_order_by_candidate = order_knob != nullptr && strcmp(order_knob, "candidate") == 0;
-		{ KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5); mismapper_flag_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->batch, ctx->candidates, read_flags.as<uint8_t>(), first_entry.as<unsigned long long>(), job_order_by_candidate); }
+		{ const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+			KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5);
+			mismapper_flag_kernel<<<grid_for(end - begin), BLOCK, 0, s>>>(ctx->batch, window, read_flags.as<uint8_t>(), first_entry.as<unsigned long long>(), job_order_by_candidate, begin, end);
+			return AGPU_OK;
+		  });
+		  if (status != AGPU_OK) return status; }
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
 		if (bytes > scratch.capacity) ALLOC(scratch, bytes);
@@ -552,8 +558,13 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 			mismapper_apply_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(ctx->batch, jobs_sorted.as<uint32_t>(), n_jobs, verdict_bytes.as<uint8_t>(), device_counters);
 		}
 		if (C > 0 && (!enabled || n > 0)) {
-			KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
-			mismapper_candidate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, ctx->candidates, ctx->params.max_mismapper_fraction, !enabled, device_counters + 2);
+			const bool count_only = !enabled;
+			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+				KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
+				mismapper_candidate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, window, ctx->params.max_mismapper_fraction, count_only, device_counters + 2, begin, end);
+				return AGPU_OK;
+			});
+			if (status != AGPU_OK) return status;
 		}
 		ctx->mismapper_jobs_ready = false;
 	}

@@ -72,10 +72,11 @@ __global__ void bitmap_popcount_kernel(const uint32_t* words, uint64_t n_words, 
 
 // best[target(read)] = min rank over the candidates that list the multi-mapping read; target = the read itself, or its ordinal among the
 // multi-mapping reads of the sample when word_prefix != NULL
-__global__ void __launch_bounds__(BLOCK) list_best_rank_kernel(uint32_t n_listed, const uint64_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index, const uint32_t* rank,
+// (first: the kernel looks at the candidates [first, n_listed) -- a window of them when the discordant lists are implicit, for_each_list_window)
+__global__ void __launch_bounds__(BLOCK) list_best_rank_kernel(uint32_t first, uint32_t n_listed, const uint64_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index, const uint32_t* rank,
                                                                  const uint32_t* multimapper_bits, const uint32_t* word_prefix, uint32_t* best) {
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t c0 = (blockIdx.x * BLOCK + threadIdx.x) & ~63u;
+	const uint32_t c0 = first + ((blockIdx.x * BLOCK + threadIdx.x) & ~63u);
 	if (c0 >= n_listed) return;
 	const uint32_t c = c0 + lane, last = min(c0 + 64, n_listed);
 	const uint64_t my_end = c < n_listed ? list_offset[3 * (uint64_t) c + 3] : ~0ull;
@@ -104,11 +105,11 @@ __global__ void __launch_bounds__(BLOCK) list_best_rank_kernel(uint32_t n_listed
 
 // reference :188-211: the counters of a candidate lose the reads that became multi-mappers.  finalize: candidates left without supporting reads get
 // the filter `multimappers`, the others are counted (single context); otherwise only the counters are lowered (owner in the sharded form).
-__global__ void __launch_bounds__(BLOCK) list_recount_kernel(CandidateTable t, uint32_t n_listed, const uint64_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index,
+__global__ void __launch_bounds__(BLOCK) list_recount_kernel(CandidateTable t, uint32_t first, uint32_t n_listed, const uint64_t* list_offset, const uint32_t* read_lists, const uint32_t* global_index,
                                                                const uint32_t* discarded_bits, bool finalize, unsigned int* remaining) {
 	__shared__ uint32_t block_sum;
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t c0 = (blockIdx.x * BLOCK + threadIdx.x) & ~63u;
+	const uint32_t c0 = first + ((blockIdx.x * BLOCK + threadIdx.x) & ~63u);
 	uint32_t kept = 0;
 	if (c0 < n_listed) {
 		const uint32_t c = c0 + lane, last = min(c0 + 64, n_listed);
@@ -285,14 +286,22 @@ extern "C" int agpu_filter_multimappers(agpu_ctx* ctx, uint64_t* remaining, uint
 		if (C > 0) {
 			{ const int status = compute_support_rank(ctx, rank.as<uint32_t>()); if (status != AGPU_OK) return status; }
 			{ const int status = build_read_bitmap(ctx, bits, BITS_MULTIMAPPER, nullptr, n); if (status != AGPU_OK) return status; }
-			KernelTimer timer(ctx, "list_best_rank_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 8);
-			list_best_rank_kernel<<<grid_for(C), BLOCK, 0, s>>>(C, t.list_offset, t.read_lists, nullptr, rank.as<uint32_t>(), bits.as<uint32_t>(), nullptr, best_rank.as<uint32_t>());
+			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+				KernelTimer timer(ctx, "list_best_rank_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 8);
+				list_best_rank_kernel<<<grid_for(end - begin), BLOCK, 0, s>>>(begin, end, window.list_offset, window.read_lists, nullptr, rank.as<uint32_t>(), bits.as<uint32_t>(), nullptr, best_rank.as<uint32_t>());
+				return AGPU_OK;
+			});
+			if (status != AGPU_OK) return status;
 		}
 		{ const int status = resolve_groups(ctx, best_rank.as<uint32_t>(), counters.as<unsigned int>()); if (status != AGPU_OK) return status; }
 		if (C > 0) {
 			{ const int status = build_read_bitmap(ctx, bits, BITS_DISCARDED, nullptr, n); if (status != AGPU_OK) return status; }
-			KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 26);
-			list_recount_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, C, t.list_offset, t.read_lists, nullptr, bits.as<uint32_t>(), true, counters.as<unsigned int>() + 1);
+			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+				KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 26);
+				list_recount_kernel<<<grid_for(end - begin), BLOCK, 0, s>>>(window, begin, end, window.list_offset, window.read_lists, nullptr, bits.as<uint32_t>(), true, counters.as<unsigned int>() + 1);
+				return AGPU_OK;
+			});
+			if (status != AGPU_OK) return status;
 		}
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
@@ -372,7 +381,7 @@ extern "C" int agpu_multimappers_partial_best(agpu_ctx* ctx, int32_t* best) {
 	HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t) partial.ptr, (int) NO_FUSION, M, s));
 	if (ctx->n_owned > 0 && ctx->params.filter_enabled[FILTER_multimappers]) {
 		KernelTimer timer(ctx, "list_best_rank_kernel", (uint64_t) ctx->n_owned_list_entries * 4 + (uint64_t) ctx->n_owned * 12);
-		list_best_rank_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(ctx->n_owned, ctx->owned_list_offset.as<uint64_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
+		list_best_rank_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(0, ctx->n_owned, ctx->owned_list_offset.as<uint64_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
 			ctx->scratch("multimappers.rank").as<uint32_t>(), ctx->scratch("multimappers.bits").as<uint32_t>(), ctx->scratch("multimappers.word_prefix").as<uint32_t>(), partial.as<uint32_t>());
 	}
 	HIP_CHECK(hipMemcpyAsync(best, partial.ptr, M * 4, hipMemcpyDefault, s));
@@ -425,7 +434,7 @@ extern "C" int agpu_multimappers_recount(agpu_ctx* ctx, const uint8_t* global_di
 		had_support_kernel<<<grid_for(C), BLOCK, 0, s>>>(t, had_support.as<uint8_t>());
 		if (ctx->n_owned > 0 && ctx->params.filter_enabled[FILTER_multimappers]) {
 			KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_owned_list_entries * 4 + (uint64_t) ctx->n_owned * 30);
-			list_recount_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(t, ctx->n_owned, ctx->owned_list_offset.as<uint64_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
+			list_recount_kernel<<<grid_for(ctx->n_owned), BLOCK, 0, s>>>(t, 0, ctx->n_owned, ctx->owned_list_offset.as<uint64_t>(), ctx->owned_read_lists.as<uint32_t>(), ctx->owned_global_index.as<uint32_t>(),
 				bits.as<uint32_t>(), false, nullptr);
 		}
 		HIP_CHECK(hipMemcpyAsync(counters, t.split_reads1, (size_t) C * 4, hipMemcpyDefault, s));

@@ -471,7 +471,7 @@ AGPU_HD int itd_verdict(const BatchView& b, const AnnotationView& ann, const Cov
 	const int32_t coverage1 = coverage_near(coverage, t.contigs[c] >> 16, breakpoint1, false), coverage2 = coverage_near(coverage, t.contigs[c] & 0xFFFF, breakpoint2, true); // directions: upstream / downstream
 	uint32_t split_reads = 0;
 	for (uint64_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 2]; ++k)
-		if (itd_read_counts(b.filter[t.read_lists[k]])) split_reads++;
+		if (itd_read_counts(b.filter[split_list_entry(t, c, k)])) split_reads++;
 	return split_reads >= min_supporting_reads &&
 	       (1.0 * split_reads / (coverage1 > coverage2 ? coverage1 : coverage2) / (1 - duplication_rate) > min_fraction_of_coverage || split_reads >= subsampling_threshold);
 }
@@ -482,7 +482,7 @@ AGPU_HD void itd_count_cleared_reads(const BatchView& b, const CandidateTable& t
 	for (uint32_t list = 0; list < 2; ++list) {
 		uint32_t cleared = 0;
 		for (uint64_t k = t.list_offset[3 * (uint64_t) c + list]; k < t.list_offset[3 * (uint64_t) c + list + 1]; ++k) {
-			const uint32_t read = t.read_lists[k];
+			const uint32_t read = split_list_entry(t, c, k);
 			if (itd_read_is_cleared(b.filter[read]) && owner[read] == my_rank) { owner[read] = ITD_READ_COUNTED; ++cleared; }
 		}
 		uint32_t* counter = list == 0 ? t.split_reads1 + c : t.split_reads2 + c;

@@ -73,7 +73,7 @@ AGPU_HD void itd_append_lists(const CandidateTable& t, const ItdAppended& append
 		uint32_t* out = appended.pool + at;
 		const uint32_t* old = appended.pool + appended.begin[2 * (uint64_t) fusion + list];
 		for (uint32_t j = 0; j < old_length; ++j) out[j] = old[j];
-		for (uint32_t j = 0; j < own_length; ++j) out[old_length + j] = t.read_lists[own_begin + j];
+		for (uint32_t j = 0; j < own_length; ++j) out[old_length + j] = split_list_entry(t, other, own_begin + j);
 		const uint32_t* theirs = appended.pool + appended.begin[2 * (uint64_t) other + list];
 		for (uint32_t j = 0; j < other_length; ++j) out[old_length + own_length + j] = theirs[j];
 		appended.begin[2 * (uint64_t) fusion + list] = at; appended.length[2 * (uint64_t) fusion + list] = new_length;

@@ -504,6 +504,62 @@ def test_workflow_from_input_files_to_output_files(built, dataset_files, tmp_pat
     assert stages[-1][1] > 300 and dict(stages)["mark_genomic_support"] > 10000
 
 
+def _with_implicit_lists(window_entries):
+    """context manager: the discordant-mate lists of the candidates implicit (fusion_core.hpp: CandidateTable::discordant_before), expanded in windows of so many entries"""
+    import contextlib
+    @contextlib.contextmanager
+    def manager():
+        os.environ["ARRIBA_IMPLICIT_LISTS"] = "1"
+        os.environ["ARRIBA_LIST_WINDOW_ENTRIES"] = str(window_entries)
+        try:
+            yield
+        finally:
+            del os.environ["ARRIBA_IMPLICIT_LISTS"], os.environ["ARRIBA_LIST_WINDOW_ENTRIES"]
+    return manager()
+
+
+def test_implicit_discordant_lists_give_the_files_of_the_reference(built, dataset_files, tmp_path):
+    """review of round 4, item 1: a candidate's discordant mates as (bucket range, predicate, cut-off at -U) instead of a list -- what BASELINE.json's config 3 needs at its stated
+    size (10^8 fragments with -U 32767 would list 92.7 G reads).  The lists are made implicit by force on the golden datasets and expanded in windows so small (1 024 entries) that a
+    toy sample has dozens of them: every stage that walks read lists -- filter_multimappers, filter_both_intronic, filter_in_vitro, recover_both_spliced, the jobs and the recount
+    of filter_mismappers, recover_internal_tandem_duplication and merge_adjacent_fusions on a sample with ITD hot spots (split-read lists appended, the lists rebuilt), the lists the
+    writer fetches -- must give the reference's counts and both output files byte for byte; and the three lists of every candidate, fetched window by window, must be the
+    reference's (parity.check_read_lists)."""
+    with _with_implicit_lists(1024):
+        for name in ("toy3k", "rules8k", "homologs8k", "wgs8k", "itd6k"):
+            os.makedirs(str(tmp_path / name))
+            stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), str(tmp_path / name), rules=name in ("rules8k", "wgs8k"), structural_variants=name == "wgs8k")
+            assert stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
+        for name in ("toy3k", "itd6k"):
+            session, pipeline = parity.run_read_level(parity.open_session, dataset_files(name))
+            pipeline.find_fusions()
+            assert pipeline.fusion_stats()["list_entries"] > 1024
+            parity.check_candidates(session, pipeline, conftest.golden_dir(name))
+            pipeline.merge_adjacent_fusions()
+            parity.check_read_lists(session, pipeline, conftest.golden_dir(name), "merge_adjacent_fusions")
+            pipeline.close(); session.close()
+    if not datasets.reference_available():
+        return
+    spec = {"args": ["--seed", "59", "--fragments", "150000", "--normal-mult", "0.3", "--contigs", "8", "--contig-len", "600000", "--junctions", "1500", "--dup", "0.15", "--rule-files", "--homolog-families", "20",
+                     "--itd-hotspots", "3", "--itd-hotspot-frac", "0.02"], "rule_files": True, "structural_variants": True}
+    prefix = datasets.generate(spec, str(tmp_path))
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    switches = {"ARRIBA_ORACLE_DUMP_LISTS": "0", "ARRIBA_ORACLE_DUMP_READS": "0", "ARRIBA_ORACLE_DUMP_STAGES": "key"}
+    os.environ.update(switches)
+    try:
+        log = datasets.run_reference(prefix, dump, spec)
+    finally:
+        for key in switches:
+            del os.environ[key]
+    with open(os.path.join(dump, "reference.log"), "w") as out:
+        out.write(log)
+    os.makedirs(str(tmp_path / "mine"))
+    with _with_implicit_lists(20000):
+        stages = parity.check_workflow(prefix, dump, str(tmp_path / "mine"), rules=True, reference_prefix=prefix, structural_variants=True, device_ingest=True)
+    assert stages[-1][1] > 300
+
+
 def test_workflow_with_non_default_options_against_the_live_reference(built, tmp_path):
     """the whole workflow on the GPU with 19 options away from their defaults, two filters off and every optional input file given, against the reference run live"""
     if not datasets.reference_available():
@@ -732,8 +788,10 @@ def test_bench_sample_of_config_2_against_the_reference(name, fragments, built, 
     session.close()
 
 
-def test_mismapper_stress_at_scale_against_the_live_reference(built, tmp_path):
-    """BASELINE.json config 3 at 0.3 M fragments: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (no read is subsampled away before
+@pytest.mark.parametrize("lists", ["explicit", "implicit"])
+def test_mismapper_stress_at_scale_against_the_live_reference(lists, built, tmp_path):
+    """(lists: the read lists in memory, or the discordant ones implicit and expanded in windows of 50 M entries -- the way a sample of the stated size of config 3 must go)
+    BASELINE.json config 3 at 0.3 M fragments: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (no read is subsampled away before
     filter_mismappers): log counts and both output files against the unmodified reference run here (the reference needs 5 1/2 minutes for 1 M fragments of this workload, and
     24 for the 3 M of the test below, which was run once where the repository is built)"""
     import subprocess
@@ -745,8 +803,36 @@ def test_mismapper_stress_at_scale_against_the_live_reference(built, tmp_path):
     subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32"] + bench.workload_args(fragments, 1000, stress=True), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     _run_plain_reference(prefix, str(tmp_path / "reference"), extra=["-U", "32767"])
     os.makedirs(str(tmp_path / "mine"))
-    stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True, params={"subsampling_threshold": 32767})
+    import contextlib
+    with (_with_implicit_lists(50000000) if lists == "implicit" else contextlib.nullcontext()):
+        stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True, params={"subsampling_threshold": 32767})
     assert dict(stages)["filter_mismappers"] > 300
+
+
+def test_implicit_lists_equal_materialised_lists_at_10m_stress(built, tmp_path):
+    """review of round 4, item 1 ("a new GPU test asserts implicit == materialised lists (candidate counters, fusions.tsv) at 10 M stress"): BASELINE.json config 3 at 10 M
+    fragments with -U 32767 -- ~9 G list entries, 36 GB: the largest size at which both ways run -- through one resident session, once with the lists in memory and once with the
+    discordant lists implicit (windows of what the device has room for): every count of the log and the bytes of fusions.tsv must be the same."""
+    import hashlib
+    import subprocess
+    import bench
+    from arriba_amd.pipeline import WorkflowSession
+    fragments = int(os.environ.get("ARRIBA_IMPLICIT_TEST_FRAGMENTS", "10000000"))
+    prefix = str(tmp_path / "stress")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(bench.cpu_budget())] + bench.workload_args(fragments, 1000, stress=True), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sha256 = lambda path: hashlib.sha256(open(path, "rb").read()).hexdigest()
+    session = WorkflowSession(prefix + ".fa", prefix + ".gtf", params={"subsampling_threshold": 32767})
+    explicit = list(session.sample(prefix + ".bam", str(tmp_path / "explicit.tsv")))
+    os.environ["ARRIBA_IMPLICIT_LISTS"] = "1"
+    try:
+        implicit = list(session.sample(prefix + ".bam", str(tmp_path / "implicit.tsv")))
+    finally:
+        del os.environ["ARRIBA_IMPLICIT_LISTS"]
+    session.close()
+    assert dict(explicit)["recover_isoforms"] > 1000
+    different = [(a, b) for a, b in zip(explicit, implicit) if a != b]
+    assert len(explicit) == len(implicit) and not different, different
+    assert sha256(str(tmp_path / "explicit.tsv")) == sha256(str(tmp_path / "implicit.tsv"))
 
 
 def test_mismapper_stress_of_config_3_against_the_reference(built, tmp_path):
