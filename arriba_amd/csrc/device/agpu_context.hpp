@@ -257,7 +257,10 @@ struct KernelTimer {
 	}
 };
 // the stages that walk the read lists of the candidates (agpu_fusions.hip: implicit discordant lists)
-int for_each_list_window(agpu_ctx* ctx, const std::function<int(const CandidateTable&, uint32_t, uint32_t)>& stage);
+// whose lists a stage reads: an expansion of implicit lists skips the candidates the stage does not look at (their part of the window holds nothing, or zeros with zero_fill --
+// for a stage that strides over the entries of a window without asking whose they are)
+enum { LISTS_OF_ALL = 0, LISTS_OF_UNFILTERED = 1, LISTS_OF_IN_VITRO = 2 /* in_vitro_looks_at */, LISTS_OF_BOTH_SPLICED = 3 /* both_spliced_is_member */ };
+int for_each_list_window(agpu_ctx* ctx, const std::function<int(const CandidateTable&, uint32_t, uint32_t)>& stage, int lists_of = LISTS_OF_ALL, bool zero_fill = false);
 int recut_list_windows(agpu_ctx* ctx);
 // resolve the pending samples whose events have completed (the caller has synchronised the streams it launched on; what another thread launched meanwhile stays pending)
 inline void collect_kernel_samples(agpu_ctx* ctx) {

@@ -173,11 +173,18 @@ struct BucketRef { uint32_t candidate, begin, end; };
 // split reads when find_fusions looked (merge_adjacent_fusions appends split reads later; the predicate of the list must not change with them).  Kept for explicit lists too.
 struct BucketRanges { uint32_t* begin; uint32_t* end; uint8_t* had_split_reads; };
 
+// does the stage an expansion is made for read the lists of candidate c? (for_each_list_window)
+__device__ __forceinline__ bool lists_wanted(const AnnotationView& ann, const CandidateTable& t, uint32_t c, int lists_of) {
+	if (lists_of == LISTS_OF_UNFILTERED) return t.filter[c] == FILTER_none;
+	if (lists_of == LISTS_OF_IN_VITRO) return in_vitro_looks_at(t, c);
+	if (lists_of == LISTS_OF_BOTH_SPLICED) return both_spliced_is_member(ann, t, c);
+	return true;
+}
 // one thread per candidate of [c_begin, c_end): small buckets are handled inline, large ones are queued for the wave kernel.
 // mode: ATTACH_COUNT the list sizes (and the bucket ranges noted), ATTACH_FILL / ATTACH_FOLD the pass behind it (lists written / not written; anchors, votes, counters),
 // ATTACH_EXPAND the lists of a window of candidates written again (t = the table of the window)
 __global__ void __launch_bounds__(BLOCK) attach_discordant_kernel(AnnotationView ann, CandidateTable t, uint32_t c_begin, uint32_t c_end, const uint64_t* bucket_keys, DiscordantBuckets buckets, uint32_t Md, BucketRanges ranges,
-                                         int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, BucketRef* worklist, uint32_t* worklist_size, int mode) {
+                                         int32_t max_mate_gap, uint32_t threshold, uint32_t* list_size, uint8_t* discordant_swapped, BucketRef* worklist, uint32_t* worklist_size, int mode, int lists_of) {
 	__shared__ uint32_t wave_offset[BLOCK / 64];
 	__shared__ uint32_t block_base;
 	const uint32_t c = c_begin + blockIdx.x * BLOCK + threadIdx.x;
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(BLOCK) attach_discordant_kernel(AnnotationView
 			}
 			has_split_reads = list_size[3 * (uint64_t) c] + list_size[3 * (uint64_t) c + 1] > 0;
 			ranges.begin[c] = begin; ranges.end[c] = end; ranges.had_split_reads[c] = has_split_reads;
-		} else if (mode != ATTACH_EXPAND || t.list_offset[3 * (uint64_t) c + 3] > t.list_offset[3 * (uint64_t) c + 2]) { // (a list that was empty stays empty)
+		} else if (mode != ATTACH_EXPAND || (t.list_offset[3 * (uint64_t) c + 3] > t.list_offset[3 * (uint64_t) c + 2] && lists_wanted(ann, t, c, lists_of))) { // (a list that was empty stays empty)
 			begin = ranges.begin[c]; end = ranges.end[c]; has_split_reads = ranges.had_split_reads[c];
 		}
 	}
@@ -232,44 +239,54 @@ __device__ __forceinline__ int32_t anchor_merge(int32_t a, int32_t b, bool upstr
 template <int MODE, bool WRITE_LIST = true> __device__ __forceinline__ void scan_bucket(const AnnotationView& ann, const DiscordantBuckets& buckets, const BucketRef& ref, uint32_t gene1, uint32_t gene2,
 		int32_t breakpoint1, int32_t breakpoint2, bool upstream1, bool upstream2, bool has_split_reads, int32_t max_mate_gap, uint32_t threshold, uint32_t lane,
 		uint32_t* out_list, uint8_t* discordant_swapped, uint32_t& unfiltered, uint32_t& appended, int32_t& lane_anchor1, int32_t& lane_anchor2, uint32_t& lane_votes, bool& zero_seen, AnchorFold& fold1, AnchorFold& fold2) {
+	// SCAN_UNROLL x 64 rows of the bucket in flight: a wavefront alone with its bucket waits for three dependent loads per 64 rows (the breakpoints of the mates, the info word of
+	// those that pass, the read of those that join) -- with -U 32767 a candidate of a hot gene pair walks tens of thousands of rows (10^8 fragments of config 3: 92.7 G rows per
+	// pass over the candidates, profiles/r05f).  The loads of four chunks are issued together; what depends on the order of the mates (the positions among those that pass, the
+	// cut-off at the threshold) is then settled chunk by chunk, as before.
+	const int SCAN_UNROLL = 4;
 	const unsigned long long lanes_before = (1ull << lane) - 1;
+	DiscordantMatePredicate predicate;
+	predicate.set(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap);
 	uint32_t passing = 0;
 	unfiltered = 0; appended = 0;
-	for (uint32_t base = ref.begin; base < ref.end; base += 64) {
-		const uint32_t k = base + lane;
-		bool pass = false, is_unfiltered = false;
-		uint32_t info = 0;
-		if (k < ref.end) {
-			pass = discordant_mate_supports(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap, buckets.breakpoint1[k], buckets.breakpoint2[k]);
-			if (pass) { info = buckets.info[k]; is_unfiltered = (info >> EINFO_FILTER_SHIFT & 255) == FILTER_none; }
+	for (uint32_t base = ref.begin; base < ref.end; base += 64 * SCAN_UNROLL) {
+		int32_t mate1[SCAN_UNROLL], mate2[SCAN_UNROLL]; uint32_t info[SCAN_UNROLL], read[SCAN_UNROLL]; bool pass[SCAN_UNROLL];
+		AGPU_UNROLL for (int u = 0; u < SCAN_UNROLL; ++u) { const uint32_t k = base + 64 * u + lane; const bool inside = k < ref.end; mate1[u] = inside ? buckets.breakpoint1[k] : 0; mate2[u] = inside ? buckets.breakpoint2[k] : 0; pass[u] = inside; }
+		AGPU_UNROLL for (int u = 0; u < SCAN_UNROLL; ++u) pass[u] = pass[u] && predicate.supports(mate1[u], mate2[u]);
+		AGPU_UNROLL for (int u = 0; u < SCAN_UNROLL; ++u) { const uint32_t k = base + 64 * u + lane; info[u] = pass[u] ? buckets.info[k] : 0; read[u] = (MODE == 1 || MODE == 3) && pass[u] ? buckets.read[k] : 0; }
+		bool done = false;
+		AGPU_UNROLL for (int u = 0; u < SCAN_UNROLL; ++u) {
+			if (done || base + 64 * u >= ref.end) break; // (the same for every lane)
+			const uint32_t k = base + 64 * u + lane;
+			const bool is_unfiltered = pass[u] && (info[u] >> EINFO_FILTER_SHIFT & 255) == FILTER_none;
+			const unsigned long long ballot_pass = __ballot(pass[u]), ballot_unfiltered = __ballot(is_unfiltered);
+			const uint32_t position = passing + __popcll(ballot_pass & lanes_before);
+			const uint32_t unfiltered_before = unfiltered + __popcll(ballot_unfiltered & lanes_before);
+			const bool joins = pass[u] && (position < threshold || (is_unfiltered && unfiltered_before < threshold));
+			const unsigned long long ballot_joins = __ballot(joins);
+			if (MODE == 3 && joins) out_list[appended + __popcll(ballot_joins & lanes_before)] = read[u]; // (an implicit list written again: the entries, nothing else)
+			if (MODE == 1 && joins) {
+				if (WRITE_LIST) out_list[appended + __popcll(ballot_joins & lanes_before)] = read[u];
+				if ((info[u] & EINFO_MATES_SWAPPED) && !discordant_swapped[read[u]]) discordant_swapped[read[u]] = 1;
+				const int32_t anchor1 = buckets.anchor1[k], anchor2 = buckets.anchor2[k];
+				if ((!upstream1 && anchor1 == 0) || (!upstream2 && anchor2 == 0)) zero_seen = true;
+				lane_anchor1 = anchor_merge(lane_anchor1, anchor1, upstream1);
+				lane_anchor2 = anchor_merge(lane_anchor2, anchor2, upstream2);
+				const int vote = discordant_mate_vote(info[u], upstream1, upstream2, breakpoint1, breakpoint2, mate1[u], mate2[u]);
+				lane_votes += (vote == 1) ? 1u : (vote == 2) ? 0x10000u : 0u; // forward in the low half, reverse in the high half (<= 64 K entries per lane)
+			}
+			if (MODE == 2 && ballot_joins != 0) {
+				AnchorFold chunk1 = wave_fold_in_lane_order(joins ? anchor_single(buckets.anchor1[k], upstream1) : anchor_identity(), upstream1);
+				AnchorFold chunk2 = wave_fold_in_lane_order(joins ? anchor_single(buckets.anchor2[k], upstream2) : anchor_identity(), upstream2);
+				fold1 = anchor_combine(fold1, chunk1, upstream1);
+				fold2 = anchor_combine(fold2, chunk2, upstream2);
+			}
+			passing += __popcll(ballot_pass);
+			unfiltered += __popcll(ballot_unfiltered);
+			appended += __popcll(ballot_joins);
+			if (unfiltered >= threshold) done = true; // the reference stops at the next unfiltered mate; filtered ones no longer fit either
 		}
-		const unsigned long long ballot_pass = __ballot(pass), ballot_unfiltered = __ballot(is_unfiltered);
-		const uint32_t position = passing + __popcll(ballot_pass & lanes_before);
-		const uint32_t unfiltered_before = unfiltered + __popcll(ballot_unfiltered & lanes_before);
-		const bool joins = pass && (position < threshold || (is_unfiltered && unfiltered_before < threshold));
-		const unsigned long long ballot_joins = __ballot(joins);
-		if (MODE == 3 && joins) out_list[appended + __popcll(ballot_joins & lanes_before)] = buckets.read[k]; // (an implicit list written again: the entries, nothing else)
-		if (MODE == 1 && joins) {
-			const uint32_t read = buckets.read[k];
-			if (WRITE_LIST) out_list[appended + __popcll(ballot_joins & lanes_before)] = read;
-			if ((info & EINFO_MATES_SWAPPED) && !discordant_swapped[read]) discordant_swapped[read] = 1;
-			const int32_t anchor1 = buckets.anchor1[k], anchor2 = buckets.anchor2[k];
-			if ((!upstream1 && anchor1 == 0) || (!upstream2 && anchor2 == 0)) zero_seen = true;
-			lane_anchor1 = anchor_merge(lane_anchor1, anchor1, upstream1);
-			lane_anchor2 = anchor_merge(lane_anchor2, anchor2, upstream2);
-			const int vote = discordant_mate_vote(info, upstream1, upstream2, breakpoint1, breakpoint2, buckets.breakpoint1[k], buckets.breakpoint2[k]);
-			lane_votes += (vote == 1) ? 1u : (vote == 2) ? 0x10000u : 0u; // forward in the low half, reverse in the high half (<= 64 K entries per lane)
-		}
-		if (MODE == 2 && ballot_joins != 0) {
-			AnchorFold chunk1 = wave_fold_in_lane_order(joins ? anchor_single(buckets.anchor1[k], upstream1) : anchor_identity(), upstream1);
-			AnchorFold chunk2 = wave_fold_in_lane_order(joins ? anchor_single(buckets.anchor2[k], upstream2) : anchor_identity(), upstream2);
-			fold1 = anchor_combine(fold1, chunk1, upstream1);
-			fold2 = anchor_combine(fold2, chunk2, upstream2);
-		}
-		passing += __popcll(ballot_pass);
-		unfiltered += __popcll(ballot_unfiltered);
-		appended += __popcll(ballot_joins);
-		if (unfiltered >= threshold) break; // the reference stops at the next unfiltered mate; filtered ones no longer fit either
+		if (done) break;
 	}
 }
 
@@ -322,9 +339,9 @@ __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable
 }
 
 // the split-read lists of the candidates of a window into the buffer of the window (one wavefront per candidate)
-__global__ void window_split_copy_kernel(CandidateTable sample, CandidateTable window, uint32_t c_begin, uint32_t c_end) {
+__global__ void window_split_copy_kernel(AnnotationView ann, CandidateTable sample, CandidateTable window, uint32_t c_begin, uint32_t c_end, int lists_of) {
 	const uint32_t c = c_begin + ((blockIdx.x * BLOCK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-	if (c >= c_end) return;
+	if (c >= c_end || !lists_wanted(ann, sample, c, lists_of)) return;
 	const uint64_t begin = sample.list_offset[3 * (uint64_t) c], end = sample.list_offset[3 * (uint64_t) c + 2];
 	for (uint64_t k = begin + lane; k < end; k += 64) window.read_lists[k] = split_list_entry(sample, c, k);
 }
@@ -407,7 +424,7 @@ int cut_list_windows(agpu_ctx* ctx) {
 }
 // all three lists of the candidates [c_begin, c_end) at their positions in a buffer: `window` = the table of the sample with read_lists pointing at that buffer (rebased) and no
 // discordant_before -- the kernels of the stages walk it as they walk explicit lists
-int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, CandidateTable& window) {
+int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, CandidateTable& window, int lists_of, bool zero_fill) {
 	hipStream_t s = ctx->stream;
 	const CandidateTable& t = ctx->candidates;
 	uint64_t bounds[2] = { 0, 0 };
@@ -420,6 +437,7 @@ int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, Candidat
 	window = t;
 	window.read_lists = buffer.as<uint32_t>() - bounds[0]; window.discordant_before = nullptr;
 	if (c_end == c_begin || entries == 0) return AGPU_OK;
+	if (zero_fill) HIP_CHECK(hipMemsetAsync(buffer.ptr, 0, (size_t) entries * 4, s));
 	DeviceBuffer& bucket_worklist = ctx->scratch("fusions.bucket_worklist"); DeviceBuffer& worklist_sizes = ctx->scratch("fusions.worklist_sizes");
 	DiscordantBuckets buckets; BucketRanges ranges;
 	{ const size_t Md1 = std::max<uint32_t>(ctx->lists_n_bucket_rows, 1);
@@ -430,9 +448,9 @@ int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, Candidat
 	HIP_CHECK(hipMemsetAsync(worklist_count, 0, 4, s));
 	const uint32_t n = c_end - c_begin, threshold = ctx->params.subsampling_threshold;
 	{ KernelTimer timer(ctx, "window_split_copy_kernel", (uint64_t) n * 16);
-	  window_split_copy_kernel<<<grid_for((uint64_t) n * 64), BLOCK, 0, s>>>(t, window, c_begin, c_end); }
+	  window_split_copy_kernel<<<grid_for((uint64_t) n * 64), BLOCK, 0, s>>>(ctx->annotation, t, window, c_begin, c_end, lists_of); }
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(window)", (uint64_t) n * 25);
-	  attach_discordant_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->annotation, window, c_begin, c_end, nullptr, buckets, ctx->lists_n_bucket_rows, ranges, ctx->lists_max_mate_gap, threshold, nullptr, nullptr, bucket_worklist.as<BucketRef>(), worklist_count, ATTACH_EXPAND); }
+	  attach_discordant_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->annotation, window, c_begin, c_end, nullptr, buckets, ctx->lists_n_bucket_rows, ranges, ctx->lists_max_mate_gap, threshold, nullptr, nullptr, bucket_worklist.as<BucketRef>(), worklist_count, ATTACH_EXPAND, lists_of); }
 	uint32_t queued = 0;
 	HIP_CHECK(hipMemcpyAsync(&queued, worklist_count, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -447,11 +465,11 @@ int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, Candidat
 
 // Runs `stage` over all candidates, a window at a time: once over [0, n) with the table of the sample while the lists are explicit; with implicit discordant lists over every window
 // with the table of the window (the lists of its candidates expanded).  What `stage` launches must restrict itself to the candidates [begin, end).
-int agpu::for_each_list_window(agpu_ctx* ctx, const std::function<int(const CandidateTable&, uint32_t, uint32_t)>& stage) {
+int agpu::for_each_list_window(agpu_ctx* ctx, const std::function<int(const CandidateTable&, uint32_t, uint32_t)>& stage, int lists_of, bool zero_fill) {
 	if (!ctx->lists_implicit) return stage(ctx->candidates, 0u, ctx->n_candidates);
 	for (size_t w = 0; w + 1 < ctx->list_window_cuts.size(); ++w) {
 		CandidateTable window;
-		int status = expand_list_window(ctx, ctx->list_window_cuts[w], ctx->list_window_cuts[w + 1], window);
+		int status = expand_list_window(ctx, ctx->list_window_cuts[w], ctx->list_window_cuts[w + 1], window, lists_of, zero_fill);
 		if (status == AGPU_OK) status = stage(window, ctx->list_window_cuts[w], ctx->list_window_cuts[w + 1]);
 		if (status != AGPU_OK) return status;
 	}
@@ -600,7 +618,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	uint32_t* worklist_counts = worklist_sizes.as<uint32_t>(); // [0] attach (count pass), [1] attach (fill pass), [2] windows
 	BucketRanges ranges; ranges.begin = range_begin.as<uint32_t>(); ranges.end = range_end.as<uint32_t>(); ranges.had_split_reads = range_split.as<uint8_t>();
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(count)", (uint64_t) C * 25);
-	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, 0, C, bucket_keys.as<uint64_t>(), buckets, Md, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, ATTACH_COUNT); }
+	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, 0, C, bucket_keys.as<uint64_t>(), buckets, Md, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, ATTACH_COUNT, LISTS_OF_ALL); }
 	uint32_t queued = 0;
 	HIP_CHECK(hipMemcpyAsync(&queued, worklist_counts + 0, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -651,7 +669,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	  split_list_fill_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), candidate_of.as<uint32_t>(), ranks.as<RankState>(), folds.as<CandidateFold>(), threshold, t); }
 	const int fill_mode = ctx->lists_implicit ? ATTACH_FOLD : ATTACH_FILL;
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(fill)", (uint64_t) C * 25);
-	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, 0, C, bucket_keys.as<uint64_t>(), buckets, Md, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, fill_mode); }
+	  attach_discordant_kernel<<<grid_for(C), BLOCK, 0, s>>>(ctx->annotation, t, 0, C, bucket_keys.as<uint64_t>(), buckets, Md, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, fill_mode, LISTS_OF_ALL); }
 	if (queued > 0) { // the fill pass queues the same candidates (possibly in another order)
 		// algorithmic bytes: every bucket row (two breakpoints, info, read, two anchors: 24 B) read once, every list entry written once (4 B; total_list
 		// also counts the few split-read entries), the queued candidates' columns.  What the kernel really moves is several times more (PMC): the

@@ -406,7 +406,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 			KernelTimer timer(ctx, "mismapper_flag_kernel", (uint64_t) ctx->n_list_entries * 5);
 			mismapper_flag_kernel<<<grid_for(end - begin), BLOCK, 0, s>>>(ctx->batch, window, read_flags.as<uint8_t>(), first_entry.as<unsigned long long>(), job_order_by_candidate, begin, end);
 			return AGPU_OK;
-		  });
+		  }, LISTS_OF_UNFILTERED);
 		  if (status != AGPU_OK) return status; }
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), read_flags.as<uint8_t>(), jobs.as<uint32_t>(), device_counters, n, s));
@@ -563,7 +563,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
 				mismapper_candidate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, window, ctx->params.max_mismapper_fraction, count_only, device_counters + 2, begin, end);
 				return AGPU_OK;
-			});
+			}, LISTS_OF_UNFILTERED);
 			if (status != AGPU_OK) return status;
 		}
 		ctx->mismapper_jobs_ready = false;

@@ -300,7 +300,7 @@ extern "C" int agpu_filter_multimappers(agpu_ctx* ctx, uint64_t* remaining, uint
 				KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 26);
 				list_recount_kernel<<<grid_for(end - begin), BLOCK, 0, s>>>(window, begin, end, window.list_offset, window.read_lists, nullptr, bits.as<uint32_t>(), true, counters.as<unsigned int>() + 1);
 				return AGPU_OK;
-			});
+			}, LISTS_OF_UNFILTERED, true); // (the counters of a filtered candidate are not touched: its lists need not be expanded, but the kernel strides over every entry of the window)
 			if (status != AGPU_OK) return status;
 		}
 	}

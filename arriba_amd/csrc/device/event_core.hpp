@@ -299,13 +299,18 @@ AGPU_HD uint32_t higher_expressed_gene(const AnnotationView& ann, const InVitroT
 	}
 	return gene;
 }
+// the candidates filter_in_vitro judges: also filtered events are tagged if they are spliced, so that the filters 'spliced' and 'many_spliced' do not recover them (:112-115)
+AGPU_HD bool in_vitro_looks_at(const CandidateTable& t, uint32_t c) {
+	const uint32_t flags = t.flags[c];
+	const uint8_t filter = t.filter[c];
+	return filter == FILTER_none || ((flags & (CFLAG_SPLICED1 | CFLAG_SPLICED2)) && (filter == FILTER_relative_support || filter == 17 /* min_support */ || filter == FILTER_homopolymer));
+}
 AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c) {
 	AGPU_FP_AS_WRITTEN
 	const uint32_t flags = t.flags[c];
 	const bool spliced1 = flags & CFLAG_SPLICED1, spliced2 = flags & CFLAG_SPLICED2, exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2;
 	const uint8_t filter = t.filter[c];
-	// also filtered events are tagged if they are spliced, so that the filters 'spliced' and 'many_spliced' do not recover them (:112-115)
-	if (filter != FILTER_none && !((spliced1 || spliced2) && (filter == FILTER_relative_support || filter == 17 /* min_support */ || filter == FILTER_homopolymer))) return false;
+	if (!in_vitro_looks_at(t, c)) return false;
 	float potential_rt_breakpoints = 0;
 	if (!exonic1) potential_rt_breakpoints += 0.5; else if (!spliced1) potential_rt_breakpoints += 1;
 	if (!exonic2) potential_rt_breakpoints += 0.5; else if (!spliced2) potential_rt_breakpoints += 1;

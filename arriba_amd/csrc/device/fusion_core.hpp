@@ -271,20 +271,33 @@ AGPU_HD bool candidate_is_intragenic(const AnnotationView& ann, uint32_t gene1, 
 	                          breakpoint2 >= ann.gene_start[gene1] - 10000 && breakpoint2 <= ann.gene_end[gene1] + 10000);
 }
 
-// does a discordant mate of the same gene pair support this candidate? (source/fusions.cpp:379-396)
+// does a discordant mate of the same gene pair support this candidate? (source/fusions.cpp:379-396)  What depends on the candidate alone is worked out once (a candidate of a
+// hot gene pair asks the question tens of thousands of times: the gene table is not looked up per mate).
+struct DiscordantMatePredicate {
+	int32_t breakpoint1, breakpoint2, limit1, limit2, max_mate_gap, gene1_start, gene1_end, gene2_start, gene2_end;
+	bool upstream1, upstream2, intragenic;
+	AGPU_HD void set(const AnnotationView& ann, uint32_t gene1, uint32_t gene2, int32_t candidate_breakpoint1, int32_t candidate_breakpoint2, bool candidate_upstream1, bool candidate_upstream2, bool has_split_reads, int32_t gap) {
+		breakpoint1 = candidate_breakpoint1; breakpoint2 = candidate_breakpoint2; upstream1 = candidate_upstream1; upstream2 = candidate_upstream2; max_mate_gap = gap;
+		const int32_t max_overlap = has_split_reads ? 2 : gap;
+		limit1 = upstream1 ? breakpoint1 - max_overlap : breakpoint1 + max_overlap;
+		limit2 = upstream2 ? breakpoint2 - max_overlap : breakpoint2 + max_overlap;
+		gene1_start = ann.gene_start[gene1]; gene1_end = ann.gene_end[gene1]; gene2_start = ann.gene_start[gene2]; gene2_end = ann.gene_end[gene2];
+		intragenic = candidate_is_intragenic(ann, gene1, gene2, breakpoint1, breakpoint2);
+	}
+	AGPU_HD bool supports(int32_t mate_breakpoint1, int32_t mate_breakpoint2) const {
+		if (!(upstream1 ? mate_breakpoint1 >= limit1 : mate_breakpoint1 <= limit1)) return false;
+		if (!(upstream2 ? mate_breakpoint2 >= limit2 : mate_breakpoint2 <= limit2)) return false;
+		int32_t d1 = breakpoint1 - mate_breakpoint1; if (d1 < 0) d1 = -d1;
+		int32_t d2 = breakpoint2 - mate_breakpoint2; if (d2 < 0) d2 = -d2;
+		const bool outside_other_gene = !intragenic && !(mate_breakpoint1 >= gene2_start && mate_breakpoint1 <= gene2_end) && !(mate_breakpoint2 >= gene1_start && mate_breakpoint2 <= gene1_end);
+		return outside_other_gene || (d1 <= max_mate_gap && d2 <= max_mate_gap);
+	}
+};
 AGPU_HD bool discordant_mate_supports(const AnnotationView& ann, uint32_t gene1, uint32_t gene2, int32_t breakpoint1, int32_t breakpoint2, bool upstream1, bool upstream2,
                                       bool has_split_reads, int32_t max_mate_gap, int32_t mate_breakpoint1, int32_t mate_breakpoint2) {
-	int32_t max_overlap = has_split_reads ? 2 : max_mate_gap;
-	int32_t limit1 = upstream1 ? breakpoint1 - max_overlap : breakpoint1 + max_overlap;
-	int32_t limit2 = upstream2 ? breakpoint2 - max_overlap : breakpoint2 + max_overlap;
-	if (!(upstream1 ? mate_breakpoint1 >= limit1 : mate_breakpoint1 <= limit1)) return false;
-	if (!(upstream2 ? mate_breakpoint2 >= limit2 : mate_breakpoint2 <= limit2)) return false;
-	int32_t d1 = breakpoint1 - mate_breakpoint1; if (d1 < 0) d1 = -d1;
-	int32_t d2 = breakpoint2 - mate_breakpoint2; if (d2 < 0) d2 = -d2;
-	bool outside_other_gene = !candidate_is_intragenic(ann, gene1, gene2, breakpoint1, breakpoint2) &&
-	                          !(mate_breakpoint1 >= ann.gene_start[gene2] && mate_breakpoint1 <= ann.gene_end[gene2]) &&
-	                          !(mate_breakpoint2 >= ann.gene_start[gene1] && mate_breakpoint2 <= ann.gene_end[gene1]);
-	return outside_other_gene || (d1 <= max_mate_gap && d2 <= max_mate_gap);
+	DiscordantMatePredicate predicate;
+	predicate.set(ann, gene1, gene2, breakpoint1, breakpoint2, upstream1, upstream2, has_split_reads, max_mate_gap);
+	return predicate.supports(mate_breakpoint1, mate_breakpoint2);
 }
 
 // which alignment slot of a discordant fragment holds the mate with the lower (contig, breakpoint)? (source/fusions.cpp:414-421)

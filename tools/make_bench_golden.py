@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/make_bench_golden.py -- run the UNMODIFIED reference (oracle/_ref/arriba_ref, oracle/Makefile) once on samples of bench.py's
 workload (workload_args(N, 1000): BASELINE.json config 2, or config 3 with --stress) where the repository is built, and keep what pins
-parity and the CPU baseline at that size: SHA-256 of the BAM file it read and of the fusions.tsv it wrote, its log in full, wall seconds
+parity and the CPU baseline at that size: SHA-256 of the BAM file it read and of the fusions.tsv and discarded.tsv it wrote, its log in full, wall seconds
 with and without its loading phase, peak memory (the reference's own last line, source/arriba.cpp:616-628).
 
     python tools/make_bench_golden.py --fragments 20000000 --golden bench20m      # tests/golden/bench20m/{meta.json,reference.log}
@@ -62,7 +62,8 @@ def main():
     generator = bench.workload_args(args.fragments, 1000, stress=args.stress)
     subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(args.threads)] + generator, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     bam_sha = sha256(prefix + ".bam")
-    command = [datasets.ARRIBA_REF, "-x", "s.bam", "-g", "s.gtf", "-a", "s.fa", "-o", "ref_fusions.tsv", "-f", "blacklist"] + (["-U", "32767"] if args.stress else [])
+    # (-O: the discarded candidates as well -- review of round 4, item 7c: the SHA pins of the large samples did not pin discarded.tsv)
+    command = [datasets.ARRIBA_REF, "-x", "s.bam", "-g", "s.gtf", "-a", "s.fa", "-o", "ref_fusions.tsv", "-O", "ref_discarded.tsv", "-f", "blacklist"] + (["-U", "32767"] if args.stress else [])
     returncode, log, elapsed, loading, total = bench.run_reference(command, cwd=directory)
     if returncode != 0:
         raise SystemExit("the reference failed:\n" + log[-2000:])
@@ -76,6 +77,8 @@ def main():
         "bam_sha256": bam_sha,
         "fusions_tsv_sha256": sha256(os.path.join(directory, "ref_fusions.tsv")),
         "fusions": fusions,
+        "discarded_tsv_sha256": sha256(os.path.join(directory, "ref_discarded.tsv")),
+        "discarded": sum(1 for line in open(os.path.join(directory, "ref_discarded.tsv")) if not line.startswith("#")),
         "chimeric_fragments": total,
         "reference_seconds_in_the_build_container": round(elapsed, 1),
         "reference_loading_seconds": round(loading, 1),
