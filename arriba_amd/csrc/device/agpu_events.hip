@@ -19,21 +19,44 @@ using namespace agpu;
 namespace {
 
 const int BLOCK = 256;
+// A candidate whose read lists hold more than LONG_LIST entries is walked by a wavefront (event_core.hpp: ListLanes): the thread that meets it notes it, a second kernel takes the
+// noted ones.  (Lists hold up to -U reads each: 300 by default, 32 767 in BASELINE.json's config 3, where in_vitro_kernel, both_spliced_reads_kernel and the both-intronic
+// predicate were 14 s of a 48 s sample with one thread per candidate -- profiles/r05g.)
+const uint32_t LONG_LIST = 192;
+struct WaveLanes {
+	uint32_t lane, lanes;
+	__device__ WaveLanes() : lane(threadIdx.x & 63), lanes(64) {}
+	__device__ uint32_t sum(uint32_t mine) const { for (int offset = 32; offset > 0; offset >>= 1) mine += __shfl_xor(mine, offset); return mine; }
+};
+__device__ __forceinline__ uint64_t list_entries_of(const CandidateTable& t, uint32_t c, int first_list) { return t.list_offset[3 * (uint64_t) c + 3] - t.list_offset[3 * (uint64_t) c + first_list]; }
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
 #define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
 
 // (the candidates [first, end): all of them, or a window of them when the stage walks read lists and the discordant lists are implicit -- for_each_list_window)
-__global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView ann, GenomeView genome, CoverageView coverage, CandidateTable t, uint32_t min_anchor_length, unsigned int* remaining, uint32_t first = 0, uint32_t end = 0xFFFFFFFFu) {
+__global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView ann, GenomeView genome, CoverageView coverage, CandidateTable t, uint32_t min_anchor_length, unsigned int* remaining, uint32_t first = 0, uint32_t end = 0xFFFFFFFFu,
+                                       uint32_t* long_list = nullptr, uint32_t* n_long = nullptr) {
 	__shared__ uint32_t block_sum;
 	uint32_t kept = 0;
 	if (end > t.n) end = t.n;
 	for (uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x; c < end; c += gridDim.x * BLOCK) {
 		if (t.filter[c] != FILTER_none) continue;
+		if (long_list != nullptr && stage == EVENT_both_intronic && list_entries_of(t, c, 0) > LONG_LIST) { long_list[atomicAdd(n_long, 1u)] = c; continue; } // (event_predicate_wave_kernel)
 		const uint8_t verdict = event_predicate(stage, b, ann, genome, coverage, t, c, min_anchor_length);
 		if (verdict == FILTER_none) ++kept; else if (verdict != EVENT_KEPT_UNCOUNTED) t.filter[c] = verdict;
 	}
 	block_tally(kept, remaining, &block_sum);
+}
+
+__global__ void __launch_bounds__(BLOCK) event_predicate_wave_kernel(int stage, BatchView b, AnnotationView ann, GenomeView genome, CoverageView coverage, CandidateTable t, uint32_t min_anchor_length, unsigned int* remaining,
+                                                                     const uint32_t* long_list, const uint32_t* n_long) {
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+	if (wave >= *n_long) return;
+	const uint32_t c = long_list[wave];
+	const WaveLanes lanes;
+	const uint8_t verdict = event_predicate(stage, b, ann, genome, coverage, t, c, min_anchor_length, lanes); // (the same for every lane)
+	if (lanes.lane != 0) return;
+	if (verdict == FILTER_none) atomicAdd(remaining, 1u); else if (verdict != EVENT_KEPT_UNCOUNTED) t.filter[c] = verdict;
 }
 
 // select_most_supported_breakpoints: sort keys and the fold over the groups
@@ -204,17 +227,40 @@ __global__ void clip_summary_kernel(BatchView b, ClipSummary* summaries) {
 	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (k < 3 * b.n) summaries[k] = clip_summary_of(b, k / 3, (int) (k % 3));
 }
-__global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end) {
+__global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long) {
 	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
-	if (c < end && is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
+	if (c >= end) return;
+	if (list_entries_of(t, c, 2) > LONG_LIST && in_vitro_looks_at(t, c)) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (the verdict walks the discordant mates: in_vitro_wave_kernel)
+	if (is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
+}
+__global__ void __launch_bounds__(BLOCK) in_vitro_wave_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, const uint32_t* long_list, const uint32_t* n_long) {
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+	if (wave >= *n_long) return;
+	const uint32_t c = long_list[wave];
+	const WaveLanes lanes;
+	const bool artifact = is_in_vitro_artifact(b, ann, coverage, tables, t, c, lanes);
+	if (artifact && lanes.lane == 0) t.filter[c] = FILTER_in_vitro;
 }
 
 // recover_both_spliced
 __global__ void both_spliced_reads_kernel(BatchView b, AnnotationView ann, CoverageView coverage, const uint32_t* gene_read_count, uint32_t threshold, CandidateTable t, int32_t max_exon_size, uint32_t max_coverage,
-                                          uint32_t* reads, uint64_t* keys, uint32_t first, uint32_t end) {
+                                          uint32_t* reads, uint64_t* keys, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long) {
 	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= end) return;
-	const uint32_t count = both_spliced_is_member(ann, t, c) ? both_spliced_supporting_reads(b, ann, coverage, gene_read_count, threshold, t, c, max_exon_size, max_coverage) : 0;
+	const bool member = both_spliced_is_member(ann, t, c);
+	if (member && list_entries_of(t, c, 0) > LONG_LIST) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (both_spliced_reads_wave_kernel)
+	const uint32_t count = member ? both_spliced_supporting_reads(b, ann, coverage, gene_read_count, threshold, t, c, max_exon_size, max_coverage) : 0;
+	reads[c] = count;
+	keys[c] = count > 0 ? both_spliced_group_key(t, c, false) : ~0ull;
+}
+__global__ void __launch_bounds__(BLOCK) both_spliced_reads_wave_kernel(BatchView b, AnnotationView ann, CoverageView coverage, const uint32_t* gene_read_count, uint32_t threshold, CandidateTable t, int32_t max_exon_size, uint32_t max_coverage,
+                                                                        uint32_t* reads, uint64_t* keys, const uint32_t* long_list, const uint32_t* n_long) {
+	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+	if (wave >= *n_long) return;
+	const uint32_t c = long_list[wave];
+	const WaveLanes lanes;
+	const uint32_t count = both_spliced_supporting_reads(b, ann, coverage, gene_read_count, threshold, t, c, max_exon_size, max_coverage, lanes);
+	if (lanes.lane != 0) return;
 	reads[c] = count;
 	keys[c] = count > 0 ? both_spliced_group_key(t, c, false) : ~0ull;
 }
@@ -286,6 +332,19 @@ int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& th
 	return AGPU_OK;
 }
 
+// the list of the candidates a thread kernel notes for the wavefronts, and their number read back (the launch of the second kernel is sized by it)
+struct LongLists {
+	uint32_t* list = nullptr; uint32_t* count = nullptr;
+	int prepare(agpu_ctx* ctx, uint32_t candidates) {
+		DeviceBuffer& buffer = ctx->scratch("events.long_list"); DeviceBuffer& counter = ctx->scratch("events.long_count");
+		ALLOC(buffer, (size_t) std::max<uint32_t>(candidates, 1) * 4); ALLOC(counter, 4);
+		HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 4, ctx->stream));
+		list = buffer.as<uint32_t>(); count = counter.as<uint32_t>();
+		return AGPU_OK;
+	}
+	int noted(agpu_ctx* ctx, uint32_t& n) { HIP_CHECK(hipMemcpyAsync(&n, count, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); return AGPU_OK; }
+};
+
 int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* kernel_name, uint32_t min_anchor_length, uint64_t* remaining) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
 	if (stage == EVENT_both_intronic && ctx->candidates_imported) { set_last_error("filter_both_intronic reads the read lists: not available on an imported (replicated) candidate table"); return AGPU_ERR_INVALID; }
@@ -301,8 +360,13 @@ int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* ker
 		const int effective_stage = ctx->params.filter_enabled[filter_id] ? stage : EVENT_count_only; // a stage switched off with -f only counts
 		if (effective_stage == EVENT_both_intronic) { // (walks the read lists)
 			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
-				KernelTimer timer(ctx, kernel_name, (uint64_t) C * 60 + (uint64_t) ctx->n_list_entries * 8);
-				event_predicate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), begin, end);
+				LongLists lists; uint32_t n_long = 0;
+				{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
+				{ KernelTimer timer(ctx, kernel_name, (uint64_t) C * 60 + (uint64_t) ctx->n_list_entries * 8);
+				  event_predicate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), begin, end, lists.list, lists.count); }
+				{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
+				if (n_long > 0) { KernelTimer timer(ctx, "event_predicate_wave_kernel(both_intronic)", (uint64_t) n_long * 60);
+				  event_predicate_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), lists.list, lists.count); }
 				return AGPU_OK;
 			}, LISTS_OF_UNFILTERED);
 			if (status != AGPU_OK) return status;
@@ -789,8 +853,13 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 		// (3) the verdicts
 		// (the verdict of a candidate looks at the tables made above -- complete -- and at its own discordant list; the filter it sets is read by no other candidate's verdict)
 		const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
-			KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
-			in_vitro_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, begin, end);
+			LongLists lists; uint32_t n_long = 0;
+			{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
+			{ KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
+			  in_vitro_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, begin, end, lists.list, lists.count); }
+			{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
+			if (n_long > 0) { KernelTimer timer(ctx, "in_vitro_wave_kernel", (uint64_t) n_long * 80);
+			  in_vitro_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, lists.list, lists.count); }
 			return AGPU_OK;
 		}, LISTS_OF_IN_VITRO);
 		if (status != AGPU_OK) return status;
@@ -829,8 +898,13 @@ extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_
 		HIP_CHECK(hipMemsetAsync(histogram.ptr, 0, (size_t) BOTH_SPLICED_HISTOGRAM_BINS * 4, s));
 		{ const uint32_t* gene_read_count = ctx->scratch("events.gene_read_count").as<uint32_t>();
 		  const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
-			KernelTimer timer(ctx, "both_spliced_reads_kernel", (uint64_t) C * 70 + (uint64_t) ctx->n_list_entries * 6);
-			both_spliced_reads_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), begin, end);
+			LongLists lists; uint32_t n_long = 0;
+			{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
+			{ KernelTimer timer(ctx, "both_spliced_reads_kernel", (uint64_t) C * 70 + (uint64_t) ctx->n_list_entries * 6);
+			  both_spliced_reads_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), begin, end, lists.list, lists.count); }
+			{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
+			if (n_long > 0) { KernelTimer timer(ctx, "both_spliced_reads_wave_kernel", (uint64_t) n_long * 70);
+			  both_spliced_reads_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), lists.list, lists.count); }
 			return AGPU_OK;
 		  }, LISTS_OF_BOTH_SPLICED);
 		  if (status != AGPU_OK) return status; }

@@ -64,16 +64,26 @@ AGPU_HD bool candidate_overlaps_both_genes(const AnnotationView& ann, const Cand
 }
 AGPU_HD bool contig_is_viral(const GenomeView& genome, uint32_t contig) { return contig < genome.n_contigs && (genome.contig_bits[contig] & CBIT_VIRAL); }
 
+// Who walks the read lists of a candidate.  The predicates below that do are sums over list entries followed by a decision: one thread takes every entry (ListLanes()), or the 64
+// lanes of a wavefront take every 64th and add their counts up (agpu_events.hip: the candidates with long lists -- a list holds up to -U reads, 32 767 in config 3 -- get a
+// wavefront each; a thread walking 98 000 entries alone was the whole time of these kernels).  sum() must give every lane the total.
+struct ListLanes {
+	uint32_t lane = 0, lanes = 1;
+	AGPU_HD uint32_t sum(uint32_t mine) const { return mine; }
+};
+
 // ---- filter_both_intronic: true = no unfiltered read of the candidate has an exonic alignment
-AGPU_HD bool has_only_intronic_reads(const BatchView& b, const GenomeView& genome, const CandidateTable& t, uint32_t c) {
+template <class Lanes = ListLanes> AGPU_HD bool has_only_intronic_reads(const BatchView& b, const GenomeView& genome, const CandidateTable& t, uint32_t c, const Lanes& lanes = Lanes()) {
 	if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return false; // viral contigs are often not annotated
-	for (uint64_t k = t.list_offset[3 * (uint64_t) c]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
+	uint32_t exonic = 0;
+	for (uint64_t k = t.list_offset[3 * (uint64_t) c] + lanes.lane; k < t.list_offset[3 * (uint64_t) c + 3]; k += lanes.lanes) {
 		const uint32_t read = t.read_lists[k];
 		if (b.filter[read] != FILTER_none) continue;
 		for (int slot = 0; slot < b.n_aln[read]; ++slot)
-			if (b.abits[slot][read] & ABIT_EXONIC) return false;
+			if (b.abits[slot][read] & ABIT_EXONIC) exonic = 1;
+		if (exonic && lanes.lanes == 1) break;
 	}
-	return true;
+	return lanes.sum(exonic) == 0;
 }
 
 // ---- filter_short_anchor
@@ -305,7 +315,7 @@ AGPU_HD bool in_vitro_looks_at(const CandidateTable& t, uint32_t c) {
 	const uint8_t filter = t.filter[c];
 	return filter == FILTER_none || ((flags & (CFLAG_SPLICED1 | CFLAG_SPLICED2)) && (filter == FILTER_relative_support || filter == 17 /* min_support */ || filter == FILTER_homopolymer));
 }
-AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c) {
+template <class Lanes = ListLanes> AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c, const Lanes& lanes = Lanes()) {
 	AGPU_FP_AS_WRITTEN
 	const uint32_t flags = t.flags[c];
 	const bool spliced1 = flags & CFLAG_SPLICED1, spliced2 = flags & CFLAG_SPLICED2, exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2;
@@ -319,7 +329,7 @@ AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann,
 	// discordant mates that are clipped right at a breakpoint count as split reads (:133-158)
 	const uint32_t min_clipped_length = 3;
 	uint32_t clipped_discordant_mates1 = 0, clipped_discordant_mates2 = 0;
-	for (uint64_t k = t.list_offset[3 * (uint64_t) c + 2]; k < t.list_offset[3 * (uint64_t) c + 3]; ++k) {
+	for (uint64_t k = t.list_offset[3 * (uint64_t) c + 2] + lanes.lane; k < t.list_offset[3 * (uint64_t) c + 3]; k += lanes.lanes) {
 		const uint32_t read = t.read_lists[k];
 		if (b.filter[read] != FILTER_none) continue;
 		if (tables.clip_summaries != nullptr) {
@@ -343,6 +353,7 @@ AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann,
 			}
 		}
 	}
+	clipped_discordant_mates1 = lanes.sum(clipped_discordant_mates1); clipped_discordant_mates2 = lanes.sum(clipped_discordant_mates2);
 	const uint32_t split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c];
 	const uint32_t total_split_reads = (clipped_discordant_mates1 < clipped_discordant_mates2 ? clipped_discordant_mates1 : clipped_discordant_mates2) + split_reads1 + split_reads2;
 	IdSetTail overlapping_tail; GeneQuery overlapping(overlapping_tail.words);
@@ -385,8 +396,8 @@ AGPU_HD bool breakpoint_in_large_exon(const AnnotationView& ann, uint32_t contig
 	return false;
 }
 // reference: count_supporting_reads (:13-70)
-AGPU_HD uint32_t both_spliced_supporting_reads(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const uint32_t* gene_read_count, uint32_t high_expression_threshold,
-                                               const CandidateTable& t, uint32_t c, int32_t max_exon_size, uint32_t max_coverage) {
+template <class Lanes = ListLanes> AGPU_HD uint32_t both_spliced_supporting_reads(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const uint32_t* gene_read_count, uint32_t high_expression_threshold,
+                                               const CandidateTable& t, uint32_t c, int32_t max_exon_size, uint32_t max_coverage, const Lanes& lanes = Lanes()) {
 	const bool both_spliced = both_breakpoints_spliced(ann, t, c);
 	const uint32_t split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c];
 	if (gene_read_count[t.gene1[c]] > high_expression_threshold || gene_read_count[t.gene2[c]] > high_expression_threshold)
@@ -400,10 +411,11 @@ AGPU_HD uint32_t both_spliced_supporting_reads(const BatchView& b, const Annotat
 	}
 	uint32_t multimappers = 0, unique_mappers = 0;
 	const uint64_t begin = t.list_offset[3 * (uint64_t) c], end = t.list_offset[3 * (uint64_t) c + 3];
-	for (uint64_t k = begin; k < end; ++k) {
+	for (uint64_t k = begin + lanes.lane; k < end; k += lanes.lanes) {
 		const uint32_t read = t.read_lists[k];
 		if (b.fbits[read] & FBIT_MULTIMAPPER) multimappers++; else if (b.filter[read] == FILTER_none) unique_mappers++;
 	}
+	multimappers = lanes.sum(multimappers); unique_mappers = lanes.sum(unique_mappers);
 	if ((double) multimappers >= 0.5 * (double) (end - begin)) return 0;
 	return unique_mappers == 0 ? 1 : unique_mappers;
 }
@@ -634,11 +646,11 @@ AGPU_HD uint8_t candidate_confidence(const AnnotationView& ann, const CoverageVi
 // the candidates on viral contigs with `continue` before they count (source/filter_both_intronic.cpp:25-26, source/filter_end_to_end.cpp:38-39)
 const uint8_t EVENT_KEPT_UNCOUNTED = 0xFF;
 enum { EVENT_count_only = -1, EVENT_both_intronic = 0, EVENT_short_anchor = 1, EVENT_end_to_end = 2, EVENT_no_coverage = 3, EVENT_marginal_read_through = 4 };
-AGPU_HD uint8_t event_predicate(int stage, const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const CoverageView& coverage, const CandidateTable& t, uint32_t c, uint32_t min_anchor_length) {
+template <class Lanes = ListLanes> AGPU_HD uint8_t event_predicate(int stage, const BatchView& b, const AnnotationView& ann, const GenomeView& genome, const CoverageView& coverage, const CandidateTable& t, uint32_t c, uint32_t min_anchor_length, const Lanes& lanes = Lanes()) {
 	switch (stage) {
 		case EVENT_both_intronic:
 			if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return EVENT_KEPT_UNCOUNTED;
-			return has_only_intronic_reads(b, genome, t, c) ? FILTER_intronic : FILTER_none;
+			return has_only_intronic_reads(b, genome, t, c, lanes) ? FILTER_intronic : FILTER_none;
 		case EVENT_short_anchor: return has_short_anchor(t, c, min_anchor_length) ? FILTER_short_anchor : FILTER_none;
 		case EVENT_end_to_end:
 			if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return EVENT_KEPT_UNCOUNTED;

@@ -776,8 +776,12 @@ def test_bench_sample_of_config_2_against_the_reference(name, fragments, built, 
         output = str(tmp_path / ("fusions%d.tsv" % repeat))
         if repeat == 0:
             session.submit(prefix + ".bam")
-        counts = dict(session.sample(prefix + ".bam", output))
+        discarded = str(tmp_path / "discarded.tsv") if repeat == 1 and "discarded_tsv_sha256" in meta else None  # (review of round 4, item 7c: -O pinned as well, 3.9 M / 7.9 M rows)
+        counts = dict(session.sample(prefix + ".bam", output, discarded))
         assert sha256(output) == meta["fusions_tsv_sha256"], repeat
+        if discarded:
+            assert sha256(discarded) == meta["discarded_tsv_sha256"], "discarded.tsv"
+            os.remove(discarded)
     log = open(os.path.join(golden, "reference.log")).read()
     assert counts["read_chimeric_alignments"] == int(re.search(r"Reading chimeric alignments[^\n]*\(total=(\d+)\)", log).group(1))
     for stage, pattern in (("filter_duplicates", "Filtering duplicates"), ("filter_mismatches", "Filtering reads with a mismatch"), ("filter_low_entropy", "Filtering reads with low entropy"), ("merge_adjacent_fusions", "Merging adjacent fusion breakpoints"),
@@ -852,8 +856,11 @@ def test_mismapper_stress_of_config_3_against_the_reference(built, tmp_path):
     assert sha256(prefix + ".bam") == meta["bam_sha256"], "the generator drifted from the sample the reference was run on (tests/golden/stress3m/meta.json)"
     session = WorkflowSession(prefix + ".fa", prefix + ".gtf", params={"subsampling_threshold": 32767})
     output = str(tmp_path / "fusions.tsv")
-    counts = dict(session.sample(prefix + ".bam", output))
+    discarded = str(tmp_path / "discarded.tsv") if "discarded_tsv_sha256" in meta else None
+    counts = dict(session.sample(prefix + ".bam", output, discarded))
     assert sha256(output) == meta["fusions_tsv_sha256"]
+    if discarded:
+        assert hashlib.sha256(open(discarded, "rb").read()).hexdigest() == meta["discarded_tsv_sha256"], "discarded.tsv"
     log = open(os.path.join(golden, "reference.log")).read()
     assert counts["read_chimeric_alignments"] == meta["chimeric_fragments"]
     for stage, pattern in (("filter_duplicates", "Filtering duplicates"), ("merge_adjacent_fusions", "Merging adjacent fusion breakpoints"), ("filter_relative_support", "Filtering fusions with an e-value"),
