@@ -22,11 +22,15 @@ const int BLOCK = 256;
 // A candidate whose read lists hold more than LONG_LIST entries is walked by a wavefront (event_core.hpp: ListLanes): the thread that meets it notes it, a second kernel takes the
 // noted ones.  (Lists hold up to -U reads each: 300 by default, 32 767 in BASELINE.json's config 3, where in_vitro_kernel, both_spliced_reads_kernel and the both-intronic
 // predicate were 14 s of a 48 s sample with one thread per candidate -- profiles/r05g.)
-const uint32_t LONG_LIST = 192;
+// (what a wavefront costs more than a thread is the part of the predicate around the walk, which 64 lanes then do for one candidate instead of for 64: with the lists of the default
+//  threshold, -U 300, a wavefront per candidate of more than 192 entries made both-intronic and in vitro SLOWER at 10^8 fragments of config 2 -- 42 -> 99 ms, 74 -> 90 ms,
+//  profiles/r05h_bench100m.json -- and both spliced faster, 84 -> 69 ms)
+const uint32_t LONG_LIST = 1024, LONG_LIST_BOTH_SPLICED = 192;
 struct WaveLanes {
 	uint32_t lane, lanes;
 	__device__ WaveLanes() : lane(threadIdx.x & 63), lanes(64) {}
 	__device__ uint32_t sum(uint32_t mine) const { for (int offset = 32; offset > 0; offset >>= 1) mine += __shfl_xor(mine, offset); return mine; }
+	__device__ bool any(bool mine) const { return __ballot(mine) != 0; }
 };
 __device__ __forceinline__ uint64_t list_entries_of(const CandidateTable& t, uint32_t c, int first_list) { return t.list_offset[3 * (uint64_t) c + 3] - t.list_offset[3 * (uint64_t) c + first_list]; }
 
@@ -248,7 +252,7 @@ __global__ void both_spliced_reads_kernel(BatchView b, AnnotationView ann, Cover
 	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= end) return;
 	const bool member = both_spliced_is_member(ann, t, c);
-	if (member && list_entries_of(t, c, 0) > LONG_LIST) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (both_spliced_reads_wave_kernel)
+	if (member && list_entries_of(t, c, 0) > LONG_LIST_BOTH_SPLICED) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (both_spliced_reads_wave_kernel)
 	const uint32_t count = member ? both_spliced_supporting_reads(b, ann, coverage, gene_read_count, threshold, t, c, max_exon_size, max_coverage) : 0;
 	reads[c] = count;
 	keys[c] = count > 0 ? both_spliced_group_key(t, c, false) : ~0ull;

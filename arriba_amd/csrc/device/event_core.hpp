@@ -70,20 +70,25 @@ AGPU_HD bool contig_is_viral(const GenomeView& genome, uint32_t contig) { return
 struct ListLanes {
 	uint32_t lane = 0, lanes = 1;
 	AGPU_HD uint32_t sum(uint32_t mine) const { return mine; }
+	AGPU_HD bool any(bool mine) const { return mine; }
 };
 
 // ---- filter_both_intronic: true = no unfiltered read of the candidate has an exonic alignment
 template <class Lanes = ListLanes> AGPU_HD bool has_only_intronic_reads(const BatchView& b, const GenomeView& genome, const CandidateTable& t, uint32_t c, const Lanes& lanes = Lanes()) {
 	if (contig_is_viral(genome, t.contigs[c] >> 16) || contig_is_viral(genome, t.contigs[c] & 0xFFFF)) return false; // viral contigs are often not annotated
-	uint32_t exonic = 0;
-	for (uint64_t k = t.list_offset[3 * (uint64_t) c] + lanes.lane; k < t.list_offset[3 * (uint64_t) c + 3]; k += lanes.lanes) {
-		const uint32_t read = t.read_lists[k];
-		if (b.filter[read] != FILTER_none) continue;
-		for (int slot = 0; slot < b.n_aln[read]; ++slot)
-			if (b.abits[slot][read] & ABIT_EXONIC) exonic = 1;
-		if (exonic && lanes.lanes == 1) break;
+	const uint64_t end = t.list_offset[3 * (uint64_t) c + 3];
+	for (uint64_t base = t.list_offset[3 * (uint64_t) c]; base < end; base += lanes.lanes) { // (all lanes make the same number of turns: any() asks every one of them)
+		bool exonic = false;
+		const uint64_t k = base + lanes.lane;
+		if (k < end) {
+			const uint32_t read = t.read_lists[k];
+			if (b.filter[read] == FILTER_none)
+				for (int slot = 0; slot < b.n_aln[read]; ++slot)
+					if (b.abits[slot][read] & ABIT_EXONIC) exonic = true;
+		}
+		if (lanes.any(exonic)) return false; // (the reference stops at the first one, too)
 	}
-	return lanes.sum(exonic) == 0;
+	return true;
 }
 
 // ---- filter_short_anchor
