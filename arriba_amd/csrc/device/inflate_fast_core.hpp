@@ -249,39 +249,39 @@ AGPU_HD int inflate_tokens(const uint8_t* input, uint32_t in_size, uint8_t* outp
 		{ const int status = fast_build_table(lengths, n_litlen, t.litlen, FAST_LITLEN_ROOT, FAST_LITLEN_ENTRIES, true, t); if (status != INFLATE_OK) return status; }
 		for (uint32_t s = 0; s < n_distance; ++s) t.code_lengths[s] = lengths[n_litlen + s]; // (out of the way of the table that is built where they stand)
 		{ const int status = fast_build_table(t.code_lengths, n_distance, t.distance, FAST_DISTANCE_ROOT, FAST_DISTANCE_ENTRIES, false, t); if (status != INFLATE_OK) return status; }
-		for (uint32_t turn = 0; ; ++turn) { // a token per turn: at most 15 + 5 + 15 + 13 = 48 bits
+		// A token per turn: at most 15 + 5 + 15 + 13 = 48 bits.  What is wrong with a token is NOTED (`wrong`), not acted upon at once: a lane that leaves the loop in the middle of a turn
+		// costs every turn of every lane the bookkeeping of who is still in it.  The note is looked at every eighth turn and at the end of the block; until then nothing is written
+		// that should not be (a literal or a match that does not fit is not stored), and a code that does not exist is met again and again (its entry drops no bits).
+		int wrong = INFLATE_OK;
+		for (uint32_t turn = 0; ; ++turn) {
 			if ((turn & 7u) == 0) { // (the lanes of a wavefront are in the same turn: they wait for HBM together, once in eight tokens)
-				if (bits.overrun()) return INFLATE_INPUT_OVERRUN; // (at most eight tokens are decoded from what lies behind the input; what they may write is checked token by token)
+				if (wrong != INFLATE_OK) return wrong;
+				if (bits.overrun()) return INFLATE_INPUT_OVERRUN; // (at most eight tokens are decoded from what lies behind the input)
 				bits.top_up();
 			}
 			bits.refill();
 			const uint32_t entry = fast_symbol(bits, t.litlen, FAST_LITLEN_ROOT);
-			if (entry == 0) return INFLATE_BAD_SYMBOL;
-			const uint32_t payload = entry >> 6;
-			if ((entry >> 4 & 3u) == FAST_LITERAL) {
-				if (produced >= out_size) return INFLATE_OUTPUT_OVERRUN;
-				output[produced++] = (uint8_t) payload;
+			const uint32_t payload = entry >> 6, type = entry >> 4 & 3u;
+			if (type == FAST_LITERAL) {
+				if (produced < out_size) output[produced++] = (uint8_t) payload; else wrong = INFLATE_OUTPUT_OVERRUN;
 				continue;
 			}
-			if (payload == 0) break; // end of block
-			if (payload > 29) return INFLATE_BAD_SYMBOL;
-			uint32_t length;
-			{ const uint32_t s = payload - 1; // 0..28 (3.2.5: lengths 3..258 in 29 codes, 0..5 extra bits)
-			  if (s < 8) length = 3 + s;
-			  else if (s == 28) length = 258;
-			  else { const uint32_t extra = (s >> 2) - 1; length = 3 + ((4 + (s & 3u)) << extra) + bits.take(extra); } }
+			if (type == FAST_LENGTH && payload == 0) break; // end of block
+			const bool known = type == FAST_LENGTH && payload <= 29;
+			const uint32_t s = known ? payload - 1 : 0; // 0..28 (3.2.5: lengths 3..258 in 29 codes, 0..5 extra bits)
+			uint32_t length_extra = s < 8 ? 0 : (s >> 2) - 1, length = s < 4 ? 3 + s : 3 + ((4 + (s & 3u)) << length_extra);
+			if (s == 28) { length = 258; length_extra = 0; }
+			length += bits.take(length_extra);
 			const uint32_t found = fast_symbol(bits, t.distance, FAST_DISTANCE_ROOT);
-			const uint32_t symbol = found >> 6;
-			if (found == 0 || symbol > 29) return INFLATE_BAD_DISTANCE;
-			uint32_t distance;
-			if (symbol < 4) distance = symbol + 1;
-			else { const uint32_t extra = (symbol >> 1) - 1; distance = 1 + ((2 + (symbol & 1u)) << extra) + bits.take(extra); }
-			if (distance > produced) return INFLATE_BAD_DISTANCE;
-			if (produced + length > out_size) return INFLATE_OUTPUT_OVERRUN;
-			if (noted == capacity) return INFLATE_RETRY;
-			notes[noted++] = inflate_match_note(produced, length, distance);
-			produced += length;
+			const bool distance_known = found != 0 && (found >> 6) <= 29;
+			const uint32_t symbol = distance_known ? found >> 6 : 0;
+			const uint32_t distance_extra = symbol < 4 ? 0 : (symbol >> 1) - 1;
+			const uint32_t distance = (symbol < 4 ? symbol + 1 : 1 + ((2 + (symbol & 1u)) << distance_extra)) + bits.take(distance_extra);
+			const int verdict = !known ? (int) INFLATE_BAD_SYMBOL : !distance_known || distance > produced ? (int) INFLATE_BAD_DISTANCE : produced + length > out_size ? (int) INFLATE_OUTPUT_OVERRUN : noted == capacity ? (int) INFLATE_RETRY : (int) INFLATE_OK;
+			if (verdict == INFLATE_OK) { notes[noted++] = inflate_match_note(produced, length, distance); produced += length; }
+			else if (wrong == INFLATE_OK) wrong = verdict;
 		}
+		if (wrong != INFLATE_OK) return wrong;
 	}
 	if (bits.overrun()) return INFLATE_INPUT_OVERRUN;
 	n_notes = noted;
