@@ -302,8 +302,8 @@ def host_only(args):
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=4)
-    parser.add_argument("--warmup", type=int, default=2, help="untimed steps in front of the timed ones; the session has two lanes that take the samples in turn, and a lane allocates its buffers with its first sample: with fewer than two that first sample is a timed step (2.99 s instead of 1.92 at 10^8 fragments, profiles/r04f_driver.err)")
+    parser.add_argument("--steps", type=int, default=None, help="timed steps (default 4; 2 for --stress at 50 M fragments and more, where a sample takes ~40 s)")
+    parser.add_argument("--warmup", type=int, default=None, help="default 2 (1 for --stress at 50 M fragments and more); untimed steps in front of the timed ones; the session has two lanes that take the samples in turn, and a lane allocates its buffers with its first sample: with fewer than two that first sample is a timed step (2.99 s instead of 1.92 at 10^8 fragments, profiles/r04f_driver.err)")
     parser.add_argument("--fragments", type=int, default=None, help="chimeric fragments per GPU (default: 100 M, BASELINE.json's 100 M-read synthetic, if the box has the memory for the 54 GB file; 20000 with --host-only)")
     parser.add_argument("--stress", action="store_true", help="BASELINE.json config 3: clipped segments of 40-70 nt copied from the partner gene, -U 32767 (filter_mismappers sees every read)")
     parser.add_argument("--subsampling-threshold", type=int, default=None, help="-U of the reference (source/options.cpp:422-423); default 300, with --stress 32767 as SURVEY.md 8(d) config 3 says")
@@ -320,6 +320,14 @@ def main():
     parser.add_argument("--keep", help="keep the sample and the output files in this directory")
     parser.add_argument("--per-rank-samples", action="store_true", help="with --gpus N: every rank works on a sample of its own (weak scaling, no collective) instead of all ranks on one sample")
     args = parser.parse_args()
+    # config 3 at its stated size (-U 32767: implicit discordant lists, ~40 s per sample): fewer steps and no deflated leg unless asked for, so that the plain command finishes in minutes
+    large_stress = args.stress and args.fragments is not None and args.fragments >= 50000000
+    if args.steps is None:
+        args.steps = 2 if large_stress else 4
+    if args.warmup is None:
+        args.warmup = 1 if large_stress else 2
+    if large_stress:
+        args.no_deflated_leg = True
     NAME_LENGTH[0] = args.name_length
     if args.host_only:
         args.fragments = args.fragments or 20000
@@ -715,7 +723,7 @@ def main():
             if args.no_cpu_baseline or distributed:  # (timed at N = 1 only)
                 line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped: the reference is timed by the run with 1 GPU" if distributed else "skipped"}
             else:
-                line["cpu_baseline"] = cpu_baseline(1000, directory, stress=args.stress, subsampling=subsampling, timed_fragments=total_fragments)
+                line["cpu_baseline"] = cpu_baseline(1000, directory, stress=args.stress, subsampling=subsampling, timed_fragments=total_fragments, sample_fragments=150000 if args.stress else 800000)  # (config 3: the reference needs 5 1/2 minutes for 1 M fragments)
             print(json.dumps(line))
     finally:
         if one_sample:
