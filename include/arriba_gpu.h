@@ -315,6 +315,9 @@ int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* n_candidate
  * list_offset[3*n+1] indexes the concatenated read lists (split_read1_list, split_read2_list, discordant_mate_list per candidate). */
 int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
                         uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor_start1, int32_t* anchor_start2, uint64_t* list_offset);
+/* Round 5: the discordant_mate_lists may be IMPLICIT on the device -- every candidate of a gene pair lists the discordant mates of the pair near its breakpoints up to -U
+ * (source/fusions.cpp:379-437): with -U 32767 a 10^8-fragment sample would hold 92.7 G entries.  list_offset is the same either way; agpu_get_candidate_read_lists then expands the
+ * lists window by window into `reads` (capacity must hold all of them), agpu_get_candidate_read_lists_of expands those of the given candidates ("Read lists"). */
 int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capacity, uint64_t* total);
 /* the read lists of the given candidates only, packed: list_offset[3*n+1] starts at 0 (the output writer wants those of the candidates it prints -- a few
  * thousand of millions); call with reads == NULL to get *total and list_offset first */
