@@ -223,6 +223,7 @@ def bind_device_api(lib, prefix="agpu_"):
         "gather_rows_copy": (c_int, [ctx, POINTER(BatchRows)]),
         "set_profiling": (c_int, [ctx, c_int]),
         "debug_fail_allocation_in_finish": (None, [c_int]),
+        "keep_batch_buffers": (c_int, [ctx, c_int]),
         "get_kernel_profile": (c_int, [ctx, c_void_p, c_void_p, c_void_p, c_uint32, POINTER(c_uint32)]),
         "last_kernel_ms": (c_int, [ctx, POINTER(c_float)]),
         "last_kernel_bytes": (c_int, [ctx, POINTER(c_uint64)]),
@@ -334,6 +335,7 @@ def workflow_library():
         lib.arriba_workflow_submit.argtypes = [c_void_p, c_char_p]; lib.arriba_workflow_submit.restype = c_int
         lib.arriba_workflow_cancel.argtypes = [c_void_p]; lib.arriba_workflow_cancel.restype = c_int
         lib.arriba_workflow_defer_output.argtypes = [c_void_p, c_int]; lib.arriba_workflow_defer_output.restype = c_int
+        lib.arriba_workflow_finish_ahead.argtypes = [c_void_p, c_int]; lib.arriba_workflow_finish_ahead.restype = c_int
         lib.arriba_workflow_flush.argtypes = [c_void_p, POINTER(ctypes.c_double)]; lib.arriba_workflow_flush.restype = c_int
         lib.arriba_workflow_device.argtypes = [c_void_p]; lib.arriba_workflow_device.restype = c_void_p
         lib.arriba_workflow_lane_device.argtypes = [c_void_p, c_int]; lib.arriba_workflow_lane_device.restype = c_void_p

@@ -64,10 +64,13 @@ bool DeviceBuffer::release_idle_buffers() {
 	}
 	return released;
 }
-void take_sample_buffers(agpu_ctx* ctx) {
+// batch_group: the columns, pools and names of the batch (what agpu_ingest_finish writes); stage_group: everything the stages behind it fill.  A session whose lanes keep their
+// batch buffers (agpu_keep_batch_buffers: the ingest of the next sample is FINISHED beside the stages of the current one) takes nothing at the finish and the stage group when
+// its stages begin (agpu_mark_multimappers), when the sibling's sample is done on the device.
+void take_sample_buffers(agpu_ctx* ctx, bool batch_group, bool stage_group) {
 	agpu_ctx* from = ctx->sibling;
-	if (from == nullptr) return;
-	(void) hipStreamSynchronize(from->stream); // (its last copies back to the host have left the buffers)
+	if (from == nullptr || (!batch_group && !stage_group)) return;
+	if (batch_group) (void) hipStreamSynchronize(from->stream); // (its last copies back to the host have left the buffers; the stage group is taken by the thread that ran the sibling's stages to their end)
 	DeviceBuffer* mine[] = { &ctx->n_aln, &ctx->fbits, &ctx->filter, &ctx->group, &ctx->pristine_fbits, &ctx->pristine_abits[0], &ctx->pristine_abits[1], &ctx->pristine_abits[2],
 		&ctx->contig[0], &ctx->contig[1], &ctx->contig[2], &ctx->start[0], &ctx->start[1], &ctx->start[2], &ctx->end[0], &ctx->end[1], &ctx->end[2], &ctx->abits[0], &ctx->abits[1], &ctx->abits[2],
 		&ctx->cigar_offset[0], &ctx->cigar_offset[1], &ctx->cigar_offset[2], &ctx->cigar_count[0], &ctx->cigar_count[1], &ctx->cigar_count[2], &ctx->cigar_pool, &ctx->seq_offset[0], &ctx->seq_offset[1],
@@ -90,11 +93,15 @@ void take_sample_buffers(agpu_ctx* ctx) {
 		&from->kmer_contig_table, &from->kmer_offsets, &from->kmer_positions, &from->splice_offset, &from->splice_sites, &from->splice_bits };
 	static_assert(sizeof(mine) == sizeof(theirs), "the same buffers of both contexts");
 	bool any = false;
-	for (size_t k = 0; k < sizeof(mine) / sizeof(mine[0]); ++k) if (theirs[k]->capacity > mine[k]->capacity) { mine[k]->swap(*theirs[k]); any = true; }
+	size_t first_of_stage_group = 0;
+	while (mine[first_of_stage_group] != &ctx->gather_ids) ++first_of_stage_group;
+	for (size_t k = batch_group ? 0 : first_of_stage_group; k < (stage_group ? sizeof(mine) / sizeof(mine[0]) : first_of_stage_group); ++k) if (theirs[k]->capacity > mine[k]->capacity) { mine[k]->swap(*theirs[k]); any = true; }
 	if (!any) return;
-	// the views of the sibling point at what it gave away: it has no sample until its next ingest
-	from->have_batch = false; from->annotated = false; from->stage1_done = false; from->stage2_done = false; from->fusions_done = false; from->evalue_done = false; from->iteration_order_done = false;
-	from->kmer_index_done = false; from->have_splice_sites = false; from->genomic_support_marked = false; from->mismapper_jobs_ready = false; from->n = 0; from->n_candidates = 0;
+	// the views of the sibling point at what it gave away: it has no sample until its next ingest (the batch flags only when the batch went: with the stage group alone the sibling
+	// may be finishing its next ingest on another thread at this very moment, and those flags are that thread's)
+	if (batch_group) { from->have_batch = false; from->annotated = false; from->stage1_done = false; from->stage2_done = false; from->n = 0; }
+	from->fusions_done = false; from->evalue_done = false; from->iteration_order_done = false;
+	from->kmer_index_done = false; from->have_splice_sites = false; from->genomic_support_marked = false; from->mismapper_jobs_ready = false; from->n_candidates = 0;
 	from->candidates = agpu::CandidateTable(); from->viral_pair_capacity = 0;
 	// ... and what this context kept of its own last sample went with the buffers
 	ctx->have_splice_sites = false; ctx->kmer_index_done = false; ctx->viral_pair_capacity = 0;
@@ -620,7 +627,7 @@ agpu_ctx* agpu_create_sibling(agpu_ctx* of) {
 	if (!of) { set_last_error("null argument"); return nullptr; }
 	if (of->sibling) { set_last_error("the context has a sibling already"); return nullptr; }
 	agpu_ctx* ctx = create_context(of->device, &of->params, of->pool);
-	if (ctx) { ctx->profiling = of->profiling; ctx->sibling = of; of->sibling = ctx; }
+	if (ctx) { ctx->profiling = of->profiling; ctx->sibling = of; of->sibling = ctx; ctx->keeps_batch_buffers = of->keeps_batch_buffers; }
 	return ctx;
 }
 static agpu_ctx* create_context(int device, const agpu_params* params, std::shared_ptr<agpu::ScratchPool> pool) {
@@ -775,9 +782,17 @@ int agpu_reset(agpu_ctx* ctx) {
 	return AGPU_OK;
 }
 
+int agpu_keep_batch_buffers(agpu_ctx* ctx, int on) {
+	if (!ctx) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	ctx->keeps_batch_buffers = on != 0;
+	if (ctx->sibling) ctx->sibling->keeps_batch_buffers = on != 0;
+	return AGPU_OK;
+}
+
 int agpu_mark_multimappers(agpu_ctx* ctx, uint64_t* marked) {
 	if (!ctx || !ctx->have_batch) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
+	if (ctx->keeps_batch_buffers) take_sample_buffers(ctx, false, true); // (the first stage of a sample: the buffers of the stages from the lane whose sample has just left the device)
 	begin_timing(ctx);
 	if (ctx->n > 0) { KernelTimer timer(ctx, "mark_multimappers_kernel", ctx->n * (4 + 1 + 1)); mark_multimappers_kernel<<<tally_grid(ctx->n, BLOCK), BLOCK, 0, ctx->stream>>>(ctx->batch, ctx->counters.as<uint32_t>()); }
 	TRY(end_timing(ctx, ctx->n * (4 + 1 + 1)));

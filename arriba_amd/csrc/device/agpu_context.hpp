@@ -121,6 +121,7 @@ struct agpu_ctx {
 	// scratch buffers of the stage calls, kept between calls (grow-only) and addressed by name
 	std::shared_ptr<agpu::ScratchPool> pool;
 	agpu::DeviceBuffer& scratch(const char* name) { return pool->get(name); }
+	bool keeps_batch_buffers = false; // agpu_keep_batch_buffers: the lanes of a session do not hand the batch over (agpu_api.hip: take_sample_buffers)
 	agpu_ctx* sibling = nullptr; // agpu_create_sibling: the other lane of a session (shares `pool`; the buffers of a sample change hands in agpu_ingest_finish: take_sample_buffers)
 
 	// annotation
@@ -228,7 +229,7 @@ namespace agpu {
 bool release_ingest_buffers(agpu_ctx* ctx);
 // agpu_api.hip: the buffers that hold a sample (batch, gene sets, candidates, read lists, k-mer index, ...) change hands between the lanes of a session: `ctx`, about to build
 // its batch, takes what its sibling -- whose sample is done on the device -- holds wherever that is the larger buffer; the sibling's sample is gone afterwards
-void take_sample_buffers(agpu_ctx* ctx);
+void take_sample_buffers(agpu_ctx* ctx, bool batch_group = true, bool stage_group = true);
 // agpu_api.hip: what follows the columns of a batch, whoever filled them (agpu_upload_batch, or the ingest on the device: agpu_ingest.hip)
 int finish_batch_setup(agpu_ctx* ctx);
 

@@ -1069,7 +1069,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	struct Finishing { agpu_ctx* ctx; explicit Finishing(agpu_ctx* c) : ctx(c) { ctx->ingest_finishing = true; g_inside_ingest_finish = true; } ~Finishing() { ctx->ingest_finishing = false; g_inside_ingest_finish = false; } } finishing(ctx);
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
-	take_sample_buffers(ctx); // (a session with two lanes: the batch of this sample is built where the sibling's last one, done on the device, lies)
+	if (!ctx->keeps_batch_buffers) take_sample_buffers(ctx); // (a session with two lanes: the batch of this sample is built where the sibling's last one, done on the device, lies -- unless the lanes keep their batch buffers, so that this ingest can be finished while the sibling's stages still run)
 	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); HIP_CHECK(hipStreamSynchronize(ctx->piece_stream2)); // (the last pieces unwrapped)
 	if (ctx->ingest_verify_crc || ctx->ingest_deflated_pieces) {
 		// a stored block whose payload does not give the CRC-32 of its trailer: the file is damaged (htslib: "CRC32 checksum mismatch").  A deflated block that did not decode (bad Huffman

@@ -81,7 +81,7 @@ template <class Sync> AGPU_HD bool inflate_build(const uint8_t* lengths, uint32_
 		for (int length = 0; length <= 15; ++length) huffman.count[length] = 0;
 		for (uint32_t s = 0; s < n; ++s) huffman.count[lengths[s]]++;
 		int left = 1, longest = 0; bool valid = true;
-		for (int length = 1; length <= 15; ++length) { left <<= 1; left -= huffman.count[length]; if (left < 0) valid = false; if (huffman.count[length] != 0) longest = length; }
+		for (int length = 1; length <= 15; ++length) { if (left >= 0) { left <<= 1; left -= huffman.count[length]; } if (left < 0) valid = false; if (huffman.count[length] != 0) longest = length; }
 		if (left > 0 && longest > 1) valid = false; // (advisor, round 4: zlib refuses an incomplete set too, unless it is a single code of one bit -- or no code at all; inftrees.c)
 		offset[1] = 0;
 		for (int length = 1; length < 15; ++length) offset[length + 1] = offset[length] + huffman.count[length];
@@ -154,7 +154,7 @@ template <class Sync, class Broadcast> AGPU_HD int inflate_block(const uint8_t* 
 						for (uint32_t k = 0; k < 19; ++k) count[code_lengths[k]]++;
 						count[0] = 0;
 						int left = 1; bool valid = true;
-						for (int l = 1; l <= 15; ++l) { left <<= 1; left -= count[l]; if (left < 0) valid = false; }
+						for (int l = 1; l <= 15; ++l) { if (left >= 0) { left <<= 1; left -= count[l]; } if (left < 0) valid = false; }
 						if (!valid || left > 0) { kind = EVENT_ERROR; error = INFLATE_BAD_CODE_LENGTHS; break; } // (zlib: the code of the code lengths must be complete)
 						offset[1] = 0;
 						for (int l = 1; l < 15; ++l) offset[l + 1] = offset[l] + count[l];

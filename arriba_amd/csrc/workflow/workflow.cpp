@@ -54,6 +54,8 @@ struct Run {
 	bool bam_open = false; uint64_t coverage_windows = 0; uint32_t bam_contigs = 0; double feed_started = 0, feed_finished = 0, feed_reading = 0, feed_pushing = 0;
 	std::string bam_path, output_path, discarded_path; // of the sample this lane works on (options.* point at them)
 	std::function<void()> after_ingest; // a session with two lanes: the stream and the tables of the ingest are free for the feed of the next sample
+	// arriba_workflow_finish_ahead: the second half ran on the feeder thread, before the caller asked for the sample; what it found is noted (report, timing) when the caller does
+	bool ingest_finished_ahead = false; uint64_t ingest_records = 0, ingest_stream_bytes = 0; double ingest_fed = 0, ingest_finished = 0, ingest_adopted = 0;
 	// arriba_workflow_defer_output: the last file of a sample is formatted and written by a thread of its own once everything it needs has left the device, while the caller goes on
 	// with the next sample; what that thread reads stays with the lane until it is joined (the staged columns and rows, the gene table below)
 	bool defer_output = false;
@@ -226,7 +228,6 @@ void finish_device_ingest(Run& run, double waited_since) {
 	struct Closer { Run& run; ~Closer() { if (run.bam_open) { ahost_bam_close(run.host); run.bam_open = false; } } } closer = { run };
 	const uint64_t windows = run.coverage_windows; const uint32_t n_contigs = run.bam_contigs;
 	const double fed = now_seconds();
-	if (run.timing) { run.timing->feed_read = run.feed_reading; run.timing->feed_push = run.feed_pushing; run.timing->feed_total = run.feed_finished - run.feed_started; }
 	agpu_ingest_result result;
 	device_check(agpu_ingest_finish(run.device, &result));
 	if (run.after_ingest) run.after_ingest();
@@ -238,9 +239,18 @@ void finish_device_ingest(Run& run, double waited_since) {
 	device_check(agpu_get_coverage(run.device, coverage.data(), starts.data(), ends.data()));
 	host_check(ahost_adopt_device_ingest(run.host, &result, viral.data(), coverage.data(), starts.data(), ends.data()));
 	run.n_fragments = result.fragments;
-	run.note("bam_records", result.records); // (for the report only: no line of the reference's log)
-	run.note("bam_stream_bytes", result.stream_bytes);
-	if (run.timing) { run.timing->feed = fed - waited_since; run.timing->ingest = finished - fed; run.timing->adopt = now_seconds() - finished; }
+	run.ingest_records = result.records; run.ingest_stream_bytes = result.stream_bytes; run.ingest_fed = fed; run.ingest_finished = finished; run.ingest_adopted = now_seconds();
+	(void) waited_since;
+}
+// ... and what it found, for the report and the timing of the call that asked for the sample (waited_since: when that call began to wait)
+void note_device_ingest(Run& run, double waited_since) {
+	if (run.timing) {
+		run.timing->feed_read = run.feed_reading; run.timing->feed_push = run.feed_pushing; run.timing->feed_total = run.feed_finished - run.feed_started;
+		if (run.ingest_finished_ahead) { run.timing->feed = now_seconds() - waited_since; run.timing->ingest = 0; run.timing->adopt = 0; } // (all of it beside the sample in front: what is left is the wait for it)
+		else { run.timing->feed = run.ingest_fed - waited_since; run.timing->ingest = run.ingest_finished - run.ingest_fed; run.timing->adopt = run.ingest_adopted - run.ingest_finished; }
+	}
+	run.note("bam_records", run.ingest_records); // (for the report only: no line of the reference's log)
+	run.note("bam_stream_bytes", run.ingest_stream_bytes);
 }
 
 // the writer prints names, CIGAR-derived pileups and sequences of the supporting reads of the candidates it writes: their rows come back from the device, and their filters.
@@ -407,7 +417,11 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 	if (!o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
 	if (run.timing) memset(run.timing, 0, sizeof(*run.timing));
 	agpu_params& params = run.params;
-	if (run.device_ingest) { if (!already_fed) feed_file(run); finish_device_ingest(run, sample_started); }
+	if (run.device_ingest) {
+		if (!already_fed) feed_file(run);
+		if (!(already_fed && run.ingest_finished_ahead)) finish_device_ingest(run, sample_started);
+		note_device_ingest(run, sample_started);
+	}
 	else {
 		host_check(ahost_ingest_bam_file(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length));
 		device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host)));
@@ -585,6 +599,7 @@ struct arriba_workflow_session {
 	std::mutex mutex; std::condition_variable changed;
 	bool ingest_busy = false; // a lane is between agpu_ingest_begin and agpu_ingest_finish
 	bool defer_output = false;
+	bool finish_ahead = false; // arriba_workflow_finish_ahead: the feeder of a sample also finishes its ingest (the lanes keep their batch buffers)
 	std::string deferred_error; // of a writer that was joined on the way (reported by the next arriba_workflow_sample / arriba_workflow_flush)
 	double deferred_seconds = 0; // the writer joined last
 	std::mutex writer_mutex; // (a writer is joined by the thread that calls the session or by the feeder of the lane's next sample)
@@ -649,7 +664,16 @@ struct arriba_workflow_session {
 		mine->feeder = std::thread([this, mine, &run, lane, ahead] {
 			if (ahead) ahost_limit_threads_of_this_thread(std::max(2u, ahost_cpu_budget() / 2));
 			{ std::unique_lock<std::mutex> lock(mutex); changed.wait(lock, [&] { return !ingest_busy && (queue.front().get() == mine || queue.front()->ingest_finished); }); ingest_busy = true; mine->started = true; }
-			try { feed_file(run); }
+			run.ingest_finished_ahead = false;
+			try {
+				feed_file(run);
+				if (finish_ahead) { // what is left of read_chimeric_alignments behind the last piece, here and now: the stages of the sample in front may still run on the other lane
+					finish_device_ingest(run, now_seconds());
+					run.ingest_finished_ahead = true;
+					{ std::lock_guard<std::mutex> lock(mutex); mine->ingest_finished = true; }
+					release_ingest();
+				}
+			}
 			catch (const Failure& failure) { mine->error = failure.text; }
 			catch (const std::exception& e) { mine->error = std::string("ERROR: ") + e.what(); }
 			{ std::lock_guard<std::mutex> lock(mutex); mine->fed = true; }
@@ -719,6 +743,14 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 int arriba_workflow_defer_output(arriba_workflow_session* session, int on) {
 	if (!session) { g_error = "ERROR: null argument"; return -1; }
 	session->defer_output = on != 0;
+	return 0;
+}
+int arriba_workflow_finish_ahead(arriba_workflow_session* session, int on) {
+	if (!session) { g_error = "ERROR: null argument"; return -1; }
+	if (!session->queue.empty()) { g_error = "ERROR: arriba_workflow_finish_ahead: samples are submitted already"; return -1; }
+	if (session->lanes[0]->options.host_ingest) { if (!on) return 0; g_error = "ERROR: arriba_workflow_finish_ahead needs read_chimeric_alignments on the device"; return -1; }
+	if (agpu_keep_batch_buffers(session->lanes[0]->device, on) != 0) { g_error = std::string("ERROR: ") + agpu_last_error(); return -1; } // (both lanes, also the one made later: agpu_create_sibling copies the flag)
+	session->finish_ahead = on != 0;
 	return 0;
 }
 int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_last_writer) {

@@ -205,7 +205,7 @@ def normal_pairs_leg(pipeline, directory, fragments=10000000, steps=2):
             "seconds_per_step": round(sum(seconds[1:]) / steps, 4), "steps": steps, "last_step": {key: round(value, 4) for key, value in timing.items()}, "generate_seconds": round(generated, 1)}
 
 
-def deflated_leg(pipeline, directory, fragments, stress, stored_output, steps=2):
+def deflated_leg(pipeline, directory, fragments, stress, stored_output, steps=2, finish_ahead=False):
     """the same sample as a BAM file with deflated BGZF blocks (zlib level 1: what STAR writes by default and what samtools writes -- the reference reads any BAM htslib opens,
     source/read_chimeric_alignments.cpp:563-566): a quarter of the bytes cross PCIe, bgzf_inflate_kernel makes the record stream in HBM.  The same records: the same fusions.tsv."""
     import hashlib
@@ -216,6 +216,7 @@ def deflated_leg(pipeline, directory, fragments, stress, stored_output, steps=2)
     bam_bytes = os.path.getsize(prefix + ".bam")
     output = prefix + ".fusions.tsv"
     seconds = []
+    pipeline.finish_ahead(finish_ahead)  # (as in the timed steps)
     pipeline.submit(prefix + ".bam")
     for k in range(steps + 1):  # (the first one is warm-up; the samples in a queue, as in the timed steps)
         if k == 1:
@@ -226,6 +227,7 @@ def deflated_leg(pipeline, directory, fragments, stress, stored_output, steps=2)
         seconds.append(time.perf_counter() - started)
     pipeline.cancel()
     pipeline.flush()
+    pipeline.finish_ahead(False)
     container_kernels = {}
     for name, ms, size in pipeline.kernel_profile():  # (the launches of the steps, and of the sample that was fed ahead and thrown away: the sums are per fed sample)
         if name.startswith("bgzf_"):
@@ -445,7 +447,7 @@ def main():
         # One GPU per sample: the step is arriba_workflow_sample of the product library (libarriba_workflow.so: the reference's main() in C++ over the two C ABIs, resident session);
         # --python-stages times the ctypes mirror of the same stage order instead (arriba_amd/pipeline.py, what rounds 1-2 timed), as do --host-ingest and one sample over N GPUs
         through_workflow_library = not one_sample and not args.host_ingest and not args.python_stages
-        pipelined, primed = through_workflow_library and not args.no_pipeline, [False]
+        pipelined, primed, finish_ahead = through_workflow_library and not args.no_pipeline, [False], [False]
         if through_workflow_library:
             pipeline = WorkflowSession(prefix + ".fa", prefix + ".gtf", params=params, device=local_rank)
             session = None
@@ -461,6 +463,11 @@ def main():
                 if pipelined:  # a resident service with a queue of samples: the next one is submitted before this one is worked on
                     if not primed[0]:
                         pipeline.defer_output(not args.no_deferred_output)
+                        # the ingest of the next sample finished by its feeder, beside the stages of this one (arriba_workflow_finish_ahead: the lanes keep their batch buffers, ~25 GB
+                        # more at 10^8 fragments): where the device has the memory; ARRIBA_FINISH_AHEAD=0 / 1 say otherwise
+                        knob = os.environ.get("ARRIBA_FINISH_AHEAD")
+                        finish_ahead[0] = (knob == "1") if knob in ("0", "1") else (torch.cuda.get_device_properties(local_rank).total_memory > (250 << 30) and not args.stress)
+                        pipeline.finish_ahead(finish_ahead[0])
                         pipeline.submit(prefix + ".bam")
                         primed[0] = True
                     pipeline.submit(prefix + ".bam")
@@ -556,6 +563,7 @@ def main():
         if pipelined:  # the sample submitted behind the last timed step is thrown away; then one sample alone, for the time from its file to its fusions.tsv when nothing overlaps it
             pipeline.cancel()
             pipeline.defer_output(False)
+            pipeline.finish_ahead(False)
             timed_profile = pipeline.kernel_profile()  # (the launches of the timed steps; the sample alone is profiled on its own)
             pipeline.set_profiling(True)
             primed[0], pipelined = False, False
@@ -676,7 +684,7 @@ def main():
                                           " + discarded.tsv" if args.discarded else ""),
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
-                           "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor; fusions.tsv of a sample is formatted and written by a thread of the session beside the next sample (arriba_workflow_defer_output), the last one complete before the clock stops (arriba_workflow_flush)" if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
+                           "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor; fusions.tsv of a sample is formatted and written by a thread of the session beside the next sample (arriba_workflow_defer_output), the last one complete before the clock stops (arriba_workflow_flush)" + ("; the ingest of a sample is finished by the thread that feeds it, beside the stages of the sample in front (arriba_workflow_finish_ahead)" if finish_ahead[0] else "") if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
                            "parallelism": ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
                                            % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0))) if one_sample
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
@@ -688,7 +696,7 @@ def main():
                 "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
                 "output_side_seconds": getattr(pipeline, "writer_seconds", None),
                 "latency_s": sample_alone["seconds"] if sample_alone else None,  # one sample alone, BAM file -> fusions.tsv, nothing of another sample beside it (`value` is the throughput of samples in a queue)
-                "samples_pipelined": bool(pipelined), "output_deferred": bool(pipelined and not args.no_deferred_output), "deferred_writer_seconds": deferred_writer_seconds, "one_sample_alone": sample_alone,
+                "samples_pipelined": bool(pipelined), "ingest_finished_ahead": bool(finish_ahead[0]), "output_deferred": bool(pipelined and not args.no_deferred_output), "deferred_writer_seconds": deferred_writer_seconds, "one_sample_alone": sample_alone,
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
                 "stages": stage_log,
                 # per step: the sum over the launches of one step (the front of the ingest runs window by window: ~200 launches of its kernels in a step of 10^8 fragments)
@@ -714,7 +722,7 @@ def main():
             progress("self-check done, kernel profile read")
             if through_workflow_library and not distributed and not args.no_deflated_leg:
                 progress("the same sample with deflated BGZF blocks")
-                line["value_deflated"] = deflated_leg(pipeline, directory, args.fragments, args.stress, outputs[0])
+                line["value_deflated"] = deflated_leg(pipeline, directory, args.fragments, args.stress, outputs[0], finish_ahead=finish_ahead[0])
                 if not line["value_deflated"]["fusions_tsv_equals_the_stored_sample's"]:
                     raise SystemExit("bench self-check failed: the deflated sample gives another fusions.tsv than the stored one")
             if through_workflow_library and not distributed and not args.stress and not args.no_normal_pairs:

@@ -227,6 +227,11 @@ typedef struct {
 } agpu_ingest_result;
 void* agpu_host_alloc(size_t bytes);  /* pinned host memory for the pieces (NULL on failure) */
 void agpu_host_free(void* pointer);
+/* A session of two lanes (agpu_create_sibling) hands the buffers of a sample from one lane to the other inside agpu_ingest_finish, when the sibling's sample is done on the device.  With
+ * agpu_keep_batch_buffers(ctx, 1) (both lanes) every lane keeps the columns and pools of its own batch (~25 GB more at 10^8 fragments) and only the buffers of the stages change hands, when
+ * the stages begin (agpu_mark_multimappers): agpu_ingest_finish of the next sample may then run -- on another thread -- while the stages of the current one still do
+ * (arriba_workflow_finish_ahead).  source/arriba.cpp has no counterpart: a resident service is not what the reference is. */
+int agpu_keep_batch_buffers(agpu_ctx* ctx, int on);
 int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config);
 int agpu_ingest_push(agpu_ctx* ctx, const void* bytes, size_t size);
 int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const agpu_bgzf_block* blocks, uint32_t n_blocks, size_t stream_bytes);

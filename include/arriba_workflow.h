@@ -91,6 +91,10 @@ int arriba_workflow_submit(arriba_workflow_session* session, const char* chimeri
  * ahost_detach_sample -- so the feed of the lane's next sample does not wait for it), or
  * arriba_workflow_flush, or arriba_workflow_close; a failure to write it is reported by the next arriba_workflow_sample or by arriba_workflow_flush.  Off by default. */
 int arriba_workflow_defer_output(arriba_workflow_session* session, int on);
+/* round 5: the ingest of a submitted sample is FINISHED by the thread that feeds its file (agpu_ingest_finish + the counters and coverage_t back to the host), beside the stages of the
+ * sample in front, instead of by the arriba_workflow_sample that asks for it: a step of a queue is then max(feed + finish, stages + filter_mismappers + results) instead of
+ * finish + max(feed, ...).  The lanes keep their batch buffers for it (agpu_keep_batch_buffers: ~25 GB more HBM at 10^8 fragments).  Before the first submit; off by default. */
+int arriba_workflow_finish_ahead(arriba_workflow_session* session, int on);
 int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_last_writer /* may be NULL */);
 int arriba_workflow_cancel(arriba_workflow_session* session); /* what was submitted and not yet worked on is thrown away (its feed is waited for first) */
 agpu_ctx* arriba_workflow_device(arriba_workflow_session* session);      /* the device context of the lane that worked on the last sample, e.g. for agpu_get_kernel_profile */

@@ -140,6 +140,7 @@ void emu_default_params(agpu_params* p) {
 }
 emu_ctx* emu_create(int, const agpu_params* params) { emu_ctx* ctx = new emu_ctx(); if (params) ctx->params = *params; else emu_default_params(&ctx->params); memset(ctx->stage_counts, 0, sizeof(ctx->stage_counts)); return ctx; }
 emu_ctx* emu_create_sibling(emu_ctx* of) { return of ? emu_create(0, &of->params) : nullptr; } // (the harness has no scratch buffers to share)
+int emu_keep_batch_buffers(emu_ctx*, int) { return AGPU_OK; } // (... and none to hand from lane to lane: every context of the harness owns its batch)
 void emu_destroy(emu_ctx* ctx) { delete ctx; }
 int emu_set_params(emu_ctx* ctx, const agpu_params* params) { ctx->params = *params; if (ctx->n) build_tables(ctx); return 0; }
 

@@ -2,6 +2,7 @@
 // tools/sanitize_workflow_threads.sh: the feeder of a sample, the writer of the sample two in front of it (from a detached sample of the same host session) and the thread that
 // runs the stages of the sample between them, under ThreadSanitizer.  queue_driver GTF FASTA OUT_PREFIX BAM [BAM ...]
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,6 +18,7 @@ int main(int argc, char** argv) {
 	if (!session) { fprintf(stderr, "%s\n", arriba_workflow_last_error()); return 1; }
 	std::vector<std::string> samples(argv + 4, argv + argc);
 	arriba_workflow_defer_output(session, 1);
+	if (getenv("QUEUE_FINISH_AHEAD") != nullptr && arriba_workflow_finish_ahead(session, 1) != 0) { fprintf(stderr, "%s\n", arriba_workflow_last_error()); return 1; } // (the feeder of a sample also finishes its ingest: one more thing that runs beside the stages)
 	int status = 0;
 	if (arriba_workflow_submit(session, samples[0].c_str()) != 0) status = 1;
 	for (size_t k = 0; k < samples.size() && status == 0; ++k) {

@@ -973,8 +973,8 @@ def test_chain_to_relative_support_without_injected_state(dataset_files, emu_api
 
 
 def check_samples_in_a_queue(mode, tmp_path):
-    """Two different samples of one genome through a resident session, one at a time and in a queue (arriba_workflow_submit): the same files; the order rule and
-    arriba_workflow_cancel behave as include/arriba_workflow.h says."""
+    """Two different samples of one genome through a resident session, one at a time and in a queue (arriba_workflow_submit), with the last files deferred and with the ingest finished
+    ahead by the feeder (arriba_workflow_finish_ahead): the same files; the order rule and arriba_workflow_cancel behave as include/arriba_workflow.h says."""
     import json
     arguments = ["--seed", "11", "--fragments", "3000", "--contigs", "4", "--contig-len", "300000", "--junctions", "60"]
     for k, read_seed in ((1, "0"), (2, "5")):
@@ -989,7 +989,9 @@ def check_samples_in_a_queue(mode, tmp_path):
     assert report["feed_overlapped"]
     assert report["alone1"] != report["alone2"]  # (two different samples)
     read = lambda name: open(str(out / name), "rb").read()
-    for queued, alone in (("queued1", "alone1"), ("queued2", "alone2"), ("queued3", "alone1"), ("queued4", "alone2"), ("deferred1", "alone1"), ("deferred2", "alone2"), ("deferred3", "alone1")):
+    assert report["ahead_ingest_seconds"] == 0  # (the sample was finished by its feeder: nothing of the ingest was left for the call that asked for it)
+    for queued, alone in (("queued1", "alone1"), ("queued2", "alone2"), ("queued3", "alone1"), ("queued4", "alone2"), ("deferred1", "alone1"), ("deferred2", "alone2"), ("deferred3", "alone1"),
+                          ("ahead1", "alone1"), ("ahead2", "alone2"), ("ahead3", "alone1"), ("ahead4", "alone1"), ("ahead5", "alone2")):
         assert report[queued] == report[alone], queued
         assert read(queued + ".tsv") == read(alone + ".tsv") and read(queued + ".discarded.tsv") == read(alone + ".discarded.tsv"), queued
     assert len(read("alone1.tsv").splitlines()) > 5

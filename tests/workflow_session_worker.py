@@ -60,6 +60,23 @@ result["deferred2"] = session.sample(bam2, path("deferred2.tsv"), path("deferred
 result["deferred3"] = session.sample(bam1, path("deferred3.tsv"), path("deferred3.discarded.tsv"))
 session.flush()
 session.defer_output(False)
+# arriba_workflow_finish_ahead: the feeder of a sample also finishes its ingest, beside the stages of the sample in front (and with the last files deferred: three threads at work)
+session.finish_ahead(True)
+session.defer_output(True)
+session.submit(bam1)
+session.submit(bam2)
+result["ahead1"] = session.sample(bam1, path("ahead1.tsv"), path("ahead1.discarded.tsv"))
+result["ahead_ingest_seconds"] = session.timing["ingest"]
+session.submit(bam1)
+result["ahead2"] = session.sample(bam2, path("ahead2.tsv"), path("ahead2.discarded.tsv"))
+result["ahead3"] = session.sample(bam1, path("ahead3.tsv"), path("ahead3.discarded.tsv"))
+session.flush()
+session.defer_output(False)
+session.submit(bam2)
+session.cancel()  # fed AND finished ahead, never asked for
+result["ahead4"] = session.sample(bam1, path("ahead4.tsv"), path("ahead4.discarded.tsv"))
+session.finish_ahead(False)
+result["ahead5"] = session.sample(bam2, path("ahead5.tsv"), path("ahead5.discarded.tsv"))
 session.submit(bam1)  # left behind: arriba_workflow_close throws it away
 session.close()
 json.dump(result, open(path("result.json"), "w"))

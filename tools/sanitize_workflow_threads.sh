@@ -22,4 +22,9 @@ ARRIBA_FEED_PIECE_MB=1 ARRIBA_WRITER_THREADS=8 ARRIBA_INGEST_THREADS=4 ./queue_t
 SAME=0; for k in 1 2 3; do ARRIBA_FEED_PIECE_MB=1 ./workflow_tsan -x q$k.bam -g d.gtf -a d.fa -o alone$k.tsv -O alone$k.discarded.tsv -X -f blacklist > /dev/null 2>&1 || true; cmp -s alone$k.tsv queued$k.tsv && cmp -s alone$k.discarded.tsv queued$k.discarded.tsv && SAME=$((SAME + 1)); done
 cmp -s f.tsv queued0.tsv && cmp -s disc.tsv queued0.discarded.tsv && SAME=$((SAME + 1))
 echo "queue of 4 samples: ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' queue_log || true); $SAME of 4 samples wrote the files of the sample alone"
+# ... and the same queue with arriba_workflow_finish_ahead (round 5): the feeder of sample k + 1 also finishes its ingest and hands it to the host session while the stages of sample k run
+QUEUE_FINISH_AHEAD=1 ARRIBA_FEED_PIECE_MB=1 ARRIBA_WRITER_THREADS=8 ARRIBA_INGEST_THREADS=4 ./queue_tsan d.gtf d.fa $WORK/ahead d.bam q1.bam q2.bam q3.bam > ahead_log 2>&1 || echo "queue_driver (finish ahead) failed: $(tail -2 ahead_log)"
+SAME=0; for k in 1 2 3; do cmp -s alone$k.tsv ahead$k.tsv && cmp -s alone$k.discarded.tsv ahead$k.discarded.tsv && SAME=$((SAME + 1)); done
+cmp -s f.tsv ahead0.tsv && cmp -s disc.tsv ahead0.discarded.tsv && SAME=$((SAME + 1))
+echo "queue of 4 samples, ingest finished ahead: ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' ahead_log || true); $SAME of 4 samples wrote the files of the sample alone"
 rm -rf $WORK
