@@ -75,8 +75,9 @@ void take_sample_buffers(agpu_ctx* ctx, bool batch_group, bool stage_group) {
 		&ctx->contig[0], &ctx->contig[1], &ctx->contig[2], &ctx->start[0], &ctx->start[1], &ctx->start[2], &ctx->end[0], &ctx->end[1], &ctx->end[2], &ctx->abits[0], &ctx->abits[1], &ctx->abits[2],
 		&ctx->cigar_offset[0], &ctx->cigar_offset[1], &ctx->cigar_offset[2], &ctx->cigar_count[0], &ctx->cigar_count[1], &ctx->cigar_count[2], &ctx->cigar_pool, &ctx->seq_offset[0], &ctx->seq_offset[1],
 		&ctx->seq_length[0], &ctx->seq_length[1], &ctx->seq_pool, &ctx->gene_count[0], &ctx->gene_count[1], &ctx->gene_count[2], &ctx->genes[0], &ctx->genes[1], &ctx->genes[2], &ctx->gene_pool,
-		&ctx->names, &ctx->name_offset, &ctx->ingest_qname_keys, &ctx->gather_ids, &ctx->gather_cigar_base, &ctx->gather_seq_base, &ctx->gather_name_base, &ctx->cand_closest1, &ctx->cand_closest2,
-		&ctx->unmapped_keys, &ctx->sort_scratch, &ctx->sorted_keys, &ctx->scan_flags, &ctx->scan_ids, &ctx->viral_pairs, &ctx->duplicate_keys, &ctx->duplicate_slots, &ctx->duplicate_entries,
+		&ctx->names, &ctx->name_offset, &ctx->ingest_qname_keys, &ctx->gather_ids, &ctx->gather_cigar_base, &ctx->gather_seq_base, &ctx->gather_name_base, &ctx->unmapped_keys, &ctx->viral_pairs,
+		/* (up to here: what agpu_ingest_finish and finish_batch_setup fill -- the batch group of take_sample_buffers; from here on: the buffers of the stages) */ &ctx->cand_closest1, &ctx->cand_closest2,
+		&ctx->sort_scratch, &ctx->sorted_keys, &ctx->scan_flags, &ctx->scan_ids, &ctx->duplicate_keys, &ctx->duplicate_slots, &ctx->duplicate_entries,
 		&ctx->sample_flags, &ctx->sample_values, &ctx->samples, &ctx->emissions, &ctx->discordant_swapped,
 		&ctx->cand_gene1, &ctx->cand_gene2, &ctx->cand_contigs, &ctx->cand_breakpoint1, &ctx->cand_breakpoint2, &ctx->cand_flags, &ctx->cand_filter, &ctx->cand_split_reads1, &ctx->cand_split_reads2, &ctx->cand_discordant_mates,
 		&ctx->cand_anchor1, &ctx->cand_anchor2, &ctx->cand_list_offset, &ctx->cand_read_lists, &ctx->cand_evalue, &ctx->cand_iteration_rank, &ctx->cand_votes, &ctx->cand_first_occurrence, &ctx->cand_extra_split_list,
@@ -85,8 +86,9 @@ void take_sample_buffers(agpu_ctx* ctx, bool batch_group, bool stage_group) {
 		&from->contig[0], &from->contig[1], &from->contig[2], &from->start[0], &from->start[1], &from->start[2], &from->end[0], &from->end[1], &from->end[2], &from->abits[0], &from->abits[1], &from->abits[2],
 		&from->cigar_offset[0], &from->cigar_offset[1], &from->cigar_offset[2], &from->cigar_count[0], &from->cigar_count[1], &from->cigar_count[2], &from->cigar_pool, &from->seq_offset[0], &from->seq_offset[1],
 		&from->seq_length[0], &from->seq_length[1], &from->seq_pool, &from->gene_count[0], &from->gene_count[1], &from->gene_count[2], &from->genes[0], &from->genes[1], &from->genes[2], &from->gene_pool,
-		&from->names, &from->name_offset, &from->ingest_qname_keys, &from->gather_ids, &from->gather_cigar_base, &from->gather_seq_base, &from->gather_name_base, &from->cand_closest1, &from->cand_closest2,
-		&from->unmapped_keys, &from->sort_scratch, &from->sorted_keys, &from->scan_flags, &from->scan_ids, &from->viral_pairs, &from->duplicate_keys, &from->duplicate_slots, &from->duplicate_entries,
+		&from->names, &from->name_offset, &from->ingest_qname_keys, &from->gather_ids, &from->gather_cigar_base, &from->gather_seq_base, &from->gather_name_base, &from->unmapped_keys, &from->viral_pairs,
+		/* (up to here: what agpu_ingest_finish and finish_batch_setup fill -- the batch group of take_sample_buffers; from here on: the buffers of the stages) */ &from->cand_closest1, &from->cand_closest2,
+		&from->sort_scratch, &from->sorted_keys, &from->scan_flags, &from->scan_ids, &from->duplicate_keys, &from->duplicate_slots, &from->duplicate_entries,
 		&from->sample_flags, &from->sample_values, &from->samples, &from->emissions, &from->discordant_swapped,
 		&from->cand_gene1, &from->cand_gene2, &from->cand_contigs, &from->cand_breakpoint1, &from->cand_breakpoint2, &from->cand_flags, &from->cand_filter, &from->cand_split_reads1, &from->cand_split_reads2, &from->cand_discordant_mates,
 		&from->cand_anchor1, &from->cand_anchor2, &from->cand_list_offset, &from->cand_read_lists, &from->cand_evalue, &from->cand_iteration_rank, &from->cand_votes, &from->cand_first_occurrence, &from->cand_extra_split_list,
@@ -94,7 +96,7 @@ void take_sample_buffers(agpu_ctx* ctx, bool batch_group, bool stage_group) {
 	static_assert(sizeof(mine) == sizeof(theirs), "the same buffers of both contexts");
 	bool any = false;
 	size_t first_of_stage_group = 0;
-	while (mine[first_of_stage_group] != &ctx->gather_ids) ++first_of_stage_group;
+	while (mine[first_of_stage_group] != &ctx->cand_closest1) ++first_of_stage_group;
 	for (size_t k = batch_group ? 0 : first_of_stage_group; k < (stage_group ? sizeof(mine) / sizeof(mine[0]) : first_of_stage_group); ++k) if (theirs[k]->capacity > mine[k]->capacity) { mine[k]->swap(*theirs[k]); any = true; }
 	if (!any) return;
 	// the views of the sibling point at what it gave away: it has no sample until its next ingest (the batch flags only when the batch went: with the stage group alone the sibling
@@ -102,9 +104,10 @@ void take_sample_buffers(agpu_ctx* ctx, bool batch_group, bool stage_group) {
 	if (batch_group) { from->have_batch = false; from->annotated = false; from->stage1_done = false; from->stage2_done = false; from->n = 0; }
 	from->fusions_done = false; from->evalue_done = false; from->iteration_order_done = false;
 	from->kmer_index_done = false; from->have_splice_sites = false; from->genomic_support_marked = false; from->mismapper_jobs_ready = false; from->n_candidates = 0;
-	from->candidates = agpu::CandidateTable(); from->viral_pair_capacity = 0;
+	from->candidates = agpu::CandidateTable();
+	if (batch_group) { from->viral_pair_capacity = 0; ctx->viral_pair_capacity = 0; } // (set again by finish_batch_setup)
 	// ... and what this context kept of its own last sample went with the buffers
-	ctx->have_splice_sites = false; ctx->kmer_index_done = false; ctx->viral_pair_capacity = 0;
+	ctx->have_splice_sites = false; ctx->kmer_index_done = false;
 }
 
 }
