@@ -47,12 +47,15 @@ struct DeviceBuffer {
 		return true;
 	}
 	static bool release_idle_buffers(); // agpu_api.hip; true if anything was given back
+	// a view of a part of another buffer (find_fusions carves its working arrays out of a buffer that is idle at that point): nothing is freed with it
+	bool borrowed = false;
+	void borrow(void* memory, size_t n) { release(); ptr = memory; bytes = n; capacity = n; borrowed = true; }
 	void release() {
 		if (!ptr) return;
-		(void) hipFree(ptr);
-		ptr = nullptr; bytes = 0; capacity = 0;
+		if (!borrowed) (void) hipFree(ptr);
+		ptr = nullptr; bytes = 0; capacity = 0; borrowed = false;
 	}
-	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); }
+	void swap(DeviceBuffer& other) { std::swap(ptr, other.ptr); std::swap(bytes, other.bytes); std::swap(capacity, other.capacity); std::swap(borrowed, other.borrowed); }
 	template <class T> T* as() const { return (T*) ptr; }
 };
 

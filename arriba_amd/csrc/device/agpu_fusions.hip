@@ -525,8 +525,21 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	uint64_t slots = 1024;
 	while (slots < 2ull * M) slots <<= 1;
 	const uint32_t mask = (uint32_t) (slots - 1);
-	DeviceBuffer& table = ctx->scratch("fusions.table"); DeviceBuffer& keys = ctx->scratch("fusions.keys"); DeviceBuffer& sorted_keys = ctx->scratch("fusions.sorted_keys");
-	ALLOC(table, slots * 4); ALLOC(keys, (size_t) M * 8); ALLOC(sorted_keys, (size_t) M * 8);
+	// The working arrays of this function (220 B per emission: 29 GB for the 1.3e8 emissions of 10^8 fragments) are carved out of the buffer that filter_mismappers uses for its
+	// memo tables (agpu_mismappers.hip: 41 GB at the default size), which is idle until then and which nothing of this function outlives: what stays (the candidate table, the
+	// bucket columns and ranges of the implicit lists) has buffers of its own.  On a session with two lanes and the finish ahead (agpu_keep_batch_buffers) this is what lets
+	// 10^8 fragments fit: each lane then holds a batch of its own.
+	DeviceBuffer table, keys, sorted_keys, sorted, heads, candidate_of, rank_in, ranks, fold_in, folds;
+	{
+		struct { DeviceBuffer* view; size_t bytes; } parts[] = { { &table, slots * 4 }, { &keys, (size_t) M * 8 }, { &sorted_keys, (size_t) M * 8 }, { &sorted, (size_t) M * sizeof(FusionEmission) }, { &heads, (size_t) M * 4 },
+			{ &candidate_of, (size_t) M * 4 }, { &rank_in, (size_t) M * sizeof(RankState) }, { &ranks, (size_t) M * sizeof(RankState) }, { &fold_in, (size_t) M * sizeof(CandidateFold) }, { &folds, (size_t) M * sizeof(CandidateFold) } };
+		size_t total = 0;
+		for (auto& part : parts) total += (part.bytes + 255) & ~(size_t) 255;
+		DeviceBuffer& arena = ctx->scratch("mismappers.memo_tables");
+		ALLOC(arena, std::max(total, arena.capacity));
+		size_t at = 0;
+		for (auto& part : parts) { part.view->borrow((uint8_t*) arena.ptr + at, part.bytes); at += (part.bytes + 255) & ~(size_t) 255; }
+	}
 	HIP_CHECK(hipMemsetAsync(table.ptr, 0xFF, slots * 4, s));
 	{ KernelTimer timer(ctx, "candidate_insert_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4)); candidate_insert_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask); }
 	{ KernelTimer timer(ctx, "candidate_resolve_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4 + 8)); candidate_resolve_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, emissions, table.as<uint32_t>(), mask, keys.as<uint64_t>()); }
@@ -534,8 +547,6 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
 	{ KernelTimer timer(ctx, "rocprim::radix_sort_keys(emissions by candidate)", (uint64_t) M * 16);
 	  HIP_CHECK(rocprim::radix_sort_keys(scratch.buffer.ptr, bytes, keys.as<uint64_t>(), sorted_keys.as<uint64_t>(), M, 0, 64, s)); }
-	DeviceBuffer& sorted = ctx->scratch("fusions.sorted"); DeviceBuffer& heads = ctx->scratch("fusions.heads"); DeviceBuffer& candidate_of = ctx->scratch("fusions.candidate_of");
-	ALLOC(sorted, (size_t) M * sizeof(FusionEmission)); ALLOC(heads, (size_t) M * 4); ALLOC(candidate_of, (size_t) M * 4);
 	{ KernelTimer timer(ctx, "gather_sorted_kernel", (uint64_t) M * (8 + 2 * sizeof(FusionEmission) + 4)); gather_sorted_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted_keys.as<uint64_t>(), emissions, sorted.as<FusionEmission>(), heads.as<uint32_t>()); }
 	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, heads.as<uint32_t>(), candidate_of.as<uint32_t>(), M, rocprim::plus<uint32_t>(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
@@ -546,14 +557,11 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	HIP_CHECK(hipStreamSynchronize(s));
 
 	// ---- prefix counts and per-candidate folds
-	DeviceBuffer& rank_in = ctx->scratch("fusions.rank_in"); DeviceBuffer& ranks = ctx->scratch("fusions.ranks"); DeviceBuffer& fold_in = ctx->scratch("fusions.fold_in"); DeviceBuffer& folds = ctx->scratch("fusions.folds");
-	ALLOC(rank_in, (size_t) M * sizeof(RankState)); ALLOC(ranks, (size_t) M * sizeof(RankState));
 	{ KernelTimer timer(ctx, "rank_input_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4 + sizeof(RankState))); rank_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), rank_in.as<RankState>()); }
 	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, rank_in.as<RankState>(), ranks.as<RankState>(), M, RankCombine(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;
 	{ KernelTimer timer(ctx, "rocprim::inclusive_scan(RankCombine)", (uint64_t) M * 2 * sizeof(RankState));
 	  HIP_CHECK(rocprim::inclusive_scan(scratch.buffer.ptr, bytes, rank_in.as<RankState>(), ranks.as<RankState>(), M, RankCombine(), s)); }
-	ALLOC(fold_in, (size_t) M * sizeof(CandidateFold)); ALLOC(folds, (size_t) M * sizeof(CandidateFold));
 	{ KernelTimer timer(ctx, "fold_input_kernel", (uint64_t) M * (sizeof(FusionEmission) + 4 + sizeof(RankState) + sizeof(CandidateFold))); fold_input_kernel<<<grid_for(M), BLOCK, 0, s>>>(M, sorted.as<FusionEmission>(), heads.as<uint32_t>(), ranks.as<RankState>(), threshold, fold_in.as<CandidateFold>()); }
 	HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, fold_in.as<CandidateFold>(), folds.as<CandidateFold>(), M, CandidateCombine(), s));
 	if (scratch.ensure(bytes) != AGPU_OK) return AGPU_ERR_DEVICE;

@@ -584,6 +584,11 @@ def main():
             total_fragments = n
 
         progress("timed steps done: %.2f s per step" % (elapsed / args.steps))
+        try:
+            free_bytes, total_bytes = torch.cuda.mem_get_info(local_rank)
+            hbm_used_gb = round((total_bytes - free_bytes) / 1e9, 1)
+        except Exception:
+            hbm_used_gb = None
         # post-conditions of the last step on the full-size batch (untimed; no oracle involved): a kernel that silently skipped a part of the batch would
         # leave alignments without a gene, or read filter counts that do not add up; the output file must exist and hold the fusions the log counted
         self_check = []
@@ -696,6 +701,7 @@ def main():
                 "read_chimeric_alignments_seconds": {key: round(sum(p.get(key, 0.0) for p in ingest_parts) / len(ingest_parts), 4) for key in ingest_parts[-1]},
                 "output_side_seconds": getattr(pipeline, "writer_seconds", None),
                 "latency_s": sample_alone["seconds"] if sample_alone else None,  # one sample alone, BAM file -> fusions.tsv, nothing of another sample beside it (`value` is the throughput of samples in a queue)
+                "hbm_used_GB": hbm_used_gb,  # (of the device, behind the timed steps: every buffer of the session is grow-only and stays)
                 "samples_pipelined": bool(pipelined), "ingest_finished_ahead": bool(finish_ahead[0]), "output_deferred": bool(pipelined and not args.no_deferred_output), "deferred_writer_seconds": deferred_writer_seconds, "one_sample_alone": sample_alone,
                 "bam_GB_per_s_end_to_end": bam_bytes / mean("total") / 1e9,
                 "stages": stage_log,
