@@ -463,10 +463,12 @@ def main():
                 if pipelined:  # a resident service with a queue of samples: the next one is submitted before this one is worked on
                     if not primed[0]:
                         pipeline.defer_output(not args.no_deferred_output)
-                        # the ingest of the next sample finished by its feeder, beside the stages of this one (arriba_workflow_finish_ahead: the lanes keep their batch buffers, ~25 GB
-                        # more at 10^8 fragments): where the device has the memory; ARRIBA_FINISH_AHEAD=0 / 1 say otherwise
+                        # the ingest of the next sample finished by its feeder, beside the stages of this one (arriba_workflow_finish_ahead: the lanes keep their batch buffers).
+                        # On by itself up to 5e7 fragments on a 288 GB device: 10 M fragments 0.43 -> 0.32 s per step (profiles/r05k_*); at 10^8 it fits (289 of 295 GB in use,
+                        # profiles/r05l_ahead100m.json) but gains nothing -- there the device is busy either way, 2.01 s against 1.99-2.03 s -- and leaves no room for the deflated leg:
+                        # off unless ARRIBA_FINISH_AHEAD=1 asks for it
                         knob = os.environ.get("ARRIBA_FINISH_AHEAD")
-                        finish_ahead[0] = (knob == "1") if knob in ("0", "1") else (torch.cuda.get_device_properties(local_rank).total_memory > (250 << 30) and not args.stress)
+                        finish_ahead[0] = (knob == "1") if knob in ("0", "1") else (torch.cuda.get_device_properties(local_rank).total_memory > (250 << 30) and not args.stress and args.fragments <= 50_000_000)
                         pipeline.finish_ahead(finish_ahead[0])
                         pipeline.submit(prefix + ".bam")
                         primed[0] = True
