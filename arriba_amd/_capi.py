@@ -143,6 +143,11 @@ def bind_device_api(lib, prefix="agpu_"):
         "get_discordant_swapped": (c_int, [ctx, c_void_p]),
         "shard_merge_rccl": (c_int, [ctx, c_void_p, c_uint32, POINTER(IngestResult)]),
         "filter_mismappers_rccl": (c_int, [ctx, c_void_p, c_int32, c_uint32, c_uint32, POINTER(c_uint64), POINTER(c_uint64)]),
+        "rccl_unique_id": (c_int, [c_void_p]),
+        "rccl_join": (c_int, [ctx, c_void_p, c_uint32, c_uint32, POINTER(c_void_p)]),
+        "rccl_leave": (c_int, [c_void_p]),
+        "rccl_all_gather_host": (c_int, [ctx, c_void_p, c_uint32, c_void_p, c_void_p, c_uint64]),
+        "rccl_all_reduce_host": (c_int, [ctx, c_void_p, c_void_p, c_uint64, c_int]),
         "get_filters": (c_int, [ctx, c_void_p]),
         "get_filters_of": (c_int, [ctx, c_void_p, c_uint64, c_void_p]),
         "select_candidates": (c_int, [ctx, c_int, POINTER(c_uint64)]),
@@ -315,7 +320,20 @@ class WorkflowReport(ctypes.Structure):
 
 
 class WorkflowTiming(ctypes.Structure):
-    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format", "feed_read", "feed_push", "feed_total")]
+    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format", "feed_read", "feed_push", "feed_total", "exchange_parts", "exchange_verdicts", "exchange_rows")]
+
+
+WORKFLOW_MAX, WORKFLOW_MIN, WORKFLOW_SUM = 0, 1, 2
+RCCL_ID_BYTES = 128
+ALL_GATHER = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64)
+ALL_REDUCE_INT64 = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_int)
+ALL_REDUCE_MAX_BYTES = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64)
+
+
+class WorkflowCommunicator(ctypes.Structure):
+    """arriba_workflow_communicator (include/arriba_workflow.h): the ranks of one sample and the three collectives over host memory the driver asks its caller for"""
+    _fields_ = [("rank", c_uint32), ("size", c_uint32), ("state", c_void_p), ("all_gather", ALL_GATHER), ("all_reduce_int64", ALL_REDUCE_INT64), ("all_reduce_max_bytes", ALL_REDUCE_MAX_BYTES),
+                ("rccl_communicator", c_void_p)]
 
 
 _workflow_lib = None
@@ -337,6 +355,9 @@ def workflow_library():
         lib.arriba_workflow_defer_output.argtypes = [c_void_p, c_int]; lib.arriba_workflow_defer_output.restype = c_int
         lib.arriba_workflow_finish_ahead.argtypes = [c_void_p, c_int]; lib.arriba_workflow_finish_ahead.restype = c_int
         lib.arriba_workflow_flush.argtypes = [c_void_p, POINTER(ctypes.c_double)]; lib.arriba_workflow_flush.restype = c_int
+        lib.arriba_workflow_set_communicator.argtypes = [c_void_p, POINTER(WorkflowCommunicator)]; lib.arriba_workflow_set_communicator.restype = c_int
+        lib.arriba_workflow_rccl_unique_id.argtypes = [c_void_p]; lib.arriba_workflow_rccl_unique_id.restype = c_int
+        lib.arriba_workflow_join_rccl.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32]; lib.arriba_workflow_join_rccl.restype = c_int
         lib.arriba_workflow_device.argtypes = [c_void_p]; lib.arriba_workflow_device.restype = c_void_p
         lib.arriba_workflow_lane_device.argtypes = [c_void_p, c_int]; lib.arriba_workflow_lane_device.restype = c_void_p
         lib.arriba_workflow_host.argtypes = [c_void_p]; lib.arriba_workflow_host.restype = c_void_p

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <rccl/rccl.h>
 #include "agpu_context.hpp"
@@ -23,13 +24,17 @@ struct Rccl {
 	ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	const char* (*error_string)(ncclResult_t) = nullptr;
+	ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
+	ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
 	bool load() {
 		if (all_reduce != nullptr) return true;
 		void* library = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
 		if (library == nullptr) library = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
 		if (library == nullptr) { set_last_error(std::string("librccl.so not found: ") + dlerror()); return false; }
 		all_reduce = (decltype(all_reduce)) dlsym(library, "ncclAllReduce"); all_gather = (decltype(all_gather)) dlsym(library, "ncclAllGather"); error_string = (decltype(error_string)) dlsym(library, "ncclGetErrorString");
-		if (all_reduce == nullptr || all_gather == nullptr) { set_last_error("librccl.so lacks ncclAllReduce / ncclAllGather"); all_reduce = nullptr; return false; }
+		get_unique_id = (decltype(get_unique_id)) dlsym(library, "ncclGetUniqueId"); comm_init_rank = (decltype(comm_init_rank)) dlsym(library, "ncclCommInitRank"); comm_destroy = (decltype(comm_destroy)) dlsym(library, "ncclCommDestroy");
+		if (all_reduce == nullptr || all_gather == nullptr || get_unique_id == nullptr || comm_init_rank == nullptr || comm_destroy == nullptr) { set_last_error("librccl.so lacks ncclAllReduce / ncclAllGather / ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy"); all_reduce = nullptr; return false; }
 		return true;
 	}
 	int check(ncclResult_t status, const char* what) const {
@@ -84,4 +89,72 @@ extern "C" int agpu_filter_mismappers_rccl(agpu_ctx* ctx, void* nccl_comm, int32
 	if (n_jobs > 0) TRY(g_rccl.check(g_rccl.all_reduce(verdicts.ptr, verdicts.ptr, n_jobs, ncclUint8, ncclMax, (ncclComm_t) nccl_comm, s), "ncclAllReduce(verdicts)"));
 	HIP_CHECK(hipStreamSynchronize(s));
 	return agpu_filter_mismappers_apply(ctx, verdicts.as<uint8_t>(), remaining, discarded_reads);
+}
+
+// ---- a communicator of RCCL alone for the hosts that have none (the C++ driver: include/arriba_workflow.h, arriba_workflow_join_rccl): the id of rank 0 travels by whatever
+// started the ranks (an environment variable, a file, torch.distributed's store), every rank joins with it; the small exchanges of the driver (sizes, status words, the texts
+// of the rows) are host memory bounced through a buffer of the context
+
+static_assert(sizeof(ncclUniqueId) == AGPU_RCCL_ID_BYTES, "include/arriba_gpu.h: AGPU_RCCL_ID_BYTES");
+
+extern "C" int agpu_rccl_unique_id(uint8_t* id) {
+	if (!id) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (!g_rccl.load()) return AGPU_ERR_DEVICE;
+	ncclUniqueId unique;
+	TRY(g_rccl.check(g_rccl.get_unique_id(&unique), "ncclGetUniqueId"));
+	memcpy(id, &unique, sizeof(unique));
+	return AGPU_OK;
+}
+
+extern "C" int agpu_rccl_join(agpu_ctx* ctx, const uint8_t* id, uint32_t rank, uint32_t n_ranks, void** nccl_comm) {
+	if (!ctx || !id || !nccl_comm || n_ranks == 0 || rank >= n_ranks) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (!g_rccl.load()) return AGPU_ERR_DEVICE;
+	HIP_CHECK(hipSetDevice(ctx->device));
+	ncclUniqueId unique;
+	memcpy(&unique, id, sizeof(unique));
+	ncclComm_t comm = nullptr;
+	TRY(g_rccl.check(g_rccl.comm_init_rank(&comm, (int) n_ranks, unique, (int) rank), "ncclCommInitRank"));
+	*nccl_comm = comm;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_rccl_leave(void* nccl_comm) {
+	if (!nccl_comm) return AGPU_OK;
+	if (!g_rccl.load()) return AGPU_ERR_DEVICE;
+	return g_rccl.check(g_rccl.comm_destroy((ncclComm_t) nccl_comm), "ncclCommDestroy");
+}
+
+extern "C" int agpu_rccl_all_gather_host(agpu_ctx* ctx, void* nccl_comm, uint32_t n_ranks, const void* mine, void* all, uint64_t bytes) {
+	if (!ctx || !nccl_comm || n_ranks == 0 || (bytes > 0 && (!mine || !all))) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (bytes == 0) return AGPU_OK;
+	if (!g_rccl.load()) return AGPU_ERR_DEVICE;
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	DeviceBuffer& bounce = ctx->scratch("rccl.bounce");
+	ALLOC(bounce, (size_t) (n_ranks + 1) * bytes);
+	uint8_t* sent = bounce.as<uint8_t>() + (size_t) n_ranks * bytes;
+	HIP_CHECK(hipMemcpyAsync(sent, mine, bytes, hipMemcpyHostToDevice, s));
+	TRY(g_rccl.check(g_rccl.all_gather(sent, bounce.ptr, bytes, ncclUint8, (ncclComm_t) nccl_comm, s), "ncclAllGather(host bytes)"));
+	HIP_CHECK(hipMemcpyAsync(all, bounce.ptr, (size_t) n_ranks * bytes, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if ((size_t) (n_ranks + 1) * bytes > ((size_t) 64 << 20)) bounce.release(); // (the texts of a large discarded.tsv: not kept)
+	return AGPU_OK;
+}
+
+extern "C" int agpu_rccl_all_reduce_host(agpu_ctx* ctx, void* nccl_comm, void* values, uint64_t count, int kind) {
+	if (!ctx || !nccl_comm || (count > 0 && !values) || kind < AGPU_REDUCE_MAX_INT64 || kind > AGPU_REDUCE_MAX_BYTES) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	if (count == 0) return AGPU_OK;
+	if (!g_rccl.load()) return AGPU_ERR_DEVICE;
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const size_t bytes = (size_t) count * (kind == AGPU_REDUCE_MAX_BYTES ? 1 : 8);
+	DeviceBuffer& bounce = ctx->scratch("rccl.bounce");
+	ALLOC(bounce, bytes);
+	HIP_CHECK(hipMemcpyAsync(bounce.ptr, values, bytes, hipMemcpyHostToDevice, s));
+	const ncclDataType_t type = kind == AGPU_REDUCE_MAX_BYTES ? ncclUint8 : ncclInt64;
+	const ncclRedOp_t operation = kind == AGPU_REDUCE_MIN_INT64 ? ncclMin : kind == AGPU_REDUCE_SUM_INT64 ? ncclSum : ncclMax;
+	TRY(g_rccl.check(g_rccl.all_reduce(bounce.ptr, bounce.ptr, count, type, operation, (ncclComm_t) nccl_comm, s), "ncclAllReduce(host values)"));
+	HIP_CHECK(hipMemcpyAsync(values, bounce.ptr, bytes, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	return AGPU_OK;
 }

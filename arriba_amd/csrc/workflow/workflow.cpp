@@ -4,6 +4,7 @@
 // the tests and the bench.
 #include "../../../include/arriba_workflow.h"
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -32,6 +33,22 @@ void host_check(int status) { if (status != 0) throw Failure{ std::string("ERROR
 enum { F_known_fusions = 18, F_blacklist = 20, F_no_genomic_support = 29, F_genomic_support = 34, F_many_spliced = 28, F_select_best = 24 };
 
 double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// One sample over several ranks: in front of every collective the ranks tell each other how they fared, so that an error on one of them (a damaged block in its part of the
+// file, no memory) ends the call on all of them with a message instead of leaving the others waiting in an all-gather (arriba_amd/one_sample.py: _together)
+void exchange_check(int status, const char* what) { if (status != 0) throw Failure{ std::string("ERROR: the exchange between the ranks failed (") + what + ")" }; }
+template <class Work> void together(const arriba_workflow_communicator* ranks, Work work) {
+	if (ranks == nullptr) { work(); return; }
+	std::string problem;
+	try { work(); }
+	catch (const Failure& failure) { problem = failure.text; }
+	catch (const std::exception& e) { problem = std::string("ERROR: ") + e.what(); }
+	int64_t ok = problem.empty() ? 1 : 0;
+	const int status = ranks->all_reduce_int64(ranks->state, &ok, 1, ARRIBA_WORKFLOW_MIN);
+	if (!problem.empty()) throw Failure{ problem };
+	exchange_check(status, "status of the ranks");
+	if (ok == 0) throw Failure{ "ERROR: another rank of the sample failed (its own message says why)" };
+}
 
 // A session (arriba_workflow_open): what is loaded once, and what a sample leaves behind for the next one.  `options` points at copies of the caller's strings.
 struct Run {
@@ -64,6 +81,9 @@ struct Run {
 	std::vector<uint16_t> writer_gene_contig; std::vector<int32_t> writer_gene_start, writer_gene_end;
 	void join_writer() { if (writer.joinable()) writer.join(); }
 	bool tags_loaded = false, domains_loaded = false;
+	// one sample over the ranks of a job (arriba_workflow_set_communicator): the session's communicator, or null; what the exchanges of the sample at work took
+	const arriba_workflow_communicator* ranks = nullptr;
+	double exchange_parts = 0, exchange_verdicts = 0, exchange_rows = 0;
 	// Host memory for what comes back from the device per sample (candidate columns, rows of supporting reads): pinned, kept by the session and only ever grown -- fresh
 	// std::vectors of some hundred MB per sample are zeroed page by page and given back to the system again, which costs more than the transfer they hold.
 	struct Staged { void* pointer = nullptr; size_t capacity = 0; };
@@ -162,7 +182,8 @@ void feed_file(Run& run) {
 	const double started = now_seconds();
 	run.feed_started = started;
 	agpu_ingest_config config;
-	host_check(ahost_bam_open(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length, &config));
+	if (run.ranks != nullptr) host_check(ahost_bam_open_part(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length, run.ranks->rank, run.ranks->size, &config)); // this rank's part of the records
+	else host_check(ahost_bam_open(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length, &config));
 	run.bam_open = true;
 	struct Closer { Run& run; bool armed; ~Closer() { if (armed && run.bam_open) { ahost_bam_close(run.host); run.bam_open = false; } } } closer = { run, true }; // (on every way out but the last line)
 	run.coverage_windows = config.n_contigs ? config.coverage_window_offset[config.n_contigs] : 0; // (the table belongs to the session: read before anything else touches it)
@@ -223,21 +244,47 @@ void feed_file(Run& run) {
 	closer.armed = false; // (finish_device_ingest closes the file)
 }
 
+// One sample over several ranks: every rank has ingested its part of the records; ONE all-gather puts the batch of the whole sample on every rank (include/arriba_gpu.h:
+// agpu_shard_export / agpu_shard_merge: fragments concatenate in name order, counters and coverage_t add up before saturation).  In device memory when the ranks hold an RCCL
+// communicator, through the callbacks in host memory otherwise.  `result` becomes that of the whole sample.
+void exchange_parts(Run& run, agpu_ingest_result& result) {
+	const arriba_workflow_communicator& ranks = *run.ranks;
+	const double started = now_seconds();
+	if (ranks.rccl_communicator != nullptr) { // (size all-reduce, export, all-gather and merge in one call: a failure inside it is told behind it)
+		together(run.ranks, [&] { device_check(agpu_shard_merge_rccl(run.device, ranks.rccl_communicator, ranks.size, &result)); });
+		run.exchange_parts = now_seconds() - started;
+		return;
+	}
+	uint64_t bytes = 0;
+	together(run.ranks, [&] { device_check(agpu_shard_export_size(run.device, &bytes)); });
+	int64_t widest = (int64_t) bytes; // the blocks travel at the stride of the largest part
+	exchange_check(ranks.all_reduce_int64(ranks.state, &widest, 1, ARRIBA_WORKFLOW_MAX), "size of the parts");
+	const uint64_t stride = ((uint64_t) widest + 15) & ~(uint64_t) 15;
+	std::unique_ptr<uint8_t[]> mine, all;
+	together(run.ranks, [&] { mine.reset(new uint8_t[stride]); all.reset(new uint8_t[(size_t) ranks.size * stride]); memset(mine.get(), 0, stride); device_check(agpu_shard_export(run.device, mine.get(), stride)); });
+	exchange_check(ranks.all_gather(ranks.state, mine.get(), all.get(), stride), "parts of the sample");
+	together(run.ranks, [&] { device_check(agpu_shard_merge(run.device, all.get(), stride, ranks.size, &result)); });
+	run.exchange_parts = now_seconds() - started;
+}
+
 // ... and what is left of read_chimeric_alignments behind the last piece (agpu_ingest_finish), the counters, coverage_t and viral read counts back to the host session
 void finish_device_ingest(Run& run, double waited_since) {
 	struct Closer { Run& run; ~Closer() { if (run.bam_open) { ahost_bam_close(run.host); run.bam_open = false; } } } closer = { run };
 	const uint64_t windows = run.coverage_windows; const uint32_t n_contigs = run.bam_contigs;
 	const double fed = now_seconds();
 	agpu_ingest_result result;
-	device_check(agpu_ingest_finish(run.device, &result));
+	together(run.ranks, [&] { device_check(agpu_ingest_finish(run.device, &result)); });
+	if (run.ranks != nullptr) exchange_parts(run, result);
 	if (run.after_ingest) run.after_ingest();
 	const double finished = now_seconds();
-	std::vector<uint64_t> viral(n_contigs > 0 ? n_contigs : 1);
-	std::vector<uint16_t> coverage(windows > 0 ? windows : 1);
-	std::vector<uint8_t> starts(coverage.size()), ends(coverage.size());
-	device_check(agpu_get_viral_read_counts(run.device, viral.data()));
-	device_check(agpu_get_coverage(run.device, coverage.data(), starts.data(), ends.data()));
-	host_check(ahost_adopt_device_ingest(run.host, &result, viral.data(), coverage.data(), starts.data(), ends.data()));
+	together(run.ranks, [&] {
+		std::vector<uint64_t> viral(n_contigs > 0 ? n_contigs : 1);
+		std::vector<uint16_t> coverage(windows > 0 ? windows : 1);
+		std::vector<uint8_t> starts(coverage.size()), ends(coverage.size());
+		device_check(agpu_get_viral_read_counts(run.device, viral.data()));
+		device_check(agpu_get_coverage(run.device, coverage.data(), starts.data(), ends.data()));
+		host_check(ahost_adopt_device_ingest(run.host, &result, viral.data(), coverage.data(), starts.data(), ends.data()));
+	});
 	run.n_fragments = result.fragments;
 	run.ingest_records = result.records; run.ingest_stream_bytes = result.stream_bytes; run.ingest_fed = fed; run.ingest_finished = finished; run.ingest_adopted = now_seconds();
 	(void) waited_since;
@@ -299,22 +346,68 @@ void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discar
 	if (profile) fprintf(stderr, "[rows] %llu rows, %llu CIGAR words, %llu sequence bytes, %llu name bytes\n", (unsigned long long) count, (unsigned long long) cigar_words, (unsigned long long) sequence_bytes, (unsigned long long) name_bytes);
 }
 
+// One sample over several ranks: the rows of a file are independent of each other (the fusion transcripts from the pileups of the supporting reads are the expensive part), so
+// rank r formats the rows r, r + size, r + 2 size, ... (ahost_format_fusions; the header line in front of the rows of rank 0), the texts are gathered and rank 0 writes row k of
+// the file from the text of rank k % size.  (An all-gather: the collectives a caller must supply are few; the texts of fusions.tsv are a few megabytes.)
+void write_file_over_ranks(Run& run, const ahost_fusion_table& table, const char* path, int write_discarded, int print_extra_info, int32_t max_mate_gap) {
+	const arriba_workflow_communicator& ranks = *run.ranks;
+	const char* text = nullptr; uint64_t bytes = 0;
+	together(run.ranks, [&] { host_check(ahost_format_fusions(run.host, &table, write_discarded, print_extra_info, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps, ranks.rank, ranks.size, &text, &bytes)); });
+	const double before = now_seconds();
+	std::vector<int64_t> sizes(ranks.size, 0);
+	sizes[ranks.rank] = (int64_t) bytes;
+	exchange_check(ranks.all_reduce_int64(ranks.state, sizes.data(), ranks.size, ARRIBA_WORKFLOW_SUM), "sizes of the row texts");
+	uint64_t width = 1;
+	for (uint32_t r = 0; r < ranks.size; ++r) width = std::max<uint64_t>(width, (uint64_t) sizes[r]);
+	std::vector<char> mine, all;
+	together(run.ranks, [&] { mine.assign(width, 0); all.resize((size_t) ranks.size * width); if (bytes > 0) memcpy(mine.data(), text, bytes); });
+	exchange_check(ranks.all_gather(ranks.state, mine.data(), all.data(), width), "texts of the rows");
+	run.exchange_rows += now_seconds() - before;
+	together(run.ranks, [&] {
+		if (ranks.rank != 0) return;
+		FILE* out = fopen(path, "wb");
+		if (!out) throw Failure{ std::string("ERROR: failed to open output file '") + path + "'" };
+		struct Closer { FILE* file; ~Closer() { if (file) fclose(file); } } closer = { out };
+		std::vector<const char*> at(ranks.size), end(ranks.size);
+		for (uint32_t r = 0; r < ranks.size; ++r) { at[r] = all.data() + (size_t) r * width; end[r] = at[r] + sizes[r]; }
+		bool ok = true;
+		auto write_line = [&](uint32_t r) { // the next line of the text of rank r (every line ends with a newline); false: there is none
+			if (at[r] >= end[r]) return false;
+			const char* stop = (const char*) memchr(at[r], '\n', (size_t) (end[r] - at[r]));
+			const size_t length = stop ? (size_t) (stop - at[r]) + 1 : (size_t) (end[r] - at[r]);
+			ok = ok && fwrite(at[r], 1, length, out) == length;
+			at[r] += length;
+			return true;
+		};
+		write_line(0); // the header
+		for (uint64_t row = 0; write_line((uint32_t) (row % ranks.size)); ++row) {}
+		for (uint32_t r = 0; r < ranks.size; ++r) if (at[r] < end[r]) throw Failure{ "ERROR: the rows of the ranks do not interleave (a rank formatted more rows than its turn)" };
+		closer.file = nullptr;
+		if (fclose(out) != 0 || !ok) throw Failure{ std::string("ERROR: failed to write output file '") + path + "'" };
+	});
+}
+
 // the output files: the device's results brought back, formatted by the host library (source/arriba.cpp:586-610).  Only the candidates a file will hold
 // travel: fusions.tsv holds the few thousand that passed every filter, of millions -- they are picked on the device (agpu_select_candidates), with their read lists, the
 // rows of their supporting reads and the filters of those.  discarded.tsv (-O) counts the discarded reads of every discarded candidate by filter: the same call, more rows.
 void write_output_files(Run& run, int32_t max_mate_gap) {
 	double mark = now_seconds();
 	auto lap = [&](double arriba_workflow_timing::* part) { const double now = now_seconds(); if (run.timing) run.timing->*part += now - mark; mark = now; };
-	device_check(agpu_assign_confidence(run.device, nullptr)); // behind the 'isoforms' filter: recovered isoforms are scored anew
-	device_check(agpu_candidate_iteration_order(run.device, nullptr));
 	const uint32_t n_genes = ahost_annotation_view(run.host)->n_genes + run.dummy_genes;
 	std::vector<uint16_t>& gene_contig = run.writer_gene_contig; std::vector<int32_t>& gene_start = run.writer_gene_start; std::vector<int32_t>& gene_end = run.writer_gene_end;
+	together(run.ranks, [&] {
+	device_check(agpu_assign_confidence(run.device, nullptr)); // behind the 'isoforms' filter: recovered isoforms are scored anew
+	device_check(agpu_candidate_iteration_order(run.device, nullptr));
 	gene_contig.assign(n_genes > 0 ? n_genes : 1, 0); gene_start.assign(gene_contig.size(), 0); gene_end.assign(gene_contig.size(), 0);
 	device_check(agpu_get_gene_table(run.device, 0, n_genes, gene_contig.data(), gene_start.data(), gene_end.data(), nullptr, nullptr));
 	if (run.options.tags_file && !run.tags_loaded) { run.say(std::string("Loading tags from '") + run.options.tags_file + "'"); host_check(ahost_load_tags(run.host, run.options.tags_file)); run.tags_loaded = true; } // (once per session)
 	if (run.options.protein_domains_file && !run.domains_loaded) { run.say(std::string("Loading protein domains from '") + run.options.protein_domains_file + "'"); host_check(ahost_load_protein_domains(run.host, run.options.protein_domains_file)); run.domains_loaded = true; }
+	});
 
 	for (int write_discarded = 0; write_discarded <= (run.options.discarded_output_file ? 1 : 0); ++write_discarded) {
+		ahost_fusion_table table;
+		const int print_extra_info = write_discarded ? run.options.print_extra_info_for_discarded_fusions : 1;
+		together(run.ranks, [&] { // (several ranks: every rank holds the same candidates and fetches the same rows; what differs is which rows it formats)
 		uint64_t w = 0;
 		device_check(agpu_select_candidates(run.device, write_discarded, &w));
 		agpu_selected_candidates columns;
@@ -330,7 +423,6 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 		device_check(agpu_get_candidate_read_lists_of(run.device, columns.candidate, w, list_offset, nullptr, 0, &total));
 		uint32_t* read_lists = run.stage<uint32_t>("table.read_lists", total);
 		if (total > 0) device_check(agpu_get_candidate_read_lists_of(run.device, columns.candidate, w, list_offset, read_lists, total, &total));
-		ahost_fusion_table table;
 		memset(&table, 0, sizeof(table));
 		table.n_candidates = (uint32_t) w;
 		table.gene1 = columns.gene1; table.gene2 = columns.gene2; table.contigs = columns.contigs; table.breakpoint1 = columns.breakpoint1; table.breakpoint2 = columns.breakpoint2; table.flags = columns.flags; table.filter = columns.filter;
@@ -338,7 +430,6 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 		table.evalue = columns.evalue; table.confidence = columns.confidence; table.iteration_rank = columns.iteration_rank;
 		table.closest_genomic_breakpoint1 = columns.closest_genomic_breakpoint1; table.closest_genomic_breakpoint2 = columns.closest_genomic_breakpoint2;
 		table.n_genes = n_genes; table.gene_contig = gene_contig.data(); table.gene_start = gene_start.data(); table.gene_end = gene_end.data();
-		const int print_extra_info = write_discarded ? run.options.print_extra_info_for_discarded_fusions : 1;
 		if (write_discarded) run.say(std::string("Writing discarded fusions to file '") + run.options.discarded_output_file + "'");
 		else run.say(std::string("Writing fusions to file '") + run.options.output_file + "' ");
 		const bool rows_from_device = print_extra_info && run.device_ingest;
@@ -351,6 +442,12 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 		if (rows_from_device) fetch_rows_for_writer(run, table, write_discarded, write_discarded == 0);
 		lap(&arriba_workflow_timing::output_rows);
 		if (run.before_host_writer) run.before_host_writer();
+		});
+		if (run.ranks != nullptr) { // rank r formats the rows r, r + size, ... of the file; rank 0 gathers the texts, puts the rows back in order and writes
+			write_file_over_ranks(run, table, write_discarded ? run.options.discarded_output_file : run.options.output_file, write_discarded, print_extra_info, max_mate_gap);
+			lap(&arriba_workflow_timing::output_format);
+			continue;
+		}
 		const bool last_file = write_discarded == (run.options.discarded_output_file ? 1 : 0);
 		if (run.defer_output && last_file) { // nothing of this file is on the device any more: formatted and written beside the next sample
 			const std::string path = write_discarded ? run.options.discarded_output_file : run.options.output_file;
@@ -381,6 +478,27 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 		host_check(ahost_write_fusions(run.host, &table, write_discarded ? run.options.discarded_output_file : run.options.output_file, write_discarded, print_extra_info, run.options.device.max_itd_length, max_mate_gap, run.options.fill_sequence_gaps));
 		lap(&arriba_workflow_timing::output_format);
 	}
+}
+
+// filter_mismappers (source/filter_mismappers.cpp:272-359) over the ranks that hold the same batch: the re-alignments are independent per read -- rank r takes the jobs
+// r, r + size, ... of the list every rank builds alike --, ONE all-reduce (max) of the verdict bytes, then every rank discards the reads and judges the candidates
+void filter_mismappers_over_ranks(Run& run, int32_t max_mate_gap, uint64_t* remaining, uint64_t* discarded_reads) {
+	const arriba_workflow_communicator& ranks = *run.ranks;
+	if (ranks.rccl_communicator != nullptr) { // (jobs, verdicts, all-reduce in device memory and apply in one call)
+		together(run.ranks, [&] { device_check(agpu_filter_mismappers_rccl(run.device, ranks.rccl_communicator, max_mate_gap, ranks.rank, ranks.size, remaining, discarded_reads)); });
+		return;
+	}
+	uint64_t n_jobs = 0;
+	std::vector<uint8_t> verdicts;
+	together(run.ranks, [&] {
+		device_check(agpu_mismapper_jobs(run.device, &n_jobs));
+		verdicts.assign(n_jobs > 0 ? n_jobs : 1, 0);
+		device_check(agpu_mismapper_verdicts(run.device, max_mate_gap, ranks.rank, ranks.size, verdicts.data()));
+	});
+	const double before = now_seconds();
+	if (n_jobs > 0) exchange_check(ranks.all_reduce_max_bytes(ranks.state, verdicts.data(), n_jobs), "verdicts of filter_mismappers");
+	run.exchange_verdicts = now_seconds() - before;
+	together(run.ranks, [&] { device_check(agpu_filter_mismappers_apply(run.device, verdicts.data(), remaining, discarded_reads)); });
 }
 
 // what main() does once per process: assembly, annotation, index (source/arriba.cpp:97-113); the device context with the annotation in HBM
@@ -417,12 +535,14 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 	if (!o.chimeric_bam_file || !o.output_file) throw Failure{ "ERROR: assembly, gene annotation, alignments and output file are required" };
 	if (run.timing) memset(run.timing, 0, sizeof(*run.timing));
 	agpu_params& params = run.params;
+	run.exchange_parts = run.exchange_verdicts = run.exchange_rows = 0;
 	if (run.device_ingest) {
-		if (!already_fed) feed_file(run);
+		if (!already_fed) together(run.ranks, [&] { feed_file(run); });
 		if (!(already_fed && run.ingest_finished_ahead)) finish_device_ingest(run, sample_started);
 		note_device_ingest(run, sample_started);
 	}
 	else {
+		if (run.ranks != nullptr) throw Failure{ "ERROR: one sample over several ranks needs read_chimeric_alignments on the device (host_ingest = 0): the parts of the batch are exchanged in device format" };
 		host_check(ahost_ingest_bam_file(run.host, o.chimeric_bam_file, o.device.external_duplicate_marking, o.device.max_itd_length));
 		device_check(agpu_upload_genome(run.device, ahost_genome_view(run.host)));
 		device_check(agpu_upload_batch(run.device, ahost_batch_view(run.host)));
@@ -435,8 +555,11 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 	const double stages_started = now_seconds();
 	double mismappers_seconds = 0;
 
+	// (one sample over several ranks: every rank holds the whole batch by now and runs the stages up to filter_homologs on it -- identical inputs, identical kernels, nothing to
+	// exchange; how the ranks fared is told once behind them, in front of the exchange of filter_mismappers)
+	uint64_t count = 0, discarded_reads = 0; int32_t max_mate_gap = 0;
+	together(run.ranks, [&] {
 	// :141-325 multi-mappers, strandedness, annotation
-	uint64_t count = 0;
 	device_check(agpu_mark_multimappers(run.device, &count)); run.note("mark_multimappers", count);
 	if (o.device.strandedness <= 2) params.strandedness = o.device.strandedness;
 	else if (run.device_ingest) { int verdict = 0; device_check(agpu_detect_strandedness(run.device, &verdict)); params.strandedness = (uint8_t) verdict; }
@@ -460,7 +583,7 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 	std::vector<int32_t> mate_gaps(100001);
 	uint32_t n_samples = 0; uint64_t visited = 0;
 	device_check(agpu_fragment_length_samples(run.device, mate_gaps.data(), &n_samples, &visited));
-	float mate_gap_mean = 0, mate_gap_stddev = 0, read_length_mean = 0; int32_t max_mate_gap = 0;
+	float mate_gap_mean = 0, mate_gap_stddev = 0, read_length_mean = 0;
 	if (run.device_ingest) { // the sequential float sum of the read lengths (hazard H4) stays on the host, over the lengths of the fragments the reference's loop visits
 		const uint64_t count = visited < run.n_fragments ? visited : run.n_fragments;
 		std::vector<uint32_t> length1(count > 0 ? count : 1), length2(length1.size());
@@ -500,7 +623,7 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 		device_check(agpu_mark_genomic_support(run.device, variants, n_variants, o.max_genomic_breakpoint_distance, &count)); run.note("mark_genomic_support", count);
 	}
 	device_check(agpu_merge_adjacent_fusions(run.device, 5, &count)); run.note("merge_adjacent_fusions", count);
-	uint64_t discarded_reads = 0, discarded[3];
+	uint64_t discarded[3];
 	device_check(agpu_filter_multimappers(run.device, &count, &discarded_reads)); run.note("filter_multimappers", count);
 	device_check(agpu_candidate_iteration_order(run.device, nullptr)); // hazard H2: the order in which the reference's container is walked, kept on the device
 	run.say("Estimating expected number of fusions by random chance (e-value) ");
@@ -541,19 +664,26 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 	run.say("Indexing gene sequences ");
 	device_check(agpu_make_kmer_index(run.device, (int32_t) ((float) max_mate_gap + 2.0f * read_length_mean), &n_positions));
 	device_check(agpu_filter_homologs(run.device, o.max_homolog_identity, &count)); run.note("filter_homologs", count);
-	{ const double before = now_seconds(); device_check(agpu_filter_mismappers(run.device, max_mate_gap, &count, &discarded_reads)); mismappers_seconds = now_seconds() - before; }
+	});
+	{ const double before = now_seconds();
+	  if (run.ranks != nullptr) filter_mismappers_over_ranks(run, max_mate_gap, &count, &discarded_reads);
+	  else device_check(agpu_filter_mismappers(run.device, max_mate_gap, &count, &discarded_reads));
+	  mismappers_seconds = now_seconds() - before; }
 	run.note("filter_mismappers", count);
+	together(run.ranks, [&] {
 	// :567-584
 	if (o.genomic_breakpoints_file && run.enabled(F_genomic_support)) { device_check(agpu_recover_genomic_support(run.device, &count)); run.note("recover_genomic_support", count); }
 	if ((o.genomic_breakpoints_file && run.enabled(F_genomic_support)) || run.enabled(F_many_spliced)) { device_check(agpu_select_most_supported_breakpoints(run.device, &count)); run.note("select_most_supported_breakpoints", count); }
 	device_check(agpu_recover_isoforms(run.device, &count)); run.note("recover_isoforms", count);
 	run.say("Assigning confidence scores to events ");
+	});
 	const double output_started = now_seconds();
 	write_output_files(run, max_mate_gap);
 	if (run.timing) {
 		const double finished = now_seconds();
 		run.timing->filter_mismappers = mismappers_seconds; run.timing->stages = output_started - stages_started - mismappers_seconds;
 		run.timing->output = finished - output_started; run.timing->total = finished - sample_started;
+		run.timing->exchange_parts = run.exchange_parts; run.timing->exchange_verdicts = run.exchange_verdicts; run.timing->exchange_rows = run.exchange_rows;
 	}
 }
 
@@ -600,6 +730,11 @@ struct arriba_workflow_session {
 	bool ingest_busy = false; // a lane is between agpu_ingest_begin and agpu_ingest_finish
 	bool defer_output = false;
 	bool finish_ahead = false; // arriba_workflow_finish_ahead: the feeder of a sample also finishes its ingest (the lanes keep their batch buffers)
+	// arriba_workflow_set_communicator / arriba_workflow_join_rccl: one sample over the ranks of a job; `joined`: the RCCL communicator this session made itself (and the state of
+	// its callbacks: host bytes bounced through the device of lane 0)
+	arriba_workflow_communicator communicator; bool over_ranks = false;
+	struct Joined { agpu_ctx* device = nullptr; void* comm = nullptr; uint32_t size = 0; } joined;
+	void leave() { if (joined.comm != nullptr) { agpu_rccl_leave(joined.comm); joined.comm = nullptr; } over_ranks = false; for (int k = 0; k < 2; ++k) if (lanes[k]) lanes[k]->ranks = nullptr; }
 	std::string deferred_error; // of a writer that was joined on the way (reported by the next arriba_workflow_sample / arriba_workflow_flush)
 	double deferred_seconds = 0; // the writer joined last
 	std::mutex writer_mutex; // (a writer is joined by the thread that calls the session or by the feeder of the lane's next sample)
@@ -615,6 +750,7 @@ struct arriba_workflow_session {
 	arriba_workflow_session(const arriba_workflow_options& o) { lanes[0] = new Run(o); lanes[1] = nullptr; }
 	~arriba_workflow_session() {
 		drain();
+		leave();
 		delete lanes[1]; delete lanes[0]; // (the sibling first: either order is allowed)
 	}
 	// the feeds in flight are waited for and thrown away
@@ -649,6 +785,7 @@ struct arriba_workflow_session {
 			if (!second->device) throw Failure{ std::string("ERROR: ") + agpu_last_error() };
 			device_check(agpu_upload_annotation(second->device, ahost_annotation_view(second->host)));
 			second->options.log_to_stdout = lanes[0]->options.log_to_stdout;
+			second->ranks = lanes[0]->ranks;
 			lanes[1] = second.release();
 		}
 		Run& run = *lanes[lane];
@@ -667,7 +804,7 @@ struct arriba_workflow_session {
 			run.ingest_finished_ahead = false;
 			try {
 				feed_file(run);
-				if (finish_ahead) { // what is left of read_chimeric_alignments behind the last piece, here and now: the stages of the sample in front may still run on the other lane
+				if (finish_ahead && !over_ranks) { // what is left of read_chimeric_alignments behind the last piece, here and now: the stages of the sample in front may still run on the other lane
 					finish_device_ingest(run, now_seconds());
 					run.ingest_finished_ahead = true;
 					{ std::lock_guard<std::mutex> lock(mutex); mine->ingest_finished = true; }
@@ -715,7 +852,7 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 		run.output_path = output_file; run.discarded_path = discarded_output_file ? discarded_output_file : "";
 		run.options.output_file = run.output_path.c_str(); run.options.discarded_output_file = discarded_output_file ? run.discarded_path.c_str() : nullptr;
 		run.report = report; run.timing = timing;
-		run.defer_output = session->defer_output;
+		run.defer_output = session->defer_output && !session->over_ranks;
 		const int other = 1 - sample.lane;
 		run.before_host_writer = [session, other] { session->join_writer_of(other); };
 		// (advisor, round 4: nothing may throw between here and `done` -- the clean-up behind the catch blocks clears the lane's options, which the feeder of this sample reads
@@ -727,7 +864,7 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 			session.abandon(sample, *session.lanes[sample.lane]); // (nothing to do behind a sample that went through)
 			{ std::lock_guard<std::mutex> lock(session.mutex); session.queue.pop_front(); }
 			session.changed.notify_all(); } } done = { *session };
-		if (!sample.error.empty()) throw Failure{ sample.error };
+		together(run.ranks, [&] { if (!sample.error.empty()) throw Failure{ sample.error }; }); // (the feed of this rank's part)
 		run.after_ingest = [session, &sample] { { std::lock_guard<std::mutex> lock(session->mutex); sample.ingest_finished = true; } session->release_ingest(); };
 		run_sample(run, run.device_ingest, sample_started);
 		// an I/O error on the deferred file of an EARLIER sample is reported behind this one: this sample has gone through and its own files are as they should be (its last
@@ -752,6 +889,43 @@ int arriba_workflow_finish_ahead(arriba_workflow_session* session, int on) {
 	if (agpu_keep_batch_buffers(session->lanes[0]->device, on) != 0) { g_error = std::string("ERROR: ") + agpu_last_error(); return -1; } // (both lanes, also the one made later: agpu_create_sibling copies the flag)
 	session->finish_ahead = on != 0;
 	return 0;
+}
+int arriba_workflow_set_communicator(arriba_workflow_session* session, const arriba_workflow_communicator* communicator) {
+	if (!session) { g_error = "ERROR: null argument"; return -1; }
+	if (!session->queue.empty()) { g_error = "ERROR: arriba_workflow_set_communicator: samples are submitted already"; return -1; }
+	session->join_writer_of(0); session->join_writer_of(1);
+	session->leave();
+	if (communicator == nullptr) return 0;
+	if (communicator->size == 0 || communicator->rank >= communicator->size || !communicator->all_gather || !communicator->all_reduce_int64 || !communicator->all_reduce_max_bytes) { g_error = "ERROR: arriba_workflow_set_communicator: rank, size and the three collectives are required"; return -1; }
+	if (session->lanes[0]->options.host_ingest) { g_error = "ERROR: one sample over several ranks needs read_chimeric_alignments on the device (host_ingest = 0)"; return -1; }
+	session->communicator = *communicator;
+	session->over_ranks = true;
+	for (int k = 0; k < 2; ++k) if (session->lanes[k]) session->lanes[k]->ranks = &session->communicator;
+	return 0;
+}
+int arriba_workflow_rccl_unique_id(unsigned char* id) {
+	if (agpu_rccl_unique_id(id) != AGPU_OK) { g_error = std::string("ERROR: ") + agpu_last_error(); return -1; }
+	return 0;
+}
+int arriba_workflow_join_rccl(arriba_workflow_session* session, const unsigned char* id, uint32_t rank, uint32_t size) {
+	if (!session || !id) { g_error = "ERROR: null argument"; return -1; }
+	if (!session->queue.empty()) { g_error = "ERROR: arriba_workflow_join_rccl: samples are submitted already"; return -1; }
+	session->leave();
+	arriba_workflow_session::Joined& joined = session->joined;
+	joined.device = session->lanes[0]->device; joined.size = size;
+	if (agpu_rccl_join(joined.device, id, rank, size, &joined.comm) != AGPU_OK) { g_error = std::string("ERROR: ") + agpu_last_error(); joined.comm = nullptr; return -1; }
+	typedef arriba_workflow_session::Joined Joined;
+	arriba_workflow_communicator communicator;
+	communicator.rank = rank; communicator.size = size; communicator.state = &joined; communicator.rccl_communicator = joined.comm;
+	communicator.all_gather = [](void* state, const void* mine, void* all, uint64_t bytes) -> int { Joined& j = *(Joined*) state; return agpu_rccl_all_gather_host(j.device, j.comm, j.size, mine, all, bytes); };
+	communicator.all_reduce_int64 = [](void* state, int64_t* values, uint64_t count, int operation) -> int { Joined& j = *(Joined*) state;
+		return agpu_rccl_all_reduce_host(j.device, j.comm, values, count, operation == ARRIBA_WORKFLOW_MIN ? AGPU_REDUCE_MIN_INT64 : operation == ARRIBA_WORKFLOW_SUM ? AGPU_REDUCE_SUM_INT64 : AGPU_REDUCE_MAX_INT64); };
+	communicator.all_reduce_max_bytes = [](void* state, uint8_t* values, uint64_t count) -> int { Joined& j = *(Joined*) state; return agpu_rccl_all_reduce_host(j.device, j.comm, values, count, AGPU_REDUCE_MAX_BYTES); };
+	void* comm = joined.comm; joined.comm = nullptr; // (set_communicator starts with leave())
+	const int status = arriba_workflow_set_communicator(session, &communicator);
+	joined.comm = comm;
+	if (status != 0) { agpu_rccl_leave(comm); joined.comm = nullptr; }
+	return status;
 }
 int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_last_writer) {
 	if (!session) { g_error = "ERROR: null argument"; return -1; }

@@ -165,6 +165,72 @@ class WorkflowSession(object):
         if self._lib.arriba_workflow_finish_ahead(self._session, int(on)) != 0:
             raise ArribaError(self._lib.arriba_workflow_last_error().decode())
 
+    def over_ranks(self, group=None):
+        """One sample over the ranks of `group` (arriba_workflow_set_communicator, include/arriba_workflow.h): `sample` becomes a collective call -- every rank feeds its part of
+        the file, one all-gather of the parts, the stages on every rank, filter_mismappers and the rows of the output files shared out, rank 0 writes.  The three collectives
+        over host memory the C++ driver asks for are torch.distributed's (gloo in the CPU tests; with the nccl backend the host bytes go through tensors on this rank's GPU)."""
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        rank, size = dist.get_rank(group), dist.get_world_size(group)
+        device = torch.device("cuda", self.options.device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+        def host_array(pointer, count, dtype):
+            return np.ctypeslib.as_array(ctypes.cast(pointer, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
+
+        def guarded(work):  # an exception must not cross the C frames above a callback: the driver is told with a status and ends the call on every rank
+            def call(*arguments):
+                try:
+                    work(*arguments)
+                    return 0
+                except Exception as problem:
+                    self.exchange_error = problem
+                    return 1
+            return call
+
+        def all_gather(state, mine, everybody, n_bytes):
+            if n_bytes == 0:
+                return
+            sent = torch.from_numpy(host_array(mine, n_bytes, np.uint8)).to(device)
+            parts = [torch.empty(n_bytes, dtype=torch.uint8, device=device) for _ in range(size)]
+            dist.all_gather(parts, sent, group=group)
+            received = host_array(everybody, size * n_bytes, np.uint8)
+            for r in range(size):
+                received[r * n_bytes:(r + 1) * n_bytes] = parts[r].cpu().numpy()
+
+        def all_reduce_int64(state, values, count, operation):
+            array = host_array(values, count, np.int64)
+            tensor = torch.from_numpy(array.copy()).to(device)
+            dist.all_reduce(tensor, op={_capi.WORKFLOW_MAX: dist.ReduceOp.MAX, _capi.WORKFLOW_MIN: dist.ReduceOp.MIN, _capi.WORKFLOW_SUM: dist.ReduceOp.SUM}[operation], group=group)
+            array[:] = tensor.cpu().numpy()
+
+        def all_reduce_max_bytes(state, values, count):
+            array = host_array(values, count, np.uint8)
+            tensor = torch.from_numpy(array.copy()).to(device)
+            dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group)
+            array[:] = tensor.cpu().numpy()
+
+        self.exchange_error = None
+        self._communicator = _capi.WorkflowCommunicator(rank, size, None, _capi.ALL_GATHER(guarded(all_gather)), _capi.ALL_REDUCE_INT64(guarded(all_reduce_int64)),
+                                                        _capi.ALL_REDUCE_MAX_BYTES(guarded(all_reduce_max_bytes)), None)  # (kept: the session calls into it)
+        if self._lib.arriba_workflow_set_communicator(self._session, byref(self._communicator)) != 0:
+            raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        self.rank, self.world = rank, size
+
+    def join_rccl(self, unique_id, rank, size):
+        """One sample over `size` GPUs with RCCL alone (arriba_workflow_join_rccl): `unique_id` = rccl_unique_id() of rank 0, brought to every rank by whatever started them; the
+        parts of the batch and the verdicts of filter_mismappers travel in device memory, sizes, status words and row texts are bounced through the device."""
+        buffer = (ctypes.c_ubyte * _capi.RCCL_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        if self._lib.arriba_workflow_join_rccl(self._session, buffer, rank, size) != 0:
+            raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        self.rank, self.world = rank, size
+
+    def rccl_unique_id(self):
+        buffer = (ctypes.c_ubyte * _capi.RCCL_ID_BYTES)()
+        if self._lib.arriba_workflow_rccl_unique_id(buffer) != 0:
+            raise ArribaError(self._lib.arriba_workflow_last_error().decode())
+        return bytes(buffer)
+
     def defer_output(self, on=True):
         """the last output file of a sample is written by a thread of the session while the next sample is worked on (complete behind flush())"""
         self._lib.arriba_workflow_defer_output(self._session, int(on))

@@ -279,6 +279,18 @@ int agpu_shard_merge(agpu_ctx* ctx, const void* blocks, uint64_t stride, uint32_
  * time (dlopen).  Compositions of the entry points above; not exercised in round 2 (RCCL needs one GPU per rank). */
 int agpu_shard_merge_rccl(agpu_ctx* ctx, void* nccl_comm, uint32_t n_ranks, agpu_ingest_result* result);
 int agpu_filter_mismappers_rccl(agpu_ctx* ctx, void* nccl_comm, int32_t max_mate_gap, uint32_t rank, uint32_t n_ranks, uint64_t* remaining, uint64_t* discarded_reads);
+/* ... and a communicator of RCCL alone, for a host that has none (the C++ driver: arriba_workflow_join_rccl, include/arriba_workflow.h).  agpu_rccl_unique_id on one rank
+ * (ncclGetUniqueId: AGPU_RCCL_ID_BYTES bytes that reach the other ranks by whatever started them), agpu_rccl_join on every rank (ncclCommInitRank on the device of the
+ * context; *nccl_comm is what the two calls above take), agpu_rccl_leave at the end.  The small exchanges of a driver -- sizes, status words, the texts of the rows of the
+ * output files -- are host memory: agpu_rccl_all_gather_host (`bytes` of every rank, in rank order, into all[n_ranks * bytes]) and agpu_rccl_all_reduce_host (in place;
+ * kind: AGPU_REDUCE_*) bounce them through a buffer of the context on its stream. */
+#define AGPU_RCCL_ID_BYTES 128
+enum { AGPU_REDUCE_MAX_INT64 = 0, AGPU_REDUCE_MIN_INT64 = 1, AGPU_REDUCE_SUM_INT64 = 2, AGPU_REDUCE_MAX_BYTES = 3 };
+int agpu_rccl_unique_id(uint8_t* id /* [AGPU_RCCL_ID_BYTES] */);
+int agpu_rccl_join(agpu_ctx* ctx, const uint8_t* id, uint32_t rank, uint32_t n_ranks, void** nccl_comm);
+int agpu_rccl_leave(void* nccl_comm);
+int agpu_rccl_all_gather_host(agpu_ctx* ctx, void* nccl_comm, uint32_t n_ranks, const void* mine, void* all, uint64_t bytes);
+int agpu_rccl_all_reduce_host(agpu_ctx* ctx, void* nccl_comm, void* values, uint64_t count, int kind);
 
 /* restore the batch to its state right after agpu_upload_batch (filters, strands and gene sets cleared) so that the stages can be run again */
 int agpu_reset(agpu_ctx* ctx);

@@ -75,6 +75,9 @@ typedef struct { /* seconds of one sample, by part (wall clock of the calling th
 	double feed_push;        /* of feed: inside agpu_ingest_push* (enqueue the copy, wait for the copy before it, move the windows of the ingest on) */
 	double feed_total;       /* the feed from the moment the file was opened to the last piece, wherever it ran: a sample submitted ahead is fed under the stages of the sample before,
 	                            and `feed` is then only what arriba_workflow_sample still had to wait for */
+	double exchange_parts;   /* one sample over several ranks (arriba_workflow_set_communicator): the parts of the batch exported, all-gathered and merged */
+	double exchange_verdicts;/*   ... the all-reduce of the verdicts of filter_mismappers (inside filter_mismappers above) */
+	double exchange_rows;    /*   ... the texts of the rows of the output file(s) gathered (inside output_format above) */
 } arriba_workflow_timing;
 /* options->chimeric_bam_file, output_file and discarded_output_file are not used by open (they belong to a sample); NULL + arriba_workflow_last_error() on failure */
 arriba_workflow_session* arriba_workflow_open(const arriba_workflow_options* options);
@@ -96,6 +99,35 @@ int arriba_workflow_defer_output(arriba_workflow_session* session, int on);
  * finish + max(feed, ...).  The lanes keep their batch buffers for it (agpu_keep_batch_buffers: ~25 GB more HBM at 10^8 fragments).  Before the first submit; off by default. */
 int arriba_workflow_finish_ahead(arriba_workflow_session* session, int on);
 int arriba_workflow_flush(arriba_workflow_session* session, double* seconds_of_last_writer /* may be NULL */);
+
+/* ---- one sample over the ranks of a job: one process per GPU, every rank with a session of its own over the same reference files (SURVEY.md section 8 row e; BASELINE.json
+ * config 4).  With a communicator set, arriba_workflow_sample is a collective call -- every rank calls it with the same file names -- and does what one rank does, shared out:
+ *   read_chimeric_alignments   rank r feeds and ingests part r of the records of the file (ahost_bam_open_part: cut between read names at places every rank finds by itself);
+ *                              ONE all-gather of the parts (agpu_shard_export -> all-gather -> agpu_shard_merge): every rank then holds the batch of the whole sample, bit for bit
+ *                              what a single ingest builds (fragments concatenate in name order, counters and coverage_t add up before saturation)
+ *   the stages                 on every rank over the whole batch: identical inputs, identical kernels, no exchange
+ *   filter_mismappers          rank r re-aligns the jobs r, r + size, ... (agpu_mismapper_verdicts), ONE all-reduce (max) of the verdict bytes, agpu_filter_mismappers_apply
+ *   the output files           rank r formats the rows r, r + size, ... (ahost_format_fusions), the texts are gathered and rank 0 writes the file(s)
+ * A failure on one rank (a damaged block in its part of the file, no memory) ends the call on all of them: in front of every collective the ranks tell each other how they fared.
+ * The transport is the caller's: three collectives over HOST memory as callbacks (torch.distributed with gloo in the CPU tests, MPI, ...), each returning 0 or non-zero; and,
+ * if the ranks hold an RCCL communicator over their GPUs, `rccl_communicator` (ncclComm_t): the two large exchanges -- the parts of the batch, 22 GB at 10^8 fragments, and the
+ * verdicts -- then stay in device memory (agpu_shard_merge_rccl, agpu_filter_mismappers_rccl) and only sizes, status words and row texts go through the callbacks.
+ * arriba_workflow_join_rccl makes such a communicator out of RCCL alone (callbacks included: host bytes bounced through the device): rank 0 calls arriba_workflow_rccl_unique_id, the
+ * id reaches the other ranks by whatever started them, every rank joins.  With a communicator the session works on one sample at a time on the calling thread's schedule:
+ * arriba_workflow_submit still feeds the next sample's part ahead, arriba_workflow_defer_output and arriba_workflow_finish_ahead are ignored (their threads would issue collectives
+ * in an order of their own).  Before the first submit / sample; NULL takes the communicator away again. */
+enum { ARRIBA_WORKFLOW_MAX = 0, ARRIBA_WORKFLOW_MIN = 1, ARRIBA_WORKFLOW_SUM = 2 };
+typedef struct {
+	uint32_t rank, size;
+	void* state;                                                                                   /* handed to the callbacks */
+	int (*all_gather)(void* state, const void* mine, void* all /* [size * bytes] */, uint64_t bytes);   /* `bytes` of every rank, in rank order */
+	int (*all_reduce_int64)(void* state, int64_t* values, uint64_t count, int operation);          /* element-wise over the ranks, in place; ARRIBA_WORKFLOW_MAX / MIN / SUM */
+	int (*all_reduce_max_bytes)(void* state, uint8_t* values, uint64_t count);                     /* element-wise maximum over the ranks, in place */
+	void* rccl_communicator;                                                                       /* ncclComm_t of the ranks' GPUs, or NULL */
+} arriba_workflow_communicator;
+int arriba_workflow_set_communicator(arriba_workflow_session* session, const arriba_workflow_communicator* communicator);
+int arriba_workflow_rccl_unique_id(unsigned char* id /* [AGPU_RCCL_ID_BYTES] */);
+int arriba_workflow_join_rccl(arriba_workflow_session* session, const unsigned char* id, uint32_t rank, uint32_t size);
 int arriba_workflow_cancel(arriba_workflow_session* session); /* what was submitted and not yet worked on is thrown away (its feed is waited for first) */
 agpu_ctx* arriba_workflow_device(arriba_workflow_session* session);      /* the device context of the lane that worked on the last sample, e.g. for agpu_get_kernel_profile */
 agpu_ctx* arriba_workflow_lane_device(arriba_workflow_session* session, int lane); /* lane 0 or 1; NULL if the lane does not exist (yet) */

@@ -142,6 +142,15 @@ emu_ctx* emu_create(int, const agpu_params* params) { emu_ctx* ctx = new emu_ctx
 emu_ctx* emu_create_sibling(emu_ctx* of) { return of ? emu_create(0, &of->params) : nullptr; } // (the harness has no scratch buffers to share)
 int emu_keep_batch_buffers(emu_ctx*, int) { return AGPU_OK; } // (... and none to hand from lane to lane: every context of the harness owns its batch)
 void emu_destroy(emu_ctx* ctx) { delete ctx; }
+// (RCCL is the device library's: a workflow driver built over the harness is given a communicator of host collectives -- arriba_workflow_set_communicator -- and never gets here)
+static int no_rccl() { g_error = "the stepping harness has no RCCL: hand the session a communicator of host collectives (arriba_workflow_set_communicator)"; return AGPU_ERR_INVALID; }
+int emu_shard_merge_rccl(emu_ctx*, void*, uint32_t, agpu_ingest_result*) { return no_rccl(); }
+int emu_filter_mismappers_rccl(emu_ctx*, void*, int32_t, uint32_t, uint32_t, uint64_t*, uint64_t*) { return no_rccl(); }
+int emu_rccl_unique_id(uint8_t*) { return no_rccl(); }
+int emu_rccl_join(emu_ctx*, const uint8_t*, uint32_t, uint32_t, void**) { return no_rccl(); }
+int emu_rccl_leave(void*) { return AGPU_OK; }
+int emu_rccl_all_gather_host(emu_ctx*, void*, uint32_t, const void*, void*, uint64_t) { return no_rccl(); }
+int emu_rccl_all_reduce_host(emu_ctx*, void*, void*, uint64_t, int) { return no_rccl(); }
 int emu_set_params(emu_ctx* ctx, const agpu_params* params) { ctx->params = *params; if (ctx->n) build_tables(ctx); return 0; }
 
 int emu_upload_annotation(emu_ctx* ctx, const agpu_annotation_view* in) {

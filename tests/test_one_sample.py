@@ -110,3 +110,54 @@ def test_an_error_on_one_rank_ends_the_run_on_all(dataset_files, emu_api, tmp_pa
     assert "failed to load alignments" in reports[2]["error"], reports[2]  # (the rank in front of it may meet the block, too, when it looks for the end of its part)
     assert "another rank of the sample failed" in reports[0]["error"], reports[0]
     assert all("error" in report for report in reports)
+
+
+def run_workflow_over_ranks(mode, prefix, world, out, port, bams=None, plain=False, environment=None):
+    """tests/workflow_ranks_worker.py under torch.distributed.run: arriba_workflow_sample of the C++ driver as a collective call of `world` ranks"""
+    os.makedirs(out, exist_ok=True)
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "tests", "workflow_ranks_worker.py"), mode, prefix + ".fa", prefix + ".gtf", out] + (bams or [prefix + ".bam"])
+    result = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=1500,
+                            env=dict(os.environ, **(dict({"WORKFLOW_RANKS_PLAIN": "1"} if plain else {}, **(environment or {})))))
+    assert result.returncode == 0, result.stdout[-3000:]
+    reports = [json.load(open(os.path.join(out, "rank%d.json" % rank))) for rank in range(world)]
+    for report in reports:
+        assert "error" not in report, report["error"]
+    return reports
+
+
+def check_workflow_over_ranks(mode, prefix, world, tmp_path, port, samples=1):
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libworkflow_on_harness.so"], check=True)
+    bams = [prefix + ".bam"] * samples
+    alone = run_workflow_over_ranks(mode, prefix, 1, str(tmp_path / "alone"), port, bams[:1], plain=True)[0]
+    reports = run_workflow_over_ranks(mode, prefix, world, str(tmp_path / "ranks"), port + 1, bams)
+    read = lambda directory, name: open(str(tmp_path / directory / name), "rb").read()
+    assert len(read("alone", "sample0.tsv").splitlines()) > 3 and len(read("alone", "sample0.discarded.tsv").splitlines()) > 100
+    for report in reports:
+        assert len(report["samples"]) == samples
+        for sample in report["samples"]:
+            assert "error" not in sample, sample["error"]
+            assert sample["report"] == alone["samples"][0]["report"]  # every "(remaining=N)" of the log, on every rank
+            assert sample["exchange_parts"] > 0
+    for k in range(samples):  # rank 0 wrote the files: byte for byte those of one rank
+        assert read("ranks", "sample%d.tsv" % k) == read("alone", "sample0.tsv")
+        assert read("ranks", "sample%d.discarded.tsv" % k) == read("alone", "sample0.discarded.tsv")
+    return reports
+
+
+@pytest.mark.parametrize("world,name,samples", [(2, "toy3k", 3), (3, "homologs8k", 1), (4, "mid30k", 1), (3, "scrambled3k", 2)])
+def test_workflow_library_over_ranks_writes_the_files_of_one_rank(world, name, samples, dataset_files, built, emu_api, tmp_path):
+    """The C++ driver as a collective call (include/arriba_workflow.h: arriba_workflow_set_communicator; the collectives are torch.distributed's, gloo): every rank feeds and
+    ingests its part of the records, ONE all-gather of the parts, the stages on every rank, the re-alignments of filter_mismappers and the rows of the output files shared out --
+    fusions.tsv and discarded.tsv of rank 0 and the counts of every stage on every rank equal those of one rank without a communicator; with several samples in a queue
+    (the part of the next file fed beside the stages of the current one)."""
+    check_workflow_over_ranks("harness", dataset_files(name), world, tmp_path, 29760 + 4 * world + (2 if name == "scrambled3k" else 0), samples)
+
+
+def test_a_failure_on_one_rank_ends_the_sample_on_all_ranks(dataset_files, built, emu_api, tmp_path):
+    """rank 1 cannot read its part of the file (a path that does not exist there): its message on rank 1, "another rank of the sample failed" on rank 0, nobody left waiting in a collective"""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libworkflow_on_harness.so"], check=True)
+    prefix = dataset_files("toy3k")
+    reports = run_workflow_over_ranks("harness", prefix, 2, str(tmp_path / "ranks"), 29795, [prefix + ".bam"], environment={"WORKFLOW_RANKS_BREAK_RANK": "1"})
+    assert "another rank of the sample failed" in reports[0]["samples"][0]["error"]
+    assert "error" in reports[1]["samples"][0] and "another rank" not in reports[1]["samples"][0]["error"]
