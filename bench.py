@@ -446,11 +446,20 @@ def main():
         stage_log, step_seconds, ingest_parts, steps_done, all_steps = [], [], [], [0], []
         # One GPU per sample: the step is arriba_workflow_sample of the product library (libarriba_workflow.so: the reference's main() in C++ over the two C ABIs, resident session);
         # --python-stages times the ctypes mirror of the same stage order instead (arriba_amd/pipeline.py, what rounds 1-2 timed), as do --host-ingest and one sample over N GPUs
-        through_workflow_library = not one_sample and not args.host_ingest and not args.python_stages
+        # (round 5: also with --gpus N -- the same call of the same library is timed at N = 1 and N = 8, arriba_workflow_sample as a collective call over a communicator:
+        # RCCL alone on the GPUs, arriba_workflow_join_rccl; torch.distributed's gloo through callbacks where the harness stands in for the device, tests/bench_on_harness.py)
+        through_workflow_library = not args.host_ingest and not args.python_stages
         pipelined, primed, finish_ahead = through_workflow_library and not args.no_pipeline, [False], [False]
         if through_workflow_library:
             pipeline = WorkflowSession(prefix + ".fa", prefix + ".gtf", params=params, device=local_rank)
             session = None
+            if one_sample:
+                if dist.get_backend() == "nccl":
+                    unique = [pipeline.rccl_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(unique, src=0)
+                    pipeline.join_rccl(unique[0], rank, world)
+                else:
+                    pipeline.over_ranks()
         else:
             session = HostSession(prefix + ".fa", prefix + ".gtf")  # assembly + annotation, once (resident)
         progress("assembly and annotation loaded")
@@ -462,13 +471,13 @@ def main():
             if through_workflow_library:
                 if pipelined:  # a resident service with a queue of samples: the next one is submitted before this one is worked on
                     if not primed[0]:
-                        pipeline.defer_output(not args.no_deferred_output)
+                        pipeline.defer_output(not args.no_deferred_output and not one_sample)
                         # the ingest of the next sample finished by its feeder, beside the stages of this one (arriba_workflow_finish_ahead: the lanes keep their batch buffers).
                         # On by itself up to 5e7 fragments on a 288 GB device: 10 M fragments 0.43 -> 0.32 s per step (profiles/r05k_*); at 10^8 it fits (289 of 295 GB in use,
                         # profiles/r05l_ahead100m.json) but gains nothing -- there the device is busy either way, 2.01 s against 1.99-2.03 s -- and leaves no room for the deflated leg:
                         # off unless ARRIBA_FINISH_AHEAD=1 asks for it
                         knob = os.environ.get("ARRIBA_FINISH_AHEAD")
-                        finish_ahead[0] = (knob == "1") if knob in ("0", "1") else (torch.cuda.get_device_properties(local_rank).total_memory > (250 << 30) and not args.stress and args.fragments <= 50_000_000)
+                        finish_ahead[0] = not one_sample and ((knob == "1") if knob in ("0", "1") else (torch.cuda.get_device_properties(local_rank).total_memory > (250 << 30) and not args.stress and args.fragments <= 50_000_000))
                         pipeline.finish_ahead(finish_ahead[0])
                         pipeline.submit(prefix + ".bam")
                         primed[0] = True
@@ -481,6 +490,8 @@ def main():
                 pipeline.writer_seconds = {key: round(timing[key], 4) for key in ("output_results", "output_rows", "output_format")}
                 stage_log.extend((stage, count, None) for stage, count in report)
                 ingest_parts.append({"feed": timing["feed"], "device": timing["ingest"], "adopt": timing["adopt"], "feed_read": timing.get("feed_read", 0.0), "feed_push": timing.get("feed_push", 0.0), "feed_total": timing.get("feed_total", 0.0)})
+                if one_sample:
+                    ingest_parts[-1].update({"exchange_parts": timing["exchange_parts"], "exchange_verdicts": timing["exchange_verdicts"], "exchange_rows": timing["exchange_rows"]})
                 ingested = started + timing["feed"] + timing["ingest"] + timing["adopt"]
                 step_seconds.append({"ingest": ingested - started, "workflow": finished - ingested, "total": finished - started, "stages": timing["stages"], "filter_mismappers": timing["filter_mismappers"], "output": timing["output"]})
                 if verbose:
@@ -692,8 +703,10 @@ def main():
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
                            "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor; fusions.tsv of a sample is formatted and written by a thread of the session beside the next sample (arriba_workflow_defer_output), the last one complete before the clock stops (arriba_workflow_flush)" + ("; the ingest of a sample is finished by the thread that feeds it, beside the stages of the sample in front (arriba_workflow_finish_ahead)" if finish_ahead[0] else "") if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
-                           "parallelism": ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
-                                           % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0))) if one_sample
+                           "parallelism": (("one sample over %d GPUs in the C++ driver (arriba_workflow_sample as a collective call; %s): every rank ingests its part of the file, one all-gather of the parts (%.3f s with export and merge), the stages on every rank, filter_mismappers shared out (one all-reduce of the verdict bytes), the rows of the files formatted by all ranks, rank 0 writes"
+                                            % (world, "RCCL: arriba_workflow_join_rccl" if dist.get_backend() == "nccl" else "host collectives through arriba_workflow_set_communicator", ingest_parts[-1].get("exchange_parts", 0.0))) if through_workflow_library else
+                                           ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
+                                            % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0)))) if one_sample
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
                            "outside_the_step": "loading assembly + annotation (ahost_open), device context; generating the sample took %.1f s" % generate_seconds,
                            "names_were_sorted": bool(pipeline.ingest_result.names_were_sorted) if pipeline.ingest_result else None,

@@ -241,6 +241,37 @@ def test_one_sample_over_two_ranks_on_one_device(built, dataset_files, tmp_path)
     assert report["mismapper_jobs"] > 0 and report["fusions"] > 0
 
 
+def test_workflow_library_over_two_ranks_on_one_device(built, dataset_files, tmp_path):
+    """The C++ driver as a collective call (include/arriba_workflow.h: arriba_workflow_set_communicator) with the kernels of the GPU: two processes on cuda:0, each with a session
+    of libarriba_workflow.so, feed their halves of the file; the parts, the verdicts of filter_mismappers and the row texts go through the host collectives of the communicator
+    (gloo; RCCL needs a GPU per rank: the next test).  fusions.tsv, discarded.tsv and every stage count equal those of one rank without a communicator; two samples in a queue."""
+    import test_one_sample
+    test_one_sample.check_workflow_over_ranks("product", dataset_files("mid30k"), 2, tmp_path, 29715, samples=2)
+
+
+def test_workflow_library_over_one_rccl_rank(built, dataset_files, tmp_path):
+    """arriba_workflow_join_rccl -- the communicator of RCCL alone that `bench.py --gpus N` gives the C++ driver -- with ONE rank (the GPU box has one GPU): ncclGetUniqueId /
+    ncclCommInitRank by dlopen, the part of the batch through agpu_shard_merge_rccl (ncclAllGather in device memory), the verdicts through agpu_filter_mismappers_rccl, sizes,
+    status words and row texts bounced through the device (agpu_rccl_all_gather_host / _all_reduce_host): the files and counts of the plain session."""
+    from arriba_amd.pipeline import WorkflowSession
+    prefix = dataset_files("mid30k")
+    plain = WorkflowSession(prefix + ".fa", prefix + ".gtf")
+    expected = plain.sample(prefix + ".bam", str(tmp_path / "plain.tsv"), str(tmp_path / "plain.discarded.tsv"))
+    plain.close()
+    session = WorkflowSession(prefix + ".fa", prefix + ".gtf")
+    session.join_rccl(session.rccl_unique_id(), 0, 1)
+    session.submit(prefix + ".bam")
+    for k in range(2):
+        if k == 0:
+            session.submit(prefix + ".bam")
+        report = session.sample(prefix + ".bam", str(tmp_path / ("rccl%d.tsv" % k)), str(tmp_path / ("rccl%d.discarded.tsv" % k)))
+        assert report == expected and session.timing["exchange_parts"] > 0
+        for name in (".tsv", ".discarded.tsv"):
+            assert open(str(tmp_path / ("rccl%d" % k)) + name, "rb").read() == open(str(tmp_path / "plain") + name, "rb").read(), (k, name)
+    session.close()
+    assert len(open(str(tmp_path / "plain.tsv")).read().splitlines()) > 3
+
+
 def test_device_ingest_in_parts_on_the_gpu(built, dataset_files, tmp_path):
     """agpu_shard_export / agpu_shard_merge on the GPU: 3 and 7 parts of a stored-BGZF file and of one with 997-byte blocks, merged from blocks in host memory
     (as a gloo all-gather leaves them) and compared column by column with the ingest of the whole file"""
