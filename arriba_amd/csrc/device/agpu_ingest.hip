@@ -432,53 +432,53 @@ __global__ void __launch_bounds__(BLOCK) AGPU_PACK_OCCUPANCY fragment_pack_kerne
 	if (threadIdx.x == 0 && block_max) atomicMax(&counters[IC_MAX_READ_LENGTH], block_max);
 }
 
-// CRC-32 of the payload of every stored block of a pushed piece against the trailer of the block (crc32_core.hpp; htslib checks every block it reads: bgzf.c): one workgroup
-// per block, 256 lanes x 256 bytes four bytes per step, the CRCs of the chunks joined in a tree with the prepared advance operators (tables and operators in LDS).
+// CRC-32 of the payload of every stored block of a pushed piece against the trailer of the block (crc32_core.hpp; htslib checks every block it reads: bgzf.c).  Round 5: one
+// WAVEFRONT per block (four blocks per workgroup, which share the tables in LDS): lane L takes chunk L of the virtual 64 KB block that ends with the payload, 16 words per round
+// through LDS (read from HBM once, sixteen neighbouring lanes 64 consecutive bytes; chunk c at word 17 c -- an odd stride, so that the lanes, each on its own chunk, hit
+// different banks), four bytes per step with the sliced tables; the 64 chunk CRCs are folded with two table-driven operators (crc32_core.hpp: Crc32Tables::join) in 14 steps.
 // Blocks of which only a part is delivered (the ends of a part of a file) carry crc32 = 0 and are not checked.
 // INFLATED: the blocks were deflated and `raw` is the stream they were inflated into: the CRC-32 of the gzip trailer is that of the inflated bytes
-template <bool INFLATED> __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, const Crc32Tables* tables, unsigned int* mismatches) {
-	__shared__ Crc32Tables t;
-	__shared__ uint32_t part[256];
-	__shared__ uint32_t length[256];
-	// The payload of the block goes through LDS: read from HBM once, in words that neighbouring lanes read next to each other.  (The first version let every lane walk its own
-	// 256 bytes straight from HBM, four at a time: 64 lanes, 64 lines per load, each line needed again 63 loads later by when the 4096 workgroups in flight had pushed it out of
-	// the L2 -- 119 GB fetched for a 5.4 GB stream, profiles/r03s_pmc_summary.txt.  The second staged the whole block: at its algorithmic bytes, but 75 KB of LDS are two
-	// workgroups per CU and the launch took 2.4 ms instead of 1.1, profiles/r03w_kernel_stats_10m.txt.)  Now in four rounds of 16 words per lane: 17 KB, chunk c at word 17 c --
-	// an odd stride, so that the lanes, each on its own chunk, hit different banks; sixteen neighbouring lanes load 64 consecutive bytes.
-	const uint32_t ROUND_WORDS = CRC32_CHUNK / 16; // words of a lane's chunk per round
-	__shared__ uint32_t staged[256 * (CRC32_CHUNK / 16 + 1)];
-	for (uint32_t k = threadIdx.x; k < sizeof(Crc32Tables) / 4; k += 256) ((uint32_t*) &t)[k] = ((const uint32_t*) tables)[k];
-	agpu_bgzf_block block = blocks[blockIdx.x];
+template <bool INFLATED> __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t* raw, const agpu_bgzf_block* blocks, uint32_t n_blocks, const Crc32Tables* tables, unsigned int* mismatches) {
+	__shared__ uint32_t slice[4][256];
+	__shared__ uint32_t join[2][4][256];
+	__shared__ uint32_t staged[4][CRC32_WAVE_LANES * (CRC32_ROUND_WORDS + 1)];
+	for (uint32_t k = threadIdx.x; k < 4 * 256; k += 256) ((uint32_t*) slice)[k] = ((const uint32_t*) tables->slice)[k];
+	for (uint32_t k = threadIdx.x; k < 2 * 4 * 256; k += 256) ((uint32_t*) join)[k] = ((const uint32_t*) tables->join)[k];
+	const uint32_t wave = threadIdx.x / CRC32_WAVE_LANES, lane = threadIdx.x % CRC32_WAVE_LANES, b = blockIdx.x * 4 + wave;
+	agpu_bgzf_block block;
+	block.crc32 = 0; block.payload_size = 0; block.raw_offset = 0; block.payload_offset = 0;
+	if (b < n_blocks) block = blocks[b];
 	if (INFLATED) { block.raw_offset = block.stream_offset; block.payload_offset = 0; block.payload_size = block.isize; }
-	if (block.crc32 == 0 || block.payload_size > 256u * CRC32_CHUNK) return; // (uniform; a BGZF block holds at most 64 KB)
+	const bool checked = b < n_blocks && block.crc32 != 0 && block.payload_size <= CRC32_VIRTUAL; // (the same for the lanes of a wavefront; a BGZF block holds at most 64 KB)
 	const uint8_t* payload = raw + block.raw_offset + block.payload_offset;
-	const uint32_t at = threadIdx.x * CRC32_CHUNK;
-	const uint32_t mine = at < block.payload_size ? (block.payload_size - at < CRC32_CHUNK ? block.payload_size - at : CRC32_CHUNK) : 0;
-	uint32_t running = 0xFFFFFFFFu;
-	for (uint32_t round = 0; round < CRC32_CHUNK / 4 / ROUND_WORDS; ++round) {
+	const uint32_t n = block.payload_size;
+	uint32_t* mine = staged[wave];
+	uint32_t c = 0;
+	const bool by_chunks = checked && n >= 4;
+	const uint32_t first_word = by_chunks ? (CRC32_VIRTUAL - n) / 4 : CRC32_VIRTUAL / 4; // the first word of the virtual block that holds a byte of the payload
+	for (uint32_t round = 0; round < CRC32_WAVE_CHUNK / 4 / CRC32_ROUND_WORDS; ++round) {
 		__syncthreads(); // (the tables are there; the words of the round before have been used)
-		for (uint32_t item = threadIdx.x; item < 256 * ROUND_WORDS; item += 256) {
-			const uint32_t chunk = item / ROUND_WORDS, j = item % ROUND_WORDS, w = chunk * (CRC32_CHUNK / 4) + round * ROUND_WORDS + j; // word w of the payload
-			uint32_t word = 0;
-			if (4 * w + 4 <= block.payload_size) word = load_u32(payload + 4 * (size_t) w);
-			else for (uint32_t b = 4 * w; b < block.payload_size; ++b) word |= (uint32_t) payload[b] << (8 * (b - 4 * w)); // (the last bytes of the block: nothing behind them is read)
-			staged[chunk * (ROUND_WORDS + 1) + j] = word;
+		for (uint32_t item = lane; item < CRC32_WAVE_LANES * CRC32_ROUND_WORDS; item += CRC32_WAVE_LANES) {
+			const uint32_t chunk = item / CRC32_ROUND_WORDS, j = item % CRC32_ROUND_WORDS, w = chunk * (CRC32_WAVE_CHUNK / 4) + round * CRC32_ROUND_WORDS + j;
+			mine[chunk * (CRC32_ROUND_WORDS + 1) + j] = w >= first_word ? crc32_virtual_word(payload, n, w) : 0u;
 		}
 		__syncthreads();
-		const uint32_t done = round * ROUND_WORDS * 4;
-		if (mine > done) running = crc32_update_sliced(t.slice, running, (const uint8_t*) &staged[threadIdx.x * (ROUND_WORDS + 1)], mine - done < ROUND_WORDS * 4 ? mine - done : ROUND_WORDS * 4);
+		for (uint32_t j = 0; j < CRC32_ROUND_WORDS; ++j) c = crc32_raw_step(slice, c, mine[lane * (CRC32_ROUND_WORDS + 1) + j]);
 	}
-	part[threadIdx.x] = mine ? running ^ 0xFFFFFFFFu : 0u;
-	length[threadIdx.x] = mine;
+	// the chunks of a group of eight, then the eight groups (crc32_fold_chunks)
 	__syncthreads();
-	for (uint32_t stride = 1; stride < 256; stride *= 2) {
-		if (threadIdx.x % (2 * stride) == 0 && length[threadIdx.x + stride] > 0) {
-			part[threadIdx.x] = crc32_joined_with(t.advance, part[threadIdx.x], part[threadIdx.x + stride], length[threadIdx.x + stride]);
-			length[threadIdx.x] += length[threadIdx.x + stride];
-		}
-		__syncthreads();
+	mine[lane] = c;
+	__syncthreads();
+	if (lane % 8 == 0) { for (uint32_t i = 1; i < 8; ++i) c = crc32_apply(join[0], c) ^ mine[lane + i]; }
+	__syncthreads();
+	if (lane % 8 == 0) mine[lane] = c;
+	__syncthreads();
+	if (lane == 0 && checked) {
+		for (uint32_t g = 1; g < 8; ++g) c = crc32_apply(join[1], c) ^ mine[8 * g];
+		c ^= 0xFFFFFFFFu;
+		if (n < 4) c = crc32_of_sliced(slice, payload, n); // (no four bytes to invert: the few bytes as they are)
+		if (c != block.crc32) atomicAdd(mismatches, 1u);
 	}
-	if (threadIdx.x == 0 && part[0] != block.crc32) atomicAdd(mismatches, 1u);
 }
 
 // agpu_shard_merge: a 32-bit column of one part into its place in the whole, pool offsets moved behind the pools of the parts before it
@@ -1049,8 +1049,8 @@ int agpu_ingest_push_bgzf(agpu_ctx* ctx, const void* raw, size_t raw_size, const
 		HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], pieces));
 		if (ctx->ingest_verify_crc) { // (~1 ms per 256 MB piece; between the copies on one stream it cost 0.3 s of a 54 GB file)
 			KernelTimer timer(ctx, "bgzf_crc_kernel", deflated ? stream_bytes : raw_size, pieces);
-			if (deflated) bgzf_crc_kernel<true><<<n_blocks, 256, 0, pieces>>>(ctx->ingest_stream.as<uint8_t>() + piece_stream_offset, ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
-			else bgzf_crc_kernel<false><<<n_blocks, 256, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+			if (deflated) bgzf_crc_kernel<true><<<(n_blocks + 3) / 4, 256, 0, pieces>>>(ctx->ingest_stream.as<uint8_t>() + piece_stream_offset, ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), n_blocks, ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
+			else bgzf_crc_kernel<false><<<(n_blocks + 3) / 4, 256, 0, pieces>>>(ctx->ingest_raw[slot].as<uint8_t>(), ctx->ingest_blocks[slot].as<agpu_bgzf_block>(), n_blocks, ctx->scratch("ingest.crc_tables").as<Crc32Tables>(), ctx->scratch("ingest.crc_mismatches").as<unsigned int>());
 		}
 		HIP_CHECK(hipEventRecord(ctx->piece_done[slot], pieces));
 	} else { HIP_CHECK(hipEventRecord(ctx->piece_copied[slot], s)); HIP_CHECK(hipEventRecord(ctx->piece_ready[slot], s)); }

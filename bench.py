@@ -722,6 +722,9 @@ def main():
                 "stages": stage_log,
                 # per step: the sum over the launches of one step (the front of the ingest runs window by window: ~200 launches of its kernels in a step of 10^8 fragments)
                 "kernel_ms": {name: round(values["ms"] / args.steps, 3) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:48]},
+                # ... and of the sample that ran alone behind the timed steps: what every kernel takes when nothing of another sample runs beside it (their sum is the device work of a sample)
+                "kernel_ms_alone": ({name: round(values["ms"], 3) for name, values in sorted(alone_kernels.items(), key=lambda item: -item[1]["ms"])[:48]} if alone_kernels else None),
+                "kernel_ms_alone_sum": round(sum(values["ms"] for values in alone_kernels.values()), 1) if alone_kernels else None,
                 "kernel_launches_per_step": {name: round(values["launches"] / args.steps, 1) for name, values in sorted(kernels.items(), key=lambda item: -item[1]["ms"])[:12]},
                 "kernel_ms_per_step": round(kernel_ms_per_step, 2),
                 "roofline": roofline,
