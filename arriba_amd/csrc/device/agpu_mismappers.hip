@@ -498,7 +498,10 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const uint32_t* todo = heavy.as<uint32_t>(); uint32_t n_todo = n_heavy;
 				if (sweep_kernel_first) {
 					{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-					  if (!four_waves) mismapper_heavy_kernel<5, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
+					  const int heavy_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr ? atoi(getenv("ARRIBA_HEAVY_WAVES")) : 5; // (6 with ARRIBA_HEAVY_WORKGROUPS=6144: 80 VGPRs, 177 spilled -- for measurements; launch bounds of 8 are not honoured: 122 VGPRs, four wavefronts)
+					  if (heavy_waves == 6) mismapper_heavy_kernel<6, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
+					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4);
+					  else if (!four_waves) mismapper_heavy_kernel<5, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
 					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4);
 					  else mismapper_heavy_kernel<4, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
 					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4); }

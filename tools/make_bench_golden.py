@@ -6,6 +6,7 @@ with and without its loading phase, peak memory (the reference's own last line, 
 
     python tools/make_bench_golden.py --fragments 20000000 --golden bench20m      # tests/golden/bench20m/{meta.json,reference.log}
     python tools/make_bench_golden.py --fragments 1000000 --fit                   # one point of tests/golden/cpu_baseline_fit.json
+    python tools/make_bench_golden.py --fragments 5000000 --normal-mult 4 --golden normal5m   # with 4 N ordinary pairs beside the N chimeric fragments
 
 The points of the fit (a*N + b*N*log2 N over the per-sample seconds, loading excluded) are what bench.py quotes beside the live
 800 k-fragment baseline: SURVEY.md section 8(d), "run 1 M / 5 M / 10 M / 20 M, fit, report the extrapolation as such".
@@ -53,6 +54,7 @@ def main():
     parser.add_argument("--fit", action="store_true", help="add the point to tests/golden/cpu_baseline_fit.json and redo the fit")
     parser.add_argument("--scratch", default=None)
     parser.add_argument("--threads", type=int, default=4)
+    parser.add_argument("--normal-mult", type=int, default=None, help="ordinary proper pairs per chimeric fragment beside them (SURVEY.md section 8d-2 asks for 4; bench.py's main sample has none)")
     args = parser.parse_args()
     import bench
     import datasets
@@ -60,6 +62,8 @@ def main():
     os.makedirs(directory, exist_ok=True)
     prefix = os.path.join(directory, "s")
     generator = bench.workload_args(args.fragments, 1000, stress=args.stress)
+    if args.normal_mult is not None:
+        generator[generator.index("--normal-mult") + 1] = str(args.normal_mult)
     subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", str(args.threads)] + generator, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     bam_sha = sha256(prefix + ".bam")
     # (-O: the discarded candidates as well -- review of round 4, item 7c: the SHA pins of the large samples did not pin discarded.tsv)
