@@ -184,6 +184,10 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, 5) mismapper_verdict_kernel(Batch
 const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 41 GB for 5120 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
                                         // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
 const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch bounds below)
+// Tried and taken back in round 5 (profiles/r05p_*, r05q_*): (a) six wavefronts per SIMD -- 80 VGPRs, 177 spilled: 457 ms instead of 419 at 10^8 fragments; (b) TWO searches per wavefront,
+// the two strands of a gene at once on 32 lanes each with a sweep, a memo and lists of their own (the calls of a block kept in LDS cut from 256 to 64 to make room): the same verdict
+// bytes under every schedule of the GPU tier, but 496 ms -- the halves of a wavefront go separate ways through the walks and the look-ups of a read position take twice the turns;
+// with 64 calls in LDS and one search per wavefront: 432 ms.
 // SWEEP_ONLY: the searches go through the sweep or are given up -- no recursion, no stack of frames in the kernel; the reads of the searches given up are appended to `leftover`
 // (counters[5]) and done by the instantiation that holds everything.  queue: the index of the queue's counter (the second launch has a queue of its own).
 // GROUPS = 2 (round 5, sweep only): the wavefront is two runners of 32 lanes, each with a sweep, a memo (half of the workgroup's table) and lists (half of its lists) of its own;
