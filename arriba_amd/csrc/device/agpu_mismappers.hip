@@ -184,43 +184,36 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, 5) mismapper_verdict_kernel(Batch
 const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 41 GB for 5120 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
                                         // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
 const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch bounds below)
-// Tried and taken back in round 5 (profiles/r05p_*, r05q_*): (a) six wavefronts per SIMD -- 80 VGPRs, 177 spilled: 457 ms instead of 419 at 10^8 fragments; (b) TWO searches per wavefront,
-// the two strands of a gene at once on 32 lanes each with a sweep, a memo and lists of their own (the calls of a block kept in LDS cut from 256 to 64 to make room): the same verdict
-// bytes under every schedule of the GPU tier, but 496 ms -- the halves of a wavefront go separate ways through the walks and the look-ups of a read position take twice the turns;
-// with 64 calls in LDS and one search per wavefront: 432 ms.
+// Tried and taken back in round 5 (profiles/r05o_waves6.json, r05p_*, r05q_*): (a) six wavefronts per SIMD -- 80 VGPRs, 177 spilled: 457 ms instead of 419 at 10^8 fragments;
+// (b) TWO searches per wavefront, the two strands of a gene at once on 32 lanes each with a sweep, a memo and lists of their own (the calls of a block kept in LDS cut from 256 to
+// 64 to make room): the same verdict bytes under every schedule of the GPU tier, but 496 ms -- the halves of a wavefront go separate ways through the walks and the look-ups of the
+// read positions take twice the turns; with 64 calls in LDS and one search per wavefront: 432 ms.
 // SWEEP_ONLY: the searches go through the sweep or are given up -- no recursion, no stack of frames in the kernel; the reads of the searches given up are appended to `leftover`
 // (counters[5]) and done by the instantiation that holds everything.  queue: the index of the queue's counter (the second launch has a queue of its own).
-// GROUPS = 2 (round 5, sweep only): the wavefront is two runners of 32 lanes, each with a sweep, a memo (half of the workgroup's table) and lists (half of its lists) of its own;
-// align_both_strands searches the two strands of a gene at once (mismapper_core.hpp: AlignRunnerT::groups).  A read's searches come one after the other -- 4 to 8 of them, each a chain
-// of dependent look-ups that keeps a few lanes busy --, so two at a time is half the chain for the same registers.
-template <int WAVES_PER_SIMD, bool SWEEP_ONLY, int GROUPS = 1> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
+template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
                                                              unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters, uint32_t* leftover, int queue) {
-	static_assert(GROUPS == 1 || (GROUPS == 2 && SWEEP_ONLY), "two runners per wavefront: the sweep only");
-	__shared__ uint8_t segment_bases[GROUPS][304];
-	__shared__ AlignSweep sweep[GROUPS];
-	__shared__ AlignMemo memo[GROUPS];
-	__shared__ AlignWorklist worklist[GROUPS];
-	__shared__ uint32_t worklist_state[GROUPS][4];
+	__shared__ uint8_t segment_bases[304];
+	__shared__ AlignSweep sweep;
+	__shared__ AlignMemo memo;
+	__shared__ AlignWorklist worklist;
+	__shared__ uint32_t worklist_state[4];
 	__shared__ uint32_t next_job;
 	__shared__ uint32_t study[8];
-	const uint32_t group = GROUPS == 1 ? 0u : threadIdx.x / (64 / GROUPS), lanes = 64 / GROUPS;
-	if (threadIdx.x % lanes == 0) { // (the workgroup's table and lists, shared out among its runners)
-		const uint32_t slots = memo_slots / GROUPS, capacity = task_capacity / GROUPS;
-		worklist[group].stats = (read_times != nullptr && GROUPS == 1) ? study : nullptr;
-		memo[group].slots = memo_tables + (size_t) blockIdx.x * memo_slots + (size_t) group * slots; memo[group].mask = slots - 1; memo[group].epoch = 0;
-		worklist[group].words = task_lists != nullptr ? task_lists + ((size_t) blockIdx.x * task_capacity + (size_t) group * capacity) * 2 : nullptr; worklist[group].capacity = capacity; worklist[group].state = worklist_state[group];
-		worklist[group].sweep = by_sweep ? &sweep[group] : nullptr; // one sweep over the read positions, every seed walked once (mismapper_core.hpp: AlignSweep)
-		worklist[group].relevant_words = task_lists != nullptr ? task_lists + (((size_t) gridDim.x + blockIdx.x) * task_capacity + (size_t) group * capacity) * 2 : nullptr; worklist[group].relevant_capacity = capacity; // (the second half of the buffer: the calls of a block beyond those kept in LDS)
+	if (threadIdx.x == 0) {
+		worklist.stats = read_times != nullptr ? study : nullptr;
+		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0;
+		worklist.words = task_lists != nullptr ? task_lists + (size_t) blockIdx.x * task_capacity * 2 : nullptr; worklist.capacity = task_capacity; worklist.state = worklist_state;
+		worklist.sweep = by_sweep ? &sweep : nullptr; // one sweep over the read positions, every seed walked once (mismapper_core.hpp: AlignSweep)
+		worklist.relevant_words = task_lists != nullptr ? task_lists + ((size_t) gridDim.x + blockIdx.x) * task_capacity * 2 : nullptr; worklist.relevant_capacity = task_capacity; // (the second half of the buffer: the calls of a block beyond those kept in LDS)
 	}
 	__syncthreads();
 	__shared__ int64_t given_up; // (SWEEP_ONLY: < 0 when a search of the read was not one for the sweep)
 	AlignFrame stack[SWEEP_ONLY ? 1 : ALIGN_MAX_DEPTH];
-	AlignRunnerT<SWEEP_ONLY> runner; runner.stack = stack; runner.lane = threadIdx.x % lanes; runner.lanes = lanes; runner.budget = SWEEP_ONLY ? &given_up : nullptr; runner.max_depth = SWEEP_ONLY ? 1 : ALIGN_MAX_DEPTH;
-	runner.group = group; runner.groups = GROUPS; runner.group_shift = group * lanes; runner.group_mask = GROUPS == 1 ? ~0ull : ((1ull << lanes) - 1ull) << (group * lanes);
+	AlignRunnerT<SWEEP_ONLY> runner; runner.stack = stack; runner.lane = threadIdx.x; runner.lanes = 64; runner.budget = SWEEP_ONLY ? &given_up : nullptr; runner.max_depth = SWEEP_ONLY ? 1 : ALIGN_MAX_DEPTH;
 	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position (when the task list is off or overflows)
-	runner.memo = &memo[group];
-	runner.worklist = task_lists != nullptr ? &worklist[group] : nullptr; // the search as rounds of up to 64 tasks (mismapper_core.hpp: AlignWorklist)
-	runner.cache = segment_bases[group]; runner.cache_stride = 1; runner.cache_capacity = 304;
+	runner.memo = &memo;
+	runner.worklist = task_lists != nullptr ? &worklist : nullptr; // the search as rounds of up to 64 tasks (mismapper_core.hpp: AlignWorklist)
+	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
 	while (true) {
 		__syncthreads(); // (every lane has read next_job of the previous round)
 		if (threadIdx.x == 0) { next_job = atomicAdd(&counters[queue], 1u); given_up = 0; }
@@ -509,12 +502,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const uint32_t* todo = heavy.as<uint32_t>(); uint32_t n_todo = n_heavy;
 				if (sweep_kernel_first) {
 					{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
-					  // (ARRIBA_MISMAPPER_GROUPS=1: one search at a time per wavefront, the way of rounds 3-4; tests: the same verdicts)
-					  const bool two_groups = !(getenv("ARRIBA_MISMAPPER_GROUPS") != nullptr && atoi(getenv("ARRIBA_MISMAPPER_GROUPS")) == 1) && getenv("ARRIBA_HEAVY_WAVES") == nullptr;
-					  const int heavy_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr ? atoi(getenv("ARRIBA_HEAVY_WAVES")) : 5;
-					  if (two_groups) mismapper_heavy_kernel<5, true, 2><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
-					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4);
-					  else // (6 with ARRIBA_HEAVY_WORKGROUPS=6144: 80 VGPRs, 177 spilled -- for measurements; launch bounds of 8 are not honoured: 122 VGPRs, four wavefronts)
+					  const int heavy_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr ? atoi(getenv("ARRIBA_HEAVY_WAVES")) : 5; // (6 with ARRIBA_HEAVY_WORKGROUPS=6144: 80 VGPRs, 177 spilled -- for measurements; launch bounds of 8 are not honoured: 122 VGPRs, four wavefronts)
 					  if (heavy_waves == 6) mismapper_heavy_kernel<6, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
 					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4);
 					  else if (!four_waves) mismapper_heavy_kernel<5, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,

@@ -190,8 +190,7 @@ AGPU_HD uint32_t align_iterations(const AlignTask& call, int32_t length, int32_t
 // 10^7 times for a read in a gene of some megabases (profiles/r03c_mismapper_second_pass.txt).
 const uint32_t ALIGN_SWEEP_BLOCK = KMER_LENGTH;     // read positions per block
 const uint32_t ALIGN_SWEEP_SEGMENT = 304;          // align_both_strands leaves segments of 300 bases and more alone
-const uint32_t ALIGN_SWEEP_CALLS = 64;             // calls of a block kept in the memory the lanes share; what is beyond goes to AlignWorklist::relevant_words (256 until round 5: a read lists
-                                                   // ~2 calls per block on average, and two searches per wavefront -- AlignRunnerT::groups -- want the LDS: 3.5 KB instead of 6.6 KB each)
+const uint32_t ALIGN_SWEEP_CALLS = 256;            // calls of a block kept in the memory the lanes share; what is beyond goes to AlignWorklist::relevant_words
 struct AlignSweep { // memory the lanes of a runner share (LDS on the device)
 	uint32_t hit_first[ALIGN_SWEEP_SEGMENT], hit_count[ALIGN_SWEEP_SEGMENT]; // per read position: the hits of its 8-mer inside the gene, as a range of the position list
 	uint32_t seed_end[ALIGN_SWEEP_BLOCK];                                     // running sums of the seeds of the read positions of the block
@@ -513,12 +512,8 @@ AGPU_HD bool align_from_read_position(const Segment& read, const AlignTarget& ta
 // SWEEP_ONLY: the wavefront-per-read kernel of the device is compiled twice -- once with nothing but the sweep (a search the sweep cannot hold -- a gene of 2^24 bases and more,
 // lists that run over -- is given up with *budget = -1 and the read left to the second instantiation), once with everything: the recursion and its stack of frames need
 // registers and scratch memory that the sweep does not, and the kernel that does almost all of the work should not carry them (agpu_mismappers.hip: mismapper_heavy_kernel).
-// groups (device, round 5): the wavefront holds `groups` runners of `lanes` lanes each, every one with a sweep, a memo and lists of its own -- align_both_strands gives the two strands
-// of a gene to the two halves of a wavefront at once.  `lane` counts inside the group; a group never waits for another one inside a search (no s_barrier: the lanes of a wavefront
-// run in lockstep, a fence orders what they write for each other), the wavefront comes together again behind align().
 template <bool SWEEP_ONLY> struct AlignRunnerT {
 	AlignFrame* stack; uint32_t lane, lanes;
-	uint32_t group = 0, groups = 1, group_shift = 0; unsigned long long group_mask = ~0ull; // (lanes of this group among the 64 of the wavefront)
 	int64_t* budget = nullptr; // steps left for the whole verdict of one read (null: unlimited)
 	int max_depth = ALIGN_MAX_DEPTH; // frames `stack` holds
 	uint8_t* cache = nullptr; uint32_t cache_stride = 1, cache_capacity = 0; // room for a copy of the segment being searched (LDS on the device), shared by the lanes of the runner
@@ -527,15 +522,18 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	AGPU_HD Segment prepared(const Segment& segment) const {
 		Segment result = segment;
 		if (cache == nullptr || segment.length > cache_capacity) return result;
-		sync_lanes(); // (lanes > 1: the lanes are one workgroup and run this code together; nobody still reads the previous copy)
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (lanes > 1) __syncthreads(); // (lanes > 1: the lanes are one workgroup and run this code together; nobody still reads the previous copy)
+#endif
 		for (uint32_t i = lane; i < segment.length; i += lanes) cache[(size_t) i * cache_stride] = (uint8_t) segment.code(i);
-		sync_lanes();
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (lanes > 1) __syncthreads();
+#endif
 		result.cache = cache; result.cache_stride = cache_stride;
 		return result;
 	}
 	AGPU_HD bool any(bool mine) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-		if (groups > 1) return (__ballot(mine) & group_mask) != 0;
 		return lanes > 1 ? __any(mine) != 0 : mine;
 #else
 		return mine;
@@ -543,16 +541,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	}
 	AGPU_HD void sync_lanes() const {
 #if defined(__HIP_DEVICE_COMPILE__)
-		if (groups > 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } // (the groups of a wavefront go separate ways: no s_barrier)
-		else if (lanes > 1) __syncthreads();
-#endif
-	}
-	// the whole wavefront, whatever its groups found
-	AGPU_HD bool any_of_wave(bool mine) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-		return groups > 1 ? __any(mine) != 0 : any(mine);
-#else
-		return mine;
+		if (lanes > 1) __syncthreads();
 #endif
 	}
 	AGPU_HD void new_memo_epoch() const {
@@ -600,14 +589,14 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 				const int32_t iterations = (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
 				relevant = call.read_pos < block + (int32_t) ALIGN_SWEEP_BLOCK && call.read_pos + iterations > block;
 			}
-			const unsigned long long mask = (__ballot(relevant) & group_mask) >> group_shift;
+			const unsigned long long mask = __ballot(relevant);
 			if (relevant) {
 				const uint32_t at = n + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
 				sweep_store_call(sweep, at, call);
 			}
 			for (uint32_t k = 0; k < ALIGN_SWEEP_BLOCK; ++k) { // which read positions of the block does one of these calls reach?
 				const int32_t read_pos = block + (int32_t) k;
-				if ((__ballot(relevant && call.read_pos <= read_pos && read_pos - call.read_pos < (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT)) & group_mask) != 0) reached |= 1u << k;
+				if (__ballot(relevant && call.read_pos <= read_pos && read_pos - call.read_pos < (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT)) != 0) reached |= 1u << k;
 			}
 			n += (uint32_t) __popcll(mask);
 		}
@@ -865,14 +854,6 @@ template <class Runner> AGPU_HD bool align_both_strands(const Segment& segment, 
 		target.contig_bases = genome.bases + genome.contig_offset[contig];
 		target.splice_sites = splice.sites + splice.offset[gene]; target.n_splice_sites = splice.offset[gene + 1] - splice.offset[gene];
 		target.splice_bits = splice.bits; target.splice_bit_base = genome.contig_offset[contig];
-		if (runner.groups == 2) { // the two strands at once, one per half of the wavefront (the verdict is an OR over the searches: their order does not matter)
-			Segment mine = segment; mine.reverse_complement = runner.group == 1;
-			const bool found = runner.align(runner.prepared(mine), target, min_score);
-			runner.sync_lanes();
-			if (runner.any_of_wave(found)) return true;
-			if (runner.exhausted()) return false;
-			continue;
-		}
 		Segment forward = segment; forward.reverse_complement = false;
 		if (runner.align(runner.prepared(forward), target, min_score)) return true;
 		if (runner.exhausted()) return false;

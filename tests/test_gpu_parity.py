@@ -911,8 +911,8 @@ def test_filter_mismappers_gives_the_same_verdicts_under_every_schedule(built, t
     lists among the 64 lanes of a wavefront and hands the reads of a queue to 5 120 persistent workgroups -- and one GPU box of round 4 once gave 3 reads another verdict
     (DESIGN.md section 2).  The stage is run again and again on two samples -- the mismapper stress of config 3 (clips of 40-70 nt copied from the partner gene, -U 32767: long
     searches, hardly a mis-mapper among them) and a sample with families of homologous genes (hundreds of reads that ARE mis-mappers) --: ten times with the workgroups of the
-    product, three times with 7, once with a single one (every read behind the other, one memo table for all of them), once with four wavefronts per SIMD, twice with one search
-    per wavefront instead of the two strands of a gene at once (the way of rounds 3-4) and once with the jobs in the other order: the verdict bytes of all runs must be the same bytes."""
+    product, three times with 7, once with a single one (every read behind the other, one memo table for all of them), once with four wavefronts per SIMD and once with the jobs
+    in the other order: the verdict bytes of all runs must be the same bytes."""
     import subprocess
     import bench
     from ctypes import byref, c_uint64
@@ -920,7 +920,7 @@ def test_filter_mismappers_gives_the_same_verdicts_under_every_schedule(built, t
     fragments = int(os.environ.get("ARRIBA_DETERMINISM_FRAGMENTS", "100000"))
     samples = [("stress", bench.workload_args(fragments, 1000, stress=True), {"subsampling_threshold": 32767}, 0),
                ("homologs", ["--seed", "29", "--fragments", str(2 * fragments), "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--homolog-families", "4"], None, 20)]
-    knobs = ("ARRIBA_HEAVY_WORKGROUPS", "ARRIBA_MISMAPPER_JOB_ORDER", "ARRIBA_HEAVY_WAVES", "ARRIBA_MISMAPPER_GROUPS")
+    knobs = ("ARRIBA_HEAVY_WORKGROUPS", "ARRIBA_MISMAPPER_JOB_ORDER", "ARRIBA_HEAVY_WAVES")
     for name, arguments, params, least_positive in samples:
         prefix = str(tmp_path / name)
         subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32"] + arguments, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -953,8 +953,7 @@ def test_filter_mismappers_gives_the_same_verdicts_under_every_schedule(built, t
         assert n_jobs > fragments // 50 and first.sum() >= least_positive, (name, n_jobs, int(first.sum()))
         assert int(first.sum()) == int(first_per_read.sum()) - int((filters_before == 11).sum()), name
         schedules = [("5120 workgroups, run %d" % k, {}) for k in range(2, 11)] + [("7 workgroups, run %d" % k, {"ARRIBA_HEAVY_WORKGROUPS": "7"}) for k in range(1, 4)] + \
-                    [("one workgroup", {"ARRIBA_HEAVY_WORKGROUPS": "1"}), ("four wavefronts per SIMD", {"ARRIBA_HEAVY_WAVES": "4", "ARRIBA_HEAVY_WORKGROUPS": "4096"})] + \
-                    [("one search per wavefront, run %d" % k, {"ARRIBA_MISMAPPER_GROUPS": "1"}) for k in range(1, 3)]  # (round 5: the product searches the two strands of a gene at once, one per half of a wavefront)
+                    [("one workgroup", {"ARRIBA_HEAVY_WORKGROUPS": "1"}), ("four wavefronts per SIMD", {"ARRIBA_HEAVY_WAVES": "4", "ARRIBA_HEAVY_WORKGROUPS": "4096"})]
         for label, environment in schedules:
             count, again, _ = verdicts(environment)
             assert count == n_jobs, (name, label)
