@@ -100,14 +100,16 @@ AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p
 // whose extensions cross splice sites again -- in a long gene with many exons the number of calls grows exponentially with the nesting (seconds to hours per
 // read), although there are only (read positions x splice sites + seeds) distinct calls.  With the memo every distinct call is searched once per score level.
 // The result is the reference's: only calls that are known to return false are skipped.
-// A slot holds epoch (8 bits: one per align() invocation, so that the table never needs clearing) | gene_pos - gene_start (24) | read_pos (9) | max_deletions (1) |
+// A slot holds epoch (14 bits: one per align() invocation, so that the table is cleared once in 16 383 searches.  8 bits until round 5: a clear of the 8 MB table of a workgroup
+// every 255 searches was 0.9 TB of writes per 10^8-fragment sample -- 29 M searches / 255 x 8 MB --, most of what the counters saw this kernel write) | gene_pos - gene_start (24) | read_pos (9) | max_deletions (1) |
 // score + 32768 (16): for equal keys the larger word is the higher failed score.
+const uint32_t ALIGN_MEMO_EPOCHS = 0x3FFFu; // the epoch field of a slot: bits 50-63
 struct AlignMemo {
 	unsigned long long* slots; uint32_t mask; uint32_t epoch; // (no default initialisers: the device keeps one in LDS)
 	// (the key holds 24 bits of gene offset and 9 bits of read position: longer genes and reads are searched without the memo)
 	AGPU_HD bool usable(int32_t gene_start, int32_t gene_end, int32_t read_length) const { return slots != nullptr && (int64_t) gene_end - gene_start < (1 << 24) && read_length < 512; }
 	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions) const {
-		return ((unsigned long long) (epoch & 255u) << 34 | (unsigned long long) (uint32_t) gene_offset << 10 | (unsigned long long) (uint32_t) read_pos << 1 | (unsigned long long) (max_deletions > 0)) << 16;
+		return ((unsigned long long) (epoch & ALIGN_MEMO_EPOCHS) << 34 | (unsigned long long) (uint32_t) gene_offset << 10 | (unsigned long long) (uint32_t) read_pos << 1 | (unsigned long long) (max_deletions > 0)) << 16;
 	}
 	AGPU_HD uint32_t slot_of(unsigned long long key) const { unsigned long long h = key * 0x9E3779B97F4A7C15ull; return (uint32_t) (h >> 40) & mask; }
 	// is a call with this key and a score <= the recorded one known to fail?
@@ -546,7 +548,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	}
 	AGPU_HD void new_memo_epoch() const {
 		sync_lanes();
-		const uint32_t next = (memo->epoch + 1) & 255u; // (every lane reads the same value)
+		const uint32_t next = (memo->epoch + 1) & ALIGN_MEMO_EPOCHS; // (every lane reads the same value)
 		if (next == 0) for (uint32_t k = lane; k <= memo->mask; k += lanes) memo->slots[k] = 0; // the epoch numbers wrap around: start clean (epoch 0 = empty slots)
 		sync_lanes();
 		if (lane == 0) memo->epoch = next == 0 ? 1 : next;
