@@ -155,34 +155,54 @@ __global__ void segment_emit_kernel(const uint8_t* bytes, uint64_t size, uint64_
 
 // ---- per record -----------------------------------------------------------------------------------------------------------------------------------
 
+// Round 5: the 64 records of a wavefront lie next to each other in the stream (12.9 KB at 202 bytes per record), and a lane reads its record's header, name and tags -- a third of
+// its bytes, in a dozen loads whose lines the 10^4 wavefronts in flight push out of the L2 between one load and the next: the counters saw the stream fetched 5.4 times over
+// (profiles/r05t_pmc100m_pmc_summary.txt).  So the wavefront copies its piece of the stream into LDS first, 16 bytes per lane and turn, every line once, and the lanes parse there.
+// A piece that does not fit (reads of some kilobases) is parsed from the stream as before.
+const uint32_t PARSE_WINDOW = 16384;
 __global__ void __launch_bounds__(BLOCK) record_parse_kernel(IngestStream in, GenomeView genome, uint64_t seed, uint64_t record_begin, uint64_t* keys, uint8_t* bits, int32_t* hit_index, uint32_t* counters) {
 	__shared__ uint32_t sums[4];
+	__shared__ __attribute__((aligned(16))) uint8_t staged[BLOCK / 64][PARSE_WINDOW + 64];
+	const uint32_t wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+	uint8_t* window = staged[wave];
 	uint32_t active = 0, mapped = 0, missing = 0, broken = 0;
-	for (uint64_t r = record_begin + blockIdx.x * (uint64_t) BLOCK + threadIdx.x; r < in.n_records; r += gridDim.x * (uint64_t) BLOCK) {
-		const uint8_t* p = in.bytes + in.record_offset[r];
-		const uint32_t block_size = load_u32(p);
-		uint64_t key = ~0ull;
-		uint8_t status = RECORD_SKIPPED;
-		int32_t hit = HIT_INDEX_UNKNOWN;
-		if (!record_sizes_ok(p + 4, block_size)) { status = RECORD_BROKEN; ++broken; }
-		else {
-			const Rec record = load_record(in, (uint32_t) r);
-			if (!((record.flag & BAMF_UNMAP) || ((record.flag & BAMF_PAIRED) && (record.flag & BAMF_MUNMAP)))) {
-				const AuxTags tags = scan_aux(record.aux, record.end);
-				if (!tags.has_hi && (record.flag & BAMF_SECONDARY)) { status = RECORD_MISSING_HI; ++missing; }
-				else if (record.contig < 0) { status = RECORD_BROKEN; ++broken; } // reference id outside the header
-				else {
-					status = RECORD_ACTIVE | (tags.has_sa ? RECORD_HAS_SA : 0);
-					key = name_key(record, tags.has_hi ? tags.hi : 1, seed);
-					hit = hit_index_to_keep(tags);
-					++active;
-					if (!(record.flag & BAMF_SUPPLEMENTARY) && (genome.contig_bits[record.contig] & CBIT_INTERESTING)) ++mapped;
+	for (uint64_t base = record_begin + ((uint64_t) blockIdx.x * (BLOCK / 64) + wave) * 64; base < in.n_records; base += (uint64_t) gridDim.x * BLOCK) { // (the same for the lanes of a wavefront)
+		const uint64_t r = base + lane;
+		const uint64_t piece_begin = in.record_offset[base] & ~15ull, piece_end = base + 64 < in.n_records ? in.record_offset[base + 64] : in.size; // (every record ends where the next one begins)
+		const bool in_lds = piece_end > piece_begin && piece_end - piece_begin <= PARSE_WINDOW;
+		if (in_lds) {
+			for (uint64_t at = piece_begin + 16 * lane; at < piece_end; at += 16 * 64) *(uint4*) (window + (at - piece_begin)) = *(const uint4*) (in.bytes + at); // (the stream is padded behind its end)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+		if (r < in.n_records) {
+			const uint64_t offset = in.record_offset[r];
+			const uint8_t* p = in.bytes + offset;
+			uint32_t block_size = load_u32(p);
+			if (in_lds && offset + 4 + (uint64_t) block_size <= piece_end && offset + 36 <= piece_end) { p = window + (offset - piece_begin); block_size = load_u32(p); } // (a record that claims more than its piece holds: from the stream)
+			uint64_t key = ~0ull;
+			uint8_t status = RECORD_SKIPPED;
+			int32_t hit = HIT_INDEX_UNKNOWN;
+			if (!record_sizes_ok(p + 4, block_size)) { status = RECORD_BROKEN; ++broken; }
+			else {
+				const Rec record = load_record_at(in, p);
+				if (!((record.flag & BAMF_UNMAP) || ((record.flag & BAMF_PAIRED) && (record.flag & BAMF_MUNMAP)))) {
+					const AuxTags tags = scan_aux(record.aux, record.end);
+					if (!tags.has_hi && (record.flag & BAMF_SECONDARY)) { status = RECORD_MISSING_HI; ++missing; }
+					else if (record.contig < 0) { status = RECORD_BROKEN; ++broken; } // reference id outside the header
+					else {
+						status = RECORD_ACTIVE | (tags.has_sa ? RECORD_HAS_SA : 0);
+						key = name_key(record, tags.has_hi ? tags.hi : 1, seed);
+						hit = hit_index_to_keep(tags);
+						++active;
+						if (!(record.flag & BAMF_SUPPLEMENTARY) && (genome.contig_bits[record.contig] & CBIT_INTERESTING)) ++mapped;
+					}
 				}
 			}
+			keys[r] = key;
+			bits[r] = status;
+			hit_index[r] = hit;
 		}
-		keys[r] = key;
-		bits[r] = status;
-		hit_index[r] = hit;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); // (the window is overwritten by the next turn)
 	}
 	block_tally(active, &counters[IC_ACTIVE], &sums[0]);
 	block_tally(mapped, &counters[IC_MAPPED_READS], &sums[1]);

@@ -103,8 +103,8 @@ AGPU_HD bool record_sizes_ok(const uint8_t* block, uint32_t block_size) {
 	return fixed <= block_size;
 }
 
-AGPU_HD Rec load_record(const IngestStream& in, uint32_t r) {
-	const uint8_t* p = in.bytes + in.record_offset[r];
+// (p: where the record starts -- in the stream, or in a copy of a piece of it: record_parse_kernel stages the records of a wavefront in LDS)
+AGPU_HD Rec load_record_at(const IngestStream& in, const uint8_t* p) {
 	const uint64_t word0 = load_u64(p), word1 = load_u64(p + 8), word2 = load_u64(p + 16); // block_size, refID | pos, l_read_name mapq bin | n_cigar, flag, l_seq: three loads instead of seven
 	const uint32_t block_size = (uint32_t) word0;
 	p += 4;
@@ -123,6 +123,7 @@ AGPU_HD Rec load_record(const IngestStream& in, uint32_t r) {
 	rec.end = p + block_size;
 	return rec;
 }
+AGPU_HD Rec load_record(const IngestStream& in, uint32_t r) { return load_record_at(in, in.bytes + in.record_offset[r]); }
 
 // ---- the record chain (every record starts where the one before it ends), cut in parallel ---------------------------------------------------------
 // Every 8 KB segment of the stream guesses its first record (two consecutive plausible headers) and walks the chain to its end; a guess counts only if it is the
