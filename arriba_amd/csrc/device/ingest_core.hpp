@@ -320,7 +320,8 @@ AGPU_HD void plan_push_tandem(FragmentPlan& plan) {
 // an alignment_t derived from a plan entry (source/common.hpp:191-207); its CIGAR is the record's, cut as add_chimeric_alignment cuts it, with up to
 // two elements replaced afterwards (remove_malformed_alignments rewrites clipped elements)
 struct Aln {
-	Rec rec;                 // source record (CIGAR); for a tandem alignment the record the sequence comes from
+	const uint8_t* cigar_bytes; // the CIGAR of the source record in the stream (round 5: the whole decoded record -- five pointers and six words -- used to sit here, three times per
+	                            // fragment, in the scratch memory of the replay and pack kernels; whoever needs more of the record loads it by its index)
 	uint32_t record;         // its index, NO_RECORD for a tandem alignment without sequence
 	uint32_t sequence_record; // record whose bases are this alignment's `sequence`, NO_RECORD = empty
 	int32_t sequence_length;
@@ -337,7 +338,7 @@ struct Aln {
 	AGPU_HD uint32_t base_cigar(uint32_t i) const {
 		if (clip == PLAN_TANDEM) return i == 0 ? tandem_cigar[0] : i == 1 ? tandem_cigar[1] : tandem_cigar[2];
 		if (i == made_index) return made_value;
-		return rec.cigar(i + shift);
+		return load_u32(cigar_bytes + 4 * (size_t) (i + shift));
 	}
 	AGPU_HD uint32_t cigar(uint32_t i) const {
 		uint32_t value = base_cigar(i);
@@ -359,19 +360,20 @@ AGPU_HD Aln materialize(const IngestStream& in, const PlanEntry& e, const Tandem
 	a.clip = e.clip; a.cigar_index = e.cigar_index;
 	a.made_index = NO_RECORD; a.made_value = 0; a.shift = 0;
 	if (e.clip == PLAN_TANDEM) {
-		a.rec = load_record(in, tandem->record);
+		const Rec source = load_record(in, tandem->record);
+		a.cigar_bytes = source.cigar_bytes;
 		a.record = NO_RECORD;
 		a.supplementary = tandem->supplementary; a.first_in_pair = tandem->first_in_pair; a.strand = tandem->strand;
-		a.contig = a.rec.contig; a.start = tandem->start; a.end = tandem->end;
+		a.contig = source.contig; a.start = tandem->start; a.end = tandem->end;
 		a.n_cigar = tandem->n_cigar;
 		for (int k = 0; k < 3; ++k) a.tandem_cigar[k] = tandem->cigar[k];
 		a.sequence_record = a.supplementary ? NO_RECORD : tandem->record;
-		a.sequence_length = a.supplementary ? 0 : a.rec.l_seq;
+		a.sequence_length = a.supplementary ? 0 : source.l_seq;
 		return a;
 	}
-	a.rec = load_record(in, e.record);
+	const Rec r = load_record(in, e.record);
+	a.cigar_bytes = r.cigar_bytes;
 	a.record = e.record;
-	const Rec& r = a.rec;
 	a.strand = r.forward(); a.first_in_pair = r.flag & BAMF_READ1; a.contig = r.contig; a.supplementary = e.supplementary;
 	a.sequence_record = e.supplementary ? NO_RECORD : e.record;
 	a.sequence_length = e.supplementary ? 0 : r.l_seq;
@@ -993,7 +995,7 @@ AGPU_HD uint32_t write_fragment(const IngestStream& in, const Fragment3& f, cons
 			out.seq_offset[s][i] = (uint32_t) (sequence_at / 4); out.seq_length[s][i] = length;
 			if (length > longest) longest = length;
 			if (length > 0) {
-				const Rec source = (a.sequence_record == a.record) ? a.rec : load_record(in, a.sequence_record);
+				const Rec source = load_record(in, a.sequence_record);
 				uint32_t* target = (uint32_t*) (out.seq_pool + sequence_at); // sequences start on 4-byte boundaries
 				for (uint32_t w = 0; w < padded / 4; ++w) {
 					uint32_t value = 0;
