@@ -229,7 +229,7 @@ __global__ void in_vitro_pair_key_kernel(CandidateTable t, uint64_t* keys) { // 
 }
 __global__ void clip_summary_kernel(BatchView b, ClipSummary* summaries) {
 	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (k < 3 * b.n) summaries[k] = clip_summary_of(b, k / 3, (int) (k % 3));
+	if (k < 3 * b.n) summaries[CLIP_SUMMARIES_PER_READ * (k / 3) + k % 3] = clip_summary_of(b, k / 3, (int) (k % 3));
 }
 __global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long) {
 	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
@@ -337,6 +337,27 @@ int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& th
 }
 
 // the list of the candidates a thread kernel notes for the wavefronts, and their number read back (the launch of the second kernel is sized by it)
+// what the walks over read lists ask of a read, in one byte per fragment (views.hpp: BatchView::walk)
+__global__ void walk_byte_kernel(BatchView b, uint8_t* walk) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	uint8_t byte = b.filter[i] == FILTER_none ? WALK_UNFILTERED : 0;
+	if (b.fbits[i] & FBIT_MULTIMAPPER) byte |= WALK_MULTIMAPPER;
+	for (int slot = 0; slot < b.n_aln[i]; ++slot) if (b.abits[slot][i] & ABIT_EXONIC) byte |= WALK_EXONIC;
+	walk[i] = byte;
+}
+// the batch with its walk bytes as of now (the filters of the reads change from stage to stage: made anew by every stage that walks with them)
+int batch_with_walk_bytes(agpu_ctx* ctx, BatchView& batch) {
+	batch = ctx->batch;
+	if (ctx->n == 0) return AGPU_OK;
+	DeviceBuffer& walk = ctx->scratch("events.walk_bytes");
+	ALLOC(walk, ctx->n);
+	{ KernelTimer timer(ctx, "walk_byte_kernel", ctx->n * 7);
+	  walk_byte_kernel<<<(unsigned int) ((ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, ctx->stream>>>(ctx->batch, walk.as<uint8_t>()); }
+	batch.walk = walk.as<uint8_t>();
+	return AGPU_OK;
+}
+
 struct LongLists {
 	uint32_t* list = nullptr; uint32_t* count = nullptr;
 	int prepare(agpu_ctx* ctx, uint32_t candidates) {
@@ -363,14 +384,16 @@ int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* ker
 	if (C > 0) {
 		const int effective_stage = ctx->params.filter_enabled[filter_id] ? stage : EVENT_count_only; // a stage switched off with -f only counts
 		if (effective_stage == EVENT_both_intronic) { // (walks the read lists)
+			BatchView batch;
+			{ const int status = batch_with_walk_bytes(ctx, batch); if (status != AGPU_OK) return status; }
 			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
 				LongLists lists; uint32_t n_long = 0;
 				{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
 				{ KernelTimer timer(ctx, kernel_name, (uint64_t) C * 60 + (uint64_t) ctx->n_list_entries * 8);
-				  event_predicate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), begin, end, lists.list, lists.count); }
+				  event_predicate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), begin, end, lists.list, lists.count); }
 				{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
 				if (n_long > 0) { KernelTimer timer(ctx, "event_predicate_wave_kernel(both_intronic)", (uint64_t) n_long * 60);
-				  event_predicate_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(effective_stage, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), lists.list, lists.count); }
+				  event_predicate_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(effective_stage, batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), lists.list, lists.count); }
 				return AGPU_OK;
 			}, LISTS_OF_UNFILTERED);
 			if (status != AGPU_OK) return status;
@@ -849,7 +872,7 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 		if (ctx->n > 0) { // the clipped ends of the alignments, summarised once in 8 bytes each: the verdicts walk the read lists and would otherwise gather CIGAR ends, strand, contig and
 			// position of up to three alignments per list entry (10^8 fragments: in_vitro_kernel 219 -> 66 + 3 ms, profiles/r03h_output_side_and_ingest.txt)
 			DeviceBuffer& summaries = ctx->scratch("events.clip_summaries");
-			ALLOC(summaries, 3 * ctx->n * sizeof(ClipSummary));
+			ALLOC(summaries, CLIP_SUMMARIES_PER_READ * ctx->n * sizeof(ClipSummary));
 			{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20));
 			  clip_summary_kernel<<<(unsigned int) ((3 * ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, summaries.as<ClipSummary>()); }
 			tables.clip_summaries = summaries.as<ClipSummary>();
@@ -901,14 +924,16 @@ extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_
 		{ const int status = expression_proxy(ctx, high_expression_quantile, threshold); if (status != AGPU_OK) return status; }
 		HIP_CHECK(hipMemsetAsync(histogram.ptr, 0, (size_t) BOTH_SPLICED_HISTOGRAM_BINS * 4, s));
 		{ const uint32_t* gene_read_count = ctx->scratch("events.gene_read_count").as<uint32_t>();
+		  BatchView batch;
+		  { const int status = batch_with_walk_bytes(ctx, batch); if (status != AGPU_OK) return status; }
 		  const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
 			LongLists lists; uint32_t n_long = 0;
 			{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
 			{ KernelTimer timer(ctx, "both_spliced_reads_kernel", (uint64_t) C * 70 + (uint64_t) ctx->n_list_entries * 6);
-			  both_spliced_reads_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), begin, end, lists.list, lists.count); }
+			  both_spliced_reads_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), begin, end, lists.list, lists.count); }
 			{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
 			if (n_long > 0) { KernelTimer timer(ctx, "both_spliced_reads_wave_kernel", (uint64_t) n_long * 70);
-			  both_spliced_reads_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), lists.list, lists.count); }
+			  both_spliced_reads_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), lists.list, lists.count); }
 			return AGPU_OK;
 		  }, LISTS_OF_BOTH_SPLICED);
 		  if (status != AGPU_OK) return status; }

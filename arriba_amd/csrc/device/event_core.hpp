@@ -82,7 +82,8 @@ template <class Lanes = ListLanes> AGPU_HD bool has_only_intronic_reads(const Ba
 		const uint64_t k = base + lanes.lane;
 		if (k < end) {
 			const uint32_t read = t.read_lists[k];
-			if (b.filter[read] == FILTER_none)
+			if (b.walk != nullptr) { const uint8_t walk = b.walk[read]; exonic = (walk & WALK_UNFILTERED) && (walk & WALK_EXONIC); }
+			else if (b.filter[read] == FILTER_none)
 				for (int slot = 0; slot < b.n_aln[read]; ++slot)
 					if (b.abits[slot][read] & ABIT_EXONIC) exonic = true;
 		}
@@ -276,9 +277,10 @@ const uint8_t FILTER_in_vitro = 22;
 // end lie?  Answered once per alignment (8 bytes) instead of once per list entry from the CIGAR, strand, contig, start and end columns (the lists hold every
 // fragment ~40 times: at 10^7 fragments the kernel moved 218 GB).
 struct ClipSummary { int32_t position; uint16_t contig; uint16_t clipped; }; // clipped: 1 = the alignment is clipped by >= 3 bases at the end `position` (forward: its end, reverse: its start)
+const uint32_t CLIP_SUMMARIES_PER_READ = 4; // three alignments and a word of padding: the summaries of a read are one 32-byte piece of one line
 AGPU_HD ClipSummary clip_summary_of(const BatchView& b, uint64_t read, int slot) {
 	ClipSummary summary = { 0, 0, 0 };
-	if (slot >= (int) b.n_aln[read]) return summary;
+	if (slot >= (int) b.n_aln[read] || b.filter[read] != FILTER_none) return summary; // (is_in_vitro_artifact looks at the reads no filter discarded: source/filter_in_vitro.cpp:133-158)
 	const uint32_t min_clipped_length = 3;
 	const uint32_t* cigar = cigar_of(b, slot, read); const uint32_t n_cigar = b.cigar_count[slot][read];
 	const bool forward = b.abits[slot][read] & ABIT_STRAND;
@@ -336,16 +338,16 @@ template <class Lanes = ListLanes> AGPU_HD bool is_in_vitro_artifact(const Batch
 	uint32_t clipped_discordant_mates1 = 0, clipped_discordant_mates2 = 0;
 	for (uint64_t k = t.list_offset[3 * (uint64_t) c + 2] + lanes.lane; k < t.list_offset[3 * (uint64_t) c + 3]; k += lanes.lanes) {
 		const uint32_t read = t.read_lists[k];
-		if (b.filter[read] != FILTER_none) continue;
-		if (tables.clip_summaries != nullptr) {
+		if (tables.clip_summaries != nullptr) { // (a read that a filter discarded has no clipped end in its summaries: clip_summary_of; 32 bytes per read, one line per list entry)
 			for (int slot = 0; slot < 3; ++slot) {
-				const ClipSummary summary = tables.clip_summaries[3 * (uint64_t) read + slot];
+				const ClipSummary summary = tables.clip_summaries[CLIP_SUMMARIES_PER_READ * (uint64_t) read + slot];
 				if (!summary.clipped) continue;
 				if (summary.contig == contig1 && summary.position == breakpoint1) clipped_discordant_mates1++;
 				else if (summary.contig == contig2 && summary.position == breakpoint2) clipped_discordant_mates2++;
 			}
 			continue;
 		}
+		if (b.filter[read] != FILTER_none) continue;
 		for (int slot = 0; slot < b.n_aln[read]; ++slot) {
 			const uint32_t* cigar = cigar_of(b, slot, read); const uint32_t n_cigar = b.cigar_count[slot][read];
 			const bool forward = b.abits[slot][read] & ABIT_STRAND;
@@ -418,7 +420,8 @@ template <class Lanes = ListLanes> AGPU_HD uint32_t both_spliced_supporting_read
 	const uint64_t begin = t.list_offset[3 * (uint64_t) c], end = t.list_offset[3 * (uint64_t) c + 3];
 	for (uint64_t k = begin + lanes.lane; k < end; k += lanes.lanes) {
 		const uint32_t read = t.read_lists[k];
-		if (b.fbits[read] & FBIT_MULTIMAPPER) multimappers++; else if (b.filter[read] == FILTER_none) unique_mappers++;
+		if (b.walk != nullptr) { const uint8_t walk = b.walk[read]; if (walk & WALK_MULTIMAPPER) multimappers++; else if (walk & WALK_UNFILTERED) unique_mappers++; }
+		else if (b.fbits[read] & FBIT_MULTIMAPPER) multimappers++; else if (b.filter[read] == FILTER_none) unique_mappers++;
 	}
 	multimappers = lanes.sum(multimappers); unique_mappers = lanes.sum(unique_mappers);
 	if ((double) multimappers >= 0.5 * (double) (end - begin)) return 0;

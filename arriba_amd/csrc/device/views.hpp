@@ -94,7 +94,11 @@ struct BatchView {
 	uint32_t* gene_pool;
 	uint32_t* gene_pool_used;  // single counter
 	uint32_t gene_pool_capacity;
+	// null, or one byte per fragment with what the walks over read lists ask of a read (WALK_*: agpu_events.hip makes it in front of filter_both_intronic and recover_both_spliced):
+	// 10^8 bytes that stay in the last-level cache, where the walks used to drag a line of each of two or four byte columns per list entry
+	const uint8_t* walk = nullptr;
 };
+enum : uint8_t { WALK_UNFILTERED = 1, WALK_MULTIMAPPER = 2, WALK_EXONIC = 4 };
 
 }
 
