@@ -733,6 +733,7 @@ int agpu_upload_genome(agpu_ctx* ctx, const agpu_genome_view* in) {
 
 int agpu_upload_batch(agpu_ctx* ctx, const agpu_batch_view* in) {
 	if (!ctx || !in) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	{ std::lock_guard<std::mutex> lock(ctx->profile_mutex); ctx->failed_launch.clear(); } // (a new sample)
 	if (in->n >= 0xFFFFFFF0ull) { set_last_error("a batch holds at most 2^32-16 fragments; shard larger inputs"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
@@ -780,7 +781,7 @@ int agpu_reset(agpu_ctx* ctx) {
 	ctx->n_dummy = 0;
 	refresh_annotation_view(ctx);
 	HIP_CHECK(hipStreamSynchronize(s));
-	ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
+	ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false; ctx->failed_launch.clear();
 	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
 	return AGPU_OK;
 }

@@ -151,6 +151,7 @@ struct agpu_ctx {
 	agpu::DeviceBuffer contig[3], start[3], end[3], abits[3], cigar_offset[3], cigar_count[3], cigar_pool;
 	agpu::DeviceBuffer seq_offset[2], seq_length[2], seq_pool;
 	agpu::DeviceBuffer gene_count[3], genes[3], gene_pool, counters;
+	std::string failed_launch; // the first kernel launch of the sample that the runtime refused (KernelTimer), or empty
 	agpu::BatchView batch;
 	uint64_t batch_input_bytes = 0;
 	uint32_t max_read_length = 0;
@@ -242,7 +243,8 @@ struct KernelTimer {
 	agpu_ctx* ctx; bool armed;
 	hipStream_t stream;
 	KernelSample sample;
-	KernelTimer(agpu_ctx* c, const char* name, uint64_t bytes, hipStream_t on = nullptr) : ctx(c), armed(false), stream(on ? on : c->stream) {
+	const char* launched;
+	KernelTimer(agpu_ctx* c, const char* name, uint64_t bytes, hipStream_t on = nullptr) : ctx(c), armed(false), stream(on ? on : c->stream), launched(name) {
 		if (!ctx->profiling) return;
 		sample.name = name; sample.bytes = bytes; sample.ms = 0; sample.start = nullptr; sample.stop = nullptr;
 		{ std::lock_guard<std::mutex> lock(ctx->profile_mutex);
@@ -254,6 +256,10 @@ struct KernelTimer {
 		armed = true;
 	}
 	~KernelTimer() {
+		// a launch that the runtime refused (a grid of more than 2^32 work-items, too much LDS) says so only here: noted with the context, and the sample fails where its results are
+		// picked (agpu_select_candidates) instead of going on with whatever the kernel's output buffer held
+		const hipError_t refused = hipGetLastError();
+		if (refused != hipSuccess) { std::lock_guard<std::mutex> lock(ctx->profile_mutex); if (ctx->failed_launch.empty()) ctx->failed_launch = std::string(launched) + ": " + hipGetErrorString(refused); }
 		if (!armed) return;
 		(void) hipEventRecord(sample.stop, stream);
 		std::lock_guard<std::mutex> lock(ctx->profile_mutex);

@@ -662,6 +662,7 @@ template <class T> int gather_column(agpu_ctx* ctx, const char* scratch_name, co
 }
 extern "C" int agpu_select_candidates(agpu_ctx* ctx, int discarded, uint64_t* n) {
 	if (!ctx || !ctx->fusions_done || !n) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->failed_launch.empty()) { set_last_error("a kernel of this sample was not launched (" + ctx->failed_launch + "): its results are not to be written"); return AGPU_ERR_DEVICE; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	const uint32_t C = ctx->n_candidates;

@@ -761,13 +761,18 @@ __global__ void list_sizes_of_kernel(CandidateTable t, const uint32_t* candidate
 	const uint64_t at = 3 * (uint64_t) candidates[k / 3] + k % 3;
 	sizes[k] = (uint32_t) (t.list_offset[at + 1] - t.list_offset[at]);
 }
-__global__ void list_copy_of_kernel(CandidateTable t, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads) {
-	const uint32_t k = blockIdx.x; // one workgroup per list
-	if (k % 3 == 2 && t.discordant_before != nullptr) return; // (an implicit list: list_expand_of_kernel)
-	const uint32_t c = candidates[k / 3];
-	const uint64_t at = 3 * (uint64_t) c + k % 3;
-	const uint64_t begin = t.list_offset[at], target = compact_offset[k]; const uint32_t size = (uint32_t) (t.list_offset[at + 1] - begin);
-	for (uint32_t e = threadIdx.x; e < size; e += BLOCK) reads[target + e] = k % 3 == 2 ? t.read_lists[begin + e] : split_list_entry(t, c, begin + e);
+// (one wavefront per list, in a loop: most lists hold a handful of reads, and there are three per candidate -- with a workgroup per list the 7.6 M discarded candidates of a 20 M-fragment
+// sample were 22.7 M workgroups x 256 lanes, more work-items than a launch takes (2^32): the launch failed without a word and discarded.tsv counted the discarded reads of its
+// candidates from whatever the buffer held.  Found by the SHA-256 pin of discarded.tsv at 20 M fragments, round 5; the launches of this file are checked now.)
+__global__ void list_copy_of_kernel(CandidateTable t, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads, uint64_t n_lists) {
+	const uint32_t lane = threadIdx.x % 64;
+	for (uint64_t k = (uint64_t) blockIdx.x * (BLOCK / 64) + threadIdx.x / 64; k < n_lists; k += (uint64_t) gridDim.x * (BLOCK / 64)) {
+		if (k % 3 == 2 && t.discordant_before != nullptr) continue; // (an implicit list: list_expand_of_kernel)
+		const uint32_t c = candidates[k / 3];
+		const uint64_t at = 3 * (uint64_t) c + k % 3;
+		const uint64_t begin = t.list_offset[at], target = compact_offset[k]; const uint32_t size = (uint32_t) (t.list_offset[at + 1] - begin);
+		for (uint32_t e = lane; e < size; e += 64) reads[target + e] = k % 3 == 2 ? t.read_lists[begin + e] : split_list_entry(t, c, begin + e);
+	}
 }
 // the implicit discordant lists of some candidates: one wavefront per candidate walks its bucket again
 __global__ void __launch_bounds__(64) list_expand_of_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, BucketRanges ranges, int32_t max_mate_gap, uint32_t threshold, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads) {
@@ -804,7 +809,8 @@ extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* c
 	if (reads && entries > 0) {
 		if (capacity < entries) { set_last_error("capacity too small for the read lists"); return AGPU_ERR_INVALID; }
 		ALLOC(out, (size_t) entries * 4);
-		list_copy_of_kernel<<<(unsigned int) (3 * n), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>());
+		list_copy_of_kernel<<<(unsigned int) std::min<uint64_t>((3 * n + BLOCK / 64 - 1) / (BLOCK / 64), 1u << 20), BLOCK, 0, s>>>(ctx->candidates, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>(), 3 * n);
+		HIP_CHECK(hipGetLastError());
 		if (ctx->lists_implicit) {
 			DiscordantBuckets buckets; BucketRanges ranges;
 			const size_t Md1 = std::max<uint32_t>(ctx->lists_n_bucket_rows, 1);
@@ -812,6 +818,7 @@ extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* c
 			buckets.breakpoint1 = columns; buckets.breakpoint2 = columns + Md1; buckets.info = (const uint32_t*) (columns + 2 * Md1); buckets.read = buckets.info + Md1; buckets.anchor1 = (const int32_t*) (buckets.read + Md1); buckets.anchor2 = buckets.anchor1 + Md1;
 			ranges.begin = ctx->scratch("lists.bucket_begin").as<uint32_t>(); ranges.end = ctx->scratch("lists.bucket_end").as<uint32_t>(); ranges.had_split_reads = ctx->scratch("lists.had_split_reads").as<uint8_t>();
 			list_expand_of_kernel<<<(unsigned int) n, 64, 0, s>>>(ctx->annotation, ctx->candidates, buckets, ranges, ctx->lists_max_mate_gap, ctx->params.subsampling_threshold, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>());
+			HIP_CHECK(hipGetLastError());
 		}
 		HIP_CHECK(hipMemcpyAsync(reads, out.ptr, (size_t) entries * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));

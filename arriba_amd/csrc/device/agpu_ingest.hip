@@ -934,6 +934,7 @@ int agpu_ingest_begin(agpu_ctx* ctx, const agpu_ingest_config* config) {
 	if (config->n_contigs != ctx->genome.n_contigs) { set_last_error("the genome view on the device does not hold the contigs of the BAM header (upload it after the header was parsed)"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
+	{ std::lock_guard<std::mutex> lock(ctx->profile_mutex); ctx->failed_launch.clear(); } // (a new sample)
 	if (!ctx->piece_stream) {
 		int least = 0, greatest = 0;
 		HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
