@@ -449,17 +449,34 @@ def main():
         # (round 5: also with --gpus N -- the same call of the same library is timed at N = 1 and N = 8, arriba_workflow_sample as a collective call over a communicator:
         # RCCL alone on the GPUs, arriba_workflow_join_rccl; torch.distributed's gloo through callbacks where the harness stands in for the device, tests/bench_on_harness.py)
         through_workflow_library = not args.host_ingest and not args.python_stages
-        pipelined, primed, finish_ahead = through_workflow_library and not args.no_pipeline, [False], [False]
+        pipelined, primed, finish_ahead, collectives = through_workflow_library and not args.no_pipeline, [False], [False], [None]
         if through_workflow_library:
             pipeline = WorkflowSession(prefix + ".fa", prefix + ".gtf", params=params, device=local_rank)
             session = None
             if one_sample:
-                if dist.get_backend() == "nccl":
-                    unique = [pipeline.rccl_unique_id() if rank == 0 else None]
+                rccl_alone = dist.get_backend() == "nccl" and os.environ.get("ARRIBA_BENCH_COLLECTIVES") != "torch"
+                if rccl_alone:  # the communicator of RCCL alone; if a rank cannot have it (librccl not found), all of them take torch.distributed's collectives through the callbacks instead
+                    joined = 1
+                    try:
+                        unique = [pipeline.rccl_unique_id() if rank == 0 else None]
+                    except Exception as problem:
+                        unique, joined = [None], 0
+                        progress("arriba_workflow_rccl_unique_id: %s" % problem)
                     dist.broadcast_object_list(unique, src=0)
-                    pipeline.join_rccl(unique[0], rank, world)
-                else:
+                    if unique[0] is None:
+                        joined = 0
+                    else:
+                        try:
+                            pipeline.join_rccl(unique[0], rank, world)
+                        except Exception as problem:
+                            joined = 0
+                            progress("arriba_workflow_join_rccl: %s" % problem)
+                    verdict = torch.tensor([joined], device="cuda")
+                    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                    rccl_alone = bool(verdict.item())
+                if not rccl_alone:
                     pipeline.over_ranks()
+                collectives[0] = "RCCL: arriba_workflow_join_rccl" if rccl_alone else "torch.distributed (%s) through arriba_workflow_set_communicator" % dist.get_backend()
         else:
             session = HostSession(prefix + ".fa", prefix + ".gtf")  # assembly + annotation, once (resident)
         progress("assembly and annotation loaded")
@@ -704,7 +721,7 @@ def main():
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
                            "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor; fusions.tsv of a sample is formatted and written by a thread of the session beside the next sample (arriba_workflow_defer_output), the last one complete before the clock stops (arriba_workflow_flush)" + ("; the ingest of a sample is finished by the thread that feeds it, beside the stages of the sample in front (arriba_workflow_finish_ahead)" if finish_ahead[0] else "") if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
                            "parallelism": (("one sample over %d GPUs in the C++ driver (arriba_workflow_sample as a collective call; %s): every rank ingests its part of the file, one all-gather of the parts (%.3f s with export and merge), the stages on every rank, filter_mismappers shared out (one all-reduce of the verdict bytes), the rows of the files formatted by all ranks, rank 0 writes"
-                                            % (world, "RCCL: arriba_workflow_join_rccl" if dist.get_backend() == "nccl" else "host collectives through arriba_workflow_set_communicator", ingest_parts[-1].get("exchange_parts", 0.0))) if through_workflow_library else
+                                            % (world, collectives[0], ingest_parts[-1].get("exchange_parts", 0.0))) if through_workflow_library else
                                            ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
                                             % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0)))) if one_sample
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
