@@ -1001,6 +1001,14 @@ def test_samples_in_a_queue_through_one_session(built, emu_api, tmp_path):
     check_samples_in_a_queue("harness", tmp_path)
 
 
+def test_crc32_by_chunks_against_zlib(built):
+    """the CRC-32 of a BGZF block as bgzf_crc_kernel computes it (crc32_core.hpp: the payload as the end of a virtual 64 KB block, raw CRCs of 64 chunks, two table-driven
+    operators) against zlib's crc32: every length up to 300, lengths around the chunk and word boundaries up to 64 KB, every alignment, random / zero / 0xFF bytes"""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "crc_check"], check=True)
+    result = subprocess.run([os.path.join(ROOT, "tests", "emu", "crc_check")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert result.returncode == 0 and " 0 failures" in result.stdout, result.stdout[-2000:]
+
+
 def test_inflate_core_against_zlib(built):
     """the DEFLATE decoder of bgzf_inflate_kernel (inflate_core.hpp), stepped with one lane: 1120 blocks of seven kinds of data x sizes x levels x strategies equal zlib's bytes"""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "inflate_check"], check=True)
