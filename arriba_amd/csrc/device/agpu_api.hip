@@ -50,8 +50,8 @@ bool DeviceBuffer::release_idle_buffers() {
 		agpu_ctx* ctx = g_contexts[k];
 		if (ctx->device != device) continue; // memory of another device does not help the allocation that failed (and its context may be at work on another thread)
 		// the lanes of a session share their pool: while one feeds the other runs its stages, and nothing of the pool is idle.  A session of two lanes therefore does NOT get
-		// memory back here: an allocation that fails in it fails the sample (message with what was asked for and what is free); the caller closes the session and runs the
-		// sample in a new one without a queue -- one lane, a pool of its own --, where this function does help ("Memory").  The memo tables and task lists of filter_mismappers,
+		// memory back here: an allocation that fails in it fails the sample (message with what was asked for and what is free); the caller drains the queue
+		// (arriba_workflow_cancel) and runs the sample alone, where this function does help ("Memory").  The memo tables and task lists of filter_mismappers,
 		// the largest reservation, fall back to fewer workgroups by themselves (agpu_mismappers.hip)
 		if (ctx->pool.use_count() > 1) continue;
 		(void) hipStreamSynchronize(ctx->stream);
