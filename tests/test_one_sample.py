@@ -161,3 +161,27 @@ def test_a_failure_on_one_rank_ends_the_sample_on_all_ranks(dataset_files, built
     reports = run_workflow_over_ranks("harness", prefix, 2, str(tmp_path / "ranks"), 29795, [prefix + ".bam"], environment={"WORKFLOW_RANKS_BREAK_RANK": "1"})
     assert "another rank of the sample failed" in reports[0]["samples"][0]["error"]
     assert "error" in reports[1]["samples"][0] and "another rank" not in reports[1]["samples"][0]["error"]
+
+
+def test_workflow_library_over_ranks_reads_deflated_parts_and_refuses_what_one_rank_refuses(dataset_files, built, emu_api, tmp_path):
+    """The parts of a DEFLATED file (small blocks that straddle the cuts) through the C++ driver over three ranks: the files of one rank on the stored file.  And a file no rank may
+    cut -- plain gzip, not seekable by blocks -- is refused on every rank with the message of the part reader, nobody left in a collective."""
+    import gzip
+    import test_host_and_device_logic as host_tests
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libworkflow_on_harness.so"], check=True)
+    prefix = dataset_files("toy3k")
+    payload = host_tests._bam_payload(prefix + ".bam")
+    deflated, plain = str(tmp_path / "deflated.bam"), str(tmp_path / "plain.bam")
+    host_tests._write_bgzf(deflated, payload, 6, block=4093)
+    with gzip.open(plain, "wb") as out:
+        out.write(payload)
+    alone = run_workflow_over_ranks("harness", prefix, 1, str(tmp_path / "alone"), 29801, [prefix + ".bam"], plain=True)[0]
+    reports = run_workflow_over_ranks("harness", prefix, 3, str(tmp_path / "ranks"), 29802, [deflated, plain, deflated])
+    read = lambda directory, name: open(str(tmp_path / directory / name), "rb").read()
+    for report in reports:
+        first, refused, third = report["samples"]
+        assert "error" not in first and first["report"] == alone["samples"][0]["report"]
+        assert "error" in refused and "another rank" not in refused["error"], refused  # (every rank hears it from its own part reader)
+        assert "error" not in third and third["report"] == alone["samples"][0]["report"]  # (the session goes on behind a refused sample)
+    for k in (0, 2):
+        assert read("ranks", "sample%d.tsv" % k) == read("alone", "sample0.tsv") and read("ranks", "sample%d.discarded.tsv" % k) == read("alone", "sample0.discarded.tsv")
