@@ -729,6 +729,7 @@ struct arriba_workflow_session {
 	std::mutex mutex; std::condition_variable changed;
 	bool ingest_busy = false; // a lane is between agpu_ingest_begin and agpu_ingest_finish
 	bool defer_output = false;
+	bool retrying = false; // arriba_workflow_sample runs a sample again after the device ran out of memory with two lanes (below)
 	bool finish_ahead = false; // arriba_workflow_finish_ahead: the feeder of a sample also finishes its ingest (the lanes keep their batch buffers)
 	// arriba_workflow_set_communicator / arriba_workflow_join_rccl: one sample over the ranks of a job; `joined`: the RCCL communicator this session made itself (and the state of
 	// its callbacks: host bytes bounced through the device of lane 0)
@@ -874,6 +875,27 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 	catch (const Failure& failure) { g_error = failure.text; status = -1; }
 	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); status = -1; }
 	if (lane) { lane->after_ingest = nullptr; lane->before_host_writer = nullptr; lane->options.chimeric_bam_file = nullptr; lane->options.output_file = nullptr; lane->options.discarded_output_file = nullptr; lane->report = nullptr; lane->timing = nullptr; session->processed_lane = (int) (lane == session->lanes[1]); }
+	// The device ran out of memory while the session had two lanes (advisor, round 4): their contexts share one pool of scratch buffers, of which nothing is idle while one lane
+	// feeds and the other runs its stages, so the device library gives nothing back by itself (DeviceBuffer::release_idle_buffers).  The session does what INTEGRATION.md ("Memory")
+	// used to ask of the caller: what was fed ahead is thrown away, the second lane is closed -- the pool belongs to one context again, which gives back what it keeps for its next
+	// sample when an allocation fails --, and the sample is run again, alone.  Once; the sample that was fed ahead is submitted again behind it.
+	if (status != 0 && lane != nullptr && !session->retrying && !session->over_ranks && session->lanes[1] != nullptr && g_error.find("hipMalloc failed") != std::string::npos) {
+		const std::string first_error = g_error;
+		const std::string behind = session->queue.empty() ? std::string() : session->queue.front()->bam;
+		session->drain();
+		session->join_writer_of(0); session->join_writer_of(1);
+		(void) session->take_deferred_error();
+		if (lane == session->lanes[1]) std::swap(session->lanes[0], session->lanes[1]);
+		delete session->lanes[1]; session->lanes[1] = nullptr; session->processed_lane = 0;
+		fprintf(stderr, "arriba_workflow_sample: %s -- with two samples in flight; '%s' is run again with the device to itself\n", first_error.c_str(), chimeric_bam_file);
+		session->retrying = true;
+		status = arriba_workflow_sample(session, chimeric_bam_file, output_file, discarded_output_file, report, timing);
+		session->retrying = false;
+		if (status == 0 && !behind.empty()) { // (as its caller submitted it: a failure to feed it is reported by the call that asks for it)
+			try { session->submit(behind.c_str()); }
+			catch (const Failure&) {} catch (const std::exception&) {}
+		}
+	}
 	return status;
 }
 

@@ -89,6 +89,8 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
  * ahead of the one at work.  arriba_workflow_sample(bam) with nothing submitted submits bam itself (the behaviour without this call).  A sample that was submitted and never
  * asked for is thrown away by arriba_workflow_close.  Returns 0, or a negative number with the text in arriba_workflow_last_error(). */
 int arriba_workflow_submit(arriba_workflow_session* session, const char* chimeric_bam_file);
+/* (If the device runs out of memory while two samples are in flight, arriba_workflow_sample throws away what was fed ahead, closes the second lane, runs its sample again with the device
+ * to itself and submits the other sample again behind it -- once; a sample that does not fit the device alone fails the call.  INTEGRATION.md, "Memory".) */
 /* on: arriba_workflow_sample returns when the last output file of the sample (-O if given, else -o) has everything it needs off the device; the file is formatted and written
  * by a thread of the session while the next sample is worked on.  It is complete when the next-but-one arriba_workflow_sample of the session has returned (the writer works from a sample detached from its host session --
  * ahost_detach_sample -- so the feed of the lane's next sample does not wait for it), or

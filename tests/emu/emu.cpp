@@ -138,10 +138,14 @@ void emu_default_params(agpu_params* p) {
 	p->mismatch_pvalue_cutoff = 0.01; p->max_kmer_content = 0.6; p->evalue_cutoff = 0.3; p->max_mismapper_fraction = 0.8; p->fragment_length = 200; p->exonic_fraction = 0.33; p->min_support = 2;
 	for (int f = 1; f < AGPU_FILTER_COUNT; ++f) p->filter_enabled[f] = 1;
 }
-emu_ctx* emu_create(int, const agpu_params* params) { emu_ctx* ctx = new emu_ctx(); if (params) ctx->params = *params; else emu_default_params(&ctx->params); memset(ctx->stage_counts, 0, sizeof(ctx->stage_counts)); return ctx; }
+// (agpu_debug_fail_allocation_in_finish on the harness: the next `count` calls of emu_ingest_finish behave as the device does when an allocation fails inside agpu_ingest_finish --
+// a context that is alone gives back its idle buffers and goes on; the lanes of a session, whose contexts share a pool, fail the sample with the device library's message)
+static int g_live_contexts = 0, g_failing_allocations = 0;
+void emu_debug_fail_allocation_in_finish(int count) { g_failing_allocations = count; }
+emu_ctx* emu_create(int, const agpu_params* params) { emu_ctx* ctx = new emu_ctx(); if (params) ctx->params = *params; else emu_default_params(&ctx->params); memset(ctx->stage_counts, 0, sizeof(ctx->stage_counts)); ++g_live_contexts; return ctx; }
 emu_ctx* emu_create_sibling(emu_ctx* of) { return of ? emu_create(0, &of->params) : nullptr; } // (the harness has no scratch buffers to share)
 int emu_keep_batch_buffers(emu_ctx*, int) { return AGPU_OK; } // (... and none to hand from lane to lane: every context of the harness owns its batch)
-void emu_destroy(emu_ctx* ctx) { delete ctx; }
+void emu_destroy(emu_ctx* ctx) { if (ctx) --g_live_contexts; delete ctx; }
 // (RCCL is the device library's: a workflow driver built over the harness is given a communicator of host collectives -- arriba_workflow_set_communicator -- and never gets here)
 static int no_rccl() { g_error = "the stepping harness has no RCCL: hand the session a communicator of host collectives (arriba_workflow_set_communicator)"; return AGPU_ERR_INVALID; }
 int emu_shard_merge_rccl(emu_ctx*, void*, uint32_t, agpu_ingest_result*) { return no_rccl(); }

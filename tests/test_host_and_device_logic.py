@@ -995,6 +995,11 @@ def check_samples_in_a_queue(mode, tmp_path):
         assert report[queued] == report[alone], queued
         assert read(queued + ".tsv") == read(alone + ".tsv") and read(queued + ".discarded.tsv") == read(alone + ".discarded.tsv"), queued
     assert len(read("alone1.tsv").splitlines()) > 5
+    if mode == "harness":  # the device out of memory with two lanes: run again alone, once (workflow.cpp: arriba_workflow_sample)
+        assert report["retried1"] == report["alone2"] and report["retried2"] == report["alone1"] and report["after_failure"] == report["alone1"]
+        assert "hipMalloc failed" in report["second_failure"], report["second_failure"]
+        for retried, alone in (("retried1", "alone2"), ("retried2", "alone1"), ("after_failure", "alone1")):
+            assert read(retried + ".tsv") == read(alone + ".tsv") and read(retried + ".discarded.tsv") == read(alone + ".discarded.tsv"), retried
 
 
 def test_samples_in_a_queue_through_one_session(built, emu_api, tmp_path):

@@ -77,6 +77,24 @@ session.cancel()  # fed AND finished ahead, never asked for
 result["ahead4"] = session.sample(bam1, path("ahead4.tsv"), path("ahead4.discarded.tsv"))
 session.finish_ahead(False)
 result["ahead5"] = session.sample(bam2, path("ahead5.tsv"), path("ahead5.discarded.tsv"))
+# the device runs out of memory while two samples are in flight (harness: agpu_debug_fail_allocation_in_finish makes the next agpu_ingest_finish fail as the device library does with
+# two lanes): the session throws away what was fed ahead, closes its second lane, runs the sample again alone and submits the other one again
+if mode == "harness":
+    session.submit(bam2)
+    session.submit(bam1)
+    _harness.emu_debug_fail_allocation_in_finish(1)
+    result["retried1"] = session.sample(bam2, path("retried1.tsv"), path("retried1.discarded.tsv"))
+    result["retried2"] = session.sample(bam1, path("retried2.tsv"), path("retried2.discarded.tsv"))  # (submitted again by the session behind the retry)
+    session.submit(bam2)
+    session.submit(bam1)
+    _harness.emu_debug_fail_allocation_in_finish(-1)  # (... and a failure of the retry as well -- a device that is too small for the sample -- is the caller's to hear)
+    try:
+        session.sample(bam2, path("failed.tsv"))
+        result["second_failure"] = "accepted"
+    except ArribaError as error:
+        result["second_failure"] = str(error)
+    _harness.emu_debug_fail_allocation_in_finish(0)
+    result["after_failure"] = session.sample(bam1, path("after_failure.tsv"), path("after_failure.discarded.tsv"))
 session.submit(bam1)  # left behind: arriba_workflow_close throws it away
 session.close()
 json.dump(result, open(path("result.json"), "w"))
