@@ -320,7 +320,7 @@ class WorkflowReport(ctypes.Structure):
 
 
 class WorkflowTiming(ctypes.Structure):
-    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format", "feed_read", "feed_push", "feed_total", "exchange_parts", "exchange_verdicts", "exchange_rows")]
+    _fields_ = [(name, ctypes.c_double) for name in ("total", "feed", "ingest", "adopt", "stages", "filter_mismappers", "output", "output_results", "output_rows", "output_format", "feed_read", "feed_push", "feed_total", "exchange_parts", "exchange_verdicts", "exchange_rows", "shard_fragments", "exchanged_bytes")]
 
 
 WORKFLOW_MAX, WORKFLOW_MIN, WORKFLOW_SUM = 0, 1, 2

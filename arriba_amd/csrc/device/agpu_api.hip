@@ -597,6 +597,7 @@ int finish_batch_setup(agpu_ctx* ctx) {
 	ctx->have_batch = true; ctx->annotated = false; ctx->stage1_done = false; ctx->stage2_done = false; ctx->fusions_done = false;
 	ctx->evalue_done = false; ctx->iteration_order_done = false; ctx->kmer_index_done = false; ctx->genomic_support_marked = false; ctx->confidence_candidates = 0xFFFFFFFFu;
 	ctx->n_dummy = 0; ctx->candidates_imported = false;
+	ctx->global_n = 0; ctx->read_sharded = false; ctx->state_imported = false; ctx->sample_gene_read_counts_set = false; // (a batch of its own until agpu_set_shard / agpu_shard_keep say otherwise)
 	refresh_annotation_view(ctx);
 	if (ctx->have_genome) TRY(build_tables(ctx));
 	return AGPU_OK;
@@ -1093,6 +1094,11 @@ int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter) {
 	if (!ctx || !ctx->have_batch || !filter) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (ctx->read_sharded) { // (the reads sharded over the ranks: the filters of the fragments of the SAMPLE, from the replicated states)
+		if (!ctx->state_imported) { set_last_error("the reads of the sample are sharded: agpu_read_state_import must run first"); return AGPU_ERR_INVALID; }
+		if (ctx->global_n) HIP_CHECK(hipMemcpy(filter, ctx->scratch("sharded.filter").ptr, ctx->global_n, hipMemcpyDeviceToHost));
+		return AGPU_OK;
+	}
 	if (ctx->n) HIP_CHECK(hipMemcpy(filter, ctx->filter.ptr, ctx->n, hipMemcpyDeviceToHost));
 	return AGPU_OK;
 }

@@ -193,6 +193,11 @@ struct agpu_ctx {
 	uint64_t annotation_serial = 1, gene_read_counts_of_annotation = 0; // every annotate of a batch takes a new serial; scratch "events.gene_read_count" holds the counts of that one
 	std::vector<uint32_t> host_gene_read_counts;
 	uint64_t global_n = 0; // fragments of the whole sample when this context holds one shard of it (agpu_set_shard); 0 = not sharded
+	// One sample over the GPUs of a node with the reads sharded (agpu_shard_keep, include/arriba_gpu.h): the candidate table and every read list are here (global name ranks), the reads
+	// of the other ranks are not; what a walk over read lists asks of a read is replicated, one byte per fragment of the SAMPLE (agpu_read_state_import): scratch "sharded.filter"
+	// (the filter ids) and "sharded.bits" (WALK_MULTIMAPPER | WALK_EXONIC) -- agpu_api.hip: candidate_walk_batch
+	bool read_sharded = false, state_imported = false, sample_gene_read_counts_set = false;
+	uint32_t n_clipped_entries = 0; // agpu_in_vitro_clipped_mates -> agpu_copy_in_vitro_clipped_mates (scratch "sharded.clipped_entries")
 
 	// scratch
 	agpu::DeviceBuffer unmapped_keys, sort_scratch, sorted_keys, scan_flags, scan_ids;
@@ -236,6 +241,11 @@ bool release_ingest_buffers(agpu_ctx* ctx);
 void take_sample_buffers(agpu_ctx* ctx, bool batch_group = true, bool stage_group = true);
 // agpu_api.hip: what follows the columns of a batch, whoever filled them (agpu_upload_batch, or the ingest on the device: agpu_ingest.hip)
 int finish_batch_setup(agpu_ctx* ctx);
+// agpu_api.hip: the batch a stage sees that judges CANDIDATES by their read lists.  One context with all reads: its own batch (with walk bytes made now, if asked for).  The reads
+// sharded over the ranks: a view of the global_n fragments of the sample that holds the replicated filters (and the walk bytes made from them) and NOTHING else -- a stage that
+// wants more of a read runs where the read is.  pull_filters_of_own_reads: behind a stage that changed filters of reads through that view (the same on every rank).
+int candidate_walk_batch(agpu_ctx* ctx, BatchView& batch, bool with_walk_bytes);
+int pull_filters_of_own_reads(agpu_ctx* ctx);
 
 // Brackets one kernel launch (or library call) with HIP events when profiling is on.  Usage:
 //   { KernelTimer timer(ctx, "stage2_kernel", bytes); stage2_kernel<<<...>>>(...); }

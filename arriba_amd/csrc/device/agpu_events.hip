@@ -237,6 +237,39 @@ __global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView co
 	if (list_entries_of(t, c, 2) > LONG_LIST && in_vitro_looks_at(t, c)) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (the verdict walks the discordant mates: in_vitro_wave_kernel)
 	if (is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
 }
+// the reads sharded over the ranks: the clipped discordant mates of every candidate the stage looks at, over the reads THIS context holds (event_core.hpp: in_vitro_clipped_mates skips
+// the others); a wavefront per 64 candidates would idle on the long lists: one wavefront per candidate, the lanes stride over its list
+__global__ void __launch_bounds__(BLOCK) in_vitro_partial_kernel(BatchView b, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end, uint32_t* clipped) {
+	const WaveLanes lanes;
+	for (uint64_t c = first + ((blockIdx.x * (uint64_t) BLOCK + threadIdx.x) >> 6); c < end; c += (uint64_t) gridDim.x * (BLOCK / 64)) { // (a bounded grid: a sample has tens of millions of candidates)
+		if (!in_vitro_looks_at(t, (uint32_t) c) || list_entries_of(t, (uint32_t) c, 2) == 0) continue;
+		uint32_t clipped1 = 0, clipped2 = 0;
+		in_vitro_clipped_mates(b, tables, t, (uint32_t) c, clipped1, clipped2, lanes);
+		if (lanes.lane == 0) { clipped[2 * c] = clipped1; clipped[2 * c + 1] = clipped2; }
+	}
+}
+__global__ void clipped_entry_flag_kernel(const uint32_t* clipped, uint32_t n, uint8_t* flags) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c < n) flags[c] = (clipped[2 * (uint64_t) c] | clipped[2 * (uint64_t) c + 1]) != 0;
+}
+__global__ void clipped_entry_write_kernel(const uint32_t* clipped, const uint32_t* selected, uint32_t n_selected, uint32_t* entries) {
+	const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= n_selected) return;
+	const uint32_t c = selected[k];
+	entries[3 * (uint64_t) k] = c; entries[3 * (uint64_t) k + 1] = clipped[2 * (uint64_t) c]; entries[3 * (uint64_t) k + 2] = clipped[2 * (uint64_t) c + 1];
+}
+__global__ void clipped_entry_add_kernel(const uint32_t* entries, uint64_t n_entries, uint32_t n_candidates, uint32_t* clipped, unsigned int* error) {
+	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (k >= n_entries) return;
+	const uint32_t c = entries[3 * k];
+	if (c >= n_candidates) { atomicOr(error, 1u); return; }
+	atomicAdd(&clipped[2 * (uint64_t) c], entries[3 * k + 1]); atomicAdd(&clipped[2 * (uint64_t) c + 1], entries[3 * k + 2]);
+}
+__global__ void in_vitro_verdict_kernel(AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, const uint32_t* clipped) {
+	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
+	if (c >= t.n || !in_vitro_looks_at(t, c)) return;
+	if (in_vitro_verdict(ann, coverage, tables, t, c, clipped[2 * (uint64_t) c], clipped[2 * (uint64_t) c + 1])) t.filter[c] = FILTER_in_vitro;
+}
 __global__ void __launch_bounds__(BLOCK) in_vitro_wave_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, const uint32_t* long_list, const uint32_t* n_long) {
 	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
 	if (wave >= *n_long) return;
@@ -323,6 +356,9 @@ int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& th
 	const size_t n_genes = (size_t) ctx->n_genes + ctx->n_dummy;
 	DeviceBuffer& gene_read_count = ctx->scratch("events.gene_read_count");
 	// (the counts depend on the gene sets of the fragments alone: filter_in_vitro and recover_both_spliced ask for them one after the other, counted once per annotation)
+	if (ctx->read_sharded) { // the reads sharded over the ranks: the counts of the SAMPLE, brought by agpu_set_gene_read_counts (this context's own reads: agpu_gene_read_counts)
+		if (!ctx->sample_gene_read_counts_set || ctx->host_gene_read_counts.size() != n_genes) { set_last_error("the reads of the sample are sharded: agpu_set_gene_read_counts must run first"); return AGPU_ERR_INVALID; }
+	} else
 	if (ctx->gene_read_counts_of_annotation != ctx->annotation_serial || ctx->host_gene_read_counts.size() != n_genes) {
 		ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4);
 		HIP_CHECK(hipMemsetAsync(gene_read_count.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
@@ -336,28 +372,11 @@ int expression_proxy(agpu_ctx* ctx, float high_expression_quantile, uint32_t& th
 	return AGPU_OK;
 }
 
-// the list of the candidates a thread kernel notes for the wavefronts, and their number read back (the launch of the second kernel is sized by it)
-// what the walks over read lists ask of a read, in one byte per fragment (views.hpp: BatchView::walk)
-__global__ void walk_byte_kernel(BatchView b, uint8_t* walk) {
-	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (i >= b.n) return;
-	uint8_t byte = b.filter[i] == FILTER_none ? WALK_UNFILTERED : 0;
-	if (b.fbits[i] & FBIT_MULTIMAPPER) byte |= WALK_MULTIMAPPER;
-	for (int slot = 0; slot < b.n_aln[i]; ++slot) if (b.abits[slot][i] & ABIT_EXONIC) byte |= WALK_EXONIC;
-	walk[i] = byte;
-}
-// the batch with its walk bytes as of now (the filters of the reads change from stage to stage: made anew by every stage that walks with them)
-int batch_with_walk_bytes(agpu_ctx* ctx, BatchView& batch) {
-	batch = ctx->batch;
-	if (ctx->n == 0) return AGPU_OK;
-	DeviceBuffer& walk = ctx->scratch("events.walk_bytes");
-	ALLOC(walk, ctx->n);
-	{ KernelTimer timer(ctx, "walk_byte_kernel", ctx->n * 7);
-	  walk_byte_kernel<<<(unsigned int) ((ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, ctx->stream>>>(ctx->batch, walk.as<uint8_t>()); }
-	batch.walk = walk.as<uint8_t>();
-	return AGPU_OK;
-}
+// the batch a stage sees that judges candidates by their read lists, with its walk bytes as of now (agpu_sharded.hip: candidate_walk_batch -- the own batch, or, the reads sharded
+// over the ranks, the replicated states of the fragments of the sample)
+int batch_with_walk_bytes(agpu_ctx* ctx, BatchView& batch) { return candidate_walk_batch(ctx, batch, true); }
 
+// the list of the candidates a thread kernel notes for the wavefronts, and their number read back (the launch of the second kernel is sized by it)
 struct LongLists {
 	uint32_t* list = nullptr; uint32_t* count = nullptr;
 	int prepare(agpu_ctx* ctx, uint32_t candidates) {
@@ -705,13 +724,16 @@ extern "C" int agpu_get_selected_candidates(agpu_ctx* ctx, const agpu_selected_c
 }
 extern "C" int agpu_get_filters_of(agpu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint8_t* filter) {
 	if (!ctx || !ctx->have_batch || (n > 0 && (!fragments || !filter))) { set_last_error("no batch uploaded"); return AGPU_ERR_INVALID; }
-	for (uint64_t k = 0; k < n; ++k) if (fragments[k] >= ctx->n) { set_last_error("fragment index out of range"); return AGPU_ERR_INVALID; }
+	// (the reads sharded over the ranks: the fragments are global name ranks, their filters the replicated ones)
+	if (ctx->read_sharded && !ctx->state_imported) { set_last_error("the reads of the sample are sharded: agpu_read_state_import must run first"); return AGPU_ERR_INVALID; }
+	const uint64_t known = ctx->read_sharded ? ctx->global_n : ctx->n;
+	for (uint64_t k = 0; k < n; ++k) if (fragments[k] >= known) { set_last_error("fragment index out of range"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	if (n == 0) return AGPU_OK;
 	DeviceBuffer& ids = ctx->scratch("filters_of.ids");
 	ALLOC(ids, n * 4);
 	HIP_CHECK(hipMemcpyAsync(ids.ptr, fragments, n * 4, hipMemcpyHostToDevice, ctx->stream));
-	const int status = gather_column<uint8_t>(ctx, "filters_of.out", ctx->filter.as<uint8_t>(), 0, ids.as<uint32_t>(), n, filter);
+	const int status = gather_column<uint8_t>(ctx, "filters_of.out", ctx->read_sharded ? ctx->scratch("sharded.filter").as<uint8_t>() : ctx->filter.as<uint8_t>(), 0, ids.as<uint32_t>(), n, filter);
 	if (status != AGPU_OK) return status;
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	return AGPU_OK;
@@ -830,9 +852,12 @@ extern "C" int agpu_recover_isoforms(agpu_ctx* ctx, uint64_t* remaining) {
 	return AGPU_OK;
 }
 
-extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantile, uint64_t* remaining) {
+namespace {
+// clipped: null = the verdicts walk the discordant lists themselves (this context holds every read); or the clipped discordant mates of every candidate [2 * C], counted where
+// the reads are (agpu_filter_in_vitro_sharded)
+int filter_in_vitro_stage(agpu_ctx* ctx, float high_expression_quantile, const uint32_t* clipped, uint64_t* remaining) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
-	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n)) { set_last_error("filter_in_vitro needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
+	if (clipped == nullptr && (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n))) { set_last_error("filter_in_vitro needs the read lists and all fragments in one context (the reads sharded over the ranks: agpu_in_vitro_clipped_mates / agpu_filter_in_vitro_sharded)"); return AGPU_ERR_INVALID; }
 	if (!ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
@@ -870,6 +895,10 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 		tables.high_expression_threshold = threshold;
 		tables.pair_keys = unique_keys.as<uint64_t>(); tables.pair_counts = unique_counts.as<uint32_t>(); tables.n_pairs = runs; // (the run of ~0 keys at the end is never looked up)
 		tables.clip_summaries = nullptr;
+		if (clipped != nullptr) { // (3') the verdicts from the counts
+			KernelTimer timer(ctx, "in_vitro_verdict_kernel", (uint64_t) C * 88);
+			in_vitro_verdict_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, tables, t, clipped);
+		} else {
 		if (ctx->n > 0) { // the clipped ends of the alignments, summarised once in 8 bytes each: the verdicts walk the read lists and would otherwise gather CIGAR ends, strand, contig and
 			// position of up to three alignments per list entry (10^8 fragments: in_vitro_kernel 219 -> 66 + 3 ms, profiles/r03h_output_side_and_ingest.txt)
 			DeviceBuffer& summaries = ctx->scratch("events.clip_summaries");
@@ -891,6 +920,7 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 			return AGPU_OK;
 		}, LISTS_OF_IN_VITRO);
 		if (status != AGPU_OK) return status;
+		}
 	}
 	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
@@ -903,10 +933,111 @@ extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantil
 	if (remaining) *remaining = kept;
 	return AGPU_OK;
 }
+}
+extern "C" int agpu_filter_in_vitro(agpu_ctx* ctx, float high_expression_quantile, uint64_t* remaining) { return filter_in_vitro_stage(ctx, high_expression_quantile, nullptr, remaining); }
+
+// ---- filter_in_vitro and the expression proxy with the reads sharded over the ranks (include/arriba_gpu.h) ---------------------------------------------------------------
+extern "C" int agpu_gene_read_counts(agpu_ctx* ctx, uint32_t* counts) {
+	if (!ctx || !ctx->annotated || !counts) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const size_t n_genes = (size_t) ctx->n_genes + ctx->n_dummy;
+	DeviceBuffer& mine = ctx->scratch("sharded.gene_read_count");
+	ALLOC(mine, std::max<size_t>(n_genes, 1) * 4);
+	HIP_CHECK(hipMemsetAsync(mine.ptr, 0, std::max<size_t>(n_genes, 1) * 4, s));
+	if (ctx->n > 0) { KernelTimer timer(ctx, "gene_read_count_kernel", ctx->n * 22); gene_read_count_kernel<<<(unsigned int) std::min<uint64_t>((ctx->n + BLOCK - 1) / BLOCK, 2048), BLOCK, 0, s>>>(ctx->batch, mine.as<uint32_t>()); }
+	if (n_genes > 0) HIP_CHECK(hipMemcpyAsync(counts, mine.ptr, n_genes * 4, hipMemcpyDefault, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	collect_kernel_samples(ctx);
+	return AGPU_OK;
+}
+extern "C" int agpu_set_gene_read_counts(agpu_ctx* ctx, const uint32_t* counts) {
+	if (!ctx || !ctx->annotated || !counts) { set_last_error("agpu_annotate must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	const size_t n_genes = (size_t) ctx->n_genes + ctx->n_dummy;
+	DeviceBuffer& gene_read_count = ctx->scratch("events.gene_read_count");
+	ALLOC(gene_read_count, std::max<size_t>(n_genes, 1) * 4);
+	ctx->host_gene_read_counts.assign(n_genes, 0);
+	if (n_genes > 0) {
+		HIP_CHECK(hipMemcpy(ctx->host_gene_read_counts.data(), counts, n_genes * 4, hipMemcpyDefault));
+		HIP_CHECK(hipMemcpy(gene_read_count.ptr, ctx->host_gene_read_counts.data(), n_genes * 4, hipMemcpyHostToDevice));
+	}
+	ctx->sample_gene_read_counts_set = true;
+	return AGPU_OK;
+}
+extern "C" int agpu_in_vitro_clipped_mates(agpu_ctx* ctx, uint64_t* n_entries) {
+	if (!ctx || !ctx->fusions_done || !ctx->read_sharded) { set_last_error("agpu_shard_keep and agpu_find_fusions_from_emissions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	ctx->n_clipped_entries = 0;
+	if (n_entries) *n_entries = 0;
+	if (C == 0 || !ctx->params.filter_enabled[FILTER_in_vitro]) return AGPU_OK;
+	DeviceBuffer& clipped = ctx->scratch("sharded.clipped"); DeviceBuffer& flags = ctx->scratch("sharded.clipped_flags"); DeviceBuffer& selected = ctx->scratch("sharded.clipped_selected");
+	DeviceBuffer& count = ctx->scratch("sharded.counter"); DeviceBuffer& scratch = ctx->scratch("events.rocprim"); DeviceBuffer& entries = ctx->scratch("sharded.clipped_entries");
+	ALLOC(clipped, (size_t) C * 8); ALLOC(flags, C); ALLOC(selected, (size_t) C * 4); ALLOC(count, 16);
+	HIP_CHECK(hipMemsetAsync(clipped.ptr, 0, (size_t) C * 8, s));
+	HIP_CHECK(hipMemsetAsync(count.ptr, 0, 16, s));
+	InVitroTables tables; memset(&tables, 0, sizeof(tables));
+	if (ctx->n > 0) {
+		DeviceBuffer& summaries = ctx->scratch("events.clip_summaries");
+		ALLOC(summaries, CLIP_SUMMARIES_PER_READ * ctx->n * sizeof(ClipSummary));
+		{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20));
+		  clip_summary_kernel<<<(unsigned int) ((3 * ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, summaries.as<ClipSummary>()); }
+		tables.clip_summaries = summaries.as<ClipSummary>();
+		const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+			KernelTimer timer(ctx, "in_vitro_partial_kernel", (uint64_t) (end - begin) * 20 + (uint64_t) ctx->n_list_entries * 4);
+			in_vitro_partial_kernel<<<(unsigned int) std::min<uint64_t>(((uint64_t) (end - begin) * 64 + BLOCK - 1) / BLOCK, 1u << 18), BLOCK, 0, s>>>(ctx->batch, tables, window, begin, end, clipped.as<uint32_t>());
+			return AGPU_OK;
+		}, LISTS_OF_IN_VITRO);
+		if (status != AGPU_OK) return status;
+	}
+	clipped_entry_flag_kernel<<<(C + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(clipped.as<uint32_t>(), C, flags.as<uint8_t>());
+	size_t bytes = 0;
+	HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), selected.as<uint32_t>(), count.as<uint32_t>(), C, s));
+	if (bytes > scratch.capacity) ALLOC(scratch, bytes);
+	HIP_CHECK(rocprim::select(scratch.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), selected.as<uint32_t>(), count.as<uint32_t>(), C, s));
+	uint32_t n_selected = 0;
+	HIP_CHECK(hipMemcpyAsync(&n_selected, count.ptr, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	ALLOC(entries, std::max<size_t>(n_selected, 1) * AGPU_CLIPPED_MATES_ENTRY_BYTES);
+	if (n_selected > 0) clipped_entry_write_kernel<<<(n_selected + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(clipped.as<uint32_t>(), selected.as<uint32_t>(), n_selected, entries.as<uint32_t>());
+	HIP_CHECK(hipStreamSynchronize(s));
+	collect_kernel_samples(ctx);
+	ctx->n_clipped_entries = n_selected;
+	if (n_entries) *n_entries = n_selected;
+	return AGPU_OK;
+}
+extern "C" int agpu_copy_in_vitro_clipped_mates(agpu_ctx* ctx, void* destination) {
+	if (!ctx || !destination) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	if (ctx->n_clipped_entries) HIP_CHECK(hipMemcpy(destination, ctx->scratch("sharded.clipped_entries").ptr, (size_t) ctx->n_clipped_entries * AGPU_CLIPPED_MATES_ENTRY_BYTES, hipMemcpyDefault));
+	return AGPU_OK;
+}
+extern "C" int agpu_filter_in_vitro_sharded(agpu_ctx* ctx, float high_expression_quantile, const void* entries, uint64_t n_entries, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done || !ctx->read_sharded || (n_entries > 0 && !entries)) { set_last_error("agpu_shard_keep and agpu_find_fusions_from_emissions must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	DeviceBuffer& clipped = ctx->scratch("sharded.clipped"); DeviceBuffer& staged = ctx->scratch("sharded.clipped_all"); DeviceBuffer& error = ctx->scratch("sharded.counter");
+	ALLOC(clipped, std::max<size_t>(C, 1) * 8); ALLOC(error, 16);
+	HIP_CHECK(hipMemsetAsync(clipped.ptr, 0, std::max<size_t>(C, 1) * 8, s));
+	HIP_CHECK(hipMemsetAsync(error.ptr, 0, 16, s));
+	if (n_entries > 0) {
+		ALLOC(staged, n_entries * AGPU_CLIPPED_MATES_ENTRY_BYTES);
+		HIP_CHECK(hipMemcpyAsync(staged.ptr, entries, n_entries * AGPU_CLIPPED_MATES_ENTRY_BYTES, hipMemcpyDefault, s));
+		clipped_entry_add_kernel<<<(unsigned int) ((n_entries + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(staged.as<uint32_t>(), n_entries, C, clipped.as<uint32_t>(), error.as<unsigned int>());
+		unsigned int bad = 0;
+		HIP_CHECK(hipMemcpyAsync(&bad, error.ptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (bad) { set_last_error("an entry of the clipped discordant mates names a candidate outside the table"); return AGPU_ERR_INVALID; }
+	}
+	return filter_in_vitro_stage(ctx, high_expression_quantile, clipped.as<uint32_t>(), remaining);
+}
 
 extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_recover, float high_expression_quantile, int32_t max_exon_size, uint32_t max_coverage, uint64_t* remaining) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
-	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n)) { set_last_error("recover_both_spliced needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
+	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n && !ctx->read_sharded)) { set_last_error("recover_both_spliced needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
 	if (!ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
@@ -965,13 +1096,17 @@ extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_
 
 extern "C" int agpu_recover_internal_tandem_duplication(agpu_ctx* ctx, uint32_t min_supporting_reads, float min_fraction_of_coverage, uint64_t* remaining) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
-	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n)) { set_last_error("recover_internal_tandem_duplication needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
+	if (ctx->candidates_imported || (ctx->global_n != 0 && ctx->global_n != ctx->n && !ctx->read_sharded)) { set_last_error("recover_internal_tandem_duplication needs the read lists and all fragments in one context"); return AGPU_ERR_INVALID; }
 	if (!ctx->have_coverage) { set_last_error("agpu_upload_coverage must run first"); return AGPU_ERR_INVALID; }
 	if (!ctx->iteration_order_done) { const int status = agpu_candidate_iteration_order(ctx, nullptr); if (status != AGPU_OK) return status; } // hazard H2
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	const uint32_t C = ctx->n_candidates;
-	const uint64_t n = ctx->n;
+	// (the reads sharded over the ranks: the stage runs on every rank over the replicated filters of ALL fragments of the sample -- the same verdicts, the same claims, the same
+	//  reads cleared everywhere -- and every rank takes the filters of its own reads from there: agpu_sharded.hip)
+	BatchView reads;
+	{ const int status = candidate_walk_batch(ctx, reads, false); if (status != AGPU_OK) return status; }
+	const uint64_t n = reads.n;
 	DeviceBuffer& counter = ctx->scratch("events.counter"); DeviceBuffer& verdict = ctx->scratch("events.itd_verdict"); DeviceBuffer& owner = ctx->scratch("events.itd_owner");
 	const size_t C1 = std::max<uint32_t>(C, 1), n1 = std::max<uint64_t>(n, 1);
 	ALLOC(counter, 16); ALLOC(verdict, C1); ALLOC(owner, n1 * 4);
@@ -981,17 +1116,18 @@ extern "C" int agpu_recover_internal_tandem_duplication(agpu_ctx* ctx, uint32_t 
 		const CandidateTable& t = ctx->candidates;
 		const unsigned int grid = (unsigned int) ((C + BLOCK - 1) / BLOCK);
 		// the duplication rate, because the coverage includes duplicates (:15-20)
-		count_duplicates_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(ctx->batch, counter.as<unsigned int>() + 1);
+		count_duplicates_kernel<<<tally_grid(n, BLOCK), BLOCK, 0, s>>>(reads, counter.as<unsigned int>() + 1);
 		unsigned int duplicates = 0;
 		HIP_CHECK(hipMemcpyAsync(&duplicates, counter.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		const float duplication_rate = 1.0 * duplicates / n;
 		HIP_CHECK(hipMemsetAsync(owner.ptr, 0xFF, n1 * 4, s));
 		{ KernelTimer timer(ctx, "itd_verdict_kernel", (uint64_t) C * 40);
-		  itd_verdict_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, t, ctx->params.max_itd_length, min_supporting_reads, min_fraction_of_coverage, ctx->params.subsampling_threshold, duplication_rate,
+		  itd_verdict_kernel<<<grid, BLOCK, 0, s>>>(reads, ctx->annotation, ctx->coverage, t, ctx->params.max_itd_length, min_supporting_reads, min_fraction_of_coverage, ctx->params.subsampling_threshold, duplication_rate,
 			ctx->cand_iteration_rank.as<uint32_t>(), verdict.as<uint8_t>(), owner.as<uint32_t>(), counter.as<unsigned int>() + 2); }
-		itd_recover_kernel<<<grid, BLOCK, 0, s>>>(ctx->batch, t, ctx->cand_iteration_rank.as<uint32_t>(), verdict.as<uint8_t>(), owner.as<uint32_t>());
-		itd_clear_reads_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, owner.as<uint32_t>());
+		itd_recover_kernel<<<grid, BLOCK, 0, s>>>(reads, t, ctx->cand_iteration_rank.as<uint32_t>(), verdict.as<uint8_t>(), owner.as<uint32_t>());
+		itd_clear_reads_kernel<<<(unsigned int) ((n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(reads, owner.as<uint32_t>());
+		{ const int status = pull_filters_of_own_reads(ctx); if (status != AGPU_OK) return status; }
 	}
 	if (C > 0) event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));

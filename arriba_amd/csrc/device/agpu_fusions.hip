@@ -650,7 +650,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	{
 		const char* knob = getenv("ARRIBA_IMPLICIT_LISTS"); const char* budget_knob = getenv("ARRIBA_LIST_BUDGET_GB");
 		const double budget_gb = budget_knob != nullptr && atof(budget_knob) > 0 ? atof(budget_knob) : 48.0;
-		const bool sharded = ctx->global_n != 0 && ctx->global_n != ctx->n;
+		const bool sharded = ctx->global_n != 0 && ctx->global_n != ctx->n && !ctx->read_sharded; // (the candidates of a gene pair with their owner: round 1.  The reads sharded and every candidate on every rank -- agpu_sharded.hip -- walks windows of lists like one context)
 		bool implicit = !sharded && ((knob != nullptr && knob[0] == '1') || (double) total_list * 4 > budget_gb * 1e9);
 		if (!implicit && !ctx->cand_read_lists.allocate((size_t) std::max<uint64_t>(total_list, 1) * 4)) {
 			if (sharded) { set_last_error("the read lists of the candidates hold " + std::to_string(total_list) + " entries (" + std::to_string(total_list * 4 >> 30) + " GB): more than the device has free; lower -U or shard the input"); return AGPU_ERR_CAPACITY; }

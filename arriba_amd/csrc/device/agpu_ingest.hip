@@ -1650,12 +1650,9 @@ int agpu_get_coverage(agpu_ctx* ctx, uint16_t* coverage, uint8_t* fragment_start
 	return AGPU_OK;
 }
 
-int agpu_detect_strandedness(agpu_ctx* ctx, int* strandedness) {
-	if (!ctx || !ctx->have_batch || !ctx->have_annotation) { set_last_error("annotation and batch must be on the device"); return AGPU_ERR_INVALID; }
-	HIP_CHECK(hipSetDevice(ctx->device));
+// the votes of detect_strandedness (source/read_stats.cpp:94-143) among the first `wanted` informative fragments of this context, in name order
+static int strandedness_votes(agpu_ctx* ctx, uint32_t wanted, uint32_t& informative, uint32_t& matching) {
 	hipStream_t s = ctx->stream;
-	const uint32_t sample_size = 100;
-	const float threshold = 0.95;
 	DeviceBuffer& counters = ctx->scratch("strandedness.counters"); DeviceBuffer& flags = ctx->scratch("strandedness.flags");
 	ALLOC(counters, IC_COUNT * 4);
 	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, IC_COUNT * 4, s));
@@ -1665,21 +1662,116 @@ int agpu_detect_strandedness(agpu_ctx* ctx, int* strandedness) {
 	for (int k = 0; k < 3; ++k) batch.abits[k] = ctx->pristine_abits[k].as<uint8_t>();
 	uint32_t host_counters[IC_COUNT]; memset(host_counters, 0, sizeof(host_counters));
 	uint64_t chunk = 1u << 20;
-	for (uint64_t first = 0; first < ctx->n && host_counters[IC_STRAND_COUNT] < sample_size; first += chunk, chunk *= 4) {
+	for (uint64_t first = 0; first < ctx->n && host_counters[IC_STRAND_COUNT] < wanted; first += chunk, chunk *= 4) {
 		const uint64_t count = std::min<uint64_t>(chunk, ctx->n - first);
 		ALLOC(flags, count);
 		strandedness_flag_kernel<<<grid_for(count), BLOCK, 0, s>>>(batch, annotation, first, count, flags.as<uint8_t>());
-		strandedness_take_kernel<<<1, 64, 0, s>>>(flags.as<uint8_t>(), count, sample_size, counters.as<uint32_t>());
+		strandedness_take_kernel<<<1, 64, 0, s>>>(flags.as<uint8_t>(), count, wanted, counters.as<uint32_t>());
 		HIP_CHECK(hipMemcpyAsync(host_counters, counters.ptr, IC_COUNT * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 	}
-	const uint32_t count = host_counters[IC_STRAND_COUNT], matching = host_counters[IC_STRAND_MATCHING];
+	informative = host_counters[IC_STRAND_COUNT]; matching = host_counters[IC_STRAND_MATCHING];
+	return AGPU_OK;
+}
+int agpu_detect_strandedness(agpu_ctx* ctx, int* strandedness) {
+	if (!ctx || !ctx->have_batch || !ctx->have_annotation) { set_last_error("annotation and batch must be on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	const uint32_t sample_size = 100;
+	const float threshold = 0.95;
+	uint32_t count = 0, matching = 0;
+	TRY(strandedness_votes(ctx, sample_size, count, matching));
 	int verdict = 0;
 	if (count >= sample_size) {
 		if (matching < (1 - threshold) * count) verdict = 2;
 		else if (matching > threshold * count) verdict = 1;
 	}
 	if (strandedness) *strandedness = verdict;
+	return AGPU_OK;
+}
+int agpu_strandedness_votes(agpu_ctx* ctx, uint32_t wanted, uint32_t* informative, uint32_t* matching) {
+	if (!ctx || !ctx->have_batch || !ctx->have_annotation) { set_last_error("annotation and batch must be on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	uint32_t count = 0, match = 0;
+	if (wanted > 0) TRY(strandedness_votes(ctx, wanted, count, match));
+	if (informative) *informative = count;
+	if (matching) *matching = match;
+	return AGPU_OK;
+}
+
+// ---- one sample over several GPUs, the reads sharded (include/arriba_gpu.h: "the READS SHARDED"; agpu_sharded.hip): this context keeps the fragments of its part ------------
+int agpu_shard_boundary_names(agpu_ctx* ctx, char* first_name, char* last_name, uint32_t capacity) {
+	if (!ctx || !ctx->batch_from_ingest || !first_name || !last_name || capacity == 0) { set_last_error("agpu_shard_boundary_names works on the batch of an ingest"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	first_name[0] = 0; last_name[0] = 0;
+	const uint64_t n = ctx->n;
+	if (n == 0) return AGPU_OK;
+	uint64_t first[2], last[2];
+	HIP_CHECK(hipMemcpy(first, ctx->name_offset.as<uint64_t>(), 16, hipMemcpyDeviceToHost));
+	HIP_CHECK(hipMemcpy(last, ctx->name_offset.as<uint64_t>() + (n - 1), 16, hipMemcpyDeviceToHost));
+	if (first[1] < first[0] || last[1] < last[0] || last[1] > ctx->names_size) { set_last_error("the names of the batch are damaged"); return AGPU_ERR_INVALID; }
+	if (first[1] - first[0] + 1 > capacity || last[1] - last[0] + 1 > capacity) { set_last_error("a read name is longer than the buffer of agpu_shard_boundary_names"); return AGPU_ERR_INVALID; }
+	if (first[1] > first[0]) HIP_CHECK(hipMemcpy(first_name, ctx->names.as<char>() + first[0], first[1] - first[0], hipMemcpyDeviceToHost));
+	first_name[first[1] - first[0]] = 0;
+	if (last[1] > last[0]) HIP_CHECK(hipMemcpy(last_name, ctx->names.as<char>() + last[0], last[1] - last[0], hipMemcpyDeviceToHost));
+	last_name[last[1] - last[0]] = 0;
+	return AGPU_OK;
+}
+
+int agpu_shard_keep(agpu_ctx* ctx, uint64_t first_rank, uint64_t global_n) {
+	if (!ctx || !ctx->batch_from_ingest || !ctx->ingest_part_of_sample || ctx->annotated) { set_last_error("agpu_shard_keep works on the batch of an ingest with part_of_sample set, before any stage has run"); return AGPU_ERR_INVALID; }
+	if (first_rank + ctx->n > global_n || global_n >= 0xFFFFFFF0ull) { set_last_error("shard range out of bounds"); return AGPU_ERR_INVALID; }
+	ctx->batch.first_rank = first_rank; ctx->global_n = global_n;
+	ctx->read_sharded = true; ctx->state_imported = false; ctx->sample_gene_read_counts_set = false;
+	ctx->ingest_part_of_sample = false;
+	ctx->coverage_windows32.release(); ctx->ingest_qname_keys.release(); // (what a part hands to agpu_shard_export: not needed, the parts stay where they are)
+	return AGPU_OK;
+}
+
+__global__ void coverage_widen_kernel(const uint16_t* windows, uint64_t n, uint32_t* out) {
+	const uint64_t w = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (w < n) out[w] = windows[w];
+}
+int agpu_coverage_partial(agpu_ctx* ctx, uint32_t* windows_out, uint8_t* fragment_starts, uint8_t* fragment_ends, uint64_t* viral_counts) {
+	if (!ctx || !ctx->batch_from_ingest || !ctx->have_coverage) { set_last_error("no coverage on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
+	if (windows > 0) {
+		if (windows_out) { // (the 16-bit windows of the part, already saturated, as 32-bit words for the sum)
+			DeviceBuffer& wide = ctx->scratch("sharded.coverage32");
+			ALLOC(wide, windows * 4);
+			coverage_widen_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_windows.as<uint16_t>(), windows, wide.as<uint32_t>());
+			HIP_CHECK(hipMemcpyAsync(windows_out, wide.ptr, windows * 4, hipMemcpyDefault, s));
+		}
+		if (fragment_starts) HIP_CHECK(hipMemcpyAsync(fragment_starts, ctx->coverage_fragment_starts.ptr, windows, hipMemcpyDefault, s));
+		if (fragment_ends) HIP_CHECK(hipMemcpyAsync(fragment_ends, ctx->coverage_fragment_ends.ptr, windows, hipMemcpyDefault, s));
+	}
+	if (viral_counts && ctx->genome.n_contigs > 0) HIP_CHECK(hipMemcpyAsync(viral_counts, ctx->ingest_viral_counts.ptr, (size_t) ctx->genome.n_contigs * 8, hipMemcpyDefault, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	return AGPU_OK;
+}
+__global__ void flags_to_bits_kernel(uint8_t* flags, uint64_t n) {
+	const uint64_t w = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	if (w < n) flags[w] = flags[w] ? 1 : 0;
+}
+int agpu_coverage_total(agpu_ctx* ctx, const uint32_t* windows_in, const uint8_t* fragment_starts, const uint8_t* fragment_ends, const uint64_t* viral_counts) {
+	if (!ctx || !ctx->batch_from_ingest || !ctx->have_coverage || !windows_in || !fragment_starts || !fragment_ends || !viral_counts) { set_last_error("no coverage on the device"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint64_t windows = ctx->host_coverage_window_offset.empty() ? 0 : ctx->host_coverage_window_offset.back();
+	if (windows > 0) {
+		DeviceBuffer& wide = ctx->scratch("sharded.coverage32");
+		ALLOC(wide, windows * 4);
+		HIP_CHECK(hipMemcpyAsync(wide.ptr, windows_in, windows * 4, hipMemcpyDefault, s));
+		coverage_clamp_kernel<<<grid_for(windows), BLOCK, 0, s>>>(wide.as<uint32_t>(), windows, ctx->coverage_windows.as<uint16_t>());
+		HIP_CHECK(hipMemcpyAsync(ctx->coverage_fragment_starts.ptr, fragment_starts, windows, hipMemcpyDefault, s));
+		HIP_CHECK(hipMemcpyAsync(ctx->coverage_fragment_ends.ptr, fragment_ends, windows, hipMemcpyDefault, s));
+		flags_to_bits_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_fragment_starts.as<uint8_t>(), windows);
+		flags_to_bits_kernel<<<grid_for(windows), BLOCK, 0, s>>>(ctx->coverage_fragment_ends.as<uint8_t>(), windows);
+	}
+	if (ctx->genome.n_contigs > 0) HIP_CHECK(hipMemcpyAsync(ctx->ingest_viral_counts.ptr, viral_counts, (size_t) ctx->genome.n_contigs * 8, hipMemcpyDefault, s));
+	HIP_CHECK(hipStreamSynchronize(s));
 	return AGPU_OK;
 }
 

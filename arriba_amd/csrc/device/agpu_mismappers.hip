@@ -134,8 +134,8 @@ __global__ void mismapper_flag_kernel(BatchView b, CandidateTable t, uint8_t* re
 	if (c >= end || t.filter[c] != FILTER_none) return;
 	const uint64_t* offsets = t.list_offset + 3 * (uint64_t) c;
 	for (uint64_t k = offsets[0]; k < offsets[3]; ++k) {
-		uint32_t read = t.read_lists[k];
-		if (b.filter[read] != FILTER_none) continue;
+		const uint64_t read = (uint64_t) t.read_lists[k] - b.first_rank; // (the lists hold global name ranks: a context that holds one shard of the sample takes the reads it holds)
+		if (read >= b.n || b.filter[read] != FILTER_none) continue;
 		if (!read_flags[read]) read_flags[read] = 1;
 		const unsigned long long key = by_candidate ? c : k;
 		if (first_entry[read] > key) atomicMin(&first_entry[read], key); // where the read stands first in the lists: jobs in that order keep the reads of one candidate together
@@ -370,7 +370,7 @@ extern "C" int agpu_make_kmer_index(agpu_ctx* ctx, int32_t padding, uint64_t* n_
 }
 
 namespace {
-enum { PHASE_JOBS = 1, PHASE_SEARCH = 2, PHASE_FINISH = 4 };
+enum { PHASE_JOBS = 1, PHASE_SEARCH = 2, PHASE_FINISH = 4, PHASE_NO_JUDGE = 8 /* with PHASE_FINISH: the verdicts are with the reads, the candidates are judged later (the reads sharded over the ranks: behind the exchange of their states) */ };
 // filter_mismappers in three phases -- the reads to look at (jobs), their re-alignment (search: all jobs, or every parts-th one from `part` on), the verdicts
 // applied to the candidates (finish) -- so that ranks which hold the same batch can share out the search (agpu_mismapper_jobs / _verdicts / agpu_filter_mismappers_apply)
 int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, uint32_t part, uint32_t parts, uint8_t* verdicts_out, const uint8_t* verdicts_in, uint64_t* remaining, uint64_t* discarded_reads) {
@@ -564,16 +564,18 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 			HIP_CHECK(hipMemsetAsync(device_counters + 1, 0, 4, s));
 			mismapper_apply_kernel<<<grid_for(n_jobs), BLOCK, 0, s>>>(ctx->batch, jobs_sorted.as<uint32_t>(), n_jobs, verdict_bytes.as<uint8_t>(), device_counters);
 		}
-		if (C > 0 && (!enabled || n > 0)) {
+		BatchView reads; // (the batch the candidates are judged by: the own one, or the replicated states of the reads of the sample -- agpu_sharded.hip)
+		if (!(phases & PHASE_NO_JUDGE)) { const int status = candidate_walk_batch(ctx, reads, false); if (status != AGPU_OK) return status; }
+		if (!(phases & PHASE_NO_JUDGE) && C > 0 && (!enabled || reads.n > 0)) {
 			const bool count_only = !enabled;
 			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
 				KernelTimer timer(ctx, "mismapper_candidate_kernel", (uint64_t) ctx->n_list_entries * 5 + (uint64_t) C * 14);
-				mismapper_candidate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(ctx->batch, window, ctx->params.max_mismapper_fraction, count_only, device_counters + 2, begin, end);
+				mismapper_candidate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(reads, window, ctx->params.max_mismapper_fraction, count_only, device_counters + 2, begin, end);
 				return AGPU_OK;
 			}, LISTS_OF_UNFILTERED);
 			if (status != AGPU_OK) return status;
 		}
-		ctx->mismapper_jobs_ready = false;
+		if (!(phases & PHASE_NO_JUDGE)) ctx->mismapper_jobs_ready = false;
 	}
 	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
 	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
@@ -603,4 +605,20 @@ extern "C" int agpu_mismapper_verdicts(agpu_ctx* ctx, int32_t max_mate_gap, uint
 extern "C" int agpu_filter_mismappers_apply(agpu_ctx* ctx, const uint8_t* verdicts, uint64_t* remaining, uint64_t* discarded_reads) {
 	if (!verdicts) { set_last_error("null argument"); return AGPU_ERR_INVALID; }
 	return filter_mismappers_phases(ctx, PHASE_FINISH, 0, 0, 1, nullptr, verdicts, remaining, discarded_reads);
+}
+
+// the reads sharded over the ranks (include/arriba_gpu.h: agpu_shard_keep): every rank re-aligns the reads it holds -- the lists, which are all here, say which --, the mis-mappers
+// travel as states of the reads (agpu_read_state_export / _import), and the candidates are judged on every rank from the replicated filters
+extern "C" int agpu_filter_mismappers_search(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* discarded_reads) {
+	if (!ctx || !ctx->read_sharded) { set_last_error("agpu_shard_keep must run first"); return AGPU_ERR_INVALID; }
+	const int status = filter_mismappers_phases(ctx, PHASE_JOBS | PHASE_SEARCH | PHASE_FINISH | PHASE_NO_JUDGE, max_mate_gap, 0, 1, nullptr, nullptr, nullptr, discarded_reads);
+	ctx->state_imported = false;
+	return status;
+}
+extern "C" int agpu_filter_mismappers_judge(agpu_ctx* ctx, uint64_t* remaining) {
+	if (!ctx || !ctx->read_sharded || !ctx->state_imported) { set_last_error("agpu_filter_mismappers_search and agpu_read_state_import must run first"); return AGPU_ERR_INVALID; }
+	// (the counter of the candidates that remain starts over; the reads discarded were counted by the search)
+	HIP_CHECK(hipSetDevice(ctx->device));
+	HIP_CHECK(hipMemsetAsync(ctx->scratch("mismappers.counters").as<unsigned int>() + 2, 0, 4, ctx->stream));
+	return filter_mismappers_phases(ctx, PHASE_FINISH, 0, 0, 1, nullptr, nullptr, remaining, nullptr);
 }

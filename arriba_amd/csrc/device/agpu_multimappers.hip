@@ -57,6 +57,13 @@ __global__ void read_bitmap_kernel(BatchView b, const uint8_t* bytes, uint64_t n
 	const unsigned long long ballot = __ballot(bit);
 	if ((threadIdx.x & 63) == 0 && i < n) { words[i >> 5] = (uint32_t) ballot; if (i + 32 < ((n + 31) & ~31ull)) words[(i >> 5) + 1] = (uint32_t) (ballot >> 32); }
 }
+// ... of the replicated states of the reads of a sample whose reads are sharded over the ranks (agpu_sharded.hip): a bit where (byte & mask) == value
+__global__ void state_bitmap_kernel(const uint8_t* bytes, uint64_t n, uint8_t mask, uint8_t value, uint32_t* words) {
+	const uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
+	const bool bit = i < n && (bytes[i] & mask) == value;
+	const unsigned long long ballot = __ballot(bit);
+	if ((threadIdx.x & 63) == 0 && i < n) { words[i >> 5] = (uint32_t) ballot; if (i + 32 < ((n + 31) & ~31ull)) words[(i >> 5) + 1] = (uint32_t) (ballot >> 32); }
+}
 const int LIST_UNROLL = 4;
 __device__ __forceinline__ bool bitmap_test(const uint32_t* words, uint32_t read) { return (words[read >> 5] >> (read & 31)) & 1u; }
 __global__ void bitmap_popcount_kernel(const uint32_t* words, uint64_t n_words, uint32_t* counts) {
@@ -464,5 +471,93 @@ extern "C" int agpu_multimappers_finish(agpu_ctx* ctx, const int32_t* counters, 
 	HIP_CHECK(hipStreamSynchronize(s));
 	ctx->multimappers_begun = false;
 	if (remaining) *remaining = kept;
+	return AGPU_OK;
+}
+
+// ---- the reads sharded over the ranks, every read list on every rank (include/arriba_gpu.h: agpu_shard_keep; agpu_sharded.hip) ------------------------------------------------
+// The best candidate of every multi-mapping read of the sample is found from the lists without an exchange (they are all here); the alignment scores and the choice inside a group
+// of alignments are made where the reads are (the parts are cut between read names: a group is never split); the reads that lost travel as states (agpu_read_state_export / _import),
+// and the recount reads the replicated filters.
+
+extern "C" int agpu_filter_multimappers_resolve(agpu_ctx* ctx, uint64_t* discarded_reads) {
+	if (!ctx || !ctx->fusions_done || !ctx->read_sharded || !ctx->state_imported) { set_last_error("agpu_shard_keep, agpu_find_fusions_from_emissions and agpu_read_state_import must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint64_t n = ctx->n, N = ctx->global_n, n_words = (N + 31) / 32;
+	DeviceBuffer& rank = ctx->scratch("multimappers.rank"); DeviceBuffer& best_rank = ctx->scratch("multimappers.best_rank"); DeviceBuffer& counters = ctx->scratch("multimappers.counters");
+	DeviceBuffer& bits = ctx->scratch("multimappers.bits"); DeviceBuffer& popcounts = ctx->scratch("multimappers.popcounts"); DeviceBuffer& word_prefix = ctx->scratch("multimappers.word_prefix");
+	DeviceBuffer& best = ctx->scratch("multimappers.partial_best"); DeviceBuffer& scratch = ctx->scratch("multimappers.rocprim");
+	const size_t C1 = std::max<uint32_t>(C, 1), n1 = std::max<uint64_t>(n, 1);
+	ALLOC(rank, C1 * 4); ALLOC(best_rank, n1 * 4); ALLOC(counters, 16); ALLOC(bits, (n_words + 2) * 4); ALLOC(popcounts, (n_words + 1) * 4); ALLOC(word_prefix, (n_words + 1) * 4);
+	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (ctx->params.filter_enabled[FILTER_multimappers]) {
+		// the multi-mapping reads of the sample, numbered: the table of the best candidates holds an entry for each of them (3 % of the fragments) instead of one per fragment
+		if (N > 0) state_bitmap_kernel<<<grid_for(N), BLOCK, 0, s>>>(ctx->scratch("sharded.bits").as<uint8_t>(), N, WALK_MULTIMAPPER, WALK_MULTIMAPPER, bits.as<uint32_t>());
+		HIP_CHECK(hipMemsetAsync(popcounts.as<uint32_t>() + n_words, 0, 4, s));
+		if (n_words) bitmap_popcount_kernel<<<grid_for(n_words), BLOCK, 0, s>>>(bits.as<uint32_t>(), n_words, popcounts.as<uint32_t>());
+		size_t temporary = 0;
+		HIP_CHECK(rocprim::exclusive_scan(nullptr, temporary, popcounts.as<uint32_t>(), word_prefix.as<uint32_t>(), 0u, n_words + 1, rocprim::plus<uint32_t>(), s));
+		if (temporary > scratch.capacity) ALLOC(scratch, temporary);
+		HIP_CHECK(rocprim::exclusive_scan(scratch.ptr, temporary, popcounts.as<uint32_t>(), word_prefix.as<uint32_t>(), 0u, n_words + 1, rocprim::plus<uint32_t>(), s));
+		uint32_t total = 0;
+		HIP_CHECK(hipMemcpyAsync(&total, word_prefix.as<uint32_t>() + n_words, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		ALLOC(best, std::max<uint32_t>(total, 1) * 4ull);
+		HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t) best.ptr, (int) NO_FUSION, std::max<uint32_t>(total, 1), s));
+		if (C > 0 && total > 0) {
+			{ const int status = compute_support_rank(ctx, rank.as<uint32_t>()); if (status != AGPU_OK) return status; }
+			const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+				KernelTimer timer(ctx, "list_best_rank_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 8);
+				list_best_rank_kernel<<<grid_for(end - begin), BLOCK, 0, s>>>(begin, end, window.list_offset, window.read_lists, nullptr, rank.as<uint32_t>(), bits.as<uint32_t>(), word_prefix.as<uint32_t>(), best.as<uint32_t>());
+				return AGPU_OK;
+			});
+			if (status != AGPU_OK) return status;
+		}
+		if (n > 0) { // the groups of alignments of the reads this context holds (their bit in the bitmap is their own multi-mapper flag)
+			local_best_rank_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, bits.as<uint32_t>(), word_prefix.as<uint32_t>(), best.as<uint32_t>(), best_rank.as<uint32_t>());
+			const int status = resolve_groups(ctx, best_rank.as<uint32_t>(), counters.as<unsigned int>()); if (status != AGPU_OK) return status;
+		}
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 60 + (uint64_t) ctx->n_list_entries * 4 + n * 6;
+	unsigned int host_counter = 0;
+	HIP_CHECK(hipMemcpy(&host_counter, counters.ptr, 4, hipMemcpyDeviceToHost));
+	ctx->state_imported = false; // (the filters of reads have changed where they live: the candidates are judged behind the next exchange of the states)
+	if (discarded_reads) *discarded_reads = host_counter;
+	return AGPU_OK;
+}
+
+extern "C" int agpu_filter_multimappers_recount(agpu_ctx* ctx, uint64_t* remaining) {
+	if (!ctx || !ctx->fusions_done || !ctx->read_sharded || !ctx->state_imported) { set_last_error("agpu_filter_multimappers_resolve and agpu_read_state_import must run first"); return AGPU_ERR_INVALID; }
+	HIP_CHECK(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+	const uint32_t C = ctx->n_candidates;
+	const uint64_t N = ctx->global_n, n_words = (N + 31) / 32;
+	DeviceBuffer& counters = ctx->scratch("multimappers.counters"); DeviceBuffer& bits = ctx->scratch("multimappers.bits");
+	ALLOC(counters, 16); ALLOC(bits, (n_words + 2) * 4);
+	HIP_CHECK(hipMemsetAsync(counters.ptr, 0, 16, s));
+	(void) hipEventRecord(ctx->event_start, s);
+	if (C > 0 && N > 0 && ctx->params.filter_enabled[FILTER_multimappers]) {
+		state_bitmap_kernel<<<grid_for(N), BLOCK, 0, s>>>(ctx->scratch("sharded.filter").as<uint8_t>(), N, 0xFF, FILTER_multimappers, bits.as<uint32_t>());
+		const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
+			KernelTimer timer(ctx, "list_recount_kernel", (uint64_t) ctx->n_list_entries * 4 + (uint64_t) C * 26);
+			list_recount_kernel<<<grid_for(end - begin), BLOCK, 0, s>>>(window, begin, end, window.list_offset, window.read_lists, nullptr, bits.as<uint32_t>(), true, counters.as<unsigned int>() + 1);
+			return AGPU_OK;
+		}, LISTS_OF_UNFILTERED, true);
+		if (status != AGPU_OK) return status;
+	}
+	HIP_CHECK(hipEventRecord(ctx->event_stop, s));
+	HIP_CHECK(hipEventSynchronize(ctx->event_stop));
+	HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->event_start, ctx->event_stop));
+	collect_kernel_samples(ctx);
+	ctx->last_bytes = (uint64_t) C * 60 + (uint64_t) ctx->n_list_entries * 4;
+	unsigned int host_counters[2] = { 0, 0 };
+	HIP_CHECK(hipMemcpy(host_counters, counters.ptr, sizeof(host_counters), hipMemcpyDeviceToHost));
+	if (remaining) *remaining = host_counters[1];
 	return AGPU_OK;
 }

@@ -322,25 +322,19 @@ AGPU_HD bool in_vitro_looks_at(const CandidateTable& t, uint32_t c) {
 	const uint8_t filter = t.filter[c];
 	return filter == FILTER_none || ((flags & (CFLAG_SPLICED1 | CFLAG_SPLICED2)) && (filter == FILTER_relative_support || filter == 17 /* min_support */ || filter == FILTER_homopolymer));
 }
-template <class Lanes = ListLanes> AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c, const Lanes& lanes = Lanes()) {
-	AGPU_FP_AS_WRITTEN
-	const uint32_t flags = t.flags[c];
-	const bool spliced1 = flags & CFLAG_SPLICED1, spliced2 = flags & CFLAG_SPLICED2, exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2;
-	const uint8_t filter = t.filter[c];
-	if (!in_vitro_looks_at(t, c)) return false;
-	float potential_rt_breakpoints = 0;
-	if (!exonic1) potential_rt_breakpoints += 0.5; else if (!spliced1) potential_rt_breakpoints += 1;
-	if (!exonic2) potential_rt_breakpoints += 0.5; else if (!spliced2) potential_rt_breakpoints += 1;
+// the walk of the verdict: the discordant mates of the candidate that are clipped right at one of its breakpoints (:133-158).  Reads outside [b.first_rank, b.first_rank + b.n) are
+// skipped: a context that holds one shard of the sample counts its own reads (agpu_in_vitro_clipped_mates), the counts of all shards add up to those of the sample.
+template <class Lanes = ListLanes> AGPU_HD void in_vitro_clipped_mates(const BatchView& b, const InVitroTables& tables, const CandidateTable& t, uint32_t c, uint32_t& clipped_discordant_mates1, uint32_t& clipped_discordant_mates2, const Lanes& lanes = Lanes()) {
 	const uint32_t contig1 = t.contigs[c] >> 16, contig2 = t.contigs[c] & 0xFFFF;
 	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
-	// discordant mates that are clipped right at a breakpoint count as split reads (:133-158)
 	const uint32_t min_clipped_length = 3;
-	uint32_t clipped_discordant_mates1 = 0, clipped_discordant_mates2 = 0;
+	clipped_discordant_mates1 = 0; clipped_discordant_mates2 = 0;
 	for (uint64_t k = t.list_offset[3 * (uint64_t) c + 2] + lanes.lane; k < t.list_offset[3 * (uint64_t) c + 3]; k += lanes.lanes) {
-		const uint32_t read = t.read_lists[k];
+		const uint64_t read = (uint64_t) t.read_lists[k] - b.first_rank;
+		if (read >= b.n) continue; // (a read of another shard; unsigned: also those in front of this one)
 		if (tables.clip_summaries != nullptr) { // (a read that a filter discarded has no clipped end in its summaries: clip_summary_of; 32 bytes per read, one line per list entry)
 			for (int slot = 0; slot < 3; ++slot) {
-				const ClipSummary summary = tables.clip_summaries[CLIP_SUMMARIES_PER_READ * (uint64_t) read + slot];
+				const ClipSummary summary = tables.clip_summaries[CLIP_SUMMARIES_PER_READ * read + slot];
 				if (!summary.clipped) continue;
 				if (summary.contig == contig1 && summary.position == breakpoint1) clipped_discordant_mates1++;
 				else if (summary.contig == contig2 && summary.position == breakpoint2) clipped_discordant_mates2++;
@@ -361,6 +355,17 @@ template <class Lanes = ListLanes> AGPU_HD bool is_in_vitro_artifact(const Batch
 		}
 	}
 	clipped_discordant_mates1 = lanes.sum(clipped_discordant_mates1); clipped_discordant_mates2 = lanes.sum(clipped_discordant_mates2);
+}
+// ... and the decision, from the counts of the walk
+AGPU_HD bool in_vitro_verdict(const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c, uint32_t clipped_discordant_mates1, uint32_t clipped_discordant_mates2) {
+	AGPU_FP_AS_WRITTEN
+	const uint32_t flags = t.flags[c];
+	const bool spliced1 = flags & CFLAG_SPLICED1, spliced2 = flags & CFLAG_SPLICED2, exonic1 = flags & CFLAG_EXONIC1, exonic2 = flags & CFLAG_EXONIC2;
+	float potential_rt_breakpoints = 0;
+	if (!exonic1) potential_rt_breakpoints += 0.5; else if (!spliced1) potential_rt_breakpoints += 1;
+	if (!exonic2) potential_rt_breakpoints += 0.5; else if (!spliced2) potential_rt_breakpoints += 1;
+	const uint32_t contig1 = t.contigs[c] >> 16, contig2 = t.contigs[c] & 0xFFFF;
+	const int32_t breakpoint1 = t.breakpoint1[c], breakpoint2 = t.breakpoint2[c];
 	const uint32_t split_reads1 = t.split_reads1[c], split_reads2 = t.split_reads2[c], discordant_mates = t.discordant_mates[c];
 	const uint32_t total_split_reads = (clipped_discordant_mates1 < clipped_discordant_mates2 ? clipped_discordant_mates1 : clipped_discordant_mates2) + split_reads1 + split_reads2;
 	IdSetTail overlapping_tail; GeneQuery overlapping(overlapping_tail.words);
@@ -382,6 +387,12 @@ template <class Lanes = ListLanes> AGPU_HD bool is_in_vitro_artifact(const Batch
 	        gene1_expression > 2 * threshold || gene2_expression > 2 * threshold || (gene1_expression > threshold && gene2_expression > threshold) ||
 	        exonic_breakpoints > max_exonic_breakpoints_by_gene_pair ||
 	        supporting_reads <= 1);
+}
+template <class Lanes = ListLanes> AGPU_HD bool is_in_vitro_artifact(const BatchView& b, const AnnotationView& ann, const CoverageView& coverage, const InVitroTables& tables, const CandidateTable& t, uint32_t c, const Lanes& lanes = Lanes()) {
+	if (!in_vitro_looks_at(t, c)) return false;
+	uint32_t clipped_discordant_mates1, clipped_discordant_mates2;
+	in_vitro_clipped_mates(b, tables, t, c, clipped_discordant_mates1, clipped_discordant_mates2, lanes);
+	return in_vitro_verdict(ann, coverage, tables, t, c, clipped_discordant_mates1, clipped_discordant_mates2);
 }
 
 // ---- recover_both_spliced (source/recover_both_spliced.cpp:13-182): candidates with two spliced breakpoints that were discarded for low support come

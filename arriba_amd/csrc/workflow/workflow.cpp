@@ -84,6 +84,10 @@ struct Run {
 	// one sample over the ranks of a job (arriba_workflow_set_communicator): the session's communicator, or null; what the exchanges of the sample at work took
 	const arriba_workflow_communicator* ranks = nullptr;
 	double exchange_parts = 0, exchange_verdicts = 0, exchange_rows = 0;
+	// ... the reads of the sample at work sharded over the ranks (shard_reads below): this rank holds the fragments [first_rank, first_rank + local_fragments) of n_fragments
+	bool sharded = false; uint64_t first_rank = 0, local_fragments = 0;
+	uint64_t exchanged_bytes = 0; // what this rank received in the exchanges of the sample at work (the part that is not its own)
+	std::vector<uint8_t> exchange_mine, exchange_all; // host buffers of gather_from_device (kept: a gigabyte of fresh vector per exchange is zeroed page by page)
 	// Host memory for what comes back from the device per sample (candidate columns, rows of supporting reads): pinned, kept by the session and only ever grown -- fresh
 	// std::vectors of some hundred MB per sample are zeroed page by page and given back to the system again, which costs more than the transfer they hold.
 	struct Staged { void* pointer = nullptr; size_t capacity = 0; };
@@ -252,7 +256,7 @@ void exchange_parts(Run& run, agpu_ingest_result& result) {
 	const double started = now_seconds();
 	if (ranks.rccl_communicator != nullptr) { // (size all-reduce, export, all-gather and merge in one call: a failure inside it is told behind it)
 		together(run.ranks, [&] { device_check(agpu_shard_merge_rccl(run.device, ranks.rccl_communicator, ranks.size, &result)); });
-		run.exchange_parts = now_seconds() - started;
+		run.exchange_parts += now_seconds() - started;
 		return;
 	}
 	uint64_t bytes = 0;
@@ -264,7 +268,133 @@ void exchange_parts(Run& run, agpu_ingest_result& result) {
 	together(run.ranks, [&] { mine.reset(new uint8_t[stride]); all.reset(new uint8_t[(size_t) ranks.size * stride]); memset(mine.get(), 0, stride); device_check(agpu_shard_export(run.device, mine.get(), stride)); });
 	exchange_check(ranks.all_gather(ranks.state, mine.get(), all.get(), stride), "parts of the sample");
 	together(run.ranks, [&] { device_check(agpu_shard_merge(run.device, all.get(), stride, ranks.size, &result)); });
-	run.exchange_parts = now_seconds() - started;
+	run.exchange_parts += now_seconds() - started;
+}
+
+// ---- One sample over several ranks, the READS SHARDED (include/arriba_gpu.h, "One sample over the GPUs of a node, the READS SHARDED"; BASELINE.json north_star: the packed batch
+// scattered across the GPUs, ONE all-gather of the emissions of find_fusions).  Rank r keeps the fragments of its part of the file; what the reference's result depends on across reads
+// travels -- sums of counters and of coverage_t, the dummy genes, the winners of the duplicate keys, the first mate-gap samples and strandedness votes in name order, the emissions,
+// one byte of state per fragment whenever the filters have changed, the verdict inputs of filter_in_vitro, the rows of the reads of the written candidates -- and the batch does not.
+
+// the bytes of every rank, in rank order (the collectives of a communicator move equal shares: padded to the largest); sizes: what every rank gave
+void gather_bytes(Run& run, const void* mine, uint64_t bytes, std::vector<uint8_t>& all, std::vector<uint64_t>& sizes, const char* what) {
+	const arriba_workflow_communicator& ranks = *run.ranks;
+	const double started = now_seconds();
+	std::vector<int64_t> given(ranks.size, 0);
+	given[ranks.rank] = (int64_t) bytes;
+	exchange_check(ranks.all_reduce_int64(ranks.state, given.data(), ranks.size, ARRIBA_WORKFLOW_SUM), what);
+	uint64_t width = 16, total = 0;
+	sizes.assign(ranks.size, 0);
+	for (uint32_t r = 0; r < ranks.size; ++r) { sizes[r] = (uint64_t) given[r]; width = std::max<uint64_t>(width, (sizes[r] + 15) & ~(uint64_t) 15); total += sizes[r]; }
+	std::unique_ptr<uint8_t[]> padded, received;
+	together(run.ranks, [&] { padded.reset(new uint8_t[width]); received.reset(new uint8_t[(size_t) ranks.size * width]); if (bytes > 0) memcpy(padded.get(), mine, bytes); if (bytes < width) memset(padded.get() + bytes, 0, width - bytes); all.resize(total); });
+	exchange_check(ranks.all_gather(ranks.state, padded.get(), received.get(), width), what);
+	uint64_t at = 0;
+	for (uint32_t r = 0; r < ranks.size; ++r) { if (sizes[r] > 0) memcpy(all.data() + at, received.get() + (size_t) r * width, sizes[r]); at += sizes[r]; }
+	run.exchanged_bytes += total - bytes;
+	run.exchange_parts += now_seconds() - started;
+}
+void sum_over_ranks(Run& run, int64_t* values, uint64_t count, const char* what) {
+	const double started = now_seconds();
+	exchange_check(run.ranks->all_reduce_int64(run.ranks->state, values, count, ARRIBA_WORKFLOW_SUM), what);
+	run.exchange_parts += now_seconds() - started;
+}
+uint64_t sum_over_ranks(Run& run, uint64_t value, const char* what) { int64_t word = (int64_t) value; sum_over_ranks(run, &word, 1, what); return (uint64_t) word; }
+
+// ... of what a kernel wrote and a kernel will read (the emissions of find_fusions: 36 bytes per read and gene pair, 4.7 GB at 10^8 fragments; the states of the reads; the winners of
+// the duplicate keys).  `fill` writes this rank's bytes to the pointer it is given; the result is the bytes of all ranks in rank order.  The ranks hold an RCCL communicator: the
+// pointers are device memory (agpu_scratch_buffer) and ncclAllGather moves them over xGMI, nothing crosses PCIe; otherwise host memory through the callbacks.
+struct Gathered { const uint8_t* data; uint64_t bytes; };
+template <class Fill> Gathered gather_from_device(Run& run, uint64_t bytes, Fill fill, const char* what) {
+	const arriba_workflow_communicator& ranks = *run.ranks;
+	if (ranks.rccl_communicator == nullptr) {
+		std::vector<uint8_t>& mine = run.exchange_mine; std::vector<uint64_t> sizes;
+		together(run.ranks, [&] { mine.resize(bytes > 0 ? bytes : 1); if (bytes > 0) fill((void*) mine.data()); });
+		gather_bytes(run, mine.data(), bytes, run.exchange_all, sizes, what);
+		Gathered all = { run.exchange_all.data(), run.exchange_all.size() };
+		return all;
+	}
+	const double started = now_seconds();
+	std::vector<int64_t> given(ranks.size, 0);
+	given[ranks.rank] = (int64_t) bytes;
+	exchange_check(ranks.all_reduce_int64(ranks.state, given.data(), ranks.size, ARRIBA_WORKFLOW_SUM), what);
+	uint64_t width = 16, total = 0;
+	for (uint32_t r = 0; r < ranks.size; ++r) { width = std::max<uint64_t>(width, ((uint64_t) given[r] + 15) & ~(uint64_t) 15); total += (uint64_t) given[r]; }
+	void* mine = nullptr; void* received = nullptr; void* all = nullptr;
+	together(run.ranks, [&] { // (local: the buffers -- the likeliest place to run out of memory -- and this rank's bytes)
+		device_check(agpu_scratch_buffer(run.device, "exchange.mine", width, &mine)); device_check(agpu_scratch_buffer(run.device, "exchange.received", (uint64_t) ranks.size * width, &received));
+		device_check(agpu_scratch_buffer(run.device, "exchange.all", total, &all));
+		if (bytes > 0) fill(mine);
+	});
+	device_check(agpu_rccl_all_gather_device(run.device, ranks.rccl_communicator, mine, received, width));
+	together(run.ranks, [&] { uint64_t at = 0; for (uint32_t r = 0; r < ranks.size; ++r) { device_check(agpu_device_copy(run.device, (uint8_t*) all + at, (const uint8_t*) received + (size_t) r * width, (uint64_t) given[r])); at += (uint64_t) given[r]; } });
+	run.exchanged_bytes += total - bytes;
+	run.exchange_parts += now_seconds() - started;
+	Gathered result = { (const uint8_t*) all, total };
+	return result;
+}
+
+// what a walk over read lists asks of a read, of every fragment of the sample on every rank: one byte per fragment (agpu_read_state_export / _import), exchanged whenever a stage
+// has changed the filters of reads where they live
+void exchange_read_state(Run& run) {
+	const Gathered all = gather_from_device(run, run.local_fragments, [&](void* mine) { device_check(agpu_read_state_export(run.device, (uint8_t*) mine)); }, "states of the reads");
+	together(run.ranks, [&] {
+		if (all.bytes != run.n_fragments) throw Failure{ "ERROR: the states of the reads of the ranks do not add up to the fragments of the sample" };
+		device_check(agpu_read_state_import(run.device, all.data));
+	});
+}
+
+// Behind agpu_ingest_finish of this rank's part.  true: the parts follow each other in name order (every part is sorted: no read name is in two of them) -- this rank keeps its
+// fragments, `result` becomes that of the sample, coverage_t and the viral read counts of the sample are on the device and with the host session.  false: the names of the file
+// are in another order (STAR writes the reads in the order of the FASTQ file when it is not asked to sort) -- the caller puts the batch together on every rank (exchange_parts).
+bool shard_reads(Run& run, agpu_ingest_result& result, uint64_t windows, uint32_t n_contigs) {
+	const arriba_workflow_communicator& ranks = *run.ranks;
+	const char* knob = getenv("ARRIBA_RANKS_SPLIT"); // "replicated": the split of rounds 2-5 (one all-gather of the batch, the stages on every rank), for comparisons
+	const bool wanted = !(knob != nullptr && strcmp(knob, "replicated") == 0);
+	enum { NAME_BYTES = 512 };
+	struct Boundary { char first[NAME_BYTES], last[NAME_BYTES]; uint64_t fragments; uint64_t wanted; } mine;
+	std::vector<uint8_t> all; std::vector<uint64_t> sizes;
+	together(run.ranks, [&] { memset(&mine, 0, sizeof(mine)); mine.fragments = result.fragments; mine.wanted = wanted ? 1 : 0; device_check(agpu_shard_boundary_names(run.device, mine.first, mine.last, NAME_BYTES)); });
+	gather_bytes(run, &mine, sizeof(mine), all, sizes, "names at the ends of the parts");
+	const Boundary* parts = (const Boundary*) all.data();
+	bool in_order = true; std::string previous; bool have_previous = false;
+	uint64_t first_rank = 0, global_n = 0;
+	for (uint32_t r = 0; r < ranks.size; ++r) {
+		if (!parts[r].wanted) in_order = false;
+		if (r < ranks.rank) first_rank += parts[r].fragments;
+		global_n += parts[r].fragments;
+		if (parts[r].fragments == 0) continue;
+		if (have_previous && !(previous < std::string(parts[r].first))) in_order = false; // (the order of std::string: the reference's std::map)
+		previous = parts[r].last; have_previous = true;
+	}
+	if (!in_order) return false;
+	// the counters of the parts add up (source/read_chimeric_alignments.cpp:560-773 leaves sums behind)
+	int64_t sums[7] = { (int64_t) result.records, (int64_t) result.mapped_reads, (int64_t) result.malformed_count, (int64_t) result.missing_hi_tag, (int64_t) result.stream_bytes, result.names_were_sorted ? 0 : 1, result.no_chimeric_reads ? 0 : 1 };
+	sum_over_ranks(run, sums, 7, "counters of the parts");
+	std::vector<uint32_t> coverage; std::vector<uint8_t> starts, ends; std::vector<uint64_t> viral; std::vector<int64_t> words;
+	together(run.ranks, [&] {
+		device_check(agpu_shard_keep(run.device, first_rank, global_n));
+		coverage.assign(windows > 0 ? windows : 1, 0); starts.assign(coverage.size(), 0); ends.assign(coverage.size(), 0); viral.assign(n_contigs > 0 ? n_contigs : 1, 0);
+		device_check(agpu_coverage_partial(run.device, coverage.data(), starts.data(), ends.data(), viral.data()));
+		// coverage_t adds up before its 16-bit saturation: the windows of a part, saturated at 65535 (min(sum of min(x, 65535), 65535) == min(sum x, 65535)), two to a 64-bit word
+		// of the all-reduce -- the sum of the low halves stays below 2^32 for up to 65 536 parts; the viral read counts behind them
+		words.assign((windows + 1) / 2 + n_contigs, 0);
+		for (uint64_t w = 0; w < windows; ++w) words[w / 2] |= (int64_t) ((uint64_t) coverage[w] << (32 * (w & 1)));
+		for (uint32_t c = 0; c < n_contigs; ++c) words[(windows + 1) / 2 + c] = (int64_t) viral[c];
+	});
+	if (!words.empty()) sum_over_ranks(run, words.data(), words.size(), "coverage of the parts");
+	{ const double started = now_seconds();
+	  if (windows > 0) { exchange_check(ranks.all_reduce_max_bytes(ranks.state, starts.data(), windows), "fragment starts of the parts"); exchange_check(ranks.all_reduce_max_bytes(ranks.state, ends.data(), windows), "fragment ends of the parts"); }
+	  run.exchange_parts += now_seconds() - started; }
+	together(run.ranks, [&] {
+		for (uint64_t w = 0; w < windows; ++w) coverage[w] = (uint32_t) ((uint64_t) words[w / 2] >> (32 * (w & 1)));
+		for (uint32_t c = 0; c < n_contigs; ++c) viral[c] = (uint64_t) words[(windows + 1) / 2 + c];
+		device_check(agpu_coverage_total(run.device, coverage.data(), starts.data(), ends.data(), viral.data()));
+	});
+	run.sharded = true; run.first_rank = first_rank; run.local_fragments = result.fragments;
+	result.fragments = global_n; result.records = (uint64_t) sums[0]; result.mapped_reads = (uint64_t) sums[1]; result.malformed_count = (uint64_t) sums[2]; result.missing_hi_tag = (uint64_t) sums[3];
+	result.stream_bytes = (uint64_t) sums[4]; result.names_were_sorted = sums[5] == 0; result.no_chimeric_reads = sums[6] == 0;
+	return true;
 }
 
 // ... and what is left of read_chimeric_alignments behind the last piece (agpu_ingest_finish), the counters, coverage_t and viral read counts back to the host session
@@ -274,7 +404,9 @@ void finish_device_ingest(Run& run, double waited_since) {
 	const double fed = now_seconds();
 	agpu_ingest_result result;
 	together(run.ranks, [&] { device_check(agpu_ingest_finish(run.device, &result)); });
-	if (run.ranks != nullptr) exchange_parts(run, result);
+	run.sharded = false; run.first_rank = 0; run.exchanged_bytes = 0;
+	if (run.ranks != nullptr && !shard_reads(run, result, windows, n_contigs)) exchange_parts(run, result);
+	if (!run.sharded) run.local_fragments = result.fragments;
 	if (run.after_ingest) run.after_ingest();
 	const double finished = now_seconds();
 	together(run.ranks, [&] {
@@ -344,6 +476,100 @@ void fetch_rows_for_writer(Run& run, ahost_fusion_table& table, int write_discar
 	host_check(ahost_set_batch_rows(run.host, &rows, in_list_order ? nullptr : (count > 0 ? fragments : nullptr)));
 	lap("ahost_set_batch_rows");
 	if (profile) fprintf(stderr, "[rows] %llu rows, %llu CIGAR words, %llu sequence bytes, %llu name bytes\n", (unsigned long long) count, (unsigned long long) cigar_words, (unsigned long long) sequence_bytes, (unsigned long long) name_bytes);
+}
+
+// ... the reads of the sample sharded over the ranks: a row lives where its read does.  Every rank gathers the rows of the entries whose fragment it holds (agpu_gather_rows_* with
+// its own fragment numbers), the rows travel with the number of their entry, and every rank puts them in the order of the entries -- the batch fetch_rows_for_writer hands to the
+// host library on one rank.  (Every rank takes all rows although it formats every size-th row of the file: the lists of the written candidates are a few hundred thousand reads.)
+void fetch_rows_from_their_ranks(Run& run, ahost_fusion_table& table, int write_discarded, bool in_list_order) {
+	uint64_t count = 0; const uint32_t* fragments = nullptr;
+	std::vector<uint32_t> local; std::vector<uint64_t> entry_of; std::vector<uint8_t> block, all; std::vector<uint64_t> sizes;
+	struct Header { uint64_t rows, cigar_words, sequence_bytes, name_bytes; };
+	// the layout of a block: Header, entry[rows] (u64), n_aln, fbits (u8), group (u32), per slot contig (u16) start end (i32) abits (u8) cigar_offset (u32) cigar_count (u16), seq_offset / seq_length x 2 (u32),
+	// name_offset[rows + 1] (u32), cigar pool (u32), sequence pool (u8), names; every array on an 8-byte boundary
+	auto aligned = [](uint64_t bytes) { return (bytes + 7) & ~(uint64_t) 7; };
+	together(run.ranks, [&] {
+		if (in_list_order) { count = table.list_offset[3 * (size_t) table.n_candidates]; fragments = table.read_lists; }
+		else {
+			host_check(ahost_fusion_table_reads(&table, write_discarded, nullptr, 0, &count));
+			uint32_t* unique = run.stage<uint32_t>("rows.fragments", count);
+			host_check(ahost_fusion_table_reads(&table, write_discarded, unique, count, &count));
+			fragments = unique;
+		}
+		for (uint64_t k = 0; k < count; ++k) { const uint64_t at = (uint64_t) fragments[k] - run.first_rank; if (at < run.local_fragments) { local.push_back((uint32_t) at); entry_of.push_back(k); } }
+		const uint64_t m = local.size();
+		Header header = { m, 0, 0, 0 };
+		static const uint32_t none = 0; // (a null pointer means "all fragments" to that call)
+		device_check(agpu_gather_rows_begin(run.device, m > 0 ? local.data() : &none, m, &header.cigar_words, &header.sequence_bytes, &header.name_bytes));
+		uint64_t bytes = sizeof(Header) + m * 8 + aligned(m) * 2 + aligned(m * 4) + 3 * (aligned(m * 2) * 2 + aligned(m * 4) * 3 + aligned(m)) + 4 * aligned(m * 4) + aligned((m + 1) * 4) + aligned((header.cigar_words + 1) * 4) + aligned(header.sequence_bytes + 4) + aligned(header.name_bytes + 1);
+		block.assign(bytes, 0);
+		uint8_t* at = block.data();
+		auto take = [&](uint64_t size) { uint8_t* here = at; at += aligned(size); return here; };
+		memcpy(take(sizeof(Header)), &header, sizeof(Header));
+		if (m > 0) memcpy(take(m * 8), entry_of.data(), m * 8); else take(0);
+		agpu_batch_rows rows; memset(&rows, 0, sizeof(rows));
+		rows.n_aln = take(m); rows.fbits = take(m); rows.group = (uint32_t*) take(m * 4);
+		for (int k = 0; k < 3; ++k) { rows.contig[k] = (uint16_t*) take(m * 2); rows.start[k] = (int32_t*) take(m * 4); rows.end[k] = (int32_t*) take(m * 4); rows.abits[k] = take(m); rows.cigar_offset[k] = (uint32_t*) take(m * 4); rows.cigar_count[k] = (uint16_t*) take(m * 2); }
+		for (int k = 0; k < 2; ++k) { rows.seq_offset[k] = (uint32_t*) take(m * 4); rows.seq_length[k] = (uint32_t*) take(m * 4); }
+		rows.name_offset = (uint32_t*) take((m + 1) * 4); rows.cigar_pool = (uint32_t*) take((header.cigar_words + 1) * 4); rows.seq_pool = take(header.sequence_bytes + 4); rows.names = (char*) take(header.name_bytes + 1);
+		if (m > 0) device_check(agpu_gather_rows_copy(run.device, &rows));
+	});
+	const double before = now_seconds();
+	gather_bytes(run, block.data(), block.size(), all, sizes, "rows of the supporting reads");
+	run.exchange_rows += now_seconds() - before;
+	together(run.ranks, [&] {
+		// sizes of the pools of the whole: the rows of a rank keep their place inside the rank's pools, the pools of the ranks follow each other; the names are laid out in entry order
+		uint64_t cigar_words = 0, sequence_bytes = 0, name_bytes = 0, rows_in_all = 0, at_block = 0;
+		for (uint32_t r = 0; r < run.ranks->size; ++r) { if (sizes[r] < sizeof(Header)) throw Failure{ "ERROR: a block of rows of another rank is damaged" }; Header h; memcpy(&h, all.data() + at_block, sizeof(h)); cigar_words += h.cigar_words; sequence_bytes += (h.sequence_bytes + 3) & ~(uint64_t) 3; name_bytes += h.name_bytes; rows_in_all += h.rows; at_block += sizes[r]; }
+		if (rows_in_all != count) throw Failure{ "ERROR: the rows of the ranks do not add up to the reads of the candidates that are written" };
+		agpu_batch_rows rows; memset(&rows, 0, sizeof(rows));
+		rows.n = count; rows.cigar_pool_size = cigar_words; rows.seq_pool_size = sequence_bytes; rows.names_size = name_bytes;
+		rows.n_aln = run.stage<uint8_t>("rows.n_aln", count); rows.fbits = run.stage<uint8_t>("rows.fbits", count); rows.group = run.stage<uint32_t>("rows.group", count);
+		static const char* const names[3][6] = { { "rows.contig0", "rows.start0", "rows.end0", "rows.abits0", "rows.cigar_offset0", "rows.cigar_count0" }, { "rows.contig1", "rows.start1", "rows.end1", "rows.abits1", "rows.cigar_offset1", "rows.cigar_count1" },
+		                                         { "rows.contig2", "rows.start2", "rows.end2", "rows.abits2", "rows.cigar_offset2", "rows.cigar_count2" } };
+		for (int k = 0; k < 3; ++k) {
+			rows.contig[k] = run.stage<uint16_t>(names[k][0], count); rows.start[k] = run.stage<int32_t>(names[k][1], count); rows.end[k] = run.stage<int32_t>(names[k][2], count);
+			rows.abits[k] = run.stage<uint8_t>(names[k][3], count); rows.cigar_offset[k] = run.stage<uint32_t>(names[k][4], count); rows.cigar_count[k] = run.stage<uint16_t>(names[k][5], count);
+		}
+		rows.seq_offset[0] = run.stage<uint32_t>("rows.seq_offset0", count); rows.seq_length[0] = run.stage<uint32_t>("rows.seq_length0", count);
+		rows.seq_offset[1] = run.stage<uint32_t>("rows.seq_offset1", count); rows.seq_length[1] = run.stage<uint32_t>("rows.seq_length1", count);
+		rows.cigar_pool = run.stage<uint32_t>("rows.cigar_pool", cigar_words + 1); rows.seq_pool = run.stage<uint8_t>("rows.seq_pool", sequence_bytes + 4);
+		rows.name_offset = run.stage<uint32_t>("rows.name_offset", count + 1); rows.names = run.stage<char>("rows.names", name_bytes + 1);
+		std::vector<uint32_t> name_length(count > 0 ? count : 1, 0);
+		std::vector<const char*> name_of(count > 0 ? count : 1, nullptr);
+		uint64_t cigar_base = 0, sequence_base = 0; at_block = 0;
+		for (uint32_t r = 0; r < run.ranks->size; ++r) {
+			const uint8_t* at = all.data() + at_block; at_block += sizes[r];
+			auto take = [&](uint64_t size) { const uint8_t* here = at; at += aligned(size); return here; };
+			Header h; memcpy(&h, take(sizeof(Header)), sizeof(h));
+			const uint64_t m = h.rows;
+			const uint64_t* entry = (const uint64_t*) take(m * 8);
+			const uint8_t* n_aln = take(m); const uint8_t* fbits = take(m); const uint32_t* group = (const uint32_t*) take(m * 4);
+			const uint16_t* contig[3]; const int32_t* start[3]; const int32_t* end[3]; const uint8_t* abits[3]; const uint32_t* cigar_offset[3]; const uint16_t* cigar_count[3]; const uint32_t* seq_offset[2]; const uint32_t* seq_length[2];
+			for (int k = 0; k < 3; ++k) { contig[k] = (const uint16_t*) take(m * 2); start[k] = (const int32_t*) take(m * 4); end[k] = (const int32_t*) take(m * 4); abits[k] = take(m); cigar_offset[k] = (const uint32_t*) take(m * 4); cigar_count[k] = (const uint16_t*) take(m * 2); }
+			for (int k = 0; k < 2; ++k) { seq_offset[k] = (const uint32_t*) take(m * 4); seq_length[k] = (const uint32_t*) take(m * 4); }
+			const uint32_t* name_offset = (const uint32_t*) take((m + 1) * 4); const uint32_t* cigar_pool = (const uint32_t*) take((h.cigar_words + 1) * 4); const uint8_t* seq_pool = take(h.sequence_bytes + 4); const char* row_names = (const char*) take(h.name_bytes + 1);
+			if ((uint64_t) (at - (all.data() + at_block - sizes[r])) > sizes[r]) throw Failure{ "ERROR: a block of rows of another rank is damaged" };
+			for (uint64_t j = 0; j < m; ++j) {
+				const uint64_t k = entry[j];
+				if (k >= count) throw Failure{ "ERROR: a block of rows of another rank is damaged" };
+				rows.n_aln[k] = n_aln[j]; rows.fbits[k] = fbits[j]; rows.group[k] = group[j];
+				for (int slot = 0; slot < 3; ++slot) { rows.contig[slot][k] = contig[slot][j]; rows.start[slot][k] = start[slot][j]; rows.end[slot][k] = end[slot][j]; rows.abits[slot][k] = abits[slot][j]; rows.cigar_offset[slot][k] = cigar_offset[slot][j] + (uint32_t) cigar_base; rows.cigar_count[slot][k] = cigar_count[slot][j]; }
+				for (int slot = 0; slot < 2; ++slot) { rows.seq_offset[slot][k] = seq_offset[slot][j] + (uint32_t) (sequence_base / 4); rows.seq_length[slot][k] = seq_length[slot][j]; }
+				name_length[k] = name_offset[j + 1] - name_offset[j]; name_of[k] = row_names + name_offset[j];
+			}
+			if (h.cigar_words > 0) memcpy(rows.cigar_pool + cigar_base, cigar_pool, h.cigar_words * 4);
+			if (h.sequence_bytes > 0) memcpy(rows.seq_pool + sequence_base, seq_pool, h.sequence_bytes);
+			cigar_base += h.cigar_words; sequence_base += (h.sequence_bytes + 3) & ~(uint64_t) 3;
+		}
+		uint64_t name_at = 0;
+		for (uint64_t k = 0; k < count; ++k) { rows.name_offset[k] = (uint32_t) name_at; if (name_length[k] > 0) memcpy(rows.names + name_at, name_of[k], name_length[k]); name_at += name_length[k]; }
+		rows.name_offset[count] = (uint32_t) name_at;
+		uint8_t* filters = run.stage<uint8_t>("rows.filter", count); // (from the replicated states of the reads: agpu_get_filters_of takes global name ranks here)
+		device_check(agpu_get_filters_of(run.device, fragments, count, filters));
+		table.read_filter_of_rows = filters;
+		host_check(ahost_set_batch_rows(run.host, &rows, in_list_order ? nullptr : (count > 0 ? fragments : nullptr)));
+	});
 }
 
 // One sample over several ranks: the rows of a file are independent of each other (the fusion transcripts from the pileups of the supporting reads are the expensive part), so
@@ -439,10 +665,11 @@ void write_output_files(Run& run, int32_t max_mate_gap) {
 			table.read_filter = read_filter;
 		}
 		lap(&arriba_workflow_timing::output_results);
-		if (rows_from_device) fetch_rows_for_writer(run, table, write_discarded, write_discarded == 0);
-		lap(&arriba_workflow_timing::output_rows);
-		if (run.before_host_writer) run.before_host_writer();
+		if (rows_from_device && !run.sharded) fetch_rows_for_writer(run, table, write_discarded, write_discarded == 0);
 		});
+		if (print_extra_info && run.device_ingest && run.sharded) fetch_rows_from_their_ranks(run, table, write_discarded, write_discarded == 0); // (an exchange: behind the status of the block above)
+		lap(&arriba_workflow_timing::output_rows);
+		together(run.ranks, [&] { if (run.before_host_writer) run.before_host_writer(); });
 		if (run.ranks != nullptr) { // rank r formats the rows r, r + size, ... of the file; rank 0 gathers the texts, puts the rows back in order and writes
 			write_file_over_ranks(run, table, write_discarded ? run.options.discarded_output_file : run.options.output_file, write_discarded, print_extra_info, max_mate_gap);
 			lap(&arriba_workflow_timing::output_format);
@@ -529,6 +756,225 @@ void prepare_sample(Run& run) {
 	run.device_ingest = !o.host_ingest;
 }
 
+// The stages of a sample whose reads are sharded over the ranks (shard_reads): source/arriba.cpp:141-584 in the reference's order.  What runs on the reads a rank holds, and what is
+// exchanged in front of the next step, is said line by line; the stages that look at candidates alone run on every rank over the same table.  In front of every exchange the ranks
+// tell each other how they fared (together()).
+void run_stages_sharded(Run& run, agpu_params& params, int32_t& max_mate_gap, double& mismappers_seconds) {
+	const arriba_workflow_options& o = run.options;
+	const arriba_workflow_communicator& ranks = *run.ranks;
+	uint64_t count = 0;
+	std::vector<uint8_t> all; std::vector<uint64_t> sizes;
+	// :141-143 mark_multimappers: the parts are cut between read names, no group of alignments is split
+	together(run.ranks, [&] { device_check(agpu_mark_multimappers(run.device, &count)); });
+	run.note("mark_multimappers", sum_over_ranks(run, count, "multi-mapping alignments"));
+	// :145-163 detect_strandedness: the first 100 informative fragments of the sample in name order -- every rank says how many of them it could give, then counts its share
+	if (o.device.strandedness <= 2) params.strandedness = o.device.strandedness;
+	else {
+		const uint32_t sample_size = 100; const float threshold = 0.95f; // (source/read_stats.cpp:96,135)
+		uint32_t informative = 0, matching = 0;
+		together(run.ranks, [&] { device_check(agpu_strandedness_votes(run.device, sample_size, &informative, &matching)); });
+		std::vector<int64_t> given(ranks.size, 0); given[ranks.rank] = informative;
+		sum_over_ranks(run, given.data(), ranks.size, "strandedness votes");
+		uint64_t before = 0; for (uint32_t r = 0; r < ranks.rank; ++r) before += (uint64_t) given[r];
+		const uint32_t share = before >= sample_size ? 0 : std::min<uint32_t>(informative, sample_size - (uint32_t) before);
+		together(run.ranks, [&] { if (share < informative) device_check(agpu_strandedness_votes(run.device, share, &informative, &matching)); if (share == 0) { informative = 0; matching = 0; } });
+		int64_t votes[2] = { informative, matching };
+		sum_over_ranks(run, votes, 2, "strandedness votes");
+		int verdict = 0;
+		if ((uint64_t) votes[0] >= sample_size) { if ((float) votes[1] < (1 - threshold) * (float) votes[0]) verdict = 2; else if ((float) votes[1] > threshold * (float) votes[0]) verdict = 1; }
+		params.strandedness = (uint8_t) verdict;
+		run.say(std::string("Detecting strandedness (") + (params.strandedness == 1 ? "yes" : params.strandedness == 2 ? "reverse" : "no") + ")");
+	}
+	if (params.strandedness != 0) run.say("Assigning strands to alignments ");
+	run.say("Annotating alignments ");
+	// :187-325 annotate_alignments: the dummy genes are cut from the unmapped positions of the whole sample
+	std::vector<uint64_t> positions; uint64_t n_unmapped = 0;
+	together(run.ranks, [&] {
+		device_check(agpu_set_params(run.device, &params));
+		device_check(agpu_annotate_begin(run.device, &n_unmapped));
+		positions.resize(n_unmapped > 0 ? n_unmapped : 1);
+		device_check(agpu_copy_unmapped_positions(run.device, positions.data()));
+	});
+	gather_bytes(run, positions.data(), n_unmapped * 8, all, sizes, "positions without a gene");
+	// :327-350 duplicates (the first fragment of a key in the name order of the SAMPLE stays), uninteresting and viral contigs (the verdicts per contig: sequential host work on the
+	// integration sites of all ranks, coverage_t and the viral read counts of the sample)
+	std::vector<uint32_t> pairs; uint64_t n_pairs = 0;
+	together(run.ranks, [&] {
+		device_check(agpu_annotate_finish(run.device, all.empty() ? nullptr : (const uint64_t*) all.data(), all.size() / 8, &run.dummy_genes));
+		device_check(agpu_get_viral_integration_sites(run.device, nullptr, 0, &n_pairs));
+		pairs.resize(2 * (n_pairs > 0 ? n_pairs : 1));
+		device_check(agpu_get_viral_integration_sites(run.device, pairs.data(), n_pairs, &n_pairs));
+	});
+	gather_bytes(run, pairs.data(), n_pairs * 8, all, sizes, "viral integration sites");
+	const uint32_t n_genes = ahost_annotation_view(run.host)->n_genes + run.dummy_genes, n_contigs = ahost_contig_count(run.host);
+	std::vector<uint8_t> top(n_contigs > 0 ? n_contigs : 1), low(top.size()); uint64_t n_entries = 0;
+	together(run.ranks, [&] {
+		std::vector<uint8_t> gene_bits(n_genes > 0 ? n_genes : 1);
+		device_check(agpu_get_gene_table(run.device, 0, n_genes, nullptr, nullptr, nullptr, gene_bits.data(), nullptr));
+		host_check(ahost_viral_verdicts(run.host, (const uint32_t*) all.data(), all.size() / 8, gene_bits.data(), n_genes, o.top_viral_contigs, o.viral_contig_min_covered_fraction, top.data(), low.data()) < 0 ? -1 : 0);
+		device_check(agpu_duplicates_begin(run.device, &n_entries));
+	});
+	const Gathered winners = gather_from_device(run, n_entries * AGPU_DUPLICATE_ENTRY_BYTES, [&](void* mine) { device_check(agpu_copy_duplicate_entries(run.device, mine)); }, "winners of the duplicate keys");
+	// :352-364 estimate_fragment_length: the mate gaps of the first 100001 qualifying fragments in name order and the read lengths of every fragment the reference's loop visits on
+	// the way, summed sequentially in float (hazards H4 / H6): shard by shard, every rank continuing the sum of the rank in front of it
+	const uint32_t max_samples = 100001;
+	std::vector<int32_t> mate_gaps(max_samples); uint32_t n_samples = 0; uint64_t visited = 0;
+	together(run.ranks, [&] {
+		device_check(agpu_read_filters_stage1_global(run.device, winners.bytes == 0 ? nullptr : winners.data, winners.bytes / AGPU_DUPLICATE_ENTRY_BYTES, top.data(), low.data()));
+		device_check(agpu_fragment_length_samples_limited(run.device, max_samples, mate_gaps.data(), &n_samples, &visited));
+	});
+	uint64_t visited_here = 0; uint32_t wanted = 0;
+	{ std::vector<int64_t> given(ranks.size, 0); given[ranks.rank] = n_samples;
+	  sum_over_ranks(run, given.data(), ranks.size, "mate-gap samples");
+	  uint64_t before = 0; for (uint32_t r = 0; r < ranks.rank; ++r) before += (uint64_t) given[r];
+	  together(run.ranks, [&] {
+		if (before >= max_samples) { wanted = 0; visited_here = 0; } // the loop stopped in a shard in front of this one
+		else if (n_samples >= max_samples - before) { // ... stops in this one, right behind the fragment that delivers sample number 100001
+			wanted = (uint32_t) (max_samples - before);
+			if (wanted < max_samples) device_check(agpu_fragment_length_samples_limited(run.device, wanted, mate_gaps.data(), &n_samples, &visited));
+			visited_here = visited;
+		} else { wanted = n_samples; visited_here = run.local_fragments; } // ... visits the whole shard
+	  }); }
+	gather_bytes(run, mate_gaps.data(), (uint64_t) wanted * 4, all, sizes, "mate-gap samples");
+	float read_length_sum = 0; uint64_t visited_in_all = 0;
+	{ std::vector<uint32_t> length1, length2;
+	  together(run.ranks, [&] { length1.resize(visited_here > 0 ? visited_here : 1); length2.resize(length1.size()); device_check(agpu_get_read_lengths(run.device, 0, visited_here, length1.data(), length2.data())); });
+	  for (uint32_t r = 0; r < ranks.size; ++r) { // (a chain: rank r adds its lengths to the sum of the ranks in front of it; the others pass a zero)
+		int64_t word = 0;
+		if (r == ranks.rank) { const float mine = ahost_read_length_sum_of(read_length_sum, length1.data(), length2.data(), visited_here); memcpy(&word, &mine, sizeof(mine)); }
+		sum_over_ranks(run, &word, 1, "sum of the read lengths");
+		memcpy(&read_length_sum, &word, sizeof(read_length_sum));
+	  }
+	  visited_in_all = sum_over_ranks(run, visited_here, "fragments visited"); }
+	float mate_gap_mean = 0, mate_gap_stddev = 0, read_length_mean = 0;
+	const uint32_t samples_in_all = (uint32_t) (all.size() / 4);
+	// :366-409 the read-level filters, each on the reads a rank holds; "(remaining=N)" is the sum
+	std::vector<uint64_t> remaining(AGPU_FILTER_COUNT);
+	together(run.ranks, [&] {
+		if (ahost_estimate_fragment_length_from_sums((const int32_t*) all.data(), samples_in_all, read_length_sum, visited_in_all, params.fragment_length, &mate_gap_mean, &mate_gap_stddev, &read_length_mean, &max_mate_gap) < 0)
+			throw Failure{ std::string("ERROR: ") + ahost_last_error() };
+		device_check(agpu_read_filters_stage2(run.device, remaining.data()));
+	});
+	sum_over_ranks(run, (int64_t*) remaining.data(), AGPU_FILTER_COUNT, "fragments remaining behind the read filters");
+	{ std::ostringstream fragment_length_line;
+	  fragment_length_line << "Estimating fragment length ";
+	  if (samples_in_all >= 10000) fragment_length_line << "(mate gap mean=" << mate_gap_mean << ", mate gap stddev=" << mate_gap_stddev << ", read length mean=" << read_length_mean << ")";
+	  static const struct { unsigned id; const char* name; } read_filters[] = { { 1, "filter_duplicates" }, { 30, "filter_uninteresting_contigs" }, { 31, "filter_viral_contigs" }, { 32, "filter_top_expressed_viral_contigs" },
+		{ 33, "filter_low_coverage_viral_contigs" }, { 4, "filter_proximal_read_through" }, { 2, "filter_inconsistently_clipped_mates" }, { 3, "filter_homopolymer" }, { 6, "filter_small_insert_size" }, { 7, "filter_long_gap" },
+		{ 5, "filter_same_gene" }, { 8, "filter_hairpin" }, { 10, "filter_mismatches" }, { 36, "filter_low_entropy" } };
+	  for (size_t f = 0; f < sizeof(read_filters) / sizeof(read_filters[0]); ++f) {
+		if (f == 5) run.say(fragment_length_line.str());
+		run.note(read_filters[f].name, remaining[read_filters[f].id]);
+	  } }
+	// :411-413 find_fusions: the emissions of the reads of every rank (one record per read x gene1 x gene2, name order), ONE all-gather, the candidates and their read lists built on
+	// every rank from the emissions of all -- the same table everywhere, its lists in global name ranks
+	uint64_t n_emissions = 0;
+	together(run.ranks, [&] { device_check(agpu_build_emissions(run.device, 1, &n_emissions)); });
+	const Gathered emissions = gather_from_device(run, n_emissions * AGPU_EMISSION_BYTES, [&](void* mine) { device_check(agpu_copy_emissions(run.device, mine)); }, "emissions of find_fusions");
+	together(run.ranks, [&] {
+		device_check(agpu_find_fusions_from_emissions(run.device, emissions.bytes == 0 ? nullptr : emissions.data, emissions.bytes / AGPU_EMISSION_BYTES, max_mate_gap, &count));
+		run.n_candidates = count;
+		if (o.log_to_stdout) {
+			std::vector<uint8_t> filter(count > 0 ? count : 1);
+			device_check(agpu_get_candidates(run.device, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, filter.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+			uint64_t unfiltered = 0;
+			for (uint64_t c = 0; c < count; ++c) unfiltered += filter[c] == 0;
+			run.progress("find_fusions", unfiltered);
+		}
+		if (run.report && run.report->n_stages < sizeof(run.report->stages) / sizeof(run.report->stages[0])) { arriba_workflow_stage& entry = run.report->stages[run.report->n_stages++]; snprintf(entry.stage, sizeof(entry.stage), "find_fusions"); entry.count = count; }
+	});
+	all.clear(); all.shrink_to_fit();
+	exchange_read_state(run); // what the walks over the read lists ask of a read: the filters of the cascade, multi-mapper, exonic -- of every fragment of the sample
+	// :415-460
+	uint64_t discarded_reads = 0;
+	together(run.ranks, [&] {
+		if (o.genomic_breakpoints_file) {
+			const agpu_genomic_breakpoint* variants = nullptr; uint32_t n_variants = 0;
+			host_check(ahost_load_genomic_breakpoints(run.host, o.genomic_breakpoints_file, &variants, &n_variants));
+			device_check(agpu_mark_genomic_support(run.device, variants, n_variants, o.max_genomic_breakpoint_distance, &count)); run.note("mark_genomic_support", count);
+		}
+		device_check(agpu_merge_adjacent_fusions(run.device, 5, &count)); run.note("merge_adjacent_fusions", count);
+		// filter_multimappers: the best candidate of every multi-mapping read from the lists (all here), the alignment scores and the choice where the reads are ...
+		device_check(agpu_filter_multimappers_resolve(run.device, &discarded_reads));
+	});
+	exchange_read_state(run); // ... the reads that lost, to every rank ...
+	uint64_t discarded[3];
+	together(run.ranks, [&] {
+		device_check(agpu_filter_multimappers_recount(run.device, &count)); run.note("filter_multimappers", count); // ... and the counters of the candidates from the replicated states
+		device_check(agpu_candidate_iteration_order(run.device, nullptr));
+		run.say("Estimating expected number of fusions by random chance (e-value) ");
+		device_check(agpu_estimate_expected_fusions(run.device, run.mapped_reads, nullptr));
+		device_check(agpu_filter_candidate_predicates(run.device, discarded));
+		if (o.log_to_stdout) {
+			const uint64_t before = count;
+			run.progress("filter_non_coding_neighbors", before - discarded[0]); run.progress("filter_intragenic_both_exonic", before - discarded[0] - discarded[1]); run.progress("filter_min_support", before - discarded[0] - discarded[1] - discarded[2]);
+		}
+		device_check(agpu_filter_relative_support(run.device, &count)); run.note("filter_relative_support", count);
+		// :463-478 (recover_internal_tandem_duplication clears filters of reads: the same reads on every rank, from the replicated states)
+		device_check(agpu_recover_internal_tandem_duplication(run.device, o.min_itd_support, o.min_itd_allele_fraction, &count)); run.note("recover_internal_tandem_duplication", count);
+		device_check(agpu_filter_both_intronic(run.device, &count)); run.note("filter_both_intronic", count);
+		if (o.known_fusions_file && run.enabled(F_known_fusions)) {
+			const agpu_range_rule* rules = nullptr; uint32_t n_rules = 0;
+			host_check(ahost_load_range_rules(run.host, o.known_fusions_file, 0, &rules, &n_rules));
+			device_check(agpu_recover_known_fusions(run.device, rules, n_rules, max_mate_gap, &count)); run.note("recover_known_fusions", count);
+		}
+	});
+	// :483-486 filter_in_vitro: chimeric fragments per gene -- sums over the ranks; the discordant mates clipped at a breakpoint -- counted per candidate over the reads a rank holds
+	std::vector<int64_t> gene_reads; std::vector<uint8_t> clipped; uint64_t n_clipped = 0;
+	together(run.ranks, [&] {
+		std::vector<uint32_t> mine(n_genes > 0 ? n_genes : 1, 0);
+		device_check(agpu_gene_read_counts(run.device, mine.data()));
+		gene_reads.assign(mine.begin(), mine.end());
+		device_check(agpu_in_vitro_clipped_mates(run.device, &n_clipped));
+		clipped.resize((n_clipped > 0 ? n_clipped : 1) * AGPU_CLIPPED_MATES_ENTRY_BYTES);
+		device_check(agpu_copy_in_vitro_clipped_mates(run.device, clipped.data()));
+	});
+	sum_over_ranks(run, gene_reads.data(), gene_reads.size(), "chimeric fragments per gene");
+	gather_bytes(run, clipped.data(), n_clipped * AGPU_CLIPPED_MATES_ENTRY_BYTES, all, sizes, "clipped discordant mates of the candidates");
+	uint64_t n_positions = 0;
+	together(run.ranks, [&] {
+		std::vector<uint32_t> sums(gene_reads.begin(), gene_reads.end());
+		device_check(agpu_set_gene_read_counts(run.device, sums.data()));
+		device_check(agpu_filter_in_vitro_sharded(run.device, o.high_expression_quantile, all.empty() ? nullptr : all.data(), all.size() / AGPU_CLIPPED_MATES_ENTRY_BYTES, &count)); run.note("filter_in_vitro", count);
+		// :489-544
+		device_check(agpu_recover_both_spliced(run.device, 200, 0.998f, 1000, 1000, &count)); run.note("recover_both_spliced", count);
+		device_check(agpu_select_most_supported_breakpoints(run.device, &count)); run.note("select_most_supported_breakpoints", count);
+		device_check(agpu_filter_marginal_read_through(run.device, &count)); run.note("filter_marginal_read_through", count);
+		device_check(agpu_recover_many_spliced(run.device, o.min_spliced_events, &count)); run.note("recover_many_spliced", count);
+		if (o.genomic_breakpoints_file && run.enabled(F_no_genomic_support)) {
+			device_check(agpu_assign_confidence(run.device, nullptr));
+			device_check(agpu_filter_no_genomic_support(run.device, &count)); run.note("filter_no_genomic_support", count);
+		}
+		if (o.blacklist_file && run.enabled(F_blacklist)) {
+			const agpu_range_rule* rules = nullptr; uint32_t n_rules = 0;
+			host_check(ahost_load_range_rules(run.host, o.blacklist_file, 1, &rules, &n_rules));
+			device_check(agpu_filter_blacklisted_ranges(run.device, rules, n_rules, params.evalue_cutoff, max_mate_gap, &count)); run.note("filter_blacklisted_ranges", count);
+		}
+		device_check(agpu_filter_short_anchor(run.device, o.min_anchor_length, &count)); run.note("filter_short_anchor", count);
+		device_check(agpu_filter_end_to_end(run.device, &count)); run.note("filter_end_to_end_fusions", count);
+		device_check(agpu_filter_no_coverage(run.device, &count)); run.note("filter_no_coverage", count);
+		// :546-560
+		run.say("Indexing gene sequences ");
+		device_check(agpu_make_kmer_index(run.device, (int32_t) ((float) max_mate_gap + 2.0f * read_length_mean), &n_positions));
+		device_check(agpu_filter_homologs(run.device, o.max_homolog_identity, &count)); run.note("filter_homologs", count);
+	});
+	// :562-565 filter_mismappers: every rank re-aligns the reads it holds (the lists say which), the mis-mappers travel as states, the candidates are judged on every rank
+	{ const double before = now_seconds();
+	  together(run.ranks, [&] { device_check(agpu_filter_mismappers_search(run.device, max_mate_gap, &discarded_reads)); });
+	  const double searched = now_seconds();
+	  exchange_read_state(run);
+	  run.exchange_verdicts = now_seconds() - searched;
+	  together(run.ranks, [&] { device_check(agpu_filter_mismappers_judge(run.device, &count)); });
+	  mismappers_seconds = now_seconds() - before; }
+	run.note("filter_mismappers", count);
+	together(run.ranks, [&] {
+		if (o.genomic_breakpoints_file && run.enabled(F_genomic_support)) { device_check(agpu_recover_genomic_support(run.device, &count)); run.note("recover_genomic_support", count); }
+		if ((o.genomic_breakpoints_file && run.enabled(F_genomic_support)) || run.enabled(F_many_spliced)) { device_check(agpu_select_most_supported_breakpoints(run.device, &count)); run.note("select_most_supported_breakpoints", count); }
+		device_check(agpu_recover_isoforms(run.device, &count)); run.note("recover_isoforms", count);
+		run.say("Assigning confidence scores to events ");
+	});
+}
+
 // already_fed: the bytes of the file are in HBM (feed_file ran on the feeder thread of a submitted sample); sample_started: when the caller began to wait for this sample
 void run_sample(Run& run, bool already_fed, double sample_started) {
 	const arriba_workflow_options& o = run.options;
@@ -558,6 +1004,8 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 	// (one sample over several ranks: every rank holds the whole batch by now and runs the stages up to filter_homologs on it -- identical inputs, identical kernels, nothing to
 	// exchange; how the ranks fared is told once behind them, in front of the exchange of filter_mismappers)
 	uint64_t count = 0, discarded_reads = 0; int32_t max_mate_gap = 0;
+	if (run.sharded) run_stages_sharded(run, params, max_mate_gap, mismappers_seconds); // (the reads of the sample are sharded over the ranks: the same stages with their exchanges)
+	else {
 	together(run.ranks, [&] {
 	// :141-325 multi-mappers, strandedness, annotation
 	device_check(agpu_mark_multimappers(run.device, &count)); run.note("mark_multimappers", count);
@@ -677,6 +1125,7 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 	device_check(agpu_recover_isoforms(run.device, &count)); run.note("recover_isoforms", count);
 	run.say("Assigning confidence scores to events ");
 	});
+	}
 	const double output_started = now_seconds();
 	write_output_files(run, max_mate_gap);
 	if (run.timing) {
@@ -684,6 +1133,7 @@ void run_sample(Run& run, bool already_fed, double sample_started) {
 		run.timing->filter_mismappers = mismappers_seconds; run.timing->stages = output_started - stages_started - mismappers_seconds;
 		run.timing->output = finished - output_started; run.timing->total = finished - sample_started;
 		run.timing->exchange_parts = run.exchange_parts; run.timing->exchange_verdicts = run.exchange_verdicts; run.timing->exchange_rows = run.exchange_rows;
+		run.timing->shard_fragments = run.sharded ? (double) run.local_fragments : 0; run.timing->exchanged_bytes = (double) run.exchanged_bytes;
 	}
 }
 

@@ -279,7 +279,13 @@ class WorkflowSession(object):
         return launches
 
     def gene_sets(self, slot):
-        return DevicePipeline.gene_sets(self, slot)
+        """of the fragments the device context of the last sample holds: all of them, or -- one sample over several ranks, the reads sharded -- this rank's share"""
+        held = int(self.timing["shard_fragments"]) if getattr(self, "timing", None) and self.timing.get("shard_fragments", 0) > 0 else self.n
+        everything, self.n = self.n, held
+        try:
+            return DevicePipeline.gene_sets(self, slot)
+        finally:
+            self.n = everything
 
     def _check(self, status):
         if status != 0:

@@ -285,12 +285,19 @@ int agpu_filter_mismappers_rccl(agpu_ctx* ctx, void* nccl_comm, int32_t max_mate
  * output files -- are host memory: agpu_rccl_all_gather_host (`bytes` of every rank, in rank order, into all[n_ranks * bytes]) and agpu_rccl_all_reduce_host (in place;
  * kind: AGPU_REDUCE_*) bounce them through a buffer of the context on its stream. */
 #define AGPU_RCCL_ID_BYTES 128
-enum { AGPU_REDUCE_MAX_INT64 = 0, AGPU_REDUCE_MIN_INT64 = 1, AGPU_REDUCE_SUM_INT64 = 2, AGPU_REDUCE_MAX_BYTES = 3 };
+enum { AGPU_REDUCE_MAX_INT64 = 0, AGPU_REDUCE_MIN_INT64 = 1, AGPU_REDUCE_SUM_INT64 = 2, AGPU_REDUCE_MAX_BYTES = 3, AGPU_REDUCE_SUM_UINT32 = 4 /* device collectives only */ };
 int agpu_rccl_unique_id(uint8_t* id /* [AGPU_RCCL_ID_BYTES] */);
 int agpu_rccl_join(agpu_ctx* ctx, const uint8_t* id, uint32_t rank, uint32_t n_ranks, void** nccl_comm);
 int agpu_rccl_leave(void* nccl_comm);
 int agpu_rccl_all_gather_host(agpu_ctx* ctx, void* nccl_comm, uint32_t n_ranks, const void* mine, void* all, uint64_t bytes);
 int agpu_rccl_all_reduce_host(agpu_ctx* ctx, void* nccl_comm, void* values, uint64_t count, int kind);
+/* ... and the same two collectives over DEVICE memory, for the exchanges of the read-sharded split below (emissions, read states, duplicate keys, coverage_t: from the kernel that wrote
+ * them to the kernel that reads them without leaving HBM).  agpu_scratch_buffer: a device buffer of the context by name (grow-only, kept for the next sample; not one of the names the
+ * stages use: "exchange.*"); agpu_device_copy: `bytes` from source to destination, either in host or device memory. */
+int agpu_rccl_all_gather_device(agpu_ctx* ctx, void* nccl_comm, const void* mine, void* all /* [n_ranks * bytes] */, uint64_t bytes);
+int agpu_rccl_all_reduce_device(agpu_ctx* ctx, void* nccl_comm, void* values, uint64_t count, int kind);
+int agpu_scratch_buffer(agpu_ctx* ctx, const char* name, uint64_t bytes, void** pointer);
+int agpu_device_copy(agpu_ctx* ctx, void* destination, const void* source, uint64_t bytes);
 
 /* restore the batch to its state right after agpu_upload_batch (filters, strands and gene sets cleared) so that the stages can be run again */
 int agpu_reset(agpu_ctx* ctx);
@@ -531,6 +538,62 @@ int agpu_get_candidate_first_occurrence(agpu_ctx* ctx, uint64_t* first_occurrenc
  * candidate-level stages can run replicated on every rank; the read lists stay with the owners */
 int agpu_import_candidates(agpu_ctx* ctx, uint64_t n_candidates, const uint32_t* gene1, const uint32_t* gene2, const uint32_t* contigs, const int32_t* breakpoint1, const int32_t* breakpoint2,
                            const uint32_t* flags, const uint8_t* filter, const uint32_t* split_reads1, const uint32_t* split_reads2, const uint32_t* discordant_mates, const int32_t* anchor_start1, const int32_t* anchor_start2);
+
+/* ---- One sample over the GPUs of a node, the READS SHARDED (round 6; SURVEY.md section 8 row e, BASELINE.json north_star: "BAM records shard naturally by read ... a single
+ * RCCL all-gather ... to merge breakpoint histograms before candidate scoring").  Rank r ingests part r of the records (agpu_ingest_config.part_of_sample) and KEEPS its
+ * fragments: the batch -- columns, CIGAR / sequence / name pools, gene sets -- exists once over the ranks, not once per rank.  What the reference's result depends on across
+ * reads travels, and nothing else:
+ *   coverage_t, mapped_viral_reads_by_contig       sums / ORs over the parts (agpu_coverage_partial -> all-reduce -> agpu_coverage_total)            source/read_stats.cpp:161-266
+ *   detect_strandedness                            the first 100 informative fragments of the sample in name order (agpu_strandedness_votes)         source/read_stats.cpp:94-143
+ *   dummy genes, duplicates, mate gaps             agpu_annotate_begin/finish, agpu_duplicates_begin / agpu_read_filters_stage1_global, agpu_fragment_length_samples_limited (above)
+ *   find_fusions                                   agpu_build_emissions(1 partition) -> ONE all-gather of the emissions (36 bytes per read x gene pair) -> agpu_find_fusions_from_emissions:
+ *                                                  every rank builds every candidate and every read list (global name ranks), identically               source/fusions.cpp:203-473
+ *   what a walk over read lists asks of a read     one byte per fragment -- its filter, is it a multi-mapper, is an alignment exonic -- replicated whenever the filters have changed
+ *                                                  (agpu_read_state_export -> all-gather -> agpu_read_state_import: 10^8 bytes at 10^8 fragments, 1/220 of the batch); the stages that
+ *                                                  judge candidates by their lists (filter_both_intronic, recover_both_spliced, recover_internal_tandem_duplication, the recounts of
+ *                                                  filter_multimappers and filter_mismappers, the filters of the rows of the output files) read that byte on every rank
+ *   what needs the alignments of a read            is computed where the read lives: the scores of filter_multimappers (agpu_filter_multimappers_resolve), the re-alignments of
+ *                                                  filter_mismappers (agpu_filter_mismappers_search), the clipped discordant mates of filter_in_vitro as partial counts per candidate
+ *                                                  over the reads a rank holds (agpu_in_vitro_clipped_mates -> all-gather -> agpu_filter_in_vitro_sharded), chimeric fragments per gene
+ *                                                  (agpu_gene_read_counts -> all-reduce -> agpu_set_gene_read_counts), the rows of the supporting reads of the written candidates
+ *                                                  (agpu_gather_rows_* with this rank's fragments)
+ * Requires that the parts follow each other in name order (agpu_shard_boundary_names: the caller checks last name of part r < first name of part r + 1 -- every part is sorted, so
+ * no read name is in two parts); a file whose names are in another order goes through agpu_shard_export / agpu_shard_merge above.  Pointers may be host or device memory. */
+/* "QNAME,HI" of the first and of the last fragment of this context's batch (empty strings when it holds none); capacity = bytes of each of the two buffers */
+int agpu_shard_boundary_names(agpu_ctx* ctx, char* first_name, char* last_name, uint32_t capacity);
+/* the batch of the part this context ingested stays its own: fragment i has the global name rank first_rank + i, the sample holds global_n fragments (agpu_set_shard); the stages
+ * behind find_fusions switch to their sharded form (below) */
+int agpu_shard_keep(agpu_ctx* ctx, uint64_t first_rank, uint64_t global_n);
+/* coverage_t of this part before its 16-bit saturation (windows[W] saturated at 65535 as 32-bit words: min(sum of min(x_r, 65535), 65535) == min(sum x_r, 65535)), its start / end
+ * flags and viral read counts[n_contigs]; agpu_coverage_total takes the sums / ORs over the parts and clamps: coverage_t of the sample on this context */
+int agpu_coverage_partial(agpu_ctx* ctx, uint32_t* windows, uint8_t* fragment_starts, uint8_t* fragment_ends, uint64_t* viral_counts);
+int agpu_coverage_total(agpu_ctx* ctx, const uint32_t* windows, const uint8_t* fragment_starts, const uint8_t* fragment_ends, const uint64_t* viral_counts);
+/* the votes of detect_strandedness among the first `wanted` informative fragments of this context: how many there are (<= wanted) and how many of them match */
+int agpu_strandedness_votes(agpu_ctx* ctx, uint32_t wanted, uint32_t* informative, uint32_t* matching);
+/* one byte per fragment: filter id (bits 0-5) | multi-mapper (bit 6) | an alignment is exonic (bit 7); export: the n fragments of this context, import: the global_n of the sample in
+ * name order (the own ones among them must be the exported ones) */
+#define AGPU_READ_STATE_MULTIMAPPER 0x40u
+#define AGPU_READ_STATE_EXONIC 0x80u
+int agpu_read_state_export(agpu_ctx* ctx, uint8_t* state /* [n] */);
+int agpu_read_state_import(agpu_ctx* ctx, const uint8_t* state /* [global_n] */);
+/* filter_multimappers (source/filter_multimappers.cpp:109-221) in two halves around an exchange of the read states: _resolve ranks the candidates, finds the best candidate of every
+ * multi-mapping read of the sample (all lists are here), scores and resolves the groups of alignments of THIS context's reads (*discarded_reads = newly filtered here);
+ * _recount (behind agpu_read_state_import) lowers the counters of the candidates and discards those left without support; *remaining = "(remaining=N)" */
+int agpu_filter_multimappers_resolve(agpu_ctx* ctx, uint64_t* discarded_reads);
+int agpu_filter_multimappers_recount(agpu_ctx* ctx, uint64_t* remaining);
+/* chimeric fragments per gene (source/filter_in_vitro.cpp:49-58) of this context's reads; counts[n_genes + n_dummy_genes]; agpu_set_gene_read_counts: those of the sample */
+int agpu_gene_read_counts(agpu_ctx* ctx, uint32_t* counts);
+int agpu_set_gene_read_counts(agpu_ctx* ctx, const uint32_t* counts);
+/* filter_in_vitro (source/filter_in_vitro.cpp:82-228): the discordant mates of a candidate that are clipped at one of its breakpoints (:133-158), counted over the reads this context
+ * holds -- entries of 12 bytes (candidate, count at breakpoint1, count at breakpoint2; candidates without any are left out); the entries of all ranks, in any order, give the verdicts */
+#define AGPU_CLIPPED_MATES_ENTRY_BYTES 12
+int agpu_in_vitro_clipped_mates(agpu_ctx* ctx, uint64_t* n_entries);
+int agpu_copy_in_vitro_clipped_mates(agpu_ctx* ctx, void* destination);
+int agpu_filter_in_vitro_sharded(agpu_ctx* ctx, float high_expression_quantile, const void* entries, uint64_t n_entries, uint64_t* remaining);
+/* filter_mismappers (source/filter_mismappers.cpp:272-359): _search re-aligns the reads of this context that the unfiltered candidates list and discards the mis-mappers among them
+ * (*discarded_reads: here); _judge (behind agpu_read_state_import) counts the mis-mappers of every candidate and discards the candidates; *remaining = "(remaining=N)" */
+int agpu_filter_mismappers_search(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* discarded_reads);
+int agpu_filter_mismappers_judge(agpu_ctx* ctx, uint64_t* remaining);
 
 /* result access (device -> host copies) */
 int agpu_get_filters(agpu_ctx* ctx, uint8_t* filter /* [n] */);

@@ -78,6 +78,9 @@ typedef struct { /* seconds of one sample, by part (wall clock of the calling th
 	double exchange_parts;   /* one sample over several ranks (arriba_workflow_set_communicator): the parts of the batch exported, all-gathered and merged */
 	double exchange_verdicts;/*   ... the all-reduce of the verdicts of filter_mismappers (inside filter_mismappers above) */
 	double exchange_rows;    /*   ... the texts of the rows of the output file(s) gathered (inside output_format above) */
+	double shard_fragments;  /* one sample over several ranks, the reads sharded (below): the fragments THIS rank held through the sample (of the `read_chimeric_alignments` of the report); 0 = every
+	                            rank held the whole batch (one rank, or the split by an all-gather of the batch) */
+	double exchanged_bytes;  /*   ... and the bytes this rank received from the others in the exchanges of the sample (host collectives) */
 } arriba_workflow_timing;
 /* options->chimeric_bam_file, output_file and discarded_output_file are not used by open (they belong to a sample); NULL + arriba_workflow_last_error() on failure */
 arriba_workflow_session* arriba_workflow_open(const arriba_workflow_options* options);

@@ -86,6 +86,11 @@ struct emu_ctx {
 	std::vector<uint64_t> unmapped;              // positions that need a dummy gene (between annotate_begin and annotate_finish)
 	std::vector<uint8_t> duplicate_entries;      // wire format of the sharded duplicate exchange: 12-byte key + 4-byte global name rank
 	uint64_t global_n = 0;
+	// the reads of the sample sharded over the ranks (emu_shard_keep, emu_sharded.inc): what the walks over read lists ask of every fragment of the SAMPLE
+	bool read_sharded = false, state_imported = false;
+	std::vector<uint8_t> global_filter, global_bits; // [global_n]; bits: WALK_MULTIMAPPER | WALK_EXONIC
+	std::vector<uint32_t> sample_gene_read_counts; bool have_sample_gene_read_counts = false; // emu_set_gene_read_counts
+	std::vector<uint32_t> clipped_entries; // emu_in_vitro_clipped_mates: triples (candidate, count1, count2)
 	std::vector<uint32_t> exon_bins, gene_bins;
 	CoverageView coverage = { 0, nullptr, nullptr, nullptr, nullptr };
 };
@@ -155,6 +160,17 @@ int emu_rccl_join(emu_ctx*, const uint8_t*, uint32_t, uint32_t, void**) { return
 int emu_rccl_leave(void*) { return AGPU_OK; }
 int emu_rccl_all_gather_host(emu_ctx*, void*, uint32_t, const void*, void*, uint64_t) { return no_rccl(); }
 int emu_rccl_all_reduce_host(emu_ctx*, void*, void*, uint64_t, int) { return no_rccl(); }
+int emu_rccl_all_gather_device(emu_ctx*, void*, const void*, void*, uint64_t) { return no_rccl(); }
+int emu_rccl_all_reduce_device(emu_ctx*, void*, void*, uint64_t, int) { return no_rccl(); }
+int emu_scratch_buffer(emu_ctx*, const char* name, uint64_t bytes, void** pointer) { // (the harness has no device memory: host memory by name)
+	static std::map<std::string, std::vector<uint8_t> > buffers; static std::mutex mutex;
+	std::lock_guard<std::mutex> lock(mutex);
+	std::vector<uint8_t>& buffer = buffers[name];
+	if (buffer.size() < std::max<uint64_t>(bytes, 16)) buffer.resize(std::max<uint64_t>(bytes, 16));
+	*pointer = buffer.data();
+	return AGPU_OK;
+}
+int emu_device_copy(emu_ctx*, void* destination, const void* source, uint64_t bytes) { if (bytes > 0) memmove(destination, source, bytes); return AGPU_OK; }
 int emu_set_params(emu_ctx* ctx, const agpu_params* params) { ctx->params = *params; if (ctx->n) build_tables(ctx); return 0; }
 
 int emu_upload_annotation(emu_ctx* ctx, const agpu_annotation_view* in) {
@@ -178,6 +194,7 @@ int emu_upload_batch(emu_ctx* ctx, const agpu_batch_view* in) {
 	const uint64_t n = in->n;
 	ctx->n = n;
 	ctx->fbits.assign(in->fbits, in->fbits + n); ctx->filter.assign(n, 0);
+	ctx->read_sharded = false; ctx->state_imported = false; ctx->global_n = 0; ctx->have_sample_gene_read_counts = false;
 	BatchView& b = ctx->batch;
 	b.n = n; b.first_rank = 0; b.n_aln = in->n_aln; b.fbits = ctx->fbits.data(); b.filter = ctx->filter.data(); b.group = in->group;
 	for (int s = 0; s < 3; ++s) {
@@ -398,8 +415,16 @@ int emu_read_filters_stage2(emu_ctx* ctx, uint64_t* remaining) {
 	return 0;
 }
 
-int emu_get_filters(emu_ctx* ctx, uint8_t* filter) { memcpy(filter, ctx->filter.data(), ctx->n); return 0; }
+int emu_get_filters(emu_ctx* ctx, uint8_t* filter) {
+	if (ctx->read_sharded) { if (!ctx->state_imported) { g_error = "agpu_read_state_import must run first"; return AGPU_ERR_INVALID; } memcpy(filter, ctx->global_filter.data(), ctx->global_n); return 0; } // (the fragments of the sample)
+	memcpy(filter, ctx->filter.data(), ctx->n); return 0;
+}
 int emu_get_filters_of(emu_ctx* ctx, const uint32_t* fragments, uint64_t n, uint8_t* filter) {
+	if (ctx->read_sharded) { // (global name ranks)
+		if (!ctx->state_imported) { g_error = "agpu_read_state_import must run first"; return AGPU_ERR_INVALID; }
+		for (uint64_t k = 0; k < n; ++k) { if (fragments[k] >= ctx->global_n) { g_error = "fragment index out of range"; return AGPU_ERR_INVALID; } filter[k] = ctx->global_filter[fragments[k]]; }
+		return 0;
+	}
 	for (uint64_t k = 0; k < n; ++k) { if (fragments[k] >= ctx->n) { g_error = "fragment index out of range"; return AGPU_ERR_INVALID; } filter[k] = ctx->filter[fragments[k]]; }
 	return 0;
 }
@@ -441,5 +466,6 @@ int emu_get_kernel_profile(emu_ctx*, char* names, float* ms, uint64_t* bytes, ui
 
 #include "emu_fusions.inc"
 #include "emu_ingest.inc"
+#include "emu_sharded.inc"
 
 }

@@ -249,6 +249,15 @@ def test_workflow_library_over_two_ranks_on_one_device(built, dataset_files, tmp
     test_one_sample.check_workflow_over_ranks("product", dataset_files("mid30k"), 2, tmp_path, 29715, samples=2)
 
 
+@pytest.mark.parametrize("world,name", [(4, "homologs8k"), (3, "itd6k"), (8, "toy3k")])
+def test_read_sharded_sample_over_ranks_on_one_device(world, name, built, dataset_files, tmp_path):
+    """The read-sharded split with the kernels of the GPU at more ranks and on the datasets that decide by re-alignments (homologs8k) and internal tandem duplications (itd6k):
+    `world` processes on cuda:0, every one holding its share of the fragments through the whole sample (tests/test_one_sample.py: check_workflow_over_ranks asserts that), the
+    sharded forms of filter_multimappers / filter_in_vitro / filter_mismappers / recover_internal_tandem_duplication on the device: both files and every count of one rank."""
+    import test_one_sample
+    test_one_sample.check_workflow_over_ranks("product", dataset_files(name), world, tmp_path, 29600 + 8 * world)
+
+
 def test_workflow_library_over_one_rccl_rank(built, dataset_files, tmp_path):
     """arriba_workflow_join_rccl -- the communicator of RCCL alone that `bench.py --gpus N` gives the C++ driver -- with ONE rank (the GPU box has one GPU): ncclGetUniqueId /
     ncclCommInitRank by dlopen, the part of the batch through agpu_shard_merge_rccl (ncclAllGather in device memory), the verdicts through agpu_filter_mismappers_rccl, sizes,
@@ -266,6 +275,7 @@ def test_workflow_library_over_one_rccl_rank(built, dataset_files, tmp_path):
             session.submit(prefix + ".bam")
         report = session.sample(prefix + ".bam", str(tmp_path / ("rccl%d.tsv" % k)), str(tmp_path / ("rccl%d.discarded.tsv" % k)))
         assert report == expected and session.timing["exchange_parts"] > 0
+        assert session.timing["shard_fragments"] == dict(report)["read_chimeric_alignments"]  # (the read-sharded split, its one rank holding every fragment)
         for name in (".tsv", ".discarded.tsv"):
             assert open(str(tmp_path / ("rccl%d" % k)) + name, "rb").read() == open(str(tmp_path / "plain") + name, "rb").read(), (k, name)
     session.close()

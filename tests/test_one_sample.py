@@ -126,11 +126,13 @@ def run_workflow_over_ranks(mode, prefix, world, out, port, bams=None, plain=Fal
     return reports
 
 
-def check_workflow_over_ranks(mode, prefix, world, tmp_path, port, samples=1):
+def check_workflow_over_ranks(mode, prefix, world, tmp_path, port, samples=1, split="sharded"):
+    """split: what the ranks are expected to do with the reads -- "sharded": every rank keeps the fragments of its part (the default whenever the parts follow each other in name order);
+    "replicated": one all-gather of the batch, the stages on every rank (names in another order; or asked for with ARRIBA_RANKS_SPLIT=replicated)"""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libworkflow_on_harness.so"], check=True)
     bams = [prefix + ".bam"] * samples
     alone = run_workflow_over_ranks(mode, prefix, 1, str(tmp_path / "alone"), port, bams[:1], plain=True)[0]
-    reports = run_workflow_over_ranks(mode, prefix, world, str(tmp_path / "ranks"), port + 1, bams)
+    reports = run_workflow_over_ranks(mode, prefix, world, str(tmp_path / "ranks"), port + 1, bams, environment={"ARRIBA_RANKS_SPLIT": "replicated"} if split == "forced_replicated" else None)
     read = lambda directory, name: open(str(tmp_path / directory / name), "rb").read()
     assert len(read("alone", "sample0.tsv").splitlines()) > 3 and len(read("alone", "sample0.discarded.tsv").splitlines()) > 100
     for report in reports:
@@ -142,16 +144,36 @@ def check_workflow_over_ranks(mode, prefix, world, tmp_path, port, samples=1):
     for k in range(samples):  # rank 0 wrote the files: byte for byte those of one rank
         assert read("ranks", "sample%d.tsv" % k) == read("alone", "sample0.tsv")
         assert read("ranks", "sample%d.discarded.tsv" % k) == read("alone", "sample0.discarded.tsv")
+        held = [report["samples"][k]["shard_fragments"] for report in reports]
+        if split == "sharded":  # every rank held its share of the fragments through the whole sample, and together they held each once
+            assert sum(held) == reports[0]["samples"][k]["fragments"] and max(held) < 0.75 * sum(held) * (2.0 / world if world > 2 else 1.0), held
+        else:
+            assert held == [0] * world, held
     return reports
 
 
-@pytest.mark.parametrize("world,name,samples", [(2, "toy3k", 3), (3, "homologs8k", 1), (4, "mid30k", 1), (3, "scrambled3k", 2)])
+@pytest.mark.parametrize("world,name,samples", [(2, "toy3k", 3), (3, "homologs8k", 1), (4, "mid30k", 1), (8, "itd6k", 1), (3, "scrambled3k", 2)])
 def test_workflow_library_over_ranks_writes_the_files_of_one_rank(world, name, samples, dataset_files, built, emu_api, tmp_path):
-    """The C++ driver as a collective call (include/arriba_workflow.h: arriba_workflow_set_communicator; the collectives are torch.distributed's, gloo): every rank feeds and
-    ingests its part of the records, ONE all-gather of the parts, the stages on every rank, the re-alignments of filter_mismappers and the rows of the output files shared out --
-    fusions.tsv and discarded.tsv of rank 0 and the counts of every stage on every rank equal those of one rank without a communicator; with several samples in a queue
-    (the part of the next file fed beside the stages of the current one)."""
-    check_workflow_over_ranks("harness", dataset_files(name), world, tmp_path, 29760 + 4 * world + (2 if name == "scrambled3k" else 0), samples)
+    """The C++ driver as a collective call (include/arriba_workflow.h: arriba_workflow_set_communicator; the collectives are torch.distributed's, gloo), THE READS SHARDED: every rank
+    feeds and ingests its part of the records and keeps its fragments through the whole sample -- the read-level cascade on the shard with its small exchanges (dummy genes, duplicate
+    keys, mate gaps, strandedness votes, coverage), ONE all-gather of the emissions of find_fusions, the candidates and their read lists built on every rank, one byte of state per
+    fragment replicated whenever the filters have changed, the stages that need alignments (scores of filter_multimappers, filter_mismappers, the clipped mates of filter_in_vitro)
+    where the reads are, the rows of the written candidates gathered from their ranks -- fusions.tsv and discarded.tsv of rank 0 and the counts of every stage on every rank equal
+    those of one rank without a communicator; with several samples in a queue (the part of the next file fed beside the stages of the current one).  scrambled3k: the names of the
+    file are not in order, so the parts do not follow each other: the ranks notice and put the batch together on every rank instead (the split of rounds 2-5)."""
+    check_workflow_over_ranks("harness", dataset_files(name), world, tmp_path, 29760 + 4 * world + (2 if name == "scrambled3k" else 0), samples, split="replicated" if name == "scrambled3k" else "sharded")
+
+
+@pytest.mark.parametrize("world,name", [(8, "toy3k"), (8, "homologs8k"), (8, "mid30k"), (2, "itd6k"), (3, "rules8k"), (3, "stacked4k")])
+def test_read_sharded_sample_over_more_ranks_and_datasets(world, name, dataset_files, built, emu_api, tmp_path):
+    """... the same at 8 ranks (parts of a few hundred fragments: ranks without a candidate's reads, without multi-mappers, without clipped mates) and on the datasets whose
+    files exercise the blacklist / known fusions (rules8k), sets of nine genes per alignment (stacked4k) and internal tandem duplications (itd6k)"""
+    check_workflow_over_ranks("harness", dataset_files(name), world, tmp_path, 29900 + 8 * world + {"toy3k": 0, "homologs8k": 2, "mid30k": 4, "itd6k": 0, "rules8k": 2, "stacked4k": 4}[name])
+
+
+def test_the_split_of_the_batch_can_still_be_asked_for(dataset_files, built, emu_api, tmp_path):
+    """ARRIBA_RANKS_SPLIT=replicated: one all-gather of the batch and the stages on every rank, for comparisons with the read-sharded split"""
+    check_workflow_over_ranks("harness", dataset_files("toy3k"), 2, tmp_path, 29990, split="forced_replicated")
 
 
 def test_a_failure_on_one_rank_ends_the_sample_on_all_ranks(dataset_files, built, emu_api, tmp_path):

@@ -42,7 +42,8 @@ try:
             bam = bam + ".is_not_there"  # (the test of a failure on one rank)
         try:
             report = session.sample(bam, name + ".tsv", name + ".discarded.tsv")
-            result["samples"].append({"report": report, "exchange_parts": session.timing["exchange_parts"], "fragments": dict(report).get("read_chimeric_alignments")})
+            result["samples"].append({"report": report, "exchange_parts": session.timing["exchange_parts"], "fragments": dict(report).get("read_chimeric_alignments"),
+                                      "shard_fragments": int(session.timing["shard_fragments"]), "exchanged_bytes": int(session.timing["exchanged_bytes"])})
         except ArribaError as error:
             result["samples"].append({"error": str(error)})
     session.close()
