@@ -176,7 +176,7 @@ def cpu_baseline(seed, directory, stress=False, sample_fragments=800000, subsamp
             at_size = {"chimeric_fragments": timed_fragments, "seconds": round(seconds_at_size, 1), "speed_of_this_core_against_the_fit": round(speed_of_this_core, 3),
                        "what": "extrapolated: the reference would need ~1 GB per million fragments (documentation/10-Current-limitations.md:14) and does not fit this box at that size"}
             sample = "extrapolated to the %d chimeric fragments of the timed sample with the fit of tests/golden/cpu_baseline_fit.json (%s), scaled by this box's core on the live sample (x%.2f); live: %s" % (timed_fragments, model["model"], speed_of_this_core, sample)
-    return {"value": value, "unit": unit, "cores": 1, "kind": "reference", "sample": sample, "live": live, "at_the_timed_size": at_size,
+    return {"value": value, "unit": unit, "cores": 1, "kind": "reference, extrapolated" if at_size else "reference", "measured_on_this_box": live["value"], "sample": sample, "live": live, "at_the_timed_size": at_size,
             "value_without_loading": live["value_without_loading"], "seconds": live["seconds"], "loading_seconds": live["loading_seconds"],
             # the reference slows down with the sample (its containers are trees and hash maps of pointers): the points measured once in the build container and their fit
             "at_larger_samples": fit}
@@ -203,6 +203,23 @@ def normal_pairs_leg(pipeline, directory, fragments=10000000, steps=2):
     return {"what": "config 2 with 4 N ordinary proper pairs (SURVEY.md 8d-2): %d chimeric fragments among %d BAM records, %.1f GB" % (counts.get("read_chimeric_alignments", 0), counts.get("bam_records", 0), bam_bytes / 1e9),
             "chimeric_reads_per_s": counts.get("read_chimeric_alignments", 0) / (sum(seconds[1:]) / steps), "bam_records_per_s": counts.get("bam_records", 0) / (sum(seconds[1:]) / steps), "bam_GB_per_s": bam_bytes / 1e9 / (sum(seconds[1:]) / steps),
             "seconds_per_step": round(sum(seconds[1:]) / steps, 4), "steps": steps, "last_step": {key: round(value, 4) for key, value in timing.items()}, "generate_seconds": round(generated, 1)}
+
+
+def stress_leg(fragments, steps=2, warmup=1):
+    """BASELINE.json's config 3 at its stated size in the default run (review of round 5): the mismapper stress -- clipped segments of 40-70 nt copied from the partner gene,
+    `-U 32767`, so that filter_mismappers sees every read and the candidates list 92.7 G supporting reads at 10^8 fragments (discordant lists implicit) -- as a run of this script
+    of its own (a session of its own: -U is a parameter of the session, and the sample wants the device to itself), behind the session of the headline sample.  Its line, in short."""
+    command = [sys.executable, os.path.abspath(__file__), "--stress", "--fragments", str(fragments), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-deflated-leg"]
+    started = time.time()
+    result = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=dict(os.environ, ARRIBA_BENCH_NO_STRESS_LEG="1"))
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{") and '"metric"' in line]
+    if result.returncode != 0 or not lines:
+        return {"error": "the run of config 3 failed: " + result.stderr[-500:], "seconds": round(time.time() - started, 1)}
+    line = json.loads(lines[-1])
+    return {"what": line["config"]["workload"], "chimeric_reads_per_s": line["value"], "seconds_per_step": round(line["ms_per_step"] / 1e3, 3), "steps": line["steps"], "warmup": line["warmup"],
+            "fragments": line["config"]["fragments_per_gpu"], "candidates": line["config"]["candidates"], "fusions": line["config"]["fusions"], "hbm_used_GB": line.get("hbm_used_GB"),
+            "seconds_per_step_by_part": line.get("seconds_per_step"), "roofline": {key: line["roofline"].get(key) for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes_per_launch", "launches_per_step")},
+            "kernel_ms": dict(list((line.get("kernel_ms") or {}).items())[:12]), "self_check": line.get("self_check"), "seconds_of_the_leg": round(time.time() - started, 1)}
 
 
 def deflated_leg(pipeline, directory, fragments, stress, stored_output, steps=2, finish_ahead=False):
@@ -317,6 +334,7 @@ def main():
     parser.add_argument("--no-deferred-output", action="store_true", help="with the samples in a queue: fusions.tsv of a sample is written before arriba_workflow_sample returns (without it: by a thread of the session, beside the next sample)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-deflated-leg", action="store_true", help="skip the secondary measurement on the same sample with deflated BGZF blocks (value_deflated: inflated on the device)")
+    parser.add_argument("--no-stress-leg", action="store_true", help="skip the secondary measurement of BASELINE.json's config 3 (value_stress: the mismapper stress with -U 32767 at the size of the headline sample, a run of its own behind it)")
     parser.add_argument("--no-normal-pairs", action="store_true", help="skip the secondary measurement on the 10 M sample with 4 N ordinary proper pairs (value_with_normal_pairs)")
     parser.add_argument("--host-only", action="store_true")
     parser.add_argument("--keep", help="keep the sample and the output files in this directory")
@@ -702,6 +720,13 @@ def main():
             if streaming:
                 also.append(roofline_of(max(streaming, key=lambda name: (alone_modelled or modelled)[name]["ms"])))
             roofline["also"] = also
+            # the cascade as a whole (review of round 5, hygiene): the algorithmic bytes of a sample -- SURVEY.md 8(d): 433 B per fragment through the read-level cascade and the key
+            # emission, plus the BAM stream the ingest reads once -- over the device work of a sample (the sum of its kernels when nothing runs beside them), against the HBM peak
+            if alone_kernels:
+                cascade_bytes = 433.0 * n + bam_bytes
+                cascade_ms = sum(values["ms"] for values in alone_kernels.values())
+                roofline["cascade"] = {"algorithmic_bytes_per_sample": cascade_bytes, "kernel_ms_alone_sum": round(cascade_ms, 1), "achieved": cascade_bytes / (cascade_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                       "frac": cascade_bytes / (cascade_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "what": "433 B x fragments (SURVEY.md 8d) + the bytes of the BAM stream, over the sum of the kernel times of one sample that ran alone"}
             kernel_ms_per_step = sum(values["ms"] for values in kernels.values()) / args.steps
             mean = lambda key: sum(s[key] for s in step_seconds) / len(step_seconds)
             resident_stages = ("mark_multimappers", "annotate", "read_filters_stage1", "fragment_length_samples", "read_filters_stage2", "find_fusions", "merge_adjacent_fusions", "filter_multimappers",
@@ -720,8 +745,11 @@ def main():
                            "fragments_per_gpu": n, "candidates": pipeline.n_candidates, "fusions": fusion_lines,
                            "read_chimeric_alignments": "host ingest (multi-threaded) + upload" if args.host_ingest else "on the device (agpu_ingest.hip), the host feeds the bytes of the file",
                            "timed_call": ("arriba_workflow_sample of libarriba_workflow.so (C++ over the two C ABIs; resident session)" + ("; samples in a queue: arriba_workflow_submit(next) before arriba_workflow_sample(current), so the file of the next sample is fed under the stages of the current one -- every timed step is one whole sample, BAM file -> fusions.tsv, and carries the feed of its successor; fusions.tsv of a sample is formatted and written by a thread of the session beside the next sample (arriba_workflow_defer_output), the last one complete before the clock stops (arriba_workflow_flush)" + ("; the ingest of a sample is finished by the thread that feeds it, beside the stages of the sample in front (arriba_workflow_finish_ahead)" if finish_ahead[0] else "") if pipelined else "; one sample at a time")) if through_workflow_library else "the ctypes mirror of the stage order (arriba_amd/pipeline.py)",
-                           "parallelism": (("one sample over %d GPUs in the C++ driver (arriba_workflow_sample as a collective call; %s): every rank ingests its part of the file, one all-gather of the parts (%.3f s with export and merge), the stages on every rank, filter_mismappers shared out (one all-reduce of the verdict bytes), the rows of the files formatted by all ranks, rank 0 writes"
-                                            % (world, collectives[0], ingest_parts[-1].get("exchange_parts", 0.0))) if through_workflow_library else
+                           "parallelism": ((("one sample over %d GPUs in the C++ driver (arriba_workflow_sample as a collective call; %s), THE READS SHARDED: every rank ingests its part of the file and keeps its fragments (this rank: %d of %d) through the read-level cascade, ONE all-gather of the emissions of find_fusions, candidates and read lists built on every rank, one byte of state per fragment replicated when filters change, "
+                                             "multi-mapper scores / re-alignments of filter_mismappers / clipped mates of filter_in_vitro where the reads are, rows of the written candidates gathered from their ranks, rows formatted by all ranks, rank 0 writes; exchanges %.3f s, %.2f GB received by this rank per sample"
+                                             % (world, collectives[0], int(pipeline.timing.get("shard_fragments", 0)), n, ingest_parts[-1].get("exchange_parts", 0.0), pipeline.timing.get("exchanged_bytes", 0) / 1e9)) if pipeline.timing.get("shard_fragments", 0) > 0 else
+                                            ("one sample over %d GPUs in the C++ driver (arriba_workflow_sample as a collective call; %s): every rank ingests its part of the file, one all-gather of the parts (%.3f s with export and merge), the stages on every rank, filter_mismappers shared out (one all-reduce of the verdict bytes), the rows of the files formatted by all ranks, rank 0 writes (the names of the file are not in order, or ARRIBA_RANKS_SPLIT=replicated)"
+                                             % (world, collectives[0], ingest_parts[-1].get("exchange_parts", 0.0)))) if through_workflow_library else
                                            ("one sample over %d GPUs: every rank ingests its part of the file, one all-gather of the parts (%s), filter_mismappers shared out (one all-reduce of %d verdict bytes), rank 0 writes"
                                             % (world, "%.2f GB per rank" % (max(pipeline.exchange["part_bytes"]) / 1e9), pipeline.exchange.get("mismapper_jobs", 0)))) if one_sample
                                           else ("%d samples, one per GPU, no collective on the data path" % world) if distributed else "1 GPU",
@@ -773,6 +801,10 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "chimeric reads/s", "cores": 1, "kind": "reference", "sample": "skipped: the reference is timed by the run with 1 GPU" if distributed else "skipped"}
             else:
                 line["cpu_baseline"] = cpu_baseline(1000, directory, stress=args.stress, subsampling=subsampling, timed_fragments=total_fragments, sample_fragments=150000 if args.stress else 800000)  # (config 3: the reference needs 5 1/2 minutes for 1 M fragments)
+            if through_workflow_library and not distributed and not args.stress and not args.no_stress_leg and not os.environ.get("ARRIBA_BENCH_NO_STRESS_LEG") and args.fragments >= 10000000:
+                progress("BASELINE.json config 3 at the size of the headline sample: the mismapper stress with -U 32767, in a session of its own")
+                pipeline.close()  # (the stress sample wants the device to itself: 92.7 G list entries at 10^8 fragments)
+                line["value_stress"] = stress_leg(args.fragments)
             print(json.dumps(line))
     finally:
         if one_sample:
