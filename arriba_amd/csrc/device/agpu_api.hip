@@ -31,6 +31,16 @@ void set_last_error(const std::string& message) { g_last_error = message; if (me
 // back, the allocation tried again -- runs where a test can see what it does to an ingest that is finishing
 static thread_local int g_fail_allocations_in_finish = 0;
 thread_local bool g_inside_ingest_finish = false;
+// test hook (agpu_debug_exhaust_memory_in_finish): the next calls of agpu_ingest_finish on this thread end as they do when the device is out of memory -- AGPU_ERR_NO_MEMORY --,
+// n > 0: the next n of a context that has a sibling (two samples in flight on one device: what the session's retry is for); n < 0: every call (a device too small for the sample)
+static thread_local int g_exhausted_finishes = 0;
+bool debug_finish_runs_out_of_memory(agpu_ctx* ctx) {
+	if (g_exhausted_finishes == 0) return false;
+	if (g_exhausted_finishes < 0) return true;
+	if (ctx->sibling == nullptr) return false;
+	--g_exhausted_finishes;
+	return true;
+}
 bool debug_allocation_fails() { if (g_fail_allocations_in_finish > 0 && g_inside_ingest_finish) { --g_fail_allocations_in_finish; return true; } return false; }
 void note_failed_allocation(size_t bytes) {
 	size_t free_bytes = 0, total_bytes = 0;
@@ -424,7 +434,7 @@ __global__ void __launch_bounds__(BLOCK) low_entropy_kernel(BatchView b, FilterT
 // ---- host helpers ---------------------------------------------------------------------------------
 
 template <class T> int upload(DeviceBuffer& buffer, const T* host, size_t count, hipStream_t stream) {
-	if (!buffer.allocate(count * sizeof(T))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!buffer.allocate(count * sizeof(T))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	if (count > 0) HIP_CHECK(hipMemcpyAsync(buffer.ptr, host, count * sizeof(T), hipMemcpyHostToDevice, stream));
 	return AGPU_OK;
 }
@@ -450,7 +460,7 @@ int upload_index(const agpu_flat_index& in, DeviceBuffer& contig_offset, DeviceB
 int grow_preserving(DeviceBuffer& buffer, size_t keep_bytes, size_t new_bytes, hipStream_t stream) {
 	if (new_bytes <= buffer.capacity) { buffer.bytes = new_bytes; return AGPU_OK; }
 	DeviceBuffer larger;
-	if (!larger.allocate(new_bytes + (new_bytes >> 2))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!larger.allocate(new_bytes + (new_bytes >> 2))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	if (keep_bytes > 0) HIP_CHECK(hipMemcpyAsync(larger.ptr, buffer.ptr, keep_bytes, hipMemcpyDeviceToDevice, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	buffer.swap(larger);
@@ -564,21 +574,21 @@ int finish_batch_setup(agpu_ctx* ctx) {
 	hipStream_t s = ctx->stream;
 	const uint64_t n = ctx->n;
 	if (ctx->max_read_length > 1024) { set_last_error("reads longer than 1024 nt are not supported by the low_entropy kernel's 8-plane k-mer counters"); return AGPU_ERR_INVALID; }
-	if (!ctx->filter.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->filter.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	HIP_CHECK(hipMemsetAsync(ctx->filter.ptr, 0, n ? n : 1, s));
-	if (!ctx->pristine_fbits.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->pristine_fbits.allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	if (n > 0) HIP_CHECK(hipMemcpyAsync(ctx->pristine_fbits.ptr, ctx->fbits.ptr, n, hipMemcpyDeviceToDevice, s));
 	for (int k = 0; k < 3; ++k) {
-		if (!ctx->pristine_abits[k].allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (!ctx->pristine_abits[k].allocate(n)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		if (n > 0) HIP_CHECK(hipMemcpyAsync(ctx->pristine_abits[k].ptr, ctx->abits[k].ptr, n, hipMemcpyDeviceToDevice, s));
-		if (!ctx->gene_count[k].allocate(n) || !ctx->genes[k].allocate(n * GENE_INLINE * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (!ctx->gene_count[k].allocate(n) || !ctx->genes[k].allocate(n * GENE_INLINE * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		HIP_CHECK(hipMemsetAsync(ctx->gene_count[k].ptr, 0, n ? n : 1, s));
 	}
 	uint32_t pool_capacity = (uint32_t) std::min<uint64_t>(n / 2 + (1u << 20), 0x7FFFFFFFull);
-	if (!ctx->gene_pool.allocate((size_t) pool_capacity * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
-	if (!ctx->unmapped_keys.allocate((2 * n + 2) * sizeof(uint64_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->gene_pool.allocate((size_t) pool_capacity * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
+	if (!ctx->unmapped_keys.allocate((2 * n + 2) * sizeof(uint64_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	ctx->viral_pair_capacity = std::max<uint64_t>(1u << 20, n / 8);
-	if (!ctx->viral_pairs.allocate(ctx->viral_pair_capacity * 2 * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->viral_pairs.allocate(ctx->viral_pair_capacity * 2 * sizeof(uint32_t))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	HIP_CHECK(hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes, s));
 	HIP_CHECK(hipMemsetAsync(ctx->stage_counts.ptr, 0, ctx->stage_counts.bytes, s));
 
@@ -715,7 +725,7 @@ int agpu_upload_genome(agpu_ctx* ctx, const agpu_genome_view* in) {
 	TRY(upload(ctx->genome_contig_bits, in->contig_bits, in->n_contigs, s));
 	{ // (16 bytes of padding behind the last base: the re-alignment of filter_mismappers reads the genome eight bases at a time)
 		const size_t bases = in->contig_offset[in->n_contigs];
-		if (!ctx->genome_bases.allocate(bases + 16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (!ctx->genome_bases.allocate(bases + 16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		HIP_CHECK(hipMemsetAsync((char*) ctx->genome_bases.ptr + bases, 0, 16, s));
 		if (bases > 0) HIP_CHECK(hipMemcpyAsync(ctx->genome_bases.ptr, in->bases, bases, hipMemcpyHostToDevice, s));
 	}
@@ -840,7 +850,7 @@ int agpu_annotate_finish(agpu_ctx* ctx, const uint64_t* positions, uint64_t n_po
 	uint32_t host_counters[COUNTER_COUNT];
 	if (positions != nullptr) { // the unmapped positions of all shards: dummy genes are cut from the sorted positions of the whole sample
 		if (n_positions >= 0xFFFFFFF0ull) { set_last_error("too many unmapped positions"); return AGPU_ERR_CAPACITY; }
-		if (!ctx->unmapped_keys.allocate((std::max<uint64_t>(n_positions, 2 * n + 2)) * 8)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (!ctx->unmapped_keys.allocate((std::max<uint64_t>(n_positions, 2 * n + 2)) * 8)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		if (n_positions) HIP_CHECK(hipMemcpyAsync(ctx->unmapped_keys.ptr, positions, (size_t) n_positions * 8, hipMemcpyDefault, s));
 		ctx->n_unmapped = (uint32_t) n_positions;
 	}
@@ -848,11 +858,11 @@ int agpu_annotate_finish(agpu_ctx* ctx, const uint64_t* positions, uint64_t n_po
 	ctx->n_dummy = 0;
 	if (unmapped > 0) {
 		// sort the unmapped positions and cut them into dummy genes (source/arriba.cpp:232-260)
-		if (!ctx->sorted_keys.allocate((size_t) unmapped * 8) || !ctx->scan_flags.allocate((size_t) unmapped * 4) || !ctx->scan_ids.allocate((size_t) unmapped * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (!ctx->sorted_keys.allocate((size_t) unmapped * 8) || !ctx->scan_flags.allocate((size_t) unmapped * 4) || !ctx->scan_ids.allocate((size_t) unmapped * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		size_t sort_bytes = 0, scan_bytes = 0;
 		HIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, ctx->unmapped_keys.as<uint64_t>(), ctx->sorted_keys.as<uint64_t>(), unmapped, 0, 48, s));
 		HIP_CHECK(rocprim::inclusive_scan(nullptr, scan_bytes, ctx->scan_flags.as<uint32_t>(), ctx->scan_ids.as<uint32_t>(), unmapped, rocprim::plus<uint32_t>(), s));
-		if (!ctx->sort_scratch.allocate(std::max(sort_bytes, scan_bytes))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (!ctx->sort_scratch.allocate(std::max(sort_bytes, scan_bytes))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		HIP_CHECK(rocprim::radix_sort_keys(ctx->sort_scratch.ptr, sort_bytes, ctx->unmapped_keys.as<uint64_t>(), ctx->sorted_keys.as<uint64_t>(), unmapped, 0, 48, s));
 		dummy_flags_kernel<<<grid_for(unmapped), BLOCK, 0, s>>>(ctx->sorted_keys.as<uint64_t>(), unmapped, ctx->annotation.gene_index, ctx->scan_flags.as<uint32_t>());
 		HIP_CHECK(rocprim::inclusive_scan(ctx->sort_scratch.ptr, scan_bytes, ctx->scan_flags.as<uint32_t>(), ctx->scan_ids.as<uint32_t>(), unmapped, rocprim::plus<uint32_t>(), s));
@@ -860,7 +870,7 @@ int agpu_annotate_finish(agpu_ctx* ctx, const uint64_t* positions, uint64_t n_po
 		HIP_CHECK(hipMemcpyAsync(&n_dummy, ctx->scan_ids.as<uint32_t>() + (unmapped - 1), 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		ctx->n_dummy = n_dummy;
-		if (!ctx->dummy_start_key.allocate((size_t) n_dummy * 8) || !ctx->dummy_end_key.allocate((size_t) n_dummy * 8)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (!ctx->dummy_start_key.allocate((size_t) n_dummy * 8) || !ctx->dummy_end_key.allocate((size_t) n_dummy * 8)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		dummy_write_kernel<<<grid_for(unmapped), BLOCK, 0, s>>>(ctx->sorted_keys.as<uint64_t>(), unmapped, ctx->scan_flags.as<uint32_t>(), ctx->scan_ids.as<uint32_t>(), ctx->dummy_start_key.as<uint64_t>(), ctx->dummy_end_key.as<uint64_t>());
 		// extend the gene table by the dummy genes
 		const uint32_t total = ctx->n_genes + n_dummy;
@@ -917,7 +927,7 @@ int build_local_duplicate_table(agpu_ctx* ctx, uint32_t& mask) {
 	uint64_t slots = 1024;
 	while (slots < 2 * n) slots <<= 1;
 	mask = (uint32_t) (slots - 1);
-	if (!ctx->duplicate_keys.allocate((size_t) std::max<uint64_t>(n, 1) * sizeof(DuplicateKey)) || !ctx->duplicate_slots.allocate(slots * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->duplicate_keys.allocate((size_t) std::max<uint64_t>(n, 1) * sizeof(DuplicateKey)) || !ctx->duplicate_slots.allocate(slots * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	HIP_CHECK(hipMemsetAsync(ctx->duplicate_slots.ptr, 0xFF, slots * 4, s));
 	if (n > 0) {
 		{ KernelTimer timer(ctx, "duplicate_keys_kernel", n * (1 + 2 * (2 + 4 + 4 + 1 + 4 + 2 + 8) + 12)); duplicate_keys_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->batch, ctx->duplicate_keys.as<DuplicateKey>()); }
@@ -963,18 +973,18 @@ int agpu_duplicates_begin(agpu_ctx* ctx, uint64_t* n_entries) {
 	begin_timing(ctx);
 	TRY(build_local_duplicate_table(ctx, mask));
 	DeviceBuffer& flags = ctx->scratch("duplicates.flags"); DeviceBuffer& winners = ctx->scratch("duplicates.winners"); DeviceBuffer& count = ctx->scratch("duplicates.count"); DeviceBuffer& scratch = ctx->scratch("duplicates.rocprim");
-	if (!flags.allocate(std::max<uint64_t>(n, 1)) || !winners.allocate(std::max<uint64_t>(n, 1) * 4) || !count.allocate(16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!flags.allocate(std::max<uint64_t>(n, 1)) || !winners.allocate(std::max<uint64_t>(n, 1) * 4) || !count.allocate(16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	uint32_t n_winners = 0;
 	if (n > 0) {
 		duplicate_winner_flag_kernel<<<grid_for(n), BLOCK, 0, s>>>(n, ctx->duplicate_keys.as<DuplicateKey>(), ctx->duplicate_slots.as<uint32_t>(), mask, flags.as<uint8_t>());
 		size_t bytes = 0;
 		HIP_CHECK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), winners.as<uint32_t>(), count.as<uint32_t>(), n, s));
-		if (bytes > scratch.capacity && !scratch.allocate(bytes)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+		if (bytes > scratch.capacity && !scratch.allocate(bytes)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 		HIP_CHECK(rocprim::select(scratch.ptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags.as<uint8_t>(), winners.as<uint32_t>(), count.as<uint32_t>(), n, s)); // keeps name order
 		HIP_CHECK(hipMemcpyAsync(&n_winners, count.ptr, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 	}
-	if (!ctx->duplicate_entries.allocate((size_t) std::max<uint32_t>(n_winners, 1) * sizeof(DuplicateEntry))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->duplicate_entries.allocate((size_t) std::max<uint32_t>(n_winners, 1) * sizeof(DuplicateEntry))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	if (n_winners > 0) duplicate_entry_write_kernel<<<grid_for(n_winners), BLOCK, 0, s>>>(n_winners, winners.as<uint32_t>(), ctx->duplicate_keys.as<DuplicateKey>(), ctx->batch.first_rank, ctx->duplicate_entries.as<DuplicateEntry>());
 	TRY(end_timing(ctx, n * 44 + (uint64_t) n_winners * 16));
 	ctx->n_duplicate_entries = n_winners;
@@ -999,7 +1009,7 @@ int agpu_read_filters_stage1_global(agpu_ctx* ctx, const void* entries, uint64_t
 	uint64_t slots = 1024;
 	while (slots < 2 * n_entries) slots <<= 1;
 	const uint32_t mask = (uint32_t) (slots - 1);
-	if (!all_entries.allocate(std::max<uint64_t>(n_entries, 1) * sizeof(DuplicateEntry)) || !global_slots.allocate(slots * 4) || !verdict.allocate(std::max<uint64_t>(n, 1))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!all_entries.allocate(std::max<uint64_t>(n_entries, 1) * sizeof(DuplicateEntry)) || !global_slots.allocate(slots * 4) || !verdict.allocate(std::max<uint64_t>(n, 1))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	if (n_entries) HIP_CHECK(hipMemcpyAsync(all_entries.ptr, entries, (size_t) n_entries * sizeof(DuplicateEntry), hipMemcpyDefault, s));
 	HIP_CHECK(hipMemsetAsync(global_slots.ptr, 0xFF, slots * 4, s));
 	begin_timing(ctx);
@@ -1026,7 +1036,7 @@ int agpu_fragment_length_samples_limited(agpu_ctx* ctx, uint32_t limit, int32_t*
 	HIP_CHECK(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
 	const uint64_t n = ctx->n, chunk = 1u << 20;
-	if (!ctx->sample_flags.allocate(chunk) || !ctx->sample_values.allocate(chunk * 4) || !ctx->samples.allocate(MAX_SAMPLES * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!ctx->sample_flags.allocate(chunk) || !ctx->sample_values.allocate(chunk * 4) || !ctx->samples.allocate(MAX_SAMPLES * 4)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	uint32_t zero[3] = { 0, 0, 0 };
 	HIP_CHECK(hipMemcpyAsync(ctx->counters.as<uint32_t>() + COUNTER_SAMPLES, zero, sizeof(zero), hipMemcpyHostToDevice, s));
 	begin_timing(ctx);
@@ -1053,7 +1063,7 @@ int agpu_read_filters_stage2(agpu_ctx* ctx, uint64_t* remaining) {
 	const uint64_t n = ctx->n;
 	begin_timing(ctx);
 	DeviceBuffer& selected = ctx->scratch("stage2.selected"); DeviceBuffer& selected_count = ctx->scratch("stage2.selected_count");
-	if (!selected.allocate(std::max<uint64_t>(n, 1) * 4) || !selected_count.allocate(16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!selected.allocate(std::max<uint64_t>(n, 1) * 4) || !selected_count.allocate(16)) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	HIP_CHECK(hipMemsetAsync(selected_count.ptr, 0, 16, s));
 	if (n > 0) {
 		// the grids are sized for all fragments (no round trip for the count); workgroups behind the end of the list return at once
@@ -1162,6 +1172,7 @@ int agpu_get_gene_table(agpu_ctx* ctx, uint32_t first, uint32_t count, uint16_t*
 }
 
 void agpu_debug_fail_allocation_in_finish(int count) { agpu::g_fail_allocations_in_finish = count; }
+void agpu_debug_exhaust_memory_in_finish(int finishes) { agpu::g_exhausted_finishes = finishes; }
 int agpu_set_profiling(agpu_ctx* ctx, int enabled) {
 	if (!ctx) return AGPU_ERR_INVALID;
 	std::lock_guard<std::mutex> lock(ctx->profile_mutex);

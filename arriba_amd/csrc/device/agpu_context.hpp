@@ -21,7 +21,8 @@ namespace agpu {
 void set_last_error(const std::string& message);
 
 bool debug_allocation_fails(); // agpu_api.hip: a test asked for the next allocation inside agpu_ingest_finish to fail once (agpu_debug_fail_allocation_in_finish)
-void note_failed_allocation(size_t bytes); // agpu_api.hip: the size asked for and what the device has free go into the next "hipMalloc failed" message of this thread
+void note_failed_allocation(size_t bytes);
+bool debug_finish_runs_out_of_memory(struct ::agpu_ctx* ctx); // agpu_api.hip: agpu_debug_exhaust_memory_in_finish // agpu_api.hip: the size asked for and what the device has free go into the next "hipMalloc failed" message of this thread
 struct DeviceBuffer {
 	void* ptr = nullptr;
 	size_t bytes = 0;

@@ -27,7 +27,7 @@ const unsigned long long EMPTY_SLOT64 = ~0ull;
 inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1) / BLOCK); }
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 
 __global__ void partner_insert_kernel(CandidateTable t, const uint32_t* iteration_rank, unsigned long long* slots, uint32_t mask) {
 	uint32_t handle = blockIdx.x * BLOCK + threadIdx.x;
@@ -166,7 +166,7 @@ __global__ void candidate_predicates_kernel(AnnotationView ann, CandidateTable t
 }
 
 template <class T> int upload_table(DeviceBuffer& buffer, const std::vector<T>& host, hipStream_t stream) {
-	if (!buffer.allocate(host.size() * sizeof(T))) { set_last_error("hipMalloc failed"); return AGPU_ERR_DEVICE; }
+	if (!buffer.allocate(host.size() * sizeof(T))) { set_last_error("hipMalloc failed"); return AGPU_ERR_NO_MEMORY; }
 	HIP_CHECK(hipMemcpyAsync(buffer.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
 	return AGPU_OK;
 }

@@ -26,6 +26,8 @@ const int BLOCK = 256;
 //  threshold, -U 300, a wavefront per candidate of more than 192 entries made both-intronic and in vitro SLOWER at 10^8 fragments of config 2 -- 42 -> 99 ms, 74 -> 90 ms,
 //  profiles/r05h_bench100m.json -- and both spliced faster, 84 -> 69 ms)
 const uint32_t LONG_LIST = 1024, LONG_LIST_BOTH_SPLICED = 192;
+// (ARRIBA_LONG_LIST = n, tests: lists of more than n entries count as long, so that the kernels of the wavefronts run on the toy samples of the test tier, too)
+inline uint32_t long_list_entries(uint32_t by_default) { const char* knob = getenv("ARRIBA_LONG_LIST"); return knob != nullptr && atoi(knob) >= 0 && knob[0] != 0 ? (uint32_t) atoi(knob) : by_default; }
 struct WaveLanes {
 	uint32_t lane, lanes;
 	__device__ WaveLanes() : lane(threadIdx.x & 63), lanes(64) {}
@@ -35,17 +37,17 @@ struct WaveLanes {
 __device__ __forceinline__ uint64_t list_entries_of(const CandidateTable& t, uint32_t c, int first_list) { return t.list_offset[3 * (uint64_t) c + 3] - t.list_offset[3 * (uint64_t) c + first_list]; }
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 
 // (the candidates [first, end): all of them, or a window of them when the stage walks read lists and the discordant lists are implicit -- for_each_list_window)
 __global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView ann, GenomeView genome, CoverageView coverage, CandidateTable t, uint32_t min_anchor_length, unsigned int* remaining, uint32_t first = 0, uint32_t end = 0xFFFFFFFFu,
-                                       uint32_t* long_list = nullptr, uint32_t* n_long = nullptr) {
+                                       uint32_t* long_list = nullptr, uint32_t* n_long = nullptr, uint32_t long_entries = LONG_LIST) {
 	__shared__ uint32_t block_sum;
 	uint32_t kept = 0;
 	if (end > t.n) end = t.n;
 	for (uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x; c < end; c += gridDim.x * BLOCK) {
 		if (t.filter[c] != FILTER_none) continue;
-		if (long_list != nullptr && stage == EVENT_both_intronic && list_entries_of(t, c, 0) > LONG_LIST) { long_list[atomicAdd(n_long, 1u)] = c; continue; } // (event_predicate_wave_kernel)
+		if (long_list != nullptr && stage == EVENT_both_intronic && list_entries_of(t, c, 0) > long_entries) { long_list[atomicAdd(n_long, 1u)] = c; continue; } // (event_predicate_wave_kernel)
 		const uint8_t verdict = event_predicate(stage, b, ann, genome, coverage, t, c, min_anchor_length);
 		if (verdict == FILTER_none) ++kept; else if (verdict != EVENT_KEPT_UNCOUNTED) t.filter[c] = verdict;
 	}
@@ -53,8 +55,8 @@ __global__ void event_predicate_kernel(int stage, BatchView b, AnnotationView an
 }
 
 __global__ void __launch_bounds__(BLOCK) event_predicate_wave_kernel(int stage, BatchView b, AnnotationView ann, GenomeView genome, CoverageView coverage, CandidateTable t, uint32_t min_anchor_length, unsigned int* remaining,
-                                                                     const uint32_t* long_list, const uint32_t* n_long) {
-	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+                                                                     const uint32_t* long_list, const uint32_t* n_long, uint32_t first_wave) {
+	const uint32_t wave = first_wave + ((blockIdx.x * BLOCK + threadIdx.x) >> 6);
 	if (wave >= *n_long) return;
 	const uint32_t c = long_list[wave];
 	const WaveLanes lanes;
@@ -93,8 +95,8 @@ __global__ void select_best_group_kernel(CandidateTable t, const uint32_t* order
 // and decides only between equal pairs by the rules that depend on the order.  So the candidate that stays is the fold, in iteration order, over the candidates that have the HIGHEST pair of the
 // group, starting with the first of them: whatever stood before it is replaced by it, and nothing of a lower pair replaces what follows.  The wavefront takes the maximum of the pairs over the
 // group (strided, one reduction), then folds the few candidates that have it in the order of their positions (ballots over chunks of 64), then marks all others.
-__global__ void __launch_bounds__(BLOCK) select_best_wave_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, const GroupRange* large_groups, const uint32_t* n_large) {
-	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+__global__ void __launch_bounds__(BLOCK) select_best_wave_kernel(CandidateTable t, const uint32_t* order, const uint64_t* group_keys, const GroupRange* large_groups, const uint32_t* n_large, uint32_t first_wave) {
+	const uint32_t wave = first_wave + ((blockIdx.x * BLOCK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
 	if (wave >= *n_large) return;
 	const uint32_t begin = large_groups[wave].begin;
 	const uint64_t group = group_keys[begin];
@@ -231,10 +233,10 @@ __global__ void clip_summary_kernel(BatchView b, ClipSummary* summaries) {
 	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
 	if (k < 3 * b.n) summaries[CLIP_SUMMARIES_PER_READ * (k / 3) + k % 3] = clip_summary_of(b, k / 3, (int) (k % 3));
 }
-__global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long) {
+__global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long, uint32_t long_entries) {
 	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= end) return;
-	if (list_entries_of(t, c, 2) > LONG_LIST && in_vitro_looks_at(t, c)) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (the verdict walks the discordant mates: in_vitro_wave_kernel)
+	if (list_entries_of(t, c, 2) > long_entries && in_vitro_looks_at(t, c)) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (the verdict walks the discordant mates: in_vitro_wave_kernel)
 	if (is_in_vitro_artifact(b, ann, coverage, tables, t, c)) t.filter[c] = FILTER_in_vitro;
 }
 // the reads sharded over the ranks: the clipped discordant mates of every candidate the stage looks at, over the reads THIS context holds (event_core.hpp: in_vitro_clipped_mates skips
@@ -270,8 +272,8 @@ __global__ void in_vitro_verdict_kernel(AnnotationView ann, CoverageView coverag
 	if (c >= t.n || !in_vitro_looks_at(t, c)) return;
 	if (in_vitro_verdict(ann, coverage, tables, t, c, clipped[2 * (uint64_t) c], clipped[2 * (uint64_t) c + 1])) t.filter[c] = FILTER_in_vitro;
 }
-__global__ void __launch_bounds__(BLOCK) in_vitro_wave_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, const uint32_t* long_list, const uint32_t* n_long) {
-	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+__global__ void __launch_bounds__(BLOCK) in_vitro_wave_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, const uint32_t* long_list, const uint32_t* n_long, uint32_t first_wave) {
+	const uint32_t wave = first_wave + ((blockIdx.x * BLOCK + threadIdx.x) >> 6);
 	if (wave >= *n_long) return;
 	const uint32_t c = long_list[wave];
 	const WaveLanes lanes;
@@ -281,18 +283,18 @@ __global__ void __launch_bounds__(BLOCK) in_vitro_wave_kernel(BatchView b, Annot
 
 // recover_both_spliced
 __global__ void both_spliced_reads_kernel(BatchView b, AnnotationView ann, CoverageView coverage, const uint32_t* gene_read_count, uint32_t threshold, CandidateTable t, int32_t max_exon_size, uint32_t max_coverage,
-                                          uint32_t* reads, uint64_t* keys, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long) {
+                                          uint32_t* reads, uint64_t* keys, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long, uint32_t long_entries) {
 	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
 	if (c >= end) return;
 	const bool member = both_spliced_is_member(ann, t, c);
-	if (member && list_entries_of(t, c, 0) > LONG_LIST_BOTH_SPLICED) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (both_spliced_reads_wave_kernel)
+	if (member && list_entries_of(t, c, 0) > long_entries) { long_list[atomicAdd(n_long, 1u)] = c; return; } // (both_spliced_reads_wave_kernel)
 	const uint32_t count = member ? both_spliced_supporting_reads(b, ann, coverage, gene_read_count, threshold, t, c, max_exon_size, max_coverage) : 0;
 	reads[c] = count;
 	keys[c] = count > 0 ? both_spliced_group_key(t, c, false) : ~0ull;
 }
 __global__ void __launch_bounds__(BLOCK) both_spliced_reads_wave_kernel(BatchView b, AnnotationView ann, CoverageView coverage, const uint32_t* gene_read_count, uint32_t threshold, CandidateTable t, int32_t max_exon_size, uint32_t max_coverage,
-                                                                        uint32_t* reads, uint64_t* keys, const uint32_t* long_list, const uint32_t* n_long) {
-	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+                                                                        uint32_t* reads, uint64_t* keys, const uint32_t* long_list, const uint32_t* n_long, uint32_t first_wave) {
+	const uint32_t wave = first_wave + ((blockIdx.x * BLOCK + threadIdx.x) >> 6);
 	if (wave >= *n_long) return;
 	const uint32_t c = long_list[wave];
 	const WaveLanes lanes;
@@ -409,10 +411,10 @@ int run_event_stage(agpu_ctx* ctx, int stage, uint8_t filter_id, const char* ker
 				LongLists lists; uint32_t n_long = 0;
 				{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
 				{ KernelTimer timer(ctx, kernel_name, (uint64_t) C * 60 + (uint64_t) ctx->n_list_entries * 8);
-				  event_predicate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), begin, end, lists.list, lists.count); }
+				  event_predicate_kernel<<<tally_grid(end - begin, BLOCK) * 4, BLOCK, 0, s>>>(effective_stage, batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), begin, end, lists.list, lists.count, long_list_entries(LONG_LIST)); }
 				{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
 				if (n_long > 0) { KernelTimer timer(ctx, "event_predicate_wave_kernel(both_intronic)", (uint64_t) n_long * 60);
-				  event_predicate_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(effective_stage, batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), lists.list, lists.count); }
+				  for_each_wave_chunk(n_long, [&](uint64_t first, uint64_t count) { event_predicate_wave_kernel<<<(unsigned int) ((count * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(effective_stage, batch, ctx->annotation, ctx->genome, ctx->coverage, window, min_anchor_length, counter.as<unsigned int>(), lists.list, lists.count, (uint32_t) first); }); }
 				return AGPU_OK;
 			}, LISTS_OF_UNFILTERED);
 			if (status != AGPU_OK) return status;
@@ -498,7 +500,7 @@ extern "C" int agpu_select_most_supported_breakpoints(agpu_ctx* ctx, uint64_t* r
 		HIP_CHECK(hipMemcpyAsync(&n_large, counter.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (n_large > 0) { KernelTimer timer(ctx, "select_best_wave_kernel", (uint64_t) n_large * small * 40);
-		  select_best_wave_kernel<<<(unsigned int) (((uint64_t) n_large * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), large_groups.as<GroupRange>(), counter.as<uint32_t>() + 1); }
+		  for_each_wave_chunk(n_large, [&](uint64_t first, uint64_t count) { select_best_wave_kernel<<<(unsigned int) ((count * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(t, order_b.as<uint32_t>(), keys_out.as<uint64_t>(), large_groups.as<GroupRange>(), counter.as<uint32_t>() + 1, (uint32_t) first); }); }
 	} else if (C > 0) {
 		event_predicate_kernel<<<tally_grid(C, BLOCK) * 4, BLOCK, 0, s>>>(EVENT_count_only, ctx->batch, ctx->annotation, ctx->genome, ctx->coverage, ctx->candidates, 0u, counter.as<unsigned int>());
 	}
@@ -913,10 +915,10 @@ int filter_in_vitro_stage(agpu_ctx* ctx, float high_expression_quantile, const u
 			LongLists lists; uint32_t n_long = 0;
 			{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
 			{ KernelTimer timer(ctx, "in_vitro_kernel", (uint64_t) C * 80 + (uint64_t) ctx->n_list_entries * 4);
-			  in_vitro_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, begin, end, lists.list, lists.count); }
+			  in_vitro_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, begin, end, lists.list, lists.count, long_list_entries(LONG_LIST)); }
 			{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
 			if (n_long > 0) { KernelTimer timer(ctx, "in_vitro_wave_kernel", (uint64_t) n_long * 80);
-			  in_vitro_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, lists.list, lists.count); }
+			  for_each_wave_chunk(n_long, [&](uint64_t first, uint64_t count) { in_vitro_wave_kernel<<<(unsigned int) ((count * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, ctx->annotation, ctx->coverage, tables, window, lists.list, lists.count, (uint32_t) first); }); }
 			return AGPU_OK;
 		}, LISTS_OF_IN_VITRO);
 		if (status != AGPU_OK) return status;
@@ -1062,10 +1064,10 @@ extern "C" int agpu_recover_both_spliced(agpu_ctx* ctx, uint32_t max_fusions_to_
 			LongLists lists; uint32_t n_long = 0;
 			{ const int status = lists.prepare(ctx, end - begin); if (status != AGPU_OK) return status; }
 			{ KernelTimer timer(ctx, "both_spliced_reads_kernel", (uint64_t) C * 70 + (uint64_t) ctx->n_list_entries * 6);
-			  both_spliced_reads_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), begin, end, lists.list, lists.count); }
+			  both_spliced_reads_kernel<<<(unsigned int) ((end - begin + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), begin, end, lists.list, lists.count, long_list_entries(LONG_LIST_BOTH_SPLICED)); }
 			{ const int status = lists.noted(ctx, n_long); if (status != AGPU_OK) return status; }
 			if (n_long > 0) { KernelTimer timer(ctx, "both_spliced_reads_wave_kernel", (uint64_t) n_long * 70);
-			  both_spliced_reads_wave_kernel<<<(unsigned int) (((uint64_t) n_long * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), lists.list, lists.count); }
+			  for_each_wave_chunk(n_long, [&](uint64_t first, uint64_t count) { both_spliced_reads_wave_kernel<<<(unsigned int) ((count * 64 + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(batch, ctx->annotation, ctx->coverage, gene_read_count, threshold, window, max_exon_size, max_coverage, reads.as<uint32_t>(), keys_in.as<uint64_t>(), lists.list, lists.count, (uint32_t) first); }); }
 			return AGPU_OK;
 		  }, LISTS_OF_BOTH_SPLICED);
 		  if (status != AGPU_OK) return status; }

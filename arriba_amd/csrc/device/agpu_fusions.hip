@@ -30,7 +30,7 @@ const uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
 inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1) / BLOCK); }
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 
 __global__ void emission_count_kernel(BatchView b, uint32_t* counts) {
 	uint64_t i = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
@@ -291,8 +291,8 @@ template <int MODE, bool WRITE_LIST = true> __device__ __forceinline__ void scan
 }
 
 __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, BucketRanges ranges, int32_t max_mate_gap, uint32_t threshold,
-                                              uint32_t* list_size, uint8_t* discordant_swapped, const BucketRef* worklist, const uint32_t* worklist_size, int mode) {
-	const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+                                              uint32_t* list_size, uint8_t* discordant_swapped, const BucketRef* worklist, const uint32_t* worklist_size, int mode, uint32_t first_wave = 0) {
+	const uint32_t wave = first_wave + ((blockIdx.x * BLOCK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
 	if (wave >= *worklist_size) return;
 	const BucketRef ref = worklist[wave];
 	const uint32_t c = ref.candidate;
@@ -339,7 +339,7 @@ __global__ void attach_discordant_wave_kernel(AnnotationView ann, CandidateTable
 }
 
 // the split-read lists of the candidates of a window into the buffer of the window (one wavefront per candidate)
-__global__ void window_split_copy_kernel(AnnotationView ann, CandidateTable sample, CandidateTable window, uint32_t c_begin, uint32_t c_end, int lists_of) {
+__global__ void window_split_copy_kernel(AnnotationView ann, CandidateTable sample, CandidateTable window, uint32_t c_begin, uint32_t c_end, int lists_of) { // (c_begin: of this launch's chunk of the window)
 	const uint32_t c = c_begin + ((blockIdx.x * BLOCK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
 	if (c >= c_end || !lists_wanted(ann, sample, c, lists_of)) return;
 	const uint64_t begin = sample.list_offset[3 * (uint64_t) c], end = sample.list_offset[3 * (uint64_t) c + 2];
@@ -386,7 +386,7 @@ __global__ void finish_kernel(AnnotationView ann, CandidateTable t) {
 struct Scratch { // grows on demand; reused by every rocprim call
 	DeviceBuffer& buffer;
 	explicit Scratch(DeviceBuffer& pooled) : buffer(pooled) {}
-	int ensure(size_t bytes) { if (bytes > buffer.capacity) { if (!buffer.allocate(bytes + (bytes >> 2))) { set_last_error("hipMalloc failed (scratch)"); return AGPU_ERR_DEVICE; } } return AGPU_OK; }
+	int ensure(size_t bytes) { if (bytes > buffer.capacity) { if (!buffer.allocate(bytes + (bytes >> 2))) { set_last_error("hipMalloc failed (scratch)"); return AGPU_ERR_NO_MEMORY; } } return AGPU_OK; }
 };
 
 }
@@ -433,7 +433,7 @@ int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, Candidat
 	HIP_CHECK(hipStreamSynchronize(s));
 	const uint64_t entries = bounds[1] - bounds[0];
 	DeviceBuffer& buffer = ctx->scratch("lists.window");
-	if (!buffer.allocate((size_t) std::max<uint64_t>(entries, 1) * 4)) { set_last_error("hipMalloc failed (a window of " + std::to_string(entries) + " read-list entries)"); return AGPU_ERR_DEVICE; }
+	if (!buffer.allocate((size_t) std::max<uint64_t>(entries, 1) * 4)) { set_last_error("hipMalloc failed (a window of " + std::to_string(entries) + " read-list entries)"); return AGPU_ERR_NO_MEMORY; }
 	window = t;
 	window.read_lists = buffer.as<uint32_t>() - bounds[0]; window.discordant_before = nullptr;
 	if (c_end == c_begin || entries == 0) return AGPU_OK;
@@ -448,7 +448,7 @@ int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, Candidat
 	HIP_CHECK(hipMemsetAsync(worklist_count, 0, 4, s));
 	const uint32_t n = c_end - c_begin, threshold = ctx->params.subsampling_threshold;
 	{ KernelTimer timer(ctx, "window_split_copy_kernel", (uint64_t) n * 16);
-	  window_split_copy_kernel<<<grid_for((uint64_t) n * 64), BLOCK, 0, s>>>(ctx->annotation, t, window, c_begin, c_end, lists_of); }
+	  for_each_wave_chunk(n, [&](uint64_t first, uint64_t count) { window_split_copy_kernel<<<grid_for(count * 64), BLOCK, 0, s>>>(ctx->annotation, t, window, c_begin + (uint32_t) first, c_begin + (uint32_t) (first + count), lists_of); }); }
 	{ KernelTimer timer(ctx, "attach_discordant_kernel(window)", (uint64_t) n * 25);
 	  attach_discordant_kernel<<<grid_for(n), BLOCK, 0, s>>>(ctx->annotation, window, c_begin, c_end, nullptr, buckets, ctx->lists_n_bucket_rows, ranges, ctx->lists_max_mate_gap, threshold, nullptr, nullptr, bucket_worklist.as<BucketRef>(), worklist_count, ATTACH_EXPAND, lists_of); }
 	uint32_t queued = 0;
@@ -456,7 +456,7 @@ int expand_list_window(agpu_ctx* ctx, uint32_t c_begin, uint32_t c_end, Candidat
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (queued > 0) {
 		KernelTimer timer(ctx, "attach_discordant_wave_kernel(window)", (uint64_t) entries * 4 + (uint64_t) queued * 25);
-		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, window, buckets, ranges, ctx->lists_max_mate_gap, threshold, nullptr, nullptr, bucket_worklist.as<BucketRef>(), worklist_count, ATTACH_EXPAND);
+		for_each_wave_chunk(queued, [&](uint64_t first, uint64_t count) { attach_discordant_wave_kernel<<<grid_for(count * 64), BLOCK, 0, s>>>(ctx->annotation, window, buckets, ranges, ctx->lists_max_mate_gap, threshold, nullptr, nullptr, bucket_worklist.as<BucketRef>(), worklist_count, ATTACH_EXPAND, (uint32_t) first); });
 	}
 	return AGPU_OK;
 }
@@ -632,7 +632,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (queued > 0) {
 		KernelTimer timer(ctx, "attach_discordant_wave_kernel(count)", (uint64_t) Md * 24 + (uint64_t) queued * 25); // every bucket row read once, one size written per queued candidate
-		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, ATTACH_COUNT);
+		for_each_wave_chunk(queued, [&](uint64_t first, uint64_t count) { attach_discordant_wave_kernel<<<grid_for(count * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 0, ATTACH_COUNT, (uint32_t) first); });
 	}
 	// the lists are addressed with 64-bit offsets (sizes of single lists are 32-bit): with -U 32767 (BASELINE.json config 3) a few million fragments already make more than 2^32
 	// entries, every candidate of a gene pair listing the discordant mates of the pair (source/fusions.cpp:398-407 lets a list grow to the subsampling threshold)
@@ -668,7 +668,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 		HIP_CHECK(rocprim::exclusive_scan(scratch.buffer.ptr, bytes, sizes.as<uint64_t>(), before.as<uint64_t>(), (uint64_t) 0, (size_t) C + 1, rocprim::plus<uint64_t>(), s));
 		HIP_CHECK(hipMemcpyAsync(&total_discordant, before.as<uint64_t>() + C, 8, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
-		if (!ctx->cand_read_lists.allocate((size_t) std::max<uint64_t>(total_list - total_discordant, 1) * 4)) { set_last_error("hipMalloc failed (the split-read lists of the candidates)"); return AGPU_ERR_DEVICE; }
+		if (!ctx->cand_read_lists.allocate((size_t) std::max<uint64_t>(total_list - total_discordant, 1) * 4)) { set_last_error("hipMalloc failed (the split-read lists of the candidates)"); return AGPU_ERR_NO_MEMORY; }
 		t.discordant_before = before.as<uint64_t>();
 	}
 	t.read_lists = ctx->cand_read_lists.as<uint32_t>();
@@ -683,7 +683,7 @@ int candidates_from_emissions(agpu_ctx* ctx, FusionEmission* emissions, uint32_t
 		// also counts the few split-read entries), the queued candidates' columns.  What the kernel really moves is several times more (PMC): the
 		// candidates of one gene pair scan the same bucket rows one after the other.
 		KernelTimer timer(ctx, "attach_discordant_wave_kernel(fill)", (uint64_t) Md * 24 + (ctx->lists_implicit ? 0 : (uint64_t) total_list * 4) + (uint64_t) queued * 25);
-		attach_discordant_wave_kernel<<<grid_for((uint64_t) queued * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, fill_mode);
+		for_each_wave_chunk(queued, [&](uint64_t first, uint64_t count) { attach_discordant_wave_kernel<<<grid_for(count * 64), BLOCK, 0, s>>>(ctx->annotation, t, buckets, ranges, max_mate_gap, threshold, list_size.as<uint32_t>(), ctx->discordant_swapped.as<uint8_t>(), bucket_worklist.as<BucketRef>(), worklist_counts + 1, fill_mode, (uint32_t) first); });
 	}
 	ctx->n_candidates = C;
 	if (ctx->lists_implicit) { const int status = cut_list_windows(ctx); if (status != AGPU_OK) return status; }
@@ -721,6 +721,7 @@ extern "C" int agpu_find_fusions(agpu_ctx* ctx, int32_t max_mate_gap, uint64_t* 
 extern "C" int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gene2, uint32_t* contigs, int32_t* breakpoint1, int32_t* breakpoint2, uint32_t* flags, uint8_t* filter,
                                    uint32_t* split_reads1, uint32_t* split_reads2, uint32_t* discordant_mates, int32_t* anchor1, int32_t* anchor2, uint64_t* list_offset) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->failed_launch.empty()) { set_last_error("a kernel of this sample was not launched (" + ctx->failed_launch + "): its results are not to be read"); return AGPU_ERR_DEVICE; } // (advisor, round 5: not only agpu_select_candidates)
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	const size_t C = ctx->n_candidates;
@@ -736,6 +737,7 @@ extern "C" int agpu_get_candidates(agpu_ctx* ctx, uint32_t* gene1, uint32_t* gen
 
 extern "C" int agpu_get_candidate_read_lists(agpu_ctx* ctx, uint32_t* reads, uint64_t capacity, uint64_t* total) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->failed_launch.empty()) { set_last_error("a kernel of this sample was not launched (" + ctx->failed_launch + "): its results are not to be read"); return AGPU_ERR_DEVICE; }
 	HIP_CHECK(hipSetDevice(ctx->device));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	if (total) *total = ctx->n_list_entries;
@@ -775,8 +777,8 @@ __global__ void list_copy_of_kernel(CandidateTable t, const uint32_t* candidates
 	}
 }
 // the implicit discordant lists of some candidates: one wavefront per candidate walks its bucket again
-__global__ void __launch_bounds__(64) list_expand_of_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, BucketRanges ranges, int32_t max_mate_gap, uint32_t threshold, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads) {
-	const uint32_t k = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(64) list_expand_of_kernel(AnnotationView ann, CandidateTable t, DiscordantBuckets buckets, BucketRanges ranges, int32_t max_mate_gap, uint32_t threshold, const uint32_t* candidates, const uint64_t* compact_offset, uint32_t* reads, uint32_t first_candidate) {
+	const uint32_t k = first_candidate + blockIdx.x, lane = threadIdx.x;
 	const uint32_t c = candidates[k];
 	if (t.list_offset[3 * (uint64_t) c + 3] == t.list_offset[3 * (uint64_t) c + 2]) return;
 	BucketRef ref; ref.candidate = c; ref.begin = ranges.begin[c]; ref.end = ranges.end[c];
@@ -788,6 +790,7 @@ __global__ void __launch_bounds__(64) list_expand_of_kernel(AnnotationView ann, 
 
 extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* candidates, uint64_t n, uint64_t* list_offset, uint32_t* reads, uint64_t capacity, uint64_t* total) {
 	if (!ctx || !ctx->fusions_done) { set_last_error("agpu_find_fusions must run first"); return AGPU_ERR_INVALID; }
+	if (!ctx->failed_launch.empty()) { set_last_error("a kernel of this sample was not launched (" + ctx->failed_launch + "): its results are not to be read"); return AGPU_ERR_DEVICE; }
 	if (n > 0x3FFFFFFFull) { set_last_error("too many candidates"); return AGPU_ERR_INVALID; }
 	for (uint64_t k = 0; k < n; ++k) if (candidates[k] >= ctx->n_candidates) { set_last_error("candidate index out of range"); return AGPU_ERR_INVALID; }
 	HIP_CHECK(hipSetDevice(ctx->device));
@@ -817,7 +820,7 @@ extern "C" int agpu_get_candidate_read_lists_of(agpu_ctx* ctx, const uint32_t* c
 			const int32_t* columns = ctx->scratch("fusions.bucket_columns").as<int32_t>();
 			buckets.breakpoint1 = columns; buckets.breakpoint2 = columns + Md1; buckets.info = (const uint32_t*) (columns + 2 * Md1); buckets.read = buckets.info + Md1; buckets.anchor1 = (const int32_t*) (buckets.read + Md1); buckets.anchor2 = buckets.anchor1 + Md1;
 			ranges.begin = ctx->scratch("lists.bucket_begin").as<uint32_t>(); ranges.end = ctx->scratch("lists.bucket_end").as<uint32_t>(); ranges.had_split_reads = ctx->scratch("lists.had_split_reads").as<uint8_t>();
-			list_expand_of_kernel<<<(unsigned int) n, 64, 0, s>>>(ctx->annotation, ctx->candidates, buckets, ranges, ctx->lists_max_mate_gap, ctx->params.subsampling_threshold, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>());
+			for_each_wave_chunk(n, [&](uint64_t first, uint64_t count) { list_expand_of_kernel<<<(unsigned int) count, 64, 0, s>>>(ctx->annotation, ctx->candidates, buckets, ranges, ctx->lists_max_mate_gap, ctx->params.subsampling_threshold, ids.as<uint32_t>(), offsets.as<uint64_t>(), out.as<uint32_t>(), (uint32_t) first); });
 			HIP_CHECK(hipGetLastError());
 		}
 		HIP_CHECK(hipMemcpyAsync(reads, out.ptr, (size_t) entries * 4, hipMemcpyDeviceToHost, s));

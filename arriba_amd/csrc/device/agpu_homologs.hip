@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "agpu_context.hpp"
+#include "device_utils.hpp"
 #include "homolog_host.hpp"
 
 using namespace agpu;
@@ -16,7 +17,7 @@ const int BLOCK = 256;
 const uint32_t MAX_REMAINING = 4u << 20; // unfiltered candidates gathered to the host (40 bytes each)
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 
 __global__ void homolog_collect_kernel(CandidateTable t, const uint32_t* iteration_rank, const float* evalue, RemainingCandidate* out, uint32_t capacity, unsigned int* count) {
 	const uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
@@ -32,8 +33,8 @@ __global__ void homolog_collect_kernel(CandidateTable t, const uint32_t* iterati
 // of each other), then every lane walks the 64 answers in position order with the reference's two early exits (homolog_walk: a few comparisons per position, no memory).  A pair
 // of long genes is 10^5 dependent look-ups for one thread -- a launch of a thread per pair waits for the longest pair -- and 10^5 / 64 rounds here (10^7 fragments: 24.4 -> 2.5 ms,
 // 10^8: 52.5 -> 19.7 ms; profiles/r03h_output_side_and_ingest.txt).
-__global__ void __launch_bounds__(64) homolog_verdict_wave_kernel(AnnotationView ann, GenomeView genome, KmerIndexView kmers, const uint64_t* pairs, uint32_t n_pairs, float max_identity_fraction, uint8_t* verdicts) {
-	const uint32_t k = blockIdx.x;
+__global__ void __launch_bounds__(64) homolog_verdict_wave_kernel(AnnotationView ann, GenomeView genome, KmerIndexView kmers, const uint64_t* pairs, uint32_t n_pairs, float max_identity_fraction, uint8_t* verdicts, uint32_t first_pair) {
+	const uint32_t k = first_pair + blockIdx.x;
 	if (k >= n_pairs) return;
 	HomologPair p;
 	if (!homolog_pair_setup(ann, genome, kmers, (uint32_t) (pairs[k] >> 32), (uint32_t) pairs[k], p)) { if (threadIdx.x == 0) verdicts[k] = 0; return; }
@@ -92,7 +93,7 @@ extern "C" int agpu_filter_homologs(agpu_ctx* ctx, float max_identity_fraction, 
 		kmers.contig_table = ctx->kmer_contig_table.as<uint32_t>(); kmers.offsets = ctx->kmer_offsets.as<uint32_t>(); kmers.positions = ctx->kmer_positions.as<int32_t>(); kmers.n_contigs = ctx->genome.n_contigs;
 		if (!pairs.empty()) {
 			KernelTimer timer(ctx, "homolog_verdict_wave_kernel", pairs.size() * 64);
-			homolog_verdict_wave_kernel<<<(unsigned int) pairs.size(), 64, 0, s>>>(ctx->annotation, ctx->genome, kmers, device_pairs.as<uint64_t>(), (uint32_t) pairs.size(), max_identity_fraction, device_verdicts.as<uint8_t>());
+			for_each_wave_chunk(pairs.size(), [&](uint64_t first, uint64_t count) { homolog_verdict_wave_kernel<<<(unsigned int) count, 64, 0, s>>>(ctx->annotation, ctx->genome, kmers, device_pairs.as<uint64_t>(), (uint32_t) pairs.size(), max_identity_fraction, device_verdicts.as<uint8_t>(), (uint32_t) first); });
 		}
 		std::vector<uint8_t> host_verdicts(pairs.size());
 		HIP_CHECK(hipMemcpyAsync(host_verdicts.data(), device_verdicts.ptr, pairs.size(), hipMemcpyDeviceToHost, s));

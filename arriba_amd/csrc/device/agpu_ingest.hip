@@ -39,7 +39,7 @@ enum { IC_ACTIVE = 0, IC_MAPPED_READS = 1, IC_MISSING_HI = 2, IC_BROKEN = 3, IC_
        IC_MAX_READ_LENGTH = 10, IC_STRAND_COUNT = 11, IC_STRAND_MATCHING = 12, IC_RUNS_UNSORTED = 13, IC_QNAME_COMMA = 14, IC_COUNT = 16 };
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 #define TRY(call) do { int s_ = (call); if (s_ != AGPU_OK) return s_; } while (0)
 
 // ---- container ------------------------------------------------------------------------------------------------------------------------------------
@@ -625,7 +625,7 @@ int grow_stream(agpu_ctx* ctx, uint64_t needed) {
 	if (needed <= ctx->ingest_stream.capacity) { ctx->ingest_stream.bytes = needed; return AGPU_OK; }
 	DeviceBuffer larger;
 	const uint64_t doubled = ctx->ingest_stream.capacity * 2;
-	if (!larger.allocate(std::max<uint64_t>(needed + (needed >> 3), std::max<uint64_t>(doubled, 64u << 20)))) { set_last_error("hipMalloc failed (BAM stream)"); return AGPU_ERR_DEVICE; }
+	if (!larger.allocate(std::max<uint64_t>(needed + (needed >> 3), std::max<uint64_t>(doubled, 64u << 20)))) { set_last_error("hipMalloc failed (BAM stream)"); return AGPU_ERR_NO_MEMORY; }
 	if (ctx->piece_stream) { HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); HIP_CHECK(hipStreamSynchronize(ctx->piece_stream2)); } // (the pieces before this one are being unwrapped into the old one)
 	if (ctx->ingest_stream_size > 0) HIP_CHECK(hipMemcpyAsync(larger.ptr, ctx->ingest_stream.ptr, ctx->ingest_stream_size, hipMemcpyDeviceToDevice, ctx->stream));
 	HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -688,7 +688,7 @@ int grow_keeping(agpu_ctx* ctx, DeviceBuffer& buffer, size_t needed, size_t used
 	if (needed == 0) needed = 16;
 	if (buffer.ptr != nullptr && needed <= buffer.capacity) { if (needed > buffer.bytes) buffer.bytes = needed; return AGPU_OK; }
 	DeviceBuffer larger;
-	if (!larger.allocate(std::max(needed + needed / 2, estimate)) && !larger.allocate(needed)) { set_last_error("hipMalloc failed (tables of the ingest)"); return AGPU_ERR_DEVICE; }
+	if (!larger.allocate(std::max(needed + needed / 2, estimate)) && !larger.allocate(needed)) { set_last_error("hipMalloc failed (tables of the ingest)"); return AGPU_ERR_NO_MEMORY; }
 	hipStream_t s = ctx->ingest_progress.work;
 	if (used > 0 && buffer.ptr != nullptr) HIP_CHECK(hipMemcpyAsync(larger.ptr, buffer.ptr, std::min(used, buffer.capacity), hipMemcpyDeviceToDevice, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -1090,6 +1090,7 @@ int agpu_ingest_finish(agpu_ctx* ctx, agpu_ingest_result* result) {
 	struct Finishing { agpu_ctx* ctx; explicit Finishing(agpu_ctx* c) : ctx(c) { ctx->ingest_finishing = true; g_inside_ingest_finish = true; } ~Finishing() { ctx->ingest_finishing = false; g_inside_ingest_finish = false; } } finishing(ctx);
 	const uint64_t size = ctx->ingest_stream_size, base = ctx->ingest_first_record;
 	if (base > size) { set_last_error("failed to read SAM header"); return AGPU_ERR_INVALID; }
+	if (agpu::debug_finish_runs_out_of_memory(ctx)) { set_last_error("hipMalloc failed (the buffers of the batch; asked for by agpu_debug_exhaust_memory_in_finish)"); return AGPU_ERR_NO_MEMORY; } // (test hook, include/arriba_gpu.h)
 	if (!ctx->keeps_batch_buffers) take_sample_buffers(ctx); // (a session with two lanes: the batch of this sample is built where the sibling's last one, done on the device, lies -- unless the lanes keep their batch buffers, so that this ingest can be finished while the sibling's stages still run)
 	HIP_CHECK(hipStreamSynchronize(ctx->piece_stream)); HIP_CHECK(hipStreamSynchronize(ctx->piece_stream2)); // (the last pieces unwrapped)
 	if (ctx->ingest_verify_crc || ctx->ingest_deflated_pieces) {

@@ -18,7 +18,7 @@ const int BLOCK = 256;
 inline unsigned int grid_for(uint64_t n) { return (unsigned int) ((n + BLOCK - 1) / BLOCK); }
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 
 __global__ void merge_coordinate_key_kernel(CandidateTable t, uint64_t* keys) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
@@ -46,9 +46,9 @@ __global__ void merged_list_size_kernel(CandidateTable t, ItdAppended appended, 
 	for (uint32_t list = 0; list < 3; ++list)
 		sizes[3 * (uint64_t) c + list] = t.list_offset[3 * (uint64_t) c + list + 1] - t.list_offset[3 * (uint64_t) c + list] + (list < 2 ? appended.length[2 * (uint64_t) c + list] : 0);
 }
-__global__ void merged_list_copy_kernel(CandidateTable t, ItdAppended appended, const uint64_t* new_offset, uint32_t* new_lists) {
+__global__ void merged_list_copy_kernel(CandidateTable t, ItdAppended appended, const uint64_t* new_offset, uint32_t* new_lists, uint32_t first_candidate) {
 	// one wavefront per candidate: the lists of a hot candidate hold hundreds of entries
-	const uint32_t c = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	const uint32_t c = first_candidate + ((blockIdx.x * BLOCK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
 	if (c >= t.n) return;
 	// (implicit discordant lists -- fusion_core.hpp: CandidateTable::discordant_before --: only the split-read lists exist, packed; they move, the discordant lists keep their
 	//  numbers of entries, so the entries in front of a candidate's stay what they were)
@@ -133,7 +133,7 @@ extern "C" int agpu_merge_adjacent_fusions(agpu_ctx* ctx, int32_t max_distance, 
 			if (ctx->lists_implicit) HIP_CHECK(hipMemcpy(&discordant_entries, t.discordant_before + C, 8, hipMemcpyDeviceToHost));
 			ALLOC(new_lists, std::max<size_t>(total - discordant_entries, 1) * 4);
 			{ KernelTimer timer(ctx, "merged_list_copy_kernel", (uint64_t) total * 8);
-			  merged_list_copy_kernel<<<grid_for((uint64_t) C * 64), BLOCK, 0, s>>>(t, appended, new_offset.as<uint64_t>(), new_lists.as<uint32_t>()); }
+			  for_each_wave_chunk(C, [&](uint64_t first, uint64_t count) { merged_list_copy_kernel<<<grid_for(count * 64), BLOCK, 0, s>>>(t, appended, new_offset.as<uint64_t>(), new_lists.as<uint32_t>(), (uint32_t) first); }); }
 			HIP_CHECK(hipStreamSynchronize(s));
 			ctx->cand_list_offset.swap(new_offset); ctx->cand_read_lists.swap(new_lists);
 			ctx->candidates.list_offset = ctx->cand_list_offset.as<uint64_t>(); ctx->candidates.read_lists = ctx->cand_read_lists.as<uint32_t>();

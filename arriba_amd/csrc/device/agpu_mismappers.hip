@@ -29,7 +29,7 @@ const int ALIGN_BLOCK = 128;
 inline unsigned int grid_for(uint64_t n, int block = BLOCK) { return (unsigned int) ((n + block - 1) / block); }
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 
 __global__ void kmer_gene_flag_kernel(CandidateTable t, uint8_t* gene_flags) {
 	uint32_t c = blockIdx.x * BLOCK + threadIdx.x;
@@ -478,7 +478,7 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				// 8 MB of memo and 4 MB of task lists per persistent workgroup: 62 GB for 5120 of them.  A device (or what other contexts have left of it) that does not hold them
 				// runs the search with fewer workgroups -- slower, the same verdicts -- instead of failing
 				while (!memo_tables.allocate((size_t) workgroups * memo_slots * 8) || (use_worklist && !task_lists.allocate((size_t) workgroups * task_capacity * 16 * 2))) {
-					if (workgroups <= 64) { set_last_error("hipMalloc failed (the memo tables and task lists of filter_mismappers)"); return AGPU_ERR_DEVICE; }
+					if (workgroups <= 64) { set_last_error("hipMalloc failed (the memo tables and task lists of filter_mismappers)"); return AGPU_ERR_NO_MEMORY; }
 					workgroups /= 2;
 				}
 				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));

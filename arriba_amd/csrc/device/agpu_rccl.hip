@@ -17,7 +17,7 @@ using namespace agpu;
 namespace {
 
 #define HIP_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); return AGPU_ERR_DEVICE; } } while (0)
-#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_DEVICE; } } while (0)
+#define ALLOC(buffer, bytes) do { if (!(buffer).allocate(bytes)) { set_last_error("hipMalloc failed (" #buffer ")"); return AGPU_ERR_NO_MEMORY; } } while (0)
 #define TRY(call) do { int s_ = (call); if (s_ != AGPU_OK) return s_; } while (0)
 
 struct Rccl {
@@ -54,7 +54,7 @@ static int agree(agpu_ctx* ctx, ncclComm_t comm, int local_status, const char* w
 	hipStream_t s = ctx->stream;
 	const std::string local_error = local_status != AGPU_OK ? std::string(agpu_last_error()) : std::string();
 	DeviceBuffer& word = ctx->scratch("rccl.status"); // (16 bytes, allocated with the communicator: agpu_rccl_join; here for callers that bring their own)
-	if (word.ptr == nullptr && !word.allocate(16)) { set_last_error("hipMalloc failed (rccl.status)"); return AGPU_ERR_DEVICE; }
+	if (word.ptr == nullptr && !word.allocate(16)) { set_last_error("hipMalloc failed (rccl.status)"); return AGPU_ERR_NO_MEMORY; }
 	int64_t ok = local_status == AGPU_OK ? 1 : 0;
 	HIP_CHECK(hipMemcpyAsync(word.ptr, &ok, 8, hipMemcpyHostToDevice, s));
 	TRY(g_rccl.check(g_rccl.all_reduce(word.ptr, word.ptr, 1, ncclInt64, ncclMin, comm, s), "ncclAllReduce(status of the ranks)"));

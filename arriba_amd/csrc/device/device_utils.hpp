@@ -2,6 +2,7 @@
 #ifndef AGPU_DEVICE_UTILS_HPP
 #define AGPU_DEVICE_UTILS_HPP 1
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,6 +55,19 @@ __device__ __forceinline__ void block_tally(uint32_t mine, unsigned int* counter
 	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(block_sum, mine);
 	__syncthreads();
 	if (threadIdx.x == 0 && *block_sum) atomicAdd(counter, *block_sum);
+}
+// A launch takes fewer than 2^32 work-items.  A kernel that gives every ITEM a wavefront (a candidate with its read lists, a bucket of discordant mates, a group of candidates) would
+// exceed that at 2^26 = 67 M items -- a sample of 2 x 10^8 fragments has that many candidates -- and the runtime refuses such a launch without a word to the caller (the bug of
+// round 5 in agpu_get_candidate_read_lists_of).  These kernels take the index of their first item, and the host launches them in chunks: for_each_wave_chunk(items, launch(first, count)).
+// ARRIBA_WAVE_CHUNK (tests/test_gpu_parity.py): a chunk of a few items, so that every such kernel of the path runs in many chunks on a small sample and must give the same files.
+inline uint64_t wave_chunk_items() {
+	const char* knob = getenv("ARRIBA_WAVE_CHUNK"); // (read at every launch: a test switches it inside one process)
+	const long long asked = knob != nullptr ? atoll(knob) : 0;
+	return asked > 0 ? (uint64_t) asked : (uint64_t) 1 << 24;
+}
+template <class Launch> inline void for_each_wave_chunk(uint64_t items, Launch launch) {
+	const uint64_t chunk = wave_chunk_items();
+	for (uint64_t first = 0; first < items; first += chunk) launch(first, items - first < chunk ? items - first : chunk);
 }
 const unsigned int TALLY_MAX_BLOCKS = 2048;
 inline unsigned int tally_grid(uint64_t n, int block_threads) {

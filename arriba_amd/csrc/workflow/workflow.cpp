@@ -24,9 +24,10 @@
 namespace {
 
 std::string g_error;
+int g_error_code = 0; // the status of the device library behind g_error (AGPU_ERR_*), 0 = the failure was not the device's
 
-struct Failure { std::string text; };
-void device_check(int status) { if (status != AGPU_OK) throw Failure{ std::string("ERROR: ") + agpu_last_error() }; }
+struct Failure { std::string text; int code = 0; Failure(const std::string& t, int c = 0) : text(t), code(c) {} };
+void device_check(int status) { if (status != AGPU_OK) throw Failure{ std::string("ERROR: ") + agpu_last_error(), status }; }
 void host_check(int status) { if (status != 0) throw Failure{ std::string("ERROR: ") + ahost_last_error() }; }
 
 // filter ids (positions in FILTERS, source/common.hpp:29-67) of the filters main() asks about itself
@@ -39,13 +40,13 @@ double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_
 void exchange_check(int status, const char* what) { if (status != 0) throw Failure{ std::string("ERROR: the exchange between the ranks failed (") + what + ")" }; }
 template <class Work> void together(const arriba_workflow_communicator* ranks, Work work) {
 	if (ranks == nullptr) { work(); return; }
-	std::string problem;
+	std::string problem; int code = 0;
 	try { work(); }
-	catch (const Failure& failure) { problem = failure.text; }
+	catch (const Failure& failure) { problem = failure.text; code = failure.code; }
 	catch (const std::exception& e) { problem = std::string("ERROR: ") + e.what(); }
 	int64_t ok = problem.empty() ? 1 : 0;
 	const int status = ranks->all_reduce_int64(ranks->state, &ok, 1, ARRIBA_WORKFLOW_MIN);
-	if (!problem.empty()) throw Failure{ problem };
+	if (!problem.empty()) throw Failure{ problem, code };
 	exchange_check(status, "status of the ranks");
 	if (ok == 0) throw Failure{ "ERROR: another rank of the sample failed (its own message says why)" };
 }
@@ -1174,7 +1175,7 @@ int arriba_workflow_run(const arriba_workflow_options* options, arriba_workflow_
 struct arriba_workflow_session {
 	Run* lanes[2];
 	int processed_lane = 0; // of the sample arriba_workflow_sample worked on last
-	struct Submitted { std::string bam; int lane = 0; std::thread feeder; bool fed = false, ingest_finished = false, started = false; std::string error; };
+	struct Submitted { std::string bam; int lane = 0; std::thread feeder; bool fed = false, ingest_finished = false, started = false; std::string error; int error_code = 0; };
 	std::deque<std::unique_ptr<Submitted>> queue; // oldest first; at most two
 	std::mutex mutex; std::condition_variable changed;
 	bool ingest_busy = false; // a lane is between agpu_ingest_begin and agpu_ingest_finish
@@ -1295,9 +1296,13 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 	Run* lane = nullptr;
 	try {
 		const double sample_started = now_seconds();
-		if (session->queue.empty()) session->submit(chimeric_bam_file);
+		// (over several ranks: what can fail in front of the first collective of the sample -- the second lane of the session that cannot be made, a sample asked for out of order -- is
+		//  told to the other ranks like every failure behind it, so that nobody waits in the status exchange of a rank that has left the call: advisor, round 5)
+		together(session->over_ranks ? &session->communicator : nullptr, [&] {
+			if (session->queue.empty()) session->submit(chimeric_bam_file);
+			if (session->queue.front()->bam != chimeric_bam_file) throw Failure{ "ERROR: samples are worked on in the order they were submitted: '" + session->queue.front()->bam + "' comes first" };
+		});
 		arriba_workflow_session::Submitted& sample = *session->queue.front();
-		if (sample.bam != chimeric_bam_file) throw Failure{ "ERROR: samples are worked on in the order they were submitted: '" + sample.bam + "' comes first" };
 		Run& run = *session->lanes[sample.lane];
 		lane = &run;
 		run.output_path = output_file; run.discarded_path = discarded_output_file ? discarded_output_file : "";
@@ -1315,26 +1320,27 @@ int arriba_workflow_sample(arriba_workflow_session* session, const char* chimeri
 			session.abandon(sample, *session.lanes[sample.lane]); // (nothing to do behind a sample that went through)
 			{ std::lock_guard<std::mutex> lock(session.mutex); session.queue.pop_front(); }
 			session.changed.notify_all(); } } done = { *session };
-		together(run.ranks, [&] { if (!sample.error.empty()) throw Failure{ sample.error }; }); // (the feed of this rank's part)
+		together(run.ranks, [&] { if (!sample.error.empty()) throw Failure{ sample.error, sample.error_code }; }); // (the feed of this rank's part)
 		run.after_ingest = [session, &sample] { { std::lock_guard<std::mutex> lock(session->mutex); sample.ingest_finished = true; } session->release_ingest(); };
 		run_sample(run, run.device_ingest, sample_started);
 		// an I/O error on the deferred file of an EARLIER sample is reported behind this one: this sample has gone through and its own files are as they should be (its last
 		// one possibly still being written, arriba_workflow_flush); the call fails with the earlier sample's message so that the caller hears of it at the first call after it happened
 		{ const std::string text = session->take_deferred_error(); if (!text.empty()) throw Failure{ text + " (writing the last file of an earlier sample; the files of this sample are not affected)" }; }
 	}
-	catch (const Failure& failure) { g_error = failure.text; status = -1; }
-	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); status = -1; }
+	catch (const Failure& failure) { g_error = failure.text; g_error_code = failure.code; status = -1; }
+	catch (const std::exception& e) { g_error = std::string("ERROR: ") + e.what(); g_error_code = 0; status = -1; }
 	if (lane) { lane->after_ingest = nullptr; lane->before_host_writer = nullptr; lane->options.chimeric_bam_file = nullptr; lane->options.output_file = nullptr; lane->options.discarded_output_file = nullptr; lane->report = nullptr; lane->timing = nullptr; session->processed_lane = (int) (lane == session->lanes[1]); }
 	// The device ran out of memory while the session had two lanes (advisor, round 4): their contexts share one pool of scratch buffers, of which nothing is idle while one lane
 	// feeds and the other runs its stages, so the device library gives nothing back by itself (DeviceBuffer::release_idle_buffers).  The session does what INTEGRATION.md ("Memory")
 	// used to ask of the caller: what was fed ahead is thrown away, the second lane is closed -- the pool belongs to one context again, which gives back what it keeps for its next
 	// sample when an allocation fails --, and the sample is run again, alone.  Once; the sample that was fed ahead is submitted again behind it.
-	if (status != 0 && lane != nullptr && !session->retrying && !session->over_ranks && session->lanes[1] != nullptr && g_error.find("hipMalloc failed") != std::string::npos) {
+	if (status != 0 && lane != nullptr && !session->retrying && !session->over_ranks && session->lanes[1] != nullptr && g_error_code == AGPU_ERR_NO_MEMORY) { // (the status code of the device library, not a word of its message: review of round 5)
 		const std::string first_error = g_error;
 		const std::string behind = session->queue.empty() ? std::string() : session->queue.front()->bam;
 		session->drain();
 		session->join_writer_of(0); session->join_writer_of(1);
-		(void) session->take_deferred_error();
+		// (an I/O error on the deferred file of an EARLIER sample stays noted -- advisor, round 5: it was dropped here, and the caller never learnt that the file is incomplete -- and is
+		//  reported behind the sample that is run again, as it is behind any sample: take_deferred_error in the call below)
 		if (lane == session->lanes[1]) std::swap(session->lanes[0], session->lanes[1]);
 		delete session->lanes[1]; session->lanes[1] = nullptr; session->processed_lane = 0;
 		fprintf(stderr, "arriba_workflow_sample: %s -- with two samples in flight; '%s' is run again with the device to itself\n", first_error.c_str(), chimeric_bam_file);

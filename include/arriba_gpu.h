@@ -32,6 +32,8 @@ extern "C" {
 #define AGPU_ERR_DEVICE (-2)        /* HIP runtime error */
 #define AGPU_ERR_CAPACITY (-3)      /* an internal device pool overflowed (retry after agpu_set_capacity) */
 #define AGPU_ERR_NO_DEVICE (-4)     /* no gfx950 device visible */
+#define AGPU_ERR_NO_MEMORY (-5)     /* a device allocation failed (also after the contexts gave back what they merely keep for their next sample): the text names the buffer, the
+                                       size asked for and what the device has free.  A session of two lanes retries the sample alone on this code (include/arriba_workflow.h) */
 
 /* filter ids == position in the reference's registry (source/common.hpp:29-67) */
 #define AGPU_FILTER_COUNT 38
@@ -176,6 +178,10 @@ agpu_ctx* agpu_create_sibling(agpu_ctx* of);
 /* test hook: the next `count` device allocations made inside agpu_ingest_finish on the calling thread are treated as failed once each -- the contexts then give back what they
  * merely keep for their next sample and the allocation is tried again (tests/test_gpu_parity.py: the stream and the tables of the ingest that is finishing must survive that) */
 void agpu_debug_fail_allocation_in_finish(int count);
+/* test hook: the next `finishes` calls of agpu_ingest_finish on the calling thread by a context that has a sibling return AGPU_ERR_NO_MEMORY ("hipMalloc failed ..."), as they do when
+ * two samples in flight do not fit the device together; finishes < 0: every call, sibling or not (a device too small for the sample alone); 0: off.  What a session of two lanes does
+ * with that code -- drain, close the second lane, run the sample again alone -- is exercised on the GPU with it (tests/workflow_session_worker.py) */
+void agpu_debug_exhaust_memory_in_finish(int finishes);
 void agpu_destroy(agpu_ctx* ctx);
 int agpu_set_params(agpu_ctx* ctx, const agpu_params* params);
 

@@ -147,6 +147,7 @@ void emu_default_params(agpu_params* p) {
 // a context that is alone gives back its idle buffers and goes on; the lanes of a session, whose contexts share a pool, fail the sample with the device library's message)
 static int g_live_contexts = 0, g_failing_allocations = 0;
 void emu_debug_fail_allocation_in_finish(int count) { g_failing_allocations = count; }
+void emu_debug_exhaust_memory_in_finish(int finishes) { g_failing_allocations = finishes; } // (the harness's hook has that meaning already)
 emu_ctx* emu_create(int, const agpu_params* params) { emu_ctx* ctx = new emu_ctx(); if (params) ctx->params = *params; else emu_default_params(&ctx->params); memset(ctx->stage_counts, 0, sizeof(ctx->stage_counts)); ++g_live_contexts; return ctx; }
 emu_ctx* emu_create_sibling(emu_ctx* of) { return of ? emu_create(0, &of->params) : nullptr; } // (the harness has no scratch buffers to share)
 int emu_keep_batch_buffers(emu_ctx*, int) { return AGPU_OK; } // (... and none to hand from lane to lane: every context of the harness owns its batch)

@@ -559,6 +559,30 @@ def _with_implicit_lists(window_entries):
     return manager()
 
 
+def test_kernels_of_a_wavefront_per_item_are_launched_in_chunks(built, dataset_files, tmp_path):
+    """review of round 5, item 8 (the bug of round 5: 22.7 M workgroups x 256 lanes are more work-items than a launch takes, the runtime refused, nobody asked).  Every kernel that
+    gives an ITEM a wavefront -- a candidate with its read lists, a queued bucket of discordant mates, a long list, a large group of select_best, a pair of homologous genes --
+    is launched in chunks of < 2^26 items with the index of its first item (device_utils.hpp: for_each_wave_chunk; tests/test_host_and_device_logic.py audits the sources for
+    launches that do not).  Here the chunk is THREE items, every list of more than 4 entries is "long", every group of select_best of two goes to the wavefront's fold, the discordant
+    lists are implicit and expanded in windows of 1 024 entries: each of those kernels runs in many chunks on the golden samples, and counts and both files must be the reference's."""
+    knobs = {"ARRIBA_WAVE_CHUNK": "3", "ARRIBA_LONG_LIST": "4", "ARRIBA_SELECT_BEST_SMALL": "1"}
+    os.environ.update(knobs)
+    try:
+        for implicit in (False, True):
+            for name in ("toy3k", "homologs8k", "itd6k"):
+                directory = str(tmp_path / ("%s_%d" % (name, implicit)))
+                os.makedirs(directory)
+                if implicit:
+                    with _with_implicit_lists(1024):
+                        stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), directory)
+                else:
+                    stages = parity.check_workflow(dataset_files(name), conftest.golden_dir(name), directory)
+                assert stages[-1][0] == "recover_isoforms" and stages[-1][1] > 40
+    finally:
+        for key in knobs:
+            del os.environ[key]
+
+
 def test_implicit_discordant_lists_give_the_files_of_the_reference(built, dataset_files, tmp_path):
     """review of round 4, item 1: a candidate's discordant mates as (bucket range, predicate, cut-off at -U) instead of a list -- what BASELINE.json's config 3 needs at its stated
     size (10^8 fragments with -U 32767 would list 92.7 G reads).  The lists are made implicit by force on the golden datasets and expanded in windows so small (1 024 entries) that a

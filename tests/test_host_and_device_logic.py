@@ -995,7 +995,7 @@ def check_samples_in_a_queue(mode, tmp_path):
         assert report[queued] == report[alone], queued
         assert read(queued + ".tsv") == read(alone + ".tsv") and read(queued + ".discarded.tsv") == read(alone + ".discarded.tsv"), queued
     assert len(read("alone1.tsv").splitlines()) > 5
-    if mode == "harness":  # the device out of memory with two lanes: run again alone, once (workflow.cpp: arriba_workflow_sample)
+    if True:  # the device out of memory with two lanes: run again alone, once (workflow.cpp: arriba_workflow_sample; keyed on AGPU_ERR_NO_MEMORY) -- on the harness and, since round 6, on the GPU
         assert report["retried1"] == report["alone2"] and report["retried2"] == report["alone1"] and report["after_failure"] == report["alone1"]
         assert "hipMalloc failed" in report["second_failure"], report["second_failure"]
         for retried, alone in (("retried1", "alone2"), ("retried2", "alone1"), ("after_failure", "alone1")):
@@ -1089,3 +1089,24 @@ def test_long_read_names_through_the_whole_workflow(built, emu_api, tmp_path):
         pipeline.run_workflow(os.path.join(mine, "fusions.tsv"), os.path.join(mine, "discarded.tsv"))
         for name in ("fusions.tsv", "discarded.tsv"):
             assert open(os.path.join(mine, name), "rb").read() == open(os.path.join(reference, name), "rb").read(), name
+
+
+def test_no_launch_of_a_wavefront_per_item_outside_a_chunk():
+    """A static audit of the device sources (review of round 5, item 8): a launch takes fewer than 2^32 work-items, so a grid of one wavefront (or one workgroup of 64 lanes) per
+    data-dependent item must go through for_each_wave_chunk (device_utils.hpp), which launches < 2^26 items at a time -- or loop over its items inside a bounded grid (std::min).
+    Every `<<<` whose grid multiplies an item count by 64, or takes an item count as its number of 64-lane workgroups, is looked at."""
+    import glob
+    import re
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "arriba_amd", "csrc", "device", "*.hip"))):
+        for number, line in enumerate(open(path), 1):
+            for launch in re.finditer(r"<<<(.*?)>>>", line):
+                arguments = launch.group(1)
+                grid = arguments.split(",")[0]
+                per_item_wave = re.search(r"\*\s*64", grid) is not None
+                block_of_64 = re.match(r"\s*[^,]+,\s*64\s*,", arguments) is not None and not re.match(r"\s*(1|workgroups|groups)\s*$", grid)
+                if (per_item_wave or block_of_64) and "for_each_wave_chunk" not in line and "std::min" not in grid:
+                    offenders.append("%s:%d: %s" % (os.path.basename(path), number, line[max(0, launch.start() - 40):launch.end()].strip()[:160]))
+    # the kernels of the container take the blocks of ONE pushed piece (at most 256 MB / 4 KB of them)
+    offenders = [entry for entry in offenders if "bgzf_inflate" not in entry]
+    assert offenders == [], offenders

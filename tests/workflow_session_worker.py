@@ -18,6 +18,7 @@ if mode == "harness":
     _bind = _capi.bind_device_api
     _harness = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libemu.so"))
     _capi.bind_device_api = lambda library, prefix: _bind(_harness, "emu_")
+from arriba_amd import _capi  # noqa: E402
 from arriba_amd.pipeline import ArribaError, WorkflowSession  # noqa: E402
 
 os.environ.setdefault("ARRIBA_FEED_PIECE_MB", "1")  # (many pieces through the reader and the pusher of the feed)
@@ -79,22 +80,23 @@ session.finish_ahead(False)
 result["ahead5"] = session.sample(bam2, path("ahead5.tsv"), path("ahead5.discarded.tsv"))
 # the device runs out of memory while two samples are in flight (harness: agpu_debug_fail_allocation_in_finish makes the next agpu_ingest_finish fail as the device library does with
 # two lanes): the session throws away what was fed ahead, closes its second lane, runs the sample again alone and submits the other one again
-if mode == "harness":
-    session.submit(bam2)
-    session.submit(bam1)
-    _harness.emu_debug_fail_allocation_in_finish(1)
-    result["retried1"] = session.sample(bam2, path("retried1.tsv"), path("retried1.discarded.tsv"))
-    result["retried2"] = session.sample(bam1, path("retried2.tsv"), path("retried2.discarded.tsv"))  # (submitted again by the session behind the retry)
-    session.submit(bam2)
-    session.submit(bam1)
-    _harness.emu_debug_fail_allocation_in_finish(-1)  # (... and a failure of the retry as well -- a device that is too small for the sample -- is the caller's to hear)
-    try:
-        session.sample(bam2, path("failed.tsv"))
-        result["second_failure"] = "accepted"
-    except ArribaError as error:
-        result["second_failure"] = str(error)
-    _harness.emu_debug_fail_allocation_in_finish(0)
-    result["after_failure"] = session.sample(bam1, path("after_failure.tsv"), path("after_failure.discarded.tsv"))
+exhaust = _harness.emu_debug_exhaust_memory_in_finish if mode == "harness" else _capi.device_library().agpu_debug_exhaust_memory_in_finish  # (the same hook of the harness and of the device library)
+exhaust.argtypes, exhaust.restype = [ctypes.c_int], None
+session.submit(bam2)
+session.submit(bam1)
+exhaust(1)
+result["retried1"] = session.sample(bam2, path("retried1.tsv"), path("retried1.discarded.tsv"))
+result["retried2"] = session.sample(bam1, path("retried2.tsv"), path("retried2.discarded.tsv"))  # (submitted again by the session behind the retry)
+session.submit(bam2)
+session.submit(bam1)
+exhaust(-1)  # (... and a failure of the retry as well -- a device that is too small for the sample -- is the caller's to hear)
+try:
+    session.sample(bam2, path("failed.tsv"))
+    result["second_failure"] = "accepted"
+except ArribaError as error:
+    result["second_failure"] = str(error)
+exhaust(0)
+result["after_failure"] = session.sample(bam1, path("after_failure.tsv"), path("after_failure.discarded.tsv"))
 session.submit(bam1)  # left behind: arriba_workflow_close throws it away
 session.close()
 json.dump(result, open(path("result.json"), "w"))
