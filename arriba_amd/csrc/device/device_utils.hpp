@@ -63,7 +63,9 @@ __device__ __forceinline__ void block_tally(uint32_t mine, unsigned int* counter
 inline uint64_t wave_chunk_items() {
 	const char* knob = getenv("ARRIBA_WAVE_CHUNK"); // (read at every launch: a test switches it inside one process)
 	const long long asked = knob != nullptr ? atoll(knob) : 0;
-	return asked > 0 ? (uint64_t) asked : (uint64_t) 1 << 24;
+	// (a multiple of 16 items: the kernels run workgroups of up to 16 wavefronts and check their item against the END OF THE LIST only -- a chunk that ended inside a workgroup
+	//  would have its last items done again by the first workgroup of the next chunk; found by the test with chunks of 3)
+	return asked > 0 ? ((uint64_t) asked + 15) & ~(uint64_t) 15 : (uint64_t) 1 << 24;
 }
 template <class Launch> inline void for_each_wave_chunk(uint64_t items, Launch launch) {
 	const uint64_t chunk = wave_chunk_items();

@@ -118,8 +118,11 @@ struct FlatIndex {
 	size_t n_contigs() const { return contig_offset.empty() ? 0 : contig_offset.size() - 1; }
 	// first key >= position on the contig; returns the global key index or contig end
 	uint32_t lower_bound(contig_t contig, position_t position) const;
-	uint32_t contig_begin(contig_t contig) const { return contig_offset[contig]; }
-	uint32_t contig_end(contig_t contig) const { return contig_offset[contig + 1]; }
+	// (size_t, not contig_t: the index has as many slots as there are FEATURES -- the reference sizes it so, source/annotation.t.hpp:26 -- and a walk over all of them, as
+	//  compute_exonic_length makes it, must not wrap at 65 536: with the 550 666 exons of a GENCODE-size annotation every real contig was visited nine times and every exonic length
+	//  came out nine-fold -- found by the test on reference data of the size of hg38, round 6)
+	uint32_t contig_begin(size_t contig) const { return contig_offset[contig]; }
+	uint32_t contig_end(size_t contig) const { return contig_offset[contig + 1]; }
 };
 template <class Feature> void make_flat_index(const std::vector<Feature>& features, size_t n_contigs, FlatIndex& index);
 // reference: source/arriba.cpp:166-184

@@ -563,9 +563,9 @@ def test_kernels_of_a_wavefront_per_item_are_launched_in_chunks(built, dataset_f
     """review of round 5, item 8 (the bug of round 5: 22.7 M workgroups x 256 lanes are more work-items than a launch takes, the runtime refused, nobody asked).  Every kernel that
     gives an ITEM a wavefront -- a candidate with its read lists, a queued bucket of discordant mates, a long list, a large group of select_best, a pair of homologous genes --
     is launched in chunks of < 2^26 items with the index of its first item (device_utils.hpp: for_each_wave_chunk; tests/test_host_and_device_logic.py audits the sources for
-    launches that do not).  Here the chunk is THREE items, every list of more than 4 entries is "long", every group of select_best of two goes to the wavefront's fold, the discordant
+    launches that do not).  Here the chunk is SIXTEEN items (the smallest: chunks are multiples of 16, a workgroup's worth of wavefronts), every list of more than 4 entries is "long", every group of select_best of two goes to the wavefront's fold, the discordant
     lists are implicit and expanded in windows of 1 024 entries: each of those kernels runs in many chunks on the golden samples, and counts and both files must be the reference's."""
-    knobs = {"ARRIBA_WAVE_CHUNK": "3", "ARRIBA_LONG_LIST": "4", "ARRIBA_SELECT_BEST_SMALL": "1"}
+    knobs = {"ARRIBA_WAVE_CHUNK": "16", "ARRIBA_LONG_LIST": "4", "ARRIBA_SELECT_BEST_SMALL": "1"}
     os.environ.update(knobs)
     try:
         for implicit in (False, True):
@@ -809,6 +809,63 @@ def test_workflow_at_config_scale_against_the_live_reference(built, tmp_path):
     os.makedirs(str(tmp_path / "mine"))
     stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True)
     assert dict(stages)["find_fusions"] > fragments // 5 and stages[-1][1] > 100
+
+
+def test_reference_data_at_the_scale_of_hg38_against_the_live_reference(built, tmp_path):
+    """review of round 5 (missing, item 4; BASELINE.json config 2 says "hg38 exon index"): every other test and the bench use a genome of 288 Mb with 5.8 k genes.  Here the reference
+    data have the SIZE of hg38 / GENCODE -- 24 contigs of 130 Mb = 3.12 Gb of bases, 6.5 x 10^4 genes, 1.4 x 10^6 exons (tools/gen_synth --contig-len 130000000 --genes-per-mb 20; no
+    download: there is no network) -- so that the flattened interval index (source/annotation.t.hpp:25-45) holds 3 x 10^6 keys per kind, coverage_t (source/read_stats.hpp:17-27)
+    1.56 x 10^8 windows, the genome 3.1 GB of HBM, and make_kmer_index (source/filter_mismappers.cpp:47-84) marks its windows in a bitmap over 3.1 G positions: 1 M chimeric
+    fragments (4.7 M records) against the unmodified reference run on the same files -- every "(remaining=N)" of its log, fusions.tsv and discarded.tsv byte for byte.  What the
+    device holds for the reference data and what the kernels that depend on their size take is written to gpurun_out/hg38_scale.json (profiles/r06*_hg38_scale.json)."""
+    import json
+    import subprocess
+    import time
+    import torch
+    from arriba_amd.pipeline import WorkflowSession
+    if not os.path.exists(datasets.ARRIBA_REF):
+        pytest.skip("oracle/_ref/arriba_ref did not travel with the repository")
+    fragments = int(os.environ.get("ARRIBA_HG38_TEST_FRAGMENTS", "1000000"))
+    prefix = str(tmp_path / "hg38")
+    started = time.time()
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32", "--seed", "3", "--fragments", str(fragments), "--contigs", "24", "--contig-len", "130000000", "--genes-per-mb", "20", "--junctions", "20000"],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    generated = time.time() - started
+    started = time.time()
+    _run_plain_reference(prefix, str(tmp_path / "reference"))
+    reference_seconds = time.time() - started
+    os.makedirs(str(tmp_path / "mine"))
+    stages = parity.check_workflow(prefix, str(tmp_path / "reference"), str(tmp_path / "mine"), reference_prefix=prefix, device_ingest=True)
+    assert dict(stages)["find_fusions"] > fragments // 5 and stages[-1][1] > 100
+    # ... and the product path (the C++ driver, a resident session) on the same files, for the numbers: the same files again, HBM of the reference data, the kernels that scale with them
+    free_before, total = torch.cuda.mem_get_info(0)
+    started = time.time()
+    session = WorkflowSession(prefix + ".fa", prefix + ".gtf")
+    opened = time.time() - started
+    free_open, _ = torch.cuda.mem_get_info(0)
+    session.set_profiling(True)
+    started = time.time()
+    report = session.sample(prefix + ".bam", str(tmp_path / "session.tsv"), str(tmp_path / "session.discarded.tsv"))
+    sample_seconds = time.time() - started
+    free_after, _ = torch.cuda.mem_get_info(0)
+    kernels = {}
+    for name, ms, size in session.kernel_profile():
+        kernels[name] = kernels.get(name, 0.0) + ms
+    session.close()
+    for mine, theirs in (("session.tsv", ".fusions.tsv"), ("session.discarded.tsv", ".discarded.tsv")):
+        assert open(str(tmp_path / mine), "rb").read() == open(prefix + theirs, "rb").read(), mine
+    genome_bytes = os.path.getsize(prefix + ".fa")
+    record = {"what": "synthetic reference data of the size of hg38 / GENCODE: 24 x 130 Mb, %d fragments" % dict(report)["read_chimeric_alignments"], "fasta_GB": round(genome_bytes / 1e9, 2),
+              "gtf_MB": round(os.path.getsize(prefix + ".gtf") / 1e6, 1), "generate_seconds": round(generated, 1), "reference_seconds_on_this_box": round(reference_seconds, 1),
+              "session_open_seconds": round(opened, 1), "sample_seconds": round(sample_seconds, 2), "hbm_GB_behind_open (annotation + index)": round((free_before - free_open) / 1e9, 2),
+              "hbm_GB_behind_the_sample (genome, coverage_t, batch, candidates, k-mer index, scratch)": round((free_before - free_after) / 1e9, 2),
+              "coverage_windows": int(genome_bytes / 20), "stages": report,
+              "kernel_ms": {name: round(ms, 3) for name, ms in sorted(kernels.items(), key=lambda item: -item[1])[:32]}}
+    try:
+        with open(os.path.join(conftest.ROOT, "gpurun_out", "hg38_scale.json"), "w") as out:
+            json.dump(record, out, indent=1)
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("name,fragments,normal_mult", [("bench10m", 10000000, None), ("bench20m", 20000000, None), ("normal5m", 5000000, 4)])

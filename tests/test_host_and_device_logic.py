@@ -1110,3 +1110,31 @@ def test_no_launch_of_a_wavefront_per_item_outside_a_chunk():
     # the kernels of the container take the blocks of ONE pushed piece (at most 256 MB / 4 KB of them)
     offenders = [entry for entry in offenders if "bgzf_inflate" not in entry]
     assert offenders == [], offenders
+
+
+def test_exonic_lengths_with_more_exons_than_a_contig_id_holds(built, tmp_path):
+    """The bug the hg38-size GPU test of round 6 found: the exon index has one slot per FEATURE (the reference sizes it so, source/annotation.t.hpp:26), compute_exonic_length
+    (source/arriba.cpp:166-184) walks all slots, and the accessor of a slot took a 16-bit contig id -- with more than 65 535 exons the walk wrapped and every real contig was
+    counted once per 65 536 slots (nine times for GENCODE's 550 k exons): every exonic length, hence every e-value, was wrong, and no sample on the 5.8 k-gene genome of the other
+    tests could show it.  Here: 2 x 40 Mb with 400 genes per Mb, > 65 536 exons, against the gene table the live reference dumps."""
+    import golden_io
+    from arriba_amd.pipeline import HostSession
+    if not os.path.exists(datasets.ARRIBA_REF_DUMP):
+        pytest.skip("oracle/_ref/arriba_ref_dump is not built")
+    prefix = str(tmp_path / "many")
+    subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--seed", "3", "--fragments", "2000", "--contigs", "2", "--contig-len", "40000000", "--genes-per-mb", "400", "--junctions", "50"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dump = str(tmp_path / "dump")
+    os.makedirs(dump)
+    switches = {"ARRIBA_ORACLE_DUMP_LISTS": "0", "ARRIBA_ORACLE_DUMP_READS": "0", "ARRIBA_ORACLE_DUMP_STAGES": "key"}
+    os.environ.update(switches)
+    try:
+        datasets.run_reference(prefix, dump)
+    finally:
+        for key in switches:
+            del os.environ[key]
+    genes = golden_io.read_genes(os.path.join(dump, "genes.tsv"))
+    session = HostSession(prefix + ".fa", prefix + ".gtf")
+    view = session._lib.ahost_annotation_view(session._session).contents
+    assert view.n_exons > 65536 and view.n_genes > 5000, (view.n_exons, view.n_genes)
+    different = [(g["id"], view.gene_exonic_length[g["id"]], g["exonic_length"]) for g in genes[:view.n_genes] if view.gene_exonic_length[g["id"]] != g["exonic_length"]]
+    assert not different, (len(different), different[:5])
