@@ -229,9 +229,12 @@ __global__ void in_vitro_pair_key_kernel(CandidateTable t, uint64_t* keys) { // 
 	keys[2 * (uint64_t) c] = counts ? (uint64_t) t.gene1[c] << 32 | t.gene2[c] : ~0ull;
 	keys[2 * (uint64_t) c + 1] = counts ? (uint64_t) t.gene2[c] << 32 | t.gene1[c] : ~0ull;
 }
-__global__ void clip_summary_kernel(BatchView b, ClipSummary* summaries) {
+__global__ void clip_summary_kernel(BatchView b, ClipSummary* summaries, uint8_t* clip_any) {
 	const uint64_t k = blockIdx.x * (uint64_t) BLOCK + threadIdx.x;
-	if (k < 3 * b.n) summaries[CLIP_SUMMARIES_PER_READ * (k / 3) + k % 3] = clip_summary_of(b, k / 3, (int) (k % 3));
+	if (k >= 3 * b.n) return;
+	const ClipSummary summary = clip_summary_of(b, k / 3, (int) (k % 3));
+	summaries[CLIP_SUMMARIES_PER_READ * (k / 3) + k % 3] = summary;
+	if (summary.clipped) clip_any[k / 3] = 1; // (cleared by the caller; the three threads of a read write the same value)
 }
 __global__ void in_vitro_kernel(BatchView b, AnnotationView ann, CoverageView coverage, InVitroTables tables, CandidateTable t, uint32_t first, uint32_t end, uint32_t* long_list, uint32_t* n_long, uint32_t long_entries) {
 	const uint32_t c = first + blockIdx.x * BLOCK + threadIdx.x;
@@ -896,18 +899,19 @@ int filter_in_vitro_stage(agpu_ctx* ctx, float high_expression_quantile, const u
 		tables.gene_read_count = gene_read_count.as<uint32_t>();
 		tables.high_expression_threshold = threshold;
 		tables.pair_keys = unique_keys.as<uint64_t>(); tables.pair_counts = unique_counts.as<uint32_t>(); tables.n_pairs = runs; // (the run of ~0 keys at the end is never looked up)
-		tables.clip_summaries = nullptr;
+		tables.clip_summaries = nullptr; tables.clip_any = nullptr;
 		if (clipped != nullptr) { // (3') the verdicts from the counts
 			KernelTimer timer(ctx, "in_vitro_verdict_kernel", (uint64_t) C * 88);
 			in_vitro_verdict_kernel<<<grid, BLOCK, 0, s>>>(ctx->annotation, ctx->coverage, tables, t, clipped);
 		} else {
 		if (ctx->n > 0) { // the clipped ends of the alignments, summarised once in 8 bytes each: the verdicts walk the read lists and would otherwise gather CIGAR ends, strand, contig and
 			// position of up to three alignments per list entry (10^8 fragments: in_vitro_kernel 219 -> 66 + 3 ms, profiles/r03h_output_side_and_ingest.txt)
-			DeviceBuffer& summaries = ctx->scratch("events.clip_summaries");
-			ALLOC(summaries, CLIP_SUMMARIES_PER_READ * ctx->n * sizeof(ClipSummary));
-			{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20));
-			  clip_summary_kernel<<<(unsigned int) ((3 * ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, summaries.as<ClipSummary>()); }
-			tables.clip_summaries = summaries.as<ClipSummary>();
+			DeviceBuffer& summaries = ctx->scratch("events.clip_summaries"); DeviceBuffer& clip_any = ctx->scratch("events.clip_any");
+			ALLOC(summaries, CLIP_SUMMARIES_PER_READ * ctx->n * sizeof(ClipSummary)); ALLOC(clip_any, ctx->n);
+			HIP_CHECK(hipMemsetAsync(clip_any.ptr, 0, ctx->n, s));
+			{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20 + 1));
+			  clip_summary_kernel<<<(unsigned int) ((3 * ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, summaries.as<ClipSummary>(), clip_any.as<uint8_t>()); }
+			tables.clip_summaries = summaries.as<ClipSummary>(); tables.clip_any = clip_any.as<uint8_t>();
 		}
 		// (3) the verdicts
 		// (the verdict of a candidate looks at the tables made above -- complete -- and at its own discordant list; the filter it sets is read by no other candidate's verdict)
@@ -982,11 +986,12 @@ extern "C" int agpu_in_vitro_clipped_mates(agpu_ctx* ctx, uint64_t* n_entries) {
 	HIP_CHECK(hipMemsetAsync(count.ptr, 0, 16, s));
 	InVitroTables tables; memset(&tables, 0, sizeof(tables));
 	if (ctx->n > 0) {
-		DeviceBuffer& summaries = ctx->scratch("events.clip_summaries");
-		ALLOC(summaries, CLIP_SUMMARIES_PER_READ * ctx->n * sizeof(ClipSummary));
-		{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20));
-		  clip_summary_kernel<<<(unsigned int) ((3 * ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, summaries.as<ClipSummary>()); }
-		tables.clip_summaries = summaries.as<ClipSummary>();
+		DeviceBuffer& summaries = ctx->scratch("events.clip_summaries"); DeviceBuffer& clip_any = ctx->scratch("events.clip_any");
+		ALLOC(summaries, CLIP_SUMMARIES_PER_READ * ctx->n * sizeof(ClipSummary)); ALLOC(clip_any, ctx->n);
+		HIP_CHECK(hipMemsetAsync(clip_any.ptr, 0, ctx->n, s));
+		{ KernelTimer summary_timer(ctx, "clip_summary_kernel", ctx->n * (3 * 8 + 3 * 20 + 1));
+		  clip_summary_kernel<<<(unsigned int) ((3 * ctx->n + BLOCK - 1) / BLOCK), BLOCK, 0, s>>>(ctx->batch, summaries.as<ClipSummary>(), clip_any.as<uint8_t>()); }
+		tables.clip_summaries = summaries.as<ClipSummary>(); tables.clip_any = clip_any.as<uint8_t>();
 		const int status = for_each_list_window(ctx, [&](const CandidateTable& window, uint32_t begin, uint32_t end) -> int {
 			KernelTimer timer(ctx, "in_vitro_partial_kernel", (uint64_t) (end - begin) * 20 + (uint64_t) ctx->n_list_entries * 4);
 			in_vitro_partial_kernel<<<(unsigned int) std::min<uint64_t>(((uint64_t) (end - begin) * 64 + BLOCK - 1) / BLOCK, 1u << 18), BLOCK, 0, s>>>(ctx->batch, tables, window, begin, end, clipped.as<uint32_t>());

@@ -293,6 +293,8 @@ struct InVitroTables {
 	uint32_t high_expression_threshold;    // the quantile of the non-zero counts (:60-80)
 	const uint64_t* pair_keys; const uint32_t* pair_counts; uint32_t n_pairs; // exonic_breakpoints_by_gene_pair (:93-105): sorted keys gene1 << 32 | gene2
 	const ClipSummary* clip_summaries;     // [3 * fragments] or null: then every list entry reads the columns of the batch
+	const uint8_t* clip_any;               // with the summaries, or null: [fragments] 1 = one of the read's summaries is a clipped end.  One byte per list entry decides whether the 32
+	                                       // bytes of its summaries are looked at at all (round 6: few discordant mates are clipped; the bytes of 10^8 reads stay in the last-level cache)
 };
 // genes of a fragment that count towards the expression proxy: those of MATE1 and of MATE2 (discordant mates) or SUPPLEMENTARY (split read) (:52-57)
 AGPU_HD int in_vitro_second_slot(const BatchView& b, uint64_t i) { return b.n_aln[i] == 2 ? MATE2 : SUPPLEMENTARY; }
@@ -333,6 +335,7 @@ template <class Lanes = ListLanes> AGPU_HD void in_vitro_clipped_mates(const Bat
 		const uint64_t read = (uint64_t) t.read_lists[k] - b.first_rank;
 		if (read >= b.n) continue; // (a read of another shard; unsigned: also those in front of this one)
 		if (tables.clip_summaries != nullptr) { // (a read that a filter discarded has no clipped end in its summaries: clip_summary_of; 32 bytes per read, one line per list entry)
+			if (tables.clip_any != nullptr && !tables.clip_any[read]) continue;
 			for (int slot = 0; slot < 3; ++slot) {
 				const ClipSummary summary = tables.clip_summaries[CLIP_SUMMARIES_PER_READ * read + slot];
 				if (!summary.clipped) continue;
