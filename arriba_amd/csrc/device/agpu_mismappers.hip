@@ -191,21 +191,27 @@ const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch boun
 // SWEEP_ONLY: the searches go through the sweep or are given up -- no recursion, no stack of frames in the kernel; the reads of the searches given up are appended to `leftover`
 // (counters[5]) and done by the instantiation that holds everything.  queue: the index of the queue's counter (the second launch has a queue of its own).
 template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
-                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters, uint32_t* leftover, int queue) {
+                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters, uint32_t* leftover, int queue, bool lds_front) {
 	__shared__ uint8_t segment_bases[304];
 	__shared__ AlignSweep sweep;
 	__shared__ AlignMemo memo;
 	__shared__ AlignWorklist worklist;
 	__shared__ uint32_t worklist_state[4];
+	__shared__ unsigned long long memo_front[ALIGN_MEMO_FRONT_SLOTS]; // (mismapper_core.hpp: the first keys of a search never leave the CU)
+	__shared__ unsigned long long list_head[2 * ALIGN_LIST_HEAD_TASKS];
+	__shared__ uint32_t memo_spilled;
 	__shared__ uint32_t next_job;
-	__shared__ uint32_t study[8];
+	__shared__ uint32_t study[16];
 	if (threadIdx.x == 0) {
 		worklist.stats = read_times != nullptr ? study : nullptr;
 		memo.slots = memo_tables + (size_t) blockIdx.x * memo_slots; memo.mask = memo_slots - 1; memo.epoch = 0;
+		memo.front = lds_front ? memo_front : nullptr; memo.front_mask = lds_front ? ALIGN_MEMO_FRONT_SLOTS - 1 : 0; memo.spilled = lds_front ? &memo_spilled : nullptr; memo_spilled = 0;
+		worklist.head = lds_front ? list_head : nullptr; worklist.head_capacity = lds_front ? ALIGN_LIST_HEAD_TASKS : 0;
 		worklist.words = task_lists != nullptr ? task_lists + (size_t) blockIdx.x * task_capacity * 2 : nullptr; worklist.capacity = task_capacity; worklist.state = worklist_state;
 		worklist.sweep = by_sweep ? &sweep : nullptr; // one sweep over the read positions, every seed walked once (mismapper_core.hpp: AlignSweep)
 		worklist.relevant_words = task_lists != nullptr ? task_lists + ((size_t) gridDim.x + blockIdx.x) * task_capacity * 2 : nullptr; worklist.relevant_capacity = task_capacity; // (the second half of the buffer: the calls of a block beyond those kept in LDS)
 	}
+	for (uint32_t k = threadIdx.x; k < ALIGN_MEMO_FRONT_SLOTS; k += 64) memo_front[k] = 0; // (epoch 0 = free)
 	__syncthreads();
 	__shared__ int64_t given_up; // (SWEEP_ONLY: < 0 when a search of the read was not one for the sweep)
 	AlignFrame stack[SWEEP_ONLY ? 1 : ALIGN_MAX_DEPTH];
@@ -221,7 +227,7 @@ template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__
 		if (next_job >= n_heavy) break;
 		const uint32_t read = heavy[next_job];
 		const unsigned long long started = read_times != nullptr ? wall_clock64() : 0ull;
-		if (read_times != nullptr && threadIdx.x == 0) for (int k = 0; k < 8; ++k) study[k] = 0;
+		if (read_times != nullptr && threadIdx.x == 0) for (int k = 0; k < 16; ++k) study[k] = 0;
 		const bool verdict = is_mismapper(b, ann, genome, kmers, splice, read, max_mate_gap, runner);
 		if (SWEEP_ONLY && runner.exhausted()) { if (threadIdx.x == 0) leftover[atomicAdd(&counters[5], 1u)] = read; continue; } // (the same for every lane: written behind a barrier)
 		if (verdict && threadIdx.x == 0) { b.filter[read] = FILTER_mismappers; atomicAdd(&counters[1], 1u); }
@@ -229,6 +235,7 @@ template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__
 			read_times[4 * (size_t) next_job] = wall_clock64() - started; read_times[4 * (size_t) next_job + 1] = (unsigned long long) study[0] << 32 | study[1]; read_times[4 * (size_t) next_job + 2] = (unsigned long long) study[2] << 32 | study[3];
 			read_times[4 * (size_t) next_job + 3] = (unsigned long long) read << 8 | b.n_aln[read];
 			atomicAdd(&read_times[4 * (size_t) n_heavy], (unsigned long long) study[4]); atomicAdd(&read_times[4 * (size_t) n_heavy + 1], (unsigned long long) study[5]); atomicAdd(&read_times[4 * (size_t) n_heavy + 2], (unsigned long long) study[6]);
+			for (int k = 8; k < 16; ++k) atomicAdd(&read_times[4 * (size_t) n_heavy + 4 + (k - 8)], (unsigned long long) study[k]);
 		}
 	}
 }
@@ -487,14 +494,16 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const bool by_sweep = !(knob != nullptr && knob[0] == '0');
 				const bool want_times = getenv("ARRIBA_MISMAPPER_TIMES") != nullptr; // a study: how long the wavefronts worked on every read of the second pass, on stderr
 				DeviceBuffer& read_times = ctx->scratch("mismappers.read_times");
-				if (want_times) { ALLOC(read_times, (size_t) n_heavy * 32 + 32); HIP_CHECK(hipMemsetAsync(read_times.as<unsigned long long>() + 4 * (size_t) n_heavy, 0, 32, s)); }
+				if (want_times) { ALLOC(read_times, (size_t) n_heavy * 32 + 96); HIP_CHECK(hipMemsetAsync(read_times.ptr, 0, (size_t) n_heavy * 32 + 96, s)); }
 				// The searches go through the sweep in a kernel that holds nothing else (SWEEP_ONLY: no recursion, no stack of frames: fewer registers, no scratch memory behind them);
 				// the few it gives up -- a gene of 2^24 bases and more, lists that ran over, ARRIBA_MISMAPPER_SWEEP=0 / ARRIBA_MISMAPPER_WORKLIST=0 -- are done by the kernel that holds
 				// everything, which is the only one with ARRIBA_MISMAPPER_KERNELS=one (the way of round 3, for measurements).
 				// (launch bounds of the full kernel: left alone the compiler takes 132 VGPRs, which fit 3 wavefronts per SIMD: 554 ms at 10^8 fragments; 4 per SIMD = 128 VGPRs, 3 spilled:
 				//  459 ms with 4096 workgroups; 5 = 96 VGPRs, 61 spilled: 416 ms with 5120 workgroups -- profiles/r03p, r03r.  ARRIBA_HEAVY_WAVES=4 with ARRIBA_HEAVY_WORKGROUPS=4096 for measurements)
 				knob = getenv("ARRIBA_MISMAPPER_KERNELS");
-				const bool sweep_kernel_first = by_sweep && use_worklist && !want_times && !(knob != nullptr && strcmp(knob, "one") == 0);
+				const bool sweep_kernel_first = by_sweep && use_worklist && !(knob != nullptr && strcmp(knob, "one") == 0); // (the study of ARRIBA_MISMAPPER_TIMES looks at the first kernel when there are two)
+				knob = getenv("ARRIBA_MEMO_FRONT"); // "0": every key of the memo and every listed call in HBM only, as until round 6 (for A/B measurements)
+				const bool lds_front = !(knob != nullptr && knob[0] == '0');
 				const bool four_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr && atoi(getenv("ARRIBA_HEAVY_WAVES")) == 4;
 				DeviceBuffer& leftover = ctx->scratch("mismappers.leftover");
 				ALLOC(leftover, (size_t) n_heavy * 4);
@@ -504,11 +513,11 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 					{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
 					  const int heavy_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr ? atoi(getenv("ARRIBA_HEAVY_WAVES")) : 5; // (6 with ARRIBA_HEAVY_WORKGROUPS=6144: 80 VGPRs, 177 spilled -- for measurements; launch bounds of 8 are not honoured: 122 VGPRs, four wavefronts)
 					  if (heavy_waves == 6) mismapper_heavy_kernel<6, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
-					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4);
+					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front);
 					  else if (!four_waves) mismapper_heavy_kernel<5, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
-					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4);
+					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front);
 					  else mismapper_heavy_kernel<4, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
-					                                                true, nullptr, device_counters, leftover.as<uint32_t>(), 4); }
+					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front); }
 					HIP_CHECK(hipMemcpyAsync(&n_todo, device_counters + 5, 4, hipMemcpyDeviceToHost, s));
 					HIP_CHECK(hipStreamSynchronize(s));
 					todo = leftover.as<uint32_t>();
@@ -519,13 +528,13 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 					if (sweep_kernel_first) HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) groups * memo_slots * 8, s)); // (the epochs of the memo start again: nothing of the first kernel's searches may match)
 					KernelTimer timer(ctx, sweep_kernel_first ? "mismapper_heavy_kernel(searches the sweep gave up)" : "mismapper_heavy_kernel", (uint64_t) n_todo * 300);
 					if (!four_waves) mismapper_heavy_kernel<5, false><<<groups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, todo, n_todo, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
-					                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4);
+					                                                by_sweep, want_times && !sweep_kernel_first ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4, lds_front);
 					else mismapper_heavy_kernel<4, false><<<groups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, todo, n_todo, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
-					                                                by_sweep, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4);
+					                                                by_sweep, want_times && !sweep_kernel_first ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4, lds_front);
 				}
 				if (want_times) {
-					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy + 4);
-					HIP_CHECK(hipMemcpyAsync(ticks.data(), read_times.ptr, (size_t) n_heavy * 32 + 32, hipMemcpyDeviceToHost, s));
+					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy + 12);
+					HIP_CHECK(hipMemcpyAsync(ticks.data(), read_times.ptr, (size_t) n_heavy * 32 + 96, hipMemcpyDeviceToHost, s));
 					HIP_CHECK(hipStreamSynchronize(s));
 					unsigned long long histogram[40] = { 0 }, total = 0, longest = 0, sums[4] = { 0, 0, 0, 0 };
 					std::vector<std::pair<unsigned long long, uint32_t> > by_time(n_heavy);
@@ -539,6 +548,9 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 					fprintf(stderr, "[mismapper_heavy_kernel] %u reads of %u jobs, %u workgroups, sweep %d: %.1f ms of wavefront time in all, longest read %.2f ms; calls listed %llu, calls reaching into the blocks %llu, seeds %llu, walks %llu; reads by time (us):", n_heavy, n_jobs, workgroups, (int) by_sweep, total / 1e5, longest / 1e5, sums[0], sums[1], sums[2], sums[3]);
 					for (int bucket = 0; bucket < 40; ++bucket) if (histogram[bucket]) fprintf(stderr, " 2^%d:%llu", bucket, histogram[bucket]);
 					fprintf(stderr, "\n[mismapper_heavy_kernel] of the wavefront time: look-ups of the seeds %.1f ms, calls of the blocks collected %.1f ms, seeds %.1f ms\n", ticks[4 * (size_t) n_heavy] / 1e5, ticks[4 * (size_t) n_heavy + 1] / 1e5, ticks[4 * (size_t) n_heavy + 2] / 1e5);
+					{ const unsigned long long* parts = &ticks[4 * (size_t) n_heavy + 4];
+					  fprintf(stderr, "[mismapper_heavy_kernel] of the seeds: bases ahead + to the left %.1f ms, arrivals of the calls %.1f ms, the walk %.1f ms (%.1f); numbering the seeds of a block %.1f ms; rounds of seeds %llu, blocks with calls %llu of %llu\n",
+					          parts[0] / 1e5, parts[1] / 1e5, parts[2] / 1e5, parts[3] / 1e5, parts[4] / 1e5, parts[5], parts[6], parts[7]); }
 					for (uint32_t rank = 0; rank < 24 && rank < n_heavy; ++rank) { // the slowest reads, and every 1/8 quantile below them
 						const uint32_t k = by_time[rank < 16 ? n_heavy - 1 - rank : (size_t) (n_heavy - 1) * (24 - rank) / 9].second;
 						fprintf(stderr, "[mismapper_heavy_kernel]   read %llu (%llu alignments): %.2f ms, calls listed %llu, reaching into blocks %llu, seeds %llu, walks %llu\n", ticks[4 * (size_t) k + 3] >> 8, ticks[4 * (size_t) k + 3] & 255, ticks[4 * (size_t) k] / 1e5,

@@ -104,8 +104,15 @@ AGPU_HD uint64_t load_bases8(const char* p) { uint64_t v; __builtin_memcpy(&v, p
 // every 255 searches was 0.9 TB of writes per 10^8-fragment sample -- 29 M searches / 255 x 8 MB --, most of what the counters saw this kernel write) | gene_pos - gene_start (24) | read_pos (9) | max_deletions (1) |
 // score + 32768 (16): for equal keys the larger word is the higher failed score.
 const uint32_t ALIGN_MEMO_EPOCHS = 0x3FFFu; // the epoch field of a slot: bits 50-63
+// The FRONT of the memo (round 6): a search lists five calls on average (1.46x10^8 calls of 2.9x10^7 searches at 10^8 fragments), and every walk that meets a mismatch asks the memo --
+// two round trips to HBM in a chain of six (profiles/r06c_mismapper_times.txt; the kernel's time goes with the number of wavefronts in flight, profiles/r06e_heavy_ab.txt: it waits).
+// The first keys of a search go into a small table in the memory the lanes share (LDS), the same slot format, the same epochs; a key that finds the ALIGN_MEMO_FRONT_PROBES slots
+// of its probe sequence taken by other keys of the search goes to the table in HBM and says so in *spilled, and only then does a look-up that misses the front go on to HBM.  A slot
+// of the front is never given back inside a search, so a key is in one of the two tables for good.
+const int ALIGN_MEMO_FRONT_PROBES = 8;
 struct AlignMemo {
 	unsigned long long* slots; uint32_t mask; uint32_t epoch; // (no default initialisers: the device keeps one in LDS)
+	unsigned long long* front; uint32_t front_mask; uint32_t* spilled; // null / 0 / null: no front table
 	// (the key holds 24 bits of gene offset and 9 bits of read position: longer genes and reads are searched without the memo)
 	AGPU_HD bool usable(int32_t gene_start, int32_t gene_end, int32_t read_length) const { return slots != nullptr && (int64_t) gene_end - gene_start < (1 << 24) && read_length < 512; }
 	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions) const {
@@ -113,7 +120,25 @@ struct AlignMemo {
 	}
 	AGPU_HD uint32_t slot_of(unsigned long long key) const { unsigned long long h = key * 0x9E3779B97F4A7C15ull; return (uint32_t) (h >> 40) & mask; }
 	// is a call with this key and a score <= the recorded one known to fail?
+	AGPU_HD uint32_t front_slot_of(unsigned long long key) const { unsigned long long h = key * 0x9E3779B97F4A7C15ull; return (uint32_t) (h >> 28) & front_mask; }
 	AGPU_HD bool known_to_fail(unsigned long long key, int32_t score) const {
+		if (front != nullptr) {
+			uint32_t at = front_slot_of(key);
+			for (int probe = 0; probe < ALIGN_MEMO_FRONT_PROBES; ++probe, at = (at + 1) & front_mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+				const unsigned long long slot = __hip_atomic_load(&front[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+				const unsigned long long slot = front[at];
+#endif
+				if ((slot >> 16) == (key >> 16)) return score + 32768 <= (int32_t) (slot & 0xFFFF);
+				if ((slot >> 50) != (key >> 50)) return false; // a free slot in its probe sequence: the key was never recorded (it would have taken this slot or one in front of it)
+			}
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (__hip_atomic_load(spilled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) return false;
+#else
+			if (*spilled == 0) return false;
+#endif
+		}
 		uint32_t at = slot_of(key);
 		for (int probe = 0; probe < 16; ++probe, at = (at + 1) & mask) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -129,6 +154,29 @@ struct AlignMemo {
 	AGPU_HD void record_failure(unsigned long long key, int32_t score) const {
 		if (score < -32768 || score > 32767) return;
 		const unsigned long long word = key | (unsigned long long) (uint32_t) (score + 32768);
+		if (front != nullptr) {
+			uint32_t at = front_slot_of(key);
+			for (int probe = 0; probe < ALIGN_MEMO_FRONT_PROBES; ++probe, at = (at + 1) & front_mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+				const unsigned long long slot = __hip_atomic_load(&front[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if ((slot >> 16) == (key >> 16)) { atomicMax(&front[at], word); return; }
+				if ((slot >> 50) != (key >> 50)) {
+					const unsigned long long seen = atomicCAS(&front[at], slot, word);
+					if (seen == slot) return;
+					if ((seen >> 16) == (key >> 16)) { atomicMax(&front[at], word); return; }
+				}
+#else
+				const unsigned long long slot = front[at];
+				if ((slot >> 16) == (key >> 16)) { if (word > slot) front[at] = word; return; }
+				if ((slot >> 50) != (key >> 50)) { front[at] = word; return; }
+#endif
+			}
+#if defined(__HIP_DEVICE_COMPILE__)
+			__hip_atomic_store(spilled, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+			*spilled = 1;
+#endif
+		}
 		uint32_t at = slot_of(key);
 		for (int probe = 0; probe < 16; ++probe, at = (at + 1) & mask) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -192,18 +240,24 @@ AGPU_HD uint32_t align_iterations(const AlignTask& call, int32_t length, int32_t
 // 10^7 times for a read in a gene of some megabases (profiles/r03c_mismapper_second_pass.txt).
 const uint32_t ALIGN_SWEEP_BLOCK = KMER_LENGTH;     // read positions per block
 const uint32_t ALIGN_SWEEP_SEGMENT = 304;          // align_both_strands leaves segments of 300 bases and more alone
-const uint32_t ALIGN_SWEEP_CALLS = 256;            // calls of a block kept in the memory the lanes share; what is beyond goes to AlignWorklist::relevant_words
+const uint32_t ALIGN_SWEEP_CALLS = 128;            // calls of a block kept in the memory the lanes share; what is beyond goes to AlignWorklist::relevant_words (256 until round 6: the 2 KB are
+                                                   // the front of the memo and the head of the task list now)
+const uint32_t ALIGN_MEMO_FRONT_SLOTS = 128;       // 1 KB: the front of the memo (AlignMemo::front)
+const uint32_t ALIGN_LIST_HEAD_TASKS = 64;         // 1 KB: the head of the task list (AlignWorklist::head)
 struct AlignSweep { // memory the lanes of a runner share (LDS on the device)
 	uint32_t hit_first[ALIGN_SWEEP_SEGMENT], hit_count[ALIGN_SWEEP_SEGMENT]; // per read position: the hits of its 8-mer inside the gene, as a range of the position list
 	uint32_t seed_end[ALIGN_SWEEP_BLOCK];                                     // running sums of the seeds of the read positions of the block
 	int32_t call_score[ALIGN_SWEEP_CALLS], call_read_pos[ALIGN_SWEEP_CALLS], call_gene_pos[ALIGN_SWEEP_CALLS]; uint32_t call_flags[ALIGN_SWEEP_CALLS];
 	uint32_t n_calls, reached;                                                // calls that reach into the block; bit k: read position k of the block is reached by one of them
+	uint32_t max_reach;                                                       // the first read position no listed call reaches (round 6: three blocks of five see no call at all -- the sweep ends there)
 };
 struct AlignWorklist {
 	unsigned long long* words; uint32_t capacity; // two 64-bit words per task
 	uint32_t* state;                              // [0] tasks listed, [1] overflow, [2] found (memory the lanes of the runner share: LDS on the device)
 	AlignSweep* sweep;                            // null: the schedule of round 2 (the lanes take whole calls from the list in rounds)
 	unsigned long long* relevant_words; uint32_t relevant_capacity; // the calls of a block beyond ALIGN_SWEEP_CALLS (two words per call; may be null: such a search is left to the recursion)
+	unsigned long long* head; uint32_t head_capacity; // null / 0, or: the first tasks of the list ALSO in the memory the lanes share (round 6: the calls of every block are collected from the whole
+	                                              // list -- one round trip to HBM per block of 8 read positions, 18 % of the wavefront time of the kernel -- and the list of most searches is short)
 	uint32_t* stats;                              // null, or a study: [0] calls listed, [1] calls that reached into a block (summed over the blocks), [2] seeds, [3] walks, shared by the lanes;
 	                                              // [4..6] ticks of the 100 MHz clock in the look-ups of the seeds / the collection of the calls of the blocks / the seeds (lane 0's view)
 	AGPU_HD void push(const AlignTask& task) const {
@@ -213,18 +267,30 @@ struct AlignWorklist {
 		const uint32_t at = state[0]++;
 #endif
 		if (at >= capacity) { state[1] = 1; return; }
+		if (sweep != nullptr) {
+			const uint32_t reach = (uint32_t) task.read_pos + (task.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicMax(&sweep->max_reach, reach);
+#else
+			if (reach > sweep->max_reach) sweep->max_reach = reach;
+#endif
+		}
 		const unsigned long long first = (unsigned long long) (uint32_t) task.score | (unsigned long long) (uint32_t) task.read_pos << 32, second = (unsigned long long) (uint32_t) task.gene_pos | (unsigned long long) task.flags << 32;
 #if defined(__HIP_DEVICE_COMPILE__)
 		__hip_atomic_store(&words[2 * (size_t) at], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&words[2 * (size_t) at + 1], second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (at < head_capacity) { __hip_atomic_store(&head[2 * (size_t) at], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&head[2 * (size_t) at + 1], second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #else
 		words[2 * (size_t) at] = first; words[2 * (size_t) at + 1] = second;
+		if (at < head_capacity) { head[2 * (size_t) at] = first; head[2 * (size_t) at + 1] = second; }
 #endif
 	}
 	AGPU_HD AlignTask task(uint32_t at) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-		const unsigned long long first = __hip_atomic_load(&words[2 * (size_t) at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), second = __hip_atomic_load(&words[2 * (size_t) at + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		unsigned long long first, second;
+		if (at < head_capacity) { first = __hip_atomic_load(&head[2 * (size_t) at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); second = __hip_atomic_load(&head[2 * (size_t) at + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+		else { first = __hip_atomic_load(&words[2 * (size_t) at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); second = __hip_atomic_load(&words[2 * (size_t) at + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
-		const unsigned long long first = words[2 * (size_t) at], second = words[2 * (size_t) at + 1];
+		const unsigned long long first = at < head_capacity ? head[2 * (size_t) at] : words[2 * (size_t) at], second = at < head_capacity ? head[2 * (size_t) at + 1] : words[2 * (size_t) at + 1];
 #endif
 		AlignTask result = { (int32_t) (uint32_t) first, (int32_t) (uint32_t) (first >> 32), (int32_t) (uint32_t) second, (uint32_t) (second >> 32) };
 		return result;
@@ -441,65 +507,86 @@ AGPU_HD int32_t align_left_matches(const LeftProfile& profile, int32_t i) {
 // The extension to the right of a seed, to its end: the rest of the body of the hit loop of the reference's align() (source/filter_mismappers.cpp:139-183) with the nested calls LISTED
 // instead of made (the search goes on as if they had failed: the result of align() is an OR over everything that gets searched, see AlignWorklist).  No stack, no state machine:
 // what ALIGN_RIGHT_LOOP .. ALIGN_ADVANCE of align_search do for one hit.  extended_score = the score behind the extension to the left.
-AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int32_t min_score, int32_t extended_score, int32_t read_pos, int32_t kmer_hit, int32_t max_deletions, const AlignMemo& memo, const AlignWorklist& worklist) {
+// What a walk needs first, asked for BEFORE the extension to the left is looked at (round 6): the eight gene bases behind the seed and whether a splice site is in reach of the walk.
+// The walk of a seed waits for a chain of loads -- position list, gene bases to the left, splice bits, gene bases to the right, memo --; these two do not depend on the ones in
+// front of them, and asked for together with the bases to the left they cost one round trip instead of three.  (The genome is padded by 16 bytes behind its last base.)
+struct SeedAhead { uint64_t right_window; bool splice_site_in_reach; };
+AGPU_HD SeedAhead align_seed_ahead(const Segment& read, const AlignTarget& target, int32_t read_pos, int32_t kmer_hit) {
+	SeedAhead ahead;
+	const int32_t extended_read_pos = read_pos + KMER_LENGTH, extended_gene_pos = kmer_hit + KMER_LENGTH;
+	ahead.right_window = load_bases8(target.contig_bases + extended_gene_pos);
+	ahead.splice_site_in_reach = target.splice_bits == nullptr || any_bit_in_range(target.splice_bits, target.splice_bit_base + (uint64_t) (extended_gene_pos - 1), target.splice_bit_base + (uint64_t) (extended_gene_pos - 1) + (uint64_t) ((int32_t) read.length - extended_read_pos));
+	return ahead;
+}
+// A nested call of a walk, listed unless the memo knows one with at least its score (see AlignWorklist).
+AGPU_HD void align_list_call(const AlignTarget& target, int32_t length, int32_t min_score, int32_t score, int32_t read_pos, int32_t gene_pos, int32_t call_max_deletions, const AlignMemo& memo, const AlignWorklist& worklist) {
+	AlignTask nested = { score, read_pos, gene_pos, call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u };
+	const uint32_t iterations = align_iterations(nested, length, min_score);
+	if (iterations == 0) return; // (a call whose loop does not run returns false at once)
+	const unsigned long long key = memo.key_of(read_pos, gene_pos - target.gene_start, call_max_deletions);
+	if (memo.known_to_fail(key, score)) { ALIGN_STAT(pruned, 1); return; } // listed before with at least this score
+	memo.record_failure(key, score);
+	nested.flags |= iterations << ALIGN_TASK_ITERATIONS_SHIFT;
+	worklist.push(nested);
+	ALIGN_STAT(calls, 1);
+}
+// The walk(s) of a seed to the right in ONE pass (round 6).  A seed is walked with the best arrival that may still delete (max_deletions 1: `score_with`) and, if an arrival that
+// may not is better, with that one as well (`score_without`); ALIGN_NO_ARRIVAL = no such walk.  The two walks compare the same bases, so their scores differ by a constant all the
+// way and they end at the same base: one pass with the higher score in the lead lists what both would list -- behind a splice site a call of each, after the first mismatch the
+// re-seed of the walk that may still delete (source/filter_mismappers.cpp:147-171) -- and succeeds when the lead reaches min_score (the other one cannot be first).
+// THE BOUND: a base of the read adds at most 1 to a score -- a match of a walk; a base a call skips and its seed then finds matching to the left costs 1 and gives 2 back; the eight of
+// a seed give 8 -- so from (score, read position) nothing above score + (length - read position) is ever reached, by the walk or by anything it lists.  A walk whose lead has fallen
+// below min_score - (bases left) is over, and a walker in that state lists nothing.  The reference walks on and lists calls that its own loop bound (:92, looser by 2 k) lets run for
+// up to eight iterations of seeds without a chance: 43 % of the steps of the walks of tests/golden's stress sample.  Only failures are left out: the verdict is an OR over successes.
+const int32_t ALIGN_NO_ARRIVAL = -0x40000000;
+AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int32_t min_score, int32_t score_with, int32_t score_without, int32_t read_pos, int32_t kmer_hit, const AlignMemo& memo, const AlignWorklist& worklist, const SeedAhead* ahead = nullptr) {
 	const int32_t length = (int32_t) read.length;
+	const bool with = score_with != ALIGN_NO_ARRIVAL, without = score_without != ALIGN_NO_ARRIVAL;
 	ALIGN_STAT(hits, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (worklist.stats != nullptr) atomicAdd(&worklist.stats[3], 1u);
+	if (worklist.stats != nullptr) atomicAdd(&worklist.stats[3], (with ? 1u : 0u) + (without ? 1u : 0u));
 #endif
-	if (extended_score >= min_score) return true;
+	int32_t lead = without ? score_without : score_with;     // (the caller passes score_without only if it is the higher one)
+	const int32_t behind = with && without ? score_without - score_with : 0; // the walk that may delete: lead - behind
+	if (lead >= min_score) return true;
 	int32_t extended_read_pos = read_pos + KMER_LENGTH, extended_gene_pos = kmer_hit + KMER_LENGTH;
 	uint32_t mismatch_count = 0, consecutive_mismatches = 0;
 	// the first splice site at or behind extended_gene_pos - 1 -- if the walk can reach one at all: it compares positions extended_gene_pos - 1 ... + (length - extended_read_pos)
 	uint32_t splice_cursor = target.n_splice_sites; int32_t next_site = 0x7FFFFFFF;
-	if (target.splice_bits == nullptr || any_bit_in_range(target.splice_bits, target.splice_bit_base + (uint64_t) (extended_gene_pos - 1), target.splice_bit_base + (uint64_t) (extended_gene_pos - 1) + (uint64_t) (length - extended_read_pos))) {
+	if (ahead != nullptr ? ahead->splice_site_in_reach : (target.splice_bits == nullptr || any_bit_in_range(target.splice_bits, target.splice_bit_base + (uint64_t) (extended_gene_pos - 1), target.splice_bit_base + (uint64_t) (extended_gene_pos - 1) + (uint64_t) (length - extended_read_pos)))) {
 		splice_cursor = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, extended_gene_pos - 1);
 		next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF;
 	}
 	uint64_t window = 0; int32_t window_at = 0, window_end = 0;                // genome bases [window_at, window_end) of the contig
+	if (ahead != nullptr) { window = ahead->right_window; window_at = extended_gene_pos; window_end = window_at + 8; }
 	uint64_t read_window = 0; int32_t read_window_at = 0, read_window_end = 0; // bases [read_window_at, read_window_end) of the read
 	ALIGN_SEED_STEP();
 	while (extended_read_pos < length && extended_gene_pos <= target.gene_end) {
+		const int32_t short_of = min_score - (length - extended_read_pos); // a score below this one cannot reach min_score any more
+		if (lead < short_of) return false;
 		ALIGN_STAT(bases, 1); ALIGN_SEED_STEP();
-		int32_t call_max_deletions = -1; // >= 0: a nested align(extended_score, extended_read_pos, extended_gene_pos, call_max_deletions) is due
 		if (next_site < extended_gene_pos - 1) {
 			while (splice_cursor < target.n_splice_sites && target.splice_sites[splice_cursor] < extended_gene_pos - 1) ++splice_cursor;
 			next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF;
 		}
-		for (int stage = 0; stage < 2; ++stage) { // 0: behind a splice site (before the base is compared), 1: after the first mismatch (before it is counted against the score)
-			if (stage == 0) { if (next_site == extended_gene_pos - 1) call_max_deletions = max_deletions; }
-			else {
-				if (extended_gene_pos >= window_end || extended_gene_pos < window_at) { window_at = extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
-				if (extended_read_pos >= read_window_end || extended_read_pos < read_window_at) { read_window_at = extended_read_pos; read_window_end = read_window_at + 8; read_window = read.chars8((uint32_t) read_window_at); }
-				if ((char) (read_window >> (8 * (extended_read_pos - read_window_at))) == (char) (window >> (8 * (extended_gene_pos - window_at)))) {
-					extended_score++;
-					if (extended_score >= min_score) return true;
-					consecutive_mismatches = 0;
-					break;
-				}
-				mismatch_count++;
-				if (mismatch_count == 1 && max_deletions > 0 && length >= 30) call_max_deletions = max_deletions - 1; // re-seed once after the first mismatch (deletion / intron)
-			}
-			if (call_max_deletions >= 0) {
-				AlignTask nested = { extended_score, extended_read_pos, extended_gene_pos, call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u };
-				const uint32_t iterations = align_iterations(nested, length, min_score);
-				if (iterations > 0) { // (a call whose loop does not run returns false at once)
-					const unsigned long long key = memo.key_of(extended_read_pos, extended_gene_pos - target.gene_start, call_max_deletions);
-					if (!memo.known_to_fail(key, extended_score)) { // not listed before with at least this score
-						memo.record_failure(key, extended_score);
-						nested.flags |= iterations << ALIGN_TASK_ITERATIONS_SHIFT;
-						worklist.push(nested);
-						ALIGN_STAT(calls, 1);
-					} else ALIGN_STAT(pruned, 1);
-				}
-				call_max_deletions = -1;
-			}
-			if (stage == 1) { // the mismatch counts
-				extended_score--;
-				consecutive_mismatches++;
-			}
+		if (next_site == extended_gene_pos - 1) { // behind a splice site, before the base is compared: a call of every walk, with its max_deletions
+			if (with && lead - behind >= short_of) align_list_call(target, length, min_score, lead - behind, extended_read_pos, extended_gene_pos, 1, memo, worklist);
+			if (without) align_list_call(target, length, min_score, lead, extended_read_pos, extended_gene_pos, 0, memo, worklist);
 		}
-		if (consecutive_mismatches >= 4) return false; // on to the next seed
+		if (extended_gene_pos >= window_end || extended_gene_pos < window_at) { window_at = extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
+		if (extended_read_pos >= read_window_end || extended_read_pos < read_window_at) { read_window_at = extended_read_pos; read_window_end = read_window_at + 8; read_window = read.chars8((uint32_t) read_window_at); }
+		if ((char) (read_window >> (8 * (extended_read_pos - read_window_at))) == (char) (window >> (8 * (extended_gene_pos - window_at)))) {
+			lead++;
+			if (lead >= min_score) return true;
+			consecutive_mismatches = 0;
+		} else {
+			mismatch_count++;
+			// the walk that may delete re-seeds once, after its first mismatch and before it is counted against the score (deletion / intron)
+			if (mismatch_count == 1 && with && length >= 30 && lead - behind >= short_of) align_list_call(target, length, min_score, lead - behind, extended_read_pos, extended_gene_pos, 0, memo, worklist);
+			lead--;
+			consecutive_mismatches++;
+			if (consecutive_mismatches >= 4) return false; // on to the next seed
+		}
 		extended_read_pos++; extended_gene_pos++;
 	}
 	return false;
@@ -550,7 +637,9 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 		sync_lanes();
 		const uint32_t next = (memo->epoch + 1) & ALIGN_MEMO_EPOCHS; // (every lane reads the same value)
 		if (next == 0) for (uint32_t k = lane; k <= memo->mask; k += lanes) memo->slots[k] = 0; // the epoch numbers wrap around: start clean (epoch 0 = empty slots)
+		if (next == 0 && memo->front != nullptr) for (uint32_t k = lane; k <= memo->front_mask; k += lanes) memo->front[k] = 0;
 		sync_lanes();
+		if (lane == 0 && memo->front != nullptr) *memo->spilled = 0;
 		if (lane == 0) memo->epoch = next == 0 ? 1 : next;
 		sync_lanes();
 	}
@@ -641,7 +730,16 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	}
 	// one seed of the block: the best arrival of the calls that reach it, walked to the right
 	AGPU_HD bool sweep_seed(const AlignSweep& sweep, const Segment& read, const AlignTarget& target, int32_t min_score, int32_t read_pos, int32_t kmer_hit) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+		const bool timed = worklist->stats != nullptr && lane == 0; // (the study of ARRIBA_MISMAPPER_TIMES: lane 0 has a seed in every round, and the lanes of a wavefront meet again behind every part)
+		unsigned long long tick = timed ? wall_clock64() : 0ull;
+#define SEED_LAP(slot) do { if (timed) { const unsigned long long now_ = wall_clock64(); worklist->stats[slot] += (uint32_t) (now_ - tick); tick = now_; } } while (0)
+#else
+#define SEED_LAP(slot) ((void) 0)
+#endif
+		const SeedAhead ahead = align_seed_ahead(read, target, read_pos, kmer_hit);
 		const LeftProfile profile = align_left_profile(read, target, read_pos, kmer_hit);
+		SEED_LAP(8);
 		const int32_t NONE = -0x40000000;
 		int32_t best[2] = { NONE, NONE }; // by max_deletions
 		const uint32_t n_calls = sweep.n_calls;
@@ -655,9 +753,13 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 			const int deletions = (call.flags & ALIGN_TASK_DELETIONS) ? 1 : 0;
 			if (extended_score > best[deletions]) best[deletions] = extended_score;
 		}
-		if (best[1] != NONE && align_walk_seed(read, target, min_score, best[1], read_pos, kmer_hit, 1, *memo, *worklist)) return true;
-		if (best[0] != NONE && best[0] > best[1] && align_walk_seed(read, target, min_score, best[0], read_pos, kmer_hit, 0, *memo, *worklist)) return true; // (with at most the score of a walk that may list more: nothing new)
-		return false;
+		SEED_LAP(9);
+		// (an arrival that may not delete with at most the score of one that may lists nothing new; one that cannot reach min_score over the bases behind the seed walks nowhere: align_walk_seed)
+		const int32_t short_of = min_score - ((int32_t) read.length - read_pos - (int32_t) KMER_LENGTH);
+		const int32_t score_with = best[1] != NONE && best[1] >= short_of ? best[1] : ALIGN_NO_ARRIVAL, score_without = best[0] != NONE && best[0] > best[1] && best[0] >= short_of ? best[0] : ALIGN_NO_ARRIVAL;
+		const bool found = (score_with != ALIGN_NO_ARRIVAL || score_without != ALIGN_NO_ARRIVAL) && align_walk_seed(read, target, min_score, score_with, score_without, read_pos, kmer_hit, *memo, *worklist, &ahead);
+		SEED_LAP(10);
+		return found;
 	}
 	// returns whether the segment aligns; worklist->state[1] != 0 afterwards: a list was too short, the answer is not known (left to the recursion)
 	AGPU_HD bool align_by_sweep(const Segment& read, const AlignTarget& target, int32_t min_score) const {
@@ -670,7 +772,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 #endif
 		sync_lanes();
 		if (lane == 0) {
-			worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0;
+			worklist->state[0] = 0; worklist->state[1] = 0; worklist->state[2] = 0; sweep.max_reach = 0;
 			AlignTask outermost = { 0, 0, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
 			outermost.flags |= align_iterations(outermost, length, min_score) << ALIGN_TASK_ITERATIONS_SHIFT;
 			worklist->push(outermost);
@@ -702,9 +804,14 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 			sync_lanes();
 			if (worklist->state[1] != 0) return false; // the list of the calls ran over
 			const uint32_t listed = worklist->state[0] < worklist->capacity ? worklist->state[0] : worklist->capacity;
+			const bool beyond_every_call = (uint32_t) block >= sweep.max_reach; // (a call is listed by a seed at least eight read positions in front of its first one: the calls of this block and all behind it are known)
 			sync_lanes(); // (nobody lists a call before everybody has read how many there are)
+			if (beyond_every_call) break;
 			if (!sweep_collect_calls(sweep, block, listed, width)) { if (lane == 0) worklist->state[1] = 1; sync_lanes(); return false; }
 			SWEEP_LAP(5);
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (worklist->stats != nullptr && lane == 0) worklist->stats[15] += 1;
+#endif
 			if (sweep.n_calls == 0) continue;
 			sync_lanes();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -717,7 +824,8 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 			sync_lanes();
 			const uint32_t seeds = sweep.seed_end[ALIGN_SWEEP_BLOCK - 1];
 #if defined(__HIP_DEVICE_COMPILE__)
-			if (worklist->stats != nullptr && lane == 0) worklist->stats[2] += seeds;
+			if (worklist->stats != nullptr && lane == 0) { worklist->stats[2] += seeds; worklist->stats[13] += (seeds + width - 1) / width; worklist->stats[14] += 1; }
+			SWEEP_LAP(12);
 #endif
 			for (uint32_t seed_base = 0; seed_base < seeds; seed_base += width) {
 #if !defined(__HIP_DEVICE_COMPILE__)
