@@ -191,8 +191,8 @@ const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch boun
 // SWEEP_ONLY: the searches go through the sweep or are given up -- no recursion, no stack of frames in the kernel; the reads of the searches given up are appended to `leftover`
 // (counters[5]) and done by the instantiation that holds everything.  queue: the index of the queue's counter (the second launch has a queue of its own).
 template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
-                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters, uint32_t* leftover, int queue, bool lds_front) {
-	__shared__ uint8_t segment_bases[304];
+                                                             unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters, uint32_t* leftover, int queue, bool lds_front, bool strands_together) {
+	__shared__ uint8_t segment_bases[2 * 304]; // (the segment being searched and its reverse complement)
 	__shared__ AlignSweep sweep;
 	__shared__ AlignMemo memo;
 	__shared__ AlignWorklist worklist;
@@ -219,7 +219,7 @@ template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__
 	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position (when the task list is off or overflows)
 	runner.memo = &memo;
 	runner.worklist = task_lists != nullptr ? &worklist : nullptr; // the search as rounds of up to 64 tasks (mismapper_core.hpp: AlignWorklist)
-	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304;
+	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304; runner.cache2 = segment_bases + 304; runner.strands_together = strands_together;
 	while (true) {
 		__syncthreads(); // (every lane has read next_job of the previous round)
 		if (threadIdx.x == 0) { next_job = atomicAdd(&counters[queue], 1u); given_up = 0; }
@@ -504,6 +504,8 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				const bool sweep_kernel_first = by_sweep && use_worklist && !(knob != nullptr && strcmp(knob, "one") == 0); // (the study of ARRIBA_MISMAPPER_TIMES looks at the first kernel when there are two)
 				knob = getenv("ARRIBA_MEMO_FRONT"); // "0": every key of the memo and every listed call in HBM only, as until round 6 (for A/B measurements)
 				const bool lds_front = !(knob != nullptr && knob[0] == '0');
+				knob = getenv("ARRIBA_STRANDS_TOGETHER"); // "0": the two strands of a segment one after the other, as until round 6 (for A/B measurements)
+				const bool strands_together = !(knob != nullptr && knob[0] == '0');
 				const bool four_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr && atoi(getenv("ARRIBA_HEAVY_WAVES")) == 4;
 				DeviceBuffer& leftover = ctx->scratch("mismappers.leftover");
 				ALLOC(leftover, (size_t) n_heavy * 4);
@@ -513,11 +515,11 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 					{ KernelTimer timer(ctx, "mismapper_heavy_kernel", (uint64_t) n_heavy * 300);
 					  const int heavy_waves = getenv("ARRIBA_HEAVY_WAVES") != nullptr ? atoi(getenv("ARRIBA_HEAVY_WAVES")) : 5; // (6 with ARRIBA_HEAVY_WORKGROUPS=6144: 80 VGPRs, 177 spilled -- for measurements; launch bounds of 8 are not honoured: 122 VGPRs, four wavefronts)
 					  if (heavy_waves == 6) mismapper_heavy_kernel<6, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
-					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front);
+					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front, strands_together);
 					  else if (!four_waves) mismapper_heavy_kernel<5, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
-					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front);
+					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front, strands_together);
 					  else mismapper_heavy_kernel<4, true><<<workgroups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, heavy.as<uint32_t>(), n_heavy, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, task_lists.as<unsigned long long>(), task_capacity,
-					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front); }
+					                                                true, want_times ? read_times.as<unsigned long long>() : nullptr, device_counters, leftover.as<uint32_t>(), 4, lds_front, strands_together); }
 					HIP_CHECK(hipMemcpyAsync(&n_todo, device_counters + 5, 4, hipMemcpyDeviceToHost, s));
 					HIP_CHECK(hipStreamSynchronize(s));
 					todo = leftover.as<uint32_t>();
@@ -528,9 +530,9 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 					if (sweep_kernel_first) HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) groups * memo_slots * 8, s)); // (the epochs of the memo start again: nothing of the first kernel's searches may match)
 					KernelTimer timer(ctx, sweep_kernel_first ? "mismapper_heavy_kernel(searches the sweep gave up)" : "mismapper_heavy_kernel", (uint64_t) n_todo * 300);
 					if (!four_waves) mismapper_heavy_kernel<5, false><<<groups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, todo, n_todo, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
-					                                                by_sweep, want_times && !sweep_kernel_first ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4, lds_front);
+					                                                by_sweep, want_times && !sweep_kernel_first ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4, lds_front, strands_together);
 					else mismapper_heavy_kernel<4, false><<<groups, 64, 0, s>>>(ctx->batch, ctx->annotation, ctx->genome, kmers, splice, todo, n_todo, max_mate_gap, memo_tables.as<unsigned long long>(), memo_slots, use_worklist ? task_lists.as<unsigned long long>() : nullptr, task_capacity,
-					                                                by_sweep, want_times && !sweep_kernel_first ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4, lds_front);
+					                                                by_sweep, want_times && !sweep_kernel_first ? read_times.as<unsigned long long>() : nullptr, device_counters, nullptr, sweep_kernel_first ? 6 : 4, lds_front, strands_together);
 				}
 				if (want_times) {
 					std::vector<unsigned long long> ticks(4 * (size_t) n_heavy + 12);

@@ -115,8 +115,8 @@ struct AlignMemo {
 	unsigned long long* front; uint32_t front_mask; uint32_t* spilled; // null / 0 / null: no front table
 	// (the key holds 24 bits of gene offset and 9 bits of read position: longer genes and reads are searched without the memo)
 	AGPU_HD bool usable(int32_t gene_start, int32_t gene_end, int32_t read_length) const { return slots != nullptr && (int64_t) gene_end - gene_start < (1 << 24) && read_length < 512; }
-	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions) const {
-		return ((unsigned long long) (epoch & ALIGN_MEMO_EPOCHS) << 34 | (unsigned long long) (uint32_t) gene_offset << 10 | (unsigned long long) (uint32_t) read_pos << 1 | (unsigned long long) (max_deletions > 0)) << 16;
+	AGPU_HD unsigned long long key_of(int32_t read_pos, int32_t gene_offset, int32_t max_deletions, uint32_t strand = 0) const { // (the epochs of the searches are even: the odd one behind belongs to the reverse strand of a sweep over both)
+		return ((unsigned long long) ((epoch + strand) & ALIGN_MEMO_EPOCHS) << 34 | (unsigned long long) (uint32_t) gene_offset << 10 | (unsigned long long) (uint32_t) read_pos << 1 | (unsigned long long) (max_deletions > 0)) << 16;
 	}
 	AGPU_HD uint32_t slot_of(unsigned long long key) const { unsigned long long h = key * 0x9E3779B97F4A7C15ull; return (uint32_t) (h >> 40) & mask; }
 	// is a call with this key and a score <= the recorded one known to fail?
@@ -221,7 +221,7 @@ const int ALIGN_SHALLOW_DEPTH = 16;       // ... of <= 128 bases: the stack of t
 // search is done by the recursion.
 // What the list holds are CALLS of align(): (score, read position, gene position) at the entry of the call, ALIGN_TASK_DELETIONS = max_deletions > 0, ALIGN_TASK_ROOT = the outermost
 // call (its skipped bases are leading ones and cost nothing); from bit ALIGN_TASK_ITERATIONS_SHIFT on: the number of iterations of its read-position loop (align_by_sweep).
-enum { ALIGN_TASK_DELETIONS = 1, ALIGN_TASK_ROOT = 2, ALIGN_TASK_ITERATIONS_SHIFT = 8 };
+enum { ALIGN_TASK_DELETIONS = 1, ALIGN_TASK_ROOT = 2, ALIGN_TASK_STRAND = 4 /* a sweep over both strands of a segment: the call belongs to the search of the reverse complement */, ALIGN_TASK_ITERATIONS_SHIFT = 8 };
 struct AlignTask { int32_t score, read_pos, gene_pos; uint32_t flags; };
 // iterations of the read-position loop of a call: for (i = 0; read_pos + i + k < length && read_pos + i + min_score <= length + (score - i) + 2 k; ++i)
 AGPU_HD uint32_t align_iterations(const AlignTask& call, int32_t length, int32_t min_score) {
@@ -239,16 +239,18 @@ AGPU_HD uint32_t align_iterations(const AlignTask& call, int32_t length, int32_t
 // the best arrival without deletions beats the best one with), where the recursion of the reference -- and the task list of round 2 -- walks it once per call that reaches it:
 // 10^7 times for a read in a gene of some megabases (profiles/r03c_mismapper_second_pass.txt).
 const uint32_t ALIGN_SWEEP_BLOCK = KMER_LENGTH;     // read positions per block
+const uint32_t ALIGN_SWEEP_LOOKUPS = 64;           // read positions whose seeds are looked up at a time (a multiple of the block)
 const uint32_t ALIGN_SWEEP_SEGMENT = 304;          // align_both_strands leaves segments of 300 bases and more alone
 const uint32_t ALIGN_SWEEP_CALLS = 128;            // calls of a block kept in the memory the lanes share; what is beyond goes to AlignWorklist::relevant_words (256 until round 6: the 2 KB are
                                                    // the front of the memo and the head of the task list now)
 const uint32_t ALIGN_MEMO_FRONT_SLOTS = 128;       // 1 KB: the front of the memo (AlignMemo::front)
 const uint32_t ALIGN_LIST_HEAD_TASKS = 64;         // 1 KB: the head of the task list (AlignWorklist::head)
 struct AlignSweep { // memory the lanes of a runner share (LDS on the device)
-	uint32_t hit_first[ALIGN_SWEEP_SEGMENT], hit_count[ALIGN_SWEEP_SEGMENT]; // per read position: the hits of its 8-mer inside the gene, as a range of the position list
-	uint32_t seed_end[ALIGN_SWEEP_BLOCK];                                     // running sums of the seeds of the read positions of the block
+	uint32_t hit_first[2 * ALIGN_SWEEP_LOOKUPS], hit_count[2 * ALIGN_SWEEP_LOOKUPS]; // [strand][read position - first one of the look-ups]: the hits of its 8-mer inside the gene, as a range of the position list
+	uint32_t seed_end[2 * ALIGN_SWEEP_BLOCK];                                 // running sums of the seeds of the read positions of the block, strand by strand
 	int32_t call_score[ALIGN_SWEEP_CALLS], call_read_pos[ALIGN_SWEEP_CALLS], call_gene_pos[ALIGN_SWEEP_CALLS]; uint32_t call_flags[ALIGN_SWEEP_CALLS];
-	uint32_t n_calls, reached;                                                // calls that reach into the block; bit k: read position k of the block is reached by one of them
+	uint32_t n_calls, reached;                                                // calls that reach into the block; bit 8 * strand + k: read position k of the block is reached by one of them
+	uint32_t n_calls_forward;                                                 // the calls of the forward strand are the first of them (a seed looks at the calls of its strand only)
 	uint32_t max_reach;                                                       // the first read position no listed call reaches (round 6: three blocks of five see no call at all -- the sweep ends there)
 };
 struct AlignWorklist {
@@ -519,11 +521,11 @@ AGPU_HD SeedAhead align_seed_ahead(const Segment& read, const AlignTarget& targe
 	return ahead;
 }
 // A nested call of a walk, listed unless the memo knows one with at least its score (see AlignWorklist).
-AGPU_HD void align_list_call(const AlignTarget& target, int32_t length, int32_t min_score, int32_t score, int32_t read_pos, int32_t gene_pos, int32_t call_max_deletions, const AlignMemo& memo, const AlignWorklist& worklist) {
-	AlignTask nested = { score, read_pos, gene_pos, call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u };
+AGPU_HD void align_list_call(const AlignTarget& target, int32_t length, int32_t min_score, int32_t score, int32_t read_pos, int32_t gene_pos, int32_t call_max_deletions, const AlignMemo& memo, const AlignWorklist& worklist, uint32_t strand) {
+	AlignTask nested = { score, read_pos, gene_pos, (call_max_deletions > 0 ? (uint32_t) ALIGN_TASK_DELETIONS : 0u) | (strand != 0 ? (uint32_t) ALIGN_TASK_STRAND : 0u) };
 	const uint32_t iterations = align_iterations(nested, length, min_score);
 	if (iterations == 0) return; // (a call whose loop does not run returns false at once)
-	const unsigned long long key = memo.key_of(read_pos, gene_pos - target.gene_start, call_max_deletions);
+	const unsigned long long key = memo.key_of(read_pos, gene_pos - target.gene_start, call_max_deletions, strand);
 	if (memo.known_to_fail(key, score)) { ALIGN_STAT(pruned, 1); return; } // listed before with at least this score
 	memo.record_failure(key, score);
 	nested.flags |= iterations << ALIGN_TASK_ITERATIONS_SHIFT;
@@ -539,7 +541,7 @@ AGPU_HD void align_list_call(const AlignTarget& target, int32_t length, int32_t 
 // below min_score - (bases left) is over, and a walker in that state lists nothing.  The reference walks on and lists calls that its own loop bound (:92, looser by 2 k) lets run for
 // up to eight iterations of seeds without a chance: 43 % of the steps of the walks of tests/golden's stress sample.  Only failures are left out: the verdict is an OR over successes.
 const int32_t ALIGN_NO_ARRIVAL = -0x40000000;
-AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int32_t min_score, int32_t score_with, int32_t score_without, int32_t read_pos, int32_t kmer_hit, const AlignMemo& memo, const AlignWorklist& worklist, const SeedAhead* ahead = nullptr) {
+AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int32_t min_score, int32_t score_with, int32_t score_without, int32_t read_pos, int32_t kmer_hit, const AlignMemo& memo, const AlignWorklist& worklist, const SeedAhead* ahead = nullptr, uint32_t strand = 0) {
 	const int32_t length = (int32_t) read.length;
 	const bool with = score_with != ALIGN_NO_ARRIVAL, without = score_without != ALIGN_NO_ARRIVAL;
 	ALIGN_STAT(hits, 1);
@@ -561,17 +563,20 @@ AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int
 	if (ahead != nullptr) { window = ahead->right_window; window_at = extended_gene_pos; window_end = window_at + 8; }
 	uint64_t read_window = 0; int32_t read_window_at = 0, read_window_end = 0; // bases [read_window_at, read_window_end) of the read
 	ALIGN_SEED_STEP();
+	// The re-seed after the first mismatch is LISTED BEHIND THE LOOP: nearly every walk has one, each lane of a wavefront at a base of its own, and listing it where it arises made
+	// the wavefront run through the listing (memo, list: ~150 instructions) once per distinct base instead of once.  (A walk that succeeds lists nothing: the search is over.)
+	bool reseed = false; int32_t reseed_score = 0, reseed_read_pos = 0, reseed_gene_pos = 0;
 	while (extended_read_pos < length && extended_gene_pos <= target.gene_end) {
 		const int32_t short_of = min_score - (length - extended_read_pos); // a score below this one cannot reach min_score any more
-		if (lead < short_of) return false;
+		if (lead < short_of) break;
 		ALIGN_STAT(bases, 1); ALIGN_SEED_STEP();
 		if (next_site < extended_gene_pos - 1) {
 			while (splice_cursor < target.n_splice_sites && target.splice_sites[splice_cursor] < extended_gene_pos - 1) ++splice_cursor;
 			next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF;
 		}
 		if (next_site == extended_gene_pos - 1) { // behind a splice site, before the base is compared: a call of every walk, with its max_deletions
-			if (with && lead - behind >= short_of) align_list_call(target, length, min_score, lead - behind, extended_read_pos, extended_gene_pos, 1, memo, worklist);
-			if (without) align_list_call(target, length, min_score, lead, extended_read_pos, extended_gene_pos, 0, memo, worklist);
+			if (with && lead - behind >= short_of) align_list_call(target, length, min_score, lead - behind, extended_read_pos, extended_gene_pos, 1, memo, worklist, strand);
+			if (without) align_list_call(target, length, min_score, lead, extended_read_pos, extended_gene_pos, 0, memo, worklist, strand);
 		}
 		if (extended_gene_pos >= window_end || extended_gene_pos < window_at) { window_at = extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
 		if (extended_read_pos >= read_window_end || extended_read_pos < read_window_at) { read_window_at = extended_read_pos; read_window_end = read_window_at + 8; read_window = read.chars8((uint32_t) read_window_at); }
@@ -582,13 +587,14 @@ AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int
 		} else {
 			mismatch_count++;
 			// the walk that may delete re-seeds once, after its first mismatch and before it is counted against the score (deletion / intron)
-			if (mismatch_count == 1 && with && length >= 30 && lead - behind >= short_of) align_list_call(target, length, min_score, lead - behind, extended_read_pos, extended_gene_pos, 0, memo, worklist);
+			if (mismatch_count == 1 && with && length >= 30 && lead - behind >= short_of) { reseed = true; reseed_score = lead - behind; reseed_read_pos = extended_read_pos; reseed_gene_pos = extended_gene_pos; }
 			lead--;
 			consecutive_mismatches++;
-			if (consecutive_mismatches >= 4) return false; // on to the next seed
+			if (consecutive_mismatches >= 4) break; // on to the next seed
 		}
 		extended_read_pos++; extended_gene_pos++;
 	}
+	if (reseed) align_list_call(target, length, min_score, reseed_score, reseed_read_pos, reseed_gene_pos, 0, memo, worklist, strand);
 	return false;
 }
 
@@ -606,6 +612,8 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	int64_t* budget = nullptr; // steps left for the whole verdict of one read (null: unlimited)
 	int max_depth = ALIGN_MAX_DEPTH; // frames `stack` holds
 	uint8_t* cache = nullptr; uint32_t cache_stride = 1, cache_capacity = 0; // room for a copy of the segment being searched (LDS on the device), shared by the lanes of the runner
+	uint8_t* cache2 = nullptr;                                               // ... and for its reverse complement (same stride and capacity): a sweep over both strands (align_strands)
+	bool strands_together = true;                                            // (false: strand by strand as until round 6, for A/B measurements)
 	AGPU_HD bool exhausted() const { return budget != nullptr && *budget < 0; }
 	// the base characters of the segment, strand applied, where the search finds them fast
 	AGPU_HD Segment prepared(const Segment& segment) const {
@@ -635,12 +643,12 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	}
 	AGPU_HD void new_memo_epoch() const {
 		sync_lanes();
-		const uint32_t next = (memo->epoch + 1) & ALIGN_MEMO_EPOCHS; // (every lane reads the same value)
+		const uint32_t next = (memo->epoch + 2) & ALIGN_MEMO_EPOCHS; // (every lane reads the same value)
 		if (next == 0) for (uint32_t k = lane; k <= memo->mask; k += lanes) memo->slots[k] = 0; // the epoch numbers wrap around: start clean (epoch 0 = empty slots)
 		if (next == 0 && memo->front != nullptr) for (uint32_t k = lane; k <= memo->front_mask; k += lanes) memo->front[k] = 0;
 		sync_lanes();
 		if (lane == 0 && memo->front != nullptr) *memo->spilled = 0;
-		if (lane == 0) memo->epoch = next == 0 ? 1 : next;
+		if (lane == 0) memo->epoch = next == 0 ? 2 : next;
 		sync_lanes();
 	}
 	// reference: align(0, read, 0, contig, gene_start, gene_start, gene_end, ...) (source/filter_mismappers.cpp:86-199)
@@ -668,9 +676,12 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	}
 	// The calls of the list that reach into the block of read positions [block, block + 8): into the memory of the sweep (the first ALIGN_SWEEP_CALLS) and the overflow list.
 	// Returns false if there are more of them than both hold.
-	AGPU_HD bool sweep_collect_calls(AlignSweep& sweep, int32_t block, uint32_t listed, uint32_t width) const {
-		uint32_t n = 0, reached = 0;
+	AGPU_HD bool sweep_collect_calls(AlignSweep& sweep, int32_t block, uint32_t listed, uint32_t width, uint32_t strands) const {
+		uint32_t n = 0, reached = 0, n_forward = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+		if (lane == 0) sweep.reached = 0;
+		sync_lanes();
+		for (uint32_t strand = 0; strand < strands; ++strand) { // (strand by strand, so that the calls of a strand stand together)
 		for (uint32_t base = 0; base < listed; base += lanes) {
 			const uint32_t j = base + lane;
 			AlignTask call = { 0, 0, 0, 0 };
@@ -678,33 +689,42 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 			if (j < listed) {
 				call = worklist->task(j);
 				const int32_t iterations = (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
-				relevant = call.read_pos < block + (int32_t) ALIGN_SWEEP_BLOCK && call.read_pos + iterations > block;
+				relevant = call.read_pos < block + (int32_t) ALIGN_SWEEP_BLOCK && call.read_pos + iterations > block && ((call.flags & ALIGN_TASK_STRAND) != 0) == (strand != 0);
 			}
 			const unsigned long long mask = __ballot(relevant);
 			if (relevant) {
 				const uint32_t at = n + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
 				sweep_store_call(sweep, at, call);
 			}
-			for (uint32_t k = 0; k < ALIGN_SWEEP_BLOCK; ++k) { // which read positions of the block does one of these calls reach?
-				const int32_t read_pos = block + (int32_t) k;
-				if (__ballot(relevant && call.read_pos <= read_pos && read_pos - call.read_pos < (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT)) != 0) reached |= 1u << k;
-			}
+			if (relevant) atomicOr(&sweep.reached, reached_bits(call, block)); // which read positions of the block does one of these calls reach?
 			n += (uint32_t) __popcll(mask);
 		}
-		sync_lanes();
-		if (lane == 0) { sweep.n_calls = n; sweep.reached = reached; }
-		sync_lanes();
-#else
-		for (uint32_t j = 0; j < listed; ++j) {
-			const AlignTask call = worklist->task(j);
-			const int32_t iterations = (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
-			if (!(call.read_pos < block + (int32_t) ALIGN_SWEEP_BLOCK && call.read_pos + iterations > block)) continue;
-			sweep_store_call(sweep, n++, call);
-			for (uint32_t k = 0; k < ALIGN_SWEEP_BLOCK; ++k) if (call.read_pos <= block + (int32_t) k && block + (int32_t) k - call.read_pos < iterations) reached |= 1u << k;
+		if (strand == 0) n_forward = n;
 		}
-		sweep.n_calls = n; sweep.reached = reached;
+		sync_lanes();
+		if (lane == 0) { sweep.n_calls = n; sweep.n_calls_forward = n_forward; }
+		sync_lanes();
+		(void) reached;
+#else
+		for (uint32_t strand = 0; strand < strands; ++strand) {
+			for (uint32_t j = 0; j < listed; ++j) {
+				const AlignTask call = worklist->task(j);
+				const int32_t iterations = (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
+				if (!(call.read_pos < block + (int32_t) ALIGN_SWEEP_BLOCK && call.read_pos + iterations > block) || ((call.flags & ALIGN_TASK_STRAND) != 0) != (strand != 0)) continue;
+				sweep_store_call(sweep, n++, call);
+				reached |= reached_bits(call, block);
+			}
+			if (strand == 0) n_forward = n;
+		}
+		sweep.n_calls = n; sweep.n_calls_forward = n_forward; sweep.reached = reached;
 #endif
 		return n <= ALIGN_SWEEP_CALLS + (worklist->relevant_words != nullptr ? worklist->relevant_capacity : 0u);
+	}
+	// the read positions [block, block + 8) that the loop of a call stands at, as bits 0-7 (forward strand) or 8-15 (a call of the search of the reverse complement); the call reaches into the block
+	AGPU_HD static uint32_t reached_bits(const AlignTask& call, int32_t block) {
+		const int32_t iterations = (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT);
+		const int32_t from = call.read_pos > block ? call.read_pos - block : 0, to = call.read_pos + iterations < block + (int32_t) ALIGN_SWEEP_BLOCK ? call.read_pos + iterations - block : (int32_t) ALIGN_SWEEP_BLOCK;
+		return (((1u << to) - 1u) & ~((1u << from) - 1u)) << ((call.flags & ALIGN_TASK_STRAND) ? ALIGN_SWEEP_BLOCK : 0u);
 	}
 	AGPU_HD void sweep_store_call(AlignSweep& sweep, uint32_t at, const AlignTask& call) const {
 		if (at < ALIGN_SWEEP_CALLS) { sweep.call_score[at] = call.score; sweep.call_read_pos[at] = call.read_pos; sweep.call_gene_pos[at] = call.gene_pos; sweep.call_flags[at] = call.flags; return; }
@@ -729,7 +749,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 		return call;
 	}
 	// one seed of the block: the best arrival of the calls that reach it, walked to the right
-	AGPU_HD bool sweep_seed(const AlignSweep& sweep, const Segment& read, const AlignTarget& target, int32_t min_score, int32_t read_pos, int32_t kmer_hit) const {
+	AGPU_HD bool sweep_seed(const AlignSweep& sweep, const Segment& read, const AlignTarget& target, int32_t min_score, int32_t read_pos, int32_t kmer_hit, uint32_t strand) const {
 #if defined(__HIP_DEVICE_COMPILE__)
 		const bool timed = worklist->stats != nullptr && lane == 0; // (the study of ARRIBA_MISMAPPER_TIMES: lane 0 has a seed in every round, and the lanes of a wavefront meet again behind every part)
 		unsigned long long tick = timed ? wall_clock64() : 0ull;
@@ -742,8 +762,8 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 		SEED_LAP(8);
 		const int32_t NONE = -0x40000000;
 		int32_t best[2] = { NONE, NONE }; // by max_deletions
-		const uint32_t n_calls = sweep.n_calls;
-		for (uint32_t c = 0; c < n_calls; ++c) {
+		const uint32_t n_calls = strand != 0 ? sweep.n_calls : sweep.n_calls_forward;
+		for (uint32_t c = strand != 0 ? sweep.n_calls_forward : 0u; c < n_calls; ++c) { // the calls of the seed's strand
 			const AlignTask call = sweep_call(sweep, c);
 			const int32_t i = read_pos - call.read_pos; // the iteration of the call's loop that stands at this read position: score - i, i skipped bases
 			if (i < 0 || i >= (int32_t) (call.flags >> ALIGN_TASK_ITERATIONS_SHIFT) || call.gene_pos > kmer_hit) continue;
@@ -757,14 +777,18 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 		// (an arrival that may not delete with at most the score of one that may lists nothing new; one that cannot reach min_score over the bases behind the seed walks nowhere: align_walk_seed)
 		const int32_t short_of = min_score - ((int32_t) read.length - read_pos - (int32_t) KMER_LENGTH);
 		const int32_t score_with = best[1] != NONE && best[1] >= short_of ? best[1] : ALIGN_NO_ARRIVAL, score_without = best[0] != NONE && best[0] > best[1] && best[0] >= short_of ? best[0] : ALIGN_NO_ARRIVAL;
-		const bool found = (score_with != ALIGN_NO_ARRIVAL || score_without != ALIGN_NO_ARRIVAL) && align_walk_seed(read, target, min_score, score_with, score_without, read_pos, kmer_hit, *memo, *worklist, &ahead);
+		const bool found = (score_with != ALIGN_NO_ARRIVAL || score_without != ALIGN_NO_ARRIVAL) && align_walk_seed(read, target, min_score, score_with, score_without, read_pos, kmer_hit, *memo, *worklist, &ahead, strand);
 		SEED_LAP(10);
 		return found;
 	}
 	// returns whether the segment aligns; worklist->state[1] != 0 afterwards: a list was too short, the answer is not known (left to the recursion)
-	AGPU_HD bool align_by_sweep(const Segment& read, const AlignTarget& target, int32_t min_score) const {
+	// strands = 2 (round 6): `forward` and its reverse complement (whose base codes the caller has put into cache2) in ONE sweep.  The two searches of align_both_strands
+	// (source/filter_mismappers.cpp:218-224) run over the same read positions against the same gene; their calls share the list (ALIGN_TASK_STRAND), their seeds the rounds of a block:
+	// a block of one search has ~22 seeds for 64 lanes, and the kernel is bound by the instructions it issues (profiles/r06f_sq_summary.txt) -- with two searches a round is twice
+	// as full and there are half as many.  The reference does not search the reverse strand when the forward one aligns; searching it anyway changes nothing: the answer is an OR.
+	AGPU_HD bool align_by_sweep(const Segment& forward, uint32_t strands, const AlignTarget& target, int32_t min_score) const {
 		AlignSweep& sweep = *worklist->sweep;
-		const int32_t length = (int32_t) read.length;
+		const int32_t length = (int32_t) forward.length;
 #if !defined(__HIP_DEVICE_COMPILE__)
 		const uint32_t width = virtual_lanes > 1 ? virtual_lanes : 1; // host stepping: the lanes of the device one after the other
 #else
@@ -776,6 +800,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 			AlignTask outermost = { 0, 0, target.gene_start, ALIGN_TASK_ROOT | ALIGN_TASK_DELETIONS };
 			outermost.flags |= align_iterations(outermost, length, min_score) << ALIGN_TASK_ITERATIONS_SHIFT;
 			worklist->push(outermost);
+			if (strands > 1) { outermost.flags |= ALIGN_TASK_STRAND; worklist->push(outermost); }
 		}
 #if defined(__HIP_DEVICE_COMPILE__)
 		unsigned long long tick = worklist->stats != nullptr ? wall_clock64() : 0ull;
@@ -783,31 +808,48 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 #else
 #define SWEEP_LAP(slot) ((void) 0)
 #endif
-		// the seeds of every read position: the hits of its 8-mer from the start of the gene to its end (source/filter_mismappers.cpp:100-106)
-		for (int32_t read_pos = (int32_t) first_of_mine(width); read_pos < length; read_pos += (int32_t) stride_of_mine(width)) {
-			uint32_t first = 0, count = 0;
-			if (read_pos + KMER_LENGTH < length && target.kmer_offsets != 0) {
-				ALIGN_STAT(read_positions, 1);
-				const uint32_t kmer = read.kmer((uint32_t) read_pos);
-				const uint32_t begin = target.kmer_offsets[kmer], end = target.kmer_offsets[kmer + 1];
-				first = lower_bound_i32(target.positions, begin, end, target.gene_start);
-				count = lower_bound_i32(target.positions, first, end, target.gene_end) - first;
-			}
-			sweep.hit_first[read_pos] = first; sweep.hit_count[read_pos] = count;
-		}
 		sync_lanes();
-		SWEEP_LAP(4);
-#if !defined(__HIP_DEVICE_COMPILE__)
-		if (round_steps != nullptr) { round_steps[0] += 16 * (((uint32_t) length + width - 1) / width); round_steps[1] += ((uint32_t) length + width - 1) / width; } // (the look-ups, in the currency of the steps of a walk)
-#endif
+		int32_t looked_up = 0; // read positions whose seeds are known
 		for (int32_t block = 0; block + KMER_LENGTH < length; block += (int32_t) ALIGN_SWEEP_BLOCK) {
+			if (block >= looked_up) {
+				// the seeds of the next 64 read positions (one per lane): the hits of the 8-mer from the start of the gene to its end (source/filter_mismappers.cpp:100-106).  Not of every
+				// read position in front of the sweep (until round 6): most sweeps end in the first 64 (max_reach); and the END of the hits is searched from their start in doubling steps --
+				// a gene holds a few of the ten thousands of places of an 8-mer
+				for (uint32_t item = first_of_mine(width); item < strands * ALIGN_SWEEP_LOOKUPS; item += stride_of_mine(width)) {
+					const uint32_t strand = item / ALIGN_SWEEP_LOOKUPS;
+					const int32_t read_pos = looked_up + (int32_t) (item % ALIGN_SWEEP_LOOKUPS);
+					if (read_pos >= length) continue;
+					const Segment read = of_strand(forward, strand);
+					uint32_t first = 0, count = 0;
+					if (read_pos + KMER_LENGTH < length && target.kmer_offsets != 0) {
+						ALIGN_STAT(read_positions, 1);
+						const uint32_t kmer = read.kmer((uint32_t) read_pos);
+						const uint32_t begin = target.kmer_offsets[kmer], end = target.kmer_offsets[kmer + 1];
+						first = lower_bound_i32(target.positions, begin, end, target.gene_start);
+						uint32_t behind = first, step = 1; // every hit in [first, behind) lies in front of the end of the gene
+						while (behind < end) {
+							const uint32_t probe = behind + step - 1 < end - 1 ? behind + step - 1 : end - 1;
+							if (target.positions[probe] < target.gene_end) { behind = probe + 1; step <<= 1; }
+							else { behind = lower_bound_i32(target.positions, behind, probe, target.gene_end); break; }
+						}
+						count = behind - first;
+					}
+					sweep.hit_first[item] = first; sweep.hit_count[item] = count;
+				}
+				looked_up += (int32_t) ALIGN_SWEEP_LOOKUPS;
+				sync_lanes();
+				SWEEP_LAP(4);
+#if !defined(__HIP_DEVICE_COMPILE__)
+				if (round_steps != nullptr) { round_steps[0] += 16 * ((strands * ALIGN_SWEEP_LOOKUPS + width - 1) / width); round_steps[1] += (strands * ALIGN_SWEEP_LOOKUPS + width - 1) / width; } // (the look-ups, in the currency of the steps of a walk)
+#endif
+			}
 			sync_lanes();
 			if (worklist->state[1] != 0) return false; // the list of the calls ran over
 			const uint32_t listed = worklist->state[0] < worklist->capacity ? worklist->state[0] : worklist->capacity;
 			const bool beyond_every_call = (uint32_t) block >= sweep.max_reach; // (a call is listed by a seed at least eight read positions in front of its first one: the calls of this block and all behind it are known)
 			sync_lanes(); // (nobody lists a call before everybody has read how many there are)
 			if (beyond_every_call) break;
-			if (!sweep_collect_calls(sweep, block, listed, width)) { if (lane == 0) worklist->state[1] = 1; sync_lanes(); return false; }
+			if (!sweep_collect_calls(sweep, block, listed, width, strands)) { if (lane == 0) worklist->state[1] = 1; sync_lanes(); return false; }
 			SWEEP_LAP(5);
 #if defined(__HIP_DEVICE_COMPILE__)
 			if (worklist->stats != nullptr && lane == 0) worklist->stats[15] += 1;
@@ -817,12 +859,17 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 #if defined(__HIP_DEVICE_COMPILE__)
 			if (worklist->stats != nullptr && lane == 0) worklist->stats[1] += sweep.n_calls;
 #endif
-			if (lane == 0) { // the seeds of the read positions that a call reaches, numbered through
+			const uint32_t in_batch = (uint32_t) (block - (looked_up - (int32_t) ALIGN_SWEEP_LOOKUPS)); // the block's place among the read positions looked up last
+			if (lane == 0) { // the seeds of the read positions that a call reaches, numbered through, strand by strand
 				uint32_t total = 0;
-				for (uint32_t k = 0; k < ALIGN_SWEEP_BLOCK; ++k) { if ((sweep.reached >> k & 1) && block + (int32_t) k < length) total += sweep.hit_count[block + (int32_t) k]; sweep.seed_end[k] = total; }
+				for (uint32_t slot = 0; slot < strands * ALIGN_SWEEP_BLOCK; ++slot) {
+					const uint32_t k = slot % ALIGN_SWEEP_BLOCK;
+					if ((sweep.reached >> slot & 1) && block + (int32_t) k < length) total += sweep.hit_count[(slot / ALIGN_SWEEP_BLOCK) * ALIGN_SWEEP_LOOKUPS + in_batch + k];
+					sweep.seed_end[slot] = total;
+				}
 			}
 			sync_lanes();
-			const uint32_t seeds = sweep.seed_end[ALIGN_SWEEP_BLOCK - 1];
+			const uint32_t seeds = sweep.seed_end[strands * ALIGN_SWEEP_BLOCK - 1];
 #if defined(__HIP_DEVICE_COMPILE__)
 			if (worklist->stats != nullptr && lane == 0) { worklist->stats[2] += seeds; worklist->stats[13] += (seeds + width - 1) / width; worklist->stats[14] += 1; }
 			SWEEP_LAP(12);
@@ -832,14 +879,16 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 				unsigned long long longest = 0;
 #endif
 				for (uint32_t seed = seed_base + first_of_mine(width); seed < seeds && seed < seed_base + width; seed += stride_of_mine(width)) {
-					uint32_t k = 0;
-					while (sweep.seed_end[k] <= seed) ++k;
+					uint32_t slot = 0;
+					while (sweep.seed_end[slot] <= seed) ++slot;
+					const uint32_t strand = slot / ALIGN_SWEEP_BLOCK, k = slot % ALIGN_SWEEP_BLOCK;
 					const int32_t read_pos = block + (int32_t) k;
-					const uint32_t hit = sweep.hit_first[read_pos] + (seed - (k > 0 ? sweep.seed_end[k - 1] : 0u));
+					const uint32_t hit = sweep.hit_first[strand * ALIGN_SWEEP_LOOKUPS + in_batch + k] + (seed - (slot > 0 ? sweep.seed_end[slot - 1] : 0u));
+					const Segment read = of_strand(forward, strand);
 #if !defined(__HIP_DEVICE_COMPILE__)
 					const unsigned long long before = g_align_seed_steps;
 #endif
-					if (sweep_seed(sweep, read, target, min_score, read_pos, target.positions[hit])) worklist->state[2] = 1;
+					if (sweep_seed(sweep, read, target, min_score, read_pos, target.positions[hit], strand)) worklist->state[2] = 1;
 #if !defined(__HIP_DEVICE_COMPILE__)
 					if (g_align_seed_steps - before > longest) longest = g_align_seed_steps - before;
 					if (budget != nullptr) *budget -= (int64_t) (g_align_seed_steps - before); // (host stepping: the steps of the read, for the statistics of the harness)
@@ -859,12 +908,36 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 #endif
 		return worklist->state[2] != 0;
 	}
+	// the segment as the search of a strand reads it: forward (base codes in `cache`) or reverse complement (in `cache2`)
+	AGPU_HD Segment of_strand(const Segment& forward, uint32_t strand) const {
+		Segment read = forward;
+		if (strand != 0) { read.reverse_complement = true; read.cache = cache2; }
+		return read;
+	}
+	// both strands of a segment against a gene in one sweep?  (needs what the sweep needs, and room for the base codes of both strands)
+	AGPU_HD bool sweeps_strands_together(const Segment& segment, const AlignTarget& target) const {
+		return strands_together && worklist != nullptr && worklist->sweep != nullptr && memo != nullptr && cache != nullptr && cache2 != nullptr && segment.length <= cache_capacity
+		       && memo->usable(target.gene_start, target.gene_end, (int32_t) segment.length) && segment.length <= ALIGN_SWEEP_SEGMENT;
+	}
+	// returns whether one of the strands aligns; *decided = false: a list ran over, nothing is known (the caller searches strand by strand)
+	AGPU_HD bool align_strands(const Segment& segment, const AlignTarget& target, int32_t min_score, bool* decided) const {
+		Segment forward = segment; forward.reverse_complement = false; forward.cache = nullptr;
+		Segment reverse = segment; reverse.reverse_complement = true; reverse.cache = nullptr;
+		sync_lanes(); // (nobody still reads the previous copies)
+		for (uint32_t i = lane; i < segment.length; i += lanes) { cache[(size_t) i * cache_stride] = (uint8_t) forward.code(i); cache2[(size_t) i * cache_stride] = (uint8_t) reverse.code(i); }
+		sync_lanes();
+		forward.cache = cache; forward.cache_stride = cache_stride;
+		new_memo_epoch();
+		const bool found = align_by_sweep(forward, 2, target, min_score);
+		*decided = worklist->state[1] == 0;
+		return found;
+	}
 	AGPU_HD bool align(const Segment& read, const AlignTarget& target, int32_t min_score) const {
 		const int32_t length = (int32_t) read.length;
 		if (memo != nullptr) new_memo_epoch(); // a new search: the entries of the previous one (other gene, strand, segment, min_score) must not match
 		if constexpr (SWEEP_ONLY) {
 			if (memo->usable(target.gene_start, target.gene_end, length) && (uint32_t) length <= ALIGN_SWEEP_SEGMENT) {
-				const bool found = align_by_sweep(read, target, min_score);
+				const bool found = align_by_sweep(read, 1, target, min_score);
 				if (worklist->state[1] == 0) return found;
 			}
 			sync_lanes();
@@ -873,7 +946,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 			return false;
 		}
 		if (worklist != nullptr && worklist->sweep != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end, length) && (uint32_t) length <= ALIGN_SWEEP_SEGMENT) {
-			const bool found = align_by_sweep(read, target, min_score);
+			const bool found = align_by_sweep(read, 1, target, min_score);
 			if (worklist->state[1] == 0) return found;
 			new_memo_epoch(); // a list was too short for this search: done again by the recursion (what the memo has "seen" are not failures)
 		} else if (worklist != nullptr && memo != nullptr && memo->usable(target.gene_start, target.gene_end, length)) {
@@ -964,6 +1037,12 @@ template <class Runner> AGPU_HD bool align_both_strands(const Segment& segment, 
 		target.contig_bases = genome.bases + genome.contig_offset[contig];
 		target.splice_sites = splice.sites + splice.offset[gene]; target.n_splice_sites = splice.offset[gene + 1] - splice.offset[gene];
 		target.splice_bits = splice.bits; target.splice_bit_base = genome.contig_offset[contig];
+		if (runner.sweeps_strands_together(segment, target)) {
+			bool decided = false;
+			const bool found = runner.align_strands(segment, target, min_score, &decided);
+			if (found) return true;
+			if (decided) continue;
+		}
 		Segment forward = segment; forward.reverse_complement = false;
 		if (runner.align(runner.prepared(forward), target, min_score)) return true;
 		if (runner.exhausted()) return false;

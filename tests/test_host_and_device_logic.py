@@ -765,13 +765,14 @@ def test_workflow_with_mismappers_switched_off_against_the_live_reference(disabl
 @pytest.mark.skipif(not datasets.reference_available(), reason="needs the oracle build of the reference (oracle/_ref)")
 @pytest.mark.parametrize("schedule", [{"EMU_MISMAPPER_BUDGET": "64"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_ROUNDS": "64"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_WORKLIST": "0"},
                                       {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_WORKLIST_CAPACITY": "6"},
-                                      {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_FRONT_SLOTS": "2"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_FRONT_SLOTS": "0"}])
+                                      {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_FRONT_SLOTS": "2"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_FRONT_SLOTS": "0"},
+                                      {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_STRANDS_TOGETHER": "0"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_ROUNDS": "64", "EMU_MISMAPPER_STRANDS_TOGETHER": "0"}])
 def test_every_schedule_of_the_mismapper_search_gives_the_reference(schedule, emu_api, tmp_path, monkeypatch):
     """The verdict of a read is a pure function of the read, whoever computes it in whatever order: with a step budget of 64 nearly every read goes to the second
     pass, which is stepped as the list of tasks the device uses (nested calls listed and deduplicated by the memo; taken one by one, and in rounds of 64 as a wavefront
     takes them -- the harness fails if a listed task was never run), as the recursion with the memo of failed calls, and with a list of 6 tasks that overflows so that
     the recursion takes over; with a front of the memo (the table in LDS of round 6) of 16 slots, of two -- nearly every key spills to the table behind it -- and
-    without one -- reads discarded, candidates and both files equal the reference's."""
+    without one; the sweep over both strands of a segment at once (the default since round 6) and strand by strand -- reads discarded, candidates and both files equal the reference's."""
     for key, value in schedule.items():
         monkeypatch.setenv(key, value)
     spec = {"args": ["--seed", "79", "--fragments", "15000", "--normal-mult", "0.4", "--contigs", "5", "--contig-len", "400000", "--junctions", "200", "--partner-clip", "0.5", "--clip-min", "40", "--clip-max", "70",
