@@ -193,6 +193,7 @@ const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch boun
 template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__(64, WAVES_PER_SIMD) mismapper_heavy_kernel(BatchView b, AnnotationView ann, GenomeView genome, KmerIndexView kmers, SpliceSiteView splice, const uint32_t* heavy, uint32_t n_heavy, int32_t max_mate_gap,
                                                              unsigned long long* memo_tables, uint32_t memo_slots, unsigned long long* task_lists, uint32_t task_capacity, bool by_sweep, unsigned long long* read_times, unsigned int* counters, uint32_t* leftover, int queue, bool lds_front, bool strands_together) {
 	__shared__ uint8_t segment_bases[2 * 304]; // (the segment being searched and its reverse complement)
+	__shared__ uint8_t segment_chars[2 * 312];  // (... as characters, eight zero bytes behind each)
 	__shared__ AlignSweep sweep;
 	__shared__ AlignMemo memo;
 	__shared__ AlignWorklist worklist;
@@ -219,7 +220,7 @@ template <int WAVES_PER_SIMD, bool SWEEP_ONLY> __global__ void __launch_bounds__
 	runner.lanes_share_seeds = true; // a read lands here because its search is long: the lanes split the seeds of every read position (when the task list is off or overflows)
 	runner.memo = &memo;
 	runner.worklist = task_lists != nullptr ? &worklist : nullptr; // the search as rounds of up to 64 tasks (mismapper_core.hpp: AlignWorklist)
-	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304; runner.cache2 = segment_bases + 304; runner.strands_together = strands_together;
+	runner.cache = segment_bases; runner.cache_stride = 1; runner.cache_capacity = 304; runner.cache2 = segment_bases + 304; runner.strands_together = strands_together; runner.chars = segment_chars; runner.chars2 = segment_chars + 312;
 	while (true) {
 		__syncthreads(); // (every lane has read next_job of the previous round)
 		if (threadIdx.x == 0) { next_job = atomicAdd(&counters[queue], 1u); given_up = 0; }

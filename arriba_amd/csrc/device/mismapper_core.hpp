@@ -40,15 +40,19 @@ struct Segment {
 	// optional copy of the segment's base characters as code(i) would give them (strand applied), element i at cache[i * cache_stride]: the search reads every base
 	// of the segment hundreds of times; on the device the copy lives in LDS
 	const uint8_t* cache = nullptr; uint32_t cache_stride = 1;
+	// ... and as CHARACTERS, one byte per base, eight zero bytes behind the last (round 6): the walks compare eight bases of the read with eight of the gene in one XOR, and
+	// code -> character cost more instructions than the comparison (chars8 was ~85 instructions, now one unaligned 8-byte read of LDS)
+	const uint8_t* chars = nullptr;
 	AGPU_HD uint32_t code(uint32_t i) const {
 		if (cache != nullptr) return cache[(size_t) i * cache_stride];
 		return reverse_complement ? complement_code(sequence.code(offset + length - 1 - i)) : sequence.code(offset + i);
 	}
-	AGPU_HD char at(uint32_t i) const { return base_char(code(i)); }
+	AGPU_HD char at(uint32_t i) const { return chars != nullptr ? (char) chars[i] : base_char(code(i)); }
 	// eight bases from position i on as characters, one per byte, the first in the low byte (0 behind the end of the segment): eight independent loads instead of
 	// one per step of the extension
 	AGPU_HD uint64_t chars8(uint32_t i) const {
 		uint64_t value = 0;
+		if (chars != nullptr) { __builtin_memcpy(&value, chars + i, 8); return value; }
 		for (uint32_t k = 0; k < 8; ++k) if (i + k < length) value |= (uint64_t) (uint8_t) at(i + k) << (8 * k);
 		return value;
 	}
@@ -492,6 +496,22 @@ AGPU_HD LeftProfile align_left_profile(const Segment& read, const AlignTarget& t
 		uint64_t window = 0;
 		if (gene_from >= 8) window = load_bases8(target.contig_bases + gene_from - 8);
 		else for (int32_t k = 0; k < gene_from; ++k) window |= (uint64_t) (uint8_t) target.contig_bases[gene_from - 1 - k] << (8 * (7 - k));
+		if (read.chars != nullptr) { // the eight bases of the read in front of read_pos - done the same way, and the mismatches from the bytes that differ
+			const int32_t read_from = read_pos - done; // (>= 1: done < limit <= read_pos)
+			uint64_t mine;
+			if (read_from >= 8) __builtin_memcpy(&mine, read.chars + read_from - 8, 8);
+			else { __builtin_memcpy(&mine, read.chars, 8); mine <<= 8 * (8 - read_from); }
+			uint64_t differ = window ^ mine;
+			const int32_t valid = profile.limit - done < 8 ? profile.limit - done : 8;
+			if (valid < 8) differ &= ~0ull << (8 * (8 - valid));
+			ALIGN_SEED_STEP();
+			while (differ != 0 && mismatches < 2) {
+				const int32_t k = __builtin_clzll(differ) >> 3;
+				if (++mismatches == 1) profile.first = done + k; else profile.second = done + k;
+				differ &= ~(0xFFull << (8 * (7 - k)));
+			}
+			continue;
+		}
 		for (int32_t k = 0; k < 8 && done + k < profile.limit; ++k) {
 			ALIGN_SEED_STEP();
 			if (read.at((uint32_t) (read_pos - 1 - done - k)) == (char) (window >> (8 * (7 - k)))) continue;
@@ -559,9 +579,9 @@ AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int
 		splice_cursor = lower_bound_i32(target.splice_sites, 0, target.n_splice_sites, extended_gene_pos - 1);
 		next_site = splice_cursor < target.n_splice_sites ? target.splice_sites[splice_cursor] : 0x7FFFFFFF;
 	}
-	uint64_t window = 0; int32_t window_at = 0, window_end = 0;                // genome bases [window_at, window_end) of the contig
-	if (ahead != nullptr) { window = ahead->right_window; window_at = extended_gene_pos; window_end = window_at + 8; }
-	uint64_t read_window = 0; int32_t read_window_at = 0, read_window_end = 0; // bases [read_window_at, read_window_end) of the read
+	// bytes that differ between the genome bases [window_at, window_at + 8) of the contig and the bases of the read that stand against them (gene and read advance together)
+	uint64_t differ = 0; int32_t window_at = extended_gene_pos - 8;
+	bool fetched = ahead != nullptr;
 	ALIGN_SEED_STEP();
 	// The re-seed after the first mismatch is LISTED BEHIND THE LOOP: nearly every walk has one, each lane of a wavefront at a base of its own, and listing it where it arises made
 	// the wavefront run through the listing (memo, list: ~150 instructions) once per distinct base instead of once.  (A walk that succeeds lists nothing: the search is over.)
@@ -578,9 +598,12 @@ AGPU_HD bool align_walk_seed(const Segment& read, const AlignTarget& target, int
 			if (with && lead - behind >= short_of) align_list_call(target, length, min_score, lead - behind, extended_read_pos, extended_gene_pos, 1, memo, worklist, strand);
 			if (without) align_list_call(target, length, min_score, lead, extended_read_pos, extended_gene_pos, 0, memo, worklist, strand);
 		}
-		if (extended_gene_pos >= window_end || extended_gene_pos < window_at) { window_at = extended_gene_pos; window_end = window_at + 8; window = load_bases8(target.contig_bases + window_at); }
-		if (extended_read_pos >= read_window_end || extended_read_pos < read_window_at) { read_window_at = extended_read_pos; read_window_end = read_window_at + 8; read_window = read.chars8((uint32_t) read_window_at); }
-		if ((char) (read_window >> (8 * (extended_read_pos - read_window_at))) == (char) (window >> (8 * (extended_gene_pos - window_at)))) {
+		if (extended_gene_pos >= window_at + 8) {
+			window_at = extended_gene_pos;
+			differ = (fetched ? ahead->right_window : load_bases8(target.contig_bases + window_at)) ^ read.chars8((uint32_t) extended_read_pos);
+			fetched = false;
+		}
+		if (((differ >> (8 * (extended_gene_pos - window_at))) & 0xFF) == 0) {
 			lead++;
 			if (lead >= min_score) return true;
 			consecutive_mismatches = 0;
@@ -612,6 +635,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	int64_t* budget = nullptr; // steps left for the whole verdict of one read (null: unlimited)
 	int max_depth = ALIGN_MAX_DEPTH; // frames `stack` holds
 	uint8_t* cache = nullptr; uint32_t cache_stride = 1, cache_capacity = 0; // room for a copy of the segment being searched (LDS on the device), shared by the lanes of the runner
+	uint8_t* chars = nullptr, * chars2 = nullptr;                            // ... and for the characters of both (cache_capacity + 8 bytes each; null: the searches translate the codes)
 	uint8_t* cache2 = nullptr;                                               // ... and for its reverse complement (same stride and capacity): a sweep over both strands (align_strands)
 	bool strands_together = true;                                            // (false: strand by strand as until round 6, for A/B measurements)
 	AGPU_HD bool exhausted() const { return budget != nullptr && *budget < 0; }
@@ -623,10 +647,11 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 		if (lanes > 1) __syncthreads(); // (lanes > 1: the lanes are one workgroup and run this code together; nobody still reads the previous copy)
 #endif
 		for (uint32_t i = lane; i < segment.length; i += lanes) cache[(size_t) i * cache_stride] = (uint8_t) segment.code(i);
+		if (chars != nullptr) for (uint32_t i = lane; i < segment.length + 8; i += lanes) chars[i] = i < segment.length ? (uint8_t) base_char(segment.code(i)) : (uint8_t) 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (lanes > 1) __syncthreads();
 #endif
-		result.cache = cache; result.cache_stride = cache_stride;
+		result.cache = cache; result.cache_stride = cache_stride; result.chars = chars;
 		return result;
 	}
 	AGPU_HD bool any(bool mine) const {
@@ -911,7 +936,7 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	// the segment as the search of a strand reads it: forward (base codes in `cache`) or reverse complement (in `cache2`)
 	AGPU_HD Segment of_strand(const Segment& forward, uint32_t strand) const {
 		Segment read = forward;
-		if (strand != 0) { read.reverse_complement = true; read.cache = cache2; }
+		if (strand != 0) { read.reverse_complement = true; read.cache = cache2; read.chars = chars2; }
 		return read;
 	}
 	// both strands of a segment against a gene in one sweep?  (needs what the sweep needs, and room for the base codes of both strands)
@@ -921,12 +946,13 @@ template <bool SWEEP_ONLY> struct AlignRunnerT {
 	}
 	// returns whether one of the strands aligns; *decided = false: a list ran over, nothing is known (the caller searches strand by strand)
 	AGPU_HD bool align_strands(const Segment& segment, const AlignTarget& target, int32_t min_score, bool* decided) const {
-		Segment forward = segment; forward.reverse_complement = false; forward.cache = nullptr;
-		Segment reverse = segment; reverse.reverse_complement = true; reverse.cache = nullptr;
+		Segment forward = segment; forward.reverse_complement = false; forward.cache = nullptr; forward.chars = nullptr;
+		Segment reverse = segment; reverse.reverse_complement = true; reverse.cache = nullptr; reverse.chars = nullptr;
 		sync_lanes(); // (nobody still reads the previous copies)
 		for (uint32_t i = lane; i < segment.length; i += lanes) { cache[(size_t) i * cache_stride] = (uint8_t) forward.code(i); cache2[(size_t) i * cache_stride] = (uint8_t) reverse.code(i); }
+		if (chars != nullptr && chars2 != nullptr) for (uint32_t i = lane; i < segment.length + 8; i += lanes) { chars[i] = i < segment.length ? (uint8_t) base_char(forward.code(i)) : (uint8_t) 0; chars2[i] = i < segment.length ? (uint8_t) base_char(reverse.code(i)) : (uint8_t) 0; }
 		sync_lanes();
-		forward.cache = cache; forward.cache_stride = cache_stride;
+		forward.cache = cache; forward.cache_stride = cache_stride; forward.chars = chars != nullptr && chars2 != nullptr ? chars : nullptr;
 		new_memo_epoch();
 		const bool found = align_by_sweep(forward, 2, target, min_score);
 		*decided = worklist->state[1] == 0;

@@ -766,7 +766,8 @@ def test_workflow_with_mismappers_switched_off_against_the_live_reference(disabl
 @pytest.mark.parametrize("schedule", [{"EMU_MISMAPPER_BUDGET": "64"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_ROUNDS": "64"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_WORKLIST": "0"},
                                       {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_WORKLIST_CAPACITY": "6"},
                                       {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_FRONT_SLOTS": "2"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_FRONT_SLOTS": "0"},
-                                      {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_STRANDS_TOGETHER": "0"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_ROUNDS": "64", "EMU_MISMAPPER_STRANDS_TOGETHER": "0"}])
+                                      {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_STRANDS_TOGETHER": "0"}, {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_ROUNDS": "64", "EMU_MISMAPPER_STRANDS_TOGETHER": "0"},
+                                      {"EMU_MISMAPPER_BUDGET": "64", "EMU_MISMAPPER_CHARS": "0"}])
 def test_every_schedule_of_the_mismapper_search_gives_the_reference(schedule, emu_api, tmp_path, monkeypatch):
     """The verdict of a read is a pure function of the read, whoever computes it in whatever order: with a step budget of 64 nearly every read goes to the second
     pass, which is stepped as the list of tasks the device uses (nested calls listed and deduplicated by the memo; taken one by one, and in rounds of 64 as a wavefront
