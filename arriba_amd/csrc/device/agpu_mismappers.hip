@@ -181,8 +181,12 @@ __global__ void __launch_bounds__(ALIGN_BLOCK, 5) mismapper_verdict_kernel(Batch
 // persistent: each owns one memo table in HBM and takes the next heavy read from a queue (counters[4]) when it is done with one -- the searches differ in
 // length by orders of magnitude, a fixed share per workgroup would wait for the unluckiest one.  The kernel waits for dependent loads (k-mer table -> hit list ->
 // genome bases -> memo slot), so the number of wavefronts in flight is what sets its speed: 5120 workgroups of one wavefront = 5 per SIMD.
-const uint32_t MEMO_SLOTS_LOG2 = 20;    // 8 MB per workgroup, 41 GB for 5120 of them (a read of a long gene makes 10^5..10^6 distinct nested calls; a full table costs repeated searches, never
-                                        // correctness; 8192 workgroups x 2^20 slots were as fast as 4096 x 2^21 at 30 M fragments: profiles/r02j_heavy_ab.txt)
+const uint32_t MEMO_SLOTS_LOG2 = 16;    // 512 KB per workgroup, 2.7 GB for 5120 of them.  2^20 (8 MB, 41 GB in all, cleared per sample) until round 6, sized for the reads of long genes that make 10^5..10^6
+                                        // distinct nested calls -- but the time of the kernel is the same from 2^11 to 2^20 slots at 10^8 fragments (profiles/r06e_heavy_ab.txt: 363 / 369 / 368 ms):
+                                        // a full table costs repeated searches, never correctness, and the 38 GB are the difference between a rank that holds its share of a sample beside
+                                        // the tables and one that does not.  ARRIBA_MEMO_SLOTS_LOG2 for measurements
+const uint32_t TASK_CAPACITY_LOG2 = 15; // 2^15 listed calls of 16 bytes per workgroup, and as many for the calls of a block beyond the memory of the sweep: 5 GB for 5120 workgroups (2^17, 21 GB,
+                                        // until round 6; the longest list of the 10^8-fragment sample has 1 600 calls).  A search that lists more is done by the recursion.  ARRIBA_TASK_CAPACITY_LOG2
 const uint32_t HEAVY_WORKGROUPS = 5120; // five wavefronts per SIMD (launch bounds below)
 // Tried and taken back in round 5 (profiles/r05o_waves6.json, r05p_*, r05q_*): (a) six wavefronts per SIMD -- 80 VGPRs, 177 spilled: 457 ms instead of 419 at 10^8 fragments;
 // (b) TWO searches per wavefront, the two strands of a gene at once on 32 lanes each with a sweep, a memo and lists of their own (the calls of a block kept in LDS cut from 256 to
@@ -480,17 +484,18 @@ int filter_mismappers_phases(agpu_ctx* ctx, int phases, int32_t max_mate_gap, ui
 				uint32_t workgroups = std::min<uint32_t>(n_heavy, wanted);
 				DeviceBuffer& memo_tables = ctx->scratch("mismappers.memo_tables");
 				DeviceBuffer& task_lists = ctx->scratch("mismappers.task_lists");
-				const uint32_t task_capacity = 1u << 17;
+				knob = getenv("ARRIBA_TASK_CAPACITY_LOG2");
+				const uint32_t task_capacity = 1u << (knob != nullptr && atoi(knob) >= 6 && atoi(knob) <= 20 ? (uint32_t) atoi(knob) : TASK_CAPACITY_LOG2);
 				knob = getenv("ARRIBA_MISMAPPER_WORKLIST");
 				const bool use_worklist = !(knob != nullptr && knob[0] == '0');
-				// 8 MB of memo and 4 MB of task lists per persistent workgroup: 62 GB for 5120 of them.  A device (or what other contexts have left of it) that does not hold them
+				// 512 KB of memo and 1 MB of task lists per persistent workgroup: 8 GB for 5120 of them (62 GB until round 6).  A device (or what other contexts have left of it) that does not hold them
 				// runs the search with fewer workgroups -- slower, the same verdicts -- instead of failing
 				while (!memo_tables.allocate((size_t) workgroups * memo_slots * 8) || (use_worklist && !task_lists.allocate((size_t) workgroups * task_capacity * 16 * 2))) {
 					if (workgroups <= 64) { set_last_error("hipMalloc failed (the memo tables and task lists of filter_mismappers)"); return AGPU_ERR_NO_MEMORY; }
 					workgroups /= 2;
 				}
 				HIP_CHECK(hipMemsetAsync(memo_tables.ptr, 0, (size_t) workgroups * memo_slots * 8, s));
-				// the task lists of the workgroups: 2^17 tasks of 16 bytes each (2 MB, and as much again for the calls of a block beyond the memory of the sweep: 21 GB for 5120 workgroups) (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
+				// the task lists of the workgroups: task_capacity tasks of 16 bytes each (and as much again for the calls of a block beyond the memory of the sweep) (a search that lists more is done by the recursion); ARRIBA_MISMAPPER_WORKLIST=0: recursion only
 				knob = getenv("ARRIBA_MISMAPPER_SWEEP"); // "0": the lanes take whole listed calls in rounds (the schedule of round 2), for A/B measurements
 				const bool by_sweep = !(knob != nullptr && knob[0] == '0');
 				const bool want_times = getenv("ARRIBA_MISMAPPER_TIMES") != nullptr; // a study: how long the wavefronts worked on every read of the second pass, on stderr
