@@ -49,11 +49,11 @@ def main():
         step = max(feed, device + exchanges + alone["output_results"] + alone["output_rows"] / n)
         report["projected"][str(n)] = {"latency_s": round(latency, 3), "speedup_of_one_sample": round(alone["total"] / latency, 2), "step_of_a_queue_s": round(step, 3), "speedup_of_the_queue": round(line["ms_per_step"] / 1e3 / step, 2),
                                        "parts_s": {"feed": round(feed, 3), "device_and_launches": round(device, 3), "exchanges": round(exchanges, 3), "output": round(output, 3)},
-                                       "hbm_per_rank_GB": round(8 + 4.7 + 12 + (54 + 35 + 25) / n, 0)}
+                                       "hbm_per_rank_GB": round(29 + 5 + 4.7 + 12 + (54 + 35 + 25) / n, 0)}
     report["reading"] = ("the kernels over candidates and read lists (%.0f ms: find_fusions from the emissions of all ranks, merge_adjacent_fusions, the list walks, select_best, both_spliced, homologs, ...) do not shrink with N: "
                          "they bound the speed-up at %.1fx however many GPUs; sharding THEM is a partition of the candidates by gene pair (arriba_amd/sharded.py has its exchange), not of the reads"
                          % (replicated, line["kernel_ms_alone_sum"] / (replicated + other)))
-    report["hbm_per_rank_GB_is"] = "8 GB of memo tables and task lists of filter_mismappers (per rank, whatever N; 62 GB until the tables shrank in round 6) + 4.7 GB of emissions + ~12 GB of candidates and read lists + (stream 54 + tables of the ingest 35 + batch and gene sets 25) / N"
+    report["hbm_per_rank_GB_is"] = "29 GB of working arrays of find_fusions over the emissions of ALL ranks (220 B per emission; the 2.7 GB of memo tables of filter_mismappers live in the same buffer later) + 5 GB of task lists (per rank, whatever N; 62 GB of tables and lists until round 6) + 4.7 GB of emissions + ~12 GB of candidates and read lists + (stream 54 + tables of the ingest 35 + batch and gene sets 25) / N"
     print(json.dumps(report, indent=1))
 
 
