@@ -1020,7 +1020,7 @@ def test_filter_mismappers_gives_the_same_verdicts_under_every_schedule(built, t
     fragments = int(os.environ.get("ARRIBA_DETERMINISM_FRAGMENTS", "100000"))
     samples = [("stress", bench.workload_args(fragments, 1000, stress=True), {"subsampling_threshold": 32767}, 0),
                ("homologs", ["--seed", "29", "--fragments", str(2 * fragments), "--contigs", "4", "--contig-len", "300000", "--junctions", "80", "--homolog-families", "4"], None, 20)]
-    knobs = ("ARRIBA_HEAVY_WORKGROUPS", "ARRIBA_MISMAPPER_JOB_ORDER", "ARRIBA_HEAVY_WAVES")
+    knobs = ("ARRIBA_HEAVY_WORKGROUPS", "ARRIBA_MISMAPPER_JOB_ORDER", "ARRIBA_HEAVY_WAVES", "ARRIBA_STRANDS_TOGETHER", "ARRIBA_MEMO_FRONT", "ARRIBA_MEMO_SLOTS_LOG2", "ARRIBA_TASK_CAPACITY_LOG2")
     for name, arguments, params, least_positive in samples:
         prefix = str(tmp_path / name)
         subprocess.run([datasets.GEN_SYNTH, "--out", prefix, "--threads", "32"] + arguments, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -1053,7 +1053,11 @@ def test_filter_mismappers_gives_the_same_verdicts_under_every_schedule(built, t
         assert n_jobs > fragments // 50 and first.sum() >= least_positive, (name, n_jobs, int(first.sum()))
         assert int(first.sum()) == int(first_per_read.sum()) - int((filters_before == 11).sum()), name
         schedules = [("5120 workgroups, run %d" % k, {}) for k in range(2, 11)] + [("7 workgroups, run %d" % k, {"ARRIBA_HEAVY_WORKGROUPS": "7"}) for k in range(1, 4)] + \
-                    [("one workgroup", {"ARRIBA_HEAVY_WORKGROUPS": "1"}), ("four wavefronts per SIMD", {"ARRIBA_HEAVY_WAVES": "4", "ARRIBA_HEAVY_WORKGROUPS": "4096"})]
+                    [("one workgroup", {"ARRIBA_HEAVY_WORKGROUPS": "1"}), ("four wavefronts per SIMD", {"ARRIBA_HEAVY_WAVES": "4", "ARRIBA_HEAVY_WORKGROUPS": "4096"}),
+                     # (round 6) the strands of a segment one after the other instead of in one sweep; no front of the memo in LDS; a memo of 2^10 slots and lists of 64 calls per workgroup:
+                     # the tables full and the lists running over, the searches the sweep gives up done by the kernel that holds the recursion
+                     ("strand by strand", {"ARRIBA_STRANDS_TOGETHER": "0"}), ("memo and list in HBM only", {"ARRIBA_MEMO_FRONT": "0"}),
+                     ("small tables, short lists", {"ARRIBA_MEMO_SLOTS_LOG2": "10", "ARRIBA_TASK_CAPACITY_LOG2": "6"})]
         for label, environment in schedules:
             count, again, _ = verdicts(environment)
             assert count == n_jobs, (name, label)
